@@ -1,0 +1,890 @@
+// oracle/detect_oracle.cpp -- CPU restatement of the reference's detect_cuboid() path.
+//
+// TEST INFRASTRUCTURE ONLY.  Nothing under cube_slam_wu_amd/ may include, link or call this file;
+// only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+//
+// PARITY STATUS: *parity unpinned*.  The reference (wuxiaolang/Cube_SLAM_wu) has no tests and cannot
+// be built here (needs Eigen, OpenCV, ROS; none on disk).  This file follows the reference's loops
+// line by line (citations below are relative to /root/reference) and is pinned only by (a) the
+// known-answer values printed in the reference's comments (tests/test_oracle_kat.py) and (b) an
+// independent numpy restatement (tools/np_detect_ref.py -> tests/golden/).  Arithmetic that lives in
+// Eigen (3x3 inverse, Quaterniond(Matrix3d), small mat-vec products, norm()) is restated from the
+// published algorithms with left-to-right summation; the last bit of those may differ from a real
+// Eigen build and cannot be checked here.
+//
+// Numeric types follow the reference exactly: double geometry, float distance-map gathers and
+// float running sum (object_3d_util.cpp:637-664), int() truncation for pixels, std::partial_sort
+// for the rankings.  Compile with -O2 -ffp-contract=off.
+//
+// atan2: the reference calls libm.  glibc 2.35's atan2 is not correctly rounded (about 1e-3 of
+// calls differ from the correctly rounded value by one ulp, see tests/test_atan2.py), and the
+// device cannot reproduce glibc's rounding errors, so the oracle can run in two modes:
+//   mode 0 "libm"   : std::atan2 everywhere (what a reference build on this host would compute);
+//   mode 1 "shared" : cs::cs_atan2 (correctly rounded, bit-reproducible on gfx950) for the atan2
+//                     calls of the sweep (merge_break_lines, line angles, VP support, box edge
+//                     angles).  Camera Euler angles (set_cam_pose) always use libm.
+// GPU parity tests compare against mode 1 bit for bit; tests/test_detect_oracle.py checks that
+// mode 0 and mode 1 yield the same integer rankings.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <iterator>
+#include <numeric>
+#include <vector>
+
+#include "../cube_slam_wu_amd/csrc/cs_atan2.h"  // the one shared primitive (see header comment)
+
+namespace {
+
+int g_atan2_mode = 1;
+inline double sweep_atan2(double y, double x) { return g_atan2_mode ? cs::cs_atan2(y, x) : std::atan2(y, x); }
+
+struct V2 { double x, y; };
+inline V2 operator-(V2 a, V2 b) { return V2{a.x - b.x, a.y - b.y}; }
+inline double norm2(V2 a) { return std::sqrt(a.x * a.x + a.y * a.y); }
+
+struct M3 { double m[3][3]; };
+struct M4 { double m[4][4]; };
+
+// Eigen compute_inverse_size3 (cofactor form).  [Eigen algorithm, restated; parity unpinned]
+inline double cof3(const M3& a, int i, int j) {
+  int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return a.m[i1][j1] * a.m[i2][j2] - a.m[i1][j2] * a.m[i2][j1];
+}
+M3 inverse3(const M3& a) {
+  double c0 = cof3(a, 0, 0), c1 = cof3(a, 1, 0), c2 = cof3(a, 2, 0);
+  double det = (c0 * a.m[0][0] + c1 * a.m[1][0]) + c2 * a.m[2][0];
+  double invdet = 1.0 / det;
+  M3 r;
+  r.m[0][0] = c0 * invdet; r.m[0][1] = c1 * invdet; r.m[0][2] = c2 * invdet;
+  r.m[1][0] = cof3(a, 0, 1) * invdet; r.m[1][1] = cof3(a, 1, 1) * invdet; r.m[1][2] = cof3(a, 2, 1) * invdet;
+  r.m[2][0] = cof3(a, 0, 2) * invdet; r.m[2][1] = cof3(a, 1, 2) * invdet; r.m[2][2] = cof3(a, 2, 2) * invdet;
+  return r;
+}
+M3 mul33(const M3& a, const M3& b) {
+  M3 r;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) r.m[i][j] = (a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j]) + a.m[i][2] * b.m[2][j];
+  return r;
+}
+
+// Eigen Quaterniond(Matrix3d) (Shoemake).  [Eigen algorithm, restated; parity unpinned]
+void quat_from_rot(const M3& R, double& w, double& x, double& y, double& z) {
+  double t = R.m[0][0] + R.m[1][1] + R.m[2][2];
+  if (t > 0.0) {
+    t = std::sqrt(t + 1.0);
+    w = 0.5 * t;
+    t = 0.5 / t;
+    x = (R.m[2][1] - R.m[1][2]) * t;
+    y = (R.m[0][2] - R.m[2][0]) * t;
+    z = (R.m[1][0] - R.m[0][1]) * t;
+  } else {
+    int i = 0;
+    if (R.m[1][1] > R.m[0][0]) i = 1;
+    if (R.m[2][2] > R.m[i][i]) i = 2;
+    int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(R.m[i][i] - R.m[j][j] - R.m[k][k] + 1.0);
+    double q[3];
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    w = (R.m[k][j] - R.m[j][k]) * t;
+    q[j] = (R.m[j][i] + R.m[i][j]) * t;
+    q[k] = (R.m[k][i] + R.m[i][k]) * t;
+    x = q[0]; y = q[1]; z = q[2];
+  }
+}
+
+// detect_3d_cuboid/src/matrix_utils.cpp:38-49
+void quat_to_euler_zyx(double qw, double qx, double qy, double qz, double& roll, double& pitch, double& yaw) {
+  roll = std::atan2(2 * (qw * qx + qy * qz), 1 - 2 * (qx * qx + qy * qy));
+  pitch = std::asin(2 * (qw * qy - qz * qx));
+  yaw = std::atan2(2 * (qw * qz + qx * qy), 1 - 2 * (qy * qy + qz * qz));
+}
+
+// detect_3d_cuboid/src/matrix_utils.cpp:81-96
+M3 euler_zyx_to_rot(double roll, double pitch, double yaw) {
+  double cp = std::cos(pitch), sp = std::sin(pitch), sr = std::sin(roll), cr = std::cos(roll), sy = std::sin(yaw), cy = std::cos(yaw);
+  M3 R;
+  R.m[0][0] = cp * cy; R.m[0][1] = (sr * sp * cy) - (cr * sy); R.m[0][2] = (cr * sp * cy) + (sr * sy);
+  R.m[1][0] = cp * sy; R.m[1][1] = (sr * sp * sy) + (cr * cy); R.m[1][2] = (cr * sp * sy) - (sr * cy);
+  R.m[2][0] = -sp; R.m[2][1] = sr * cp; R.m[2][2] = cr * cp;
+  return R;
+}
+
+// detect_3d_cuboid/src/matrix_utils.cpp:344-353
+inline double normalize_to_pi(double a) {
+  if (a > M_PI / 2) return a - M_PI;
+  else if (a < -M_PI / 2) return a + M_PI;
+  else return a;
+}
+
+// detect_3d_cuboid/src/matrix_utils.cpp:368-380
+template <class T>
+void linespace(T starting, T ending, T step, std::vector<T>& res) {
+  while (starting <= ending) {
+    res.push_back(starting);
+    starting += step;
+    if (res.size() > 1000) break;
+  }
+}
+
+// detect_3d_cuboid/src/matrix_utils.cpp:327-335
+void sort_indexes(const std::vector<double>& vec, std::vector<int>& idx, int top_k) {
+  std::partial_sort(idx.begin(), idx.begin() + top_k, idx.end(), [&vec](int i1, int i2) { return vec[i1] < vec[i2]; });
+}
+
+// detect_3d_cuboid.h:59-71 cam_pose_infos
+struct CamPose {
+  M4 transToWolrd;
+  M3 Kalib, rotationToWorld, invR, invK, KinvR;
+  double euler_angle[3];
+  double camera_yaw;
+};
+
+// object_3d_util.cpp:239-242
+inline bool check_inside_box(V2 pt, V2 lt, V2 rb) { return lt.x <= pt.x && pt.x <= rb.x && lt.y <= pt.y && pt.y <= rb.y; }
+
+// object_3d_util.cpp:309-353
+V2 seg_hit_boundary(V2 pt_start, V2 pt_end, double bx0, double by0, double bx1, double by1) {
+  V2 direc = pt_end - pt_start;
+  V2 hit{-1, -1};
+  if (by0 == by1) {
+    double lambd = (by0 - pt_start.y) / direc.y;
+    if (lambd >= 0) {
+      V2 tmp{pt_start.x + lambd * direc.x, pt_start.y + lambd * direc.y};
+      if ((bx0 <= tmp.x) && (tmp.x <= bx1)) { hit = tmp; hit.y = by0; }
+    }
+  }
+  if (bx0 == bx1) {
+    double lambd = (bx0 - pt_start.x) / direc.x;
+    if (lambd >= 0) {
+      V2 tmp{pt_start.x + lambd * direc.x, pt_start.y + lambd * direc.y};
+      if ((by0 <= tmp.y) && (tmp.y <= by1)) { hit = tmp; hit.x = bx0; }
+    }
+  }
+  return hit;
+}
+
+// object_3d_util.cpp:357-382 (always called with infinite_line = true on this path)
+V2 lineSegmentIntersect(V2 p1s, V2 p1e, V2 p2s, V2 p2e) {
+  double X2_X1 = p1e.x - p1s.x, Y2_Y1 = p1e.y - p1s.y;
+  double X4_X3 = p2e.x - p2s.x, Y4_Y3 = p2e.y - p2s.y;
+  double X1_X3 = p1s.x - p2s.x, Y1_Y3 = p1s.y - p2s.y;
+  double u_a = (X4_X3 * Y1_Y3 - Y4_Y3 * X1_X3) / (Y4_Y3 * X2_X1 - X4_X3 * Y2_Y1);
+  double INT_X = p1s.x + X2_X1 * u_a;
+  double INT_Y = p1s.y + Y2_Y1 * u_a;
+  double INT_B = 1;
+  return V2{INT_X * INT_B, INT_Y * INT_B};
+}
+
+// object_3d_util.cpp:431-543.  lines: n x 4 row-major, modified/shrunk in place; returns kept rows.
+void merge_break_lines(const std::vector<double>& all_lines, std::vector<double>& out, double pre_merge_dist_thre,
+                       double pre_merge_angle_thre_degree, double edge_length_threshold) {
+  bool can_force_merge = true;
+  std::vector<double> L = all_lines;
+  int total = (int)(L.size() / 4);
+  int counter = 0;
+  double pre_merge_angle_thre = pre_merge_angle_thre_degree / 180.0 * M_PI;
+  std::vector<double> ang;
+  while (can_force_merge && counter < 500) {
+    counter++;
+    can_force_merge = false;
+    ang.resize(total);
+    for (int i = 0; i < total; i++) ang[i] = sweep_atan2(L[4 * i + 3] - L[4 * i + 1], L[4 * i + 2] - L[4 * i + 0]);
+    for (int s1 = 0; s1 < total - 1; s1++) {
+      for (int s2 = s1 + 1; s2 < total; s2++) {
+        double diff = std::abs(ang[s1] - ang[s2]);
+        double angle_diff = std::min(diff, M_PI - diff);
+        if (angle_diff < pre_merge_angle_thre) {
+          double d12 = norm2(V2{L[4 * s1 + 2] - L[4 * s2 + 0], L[4 * s1 + 3] - L[4 * s2 + 1]});
+          double d21 = norm2(V2{L[4 * s2 + 2] - L[4 * s1 + 0], L[4 * s2 + 3] - L[4 * s1 + 1]});
+          if ((d12 < pre_merge_dist_thre) || (d21 < pre_merge_dist_thre)) {
+            V2 ms, me;
+            if (L[4 * s1 + 0] < L[4 * s2 + 0]) ms = V2{L[4 * s1 + 0], L[4 * s1 + 1]};
+            else ms = V2{L[4 * s2 + 0], L[4 * s2 + 1]};
+            if (L[4 * s1 + 2] > L[4 * s2 + 2]) me = V2{L[4 * s1 + 2], L[4 * s1 + 3]};
+            else me = V2{L[4 * s2 + 2], L[4 * s2 + 3]};
+            double merged_angle = sweep_atan2(me.y - ms.y, me.x - ms.x);
+            double temp = std::abs(ang[s1] - merged_angle);
+            double merge_angle_diff = std::min(temp, M_PI - temp);
+            if (merge_angle_diff < pre_merge_angle_thre) {
+              L[4 * s1 + 0] = ms.x; L[4 * s1 + 1] = ms.y; L[4 * s1 + 2] = me.x; L[4 * s1 + 3] = me.y;
+              // fast_RemoveRow (matrix_utils.cpp:183-187)
+              for (int c = 0; c < 4; c++) L[4 * s2 + c] = L[4 * (total - 1) + c];
+              total--;
+              can_force_merge = true;
+              break;
+            }
+          }
+        }
+      }
+      if (can_force_merge) break;
+    }
+  }
+  out.clear();
+  if (edge_length_threshold > 0) {
+    for (int i = 0; i < total; i++) {
+      double len = norm2(V2{L[4 * i + 2] - L[4 * i + 0], L[4 * i + 3] - L[4 * i + 1]});
+      if (len > edge_length_threshold)
+        for (int c = 0; c < 4; c++) out.push_back(L[4 * i + c]);
+    }
+  } else {
+    out.assign(L.begin(), L.begin() + 4 * total);
+  }
+}
+
+// object_3d_util.cpp:548-619.  vps[3], mids m x 2, angles m -> out[3][2] (NaN when not found)
+void VP_support_edge_infos(const V2 vps[3], const std::vector<double>& mids, const std::vector<double>& edge_angles,
+                           double thre12_deg, double thre3_deg, double out[3][2]) {
+  for (int i = 0; i < 3; i++) out[i][0] = out[i][1] = std::nan("");
+  int m = (int)edge_angles.size();
+  if (m > 0) {
+    std::vector<int> inlier_id;
+    std::vector<double> raw_inlier(m);
+    for (int vp_id = 0; vp_id < 3; vp_id++) {
+      double vp_angle_thre = (vp_id != 2) ? thre12_deg / 180.0 * M_PI : thre3_deg / 180.0 * M_PI;
+      inlier_id.clear();
+      for (int e = 0; e < m; e++) {
+        double raw = sweep_atan2(mids[2 * e + 1] - vps[vp_id].y, mids[2 * e + 0] - vps[vp_id].x);
+        double nrm = normalize_to_pi(raw);
+        double d = std::abs(edge_angles[e] - nrm);
+        d = std::min(d, M_PI - d);
+        if (d < vp_angle_thre) {
+          raw_inlier[inlier_id.size()] = raw;
+          inlier_id.push_back(e);
+        }
+      }
+      if (!inlier_id.empty()) {
+        int n = (int)inlier_id.size();
+        // smooth_jump_angles (object_3d_util.cpp:278-302)
+        std::vector<double> sh(raw_inlier.begin(), raw_inlier.begin() + n);
+        double base = raw_inlier[0];
+        for (int i = 0; i < n; i++) {
+          if ((raw_inlier[i] - base) < -M_PI) sh[i] = raw_inlier[i] + 2 * M_PI;
+          else if ((raw_inlier[i] - base) > M_PI) sh[i] = raw_inlier[i] - 2 * M_PI;
+        }
+        int lo_id = 0, top_id = 0;  // Eigen maxCoeff/minCoeff(&idx): first occurrence, strict compare
+        for (int i = 1; i < n; i++) {
+          if (sh[i] > sh[lo_id]) lo_id = i;
+          if (sh[i] < sh[top_id]) top_id = i;
+        }
+        if (vp_id > 0) std::swap(lo_id, top_id);
+        out[vp_id][0] = edge_angles[inlier_id[lo_id]];
+        out[vp_id][1] = edge_angles[inlier_id[top_id]];
+      }
+    }
+  }
+}
+
+// object_3d_util.cpp:622-667.  corners 2x8 (row 0 = x, row 1 = y) already shifted to ROI origin.
+double box_edge_sum_dists(const float* dist_map, int map_w, const double c[2][8], const int (*edges)[2], int n_edges, bool reweight) {
+  float sum_dist = 0;
+  for (int e = 0; e < n_edges; e++) {
+    double x1 = c[0][edges[e][0]], y1 = c[1][edges[e][0]], x2 = c[0][edges[e][1]], y2 = c[1][edges[e][1]];
+    for (double s = 0; s < 11; s++) {
+      double sx = s / 10.0 * x1 + (1 - s / 10.0) * x2;
+      double sy = s / 10.0 * y1 + (1 - s / 10.0) * y2;
+      // cv::Mat::at<float>(row, col) on a continuous h x w buffer: linear index, no bounds check
+      float dist1 = dist_map[(long)int(sy) * map_w + int(sx)];
+      if (reweight) {
+        if ((4 <= e) && (e <= 5)) dist1 = dist1 * 3.0 / 2.0;
+        if (6 == e) dist1 = dist1 * 2.0;
+      }
+      sum_dist = sum_dist + dist1;
+    }
+  }
+  return double(sum_dist);
+}
+
+// object_3d_util.cpp:670-723
+double box_edge_alignment_angle_error(const double bound[3][2], const int vps_ids[3][4], const double c[2][8]) {
+  double total = 0;
+  double not_found_penalty = 30.0 / 180.0 * M_PI * 2;
+  for (int vp_id = 0; vp_id < 3; vp_id++) {
+    double valid[2];
+    int nv = 0;
+    for (int i = 0; i < 2; i++)
+      if (!std::isnan(bound[vp_id][i])) valid[nv++] = bound[vp_id][i];
+    if (nv > 0) {
+      for (int ee = 0; ee < 2; ee++) {
+        int a = vps_ids[vp_id][2 * ee], b = vps_ids[vp_id][2 * ee + 1];
+        double ang = normalize_to_pi(sweep_atan2(c[1][b] - c[1][a], c[0][b] - c[0][a]));
+        double best = 100;
+        for (int i = 0; i < nv; i++) {
+          double temp = std::abs(ang - valid[i]);
+          temp = std::min(temp, M_PI - temp);
+          if (temp < best) best = temp;
+        }
+        total = total + best;
+      }
+    } else {
+      total = total + not_found_penalty;
+    }
+  }
+  return total;
+}
+
+// object_3d_util.cpp:726-837
+void fuse_normalize_scores_v2(const std::vector<double>& dist_error, const std::vector<double>& angle_error,
+                              std::vector<double>& combined, std::vector<int>& final_keep, double weight_vp_angle, bool whether_normalize) {
+  int raw = (int)dist_error.size();
+  final_keep.clear();
+  if (raw > 4) {
+    int bn = (int)round(float(raw) / 3.0 * 2.0);
+    std::vector<int> dist_sorted(raw);
+    std::iota(dist_sorted.begin(), dist_sorted.end(), 0);
+    std::vector<int> angle_sorted = dist_sorted;
+    sort_indexes(dist_error, dist_sorted, bn);
+    sort_indexes(angle_error, angle_sorted, bn);
+    std::vector<int> dist_keep(dist_sorted.begin(), dist_sorted.begin() + bn - 1);
+    if (angle_error[angle_sorted[bn - 1]] > angle_error[angle_sorted[bn - 2]]) {
+      std::vector<int> angle_keep(angle_sorted.begin(), angle_sorted.begin() + bn - 1);
+      std::sort(dist_keep.begin(), dist_keep.end());
+      std::sort(angle_keep.begin(), angle_keep.end());
+      std::set_intersection(dist_keep.begin(), dist_keep.end(), angle_keep.begin(), angle_keep.end(), std::back_inserter(final_keep));
+    } else {
+      final_keep = dist_keep;
+    }
+  } else {
+    final_keep.resize(raw);
+    std::iota(final_keep.begin(), final_keep.end(), 0);
+  }
+  int n = (int)final_keep.size();
+  double min_d = 1e6, max_d = -1, min_a = 1e6, max_a = -1;
+  std::vector<double> dk(n), ak(n);
+  for (int i = 0; i < n; i++) {
+    double td = dist_error[final_keep[i]], ta = angle_error[final_keep[i]];
+    min_d = std::min(min_d, td); max_d = std::max(max_d, td);
+    min_a = std::min(min_a, ta); max_a = std::max(max_a, ta);
+    dk[i] = td; ak[i] = ta;
+  }
+  combined.resize(n);
+  if (whether_normalize && (n > 1)) {
+    for (int i = 0; i < n; i++) combined[i] = (dk[i] - min_d) / (max_d - min_d);
+    if ((max_a - min_a) > 0)
+      for (int i = 0; i < n; i++) ak[i] = (ak[i] - min_a) / (max_a - min_a);
+    for (int i = 0; i < n; i++) combined[i] = (combined[i] + weight_vp_angle * ak[i]) / (1 + weight_vp_angle);
+  } else {
+    for (int i = 0; i < n; i++) combined[i] = (dk[i] + weight_vp_angle * ak[i]) / (1 + weight_vp_angle);
+  }
+}
+
+inline void mat4_vec(const M4& T, const double p[4], double o[4]) {
+  for (int i = 0; i < 4; i++) o[i] = ((T.m[i][0] * p[0] + T.m[i][1] * p[1]) + T.m[i][2] * p[2]) + T.m[i][3] * p[3];
+}
+inline void mat4T_vec(const M4& T, const double p[4], double o[4]) {
+  for (int i = 0; i < 4; i++) o[i] = ((T.m[0][i] * p[0] + T.m[1][i] * p[1]) + T.m[2][i] * p[2]) + T.m[3][i] * p[3];
+}
+
+// object_3d_util.cpp:853-876 (+ ray_plane_interact :841-847), one pixel
+void plane_hits_3d(const M4& T, const M3& invK, const double plane[4], double px, double py, double out[3]) {
+  double ray[3];
+  for (int i = 0; i < 3; i++) ray[i] = (invK.m[i][0] * px + invK.m[i][1] * py) + invK.m[i][2] * 1.0;
+  double den = (plane[0] * ray[0] + plane[1] * ray[1]) + plane[2] * ray[2];
+  double frac = -plane[3] / den;
+  double ps[4] = {frac * ray[0], frac * ray[1], frac * ray[2], 1.0};
+  double pw[4];
+  mat4_vec(T, ps, pw);
+  for (int i = 0; i < 3; i++) out[i] = pw[i] / pw[3];
+}
+
+}  // namespace
+
+extern "C" {
+
+// Mirrors class cuboid (detect_3d_cuboid.h:20-41) as a POD.
+struct oracle_cuboid {
+  double pos[3];
+  double scale[3];
+  double rotY;
+  double box_config_type[2];
+  int box_corners_2d[16];            // 2x8 row-major (row 0 = x)
+  double box_corners_3d_world[24];   // 3x8 row-major
+  double rect_detect_2d[4];
+  double edge_distance_error, edge_angle_error, normalized_error, skew_ratio, down_expand_height;
+  double camera_roll_delta, camera_pitch_delta;
+};
+
+// Mirrors the public flags of class detect_3d_cuboid (detect_3d_cuboid.h:95-117) plus the yaw sweep,
+// which the reference hard-codes at +-45 deg / 6 deg (box_proposal_detail.cpp:184).
+struct oracle_params {
+  int consider_config_1, consider_config_2;
+  int whether_sample_cam_roll_pitch, whether_sample_bbox_height;
+  int max_cuboid_num;
+  double nominal_skew_ratio, max_cut_skew;
+  double yaw_range_deg, yaw_step_deg;  // 45, 6 in the reference
+};
+
+// Optional per-(box, height-sample) dump of the sweep, for stage-by-stage parity tests.
+struct oracle_debug {
+  int cap_candidates;      // capacity (rows) of cand_rows / cand_corners per (box,height)
+  int max_heights;         // 3
+  int* n_valid;            // [n_boxes*3]
+  double* cand_rows;       // [n_boxes*3][cap][9]
+  double* cand_corners;    // [n_boxes*3][cap][16] (2x8 row-major)
+  int* n_keep;             // [n_boxes*3]
+  int* keep_ids;           // [n_boxes*3][cap]
+  double* keep_scores;     // [n_boxes*3][cap]
+  int* n_merged_lines;     // [n_boxes*3]
+  int* n_raw_proposals;    // [n_boxes]
+  double* combined_scores; // [n_boxes][3*cap]
+  int* yaw_count;          // [n_boxes]
+};
+
+void oracle_set_atan2_mode(int mode) { g_atan2_mode = mode; }
+int oracle_get_atan2_mode() { return g_atan2_mode; }
+double oracle_atan2(double y, double x) { return sweep_atan2(y, x); }
+
+}  // extern "C"
+
+namespace {
+
+struct Detector {
+  CamPose cam_pose, cam_pose_raw;
+  // box_proposal_detail.cpp:38-42
+  void set_calibration(const M3& K) { cam_pose.Kalib = K; cam_pose.invK = inverse3(K); }
+  // box_proposal_detail.cpp:45-56 (projectionMatrix is computed there but never read on this path)
+  void set_cam_pose(const M4& T) {
+    cam_pose.transToWolrd = T;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) cam_pose.rotationToWorld.m[i][j] = T.m[i][j];
+    double qw, qx, qy, qz;
+    quat_from_rot(cam_pose.rotationToWorld, qw, qx, qy, qz);
+    quat_to_euler_zyx(qw, qx, qy, qz, cam_pose.euler_angle[0], cam_pose.euler_angle[1], cam_pose.euler_angle[2]);
+    cam_pose.invR = inverse3(cam_pose.rotationToWorld);
+    cam_pose.KinvR = mul33(cam_pose.Kalib, cam_pose.invR);
+    cam_pose.camera_yaw = cam_pose.euler_angle[2];
+  }
+};
+
+// object_3d_util.cpp:941-1011 (+ :15-44, :59-73, :909-925)
+void change_2d_corner_to_3d_object(const double c[2][8], const double configs[3], const double ground_plane_sensor[4],
+                                   const M4& T, const M3& invK, oracle_cuboid& o) {
+  double g[4][3];
+  for (int k = 0; k < 4; k++) plane_hits_3d(T, invK, ground_plane_sensor, c[0][4 + k], c[1][4 + k], g[k]);
+  auto n3 = [](const double a[3], const double b[3]) {
+    double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    return std::sqrt((dx * dx + dy * dy) + dz * dz);
+  };
+  double length_half = n3(g[0], g[3]) / 2;
+  double width_half = n3(g[0], g[1]) / 2;
+  // get_wall_plane_equation(g0, g1): (g0-g1) x (0,0,1)
+  double d[3] = {g[0][0] - g[1][0], g[0][1] - g[1][1], g[0][2] - g[1][2]};
+  double nrm[3] = {d[1] * 1.0 - d[2] * 0.0, d[2] * 0.0 - d[0] * 1.0, d[0] * 0.0 - d[1] * 0.0};
+  double nn = std::sqrt((nrm[0] * nrm[0] + nrm[1] * nrm[1]) + nrm[2] * nrm[2]);
+  for (int i = 0; i < 3; i++) nrm[i] /= nn;
+  double dist = -((nrm[0] * g[0][0] + nrm[1] * g[0][1]) + nrm[2] * g[0][2]);
+  double plane_w[4] = {nrm[0], nrm[1], nrm[2], dist};
+  if (dist < 0) for (int i = 0; i < 4; i++) plane_w[i] = -plane_w[i];
+  double plane_s[4];
+  mat4T_vec(T, plane_w, plane_s);
+  double top[3];
+  plane_hits_3d(T, invK, plane_s, c[0][1], c[1][1], top);
+  double height_half = top[2] / 2;
+  double mean_x = (((g[0][0] + g[1][0]) + g[2][0]) + g[3][0]) / 4.0;
+  double mean_y = (((g[0][1] + g[1][1]) + g[2][1]) + g[3][1]) / 4.0;
+  double vp_1_position = configs[1];
+  double yaw_esti = configs[2];
+  o.pos[0] = mean_x; o.pos[1] = mean_y; o.pos[2] = height_half;
+  o.rotY = yaw_esti;
+  o.scale[0] = length_half; o.scale[1] = width_half; o.scale[2] = height_half;
+  o.box_config_type[0] = configs[0]; o.box_config_type[1] = configs[1];
+  int ids[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+  const int left_ids[8] = {6, 5, 8, 7, 2, 3, 4, 1}, right_ids[8] = {5, 6, 7, 8, 3, 2, 1, 4};
+  if (vp_1_position == 1) std::memcpy(ids, left_ids, sizeof(ids));
+  if (vp_1_position == 2) std::memcpy(ids, right_ids, sizeof(ids));
+  for (int i = 0; i < 8; i++) {
+    o.box_corners_2d[0 * 8 + i] = (int)c[0][ids[i] - 1];
+    o.box_corners_2d[1 * 8 + i] = (int)c[1][ids[i] - 1];
+  }
+  // compute3D_BoxCorner: similarityTransformation * corners_body
+  const double body[3][8] = {{1, 1, -1, -1, 1, 1, -1, -1}, {1, -1, -1, 1, 1, -1, -1, 1}, {-1, -1, -1, -1, 1, 1, 1, 1}};
+  double cr = std::cos(o.rotY), sr = std::sin(o.rotY);
+  double rot[3][3] = {{cr, -sr, 0}, {sr, cr, 0}, {0, 0, 1}};
+  double S[4][4] = {{0}};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) S[i][j] = rot[i][j] * o.scale[j];
+  for (int i = 0; i < 3; i++) S[i][3] = o.pos[i];
+  S[3][3] = 1;
+  for (int k = 0; k < 8; k++) {
+    double p[4] = {body[0][k], body[1][k], body[2][k], 1.0}, w[4];
+    for (int i = 0; i < 4; i++) w[i] = ((S[i][0] * p[0] + S[i][1] * p[1]) + S[i][2] * p[2]) + S[i][3] * p[3];
+    for (int i = 0; i < 3; i++) o.box_corners_3d_world[i * 8 + k] = w[i] / w[3];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// ROI of (box, height sample): box_proposal_detail.cpp:143-172, 204-205, 242-248.
+// Returns the number of height samples (1 or <=3); roi[k] = {left, top, width, height} of the distance
+// map the reference would build with cv::Rect (:320), heights[k] = down_expand_sample.
+int oracle_box_rois(const double* box5, int img_w, int img_h, int whether_sample_bbox_height, int roi[3][4], int heights[3]) {
+  int left_x_raw = box5[0], top_y_raw = box5[1], obj_width_raw = box5[2], obj_height_raw = box5[3];
+  int right_x_raw = left_x_raw + box5[2];
+  std::vector<int> down;
+  down.push_back(0);
+  if (whether_sample_bbox_height) {
+    int r = std::max(std::min(20, obj_height_raw - 90), 20);
+    r = std::min(r, img_h - top_y_raw - obj_height_raw - 1);
+    if (r > 10) down.push_back(round(r / 2));
+    down.push_back(r);
+  }
+  for (size_t k = 0; k < down.size(); k++) {
+    int obj_height_expan = obj_height_raw + down[k];
+    int down_y_expan = top_y_raw + obj_height_expan;
+    int e = std::min(std::max(std::min(20, obj_width_raw - 100), 10), std::max(std::min(20, obj_height_expan - 100), 10));
+    int l = std::max(0, left_x_raw - e), r = std::min(img_w - 1, right_x_raw + e);
+    int t = std::max(0, top_y_raw - e), b = std::min(img_h - 1, down_y_expan + e);
+    roi[k][0] = l; roi[k][1] = t; roi[k][2] = r - l; roi[k][3] = b - t;
+    heights[k] = down[k];
+  }
+  return (int)down.size();
+}
+
+// detect_3d_cuboid::detect_cuboid (box_proposal_detail.cpp:65-861) on raw arrays.
+//   K[9], T_wc[16] row-major; boxes n x 5 (x y w h prob); lines M x 4 row-major (x1 y1 x2 y2);
+//   dist_maps[box*3 + k]: float32 h x w map of (box, height sample k) as cv::distanceTransform would
+//   return it for the ROI of oracle_box_rois(), followed by at least w+1 readable floats (the
+//   reference indexes one row / one column past the map when a corner sits on the ROI's far edge);
+//   out: n x max_cuboid_num records, out_counts[n].
+// Returns 0, or <0 on invalid arguments.
+int oracle_detect_cuboid(const oracle_params* prm, const double* K, const double* T_wc, int img_w, int img_h,
+                         const double* boxes, int n_boxes, const double* lines_in, int n_lines,
+                         const float* const* dist_maps, oracle_cuboid* out, int* out_counts, oracle_debug* dbg) {
+  if (!prm || !K || !T_wc || (!boxes && n_boxes) || !out || !out_counts) return -1;
+  Detector det;
+  M3 Kalib; M4 transToWolrd;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Kalib.m[i][j] = K[3 * i + j];
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) transToWolrd.m[i][j] = T_wc[4 * i + j];
+  det.set_calibration(Kalib);
+  det.set_cam_pose(transToWolrd);           // :78
+  det.cam_pose_raw = det.cam_pose;          // :79
+  CamPose& cam_pose = det.cam_pose;
+  const CamPose& cam_pose_raw = det.cam_pose_raw;
+
+  bool all_configs[2] = {prm->consider_config_1 != 0, prm->consider_config_2 != 0};
+  double vp12_edge_angle_thre = 15, vp3_edge_angle_thre = 10, shorted_edge_thre = 20;
+  bool reweight_edge_distance = true;
+  bool whether_normalize_two_errors = true;
+  double weight_vp_angle = 0.8, weight_skew_error = 1.5;
+
+  // :114 align_left_right_edges (object_3d_util.cpp:246-258)
+  std::vector<double> all_lines_raw(lines_in, lines_in + 4 * (size_t)n_lines);
+  for (int i = 0; i < n_lines; i++)
+    if (all_lines_raw[4 * i + 2] < all_lines_raw[4 * i + 0]) {
+      std::swap(all_lines_raw[4 * i + 0], all_lines_raw[4 * i + 2]);
+      std::swap(all_lines_raw[4 * i + 1], all_lines_raw[4 * i + 3]);
+    }
+
+  const double ground_plane_world[4] = {0, 0, 1, 0};
+  double ground_plane_sensor[4];
+  mat4T_vec(cam_pose.transToWolrd, ground_plane_world, ground_plane_sensor);  // :131
+
+  for (int object_id = 0; object_id < n_boxes; object_id++) {
+    out_counts[object_id] = 0;
+    const double* bb = boxes + 5 * object_id;
+    int left_x_raw = bb[0], top_y_raw = bb[1], obj_width_raw = bb[2], obj_height_raw = bb[3];
+    int right_x_raw = left_x_raw + bb[2];
+    int down_y_raw = top_y_raw + obj_height_raw;
+    (void)down_y_raw;
+
+    std::vector<int> down_expand_sample_all;
+    down_expand_sample_all.push_back(0);
+    if (prm->whether_sample_bbox_height) {
+      int r = std::max(std::min(20, obj_height_raw - 90), 20);
+      r = std::min(r, img_h - top_y_raw - obj_height_raw - 1);
+      if (r > 10) down_expand_sample_all.push_back(round(r / 2));
+      down_expand_sample_all.push_back(r);
+    }
+
+    double yaw_init = cam_pose.camera_yaw - 90.0 / 180.0 * M_PI;  // :180 (uses the *current* cam_pose)
+    std::vector<double> obj_yaw_samples;
+    linespace<double>(yaw_init - prm->yaw_range_deg / 180.0 * M_PI, yaw_init + prm->yaw_range_deg / 180.0 * M_PI,
+                      prm->yaw_step_deg / 180.0 * M_PI, obj_yaw_samples);
+    if (dbg && dbg->yaw_count) dbg->yaw_count[object_id] = (int)obj_yaw_samples.size();
+
+    std::vector<oracle_cuboid> raw_obj_proposals;
+
+    for (size_t sample_down_expan_id = 0; sample_down_expan_id < down_expand_sample_all.size(); sample_down_expan_id++) {
+      int down_expand_sample = down_expand_sample_all[sample_down_expan_id];
+      int obj_height_expan = obj_height_raw + down_expand_sample;
+      int down_y_expan = top_y_raw + obj_height_expan;
+      double obj_diaglength_expan = std::sqrt(double(obj_width_raw * obj_width_raw + obj_height_expan * obj_height_expan));
+
+      int top_sample_resolution = round(std::min(20, obj_width_raw / 10));
+      if (top_sample_resolution < 1) break;  // :215
+      std::vector<int> top_x_samples;
+      linespace<int>(left_x_raw + 5, right_x_raw - 5, top_sample_resolution, top_x_samples);
+
+      int distmap_expand_wid = std::min(std::max(std::min(20, obj_width_raw - 100), 10), std::max(std::min(20, obj_height_expan - 100), 10));
+      int left_x_expan_distmap = std::max(0, left_x_raw - distmap_expand_wid);
+      int right_x_expan_distmap = std::min(img_w - 1, right_x_raw + distmap_expand_wid);
+      int top_y_expan_distmap = std::max(0, top_y_raw - distmap_expand_wid);
+      int down_y_expan_distmap = std::min(img_h - 1, down_y_expan + distmap_expand_wid);
+      int width_expan_distmap = right_x_expan_distmap - left_x_expan_distmap;
+      V2 expan_lt{(double)left_x_expan_distmap, (double)top_y_expan_distmap};
+      V2 expan_rb{(double)right_x_expan_distmap, (double)down_y_expan_distmap};
+
+      // :271-283 lines inside the expanded box
+      std::vector<double> inside;
+      for (int e = 0; e < n_lines; e++) {
+        const double* l = &all_lines_raw[4 * e];
+        if (check_inside_box(V2{l[0], l[1]}, expan_lt, expan_rb))
+          if (check_inside_box(V2{l[2], l[3]}, expan_lt, expan_rb)) inside.insert(inside.end(), l, l + 4);
+      }
+      std::vector<double> merged;
+      merge_break_lines(inside, merged, 20, 5, 30);  // :288-296
+      int m = (int)(merged.size() / 4);
+      std::vector<double> lines_inobj_angles(m), edge_mid_pts(2 * m);
+      for (int i = 0; i < m; i++) {  // :311-315
+        lines_inobj_angles[i] = sweep_atan2(merged[4 * i + 3] - merged[4 * i + 1], merged[4 * i + 2] - merged[4 * i + 0]);
+        edge_mid_pts[2 * i + 0] = (merged[4 * i + 0] + merged[4 * i + 2]) / 2;
+        edge_mid_pts[2 * i + 1] = (merged[4 * i + 1] + merged[4 * i + 3]) / 2;
+      }
+      const float* dist_map = dist_maps[object_id * 3 + sample_down_expan_id];  // :320-327 (input here)
+
+      std::vector<double> rows;     // V x 9
+      std::vector<double> corners;  // V x 16
+      int valid_n = 0;
+
+      std::vector<double> cam_roll_samples, cam_pitch_samples;
+      if (prm->whether_sample_cam_roll_pitch) {
+        linespace<double>(cam_pose_raw.euler_angle[0] - 6.0 / 180.0 * M_PI, cam_pose_raw.euler_angle[0] + 6.0 / 180.0 * M_PI, 3.0 / 180.0 * M_PI, cam_roll_samples);
+        linespace<double>(cam_pose_raw.euler_angle[1] - 6.0 / 180.0 * M_PI, cam_pose_raw.euler_angle[1] + 6.0 / 180.0 * M_PI, 3.0 / 180.0 * M_PI, cam_pitch_samples);
+      } else {
+        cam_roll_samples.push_back(cam_pose_raw.euler_angle[0]);
+        cam_pitch_samples.push_back(cam_pose_raw.euler_angle[1]);
+      }
+
+      for (size_t cam_roll_id = 0; cam_roll_id < cam_roll_samples.size(); cam_roll_id++)
+      for (size_t cam_pitch_id = 0; cam_pitch_id < cam_pitch_samples.size(); cam_pitch_id++)
+      for (size_t obj_yaw_id = 0; obj_yaw_id < obj_yaw_samples.size(); obj_yaw_id++) {
+        if (prm->whether_sample_cam_roll_pitch) {  // :368-377
+          M4 Tn = transToWolrd;
+          M3 R = euler_zyx_to_rot(cam_roll_samples[cam_roll_id], cam_pitch_samples[cam_pitch_id], cam_pose_raw.euler_angle[2]);
+          for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Tn.m[i][j] = R.m[i][j];
+          det.set_cam_pose(Tn);
+          mat4T_vec(cam_pose.transToWolrd, ground_plane_world, ground_plane_sensor);
+        }
+        double obj_yaw_esti = obj_yaw_samples[obj_yaw_id];
+        // getVanishingPoints (object_3d_util.cpp:928-937)
+        V2 vps[3];
+        {
+          const M3& A = cam_pose.KinvR;
+          double d1[3] = {std::cos(obj_yaw_esti), std::sin(obj_yaw_esti), 0};
+          double d2[3] = {-std::sin(obj_yaw_esti), std::cos(obj_yaw_esti), 0};
+          double d3[3] = {0, 0, 1};
+          const double* ds[3] = {d1, d2, d3};
+          for (int v = 0; v < 3; v++) {
+            double h[3];
+            for (int i = 0; i < 3; i++) h[i] = (A.m[i][0] * ds[v][0] + A.m[i][1] * ds[v][1]) + A.m[i][2] * ds[v][2];
+            vps[v] = V2{h[0] / h[2], h[1] / h[2]};
+          }
+        }
+        V2 vp_1 = vps[0], vp_2 = vps[1], vp_3 = vps[2];
+        double bound[3][2];
+        VP_support_edge_infos(vps, edge_mid_pts, lines_inobj_angles, vp12_edge_angle_thre, vp3_edge_angle_thre, bound);  // :401
+
+        for (size_t sample_top_pt_id = 0; sample_top_pt_id < top_x_samples.size(); sample_top_pt_id++) {
+          V2 corner_1_top{(double)top_x_samples[sample_top_pt_id], (double)top_y_raw};
+          int vp_1_position = 0;
+          V2 corner_2_top = seg_hit_boundary(vp_1, corner_1_top, right_x_raw, top_y_raw, right_x_raw, down_y_expan);
+          if (corner_2_top.x == -1) {
+            corner_2_top = seg_hit_boundary(vp_1, corner_1_top, left_x_raw, top_y_raw, left_x_raw, down_y_expan);
+            if (corner_2_top.x != -1) vp_1_position = 2;
+          } else {
+            vp_1_position = 1;
+          }
+          if (!(vp_1_position > 0)) continue;
+          if (norm2(corner_1_top - corner_2_top) < shorted_edge_thre) continue;
+
+          for (int config_id = 1; config_id < 3; config_id++) {
+            if (!all_configs[config_id - 1]) continue;
+            V2 corner_3_top, corner_4_top;
+            if (config_id == 1) {
+              if (vp_1_position == 1) corner_4_top = seg_hit_boundary(vp_2, corner_1_top, left_x_raw, top_y_raw, left_x_raw, down_y_expan);
+              else corner_4_top = seg_hit_boundary(vp_2, corner_1_top, right_x_raw, top_y_raw, right_x_raw, down_y_expan);
+              if (corner_4_top.y == -1) continue;  // :489 (tests y)
+              if (norm2(corner_1_top - corner_4_top) < shorted_edge_thre) continue;
+              corner_3_top = lineSegmentIntersect(vp_2, corner_2_top, vp_1, corner_4_top);
+              if (!check_inside_box(corner_3_top, V2{(double)left_x_raw, (double)top_y_raw}, V2{(double)right_x_raw, (double)down_y_expan})) continue;
+              if ((norm2(corner_3_top - corner_4_top) < shorted_edge_thre) || (norm2(corner_3_top - corner_2_top) < shorted_edge_thre)) continue;
+            }
+            if (config_id == 2) {
+              if (vp_1_position == 1) corner_3_top = seg_hit_boundary(vp_2, corner_2_top, left_x_raw, top_y_raw, left_x_raw, down_y_expan);
+              else corner_3_top = seg_hit_boundary(vp_2, corner_2_top, right_x_raw, top_y_raw, right_x_raw, down_y_expan);
+              if (corner_3_top.y == -1) continue;
+              if (norm2(corner_2_top - corner_3_top) < shorted_edge_thre) continue;
+              corner_4_top = lineSegmentIntersect(vp_1, corner_3_top, vp_2, corner_1_top);
+              // :558 mixed raw-x / expanded-y bounds
+              if (!check_inside_box(corner_4_top, V2{(double)left_x_raw, (double)top_y_expan_distmap}, V2{(double)right_x_raw, (double)down_y_expan_distmap})) continue;
+              if ((norm2(corner_3_top - corner_4_top) < shorted_edge_thre) || (norm2(corner_4_top - corner_1_top) < shorted_edge_thre)) continue;
+            }
+            V2 corner_5_down = seg_hit_boundary(vp_3, corner_3_top, left_x_raw, down_y_expan, right_x_raw, down_y_expan);
+            if (corner_5_down.y == -1) continue;
+            if (norm2(corner_3_top - corner_5_down) < shorted_edge_thre) continue;
+            V2 corner_6_down = lineSegmentIntersect(vp_2, corner_5_down, vp_3, corner_2_top);
+            if (!check_inside_box(corner_6_down, expan_lt, expan_rb)) continue;
+            if ((norm2(corner_6_down - corner_2_top) < shorted_edge_thre) || (norm2(corner_6_down - corner_5_down) < shorted_edge_thre)) continue;
+            V2 corner_7_down = lineSegmentIntersect(vp_1, corner_6_down, vp_3, corner_1_top);
+            if (!check_inside_box(corner_7_down, expan_lt, expan_rb)) continue;
+            if ((norm2(corner_7_down - corner_1_top) < shorted_edge_thre) || (norm2(corner_7_down - corner_6_down) < shorted_edge_thre)) continue;
+            V2 corner_8_down = lineSegmentIntersect(vp_1, corner_5_down, vp_2, corner_7_down);
+            if (!check_inside_box(corner_8_down, expan_lt, expan_rb)) continue;
+            if ((norm2(corner_8_down - corner_4_top) < shorted_edge_thre) || (norm2(corner_8_down - corner_5_down) < shorted_edge_thre) ||
+                (norm2(corner_8_down - corner_7_down) < shorted_edge_thre)) continue;
+
+            V2 cs8[8] = {corner_1_top, corner_2_top, corner_3_top, corner_4_top, corner_5_down, corner_6_down, corner_7_down, corner_8_down};
+            double c[2][8], cshift[2][8];
+            for (int k = 0; k < 8; k++) {
+              c[0][k] = cs8[k].x; c[1][k] = cs8[k].y;
+              cshift[0][k] = cs8[k].x - left_x_expan_distmap;
+              cshift[1][k] = cs8[k].y - top_y_expan_distmap;
+            }
+            double sum_dist;
+            int vps_ids[3][4];
+            if (config_id == 1) {
+              static const int vis[9][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {1, 5}, {2, 4}, {3, 7}, {4, 7}, {4, 5}};
+              static const int vi[3][4] = {{0, 1, 7, 4}, {3, 0, 4, 5}, {3, 7, 1, 5}};
+              std::memcpy(vps_ids, vi, sizeof(vi));
+              sum_dist = box_edge_sum_dists(dist_map, width_expan_distmap, cshift, vis, 9, false);
+            } else {
+              static const int vis[7][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {1, 5}, {2, 4}, {4, 5}};
+              static const int vi[3][4] = {{0, 1, 2, 3}, {3, 0, 4, 5}, {2, 4, 1, 5}};
+              std::memcpy(vps_ids, vi, sizeof(vi));
+              sum_dist = box_edge_sum_dists(dist_map, width_expan_distmap, cshift, vis, 7, reweight_edge_distance);
+            }
+            double total_angle_diff = box_edge_alignment_angle_error(bound, vps_ids, c);
+            double row[9];
+            row[0] = config_id; row[1] = vp_1_position; row[2] = obj_yaw_esti; row[3] = (double)sample_top_pt_id;
+            row[4] = sum_dist / obj_diaglength_expan; row[5] = total_angle_diff; row[6] = down_expand_sample;
+            if (prm->whether_sample_cam_roll_pitch) { row[7] = cam_roll_samples[cam_roll_id]; row[8] = cam_pitch_samples[cam_pitch_id]; }
+            else { row[7] = cam_pose_raw.euler_angle[0]; row[8] = cam_pose_raw.euler_angle[1]; }
+            rows.insert(rows.end(), row, row + 9);
+            for (int r = 0; r < 2; r++) for (int k = 0; k < 8; k++) corners.push_back(c[r][k]);
+            valid_n++;
+          }
+        }
+      }
+
+      std::vector<double> dist_err(valid_n), angle_err(valid_n);
+      for (int i = 0; i < valid_n; i++) { dist_err[i] = rows[9 * i + 4]; angle_err[i] = rows[9 * i + 5]; }
+      std::vector<double> normalized_score;
+      std::vector<int> good_proposal_ids;
+      fuse_normalize_scores_v2(dist_err, angle_err, normalized_score, good_proposal_ids, weight_vp_angle, whether_normalize_two_errors);
+
+      if (dbg) {
+        int slot = object_id * 3 + (int)sample_down_expan_id;
+        int cap = dbg->cap_candidates;
+        if (dbg->n_valid) dbg->n_valid[slot] = valid_n;
+        if (dbg->n_merged_lines) dbg->n_merged_lines[slot] = m;
+        int nv = std::min(valid_n, cap);
+        if (dbg->cand_rows) std::memcpy(dbg->cand_rows + (size_t)slot * cap * 9, rows.data(), sizeof(double) * 9 * nv);
+        if (dbg->cand_corners) std::memcpy(dbg->cand_corners + (size_t)slot * cap * 16, corners.data(), sizeof(double) * 16 * nv);
+        int nk = std::min((int)good_proposal_ids.size(), cap);
+        if (dbg->n_keep) dbg->n_keep[slot] = (int)good_proposal_ids.size();
+        if (dbg->keep_ids) std::memcpy(dbg->keep_ids + (size_t)slot * cap, good_proposal_ids.data(), sizeof(int) * nk);
+        if (dbg->keep_scores) std::memcpy(dbg->keep_scores + (size_t)slot * cap, normalized_score.data(), sizeof(double) * nk);
+      }
+
+      for (size_t box_id = 0; box_id < good_proposal_ids.size(); box_id++) {
+        int raw_cube_ind = good_proposal_ids[box_id];
+        if (prm->whether_sample_cam_roll_pitch) {  // :727-737
+          M4 Tn = transToWolrd;
+          M3 R = euler_zyx_to_rot(rows[9 * raw_cube_ind + 7], rows[9 * raw_cube_ind + 8], cam_pose_raw.euler_angle[2]);
+          for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Tn.m[i][j] = R.m[i][j];
+          det.set_cam_pose(Tn);
+          mat4T_vec(cam_pose.transToWolrd, ground_plane_world, ground_plane_sensor);
+        }
+        oracle_cuboid o;
+        std::memset(&o, 0, sizeof(o));
+        double c[2][8];
+        for (int r = 0; r < 2; r++) for (int k = 0; k < 8; k++) c[r][k] = corners[16 * raw_cube_ind + 8 * r + k];
+        double configs[3] = {rows[9 * raw_cube_ind + 0], rows[9 * raw_cube_ind + 1], rows[9 * raw_cube_ind + 2]};
+        change_2d_corner_to_3d_object(c, configs, ground_plane_sensor, cam_pose.transToWolrd, cam_pose.invK, o);
+        if (o.scale[0] < 0 || o.scale[1] < 0 || o.scale[2] < 0) continue;  // :766
+        o.rect_detect_2d[0] = left_x_raw; o.rect_detect_2d[1] = top_y_raw; o.rect_detect_2d[2] = obj_width_raw; o.rect_detect_2d[3] = obj_height_raw;
+        o.edge_distance_error = rows[9 * raw_cube_ind + 4];
+        o.edge_angle_error = rows[9 * raw_cube_ind + 5];
+        o.normalized_error = normalized_score[box_id];
+        o.skew_ratio = std::max(o.scale[0], o.scale[1]) / std::min(o.scale[0], o.scale[1]);
+        o.down_expand_height = rows[9 * raw_cube_ind + 6];
+        if (prm->whether_sample_cam_roll_pitch) {
+          o.camera_roll_delta = rows[9 * raw_cube_ind + 7] - cam_pose_raw.euler_angle[0];
+          o.camera_pitch_delta = rows[9 * raw_cube_ind + 8] - cam_pose_raw.euler_angle[1];
+        } else {
+          o.camera_roll_delta = 0; o.camera_pitch_delta = 0;
+        }
+        raw_obj_proposals.push_back(o);
+      }
+    }  // height samples
+
+    // :804-838 final ranking
+    int actual_cuboid_num_small = std::min(prm->max_cuboid_num, (int)raw_obj_proposals.size());
+    std::vector<double> all_combined_score(raw_obj_proposals.size());
+    for (size_t box_id = 0; box_id < raw_obj_proposals.size(); box_id++) {
+      const oracle_cuboid& o = raw_obj_proposals[box_id];
+      double skew_error = weight_skew_error * std::max(o.skew_ratio - prm->nominal_skew_ratio, 0.0);
+      if (o.skew_ratio > prm->max_cut_skew) skew_error = 100;
+      all_combined_score[box_id] = o.normalized_error + weight_skew_error * skew_error;
+    }
+    std::vector<int> sort_idx_small(all_combined_score.size());
+    std::iota(sort_idx_small.begin(), sort_idx_small.end(), 0);
+    sort_indexes(all_combined_score, sort_idx_small, actual_cuboid_num_small);
+    for (int ii = 0; ii < actual_cuboid_num_small; ii++) out[(size_t)object_id * prm->max_cuboid_num + ii] = raw_obj_proposals[sort_idx_small[ii]];
+    out_counts[object_id] = actual_cuboid_num_small;
+    if (dbg) {
+      if (dbg->n_raw_proposals) dbg->n_raw_proposals[object_id] = (int)raw_obj_proposals.size();
+      if (dbg->combined_scores) {
+        int cap3 = 3 * dbg->cap_candidates;
+        int nn = std::min((int)all_combined_score.size(), cap3);
+        std::memcpy(dbg->combined_scores + (size_t)object_id * cap3, all_combined_score.data(), sizeof(double) * nn);
+      }
+    }
+  }
+  return 0;
+}
+
+// Known-answer helpers (tests/test_oracle_kat.py): the 3D lift alone and the 3D corners alone.
+void oracle_compute3d_box_corner(const double pos[3], const double scale[3], double rotY, double out24[24]) {
+  oracle_cuboid o;
+  std::memset(&o, 0, sizeof(o));
+  for (int i = 0; i < 3; i++) { o.pos[i] = pos[i]; o.scale[i] = scale[i]; }
+  o.rotY = rotY;
+  const double body[3][8] = {{1, 1, -1, -1, 1, 1, -1, -1}, {1, -1, -1, 1, 1, -1, -1, 1}, {-1, -1, -1, -1, 1, 1, 1, 1}};
+  double cr = std::cos(rotY), sr = std::sin(rotY);
+  double rot[3][3] = {{cr, -sr, 0}, {sr, cr, 0}, {0, 0, 1}};
+  for (int k = 0; k < 8; k++)
+    for (int i = 0; i < 3; i++)
+      out24[i * 8 + k] = ((rot[i][0] * scale[0] * body[0][k] + rot[i][1] * scale[1] * body[1][k]) + rot[i][2] * scale[2] * body[2][k]) + pos[i];
+}
+
+void oracle_plane_hits_3d(const double T_wc[16], const double K[9], const double plane_sensor[4], const double* pixels_xy, int n, double* out_xyz) {
+  M4 T; M3 Km;
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) T.m[i][j] = T_wc[4 * i + j];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Km.m[i][j] = K[3 * i + j];
+  M3 invK = inverse3(Km);
+  for (int k = 0; k < n; k++) plane_hits_3d(T, invK, plane_sensor, pixels_xy[2 * k], pixels_xy[2 * k + 1], out_xyz + 3 * k);
+}
+
+void oracle_change_2d_corner_to_3d(const double corners16[16], const double configs[3], const double T_wc[16], const double K[9], oracle_cuboid* o) {
+  M4 T; M3 Km;
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) T.m[i][j] = T_wc[4 * i + j];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Km.m[i][j] = K[3 * i + j];
+  M3 invK = inverse3(Km);
+  const double gw[4] = {0, 0, 1, 0};
+  double gs[4];
+  mat4T_vec(T, gw, gs);
+  double c[2][8];
+  for (int r = 0; r < 2; r++) for (int k = 0; k < 8; k++) c[r][k] = corners16[8 * r + k];
+  std::memset(o, 0, sizeof(*o));
+  change_2d_corner_to_3d_object(c, configs, gs, T, invK, *o);
+}
+
+int oracle_sizeof_cuboid() { return (int)sizeof(oracle_cuboid); }
+
+}  // extern "C"
