@@ -1,0 +1,999 @@
+// detect_host.cpp -- host side of path A (detect_cuboid) behind the C ABI of include/cubeslam_hip.h.
+//
+// Stages of one cs_batch_run():
+//   setup   (host, threaded)  per frame: camera cache (box_proposal_detail.cpp:45-56); per box and height
+//                             sample: integer box/ROI geometry (:143-256), ROI line filter (:271-283),
+//                             merge_break_lines (object_3d_util.cpp:431-543), line angles/midpoints
+//                             (:309-315), yaw / top-edge / roll-pitch sample lists (:180-184, :212-219,
+//                             :344-355)  ->  JobDesc + pooled SoA arrays, one H2D copy;
+//   sweep   (HIP)             vp_support_kernel, candidate_kernel, ordered compaction (detect_kernels.hip);
+//   rank    (host, threaded)  fuse_normalize_scores_v2 (object_3d_util.cpp:726-837) and the final
+//                             skew-weighted ranking (box_proposal_detail.cpp:766-838) on the compacted
+//                             (dist, angle, skew) columns;
+//   finish  (HIP + host)      gather the winners' corners, build the cs_cuboid records (:740-798,
+//                             object_3d_util.cpp:941-1011).
+// With whether_sample_cam_roll_pitch the reference carries cam_pose.camera_yaw from one box to the next
+// (:180 reads what :374/:734 left behind), so boxes of a frame are processed in rounds (round r = box r of
+// every frame); without it all boxes of all frames go through the sweep in one launch.
+//
+// There is no CPU fallback for the sweep: without a HIP device cs_detector_create() fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/cubeslam_hip.h"
+#include "detect_types.h"
+
+namespace cs {
+void launch_vp_support(const DetectDeviceView& v, const SweepParams& sp, int vp_total, hipStream_t st);
+void launch_candidates(const DetectDeviceView& v, const SweepParams& sp, long long slot_total, hipStream_t st);
+void launch_scan_compact(const DetectDeviceView& v, hipStream_t st);
+void launch_gather_corners(const double* corners, const long long* slots, int n, double* out, hipStream_t st);
+}  // namespace cs
+
+namespace {
+
+thread_local std::string g_err;
+void set_err(const std::string& s) { g_err = s; }
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      set_err(std::string(#expr) + ": " + hipGetErrorString(_e));                             \
+      return CS_ERR_HIP;                                                                      \
+    }                                                                                         \
+  } while (0)
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+void parallel_for(int n, int n_threads, const std::function<void(int)>& fn) {
+  if (n <= 0) return;
+  int nt = std::max(1, std::min(n_threads, n));
+  if (nt == 1) {
+    for (int i = 0; i < n; i++) fn(i);
+    return;
+  }
+  std::atomic<int> next(0);
+  std::vector<std::thread> th;
+  th.reserve(nt);
+  for (int t = 0; t < nt; t++)
+    th.emplace_back([&]() {
+      for (;;) {
+        int i = next.fetch_add(1);
+        if (i >= n) break;
+        fn(i);
+      }
+    });
+  for (auto& t : th) t.join();
+}
+
+// Grow-only device / pinned buffers.
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n) {
+    if (n <= cap) return CS_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = n + n / 8 + 64;
+    HIP_TRY(hipMalloc((void**)&p, want * sizeof(T)));
+    cap = want;
+    return CS_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+template <class T>
+struct PinBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n) {
+    if (n <= cap) return CS_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    size_t want = n + n / 8 + 64;
+    HIP_TRY(hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault));
+    cap = want;
+    return CS_OK;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+// ---------------------------------------------------------------- camera cache (set_cam_pose) ---
+struct M3 { double m[9]; };
+
+inline double cof3(const double* a, int i, int j) {
+  int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return a[3 * i1 + j1] * a[3 * i2 + j2] - a[3 * i1 + j2] * a[3 * i2 + j1];
+}
+// 3x3 inverse in cofactor form, the algorithm Eigen's Matrix3d::inverse() uses.
+void inv3(const double* a, double* r) {
+  double c0 = cof3(a, 0, 0), c1 = cof3(a, 1, 0), c2 = cof3(a, 2, 0);
+  double det = (c0 * a[0] + c1 * a[3]) + c2 * a[6];
+  double id = 1.0 / det;
+  r[0] = c0 * id; r[1] = c1 * id; r[2] = c2 * id;
+  r[3] = cof3(a, 0, 1) * id; r[4] = cof3(a, 1, 1) * id; r[5] = cof3(a, 2, 1) * id;
+  r[6] = cof3(a, 0, 2) * id; r[7] = cof3(a, 1, 2) * id; r[8] = cof3(a, 2, 2) * id;
+}
+void mul3(const double* a, const double* b, double* r) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) r[3 * i + j] = (a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j]) + a[3 * i + 2] * b[6 + j];
+}
+// Rotation matrix -> quaternion (Shoemake, as Eigen::Quaterniond(Matrix3d)) -> ZYX Euler angles
+// (matrix_utils.cpp:38-49).
+void rot_to_euler(const double* R, double e[3]) {
+  double w, q[3];
+  double t = R[0] + R[4] + R[8];
+  if (t > 0.0) {
+    t = std::sqrt(t + 1.0);
+    w = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[4 * i]) i = 2;
+    int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    w = (R[3 * k + j] - R[3 * j + k]) * t;
+    q[j] = (R[3 * j + i] + R[3 * i + j]) * t;
+    q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+  }
+  double qx = q[0], qy = q[1], qz = q[2];
+  e[0] = std::atan2(2 * (w * qx + qy * qz), 1 - 2 * (qx * qx + qy * qy));
+  e[1] = std::asin(2 * (w * qy - qz * qx));
+  e[2] = std::atan2(2 * (w * qz + qx * qy), 1 - 2 * (qy * qy + qz * qz));
+}
+// matrix_utils.cpp:81-96
+void euler_to_rot(double roll, double pitch, double yaw, double* R) {
+  double cp = std::cos(pitch), sp = std::sin(pitch), sr = std::sin(roll), cr = std::cos(roll), sy = std::sin(yaw), cy = std::cos(yaw);
+  R[0] = cp * cy; R[1] = (sr * sp * cy) - (cr * sy); R[2] = (cr * sp * cy) + (sr * sy);
+  R[3] = cp * sy; R[4] = (sr * sp * sy) + (cr * cy); R[5] = (cr * sp * sy) - (sr * cy);
+  R[6] = -sp; R[7] = sr * cp; R[8] = cr * cp;
+}
+
+struct CamCache {
+  cs::RpPose pose;  // KinvR, R, t, ground plane, roll, pitch
+  double euler[3];
+  double cam_yaw;
+};
+// set_cam_pose (box_proposal_detail.cpp:45-56) for rotation R (row-major 3x3) and position t.
+void make_cam(const double* K, const double* R, const double* t, CamCache& c) {
+  std::memcpy(c.pose.R, R, 9 * sizeof(double));
+  std::memcpy(c.pose.t, t, 3 * sizeof(double));
+  rot_to_euler(R, c.euler);
+  double invR[9];
+  inv3(R, invR);
+  mul3(K, invR, c.pose.KinvR);
+  c.cam_yaw = c.euler[2];
+  // ground plane in the sensor frame: T_wc^T (0,0,1,0)  (:130-131)
+  for (int i = 0; i < 3; i++) c.pose.plane[i] = ((R[0 + i] * 0.0 + R[3 + i] * 0.0) + R[6 + i] * 1.0) + 0.0 * 0.0;
+  c.pose.plane[3] = ((t[0] * 0.0 + t[1] * 0.0) + t[2] * 1.0) + 1.0 * 0.0;
+  c.pose.roll = c.euler[0];
+  c.pose.pitch = c.euler[1];
+}
+
+template <class T>
+void linespace(T a, T b, T step, std::vector<T>& out) {  // matrix_utils.cpp:368-380
+  while (a <= b) {
+    out.push_back(a);
+    a += step;
+    if (out.size() > 1000) break;
+  }
+}
+
+// merge_break_lines (object_3d_util.cpp:431-543) on a row-major n x 4 array.
+void merge_lines(std::vector<double>& L, double dist_thre, double angle_thre_deg, double len_thre) {
+  int total = (int)(L.size() / 4);
+  const double athre = angle_thre_deg / 180.0 * CS_PI;
+  std::vector<double> ang;
+  bool merged = true;
+  int rounds = 0;
+  while (merged && rounds < 500) {
+    rounds++;
+    merged = false;
+    ang.resize(total);
+    for (int i = 0; i < total; i++) ang[i] = cs::cs_atan2(L[4 * i + 3] - L[4 * i + 1], L[4 * i + 2] - L[4 * i]);
+    for (int a = 0; a < total - 1 && !merged; a++) {
+      for (int b = a + 1; b < total; b++) {
+        double diff = std::abs(ang[a] - ang[b]);
+        if (std::min(diff, CS_PI - diff) >= athre) continue;
+        double d_ab = cs::v2_dist(cs::v2(L[4 * a + 2], L[4 * a + 3]), cs::v2(L[4 * b], L[4 * b + 1]));
+        double d_ba = cs::v2_dist(cs::v2(L[4 * b + 2], L[4 * b + 3]), cs::v2(L[4 * a], L[4 * a + 1]));
+        if (!((d_ab < dist_thre) || (d_ba < dist_thre))) continue;
+        const double* s = (L[4 * a] < L[4 * b]) ? &L[4 * a] : &L[4 * b];
+        const double* e = (L[4 * a + 2] > L[4 * b + 2]) ? &L[4 * a + 2] : &L[4 * b + 2];
+        double sx = s[0], sy = s[1], ex = e[0], ey = e[1];
+        double ma = cs::cs_atan2(ey - sy, ex - sx);
+        double t = std::abs(ang[a] - ma);
+        if (std::min(t, CS_PI - t) < athre) {
+          L[4 * a] = sx; L[4 * a + 1] = sy; L[4 * a + 2] = ex; L[4 * a + 3] = ey;
+          for (int c = 0; c < 4; c++) L[4 * b + c] = L[4 * (total - 1) + c];  // swap-remove (matrix_utils.cpp:183)
+          total--;
+          merged = true;
+          break;
+        }
+      }
+    }
+  }
+  if (len_thre > 0) {
+    int k = 0;
+    for (int i = 0; i < total; i++) {
+      double len = cs::v2_dist(cs::v2(L[4 * i + 2], L[4 * i + 3]), cs::v2(L[4 * i], L[4 * i + 1]));
+      if (len > len_thre) {
+        if (k != i) for (int c = 0; c < 4; c++) L[4 * k + c] = L[4 * i + c];
+        k++;
+      }
+    }
+    total = k;
+  }
+  L.resize(4 * (size_t)total);
+}
+
+// fuse_normalize_scores_v2 (object_3d_util.cpp:726-837)
+void fuse_scores(const double* dist, const double* angle, int n, double w_angle, std::vector<int>& keep, std::vector<double>& score) {
+  keep.clear();
+  if (n > 4) {
+    int bn = (int)std::round(float(n) / 3.0 * 2.0);
+    std::vector<int> di(n), ai;
+    std::iota(di.begin(), di.end(), 0);
+    ai = di;
+    std::partial_sort(di.begin(), di.begin() + bn, di.end(), [dist](int a, int b) { return dist[a] < dist[b]; });
+    std::partial_sort(ai.begin(), ai.begin() + bn, ai.end(), [angle](int a, int b) { return angle[a] < angle[b]; });
+    std::vector<int> dk(di.begin(), di.begin() + bn - 1);
+    if (angle[ai[bn - 1]] > angle[ai[bn - 2]]) {
+      std::vector<int> ak(ai.begin(), ai.begin() + bn - 1);
+      std::sort(dk.begin(), dk.end());
+      std::sort(ak.begin(), ak.end());
+      std::set_intersection(dk.begin(), dk.end(), ak.begin(), ak.end(), std::back_inserter(keep));
+    } else {
+      keep = dk;
+    }
+  } else {
+    keep.resize(n);
+    std::iota(keep.begin(), keep.end(), 0);
+  }
+  int k = (int)keep.size();
+  double dmin = 1e6, dmax = -1, amin = 1e6, amax = -1;
+  for (int i = 0; i < k; i++) {
+    double d = dist[keep[i]], a = angle[keep[i]];
+    dmin = std::min(dmin, d); dmax = std::max(dmax, d);
+    amin = std::min(amin, a); amax = std::max(amax, a);
+  }
+  score.resize(k);
+  if (k > 1) {
+    bool na = (amax - amin) > 0;
+    for (int i = 0; i < k; i++) {
+      double d = (dist[keep[i]] - dmin) / (dmax - dmin);
+      double a = angle[keep[i]];
+      if (na) a = (a - amin) / (amax - amin);
+      score[i] = (d + w_angle * a) / (1 + w_angle);
+    }
+  } else {
+    for (int i = 0; i < k; i++) score[i] = (dist[keep[i]] + w_angle * angle[keep[i]]) / (1 + w_angle);
+  }
+}
+
+}  // namespace
+
+// ================================================================== handles ======================
+struct cs_detector {
+  cs_detect_params prm;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8] = {};
+  int n_threads = 1;
+};
+
+struct FrameIn {
+  double K[9], invK[9], R[9], t[3];
+  int img_w, img_h, n_boxes, n_lines;
+  std::vector<double> boxes;     // n x 5
+  std::vector<double> lines;     // M x 4, left-to-right aligned (object_3d_util.cpp:246-258)
+  std::vector<long long> map_offs;  // per (box, k): float offset into the device map pool (-1 = absent)
+  std::vector<cs_roi> rois;      // n x 3
+  std::vector<int> n_heights;    // n
+};
+
+struct JobHost {          // host-side companion of a JobDesc of the current round
+  int frame, box, hid;
+  int yaw_off_local;
+  std::vector<double> mids_x, mids_y, angs;
+  std::vector<int> tops;
+};
+
+struct FrameRound {       // setup products of one frame in one round
+  std::vector<cs::JobDesc> jobs;
+  std::vector<JobHost> jh;
+  std::vector<double> yaw, yaw_c, yaw_s;   // concatenated yaw lists of the boxes in this round
+};
+
+struct JobResult {        // rank-stage products retained for cs_batch_debug_*
+  int frame, box, hid, n_valid;
+  std::vector<double> rows9;     // V x 9
+  std::vector<long long> slots;  // V
+  std::vector<int> rp_idx;       // V: roll/pitch sample of each candidate
+  std::vector<int> keep;
+  std::vector<double> score;
+  std::vector<double> corners;   // V x 16 when debug is on
+};
+
+struct cs_batch {
+  cs_detector* det = nullptr;
+  int n_frames = 0, max_boxes = 0;
+  std::vector<FrameIn> frames;
+  DevBuf<float> d_maps;
+  DevBuf<double> d_invK;
+  // per-round device pools
+  DevBuf<cs::JobDesc> d_jobs;
+  DevBuf<long long> d_slot_prefix, d_job_cbase, d_c_slot, d_win_slots;
+  DevBuf<int> d_vp_prefix, d_top_x, d_flag, d_job_valid, d_c_flag;
+  DevBuf<double> d_mid_x, d_mid_y, d_ang, d_yaw, d_yaw_c, d_yaw_s, d_vp, d_bound, d_dist, d_angle, d_skew, d_corners, d_c_dist, d_c_angle, d_c_skew, d_win_corners;
+  DevBuf<cs::RpPose> d_rp;
+  PinBuf<char> h_stage;
+  PinBuf<long long> h_c_slot, h_job_cbase;
+  PinBuf<int> h_c_flag, h_job_valid;
+  PinBuf<double> h_c_dist, h_c_angle, h_c_skew, h_win_corners;
+  // state
+  bool debug = false, ran = false;
+  std::vector<JobResult> results;             // all jobs of the last run (index via job_index)
+  std::vector<int> job_index;                 // (frame*max_boxes + box)*3 + k -> results idx or -1
+  cs_detect_timing timing{};
+};
+
+extern "C" {
+
+const char* cs_last_error(void) { return g_err.c_str(); }
+
+int cs_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void cs_detect_default_params(cs_detect_params* p) {
+  if (!p) return;
+  p->consider_config_1 = 1; p->consider_config_2 = 1;
+  p->whether_sample_cam_roll_pitch = 1; p->whether_sample_bbox_height = 0;
+  p->max_cuboid_num = 1; p->nominal_skew_ratio = 1; p->max_cut_skew = 3;
+  p->yaw_range_deg = 45; p->yaw_step_deg = 6;
+  p->vp12_edge_angle_thre = 15; p->vp3_edge_angle_thre = 10; p->shorted_edge_thre = 20;
+  p->weight_vp_angle = 0.8; p->weight_skew_error = 1.5;
+  p->pre_merge_dist_thre = 20; p->pre_merge_angle_thre = 5; p->edge_length_threshold = 30;
+  p->host_threads = 0;
+}
+
+int cs_box_rois(const double box5[5], int img_w, int img_h, int sample_height, cs_roi out[3]) {
+  if (!box5 || !out) return CS_ERR_INVALID_ARG;
+  int left = box5[0], top = box5[1], w = box5[2], h = box5[3];
+  int right = left + box5[2];
+  int downs[3], nd = 0;
+  downs[nd++] = 0;
+  if (sample_height) {
+    int r = std::max(std::min(20, h - 90), 20);
+    r = std::min(r, img_h - top - h - 1);
+    if (r > 10) downs[nd++] = (int)std::round(r / 2);
+    downs[nd++] = r;
+  }
+  for (int k = 0; k < nd; k++) {
+    int he = h + downs[k];
+    int dy = top + he;
+    int e = std::min(std::max(std::min(20, w - 100), 10), std::max(std::min(20, he - 100), 10));
+    int l = std::max(0, left - e), r = std::min(img_w - 1, right + e);
+    int t = std::max(0, top - e), b = std::min(img_h - 1, dy + e);
+    out[k].left = l; out[k].top = t; out[k].width = r - l; out[k].height = b - t; out[k].down_expand = downs[k];
+  }
+  return nd;
+}
+
+int cs_detector_create(const cs_detect_params* params, int device, cs_detector** out) {
+  if (!out) return CS_ERR_INVALID_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    set_err("no HIP device visible; libcubeslam_hip has no CPU fallback");
+    return CS_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) { set_err("device index out of range"); return CS_ERR_INVALID_ARG; }
+  cs_detector* d = new cs_detector();
+  if (params) d->prm = *params; else cs_detect_default_params(&d->prm);
+  if (d->prm.max_cuboid_num < 1 || d->prm.yaw_step_deg <= 0) { delete d; set_err("bad params"); return CS_ERR_INVALID_ARG; }
+  d->device = device;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+  for (auto& e : d->ev) HIP_TRY(hipEventCreate(&e));
+  int hc = (int)std::thread::hardware_concurrency();
+  d->n_threads = d->prm.host_threads > 0 ? d->prm.host_threads : std::max(1, hc);
+  *out = d;
+  return CS_OK;
+}
+
+void cs_detector_destroy(cs_detector* d) {
+  if (!d) return;
+  (void)hipSetDevice(d->device);
+  for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
+  if (d->stream) (void)hipStreamDestroy(d->stream);
+  delete d;
+}
+
+int cs_batch_create(cs_detector* d, const cs_frame_desc* fr, int n_frames, cs_batch** out) {
+  if (!d || !out || (!fr && n_frames) || n_frames < 0) return CS_ERR_INVALID_ARG;
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(d->device));
+  cs_batch* b = new cs_batch();
+  b->det = d;
+  b->n_frames = n_frames;
+  b->frames.resize(n_frames);
+  size_t map_floats = 0;
+  for (int f = 0; f < n_frames; f++) {
+    const cs_frame_desc& s = fr[f];
+    FrameIn& F = b->frames[f];
+    if (!s.K || !s.T_wc || s.n_boxes < 0 || s.n_lines < 0 || (s.n_boxes && (!s.boxes || !s.dist_maps)) || (s.n_lines && !s.lines)) {
+      delete b; set_err("bad frame descriptor"); return CS_ERR_INVALID_ARG;
+    }
+    if (s.T_wc[12] != 0 || s.T_wc[13] != 0 || s.T_wc[14] != 0 || s.T_wc[15] != 1) {
+      delete b; set_err("T_wc must have last row 0 0 0 1"); return CS_ERR_INVALID_ARG;
+    }
+    std::memcpy(F.K, s.K, sizeof(F.K));
+    inv3(F.K, F.invK);  // set_calibration (box_proposal_detail.cpp:38-42)
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < 3; j++) F.R[3 * i + j] = s.T_wc[4 * i + j];
+      F.t[i] = s.T_wc[4 * i + 3];
+    }
+    F.img_w = s.img_w; F.img_h = s.img_h; F.n_boxes = s.n_boxes; F.n_lines = s.n_lines;
+    F.boxes.assign(s.boxes, s.boxes + 5 * (size_t)s.n_boxes);
+    F.lines.assign(s.lines, s.lines + 4 * (size_t)s.n_lines);
+    for (int i = 0; i < s.n_lines; i++)  // align_left_right_edges
+      if (F.lines[4 * i + 2] < F.lines[4 * i]) {
+        std::swap(F.lines[4 * i], F.lines[4 * i + 2]);
+        std::swap(F.lines[4 * i + 1], F.lines[4 * i + 3]);
+      }
+    F.rois.resize(3 * (size_t)s.n_boxes);
+    F.n_heights.resize(s.n_boxes);
+    F.map_offs.assign(3 * (size_t)s.n_boxes, -1);
+    for (int i = 0; i < s.n_boxes; i++) {
+      int nh = cs_box_rois(&F.boxes[5 * i], F.img_w, F.img_h, d->prm.whether_sample_bbox_height, &F.rois[3 * i]);
+      F.n_heights[i] = nh;
+      for (int k = 0; k < nh; k++) {
+        const cs_roi& r = F.rois[3 * i + k];
+        if (r.width <= 0 || r.height <= 0 || !s.dist_maps[3 * i + k]) { delete b; set_err("missing distance map / empty ROI"); return CS_ERR_INVALID_ARG; }
+        F.map_offs[3 * i + k] = (long long)map_floats;
+        map_floats += (size_t)r.width * r.height + r.width + 1;  // + one row + one float of zero padding
+      }
+    }
+    b->max_boxes = std::max(b->max_boxes, s.n_boxes);
+  }
+  // upload the distance maps (zero padded) and the per-frame invK
+  int rc = b->d_maps.ensure(map_floats + 1);
+  if (rc) { delete b; return rc; }
+  {
+    std::vector<float> stage(map_floats + 1, 0.0f);
+    for (int f = 0; f < n_frames; f++) {
+      FrameIn& F = b->frames[f];
+      for (int i = 0; i < F.n_boxes; i++)
+        for (int k = 0; k < F.n_heights[i]; k++) {
+          const cs_roi& r = F.rois[3 * i + k];
+          std::memcpy(&stage[F.map_offs[3 * i + k]], fr[f].dist_maps[3 * i + k], sizeof(float) * (size_t)r.width * r.height);
+        }
+    }
+    HIP_TRY(hipMemcpy(b->d_maps.p, stage.data(), sizeof(float) * (map_floats + 1), hipMemcpyHostToDevice));
+    std::vector<double> ik(9 * (size_t)std::max(1, n_frames));
+    for (int f = 0; f < n_frames; f++) std::memcpy(&ik[9 * f], b->frames[f].invK, 9 * sizeof(double));
+    rc = b->d_invK.ensure(ik.size());
+    if (rc) { delete b; return rc; }
+    HIP_TRY(hipMemcpy(b->d_invK.p, ik.data(), sizeof(double) * ik.size(), hipMemcpyHostToDevice));
+  }
+  *out = b;
+  return CS_OK;
+}
+
+int cs_batch_max_boxes(const cs_batch* b) { return b ? b->max_boxes : CS_ERR_INVALID_ARG; }
+
+void cs_batch_destroy(cs_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->det->device);
+  b->d_maps.release(); b->d_invK.release(); b->d_jobs.release(); b->d_slot_prefix.release(); b->d_job_cbase.release();
+  b->d_c_slot.release(); b->d_win_slots.release(); b->d_vp_prefix.release(); b->d_top_x.release(); b->d_flag.release();
+  b->d_job_valid.release(); b->d_c_flag.release(); b->d_mid_x.release(); b->d_mid_y.release(); b->d_ang.release();
+  b->d_yaw.release(); b->d_yaw_c.release(); b->d_yaw_s.release(); b->d_vp.release(); b->d_bound.release(); b->d_dist.release();
+  b->d_angle.release(); b->d_skew.release(); b->d_corners.release(); b->d_c_dist.release(); b->d_c_angle.release();
+  b->d_c_skew.release(); b->d_win_corners.release(); b->d_rp.release();
+  b->h_stage.release(); b->h_c_slot.release(); b->h_job_cbase.release(); b->h_c_flag.release(); b->h_job_valid.release();
+  b->h_c_dist.release(); b->h_c_angle.release(); b->h_c_skew.release(); b->h_win_corners.release();
+  delete b;
+}
+
+int cs_batch_set_debug(cs_batch* b, int enable) {
+  if (!b) return CS_ERR_INVALID_ARG;
+  b->debug = enable != 0;
+  return CS_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct Proposal {   // one entry of raw_obj_proposals (box_proposal_detail.cpp:195, :797)
+  int res_idx;      // JobResult index
+  int cand;         // candidate index inside the job (raw_cube_ind)
+  double normalized_error, skew;
+};
+
+struct Winner {
+  int frame, box, rank;
+  int res_idx, cand;
+  double normalized_error, skew;
+};
+
+// Build one cs_cuboid from the winner's corners (box_proposal_detail.cpp:740-798, object_3d_util.cpp:941-1011).
+void finish_cuboid(const FrameIn& F, const cs::RpPose& pose, const double* rows9, const double* corners16, const double raw_euler[3],
+                   bool sample_rp, double normalized_error, cs_cuboid& o) {
+  std::memset(&o, 0, sizeof(o));
+  cs::V2 c[8];
+  for (int i = 0; i < 8; i++) c[i] = cs::v2(corners16[i], corners16[8 + i]);
+  cs::lift_to_3d(c, pose.R, pose.t, F.invK, pose.plane, o.pos, o.scale);
+  o.rotY = rows9[2];
+  o.box_config_type[0] = rows9[0]; o.box_config_type[1] = rows9[1];
+  static const int left_ids[8] = {6, 5, 8, 7, 2, 3, 4, 1}, right_ids[8] = {5, 6, 7, 8, 3, 2, 1, 4};
+  const int* ids = (rows9[1] == 1) ? left_ids : right_ids;
+  for (int i = 0; i < 8; i++) {
+    o.box_corners_2d[i] = (int)corners16[ids[i] - 1];
+    o.box_corners_2d[8 + i] = (int)corners16[8 + ids[i] - 1];
+  }
+  // compute3D_BoxCorner (object_3d_util.cpp:59-73) with similarityTransformation (:15-44)
+  static const double body[3][8] = {{1, 1, -1, -1, 1, 1, -1, -1}, {1, -1, -1, 1, 1, -1, -1, 1}, {-1, -1, -1, -1, 1, 1, 1, 1}};
+  double cr = std::cos(o.rotY), sr = std::sin(o.rotY);
+  double rot[3][3] = {{cr, -sr, 0}, {sr, cr, 0}, {0, 0, 1}};
+  double S[4][4] = {{0}};
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) S[i][j] = rot[i][j] * o.scale[j];
+    S[i][3] = o.pos[i];
+  }
+  S[3][3] = 1;
+  for (int k = 0; k < 8; k++) {
+    double p[4] = {body[0][k], body[1][k], body[2][k], 1.0}, w[4];
+    for (int i = 0; i < 4; i++) w[i] = ((S[i][0] * p[0] + S[i][1] * p[1]) + S[i][2] * p[2]) + S[i][3] * p[3];
+    for (int i = 0; i < 3; i++) o.box_corners_3d_world[8 * i + k] = w[i] / w[3];
+  }
+  o.edge_distance_error = rows9[4];
+  o.edge_angle_error = rows9[5];
+  o.normalized_error = normalized_error;
+  o.skew_ratio = std::max(o.scale[0], o.scale[1]) / std::min(o.scale[0], o.scale[1]);
+  o.down_expand_height = rows9[6];
+  if (sample_rp) {
+    o.camera_roll_delta = rows9[7] - raw_euler[0];
+    o.camera_pitch_delta = rows9[8] - raw_euler[1];
+  }
+}
+
+}  // namespace
+
+extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_counts) {
+  if (!d || !b || b->det != d || !out || !out_counts) return CS_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(d->device));
+  const cs_detect_params& P = d->prm;
+  const bool sample_rp = P.whether_sample_cam_roll_pitch != 0;
+  const int NF = b->n_frames, MB = b->max_boxes, KMAX = P.max_cuboid_num;
+  const int NT = d->n_threads;
+  hipStream_t st = d->stream;
+  cs_detect_timing tm{};
+  double t_begin = now_ms();
+
+  std::fill(out_counts, out_counts + (size_t)NF * std::max(MB, 0), 0);
+  b->results.clear();
+  b->job_index.assign((size_t)NF * std::max(MB, 1) * 3, -1);
+
+  cs::SweepParams sp;
+  sp.vp12_thre_rad = P.vp12_edge_angle_thre / 180.0 * CS_PI;
+  sp.vp3_thre_rad = P.vp3_edge_angle_thre / 180.0 * CS_PI;
+  sp.short_thre = P.shorted_edge_thre;
+  sp.consider_config_1 = P.consider_config_1; sp.consider_config_2 = P.consider_config_2;
+
+  // ---- per-frame camera caches: raw pose and the roll/pitch sample poses (:78-79, :344-355, :368-377)
+  double t0 = now_ms();
+  std::vector<CamCache> cam_raw(NF);
+  std::vector<std::vector<CamCache>> cam_rp(NF);
+  std::vector<double> cur_yaw(NF);  // cam_pose.camera_yaw as the next box will see it (:180)
+  parallel_for(NF, NT, [&](int f) {
+    const FrameIn& F = b->frames[f];
+    make_cam(F.K, F.R, F.t, cam_raw[f]);
+    cur_yaw[f] = cam_raw[f].cam_yaw;
+    if (sample_rp) {
+      std::vector<double> rs, ps;
+      linespace<double>(cam_raw[f].euler[0] - 6.0 / 180.0 * CS_PI, cam_raw[f].euler[0] + 6.0 / 180.0 * CS_PI, 3.0 / 180.0 * CS_PI, rs);
+      linespace<double>(cam_raw[f].euler[1] - 6.0 / 180.0 * CS_PI, cam_raw[f].euler[1] + 6.0 / 180.0 * CS_PI, 3.0 / 180.0 * CS_PI, ps);
+      for (double r : rs)
+        for (double p : ps) {
+          double Rn[9];
+          euler_to_rot(r, p, cam_raw[f].euler[2], Rn);
+          CamCache c;
+          make_cam(F.K, Rn, F.t, c);
+          c.pose.roll = r; c.pose.pitch = p;  // the row stores the *sample* angles (:686)
+          cam_rp[f].push_back(c);
+        }
+    } else {
+      cam_rp[f].push_back(cam_raw[f]);
+    }
+  });
+  // rp pool: identical for every round -> upload once
+  std::vector<int> rp_off(NF + 1, 0);
+  for (int f = 0; f < NF; f++) rp_off[f + 1] = rp_off[f] + (int)cam_rp[f].size();
+  {
+    std::vector<cs::RpPose> pool(std::max(1, rp_off[NF]));
+    for (int f = 0; f < NF; f++)
+      for (size_t k = 0; k < cam_rp[f].size(); k++) pool[rp_off[f] + k] = cam_rp[f][k].pose;
+    int rc = b->d_rp.ensure(pool.size());
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(b->d_rp.p, pool.data(), sizeof(cs::RpPose) * pool.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  tm.setup_host_ms += now_ms() - t0;
+
+  // proposals per (frame, box) accumulate over height samples inside a round
+  std::vector<Winner> winners;
+  const int n_rounds = sample_rp ? MB : (MB > 0 ? 1 : 0);
+  for (int round = 0; round < n_rounds; round++) {
+    // ------------------------------------------------------------------ setup (host) ---------
+    t0 = now_ms();
+    std::vector<FrameRound> fr(NF);
+    parallel_for(NF, NT, [&](int f) {
+      const FrameIn& F = b->frames[f];
+      FrameRound& R = fr[f];
+      int b0 = sample_rp ? round : 0, b1 = sample_rp ? std::min(round + 1, F.n_boxes) : F.n_boxes;
+      for (int bi = b0; bi < b1; bi++) {
+        const double* bb = &F.boxes[5 * bi];
+        int left = bb[0], top = bb[1], w = bb[2], h = bb[3];
+        int right = left + bb[2];
+        int res = (int)std::round(std::min(20, w / 10));
+        if (res < 1) continue;  // :215 break (same for every height sample)
+        // yaw samples (:180-184)
+        double yaw_init = cur_yaw[f] - 90.0 / 180.0 * CS_PI;
+        std::vector<double> yaws;
+        linespace<double>(yaw_init - P.yaw_range_deg / 180.0 * CS_PI, yaw_init + P.yaw_range_deg / 180.0 * CS_PI, P.yaw_step_deg / 180.0 * CS_PI, yaws);
+        int yoff = (int)R.yaw.size();
+        for (double y : yaws) { R.yaw.push_back(y); R.yaw_c.push_back(std::cos(y)); R.yaw_s.push_back(std::sin(y)); }
+        std::vector<int> tops;
+        linespace<int>(left + 5, right - 5, res, tops);
+        for (int k = 0; k < F.n_heights[bi]; k++) {
+          const cs_roi& roi = F.rois[3 * bi + k];
+          cs::JobDesc jd;
+          std::memset(&jd, 0, sizeof(jd));
+          int he = h + roi.down_expand;
+          jd.g.left = left; jd.g.top = top; jd.g.right = right; jd.g.down = top + he;
+          jd.g.el = roi.left; jd.g.et = roi.top; jd.g.er = roi.left + roi.width; jd.g.eb = roi.top + roi.height;
+          jd.map_w = roi.width;
+          jd.Y = (int)yaws.size(); jd.T = (int)tops.size(); jd.RP = (int)cam_rp[f].size();
+          jd.down_expand = roi.down_expand;
+          jd.frame = f; jd.box = bi; jd.hid = k;
+          jd.map_off = F.map_offs[3 * bi + k];
+          jd.rp_off = rp_off[f];
+          jd.diag = std::sqrt(double(w * w + he * he));
+          JobHost jh;
+          jh.frame = f; jh.box = bi; jh.hid = k; jh.yaw_off_local = yoff; jh.tops = tops;
+          // ROI line filter (:271-283) + merge (:288-296) + angles/midpoints (:309-315)
+          std::vector<double> in;
+          for (int e = 0; e < F.n_lines; e++) {
+            const double* l = &F.lines[4 * e];
+            if (cs::inside_box(cs::v2(l[0], l[1]), jd.g.el, jd.g.et, jd.g.er, jd.g.eb) &&
+                cs::inside_box(cs::v2(l[2], l[3]), jd.g.el, jd.g.et, jd.g.er, jd.g.eb))
+              in.insert(in.end(), l, l + 4);
+          }
+          merge_lines(in, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold);
+          jd.m = (int)(in.size() / 4);
+          for (int i = 0; i < jd.m; i++) {
+            jh.angs.push_back(cs::cs_atan2(in[4 * i + 3] - in[4 * i + 1], in[4 * i + 2] - in[4 * i]));
+            jh.mids_x.push_back((in[4 * i] + in[4 * i + 2]) / 2);
+            jh.mids_y.push_back((in[4 * i + 1] + in[4 * i + 3]) / 2);
+          }
+          R.jobs.push_back(jd);
+          R.jh.push_back(std::move(jh));
+        }
+      }
+    });
+    // pack: offsets + one staging buffer
+    size_t nj = 0, n_lines = 0, n_yaw = 0, n_top = 0;
+    for (int f = 0; f < NF; f++) {
+      nj += fr[f].jobs.size();
+      n_yaw += fr[f].yaw.size();
+      for (auto& j : fr[f].jh) { n_lines += j.angs.size(); n_top += j.tops.size(); }
+    }
+    if (nj == 0) { tm.setup_host_ms += now_ms() - t0; continue; }
+    std::vector<cs::JobDesc> jobs(nj);
+    std::vector<long long> slot_prefix(nj + 1);
+    std::vector<int> vp_prefix(nj + 1);
+    std::vector<double> mid_x(n_lines), mid_y(n_lines), ang(n_lines), yaw(n_yaw), yaw_c(n_yaw), yaw_s(n_yaw);
+    std::vector<int> top_x(n_top);
+    std::vector<const JobHost*> jhp(nj);
+    {
+      size_t ji = 0, lo = 0, yo = 0, to = 0;
+      long long so = 0;
+      long long vo = 0;
+      for (int f = 0; f < NF; f++) {
+        FrameRound& R = fr[f];
+        std::copy(R.yaw.begin(), R.yaw.end(), yaw.begin() + yo);
+        std::copy(R.yaw_c.begin(), R.yaw_c.end(), yaw_c.begin() + yo);
+        std::copy(R.yaw_s.begin(), R.yaw_s.end(), yaw_s.begin() + yo);
+        for (size_t q = 0; q < R.jobs.size(); q++, ji++) {
+          cs::JobDesc& jd = R.jobs[q];
+          const JobHost& jh = R.jh[q];
+          jd.line_off = (int)lo; jd.yaw_off = (int)(yo + jh.yaw_off_local); jd.top_off = (int)to;
+          jd.vp_off = (int)vo; jd.slot_off = so;
+          std::copy(jh.mids_x.begin(), jh.mids_x.end(), mid_x.begin() + lo);
+          std::copy(jh.mids_y.begin(), jh.mids_y.end(), mid_y.begin() + lo);
+          std::copy(jh.angs.begin(), jh.angs.end(), ang.begin() + lo);
+          std::copy(jh.tops.begin(), jh.tops.end(), top_x.begin() + to);
+          lo += jh.angs.size(); to += jh.tops.size();
+          slot_prefix[ji] = so; vp_prefix[ji] = (int)vo;
+          vo += (long long)jd.RP * jd.Y;
+          so += (long long)jd.RP * jd.Y * jd.T * 2;
+          jobs[ji] = jd;
+          jhp[ji] = &jh;
+        }
+        yo += R.yaw.size();
+      }
+      slot_prefix[nj] = so; vp_prefix[nj] = (int)vo;
+      if (vo > 0x7fffffffLL) { set_err("too many (roll,pitch,yaw) samples in one round"); return CS_ERR_CAPACITY; }
+    }
+    const long long slot_total = slot_prefix[nj];
+    const int vp_total = vp_prefix[nj];
+    tm.setup_host_ms += now_ms() - t0;
+    tm.n_jobs += (long long)nj; tm.n_slots += slot_total;
+
+    // ------------------------------------------------------------------ H2D -----------------
+    t0 = now_ms();
+    int rc;
+#define ENS(buf, n) do { rc = (buf).ensure(n); if (rc) return rc; } while (0)
+    ENS(b->d_jobs, nj); ENS(b->d_slot_prefix, nj + 1); ENS(b->d_vp_prefix, nj + 1); ENS(b->d_job_valid, nj); ENS(b->d_job_cbase, nj + 1);
+    ENS(b->d_mid_x, n_lines + 1); ENS(b->d_mid_y, n_lines + 1); ENS(b->d_ang, n_lines + 1);
+    ENS(b->d_yaw, n_yaw + 1); ENS(b->d_yaw_c, n_yaw + 1); ENS(b->d_yaw_s, n_yaw + 1); ENS(b->d_top_x, n_top + 1);
+    ENS(b->d_vp, 6 * (size_t)vp_total + 6); ENS(b->d_bound, 6 * (size_t)vp_total + 6);
+    ENS(b->d_flag, slot_total + 1); ENS(b->d_dist, slot_total + 1); ENS(b->d_angle, slot_total + 1); ENS(b->d_skew, slot_total + 1);
+    ENS(b->d_corners, 16 * (size_t)slot_total + 16);
+#define H2D(dst, vec) HIP_TRY(hipMemcpyAsync((dst).p, (vec).data(), sizeof((vec)[0]) * (vec).size(), hipMemcpyHostToDevice, st))
+    H2D(b->d_jobs, jobs); H2D(b->d_slot_prefix, slot_prefix); H2D(b->d_vp_prefix, vp_prefix);
+    if (n_lines) { H2D(b->d_mid_x, mid_x); H2D(b->d_mid_y, mid_y); H2D(b->d_ang, ang); }
+    if (n_yaw) { H2D(b->d_yaw, yaw); H2D(b->d_yaw_c, yaw_c); H2D(b->d_yaw_s, yaw_s); }
+    if (n_top) H2D(b->d_top_x, top_x);
+    HIP_TRY(hipMemsetAsync(b->d_job_valid.p, 0, sizeof(int) * nj, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    tm.h2d_ms += now_ms() - t0;
+
+    // ------------------------------------------------------------------ sweep (HIP) ----------
+    cs::DetectDeviceView v{};
+    v.jobs = b->d_jobs.p; v.n_jobs = (int)nj; v.slot_prefix = b->d_slot_prefix.p; v.vp_prefix = b->d_vp_prefix.p;
+    v.maps = b->d_maps.p; v.mid_x = b->d_mid_x.p; v.mid_y = b->d_mid_y.p; v.line_angle = b->d_ang.p;
+    v.yaw = b->d_yaw.p; v.yaw_cos = b->d_yaw_c.p; v.yaw_sin = b->d_yaw_s.p; v.top_x = b->d_top_x.p; v.rp = b->d_rp.p; v.invK = b->d_invK.p;
+    v.vp = b->d_vp.p; v.bound = b->d_bound.p; v.flag = b->d_flag.p; v.dist_err = b->d_dist.p; v.angle_err = b->d_angle.p;
+    v.skew = b->d_skew.p; v.corners = b->d_corners.p; v.job_valid = b->d_job_valid.p; v.job_cbase = b->d_job_cbase.p;
+    HIP_TRY(hipEventRecord(d->ev[0], st));
+    cs::launch_vp_support(v, sp, vp_total, st);
+    HIP_TRY(hipEventRecord(d->ev[1], st));
+    cs::launch_candidates(v, sp, slot_total, st);
+    HIP_TRY(hipEventRecord(d->ev[2], st));
+    HIP_TRY(hipGetLastError());
+    // valid counts -> host -> size the compact arrays
+    ENS(b->h_job_valid, nj); ENS(b->h_job_cbase, nj + 1);
+    HIP_TRY(hipMemcpyAsync(b->h_job_valid.p, b->d_job_valid.p, sizeof(int) * nj, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    long long n_valid = 0;
+    for (size_t j = 0; j < nj; j++) { b->h_job_cbase.p[j] = n_valid; n_valid += b->h_job_valid.p[j]; }
+    b->h_job_cbase.p[nj] = n_valid;
+    tm.n_valid += n_valid;
+    ENS(b->d_c_slot, n_valid + 1); ENS(b->d_c_flag, n_valid + 1); ENS(b->d_c_dist, n_valid + 1); ENS(b->d_c_angle, n_valid + 1); ENS(b->d_c_skew, n_valid + 1);
+    v.c_slot = b->d_c_slot.p; v.c_flag = b->d_c_flag.p; v.c_dist = b->d_c_dist.p; v.c_angle = b->d_c_angle.p; v.c_skew = b->d_c_skew.p;
+    HIP_TRY(hipEventRecord(d->ev[3], st));
+    cs::launch_scan_compact(v, st);
+    HIP_TRY(hipEventRecord(d->ev[4], st));
+    HIP_TRY(hipGetLastError());
+    ENS(b->h_c_slot, n_valid + 1); ENS(b->h_c_flag, n_valid + 1); ENS(b->h_c_dist, n_valid + 1); ENS(b->h_c_angle, n_valid + 1); ENS(b->h_c_skew, n_valid + 1);
+    double t_d2h = now_ms();
+    if (n_valid) {
+      HIP_TRY(hipMemcpyAsync(b->h_c_slot.p, b->d_c_slot.p, sizeof(long long) * n_valid, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(b->h_c_flag.p, b->d_c_flag.p, sizeof(int) * n_valid, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(b->h_c_dist.p, b->d_c_dist.p, sizeof(double) * n_valid, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(b->h_c_angle.p, b->d_c_angle.p, sizeof(double) * n_valid, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(b->h_c_skew.p, b->d_c_skew.p, sizeof(double) * n_valid, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    tm.d2h_ms += now_ms() - t_d2h;
+    {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1])); tm.vp_kernel_ms += ms;
+      HIP_TRY(hipEventElapsedTime(&ms, d->ev[1], d->ev[2])); tm.cand_kernel_ms += ms;
+      HIP_TRY(hipEventElapsedTime(&ms, d->ev[3], d->ev[4])); tm.compact_ms += ms;
+      tm.cand_kernel_launches += 1;
+      // algorithmic bytes of the candidate kernel: maps + line arrays + vp/bound read once,
+      // 200 B written per valid proposal, 4 B flag per slot
+      long long bytes = 0;
+      for (size_t j = 0; j < nj; j++) bytes += 4LL * jobs[j].map_w * (jobs[j].g.eb - jobs[j].g.et) + 24LL * jobs[j].m;
+      bytes += 96LL * vp_total + 4LL * slot_total + 200LL * n_valid;
+      tm.cand_kernel_bytes += bytes;
+    }
+
+    // ------------------------------------------------------------------ rank (host) ----------
+    t0 = now_ms();
+    size_t res_base = b->results.size();
+    b->results.resize(res_base + nj);
+    parallel_for((int)nj, NT, [&](int j) {
+      const cs::JobDesc& jd = jobs[j];
+      JobResult& R = b->results[res_base + j];
+      R.frame = jd.frame; R.box = jd.box; R.hid = jd.hid;
+      long long c0 = b->h_job_cbase.p[j];
+      int V = b->h_job_valid.p[j];
+      R.n_valid = V;
+      R.rows9.resize(9 * (size_t)V);
+      R.slots.assign(b->h_c_slot.p + c0, b->h_c_slot.p + c0 + V);
+      R.rp_idx.resize(V);
+      const cs::RpPose* rpp = nullptr;
+      for (int i = 0; i < V; i++) {
+        long long local = R.slots[i] - jd.slot_off;
+        int cfg = (int)(local & 1) + 1;
+        long long rest = local >> 1;
+        int t = (int)(rest % jd.T);
+        int ry = (int)(rest / jd.T);
+        int rp = ry / jd.Y, y = ry - rp * jd.Y;
+        rpp = &cam_rp[jd.frame][rp].pose;
+        R.rp_idx[i] = rp;
+        double* r9 = &R.rows9[9 * (size_t)i];
+        r9[0] = cfg; r9[1] = b->h_c_flag.p[c0 + i] & cs::CAND_VP_MASK; r9[2] = yaw[jd.yaw_off + y]; r9[3] = t;
+        r9[4] = b->h_c_dist.p[c0 + i]; r9[5] = b->h_c_angle.p[c0 + i]; r9[6] = jd.down_expand;
+        r9[7] = rpp->roll; r9[8] = rpp->pitch;
+      }
+      fuse_scores(b->h_c_dist.p + c0, b->h_c_angle.p + c0, V, P.weight_vp_angle, R.keep, R.score);
+    });
+    for (size_t j = 0; j < nj; j++) b->job_index[((size_t)jobs[j].frame * MB + jobs[j].box) * 3 + jobs[j].hid] = (int)(res_base + j);
+
+    // per box: proposals over its height samples (in order), final ranking (:804-838)
+    std::vector<std::pair<int, int>> round_boxes;  // (frame, box)
+    for (size_t j = 0; j < nj; j++)
+      if (jobs[j].hid == 0) round_boxes.emplace_back(jobs[j].frame, jobs[j].box);
+    std::vector<std::vector<Winner>> win_per_box(round_boxes.size());
+    parallel_for((int)round_boxes.size(), NT, [&](int q) {
+      int f = round_boxes[q].first, bi = round_boxes[q].second;
+      const FrameIn& F = b->frames[f];
+      std::vector<Proposal> props;
+      int last_ri = -1;
+      for (int k = 0; k < F.n_heights[bi]; k++) {
+        int ri = b->job_index[((size_t)f * MB + bi) * 3 + k];
+        if (ri < 0) continue;
+        last_ri = ri;
+        const JobResult& R = b->results[ri];
+        long long c0 = b->h_job_cbase.p[ri - res_base];
+        for (size_t q2 = 0; q2 < R.keep.size(); q2++) {
+          int cand = R.keep[q2];
+          if (b->h_c_flag.p[c0 + cand] & cs::CAND_NEG_SCALE) continue;  // :766
+          props.push_back(Proposal{ri, cand, R.score[q2], b->h_c_skew.p[c0 + cand]});
+        }
+      }
+      if (sample_rp && last_ri >= 0) {
+        // cam_pose.camera_yaw as the next box of this frame reads it (:180): the reference's last
+        // set_cam_pose() of this box is the one for the last kept proposal of the last height sample
+        // (:727-737), or, when nothing was kept, the sweep's last (roll, pitch) sample (:368-377).
+        const JobResult& R = b->results[last_ri];
+        if (!R.keep.empty()) cur_yaw[f] = cam_rp[f][R.rp_idx[R.keep.back()]].cam_yaw;
+        else cur_yaw[f] = cam_rp[f].back().cam_yaw;
+      }
+      int n = (int)props.size();
+      int kk = std::min(KMAX, n);
+      std::vector<double> comb(n);
+      for (int i = 0; i < n; i++) {
+        double skew_error = P.weight_skew_error * std::max(props[i].skew - P.nominal_skew_ratio, 0.0);
+        if (props[i].skew > P.max_cut_skew) skew_error = 100;
+        comb[i] = props[i].normalized_error + P.weight_skew_error * skew_error;  // weight applied twice (:813,:820)
+      }
+      std::vector<int> idx(n);
+      std::iota(idx.begin(), idx.end(), 0);
+      std::partial_sort(idx.begin(), idx.begin() + kk, idx.end(), [&comb](int a, int c) { return comb[a] < comb[c]; });
+      for (int r = 0; r < kk; r++) {
+        const Proposal& p = props[idx[r]];
+        win_per_box[q].push_back(Winner{f, bi, r, p.res_idx, p.cand, p.normalized_error, p.skew});
+      }
+    });
+    size_t w0 = winners.size();
+    for (auto& wv : win_per_box) winners.insert(winners.end(), wv.begin(), wv.end());
+    tm.rank_host_ms += now_ms() - t0;
+
+    // ------------------------------------------------------------------ finish ---------------
+    t0 = now_ms();
+    size_t nw = winners.size() - w0;
+    std::vector<long long> wslots(nw);
+    for (size_t i = 0; i < nw; i++) wslots[i] = b->results[winners[w0 + i].res_idx].slots[winners[w0 + i].cand];
+    // debug: corners of every valid candidate of this round
+    size_t n_gather = nw + (b->debug ? (size_t)n_valid : 0);
+    if (b->debug) wslots.insert(wslots.end(), b->h_c_slot.p, b->h_c_slot.p + n_valid);
+    if (n_gather) {
+      ENS(b->d_win_slots, n_gather); ENS(b->d_win_corners, 16 * n_gather); ENS(b->h_win_corners, 16 * n_gather);
+      HIP_TRY(hipMemcpyAsync(b->d_win_slots.p, wslots.data(), sizeof(long long) * n_gather, hipMemcpyHostToDevice, st));
+      cs::launch_gather_corners(b->d_corners.p, b->d_win_slots.p, (int)n_gather, b->d_win_corners.p, st);
+      HIP_TRY(hipMemcpyAsync(b->h_win_corners.p, b->d_win_corners.p, sizeof(double) * 16 * n_gather, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+    for (size_t i = 0; i < nw; i++) {
+      const Winner& w = winners[w0 + i];
+      const JobResult& R = b->results[w.res_idx];
+      const FrameIn& F = b->frames[w.frame];
+      const double* r9 = &R.rows9[9 * (size_t)w.cand];
+      const cs::RpPose* pose = &cam_rp[w.frame][R.rp_idx[w.cand]].pose;
+      cs_cuboid& o = out[((size_t)w.frame * MB + w.box) * KMAX + w.rank];
+      finish_cuboid(F, *pose, r9, b->h_win_corners.p + 16 * i, cam_raw[w.frame].euler, sample_rp, w.normalized_error, o);
+      const double* bb = &F.boxes[5 * w.box];
+      o.rect_detect_2d[0] = (int)bb[0]; o.rect_detect_2d[1] = (int)bb[1]; o.rect_detect_2d[2] = (int)bb[2]; o.rect_detect_2d[3] = (int)bb[3];
+      out_counts[(size_t)w.frame * MB + w.box] = std::max(out_counts[(size_t)w.frame * MB + w.box], w.rank + 1);
+    }
+    if (b->debug) {
+      for (size_t j = 0; j < nj; j++) {
+        JobResult& R = b->results[res_base + j];
+        long long c0 = b->h_job_cbase.p[j];
+        R.corners.assign(b->h_win_corners.p + 16 * (nw + c0), b->h_win_corners.p + 16 * (nw + c0 + R.n_valid));
+      }
+    }
+    tm.finalize_ms += now_ms() - t0;
+  }
+  tm.total_ms = now_ms() - t_begin;
+  b->timing = tm;
+  b->ran = true;
+  return CS_OK;
+}
+
+extern "C" {
+
+int cs_batch_last_timing(const cs_batch* b, cs_detect_timing* t) {
+  if (!b || !t) return CS_ERR_INVALID_ARG;
+  if (!b->ran) return CS_ERR_NOT_RUN;
+  *t = b->timing;
+  return CS_OK;
+}
+
+int cs_batch_debug_candidates(cs_batch* b, int frame, int box, int k, int cap, double* rows9, double* corners16) {
+  if (!b || frame < 0 || frame >= b->n_frames || box < 0 || box >= b->max_boxes || k < 0 || k > 2) return CS_ERR_INVALID_ARG;
+  if (!b->ran) return CS_ERR_NOT_RUN;
+  int ri = b->job_index[((size_t)frame * b->max_boxes + box) * 3 + k];
+  if (ri < 0) return 0;
+  const JobResult& R = b->results[ri];
+  int n = std::min(cap, R.n_valid);
+  if (rows9) std::memcpy(rows9, R.rows9.data(), sizeof(double) * 9 * (size_t)n);
+  if (corners16) {
+    if (R.corners.size() < 16 * (size_t)R.n_valid) { set_err("corners not retained: call cs_batch_set_debug(b,1) before cs_batch_run"); return CS_ERR_NOT_RUN; }
+    std::memcpy(corners16, R.corners.data(), sizeof(double) * 16 * (size_t)n);
+  }
+  return R.n_valid;
+}
+
+int cs_batch_debug_kept(cs_batch* b, int frame, int box, int k, int cap, int* keep_ids, double* scores) {
+  if (!b || frame < 0 || frame >= b->n_frames || box < 0 || box >= b->max_boxes || k < 0 || k > 2) return CS_ERR_INVALID_ARG;
+  if (!b->ran) return CS_ERR_NOT_RUN;
+  int ri = b->job_index[((size_t)frame * b->max_boxes + box) * 3 + k];
+  if (ri < 0) return 0;
+  const JobResult& R = b->results[ri];
+  int n = std::min(cap, (int)R.keep.size());
+  if (keep_ids) std::memcpy(keep_ids, R.keep.data(), sizeof(int) * (size_t)n);
+  if (scores) std::memcpy(scores, R.score.data(), sizeof(double) * (size_t)n);
+  return (int)R.keep.size();
+}
+
+int cs_detect_cuboids(cs_detector* d, const cs_frame_desc* frame, cs_cuboid* out, int* out_counts) {
+  if (!d || !frame || !out || !out_counts) return CS_ERR_INVALID_ARG;
+  cs_batch* b = nullptr;
+  int rc = cs_batch_create(d, frame, 1, &b);
+  if (rc) return rc;
+  rc = cs_batch_run(d, b, out, out_counts);
+  cs_batch_destroy(b);
+  return rc;
+}
+
+}  // extern "C"

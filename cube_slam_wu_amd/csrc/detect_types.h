@@ -1,0 +1,67 @@
+// detect_types.h -- device data layout of the proposal sweep (shared by detect_kernels.hip and
+// detect_host.cpp).  See DESIGN.md "Path A: data layout in HBM".
+#pragma once
+#include <cstdint>
+
+#include "cs_geom.h"
+
+namespace cs {
+
+// One (frame, box, height sample) of detect_cuboid(): the unit the reference's loops L2..L5 run over
+// (box_proposal_detail.cpp:200-705).  All offsets index the pooled SoA arrays in DetectDeviceView.
+struct JobDesc {
+  BoxGeom g;
+  int map_w;             // width of the distance map (right_expan - left_expan, :248)
+  int m;                 // merged line segments inside the ROI (:292)
+  int Y;                 // yaw samples (:184)
+  int T;                 // top-edge samples (:219)
+  int RP;                // roll x pitch samples (:344-355)
+  int down_expand;       // height sample (:202)
+  int line_off;          // -> mid_x / mid_y / line_angle
+  int yaw_off;           // -> yaw / yaw_cos / yaw_sin
+  int top_off;           // -> top_x
+  int rp_off;            // -> rp (RpPose records)
+  int vp_off;            // -> vp / bound: first (rp, yaw) entry of this job
+  int frame, box, hid;
+  long long map_off;     // -> maps (float index)
+  long long slot_off;    // first candidate slot; slot = slot_off + ((rp*Y + yaw)*T + top)*2 + (config-1)
+  double diag;           // obj_diaglength_expan (:207)
+};
+
+struct SweepParams {
+  double vp12_thre_rad, vp3_thre_rad;  // 15 deg, 10 deg (:102-103)
+  double short_thre;                   // 20 px (:104)
+  int consider_config_1, consider_config_2;
+};
+
+// Candidate flag bits (one int per slot): low 2 bits = vp_1_position (0 = rejected), bit 2 = a
+// negative half size after the 3D lift (the reference drops those only after normalisation, :766).
+enum { CAND_VP_MASK = 3, CAND_NEG_SCALE = 4 };
+
+struct DetectDeviceView {
+  const JobDesc* jobs;
+  int n_jobs;
+  const long long* slot_prefix;  // n_jobs + 1 (== jobs[j].slot_off, total at the end)
+  const int* vp_prefix;          // n_jobs + 1
+  const float* maps;
+  const double* mid_x; const double* mid_y; const double* line_angle;
+  const double* yaw; const double* yaw_cos; const double* yaw_sin;
+  const int* top_x;
+  const RpPose* rp;
+  const double* invK;            // 9 per frame
+  // sweep intermediates
+  double* vp;                    // 6 per (job, rp, yaw): vp1.x vp1.y vp2.x vp2.y vp3.x vp3.y
+  double* bound;                 // 6 per (job, rp, yaw): the 3x2 VP support angles (NaN = none)
+  // per-slot outputs
+  int* flag;
+  double* dist_err; double* angle_err; double* skew;
+  double* corners;               // 16 per slot (x0..x7, y0..y7), written for valid slots only
+  // per-job valid counts and compacted outputs
+  int* job_valid;                // n_jobs
+  long long* job_cbase;          // n_jobs + 1, exclusive scan of job_valid
+  long long* c_slot;             // compacted: slot id
+  double* c_dist; double* c_angle; double* c_skew;
+  int* c_flag;
+};
+
+}  // namespace cs

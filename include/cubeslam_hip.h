@@ -1,0 +1,157 @@
+/* cubeslam_hip.h -- C ABI of the MI355X-native Cube SLAM hot path (libcubeslam_hip.so).
+ *
+ * Path A: detect_3d_cuboid::detect_cuboid() -- the cuboid proposal sampler/scorer.
+ *   Replaces  void detect_3d_cuboid::detect_cuboid(const cv::Mat&, const Eigen::Matrix4d&,
+ *             const Eigen::MatrixXd&, Eigen::MatrixXd, std::vector<ObjectSet>&)
+ *             (detect_3d_cuboid/include/detect_3d_cuboid/detect_3d_cuboid.h:88-92,
+ *              detect_3d_cuboid/src/box_proposal_detail.cpp:65-861)
+ *   plus      set_calibration / set_cam_pose (box_proposal_detail.cpp:38-56), which become the K
+ *             and T_wc arguments of every call.
+ * Path B (g2o bundle adjustment) is declared further down.
+ *
+ * Conventions: all matrices are row-major C arrays; pixel coordinates are 0-based; every function
+ * returns 0 on success or a negative cs_status; no C++ or torch types cross this boundary.
+ * A cs_detector owns one HIP stream; calls on one handle must not overlap (the reference class is
+ * not re-entrant either: it mutates its cam_pose member, box_proposal_detail.cpp:374,734).
+ */
+#ifndef CUBESLAM_HIP_H
+#define CUBESLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cs_status {
+  CS_OK = 0,
+  CS_ERR_INVALID_ARG = -1,
+  CS_ERR_HIP = -2,          /* a HIP runtime call failed; cs_last_error() has the text            */
+  CS_ERR_NO_DEVICE = -3,    /* no gfx950 device visible: the library never falls back to the CPU */
+  CS_ERR_CAPACITY = -4,
+  CS_ERR_NOT_RUN = -5
+} cs_status;
+
+const char* cs_last_error(void);
+int cs_device_count(void);
+
+/* ------------------------------------------------------------------ Path A: detect_cuboid ----- */
+
+/* Public flags of class detect_3d_cuboid (detect_3d_cuboid.h:95-117) + the constants hard-coded in
+ * detect_cuboid() (box_proposal_detail.cpp:102-110,184,288-290).  cs_detect_default_params() fills
+ * the reference's values.                                                                        */
+typedef struct cs_detect_params {
+  int consider_config_1;              /* detect_3d_cuboid.h:108 */
+  int consider_config_2;              /* :109 */
+  int whether_sample_cam_roll_pitch;  /* :110 */
+  int whether_sample_bbox_height;     /* :111 */
+  int max_cuboid_num;                 /* :113 */
+  double nominal_skew_ratio;          /* :114 */
+  double max_cut_skew;                /* :115 */
+  double yaw_range_deg;               /* 45  (box_proposal_detail.cpp:184) */
+  double yaw_step_deg;                /* 6   (box_proposal_detail.cpp:184) */
+  double vp12_edge_angle_thre;        /* 15  (:102) */
+  double vp3_edge_angle_thre;         /* 10  (:103) */
+  double shorted_edge_thre;           /* 20  (:104) */
+  double weight_vp_angle;             /* 0.8 (:109) */
+  double weight_skew_error;           /* 1.5 (:110) */
+  double pre_merge_dist_thre;         /* 20  (:288) */
+  double pre_merge_angle_thre;        /* 5   (:289) */
+  double edge_length_threshold;       /* 30  (:290) */
+  int host_threads;                   /* worker threads for the host stages; 0 = hardware concurrency */
+} cs_detect_params;
+
+void cs_detect_default_params(cs_detect_params* p);
+
+/* POD mirror of class cuboid (detect_3d_cuboid.h:20-41). */
+typedef struct cs_cuboid {
+  double pos[3];
+  double scale[3];                   /* half sizes */
+  double rotY;
+  double box_config_type[2];         /* configuration id, vp1 left(1)/right(2) */
+  int32_t box_corners_2d[16];        /* 2x8 row-major, row 0 = x */
+  double box_corners_3d_world[24];   /* 3x8 row-major */
+  double rect_detect_2d[4];
+  double edge_distance_error;
+  double edge_angle_error;
+  double normalized_error;
+  double skew_ratio;
+  double down_expand_height;
+  double camera_roll_delta;
+  double camera_pitch_delta;
+} cs_cuboid;
+
+/* Region of the image whose distance transform the scorer reads for (box, height sample k)
+ * (box_proposal_detail.cpp:242-248,320).  A distance map handed to this library is the float32
+ * height x width result of cv::distanceTransform(255 - cv::Canny(gray(roi),80,200), DIST_L2, 3)
+ * (:324-327).  The reference indexes it without bounds checks and, when a cuboid corner sits on the
+ * ROI's far edge, reads one row / one column past it (object_3d_util.cpp:651 with the inclusive test
+ * at :241); this library defines those reads as 0.0f.                                             */
+typedef struct cs_roi {
+  int left, top, width, height;
+  int down_expand;                   /* 0 / half / full height expansion of this sample (:160-172) */
+} cs_roi;
+
+/* Host-only helper: ROIs of the 1..3 height samples of one box [x y w h prob]; returns their count. */
+int cs_box_rois(const double box5[5], int img_w, int img_h, int whether_sample_bbox_height, cs_roi out[3]);
+
+typedef struct cs_detector cs_detector;
+typedef struct cs_batch cs_batch;
+
+/* One frame worth of detect_cuboid() arguments. */
+typedef struct cs_frame_desc {
+  const double* K;                   /* 3x3  (set_calibration)                                    */
+  const double* T_wc;                /* 4x4  camera-to-world (transToWolrd)                        */
+  int img_w, img_h;                  /* rgb_img.cols / rows                                       */
+  const double* boxes;               /* n_boxes x 5: x y w h prob (obj_bbox_coors)                */
+  int n_boxes;
+  const double* lines;               /* n_lines x 4: x1 y1 x2 y2 (all_lines_raw)                  */
+  int n_lines;
+  const float* const* dist_maps;     /* [n_boxes*3]: map of (box i, height sample k) at [3*i+k],  */
+                                     /* height*width floats of the cs_box_rois() ROI; host memory  */
+} cs_frame_desc;
+
+int cs_detector_create(const cs_detect_params* params, int device, cs_detector** out);
+void cs_detector_destroy(cs_detector* d);
+
+/* Drop-in single call: what the adapter's detect_cuboid() executes.  out: n_boxes x max_cuboid_num
+ * records (box-major), out_counts[n_boxes] = cuboids returned per box (the size of each ObjectSet). */
+int cs_detect_cuboids(cs_detector* d, const cs_frame_desc* frame, cs_cuboid* out, int* out_counts);
+
+/* Batched form for throughput: cs_batch_create() copies the frames' inputs into HBM (maps, lines,
+ * boxes, cameras); cs_batch_run() is the hot path proper -- resident inputs in, cuboids out.
+ * out / out_counts are laid out frame-major with stride max_boxes = max over frames of n_boxes:
+ * out[(f*max_boxes + i)*max_cuboid_num + k], out_counts[f*max_boxes + i].                         */
+int cs_batch_create(cs_detector* d, const cs_frame_desc* frames, int n_frames, cs_batch** out);
+int cs_batch_max_boxes(const cs_batch* b);
+int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_counts);
+void cs_batch_destroy(cs_batch* b);
+
+/* Timing of the last cs_batch_run() (milliseconds; kernel times from hipEvents on the detector's
+ * stream, host stages from a monotonic clock).                                                    */
+typedef struct cs_detect_timing {
+  double setup_host_ms, h2d_ms, vp_kernel_ms, cand_kernel_ms, compact_ms, d2h_ms, rank_host_ms, finalize_ms, total_ms;
+  long long n_jobs, n_slots, n_valid;
+  long long cand_kernel_bytes;       /* algorithmic bytes of the candidate kernel     */
+  int cand_kernel_launches;
+} cs_detect_timing;
+int cs_batch_last_timing(const cs_batch* b, cs_detect_timing* t);
+
+/* Retain every valid proposal's corners on the host during cs_batch_run() (off by default: it costs
+ * one extra device-to-host copy per run).  Needed by cs_batch_debug_candidates(..., corners16).    */
+int cs_batch_set_debug(cs_batch* b, int enable);
+
+/* Stage-by-stage inspection after cs_batch_run(), for parity tests.  (frame, box, k) names one
+ * (box, height sample) job.  Rows follow all_configs_error_one_objH (box_proposal_detail.cpp:677-690):
+ * [config, vp1 position, yaw, top sample id, dist error, angle error, down expand, roll, pitch];
+ * corners are the 2x8 box_corners_2d_float (:628-630), row-major.  Pass NULL to skip an output;
+ * cap = capacity in candidates.  Returns the number of valid candidates, or a negative cs_status. */
+int cs_batch_debug_candidates(cs_batch* b, int frame, int box, int k, int cap, double* rows9, double* corners16);
+/* good_proposal_ids / normalized_score of fuse_normalize_scores_v2 (object_3d_util.cpp:726-837). */
+int cs_batch_debug_kept(cs_batch* b, int frame, int box, int k, int cap, int* keep_ids, double* scores);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUBESLAM_HIP_H */

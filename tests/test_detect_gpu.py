@@ -1,0 +1,132 @@
+"""GPU parity: the HIP sweep (through the C ABI) against the CPU oracle, bit for bit.
+
+Stages compared per (box, height sample): candidate rows [config, vp1 side, yaw, top id, dist error,
+angle error, down expand, roll, pitch] and the 2x8 corners (box_proposal_detail.cpp:677-693), the kept
+ids and normalised scores of fuse_normalize_scores_v2, and the final cuboid records.  Integer/ranking
+outputs must be identical; doubles are compared with array_equal (bit-exact): both sides evaluate the
+same IEEE operations in the same order with contraction off and share cs_atan2.
+"""
+import numpy as np
+import pytest
+
+from cube_slam_wu_amd import capi, synth
+from oracle import oracle_py
+
+pytestmark = pytest.mark.gpu
+
+CUBOID_KEYS = ["pos", "scale", "rotY", "box_config_type", "box_corners_2d", "box_corners_3d_world", "rect_detect_2d",
+               "edge_distance_error", "edge_angle_error", "normalized_error", "skew_ratio", "down_expand_height",
+               "camera_roll_delta", "camera_pitch_delta"]
+
+
+def _oracle_params(p):
+    return oracle_py.default_params(
+        consider_config_1=p.consider_config_1, consider_config_2=p.consider_config_2,
+        whether_sample_cam_roll_pitch=p.whether_sample_cam_roll_pitch, whether_sample_bbox_height=p.whether_sample_bbox_height,
+        max_cuboid_num=p.max_cuboid_num, nominal_skew_ratio=p.nominal_skew_ratio, max_cut_skew=p.max_cut_skew,
+        yaw_range_deg=p.yaw_range_deg, yaw_step_deg=p.yaw_step_deg)
+
+
+def _check(frames, params, cap=20000):
+    det = capi.Detector(params)
+    bat = capi.Batch(det, frames, debug=True)
+    bat.run()
+    n_cmp = 0
+    for f, fr in enumerate(frames):
+        ref, dbg = oracle_py.detect_cuboid(fr, _oracle_params(params), atan2_mode=1, debug_cap=cap)
+        got = bat.cuboids(f)
+        nb = len(fr["boxes"])
+        for i in range(nb):
+            nh = len(fr["maps"][i])
+            for k in range(nh):
+                slot = 3 * i + k
+                V = int(dbg["n_valid"][slot])
+                assert V <= cap
+                rows, corners = bat.debug_candidates(f, i, k)
+                assert rows.shape[0] == V, (f, i, k, rows.shape[0], V)
+                assert np.array_equal(rows, dbg["cand_rows"][slot][:V]), (f, i, k)
+                assert np.array_equal(corners, dbg["cand_corners"][slot][:V]), (f, i, k)
+                ids, sc = bat.debug_kept(f, i, k)
+                nk = int(dbg["n_keep"][slot])
+                assert len(ids) == nk
+                assert np.array_equal(ids, dbg["keep_ids"][slot][:nk])
+                assert np.array_equal(sc, dbg["keep_scores"][slot][:nk])
+                n_cmp += V
+            assert len(got[i]) == len(ref[i]), (f, i, len(got[i]), len(ref[i]))
+            for a, b in zip(got[i], ref[i]):
+                for key in CUBOID_KEYS:
+                    assert np.array_equal(np.asarray(a[key]), np.asarray(b[key])), (f, i, key, a[key], b[key])
+    bat.close()
+    det.close()
+    return n_cmp
+
+
+def test_reference_sweep_6deg_no_sampling():
+    frames = [synth.make_frame(1000 + s) for s in range(3)]
+    n = _check(frames, capi.default_params(whether_sample_cam_roll_pitch=0))
+    assert n > 500
+
+
+def test_headline_sweep_half_degree():
+    frames = [synth.make_frame(2000 + s) for s in range(2)]
+    n = _check(frames, capi.default_params(whether_sample_cam_roll_pitch=0, yaw_step_deg=0.5))
+    assert n > 10000
+
+
+def test_roll_pitch_sampling_carries_camera_yaw():
+    frames = [synth.make_frame(3000 + s, n_boxes=4, n_lines=250) for s in range(2)]
+    n = _check(frames, capi.default_params(whether_sample_cam_roll_pitch=1, yaw_step_deg=6.0))
+    assert n > 5000
+
+
+def test_height_sampling_and_topk():
+    frames = [synth.make_frame(4000 + s, n_boxes=3, n_lines=200, sample_height=True) for s in range(2)]
+    n = _check(frames, capi.default_params(whether_sample_cam_roll_pitch=0, whether_sample_bbox_height=1, max_cuboid_num=5, yaw_step_deg=3.0))
+    assert n > 1000
+
+
+def test_single_config_flags():
+    frames = [synth.make_frame(5000)]
+    _check(frames, capi.default_params(whether_sample_cam_roll_pitch=0, consider_config_2=0))
+    _check(frames, capi.default_params(whether_sample_cam_roll_pitch=0, consider_config_1=0))
+
+
+def test_edge_cases_empty_and_ragged():
+    fr = synth.make_frame(6000, n_boxes=3, n_lines=120)
+    # no line segments at all: every VP support is NaN -> constant angle penalty
+    fr_nolines = dict(fr)
+    fr_nolines["lines"] = np.zeros((0, 4))
+    # a box too narrow to sample the top edge (w/10 < 1 -> the reference breaks, :215)
+    fr_narrow = synth.make_frame(6001, n_boxes=2, n_lines=80)
+    fr_narrow["boxes"] = fr_narrow["boxes"].copy()
+    fr_narrow["boxes"][0, 2] = 9
+    fr_narrow["rois"] = [synth.box_rois(b, fr_narrow["img_w"], fr_narrow["img_h"]) for b in fr_narrow["boxes"]]
+    fr_narrow["maps"] = [[np.zeros(r[0][2] * r[0][3] + r[0][2] + 1, np.float32) for r in rr] for rr in fr_narrow["rois"]]
+    # a frame without boxes, in the middle of a batch (ragged)
+    fr_empty = dict(fr)
+    fr_empty["boxes"] = np.zeros((0, 5)); fr_empty["maps"] = []; fr_empty["rois"] = []
+    _check([fr, fr_empty, fr_nolines, fr_narrow], capi.default_params(whether_sample_cam_roll_pitch=0))
+
+
+def test_single_frame_entry_point_matches_batch():
+    import ctypes as C
+    fr = synth.make_frame(7000, n_boxes=2, n_lines=100)
+    p = capi.default_params(whether_sample_cam_roll_pitch=0)
+    det = capi.Detector(p)
+    bat = capi.Batch(det, [fr])
+    bat.run()
+    ref = bat.raw_out_bytes()
+    # cs_detect_cuboids on the same frame
+    K = np.ascontiguousarray(fr["K"]).reshape(9); T = np.ascontiguousarray(fr["T_wc"]).reshape(16)
+    boxes = np.ascontiguousarray(fr["boxes"]); lines = np.ascontiguousarray(fr["lines"])
+    arr = (C.POINTER(C.c_float) * 6)()
+    keep = []
+    for i in range(2):
+        m = np.ascontiguousarray(fr["maps"][i][0]); keep.append(m)
+        arr[3 * i] = m.ctypes.data_as(C.POINTER(C.c_float))
+    d = capi.CsFrameDesc(capi._dp(K), capi._dp(T), fr["img_w"], fr["img_h"], capi._dp(boxes), 2, capi._dp(lines), len(lines), arr)
+    out = (capi.CsCuboid * 2)()
+    cnt = np.zeros(2, np.int32)
+    rc = capi.lib().cs_detect_cuboids(det.h, C.byref(d), out, cnt.ctypes.data_as(C.POINTER(C.c_int)))
+    assert rc == 0, capi.last_error()
+    assert bytes(out) == ref
