@@ -112,6 +112,11 @@ struct PinBuf {
   void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
+// sin and cos stay two libm calls (the reference's default Debug build makes two calls; glibc's fused
+// sincos() rounds differently in ~1.4e-3 of arguments).  The volatile copy keeps compilers from merging.
+inline double h_sin(double x) { volatile double v = x; return std::sin(v); }
+inline double h_cos(double x) { volatile double v = x; return std::cos(v); }
+
 // ---------------------------------------------------------------- camera cache (set_cam_pose) ---
 struct M3 { double m[9]; };
 
@@ -161,7 +166,7 @@ void rot_to_euler(const double* R, double e[3]) {
 }
 // matrix_utils.cpp:81-96
 void euler_to_rot(double roll, double pitch, double yaw, double* R) {
-  double cp = std::cos(pitch), sp = std::sin(pitch), sr = std::sin(roll), cr = std::cos(roll), sy = std::sin(yaw), cy = std::cos(yaw);
+  double cp = h_cos(pitch), sp = h_sin(pitch), sr = h_sin(roll), cr = h_cos(roll), sy = h_sin(yaw), cy = h_cos(yaw);
   R[0] = cp * cy; R[1] = (sr * sp * cy) - (cr * sy); R[2] = (cr * sp * cy) + (sr * sy);
   R[3] = cp * sy; R[4] = (sr * sp * sy) + (cr * cy); R[5] = (cr * sp * sy) - (sr * cy);
   R[6] = -sp; R[7] = sr * cp; R[8] = cr * cp;
@@ -557,7 +562,7 @@ void finish_cuboid(const FrameIn& F, const cs::RpPose& pose, const double* rows9
   }
   // compute3D_BoxCorner (object_3d_util.cpp:59-73) with similarityTransformation (:15-44)
   static const double body[3][8] = {{1, 1, -1, -1, 1, 1, -1, -1}, {1, -1, -1, 1, 1, -1, -1, 1}, {-1, -1, -1, -1, 1, 1, 1, 1}};
-  double cr = std::cos(o.rotY), sr = std::sin(o.rotY);
+  double cr = h_cos(o.rotY), sr = h_sin(o.rotY);
   double rot[3][3] = {{cr, -sr, 0}, {sr, cr, 0}, {0, 0, 1}};
   double S[4][4] = {{0}};
   for (int i = 0; i < 3; i++) {
@@ -666,7 +671,7 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
         std::vector<double> yaws;
         linespace<double>(yaw_init - P.yaw_range_deg / 180.0 * CS_PI, yaw_init + P.yaw_range_deg / 180.0 * CS_PI, P.yaw_step_deg / 180.0 * CS_PI, yaws);
         int yoff = (int)R.yaw.size();
-        for (double y : yaws) { R.yaw.push_back(y); R.yaw_c.push_back(std::cos(y)); R.yaw_s.push_back(std::sin(y)); }
+        for (double y : yaws) { R.yaw.push_back(y); R.yaw_c.push_back(h_cos(y)); R.yaw_s.push_back(h_sin(y)); }
         std::vector<int> tops;
         linespace<int>(left + 5, right - 5, res, tops);
         for (int k = 0; k < F.n_heights[bi]; k++) {

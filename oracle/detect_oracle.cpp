@@ -42,6 +42,12 @@ namespace {
 int g_atan2_mode = 1;
 inline double sweep_atan2(double y, double x) { return g_atan2_mode ? cs::cs_atan2(y, x) : std::atan2(y, x); }
 
+// sin/cos are called separately, never fused into glibc's sincos(): the reference's default Debug build
+// (detect_3d_cuboid/CMakeLists.txt:7-9) makes separate calls, and glibc 2.35's sincos() differs from
+// sin()/cos() by one ulp in ~1.4e-3 of arguments.  The volatile copy stops the compiler from merging.
+inline double o_sin(double x) { volatile double v = x; return std::sin(v); }
+inline double o_cos(double x) { volatile double v = x; return std::cos(v); }
+
 struct V2 { double x, y; };
 inline V2 operator-(V2 a, V2 b) { return V2{a.x - b.x, a.y - b.y}; }
 inline double norm2(V2 a) { return std::sqrt(a.x * a.x + a.y * a.y); }
@@ -106,7 +112,7 @@ void quat_to_euler_zyx(double qw, double qx, double qy, double qz, double& roll,
 
 // detect_3d_cuboid/src/matrix_utils.cpp:81-96
 M3 euler_zyx_to_rot(double roll, double pitch, double yaw) {
-  double cp = std::cos(pitch), sp = std::sin(pitch), sr = std::sin(roll), cr = std::cos(roll), sy = std::sin(yaw), cy = std::cos(yaw);
+  double cp = o_cos(pitch), sp = o_sin(pitch), sr = o_sin(roll), cr = o_cos(roll), sy = o_sin(yaw), cy = o_cos(yaw);
   M3 R;
   R.m[0][0] = cp * cy; R.m[0][1] = (sr * sp * cy) - (cr * sy); R.m[0][2] = (cr * sp * cy) + (sr * sy);
   R.m[1][0] = cp * sy; R.m[1][1] = (sr * sp * sy) + (cr * cy); R.m[1][2] = (cr * sp * sy) - (sr * cy);
@@ -501,7 +507,7 @@ void change_2d_corner_to_3d_object(const double c[2][8], const double configs[3]
   }
   // compute3D_BoxCorner: similarityTransformation * corners_body
   const double body[3][8] = {{1, 1, -1, -1, 1, 1, -1, -1}, {1, -1, -1, 1, 1, -1, -1, 1}, {-1, -1, -1, -1, 1, 1, 1, 1}};
-  double cr = std::cos(o.rotY), sr = std::sin(o.rotY);
+  double cr = o_cos(o.rotY), sr = o_sin(o.rotY);
   double rot[3][3] = {{cr, -sr, 0}, {sr, cr, 0}, {0, 0, 1}};
   double S[4][4] = {{0}};
   for (int i = 0; i < 3; i++)
@@ -675,8 +681,8 @@ int oracle_detect_cuboid(const oracle_params* prm, const double* K, const double
         V2 vps[3];
         {
           const M3& A = cam_pose.KinvR;
-          double d1[3] = {std::cos(obj_yaw_esti), std::sin(obj_yaw_esti), 0};
-          double d2[3] = {-std::sin(obj_yaw_esti), std::cos(obj_yaw_esti), 0};
+          double d1[3] = {o_cos(obj_yaw_esti), o_sin(obj_yaw_esti), 0};
+          double d2[3] = {-o_sin(obj_yaw_esti), o_cos(obj_yaw_esti), 0};
           double d3[3] = {0, 0, 1};
           const double* ds[3] = {d1, d2, d3};
           for (int v = 0; v < 3; v++) {
@@ -856,7 +862,7 @@ void oracle_compute3d_box_corner(const double pos[3], const double scale[3], dou
   for (int i = 0; i < 3; i++) { o.pos[i] = pos[i]; o.scale[i] = scale[i]; }
   o.rotY = rotY;
   const double body[3][8] = {{1, 1, -1, -1, 1, 1, -1, -1}, {1, -1, -1, 1, 1, -1, -1, 1}, {-1, -1, -1, -1, 1, 1, 1, 1}};
-  double cr = std::cos(rotY), sr = std::sin(rotY);
+  double cr = o_cos(rotY), sr = o_sin(rotY);
   double rot[3][3] = {{cr, -sr, 0}, {sr, cr, 0}, {0, 0, 1}};
   for (int k = 0; k < 8; k++)
     for (int i = 0; i < 3; i++)

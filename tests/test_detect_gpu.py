@@ -27,6 +27,14 @@ def _oracle_params(p):
         yaw_range_deg=p.yaw_range_deg, yaw_step_deg=p.yaw_step_deg)
 
 
+def _same(a, b):
+    """Bit-exact equality; NaN matches NaN (0/0 scores when every kept proposal has the same error)."""
+    a, b = np.asarray(a), np.asarray(b)
+    if a.dtype.kind == "f":
+        return np.array_equal(a, b, equal_nan=True)
+    return np.array_equal(a, b)
+
+
 def _check(frames, params, cap=20000):
     det = capi.Detector(params)
     bat = capi.Batch(det, frames, debug=True)
@@ -44,18 +52,18 @@ def _check(frames, params, cap=20000):
                 assert V <= cap
                 rows, corners = bat.debug_candidates(f, i, k)
                 assert rows.shape[0] == V, (f, i, k, rows.shape[0], V)
-                assert np.array_equal(rows, dbg["cand_rows"][slot][:V]), (f, i, k)
-                assert np.array_equal(corners, dbg["cand_corners"][slot][:V]), (f, i, k)
+                assert _same(rows, dbg["cand_rows"][slot][:V]), (f, i, k)
+                assert _same(corners, dbg["cand_corners"][slot][:V]), (f, i, k)
                 ids, sc = bat.debug_kept(f, i, k)
                 nk = int(dbg["n_keep"][slot])
                 assert len(ids) == nk
-                assert np.array_equal(ids, dbg["keep_ids"][slot][:nk])
-                assert np.array_equal(sc, dbg["keep_scores"][slot][:nk])
+                assert _same(ids, dbg["keep_ids"][slot][:nk])
+                assert _same(sc, dbg["keep_scores"][slot][:nk])
                 n_cmp += V
             assert len(got[i]) == len(ref[i]), (f, i, len(got[i]), len(ref[i]))
             for a, b in zip(got[i], ref[i]):
                 for key in CUBOID_KEYS:
-                    assert np.array_equal(np.asarray(a[key]), np.asarray(b[key])), (f, i, key, a[key], b[key])
+                    assert _same(a[key], b[key]), (f, i, key, a[key], b[key])
     bat.close()
     det.close()
     return n_cmp
