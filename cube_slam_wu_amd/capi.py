@@ -228,3 +228,132 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+# ------------------------------------------------------------------ Path B: bundle adjustment ----------
+class CsBaTiming(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("errors_ms", "linearize_ms", "reduce_ms", "schur_ms", "factor_ms", "backsub_ms", "update_ms", "total_ms")] + \
+               [("n_linearizations", C.c_longlong), ("n_solves", C.c_longlong), ("linearize_bytes", C.c_longlong), ("schur_entries", C.c_longlong)]
+
+
+DECLARED_SYMBOLS += [
+    "cs_ba_create", "cs_ba_destroy", "cs_ba_set_vertices", "cs_ba_set_edges_proj", "cs_ba_set_edges_cuboid", "cs_ba_set_edges_odom",
+    "cs_ba_compute_errors", "cs_ba_build_system", "cs_ba_solve", "cs_ba_update", "cs_ba_push", "cs_ba_pop", "cs_ba_optimize",
+    "cs_ba_get_state", "cs_ba_sizes", "cs_ba_get_system", "cs_ba_last_timing",
+]
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int)) if a is not None else None
+
+
+def _f64(a, shape):
+    return np.ascontiguousarray(np.asarray(a, np.float64).reshape(shape))
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a, np.int32).ravel())
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, last_error()))
+
+
+class BaProblem:
+    """cs_ba handle; the method names mirror the g2o calls each one replaces."""
+
+    def __init__(self, cams, cam_fixed, cuboids=None, cub_fixed=None, points=None, pt_fixed=None, cuboids_first=False, device=0):
+        L = lib()
+        self.h = C.c_void_p()
+        _chk(L.cs_ba_create(int(device), C.byref(self.h)), "cs_ba_create")
+        cams = _f64(cams, (-1, 7)); self.nc = len(cams)
+        cub = _f64(cuboids if cuboids is not None else np.zeros((0, 10)), (-1, 10)); self.no = len(cub)
+        pts = _f64(points if points is not None else np.zeros((0, 3)), (-1, 3)); self.np_ = len(pts)
+        cf = _i32(cam_fixed); of = _i32(cub_fixed if cub_fixed is not None else np.zeros(self.no)); pf = _i32(pt_fixed if pt_fixed is not None else np.zeros(self.np_))
+        _chk(L.cs_ba_set_vertices(self.h, _dp(cams), _ip(cf), self.nc, _dp(cub), _ip(of), self.no, _dp(pts), _ip(pf), self.np_, int(cuboids_first)), "cs_ba_set_vertices")
+        self.n_proj = self.n_cub = self.n_odom = 0
+
+    def set_edges_proj(self, pt, cam, uv, info4, intr4, huber=None):
+        pt, cam = _i32(pt), _i32(cam); self.n_proj = len(pt)
+        hb = _f64(huber, (-1,)) if huber is not None else None
+        _chk(lib().cs_ba_set_edges_proj(self.h, self.n_proj, _ip(pt), _ip(cam), _dp(_f64(uv, (-1, 2))), _dp(_f64(info4, (-1, 4))), _dp(_f64(intr4, (-1, 4))),
+                                        _dp(hb) if hb is not None else None), "cs_ba_set_edges_proj")
+
+    def set_edges_cuboid(self, cam, cub, meas10, info81):
+        cam, cub = _i32(cam), _i32(cub); self.n_cub = len(cam)
+        _chk(lib().cs_ba_set_edges_cuboid(self.h, self.n_cub, _ip(cam), _ip(cub), _dp(_f64(meas10, (-1, 10))), _dp(_f64(info81, (-1, 81)))), "cs_ba_set_edges_cuboid")
+
+    def set_edges_odom(self, ci, cj, meas7, info36):
+        ci, cj = _i32(ci), _i32(cj); self.n_odom = len(ci)
+        _chk(lib().cs_ba_set_edges_odom(self.h, self.n_odom, _ip(ci), _ip(cj), _dp(_f64(meas7, (-1, 7))), _dp(_f64(info36, (-1, 36)))), "cs_ba_set_edges_odom")
+
+    def compute_errors(self):
+        chi = C.c_double()
+        _chk(lib().cs_ba_compute_errors(self.h, C.byref(chi)), "cs_ba_compute_errors")
+        return chi.value
+
+    def sizes(self):
+        a, b = C.c_int(), C.c_int()
+        _chk(lib().cs_ba_sizes(self.h, C.byref(a), C.byref(b)), "cs_ba_sizes")
+        return a.value, b.value
+
+    def build_system(self):
+        _chk(lib().cs_ba_build_system(self.h), "cs_ba_build_system")
+        n, nl = self.sizes()
+        Hpp, Hll, Hpl, b = np.zeros((n, n)), np.zeros((nl // 3, 9)), np.zeros((self.n_proj, 18)), np.zeros(n + nl)
+        _chk(lib().cs_ba_get_system(self.h, _dp(Hpp), _dp(Hll), _dp(Hpl), _dp(b), None), "cs_ba_get_system")
+        return Hpp, Hll, Hpl, b
+
+    def solve(self, lam):
+        pd = C.c_int()
+        _chk(lib().cs_ba_solve(self.h, C.c_double(lam), C.byref(pd)), "cs_ba_solve")
+        n, nl = self.sizes()
+        x = np.zeros(n + nl)
+        if pd.value:
+            _chk(lib().cs_ba_get_system(self.h, None, None, None, None, _dp(x)), "cs_ba_get_system")
+        return bool(pd.value), x
+
+    def optimize(self, iters, cap=64):
+        done = C.c_int()
+        self._chi, self._lam, self._tr = np.zeros(cap), np.zeros(cap), np.zeros(cap, np.int32)
+        _chk(lib().cs_ba_optimize(self.h, int(iters), C.byref(done), _dp(self._chi), _dp(self._lam), _ip(self._tr), cap), "cs_ba_optimize")
+        self._done = done.value
+        return done.value
+
+    def history(self):
+        n = self._done
+        return self._chi[:n], self._lam[:n], self._tr[:n]
+
+    def state(self):
+        cams, cubs, pts = np.zeros((self.nc, 7)), np.zeros((self.no, 10)), np.zeros((self.np_, 3))
+        _chk(lib().cs_ba_get_state(self.h, _dp(cams), _dp(cubs), _dp(pts)), "cs_ba_get_state")
+        return cams, cubs, pts
+
+    def timing(self):
+        t = CsBaTiming()
+        _chk(lib().cs_ba_last_timing(self.h, C.byref(t)), "cs_ba_last_timing")
+        return {n: getattr(t, n) for n, _ in CsBaTiming._fields_}
+
+    def close(self):
+        if self.h:
+            lib().cs_ba_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ba_from_dict(pr, device=0, cuboids_first=False):
+    """BaProblem from a cube_slam_wu_amd.synth_ba.make_problem() dict."""
+    P = BaProblem(pr["cams"], pr["cam_fixed"], pr["cuboids"], pr["cub_fixed"], pr["points"], pr["pt_fixed"], cuboids_first=cuboids_first, device=device)
+    if len(pr["e_pt"]):
+        P.set_edges_proj(pr["e_pt"], pr["e_cam"], pr["e_uv"], pr["e_info"], pr["e_intr"], pr["e_huber"])
+    if len(pr["ce_cam"]):
+        P.set_edges_cuboid(pr["ce_cam"], pr["ce_cub"], pr["ce_meas"], pr["ce_info"])
+    if len(pr["oe_i"]):
+        P.set_edges_odom(pr["oe_i"], pr["oe_j"], pr["oe_meas"], pr["oe_info"])
+    return P

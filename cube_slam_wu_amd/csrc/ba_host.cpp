@@ -1,0 +1,632 @@
+// ba_host.cpp -- host side of path B (g2o bundle adjustment) behind the C ABI of include/cubeslam_hip.h.
+//
+// Mirrors, step for step, what g2o's BlockSolver + OptimizationAlgorithmLevenberg do
+// (object_slam/Thirdparty/g2o/g2o/core/block_solver.hpp, optimization_algorithm_levenberg.cpp): the
+// structure phase (index mapping, edge orderings, Schur pattern) runs once on the host when the edges are
+// set; every numeric step is a HIP kernel on resident data; the LM control flow (lambda schedule, accept /
+// reject, termination) is scalar host code fed by one chi2 read-back per trial.  The reduced camera/cuboid
+// system is dense and factorised with rocSOLVER potrf/potrs (the reference's LinearSolverDense uses a dense
+// Eigen::LDLT, solvers/linear_solver_dense.h:104-111).  There is no CPU fallback.
+#include <hip/hip_runtime.h>
+#include <rocsolver/rocsolver.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/cubeslam_hip.h"
+#include "ba_types.h"
+
+namespace cs {
+int ba_chi2_blocks(int n_proj);
+void ba_launch_chi2(const BaView& v, int nb_proj, hipStream_t st);
+void ba_launch_linearize(const BaView& v, hipStream_t st);
+void ba_launch_reduce(const BaView& v, double lambda, hipStream_t st);
+void ba_launch_backsub(const BaView& v, hipStream_t st);
+void ba_launch_update(const BaView& v, hipStream_t st);
+}  // namespace cs
+
+extern "C" const char* cs_last_error(void);
+void cs_set_error_ba(const std::string& s);
+
+namespace {
+
+#define BA_TRY(expr)                                                           \
+  do {                                                                         \
+    hipError_t _e = (expr);                                                    \
+    if (_e != hipSuccess) {                                                    \
+      cs_set_error_ba(std::string(#expr) + ": " + hipGetErrorString(_e));      \
+      return CS_ERR_HIP;                                                       \
+    }                                                                          \
+  } while (0)
+#define BA_ROC(expr)                                                           \
+  do {                                                                         \
+    rocblas_status _s = (expr);                                                \
+    if (_s != rocblas_status_success) {                                        \
+      cs_set_error_ba(std::string(#expr) + ": rocblas status " + std::to_string((int)_s)); \
+      return CS_ERR_HIP;                                                       \
+    }                                                                          \
+  } while (0)
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+template <class T>
+struct DBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int upload(const std::vector<T>& h) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    n = h.size();
+    BA_TRY(hipMalloc((void**)&p, std::max<size_t>(1, n) * sizeof(T)));
+    if (n) BA_TRY(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+    return CS_OK;
+  }
+  int alloc(size_t count) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    n = count;
+    BA_TRY(hipMalloc((void**)&p, std::max<size_t>(1, n) * sizeof(T)));
+    BA_TRY(hipMemset(p, 0, std::max<size_t>(1, n) * sizeof(T)));
+    return CS_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct cs_ba {
+  int device = 0;
+  hipStream_t st = nullptr;
+  rocblas_handle blas = nullptr;
+  hipEvent_t ev[2] = {};
+  // host copy of the problem description
+  int nc = 0, no = 0, np = 0, cuboids_first = 0;
+  std::vector<int> cam_fixed, cub_fixed, pt_fixed, cam_col, cub_col, pt_lm;  // pt_lm: landmark index among free points or -1
+  int n_pose = 0, n_lm = 0;
+  int n_proj = 0, n_cub = 0, n_odom = 0;
+  std::vector<int> e_pt, e_cam;      // projection edges, caller order
+  std::vector<int> pm_of_orig;       // caller edge -> point-major slot
+  std::vector<int> ce_cam, ce_cub, oe_i, oe_j;
+  bool structure_dirty = true;
+  // device buffers
+  DBuf<double> cams, points, cubes, cams_bak, points_bak, cubes_bak;
+  DBuf<int> d_cam_col, d_cub_col, d_pt_free;
+  DBuf<int> pm_pt, pm_cam, pt_ptr, cm_pm, cm_pt, cam_ptr;
+  DBuf<double> pm_uv, pm_info, pm_intr, pm_huber, cm_uv, cm_info, cm_intr, cm_huber;
+  DBuf<int> d_ce_cam, d_ce_cub, d_oe_i, d_oe_j;
+  DBuf<double> ce_meas, ce_info, ce_Hcc, ce_Hoo, ce_Hco, ce_bc, ce_bo, oe_meas, oe_info, oe_Hii, oe_Hjj, oe_Hij, oe_bi, oe_bj;
+  DBuf<int> cam_ce_ptr, cam_ce_idx, cam_oei_ptr, cam_oei_idx, cam_oej_ptr, cam_oej_idx, cub_ce_ptr, cub_ce_idx;
+  DBuf<double> Hcam, bcam, Hcub, bcub, Hll, bl, W, WD, Dinv, dbl, S, rhs, xl, chi_partial;
+  DBuf<int> pair_ptr, pair_i1, pair_i2, ent_a, ent_b;
+  DBuf<rocblas_int> d_info;
+  int n_pairs = 0, nb_chi = 1, n_chi_partials = 1;
+  long long schur_entries = 0;
+  // raw edge payloads kept until finalisation
+  std::vector<double> h_uv, h_info, h_intr, h_huber, h_ce_meas, h_ce_info, h_oe_meas, h_oe_info;
+  // last solution / rhs on the host (for LM's scale term and for inspection)
+  std::vector<double> h_b, h_x;
+  bool have_system = false;
+  cs_ba_timing tm{};
+  cs::BaView view{};
+};
+
+
+namespace {
+
+int finalize_structure(cs_ba* B) {
+  if (!B->structure_dirty) return CS_OK;
+  BA_TRY(hipSetDevice(B->device));
+  const int nc = B->nc, no = B->no, np = B->np;
+  // ---- index mapping (sparse_optimizer.cpp:166-190): non-marginalised vertices by id, then the points
+  B->cam_col.assign(nc, -1); B->cub_col.assign(no, -1); B->pt_lm.assign(np, -1);
+  int col = 0;
+  auto do_cams = [&]() { for (int i = 0; i < nc; i++) if (!B->cam_fixed[i]) { B->cam_col[i] = col; col += 6; } };
+  auto do_cubs = [&]() { for (int i = 0; i < no; i++) if (!B->cub_fixed[i]) { B->cub_col[i] = col; col += 9; } };
+  if (B->cuboids_first) { do_cubs(); do_cams(); } else { do_cams(); do_cubs(); }
+  B->n_pose = col;
+  int nl = 0;
+  std::vector<int> pt_free(np);
+  for (int i = 0; i < np; i++) { pt_free[i] = B->pt_fixed[i] ? 0 : 1; if (pt_free[i]) B->pt_lm[i] = nl++; }
+  B->n_lm = nl;
+  int rc;
+#define UP(buf, vec) do { rc = (buf).upload(vec); if (rc) return rc; } while (0)
+#define AL(buf, n) do { rc = (buf).alloc(n); if (rc) return rc; } while (0)
+  UP(B->d_cam_col, B->cam_col); UP(B->d_cub_col, B->cub_col); UP(B->d_pt_free, pt_free);
+  // ---- projection edges: point-major order (sorted by pose column inside a point), camera-major copy
+  const int E = B->n_proj;
+  for (int k = 0; k < E; k++)
+    if (B->e_pt[k] < 0 || B->e_pt[k] >= np || B->e_cam[k] < 0 || B->e_cam[k] >= nc) { cs_set_error_ba("projection edge index out of range"); return CS_ERR_INVALID_ARG; }
+  std::vector<int> order(E);
+  for (int k = 0; k < E; k++) order[k] = k;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    if (B->e_pt[a] != B->e_pt[b]) return B->e_pt[a] < B->e_pt[b];
+    return B->cam_col[B->e_cam[a]] < B->cam_col[B->e_cam[b]];
+  });
+  B->pm_of_orig.assign(E, 0);
+  std::vector<int> pm_pt(E), pm_cam(E), pt_ptr(np + 1, 0);
+  std::vector<double> pm_uv(2 * (size_t)E), pm_info(4 * (size_t)E), pm_intr(4 * (size_t)E), pm_huber(E);
+  for (int s = 0; s < E; s++) {
+    int k = order[s];
+    B->pm_of_orig[k] = s;
+    pm_pt[s] = B->e_pt[k]; pm_cam[s] = B->e_cam[k];
+    std::memcpy(&pm_uv[2 * (size_t)s], &B->h_uv[2 * (size_t)k], 16);
+    std::memcpy(&pm_info[4 * (size_t)s], &B->h_info[4 * (size_t)k], 32);
+    std::memcpy(&pm_intr[4 * (size_t)s], &B->h_intr[4 * (size_t)k], 32);
+    pm_huber[s] = B->h_huber.empty() ? 0.0 : B->h_huber[k];
+    pt_ptr[pm_pt[s] + 1]++;
+  }
+  for (int i = 0; i < np; i++) pt_ptr[i + 1] += pt_ptr[i];
+  std::vector<int> cm_pm(E), cm_pt(E), cam_ptr(nc + 1, 0);
+  for (int s = 0; s < E; s++) cam_ptr[pm_cam[s] + 1]++;
+  for (int i = 0; i < nc; i++) cam_ptr[i + 1] += cam_ptr[i];
+  {
+    std::vector<int> fill(cam_ptr.begin(), cam_ptr.end() - 1);
+    for (int s = 0; s < E; s++) { int q = fill[pm_cam[s]]++; cm_pm[q] = s; cm_pt[q] = pm_pt[s]; }
+  }
+  std::vector<double> cm_uv(2 * (size_t)E), cm_info(4 * (size_t)E), cm_intr(4 * (size_t)E), cm_huber(E);
+  for (int q = 0; q < E; q++) {
+    int s = cm_pm[q];
+    std::memcpy(&cm_uv[2 * (size_t)q], &pm_uv[2 * (size_t)s], 16);
+    std::memcpy(&cm_info[4 * (size_t)q], &pm_info[4 * (size_t)s], 32);
+    std::memcpy(&cm_intr[4 * (size_t)q], &pm_intr[4 * (size_t)s], 32);
+    cm_huber[q] = pm_huber[s];
+  }
+  UP(B->pm_pt, pm_pt); UP(B->pm_cam, pm_cam); UP(B->pt_ptr, pt_ptr); UP(B->pm_uv, pm_uv); UP(B->pm_info, pm_info); UP(B->pm_intr, pm_intr); UP(B->pm_huber, pm_huber);
+  UP(B->cm_pm, cm_pm); UP(B->cm_pt, cm_pt); UP(B->cam_ptr, cam_ptr); UP(B->cm_uv, cm_uv); UP(B->cm_info, cm_info); UP(B->cm_intr, cm_intr); UP(B->cm_huber, cm_huber);
+  // ---- Schur pattern (block_solver.hpp:262-292): (landmark, i1 <= i2) entries grouped by camera pair
+  {
+    struct Ent { long long key; int a, b; };
+    std::vector<Ent> ents;
+    const long long NP = std::max(1, B->n_pose);
+    for (int p = 0; p < np; p++) {
+      if (!pt_free[p]) continue;
+      for (int a = pt_ptr[p]; a < pt_ptr[p + 1]; a++) {
+        int ca = B->cam_col[pm_cam[a]];
+        if (ca < 0) continue;
+        for (int b = a; b < pt_ptr[p + 1]; b++) {
+          int cb = B->cam_col[pm_cam[b]];
+          if (cb < 0) continue;
+          ents.push_back(Ent{(long long)ca * NP + cb, a, b});
+        }
+      }
+    }
+    std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.key < y.key; });
+    std::vector<int> pair_ptr, pair_i1, pair_i2, ent_a(ents.size()), ent_b(ents.size());
+    for (size_t i = 0; i < ents.size(); i++) {
+      if (i == 0 || ents[i].key != ents[i - 1].key) {
+        pair_ptr.push_back((int)i);
+        pair_i1.push_back((int)(ents[i].key / NP));
+        pair_i2.push_back((int)(ents[i].key % NP));
+      }
+      ent_a[i] = ents[i].a; ent_b[i] = ents[i].b;
+    }
+    pair_ptr.push_back((int)ents.size());
+    B->n_pairs = (int)pair_i1.size();
+    B->schur_entries = (long long)ents.size();
+    UP(B->pair_ptr, pair_ptr); UP(B->pair_i1, pair_i1); UP(B->pair_i2, pair_i2); UP(B->ent_a, ent_a); UP(B->ent_b, ent_b);
+  }
+  // ---- cuboid / odometry edges and their vertex adjacency
+  for (int k = 0; k < B->n_cub; k++)
+    if (B->ce_cam[k] < 0 || B->ce_cam[k] >= nc || B->ce_cub[k] < 0 || B->ce_cub[k] >= no) { cs_set_error_ba("cuboid edge index out of range"); return CS_ERR_INVALID_ARG; }
+  for (int k = 0; k < B->n_odom; k++)
+    if (B->oe_i[k] < 0 || B->oe_i[k] >= nc || B->oe_j[k] < 0 || B->oe_j[k] >= nc) { cs_set_error_ba("odometry edge index out of range"); return CS_ERR_INVALID_ARG; }
+  auto csr = [&](int nv, const std::vector<int>& owner, std::vector<int>& ptr, std::vector<int>& idx) {
+    ptr.assign(nv + 1, 0);
+    for (int o : owner) ptr[o + 1]++;
+    for (int i = 0; i < nv; i++) ptr[i + 1] += ptr[i];
+    idx.resize(owner.size());
+    std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+    for (size_t k = 0; k < owner.size(); k++) idx[fill[owner[k]]++] = (int)k;
+  };
+  std::vector<int> p1, i1, p2, i2, p3, i3, p4, i4;
+  csr(nc, B->ce_cam, p1, i1); csr(nc, B->oe_i, p2, i2); csr(nc, B->oe_j, p3, i3); csr(no, B->ce_cub, p4, i4);
+  UP(B->cam_ce_ptr, p1); UP(B->cam_ce_idx, i1); UP(B->cam_oei_ptr, p2); UP(B->cam_oei_idx, i2);
+  UP(B->cam_oej_ptr, p3); UP(B->cam_oej_idx, i3); UP(B->cub_ce_ptr, p4); UP(B->cub_ce_idx, i4);
+  UP(B->d_ce_cam, B->ce_cam); UP(B->d_ce_cub, B->ce_cub); UP(B->d_oe_i, B->oe_i); UP(B->d_oe_j, B->oe_j);
+  UP(B->ce_meas, B->h_ce_meas); UP(B->ce_info, B->h_ce_info); UP(B->oe_meas, B->h_oe_meas); UP(B->oe_info, B->h_oe_info);
+  AL(B->ce_Hcc, 36 * (size_t)B->n_cub); AL(B->ce_Hoo, 81 * (size_t)B->n_cub); AL(B->ce_Hco, 54 * (size_t)B->n_cub); AL(B->ce_bc, 6 * (size_t)B->n_cub); AL(B->ce_bo, 9 * (size_t)B->n_cub);
+  AL(B->oe_Hii, 36 * (size_t)B->n_odom); AL(B->oe_Hjj, 36 * (size_t)B->n_odom); AL(B->oe_Hij, 36 * (size_t)B->n_odom); AL(B->oe_bi, 6 * (size_t)B->n_odom); AL(B->oe_bj, 6 * (size_t)B->n_odom);
+  // ---- linear system storage
+  AL(B->Hcam, 36 * (size_t)nc); AL(B->bcam, 6 * (size_t)nc); AL(B->Hcub, 81 * (size_t)no); AL(B->bcub, 9 * (size_t)no);
+  AL(B->Hll, 9 * (size_t)np); AL(B->bl, 3 * (size_t)np); AL(B->W, 18 * (size_t)E); AL(B->WD, 18 * (size_t)E);
+  AL(B->Dinv, 9 * (size_t)np); AL(B->dbl, 3 * (size_t)np); AL(B->S, (size_t)B->n_pose * B->n_pose); AL(B->rhs, B->n_pose); AL(B->xl, 3 * (size_t)np);
+  B->nb_chi = cs::ba_chi2_blocks(E);
+  B->n_chi_partials = B->nb_chi + (B->n_cub + B->n_odom + 63) / 64;
+  AL(B->chi_partial, B->n_chi_partials);
+  AL(B->d_info, 1);
+  AL(B->cams_bak, 7 * (size_t)nc); AL(B->points_bak, 3 * (size_t)np); AL(B->cubes_bak, 10 * (size_t)no);
+#undef UP
+#undef AL
+  cs::BaView& v = B->view;
+  v.cams = B->cams.p; v.points = B->points.p; v.cubes = B->cubes.p; v.cam_col = B->d_cam_col.p; v.cub_col = B->d_cub_col.p; v.pt_free = B->d_pt_free.p;
+  v.nc = nc; v.np = np; v.no = no; v.n_pose = B->n_pose;
+  v.n_proj = E; v.pm_pt = B->pm_pt.p; v.pm_cam = B->pm_cam.p; v.pm_uv = B->pm_uv.p; v.pm_info = B->pm_info.p; v.pm_intr = B->pm_intr.p; v.pm_huber = B->pm_huber.p;
+  v.pt_ptr = B->pt_ptr.p; v.cm_pm = B->cm_pm.p; v.cm_pt = B->cm_pt.p; v.cm_uv = B->cm_uv.p; v.cm_info = B->cm_info.p; v.cm_intr = B->cm_intr.p; v.cm_huber = B->cm_huber.p; v.cam_ptr = B->cam_ptr.p;
+  v.n_cub = B->n_cub; v.ce_cam = B->d_ce_cam.p; v.ce_cub = B->d_ce_cub.p; v.ce_meas = B->ce_meas.p; v.ce_info = B->ce_info.p;
+  v.ce_Hcc = B->ce_Hcc.p; v.ce_Hoo = B->ce_Hoo.p; v.ce_Hco = B->ce_Hco.p; v.ce_bc = B->ce_bc.p; v.ce_bo = B->ce_bo.p;
+  v.n_odom = B->n_odom; v.oe_i = B->d_oe_i.p; v.oe_j = B->d_oe_j.p; v.oe_meas = B->oe_meas.p; v.oe_info = B->oe_info.p;
+  v.oe_Hii = B->oe_Hii.p; v.oe_Hjj = B->oe_Hjj.p; v.oe_Hij = B->oe_Hij.p; v.oe_bi = B->oe_bi.p; v.oe_bj = B->oe_bj.p;
+  v.cam_ce_ptr = B->cam_ce_ptr.p; v.cam_ce_idx = B->cam_ce_idx.p; v.cam_oei_ptr = B->cam_oei_ptr.p; v.cam_oei_idx = B->cam_oei_idx.p;
+  v.cam_oej_ptr = B->cam_oej_ptr.p; v.cam_oej_idx = B->cam_oej_idx.p; v.cub_ce_ptr = B->cub_ce_ptr.p; v.cub_ce_idx = B->cub_ce_idx.p;
+  v.Hcam = B->Hcam.p; v.bcam = B->bcam.p; v.Hcub = B->Hcub.p; v.bcub = B->bcub.p; v.Hll = B->Hll.p; v.bl = B->bl.p; v.W = B->W.p; v.WD = B->WD.p;
+  v.Dinv = B->Dinv.p; v.dbl = B->dbl.p; v.S = B->S.p; v.rhs = B->rhs.p; v.xl = B->xl.p;
+  v.n_pairs = B->n_pairs; v.pair_ptr = B->pair_ptr.p; v.pair_i1 = B->pair_i1.p; v.pair_i2 = B->pair_i2.p; v.ent_a = B->ent_a.p; v.ent_b = B->ent_b.p;
+  v.chi_partial = B->chi_partial.p;
+  B->structure_dirty = false;
+  B->have_system = false;
+  return CS_OK;
+}
+
+int chi2_device(cs_ba* B, double* chi) {
+  cs::ba_launch_chi2(B->view, B->nb_chi, B->st);
+  BA_TRY(hipGetLastError());
+  std::vector<double> part(B->n_chi_partials);
+  BA_TRY(hipMemcpyAsync(part.data(), B->chi_partial.p, sizeof(double) * part.size(), hipMemcpyDeviceToHost, B->st));
+  BA_TRY(hipStreamSynchronize(B->st));
+  double s = 0;
+  for (double p : part) s += p;  // fixed order
+  *chi = s;
+  return CS_OK;
+}
+
+// b (poses then landmarks) to the host: LM's scale term needs it (optimization_algorithm_levenberg.cpp:182-189)
+int fetch_b(cs_ba* B) {
+  B->h_b.assign(B->n_pose + 3 * (size_t)B->n_lm, 0.0);
+  std::vector<double> bc(6 * (size_t)B->nc), bo(9 * (size_t)B->no), bl(3 * (size_t)B->np);
+  if (B->nc) BA_TRY(hipMemcpyAsync(bc.data(), B->bcam.p, 8 * bc.size(), hipMemcpyDeviceToHost, B->st));
+  if (B->no) BA_TRY(hipMemcpyAsync(bo.data(), B->bcub.p, 8 * bo.size(), hipMemcpyDeviceToHost, B->st));
+  if (B->np) BA_TRY(hipMemcpyAsync(bl.data(), B->bl.p, 8 * bl.size(), hipMemcpyDeviceToHost, B->st));
+  BA_TRY(hipStreamSynchronize(B->st));
+  for (int i = 0; i < B->nc; i++) if (B->cam_col[i] >= 0) std::memcpy(&B->h_b[B->cam_col[i]], &bc[6 * (size_t)i], 48);
+  for (int i = 0; i < B->no; i++) if (B->cub_col[i] >= 0) std::memcpy(&B->h_b[B->cub_col[i]], &bo[9 * (size_t)i], 72);
+  for (int i = 0; i < B->np; i++) if (B->pt_lm[i] >= 0) std::memcpy(&B->h_b[B->n_pose + 3 * (size_t)B->pt_lm[i]], &bl[3 * (size_t)i], 24);
+  return CS_OK;
+}
+
+int fetch_x(cs_ba* B) {
+  B->h_x.assign(B->n_pose + 3 * (size_t)B->n_lm, 0.0);
+  std::vector<double> xl(3 * (size_t)B->np);
+  if (B->n_pose) BA_TRY(hipMemcpyAsync(B->h_x.data(), B->rhs.p, 8 * (size_t)B->n_pose, hipMemcpyDeviceToHost, B->st));
+  if (B->np) BA_TRY(hipMemcpyAsync(xl.data(), B->xl.p, 8 * xl.size(), hipMemcpyDeviceToHost, B->st));
+  BA_TRY(hipStreamSynchronize(B->st));
+  for (int i = 0; i < B->np; i++) if (B->pt_lm[i] >= 0) std::memcpy(&B->h_x[B->n_pose + 3 * (size_t)B->pt_lm[i]], &xl[3 * (size_t)i], 24);
+  return CS_OK;
+}
+
+int build_system_device(cs_ba* B) {
+  double t0 = now_ms();
+  cs::ba_launch_linearize(B->view, B->st);
+  BA_TRY(hipGetLastError());
+  BA_TRY(hipStreamSynchronize(B->st));
+  B->tm.linearize_ms += now_ms() - t0;
+  B->tm.n_linearizations++;
+  B->have_system = true;
+  return CS_OK;
+}
+
+// setLambda + solve + restoreDiagonal (block_solver.hpp:353-486, :563-604): lambda is applied while the
+// reduced system is assembled, so the stored blocks are never modified and nothing needs restoring.
+int solve_device(cs_ba* B, double lambda, bool* ok) {
+  double t0 = now_ms();
+  const int n = B->n_pose;
+  *ok = true;
+  if (n > 0) {
+    BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (size_t)n * n, B->st));
+    cs::ba_launch_reduce(B->view, lambda, B->st);
+    BA_TRY(hipGetLastError());
+    BA_TRY(hipStreamSynchronize(B->st));
+    double t1 = now_ms();
+    B->tm.reduce_ms += t1 - t0;
+    BA_ROC(rocsolver_dpotrf(B->blas, rocblas_fill_lower, n, B->S.p, n, B->d_info.p));
+    rocblas_int info = 0;
+    BA_TRY(hipMemcpyAsync(&info, B->d_info.p, sizeof(info), hipMemcpyDeviceToHost, B->st));
+    BA_TRY(hipStreamSynchronize(B->st));
+    if (info != 0) { *ok = false; }
+    else BA_ROC(rocsolver_dpotrs(B->blas, rocblas_fill_lower, n, 1, B->S.p, n, B->rhs.p, n));
+    BA_TRY(hipStreamSynchronize(B->st));
+    double t2 = now_ms();
+    B->tm.factor_ms += t2 - t1;
+    if (*ok) {
+      cs::ba_launch_backsub(B->view, B->st);
+      BA_TRY(hipGetLastError());
+      BA_TRY(hipStreamSynchronize(B->st));
+    }
+    B->tm.backsub_ms += now_ms() - t2;
+  }
+  B->tm.n_solves++;
+  return CS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cs_ba_create(int device, cs_ba** out) {
+  if (!out) return CS_ERR_INVALID_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { cs_set_error_ba("no HIP device visible; libcubeslam_hip has no CPU fallback"); return CS_ERR_NO_DEVICE; }
+  if (device < 0 || device >= n) { cs_set_error_ba("device index out of range"); return CS_ERR_INVALID_ARG; }
+  cs_ba* B = new cs_ba();
+  B->device = device;
+  BA_TRY(hipSetDevice(device));
+  BA_TRY(hipStreamCreateWithFlags(&B->st, hipStreamNonBlocking));
+  BA_ROC(rocblas_create_handle(&B->blas));
+  BA_ROC(rocblas_set_stream(B->blas, B->st));
+  *out = B;
+  return CS_OK;
+}
+
+void cs_ba_destroy(cs_ba* B) {
+  if (!B) return;
+  (void)hipSetDevice(B->device);
+  DBuf<double>* dd[] = {&B->cams, &B->points, &B->cubes, &B->cams_bak, &B->points_bak, &B->cubes_bak, &B->pm_uv, &B->pm_info, &B->pm_intr, &B->pm_huber,
+                        &B->cm_uv, &B->cm_info, &B->cm_intr, &B->cm_huber, &B->ce_meas, &B->ce_info, &B->ce_Hcc, &B->ce_Hoo, &B->ce_Hco, &B->ce_bc, &B->ce_bo,
+                        &B->oe_meas, &B->oe_info, &B->oe_Hii, &B->oe_Hjj, &B->oe_Hij, &B->oe_bi, &B->oe_bj, &B->Hcam, &B->bcam, &B->Hcub, &B->bcub, &B->Hll, &B->bl,
+                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial};
+  for (auto* d : dd) d->release();
+  DBuf<int>* di[] = {&B->d_cam_col, &B->d_cub_col, &B->d_pt_free, &B->pm_pt, &B->pm_cam, &B->pt_ptr, &B->cm_pm, &B->cm_pt, &B->cam_ptr, &B->d_ce_cam, &B->d_ce_cub,
+                     &B->d_oe_i, &B->d_oe_j, &B->cam_ce_ptr, &B->cam_ce_idx, &B->cam_oei_ptr, &B->cam_oei_idx, &B->cam_oej_ptr, &B->cam_oej_idx, &B->cub_ce_ptr,
+                     &B->cub_ce_idx, &B->pair_ptr, &B->pair_i1, &B->pair_i2, &B->ent_a, &B->ent_b};
+  for (auto* d : di) d->release();
+  B->d_info.release();
+  if (B->blas) rocblas_destroy_handle(B->blas);
+  if (B->st) (void)hipStreamDestroy(B->st);
+  delete B;
+}
+
+int cs_ba_set_vertices(cs_ba* B, const double* cams7, const int* cam_fixed, int nc, const double* cuboids10, const int* cub_fixed, int no,
+                       const double* points3, const int* pt_fixed, int np, int cuboids_first) {
+  if (!B || nc < 0 || no < 0 || np < 0 || (nc && (!cams7 || !cam_fixed)) || (no && (!cuboids10 || !cub_fixed)) || (np && (!points3 || !pt_fixed))) return CS_ERR_INVALID_ARG;
+  BA_TRY(hipSetDevice(B->device));
+  B->nc = nc; B->no = no; B->np = np; B->cuboids_first = cuboids_first;
+  B->cam_fixed.assign(cam_fixed, cam_fixed + nc); B->cub_fixed.assign(cub_fixed, cub_fixed + no); B->pt_fixed.assign(pt_fixed, pt_fixed + np);
+  // SE3Quat(Vector7d) normalises the rotation and makes w >= 0 (se3quat.h:68-71); cuboid::fromVector does not.
+  std::vector<double> c(cams7, cams7 + 7 * (size_t)nc);
+  for (int i = 0; i < nc; i++) { cs::Pose p = cs::pose_load(&c[7 * (size_t)i]); cs::pose_normalize(p); cs::pose_store(p, &c[7 * (size_t)i]); }
+  int rc = B->cams.upload(c); if (rc) return rc;
+  rc = B->cubes.upload(std::vector<double>(cuboids10, cuboids10 + 10 * (size_t)no)); if (rc) return rc;
+  rc = B->points.upload(std::vector<double>(points3, points3 + 3 * (size_t)np)); if (rc) return rc;
+  B->structure_dirty = true;
+  return CS_OK;
+}
+
+int cs_ba_set_edges_proj(cs_ba* B, int n, const int* pt, const int* cam, const double* uv, const double* info4, const double* intr4, const double* huber) {
+  if (!B || n < 0 || (n && (!pt || !cam || !uv || !info4 || !intr4))) return CS_ERR_INVALID_ARG;
+  B->n_proj = n;
+  B->e_pt.assign(pt, pt + n); B->e_cam.assign(cam, cam + n);
+  B->h_uv.assign(uv, uv + 2 * (size_t)n); B->h_info.assign(info4, info4 + 4 * (size_t)n); B->h_intr.assign(intr4, intr4 + 4 * (size_t)n);
+  if (huber) B->h_huber.assign(huber, huber + n); else B->h_huber.clear();
+  B->structure_dirty = true;
+  return CS_OK;
+}
+
+int cs_ba_set_edges_cuboid(cs_ba* B, int n, const int* cam, const int* cub, const double* meas10, const double* info81) {
+  if (!B || n < 0 || (n && (!cam || !cub || !meas10 || !info81))) return CS_ERR_INVALID_ARG;
+  B->n_cub = n;
+  B->ce_cam.assign(cam, cam + n); B->ce_cub.assign(cub, cub + n);
+  B->h_ce_meas.assign(meas10, meas10 + 10 * (size_t)n); B->h_ce_info.assign(info81, info81 + 81 * (size_t)n);
+  B->structure_dirty = true;
+  return CS_OK;
+}
+
+int cs_ba_set_edges_odom(cs_ba* B, int n, const int* ci, const int* cj, const double* meas7, const double* info36) {
+  if (!B || n < 0 || (n && (!ci || !cj || !meas7 || !info36))) return CS_ERR_INVALID_ARG;
+  B->n_odom = n;
+  B->oe_i.assign(ci, ci + n); B->oe_j.assign(cj, cj + n);
+  B->h_oe_meas.assign(meas7, meas7 + 7 * (size_t)n);
+  for (int k = 0; k < n; k++) { cs::Pose p = cs::pose_load(&B->h_oe_meas[7 * (size_t)k]); cs::pose_normalize(p); cs::pose_store(p, &B->h_oe_meas[7 * (size_t)k]); }
+  B->h_oe_info.assign(info36, info36 + 36 * (size_t)n);
+  B->structure_dirty = true;
+  return CS_OK;
+}
+
+int cs_ba_compute_errors(cs_ba* B, double* chi2) {
+  if (!B || !chi2) return CS_ERR_INVALID_ARG;
+  BA_TRY(hipSetDevice(B->device));
+  int rc = finalize_structure(B); if (rc) return rc;
+  double t0 = now_ms();
+  rc = chi2_device(B, chi2);
+  B->tm.errors_ms += now_ms() - t0;
+  return rc;
+}
+
+int cs_ba_build_system(cs_ba* B) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  BA_TRY(hipSetDevice(B->device));
+  int rc = finalize_structure(B); if (rc) return rc;
+  rc = build_system_device(B); if (rc) return rc;
+  return fetch_b(B);
+}
+
+int cs_ba_solve(cs_ba* B, double lambda, int* pd) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  BA_TRY(hipSetDevice(B->device));
+  if (B->structure_dirty || !B->have_system) { cs_set_error_ba("cs_ba_solve: call cs_ba_build_system first"); return CS_ERR_NOT_RUN; }
+  bool ok = false;
+  int rc = solve_device(B, lambda, &ok); if (rc) return rc;
+  if (pd) *pd = ok ? 1 : 0;
+  return ok ? fetch_x(B) : CS_OK;
+}
+
+int cs_ba_update(cs_ba* B) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  BA_TRY(hipSetDevice(B->device));
+  double t0 = now_ms();
+  cs::ba_launch_update(B->view, B->st);
+  BA_TRY(hipGetLastError());
+  BA_TRY(hipStreamSynchronize(B->st));
+  B->tm.update_ms += now_ms() - t0;
+  return CS_OK;
+}
+
+int cs_ba_push(cs_ba* B) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  BA_TRY(hipSetDevice(B->device));
+  int rc = finalize_structure(B); if (rc) return rc;
+  if (B->nc) BA_TRY(hipMemcpyAsync(B->cams_bak.p, B->cams.p, 56 * (size_t)B->nc, hipMemcpyDeviceToDevice, B->st));
+  if (B->np) BA_TRY(hipMemcpyAsync(B->points_bak.p, B->points.p, 24 * (size_t)B->np, hipMemcpyDeviceToDevice, B->st));
+  if (B->no) BA_TRY(hipMemcpyAsync(B->cubes_bak.p, B->cubes.p, 80 * (size_t)B->no, hipMemcpyDeviceToDevice, B->st));
+  return CS_OK;
+}
+
+int cs_ba_pop(cs_ba* B) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  BA_TRY(hipSetDevice(B->device));
+  if (B->nc) BA_TRY(hipMemcpyAsync(B->cams.p, B->cams_bak.p, 56 * (size_t)B->nc, hipMemcpyDeviceToDevice, B->st));
+  if (B->np) BA_TRY(hipMemcpyAsync(B->points.p, B->points_bak.p, 24 * (size_t)B->np, hipMemcpyDeviceToDevice, B->st));
+  if (B->no) BA_TRY(hipMemcpyAsync(B->cubes.p, B->cubes_bak.p, 80 * (size_t)B->no, hipMemcpyDeviceToDevice, B->st));
+  return CS_OK;
+}
+
+// optimization_algorithm_levenberg.cpp:61-163 + sparse_optimizer.cpp:354-419
+int cs_ba_optimize(cs_ba* B, int iterations, int* iterations_done, double* chi_hist, double* lambda_hist, int* trials_hist, int cap) {
+  if (!B || iterations < 0) return CS_ERR_INVALID_ARG;
+  BA_TRY(hipSetDevice(B->device));
+  int rc = finalize_structure(B); if (rc) return rc;
+  double t_begin = now_ms();
+  double lambda = -1, ni = 2;
+  int nBad = 0, done = 0;
+  for (int it = 0; it < iterations; it++) {
+    double currentChi = 0;
+    double t0 = now_ms();
+    rc = chi2_device(B, &currentChi); if (rc) return rc;
+    B->tm.errors_ms += now_ms() - t0;
+    double tempChi = currentChi, iniChi = currentChi;
+    rc = build_system_device(B); if (rc) return rc;
+    rc = fetch_b(B); if (rc) return rc;
+    if (it == 0) {  // computeLambdaInit (:166-180): tau * max |H_jj| over all non-fixed vertices, landmarks included
+      std::vector<double> hc(36 * (size_t)B->nc), ho(81 * (size_t)B->no), hl(9 * (size_t)B->np);
+      if (B->nc) BA_TRY(hipMemcpy(hc.data(), B->Hcam.p, 8 * hc.size(), hipMemcpyDeviceToHost));
+      if (B->no) BA_TRY(hipMemcpy(ho.data(), B->Hcub.p, 8 * ho.size(), hipMemcpyDeviceToHost));
+      if (B->np) BA_TRY(hipMemcpy(hl.data(), B->Hll.p, 8 * hl.size(), hipMemcpyDeviceToHost));
+      double md = 0;
+      for (int i = 0; i < B->nc; i++) if (B->cam_col[i] >= 0) for (int d = 0; d < 6; d++) md = std::max(std::fabs(hc[36 * (size_t)i + 7 * d]), md);
+      for (int i = 0; i < B->no; i++) if (B->cub_col[i] >= 0) for (int d = 0; d < 9; d++) md = std::max(std::fabs(ho[81 * (size_t)i + 10 * d]), md);
+      for (int i = 0; i < B->np; i++) if (B->pt_lm[i] >= 0) for (int d = 0; d < 3; d++) md = std::max(std::fabs(hl[9 * (size_t)i + 4 * d]), md);
+      lambda = 1e-5 * md;
+      ni = 2; nBad = 0;
+    }
+    double rho = 0;
+    int qmax = 0;
+    do {
+      rc = cs_ba_push(B); if (rc) return rc;
+      bool ok2 = false;
+      rc = solve_device(B, lambda, &ok2); if (rc) return rc;
+      if (ok2) {
+        rc = fetch_x(B); if (rc) return rc;
+        rc = cs_ba_update(B); if (rc) return rc;
+      } else {
+        B->h_x.assign(B->n_pose + 3 * (size_t)B->n_lm, 0.0);
+      }
+      t0 = now_ms();
+      rc = chi2_device(B, &tempChi); if (rc) return rc;
+      B->tm.errors_ms += now_ms() - t0;
+      if (!ok2) tempChi = std::numeric_limits<double>::max();
+      rho = currentChi - tempChi;
+      double scale = 0;
+      for (size_t j = 0; j < B->h_x.size(); j++) scale += B->h_x[j] * (lambda * B->h_x[j] + B->h_b[j]);
+      scale += 1e-3;
+      rho /= scale;
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - std::pow((2 * rho - 1), 3);
+        alpha = std::min(alpha, 2. / 3.);
+        lambda *= std::max(1. / 3., alpha);
+        ni = 2;
+        currentChi = tempChi;
+      } else {
+        lambda *= ni;
+        ni *= 2;
+        rc = cs_ba_pop(B); if (rc) return rc;
+      }
+      qmax++;
+    } while (rho < 0 && qmax < 10);
+    BA_TRY(hipStreamSynchronize(B->st));
+    if (done < cap) {
+      if (chi_hist) chi_hist[done] = currentChi;
+      if (lambda_hist) lambda_hist[done] = lambda;
+      if (trials_hist) trials_hist[done] = qmax;
+    }
+    done++;
+    if (qmax == 10 || rho == 0) break;
+    if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+    if (nBad >= 3) break;
+  }
+  if (iterations_done) *iterations_done = done;
+  B->tm.total_ms += now_ms() - t_begin;
+  return CS_OK;
+}
+
+int cs_ba_get_state(cs_ba* B, double* cams7, double* cuboids10, double* points3) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  BA_TRY(hipSetDevice(B->device));
+  BA_TRY(hipStreamSynchronize(B->st));
+  if (cams7 && B->nc) BA_TRY(hipMemcpy(cams7, B->cams.p, 56 * (size_t)B->nc, hipMemcpyDeviceToHost));
+  if (cuboids10 && B->no) BA_TRY(hipMemcpy(cuboids10, B->cubes.p, 80 * (size_t)B->no, hipMemcpyDeviceToHost));
+  if (points3 && B->np) BA_TRY(hipMemcpy(points3, B->points.p, 24 * (size_t)B->np, hipMemcpyDeviceToHost));
+  return CS_OK;
+}
+
+int cs_ba_sizes(cs_ba* B, int* size_pose, int* size_lm) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  int rc = finalize_structure(B); if (rc) return rc;
+  if (size_pose) *size_pose = B->n_pose;
+  if (size_lm) *size_lm = 3 * B->n_lm;
+  return CS_OK;
+}
+
+int cs_ba_get_system(cs_ba* B, double* Hpp, double* Hll9, double* Hpl18, double* b, double* x) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  if (B->structure_dirty || !B->have_system) return CS_ERR_NOT_RUN;
+  BA_TRY(hipSetDevice(B->device));
+  const int n = B->n_pose;
+  if (Hpp) {
+    std::memset(Hpp, 0, sizeof(double) * (size_t)n * n);
+    std::vector<double> hc(36 * (size_t)B->nc), ho(81 * (size_t)B->no), hco(54 * (size_t)B->n_cub), hij(36 * (size_t)B->n_odom);
+    if (B->nc) BA_TRY(hipMemcpy(hc.data(), B->Hcam.p, 8 * hc.size(), hipMemcpyDeviceToHost));
+    if (B->no) BA_TRY(hipMemcpy(ho.data(), B->Hcub.p, 8 * ho.size(), hipMemcpyDeviceToHost));
+    if (B->n_cub) BA_TRY(hipMemcpy(hco.data(), B->ce_Hco.p, 8 * hco.size(), hipMemcpyDeviceToHost));
+    if (B->n_odom) BA_TRY(hipMemcpy(hij.data(), B->oe_Hij.p, 8 * hij.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < B->nc; i++) { int c = B->cam_col[i]; if (c < 0) continue; for (int r = 0; r < 6; r++) for (int q = 0; q < 6; q++) Hpp[(size_t)(c + r) * n + c + q] = hc[36 * (size_t)i + 6 * r + q]; }
+    for (int i = 0; i < B->no; i++) { int c = B->cub_col[i]; if (c < 0) continue; for (int r = 0; r < 9; r++) for (int q = 0; q < 9; q++) Hpp[(size_t)(c + r) * n + c + q] = ho[81 * (size_t)i + 9 * r + q]; }
+    for (int k = 0; k < B->n_cub; k++) {
+      int ca = B->cam_col[B->ce_cam[k]], cb = B->cub_col[B->ce_cub[k]];
+      if (ca < 0 || cb < 0) continue;
+      for (int r = 0; r < 6; r++) for (int q = 0; q < 9; q++) { double val = hco[54 * (size_t)k + 9 * r + q]; Hpp[(size_t)(ca + r) * n + cb + q] += val; Hpp[(size_t)(cb + q) * n + ca + r] += val; }
+    }
+    for (int k = 0; k < B->n_odom; k++) {
+      int ca = B->cam_col[B->oe_i[k]], cb = B->cam_col[B->oe_j[k]];
+      if (ca < 0 || cb < 0) continue;
+      for (int r = 0; r < 6; r++) for (int q = 0; q < 6; q++) { double val = hij[36 * (size_t)k + 6 * r + q]; Hpp[(size_t)(ca + r) * n + cb + q] += val; Hpp[(size_t)(cb + q) * n + ca + r] += val; }
+    }
+  }
+  if (Hll9) {
+    std::vector<double> hl(9 * (size_t)B->np);
+    if (B->np) BA_TRY(hipMemcpy(hl.data(), B->Hll.p, 8 * hl.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < B->np; i++) if (B->pt_lm[i] >= 0) std::memcpy(Hll9 + 9 * (size_t)B->pt_lm[i], &hl[9 * (size_t)i], 72);
+  }
+  if (Hpl18) {
+    std::vector<double> w(18 * (size_t)B->n_proj);
+    if (B->n_proj) BA_TRY(hipMemcpy(w.data(), B->W.p, 8 * w.size(), hipMemcpyDeviceToHost));
+    for (int k = 0; k < B->n_proj; k++) std::memcpy(Hpl18 + 18 * (size_t)k, &w[18 * (size_t)B->pm_of_orig[k]], 144);
+  }
+  if (b) std::memcpy(b, B->h_b.data(), 8 * B->h_b.size());
+  if (x && !B->h_x.empty()) std::memcpy(x, B->h_x.data(), 8 * B->h_x.size());
+  return CS_OK;
+}
+
+int cs_ba_last_timing(cs_ba* B, cs_ba_timing* t) {
+  if (!B || !t) return CS_ERR_INVALID_ARG;
+  *t = B->tm;
+  t->schur_entries = B->schur_entries;
+  // algorithmic bytes per linearisation + Schur build: per projection edge 136 B read
+  // + 144 B Hpl written, re-read once by the Schur stage; per camera 336 B; per point 96 B written, 96 B read,
+  // 72 B Dinv written; per cuboid edge 864 B read + 432 B written.
+  t->linearize_bytes = (long long)B->n_proj * (136 + 144 + 144) + (long long)B->nc * 336 + (long long)B->np * 264 + (long long)B->n_cub * (864 + 432);
+  return CS_OK;
+}
+
+}  // extern "C"

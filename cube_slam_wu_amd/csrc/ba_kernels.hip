@@ -1,0 +1,506 @@
+// ba_kernels.hip -- HIP kernels of the g2o bundle-adjustment iteration for gfx950 (MI355X).
+//
+// One LM linearisation = computeActiveErrors + buildSystem + Schur complement + back-substitution
+// (object_slam/Thirdparty/g2o/g2o/core/sparse_optimizer.cpp:61-114, block_solver.hpp:353-560):
+//   ba_chi2_*            residuals + (robust) chi2, fixed-shape block reduction (deterministic);
+//   ba_lin_cam_kernel    one workgroup per camera: residual, analytic 2x6 Jacobian
+//                        (types_six_dof_expmap.cpp:148-184), rho'-weighted J^T Omega J and -J^T Omega e
+//                        accumulated per lane and reduced with wavefront shuffles -> A_ii (6x6), b_i;
+//   ba_lin_pt_kernel     one lane per landmark over its (contiguous) edges: A_jj (3x3), b_j in registers, the
+//                        6x3 H_pl block of every edge streamed out once;
+//   ba_cub_edge_kernel / ba_odom_edge_kernel   numeric central-difference Jacobians, delta = 1e-9
+//                        (base_binary_edge.hpp:130-205) through oplus + computeError, then the quadratic form
+//                        (base_binary_edge.hpp:54-120) into per-edge blocks; ba_accum_pose_kernel gathers them;
+//   ba_prep_kernel       D_j^-1 = (H_ll,j + lambda I)^-1, D^-1 b_l, W D^-1 per edge (block_solver.hpp:385-407);
+//   ba_cam_rhs_kernel / ba_cub_scatter_kernel / ba_offdiag_kernel   reduced system S = H_pp (+lambda) and
+//                        b_schur = b_p - sum W D^-1 b_l (:373-439);
+//   ba_schur_kernel      one wavefront per covisible camera pair (i1 <= i2): S_{i1 i2} -= sum_j (W D^-1)_{i1 j} W_{i2 j}^T
+//                        over the landmarks both cameras see (:409-431);
+//   ba_backsub_kernel    x_l = D^-1 (b_l - W^T x_p) (:457-482);
+//   ba_update_*          oplus on every vertex (sparse_optimizer.cpp:422-435).
+// All FP64.  No atomics on the data path except the (unique-pair) off-diagonal pose blocks.
+#include <hip/hip_runtime.h>
+
+#include "ba_types.h"
+
+namespace cs {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  return v;
+}
+
+// Huber (robust_kernel_impl.cpp:78-91): rho0, rho1 for squared error e
+__device__ __forceinline__ void huber_rho(double e, double delta, double& rho0, double& rho1) {
+  if (delta > 0) {
+    double dsqr = delta * delta;
+    if (e <= dsqr) { rho0 = e; rho1 = 1.0; }
+    else { double sq = sqrt(e); rho0 = 2 * sq * delta - dsqr; rho1 = delta / sq; }
+  } else { rho0 = e; rho1 = 1.0; }
+}
+
+struct ProjLin {
+  double e[2];     // error
+  double Jp[6];    // 2x3  d e / d point
+  double Jc[12];   // 2x6  d e / d camera (rot 0..2, trans 3..5)
+  double Wm[4];    // rho' * Omega
+  double r[2];     // -rho' * Omega e
+  double chi;      // rho0
+};
+
+__device__ __forceinline__ void proj_linearize(const Pose& T, const double* R, const double* X, const double* uv, const double* info, const double* intr, double huber, ProjLin& L) {
+  double pc[3];
+  proj_error(T, X, uv, intr, L.e, pc);
+  double x = pc[0], y = pc[1], z = pc[2], z_2 = z * z, fx = intr[0], fy = intr[1];
+  double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      double s = 0;
+#pragma unroll
+      for (int q = 0; q < 3; q++) s += (-1. / z * tmp[3 * i + q]) * R[3 * q + j];
+      L.Jp[3 * i + j] = s;
+    }
+  L.Jc[0] = x * y / z_2 * fx; L.Jc[1] = -(1 + (x * x / z_2)) * fx; L.Jc[2] = y / z * fx; L.Jc[3] = -1. / z * fx; L.Jc[4] = 0; L.Jc[5] = x / z_2 * fx;
+  L.Jc[6] = (1 + y * y / z_2) * fy; L.Jc[7] = -x * y / z_2 * fy; L.Jc[8] = -x / z * fy; L.Jc[9] = 0; L.Jc[10] = -1. / z * fy; L.Jc[11] = y / z_2 * fy;
+  double c = L.e[0] * (info[0] * L.e[0] + info[1] * L.e[1]) + L.e[1] * (info[2] * L.e[0] + info[3] * L.e[1]);
+  double rho1;
+  huber_rho(c, huber, L.chi, rho1);
+#pragma unroll
+  for (int i = 0; i < 4; i++) L.Wm[i] = rho1 * info[i];
+  L.r[0] = -(info[0] * L.e[0] + info[1] * L.e[1]) * rho1;
+  L.r[1] = -(info[2] * L.e[0] + info[3] * L.e[1]) * rho1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ba_chi2_proj_kernel(BaView v) {
+  __shared__ double ws[4];
+  double acc = 0;
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < v.n_proj; k += gridDim.x * 256) {
+    Pose T = pose_load(v.cams + 7 * v.pm_cam[k]);
+    double e[2], pc[3];
+    proj_error(T, v.points + 3 * v.pm_pt[k], v.pm_uv + 2 * k, v.pm_intr + 4 * k, e, pc);
+    const double* info = v.pm_info + 4 * k;
+    double c = e[0] * (info[0] * e[0] + info[1] * e[1]) + e[1] * (info[2] * e[0] + info[3] * e[1]);
+    double rho0, rho1;
+    huber_rho(c, v.pm_huber[k], rho0, rho1);
+    acc += rho0;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) v.chi_partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+__device__ __forceinline__ double quad_form(const double* e, const double* info, int n) {
+  double s = 0;
+  for (int i = 0; i < n; i++) {
+    double t = 0;
+    for (int j = 0; j < n; j++) t += info[n * i + j] * e[j];
+    s += e[i] * t;
+  }
+  return s;
+}
+
+// one lane per cuboid / odometry edge; partial sums appended after the projection partials
+__global__ __launch_bounds__(64) void ba_chi2_pose_edges_kernel(BaView v, int partial_off) {
+  int k = blockIdx.x * 64 + threadIdx.x;
+  double c = 0;
+  if (k < v.n_cub) {
+    double e[9];
+    cuboid_edge_error(pose_load(v.cams + 7 * v.ce_cam[k]), cube_load(v.cubes + 10 * v.ce_cub[k]), cube_load(v.ce_meas + 10 * k), e);
+    c = quad_form(e, v.ce_info + 81 * k, 9);
+  } else if (k < v.n_cub + v.n_odom) {
+    int q = k - v.n_cub;
+    double e[6];
+    odom_edge_error(pose_load(v.cams + 7 * v.oe_i[q]), pose_load(v.cams + 7 * v.oe_j[q]), pose_load(v.oe_meas + 7 * q), e);
+    c = quad_form(e, v.oe_info + 36 * q, 6);
+  }
+  c = wave_sum(c);
+  if (threadIdx.x == 0) v.chi_partial[partial_off + blockIdx.x] = c;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ba_lin_cam_kernel(BaView v) {
+  int c = blockIdx.x;
+  if (v.cam_col[c] < 0) return;
+  __shared__ double red[4][27];
+  Pose T = pose_load(v.cams + 7 * c);
+  double R[9];
+  pose_rotmat(T, R);
+  double A[21], b[6];
+#pragma unroll
+  for (int i = 0; i < 21; i++) A[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) b[i] = 0;
+  int e0 = v.cam_ptr[c], e1 = v.cam_ptr[c + 1];
+  for (int k = e0 + threadIdx.x; k < e1; k += 256) {
+    ProjLin L;
+    proj_linearize(T, R, v.points + 3 * v.cm_pt[k], v.cm_uv + 2 * k, v.cm_info + 4 * k, v.cm_intr + 4 * k, v.cm_huber[k], L);
+    // JW = Jc^T W (6x2)
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      double jw0 = L.Jc[i] * L.Wm[0] + L.Jc[6 + i] * L.Wm[2];
+      double jw1 = L.Jc[i] * L.Wm[1] + L.Jc[6 + i] * L.Wm[3];
+#pragma unroll
+      for (int j = i; j < 6; j++) A[q++] += jw0 * L.Jc[j] + jw1 * L.Jc[6 + j];
+      b[i] += L.Jc[i] * L.r[0] + L.Jc[6 + i] * L.r[1];
+    }
+  }
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 21; i++) { double s = wave_sum(A[i]); if (lane == 0) red[w][i] = s; }
+#pragma unroll
+  for (int i = 0; i < 6; i++) { double s = wave_sum(b[i]); if (lane == 0) red[w][21 + i] = s; }
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x < 21) {
+      // upper-triangular index -> (i, j)
+      int t = threadIdx.x, i = 0;
+      while (t >= 6 - i) { t -= 6 - i; i++; }
+      int j = i + t;
+      v.Hcam[36 * c + 6 * i + j] = s;
+      v.Hcam[36 * c + 6 * j + i] = s;
+    } else {
+      v.bcam[6 * c + (threadIdx.x - 21)] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ba_lin_pt_kernel(BaView v) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= v.np) return;
+  double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+  bool free_pt = v.pt_free[p] != 0;
+  int e0 = v.pt_ptr[p], e1 = v.pt_ptr[p + 1];
+  const double* X = v.points + 3 * p;
+  for (int k = e0; k < e1; k++) {
+    int c = v.pm_cam[k];
+    Pose T = pose_load(v.cams + 7 * c);
+    double R[9];
+    pose_rotmat(T, R);
+    ProjLin L;
+    proj_linearize(T, R, X, v.pm_uv + 2 * k, v.pm_info + 4 * k, v.pm_intr + 4 * k, v.pm_huber[k], L);
+    double pw[6];  // Jp^T W (3x2)
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      pw[2 * i] = L.Jp[i] * L.Wm[0] + L.Jp[3 + i] * L.Wm[2];
+      pw[2 * i + 1] = L.Jp[i] * L.Wm[1] + L.Jp[3 + i] * L.Wm[3];
+    }
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+      for (int j = i; j < 3; j++) H[q++] += pw[2 * i] * L.Jp[j] + pw[2 * i + 1] * L.Jp[3 + j];
+      b[i] += L.Jp[i] * L.r[0] + L.Jp[3 + i] * L.r[1];
+    }
+    double* Wk = v.W + 18 * (size_t)k;
+    bool both = free_pt && v.cam_col[c] >= 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      double jw0 = L.Jc[i] * L.Wm[0] + L.Jc[6 + i] * L.Wm[2];
+      double jw1 = L.Jc[i] * L.Wm[1] + L.Jc[6 + i] * L.Wm[3];
+#pragma unroll
+      for (int j = 0; j < 3; j++) Wk[3 * i + j] = both ? (jw0 * L.Jp[j] + jw1 * L.Jp[3 + j]) : 0.0;
+    }
+  }
+  double* Hp = v.Hll + 9 * (size_t)p;
+  Hp[0] = H[0]; Hp[1] = H[1]; Hp[2] = H[2]; Hp[3] = H[1]; Hp[4] = H[3]; Hp[5] = H[4]; Hp[6] = H[2]; Hp[7] = H[4]; Hp[8] = H[5];
+  v.bl[3 * p] = b[0]; v.bl[3 * p + 1] = b[1]; v.bl[3 * p + 2] = b[2];
+}
+
+// ---- numeric-Jacobian edges -------------------------------------------------------------------------
+// blocks: Haa += Ja^T Om Ja, Hab += Ja^T Om Jb, Hbb += Jb^T Om Jb, ba += -Ja^T Om e, bb += -Jb^T Om e
+template <int D, int DA, int DB>
+__device__ void edge_blocks(const double* Ja, const double* Jb, const double* e, const double* info, double* Haa, double* Hbb, double* Hab, double* ba, double* bb) {
+  double Oe[D];
+  for (int i = 0; i < D; i++) { double s = 0; for (int j = 0; j < D; j++) s += info[D * i + j] * e[j]; Oe[i] = -s; }
+  for (int i = 0; i < DA; i++) { double s = 0; for (int k = 0; k < D; k++) s += Ja[k * DA + i] * Oe[k]; ba[i] = s; }
+  for (int i = 0; i < DB; i++) { double s = 0; for (int k = 0; k < D; k++) s += Jb[k * DB + i] * Oe[k]; bb[i] = s; }
+  for (int i = 0; i < DA; i++) {
+    double t[D];
+    for (int j = 0; j < D; j++) { double s = 0; for (int k = 0; k < D; k++) s += Ja[k * DA + i] * info[D * k + j]; t[j] = s; }
+    for (int j = 0; j < DA; j++) { double s = 0; for (int k = 0; k < D; k++) s += t[k] * Ja[k * DA + j]; Haa[i * DA + j] = s; }
+    for (int j = 0; j < DB; j++) { double s = 0; for (int k = 0; k < D; k++) s += t[k] * Jb[k * DB + j]; Hab[i * DB + j] = s; }
+  }
+  for (int i = 0; i < DB; i++) {
+    double t[D];
+    for (int j = 0; j < D; j++) { double s = 0; for (int k = 0; k < D; k++) s += Jb[k * DB + i] * info[D * k + j]; t[j] = s; }
+    for (int j = 0; j < DB; j++) { double s = 0; for (int k = 0; k < D; k++) s += t[k] * Jb[k * DB + j]; Hbb[i * DB + j] = s; }
+  }
+}
+
+__global__ __launch_bounds__(64) void ba_cub_edge_kernel(BaView v) {
+  int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= v.n_cub) return;
+  const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+  Pose T = pose_load(v.cams + 7 * v.ce_cam[k]);
+  Cube cube = cube_load(v.cubes + 10 * v.ce_cub[k]);
+  Cube meas = cube_load(v.ce_meas + 10 * k);
+  bool fa = v.cam_col[v.ce_cam[k]] >= 0, fb = v.cub_col[v.ce_cub[k]] >= 0;
+  double Ja[54], Jb[81], e0[9];
+  cuboid_edge_error(T, cube, meas, e0);
+  for (int d = 0; d < 6; d++) {
+    double e1[9], e2[9], add[6] = {0, 0, 0, 0, 0, 0};
+    if (fa) {
+      add[d] = delta; cuboid_edge_error(cam_oplus(T, add), cube, meas, e1);
+      add[d] = -delta; cuboid_edge_error(cam_oplus(T, add), cube, meas, e2);
+    }
+    for (int r = 0; r < 9; r++) Ja[r * 6 + d] = fa ? scalar * (e1[r] - e2[r]) : 0.0;
+  }
+  for (int d = 0; d < 9; d++) {
+    double e1[9], e2[9], add[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (fb) {
+      add[d] = delta; cuboid_edge_error(T, cube_oplus(cube, add), meas, e1);
+      add[d] = -delta; cuboid_edge_error(T, cube_oplus(cube, add), meas, e2);
+    }
+    for (int r = 0; r < 9; r++) Jb[r * 9 + d] = fb ? scalar * (e1[r] - e2[r]) : 0.0;
+  }
+  edge_blocks<9, 6, 9>(Ja, Jb, e0, v.ce_info + 81 * (size_t)k, v.ce_Hcc + 36 * (size_t)k, v.ce_Hoo + 81 * (size_t)k, v.ce_Hco + 54 * (size_t)k,
+                       v.ce_bc + 6 * (size_t)k, v.ce_bo + 9 * (size_t)k);
+}
+
+__global__ __launch_bounds__(64) void ba_odom_edge_kernel(BaView v) {
+  int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= v.n_odom) return;
+  const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+  Pose T1 = pose_load(v.cams + 7 * v.oe_i[k]), T2 = pose_load(v.cams + 7 * v.oe_j[k]), M = pose_load(v.oe_meas + 7 * k);
+  bool fa = v.cam_col[v.oe_i[k]] >= 0, fb = v.cam_col[v.oe_j[k]] >= 0;
+  double Ja[36], Jb[36], e0[6];
+  odom_edge_error(T1, T2, M, e0);
+  for (int d = 0; d < 6; d++) {
+    double e1[6], e2[6], add[6] = {0, 0, 0, 0, 0, 0};
+    if (fa) {
+      add[d] = delta; odom_edge_error(cam_oplus(T1, add), T2, M, e1);
+      add[d] = -delta; odom_edge_error(cam_oplus(T1, add), T2, M, e2);
+    }
+    for (int r = 0; r < 6; r++) Ja[r * 6 + d] = fa ? scalar * (e1[r] - e2[r]) : 0.0;
+    if (fb) {
+      add[d] = delta; odom_edge_error(T1, cam_oplus(T2, add), M, e1);
+      add[d] = -delta; odom_edge_error(T1, cam_oplus(T2, add), M, e2);
+    }
+    for (int r = 0; r < 6; r++) Jb[r * 6 + d] = fb ? scalar * (e1[r] - e2[r]) : 0.0;
+  }
+  edge_blocks<6, 6, 6>(Ja, Jb, e0, v.oe_info + 36 * (size_t)k, v.oe_Hii + 36 * (size_t)k, v.oe_Hjj + 36 * (size_t)k, v.oe_Hij + 36 * (size_t)k,
+                       v.oe_bi + 6 * (size_t)k, v.oe_bj + 6 * (size_t)k);
+}
+
+// gather the numeric-edge blocks into the pose vertices' A_ii / b_i (fixed order: deterministic)
+__global__ __launch_bounds__(128) void ba_accum_pose_kernel(BaView v, int zero_cam_first) {
+  int vid = blockIdx.x, t = threadIdx.x;
+  if (vid < v.nc) {
+    int c = vid;
+    if (v.cam_col[c] < 0 || t >= 42) return;
+    double s = zero_cam_first ? 0.0 : ((t < 36) ? v.Hcam[36 * c + t] : v.bcam[6 * c + t - 36]);
+    for (int q = v.cam_ce_ptr[c]; q < v.cam_ce_ptr[c + 1]; q++) { int k = v.cam_ce_idx[q]; s += (t < 36) ? v.ce_Hcc[36 * (size_t)k + t] : v.ce_bc[6 * (size_t)k + t - 36]; }
+    for (int q = v.cam_oei_ptr[c]; q < v.cam_oei_ptr[c + 1]; q++) { int k = v.cam_oei_idx[q]; s += (t < 36) ? v.oe_Hii[36 * (size_t)k + t] : v.oe_bi[6 * (size_t)k + t - 36]; }
+    for (int q = v.cam_oej_ptr[c]; q < v.cam_oej_ptr[c + 1]; q++) { int k = v.cam_oej_idx[q]; s += (t < 36) ? v.oe_Hjj[36 * (size_t)k + t] : v.oe_bj[6 * (size_t)k + t - 36]; }
+    if (t < 36) v.Hcam[36 * c + t] = s; else v.bcam[6 * c + t - 36] = s;
+  } else {
+    int o = vid - v.nc;
+    if (o >= v.no || v.cub_col[o] < 0 || t >= 90) return;
+    double s = 0;
+    for (int q = v.cub_ce_ptr[o]; q < v.cub_ce_ptr[o + 1]; q++) { int k = v.cub_ce_idx[q]; s += (t < 81) ? v.ce_Hoo[81 * (size_t)k + t] : v.ce_bo[9 * (size_t)k + t - 81]; }
+    if (t < 81) v.Hcub[81 * o + t] = s; else v.bcub[9 * o + t - 81] = s;
+  }
+}
+
+// ---- Schur complement ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ba_prep_kernel(BaView v, double lambda) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= v.np) return;
+  double D[9], Di[9];
+  bool free_pt = v.pt_free[p] != 0;
+  if (free_pt) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) D[i] = v.Hll[9 * (size_t)p + i];
+    D[0] += lambda; D[4] += lambda; D[8] += lambda;
+    inv3x3(D, Di);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 9; i++) Di[i] = 0;
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) v.Dinv[9 * (size_t)p + i] = Di[i];
+  double b[3] = {v.bl[3 * p], v.bl[3 * p + 1], v.bl[3 * p + 2]}, db[3];
+  mat3_vec(Di, b, db);
+  v.dbl[3 * p] = db[0]; v.dbl[3 * p + 1] = db[1]; v.dbl[3 * p + 2] = db[2];
+  for (int k = v.pt_ptr[p]; k < v.pt_ptr[p + 1]; k++) {
+    const double* Wk = v.W + 18 * (size_t)k;
+    double* WDk = v.WD + 18 * (size_t)k;
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) WDk[3 * r + c] = Wk[3 * r] * Di[c] + Wk[3 * r + 1] * Di[3 + c] + Wk[3 * r + 2] * Di[6 + c];
+  }
+}
+
+// camera part of the reduced system: S_cc = A_cc + lambda I, b_schur,c = b_c - sum_e W_e (D^-1 b_l)
+__global__ __launch_bounds__(256) void ba_cam_rhs_kernel(BaView v, double lambda) {
+  int c = blockIdx.x;
+  int col = v.cam_col[c];
+  if (col < 0) return;
+  __shared__ double red[4][6];
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int k = v.cam_ptr[c] + threadIdx.x; k < v.cam_ptr[c + 1]; k += 256) {
+    int pm = v.cm_pm[k];
+    const double* Wk = v.W + 18 * (size_t)pm;
+    const double* db = v.dbl + 3 * v.cm_pt[k];
+#pragma unroll
+    for (int r = 0; r < 6; r++) acc[r] += Wk[3 * r] * db[0] + Wk[3 * r + 1] * db[1] + Wk[3 * r + 2] * db[2];
+  }
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < 6; r++) { double s = wave_sum(acc[r]); if (lane == 0) red[w][r] = s; }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    v.rhs[col + threadIdx.x] = v.bcam[6 * c + threadIdx.x] - s;
+  }
+  if (threadIdx.x < 36) {
+    int i = threadIdx.x / 6, j = threadIdx.x % 6;
+    v.S[(size_t)(col + i) * v.n_pose + col + j] = v.Hcam[36 * c + threadIdx.x] + ((i == j) ? lambda : 0.0);
+  }
+}
+
+__global__ __launch_bounds__(128) void ba_cub_scatter_kernel(BaView v, double lambda) {
+  int o = blockIdx.x, t = threadIdx.x;
+  int col = v.cub_col[o];
+  if (col < 0) return;
+  if (t < 81) {
+    int i = t / 9, j = t % 9;
+    v.S[(size_t)(col + i) * v.n_pose + col + j] = v.Hcub[81 * o + t] + ((i == j) ? lambda : 0.0);
+  } else if (t < 90) {
+    v.rhs[col + t - 81] = v.bcub[9 * o + t - 81];
+  }
+}
+
+// off-diagonal pose blocks: camera-cuboid (6x9) per cuboid edge, camera-camera (6x6) per odometry edge
+__global__ __launch_bounds__(64) void ba_offdiag_kernel(BaView v) {
+  int k = blockIdx.x, t = threadIdx.x;
+  if (k < v.n_cub) {
+    int ca = v.cam_col[v.ce_cam[k]], cb = v.cub_col[v.ce_cub[k]];
+    if (ca < 0 || cb < 0 || t >= 54) return;
+    int i = t / 9, j = t % 9;
+    double val = v.ce_Hco[54 * (size_t)k + t];
+    atomicAdd(&v.S[(size_t)(ca + i) * v.n_pose + cb + j], val);
+    atomicAdd(&v.S[(size_t)(cb + j) * v.n_pose + ca + i], val);
+  } else {
+    int q = k - v.n_cub;
+    if (q >= v.n_odom) return;
+    int ca = v.cam_col[v.oe_i[q]], cb = v.cam_col[v.oe_j[q]];
+    if (ca < 0 || cb < 0 || t >= 36) return;
+    int i = t / 6, j = t % 6;
+    double val = v.oe_Hij[36 * (size_t)q + t];
+    atomicAdd(&v.S[(size_t)(ca + i) * v.n_pose + cb + j], val);
+    atomicAdd(&v.S[(size_t)(cb + j) * v.n_pose + ca + i], val);
+  }
+}
+
+// one wavefront per covisible camera pair; lane l < 36 owns element (l / 6, l % 6) of the 6x6 block
+__global__ __launch_bounds__(256) void ba_schur_kernel(BaView v) {
+  int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= v.n_pairs) return;
+  int lane = threadIdx.x & 63;
+  int r = lane / 6, c = lane % 6;
+  bool act = lane < 36;
+  int q0 = v.pair_ptr[pair], q1 = v.pair_ptr[pair + 1];
+  double acc0 = 0, acc1 = 0;
+  int q = q0;
+  for (; q + 1 < q1; q += 2) {
+    int a0 = v.ent_a[q], b0 = v.ent_b[q], a1 = v.ent_a[q + 1], b1 = v.ent_b[q + 1];
+    if (act) {
+      const double* x0 = v.WD + 18 * (size_t)a0 + 3 * r; const double* y0 = v.W + 18 * (size_t)b0 + 3 * c;
+      const double* x1 = v.WD + 18 * (size_t)a1 + 3 * r; const double* y1 = v.W + 18 * (size_t)b1 + 3 * c;
+      acc0 += x0[0] * y0[0] + x0[1] * y0[1] + x0[2] * y0[2];
+      acc1 += x1[0] * y1[0] + x1[1] * y1[1] + x1[2] * y1[2];
+    }
+  }
+  if (q < q1 && act) {
+    const double* x0 = v.WD + 18 * (size_t)v.ent_a[q] + 3 * r; const double* y0 = v.W + 18 * (size_t)v.ent_b[q] + 3 * c;
+    acc0 += x0[0] * y0[0] + x0[1] * y0[1] + x0[2] * y0[2];
+  }
+  if (act) {
+    double s = acc0 + acc1;
+    int i1 = v.pair_i1[pair], i2 = v.pair_i2[pair];
+    v.S[(size_t)(i1 + r) * v.n_pose + i2 + c] -= s;
+    if (i1 != i2) v.S[(size_t)(i2 + c) * v.n_pose + i1 + r] -= s;
+  }
+}
+
+__global__ __launch_bounds__(256) void ba_backsub_kernel(BaView v) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= v.np) return;
+  double cl[3] = {v.bl[3 * p], v.bl[3 * p + 1], v.bl[3 * p + 2]};
+  for (int k = v.pt_ptr[p]; k < v.pt_ptr[p + 1]; k++) {
+    int col = v.cam_col[v.pm_cam[k]];
+    if (col < 0) continue;
+    const double* Wk = v.W + 18 * (size_t)k;
+    const double* xp = v.rhs + col;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      double s = 0;
+#pragma unroll
+      for (int r = 0; r < 6; r++) s += Wk[3 * r + c] * (-xp[r]);
+      cl[c] += s;
+    }
+  }
+  double x[3];
+  mat3_vec(v.Dinv + 9 * (size_t)p, cl, x);
+  v.xl[3 * p] = x[0]; v.xl[3 * p + 1] = x[1]; v.xl[3 * p + 2] = x[2];
+}
+
+__global__ __launch_bounds__(256) void ba_update_kernel(BaView v) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < v.np) {
+    if (v.pt_free[i]) { v.points[3 * i] += v.xl[3 * i]; v.points[3 * i + 1] += v.xl[3 * i + 1]; v.points[3 * i + 2] += v.xl[3 * i + 2]; }
+    return;
+  }
+  i -= v.np;
+  if (i < v.nc) {
+    int col = v.cam_col[i];
+    if (col >= 0) pose_store(cam_oplus(pose_load(v.cams + 7 * i), v.rhs + col), v.cams + 7 * i);
+    return;
+  }
+  i -= v.nc;
+  if (i < v.no) {
+    int col = v.cub_col[i];
+    if (col >= 0) cube_store(cube_oplus(cube_load(v.cubes + 10 * i), v.rhs + col), v.cubes + 10 * i);
+  }
+}
+
+// ---------------------------------------------------------------------------------------- launchers --
+int ba_chi2_blocks(int n_proj) { int nb = (n_proj + 255) / 256; return nb < 1 ? 1 : (nb > 2048 ? 2048 : nb); }
+
+void ba_launch_chi2(const BaView& v, int nb_proj, hipStream_t st) {
+  hipLaunchKernelGGL(ba_chi2_proj_kernel, dim3(nb_proj), dim3(256), 0, st, v);
+  int ne = v.n_cub + v.n_odom;
+  if (ne > 0) hipLaunchKernelGGL(ba_chi2_pose_edges_kernel, dim3((ne + 63) / 64), dim3(64), 0, st, v, nb_proj);
+}
+void ba_launch_linearize(const BaView& v, hipStream_t st) {
+  if (v.n_proj > 0 || v.nc > 0) hipLaunchKernelGGL(ba_lin_cam_kernel, dim3(v.nc), dim3(256), 0, st, v);
+  if (v.np > 0) hipLaunchKernelGGL(ba_lin_pt_kernel, dim3((v.np + 255) / 256), dim3(256), 0, st, v);
+  if (v.n_cub > 0) hipLaunchKernelGGL(ba_cub_edge_kernel, dim3((v.n_cub + 63) / 64), dim3(64), 0, st, v);
+  if (v.n_odom > 0) hipLaunchKernelGGL(ba_odom_edge_kernel, dim3((v.n_odom + 63) / 64), dim3(64), 0, st, v);
+  hipLaunchKernelGGL(ba_accum_pose_kernel, dim3(v.nc + v.no), dim3(128), 0, st, v, 0);
+}
+void ba_launch_reduce(const BaView& v, double lambda, hipStream_t st) {
+  if (v.np > 0) hipLaunchKernelGGL(ba_prep_kernel, dim3((v.np + 255) / 256), dim3(256), 0, st, v, lambda);
+  hipLaunchKernelGGL(ba_cam_rhs_kernel, dim3(v.nc), dim3(256), 0, st, v, lambda);
+  if (v.no > 0) hipLaunchKernelGGL(ba_cub_scatter_kernel, dim3(v.no), dim3(128), 0, st, v, lambda);
+  if (v.n_cub + v.n_odom > 0) hipLaunchKernelGGL(ba_offdiag_kernel, dim3(v.n_cub + v.n_odom), dim3(64), 0, st, v);
+  if (v.n_pairs > 0) hipLaunchKernelGGL(ba_schur_kernel, dim3((v.n_pairs + 3) / 4), dim3(256), 0, st, v);
+}
+void ba_launch_backsub(const BaView& v, hipStream_t st) {
+  if (v.np > 0) hipLaunchKernelGGL(ba_backsub_kernel, dim3((v.np + 255) / 256), dim3(256), 0, st, v);
+}
+void ba_launch_update(const BaView& v, hipStream_t st) {
+  int n = v.np + v.nc + v.no;
+  if (n > 0) hipLaunchKernelGGL(ba_update_kernel, dim3((n + 255) / 256), dim3(256), 0, st, v);
+}
+
+}  // namespace cs

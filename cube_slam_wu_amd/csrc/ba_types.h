@@ -1,0 +1,54 @@
+// ba_types.h -- device data layout of the bundle-adjustment path (shared by ba_kernels.hip / ba_host.cpp).
+// See DESIGN.md "Path B: data layout in HBM".
+#pragma once
+#include "cs_se3.h"
+
+namespace cs {
+
+struct BaView {
+  // ---- vertices (estimates) -------------------------------------------------------------------------
+  double* cams;      // nc x 7   world-to-camera SE3Quat (VertexSE3Expmap)
+  double* points;    // np x 3   (VertexSBAPointXYZ, marginalised)
+  double* cubes;     // no x 10  (VertexCuboid: pose 7 + half sizes 3)
+  const int* cam_col;  // nc: scalar column of the vertex in the reduced (pose) system, -1 = fixed
+  const int* cub_col;  // no
+  const int* pt_free;  // np: 1 = optimised, 0 = fixed
+  int nc, np, no, n_pose;
+  // ---- projection edges (EdgeSE3ProjectXYZ) ---------------------------------------------------------
+  // point-major copy: edges of one landmark are contiguous, sorted by pose column (the CCS column order of
+  // block_solver.hpp:398-431); camera-major copy: edges of one camera are contiguous.
+  int n_proj;
+  const int* pm_pt; const int* pm_cam; const double* pm_uv; const double* pm_info; const double* pm_intr; const double* pm_huber;
+  const int* pt_ptr;   // np + 1
+  const int* cm_pm;    // n_proj: index into the point-major arrays
+  const int* cm_pt; const double* cm_uv; const double* cm_info; const double* cm_intr; const double* cm_huber;
+  const int* cam_ptr;  // nc + 1
+  // ---- cuboid edges (EdgeSE3Cuboid) and odometry edges (EdgeSE3Expmap): numeric Jacobians ------------
+  int n_cub; const int* ce_cam; const int* ce_cub; const double* ce_meas; const double* ce_info;
+  double* ce_Hcc; double* ce_Hoo; double* ce_Hco; double* ce_bc; double* ce_bo;   // 36, 81, 54, 6, 9 per edge
+  int n_odom; const int* oe_i; const int* oe_j; const double* oe_meas; const double* oe_info;
+  double* oe_Hii; double* oe_Hjj; double* oe_Hij; double* oe_bi; double* oe_bj;   // 36, 36, 36, 6, 6 per edge
+  // pose-vertex adjacency of those edges (CSR), for a deterministic gather-accumulate
+  const int* cam_ce_ptr; const int* cam_ce_idx;     // cuboid edges of a camera
+  const int* cam_oei_ptr; const int* cam_oei_idx;   // odometry edges where the camera is vertex 0
+  const int* cam_oej_ptr; const int* cam_oej_idx;   // ... vertex 1
+  const int* cub_ce_ptr; const int* cub_ce_idx;     // cuboid edges of a cuboid
+  // ---- linear system --------------------------------------------------------------------------------
+  double* Hcam; double* bcam;   // nc x 36, nc x 6   (A_ii, b_i of the cameras)
+  double* Hcub; double* bcub;   // no x 81, no x 9
+  double* Hll; double* bl;      // np x 9,  np x 3
+  double* W;                    // n_proj x 18  Hpl block of each projection edge (6x3, point-major order)
+  double* WD;                   // n_proj x 18  W * Dinv
+  double* Dinv;                 // np x 9       (Hll + lambda I)^-1
+  double* dbl;                  // np x 3       Dinv * b_l
+  double* S;                    // n_pose x n_pose reduced system (row-major, symmetric, both triangles)
+  double* rhs;                  // n_pose       b_schur, overwritten by x_p
+  double* xl;                   // np x 3       landmark increments
+  // Schur structure: one entry per (landmark, ordered camera pair i1 <= i2), grouped by block pair
+  int n_pairs; const int* pair_ptr; const int* pair_i1; const int* pair_i2;   // columns of the block
+  const int* ent_a; const int* ent_b;                                          // point-major edge ids
+  // chi2 partial sums
+  double* chi_partial;
+};
+
+}  // namespace cs

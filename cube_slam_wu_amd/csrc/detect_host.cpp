@@ -41,10 +41,12 @@ void launch_scan_compact(const DetectDeviceView& v, hipStream_t st);
 void launch_gather_corners(const double* corners, const long long* slots, int n, double* out, hipStream_t st);
 }  // namespace cs
 
+thread_local std::string g_cs_err;  // shared by both paths (ba_host.cpp reports through cs_set_error_ba)
+void cs_set_error_ba(const std::string& s) { g_cs_err = s; }
+
 namespace {
 
-thread_local std::string g_err;
-void set_err(const std::string& s) { g_err = s; }
+void set_err(const std::string& s) { g_cs_err = s; }
 
 #define HIP_TRY(expr)                                                                         \
   do {                                                                                        \
@@ -363,7 +365,7 @@ struct cs_batch {
 
 extern "C" {
 
-const char* cs_last_error(void) { return g_err.c_str(); }
+const char* cs_last_error(void) { return g_cs_err.c_str(); }
 
 int cs_device_count(void) {
   int n = 0;

@@ -1,0 +1,169 @@
+"""Synthetic KITTI-00-shaped bundle-adjustment problems.
+
+Cameras every 0.8 m along a gently curving planar path (1.65 m above the ground, looking forward), points in
+a corridor around the path each observed by up to 5 consecutive cameras (pixel noise N(0,1), information I2,
+optional Huber delta = sqrt(5.991)), cuboids on the ground each observed from 20 consecutive cameras
+(measurement = true camera-frame cuboid perturbed by N(0, 0.05), information diag((2q)^2), q in [0.5, 1],
+object_slam/src/main_obj.cpp:732,775-780), odometry edges between consecutive cameras (information I6,
+main_obj.cpp:794-798).  Initial estimates = truth perturbed by N(0, 0.02 rad / 0.1 m) (cameras, cuboids) and
+N(0, 0.1 m) (points).  Camera 0 is fixed; points are marginalised.
+
+Workload generation only; does not touch the oracle.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+FX = FY = 718.856
+CX, CY = 607.19, 185.22
+IMG_W, IMG_H = 1241, 376
+
+
+def quat_mul(a, b):
+    """Hamilton product, quaternions as (..., 4) arrays in x y z w order."""
+    ax, ay, az, aw = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    bx, by, bz, bw = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    return np.stack([aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by + ay * bw + az * bx - ax * bz,
+                     aw * bz + az * bw + ax * by - ay * bx,
+                     aw * bw - ax * bx - ay * by - az * bz], -1)
+
+
+def quat_rot(q, v):
+    qv = q[..., :3]
+    uv = 2 * np.cross(qv, v)
+    return v + q[..., 3:4] * uv + np.cross(qv, uv)
+
+
+def quat_from_R(R):
+    from scipy.spatial.transform import Rotation
+    q = Rotation.from_matrix(R).as_quat()
+    q = np.where(q[..., 3:4] < 0, -q, q)
+    return q
+
+
+def pose_mul(a, b):
+    """SE3 compose of 7-vectors x y z qx qy qz qw."""
+    t = a[..., :3] + quat_rot(a[..., 3:], b[..., :3])
+    q = quat_mul(a[..., 3:], b[..., 3:])
+    q = q / np.linalg.norm(q, axis=-1, keepdims=True)
+    q = np.where(q[..., 3:4] < 0, -q, q)
+    return np.concatenate([t, q], -1)
+
+
+def pose_inv(a):
+    q = a[..., 3:] * np.array([-1, -1, -1, 1.0])
+    t = -quat_rot(q, a[..., :3])
+    return np.concatenate([t, q], -1)
+
+
+def small_pose(rng, n, rot_sigma, trans_sigma):
+    w = rng.normal(0, rot_sigma, (n, 3))
+    th = np.linalg.norm(w, axis=1, keepdims=True)
+    q = np.concatenate([np.where(th > 0, np.sin(th / 2) / np.maximum(th, 1e-300), 0.5) * w, np.cos(th / 2)], 1)
+    return np.concatenate([rng.normal(0, trans_sigma, (n, 3)), q], 1)
+
+
+def make_problem(n_cams=200, n_points=20000, n_cuboids=50, seed=42, huber=True, obs_per_point=5, obs_per_cuboid=20):
+    rng = np.random.default_rng(seed)
+    # ---- trajectory: arc of radius 400 m, camera z forward along the tangent, y down, x right
+    s = 0.8 * np.arange(n_cams)
+    Rad = 400.0
+    ang = s / Rad
+    pos = np.stack([Rad * np.sin(ang), Rad * (1 - np.cos(ang)), np.full(n_cams, 1.65)], 1)
+    fwd = np.stack([np.cos(ang), np.sin(ang), np.zeros(n_cams)], 1)
+    down = np.tile(np.array([0, 0, -1.0]), (n_cams, 1))
+    right = np.cross(down, fwd)
+    R_wc = np.stack([right, down, fwd], 2)  # columns = camera axes in the world
+    q_wc = quat_from_R(R_wc)
+    T_wc = np.concatenate([pos, q_wc], 1)
+    T_cw_true = pose_inv(T_wc)
+
+    # ---- points: pick an anchor camera, sample in front of it, observe from the consecutive cameras behind it
+    pts = np.zeros((n_points, 3))
+    e_pt, e_cam, e_uv = [], [], []
+    filled = 0
+    while filled < n_points:
+        m = int((n_points - filled) * 1.3) + 16
+        anchor = rng.integers(0, n_cams, m)
+        pc = np.stack([rng.uniform(-10, 10, m), rng.uniform(-2.3, 1.6, m), rng.uniform(8, 40, m)], 1)  # camera frame
+        pw = quat_rot(q_wc[anchor], pc) + pos[anchor]
+        ok_count = np.zeros(m, int)
+        obs = []
+        for d in range(obs_per_point):
+            cam = anchor - d
+            valid = cam >= 0
+            camc = np.clip(cam, 0, n_cams - 1)
+            p = quat_rot(T_cw_true[camc, 3:], pw) + T_cw_true[camc, :3]
+            z = p[:, 2]
+            u = FX * p[:, 0] / np.where(z > 0.1, z, 1) + CX
+            v = FY * p[:, 1] / np.where(z > 0.1, z, 1) + CY
+            valid &= (z > 0.5) & (u >= 0) & (u < IMG_W) & (v >= 0) & (v < IMG_H)
+            obs.append((camc, u, v, valid))
+            ok_count += valid
+        keep = np.nonzero(ok_count >= 2)[0][: n_points - filled]
+        for camc, u, v, valid in obs:
+            kk = keep[valid[keep]]
+            e_pt.append(filled + np.searchsorted(keep, kk))
+            e_cam.append(camc[kk])
+            e_uv.append(np.stack([u[kk], v[kk]], 1))
+        pts[filled:filled + len(keep)] = pw[keep]
+        filled += len(keep)
+    e_pt = np.concatenate(e_pt).astype(np.int32)
+    e_cam = np.concatenate(e_cam).astype(np.int32)
+    e_uv = np.concatenate(e_uv) + rng.normal(0, 1.0, (len(e_pt), 2))
+    n_e = len(e_pt)
+    perm = rng.permutation(n_e)  # graph insertion order is not sorted
+    e_pt, e_cam, e_uv = e_pt[perm], e_cam[perm], e_uv[perm]
+    info4 = np.tile(np.eye(2).ravel(), (n_e, 1))
+    intr4 = np.tile(np.array([FX, FY, CX, CY]), (n_e, 1))
+    hub = np.full(n_e, np.sqrt(5.991) if huber else 0.0)
+
+    # ---- cuboids on the ground next to the path
+    cub_true = np.zeros((n_cuboids, 10))
+    ce_cam, ce_cub, ce_meas, ce_info = [], [], [], []
+    for o in range(n_cuboids):
+        c0 = int(rng.integers(0, max(1, n_cams - obs_per_cuboid)))
+        mid = min(n_cams - 1, c0 + obs_per_cuboid // 2)
+        side = rng.choice([-1.0, 1.0]) * rng.uniform(3, 7)
+        ahead = rng.uniform(10, 18)
+        half = np.array([rng.uniform(1.5, 2.4), rng.uniform(0.7, 1.0), rng.uniform(0.5, 0.76)])
+        center = pos[mid] + ahead * fwd[mid] + side * right[mid]
+        center[2] = half[2]
+        yaw = rng.uniform(-np.pi, np.pi)
+        cub_true[o, :3] = center
+        cub_true[o, 3:7] = [0, 0, np.sin(yaw / 2), np.cos(yaw / 2)]
+        if cub_true[o, 6] < 0:
+            cub_true[o, 3:7] *= -1
+        cub_true[o, 7:] = half
+        for c in range(c0, min(n_cams, c0 + obs_per_cuboid)):
+            local = pose_mul(T_cw_true[c], cub_true[o, :7])
+            noisy = pose_mul(local, small_pose(rng, 1, 0.05, 0.05)[0])
+            q = rng.uniform(0.5, 1.0)
+            ce_cam.append(c); ce_cub.append(o)
+            ce_meas.append(np.concatenate([noisy, half + rng.normal(0, 0.05, 3)]))
+            ce_info.append(np.diag(np.full(9, (2 * q) ** 2)).ravel())
+    # ---- odometry
+    oe_i = np.arange(n_cams - 1, dtype=np.int32)
+    oe_j = oe_i + 1
+    oe_meas = pose_mul(T_cw_true[1:], pose_inv(T_cw_true[:-1]))   # error = log(C * T_i * T_j^-1) = 0 for C = T_j T_i^-1
+    oe_meas = pose_mul(small_pose(rng, n_cams - 1, 0.002, 0.01), oe_meas)
+    oe_info = np.tile(np.eye(6).ravel(), (n_cams - 1, 1))
+
+    # ---- initial estimates
+    cams0 = pose_mul(small_pose(rng, n_cams, 0.02, 0.1), T_cw_true)
+    cams0[0] = T_cw_true[0]
+    cub0 = cub_true.copy()
+    if n_cuboids:
+        cub0[:, :7] = pose_mul(cub_true[:, :7], small_pose(rng, n_cuboids, 0.02, 0.1))
+        cub0[:, 7:] += rng.normal(0, 0.05, (n_cuboids, 3))
+    pts0 = pts + rng.normal(0, 0.1, pts.shape)
+    cam_fixed = np.zeros(n_cams, np.int32); cam_fixed[0] = 1
+    return dict(
+        cams=cams0, cam_fixed=cam_fixed, cuboids=cub0, cub_fixed=np.zeros(n_cuboids, np.int32), points=pts0,
+        pt_fixed=np.zeros(n_points, np.int32),
+        e_pt=e_pt, e_cam=e_cam, e_uv=e_uv, e_info=info4, e_intr=intr4, e_huber=hub,
+        ce_cam=np.array(ce_cam, np.int32), ce_cub=np.array(ce_cub, np.int32),
+        ce_meas=np.array(ce_meas).reshape(-1, 10), ce_info=np.array(ce_info).reshape(-1, 81),
+        oe_i=oe_i, oe_j=oe_j, oe_meas=oe_meas, oe_info=oe_info,
+        truth=dict(cams=T_cw_true, cuboids=cub_true, points=pts))

@@ -151,6 +151,67 @@ int cs_batch_debug_candidates(cs_batch* b, int frame, int box, int k, int cap, d
 /* good_proposal_ids / normalized_score of fuse_normalize_scores_v2 (object_3d_util.cpp:726-837). */
 int cs_batch_debug_kept(cs_batch* b, int frame, int box, int k, int cap, int* keep_ids, double* scores);
 
+
+/* ------------------------------------------------------------------ Path B: g2o bundle adjustment -- */
+/* Replaces, for graphs made of VertexSE3Expmap / VertexSBAPointXYZ / VertexCuboid and EdgeSE3ProjectXYZ /
+ * EdgeSE3Cuboid / EdgeSE3Expmap, what g2o::BlockSolver + OptimizationAlgorithmLevenberg do per iteration:
+ *   g2o::Solver virtuals  object_slam/Thirdparty/g2o/g2o/core/solver.h:53-132
+ *                         (buildStructure, buildSystem, setLambda, restoreDiagonal, solve, x(), b())
+ *   their implementation  core/block_solver.hpp:142-295 (structure), :501-560 (buildSystem),
+ *                         :563-604 (lambda), :353-486 (Schur complement solve)
+ *   the edge virtuals the solver drives: computeError / linearizeOplus / constructQuadraticForm
+ *                         core/optimizable_graph.h:382-525, core/base_binary_edge.hpp:54-205
+ *   and the LM driver     core/optimization_algorithm_levenberg.cpp:61-189, core/sparse_optimizer.cpp:354-435.
+ * The problem is described in flat arrays (a C++ adapter packs them from activeVertices()/activeEdges(),
+ * see INTEGRATION.md).  Poses are 7 doubles x y z qx qy qz qw (SE3Quat::toVector, types/se3quat.h:151-163);
+ * a camera vertex stores world-to-camera; a cuboid is its object-to-world pose + 3 half sizes
+ * (g2o::cuboid::toVector, object_slam/include/object_slam/g2o_Object.h:145-151).
+ * Vertex ids, which fix the ordering of the system like g2o's sort-by-id (sparse_optimizer.cpp:166-190):
+ * cuboids_first ? (cuboids, then cameras) : (cameras, then cuboids); points follow and are marginalised
+ * (setMarginalized(true)), so the pose block is solved through the Schur complement.                  */
+typedef struct cs_ba cs_ba;
+
+int cs_ba_create(int device, cs_ba** out);
+void cs_ba_destroy(cs_ba* ba);
+int cs_ba_set_vertices(cs_ba* ba, const double* cams7, const int* cam_fixed, int n_cams,
+                       const double* cuboids10, const int* cub_fixed, int n_cuboids,
+                       const double* points3, const int* pt_fixed, int n_points, int cuboids_first);
+/* EdgeSE3ProjectXYZ (types/types_six_dof_expmap.h:145-174): vertex 0 = point, vertex 1 = camera;
+ * info4 = 2x2 information, intr4 = fx fy cx cy, huber[k] <= 0 means no robust kernel (NULL: none). */
+int cs_ba_set_edges_proj(cs_ba* ba, int n, const int* point, const int* cam, const double* uv2,
+                         const double* info4, const double* intr4, const double* huber);
+/* EdgeSE3Cuboid (g2o_Object.h:235-260): vertex 0 = camera, vertex 1 = cuboid; meas10 = cuboid in the
+ * camera frame, info81 = 9x9 information.                                                          */
+int cs_ba_set_edges_cuboid(cs_ba* ba, int n, const int* cam, const int* cuboid, const double* meas10, const double* info81);
+/* EdgeSE3Expmap (types_six_dof_expmap.h:83-99): error = log(meas * T_i * T_j^-1); info36 = 6x6.      */
+int cs_ba_set_edges_odom(cs_ba* ba, int n, const int* cam_i, const int* cam_j, const double* meas7, const double* info36);
+
+/* The g2o::Solver / SparseOptimizer steps, one call each (all state stays in HBM):                   */
+int cs_ba_compute_errors(cs_ba* ba, double* robust_chi2);   /* computeActiveErrors + activeRobustChi2 */
+int cs_ba_build_system(cs_ba* ba);                           /* Solver::buildSystem (needs current errors) */
+int cs_ba_solve(cs_ba* ba, double lambda, int* positive_definite); /* setLambda + solve + restoreDiagonal */
+int cs_ba_update(cs_ba* ba);                                 /* SparseOptimizer::update(x)              */
+int cs_ba_push(cs_ba* ba);                                   /* SparseOptimizer::push / pop / discardTop */
+int cs_ba_pop(cs_ba* ba);
+
+/* SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg; returns (in *iterations_done)
+ * what g2o returns.  History arrays (may be NULL) receive chi2 / lambda / LM trials of every iteration. */
+int cs_ba_optimize(cs_ba* ba, int iterations, int* iterations_done, double* chi2_hist, double* lambda_hist, int* trials_hist, int hist_cap);
+
+int cs_ba_get_state(cs_ba* ba, double* cams7, double* cuboids10, double* points3);
+int cs_ba_sizes(cs_ba* ba, int* size_pose, int* size_landmarks);
+/* Inspection for parity tests (host copies, caller-sized): dense Hpp (size_pose^2, no lambda), Hll (9 per
+ * free point in point order), Hpl (18 per projection edge in the caller's edge order), b, x.            */
+int cs_ba_get_system(cs_ba* ba, double* Hpp_dense, double* Hll9, double* Hpl18, double* b, double* x);
+
+typedef struct cs_ba_timing {
+  double errors_ms, linearize_ms, reduce_ms, schur_ms, factor_ms, backsub_ms, update_ms, total_ms;
+  long long n_linearizations, n_solves;
+  long long linearize_bytes;        /* algorithmic bytes of one linearisation + Schur build */
+  long long schur_entries;          /* sum over landmarks of k_j (k_j + 1) / 2                           */
+} cs_ba_timing;
+int cs_ba_last_timing(cs_ba* ba, cs_ba_timing* t);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,217 @@
+"""ctypes binding of oracle/liboracle_ba.so + the reference's offline 58-frame graph driver.
+
+TEST INFRASTRUCTURE (same rule as oracle_py.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "liboracle_ba.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-s", "-C", _HERE])
+        L = C.CDLL(path)
+        L.ba_oracle_create.restype = C.c_void_p
+        L.ba_oracle_compute_errors.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int)) if a is not None else None
+
+
+def _f(a, shape):
+    return np.ascontiguousarray(np.asarray(a, np.float64).reshape(shape))
+
+
+def _i(a):
+    return np.ascontiguousarray(np.asarray(a, np.int32).ravel())
+
+
+class Problem:
+    """A g2o graph in flat arrays (see ba_oracle.cpp: ba_oracle_set_*)."""
+
+    def __init__(self, cams, cam_fixed, cuboids=None, cub_fixed=None, points=None, pt_fixed=None, cuboids_first=False, marginalize_points=True):
+        L = lib()
+        self.h = C.c_void_p(L.ba_oracle_create())
+        self.cams = _f(cams, (-1, 7)); self.nc = len(self.cams)
+        self.cuboids = _f(cuboids if cuboids is not None else np.zeros((0, 10)), (-1, 10)); self.no = len(self.cuboids)
+        self.points = _f(points if points is not None else np.zeros((0, 3)), (-1, 3)); self.np_ = len(self.points)
+        cf = _i(cam_fixed); of = _i(cub_fixed if cub_fixed is not None else np.zeros(self.no)); pf = _i(pt_fixed if pt_fixed is not None else np.zeros(self.np_))
+        L.ba_oracle_set_vertices(self.h, _dp(self.cams), _ip(cf), self.nc, _dp(self.cuboids), _ip(of), self.no, _dp(self.points), _ip(pf), self.np_,
+                                 int(cuboids_first), int(marginalize_points))
+        self.n_proj = self.n_cub = self.n_odom = 0
+
+    def set_edges_proj(self, pt, cam, uv, info4, intr4, huber=None):
+        pt, cam = _i(pt), _i(cam); self.n_proj = len(pt)
+        uv, info4, intr4 = _f(uv, (-1, 2)), _f(info4, (-1, 4)), _f(intr4, (-1, 4))
+        hb = _f(huber, (-1,)) if huber is not None else None
+        lib().ba_oracle_set_edges_proj(self.h, self.n_proj, _ip(pt), _ip(cam), _dp(uv), _dp(info4), _dp(intr4), _dp(hb))
+
+    def set_edges_cuboid(self, cam, cub, meas10, info81):
+        cam, cub = _i(cam), _i(cub); self.n_cub = len(cam)
+        lib().ba_oracle_set_edges_cuboid(self.h, self.n_cub, _ip(cam), _ip(cub), _dp(_f(meas10, (-1, 10))), _dp(_f(info81, (-1, 81))))
+
+    def set_edges_odom(self, ci, cj, meas7, info36):
+        ci, cj = _i(ci), _i(cj); self.n_odom = len(ci)
+        lib().ba_oracle_set_edges_odom(self.h, self.n_odom, _ip(ci), _ip(cj), _dp(_f(meas7, (-1, 7))), _dp(_f(info36, (-1, 36))))
+
+    def optimize(self, iters):
+        return lib().ba_oracle_optimize(self.h, int(iters))
+
+    def history(self, cap=64):
+        chi, lam, tr = np.zeros(cap), np.zeros(cap), np.zeros(cap, np.int32)
+        n = lib().ba_oracle_history(self.h, _dp(chi), _dp(lam), _ip(tr), cap)
+        return chi[:n], lam[:n], tr[:n]
+
+    def state(self):
+        cams, cubs, pts = np.zeros((self.nc, 7)), np.zeros((self.no, 10)), np.zeros((self.np_, 3))
+        lib().ba_oracle_get_state(self.h, _dp(cams), _dp(cubs), _dp(pts))
+        return cams, cubs, pts
+
+    def compute_errors(self):
+        chi = lib().ba_oracle_compute_errors(self.h)
+        ep, ec, eo = np.zeros((self.n_proj, 2)), np.zeros((self.n_cub, 9)), np.zeros((self.n_odom, 6))
+        lib().ba_oracle_get_errors(self.h, _dp(ep), _dp(ec), _dp(eo))
+        return chi, ep, ec, eo
+
+    def sizes(self):
+        a, b = C.c_int(), C.c_int()
+        lib().ba_oracle_sizes(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def build_system(self):
+        lib().ba_oracle_build_system(self.h)
+        n, nl = self.sizes()
+        Hpp, Hll, Hpl, b = np.zeros((n, n)), np.zeros((nl // 3, 9)), np.zeros((self.n_proj, 18)), np.zeros(n + nl)
+        lib().ba_oracle_get_system(self.h, _dp(Hpp), _dp(Hll), _dp(Hpl), _dp(b))
+        return Hpp, Hll, Hpl, b
+
+    def solve(self, lam):
+        n, nl = self.sizes()
+        x = np.zeros(n + nl)
+        ok = lib().ba_oracle_solve(self.h, C.c_double(lam), _dp(x))
+        return bool(ok), x
+
+    def close(self):
+        if self.h:
+            lib().ba_oracle_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def se3_exp(u):
+    o = np.zeros(7); lib().ba_oracle_se3_exp(_dp(_f(u, (6,))), _dp(o)); return o
+
+
+def se3_log(v7):
+    o = np.zeros(6); lib().ba_oracle_se3_log(_dp(_f(v7, (7,))), _dp(o)); return o
+
+
+def se3_mul(a, b):
+    o = np.zeros(7); lib().ba_oracle_se3_mul(_dp(_f(a, (7,))), _dp(_f(b, (7,))), _dp(o)); return o
+
+
+def se3_inv(a):
+    o = np.zeros(7); lib().ba_oracle_se3_inv(_dp(_f(a, (7,))), _dp(o)); return o
+
+
+def cuboid_from_minimal(v9):
+    o = np.zeros(10); lib().ba_oracle_cuboid_from_minimal(_dp(_f(v9, (9,))), _dp(o)); return o
+
+
+def cuboid_transform(c10, Twc7, to_local):
+    o = np.zeros(10); lib().ba_oracle_cuboid_transform(_dp(_f(c10, (10,))), _dp(_f(Twc7, (7,))), int(to_local), _dp(o)); return o
+
+
+def cuboid_to_minimal(c10):
+    o = np.zeros(9); lib().ba_oracle_cuboid_to_minimal(_dp(_f(c10, (10,))), _dp(o)); return o
+
+
+IDENT7 = np.array([0, 0, 0, 0, 0, 0, 1.0])
+
+
+def run_offline_sequence(data_dir, make_problem=None, n_frames=None):
+    """incremental_build_graph() in offline mode (object_slam/src/main_obj.cpp:479-841, 682-722).
+
+    make_problem(cams, cam_fixed, cuboid, edges...) -> object with optimize()/state(); defaults to the oracle.
+    Returns per-frame optimised camera poses Twc (n x 7) and the cuboid after every frame (n x 9 minimal).
+    """
+    truth = np.loadtxt(os.path.join(data_dir, "truth_cam_poses.txt"))
+    init = np.loadtxt(os.path.join(data_dir, "pop_cam_poses_saved.txt"))
+    obs = np.loadtxt(os.path.join(data_dir, "detect_cuboids_saved.txt"))
+    N = len(truth) if n_frames is None else n_frames
+    fixed_init_Twc = se3_mul(IDENT7, truth[0, 1:8])  # SE3Quat(Vector7d) normalises
+    cam_Tcw = []            # optimised world-to-camera per frame
+    cube = None
+    cub_edges = []          # (frame, meas10, info81)
+    odom_edges = []         # (i, j, meas7)
+    out_cam, out_obj, iters = [], [], []
+    row = 0
+    for k in range(N):
+        odom_val = IDENT7.copy()
+        if k == 0:
+            Twc = fixed_init_Twc
+        else:
+            prev = cam_Tcw[k - 1]
+            if k > 1:
+                odom_val = se3_mul(prev, se3_inv(cam_Tcw[k - 2]))
+            Twc = se3_inv(se3_mul(odom_val, prev))
+        has = row < len(obs) and int(obs[row, 0]) == k
+        if has:
+            m = obs[row]
+            ground = cuboid_from_minimal([m[1], m[2], m[3], 0, 0, m[4], m[5], m[6], m[7]])
+            cam_val_Twc = se3_mul(IDENT7, init[k, 1:8])
+            local = cuboid_transform(ground, cam_val_Twc, True)
+            quality = (1 - m[8] + 0.5) / 2
+            row += 1
+        if k == 0:
+            cube = cuboid_transform(local, Twc, False)
+        cam_Tcw.append(se3_inv(Twc))
+        if has:
+            inv_sigma = np.ones(9) * 2.0 * quality
+            cub_edges.append((k, local, np.diag(inv_sigma * inv_sigma).ravel()))
+        if k > 0:
+            odom_edges.append((k - 1, k, odom_val))
+        cams = np.array(cam_Tcw)
+        fixed = np.zeros(len(cams), np.int32); fixed[0] = 1
+        mk = make_problem or (lambda **kw: _oracle_problem(**kw))
+        P = mk(cams=cams, cam_fixed=fixed, cuboid=cube, cub_edges=cub_edges, odom_edges=odom_edges)
+        iters.append(P.optimize(5))
+        c, o, _ = P.state()
+        cam_Tcw = [c[i].copy() for i in range(len(c))]
+        cube = o[0].copy()
+        P.close()
+        out_cam.append(se3_inv(cam_Tcw[k]))
+        out_obj.append(cuboid_to_minimal(cube))
+    return np.array(out_cam), np.array(out_obj), np.array(iters), np.array([se3_inv(t) for t in cam_Tcw])
+
+
+def _oracle_problem(cams, cam_fixed, cuboid, cub_edges, odom_edges):
+    P = Problem(cams, cam_fixed, cuboids=cuboid[None, :], cub_fixed=[0], cuboids_first=True)
+    if cub_edges:
+        P.set_edges_cuboid([e[0] for e in cub_edges], [0] * len(cub_edges), np.array([e[1] for e in cub_edges]), np.array([e[2] for e in cub_edges]))
+    if odom_edges:
+        P.set_edges_odom([e[0] for e in odom_edges], [e[1] for e in odom_edges], np.array([e[2] for e in odom_edges]),
+                         np.tile(np.eye(6).ravel(), (len(odom_edges), 1)))
+    return P

@@ -1,0 +1,113 @@
+"""GPU parity of the bundle-adjustment path (through the C ABI) against the CPU oracle.
+
+Floating point: FP64 on both sides, but sums are associated differently (per-camera shuffle reductions vs
+g2o's edge-order accumulation) and sin/cos/acos/tan come from ocml vs glibc, so the bar is the one
+BASELINE.json states: states within 1e-5 relative after the same number of LM iterations, with the same
+accept/reject sequence.  Intermediate quantities are held to tighter bounds where they are analytic
+(1e-9 relative to the matrix scale) and to 1e-5 where they go through 1e-9-step numeric Jacobians.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from cube_slam_wu_amd import capi, synth_ba
+from oracle import ba_oracle_py as O
+
+pytestmark = pytest.mark.gpu
+DATA = os.path.join(os.path.dirname(__file__), "golden", "object_slam_data")
+
+
+def _oracle(pr, cuboids_first=False):
+    P = O.Problem(pr["cams"], pr["cam_fixed"], pr["cuboids"], pr["cub_fixed"], pr["points"], pr["pt_fixed"], cuboids_first=cuboids_first)
+    if len(pr["e_pt"]):
+        P.set_edges_proj(pr["e_pt"], pr["e_cam"], pr["e_uv"], pr["e_info"], pr["e_intr"], pr["e_huber"])
+    if len(pr["ce_cam"]):
+        P.set_edges_cuboid(pr["ce_cam"], pr["ce_cub"], pr["ce_meas"], pr["ce_info"])
+    if len(pr["oe_i"]):
+        P.set_edges_odom(pr["oe_i"], pr["oe_j"], pr["oe_meas"], pr["oe_info"])
+    return P
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(1e-300, np.abs(b).max())
+
+
+def test_system_parity_projection_only():
+    pr = synth_ba.make_problem(n_cams=24, n_points=1200, n_cuboids=0, seed=7)
+    pr["oe_i"] = pr["oe_i"][:0]; pr["oe_j"] = pr["oe_j"][:0]; pr["oe_meas"] = pr["oe_meas"][:0]; pr["oe_info"] = pr["oe_info"][:0]
+    G, R = capi.ba_from_dict(pr), _oracle(pr)
+    chi_r = R.compute_errors()[0]
+    assert abs(G.compute_errors() - chi_r) <= 1e-11 * chi_r
+    Hpp_g, Hll_g, Hpl_g, b_g = G.build_system()
+    Hpp_r, Hll_r, Hpl_r, b_r = R.build_system()
+    assert _rel(Hpp_g, Hpp_r) < 1e-11 and _rel(Hll_g, Hll_r) < 1e-11 and _rel(Hpl_g, Hpl_r) < 1e-11 and _rel(b_g, b_r) < 1e-11
+    ok_g, x_g = G.solve(10.0)
+    ok_r, x_r = R.solve(10.0)
+    assert ok_g and ok_r
+    assert _rel(x_g, x_r) < 1e-8
+
+
+def test_system_parity_all_edge_types():
+    pr = synth_ba.make_problem(n_cams=30, n_points=1500, n_cuboids=6, seed=11)
+    G, R = capi.ba_from_dict(pr), _oracle(pr)
+    chi_r = R.compute_errors()[0]
+    assert abs(G.compute_errors() - chi_r) <= 1e-10 * chi_r
+    Hpp_g, Hll_g, Hpl_g, b_g = G.build_system()
+    Hpp_r, Hll_r, Hpl_r, b_r = R.build_system()
+    assert _rel(Hll_g, Hll_r) < 1e-11 and _rel(Hpl_g, Hpl_r) < 1e-11
+    assert _rel(Hpp_g, Hpp_r) < 1e-5 and _rel(b_g, b_r) < 1e-5      # numeric (delta = 1e-9) Jacobians inside
+    ok_g, x_g = G.solve(50.0)
+    ok_r, x_r = R.solve(50.0)
+    assert ok_g and ok_r
+    assert _rel(x_g, x_r) < 1e-5
+
+
+@pytest.mark.parametrize("huber", [True, False])
+def test_optimize_parity_10_iterations(huber):
+    pr = synth_ba.make_problem(n_cams=40, n_points=2500, n_cuboids=8, seed=3, huber=huber)
+    G, R = capi.ba_from_dict(pr), _oracle(pr)
+    n_g, n_r = G.optimize(10), R.optimize(10)
+    assert n_g == n_r
+    chi_g, lam_g, tr_g = G.history()
+    chi_r, lam_r, tr_r = R.history()
+    assert np.array_equal(tr_g, tr_r)                       # same accept / reject sequence
+    assert np.allclose(chi_g, chi_r, rtol=1e-6)
+    cg, og, pg = G.state()
+    cr, orr, prr = R.state()
+    # 1e-5 relative (BASELINE.json); translations relative to the scene scale
+    scale = np.abs(prr).max()
+    assert np.abs(pg - prr).max() < 1e-5 * scale
+    assert np.abs(cg[:, :3] - cr[:, :3]).max() < 1e-5 * scale and np.abs(cg[:, 3:] - cr[:, 3:]).max() < 1e-5
+    assert np.abs(og[:, :3] - orr[:, :3]).max() < 1e-5 * scale and np.abs(og[:, 3:] - orr[:, 3:]).max() < 1e-5
+
+
+def test_fixed_points_and_cuboids_first_ordering():
+    pr = synth_ba.make_problem(n_cams=16, n_points=500, n_cuboids=3, seed=5)
+    pr["pt_fixed"] = pr["pt_fixed"].copy(); pr["pt_fixed"][::7] = 1
+    G, R = capi.ba_from_dict(pr, cuboids_first=True), _oracle(pr, cuboids_first=True)
+    Hpp_g, Hll_g, Hpl_g, b_g = G.build_system()
+    Hpp_r, Hll_r, Hpl_r, b_r = R.build_system()
+    assert Hpp_g.shape == Hpp_r.shape and Hll_g.shape == Hll_r.shape
+    assert _rel(Hpp_g, Hpp_r) < 1e-5 and _rel(Hll_g, Hll_r) < 1e-11 and _rel(Hpl_g, Hpl_r) < 1e-11 and _rel(b_g, b_r) < 1e-5
+    assert G.optimize(4) == R.optimize(4)
+    assert np.abs(G.state()[2] - R.state()[2]).max() < 1e-5 * np.abs(R.state()[2]).max()
+
+
+def test_reference_offline_sequence_on_gpu():
+    """The reference's bundled 58-frame graph (main_obj.cpp:479-841, offline mode) through the HIP solver."""
+    def mk(cams, cam_fixed, cuboid, cub_edges, odom_edges):
+        P = capi.BaProblem(cams, cam_fixed, cuboids=cuboid[None, :], cub_fixed=[0], cuboids_first=True)
+        if cub_edges:
+            P.set_edges_cuboid([e[0] for e in cub_edges], [0] * len(cub_edges), np.array([e[1] for e in cub_edges]), np.array([e[2] for e in cub_edges]))
+        if odom_edges:
+            P.set_edges_odom([e[0] for e in odom_edges], [e[1] for e in odom_edges], np.array([e[2] for e in odom_edges]), np.tile(np.eye(6).ravel(), (len(odom_edges), 1)))
+        return P
+    cam_g, obj_g, it_g, fin_g = O.run_offline_sequence(DATA, make_problem=mk)
+    cam_r, obj_r, it_r, fin_r = O.run_offline_sequence(DATA)
+    # Every frame re-optimises a graph that is already at its minimum, so g2o's stop rules (rho == 0, three
+    # iterations without 1e-3 relative progress) fire on rounding noise; the iteration count may differ on the
+    # odd frame (measured: 2 of 58) while the states still agree to < 1e-6.
+    assert (it_g == it_r).mean() >= 0.9
+    assert np.abs(obj_g - obj_r).max() < 1e-5 * max(1.0, np.abs(obj_r).max())
+    assert np.abs(fin_g - fin_r).max() < 1e-5 * max(1.0, np.abs(fin_r).max())
