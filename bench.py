@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--unique", type=int, default=100, help="distinct synthetic frames generated (tiled to --frames)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-threads", type=int, default=0, help="worker threads of the host stages (0 = library default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -63,7 +64,7 @@ def main():
     n_unique = max(1, min(args.unique, args.frames))
     uniq = [synth.make_frame(100000 * (rank + 1) + s) for s in range(n_unique)]
     frames = [uniq[i % n_unique] for i in range(args.frames)]
-    params = capi.default_params(whether_sample_cam_roll_pitch=0, whether_sample_bbox_height=0, yaw_range_deg=45.0, yaw_step_deg=0.5)
+    params = capi.default_params(whether_sample_cam_roll_pitch=0, whether_sample_bbox_height=0, yaw_range_deg=45.0, yaw_step_deg=0.5, host_threads=args.host_threads)
     det = capi.Detector(params, device=local_rank)
     bat = capi.Batch(det, frames)
 
@@ -101,6 +102,7 @@ def main():
             "roofline": {"kernel": "candidate_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": kern_ms},
             "stage_ms_per_step": {k: acc[k] / args.steps for k in acc if k.endswith("_ms")},
+            "fallback_boxes_per_step": acc["n_fallback_boxes"] / args.steps,
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle_py

@@ -21,6 +21,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -39,6 +42,12 @@ void launch_vp_support(const DetectDeviceView& v, const SweepParams& sp, int vp_
 void launch_candidates(const DetectDeviceView& v, const SweepParams& sp, long long slot_total, hipStream_t st);
 void launch_scan_compact(const DetectDeviceView& v, hipStream_t st);
 void launch_gather_corners(const double* corners, const long long* slots, int n, double* out, hipStream_t st);
+void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams& rp, hipStream_t st);
+void launch_line_setup(JobDesc* jobs, int n_jobs, const double* frame_lines, const int* frame_line_ptr, double* mid_x, double* mid_y, double* line_angle,
+                       double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st);
+int line_setup_capacity();
+void launch_gather_ranges(const DetectDeviceView& v, const long long* src_off, const int* count, const long long* dst_off, int n_ranges,
+                          double* o_dist, double* o_angle, double* o_skew, int* o_flag, long long* o_slot, hipStream_t st);
 }  // namespace cs
 
 thread_local std::string g_cs_err;  // shared by both paths (ba_host.cpp reports through cs_set_error_ba)
@@ -61,26 +70,63 @@ double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-void parallel_for(int n, int n_threads, const std::function<void(int)>& fn) {
-  if (n <= 0) return;
-  int nt = std::max(1, std::min(n_threads, n));
-  if (nt == 1) {
-    for (int i = 0; i < n; i++) fn(i);
-    return;
+// Persistent worker pool for the host stages (one per detector; the calling thread takes part).
+class WorkerPool {
+ public:
+  explicit WorkerPool(int n_workers) {
+    for (int i = 0; i < n_workers; i++) th_.emplace_back([this]() { loop(); });
   }
-  std::atomic<int> next(0);
-  std::vector<std::thread> th;
-  th.reserve(nt);
-  for (int t = 0; t < nt; t++)
-    th.emplace_back([&]() {
-      for (;;) {
-        int i = next.fetch_add(1);
-        if (i >= n) break;
-        fn(i);
+  ~WorkerPool() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; gen_++; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  void run(int n, const std::function<void(int)>& fn) {
+    if (n <= 0) return;
+    if (th_.empty() || n == 1) { for (int i = 0; i < n; i++) fn(i); return; }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn; n_ = n; next_.store(0); pending_ = (int)th_.size(); gen_++;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this]() { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+ private:
+  void work() {
+    for (;;) {
+      int i = next_.fetch_add(1);
+      if (i >= n_) break;
+      (*fn_)(i);
+    }
+  }
+  void loop() {
+    unsigned long long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&]() { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
       }
-    });
-  for (auto& t : th) t.join();
-}
+      work();
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (--pending_ == 0) done_.notify_all();
+      }
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  std::atomic<int> next_{0};
+  int n_ = 0, pending_ = 0;
+  unsigned long long gen_ = 0;
+  bool stop_ = false;
+};
 
 // Grow-only device / pinned buffers.
 template <class T>
@@ -208,14 +254,15 @@ void linespace(T a, T b, T step, std::vector<T>& out) {  // matrix_utils.cpp:368
 void merge_lines(std::vector<double>& L, double dist_thre, double angle_thre_deg, double len_thre) {
   int total = (int)(L.size() / 4);
   const double athre = angle_thre_deg / 180.0 * CS_PI;
-  std::vector<double> ang;
+  // The reference recomputes every segment's angle at the top of each round (:451-456).  Only two rows change per
+  // merge (row a is overwritten, row b receives the last row), so the cached angles below are the same doubles.
+  std::vector<double> ang(total);
+  for (int i = 0; i < total; i++) ang[i] = cs::cs_atan2(L[4 * i + 3] - L[4 * i + 1], L[4 * i + 2] - L[4 * i]);
   bool merged = true;
   int rounds = 0;
   while (merged && rounds < 500) {
     rounds++;
     merged = false;
-    ang.resize(total);
-    for (int i = 0; i < total; i++) ang[i] = cs::cs_atan2(L[4 * i + 3] - L[4 * i + 1], L[4 * i + 2] - L[4 * i]);
     for (int a = 0; a < total - 1 && !merged; a++) {
       for (int b = a + 1; b < total; b++) {
         double diff = std::abs(ang[a] - ang[b]);
@@ -231,6 +278,8 @@ void merge_lines(std::vector<double>& L, double dist_thre, double angle_thre_deg
         if (std::min(t, CS_PI - t) < athre) {
           L[4 * a] = sx; L[4 * a + 1] = sy; L[4 * a + 2] = ex; L[4 * a + 3] = ey;
           for (int c = 0; c < 4; c++) L[4 * b + c] = L[4 * (total - 1) + c];  // swap-remove (matrix_utils.cpp:183)
+          ang[a] = ma;               // atan2 of the merged row == merged_angle (:490)
+          ang[b] = ang[total - 1];
           total--;
           merged = true;
           break;
@@ -305,6 +354,7 @@ struct cs_detector {
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {};
   int n_threads = 1;
+  std::unique_ptr<WorkerPool> pool;
 };
 
 struct FrameIn {
@@ -322,6 +372,7 @@ struct JobHost {          // host-side companion of a JobDesc of the current rou
   int yaw_off_local;
   std::vector<double> mids_x, mids_y, angs;
   std::vector<int> tops;
+  int line_cap = 0;          // entries reserved in the pooled line tables (device setup: the frame's segment count)
 };
 
 struct FrameRound {       // setup products of one frame in one round
@@ -345,7 +396,10 @@ struct cs_batch {
   int n_frames = 0, max_boxes = 0;
   std::vector<FrameIn> frames;
   DevBuf<float> d_maps;
-  DevBuf<double> d_invK;
+  DevBuf<double> d_invK, d_frame_lines;
+  DevBuf<int> d_frame_line_ptr;
+  bool device_setup = false;   // every frame's segment count fits the line-setup kernel's LDS table
+  bool force_host_setup = false;
   // per-round device pools
   DevBuf<cs::JobDesc> d_jobs;
   DevBuf<long long> d_slot_prefix, d_job_cbase, d_c_slot, d_win_slots;
@@ -356,6 +410,15 @@ struct cs_batch {
   PinBuf<long long> h_c_slot, h_job_cbase;
   PinBuf<int> h_c_flag, h_job_valid;
   PinBuf<double> h_c_dist, h_c_angle, h_c_skew, h_win_corners;
+  DevBuf<int> d_box_job0, d_box_njobs, d_win_count, d_fallback;
+  DevBuf<cs::RankWinner> d_winners;
+  DevBuf<long long> d_fb_src, d_fb_dst, d_fb_slot;
+  DevBuf<int> d_fb_cnt, d_fb_flag;
+  DevBuf<double> d_fb_dist, d_fb_angle, d_fb_skew;
+  PinBuf<cs::RankWinner> h_winners;
+  PinBuf<int> h_win_count, h_fallback;
+  PinBuf<cs::JobDesc> h_jobs;
+  bool force_host_rank = false;
   // state
   bool debug = false, ran = false;
   std::vector<JobResult> results;             // all jobs of the last run (index via job_index)
@@ -408,6 +471,14 @@ int cs_box_rois(const double box5[5], int img_w, int img_h, int sample_height, c
   return nd;
 }
 
+int cs_cam_euler_zyx(const double T_wc[16], double euler3[3]) {
+  if (!T_wc || !euler3) return CS_ERR_INVALID_ARG;
+  double R[9];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[3 * i + j] = T_wc[4 * i + j];
+  rot_to_euler(R, euler3);
+  return CS_OK;
+}
+
 int cs_detector_create(const cs_detect_params* params, int device, cs_detector** out) {
   if (!out) return CS_ERR_INVALID_ARG;
   *out = nullptr;
@@ -425,7 +496,8 @@ int cs_detector_create(const cs_detect_params* params, int device, cs_detector**
   HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
   for (auto& e : d->ev) HIP_TRY(hipEventCreate(&e));
   int hc = (int)std::thread::hardware_concurrency();
-  d->n_threads = d->prm.host_threads > 0 ? d->prm.host_threads : std::max(1, hc);
+  d->n_threads = d->prm.host_threads > 0 ? d->prm.host_threads : std::max(1, std::min(hc, 64));
+  d->pool.reset(new WorkerPool(d->n_threads - 1));
   *out = d;
   return CS_OK;
 }
@@ -504,6 +576,16 @@ int cs_batch_create(cs_detector* d, const cs_frame_desc* fr, int n_frames, cs_ba
     rc = b->d_invK.ensure(ik.size());
     if (rc) { delete b; return rc; }
     HIP_TRY(hipMemcpy(b->d_invK.p, ik.data(), sizeof(double) * ik.size(), hipMemcpyHostToDevice));
+    // line segments (already left-to-right aligned), pooled, for the device-side line setup
+    std::vector<int> lp(n_frames + 1, 0);
+    b->device_setup = true;
+    for (int f = 0; f < n_frames; f++) { lp[f + 1] = lp[f] + b->frames[f].n_lines; if (b->frames[f].n_lines > cs::line_setup_capacity()) b->device_setup = false; }
+    std::vector<double> fl(4 * (size_t)std::max(1, lp[n_frames]));
+    for (int f = 0; f < n_frames; f++) if (b->frames[f].n_lines) std::memcpy(&fl[4 * (size_t)lp[f]], b->frames[f].lines.data(), 32 * (size_t)b->frames[f].n_lines);
+    rc = b->d_frame_lines.ensure(fl.size()); if (rc) { delete b; return rc; }
+    rc = b->d_frame_line_ptr.ensure(lp.size()); if (rc) { delete b; return rc; }
+    HIP_TRY(hipMemcpy(b->d_frame_lines.p, fl.data(), 8 * fl.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_frame_line_ptr.p, lp.data(), 4 * lp.size(), hipMemcpyHostToDevice));
   }
   *out = b;
   return CS_OK;
@@ -514,7 +596,7 @@ int cs_batch_max_boxes(const cs_batch* b) { return b ? b->max_boxes : CS_ERR_INV
 void cs_batch_destroy(cs_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->det->device);
-  b->d_maps.release(); b->d_invK.release(); b->d_jobs.release(); b->d_slot_prefix.release(); b->d_job_cbase.release();
+  b->d_maps.release(); b->d_invK.release(); b->d_frame_lines.release(); b->d_frame_line_ptr.release(); b->d_jobs.release(); b->d_slot_prefix.release(); b->d_job_cbase.release();
   b->d_c_slot.release(); b->d_win_slots.release(); b->d_vp_prefix.release(); b->d_top_x.release(); b->d_flag.release();
   b->d_job_valid.release(); b->d_c_flag.release(); b->d_mid_x.release(); b->d_mid_y.release(); b->d_ang.release();
   b->d_yaw.release(); b->d_yaw_c.release(); b->d_yaw_s.release(); b->d_vp.release(); b->d_bound.release(); b->d_dist.release();
@@ -522,12 +604,18 @@ void cs_batch_destroy(cs_batch* b) {
   b->d_c_skew.release(); b->d_win_corners.release(); b->d_rp.release();
   b->h_stage.release(); b->h_c_slot.release(); b->h_job_cbase.release(); b->h_c_flag.release(); b->h_job_valid.release();
   b->h_c_dist.release(); b->h_c_angle.release(); b->h_c_skew.release(); b->h_win_corners.release();
+  b->d_box_job0.release(); b->d_box_njobs.release(); b->d_win_count.release(); b->d_fallback.release(); b->d_winners.release();
+  b->h_winners.release(); b->h_win_count.release(); b->h_fallback.release(); b->h_jobs.release();
+  b->d_fb_src.release(); b->d_fb_dst.release(); b->d_fb_slot.release(); b->d_fb_cnt.release(); b->d_fb_flag.release();
+  b->d_fb_dist.release(); b->d_fb_angle.release(); b->d_fb_skew.release();
   delete b;
 }
 
 int cs_batch_set_debug(cs_batch* b, int enable) {
   if (!b) return CS_ERR_INVALID_ARG;
-  b->debug = enable != 0;
+  b->debug = (enable & 1) != 0;
+  b->force_host_rank = (enable & 2) != 0;
+  b->force_host_setup = (enable & 4) != 0;
   return CS_OK;
 }
 
@@ -596,6 +684,7 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
   const cs_detect_params& P = d->prm;
   const bool sample_rp = P.whether_sample_cam_roll_pitch != 0;
   const int NF = b->n_frames, MB = b->max_boxes, KMAX = P.max_cuboid_num;
+  auto parallel_for = [d](int n, int /*nt*/, const std::function<void(int)>& fn) { d->pool->run(n, fn); };
   const int NT = d->n_threads;
   hipStream_t st = d->stream;
   cs_detect_timing tm{};
@@ -657,11 +746,13 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
   for (int round = 0; round < n_rounds; round++) {
     // ------------------------------------------------------------------ setup (host) ---------
     t0 = now_ms();
+    const bool dev_setup = b->device_setup && !b->force_host_setup;
     std::vector<FrameRound> fr(NF);
     parallel_for(NF, NT, [&](int f) {
       const FrameIn& F = b->frames[f];
       FrameRound& R = fr[f];
       int b0 = sample_rp ? round : 0, b1 = sample_rp ? std::min(round + 1, F.n_boxes) : F.n_boxes;
+      int shared_yoff = -1, shared_Y = 0;  // without roll/pitch sampling cam_pose never changes: every box of the frame sweeps the same yaw list (:180-184)
       for (int bi = b0; bi < b1; bi++) {
         const double* bb = &F.boxes[5 * bi];
         int left = bb[0], top = bb[1], w = bb[2], h = bb[3];
@@ -669,11 +760,16 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
         int res = (int)std::round(std::min(20, w / 10));
         if (res < 1) continue;  // :215 break (same for every height sample)
         // yaw samples (:180-184)
-        double yaw_init = cur_yaw[f] - 90.0 / 180.0 * CS_PI;
-        std::vector<double> yaws;
-        linespace<double>(yaw_init - P.yaw_range_deg / 180.0 * CS_PI, yaw_init + P.yaw_range_deg / 180.0 * CS_PI, P.yaw_step_deg / 180.0 * CS_PI, yaws);
-        int yoff = (int)R.yaw.size();
-        for (double y : yaws) { R.yaw.push_back(y); R.yaw_c.push_back(h_cos(y)); R.yaw_s.push_back(h_sin(y)); }
+        int yoff, nY;
+        if (shared_yoff >= 0) { yoff = shared_yoff; nY = shared_Y; }
+        else {
+          double yaw_init = cur_yaw[f] - 90.0 / 180.0 * CS_PI;
+          std::vector<double> yaws;
+          linespace<double>(yaw_init - P.yaw_range_deg / 180.0 * CS_PI, yaw_init + P.yaw_range_deg / 180.0 * CS_PI, P.yaw_step_deg / 180.0 * CS_PI, yaws);
+          yoff = (int)R.yaw.size(); nY = (int)yaws.size();
+          for (double y : yaws) { R.yaw.push_back(y); R.yaw_c.push_back(h_cos(y)); R.yaw_s.push_back(h_sin(y)); }
+          if (!sample_rp) { shared_yoff = yoff; shared_Y = nY; }
+        }
         std::vector<int> tops;
         linespace<int>(left + 5, right - 5, res, tops);
         for (int k = 0; k < F.n_heights[bi]; k++) {
@@ -684,7 +780,7 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
           jd.g.left = left; jd.g.top = top; jd.g.right = right; jd.g.down = top + he;
           jd.g.el = roi.left; jd.g.et = roi.top; jd.g.er = roi.left + roi.width; jd.g.eb = roi.top + roi.height;
           jd.map_w = roi.width;
-          jd.Y = (int)yaws.size(); jd.T = (int)tops.size(); jd.RP = (int)cam_rp[f].size();
+          jd.Y = nY; jd.T = (int)tops.size(); jd.RP = (int)cam_rp[f].size();
           jd.down_expand = roi.down_expand;
           jd.frame = f; jd.box = bi; jd.hid = k;
           jd.map_off = F.map_offs[3 * bi + k];
@@ -692,7 +788,8 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
           jd.diag = std::sqrt(double(w * w + he * he));
           JobHost jh;
           jh.frame = f; jh.box = bi; jh.hid = k; jh.yaw_off_local = yoff; jh.tops = tops;
-          // ROI line filter (:271-283) + merge (:288-296) + angles/midpoints (:309-315)
+          // ROI line filter (:271-283) + merge (:288-296) + angles/midpoints (:309-315): line_setup_kernel, or here
+          if (dev_setup) { jd.m = 0; jh.line_cap = F.n_lines; R.jobs.push_back(jd); R.jh.push_back(std::move(jh)); continue; }
           std::vector<double> in;
           for (int e = 0; e < F.n_lines; e++) {
             const double* l = &F.lines[4 * e];
@@ -707,55 +804,61 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
             jh.mids_x.push_back((in[4 * i] + in[4 * i + 2]) / 2);
             jh.mids_y.push_back((in[4 * i + 1] + in[4 * i + 3]) / 2);
           }
+          jh.line_cap = jd.m;
           R.jobs.push_back(jd);
           R.jh.push_back(std::move(jh));
         }
       }
     });
-    // pack: offsets + one staging buffer
-    size_t nj = 0, n_lines = 0, n_yaw = 0, n_top = 0;
+    // pack: per-frame sizes -> offsets (serial prefix over frames) -> parallel copy into the pooled arrays
+    std::vector<size_t> f_job(NF + 1, 0), f_line(NF + 1, 0), f_yaw(NF + 1, 0), f_top(NF + 1, 0);
+    std::vector<long long> f_slot(NF + 1, 0), f_vp(NF + 1, 0);
     for (int f = 0; f < NF; f++) {
-      nj += fr[f].jobs.size();
-      n_yaw += fr[f].yaw.size();
-      for (auto& j : fr[f].jh) { n_lines += j.angs.size(); n_top += j.tops.size(); }
+      size_t nl = 0, nt = 0;
+      long long ns = 0, nv = 0;
+      for (size_t q = 0; q < fr[f].jobs.size(); q++) {
+        const cs::JobDesc& jd = fr[f].jobs[q];
+        nl += fr[f].jh[q].line_cap; nt += fr[f].jh[q].tops.size();
+        nv += (long long)jd.RP * jd.Y; ns += (long long)jd.RP * jd.Y * jd.T * 2;
+      }
+      f_job[f + 1] = f_job[f] + fr[f].jobs.size(); f_line[f + 1] = f_line[f] + nl; f_yaw[f + 1] = f_yaw[f] + fr[f].yaw.size();
+      f_top[f + 1] = f_top[f] + nt; f_slot[f + 1] = f_slot[f] + ns; f_vp[f + 1] = f_vp[f] + nv;
     }
+    const size_t nj = f_job[NF], n_lines = f_line[NF], n_yaw = f_yaw[NF], n_top = f_top[NF];
     if (nj == 0) { tm.setup_host_ms += now_ms() - t0; continue; }
+    if (f_vp[NF] > 0x7fffffffLL) { set_err("too many (roll,pitch,yaw) samples in one round"); return CS_ERR_CAPACITY; }
     std::vector<cs::JobDesc> jobs(nj);
     std::vector<long long> slot_prefix(nj + 1);
     std::vector<int> vp_prefix(nj + 1);
-    std::vector<double> mid_x(n_lines), mid_y(n_lines), ang(n_lines), yaw(n_yaw), yaw_c(n_yaw), yaw_s(n_yaw);
+    const size_t n_lines_host = dev_setup ? 0 : n_lines;  // with the device line setup these tables are only ever written by the kernel
+    std::vector<double> mid_x(n_lines_host), mid_y(n_lines_host), ang(n_lines_host), yaw(n_yaw), yaw_c(n_yaw), yaw_s(n_yaw);
     std::vector<int> top_x(n_top);
-    std::vector<const JobHost*> jhp(nj);
-    {
-      size_t ji = 0, lo = 0, yo = 0, to = 0;
-      long long so = 0;
-      long long vo = 0;
-      for (int f = 0; f < NF; f++) {
-        FrameRound& R = fr[f];
-        std::copy(R.yaw.begin(), R.yaw.end(), yaw.begin() + yo);
-        std::copy(R.yaw_c.begin(), R.yaw_c.end(), yaw_c.begin() + yo);
-        std::copy(R.yaw_s.begin(), R.yaw_s.end(), yaw_s.begin() + yo);
-        for (size_t q = 0; q < R.jobs.size(); q++, ji++) {
-          cs::JobDesc& jd = R.jobs[q];
-          const JobHost& jh = R.jh[q];
-          jd.line_off = (int)lo; jd.yaw_off = (int)(yo + jh.yaw_off_local); jd.top_off = (int)to;
-          jd.vp_off = (int)vo; jd.slot_off = so;
+    parallel_for(NF, NT, [&](int f) {
+      FrameRound& R = fr[f];
+      size_t ji = f_job[f], lo = f_line[f], yo = f_yaw[f], to = f_top[f];
+      long long so = f_slot[f], vo = f_vp[f];
+      std::copy(R.yaw.begin(), R.yaw.end(), yaw.begin() + yo);
+      std::copy(R.yaw_c.begin(), R.yaw_c.end(), yaw_c.begin() + yo);
+      std::copy(R.yaw_s.begin(), R.yaw_s.end(), yaw_s.begin() + yo);
+      for (size_t q = 0; q < R.jobs.size(); q++, ji++) {
+        cs::JobDesc& jd = R.jobs[q];
+        const JobHost& jh = R.jh[q];
+        jd.line_off = (int)lo; jd.yaw_off = (int)(yo + jh.yaw_off_local); jd.top_off = (int)to;
+        jd.vp_off = (int)vo; jd.slot_off = so;
+        if (!dev_setup) {
           std::copy(jh.mids_x.begin(), jh.mids_x.end(), mid_x.begin() + lo);
           std::copy(jh.mids_y.begin(), jh.mids_y.end(), mid_y.begin() + lo);
           std::copy(jh.angs.begin(), jh.angs.end(), ang.begin() + lo);
-          std::copy(jh.tops.begin(), jh.tops.end(), top_x.begin() + to);
-          lo += jh.angs.size(); to += jh.tops.size();
-          slot_prefix[ji] = so; vp_prefix[ji] = (int)vo;
-          vo += (long long)jd.RP * jd.Y;
-          so += (long long)jd.RP * jd.Y * jd.T * 2;
-          jobs[ji] = jd;
-          jhp[ji] = &jh;
         }
-        yo += R.yaw.size();
+        std::copy(jh.tops.begin(), jh.tops.end(), top_x.begin() + to);
+        lo += jh.line_cap; to += jh.tops.size();
+        slot_prefix[ji] = so; vp_prefix[ji] = (int)vo;
+        vo += (long long)jd.RP * jd.Y;
+        so += (long long)jd.RP * jd.Y * jd.T * 2;
+        jobs[ji] = jd;
       }
-      slot_prefix[nj] = so; vp_prefix[nj] = (int)vo;
-      if (vo > 0x7fffffffLL) { set_err("too many (roll,pitch,yaw) samples in one round"); return CS_ERR_CAPACITY; }
-    }
+    });
+    slot_prefix[nj] = f_slot[NF]; vp_prefix[nj] = (int)f_vp[NF];
     const long long slot_total = slot_prefix[nj];
     const int vp_total = vp_prefix[nj];
     tm.setup_host_ms += now_ms() - t0;
@@ -773,7 +876,7 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
     ENS(b->d_corners, 16 * (size_t)slot_total + 16);
 #define H2D(dst, vec) HIP_TRY(hipMemcpyAsync((dst).p, (vec).data(), sizeof((vec)[0]) * (vec).size(), hipMemcpyHostToDevice, st))
     H2D(b->d_jobs, jobs); H2D(b->d_slot_prefix, slot_prefix); H2D(b->d_vp_prefix, vp_prefix);
-    if (n_lines) { H2D(b->d_mid_x, mid_x); H2D(b->d_mid_y, mid_y); H2D(b->d_ang, ang); }
+    if (n_lines && !dev_setup) { H2D(b->d_mid_x, mid_x); H2D(b->d_mid_y, mid_y); H2D(b->d_ang, ang); }
     if (n_yaw) { H2D(b->d_yaw, yaw); H2D(b->d_yaw_c, yaw_c); H2D(b->d_yaw_s, yaw_s); }
     if (n_top) H2D(b->d_top_x, top_x);
     HIP_TRY(hipMemsetAsync(b->d_job_valid.p, 0, sizeof(int) * nj, st));
@@ -787,16 +890,211 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
     v.yaw = b->d_yaw.p; v.yaw_cos = b->d_yaw_c.p; v.yaw_sin = b->d_yaw_s.p; v.top_x = b->d_top_x.p; v.rp = b->d_rp.p; v.invK = b->d_invK.p;
     v.vp = b->d_vp.p; v.bound = b->d_bound.p; v.flag = b->d_flag.p; v.dist_err = b->d_dist.p; v.angle_err = b->d_angle.p;
     v.skew = b->d_skew.p; v.corners = b->d_corners.p; v.job_valid = b->d_job_valid.p; v.job_cbase = b->d_job_cbase.p;
+    HIP_TRY(hipEventRecord(d->ev[6], st));
+    if (dev_setup) {
+      cs::launch_line_setup(b->d_jobs.p, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, b->d_mid_x.p, b->d_mid_y.p, b->d_ang.p,
+                            P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st);
+    }
+    HIP_TRY(hipEventRecord(d->ev[7], st));
+    if (dev_setup) {
+      // the merged segment counts come back with the results (byte accounting, debug getters)
+      ENS(b->h_jobs, nj);
+      HIP_TRY(hipMemcpyAsync(b->h_jobs.p, b->d_jobs.p, sizeof(cs::JobDesc) * nj, hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(hipEventRecord(d->ev[0], st));
     cs::launch_vp_support(v, sp, vp_total, st);
     HIP_TRY(hipEventRecord(d->ev[1], st));
     cs::launch_candidates(v, sp, slot_total, st);
     HIP_TRY(hipEventRecord(d->ev[2], st));
     HIP_TRY(hipGetLastError());
+
+    // ------------------------------------------------------------------ rank on the device --------
+    // (no roll/pitch sampling: boxes are independent, so nothing has to come back to the host before the ranking)
+    const bool device_rank = !sample_rp && !b->debug && !b->force_host_rank && KMAX <= cs::RANK_KMAX;
+    if (device_rank) {
+      ENS(b->d_c_slot, slot_total + 1); ENS(b->d_c_flag, slot_total + 1); ENS(b->d_c_dist, slot_total + 1); ENS(b->d_c_angle, slot_total + 1); ENS(b->d_c_skew, slot_total + 1);
+      v.c_slot = b->d_c_slot.p; v.c_flag = b->d_c_flag.p; v.c_dist = b->d_c_dist.p; v.c_angle = b->d_c_angle.p; v.c_skew = b->d_c_skew.p;
+      HIP_TRY(hipEventRecord(d->ev[3], st));
+      cs::launch_scan_compact(v, st);
+      HIP_TRY(hipEventRecord(d->ev[4], st));
+      std::vector<int> box_job0, box_njobs;
+      for (size_t j = 0; j < nj; j++)
+        if (jobs[j].hid == 0) { box_job0.push_back((int)j); box_njobs.push_back(b->frames[jobs[j].frame].n_heights[jobs[j].box]); }
+      const size_t nb = box_job0.size();
+      ENS(b->d_box_job0, nb); ENS(b->d_box_njobs, nb); ENS(b->d_win_count, nb); ENS(b->d_fallback, nb); ENS(b->d_winners, nb * KMAX);
+      ENS(b->h_winners, nb * KMAX); ENS(b->h_win_count, nb); ENS(b->h_fallback, nb); ENS(b->h_job_valid, nj); ENS(b->h_job_cbase, nj + 1);
+      H2D(b->d_box_job0, box_job0); H2D(b->d_box_njobs, box_njobs);
+      cs::RankView rv{};
+      rv.box_job0 = b->d_box_job0.p; rv.box_njobs = b->d_box_njobs.p; rv.n_boxes = (int)nb;
+      rv.winners = b->d_winners.p; rv.win_count = b->d_win_count.p; rv.fallback = b->d_fallback.p;
+      cs::RankParams rkp{P.weight_vp_angle, P.weight_skew_error, P.nominal_skew_ratio, P.max_cut_skew, KMAX};
+      cs::launch_rank(v, rv, rkp, st);
+      HIP_TRY(hipEventRecord(d->ev[5], st));
+      HIP_TRY(hipGetLastError());
+      double t_d2h = now_ms();
+      HIP_TRY(hipMemcpyAsync(b->h_winners.p, b->d_winners.p, sizeof(cs::RankWinner) * nb * KMAX, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(b->h_win_count.p, b->d_win_count.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(b->h_fallback.p, b->d_fallback.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(b->h_job_valid.p, b->d_job_valid.p, sizeof(int) * nj, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(b->h_job_cbase.p, b->d_job_cbase.p, sizeof(long long) * (nj + 1), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      tm.d2h_ms += now_ms() - t_d2h;
+      if (dev_setup) for (size_t j = 0; j < nj; j++) jobs[j].m = b->h_jobs.p[j].m;
+      const long long n_valid = b->h_job_cbase.p[nj];
+      tm.n_valid += n_valid;
+      {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1])); tm.vp_kernel_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, d->ev[1], d->ev[2])); tm.cand_kernel_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, d->ev[3], d->ev[4])); tm.compact_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, d->ev[4], d->ev[5])); tm.rank_kernel_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, d->ev[6], d->ev[7])); tm.line_setup_ms += ms;
+        tm.cand_kernel_launches += 1;
+        long long bytes = 0;
+        for (size_t j = 0; j < nj; j++) bytes += 4LL * jobs[j].map_w * (jobs[j].g.eb - jobs[j].g.et) + 24LL * jobs[j].m;
+        bytes += 96LL * vp_total + 4LL * slot_total + 200LL * n_valid;
+        tm.cand_kernel_bytes += bytes;
+      }
+      // ---- finish on the host: records of the winners; boxes flagged by the kernel are re-ranked exactly
+      t0 = now_ms();
+      auto rows_of = [&](const cs::JobDesc& jd, long long slot, int flag, double de, double ae, double* r9, int* rp_out) {
+        long long local = slot - jd.slot_off;
+        int cfg = (int)(local & 1) + 1;
+        long long rest = local >> 1;
+        int t = (int)(rest % jd.T);
+        int ry = (int)(rest / jd.T);
+        int rp = ry / jd.Y, y = ry - rp * jd.Y;
+        *rp_out = rp;
+        r9[0] = cfg; r9[1] = flag & cs::CAND_VP_MASK; r9[2] = yaw[jd.yaw_off + y]; r9[3] = t; r9[4] = de; r9[5] = ae; r9[6] = jd.down_expand;
+        r9[7] = cam_rp[jd.frame][rp].pose.roll; r9[8] = cam_rp[jd.frame][rp].pose.pitch;
+      };
+      // columns of every flagged box, fetched with one gather + one copy per column
+      std::vector<long long> fb_src, fb_dst;
+      std::vector<int> fb_cnt, fb_range_of_job(nj, -1);
+      std::vector<double> fb_dist, fb_angle, fb_skew;
+      std::vector<int> fb_flag;
+      std::vector<long long> fb_slot;
+      {
+        long long tot = 0;
+        for (size_t q = 0; q < nb; q++)
+          if (b->h_fallback.p[q])
+            for (int h = 0; h < box_njobs[q]; h++) {
+              int j = box_job0[q] + h;
+              fb_range_of_job[j] = (int)fb_src.size();
+              fb_src.push_back(b->h_job_cbase.p[j]); fb_cnt.push_back(b->h_job_valid.p[j]); fb_dst.push_back(tot);
+              tot += b->h_job_valid.p[j];
+            }
+        if (!fb_src.empty()) {
+          size_t nr = fb_src.size();
+          ENS(b->d_fb_src, nr); ENS(b->d_fb_dst, nr); ENS(b->d_fb_cnt, nr);
+          ENS(b->d_fb_dist, tot + 1); ENS(b->d_fb_angle, tot + 1); ENS(b->d_fb_skew, tot + 1); ENS(b->d_fb_flag, tot + 1); ENS(b->d_fb_slot, tot + 1);
+          H2D(b->d_fb_src, fb_src); H2D(b->d_fb_dst, fb_dst); H2D(b->d_fb_cnt, fb_cnt);
+          cs::launch_gather_ranges(v, b->d_fb_src.p, b->d_fb_cnt.p, b->d_fb_dst.p, (int)nr, b->d_fb_dist.p, b->d_fb_angle.p, b->d_fb_skew.p, b->d_fb_flag.p, b->d_fb_slot.p, st);
+          fb_dist.resize(tot); fb_angle.resize(tot); fb_skew.resize(tot); fb_flag.resize(tot); fb_slot.resize(tot);
+          if (tot) {
+            HIP_TRY(hipMemcpyAsync(fb_dist.data(), b->d_fb_dist.p, 8 * (size_t)tot, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(fb_angle.data(), b->d_fb_angle.p, 8 * (size_t)tot, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(fb_skew.data(), b->d_fb_skew.p, 8 * (size_t)tot, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(fb_flag.data(), b->d_fb_flag.p, 4 * (size_t)tot, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(fb_slot.data(), b->d_fb_slot.p, 8 * (size_t)tot, hipMemcpyDeviceToHost, st));
+          }
+          HIP_TRY(hipStreamSynchronize(st));
+        }
+      }
+      std::vector<std::vector<cs::RankWinner>> fb_winners(nb);
+      int hip_err = 0;
+      auto finish_box = [&](size_t q, int phase) -> int {
+        const int j0 = box_job0[q], nh = box_njobs[q];
+        const int f = jobs[j0].frame, bi = jobs[j0].box;
+        const FrameIn& F = b->frames[f];
+        const double* bb = &F.boxes[5 * bi];
+        std::vector<cs::RankWinner> wl;
+        if (!b->h_fallback.p[q]) {
+          for (int r = 0; r < b->h_win_count.p[q]; r++) wl.push_back(b->h_winners.p[q * KMAX + r]);
+        } else if (phase == 1) {
+          wl = fb_winners[q];
+        } else {
+          struct HP { int h, cand; double score, skew; };
+          std::vector<HP> props;
+          std::vector<std::vector<double>> hd(nh), ha(nh), hs(nh);
+          std::vector<std::vector<int>> hf(nh);
+          std::vector<std::vector<long long>> hsl(nh);
+          for (int h = 0; h < nh; h++) {
+            int j = j0 + h;
+            long long c0 = b->h_job_cbase.p[j];
+            int V = b->h_job_valid.p[j];
+            long long p0 = fb_dst[fb_range_of_job[j]];
+            hd[h].assign(fb_dist.begin() + p0, fb_dist.begin() + p0 + V); ha[h].assign(fb_angle.begin() + p0, fb_angle.begin() + p0 + V);
+            hs[h].assign(fb_skew.begin() + p0, fb_skew.begin() + p0 + V); hf[h].assign(fb_flag.begin() + p0, fb_flag.begin() + p0 + V);
+            hsl[h].assign(fb_slot.begin() + p0, fb_slot.begin() + p0 + V);
+            std::vector<int> keep;
+            std::vector<double> score;
+            fuse_scores(hd[h].data(), ha[h].data(), V, P.weight_vp_angle, keep, score);
+            for (size_t z = 0; z < keep.size(); z++) {
+              if (hf[h][keep[z]] & cs::CAND_NEG_SCALE) continue;
+              props.push_back(HP{h, keep[z], score[z], hs[h][keep[z]]});
+            }
+          }
+          int n = (int)props.size(), kk = std::min(KMAX, n);
+          std::vector<double> comb(n);
+          for (int i = 0; i < n; i++) {
+            double skew_error = P.weight_skew_error * std::max(props[i].skew - P.nominal_skew_ratio, 0.0);
+            if (props[i].skew > P.max_cut_skew) skew_error = 100;
+            comb[i] = props[i].score + P.weight_skew_error * skew_error;
+          }
+          std::vector<int> idx(n);
+          std::iota(idx.begin(), idx.end(), 0);
+          std::partial_sort(idx.begin(), idx.begin() + kk, idx.end(), [&comb](int a, int c) { return comb[a] < comb[c]; });
+          for (int r = 0; r < kk; r++) {
+            const HP& hp = props[idx[r]];
+            cs::RankWinner w{};
+            w.slot = hsl[hp.h][hp.cand]; w.normalized_error = hp.score; w.dist_err = hd[hp.h][hp.cand]; w.angle_err = ha[hp.h][hp.cand];
+            w.flag = hf[hp.h][hp.cand] & cs::CAND_VP_MASK;
+            wl.push_back(w);  // corners fetched below, in one gather for all fallback winners
+          }
+          fb_winners[q] = wl;
+          return CS_OK;
+        }
+        for (size_t r = 0; r < wl.size(); r++) {
+          const cs::RankWinner& w = wl[r];
+          int h = 0;
+          while (h + 1 < nh && w.slot >= jobs[j0 + h + 1].slot_off) h++;
+          double r9[9];
+          int rpi = 0;
+          rows_of(jobs[j0 + h], w.slot, w.flag, w.dist_err, w.angle_err, r9, &rpi);
+          cs_cuboid& o = out[((size_t)f * MB + bi) * KMAX + r];
+          finish_cuboid(F, cam_rp[f][rpi].pose, r9, w.corners, cam_raw[f].euler, sample_rp, w.normalized_error, o);
+          o.rect_detect_2d[0] = (int)bb[0]; o.rect_detect_2d[1] = (int)bb[1]; o.rect_detect_2d[2] = (int)bb[2]; o.rect_detect_2d[3] = (int)bb[3];
+        }
+        out_counts[(size_t)f * MB + bi] = (int)wl.size();
+        return CS_OK;
+      };
+      parallel_for((int)nb, NT, [&](int q) { (void)finish_box((size_t)q, 0); });  // flagged boxes: exact host ranking only
+      {
+        std::vector<long long> ws;
+        for (size_t q = 0; q < nb; q++) { if (b->h_fallback.p[q]) { tm.n_fallback_boxes++; for (auto& w : fb_winners[q]) ws.push_back(w.slot); } }
+        if (!ws.empty()) {
+          ENS(b->d_win_slots, ws.size()); ENS(b->d_win_corners, 16 * ws.size()); ENS(b->h_win_corners, 16 * ws.size());
+          H2D(b->d_win_slots, ws);
+          cs::launch_gather_corners(b->d_corners.p, b->d_win_slots.p, (int)ws.size(), b->d_win_corners.p, st);
+          HIP_TRY(hipMemcpyAsync(b->h_win_corners.p, b->d_win_corners.p, sizeof(double) * 16 * ws.size(), hipMemcpyDeviceToHost, st));
+          HIP_TRY(hipStreamSynchronize(st));
+          size_t z = 0;
+          for (size_t q = 0; q < nb; q++)
+            if (b->h_fallback.p[q])
+              for (auto& w : fb_winners[q]) { std::memcpy(w.corners, b->h_win_corners.p + 16 * z, 128); z++; }
+        }
+        parallel_for((int)nb, NT, [&](int q) { if (b->h_fallback.p[q]) (void)finish_box((size_t)q, 1); });
+      }
+      if (hip_err) return hip_err;
+      tm.finalize_ms += now_ms() - t0;
+      continue;
+    }
     // valid counts -> host -> size the compact arrays
     ENS(b->h_job_valid, nj); ENS(b->h_job_cbase, nj + 1);
     HIP_TRY(hipMemcpyAsync(b->h_job_valid.p, b->d_job_valid.p, sizeof(int) * nj, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (dev_setup) for (size_t j = 0; j < nj; j++) jobs[j].m = b->h_jobs.p[j].m;
     long long n_valid = 0;
     for (size_t j = 0; j < nj; j++) { b->h_job_cbase.p[j] = n_valid; n_valid += b->h_job_valid.p[j]; }
     b->h_job_cbase.p[nj] = n_valid;
@@ -823,6 +1121,7 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
       HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1])); tm.vp_kernel_ms += ms;
       HIP_TRY(hipEventElapsedTime(&ms, d->ev[1], d->ev[2])); tm.cand_kernel_ms += ms;
       HIP_TRY(hipEventElapsedTime(&ms, d->ev[3], d->ev[4])); tm.compact_ms += ms;
+      HIP_TRY(hipEventElapsedTime(&ms, d->ev[6], d->ev[7])); tm.line_setup_ms += ms;
       tm.cand_kernel_launches += 1;
       // algorithmic bytes of the candidate kernel: maps + line arrays + vp/bound read once,
       // 200 B written per valid proposal, 4 B flag per slot

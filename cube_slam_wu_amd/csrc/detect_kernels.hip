@@ -15,6 +15,9 @@
 // Compiled with -ffp-contract=off: every result is bit-identical to the CPU oracle.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "detect_types.h"
 
 namespace cs {
@@ -292,6 +295,401 @@ __global__ __launch_bounds__(256) void gather_corners_kernel(const double* corne
   out[i] = (s >= 0) ? corners[16 * s + k] : 0.0;
 }
 
+
+// ------------------------------------------------------------------ ranking on the device --------
+// fuse_normalize_scores_v2 (object_3d_util.cpp:726-837) keeps the best 2/3 by distance error, intersects with the
+// best 2/3 by angle error when the angle errors do not saturate at the cut, min-max normalises both over the kept
+// set and fuses them; box_proposal_detail.cpp:804-838 adds the skew penalty and takes the max_cuboid_num smallest.
+// The reference does this with std::partial_sort, whose order among *equal* keys is an artefact of the heap.  The
+// results here are order statistics and arg-mins, which are identical to the reference's whenever no tie straddles
+// a cut or the final top-k; when one does, the box is flagged and the host stage (exact std::partial_sort) redoes it.
+__device__ __forceinline__ unsigned long long order_key(double x) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// key of rank r (0-based, ascending) among n doubles; all 256 threads of the block must call it
+__device__ unsigned long long block_radix_select(const double* __restrict__ a, int n, int r, unsigned* hist /* LDS, 256 */, unsigned long long* bcast /* LDS, 2 */) {
+  unsigned long long prefix = 0, mask = 0;
+  for (int pass = 0; pass < 8; pass++) {
+    int shift = 56 - 8 * pass;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+      unsigned long long k = order_key(a[i]);
+      if ((k & mask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // wave 0: each lane owns 4 consecutive bins
+      unsigned c0 = hist[4 * threadIdx.x], c1 = hist[4 * threadIdx.x + 1], c2 = hist[4 * threadIdx.x + 2], c3 = hist[4 * threadIdx.x + 3];
+      unsigned tot = c0 + c1 + c2 + c3, incl = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { unsigned y = __shfl_up(incl, o); if ((int)threadIdx.x >= o) incl += y; }
+      unsigned excl = incl - tot;
+      if ((unsigned)r >= excl && (unsigned)r < incl) {
+        unsigned rr = (unsigned)r - excl, d;
+        if (rr < c0) { d = 0; }
+        else if (rr < c0 + c1) { d = 1; rr -= c0; }
+        else if (rr < c0 + c1 + c2) { d = 2; rr -= c0 + c1; }
+        else { d = 3; rr -= c0 + c1 + c2; }
+        bcast[0] = (unsigned long long)(4 * threadIdx.x + d);
+        bcast[1] = rr;
+      }
+    }
+    __syncthreads();
+    prefix |= bcast[0] << shift;
+    mask |= 255ull << shift;
+    r = (int)bcast[1];
+    __syncthreads();
+  }
+  return prefix;
+}
+
+__device__ __forceinline__ double block_reduce_min(double v, double* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { double y = __shfl_down(v, o); v = (y < v) ? y : v; }
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = sh[0];
+  for (int w = 1; w < 4; w++) r = (sh[w] < r) ? sh[w] : r;
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ double block_reduce_max(double v, double* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { double y = __shfl_down(v, o); v = (y > v) ? y : v; }
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = sh[0];
+  for (int w = 1; w < 4; w++) r = (sh[w] > r) ? sh[w] : r;
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ int block_reduce_sum_i(int v, int* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int r = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return r;
+}
+
+struct JobCut {      // per height sample of the box
+  double vd, va;     // keep a proposal iff dist <= vd (and angle <= va when use_angle)
+  double dmin, dmax, amin, amax;
+  int use_angle, n_keep, V;
+};
+
+__global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView rv, RankParams rp) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned long long bcast[2];
+  __shared__ double shd[4];
+  __shared__ int shi[4];
+  __shared__ JobCut cuts[3];
+  __shared__ int s_fallback;
+  int box = blockIdx.x;
+  if (box >= rv.n_boxes) return;
+  if (threadIdx.x == 0) s_fallback = 0;
+  __syncthreads();
+  const int j0 = rv.box_job0[box], nj = rv.box_njobs[box];
+  const double INF = __builtin_huge_val();
+  // ---- per height sample: the cuts of fuse_normalize_scores_v2 and the min/max over the kept set
+  for (int h = 0; h < nj; h++) {
+    int j = j0 + h;
+    long long c0 = v.job_cbase[j];
+    int V = v.job_valid[j];
+    const double* D = v.c_dist + c0;
+    const double* A = v.c_angle + c0;
+    double vd = INF, va = INF;
+    int use_angle = 0;
+    if (V > 4) {
+      int bn = (int)round((double)((float)V) / 3.0 * 2.0);
+      unsigned long long kd = block_radix_select(D, V, bn - 2, hist, bcast);
+      unsigned long long ka = block_radix_select(A, V, bn - 2, hist, bcast);
+      int cd = 0, ca = 0, nan = 0;
+      for (int i = threadIdx.x; i < V; i += 256) {
+        double d = D[i], a = A[i];
+        cd += order_key(d) <= kd; ca += order_key(a) <= ka;
+        nan += (d != d) || (a != a);
+      }
+      cd = block_reduce_sum_i(cd, shi); ca = block_reduce_sum_i(ca, shi); nan = block_reduce_sum_i(nan, shi);
+      // the (bn-1)-th and bn-th smallest distance errors must differ, else which one is kept depends on the heap
+      if ((cd != bn - 1 || nan) && threadIdx.x == 0) s_fallback = 1;
+      use_angle = (ca == bn - 1);  // angle[sorted[bn-1]] > angle[sorted[bn-2]] (:766)
+      // thresholds as doubles: the largest kept value
+      double md = -INF, ma = -INF;
+      for (int i = threadIdx.x; i < V; i += 256) {
+        if (order_key(D[i]) <= kd) md = (D[i] > md) ? D[i] : md;
+        if (order_key(A[i]) <= ka) ma = (A[i] > ma) ? A[i] : ma;
+      }
+      vd = block_reduce_max(md, shd);
+      va = block_reduce_max(ma, shd);
+    }
+    double dmin = 1e6, dmax = -1, amin = 1e6, amax = -1;  // :798-801
+    int nk = 0;
+    for (int i = threadIdx.x; i < V; i += 256) {
+      double d = D[i], a = A[i];
+      bool keep = (d <= vd) && (!use_angle || a <= va);
+      if (keep) {
+        nk++;
+        dmin = (d < dmin) ? d : dmin; dmax = (dmax < d) ? d : dmax;
+        amin = (a < amin) ? a : amin; amax = (amax < a) ? a : amax;
+      }
+    }
+    dmin = block_reduce_min(dmin, shd); dmax = block_reduce_max(dmax, shd);
+    amin = block_reduce_min(amin, shd); amax = block_reduce_max(amax, shd);
+    nk = block_reduce_sum_i(nk, shi);
+    if (threadIdx.x == 0) {
+      JobCut c; c.vd = vd; c.va = va; c.dmin = dmin; c.dmax = dmax; c.amin = amin; c.amax = amax; c.use_angle = use_angle; c.n_keep = nk; c.V = V;
+      cuts[h] = c;
+    }
+    __syncthreads();
+  }
+  // ---- final ranking over the proposals of all height samples: kmax rounds of arg-min
+  double prev = -INF;
+  int n_win = 0;
+  for (int round = 0; round < rp.kmax; round++) {
+    double best = INF;
+    int best_h = -1, best_i = -1, bad = 0;
+    for (int h = 0; h < nj; h++) {
+      const JobCut c = cuts[h];
+      long long c0 = v.job_cbase[j0 + h];
+      for (int i = threadIdx.x; i < c.V; i += 256) {
+        double d = v.c_dist[c0 + i], a = v.c_angle[c0 + i];
+        bool keep = (d <= c.vd) && (!c.use_angle || a <= c.va);
+        if (!keep || (v.c_flag[c0 + i] & CAND_NEG_SCALE)) continue;
+        double score;
+        if (c.n_keep > 1) {
+          double dn = (d - c.dmin) / (c.dmax - c.dmin);
+          double an = ((c.amax - c.amin) > 0) ? (a - c.amin) / (c.amax - c.amin) : a;
+          score = (dn + rp.w_angle * an) / (1 + rp.w_angle);
+        } else {
+          score = (d + rp.w_angle * a) / (1 + rp.w_angle);
+        }
+        double sk = v.c_skew[c0 + i];
+        double skew_error = rp.w_skew * dmax(sk - rp.nominal_skew, 0.0);
+        if (sk > rp.max_cut_skew) skew_error = 100;
+        double comb = score + rp.w_skew * skew_error;
+        if (comb != comb || comb == INF || comb == -INF) { bad = 1; continue; }  // NaN / inf: let the host decide
+        if (comb > prev && comb < best) { best = comb; best_h = h; best_i = i; }
+      }
+    }
+    bad = block_reduce_sum_i(bad, shi);
+    double gbest = block_reduce_min(best, shd);
+    if (bad && threadIdx.x == 0) s_fallback = 1;
+    if (!(gbest < INF)) break;  // no proposal left
+    // how many proposals attain the minimum?  (> 1: the reference's pick depends on the heap order)
+    int cnt = 0;
+    for (int h = 0; h < nj; h++) {
+      const JobCut c = cuts[h];
+      long long c0 = v.job_cbase[j0 + h];
+      for (int i = threadIdx.x; i < c.V; i += 256) {
+        double d = v.c_dist[c0 + i], a = v.c_angle[c0 + i];
+        bool keep = (d <= c.vd) && (!c.use_angle || a <= c.va);
+        if (!keep || (v.c_flag[c0 + i] & CAND_NEG_SCALE)) continue;
+        double score;
+        if (c.n_keep > 1) {
+          double dn = (d - c.dmin) / (c.dmax - c.dmin);
+          double an = ((c.amax - c.amin) > 0) ? (a - c.amin) / (c.amax - c.amin) : a;
+          score = (dn + rp.w_angle * an) / (1 + rp.w_angle);
+        } else {
+          score = (d + rp.w_angle * a) / (1 + rp.w_angle);
+        }
+        double sk = v.c_skew[c0 + i];
+        double skew_error = rp.w_skew * dmax(sk - rp.nominal_skew, 0.0);
+        if (sk > rp.max_cut_skew) skew_error = 100;
+        double comb = score + rp.w_skew * skew_error;
+        if (comb == gbest) {
+          cnt++;
+          // the (unique) owner writes the winner record
+          RankWinner* w = rv.winners + (size_t)box * rp.kmax + round;
+          long long slot = v.c_slot[c0 + i];
+          w->slot = slot; w->normalized_error = score; w->dist_err = d; w->angle_err = a; w->flag = v.c_flag[c0 + i] & CAND_VP_MASK; w->pad = 0;
+          const double* co = v.corners + 16 * slot;
+#pragma unroll
+          for (int q = 0; q < 16; q++) w->corners[q] = co[q];
+        }
+      }
+    }
+    cnt = block_reduce_sum_i(cnt, shi);
+    if (cnt != 1 && threadIdx.x == 0) s_fallback = 1;
+    prev = gbest;
+    n_win++;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { rv.win_count[box] = n_win; rv.fallback[box] = s_fallback; }
+}
+
+
+// ------------------------------------------------------------------ line setup on the device ------
+// Per (box, height sample): the ROI line filter (box_proposal_detail.cpp:271-283), merge_break_lines
+// (object_3d_util.cpp:431-543) and the angle / midpoint tables (:309-315), one wavefront per job.
+//
+// merge_break_lines is sequential -- merge the lexicographically first pair (a, b), a < b, that passes three tests
+// (angle difference, end-point gap, angle of the merged segment), overwrite row a, move the last row into b,
+// restart -- and its result depends on that order, so the order is reproduced exactly.  Rescanning all pairs every
+// round (what the reference does) costs O(m^2) per merge; instead the wave keeps F[a] = the first partner b > a of
+// every row, picks the smallest a with a partner (a wave-wide minimum), applies the merge, and repairs F: only
+// pairs that involve the two rewritten rows can change, so every other row re-tests exactly two pairs, and the
+// rewritten rows (plus the rare row whose first partner was rewritten) are re-scanned cooperatively, 64 partners
+// per step.  Same merges in the same order as the reference, O(m) work per merge.
+enum { LS_CAP = 512, LS_THREADS = 64 };
+
+struct LineSetupParams {
+  double dist_thre, angle_thre_rad, len_thre;  // 20 px, 5 deg, 30 px (:288-290)
+};
+
+struct LsRow { double ang, x1, y1, x2, y2; };
+
+// the three tests of object_3d_util.cpp:464-497 for the ordered pair (a, b)
+__device__ __forceinline__ bool ls_pair_pass(const LsRow& A, const LsRow& B, const LineSetupParams& lp) {
+  double diff = dabs(A.ang - B.ang);
+  if (dmin(diff, CS_PI - diff) >= lp.angle_thre_rad) return false;
+  double d_ab = v2_dist(v2(A.x2, A.y2), v2(B.x1, B.y1));
+  double d_ba = v2_dist(v2(B.x2, B.y2), v2(A.x1, A.y1));
+  if (!((d_ab < lp.dist_thre) || (d_ba < lp.dist_thre))) return false;
+  bool sa = A.x1 < B.x1, ea = A.x2 > B.x2;
+  double sx = sa ? A.x1 : B.x1, sy = sa ? A.y1 : B.y1, ex = ea ? A.x2 : B.x2, ey = ea ? A.y2 : B.y2;
+  double ma = cs_atan2(ey - sy, ex - sx);
+  double t = dabs(A.ang - ma);
+  return dmin(t, CS_PI - t) < lp.angle_thre_rad;
+}
+
+__global__ __launch_bounds__(LS_THREADS) void line_setup_kernel(JobDesc* jobs, int n_jobs, const double* __restrict__ frame_lines, const int* __restrict__ frame_line_ptr,
+                                                               double* mid_x, double* mid_y, double* line_angle, LineSetupParams lp) {
+  __shared__ double X1[LS_CAP], Y1[LS_CAP], X2[LS_CAP], Y2[LS_CAP], ANG[LS_CAP];
+  __shared__ int F[LS_CAP];
+  int j = blockIdx.x;
+  if (j >= n_jobs) return;
+  const JobDesc jd = jobs[j];
+  const double* FL = frame_lines + 4 * (size_t)frame_line_ptr[jd.frame];
+  const int M = frame_line_ptr[jd.frame + 1] - frame_line_ptr[jd.frame];
+  const int lane = threadIdx.x;
+  const int NONE = 0x7fffffff;
+  auto row = [&](int i) { return LsRow{ANG[i], X1[i], Y1[i], X2[i], Y2[i]}; };
+  // cooperative scan of row r: F[r] = first k > r with pair_pass(r, k)
+  auto rescan = [&](int r, int total) {
+    LsRow R = row(r);
+    int f = NONE;
+    for (int k0 = r + 1; k0 < total; k0 += 64) {
+      int k = k0 + lane;
+      bool ok = (k < total) && ls_pair_pass(R, row(k), lp);
+      unsigned long long bal = __ballot(ok);
+      if (bal) { f = k0 + __ffsll((long long)bal) - 1; break; }
+    }
+    if (lane == 0) F[r] = f;
+  };
+
+  // ---- 1. segments with both end points inside the expanded ROI, in input order
+  int total = 0;
+  for (int base = 0; base < M; base += 64) {
+    int i = base + lane;
+    double x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+    bool in = false;
+    if (i < M) {
+      x1 = FL[4 * i]; y1 = FL[4 * i + 1]; x2 = FL[4 * i + 2]; y2 = FL[4 * i + 3];
+      in = inside_box(v2(x1, y1), jd.g.el, jd.g.et, jd.g.er, jd.g.eb) && inside_box(v2(x2, y2), jd.g.el, jd.g.et, jd.g.er, jd.g.eb);
+    }
+    unsigned long long bal = __ballot(in);
+    int off = total + __popcll(bal & ((1ull << lane) - 1ull));
+    if (in && off < LS_CAP) { X1[off] = x1; Y1[off] = y1; X2[off] = x2; Y2[off] = y2; ANG[off] = cs_atan2(y2 - y1, x2 - x1); }
+    total = min(LS_CAP, total + __popcll(bal));
+  }
+  __syncthreads();
+  // ---- 2. first partner of every row
+  for (int a0 = 0; a0 < total; a0 += 64) {
+    int a = a0 + lane;
+    int f = NONE;
+    if (a < total - 1) {
+      LsRow A = row(a);
+      for (int b = a + 1; b < total; b++)
+        if (ls_pair_pass(A, row(b), lp)) { f = b; break; }
+    }
+    if (a < total) F[a] = f;
+  }
+  __syncthreads();
+  // ---- 3. merge rounds
+  for (int rounds = 0; rounds < 500; rounds++) {
+    int best = NONE;
+    for (int a = lane; a < total - 1; a += 64) {
+      int f = F[a];
+      if (f != NONE) { best = a * LS_CAP + f; break; }  // rows are visited in increasing order: the first hit is this lane's smallest
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { int y = __shfl_xor(best, o); best = (y < best) ? y : best; }
+    if (best == NONE) break;
+    const int as = best / LS_CAP, bs = best % LS_CAP, last = total - 1;
+    if (lane == 0) {
+      bool sa = X1[as] < X1[bs], ea = X2[as] > X2[bs];
+      double sx = sa ? X1[as] : X1[bs], sy = sa ? Y1[as] : Y1[bs], ex = ea ? X2[as] : X2[bs], ey = ea ? Y2[as] : Y2[bs];
+      X1[as] = sx; Y1[as] = sy; X2[as] = ex; Y2[as] = ey;
+      ANG[as] = cs_atan2(ey - sy, ex - sx);
+      X1[bs] = X1[last]; Y1[bs] = Y1[last]; X2[bs] = X2[last]; Y2[bs] = Y2[last]; ANG[bs] = ANG[last];  // fast_RemoveRow (matrix_utils.cpp:183)
+      F[bs] = F[last];  // placeholder; row bs is re-scanned below
+    }
+    total = last;
+    __syncthreads();
+    const bool moved = (bs != last);  // row bs now holds what used to be the last row
+    // every other row: only its pairs with the two rewritten rows can have changed
+    unsigned long long need = 0;
+    for (int a0 = 0; a0 < total; a0 += 64) {
+      int a = a0 + lane;
+      bool redo = false;
+      if (a < total && a != as && !(moved && a == bs)) {
+        int f = F[a];
+        if (f == last) f = NONE;                            // partner moved (re-tested as bs below) or vanished; everything before it failed
+        if (f == as || (moved && f == bs)) redo = true;     // first partner was rewritten: what comes after it was never tested
+        else {
+          LsRow A = row(a);
+          if (a < as && as < f && ls_pair_pass(A, row(as), lp)) f = as;
+          if (moved && a < bs && bs < f && ls_pair_pass(A, row(bs), lp)) f = bs;
+          F[a] = f;
+        }
+      }
+      unsigned long long bal = __ballot(redo);
+      // cooperative re-scans of the flagged rows of this stripe (rare)
+      while (bal) {
+        int l = __ffsll((long long)bal) - 1;
+        bal &= bal - 1;
+        rescan(a0 + l, total);
+      }
+      (void)need;
+    }
+    rescan(as, total);
+    if (moved) rescan(bs, total);
+    if (lane == 0 && total > 0) F[total - 1] = NONE;
+    __syncthreads();
+  }
+  // ---- 4. keep segments longer than the threshold (in order) and emit angle / midpoint tables
+  int kept = 0;
+  for (int base = 0; base < total; base += 64) {
+    int i = base + lane;
+    bool keep = false;
+    if (i < total) {
+      double len = v2_dist(v2(X2[i], Y2[i]), v2(X1[i], Y1[i]));
+      keep = (lp.len_thre > 0) ? (len > lp.len_thre) : true;
+    }
+    unsigned long long bal = __ballot(keep);
+    int off = kept + __popcll(bal & ((1ull << lane) - 1ull));
+    if (keep) {
+      line_angle[jd.line_off + off] = ANG[i];
+      mid_x[jd.line_off + off] = (X1[i] + X2[i]) / 2;
+      mid_y[jd.line_off + off] = (Y1[i] + Y2[i]) / 2;
+    }
+    kept += __popcll(bal);
+  }
+  if (lane == 0) jobs[j].m = kept;
+}
+
+void launch_line_setup(JobDesc* jobs, int n_jobs, const double* frame_lines, const int* frame_line_ptr, double* mid_x, double* mid_y, double* line_angle,
+                       double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st) {
+  if (n_jobs <= 0) return;
+  LineSetupParams lp{dist_thre, angle_thre_deg / 180.0 * CS_PI, len_thre};
+  hipLaunchKernelGGL(line_setup_kernel, dim3(n_jobs), dim3(LS_THREADS), 0, st, jobs, n_jobs, frame_lines, frame_line_ptr, mid_x, mid_y, line_angle, lp);
+}
+int line_setup_capacity() { return LS_CAP; }
+
 // ------------------------------------------------------------------ launchers (host side) -----
 static inline unsigned grid8(long long n, int bs) {
   long long nb = (n + bs - 1) / bs;
@@ -311,6 +709,26 @@ void launch_scan_compact(const DetectDeviceView& v, hipStream_t st) {
   if (v.n_jobs <= 0) return;
   hipLaunchKernelGGL(scan_jobs_kernel, dim3(1), dim3(1024), 0, st, v.job_valid, v.job_cbase, v.n_jobs);
   hipLaunchKernelGGL(compact_kernel, dim3(v.n_jobs), dim3(256), 0, st, v);
+}
+// copy [src_off, src_off + count) ranges of the compacted columns into packed buffers (fallback boxes)
+__global__ __launch_bounds__(256) void gather_ranges_kernel(DetectDeviceView v, const long long* src_off, const int* count, const long long* dst_off, int n_ranges,
+                                                            double* o_dist, double* o_angle, double* o_skew, int* o_flag, long long* o_slot) {
+  int r = blockIdx.x;
+  if (r >= n_ranges) return;
+  long long s0 = src_off[r], d0 = dst_off[r];
+  for (int i = threadIdx.x; i < count[r]; i += 256) {
+    o_dist[d0 + i] = v.c_dist[s0 + i]; o_angle[d0 + i] = v.c_angle[s0 + i]; o_skew[d0 + i] = v.c_skew[s0 + i];
+    o_flag[d0 + i] = v.c_flag[s0 + i]; o_slot[d0 + i] = v.c_slot[s0 + i];
+  }
+}
+void launch_gather_ranges(const DetectDeviceView& v, const long long* src_off, const int* count, const long long* dst_off, int n_ranges,
+                          double* o_dist, double* o_angle, double* o_skew, int* o_flag, long long* o_slot, hipStream_t st) {
+  if (n_ranges <= 0) return;
+  hipLaunchKernelGGL(gather_ranges_kernel, dim3(n_ranges), dim3(256), 0, st, v, src_off, count, dst_off, n_ranges, o_dist, o_angle, o_skew, o_flag, o_slot);
+}
+void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams& rp, hipStream_t st) {
+  if (rv.n_boxes <= 0) return;
+  hipLaunchKernelGGL(rank_kernel, dim3(rv.n_boxes), dim3(256), 0, st, v, rv, rp);
 }
 void launch_gather_corners(const double* corners, const long long* slots, int n, double* out, hipStream_t st) {
   if (n <= 0) return;

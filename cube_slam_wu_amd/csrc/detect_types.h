@@ -64,4 +64,32 @@ struct DetectDeviceView {
   int* c_flag;
 };
 
+// Ranking stage on the device (fuse_normalize_scores_v2 + the skew-weighted final ranking).
+struct RankParams {
+  double w_angle;        // weight_vp_angle 0.8 (box_proposal_detail.cpp:109)
+  double w_skew;         // weight_skew_error 1.5 (:110)
+  double nominal_skew;   // nominal_skew_ratio
+  double max_cut_skew;   // max_cut_skew
+  int kmax;              // max_cuboid_num (<= RANK_KMAX on the device path)
+};
+enum { RANK_KMAX = 8 };
+
+// One winner of the final ranking of a box.
+struct RankWinner {
+  long long slot;        // global proposal slot, -1 = none
+  double normalized_error, dist_err, angle_err;
+  int flag;              // vp_1_position
+  int pad;
+  double corners[16];
+};
+
+struct RankView {
+  const int* box_job0;   // n_boxes: first job of the box (its height samples are consecutive jobs)
+  const int* box_njobs;  // n_boxes
+  int n_boxes;
+  RankWinner* winners;   // n_boxes * kmax
+  int* win_count;        // n_boxes
+  int* fallback;         // n_boxes: 1 = a tie made the host ordering matter; redo this box on the host
+};
+
 }  // namespace cs

@@ -96,6 +96,11 @@ typedef struct cs_roi {
 /* Host-only helper: ROIs of the 1..3 height samples of one box [x y w h prob]; returns their count. */
 int cs_box_rois(const double box5[5], int img_w, int img_h, int whether_sample_bbox_height, cs_roi out[3]);
 
+/* Host-only helper: the ZYX Euler angles (roll, pitch, yaw) set_cam_pose() stores in cam_pose.euler_angle
+ * (box_proposal_detail.cpp:49-50 via matrix_utils.cpp:38-49); callers read cam_pose_raw.euler_angle back
+ * after detect_cuboid() (object_slam/src/main_obj.cpp:664).                                          */
+int cs_cam_euler_zyx(const double T_wc[16], double euler3[3]);
+
 typedef struct cs_detector cs_detector;
 typedef struct cs_batch cs_batch;
 
@@ -135,11 +140,16 @@ typedef struct cs_detect_timing {
   long long n_jobs, n_slots, n_valid;
   long long cand_kernel_bytes;       /* algorithmic bytes of the candidate kernel     */
   int cand_kernel_launches;
+  int n_fallback_boxes;              /* boxes whose ranking hit a tie and was redone on the host  */
+  double rank_kernel_ms;
+  double line_setup_ms;              /* line_setup_kernel (ROI filter + merge_break_lines on the device)  */
 } cs_detect_timing;
 int cs_batch_last_timing(const cs_batch* b, cs_detect_timing* t);
 
-/* Retain every valid proposal's corners on the host during cs_batch_run() (off by default: it costs
- * one extra device-to-host copy per run).  Needed by cs_batch_debug_candidates(..., corners16).    */
+/* Bit 0: retain every valid proposal (rows, corners, kept ids) on the host during cs_batch_run() for the
+ * cs_batch_debug_* getters (off by default: it costs the device-to-host copy of every proposal).
+ * Bit 1: force the ranking stage onto the host (the exact std::partial_sort path that otherwise only handles
+ * ties and roll/pitch sampling).  Bit 2: force the line setup (ROI filter + merge_break_lines) onto the host. */
 int cs_batch_set_debug(cs_batch* b, int enable);
 
 /* Stage-by-stage inspection after cs_batch_run(), for parity tests.  (frame, box, k) names one

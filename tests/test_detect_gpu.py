@@ -138,3 +138,64 @@ def test_single_frame_entry_point_matches_batch():
     rc = capi.lib().cs_detect_cuboids(det.h, C.byref(d), out, cnt.ctypes.data_as(C.POINTER(C.c_int)))
     assert rc == 0, capi.last_error()
     assert bytes(out) == ref
+
+
+def _check_final(frames, params):
+    """Production path (ranking on the device, nothing but the winners comes back): final records vs the oracle."""
+    det = capi.Detector(params)
+    bat = capi.Batch(det, frames)
+    bat.run()
+    n = 0
+    for f, fr in enumerate(frames):
+        ref, _ = oracle_py.detect_cuboid(fr, _oracle_params(params), atan2_mode=1)
+        got = bat.cuboids(f)
+        for i in range(len(fr["boxes"])):
+            assert len(got[i]) == len(ref[i]), (f, i, len(got[i]), len(ref[i]))
+            for a, b in zip(got[i], ref[i]):
+                for key in CUBOID_KEYS:
+                    assert _same(a[key], b[key]), (f, i, key, a[key], b[key])
+                n += 1
+    tm = bat.timing()
+    bat.close(); det.close()
+    return n, tm
+
+
+def test_device_ranking_matches_oracle_top1():
+    frames = [synth.make_frame(8000 + s) for s in range(6)]
+    n, tm = _check_final(frames, capi.default_params(whether_sample_cam_roll_pitch=0, yaw_step_deg=0.5))
+    assert n >= 40 and tm["rank_kernel_ms"] > 0
+    assert tm["n_fallback_boxes"] <= 4     # ties at a cut are rare on real-valued scores
+
+
+def test_device_ranking_matches_oracle_topk_and_heights():
+    frames = [synth.make_frame(8100 + s, n_boxes=4, n_lines=250, sample_height=True) for s in range(3)]
+    n, tm = _check_final(frames, capi.default_params(whether_sample_cam_roll_pitch=0, whether_sample_bbox_height=1, max_cuboid_num=5, yaw_step_deg=2.0))
+    assert n >= 40
+
+
+def test_device_ranking_falls_back_on_ties():
+    """A constant distance map makes every distance error equal: every cut is a tie, so the kernel must hand the
+    box to the exact host ranking -- and the result must still be the oracle's."""
+    fr = synth.make_frame(8200, n_boxes=3, n_lines=200)
+    fr["maps"] = [[np.zeros_like(m) for m in mm] for mm in fr["maps"]]
+    n, tm = _check_final([fr], capi.default_params(whether_sample_cam_roll_pitch=0))
+    assert tm["n_fallback_boxes"] == 3
+
+
+def test_host_ranking_path_still_exact():
+    frames = [synth.make_frame(8300)]
+    det = capi.Detector(capi.default_params(whether_sample_cam_roll_pitch=0))
+    a = capi.Batch(det, frames); a.run()
+    b = capi.Batch(det, frames, force_host_rank=True); b.run()
+    assert a.raw_out_bytes() == b.raw_out_bytes()
+    assert b.timing()["rank_kernel_ms"] == 0
+
+
+def test_host_and_device_line_setup_agree():
+    """merge_break_lines on the device (line_setup_kernel) against the host implementation: identical records."""
+    frames = [synth.make_frame(8400 + s, n_lines=600) for s in range(3)]
+    det = capi.Detector(capi.default_params(whether_sample_cam_roll_pitch=0, yaw_step_deg=2.0, max_cuboid_num=3))
+    a = capi.Batch(det, frames); a.run()
+    b = capi.Batch(det, frames, force_host_setup=True); b.run()
+    assert a.raw_out_bytes() == b.raw_out_bytes()
+    assert a.timing()["line_setup_ms"] > 0 and b.timing()["line_setup_ms"] < 0.05
