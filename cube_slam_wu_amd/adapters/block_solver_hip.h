@@ -16,6 +16,7 @@
 // Needs g2o + Eigen headers; not compiled in the build container (neither is installed there).
 #pragma once
 
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -117,7 +118,13 @@ class BlockSolverHIP : public g2o::Solver {
   virtual bool saveHessian(const std::string&) const { return false; }
 
  private:
-  void upload_estimates();  // same packing as buildStructure(), estimates only (omitted here for brevity: calls cs_ba_set_vertices)
+  void upload_estimates() {  // estimates may have been changed by g2o's update()/pop() since the last call
+    std::vector<double> cam7, cub10, pt3;
+    for (auto* c : cams_) { g2o::Vector7d e = c->estimate().toVector(); cam7.insert(cam7.end(), e.data(), e.data() + 7); }
+    for (auto* o : cubs_) { Vector10d e = o->estimate().toVector(); cub10.insert(cub10.end(), e.data(), e.data() + 10); }
+    for (auto* p : pts_) pt3.insert(pt3.end(), p->estimate().data(), p->estimate().data() + 3);
+    if (cs_ba_set_estimates(ba_, cam7.data(), cub10.data(), pt3.data()) != CS_OK) throw std::runtime_error(cs_last_error());
+  }
   cs_ba* ba_ = nullptr;
   double lambda_ = 0;
   std::vector<g2o::VertexSE3Expmap*> cams_;

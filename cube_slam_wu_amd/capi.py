@@ -238,7 +238,7 @@ class CsBaTiming(C.Structure):
 
 
 DECLARED_SYMBOLS += [
-    "cs_ba_create", "cs_ba_destroy", "cs_ba_set_vertices", "cs_ba_set_edges_proj", "cs_ba_set_edges_cuboid", "cs_ba_set_edges_odom",
+    "cs_ba_create", "cs_ba_destroy", "cs_ba_set_vertices", "cs_ba_set_estimates", "cs_ba_set_edges_proj", "cs_ba_set_edges_cuboid", "cs_ba_set_edges_odom",
     "cs_ba_compute_errors", "cs_ba_build_system", "cs_ba_solve", "cs_ba_update", "cs_ba_push", "cs_ba_pop", "cs_ba_optimize",
     "cs_ba_get_state", "cs_ba_sizes", "cs_ba_get_system", "cs_ba_last_timing",
 ]

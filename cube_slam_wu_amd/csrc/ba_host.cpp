@@ -394,6 +394,20 @@ int cs_ba_set_vertices(cs_ba* B, const double* cams7, const int* cam_fixed, int 
   return CS_OK;
 }
 
+int cs_ba_set_estimates(cs_ba* B, const double* cams7, const double* cuboids10, const double* points3) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  BA_TRY(hipSetDevice(B->device));
+  if (cams7 && B->nc) {
+    std::vector<double> c(cams7, cams7 + 7 * (size_t)B->nc);
+    for (int i = 0; i < B->nc; i++) { cs::Pose p = cs::pose_load(&c[7 * (size_t)i]); cs::pose_normalize(p); cs::pose_store(p, &c[7 * (size_t)i]); }
+    BA_TRY(hipMemcpy(B->cams.p, c.data(), 56 * (size_t)B->nc, hipMemcpyHostToDevice));
+  }
+  if (cuboids10 && B->no) BA_TRY(hipMemcpy(B->cubes.p, cuboids10, 80 * (size_t)B->no, hipMemcpyHostToDevice));
+  if (points3 && B->np) BA_TRY(hipMemcpy(B->points.p, points3, 24 * (size_t)B->np, hipMemcpyHostToDevice));
+  B->have_system = false;
+  return CS_OK;
+}
+
 int cs_ba_set_edges_proj(cs_ba* B, int n, const int* pt, const int* cam, const double* uv, const double* info4, const double* intr4, const double* huber) {
   if (!B || n < 0 || (n && (!pt || !cam || !uv || !info4 || !intr4))) return CS_ERR_INVALID_ARG;
   B->n_proj = n;

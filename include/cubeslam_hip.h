@@ -186,6 +186,8 @@ void cs_ba_destroy(cs_ba* ba);
 int cs_ba_set_vertices(cs_ba* ba, const double* cams7, const int* cam_fixed, int n_cams,
                        const double* cuboids10, const int* cub_fixed, int n_cuboids,
                        const double* points3, const int* pt_fixed, int n_points, int cuboids_first);
+/* New estimates for the same graph (after g2o-side update()/pop()): no structure rebuild.  NULL = keep. */
+int cs_ba_set_estimates(cs_ba* ba, const double* cams7, const double* cuboids10, const double* points3);
 /* EdgeSE3ProjectXYZ (types/types_six_dof_expmap.h:145-174): vertex 0 = point, vertex 1 = camera;
  * info4 = 2x2 information, intr4 = fx fy cx cy, huber[k] <= 0 means no robust kernel (NULL: none). */
 int cs_ba_set_edges_proj(cs_ba* ba, int n, const int* point, const int* cam, const double* uv2,
