@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -28,6 +29,7 @@ void ba_launch_linearize(const BaView& v, hipStream_t st);
 void ba_launch_reduce(const BaView& v, double lambda, hipStream_t st);
 void ba_launch_backsub(const BaView& v, hipStream_t st);
 void ba_launch_update(const BaView& v, hipStream_t st);
+void ba_launch_band_cholesky(double* Sb, double* Linv, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st);
 }  // namespace cs
 
 extern "C" const char* cs_last_error(void);
@@ -85,6 +87,9 @@ struct cs_ba {
   // host copy of the problem description
   int nc = 0, no = 0, np = 0, cuboids_first = 0;
   std::vector<int> cam_fixed, cub_fixed, pt_fixed, cam_col, cub_col, pt_lm;  // pt_lm: landmark index among free points or -1
+  std::vector<int> cam_col_ref, cub_col_ref;  // columns in g2o's sort-by-id order (inspection only); cam_col / cub_col are in solver (RCM) order
+  int band_ld = 0;                            // 0 = dense reduced system
+  int force_dense = 0;
   int n_pose = 0, n_lm = 0;
   int n_proj = 0, n_cub = 0, n_odom = 0;
   std::vector<int> e_pt, e_cam;      // projection edges, caller order
@@ -99,9 +104,10 @@ struct cs_ba {
   DBuf<int> d_ce_cam, d_ce_cub, d_oe_i, d_oe_j;
   DBuf<double> ce_meas, ce_info, ce_Hcc, ce_Hoo, ce_Hco, ce_bc, ce_bo, oe_meas, oe_info, oe_Hii, oe_Hjj, oe_Hij, oe_bi, oe_bj;
   DBuf<int> cam_ce_ptr, cam_ce_idx, cam_oei_ptr, cam_oei_idx, cam_oej_ptr, cam_oej_idx, cub_ce_ptr, cub_ce_idx;
-  DBuf<double> Hcam, bcam, Hcub, bcub, Hll, bl, W, WD, Dinv, dbl, S, rhs, xl, chi_partial;
+  DBuf<double> Hcam, bcam, Hcub, bcub, Hll, bl, W, WD, Dinv, dbl, S, rhs, xl, chi_partial, band_linv;
   DBuf<int> pair_ptr, pair_i1, pair_i2, ent_a, ent_b;
   DBuf<rocblas_int> d_info;
+  DBuf<int> d_band_info;
   int n_pairs = 0, nb_chi = 1, n_chi_partials = 1;
   long long schur_entries = 0;
   // raw edge payloads kept until finalisation
@@ -121,12 +127,78 @@ int finalize_structure(cs_ba* B) {
   BA_TRY(hipSetDevice(B->device));
   const int nc = B->nc, no = B->no, np = B->np;
   // ---- index mapping (sparse_optimizer.cpp:166-190): non-marginalised vertices by id, then the points
-  B->cam_col.assign(nc, -1); B->cub_col.assign(no, -1); B->pt_lm.assign(np, -1);
-  int col = 0;
-  auto do_cams = [&]() { for (int i = 0; i < nc; i++) if (!B->cam_fixed[i]) { B->cam_col[i] = col; col += 6; } };
-  auto do_cubs = [&]() { for (int i = 0; i < no; i++) if (!B->cub_fixed[i]) { B->cub_col[i] = col; col += 9; } };
-  if (B->cuboids_first) { do_cubs(); do_cams(); } else { do_cams(); do_cubs(); }
-  B->n_pose = col;
+  B->cam_col_ref.assign(nc, -1); B->cub_col_ref.assign(no, -1); B->pt_lm.assign(np, -1);
+  {
+    int col = 0;
+    auto do_cams = [&]() { for (int i = 0; i < nc; i++) if (!B->cam_fixed[i]) { B->cam_col_ref[i] = col; col += 6; } };
+    auto do_cubs = [&]() { for (int i = 0; i < no; i++) if (!B->cub_fixed[i]) { B->cub_col_ref[i] = col; col += 9; } };
+    if (B->cuboids_first) { do_cubs(); do_cams(); } else { do_cams(); do_cubs(); }
+    B->n_pose = col;
+  }
+  // ---- solver ordering of the pose vertices: reverse Cuthill-McKee on the block graph of the reduced system
+  // (camera-camera through shared landmarks and odometry edges, camera-cuboid through cuboid edges), so that S is
+  // banded for trajectory-shaped graphs.  The ordering only permutes the linear system; g2o's order is kept for x/b
+  // inspection (cam_col_ref).
+  B->cam_col.assign(nc, -1); B->cub_col.assign(no, -1);
+  {
+    const int NV = nc + no;
+    std::vector<std::vector<int>> adj(NV);
+    auto is_free = [&](int v) { return v < nc ? !B->cam_fixed[v] : !B->cub_fixed[v - nc]; };
+    auto link = [&](int a, int b) { if (a != b && is_free(a) && is_free(b)) { adj[a].push_back(b); adj[b].push_back(a); } };
+    for (int k = 0; k < B->n_proj; k++)
+      if (B->e_pt[k] < 0 || B->e_pt[k] >= np || B->e_cam[k] < 0 || B->e_cam[k] >= nc) { cs_set_error_ba("projection edge index out of range"); return CS_ERR_INVALID_ARG; }
+    {
+      std::vector<int> cnt(np + 1, 0), cams_of(B->n_proj);
+      for (int k = 0; k < B->n_proj; k++) cnt[B->e_pt[k] + 1]++;
+      for (int i = 0; i < np; i++) cnt[i + 1] += cnt[i];
+      std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+      for (int k = 0; k < B->n_proj; k++) cams_of[fill[B->e_pt[k]]++] = B->e_cam[k];
+      for (int p = 0; p < np; p++) {
+        if (B->pt_fixed[p]) continue;
+        for (int a = cnt[p]; a < cnt[p + 1]; a++) for (int b = a + 1; b < cnt[p + 1]; b++) link(cams_of[a], cams_of[b]);
+      }
+    }
+    for (int k = 0; k < B->n_odom; k++) if (B->oe_i[k] >= 0 && B->oe_i[k] < nc && B->oe_j[k] >= 0 && B->oe_j[k] < nc) link(B->oe_i[k], B->oe_j[k]);
+    for (int k = 0; k < B->n_cub; k++) if (B->ce_cam[k] >= 0 && B->ce_cam[k] < nc && B->ce_cub[k] >= 0 && B->ce_cub[k] < no) link(B->ce_cam[k], nc + B->ce_cub[k]);
+    for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+    std::vector<int> order;  // Cuthill-McKee, component by component, starting from a minimum-degree vertex
+    std::vector<char> seen(NV, 0);
+    std::vector<int> by_deg;
+    for (int v = 0; v < NV; v++) if (is_free(v)) by_deg.push_back(v);
+    std::stable_sort(by_deg.begin(), by_deg.end(), [&](int a, int b) { return adj[a].size() < adj[b].size(); });
+    for (int s0 : by_deg) {
+      if (seen[s0]) continue;
+      // pseudo-peripheral start: two BFS sweeps from the minimum-degree vertex of the component
+      int start = s0;
+      for (int sweep = 0; sweep < 2; sweep++) {
+        std::vector<int> q{start}, dist(NV, -1);
+        dist[start] = 0;
+        for (size_t h = 0; h < q.size(); h++) for (int w : adj[q[h]]) if (dist[w] < 0) { dist[w] = dist[q[h]] + 1; q.push_back(w); }
+        int far = q.back();
+        for (int v : q) if (dist[v] == dist[far] && adj[v].size() < adj[far].size()) far = v;
+        start = far;
+      }
+      size_t head = order.size();
+      order.push_back(start); seen[start] = 1;
+      for (; head < order.size(); head++) {
+        std::vector<int> nb;
+        for (int w : adj[order[head]]) if (!seen[w]) { seen[w] = 1; nb.push_back(w); }
+        std::stable_sort(nb.begin(), nb.end(), [&](int a, int b) { return adj[a].size() < adj[b].size(); });
+        order.insert(order.end(), nb.begin(), nb.end());
+      }
+    }
+    std::reverse(order.begin(), order.end());
+    int col = 0;
+    for (int v : order) { if (v < nc) { B->cam_col[v] = col; col += 6; } else { B->cub_col[v - nc] = col; col += 9; } }
+    auto vcol = [&](int v) { return v < nc ? B->cam_col[v] : B->cub_col[v - nc]; };
+    auto vdim = [&](int v) { return v < nc ? 6 : 9; };
+    int bw = 0;
+    for (int v : order) {
+      bw = std::max(bw, vdim(v) - 1);
+      for (int w : adj[v]) { int lo = std::min(vcol(v), vcol(w)); int hi = (vcol(v) > vcol(w)) ? vcol(v) + vdim(v) - 1 : vcol(w) + vdim(w) - 1; bw = std::max(bw, hi - lo); }
+    }
+    B->band_ld = (!B->force_dense && B->n_pose > 128 && bw + 1 <= B->n_pose / 2) ? bw + 1 : 0;
+  }
   int nl = 0;
   std::vector<int> pt_free(np);
   for (int i = 0; i < np; i++) { pt_free[i] = B->pt_fixed[i] ? 0 : 1; if (pt_free[i]) B->pt_lm[i] = nl++; }
@@ -232,7 +304,9 @@ int finalize_structure(cs_ba* B) {
   // ---- linear system storage
   AL(B->Hcam, 36 * (size_t)nc); AL(B->bcam, 6 * (size_t)nc); AL(B->Hcub, 81 * (size_t)no); AL(B->bcub, 9 * (size_t)no);
   AL(B->Hll, 9 * (size_t)np); AL(B->bl, 3 * (size_t)np); AL(B->W, 18 * (size_t)E); AL(B->WD, 18 * (size_t)E);
-  AL(B->Dinv, 9 * (size_t)np); AL(B->dbl, 3 * (size_t)np); AL(B->S, (size_t)B->n_pose * B->n_pose); AL(B->rhs, B->n_pose); AL(B->xl, 3 * (size_t)np);
+  AL(B->Dinv, 9 * (size_t)np); AL(B->dbl, 3 * (size_t)np); AL(B->S, (size_t)B->n_pose * (B->band_ld ? B->band_ld : B->n_pose)); AL(B->rhs, B->n_pose); AL(B->xl, 3 * (size_t)np);
+  AL(B->d_band_info, 1);
+  AL(B->band_linv, (size_t)((B->n_pose + 31) / 32) * 1024);
   B->nb_chi = cs::ba_chi2_blocks(E);
   B->n_chi_partials = B->nb_chi + (B->n_cub + B->n_odom + 63) / 64;
   AL(B->chi_partial, B->n_chi_partials);
@@ -252,7 +326,7 @@ int finalize_structure(cs_ba* B) {
   v.cam_ce_ptr = B->cam_ce_ptr.p; v.cam_ce_idx = B->cam_ce_idx.p; v.cam_oei_ptr = B->cam_oei_ptr.p; v.cam_oei_idx = B->cam_oei_idx.p;
   v.cam_oej_ptr = B->cam_oej_ptr.p; v.cam_oej_idx = B->cam_oej_idx.p; v.cub_ce_ptr = B->cub_ce_ptr.p; v.cub_ce_idx = B->cub_ce_idx.p;
   v.Hcam = B->Hcam.p; v.bcam = B->bcam.p; v.Hcub = B->Hcub.p; v.bcub = B->bcub.p; v.Hll = B->Hll.p; v.bl = B->bl.p; v.W = B->W.p; v.WD = B->WD.p;
-  v.Dinv = B->Dinv.p; v.dbl = B->dbl.p; v.S = B->S.p; v.rhs = B->rhs.p; v.xl = B->xl.p;
+  v.Dinv = B->Dinv.p; v.dbl = B->dbl.p; v.S = B->S.p; v.band_ld = B->band_ld; v.rhs = B->rhs.p; v.xl = B->xl.p;
   v.n_pairs = B->n_pairs; v.pair_ptr = B->pair_ptr.p; v.pair_i1 = B->pair_i1.p; v.pair_i2 = B->pair_i2.p; v.ent_a = B->ent_a.p; v.ent_b = B->ent_b.p;
   v.chi_partial = B->chi_partial.p;
   B->structure_dirty = false;
@@ -314,19 +388,30 @@ int solve_device(cs_ba* B, double lambda, bool* ok) {
   const int n = B->n_pose;
   *ok = true;
   if (n > 0) {
-    BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (size_t)n * n, B->st));
+    BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (size_t)n * (B->band_ld ? B->band_ld : n), B->st));
     cs::ba_launch_reduce(B->view, lambda, B->st);
     BA_TRY(hipGetLastError());
     BA_TRY(hipStreamSynchronize(B->st));
     double t1 = now_ms();
     B->tm.reduce_ms += t1 - t0;
-    BA_ROC(rocsolver_dpotrf(B->blas, rocblas_fill_lower, n, B->S.p, n, B->d_info.p));
-    rocblas_int info = 0;
-    BA_TRY(hipMemcpyAsync(&info, B->d_info.p, sizeof(info), hipMemcpyDeviceToHost, B->st));
-    BA_TRY(hipStreamSynchronize(B->st));
-    if (info != 0) { *ok = false; }
-    else BA_ROC(rocsolver_dpotrs(B->blas, rocblas_fill_lower, n, 1, B->S.p, n, B->rhs.p, n));
-    BA_TRY(hipStreamSynchronize(B->st));
+    if (B->band_ld) {
+      BA_TRY(hipMemsetAsync(B->d_band_info.p, 0, sizeof(int), B->st));
+      cs::ba_launch_band_cholesky(B->S.p, B->band_linv.p, n, B->band_ld, B->rhs.p, B->d_band_info.p, true, B->st);
+      BA_TRY(hipGetLastError());
+      int info = 0;
+      BA_TRY(hipMemcpyAsync(&info, B->d_band_info.p, sizeof(info), hipMemcpyDeviceToHost, B->st));
+      BA_TRY(hipStreamSynchronize(B->st));
+      if (info != 0) *ok = false;
+    } else {
+      // dense: the lower triangle of the row-major S is the upper triangle of the column-major matrix rocSOLVER sees
+      BA_ROC(rocsolver_dpotrf(B->blas, rocblas_fill_upper, n, B->S.p, n, B->d_info.p));
+      rocblas_int info = 0;
+      BA_TRY(hipMemcpyAsync(&info, B->d_info.p, sizeof(info), hipMemcpyDeviceToHost, B->st));
+      BA_TRY(hipStreamSynchronize(B->st));
+      if (info != 0) { *ok = false; }
+      else BA_ROC(rocsolver_dpotrs(B->blas, rocblas_fill_upper, n, 1, B->S.p, n, B->rhs.p, n));
+      BA_TRY(hipStreamSynchronize(B->st));
+    }
     double t2 = now_ms();
     B->tm.factor_ms += t2 - t1;
     if (*ok) {
@@ -352,6 +437,7 @@ int cs_ba_create(int device, cs_ba** out) {
   if (device < 0 || device >= n) { cs_set_error_ba("device index out of range"); return CS_ERR_INVALID_ARG; }
   cs_ba* B = new cs_ba();
   B->device = device;
+  { const char* e = getenv("CS_BA_FORCE_DENSE"); B->force_dense = (e && atoi(e)) ? 1 : 0; }  // diagnostics: rocSOLVER dense path
   BA_TRY(hipSetDevice(device));
   BA_TRY(hipStreamCreateWithFlags(&B->st, hipStreamNonBlocking));
   BA_ROC(rocblas_create_handle(&B->blas));
@@ -366,7 +452,7 @@ void cs_ba_destroy(cs_ba* B) {
   DBuf<double>* dd[] = {&B->cams, &B->points, &B->cubes, &B->cams_bak, &B->points_bak, &B->cubes_bak, &B->pm_uv, &B->pm_info, &B->pm_intr, &B->pm_huber,
                         &B->cm_uv, &B->cm_info, &B->cm_intr, &B->cm_huber, &B->ce_meas, &B->ce_info, &B->ce_Hcc, &B->ce_Hoo, &B->ce_Hco, &B->ce_bc, &B->ce_bo,
                         &B->oe_meas, &B->oe_info, &B->oe_Hii, &B->oe_Hjj, &B->oe_Hij, &B->oe_bi, &B->oe_bj, &B->Hcam, &B->bcam, &B->Hcub, &B->bcub, &B->Hll, &B->bl,
-                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial};
+                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv};
   for (auto* d : dd) d->release();
   DBuf<int>* di[] = {&B->d_cam_col, &B->d_cub_col, &B->d_pt_free, &B->pm_pt, &B->pm_cam, &B->pt_ptr, &B->cm_pm, &B->cm_pt, &B->cam_ptr, &B->d_ce_cam, &B->d_ce_cub,
                      &B->d_oe_i, &B->d_oe_j, &B->cam_ce_ptr, &B->cam_ce_idx, &B->cam_oei_ptr, &B->cam_oei_idx, &B->cam_oej_ptr, &B->cam_oej_idx, &B->cub_ce_ptr,
@@ -604,15 +690,15 @@ int cs_ba_get_system(cs_ba* B, double* Hpp, double* Hll9, double* Hpl18, double*
     if (B->no) BA_TRY(hipMemcpy(ho.data(), B->Hcub.p, 8 * ho.size(), hipMemcpyDeviceToHost));
     if (B->n_cub) BA_TRY(hipMemcpy(hco.data(), B->ce_Hco.p, 8 * hco.size(), hipMemcpyDeviceToHost));
     if (B->n_odom) BA_TRY(hipMemcpy(hij.data(), B->oe_Hij.p, 8 * hij.size(), hipMemcpyDeviceToHost));
-    for (int i = 0; i < B->nc; i++) { int c = B->cam_col[i]; if (c < 0) continue; for (int r = 0; r < 6; r++) for (int q = 0; q < 6; q++) Hpp[(size_t)(c + r) * n + c + q] = hc[36 * (size_t)i + 6 * r + q]; }
-    for (int i = 0; i < B->no; i++) { int c = B->cub_col[i]; if (c < 0) continue; for (int r = 0; r < 9; r++) for (int q = 0; q < 9; q++) Hpp[(size_t)(c + r) * n + c + q] = ho[81 * (size_t)i + 9 * r + q]; }
+    for (int i = 0; i < B->nc; i++) { int c = B->cam_col_ref[i]; if (c < 0) continue; for (int r = 0; r < 6; r++) for (int q = 0; q < 6; q++) Hpp[(size_t)(c + r) * n + c + q] = hc[36 * (size_t)i + 6 * r + q]; }
+    for (int i = 0; i < B->no; i++) { int c = B->cub_col_ref[i]; if (c < 0) continue; for (int r = 0; r < 9; r++) for (int q = 0; q < 9; q++) Hpp[(size_t)(c + r) * n + c + q] = ho[81 * (size_t)i + 9 * r + q]; }
     for (int k = 0; k < B->n_cub; k++) {
-      int ca = B->cam_col[B->ce_cam[k]], cb = B->cub_col[B->ce_cub[k]];
+      int ca = B->cam_col_ref[B->ce_cam[k]], cb = B->cub_col_ref[B->ce_cub[k]];
       if (ca < 0 || cb < 0) continue;
       for (int r = 0; r < 6; r++) for (int q = 0; q < 9; q++) { double val = hco[54 * (size_t)k + 9 * r + q]; Hpp[(size_t)(ca + r) * n + cb + q] += val; Hpp[(size_t)(cb + q) * n + ca + r] += val; }
     }
     for (int k = 0; k < B->n_odom; k++) {
-      int ca = B->cam_col[B->oe_i[k]], cb = B->cam_col[B->oe_j[k]];
+      int ca = B->cam_col_ref[B->oe_i[k]], cb = B->cam_col_ref[B->oe_j[k]];
       if (ca < 0 || cb < 0) continue;
       for (int r = 0; r < 6; r++) for (int q = 0; q < 6; q++) { double val = hij[36 * (size_t)k + 6 * r + q]; Hpp[(size_t)(ca + r) * n + cb + q] += val; Hpp[(size_t)(cb + q) * n + ca + r] += val; }
     }
@@ -627,8 +713,13 @@ int cs_ba_get_system(cs_ba* B, double* Hpp, double* Hll9, double* Hpl18, double*
     if (B->n_proj) BA_TRY(hipMemcpy(w.data(), B->W.p, 8 * w.size(), hipMemcpyDeviceToHost));
     for (int k = 0; k < B->n_proj; k++) std::memcpy(Hpl18 + 18 * (size_t)k, &w[18 * (size_t)B->pm_of_orig[k]], 144);
   }
-  if (b) std::memcpy(b, B->h_b.data(), 8 * B->h_b.size());
-  if (x && !B->h_x.empty()) std::memcpy(x, B->h_x.data(), 8 * B->h_x.size());
+  auto to_ref = [&](const std::vector<double>& src, double* dst) {  // solver order -> g2o's order
+    for (int i = 0; i < B->nc; i++) if (B->cam_col[i] >= 0) std::memcpy(dst + B->cam_col_ref[i], &src[B->cam_col[i]], 48);
+    for (int i = 0; i < B->no; i++) if (B->cub_col[i] >= 0) std::memcpy(dst + B->cub_col_ref[i], &src[B->cub_col[i]], 72);
+    std::memcpy(dst + B->n_pose, &src[B->n_pose], 8 * (src.size() - B->n_pose));
+  };
+  if (b) to_ref(B->h_b, b);
+  if (x && !B->h_x.empty()) to_ref(B->h_x, x);
   return CS_OK;
 }
 

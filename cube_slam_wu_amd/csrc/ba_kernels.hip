@@ -21,6 +21,8 @@
 // All FP64.  No atomics on the data path except the (unique-pair) off-diagonal pose blocks.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "ba_types.h"
 
 namespace cs {
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(256) void ba_cam_rhs_kernel(BaView v, double lambda
   }
   if (threadIdx.x < 36) {
     int i = threadIdx.x / 6, j = threadIdx.x % 6;
-    v.S[(size_t)(col + i) * v.n_pose + col + j] = v.Hcam[36 * c + threadIdx.x] + ((i == j) ? lambda : 0.0);
+    if (i >= j) *ba_S_at(v, col + i, col + j) = v.Hcam[36 * c + threadIdx.x] + ((i == j) ? lambda : 0.0);
   }
 }
 
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(128) void ba_cub_scatter_kernel(BaView v, double la
   if (col < 0) return;
   if (t < 81) {
     int i = t / 9, j = t % 9;
-    v.S[(size_t)(col + i) * v.n_pose + col + j] = v.Hcub[81 * o + t] + ((i == j) ? lambda : 0.0);
+    if (i >= j) *ba_S_at(v, col + i, col + j) = v.Hcub[81 * o + t] + ((i == j) ? lambda : 0.0);
   } else if (t < 90) {
     v.rhs[col + t - 81] = v.bcub[9 * o + t - 81];
   }
@@ -387,8 +389,8 @@ __global__ __launch_bounds__(64) void ba_offdiag_kernel(BaView v) {
     if (ca < 0 || cb < 0 || t >= 54) return;
     int i = t / 9, j = t % 9;
     double val = v.ce_Hco[54 * (size_t)k + t];
-    atomicAdd(&v.S[(size_t)(ca + i) * v.n_pose + cb + j], val);
-    atomicAdd(&v.S[(size_t)(cb + j) * v.n_pose + ca + i], val);
+    // block (ca+i, cb+j): stored in the lower triangle, whichever vertex comes later in the ordering
+    if (cb > ca) atomicAdd(ba_S_at(v, cb + j, ca + i), val); else atomicAdd(ba_S_at(v, ca + i, cb + j), val);
   } else {
     int q = k - v.n_cub;
     if (q >= v.n_odom) return;
@@ -396,8 +398,7 @@ __global__ __launch_bounds__(64) void ba_offdiag_kernel(BaView v) {
     if (ca < 0 || cb < 0 || t >= 36) return;
     int i = t / 6, j = t % 6;
     double val = v.oe_Hij[36 * (size_t)q + t];
-    atomicAdd(&v.S[(size_t)(ca + i) * v.n_pose + cb + j], val);
-    atomicAdd(&v.S[(size_t)(cb + j) * v.n_pose + ca + i], val);
+    if (cb > ca) atomicAdd(ba_S_at(v, cb + j, ca + i), val); else atomicAdd(ba_S_at(v, ca + i, cb + j), val);
   }
 }
 
@@ -427,8 +428,8 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(BaView v) {
   if (act) {
     double s = acc0 + acc1;
     int i1 = v.pair_i1[pair], i2 = v.pair_i2[pair];
-    v.S[(size_t)(i1 + r) * v.n_pose + i2 + c] -= s;
-    if (i1 != i2) v.S[(size_t)(i2 + c) * v.n_pose + i1 + r] -= s;
+    // element (i1 + r, i2 + c) of the symmetric S, i1 <= i2: its lower-triangle home is (i2 + c, i1 + r)
+    if (i1 != i2 || c >= r) *ba_S_at(v, i2 + c, i1 + r) -= s;
   }
 }
 
@@ -471,6 +472,199 @@ __global__ __launch_bounds__(256) void ba_update_kernel(BaView v) {
     int col = v.cub_col[i];
     if (col >= 0) cube_store(cube_oplus(cube_load(v.cubes + 10 * i), v.rhs + col), v.cubes + 10 * i);
   }
+}
+
+
+// ------------------------------------------------------------------ banded Cholesky of the reduced system --
+// The pose graph of a trajectory is banded once its vertices are ordered by reverse Cuthill-McKee: cameras are
+// coupled to the few neighbours they share landmarks with and to the cuboids they observe.  S is stored as a lower
+// band (LD = bandwidth + 1 doubles per column) and factorised right-looking in column blocks of BS = 32:
+//   band_panel_kernel   POTF2 of the 32 x 32 diagonal block (redundantly per workgroup, in LDS) + TRSM of the panel
+//                       rows below it (one lane per row, the row in registers);
+//   band_syrk_kernel    trailing window (at most bandwidth rows) -= panel * panel^T, one 32 x 32 tile per workgroup;
+//   band_solve_kernel   forward + backward substitution, one workgroup walking the column blocks.
+// n * bw^2 flops instead of n^3 / 3: 0.4 Gflop instead of 385 Gflop at C4 (n = 10494, bw ~ 200).
+enum { BS = 32 };
+
+// POTF2 of the diagonal block in registers (lane r owns row r; columns travel by wave shuffles), result to LDS
+__device__ __attribute__((noinline)) bool band_potf2_to_lds(const double* __restrict__ Sb, int LD, int k0, int nb, double (*D)[BS + 1]) {
+  const int lane = threadIdx.x;
+  double a[BS];
+#pragma unroll
+  for (int c = 0; c < BS; c++) a[c] = (lane < nb && c <= lane && lane - c < LD) ? Sb[(size_t)(k0 + c) * LD + (lane - c)] : ((c == lane) ? 1.0 : 0.0);
+  bool bad = false;
+#pragma unroll
+  for (int c = 0; c < BS; c++) {
+    double dcc = __shfl(a[c], c);
+    if (c < nb && !(dcc > 0.0)) bad = true;
+    double sd = sqrt(dcc);
+    if (lane == c) a[c] = sd; else if (lane > c) a[c] = a[c] / sd;
+#pragma unroll
+    for (int q = c + 1; q < BS; q++) {
+      double lqc = __shfl(a[c], q);
+      if (lane >= q) a[q] -= a[c] * lqc;
+    }
+  }
+  if (lane < BS) {
+#pragma unroll
+    for (int c = 0; c < BS; c++) D[lane][c] = (c <= lane) ? a[c] : 0.0;
+  }
+  return bad;
+}
+
+__global__ __launch_bounds__(64) void band_panel_kernel(double* __restrict__ Sb, double* __restrict__ Linv, int n, int LD, int k0, int* info, int dbg) {
+  __shared__ double D[BS][BS + 1];   // L of the diagonal block
+  __shared__ double X[BS][BS + 1];   // L^-1
+  __shared__ double P[64][BS + 1];   // this workgroup's 64 panel rows
+  const int lane = threadIdx.x;
+  const int nb = min(BS, n - k0);
+  bool bad = false;
+  if (dbg == 1) { for (int e = lane; e < BS * BS; e += 64) D[e / BS][e % BS] = (e / BS == e % BS) ? 1.0 : 0.0; } else bad = band_potf2_to_lds(Sb, LD, k0, nb, D);
+  if (bad && lane == 0 && blockIdx.x == 0) atomicCAS(info, 0, k0 + 1);
+  // this workgroup's panel rows (loaded while the factor settles)
+  const int i = k0 + nb + blockIdx.x * 64 + lane;
+  const int i_end = min(n, k0 + nb - 1 + LD);  // last row inside the band of the block's last column
+  for (int c = 0; c < BS; c++) P[lane][c] = (i < i_end && c < nb && i - (k0 + c) < LD) ? Sb[(size_t)(k0 + c) * LD + (i - k0 - c)] : 0.0;
+  __syncthreads();
+  if (blockIdx.x == 0)
+    for (int e = lane; e < BS * BS; e += 64) {
+      int r = e / BS, c = e % BS;
+      if (r < nb && c <= r && r - c < LD) Sb[(size_t)(k0 + c) * LD + (r - c)] = D[r][c];
+    }
+  // inverse of L: lane c < 32 solves L x = e_c by forward substitution; L(r, q) is a broadcast LDS read
+  if (lane < BS && dbg != 2) {
+    for (int r = 0; r < BS; r++) X[r][lane] = 0.0;
+    for (int r = 0; r < BS; r++) {
+      double sacc = (r == lane) ? 1.0 : 0.0;
+#pragma unroll 8
+      for (int q = 0; q < r; q++) sacc -= D[r][q] * X[q][lane];   // X(q, lane) = 0 for q < lane (rows start zeroed below)
+      X[r][lane] = (r >= lane) ? sacc / D[r][r] : 0.0;
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    double* Li = Linv + (size_t)(k0 / BS) * BS * BS;
+    for (int e = lane; e < BS * BS; e += 64) Li[e] = X[e / BS][e % BS];
+  }
+  // panel rows: P(i, :) <- P(i, :) L^-T, i.e. out[c] = sum_{q <= c} P(i, q) Linv(c, q)
+  if (i < i_end && dbg != 3) {
+    for (int c = 0; c < nb; c++) {
+      double sacc = 0;
+#pragma unroll 8
+      for (int q = 0; q <= c; q++) sacc += P[lane][q] * X[c][q];
+      if (i - (k0 + c) < LD) Sb[(size_t)(k0 + c) * LD + (i - k0 - c)] = sacc;
+    }
+  }
+}
+
+// trailing update: T(i, j) -= sum_c P(i, c) P(j, c) for i >= j in the window below / right of the block
+__global__ __launch_bounds__(256) void band_syrk_kernel(double* __restrict__ Sb, int n, int LD, int k0, int nt) {
+  __shared__ double Pi[BS][BS + 1], Pj[BS][BS + 1];
+  // tile index -> (ti, tj), ti >= tj
+  int t = blockIdx.x, ti = 0;
+  while (t >= ti + 1) { t -= ti + 1; ti++; }
+  const int tj = t;
+  if (ti >= nt) return;
+  const int nb = min(BS, n - k0);
+  const int w0 = k0 + nb;
+  const int i_end = min(n, k0 + nb - 1 + LD);
+  const int ri = w0 + ti * BS, rj = w0 + tj * BS;
+  for (int e = threadIdx.x; e < BS * BS; e += 256) {
+    int r = e / BS, c = e % BS;
+    int gi = ri + r, gj = rj + r;
+    Pi[r][c] = (gi < i_end && c < nb && gi - (k0 + c) < LD) ? Sb[(size_t)(k0 + c) * LD + (gi - k0 - c)] : 0.0;
+    Pj[r][c] = (gj < i_end && c < nb && gj - (k0 + c) < LD) ? Sb[(size_t)(k0 + c) * LD + (gj - k0 - c)] : 0.0;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < BS * BS; e += 256) {
+    int r = e / BS, q = e % BS;
+    int gi = ri + r, gj = rj + q;
+    if (gi < i_end && gj < i_end && gi >= gj && gi - gj < LD) {
+      double acc = 0;
+#pragma unroll
+      for (int c = 0; c < BS; c++) acc += Pi[r][c] * Pj[q][c];
+      Sb[(size_t)gj * LD + (gi - gj)] -= acc;
+    }
+  }
+}
+
+// L y = b, then L^T x = y, in place in rhs; one workgroup walks the column blocks.  The diagonal blocks were inverted
+// by band_panel_kernel, so each block step is two small mat-vecs instead of a 32-step triangular recurrence.
+__global__ __launch_bounds__(256) void band_solve_kernel(const double* __restrict__ Sb, const double* __restrict__ Linv, int n, int LD, double* rhs) {
+  __shared__ double y[BS], z[BS];
+  __shared__ double Li[BS][BS + 1];
+  __shared__ double part[8][BS];
+  const int tid = threadIdx.x;
+  const int bw = LD - 1;
+  const int nblk = (n + BS - 1) / BS;
+  // ---- forward: L y = b
+  for (int kb = 0; kb < nblk; kb++) {
+    const int k0 = kb * BS, nb = min(BS, n - k0);
+    for (int e = tid; e < BS * BS; e += 256) Li[e / BS][e % BS] = Linv[(size_t)kb * BS * BS + e];
+    if (tid < BS) z[tid] = (tid < nb) ? rhs[k0 + tid] : 0.0;
+    __syncthreads();
+    if (tid < BS) {
+      double acc = 0;
+#pragma unroll 8
+      for (int q = 0; q < BS; q++) acc += Li[tid][q] * z[q];   // upper part of Li is zero
+      y[tid] = acc;
+      if (tid < nb) rhs[k0 + tid] = acc;
+    }
+    __syncthreads();
+    const int i_end = min(n, k0 + nb + bw);
+    for (int i = k0 + nb + tid; i < i_end; i += 256) {
+      double acc = 0;
+#pragma unroll 8
+      for (int c = 0; c < nb; c++) if (i - (k0 + c) <= bw) acc += Sb[(size_t)(k0 + c) * LD + (i - k0 - c)] * y[c];
+      rhs[i] -= acc;
+    }
+    __syncthreads();
+  }
+  // ---- backward: L^T x = y
+  for (int kb = nblk - 1; kb >= 0; kb--) {
+    const int k0 = kb * BS, nb = min(BS, n - k0);
+    const int i_end = min(n, k0 + nb + bw);
+    for (int e = tid; e < BS * BS; e += 256) Li[e / BS][e % BS] = Linv[(size_t)kb * BS * BS + e];
+    {
+      int c = tid & 31, g = tid >> 5;  // 8 groups of rows; t[c] = sum_{i below the block} L(i, k0 + c) x[i]
+      double acc = 0;
+      if (c < nb)
+        for (int i = k0 + nb + g; i < i_end; i += 8) if (i - (k0 + c) <= bw) acc += Sb[(size_t)(k0 + c) * LD + (i - k0 - c)] * rhs[i];
+      part[g][c] = acc;
+    }
+    __syncthreads();
+    if (tid < BS) {
+      double tt = 0;
+      for (int g = 0; g < 8; g++) tt += part[g][tid];
+      z[tid] = (tid < nb) ? rhs[k0 + tid] - tt : 0.0;
+    }
+    __syncthreads();
+    if (tid < nb) {
+      double acc = 0;
+#pragma unroll 8
+      for (int r = 0; r < BS; r++) acc += Li[r][tid] * z[r];   // (L^-1)^T z (Li is lower triangular: zeros above)
+      rhs[k0 + tid] = acc;
+    }
+    __syncthreads();
+  }
+}
+
+void ba_launch_band_cholesky(double* Sb, double* Linv, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st) {
+  const int bw = LD - 1;
+  static const int dbg = getenv("CS_BAND_DEBUG") ? atoi(getenv("CS_BAND_DEBUG")) : 0;
+  for (int k0 = 0; k0 < n; k0 += BS) {
+    int nb = n - k0 < BS ? n - k0 : BS;
+    int rows = n - (k0 + nb);
+    if (rows > bw) rows = bw;  // rows below the block inside the band of its last column
+    if (rows < 0) rows = 0;
+    int g = (rows + 63) / 64;
+    hipLaunchKernelGGL(band_panel_kernel, dim3(g < 1 ? 1 : g), dim3(64), 0, st, Sb, Linv, n, LD, k0, info, dbg);
+    if (rows > 0) {
+      int nt = (rows + BS - 1) / BS;
+      hipLaunchKernelGGL(band_syrk_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, Sb, n, LD, k0, nt);
+    }
+  }
+  if (solve) hipLaunchKernelGGL(band_solve_kernel, dim3(1), dim3(256), 0, st, Sb, Linv, n, LD, rhs);
 }
 
 // ---------------------------------------------------------------------------------------- launchers --

@@ -41,7 +41,10 @@ struct BaView {
   double* WD;                   // n_proj x 18  W * Dinv
   double* Dinv;                 // np x 9       (Hll + lambda I)^-1
   double* dbl;                  // np x 3       Dinv * b_l
-  double* S;                    // n_pose x n_pose reduced system (row-major, symmetric, both triangles)
+  double* S;                    // reduced system, LOWER triangle only.  band_ld == 0: dense, element (r, c), r >= c, at
+                                // S[r * n_pose + c]; band_ld > 0: band storage, element (r, c) at S[c * band_ld + (r - c)],
+                                // band_ld = bandwidth + 1 (the pose vertices are ordered by reverse Cuthill-McKee)
+  int band_ld;
   double* rhs;                  // n_pose       b_schur, overwritten by x_p
   double* xl;                   // np x 3       landmark increments
   // Schur structure: one entry per (landmark, ordered camera pair i1 <= i2), grouped by block pair
@@ -50,5 +53,9 @@ struct BaView {
   // chi2 partial sums
   double* chi_partial;
 };
+
+CS_HD double* ba_S_at(const BaView& v, int r, int c) {  // requires r >= c (and r - c < band_ld in band mode)
+  return v.band_ld ? v.S + (size_t)c * v.band_ld + (r - c) : v.S + (size_t)r * v.n_pose + c;
+}
 
 }  // namespace cs
