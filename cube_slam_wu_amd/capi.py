@@ -74,6 +74,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libcubeslam_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        # One HIP runtime per process: the PyTorch wheel ships its own libamdhip64, and whichever copy is loaded
+        # first serves both (same SONAME).  Loading ours first leaves torch unable to see the GPU, so when torch is
+        # installed it goes first.  (A C++ host, e.g. the reference's ROS nodes, has no torch and no such issue.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.cs_last_error.restype = C.c_char_p
         _lib = L
@@ -240,7 +247,8 @@ class CsBaTiming(C.Structure):
 DECLARED_SYMBOLS += [
     "cs_ba_create", "cs_ba_destroy", "cs_ba_set_vertices", "cs_ba_set_estimates", "cs_ba_set_edges_proj", "cs_ba_set_edges_cuboid", "cs_ba_set_edges_odom",
     "cs_ba_compute_errors", "cs_ba_build_system", "cs_ba_solve", "cs_ba_update", "cs_ba_push", "cs_ba_pop", "cs_ba_optimize",
-    "cs_ba_get_state", "cs_ba_sizes", "cs_ba_get_system", "cs_ba_last_timing",
+    "cs_ba_get_state", "cs_ba_sizes", "cs_ba_get_system", "cs_ba_last_timing", "cs_ba_set_shard", "cs_ba_optimize_sharded",
+    "cs_ba_shard_landmark_owners",
 ]
 
 
@@ -326,6 +334,29 @@ class BaProblem:
         n = self._done
         return self._chi[:n], self._lam[:n], self._tr[:n]
 
+    # ---- sharded BA -------------------------------------------------------------------------------
+    def set_shard(self, rank, n_ranks):
+        _chk(lib().cs_ba_set_shard(self.h, int(rank), int(n_ranks)), "cs_ba_set_shard")
+        self.shard = (int(rank), int(n_ranks))
+
+    def optimize_sharded(self, iters, allreduce, cap=64):
+        """allreduce(ptr, n_doubles, on_device, op) -> 0: in-place all-reduce (op 0 = SUM, 1 = MAX) of n doubles."""
+        CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int)
+
+        def _cb(ctx, data, n, on_device, op):
+            try:
+                return int(allreduce(data, int(n), int(on_device), int(op)) or 0)
+            except Exception as e:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = CB(_cb)
+        done = C.c_int()
+        self._chi, self._lam, self._tr = np.zeros(cap), np.zeros(cap), np.zeros(cap, np.int32)
+        _chk(lib().cs_ba_optimize_sharded(self.h, int(iters), cb, None, C.byref(done), _dp(self._chi), _dp(self._lam), _ip(self._tr), cap), "cs_ba_optimize_sharded")
+        self._done = done.value
+        return done.value
+
     def state(self):
         cams, cubs, pts = np.zeros((self.nc, 7)), np.zeros((self.no, 10)), np.zeros((self.np_, 3))
         _chk(lib().cs_ba_get_state(self.h, _dp(cams), _dp(cubs), _dp(pts)), "cs_ba_get_state")
@@ -358,3 +389,56 @@ def ba_from_dict(pr, device=0, cuboids_first=False):
     if len(pr["oe_i"]):
         P.set_edges_odom(pr["oe_i"], pr["oe_j"], pr["oe_meas"], pr["oe_info"])
     return P
+
+
+def landmark_owners(n_ranks, n_cams, n_points, e_pt, e_cam):
+    """Host-only: rank owning each landmark in the sharded BA (cs_ba_shard_landmark_owners)."""
+    e_pt, e_cam = _i32(e_pt), _i32(e_cam)
+    out = np.zeros(int(n_points), np.int32)
+    _chk(lib().cs_ba_shard_landmark_owners(int(n_ranks), int(n_cams), int(n_points), len(e_pt), _ip(e_pt), _ip(e_cam), _ip(out)), "cs_ba_shard_landmark_owners")
+    return out
+
+
+class DeviceDoubles:
+    """__cuda_array_interface__ view of n doubles at a raw device pointer (for torch.as_tensor(..., device='cuda'))."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def torch_allreduce(dist, device):
+    """all-reduce callback for BaProblem.optimize_sharded backed by torch.distributed (NCCL = RCCL on ROCm)."""
+    import torch
+
+    def fn(ptr, n, on_device, op):
+        rop = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX
+        if on_device:
+            t = torch.as_tensor(DeviceDoubles(ptr, n), device=device)
+            if dist.get_backend() == "gloo":      # CPU collective: stage through the host
+                h = t.cpu()
+                dist.all_reduce(h, op=rop)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=rop)
+            torch.cuda.synchronize(device)
+        else:
+            a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(n,))
+            t = torch.from_numpy(a)
+            if dist.get_backend() == "gloo":
+                dist.all_reduce(t, op=rop)
+            else:
+                d = t.to(device)
+                dist.all_reduce(d, op=rop)
+                t.copy_(d.cpu())
+        return 0
+    return fn
+
+
+def cam_rank(cam, n_cams, n_ranks):
+    """Rank owning a camera in the sharded BA: contiguous subsequences [r*Nc/R, (r+1)*Nc/R) (ba_host.cpp cam_rank)."""
+    return (np.asarray(cam, np.int64) * int(n_ranks)) // max(1, int(n_cams))
+
+
+def shard_frames(n_frames, rank, world):
+    """Path A multi-GPU: frames are independent units, dealt round-robin; returns this rank's frame indices."""
+    return list(range(int(rank), int(n_frames), int(world)))

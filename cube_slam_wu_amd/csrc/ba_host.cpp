@@ -90,6 +90,11 @@ struct cs_ba {
   std::vector<int> cam_col_ref, cub_col_ref;  // columns in g2o's sort-by-id order (inspection only); cam_col / cub_col are in solver (RCM) order
   int band_ld = 0;                            // 0 = dense reduced system
   int force_dense = 0;
+  // sharded BA: landmarks (with all their projection edges) are dealt to ranks by the camera subsequence of their
+  // first observation; cuboid / odometry edges follow their camera.  Every rank keeps all vertices.
+  int shard_rank = 0, shard_n = 1;
+  std::vector<int> keep;                      // caller indices of the projection edges this rank owns
+  size_t s_doubles = 0;                       // size of S; rhs follows it in the same allocation (one all-reduce)
   int n_pose = 0, n_lm = 0;
   int n_proj = 0, n_cub = 0, n_odom = 0;
   std::vector<int> e_pt, e_cam;      // projection edges, caller order
@@ -101,7 +106,7 @@ struct cs_ba {
   DBuf<int> d_cam_col, d_cub_col, d_pt_free;
   DBuf<int> pm_pt, pm_cam, pt_ptr, cm_pm, cm_pt, cam_ptr;
   DBuf<double> pm_uv, pm_info, pm_intr, pm_huber, cm_uv, cm_info, cm_intr, cm_huber;
-  DBuf<int> d_ce_cam, d_ce_cub, d_oe_i, d_oe_j;
+  DBuf<int> d_ce_cam, d_ce_cub, d_oe_i, d_oe_j, d_ce_active, d_oe_active;
   DBuf<double> ce_meas, ce_info, ce_Hcc, ce_Hoo, ce_Hco, ce_bc, ce_bo, oe_meas, oe_info, oe_Hii, oe_Hjj, oe_Hij, oe_bi, oe_bj;
   DBuf<int> cam_ce_ptr, cam_ce_idx, cam_oei_ptr, cam_oei_idx, cam_oej_ptr, cam_oej_idx, cub_ce_ptr, cub_ce_idx;
   DBuf<double> Hcam, bcam, Hcub, bcub, Hll, bl, W, WD, Dinv, dbl, S, rhs, xl, chi_partial, band_linv;
@@ -121,6 +126,15 @@ struct cs_ba {
 
 
 namespace {
+
+// camera -> rank (contiguous subsequences), landmark -> rank of the subsequence of its lowest-index observing camera
+inline int cam_rank(int cam, int n_cams, int n_ranks) { return (int)(((long long)cam * n_ranks) / std::max(1, n_cams)); }
+void landmark_owners(int n_ranks, int n_cams, int n_points, int n_proj, const int* e_pt, const int* e_cam, std::vector<int>& owner) {
+  std::vector<int> first(n_points, 0x7fffffff);
+  for (int k = 0; k < n_proj; k++) if (e_pt[k] >= 0 && e_pt[k] < n_points) first[e_pt[k]] = std::min(first[e_pt[k]], e_cam[k]);
+  owner.assign(n_points, 0);
+  for (int p = 0; p < n_points; p++) owner[p] = (first[p] == 0x7fffffff) ? 0 : cam_rank(first[p], n_cams, n_ranks);
+}
 
 int finalize_structure(cs_ba* B) {
   if (!B->structure_dirty) return CS_OK;
@@ -199,6 +213,13 @@ int finalize_structure(cs_ba* B) {
     }
     B->band_ld = (!B->force_dense && B->n_pose > 128 && bw + 1 <= B->n_pose / 2) ? bw + 1 : 0;
   }
+  // ---- this rank's projection edges
+  {
+    std::vector<int> owner;
+    landmark_owners(B->shard_n, nc, np, B->n_proj, B->e_pt.data(), B->e_cam.data(), owner);
+    B->keep.clear();
+    for (int k = 0; k < B->n_proj; k++) if (owner[B->e_pt[k]] == B->shard_rank) B->keep.push_back(k);
+  }
   int nl = 0;
   std::vector<int> pt_free(np);
   for (int i = 0; i < np; i++) { pt_free[i] = B->pt_fixed[i] ? 0 : 1; if (pt_free[i]) B->pt_lm[i] = nl++; }
@@ -208,20 +229,19 @@ int finalize_structure(cs_ba* B) {
 #define AL(buf, n) do { rc = (buf).alloc(n); if (rc) return rc; } while (0)
   UP(B->d_cam_col, B->cam_col); UP(B->d_cub_col, B->cub_col); UP(B->d_pt_free, pt_free);
   // ---- projection edges: point-major order (sorted by pose column inside a point), camera-major copy
-  const int E = B->n_proj;
-  for (int k = 0; k < E; k++)
-    if (B->e_pt[k] < 0 || B->e_pt[k] >= np || B->e_cam[k] < 0 || B->e_cam[k] >= nc) { cs_set_error_ba("projection edge index out of range"); return CS_ERR_INVALID_ARG; }
+  const int E = (int)B->keep.size();   // local edges; slot s of the point-major order holds caller edge keep[order[s]]
   std::vector<int> order(E);
   for (int k = 0; k < E; k++) order[k] = k;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-    if (B->e_pt[a] != B->e_pt[b]) return B->e_pt[a] < B->e_pt[b];
-    return B->cam_col[B->e_cam[a]] < B->cam_col[B->e_cam[b]];
+    int ka = B->keep[a], kb = B->keep[b];
+    if (B->e_pt[ka] != B->e_pt[kb]) return B->e_pt[ka] < B->e_pt[kb];
+    return B->cam_col[B->e_cam[ka]] < B->cam_col[B->e_cam[kb]];
   });
-  B->pm_of_orig.assign(E, 0);
+  B->pm_of_orig.assign(B->n_proj, -1);
   std::vector<int> pm_pt(E), pm_cam(E), pt_ptr(np + 1, 0);
   std::vector<double> pm_uv(2 * (size_t)E), pm_info(4 * (size_t)E), pm_intr(4 * (size_t)E), pm_huber(E);
   for (int s = 0; s < E; s++) {
-    int k = order[s];
+    int k = B->keep[order[s]];
     B->pm_of_orig[k] = s;
     pm_pt[s] = B->e_pt[k]; pm_cam[s] = B->e_cam[k];
     std::memcpy(&pm_uv[2 * (size_t)s], &B->h_uv[2 * (size_t)k], 16);
@@ -298,13 +318,21 @@ int finalize_structure(cs_ba* B) {
   UP(B->cam_ce_ptr, p1); UP(B->cam_ce_idx, i1); UP(B->cam_oei_ptr, p2); UP(B->cam_oei_idx, i2);
   UP(B->cam_oej_ptr, p3); UP(B->cam_oej_idx, i3); UP(B->cub_ce_ptr, p4); UP(B->cub_ce_idx, i4);
   UP(B->d_ce_cam, B->ce_cam); UP(B->d_ce_cub, B->ce_cub); UP(B->d_oe_i, B->oe_i); UP(B->d_oe_j, B->oe_j);
+  {
+    std::vector<int> ca(B->n_cub), oa(B->n_odom);
+    for (int k = 0; k < B->n_cub; k++) ca[k] = cam_rank(B->ce_cam[k], nc, B->shard_n) == B->shard_rank;
+    for (int k = 0; k < B->n_odom; k++) oa[k] = cam_rank(B->oe_j[k], nc, B->shard_n) == B->shard_rank;
+    UP(B->d_ce_active, ca); UP(B->d_oe_active, oa);
+  }
   UP(B->ce_meas, B->h_ce_meas); UP(B->ce_info, B->h_ce_info); UP(B->oe_meas, B->h_oe_meas); UP(B->oe_info, B->h_oe_info);
   AL(B->ce_Hcc, 36 * (size_t)B->n_cub); AL(B->ce_Hoo, 81 * (size_t)B->n_cub); AL(B->ce_Hco, 54 * (size_t)B->n_cub); AL(B->ce_bc, 6 * (size_t)B->n_cub); AL(B->ce_bo, 9 * (size_t)B->n_cub);
   AL(B->oe_Hii, 36 * (size_t)B->n_odom); AL(B->oe_Hjj, 36 * (size_t)B->n_odom); AL(B->oe_Hij, 36 * (size_t)B->n_odom); AL(B->oe_bi, 6 * (size_t)B->n_odom); AL(B->oe_bj, 6 * (size_t)B->n_odom);
   // ---- linear system storage
   AL(B->Hcam, 36 * (size_t)nc); AL(B->bcam, 6 * (size_t)nc); AL(B->Hcub, 81 * (size_t)no); AL(B->bcub, 9 * (size_t)no);
   AL(B->Hll, 9 * (size_t)np); AL(B->bl, 3 * (size_t)np); AL(B->W, 18 * (size_t)E); AL(B->WD, 18 * (size_t)E);
-  AL(B->Dinv, 9 * (size_t)np); AL(B->dbl, 3 * (size_t)np); AL(B->S, (size_t)B->n_pose * (B->band_ld ? B->band_ld : B->n_pose)); AL(B->rhs, B->n_pose); AL(B->xl, 3 * (size_t)np);
+  AL(B->Dinv, 9 * (size_t)np); AL(B->dbl, 3 * (size_t)np); B->s_doubles = (size_t)B->n_pose * (B->band_ld ? B->band_ld : B->n_pose);
+  AL(B->S, B->s_doubles + B->n_pose);   // [S | rhs]: one buffer, one all-reduce in the sharded solve
+  AL(B->xl, 3 * (size_t)np);
   AL(B->d_band_info, 1);
   AL(B->band_linv, (size_t)((B->n_pose + 31) / 32) * 1024);
   B->nb_chi = cs::ba_chi2_blocks(E);
@@ -319,14 +347,14 @@ int finalize_structure(cs_ba* B) {
   v.nc = nc; v.np = np; v.no = no; v.n_pose = B->n_pose;
   v.n_proj = E; v.pm_pt = B->pm_pt.p; v.pm_cam = B->pm_cam.p; v.pm_uv = B->pm_uv.p; v.pm_info = B->pm_info.p; v.pm_intr = B->pm_intr.p; v.pm_huber = B->pm_huber.p;
   v.pt_ptr = B->pt_ptr.p; v.cm_pm = B->cm_pm.p; v.cm_pt = B->cm_pt.p; v.cm_uv = B->cm_uv.p; v.cm_info = B->cm_info.p; v.cm_intr = B->cm_intr.p; v.cm_huber = B->cm_huber.p; v.cam_ptr = B->cam_ptr.p;
-  v.n_cub = B->n_cub; v.ce_cam = B->d_ce_cam.p; v.ce_cub = B->d_ce_cub.p; v.ce_meas = B->ce_meas.p; v.ce_info = B->ce_info.p;
+  v.n_cub = B->n_cub; v.ce_cam = B->d_ce_cam.p; v.ce_cub = B->d_ce_cub.p; v.ce_meas = B->ce_meas.p; v.ce_info = B->ce_info.p; v.ce_active = B->d_ce_active.p;
   v.ce_Hcc = B->ce_Hcc.p; v.ce_Hoo = B->ce_Hoo.p; v.ce_Hco = B->ce_Hco.p; v.ce_bc = B->ce_bc.p; v.ce_bo = B->ce_bo.p;
-  v.n_odom = B->n_odom; v.oe_i = B->d_oe_i.p; v.oe_j = B->d_oe_j.p; v.oe_meas = B->oe_meas.p; v.oe_info = B->oe_info.p;
+  v.n_odom = B->n_odom; v.oe_i = B->d_oe_i.p; v.oe_j = B->d_oe_j.p; v.oe_meas = B->oe_meas.p; v.oe_info = B->oe_info.p; v.oe_active = B->d_oe_active.p;
   v.oe_Hii = B->oe_Hii.p; v.oe_Hjj = B->oe_Hjj.p; v.oe_Hij = B->oe_Hij.p; v.oe_bi = B->oe_bi.p; v.oe_bj = B->oe_bj.p;
   v.cam_ce_ptr = B->cam_ce_ptr.p; v.cam_ce_idx = B->cam_ce_idx.p; v.cam_oei_ptr = B->cam_oei_ptr.p; v.cam_oei_idx = B->cam_oei_idx.p;
   v.cam_oej_ptr = B->cam_oej_ptr.p; v.cam_oej_idx = B->cam_oej_idx.p; v.cub_ce_ptr = B->cub_ce_ptr.p; v.cub_ce_idx = B->cub_ce_idx.p;
   v.Hcam = B->Hcam.p; v.bcam = B->bcam.p; v.Hcub = B->Hcub.p; v.bcub = B->bcub.p; v.Hll = B->Hll.p; v.bl = B->bl.p; v.W = B->W.p; v.WD = B->WD.p;
-  v.Dinv = B->Dinv.p; v.dbl = B->dbl.p; v.S = B->S.p; v.band_ld = B->band_ld; v.rhs = B->rhs.p; v.xl = B->xl.p;
+  v.Dinv = B->Dinv.p; v.dbl = B->dbl.p; v.S = B->S.p; v.band_ld = B->band_ld; v.add_lambda = (B->shard_rank == 0); v.rhs = B->S.p + B->s_doubles; v.xl = B->xl.p;
   v.n_pairs = B->n_pairs; v.pair_ptr = B->pair_ptr.p; v.pair_i1 = B->pair_i1.p; v.pair_i2 = B->pair_i2.p; v.ent_a = B->ent_a.p; v.ent_b = B->ent_b.p;
   v.chi_partial = B->chi_partial.p;
   B->structure_dirty = false;
@@ -363,7 +391,7 @@ int fetch_b(cs_ba* B) {
 int fetch_x(cs_ba* B) {
   B->h_x.assign(B->n_pose + 3 * (size_t)B->n_lm, 0.0);
   std::vector<double> xl(3 * (size_t)B->np);
-  if (B->n_pose) BA_TRY(hipMemcpyAsync(B->h_x.data(), B->rhs.p, 8 * (size_t)B->n_pose, hipMemcpyDeviceToHost, B->st));
+  if (B->n_pose) BA_TRY(hipMemcpyAsync(B->h_x.data(), B->view.rhs, 8 * (size_t)B->n_pose, hipMemcpyDeviceToHost, B->st));
   if (B->np) BA_TRY(hipMemcpyAsync(xl.data(), B->xl.p, 8 * xl.size(), hipMemcpyDeviceToHost, B->st));
   BA_TRY(hipStreamSynchronize(B->st));
   for (int i = 0; i < B->np; i++) if (B->pt_lm[i] >= 0) std::memcpy(&B->h_x[B->n_pose + 3 * (size_t)B->pt_lm[i]], &xl[3 * (size_t)i], 24);
@@ -383,20 +411,23 @@ int build_system_device(cs_ba* B) {
 
 // setLambda + solve + restoreDiagonal (block_solver.hpp:353-486, :563-604): lambda is applied while the
 // reduced system is assembled, so the stored blocks are never modified and nothing needs restoring.
-int solve_device(cs_ba* B, double lambda, bool* ok) {
+int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr, void* ctx = nullptr) {
   double t0 = now_ms();
   const int n = B->n_pose;
   *ok = true;
   if (n > 0) {
-    BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (size_t)n * (B->band_ld ? B->band_ld : n), B->st));
+    BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (B->s_doubles + n), B->st));
     cs::ba_launch_reduce(B->view, lambda, B->st);
     BA_TRY(hipGetLastError());
     BA_TRY(hipStreamSynchronize(B->st));
+    if (fn && B->shard_n > 1) {  // sum the ranks' partial reduced systems: [S | rhs] in one message
+      if (fn(ctx, B->S.p, B->s_doubles + n, 1, 0) != 0) { cs_set_error_ba("all-reduce callback failed"); return CS_ERR_HIP; }
+    }
     double t1 = now_ms();
     B->tm.reduce_ms += t1 - t0;
     if (B->band_ld) {
       BA_TRY(hipMemsetAsync(B->d_band_info.p, 0, sizeof(int), B->st));
-      cs::ba_launch_band_cholesky(B->S.p, B->band_linv.p, n, B->band_ld, B->rhs.p, B->d_band_info.p, true, B->st);
+      cs::ba_launch_band_cholesky(B->S.p, B->band_linv.p, n, B->band_ld, B->view.rhs, B->d_band_info.p, true, B->st);
       BA_TRY(hipGetLastError());
       int info = 0;
       BA_TRY(hipMemcpyAsync(&info, B->d_band_info.p, sizeof(info), hipMemcpyDeviceToHost, B->st));
@@ -409,7 +440,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok) {
       BA_TRY(hipMemcpyAsync(&info, B->d_info.p, sizeof(info), hipMemcpyDeviceToHost, B->st));
       BA_TRY(hipStreamSynchronize(B->st));
       if (info != 0) { *ok = false; }
-      else BA_ROC(rocsolver_dpotrs(B->blas, rocblas_fill_upper, n, 1, B->S.p, n, B->rhs.p, n));
+      else BA_ROC(rocsolver_dpotrs(B->blas, rocblas_fill_upper, n, 1, B->S.p, n, B->view.rhs, n));
       BA_TRY(hipStreamSynchronize(B->st));
     }
     double t2 = now_ms();
@@ -454,7 +485,7 @@ void cs_ba_destroy(cs_ba* B) {
                         &B->oe_meas, &B->oe_info, &B->oe_Hii, &B->oe_Hjj, &B->oe_Hij, &B->oe_bi, &B->oe_bj, &B->Hcam, &B->bcam, &B->Hcub, &B->bcub, &B->Hll, &B->bl,
                         &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv};
   for (auto* d : dd) d->release();
-  DBuf<int>* di[] = {&B->d_cam_col, &B->d_cub_col, &B->d_pt_free, &B->pm_pt, &B->pm_cam, &B->pt_ptr, &B->cm_pm, &B->cm_pt, &B->cam_ptr, &B->d_ce_cam, &B->d_ce_cub,
+  DBuf<int>* di[] = {&B->d_ce_active, &B->d_oe_active, &B->d_cam_col, &B->d_cub_col, &B->d_pt_free, &B->pm_pt, &B->pm_cam, &B->pt_ptr, &B->cm_pm, &B->cm_pt, &B->cam_ptr, &B->d_ce_cam, &B->d_ce_cub,
                      &B->d_oe_i, &B->d_oe_j, &B->cam_ce_ptr, &B->cam_ce_idx, &B->cam_oei_ptr, &B->cam_oei_idx, &B->cam_oej_ptr, &B->cam_oej_idx, &B->cub_ce_ptr,
                      &B->cub_ce_idx, &B->pair_ptr, &B->pair_i1, &B->pair_i2, &B->ent_a, &B->ent_b};
   for (auto* d : di) d->release();
@@ -583,8 +614,30 @@ int cs_ba_pop(cs_ba* B) {
 }
 
 // optimization_algorithm_levenberg.cpp:61-163 + sparse_optimizer.cpp:354-419
+int cs_ba_set_shard(cs_ba* B, int rank, int n_ranks) {
+  if (!B || n_ranks < 1 || rank < 0 || rank >= n_ranks) return CS_ERR_INVALID_ARG;
+  B->shard_rank = rank; B->shard_n = n_ranks;
+  B->structure_dirty = true;
+  return CS_OK;
+}
+
+int cs_ba_shard_landmark_owners(int n_ranks, int n_cams, int n_points, int n_proj, const int* e_pt, const int* e_cam, int* owner_out) {
+  if (n_ranks < 1 || n_cams < 0 || n_points < 0 || n_proj < 0 || (n_proj && (!e_pt || !e_cam)) || (n_points && !owner_out)) return CS_ERR_INVALID_ARG;
+  std::vector<int> owner;
+  landmark_owners(n_ranks, n_cams, n_points, n_proj, e_pt, e_cam, owner);
+  std::copy(owner.begin(), owner.end(), owner_out);
+  return CS_OK;
+}
+
 int cs_ba_optimize(cs_ba* B, int iterations, int* iterations_done, double* chi_hist, double* lambda_hist, int* trials_hist, int cap) {
+  return cs_ba_optimize_sharded(B, iterations, nullptr, nullptr, iterations_done, chi_hist, lambda_hist, trials_hist, cap);
+}
+
+int cs_ba_optimize_sharded(cs_ba* B, int iterations, cs_allreduce_fn fn, void* ctx, int* iterations_done, double* chi_hist, double* lambda_hist, int* trials_hist, int cap) {
   if (!B || iterations < 0) return CS_ERR_INVALID_ARG;
+  if (B->shard_n > 1 && !fn) { cs_set_error_ba("sharded problem needs an all-reduce callback"); return CS_ERR_INVALID_ARG; }
+  const bool sharded = fn && B->shard_n > 1;
+  auto reduce_host = [&](double* v, size_t n, int op) -> int { return sharded ? fn(ctx, v, n, 0, op) : 0; };
   BA_TRY(hipSetDevice(B->device));
   int rc = finalize_structure(B); if (rc) return rc;
   double t_begin = now_ms();
@@ -594,6 +647,7 @@ int cs_ba_optimize(cs_ba* B, int iterations, int* iterations_done, double* chi_h
     double currentChi = 0;
     double t0 = now_ms();
     rc = chi2_device(B, &currentChi); if (rc) return rc;
+    if (reduce_host(&currentChi, 1, 0)) return CS_ERR_HIP;
     B->tm.errors_ms += now_ms() - t0;
     double tempChi = currentChi, iniChi = currentChi;
     rc = build_system_device(B); if (rc) return rc;
@@ -603,10 +657,15 @@ int cs_ba_optimize(cs_ba* B, int iterations, int* iterations_done, double* chi_h
       if (B->nc) BA_TRY(hipMemcpy(hc.data(), B->Hcam.p, 8 * hc.size(), hipMemcpyDeviceToHost));
       if (B->no) BA_TRY(hipMemcpy(ho.data(), B->Hcub.p, 8 * ho.size(), hipMemcpyDeviceToHost));
       if (B->np) BA_TRY(hipMemcpy(hl.data(), B->Hll.p, 8 * hl.size(), hipMemcpyDeviceToHost));
+      // pose diagonals are partial sums on every rank: sum them before taking the maximum
+      std::vector<double> pd(std::max(1, B->n_pose), 0.0);
+      for (int i = 0; i < B->nc; i++) if (B->cam_col[i] >= 0) for (int d = 0; d < 6; d++) pd[B->cam_col[i] + d] = hc[36 * (size_t)i + 7 * d];
+      for (int i = 0; i < B->no; i++) if (B->cub_col[i] >= 0) for (int d = 0; d < 9; d++) pd[B->cub_col[i] + d] = ho[81 * (size_t)i + 10 * d];
+      if (reduce_host(pd.data(), pd.size(), 0)) return CS_ERR_HIP;
       double md = 0;
-      for (int i = 0; i < B->nc; i++) if (B->cam_col[i] >= 0) for (int d = 0; d < 6; d++) md = std::max(std::fabs(hc[36 * (size_t)i + 7 * d]), md);
-      for (int i = 0; i < B->no; i++) if (B->cub_col[i] >= 0) for (int d = 0; d < 9; d++) md = std::max(std::fabs(ho[81 * (size_t)i + 10 * d]), md);
+      for (int i = 0; i < B->n_pose; i++) md = std::max(std::fabs(pd[i]), md);
       for (int i = 0; i < B->np; i++) if (B->pt_lm[i] >= 0) for (int d = 0; d < 3; d++) md = std::max(std::fabs(hl[9 * (size_t)i + 4 * d]), md);
+      if (reduce_host(&md, 1, 1)) return CS_ERR_HIP;
       lambda = 1e-5 * md;
       ni = 2; nBad = 0;
     }
@@ -615,7 +674,7 @@ int cs_ba_optimize(cs_ba* B, int iterations, int* iterations_done, double* chi_h
     do {
       rc = cs_ba_push(B); if (rc) return rc;
       bool ok2 = false;
-      rc = solve_device(B, lambda, &ok2); if (rc) return rc;
+      rc = solve_device(B, lambda, &ok2, fn, ctx); if (rc) return rc;
       if (ok2) {
         rc = fetch_x(B); if (rc) return rc;
         rc = cs_ba_update(B); if (rc) return rc;
@@ -624,11 +683,16 @@ int cs_ba_optimize(cs_ba* B, int iterations, int* iterations_done, double* chi_h
       }
       t0 = now_ms();
       rc = chi2_device(B, &tempChi); if (rc) return rc;
+      if (reduce_host(&tempChi, 1, 0)) return CS_ERR_HIP;
       B->tm.errors_ms += now_ms() - t0;
       if (!ok2) tempChi = std::numeric_limits<double>::max();
       rho = currentChi - tempChi;
+      // x^T (lambda x + b): b is a per-rank partial sum, x is replicated for the poses; the lambda x^2 term of the
+      // poses is counted once (rank 0), landmarks belong to exactly one rank
       double scale = 0;
-      for (size_t j = 0; j < B->h_x.size(); j++) scale += B->h_x[j] * (lambda * B->h_x[j] + B->h_b[j]);
+      for (int j = 0; j < B->n_pose; j++) scale += B->h_x[j] * ((B->shard_rank == 0 ? lambda * B->h_x[j] : 0.0) + B->h_b[j]);
+      for (size_t j = B->n_pose; j < B->h_x.size(); j++) scale += B->h_x[j] * (lambda * B->h_x[j] + B->h_b[j]);
+      if (reduce_host(&scale, 1, 0)) return CS_ERR_HIP;
       scale += 1e-3;
       rho /= scale;
       if (rho > 0 && std::isfinite(tempChi)) {
@@ -709,9 +773,12 @@ int cs_ba_get_system(cs_ba* B, double* Hpp, double* Hll9, double* Hpl18, double*
     for (int i = 0; i < B->np; i++) if (B->pt_lm[i] >= 0) std::memcpy(Hll9 + 9 * (size_t)B->pt_lm[i], &hl[9 * (size_t)i], 72);
   }
   if (Hpl18) {
-    std::vector<double> w(18 * (size_t)B->n_proj);
-    if (B->n_proj) BA_TRY(hipMemcpy(w.data(), B->W.p, 8 * w.size(), hipMemcpyDeviceToHost));
-    for (int k = 0; k < B->n_proj; k++) std::memcpy(Hpl18 + 18 * (size_t)k, &w[18 * (size_t)B->pm_of_orig[k]], 144);
+    std::vector<double> w(18 * B->keep.size());
+    if (!w.empty()) BA_TRY(hipMemcpy(w.data(), B->W.p, 8 * w.size(), hipMemcpyDeviceToHost));
+    for (int k = 0; k < B->n_proj; k++) {
+      if (B->pm_of_orig[k] >= 0) std::memcpy(Hpl18 + 18 * (size_t)k, &w[18 * (size_t)B->pm_of_orig[k]], 144);
+      else std::memset(Hpl18 + 18 * (size_t)k, 0, 144);  // edge owned by another rank
+    }
   }
   auto to_ref = [&](const std::vector<double>& src, double* dst) {  // solver order -> g2o's order
     for (int i = 0; i < B->nc; i++) if (B->cam_col[i] >= 0) std::memcpy(dst + B->cam_col_ref[i], &src[B->cam_col[i]], 48);
@@ -730,7 +797,7 @@ int cs_ba_last_timing(cs_ba* B, cs_ba_timing* t) {
   // algorithmic bytes per linearisation + Schur build: per projection edge 136 B read
   // + 144 B Hpl written, re-read once by the Schur stage; per camera 336 B; per point 96 B written, 96 B read,
   // 72 B Dinv written; per cuboid edge 864 B read + 432 B written.
-  t->linearize_bytes = (long long)B->n_proj * (136 + 144 + 144) + (long long)B->nc * 336 + (long long)B->np * 264 + (long long)B->n_cub * (864 + 432);
+  t->linearize_bytes = (long long)B->keep.size() * (136 + 144 + 144) + (long long)B->nc * 336 + (long long)B->np * 264 + (long long)B->n_cub * (864 + 432);
   return CS_OK;
 }
 

@@ -112,13 +112,15 @@ __global__ __launch_bounds__(64) void ba_chi2_pose_edges_kernel(BaView v, int pa
   double c = 0;
   if (k < v.n_cub) {
     double e[9];
-    cuboid_edge_error(pose_load(v.cams + 7 * v.ce_cam[k]), cube_load(v.cubes + 10 * v.ce_cub[k]), cube_load(v.ce_meas + 10 * k), e);
-    c = quad_form(e, v.ce_info + 81 * k, 9);
+    if (v.ce_active[k]) cuboid_edge_error(pose_load(v.cams + 7 * v.ce_cam[k]), cube_load(v.cubes + 10 * v.ce_cub[k]), cube_load(v.ce_meas + 10 * k), e);
+    if (v.ce_active[k]) c = quad_form(e, v.ce_info + 81 * k, 9);
   } else if (k < v.n_cub + v.n_odom) {
     int q = k - v.n_cub;
     double e[6];
-    odom_edge_error(pose_load(v.cams + 7 * v.oe_i[q]), pose_load(v.cams + 7 * v.oe_j[q]), pose_load(v.oe_meas + 7 * q), e);
-    c = quad_form(e, v.oe_info + 36 * q, 6);
+    if (v.oe_active[q]) {
+      odom_edge_error(pose_load(v.cams + 7 * v.oe_i[q]), pose_load(v.cams + 7 * v.oe_j[q]), pose_load(v.oe_meas + 7 * q), e);
+      c = quad_form(e, v.oe_info + 36 * q, 6);
+    }
   }
   c = wave_sum(c);
   if (threadIdx.x == 0) v.chi_partial[partial_off + blockIdx.x] = c;
@@ -243,9 +245,11 @@ __global__ __launch_bounds__(64) void ba_cub_edge_kernel(BaView v) {
   Pose T = pose_load(v.cams + 7 * v.ce_cam[k]);
   Cube cube = cube_load(v.cubes + 10 * v.ce_cub[k]);
   Cube meas = cube_load(v.ce_meas + 10 * k);
-  bool fa = v.cam_col[v.ce_cam[k]] >= 0, fb = v.cub_col[v.ce_cub[k]] >= 0;
+  const bool act = v.ce_active[k] != 0;  // sharded BA: the edge belongs to another rank -> zero blocks
+  bool fa = act && v.cam_col[v.ce_cam[k]] >= 0, fb = act && v.cub_col[v.ce_cub[k]] >= 0;
   double Ja[54], Jb[81], e0[9];
   cuboid_edge_error(T, cube, meas, e0);
+  if (!act) for (int r = 0; r < 9; r++) e0[r] = 0.0;
   for (int d = 0; d < 6; d++) {
     double e1[9], e2[9], add[6] = {0, 0, 0, 0, 0, 0};
     if (fa) {
@@ -271,9 +275,11 @@ __global__ __launch_bounds__(64) void ba_odom_edge_kernel(BaView v) {
   if (k >= v.n_odom) return;
   const double delta = 1e-9, scalar = 1.0 / (2 * delta);
   Pose T1 = pose_load(v.cams + 7 * v.oe_i[k]), T2 = pose_load(v.cams + 7 * v.oe_j[k]), M = pose_load(v.oe_meas + 7 * k);
-  bool fa = v.cam_col[v.oe_i[k]] >= 0, fb = v.cam_col[v.oe_j[k]] >= 0;
+  const bool act = v.oe_active[k] != 0;
+  bool fa = act && v.cam_col[v.oe_i[k]] >= 0, fb = act && v.cam_col[v.oe_j[k]] >= 0;
   double Ja[36], Jb[36], e0[6];
   odom_edge_error(T1, T2, M, e0);
+  if (!act) for (int r = 0; r < 6; r++) e0[r] = 0.0;
   for (int d = 0; d < 6; d++) {
     double e1[6], e2[6], add[6] = {0, 0, 0, 0, 0, 0};
     if (fa) {
@@ -316,7 +322,8 @@ __global__ __launch_bounds__(256) void ba_prep_kernel(BaView v, double lambda) {
   int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= v.np) return;
   double D[9], Di[9];
-  bool free_pt = v.pt_free[p] != 0;
+  // a landmark without edges on this rank (sharded BA: it lives elsewhere) gets a zero increment
+  bool free_pt = v.pt_free[p] != 0 && v.pt_ptr[p + 1] > v.pt_ptr[p];
   if (free_pt) {
 #pragma unroll
     for (int i = 0; i < 9; i++) D[i] = v.Hll[9 * (size_t)p + i];
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(256) void ba_cam_rhs_kernel(BaView v, double lambda
   }
   if (threadIdx.x < 36) {
     int i = threadIdx.x / 6, j = threadIdx.x % 6;
-    if (i >= j) *ba_S_at(v, col + i, col + j) = v.Hcam[36 * c + threadIdx.x] + ((i == j) ? lambda : 0.0);
+    if (i >= j) *ba_S_at(v, col + i, col + j) = v.Hcam[36 * c + threadIdx.x] + ((i == j && v.add_lambda) ? lambda : 0.0);
   }
 }
 
@@ -375,7 +382,7 @@ __global__ __launch_bounds__(128) void ba_cub_scatter_kernel(BaView v, double la
   if (col < 0) return;
   if (t < 81) {
     int i = t / 9, j = t % 9;
-    if (i >= j) *ba_S_at(v, col + i, col + j) = v.Hcub[81 * o + t] + ((i == j) ? lambda : 0.0);
+    if (i >= j) *ba_S_at(v, col + i, col + j) = v.Hcub[81 * o + t] + ((i == j && v.add_lambda) ? lambda : 0.0);
   } else if (t < 90) {
     v.rhs[col + t - 81] = v.bcub[9 * o + t - 81];
   }

@@ -24,9 +24,9 @@ struct BaView {
   const int* cm_pt; const double* cm_uv; const double* cm_info; const double* cm_intr; const double* cm_huber;
   const int* cam_ptr;  // nc + 1
   // ---- cuboid edges (EdgeSE3Cuboid) and odometry edges (EdgeSE3Expmap): numeric Jacobians ------------
-  int n_cub; const int* ce_cam; const int* ce_cub; const double* ce_meas; const double* ce_info;
+  int n_cub; const int* ce_cam; const int* ce_cub; const double* ce_meas; const double* ce_info; const int* ce_active;
   double* ce_Hcc; double* ce_Hoo; double* ce_Hco; double* ce_bc; double* ce_bo;   // 36, 81, 54, 6, 9 per edge
-  int n_odom; const int* oe_i; const int* oe_j; const double* oe_meas; const double* oe_info;
+  int n_odom; const int* oe_i; const int* oe_j; const double* oe_meas; const double* oe_info; const int* oe_active;
   double* oe_Hii; double* oe_Hjj; double* oe_Hij; double* oe_bi; double* oe_bj;   // 36, 36, 36, 6, 6 per edge
   // pose-vertex adjacency of those edges (CSR), for a deterministic gather-accumulate
   const int* cam_ce_ptr; const int* cam_ce_idx;     // cuboid edges of a camera
@@ -45,6 +45,7 @@ struct BaView {
                                 // S[r * n_pose + c]; band_ld > 0: band storage, element (r, c) at S[c * band_ld + (r - c)],
                                 // band_ld = bandwidth + 1 (the pose vertices are ordered by reverse Cuthill-McKee)
   int band_ld;
+  int add_lambda;               // sharded BA: exactly one rank adds lambda to the pose diagonals (the partial systems are summed)
   double* rhs;                  // n_pose       b_schur, overwritten by x_p
   double* xl;                   // np x 3       landmark increments
   // Schur structure: one entry per (landmark, ordered camera pair i1 <= i2), grouped by block pair

@@ -210,6 +210,22 @@ int cs_ba_pop(cs_ba* ba);
  * what g2o returns.  History arrays (may be NULL) receive chi2 / lambda / LM trials of every iteration. */
 int cs_ba_optimize(cs_ba* ba, int iterations, int* iterations_done, double* chi2_hist, double* lambda_hist, int* trials_hist, int hist_cap);
 
+/* Sharded BA over the GPUs of one node (one process per GPU).  Every rank describes the FULL problem
+ * (cs_ba_set_vertices / set_edges_*) and then calls cs_ba_set_shard(rank, n_ranks): the library keeps the landmarks
+ * whose first observing camera falls into this rank's camera subsequence [rank*Nc/R, (rank+1)*Nc/R) together with
+ * all their projection edges, and the cuboid / odometry edges of its own cameras.  Residuals, Jacobians, landmark
+ * blocks and Schur products are then rank-local; the ranks' partial reduced systems [S | b_schur] are summed with
+ * ONE all-reduce per damped solve (RCCL over xGMI when the caller passes torch.distributed / ncclAllReduce), the
+ * reduced solve is replicated, back-substitution is local.  `fn` performs an in-place all-reduce of n doubles at
+ * `data` (device memory if on_device != 0, else host), op 0 = SUM, 1 = MAX; it must return 0 on success and have
+ * completed when it returns.  With n_ranks == 1 (or fn == NULL) this is cs_ba_optimize.                          */
+typedef int (*cs_allreduce_fn)(void* ctx, void* data, size_t n_doubles, int on_device, int op);
+int cs_ba_set_shard(cs_ba* ba, int rank, int n_ranks);
+int cs_ba_optimize_sharded(cs_ba* ba, int iterations, cs_allreduce_fn fn, void* ctx, int* iterations_done,
+                           double* chi2_hist, double* lambda_hist, int* trials_hist, int hist_cap);
+/* Host-only: the rank that owns each landmark under that rule (no GPU needed; used by the CPU multi-process test). */
+int cs_ba_shard_landmark_owners(int n_ranks, int n_cams, int n_points, int n_proj, const int* e_pt, const int* e_cam, int* owner_out);
+
 int cs_ba_get_state(cs_ba* ba, double* cams7, double* cuboids10, double* points3);
 int cs_ba_sizes(cs_ba* ba, int* size_pose, int* size_landmarks);
 /* Inspection for parity tests (host copies, caller-sized): dense Hpp (size_pose^2, no lambda), Hll (9 per

@@ -111,3 +111,68 @@ def test_reference_offline_sequence_on_gpu():
     assert (it_g == it_r).mean() >= 0.9
     assert np.abs(obj_g - obj_r).max() < 1e-5 * max(1.0, np.abs(obj_r).max())
     assert np.abs(fin_g - fin_r).max() < 1e-5 * max(1.0, np.abs(fin_r).max())
+
+
+def _run_sharded_in_threads(pr, n_ranks, iters):
+    """n_ranks cs_ba instances on one GPU, one thread each, with an in-process all-reduce (sum / max over threads)."""
+    import ctypes as C
+    import threading
+
+    probs = []
+    for r in range(n_ranks):
+        P = capi.ba_from_dict(pr)
+        P.set_shard(r, n_ranks)
+        probs.append(P)
+    barrier = threading.Barrier(n_ranks)
+    slots = [None] * n_ranks
+    import torch
+
+    def make_cb(rank):
+        def cb(ptr, n, on_device, op):
+            if on_device:
+                t = torch.as_tensor(capi.DeviceDoubles(ptr, n), device="cuda")
+                slots[rank] = t.clone()
+            else:
+                a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(n,))
+                slots[rank] = torch.from_numpy(a.copy())
+            barrier.wait()
+            tot = slots[0].clone()
+            for s in slots[1:]:
+                tot = tot + s if op == 0 else torch.maximum(tot, s)
+            barrier.wait()
+            if on_device:
+                t.copy_(tot); torch.cuda.synchronize()
+            else:
+                a[:] = tot.cpu().numpy()
+            return 0
+        return cb
+
+    done = [0] * n_ranks
+    def work(r):
+        done[r] = probs[r].optimize_sharded(iters, make_cb(r))
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n_ranks)]
+    [t.start() for t in th]; [t.join() for t in th]
+    owners = capi.landmark_owners(n_ranks, len(pr["cams"]), len(pr["points"]), pr["e_pt"], pr["e_cam"])
+    cams, cubs, _ = probs[0].state()
+    pts = np.zeros_like(pr["points"])
+    for r in range(n_ranks):
+        pts[owners == r] = probs[r].state()[2][owners == r]
+    hist = probs[0].history()
+    for P in probs:
+        P.close()
+    return done, hist, cams, cubs, pts
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3])
+def test_sharded_ba_equals_single_rank(n_ranks):
+    """Landmark-sharded BA with summed partial reduced systems == the unsharded optimisation (same LM trajectory)."""
+    pr = synth_ba.make_problem(n_cams=60, n_points=4000, n_cuboids=8, seed=21)
+    G = capi.ba_from_dict(pr)
+    n1 = G.optimize(6)
+    chi1, lam1, tr1 = G.history()
+    c1, o1, p1 = G.state()
+    done, (chiS, lamS, trS), cS, oS, pS = _run_sharded_in_threads(pr, n_ranks, 6)
+    assert done == [n1] * n_ranks
+    assert np.array_equal(tr1, trS) and np.allclose(chi1, chiS, rtol=1e-9) and np.allclose(lam1, lamS, rtol=1e-9)
+    scale = np.abs(p1).max()
+    assert np.abs(pS - p1).max() < 1e-7 * scale and np.abs(cS - c1).max() < 1e-7 * scale and np.abs(oS - o1).max() < 1e-7 * scale
