@@ -55,14 +55,14 @@ class CsDetectTiming(C.Structure):
                                           "rank_host_ms", "finalize_ms", "total_ms")] + \
                [("n_jobs", C.c_longlong), ("n_slots", C.c_longlong), ("n_valid", C.c_longlong),
                 ("cand_kernel_bytes", C.c_longlong), ("cand_kernel_launches", C.c_int), ("n_fallback_boxes", C.c_int),
-                ("rank_kernel_ms", C.c_double), ("line_setup_ms", C.c_double)]
+                ("rank_kernel_ms", C.c_double), ("line_setup_ms", C.c_double), ("score_kernel_ms", C.c_double), ("score_kernel_bytes", C.c_longlong)]
 
 
 # every symbol include/cubeslam_hip.h declares (tests/test_capi_symbols.py checks the export table)
 DECLARED_SYMBOLS = [
     "cs_last_error", "cs_device_count", "cs_detect_default_params", "cs_box_rois", "cs_cam_euler_zyx", "cs_detector_create",
     "cs_detector_destroy", "cs_detect_cuboids", "cs_batch_create", "cs_batch_max_boxes", "cs_batch_run",
-    "cs_batch_destroy", "cs_batch_last_timing", "cs_batch_debug_candidates", "cs_batch_debug_kept", "cs_batch_set_debug",
+    "cs_batch_destroy", "cs_batch_last_timing", "cs_batch_debug_candidates", "cs_batch_debug_kept", "cs_batch_set_debug", "cs_batch_set_pipeline_chunks",
 ]
 
 _lib = None
@@ -147,7 +147,7 @@ class Detector:
 class Batch:
     """cs_batch handle over a list of frame dicts (cube_slam_wu_amd.synth.make_frame layout)."""
 
-    def __init__(self, det: Detector, frames, debug=False, force_host_rank=False, force_host_setup=False):
+    def __init__(self, det: Detector, frames, debug=False, force_host_rank=False, force_host_setup=False, force_no_pipeline=False, pipeline_chunks=1):
         self.det = det
         self.n_frames = len(frames)
         self._keep = []
@@ -177,8 +177,12 @@ class Batch:
         self.kmax = det.params.max_cuboid_num
         self._out = (CsCuboid * max(1, self.n_frames * max(1, self.max_boxes) * self.kmax))()
         self._counts = np.zeros(max(1, self.n_frames * max(1, self.max_boxes)), np.int32)
-        if debug or force_host_rank or force_host_setup:
-            lib().cs_batch_set_debug(self.h, (1 if debug else 0) | (2 if force_host_rank else 0) | (4 if force_host_setup else 0))
+        if debug or force_host_rank or force_host_setup or force_no_pipeline:
+            lib().cs_batch_set_debug(self.h, (1 if debug else 0) | (2 if force_host_rank else 0) | (4 if force_host_setup else 0) | (8 if force_no_pipeline else 0))
+
+        if pipeline_chunks != 1:
+            if lib().cs_batch_set_pipeline_chunks(self.h, int(pipeline_chunks)) != 0:
+                raise RuntimeError("cs_batch_set_pipeline_chunks failed")
 
     def run(self):
         rc = lib().cs_batch_run(self.det.h, self.h, self._out, self._counts.ctypes.data_as(C.POINTER(C.c_int)))
@@ -194,6 +198,9 @@ class Batch:
 
     def raw_out_bytes(self):
         return bytes(self._out)
+
+    def counts_bytes(self):
+        return self._counts.tobytes()
 
     def timing(self):
         t = CsDetectTiming()

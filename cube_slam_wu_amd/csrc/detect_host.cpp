@@ -41,6 +41,7 @@ namespace cs {
 void launch_vp_support(const DetectDeviceView& v, const SweepParams& sp, int vp_total, hipStream_t st);
 void launch_candidates(const DetectDeviceView& v, const SweepParams& sp, long long slot_total, hipStream_t st);
 void launch_scan_compact(const DetectDeviceView& v, hipStream_t st);
+void launch_score(const DetectDeviceView& v, long long n_valid_bound, long long slot_total, hipStream_t st);
 void launch_gather_corners(const double* corners, const long long* slots, int n, double* out, hipStream_t st);
 void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams& rp, hipStream_t st);
 void launch_line_setup(JobDesc* jobs, int n_jobs, const double* frame_lines, const int* frame_line_ptr, double* mid_x, double* mid_y, double* line_angle,
@@ -352,7 +353,8 @@ struct cs_detector {
   cs_detect_params prm;
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[8] = {};
+  hipStream_t stream2 = nullptr;   // tie-break re-ranking fetches of the previous chunk, concurrent with the next chunk's sweep
+  hipEvent_t ev[12] = {};
   int n_threads = 1;
   std::unique_ptr<WorkerPool> pool;
 };
@@ -391,8 +393,48 @@ struct JobResult {        // rank-stage products retained for cs_batch_debug_*
   std::vector<double> corners;   // V x 16 when debug is on
 };
 
+// One of the two in-flight chunks of the pipelined production path (run_pipelined).
+struct PipeSlot {
+  DevBuf<cs::JobDesc> jobs;
+  DevBuf<long long> slot_prefix, job_cbase, c_slot, fb_src, fb_dst, fb_slot, win_slots;
+  DevBuf<int> vp_prefix, top_x, flag, job_valid, c_flag, box_job0, box_njobs, win_count, fallback, fb_cnt, fb_flag;
+  DevBuf<double> mid_x, mid_y, ang, yaw, yaw_c, yaw_s, vp, bound, corners, c_dist, c_angle, c_skew, fb_dist, fb_angle, fb_skew, win_corners;
+  DevBuf<cs::RankWinner> winners;
+  PinBuf<cs::JobDesc> h_jobs_in, h_jobs_out;
+  PinBuf<long long> h_slot_prefix, h_job_cbase;
+  PinBuf<int> h_vp_prefix, h_top_x, h_box_job0, h_box_njobs, h_win_count, h_fallback, h_job_valid;
+  PinBuf<double> h_yaw, h_yaw_c, h_yaw_s;
+  PinBuf<cs::RankWinner> h_winners;
+  PinBuf<long long> h_fb_src, h_fb_dst, h_fb_slot, h_win_slots;
+  PinBuf<int> h_fb_cnt, h_fb_flag;
+  PinBuf<double> h_fb_dist, h_fb_angle, h_fb_skew, h_win_corners;
+  hipEvent_t done = nullptr, ev[9] = {};
+  cs::DetectDeviceView view{};
+  int f0 = 0, f1 = 0, vp_total = 0;
+  size_t nj = 0, nb = 0;
+  long long slot_total = 0;
+  bool in_flight = false;
+  void release() {
+    jobs.release(); slot_prefix.release(); job_cbase.release(); c_slot.release(); fb_src.release(); fb_dst.release(); fb_slot.release(); win_slots.release();
+    vp_prefix.release(); top_x.release(); flag.release(); job_valid.release(); c_flag.release(); box_job0.release(); box_njobs.release(); win_count.release();
+    fallback.release(); fb_cnt.release(); fb_flag.release(); mid_x.release(); mid_y.release(); ang.release(); yaw.release(); yaw_c.release(); yaw_s.release();
+    vp.release(); bound.release(); corners.release(); c_dist.release(); c_angle.release(); c_skew.release(); fb_dist.release(); fb_angle.release(); fb_skew.release();
+    win_corners.release(); winners.release(); h_jobs_in.release(); h_jobs_out.release(); h_slot_prefix.release(); h_job_cbase.release(); h_vp_prefix.release();
+    h_top_x.release(); h_box_job0.release(); h_box_njobs.release(); h_win_count.release(); h_fallback.release(); h_job_valid.release(); h_yaw.release();
+    h_yaw_c.release(); h_yaw_s.release(); h_winners.release();
+    h_fb_src.release(); h_fb_dst.release(); h_fb_slot.release(); h_win_slots.release(); h_fb_cnt.release(); h_fb_flag.release(); h_fb_dist.release(); h_fb_angle.release();
+    h_fb_skew.release(); h_win_corners.release();
+    if (done) (void)hipEventDestroy(done);
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    done = nullptr; for (auto& e : ev) e = nullptr;
+  }
+};
+
 struct cs_batch {
   cs_detector* det = nullptr;
+  PipeSlot pipe[2];
+  bool force_no_pipeline = false;
+  int pipe_chunks = 1;   // chunks of the two-slot pipeline (cs_batch_set_pipeline_chunks)
   int n_frames = 0, max_boxes = 0;
   std::vector<FrameIn> frames;
   DevBuf<float> d_maps;
@@ -494,6 +536,7 @@ int cs_detector_create(const cs_detect_params* params, int device, cs_detector**
   d->device = device;
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking));
   for (auto& e : d->ev) HIP_TRY(hipEventCreate(&e));
   int hc = (int)std::thread::hardware_concurrency();
   d->n_threads = d->prm.host_threads > 0 ? d->prm.host_threads : std::max(1, std::min(hc, 64));
@@ -507,6 +550,7 @@ void cs_detector_destroy(cs_detector* d) {
   (void)hipSetDevice(d->device);
   for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
   if (d->stream) (void)hipStreamDestroy(d->stream);
+  if (d->stream2) (void)hipStreamDestroy(d->stream2);
   delete d;
 }
 
@@ -596,6 +640,7 @@ int cs_batch_max_boxes(const cs_batch* b) { return b ? b->max_boxes : CS_ERR_INV
 void cs_batch_destroy(cs_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->det->device);
+  b->pipe[0].release(); b->pipe[1].release();
   b->d_maps.release(); b->d_invK.release(); b->d_frame_lines.release(); b->d_frame_line_ptr.release(); b->d_jobs.release(); b->d_slot_prefix.release(); b->d_job_cbase.release();
   b->d_c_slot.release(); b->d_win_slots.release(); b->d_vp_prefix.release(); b->d_top_x.release(); b->d_flag.release();
   b->d_job_valid.release(); b->d_c_flag.release(); b->d_mid_x.release(); b->d_mid_y.release(); b->d_ang.release();
@@ -616,6 +661,7 @@ int cs_batch_set_debug(cs_batch* b, int enable) {
   b->debug = (enable & 1) != 0;
   b->force_host_rank = (enable & 2) != 0;
   b->force_host_setup = (enable & 4) != 0;
+  b->force_no_pipeline = (enable & 8) != 0;
   return CS_OK;
 }
 
@@ -678,6 +724,319 @@ void finish_cuboid(const FrameIn& F, const cs::RpPose& pose, const double* rows9
 
 }  // namespace
 
+
+// ================================================================== pipelined production path =====
+// No roll/pitch sampling, no debug retention: boxes are independent, line setup and ranking run on the device, and
+// nothing but the winners comes back.  The batch is cut into chunks that flow through a two-slot software pipeline:
+// while the GPU sweeps chunk k, the host packs chunk k+1 and writes the records of chunk k-1.
+namespace {
+
+struct PipeCtx {
+  cs_detector* d; cs_batch* b; cs_cuboid* out; int* out_counts;
+  const std::vector<CamCache>* cam_raw; const std::vector<int>* rp_off;
+  cs::SweepParams sp; cs_detect_timing* tm;
+};
+
+int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
+  cs_detector* d = C.d; cs_batch* b = C.b;
+  const cs_detect_params& P = d->prm;
+  hipStream_t st = d->stream;
+  const int KMAX = P.max_cuboid_num;
+  double t0 = now_ms();
+  if (!S.done) { HIP_TRY(hipEventCreate(&S.done)); for (auto& e : S.ev) HIP_TRY(hipEventCreate(&e)); }
+  S.f0 = f0; S.f1 = f1;
+  const int nf = f1 - f0;
+  // ---- per frame: job descriptors + sample lists (everything else of the setup happens in line_setup_kernel)
+  struct FrameJobs { std::vector<cs::JobDesc> jobs; std::vector<double> yaw, yc, ys; std::vector<int> tops; };
+  std::vector<FrameJobs> fj(nf);
+  d->pool->run(nf, [&](int q) {
+    const int f = f0 + q;
+    const FrameIn& F = b->frames[f];
+    FrameJobs& R = fj[q];
+    int yoff = -1, nY = 0;
+    for (int bi = 0; bi < F.n_boxes; bi++) {
+      const double* bb = &F.boxes[5 * bi];
+      int left = bb[0], top = bb[1], w = bb[2], h = bb[3];
+      int right = left + bb[2];
+      int res = (int)std::round(std::min(20, w / 10));
+      if (res < 1) continue;  // :215
+      if (yoff < 0) {  // cam_pose never changes without roll/pitch sampling: one yaw list per frame (:180-184)
+        double yaw_init = (*C.cam_raw)[f].cam_yaw - 90.0 / 180.0 * CS_PI;
+        linespace<double>(yaw_init - P.yaw_range_deg / 180.0 * CS_PI, yaw_init + P.yaw_range_deg / 180.0 * CS_PI, P.yaw_step_deg / 180.0 * CS_PI, R.yaw);
+        for (double y : R.yaw) { R.yc.push_back(h_cos(y)); R.ys.push_back(h_sin(y)); }
+        yoff = 0; nY = (int)R.yaw.size();
+      }
+      std::vector<int> tops;
+      linespace<int>(left + 5, right - 5, res, tops);
+      int toff = (int)R.tops.size();
+      R.tops.insert(R.tops.end(), tops.begin(), tops.end());
+      for (int k = 0; k < F.n_heights[bi]; k++) {
+        const cs_roi& roi = F.rois[3 * bi + k];
+        cs::JobDesc jd;
+        std::memset(&jd, 0, sizeof(jd));
+        int he = h + roi.down_expand;
+        jd.g.left = left; jd.g.top = top; jd.g.right = right; jd.g.down = top + he;
+        jd.g.el = roi.left; jd.g.et = roi.top; jd.g.er = roi.left + roi.width; jd.g.eb = roi.top + roi.height;
+        jd.map_w = roi.width; jd.Y = nY; jd.T = (int)tops.size(); jd.RP = 1; jd.down_expand = roi.down_expand;
+        jd.frame = f; jd.box = bi; jd.hid = k; jd.map_off = F.map_offs[3 * bi + k]; jd.rp_off = (*C.rp_off)[f];
+        jd.diag = std::sqrt(double(w * w + he * he));
+        jd.yaw_off = 0; jd.top_off = toff;  // frame-local for now
+        R.jobs.push_back(jd);
+      }
+    }
+  });
+  // ---- offsets (serial prefix over frames), then parallel packing straight into pinned staging buffers
+  std::vector<size_t> o_job(nf + 1, 0), o_line(nf + 1, 0), o_yaw(nf + 1, 0), o_top(nf + 1, 0);
+  std::vector<long long> o_slot(nf + 1, 0), o_vp(nf + 1, 0);
+  for (int q = 0; q < nf; q++) {
+    long long ns = 0, nv = 0;
+    for (auto& jd : fj[q].jobs) { nv += (long long)jd.Y; ns += (long long)jd.Y * jd.T * 2; }
+    o_job[q + 1] = o_job[q] + fj[q].jobs.size();
+    o_line[q + 1] = o_line[q] + fj[q].jobs.size() * (size_t)b->frames[f0 + q].n_lines;
+    o_yaw[q + 1] = o_yaw[q] + fj[q].yaw.size(); o_top[q + 1] = o_top[q] + fj[q].tops.size();
+    o_slot[q + 1] = o_slot[q] + ns; o_vp[q + 1] = o_vp[q] + nv;
+  }
+  const size_t nj = o_job[nf], n_lines = o_line[nf], n_yaw = o_yaw[nf], n_top = o_top[nf];
+  S.nj = nj; S.slot_total = o_slot[nf]; S.vp_total = (int)o_vp[nf];
+  if (o_vp[nf] > 0x7fffffffLL) { set_err("too many yaw samples in one chunk"); return CS_ERR_CAPACITY; }
+  if (nj == 0) { S.nb = 0; S.in_flight = true; C.tm->setup_host_ms += now_ms() - t0; HIP_TRY(hipEventRecord(S.done, st)); return CS_OK; }
+  int rc;
+#define PENS(buf, n) do { rc = (buf).ensure(n); if (rc) return rc; } while (0)
+  PENS(S.h_jobs_in, nj); PENS(S.h_slot_prefix, nj + 1); PENS(S.h_vp_prefix, nj + 1); PENS(S.h_yaw, n_yaw + 1); PENS(S.h_yaw_c, n_yaw + 1); PENS(S.h_yaw_s, n_yaw + 1);
+  PENS(S.h_top_x, n_top + 1); PENS(S.h_box_job0, nj); PENS(S.h_box_njobs, nj);
+  d->pool->run(nf, [&](int q) {
+    FrameJobs& R = fj[q];
+    size_t ji = o_job[q], lo = o_line[q];
+    long long so = o_slot[q], vo = o_vp[q];
+    std::copy(R.yaw.begin(), R.yaw.end(), S.h_yaw.p + o_yaw[q]);
+    std::copy(R.yc.begin(), R.yc.end(), S.h_yaw_c.p + o_yaw[q]);
+    std::copy(R.ys.begin(), R.ys.end(), S.h_yaw_s.p + o_yaw[q]);
+    std::copy(R.tops.begin(), R.tops.end(), S.h_top_x.p + o_top[q]);
+    const int M = b->frames[f0 + q].n_lines;
+    for (auto& jd : R.jobs) {
+      jd.line_off = (int)lo; jd.yaw_off = (int)o_yaw[q]; jd.top_off += (int)o_top[q]; jd.vp_off = (int)vo; jd.slot_off = so;
+      S.h_slot_prefix.p[ji] = so; S.h_vp_prefix.p[ji] = (int)vo;
+      vo += jd.Y; so += (long long)jd.Y * jd.T * 2; lo += M;
+      S.h_jobs_in.p[ji++] = jd;
+    }
+  });
+  S.h_slot_prefix.p[nj] = o_slot[nf]; S.h_vp_prefix.p[nj] = (int)o_vp[nf];
+  size_t nb = 0;
+  for (size_t j = 0; j < nj; j++)
+    if (S.h_jobs_in.p[j].hid == 0) { S.h_box_job0.p[nb] = (int)j; S.h_box_njobs.p[nb] = b->frames[S.h_jobs_in.p[j].frame].n_heights[S.h_jobs_in.p[j].box]; nb++; }
+  S.nb = nb;
+  C.tm->setup_host_ms += now_ms() - t0;
+  C.tm->n_jobs += (long long)nj; C.tm->n_slots += S.slot_total;
+  // ---- device buffers, H2D, kernels, D2H: all asynchronous on the detector's stream
+  const long long slot_total = S.slot_total;
+  PENS(S.jobs, nj); PENS(S.slot_prefix, nj + 1); PENS(S.vp_prefix, nj + 1); PENS(S.job_valid, nj); PENS(S.job_cbase, nj + 1);
+  PENS(S.mid_x, n_lines + 1); PENS(S.mid_y, n_lines + 1); PENS(S.ang, n_lines + 1); PENS(S.yaw, n_yaw + 1); PENS(S.yaw_c, n_yaw + 1); PENS(S.yaw_s, n_yaw + 1);
+  PENS(S.top_x, n_top + 1); PENS(S.vp, 6 * (size_t)S.vp_total + 6); PENS(S.bound, 6 * (size_t)S.vp_total + 6); PENS(S.flag, slot_total + 1);
+  PENS(S.corners, 16 * (size_t)slot_total + 16); PENS(S.c_slot, slot_total + 1); PENS(S.c_flag, slot_total + 1); PENS(S.c_dist, slot_total + 1);
+  PENS(S.c_angle, slot_total + 1); PENS(S.c_skew, slot_total + 1); PENS(S.box_job0, nb + 1); PENS(S.box_njobs, nb + 1); PENS(S.win_count, nb + 1);
+  PENS(S.fallback, nb + 1); PENS(S.winners, nb * KMAX + 1);
+  PENS(S.h_winners, nb * KMAX + 1); PENS(S.h_win_count, nb + 1); PENS(S.h_fallback, nb + 1); PENS(S.h_job_valid, nj); PENS(S.h_job_cbase, nj + 1); PENS(S.h_jobs_out, nj);
+#define PH2D(dst, src, n) HIP_TRY(hipMemcpyAsync((dst).p, (src).p, sizeof(*(src).p) * (n), hipMemcpyHostToDevice, st))
+  PH2D(S.jobs, S.h_jobs_in, nj); PH2D(S.slot_prefix, S.h_slot_prefix, nj + 1); PH2D(S.vp_prefix, S.h_vp_prefix, nj + 1);
+  if (n_yaw) { PH2D(S.yaw, S.h_yaw, n_yaw); PH2D(S.yaw_c, S.h_yaw_c, n_yaw); PH2D(S.yaw_s, S.h_yaw_s, n_yaw); }
+  if (n_top) PH2D(S.top_x, S.h_top_x, n_top);
+  if (nb) { PH2D(S.box_job0, S.h_box_job0, nb); PH2D(S.box_njobs, S.h_box_njobs, nb); }
+  HIP_TRY(hipMemsetAsync(S.job_valid.p, 0, sizeof(int) * nj, st));
+  cs::DetectDeviceView& v = S.view;
+  v = cs::DetectDeviceView{};
+  v.jobs = S.jobs.p; v.n_jobs = (int)nj; v.slot_prefix = S.slot_prefix.p; v.vp_prefix = S.vp_prefix.p; v.maps = b->d_maps.p;
+  v.mid_x = S.mid_x.p; v.mid_y = S.mid_y.p; v.line_angle = S.ang.p; v.yaw = S.yaw.p; v.yaw_cos = S.yaw_c.p; v.yaw_sin = S.yaw_s.p; v.top_x = S.top_x.p;
+  v.rp = b->d_rp.p; v.invK = b->d_invK.p; v.vp = S.vp.p; v.bound = S.bound.p; v.flag = S.flag.p; v.corners = S.corners.p; v.job_valid = S.job_valid.p;
+  v.job_cbase = S.job_cbase.p; v.c_slot = S.c_slot.p; v.c_flag = S.c_flag.p; v.c_dist = S.c_dist.p; v.c_angle = S.c_angle.p; v.c_skew = S.c_skew.p;
+  HIP_TRY(hipEventRecord(S.ev[0], st));
+  cs::launch_line_setup(S.jobs.p, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st);
+  HIP_TRY(hipEventRecord(S.ev[1], st));
+  cs::launch_vp_support(v, C.sp, S.vp_total, st);
+  HIP_TRY(hipEventRecord(S.ev[2], st));
+  cs::launch_candidates(v, C.sp, slot_total, st);
+  HIP_TRY(hipEventRecord(S.ev[3], st));
+  cs::launch_scan_compact(v, st);
+  HIP_TRY(hipEventRecord(S.ev[4], st));
+  cs::launch_score(v, slot_total, slot_total, st);
+  HIP_TRY(hipEventRecord(S.ev[5], st));
+  cs::RankView rv{};
+  rv.box_job0 = S.box_job0.p; rv.box_njobs = S.box_njobs.p; rv.n_boxes = (int)nb; rv.winners = S.winners.p; rv.win_count = S.win_count.p; rv.fallback = S.fallback.p;
+  cs::RankParams rkp{P.weight_vp_angle, P.weight_skew_error, P.nominal_skew_ratio, P.max_cut_skew, KMAX};
+  cs::launch_rank(v, rv, rkp, st);
+  HIP_TRY(hipEventRecord(S.ev[6], st));
+  HIP_TRY(hipGetLastError());
+  if (nb) {
+    HIP_TRY(hipMemcpyAsync(S.h_winners.p, S.winners.p, sizeof(cs::RankWinner) * nb * KMAX, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(S.h_win_count.p, S.win_count.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(S.h_fallback.p, S.fallback.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipMemcpyAsync(S.h_job_valid.p, S.job_valid.p, sizeof(int) * nj, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(S.h_job_cbase.p, S.job_cbase.p, sizeof(long long) * (nj + 1), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(S.h_jobs_out.p, S.jobs.p, sizeof(cs::JobDesc) * nj, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipEventRecord(S.done, st));
+  S.in_flight = true;
+  return CS_OK;
+}
+
+int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>>& cam_rp) {
+  cs_detector* d = C.d; cs_batch* b = C.b;
+  const cs_detect_params& P = d->prm;
+  const int KMAX = P.max_cuboid_num, MB = b->max_boxes;
+  cs_detect_timing& tm = *C.tm;
+  double tw = now_ms();
+  HIP_TRY(hipEventSynchronize(S.done));
+  tm.d2h_ms += now_ms() - tw;   // time the host actually waited for the GPU
+  S.in_flight = false;
+  const size_t nj = S.nj, nb = S.nb;
+  if (nj == 0) return CS_OK;
+  double t0 = now_ms();
+  {
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, S.ev[0], S.ev[1])); tm.line_setup_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, S.ev[1], S.ev[2])); tm.vp_kernel_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, S.ev[2], S.ev[3])); tm.cand_kernel_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, S.ev[3], S.ev[4])); tm.compact_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, S.ev[4], S.ev[5])); tm.score_kernel_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, S.ev[5], S.ev[6])); tm.rank_kernel_ms += ms;
+    tm.cand_kernel_launches += 1;
+    const long long n_valid = S.h_job_cbase.p[nj];
+    tm.n_valid += n_valid;
+    tm.cand_kernel_bytes += 48LL * S.vp_total + 4LL * S.slot_total + 128LL * n_valid;
+    long long sbytes = 48LL * S.vp_total + (128LL + 28LL + 8LL) * n_valid;
+    for (size_t j = 0; j < nj; j++) sbytes += 4LL * S.h_jobs_in.p[j].map_w * (S.h_jobs_in.p[j].g.eb - S.h_jobs_in.p[j].g.et);
+    tm.score_kernel_bytes += sbytes;
+  }
+  const cs::JobDesc* jobs = S.h_jobs_in.p;
+  hipStream_t st2 = d->stream2;
+  // ---- boxes the kernel flagged (a tie at a cut or at the top): exact std::partial_sort ranking on the host.  Their
+  // columns are fetched on the second stream, concurrently with the next chunk's sweep on the first.
+  std::vector<long long> fb_src, fb_dst;
+  std::vector<int> fb_cnt, fb_range_of_job(nj, -1);
+  long long tot = 0;
+  for (size_t q = 0; q < nb; q++)
+    if (S.h_fallback.p[q])
+      for (int h = 0; h < S.h_box_njobs.p[q]; h++) {
+        int j = S.h_box_job0.p[q] + h;
+        fb_range_of_job[j] = (int)fb_src.size();
+        fb_src.push_back(S.h_job_cbase.p[j]); fb_cnt.push_back(S.h_job_valid.p[j]); fb_dst.push_back(tot);
+        tot += S.h_job_valid.p[j];
+      }
+  int rc;
+  if (!fb_src.empty()) {
+    size_t nr = fb_src.size();
+    PENS(S.fb_src, nr); PENS(S.fb_dst, nr); PENS(S.fb_cnt, nr); PENS(S.h_fb_src, nr); PENS(S.h_fb_dst, nr); PENS(S.h_fb_cnt, nr);
+    PENS(S.fb_dist, tot + 1); PENS(S.fb_angle, tot + 1); PENS(S.fb_skew, tot + 1); PENS(S.fb_flag, tot + 1); PENS(S.fb_slot, tot + 1);
+    PENS(S.h_fb_dist, tot + 1); PENS(S.h_fb_angle, tot + 1); PENS(S.h_fb_skew, tot + 1); PENS(S.h_fb_flag, tot + 1); PENS(S.h_fb_slot, tot + 1);
+    std::copy(fb_src.begin(), fb_src.end(), S.h_fb_src.p); std::copy(fb_dst.begin(), fb_dst.end(), S.h_fb_dst.p); std::copy(fb_cnt.begin(), fb_cnt.end(), S.h_fb_cnt.p);
+    HIP_TRY(hipMemcpyAsync(S.fb_src.p, S.h_fb_src.p, 8 * nr, hipMemcpyHostToDevice, st2));
+    HIP_TRY(hipMemcpyAsync(S.fb_dst.p, S.h_fb_dst.p, 8 * nr, hipMemcpyHostToDevice, st2));
+    HIP_TRY(hipMemcpyAsync(S.fb_cnt.p, S.h_fb_cnt.p, 4 * nr, hipMemcpyHostToDevice, st2));
+    cs::launch_gather_ranges(S.view, S.fb_src.p, S.fb_cnt.p, S.fb_dst.p, (int)nr, S.fb_dist.p, S.fb_angle.p, S.fb_skew.p, S.fb_flag.p, S.fb_slot.p, st2);
+    if (tot) {
+      HIP_TRY(hipMemcpyAsync(S.h_fb_dist.p, S.fb_dist.p, 8 * (size_t)tot, hipMemcpyDeviceToHost, st2));
+      HIP_TRY(hipMemcpyAsync(S.h_fb_angle.p, S.fb_angle.p, 8 * (size_t)tot, hipMemcpyDeviceToHost, st2));
+      HIP_TRY(hipMemcpyAsync(S.h_fb_skew.p, S.fb_skew.p, 8 * (size_t)tot, hipMemcpyDeviceToHost, st2));
+      HIP_TRY(hipMemcpyAsync(S.h_fb_flag.p, S.fb_flag.p, 4 * (size_t)tot, hipMemcpyDeviceToHost, st2));
+      HIP_TRY(hipMemcpyAsync(S.h_fb_slot.p, S.fb_slot.p, 8 * (size_t)tot, hipMemcpyDeviceToHost, st2));
+    }
+    HIP_TRY(hipStreamSynchronize(st2));
+  }
+  const double* fb_dist = S.h_fb_dist.p; const double* fb_angle = S.h_fb_angle.p; const double* fb_skew = S.h_fb_skew.p;
+  const int* fb_flag = S.h_fb_flag.p; const long long* fb_slot = S.h_fb_slot.p;
+  std::vector<std::vector<cs::RankWinner>> fb_winners(nb);
+  auto rank_on_host = [&](size_t q) {
+    const int j0 = S.h_box_job0.p[q], nh = S.h_box_njobs.p[q];
+    struct HP { int h, cand; double score, skew; };
+    std::vector<HP> props;
+    for (int h = 0; h < nh; h++) {
+      int j = j0 + h, V = S.h_job_valid.p[j];
+      long long p0 = fb_dst[fb_range_of_job[j]];
+      std::vector<int> keep;
+      std::vector<double> score;
+      fuse_scores(fb_dist + p0, fb_angle + p0, V, P.weight_vp_angle, keep, score);
+      for (size_t z = 0; z < keep.size(); z++) {
+        if (fb_flag[p0 + keep[z]] & cs::CAND_NEG_SCALE) continue;
+        props.push_back(HP{h, keep[z], score[z], fb_skew[p0 + keep[z]]});
+      }
+    }
+    int n = (int)props.size(), kk = std::min(KMAX, n);
+    std::vector<double> comb(n);
+    for (int i = 0; i < n; i++) {
+      double skew_error = P.weight_skew_error * std::max(props[i].skew - P.nominal_skew_ratio, 0.0);
+      if (props[i].skew > P.max_cut_skew) skew_error = 100;
+      comb[i] = props[i].score + P.weight_skew_error * skew_error;
+    }
+    std::vector<int> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::partial_sort(idx.begin(), idx.begin() + kk, idx.end(), [&comb](int a, int c) { return comb[a] < comb[c]; });
+    for (int r = 0; r < kk; r++) {
+      const HP& hp = props[idx[r]];
+      long long p0 = fb_dst[fb_range_of_job[j0 + hp.h]];
+      cs::RankWinner w{};
+      w.slot = fb_slot[p0 + hp.cand]; w.normalized_error = hp.score; w.dist_err = fb_dist[p0 + hp.cand]; w.angle_err = fb_angle[p0 + hp.cand];
+      w.flag = fb_flag[p0 + hp.cand] & cs::CAND_VP_MASK;
+      fb_winners[q].push_back(w);
+    }
+  };
+  std::vector<int> fbq;
+  for (size_t q = 0; q < nb; q++) if (S.h_fallback.p[q]) fbq.push_back((int)q);
+  tm.n_fallback_boxes += (int)fbq.size();
+  d->pool->run((int)fbq.size(), [&](int z) { rank_on_host((size_t)fbq[z]); });
+  {
+    std::vector<long long> ws;
+    for (int q : fbq) for (auto& w : fb_winners[q]) ws.push_back(w.slot);
+    if (!ws.empty()) {
+      PENS(S.win_slots, ws.size()); PENS(S.win_corners, 16 * ws.size()); PENS(S.h_win_slots, ws.size()); PENS(S.h_win_corners, 16 * ws.size());
+      std::copy(ws.begin(), ws.end(), S.h_win_slots.p);
+      HIP_TRY(hipMemcpyAsync(S.win_slots.p, S.h_win_slots.p, 8 * ws.size(), hipMemcpyHostToDevice, st2));
+      cs::launch_gather_corners(S.corners.p, S.win_slots.p, (int)ws.size(), S.win_corners.p, st2);
+      HIP_TRY(hipMemcpyAsync(S.h_win_corners.p, S.win_corners.p, 8 * 16 * ws.size(), hipMemcpyDeviceToHost, st2));
+      HIP_TRY(hipStreamSynchronize(st2));
+      const double* hc = S.h_win_corners.p;
+      size_t z = 0;
+      for (int q : fbq) for (auto& w : fb_winners[q]) { std::memcpy(w.corners, &hc[16 * z], 128); z++; }
+    }
+  }
+  // ---- records of the winners
+  d->pool->run((int)nb, [&](int qi) {
+    const size_t q = (size_t)qi;
+    const int j0 = S.h_box_job0.p[q], nh = S.h_box_njobs.p[q];
+    const int f = jobs[j0].frame, bi = jobs[j0].box;
+    const FrameIn& F = b->frames[f];
+    const double* bb = &F.boxes[5 * bi];
+    const cs::RankWinner* wl = S.h_fallback.p[q] ? fb_winners[q].data() : S.h_winners.p + q * KMAX;
+    const int nw = S.h_fallback.p[q] ? (int)fb_winners[q].size() : S.h_win_count.p[q];
+    for (int r = 0; r < nw; r++) {
+      const cs::RankWinner& w = wl[r];
+      int h = 0;
+      while (h + 1 < nh && w.slot >= jobs[j0 + h + 1].slot_off) h++;
+      const cs::JobDesc& jd = jobs[j0 + h];
+      long long local = w.slot - jd.slot_off;
+      long long rest = local >> 1;
+      int t = (int)(rest % jd.T), y = (int)(rest / jd.T);
+      const cs::RpPose& pose = cam_rp[f][0].pose;
+      double r9[9] = {(double)((local & 1) + 1), (double)(w.flag & cs::CAND_VP_MASK), S.h_yaw.p[jd.yaw_off + y], (double)t, w.dist_err, w.angle_err,
+                      (double)jd.down_expand, pose.roll, pose.pitch};
+      cs_cuboid& o = C.out[((size_t)f * MB + bi) * KMAX + r];
+      finish_cuboid(F, pose, r9, w.corners, (*C.cam_raw)[f].euler, false, w.normalized_error, o);
+      o.rect_detect_2d[0] = (int)bb[0]; o.rect_detect_2d[1] = (int)bb[1]; o.rect_detect_2d[2] = (int)bb[2]; o.rect_detect_2d[3] = (int)bb[3];
+    }
+    C.out_counts[(size_t)f * MB + bi] = nw;
+  });
+  tm.finalize_ms += now_ms() - t0;
+  return CS_OK;
+}
+#undef PENS
+#undef PH2D
+
+}  // namespace
+
+extern "C" int cs_batch_set_pipeline_chunks(cs_batch* b, int n_chunks) {
+  if (!b || n_chunks < 1) return CS_ERR_INVALID_ARG;
+  b->pipe_chunks = n_chunks;
+  return CS_OK;
+}
+
 extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_counts) {
   if (!d || !b || b->det != d || !out || !out_counts) return CS_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(d->device));
@@ -739,6 +1098,27 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
     HIP_TRY(hipStreamSynchronize(st));
   }
   tm.setup_host_ms += now_ms() - t0;
+
+  // ---- production path: chunked two-slot pipeline (host packs chunk k+1 / finishes chunk k-1 while the GPU sweeps k)
+  if (!sample_rp && !b->debug && !b->force_host_rank && !b->force_host_setup && !b->force_no_pipeline && b->device_setup && KMAX <= cs::RANK_KMAX && MB > 0) {
+    PipeCtx C{d, b, out, out_counts, &cam_raw, &rp_off, sp, &tm};
+    const int n_chunks = std::max(1, std::min(NF, b->pipe_chunks));
+    for (int k = 0; k <= n_chunks; k++) {
+      if (k < n_chunks) {
+        int f0 = (int)((long long)NF * k / n_chunks), f1 = (int)((long long)NF * (k + 1) / n_chunks);
+        int rc = pipe_launch(C, b->pipe[k & 1], f0, f1);
+        if (rc) return rc;
+      }
+      if (k >= 1) {
+        int rc = pipe_finish(C, b->pipe[(k - 1) & 1], cam_rp);
+        if (rc) return rc;
+      }
+    }
+    tm.total_ms = now_ms() - t_begin;
+    b->timing = tm;
+    b->ran = true;
+    return CS_OK;
+  }
 
   // proposals per (frame, box) accumulate over height samples inside a round
   std::vector<Winner> winners;
@@ -872,7 +1252,7 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
     ENS(b->d_mid_x, n_lines + 1); ENS(b->d_mid_y, n_lines + 1); ENS(b->d_ang, n_lines + 1);
     ENS(b->d_yaw, n_yaw + 1); ENS(b->d_yaw_c, n_yaw + 1); ENS(b->d_yaw_s, n_yaw + 1); ENS(b->d_top_x, n_top + 1);
     ENS(b->d_vp, 6 * (size_t)vp_total + 6); ENS(b->d_bound, 6 * (size_t)vp_total + 6);
-    ENS(b->d_flag, slot_total + 1); ENS(b->d_dist, slot_total + 1); ENS(b->d_angle, slot_total + 1); ENS(b->d_skew, slot_total + 1);
+    ENS(b->d_flag, slot_total + 1);
     ENS(b->d_corners, 16 * (size_t)slot_total + 16);
 #define H2D(dst, vec) HIP_TRY(hipMemcpyAsync((dst).p, (vec).data(), sizeof((vec)[0]) * (vec).size(), hipMemcpyHostToDevice, st))
     H2D(b->d_jobs, jobs); H2D(b->d_slot_prefix, slot_prefix); H2D(b->d_vp_prefix, vp_prefix);
@@ -888,8 +1268,8 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
     v.jobs = b->d_jobs.p; v.n_jobs = (int)nj; v.slot_prefix = b->d_slot_prefix.p; v.vp_prefix = b->d_vp_prefix.p;
     v.maps = b->d_maps.p; v.mid_x = b->d_mid_x.p; v.mid_y = b->d_mid_y.p; v.line_angle = b->d_ang.p;
     v.yaw = b->d_yaw.p; v.yaw_cos = b->d_yaw_c.p; v.yaw_sin = b->d_yaw_s.p; v.top_x = b->d_top_x.p; v.rp = b->d_rp.p; v.invK = b->d_invK.p;
-    v.vp = b->d_vp.p; v.bound = b->d_bound.p; v.flag = b->d_flag.p; v.dist_err = b->d_dist.p; v.angle_err = b->d_angle.p;
-    v.skew = b->d_skew.p; v.corners = b->d_corners.p; v.job_valid = b->d_job_valid.p; v.job_cbase = b->d_job_cbase.p;
+    v.vp = b->d_vp.p; v.bound = b->d_bound.p; v.flag = b->d_flag.p;
+    v.corners = b->d_corners.p; v.job_valid = b->d_job_valid.p; v.job_cbase = b->d_job_cbase.p;
     HIP_TRY(hipEventRecord(d->ev[6], st));
     if (dev_setup) {
       cs::launch_line_setup(b->d_jobs.p, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, b->d_mid_x.p, b->d_mid_y.p, b->d_ang.p,
@@ -916,6 +1296,8 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
       v.c_slot = b->d_c_slot.p; v.c_flag = b->d_c_flag.p; v.c_dist = b->d_c_dist.p; v.c_angle = b->d_c_angle.p; v.c_skew = b->d_c_skew.p;
       HIP_TRY(hipEventRecord(d->ev[3], st));
       cs::launch_scan_compact(v, st);
+      HIP_TRY(hipEventRecord(d->ev[8], st));
+      cs::launch_score(v, slot_total, slot_total, st);   // the exact number of valid proposals stays on the device
       HIP_TRY(hipEventRecord(d->ev[4], st));
       std::vector<int> box_job0, box_njobs;
       for (size_t j = 0; j < nj; j++)
@@ -946,14 +1328,18 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1])); tm.vp_kernel_ms += ms;
         HIP_TRY(hipEventElapsedTime(&ms, d->ev[1], d->ev[2])); tm.cand_kernel_ms += ms;
-        HIP_TRY(hipEventElapsedTime(&ms, d->ev[3], d->ev[4])); tm.compact_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, d->ev[3], d->ev[8])); tm.compact_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, d->ev[8], d->ev[4])); tm.score_kernel_ms += ms;
         HIP_TRY(hipEventElapsedTime(&ms, d->ev[4], d->ev[5])); tm.rank_kernel_ms += ms;
         HIP_TRY(hipEventElapsedTime(&ms, d->ev[6], d->ev[7])); tm.line_setup_ms += ms;
         tm.cand_kernel_launches += 1;
-        long long bytes = 0;
-        for (size_t j = 0; j < nj; j++) bytes += 4LL * jobs[j].map_w * (jobs[j].g.eb - jobs[j].g.et) + 24LL * jobs[j].m;
-        bytes += 96LL * vp_total + 4LL * slot_total + 200LL * n_valid;
-        tm.cand_kernel_bytes += bytes;
+        // algorithmic bytes: geometry kernel = vanishing points read once per (job, rp, yaw) + one flag
+        // per slot + 128 B of corners per valid proposal; scoring kernel = each distance map once + the VP support table
+        // + 128 B of corners read and 28 B of scores written per valid proposal
+        tm.cand_kernel_bytes += 48LL * vp_total + 4LL * slot_total + 128LL * n_valid;
+        long long sbytes = 48LL * vp_total + (128LL + 28LL + 8LL) * n_valid;
+        for (size_t j = 0; j < nj; j++) sbytes += 4LL * jobs[j].map_w * (jobs[j].g.eb - jobs[j].g.et);
+        tm.score_kernel_bytes += sbytes;
       }
       // ---- finish on the host: records of the winners; boxes flagged by the kernel are re-ranked exactly
       t0 = now_ms();
@@ -1103,6 +1489,8 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
     v.c_slot = b->d_c_slot.p; v.c_flag = b->d_c_flag.p; v.c_dist = b->d_c_dist.p; v.c_angle = b->d_c_angle.p; v.c_skew = b->d_c_skew.p;
     HIP_TRY(hipEventRecord(d->ev[3], st));
     cs::launch_scan_compact(v, st);
+    HIP_TRY(hipEventRecord(d->ev[8], st));
+    cs::launch_score(v, n_valid, slot_total, st);
     HIP_TRY(hipEventRecord(d->ev[4], st));
     HIP_TRY(hipGetLastError());
     ENS(b->h_c_slot, n_valid + 1); ENS(b->h_c_flag, n_valid + 1); ENS(b->h_c_dist, n_valid + 1); ENS(b->h_c_angle, n_valid + 1); ENS(b->h_c_skew, n_valid + 1);
@@ -1120,15 +1508,19 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
       float ms = 0;
       HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1])); tm.vp_kernel_ms += ms;
       HIP_TRY(hipEventElapsedTime(&ms, d->ev[1], d->ev[2])); tm.cand_kernel_ms += ms;
-      HIP_TRY(hipEventElapsedTime(&ms, d->ev[3], d->ev[4])); tm.compact_ms += ms;
+      HIP_TRY(hipEventElapsedTime(&ms, d->ev[3], d->ev[8])); tm.compact_ms += ms;
+      HIP_TRY(hipEventElapsedTime(&ms, d->ev[8], d->ev[4])); tm.score_kernel_ms += ms;
       HIP_TRY(hipEventElapsedTime(&ms, d->ev[6], d->ev[7])); tm.line_setup_ms += ms;
       tm.cand_kernel_launches += 1;
       // algorithmic bytes of the candidate kernel: maps + line arrays + vp/bound read once,
       // 200 B written per valid proposal, 4 B flag per slot
-      long long bytes = 0;
-      for (size_t j = 0; j < nj; j++) bytes += 4LL * jobs[j].map_w * (jobs[j].g.eb - jobs[j].g.et) + 24LL * jobs[j].m;
-      bytes += 96LL * vp_total + 4LL * slot_total + 200LL * n_valid;
-      tm.cand_kernel_bytes += bytes;
+      // algorithmic bytes: geometry kernel = vanishing points read once per (job, rp, yaw) + one flag
+      // per slot + 128 B of corners per valid proposal; scoring kernel = each distance map once + the VP support table
+      // + 128 B of corners read and 28 B of scores written per valid proposal
+      tm.cand_kernel_bytes += 48LL * vp_total + 4LL * slot_total + 128LL * n_valid;
+      long long sbytes = 48LL * vp_total + (128LL + 28LL + 8LL) * n_valid;
+      for (size_t j = 0; j < nj; j++) sbytes += 4LL * jobs[j].map_w * (jobs[j].g.eb - jobs[j].g.et);
+      tm.score_kernel_bytes += sbytes;
     }
 
     // ------------------------------------------------------------------ rank (host) ----------

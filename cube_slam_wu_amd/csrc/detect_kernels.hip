@@ -82,20 +82,53 @@ __global__ __launch_bounds__(256) void vp_support_kernel(DetectDeviceView v, Swe
     double thre = (k != 2) ? sp.vp12_thre_rad : sp.vp3_thre_rad;
     bool have = false;
     double base = 0, best_hi = 0, best_lo = 0, ang_hi = NaN, ang_lo = NaN;
-    for (int i = 0; i < jd.m; i++) {
-      double raw = cs_atan2(my[i] - vpy[k], mx[i] - vpx[k]);
-      double nrm = normalize_to_pi(raw);
-      double df = dabs(la[i] - nrm);
-      df = dmin(df, CS_PI - df);
-      if (df < thre) {
-        if (!have) {  // first inlier: base of smooth_jump_angles (:278-302), and initial arg-max / arg-min
-          have = true; base = raw; best_hi = raw; best_lo = raw; ang_hi = la[i]; ang_lo = la[i];
-        } else {
-          double sh = raw;
-          if ((raw - base) < -CS_PI) sh = raw + 2 * CS_PI;
-          else if ((raw - base) > CS_PI) sh = raw - 2 * CS_PI;
-          if (sh > best_hi) { best_hi = sh; ang_hi = la[i]; }  // maxCoeff: first occurrence, strict
-          if (sh < best_lo) { best_lo = sh; ang_lo = la[i]; }  // minCoeff
+    // Only inliers (a few percent of the segments) need the exact angle.  Per chunk of 64 segments: (1) a float
+    // approximation of atan2 (|error| < 2e-6 rad, checked in tests/test_detect_oracle.py) marks every segment that is
+    // not certainly an outlier -- "certainly" = further than 1e-4 rad from the threshold and from the +-pi/2 fold of
+    // normalize_to_pi; (2) the marked ones are evaluated exactly, in order.  The wave runs the expensive cs_atan2
+    // only max-over-lanes(marked) times instead of m times, and every decision is the exact one.
+    for (int i0 = 0; i0 < jd.m; i0 += 64) {
+      unsigned long long mask = 0;
+      const int i1 = min(jd.m, i0 + 64);
+      for (int i = i0; i < i1; i++) {
+        float fy = (float)(my[i] - vpy[k]), fx = (float)(mx[i] - vpx[k]);
+        float ay = fabsf(fy), ax = fabsf(fx);
+        float hi = fmaxf(ax, ay), lo = fminf(ax, ay);
+        bool maybe = true;
+        if (hi > 0.0f && hi < 3.0e38f) {  // finite, non-degenerate; anything else goes to the exact evaluation
+          float q = lo / hi, q2 = q * q;
+          float at = q * (0.99997726f + q2 * (-0.33262347f + q2 * (0.19354346f + q2 * (-0.11643287f + q2 * (0.05265332f + q2 * -0.01172120f)))));
+          if (ay > ax) at = 1.57079637f - at;
+          if (fx < 0.0f) at = 3.14159274f - at;
+          if (fy < 0.0f) at = -at;
+          const float fold = fabsf(fabsf(at) - 1.57079637f);
+          float nr = at;
+          if (at > 1.57079637f) nr = at - 3.14159274f; else if (at < -1.57079637f) nr = at + 3.14159274f;
+          float df = fabsf((float)la[i] - nr);
+          df = fminf(df, 3.14159274f - df);
+          maybe = !(fold > 1.0e-4f && df > (float)thre + 1.0e-4f);
+        }
+        if (maybe) mask |= 1ull << (i - i0);
+      }
+      while (__any(mask != 0)) {
+        if (mask != 0) {
+          const int i = i0 + __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          double raw = cs_atan2(my[i] - vpy[k], mx[i] - vpx[k]);
+          double nrm = normalize_to_pi(raw);
+          double df = dabs(la[i] - nrm);
+          df = dmin(df, CS_PI - df);
+          if (df < thre) {
+            if (!have) {  // first inlier: base of smooth_jump_angles (:278-302), and initial arg-max / arg-min
+              have = true; base = raw; best_hi = raw; best_lo = raw; ang_hi = la[i]; ang_lo = la[i];
+            } else {
+              double sh = raw;
+              if ((raw - base) < -CS_PI) sh = raw + 2 * CS_PI;
+              else if ((raw - base) > CS_PI) sh = raw - 2 * CS_PI;
+              if (sh > best_hi) { best_hi = sh; ang_hi = la[i]; }  // maxCoeff: first occurrence, strict
+              if (sh < best_lo) { best_lo = sh; ang_lo = la[i]; }  // minCoeff
+            }
+          }
         }
       }
     }
@@ -105,65 +138,14 @@ __global__ __launch_bounds__(256) void vp_support_kernel(DetectDeviceView v, Swe
   }
 }
 
-// box_edge_sum_dists (object_3d_util.cpp:622-667): 11 samples per edge, float gathers, float running sum.
-template <int NE, bool REWEIGHT>
-__device__ __forceinline__ double edge_sum_dists(const float* __restrict__ map, int map_w, const V2 c[8], const int (&ea)[NE], const int (&eb)[NE], double ox, double oy) {
-  float sum_dist = 0;
-#pragma unroll
-  for (int e = 0; e < NE; e++) {
-    double x1 = c[ea[e]].x - ox, y1 = c[ea[e]].y - oy, x2 = c[eb[e]].x - ox, y2 = c[eb[e]].y - oy;
-    float dv[11];
-#pragma unroll
-    for (int s = 0; s < 11; s++) {
-      double w = (double)s / 10.0;
-      double sx = w * x1 + (1 - w) * x2;
-      double sy = w * y1 + (1 - w) * y2;
-      dv[s] = map[(long long)(int)sy * map_w + (int)sx];
-    }
-#pragma unroll
-    for (int s = 0; s < 11; s++) {
-      float d1 = dv[s];
-      if (REWEIGHT) {
-        if (e == 4 || e == 5) d1 = (float)((double)d1 * 3.0 / 2.0);
-        if (e == 6) d1 = (float)((double)d1 * 2.0);
-      }
-      sum_dist = sum_dist + d1;
-    }
-  }
-  return (double)sum_dist;
-}
-
-// box_edge_alignment_angle_error (object_3d_util.cpp:670-723)
-__device__ __forceinline__ double angle_alignment_error(const double* bound, const int (&ids)[3][4], const V2 c[8]) {
-  double total = 0;
-  const double not_found_penalty = 30.0 / 180.0 * CS_PI * 2;
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    double b0 = bound[2 * k], b1 = bound[2 * k + 1];
-    bool v0 = !(b0 != b0), v1 = !(b1 != b1);
-    if (v0 || v1) {
-#pragma unroll
-      for (int ee = 0; ee < 2; ee++) {
-        V2 p1 = c[ids[k][2 * ee]], p2 = c[ids[k][2 * ee + 1]];
-        double ang = normalize_to_pi(cs_atan2(p2.y - p1.y, p2.x - p1.x));
-        double best = 100;
-        if (v0) { double t = dabs(ang - b0); t = dmin(t, CS_PI - t); if (t < best) best = t; }
-        if (v1) { double t = dabs(ang - b1); t = dmin(t, CS_PI - t); if (t < best) best = t; }
-        total = total + best;
-      }
-    } else {
-      total = total + not_found_penalty;
-    }
-  }
-  return total;
-}
-
+// ---- proposal geometry: one lane per slot -----------------------------------------------------------
+// The eight corners (box_proposal_detail.cpp:413-625).  ~70 % of the slots are rejected here, so scoring runs as a
+// second kernel over the compacted survivors (dense wavefronts) instead of inside this one.
 __global__ __launch_bounds__(256) void candidate_kernel(DetectDeviceView v, SweepParams sp, long long slot_total) {
   long long tid = xcd_virtual_block() * blockDim.x + threadIdx.x;
   bool active = tid < slot_total;
   int flag = 0;
   int j = 0;
-  long long slot = 0;
   if (active) {
     j = find_job_i64(v.slot_prefix, v.n_jobs, tid);
     const JobDesc jd = v.jobs[j];
@@ -174,37 +156,13 @@ __global__ __launch_bounds__(256) void candidate_kernel(DetectDeviceView v, Swee
     long long rest = (k >= half) ? k - half : k;
     int t = (int)(rest % jd.T);
     int ry = (int)(rest / jd.T);  // rp*Y + yaw
-    int rp = ry / jd.Y;
-    slot = jd.slot_off + rest * 2 + (cfg - 1);
+    long long slot = jd.slot_off + rest * 2 + (cfg - 1);
     bool enabled = (cfg == 1) ? (sp.consider_config_1 != 0) : (sp.consider_config_2 != 0);
     if (enabled) {
       const double* vp = v.vp + 6 * (long long)(jd.vp_off + ry);
-      V2 vp1 = v2(vp[0], vp[1]), vp2 = v2(vp[2], vp[3]), vp3 = v2(vp[4], vp[5]);
       V2 c[8];
-      int pos = build_corners(jd.g, vp1, vp2, vp3, (double)v.top_x[jd.top_off + t], cfg, sp.short_thre, c);
-      if (pos) {
-        const float* map = v.maps + jd.map_off;
-        const double* bound = v.bound + 6 * (long long)(jd.vp_off + ry);
-        double sum_dist, ang;
-        if (cfg == 1) {
-          const int ea[9] = {0, 1, 2, 3, 1, 2, 3, 4, 4}, eb[9] = {1, 2, 3, 0, 5, 4, 7, 7, 5};  // :646
-          const int ids[3][4] = {{0, 1, 7, 4}, {3, 0, 4, 5}, {3, 7, 1, 5}};                     // :651
-          sum_dist = edge_sum_dists<9, false>(map, jd.map_w, c, ea, eb, (double)jd.g.el, (double)jd.g.et);
-          ang = angle_alignment_error(bound, ids, c);
-        } else {
-          const int ea[7] = {0, 1, 2, 3, 1, 2, 4}, eb[7] = {1, 2, 3, 0, 5, 4, 5};               // :663
-          const int ids[3][4] = {{0, 1, 2, 3}, {3, 0, 4, 5}, {2, 4, 1, 5}};                     // :665
-          sum_dist = edge_sum_dists<7, true>(map, jd.map_w, c, ea, eb, (double)jd.g.el, (double)jd.g.et);
-          ang = angle_alignment_error(bound, ids, c);
-        }
-        const RpPose* pose = v.rp + jd.rp_off + rp;
-        double p3[3], s3[3];
-        lift_to_3d(c, pose->R, pose->t, v.invK + 9 * jd.frame, pose->plane, p3, s3);
-        flag = pos;
-        if (s3[0] < 0 || s3[1] < 0 || s3[2] < 0) flag |= CAND_NEG_SCALE;
-        v.dist_err[slot] = sum_dist / jd.diag;
-        v.angle_err[slot] = ang;
-        v.skew[slot] = dmax(s3[0], s3[1]) / dmin(s3[0], s3[1]);
+      flag = build_corners(jd.g, v2(vp[0], vp[1]), v2(vp[2], vp[3]), v2(vp[4], vp[5]), (double)v.top_x[jd.top_off + t], cfg, sp.short_thre, c);
+      if (flag) {
         double* co = v.corners + 16 * slot;
 #pragma unroll
         for (int i = 0; i < 8; i++) { co[i] = c[i].x; co[8 + i] = c[i].y; }
@@ -224,6 +182,106 @@ __global__ __launch_bounds__(256) void candidate_kernel(DetectDeviceView v, Swee
       atomicAdd(&v.job_valid[j], 1);
     }
   }
+}
+
+// ---- proposal scoring: one lane per VALID proposal (compacted, in the reference's row order) ------------------
+// box_edge_sum_dists (object_3d_util.cpp:622-667: 11 samples per visible edge, float gathers from the distance map,
+// sequential float running sum), box_edge_alignment_angle_error (:670-723) and the 3D half sizes (:941-990).
+// Both configurations share one code path: the edge / VP tables are indexed by configuration and the corners sit in
+// LDS so that they can be indexed dynamically.
+// edge tables as compile-time constants, selected per lane by configuration with register selects (no table loads)
+//   config 1 (0): visible edges 1-2 2-3 3-4 4-1 2-6 3-5 4-8 5-8 5-6 (:646); VP edges 1-2,8-5 / 4-1,5-6 / 4-8,2-6 (:651)
+//   config 2 (1): visible edges 1-2 2-3 3-4 4-1 2-6 3-5 5-6         (:663); VP edges 1-2,3-4 / 4-1,5-6 / 3-5,2-6 (:665)
+__device__ __forceinline__ int sel(int cfg, int a, int b) { return cfg ? b : a; }
+
+__global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long long slot_total) {
+  __shared__ double CX[256][9], CY[256][9];   // [lane][corner], padded to 9 against bank conflicts
+  // the grid is sized for the worst case (every slot valid) because the exact count lives on the device; spread the
+  // ACTIVE blocks over the 8 XCDs (contiguous range per XCD), the surplus blocks exit immediately
+  const long long n_valid = v.job_cbase[v.n_jobs];
+  const long long per_xcd = ((n_valid + 255) / 256 + 7) / 8;
+  const long long kx = blockIdx.x >> 3;
+  if (kx >= per_xcd) return;
+  long long i = ((long long)(blockIdx.x & 7) * per_xcd + kx) * blockDim.x + threadIdx.x;
+  if (i >= n_valid) return;
+  const long long slot = v.c_slot[i];
+  const int j = find_job_i64(v.slot_prefix, v.n_jobs, slot);
+  const JobDesc jd = v.jobs[j];
+  const long long local = slot - jd.slot_off;
+  const int cfg = (int)(local & 1);          // 0 = configuration 1
+  const int ry = (int)((local >> 1) / jd.T);
+  const int rp = ry / jd.Y;
+  const int tx = threadIdx.x;
+  {
+    const double* co = v.corners + 16 * slot;
+#pragma unroll
+    for (int q = 0; q < 8; q++) { CX[tx][q] = co[q]; CY[tx][q] = co[8 + q]; }
+  }
+  const double ox = (double)jd.g.el, oy = (double)jd.g.et;
+  const float* __restrict__ map = v.maps + jd.map_off;
+  // ---- distance error: all gathers of an edge are issued before its (sequential, float) accumulation
+  float sum_dist = 0;
+  const int EA1[9] = {0, 1, 2, 3, 1, 2, 3, 4, 4}, EB1[9] = {1, 2, 3, 0, 5, 4, 7, 7, 5};
+  const int EA2[9] = {0, 1, 2, 3, 1, 2, 4, 0, 0}, EB2[9] = {1, 2, 3, 0, 5, 4, 5, 0, 0};
+#pragma unroll
+  for (int e = 0; e < 9; e++) {
+    const bool on = (e < 7) || (cfg == 0);
+    const int a = sel(cfg, EA1[e], EA2[e]), b = sel(cfg, EB1[e], EB2[e]);
+    const double x1 = CX[tx][a] - ox, y1 = CY[tx][a] - oy, x2 = CX[tx][b] - ox, y2 = CY[tx][b] - oy;
+    float dv[11];
+#pragma unroll
+    for (int s = 0; s < 11; s++) {
+      double w = (double)s / 10.0;
+      double sx = w * x1 + (1 - w) * x2;
+      double sy = w * y1 + (1 - w) * y2;
+      dv[s] = on ? map[(long long)(int)sy * jd.map_w + (int)sx] : 0.0f;
+    }
+    // config 2 reweights edges 4, 5 by 3/2 and edge 6 by 2 (:655-661); x * 3.0 / 2.0 == (x * 3.0) * 0.5 exactly
+    const bool w32 = cfg && (e == 4 || e == 5), w2 = cfg && (e == 6);
+#pragma unroll
+    for (int s = 0; s < 11; s++) {
+      float d1 = dv[s];
+      if (w32) d1 = (float)((double)d1 * 3.0 * 0.5);
+      if (w2) d1 = (float)((double)d1 * 2.0);
+      if (on) sum_dist = sum_dist + d1;
+    }
+  }
+  // ---- angle alignment error
+  const double* bound = v.bound + 6 * (long long)(jd.vp_off + ry);
+  double total = 0;
+  const double not_found_penalty = 30.0 / 180.0 * CS_PI * 2;
+  const int ID1[3][4] = {{0, 1, 7, 4}, {3, 0, 4, 5}, {3, 7, 1, 5}}, ID2[3][4] = {{0, 1, 2, 3}, {3, 0, 4, 5}, {2, 4, 1, 5}};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    double b0 = bound[2 * k], b1 = bound[2 * k + 1];
+    bool v0 = !(b0 != b0), v1 = !(b1 != b1);
+    if (v0 || v1) {
+#pragma unroll
+      for (int ee = 0; ee < 2; ee++) {
+        int pa = sel(cfg, ID1[k][2 * ee], ID2[k][2 * ee]), pb = sel(cfg, ID1[k][2 * ee + 1], ID2[k][2 * ee + 1]);
+        double ang = normalize_to_pi(cs_atan2(CY[tx][pb] - CY[tx][pa], CX[tx][pb] - CX[tx][pa]));
+        double best = 100;
+        if (v0) { double t = dabs(ang - b0); t = dmin(t, CS_PI - t); if (t < best) best = t; }
+        if (v1) { double t = dabs(ang - b1); t = dmin(t, CS_PI - t); if (t < best) best = t; }
+        total = total + best;
+      }
+    } else {
+      total = total + not_found_penalty;
+    }
+  }
+  // ---- half sizes of the lifted cuboid -> skew ratio, negative-scale flag
+  V2 c[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) c[q] = v2(CX[tx][q], CY[tx][q]);
+  const RpPose* pose = v.rp + jd.rp_off + rp;
+  double p3[3], s3[3];
+  lift_to_3d(c, pose->R, pose->t, v.invK + 9 * jd.frame, pose->plane, p3, s3);
+  int flag = v.c_flag[i];
+  if (s3[0] < 0 || s3[1] < 0 || s3[2] < 0) flag |= CAND_NEG_SCALE;
+  v.c_flag[i] = flag;
+  v.c_dist[i] = (double)sum_dist / jd.diag;
+  v.c_angle[i] = total;
+  v.c_skew[i] = dmax(s3[0], s3[1]) / dmin(s3[0], s3[1]);
 }
 
 // Exclusive scan of job_valid -> job_cbase (n_jobs + 1).  Single block.
@@ -277,9 +335,6 @@ __global__ __launch_bounds__(256) void compact_kernel(DetectDeviceView v) {
       long long pos = off + __popcll(b & ((1ull << lane) - 1ull));
       v.c_slot[pos] = s;
       v.c_flag[pos] = f;
-      v.c_dist[pos] = v.dist_err[s];
-      v.c_angle[pos] = v.angle_err[s];
-      v.c_skew[pos] = v.skew[s];
     }
     __syncthreads();
     if (threadIdx.x == 0) run_s = off + wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
@@ -709,6 +764,11 @@ void launch_scan_compact(const DetectDeviceView& v, hipStream_t st) {
   if (v.n_jobs <= 0) return;
   hipLaunchKernelGGL(scan_jobs_kernel, dim3(1), dim3(1024), 0, st, v.job_valid, v.job_cbase, v.n_jobs);
   hipLaunchKernelGGL(compact_kernel, dim3(v.n_jobs), dim3(256), 0, st, v);
+}
+// scoring over the compacted proposals; n_valid_bound is an upper bound known on the host (the exact count stays on the device)
+void launch_score(const DetectDeviceView& v, long long n_valid_bound, long long slot_total, hipStream_t st) {
+  if (n_valid_bound <= 0) return;
+  hipLaunchKernelGGL(score_kernel, dim3(grid8(n_valid_bound, 256)), dim3(256), 0, st, v, slot_total);
 }
 // copy [src_off, src_off + count) ranges of the compacted columns into packed buffers (fallback boxes)
 __global__ __launch_bounds__(256) void gather_ranges_kernel(DetectDeviceView v, const long long* src_off, const int* count, const long long* dst_off, int n_ranges,

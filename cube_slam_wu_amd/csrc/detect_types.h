@@ -54,13 +54,12 @@ struct DetectDeviceView {
   double* bound;                 // 6 per (job, rp, yaw): the 3x2 VP support angles (NaN = none)
   // per-slot outputs
   int* flag;
-  double* dist_err; double* angle_err; double* skew;
   double* corners;               // 16 per slot (x0..x7, y0..y7), written for valid slots only
   // per-job valid counts and compacted outputs
   int* job_valid;                // n_jobs
   long long* job_cbase;          // n_jobs + 1, exclusive scan of job_valid
-  long long* c_slot;             // compacted: slot id
-  double* c_dist; double* c_angle; double* c_skew;
+  long long* c_slot;             // compacted (valid proposals in the reference's row order): slot id
+  double* c_dist; double* c_angle; double* c_skew;   // written by score_kernel
   int* c_flag;
 };
 

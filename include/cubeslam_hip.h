@@ -143,14 +143,22 @@ typedef struct cs_detect_timing {
   int n_fallback_boxes;              /* boxes whose ranking hit a tie and was redone on the host  */
   double rank_kernel_ms;
   double line_setup_ms;              /* line_setup_kernel (ROI filter + merge_break_lines on the device)  */
+  double score_kernel_ms;            /* score_kernel: distance + angle errors of the valid proposals       */
+  long long score_kernel_bytes;      /* its algorithmic bytes                                   */
 } cs_detect_timing;
 int cs_batch_last_timing(const cs_batch* b, cs_detect_timing* t);
 
 /* Bit 0: retain every valid proposal (rows, corners, kept ids) on the host during cs_batch_run() for the
  * cs_batch_debug_* getters (off by default: it costs the device-to-host copy of every proposal).
  * Bit 1: force the ranking stage onto the host (the exact std::partial_sort path that otherwise only handles
- * ties and roll/pitch sampling).  Bit 2: force the line setup (ROI filter + merge_break_lines) onto the host. */
+ * ties and roll/pitch sampling).  Bit 2: force the line setup (ROI filter + merge_break_lines) onto the host.
+ * Bit 3: take the general round-based code path even where the lean single-pass path applies. */
 int cs_batch_set_debug(cs_batch* b, int enable);
+
+/* Without roll/pitch sampling the boxes are independent and cs_batch_run() can cut the batch into n_chunks
+ * chunks that flow through a two-slot pipeline (host packing / record writing of one chunk overlaps the sweep of
+ * the next).  Default 1: on MI355X the sweep's kernels are long enough that one pass wins. */
+int cs_batch_set_pipeline_chunks(cs_batch* b, int n_chunks);
 
 /* Stage-by-stage inspection after cs_batch_run(), for parity tests.  (frame, box, k) names one
  * (box, height sample) job.  Rows follow all_configs_error_one_objH (box_proposal_detail.cpp:677-690):

@@ -199,3 +199,30 @@ def test_host_and_device_line_setup_agree():
     b = capi.Batch(det, frames, force_host_setup=True); b.run()
     assert a.raw_out_bytes() == b.raw_out_bytes()
     assert a.timing()["line_setup_ms"] > 0 and b.timing()["line_setup_ms"] < 0.05
+
+
+def test_chunk_pipeline_matches_single_pass():
+    """The lean production path cut into 4 chunks of a two-slot pipeline (host packs / finishes one chunk while the GPU sweeps the next);
+    the records must be byte-identical to the one-pass path, also on a second run that reuses the slots, with ragged
+    frames (no boxes, no lines) and tie boxes (host re-rank on the second stream) in the middle of the batch."""
+    uniq = [synth.make_frame(8500 + s, n_boxes=1 + s % 4, n_lines=150 + 20 * s) for s in range(12)]
+    empty = dict(uniq[0]); empty["boxes"] = np.zeros((0, 5)); empty["maps"] = []
+    nolines = dict(uniq[1]); nolines["lines"] = np.zeros((0, 4))
+    tie = synth.make_frame(8600, n_boxes=2, n_lines=150)
+    tie["maps"] = [[np.zeros_like(m) for m in mm] for mm in tie["maps"]]
+    frames = [uniq[i % 12] for i in range(70)]
+    frames[17] = empty; frames[18] = nolines; frames[40] = tie; frames[69] = empty
+    det = capi.Detector(capi.default_params(whether_sample_cam_roll_pitch=0, yaw_step_deg=3.0, max_cuboid_num=2))
+    a = capi.Batch(det, frames, pipeline_chunks=4); a.run()
+    b = capi.Batch(det, frames, force_no_pipeline=True); b.run()
+    c = capi.Batch(det, frames); c.run()     # default: the lean path in one pass
+    ref = b.raw_out_bytes()
+    assert c.raw_out_bytes() == ref; c.close()
+    assert a.raw_out_bytes() == ref
+    assert a.counts_bytes() == b.counts_bytes()
+    a.run()
+    assert a.raw_out_bytes() == ref
+    ta, tb = a.timing(), b.timing()
+    assert ta["cand_kernel_launches"] == 4 and tb["cand_kernel_launches"] == 1
+    assert ta["n_valid"] == tb["n_valid"] and ta["n_slots"] == tb["n_slots"] and ta["n_fallback_boxes"] == tb["n_fallback_boxes"] >= 2
+    a.close(); b.close(); det.close()
