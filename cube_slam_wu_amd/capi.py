@@ -254,7 +254,7 @@ class CsBaTiming(C.Structure):
 DECLARED_SYMBOLS += [
     "cs_ba_create", "cs_ba_destroy", "cs_ba_set_vertices", "cs_ba_set_estimates", "cs_ba_set_edges_proj", "cs_ba_set_edges_cuboid", "cs_ba_set_edges_odom",
     "cs_ba_compute_errors", "cs_ba_build_system", "cs_ba_solve", "cs_ba_update", "cs_ba_push", "cs_ba_pop", "cs_ba_optimize",
-    "cs_ba_get_state", "cs_ba_sizes", "cs_ba_get_system", "cs_ba_last_timing", "cs_ba_set_shard", "cs_ba_optimize_sharded",
+    "cs_ba_get_state", "cs_ba_sizes", "cs_ba_solver_layout", "cs_ba_get_system", "cs_ba_last_timing", "cs_ba_set_shard", "cs_ba_optimize_sharded",
     "cs_ba_shard_landmark_owners",
 ]
 
@@ -320,6 +320,11 @@ class BaProblem:
         Hpp, Hll, Hpl, b = np.zeros((n, n)), np.zeros((nl // 3, 9)), np.zeros((self.n_proj, 18)), np.zeros(n + nl)
         _chk(lib().cs_ba_get_system(self.h, _dp(Hpp), _dp(Hll), _dp(Hpl), _dp(b), None), "cs_ba_get_system")
         return Hpp, Hll, Hpl, b
+
+    def solver_layout(self):
+        a, b = C.c_int(), C.c_int()
+        _chk(lib().cs_ba_solver_layout(self.h, C.byref(a), C.byref(b)), "cs_ba_solver_layout")
+        return a.value, b.value
 
     def solve(self, lam):
         pd = C.c_int()

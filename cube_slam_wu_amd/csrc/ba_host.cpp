@@ -30,6 +30,7 @@ void ba_launch_reduce(const BaView& v, double lambda, hipStream_t st);
 void ba_launch_backsub(const BaView& v, hipStream_t st);
 void ba_launch_update(const BaView& v, hipStream_t st);
 void ba_launch_band_cholesky(double* Sb, double* Linv, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st);
+int ba_band_team(int LD, int* rw_out);
 }  // namespace cs
 
 extern "C" const char* cs_last_error(void);
@@ -211,7 +212,7 @@ int finalize_structure(cs_ba* B) {
       bw = std::max(bw, vdim(v) - 1);
       for (int w : adj[v]) { int lo = std::min(vcol(v), vcol(w)); int hi = (vcol(v) > vcol(w)) ? vcol(v) + vdim(v) - 1 : vcol(w) + vdim(w) - 1; bw = std::max(bw, hi - lo); }
     }
-    B->band_ld = (!B->force_dense && B->n_pose > 128 && bw + 1 <= B->n_pose / 2) ? bw + 1 : 0;
+    B->band_ld = (!B->force_dense && B->n_pose > 128 && bw + 1 <= B->n_pose / 2 && bw <= 4096) ? bw + 1 : 0;
   }
   // ---- this rank's projection edges
   {
@@ -333,7 +334,7 @@ int finalize_structure(cs_ba* B) {
   AL(B->Dinv, 9 * (size_t)np); AL(B->dbl, 3 * (size_t)np); B->s_doubles = (size_t)B->n_pose * (B->band_ld ? B->band_ld : B->n_pose);
   AL(B->S, B->s_doubles + B->n_pose);   // [S | rhs]: one buffer, one all-reduce in the sharded solve
   AL(B->xl, 3 * (size_t)np);
-  AL(B->d_band_info, 1);
+  AL(B->d_band_info, 4);   // [first bad pivot + 1, grid-barrier counter, a zero double]
   AL(B->band_linv, (size_t)((B->n_pose + 31) / 32) * 1024);
   B->nb_chi = cs::ba_chi2_blocks(E);
   B->n_chi_partials = B->nb_chi + (B->n_cub + B->n_odom + 63) / 64;
@@ -426,7 +427,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
     double t1 = now_ms();
     B->tm.reduce_ms += t1 - t0;
     if (B->band_ld) {
-      BA_TRY(hipMemsetAsync(B->d_band_info.p, 0, sizeof(int), B->st));
+      BA_TRY(hipMemsetAsync(B->d_band_info.p, 0, 4 * sizeof(int), B->st));
       cs::ba_launch_band_cholesky(B->S.p, B->band_linv.p, n, B->band_ld, B->view.rhs, B->d_band_info.p, true, B->st);
       BA_TRY(hipGetLastError());
       int info = 0;
@@ -739,6 +740,15 @@ int cs_ba_sizes(cs_ba* B, int* size_pose, int* size_lm) {
   int rc = finalize_structure(B); if (rc) return rc;
   if (size_pose) *size_pose = B->n_pose;
   if (size_lm) *size_lm = 3 * B->n_lm;
+  return CS_OK;
+}
+
+int cs_ba_solver_layout(cs_ba* B, int* band_ld, int* team) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  int rc = finalize_structure(B); if (rc) return rc;
+  int rw = 0;
+  if (band_ld) *band_ld = B->band_ld;
+  if (team) *team = B->band_ld ? cs::ba_band_team(B->band_ld, &rw) : 0;
   return CS_OK;
 }
 

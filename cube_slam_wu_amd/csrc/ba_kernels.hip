@@ -485,193 +485,347 @@ __global__ __launch_bounds__(256) void ba_update_kernel(BaView v) {
 // ------------------------------------------------------------------ banded Cholesky of the reduced system --
 // The pose graph of a trajectory is banded once its vertices are ordered by reverse Cuthill-McKee: cameras are
 // coupled to the few neighbours they share landmarks with and to the cuboids they observe.  S is stored as a lower
-// band (LD = bandwidth + 1 doubles per column) and factorised right-looking in column blocks of BS = 32:
-//   band_panel_kernel   POTF2 of the 32 x 32 diagonal block (redundantly per workgroup, in LDS) + TRSM of the panel
-//                       rows below it (one lane per row, the row in registers);
-//   band_syrk_kernel    trailing window (at most bandwidth rows) -= panel * panel^T, one 32 x 32 tile per workgroup;
-//   band_solve_kernel   forward + backward substitution, one workgroup walking the column blocks.
-// n * bw^2 flops instead of n^3 / 3: 0.4 Gflop instead of 385 Gflop at C4 (n = 10494, bw ~ 200).
+// band (LD = bandwidth + 1 doubles per column): n * bw^2 flops instead of n^3 / 3 (1 Gflop instead of 385 Gflop at
+// C4, n = 10491, bw ~ 300).  So little arithmetic that the factorisation is a chain of n / 32 dependent steps and
+// its cost is their latency; it therefore runs as ONE persistent kernel:
+//   band_chol_coop_kernel   left-looking over column blocks of BS = 32.  Per step every workgroup gathers the block
+//                           row's history (32 x bw strip of L) through LDS, updates + factorises the diagonal block
+//                           redundantly (POTF2 and its inverse in the registers of one wave), updates and scales its
+//                           own RW panel rows, and meets the others at a grid barrier (one per step).  The right-hand
+//                           side rides along as one more row below the band, so L y = b costs no extra step.
+//   band_backsolve_kernel   L^T x = y, one workgroup walking the column blocks backwards with the inverted diagonal
+//                           blocks (two small mat-vecs per step, one global round trip).
 enum { BS = 32 };
 
-// POTF2 of the diagonal block in registers (lane r owns row r; columns travel by wave shuffles), result to LDS
-__device__ __attribute__((noinline)) bool band_potf2_to_lds(const double* __restrict__ Sb, int LD, int k0, int nb, double (*D)[BS + 1]) {
-  const int lane = threadIdx.x;
-  double a[BS];
-#pragma unroll
-  for (int c = 0; c < BS; c++) a[c] = (lane < nb && c <= lane && lane - c < LD) ? Sb[(size_t)(k0 + c) * LD + (lane - c)] : ((c == lane) ? 1.0 : 0.0);
-  bool bad = false;
+// All workgroups of the (co-resident) grid arrive; thread 0 spins on the monotone counter.  Producer side: every
+// wave drains its stores, lane 0 writes the XCD's L2 back (agent-scope release; the explicit wait restates the one the
+// compiler may drop after buffer_wbl2) and arrives; consumer side: relaxed poll, one agent-scope acquire for the CU.
+__device__ __forceinline__ void band_grid_sync(unsigned* bar, unsigned target) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ double band_rdlane(double v, int l) {   // l uniform
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+// 1 / sqrt(x): hardware estimate + two Goldschmidt steps (this solver is held to a tolerance, not to bit parity)
+__device__ __forceinline__ double band_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  h = fma(h, r, h);
+  return h + h;
+}
+
+// Wave 0: Cholesky of the 32 x 32 block in U and the inverse of its factor, in one sweep over the columns.
+// Lanes 0..31 own row r of L, lanes 32..63 own column r of L^-1, both in the same register array v[]: once column c of
+// L is known, the trailing update of L, v[q] -= v[c] L(q, c), and the forward substitution of L^-1 are the same
+// instruction.  Column c travels unscaled through an LDS line (uniform-address reads) together with each lane's
+// v[c + 1], so every lane can form the NEXT pivot itself and its 1/sqrt leaves the critical path: per column the chain
+// is one LDS round trip and two multiply-adds.  colbuf: 2 x 128 doubles (double-buffered {v[c], v[c + 1]} pairs).
+__device__ __attribute__((noinline)) bool band_potf2_inv(const double (*U)[BS + 1], int nb, double (*Dl)[BS + 1], double (*X)[BS + 1], double* colbuf) {
+  const int lane = threadIdx.x & 63;
+  const int row = lane & 31;
+  const bool lower = lane < BS;
+  double v[BS + 1];
 #pragma unroll
   for (int c = 0; c < BS; c++) {
-    double dcc = __shfl(a[c], c);
-    if (c < nb && !(dcc > 0.0)) bad = true;
-    double sd = sqrt(dcc);
-    if (lane == c) a[c] = sd; else if (lane > c) a[c] = a[c] / sd;
-#pragma unroll
-    for (int q = c + 1; q < BS; q++) {
-      double lqc = __shfl(a[c], q);
-      if (lane >= q) a[q] -= a[c] * lqc;
-    }
+    const double u = U[row][c];
+    v[c] = (lower && row < nb && c <= row) ? u : ((c == row) ? 1.0 : 0.0);
   }
-  if (lane < BS) {
+  v[BS] = 0.0;
+  double piv = (nb > 0) ? U[0][0] : 1.0;   // pivot of column 0, uniform
+  int bad = 0;
 #pragma unroll
-    for (int c = 0; c < BS; c++) D[lane][c] = (c <= lane) ? a[c] : 0.0;
+  for (int c = 0; c < BS; c++) {
+    double* cbA = colbuf + (c & 1) * 128;   // column c of every lane
+    double* cbB = cbA + 64;                 // v[c + 1] of every lane (only lane c + 1's is read)
+    cbA[lane] = v[c]; cbB[lane] = v[c + 1];
+    __builtin_amdgcn_wave_barrier();
+    double col[BS];
+#pragma unroll
+    for (int q = c + 1; q < BS; q++) col[q] = cbA[q];     // one batch of uniform-address reads
+    const double nxt = (c + 1 < BS) ? cbB[c + 1] : 1.0;
+    bad |= (c < nb) & !(piv > 0.0);
+    const double rs = band_rsqrt(piv);
+    const double vc = v[c] * rs;    // L(row, c) for row >= c (the diagonal becomes d / sqrt(d)); X(c, col) in the upper lanes
+    const double vc2 = vc * rs;     // v[q] -= L(row, c) L(q, c) = (v[c] / d) * (unscaled column entry of row q)
+    v[c] = vc;
+    if (c + 1 < BS) piv = fma(-(col[c + 1] * rs * rs), col[c + 1], nxt);   // next pivot, with lane c + 1's own arithmetic
+#pragma unroll
+    for (int q = c + 1; q < BS; q++) v[q] = fma(-vc2, col[q], v[q]);
   }
-  return bad;
+  double* dst = lower ? &Dl[row][0] : &X[0][row];
+  const int stride = lower ? 1 : BS + 1;
+#pragma unroll
+  for (int c = 0; c < BS; c++) dst[c * stride] = ((lower ? row - c : c - row) >= 0) ? v[c] : 0.0;
+  return bad != 0;
 }
 
-__global__ __launch_bounds__(64) void band_panel_kernel(double* __restrict__ Sb, double* __restrict__ Linv, int n, int LD, int k0, int* info, int dbg) {
-  __shared__ double D[BS][BS + 1];   // L of the diagonal block
-  __shared__ double X[BS][BS + 1];   // L^-1
-  __shared__ double P[64][BS + 1];   // this workgroup's 64 panel rows
-  const int lane = threadIdx.x;
-  const int nb = min(BS, n - k0);
-  bool bad = false;
-  if (dbg == 1) { for (int e = lane; e < BS * BS; e += 64) D[e / BS][e % BS] = (e / BS == e % BS) ? 1.0 : 0.0; } else bad = band_potf2_to_lds(Sb, LD, k0, nb, D);
-  if (bad && lane == 0 && blockIdx.x == 0) atomicCAS(info, 0, k0 + 1);
-  // this workgroup's panel rows (loaded while the factor settles)
-  const int i = k0 + nb + blockIdx.x * 64 + lane;
-  const int i_end = min(n, k0 + nb - 1 + LD);  // last row inside the band of the block's last column
-  for (int c = 0; c < BS; c++) P[lane][c] = (i < i_end && c < nb && i - (k0 + c) < LD) ? Sb[(size_t)(k0 + c) * LD + (i - k0 - c)] : 0.0;
-  __syncthreads();
-  if (blockIdx.x == 0)
-    for (int e = lane; e < BS * BS; e += 64) {
-      int r = e / BS, c = e % BS;
-      if (r < nb && c <= r && r - c < LD) Sb[(size_t)(k0 + c) * LD + (r - c)] = D[r][c];
-    }
-  // inverse of L: lane c < 32 solves L x = e_c by forward substitution; L(r, q) is a broadcast LDS read
-  if (lane < BS && dbg != 2) {
-    for (int r = 0; r < BS; r++) X[r][lane] = 0.0;
-    for (int r = 0; r < BS; r++) {
-      double sacc = (r == lane) ? 1.0 : 0.0;
-#pragma unroll 8
-      for (int q = 0; q < r; q++) sacc -= D[r][q] * X[q][lane];   // X(q, lane) = 0 for q < lane (rows start zeroed below)
-      X[r][lane] = (r >= lane) ? sacc / D[r][r] : 0.0;
-    }
-  }
-  __syncthreads();
-  if (blockIdx.x == 0) {
-    double* Li = Linv + (size_t)(k0 / BS) * BS * BS;
-    for (int e = lane; e < BS * BS; e += 64) Li[e] = X[e / BS][e % BS];
-  }
-  // panel rows: P(i, :) <- P(i, :) L^-T, i.e. out[c] = sum_{q <= c} P(i, q) Linv(c, q)
-  if (i < i_end && dbg != 3) {
-    for (int c = 0; c < nb; c++) {
-      double sacc = 0;
-#pragma unroll 8
-      for (int q = 0; q <= c; q++) sacc += P[lane][q] * X[c][q];
-      if (i - (k0 + c) < LD) Sb[(size_t)(k0 + c) * LD + (i - k0 - c)] = sacc;
-    }
-  }
-}
+typedef const __attribute__((address_space(1))) double* band_gptr;   // global address space: a noinline function would otherwise emit flat loads
+__device__ __forceinline__ double band_gload(const double* p) { return *(band_gptr)(p); }
 
-// trailing update: T(i, j) -= sum_c P(i, c) P(j, c) for i >= j in the window below / right of the block
-__global__ __launch_bounds__(256) void band_syrk_kernel(double* __restrict__ Sb, int n, int LD, int k0, int nt) {
-  __shared__ double Pi[BS][BS + 1], Pj[BS][BS + 1];
-  // tile index -> (ti, tj), ti >= tj
-  int t = blockIdx.x, ti = 0;
-  while (t >= ti + 1) { t -= ti + 1; ti++; }
-  const int tj = t;
-  if (ti >= nt) return;
-  const int nb = min(BS, n - k0);
-  const int w0 = k0 + nb;
-  const int i_end = min(n, k0 + nb - 1 + LD);
-  const int ri = w0 + ti * BS, rj = w0 + tj * BS;
-  for (int e = threadIdx.x; e < BS * BS; e += 256) {
-    int r = e / BS, c = e % BS;
-    int gi = ri + r, gj = rj + r;
-    Pi[r][c] = (gi < i_end && c < nb && gi - (k0 + c) < LD) ? Sb[(size_t)(k0 + c) * LD + (gi - k0 - c)] : 0.0;
-    Pj[r][c] = (gj < i_end && c < nb && gj - (k0 + c) < LD) ? Sb[(size_t)(k0 + c) * LD + (gj - k0 - c)] : 0.0;
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < BS * BS; e += 256) {
-    int r = e / BS, q = e % BS;
-    int gi = ri + r, gj = rj + q;
-    if (gi < i_end && gj < i_end && gi >= gj && gi - gj < LD) {
-      double acc = 0;
+enum { BAND_RW = 16, BAND_NR = BS + BAND_RW + 8, BAND_NRP = 64, BAND_NRT = BAND_NR / 8, BAND_TR = BAND_NRP / 8, BAND_DC = 192, BAND_NV = BAND_DC * BAND_NRP / 256 };
+
+// Strip gather + product of one step: U(rr, c) = A(rr, k0 + c) - sum_j L(rr, j) L(k0 + c, j) for the 32 block rows and
+// this workgroup's rows.  A thread gathers ONE row (rr = tid & 63) at every fourth column, so the addresses are a
+// pointer walk, and all BAND_NV loads are unconditional (masked lanes read the zero word) and in flight together.
+__device__ __attribute__((noinline)) void band_gather_gemm(const double* Sb, const double* rhs, const double* zero, int LD, int k0, int nb, const int* rowidx,
+                                                           double* R, double (*U)[BS + 1], long long* tp, long long* t_prev) {
+  constexpr int NR = BAND_NR, NRP = BAND_NRP, NRT = BAND_NRT, TR = BAND_TR, NV = BAND_NV, DC = BAND_DC;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int cg = lane & 7, rgp = lane >> 3;     // register tile: rows 8 rgp .. 8 rgp + 7 of the 64 padded rows, columns 4 cg .. 4 cg + 3
+  const int c1 = tid & 31, rg1 = tid >> 5;      // one-column mapping of the finishing pass
+  const int bw = LD - 1;
+#define BAND_TICK(k) do { if (tp) { long long t_now = wall_clock64(); tp[k] += t_now - *t_prev; *t_prev = t_now; } } while (0)
+  // the block's own columns (A of U = A - sum): loads in flight while the strip is gathered
+  double aval[NRT];
 #pragma unroll
-      for (int c = 0; c < BS; c++) acc += Pi[r][c] * Pj[q][c];
-      Sb[(size_t)gj * LD + (gi - gj)] -= acc;
-    }
+  for (int m = 0; m < NRT; m++) {
+    const int i = rowidx[rg1 + 8 * m], dlt = i - (k0 + c1);
+    const bool ok = c1 < nb && (i == -2 || (i >= 0 && dlt >= 0 && dlt <= bw));
+    const double* ptr = (i == -2) ? rhs + (k0 + c1) : Sb + (size_t)(k0 + c1) * LD + dlt;
+    aval[m] = band_gload(ok ? ptr : zero);
   }
+  double acc[TR][4];
+#pragma unroll
+  for (int m = 0; m < TR; m++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[m][t] = 0.0;
+  const int jlo = max(0, k0 - bw);
+  const int my_i = lane < NR ? rowidx[lane] : -1;            // the row this thread gathers
+  const int jmin = my_i >= 0 ? max(jlo, my_i - bw) : jlo;    // in-band columns of that row: j >= i - bw
+  double vals[NV];
+  auto fetch = [&](int j0) {
+    const int jend = (my_i == -1) ? 0 : min(k0, j0 + DC);
+    int j = j0 + wv;
+    const double* p = (my_i == -2) ? rhs + j : Sb + (size_t)j * bw + (my_i >= 0 ? my_i : 0);   // &Sb[j * LD + (i - j)]
+    const size_t step = (my_i == -2) ? 4 : 4 * (size_t)bw;
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+      const bool ok = j >= jmin && j < jend;
+      vals[u] = band_gload(ok ? p : zero);
+      p += step; j += 4;
+    }
+  };
+  if (jlo < k0) fetch(jlo);
+  BAND_TICK(6);
+  for (int j0 = jlo; j0 < k0; j0 += DC) {
+    const int jn = min(DC, k0 - j0);
+#pragma unroll
+    for (int u = 0; u < NV; u++) R[(wv + 4 * u) * NRP + lane] = vals[u];
+    __syncthreads();
+    BAND_TICK(7);
+    if (j0 + DC < k0) fetch(j0 + DC);
+    BAND_TICK(6);
+    // this wave's quarter of the depth: acc(rows, cols) += R(jj, rows) * R(jj, cols)   (LDS-bandwidth bound: 96 B of
+    // operands per lane and depth index for 32 multiply-adds)
+#pragma unroll 4
+    for (int jj = wv; jj < jn; jj += 4) {
+      const double* rj = R + jj * NRP;
+      double colv[4], rowv[TR];
+#pragma unroll
+      for (int t = 0; t < 4; t++) colv[t] = rj[4 * cg + t];
+#pragma unroll
+      for (int m = 0; m < TR; m++) rowv[m] = rj[rgp * TR + m];
+#pragma unroll
+      for (int m = 0; m < TR; m++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[m][t] = fma(rowv[m], colv[t], acc[m][t]);
+    }
+    __syncthreads();
+    BAND_TICK(8);
+  }
+  // partial sums of the 4 waves -> LDS (over the strip buffer), then U = A - sum
+#pragma unroll
+  for (int m = 0; m < TR; m++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) R[(wv * NRP + rgp * TR + m) * BS + 4 * cg + t] = acc[m][t];
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < NRT; m++) {
+    const int rr = rg1 + 8 * m;
+    const double sum = (R[(0 * NRP + rr) * BS + c1] + R[(1 * NRP + rr) * BS + c1]) + (R[(2 * NRP + rr) * BS + c1] + R[(3 * NRP + rr) * BS + c1]);
+    U[rr][c1] = aval[m] - sum;
+  }
+  __syncthreads();
+  BAND_TICK(1);
+#undef BAND_TICK
 }
 
-// L y = b, then L^T x = y, in place in rhs; one workgroup walks the column blocks.  The diagonal blocks were inverted
-// by band_panel_kernel, so each block step is two small mat-vecs instead of a 32-step triangular recurrence.
-__global__ __launch_bounds__(256) void band_solve_kernel(const double* __restrict__ Sb, const double* __restrict__ Linv, int n, int LD, double* rhs) {
-  __shared__ double y[BS], z[BS];
-  __shared__ double Li[BS][BS + 1];
-  __shared__ double part[8][BS];
+__global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double* __restrict__ Linv, double* rhs, const double* zero, int n, int LD,
+                                                             int* info, unsigned* bar, int G, int xcd_shift, long long* prof) {
+  constexpr int RW = BAND_RW, NR = BAND_NR;
+  __shared__ double R[BAND_DC * BAND_NRP];   // strip chunk, transposed: R[jj * 64 + rr]; afterwards the 4 waves' partial sums
+  __shared__ double U[NR][BS + 1];
+  __shared__ double Dl[BS][BS + 1];
+  __shared__ double X[BS][BS + 1];
+  __shared__ double colbuf[2 * 128];
+  __shared__ int rowidx[NR];
+  const int w = blockIdx.x >> xcd_shift;
+  if ((blockIdx.x & ((1 << xcd_shift) - 1)) != 0) return;
   const int tid = threadIdx.x;
   const int bw = LD - 1;
-  const int nblk = (n + BS - 1) / BS;
-  // ---- forward: L y = b
-  for (int kb = 0; kb < nblk; kb++) {
-    const int k0 = kb * BS, nb = min(BS, n - k0);
-    for (int e = tid; e < BS * BS; e += 256) Li[e / BS][e % BS] = Linv[(size_t)kb * BS * BS + e];
-    if (tid < BS) z[tid] = (tid < nb) ? rhs[k0 + tid] : 0.0;
-    __syncthreads();
-    if (tid < BS) {
-      double acc = 0;
-#pragma unroll 8
-      for (int q = 0; q < BS; q++) acc += Li[tid][q] * z[q];   // upper part of Li is zero
-      y[tid] = acc;
-      if (tid < nb) rhs[k0 + tid] = acc;
+  const bool has_rhs = (w == G - 1);
+  unsigned epoch = 0;
+  long long tp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = prof ? wall_clock64() : 0;   // optional phase clock (CS_BAND_PROF)
+  const long long c_begin = prof ? clock64() : 0, w_begin = t_prev;
+#define BAND_TICK(k) do { if (prof) { long long t_now = wall_clock64(); tp[k] += t_now - t_prev; t_prev = t_now; } } while (0)
+  for (int k0 = 0; k0 < n; k0 += BS) {
+    const int nb = min(BS, n - k0);
+    const int i_end = min(n, k0 + nb + bw);           // panel rows: k0 + nb .. i_end - 1
+    const int own0 = k0 + nb + w * RW;
+    if (tid < NR) {                                   // global row of gathered row rr; -1 = none, -2 = right-hand side
+      int i = -1;
+      if (tid < BS) i = tid < nb ? k0 + tid : -1;
+      else if (tid - BS < RW) { int q = own0 + (tid - BS); i = q < i_end ? q : -1; }
+      else if (tid - BS == RW && has_rhs) i = -2;
+      rowidx[tid] = i;
     }
     __syncthreads();
-    const int i_end = min(n, k0 + nb + bw);
-    for (int i = k0 + nb + tid; i < i_end; i += 256) {
-      double acc = 0;
-#pragma unroll 8
-      for (int c = 0; c < nb; c++) if (i - (k0 + c) <= bw) acc += Sb[(size_t)(k0 + c) * LD + (i - k0 - c)] * y[c];
-      rhs[i] -= acc;
+    band_gather_gemm(Sb, rhs, zero, LD, k0, nb, rowidx, R, U, prof ? tp : nullptr, &t_prev);
+    if (tid < 64) {
+      bool bad = band_potf2_inv(U, nb, Dl, X, colbuf);
+      if (bad && tid == 0 && w == 0) atomicCAS(info, 0, k0 + 1);
     }
     __syncthreads();
+    BAND_TICK(2);
+    // own rows (and the right-hand side): row <- row * L^-T
+    for (int e = tid; e < (RW + 1) * BS; e += 256) {
+      const int q = e >> 5, cc = e & 31, rr = BS + q, i = rowidx[rr];
+      if (cc < nb && i != -1) {
+        double sacc = 0.0;
+#pragma unroll 8
+        for (int t = 0; t <= cc; t++) sacc = fma(U[rr][t], X[cc][t], sacc);
+        if (i >= 0) { const int dlt = i - (k0 + cc); if (dlt <= bw) Sb[(size_t)(k0 + cc) * LD + dlt] = sacc; }
+        else rhs[k0 + cc] = sacc;
+      }
+    }
+    if (w == 0) {
+      double* Li = Linv + (size_t)(k0 / BS) * BS * BS;
+      for (int e = tid; e < BS * BS; e += 256) Li[e] = X[e >> 5][e & 31];
+    }
+    epoch++;
+    BAND_TICK(4);
+    if (k0 + BS < n) band_grid_sync(bar, epoch * (unsigned)G);
+    // L's diagonal block replaces A's only now: until the barrier the other workgroups may still be reading A's block
+    // (every one of them factorises it redundantly); nothing in later steps reads it (they use Linv)
+    if (w == 0)
+      for (int e = tid; e < BS * BS; e += 256) {
+        const int r = e >> 5, cc = e & 31;
+        if (r < nb && cc <= r && r - cc <= bw) Sb[(size_t)(k0 + cc) * LD + (r - cc)] = Dl[r][cc];
+      }
+    BAND_TICK(5);
   }
-  // ---- backward: L^T x = y
+  if (prof && tid == 0 && (w == 0 || w == G - 1)) for (int k = 0; k < 9; k++) prof[(w == 0 ? 0 : 9) + k] = tp[k];
+  if (prof && tid == 0 && w == 0) { prof[18] = clock64() - c_begin; prof[19] = wall_clock64() - w_begin; }
+#undef BAND_TICK
+}
+
+// L^T x = y in place in rhs; one workgroup walks the column blocks backwards.  Per block: t = (rows below)^T x with x
+// from an LDS window, x_k = L_kk^-T (y_k - t) with the inverted diagonal block.  Everything a step reads from memory
+// (its panel of L, L_kk^-1, y_k) is independent of x and is fetched one step ahead, all loads unconditional.
+__global__ __launch_bounds__(256) void band_backsolve_kernel(const double* __restrict__ Sb, const double* __restrict__ Linv, const double* __restrict__ zero, int n, int LD, double* rhs) {
+  enum { WIN = 8192, PF = 24 };      // x window (a step touches <= 32 + 4096 consecutive rows); prefetched rows per thread
+  __shared__ double xw[WIN];
+  __shared__ double z[BS];
+  __shared__ double Li[BS][BS + 1];
+  __shared__ double part[8][BS];
+  const int tid = threadIdx.x, c = tid & 31, g = tid >> 5;
+  const int bw = LD - 1;
+  const int nblk = (n + BS - 1) / BS;
+  for (int e = tid; e < WIN; e += 256) xw[e] = 0.0;
+  double lv[PF], li[4], yv = 0.0;
+  auto prefetch = [&](int kb) {
+    const int k0 = kb * BS, nb = min(BS, n - k0), i_end = min(n, k0 + nb + bw);
+    const double* col = Sb + (size_t)(k0 + c) * LD - (k0 + c);     // &L(i, k0 + c) = col + i
+#pragma unroll
+    for (int s = 0; s < PF; s++) {
+      const int i = k0 + nb + g + 8 * s;
+      const bool ok = c < nb && i < i_end && i - (k0 + c) <= bw;
+      lv[s] = *(ok ? col + i : zero);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) li[u] = Linv[(size_t)kb * BS * BS + tid + 256 * u];
+    yv = (tid < nb) ? rhs[k0 + tid] : 0.0;
+  };
+  prefetch(nblk - 1);
+  __syncthreads();
   for (int kb = nblk - 1; kb >= 0; kb--) {
     const int k0 = kb * BS, nb = min(BS, n - k0);
     const int i_end = min(n, k0 + nb + bw);
-    for (int e = tid; e < BS * BS; e += 256) Li[e / BS][e % BS] = Linv[(size_t)kb * BS * BS + e];
-    {
-      int c = tid & 31, g = tid >> 5;  // 8 groups of rows; t[c] = sum_{i below the block} L(i, k0 + c) x[i]
-      double acc = 0;
-      if (c < nb)
-        for (int i = k0 + nb + g; i < i_end; i += 8) if (i - (k0 + c) <= bw) acc += Sb[(size_t)(k0 + c) * LD + (i - k0 - c)] * rhs[i];
-      part[g][c] = acc;
-    }
+    double acc = 0;   // t[c] = sum over the rows below the block of L(i, k0 + c) x[i]; 8 row groups
+#pragma unroll
+    for (int s = 0; s < PF; s++) acc = fma(lv[s], xw[(k0 + nb + g + 8 * s) & (WIN - 1)], acc);
+    if (c < nb)
+      for (int i = k0 + nb + g + 8 * PF; i < i_end; i += 8) if (i - (k0 + c) <= bw) acc = fma(Sb[(size_t)(k0 + c) * LD + (i - k0 - c)], xw[i & (WIN - 1)], acc);
+    part[g][c] = acc;
+#pragma unroll
+    for (int u = 0; u < 4; u++) { int e = tid + 256 * u; Li[e >> 5][e & 31] = li[u]; }
     __syncthreads();
     if (tid < BS) {
       double tt = 0;
-      for (int g = 0; g < 8; g++) tt += part[g][tid];
-      z[tid] = (tid < nb) ? rhs[k0 + tid] - tt : 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; q++) tt += part[q][tid];
+      z[tid] = (tid < nb) ? yv - tt : 0.0;
     }
     __syncthreads();
+    if (kb > 0) prefetch(kb - 1);
     if (tid < nb) {
-      double acc = 0;
+      double a2 = 0;
 #pragma unroll 8
-      for (int r = 0; r < BS; r++) acc += Li[r][tid] * z[r];   // (L^-1)^T z (Li is lower triangular: zeros above)
-      rhs[k0 + tid] = acc;
+      for (int r = 0; r < BS; r++) a2 = fma(Li[r][tid], z[r], a2);   // (L^-1)^T z
+      rhs[k0 + tid] = a2;
+      xw[(k0 + tid) & (WIN - 1)] = a2;
     }
     __syncthreads();
   }
 }
 
-void ba_launch_band_cholesky(double* Sb, double* Linv, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st) {
+int ba_band_team(int LD, int* rw_out) {   // workgroups of the factorisation team and their rows per step
   const int bw = LD - 1;
-  static const int dbg = getenv("CS_BAND_DEBUG") ? atoi(getenv("CS_BAND_DEBUG")) : 0;
-  for (int k0 = 0; k0 < n; k0 += BS) {
-    int nb = n - k0 < BS ? n - k0 : BS;
-    int rows = n - (k0 + nb);
-    if (rows > bw) rows = bw;  // rows below the block inside the band of its last column
-    if (rows < 0) rows = 0;
-    int g = (rows + 63) / 64;
-    hipLaunchKernelGGL(band_panel_kernel, dim3(g < 1 ? 1 : g), dim3(64), 0, st, Sb, Linv, n, LD, k0, info, dbg);
-    if (rows > 0) {
-      int nt = (rows + BS - 1) / BS;
-      hipLaunchKernelGGL(band_syrk_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, Sb, n, LD, k0, nt);
+  int G = (bw + BAND_RW - 1) / BAND_RW;
+  if (G < 1) G = 1;
+  *rw_out = BAND_RW;
+  return G;
+}
+
+// info[0] = first non-positive pivot (+1), info[1] = barrier counter, info[2..3] = a zero double (the target of masked
+// loads); all zeroed by the caller.
+void ba_launch_band_cholesky(double* Sb, double* Linv, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st) {
+  int rw = 0;
+  const int G = ba_band_team(LD, &rw);
+  unsigned* bar = reinterpret_cast<unsigned*>(info + 1);
+  const double* zero = reinterpret_cast<const double*>(info + 2);
+  static const bool want_prof = getenv("CS_BAND_PROF") != nullptr;   // diagnostics: phase clock of the first / last workgroup
+  static long long* prof = nullptr;
+  static const int xs = getenv("CS_BAND_ONE_XCD") ? 3 : 0;   // diagnostics: confine the team to one XCD (slower barrier, measured)
+  if (want_prof && !prof) (void)hipMalloc(&prof, 20 * sizeof(long long));
+  hipLaunchKernelGGL(band_chol_coop_kernel, dim3(G << xs), dim3(256), 0, st, Sb, Linv, rhs, zero, n, LD, info, bar, G, xs, prof);
+  if (prof) {
+    long long h[20];
+    (void)hipMemcpyAsync(h, prof, sizeof(h), hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    static int shown = 0;
+    if (shown++ < 3) {
+      fprintf(stderr, "[band] shader clock %.0f MHz over %.0f us\n", h[18] / (h[19] * 0.01), h[19] * 0.01);
+      for (int q = 0; q < 2; q++)
+        fprintf(stderr, "[band] n=%d LD=%d G=%d wg%s us: fetch-issue %.0f  store+wait %.0f  gemm %.0f  reduce+U %.0f  potf2+inverse %.0f  panel %.0f  barrier %.0f\n", n, LD, G, q ? "last" : "0",
+                h[9 * q + 6] * 0.01, h[9 * q + 7] * 0.01, h[9 * q + 8] * 0.01, h[9 * q + 1] * 0.01, h[9 * q + 2] * 0.01, h[9 * q + 4] * 0.01, h[9 * q + 5] * 0.01);
     }
   }
-  if (solve) hipLaunchKernelGGL(band_solve_kernel, dim3(1), dim3(256), 0, st, Sb, Linv, n, LD, rhs);
+  if (solve) hipLaunchKernelGGL(band_backsolve_kernel, dim3(1), dim3(256), 0, st, Sb, Linv, zero, n, LD, rhs);
 }
 
 // ---------------------------------------------------------------------------------------- launchers --

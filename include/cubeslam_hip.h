@@ -236,6 +236,10 @@ int cs_ba_shard_landmark_owners(int n_ranks, int n_cams, int n_points, int n_pro
 
 int cs_ba_get_state(cs_ba* ba, double* cams7, double* cuboids10, double* points3);
 int cs_ba_sizes(cs_ba* ba, int* size_pose, int* size_landmarks);
+/* How the reduced (pose) system is solved: band_ld > 0 = reverse Cuthill-McKee ordering + banded Cholesky with
+ * band_ld = bandwidth + 1 (one persistent kernel, `team` workgroups); band_ld == 0 = dense rocSOLVER potrf/potrs
+ * (graphs whose bandwidth exceeds half the system, systems under 128 unknowns). */
+int cs_ba_solver_layout(cs_ba* ba, int* band_ld, int* team);
 /* Inspection for parity tests (host copies, caller-sized): dense Hpp (size_pose^2, no lambda), Hll (9 per
  * free point in point order), Hpl (18 per projection edge in the caller's edge order), b, x.            */
 int cs_ba_get_system(cs_ba* ba, double* Hpp_dense, double* Hll9, double* Hpl18, double* b, double* x);

@@ -1,0 +1,76 @@
+// band_bench -- standalone timing + residual check of the banded Cholesky kernels (development tool, not shipped).
+//   hipcc --offload-arch=gfx950 -O3 -x hip tools/microbench/band_bench.cpp cube_slam_wu_amd/csrc/ba_kernels.o -o /tmp/band_bench
+//   /tmp/band_bench [n] [LD] [reps]
+#include <hip/hip_runtime.h>
+#pragma clang diagnostic ignored "-Wunused-value"
+#pragma clang diagnostic ignored "-Wunused-result"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace cs {
+void ba_launch_band_cholesky(double* Sb, double* Linv, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st);
+}
+
+int main(int argc, char** argv) {
+  int n = argc > 1 ? atoi(argv[1]) : 10494, LD = argc > 2 ? atoi(argv[2]) : 183, reps = argc > 3 ? atoi(argv[3]) : 5;
+  const int bw = LD - 1;
+  // SPD band: random off-diagonals in [-1, 1], diagonal = row sum of |.| + 1
+  std::vector<double> A((size_t)n * LD, 0.0), b(n), diag(n, 1.0);
+  unsigned long long s = 12345;
+  auto rnd = [&]() { s = s * 6364136223846793005ULL + 1442695040888963407ULL; return ((s >> 11) * (1.0 / 9007199254740992.0)) * 2 - 1; };
+  for (int c = 0; c < n; c++)
+    for (int d = 1; d <= bw && c + d < n; d++) { double v = rnd(); A[(size_t)c * LD + d] = v; diag[c] += std::fabs(v); diag[c + d] += std::fabs(v); }
+  for (int c = 0; c < n; c++) { A[(size_t)c * LD] = diag[c]; b[c] = rnd(); }
+  double *dS, *dL, *dr; int* dinfo;
+  const int nblk = (n + 31) / 32;
+  hipMalloc(&dS, A.size() * 8); hipMalloc(&dL, (size_t)nblk * 1024 * 8); hipMalloc(&dr, n * 8); hipMalloc(&dinfo, 16);
+  hipStream_t st; hipStreamCreate(&st);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  std::vector<double> x(n);
+  for (int r = 0; r < reps; r++) {
+    // a different system every repetition (stale cached values of the previous one must not look right)
+    if (r > 0) { for (auto& v : A) v *= 1.25; for (int c = 0; c < n; c++) A[(size_t)c * LD] += 0.5 * r; for (auto& v : b) v = rnd(); }
+    hipMemcpyAsync(dS, A.data(), A.size() * 8, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(dr, b.data(), n * 8, hipMemcpyHostToDevice, st);
+    hipMemsetAsync(dinfo, 0, 16, st);
+    hipEventRecord(e0, st);
+    cs::ba_launch_band_cholesky(dS, dL, n, LD, dr, dinfo, true, st);
+    hipEventRecord(e1, st);
+    hipStreamSynchronize(st);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    int info[2]; hipMemcpy(info, dinfo, 8, hipMemcpyDeviceToHost);
+    hipMemcpy(x.data(), dr, n * 8, hipMemcpyDeviceToHost);
+    // residual ||A x - b||_inf / ||b||_inf
+    double rmax = 0, bmax = 0;
+    for (int i = 0; i < n; i++) {
+      double acc = 0;
+      for (int j = std::max(0, i - bw); j <= std::min(n - 1, i + bw); j++) acc += (j <= i ? A[(size_t)j * LD + (i - j)] : A[(size_t)i * LD + (j - i)]) * x[j];
+      rmax = std::max(rmax, std::fabs(acc - b[i])); bmax = std::max(bmax, std::fabs(b[i]));
+    }
+    printf("rep %d: factor+solve %.3f ms  info %d  residual %.3e\n", r, ms, info[0], rmax / bmax);
+    if (rmax / bmax > 1e-9) {   // locate the first wrong entry of L against a CPU band Cholesky
+      std::vector<double> L(A), Lg(A.size());
+      hipMemcpy(Lg.data(), dS, A.size() * 8, hipMemcpyDeviceToHost);
+      for (int c = 0; c < n; c++) {
+        for (int j = std::max(0, c - bw); j < c; j++) {
+          double ljc = L[(size_t)j * LD + (c - j)];
+          if (ljc == 0.0) continue;
+          for (int i = c; i <= std::min(n - 1, j + bw); i++) L[(size_t)c * LD + (i - c)] -= L[(size_t)j * LD + (i - j)] * ljc;
+        }
+        double d = std::sqrt(L[(size_t)c * LD]);
+        L[(size_t)c * LD] = d;
+        for (int i = c + 1; i <= std::min(n - 1, c + bw); i++) L[(size_t)c * LD + (i - c)] /= d;
+      }
+      int shown = 0;
+      for (int c = 0; c < n && shown < 12; c++)
+        for (int d = 0; d <= bw && c + d < n; d++) {
+          double ref = L[(size_t)c * LD + d], got = Lg[(size_t)c * LD + d];
+          if (std::fabs(ref - got) > 1e-9 * (1 + std::fabs(ref))) { printf("  L(%d, %d) [block col %d, row offset %d]: got %.6e want %.6e\n", c + d, c, c / 32, c + d - (c / 32) * 32 - 32, got, ref); if (++shown >= 12) break; }
+        }
+    }
+  }
+  return 0;
+}

@@ -1,0 +1,7 @@
+#!/bin/bash
+# builds build_tmp/band_bench against the current ba_kernels.o (run `make -C cube_slam_wu_amd/csrc` first)
+set -e
+cd "$(dirname "$0")/../.."
+mkdir -p build_tmp
+hipcc --offload-arch=gfx950 -O3 -c -x hip tools/microbench/band_bench.cpp -o build_tmp/band_bench.o
+hipcc --offload-arch=gfx950 build_tmp/band_bench.o cube_slam_wu_amd/csrc/ba_kernels.o -o build_tmp/band_bench
