@@ -218,83 +218,100 @@ __global__ __launch_bounds__(256) void ba_lin_pt_kernel(BaView v) {
 }
 
 // ---- numeric-Jacobian edges -------------------------------------------------------------------------
-// blocks: Haa += Ja^T Om Ja, Hab += Ja^T Om Jb, Hbb += Jb^T Om Jb, ba += -Ja^T Om e, bb += -Jb^T Om e
-template <int D, int DA, int DB>
-__device__ void edge_blocks(const double* Ja, const double* Jb, const double* e, const double* info, double* Haa, double* Hbb, double* Hab, double* ba, double* bb) {
-  double Oe[D];
-  for (int i = 0; i < D; i++) { double s = 0; for (int j = 0; j < D; j++) s += info[D * i + j] * e[j]; Oe[i] = -s; }
-  for (int i = 0; i < DA; i++) { double s = 0; for (int k = 0; k < D; k++) s += Ja[k * DA + i] * Oe[k]; ba[i] = s; }
-  for (int i = 0; i < DB; i++) { double s = 0; for (int k = 0; k < D; k++) s += Jb[k * DB + i] * Oe[k]; bb[i] = s; }
-  for (int i = 0; i < DA; i++) {
-    double t[D];
-    for (int j = 0; j < D; j++) { double s = 0; for (int k = 0; k < D; k++) s += Ja[k * DA + i] * info[D * k + j]; t[j] = s; }
-    for (int j = 0; j < DA; j++) { double s = 0; for (int k = 0; k < D; k++) s += t[k] * Ja[k * DA + j]; Haa[i * DA + j] = s; }
-    for (int j = 0; j < DB; j++) { double s = 0; for (int k = 0; k < D; k++) s += t[k] * Jb[k * DB + j]; Hab[i * DB + j] = s; }
-  }
-  for (int i = 0; i < DB; i++) {
-    double t[D];
-    for (int j = 0; j < D; j++) { double s = 0; for (int k = 0; k < D; k++) s += Jb[k * DB + i] * info[D * k + j]; t[j] = s; }
-    for (int j = 0; j < DB; j++) { double s = 0; for (int k = 0; k < D; k++) s += t[k] * Jb[k * DB + j]; Hbb[i * DB + j] = s; }
+// One edge per 16 lanes: lane d evaluates the two perturbed errors of Jacobian column d (lane 15 the unperturbed
+// error), the columns meet in LDS, and lane i then forms row i of J^T Omega J and of -J^T Omega e.
+// NA / NB = tangent dimensions of the two vertices, D = error dimension; J is stored J[d][r] (column d, row r).
+template <int D, int NA, int NB>
+__device__ __forceinline__ void edge_rows_from_columns(const double (*J)[D], const double* e0, const double* __restrict__ info, int i,
+                                                       double* Haa, double* Hbb, double* Hab, double* ba, double* bb) {
+  constexpr int N = NA + NB;
+  if (i >= N) return;
+  double t[D];   // t = J(:, i)^T Omega
+#pragma unroll
+  for (int j = 0; j < D; j++) { double s = 0; for (int k = 0; k < D; k++) s = fma(J[i][k], info[D * k + j], s); t[j] = s; }
+  double bi = 0;
+#pragma unroll
+  for (int k = 0; k < D; k++) bi = fma(t[k], e0[k], bi);
+  if (i < NA) ba[i] = -bi; else bb[i - NA] = -bi;
+  for (int j = 0; j < N; j++) {
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < D; k++) s = fma(t[k], J[j][k], s);
+    if (i < NA) { if (j < NA) Haa[i * NA + j] = s; else Hab[i * NB + (j - NA)] = s; }
+    else if (j >= NA) Hbb[(i - NA) * NB + (j - NA)] = s;
   }
 }
 
 __global__ __launch_bounds__(64) void ba_cub_edge_kernel(BaView v) {
-  int k = blockIdx.x * 64 + threadIdx.x;
-  if (k >= v.n_cub) return;
+  __shared__ double J[4][16][9];    // [edge in block][column d (15 = e0)][row]
+  const int sub = threadIdx.x >> 4, d = threadIdx.x & 15;
+  const int k = blockIdx.x * 4 + sub;
+  const bool live = k < v.n_cub;
   const double delta = 1e-9, scalar = 1.0 / (2 * delta);
-  Pose T = pose_load(v.cams + 7 * v.ce_cam[k]);
-  Cube cube = cube_load(v.cubes + 10 * v.ce_cub[k]);
-  Cube meas = cube_load(v.ce_meas + 10 * k);
-  const bool act = v.ce_active[k] != 0;  // sharded BA: the edge belongs to another rank -> zero blocks
-  bool fa = act && v.cam_col[v.ce_cam[k]] >= 0, fb = act && v.cub_col[v.ce_cub[k]] >= 0;
-  double Ja[54], Jb[81], e0[9];
-  cuboid_edge_error(T, cube, meas, e0);
-  if (!act) for (int r = 0; r < 9; r++) e0[r] = 0.0;
-  for (int d = 0; d < 6; d++) {
-    double e1[9], e2[9], add[6] = {0, 0, 0, 0, 0, 0};
-    if (fa) {
-      add[d] = delta; cuboid_edge_error(cam_oplus(T, add), cube, meas, e1);
-      add[d] = -delta; cuboid_edge_error(cam_oplus(T, add), cube, meas, e2);
+  if (live) {
+    Pose T = pose_load(v.cams + 7 * v.ce_cam[k]);
+    Cube cube = cube_load(v.cubes + 10 * v.ce_cub[k]);
+    Cube meas = cube_load(v.ce_meas + 10 * k);
+    const bool act = v.ce_active[k] != 0;  // sharded BA: the edge belongs to another rank -> zero blocks
+    const bool fa = act && v.cam_col[v.ce_cam[k]] >= 0, fb = act && v.cub_col[v.ce_cub[k]] >= 0;
+    double e1[9], e2[9];
+    if (d == 15) {
+      cuboid_edge_error(T, cube, meas, e1);
+      for (int r = 0; r < 9; r++) J[sub][15][r] = act ? e1[r] : 0.0;
+    } else if (d < 6) {
+      double add[6] = {0, 0, 0, 0, 0, 0};
+      if (fa) {
+        add[d] = delta; cuboid_edge_error(cam_oplus(T, add), cube, meas, e1);
+        add[d] = -delta; cuboid_edge_error(cam_oplus(T, add), cube, meas, e2);
+      }
+      for (int r = 0; r < 9; r++) J[sub][d][r] = fa ? scalar * (e1[r] - e2[r]) : 0.0;
+    } else {
+      double add[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if (fb) {
+        add[d - 6] = delta; cuboid_edge_error(T, cube_oplus(cube, add), meas, e1);
+        add[d - 6] = -delta; cuboid_edge_error(T, cube_oplus(cube, add), meas, e2);
+      }
+      for (int r = 0; r < 9; r++) J[sub][d][r] = fb ? scalar * (e1[r] - e2[r]) : 0.0;
     }
-    for (int r = 0; r < 9; r++) Ja[r * 6 + d] = fa ? scalar * (e1[r] - e2[r]) : 0.0;
   }
-  for (int d = 0; d < 9; d++) {
-    double e1[9], e2[9], add[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (fb) {
-      add[d] = delta; cuboid_edge_error(T, cube_oplus(cube, add), meas, e1);
-      add[d] = -delta; cuboid_edge_error(T, cube_oplus(cube, add), meas, e2);
-    }
-    for (int r = 0; r < 9; r++) Jb[r * 9 + d] = fb ? scalar * (e1[r] - e2[r]) : 0.0;
-  }
-  edge_blocks<9, 6, 9>(Ja, Jb, e0, v.ce_info + 81 * (size_t)k, v.ce_Hcc + 36 * (size_t)k, v.ce_Hoo + 81 * (size_t)k, v.ce_Hco + 54 * (size_t)k,
-                       v.ce_bc + 6 * (size_t)k, v.ce_bo + 9 * (size_t)k);
+  __syncthreads();
+  if (live)
+    edge_rows_from_columns<9, 6, 9>(J[sub], J[sub][15], v.ce_info + 81 * (size_t)k, d, v.ce_Hcc + 36 * (size_t)k, v.ce_Hoo + 81 * (size_t)k,
+                                    v.ce_Hco + 54 * (size_t)k, v.ce_bc + 6 * (size_t)k, v.ce_bo + 9 * (size_t)k);
 }
 
 __global__ __launch_bounds__(64) void ba_odom_edge_kernel(BaView v) {
-  int k = blockIdx.x * 64 + threadIdx.x;
-  if (k >= v.n_odom) return;
+  __shared__ double J[4][16][6];
+  const int sub = threadIdx.x >> 4, d = threadIdx.x & 15;
+  const int k = blockIdx.x * 4 + sub;
+  const bool live = k < v.n_odom;
   const double delta = 1e-9, scalar = 1.0 / (2 * delta);
-  Pose T1 = pose_load(v.cams + 7 * v.oe_i[k]), T2 = pose_load(v.cams + 7 * v.oe_j[k]), M = pose_load(v.oe_meas + 7 * k);
-  const bool act = v.oe_active[k] != 0;
-  bool fa = act && v.cam_col[v.oe_i[k]] >= 0, fb = act && v.cam_col[v.oe_j[k]] >= 0;
-  double Ja[36], Jb[36], e0[6];
-  odom_edge_error(T1, T2, M, e0);
-  if (!act) for (int r = 0; r < 6; r++) e0[r] = 0.0;
-  for (int d = 0; d < 6; d++) {
+  if (live) {
+    Pose T1 = pose_load(v.cams + 7 * v.oe_i[k]), T2 = pose_load(v.cams + 7 * v.oe_j[k]), M = pose_load(v.oe_meas + 7 * k);
+    const bool act = v.oe_active[k] != 0;
+    const bool fa = act && v.cam_col[v.oe_i[k]] >= 0, fb = act && v.cam_col[v.oe_j[k]] >= 0;
     double e1[6], e2[6], add[6] = {0, 0, 0, 0, 0, 0};
-    if (fa) {
-      add[d] = delta; odom_edge_error(cam_oplus(T1, add), T2, M, e1);
-      add[d] = -delta; odom_edge_error(cam_oplus(T1, add), T2, M, e2);
+    if (d == 15) {
+      odom_edge_error(T1, T2, M, e1);
+      for (int r = 0; r < 6; r++) J[sub][15][r] = act ? e1[r] : 0.0;
+    } else if (d < 6) {
+      if (fa) {
+        add[d] = delta; odom_edge_error(cam_oplus(T1, add), T2, M, e1);
+        add[d] = -delta; odom_edge_error(cam_oplus(T1, add), T2, M, e2);
+      }
+      for (int r = 0; r < 6; r++) J[sub][d][r] = fa ? scalar * (e1[r] - e2[r]) : 0.0;
+    } else if (d < 12) {
+      if (fb) {
+        add[d - 6] = delta; odom_edge_error(T1, cam_oplus(T2, add), M, e1);
+        add[d - 6] = -delta; odom_edge_error(T1, cam_oplus(T2, add), M, e2);
+      }
+      for (int r = 0; r < 6; r++) J[sub][d][r] = fb ? scalar * (e1[r] - e2[r]) : 0.0;
     }
-    for (int r = 0; r < 6; r++) Ja[r * 6 + d] = fa ? scalar * (e1[r] - e2[r]) : 0.0;
-    if (fb) {
-      add[d] = delta; odom_edge_error(T1, cam_oplus(T2, add), M, e1);
-      add[d] = -delta; odom_edge_error(T1, cam_oplus(T2, add), M, e2);
-    }
-    for (int r = 0; r < 6; r++) Jb[r * 6 + d] = fb ? scalar * (e1[r] - e2[r]) : 0.0;
   }
-  edge_blocks<6, 6, 6>(Ja, Jb, e0, v.oe_info + 36 * (size_t)k, v.oe_Hii + 36 * (size_t)k, v.oe_Hjj + 36 * (size_t)k, v.oe_Hij + 36 * (size_t)k,
-                       v.oe_bi + 6 * (size_t)k, v.oe_bj + 6 * (size_t)k);
+  __syncthreads();
+  if (live)
+    edge_rows_from_columns<6, 6, 6>(J[sub], J[sub][15], v.oe_info + 36 * (size_t)k, d, v.oe_Hii + 36 * (size_t)k, v.oe_Hjj + 36 * (size_t)k,
+                                    v.oe_Hij + 36 * (size_t)k, v.oe_bi + 6 * (size_t)k, v.oe_bj + 6 * (size_t)k);
 }
 
 // gather the numeric-edge blocks into the pose vertices' A_ii / b_i (fixed order: deterministic)
@@ -338,14 +355,17 @@ __global__ __launch_bounds__(256) void ba_prep_kernel(BaView v, double lambda) {
   double b[3] = {v.bl[3 * p], v.bl[3 * p + 1], v.bl[3 * p + 2]}, db[3];
   mat3_vec(Di, b, db);
   v.dbl[3 * p] = db[0]; v.dbl[3 * p + 1] = db[1]; v.dbl[3 * p + 2] = db[2];
-  for (int k = v.pt_ptr[p]; k < v.pt_ptr[p + 1]; k++) {
-    const double* Wk = v.W + 18 * (size_t)k;
-    double* WDk = v.WD + 18 * (size_t)k;
+}
+
+// WD = W D^-1, one thread per (projection edge, row of its 6 x 3 block): reads and writes are contiguous across the wave
+__global__ __launch_bounds__(256) void ba_wd_kernel(BaView v) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= 6 * (size_t)v.n_proj) return;
+  const int k = (int)(t / 6);
+  const double* Di = v.Dinv + 9 * (size_t)v.pm_pt[k];
+  const double w0 = v.W[3 * t], w1 = v.W[3 * t + 1], w2 = v.W[3 * t + 2];
 #pragma unroll
-    for (int r = 0; r < 6; r++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) WDk[3 * r + c] = Wk[3 * r] * Di[c] + Wk[3 * r + 1] * Di[3 + c] + Wk[3 * r + 2] * Di[6 + c];
-  }
+  for (int c = 0; c < 3; c++) v.WD[3 * t + c] = w0 * Di[c] + w1 * Di[3 + c] + w2 * Di[6 + c];
 }
 
 // camera part of the reduced system: S_cc = A_cc + lambda I, b_schur,c = b_c - sum_e W_e (D^-1 b_l)
@@ -409,32 +429,39 @@ __global__ __launch_bounds__(64) void ba_offdiag_kernel(BaView v) {
   }
 }
 
-// one wavefront per covisible camera pair; lane l < 36 owns element (l / 6, l % 6) of the 6x6 block
-__global__ __launch_bounds__(256) void ba_schur_kernel(BaView v) {
-  int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (pair >= v.n_pairs) return;
-  int lane = threadIdx.x & 63;
-  int r = lane / 6, c = lane % 6;
-  bool act = lane < 36;
-  int q0 = v.pair_ptr[pair], q1 = v.pair_ptr[pair + 1];
-  double acc0 = 0, acc1 = 0;
-  int q = q0;
-  for (; q + 1 < q1; q += 2) {
-    int a0 = v.ent_a[q], b0 = v.ent_b[q], a1 = v.ent_a[q + 1], b1 = v.ent_b[q + 1];
-    if (act) {
-      const double* x0 = v.WD + 18 * (size_t)a0 + 3 * r; const double* y0 = v.W + 18 * (size_t)b0 + 3 * c;
-      const double* x1 = v.WD + 18 * (size_t)a1 + 3 * r; const double* y1 = v.W + 18 * (size_t)b1 + 3 * c;
-      acc0 += x0[0] * y0[0] + x0[1] * y0[1] + x0[2] * y0[2];
-      acc1 += x1[0] * y1[0] + x1[1] * y1[1] + x1[2] * y1[2];
+// One wavefront per covisible camera pair.  Every lane walks its own landmarks of the pair (entries q0 + lane,
+// + 64, ...), accumulating the whole 6 x 6 block W_a D^-1 W_b^T in registers (each lane streams two contiguous
+// 144-byte records per entry); the 64 partial blocks are summed through an LDS tile in a fixed order.
+__global__ __launch_bounds__(128) void ba_schur_kernel(BaView v) {
+  __shared__ double red[2][64][37];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int pair = blockIdx.x * 2 + wv;
+  if (pair < v.n_pairs) {
+    const int q0 = v.pair_ptr[pair], q1 = v.pair_ptr[pair + 1];
+    double acc[36];
+#pragma unroll
+    for (int o = 0; o < 36; o++) acc[o] = 0.0;
+    for (int q = q0 + lane; q < q1; q += 64) {
+      const double* x = v.WD + 18 * (size_t)v.ent_a[q];
+      const double* y = v.W + 18 * (size_t)v.ent_b[q];
+      double xv[18], yv[18];
+#pragma unroll
+      for (int i = 0; i < 18; i++) { xv[i] = x[i]; yv[i] = y[i]; }
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) acc[6 * r + c] = fma(xv[3 * r + 2], yv[3 * c + 2], fma(xv[3 * r + 1], yv[3 * c + 1], fma(xv[3 * r], yv[3 * c], acc[6 * r + c])));
     }
+#pragma unroll
+    for (int o = 0; o < 36; o++) red[wv][lane][o] = acc[o];
   }
-  if (q < q1 && act) {
-    const double* x0 = v.WD + 18 * (size_t)v.ent_a[q] + 3 * r; const double* y0 = v.W + 18 * (size_t)v.ent_b[q] + 3 * c;
-    acc0 += x0[0] * y0[0] + x0[1] * y0[1] + x0[2] * y0[2];
-  }
-  if (act) {
-    double s = acc0 + acc1;
-    int i1 = v.pair_i1[pair], i2 = v.pair_i2[pair];
+  __syncthreads();
+  if (pair < v.n_pairs && lane < 36) {
+    double s = 0;
+#pragma unroll 8
+    for (int j = 0; j < 64; j++) s += red[wv][j][lane];
+    const int r = lane / 6, c = lane % 6;
+    const int i1 = v.pair_i1[pair], i2 = v.pair_i2[pair];
     // element (i1 + r, i2 + c) of the symmetric S, i1 <= i2: its lower-triangle home is (i2 + c, i1 + r)
     if (i1 != i2 || c >= r) *ba_S_at(v, i2 + c, i1 + r) -= s;
   }
@@ -839,16 +866,17 @@ void ba_launch_chi2(const BaView& v, int nb_proj, hipStream_t st) {
 void ba_launch_linearize(const BaView& v, hipStream_t st) {
   if (v.n_proj > 0 || v.nc > 0) hipLaunchKernelGGL(ba_lin_cam_kernel, dim3(v.nc), dim3(256), 0, st, v);
   if (v.np > 0) hipLaunchKernelGGL(ba_lin_pt_kernel, dim3((v.np + 255) / 256), dim3(256), 0, st, v);
-  if (v.n_cub > 0) hipLaunchKernelGGL(ba_cub_edge_kernel, dim3((v.n_cub + 63) / 64), dim3(64), 0, st, v);
-  if (v.n_odom > 0) hipLaunchKernelGGL(ba_odom_edge_kernel, dim3((v.n_odom + 63) / 64), dim3(64), 0, st, v);
+  if (v.n_cub > 0) hipLaunchKernelGGL(ba_cub_edge_kernel, dim3((v.n_cub + 3) / 4), dim3(64), 0, st, v);
+  if (v.n_odom > 0) hipLaunchKernelGGL(ba_odom_edge_kernel, dim3((v.n_odom + 3) / 4), dim3(64), 0, st, v);
   hipLaunchKernelGGL(ba_accum_pose_kernel, dim3(v.nc + v.no), dim3(128), 0, st, v, 0);
 }
 void ba_launch_reduce(const BaView& v, double lambda, hipStream_t st) {
   if (v.np > 0) hipLaunchKernelGGL(ba_prep_kernel, dim3((v.np + 255) / 256), dim3(256), 0, st, v, lambda);
+  if (v.n_proj > 0) hipLaunchKernelGGL(ba_wd_kernel, dim3((unsigned)((6 * (size_t)v.n_proj + 255) / 256)), dim3(256), 0, st, v);
   hipLaunchKernelGGL(ba_cam_rhs_kernel, dim3(v.nc), dim3(256), 0, st, v, lambda);
   if (v.no > 0) hipLaunchKernelGGL(ba_cub_scatter_kernel, dim3(v.no), dim3(128), 0, st, v, lambda);
   if (v.n_cub + v.n_odom > 0) hipLaunchKernelGGL(ba_offdiag_kernel, dim3(v.n_cub + v.n_odom), dim3(64), 0, st, v);
-  if (v.n_pairs > 0) hipLaunchKernelGGL(ba_schur_kernel, dim3((v.n_pairs + 3) / 4), dim3(256), 0, st, v);
+  if (v.n_pairs > 0) hipLaunchKernelGGL(ba_schur_kernel, dim3((v.n_pairs + 1) / 2), dim3(128), 0, st, v);
 }
 void ba_launch_backsub(const BaView& v, hipStream_t st) {
   if (v.np > 0) hipLaunchKernelGGL(ba_backsub_kernel, dim3((v.np + 255) / 256), dim3(256), 0, st, v);
