@@ -7,7 +7,7 @@ over +-45 deg) x ~10 top-edge samples x 2 configurations over ~400 line segments
 With --gpus N every rank runs its own batch (frames are independent units: no data-path collective,
 weak scaling); value = frames of all ranks / max-over-ranks time.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" for the dominant kernel (candidate_kernel),
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" for the dominant kernel (score_kernel),
 "cpu_baseline" = the CPU oracle timed on a bounded sample of the same workload (rank 0, N=1 only).
 """
 from __future__ import annotations
@@ -134,6 +134,17 @@ def main():
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         geo_ms = acc["cand_kernel_ms"] / launches
         geo_bytes = acc["cand_kernel_bytes"] / launches
+        # HBM traffic of the kernel as measured by the PMC passes of the same workload (profiles/pmc_traffic.json, written
+        # by tools/profile_round.sh); null when this run's workload differs from the profiled one
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                pt = json.load(fh)
+            wl = pt["workload"]
+            if wl["frames_per_batch"] == args.frames and wl["unique"] == n_unique and world == 1:
+                traffic = pt["kernels"]["score_kernel"]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         out = {
             "metric": "frames/sec detect_cuboid", "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -143,7 +154,7 @@ def main():
                        "proposal_slots_per_frame": acc["n_slots"] / args.steps / args.frames,
                        "valid_proposals_per_frame": acc["n_valid"] / args.steps / args.frames, "parallelism": "frames sharded, no collective"},
             "roofline": {"kernel": "score_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": kern_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": kern_ms,
                          "other_kernels": {"candidate_kernel": {"ms": geo_ms, "alg_bytes": geo_bytes, "GB/s": geo_bytes / (geo_ms * 1e-3) / 1e9 if geo_ms > 0 else 0.0}}},
             "stage_ms_per_step": {k: acc[k] / args.steps for k in acc if k.endswith("_ms")},
             "fallback_boxes_per_step": acc["n_fallback_boxes"] / args.steps,
