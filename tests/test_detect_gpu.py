@@ -201,6 +201,27 @@ def test_host_and_device_line_setup_agree():
     assert a.timing()["line_setup_ms"] > 0 and b.timing()["line_setup_ms"] < 0.05
 
 
+def test_line_setup_crowded_rois():
+    """ROIs that hold nearly every segment of the frame (long merge chains, LDS tables close to capacity): the device
+    line setup must still produce the host implementation's records."""
+    frames = []
+    for s in range(3):
+        fr = synth.make_frame(8450 + s, n_boxes=3, n_lines=480)
+        left, top, w, h = fr["boxes"][0][:4]
+        L = np.asarray(fr["lines"], np.float64).reshape(-1, 4).copy()
+        W, H = float(fr["img_w"]), float(fr["img_h"])
+        L[:, [0, 2]] = left + 2 + L[:, [0, 2]] / W * (w - 4)      # squeeze every segment into box 0
+        L[:, [1, 3]] = top + 2 + L[:, [1, 3]] / H * (h - 4)
+        fr = dict(fr); fr["lines"] = L
+        frames.append(fr)
+    det = capi.Detector(capi.default_params(whether_sample_cam_roll_pitch=0, yaw_step_deg=3.0, max_cuboid_num=2))
+    a = capi.Batch(det, frames); a.run()
+    b = capi.Batch(det, frames, force_host_setup=True); b.run()
+    assert a.raw_out_bytes() == b.raw_out_bytes() and a.counts_bytes() == b.counts_bytes()
+    assert a.timing()["line_setup_ms"] > 0 and b.timing()["line_setup_ms"] < 0.05
+    a.close(); b.close(); det.close()
+
+
 def test_chunk_pipeline_matches_single_pass():
     """The lean production path cut into 4 chunks of a two-slot pipeline (host packs / finishes one chunk while the GPU sweeps the next);
     the records must be byte-identical to the one-pass path, also on a second run that reuses the slots, with ragged
