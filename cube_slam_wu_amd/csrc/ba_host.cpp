@@ -358,6 +358,9 @@ int finalize_structure(cs_ba* B) {
   v.Dinv = B->Dinv.p; v.dbl = B->dbl.p; v.S = B->S.p; v.band_ld = B->band_ld; v.add_lambda = (B->shard_rank == 0); v.rhs = B->S.p + B->s_doubles; v.xl = B->xl.p;
   v.n_pairs = B->n_pairs; v.pair_ptr = B->pair_ptr.p; v.pair_i1 = B->pair_i1.p; v.pair_i2 = B->pair_i2.p; v.ent_a = B->ent_a.p; v.ent_b = B->ent_b.p;
   v.chi_partial = B->chi_partial.p;
+  // the allocations above were zeroed by hipMemset on the NULL stream, which a non-blocking stream does not wait for:
+  // drain it before the first kernel of B->st can write into those buffers
+  BA_TRY(hipDeviceSynchronize());
   B->structure_dirty = false;
   B->have_system = false;
   return CS_OK;
