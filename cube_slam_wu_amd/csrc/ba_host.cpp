@@ -28,6 +28,8 @@ void ba_launch_chi2(const BaView& v, int nb_proj, hipStream_t st);
 void ba_launch_linearize(const BaView& v, hipStream_t st);
 void ba_launch_reduce(const BaView& v, double lambda, hipStream_t st);
 void ba_launch_backsub(const BaView& v, hipStream_t st);
+int ba_scale_blocks();
+void ba_launch_scale(const BaView& v, double lambda_pose, double lambda_lm, double* partial, hipStream_t st);
 void ba_launch_update(const BaView& v, hipStream_t st);
 void ba_launch_band_cholesky(double* Sb, double* Linv, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st);
 int ba_band_team(int LD, int* rw_out);
@@ -84,7 +86,9 @@ struct cs_ba {
   int device = 0;
   hipStream_t st = nullptr;
   rocblas_handle blas = nullptr;
-  hipEvent_t ev[2] = {};
+  hipEvent_t ev[8] = {};   // phase marks on the stream (linearise: 0-1; solve: 2 reduce 3 factor 4 back-substitution 5)
+  bool lin_pending = false;  // ev[0..1] recorded but not yet read
+  int* h_status = nullptr;   // pinned: factorisation status
   // host copy of the problem description
   int nc = 0, no = 0, np = 0, cuboids_first = 0;
   std::vector<int> cam_fixed, cub_fixed, pt_fixed, cam_col, cub_col, pt_lm;  // pt_lm: landmark index among free points or -1
@@ -110,7 +114,7 @@ struct cs_ba {
   DBuf<int> d_ce_cam, d_ce_cub, d_oe_i, d_oe_j, d_ce_active, d_oe_active;
   DBuf<double> ce_meas, ce_info, ce_Hcc, ce_Hoo, ce_Hco, ce_bc, ce_bo, oe_meas, oe_info, oe_Hii, oe_Hjj, oe_Hij, oe_bi, oe_bj;
   DBuf<int> cam_ce_ptr, cam_ce_idx, cam_oei_ptr, cam_oei_idx, cam_oej_ptr, cam_oej_idx, cub_ce_ptr, cub_ce_idx;
-  DBuf<double> Hcam, bcam, Hcub, bcub, Hll, bl, W, WD, Dinv, dbl, S, rhs, xl, chi_partial, band_linv;
+  DBuf<double> Hcam, bcam, Hcub, bcub, Hll, bl, W, WD, Dinv, dbl, S, rhs, xl, chi_partial, band_linv, scale_partial;
   DBuf<int> pair_ptr, pair_i1, pair_i2, ent_a, ent_b;
   DBuf<rocblas_int> d_info;
   DBuf<int> d_band_info;
@@ -339,6 +343,7 @@ int finalize_structure(cs_ba* B) {
   B->nb_chi = cs::ba_chi2_blocks(E);
   B->n_chi_partials = B->nb_chi + (B->n_cub + B->n_odom + 63) / 64;
   AL(B->chi_partial, B->n_chi_partials);
+  AL(B->scale_partial, (size_t)cs::ba_scale_blocks());
   AL(B->d_info, 1);
   AL(B->cams_bak, 7 * (size_t)nc); AL(B->points_bak, 3 * (size_t)np); AL(B->cubes_bak, 10 * (size_t)no);
 #undef UP
@@ -402,12 +407,22 @@ int fetch_x(cs_ba* B) {
   return CS_OK;
 }
 
+// phase times come from events read after the next stream synchronisation, so that no phase boundary stalls the host
+int collect_lin_time(cs_ba* B) {
+  if (!B->lin_pending) return CS_OK;
+  float ms = 0;
+  BA_TRY(hipEventElapsedTime(&ms, B->ev[0], B->ev[1]));
+  B->tm.linearize_ms += ms;
+  B->lin_pending = false;
+  return CS_OK;
+}
+
 int build_system_device(cs_ba* B) {
-  double t0 = now_ms();
+  BA_TRY(hipEventRecord(B->ev[0], B->st));
   cs::ba_launch_linearize(B->view, B->st);
   BA_TRY(hipGetLastError());
-  BA_TRY(hipStreamSynchronize(B->st));
-  B->tm.linearize_ms += now_ms() - t0;
+  BA_TRY(hipEventRecord(B->ev[1], B->st));
+  B->lin_pending = true;
   B->tm.n_linearizations++;
   B->have_system = true;
   return CS_OK;
@@ -416,45 +431,49 @@ int build_system_device(cs_ba* B) {
 // setLambda + solve + restoreDiagonal (block_solver.hpp:353-486, :563-604): lambda is applied while the
 // reduced system is assembled, so the stored blocks are never modified and nothing needs restoring.
 int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr, void* ctx = nullptr) {
-  double t0 = now_ms();
   const int n = B->n_pose;
   *ok = true;
   if (n > 0) {
+    BA_TRY(hipEventRecord(B->ev[2], B->st));
     BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (B->s_doubles + n), B->st));
     cs::ba_launch_reduce(B->view, lambda, B->st);
     BA_TRY(hipGetLastError());
-    BA_TRY(hipStreamSynchronize(B->st));
     if (fn && B->shard_n > 1) {  // sum the ranks' partial reduced systems: [S | rhs] in one message
+      BA_TRY(hipStreamSynchronize(B->st));
       if (fn(ctx, B->S.p, B->s_doubles + n, 1, 0) != 0) { cs_set_error_ba("all-reduce callback failed"); return CS_ERR_HIP; }
     }
-    double t1 = now_ms();
-    B->tm.reduce_ms += t1 - t0;
+    BA_TRY(hipEventRecord(B->ev[3], B->st));
     if (B->band_ld) {
+      // banded: factorisation, both substitutions and the landmark back-substitution are queued back to back; the
+      // pivot flag comes home with the single synchronisation (a failed factorisation just leaves garbage increments
+      // that the caller discards)
       BA_TRY(hipMemsetAsync(B->d_band_info.p, 0, 4 * sizeof(int), B->st));
       cs::ba_launch_band_cholesky(B->S.p, B->band_linv.p, n, B->band_ld, B->view.rhs, B->d_band_info.p, true, B->st);
       BA_TRY(hipGetLastError());
-      int info = 0;
-      BA_TRY(hipMemcpyAsync(&info, B->d_band_info.p, sizeof(info), hipMemcpyDeviceToHost, B->st));
+      BA_TRY(hipEventRecord(B->ev[4], B->st));
+      cs::ba_launch_backsub(B->view, B->st);
+      BA_TRY(hipGetLastError());
+      BA_TRY(hipEventRecord(B->ev[5], B->st));
+      BA_TRY(hipMemcpyAsync(B->h_status, B->d_band_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
       BA_TRY(hipStreamSynchronize(B->st));
-      if (info != 0) *ok = false;
+      if (*B->h_status != 0) *ok = false;
     } else {
       // dense: the lower triangle of the row-major S is the upper triangle of the column-major matrix rocSOLVER sees
       BA_ROC(rocsolver_dpotrf(B->blas, rocblas_fill_upper, n, B->S.p, n, B->d_info.p));
-      rocblas_int info = 0;
-      BA_TRY(hipMemcpyAsync(&info, B->d_info.p, sizeof(info), hipMemcpyDeviceToHost, B->st));
+      BA_TRY(hipMemcpyAsync(B->h_status, B->d_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
       BA_TRY(hipStreamSynchronize(B->st));
-      if (info != 0) { *ok = false; }
+      if (*B->h_status != 0) *ok = false;
       else BA_ROC(rocsolver_dpotrs(B->blas, rocblas_fill_upper, n, 1, B->S.p, n, B->view.rhs, n));
+      BA_TRY(hipEventRecord(B->ev[4], B->st));
+      if (*ok) { cs::ba_launch_backsub(B->view, B->st); BA_TRY(hipGetLastError()); }
+      BA_TRY(hipEventRecord(B->ev[5], B->st));
       BA_TRY(hipStreamSynchronize(B->st));
     }
-    double t2 = now_ms();
-    B->tm.factor_ms += t2 - t1;
-    if (*ok) {
-      cs::ba_launch_backsub(B->view, B->st);
-      BA_TRY(hipGetLastError());
-      BA_TRY(hipStreamSynchronize(B->st));
-    }
-    B->tm.backsub_ms += now_ms() - t2;
+    float ms = 0;
+    BA_TRY(hipEventElapsedTime(&ms, B->ev[2], B->ev[3])); B->tm.reduce_ms += ms;
+    BA_TRY(hipEventElapsedTime(&ms, B->ev[3], B->ev[4])); B->tm.factor_ms += ms;
+    BA_TRY(hipEventElapsedTime(&ms, B->ev[4], B->ev[5])); B->tm.backsub_ms += ms;
+    int rc = collect_lin_time(B); if (rc) return rc;
   }
   B->tm.n_solves++;
   return CS_OK;
@@ -475,6 +494,8 @@ int cs_ba_create(int device, cs_ba** out) {
   { const char* e = getenv("CS_BA_FORCE_DENSE"); B->force_dense = (e && atoi(e)) ? 1 : 0; }  // diagnostics: rocSOLVER dense path
   BA_TRY(hipSetDevice(device));
   BA_TRY(hipStreamCreateWithFlags(&B->st, hipStreamNonBlocking));
+  for (auto& e : B->ev) BA_TRY(hipEventCreate(&e));
+  BA_TRY(hipHostMalloc((void**)&B->h_status, sizeof(int)));
   BA_ROC(rocblas_create_handle(&B->blas));
   BA_ROC(rocblas_set_stream(B->blas, B->st));
   *out = B;
@@ -487,13 +508,15 @@ void cs_ba_destroy(cs_ba* B) {
   DBuf<double>* dd[] = {&B->cams, &B->points, &B->cubes, &B->cams_bak, &B->points_bak, &B->cubes_bak, &B->pm_uv, &B->pm_info, &B->pm_intr, &B->pm_huber,
                         &B->cm_uv, &B->cm_info, &B->cm_intr, &B->cm_huber, &B->ce_meas, &B->ce_info, &B->ce_Hcc, &B->ce_Hoo, &B->ce_Hco, &B->ce_bc, &B->ce_bo,
                         &B->oe_meas, &B->oe_info, &B->oe_Hii, &B->oe_Hjj, &B->oe_Hij, &B->oe_bi, &B->oe_bj, &B->Hcam, &B->bcam, &B->Hcub, &B->bcub, &B->Hll, &B->bl,
-                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv};
+                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv, &B->scale_partial};
   for (auto* d : dd) d->release();
   DBuf<int>* di[] = {&B->d_ce_active, &B->d_oe_active, &B->d_cam_col, &B->d_cub_col, &B->d_pt_free, &B->pm_pt, &B->pm_cam, &B->pt_ptr, &B->cm_pm, &B->cm_pt, &B->cam_ptr, &B->d_ce_cam, &B->d_ce_cub,
                      &B->d_oe_i, &B->d_oe_j, &B->cam_ce_ptr, &B->cam_ce_idx, &B->cam_oei_ptr, &B->cam_oei_idx, &B->cam_oej_ptr, &B->cam_oej_idx, &B->cub_ce_ptr,
                      &B->cub_ce_idx, &B->pair_ptr, &B->pair_i1, &B->pair_i2, &B->ent_a, &B->ent_b};
   for (auto* d : di) d->release();
-  B->d_info.release();
+  B->d_info.release(); B->d_band_info.release();
+  for (auto& e : B->ev) if (e) (void)hipEventDestroy(e);
+  if (B->h_status) (void)hipHostFree(B->h_status);
   if (B->blas) rocblas_destroy_handle(B->blas);
   if (B->st) (void)hipStreamDestroy(B->st);
   delete B;
@@ -655,8 +678,8 @@ int cs_ba_optimize_sharded(cs_ba* B, int iterations, cs_allreduce_fn fn, void* c
     B->tm.errors_ms += now_ms() - t0;
     double tempChi = currentChi, iniChi = currentChi;
     rc = build_system_device(B); if (rc) return rc;
-    rc = fetch_b(B); if (rc) return rc;
     if (it == 0) {  // computeLambdaInit (:166-180): tau * max |H_jj| over all non-fixed vertices, landmarks included
+      BA_TRY(hipStreamSynchronize(B->st));   // the copies below run on the NULL stream, which B->st does not order with
       std::vector<double> hc(36 * (size_t)B->nc), ho(81 * (size_t)B->no), hl(9 * (size_t)B->np);
       if (B->nc) BA_TRY(hipMemcpy(hc.data(), B->Hcam.p, 8 * hc.size(), hipMemcpyDeviceToHost));
       if (B->no) BA_TRY(hipMemcpy(ho.data(), B->Hcub.p, 8 * ho.size(), hipMemcpyDeviceToHost));
@@ -679,11 +702,18 @@ int cs_ba_optimize_sharded(cs_ba* B, int iterations, cs_allreduce_fn fn, void* c
       rc = cs_ba_push(B); if (rc) return rc;
       bool ok2 = false;
       rc = solve_device(B, lambda, &ok2, fn, ctx); if (rc) return rc;
+      // x^T (lambda x + b) on the device, before the update overwrites nothing it reads: b is a per-rank partial sum,
+      // x is replicated for the poses -- the lambda x^2 term of the poses is counted once (rank 0); a landmark's terms
+      // live on exactly one rank
+      double scale = 0;
       if (ok2) {
-        rc = fetch_x(B); if (rc) return rc;
-        rc = cs_ba_update(B); if (rc) return rc;
-      } else {
-        B->h_x.assign(B->n_pose + 3 * (size_t)B->n_lm, 0.0);
+        const int nsb = cs::ba_scale_blocks();
+        std::vector<double> sp(nsb);
+        cs::ba_launch_scale(B->view, B->shard_rank == 0 ? lambda : 0.0, lambda, B->scale_partial.p, B->st);
+        BA_TRY(hipGetLastError());
+        BA_TRY(hipMemcpyAsync(sp.data(), B->scale_partial.p, sizeof(double) * nsb, hipMemcpyDeviceToHost, B->st));
+        rc = cs_ba_update(B); if (rc) return rc;   // synchronises the stream
+        for (double p : sp) scale += p;
       }
       t0 = now_ms();
       rc = chi2_device(B, &tempChi); if (rc) return rc;
@@ -691,11 +721,6 @@ int cs_ba_optimize_sharded(cs_ba* B, int iterations, cs_allreduce_fn fn, void* c
       B->tm.errors_ms += now_ms() - t0;
       if (!ok2) tempChi = std::numeric_limits<double>::max();
       rho = currentChi - tempChi;
-      // x^T (lambda x + b): b is a per-rank partial sum, x is replicated for the poses; the lambda x^2 term of the
-      // poses is counted once (rank 0), landmarks belong to exactly one rank
-      double scale = 0;
-      for (int j = 0; j < B->n_pose; j++) scale += B->h_x[j] * ((B->shard_rank == 0 ? lambda * B->h_x[j] : 0.0) + B->h_b[j]);
-      for (size_t j = B->n_pose; j < B->h_x.size(); j++) scale += B->h_x[j] * (lambda * B->h_x[j] + B->h_b[j]);
       if (reduce_host(&scale, 1, 0)) return CS_ERR_HIP;
       scale += 1e-3;
       rho /= scale;

@@ -126,6 +126,37 @@ __global__ __launch_bounds__(64) void ba_chi2_pose_edges_kernel(BaView v, int pa
   if (threadIdx.x == 0) v.chi_partial[partial_off + blockIdx.x] = c;
 }
 
+// x^T (lambda x + b) of the LM gain ratio (optimization_algorithm_levenberg.cpp:117-126, computeScale :182-189) over
+// the pose increments (x in v.rhs, b in bcam / bcub) and the landmark increments (xl, bl); fixed-shape reduction:
+// SCALE_BLOCKS partial sums, added up by the host in order.
+enum { SCALE_BLOCKS = 256 };
+__global__ __launch_bounds__(256) void ba_scale_kernel(BaView v, double lambda_pose, double lambda_lm, double* partial) {
+  __shared__ double ws[4];
+  double acc = 0;
+  const int n = v.np + v.nc + v.no;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += SCALE_BLOCKS * 256) {
+    if (i < v.np) {
+      if (v.pt_free[i])
+#pragma unroll
+        for (int d = 0; d < 3; d++) { const double x = v.xl[3 * (size_t)i + d]; acc += x * (lambda_lm * x + v.bl[3 * (size_t)i + d]); }
+    } else if (i < v.np + v.nc) {
+      const int c = i - v.np, col = v.cam_col[c];
+      if (col >= 0)
+#pragma unroll
+        for (int d = 0; d < 6; d++) { const double x = v.rhs[col + d]; acc += x * (lambda_pose * x + v.bcam[6 * c + d]); }
+    } else {
+      const int o = i - v.np - v.nc, col = v.cub_col[o];
+      if (col >= 0)
+#pragma unroll
+        for (int d = 0; d < 9; d++) { const double x = v.rhs[col + d]; acc += x * (lambda_pose * x + v.bcub[9 * o + d]); }
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ba_lin_cam_kernel(BaView v) {
   int c = blockIdx.x;
@@ -877,6 +908,10 @@ void ba_launch_reduce(const BaView& v, double lambda, hipStream_t st) {
   if (v.no > 0) hipLaunchKernelGGL(ba_cub_scatter_kernel, dim3(v.no), dim3(128), 0, st, v, lambda);
   if (v.n_cub + v.n_odom > 0) hipLaunchKernelGGL(ba_offdiag_kernel, dim3(v.n_cub + v.n_odom), dim3(64), 0, st, v);
   if (v.n_pairs > 0) hipLaunchKernelGGL(ba_schur_kernel, dim3((v.n_pairs + 1) / 2), dim3(128), 0, st, v);
+}
+int ba_scale_blocks() { return SCALE_BLOCKS; }
+void ba_launch_scale(const BaView& v, double lambda_pose, double lambda_lm, double* partial, hipStream_t st) {
+  hipLaunchKernelGGL(ba_scale_kernel, dim3(SCALE_BLOCKS), dim3(256), 0, st, v, lambda_pose, lambda_lm, partial);
 }
 void ba_launch_backsub(const BaView& v, hipStream_t st) {
   if (v.np > 0) hipLaunchKernelGGL(ba_backsub_kernel, dim3((v.np + 255) / 256), dim3(256), 0, st, v);
