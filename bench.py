@@ -51,16 +51,31 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
+    # CS_BENCH_SHARE_GPU=1: functional check of the N > 1 code path on a box with fewer GPUs than ranks (every rank on
+    # device 0, gloo instead of RCCL, which refuses two ranks on one device); never a performance number
+    share_gpu = os.environ.get("CS_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     # ---- workload: distinct seeds per rank, tiled to the batch size (each copy gets its own HBM buffers)
     n_unique = max(1, min(args.unique, args.frames))
@@ -80,11 +95,7 @@ def main():
         for k, v in bat.timing().items():
             acc[k] = acc.get(k, 0) + v
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
 
     # ---- second half of the metric: LM iterations/s of the BA path (C4: 1k cams / 200k points / 500 cuboids).
     # N > 1: the landmarks are sharded by camera subsequence; one RCCL all-reduce of [S | b_schur] per damped solve.
@@ -104,11 +115,7 @@ def main():
         tb = time.perf_counter()
         n_it = run(args.ba_iters)
         barrier()
-        ba_el = time.perf_counter() - tb
-        if dist is not None:
-            t = torch.tensor([ba_el], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            ba_el = float(t.item())
+        ba_el = max_over_ranks(time.perf_counter() - tb)
         tm = P.timing()
         d = {k: tm[k] - t_before[k] for k in tm if k.endswith("_ms")}
         nlin = max(1, tm["n_linearizations"] - t_before["n_linearizations"])
@@ -148,7 +155,7 @@ def main():
         out = {
             "metric": "frames/sec detect_cuboid", "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not share_gpu else "synthetic (CS_BENCH_SHARE_GPU functional check: ranks share one device, not a performance number)",
             "config": {"workload": "C2: per-frame cuboid proposal sweep, 181 yaw x 8 boxes x ~400 line segments, 1241x376 KITTI-shaped",
                        "frames_per_batch_per_gpu": args.frames, "unique_frames": n_unique, "yaw_step_deg": 0.5,
                        "proposal_slots_per_frame": acc["n_slots"] / args.steps / args.frames,
