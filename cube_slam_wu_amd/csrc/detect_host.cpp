@@ -433,6 +433,10 @@ struct PipeSlot {
 struct cs_batch {
   cs_detector* det = nullptr;
   PipeSlot pipe[2];
+  // capacity layout of the lean path's staging pools (from the inputs alone): first job / first box of a frame, first
+  // merged-segment row of a frame's jobs, first top-edge sample of a box
+  std::vector<int> job_base, box_base, top_base;
+  std::vector<long long> line_base;
   bool force_no_pipeline = false;
   int pipe_chunks = 1;   // chunks of the two-slot pipeline (cs_batch_set_pipeline_chunks)
   int n_frames = 0, max_boxes = 0;
@@ -539,7 +543,7 @@ int cs_detector_create(const cs_detect_params* params, int device, cs_detector**
   HIP_TRY(hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking));
   for (auto& e : d->ev) HIP_TRY(hipEventCreate(&e));
   int hc = (int)std::thread::hardware_concurrency();
-  d->n_threads = d->prm.host_threads > 0 ? d->prm.host_threads : std::max(1, std::min(hc, 64));
+  d->n_threads = d->prm.host_threads > 0 ? d->prm.host_threads : std::max(1, std::min(hc, 64));   // measured on a 256-thread EPYC: 64 beats 32 and 128
   d->pool.reset(new WorkerPool(d->n_threads - 1));
   *out = d;
   return CS_OK;
@@ -630,6 +634,26 @@ int cs_batch_create(cs_detector* d, const cs_frame_desc* fr, int n_frames, cs_ba
     rc = b->d_frame_line_ptr.ensure(lp.size()); if (rc) { delete b; return rc; }
     HIP_TRY(hipMemcpy(b->d_frame_lines.p, fl.data(), 8 * fl.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_frame_line_ptr.p, lp.data(), 4 * lp.size(), hipMemcpyHostToDevice));
+  }
+  {
+    b->job_base.assign(n_frames + 1, 0); b->box_base.assign(n_frames + 1, 0); b->line_base.assign(n_frames + 1, 0);
+    b->top_base.assign(1, 0);
+    for (int f = 0; f < n_frames; f++) {
+      const FrameIn& F = b->frames[f];
+      int nj = 0;
+      for (int bi = 0; bi < F.n_boxes; bi++) {
+        nj += F.n_heights[bi];
+        const double* bb = &F.boxes[5 * bi];
+        int left = bb[0], w = bb[2], right = left + bb[2];
+        int res = (int)std::round(std::min(20, w / 10));
+        std::vector<int> tops;
+        if (res >= 1) linespace<int>(left + 5, right - 5, res, tops);   // :215-219: the count depends on the box alone
+        b->top_base.push_back(b->top_base.back() + (int)tops.size());
+      }
+      b->job_base[f + 1] = b->job_base[f] + nj;
+      b->box_base[f + 1] = b->box_base[f] + F.n_boxes;
+      b->line_base[f + 1] = b->line_base[f] + (long long)nj * F.n_lines;
+    }
   }
   *out = b;
   return CS_OK;
@@ -737,39 +761,62 @@ struct PipeCtx {
   cs::SweepParams sp; cs_detect_timing* tm;
 };
 
+static double g_mark[16];
+static int g_runs = 0;
+static const bool g_prof = getenv("CS_DETECT_PROF") != nullptr;   // diagnostics: host phase clock of the lean path
+#define MARK(k, t_ref) do { if (g_prof) { double t_now = now_ms(); g_mark[k] += t_now - (t_ref); (t_ref) = t_now; } } while (0)
+
 int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   cs_detector* d = C.d; cs_batch* b = C.b;
   const cs_detect_params& P = d->prm;
   hipStream_t st = d->stream;
   const int KMAX = P.max_cuboid_num;
-  double t0 = now_ms();
+  double t0 = now_ms(), tq = t0;
   if (!S.done) { HIP_TRY(hipEventCreate(&S.done)); for (auto& e : S.ev) HIP_TRY(hipEventCreate(&e)); }
   S.f0 = f0; S.f1 = f1;
   const int nf = f1 - f0;
-  // ---- per frame: job descriptors + sample lists (everything else of the setup happens in line_setup_kernel)
-  struct FrameJobs { std::vector<cs::JobDesc> jobs; std::vector<double> yaw, yc, ys; std::vector<int> tops; };
-  std::vector<FrameJobs> fj(nf);
+  // ---- per frame, in parallel and straight into the pinned staging pools: job descriptors + sample lists (everything
+  // else of the setup happens in line_setup_kernel).  The pools use a capacity layout fixed by the inputs (a frame's
+  // jobs, yaw samples and top-edge samples have known upper bounds), so no frame waits for another one's counts; a
+  // box the reference skips (:215) leaves null jobs (Y = T = 0) that own no slots.
+  const int jb0 = b->job_base[f0], bx0 = b->box_base[f0], tp0 = b->top_base[bx0];
+  const long long ln0 = b->line_base[f0];
+  const size_t nj = (size_t)(b->job_base[f1] - jb0), n_lines = (size_t)(b->line_base[f1] - ln0);
+  const int YCAP = (int)(2.0 * P.yaw_range_deg / std::max(1e-9, P.yaw_step_deg)) + 3;
+  const size_t n_yaw = (size_t)nf * YCAP, n_top = (size_t)(b->top_base[b->box_base[f1]] - tp0);
+  if ((long long)nj * 1 > 0x7fffffffLL || (long long)n_lines > 0x7fffffffLL) { set_err("chunk too large"); return CS_ERR_CAPACITY; }
+  S.nj = nj;
+  if (nj == 0) { S.nb = 0; S.slot_total = 0; S.vp_total = 0; S.in_flight = true; C.tm->setup_host_ms += now_ms() - t0; HIP_TRY(hipEventRecord(S.done, st)); return CS_OK; }
+  int rc;
+#define PENS(buf, n) do { rc = (buf).ensure(n); if (rc) return rc; } while (0)
+  PENS(S.h_jobs_in, nj); PENS(S.h_slot_prefix, nj + 1); PENS(S.h_vp_prefix, nj + 1); PENS(S.h_yaw, n_yaw + 1); PENS(S.h_yaw_c, n_yaw + 1); PENS(S.h_yaw_s, n_yaw + 1);
+  PENS(S.h_top_x, n_top + 1); PENS(S.h_box_job0, nj); PENS(S.h_box_njobs, nj);
+  std::atomic<int> overflow{0};
   d->pool->run(nf, [&](int q) {
     const int f = f0 + q;
     const FrameIn& F = b->frames[f];
-    FrameJobs& R = fj[q];
-    int yoff = -1, nY = 0;
+    cs::JobDesc* jout = S.h_jobs_in.p + (b->job_base[f] - jb0);
+    double* yw = S.h_yaw.p + (size_t)q * YCAP; double* yc = S.h_yaw_c.p + (size_t)q * YCAP; double* ys = S.h_yaw_s.p + (size_t)q * YCAP;
+    int nY = -1, ji = 0;
     for (int bi = 0; bi < F.n_boxes; bi++) {
       const double* bb = &F.boxes[5 * bi];
       int left = bb[0], top = bb[1], w = bb[2], h = bb[3];
       int right = left + bb[2];
       int res = (int)std::round(std::min(20, w / 10));
-      if (res < 1) continue;  // :215
-      if (yoff < 0) {  // cam_pose never changes without roll/pitch sampling: one yaw list per frame (:180-184)
-        double yaw_init = (*C.cam_raw)[f].cam_yaw - 90.0 / 180.0 * CS_PI;
-        linespace<double>(yaw_init - P.yaw_range_deg / 180.0 * CS_PI, yaw_init + P.yaw_range_deg / 180.0 * CS_PI, P.yaw_step_deg / 180.0 * CS_PI, R.yaw);
-        for (double y : R.yaw) { R.yc.push_back(h_cos(y)); R.ys.push_back(h_sin(y)); }
-        yoff = 0; nY = (int)R.yaw.size();
+      const int tb = b->top_base[b->box_base[f] + bi] - tp0, tcap = b->top_base[b->box_base[f] + bi + 1] - tp0 - tb;
+      int nT = 0;
+      if (res >= 1) {
+        if (nY < 0) {  // cam_pose never changes without roll/pitch sampling: one yaw list per frame (:180-184)
+          double yaw_init = (*C.cam_raw)[f].cam_yaw - 90.0 / 180.0 * CS_PI;
+          std::vector<double> yl;
+          linespace<double>(yaw_init - P.yaw_range_deg / 180.0 * CS_PI, yaw_init + P.yaw_range_deg / 180.0 * CS_PI, P.yaw_step_deg / 180.0 * CS_PI, yl);
+          nY = (int)yl.size();
+          if (nY > YCAP) { overflow = 1; nY = 0; }
+          for (int y = 0; y < nY; y++) { yw[y] = yl[y]; yc[y] = h_cos(yl[y]); ys[y] = h_sin(yl[y]); }
+        }
+        int* tx = S.h_top_x.p + tb;
+        for (int x = left + 5; x <= right - 5 && nT < tcap; x += res) tx[nT++] = x;   // linespace<int> (matrix_utils.cpp:368-380)
       }
-      std::vector<int> tops;
-      linespace<int>(left + 5, right - 5, res, tops);
-      int toff = (int)R.tops.size();
-      R.tops.insert(R.tops.end(), tops.begin(), tops.end());
       for (int k = 0; k < F.n_heights[bi]; k++) {
         const cs_roi& roi = F.rois[3 * bi + k];
         cs::JobDesc jd;
@@ -777,54 +824,35 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
         int he = h + roi.down_expand;
         jd.g.left = left; jd.g.top = top; jd.g.right = right; jd.g.down = top + he;
         jd.g.el = roi.left; jd.g.et = roi.top; jd.g.er = roi.left + roi.width; jd.g.eb = roi.top + roi.height;
-        jd.map_w = roi.width; jd.Y = nY; jd.T = (int)tops.size(); jd.RP = 1; jd.down_expand = roi.down_expand;
+        jd.map_w = roi.width; jd.Y = (res >= 1) ? std::max(nY, 0) : 0; jd.T = nT; jd.RP = 1; jd.down_expand = roi.down_expand;
         jd.frame = f; jd.box = bi; jd.hid = k; jd.map_off = F.map_offs[3 * bi + k]; jd.rp_off = (*C.rp_off)[f];
         jd.diag = std::sqrt(double(w * w + he * he));
-        jd.yaw_off = 0; jd.top_off = toff;  // frame-local for now
-        R.jobs.push_back(jd);
+        jd.yaw_off = q * YCAP; jd.top_off = tb;
+        jd.line_off = (int)(b->line_base[f] - ln0) + ji * F.n_lines;
+        jout[ji++] = jd;
       }
     }
   });
-  // ---- offsets (serial prefix over frames), then parallel packing straight into pinned staging buffers
-  std::vector<size_t> o_job(nf + 1, 0), o_line(nf + 1, 0), o_yaw(nf + 1, 0), o_top(nf + 1, 0);
-  std::vector<long long> o_slot(nf + 1, 0), o_vp(nf + 1, 0);
-  for (int q = 0; q < nf; q++) {
-    long long ns = 0, nv = 0;
-    for (auto& jd : fj[q].jobs) { nv += (long long)jd.Y; ns += (long long)jd.Y * jd.T * 2; }
-    o_job[q + 1] = o_job[q] + fj[q].jobs.size();
-    o_line[q + 1] = o_line[q] + fj[q].jobs.size() * (size_t)b->frames[f0 + q].n_lines;
-    o_yaw[q + 1] = o_yaw[q] + fj[q].yaw.size(); o_top[q + 1] = o_top[q] + fj[q].tops.size();
-    o_slot[q + 1] = o_slot[q] + ns; o_vp[q + 1] = o_vp[q] + nv;
-  }
-  const size_t nj = o_job[nf], n_lines = o_line[nf], n_yaw = o_yaw[nf], n_top = o_top[nf];
-  S.nj = nj; S.slot_total = o_slot[nf]; S.vp_total = (int)o_vp[nf];
-  if (o_vp[nf] > 0x7fffffffLL) { set_err("too many yaw samples in one chunk"); return CS_ERR_CAPACITY; }
-  if (nj == 0) { S.nb = 0; S.in_flight = true; C.tm->setup_host_ms += now_ms() - t0; HIP_TRY(hipEventRecord(S.done, st)); return CS_OK; }
-  int rc;
-#define PENS(buf, n) do { rc = (buf).ensure(n); if (rc) return rc; } while (0)
-  PENS(S.h_jobs_in, nj); PENS(S.h_slot_prefix, nj + 1); PENS(S.h_vp_prefix, nj + 1); PENS(S.h_yaw, n_yaw + 1); PENS(S.h_yaw_c, n_yaw + 1); PENS(S.h_yaw_s, n_yaw + 1);
-  PENS(S.h_top_x, n_top + 1); PENS(S.h_box_job0, nj); PENS(S.h_box_njobs, nj);
-  d->pool->run(nf, [&](int q) {
-    FrameJobs& R = fj[q];
-    size_t ji = o_job[q], lo = o_line[q];
-    long long so = o_slot[q], vo = o_vp[q];
-    std::copy(R.yaw.begin(), R.yaw.end(), S.h_yaw.p + o_yaw[q]);
-    std::copy(R.yc.begin(), R.yc.end(), S.h_yaw_c.p + o_yaw[q]);
-    std::copy(R.ys.begin(), R.ys.end(), S.h_yaw_s.p + o_yaw[q]);
-    std::copy(R.tops.begin(), R.tops.end(), S.h_top_x.p + o_top[q]);
-    const int M = b->frames[f0 + q].n_lines;
-    for (auto& jd : R.jobs) {
-      jd.line_off = (int)lo; jd.yaw_off = (int)o_yaw[q]; jd.top_off += (int)o_top[q]; jd.vp_off = (int)vo; jd.slot_off = so;
-      S.h_slot_prefix.p[ji] = so; S.h_vp_prefix.p[ji] = (int)vo;
-      vo += jd.Y; so += (long long)jd.Y * jd.T * 2; lo += M;
-      S.h_jobs_in.p[ji++] = jd;
-    }
-  });
-  S.h_slot_prefix.p[nj] = o_slot[nf]; S.h_vp_prefix.p[nj] = (int)o_vp[nf];
+  if (overflow) { set_err("yaw sample list exceeds its capacity"); return CS_ERR_CAPACITY; }
+  MARK(0, tq);   // per-frame jobs + sample lists
+  // ---- slot / vanishing-point prefixes and the box table: one serial pass over the jobs
   size_t nb = 0;
-  for (size_t j = 0; j < nj; j++)
-    if (S.h_jobs_in.p[j].hid == 0) { S.h_box_job0.p[nb] = (int)j; S.h_box_njobs.p[nb] = b->frames[S.h_jobs_in.p[j].frame].n_heights[S.h_jobs_in.p[j].box]; nb++; }
+  {
+    long long so = 0, vo = 0;
+    for (size_t j = 0; j < nj; j++) {
+      cs::JobDesc& jd = S.h_jobs_in.p[j];
+      jd.slot_off = so; jd.vp_off = (int)vo;
+      S.h_slot_prefix.p[j] = so; S.h_vp_prefix.p[j] = (int)vo;
+      so += (long long)jd.Y * jd.T * 2; vo += jd.Y;
+      if (jd.hid == 0 && jd.Y > 0 && jd.T > 0) { S.h_box_job0.p[nb] = (int)j; S.h_box_njobs.p[nb] = b->frames[jd.frame].n_heights[jd.box]; nb++; }
+    }
+    S.h_slot_prefix.p[nj] = so; S.h_vp_prefix.p[nj] = (int)vo;
+    S.slot_total = so; S.vp_total = (int)vo;
+    if (vo > 0x7fffffffLL) { set_err("too many yaw samples in one chunk"); return CS_ERR_CAPACITY; }
+  }
   S.nb = nb;
+  MARK(1, tq);   // prefixes + box table
+  MARK(2, tq);   // box table
   C.tm->setup_host_ms += now_ms() - t0;
   C.tm->n_jobs += (long long)nj; C.tm->n_slots += S.slot_total;
   // ---- device buffers, H2D, kernels, D2H: all asynchronous on the detector's stream
@@ -875,6 +903,7 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   HIP_TRY(hipMemcpyAsync(S.h_jobs_out.p, S.jobs.p, sizeof(cs::JobDesc) * nj, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipEventRecord(S.done, st));
   S.in_flight = true;
+  MARK(3, tq);   // allocations + enqueue of copies and kernels
   return CS_OK;
 }
 
@@ -883,7 +912,7 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
   const cs_detect_params& P = d->prm;
   const int KMAX = P.max_cuboid_num, MB = b->max_boxes;
   cs_detect_timing& tm = *C.tm;
-  double tw = now_ms();
+  double tw = now_ms(), tq = tw;
   HIP_TRY(hipEventSynchronize(S.done));
   tm.d2h_ms += now_ms() - tw;   // time the host actually waited for the GPU
   S.in_flight = false;
@@ -903,11 +932,12 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
     tm.n_valid += n_valid;
     tm.cand_kernel_bytes += 48LL * S.vp_total + 4LL * S.slot_total + 128LL * n_valid;
     long long sbytes = 48LL * S.vp_total + (128LL + 28LL + 8LL) * n_valid;
-    for (size_t j = 0; j < nj; j++) sbytes += 4LL * S.h_jobs_in.p[j].map_w * (S.h_jobs_in.p[j].g.eb - S.h_jobs_in.p[j].g.et);
+    for (size_t j = 0; j < nj; j++) if (S.h_jobs_in.p[j].Y > 0 && S.h_jobs_in.p[j].T > 0) sbytes += 4LL * S.h_jobs_in.p[j].map_w * (S.h_jobs_in.p[j].g.eb - S.h_jobs_in.p[j].g.et);
     tm.score_kernel_bytes += sbytes;
   }
   const cs::JobDesc* jobs = S.h_jobs_in.p;
   hipStream_t st2 = d->stream2;
+  MARK(4, tq);   // wait for the GPU + timing bookkeeping
   // ---- boxes the kernel flagged (a tie at a cut or at the top): exact std::partial_sort ranking on the host.  Their
   // columns are fetched on the second stream, concurrently with the next chunk's sweep on the first.
   std::vector<long long> fb_src, fb_dst;
@@ -939,8 +969,38 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
       HIP_TRY(hipMemcpyAsync(S.h_fb_flag.p, S.fb_flag.p, 4 * (size_t)tot, hipMemcpyDeviceToHost, st2));
       HIP_TRY(hipMemcpyAsync(S.h_fb_slot.p, S.fb_slot.p, 8 * (size_t)tot, hipMemcpyDeviceToHost, st2));
     }
-    HIP_TRY(hipStreamSynchronize(st2));
   }
+  MARK(5, tq);   // tie lists + gather enqueue
+  // ---- records of the winners.  The boxes the device ranked are written while the tie boxes' columns travel.
+  auto write_box = [&](size_t q, const cs::RankWinner* wl, int nw) {
+    const int j0 = S.h_box_job0.p[q], nh = S.h_box_njobs.p[q];
+    const int f = jobs[j0].frame, bi = jobs[j0].box;
+    const FrameIn& F = b->frames[f];
+    const double* bb = &F.boxes[5 * bi];
+    for (int r = 0; r < nw; r++) {
+      const cs::RankWinner& w = wl[r];
+      int h = 0;
+      while (h + 1 < nh && w.slot >= jobs[j0 + h + 1].slot_off) h++;
+      const cs::JobDesc& jd = jobs[j0 + h];
+      long long local = w.slot - jd.slot_off;
+      long long rest = local >> 1;
+      int t = (int)(rest % jd.T), y = (int)(rest / jd.T);
+      const cs::RpPose& pose = cam_rp[f][0].pose;
+      double r9[9] = {(double)((local & 1) + 1), (double)(w.flag & cs::CAND_VP_MASK), S.h_yaw.p[jd.yaw_off + y], (double)t, w.dist_err, w.angle_err,
+                      (double)jd.down_expand, pose.roll, pose.pitch};
+      cs_cuboid& o = C.out[((size_t)f * MB + bi) * KMAX + r];
+      finish_cuboid(F, pose, r9, w.corners, (*C.cam_raw)[f].euler, false, w.normalized_error, o);
+      o.rect_detect_2d[0] = (int)bb[0]; o.rect_detect_2d[1] = (int)bb[1]; o.rect_detect_2d[2] = (int)bb[2]; o.rect_detect_2d[3] = (int)bb[3];
+    }
+    C.out_counts[(size_t)f * MB + bi] = nw;
+  };
+  d->pool->run((int)nb, [&](int qi) {
+    const size_t q = (size_t)qi;
+    if (!S.h_fallback.p[q]) write_box(q, S.h_winners.p + q * KMAX, S.h_win_count.p[q]);
+  });
+  MARK(6, tq);   // records of the device-ranked boxes
+  if (!fb_src.empty()) HIP_TRY(hipStreamSynchronize(st2));
+  MARK(7, tq);   // wait for the tie columns
   const double* fb_dist = S.h_fb_dist.p; const double* fb_angle = S.h_fb_angle.p; const double* fb_skew = S.h_fb_skew.p;
   const int* fb_flag = S.h_fb_flag.p; const long long* fb_slot = S.h_fb_slot.p;
   std::vector<std::vector<cs::RankWinner>> fb_winners(nb);
@@ -982,6 +1042,7 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
   for (size_t q = 0; q < nb; q++) if (S.h_fallback.p[q]) fbq.push_back((int)q);
   tm.n_fallback_boxes += (int)fbq.size();
   d->pool->run((int)fbq.size(), [&](int z) { rank_on_host((size_t)fbq[z]); });
+  MARK(8, tq);   // exact ranking of the tie boxes
   {
     std::vector<long long> ws;
     for (int q : fbq) for (auto& w : fb_winners[q]) ws.push_back(w.slot);
@@ -997,32 +1058,9 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
       for (int q : fbq) for (auto& w : fb_winners[q]) { std::memcpy(w.corners, &hc[16 * z], 128); z++; }
     }
   }
-  // ---- records of the winners
-  d->pool->run((int)nb, [&](int qi) {
-    const size_t q = (size_t)qi;
-    const int j0 = S.h_box_job0.p[q], nh = S.h_box_njobs.p[q];
-    const int f = jobs[j0].frame, bi = jobs[j0].box;
-    const FrameIn& F = b->frames[f];
-    const double* bb = &F.boxes[5 * bi];
-    const cs::RankWinner* wl = S.h_fallback.p[q] ? fb_winners[q].data() : S.h_winners.p + q * KMAX;
-    const int nw = S.h_fallback.p[q] ? (int)fb_winners[q].size() : S.h_win_count.p[q];
-    for (int r = 0; r < nw; r++) {
-      const cs::RankWinner& w = wl[r];
-      int h = 0;
-      while (h + 1 < nh && w.slot >= jobs[j0 + h + 1].slot_off) h++;
-      const cs::JobDesc& jd = jobs[j0 + h];
-      long long local = w.slot - jd.slot_off;
-      long long rest = local >> 1;
-      int t = (int)(rest % jd.T), y = (int)(rest / jd.T);
-      const cs::RpPose& pose = cam_rp[f][0].pose;
-      double r9[9] = {(double)((local & 1) + 1), (double)(w.flag & cs::CAND_VP_MASK), S.h_yaw.p[jd.yaw_off + y], (double)t, w.dist_err, w.angle_err,
-                      (double)jd.down_expand, pose.roll, pose.pitch};
-      cs_cuboid& o = C.out[((size_t)f * MB + bi) * KMAX + r];
-      finish_cuboid(F, pose, r9, w.corners, (*C.cam_raw)[f].euler, false, w.normalized_error, o);
-      o.rect_detect_2d[0] = (int)bb[0]; o.rect_detect_2d[1] = (int)bb[1]; o.rect_detect_2d[2] = (int)bb[2]; o.rect_detect_2d[3] = (int)bb[3];
-    }
-    C.out_counts[(size_t)f * MB + bi] = nw;
-  });
+  MARK(9, tq);   // corners of the tie winners
+  d->pool->run((int)fbq.size(), [&](int z) { const size_t q = (size_t)fbq[z]; write_box(q, fb_winners[q].data(), (int)fb_winners[q].size()); });
+  MARK(10, tq);  // records of the tie boxes
   tm.finalize_ms += now_ms() - t0;
   return CS_OK;
 }
@@ -1099,6 +1137,7 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
   }
   tm.setup_host_ms += now_ms() - t0;
 
+  if (g_prof) g_mark[11] += now_ms() - t_begin;   // camera caches + pose pool upload
   // ---- production path: chunked two-slot pipeline (host packs chunk k+1 / finishes chunk k-1 while the GPU sweeps k)
   if (!sample_rp && !b->debug && !b->force_host_rank && !b->force_host_setup && !b->force_no_pipeline && b->device_setup && KMAX <= cs::RANK_KMAX && MB > 0) {
     PipeCtx C{d, b, out, out_counts, &cam_raw, &rp_off, sp, &tm};
@@ -1117,6 +1156,12 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
     tm.total_ms = now_ms() - t_begin;
     b->timing = tm;
     b->ran = true;
+    if (g_prof && (++g_runs % 8) == 0) {
+      const char* nm[11] = {"jobs+samples", "prefix+pack", "box table", "alloc+enqueue", "gpu wait", "tie lists", "records", "tie wait", "tie rank", "tie corners", "tie records"};
+      fprintf(stderr, "[detect] host ms/run:");
+      for (int k = 0; k < 11; k++) { fprintf(stderr, " %s %.3f", nm[k], g_mark[k] / 8); g_mark[k] = 0; }
+      fprintf(stderr, " | pre %.3f total %.3f\n", g_mark[11] / 8, tm.total_ms); g_mark[11] = 0;
+    }
     return CS_OK;
   }
 

@@ -618,6 +618,7 @@ __global__ __launch_bounds__(LS_THREADS) void line_setup_kernel(JobDesc* jobs, i
   int j = blockIdx.x;
   if (j >= n_jobs) return;
   const JobDesc jd = jobs[j];
+  if (jd.Y == 0 || jd.T == 0) return;   // a box the sweep skips (no yaw / top-edge samples): m stays 0
   const double* FL = frame_lines + 4 * (size_t)frame_line_ptr[jd.frame];
   const int M = frame_line_ptr[jd.frame + 1] - frame_line_ptr[jd.frame];
   const int lane = threadIdx.x;
