@@ -10,7 +10,7 @@
 // setLambda(), solve(), restoreDiagonal(), reads x()/b()/vectorSize() (core/solver.h:95-103), and calls the
 // optimizer's computeActiveErrors()/activeRobustChi2()/update()/push()/pop() -- which stay on the CPU unless the
 // caller swaps the whole loop for cs_ba_optimize().  Vertex/edge types handled on the device:
-// VertexSE3Expmap, VertexSBAPointXYZ, VertexCuboid, EdgeSE3ProjectXYZ, EdgeSE3Cuboid, EdgeSE3Expmap; any other
+// VertexSE3Expmap, VertexSBAPointXYZ, VertexCuboid, EdgeSE3ProjectXYZ, EdgeSE3Cuboid, EdgeSE3CuboidProj, EdgeSE3Expmap; any other
 // active edge makes init() fail loudly (no silent CPU fallback).
 //
 // Needs g2o + Eigen headers; not compiled in the build container (neither is installed there).
@@ -63,8 +63,8 @@ class BlockSolverHIP : public g2o::Solver {
     }
     if (cs_ba_set_vertices(ba_, cam7.data(), cam_fixed.data(), (int)cams_.size(), cub10.data(), cub_fixed.data(), (int)cubs_.size(),
                            pt3.data(), pt_fixed.data(), (int)pts_.size(), min_cub_id < min_cam_id) != CS_OK) return false;
-    std::vector<int> e_pt, e_cam, ce_cam, ce_cub, oe_i, oe_j;
-    std::vector<double> uv, info4, intr4, huber, meas10, info81, meas7, info36;
+    std::vector<int> e_pt, e_cam, ce_cam, ce_cub, pe_cam, pe_cub, oe_i, oe_j;
+    std::vector<double> uv, info4, intr4, huber, meas10, info81, meas7, info36, meas4, info16, K9;
     for (auto* e : _optimizer->activeEdges()) {
       if (auto* pe = dynamic_cast<g2o::EdgeSE3ProjectXYZ*>(e)) {
         e_pt.push_back(index_[pe->vertex(0)]); e_cam.push_back(index_[pe->vertex(1)]);
@@ -77,6 +77,11 @@ class BlockSolverHIP : public g2o::Solver {
         ce_cam.push_back(index_[ce->vertex(0)]); ce_cub.push_back(index_[ce->vertex(1)]);
         Vector10d m = ce->measurement().toVector(); meas10.insert(meas10.end(), m.data(), m.data() + 10);
         for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) info81.push_back(ce->information()(i, j));
+      } else if (auto* qe = dynamic_cast<g2o::EdgeSE3CuboidProj*>(e)) {
+        pe_cam.push_back(index_[qe->vertex(0)]); pe_cub.push_back(index_[qe->vertex(1)]);
+        for (int i = 0; i < 4; i++) meas4.push_back(qe->measurement()[i]);
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) info16.push_back(qe->information()(i, j));
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) K9.push_back(qe->Kalib(i, j));
       } else if (auto* oe = dynamic_cast<g2o::EdgeSE3Expmap*>(e)) {
         oe_i.push_back(index_[oe->vertex(0)]); oe_j.push_back(index_[oe->vertex(1)]);
         g2o::Vector7d m = oe->measurement().toVector(); meas7.insert(meas7.end(), m.data(), m.data() + 7);
@@ -87,6 +92,7 @@ class BlockSolverHIP : public g2o::Solver {
     }
     cs_ba_set_edges_proj(ba_, (int)e_pt.size(), e_pt.data(), e_cam.data(), uv.data(), info4.data(), intr4.data(), huber.data());
     cs_ba_set_edges_cuboid(ba_, (int)ce_cam.size(), ce_cam.data(), ce_cub.data(), meas10.data(), info81.data());
+    cs_ba_set_edges_cuboid_proj(ba_, (int)pe_cam.size(), pe_cam.data(), pe_cub.data(), meas4.data(), info16.data(), K9.data());
     cs_ba_set_edges_odom(ba_, (int)oe_i.size(), oe_i.data(), oe_j.data(), meas7.data(), info36.data());
     int sp = 0, sl = 0;
     cs_ba_sizes(ba_, &sp, &sl);

@@ -252,7 +252,7 @@ class CsBaTiming(C.Structure):
 
 
 DECLARED_SYMBOLS += [
-    "cs_ba_create", "cs_ba_destroy", "cs_ba_set_vertices", "cs_ba_set_estimates", "cs_ba_set_edges_proj", "cs_ba_set_edges_cuboid", "cs_ba_set_edges_odom",
+    "cs_ba_create", "cs_ba_destroy", "cs_ba_set_vertices", "cs_ba_set_estimates", "cs_ba_set_edges_proj", "cs_ba_set_edges_cuboid", "cs_ba_set_edges_cuboid_proj", "cs_ba_set_edges_odom",
     "cs_ba_compute_errors", "cs_ba_build_system", "cs_ba_solve", "cs_ba_update", "cs_ba_push", "cs_ba_pop", "cs_ba_optimize",
     "cs_ba_get_state", "cs_ba_sizes", "cs_ba_solver_layout", "cs_ba_get_system", "cs_ba_last_timing", "cs_ba_set_shard", "cs_ba_optimize_sharded",
     "cs_ba_shard_landmark_owners",
@@ -299,6 +299,12 @@ class BaProblem:
     def set_edges_cuboid(self, cam, cub, meas10, info81):
         cam, cub = _i32(cam), _i32(cub); self.n_cub = len(cam)
         _chk(lib().cs_ba_set_edges_cuboid(self.h, self.n_cub, _ip(cam), _ip(cub), _dp(_f64(meas10, (-1, 10))), _dp(_f64(info81, (-1, 81)))), "cs_ba_set_edges_cuboid")
+
+    def set_edges_cuboid_proj(self, cam, cub, meas4, info16, K9):
+        """EdgeSE3CuboidProj: bounding-box (cx, cy, w, h) error of the projected cuboid."""
+        cam, cub = _i32(cam), _i32(cub); self.n_cproj = len(cam)
+        _chk(lib().cs_ba_set_edges_cuboid_proj(self.h, self.n_cproj, _ip(cam), _ip(cub), _dp(_f64(meas4, (-1, 4))), _dp(_f64(info16, (-1, 16))), _dp(_f64(K9, (-1, 9)))),
+             "cs_ba_set_edges_cuboid_proj")
 
     def set_edges_odom(self, ci, cj, meas7, info36):
         ci, cj = _i32(ci), _i32(cj); self.n_odom = len(ci)
@@ -398,6 +404,8 @@ def ba_from_dict(pr, device=0, cuboids_first=False):
         P.set_edges_proj(pr["e_pt"], pr["e_cam"], pr["e_uv"], pr["e_info"], pr["e_intr"], pr["e_huber"])
     if len(pr["ce_cam"]):
         P.set_edges_cuboid(pr["ce_cam"], pr["ce_cub"], pr["ce_meas"], pr["ce_info"])
+    if len(pr.get("pe_cam", [])):
+        P.set_edges_cuboid_proj(pr["pe_cam"], pr["pe_cub"], pr["pe_meas"], pr["pe_info"], pr["pe_K"])
     if len(pr["oe_i"]):
         P.set_edges_odom(pr["oe_i"], pr["oe_j"], pr["oe_meas"], pr["oe_info"])
     return P

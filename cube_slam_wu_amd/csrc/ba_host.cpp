@@ -101,7 +101,11 @@ struct cs_ba {
   std::vector<int> keep;                      // caller indices of the projection edges this rank owns
   size_t s_doubles = 0;                       // size of S; rhs follows it in the same allocation (one all-reduce)
   int n_pose = 0, n_lm = 0;
-  int n_proj = 0, n_cub = 0, n_odom = 0;
+  int n_proj = 0, n_cub = 0, n_odom = 0;   // n_cub = EdgeSE3Cuboid + EdgeSE3CuboidProj edges (the combined list ce_cam / ce_cub)
+  int n_cub3 = 0;                          // of which EdgeSE3Cuboid (they come first)
+  std::vector<int> u3_cam, u3_cub, up_cam, up_cub;      // the caller's two lists
+  std::vector<double> h_pe_meas, h_pe_info, h_pe_K;
+  DBuf<double> pe_meas, pe_info, pe_K;
   std::vector<int> e_pt, e_cam;      // projection edges, caller order
   std::vector<int> pm_of_orig;       // caller edge -> point-major slot
   std::vector<int> ce_cam, ce_cub, oe_i, oe_j;
@@ -145,6 +149,11 @@ int finalize_structure(cs_ba* B) {
   if (!B->structure_dirty) return CS_OK;
   BA_TRY(hipSetDevice(B->device));
   const int nc = B->nc, no = B->no, np = B->np;
+  // camera-cuboid edges of both kinds as one list: EdgeSE3Cuboid first, then EdgeSE3CuboidProj
+  B->ce_cam = B->u3_cam; B->ce_cam.insert(B->ce_cam.end(), B->up_cam.begin(), B->up_cam.end());
+  B->ce_cub = B->u3_cub; B->ce_cub.insert(B->ce_cub.end(), B->up_cub.begin(), B->up_cub.end());
+  B->n_cub3 = (int)B->u3_cam.size();
+  B->n_cub = (int)B->ce_cam.size();
   // ---- index mapping (sparse_optimizer.cpp:166-190): non-marginalised vertices by id, then the points
   B->cam_col_ref.assign(nc, -1); B->cub_col_ref.assign(no, -1); B->pt_lm.assign(np, -1);
   {
@@ -330,6 +339,7 @@ int finalize_structure(cs_ba* B) {
     UP(B->d_ce_active, ca); UP(B->d_oe_active, oa);
   }
   UP(B->ce_meas, B->h_ce_meas); UP(B->ce_info, B->h_ce_info); UP(B->oe_meas, B->h_oe_meas); UP(B->oe_info, B->h_oe_info);
+  UP(B->pe_meas, B->h_pe_meas); UP(B->pe_info, B->h_pe_info); UP(B->pe_K, B->h_pe_K);
   AL(B->ce_Hcc, 36 * (size_t)B->n_cub); AL(B->ce_Hoo, 81 * (size_t)B->n_cub); AL(B->ce_Hco, 54 * (size_t)B->n_cub); AL(B->ce_bc, 6 * (size_t)B->n_cub); AL(B->ce_bo, 9 * (size_t)B->n_cub);
   AL(B->oe_Hii, 36 * (size_t)B->n_odom); AL(B->oe_Hjj, 36 * (size_t)B->n_odom); AL(B->oe_Hij, 36 * (size_t)B->n_odom); AL(B->oe_bi, 6 * (size_t)B->n_odom); AL(B->oe_bj, 6 * (size_t)B->n_odom);
   // ---- linear system storage
@@ -353,6 +363,7 @@ int finalize_structure(cs_ba* B) {
   v.nc = nc; v.np = np; v.no = no; v.n_pose = B->n_pose;
   v.n_proj = E; v.pm_pt = B->pm_pt.p; v.pm_cam = B->pm_cam.p; v.pm_uv = B->pm_uv.p; v.pm_info = B->pm_info.p; v.pm_intr = B->pm_intr.p; v.pm_huber = B->pm_huber.p;
   v.pt_ptr = B->pt_ptr.p; v.cm_pm = B->cm_pm.p; v.cm_pt = B->cm_pt.p; v.cm_uv = B->cm_uv.p; v.cm_info = B->cm_info.p; v.cm_intr = B->cm_intr.p; v.cm_huber = B->cm_huber.p; v.cam_ptr = B->cam_ptr.p;
+  v.n_cub3 = B->n_cub3; v.pe_meas = B->pe_meas.p; v.pe_info = B->pe_info.p; v.pe_K = B->pe_K.p;
   v.n_cub = B->n_cub; v.ce_cam = B->d_ce_cam.p; v.ce_cub = B->d_ce_cub.p; v.ce_meas = B->ce_meas.p; v.ce_info = B->ce_info.p; v.ce_active = B->d_ce_active.p;
   v.ce_Hcc = B->ce_Hcc.p; v.ce_Hoo = B->ce_Hoo.p; v.ce_Hco = B->ce_Hco.p; v.ce_bc = B->ce_bc.p; v.ce_bo = B->ce_bo.p;
   v.n_odom = B->n_odom; v.oe_i = B->d_oe_i.p; v.oe_j = B->d_oe_j.p; v.oe_meas = B->oe_meas.p; v.oe_info = B->oe_info.p; v.oe_active = B->d_oe_active.p;
@@ -508,7 +519,7 @@ void cs_ba_destroy(cs_ba* B) {
   DBuf<double>* dd[] = {&B->cams, &B->points, &B->cubes, &B->cams_bak, &B->points_bak, &B->cubes_bak, &B->pm_uv, &B->pm_info, &B->pm_intr, &B->pm_huber,
                         &B->cm_uv, &B->cm_info, &B->cm_intr, &B->cm_huber, &B->ce_meas, &B->ce_info, &B->ce_Hcc, &B->ce_Hoo, &B->ce_Hco, &B->ce_bc, &B->ce_bo,
                         &B->oe_meas, &B->oe_info, &B->oe_Hii, &B->oe_Hjj, &B->oe_Hij, &B->oe_bi, &B->oe_bj, &B->Hcam, &B->bcam, &B->Hcub, &B->bcub, &B->Hll, &B->bl,
-                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv, &B->scale_partial};
+                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv, &B->scale_partial, &B->pe_meas, &B->pe_info, &B->pe_K};
   for (auto* d : dd) d->release();
   DBuf<int>* di[] = {&B->d_ce_active, &B->d_oe_active, &B->d_cam_col, &B->d_cub_col, &B->d_pt_free, &B->pm_pt, &B->pm_cam, &B->pt_ptr, &B->cm_pm, &B->cm_pt, &B->cam_ptr, &B->d_ce_cam, &B->d_ce_cub,
                      &B->d_oe_i, &B->d_oe_j, &B->cam_ce_ptr, &B->cam_ce_idx, &B->cam_oei_ptr, &B->cam_oei_idx, &B->cam_oej_ptr, &B->cam_oej_idx, &B->cub_ce_ptr,
@@ -564,9 +575,16 @@ int cs_ba_set_edges_proj(cs_ba* B, int n, const int* pt, const int* cam, const d
 
 int cs_ba_set_edges_cuboid(cs_ba* B, int n, const int* cam, const int* cub, const double* meas10, const double* info81) {
   if (!B || n < 0 || (n && (!cam || !cub || !meas10 || !info81))) return CS_ERR_INVALID_ARG;
-  B->n_cub = n;
-  B->ce_cam.assign(cam, cam + n); B->ce_cub.assign(cub, cub + n);
+  B->u3_cam.assign(cam, cam + n); B->u3_cub.assign(cub, cub + n);
   B->h_ce_meas.assign(meas10, meas10 + 10 * (size_t)n); B->h_ce_info.assign(info81, info81 + 81 * (size_t)n);
+  B->structure_dirty = true;
+  return CS_OK;
+}
+
+int cs_ba_set_edges_cuboid_proj(cs_ba* B, int n, const int* cam, const int* cub, const double* meas4, const double* info16, const double* K9) {
+  if (!B || n < 0 || (n && (!cam || !cub || !meas4 || !info16 || !K9))) return CS_ERR_INVALID_ARG;
+  B->up_cam.assign(cam, cam + n); B->up_cub.assign(cub, cub + n);
+  B->h_pe_meas.assign(meas4, meas4 + 4 * (size_t)n); B->h_pe_info.assign(info16, info16 + 16 * (size_t)n); B->h_pe_K.assign(K9, K9 + 9 * (size_t)n);
   B->structure_dirty = true;
   return CS_OK;
 }
@@ -835,7 +853,7 @@ int cs_ba_last_timing(cs_ba* B, cs_ba_timing* t) {
   // algorithmic bytes per linearisation + Schur build: per projection edge 136 B read
   // + 144 B Hpl written, re-read once by the Schur stage; per camera 336 B; per point 96 B written, 96 B read,
   // 72 B Dinv written; per cuboid edge 864 B read + 432 B written.
-  t->linearize_bytes = (long long)B->keep.size() * (136 + 144 + 144) + (long long)B->nc * 336 + (long long)B->np * 264 + (long long)B->n_cub * (864 + 432);
+  t->linearize_bytes = (long long)B->keep.size() * (136 + 144 + 144) + (long long)B->nc * 336 + (long long)B->np * 264 + (long long)B->n_cub3 * (864 + 432) + (long long)(B->n_cub - B->n_cub3) * (368 + 1400);
   return CS_OK;
 }
 

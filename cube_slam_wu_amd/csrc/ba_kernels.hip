@@ -110,10 +110,17 @@ __device__ __forceinline__ double quad_form(const double* e, const double* info,
 __global__ __launch_bounds__(64) void ba_chi2_pose_edges_kernel(BaView v, int partial_off) {
   int k = blockIdx.x * 64 + threadIdx.x;
   double c = 0;
-  if (k < v.n_cub) {
+  if (k < v.n_cub3) {
     double e[9];
     if (v.ce_active[k]) cuboid_edge_error(pose_load(v.cams + 7 * v.ce_cam[k]), cube_load(v.cubes + 10 * v.ce_cub[k]), cube_load(v.ce_meas + 10 * k), e);
     if (v.ce_active[k]) c = quad_form(e, v.ce_info + 81 * k, 9);
+  } else if (k < v.n_cub) {
+    const int q = k - v.n_cub3;
+    double e[4];
+    if (v.ce_active[k]) {
+      cuboid_proj_error(pose_load(v.cams + 7 * v.ce_cam[k]), cube_load(v.cubes + 10 * v.ce_cub[k]), v.pe_K + 9 * (size_t)q, v.pe_meas + 4 * (size_t)q, e);
+      c = quad_form(e, v.pe_info + 16 * (size_t)q, 4);
+    }
   } else if (k < v.n_cub + v.n_odom) {
     int q = k - v.n_cub;
     double e[6];
@@ -279,7 +286,37 @@ __global__ __launch_bounds__(64) void ba_cub_edge_kernel(BaView v) {
   const int k = blockIdx.x * 4 + sub;
   const bool live = k < v.n_cub;
   const double delta = 1e-9, scalar = 1.0 / (2 * delta);
-  if (live) {
+  const bool is3d = k < v.n_cub3;      // EdgeSE3Cuboid, else EdgeSE3CuboidProj
+  double (*Jq)[4] = reinterpret_cast<double (*)[4]>(&J[sub][0][0]);   // the 4-row view of this edge's column store
+  if (live && !is3d) {
+    const int q = k - v.n_cub3;
+    Pose T = pose_load(v.cams + 7 * v.ce_cam[k]);
+    Cube cube = cube_load(v.cubes + 10 * v.ce_cub[k]);
+    const double* K = v.pe_K + 9 * (size_t)q;
+    const double* meas = v.pe_meas + 4 * (size_t)q;
+    const bool act = v.ce_active[k] != 0;
+    const bool fa = act && v.cam_col[v.ce_cam[k]] >= 0, fb = act && v.cub_col[v.ce_cub[k]] >= 0;
+    double e1[4], e2[4];
+    if (d == 15) {
+      cuboid_proj_error(T, cube, K, meas, e1);
+      for (int r = 0; r < 4; r++) Jq[15][r] = act ? e1[r] : 0.0;
+    } else if (d < 6) {
+      double add[6] = {0, 0, 0, 0, 0, 0};
+      if (fa) {
+        add[d] = delta; cuboid_proj_error(cam_oplus(T, add), cube, K, meas, e1);
+        add[d] = -delta; cuboid_proj_error(cam_oplus(T, add), cube, K, meas, e2);
+      }
+      for (int r = 0; r < 4; r++) Jq[d][r] = fa ? scalar * (e1[r] - e2[r]) : 0.0;
+    } else {
+      double add[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if (fb) {
+        add[d - 6] = delta; cuboid_proj_error(T, cube_oplus(cube, add), K, meas, e1);
+        add[d - 6] = -delta; cuboid_proj_error(T, cube_oplus(cube, add), K, meas, e2);
+      }
+      for (int r = 0; r < 4; r++) Jq[d][r] = fb ? scalar * (e1[r] - e2[r]) : 0.0;
+    }
+  }
+  if (live && is3d) {
     Pose T = pose_load(v.cams + 7 * v.ce_cam[k]);
     Cube cube = cube_load(v.cubes + 10 * v.ce_cub[k]);
     Cube meas = cube_load(v.ce_meas + 10 * k);
@@ -306,8 +343,11 @@ __global__ __launch_bounds__(64) void ba_cub_edge_kernel(BaView v) {
     }
   }
   __syncthreads();
-  if (live)
+  if (live && is3d)
     edge_rows_from_columns<9, 6, 9>(J[sub], J[sub][15], v.ce_info + 81 * (size_t)k, d, v.ce_Hcc + 36 * (size_t)k, v.ce_Hoo + 81 * (size_t)k,
+                                    v.ce_Hco + 54 * (size_t)k, v.ce_bc + 6 * (size_t)k, v.ce_bo + 9 * (size_t)k);
+  if (live && !is3d)
+    edge_rows_from_columns<4, 6, 9>(Jq, Jq[15], v.pe_info + 16 * (size_t)(k - v.n_cub3), d, v.ce_Hcc + 36 * (size_t)k, v.ce_Hoo + 81 * (size_t)k,
                                     v.ce_Hco + 54 * (size_t)k, v.ce_bc + 6 * (size_t)k, v.ce_bo + 9 * (size_t)k);
 }
 

@@ -23,7 +23,11 @@ struct BaView {
   const int* cm_pm;    // n_proj: index into the point-major arrays
   const int* cm_pt; const double* cm_uv; const double* cm_info; const double* cm_intr; const double* cm_huber;
   const int* cam_ptr;  // nc + 1
-  // ---- cuboid edges (EdgeSE3Cuboid) and odometry edges (EdgeSE3Expmap): numeric Jacobians ------------
+  // ---- cuboid edges and odometry edges (EdgeSE3Expmap): numeric Jacobians ------------------------------
+  // camera-cuboid edges 0 .. n_cub3 - 1 are EdgeSE3Cuboid (9-dim, ce_meas / ce_info), edges n_cub3 .. n_cub - 1 are
+  // EdgeSE3CuboidProj (4-dim bounding-box error, pe_meas 4 / pe_info 16 / pe_K 9 per edge, indexed k - n_cub3); both
+  // kinds share the index lists, the output blocks and the vertex adjacency
+  int n_cub3; const double* pe_meas; const double* pe_info; const double* pe_K;
   int n_cub; const int* ce_cam; const int* ce_cub; const double* ce_meas; const double* ce_info; const int* ce_active;
   double* ce_Hcc; double* ce_Hoo; double* ce_Hco; double* ce_bc; double* ce_bo;   // 36, 81, 54, 6, 9 per edge
   int n_odom; const int* oe_i; const int* oe_j; const double* oe_meas; const double* oe_info; const int* oe_active;

@@ -220,6 +220,32 @@ CS_HD void cuboid_edge_error(const Pose& Tcw, const Cube& cube, const Cube& meas
   esti.scale[0] = meas.scale[0]; esti.scale[1] = meas.scale[1]; esti.scale[2] = meas.scale[2];
   cube_min_log_error(cube, esti, r);
 }
+// EdgeSE3CuboidProj::computeError (g2o_Object.h:279-290): cuboid::projectOntoImageBbox (:181-197) of the cuboid's 8
+// corners (compute3D_BoxCorner :165-178, similarityTransform :154-160) minus the measured (centre x, centre y, w, h)
+CS_HD void cuboid_proj_error(const Pose& Tcw, const Cube& cube, const double* K, const double* meas4, double* r) {
+  double Ro[9], Rc[9], M[9];
+  pose_rotmat(cube.pose, Ro);
+  pose_rotmat(Tcw, Rc);
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[3 * i + j] = Ro[3 * i + j] * cube.scale[j];
+  double xmin = 0, xmax = 0, ymin = 0, ymax = 0;
+  for (int c = 0; c < 8; c++) {
+    // corner pattern of compute3D_BoxCorner: x = + + - - + + - -, y = + - - + + - - +, z = - - - - + + + +
+    const double sx = ((c >> 1) & 1) ? -1.0 : 1.0, sy = (((c + 1) >> 1) & 1) ? -1.0 : 1.0, sz = (c < 4) ? -1.0 : 1.0;
+    double Xw[3], Xc[3], p[3];
+    for (int i = 0; i < 3; i++) Xw[i] = ((M[3 * i] * sx + M[3 * i + 1] * sy) + M[3 * i + 2] * sz) + cube.pose.t[i] * 1.0;
+    for (int i = 0; i < 3; i++) Xc[i] = ((Rc[3 * i] * Xw[0] + Rc[3 * i + 1] * Xw[1]) + Rc[3 * i + 2] * Xw[2]) + Tcw.t[i] * 1.0;
+    for (int i = 0; i < 3; i++) p[i] = (K[3 * i] * Xc[0] + K[3 * i + 1] * Xc[1]) + K[3 * i + 2] * Xc[2];
+    const double u = p[0] / p[2], v = p[1] / p[2];
+    if (c == 0) { xmin = xmax = u; ymin = ymax = v; }
+    else {
+      if (u > xmax) xmax = u;
+      if (u < xmin) xmin = u;
+      if (v > ymax) ymax = v;
+      if (v < ymin) ymin = v;
+    }
+  }
+  r[0] = (xmax + xmin) / 2 - meas4[0]; r[1] = (ymax + ymin) / 2 - meas4[1]; r[2] = (xmax - xmin) - meas4[2]; r[3] = (ymax - ymin) - meas4[3];
+}
 // EdgeSE3Expmap::computeError (types_six_dof_expmap.h:90-99)
 CS_HD void odom_edge_error(const Pose& T1, const Pose& T2, const Pose& meas, double* r) {
   pose_log(pose_mul(pose_mul(meas, T1), pose_inv(T2)), r);

@@ -64,7 +64,27 @@ def small_pose(rng, n, rot_sigma, trans_sigma):
     return np.concatenate([rng.normal(0, trans_sigma, (n, 3)), q], 1)
 
 
-def make_problem(n_cams=200, n_points=20000, n_cuboids=50, seed=42, huber=True, obs_per_point=5, obs_per_cuboid=20):
+def quat_to_R(q):
+    """(x, y, z, w) -> 3x3 rotation."""
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+CORNERS_BODY = np.array([[1, 1, -1, -1, 1, 1, -1, -1], [1, -1, -1, 1, 1, -1, -1, 1], [-1, -1, -1, -1, 1, 1, 1, 1]], float)  # g2o_Object.h:169-171
+
+
+def project_bbox(T_cw7, cub10, K):
+    """cuboid::projectOntoImageBbox (g2o_Object.h:181-197) in numpy: (centre x, centre y, width, height)."""
+    Xw = quat_to_R(cub10[3:7]) @ (CORNERS_BODY * cub10[7:10, None]) + cub10[:3, None]
+    Xc = quat_to_R(T_cw7[3:7]) @ Xw + T_cw7[:3, None]
+    p = K @ Xc
+    u, v = p[0] / p[2], p[1] / p[2]
+    return np.array([(u.max() + u.min()) / 2, (v.max() + v.min()) / 2, u.max() - u.min(), v.max() - v.min()])
+
+
+def make_problem(n_cams=200, n_points=20000, n_cuboids=50, seed=42, huber=True, obs_per_point=5, obs_per_cuboid=20, bbox_edges=False):
     rng = np.random.default_rng(seed)
     # ---- trajectory: arc of radius 400 m, camera z forward along the tangent, y down, x right
     s = 0.8 * np.arange(n_cams)
@@ -159,7 +179,19 @@ def make_problem(n_cams=200, n_points=20000, n_cuboids=50, seed=42, huber=True, 
         cub0[:, 7:] += rng.normal(0, 0.05, (n_cuboids, 3))
     pts0 = pts + rng.normal(0, 0.1, pts.shape)
     cam_fixed = np.zeros(n_cams, np.int32); cam_fixed[0] = 1
+    # ---- optional EdgeSE3CuboidProj edges: the 2D detection box of every cuboid observation (own random stream, so that
+    # the rest of the problem does not depend on the switch)
+    pe_cam, pe_cub, pe_meas = [], [], []
+    Kmat = np.array([[FX, 0, CX], [0, FY, CY], [0, 0, 1.0]])
+    if bbox_edges:
+        rng2 = np.random.default_rng(seed + 7919)
+        for c, o in zip(ce_cam, ce_cub):
+            pe_cam.append(c); pe_cub.append(o)
+            pe_meas.append(project_bbox(T_cw_true[c], cub_true[o], Kmat) + rng2.normal(0, 2.0, 4))
+    n_pe = len(pe_cam)
     return dict(
+        pe_cam=np.array(pe_cam, np.int32), pe_cub=np.array(pe_cub, np.int32), pe_meas=np.array(pe_meas).reshape(-1, 4),
+        pe_info=np.tile((np.eye(4) * 0.25).ravel(), (n_pe, 1)), pe_K=np.tile(Kmat.ravel(), (n_pe, 1)),
         cams=cams0, cam_fixed=cam_fixed, cuboids=cub0, cub_fixed=np.zeros(n_cuboids, np.int32), points=pts0,
         pt_fixed=np.zeros(n_points, np.int32),
         e_pt=e_pt, e_cam=e_cam, e_uv=e_uv, e_info=info4, e_intr=intr4, e_huber=hub,

@@ -204,6 +204,12 @@ int cs_ba_set_edges_proj(cs_ba* ba, int n, const int* point, const int* cam, con
  * camera frame, info81 = 9x9 information.                                                          */
 int cs_ba_set_edges_cuboid(cs_ba* ba, int n, const int* cam, const int* cuboid, const double* meas10, const double* info81);
 /* EdgeSE3Expmap (types_six_dof_expmap.h:83-99): error = log(meas * T_i * T_j^-1); info36 = 6x6.      */
+/* EdgeSE3CuboidProj (object_slam/include/object_slam/g2o_Object.h:264-293): 4-dim error = bounding rectangle
+ * (centre x, centre y, width, height) of the cuboid's 8 projected corners (cuboid::projectOntoImageBbox :181-197) minus
+ * the measured one; vertex 0 = camera, vertex 1 = cuboid; numeric Jacobians like EdgeSE3Cuboid.  meas4: n x 4,
+ * info16: n x 16 (row-major 4 x 4), K9: n x 9 (the edge's public Kalib member, row-major).  In g2o's edge order these
+ * follow the EdgeSE3Cuboid edges. */
+int cs_ba_set_edges_cuboid_proj(cs_ba* ba, int n, const int* cam, const int* cub, const double* meas4, const double* info16, const double* K9);
 int cs_ba_set_edges_odom(cs_ba* ba, int n, const int* cam_i, const int* cam_j, const double* meas7, const double* info36);
 
 /* The g2o::Solver / SparseOptimizer steps, one call each (all state stays in HBM):                   */

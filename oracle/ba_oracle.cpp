@@ -244,6 +244,7 @@ inline void min_log_error(const Cuboid& self, const Cuboid& newone, double res[9
 struct EdgeProj { int pt, cam; double uv[2], info[4], intr[4], huber; };
 struct EdgeCub { int cam, cub; Cuboid meas; double info[81]; };
 struct EdgeOdom { int ci, cj; SE3 meas; double info[36]; };
+struct EdgeCubProj { int cam, cub; double meas[4], info[16], K[9]; };  // EdgeSE3CuboidProj (g2o_Object.h:264-293): bbox centre, width, height
 
 struct Problem {
   std::vector<SE3> cams; std::vector<int> cam_fixed;
@@ -251,7 +252,7 @@ struct Problem {
   std::vector<double> pts; std::vector<int> pt_fixed;  // 3 per point; points are marginalised
   int cuboids_first = 0;  // vertex-id order: 0 = cams, cuboids ; 1 = cuboids, cams (main_obj.cpp:741-757 uses cube id 0)
   int marginalize_points = 1;
-  std::vector<EdgeProj> eproj; std::vector<EdgeCub> ecub; std::vector<EdgeOdom> eodom;
+  std::vector<EdgeProj> eproj; std::vector<EdgeCub> ecub; std::vector<EdgeCubProj> ecproj; std::vector<EdgeOdom> eodom;
   // index mapping
   std::vector<int> cam_col, cub_col, pt_col;  // column (scalar offset) in the pose / landmark part, -1 if fixed
   int size_pose = 0, size_lm = 0, n_lm = 0;
@@ -263,7 +264,7 @@ struct Problem {
   std::vector<double> b, x;   // size_pose + size_lm
   std::vector<double> diag_backup_p, diag_backup_l;
   // errors
-  std::vector<double> err_proj, err_cub, err_odom;  // 2, 9, 6 per edge
+  std::vector<double> err_proj, err_cub, err_cproj, err_odom;  // 2, 9, 4, 6 per edge
   // LM state
   double lambda = -1, ni = 2; int nBad = 0, levenberg_iterations = 0;
   // backup stack (depth 1 is all LM needs)
@@ -306,6 +307,38 @@ inline void err_cub_fn(const SE3& Tcw, const Cuboid& cube, const EdgeCub& e, dou
   for (int i = 0; i < 3; i++) esti.scale[i] = e.meas.scale[i];
   min_log_error(cube, esti, r);
 }
+// cuboid::projectOntoImageBbox (g2o_Object.h:181-197) through compute3D_BoxCorner (:165-178) and similarityTransform
+// (:154-160): the 8 corners (+-1 pattern) * diag(scale), rotated / translated to the world, mapped by Tcw, projected
+// by K; bounding rectangle as (centre x, centre y, width, height).  The homogeneous divisions by w = 1 are exact.
+inline void cuboid_project_bbox(const SE3& Tcw, const Cuboid& cube, const double K[9], double out[4]) {
+  static const double cb[3][8] = {{1, 1, -1, -1, 1, 1, -1, -1}, {1, -1, -1, 1, 1, -1, -1, 1}, {-1, -1, -1, -1, 1, 1, 1, 1}};
+  double Ro[9], Rc[9];
+  q2R(cube.pose.r, Ro);
+  q2R(Tcw.r, Rc);
+  double M[9];  // R * diag(scale)
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[3 * i + j] = Ro[3 * i + j] * cube.scale[j];
+  double xmin = 0, xmax = 0, ymin = 0, ymax = 0;
+  for (int c = 0; c < 8; c++) {
+    double Xw[3], Xc[3], p[3];
+    for (int i = 0; i < 3; i++) Xw[i] = ((M[3 * i] * cb[0][c] + M[3 * i + 1] * cb[1][c]) + M[3 * i + 2] * cb[2][c]) + cube.pose.t[i] * 1.0;
+    for (int i = 0; i < 3; i++) Xc[i] = ((Rc[3 * i] * Xw[0] + Rc[3 * i + 1] * Xw[1]) + Rc[3 * i + 2] * Xw[2]) + Tcw.t[i] * 1.0;
+    for (int i = 0; i < 3; i++) p[i] = (K[3 * i] * Xc[0] + K[3 * i + 1] * Xc[1]) + K[3 * i + 2] * Xc[2];
+    double u = p[0] / p[2], v = p[1] / p[2];
+    if (c == 0) { xmin = xmax = u; ymin = ymax = v; }
+    else {  // Eigen maxCoeff / minCoeff: strict comparisons, first occurrence wins
+      if (u > xmax) xmax = u;
+      if (u < xmin) xmin = u;
+      if (v > ymax) ymax = v;
+      if (v < ymin) ymin = v;
+    }
+  }
+  out[0] = (xmax + xmin) / 2; out[1] = (ymax + ymin) / 2; out[2] = xmax - xmin; out[3] = ymax - ymin;
+}
+inline void err_cproj_fn(const SE3& Tcw, const Cuboid& cube, const EdgeCubProj& e, double r[4]) {  // g2o_Object.h:279-290
+  double rect[4];
+  cuboid_project_bbox(Tcw, cube, e.K, rect);
+  for (int i = 0; i < 4; i++) r[i] = rect[i] - e.meas[i];
+}
 inline void err_odom_fn(const SE3& T1, const SE3& T2, const EdgeOdom& e, double r[6]) {  // types_six_dof_expmap.h:90-99
   SE3 err = se3_mul(se3_mul(e.meas, T1), se3_inv(T2));
   se3_log(err, r);
@@ -323,9 +356,10 @@ inline double quad(const double* e, const double* info, int n) {  // chi2 = e^T 
 }
 
 void compute_errors(Problem& P) {  // sparse_optimizer.cpp:61-76
-  P.err_proj.resize(2 * P.eproj.size()); P.err_cub.resize(9 * P.ecub.size()); P.err_odom.resize(6 * P.eodom.size());
+  P.err_proj.resize(2 * P.eproj.size()); P.err_cub.resize(9 * P.ecub.size()); P.err_cproj.resize(4 * P.ecproj.size()); P.err_odom.resize(6 * P.eodom.size());
   for (size_t k = 0; k < P.eproj.size(); k++) err_proj_fn(P.cams[P.eproj[k].cam], &P.pts[3 * P.eproj[k].pt], P.eproj[k], &P.err_proj[2 * k]);
   for (size_t k = 0; k < P.ecub.size(); k++) err_cub_fn(P.cams[P.ecub[k].cam], P.cubs[P.ecub[k].cub], P.ecub[k], &P.err_cub[9 * k]);
+  for (size_t k = 0; k < P.ecproj.size(); k++) err_cproj_fn(P.cams[P.ecproj[k].cam], P.cubs[P.ecproj[k].cub], P.ecproj[k], &P.err_cproj[4 * k]);
   for (size_t k = 0; k < P.eodom.size(); k++) err_odom_fn(P.cams[P.eodom[k].ci], P.cams[P.eodom[k].cj], P.eodom[k], &P.err_odom[6 * k]);
 }
 
@@ -335,13 +369,14 @@ inline void huber(double e, double delta, double rho[3]) {  // robust_kernel_imp
   else { double sq = std::sqrt(e); rho[0] = 2 * sq * delta - dsqr; rho[1] = delta / sq; rho[2] = -0.5 * rho[1] / e; }
 }
 
-double robust_chi2(const Problem& P) {  // sparse_optimizer.cpp:100-114 (edges in insertion order: proj, cuboid, odom)
+double robust_chi2(const Problem& P) {  // sparse_optimizer.cpp:100-114 (edges in insertion order: proj, cuboid, cuboid-projection, odom)
   double chi = 0;
   for (size_t k = 0; k < P.eproj.size(); k++) {
     double c = quad(&P.err_proj[2 * k], P.eproj[k].info, 2);
     if (P.eproj[k].huber > 0) { double rho[3]; huber(c, P.eproj[k].huber, rho); chi += rho[0]; } else chi += c;
   }
   for (size_t k = 0; k < P.ecub.size(); k++) chi += quad(&P.err_cub[9 * k], P.ecub[k].info, 9);
+  for (size_t k = 0; k < P.ecproj.size(); k++) chi += quad(&P.err_cproj[4 * k], P.ecproj[k].info, 4);
   for (size_t k = 0; k < P.eodom.size(); k++) chi += quad(&P.err_odom[6 * k], P.eodom[k].info, 6);
   return chi;
 }
@@ -487,6 +522,32 @@ void build_system(Problem& P) {  // block_solver.hpp:501-560
         for (int r = 0; r < 9; r++) Jj[r * 9 + d] = scalar * (e1[r] - e2[r]);
       }
     quadratic_form_pp(P, ca, 6, Ji, cb, 9, Jj, &P.err_cub[9 * k], e.info, 9, 1.0);
+  }
+  // --- cuboid projection edges (EdgeSE3CuboidProj): vertex 0 = camera, vertex 1 = cuboid; numeric Jacobians, 4-dim error
+  for (size_t k = 0; k < P.ecproj.size(); k++) {
+    const EdgeCubProj& e = P.ecproj[k];
+    int ca = P.cam_col[e.cam], cb = P.cub_col[e.cub];
+    if (ca < 0 && cb < 0) continue;
+    double Ji[4 * 6] = {0}, Jj[4 * 9] = {0};
+    if (ca >= 0)
+      for (int d = 0; d < 6; d++) {
+        double add[6] = {0}, e1[4], e2[4];
+        add[d] = delta;
+        err_cproj_fn(cam_oplus(P.cams[e.cam], add), P.cubs[e.cub], e, e1);
+        add[d] = -delta;
+        err_cproj_fn(cam_oplus(P.cams[e.cam], add), P.cubs[e.cub], e, e2);
+        for (int r = 0; r < 4; r++) Ji[r * 6 + d] = scalar * (e1[r] - e2[r]);
+      }
+    if (cb >= 0)
+      for (int d = 0; d < 9; d++) {
+        double add[9] = {0}, e1[4], e2[4];
+        add[d] = delta;
+        err_cproj_fn(P.cams[e.cam], cub_exp_update(P.cubs[e.cub], add), e, e1);
+        add[d] = -delta;
+        err_cproj_fn(P.cams[e.cam], cub_exp_update(P.cubs[e.cub], add), e, e2);
+        for (int r = 0; r < 4; r++) Jj[r * 9 + d] = scalar * (e1[r] - e2[r]);
+      }
+    quadratic_form_pp(P, ca, 6, Ji, cb, 9, Jj, &P.err_cproj[4 * k], e.info, 4, 1.0);
   }
   // --- odometry edges
   for (size_t k = 0; k < P.eodom.size(); k++) {
@@ -739,6 +800,16 @@ void ba_oracle_set_edges_cuboid(void* h, int n, const int* cam, const int* cub, 
     std::memcpy(e.info, info81 + 81 * k, 81 * 8);
   }
 }
+// EdgeSE3CuboidProj: measured bbox (centre x, centre y, width, height), 4x4 information, the edge's Kalib (row-major)
+void ba_oracle_set_edges_cuboid_proj(void* h, int n, const int* cam, const int* cub, const double* meas4, const double* info16, const double* K9) {
+  Problem& P = *(Problem*)h;
+  P.ecproj.resize(n);
+  for (int k = 0; k < n; k++) {
+    EdgeCubProj& e = P.ecproj[k];
+    e.cam = cam[k]; e.cub = cub[k];
+    std::memcpy(e.meas, meas4 + 4 * k, 32); std::memcpy(e.info, info16 + 16 * k, 128); std::memcpy(e.K, K9 + 9 * k, 72);
+  }
+}
 void ba_oracle_set_edges_odom(void* h, int n, const int* ci, const int* cj, const double* meas7, const double* info36) {
   Problem& P = *(Problem*)h;
   P.eodom.resize(n);
@@ -775,6 +846,7 @@ void ba_oracle_get_state(void* h, double* cams7, double* cuboids10, double* poin
 }
 // stage-level access for parity tests
 double ba_oracle_compute_errors(void* h) { Problem& P = *(Problem*)h; compute_errors(P); return robust_chi2(P); }
+void ba_oracle_get_errors_cproj(void* h, double* cproj4) { Problem& P = *(Problem*)h; if (cproj4) std::memcpy(cproj4, P.err_cproj.data(), 8 * P.err_cproj.size()); }
 void ba_oracle_get_errors(void* h, double* proj2, double* cub9, double* odom6) {
   Problem& P = *(Problem*)h;
   if (proj2) std::memcpy(proj2, P.err_proj.data(), 8 * P.err_proj.size());
@@ -818,6 +890,11 @@ void ba_oracle_cuboid_from_minimal(const double v9[9], double out10[10]) {
   normalizeRotation(T);
   se3_to7(T, out10);
   for (int d = 0; d < 3; d++) out10[7 + d] = v9[6 + d];
+}
+// cuboid::projectOntoImageBbox(campose_cw, Kalib) (g2o_Object.h:190-197)
+void ba_oracle_cuboid_project_bbox(const double cub10[10], const double Tcw7[7], const double K9[9], double out4[4]) {
+  Cuboid c; c.pose = se3_from7(cub10, false); for (int d = 0; d < 3; d++) c.scale[d] = cub10[7 + d];
+  cuboid_project_bbox(se3_from7(Tcw7, false), c, K9, out4);
 }
 // cuboid.transform_to(Twc) / transform_from(Twc) (g2o_Object.h:117-133)
 void ba_oracle_cuboid_transform(const double cub10[10], const double Twc7[7], int to_local, double out10[10]) {

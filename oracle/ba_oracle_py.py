@@ -14,6 +14,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 
 
+def project_bbox(cub10, Tcw7, K9):
+    """cuboid::projectOntoImageBbox of the oracle (known-answer tests)."""
+    out = np.zeros(4)
+    lib().ba_oracle_cuboid_project_bbox(_dp(_f(cub10, (10,))), _dp(_f(Tcw7, (7,))), _dp(_f(K9, (9,))), _dp(out))
+    return out
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -67,6 +74,11 @@ class Problem:
         cam, cub = _i(cam), _i(cub); self.n_cub = len(cam)
         lib().ba_oracle_set_edges_cuboid(self.h, self.n_cub, _ip(cam), _ip(cub), _dp(_f(meas10, (-1, 10))), _dp(_f(info81, (-1, 81))))
 
+    def set_edges_cuboid_proj(self, cam, cub, meas4, info16, K9):
+        """EdgeSE3CuboidProj (g2o_Object.h:264-293): bbox (cx, cy, w, h) of the projected cuboid against a measured one."""
+        cam, cub = _i(cam), _i(cub); self.n_cproj = len(cam)
+        lib().ba_oracle_set_edges_cuboid_proj(self.h, self.n_cproj, _ip(cam), _ip(cub), _dp(_f(meas4, (-1, 4))), _dp(_f(info16, (-1, 16))), _dp(_f(K9, (-1, 9))))
+
     def set_edges_odom(self, ci, cj, meas7, info36):
         ci, cj = _i(ci), _i(cj); self.n_odom = len(ci)
         lib().ba_oracle_set_edges_odom(self.h, self.n_odom, _ip(ci), _ip(cj), _dp(_f(meas7, (-1, 7))), _dp(_f(info36, (-1, 36))))
@@ -89,6 +101,12 @@ class Problem:
         ep, ec, eo = np.zeros((self.n_proj, 2)), np.zeros((self.n_cub, 9)), np.zeros((self.n_odom, 6))
         lib().ba_oracle_get_errors(self.h, _dp(ep), _dp(ec), _dp(eo))
         return chi, ep, ec, eo
+
+    def errors_cuboid_proj(self):
+        """EdgeSE3CuboidProj error vectors (n x 4) of the last compute_errors()."""
+        e = np.zeros((getattr(self, "n_cproj", 0), 4))
+        lib().ba_oracle_get_errors_cproj(self.h, _dp(e))
+        return e
 
     def sizes(self):
         a, b = C.c_int(), C.c_int()

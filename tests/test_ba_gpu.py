@@ -24,6 +24,8 @@ def _oracle(pr, cuboids_first=False):
         P.set_edges_proj(pr["e_pt"], pr["e_cam"], pr["e_uv"], pr["e_info"], pr["e_intr"], pr["e_huber"])
     if len(pr["ce_cam"]):
         P.set_edges_cuboid(pr["ce_cam"], pr["ce_cub"], pr["ce_meas"], pr["ce_info"])
+    if len(pr.get("pe_cam", [])):
+        P.set_edges_cuboid_proj(pr["pe_cam"], pr["pe_cub"], pr["pe_meas"], pr["pe_info"], pr["pe_K"])
     if len(pr["oe_i"]):
         P.set_edges_odom(pr["oe_i"], pr["oe_j"], pr["oe_meas"], pr["oe_info"])
     return P
@@ -243,3 +245,29 @@ def test_full_size_c4_properties(monkeypatch):
     for a, b in zip(B.state(), D.state()):
         assert np.abs(a - b).max() < 1e-7 * max(1.0, np.abs(b).max())
     B.close(); D.close()
+
+
+def test_cuboid_projection_edges_system_and_optimize_parity():
+    """EdgeSE3CuboidProj (4-dim bounding-box error of the projected cuboid, numeric Jacobians) next to the other three
+    edge types: linear system and a 6-iteration LM run against the oracle."""
+    pr = synth_ba.make_problem(n_cams=40, n_points=2000, n_cuboids=6, seed=13, bbox_edges=True)
+    assert len(pr["pe_cam"]) == len(pr["ce_cam"]) > 50
+    G, R = capi.ba_from_dict(pr), _oracle(pr)
+    chi_r = R.compute_errors()[0]
+    assert abs(G.compute_errors() - chi_r) < 1e-9 * chi_r
+    Hpp_g, Hll_g, Hpl_g, b_g = G.build_system()
+    Hpp_r, Hll_r, Hpl_r, b_r = R.build_system()
+    # numeric Jacobians of pixel-sized errors with a 1e-9 step: ~1e-6 relative agreement is what the step allows
+    assert _rel(Hpp_g, Hpp_r) < 1e-5 and _rel(b_g, b_r) < 1e-5 and _rel(Hll_g, Hll_r) < 1e-11
+    n_g, n_r = G.optimize(6), R.optimize(6)
+    assert n_g == n_r
+    assert np.array_equal(G.history()[2], R.history()[2]) and np.allclose(G.history()[0], R.history()[0], rtol=1e-6)
+    cg, og, pg = G.state()
+    cr, orr, prr = R.state()
+    scale = np.abs(prr).max()
+    assert np.abs(pg - prr).max() < 1e-5 * scale and np.abs(cg - cr).max() < 1e-5 * scale and np.abs(og - orr).max() < 1e-5 * scale
+    # the box edges must matter: without them the optimum differs
+    pr2 = dict(pr); pr2["pe_cam"] = pr["pe_cam"][:0]
+    G2 = capi.ba_from_dict(pr2); G2.optimize(6)
+    assert np.abs(G2.state()[1] - og).max() > 1e-4
+    G.close(); G2.close()

@@ -95,3 +95,47 @@ def test_schur_solve_equals_full_solve():
     x_full = np.linalg.solve(H + lam * np.eye(n + nl), b)
     ok, x = P.solve(lam)
     assert ok and np.allclose(x, x_full, rtol=1e-8, atol=1e-10)
+
+
+def test_cuboid_projection_bbox_known_answers():
+    """cuboid::projectOntoImageBbox (g2o_Object.h:181-197): a hand-computed case and an independent numpy restatement."""
+    from cube_slam_wu_amd import synth_ba
+    K = np.array([[100.0, 0, 50], [0, 100.0, 60], [0, 0, 1]])
+    cub = np.array([0, 0, 10.0, 0, 0, 0, 1, 1.0, 2.0, 3.0])          # axis-aligned, 10 m ahead, half sizes 1 2 3
+    Tcw = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    got = O.project_bbox(cub, Tcw, K.ravel())
+    # nearest face at z = 7: u = 50 +- 100/7, v = 60 +- 200/7
+    assert np.allclose(got, [50.0, 60.0, 200.0 / 7, 400.0 / 7], rtol=0, atol=1e-12)
+    rng = np.random.default_rng(3)
+    Kk = np.array([[718.856, 0, 607.19], [0, 718.856, 185.22], [0, 0, 1]])
+    for _ in range(50):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        qc = rng.normal(size=4) * [0.05, 0.05, 0.05, 1]; qc /= np.linalg.norm(qc)
+        cub = np.concatenate([rng.uniform(-3, 3, 2), [rng.uniform(8, 30)], q, rng.uniform(0.3, 2.5, 3)])
+        Tcw = np.concatenate([rng.normal(0, 0.5, 3), qc])
+        assert np.allclose(O.project_bbox(cub, Tcw, Kk.ravel()), synth_ba.project_bbox(Tcw, cub, Kk), rtol=1e-12, atol=1e-10)
+
+
+def test_cuboid_projection_edges_errors_and_descent():
+    """EdgeSE3CuboidProj (g2o_Object.h:264-293) inside a problem: error vectors equal rect - measurement, the edges enter
+    chi2 with their information, and LM with all four edge types still descends."""
+    from cube_slam_wu_amd import synth_ba
+    pr = synth_ba.make_problem(n_cams=12, n_points=300, n_cuboids=2, seed=4, bbox_edges=True)
+    P = O.Problem(pr["cams"], pr["cam_fixed"], pr["cuboids"], pr["cub_fixed"], pr["points"], pr["pt_fixed"])
+    P.set_edges_proj(pr["e_pt"], pr["e_cam"], pr["e_uv"], pr["e_info"], pr["e_intr"], pr["e_huber"])
+    P.set_edges_cuboid(pr["ce_cam"], pr["ce_cub"], pr["ce_meas"], pr["ce_info"])
+    P.set_edges_cuboid_proj(pr["pe_cam"], pr["pe_cub"], pr["pe_meas"], pr["pe_info"], pr["pe_K"])
+    P.set_edges_odom(pr["oe_i"], pr["oe_j"], pr["oe_meas"], pr["oe_info"])
+    chi = P.compute_errors()[0]
+    e = P.errors_cuboid_proj()
+    K = pr["pe_K"][0].reshape(3, 3)
+    want = np.array([synth_ba.project_bbox(pr["cams"][c], pr["cuboids"][o], K) - m for c, o, m in zip(pr["pe_cam"], pr["pe_cub"], pr["pe_meas"])])
+    assert e.shape == want.shape and np.allclose(e, want, rtol=1e-10, atol=1e-9)
+    Q = O.Problem(pr["cams"], pr["cam_fixed"], pr["cuboids"], pr["cub_fixed"], pr["points"], pr["pt_fixed"])
+    Q.set_edges_proj(pr["e_pt"], pr["e_cam"], pr["e_uv"], pr["e_info"], pr["e_intr"], pr["e_huber"])
+    Q.set_edges_cuboid(pr["ce_cam"], pr["ce_cub"], pr["ce_meas"], pr["ce_info"])
+    Q.set_edges_odom(pr["oe_i"], pr["oe_j"], pr["oe_meas"], pr["oe_info"])
+    assert np.isclose(chi - Q.compute_errors()[0], 0.25 * (want ** 2).sum(), rtol=1e-9)   # information = 0.25 I
+    n = P.optimize(5)
+    hist = P.history()[0]
+    assert n >= 2 and hist[n - 1] < 0.5 * chi
