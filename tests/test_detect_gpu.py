@@ -6,6 +6,8 @@ ids and normalised scores of fuse_normalize_scores_v2, and the final cuboid reco
 outputs must be identical; doubles are compared with array_equal (bit-exact): both sides evaluate the
 same IEEE operations in the same order with contraction off and share cs_atan2.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -288,3 +290,37 @@ def test_full_size_c2_batch_against_oracle_sample_and_properties():
     bat.run()
     assert bat.raw_out_bytes() == first
     bat.close(); det.close()
+
+
+def _bundled_frame_c1(sample_height=False):
+    """BASELINE.json's C1: the reference's bundled frame -- detect_3d_cuboid/src/main.cpp:37-60 constants (K, T_wc, the
+    1-based box made 0-based) and data/edge_detection/LSD/0000_edge.txt (271 segments).  The distance map would come
+    from cv::Canny + cv::distanceTransform of the bundled JPEG (OpenCV, absent here); the exact L2 transform of the
+    rasterised segments stands in for it on both sides."""
+    from scipy import ndimage
+    K = np.array([[529.5, 0, 365.0], [0, 529.5, 265.0], [0, 0, 1.0]])
+    T = np.array([[1, 0.0011, 0.0004, 0], [0, -0.3376, 0.9413, 0], [0.0011, -0.9413, -0.3376, 1.35], [0, 0, 0, 1.0]])
+    box = np.array([[188 - 1, 189 - 1, 201, 311, 0.88]])
+    lines = np.loadtxt(os.path.join(os.path.dirname(__file__), "golden", "detect_3d_cuboid_data", "0000_edge.txt"))
+    rois = [synth.box_rois(box[0], 730, 530, sample_height)]
+    maps = []
+    for (l, t, w, h), _ in rois[0]:
+        edge = synth._rasterise(lines, l, t, w, h)
+        buf = np.zeros(h * w + w + 1, np.float32)
+        buf[: h * w] = ndimage.distance_transform_edt(~edge).astype(np.float32).ravel()
+        maps.append(buf)
+    return dict(K=K, T_wc=T, boxes=box, lines=lines, rois=rois, maps=[maps], img_w=730, img_h=530)
+
+
+def test_c1_bundled_reference_frame():
+    """C1 (the reference's own runnable case): every proposal row, kept set, score and the final cuboid bit-identical
+    to the oracle, at the reference's settings (6 deg yaw step: 111 valid of 320 slots), at the headline 0.5 deg step
+    (1251 valid), with roll/pitch sampling (RP = 20: 1799 valid) and with height sampling + top-5."""
+    fr = _bundled_frame_c1()
+    assert _check([fr], capi.default_params(whether_sample_cam_roll_pitch=0)) == 111
+    assert _check([fr], capi.default_params(whether_sample_cam_roll_pitch=0, yaw_step_deg=0.5)) == 1251
+    assert _check([fr], capi.default_params(whether_sample_cam_roll_pitch=1)) == 1799
+    frh = _bundled_frame_c1(sample_height=True)
+    assert _check([frh], capi.default_params(whether_sample_cam_roll_pitch=0, whether_sample_bbox_height=1, max_cuboid_num=5)) > 111
+    n, tm = _check_final([fr, fr], capi.default_params(whether_sample_cam_roll_pitch=0, yaw_step_deg=0.5))
+    assert n == 2
