@@ -81,7 +81,11 @@ def main():
     n_unique = max(1, min(args.unique, args.frames))
     uniq = [synth.make_frame(100000 * (rank + 1) + s) for s in range(n_unique)]
     frames = [uniq[i % n_unique] for i in range(args.frames)]
-    params = capi.default_params(whether_sample_cam_roll_pitch=0, whether_sample_bbox_height=0, yaw_range_deg=45.0, yaw_step_deg=0.5, host_threads=args.host_threads)
+    # host stages run on a worker pool per rank: with N ranks on one node the pools share the host's cores
+    host_threads = args.host_threads
+    if host_threads == 0 and world > 1:
+        host_threads = max(8, min(64, (os.cpu_count() or 64) // world))
+    params = capi.default_params(whether_sample_cam_roll_pitch=0, whether_sample_bbox_height=0, yaw_range_deg=45.0, yaw_step_deg=0.5, host_threads=host_threads)
     det = capi.Detector(params, device=local_rank)
     bat = capi.Batch(det, frames)
 
