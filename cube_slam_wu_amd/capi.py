@@ -62,7 +62,7 @@ class CsDetectTiming(C.Structure):
 DECLARED_SYMBOLS = [
     "cs_last_error", "cs_device_count", "cs_detect_default_params", "cs_box_rois", "cs_cam_euler_zyx", "cs_detector_create",
     "cs_detector_destroy", "cs_detect_cuboids", "cs_batch_create", "cs_batch_max_boxes", "cs_batch_run",
-    "cs_batch_destroy", "cs_batch_last_timing", "cs_batch_debug_candidates", "cs_batch_debug_kept", "cs_batch_set_debug", "cs_batch_set_pipeline_chunks",
+    "cs_bgr_to_gray", "cs_edge_distance_maps", "cs_detect_cuboids_gray", "cs_batch_destroy", "cs_batch_last_timing", "cs_batch_debug_candidates", "cs_batch_debug_kept", "cs_batch_set_debug", "cs_batch_set_pipeline_chunks",
 ]
 
 _lib = None
@@ -131,6 +131,42 @@ class Detector:
         rc = lib().cs_detector_create(C.byref(self.params), int(device), C.byref(self.h))
         if rc != 0:
             raise RuntimeError("cs_detector_create failed (%d): %s" % (rc, last_error()))
+
+    def edge_distance_maps(self, gray, rois):
+        """Canny(80, 200) + 3x3 L2 distance transform of each ROI (left, top, width, height) of a uint8 gray image, on the
+        device (cs_edge_distance_maps).  Returns one float32 (h, w) array per ROI."""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        H, W = gray.shape
+        n = len(rois)
+        rr = (CsRoi * max(1, n))()
+        outs, ptrs = [], (C.POINTER(C.c_float) * max(1, n))()
+        for k, (l, t, w, h) in enumerate(rois):
+            rr[k].left, rr[k].top, rr[k].width, rr[k].height, rr[k].down_expand = int(l), int(t), int(w), int(h), 0
+            o = np.zeros((int(h), int(w)), np.float32)
+            outs.append(o)
+            ptrs[k] = o.ctypes.data_as(C.POINTER(C.c_float))
+        rc = lib().cs_edge_distance_maps(self.h, gray.ctypes.data_as(C.POINTER(C.c_ubyte)), W, H, rr, n, ptrs)
+        if rc != 0:
+            raise RuntimeError("cs_edge_distance_maps failed (%d): %s" % (rc, last_error()))
+        return outs
+
+    def detect_gray(self, frame, gray):
+        """cs_detect_cuboids_gray: image in, cuboids out (the frame's 'maps' are not used)."""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        K = np.ascontiguousarray(frame["K"], np.float64).reshape(9)
+        T = np.ascontiguousarray(frame["T_wc"], np.float64).reshape(16)
+        boxes = np.ascontiguousarray(frame["boxes"], np.float64).reshape(-1, 5)
+        lines = np.ascontiguousarray(frame["lines"], np.float64).reshape(-1, 4)
+        d = CsFrameDesc()
+        d.K, d.T_wc, d.img_w, d.img_h = _dp(K), _dp(T), int(frame["img_w"]), int(frame["img_h"])
+        d.boxes, d.n_boxes, d.lines, d.n_lines, d.dist_maps = _dp(boxes), boxes.shape[0], _dp(lines), lines.shape[0], None
+        kmax = self.params.max_cuboid_num
+        out = (CsCuboid * max(1, boxes.shape[0] * kmax))()
+        counts = np.zeros(max(1, boxes.shape[0]), np.int32)
+        rc = lib().cs_detect_cuboids_gray(self.h, C.byref(d), gray.ctypes.data_as(C.POINTER(C.c_ubyte)), out, counts.ctypes.data_as(C.POINTER(C.c_int)))
+        if rc != 0:
+            raise RuntimeError("cs_detect_cuboids_gray failed (%d): %s" % (rc, last_error()))
+        return [[cuboid_to_dict(out[i * kmax + k]) for k in range(int(counts[i]))] for i in range(boxes.shape[0])]
 
     def close(self):
         if self.h:

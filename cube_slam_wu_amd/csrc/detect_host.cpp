@@ -44,6 +44,9 @@ void launch_scan_compact(const DetectDeviceView& v, hipStream_t st);
 void launch_score(const DetectDeviceView& v, long long n_valid_bound, long long slot_total, hipStream_t st);
 void launch_gather_corners(const double* corners, const long long* slots, int n, double* out, hipStream_t st);
 void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams& rp, hipStream_t st);
+struct EdgeRoi { int l, t, w, h; long long cls_off, map_off; };
+void launch_edge_maps(const unsigned char* gray, int W, int H, const EdgeRoi* rois, int n_rois, unsigned char* cls_pool, float* map_pool, int max_w, int low, int high,
+                      hipStream_t st);
 void launch_line_setup(JobDesc* jobs, int n_jobs, const double* frame_lines, const int* frame_line_ptr, double* mid_x, double* mid_y, double* line_angle,
                        double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st);
 int line_setup_capacity();
@@ -1727,6 +1730,72 @@ int cs_batch_debug_kept(cs_batch* b, int frame, int box, int k, int cap, int* ke
   if (keep_ids) std::memcpy(keep_ids, R.keep.data(), sizeof(int) * (size_t)n);
   if (scores) std::memcpy(scores, R.score.data(), sizeof(double) * (size_t)n);
   return (int)R.keep.size();
+}
+
+// ------------------------------------------------------------------ distance-map front end -----
+int cs_bgr_to_gray(const unsigned char* bgr, int n_pixels, unsigned char* gray) {   // cvtColor(BGR2GRAY), box_proposal_detail.cpp:84
+  if (n_pixels < 0 || (n_pixels && (!bgr || !gray))) return CS_ERR_INVALID_ARG;
+  for (int i = 0; i < n_pixels; i++) gray[i] = (unsigned char)((bgr[3 * i] * 1868 + bgr[3 * i + 1] * 9617 + bgr[3 * i + 2] * 4899 + (1 << 13)) >> 14);
+  return CS_OK;
+}
+
+int cs_edge_distance_maps(cs_detector* d, const unsigned char* gray, int img_w, int img_h, const cs_roi* rois, int n_rois, float* const* out_maps) {
+  if (!d || !gray || img_w <= 0 || img_h <= 0 || n_rois < 0 || (n_rois && (!rois || !out_maps))) return CS_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(d->device));
+  if (n_rois == 0) return CS_OK;
+  std::vector<cs::EdgeRoi> er(n_rois);
+  long long tot = 0;
+  int max_w = 1;
+  for (int k = 0; k < n_rois; k++) {
+    const cs_roi& r = rois[k];
+    if (r.width <= 0 || r.height <= 0 || r.left < 0 || r.top < 0 || r.left + r.width > img_w || r.top + r.height > img_h || !out_maps[k]) {
+      set_err("cs_edge_distance_maps: ROI outside the image");
+      return CS_ERR_INVALID_ARG;
+    }
+    er[k] = cs::EdgeRoi{r.left, r.top, r.width, r.height, tot, tot};
+    tot += (long long)r.width * r.height;
+    max_w = std::max(max_w, r.width);
+  }
+  DevBuf<unsigned char> d_gray, d_cls;
+  DevBuf<cs::EdgeRoi> d_rois;
+  DevBuf<float> d_map;
+  int rc;
+  if ((rc = d_gray.ensure((size_t)img_w * img_h)) || (rc = d_cls.ensure((size_t)tot)) || (rc = d_rois.ensure((size_t)n_rois)) || (rc = d_map.ensure((size_t)tot))) return rc;
+  hipStream_t st = d->stream;
+  HIP_TRY(hipMemcpyAsync(d_gray.p, gray, (size_t)img_w * img_h, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_rois.p, er.data(), sizeof(cs::EdgeRoi) * n_rois, hipMemcpyHostToDevice, st));
+  // cv::Canny(gray_img(object_bbox), im_canny, 80, 200): the thresholds are literals of the reference (:324)
+  cs::launch_edge_maps(d_gray.p, img_w, img_h, d_rois.p, n_rois, d_cls.p, d_map.p, max_w, 80, 200, st);
+  HIP_TRY(hipGetLastError());
+  for (int k = 0; k < n_rois; k++)
+    HIP_TRY(hipMemcpyAsync(out_maps[k], d_map.p + er[k].map_off, sizeof(float) * (size_t)er[k].w * er[k].h, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  d_gray.release(); d_cls.release(); d_rois.release(); d_map.release();
+  return CS_OK;
+}
+
+// image in, cuboids out: the frame's dist_maps are ignored and computed from the gray image on the device
+int cs_detect_cuboids_gray(cs_detector* d, const cs_frame_desc* frame, const unsigned char* gray, cs_cuboid* out, int* out_counts) {
+  if (!d || !frame || !gray || !out || !out_counts) return CS_ERR_INVALID_ARG;
+  const int n = frame->n_boxes;
+  std::vector<cs_roi> rois;
+  std::vector<int> first(n + 1, 0);
+  for (int i = 0; i < n; i++) {
+    cs_roi r3[3];
+    int nh = cs_box_rois(frame->boxes + 5 * i, frame->img_w, frame->img_h, d->prm.whether_sample_bbox_height, r3);
+    for (int k = 0; k < nh; k++) rois.push_back(r3[k]);
+    first[i + 1] = (int)rois.size();
+  }
+  std::vector<std::vector<float>> store(rois.size());
+  std::vector<float*> outp(rois.size());
+  for (size_t k = 0; k < rois.size(); k++) { store[k].assign((size_t)rois[k].width * rois[k].height, 0.f); outp[k] = store[k].data(); }
+  int rc = cs_edge_distance_maps(d, gray, frame->img_w, frame->img_h, rois.data(), (int)rois.size(), outp.data());
+  if (rc) return rc;
+  std::vector<const float*> maps(3 * (size_t)std::max(n, 1), nullptr);
+  for (int i = 0; i < n; i++) for (int k = first[i]; k < first[i + 1]; k++) maps[3 * i + (k - first[i])] = outp[k];
+  cs_frame_desc f2 = *frame;
+  f2.dist_maps = maps.data();
+  return cs_detect_cuboids(d, &f2, out, out_counts);
 }
 
 int cs_detect_cuboids(cs_detector* d, const cs_frame_desc* frame, cs_cuboid* out, int* out_counts) {

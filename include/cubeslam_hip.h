@@ -124,6 +124,19 @@ void cs_detector_destroy(cs_detector* d);
  * records (box-major), out_counts[n_boxes] = cuboids returned per box (the size of each ObjectSet). */
 int cs_detect_cuboids(cs_detector* d, const cs_frame_desc* frame, cs_cuboid* out, int* out_counts);
 
+/* ---- distance-map front end --------------------------------------------------------
+ * What detect_cuboid() does before the sweep (box_proposal_detail.cpp:84, :320-327): cvtColor(BGR2GRAY), then per
+ * (box, height sample) cv::Canny(gray_img(object_bbox), im_canny, 80, 200) and
+ * cv::distanceTransform(255 - im_canny, dist_map, CV_DIST_L2, 3).  OpenCV is a third-party dependency of the
+ * reference; these entry points implement the published algorithms of its imgproc module (3x3 Sobel, L1 magnitude,
+ * 4-sector non-maximum suppression, hysteresis; two-pass 3x3 chamfer in 16.16 fixed point), integer arithmetic
+ * throughout.  The adapter may keep calling OpenCV instead.                                     */
+int cs_bgr_to_gray(const unsigned char* bgr, int n_pixels, unsigned char* gray);               /* host helper      */
+/* out_maps[k]: rois[k].height x rois[k].width floats (host memory), the dist_map of ROI k of the gray image.     */
+int cs_edge_distance_maps(cs_detector* d, const unsigned char* gray, int img_w, int img_h, const cs_roi* rois, int n_rois, float* const* out_maps);
+/* cs_detect_cuboids() with the frame's dist_maps computed here from the gray image (frame->dist_maps is ignored). */
+int cs_detect_cuboids_gray(cs_detector* d, const cs_frame_desc* frame, const unsigned char* gray, cs_cuboid* out, int* out_counts);
+
 /* Batched form for throughput: cs_batch_create() copies the frames' inputs into HBM (maps, lines,
  * boxes, cameras); cs_batch_run() is the hot path proper -- resident inputs in, cuboids out.
  * out / out_counts are laid out frame-major with stride max_boxes = max over frames of n_boxes:
