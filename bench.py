@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0, help="worker threads of the host stages (0 = library default)")
     ap.add_argument("--ba", default="C4", choices=["C4", "C3", "none"], help="also time the g2o BA path (second half of the BASELINE metric)")
     ap.add_argument("--ba-iters", type=int, default=10)
+    ap.add_argument("--no-edge", action="store_true", help="skip the distance-map front end (Canny + distance transform) timing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,6 +136,42 @@ def main():
                                "ms_linearise_plus_schur": build_ms}}
         P.close()
 
+    # ---- next row: the distance-map front end (Canny + 3x3 distance transform of every ROI) on the device, timed on the
+    # ROIs of this batch over synthetic gray images; not part of `value` (BASELINE.json's metric excludes Canny/DT)
+    edge_out = None
+    if rank == 0 and not args.no_edge:
+        rng = np.random.default_rng(7)
+        n_img = 16
+        H, W = int(uniq[0]["img_h"]), int(uniq[0]["img_w"])
+        yy, xx = np.mgrid[0:H, 0:W]
+        grays = []
+        for _ in range(n_img):
+            img = np.full((H, W), 90.0)
+            for _ in range(25):
+                a = rng.uniform(0, np.pi)
+                img += np.where((xx - rng.uniform(0, W)) * np.cos(a) + (yy - rng.uniform(0, H)) * np.sin(a) > 0, rng.uniform(-40, 40), 0)
+            img += 12 * np.sin(xx / 7.0) * np.cos(yy / 5.0) + rng.normal(0, 6, (H, W))
+            grays.append(np.clip(img, 0, 255).astype(np.uint8))
+        rois, roi_img = [], []
+        for f, fr in enumerate(frames):
+            for rr in fr["rois"]:
+                for (l, t, w, h), _ in rr:
+                    rois.append((l, t, w, h)); roi_img.append(f % n_img)
+        det.edge_distance_maps_time(grays, rois[:64], roi_img[:64])     # warm-up
+        ms = det.edge_distance_maps_time(grays, rois, roi_img)
+        px = sum(w * h for _, _, w, h in rois)
+        edge_out = {"what": "cv::Canny(80,200) + cv::distanceTransform(DIST_L2,3) of every ROI, on the device (edge_canny_kernel + edge_dt_kernel)",
+                    "rois": len(rois), "pixels": int(px), "device_ms": ms, "rois_per_s": len(rois) / (ms * 1e-3), "ms_per_1000_frames": ms * 1000.0 / max(1, args.frames),
+                    "alg_bytes": int(px * (1 + 1 + 1 + 4 * 3)), "GB/s": px * 15 / (ms * 1e-3) / 1e9}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import edge_oracle_py
+            edge_oracle_py.lib()
+            t1, n = time.perf_counter(), 0
+            while time.perf_counter() - t1 < 3.0:
+                edge_oracle_py.edge_distance_map(grays[roi_img[n % len(rois)]], rois[n % len(rois)])
+                n += 1
+            edge_out["cpu_oracle_rois_per_s"] = n / (time.perf_counter() - t1)
+
     if rank == 0:
         total_frames = args.frames * args.steps * world
         value = total_frames / elapsed
@@ -184,6 +221,8 @@ def main():
                                    "sample": "%d frames of the same workload through oracle/detect_oracle.cpp (-O2, libm atan2, single thread) in %.1f s" % (n, dt)}
         if ba_out is not None:
             out["ba"] = ba_out
+        if edge_out is not None:
+            out["edge_front_end"] = edge_out
         print(json.dumps(out))
     bat.close()
     det.close()

@@ -62,7 +62,7 @@ class CsDetectTiming(C.Structure):
 DECLARED_SYMBOLS = [
     "cs_last_error", "cs_device_count", "cs_detect_default_params", "cs_box_rois", "cs_cam_euler_zyx", "cs_detector_create",
     "cs_detector_destroy", "cs_detect_cuboids", "cs_batch_create", "cs_batch_max_boxes", "cs_batch_run",
-    "cs_bgr_to_gray", "cs_edge_distance_maps", "cs_detect_cuboids_gray", "cs_batch_destroy", "cs_batch_last_timing", "cs_batch_debug_candidates", "cs_batch_debug_kept", "cs_batch_set_debug", "cs_batch_set_pipeline_chunks",
+    "cs_bgr_to_gray", "cs_edge_distance_maps", "cs_edge_distance_maps_multi", "cs_detect_cuboids_gray", "cs_batch_destroy", "cs_batch_last_timing", "cs_batch_debug_candidates", "cs_batch_debug_kept", "cs_batch_set_debug", "cs_batch_set_pipeline_chunks",
 ]
 
 _lib = None
@@ -149,6 +149,22 @@ class Detector:
         if rc != 0:
             raise RuntimeError("cs_edge_distance_maps failed (%d): %s" % (rc, last_error()))
         return outs
+
+    def edge_distance_maps_time(self, grays, rois, roi_image):
+        """Device time (ms) of Canny + distance transform over ROIs of several equally sized images; maps are discarded."""
+        grays = [np.ascontiguousarray(g, np.uint8) for g in grays]
+        H, W = grays[0].shape
+        gp = (C.POINTER(C.c_ubyte) * len(grays))(*[g.ctypes.data_as(C.POINTER(C.c_ubyte)) for g in grays])
+        n = len(rois)
+        rr = (CsRoi * max(1, n))()
+        for k, (l, t, w, h) in enumerate(rois):
+            rr[k].left, rr[k].top, rr[k].width, rr[k].height, rr[k].down_expand = int(l), int(t), int(w), int(h), 0
+        ri = np.ascontiguousarray(roi_image, np.int32)
+        ms = C.c_double()
+        rc = lib().cs_edge_distance_maps_multi(self.h, gp, len(grays), W, H, rr, ri.ctypes.data_as(C.POINTER(C.c_int)), n, None, C.byref(ms))
+        if rc != 0:
+            raise RuntimeError("cs_edge_distance_maps_multi failed (%d): %s" % (rc, last_error()))
+        return ms.value
 
     def detect_gray(self, frame, gray):
         """cs_detect_cuboids_gray: image in, cuboids out (the frame's 'maps' are not used)."""

@@ -44,7 +44,7 @@ void launch_scan_compact(const DetectDeviceView& v, hipStream_t st);
 void launch_score(const DetectDeviceView& v, long long n_valid_bound, long long slot_total, hipStream_t st);
 void launch_gather_corners(const double* corners, const long long* slots, int n, double* out, hipStream_t st);
 void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams& rp, hipStream_t st);
-struct EdgeRoi { int l, t, w, h; long long cls_off, map_off; };
+struct EdgeRoi { int l, t, w, h; long long img_off, cls_off, map_off; };
 void launch_edge_maps(const unsigned char* gray, int W, int H, const EdgeRoi* rois, int n_rois, unsigned char* cls_pool, float* map_pool, int max_w, int low, int high,
                       hipStream_t st);
 void launch_line_setup(JobDesc* jobs, int n_jobs, const double* frame_lines, const int* frame_line_ptr, double* mid_x, double* mid_y, double* line_angle,
@@ -1739,20 +1739,24 @@ int cs_bgr_to_gray(const unsigned char* bgr, int n_pixels, unsigned char* gray) 
   return CS_OK;
 }
 
-int cs_edge_distance_maps(cs_detector* d, const unsigned char* gray, int img_w, int img_h, const cs_roi* rois, int n_rois, float* const* out_maps) {
-  if (!d || !gray || img_w <= 0 || img_h <= 0 || n_rois < 0 || (n_rois && (!rois || !out_maps))) return CS_ERR_INVALID_ARG;
+int cs_edge_distance_maps_multi(cs_detector* d, const unsigned char* const* grays, int n_images, int img_w, int img_h, const cs_roi* rois, const int* roi_image,
+                                int n_rois, float* const* out_maps, double* kernel_ms) {
+  if (!d || n_images <= 0 || !grays || img_w <= 0 || img_h <= 0 || n_rois < 0 || (n_rois && (!rois || !roi_image))) return CS_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(d->device));
+  if (kernel_ms) *kernel_ms = 0;
   if (n_rois == 0) return CS_OK;
+  const size_t img_px = (size_t)img_w * img_h;
   std::vector<cs::EdgeRoi> er(n_rois);
   long long tot = 0;
   int max_w = 1;
   for (int k = 0; k < n_rois; k++) {
     const cs_roi& r = rois[k];
-    if (r.width <= 0 || r.height <= 0 || r.left < 0 || r.top < 0 || r.left + r.width > img_w || r.top + r.height > img_h || !out_maps[k]) {
+    if (r.width <= 0 || r.height <= 0 || r.left < 0 || r.top < 0 || r.left + r.width > img_w || r.top + r.height > img_h || roi_image[k] < 0 || roi_image[k] >= n_images ||
+        (out_maps && !out_maps[k])) {
       set_err("cs_edge_distance_maps: ROI outside the image");
       return CS_ERR_INVALID_ARG;
     }
-    er[k] = cs::EdgeRoi{r.left, r.top, r.width, r.height, tot, tot};
+    er[k] = cs::EdgeRoi{r.left, r.top, r.width, r.height, (long long)(roi_image[k] * img_px), tot, tot};
     tot += (long long)r.width * r.height;
     max_w = std::max(max_w, r.width);
   }
@@ -1760,18 +1764,31 @@ int cs_edge_distance_maps(cs_detector* d, const unsigned char* gray, int img_w, 
   DevBuf<cs::EdgeRoi> d_rois;
   DevBuf<float> d_map;
   int rc;
-  if ((rc = d_gray.ensure((size_t)img_w * img_h)) || (rc = d_cls.ensure((size_t)tot)) || (rc = d_rois.ensure((size_t)n_rois)) || (rc = d_map.ensure((size_t)tot))) return rc;
+  if ((rc = d_gray.ensure(img_px * n_images)) || (rc = d_cls.ensure((size_t)tot)) || (rc = d_rois.ensure((size_t)n_rois)) || (rc = d_map.ensure((size_t)tot))) return rc;
   hipStream_t st = d->stream;
-  HIP_TRY(hipMemcpyAsync(d_gray.p, gray, (size_t)img_w * img_h, hipMemcpyHostToDevice, st));
+  for (int i = 0; i < n_images; i++) {
+    if (!grays[i]) { set_err("cs_edge_distance_maps: null image"); return CS_ERR_INVALID_ARG; }
+    HIP_TRY(hipMemcpyAsync(d_gray.p + img_px * i, grays[i], img_px, hipMemcpyHostToDevice, st));
+  }
   HIP_TRY(hipMemcpyAsync(d_rois.p, er.data(), sizeof(cs::EdgeRoi) * n_rois, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(d->ev[0], st));
   // cv::Canny(gray_img(object_bbox), im_canny, 80, 200): the thresholds are literals of the reference (:324)
   cs::launch_edge_maps(d_gray.p, img_w, img_h, d_rois.p, n_rois, d_cls.p, d_map.p, max_w, 80, 200, st);
   HIP_TRY(hipGetLastError());
-  for (int k = 0; k < n_rois; k++)
-    HIP_TRY(hipMemcpyAsync(out_maps[k], d_map.p + er[k].map_off, sizeof(float) * (size_t)er[k].w * er[k].h, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipEventRecord(d->ev[1], st));
+  if (out_maps)
+    for (int k = 0; k < n_rois; k++)
+      HIP_TRY(hipMemcpyAsync(out_maps[k], d_map.p + er[k].map_off, sizeof(float) * (size_t)er[k].w * er[k].h, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  if (kernel_ms) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1])); *kernel_ms = ms; }
   d_gray.release(); d_cls.release(); d_rois.release(); d_map.release();
   return CS_OK;
+}
+
+int cs_edge_distance_maps(cs_detector* d, const unsigned char* gray, int img_w, int img_h, const cs_roi* rois, int n_rois, float* const* out_maps) {
+  if (!gray || (n_rois > 0 && !out_maps)) return CS_ERR_INVALID_ARG;
+  std::vector<int> zero(std::max(n_rois, 1), 0);
+  return cs_edge_distance_maps_multi(d, &gray, 1, img_w, img_h, rois, zero.data(), n_rois, out_maps, nullptr);
 }
 
 // image in, cuboids out: the frame's dist_maps are ignored and computed from the gray image on the device

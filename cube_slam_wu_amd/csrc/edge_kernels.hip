@@ -12,6 +12,7 @@ namespace cs {
 
 struct EdgeRoi {
   int l, t, w, h;            // ROI inside the gray image
+  long long img_off;         // -> first pixel of the ROI's image in the gray pool
   long long cls_off;         // -> class bytes (w * h)
   long long map_off;         // -> output floats (w * h)
 };
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(256) void edge_canny_kernel(const unsigned char* __
   __shared__ int n_cand;
   __shared__ int changed;
   const EdgeRoi R = rois[blockIdx.x];
+  gray += R.img_off;
   unsigned char* cls = cls_pool + R.cls_off;
   const int n = R.w * R.h;
   if (threadIdx.x == 0) n_cand = 0;

@@ -134,6 +134,10 @@ int cs_detect_cuboids(cs_detector* d, const cs_frame_desc* frame, cs_cuboid* out
 int cs_bgr_to_gray(const unsigned char* bgr, int n_pixels, unsigned char* gray);               /* host helper      */
 /* out_maps[k]: rois[k].height x rois[k].width floats (host memory), the dist_map of ROI k of the gray image.     */
 int cs_edge_distance_maps(cs_detector* d, const unsigned char* gray, int img_w, int img_h, const cs_roi* rois, int n_rois, float* const* out_maps);
+/* The same over several images of one size: ROI k belongs to image roi_image[k].  out_maps may be NULL (maps stay on
+ * the device and are discarded: timing); kernel_ms, if not NULL, receives the device time of the two kernels.      */
+int cs_edge_distance_maps_multi(cs_detector* d, const unsigned char* const* grays, int n_images, int img_w, int img_h, const cs_roi* rois, const int* roi_image,
+                                int n_rois, float* const* out_maps, double* kernel_ms);
 /* cs_detect_cuboids() with the frame's dist_maps computed here from the gray image (frame->dist_maps is ignored). */
 int cs_detect_cuboids_gray(cs_detector* d, const cs_frame_desc* frame, const unsigned char* gray, cs_cuboid* out, int* out_counts);
 
