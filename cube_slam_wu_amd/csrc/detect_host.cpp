@@ -310,17 +310,23 @@ void fuse_scores(const double* dist, const double* angle, int n, double w_angle,
   keep.clear();
   if (n > 4) {
     int bn = (int)std::round(float(n) / 3.0 * 2.0);
-    std::vector<int> di(n), ai;
-    std::iota(di.begin(), di.end(), 0);
-    ai = di;
-    std::partial_sort(di.begin(), di.begin() + bn, di.end(), [dist](int a, int b) { return dist[a] < dist[b]; });
-    std::partial_sort(ai.begin(), ai.begin() + bn, ai.end(), [angle](int a, int b) { return angle[a] < angle[b]; });
+    // std::partial_sort of the ids by value (sort_indexes, matrix_utils.cpp:327-335).  The keys travel with the ids: the
+    // algorithm makes the same comparisons and moves as on a bare id array (so ties resolve identically), without the
+    // indirect loads
+    struct KI { double key; int id; };
+    std::vector<KI> ds(n), as(n);
+    for (int i = 0; i < n; i++) { ds[i] = KI{dist[i], i}; as[i] = KI{angle[i], i}; }
+    auto by_key = [](const KI& a, const KI& b) { return a.key < b.key; };
+    std::partial_sort(ds.begin(), ds.begin() + bn, ds.end(), by_key);
+    std::partial_sort(as.begin(), as.begin() + bn, as.end(), by_key);
+    std::vector<int> di(bn), ai(bn);
+    for (int i = 0; i < bn; i++) { di[i] = ds[i].id; ai[i] = as[i].id; }
     std::vector<int> dk(di.begin(), di.begin() + bn - 1);
     if (angle[ai[bn - 1]] > angle[ai[bn - 2]]) {
-      std::vector<int> ak(ai.begin(), ai.begin() + bn - 1);
-      std::sort(dk.begin(), dk.end());
-      std::sort(ak.begin(), ak.end());
-      std::set_intersection(dk.begin(), dk.end(), ak.begin(), ak.end(), std::back_inserter(keep));
+      // sort both id lists + set_intersection (:771-776) = the ids present in both, ascending: one pass over a marker array
+      std::vector<unsigned char> in(n, 0);
+      for (int i = 0; i < bn - 1; i++) { in[di[i]] |= 1; in[ai[i]] |= 2; }
+      for (int id = 0; id < n; id++) if (in[id] == 3) keep.push_back(id);
     } else {
       keep = dk;
     }
