@@ -39,6 +39,8 @@
 
 namespace cs {
 void launch_vp_support(const DetectDeviceView& v, const SweepParams& sp, int vp_total, hipStream_t st);
+void launch_vp_support_only(const DetectDeviceView& v, const SweepParams& sp, int vp_total, hipStream_t st);
+void launch_vp_points(const DetectDeviceView& v, int vp_total, hipStream_t st);
 void launch_candidates(const DetectDeviceView& v, const SweepParams& sp, long long slot_total, hipStream_t st);
 void launch_scan_compact(const DetectDeviceView& v, hipStream_t st);
 void launch_score(const DetectDeviceView& v, long long n_valid_bound, long long slot_total, hipStream_t st);
@@ -417,7 +419,7 @@ struct PipeSlot {
   PinBuf<long long> h_fb_src, h_fb_dst, h_fb_slot, h_win_slots;
   PinBuf<int> h_fb_cnt, h_fb_flag;
   PinBuf<double> h_fb_dist, h_fb_angle, h_fb_skew, h_win_corners;
-  hipEvent_t done = nullptr, ev[9] = {};
+  hipEvent_t done = nullptr, ev[13] = {};   // 0-6: phase marks on the main stream; 7: inputs resident; 8-11: second stream (corner construction); 12: spare
   cs::DetectDeviceView view{};
   int f0 = 0, f1 = 0, vp_total = 0;
   size_t nj = 0, nb = 0;
@@ -885,14 +887,23 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   v.mid_x = S.mid_x.p; v.mid_y = S.mid_y.p; v.line_angle = S.ang.p; v.yaw = S.yaw.p; v.yaw_cos = S.yaw_c.p; v.yaw_sin = S.yaw_s.p; v.top_x = S.top_x.p;
   v.rp = b->d_rp.p; v.invK = b->d_invK.p; v.vp = S.vp.p; v.bound = S.bound.p; v.flag = S.flag.p; v.corners = S.corners.p; v.job_valid = S.job_valid.p;
   v.job_cbase = S.job_cbase.p; v.c_slot = S.c_slot.p; v.c_flag = S.c_flag.p; v.c_dist = S.c_dist.p; v.c_angle = S.c_angle.p; v.c_skew = S.c_skew.p;
+  // The corner construction needs the vanishing points but not the segments: it runs on the second stream beside line
+  // setup + VP support (a latency-bound and an ALU-bound kernel), and the scorer waits for both.
+  hipStream_t stB = d->stream2;
+  HIP_TRY(hipEventRecord(S.ev[7], st));                      // inputs resident, job_valid zeroed
+  HIP_TRY(hipStreamWaitEvent(stB, S.ev[7], 0));
+  HIP_TRY(hipEventRecord(S.ev[8], stB));
+  cs::launch_vp_points(v, S.vp_total, stB);
+  cs::launch_candidates(v, C.sp, slot_total, stB);
+  HIP_TRY(hipEventRecord(S.ev[9], stB));
+  cs::launch_scan_compact(v, stB);
+  HIP_TRY(hipEventRecord(S.ev[10], stB));
   HIP_TRY(hipEventRecord(S.ev[0], st));
   cs::launch_line_setup(S.jobs.p, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st);
   HIP_TRY(hipEventRecord(S.ev[1], st));
-  cs::launch_vp_support(v, C.sp, S.vp_total, st);
+  cs::launch_vp_support_only(v, C.sp, S.vp_total, st);
   HIP_TRY(hipEventRecord(S.ev[2], st));
-  cs::launch_candidates(v, C.sp, slot_total, st);
-  HIP_TRY(hipEventRecord(S.ev[3], st));
-  cs::launch_scan_compact(v, st);
+  HIP_TRY(hipStreamWaitEvent(st, S.ev[10], 0));
   HIP_TRY(hipEventRecord(S.ev[4], st));
   cs::launch_score(v, slot_total, slot_total, st);
   HIP_TRY(hipEventRecord(S.ev[5], st));
@@ -932,8 +943,8 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, S.ev[0], S.ev[1])); tm.line_setup_ms += ms;
     HIP_TRY(hipEventElapsedTime(&ms, S.ev[1], S.ev[2])); tm.vp_kernel_ms += ms;
-    HIP_TRY(hipEventElapsedTime(&ms, S.ev[2], S.ev[3])); tm.cand_kernel_ms += ms;
-    HIP_TRY(hipEventElapsedTime(&ms, S.ev[3], S.ev[4])); tm.compact_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, S.ev[8], S.ev[9])); tm.cand_kernel_ms += ms;    // second stream: vanishing points + corners
+    HIP_TRY(hipEventElapsedTime(&ms, S.ev[9], S.ev[10])); tm.compact_ms += ms;
     HIP_TRY(hipEventElapsedTime(&ms, S.ev[4], S.ev[5])); tm.score_kernel_ms += ms;
     HIP_TRY(hipEventElapsedTime(&ms, S.ev[5], S.ev[6])); tm.rank_kernel_ms += ms;
     tm.cand_kernel_launches += 1;

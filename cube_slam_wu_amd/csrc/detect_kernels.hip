@@ -47,6 +47,9 @@ __device__ __forceinline__ long long xcd_virtual_block() {
   return (b & 7) * (nb >> 3) + (b >> 3);
 }
 
+// WRITE_VP = false: the vanishing points themselves are produced by vp_points_kernel on another stream (they do not depend
+// on the segments, so the corner construction can run beside line setup + VP support); this kernel then only writes `bound`
+template <bool WRITE_VP>
 __global__ __launch_bounds__(256) void vp_support_kernel(DetectDeviceView v, SweepParams sp, int vp_total) {
   long long e = xcd_virtual_block() * blockDim.x + threadIdx.x;
   if (e >= vp_total) return;
@@ -68,8 +71,10 @@ __global__ __launch_bounds__(256) void vp_support_kernel(DetectDeviceView v, Swe
     vpx[k] = h0 / h2;
     vpy[k] = h1 / h2;
   }
-  double* vout = v.vp + 6 * e;
-  vout[0] = vpx[0]; vout[1] = vpy[0]; vout[2] = vpx[1]; vout[3] = vpy[1]; vout[4] = vpx[2]; vout[5] = vpy[2];
+  if (WRITE_VP) {
+    double* vout = v.vp + 6 * e;
+    vout[0] = vpx[0]; vout[1] = vpy[0]; vout[2] = vpx[1]; vout[3] = vpy[1]; vout[4] = vpx[2]; vout[5] = vpy[2];
+  }
 
   // VP_support_edge_infos (object_3d_util.cpp:548-619): sequential over the job's merged lines.
   const double* mx = v.mid_x + jd.line_off;
@@ -135,6 +140,29 @@ __global__ __launch_bounds__(256) void vp_support_kernel(DetectDeviceView v, Swe
     // vp 1: (max, min); vp 2,3: swapped (:609-614)
     bout[2 * k + 0] = (k > 0) ? ang_lo : ang_hi;
     bout[2 * k + 1] = (k > 0) ? ang_hi : ang_lo;
+  }
+}
+
+// getVanishingPoints (object_3d_util.cpp:928-937) alone: the same arithmetic as the head of vp_support_kernel
+__global__ __launch_bounds__(256) void vp_points_kernel(DetectDeviceView v, int vp_total) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= vp_total) return;
+  int j = find_job_i32(v.vp_prefix, v.n_jobs, (int)e);
+  const JobDesc jd = v.jobs[j];
+  int local = (int)e - jd.vp_off;
+  int rp = local / jd.Y, y = local - rp * jd.Y;
+  const RpPose* pose = v.rp + jd.rp_off + rp;
+  double cy = v.yaw_cos[jd.yaw_off + y], sy = v.yaw_sin[jd.yaw_off + y];
+  const double* A = pose->KinvR;
+  double d[3][3] = {{cy, sy, 0.0}, {-sy, cy, 0.0}, {0.0, 0.0, 1.0}};
+  double* vout = v.vp + 6 * e;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    double h0 = (A[0] * d[k][0] + A[1] * d[k][1]) + A[2] * d[k][2];
+    double h1 = (A[3] * d[k][0] + A[4] * d[k][1]) + A[5] * d[k][2];
+    double h2 = (A[6] * d[k][0] + A[7] * d[k][1]) + A[8] * d[k][2];
+    vout[2 * k] = h0 / h2;
+    vout[2 * k + 1] = h1 / h2;
   }
 }
 
@@ -755,7 +783,15 @@ static inline unsigned grid8(long long n, int bs) {
 
 void launch_vp_support(const DetectDeviceView& v, const SweepParams& sp, int vp_total, hipStream_t st) {
   if (vp_total <= 0) return;
-  hipLaunchKernelGGL(vp_support_kernel, dim3(grid8(vp_total, 256)), dim3(256), 0, st, v, sp, vp_total);
+  vp_support_kernel<true><<<dim3(grid8(vp_total, 256)), dim3(256), 0, st>>>(v, sp, vp_total);
+}
+void launch_vp_support_only(const DetectDeviceView& v, const SweepParams& sp, int vp_total, hipStream_t st) {
+  if (vp_total <= 0) return;
+  vp_support_kernel<false><<<dim3(grid8(vp_total, 256)), dim3(256), 0, st>>>(v, sp, vp_total);
+}
+void launch_vp_points(const DetectDeviceView& v, int vp_total, hipStream_t st) {
+  if (vp_total <= 0) return;
+  hipLaunchKernelGGL(vp_points_kernel, dim3((vp_total + 255) / 256), dim3(256), 0, st, v, vp_total);
 }
 void launch_candidates(const DetectDeviceView& v, const SweepParams& sp, long long slot_total, hipStream_t st) {
   if (slot_total <= 0) return;
