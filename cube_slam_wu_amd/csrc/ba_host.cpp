@@ -348,8 +348,8 @@ int finalize_structure(cs_ba* B) {
   AL(B->Dinv, 9 * (size_t)np); AL(B->dbl, 3 * (size_t)np); B->s_doubles = (size_t)B->n_pose * (B->band_ld ? B->band_ld : B->n_pose);
   AL(B->S, B->s_doubles + B->n_pose);   // [S | rhs]: one buffer, one all-reduce in the sharded solve
   AL(B->xl, 3 * (size_t)np);
-  AL(B->d_band_info, 4);   // [first bad pivot + 1, grid-barrier counter, a zero double]
-  AL(B->band_linv, (size_t)((B->n_pose + 31) / 32) * 1024);
+  AL(B->d_band_info, 8);   // [first bad pivot + 1, 3 grid-barrier counters, a zero double]
+  AL(B->band_linv, 2 * (size_t)((B->n_pose + 31) / 32) * 1024);   // forward front + middle block, then the reverse front
   B->nb_chi = cs::ba_chi2_blocks(E);
   B->n_chi_partials = B->nb_chi + (B->n_cub + B->n_odom + 63) / 64;
   AL(B->chi_partial, B->n_chi_partials);
@@ -458,7 +458,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       // banded: factorisation, both substitutions and the landmark back-substitution are queued back to back; the
       // pivot flag comes home with the single synchronisation (a failed factorisation just leaves garbage increments
       // that the caller discards)
-      BA_TRY(hipMemsetAsync(B->d_band_info.p, 0, 4 * sizeof(int), B->st));
+      BA_TRY(hipMemsetAsync(B->d_band_info.p, 0, 8 * sizeof(int), B->st));
       cs::ba_launch_band_cholesky(B->S.p, B->band_linv.p, n, B->band_ld, B->view.rhs, B->d_band_info.p, true, B->st);
       BA_TRY(hipGetLastError());
       BA_TRY(hipEventRecord(B->ev[4], B->st));

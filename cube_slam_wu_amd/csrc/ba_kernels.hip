@@ -676,24 +676,38 @@ __device__ __forceinline__ double band_gload(const double* p) { return *(band_gp
 
 enum { BAND_RW = 16, BAND_NR = BS + BAND_RW + 8, BAND_NRP = 64, BAND_NRT = BAND_NR / 8, BAND_TR = BAND_NRP / 8, BAND_DC = 192, BAND_NV = BAND_DC * BAND_NRP / 256 };
 
+// An elimination front addresses the band through its own index space (v = 0 is where it starts): the forward front
+// walks the matrix top-left to bottom-right (v = original index), the reverse front bottom-right to top-left
+// (v = n - 1 - original index).  In both spaces the factor is lower triangular and banded; only the strides differ:
+//   &L(i, j) = base + i * si + j * sj   (i >= j, i - j <= bw),      &rhs(v) = rb + v * sr
+//   forward: base = Sb, si = 1, sj = bw              reverse: base = Sb + (n - 1) LD, si = -bw, sj = -1
+struct BandView {
+  double* base; long long si, sj;
+  double* rb; long long sr;
+};
+struct BandSeg {            // one run of history columns [jlo, jhi) of a view; flip: the step's rows are re-indexed i -> n - 1 - i
+  BandView v; int jlo, jhi, flip;
+};
+
 // Strip gather + product of one step: U(rr, c) = A(rr, k0 + c) - sum_j L(rr, j) L(k0 + c, j) for the 32 block rows and
-// this workgroup's rows.  A thread gathers ONE row (rr = tid & 63) at every fourth column, so the addresses are a
-// pointer walk, and all BAND_NV loads are unconditional (masked lanes read the zero word) and in flight together.
-__device__ __attribute__((noinline)) void band_gather_gemm(const double* Sb, const double* rhs, const double* zero, int LD, int k0, int nb, const int* rowidx,
+// this workgroup's rows, the history columns j coming from one or two segments (the second one only in the middle
+// phase of the two-sided elimination: the other front's columns).  A thread gathers ONE row (rr = tid & 63) at every
+// fourth column, so the addresses are a pointer walk, and all BAND_NV loads are unconditional (masked lanes read the
+// zero word) and in flight together.
+__device__ __attribute__((noinline)) void band_gather_gemm(BandSeg s0, BandSeg s1, int nseg, const double* zero, int n, int bw, int k0, int nb, const int* rowidx,
                                                            double* R, double (*U)[BS + 1], long long* tp, long long* t_prev) {
   constexpr int NR = BAND_NR, NRP = BAND_NRP, NRT = BAND_NRT, TR = BAND_TR, NV = BAND_NV, DC = BAND_DC;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int cg = lane & 7, rgp = lane >> 3;     // register tile: rows 8 rgp .. 8 rgp + 7 of the 64 padded rows, columns 4 cg .. 4 cg + 3
   const int c1 = tid & 31, rg1 = tid >> 5;      // one-column mapping of the finishing pass
-  const int bw = LD - 1;
 #define BAND_TICK(k) do { if (tp) { long long t_now = wall_clock64(); tp[k] += t_now - *t_prev; *t_prev = t_now; } } while (0)
-  // the block's own columns (A of U = A - sum): loads in flight while the strip is gathered
+  // the block's own columns (A of U = A - sum), in the step's own view s0.v: loads in flight while the strip is gathered
   double aval[NRT];
 #pragma unroll
   for (int m = 0; m < NRT; m++) {
     const int i = rowidx[rg1 + 8 * m], dlt = i - (k0 + c1);
     const bool ok = c1 < nb && (i == -2 || (i >= 0 && dlt >= 0 && dlt <= bw));
-    const double* ptr = (i == -2) ? rhs + (k0 + c1) : Sb + (size_t)(k0 + c1) * LD + dlt;
+    const double* ptr = (i == -2) ? s0.v.rb + (long long)(k0 + c1) * s0.v.sr : s0.v.base + (long long)i * s0.v.si + (long long)(k0 + c1) * s0.v.sj;
     aval[m] = band_gload(ok ? ptr : zero);
   }
   double acc[TR][4];
@@ -701,49 +715,52 @@ __device__ __attribute__((noinline)) void band_gather_gemm(const double* Sb, con
   for (int m = 0; m < TR; m++)
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[m][t] = 0.0;
-  const int jlo = max(0, k0 - bw);
-  const int my_i = lane < NR ? rowidx[lane] : -1;            // the row this thread gathers
-  const int jmin = my_i >= 0 ? max(jlo, my_i - bw) : jlo;    // in-band columns of that row: j >= i - bw
-  double vals[NV];
-  auto fetch = [&](int j0) {
-    const int jend = (my_i == -1) ? 0 : min(k0, j0 + DC);
-    int j = j0 + wv;
-    const double* p = (my_i == -2) ? rhs + j : Sb + (size_t)j * bw + (my_i >= 0 ? my_i : 0);   // &Sb[j * LD + (i - j)]
-    const size_t step = (my_i == -2) ? 4 : 4 * (size_t)bw;
+  const int row0 = lane < NR ? rowidx[lane] : -1;            // the row this thread gathers (in the step's view)
+  for (int sg = 0; sg < nseg; sg++) {
+    const BandSeg S = sg ? s1 : s0;
+    const int my_i = (S.flip && row0 >= 0) ? n - 1 - row0 : row0;
+    const int jmin = my_i >= 0 ? max(S.jlo, my_i - bw) : S.jlo;   // in-band columns of that row: j >= i - bw
+    double vals[NV];
+    auto fetch = [&](int j0) {
+      const int jend = (my_i == -1) ? 0 : min(S.jhi, j0 + DC);
+      int j = j0 + wv;
+      const double* p = (my_i == -2) ? S.v.rb + (long long)j * S.v.sr : S.v.base + (long long)(my_i >= 0 ? my_i : 0) * S.v.si + (long long)j * S.v.sj;
+      const long long step = (my_i == -2) ? 4 * S.v.sr : 4 * S.v.sj;
 #pragma unroll
-    for (int u = 0; u < NV; u++) {
-      const bool ok = j >= jmin && j < jend;
-      vals[u] = band_gload(ok ? p : zero);
-      p += step; j += 4;
-    }
-  };
-  if (jlo < k0) fetch(jlo);
-  BAND_TICK(6);
-  for (int j0 = jlo; j0 < k0; j0 += DC) {
-    const int jn = min(DC, k0 - j0);
-#pragma unroll
-    for (int u = 0; u < NV; u++) R[(wv + 4 * u) * NRP + lane] = vals[u];
-    __syncthreads();
-    BAND_TICK(7);
-    if (j0 + DC < k0) fetch(j0 + DC);
+      for (int u = 0; u < NV; u++) {
+        const bool ok = j >= jmin && j < jend;
+        vals[u] = band_gload(ok ? p : zero);
+        p += step; j += 4;
+      }
+    };
+    if (S.jlo < S.jhi) fetch(S.jlo);
     BAND_TICK(6);
-    // this wave's quarter of the depth: acc(rows, cols) += R(jj, rows) * R(jj, cols)   (LDS-bandwidth bound: 96 B of
-    // operands per lane and depth index for 32 multiply-adds)
+    for (int j0 = S.jlo; j0 < S.jhi; j0 += DC) {
+      const int jn = min(DC, S.jhi - j0);
+#pragma unroll
+      for (int u = 0; u < NV; u++) R[(wv + 4 * u) * NRP + lane] = vals[u];
+      __syncthreads();
+      BAND_TICK(7);
+      if (j0 + DC < S.jhi) fetch(j0 + DC);
+      BAND_TICK(6);
+      // this wave's quarter of the depth: acc(rows, cols) += R(jj, rows) * R(jj, cols)   (LDS-bandwidth bound: 96 B of
+      // operands per lane and depth index for 32 multiply-adds)
 #pragma unroll 4
-    for (int jj = wv; jj < jn; jj += 4) {
-      const double* rj = R + jj * NRP;
-      double colv[4], rowv[TR];
+      for (int jj = wv; jj < jn; jj += 4) {
+        const double* rj = R + jj * NRP;
+        double colv[4], rowv[TR];
 #pragma unroll
-      for (int t = 0; t < 4; t++) colv[t] = rj[4 * cg + t];
+        for (int t = 0; t < 4; t++) colv[t] = rj[4 * cg + t];
 #pragma unroll
-      for (int m = 0; m < TR; m++) rowv[m] = rj[rgp * TR + m];
+        for (int m = 0; m < TR; m++) rowv[m] = rj[rgp * TR + m];
 #pragma unroll
-      for (int m = 0; m < TR; m++)
+        for (int m = 0; m < TR; m++)
 #pragma unroll
-        for (int t = 0; t < 4; t++) acc[m][t] = fma(rowv[m], colv[t], acc[m][t]);
+          for (int t = 0; t < 4; t++) acc[m][t] = fma(rowv[m], colv[t], acc[m][t]);
+      }
+      __syncthreads();
+      BAND_TICK(8);
     }
-    __syncthreads();
-    BAND_TICK(8);
   }
   // partial sums of the 4 waves -> LDS (over the strip buffer), then U = A - sum
 #pragma unroll
@@ -762,8 +779,25 @@ __device__ __attribute__((noinline)) void band_gather_gemm(const double* Sb, con
 #undef BAND_TICK
 }
 
-__global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double* __restrict__ Linv, double* rhs, const double* zero, int n, int LD,
-                                                             int* info, unsigned* bar, int G, int xcd_shift, long long* prof) {
+// arrive without waiting (a workgroup that leaves the kernel): the release half of band_grid_sync
+__device__ __forceinline__ void band_grid_arrive(unsigned* bar) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Two-sided ("burn at both ends") elimination.  Phase 1: team 0 eliminates the first K1 column blocks with the forward
+// front while team 1 eliminates the last K2 column blocks with the reverse front -- the two regions are further apart
+// than the bandwidth, so they never touch the same entries; each front also produces the rows of L that reach into the
+// middle block M = [32 K1, n - 32 K2).  Phase 2: team 0 eliminates M, whose history now has two segments (the tails of
+// both fronts).  The chain of dependent steps is halved.  K2 = 0 degenerates to the one-sided left-looking algorithm.
+// bars: [team 0, team 1, both].
+__global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double* __restrict__ Linv_f, double* __restrict__ Linv_r, double* rhs, const double* zero, int n,
+                                                             int LD, int K1, int K2, int* info, unsigned* bars, int G, long long* prof) {
   constexpr int RW = BAND_RW, NR = BAND_NR;
   __shared__ double R[BAND_DC * BAND_NRP];   // strip chunk, transposed: R[jj * 64 + rr]; afterwards the 4 waves' partial sums
   __shared__ double U[NR][BS + 1];
@@ -771,20 +805,21 @@ __global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double*
   __shared__ double X[BS][BS + 1];
   __shared__ double colbuf[2 * 128];
   __shared__ int rowidx[NR];
-  const int w = blockIdx.x >> xcd_shift;
-  if ((blockIdx.x & ((1 << xcd_shift) - 1)) != 0) return;
+  const int team = blockIdx.x / G, w = blockIdx.x % G;
   const int tid = threadIdx.x;
   const int bw = LD - 1;
   const bool has_rhs = (w == G - 1);
-  unsigned epoch = 0;
+  const BandView fwd{Sb, 1, (long long)bw, rhs, 1};
+  const BandView rev{Sb + (size_t)(n - 1) * LD, -(long long)bw, -1, rhs + (n - 1), -1};
+  const int m_begin = BS * K1, m_end = n - BS * K2;      // the middle block (original indices)
   long long tp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = prof ? wall_clock64() : 0;   // optional phase clock (CS_BAND_PROF)
   const long long c_begin = prof ? clock64() : 0, w_begin = t_prev;
-#define BAND_TICK(k) do { if (prof) { long long t_now = wall_clock64(); tp[k] += t_now - t_prev; t_prev = t_now; } } while (0)
-  for (int k0 = 0; k0 < n; k0 += BS) {
-    const int nb = min(BS, n - k0);
-    const int i_end = min(n, k0 + nb + bw);           // panel rows: k0 + nb .. i_end - 1
+  const bool clocked = prof && team == 0;
+#define BAND_TICK(k) do { if (clocked) { long long t_now = wall_clock64(); tp[k] += t_now - t_prev; t_prev = t_now; } } while (0)
+  // one elimination step of `view`: block column k0 (nb wide), rows up to i_end, history segments s0 (own view) and s1
+  auto step = [&](const BandView& view, double* Linv, int k0, int nb, int i_end, const BandSeg& s0, const BandSeg& s1, int nseg) {
     const int own0 = k0 + nb + w * RW;
-    if (tid < NR) {                                   // global row of gathered row rr; -1 = none, -2 = right-hand side
+    if (tid < NR) {                                   // row (in the view's index space) of gathered row rr; -1 = none, -2 = right-hand side
       int i = -1;
       if (tid < BS) i = tid < nb ? k0 + tid : -1;
       else if (tid - BS < RW) { int q = own0 + (tid - BS); i = q < i_end ? q : -1; }
@@ -792,7 +827,7 @@ __global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double*
       rowidx[tid] = i;
     }
     __syncthreads();
-    band_gather_gemm(Sb, rhs, zero, LD, k0, nb, rowidx, R, U, prof ? tp : nullptr, &t_prev);
+    band_gather_gemm(s0, s1, nseg, zero, n, bw, k0, nb, rowidx, R, U, clocked ? tp : nullptr, &t_prev);
     if (tid < 64) {
       bool bad = band_potf2_inv(U, nb, Dl, X, colbuf);
       if (bad && tid == 0 && w == 0) atomicCAS(info, 0, k0 + 1);
@@ -806,24 +841,58 @@ __global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double*
         double sacc = 0.0;
 #pragma unroll 8
         for (int t = 0; t <= cc; t++) sacc = fma(U[rr][t], X[cc][t], sacc);
-        if (i >= 0) { const int dlt = i - (k0 + cc); if (dlt <= bw) Sb[(size_t)(k0 + cc) * LD + dlt] = sacc; }
-        else rhs[k0 + cc] = sacc;
+        if (i >= 0) { if (i - (k0 + cc) <= bw) view.base[(long long)i * view.si + (long long)(k0 + cc) * view.sj] = sacc; }
+        else view.rb[(long long)(k0 + cc) * view.sr] = sacc;
       }
     }
     if (w == 0) {
       double* Li = Linv + (size_t)(k0 / BS) * BS * BS;
       for (int e = tid; e < BS * BS; e += 256) Li[e] = X[e >> 5][e & 31];
     }
-    epoch++;
     BAND_TICK(4);
-    if (k0 + BS < n) band_grid_sync(bar, epoch * (unsigned)G);
-    // L's diagonal block replaces A's only now: until the barrier the other workgroups may still be reading A's block
-    // (every one of them factorises it redundantly); nothing in later steps reads it (they use Linv)
+  };
+  // L's diagonal block replaces A's only after the step's barrier: until then the other workgroups may still be reading
+  // A's block (every one of them factorises it redundantly); nothing in later steps reads it (they use Linv)
+  auto write_diag = [&](const BandView& view, int k0, int nb) {
     if (w == 0)
       for (int e = tid; e < BS * BS; e += 256) {
         const int r = e >> 5, cc = e & 31;
-        if (r < nb && cc <= r && r - cc <= bw) Sb[(size_t)(k0 + cc) * LD + (r - cc)] = Dl[r][cc];
+        if (r < nb && cc <= r && r - cc <= bw) view.base[(long long)(k0 + r) * view.si + (long long)(k0 + cc) * view.sj] = Dl[r][cc];
       }
+  };
+  const BandSeg none{fwd, 0, 0, 0};
+  // ---- phase 1: the two fronts, each with its own barrier (after every step, the last one included: the deferred
+  // write of the diagonal block must not overtake a team-mate still reading A's block)
+  unsigned ep = 0;   // barriers completed on this team's counter
+  {
+    const BandView view = team ? rev : fwd;
+    double* Linv = team ? Linv_r : Linv_f;
+    const int Kt = team ? K2 : K1;
+    for (int kb = 0; kb < Kt; kb++) {
+      const int k0 = kb * BS;
+      const BandSeg s0{view, max(0, k0 - bw), k0, 0};
+      step(view, Linv, k0, BS, min(n, k0 + BS + bw), s0, none, 1);
+      ep++;
+      band_grid_sync(bars + team, ep * (unsigned)G);
+      write_diag(view, k0, BS);
+      BAND_TICK(5);
+    }
+    if (K2 > 0) {   // the fronts meet: the reverse team publishes and leaves, the forward team waits for it
+      if (team) { band_grid_arrive(bars + 2); return; }
+      band_grid_sync(bars + 2, 2u * (unsigned)G);
+    }
+  }
+  // ---- phase 2: the middle block, forward front, history = tail of the forward front (+ M's own earlier columns) and
+  // tail of the reverse front
+  for (int k0 = m_begin; k0 < m_end; k0 += BS) {
+    const int nb = min(BS, m_end - k0);
+    const int i_end = min(m_end, k0 + nb + bw);
+    const BandSeg s0{fwd, max(0, k0 - bw), k0, 0};
+    const BandSeg s1{rev, max(0, (n - i_end) - bw), BS * K2, 1};     // rows i -> i' = n - 1 - i; columns of the reverse front within the band
+    step(fwd, Linv_f, k0, nb, i_end, s0, s1, K2 > 0 ? 2 : 1);
+    ep++;
+    band_grid_sync(bars + 0, ep * (unsigned)G);
+    write_diag(fwd, k0, nb);
     BAND_TICK(5);
   }
   if (prof && tid == 0 && (w == 0 || w == G - 1)) for (int k = 0; k < 9; k++) prof[(w == 0 ? 0 : 9) + k] = tp[k];
@@ -831,10 +900,13 @@ __global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double*
 #undef BAND_TICK
 }
 
-// L^T x = y in place in rhs; one workgroup walks the column blocks backwards.  Per block: t = (rows below)^T x with x
-// from an LDS window, x_k = L_kk^-T (y_k - t) with the inverted diagonal block.  Everything a step reads from memory
-// (its panel of L, L_kk^-1, y_k) is independent of x and is fetched one step ahead, all loads unconditional.
-__global__ __launch_bounds__(256) void band_backsolve_kernel(const double* __restrict__ Sb, const double* __restrict__ Linv, const double* __restrict__ zero, int n, int LD, double* rhs) {
+// L^T x = y in place in rhs, in the elimination order reversed: first the middle block (forward view), then the two
+// fronts' regions independently -- workgroup 0 walks the forward front's blocks back to the top, workgroup 1 (it
+// repeats the middle block for itself) the reverse front's blocks back to the bottom.  Per block: t = (rows below)^T x
+// with x from an LDS window, x_k = L_kk^-T (y_k - t) with the inverted diagonal block.  Everything a step reads from
+// memory (its panel of L, L_kk^-1, y_k) is independent of x and is fetched one step ahead, all loads unconditional.
+__global__ __launch_bounds__(256) void band_backsolve_kernel(double* Sb, const double* __restrict__ Linv_f, const double* __restrict__ Linv_r, const double* __restrict__ zero,
+                                                             int n, int LD, int K1, int K2, double* rhs) {
   enum { WIN = 8192, PF = 24 };      // x window (a step touches <= 32 + 4096 consecutive rows); prefetched rows per thread
   __shared__ double xw[WIN];
   __shared__ double z[BS];
@@ -842,52 +914,72 @@ __global__ __launch_bounds__(256) void band_backsolve_kernel(const double* __res
   __shared__ double part[8][BS];
   const int tid = threadIdx.x, c = tid & 31, g = tid >> 5;
   const int bw = LD - 1;
-  const int nblk = (n + BS - 1) / BS;
+  const int m_end = n - BS * K2;
+  const BandView fwd{Sb, 1, (long long)bw, rhs, 1};
+  const BandView rev{Sb + (size_t)(n - 1) * LD, -(long long)bw, -1, rhs + (n - 1), -1};
   for (int e = tid; e < WIN; e += 256) xw[e] = 0.0;
   double lv[PF], li[4], yv = 0.0;
-  auto prefetch = [&](int kb) {
-    const int k0 = kb * BS, nb = min(BS, n - k0), i_end = min(n, k0 + nb + bw);
-    const double* col = Sb + (size_t)(k0 + c) * LD - (k0 + c);     // &L(i, k0 + c) = col + i
+  // blocks kb_hi .. kb_lo (descending) of `view`; rows of the view at or beyond row_limit do not exist
+  auto run = [&](const BandView& view, const double* Linv, int kb_hi, int kb_lo, int row_limit) {
+    auto prefetch = [&](int kb) {
+      const int k0 = kb * BS, nb = min(BS, row_limit - k0), i_end = min(row_limit, k0 + nb + bw);
+      const double* col = view.base + (long long)(k0 + c) * view.sj;     // &L(i, k0 + c) = col + i * si
 #pragma unroll
-    for (int s = 0; s < PF; s++) {
-      const int i = k0 + nb + g + 8 * s;
-      const bool ok = c < nb && i < i_end && i - (k0 + c) <= bw;
-      lv[s] = *(ok ? col + i : zero);
-    }
+      for (int s = 0; s < PF; s++) {
+        const int i = k0 + nb + g + 8 * s;
+        const bool ok = c < nb && i < i_end && i - (k0 + c) <= bw;
+        lv[s] = *(ok ? col + (long long)i * view.si : zero);
+      }
 #pragma unroll
-    for (int u = 0; u < 4; u++) li[u] = Linv[(size_t)kb * BS * BS + tid + 256 * u];
-    yv = (tid < nb) ? rhs[k0 + tid] : 0.0;
-  };
-  prefetch(nblk - 1);
-  __syncthreads();
-  for (int kb = nblk - 1; kb >= 0; kb--) {
-    const int k0 = kb * BS, nb = min(BS, n - k0);
-    const int i_end = min(n, k0 + nb + bw);
-    double acc = 0;   // t[c] = sum over the rows below the block of L(i, k0 + c) x[i]; 8 row groups
-#pragma unroll
-    for (int s = 0; s < PF; s++) acc = fma(lv[s], xw[(k0 + nb + g + 8 * s) & (WIN - 1)], acc);
-    if (c < nb)
-      for (int i = k0 + nb + g + 8 * PF; i < i_end; i += 8) if (i - (k0 + c) <= bw) acc = fma(Sb[(size_t)(k0 + c) * LD + (i - k0 - c)], xw[i & (WIN - 1)], acc);
-    part[g][c] = acc;
-#pragma unroll
-    for (int u = 0; u < 4; u++) { int e = tid + 256 * u; Li[e >> 5][e & 31] = li[u]; }
+      for (int u = 0; u < 4; u++) li[u] = Linv[(size_t)kb * BS * BS + tid + 256 * u];
+      yv = (tid < nb) ? view.rb[(long long)(k0 + tid) * view.sr] : 0.0;
+    };
+    if (kb_hi < kb_lo) return;
+    prefetch(kb_hi);
     __syncthreads();
-    if (tid < BS) {
-      double tt = 0;
+    for (int kb = kb_hi; kb >= kb_lo; kb--) {
+      const int k0 = kb * BS, nb = min(BS, row_limit - k0);
+      const int i_end = min(row_limit, k0 + nb + bw);
+      double acc = 0;   // t[c] = sum over the rows below the block of L(i, k0 + c) x[i]; 8 row groups
 #pragma unroll
-      for (int q = 0; q < 8; q++) tt += part[q][tid];
-      z[tid] = (tid < nb) ? yv - tt : 0.0;
-    }
-    __syncthreads();
-    if (kb > 0) prefetch(kb - 1);
-    if (tid < nb) {
-      double a2 = 0;
+      for (int s = 0; s < PF; s++) acc = fma(lv[s], xw[(k0 + nb + g + 8 * s) & (WIN - 1)], acc);
+      if (c < nb)
+        for (int i = k0 + nb + g + 8 * PF; i < i_end; i += 8)
+          if (i - (k0 + c) <= bw) acc = fma(view.base[(long long)i * view.si + (long long)(k0 + c) * view.sj], xw[i & (WIN - 1)], acc);
+      part[g][c] = acc;
+#pragma unroll
+      for (int u = 0; u < 4; u++) { int e = tid + 256 * u; Li[e >> 5][e & 31] = li[u]; }
+      __syncthreads();
+      if (tid < BS) {
+        double tt = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) tt += part[q][tid];
+        z[tid] = (tid < nb) ? yv - tt : 0.0;
+      }
+      __syncthreads();
+      if (kb > kb_lo) prefetch(kb - 1);
+      if (tid < nb) {
+        double a2 = 0;
 #pragma unroll 8
-      for (int r = 0; r < BS; r++) a2 = fma(Li[r][tid], z[r], a2);   // (L^-1)^T z
-      rhs[k0 + tid] = a2;
-      xw[(k0 + tid) & (WIN - 1)] = a2;
+        for (int r = 0; r < BS; r++) a2 = fma(Li[r][tid], z[r], a2);   // (L^-1)^T z
+        view.rb[(long long)(k0 + tid) * view.sr] = a2;
+        xw[(k0 + tid) & (WIN - 1)] = a2;
+      }
+      __syncthreads();
     }
+  };
+  // the middle block (forward view; rows end at m_end)
+  run(fwd, Linv_f, (m_end - 1) / BS, K1, m_end);
+  if (blockIdx.x == 0) {
+    run(fwd, Linv_f, K1 - 1, 0, n);
+  } else {
+    // the same unknowns seen from the reverse front: x of the middle block into the window at its reverse indices
     __syncthreads();
+    for (int e = tid; e < WIN; e += 256) xw[e] = 0.0;
+    __syncthreads();
+    for (int v = BS * K2 + tid; v < min(n, BS * K2 + bw + BS); v += 256) xw[v & (WIN - 1)] = rhs[n - 1 - v];
+    __syncthreads();
+    run(rev, Linv_r, K2 - 1, 0, n);
   }
 }
 
@@ -899,31 +991,41 @@ int ba_band_team(int LD, int* rw_out) {   // workgroups of the factorisation tea
   return G;
 }
 
-// info[0] = first non-positive pivot (+1), info[1] = barrier counter, info[2..3] = a zero double (the target of masked
-// loads); all zeroed by the caller.
+// info[0] = first non-positive pivot (+1), info[1..3] = barrier counters (forward team, reverse team, both),
+// info[4..5] = a zero double (the target of masked loads); all zeroed by the caller.  Linv: 2 * ceil(n / 32) blocks of
+// 32 x 32 (forward front and middle block first, then the reverse front).
+void ba_band_split(int n, int LD, int* K1, int* K2) {   // column blocks of the two fronts; the middle block keeps >= bw columns
+  const int bw = LD - 1;
+  const int Kt = n > bw ? (n - bw) / BS : 0;
+  static const bool one_sided = getenv("CS_BAND_ONE_SIDED") != nullptr;   // diagnostics: plain left-looking order
+  *K2 = (Kt >= 8 && !one_sided) ? Kt / 2 : 0;
+  *K1 = Kt - *K2;
+}
 void ba_launch_band_cholesky(double* Sb, double* Linv, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st) {
-  int rw = 0;
+  int rw = 0, K1 = 0, K2 = 0;
   const int G = ba_band_team(LD, &rw);
-  unsigned* bar = reinterpret_cast<unsigned*>(info + 1);
-  const double* zero = reinterpret_cast<const double*>(info + 2);
-  static const bool want_prof = getenv("CS_BAND_PROF") != nullptr;   // diagnostics: phase clock of the first / last workgroup
+  ba_band_split(n, LD, &K1, &K2);
+  unsigned* bars = reinterpret_cast<unsigned*>(info + 1);
+  const double* zero = reinterpret_cast<const double*>(info + 4);
+  double* Linv_f = Linv;
+  double* Linv_r = Linv + (size_t)((n + BS - 1) / BS) * BS * BS;
+  static const bool want_prof = getenv("CS_BAND_PROF") != nullptr;   // diagnostics: phase clock of the forward team's first / last workgroup
   static long long* prof = nullptr;
-  static const int xs = getenv("CS_BAND_ONE_XCD") ? 3 : 0;   // diagnostics: confine the team to one XCD (slower barrier, measured)
   if (want_prof && !prof) (void)hipMalloc(&prof, 20 * sizeof(long long));
-  hipLaunchKernelGGL(band_chol_coop_kernel, dim3(G << xs), dim3(256), 0, st, Sb, Linv, rhs, zero, n, LD, info, bar, G, xs, prof);
+  hipLaunchKernelGGL(band_chol_coop_kernel, dim3(K2 > 0 ? 2 * G : G), dim3(256), 0, st, Sb, Linv_f, Linv_r, rhs, zero, n, LD, K1, K2, info, bars, G, prof);
   if (prof) {
     long long h[20];
     (void)hipMemcpyAsync(h, prof, sizeof(h), hipMemcpyDeviceToHost, st);
     (void)hipStreamSynchronize(st);
     static int shown = 0;
     if (shown++ < 3) {
-      fprintf(stderr, "[band] shader clock %.0f MHz over %.0f us\n", h[18] / (h[19] * 0.01), h[19] * 0.01);
+      fprintf(stderr, "[band] shader clock %.0f MHz over %.0f us; fronts %d + %d blocks, middle %d columns\n", h[18] / (h[19] * 0.01), h[19] * 0.01, K1, K2, n - BS * (K1 + K2));
       for (int q = 0; q < 2; q++)
         fprintf(stderr, "[band] n=%d LD=%d G=%d wg%s us: fetch-issue %.0f  store+wait %.0f  gemm %.0f  reduce+U %.0f  potf2+inverse %.0f  panel %.0f  barrier %.0f\n", n, LD, G, q ? "last" : "0",
                 h[9 * q + 6] * 0.01, h[9 * q + 7] * 0.01, h[9 * q + 8] * 0.01, h[9 * q + 1] * 0.01, h[9 * q + 2] * 0.01, h[9 * q + 4] * 0.01, h[9 * q + 5] * 0.01);
     }
   }
-  if (solve) hipLaunchKernelGGL(band_backsolve_kernel, dim3(1), dim3(256), 0, st, Sb, Linv, zero, n, LD, rhs);
+  if (solve) hipLaunchKernelGGL(band_backsolve_kernel, dim3(K2 > 0 ? 2 : 1), dim3(256), 0, st, Sb, Linv_f, Linv_r, zero, n, LD, K1, K2, rhs);
 }
 
 // ---------------------------------------------------------------------------------------- launchers --

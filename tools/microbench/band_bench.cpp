@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
   for (int c = 0; c < n; c++) { A[(size_t)c * LD] = diag[c]; b[c] = rnd(); }
   double *dS, *dL, *dr; int* dinfo;
   const int nblk = (n + 31) / 32;
-  hipMalloc(&dS, A.size() * 8); hipMalloc(&dL, (size_t)nblk * 1024 * 8); hipMalloc(&dr, n * 8); hipMalloc(&dinfo, 16);
+  hipMalloc(&dS, A.size() * 8); hipMalloc(&dL, 2 * (size_t)nblk * 1024 * 8); hipMalloc(&dr, n * 8); hipMalloc(&dinfo, 32);
   hipStream_t st; hipStreamCreate(&st);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   std::vector<double> x(n);
@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
     if (r > 0) { for (auto& v : A) v *= 1.25; for (int c = 0; c < n; c++) A[(size_t)c * LD] += 0.5 * r; for (auto& v : b) v = rnd(); }
     hipMemcpyAsync(dS, A.data(), A.size() * 8, hipMemcpyHostToDevice, st);
     hipMemcpyAsync(dr, b.data(), n * 8, hipMemcpyHostToDevice, st);
-    hipMemsetAsync(dinfo, 0, 16, st);
+    hipMemsetAsync(dinfo, 0, 32, st);
     hipEventRecord(e0, st);
     cs::ba_launch_band_cholesky(dS, dL, n, LD, dr, dinfo, true, st);
     hipEventRecord(e1, st);
