@@ -17,6 +17,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/cubeslam_hip.h"
@@ -441,6 +442,11 @@ int build_system_device(cs_ba* B) {
 
 // setLambda + solve + restoreDiagonal (block_solver.hpp:353-486, :563-604): lambda is applied while the
 // reduced system is assembled, so the stored blocks are never modified and nothing needs restoring.
+// The banded factorisation is a persistent kernel whose workgroups wait for each other: all of them must be resident.
+// One such kernel fits many times over, but an unbounded number of concurrent solves (handles on different streams of
+// one process) would not; they take turns.
+static std::mutex g_coop_mutex;
+
 int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr, void* ctx = nullptr) {
   const int n = B->n_pose;
   *ok = true;
@@ -458,6 +464,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       // banded: factorisation, both substitutions and the landmark back-substitution are queued back to back; the
       // pivot flag comes home with the single synchronisation (a failed factorisation just leaves garbage increments
       // that the caller discards)
+      std::lock_guard<std::mutex> coop_turn(g_coop_mutex);
       BA_TRY(hipMemsetAsync(B->d_band_info.p, 0, 8 * sizeof(int), B->st));
       cs::ba_launch_band_cholesky(B->S.p, B->band_linv.p, n, B->band_ld, B->view.rhs, B->d_band_info.p, true, B->st);
       BA_TRY(hipGetLastError());
