@@ -41,6 +41,7 @@ namespace cs {
 void launch_vp_support(const DetectDeviceView& v, const SweepParams& sp, int vp_total, hipStream_t st);
 void launch_vp_support_only(const DetectDeviceView& v, const SweepParams& sp, int vp_total, hipStream_t st);
 void launch_vp_points(const DetectDeviceView& v, int vp_total, hipStream_t st);
+int vp3_table_doubles_per_job();
 void launch_candidates(const DetectDeviceView& v, const SweepParams& sp, long long slot_total, hipStream_t st);
 void launch_scan_compact(const DetectDeviceView& v, hipStream_t st);
 void launch_score(const DetectDeviceView& v, long long n_valid_bound, long long slot_total, hipStream_t st);
@@ -409,6 +410,7 @@ struct PipeSlot {
   DevBuf<cs::JobDesc> jobs;
   DevBuf<long long> slot_prefix, job_cbase, c_slot, fb_src, fb_dst, fb_slot, win_slots;
   DevBuf<int> vp_prefix, top_x, flag, job_valid, c_flag, box_job0, box_njobs, win_count, fallback, fb_cnt, fb_flag;
+  DevBuf<double> bound3;
   DevBuf<double> mid_x, mid_y, ang, yaw, yaw_c, yaw_s, vp, bound, corners, c_dist, c_angle, c_skew, fb_dist, fb_angle, fb_skew, win_corners;
   DevBuf<cs::RankWinner> winners;
   PinBuf<cs::JobDesc> h_jobs_in, h_jobs_out;
@@ -429,7 +431,7 @@ struct PipeSlot {
     jobs.release(); slot_prefix.release(); job_cbase.release(); c_slot.release(); fb_src.release(); fb_dst.release(); fb_slot.release(); win_slots.release();
     vp_prefix.release(); top_x.release(); flag.release(); job_valid.release(); c_flag.release(); box_job0.release(); box_njobs.release(); win_count.release();
     fallback.release(); fb_cnt.release(); fb_flag.release(); mid_x.release(); mid_y.release(); ang.release(); yaw.release(); yaw_c.release(); yaw_s.release();
-    vp.release(); bound.release(); corners.release(); c_dist.release(); c_angle.release(); c_skew.release(); fb_dist.release(); fb_angle.release(); fb_skew.release();
+    vp.release(); bound.release(); bound3.release(); corners.release(); c_dist.release(); c_angle.release(); c_skew.release(); fb_dist.release(); fb_angle.release(); fb_skew.release();
     win_corners.release(); winners.release(); h_jobs_in.release(); h_jobs_out.release(); h_slot_prefix.release(); h_job_cbase.release(); h_vp_prefix.release();
     h_top_x.release(); h_box_job0.release(); h_box_njobs.release(); h_win_count.release(); h_fallback.release(); h_job_valid.release(); h_yaw.release();
     h_yaw_c.release(); h_yaw_s.release(); h_winners.release();
@@ -870,7 +872,7 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   const long long slot_total = S.slot_total;
   PENS(S.jobs, nj); PENS(S.slot_prefix, nj + 1); PENS(S.vp_prefix, nj + 1); PENS(S.job_valid, nj); PENS(S.job_cbase, nj + 1);
   PENS(S.mid_x, n_lines + 1); PENS(S.mid_y, n_lines + 1); PENS(S.ang, n_lines + 1); PENS(S.yaw, n_yaw + 1); PENS(S.yaw_c, n_yaw + 1); PENS(S.yaw_s, n_yaw + 1);
-  PENS(S.top_x, n_top + 1); PENS(S.vp, 6 * (size_t)S.vp_total + 6); PENS(S.bound, 6 * (size_t)S.vp_total + 6); PENS(S.flag, slot_total + 1);
+  PENS(S.top_x, n_top + 1); PENS(S.vp, 6 * (size_t)S.vp_total + 6); PENS(S.bound, 6 * (size_t)S.vp_total + 6); PENS(S.bound3, nj * (size_t)cs::vp3_table_doubles_per_job()); PENS(S.flag, slot_total + 1);
   PENS(S.corners, 16 * (size_t)slot_total + 16); PENS(S.c_slot, slot_total + 1); PENS(S.c_flag, slot_total + 1); PENS(S.c_dist, slot_total + 1);
   PENS(S.c_angle, slot_total + 1); PENS(S.c_skew, slot_total + 1); PENS(S.box_job0, nb + 1); PENS(S.box_njobs, nb + 1); PENS(S.win_count, nb + 1);
   PENS(S.fallback, nb + 1); PENS(S.winners, nb * KMAX + 1);
@@ -885,7 +887,7 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   v = cs::DetectDeviceView{};
   v.jobs = S.jobs.p; v.n_jobs = (int)nj; v.slot_prefix = S.slot_prefix.p; v.vp_prefix = S.vp_prefix.p; v.maps = b->d_maps.p;
   v.mid_x = S.mid_x.p; v.mid_y = S.mid_y.p; v.line_angle = S.ang.p; v.yaw = S.yaw.p; v.yaw_cos = S.yaw_c.p; v.yaw_sin = S.yaw_s.p; v.top_x = S.top_x.p;
-  v.rp = b->d_rp.p; v.invK = b->d_invK.p; v.vp = S.vp.p; v.bound = S.bound.p; v.flag = S.flag.p; v.corners = S.corners.p; v.job_valid = S.job_valid.p;
+  v.rp = b->d_rp.p; v.invK = b->d_invK.p; v.vp = S.vp.p; v.bound = S.bound.p; v.bound3 = S.bound3.p; v.flag = S.flag.p; v.corners = S.corners.p; v.job_valid = S.job_valid.p;
   v.job_cbase = S.job_cbase.p; v.c_slot = S.c_slot.p; v.c_flag = S.c_flag.p; v.c_dist = S.c_dist.p; v.c_angle = S.c_angle.p; v.c_skew = S.c_skew.p;
   // The corner construction needs the vanishing points but not the segments: it runs on the second stream beside line
   // setup + VP support (a latency-bound and an ALU-bound kernel), and the scorer waits for both.

@@ -47,100 +47,138 @@ __device__ __forceinline__ long long xcd_virtual_block() {
   return (b & 7) * (nb >> 3) + (b >> 3);
 }
 
-// WRITE_VP = false: the vanishing points themselves are produced by vp_points_kernel on another stream (they do not depend
-// on the segments, so the corner construction can run beside line setup + VP support); this kernel then only writes `bound`
-template <bool WRITE_VP>
-__global__ __launch_bounds__(256) void vp_support_kernel(DetectDeviceView v, SweepParams sp, int vp_total) {
-  long long e = xcd_virtual_block() * blockDim.x + threadIdx.x;
-  if (e >= vp_total) return;
-  int j = find_job_i32(v.vp_prefix, v.n_jobs, (int)e);
-  const JobDesc jd = v.jobs[j];
-  int local = (int)e - jd.vp_off;
-  int rp = local / jd.Y, y = local - rp * jd.Y;
-  const RpPose* pose = v.rp + jd.rp_off + rp;
-  double cy = v.yaw_cos[jd.yaw_off + y], sy = v.yaw_sin[jd.yaw_off + y];
-  const double* A = pose->KinvR;
-  // getVanishingPoints (object_3d_util.cpp:928-937)
-  double d[3][3] = {{cy, sy, 0.0}, {-sy, cy, 0.0}, {0.0, 0.0, 1.0}};
-  double vpx[3], vpy[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    double h0 = (A[0] * d[k][0] + A[1] * d[k][1]) + A[2] * d[k][2];
-    double h1 = (A[3] * d[k][0] + A[4] * d[k][1]) + A[5] * d[k][2];
-    double h2 = (A[6] * d[k][0] + A[7] * d[k][1]) + A[8] * d[k][2];
-    vpx[k] = h0 / h2;
-    vpy[k] = h1 / h2;
-  }
-  if (WRITE_VP) {
-    double* vout = v.vp + 6 * e;
-    vout[0] = vpx[0]; vout[1] = vpy[0]; vout[2] = vpx[1]; vout[3] = vpy[1]; vout[4] = vpx[2]; vout[5] = vpy[2];
-  }
-
-  // VP_support_edge_infos (object_3d_util.cpp:548-619): sequential over the job's merged lines.
-  const double* mx = v.mid_x + jd.line_off;
-  const double* my = v.mid_y + jd.line_off;
-  const double* la = v.line_angle + jd.line_off;
-  double* bout = v.bound + 6 * e;
+// VP_support_edge_infos (object_3d_util.cpp:548-619) for ONE vanishing point: sequential over the job's merged lines.
+// Only inliers (a few percent of the segments) need the exact angle.  Per chunk of 64 segments: (1) a float
+// approximation of atan2 (|error| < 2e-6 rad, checked in tests/test_detect_oracle.py) marks every segment that is
+// not certainly an outlier -- "certainly" = further than 1e-4 rad from the threshold and from the +-pi/2 fold of
+// normalize_to_pi; (2) the marked ones are evaluated exactly, in order.  The wave runs the expensive cs_atan2
+// only max-over-lanes(marked) times instead of m times, and every decision is the exact one.
+// out[0], out[1] = the two bounding segment angles (NaN = none): (max, min) for vp 1, swapped for vp 2, 3 (:609-614).
+__device__ __forceinline__ void vp_support_one(const double* __restrict__ mx, const double* __restrict__ my, const double* __restrict__ la, int m, double vpxk, double vpyk,
+                                               double thre, bool swapped, bool lane_on, double* out) {
   const double NaN = __builtin_nan("");
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    double thre = (k != 2) ? sp.vp12_thre_rad : sp.vp3_thre_rad;
-    bool have = false;
-    double base = 0, best_hi = 0, best_lo = 0, ang_hi = NaN, ang_lo = NaN;
-    // Only inliers (a few percent of the segments) need the exact angle.  Per chunk of 64 segments: (1) a float
-    // approximation of atan2 (|error| < 2e-6 rad, checked in tests/test_detect_oracle.py) marks every segment that is
-    // not certainly an outlier -- "certainly" = further than 1e-4 rad from the threshold and from the +-pi/2 fold of
-    // normalize_to_pi; (2) the marked ones are evaluated exactly, in order.  The wave runs the expensive cs_atan2
-    // only max-over-lanes(marked) times instead of m times, and every decision is the exact one.
-    for (int i0 = 0; i0 < jd.m; i0 += 64) {
-      unsigned long long mask = 0;
-      const int i1 = min(jd.m, i0 + 64);
-      for (int i = i0; i < i1; i++) {
-        float fy = (float)(my[i] - vpy[k]), fx = (float)(mx[i] - vpx[k]);
-        float ay = fabsf(fy), ax = fabsf(fx);
-        float hi = fmaxf(ax, ay), lo = fminf(ax, ay);
-        bool maybe = true;
-        if (hi > 0.0f && hi < 3.0e38f) {  // finite, non-degenerate; anything else goes to the exact evaluation
-          float q = lo / hi, q2 = q * q;
-          float at = q * (0.99997726f + q2 * (-0.33262347f + q2 * (0.19354346f + q2 * (-0.11643287f + q2 * (0.05265332f + q2 * -0.01172120f)))));
-          if (ay > ax) at = 1.57079637f - at;
-          if (fx < 0.0f) at = 3.14159274f - at;
-          if (fy < 0.0f) at = -at;
-          const float fold = fabsf(fabsf(at) - 1.57079637f);
-          float nr = at;
-          if (at > 1.57079637f) nr = at - 3.14159274f; else if (at < -1.57079637f) nr = at + 3.14159274f;
-          float df = fabsf((float)la[i] - nr);
-          df = fminf(df, 3.14159274f - df);
-          maybe = !(fold > 1.0e-4f && df > (float)thre + 1.0e-4f);
-        }
-        if (maybe) mask |= 1ull << (i - i0);
+  bool have = false;
+  double base = 0, best_hi = 0, best_lo = 0, ang_hi = NaN, ang_lo = NaN;
+  const int mm = lane_on ? m : 0;
+  for (int i0 = 0; __any(i0 < mm); i0 += 64) {
+    unsigned long long mask = 0;
+    const int i1 = min(mm, i0 + 64);
+    for (int i = i0; i < i1; i++) {
+      float fy = (float)(my[i] - vpyk), fx = (float)(mx[i] - vpxk);
+      float ay = fabsf(fy), ax = fabsf(fx);
+      float hi = fmaxf(ax, ay), lo = fminf(ax, ay);
+      bool maybe = true;
+      if (hi > 0.0f && hi < 3.0e38f) {  // finite, non-degenerate; anything else goes to the exact evaluation
+        float q = lo / hi, q2 = q * q;
+        float at = q * (0.99997726f + q2 * (-0.33262347f + q2 * (0.19354346f + q2 * (-0.11643287f + q2 * (0.05265332f + q2 * -0.01172120f)))));
+        if (ay > ax) at = 1.57079637f - at;
+        if (fx < 0.0f) at = 3.14159274f - at;
+        if (fy < 0.0f) at = -at;
+        const float fold = fabsf(fabsf(at) - 1.57079637f);
+        float nr = at;
+        if (at > 1.57079637f) nr = at - 3.14159274f; else if (at < -1.57079637f) nr = at + 3.14159274f;
+        float df = fabsf((float)la[i] - nr);
+        df = fminf(df, 3.14159274f - df);
+        maybe = !(fold > 1.0e-4f && df > (float)thre + 1.0e-4f);
       }
-      while (__any(mask != 0)) {
-        if (mask != 0) {
-          const int i = i0 + __ffsll((long long)mask) - 1;
-          mask &= mask - 1;
-          double raw = cs_atan2(my[i] - vpy[k], mx[i] - vpx[k]);
-          double nrm = normalize_to_pi(raw);
-          double df = dabs(la[i] - nrm);
-          df = dmin(df, CS_PI - df);
-          if (df < thre) {
-            if (!have) {  // first inlier: base of smooth_jump_angles (:278-302), and initial arg-max / arg-min
-              have = true; base = raw; best_hi = raw; best_lo = raw; ang_hi = la[i]; ang_lo = la[i];
-            } else {
-              double sh = raw;
-              if ((raw - base) < -CS_PI) sh = raw + 2 * CS_PI;
-              else if ((raw - base) > CS_PI) sh = raw - 2 * CS_PI;
-              if (sh > best_hi) { best_hi = sh; ang_hi = la[i]; }  // maxCoeff: first occurrence, strict
-              if (sh < best_lo) { best_lo = sh; ang_lo = la[i]; }  // minCoeff
-            }
+      if (maybe) mask |= 1ull << (i - i0);
+    }
+    while (__any(mask != 0)) {
+      if (mask != 0) {
+        const int i = i0 + __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        double raw = cs_atan2(my[i] - vpyk, mx[i] - vpxk);
+        double nrm = normalize_to_pi(raw);
+        double df = dabs(la[i] - nrm);
+        df = dmin(df, CS_PI - df);
+        if (df < thre) {
+          if (!have) {  // first inlier: base of smooth_jump_angles (:278-302), and initial arg-max / arg-min
+            have = true; base = raw; best_hi = raw; best_lo = raw; ang_hi = la[i]; ang_lo = la[i];
+          } else {
+            double sh = raw;
+            if ((raw - base) < -CS_PI) sh = raw + 2 * CS_PI;
+            else if ((raw - base) > CS_PI) sh = raw - 2 * CS_PI;
+            if (sh > best_hi) { best_hi = sh; ang_hi = la[i]; }  // maxCoeff: first occurrence, strict
+            if (sh < best_lo) { best_lo = sh; ang_lo = la[i]; }  // minCoeff
           }
         }
       }
     }
-    // vp 1: (max, min); vp 2,3: swapped (:609-614)
-    bout[2 * k + 0] = (k > 0) ? ang_lo : ang_hi;
-    bout[2 * k + 1] = (k > 0) ? ang_hi : ang_lo;
   }
+  out[0] = swapped ? ang_lo : ang_hi;
+  out[1] = swapped ? ang_hi : ang_lo;
+}
+
+enum { VP3_RPCAP = 32 };   // slots of the per-(job, roll/pitch sample) table of the third vanishing point's support angles
+
+// MODE 0: everything in one kernel (vanishing points written, three VP supports).
+// MODE 1: the lean path -- the vanishing points are produced by vp_points_kernel on another stream (they do not depend on
+// the segments, so the corner construction runs beside line setup + VP support), and the support of the third
+// (vertical) vanishing point, which does not depend on the yaw sample, comes from vp3_support_kernel's table.
+template <int MODE>
+__global__ __launch_bounds__(256) void vp_support_kernel(DetectDeviceView v, SweepParams sp, int vp_total) {
+  long long e = xcd_virtual_block() * blockDim.x + threadIdx.x;
+  const bool on = e < vp_total;
+  int j = 0;
+  JobDesc jd{};
+  int rp = 0, y = 0;
+  if (on) {
+    j = find_job_i32(v.vp_prefix, v.n_jobs, (int)e);
+    jd = v.jobs[j];
+    int local = (int)e - jd.vp_off;
+    rp = local / jd.Y; y = local - rp * jd.Y;
+  }
+  double vpx[3] = {0, 0, 0}, vpy[3] = {0, 0, 0};
+  if (on) {
+    const RpPose* pose = v.rp + jd.rp_off + rp;
+    double cy = v.yaw_cos[jd.yaw_off + y], sy = v.yaw_sin[jd.yaw_off + y];
+    const double* A = pose->KinvR;
+    // getVanishingPoints (object_3d_util.cpp:928-937)
+    double d[3][3] = {{cy, sy, 0.0}, {-sy, cy, 0.0}, {0.0, 0.0, 1.0}};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      double h0 = (A[0] * d[k][0] + A[1] * d[k][1]) + A[2] * d[k][2];
+      double h1 = (A[3] * d[k][0] + A[4] * d[k][1]) + A[5] * d[k][2];
+      double h2 = (A[6] * d[k][0] + A[7] * d[k][1]) + A[8] * d[k][2];
+      vpx[k] = h0 / h2;
+      vpy[k] = h1 / h2;
+    }
+    if (MODE == 0) {
+      double* vout = v.vp + 6 * e;
+      vout[0] = vpx[0]; vout[1] = vpy[0]; vout[2] = vpx[1]; vout[3] = vpy[1]; vout[4] = vpx[2]; vout[5] = vpy[2];
+    }
+  }
+  const double* mx = v.mid_x + jd.line_off;
+  const double* my = v.mid_y + jd.line_off;
+  const double* la = v.line_angle + jd.line_off;
+  double b6[6];
+#pragma unroll
+  for (int k = 0; k < (MODE == 0 ? 3 : 2); k++) vp_support_one(mx, my, la, jd.m, vpx[k], vpy[k], (k != 2) ? sp.vp12_thre_rad : sp.vp3_thre_rad, k > 0, on, b6 + 2 * k);
+  if (!on) return;
+  if (MODE == 1) { const double* t3 = v.bound3 + 2 * ((size_t)j * VP3_RPCAP + rp); b6[4] = t3[0]; b6[5] = t3[1]; }
+  double* bout = v.bound + 6 * e;
+#pragma unroll
+  for (int q = 0; q < 6; q++) bout[q] = b6[q];
+}
+
+// support angles of the third vanishing point, K R^-1 (0, 0, 1): one lane per (job, roll/pitch sample)
+__global__ __launch_bounds__(64) void vp3_support_kernel(DetectDeviceView v, SweepParams sp) {
+  const long long e = (long long)blockIdx.x * 64 + threadIdx.x;
+  const int j = (int)(e / VP3_RPCAP), rp = (int)(e % VP3_RPCAP);
+  bool on = j < v.n_jobs;
+  JobDesc jd{};
+  if (on) { jd = v.jobs[j]; on = rp < jd.RP && jd.Y > 0; }
+  double vx = 0, vy = 0;
+  if (on) {
+    const double* A = (v.rp + jd.rp_off + rp)->KinvR;
+    double h0 = (A[0] * 0.0 + A[1] * 0.0) + A[2] * 1.0;
+    double h1 = (A[3] * 0.0 + A[4] * 0.0) + A[5] * 1.0;
+    double h2 = (A[6] * 0.0 + A[7] * 0.0) + A[8] * 1.0;
+    vx = h0 / h2; vy = h1 / h2;
+  }
+  double o2[2];
+  vp_support_one(v.mid_x + jd.line_off, v.mid_y + jd.line_off, v.line_angle + jd.line_off, jd.m, vx, vy, sp.vp3_thre_rad, true, on, o2);
+  if (on) { double* t3 = v.bound3 + 2 * ((size_t)j * VP3_RPCAP + rp); t3[0] = o2[0]; t3[1] = o2[1]; }
 }
 
 // getVanishingPoints (object_3d_util.cpp:928-937) alone: the same arithmetic as the head of vp_support_kernel
@@ -783,12 +821,14 @@ static inline unsigned grid8(long long n, int bs) {
 
 void launch_vp_support(const DetectDeviceView& v, const SweepParams& sp, int vp_total, hipStream_t st) {
   if (vp_total <= 0) return;
-  vp_support_kernel<true><<<dim3(grid8(vp_total, 256)), dim3(256), 0, st>>>(v, sp, vp_total);
+  vp_support_kernel<0><<<dim3(grid8(vp_total, 256)), dim3(256), 0, st>>>(v, sp, vp_total);
 }
 void launch_vp_support_only(const DetectDeviceView& v, const SweepParams& sp, int vp_total, hipStream_t st) {
   if (vp_total <= 0) return;
-  vp_support_kernel<false><<<dim3(grid8(vp_total, 256)), dim3(256), 0, st>>>(v, sp, vp_total);
+  hipLaunchKernelGGL(vp3_support_kernel, dim3((unsigned)(((long long)v.n_jobs * VP3_RPCAP + 63) / 64)), dim3(64), 0, st, v, sp);
+  vp_support_kernel<1><<<dim3(grid8(vp_total, 256)), dim3(256), 0, st>>>(v, sp, vp_total);
 }
+int vp3_table_doubles_per_job() { return 2 * VP3_RPCAP; }
 void launch_vp_points(const DetectDeviceView& v, int vp_total, hipStream_t st) {
   if (vp_total <= 0) return;
   hipLaunchKernelGGL(vp_points_kernel, dim3((vp_total + 255) / 256), dim3(256), 0, st, v, vp_total);

@@ -52,6 +52,7 @@ struct DetectDeviceView {
   // sweep intermediates
   double* vp;                    // 6 per (job, rp, yaw): vp1.x vp1.y vp2.x vp2.y vp3.x vp3.y
   double* bound;                 // 6 per (job, rp, yaw): the 3x2 VP support angles (NaN = none)
+  double* bound3;                // lean path: 2 per (job, rp) slot -- the third VP's support angles (they do not depend on yaw)
   // per-slot outputs
   int* flag;
   double* corners;               // 16 per slot (x0..x7, y0..y7), written for valid slots only
