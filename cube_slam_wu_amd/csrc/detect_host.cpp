@@ -51,7 +51,7 @@ struct EdgeRoi { int l, t, w, h; long long img_off, cls_off, map_off; };
 void launch_edge_maps(const unsigned char* gray, int W, int H, const EdgeRoi* rois, int n_rois, unsigned char* cls_pool, float* map_pool, int max_w, int low, int high,
                       hipStream_t st);
 void launch_line_setup(JobDesc* jobs, int n_jobs, const double* frame_lines, const int* frame_line_ptr, double* mid_x, double* mid_y, double* line_angle,
-                       double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st);
+                       double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st, const int* order = nullptr);
 int line_setup_capacity();
 void launch_gather_ranges(const DetectDeviceView& v, const long long* src_off, const int* count, const long long* dst_off, int n_ranges,
                           double* o_dist, double* o_angle, double* o_skew, int* o_flag, long long* o_slot, hipStream_t st);
@@ -411,6 +411,8 @@ struct PipeSlot {
   DevBuf<long long> slot_prefix, job_cbase, c_slot, fb_src, fb_dst, fb_slot, win_slots;
   DevBuf<int> vp_prefix, top_x, flag, job_valid, c_flag, box_job0, box_njobs, win_count, fallback, fb_cnt, fb_flag;
   DevBuf<double> bound3;
+  DevBuf<int> ls_order;
+  PinBuf<int> h_ls_order;
   DevBuf<double> mid_x, mid_y, ang, yaw, yaw_c, yaw_s, vp, bound, corners, c_dist, c_angle, c_skew, fb_dist, fb_angle, fb_skew, win_corners;
   DevBuf<cs::RankWinner> winners;
   PinBuf<cs::JobDesc> h_jobs_in, h_jobs_out;
@@ -431,7 +433,7 @@ struct PipeSlot {
     jobs.release(); slot_prefix.release(); job_cbase.release(); c_slot.release(); fb_src.release(); fb_dst.release(); fb_slot.release(); win_slots.release();
     vp_prefix.release(); top_x.release(); flag.release(); job_valid.release(); c_flag.release(); box_job0.release(); box_njobs.release(); win_count.release();
     fallback.release(); fb_cnt.release(); fb_flag.release(); mid_x.release(); mid_y.release(); ang.release(); yaw.release(); yaw_c.release(); yaw_s.release();
-    vp.release(); bound.release(); bound3.release(); corners.release(); c_dist.release(); c_angle.release(); c_skew.release(); fb_dist.release(); fb_angle.release(); fb_skew.release();
+    vp.release(); bound.release(); bound3.release(); ls_order.release(); h_ls_order.release(); corners.release(); c_dist.release(); c_angle.release(); c_skew.release(); fb_dist.release(); fb_angle.release(); fb_skew.release();
     win_corners.release(); winners.release(); h_jobs_in.release(); h_jobs_out.release(); h_slot_prefix.release(); h_job_cbase.release(); h_vp_prefix.release();
     h_top_x.release(); h_box_job0.release(); h_box_njobs.release(); h_win_count.release(); h_fallback.release(); h_job_valid.release(); h_yaw.release();
     h_yaw_c.release(); h_yaw_s.release(); h_winners.release();
@@ -803,7 +805,7 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   int rc;
 #define PENS(buf, n) do { rc = (buf).ensure(n); if (rc) return rc; } while (0)
   PENS(S.h_jobs_in, nj); PENS(S.h_slot_prefix, nj + 1); PENS(S.h_vp_prefix, nj + 1); PENS(S.h_yaw, n_yaw + 1); PENS(S.h_yaw_c, n_yaw + 1); PENS(S.h_yaw_s, n_yaw + 1);
-  PENS(S.h_top_x, n_top + 1); PENS(S.h_box_job0, nj); PENS(S.h_box_njobs, nj);
+  PENS(S.h_top_x, n_top + 1); PENS(S.h_box_job0, nj); PENS(S.h_box_njobs, nj); PENS(S.h_ls_order, nj);
   std::atomic<int> overflow{0};
   d->pool->run(nf, [&](int q) {
     const int f = f0 + q;
@@ -861,6 +863,18 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
     }
     S.h_slot_prefix.p[nj] = so; S.h_vp_prefix.p[nj] = (int)vo;
     S.slot_total = so; S.vp_total = (int)vo;
+    // launch order of the line setup: jobs with the largest ROI x segment count first (a counting sort on that proxy of
+    // their sequential merge work), so that the kernel's tail is not a late-started long job
+    {
+      enum { NBK = 64 };
+      long long wmax = 1;
+      for (size_t j = 0; j < nj; j++) { const cs::JobDesc& jd = S.h_jobs_in.p[j]; wmax = std::max(wmax, (long long)(jd.g.er - jd.g.el) * (jd.g.eb - jd.g.et) * b->frames[jd.frame].n_lines); }
+      int cnt[NBK + 1] = {0};
+      auto bucket = [&](const cs::JobDesc& jd) { return NBK - 1 - (int)(((long long)(jd.g.er - jd.g.el) * (jd.g.eb - jd.g.et) * b->frames[jd.frame].n_lines) * (NBK - 1) / wmax); };
+      for (size_t j = 0; j < nj; j++) cnt[bucket(S.h_jobs_in.p[j]) + 1]++;
+      for (int q = 0; q < NBK; q++) cnt[q + 1] += cnt[q];
+      for (size_t j = 0; j < nj; j++) S.h_ls_order.p[cnt[bucket(S.h_jobs_in.p[j])]++] = (int)j;
+    }
     if (vo > 0x7fffffffLL) { set_err("too many yaw samples in one chunk"); return CS_ERR_CAPACITY; }
   }
   S.nb = nb;
@@ -870,7 +884,7 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   C.tm->n_jobs += (long long)nj; C.tm->n_slots += S.slot_total;
   // ---- device buffers, H2D, kernels, D2H: all asynchronous on the detector's stream
   const long long slot_total = S.slot_total;
-  PENS(S.jobs, nj); PENS(S.slot_prefix, nj + 1); PENS(S.vp_prefix, nj + 1); PENS(S.job_valid, nj); PENS(S.job_cbase, nj + 1);
+  PENS(S.ls_order, nj); PENS(S.jobs, nj); PENS(S.slot_prefix, nj + 1); PENS(S.vp_prefix, nj + 1); PENS(S.job_valid, nj); PENS(S.job_cbase, nj + 1);
   PENS(S.mid_x, n_lines + 1); PENS(S.mid_y, n_lines + 1); PENS(S.ang, n_lines + 1); PENS(S.yaw, n_yaw + 1); PENS(S.yaw_c, n_yaw + 1); PENS(S.yaw_s, n_yaw + 1);
   PENS(S.top_x, n_top + 1); PENS(S.vp, 6 * (size_t)S.vp_total + 6); PENS(S.bound, 6 * (size_t)S.vp_total + 6); PENS(S.bound3, nj * (size_t)cs::vp3_table_doubles_per_job()); PENS(S.flag, slot_total + 1);
   PENS(S.corners, 16 * (size_t)slot_total + 16); PENS(S.c_slot, slot_total + 1); PENS(S.c_flag, slot_total + 1); PENS(S.c_dist, slot_total + 1);
@@ -878,7 +892,7 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   PENS(S.fallback, nb + 1); PENS(S.winners, nb * KMAX + 1);
   PENS(S.h_winners, nb * KMAX + 1); PENS(S.h_win_count, nb + 1); PENS(S.h_fallback, nb + 1); PENS(S.h_job_valid, nj); PENS(S.h_job_cbase, nj + 1); PENS(S.h_jobs_out, nj);
 #define PH2D(dst, src, n) HIP_TRY(hipMemcpyAsync((dst).p, (src).p, sizeof(*(src).p) * (n), hipMemcpyHostToDevice, st))
-  PH2D(S.jobs, S.h_jobs_in, nj); PH2D(S.slot_prefix, S.h_slot_prefix, nj + 1); PH2D(S.vp_prefix, S.h_vp_prefix, nj + 1);
+  PH2D(S.ls_order, S.h_ls_order, nj); PH2D(S.jobs, S.h_jobs_in, nj); PH2D(S.slot_prefix, S.h_slot_prefix, nj + 1); PH2D(S.vp_prefix, S.h_vp_prefix, nj + 1);
   if (n_yaw) { PH2D(S.yaw, S.h_yaw, n_yaw); PH2D(S.yaw_c, S.h_yaw_c, n_yaw); PH2D(S.yaw_s, S.h_yaw_s, n_yaw); }
   if (n_top) PH2D(S.top_x, S.h_top_x, n_top);
   if (nb) { PH2D(S.box_job0, S.h_box_job0, nb); PH2D(S.box_njobs, S.h_box_njobs, nb); }
@@ -901,7 +915,7 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   cs::launch_scan_compact(v, stB);
   HIP_TRY(hipEventRecord(S.ev[10], stB));
   HIP_TRY(hipEventRecord(S.ev[0], st));
-  cs::launch_line_setup(S.jobs.p, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st);
+  cs::launch_line_setup(S.jobs.p, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st, S.ls_order.p);
   HIP_TRY(hipEventRecord(S.ev[1], st));
   cs::launch_vp_support_only(v, C.sp, S.vp_total, st);
   HIP_TRY(hipEventRecord(S.ev[2], st));

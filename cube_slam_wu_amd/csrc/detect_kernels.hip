@@ -678,10 +678,10 @@ __device__ __forceinline__ bool ls_pair_pass(const LsRow& A, const LsRow& B, con
 }
 
 __global__ __launch_bounds__(LS_THREADS) void line_setup_kernel(JobDesc* jobs, int n_jobs, const double* __restrict__ frame_lines, const int* __restrict__ frame_line_ptr,
-                                                               double* mid_x, double* mid_y, double* line_angle, LineSetupParams lp) {
+                                                               double* mid_x, double* mid_y, double* line_angle, LineSetupParams lp, const int* __restrict__ order) {
   __shared__ double X1[LS_CAP], Y1[LS_CAP], X2[LS_CAP], Y2[LS_CAP], ANG[LS_CAP];
   __shared__ int F[LS_CAP];
-  int j = blockIdx.x;
+  int j = order ? order[blockIdx.x] : blockIdx.x;   // longest jobs first (the kernel ends with its slowest workgroup)
   if (j >= n_jobs) return;
   const JobDesc jd = jobs[j];
   if (jd.Y == 0 || jd.T == 0) return;   // a box the sweep skips (no yaw / top-edge samples): m stays 0
@@ -805,10 +805,10 @@ __global__ __launch_bounds__(LS_THREADS) void line_setup_kernel(JobDesc* jobs, i
 }
 
 void launch_line_setup(JobDesc* jobs, int n_jobs, const double* frame_lines, const int* frame_line_ptr, double* mid_x, double* mid_y, double* line_angle,
-                       double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st) {
+                       double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st, const int* order) {
   if (n_jobs <= 0) return;
   LineSetupParams lp{dist_thre, angle_thre_deg / 180.0 * CS_PI, len_thre};
-  hipLaunchKernelGGL(line_setup_kernel, dim3(n_jobs), dim3(LS_THREADS), 0, st, jobs, n_jobs, frame_lines, frame_line_ptr, mid_x, mid_y, line_angle, lp);
+  hipLaunchKernelGGL(line_setup_kernel, dim3(n_jobs), dim3(LS_THREADS), 0, st, jobs, n_jobs, frame_lines, frame_line_ptr, mid_x, mid_y, line_angle, lp, order);
 }
 int line_setup_capacity() { return LS_CAP; }
 
