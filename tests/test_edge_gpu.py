@@ -77,3 +77,52 @@ def test_image_in_cuboids_out_matches_oracle_on_the_same_maps():
             n += 1
     assert n >= 3
     det.close()
+
+
+def test_cpp_driver_on_the_bundled_frame(tmp_path):
+    """examples/detect_main.cpp = the reference's main.cpp (same constants, its txt reader) on the C ABI, image in /
+    cuboid out: its printed cuboid equals the Python binding's and the oracle's (oracle Canny/DT maps + oracle sweep)."""
+    import os
+    import subprocess
+
+    from PIL import Image
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "build_tmp", "detect_main")
+    if not os.path.exists(exe):
+        import __graft_entry__
+        __graft_entry__.build()
+    gdir = os.path.join(root, "tests", "golden", "detect_3d_cuboid_data")
+    gray = np.asarray(Image.open(os.path.join(gdir, "0000_gray.png")))
+    assert gray.shape == (530, 730) and gray.dtype == np.uint8
+    pgm = tmp_path / "0000_gray.pgm"
+    with open(pgm, "wb") as f:
+        f.write(b"P5\n730 530\n255\n" + gray.tobytes())
+    out = subprocess.run([exe, str(pgm), os.path.join(gdir, "0000_edge.txt")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    rows = {l.split()[0]: l.split()[1:] for l in out.stdout.strip().splitlines()}
+    assert rows["segments"][0] == "271" and rows["segments"][2] == "1"
+    # the same through the Python binding and through the oracle
+    K = np.array([[529.5, 0, 365.0], [0, 529.5, 265.0], [0, 0, 1.0]])
+    T = np.array([[1, 0.0011, 0.0004, 0], [0, -0.3376, 0.9413, 0], [0.0011, -0.9413, -0.3376, 1.35], [0, 0, 0, 1.0]])
+    box = np.array([[187.0, 188.0, 201, 311, 0.88]])
+    lines = np.loadtxt(os.path.join(gdir, "0000_edge.txt"))
+    rois = [synth.box_rois(box[0], 730, 530, False)]
+    fr = dict(K=K, T_wc=T, boxes=box, lines=lines, rois=rois, maps=None, img_w=730, img_h=530)
+    det = capi.Detector(capi.default_params(whether_sample_cam_roll_pitch=0, whether_sample_bbox_height=0))
+    got = det.detect_gray(fr, gray)[0][0]
+    det.close()
+    (l, t, w, h), _ = rois[0][0]
+    buf = np.zeros(h * w + w + 1, np.float32)
+    buf[: h * w] = E.edge_distance_map(gray, (l, t, w, h)).ravel()
+    fr2 = dict(fr); fr2["maps"] = [[buf]]
+    ref = oracle_py.detect_cuboid(fr2, oracle_py.default_params(whether_sample_cam_roll_pitch=0), atan2_mode=1)[0][0][0]
+    for key, n in (("pos", 3), ("scale", 3), ("rotY", 1), ("normalized_error", 1), ("skew_ratio", 1)):
+        drv = np.array([float(v) for v in rows[key]])
+        assert np.array_equal(drv, np.atleast_1d(np.asarray(got[key], float))), key
+        assert np.array_equal(drv, np.atleast_1d(np.asarray(ref[key], float))), key
+    assert [int(v) for v in rows["corners2d"]] == list(np.asarray(ref["box_corners_2d"]).ravel())
+    assert [int(v) for v in rows["config"]] == [int(v) for v in np.asarray(ref["box_config_type"]).ravel()]
+    # plausibility against the scene: a ~0.3-1 m object 2-4 m in front of a camera 1.35 m above the ground
+    pos, scale = np.array(ref["pos"]), np.array(ref["scale"])
+    assert 1.0 < np.linalg.norm(pos[:2]) < 6.0 and np.all(scale > 0.05) and np.all(scale < 2.0)
