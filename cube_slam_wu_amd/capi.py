@@ -62,7 +62,7 @@ class CsDetectTiming(C.Structure):
 DECLARED_SYMBOLS = [
     "cs_last_error", "cs_device_count", "cs_detect_default_params", "cs_box_rois", "cs_cam_euler_zyx", "cs_detector_create",
     "cs_detector_destroy", "cs_detect_cuboids", "cs_batch_create", "cs_batch_max_boxes", "cs_batch_run",
-    "cs_bgr_to_gray", "cs_edge_distance_maps", "cs_edge_distance_maps_multi", "cs_detect_cuboids_gray", "cs_batch_destroy", "cs_batch_last_timing", "cs_batch_debug_candidates", "cs_batch_debug_kept", "cs_batch_set_debug", "cs_batch_set_pipeline_chunks",
+    "cs_bgr_to_gray", "cs_edge_distance_maps", "cs_edge_distance_maps_multi", "cs_detect_cuboids_gray", "cs_batch_create_gray", "cs_batch_destroy", "cs_batch_last_timing", "cs_batch_debug_candidates", "cs_batch_debug_kept", "cs_batch_set_debug", "cs_batch_set_pipeline_chunks",
 ]
 
 _lib = None
@@ -199,7 +199,7 @@ class Detector:
 class Batch:
     """cs_batch handle over a list of frame dicts (cube_slam_wu_amd.synth.make_frame layout)."""
 
-    def __init__(self, det: Detector, frames, debug=False, force_host_rank=False, force_host_setup=False, force_no_pipeline=False, pipeline_chunks=1):
+    def __init__(self, det: Detector, frames, debug=False, force_host_rank=False, force_host_setup=False, force_no_pipeline=False, pipeline_chunks=1, grays=None):
         self.det = det
         self.n_frames = len(frames)
         self._keep = []
@@ -211,7 +211,7 @@ class Batch:
             lines = np.ascontiguousarray(fr["lines"], np.float64).reshape(-1, 4)
             n = boxes.shape[0]
             arr = (C.POINTER(C.c_float) * max(1, 3 * n))()
-            for i in range(n):
+            for i in range(n if grays is None else 0):
                 for k, m in enumerate(fr["maps"][i]):
                     m = np.ascontiguousarray(m, np.float32)
                     self._keep.append(m)
@@ -221,7 +221,12 @@ class Batch:
             d.K, d.T_wc, d.img_w, d.img_h = _dp(K), _dp(T), int(fr["img_w"]), int(fr["img_h"])
             d.boxes, d.n_boxes, d.lines, d.n_lines, d.dist_maps = _dp(boxes), n, _dp(lines), lines.shape[0], arr
         self.h = C.c_void_p()
-        rc = lib().cs_batch_create(det.h, descs, self.n_frames, C.byref(self.h))
+        if grays is None:
+            rc = lib().cs_batch_create(det.h, descs, self.n_frames, C.byref(self.h))
+        else:   # image input: the maps are produced on the device from the gray images
+            gs = [np.ascontiguousarray(g, np.uint8) for g in grays]
+            gp = (C.POINTER(C.c_ubyte) * max(1, len(gs)))(*[g.ctypes.data_as(C.POINTER(C.c_ubyte)) for g in gs])
+            rc = lib().cs_batch_create_gray(det.h, descs, gp, self.n_frames, C.byref(self.h))
         if rc != 0:
             raise RuntimeError("cs_batch_create failed (%d): %s" % (rc, last_error()))
         self._keep = []  # inputs were copied by the library

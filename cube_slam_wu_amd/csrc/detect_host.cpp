@@ -573,7 +573,7 @@ void cs_detector_destroy(cs_detector* d) {
   delete d;
 }
 
-int cs_batch_create(cs_detector* d, const cs_frame_desc* fr, int n_frames, cs_batch** out) {
+static int batch_create_impl(cs_detector* d, const cs_frame_desc* fr, const unsigned char* const* grays, int n_frames, cs_batch** out) {
   if (!d || !out || (!fr && n_frames) || n_frames < 0) return CS_ERR_INVALID_ARG;
   *out = nullptr;
   HIP_TRY(hipSetDevice(d->device));
@@ -585,7 +585,7 @@ int cs_batch_create(cs_detector* d, const cs_frame_desc* fr, int n_frames, cs_ba
   for (int f = 0; f < n_frames; f++) {
     const cs_frame_desc& s = fr[f];
     FrameIn& F = b->frames[f];
-    if (!s.K || !s.T_wc || s.n_boxes < 0 || s.n_lines < 0 || (s.n_boxes && (!s.boxes || !s.dist_maps)) || (s.n_lines && !s.lines)) {
+    if (!s.K || !s.T_wc || s.n_boxes < 0 || s.n_lines < 0 || (s.n_boxes && (!s.boxes || (!grays && !s.dist_maps))) || (s.n_lines && !s.lines) || (grays && !grays[f])) {
       delete b; set_err("bad frame descriptor"); return CS_ERR_INVALID_ARG;
     }
     if (s.T_wc[12] != 0 || s.T_wc[13] != 0 || s.T_wc[14] != 0 || s.T_wc[15] != 1) {
@@ -613,7 +613,7 @@ int cs_batch_create(cs_detector* d, const cs_frame_desc* fr, int n_frames, cs_ba
       F.n_heights[i] = nh;
       for (int k = 0; k < nh; k++) {
         const cs_roi& r = F.rois[3 * i + k];
-        if (r.width <= 0 || r.height <= 0 || !s.dist_maps[3 * i + k]) { delete b; set_err("missing distance map / empty ROI"); return CS_ERR_INVALID_ARG; }
+        if (r.width <= 0 || r.height <= 0 || (!grays && !s.dist_maps[3 * i + k])) { delete b; set_err("missing distance map / empty ROI"); return CS_ERR_INVALID_ARG; }
         F.map_offs[3 * i + k] = (long long)map_floats;
         map_floats += (size_t)r.width * r.height + r.width + 1;  // + one row + one float of zero padding
       }
@@ -624,16 +624,50 @@ int cs_batch_create(cs_detector* d, const cs_frame_desc* fr, int n_frames, cs_ba
   int rc = b->d_maps.ensure(map_floats + 1);
   if (rc) { delete b; return rc; }
   {
-    std::vector<float> stage(map_floats + 1, 0.0f);
-    for (int f = 0; f < n_frames; f++) {
-      FrameIn& F = b->frames[f];
-      for (int i = 0; i < F.n_boxes; i++)
-        for (int k = 0; k < F.n_heights[i]; k++) {
-          const cs_roi& r = F.rois[3 * i + k];
-          std::memcpy(&stage[F.map_offs[3 * i + k]], fr[f].dist_maps[3 * i + k], sizeof(float) * (size_t)r.width * r.height);
-        }
+    if (!grays) {
+      std::vector<float> stage(map_floats + 1, 0.0f);
+      for (int f = 0; f < n_frames; f++) {
+        FrameIn& F = b->frames[f];
+        for (int i = 0; i < F.n_boxes; i++)
+          for (int k = 0; k < F.n_heights[i]; k++) {
+            const cs_roi& r = F.rois[3 * i + k];
+            std::memcpy(&stage[F.map_offs[3 * i + k]], fr[f].dist_maps[3 * i + k], sizeof(float) * (size_t)r.width * r.height);
+          }
+      }
+      HIP_TRY(hipMemcpy(b->d_maps.p, stage.data(), sizeof(float) * (map_floats + 1), hipMemcpyHostToDevice));
+    } else {
+      // image in: upload the gray images, produce every job's map in place in the pool (Canny + distance transform on the
+      // device, box_proposal_detail.cpp:320-327); the padding between the maps stays zero.  All frames share one size.
+      const int W = n_frames ? fr[0].img_w : 0, H = n_frames ? fr[0].img_h : 0;
+      std::vector<cs::EdgeRoi> er;
+      long long cls_tot = 0;
+      int max_w = 1;
+      for (int f = 0; f < n_frames; f++) {
+        FrameIn& F = b->frames[f];
+        if (F.img_w != W || F.img_h != H) { delete b; set_err("cs_batch_create_gray: all frames must have the same image size"); return CS_ERR_INVALID_ARG; }
+        for (int i = 0; i < F.n_boxes; i++)
+          for (int k = 0; k < F.n_heights[i]; k++) {
+            const cs_roi& r = F.rois[3 * i + k];
+            if (r.left < 0 || r.top < 0 || r.left + r.width > W || r.top + r.height > H) { delete b; set_err("ROI outside the image"); return CS_ERR_INVALID_ARG; }
+            er.push_back(cs::EdgeRoi{r.left, r.top, r.width, r.height, (long long)f * W * H, cls_tot, F.map_offs[3 * i + k]});
+            cls_tot += (long long)r.width * r.height;
+            max_w = std::max(max_w, r.width);
+          }
+      }
+      DevBuf<unsigned char> d_gray, d_cls;
+      DevBuf<cs::EdgeRoi> d_rois;
+      if ((rc = d_gray.ensure((size_t)W * H * std::max(1, n_frames))) || (rc = d_cls.ensure((size_t)cls_tot + 1)) || (rc = d_rois.ensure(er.size() + 1))) { delete b; return rc; }
+      hipStream_t st = d->stream;
+      HIP_TRY(hipMemsetAsync(b->d_maps.p, 0, sizeof(float) * (map_floats + 1), st));
+      for (int f = 0; f < n_frames; f++) HIP_TRY(hipMemcpyAsync(d_gray.p + (size_t)f * W * H, grays[f], (size_t)W * H, hipMemcpyHostToDevice, st));
+      if (!er.empty()) {
+        HIP_TRY(hipMemcpyAsync(d_rois.p, er.data(), sizeof(cs::EdgeRoi) * er.size(), hipMemcpyHostToDevice, st));
+        cs::launch_edge_maps(d_gray.p, W, H, d_rois.p, (int)er.size(), d_cls.p, b->d_maps.p, max_w, 80, 200, st);
+        HIP_TRY(hipGetLastError());
+      }
+      HIP_TRY(hipStreamSynchronize(st));
+      d_gray.release(); d_cls.release(); d_rois.release();
     }
-    HIP_TRY(hipMemcpy(b->d_maps.p, stage.data(), sizeof(float) * (map_floats + 1), hipMemcpyHostToDevice));
     std::vector<double> ik(9 * (size_t)std::max(1, n_frames));
     for (int f = 0; f < n_frames; f++) std::memcpy(&ik[9 * f], b->frames[f].invK, 9 * sizeof(double));
     rc = b->d_invK.ensure(ik.size());
@@ -672,6 +706,13 @@ int cs_batch_create(cs_detector* d, const cs_frame_desc* fr, int n_frames, cs_ba
   }
   *out = b;
   return CS_OK;
+}
+
+int cs_batch_create(cs_detector* d, const cs_frame_desc* fr, int n_frames, cs_batch** out) { return batch_create_impl(d, fr, nullptr, n_frames, out); }
+
+int cs_batch_create_gray(cs_detector* d, const cs_frame_desc* fr, const unsigned char* const* grays, int n_frames, cs_batch** out) {
+  if (n_frames > 0 && !grays) return CS_ERR_INVALID_ARG;
+  return batch_create_impl(d, fr, grays, n_frames, out);
 }
 
 int cs_batch_max_boxes(const cs_batch* b) { return b ? b->max_boxes : CS_ERR_INVALID_ARG; }

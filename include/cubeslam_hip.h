@@ -138,6 +138,9 @@ int cs_edge_distance_maps(cs_detector* d, const unsigned char* gray, int img_w, 
  * the device and are discarded: timing); kernel_ms, if not NULL, receives the device time of the two kernels.      */
 int cs_edge_distance_maps_multi(cs_detector* d, const unsigned char* const* grays, int n_images, int img_w, int img_h, const cs_roi* rois, const int* roi_image,
                                 int n_rois, float* const* out_maps, double* kernel_ms);
+/* cs_batch_create() for image input: grays[f] is frame f's 8-bit gray image (img_h x img_w, all frames one size); the
+ * frames' dist_maps are ignored and every (box, height sample) map is produced in HBM by the kernels above.          */
+int cs_batch_create_gray(cs_detector* d, const cs_frame_desc* frames, const unsigned char* const* grays, int n_frames, cs_batch** out);
 /* cs_detect_cuboids() with the frame's dist_maps computed here from the gray image (frame->dist_maps is ignored). */
 int cs_detect_cuboids_gray(cs_detector* d, const cs_frame_desc* frame, const unsigned char* gray, cs_cuboid* out, int* out_counts);
 

@@ -126,3 +126,33 @@ def test_cpp_driver_on_the_bundled_frame(tmp_path):
     # plausibility against the scene: a ~0.3-1 m object 2-4 m in front of a camera 1.35 m above the ground
     pos, scale = np.array(ref["pos"]), np.array(ref["scale"])
     assert 1.0 < np.linalg.norm(pos[:2]) < 6.0 and np.all(scale > 0.05) and np.all(scale < 2.0)
+
+
+def test_batch_from_gray_images_equals_batch_from_host_maps():
+    """cs_batch_create_gray (maps produced in HBM by the Canny / distance-transform kernels) against cs_batch_create fed
+    with the oracle's maps of the same images: byte-identical records, ragged frames included."""
+    grays = [_scene(10 + s) for s in range(3)]
+    frames = []
+    for s in range(7):
+        fr = synth.make_frame(9200 + s, n_boxes=1 + s % 4, n_lines=200)
+        g = grays[s % 3]
+        maps = []
+        for rr in fr["rois"]:
+            mm = []
+            for (l, t, w, h), _ in rr:
+                buf = np.zeros(h * w + w + 1, np.float32)
+                buf[: h * w] = E.edge_distance_map(g, (l, t, w, h)).ravel()
+                mm.append(buf)
+            maps.append(mm)
+        fr = dict(fr); fr["maps"] = maps
+        frames.append(fr)
+    empty = dict(frames[0]); empty["boxes"] = np.zeros((0, 5)); empty["maps"] = []; empty["rois"] = []
+    frames.insert(3, empty)
+    gl = [grays[s % 3] for s in range(7)]
+    gl.insert(3, grays[0])
+    det = capi.Detector(capi.default_params(whether_sample_cam_roll_pitch=0, yaw_step_deg=3.0, max_cuboid_num=2))
+    a = capi.Batch(det, frames); a.run()
+    b = capi.Batch(det, frames, grays=gl); b.run()
+    assert a.raw_out_bytes() == b.raw_out_bytes() and a.counts_bytes() == b.counts_bytes()
+    assert sum(len(c) for f in range(len(frames)) for c in a.cuboids(f)) >= 10
+    a.close(); b.close(); det.close()
