@@ -36,54 +36,96 @@ __device__ __forceinline__ int edge_mag(const unsigned char* __restrict__ g, int
   return abs(gx) + abs(gy);
 }
 
-// class per pixel: 0 = may belong to an edge, 1 = not an edge, 2 = edge; then hysteresis; then 0 / 255
+// class per pixel: 0 = may belong to an edge, 1 = not an edge, 2 = edge.  Pass 1: one Sobel per pixel, L1 magnitude and
+// the suppression sector packed into the (not yet used) output buffer; pass 2: non-maximum suppression + thresholds
+// from the packed values; then hysteresis.  Waves walk rows, lanes walk columns (no divisions).
 __global__ __launch_bounds__(256) void edge_canny_kernel(const unsigned char* __restrict__ gray, int W, int H, const EdgeRoi* __restrict__ rois, unsigned char* cls_pool,
-                                                         int low, int high) {
-  enum { cand_cap = 8192 };           // weak pixels listed in LDS; a ROI with more of them sweeps all its pixels instead
-  __shared__ int cand[cand_cap];
-  __shared__ int n_cand;
+                                                         float* map_pool, int low, int high) {
+  __shared__ int n_front[2];
   __shared__ int changed;
   const EdgeRoi R = rois[blockIdx.x];
   gray += R.img_off;
   unsigned char* cls = cls_pool + R.cls_off;
+  unsigned* pk = reinterpret_cast<unsigned*>(map_pool + R.map_off);   // magnitude (bits 0-15) | sector (16-17): 0 horizontal, 1 vertical, 2 diagonal same sign, 3 diagonal opposite sign
   const int n = R.w * R.h;
-  if (threadIdx.x == 0) n_cand = 0;
-  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int TG22 = 13573;
-  for (int p = threadIdx.x; p < n; p += 256) {
-    const int i = p / R.w, j = p - i * R.w;
-    int xs, ys;
-    edge_sobel(gray, W, H, R.l + j, R.t + i, xs, ys);
-    const int m = abs(xs) + abs(ys);
-    unsigned char c = 1;
-    if (m > low) {
+  for (int i = wv; i < R.h; i += 4)
+    for (int j = lane; j < R.w; j += 64) {
+      int xs, ys;
+      edge_sobel(gray, W, H, R.l + j, R.t + i, xs, ys);
       const int x = abs(xs), y = abs(ys) << 15;
       const int tg22x = x * TG22;
-      bool keep;
-      if (y < tg22x) keep = m > edge_mag(gray, W, H, R, i, j - 1) && m >= edge_mag(gray, W, H, R, i, j + 1);
-      else {
-        const int tg67x = tg22x + (x << 16);
-        if (y > tg67x) keep = m > edge_mag(gray, W, H, R, i - 1, j) && m >= edge_mag(gray, W, H, R, i + 1, j);
-        else { const int s = (xs ^ ys) < 0 ? -1 : 1; keep = m > edge_mag(gray, W, H, R, i - 1, j - s) && m > edge_mag(gray, W, H, R, i + 1, j + s); }
-      }
-      if (keep) {
-        c = (m > high) ? 2 : 0;
-        if (c == 0) { int k = atomicAdd(&n_cand, 1); if (k < cand_cap) cand[k] = p; }
-      }
+      unsigned sector;
+      if (y < tg22x) sector = 0;
+      else if (y > tg22x + (x << 16)) sector = 1;
+      else sector = ((xs ^ ys) < 0) ? 3u : 2u;
+      pk[i * R.w + j] = (unsigned)(abs(xs) + abs(ys)) | (sector << 16);
     }
-    cls[p] = c;
-  }
   __syncthreads();
-  // hysteresis: a weak pixel next to an edge pixel becomes an edge pixel, until nothing changes (the fixed point is the
-  // set of 8-connected components that contain a strong pixel -- independent of the visiting order)
-  const int nc = min(n_cand, cand_cap);
-  const bool overflow = n_cand > cand_cap;     // more weak pixels than the list holds: sweep every pixel instead
+  auto mag = [&](int i, int j) -> int { return (i < 0 || i >= R.h || j < 0 || j >= R.w) ? 0 : (int)(pk[i * R.w + j] & 0xffffu); };   // zero-padded like cv::Canny's buffer
+  for (int i = wv; i < R.h; i += 4)
+    for (int j = lane; j < R.w; j += 64) {
+      const unsigned v = pk[i * R.w + j];
+      const int m = (int)(v & 0xffffu);
+      unsigned char c = 1;
+      if (m > low) {
+        const unsigned sector = v >> 16;
+        bool keep;
+        if (sector == 0) keep = m > mag(i, j - 1) && m >= mag(i, j + 1);
+        else if (sector == 1) keep = m > mag(i - 1, j) && m >= mag(i + 1, j);
+        else { const int s = (sector == 3) ? -1 : 1; keep = m > mag(i - 1, j - s) && m > mag(i + 1, j + s); }
+        if (keep) c = (m > high) ? 2 : 0;
+      }
+      cls[i * R.w + j] = c;
+    }
+  __syncthreads();
+  // hysteresis = 8-connected components of the surviving pixels that contain a strong one, by breadth-first growth from
+  // the strong pixels: a frontier pixel claims its weak neighbours (atomic OR on the class word: exactly one claimant)
+  // and they form the next frontier.  The two frontier lists live in the packed scratch, which is free now.
+  int* lists[2] = {reinterpret_cast<int*>(pk), reinterpret_cast<int*>(pk) + n / 2};
+  const int cap = n / 2;
+  bool overflow = false;
+  if (threadIdx.x < 2) n_front[threadIdx.x] = 0;
+  __syncthreads();
+  for (int p = threadIdx.x; p < n; p += 256)
+    if (cls[p] == 2) { int k = atomicAdd(&n_front[0], 1); if (k < cap) lists[0][k] = p; }
+  __syncthreads();
+  int curl = 0;
   for (int it = 0; it < n; it++) {
+    const int ncur = n_front[curl];
+    if (ncur > cap) overflow = true;
+    if (ncur == 0) break;
+    __syncthreads();
+    if (threadIdx.x == 0) n_front[curl ^ 1] = 0;
+    __syncthreads();
+    const int* cur = lists[curl];
+    int* nxt = lists[curl ^ 1];
+    for (int q = threadIdx.x; q < min(ncur, cap); q += 256) {
+      const int p = cur[q];
+      const int i = p / R.w, j = p - i * R.w;
+      for (int di = -1; di <= 1; di++)
+        for (int dj = -1; dj <= 1; dj++) {
+          const int a = i + di, b = j + dj;
+          if (!(di | dj) || a < 0 || a >= R.h || b < 0 || b >= R.w) continue;
+          unsigned char* cp = cls + a * R.w + b;
+          if (*cp != 0) continue;
+          const unsigned long long ad = reinterpret_cast<unsigned long long>(cp);
+          const unsigned sh = (unsigned)(ad & 3) * 8;
+          const unsigned old = atomicOr(reinterpret_cast<unsigned*>(ad & ~3ull), 2u << sh);
+          if (((old >> sh) & 0xffu) == 0) { int k = atomicAdd(&n_front[curl ^ 1], 1); if (k < cap) nxt[k] = a * R.w + b; }
+        }
+    }
+    __syncthreads();
+    curl ^= 1;
+  }
+  if (!overflow) return;
+  // a frontier outgrew its list (more than half of the ROI at once): finish by relaxation sweeps over all pixels
+  for (int it = 0; it < n; it++) {
+    __syncthreads();
     if (threadIdx.x == 0) changed = 0;
     __syncthreads();
-    const int cnt = overflow ? n : nc;
-    for (int q = threadIdx.x; q < cnt; q += 256) {
-      const int p = overflow ? q : cand[q];
+    for (int p = threadIdx.x; p < n; p += 256) {
       if (cls[p] != 0) continue;
       const int i = p / R.w, j = p - i * R.w;
       bool hit = false;
@@ -96,114 +138,84 @@ __global__ __launch_bounds__(256) void edge_canny_kernel(const unsigned char* __
     }
     __syncthreads();
     if (!changed) break;
-    __syncthreads();
   }
 }
 
-// inclusive prefix minimum over the 256 threads of a workgroup (one value each); ws: 4 int64 of LDS
-__device__ __forceinline__ long long block_prefix_min(long long v, long long* ws) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+// inclusive prefix minimum over the 64 lanes of a wave
+__device__ __forceinline__ int wave_prefix_min(int v) {
+  const int lane = threadIdx.x & 63;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { long long u = __shfl_up(v, o); if (lane >= o) v = u < v ? u : v; }
-  if (lane == 63) ws[wv] = v;
-  __syncthreads();
-  long long pre = 0x7fffffffffffffffLL;
-  for (int q = 0; q < wv; q++) pre = ws[q] < pre ? ws[q] : pre;
-  __syncthreads();
-  return pre < v ? pre : v;
+  for (int o = 1; o < 64; o <<= 1) { int u = __shfl_up(v, o); if (lane >= o) v = min(u, v); }
+  return v;
 }
 
-// two-pass 3x3 chamfer distance (distanceTransform(255 - canny, DIST_L2, 3)); the 16.16 fixed-point working values live
-// in the output buffer itself and are turned into floats by the backward pass
-__global__ __launch_bounds__(256) void edge_dt_kernel(const EdgeRoi* __restrict__ rois, const unsigned char* __restrict__ cls_pool, float* map_pool, int row_cap) {
-  extern __shared__ unsigned row_lds[];     // neighbouring row: row_cap + 2 values (border cells at both ends)
-  __shared__ long long ws[4];
+// two-pass 3x3 chamfer distance (distanceTransform(255 - canny, DIST_L2, 3)), ONE WAVE per ROI: the rows are a
+// dependent chain, the batch supplies the parallelism (thousands of ROIs), and a wave needs no barriers.  The
+// recurrence along a row, d[j] = min(t[j], d[j-1] + a), is a prefix minimum of t[k] - k a.
+// Working values: OpenCV's are 16.16 fixed point in unsigned 32 bits, saturated at DIST_MAX = UINT_MAX - b ("no feature
+// reachable").  Every finite distance inside an image is below 2^30, so the kernel carries 2^30 for "unreachable" in
+// signed 32 bits (nothing overflows, sums stay ordered) and writes DIST_MAX's float for it; finite values are identical.
+__global__ __launch_bounds__(64) void edge_dt_kernel(const EdgeRoi* __restrict__ rois, const unsigned char* __restrict__ cls_pool, float* map_pool, int row_cap) {
+  extern __shared__ int row_lds_i[];        // two rows of row_cap + 2 values (border cells at both ends): neighbour row, current row
   const EdgeRoi R = rois[blockIdx.x];
   const unsigned char* cls = cls_pool + R.cls_off;
-  unsigned* tmp = reinterpret_cast<unsigned*>(map_pool + R.map_off);
-  const unsigned HV = 62587u, DIAG = 89738u, DMAX = 0xffffffffu - DIAG;
+  int* tmp = reinterpret_cast<int*>(map_pool + R.map_off);
+  const int HV = 62587, DIAG = 89738, INF = 1 << 30;
   const float scale = 1.f / (1 << 16);
-  const int w = R.w, h = R.h;
-  unsigned* nb = row_lds + 1;               // nb[-1 .. w]
+  const float far = (float)(0xffffffffu - 89738u) * scale;     // what OpenCV writes where no feature is reachable
+  const int w = R.w, h = R.h, lane = threadIdx.x;
+  int* nb = row_lds_i + 1;                  // nb[-1 .. w]: the neighbour row
+  int* cur = row_lds_i + (row_cap + 2) + 1; // the row being produced (becomes the neighbour row of the next one)
   // ---- forward: top-left to bottom-right
-  for (int j = threadIdx.x; j < w + 2; j += 256) row_lds[j] = DMAX;
-  __syncthreads();
+  for (int j = lane; j < 2 * (row_cap + 2); j += 64) row_lds_i[j] = INF;
   for (int i = 0; i < h; i++) {
-    long long carry = (long long)DMAX;      // d[j0 - 1] of the running chunk, as "value at column j0 - 1"
-    for (int j0 = 0; j0 < w; j0 += 256) {
-      const int j = j0 + threadIdx.x;
-      long long a = 0x7fffffffffffffffLL;
-      unsigned t = DMAX;
+    int carry = INF;                        // d at the column left of the running chunk
+    for (int j0 = 0; j0 < w; j0 += 64) {
+      const int j = j0 + lane;
+      int a = 0x7fffffff;
       if (j < w) {
-        if (cls[i * w + j] == 2) t = 0;
-        else {
-          unsigned t0 = nb[j - 1] + DIAG, u = nb[j] + HV;
-          if (t0 > u) t0 = u;
-          u = nb[j + 1] + DIAG; if (t0 > u) t0 = u;
-          t = t0;
-        }
-        a = (long long)t - (long long)j * HV;
+        int t = 0;
+        if (cls[i * w + j] != 2) t = min(min(nb[j - 1] + DIAG, nb[j] + HV), nb[j + 1] + DIAG);
+        a = t - j * HV;
       }
-      // d[j] = min over k <= j of t[k] + (j - k) HV, and of the value carried in from the left
-      long long pm = block_prefix_min(a, ws);
-      long long d = pm + (long long)j * HV;
-      const long long from_left = carry + (long long)(j - j0 + 1) * HV;
-      if (from_left < d) d = from_left;
-      if (d > (long long)DMAX) d = DMAX;
-      __shared__ long long last;
-      if (j < w && (threadIdx.x == 255 || j == w - 1)) last = d;
-      __syncthreads();
-      if (j < w) tmp[i * w + j] = (unsigned)d;
-      carry = last;
-      __syncthreads();
+      int d = wave_prefix_min(a);
+      d = (d == 0x7fffffff) ? INF : d + j * HV;
+      d = min(min(d, carry + (lane + 1) * HV), INF);
+      if (j < w) { tmp[i * w + j] = d; cur[j] = d; }
+      carry = __shfl(d, min(63, w - 1 - j0));
     }
-    for (int j = threadIdx.x; j < w; j += 256) nb[j] = tmp[i * w + j];
-    __syncthreads();
+    int* sw = nb; nb = cur; cur = sw;       // the row just produced becomes the neighbour row (border cells stay INF)
   }
+  __syncthreads();   // (one wave) the forward values written by other lanes are read back below
   // ---- backward: bottom-right to top-left (mirrored scan), writing the floats
-  for (int j = threadIdx.x; j < w + 2; j += 256) row_lds[j] = DMAX;
-  __syncthreads();
+  for (int j = lane; j < 2 * (row_cap + 2); j += 64) row_lds_i[j] = INF;
   for (int i = h - 1; i >= 0; i--) {
-    long long carry = (long long)DMAX;      // d[j + 1] to the right of the running chunk
-    const int nchunk = (w + 255) / 256;
+    int carry = INF;                        // d at the column right of the running chunk
+    const int nchunk = (w + 63) / 64;
     for (int cch = nchunk - 1; cch >= 0; cch--) {
-      const int j0 = cch * 256;
-      const int jr = j0 + 255 - (int)threadIdx.x;   // thread 0 takes the chunk's rightmost column: scan order = right to left
-      long long a = 0x7fffffffffffffffLL;
+      const int j0 = cch * 64;
+      const int jr = j0 + 63 - lane;        // lane 0 takes the chunk's rightmost column: scan order = right to left
+      int a = 0x7fffffff;
       if (jr < w) {
-        unsigned t0 = tmp[i * w + jr];
-        unsigned u = nb[jr + 1] + DIAG; if (t0 > u) t0 = u;
-        u = nb[jr] + HV; if (t0 > u) t0 = u;
-        u = nb[jr - 1] + DIAG; if (t0 > u) t0 = u;
-        a = (long long)t0 + (long long)jr * HV;     // d[j] = min over k >= j of u[k] + (k - j) HV
+        const int t0 = min(min(tmp[i * w + jr], nb[jr + 1] + DIAG), min(nb[jr] + HV, nb[jr - 1] + DIAG));
+        a = t0 + jr * HV;                   // d[j] = min over k >= j of u[k] + (k - j) HV
       }
-      long long pm = block_prefix_min(a, ws);
-      long long d = pm - (long long)jr * HV;
-      const int chunk_right = min(w - 1, j0 + 255);
-      const long long from_right = carry + (long long)(chunk_right - jr + 1) * HV;
-      if (from_right < d) d = from_right;
-      if (d > (long long)DMAX) d = DMAX;
-      __shared__ long long lastb;
-      if (jr == j0) lastb = d;
-      __syncthreads();
-      if (jr < w) tmp[i * w + jr] = (unsigned)d;
-      carry = lastb;
-      __syncthreads();
+      int d = wave_prefix_min(a);
+      d = (d == 0x7fffffff) ? INF : d - jr * HV;
+      const int chunk_right = min(w - 1, j0 + 63);
+      d = min(min(d, carry + (chunk_right - jr + 1) * HV), INF);
+      if (jr < w) { cur[jr] = d; reinterpret_cast<float*>(tmp)[i * w + jr] = (d >= INF) ? far : (float)(unsigned)d * scale; }
+      carry = __shfl(d, 63);                 // the chunk's leftmost column
     }
-    for (int j = threadIdx.x; j < w; j += 256) {
-      const unsigned v = tmp[i * w + j];
-      nb[j] = v;
-      reinterpret_cast<float*>(tmp)[i * w + j] = (float)v * scale;
-    }
-    __syncthreads();
+    int* sw = nb; nb = cur; cur = sw;
   }
 }
 
 void launch_edge_maps(const unsigned char* gray, int W, int H, const EdgeRoi* rois, int n_rois, unsigned char* cls_pool, float* map_pool, int max_w, int low, int high,
                       hipStream_t st) {
   if (n_rois <= 0) return;
-  hipLaunchKernelGGL(edge_canny_kernel, dim3(n_rois), dim3(256), 0, st, gray, W, H, rois, cls_pool, low, high);
-  hipLaunchKernelGGL(edge_dt_kernel, dim3(n_rois), dim3(256), (size_t)(max_w + 2) * sizeof(unsigned), st, rois, cls_pool, map_pool, max_w);
+  hipLaunchKernelGGL(edge_canny_kernel, dim3(n_rois), dim3(256), 0, st, gray, W, H, rois, cls_pool, map_pool, low, high);
+  hipLaunchKernelGGL(edge_dt_kernel, dim3(n_rois), dim3(64), 2 * (size_t)(max_w + 2) * sizeof(unsigned), st, rois, cls_pool, map_pool, max_w);
 }
 
 }  // namespace cs
