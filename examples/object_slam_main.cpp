@@ -1,0 +1,208 @@
+// object_slam_main -- the reference's graph driver (object_slam/src/main_obj.cpp:479-841, offline mode :682-722, result
+// files :305-336) on top of the C ABI.
+//
+// Inputs are the reference's own text tables (read with the semantics of read_all_number_txt, matrix_utils.cpp:209-244):
+//   truth_cam_poses.txt        time x y z qx qy qz qw        only row 0 is used: the fixed first camera (:523)
+//   pop_cam_poses_saved.txt    time x y z qx qy qz qw        camera pose the saved detections are expressed against (:706-708)
+//   detect_cuboids_saved.txt   frame x y z yaw sx sy sz err  at most one cuboid per frame, on the frame's ground plane (:692-705)
+// One object, perfect association, as in the reference.  Every frame adds a camera vertex (constant-motion initial guess
+// from the two previous optimised cameras, :545-564), its EdgeSE3Cuboid (information (2 q)^2 I9 with
+// q = (1 - err + 0.5) / 2, :727-780) and an EdgeSE3Expmap to the previous camera (identity information, :786-800), then
+// runs optimize(5) over the whole graph so far (:805-806) -- here cs_ba_optimize, i.e. the Levenberg loop with the
+// linearisation, Schur reduction and solve on the device.  Outputs follow :305-336: output_cam_poses.txt (final camera
+// poses, camera-to-world) and output_obj_poses.txt (the cuboid after every frame as toMinimalVector).
+//
+//   g++ -O2 -I include -I cube_slam_wu_amd/csrc examples/object_slam_main.cpp -L cube_slam_wu_amd -lcubeslam_hip ... -o build_tmp/object_slam_main
+//   build_tmp/object_slam_main <data_dir> <out_dir> [digits]
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "cs_se3.h"
+#include "cubeslam_hip.h"
+
+using cs::Cube;
+using cs::Pose;
+
+static bool read_all_number_txt(const std::string& name, int cols, std::vector<double>& out, int& rows) {
+  std::ifstream f(name.c_str());
+  if (!f) { std::cout << "ERROR!!! Cannot read txt file " << name << std::endl; return false; }
+  rows = 0;
+  out.clear();
+  std::string line;
+  while (std::getline(f, line)) {
+    if (line.empty()) continue;
+    std::stringstream ss(line);
+    std::vector<double> row(cols, 0.0);
+    double t;
+    int c = 0;
+    while (ss >> t) { if (c < cols) row[c] = t; c++; }
+    out.insert(out.end(), row.begin(), row.end());
+    rows++;
+  }
+  return true;
+}
+
+// SE3Quat(Vector7d) (se3quat.h:84-100): x y z qx qy qz qw, rotation normalised with w >= 0
+static Pose pose_from_vector7(const double* v) {
+  Pose p = cs::pose_load(v);
+  cs::pose_normalize(p);
+  return p;
+}
+
+// g2o::cuboid::fromMinimalVector (g2o_Object.h:37-42) with zyx_euler_to_quat (matrix_utils.cpp:19-33)
+static Cube cuboid_from_minimal(const double* v) {
+  const double roll = v[3], pitch = v[4], yaw = v[5];
+  const double sy = std::sin(yaw * 0.5), cy = std::cos(yaw * 0.5), sp = std::sin(pitch * 0.5), cp = std::cos(pitch * 0.5);
+  const double sr = std::sin(roll * 0.5), cr = std::cos(roll * 0.5);
+  Cube c;
+  c.pose.qw = cr * cp * cy + sr * sp * sy;
+  c.pose.qx = sr * cp * cy - cr * sp * sy;
+  c.pose.qy = cr * sp * cy + sr * cp * sy;
+  c.pose.qz = cr * cp * sy - sr * sp * cy;
+  for (int d = 0; d < 3; d++) { c.pose.t[d] = v[d]; c.scale[d] = v[6 + d]; }
+  cs::pose_normalize(c.pose);
+  return c;
+}
+
+// toMinimalVector (g2o_Object.h:137-143; SE3Quat::toXYZPRYVector se3quat.h:196-222)
+static void cuboid_to_minimal(const Cube& c, double* o) {
+  const double qx = c.pose.qx, qy = c.pose.qy, qz = c.pose.qz, qw = c.pose.qw;
+  for (int d = 0; d < 3; d++) { o[d] = c.pose.t[d]; o[6 + d] = c.scale[d]; }
+  o[3] = std::atan2(2 * (qw * qx + qy * qz), 1 - 2 * (qx * qx + qy * qy));
+  o[4] = std::asin(2 * (qw * qy - qz * qx));
+  o[5] = std::atan2(2 * (qw * qz + qx * qy), 1 - 2 * (qy * qy + qz * qz));
+}
+
+// transform_to / transform_from (g2o_Object.h:117-133): the pose moves, the half sizes stay
+static Cube cuboid_transform_to(const Cube& c, const Pose& Twc) { Cube r = c; r.pose = cs::pose_mul(cs::pose_inv(Twc), c.pose); return r; }
+static Cube cuboid_transform_from(const Cube& c, const Pose& Twc) { Cube r = c; r.pose = cs::pose_mul(Twc, c.pose); return r; }
+
+#define CHECK(call) do { int st_ = (call); if (st_ != 0) { std::fprintf(stderr, "%s failed: %d\n", #call, st_); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+  if (argc < 3) { std::fprintf(stderr, "usage: %s <data_dir> <out_dir> [digits]\n", argv[0]); return 2; }
+  const std::string base_folder = std::string(argv[1]) + "/", out_folder = std::string(argv[2]) + "/";
+  const int digits = argc > 3 ? std::atoi(argv[3]) : 6;      // Eigen's stream precision is 6 significant digits
+
+  std::vector<double> pred_frame_objects, init_frame_poses, truth_frame_poses;
+  int n_obs = 0, n_init = 0, total_frame_number = 0;
+  if (!read_all_number_txt(base_folder + "detect_cuboids_saved.txt", 9, pred_frame_objects, n_obs)) return 1;
+  if (!read_all_number_txt(base_folder + "pop_cam_poses_saved.txt", 8, init_frame_poses, n_init)) return 1;
+  if (!read_all_number_txt(base_folder + "truth_cam_poses.txt", 8, truth_frame_poses, total_frame_number)) return 1;
+  std::cout << "read data size:  " << n_obs << "  " << n_init << "  " << total_frame_number << std::endl;
+  if (total_frame_number < 1 || n_init < total_frame_number) { std::fprintf(stderr, "pose tables too short\n"); return 1; }
+
+  const Pose fixed_init_cam_pose_Twc = pose_from_vector7(&truth_frame_poses[1]);
+
+  std::vector<double> cam_Tcw;                       // 7 per frame: optimised world-to-camera (the vertex estimates)
+  std::vector<int> cam_fixed;
+  std::vector<int> ce_cam, ce_cub;                   // EdgeSE3Cuboid list
+  std::vector<double> ce_meas, ce_info;
+  std::vector<int> oe_i, oe_j;                       // EdgeSE3Expmap list
+  std::vector<double> oe_meas, oe_info;
+  double cube10[10] = {0, 0, 0, 0, 0, 0, 1, 0, 0, 0};
+  std::vector<double> cube_history;                  // 9 per frame
+  int offline_cube_obs_row_id = 0, total_iterations = 0;
+
+  for (int frame_index = 0; frame_index < total_frame_number; frame_index++) {
+    Pose curr_cam_pose_Twc, odom_val = {{0, 0, 0}, 0, 0, 0, 1};
+    if (frame_index == 0) {
+      curr_cam_pose_Twc = fixed_init_cam_pose_Twc;
+    } else {
+      const Pose prev_pose_Tcw = cs::pose_load(&cam_Tcw[7 * (frame_index - 1)]);
+      if (frame_index > 1)                           // constant-motion model from the third frame on
+        odom_val = cs::pose_mul(prev_pose_Tcw, cs::pose_inv(cs::pose_load(&cam_Tcw[7 * (frame_index - 2)])));
+      curr_cam_pose_Twc = cs::pose_inv(cs::pose_mul(odom_val, prev_pose_Tcw));
+    }
+
+    bool has_detected_cuboid = false;
+    Cube cube_local_meas = {{{0, 0, 0}, 0, 0, 0, 1}, {0, 0, 0}};
+    double proposal_error = 0;
+    if (offline_cube_obs_row_id < n_obs) {
+      const double* m = &pred_frame_objects[9 * offline_cube_obs_row_id];
+      has_detected_cuboid = (int)m[0] == frame_index;
+      if (has_detected_cuboid) {
+        const double cube_pose[9] = {m[1], m[2], m[3], 0, 0, m[4], m[5], m[6], m[7]};   // xyz roll pitch yaw scale
+        const Pose cam_val_Twc = pose_from_vector7(&init_frame_poses[8 * frame_index + 1]);
+        cube_local_meas = cuboid_transform_to(cuboid_from_minimal(cube_pose), cam_val_Twc);
+        proposal_error = m[8];
+        offline_cube_obs_row_id++;
+      }
+    }
+    if (frame_index == 0) cs::cube_store(cuboid_transform_from(cube_local_meas, curr_cam_pose_Twc), cube10);
+
+    double tcw[7];
+    cs::pose_store(cs::pose_inv(curr_cam_pose_Twc), tcw);
+    cam_Tcw.insert(cam_Tcw.end(), tcw, tcw + 7);
+    cam_fixed.push_back(frame_index == 0);
+
+    if (has_detected_cuboid) {
+      const double meas_quality = (1 - proposal_error + 0.5) / 2;
+      const double inv_sigma = 1.0 * 2.0 * meas_quality;
+      double meas[10], info[81] = {0};
+      cs::cube_store(cube_local_meas, meas);
+      for (int d = 0; d < 9; d++) info[d * 9 + d] = inv_sigma * inv_sigma;
+      ce_cam.push_back(frame_index); ce_cub.push_back(0);
+      ce_meas.insert(ce_meas.end(), meas, meas + 10);
+      ce_info.insert(ce_info.end(), info, info + 81);
+    }
+    if (frame_index > 0) {
+      double meas[7], info[36] = {0};
+      cs::pose_store(odom_val, meas);
+      for (int d = 0; d < 6; d++) info[d * 6 + d] = 1.0;
+      oe_i.push_back(frame_index - 1); oe_j.push_back(frame_index);
+      oe_meas.insert(oe_meas.end(), meas, meas + 7);
+      oe_info.insert(oe_info.end(), info, info + 36);
+    }
+
+    // graph.initializeOptimization(); graph.optimize(5);  -- cuboid id 0 sorts before the cameras (ids frame + 1)
+    cs_ba* ba = nullptr;
+    const int cub_fixed = 0;
+    CHECK(cs_ba_create(0, &ba));
+    CHECK(cs_ba_set_vertices(ba, cam_Tcw.data(), cam_fixed.data(), frame_index + 1, cube10, &cub_fixed, 1, nullptr, nullptr, 0, 1));
+    if (!ce_cam.empty()) CHECK(cs_ba_set_edges_cuboid(ba, (int)ce_cam.size(), ce_cam.data(), ce_cub.data(), ce_meas.data(), ce_info.data()));
+    if (!oe_i.empty()) CHECK(cs_ba_set_edges_odom(ba, (int)oe_i.size(), oe_i.data(), oe_j.data(), oe_meas.data(), oe_info.data()));
+    int iterations_done = 0;
+    CHECK(cs_ba_optimize(ba, 5, &iterations_done, nullptr, nullptr, nullptr, 0));
+    CHECK(cs_ba_get_state(ba, cam_Tcw.data(), cube10, nullptr));
+    cs_ba_destroy(ba);
+    total_iterations += iterations_done;
+
+    double minimal[9];
+    cuboid_to_minimal(cs::cube_load(cube10), minimal);
+    cube_history.insert(cube_history.end(), minimal, minimal + 9);
+  }
+  std::cout << "+++++++++++++Finish all optimization!+++++++++++++  LM iterations: " << total_iterations << std::endl;
+
+  {
+    const std::string path = out_folder + "output_cam_poses.txt";
+    FILE* f = std::fopen(path.c_str(), "w");
+    if (!f) { std::fprintf(stderr, "cannot write %s\n", path.c_str()); return 1; }
+    std::fprintf(f, "# timestamp tx ty tz qx qy qz qw\n");
+    for (int i = 0; i < total_frame_number; i++) {
+      double twc[7];
+      cs::pose_store(cs::pose_inv(cs::pose_load(&cam_Tcw[7 * i])), twc);
+      std::fprintf(f, "%.9f  ", truth_frame_poses[8 * i]);
+      for (int d = 0; d < 7; d++) std::fprintf(f, "%s%.*g", d ? " " : "", digits, twc[d]);
+      std::fprintf(f, "\n");
+    }
+    std::fclose(f);
+  }
+  {
+    const std::string path = out_folder + "output_obj_poses.txt";
+    FILE* f = std::fopen(path.c_str(), "w");
+    if (!f) { std::fprintf(stderr, "cannot write %s\n", path.c_str()); return 1; }
+    for (int j = 0; j < total_frame_number; j++) {
+      for (int d = 0; d < 9; d++) std::fprintf(f, "%s%.*g", d ? " " : "", digits, cube_history[9 * j + d]);
+      std::fprintf(f, " \n");
+    }
+    std::fclose(f);
+  }
+  return 0;
+}
