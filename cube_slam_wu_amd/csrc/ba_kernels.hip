@@ -632,7 +632,7 @@ __device__ __forceinline__ double band_rsqrt(double x) {
 // instruction.  Column c travels unscaled through an LDS line (uniform-address reads) together with each lane's
 // v[c + 1], so every lane can form the NEXT pivot itself and its 1/sqrt leaves the critical path: per column the chain
 // is one LDS round trip and two multiply-adds.  colbuf: 2 x 128 doubles (double-buffered {v[c], v[c + 1]} pairs).
-__device__ __attribute__((noinline)) bool band_potf2_inv(const double (*U)[BS + 1], int nb, double (*Dl)[BS + 1], double (*X)[BS + 1], double* colbuf) {
+__device__ __forceinline__ bool band_potf2_inv_impl(const double (*U)[BS + 1], int nb, double (*Dl)[BS + 1], double (*X)[BS + 1], double* colbuf) {
   const int lane = threadIdx.x & 63;
   const int row = lane & 31;
   const bool lower = lane < BS;
@@ -670,6 +670,10 @@ __device__ __attribute__((noinline)) bool band_potf2_inv(const double (*U)[BS + 
   for (int c = 0; c < BS; c++) dst[c * stride] = ((lower ? row - c : c - row) >= 0) ? v[c] : 0.0;
   return bad != 0;
 }
+// Out-of-line, one instance per kernel: a device function with a single calling kernel keeps no callee-saved registers
+// (the compiler specialises its convention); shared between two kernels it would save and restore ~45 of them per call.
+__device__ __attribute__((noinline)) bool band_potf2_inv_k0(const double (*U)[BS + 1], int nb, double (*Dl)[BS + 1], double (*X)[BS + 1], double* colbuf) { return band_potf2_inv_impl(U, nb, Dl, X, colbuf); }
+__device__ __attribute__((noinline)) bool band_potf2_inv_k1(const double (*U)[BS + 1], int nb, double (*Dl)[BS + 1], double (*X)[BS + 1], double* colbuf) { return band_potf2_inv_impl(U, nb, Dl, X, colbuf); }
 
 typedef const __attribute__((address_space(1))) double* band_gptr;   // global address space: a noinline function would otherwise emit flat loads
 __device__ __forceinline__ double band_gload(const double* p) { return *(band_gptr)(p); }
@@ -688,13 +692,30 @@ struct BandView {
 struct BandSeg {            // one run of history columns [jlo, jhi) of a view; flip: the step's rows are re-indexed i -> n - 1 - i
   BandView v; int jlo, jhi, flip;
 };
+struct BandSegX : BandSeg { // ... of a front that carries separator rows (BandAug): their history of view column j >= lc_jmin
+  int lc_t0, lc_jmin;       // is column lc_t0 + j of aug.lc
+};
+// Rows of a separator block that ride below a front (nested elimination, see band_chol_nested_kernel): row q of the
+// separator against column j of the front's view.  A(q, j) is an entry of the band (zero outside it); the factor's
+// entries fill in, so they live in their own array.  wc == 0: no such rows.
+struct BandAug {
+  const double* a_base; long long a_sq, a_sj;   // &A(q, j) = a_base + q a_sq + j a_sj, inside the band iff m0 + q + ms j <= bw
+  int m0, ms;
+  double* lc; int wc, qflip, t0;                // &L(q, j) = lc + (t0 + j) wc + (qflip ? wc - 1 - q : q)   (t0: the view being eliminated)
+};
+struct BandLds { double* R; double (*U)[BS + 1]; double (*Dl)[BS + 1]; double (*X)[BS + 1]; double* colbuf; int* rowidx; };
 
 // Strip gather + product of one step: U(rr, c) = A(rr, k0 + c) - sum_j L(rr, j) L(k0 + c, j) for the 32 block rows and
 // this workgroup's rows, the history columns j coming from one or two segments (the second one only in the middle
 // phase of the two-sided elimination: the other front's columns).  A thread gathers ONE row (rr = tid & 63) at every
 // fourth column, so the addresses are a pointer walk, and all BAND_NV loads are unconditional (masked lanes read the
 // zero word) and in flight together.
-__device__ __attribute__((noinline)) void band_gather_gemm(BandSeg s0, BandSeg s1, int nseg, const double* zero, int n, int bw, int k0, int nb, const int* rowidx,
+__device__ __forceinline__ int band_seg_jmin(const BandSeg&) { return 0; }
+__device__ __forceinline__ int band_seg_jmin(const BandSegX& s) { return s.lc_jmin; }
+__device__ __forceinline__ int band_seg_t0(const BandSeg&) { return 0; }
+__device__ __forceinline__ int band_seg_t0(const BandSegX& s) { return s.lc_t0; }
+template <bool AUG, class SEG>
+__device__ __forceinline__ void band_gather_gemm_impl(const SEG& s0, const SEG& s1, int nseg, const BandAug& aug, const double* zero, int n, int bw, int k0, int nb, const int* rowidx,
                                                            double* R, double (*U)[BS + 1], long long* tp, long long* t_prev) {
   constexpr int NR = BAND_NR, NRP = BAND_NRP, NRT = BAND_NRT, TR = BAND_TR, NV = BAND_NV, DC = BAND_DC;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -705,9 +726,11 @@ __device__ __attribute__((noinline)) void band_gather_gemm(BandSeg s0, BandSeg s
   double aval[NRT];
 #pragma unroll
   for (int m = 0; m < NRT; m++) {
-    const int i = rowidx[rg1 + 8 * m], dlt = i - (k0 + c1);
-    const bool ok = c1 < nb && (i == -2 || (i >= 0 && dlt >= 0 && dlt <= bw));
-    const double* ptr = (i == -2) ? s0.v.rb + (long long)(k0 + c1) * s0.v.sr : s0.v.base + (long long)i * s0.v.si + (long long)(k0 + c1) * s0.v.sj;
+    const int i = rowidx[rg1 + 8 * m], dlt = i - (k0 + c1), qa = -16 - i;   // i <= -16: separator row qa
+    const bool ok = c1 < nb && (i == -2 || (i >= 0 && dlt >= 0 && dlt <= bw) || (AUG && i <= -16 && aug.m0 + qa + aug.ms * (k0 + c1) <= bw));
+    const double* ptr = (i == -2) ? s0.v.rb + (long long)(k0 + c1) * s0.v.sr
+                      : (AUG && i <= -16) ? aug.a_base + (long long)qa * aug.a_sq + (long long)(k0 + c1) * aug.a_sj
+                                          : s0.v.base + (long long)i * s0.v.si + (long long)(k0 + c1) * s0.v.sj;
     aval[m] = band_gload(ok ? ptr : zero);
   }
   double acc[TR][4];
@@ -717,15 +740,19 @@ __device__ __attribute__((noinline)) void band_gather_gemm(BandSeg s0, BandSeg s
     for (int t = 0; t < 4; t++) acc[m][t] = 0.0;
   const int row0 = lane < NR ? rowidx[lane] : -1;            // the row this thread gathers (in the step's view)
   for (int sg = 0; sg < nseg; sg++) {
-    const BandSeg S = sg ? s1 : s0;
+    const SEG S = sg ? s1 : s0;
     const int my_i = (S.flip && row0 >= 0) ? n - 1 - row0 : row0;
-    const int jmin = my_i >= 0 ? max(S.jlo, my_i - bw) : S.jlo;   // in-band columns of that row: j >= i - bw
+    const bool sep = AUG && my_i <= -16;                           // a separator row: history in aug.lc
+    const int qc = aug.qflip ? aug.wc - 1 - (-16 - my_i) : (-16 - my_i);
+    const int jmin = my_i >= 0 ? max(S.jlo, my_i - bw) : (sep ? max(S.jlo, band_seg_jmin(S)) : S.jlo);   // in-band columns of that row: j >= i - bw
     double vals[NV];
     auto fetch = [&](int j0) {
       const int jend = (my_i == -1) ? 0 : min(S.jhi, j0 + DC);
       int j = j0 + wv;
-      const double* p = (my_i == -2) ? S.v.rb + (long long)j * S.v.sr : S.v.base + (long long)(my_i >= 0 ? my_i : 0) * S.v.si + (long long)j * S.v.sj;
-      const long long step = (my_i == -2) ? 4 * S.v.sr : 4 * S.v.sj;
+      const double* p = (my_i == -2) ? S.v.rb + (long long)j * S.v.sr
+                      : sep ? aug.lc + (long long)(band_seg_t0(S) + j) * aug.wc + qc
+                            : S.v.base + (long long)(my_i >= 0 ? my_i : 0) * S.v.si + (long long)j * S.v.sj;
+      const long long step = (my_i == -2) ? 4 * S.v.sr : (sep ? 4LL * aug.wc : 4 * S.v.sj);
 #pragma unroll
       for (int u = 0; u < NV; u++) {
         const bool ok = j >= jmin && j < jend;
@@ -778,6 +805,21 @@ __device__ __attribute__((noinline)) void band_gather_gemm(BandSeg s0, BandSeg s
   BAND_TICK(1);
 #undef BAND_TICK
 }
+// out-of-line instances: fronts without / with separator rows
+__device__ __attribute__((noinline)) void band_gather_gemm_plain_k0(BandSeg s0, BandSeg s1, int nseg, const double* zero, int n, int bw, int k0, int nb, const int* rowidx,
+                                                                    double* R, double (*U)[BS + 1], long long* tp, long long* t_prev) {
+  const BandAug noaug{zero, 0, 0, 0, 0, nullptr, 0, 0, 0};
+  band_gather_gemm_impl<false, BandSeg>(s0, s1, nseg, noaug, zero, n, bw, k0, nb, rowidx, R, U, tp, t_prev);
+}
+__device__ __attribute__((noinline)) void band_gather_gemm_plain_k1(BandSeg s0, BandSeg s1, int nseg, const double* zero, int n, int bw, int k0, int nb, const int* rowidx,
+                                                                    double* R, double (*U)[BS + 1], long long* tp, long long* t_prev) {
+  const BandAug noaug{zero, 0, 0, 0, 0, nullptr, 0, 0, 0};
+  band_gather_gemm_impl<false, BandSeg>(s0, s1, nseg, noaug, zero, n, bw, k0, nb, rowidx, R, U, tp, t_prev);
+}
+__device__ __attribute__((noinline)) void band_gather_gemm_sep(BandSegX s0, BandSegX s1, int nseg, BandAug aug, const double* zero, int n, int bw, int k0, int nb, const int* rowidx,
+                                                               double* R, double (*U)[BS + 1], long long* tp, long long* t_prev) {
+  band_gather_gemm_impl<true, BandSegX>(s0, s1, nseg, aug, zero, n, bw, k0, nb, rowidx, R, U, tp, t_prev);
+}
 
 // arrive without waiting (a workgroup that leaves the kernel): the release half of band_grid_sync
 __device__ __forceinline__ void band_grid_arrive(unsigned* bar) {
@@ -790,6 +832,71 @@ __device__ __forceinline__ void band_grid_arrive(unsigned* bar) {
   }
 }
 
+// One elimination step of `view`: block column k0 (nb wide), rows up to i_end, history segments s0 (the view's own
+// columns) and s1.  Workgroup roles: cw < 0: panel rows own0 = k0 + nb + RW w ... of the view (has_rhs: plus the
+// right-hand side); cw >= 0: separator rows RW cw ... of aug.  Every workgroup factorises the diagonal block itself.
+template <int KID>
+__device__ __forceinline__ void band_gather_gemm(const BandSeg& s0, const BandSeg& s1, int nseg, const BandAug&, const double* zero, int n, int bw, int k0, int nb, const int* rowidx,
+                                                 double* R, double (*U)[BS + 1], long long* tp, long long* t_prev) {
+  if (KID == 0) band_gather_gemm_plain_k0(s0, s1, nseg, zero, n, bw, k0, nb, rowidx, R, U, tp, t_prev);
+  else band_gather_gemm_plain_k1(s0, s1, nseg, zero, n, bw, k0, nb, rowidx, R, U, tp, t_prev);
+}
+template <int KID>
+__device__ __forceinline__ void band_gather_gemm(const BandSegX& s0, const BandSegX& s1, int nseg, const BandAug& aug, const double* zero, int n, int bw, int k0, int nb, const int* rowidx,
+                                                 double* R, double (*U)[BS + 1], long long* tp, long long* t_prev) {
+  band_gather_gemm_sep(s0, s1, nseg, aug, zero, n, bw, k0, nb, rowidx, R, U, tp, t_prev);
+}
+template <bool AUG, int KID, class SEG>
+__device__ __forceinline__ void band_step(const BandLds& M, const BandView& view, double* Linv, int k0, int nb, int i_end, const SEG& s0, const SEG& s1, int nseg,
+                                          const BandAug& aug, int w, int cw, bool has_rhs, int n, int bw, const double* zero, int* info, long long* tp, long long* t_prev) {
+  constexpr int RW = BAND_RW, NR = BAND_NR;
+  const int tid = threadIdx.x;
+  const int own0 = k0 + nb + w * RW;
+  if (tid < NR) {                                   // row (in the view's index space) of gathered row rr; -1 = none, -2 = right-hand side, <= -16: separator row
+    int i = -1;
+    if (tid < BS) i = tid < nb ? k0 + tid : -1;
+    else if (tid - BS < RW) {
+      if (cw >= 0) { const int q = cw * RW + (tid - BS); i = q < aug.wc ? -16 - q : -1; }
+      else { const int q = own0 + (tid - BS); i = q < i_end ? q : -1; }
+    }
+    else if (tid - BS == RW && has_rhs) i = -2;
+    M.rowidx[tid] = i;
+  }
+  __syncthreads();
+  band_gather_gemm<KID>(s0, s1, nseg, aug, zero, n, bw, k0, nb, M.rowidx, M.R, M.U, tp, t_prev);
+  if (tid < 64) {
+    bool bad = KID == 0 ? band_potf2_inv_k0(M.U, nb, M.Dl, M.X, M.colbuf) : band_potf2_inv_k1(M.U, nb, M.Dl, M.X, M.colbuf);
+    if (bad && tid == 0 && w == 0 && cw < 0) atomicCAS(info, 0, k0 + 1);
+  }
+  __syncthreads();
+  if (tp) { long long t_now = wall_clock64(); tp[2] += t_now - *t_prev; *t_prev = t_now; }
+  // own rows (and the right-hand side): row <- row * L^-T
+  for (int e = tid; e < (RW + 1) * BS; e += 256) {
+    const int q = e >> 5, cc = e & 31, rr = BS + q, i = M.rowidx[rr];
+    if (cc < nb && i != -1) {
+      double sacc = 0.0;
+#pragma unroll 8
+      for (int t = 0; t <= cc; t++) sacc = fma(M.U[rr][t], M.X[cc][t], sacc);
+      if (i >= 0) { if (i - (k0 + cc) <= bw) view.base[(long long)i * view.si + (long long)(k0 + cc) * view.sj] = sacc; }
+      else if (i == -2) view.rb[(long long)(k0 + cc) * view.sr] = sacc;
+      else if (AUG) { const int qa = -16 - i; aug.lc[(long long)(aug.t0 + k0 + cc) * aug.wc + (aug.qflip ? aug.wc - 1 - qa : qa)] = sacc; }
+    }
+  }
+  if (w == 0 && cw < 0) {
+    double* Li = Linv + (size_t)(k0 / BS) * BS * BS;
+    for (int e = tid; e < BS * BS; e += 256) Li[e] = M.X[e >> 5][e & 31];
+  }
+  if (tp) { long long t_now = wall_clock64(); tp[4] += t_now - *t_prev; *t_prev = t_now; }
+}
+// L's diagonal block replaces A's only after the step's barrier: until then the other workgroups may still be reading
+// A's block (every one of them factorises it redundantly); nothing in later steps reads it (they use Linv)
+__device__ __forceinline__ void band_write_diag(const BandLds& M, const BandView& view, int k0, int nb, int bw) {
+  for (int e = threadIdx.x; e < BS * BS; e += 256) {
+    const int r = e >> 5, cc = e & 31;
+    if (r < nb && cc <= r && r - cc <= bw) view.base[(long long)(k0 + r) * view.si + (long long)(k0 + cc) * view.sj] = M.Dl[r][cc];
+  }
+}
+
 // Two-sided ("burn at both ends") elimination.  Phase 1: team 0 eliminates the first K1 column blocks with the forward
 // front while team 1 eliminates the last K2 column blocks with the reverse front -- the two regions are further apart
 // than the bandwidth, so they never touch the same entries; each front also produces the rows of L that reach into the
@@ -798,13 +905,13 @@ __device__ __forceinline__ void band_grid_arrive(unsigned* bar) {
 // bars: [team 0, team 1, both].
 __global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double* __restrict__ Linv_f, double* __restrict__ Linv_r, double* rhs, const double* zero, int n,
                                                              int LD, int K1, int K2, int* info, unsigned* bars, int G, long long* prof) {
-  constexpr int RW = BAND_RW, NR = BAND_NR;
   __shared__ double R[BAND_DC * BAND_NRP];   // strip chunk, transposed: R[jj * 64 + rr]; afterwards the 4 waves' partial sums
-  __shared__ double U[NR][BS + 1];
+  __shared__ double U[BAND_NR][BS + 1];
   __shared__ double Dl[BS][BS + 1];
   __shared__ double X[BS][BS + 1];
   __shared__ double colbuf[2 * 128];
-  __shared__ int rowidx[NR];
+  __shared__ int rowidx[BAND_NR];
+  const BandLds M{R, U, Dl, X, colbuf, rowidx};
   const int team = blockIdx.x / G, w = blockIdx.x % G;
   const int tid = threadIdx.x;
   const int bw = LD - 1;
@@ -815,52 +922,10 @@ __global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double*
   long long tp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = prof ? wall_clock64() : 0;   // optional phase clock (CS_BAND_PROF)
   const long long c_begin = prof ? clock64() : 0, w_begin = t_prev;
   const bool clocked = prof && team == 0;
+  long long* tpp = clocked ? tp : nullptr;
 #define BAND_TICK(k) do { if (clocked) { long long t_now = wall_clock64(); tp[k] += t_now - t_prev; t_prev = t_now; } } while (0)
-  // one elimination step of `view`: block column k0 (nb wide), rows up to i_end, history segments s0 (own view) and s1
-  auto step = [&](const BandView& view, double* Linv, int k0, int nb, int i_end, const BandSeg& s0, const BandSeg& s1, int nseg) {
-    const int own0 = k0 + nb + w * RW;
-    if (tid < NR) {                                   // row (in the view's index space) of gathered row rr; -1 = none, -2 = right-hand side
-      int i = -1;
-      if (tid < BS) i = tid < nb ? k0 + tid : -1;
-      else if (tid - BS < RW) { int q = own0 + (tid - BS); i = q < i_end ? q : -1; }
-      else if (tid - BS == RW && has_rhs) i = -2;
-      rowidx[tid] = i;
-    }
-    __syncthreads();
-    band_gather_gemm(s0, s1, nseg, zero, n, bw, k0, nb, rowidx, R, U, clocked ? tp : nullptr, &t_prev);
-    if (tid < 64) {
-      bool bad = band_potf2_inv(U, nb, Dl, X, colbuf);
-      if (bad && tid == 0 && w == 0) atomicCAS(info, 0, k0 + 1);
-    }
-    __syncthreads();
-    BAND_TICK(2);
-    // own rows (and the right-hand side): row <- row * L^-T
-    for (int e = tid; e < (RW + 1) * BS; e += 256) {
-      const int q = e >> 5, cc = e & 31, rr = BS + q, i = rowidx[rr];
-      if (cc < nb && i != -1) {
-        double sacc = 0.0;
-#pragma unroll 8
-        for (int t = 0; t <= cc; t++) sacc = fma(U[rr][t], X[cc][t], sacc);
-        if (i >= 0) { if (i - (k0 + cc) <= bw) view.base[(long long)i * view.si + (long long)(k0 + cc) * view.sj] = sacc; }
-        else view.rb[(long long)(k0 + cc) * view.sr] = sacc;
-      }
-    }
-    if (w == 0) {
-      double* Li = Linv + (size_t)(k0 / BS) * BS * BS;
-      for (int e = tid; e < BS * BS; e += 256) Li[e] = X[e >> 5][e & 31];
-    }
-    BAND_TICK(4);
-  };
-  // L's diagonal block replaces A's only after the step's barrier: until then the other workgroups may still be reading
-  // A's block (every one of them factorises it redundantly); nothing in later steps reads it (they use Linv)
-  auto write_diag = [&](const BandView& view, int k0, int nb) {
-    if (w == 0)
-      for (int e = tid; e < BS * BS; e += 256) {
-        const int r = e >> 5, cc = e & 31;
-        if (r < nb && cc <= r && r - cc <= bw) view.base[(long long)(k0 + r) * view.si + (long long)(k0 + cc) * view.sj] = Dl[r][cc];
-      }
-  };
   const BandSeg none{fwd, 0, 0, 0};
+  const BandAug noaug{zero, 0, 0, 0, 0, nullptr, 0, 0, 0};
   // ---- phase 1: the two fronts, each with its own barrier (after every step, the last one included: the deferred
   // write of the diagonal block must not overtake a team-mate still reading A's block)
   unsigned ep = 0;   // barriers completed on this team's counter
@@ -871,10 +936,10 @@ __global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double*
     for (int kb = 0; kb < Kt; kb++) {
       const int k0 = kb * BS;
       const BandSeg s0{view, max(0, k0 - bw), k0, 0};
-      step(view, Linv, k0, BS, min(n, k0 + BS + bw), s0, none, 1);
+      band_step<false, 0>(M, view, Linv, k0, BS, min(n, k0 + BS + bw), s0, none, 1, noaug, w, -1, has_rhs, n, bw, zero, info, tpp, &t_prev);
       ep++;
       band_grid_sync(bars + team, ep * (unsigned)G);
-      write_diag(view, k0, BS);
+      if (w == 0) band_write_diag(M, view, k0, BS, bw);
       BAND_TICK(5);
     }
     if (K2 > 0) {   // the fronts meet: the reverse team publishes and leaves, the forward team waits for it
@@ -889,10 +954,10 @@ __global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double*
     const int i_end = min(m_end, k0 + nb + bw);
     const BandSeg s0{fwd, max(0, k0 - bw), k0, 0};
     const BandSeg s1{rev, max(0, (n - i_end) - bw), BS * K2, 1};     // rows i -> i' = n - 1 - i; columns of the reverse front within the band
-    step(fwd, Linv_f, k0, nb, i_end, s0, s1, K2 > 0 ? 2 : 1);
+    band_step<false, 0>(M, fwd, Linv_f, k0, nb, i_end, s0, s1, K2 > 0 ? 2 : 1, noaug, w, -1, has_rhs, n, bw, zero, info, tpp, &t_prev);
     ep++;
     band_grid_sync(bars + 0, ep * (unsigned)G);
-    write_diag(fwd, k0, nb);
+    if (w == 0) band_write_diag(M, fwd, k0, nb, bw);
     BAND_TICK(5);
   }
   if (prof && tid == 0 && (w == 0 || w == G - 1)) for (int k = 0; k < 9; k++) prof[(w == 0 ? 0 : 9) + k] = tp[k];
@@ -900,86 +965,296 @@ __global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double*
 #undef BAND_TICK
 }
 
+// Nested elimination: four fronts.  A separator block C (wc >= bw columns in the middle of the matrix) splits the band
+// into a left and a right half that touch only through C.  Each half is eliminated "at both ends" as above -- the left
+// one in the matrix's own index space, the right one in the mirrored one (v = n - 1 - index), so that in both C lies
+// below the half -- by two teams: team 0 the front that starts at the far end, team 1 the front that starts next to C
+// and then the half's middle block.  The rows of C ride along with team 1 as extra panel rows (GC more workgroups): they
+// fill in across everything team 1 eliminates, so their factor entries go to a dense array lc[t][q] (t: elimination
+// column of the half, q: row of C).  A third team per half (GC workgroups, 16 rows of C each) accumulates C's Schur
+// complement sum_t L(i, t) L(j, t) one step behind team 1, off the chain.  When both halves are done, C -- a dense
+// wc x wc block in its own storage -- is factorised by the same step routine.  Chain of dependent steps: about
+// n / (4 * 32) instead of n / (2 * 32).
+struct BandHalf {
+  BandView fv, rv;        // the half's index space [0, nh) (C at rows nh ...) and its reverse front's (u = nh - 1 - v)
+  int nh, K1, K2, qflip;  // column blocks of the two fronts; qflip: C's rows appear in reverse order below this half
+  double* Linv_f; double* Linv_r; double* lc;
+};
+struct BandNested {
+  BandHalf h[2];
+  int n, bw, wc, c0, LD, G, GC;         // C = [c0, c0 + wc); G workgroups per front, GC for C's rows, GC for C's Schur complement
+  double* Sb; double* rhs; double* SC; double* rhsC; double* LinvC; double* part;
+  const double* zero; int* info; unsigned* bars;   // bars: [half 0: team 0, team 1, join][half 1: ...][teams 1 + 2 of both halves][-][C team]
+  long long* prof;                                 // optional phase stamps of half 0's team 1 (CS_BAND_PROF)
+};
+__device__ __forceinline__ const double* band_half_y(const BandHalf& H, int t) {   // right-hand side entry of elimination column t of team 1
+  const int Trev = BS * H.K2;
+  return t < Trev ? H.rv.rb + (long long)t * H.rv.sr : H.fv.rb + (long long)(BS * H.K1 + t - Trev) * H.fv.sr;
+}
+__global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
+  __shared__ double R[BAND_DC * BAND_NRP];
+  __shared__ double U[BAND_NR][BS + 1];
+  __shared__ double Dl[BS][BS + 1];
+  __shared__ double X[BS][BS + 1];
+  __shared__ double colbuf[2 * 128];
+  __shared__ int rowidx[BAND_NR];
+  const BandLds M{R, U, Dl, X, colbuf, rowidx};
+  const int tid = threadIdx.x;
+  const int G = P.G, G1 = P.G + P.GC, per = G + G1 + P.GC;
+  const int hid = blockIdx.x / per, r = blockIdx.x % per;
+  const int team = r < G ? 0 : (r < G + G1 ? 1 : 2), wi = team == 2 ? r - G - G1 : (team ? r - G : r);
+  const int cw = (team == 1 && wi >= G) ? wi - G : -1;  // separator-row workgroup
+  const int w = cw < 0 ? wi : 0;
+  const bool has_rhs = (cw < 0 && w == G - 1);
+  const BandHalf H = P.h[hid];
+  unsigned* bars = P.bars + 3 * hid;
+  const int nh = H.nh, bw = P.bw, wc = P.wc;
+  const int Trev = BS * H.K2, m_begin = BS * H.K1, m_end = nh - BS * H.K2;
+  const double* zero = P.zero;
+  const BandSeg none{H.fv, 0, 0, 0};
+  const BandSegX nonex{{H.fv, 0, 0, 0}, 0, 0};
+  const BandAug noaug{zero, 0, 0, 0, 0, nullptr, 0, 0, 0};
+  // (the clock words are passed by address to the out-of-line step functions: with a caller-side object escaping, their calls
+  // are not tail-call candidates and the functions keep the no-callee-saved-registers convention, see band_potf2_inv_k0)
+  long long tp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+  long long* tpp = (P.prof && blockIdx.x == 0x7fffffff) ? tp : nullptr;
+  unsigned ep = 0;
+  const bool stamp = P.prof && hid == 0 && team == 1 && wi == 0 && tid == 0;
+#define BAND_STAMP(k) do { if (stamp) P.prof[k] = wall_clock64(); } while (0)
+  BAND_STAMP(0);
+  if (team == 0) {
+    for (int kb = 0; kb < H.K1; kb++) {
+      const int k0 = kb * BS;
+      const BandSeg s0{H.fv, max(0, k0 - bw), k0, 0};
+      band_step<false, 1>(M, H.fv, H.Linv_f, k0, BS, min(nh, k0 + BS + bw), s0, none, 1, noaug, w, -1, has_rhs, nh, bw, zero, P.info, tpp, &t_prev);
+      ep++;
+      band_grid_sync(bars + 0, ep * (unsigned)G);
+      if (w == 0) band_write_diag(M, H.fv, k0, BS, bw);
+    }
+    band_grid_arrive(bars + 2);
+    return;
+  }
+  if (team == 2) {
+    // Schur accumulator of C: 16 rows of sum_t L(i, t) L(j, t) and sum_t L(i, t) y(t) over everything team 1 eliminates,
+    // one 32-column block behind it (waits on team 1's barrier counter without taking part in it)
+    const int ldb = wc + 1, Th = nh - BS * H.K1, nstep = (Th + BS - 1) / BS;
+    double* buf = R;                         // 32 x (wc + 1): rows of lc + the right-hand side entry
+    const int rr = tid >> 4, cg = tid & 15, tt8 = tid >> 3, l8 = tid & 7;
+    double acc[16], accy = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; u++) acc[u] = 0.0;
+    for (int sidx = 0; sidx < nstep; sidx++) {
+      if (tid == 0) {
+        while (__hip_atomic_load(bars + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(sidx + 1) * (unsigned)G1) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+      const int t = sidx * BS + tt8;
+      const double* row = H.lc + (long long)t * wc + l8;
+      double vals[32];
+#pragma unroll
+      for (int u = 0; u < 32; u++) vals[u] = band_gload((t < Th && 8 * u + l8 < wc) ? row + 8 * u : zero);
+      const double yv = band_gload((t < Th && l8 == 0) ? band_half_y(H, t) : zero);
+#pragma unroll
+      for (int u = 0; u < 32; u++) if (8 * u < wc) buf[tt8 * ldb + l8 + 8 * u] = vals[u];
+      if (l8 == 0) buf[tt8 * ldb + wc] = yv;
+      __syncthreads();
+#pragma unroll 4
+      for (int tt = 0; tt < 32; tt++) {
+        const double rv = buf[tt * ldb + wi * 16 + rr];
+#pragma unroll
+        for (int u = 0; u < 16; u++) if (16 * u < wc) acc[u] = fma(rv, buf[tt * ldb + cg + 16 * u], acc[u]);
+        accy = fma(rv, buf[tt * ldb + wc], accy);
+      }
+    }
+    double* po = P.part + ((size_t)hid * wc + wi * 16 + rr) * ldb;
+#pragma unroll
+    for (int u = 0; u < 16; u++) if (16 * u < wc) po[cg + 16 * u] = acc[u];
+    if (cg == 0) po[wc] = accy;
+    band_grid_arrive(P.bars + 6);
+    return;
+  }
+  // ---- team 1: the front next to C (reverse view of the half), C's rows below it
+  {
+    // A(q, u): entry (nh + q, nh - 1 - u) of the half's space, inside the band iff q + 1 + u <= bw
+    const BandAug aug{H.fv.base + (long long)nh * H.fv.si + (long long)(nh - 1) * H.fv.sj, H.fv.si, -H.fv.sj, 1, 1, H.lc, wc, H.qflip, 0};
+    for (int kb = 0; kb < H.K2; kb++) {
+      const int k0 = kb * BS;
+      const BandSegX s0{{H.rv, max(0, k0 - bw), k0, 0}, 0, 0};
+      band_step<true, 1>(M, H.rv, H.Linv_r, k0, BS, min(nh, k0 + BS + bw), s0, nonex, 1, aug, w, cw, has_rhs, nh, bw, zero, P.info, tpp, &t_prev);
+      ep++;
+      band_grid_sync(bars + 1, ep * (unsigned)G1);
+      if (w == 0 && cw < 0) band_write_diag(M, H.rv, k0, BS, bw);
+    }
+  }
+  BAND_STAMP(1);
+  band_grid_sync(bars + 2, (unsigned)(G + G1));
+  BAND_STAMP(2);
+  // ---- the half's middle block (its own space): history = tail of team 0's front + the block's earlier columns, and
+  // the tail of the reverse front; C's rows: entry (nh + q, j), inside the band iff nh + q - j <= bw
+  {
+    const BandAug aug{H.fv.base + (long long)nh * H.fv.si, H.fv.si, H.fv.sj, nh, -1, H.lc, wc, H.qflip, Trev - m_begin};
+    for (int k0 = m_begin; k0 < m_end; k0 += BS) {
+      const int nb = min(BS, m_end - k0);
+      const int i_end = min(m_end, k0 + nb + bw);
+      const BandSegX s0{{H.fv, max(0, k0 - bw), k0, 0}, Trev - m_begin, m_begin};
+      const BandSegX s1{{H.rv, max(0, (nh - i_end) - bw), Trev, 1}, 0, 0};
+      band_step<true, 1>(M, H.fv, H.Linv_f, k0, nb, i_end, s0, s1, 2, aug, w, cw, has_rhs, nh, bw, zero, P.info, tpp, &t_prev);
+      ep++;
+      band_grid_sync(bars + 1, ep * (unsigned)G1);
+      if (w == 0 && cw < 0) band_write_diag(M, H.fv, k0, nb, bw);
+    }
+  }
+  // ---- both halves (and their Schur accumulators, team 2) done
+  BAND_STAMP(3);
+  const int nslab = wc / 16;
+  band_grid_sync(P.bars + 6, 2u * (unsigned)(G1 + nslab));
+  BAND_STAMP(4);
+  if (hid != 0 || wi >= nslab) return;
+  // ---- the C team: Schur complement of its row slab (lower triangle), then the dense factorisation
+  {
+    const int ldb = wc + 1, rr = tid >> 4, cg = tid & 15, i = wi * 16 + rr;
+    for (int j = cg; j <= wc; j += 16) {
+      const double s = P.part[(size_t)i * ldb + j] + P.part[((size_t)wc + i) * ldb + j];
+      if (j < wc) {
+        if (j <= i) P.SC[(size_t)j * wc + i] = ((i - j <= bw) ? P.Sb[(size_t)(P.c0 + j) * P.LD + (i - j)] : 0.0) - s;
+      } else {
+        P.rhsC[i] = P.rhs[P.c0 + i] - s;
+      }
+    }
+  }
+  unsigned epc = 1;
+  band_grid_sync(P.bars + 8, epc * (unsigned)nslab);
+  BAND_STAMP(7);
+  const BandView vc{P.SC, 1, (long long)wc, P.rhsC, 1};
+  for (int k0 = 0; k0 < wc; k0 += BS) {
+    const BandSeg s0{vc, 0, k0, 0};
+    band_step<false, 1>(M, vc, P.LinvC, k0, BS, wc, s0, none, 1, noaug, wi, -1, wi == nslab - 1, wc, wc - 1, zero, P.info, tpp, &t_prev);
+    epc++;
+    band_grid_sync(P.bars + 8, epc * (unsigned)nslab);
+    if (wi == 0) band_write_diag(M, vc, k0, BS, wc - 1);
+  }
+  BAND_STAMP(8);
+#undef BAND_STAMP
+}
+
 // L^T x = y in place in rhs, in the elimination order reversed: first the middle block (forward view), then the two
 // fronts' regions independently -- workgroup 0 walks the forward front's blocks back to the top, workgroup 1 (it
 // repeats the middle block for itself) the reverse front's blocks back to the bottom.  Per block: t = (rows below)^T x
 // with x from an LDS window, x_k = L_kk^-T (y_k - t) with the inverted diagonal block.  Everything a step reads from
 // memory (its panel of L, L_kk^-1, y_k) is independent of x and is fetched one step ahead, all loads unconditional.
-__global__ __launch_bounds__(256) void band_backsolve_kernel(double* Sb, const double* __restrict__ Linv_f, const double* __restrict__ Linv_r, const double* __restrict__ zero,
-                                                             int n, int LD, int K1, int K2, double* rhs) {
-  enum { WIN = 8192, PF = 24 };      // x window (a step touches <= 32 + 4096 consecutive rows); prefetched rows per thread
-  __shared__ double xw[WIN];
+// With the nested elimination the same runs per half (4 workgroups), after C's unknowns have been solved and their
+// contribution taken out of the halves' right-hand sides (band_sep_solve_kernel, band_sep_correct_kernel).
+enum { BAND_WIN = 8192, BAND_PF = 24 };      // x window (a step touches <= 32 + 4096 consecutive rows); prefetched rows per thread
+struct BandSolveLds { double* xw; double* z; double (*Li)[BS + 1]; double (*part)[BS]; };
+// blocks kb_hi .. kb_lo (descending) of `view`; rows of the view at or beyond row_limit do not exist
+__device__ __forceinline__ void band_backsolve_run(const BandSolveLds& M, const BandView& view, const double* Linv, int kb_hi, int kb_lo, int row_limit, int bw, const double* zero) {
+  constexpr int WIN = BAND_WIN, PF = BAND_PF;
+  const int tid = threadIdx.x, c = tid & 31, g = tid >> 5;
+  double lv[PF], li[4], yv = 0.0;
+  auto prefetch = [&](int kb) {
+    const int k0 = kb * BS, nb = min(BS, row_limit - k0), i_end = min(row_limit, k0 + nb + bw);
+    const double* col = view.base + (long long)(k0 + c) * view.sj;     // &L(i, k0 + c) = col + i * si
+#pragma unroll
+    for (int s = 0; s < PF; s++) {
+      const int i = k0 + nb + g + 8 * s;
+      const bool ok = c < nb && i < i_end && i - (k0 + c) <= bw;
+      lv[s] = *(ok ? col + (long long)i * view.si : zero);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) li[u] = Linv[(size_t)kb * BS * BS + tid + 256 * u];
+    yv = (tid < nb) ? view.rb[(long long)(k0 + tid) * view.sr] : 0.0;
+  };
+  if (kb_hi < kb_lo) return;
+  prefetch(kb_hi);
+  __syncthreads();
+  for (int kb = kb_hi; kb >= kb_lo; kb--) {
+    const int k0 = kb * BS, nb = min(BS, row_limit - k0);
+    const int i_end = min(row_limit, k0 + nb + bw);
+    double acc = 0;   // t[c] = sum over the rows below the block of L(i, k0 + c) x[i]; 8 row groups
+#pragma unroll
+    for (int s = 0; s < PF; s++) acc = fma(lv[s], M.xw[(k0 + nb + g + 8 * s) & (WIN - 1)], acc);
+    if (c < nb)
+      for (int i = k0 + nb + g + 8 * PF; i < i_end; i += 8)
+        if (i - (k0 + c) <= bw) acc = fma(view.base[(long long)i * view.si + (long long)(k0 + c) * view.sj], M.xw[i & (WIN - 1)], acc);
+    M.part[g][c] = acc;
+#pragma unroll
+    for (int u = 0; u < 4; u++) { int e = tid + 256 * u; M.Li[e >> 5][e & 31] = li[u]; }
+    __syncthreads();
+    if (tid < BS) {
+      double tt = 0;
+#pragma unroll
+      for (int q = 0; q < 8; q++) tt += M.part[q][tid];
+      M.z[tid] = (tid < nb) ? yv - tt : 0.0;
+    }
+    __syncthreads();
+    if (kb > kb_lo) prefetch(kb - 1);
+    if (tid < nb) {
+      double a2 = 0;
+#pragma unroll 8
+      for (int r = 0; r < BS; r++) a2 = fma(M.Li[r][tid], M.z[r], a2);   // (L^-1)^T z
+      view.rb[(long long)(k0 + tid) * view.sr] = a2;
+      M.xw[(k0 + tid) & (WIN - 1)] = a2;
+    }
+    __syncthreads();
+  }
+}
+struct BandSolve { BandHalf h[2]; int bw; const double* zero; };   // one half (the whole matrix) or two
+__global__ __launch_bounds__(256) void band_backsolve_kernel(BandSolve P) {
+  __shared__ double xw[BAND_WIN];
   __shared__ double z[BS];
   __shared__ double Li[BS][BS + 1];
   __shared__ double part[8][BS];
-  const int tid = threadIdx.x, c = tid & 31, g = tid >> 5;
-  const int bw = LD - 1;
-  const int m_end = n - BS * K2;
-  const BandView fwd{Sb, 1, (long long)bw, rhs, 1};
-  const BandView rev{Sb + (size_t)(n - 1) * LD, -(long long)bw, -1, rhs + (n - 1), -1};
-  for (int e = tid; e < WIN; e += 256) xw[e] = 0.0;
-  double lv[PF], li[4], yv = 0.0;
-  // blocks kb_hi .. kb_lo (descending) of `view`; rows of the view at or beyond row_limit do not exist
-  auto run = [&](const BandView& view, const double* Linv, int kb_hi, int kb_lo, int row_limit) {
-    auto prefetch = [&](int kb) {
-      const int k0 = kb * BS, nb = min(BS, row_limit - k0), i_end = min(row_limit, k0 + nb + bw);
-      const double* col = view.base + (long long)(k0 + c) * view.sj;     // &L(i, k0 + c) = col + i * si
-#pragma unroll
-      for (int s = 0; s < PF; s++) {
-        const int i = k0 + nb + g + 8 * s;
-        const bool ok = c < nb && i < i_end && i - (k0 + c) <= bw;
-        lv[s] = *(ok ? col + (long long)i * view.si : zero);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) li[u] = Linv[(size_t)kb * BS * BS + tid + 256 * u];
-      yv = (tid < nb) ? view.rb[(long long)(k0 + tid) * view.sr] : 0.0;
-    };
-    if (kb_hi < kb_lo) return;
-    prefetch(kb_hi);
-    __syncthreads();
-    for (int kb = kb_hi; kb >= kb_lo; kb--) {
-      const int k0 = kb * BS, nb = min(BS, row_limit - k0);
-      const int i_end = min(row_limit, k0 + nb + bw);
-      double acc = 0;   // t[c] = sum over the rows below the block of L(i, k0 + c) x[i]; 8 row groups
-#pragma unroll
-      for (int s = 0; s < PF; s++) acc = fma(lv[s], xw[(k0 + nb + g + 8 * s) & (WIN - 1)], acc);
-      if (c < nb)
-        for (int i = k0 + nb + g + 8 * PF; i < i_end; i += 8)
-          if (i - (k0 + c) <= bw) acc = fma(view.base[(long long)i * view.si + (long long)(k0 + c) * view.sj], xw[i & (WIN - 1)], acc);
-      part[g][c] = acc;
-#pragma unroll
-      for (int u = 0; u < 4; u++) { int e = tid + 256 * u; Li[e >> 5][e & 31] = li[u]; }
-      __syncthreads();
-      if (tid < BS) {
-        double tt = 0;
-#pragma unroll
-        for (int q = 0; q < 8; q++) tt += part[q][tid];
-        z[tid] = (tid < nb) ? yv - tt : 0.0;
-      }
-      __syncthreads();
-      if (kb > kb_lo) prefetch(kb - 1);
-      if (tid < nb) {
-        double a2 = 0;
-#pragma unroll 8
-        for (int r = 0; r < BS; r++) a2 = fma(Li[r][tid], z[r], a2);   // (L^-1)^T z
-        view.rb[(long long)(k0 + tid) * view.sr] = a2;
-        xw[(k0 + tid) & (WIN - 1)] = a2;
-      }
-      __syncthreads();
-    }
-  };
-  // the middle block (forward view; rows end at m_end)
-  run(fwd, Linv_f, (m_end - 1) / BS, K1, m_end);
-  if (blockIdx.x == 0) {
-    run(fwd, Linv_f, K1 - 1, 0, n);
+  const BandSolveLds M{xw, z, Li, part};
+  const int tid = threadIdx.x;
+  const BandHalf H = P.h[blockIdx.x >> 1];
+  const int bw = P.bw, nh = H.nh, m_end = nh - BS * H.K2;
+  for (int e = tid; e < BAND_WIN; e += 256) xw[e] = 0.0;
+  // the middle block (the half's own view; rows end at m_end)
+  band_backsolve_run(M, H.fv, H.Linv_f, (m_end - 1) / BS, H.K1, m_end, bw, P.zero);
+  if ((blockIdx.x & 1) == 0) {
+    band_backsolve_run(M, H.fv, H.Linv_f, H.K1 - 1, 0, nh, bw, P.zero);
   } else {
     // the same unknowns seen from the reverse front: x of the middle block into the window at its reverse indices
     __syncthreads();
-    for (int e = tid; e < WIN; e += 256) xw[e] = 0.0;
+    for (int e = tid; e < BAND_WIN; e += 256) xw[e] = 0.0;
     __syncthreads();
-    for (int v = BS * K2 + tid; v < min(n, BS * K2 + bw + BS); v += 256) xw[v & (WIN - 1)] = rhs[n - 1 - v];
+    for (int v = BS * H.K2 + tid; v < min(nh, BS * H.K2 + bw + BS); v += 256) xw[v & (BAND_WIN - 1)] = H.rv.rb[(long long)v * H.rv.sr];
     __syncthreads();
-    run(rev, Linv_r, K2 - 1, 0, n);
+    band_backsolve_run(M, H.rv, H.Linv_r, H.K2 - 1, 0, nh, bw, P.zero);
+  }
+}
+// C's unknowns: L_C^T x_C = y_C on the dense block (one workgroup)
+__global__ __launch_bounds__(256) void band_sep_solve_kernel(BandNested P) {
+  __shared__ double xw[BAND_WIN];
+  __shared__ double z[BS];
+  __shared__ double Li[BS][BS + 1];
+  __shared__ double part[8][BS];
+  const BandSolveLds M{xw, z, Li, part};
+  for (int e = threadIdx.x; e < BAND_WIN; e += 256) xw[e] = 0.0;
+  const BandView vc{P.SC, 1, (long long)P.wc, P.rhsC, 1};
+  band_backsolve_run(M, vc, P.LinvC, P.wc / BS - 1, 0, P.wc, P.wc - 1, P.zero);
+}
+// y(t) -= sum_q L(q, t) x_C(q) for every elimination column t that carries C's rows (32 per workgroup, 8 lanes each);
+// workgroup 0 also stores x_C at C's place in the solution vector
+__global__ __launch_bounds__(256) void band_sep_correct_kernel(BandNested P) {
+  __shared__ double xc[256];
+  const int tid = threadIdx.x, wc = P.wc;
+  for (int e = tid; e < wc; e += 256) xc[e] = P.rhsC[e];
+  __syncthreads();
+  if (blockIdx.x == 0) for (int e = tid; e < wc; e += 256) P.rhs[P.c0 + e] = xc[e];
+  const int T0 = P.h[0].nh - BS * P.h[0].K1, T1 = P.h[1].nh - BS * P.h[1].K1;
+  const int t = blockIdx.x * 32 + (tid >> 3), l8 = tid & 7;
+  double s = 0.0;
+  if (t < T0 + T1) {
+    const BandHalf& H = P.h[t < T0 ? 0 : 1];
+    const double* row = H.lc + (long long)(t < T0 ? t : t - T0) * wc;
+    for (int q = l8; q < wc; q += 8) s = fma(row[q], xc[q], s);
+  }
+  s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+  if (t < T0 + T1 && l8 == 0) {
+    double* y = const_cast<double*>(band_half_y(P.h[t < T0 ? 0 : 1], t < T0 ? t : t - T0));
+    *y -= s;
   }
 }
 
@@ -991,9 +1266,6 @@ int ba_band_team(int LD, int* rw_out) {   // workgroups of the factorisation tea
   return G;
 }
 
-// info[0] = first non-positive pivot (+1), info[1..3] = barrier counters (forward team, reverse team, both),
-// info[4..5] = a zero double (the target of masked loads); all zeroed by the caller.  Linv: 2 * ceil(n / 32) blocks of
-// 32 x 32 (forward front and middle block first, then the reverse front).
 void ba_band_split(int n, int LD, int* K1, int* K2) {   // column blocks of the two fronts; the middle block keeps >= bw columns
   const int bw = LD - 1;
   const int Kt = n > bw ? (n - bw) / BS : 0;
@@ -1001,14 +1273,93 @@ void ba_band_split(int n, int LD, int* K1, int* K2) {   // column blocks of the 
   *K2 = (Kt >= 8 && !one_sided) ? Kt / 2 : 0;
   *K1 = Kt - *K2;
 }
-void ba_launch_band_cholesky(double* Sb, double* Linv, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st) {
-  int rw = 0, K1 = 0, K2 = 0;
+// The nested (four-front) order pays when both halves still have two real fronts; it needs the separator's row
+// workgroups co-resident with the four teams, which bounds the bandwidth it is used for.
+bool ba_band_nested(int n, int LD, int* wc_out, int* c0_out) {
+  static const bool off = getenv("CS_BAND_TWO_FRONTS") != nullptr || getenv("CS_BAND_ONE_SIDED") != nullptr;   // diagnostics: the two-front order
+  const int bw = LD - 1;
+  const int wc = ((bw + BS - 1) / BS) * BS;
+  const int nh = (n - wc) / 2;
+  if (off || bw > 256 || bw < 1 || nh < bw + 16 * BS) return false;
+  *wc_out = wc; *c0_out = nh;
+  return true;
+}
+static size_t band_blocks(int n) { return (size_t)((n + BS - 1) / BS) * BS * BS; }
+// doubles of workspace behind `work` (inverted diagonal blocks; nested order: + the separator's factor rows, partial
+// Schur complements and dense block)
+size_t ba_band_workspace_doubles(int n, int LD) {
+  size_t two = 2 * band_blocks(n);
+  int wc = 0, c0 = 0;
+  if (!ba_band_nested(n, LD, &wc, &c0)) return two;
+  const int nh0 = c0, nh1 = n - c0 - wc;
+  size_t nest = 2 * band_blocks(nh0) + 2 * band_blocks(nh1) + band_blocks(wc) + (size_t)(nh0 + nh1) * wc + (size_t)2 * wc * (wc + 1) + (size_t)wc * wc + wc;
+  return nest > two ? nest : two;
+}
+
+// info (16 ints, zeroed by the caller): [0] first non-positive pivot (+1), [1..3] barrier counters of the two-front
+// order (forward team, reverse team, both), [4..5] a zero double (the target of masked loads), [6..14] barrier counters
+// of the nested order.  work: ba_band_workspace_doubles(n, LD) doubles.
+void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st) {
+  int rw = 0, K1 = 0, K2 = 0, wc = 0, c0 = 0;
   const int G = ba_band_team(LD, &rw);
+  const int bw = LD - 1;
+  const double* zero = reinterpret_cast<const double*>(info + 4);
+  const BandView fwd{Sb, 1, (long long)bw, rhs, 1};
+  const BandView rev{Sb + (size_t)(n - 1) * LD, -(long long)bw, -1, rhs + (n - 1), -1};
+  if (ba_band_nested(n, LD, &wc, &c0)) {
+    BandNested P;
+    const int c1 = c0 + wc, nh[2] = {c0, n - c1};
+    double* wp = work;
+    for (int h = 0; h < 2; h++) {
+      BandHalf& H = P.h[h];
+      H.nh = nh[h];
+      ba_band_split(nh[h], LD, &H.K1, &H.K2);
+      H.qflip = h;
+      H.Linv_f = wp; wp += band_blocks(nh[h]);
+      H.Linv_r = wp; wp += band_blocks(nh[h]);
+    }
+    // left half: the matrix's own index space, reverse front from c0 - 1 down; right half: the mirrored space, its
+    // reverse front therefore walks forward from c1
+    P.h[0].fv = fwd;
+    P.h[0].rv = BandView{Sb + (size_t)(c0 - 1) * LD, -(long long)bw, -1, rhs + (c0 - 1), -1};
+    P.h[1].fv = rev;
+    P.h[1].rv = BandView{Sb + (size_t)c1 * LD, 1, (long long)bw, rhs + c1, 1};
+    P.LinvC = wp; wp += band_blocks(wc);
+    for (int h = 0; h < 2; h++) { P.h[h].lc = wp; wp += (size_t)nh[h] * wc; }
+    P.part = wp; wp += (size_t)2 * wc * (wc + 1);
+    P.SC = wp; wp += (size_t)wc * wc;
+    P.rhsC = wp; wp += wc;
+    P.n = n; P.bw = bw; P.wc = wc; P.c0 = c0; P.LD = LD; P.G = G; P.GC = wc / 16;
+    const int G1 = P.G + P.GC;
+    P.Sb = Sb; P.rhs = rhs; P.zero = zero; P.info = info; P.bars = reinterpret_cast<unsigned*>(info + 6);
+    static const bool want_stamps = getenv("CS_BAND_PROF") != nullptr;
+    static long long* stamps = nullptr;
+    if (want_stamps && !stamps) (void)hipMalloc(&stamps, 16 * sizeof(long long));
+    P.prof = stamps;
+    hipLaunchKernelGGL(band_chol_nested_kernel, dim3(2 * (P.G + G1 + P.GC)), dim3(256), 0, st, P);
+    if (stamps) {
+      long long h[16];
+      (void)hipMemcpyAsync(h, stamps, sizeof(h), hipMemcpyDeviceToHost, st);
+      (void)hipStreamSynchronize(st);
+      static int shown = 0;
+      if (shown++ < 3)
+        fprintf(stderr, "[band nested] n=%d bw=%d C=%d+%d halves %d/%d fronts %d+%d / %d+%d us: reverse front %.0f  join wait %.0f  middle %.0f  halves wait %.0f  C build %.0f  C factor %.0f\n",
+                n, bw, c0, wc, nh[0], nh[1], P.h[0].K1, P.h[0].K2, P.h[1].K1, P.h[1].K2, (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01, (h[3] - h[2]) * 0.01, (h[4] - h[3]) * 0.01,
+                (h[7] - h[4]) * 0.01, (h[8] - h[7]) * 0.01);
+    }
+    if (solve) {
+      const int TT = (nh[0] - BS * P.h[0].K1) + (nh[1] - BS * P.h[1].K1);
+      hipLaunchKernelGGL(band_sep_solve_kernel, dim3(1), dim3(256), 0, st, P);
+      hipLaunchKernelGGL(band_sep_correct_kernel, dim3((TT + 31) / 32), dim3(256), 0, st, P);
+      BandSolve Q; Q.h[0] = P.h[0]; Q.h[1] = P.h[1]; Q.bw = bw; Q.zero = zero;
+      hipLaunchKernelGGL(band_backsolve_kernel, dim3(4), dim3(256), 0, st, Q);
+    }
+    return;
+  }
   ba_band_split(n, LD, &K1, &K2);
   unsigned* bars = reinterpret_cast<unsigned*>(info + 1);
-  const double* zero = reinterpret_cast<const double*>(info + 4);
-  double* Linv_f = Linv;
-  double* Linv_r = Linv + (size_t)((n + BS - 1) / BS) * BS * BS;
+  double* Linv_f = work;
+  double* Linv_r = work + band_blocks(n);
   static const bool want_prof = getenv("CS_BAND_PROF") != nullptr;   // diagnostics: phase clock of the forward team's first / last workgroup
   static long long* prof = nullptr;
   if (want_prof && !prof) (void)hipMalloc(&prof, 20 * sizeof(long long));
@@ -1025,7 +1376,11 @@ void ba_launch_band_cholesky(double* Sb, double* Linv, int n, int LD, double* rh
                 h[9 * q + 6] * 0.01, h[9 * q + 7] * 0.01, h[9 * q + 8] * 0.01, h[9 * q + 1] * 0.01, h[9 * q + 2] * 0.01, h[9 * q + 4] * 0.01, h[9 * q + 5] * 0.01);
     }
   }
-  if (solve) hipLaunchKernelGGL(band_backsolve_kernel, dim3(K2 > 0 ? 2 : 1), dim3(256), 0, st, Sb, Linv_f, Linv_r, zero, n, LD, K1, K2, rhs);
+  if (solve) {
+    BandSolve Q;
+    Q.h[0] = BandHalf{fwd, rev, n, K1, K2, 0, Linv_f, Linv_r, nullptr}; Q.h[1] = Q.h[0]; Q.bw = bw; Q.zero = zero;
+    hipLaunchKernelGGL(band_backsolve_kernel, dim3(K2 > 0 ? 2 : 1), dim3(256), 0, st, Q);
+  }
 }
 
 // ---------------------------------------------------------------------------------------- launchers --

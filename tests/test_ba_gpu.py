@@ -309,18 +309,25 @@ def test_cuboid_projection_edges_system_and_optimize_parity():
 
 def test_band_solver_harness_shapes():
     """tools/microbench/band_bench: random SPD bands through the persistent Cholesky + substitution kernels, residual of
-    A x = b computed on the host.  Shapes cover the one-sided order (fewer than 8 column blocks outside the middle), the
-    two-front order, a middle block barely wider than the band, single-chunk and multi-chunk strips (bw > 192), tiny
-    bandwidths, and sizes that are not multiples of the block."""
+    A x = b computed on the host.  Shapes cover the nested four-front order (large n, bandwidth <= 256: separator rows,
+    Schur accumulators, dense separator block; halves of unequal size; bandwidths at and next to multiples of 32), the
+    two-front order (the same shapes forced with CS_BAND_TWO_FRONTS, and the ones too small or too wide for nesting), the
+    one-sided order (fewer than 8 column blocks outside the middle), a middle block barely wider than the band,
+    single-chunk and multi-chunk strips (bw > 192), tiny bandwidths, and sizes that are not multiples of the block."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "build_tmp", "band_bench")
     if not os.path.exists(exe):
         import __graft_entry__
         __graft_entry__.build()
-    for n, ld in [(10494, 183), (5000, 700), (3000, 40), (1000, 300), (777, 12), (500, 200), (439, 183), (440, 184), (471, 184), (300, 290), (2049, 33), (4097, 2)]:
-        out = subprocess.run([exe, str(n), str(ld), "2"], capture_output=True, text=True, timeout=300)
-        assert out.returncode == 0, out.stderr
-        res = [float(l.split("residual")[1]) for l in out.stdout.splitlines() if "residual" in l]
-        infos = [int(l.split("info")[1].split()[0]) for l in out.stdout.splitlines() if "info" in l]
-        assert len(res) == 2 and max(res) < 1e-12 and infos == [0, 0], (n, ld, out.stdout)
+    shapes = [(10494, 183), (5000, 700), (3000, 40), (1000, 300), (777, 12), (500, 200), (439, 183), (440, 184), (471, 184), (300, 290), (2049, 33), (4097, 2),
+              (5000, 257), (2001, 193), (2000, 192), (1500, 33), (1473, 161), (1217, 100), (1345, 129), (9999, 65)]
+    for n, ld in shapes:
+        for env in ({}, {"CS_BAND_TWO_FRONTS": "1"}):
+            if env and (n, ld) not in [(10494, 183), (2001, 193), (1500, 33)]:
+                continue
+            out = subprocess.run([exe, str(n), str(ld), "2"], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
+            assert out.returncode == 0, out.stderr
+            res = [float(l.split("residual")[1]) for l in out.stdout.splitlines() if "residual" in l]
+            infos = [int(l.split("info")[1].split()[0]) for l in out.stdout.splitlines() if "info" in l]
+            assert len(res) == 2 and max(res) < 1e-12 and infos == [0, 0], (n, ld, env, out.stdout)
