@@ -350,7 +350,7 @@ int finalize_structure(cs_ba* B) {
   AL(B->Dinv, 9 * (size_t)np); AL(B->dbl, 3 * (size_t)np); B->s_doubles = (size_t)B->n_pose * (B->band_ld ? B->band_ld : B->n_pose);
   AL(B->S, B->s_doubles + B->n_pose);   // [S | rhs]: one buffer, one all-reduce in the sharded solve
   AL(B->xl, 3 * (size_t)np);
-  AL(B->d_band_info, 16);  // [first bad pivot + 1, grid-barrier counters, a zero double]
+  AL(B->d_band_info, 24);  // [first bad pivot + 1, grid-barrier counters, a zero double]
   AL(B->band_linv, B->band_ld ? cs::ba_band_workspace_doubles(B->n_pose, B->band_ld) : 1);   // inverted diagonal blocks (+ the separator's rows in the nested order)
   B->nb_chi = cs::ba_chi2_blocks(E);
   B->n_chi_partials = B->nb_chi + (B->n_cub + B->n_odom + 63) / 64;
@@ -466,7 +466,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       // pivot flag comes home with the single synchronisation (a failed factorisation just leaves garbage increments
       // that the caller discards)
       std::lock_guard<std::mutex> coop_turn(g_coop_mutex);
-      BA_TRY(hipMemsetAsync(B->d_band_info.p, 0, 16 * sizeof(int), B->st));
+      BA_TRY(hipMemsetAsync(B->d_band_info.p, 0, 24 * sizeof(int), B->st));
       cs::ba_launch_band_cholesky(B->S.p, B->band_linv.p, n, B->band_ld, B->view.rhs, B->d_band_info.p, true, B->st);
       BA_TRY(hipGetLastError());
       BA_TRY(hipEventRecord(B->ev[4], B->st));

@@ -717,16 +717,17 @@ __device__ __forceinline__ int band_seg_t0(const BandSegX& s) { return s.lc_t0; 
 template <bool AUG, class SEG>
 __device__ __forceinline__ void band_gather_gemm_impl(const SEG& s0, const SEG& s1, int nseg, const BandAug& aug, const double* zero, int n, int bw, int k0, int nb, const int* rowidx,
                                                            double* R, double (*U)[BS + 1], long long* tp, long long* t_prev) {
-  constexpr int NR = BAND_NR, NRP = BAND_NRP, NRT = BAND_NRT, TR = BAND_TR, NV = BAND_NV, DC = BAND_DC;
+  constexpr int NR = BAND_NR, NRP = BAND_NRP, NOWN = BAND_NR - BS, NRT = NOWN / 8, TR = NOWN / 8, NV = BAND_NV, DC = BAND_DC;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int cg = lane & 7, rgp = lane >> 3;     // register tile: rows 8 rgp .. 8 rgp + 7 of the 64 padded rows, columns 4 cg .. 4 cg + 3
+  const int cg = lane & 7, rgp = lane >> 3;     // register tile: own rows BS + 3 rgp .. + 2 (the block's 32 rows are only the other operand: their
+                                                // diagonal block belongs to the diagonal workgroup), columns 4 cg .. 4 cg + 3
   const int c1 = tid & 31, rg1 = tid >> 5;      // one-column mapping of the finishing pass
 #define BAND_TICK(k) do { if (tp) { long long t_now = wall_clock64(); tp[k] += t_now - *t_prev; *t_prev = t_now; } } while (0)
   // the block's own columns (A of U = A - sum), in the step's own view s0.v: loads in flight while the strip is gathered
   double aval[NRT];
 #pragma unroll
   for (int m = 0; m < NRT; m++) {
-    const int i = rowidx[rg1 + 8 * m], dlt = i - (k0 + c1), qa = -16 - i;   // i <= -16: separator row qa
+    const int i = rowidx[BS + rg1 + 8 * m], dlt = i - (k0 + c1), qa = -16 - i;   // i <= -16: separator row qa
     const bool ok = c1 < nb && (i == -2 || (i >= 0 && dlt >= 0 && dlt <= bw) || (AUG && i <= -16 && aug.m0 + qa + aug.ms * (k0 + c1) <= bw));
     const double* ptr = (i == -2) ? s0.v.rb + (long long)(k0 + c1) * s0.v.sr
                       : (AUG && i <= -16) ? aug.a_base + (long long)qa * aug.a_sq + (long long)(k0 + c1) * aug.a_sj
@@ -770,8 +771,8 @@ __device__ __forceinline__ void band_gather_gemm_impl(const SEG& s0, const SEG& 
       BAND_TICK(7);
       if (j0 + DC < S.jhi) fetch(j0 + DC);
       BAND_TICK(6);
-      // this wave's quarter of the depth: acc(rows, cols) += R(jj, rows) * R(jj, cols)   (LDS-bandwidth bound: 96 B of
-      // operands per lane and depth index for 32 multiply-adds)
+      // this wave's quarter of the depth: acc(rows, cols) += R(jj, rows) * R(jj, cols)   (LDS-bandwidth bound: 56 B of
+      // operands per lane and depth index for 12 multiply-adds)
 #pragma unroll 4
       for (int jj = wv; jj < jn; jj += 4) {
         const double* rj = R + jj * NRP;
@@ -779,7 +780,7 @@ __device__ __forceinline__ void band_gather_gemm_impl(const SEG& s0, const SEG& 
 #pragma unroll
         for (int t = 0; t < 4; t++) colv[t] = rj[4 * cg + t];
 #pragma unroll
-        for (int m = 0; m < TR; m++) rowv[m] = rj[rgp * TR + m];
+        for (int m = 0; m < TR; m++) rowv[m] = rj[BS + rgp * TR + m];
 #pragma unroll
         for (int m = 0; m < TR; m++)
 #pragma unroll
@@ -793,11 +794,11 @@ __device__ __forceinline__ void band_gather_gemm_impl(const SEG& s0, const SEG& 
 #pragma unroll
   for (int m = 0; m < TR; m++)
 #pragma unroll
-    for (int t = 0; t < 4; t++) R[(wv * NRP + rgp * TR + m) * BS + 4 * cg + t] = acc[m][t];
+    for (int t = 0; t < 4; t++) R[(wv * NRP + BS + rgp * TR + m) * BS + 4 * cg + t] = acc[m][t];
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < NRT; m++) {
-    const int rr = rg1 + 8 * m;
+    const int rr = BS + rg1 + 8 * m;
     const double sum = (R[(0 * NRP + rr) * BS + c1] + R[(1 * NRP + rr) * BS + c1]) + (R[(2 * NRP + rr) * BS + c1] + R[(3 * NRP + rr) * BS + c1]);
     U[rr][c1] = aval[m] - sum;
   }
@@ -848,7 +849,7 @@ __device__ __forceinline__ void band_gather_gemm(const BandSegX& s0, const BandS
 }
 template <bool AUG, int KID, class SEG>
 __device__ __forceinline__ void band_step(const BandLds& M, const BandView& view, double* Linv, int k0, int nb, int i_end, const SEG& s0, const SEG& s1, int nseg,
-                                          const BandAug& aug, int w, int cw, bool has_rhs, int n, int bw, const double* zero, int* info, long long* tp, long long* t_prev) {
+                                          const BandAug& aug, int w, int cw, bool has_rhs, int n, int bw, const double* zero, unsigned* dflag, unsigned dtarget, long long* tp, long long* t_prev) {
   constexpr int RW = BAND_RW, NR = BAND_NR;
   const int tid = threadIdx.x;
   const int own0 = k0 + nb + w * RW;
@@ -864,9 +865,19 @@ __device__ __forceinline__ void band_step(const BandLds& M, const BandView& view
   }
   __syncthreads();
   band_gather_gemm<KID>(s0, s1, nseg, aug, zero, n, bw, k0, nb, M.rowidx, M.R, M.U, tp, t_prev);
-  if (tid < 64) {
-    bool bad = KID == 0 ? band_potf2_inv_k0(M.U, nb, M.Dl, M.X, M.colbuf) : band_potf2_inv_k1(M.U, nb, M.Dl, M.X, M.colbuf);
-    if (bad && tid == 0 && w == 0 && cw < 0) atomicCAS(info, 0, k0 + 1);
+  // the inverse of the block's factor comes from the front's diagonal workgroup (band_diag_phase), normally before it is asked for
+  if (tid == 0) {
+    while (__hip_atomic_load(dflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < dtarget) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  {
+    const double* Li = Linv + (size_t)(k0 / BS) * BS * BS;
+    double xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) xv[u] = band_gload(Li + tid + 256 * u);
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int e = tid + 256 * u; M.X[e >> 5][e & 31] = xv[u]; }
   }
   __syncthreads();
   if (tp) { long long t_now = wall_clock64(); tp[2] += t_now - *t_prev; *t_prev = t_now; }
@@ -882,20 +893,143 @@ __device__ __forceinline__ void band_step(const BandLds& M, const BandView& view
       else if (AUG) { const int qa = -16 - i; aug.lc[(long long)(aug.t0 + k0 + cc) * aug.wc + (aug.qflip ? aug.wc - 1 - qa : qa)] = sacc; }
     }
   }
-  if (w == 0 && cw < 0) {
-    double* Li = Linv + (size_t)(k0 / BS) * BS * BS;
-    for (int e = tid; e < BS * BS; e += 256) Li[e] = M.X[e >> 5][e & 31];
-  }
   if (tp) { long long t_now = wall_clock64(); tp[4] += t_now - *t_prev; *t_prev = t_now; }
 }
-// L's diagonal block replaces A's only after the step's barrier: until then the other workgroups may still be reading
-// A's block (every one of them factorises it redundantly); nothing in later steps reads it (they use Linv)
-__device__ __forceinline__ void band_write_diag(const BandLds& M, const BandView& view, int k0, int nb, int bw) {
-  for (int e = threadIdx.x; e < BS * BS; e += 256) {
-    const int r = e >> 5, cc = e & 31;
-    if (r < nb && cc <= r && r - cc <= bw) view.base[(long long)(k0 + r) * view.si + (long long)(k0 + cc) * view.sj] = M.Dl[r][cc];
+// ---- the diagonal workgroup of a front.  One extra workgroup per front factorises the diagonal blocks, so the 32-step
+// chain of POTF2 leaves the other workgroups' step: while they still gather and multiply their strips of step k, it
+// already holds sum_j L(k rows, j) L(k rows, j)^T over all history but the newest 32 columns (accumulated during step
+// k - 1), adds those after the team's barrier, factorises, and publishes L_kk^-1 (and L_kk) with a monotone flag.
+
+// acc(4 rg + m, 4 cg + t) += this wave's quarter of sum over columns j in [jlo, jhi) of S.v of L(k0 + row, j) L(k0 + col, j);
+// rg = lane >> 3, cg = lane & 7; the four waves' partial sums meet when U is formed
+template <class SEG>
+__device__ __forceinline__ void band_diag_accum(const SEG& S, int jlo, int jhi, int n, int bw, int k0, int nb, const double* zero, double* R, double (&acc)[4][4]) {
+  constexpr int DC = BAND_DC, LDR = BS + 1;
+  const int tid = threadIdx.x, gr = tid & 31, ph = tid >> 5, lane = tid & 63, wv = tid >> 6, rg = lane >> 3, cg = lane & 7;
+  const int i = k0 + gr, my_i = S.flip ? n - 1 - i : i;
+  const int jmin = max(jlo, my_i - bw);
+  const double* rowp = S.v.base + (long long)my_i * S.v.si;
+  for (int j0 = jlo; j0 < jhi; j0 += DC) {
+    const int jend = gr < nb ? min(jhi, j0 + DC) : 0;
+    double vals[DC / 8];
+#pragma unroll
+    for (int u = 0; u < DC / 8; u++) {
+      const int j = j0 + ph + 8 * u;
+      vals[u] = band_gload((j >= jmin && j < jend) ? rowp + (long long)j * S.v.sj : zero);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < DC / 8; u++) R[(ph + 8 * u) * LDR + gr] = vals[u];
+    __syncthreads();
+    const int jn = min(DC, jhi - j0);
+#pragma unroll 4
+    for (int jj = wv; jj < jn; jj += 4) {
+      const double* rj = R + jj * LDR;
+      double rowv[4], colv[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++) { rowv[m] = rj[4 * rg + m]; colv[m] = rj[4 * cg + m]; }
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[m][t] = fma(rowv[m], colv[t], acc[m][t]);
+    }
   }
 }
+// The diagonal blocks k_begin, k_begin + 32, ... < k_end of `view` (one phase of a front).  History of block k0: the
+// view's own columns [max(0, k0 - bw), k0) and, with two_seg, the columns [max(0, (n - min(k_end, k0 + nb + bw)) - bw), jhi1)
+// of the other front's view v1 (rows re-indexed i -> n - 1 - i).  start: counter/target that opens the phase (may be null);
+// bar: the team's step barrier, which reads G ep0 when the phase starts; flag: published block count, f0 at the start.
+template <int KID>
+__device__ __forceinline__ void band_diag_phase(const BandLds& M, const BandView& view, double* Linv, int k_begin, int k_end, bool two_seg, const BandView& v1, int jhi1,
+                                                unsigned* start, unsigned start_target, unsigned* bar, unsigned G, unsigned ep0, unsigned* flag, unsigned f0,
+                                                int n, int bw, const double* zero, int* info) {
+  const int tid = threadIdx.x, r = tid >> 3, cq = tid & 7, lane = tid & 63, wv = tid >> 6, rg = lane >> 3, cg = lane & 7;
+  auto wait_for = [&](unsigned* ctr, unsigned target) {
+    if (tid == 0) {
+      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+  };
+  auto seg1 = [&](int k0, int nb) { return BandSeg{v1, max(0, (n - min(k_end, k0 + nb + bw)) - bw), jhi1, 1}; };
+  double acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[m][t] = 0.0;
+  unsigned s = 0;
+  for (int k0 = k_begin; k0 < k_end; k0 += BS, s++) {
+    const int nb = min(BS, k_end - k0);
+    const BandSeg s0{view, max(0, k0 - bw), k0, 0};
+    if (s == 0) {
+      if (start) wait_for(start, start_target);
+      band_diag_accum(s0, s0.jlo, k0, n, bw, k0, nb, zero, M.R, acc);
+      if (two_seg) { const BandSeg s1 = seg1(k0, nb); band_diag_accum(s1, s1.jlo, s1.jhi, n, bw, k0, nb, zero, M.R, acc); }
+    } else {
+      wait_for(bar, (ep0 + s) * G);
+      band_diag_accum(s0, max(s0.jlo, k0 - BS), k0, n, bw, k0, nb, zero, M.R, acc);
+    }
+    // U = A - sum of the four waves' partial sums (lower triangle)
+    {
+      double av[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int c = 4 * cq + t;
+        const bool ok = r < nb && c <= r && r - c <= bw;
+        av[t] = band_gload(ok ? view.base + (long long)(k0 + r) * view.si + (long long)(k0 + c) * view.sj : zero);
+      }
+      __syncthreads();
+      double* part = M.R;                       // [wave][32][33]
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) part[(wv * BS + 4 * rg + m) * (BS + 1) + 4 * cg + t] = acc[m][t];
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int o = r * (BS + 1) + 4 * cq + t, ws = BS * (BS + 1);
+        M.U[r][4 * cq + t] = av[t] - ((part[o] + part[ws + o]) + (part[2 * ws + o] + part[3 * ws + o]));
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const bool bad = KID == 0 ? band_potf2_inv_k0(M.U, nb, M.Dl, M.X, M.colbuf) : band_potf2_inv_k1(M.U, nb, M.Dl, M.X, M.colbuf);
+      if (bad && tid == 0) atomicCAS(info, 0, k0 + 1);
+    }
+    __syncthreads();
+    {
+      double* Li = Linv + (size_t)(k0 / BS) * BS * BS;
+      for (int e = tid; e < BS * BS; e += 256) {
+        const int rr = e >> 5, cc = e & 31;
+        Li[e] = M.X[rr][cc];
+        if (rr < nb && cc <= rr && rr - cc <= bw) view.base[(long long)(k0 + rr) * view.si + (long long)(k0 + cc) * view.sj] = M.Dl[rr][cc];
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(flag, f0 + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the next block's history except its newest 32 columns (those wait for the team's barrier)
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int t = 0; t < 4; t++) acc[m][t] = 0.0;
+    const int k1 = k0 + BS;
+    if (k1 < k_end) {
+      const int nb1 = min(BS, k_end - k1);
+      const BandSeg n0{view, max(0, k1 - bw), k1, 0};
+      band_diag_accum(n0, n0.jlo, max(n0.jlo, k1 - BS), n, bw, k1, nb1, zero, M.R, acc);
+      if (two_seg) { const BandSeg n1 = seg1(k1, nb1); band_diag_accum(n1, n1.jlo, n1.jhi, n, bw, k1, nb1, zero, M.R, acc); }
+    }
+  }
+}
+
+// (see band_potf2_inv_k0: a caller-side object whose address escapes before the first out-of-line call keeps those calls from
+// being marked as tail-call candidates, which would switch the callees back to the save-everything convention)
+__device__ __attribute__((noinline)) void band_clock_init(long long* t) { asm volatile("" : : "v"(t) : "memory"); *t = 0; }
 
 // Two-sided ("burn at both ends") elimination.  Phase 1: team 0 eliminates the first K1 column blocks with the forward
 // front while team 1 eliminates the last K2 column blocks with the reverse front -- the two regions are further apart
@@ -912,10 +1046,12 @@ __global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double*
   __shared__ double colbuf[2 * 128];
   __shared__ int rowidx[BAND_NR];
   const BandLds M{R, U, Dl, X, colbuf, rowidx};
-  const int team = blockIdx.x / G, w = blockIdx.x % G;
+  const int team = blockIdx.x / (G + 1), w = blockIdx.x % (G + 1);   // w == G: the front's diagonal workgroup
   const int tid = threadIdx.x;
   const int bw = LD - 1;
   const bool has_rhs = (w == G - 1);
+  unsigned* dflag = bars + 14 + team;     // info[15 + team]
+  long long t_escape; band_clock_init(&t_escape);
   const BandView fwd{Sb, 1, (long long)bw, rhs, 1};
   const BandView rev{Sb + (size_t)(n - 1) * LD, -(long long)bw, -1, rhs + (n - 1), -1};
   const int m_begin = BS * K1, m_end = n - BS * K2;      // the middle block (original indices)
@@ -929,6 +1065,13 @@ __global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double*
   // ---- phase 1: the two fronts, each with its own barrier (after every step, the last one included: the deferred
   // write of the diagonal block must not overtake a team-mate still reading A's block)
   unsigned ep = 0;   // barriers completed on this team's counter
+  if (w == G) {
+    const BandView view = team ? rev : fwd;
+    band_diag_phase<0>(M, view, team ? Linv_r : Linv_f, 0, BS * (team ? K2 : K1), false, rev, 0, nullptr, 0, bars + team, (unsigned)G, 0, dflag, 0, n, bw, zero, info);
+    // the middle block opens when both fronts have met (one-sided order: when the forward front's last barrier is through)
+    if (team == 0) band_diag_phase<0>(M, fwd, Linv_f, m_begin, m_end, K2 > 0, rev, BS * K2, K2 > 0 ? bars + 2 : bars + 0, K2 > 0 ? 2u * (unsigned)G : (unsigned)K1 * (unsigned)G, bars + 0, (unsigned)G, (unsigned)K1, dflag, (unsigned)K1, n, bw, zero, info);
+    return;
+  }
   {
     const BandView view = team ? rev : fwd;
     double* Linv = team ? Linv_r : Linv_f;
@@ -936,10 +1079,9 @@ __global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double*
     for (int kb = 0; kb < Kt; kb++) {
       const int k0 = kb * BS;
       const BandSeg s0{view, max(0, k0 - bw), k0, 0};
-      band_step<false, 0>(M, view, Linv, k0, BS, min(n, k0 + BS + bw), s0, none, 1, noaug, w, -1, has_rhs, n, bw, zero, info, tpp, &t_prev);
+      band_step<false, 0>(M, view, Linv, k0, BS, min(n, k0 + BS + bw), s0, none, 1, noaug, w, -1, has_rhs, n, bw, zero, dflag, ep + 1, tpp, &t_prev);
       ep++;
       band_grid_sync(bars + team, ep * (unsigned)G);
-      if (w == 0) band_write_diag(M, view, k0, BS, bw);
       BAND_TICK(5);
     }
     if (K2 > 0) {   // the fronts meet: the reverse team publishes and leaves, the forward team waits for it
@@ -954,10 +1096,9 @@ __global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double*
     const int i_end = min(m_end, k0 + nb + bw);
     const BandSeg s0{fwd, max(0, k0 - bw), k0, 0};
     const BandSeg s1{rev, max(0, (n - i_end) - bw), BS * K2, 1};     // rows i -> i' = n - 1 - i; columns of the reverse front within the band
-    band_step<false, 0>(M, fwd, Linv_f, k0, nb, i_end, s0, s1, K2 > 0 ? 2 : 1, noaug, w, -1, has_rhs, n, bw, zero, info, tpp, &t_prev);
+    band_step<false, 0>(M, fwd, Linv_f, k0, nb, i_end, s0, s1, K2 > 0 ? 2 : 1, noaug, w, -1, has_rhs, n, bw, zero, dflag, ep + 1, tpp, &t_prev);
     ep++;
     band_grid_sync(bars + 0, ep * (unsigned)G);
-    if (w == 0) band_write_diag(M, fwd, k0, nb, bw);
     BAND_TICK(5);
   }
   if (prof && tid == 0 && (w == 0 || w == G - 1)) for (int k = 0; k < 9; k++) prof[(w == 0 ? 0 : 9) + k] = tp[k];
@@ -1000,10 +1141,13 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
   __shared__ int rowidx[BAND_NR];
   const BandLds M{R, U, Dl, X, colbuf, rowidx};
   const int tid = threadIdx.x;
-  const int G = P.G, G1 = P.G + P.GC, per = G + G1 + P.GC;
+  const int G = P.G, G1 = P.G + P.GC, per = (G + 1) + (G1 + 1) + P.GC;   // team 0 + its diagonal workgroup, team 1 + its, team 2
   const int hid = blockIdx.x / per, r = blockIdx.x % per;
-  const int team = r < G ? 0 : (r < G + G1 ? 1 : 2), wi = team == 2 ? r - G - G1 : (team ? r - G : r);
-  const int cw = (team == 1 && wi >= G) ? wi - G : -1;  // separator-row workgroup
+  const int team = r < G + 1 ? 0 : (r < G + 1 + G1 + 1 ? 1 : 2), wi = team == 2 ? r - (G + 1) - (G1 + 1) : (team ? r - (G + 1) : r);
+  const bool diag = (team == 0 && wi == G) || (team == 1 && wi == G1);   // the front's diagonal workgroup
+  const int cw = (team == 1 && !diag && wi >= G) ? wi - G : -1;           // separator-row workgroup
+  unsigned* dflag = P.bars + 9 + 2 * hid + (team == 1);                  // info[15 + 2 hid + team]
+  long long t_escape; band_clock_init(&t_escape);
   const int w = cw < 0 ? wi : 0;
   const bool has_rhs = (cw < 0 && w == G - 1);
   const BandHalf H = P.h[hid];
@@ -1022,14 +1166,24 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
   const bool stamp = P.prof && hid == 0 && team == 1 && wi == 0 && tid == 0;
 #define BAND_STAMP(k) do { if (stamp) P.prof[k] = wall_clock64(); } while (0)
   BAND_STAMP(0);
+  const int nslab = wc / 16;
+  if (diag) {
+    if (team == 0) { band_diag_phase<1>(M, H.fv, H.Linv_f, 0, m_begin, false, H.rv, 0, nullptr, 0, bars + 0, (unsigned)G, 0, dflag, 0, nh, bw, zero, P.info); return; }
+    band_diag_phase<1>(M, H.rv, H.Linv_r, 0, Trev, false, H.fv, 0, nullptr, 0, bars + 1, (unsigned)G1, 0, dflag, 0, nh, bw, zero, P.info);
+    band_diag_phase<1>(M, H.fv, H.Linv_f, m_begin, m_end, true, H.rv, Trev, bars + 2, (unsigned)(G + G1), bars + 1, (unsigned)G1, (unsigned)H.K2, dflag, (unsigned)H.K2, nh, bw, zero, P.info);
+    if (hid != 0) return;
+    const BandView vcd{P.SC, 1, (long long)wc, P.rhsC, 1};
+    const unsigned km = (unsigned)((m_end - m_begin + BS - 1) / BS);
+    band_diag_phase<1>(M, vcd, P.LinvC, 0, wc, false, vcd, 0, P.bars + 8, (unsigned)nslab, P.bars + 8, (unsigned)nslab, 1, dflag, (unsigned)H.K2 + km, wc, wc - 1, zero, P.info);
+    return;
+  }
   if (team == 0) {
     for (int kb = 0; kb < H.K1; kb++) {
       const int k0 = kb * BS;
       const BandSeg s0{H.fv, max(0, k0 - bw), k0, 0};
-      band_step<false, 1>(M, H.fv, H.Linv_f, k0, BS, min(nh, k0 + BS + bw), s0, none, 1, noaug, w, -1, has_rhs, nh, bw, zero, P.info, tpp, &t_prev);
+      band_step<false, 1>(M, H.fv, H.Linv_f, k0, BS, min(nh, k0 + BS + bw), s0, none, 1, noaug, w, -1, has_rhs, nh, bw, zero, dflag, ep + 1, tpp, &t_prev);
       ep++;
       band_grid_sync(bars + 0, ep * (unsigned)G);
-      if (w == 0) band_write_diag(M, H.fv, k0, BS, bw);
     }
     band_grid_arrive(bars + 2);
     return;
@@ -1081,10 +1235,9 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
     for (int kb = 0; kb < H.K2; kb++) {
       const int k0 = kb * BS;
       const BandSegX s0{{H.rv, max(0, k0 - bw), k0, 0}, 0, 0};
-      band_step<true, 1>(M, H.rv, H.Linv_r, k0, BS, min(nh, k0 + BS + bw), s0, nonex, 1, aug, w, cw, has_rhs, nh, bw, zero, P.info, tpp, &t_prev);
+      band_step<true, 1>(M, H.rv, H.Linv_r, k0, BS, min(nh, k0 + BS + bw), s0, nonex, 1, aug, w, cw, has_rhs, nh, bw, zero, dflag, ep + 1, tpp, &t_prev);
       ep++;
       band_grid_sync(bars + 1, ep * (unsigned)G1);
-      if (w == 0 && cw < 0) band_write_diag(M, H.rv, k0, BS, bw);
     }
   }
   BAND_STAMP(1);
@@ -1099,15 +1252,13 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
       const int i_end = min(m_end, k0 + nb + bw);
       const BandSegX s0{{H.fv, max(0, k0 - bw), k0, 0}, Trev - m_begin, m_begin};
       const BandSegX s1{{H.rv, max(0, (nh - i_end) - bw), Trev, 1}, 0, 0};
-      band_step<true, 1>(M, H.fv, H.Linv_f, k0, nb, i_end, s0, s1, 2, aug, w, cw, has_rhs, nh, bw, zero, P.info, tpp, &t_prev);
+      band_step<true, 1>(M, H.fv, H.Linv_f, k0, nb, i_end, s0, s1, 2, aug, w, cw, has_rhs, nh, bw, zero, dflag, ep + 1, tpp, &t_prev);
       ep++;
       band_grid_sync(bars + 1, ep * (unsigned)G1);
-      if (w == 0 && cw < 0) band_write_diag(M, H.fv, k0, nb, bw);
     }
   }
   // ---- both halves (and their Schur accumulators, team 2) done
   BAND_STAMP(3);
-  const int nslab = wc / 16;
   band_grid_sync(P.bars + 6, 2u * (unsigned)(G1 + nslab));
   BAND_STAMP(4);
   if (hid != 0 || wi >= nslab) return;
@@ -1129,10 +1280,9 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
   const BandView vc{P.SC, 1, (long long)wc, P.rhsC, 1};
   for (int k0 = 0; k0 < wc; k0 += BS) {
     const BandSeg s0{vc, 0, k0, 0};
-    band_step<false, 1>(M, vc, P.LinvC, k0, BS, wc, s0, none, 1, noaug, wi, -1, wi == nslab - 1, wc, wc - 1, zero, P.info, tpp, &t_prev);
+    band_step<false, 1>(M, vc, P.LinvC, k0, BS, wc, s0, none, 1, noaug, wi, -1, wi == nslab - 1, wc, wc - 1, zero, dflag, ep + epc, tpp, &t_prev);
     epc++;
     band_grid_sync(P.bars + 8, epc * (unsigned)nslab);
-    if (wi == 0) band_write_diag(M, vc, k0, BS, wc - 1);
   }
   BAND_STAMP(8);
 #undef BAND_STAMP
@@ -1296,9 +1446,9 @@ size_t ba_band_workspace_doubles(int n, int LD) {
   return nest > two ? nest : two;
 }
 
-// info (16 ints, zeroed by the caller): [0] first non-positive pivot (+1), [1..3] barrier counters of the two-front
+// info (24 ints, zeroed by the caller): [0] first non-positive pivot (+1), [1..3] barrier counters of the two-front
 // order (forward team, reverse team, both), [4..5] a zero double (the target of masked loads), [6..14] barrier counters
-// of the nested order.  work: ba_band_workspace_doubles(n, LD) doubles.
+// of the nested order, [15..18] published-block counters of the fronts' diagonal workgroups.  work: ba_band_workspace_doubles(n, LD) doubles.
 void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st) {
   int rw = 0, K1 = 0, K2 = 0, wc = 0, c0 = 0;
   const int G = ba_band_team(LD, &rw);
@@ -1336,7 +1486,7 @@ void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rh
     static long long* stamps = nullptr;
     if (want_stamps && !stamps) (void)hipMalloc(&stamps, 16 * sizeof(long long));
     P.prof = stamps;
-    hipLaunchKernelGGL(band_chol_nested_kernel, dim3(2 * (P.G + G1 + P.GC)), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(band_chol_nested_kernel, dim3(2 * (P.G + 1 + G1 + 1 + P.GC)), dim3(256), 0, st, P);
     if (stamps) {
       long long h[16];
       (void)hipMemcpyAsync(h, stamps, sizeof(h), hipMemcpyDeviceToHost, st);
@@ -1363,7 +1513,7 @@ void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rh
   static const bool want_prof = getenv("CS_BAND_PROF") != nullptr;   // diagnostics: phase clock of the forward team's first / last workgroup
   static long long* prof = nullptr;
   if (want_prof && !prof) (void)hipMalloc(&prof, 20 * sizeof(long long));
-  hipLaunchKernelGGL(band_chol_coop_kernel, dim3(K2 > 0 ? 2 * G : G), dim3(256), 0, st, Sb, Linv_f, Linv_r, rhs, zero, n, LD, K1, K2, info, bars, G, prof);
+  hipLaunchKernelGGL(band_chol_coop_kernel, dim3(K2 > 0 ? 2 * (G + 1) : G + 1), dim3(256), 0, st, Sb, Linv_f, Linv_r, rhs, zero, n, LD, K1, K2, info, bars, G, prof);
   if (prof) {
     long long h[20];
     (void)hipMemcpyAsync(h, prof, sizeof(h), hipMemcpyDeviceToHost, st);

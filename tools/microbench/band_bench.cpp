@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
     for (int d = 1; d <= bw && c + d < n; d++) { double v = rnd(); A[(size_t)c * LD + d] = v; diag[c] += std::fabs(v); diag[c + d] += std::fabs(v); }
   for (int c = 0; c < n; c++) { A[(size_t)c * LD] = diag[c]; b[c] = rnd(); }
   double *dS, *dL, *dr; int* dinfo;
-  hipMalloc(&dS, A.size() * 8); hipMalloc(&dL, cs::ba_band_workspace_doubles(n, LD) * 8); hipMalloc(&dr, n * 8); hipMalloc(&dinfo, 64);
+  hipMalloc(&dS, A.size() * 8); hipMalloc(&dL, cs::ba_band_workspace_doubles(n, LD) * 8); hipMalloc(&dr, n * 8); hipMalloc(&dinfo, 96);
   hipStream_t st; hipStreamCreate(&st);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   std::vector<double> x(n);
@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
     if (r > 0) { for (auto& v : A) v *= 1.25; for (int c = 0; c < n; c++) A[(size_t)c * LD] += 0.5 * r; for (auto& v : b) v = rnd(); }
     hipMemcpyAsync(dS, A.data(), A.size() * 8, hipMemcpyHostToDevice, st);
     hipMemcpyAsync(dr, b.data(), n * 8, hipMemcpyHostToDevice, st);
-    hipMemsetAsync(dinfo, 0, 64, st);
+    hipMemsetAsync(dinfo, 0, 96, st);
     hipEventRecord(e0, st);
     cs::ba_launch_band_cholesky(dS, dL, n, LD, dr, dinfo, true, st);
     hipEventRecord(e1, st);
