@@ -773,7 +773,7 @@ __device__ __forceinline__ void band_gather_gemm_impl(const SEG& s0, const SEG& 
       BAND_TICK(6);
       // this wave's quarter of the depth: acc(rows, cols) += R(jj, rows) * R(jj, cols)   (LDS-bandwidth bound: 56 B of
       // operands per lane and depth index for 12 multiply-adds)
-#pragma unroll 4
+#pragma unroll 8
       for (int jj = wv; jj < jn; jj += 4) {
         const double* rj = R + jj * NRP;
         double colv[4], rowv[TR];
@@ -885,9 +885,13 @@ __device__ __forceinline__ void band_step(const BandLds& M, const BandView& view
   for (int e = tid; e < (RW + 1) * BS; e += 256) {
     const int q = e >> 5, cc = e & 31, rr = BS + q, i = M.rowidx[rr];
     if (cc < nb && i != -1) {
-      double sacc = 0.0;
-#pragma unroll 8
-      for (int t = 0; t <= cc; t++) sacc = fma(M.U[rr][t], M.X[cc][t], sacc);
+      // X is stored with its upper triangle zeroed: the full-length dot product in four independent chains
+      double sa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int t = 0; t < BS; t += 4)
+#pragma unroll
+        for (int u = 0; u < 4; u++) sa[u] = fma(M.U[rr][t + u], M.X[cc][t + u], sa[u]);
+      const double sacc = (sa[0] + sa[1]) + (sa[2] + sa[3]);
       if (i >= 0) { if (i - (k0 + cc) <= bw) view.base[(long long)i * view.si + (long long)(k0 + cc) * view.sj] = sacc; }
       else if (i == -2) view.rb[(long long)(k0 + cc) * view.sr] = sacc;
       else if (AUG) { const int qa = -16 - i; aug.lc[(long long)(aug.t0 + k0 + cc) * aug.wc + (aug.qflip ? aug.wc - 1 - qa : qa)] = sacc; }
@@ -902,9 +906,9 @@ __device__ __forceinline__ void band_step(const BandLds& M, const BandView& view
 
 // acc(4 rg + m, 4 cg + t) += this wave's quarter of sum over columns j in [jlo, jhi) of S.v of L(k0 + row, j) L(k0 + col, j);
 // rg = lane >> 3, cg = lane & 7; the four waves' partial sums meet when U is formed
-template <class SEG>
+template <int DC, class SEG>
 __device__ __forceinline__ void band_diag_accum(const SEG& S, int jlo, int jhi, int n, int bw, int k0, int nb, const double* zero, double* R, double (&acc)[4][4]) {
-  constexpr int DC = BAND_DC, LDR = BS + 1;
+  constexpr int LDR = BS + 1;
   const int tid = threadIdx.x, gr = tid & 31, ph = tid >> 5, lane = tid & 63, wv = tid >> 6, rg = lane >> 3, cg = lane & 7;
   const int i = k0 + gr, my_i = S.flip ? n - 1 - i : i;
   const int jmin = max(jlo, my_i - bw);
@@ -961,23 +965,27 @@ __device__ __forceinline__ void band_diag_phase(const BandLds& M, const BandView
   for (int k0 = k_begin; k0 < k_end; k0 += BS, s++) {
     const int nb = min(BS, k_end - k0);
     const BandSeg s0{view, max(0, k0 - bw), k0, 0};
-    if (s == 0) {
-      if (start) wait_for(start, start_target);
-      band_diag_accum(s0, s0.jlo, k0, n, bw, k0, nb, zero, M.R, acc);
-      if (two_seg) { const BandSeg s1 = seg1(k0, nb); band_diag_accum(s1, s1.jlo, s1.jhi, n, bw, k0, nb, zero, M.R, acc); }
-    } else {
-      wait_for(bar, (ep0 + s) * G);
-      band_diag_accum(s0, max(s0.jlo, k0 - BS), k0, n, bw, k0, nb, zero, M.R, acc);
-    }
-    // U = A - sum of the four waves' partial sums (lower triangle)
-    {
-      double av[4];
+    double av[4];                                // the block's own entries (lower triangle)
+    auto load_block = [&]() {
 #pragma unroll
       for (int t = 0; t < 4; t++) {
         const int c = 4 * cq + t;
         const bool ok = r < nb && c <= r && r - c <= bw;
         av[t] = band_gload(ok ? view.base + (long long)(k0 + r) * view.si + (long long)(k0 + c) * view.sj : zero);
       }
+    };
+    if (s > 0) load_block();                     // in flight across the wait (nobody writes the block before this workgroup does)
+    if (s == 0) {
+      if (start) wait_for(start, start_target);  // (the gate may be what completes the matrix itself: the separator block)
+      load_block();
+      band_diag_accum<BAND_DC>(s0, s0.jlo, k0, n, bw, k0, nb, zero, M.R, acc);
+      if (two_seg) { const BandSeg s1 = seg1(k0, nb); band_diag_accum<BAND_DC>(s1, s1.jlo, s1.jhi, n, bw, k0, nb, zero, M.R, acc); }
+    } else {
+      wait_for(bar, (ep0 + s) * G);
+      band_diag_accum<BS>(s0, max(s0.jlo, k0 - BS), k0, n, bw, k0, nb, zero, M.R, acc);   // the newest block: 4 loads per thread
+    }
+    // U = A - sum of the four waves' partial sums (lower triangle)
+    {
       __syncthreads();
       double* part = M.R;                       // [wave][32][33]
 #pragma unroll
@@ -1021,8 +1029,8 @@ __device__ __forceinline__ void band_diag_phase(const BandLds& M, const BandView
     if (k1 < k_end) {
       const int nb1 = min(BS, k_end - k1);
       const BandSeg n0{view, max(0, k1 - bw), k1, 0};
-      band_diag_accum(n0, n0.jlo, max(n0.jlo, k1 - BS), n, bw, k1, nb1, zero, M.R, acc);
-      if (two_seg) { const BandSeg n1 = seg1(k1, nb1); band_diag_accum(n1, n1.jlo, n1.jhi, n, bw, k1, nb1, zero, M.R, acc); }
+      band_diag_accum<BAND_DC>(n0, n0.jlo, max(n0.jlo, k1 - BS), n, bw, k1, nb1, zero, M.R, acc);
+      if (two_seg) { const BandSeg n1 = seg1(k1, nb1); band_diag_accum<BAND_DC>(n1, n1.jlo, n1.jhi, n, bw, k1, nb1, zero, M.R, acc); }
     }
   }
 }
@@ -1161,7 +1169,8 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
   // (the clock words are passed by address to the out-of-line step functions: with a caller-side object escaping, their calls
   // are not tail-call candidates and the functions keep the no-callee-saved-registers convention, see band_potf2_inv_k0)
   long long tp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
-  long long* tpp = (P.prof && blockIdx.x == 0x7fffffff) ? tp : nullptr;
+  long long* tpp = (P.prof && hid == 0 && team == 1 && (wi == 0 || wi == G1 - 1)) ? tp : nullptr;   // phase clock of a panel-row and a separator-row workgroup
+  if (tpp) t_prev = wall_clock64();
   unsigned ep = 0;
   const bool stamp = P.prof && hid == 0 && team == 1 && wi == 0 && tid == 0;
 #define BAND_STAMP(k) do { if (stamp) P.prof[k] = wall_clock64(); } while (0)
@@ -1238,8 +1247,10 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
       band_step<true, 1>(M, H.rv, H.Linv_r, k0, BS, min(nh, k0 + BS + bw), s0, nonex, 1, aug, w, cw, has_rhs, nh, bw, zero, dflag, ep + 1, tpp, &t_prev);
       ep++;
       band_grid_sync(bars + 1, ep * (unsigned)G1);
+      if (tpp) { long long t_now = wall_clock64(); tp[5] += t_now - t_prev; t_prev = t_now; }
     }
   }
+  if (tpp && tid == 0) for (int k = 0; k < 9; k++) P.prof[16 + (wi == 0 ? 0 : 9) + k] = tp[k];
   BAND_STAMP(1);
   band_grid_sync(bars + 2, (unsigned)(G + G1));
   BAND_STAMP(2);
@@ -1484,11 +1495,11 @@ void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rh
     P.Sb = Sb; P.rhs = rhs; P.zero = zero; P.info = info; P.bars = reinterpret_cast<unsigned*>(info + 6);
     static const bool want_stamps = getenv("CS_BAND_PROF") != nullptr;
     static long long* stamps = nullptr;
-    if (want_stamps && !stamps) (void)hipMalloc(&stamps, 16 * sizeof(long long));
+    if (want_stamps && !stamps) (void)hipMalloc(&stamps, 34 * sizeof(long long));
     P.prof = stamps;
     hipLaunchKernelGGL(band_chol_nested_kernel, dim3(2 * (P.G + 1 + G1 + 1 + P.GC)), dim3(256), 0, st, P);
     if (stamps) {
-      long long h[16];
+      long long h[34];
       (void)hipMemcpyAsync(h, stamps, sizeof(h), hipMemcpyDeviceToHost, st);
       (void)hipStreamSynchronize(st);
       static int shown = 0;
@@ -1496,6 +1507,10 @@ void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rh
         fprintf(stderr, "[band nested] n=%d bw=%d C=%d+%d halves %d/%d fronts %d+%d / %d+%d us: reverse front %.0f  join wait %.0f  middle %.0f  halves wait %.0f  C build %.0f  C factor %.0f\n",
                 n, bw, c0, wc, nh[0], nh[1], P.h[0].K1, P.h[0].K2, P.h[1].K1, P.h[1].K2, (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01, (h[3] - h[2]) * 0.01, (h[4] - h[3]) * 0.01,
                 (h[7] - h[4]) * 0.01, (h[8] - h[7]) * 0.01);
+      if (shown <= 3)
+        for (int q = 0; q < 2; q++)
+          fprintf(stderr, "[band nested] reverse front, %s workgroup us: fetch-issue %.0f  store+wait %.0f  gemm %.0f  reduce+U %.0f  wait for L^-1 %.0f  panel %.0f  barrier %.0f\n", q ? "separator-row" : "panel-row",
+                  h[16 + 9 * q + 6] * 0.01, h[16 + 9 * q + 7] * 0.01, h[16 + 9 * q + 8] * 0.01, h[16 + 9 * q + 1] * 0.01, h[16 + 9 * q + 2] * 0.01, h[16 + 9 * q + 4] * 0.01, h[16 + 9 * q + 5] * 0.01);
     }
     if (solve) {
       const int TT = (nh[0] - BS * P.h[0].K1) + (nh[1] - BS * P.h[1].K1);
