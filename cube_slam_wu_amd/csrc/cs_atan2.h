@@ -10,6 +10,12 @@
 // uses only +,-,*,/ and fma -- all IEEE-exact on x86-64 and gfx950 -- and is therefore
 // bit-reproducible across the two.  tests/test_atan2.py measures its agreement with glibc.
 //
+// Two evaluations, one result.  The double-double evaluation costs ~230 FP64 instructions; a lighter one (finer table,
+// one division, the cubic series in plain doubles: ~90 instructions) is accurate to ~2^-70 and comes with its error
+// bound: when both ends of [value - bound, value + bound] round to the same double, that double IS the correctly
+// rounded result and is returned; otherwise (about 2^-15 of the calls) the double-double evaluation decides.  Both
+// paths consist of IEEE-exact operations only, so host and device still take the same path and return the same bits.
+//
 // Build rule for every TU that includes this header: -ffp-contract=off (explicit fma() calls below
 // are intended; implicit contraction is not).
 #pragma once
@@ -17,8 +23,10 @@
 
 #if defined(__HIPCC__)
 #define CS_HD __host__ __device__ __forceinline__
+#define CS_HD_COLD inline __host__ __device__ __attribute__((noinline))   /* rarely taken: out of line, so that it does not set the caller's register budget */
 #else
 #define CS_HD static inline
+#define CS_HD_COLD static
 #endif
 
 namespace cs {
@@ -119,6 +127,51 @@ CS_HD dd_t dd_atan_unit(dd_t num, dd_t den, double q_approx) {
   return dd_add(dd_t{tab[i][0], tab[i][1]}, at);
 }
 
+// Fast path.  0 < small <= big, big in [1, 2).  atan(small / big) = atan(c) + atan(t), c = i / 256 next to the quotient,
+// t = (small - c big) / (big + c small), |t| <= 2^-9 (+ the slack of the single-precision quotient that picks i: any
+// neighbouring i is as good).  Numerator and denominator are kept as unevaluated sums of two doubles, t = th + tl comes
+// from one division and its remainder, atan(t) = t - t^3/3 + t^5/5 - t^7/7 with the corrections in plain doubles
+// (|t^3| <= 2^-18 |t|: their rounding errors stay below 2^-70 |t|; the series ends below 2^-75 |t|).  Returns the value as
+// a double-double; relative error < 2^-69.
+CS_HD dd_t dd_atan_fast(double small, double big) {
+  static const double ftab[CS_ATAN_FTAB_N][2] = CS_ATAN_FTAB_INIT;
+  const float qf = (float)small / (float)big;
+  int i = (int)(qf * 256.0f + 0.5f);
+  i = i < 0 ? 0 : (i > 256 ? 256 : i);
+  const double c = (double)i * (1.0 / 256.0);
+  const dd_t pb = dd_two_prod(c, big);
+  const dd_t ns = dd_two_sum(small, -pb.hi);
+  const double Nl = ns.lo - pb.lo;
+  const dd_t ps = dd_two_prod(c, small);
+  const dd_t ds = dd_two_sum(big, ps.hi);
+  const double Dl = ds.lo + ps.lo;
+  const double inv = 1.0 / ds.hi;
+  const double th = ns.hi * inv;
+  const double r = __builtin_fma(-th, ds.hi, ns.hi) + (Nl - th * Dl);
+  const double tl = r * inv;
+  const double u = th * th;
+  const double corr = th * (u * (-1.0 / 3.0 + u * (1.0 / 5.0 + u * (-1.0 / 7.0))));
+  const dd_t s = dd_two_sum(ftab[i][0], th);
+  const double lo = s.lo + (ftab[i][1] + (tl + corr));
+  return dd_fast_two_sum(s.hi, lo);
+}
+
+// The double-double evaluation of the first-quadrant angle, reflected into the octant (small / big scaled, lo / hi the
+// unscaled magnitudes in the same order).
+CS_HD_COLD double cs_atan2_dd(double small, double big, double lo_mag, double hi_mag, bool swap, bool xneg) {
+  double q = small / big;
+  dd_t a;
+  if (q < 0x1p-900) {
+    // atan(q) == q to far beyond double precision; keep the plain quotient of the originals.
+    a = dd_t{lo_mag / hi_mag, 0.0};
+  } else {
+    a = dd_atan_unit(dd_t{small, 0.0}, dd_t{big, 0.0}, q);
+  }
+  if (swap) a = dd_add(dd_t{CS_DD_PI_2_HI, CS_DD_PI_2_LO}, dd_neg(a));
+  if (xneg) a = dd_add(dd_t{CS_DD_PI_HI, CS_DD_PI_LO}, dd_neg(a));
+  return a.hi;
+}
+
 // IEEE-754 atan2 semantics (C11 F.10.1.4) for zeros, infinities and NaN.
 CS_HD double cs_atan2(double y, double x) {
   if (x != x || y != y) return x + y;
@@ -152,18 +205,25 @@ CS_HD double cs_atan2(double y, double x) {
     double f1 = cs_from_bits((long long)(1023 + sh1) << 52), f2 = cs_from_bits((long long)(1023 + sh2) << 52);
     big = big * f1 * f2;
     small = small * f1 * f2;  // may underflow when the ratio is below ~2^-1000: atan ~ ratio
-    double q = small / big;
-    dd_t a;
-    if (q < 0x1p-900) {
-      // atan(q) == q to far beyond double precision; keep the plain quotient of the originals.
-      double qq = (swap ? ax : ay) / (swap ? ay : ax);
-      a = dd_t{qq, 0.0};
-    } else {
-      a = dd_atan_unit(dd_t{small, 0.0}, dd_t{big, 0.0}, q);
+    bool done = false;
+#ifndef CS_ATAN2_NO_FAST   /* (the checker builds one copy without the fast path to compare against) */
+    if (small >= 0x1p-200) {
+      // fast path + rounding test.  The octant reflections subtract from constants known to 2^-106, and the result is never
+      // smaller than the value it was reflected from, so one relative bound on the final value covers everything.
+      dd_t f = dd_atan_fast(small, big);
+      if (swap) { dd_t v = dd_two_sum(CS_DD_PI_2_HI, -f.hi); v.lo = v.lo + (CS_DD_PI_2_LO - f.lo); f = dd_fast_two_sum(v.hi, v.lo); }
+      if (xneg) { dd_t v = dd_two_sum(CS_DD_PI_HI, -f.hi); v.lo = v.lo + (CS_DD_PI_LO - f.lo); f = dd_fast_two_sum(v.hi, v.lo); }
+      const double bound = f.hi * 0x1p-68;
+      const double up = f.hi + (f.lo + bound), dn = f.hi + (f.lo - bound);
+      if (up == dn) { r = up; done = true; }
     }
-    if (swap) a = dd_add(dd_t{CS_DD_PI_2_HI, CS_DD_PI_2_LO}, dd_neg(a));
-    if (xneg) a = dd_add(dd_t{CS_DD_PI_HI, CS_DD_PI_LO}, dd_neg(a));
-    r = a.hi;
+#endif
+    if (!done) {
+#ifdef CS_ATAN2_ON_FALLBACK   /* checker hook: counts how often the rounding test defers to the double-double evaluation */
+      CS_ATAN2_ON_FALLBACK;
+#endif
+      r = cs_atan2_dd(small, big, swap ? ax : ay, swap ? ay : ax, swap, xneg);
+    }
   }
   return yneg ? -r : r;
 }

@@ -260,18 +260,67 @@ __global__ __launch_bounds__(256) void candidate_kernel(DetectDeviceView v, Swee
 //   config 2 (1): visible edges 1-2 2-3 3-4 4-1 2-6 3-5 5-6         (:663); VP edges 1-2,3-4 / 4-1,5-6 / 3-5,2-6 (:665)
 __device__ __forceinline__ int sel(int cfg, int a, int b) { return cfg ? b : a; }
 
+enum { SCORE_JOBS = 4, SCORE_SUB = 128, SCORE_BINS = SCORE_JOBS * SCORE_SUB };   // sort keys of score_kernel: (job within the block, configuration x top sample)
 __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long long slot_total) {
-  __shared__ double CX[256][9], CY[256][9];   // [lane][corner], padded to 9 against bank conflicts
+  __shared__ double CXt[8][256], CYt[8][256];   // [corner][lane]: lanes of a wave mostly ask for the same corner (sorted by configuration)
   // the grid is sized for the worst case (every slot valid) because the exact count lives on the device; spread the
   // ACTIVE blocks over the 8 XCDs (contiguous range per XCD), the surplus blocks exit immediately
   const long long n_valid = v.job_cbase[v.n_jobs];
   const long long per_xcd = ((n_valid + 255) / 256 + 7) / 8;
   const long long kx = blockIdx.x >> 3;
   if (kx >= per_xcd) return;
-  long long i = ((long long)(blockIdx.x & 7) * per_xcd + kx) * blockDim.x + threadIdx.x;
-  if (i >= n_valid) return;
-  const long long slot = v.c_slot[i];
-  const int j = find_job_i64(v.slot_prefix, v.n_jobs, slot);
+  const long long base = ((long long)(blockIdx.x & 7) * per_xcd + kx) * blockDim.x;
+  if (base >= n_valid) return;
+  // ---- who scores what.  The 256 proposals of this block are consecutive in the reference's order: configuration
+  // fastest, then top-edge sample, then yaw.  Neighbouring lanes would gather from unrelated places of the distance map,
+  // and a wave load that touches 64 different cache lines occupies the L1 tag pipeline for 64 cycles -- that, not the
+  // arithmetic, used to bound this kernel.  Proposals that differ only in yaw (0.5 degrees: corners 1-2 px apart) sample
+  // almost the same pixels, so the block re-sorts its proposals by (job, configuration, top-edge sample) with a counting
+  // sort in LDS and every lane takes the proposal at its sorted position; results go back to the proposal's own index.
+  __shared__ int hist[SCORE_BINS + 1];
+  __shared__ int s_src[256], s_job[256];
+  __shared__ long long s_slot[256];
+  {
+    const int t0 = threadIdx.x;
+    for (int b = t0; b <= SCORE_BINS; b += 256) hist[b] = 0;
+    __syncthreads();
+    const long long i0 = base + t0;
+    long long slot0 = 0;
+    int j0 = 0;
+    if (i0 < n_valid) { slot0 = v.c_slot[i0]; j0 = find_job_i64(v.slot_prefix, v.n_jobs, slot0); }
+    s_slot[t0] = slot0; s_job[t0] = j0;
+    __syncthreads();
+    int key = SCORE_BINS;                       // beyond the list: sorted last, skipped below
+    if (i0 < n_valid) {
+      const int T0 = v.jobs[j0].T;
+      const long long loc = slot0 - v.jobs[j0].slot_off;
+      const int jrel = j0 - s_job[0];                                                // jobs in this block, in order
+      const int sub = (int)(loc & 1) * T0 + (int)((loc >> 1) % T0);                  // configuration-major, then top-edge sample
+      key = (jrel < SCORE_JOBS && sub < SCORE_SUB) ? jrel * SCORE_SUB + sub : SCORE_BINS - 1;
+    }
+    const int rank = atomicAdd(&hist[key], 1);
+    __syncthreads();
+    if (t0 < 64) {                              // exclusive prefix over the bins: 64 lanes x (SCORE_BINS + 1) / 64 bins each
+      constexpr int PER = (SCORE_BINS + 1 + 63) / 64;
+      int loc_sum = 0, vals[PER];
+#pragma unroll
+      for (int q = 0; q < PER; q++) { const int b = t0 * PER + q; vals[q] = b <= SCORE_BINS ? hist[b] : 0; loc_sum += vals[q]; }
+      int incl = loc_sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (t0 >= o) incl += y; }
+      int run = incl - loc_sum;
+#pragma unroll
+      for (int q = 0; q < PER; q++) { const int b = t0 * PER + q; if (b <= SCORE_BINS) hist[b] = run; run += vals[q]; }
+    }
+    __syncthreads();
+    s_src[hist[key] + rank] = t0;
+    __syncthreads();
+  }
+  const int mine = s_src[threadIdx.x];
+  const long long i = base + mine;
+  if (i >= n_valid) return;                     // (no barrier below this point)
+  const long long slot = s_slot[mine];
+  const int j = s_job[mine];
   const JobDesc jd = v.jobs[j];
   const long long local = slot - jd.slot_off;
   const int cfg = (int)(local & 1);          // 0 = configuration 1
@@ -281,19 +330,19 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
   {
     const double* co = v.corners + 16 * slot;
 #pragma unroll
-    for (int q = 0; q < 8; q++) { CX[tx][q] = co[q]; CY[tx][q] = co[8 + q]; }
+    for (int q = 0; q < 8; q++) { CXt[q][tx] = co[q]; CYt[q][tx] = co[8 + q]; }
   }
   const double ox = (double)jd.g.el, oy = (double)jd.g.et;
   const float* __restrict__ map = v.maps + jd.map_off;
   // ---- distance error: all gathers of an edge are issued before its (sequential, float) accumulation
   float sum_dist = 0;
-  const int EA1[9] = {0, 1, 2, 3, 1, 2, 3, 4, 4}, EB1[9] = {1, 2, 3, 0, 5, 4, 7, 7, 5};
-  const int EA2[9] = {0, 1, 2, 3, 1, 2, 4, 0, 0}, EB2[9] = {1, 2, 3, 0, 5, 4, 5, 0, 0};
-#pragma unroll
+  // corner ids of the 9 edges, one nibble each (edge 0 lowest): {0,1,2,3,1,2,3,4,4}-{1,2,3,0,5,4,7,7,5} / {0,1,2,3,1,2,4,0,0}-{1,2,3,0,5,4,5,0,0}
+  const unsigned long long EA = cfg ? 0x004213210ull : 0x443213210ull, EB = cfg ? 0x005450321ull : 0x577450321ull;
+#pragma unroll 1
   for (int e = 0; e < 9; e++) {
     const bool on = (e < 7) || (cfg == 0);
-    const int a = sel(cfg, EA1[e], EA2[e]), b = sel(cfg, EB1[e], EB2[e]);
-    const double x1 = CX[tx][a] - ox, y1 = CY[tx][a] - oy, x2 = CX[tx][b] - ox, y2 = CY[tx][b] - oy;
+    const int a = (int)((EA >> (4 * e)) & 7), b = (int)((EB >> (4 * e)) & 7);
+    const double x1 = CXt[a][tx] - ox, y1 = CYt[a][tx] - oy, x2 = CXt[b][tx] - ox, y2 = CYt[b][tx] - oy;
     float dv[11];
 #pragma unroll
     for (int s = 0; s < 11; s++) {
@@ -325,7 +374,7 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
 #pragma unroll
       for (int ee = 0; ee < 2; ee++) {
         int pa = sel(cfg, ID1[k][2 * ee], ID2[k][2 * ee]), pb = sel(cfg, ID1[k][2 * ee + 1], ID2[k][2 * ee + 1]);
-        double ang = normalize_to_pi(cs_atan2(CY[tx][pb] - CY[tx][pa], CX[tx][pb] - CX[tx][pa]));
+        double ang = normalize_to_pi(cs_atan2(CYt[pb][tx] - CYt[pa][tx], CXt[pb][tx] - CXt[pa][tx]));
         double best = 100;
         if (v0) { double t = dabs(ang - b0); t = dmin(t, CS_PI - t); if (t < best) best = t; }
         if (v1) { double t = dabs(ang - b1); t = dmin(t, CS_PI - t); if (t < best) best = t; }
@@ -338,7 +387,7 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
   // ---- half sizes of the lifted cuboid -> skew ratio, negative-scale flag
   V2 c[8];
 #pragma unroll
-  for (int q = 0; q < 8; q++) c[q] = v2(CX[tx][q], CY[tx][q]);
+  for (int q = 0; q < 8; q++) c[q] = v2(CXt[q][tx], CYt[q][tx]);
   const RpPose* pose = v.rp + jd.rp_off + rp;
   double p3[3], s3[3];
   lift_to_3d(c, pose->R, pose->t, v.invK + 9 * jd.frame, pose->plane, p3, s3);
