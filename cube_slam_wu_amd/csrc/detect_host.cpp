@@ -1118,7 +1118,9 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
   std::vector<int> fbq;
   for (size_t q = 0; q < nb; q++) if (S.h_fallback.p[q]) fbq.push_back((int)q);
   tm.n_fallback_boxes += (int)fbq.size();
-  d->pool->run((int)fbq.size(), [&](int z) { rank_on_host((size_t)fbq[z]); });
+  // (a handful of boxes: not worth waking the pool)
+  if (fbq.size() <= 24) { for (size_t z = 0; z < fbq.size(); z++) rank_on_host((size_t)fbq[z]); }
+  else d->pool->run((int)fbq.size(), [&](int z) { rank_on_host((size_t)fbq[z]); });
   MARK(8, tq);   // exact ranking of the tie boxes
   {
     std::vector<long long> ws;
@@ -1136,7 +1138,8 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
     }
   }
   MARK(9, tq);   // corners of the tie winners
-  d->pool->run((int)fbq.size(), [&](int z) { const size_t q = (size_t)fbq[z]; write_box(q, fb_winners[q].data(), (int)fb_winners[q].size()); });
+  if (fbq.size() <= 24) { for (size_t z = 0; z < fbq.size(); z++) { const size_t q = (size_t)fbq[z]; write_box(q, fb_winners[q].data(), (int)fb_winners[q].size()); } }
+  else d->pool->run((int)fbq.size(), [&](int z) { const size_t q = (size_t)fbq[z]; write_box(q, fb_winners[q].data(), (int)fb_winners[q].size()); });
   MARK(10, tq);  // records of the tie boxes
   tm.finalize_ms += now_ms() - t0;
   return CS_OK;

@@ -549,6 +549,7 @@ struct JobCut {      // per height sample of the box
   double vd, va;     // keep a proposal iff dist <= vd (and angle <= va when use_angle)
   double dmin, dmax, amin, amax;
   int use_angle, n_keep, V;
+  int tie;           // several proposals share the cut value vd, and which of them the reference keeps depends on its heap order
 };
 
 __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView rv, RankParams rp) {
@@ -572,9 +573,10 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
     const double* D = v.c_dist + c0;
     const double* A = v.c_angle + c0;
     double vd = INF, va = INF;
-    int use_angle = 0;
+    int use_angle = 0, tie = 0, c_tied = 0, bn_keep = 0;
     if (V > 4) {
       int bn = (int)round((double)((float)V) / 3.0 * 2.0);
+      bn_keep = bn - 1;
       unsigned long long kd = block_radix_select(D, V, bn - 2, hist, bcast);
       unsigned long long ka = block_radix_select(A, V, bn - 2, hist, bcast);
       int cd = 0, ca = 0, nan = 0;
@@ -584,8 +586,12 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
         nan += (d != d) || (a != a);
       }
       cd = block_reduce_sum_i(cd, shi); ca = block_reduce_sum_i(ca, shi); nan = block_reduce_sum_i(nan, shi);
-      // the (bn-1)-th and bn-th smallest distance errors must differ, else which one is kept depends on the heap
-      if ((cd != bn - 1 || nan) && threadIdx.x == 0) s_fallback = 1;
+      // the (bn-1)-th and bn-th smallest distance errors may coincide (float sums: 4 % of the boxes): then which of the tied
+      // proposals is kept depends on the heap order of std::partial_sort.  That is decided below -- the box only goes to the
+      // host when the choice can change the output
+      if (nan && threadIdx.x == 0) s_fallback = 1;
+      tie = (cd != bn - 1);
+      c_tied = cd;                 // becomes the number of proposals AT the cut value below
       use_angle = (ca == bn - 1);  // angle[sorted[bn-1]] > angle[sorted[bn-2]] (:766)
       // thresholds as doubles: the largest kept value
       double md = -INF, ma = -INF;
@@ -610,8 +616,29 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
     dmin = block_reduce_min(dmin, shd); dmax = block_reduce_max(dmax, shd);
     amin = block_reduce_min(amin, shd); amax = block_reduce_max(amax, shd);
     nk = block_reduce_sum_i(nk, shi);
+    if (tie) {
+      // The reference keeps all proposals below the cut value ("sure") and r >= 1 of the ct proposals at it.  The constants
+      // above were taken over sure + ALL tied proposals (that pass the angle cut).  They equal the reference's whatever it
+      // picks iff: two or more sure proposals are kept (same normalisation formula, dmin from a sure one), the tied ones do
+      // not extend the angle range, and -- with the angle cut on -- either none of the tied ones passes it or the reference
+      // cannot avoid keeping one that does (dmax = the cut value either way).  Then a tied proposal only matters if it wins.
+      double amin_s = 1e6, amax_s = -1;
+      int nk_s = 0, nt = 0, ct = 0, cl = 0;
+      for (int i = threadIdx.x; i < V; i += 256) {
+        double d = D[i], a = A[i];
+        const bool pass = !use_angle || a <= va;
+        if (d < vd) { cl++; if (pass) { nk_s++; amin_s = (a < amin_s) ? a : amin_s; amax_s = (amax_s < a) ? a : amax_s; } }
+        else if (d == vd) { ct++; nt += pass; }
+      }
+      amin_s = block_reduce_min(amin_s, shd); amax_s = block_reduce_max(amax_s, shd);
+      nk_s = block_reduce_sum_i(nk_s, shi); nt = block_reduce_sum_i(nt, shi); ct = block_reduce_sum_i(ct, shi); cl = block_reduce_sum_i(cl, shi);
+      const int r = bn_keep - cl;                  // tied proposals the reference keeps
+      const bool safe = nk_s >= 2 && amin_s == amin && amax_s == amax && (nt == 0 || r - (ct - nt) >= 1);
+      if (!safe && threadIdx.x == 0) s_fallback = 1;
+      (void)c_tied;
+    }
     if (threadIdx.x == 0) {
-      JobCut c; c.vd = vd; c.va = va; c.dmin = dmin; c.dmax = dmax; c.amin = amin; c.amax = amax; c.use_angle = use_angle; c.n_keep = nk; c.V = V;
+      JobCut c; c.vd = vd; c.va = va; c.dmin = dmin; c.dmax = dmax; c.amin = amin; c.amax = amax; c.use_angle = use_angle; c.n_keep = nk; c.V = V; c.tie = tie;
       cuts[h] = c;
     }
     __syncthreads();
@@ -672,6 +699,7 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
         double comb = score + rp.w_skew * skew_error;
         if (comb == gbest) {
           cnt++;
+          if (c.tie && d == c.vd) cnt += 2;   // a winner among the tied proposals: the reference may not have kept it -> host
           // the (unique) owner writes the winner record
           RankWinner* w = rv.winners + (size_t)box * rp.kmax + round;
           long long slot = v.c_slot[c0 + i];
