@@ -57,6 +57,9 @@ def main():
     share_gpu = os.environ.get("CS_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
+        # the banded solver's persistent kernels need all their workgroups co-resident: several processes on one device can
+        # only promise that for the small two-front teams (26 workgroups each), not for the nested order (106 each)
+        os.environ.setdefault("CS_BAND_TWO_FRONTS", "1")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
