@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0, help="worker threads of the host stages (0 = library default)")
     ap.add_argument("--ba", default="C4", choices=["C4", "C3", "none"], help="also time the g2o BA path (second half of the BASELINE metric)")
     ap.add_argument("--ba-iters", type=int, default=10)
+    ap.add_argument("--chunks", type=int, default=0, help="cut the batch into this many chunks of the two-slot host/GPU pipeline (0 = library default)")
     ap.add_argument("--no-edge", action="store_true", help="skip the distance-map front end (Canny + distance transform) timing")
     args = ap.parse_args()
 
@@ -91,7 +92,7 @@ def main():
         host_threads = max(8, min(64, (os.cpu_count() or 64) // world))
     params = capi.default_params(whether_sample_cam_roll_pitch=0, whether_sample_bbox_height=0, yaw_range_deg=45.0, yaw_step_deg=0.5, host_threads=host_threads)
     det = capi.Detector(params, device=local_rank)
-    bat = capi.Batch(det, frames)
+    bat = capi.Batch(det, frames, pipeline_chunks=(args.chunks if args.chunks > 0 else 1))
 
     for _ in range(args.warmup):
         bat.run()

@@ -149,6 +149,9 @@ CS_HD dd_t dd_atan_fast(double small, double big) {
   const double th = ns.hi * inv;
   const double r = __builtin_fma(-th, ds.hi, ns.hi) + (Nl - th * Dl);
   const double tl = r * inv;
+  // the error bound below assumes |t| <= 2^-9 (+ slack); should the table index ever be off, decline (NaN fails the caller's
+  // rounding test, which sends the call to the double-double evaluation)
+  if (!(th <= 0x1.1p-9 && th >= -0x1.1p-9)) return dd_t{__builtin_nan(""), 0.0};
   const double u = th * th;
   const double corr = th * (u * (-1.0 / 3.0 + u * (1.0 / 5.0 + u * (-1.0 / 7.0))));
   const dd_t s = dd_two_sum(ftab[i][0], th);
