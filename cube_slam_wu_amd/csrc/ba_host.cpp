@@ -227,7 +227,7 @@ int finalize_structure(cs_ba* B) {
       bw = std::max(bw, vdim(v) - 1);
       for (int w : adj[v]) { int lo = std::min(vcol(v), vcol(w)); int hi = (vcol(v) > vcol(w)) ? vcol(v) + vdim(v) - 1 : vcol(w) + vdim(w) - 1; bw = std::max(bw, hi - lo); }
     }
-    B->band_ld = (!B->force_dense && B->n_pose > 128 && bw + 1 <= B->n_pose / 2 && bw <= 4096) ? bw + 1 : 0;
+    B->band_ld = (!B->force_dense && B->n_pose > 128 && bw + 1 <= B->n_pose / 2 && bw <= 1900) ? bw + 1 : 0;   // (1900: two teams of ceil(bw / 16) + 1 workgroups must be co-resident on 256 CUs)
   }
   // ---- this rank's projection edges
   {

@@ -678,7 +678,11 @@ __device__ __attribute__((noinline)) bool band_potf2_inv_k1(const double (*U)[BS
 typedef const __attribute__((address_space(1))) double* band_gptr;   // global address space: a noinline function would otherwise emit flat loads
 __device__ __forceinline__ double band_gload(const double* p) { return *(band_gptr)(p); }
 
-enum { BAND_RW = 16, BAND_NR = BS + BAND_RW + 8, BAND_NRP = 64, BAND_NRT = BAND_NR / 8, BAND_TR = BAND_NRP / 8, BAND_DC = 192, BAND_NV = BAND_DC * BAND_NRP / 256 };
+// panel rows per workgroup, per kernel.  16 in both: 8 rows in the nested kernel (twice the workgroups, half the product and
+// panel work) was measured slower, 1.95 -> 2.15 ms at C4 -- what the halves save, the doubled teams lose in the barrier (2.5 ->
+// 4.6 us), the gather (more workgroups behind the same L2) and the wait for the diagonal workgroup
+enum { BAND_RW = 16, BAND_RW_NESTED = 16, BAND_NR = BS + BAND_RW + 8, BAND_NRP = 64, BAND_DC = 192, BAND_NV = BAND_DC * BAND_NRP / 256 };
+__host__ __device__ constexpr int band_rw(int kid) { return kid ? BAND_RW_NESTED : BAND_RW; }
 
 // An elimination front addresses the band through its own index space (v = 0 is where it starts): the forward front
 // walks the matrix top-left to bottom-right (v = original index), the reverse front bottom-right to top-left
@@ -714,10 +718,10 @@ __device__ __forceinline__ int band_seg_jmin(const BandSeg&) { return 0; }
 __device__ __forceinline__ int band_seg_jmin(const BandSegX& s) { return s.lc_jmin; }
 __device__ __forceinline__ int band_seg_t0(const BandSeg&) { return 0; }
 __device__ __forceinline__ int band_seg_t0(const BandSegX& s) { return s.lc_t0; }
-template <bool AUG, class SEG>
+template <bool AUG, class SEG, int RW>
 __device__ __forceinline__ void band_gather_gemm_impl(const SEG& s0, const SEG& s1, int nseg, const BandAug& aug, const double* zero, int n, int bw, int k0, int nb, const int* rowidx,
                                                            double* R, double (*U)[BS + 1], long long* tp, long long* t_prev) {
-  constexpr int NR = BAND_NR, NRP = BAND_NRP, NOWN = BAND_NR - BS, NRT = NOWN / 8, TR = NOWN / 8, NV = BAND_NV, DC = BAND_DC;
+  constexpr int NR = BS + RW + 8, NRP = BAND_NRP, NOWN = RW + 8, NRT = NOWN / 8, TR = NOWN / 8, NV = BAND_NV, DC = BAND_DC;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int cg = lane & 7, rgp = lane >> 3;     // register tile: own rows BS + 3 rgp .. + 2 (the block's 32 rows are only the other operand: their
                                                 // diagonal block belongs to the diagonal workgroup), columns 4 cg .. 4 cg + 3
@@ -810,16 +814,16 @@ __device__ __forceinline__ void band_gather_gemm_impl(const SEG& s0, const SEG& 
 __device__ __attribute__((noinline)) void band_gather_gemm_plain_k0(BandSeg s0, BandSeg s1, int nseg, const double* zero, int n, int bw, int k0, int nb, const int* rowidx,
                                                                     double* R, double (*U)[BS + 1], long long* tp, long long* t_prev) {
   const BandAug noaug{zero, 0, 0, 0, 0, nullptr, 0, 0, 0};
-  band_gather_gemm_impl<false, BandSeg>(s0, s1, nseg, noaug, zero, n, bw, k0, nb, rowidx, R, U, tp, t_prev);
+  band_gather_gemm_impl<false, BandSeg, band_rw(0)>(s0, s1, nseg, noaug, zero, n, bw, k0, nb, rowidx, R, U, tp, t_prev);
 }
 __device__ __attribute__((noinline)) void band_gather_gemm_plain_k1(BandSeg s0, BandSeg s1, int nseg, const double* zero, int n, int bw, int k0, int nb, const int* rowidx,
                                                                     double* R, double (*U)[BS + 1], long long* tp, long long* t_prev) {
   const BandAug noaug{zero, 0, 0, 0, 0, nullptr, 0, 0, 0};
-  band_gather_gemm_impl<false, BandSeg>(s0, s1, nseg, noaug, zero, n, bw, k0, nb, rowidx, R, U, tp, t_prev);
+  band_gather_gemm_impl<false, BandSeg, band_rw(1)>(s0, s1, nseg, noaug, zero, n, bw, k0, nb, rowidx, R, U, tp, t_prev);
 }
 __device__ __attribute__((noinline)) void band_gather_gemm_sep(BandSegX s0, BandSegX s1, int nseg, BandAug aug, const double* zero, int n, int bw, int k0, int nb, const int* rowidx,
                                                                double* R, double (*U)[BS + 1], long long* tp, long long* t_prev) {
-  band_gather_gemm_impl<true, BandSegX>(s0, s1, nseg, aug, zero, n, bw, k0, nb, rowidx, R, U, tp, t_prev);
+  band_gather_gemm_impl<true, BandSegX, band_rw(1)>(s0, s1, nseg, aug, zero, n, bw, k0, nb, rowidx, R, U, tp, t_prev);
 }
 
 // arrive without waiting (a workgroup that leaves the kernel): the release half of band_grid_sync
@@ -850,7 +854,7 @@ __device__ __forceinline__ void band_gather_gemm(const BandSegX& s0, const BandS
 template <bool AUG, int KID, class SEG>
 __device__ __forceinline__ void band_step(const BandLds& M, const BandView& view, double* Linv, int k0, int nb, int i_end, const SEG& s0, const SEG& s1, int nseg,
                                           const BandAug& aug, int w, int cw, bool has_rhs, int n, int bw, const double* zero, unsigned* dflag, unsigned dtarget, long long* tp, long long* t_prev) {
-  constexpr int RW = BAND_RW, NR = BAND_NR;
+  constexpr int RW = band_rw(KID), NR = BS + RW + 8;
   const int tid = threadIdx.x;
   const int own0 = k0 + nb + w * RW;
   if (tid < NR) {                                   // row (in the view's index space) of gathered row rr; -1 = none, -2 = right-hand side, <= -16: separator row
@@ -1131,7 +1135,7 @@ struct BandHalf {
 };
 struct BandNested {
   BandHalf h[2];
-  int n, bw, wc, c0, LD, G, GC;         // C = [c0, c0 + wc); G workgroups per front, GC for C's rows, GC for C's Schur complement
+  int n, bw, wc, c0, LD, G, GC, GS;     // C = [c0, c0 + wc); G workgroups per front, GC for C's rows (and C's own factorisation), GS Schur accumulators
   double* Sb; double* rhs; double* SC; double* rhsC; double* LinvC; double* part;
   const double* zero; int* info; unsigned* bars;   // bars: [half 0: team 0, team 1, join][half 1: ...][teams 1 + 2 of both halves][-][C team]
   long long* prof;                                 // optional phase stamps of half 0's team 1 (CS_BAND_PROF)
@@ -1149,7 +1153,7 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
   __shared__ int rowidx[BAND_NR];
   const BandLds M{R, U, Dl, X, colbuf, rowidx};
   const int tid = threadIdx.x;
-  const int G = P.G, G1 = P.G + P.GC, per = (G + 1) + (G1 + 1) + P.GC;   // team 0 + its diagonal workgroup, team 1 + its, team 2
+  const int G = P.G, G1 = P.G + P.GC, per = (G + 1) + (G1 + 1) + P.GS;   // team 0 + its diagonal workgroup, team 1 + its, team 2
   const int hid = blockIdx.x / per, r = blockIdx.x % per;
   const int team = r < G + 1 ? 0 : (r < G + 1 + G1 + 1 ? 1 : 2), wi = team == 2 ? r - (G + 1) - (G1 + 1) : (team ? r - (G + 1) : r);
   const bool diag = (team == 0 && wi == G) || (team == 1 && wi == G1);   // the front's diagonal workgroup
@@ -1175,7 +1179,7 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
   const bool stamp = P.prof && hid == 0 && team == 1 && wi == 0 && tid == 0;
 #define BAND_STAMP(k) do { if (stamp) P.prof[k] = wall_clock64(); } while (0)
   BAND_STAMP(0);
-  const int nslab = wc / 16;
+  const int nslab = P.GS, GCC = P.GC;   // Schur slabs of 16 rows; workgroups of C's own factorisation
   if (diag) {
     if (team == 0) { band_diag_phase<1>(M, H.fv, H.Linv_f, 0, m_begin, false, H.rv, 0, nullptr, 0, bars + 0, (unsigned)G, 0, dflag, 0, nh, bw, zero, P.info); return; }
     band_diag_phase<1>(M, H.rv, H.Linv_r, 0, Trev, false, H.fv, 0, nullptr, 0, bars + 1, (unsigned)G1, 0, dflag, 0, nh, bw, zero, P.info);
@@ -1183,7 +1187,7 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
     if (hid != 0) return;
     const BandView vcd{P.SC, 1, (long long)wc, P.rhsC, 1};
     const unsigned km = (unsigned)((m_end - m_begin + BS - 1) / BS);
-    band_diag_phase<1>(M, vcd, P.LinvC, 0, wc, false, vcd, 0, P.bars + 8, (unsigned)nslab, P.bars + 8, (unsigned)nslab, 1, dflag, (unsigned)H.K2 + km, wc, wc - 1, zero, P.info);
+    band_diag_phase<1>(M, vcd, P.LinvC, 0, wc, false, vcd, 0, P.bars + 8, (unsigned)GCC, P.bars + 8, (unsigned)GCC, 1, dflag, (unsigned)H.K2 + km, wc, wc - 1, zero, P.info);
     return;
   }
   if (team == 0) {
@@ -1272,9 +1276,9 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
   BAND_STAMP(3);
   band_grid_sync(P.bars + 6, 2u * (unsigned)(G1 + nslab));
   BAND_STAMP(4);
-  if (hid != 0 || wi >= nslab) return;
-  // ---- the C team: Schur complement of its row slab (lower triangle), then the dense factorisation
-  {
+  if (hid != 0 || wi >= GCC) return;
+  // ---- the C team: Schur complement of its row slab (lower triangle; the first GS workgroups, 16 rows each), then the dense factorisation
+  if (wi < nslab) {
     const int ldb = wc + 1, rr = tid >> 4, cg = tid & 15, i = wi * 16 + rr;
     for (int j = cg; j <= wc; j += 16) {
       const double s = P.part[(size_t)i * ldb + j] + P.part[((size_t)wc + i) * ldb + j];
@@ -1286,14 +1290,14 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
     }
   }
   unsigned epc = 1;
-  band_grid_sync(P.bars + 8, epc * (unsigned)nslab);
+  band_grid_sync(P.bars + 8, epc * (unsigned)GCC);
   BAND_STAMP(7);
   const BandView vc{P.SC, 1, (long long)wc, P.rhsC, 1};
   for (int k0 = 0; k0 < wc; k0 += BS) {
     const BandSeg s0{vc, 0, k0, 0};
-    band_step<false, 1>(M, vc, P.LinvC, k0, BS, wc, s0, none, 1, noaug, wi, -1, wi == nslab - 1, wc, wc - 1, zero, dflag, ep + epc, tpp, &t_prev);
+    band_step<false, 1>(M, vc, P.LinvC, k0, BS, wc, s0, none, 1, noaug, wi, -1, wi == GCC - 1, wc, wc - 1, zero, dflag, ep + epc, tpp, &t_prev);
     epc++;
-    band_grid_sync(P.bars + 8, epc * (unsigned)nslab);
+    band_grid_sync(P.bars + 8, epc * (unsigned)GCC);
   }
   BAND_STAMP(8);
 #undef BAND_STAMP
@@ -1490,14 +1494,14 @@ void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rh
     P.part = wp; wp += (size_t)2 * wc * (wc + 1);
     P.SC = wp; wp += (size_t)wc * wc;
     P.rhsC = wp; wp += wc;
-    P.n = n; P.bw = bw; P.wc = wc; P.c0 = c0; P.LD = LD; P.G = G; P.GC = wc / 16;
+    P.n = n; P.bw = bw; P.wc = wc; P.c0 = c0; P.LD = LD; P.G = (bw + BAND_RW_NESTED - 1) / BAND_RW_NESTED; P.GC = wc / BAND_RW_NESTED; P.GS = wc / 16;
     const int G1 = P.G + P.GC;
     P.Sb = Sb; P.rhs = rhs; P.zero = zero; P.info = info; P.bars = reinterpret_cast<unsigned*>(info + 6);
     static const bool want_stamps = getenv("CS_BAND_PROF") != nullptr;
     static long long* stamps = nullptr;
     if (want_stamps && !stamps) (void)hipMalloc(&stamps, 34 * sizeof(long long));
     P.prof = stamps;
-    hipLaunchKernelGGL(band_chol_nested_kernel, dim3(2 * (P.G + 1 + G1 + 1 + P.GC)), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(band_chol_nested_kernel, dim3(2 * (P.G + 1 + G1 + 1 + P.GS)), dim3(256), 0, st, P);
     if (stamps) {
       long long h[34];
       (void)hipMemcpyAsync(h, stamps, sizeof(h), hipMemcpyDeviceToHost, st);
