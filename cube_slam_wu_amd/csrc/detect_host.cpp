@@ -1532,7 +1532,6 @@ extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* ou
           std::vector<std::vector<long long>> hsl(nh);
           for (int h = 0; h < nh; h++) {
             int j = j0 + h;
-            long long c0 = b->h_job_cbase.p[j];
             int V = b->h_job_valid.p[j];
             long long p0 = fb_dst[fb_range_of_job[j]];
             hd[h].assign(fb_dist.begin() + p0, fb_dist.begin() + p0 + V); ha[h].assign(fb_angle.begin() + p0, fb_angle.begin() + p0 + V);

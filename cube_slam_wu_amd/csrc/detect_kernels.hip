@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
     const double* D = v.c_dist + c0;
     const double* A = v.c_angle + c0;
     double vd = INF, va = INF;
-    int use_angle = 0, tie = 0, c_tied = 0, bn_keep = 0;
+    int use_angle = 0, tie = 0, bn_keep = 0;
     if (V > 4) {
       int bn = (int)round((double)((float)V) / 3.0 * 2.0);
       bn_keep = bn - 1;
@@ -591,7 +591,6 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
       // host when the choice can change the output
       if (nan && threadIdx.x == 0) s_fallback = 1;
       tie = (cd != bn - 1);
-      c_tied = cd;                 // becomes the number of proposals AT the cut value below
       use_angle = (ca == bn - 1);  // angle[sorted[bn-1]] > angle[sorted[bn-2]] (:766)
       // thresholds as doubles: the largest kept value
       double md = -INF, ma = -INF;
@@ -635,7 +634,6 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
       const int r = bn_keep - cl;                  // tied proposals the reference keeps
       const bool safe = nk_s >= 2 && amin_s == amin && amax_s == amax && (nt == 0 || r - (ct - nt) >= 1);
       if (!safe && threadIdx.x == 0) s_fallback = 1;
-      (void)c_tied;
     }
     if (threadIdx.x == 0) {
       JobCut c; c.vd = vd; c.va = va; c.dmin = dmin; c.dmax = dmax; c.amin = amin; c.amax = amax; c.use_angle = use_angle; c.n_keep = nk; c.V = V; c.tie = tie;
@@ -648,7 +646,7 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
   int n_win = 0;
   for (int round = 0; round < rp.kmax; round++) {
     double best = INF;
-    int best_h = -1, best_i = -1, bad = 0;
+    int bad = 0;
     for (int h = 0; h < nj; h++) {
       const JobCut c = cuts[h];
       long long c0 = v.job_cbase[j0 + h];
@@ -669,7 +667,7 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
         if (sk > rp.max_cut_skew) skew_error = 100;
         double comb = score + rp.w_skew * skew_error;
         if (comb != comb || comb == INF || comb == -INF) { bad = 1; continue; }  // NaN / inf: let the host decide
-        if (comb > prev && comb < best) { best = comb; best_h = h; best_i = i; }
+        if (comb > prev && comb < best) best = comb;
       }
     }
     bad = block_reduce_sum_i(bad, shi);
