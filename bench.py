@@ -21,6 +21,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP64_FLOP_PER_PROPOSAL = 1400.0
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak = half the FP32 vector peak of MI355X_MICROARCH.md (157.3)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -207,6 +209,11 @@ def main():
                        "valid_proposals_per_frame": acc["n_valid"] / args.steps / args.frames, "parallelism": "frames sharded, no collective"},
             "roofline": {"kernel": "score_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": kern_ms,
+                         # the per-proposal math is FP64 vector ALU -- both fractions, the larger one names the bound.
+                         # ~1400 FP64 flop per valid proposal: 88 map samples x 6, six cs_atan2 (light path ~90) + comparisons, the 3D lift
+                         "fp64_alu": {"flop_per_valid_proposal": FP64_FLOP_PER_PROPOSAL, "achieved": FP64_FLOP_PER_PROPOSAL * (acc["n_valid"] / launches) / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0,
+                                      "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": FP64_FLOP_PER_PROPOSAL * (acc["n_valid"] / launches) / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS if kern_ms > 0 else 0.0},
                          "other_kernels": {"candidate_kernel": {"ms": geo_ms, "alg_bytes": geo_bytes, "GB/s": geo_bytes / (geo_ms * 1e-3) / 1e9 if geo_ms > 0 else 0.0}}},
             "stage_ms_per_step": {k: acc[k] / args.steps for k in acc if k.endswith("_ms")},
             "fallback_boxes_per_step": acc["n_fallback_boxes"] / args.steps,
