@@ -1071,13 +1071,6 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
     }
     C.out_counts[(size_t)f * MB + bi] = nw;
   };
-  d->pool->run((int)nb, [&](int qi) {
-    const size_t q = (size_t)qi;
-    if (!S.h_fallback.p[q]) write_box(q, S.h_winners.p + q * KMAX, S.h_win_count.p[q]);
-  });
-  MARK(6, tq);   // records of the device-ranked boxes
-  if (!fb_src.empty()) HIP_TRY(hipStreamSynchronize(st2));
-  MARK(7, tq);   // wait for the tie columns
   const double* fb_dist = S.h_fb_dist.p; const double* fb_angle = S.h_fb_angle.p; const double* fb_skew = S.h_fb_skew.p;
   const int* fb_flag = S.h_fb_flag.p; const long long* fb_slot = S.h_fb_slot.p;
   std::vector<std::vector<cs::RankWinner>> fb_winners(nb);
@@ -1118,9 +1111,26 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
   std::vector<int> fbq;
   for (size_t q = 0; q < nb; q++) if (S.h_fallback.p[q]) fbq.push_back((int)q);
   tm.n_fallback_boxes += (int)fbq.size();
-  // (a handful of boxes: not worth waking the pool)
-  if (fbq.size() <= 24) { for (size_t z = 0; z < fbq.size(); z++) rank_on_host((size_t)fbq[z]); }
-  else d->pool->run((int)fbq.size(), [&](int z) { rank_on_host((size_t)fbq[z]); });
+  auto records = [&](int qi) {
+    const size_t q = (size_t)qi;
+    if (!S.h_fallback.p[q]) write_box(q, S.h_winners.p + q * KMAX, S.h_win_count.p[q]);
+  };
+  static const bool tie_separate = getenv("CS_TIE_SEPARATE_PASS") != nullptr;   // diagnostics: always the two-pass order
+  if (fbq.size() <= 64 && !tie_separate) {
+    // a handful of tie boxes (the usual case): their columns are a few kilobytes and already here; their exact ranking
+    // (tens of microseconds each) rides in the same parallel pass as the records of the other boxes, first in the queue
+    if (!fb_src.empty()) HIP_TRY(hipStreamSynchronize(st2));
+    MARK(7, tq);   // wait for the tie columns
+    const int nfb = (int)fbq.size();
+    d->pool->run(nfb + (int)nb, [&](int z) { if (z < nfb) rank_on_host((size_t)fbq[z]); else records(z - nfb); });
+    MARK(6, tq);   // records of the device-ranked boxes (+ exact ranking of the tie boxes)
+  } else {
+    d->pool->run((int)nb, records);
+    MARK(6, tq);   // records of the device-ranked boxes, written while the tie boxes' columns travel
+    if (!fb_src.empty()) HIP_TRY(hipStreamSynchronize(st2));
+    MARK(7, tq);   // wait for the tie columns
+    d->pool->run((int)fbq.size(), [&](int z) { rank_on_host((size_t)fbq[z]); });
+  }
   MARK(8, tq);   // exact ranking of the tie boxes
   {
     std::vector<long long> ws;

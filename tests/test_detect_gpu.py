@@ -184,6 +184,18 @@ def test_device_ranking_falls_back_on_ties():
     assert tm["n_fallback_boxes"] == 3
 
 
+def test_many_tie_boxes_take_the_separate_host_pass():
+    """More than 64 boxes whose ties reach the output (constant maps again): the host ranks them in their own parallel pass
+    after the records of the other boxes instead of inside it."""
+    frames = []
+    for s in range(10):
+        fr = synth.make_frame(8400 + s, n_boxes=8, n_lines=150)
+        fr["maps"] = [[np.zeros_like(m) for m in mm] for mm in fr["maps"]]
+        frames.append(fr)
+    n, tm = _check_final(frames, capi.default_params(whether_sample_cam_roll_pitch=0))
+    assert tm["n_fallback_boxes"] == 80
+
+
 def test_host_ranking_path_still_exact():
     frames = [synth.make_frame(8300)]
     det = capi.Detector(capi.default_params(whether_sample_cam_roll_pitch=0))
