@@ -29,8 +29,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=1000, help="frames per batch (per GPU)")
     ap.add_argument("--unique", type=int, default=100, help="distinct synthetic frames generated (tiled to --frames)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
@@ -91,7 +91,14 @@ def main():
     # host stages run on a worker pool per rank: with N ranks on one node the pools share the host's cores
     host_threads = args.host_threads
     if host_threads == 0 and world > 1:
-        host_threads = max(8, min(64, (os.cpu_count() or 64) // world))
+        cpus = os.cpu_count() or 64
+        try:   # a cgroup CPU quota is what the ranks really share (three threads per granted CPU, as the library's default)
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                cpus = min(cpus, 3 * int(q) // int(per))
+        except (OSError, ValueError):
+            pass
+        host_threads = max(8, min(64, cpus // world))
     params = capi.default_params(whether_sample_cam_roll_pitch=0, whether_sample_bbox_height=0, yaw_range_deg=45.0, yaw_step_deg=0.5, host_threads=host_threads)
     det = capi.Detector(params, device=local_rank)
     bat = capi.Batch(det, frames, pipeline_chunks=(args.chunks if args.chunks > 0 else 1))

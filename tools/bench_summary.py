@@ -1,5 +1,6 @@
 import sys, json
-for line in sys.stdin:
+src = open(sys.argv[1]) if len(sys.argv) > 1 else sys.stdin   # a file argument, or a pipe
+for line in src:
     line=line.strip()
     if not line.startswith('{'): continue
     d=json.loads(line)
