@@ -583,16 +583,20 @@ __global__ __launch_bounds__(256) void ba_update_kernel(BaView v) {
 // ------------------------------------------------------------------ banded Cholesky of the reduced system --
 // The pose graph of a trajectory is banded once its vertices are ordered by reverse Cuthill-McKee: cameras are
 // coupled to the few neighbours they share landmarks with and to the cuboids they observe.  S is stored as a lower
-// band (LD = bandwidth + 1 doubles per column): n * bw^2 flops instead of n^3 / 3 (1 Gflop instead of 385 Gflop at
-// C4, n = 10491, bw ~ 300).  So little arithmetic that the factorisation is a chain of n / 32 dependent steps and
-// its cost is their latency; it therefore runs as ONE persistent kernel:
-//   band_chol_coop_kernel   left-looking over column blocks of BS = 32.  Per step every workgroup gathers the block
-//                           row's history (32 x bw strip of L) through LDS, updates + factorises the diagonal block
-//                           redundantly (POTF2 and its inverse in the registers of one wave), updates and scales its
-//                           own RW panel rows, and meets the others at a grid barrier (one per step).  The right-hand
+// band (LD = bandwidth + 1 doubles per column): n * bw^2 flops instead of n^3 / 3 (0.35 Gflop instead of 385 Gflop at
+// C4, n = 10494, bw = 182).  So little arithmetic that the factorisation is a chain of dependent 32-column steps and
+// its cost is their latency; it therefore runs as ONE persistent (co-resident) kernel, left-looking over column blocks:
+//   band_step               a worker workgroup's step: gather the block row's history (64-row x bw strip of L: the block's 32
+//                           rows + its own 16 panel rows) through LDS, multiply its rows against the block rows, scale by
+//                           the inverse of the diagonal block's factor, meet the team at a grid barrier.  The right-hand
 //                           side rides along as one more row below the band, so L y = b costs no extra step.
-//   band_backsolve_kernel   L^T x = y, one workgroup walking the column blocks backwards with the inverted diagonal
-//                           blocks (two small mat-vecs per step, one global round trip).
+//   band_diag_phase         one extra workgroup per front factorises the diagonal blocks (POTF2 + inverse in the registers
+//                           of one wave) one step ahead of the workers and publishes the inverses.
+//   band_chol_coop_kernel   two fronts (forward from the top, reverse from the bottom) + the middle block.
+//   band_chol_nested_kernel four fronts: a separator block splits the band in two halves, each eliminated at both ends;
+//                           the separator's rows ride along, its Schur complement is accumulated beside the fronts.
+//   band_backsolve_kernel   L^T x = y per front with the inverted diagonal blocks (two small mat-vecs per step, every load
+//                           that does not depend on x prefetched one step ahead); band_sep_* handle the separator.
 enum { BS = 32 };
 
 // All workgroups of the (co-resident) grid arrive; thread 0 spins on the monotone counter.  Producer side: every
