@@ -156,3 +156,34 @@ def test_batch_from_gray_images_equals_batch_from_host_maps():
     assert a.raw_out_bytes() == b.raw_out_bytes() and a.counts_bytes() == b.counts_bytes()
     assert sum(len(c) for f in range(len(frames)) for c in a.cuboids(f)) >= 10
     a.close(); b.close(); det.close()
+
+
+def test_reference_tum_frames_image_in_on_the_device_equal_the_oracle():
+    """The reference's 51 bundled TUM frames with a 2D box (tests/tum_frames.py; tests/test_reference_frames.py compares the
+    oracle's cuboids with the detections the reference saved for them): cs_bgr_to_gray + cs_detect_cuboids_gray, image in /
+    cuboid out on the device, are bit-identical to the oracle's gray conversion, maps and sweep on every frame."""
+    pytest.importorskip("PIL")
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import tum_frames
+    det = capi.Detector(capi.default_params(whether_sample_cam_roll_pitch=0, nominal_skew_ratio=2.0))
+    op = oracle_py.default_params(nominal_skew_ratio=2.0)
+    n = 0
+    for k in tum_frames.frame_ids():
+        fr, gray, _ = tum_frames.load(k, E.bgr_to_gray)
+        got = det.detect_gray(fr, gray)
+        maps = []
+        for (l, t, w, h), _ in fr["rois"][0]:
+            buf = np.zeros(h * w + w + 1, np.float32)
+            buf[: h * w] = E.edge_distance_map(gray, (l, t, w, h)).ravel()
+            maps.append(buf)
+        fr["maps"] = [maps]
+        ref, _ = oracle_py.detect_cuboid(fr, op, atan2_mode=1)
+        assert len(got[0]) == len(ref[0]) == 1, k
+        for key in got[0][0]:
+            a, b = np.asarray(got[0][0][key]), np.asarray(ref[0][0][key])
+            assert np.array_equal(a, b, equal_nan=True) if a.dtype.kind == "f" else np.array_equal(a, b), (k, key)
+        n += 1
+    assert n == 51
+    det.close()
