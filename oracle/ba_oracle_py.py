@@ -225,6 +225,109 @@ def run_offline_sequence(data_dir, make_problem=None, n_frames=None):
     return np.array(out_cam), np.array(out_obj), np.array(iters), np.array([se3_inv(t) for t in cam_Tcw])
 
 
+def _rot_to_quat(R):
+    """Eigen Quaterniond(Matrix3d) (the constructor g2o::SE3Quat(R, t) goes through), x y z w."""
+    t = R[0, 0] + R[1, 1] + R[2, 2]
+    if t > 0:
+        s = np.sqrt(t + 1.0)
+        w = 0.5 * s
+        s = 0.5 / s
+        return np.array([(R[2, 1] - R[1, 2]) * s, (R[0, 2] - R[2, 0]) * s, (R[1, 0] - R[0, 1]) * s, w])
+    i = 0
+    if R[1, 1] > R[0, 0]:
+        i = 1
+    if R[2, 2] > R[i, i]:
+        i = 2
+    j, k = (i + 1) % 3, (i + 2) % 3
+    s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0)
+    q = np.zeros(4)
+    q[i] = 0.5 * s
+    s = 0.5 / s
+    q[3] = (R[k, j] - R[j, k]) * s
+    q[j] = (R[j, i] + R[i, j]) * s
+    q[k] = (R[k, i] + R[i, k]) * s
+    return q
+
+
+def _quat_to_rot(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def run_online_sequence(data_dir, load_frame, detect, make_problem=None):
+    """incremental_build_graph() in ONLINE mode (object_slam/src/main_obj.cpp:479-841 with the branch :585-680): every frame
+    is detected from its image, the detection becomes the cuboid measurement, the graph grows and is optimised.
+
+    load_frame(k) -> (frame dict without pose, gray image) or None when the frame has no 2D box (an empty yolo file: no
+    detection, :619-641); detect(frame, gray, sample_roll_pitch) -> cuboid dict or None.  The camera pose handed to the detector
+    is the current estimate for frame 0 and the FIRST frame's pose with roll/pitch sampling for all later frames (:624-629);
+    with sampling, the measurement is re-expressed in the sampled camera frame (:660-668).  Returns the cuboid after every
+    frame (n x 9 minimal) and the final camera poses Twc (n x 7).
+    """
+    truth = np.loadtxt(os.path.join(data_dir, "truth_cam_poses.txt"))
+    fixed_init_Twc = se3_mul(IDENT7, truth[0, 1:8])
+    mk = make_problem or (lambda **kw: _oracle_problem(**kw))
+    cam_Tcw, cub_edges, odom_edges, out_obj = [], [], [], []
+    cube = None
+    n_det = 0
+    for k in range(len(truth)):
+        odom_val = IDENT7.copy()
+        if k == 0:
+            Twc = fixed_init_Twc
+        else:
+            prev = cam_Tcw[k - 1]
+            if k > 1:
+                odom_val = se3_mul(prev, se3_inv(cam_Tcw[k - 2]))
+            Twc = se3_inv(se3_mul(odom_val, prev))
+        has = False
+        loaded = load_frame(k)
+        if loaded is not None:
+            fr, gray = loaded
+            sample = int(k != 0)
+            pose = fixed_init_Twc if sample else Twc
+            T = np.eye(4)
+            T[:3, :3] = _quat_to_rot(pose[3:7])
+            T[:3, 3] = pose[:3]
+            fr = dict(fr, T_wc=T)
+            c = detect(fr, gray, sample)
+            if c is not None:
+                has = True
+                n_det += 1
+                ground = cuboid_from_minimal([c["pos"][0], c["pos"][1], c["pos"][2], 0, 0, c["rotY"], c["scale"][0], c["scale"][1], c["scale"][2]])
+                local = cuboid_transform(ground, Twc, True)
+                if sample:   # the camera frame the detector actually used: sampled roll / pitch at the first frame's position
+                    qx, qy, qz, qw = _rot_to_quat(T[:3, :3])
+                    roll = np.arctan2(2 * (qw * qx + qy * qz), 1 - 2 * (qx * qx + qy * qy)) + c["camera_roll_delta"]
+                    pitch = np.arcsin(2 * (qw * qy - qz * qx)) + c["camera_pitch_delta"]
+                    yaw = np.arctan2(2 * (qw * qz + qx * qy), 1 - 2 * (qy * qy + qz * qz))
+                    cr, sr, cp, sp, cy, sy = np.cos(roll), np.sin(roll), np.cos(pitch), np.sin(pitch), np.cos(yaw), np.sin(yaw)
+                    Rn = np.array([[cp * cy, sr * sp * cy - cr * sy, cr * sp * cy + sr * sy],
+                                   [cp * sy, sr * sp * sy + cr * cy, cr * sp * sy - sr * cy],
+                                   [-sp, sr * cp, cr * cp]])    # euler_zyx_to_rot (matrix_utils.cpp:84-99)
+                    local = cuboid_transform(ground, se3_mul(IDENT7, np.concatenate([T[:3, 3], _rot_to_quat(Rn)])), True)
+                quality = (1 - c["normalized_error"] + 0.5) / 2
+        if k == 0:
+            cube = cuboid_transform(local, Twc, False)
+        cam_Tcw.append(se3_inv(Twc))
+        if has:
+            inv_sigma = np.ones(9) * 2.0 * quality
+            cub_edges.append((k, local, np.diag(inv_sigma * inv_sigma).ravel()))
+        if k > 0:
+            odom_edges.append((k - 1, k, odom_val))
+        fixed = np.zeros(len(cam_Tcw), np.int32)
+        fixed[0] = 1
+        P = mk(cams=np.array(cam_Tcw), cam_fixed=fixed, cuboid=cube, cub_edges=cub_edges, odom_edges=odom_edges)
+        P.optimize(5)
+        c_state, o_state, _ = P.state()
+        cam_Tcw = [c_state[i].copy() for i in range(len(c_state))]
+        cube = o_state[0].copy()
+        P.close()
+        out_obj.append(cuboid_to_minimal(cube))
+    return np.array(out_obj), np.array([se3_inv(t) for t in cam_Tcw]), n_det
+
+
 def _oracle_problem(cams, cam_fixed, cuboid, cub_edges, odom_edges):
     P = Problem(cams, cam_fixed, cuboids=cuboid[None, :], cub_fixed=[0], cuboids_first=True)
     if cub_edges:

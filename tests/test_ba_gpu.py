@@ -149,6 +149,42 @@ def test_graph_driver_reads_and_writes_the_reference_formats(tmp_path):
     assert np.abs(cams6[:, 1:4] - saved_cam[:, 1:4]).max() < 0.6
 
 
+def test_online_run_on_the_device_reproduces_the_references_saved_outputs():
+    """main_obj.cpp's ONLINE mode over the reference's 58 bundled TUM frames with both paths on the device: every frame's
+    cuboid from cs_detect_cuboids_gray (image in; roll/pitch sampling from the second frame on), the growing graph optimised by
+    cs_ba_optimize.  Checked against the two result files the reference saved from its own run (object position to
+    millimetres in every frame) and against the same pipeline on the two oracles."""
+    pytest.importorskip("PIL")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_reference_frames as TR
+    import tum_frames
+    from oracle import edge_oracle_py as E
+    dets = [capi.Detector(capi.default_params(whether_sample_cam_roll_pitch=s, nominal_skew_ratio=2.0)) for s in (0, 1)]
+
+    def detect(fr, gray, sample):
+        got = dets[sample].detect_gray(fr, gray)
+        return got[0][0] if got[0] else None
+
+    def mk(cams, cam_fixed, cuboid, cub_edges, odom_edges):
+        P = capi.BaProblem(cams, cam_fixed, cuboids=cuboid[None, :], cub_fixed=[0], cuboids_first=True)
+        if cub_edges:
+            P.set_edges_cuboid([e[0] for e in cub_edges], [0] * len(cub_edges), np.array([e[1] for e in cub_edges]), np.array([e[2] for e in cub_edges]))
+        if odom_edges:
+            P.set_edges_odom([e[0] for e in odom_edges], [e[1] for e in odom_edges], np.array([e[2] for e in odom_edges]), np.tile(np.eye(6).ravel(), (len(odom_edges), 1)))
+        return P
+
+    loader = lambda k: tum_frames.load_for_online_run(k, E.bgr_to_gray)
+    obj_g, cam_g, n_g = O.run_online_sequence(tum_frames.DATA, loader, detect, make_problem=mk)
+    assert n_g == 51
+    TR.check_online_run_against_saved_outputs(obj_g, cam_g)
+    obj_r, cam_r, _ = O.run_online_sequence(tum_frames.DATA, loader, TR._oracle_detect)
+    assert np.abs(obj_g - obj_r).max() < 1e-5 * max(1.0, np.abs(obj_r).max())
+    assert np.abs(cam_g - cam_r).max() < 1e-5 * max(1.0, np.abs(cam_r).max())
+    for d in dets:
+        d.close()
+
+
 def _run_sharded_in_threads(pr, n_ranks, iters):
     """n_ranks cs_ba instances on one GPU, one thread each, with an in-process all-reduce (sum / max over threads)."""
     import ctypes as C

@@ -10,6 +10,7 @@ to the three digits the file carries, and up to the different segment detector.
 import numpy as np
 import pytest
 
+from oracle import ba_oracle_py as O
 from oracle import edge_oracle_py as E
 from oracle import oracle_py
 
@@ -52,3 +53,36 @@ def test_oracle_reproduces_the_references_saved_detections():
     assert (dxy < 0.2).mean() > 0.9 and dxy.max() < 0.5
     assert (steps == 0).mean() >= 0.5 and steps.max() <= 2
     assert exact >= 18
+
+
+def _oracle_detect(fr, gray, sample_roll_pitch):
+    maps = []
+    for (l, t, w, h), _ in fr["rois"][0]:
+        buf = np.zeros(h * w + w + 1, np.float32)
+        buf[: h * w] = E.edge_distance_map(gray, (l, t, w, h)).ravel()
+        maps.append(buf)
+    res, _ = oracle_py.detect_cuboid(dict(fr, maps=[maps]), oracle_py.default_params(nominal_skew_ratio=2.0, whether_sample_cam_roll_pitch=sample_roll_pitch))
+    return res[0][0] if res[0] else None
+
+
+def check_online_run_against_saved_outputs(out_obj, final_cams):
+    """output_obj_poses.txt / output_cam_poses.txt are what the reference wrote after its own online run over these images."""
+    import os
+    so = np.loadtxt(os.path.join(tum_frames.DATA, "output_obj_poses.txt"))
+    sc = np.loadtxt(os.path.join(tum_frames.DATA, "output_cam_poses.txt"))
+    assert out_obj.shape == so.shape == (58, 9)
+    assert np.linalg.norm(out_obj[:, :3] - so[:, :3], axis=1).max() < 0.003            # object position: millimetres, every frame
+    dyaw = (out_obj[:, 5] - so[:, 5] + np.pi / 4) % (np.pi / 2) - np.pi / 4
+    assert np.abs(dyaw).max() < 0.003 and np.abs(out_obj[:, 3:5] - so[:, 3:5]).max() < 0.002
+    assert np.abs(out_obj[:, 6:] - so[:, 6:]).max() < 0.012                            # half sizes (they average the detections)
+    d = np.linalg.norm(final_cams[:, :3] - sc[:, 1:4], axis=1)
+    assert d.mean() < 0.05 and d.max() < 0.2                                           # cameras follow the single detections
+
+
+def test_online_run_reproduces_the_references_saved_outputs():
+    """Image in, trajectory and object out: the detector oracle (roll/pitch sampling as the reference's online branch uses it)
+    feeding the bundle-adjustment oracle through main_obj.cpp's online graph construction, against the two result files the
+    reference saved from its own run.  Both paths and the driver between them are pinned here -- up to the segment detector."""
+    out_obj, final_cams, n_det = O.run_online_sequence(tum_frames.DATA, lambda k: tum_frames.load_for_online_run(k, E.bgr_to_gray), _oracle_detect)
+    assert n_det == 51
+    check_online_run_against_saved_outputs(out_obj, final_cams)

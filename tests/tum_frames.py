@@ -53,3 +53,12 @@ def load(k, bgr_to_gray):
     row = saved[saved[:, 0] == k][0][1:]
     fr = dict(K=K_TUM, T_wc=T, boxes=box, lines=lines, rois=[synth.box_rois(box[0], W, H, False)], img_w=W, img_h=H)
     return fr, gray, row
+
+
+def load_for_online_run(k, bgr_to_gray):
+    """(frame dict without pose and maps, gray) of frame k for oracle.ba_oracle_py.run_online_sequence, None without a 2D box."""
+    if os.path.getsize(os.path.join(DATA, "filter_2d_obj_txts", "%04d_yolo2_0.15.txt" % k)) == 0:
+        return None
+    fr, gray, _ = load(k, bgr_to_gray)
+    fr.pop("T_wc")
+    return fr, gray
