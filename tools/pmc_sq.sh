@@ -10,7 +10,7 @@ for d in ("gpurun_out/pmc_${tag}_sq", "gpurun_out/pmc_${tag}_sq2"):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     names = sorted({c for k in acc for c in acc[k]})
     print("kernel," + ",".join(names))
