@@ -12,8 +12,16 @@
 // linearisation, Schur reduction and solve on the device.  Outputs follow :305-336: output_cam_poses.txt (final camera
 // poses, camera-to-world) and output_obj_poses.txt (the cuboid after every frame as toMinimalVector).
 //
+// With --online the driver follows the reference's online branch instead (:585-680): every frame's colour image is read
+// (binary PPM here; the reference reads the JPEG with cv::imread), converted with cs_bgr_to_gray (cvtColor) and handed to
+// cs_detect_cuboids_gray together with the frame's first 2D box (filter_2d_obj_txts/NNNN_yolo2_0.15.txt, 1-based, :619-621)
+// and its line segments (one x1 y1 x2 y2 row per segment; the reference gets them from line_lbd, :590-597).  The camera pose
+// handed to the detector is the current estimate for frame 0 and the first frame's pose with roll/pitch sampling afterwards
+// (:623-629); with sampling the measurement is re-expressed in the sampled camera frame (:660-668).
+//
 //   g++ -O2 -I include -I cube_slam_wu_amd/csrc examples/object_slam_main.cpp -L cube_slam_wu_amd -lcubeslam_hip ... -o build_tmp/object_slam_main
 //   build_tmp/object_slam_main <data_dir> <out_dir> [digits]
+//   build_tmp/object_slam_main --online <data_dir> <ppm_dir> <segments_dir> <out_dir> [digits]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -83,20 +91,79 @@ static void cuboid_to_minimal(const Cube& c, double* o) {
 static Cube cuboid_transform_to(const Cube& c, const Pose& Twc) { Cube r = c; r.pose = cs::pose_mul(cs::pose_inv(Twc), c.pose); return r; }
 static Cube cuboid_transform_from(const Cube& c, const Pose& Twc) { Cube r = c; r.pose = cs::pose_mul(Twc, c.pose); return r; }
 
+// binary PPM (P6, 8 bit), returned in OpenCV's BGR order
+static bool read_ppm_as_bgr(const std::string& name, std::vector<unsigned char>& bgr, int& w, int& h) {
+  std::ifstream f(name.c_str(), std::ios::binary);
+  std::string magic;
+  int maxv = 0;
+  if (!(f >> magic >> w >> h >> maxv) || magic != "P6" || maxv != 255) return false;
+  f.get();
+  bgr.resize((size_t)w * h * 3);
+  f.read(reinterpret_cast<char*>(bgr.data()), (std::streamsize)bgr.size());
+  if (!f) return false;
+  for (size_t p = 0; p < (size_t)w * h; p++) std::swap(bgr[3 * p], bgr[3 * p + 2]);
+  return true;
+}
+
+// SE3Quat::to_homogeneous_matrix (se3quat.h:332-340), row-major 4 x 4
+static void pose_to_matrix(const Pose& p, double* T) {
+  double R[9];
+  cs::pose_rotmat(p, R);
+  for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T[4 * r + c] = R[3 * r + c]; T[4 * r + 3] = p.t[r]; }
+  T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+}
+
+// SE3Quat(R, t) (se3quat.h:65-69) with R = euler_zyx_to_rot(roll, pitch, yaw) (matrix_utils.cpp:84-99)
+static Pose pose_from_euler_zyx(double roll, double pitch, double yaw, const double* t) {
+  const double cp = std::cos(pitch), sp = std::sin(pitch), sr = std::sin(roll), cr = std::cos(roll), sy = std::sin(yaw), cy = std::cos(yaw);
+  const double R[9] = {cp * cy, (sr * sp * cy) - (cr * sy), (cr * sp * cy) + (sr * sy),
+                       cp * sy, (sr * sp * sy) + (cr * cy), (cr * sp * sy) - (sr * cy),
+                       -sp, sr * cp, cr * cp};
+  Pose p;
+  cs::quat_from_rotmat(R, p);
+  for (int d = 0; d < 3; d++) p.t[d] = t[d];
+  cs::pose_normalize(p);
+  return p;
+}
+
 #define CHECK(call) do { int st_ = (call); if (st_ != 0) { std::fprintf(stderr, "%s failed: %d\n", #call, st_); return 1; } } while (0)
 
 int main(int argc, char** argv) {
-  if (argc < 3) { std::fprintf(stderr, "usage: %s <data_dir> <out_dir> [digits]\n", argv[0]); return 2; }
-  const std::string base_folder = std::string(argv[1]) + "/", out_folder = std::string(argv[2]) + "/";
-  const int digits = argc > 3 ? std::atoi(argv[3]) : 6;      // Eigen's stream precision is 6 significant digits
+  const bool online_detect_mode = argc > 1 && std::string(argv[1]) == "--online";
+  if ((!online_detect_mode && argc < 3) || (online_detect_mode && argc < 6)) {
+    std::fprintf(stderr, "usage: %s <data_dir> <out_dir> [digits]\n       %s --online <data_dir> <ppm_dir> <segments_dir> <out_dir> [digits]\n", argv[0], argv[0]);
+    return 2;
+  }
+  const int a0 = online_detect_mode ? 2 : 1;
+  const std::string base_folder = std::string(argv[a0]) + "/";
+  const std::string ppm_folder = online_detect_mode ? std::string(argv[3]) + "/" : "", seg_folder = online_detect_mode ? std::string(argv[4]) + "/" : "";
+  const std::string out_folder = std::string(argv[online_detect_mode ? 5 : 2]) + "/";
+  const int a_digits = online_detect_mode ? 6 : 3;
+  const int digits = argc > a_digits ? std::atoi(argv[a_digits]) : 6;      // Eigen's stream precision is 6 significant digits
 
   std::vector<double> pred_frame_objects, init_frame_poses, truth_frame_poses;
   int n_obs = 0, n_init = 0, total_frame_number = 0;
-  if (!read_all_number_txt(base_folder + "detect_cuboids_saved.txt", 9, pred_frame_objects, n_obs)) return 1;
-  if (!read_all_number_txt(base_folder + "pop_cam_poses_saved.txt", 8, init_frame_poses, n_init)) return 1;
+  if (!online_detect_mode) {
+    if (!read_all_number_txt(base_folder + "detect_cuboids_saved.txt", 9, pred_frame_objects, n_obs)) return 1;
+    if (!read_all_number_txt(base_folder + "pop_cam_poses_saved.txt", 8, init_frame_poses, n_init)) return 1;
+  }
   if (!read_all_number_txt(base_folder + "truth_cam_poses.txt", 8, truth_frame_poses, total_frame_number)) return 1;
   std::cout << "read data size:  " << n_obs << "  " << n_init << "  " << total_frame_number << std::endl;
-  if (total_frame_number < 1 || n_init < total_frame_number) { std::fprintf(stderr, "pose tables too short\n"); return 1; }
+  if (total_frame_number < 1 || (!online_detect_mode && n_init < total_frame_number)) { std::fprintf(stderr, "pose tables too short\n"); return 1; }
+
+  // the detector of the online branch (main_obj.cpp:491-500): no height sampling, nominal_skew_ratio 2; roll/pitch sampling
+  // is switched per frame (:623), here one detector for each setting
+  const double calib[9] = {535.4, 0, 320.1, 0, 539.2, 247.6, 0, 0, 1};
+  cs_detector* detect_cuboid_obj[2] = {nullptr, nullptr};
+  if (online_detect_mode)
+    for (int sample = 0; sample < 2; sample++) {
+      cs_detect_params prm;
+      cs_detect_default_params(&prm);
+      prm.whether_sample_bbox_height = 0;
+      prm.nominal_skew_ratio = 2;
+      prm.whether_sample_cam_roll_pitch = sample;
+      CHECK(cs_detector_create(&prm, 0, &detect_cuboid_obj[sample]));
+    }
 
   const Pose fixed_init_cam_pose_Twc = pose_from_vector7(&truth_frame_poses[1]);
 
@@ -124,7 +191,46 @@ int main(int argc, char** argv) {
     bool has_detected_cuboid = false;
     Cube cube_local_meas = {{{0, 0, 0}, 0, 0, 0, 1}, {0, 0, 0}};
     double proposal_error = 0;
-    if (offline_cube_obs_row_id < n_obs) {
+    if (online_detect_mode) {
+      char frame_index_c[16];
+      std::snprintf(frame_index_c, sizeof(frame_index_c), "%04d", frame_index);
+      std::vector<double> raw_2d_objs, all_lines_raw;
+      int n_objs = 0, n_lines = 0;
+      if (!read_all_number_txt(base_folder + "filter_2d_obj_txts/" + frame_index_c + "_yolo2_0.15.txt", 5, raw_2d_objs, n_objs)) return 1;
+      if (n_objs > 0) {
+        std::vector<unsigned char> bgr;
+        int img_w = 0, img_h = 0;
+        if (!read_ppm_as_bgr(ppm_folder + frame_index_c + ".ppm", bgr, img_w, img_h)) { std::fprintf(stderr, "cannot read image of frame %d\n", frame_index); return 1; }
+        std::vector<unsigned char> gray((size_t)img_w * img_h);
+        CHECK(cs_bgr_to_gray(bgr.data(), img_w * img_h, gray.data()));
+        if (!read_all_number_txt(seg_folder + frame_index_c + ".txt", 4, all_lines_raw, n_lines)) return 1;
+        raw_2d_objs[0] -= 1; raw_2d_objs[1] -= 1;               // change matlab coordinate to c++, minus 1; only one landmark in this data
+        const int sample = frame_index != 0;                     // first frame doesn't need to sample cam pose
+        double transToWolrd[16];
+        pose_to_matrix(sample ? fixed_init_cam_pose_Twc : curr_cam_pose_Twc, transToWolrd);
+        cs_frame_desc fr{};
+        fr.K = calib; fr.T_wc = transToWolrd; fr.img_w = img_w; fr.img_h = img_h;
+        fr.boxes = raw_2d_objs.data(); fr.n_boxes = 1; fr.lines = all_lines_raw.data(); fr.n_lines = n_lines; fr.dist_maps = nullptr;
+        cs_cuboid detected_cube;
+        int count = 0;
+        CHECK(cs_detect_cuboids_gray(detect_cuboid_obj[sample], &fr, gray.data(), &detected_cube, &count));
+        has_detected_cuboid = count > 0;
+        if (has_detected_cuboid) {
+          const double cube_pose[9] = {detected_cube.pos[0], detected_cube.pos[1], detected_cube.pos[2], 0, 0, detected_cube.rotY,
+                                       detected_cube.scale[0], detected_cube.scale[1], detected_cube.scale[2]};   // xyz roll pitch yaw scale
+          const Cube cube_ground_value = cuboid_from_minimal(cube_pose);
+          cube_local_meas = cuboid_transform_to(cube_ground_value, curr_cam_pose_Twc);     // measurement is in local camera frame
+          if (sample) {   // camera roll/pitch was sampled: transform to the camera frame the detector used
+            double new_camera_eulers[3];
+            CHECK(cs_cam_euler_zyx(transToWolrd, new_camera_eulers));
+            new_camera_eulers[0] += detected_cube.camera_roll_delta; new_camera_eulers[1] += detected_cube.camera_pitch_delta;
+            const double trans[3] = {transToWolrd[3], transToWolrd[7], transToWolrd[11]};
+            cube_local_meas = cuboid_transform_to(cube_ground_value, pose_from_euler_zyx(new_camera_eulers[0], new_camera_eulers[1], new_camera_eulers[2], trans));
+          }
+          proposal_error = detected_cube.normalized_error;
+        }
+      }
+    } else if (offline_cube_obs_row_id < n_obs) {
       const double* m = &pred_frame_objects[9 * offline_cube_obs_row_id];
       has_detected_cuboid = (int)m[0] == frame_index;
       if (has_detected_cuboid) {
@@ -178,6 +284,7 @@ int main(int argc, char** argv) {
     cuboid_to_minimal(cs::cube_load(cube10), minimal);
     cube_history.insert(cube_history.end(), minimal, minimal + 9);
   }
+  for (int sample = 0; sample < 2; sample++) if (detect_cuboid_obj[sample]) cs_detector_destroy(detect_cuboid_obj[sample]);
   std::cout << "+++++++++++++Finish all optimization!+++++++++++++  LM iterations: " << total_iterations << std::endl;
 
   {

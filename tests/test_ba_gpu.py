@@ -185,6 +185,40 @@ def test_online_run_on_the_device_reproduces_the_references_saved_outputs():
         d.close()
 
 
+def test_graph_driver_online_mode_from_images(tmp_path):
+    """examples/object_slam_main.cpp --online: the reference's online branch in C++ on the C ABI -- colour image in
+    (PPM copies of the reference's JPEGs), cs_bgr_to_gray, cs_detect_cuboids_gray with the roll/pitch sampling schedule of
+    main_obj.cpp:623, measurement conversion, graph, cs_ba_optimize, result files.  Against the restated driver on the two
+    oracles and against the reference's saved output files."""
+    pytest.importorskip("PIL")
+    import subprocess
+    import sys
+    from PIL import Image
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_reference_frames as TR
+    import tum_frames
+    from oracle import edge_oracle_py as E
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "build_tmp", "object_slam_main")
+    if not os.path.exists(exe):
+        import __graft_entry__
+        __graft_entry__.build()
+    ppm = tmp_path / "ppm"
+    ppm.mkdir()
+    for k in range(58):
+        img = np.asarray(Image.open(os.path.join(tum_frames.DATA, "raw_imgs", "%04d_rgb_raw.jpg" % k)).convert("RGB"))
+        with open(ppm / ("%04d.ppm" % k), "wb") as f:
+            f.write(b"P6\n%d %d\n255\n" % (img.shape[1], img.shape[0]) + np.ascontiguousarray(img).tobytes())
+    out = subprocess.run([exe, "--online", tum_frames.DATA, str(ppm), os.path.join(tum_frames.DATA, "segments"), str(tmp_path), "12"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    cams = np.loadtxt(tmp_path / "output_cam_poses.txt")
+    objs = np.loadtxt(tmp_path / "output_obj_poses.txt")
+    TR.check_online_run_against_saved_outputs(objs, cams[:, 1:])
+    obj_r, cam_r, _ = O.run_online_sequence(tum_frames.DATA, lambda k: tum_frames.load_for_online_run(k, E.bgr_to_gray), TR._oracle_detect)
+    assert np.abs(objs - obj_r).max() < 1e-5 * max(1.0, np.abs(obj_r).max())
+    assert np.abs(cams[:, 1:] - cam_r).max() < 1e-5 * max(1.0, np.abs(cam_r).max())
+
+
 def _run_sharded_in_threads(pr, n_ranks, iters):
     """n_ranks cs_ba instances on one GPU, one thread each, with an in-process all-reduce (sum / max over threads)."""
     import ctypes as C
