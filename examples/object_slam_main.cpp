@@ -204,8 +204,8 @@ int main(int argc, char** argv) {
         std::vector<unsigned char> gray((size_t)img_w * img_h);
         CHECK(cs_bgr_to_gray(bgr.data(), img_w * img_h, gray.data()));
         if (!read_all_number_txt(seg_folder + frame_index_c + ".txt", 4, all_lines_raw, n_lines)) return 1;
-        raw_2d_objs[0] -= 1; raw_2d_objs[1] -= 1;               // change matlab coordinate to c++, minus 1; only one landmark in this data
-        const int sample = frame_index != 0;                     // first frame doesn't need to sample cam pose
+        raw_2d_objs[0] -= 1; raw_2d_objs[1] -= 1;               // the box file is 1-based (:621); this data has one landmark, the first box is it
+        const int sample = frame_index != 0;                     // roll/pitch sampling from the second frame on (:623)
         double transToWolrd[16];
         pose_to_matrix(sample ? fixed_init_cam_pose_Twc : curr_cam_pose_Twc, transToWolrd);
         cs_frame_desc fr{};
@@ -217,10 +217,10 @@ int main(int argc, char** argv) {
         has_detected_cuboid = count > 0;
         if (has_detected_cuboid) {
           const double cube_pose[9] = {detected_cube.pos[0], detected_cube.pos[1], detected_cube.pos[2], 0, 0, detected_cube.rotY,
-                                       detected_cube.scale[0], detected_cube.scale[1], detected_cube.scale[2]};   // xyz roll pitch yaw scale
+                                       detected_cube.scale[0], detected_cube.scale[1], detected_cube.scale[2]};   // x y z, roll, pitch, yaw, half sizes
           const Cube cube_ground_value = cuboid_from_minimal(cube_pose);
-          cube_local_meas = cuboid_transform_to(cube_ground_value, curr_cam_pose_Twc);     // measurement is in local camera frame
-          if (sample) {   // camera roll/pitch was sampled: transform to the camera frame the detector used
+          cube_local_meas = cuboid_transform_to(cube_ground_value, curr_cam_pose_Twc);     // the measurement lives in the camera's frame (:658)
+          if (sample) {   // with sampling: the frame of the camera pose the winning proposal was built with (:660-668)
             double new_camera_eulers[3];
             CHECK(cs_cam_euler_zyx(transToWolrd, new_camera_eulers));
             new_camera_eulers[0] += detected_cube.camera_roll_delta; new_camera_eulers[1] += detected_cube.camera_pitch_delta;
@@ -234,7 +234,7 @@ int main(int argc, char** argv) {
       const double* m = &pred_frame_objects[9 * offline_cube_obs_row_id];
       has_detected_cuboid = (int)m[0] == frame_index;
       if (has_detected_cuboid) {
-        const double cube_pose[9] = {m[1], m[2], m[3], 0, 0, m[4], m[5], m[6], m[7]};   // xyz roll pitch yaw scale
+        const double cube_pose[9] = {m[1], m[2], m[3], 0, 0, m[4], m[5], m[6], m[7]};   // x y z, roll, pitch, yaw, half sizes
         const Pose cam_val_Twc = pose_from_vector7(&init_frame_poses[8 * frame_index + 1]);
         cube_local_meas = cuboid_transform_to(cuboid_from_minimal(cube_pose), cam_val_Twc);
         proposal_error = m[8];
