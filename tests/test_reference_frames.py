@@ -83,6 +83,19 @@ def test_online_run_reproduces_the_references_saved_outputs():
     """Image in, trajectory and object out: the detector oracle (roll/pitch sampling as the reference's online branch uses it)
     feeding the bundle-adjustment oracle through main_obj.cpp's online graph construction, against the two result files the
     reference saved from its own run.  Both paths and the driver between them are pinned here -- up to the segment detector."""
-    out_obj, final_cams, n_det = O.run_online_sequence(tum_frames.DATA, lambda k: tum_frames.load_for_online_run(k, E.bgr_to_gray), _oracle_detect)
+    yaws = []
+
+    def detect(fr, gray, sample):
+        c = _oracle_detect(fr, gray, sample)
+        if c is not None and sample:
+            yaws.append(c["rotY"])
+        return c
+
+    out_obj, final_cams, n_det = O.run_online_sequence(tum_frames.DATA, lambda k: tum_frames.load_for_online_run(k, E.bgr_to_gray), detect)
     assert n_det == 51
     check_online_run_against_saved_outputs(out_obj, final_cams)
+    # detect_3d_cuboid.h:44-56 prints a cuboid of this sequence (640 x 480 corners, the first camera's height in the plane
+    # printed at object_3d_util.cpp:893-896): its rotY, -2.90009, is a value of the yaw sweep around the first camera's pose
+    # (camera yaw from the quaternion, minus 90 degrees, +- k x 6 degrees accumulated by linespace) -- the oracle returns
+    # exactly that number, to all six printed digits, for two of the frames
+    assert sum(abs(y - (-2.90009)) < 5e-6 for y in yaws) >= 2
