@@ -9,7 +9,9 @@
 // (Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:61-163): it calls buildStructure(), buildSystem(),
 // setLambda(), solve(), restoreDiagonal(), reads x()/b()/vectorSize() (core/solver.h:95-103), and calls the
 // optimizer's computeActiveErrors()/activeRobustChi2()/update()/push()/pop() -- which stay on the CPU unless the
-// caller swaps the whole loop for cs_ba_optimize().  Vertex/edge types handled on the device:
+// caller swaps the whole loop for cs_ba_optimize().  It also reads v->hessian(j, j) of every vertex for
+// lambda_0 (:166-180): buildStructure() maps memory behind the vertices' diagonal blocks and buildSystem() fills it.
+// tests/test_ba_gpu.py::test_stepwise_abi_driven_like_g2o_levenberg drives the same call sequence from a host-side LM loop.  Vertex/edge types handled on the device:
 // VertexSE3Expmap, VertexSBAPointXYZ, VertexCuboid, EdgeSE3ProjectXYZ, EdgeSE3Cuboid, EdgeSE3CuboidProj, EdgeSE3Expmap; any other
 // active edge makes init() fail loudly (no silent CPU fallback).
 //
@@ -95,8 +97,31 @@ class BlockSolverHIP : public g2o::Solver {
     cs_ba_set_edges_cuboid_proj(ba_, (int)pe_cam.size(), pe_cam.data(), pe_cub.data(), meas4.data(), info16.data(), K9.data());
     cs_ba_set_edges_odom(ba_, (int)oe_i.size(), oe_i.data(), oe_j.data(), meas7.data(), info36.data());
     int sp = 0, sl = 0;
-    cs_ba_sizes(ba_, &sp, &sl);
+    if (cs_ba_sizes(ba_, &sp, &sl) != CS_OK) return false;
     resizeVector(sp + sl);
+    // BlockSolver::buildStructure maps real memory behind every active vertex's A_ii (block_solver.hpp:185,191): a vertex is
+    // born with _hessian(0, D, D) (core/base_vertex.hpp:30) and OptimizationAlgorithmLevenberg::computeLambdaInit()
+    // dereferences v->hessian(j, j) of every vertex of indexMapping() on iteration 0
+    // (optimization_algorithm_levenberg.cpp:166-180).  The blocks live in diag_ and are refreshed by buildSystem().
+    size_t tot = 0;
+    for (auto* v : _optimizer->indexMapping()) tot += (size_t)v->dimension() * v->dimension();
+    diag_.assign(tot, 0.0);
+    size_t off = 0;
+    for (auto* v : _optimizer->indexMapping()) { v->mapHessianMemory(diag_.data() + off); off += (size_t)v->dimension() * v->dimension(); }
+    // x()/b() follow indexMapping() (SparseOptimizer::update walks it, sparse_optimizer.cpp:422-435); the library lays its
+    // vectors out as [cameras | cuboids] or [cuboids | cameras], then the points, each class in caller order.  That is g2o's
+    // order exactly when ids are class-contiguous, which is how the reference numbers its vertices (main_obj.cpp:541,599).
+    {
+      int prev_class = -1, prev_idx = -1, seen = 0;
+      for (auto* v : _optimizer->indexMapping()) {
+        const int cls = dynamic_cast<g2o::VertexSBAPointXYZ*>(v) ? 2 : (dynamic_cast<g2o::VertexCuboid*>(v) ? (min_cub_id < min_cam_id ? 0 : 1) : (min_cub_id < min_cam_id ? 1 : 0));
+        const int idx = index_[v];
+        if (cls < prev_class || (cls == prev_class && idx < prev_idx)) throw std::runtime_error("BlockSolverHIP: vertex ids must be contiguous per class (cameras, cuboids) and points marginalised");
+        if (cls != prev_class) seen++;
+        prev_class = cls; prev_idx = idx;
+      }
+      (void)seen;
+    }
     return true;
   }
   virtual bool updateStructure(const std::vector<g2o::HyperGraph::Vertex*>&, const g2o::HyperGraph::EdgeSet&) { return buildStructure(); }
@@ -106,7 +131,18 @@ class BlockSolverHIP : public g2o::Solver {
     upload_estimates();
     double chi;
     if (cs_ba_compute_errors(ba_, &chi) != CS_OK || cs_ba_build_system(ba_) != CS_OK) return false;
-    return cs_ba_get_system(ba_, nullptr, nullptr, nullptr, _b, nullptr) == CS_OK;
+    if (cs_ba_get_system(ba_, nullptr, nullptr, nullptr, _b, nullptr) != CS_OK) return false;
+    // refresh the vertices' mapped A_ii (symmetric blocks: Eigen's column-major view reads the same numbers)
+    hc_.resize(36 * cams_.size()); ho_.resize(81 * cubs_.size()); hp_.resize(9 * pts_.size());
+    if (cs_ba_get_vertex_hessians(ba_, hc_.data(), ho_.data(), hp_.data()) != CS_OK) return false;
+    size_t off = 0;
+    for (auto* v : _optimizer->indexMapping()) {
+      const int d = v->dimension(), i = index_[v];
+      const double* src = d == 6 ? &hc_[36 * (size_t)i] : (d == 9 ? &ho_[81 * (size_t)i] : &hp_[9 * (size_t)i]);
+      std::copy(src, src + (size_t)d * d, diag_.begin() + off);
+      off += (size_t)d * d;
+    }
+    return true;
   }
   virtual bool setLambda(double lambda, bool /*backup*/ = false) { lambda_ = lambda; return true; }  // :563-589
   virtual void restoreDiagonal() {}                                                                   // :591-604: nothing was modified
@@ -137,6 +173,7 @@ class BlockSolverHIP : public g2o::Solver {
   std::vector<g2o::VertexCuboid*> cubs_;
   std::vector<g2o::VertexSBAPointXYZ*> pts_;
   std::map<g2o::HyperGraph::Vertex*, int> index_;
+  std::vector<double> diag_, hc_, ho_, hp_;   // the vertices' mapped diagonal blocks (indexMapping order) and their staging copies
 };
 
 }  // namespace cubeslam

@@ -54,7 +54,7 @@ class detect_3d_cuboid {
   cam_pose_infos cam_pose_raw;
 
   detect_3d_cuboid() {}
-  ~detect_3d_cuboid() { if (det_) cs_detector_destroy(det_); }
+  ~detect_3d_cuboid() { for (auto* d : dets_) if (d) cs_detector_destroy(d); }
 
   void set_calibration(const Eigen::Matrix3d& Kalib) { cam_pose.Kalib = Kalib; }
   void set_cam_pose(const Eigen::Matrix4d& transToWolrd) {
@@ -141,18 +141,33 @@ class detect_3d_cuboid {
   double max_cut_skew = 3;
 
  private:
-  cs_detector* det_ = nullptr;
-  cs_detect_params last_{};
+  // One detector per sampling mode: main_obj.cpp:623 toggles whether_sample_cam_roll_pitch between frame 0 and the rest, and a
+  // detector owns streams, events and a worker pool -- it must not be rebuilt per call.  The other flags are compared field by
+  // field (a memcmp would read the struct's padding).
+  cs_detector* dets_[2] = {nullptr, nullptr};
+  cs_detect_params last_[2] = {};
+  cs_detector* det_ = nullptr;   // the one the current call uses
+  static bool same_params(const cs_detect_params& a, const cs_detect_params& b) {
+    return a.consider_config_1 == b.consider_config_1 && a.consider_config_2 == b.consider_config_2 &&
+           a.whether_sample_cam_roll_pitch == b.whether_sample_cam_roll_pitch && a.whether_sample_bbox_height == b.whether_sample_bbox_height &&
+           a.max_cuboid_num == b.max_cuboid_num && a.nominal_skew_ratio == b.nominal_skew_ratio && a.max_cut_skew == b.max_cut_skew &&
+           a.yaw_range_deg == b.yaw_range_deg && a.yaw_step_deg == b.yaw_step_deg && a.vp12_edge_angle_thre == b.vp12_edge_angle_thre &&
+           a.vp3_edge_angle_thre == b.vp3_edge_angle_thre && a.shorted_edge_thre == b.shorted_edge_thre && a.weight_vp_angle == b.weight_vp_angle &&
+           a.weight_skew_error == b.weight_skew_error && a.pre_merge_dist_thre == b.pre_merge_dist_thre && a.pre_merge_angle_thre == b.pre_merge_angle_thre &&
+           a.edge_length_threshold == b.edge_length_threshold && a.host_threads == b.host_threads;
+  }
   void ensure_detector() {
-    cs_detect_params p;
+    cs_detect_params p{};
     cs_detect_default_params(&p);
     p.consider_config_1 = consider_config_1; p.consider_config_2 = consider_config_2;
     p.whether_sample_cam_roll_pitch = whether_sample_cam_roll_pitch; p.whether_sample_bbox_height = whether_sample_bbox_height;
     p.max_cuboid_num = max_cuboid_num; p.nominal_skew_ratio = nominal_skew_ratio; p.max_cut_skew = max_cut_skew;
-    if (det_ && std::memcmp(&p, &last_, sizeof(p)) == 0) return;
-    if (det_) cs_detector_destroy(det_);
-    det_ = nullptr;
-    if (cs_detector_create(&p, 0, &det_) != CS_OK) throw std::runtime_error(std::string("cs_detector_create: ") + cs_last_error());
-    last_ = p;
+    const int slot = whether_sample_cam_roll_pitch ? 1 : 0;
+    if (dets_[slot] && same_params(p, last_[slot])) { det_ = dets_[slot]; return; }
+    if (dets_[slot]) cs_detector_destroy(dets_[slot]);
+    dets_[slot] = nullptr;
+    if (cs_detector_create(&p, 0, &dets_[slot]) != CS_OK) throw std::runtime_error(std::string("cs_detector_create: ") + cs_last_error());
+    last_[slot] = p;
+    det_ = dets_[slot];
   }
 };

@@ -312,7 +312,7 @@ DECLARED_SYMBOLS += [
     "cs_ba_create", "cs_ba_destroy", "cs_ba_set_vertices", "cs_ba_set_estimates", "cs_ba_set_edges_proj", "cs_ba_set_edges_cuboid", "cs_ba_set_edges_cuboid_proj", "cs_ba_set_edges_odom",
     "cs_ba_compute_errors", "cs_ba_build_system", "cs_ba_solve", "cs_ba_update", "cs_ba_push", "cs_ba_pop", "cs_ba_optimize",
     "cs_ba_get_state", "cs_ba_sizes", "cs_ba_solver_layout", "cs_ba_get_system", "cs_ba_last_timing", "cs_ba_set_shard", "cs_ba_optimize_sharded",
-    "cs_ba_shard_landmark_owners",
+    "cs_ba_shard_landmark_owners", "cs_ba_get_vertex_hessians",
 ]
 
 
@@ -383,6 +383,35 @@ class BaProblem:
         Hpp, Hll, Hpl, b = np.zeros((n, n)), np.zeros((nl // 3, 9)), np.zeros((self.n_proj, 18)), np.zeros(n + nl)
         _chk(lib().cs_ba_get_system(self.h, _dp(Hpp), _dp(Hll), _dp(Hpl), _dp(b), None), "cs_ba_get_system")
         return Hpp, Hll, Hpl, b
+
+    def vertex_hessians(self):
+        """A_ii of every vertex (what g2o maps into BaseVertex::_hessian): (nc, 6, 6), (no, 9, 9), (np, 3, 3)."""
+        hc, ho, hp = np.zeros((self.nc, 36)), np.zeros((self.no, 81)), np.zeros((self.np_, 9))
+        _chk(lib().cs_ba_get_vertex_hessians(self.h, _dp(hc), _dp(ho), _dp(hp)), "cs_ba_get_vertex_hessians")
+        return hc.reshape(-1, 6, 6), ho.reshape(-1, 9, 9), hp.reshape(-1, 3, 3)
+
+    def set_estimates(self, cams=None, cuboids=None, points=None):
+        """New estimates for the same graph (after a g2o-side update()/pop()): no structure rebuild."""
+        c = _f64(cams, (-1, 7)) if cams is not None else None
+        o = _f64(cuboids, (-1, 10)) if cuboids is not None else None
+        q = _f64(points, (-1, 3)) if points is not None else None
+        _chk(lib().cs_ba_set_estimates(self.h, _dp(c) if c is not None else None, _dp(o) if o is not None else None, _dp(q) if q is not None else None), "cs_ba_set_estimates")
+
+    def update(self):
+        _chk(lib().cs_ba_update(self.h), "cs_ba_update")
+
+    def push(self):
+        _chk(lib().cs_ba_push(self.h), "cs_ba_push")
+
+    def pop(self):
+        _chk(lib().cs_ba_pop(self.h), "cs_ba_pop")
+
+    def system_vectors(self):
+        """(b, x) of the last build / solve in g2o's order [poses..., landmarks...] (Solver::b(), Solver::x())."""
+        n, nl = self.sizes()
+        b, x = np.zeros(n + nl), np.zeros(n + nl)
+        _chk(lib().cs_ba_get_system(self.h, None, None, None, _dp(b), _dp(x)), "cs_ba_get_system")
+        return b, x
 
     def solver_layout(self):
         a, b = C.c_int(), C.c_int()

@@ -35,6 +35,7 @@ void ba_launch_update(const BaView& v, hipStream_t st);
 void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st);
 size_t ba_band_workspace_doubles(int n, int LD);
 int ba_band_team(int LD, int* rw_out);
+bool ba_band_fits_device(int n, int LD);
 }  // namespace cs
 
 extern "C" const char* cs_last_error(void);
@@ -58,6 +59,12 @@ namespace {
       return CS_ERR_HIP;                                                       \
     }                                                                          \
   } while (0)
+
+// no C++ exception crosses the C boundary
+#define BA_GUARD_BEGIN try {
+#define BA_GUARD_END(fn_name)                                                                                                   \
+  } catch (const std::bad_alloc&) { cs_set_error_ba(std::string(fn_name) + ": out of host memory"); return CS_ERR_CAPACITY; }   \
+    catch (const std::exception& ex) { cs_set_error_ba(std::string(fn_name) + ": " + ex.what()); return CS_ERR_CAPACITY; }
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -227,7 +234,9 @@ int finalize_structure(cs_ba* B) {
       bw = std::max(bw, vdim(v) - 1);
       for (int w : adj[v]) { int lo = std::min(vcol(v), vcol(w)); int hi = (vcol(v) > vcol(w)) ? vcol(v) + vdim(v) - 1 : vcol(w) + vdim(w) - 1; bw = std::max(bw, hi - lo); }
     }
-    B->band_ld = (!B->force_dense && B->n_pose > 128 && bw + 1 <= B->n_pose / 2 && bw <= 1900) ? bw + 1 : 0;   // (1900: two teams of ceil(bw / 16) + 1 workgroups must be co-resident on 256 CUs)
+    // banded path only where the persistent kernel's team is guaranteed to be resident on THIS device (occupancy query x CUs:
+    // 256 CUs admit bandwidths up to ~1900; a partitioned or smaller device proportionally less); dense rocSOLVER otherwise
+    B->band_ld = (!B->force_dense && B->n_pose > 128 && bw + 1 <= B->n_pose / 2 && cs::ba_band_fits_device(B->n_pose, bw + 1)) ? bw + 1 : 0;
   }
   // ---- this rank's projection edges
   {
@@ -475,6 +484,10 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       BA_TRY(hipEventRecord(B->ev[5], B->st));
       BA_TRY(hipMemcpyAsync(B->h_status, B->d_band_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
       BA_TRY(hipStreamSynchronize(B->st));
+      if (*B->h_status == 0x7fffffff) {   // a workgroup waited ~1 s for its team: the device is shared with another persistent kernel
+        cs_set_error_ba("banded solver: team not co-resident (wait timed out); set CS_BA_FORCE_DENSE=1 on a shared device");
+        return CS_ERR_HIP;
+      }
       if (*B->h_status != 0) *ok = false;
     } else {
       // dense: the lower triangle of the row-major S is the upper triangle of the column-major matrix rocSOLVER sees
@@ -508,7 +521,9 @@ int cs_ba_create(int device, cs_ba** out) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { cs_set_error_ba("no HIP device visible; libcubeslam_hip has no CPU fallback"); return CS_ERR_NO_DEVICE; }
   if (device < 0 || device >= n) { cs_set_error_ba("device index out of range"); return CS_ERR_INVALID_ARG; }
-  cs_ba* B = new cs_ba();
+  BA_GUARD_BEGIN
+  struct Guard { cs_ba* b; ~Guard() { if (b) cs_ba_destroy(b); } } g{new cs_ba()};   // freed on every early return
+  cs_ba* B = g.b;
   B->device = device;
   { const char* e = getenv("CS_BA_FORCE_DENSE"); B->force_dense = (e && atoi(e)) ? 1 : 0; }  // diagnostics: rocSOLVER dense path
   BA_TRY(hipSetDevice(device));
@@ -518,7 +533,9 @@ int cs_ba_create(int device, cs_ba** out) {
   BA_ROC(rocblas_create_handle(&B->blas));
   BA_ROC(rocblas_set_stream(B->blas, B->st));
   *out = B;
+  g.b = nullptr;
   return CS_OK;
+  BA_GUARD_END("cs_ba_create")
 }
 
 void cs_ba_destroy(cs_ba* B) {
@@ -541,7 +558,7 @@ void cs_ba_destroy(cs_ba* B) {
   delete B;
 }
 
-int cs_ba_set_vertices(cs_ba* B, const double* cams7, const int* cam_fixed, int nc, const double* cuboids10, const int* cub_fixed, int no,
+static int cs_ba_set_vertices_impl(cs_ba* B, const double* cams7, const int* cam_fixed, int nc, const double* cuboids10, const int* cub_fixed, int no,
                        const double* points3, const int* pt_fixed, int np, int cuboids_first) {
   if (!B || nc < 0 || no < 0 || np < 0 || (nc && (!cams7 || !cam_fixed)) || (no && (!cuboids10 || !cub_fixed)) || (np && (!points3 || !pt_fixed))) return CS_ERR_INVALID_ARG;
   BA_TRY(hipSetDevice(B->device));
@@ -556,8 +573,14 @@ int cs_ba_set_vertices(cs_ba* B, const double* cams7, const int* cam_fixed, int 
   B->structure_dirty = true;
   return CS_OK;
 }
+int cs_ba_set_vertices(cs_ba* B, const double* cams7, const int* cam_fixed, int nc, const double* cuboids10, const int* cub_fixed, int no,
+                       const double* points3, const int* pt_fixed, int np, int cuboids_first) {
+  BA_GUARD_BEGIN
+  return cs_ba_set_vertices_impl(B, cams7, cam_fixed, nc, cuboids10, cub_fixed, no, points3, pt_fixed, np, cuboids_first);
+  BA_GUARD_END("cs_ba_set_vertices")
+}
 
-int cs_ba_set_estimates(cs_ba* B, const double* cams7, const double* cuboids10, const double* points3) {
+static int cs_ba_set_estimates_impl(cs_ba* B, const double* cams7, const double* cuboids10, const double* points3) {
   if (!B) return CS_ERR_INVALID_ARG;
   BA_TRY(hipSetDevice(B->device));
   if (cams7 && B->nc) {
@@ -570,8 +593,13 @@ int cs_ba_set_estimates(cs_ba* B, const double* cams7, const double* cuboids10, 
   B->have_system = false;
   return CS_OK;
 }
+int cs_ba_set_estimates(cs_ba* B, const double* cams7, const double* cuboids10, const double* points3) {
+  BA_GUARD_BEGIN
+  return cs_ba_set_estimates_impl(B, cams7, cuboids10, points3);
+  BA_GUARD_END("cs_ba_set_estimates")
+}
 
-int cs_ba_set_edges_proj(cs_ba* B, int n, const int* pt, const int* cam, const double* uv, const double* info4, const double* intr4, const double* huber) {
+static int cs_ba_set_edges_proj_impl(cs_ba* B, int n, const int* pt, const int* cam, const double* uv, const double* info4, const double* intr4, const double* huber) {
   if (!B || n < 0 || (n && (!pt || !cam || !uv || !info4 || !intr4))) return CS_ERR_INVALID_ARG;
   B->n_proj = n;
   B->e_pt.assign(pt, pt + n); B->e_cam.assign(cam, cam + n);
@@ -580,24 +608,39 @@ int cs_ba_set_edges_proj(cs_ba* B, int n, const int* pt, const int* cam, const d
   B->structure_dirty = true;
   return CS_OK;
 }
+int cs_ba_set_edges_proj(cs_ba* B, int n, const int* pt, const int* cam, const double* uv, const double* info4, const double* intr4, const double* huber) {
+  BA_GUARD_BEGIN
+  return cs_ba_set_edges_proj_impl(B, n, pt, cam, uv, info4, intr4, huber);
+  BA_GUARD_END("cs_ba_set_edges_proj")
+}
 
-int cs_ba_set_edges_cuboid(cs_ba* B, int n, const int* cam, const int* cub, const double* meas10, const double* info81) {
+static int cs_ba_set_edges_cuboid_impl(cs_ba* B, int n, const int* cam, const int* cub, const double* meas10, const double* info81) {
   if (!B || n < 0 || (n && (!cam || !cub || !meas10 || !info81))) return CS_ERR_INVALID_ARG;
   B->u3_cam.assign(cam, cam + n); B->u3_cub.assign(cub, cub + n);
   B->h_ce_meas.assign(meas10, meas10 + 10 * (size_t)n); B->h_ce_info.assign(info81, info81 + 81 * (size_t)n);
   B->structure_dirty = true;
   return CS_OK;
 }
+int cs_ba_set_edges_cuboid(cs_ba* B, int n, const int* cam, const int* cub, const double* meas10, const double* info81) {
+  BA_GUARD_BEGIN
+  return cs_ba_set_edges_cuboid_impl(B, n, cam, cub, meas10, info81);
+  BA_GUARD_END("cs_ba_set_edges_cuboid")
+}
 
-int cs_ba_set_edges_cuboid_proj(cs_ba* B, int n, const int* cam, const int* cub, const double* meas4, const double* info16, const double* K9) {
+static int cs_ba_set_edges_cuboid_proj_impl(cs_ba* B, int n, const int* cam, const int* cub, const double* meas4, const double* info16, const double* K9) {
   if (!B || n < 0 || (n && (!cam || !cub || !meas4 || !info16 || !K9))) return CS_ERR_INVALID_ARG;
   B->up_cam.assign(cam, cam + n); B->up_cub.assign(cub, cub + n);
   B->h_pe_meas.assign(meas4, meas4 + 4 * (size_t)n); B->h_pe_info.assign(info16, info16 + 16 * (size_t)n); B->h_pe_K.assign(K9, K9 + 9 * (size_t)n);
   B->structure_dirty = true;
   return CS_OK;
 }
+int cs_ba_set_edges_cuboid_proj(cs_ba* B, int n, const int* cam, const int* cub, const double* meas4, const double* info16, const double* K9) {
+  BA_GUARD_BEGIN
+  return cs_ba_set_edges_cuboid_proj_impl(B, n, cam, cub, meas4, info16, K9);
+  BA_GUARD_END("cs_ba_set_edges_cuboid_proj")
+}
 
-int cs_ba_set_edges_odom(cs_ba* B, int n, const int* ci, const int* cj, const double* meas7, const double* info36) {
+static int cs_ba_set_edges_odom_impl(cs_ba* B, int n, const int* ci, const int* cj, const double* meas7, const double* info36) {
   if (!B || n < 0 || (n && (!ci || !cj || !meas7 || !info36))) return CS_ERR_INVALID_ARG;
   B->n_odom = n;
   B->oe_i.assign(ci, ci + n); B->oe_j.assign(cj, cj + n);
@@ -607,8 +650,13 @@ int cs_ba_set_edges_odom(cs_ba* B, int n, const int* ci, const int* cj, const do
   B->structure_dirty = true;
   return CS_OK;
 }
+int cs_ba_set_edges_odom(cs_ba* B, int n, const int* ci, const int* cj, const double* meas7, const double* info36) {
+  BA_GUARD_BEGIN
+  return cs_ba_set_edges_odom_impl(B, n, ci, cj, meas7, info36);
+  BA_GUARD_END("cs_ba_set_edges_odom")
+}
 
-int cs_ba_compute_errors(cs_ba* B, double* chi2) {
+static int cs_ba_compute_errors_impl(cs_ba* B, double* chi2) {
   if (!B || !chi2) return CS_ERR_INVALID_ARG;
   BA_TRY(hipSetDevice(B->device));
   int rc = finalize_structure(B); if (rc) return rc;
@@ -617,16 +665,26 @@ int cs_ba_compute_errors(cs_ba* B, double* chi2) {
   B->tm.errors_ms += now_ms() - t0;
   return rc;
 }
+int cs_ba_compute_errors(cs_ba* B, double* chi2) {
+  BA_GUARD_BEGIN
+  return cs_ba_compute_errors_impl(B, chi2);
+  BA_GUARD_END("cs_ba_compute_errors")
+}
 
-int cs_ba_build_system(cs_ba* B) {
+static int cs_ba_build_system_impl(cs_ba* B) {
   if (!B) return CS_ERR_INVALID_ARG;
   BA_TRY(hipSetDevice(B->device));
   int rc = finalize_structure(B); if (rc) return rc;
   rc = build_system_device(B); if (rc) return rc;
   return fetch_b(B);
 }
+int cs_ba_build_system(cs_ba* B) {
+  BA_GUARD_BEGIN
+  return cs_ba_build_system_impl(B);
+  BA_GUARD_END("cs_ba_build_system")
+}
 
-int cs_ba_solve(cs_ba* B, double lambda, int* pd) {
+static int cs_ba_solve_impl(cs_ba* B, double lambda, int* pd) {
   if (!B) return CS_ERR_INVALID_ARG;
   BA_TRY(hipSetDevice(B->device));
   if (B->structure_dirty || !B->have_system) { cs_set_error_ba("cs_ba_solve: call cs_ba_build_system first"); return CS_ERR_NOT_RUN; }
@@ -634,6 +692,11 @@ int cs_ba_solve(cs_ba* B, double lambda, int* pd) {
   int rc = solve_device(B, lambda, &ok); if (rc) return rc;
   if (pd) *pd = ok ? 1 : 0;
   return ok ? fetch_x(B) : CS_OK;
+}
+int cs_ba_solve(cs_ba* B, double lambda, int* pd) {
+  BA_GUARD_BEGIN
+  return cs_ba_solve_impl(B, lambda, pd);
+  BA_GUARD_END("cs_ba_solve")
 }
 
 int cs_ba_update(cs_ba* B) {
@@ -686,7 +749,7 @@ int cs_ba_optimize(cs_ba* B, int iterations, int* iterations_done, double* chi_h
   return cs_ba_optimize_sharded(B, iterations, nullptr, nullptr, iterations_done, chi_hist, lambda_hist, trials_hist, cap);
 }
 
-int cs_ba_optimize_sharded(cs_ba* B, int iterations, cs_allreduce_fn fn, void* ctx, int* iterations_done, double* chi_hist, double* lambda_hist, int* trials_hist, int cap) {
+static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn fn, void* ctx, int* iterations_done, double* chi_hist, double* lambda_hist, int* trials_hist, int cap) {
   if (!B || iterations < 0) return CS_ERR_INVALID_ARG;
   if (B->shard_n > 1 && !fn) { cs_set_error_ba("sharded problem needs an all-reduce callback"); return CS_ERR_INVALID_ARG; }
   const bool sharded = fn && B->shard_n > 1;
@@ -778,6 +841,11 @@ int cs_ba_optimize_sharded(cs_ba* B, int iterations, cs_allreduce_fn fn, void* c
   B->tm.total_ms += now_ms() - t_begin;
   return CS_OK;
 }
+int cs_ba_optimize_sharded(cs_ba* B, int iterations, cs_allreduce_fn fn, void* ctx, int* iterations_done, double* chi_hist, double* lambda_hist, int* trials_hist, int cap) {
+  BA_GUARD_BEGIN
+  return cs_ba_optimize_sharded_impl(B, iterations, fn, ctx, iterations_done, chi_hist, lambda_hist, trials_hist, cap);
+  BA_GUARD_END("cs_ba_optimize_sharded")
+}
 
 int cs_ba_get_state(cs_ba* B, double* cams7, double* cuboids10, double* points3) {
   if (!B) return CS_ERR_INVALID_ARG;
@@ -789,15 +857,20 @@ int cs_ba_get_state(cs_ba* B, double* cams7, double* cuboids10, double* points3)
   return CS_OK;
 }
 
-int cs_ba_sizes(cs_ba* B, int* size_pose, int* size_lm) {
+static int cs_ba_sizes_impl(cs_ba* B, int* size_pose, int* size_lm) {
   if (!B) return CS_ERR_INVALID_ARG;
   int rc = finalize_structure(B); if (rc) return rc;
   if (size_pose) *size_pose = B->n_pose;
   if (size_lm) *size_lm = 3 * B->n_lm;
   return CS_OK;
 }
+int cs_ba_sizes(cs_ba* B, int* size_pose, int* size_lm) {
+  BA_GUARD_BEGIN
+  return cs_ba_sizes_impl(B, size_pose, size_lm);
+  BA_GUARD_END("cs_ba_sizes")
+}
 
-int cs_ba_solver_layout(cs_ba* B, int* band_ld, int* team) {
+static int cs_ba_solver_layout_impl(cs_ba* B, int* band_ld, int* team) {
   if (!B) return CS_ERR_INVALID_ARG;
   int rc = finalize_structure(B); if (rc) return rc;
   int rw = 0;
@@ -805,8 +878,13 @@ int cs_ba_solver_layout(cs_ba* B, int* band_ld, int* team) {
   if (team) *team = B->band_ld ? cs::ba_band_team(B->band_ld, &rw) : 0;
   return CS_OK;
 }
+int cs_ba_solver_layout(cs_ba* B, int* band_ld, int* team) {
+  BA_GUARD_BEGIN
+  return cs_ba_solver_layout_impl(B, band_ld, team);
+  BA_GUARD_END("cs_ba_solver_layout")
+}
 
-int cs_ba_get_system(cs_ba* B, double* Hpp, double* Hll9, double* Hpl18, double* b, double* x) {
+static int cs_ba_get_system_impl(cs_ba* B, double* Hpp, double* Hll9, double* Hpl18, double* b, double* x) {
   if (!B) return CS_ERR_INVALID_ARG;
   if (B->structure_dirty || !B->have_system) return CS_ERR_NOT_RUN;
   BA_TRY(hipSetDevice(B->device));
@@ -851,6 +929,34 @@ int cs_ba_get_system(cs_ba* B, double* Hpp, double* Hll9, double* Hpl18, double*
   };
   if (b) to_ref(B->h_b, b);
   if (x && !B->h_x.empty()) to_ref(B->h_x, x);
+  return CS_OK;
+}
+int cs_ba_get_system(cs_ba* B, double* Hpp, double* Hll9, double* Hpl18, double* b, double* x) {
+  BA_GUARD_BEGIN
+  return cs_ba_get_system_impl(B, Hpp, Hll9, Hpl18, b, x);
+  BA_GUARD_END("cs_ba_get_system")
+}
+
+// The diagonal Hessian blocks g2o keeps mapped into its vertices (BaseVertex::_hessian, core/base_vertex.hpp:30,52-54; mapped by
+// BlockSolver::buildStructure, block_solver.hpp:185,191) and that OptimizationAlgorithmLevenberg::computeLambdaInit reads
+// (optimization_algorithm_levenberg.cpp:166-180): A_ii of every vertex, caller's vertex order, zeros for fixed vertices.
+int cs_ba_get_vertex_hessians(cs_ba* B, double* cam36, double* cub81, double* pt9) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  if (B->structure_dirty || !B->have_system) { cs_set_error_ba("cs_ba_get_vertex_hessians: call cs_ba_build_system first"); return CS_ERR_NOT_RUN; }
+  BA_TRY(hipSetDevice(B->device));
+  BA_TRY(hipStreamSynchronize(B->st));
+  if (cam36 && B->nc) {
+    BA_TRY(hipMemcpy(cam36, B->Hcam.p, 8 * 36 * (size_t)B->nc, hipMemcpyDeviceToHost));
+    for (int i = 0; i < B->nc; i++) if (B->cam_fixed[i]) std::memset(cam36 + 36 * (size_t)i, 0, 288);
+  }
+  if (cub81 && B->no) {
+    BA_TRY(hipMemcpy(cub81, B->Hcub.p, 8 * 81 * (size_t)B->no, hipMemcpyDeviceToHost));
+    for (int i = 0; i < B->no; i++) if (B->cub_fixed[i]) std::memset(cub81 + 81 * (size_t)i, 0, 648);
+  }
+  if (pt9 && B->np) {
+    BA_TRY(hipMemcpy(pt9, B->Hll.p, 8 * 9 * (size_t)B->np, hipMemcpyDeviceToHost));
+    for (int i = 0; i < B->np; i++) if (B->pt_fixed[i]) std::memset(pt9 + 9 * (size_t)i, 0, 72);
+  }
   return CS_OK;
 }
 

@@ -599,6 +599,28 @@ __global__ __launch_bounds__(256) void ba_update_kernel(BaView v) {
 //                           that does not depend on x prefetched one step ahead); band_sep_* handle the separator.
 enum { BS = 32 };
 
+// Bounded wait on a monotone counter.  The persistent kernels below need their whole team resident; the host checks that
+// against the occupancy query before choosing the banded path (ba_band_fits_device), but a GPU shared with another process's
+// persistent kernel can still starve a team.  Such a launch must fail, not hang: after ~1 s of polling the waiter raises the
+// abort word of the launch's info block (all barrier counters and flags live in that one 96-byte, 256-byte-aligned block:
+// info[19]), marks the factorisation as failed (info[0] = INT_MAX) and every later wait of the launch returns at once.
+enum { BAND_ABORT_SLOT = 19, BAND_SPIN_LIMIT = 1 << 21, BAND_TIMEOUT_INFO = 0x7fffffff };
+__device__ __forceinline__ void band_wait_ge(unsigned* ctr, unsigned target) {
+  unsigned spins = 0;
+  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 1023u) == 0) {
+      unsigned* base = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned long long>(ctr) & ~127ull);
+      if (__hip_atomic_load(base + BAND_ABORT_SLOT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      if (spins >= (unsigned)BAND_SPIN_LIMIT) {
+        __hip_atomic_store(base + BAND_ABORT_SLOT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(base, (unsigned)BAND_TIMEOUT_INFO, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+}
+
 // All workgroups of the (co-resident) grid arrive; thread 0 spins on the monotone counter.  Producer side: every
 // wave drains its stores, lane 0 writes the XCD's L2 back (agent-scope release; the explicit wait restates the one the
 // compiler may drop after buffer_wbl2) and arrives; consumer side: relaxed poll, one agent-scope acquire for the CU.
@@ -609,7 +631,7 @@ __device__ __forceinline__ void band_grid_sync(unsigned* bar, unsigned target) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    band_wait_ge(bar, target);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
@@ -875,7 +897,7 @@ __device__ __forceinline__ void band_step(const BandLds& M, const BandView& view
   band_gather_gemm<KID>(s0, s1, nseg, aug, zero, n, bw, k0, nb, M.rowidx, M.R, M.U, tp, t_prev);
   // the inverse of the block's factor comes from the front's diagonal workgroup (band_diag_phase), normally before it is asked for
   if (tid == 0) {
-    while (__hip_atomic_load(dflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < dtarget) __builtin_amdgcn_s_sleep(1);
+    band_wait_ge(dflag, dtarget);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
@@ -958,7 +980,7 @@ __device__ __forceinline__ void band_diag_phase(const BandLds& M, const BandView
   const int tid = threadIdx.x, r = tid >> 3, cq = tid & 7, lane = tid & 63, wv = tid >> 6, rg = lane >> 3, cg = lane & 7;
   auto wait_for = [&](unsigned* ctr, unsigned target) {
     if (tid == 0) {
-      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+      band_wait_ge(ctr, target);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -1216,7 +1238,7 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
     for (int u = 0; u < 16; u++) acc[u] = 0.0;
     for (int sidx = 0; sidx < nstep; sidx++) {
       if (tid == 0) {
-        while (__hip_atomic_load(bars + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(sidx + 1) * (unsigned)G1) __builtin_amdgcn_s_sleep(1);
+        band_wait_ge(bars + 1, (unsigned)(sidx + 1) * (unsigned)G1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
       __syncthreads();
@@ -1465,9 +1487,31 @@ size_t ba_band_workspace_doubles(int n, int LD) {
   return nest > two ? nest : two;
 }
 
-// info (24 ints, zeroed by the caller): [0] first non-positive pivot (+1), [1..3] barrier counters of the two-front
+// Does the persistent factorisation of an n x n band with LD = bandwidth + 1 fit the current device?  Its workgroups wait for
+// each other, so the whole grid must be resident at once: the grid may not exceed (workgroups the occupancy query admits per
+// CU, capped at 1: the kernels are written for one workgroup per CU) x (CUs of the device or partition).  The caller takes the
+// dense rocSOLVER path otherwise.
+bool ba_band_fits_device(int n, int LD) {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+  int rw = 0, K1 = 0, K2 = 0, wc = 0, c0 = 0, occ = 0, grid = 0;
+  const int G = ba_band_team(LD, &rw), bw = LD - 1;
+  if (ba_band_nested(n, LD, &wc, &c0)) {
+    const int Gn = (bw + BAND_RW_NESTED - 1) / BAND_RW_NESTED, GC = wc / BAND_RW_NESTED, GS = wc / 16;
+    grid = 2 * (Gn + 1 + Gn + GC + 1 + GS);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, band_chol_nested_kernel, 256, 0) != hipSuccess) return false;
+  } else {
+    ba_band_split(n, LD, &K1, &K2);
+    grid = K2 > 0 ? 2 * (G + 1) : G + 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, band_chol_coop_kernel, 256, 0) != hipSuccess) return false;
+  }
+  return occ >= 1 && grid <= prop.multiProcessorCount;
+}
+
+// info (24 ints, zeroed by the caller): [0] first non-positive pivot (+1; INT_MAX: a wait timed out, see band_wait_ge), [1..3] barrier counters of the two-front
 // order (forward team, reverse team, both), [4..5] a zero double (the target of masked loads), [6..14] barrier counters
-// of the nested order, [15..18] published-block counters of the fronts' diagonal workgroups.  work: ba_band_workspace_doubles(n, LD) doubles.
+// of the nested order, [15..18] published-block counters of the fronts' diagonal workgroups, [19] abort word.  work: ba_band_workspace_doubles(n, LD) doubles.
 void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st) {
   int rw = 0, K1 = 0, K2 = 0, wc = 0, c0 = 0;
   const int G = ba_band_team(LD, &rw);

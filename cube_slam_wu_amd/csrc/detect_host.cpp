@@ -487,6 +487,24 @@ struct cs_batch {
   cs_detect_timing timing{};
 };
 
+
+// The C ABI is the trust boundary: a 2D box must lie inside the image (its far edges are pixel coordinates the sweep
+// intersects rays with and samples the distance map at).  The reference indexes the map unchecked (object_3d_util.cpp:651), so a
+// box outside the image is undefined behaviour there; here it is CS_ERR_INVALID_ARG.
+static bool box_inside_image(const double* box5, int img_w, int img_h) {
+  if (img_w <= 0 || img_h <= 0) return false;
+  for (int q = 0; q < 4; q++) if (!(box5[q] > -1e9 && box5[q] < 1e9)) return false;   // NaN / inf / absurd
+  const int left = (int)box5[0], top = (int)box5[1], w = (int)box5[2], h = (int)box5[3];
+  const int right = (int)(left + box5[2]), bottom = top + h;
+  return left >= 0 && top >= 0 && w > 0 && h > 0 && right <= img_w - 1 && bottom <= img_h - 1;
+}
+
+// No C++ exception may cross the C boundary (std::bad_alloc / std::length_error from a host buffer would terminate the caller).
+#define CS_GUARD_BEGIN try {
+#define CS_GUARD_END(fn_name)                                                                      \
+  } catch (const std::bad_alloc&) { set_err(std::string(fn_name) + ": out of host memory"); return CS_ERR_CAPACITY; } \
+    catch (const std::exception& ex) { set_err(std::string(fn_name) + ": " + ex.what()); return CS_ERR_CAPACITY; }
+
 extern "C" {
 
 const char* cs_last_error(void) { return g_cs_err.c_str(); }
@@ -549,9 +567,11 @@ int cs_detector_create(const cs_detect_params* params, int device, cs_detector**
     return CS_ERR_NO_DEVICE;
   }
   if (device < 0 || device >= n) { set_err("device index out of range"); return CS_ERR_INVALID_ARG; }
-  cs_detector* d = new cs_detector();
+  CS_GUARD_BEGIN
+  struct Guard { cs_detector* d; ~Guard() { if (d) cs_detector_destroy(d); } } g{new cs_detector()};   // freed on every early return
+  cs_detector* d = g.d;
   if (params) d->prm = *params; else cs_detect_default_params(&d->prm);
-  if (d->prm.max_cuboid_num < 1 || d->prm.yaw_step_deg <= 0) { delete d; set_err("bad params"); return CS_ERR_INVALID_ARG; }
+  if (d->prm.max_cuboid_num < 1 || !(d->prm.yaw_step_deg > 0) || !(d->prm.yaw_range_deg >= 0)) { set_err("bad params"); return CS_ERR_INVALID_ARG; }
   d->device = device;
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
@@ -571,7 +591,9 @@ int cs_detector_create(const cs_detect_params* params, int device, cs_detector**
   d->n_threads = d->prm.host_threads > 0 ? d->prm.host_threads : dflt;
   d->pool.reset(new WorkerPool(d->n_threads - 1));
   *out = d;
+  g.d = nullptr;
   return CS_OK;
+  CS_GUARD_END("cs_detector_create")
 }
 
 void cs_detector_destroy(cs_detector* d) {
@@ -586,8 +608,10 @@ void cs_detector_destroy(cs_detector* d) {
 static int batch_create_impl(cs_detector* d, const cs_frame_desc* fr, const unsigned char* const* grays, int n_frames, cs_batch** out) {
   if (!d || !out || (!fr && n_frames) || n_frames < 0) return CS_ERR_INVALID_ARG;
   *out = nullptr;
+  CS_GUARD_BEGIN
   HIP_TRY(hipSetDevice(d->device));
-  cs_batch* b = new cs_batch();
+  struct Guard { cs_batch* b; ~Guard() { if (b) cs_batch_destroy(b); } } g{new cs_batch()};   // freed on every early return
+  cs_batch* b = g.b;
   b->det = d;
   b->n_frames = n_frames;
   b->frames.resize(n_frames);
@@ -596,10 +620,12 @@ static int batch_create_impl(cs_detector* d, const cs_frame_desc* fr, const unsi
     const cs_frame_desc& s = fr[f];
     FrameIn& F = b->frames[f];
     if (!s.K || !s.T_wc || s.n_boxes < 0 || s.n_lines < 0 || (s.n_boxes && (!s.boxes || (!grays && !s.dist_maps))) || (s.n_lines && !s.lines) || (grays && !grays[f])) {
-      delete b; set_err("bad frame descriptor"); return CS_ERR_INVALID_ARG;
+      set_err("bad frame descriptor"); return CS_ERR_INVALID_ARG;
     }
+    for (int i = 0; i < s.n_boxes; i++)
+      if (!box_inside_image(s.boxes + 5 * (size_t)i, s.img_w, s.img_h)) { set_err("2D box outside the image (need 0 <= x, 0 <= y, x + w <= img_w - 1, y + h <= img_h - 1)"); return CS_ERR_INVALID_ARG; }
     if (s.T_wc[12] != 0 || s.T_wc[13] != 0 || s.T_wc[14] != 0 || s.T_wc[15] != 1) {
-      delete b; set_err("T_wc must have last row 0 0 0 1"); return CS_ERR_INVALID_ARG;
+      set_err("T_wc must have last row 0 0 0 1"); return CS_ERR_INVALID_ARG;
     }
     std::memcpy(F.K, s.K, sizeof(F.K));
     inv3(F.K, F.invK);  // set_calibration (box_proposal_detail.cpp:38-42)
@@ -623,7 +649,7 @@ static int batch_create_impl(cs_detector* d, const cs_frame_desc* fr, const unsi
       F.n_heights[i] = nh;
       for (int k = 0; k < nh; k++) {
         const cs_roi& r = F.rois[3 * i + k];
-        if (r.width <= 0 || r.height <= 0 || (!grays && !s.dist_maps[3 * i + k])) { delete b; set_err("missing distance map / empty ROI"); return CS_ERR_INVALID_ARG; }
+        if (r.width <= 0 || r.height <= 0 || (!grays && !s.dist_maps[3 * i + k])) { set_err("missing distance map / empty ROI"); return CS_ERR_INVALID_ARG; }
         F.map_offs[3 * i + k] = (long long)map_floats;
         map_floats += (size_t)r.width * r.height + r.width + 1;  // + one row + one float of zero padding
       }
@@ -632,7 +658,7 @@ static int batch_create_impl(cs_detector* d, const cs_frame_desc* fr, const unsi
   }
   // upload the distance maps (zero padded) and the per-frame invK
   int rc = b->d_maps.ensure(map_floats + 1);
-  if (rc) { delete b; return rc; }
+  if (rc) { return rc; }
   {
     if (!grays) {
       std::vector<float> stage(map_floats + 1, 0.0f);
@@ -654,11 +680,11 @@ static int batch_create_impl(cs_detector* d, const cs_frame_desc* fr, const unsi
       int max_w = 1;
       for (int f = 0; f < n_frames; f++) {
         FrameIn& F = b->frames[f];
-        if (F.img_w != W || F.img_h != H) { delete b; set_err("cs_batch_create_gray: all frames must have the same image size"); return CS_ERR_INVALID_ARG; }
+        if (F.img_w != W || F.img_h != H) { set_err("cs_batch_create_gray: all frames must have the same image size"); return CS_ERR_INVALID_ARG; }
         for (int i = 0; i < F.n_boxes; i++)
           for (int k = 0; k < F.n_heights[i]; k++) {
             const cs_roi& r = F.rois[3 * i + k];
-            if (r.left < 0 || r.top < 0 || r.left + r.width > W || r.top + r.height > H) { delete b; set_err("ROI outside the image"); return CS_ERR_INVALID_ARG; }
+            if (r.left < 0 || r.top < 0 || r.left + r.width > W || r.top + r.height > H) { set_err("ROI outside the image"); return CS_ERR_INVALID_ARG; }
             er.push_back(cs::EdgeRoi{r.left, r.top, r.width, r.height, (long long)f * W * H, cls_tot, F.map_offs[3 * i + k]});
             cls_tot += (long long)r.width * r.height;
             max_w = std::max(max_w, r.width);
@@ -666,7 +692,7 @@ static int batch_create_impl(cs_detector* d, const cs_frame_desc* fr, const unsi
       }
       DevBuf<unsigned char> d_gray, d_cls;
       DevBuf<cs::EdgeRoi> d_rois;
-      if ((rc = d_gray.ensure((size_t)W * H * std::max(1, n_frames))) || (rc = d_cls.ensure((size_t)cls_tot + 1)) || (rc = d_rois.ensure(er.size() + 1))) { delete b; return rc; }
+      if ((rc = d_gray.ensure((size_t)W * H * std::max(1, n_frames))) || (rc = d_cls.ensure((size_t)cls_tot + 1)) || (rc = d_rois.ensure(er.size() + 1))) { return rc; }
       hipStream_t st = d->stream;
       HIP_TRY(hipMemsetAsync(b->d_maps.p, 0, sizeof(float) * (map_floats + 1), st));
       for (int f = 0; f < n_frames; f++) HIP_TRY(hipMemcpyAsync(d_gray.p + (size_t)f * W * H, grays[f], (size_t)W * H, hipMemcpyHostToDevice, st));
@@ -681,7 +707,7 @@ static int batch_create_impl(cs_detector* d, const cs_frame_desc* fr, const unsi
     std::vector<double> ik(9 * (size_t)std::max(1, n_frames));
     for (int f = 0; f < n_frames; f++) std::memcpy(&ik[9 * f], b->frames[f].invK, 9 * sizeof(double));
     rc = b->d_invK.ensure(ik.size());
-    if (rc) { delete b; return rc; }
+    if (rc) { return rc; }
     HIP_TRY(hipMemcpy(b->d_invK.p, ik.data(), sizeof(double) * ik.size(), hipMemcpyHostToDevice));
     // line segments (already left-to-right aligned), pooled, for the device-side line setup
     std::vector<int> lp(n_frames + 1, 0);
@@ -689,8 +715,8 @@ static int batch_create_impl(cs_detector* d, const cs_frame_desc* fr, const unsi
     for (int f = 0; f < n_frames; f++) { lp[f + 1] = lp[f] + b->frames[f].n_lines; if (b->frames[f].n_lines > cs::line_setup_capacity()) b->device_setup = false; }
     std::vector<double> fl(4 * (size_t)std::max(1, lp[n_frames]));
     for (int f = 0; f < n_frames; f++) if (b->frames[f].n_lines) std::memcpy(&fl[4 * (size_t)lp[f]], b->frames[f].lines.data(), 32 * (size_t)b->frames[f].n_lines);
-    rc = b->d_frame_lines.ensure(fl.size()); if (rc) { delete b; return rc; }
-    rc = b->d_frame_line_ptr.ensure(lp.size()); if (rc) { delete b; return rc; }
+    rc = b->d_frame_lines.ensure(fl.size()); if (rc) { return rc; }
+    rc = b->d_frame_line_ptr.ensure(lp.size()); if (rc) { return rc; }
     HIP_TRY(hipMemcpy(b->d_frame_lines.p, fl.data(), 8 * fl.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_frame_line_ptr.p, lp.data(), 4 * lp.size(), hipMemcpyHostToDevice));
   }
@@ -715,7 +741,9 @@ static int batch_create_impl(cs_detector* d, const cs_frame_desc* fr, const unsi
     }
   }
   *out = b;
+  g.b = nullptr;
   return CS_OK;
+  CS_GUARD_END("cs_batch_create")
 }
 
 int cs_batch_create(cs_detector* d, const cs_frame_desc* fr, int n_frames, cs_batch** out) { return batch_create_impl(d, fr, nullptr, n_frames, out); }
@@ -1175,7 +1203,13 @@ extern "C" int cs_batch_set_pipeline_chunks(cs_batch* b, int n_chunks) {
   return CS_OK;
 }
 
+static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_counts);
 extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_counts) {
+  CS_GUARD_BEGIN
+  return batch_run_impl(d, b, out, out_counts);
+  CS_GUARD_END("cs_batch_run")
+}
+static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_counts) {
   if (!d || !b || b->det != d || !out || !out_counts) return CS_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(d->device));
   const cs_detect_params& P = d->prm;
@@ -1838,6 +1872,7 @@ int cs_bgr_to_gray(const unsigned char* bgr, int n_pixels, unsigned char* gray) 
 int cs_edge_distance_maps_multi(cs_detector* d, const unsigned char* const* grays, int n_images, int img_w, int img_h, const cs_roi* rois, const int* roi_image,
                                 int n_rois, float* const* out_maps, double* kernel_ms) {
   if (!d || n_images <= 0 || !grays || img_w <= 0 || img_h <= 0 || n_rois < 0 || (n_rois && (!rois || !roi_image))) return CS_ERR_INVALID_ARG;
+  CS_GUARD_BEGIN
   HIP_TRY(hipSetDevice(d->device));
   if (kernel_ms) *kernel_ms = 0;
   if (n_rois == 0) return CS_OK;
@@ -1879,6 +1914,7 @@ int cs_edge_distance_maps_multi(cs_detector* d, const unsigned char* const* gray
   if (kernel_ms) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, d->ev[0], d->ev[1])); *kernel_ms = ms; }
   d_gray.release(); d_cls.release(); d_rois.release(); d_map.release();
   return CS_OK;
+  CS_GUARD_END("cs_edge_distance_maps")
 }
 
 int cs_edge_distance_maps(cs_detector* d, const unsigned char* gray, int img_w, int img_h, const cs_roi* rois, int n_rois, float* const* out_maps) {
@@ -1891,6 +1927,10 @@ int cs_edge_distance_maps(cs_detector* d, const unsigned char* gray, int img_w, 
 int cs_detect_cuboids_gray(cs_detector* d, const cs_frame_desc* frame, const unsigned char* gray, cs_cuboid* out, int* out_counts) {
   if (!d || !frame || !gray || !out || !out_counts) return CS_ERR_INVALID_ARG;
   const int n = frame->n_boxes;
+  if (n < 0 || (n && !frame->boxes)) return CS_ERR_INVALID_ARG;
+  for (int i = 0; i < n; i++)
+    if (!box_inside_image(frame->boxes + 5 * (size_t)i, frame->img_w, frame->img_h)) { set_err("2D box outside the image"); return CS_ERR_INVALID_ARG; }
+  CS_GUARD_BEGIN
   std::vector<cs_roi> rois;
   std::vector<int> first(n + 1, 0);
   for (int i = 0; i < n; i++) {
@@ -1909,6 +1949,7 @@ int cs_detect_cuboids_gray(cs_detector* d, const cs_frame_desc* frame, const uns
   cs_frame_desc f2 = *frame;
   f2.dist_maps = maps.data();
   return cs_detect_cuboids(d, &f2, out, out_counts);
+  CS_GUARD_END("cs_detect_cuboids_gray")
 }
 
 int cs_detect_cuboids(cs_detector* d, const cs_frame_desc* frame, cs_cuboid* out, int* out_counts) {

@@ -270,6 +270,13 @@ int cs_ba_solver_layout(cs_ba* ba, int* band_ld, int* team);
  * free point in point order), Hpl (18 per projection edge in the caller's edge order), b, x.            */
 int cs_ba_get_system(cs_ba* ba, double* Hpp_dense, double* Hll9, double* Hpl18, double* b, double* x);
 
+/* A_ii of every vertex after cs_ba_build_system(): what g2o keeps mapped into its vertices (BaseVertex::mapHessianMemory,
+ * core/base_vertex.hpp:52-54, mapped by BlockSolver::buildStructure block_solver.hpp:185,191) and what
+ * OptimizationAlgorithmLevenberg::computeLambdaInit() reads through v->hessian(j, j)
+ * (optimization_algorithm_levenberg.cpp:166-180).  Caller's vertex order; cam36: n_cams x 36, cub81: n_cuboids x 81,
+ * pt9: n_points x 9 (NULL = skip); fixed vertices read as zero.                                                    */
+int cs_ba_get_vertex_hessians(cs_ba* ba, double* cam36, double* cub81, double* pt9);
+
 typedef struct cs_ba_timing {
   double errors_ms, linearize_ms, reduce_ms, schur_ms, factor_ms, backsub_ms, update_ms, total_ms;
   long long n_linearizations, n_solves;

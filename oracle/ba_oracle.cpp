@@ -31,6 +31,7 @@
 // (sparse_optimizer.cpp:166-190).  Ids: see ba_set_vertices().
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -275,7 +276,15 @@ struct Problem {
   std::vector<SE3> cams_bak; std::vector<Cuboid> cubs_bak; std::vector<double> pts_bak;
   // stats
   std::vector<double> chi_hist; std::vector<double> lambda_hist; std::vector<int> trials_hist;
+  // wall time per stage, the split of G2OBatchStatistics (Thirdparty/g2o/g2o/core/batch_stats.h:48-62): [0] residuals
+  // (timeResiduals), [1] linearisation + quadratic form (timeLinearization + timeQuadraticForm), [2] Schur complement
+  // (timeSchurComplement), [3] linear solver incl. back-substitution (timeLinearSolver), [4] update (timeUpdate); milliseconds
+  double stage_ms[5] = {0, 0, 0, 0, 0};
+  // bench.py's cpu_baseline at C4 only: > 1 = time every ldlt_stride-th column of the dense LDL^T and scale up (the
+  // factorisation of a 10 494 x 10 494 system is ~5e11 flop, minutes on one core); the increment is then NOT computed
+  int ldlt_stride = 1;
 };
+inline double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 void build_index(Problem& P) {
   int nc = (int)P.cams.size(), no = (int)P.cubs.size(), np = (int)(P.pts.size() / 3);
@@ -625,6 +634,28 @@ bool ldlt_solve(std::vector<double> A, int n, const double* b, double* x) {
   return true;
 }
 
+// Timing only: the arithmetic of every stride-th column of the factorisation above (same loops, same operands), wall time scaled
+// by the sampled share of the multiply-adds.  Leaves A untouched in the columns it skips; returns the estimated milliseconds.
+double ldlt_sampled_ms(std::vector<double>& A, int n, int stride) {
+  std::vector<double> D(n, 1.0);
+  double work_all = 0, work_done = 0;
+  for (int j = 0; j < n; j++) work_all += (double)j * (n - j);
+  const double t0 = wall_ms();
+  for (int j = stride / 2; j < n; j += stride) {
+    double d = A[(size_t)j * n + j];
+    for (int k = 0; k < j; k++) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k] * D[k];
+    D[j] = (d != 0) ? d : 1.0;
+    for (int i = j + 1; i < n; i++) {
+      double s = A[(size_t)i * n + j];
+      for (int k = 0; k < j; k++) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k] * D[k];
+      A[(size_t)i * n + j] = s / D[j];
+    }
+    work_done += (double)j * (n - j);
+  }
+  const double t = wall_ms() - t0;
+  return work_done > 0 ? t * work_all / work_done : 0.0;
+}
+
 inline void inv3(const double* a, double* r) {  // Eigen 3x3 inverse, cofactor form
   auto cof = [&](int i, int j) {
     int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
@@ -641,7 +672,8 @@ inline void inv3(const double* a, double* r) {  // Eigen 3x3 inverse, cofactor f
 bool solve_system(Problem& P) {  // block_solver.hpp:353-486
   int n = P.size_pose;
   P.x.assign(n + P.size_lm, 0.0);
-  if (P.n_lm == 0) return ldlt_solve(P.Hpp, n, P.b.data(), P.x.data());
+  if (P.n_lm == 0) { const double t0 = wall_ms(); bool ok = ldlt_solve(P.Hpp, n, P.b.data(), P.x.data()); P.stage_ms[3] += wall_ms() - t0; return ok; }
+  double t_stage = wall_ms();
   std::vector<double> S = P.Hpp;  // Hschur = Hpp
   std::vector<double> coeff(n, 0.0);
   std::vector<double> Dinv((size_t)P.n_lm * 9);
@@ -679,7 +711,10 @@ bool solve_system(Problem& P) {  // block_solver.hpp:353-486
   }
   std::vector<double> bschur(n);
   for (int i = 0; i < n; i++) bschur[i] = P.b[i] - coeff[i];
-  if (!ldlt_solve(S, n, bschur.data(), P.x.data())) return false;
+  P.stage_ms[2] += wall_ms() - t_stage;
+  t_stage = wall_ms();
+  if (P.ldlt_stride > 1) { P.stage_ms[3] += ldlt_sampled_ms(S, n, P.ldlt_stride); return true; }   // timing run: no increment
+  if (!ldlt_solve(std::move(S), n, bschur.data(), P.x.data())) { P.stage_ms[3] += wall_ms() - t_stage; return false; }
   // landmarks: xl = Dinv (bl - Hpl^T xp)
   std::vector<double> cl(P.b.begin() + n, P.b.end());
   for (size_t k = 0; k < P.eproj.size(); k++) {
@@ -693,6 +728,7 @@ bool solve_system(Problem& P) {  // block_solver.hpp:353-486
     }
   }
   for (int j = 0; j < P.n_lm; j++) mv3(&Dinv[9 * j], &cl[3 * j], &P.x[n + 3 * j]);
+  P.stage_ms[3] += wall_ms() - t_stage;
   return true;
 }
 
@@ -711,9 +747,13 @@ void apply_update(Problem& P) {  // sparse_optimizer.cpp:422-435
 
 // optimization_algorithm_levenberg.cpp:61-163; returns 0 = OK, 1 = Terminate
 int lm_solve(Problem& P, int iteration) {
+  double t_stage = wall_ms();
   compute_errors(P);
   double currentChi = robust_chi2(P), tempChi = currentChi, iniChi = currentChi;
+  P.stage_ms[0] += wall_ms() - t_stage;
+  t_stage = wall_ms();
   build_system(P);
+  P.stage_ms[1] += wall_ms() - t_stage;
   if (iteration == 0) {  // computeLambdaInit (:166-180): tau * max |H_jj| over all non-fixed vertices
     double maxDiagonal = 0;
     int n = P.size_pose;
@@ -728,10 +768,14 @@ int lm_solve(Problem& P, int iteration) {
     P.cams_bak = P.cams; P.cubs_bak = P.cubs; P.pts_bak = P.pts;  // push
     set_lambda(P, P.lambda);
     bool ok2 = solve_system(P);
+    t_stage = wall_ms();
     apply_update(P);
+    P.stage_ms[4] += wall_ms() - t_stage;
     restore_diagonal(P);
+    t_stage = wall_ms();
     compute_errors(P);
     tempChi = robust_chi2(P);
+    P.stage_ms[0] += wall_ms() - t_stage;
     if (!ok2) tempChi = std::numeric_limits<double>::max();
     rho = (currentChi - tempChi);
     double scale = 0;
@@ -848,6 +892,13 @@ void ba_oracle_get_state(void* h, double* cams7, double* cuboids10, double* poin
   for (size_t i = 0; i < P.cubs.size(); i++) { se3_to7(P.cubs[i].pose, cuboids10 + 10 * i); for (int d = 0; d < 3; d++) cuboids10[10 * i + 7 + d] = P.cubs[i].scale[d]; }
   if (points3) std::memcpy(points3, P.pts.data(), sizeof(double) * P.pts.size());
 }
+// wall time per stage accumulated by ba_oracle_optimize since the last reset (milliseconds; Problem::stage_ms)
+void ba_oracle_stage_ms(void* h, double out5[5], int reset) {
+  Problem& P = *(Problem*)h;
+  for (int i = 0; i < 5; i++) { out5[i] = P.stage_ms[i]; if (reset) P.stage_ms[i] = 0; }
+}
+// bench.py's cpu_baseline at C4: time every stride-th column of the dense LDL^T (Problem::ldlt_stride); 1 = the real solve
+void ba_oracle_set_ldlt_stride(void* h, int stride) { ((Problem*)h)->ldlt_stride = stride < 1 ? 1 : stride; }
 // stage-level access for parity tests
 double ba_oracle_compute_errors(void* h) { Problem& P = *(Problem*)h; compute_errors(P); return robust_chi2(P); }
 void ba_oracle_get_errors_cproj(void* h, double* cproj4) { Problem& P = *(Problem*)h; if (cproj4) std::memcpy(cproj4, P.err_cproj.data(), 8 * P.err_cproj.size()); }

@@ -86,6 +86,16 @@ class Problem:
     def optimize(self, iters):
         return lib().ba_oracle_optimize(self.h, int(iters))
 
+    def stage_ms(self, reset=False):
+        """Wall milliseconds per stage since the last reset: residuals, linearise + quadratic form, Schur, linear solve, update."""
+        out = np.zeros(5)
+        lib().ba_oracle_stage_ms(self.h, _dp(out), int(bool(reset)))
+        return dict(zip(("errors_ms", "linearize_ms", "schur_ms", "solve_ms", "update_ms"), out.tolist()))
+
+    def set_ldlt_stride(self, stride):
+        """Timing runs only: sample every stride-th column of the dense LDL^T (no increment is computed)."""
+        lib().ba_oracle_set_ldlt_stride(self.h, int(stride))
+
     def history(self, cap=64):
         chi, lam, tr = np.zeros(cap), np.zeros(cap), np.zeros(cap, np.int32)
         n = lib().ba_oracle_history(self.h, _dp(chi), _dp(lam), _ip(tr), cap)

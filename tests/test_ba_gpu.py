@@ -403,3 +403,115 @@ def test_band_solver_harness_shapes():
             res = [float(l.split("residual")[1]) for l in out.stdout.splitlines() if "residual" in l]
             infos = [int(l.split("info")[1].split()[0]) for l in out.stdout.splitlines() if "info" in l]
             assert len(res) == 2 and max(res) < 1e-12 and infos == [0, 0], (n, ld, env, out.stdout)
+
+
+def test_c3_at_its_named_size_against_the_oracle():
+    """BASELINE.json config C3 at full size -- 200 cameras, 20 000 points, 50 cuboids, 10 LM iterations -- against the CPU
+    oracle: same accept / reject sequence, chi2 history to 1e-6, states to 1e-5 relative (north_star's bar)."""
+    pr = synth_ba.make_problem(n_cams=200, n_points=20000, n_cuboids=50, seed=42)
+    assert len(pr["e_pt"]) > 90000 and len(pr["ce_cam"]) == 1000
+    G, R = capi.ba_from_dict(pr), _oracle(pr)
+    assert G.sizes() == (6 * 199 + 9 * 50, 3 * 20000)
+    n_g, n_r = G.optimize(10), R.optimize(10)
+    assert n_g == n_r == 10
+    chi_g, lam_g, tr_g = G.history()
+    chi_r, lam_r, tr_r = R.history()
+    assert np.array_equal(tr_g, tr_r)
+    assert np.allclose(chi_g, chi_r, rtol=1e-6) and np.allclose(lam_g, lam_r, rtol=1e-6)
+    assert chi_g[-1] < 0.2 * chi_g[0]
+    cg, og, pg = G.state()
+    cr, orr, prr = R.state()
+    scale = np.abs(prr).max()
+    assert np.abs(pg - prr).max() < 1e-5 * scale
+    assert np.abs(cg[:, :3] - cr[:, :3]).max() < 1e-5 * scale and np.abs(cg[:, 3:] - cr[:, 3:]).max() < 1e-5
+    assert np.abs(og[:, :3] - orr[:, :3]).max() < 1e-5 * scale and np.abs(og[:, 3:] - orr[:, 3:]).max() < 1e-5
+    G.close(); R.close()
+
+
+def test_c5_eight_shards_of_the_c4_problem_equal_the_single_rank_run():
+    """BASELINE.json config C5: the C4 problem (1 000 cameras, 200 000 points, 500 cuboids) cut into 8 camera subsequences.
+    Eight cs_ba handles share one GPU here (one thread each, in-process all-reduce); the sharded LM trajectory must be the
+    single-rank one: same trials, chi2 / lambda histories to 1e-9, states to 1e-7 of the scene scale."""
+    pr = synth_ba.make_problem(n_cams=1000, n_points=200000, n_cuboids=500, seed=42)
+    G = capi.ba_from_dict(pr)
+    n1 = G.optimize(3)
+    chi1, lam1, tr1 = G.history()
+    c1, o1, p1 = G.state()
+    G.close()
+    done, (chiS, lamS, trS), cS, oS, pS = _run_sharded_in_threads(pr, 8, 3)
+    assert done == [n1] * 8
+    assert np.array_equal(tr1, trS) and np.allclose(chi1, chiS, rtol=1e-9) and np.allclose(lam1, lamS, rtol=1e-9)
+    scale = np.abs(p1).max()
+    assert np.abs(pS - p1).max() < 1e-7 * scale and np.abs(cS - c1).max() < 1e-7 * scale and np.abs(oS - o1).max() < 1e-7 * scale
+    # every shard owns a share of the landmarks and the shares partition them
+    owners = capi.landmark_owners(8, 1000, 200000, pr["e_pt"], pr["e_cam"])
+    cnt = np.bincount(owners, minlength=8)
+    assert cnt.sum() == 200000 and cnt.min() > 0.5 * 200000 / 8
+
+
+def test_stepwise_abi_driven_like_g2o_levenberg():
+    """The step-wise C ABI driven exactly the way g2o's OptimizationAlgorithmLevenberg drives a g2o::Solver
+    (optimization_algorithm_levenberg.cpp:61-189 through adapters/block_solver_hip.h): estimates uploaded
+    (cs_ba_set_estimates), computeActiveErrors (cs_ba_compute_errors), buildSystem (cs_ba_build_system), lambda_0 from the
+    vertices' mapped diagonal blocks (cs_ba_get_vertex_hessians = v->hessian(j, j), :166-180), then per trial push / setLambda +
+    solve / update / chi2 / pop.  The host-side loop must land on cs_ba_optimize()'s trajectory, and lambda_0 on the oracle's."""
+    pr = synth_ba.make_problem(n_cams=40, n_points=2500, n_cuboids=8, seed=3)
+    A = capi.ba_from_dict(pr)       # driven step by step
+    B = capi.ba_from_dict(pr)       # one-shot reference
+    n_b = B.optimize(6)
+    chi_b, lam_b, tr_b = B.history()
+    cams, cubs, pts = (np.asarray(pr[k], float).copy() for k in ("cams", "cuboids", "points"))
+    lam, ni, n_bad = -1.0, 2.0, 0
+    chis, lams, trials = [], [], []
+    for it in range(6):
+        A.set_estimates(cams, cubs, pts)                 # adapter: upload_estimates() in buildSystem()
+        cur = A.compute_errors()
+        ini = tmp = cur
+        A.build_system()
+        if it == 0:
+            hc, ho, hp = A.vertex_hessians()
+            md = max(np.abs(np.einsum("kii->ki", hc)).max(), np.abs(np.einsum("kii->ki", ho)).max(), np.abs(np.einsum("kii->ki", hp)).max())
+            lam = 1e-5 * md
+            assert np.all(hc[np.asarray(pr["cam_fixed"]) != 0] == 0)      # fixed vertices carry no block
+        rho, q = 0.0, 0
+        while True:
+            A.push()
+            ok, _ = A.solve(lam)
+            b, x = A.system_vectors()
+            A.update()
+            tmp = A.compute_errors()
+            if not ok:
+                tmp = np.finfo(float).max
+            scale = float(np.dot(x, lam * x + b)) + 1e-3
+            rho = (cur - tmp) / scale
+            if rho > 0 and np.isfinite(tmp):
+                lam *= max(1.0 / 3.0, min(1.0 - (2 * rho - 1) ** 3, 2.0 / 3.0))
+                ni = 2.0
+                cur = tmp
+            else:
+                lam *= ni
+                ni *= 2
+                A.pop()
+            q += 1
+            if not (rho < 0 and q < 10):
+                break
+        cams, cubs, pts = A.state()                      # g2o keeps the estimates on its side between iterations
+        chis.append(cur); lams.append(lam); trials.append(q)
+        if q == 10 or rho == 0:
+            break
+        n_bad = n_bad + 1 if (ini - cur) * 1e3 < ini else 0
+        if n_bad >= 3:
+            break
+    assert len(chis) == n_b and trials == list(tr_b)
+    assert np.allclose(chis, chi_b, rtol=1e-9) and np.allclose(lams, lam_b, rtol=1e-9)
+    for a, b in zip(A.state(), B.state()):
+        assert np.abs(a - b).max() < 1e-9 * max(1.0, np.abs(b).max())
+    # lambda_0 is the oracle's (max |H_jj| over all free vertices, landmarks included)
+    C2 = capi.ba_from_dict(pr)
+    C2.compute_errors(); C2.build_system()
+    hc, ho, hp = C2.vertex_hessians()
+    md = max(np.abs(np.einsum("kii->ki", hc)).max(), np.abs(np.einsum("kii->ki", ho)).max(), np.abs(np.einsum("kii->ki", hp)).max())
+    Hpp_r, Hll_r, _, _ = _oracle(pr).build_system()
+    md_r = max(np.abs(np.diag(Hpp_r)).max(), np.abs(Hll_r[:, [0, 4, 8]]).max())
+    assert abs(md - md_r) < 1e-5 * md_r
+    A.close(); B.close(); C2.close()
