@@ -162,7 +162,7 @@ def main():
         # CPU baseline of the BA half (rank 0, N = 1): the oracle (oracle/ba_oracle.cpp, -O2, one thread) on the SAME problem, wall time
         # per LM iteration split as g2o's G2OBatchStatistics does (core/batch_stats.h:48-62).  C3: the full run.  C4: one LM
         # iteration with residuals / linearisation / Schur complement / update in full and the dense LDL^T (the reference
-        # constructs LinearSolverDense, main_obj.cpp:512) timed on every 64th column and scaled up (the whole factorisation of
+        # constructs LinearSolverDense, main_obj.cpp:512) timed on every 256th column and scaled up (the whole factorisation of
         # the 10 494-unknown system is ~5e11 flop: minutes on one core).
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             from oracle import ba_oracle_py
@@ -173,18 +173,41 @@ def main():
             R.set_edges_odom(pr["oe_i"], pr["oe_j"], pr["oe_meas"], pr["oe_info"])
             sampled = args.ba == "C4"
             if sampled:
-                R.set_ldlt_stride(64)
+                R.set_ldlt_stride(256)
             tc = time.perf_counter()
             n_cpu = R.optimize(1 if sampled else args.ba_iters)
             cpu_wall = time.perf_counter() - tc
             st = R.stage_ms()
-            tot_ms = sum(st.values())
+            note = ""
+            if sampled:
+                # The oracle's LDL^T is the textbook unblocked loop: at n = 10 494 it streams the 881 MB matrix once per column and
+                # would take ~25 minutes, far slower than the blocked Eigen::LDLT the reference links.  The baseline therefore
+                # prices the dense solve with LAPACK's blocked dpotrf on ONE thread (at least as fast as Eigen's), measured at
+                # n = 4096 and scaled by n^3; the oracle's own extrapolated figure is kept beside it.
+                import scipy.linalg
+                from threadpoolctl import threadpool_limits
+                n_pose = P.sizes()[0]
+                rng2 = np.random.default_rng(1)
+                m = 4096
+                M = rng2.standard_normal((m, 64))
+                A = M @ M.T + m * np.eye(m)
+                with threadpool_limits(limits=1):
+                    scipy.linalg.cho_factor(A[:512, :512].copy(), lower=True)
+                    t1 = time.perf_counter()
+                    scipy.linalg.cho_factor(A, lower=True, overwrite_a=True, check_finite=False)
+                    t_chol = time.perf_counter() - t1
+                st["solve_unblocked_oracle_ms_extrapolated"] = st["solve_ms"]
+                st["solve_ms"] = t_chol * 1e3 * (n_pose / m) ** 3
+                note = "; dense solve = LAPACK dpotrf, 1 thread, %.2f s at n = %d scaled by (%d/%d)^3" % (t_chol, m, n_pose, m)
+            tot_ms = sum(v for k, v in st.items() if not k.startswith("solve_unblocked"))
             ba_out["cpu_baseline"] = {"value": n_cpu / (tot_ms * 1e-3), "unit": "iters/s", "cores": 1, "kind": "port",
                                       "stage_ms_per_iteration": {k: v / n_cpu for k, v in st.items()},
-                                      "sample": ("1 LM iteration (1 trial) of the same C4 problem through oracle/ba_oracle.cpp: residuals, linearisation, Schur complement and update in full; "
-                                                 "dense LDL^T timed on every 64th column and scaled by the multiply-add count (%.1f s measured wall)" % cpu_wall) if sampled else
+                                      "sample": ("1 LM iteration (1 trial) of the same C4 problem through oracle/ba_oracle.cpp (-O2, single thread): residuals, linearisation, Schur complement "
+                                                 "and update in full (%.1f s wall incl. the sampled unblocked LDL^T)%s" % (cpu_wall, note)) if sampled else
                                                 ("%d LM iterations of the same problem through oracle/ba_oracle.cpp (-O2, single thread), dense LDL^T in full, %.1f s" % (n_cpu, cpu_wall))}
             ba_out["speedup_vs_cpu"] = ba_out["value"] / ba_out["cpu_baseline"]["value"]
+            build_cpu = (st["errors_ms"] + st["linearize_ms"] + st["schur_ms"]) / n_cpu
+            ba_out["speedup_vs_cpu_build_only"] = build_cpu / ba_out["build_only_ms_per_iteration"]
             R.close()
         P.close()
 

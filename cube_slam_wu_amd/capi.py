@@ -312,7 +312,7 @@ DECLARED_SYMBOLS += [
     "cs_ba_create", "cs_ba_destroy", "cs_ba_set_vertices", "cs_ba_set_estimates", "cs_ba_set_edges_proj", "cs_ba_set_edges_cuboid", "cs_ba_set_edges_cuboid_proj", "cs_ba_set_edges_odom",
     "cs_ba_compute_errors", "cs_ba_build_system", "cs_ba_solve", "cs_ba_update", "cs_ba_push", "cs_ba_pop", "cs_ba_optimize",
     "cs_ba_get_state", "cs_ba_sizes", "cs_ba_solver_layout", "cs_ba_get_system", "cs_ba_last_timing", "cs_ba_set_shard", "cs_ba_optimize_sharded",
-    "cs_ba_shard_landmark_owners", "cs_ba_get_vertex_hessians",
+    "cs_ba_shard_landmark_owners", "cs_ba_get_vertex_hessians", "cs_ba_schur_layout",
 ]
 
 
@@ -412,6 +412,12 @@ class BaProblem:
         b, x = np.zeros(n + nl), np.zeros(n + nl)
         _chk(lib().cs_ba_get_system(self.h, None, None, None, _dp(b), _dp(x)), "cs_ba_get_system")
         return b, x
+
+    def schur_layout(self):
+        """(fused, segments, partial blocks, destination blocks) of the Schur-complement build (cs_ba_schur_layout)."""
+        a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _chk(lib().cs_ba_schur_layout(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "cs_ba_schur_layout")
+        return bool(a.value), b.value, c.value, d.value
 
     def solver_layout(self):
         a, b = C.c_int(), C.c_int()

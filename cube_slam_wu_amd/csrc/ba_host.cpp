@@ -129,6 +129,11 @@ struct cs_ba {
   DBuf<int> cam_ce_ptr, cam_ce_idx, cam_oei_ptr, cam_oei_idx, cam_oej_ptr, cam_oej_idx, cub_ce_ptr, cub_ce_idx;
   DBuf<double> Hcam, bcam, Hcub, bcub, Hll, bl, W, WD, Dinv, dbl, S, rhs, xl, chi_partial, band_linv, scale_partial;
   DBuf<int> pair_ptr, pair_i1, pair_i2, ent_a, ent_b;
+  // fused Schur schedule (BaView::fused)
+  bool fused = false;
+  int n_seg = 0, n_gpairs = 0, seg_class[2] = {0, 0};
+  DBuf<int> d_run_lm, d_seg_ptr, d_seg_k, d_seg_tile, d_seg_slot, d_gp_ptr, d_gp_i1, d_gp_i2, d_gtile, d_gcam_ptr, d_gslot;
+  DBuf<double> part_tiles, part_coef;
   DBuf<rocblas_int> d_info;
   DBuf<int> d_band_info;
   int n_pairs = 0, nb_chi = 1, n_chi_partials = 1;
@@ -172,6 +177,37 @@ int finalize_structure(cs_ba* B) {
     if (B->cuboids_first) { do_cubs(); do_cams(); } else { do_cams(); do_cubs(); }
     B->n_pose = col;
   }
+  // ---- the free landmarks grouped by the set of cameras that see them.  cams_of: every landmark's cameras sorted by id;
+  // gorder: free landmarks with >= 1 edge sorted by (number of cameras, camera list); run_first: where each distinct set starts
+  for (int k = 0; k < B->n_proj; k++)
+    if (B->e_pt[k] < 0 || B->e_pt[k] >= np || B->e_cam[k] < 0 || B->e_cam[k] >= nc) { cs_set_error_ba("projection edge index out of range"); return CS_ERR_INVALID_ARG; }
+  std::vector<int> cam_cnt(np + 1, 0), cams_of(B->n_proj), gorder, run_first;
+  {
+    for (int k = 0; k < B->n_proj; k++) cam_cnt[B->e_pt[k] + 1]++;
+    for (int i = 0; i < np; i++) cam_cnt[i + 1] += cam_cnt[i];
+    std::vector<int> fill(cam_cnt.begin(), cam_cnt.end() - 1);
+    for (int k = 0; k < B->n_proj; k++) cams_of[fill[B->e_pt[k]]++] = B->e_cam[k];
+    for (int p = 0; p < np; p++) {
+      std::sort(cams_of.begin() + cam_cnt[p], cams_of.begin() + cam_cnt[p + 1]);
+      for (int a = cam_cnt[p] + 1; a < cam_cnt[p + 1]; a++)
+        if (cams_of[a] == cams_of[a - 1]) { cs_set_error_ba("two projection edges between the same point and camera"); return CS_ERR_INVALID_ARG; }
+      if (!B->pt_fixed[p] && cam_cnt[p + 1] > cam_cnt[p]) gorder.push_back(p);
+    }
+    auto same_set = [&](int p, int q) {
+      const int kp = cam_cnt[p + 1] - cam_cnt[p];
+      return kp == cam_cnt[q + 1] - cam_cnt[q] && std::equal(cams_of.begin() + cam_cnt[p], cams_of.begin() + cam_cnt[p + 1], cams_of.begin() + cam_cnt[q]);
+    };
+    std::sort(gorder.begin(), gorder.end(), [&](int p, int q) {
+      const int kp = cam_cnt[p + 1] - cam_cnt[p], kq = cam_cnt[q + 1] - cam_cnt[q];
+      if (kp != kq) return kp < kq;
+      const int c = std::lexicographical_compare(cams_of.begin() + cam_cnt[p], cams_of.begin() + cam_cnt[p + 1], cams_of.begin() + cam_cnt[q], cams_of.begin() + cam_cnt[q + 1]);
+      if (c) return true;
+      if (std::lexicographical_compare(cams_of.begin() + cam_cnt[q], cams_of.begin() + cam_cnt[q + 1], cams_of.begin() + cam_cnt[p], cams_of.begin() + cam_cnt[p + 1])) return false;
+      return p < q;
+    });
+    for (size_t i = 0; i < gorder.size(); i++) if (i == 0 || !same_set(gorder[i - 1], gorder[i])) run_first.push_back((int)i);
+    run_first.push_back((int)gorder.size());
+  }
   // ---- solver ordering of the pose vertices: reverse Cuthill-McKee on the block graph of the reduced system
   // (camera-camera through shared landmarks and odometry edges, camera-cuboid through cuboid edges), so that S is
   // banded for trajectory-shaped graphs.  The ordering only permutes the linear system; g2o's order is kept for x/b
@@ -182,18 +218,11 @@ int finalize_structure(cs_ba* B) {
     std::vector<std::vector<int>> adj(NV);
     auto is_free = [&](int v) { return v < nc ? !B->cam_fixed[v] : !B->cub_fixed[v - nc]; };
     auto link = [&](int a, int b) { if (a != b && is_free(a) && is_free(b)) { adj[a].push_back(b); adj[b].push_back(a); } };
-    for (int k = 0; k < B->n_proj; k++)
-      if (B->e_pt[k] < 0 || B->e_pt[k] >= np || B->e_cam[k] < 0 || B->e_cam[k] >= nc) { cs_set_error_ba("projection edge index out of range"); return CS_ERR_INVALID_ARG; }
-    {
-      std::vector<int> cnt(np + 1, 0), cams_of(B->n_proj);
-      for (int k = 0; k < B->n_proj; k++) cnt[B->e_pt[k] + 1]++;
-      for (int i = 0; i < np; i++) cnt[i + 1] += cnt[i];
-      std::vector<int> fill(cnt.begin(), cnt.end() - 1);
-      for (int k = 0; k < B->n_proj; k++) cams_of[fill[B->e_pt[k]]++] = B->e_cam[k];
-      for (int p = 0; p < np; p++) {
-        if (B->pt_fixed[p]) continue;
-        for (int a = cnt[p]; a < cnt[p + 1]; a++) for (int b = a + 1; b < cnt[p + 1]; b++) link(cams_of[a], cams_of[b]);
-      }
+    // landmarks couple the cameras that see them: one clique per DISTINCT camera set (the landmarks were grouped by camera set
+    // above; KITTI-shaped problems have ~100x fewer sets than landmarks)
+    for (size_t r = 0; r + 1 < run_first.size(); r++) {
+      const int p = gorder[run_first[r]];
+      for (int a = cam_cnt[p]; a < cam_cnt[p + 1]; a++) for (int b = a + 1; b < cam_cnt[p + 1]; b++) link(cams_of[a], cams_of[b]);
     }
     for (int k = 0; k < B->n_odom; k++) if (B->oe_i[k] >= 0 && B->oe_i[k] < nc && B->oe_j[k] >= 0 && B->oe_j[k] < nc) link(B->oe_i[k], B->oe_j[k]);
     for (int k = 0; k < B->n_cub; k++) if (B->ce_cam[k] >= 0 && B->ce_cam[k] < nc && B->ce_cub[k] >= 0 && B->ce_cub[k] < no) link(B->ce_cam[k], nc + B->ce_cub[k]);
@@ -239,12 +268,10 @@ int finalize_structure(cs_ba* B) {
     B->band_ld = (!B->force_dense && B->n_pose > 128 && bw + 1 <= B->n_pose / 2 && cs::ba_band_fits_device(B->n_pose, bw + 1)) ? bw + 1 : 0;
   }
   // ---- this rank's projection edges
-  {
-    std::vector<int> owner;
-    landmark_owners(B->shard_n, nc, np, B->n_proj, B->e_pt.data(), B->e_cam.data(), owner);
-    B->keep.clear();
-    for (int k = 0; k < B->n_proj; k++) if (owner[B->e_pt[k]] == B->shard_rank) B->keep.push_back(k);
-  }
+  std::vector<int> owner;
+  landmark_owners(B->shard_n, nc, np, B->n_proj, B->e_pt.data(), B->e_cam.data(), owner);
+  B->keep.clear();
+  for (int k = 0; k < B->n_proj; k++) if (owner[B->e_pt[k]] == B->shard_rank) B->keep.push_back(k);
   int nl = 0;
   std::vector<int> pt_free(np);
   for (int i = 0; i < np; i++) { pt_free[i] = B->pt_fixed[i] ? 0 : 1; if (pt_free[i]) B->pt_lm[i] = nl++; }
@@ -260,7 +287,8 @@ int finalize_structure(cs_ba* B) {
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
     int ka = B->keep[a], kb = B->keep[b];
     if (B->e_pt[ka] != B->e_pt[kb]) return B->e_pt[ka] < B->e_pt[kb];
-    return B->cam_col[B->e_cam[ka]] < B->cam_col[B->e_cam[kb]];
+    if (B->cam_col[B->e_cam[ka]] != B->cam_col[B->e_cam[kb]]) return B->cam_col[B->e_cam[ka]] < B->cam_col[B->e_cam[kb]];
+    return B->e_cam[ka] < B->e_cam[kb];   // fixed cameras (column -1) by id: landmarks with one camera set share one slot order
   });
   B->pm_of_orig.assign(B->n_proj, -1);
   std::vector<int> pm_pt(E), pm_cam(E), pt_ptr(np + 1, 0);
@@ -293,8 +321,66 @@ int finalize_structure(cs_ba* B) {
   }
   UP(B->pm_pt, pm_pt); UP(B->pm_cam, pm_cam); UP(B->pt_ptr, pt_ptr); UP(B->pm_uv, pm_uv); UP(B->pm_info, pm_info); UP(B->pm_intr, pm_intr); UP(B->pm_huber, pm_huber);
   UP(B->cm_pm, cm_pm); UP(B->cm_pt, cm_pt); UP(B->cam_ptr, cam_ptr); UP(B->cm_uv, cm_uv); UP(B->cm_info, cm_info); UP(B->cm_intr, cm_intr); UP(B->cm_huber, cm_huber);
-  // ---- Schur pattern (block_solver.hpp:262-292): (landmark, i1 <= i2) entries grouped by camera pair
-  {
+  // ---- Schur pattern (block_solver.hpp:262-292).  Fused path: segments of landmarks with one camera set + the destination
+  // schedule of their partial blocks (BaView::fused).  It needs every landmark to be seen by <= BA_FUSED_KMAX cameras; otherwise
+  // (or with CS_BA_SCHUR_PAIRS=1, diagnostics) the pair-major path: (landmark, i1 <= i2) entries grouped by camera pair.
+  B->fused = getenv("CS_BA_SCHUR_PAIRS") == nullptr;
+  for (int p : gorder) if (owner[p] == B->shard_rank && cam_cnt[p + 1] - cam_cnt[p] > cs::BA_FUSED_KMAX) { B->fused = false; break; }
+  B->n_seg = 0; B->n_gpairs = 0; B->seg_class[0] = B->seg_class[1] = 0;
+  B->schur_entries = 0;
+  for (int p : gorder) if (owner[p] == B->shard_rank) { const long long k = cam_cnt[p + 1] - cam_cnt[p]; B->schur_entries += k * (k + 1) / 2; }
+  if (B->fused) {
+    std::vector<int> run_lm, seg_ptr{0}, seg_k, seg_tile, seg_slot;
+    struct Dst { long long key; int id; };
+    std::vector<Dst> dst;                      // (block key, partial block id), segment order
+    std::vector<std::pair<int, int>> cdst;     // (camera, partial vector id)
+    const long long NP = std::max(1, B->n_pose);
+    int n_tiles = 0, n_slots = 0;
+    for (size_t r = 0; r + 1 < run_first.size(); r++) {
+      const int p0 = gorder[run_first[r]], k = cam_cnt[p0 + 1] - cam_cnt[p0];
+      // slot order of the run = the point-major edge order: by (column, camera id)
+      std::vector<int> slot_cam(cams_of.begin() + cam_cnt[p0], cams_of.begin() + cam_cnt[p0 + 1]);
+      std::sort(slot_cam.begin(), slot_cam.end(), [&](int a, int b) { return B->cam_col[a] != B->cam_col[b] ? B->cam_col[a] < B->cam_col[b] : a < b; });
+      int in_seg = 0;
+      for (int q = run_first[r]; q < run_first[r + 1]; q++) {
+        const int p = gorder[q];
+        if (owner[p] != B->shard_rank) continue;
+        if (in_seg == 0) {   // open a segment
+          seg_k.push_back(k); seg_tile.push_back(n_tiles); seg_slot.push_back(n_slots);
+          for (int a = 0; a < k; a++) {
+            const int ca = B->cam_col[slot_cam[a]];
+            if (ca < 0) continue;
+            cdst.push_back({slot_cam[a], n_slots + a});
+            for (int b = a; b < k; b++) dst.push_back(Dst{(long long)ca * NP + B->cam_col[slot_cam[b]], n_tiles + a * k - a * (a - 1) / 2 + (b - a)});
+          }
+          n_tiles += k * (k + 1) / 2; n_slots += k;
+        }
+        run_lm.push_back(p);
+        if (++in_seg == cs::BA_SEG_LM) { seg_ptr.push_back((int)run_lm.size()); in_seg = 0; }
+      }
+      if (in_seg) seg_ptr.push_back((int)run_lm.size());
+    }
+    B->n_seg = (int)seg_k.size();
+    for (int sgi = 0; sgi < B->n_seg; sgi++) { if (seg_k[sgi] <= 2) B->seg_class[0] = sgi + 1; if (seg_k[sgi] <= 5) B->seg_class[1] = sgi + 1; }   // segments are sorted by k
+    std::stable_sort(dst.begin(), dst.end(), [](const Dst& x, const Dst& y) { return x.key < y.key; });
+    std::vector<int> gp_ptr, gp_i1, gp_i2, gtile(dst.size());
+    for (size_t i = 0; i < dst.size(); i++) {
+      if (i == 0 || dst[i].key != dst[i - 1].key) { gp_ptr.push_back((int)i); gp_i1.push_back((int)(dst[i].key / NP)); gp_i2.push_back((int)(dst[i].key % NP)); }
+      gtile[i] = dst[i].id;
+    }
+    gp_ptr.push_back((int)dst.size());
+    B->n_gpairs = (int)gp_i1.size();
+    std::vector<int> gcam_ptr(nc + 1, 0), gslot(cdst.size());
+    for (auto& e : cdst) gcam_ptr[e.first + 1]++;
+    for (int i = 0; i < nc; i++) gcam_ptr[i + 1] += gcam_ptr[i];
+    { std::vector<int> fill(gcam_ptr.begin(), gcam_ptr.end() - 1); for (auto& e : cdst) gslot[fill[e.first]++] = e.second; }
+    UP(B->d_run_lm, run_lm); UP(B->d_seg_ptr, seg_ptr); UP(B->d_seg_k, seg_k); UP(B->d_seg_tile, seg_tile); UP(B->d_seg_slot, seg_slot);
+    UP(B->d_gp_ptr, gp_ptr); UP(B->d_gp_i1, gp_i1); UP(B->d_gp_i2, gp_i2); UP(B->d_gtile, gtile); UP(B->d_gcam_ptr, gcam_ptr); UP(B->d_gslot, gslot);
+    AL(B->part_tiles, 36 * (size_t)n_tiles); AL(B->part_coef, 6 * (size_t)n_slots);
+    B->n_pairs = 0;
+    std::vector<int> none(1, 0);
+    UP(B->pair_ptr, none); UP(B->pair_i1, none); UP(B->pair_i2, none); UP(B->ent_a, none); UP(B->ent_b, none);
+  } else {
     struct Ent { long long key; int a, b; };
     std::vector<Ent> ents;
     const long long NP = std::max(1, B->n_pose);
@@ -322,8 +408,11 @@ int finalize_structure(cs_ba* B) {
     }
     pair_ptr.push_back((int)ents.size());
     B->n_pairs = (int)pair_i1.size();
-    B->schur_entries = (long long)ents.size();
     UP(B->pair_ptr, pair_ptr); UP(B->pair_i1, pair_i1); UP(B->pair_i2, pair_i2); UP(B->ent_a, ent_a); UP(B->ent_b, ent_b);
+    std::vector<int> none(1, 0);
+    UP(B->d_run_lm, none); UP(B->d_seg_ptr, none); UP(B->d_seg_k, none); UP(B->d_seg_tile, none); UP(B->d_seg_slot, none);
+    UP(B->d_gp_ptr, none); UP(B->d_gp_i1, none); UP(B->d_gp_i2, none); UP(B->d_gtile, none); UP(B->d_gcam_ptr, none); UP(B->d_gslot, none);
+    AL(B->part_tiles, 1); AL(B->part_coef, 1);
   }
   // ---- cuboid / odometry edges and their vertex adjacency
   for (int k = 0; k < B->n_cub; k++)
@@ -384,6 +473,11 @@ int finalize_structure(cs_ba* B) {
   v.Hcam = B->Hcam.p; v.bcam = B->bcam.p; v.Hcub = B->Hcub.p; v.bcub = B->bcub.p; v.Hll = B->Hll.p; v.bl = B->bl.p; v.W = B->W.p; v.WD = B->WD.p;
   v.Dinv = B->Dinv.p; v.dbl = B->dbl.p; v.S = B->S.p; v.band_ld = B->band_ld; v.add_lambda = (B->shard_rank == 0); v.rhs = B->S.p + B->s_doubles; v.xl = B->xl.p;
   v.n_pairs = B->n_pairs; v.pair_ptr = B->pair_ptr.p; v.pair_i1 = B->pair_i1.p; v.pair_i2 = B->pair_i2.p; v.ent_a = B->ent_a.p; v.ent_b = B->ent_b.p;
+  v.fused = B->fused ? 1 : 0; v.n_seg = B->n_seg; v.seg_class[0] = B->seg_class[0]; v.seg_class[1] = B->seg_class[1];
+  v.seg_ptr = B->d_seg_ptr.p; v.seg_k = B->d_seg_k.p; v.seg_tile = B->d_seg_tile.p; v.seg_slot = B->d_seg_slot.p; v.run_lm = B->d_run_lm.p;
+  v.part_tiles = B->part_tiles.p; v.part_coef = B->part_coef.p;
+  v.n_gpairs = B->n_gpairs; v.gpair_ptr = B->d_gp_ptr.p; v.gpair_i1 = B->d_gp_i1.p; v.gpair_i2 = B->d_gp_i2.p; v.gtile = B->d_gtile.p;
+  v.gcam_ptr = B->d_gcam_ptr.p; v.gslot = B->d_gslot.p;
   v.chi_partial = B->chi_partial.p;
   // the allocations above were zeroed by hipMemset on the NULL stream, which a non-blocking stream does not wait for:
   // drain it before the first kernel of B->st can write into those buffers
@@ -544,11 +638,12 @@ void cs_ba_destroy(cs_ba* B) {
   DBuf<double>* dd[] = {&B->cams, &B->points, &B->cubes, &B->cams_bak, &B->points_bak, &B->cubes_bak, &B->pm_uv, &B->pm_info, &B->pm_intr, &B->pm_huber,
                         &B->cm_uv, &B->cm_info, &B->cm_intr, &B->cm_huber, &B->ce_meas, &B->ce_info, &B->ce_Hcc, &B->ce_Hoo, &B->ce_Hco, &B->ce_bc, &B->ce_bo,
                         &B->oe_meas, &B->oe_info, &B->oe_Hii, &B->oe_Hjj, &B->oe_Hij, &B->oe_bi, &B->oe_bj, &B->Hcam, &B->bcam, &B->Hcub, &B->bcub, &B->Hll, &B->bl,
-                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv, &B->scale_partial, &B->pe_meas, &B->pe_info, &B->pe_K};
+                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv, &B->scale_partial, &B->pe_meas, &B->pe_info, &B->pe_K, &B->part_tiles, &B->part_coef};
   for (auto* d : dd) d->release();
   DBuf<int>* di[] = {&B->d_ce_active, &B->d_oe_active, &B->d_cam_col, &B->d_cub_col, &B->d_pt_free, &B->pm_pt, &B->pm_cam, &B->pt_ptr, &B->cm_pm, &B->cm_pt, &B->cam_ptr, &B->d_ce_cam, &B->d_ce_cub,
                      &B->d_oe_i, &B->d_oe_j, &B->cam_ce_ptr, &B->cam_ce_idx, &B->cam_oei_ptr, &B->cam_oei_idx, &B->cam_oej_ptr, &B->cam_oej_idx, &B->cub_ce_ptr,
-                     &B->cub_ce_idx, &B->pair_ptr, &B->pair_i1, &B->pair_i2, &B->ent_a, &B->ent_b};
+                     &B->cub_ce_idx, &B->pair_ptr, &B->pair_i1, &B->pair_i2, &B->ent_a, &B->ent_b, &B->d_run_lm, &B->d_seg_ptr, &B->d_seg_k, &B->d_seg_tile, &B->d_seg_slot,
+                     &B->d_gp_ptr, &B->d_gp_i1, &B->d_gp_i2, &B->d_gtile, &B->d_gcam_ptr, &B->d_gslot};
   for (auto* d : di) d->release();
   B->d_info.release(); B->d_band_info.release();
   for (auto& e : B->ev) if (e) (void)hipEventDestroy(e);
@@ -935,6 +1030,18 @@ int cs_ba_get_system(cs_ba* B, double* Hpp, double* Hll9, double* Hpl18, double*
   BA_GUARD_BEGIN
   return cs_ba_get_system_impl(B, Hpp, Hll9, Hpl18, b, x);
   BA_GUARD_END("cs_ba_get_system")
+}
+
+int cs_ba_schur_layout(cs_ba* B, int* fused, int* n_segments, int* n_partial_blocks, int* n_blocks) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  BA_GUARD_BEGIN
+  int rc = finalize_structure(B); if (rc) return rc;
+  if (fused) *fused = B->fused ? 1 : 0;
+  if (n_segments) *n_segments = B->n_seg;
+  if (n_partial_blocks) *n_partial_blocks = (int)(B->part_tiles.n / 36);
+  if (n_blocks) *n_blocks = B->fused ? B->n_gpairs : B->n_pairs;
+  return CS_OK;
+  BA_GUARD_END("cs_ba_schur_layout")
 }
 
 // The diagonal Hessian blocks g2o keeps mapped into its vertices (BaseVertex::_hessian, core/base_vertex.hpp:30,52-54; mapped by

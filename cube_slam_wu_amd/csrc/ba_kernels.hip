@@ -538,6 +538,159 @@ __global__ __launch_bounds__(128) void ba_schur_kernel(BaView v) {
   }
 }
 
+// ---- fused Schur product on the matrix cores ----------------------------------------------------------------------------
+// block_solver.hpp:385-431 for one segment of landmarks that are seen by the same k cameras.  Their Hpl blocks form, per
+// landmark j, a (6k x 3) matrix W_j (rows: camera slot a, row r of its 6 x 3 block; contiguous in the point-major W array), and
+//     sum_j W_j D_j^-1 W_j^T   (6k x 6k)       sum_j W_j D_j^-1 b_l,j   (6k)
+// is ONE matrix product whose contraction index runs over (landmark, landmark coordinate): A = [W_j D_j^-1]_j (6k x 3m),
+// B = [W_j | b_l,j]_j^T (3m x (6k + 1)).  v_mfma_f64_16x16x4_f64 takes the K = 3 coordinates of one landmark (padded to 4) per
+// issue; a wavefront walks its segment, keeping the upper block triangle of the product in accumulator registers
+// (MT x MT tiles of 16 x 16), i.e. the cross-landmark reduction happens inside the matrix core, not through LDS or atomics.
+// Operand lane map of the f64 16x16x4 form: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+// D[row = (lane >> 4) + 4 reg][col = lane & 15].
+// Every W record is read from HBM exactly once (the pair-major kernel re-read it once per camera pair), D^-1 is written once for
+// the back-substitution, and W D^-1 never exists in memory.
+typedef double ba_v4d __attribute__((ext_vector_type(4)));
+
+template <int MT>
+struct BaSegOperands {
+  double Dm[9];        // H_ll of the landmark (lambda not yet added)
+  double w[MT][3];     // W row 16 t + i
+  double bcol[MT];     // B operand of N-tile u
+  int p;
+};
+
+// all loads unconditional (clamped addresses, values selected afterwards): no exec-masked branches, so the compiler can count
+// the loads in flight and the prefetch of the next landmark really overlaps this one's products
+template <int MT>
+__device__ __forceinline__ void ba_seg_load(const BaView& v, int p, int e0, int rows, int i, int kk, BaSegOperands<MT>& o) {
+  o.p = p;
+  const double* H = v.Hll + 9 * (size_t)p;
+#pragma unroll
+  for (int q = 0; q < 9; q++) o.Dm[q] = H[q];
+  const double* Wp = v.W + 18 * (size_t)e0;
+  const int k3 = kk < 3 ? kk : 0;
+  const double blv = v.bl[3 * (size_t)p + k3];
+#pragma unroll
+  for (int t = 0; t < MT; t++) {
+    const int row = 16 * t + i;
+    const bool in = row < rows;
+    const double* wr = Wp + 3 * (in ? row : rows - 1);
+    const double w0 = wr[0], w1 = wr[1], w2 = wr[2];
+    o.w[t][0] = in ? w0 : 0.0; o.w[t][1] = in ? w1 : 0.0; o.w[t][2] = in ? w2 : 0.0;
+    // B: column `row` of [W_j^T | b_l]: W(row, kk) below `rows`, the right-hand-side column at `rows`
+    const double wk = k3 == 0 ? w0 : (k3 == 1 ? w1 : w2);
+    o.bcol[t] = kk < 3 ? (in ? wk : (row == rows ? blv : 0.0)) : 0.0;
+  }
+}
+
+template <int MT>
+__device__ __forceinline__ void ba_schur_segment(const BaView& v, double lambda, int seg, int k) {
+  const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4, rows = 6 * k;
+  const int q0 = v.seg_ptr[seg], q1 = v.seg_ptr[seg + 1];
+  // the segment's landmark ids and first-edge slots, one per lane, broadcast with readlane inside the loop (no dependent
+  // scalar loads on the chain)
+  int my_p = 0, my_e0 = 0;
+  if (q0 + lane < q1) { my_p = v.run_lm[q0 + lane]; my_e0 = v.pt_ptr[my_p]; }
+  ba_v4d acc[MT][MT];
+#pragma unroll
+  for (int t = 0; t < MT; t++)
+#pragma unroll
+    for (int u = 0; u < MT; u++) acc[t][u] = ba_v4d{0.0, 0.0, 0.0, 0.0};
+  // ping-pong operand buffers: while landmark q is multiplied, the loads of landmark q + 1 are in flight
+  BaSegOperands<MT> bufA, bufB;
+  const int n = q1 - q0;
+  auto load = [&](BaSegOperands<MT>& o, int q) {
+    const int qq = q < n ? q : n - 1;            // past the end: re-load the last landmark (harmless, keeps the loop branch-free)
+    ba_seg_load<MT>(v, __builtin_amdgcn_readlane(my_p, qq), __builtin_amdgcn_readlane(my_e0, qq), rows, i, kk, o);
+  };
+  auto product = [&](const BaSegOperands<MT>& o) {
+    double D[9], Di[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) D[e] = o.Dm[e];
+    D[0] += lambda; D[4] += lambda; D[8] += lambda;
+    inv3x3(D, Di);
+    if (lane < 9) v.Dinv[9 * (size_t)o.p + lane] = Di[lane];       // for the back-substitution (block_solver.hpp:457-482)
+    const int k3 = kk < 3 ? kk : 0;
+    double a[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+      const double wd = o.w[t][0] * Di[k3] + o.w[t][1] * Di[3 + k3] + o.w[t][2] * Di[6 + k3];   // (W D^-1)(row, kk), as ba_wd_kernel
+      a[t] = kk < 3 ? wd : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+      for (int u = t; u < MT; u++) acc[t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], o.bcol[u], acc[t][u], 0, 0, 0);
+  };
+  load(bufA, 0);
+  for (int q = 0; q < n; q += 2) {
+    load(bufB, q + 1);
+    product(bufA);
+    if (q + 1 < n) {            // wave-uniform
+      load(bufA, q + 2);
+      product(bufB);
+    }
+  }
+  // flush: the k (k + 1) / 2 blocks (a <= b; diagonal blocks: upper triangle c >= r, what the reduced system stores) and
+  // the k coefficient vectors
+  const int tile0 = v.seg_tile[seg], slot0 = v.seg_slot[seg];
+#pragma unroll
+  for (int t = 0; t < MT; t++)
+#pragma unroll
+    for (int u = t; u < MT; u++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int R = 16 * t + (lane >> 4) + 4 * g, Cc = 16 * u + (lane & 15);
+        if (R >= rows) continue;
+        const int sa = R / 6, r = R - 6 * sa;
+        const double val = acc[t][u][g];
+        if (Cc < rows) {
+          const int sb = Cc / 6, c = Cc - 6 * sb;
+          if (sa < sb || (sa == sb && c >= r)) v.part_tiles[36 * (size_t)(tile0 + sa * k - sa * (sa - 1) / 2 + (sb - sa)) + 6 * r + c] = val;
+        } else if (Cc == rows) {
+          v.part_coef[6 * (size_t)(slot0 + sa) + r] = val;
+        }
+      }
+}
+
+// one instantiation per tile count (the segments are sorted by k, so each launch covers a contiguous range): MT = 1 for k <= 2
+// (12 rows + the right-hand-side column), 2 for k <= 5 (30 + 1), 3 for k <= BA_FUSED_KMAX = 7 (42 + 1)
+template <int MT>
+__global__ __launch_bounds__(256) void ba_schur_fused_kernel(BaView v, double lambda, int seg_begin, int seg_end) {
+  const int seg = __builtin_amdgcn_readfirstlane(seg_begin + blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform: scalar loads below
+  if (seg >= seg_end) return;
+  ba_schur_segment<MT>(v, lambda, seg, v.seg_k[seg]);
+}
+
+// destination schedule, blocks: one wavefront per block of the reduced system sums the partial blocks written for it, in the
+// order of the segments (fixed: the result does not depend on scheduling), and subtracts the sum (block_solver.hpp:409-431)
+__global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaView v) {
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (pair >= v.n_gpairs || lane >= 36) return;
+  double s = 0;
+  for (int q = v.gpair_ptr[pair]; q < v.gpair_ptr[pair + 1]; q++) s += v.part_tiles[36 * (size_t)v.gtile[q] + lane];
+  const int r = lane / 6, c = lane % 6;
+  const int i1 = v.gpair_i1[pair], i2 = v.gpair_i2[pair];
+  if (i1 != i2 || c >= r) *ba_S_at(v, i2 + c, i1 + r) -= s;
+}
+
+// destination schedule, right-hand side: S_cc = A_cc + lambda I and b_schur,c = b_c - sum of the camera's partial W D^-1 b_l
+__global__ __launch_bounds__(64) void ba_cam_rhs_fused_kernel(BaView v, double lambda) {
+  const int c = blockIdx.x, t = threadIdx.x;
+  const int col = v.cam_col[c];
+  if (col < 0) return;
+  if (t < 6) {
+    double s = 0;
+    for (int q = v.gcam_ptr[c]; q < v.gcam_ptr[c + 1]; q++) s += v.part_coef[6 * (size_t)v.gslot[q] + t];
+    v.rhs[col + t] = v.bcam[6 * c + t] - s;
+  }
+  if (t < 36) {
+    const int i = t / 6, j = t % 6;
+    if (i >= j) *ba_S_at(v, col + i, col + j) = v.Hcam[36 * c + t] + ((i == j && v.add_lambda) ? lambda : 0.0);
+  }
+}
+
 __global__ __launch_bounds__(256) void ba_backsub_kernel(BaView v) {
   int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= v.np) return;
@@ -1616,6 +1769,18 @@ void ba_launch_linearize(const BaView& v, hipStream_t st) {
   hipLaunchKernelGGL(ba_accum_pose_kernel, dim3(v.nc + v.no), dim3(128), 0, st, v, 0);
 }
 void ba_launch_reduce(const BaView& v, double lambda, hipStream_t st) {
+  if (v.fused) {
+    // the diagonal blocks / right-hand side of the cameras need the segments' partial vectors; the gather of the blocks runs last
+    // (it subtracts from entries the vertex kernels have written)
+    if (v.seg_class[0] > 0) hipLaunchKernelGGL(ba_schur_fused_kernel<1>, dim3((v.seg_class[0] + 3) / 4), dim3(256), 0, st, v, lambda, 0, v.seg_class[0]);
+    if (v.seg_class[1] > v.seg_class[0]) hipLaunchKernelGGL(ba_schur_fused_kernel<2>, dim3((v.seg_class[1] - v.seg_class[0] + 3) / 4), dim3(256), 0, st, v, lambda, v.seg_class[0], v.seg_class[1]);
+    if (v.n_seg > v.seg_class[1]) hipLaunchKernelGGL(ba_schur_fused_kernel<3>, dim3((v.n_seg - v.seg_class[1] + 3) / 4), dim3(256), 0, st, v, lambda, v.seg_class[1], v.n_seg);
+    hipLaunchKernelGGL(ba_cam_rhs_fused_kernel, dim3(v.nc), dim3(64), 0, st, v, lambda);
+    if (v.no > 0) hipLaunchKernelGGL(ba_cub_scatter_kernel, dim3(v.no), dim3(128), 0, st, v, lambda);
+    if (v.n_cub + v.n_odom > 0) hipLaunchKernelGGL(ba_offdiag_kernel, dim3(v.n_cub + v.n_odom), dim3(64), 0, st, v);
+    if (v.n_gpairs > 0) hipLaunchKernelGGL(ba_schur_gather_kernel, dim3((v.n_gpairs + 3) / 4), dim3(256), 0, st, v);
+    return;
+  }
   if (v.np > 0) hipLaunchKernelGGL(ba_prep_kernel, dim3((v.np + 255) / 256), dim3(256), 0, st, v, lambda);
   if (v.n_proj > 0) hipLaunchKernelGGL(ba_wd_kernel, dim3((unsigned)((6 * (size_t)v.n_proj + 255) / 256)), dim3(256), 0, st, v);
   hipLaunchKernelGGL(ba_cam_rhs_kernel, dim3(v.nc), dim3(256), 0, st, v, lambda);

@@ -55,9 +55,22 @@ struct BaView {
   // Schur structure: one entry per (landmark, ordered camera pair i1 <= i2), grouped by block pair
   int n_pairs; const int* pair_ptr; const int* pair_i1; const int* pair_i2;   // columns of the block
   const int* ent_a; const int* ent_b;                                          // point-major edge ids
+  // Fused Schur schedule (ba_schur_fused_kernel): the landmarks that take part in the Schur complement, grouped by the set of
+  // cameras that see them and cut into segments of at most BA_SEG_LM landmarks.  One wavefront multiplies a segment's
+  // W_j D_j^-1 W_j^T (6k x 6k, k <= BA_FUSED_KMAX cameras) on the matrix cores, the segment's landmarks being the contraction
+  // dimension, and writes k (k + 1) / 2 partial 6 x 6 blocks + k partial 6-vectors of W D^-1 b_l; per destination block / camera
+  // the partials are then summed in a fixed order (gpair_* / gcam_*: the destination schedule).
+  int fused;                    // 0 = pair-major path (ba_prep / ba_wd / ba_schur kernels)
+  int n_seg; int seg_class[2];   // segments [0, seg_class[0]): k <= 2, [seg_class[0], seg_class[1]): k <= 5, the rest: k <= 7
+  const int* seg_ptr; const int* seg_k; const int* seg_tile; const int* seg_slot; const int* run_lm;
+  double* part_tiles;           // 36 per partial block
+  double* part_coef;            // 6 per (segment, camera slot)
+  int n_gpairs; const int* gpair_ptr; const int* gpair_i1; const int* gpair_i2; const int* gtile;
+  const int* gcam_ptr; const int* gslot;   // nc + 1; partial-vector ids of a camera
   // chi2 partial sums
   double* chi_partial;
 };
+enum { BA_SEG_LM = 32, BA_FUSED_KMAX = 7 };
 
 CS_HD double* ba_S_at(const BaView& v, int r, int c) {  // requires r >= c (and r - c < band_ld in band mode)
   return v.band_ld ? v.S + (size_t)c * v.band_ld + (r - c) : v.S + (size_t)r * v.n_pose + c;

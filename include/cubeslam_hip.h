@@ -266,6 +266,12 @@ int cs_ba_sizes(cs_ba* ba, int* size_pose, int* size_landmarks);
  * band_ld = bandwidth + 1 (one persistent kernel, `team` workgroups); band_ld == 0 = dense rocSOLVER potrf/potrs
  * (graphs whose bandwidth exceeds half the system, systems under 128 unknowns). */
 int cs_ba_solver_layout(cs_ba* ba, int* band_ld, int* team);
+/* How the Schur complement S -= sum_j W_j D_j^-1 W_j^T (block_solver.hpp:385-431) is formed.  fused = 1: landmarks grouped by
+ * camera set, one wavefront per segment of <= 32 landmarks, the product on the matrix cores (v_mfma_f64_16x16x4_f64) with the
+ * landmarks as contraction dimension, n_partial_blocks partial 6x6 blocks summed per destination in a fixed order; fused = 0
+ * (some landmark is seen by more than 7 cameras, or CS_BA_SCHUR_PAIRS=1): one wavefront per covisible camera pair.
+ * n_blocks = 6x6 blocks of S the landmarks touch.                                                                  */
+int cs_ba_schur_layout(cs_ba* ba, int* fused, int* n_segments, int* n_partial_blocks, int* n_blocks);
 /* Inspection for parity tests (host copies, caller-sized): dense Hpp (size_pose^2, no lambda), Hll (9 per
  * free point in point order), Hpl (18 per projection edge in the caller's edge order), b, x.            */
 int cs_ba_get_system(cs_ba* ba, double* Hpp_dense, double* Hll9, double* Hpl18, double* b, double* x);

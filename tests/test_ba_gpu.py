@@ -504,8 +504,10 @@ def test_stepwise_abi_driven_like_g2o_levenberg():
             break
     assert len(chis) == n_b and trials == list(tr_b)
     assert np.allclose(chis, chi_b, rtol=1e-9) and np.allclose(lams, lam_b, rtol=1e-9)
+    # (the estimates make a host round trip per iteration -- re-normalised quaternions -- and the cuboid / odometry Jacobians are
+    # 1e-9-step differences, which amplify that last-bit change: measured 3e-9 of the scene scale)
     for a, b in zip(A.state(), B.state()):
-        assert np.abs(a - b).max() < 1e-9 * max(1.0, np.abs(b).max())
+        assert np.abs(a - b).max() < 1e-7 * max(1.0, np.abs(b).max())
     # lambda_0 is the oracle's (max |H_jj| over all free vertices, landmarks included)
     C2 = capi.ba_from_dict(pr)
     C2.compute_errors(); C2.build_system()
@@ -515,3 +517,56 @@ def test_stepwise_abi_driven_like_g2o_levenberg():
     md_r = max(np.abs(np.diag(Hpp_r)).max(), np.abs(Hll_r[:, [0, 4, 8]]).max())
     assert abs(md - md_r) < 1e-5 * md_r
     A.close(); B.close(); C2.close()
+
+
+@pytest.mark.parametrize("obs", [2, 5, 7, 9])
+def test_fused_mfma_schur_matches_the_pair_major_path_and_the_oracle(obs, monkeypatch):
+    """The Schur complement formed per segment of landmarks on the matrix cores (v_mfma_f64_16x16x4_f64; one, two or three
+    16-row tiles for landmarks seen by <= 2 / 5 / 7 cameras) against the pair-major kernel (CS_BA_SCHUR_PAIRS=1, also what a
+    landmark with more than 7 observations selects) and against the oracle's block_solver.hpp:385-431 restatement."""
+    pr = synth_ba.make_problem(n_cams=60, n_points=3000, n_cuboids=6, seed=17, obs_per_point=obs)
+    kmax = np.bincount(np.asarray(pr["e_pt"])).max()
+    assert kmax == obs
+    F = capi.ba_from_dict(pr)
+    fused, n_seg, n_part, n_blk = F.schur_layout()
+    assert fused == (obs <= 7)
+    monkeypatch.setenv("CS_BA_SCHUR_PAIRS", "1")
+    Q = capi.ba_from_dict(pr)
+    assert Q.schur_layout()[0] is False
+    monkeypatch.delenv("CS_BA_SCHUR_PAIRS")
+    if fused:
+        assert n_seg > 0 and n_part < 0.5 * sum(k * (k + 1) // 2 for k in np.bincount(np.asarray(pr["e_pt"])))   # far fewer partial blocks than (landmark, pair) entries
+        assert n_blk == Q.schur_layout()[3]
+    R = _oracle(pr)
+    for P in (F, Q, R):
+        P.compute_errors() if P is not R else None
+        P.build_system()
+    for lam in (1e-3, 30.0):
+        ok_f, x_f = F.solve(lam)
+        ok_q, x_q = Q.solve(lam)
+        ok_r, x_r = R.solve(lam)
+        assert ok_f and ok_q and ok_r
+        assert _rel(x_f, x_q) < 1e-8          # same products, differently associated (2-view landmarks condition the system worst: 2e-10 measured)
+        assert _rel(x_f, x_r) < 1e-5          # numeric cuboid / odometry Jacobians inside
+    assert F.optimize(5) == Q.optimize(5)
+    assert np.array_equal(F.history()[2], Q.history()[2]) and np.allclose(F.history()[0], Q.history()[0], rtol=1e-9)
+    for a, b in zip(F.state(), Q.state()):
+        assert a.size == 0 or np.abs(a - b).max() < 1e-8 * max(1.0, np.abs(b).max())
+    F.close(); Q.close(); R.close()
+
+
+def test_fused_schur_with_fixed_cameras_and_fixed_points():
+    """Fixed cameras (column -1: their W rows are zero and their blocks have no destination) and fixed points (no Schur term at
+    all) inside the segments."""
+    pr = synth_ba.make_problem(n_cams=30, n_points=1500, n_cuboids=0, seed=19)
+    pr["cam_fixed"] = pr["cam_fixed"].copy(); pr["cam_fixed"][[0, 7, 8, 21]] = 1
+    pr["pt_fixed"] = pr["pt_fixed"].copy(); pr["pt_fixed"][::5] = 1
+    G, R = capi.ba_from_dict(pr), _oracle(pr)
+    assert G.schur_layout()[0]
+    G.compute_errors(); G.build_system(); R.build_system()
+    ok_g, x_g = G.solve(5.0)
+    ok_r, x_r = R.solve(5.0)
+    assert ok_g and ok_r and _rel(x_g, x_r) < 1e-5
+    assert G.optimize(4) == R.optimize(4)
+    assert np.array_equal(G.history()[2], R.history()[2]) and np.allclose(G.history()[0], R.history()[0], rtol=1e-6)
+    G.close(); R.close()
