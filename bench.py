@@ -128,12 +128,20 @@ def main():
         torch.cuda.synchronize()
         ts = time.perf_counter()
         P = capi.ba_from_dict(pr, device=local_rank)
+        use_cb = share_gpu or os.environ.get("CS_BA_COMM") == "callback"   # RCCL refuses two ranks on one device
         if world > 1:
-            P.set_shard(rank, world)
+            if use_cb:
+                P.set_shard(rank, world)
+            else:   # the library's own RCCL communicator: rank 0 draws the id, torch.distributed carries the 128 bytes
+                idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    idt = torch.tensor(list(capi.comm_unique_id()), dtype=torch.uint8, device="cuda")
+                dist.broadcast(idt, 0)
+                P.comm_init(rank, world, bytes(idt.cpu().tolist()))
         P.sizes()                     # forces the structure phase
         torch.cuda.synchronize()
         structure_ms = (time.perf_counter() - ts) * 1e3
-        ar = capi.torch_allreduce(dist, torch.device("cuda", local_rank)) if world > 1 else None
+        ar = capi.torch_allreduce(dist, torch.device("cuda", local_rank)) if (world > 1 and use_cb) else None
         run = (lambda n: P.optimize_sharded(n, ar)) if world > 1 else (lambda n: P.optimize(n))
         run(1)  # warm-up: first-launch costs (code object load, rocSOLVER handles)
         t_before = P.timing()
@@ -149,7 +157,8 @@ def main():
         nsol = max(1, tm["n_solves"] - t_before["n_solves"])
         build_ms = d["linearize_ms"] / nlin + d["reduce_ms"] / nsol
         ba_out = {"metric": "BA LM iterations/sec", "value": n_it / ba_el, "unit": "iters/s", "config": args.ba, "cams": nc, "points": npt, "cuboids": no,
-                  "projection_edges": int(len(pr["e_pt"])), "iterations": int(n_it), "lm_trials": int(nsol), "sharding": "landmarks by camera subsequence, 1 all-reduce/solve" if world > 1 else "none",
+                  "projection_edges": int(len(pr["e_pt"])), "iterations": int(n_it), "lm_trials": int(nsol), "sharding": ("landmarks by camera subsequence; per LM trial one ncclAllReduce of [S | b_schur] + one of [chi2, scale], issued by the library on its own stream"
+                                                                                                                                   if not use_cb else "landmarks by camera subsequence, all-reduce through a torch.distributed callback") if world > 1 else "none",
                   "ms_per_iteration": ba_el / max(1, n_it) * 1e3,
                   "structure_ms": structure_ms,
                   "value_including_structure": n_it / (ba_el + structure_ms * 1e-3),

@@ -312,7 +312,7 @@ DECLARED_SYMBOLS += [
     "cs_ba_create", "cs_ba_destroy", "cs_ba_set_vertices", "cs_ba_set_estimates", "cs_ba_set_edges_proj", "cs_ba_set_edges_cuboid", "cs_ba_set_edges_cuboid_proj", "cs_ba_set_edges_odom",
     "cs_ba_compute_errors", "cs_ba_build_system", "cs_ba_solve", "cs_ba_update", "cs_ba_push", "cs_ba_pop", "cs_ba_optimize",
     "cs_ba_get_state", "cs_ba_sizes", "cs_ba_solver_layout", "cs_ba_get_system", "cs_ba_last_timing", "cs_ba_set_shard", "cs_ba_optimize_sharded",
-    "cs_ba_shard_landmark_owners", "cs_ba_get_vertex_hessians", "cs_ba_schur_layout",
+    "cs_ba_shard_landmark_owners", "cs_ba_get_vertex_hessians", "cs_ba_schur_layout", "cs_ba_comm_unique_id", "cs_ba_comm_init",
 ]
 
 
@@ -449,8 +449,21 @@ class BaProblem:
         _chk(lib().cs_ba_set_shard(self.h, int(rank), int(n_ranks)), "cs_ba_set_shard")
         self.shard = (int(rank), int(n_ranks))
 
-    def optimize_sharded(self, iters, allreduce, cap=64):
-        """allreduce(ptr, n_doubles, on_device, op) -> 0: in-place all-reduce (op 0 = SUM, 1 = MAX) of n doubles."""
+    def comm_init(self, rank, n_ranks, unique_id):
+        """RCCL communicator for the sharded BA (cs_ba_comm_init): unique_id = the 128 bytes rank 0 got from comm_unique_id()."""
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        _chk(lib().cs_ba_comm_init(self.h, int(rank), int(n_ranks), buf), "cs_ba_comm_init")
+        self.shard = (int(rank), int(n_ranks))
+
+    def optimize_sharded(self, iters, allreduce=None, cap=64):
+        """allreduce(ptr, n_doubles, on_device, op) -> 0: in-place all-reduce (op 0 = SUM, 1 = MAX) of n doubles; None = the
+        library's own RCCL communicator (comm_init)."""
+        if allreduce is None:
+            done = C.c_int()
+            self._chi, self._lam, self._tr = np.zeros(cap), np.zeros(cap), np.zeros(cap, np.int32)
+            _chk(lib().cs_ba_optimize_sharded(self.h, int(iters), None, None, C.byref(done), _dp(self._chi), _dp(self._lam), _ip(self._tr), cap), "cs_ba_optimize_sharded")
+            self._done = done.value
+            return done.value
         CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int)
 
         def _cb(ctx, data, n, on_device, op):
@@ -501,6 +514,13 @@ def ba_from_dict(pr, device=0, cuboids_first=False):
     if len(pr["oe_i"]):
         P.set_edges_odom(pr["oe_i"], pr["oe_j"], pr["oe_meas"], pr["oe_info"])
     return P
+
+
+def comm_unique_id():
+    """128-byte RCCL unique id (ncclGetUniqueId); call on rank 0 and broadcast."""
+    buf = (C.c_ubyte * 128)()
+    _chk(lib().cs_ba_comm_unique_id(buf), "cs_ba_comm_unique_id")
+    return bytes(buf)
 
 
 def landmark_owners(n_ranks, n_cams, n_points, e_pt, e_cam):

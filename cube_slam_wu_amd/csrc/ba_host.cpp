@@ -9,6 +9,7 @@
 // Eigen::LDLT, solvers/linear_solver_dense.h:104-111).  There is no CPU fallback.
 #include <hip/hip_runtime.h>
 #include <rocsolver/rocsolver.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
@@ -36,6 +37,7 @@ void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rh
 size_t ba_band_workspace_doubles(int n, int LD);
 int ba_band_team(int LD, int* rw_out);
 bool ba_band_fits_device(int n, int LD);
+void ba_launch_sum2(const double* a, int na, const double* b, int nb, double* out, hipStream_t st);
 }  // namespace cs
 
 extern "C" const char* cs_last_error(void);
@@ -48,6 +50,14 @@ namespace {
     hipError_t _e = (expr);                                                    \
     if (_e != hipSuccess) {                                                    \
       cs_set_error_ba(std::string(#expr) + ": " + hipGetErrorString(_e));      \
+      return CS_ERR_HIP;                                                       \
+    }                                                                          \
+  } while (0)
+#define BA_NCCL(expr)                                                          \
+  do {                                                                         \
+    ncclResult_t _r = (expr);                                                  \
+    if (_r != ncclSuccess) {                                                   \
+      cs_set_error_ba(std::string(#expr) + ": " + ncclGetErrorString(_r));     \
       return CS_ERR_HIP;                                                       \
     }                                                                          \
   } while (0)
@@ -98,6 +108,11 @@ struct cs_ba {
   hipEvent_t ev[8] = {};   // phase marks on the stream (linearise: 0-1; solve: 2 reduce 3 factor 4 back-substitution 5)
   bool lin_pending = false;  // ev[0..1] recorded but not yet read
   int* h_status = nullptr;   // pinned: factorisation status
+  // sharded BA over RCCL (cs_ba_comm_init): the collectives are issued from here, on this handle's stream
+  ncclComm_t comm = nullptr;
+  DBuf<double> d_scalars;    // [chi2, LM scale term] of a trial; lambda_0's diagonal on iteration 0
+  double* h_scalars = nullptr;   // pinned mirror
+  size_t scalars_cap = 0;
   // host copy of the problem description
   int nc = 0, no = 0, np = 0, cuboids_first = 0;
   std::vector<int> cam_fixed, cub_fixed, pt_fixed, cam_col, cub_col, pt_lm;  // pt_lm: landmark index among free points or -1
@@ -455,6 +470,16 @@ int finalize_structure(cs_ba* B) {
   AL(B->chi_partial, B->n_chi_partials);
   AL(B->scale_partial, (size_t)cs::ba_scale_blocks());
   AL(B->d_info, 1);
+  {
+    const size_t need = std::max<size_t>(16, (size_t)B->n_pose + 2);
+    AL(B->d_scalars, need);
+    if (B->scalars_cap < need) {
+      if (B->h_scalars) (void)hipHostFree(B->h_scalars);
+      B->h_scalars = nullptr;
+      BA_TRY(hipHostMalloc((void**)&B->h_scalars, need * sizeof(double)));
+      B->scalars_cap = need;
+    }
+  }
   AL(B->cams_bak, 7 * (size_t)nc); AL(B->points_bak, 3 * (size_t)np); AL(B->cubes_bak, 10 * (size_t)no);
 #undef UP
 #undef AL
@@ -551,7 +576,18 @@ int build_system_device(cs_ba* B) {
 // one process) would not; they take turns.
 static std::mutex g_coop_mutex;
 
-int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr, void* ctx = nullptr) {
+// phase times of the last solve, read once the stream has been synchronised
+int collect_solve_times(cs_ba* B) {
+  float ms = 0;
+  BA_TRY(hipEventElapsedTime(&ms, B->ev[2], B->ev[3])); B->tm.reduce_ms += ms;
+  BA_TRY(hipEventElapsedTime(&ms, B->ev[3], B->ev[4])); B->tm.factor_ms += ms;
+  BA_TRY(hipEventElapsedTime(&ms, B->ev[4], B->ev[5])); B->tm.backsub_ms += ms;
+  return collect_lin_time(B);
+}
+
+// defer != nullptr (banded path only): everything is queued and the function returns WITHOUT synchronising; *defer then holds the
+// persistent-kernel turn, and the caller synchronises, reads *h_status, calls collect_solve_times() and releases the turn.
+int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr, void* ctx = nullptr, std::unique_lock<std::mutex>* defer = nullptr) {
   const int n = B->n_pose;
   *ok = true;
   if (n > 0) {
@@ -562,13 +598,15 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
     if (fn && B->shard_n > 1) {  // sum the ranks' partial reduced systems: [S | rhs] in one message
       BA_TRY(hipStreamSynchronize(B->st));
       if (fn(ctx, B->S.p, B->s_doubles + n, 1, 0) != 0) { cs_set_error_ba("all-reduce callback failed"); return CS_ERR_HIP; }
+    } else if (!fn && B->comm) {  // RCCL, queued on this stream behind the kernels that produced the partial system: no host round trip
+      BA_NCCL(ncclAllReduce(B->S.p, B->S.p, B->s_doubles + n, ncclDouble, ncclSum, B->comm, B->st));
     }
     BA_TRY(hipEventRecord(B->ev[3], B->st));
     if (B->band_ld) {
       // banded: factorisation, both substitutions and the landmark back-substitution are queued back to back; the
       // pivot flag comes home with the single synchronisation (a failed factorisation just leaves garbage increments
       // that the caller discards)
-      std::lock_guard<std::mutex> coop_turn(g_coop_mutex);
+      std::unique_lock<std::mutex> coop_turn(g_coop_mutex);
       BA_TRY(hipMemsetAsync(B->d_band_info.p, 0, 24 * sizeof(int), B->st));
       cs::ba_launch_band_cholesky(B->S.p, B->band_linv.p, n, B->band_ld, B->view.rhs, B->d_band_info.p, true, B->st);
       BA_TRY(hipGetLastError());
@@ -577,6 +615,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       BA_TRY(hipGetLastError());
       BA_TRY(hipEventRecord(B->ev[5], B->st));
       BA_TRY(hipMemcpyAsync(B->h_status, B->d_band_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
+      if (defer) { *defer = std::move(coop_turn); B->tm.n_solves++; return CS_OK; }
       BA_TRY(hipStreamSynchronize(B->st));
       if (*B->h_status == 0x7fffffff) {   // a workgroup waited ~1 s for its team: the device is shared with another persistent kernel
         cs_set_error_ba("banded solver: team not co-resident (wait timed out); set CS_BA_FORCE_DENSE=1 on a shared device");
@@ -595,11 +634,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       BA_TRY(hipEventRecord(B->ev[5], B->st));
       BA_TRY(hipStreamSynchronize(B->st));
     }
-    float ms = 0;
-    BA_TRY(hipEventElapsedTime(&ms, B->ev[2], B->ev[3])); B->tm.reduce_ms += ms;
-    BA_TRY(hipEventElapsedTime(&ms, B->ev[3], B->ev[4])); B->tm.factor_ms += ms;
-    BA_TRY(hipEventElapsedTime(&ms, B->ev[4], B->ev[5])); B->tm.backsub_ms += ms;
-    int rc = collect_lin_time(B); if (rc) return rc;
+    int rc = collect_solve_times(B); if (rc) return rc;
   }
   B->tm.n_solves++;
   return CS_OK;
@@ -648,6 +683,9 @@ void cs_ba_destroy(cs_ba* B) {
   B->d_info.release(); B->d_band_info.release();
   for (auto& e : B->ev) if (e) (void)hipEventDestroy(e);
   if (B->h_status) (void)hipHostFree(B->h_status);
+  if (B->h_scalars) (void)hipHostFree(B->h_scalars);
+  if (B->comm) (void)ncclCommDestroy(B->comm);
+  B->d_scalars.release();
   if (B->blas) rocblas_destroy_handle(B->blas);
   if (B->st) (void)hipStreamDestroy(B->st);
   delete B;
@@ -846,11 +884,28 @@ int cs_ba_optimize(cs_ba* B, int iterations, int* iterations_done, double* chi_h
 
 static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn fn, void* ctx, int* iterations_done, double* chi_hist, double* lambda_hist, int* trials_hist, int cap) {
   if (!B || iterations < 0) return CS_ERR_INVALID_ARG;
-  if (B->shard_n > 1 && !fn) { cs_set_error_ba("sharded problem needs an all-reduce callback"); return CS_ERR_INVALID_ARG; }
-  const bool sharded = fn && B->shard_n > 1;
-  auto reduce_host = [&](double* v, size_t n, int op) -> int { return sharded ? fn(ctx, v, n, 0, op) : 0; };
+  if (B->shard_n > 1 && !fn && !B->comm) { cs_set_error_ba("sharded problem needs cs_ba_comm_init() (RCCL) or an all-reduce callback"); return CS_ERR_INVALID_ARG; }
+  const bool cb = fn && B->shard_n > 1;          // collectives through the caller's callback (CPU / gloo tests, ranks as threads)
+  const bool rccl = !fn && B->comm != nullptr;   // collectives issued here, on this handle's stream
   BA_TRY(hipSetDevice(B->device));
   int rc = finalize_structure(B); if (rc) return rc;
+  // host scalars: sum / max over the ranks
+  auto reduce_host = [&](double* v, size_t n, int op) -> int {
+    if (cb) return fn(ctx, v, n, 0, op);
+    if (rccl) {
+      if (n > B->scalars_cap) return 1;
+      std::memcpy(B->h_scalars, v, n * sizeof(double));
+      if (hipMemcpyAsync(B->d_scalars.p, B->h_scalars, n * sizeof(double), hipMemcpyHostToDevice, B->st) != hipSuccess) return 1;
+      if (ncclAllReduce(B->d_scalars.p, B->d_scalars.p, n, ncclDouble, op == 0 ? ncclSum : ncclMax, B->comm, B->st) != ncclSuccess) return 1;
+      if (hipMemcpyAsync(B->h_scalars, B->d_scalars.p, n * sizeof(double), hipMemcpyDeviceToHost, B->st) != hipSuccess) return 1;
+      if (hipStreamSynchronize(B->st) != hipSuccess) return 1;
+      std::memcpy(v, B->h_scalars, n * sizeof(double));
+    }
+    return 0;
+  };
+  // One trial entirely on the stream (banded solver, no callback): damped solve, LM scale term, update, chi2 of the new state and --
+  // sharded -- ONE RCCL all-reduce of the pair [chi2, scale] are queued back to back; the host synchronises once per trial.
+  const bool stream_flow = !cb && B->band_ld > 0 && B->n_pose > 0;
   double t_begin = now_ms();
   double lambda = -1, ni = 2;
   int nBad = 0, done = 0;
@@ -858,7 +913,7 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
     double currentChi = 0;
     double t0 = now_ms();
     rc = chi2_device(B, &currentChi); if (rc) return rc;
-    if (reduce_host(&currentChi, 1, 0)) return CS_ERR_HIP;
+    if (reduce_host(&currentChi, 1, 0)) { cs_set_error_ba("all-reduce failed"); return CS_ERR_HIP; }
     B->tm.errors_ms += now_ms() - t0;
     double tempChi = currentChi, iniChi = currentChi;
     rc = build_system_device(B); if (rc) return rc;
@@ -872,11 +927,11 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
       std::vector<double> pd(std::max(1, B->n_pose), 0.0);
       for (int i = 0; i < B->nc; i++) if (B->cam_col[i] >= 0) for (int d = 0; d < 6; d++) pd[B->cam_col[i] + d] = hc[36 * (size_t)i + 7 * d];
       for (int i = 0; i < B->no; i++) if (B->cub_col[i] >= 0) for (int d = 0; d < 9; d++) pd[B->cub_col[i] + d] = ho[81 * (size_t)i + 10 * d];
-      if (reduce_host(pd.data(), pd.size(), 0)) return CS_ERR_HIP;
+      if (reduce_host(pd.data(), pd.size(), 0)) { cs_set_error_ba("all-reduce failed"); return CS_ERR_HIP; }
       double md = 0;
       for (int i = 0; i < B->n_pose; i++) md = std::max(std::fabs(pd[i]), md);
       for (int i = 0; i < B->np; i++) if (B->pt_lm[i] >= 0) for (int d = 0; d < 3; d++) md = std::max(std::fabs(hl[9 * (size_t)i + 4 * d]), md);
-      if (reduce_host(&md, 1, 1)) return CS_ERR_HIP;
+      if (reduce_host(&md, 1, 1)) { cs_set_error_ba("all-reduce failed"); return CS_ERR_HIP; }
       lambda = 1e-5 * md;
       ni = 2; nBad = 0;
     }
@@ -884,28 +939,51 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
     int qmax = 0;
     do {
       rc = cs_ba_push(B); if (rc) return rc;
-      bool ok2 = false;
-      rc = solve_device(B, lambda, &ok2, fn, ctx); if (rc) return rc;
-      // x^T (lambda x + b) on the device, before the update overwrites nothing it reads: b is a per-rank partial sum,
-      // x is replicated for the poses -- the lambda x^2 term of the poses is counted once (rank 0); a landmark's terms
-      // live on exactly one rank
+      bool ok2 = true;
       double scale = 0;
-      if (ok2) {
-        const int nsb = cs::ba_scale_blocks();
-        std::vector<double> sp(nsb);
+      if (stream_flow) {
+        std::unique_lock<std::mutex> turn;
+        rc = solve_device(B, lambda, &ok2, nullptr, nullptr, &turn); if (rc) return rc;
+        // x^T (lambda x + b): b is a per-rank partial sum, x is replicated for the poses -- their lambda x^2 term is counted once
+        // (rank 0); a landmark's terms live on exactly one rank.  A failed factorisation leaves garbage in x; the update below then
+        // writes garbage estimates, which the pop restores (the decision is taken after the synchronisation).
         cs::ba_launch_scale(B->view, B->shard_rank == 0 ? lambda : 0.0, lambda, B->scale_partial.p, B->st);
+        cs::ba_launch_update(B->view, B->st);
+        BA_TRY(hipEventRecord(B->ev[6], B->st));
+        cs::ba_launch_chi2(B->view, B->nb_chi, B->st);
+        cs::ba_launch_sum2(B->chi_partial.p, B->n_chi_partials, B->scale_partial.p, cs::ba_scale_blocks(), B->d_scalars.p, B->st);
         BA_TRY(hipGetLastError());
-        BA_TRY(hipMemcpyAsync(sp.data(), B->scale_partial.p, sizeof(double) * nsb, hipMemcpyDeviceToHost, B->st));
-        rc = cs_ba_update(B); if (rc) return rc;   // synchronises the stream
-        for (double p : sp) scale += p;
+        if (rccl) BA_NCCL(ncclAllReduce(B->d_scalars.p, B->d_scalars.p, 2, ncclDouble, ncclSum, B->comm, B->st));
+        BA_TRY(hipMemcpyAsync(B->h_scalars, B->d_scalars.p, 2 * sizeof(double), hipMemcpyDeviceToHost, B->st));
+        BA_TRY(hipEventRecord(B->ev[7], B->st));
+        BA_TRY(hipStreamSynchronize(B->st));
+        turn.unlock();
+        if (*B->h_status == 0x7fffffff) { cs_set_error_ba("banded solver: team not co-resident (wait timed out); set CS_BA_FORCE_DENSE=1 on a shared device"); return CS_ERR_HIP; }
+        ok2 = *B->h_status == 0;
+        tempChi = B->h_scalars[0];
+        scale = ok2 ? B->h_scalars[1] : 0.0;
+        rc = collect_solve_times(B); if (rc) return rc;
+        float ms = 0;
+        BA_TRY(hipEventElapsedTime(&ms, B->ev[6], B->ev[7])); B->tm.errors_ms += ms;
+      } else {
+        rc = solve_device(B, lambda, &ok2, fn, ctx); if (rc) return rc;
+        if (ok2) {
+          const int nsb = cs::ba_scale_blocks();
+          std::vector<double> sp(nsb);
+          cs::ba_launch_scale(B->view, B->shard_rank == 0 ? lambda : 0.0, lambda, B->scale_partial.p, B->st);
+          BA_TRY(hipGetLastError());
+          BA_TRY(hipMemcpyAsync(sp.data(), B->scale_partial.p, sizeof(double) * nsb, hipMemcpyDeviceToHost, B->st));
+          rc = cs_ba_update(B); if (rc) return rc;   // synchronises the stream
+          for (double p : sp) scale += p;
+        }
+        t0 = now_ms();
+        rc = chi2_device(B, &tempChi); if (rc) return rc;
+        if (reduce_host(&tempChi, 1, 0)) { cs_set_error_ba("all-reduce failed"); return CS_ERR_HIP; }
+        B->tm.errors_ms += now_ms() - t0;
+        if (reduce_host(&scale, 1, 0)) { cs_set_error_ba("all-reduce failed"); return CS_ERR_HIP; }
       }
-      t0 = now_ms();
-      rc = chi2_device(B, &tempChi); if (rc) return rc;
-      if (reduce_host(&tempChi, 1, 0)) return CS_ERR_HIP;
-      B->tm.errors_ms += now_ms() - t0;
       if (!ok2) tempChi = std::numeric_limits<double>::max();
       rho = currentChi - tempChi;
-      if (reduce_host(&scale, 1, 0)) return CS_ERR_HIP;
       scale += 1e-3;
       rho /= scale;
       if (rho > 0 && std::isfinite(tempChi)) {
@@ -940,6 +1018,26 @@ int cs_ba_optimize_sharded(cs_ba* B, int iterations, cs_allreduce_fn fn, void* c
   BA_GUARD_BEGIN
   return cs_ba_optimize_sharded_impl(B, iterations, fn, ctx, iterations_done, chi_hist, lambda_hist, trials_hist, cap);
   BA_GUARD_END("cs_ba_optimize_sharded")
+}
+
+// ---- RCCL: one process per GPU, the library issues the collectives itself (ncclAllReduce on the handle's stream)
+int cs_ba_comm_unique_id(unsigned char id128[128]) {
+  if (!id128) return CS_ERR_INVALID_ARG;
+  ncclUniqueId id;
+  BA_NCCL(ncclGetUniqueId(&id));
+  static_assert(sizeof(id.internal) == 128, "ncclUniqueId is 128 bytes");
+  std::memcpy(id128, id.internal, 128);
+  return CS_OK;
+}
+
+int cs_ba_comm_init(cs_ba* B, int rank, int n_ranks, const unsigned char id128[128]) {
+  if (!B || !id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return CS_ERR_INVALID_ARG;
+  BA_TRY(hipSetDevice(B->device));
+  if (B->comm) { (void)ncclCommDestroy(B->comm); B->comm = nullptr; }
+  ncclUniqueId id;
+  std::memcpy(id.internal, id128, 128);
+  BA_NCCL(ncclCommInitRank(&B->comm, n_ranks, id, rank));
+  return cs_ba_set_shard(B, rank, n_ranks);
 }
 
 int cs_ba_get_state(cs_ba* B, double* cams7, double* cuboids10, double* points3) {

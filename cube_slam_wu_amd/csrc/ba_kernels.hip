@@ -1789,6 +1789,21 @@ void ba_launch_reduce(const BaView& v, double lambda, hipStream_t st) {
   if (v.n_pairs > 0) hipLaunchKernelGGL(ba_schur_kernel, dim3((v.n_pairs + 1) / 2), dim3(128), 0, st, v);
 }
 int ba_scale_blocks() { return SCALE_BLOCKS; }
+// out[0] = sum of a[0 .. na), out[1] = sum of b[0 .. nb): fixed-shape tree (one workgroup), so the value does not depend on
+// scheduling; lets chi2 and the LM scale term stay on the device until the one read-back (and RCCL all-reduce) of a trial
+__global__ __launch_bounds__(256) void ba_sum2_kernel(const double* a, int na, const double* b, int nb, double* out) {
+  __shared__ double ws[2][4];
+  double sa = 0, sb = 0;
+  for (int i = threadIdx.x; i < na; i += 256) sa += a[i];
+  for (int i = threadIdx.x; i < nb; i += 256) sb += b[i];
+  sa = wave_sum(sa); sb = wave_sum(sb);
+  if ((threadIdx.x & 63) == 0) { ws[0][threadIdx.x >> 6] = sa; ws[1][threadIdx.x >> 6] = sb; }
+  __syncthreads();
+  if (threadIdx.x == 0) { out[0] = (ws[0][0] + ws[0][1]) + (ws[0][2] + ws[0][3]); out[1] = (ws[1][0] + ws[1][1]) + (ws[1][2] + ws[1][3]); }
+}
+void ba_launch_sum2(const double* a, int na, const double* b, int nb, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(ba_sum2_kernel, dim3(1), dim3(256), 0, st, a, na, b, nb, out);
+}
 void ba_launch_scale(const BaView& v, double lambda_pose, double lambda_lm, double* partial, hipStream_t st) {
   hipLaunchKernelGGL(ba_scale_kernel, dim3(SCALE_BLOCKS), dim3(256), 0, st, v, lambda_pose, lambda_lm, partial);
 }

@@ -255,6 +255,14 @@ int cs_ba_optimize(cs_ba* ba, int iterations, int* iterations_done, double* chi2
  * completed when it returns.  With n_ranks == 1 (or fn == NULL) this is cs_ba_optimize.                          */
 typedef int (*cs_allreduce_fn)(void* ctx, void* data, size_t n_doubles, int on_device, int op);
 int cs_ba_set_shard(cs_ba* ba, int rank, int n_ranks);
+/* RCCL (librccl, the collectives run over xGMI): the library issues ncclAllReduce itself, on the handle's own stream, queued
+ * behind the kernels that produce the data -- no host round trip, no caller code in the loop.  Rank 0 calls
+ * cs_ba_comm_unique_id() (ncclGetUniqueId) and hands the 128 bytes to every rank by whatever means the application has (MPI,
+ * torch.distributed, a file); every rank then calls cs_ba_comm_init(), which creates the communicator (ncclCommInitRank: a
+ * collective call) and sets the shard like cs_ba_set_shard().  cs_ba_optimize_sharded(..., fn = NULL, ...) then uses it: per LM
+ * trial one all-reduce of [S | b_schur] and one of the pair [chi2, x^T(lambda x + b)], one host synchronisation.            */
+int cs_ba_comm_unique_id(unsigned char id128[128]);
+int cs_ba_comm_init(cs_ba* ba, int rank, int n_ranks, const unsigned char id128[128]);
 int cs_ba_optimize_sharded(cs_ba* ba, int iterations, cs_allreduce_fn fn, void* ctx, int* iterations_done,
                            double* chi2_hist, double* lambda_hist, int* trials_hist, int hist_cap);
 /* Host-only: the rank that owns each landmark under that rule (no GPU needed; used by the CPU multi-process test). */

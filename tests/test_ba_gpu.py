@@ -570,3 +570,22 @@ def test_fused_schur_with_fixed_cameras_and_fixed_points():
     assert G.optimize(4) == R.optimize(4)
     assert np.array_equal(G.history()[2], R.history()[2]) and np.allclose(G.history()[0], R.history()[0], rtol=1e-6)
     G.close(); R.close()
+
+
+def test_rccl_path_inside_the_library_single_rank_communicator():
+    """cs_ba_comm_unique_id / cs_ba_comm_init: the library creates its own RCCL communicator and issues ncclAllReduce on its stream
+    (per trial: [S | b_schur], then [chi2, scale]).  One GPU here, so the communicator has one rank -- every collective call is
+    executed for real and must leave the single-rank trajectory untouched.  (Two ranks cannot share a device under RCCL; the
+    multi-rank arithmetic is covered by the thread / gloo tests through the callback entry.)"""
+    pr = synth_ba.make_problem(n_cams=150, n_points=6000, n_cuboids=20, seed=23)
+    A = capi.ba_from_dict(pr)
+    n_a = A.optimize(5)
+    B = capi.ba_from_dict(pr)
+    B.comm_init(0, 1, capi.comm_unique_id())
+    assert B.solver_layout()[0] > 0
+    n_b = B.optimize_sharded(5)
+    assert n_a == n_b
+    assert np.array_equal(A.history()[2], B.history()[2]) and np.allclose(A.history()[0], B.history()[0], rtol=1e-12)
+    for a, b in zip(A.state(), B.state()):
+        assert np.array_equal(a, b)
+    A.close(); B.close()
