@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--ba-iters", type=int, default=10)
     ap.add_argument("--chunks", type=int, default=0, help="cut the batch into this many chunks of the two-slot host/GPU pipeline (0 = library default)")
     ap.add_argument("--no-edge", action="store_true", help="skip the distance-map front end (Canny + distance transform) timing")
+    ap.add_argument("--inflight", type=int, default=2, help="batches in flight per GPU: each has its own detector (streams, worker pool) and is driven by its own host thread, "
+                    "so one batch's host stages (packing, record writing) overlap the other's sweep on the device")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -89,31 +91,59 @@ def main():
     uniq = [synth.make_frame(100000 * (rank + 1) + s) for s in range(n_unique)]
     frames = [uniq[i % n_unique] for i in range(args.frames)]
     # host stages run on a worker pool per rank: with N ranks on one node the pools share the host's cores
+    # Batches in flight: every one is a full copy of the workload with its own detector; step s is run by pipeline s % inflight.
+    import threading
+    inflight = max(1, args.inflight)
     host_threads = args.host_threads
-    if host_threads == 0 and world > 1:
+    if host_threads == 0 and world * inflight > 1:
         cpus = os.cpu_count() or 64
-        try:   # a cgroup CPU quota is what the ranks really share (three threads per granted CPU, as the library's default)
+        try:   # a cgroup CPU quota is what the pools really share (three threads per granted CPU, as the library's default)
             q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
             if q != "max":
                 cpus = min(cpus, 3 * int(q) // int(per))
         except (OSError, ValueError):
             pass
-        host_threads = max(8, min(64, cpus // world))
+        host_threads = max(8, min(64, cpus // (world * inflight)))
     params = capi.default_params(whether_sample_cam_roll_pitch=0, whether_sample_bbox_height=0, yaw_range_deg=45.0, yaw_step_deg=0.5, host_threads=host_threads)
-    det = capi.Detector(params, device=local_rank)
-    bat = capi.Batch(det, frames, pipeline_chunks=(args.chunks if args.chunks > 0 else 1))
+    dets = [capi.Detector(params, device=local_rank) for _ in range(inflight)]
+    bats = [capi.Batch(dets[p], frames, pipeline_chunks=(args.chunks if args.chunks > 0 else 1)) for p in range(inflight)]
+    det, bat = dets[0], bats[0]
 
-    for _ in range(args.warmup):
-        bat.run()
+    # warm-up: every pipeline alone (also the isolated kernel timings: nothing else runs on the device)
+    iso = {}
+    for p in range(inflight):
+        for _ in range(args.warmup):
+            bats[p].run()
+            if p == 0:
+                for k, v in bats[p].timing().items():
+                    iso[k] = iso.get(k, 0) + v
+    accs = [dict() for _ in range(inflight)]
+    errs = []
+
+    def drive(p):
+        try:
+            for s_i in range(p, args.steps, inflight):
+                bats[p].run()
+                for k, v in bats[p].timing().items():
+                    accs[p][k] = accs[p].get(k, 0) + v
+        except Exception as e:   # surfaced after the join
+            errs.append(e)
     barrier()
     t0 = time.perf_counter()
-    acc = {}
-    for _ in range(args.steps):
-        bat.run()
-        for k, v in bat.timing().items():
-            acc[k] = acc.get(k, 0) + v
+    if inflight == 1:
+        drive(0)
+    else:
+        th = [threading.Thread(target=drive, args=(p,)) for p in range(inflight)]
+        [t.start() for t in th]
+        [t.join() for t in th]
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    if errs:
+        raise errs[0]
+    acc = {}
+    for a in accs:
+        for k, v in a.items():
+            acc[k] = acc.get(k, 0) + v
 
     # ---- second half of the metric: LM iterations/s of the BA path (C4: 1k cams / 200k points / 500 cuboids).
     # N > 1: the landmarks are sharded by camera subsequence; one RCCL all-reduce of [S | b_schur] per damped solve.
@@ -282,11 +312,16 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not share_gpu else "synthetic (CS_BENCH_SHARE_GPU functional check: ranks share one device, not a performance number)",
             "config": {"workload": "C2: per-frame cuboid proposal sweep, 181 yaw x 8 boxes x ~400 line segments, 1241x376 KITTI-shaped",
-                       "frames_per_batch_per_gpu": args.frames, "unique_frames": n_unique, "yaw_step_deg": 0.5,
+                       "frames_per_batch_per_gpu": args.frames, "unique_frames": n_unique, "yaw_step_deg": 0.5, "batches_in_flight": inflight,
                        "proposal_slots_per_frame": acc["n_slots"] / args.steps / args.frames,
                        "valid_proposals_per_frame": acc["n_valid"] / args.steps / args.frames, "parallelism": "frames sharded, no collective"},
             "roofline": {"kernel": "score_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": kern_ms,
+                         # the same kernel with nothing else on the device (warm-up steps, one batch in flight): with several batches in
+                         # flight the timed region's launches share the CUs with the other batch's kernels
+                         "isolated": ({"kernel_ms_per_launch": iso["score_kernel_ms"] / max(1, int(iso["cand_kernel_launches"])),
+                                       "achieved": alg_bytes / (iso["score_kernel_ms"] / max(1, int(iso["cand_kernel_launches"])) * 1e-3) / 1e9,
+                                       "frac": alg_bytes / (iso["score_kernel_ms"] / max(1, int(iso["cand_kernel_launches"])) * 1e-3) / 1e9 / HBM_PEAK_GBS} if iso.get("score_kernel_ms") else None),
                          # the per-proposal math is FP64 vector ALU -- both fractions, the larger one names the bound.
                          # ~1400 FP64 flop per valid proposal: 88 map samples x 6, six cs_atan2 (light path ~90) + comparisons, the 3D lift
                          "fp64_alu": {"flop_per_valid_proposal": FP64_FLOP_PER_PROPOSAL, "achieved": FP64_FLOP_PER_PROPOSAL * (acc["n_valid"] / launches) / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0,
@@ -313,8 +348,10 @@ def main():
         if edge_out is not None:
             out["edge_front_end"] = edge_out
         print(json.dumps(out))
-    bat.close()
-    det.close()
+    for b_ in bats:
+        b_.close()
+    for d_ in dets:
+        d_.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -28,7 +28,10 @@
 //                     calls of the sweep (merge_break_lines, line angles, VP support, box edge
 //                     angles).  Camera Euler angles (set_cam_pose) always use libm.
 // GPU parity tests compare against mode 1 bit for bit; tests/test_detect_oracle.py checks that
-// mode 0 and mode 1 yield the same integer rankings.
+// mode 0 and mode 1 yield the same integer rankings (also over the 1000 frames of config C2).
+// Built with -DORACLE_LIBM_ONLY (liboracle_detect_libm.so) this file includes NOTHING from the product
+// tree: std::atan2 is the only atan2, mode 1 cannot be selected.  tests/test_detect_gpu.py holds the
+// device's integer outputs against that build, so the comparison does not rest on shared code.
 
 #include <algorithm>
 #include <cmath>
@@ -39,12 +42,19 @@
 #include <numeric>
 #include <vector>
 
+#ifndef ORACLE_LIBM_ONLY
 #include "../cube_slam_wu_amd/csrc/cs_atan2.h"  // the one shared primitive (see header comment)
+#endif
 
 namespace {
 
+#ifdef ORACLE_LIBM_ONLY
+int g_atan2_mode = 0;
+inline double sweep_atan2(double y, double x) { return std::atan2(y, x); }
+#else
 int g_atan2_mode = 1;
 inline double sweep_atan2(double y, double x) { return g_atan2_mode ? cs::cs_atan2(y, x) : std::atan2(y, x); }
+#endif
 
 // sin/cos are called separately, never fused into glibc's sincos(): the reference's default Debug build
 // (detect_3d_cuboid/CMakeLists.txt:7-9) makes separate calls, and glibc 2.35's sincos() differs from
@@ -444,7 +454,13 @@ struct oracle_debug {
   int* yaw_count;          // [n_boxes]
 };
 
+#ifdef ORACLE_LIBM_ONLY
+void oracle_set_atan2_mode(int) { g_atan2_mode = 0; }   // libm is all this build has
+int oracle_libm_only() { return 1; }
+#else
 void oracle_set_atan2_mode(int mode) { g_atan2_mode = mode; }
+int oracle_libm_only() { return 0; }
+#endif
 int oracle_get_atan2_mode() { return g_atan2_mode; }
 double oracle_atan2(double y, double x) { return sweep_atan2(y, x); }
 

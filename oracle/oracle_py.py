@@ -55,19 +55,34 @@ def default_params(**kw):
 
 
 _lib = None
+_lib_libm = None
+
+
+def _load(name):
+    path = os.path.join(_HERE, name)
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    L.oracle_atan2.restype = C.c_double
+    L.oracle_atan2.argtypes = [C.c_double, C.c_double]
+    assert L.oracle_sizeof_cuboid() == C.sizeof(OracleCuboid)
+    return L
 
 
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(_HERE, "liboracle_detect.so")
-        if not os.path.exists(path):
-            build()
-        _lib = C.CDLL(path)
-        _lib.oracle_atan2.restype = C.c_double
-        _lib.oracle_atan2.argtypes = [C.c_double, C.c_double]
-        assert _lib.oracle_sizeof_cuboid() == C.sizeof(OracleCuboid)
+        _lib = _load("liboracle_detect.so")
     return _lib
+
+
+def lib_libm():
+    """The restatement built with -DORACLE_LIBM_ONLY: std::atan2 only, no include from the product tree."""
+    global _lib_libm
+    if _lib_libm is None:
+        _lib_libm = _load("liboracle_detect_libm.so")
+        assert _lib_libm.oracle_libm_only() == 1
+    return _lib_libm
 
 
 def _dp(a):
@@ -88,13 +103,13 @@ def cuboid_to_dict(c):
         down_expand_height=c.down_expand_height, camera_roll_delta=c.camera_roll_delta, camera_pitch_delta=c.camera_pitch_delta)
 
 
-def detect_cuboid(frame, params=None, atan2_mode=1, debug_cap=0):
+def detect_cuboid(frame, params=None, atan2_mode=1, debug_cap=0, libm_only=False):
     """Run the oracle on one frame dict (see cube_slam_wu_amd.synth.make_frame).
 
     Returns (cuboids, dbg): cuboids[i] = list of dicts (<= max_cuboid_num) for box i; dbg = dict of numpy
     arrays when debug_cap > 0 (per (box, height) candidates, kept ids, scores).
     """
-    L = lib()
+    L = lib_libm() if libm_only else lib()
     L.oracle_set_atan2_mode(int(atan2_mode))
     p = OracleParams(**(params or default_params()))
     K = np.ascontiguousarray(frame["K"], np.float64).reshape(9)

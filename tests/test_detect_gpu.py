@@ -349,3 +349,43 @@ def test_c1_bundled_reference_frame():
     assert _check([frh], capi.default_params(whether_sample_cam_roll_pitch=0, whether_sample_bbox_height=1, max_cuboid_num=5)) > 111
     n, tm = _check_final([fr, fr], capi.default_params(whether_sample_cam_roll_pitch=0, yaw_step_deg=0.5))
     assert n == 2
+
+
+def test_integer_outputs_against_the_libm_only_oracle_build():
+    """The oracle build that shares NO code with the product (oracle/liboracle_detect_libm.so: -DORACLE_LIBM_ONLY, std::atan2
+    like a build of the reference): everything the reference decides in integers -- which proposals are valid, their
+    configuration / vanishing-point side / yaw sample / top-edge sample, which ones fuse_normalize_scores_v2 keeps and in which
+    order, how many cuboids come back, the winner's integer corners and configuration -- must be the device's, at the
+    reference's 6 degree sweep and at the 0.5 degree headline sweep.  (Doubles that pass through atan2 may differ in the last
+    place between libm and the correctly rounded cs_atan2; the float distance sums contain no atan2 and must be identical.)"""
+    n_cmp = n_win = 0
+    for params, seeds in ((capi.default_params(whether_sample_cam_roll_pitch=0), range(7000, 7004)),
+                          (capi.default_params(whether_sample_cam_roll_pitch=0, yaw_step_deg=0.5), range(7100, 7103)),
+                          (capi.default_params(whether_sample_cam_roll_pitch=1, max_cuboid_num=3), range(7200, 7202))):
+        frames = [synth.make_frame(s, n_boxes=4, n_lines=300) for s in seeds]
+        det = capi.Detector(params)
+        bat = capi.Batch(det, frames, debug=True)
+        bat.run()
+        for f, fr in enumerate(frames):
+            ref, dbg = oracle_py.detect_cuboid(fr, _oracle_params(params), atan2_mode=0, debug_cap=20000, libm_only=True)
+            got = bat.cuboids(f)
+            for i in range(len(fr["boxes"])):
+                for k in range(len(fr["maps"][i])):
+                    slot = 3 * i + k
+                    V, nk = int(dbg["n_valid"][slot]), int(dbg["n_keep"][slot])
+                    rows, _ = bat.debug_candidates(f, i, k)
+                    ids, _ = bat.debug_kept(f, i, k)
+                    assert rows.shape[0] == V and len(ids) == nk
+                    assert np.array_equal(rows[:, :5], dbg["cand_rows"][slot][:V, :5])      # config, vp side, yaw, top id, distance error
+                    assert np.array_equal(rows[:, 6:], dbg["cand_rows"][slot][:V, 6:])
+                    assert np.allclose(rows[:, 5], dbg["cand_rows"][slot][:V, 5], rtol=0, atol=1e-13)
+                    assert np.array_equal(ids, dbg["keep_ids"][slot][:nk])
+                    n_cmp += V
+                assert len(got[i]) == len(ref[i])
+                for a, b in zip(got[i], ref[i]):
+                    assert np.array_equal(a["box_corners_2d"], b["box_corners_2d"]) and np.array_equal(a["box_config_type"], b["box_config_type"])
+                    assert a["rotY"] == b["rotY"] and a["edge_distance_error"] == b["edge_distance_error"]
+                    assert np.array_equal(a["pos"], b["pos"]) and np.array_equal(a["scale"], b["scale"])
+                    n_win += 1
+        bat.close(); det.close()
+    assert n_cmp > 20000 and n_win > 20

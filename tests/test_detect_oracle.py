@@ -66,3 +66,60 @@ def test_golden_regression():
             assert got["box_corners_2d"].ravel().tolist() == want["box_corners_2d"]
             assert float(got["rotY"]).hex() == want["rotY_hex"] and float(got["normalized_error"]).hex() == want["normalized_error_hex"]
             assert [float(v).hex() for v in got["pos"]] == want["pos_hex"]
+
+
+def _c2_chunk(seeds):
+    """Worker of test_c2_at_full_size_...: both atan2 flavours on a chunk of C2 frames; returns counters."""
+    from cube_slam_wu_amd import synth as S
+    from oracle import oracle_py as O
+    prm = O.default_params(yaw_step_deg=0.5)
+    out = dict(frames=0, proposals=0, kept=0, winners=0, int_mismatch=0, angle_ulp=0, angle_n=0, score_ulp=0, winner_double_ulp=0, winner_double_n=0)
+    for seed in seeds:
+        fr = S.make_frame(seed)
+        r0, d0 = O.detect_cuboid(fr, prm, atan2_mode=0, debug_cap=6000, libm_only=True)     # libm, no product code
+        r1, d1 = O.detect_cuboid(fr, prm, atan2_mode=1, debug_cap=6000)                     # correctly rounded cs_atan2
+        ok = np.array_equal(d0["n_valid"], d1["n_valid"]) and np.array_equal(d0["n_keep"], d1["n_keep"]) and np.array_equal(d0["keep_ids"], d1["keep_ids"])
+        ok = ok and np.array_equal(d0["cand_rows"][..., :5], d1["cand_rows"][..., :5]) and np.array_equal(d0["cand_corners"], d1["cand_corners"])
+        ok = ok and all(len(a) == len(b) for a, b in zip(r0, r1))
+        for a, b in zip(r0, r1):
+            for ca, cb in zip(a, b):
+                ok = ok and np.array_equal(ca["box_corners_2d"], cb["box_corners_2d"]) and np.array_equal(ca["box_config_type"], cb["box_config_type"])
+                out["winners"] += 1
+                for key in ("pos", "scale", "rotY", "edge_distance_error", "edge_angle_error", "normalized_error", "skew_ratio", "box_corners_3d_world"):
+                    va, vb = np.atleast_1d(np.asarray(ca[key], float)), np.atleast_1d(np.asarray(cb[key], float))
+                    out["winner_double_n"] += va.size
+                    out["winner_double_ulp"] += int(np.count_nonzero(va != vb))
+        out["int_mismatch"] += 0 if ok else 1
+        nv = d0["n_valid"]
+        for slot in range(len(nv)):
+            V = int(nv[slot])
+            out["proposals"] += V
+            out["angle_n"] += V
+            out["angle_ulp"] += int(np.count_nonzero(d0["cand_rows"][slot][:V, 5] != d1["cand_rows"][slot][:V, 5]))
+            nk = int(d0["n_keep"][slot])
+            out["kept"] += nk
+            out["score_ulp"] += int(np.count_nonzero(d0["keep_scores"][slot][:nk] != d1["keep_scores"][slot][:nk]))
+        out["frames"] += 1
+    return out
+
+
+def test_c2_at_full_size_libm_and_correctly_rounded_atan2_agree_on_every_integer():
+    """BASELINE.json's C2 at its full size (1000 frames x 8 boxes x 181 yaw samples x ~400 segments, ~7.8 M valid proposals):
+    the restatement with glibc's atan2 (the libm-only build: what the reference computes) and with the correctly rounded
+    cs_atan2 (what the device computes, bit for bit) must take every integer decision alike -- validity, configuration, yaw and
+    top-edge sample ids, the kept-id lists of fuse_normalize_scores_v2 in order, cuboid counts, integer corners of the winners --
+    and produce bit-identical float distance sums and corner coordinates.  Doubles downstream of atan2 may differ in the last
+    place: their count is measured and bounded (glibc 2.35 is off by one ulp in ~1e-3 of calls)."""
+    import multiprocessing as mp
+    seeds = list(range(100000, 101000))
+    nproc = min(8, os.cpu_count() or 1)
+    chunks = [seeds[i::nproc] for i in range(nproc)]
+    with mp.get_context("fork").Pool(nproc) as pool:
+        parts = pool.map(_c2_chunk, chunks)
+    tot = {k: sum(p[k] for p in parts) for k in parts[0]}
+    assert tot["frames"] == 1000 and tot["proposals"] > 7_000_000 and tot["winners"] > 7000
+    assert tot["int_mismatch"] == 0, tot
+    # last-place differences of doubles that went through atan2
+    assert 0 < tot["angle_ulp"] < 0.01 * tot["angle_n"], tot
+    assert tot["winner_double_ulp"] < 0.01 * tot["winner_double_n"], tot
+    print("C2 libm vs cs_atan2:", tot)
