@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--ba-iters", type=int, default=10)
     ap.add_argument("--chunks", type=int, default=0, help="cut the batch into this many chunks of the two-slot host/GPU pipeline (0 = library default)")
     ap.add_argument("--no-edge", action="store_true", help="skip the distance-map front end (Canny + distance transform) timing")
+    ap.add_argument("--rp-frames", type=int, default=100, help="frames of the roll/pitch-sampling stress variant (RP = 25 poses per box, the reference's class default); 0 = skip")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight per GPU: each has its own detector (streams, worker pool) and is driven by its own host thread, "
                     "so one batch's host stages (packing, record writing) overlap the other's sweep on the device")
     args = ap.parse_args()
@@ -144,6 +145,39 @@ def main():
     for a in accs:
         for k, v in a.items():
             acc[k] = acc.get(k, 0) + v
+
+    # ---- stress variant of SURVEY 8(d): whether_sample_cam_roll_pitch = 1 (the reference class's default, detect_3d_cuboid.h:110;
+    # main_obj.cpp:623 uses it from the second frame on): 5 x 5 roll / pitch samples around the camera pose, i.e. 25x the proposals
+    # per box, boxes of a frame processed in rounds because the camera yaw carries over from box to box (box_proposal_detail.cpp:180).
+    rp_out = None
+    if rank == 0 and args.rp_frames > 0:
+        prp = capi.default_params(whether_sample_cam_roll_pitch=1, whether_sample_bbox_height=0, yaw_range_deg=45.0, yaw_step_deg=0.5, host_threads=host_threads)
+        drp = capi.Detector(prp, device=local_rank)
+        brp = capi.Batch(drp, frames[:args.rp_frames])
+        brp.run()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_rp = 3
+        tacc = {}
+        for _ in range(n_rp):
+            brp.run()
+            for k, v in brp.timing().items():
+                tacc[k] = tacc.get(k, 0) + v
+        dt = time.perf_counter() - t1
+        rp_out = {"what": "C2 with roll/pitch sampling (RP = 25 camera poses per box, 0.5 deg yaw step): ~25x the proposals of the headline sweep",
+                  "frames_per_batch": args.rp_frames, "value": args.rp_frames * n_rp / dt, "unit": "frames/s",
+                  "valid_proposals_per_frame": tacc["n_valid"] / n_rp / args.rp_frames, "proposal_slots_per_frame": tacc["n_slots"] / n_rp / args.rp_frames,
+                  "stage_ms_per_batch": {k: tacc[k] / n_rp for k in tacc if k.endswith("_ms")}}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle_py
+            oprp = oracle_py.default_params(yaw_step_deg=0.5, whether_sample_cam_roll_pitch=1)
+            t1 = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t1 < 4.0:
+                oracle_py.detect_cuboid(uniq[n % n_unique], oprp, atan2_mode=0)
+                n += 1
+            rp_out["cpu_oracle_frames_per_s"] = n / (time.perf_counter() - t1)
+        brp.close(); drp.close()
 
     # ---- second half of the metric: LM iterations/s of the BA path (C4: 1k cams / 200k points / 500 cuboids).
     # N > 1: the landmarks are sharded by camera subsequence; one RCCL all-reduce of [S | b_schur] per damped solve.
@@ -347,6 +381,8 @@ def main():
             out["ba"] = ba_out
         if edge_out is not None:
             out["edge_front_end"] = edge_out
+        if rp_out is not None:
+            out["roll_pitch_sampling_stress"] = rp_out
         print(json.dumps(out))
     for b_ in bats:
         b_.close()

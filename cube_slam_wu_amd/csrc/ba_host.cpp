@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -177,6 +178,9 @@ void landmark_owners(int n_ranks, int n_cams, int n_points, int n_proj, const in
 int finalize_structure(cs_ba* B) {
   if (!B->structure_dirty) return CS_OK;
   BA_TRY(hipSetDevice(B->device));
+  static const bool prof = getenv("CS_BA_PROF") != nullptr;   // diagnostics: host phase clock of the structure phase
+  double t_ph = now_ms();
+  auto mark = [&](const char* what) { if (prof) { double t = now_ms(); fprintf(stderr, "[ba structure] %-28s %8.2f ms\n", what, t - t_ph); t_ph = t; } };
   const int nc = B->nc, no = B->no, np = B->np;
   // camera-cuboid edges of both kinds as one list: EdgeSE3Cuboid first, then EdgeSE3CuboidProj
   B->ce_cam = B->u3_cam; B->ce_cam.insert(B->ce_cam.end(), B->up_cam.begin(), B->up_cam.end());
@@ -223,6 +227,7 @@ int finalize_structure(cs_ba* B) {
     for (size_t i = 0; i < gorder.size(); i++) if (i == 0 || !same_set(gorder[i - 1], gorder[i])) run_first.push_back((int)i);
     run_first.push_back((int)gorder.size());
   }
+  mark("camera sets");
   // ---- solver ordering of the pose vertices: reverse Cuthill-McKee on the block graph of the reduced system
   // (camera-camera through shared landmarks and odometry edges, camera-cuboid through cuboid edges), so that S is
   // banded for trajectory-shaped graphs.  The ordering only permutes the linear system; g2o's order is kept for x/b
@@ -283,6 +288,7 @@ int finalize_structure(cs_ba* B) {
     B->band_ld = (!B->force_dense && B->n_pose > 128 && bw + 1 <= B->n_pose / 2 && cs::ba_band_fits_device(B->n_pose, bw + 1)) ? bw + 1 : 0;
   }
   // ---- this rank's projection edges
+  mark("ordering (RCM)");
   std::vector<int> owner;
   landmark_owners(B->shard_n, nc, np, B->n_proj, B->e_pt.data(), B->e_cam.data(), owner);
   B->keep.clear();
@@ -297,14 +303,21 @@ int finalize_structure(cs_ba* B) {
   UP(B->d_cam_col, B->cam_col); UP(B->d_cub_col, B->cub_col); UP(B->d_pt_free, pt_free);
   // ---- projection edges: point-major order (sorted by pose column inside a point), camera-major copy
   const int E = (int)B->keep.size();   // local edges; slot s of the point-major order holds caller edge keep[order[s]]
+  // counting sort by landmark (stable: caller order inside a landmark), then each landmark's handful of edges by (column, camera id)
   std::vector<int> order(E);
-  for (int k = 0; k < E; k++) order[k] = k;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-    int ka = B->keep[a], kb = B->keep[b];
-    if (B->e_pt[ka] != B->e_pt[kb]) return B->e_pt[ka] < B->e_pt[kb];
-    if (B->cam_col[B->e_cam[ka]] != B->cam_col[B->e_cam[kb]]) return B->cam_col[B->e_cam[ka]] < B->cam_col[B->e_cam[kb]];
-    return B->e_cam[ka] < B->e_cam[kb];   // fixed cameras (column -1) by id: landmarks with one camera set share one slot order
-  });
+  {
+    std::vector<int> off(np + 1, 0);
+    for (int k = 0; k < E; k++) off[B->e_pt[B->keep[k]] + 1]++;
+    for (int i = 0; i < np; i++) off[i + 1] += off[i];
+    std::vector<int> fill(off.begin(), off.end() - 1);
+    for (int k = 0; k < E; k++) order[fill[B->e_pt[B->keep[k]]]++] = k;
+    for (int p = 0; p < np; p++)
+      std::stable_sort(order.begin() + off[p], order.begin() + off[p + 1], [&](int a, int b) {
+        const int ka = B->keep[a], kb = B->keep[b];
+        if (B->cam_col[B->e_cam[ka]] != B->cam_col[B->e_cam[kb]]) return B->cam_col[B->e_cam[ka]] < B->cam_col[B->e_cam[kb]];
+        return B->e_cam[ka] < B->e_cam[kb];   // fixed cameras (column -1) by id: landmarks with one camera set share one slot order
+      });
+  }
   B->pm_of_orig.assign(B->n_proj, -1);
   std::vector<int> pm_pt(E), pm_cam(E), pt_ptr(np + 1, 0);
   std::vector<double> pm_uv(2 * (size_t)E), pm_info(4 * (size_t)E), pm_intr(4 * (size_t)E), pm_huber(E);
@@ -336,6 +349,7 @@ int finalize_structure(cs_ba* B) {
   }
   UP(B->pm_pt, pm_pt); UP(B->pm_cam, pm_cam); UP(B->pt_ptr, pt_ptr); UP(B->pm_uv, pm_uv); UP(B->pm_info, pm_info); UP(B->pm_intr, pm_intr); UP(B->pm_huber, pm_huber);
   UP(B->cm_pm, cm_pm); UP(B->cm_pt, cm_pt); UP(B->cam_ptr, cam_ptr); UP(B->cm_uv, cm_uv); UP(B->cm_info, cm_info); UP(B->cm_intr, cm_intr); UP(B->cm_huber, cm_huber);
+  mark("edge orderings + upload");
   // ---- Schur pattern (block_solver.hpp:262-292).  Fused path: segments of landmarks with one camera set + the destination
   // schedule of their partial blocks (BaView::fused).  It needs every landmark to be seen by <= BA_FUSED_KMAX cameras; otherwise
   // (or with CS_BA_SCHUR_PAIRS=1, diagnostics) the pair-major path: (landmark, i1 <= i2) entries grouped by camera pair.
@@ -429,6 +443,7 @@ int finalize_structure(cs_ba* B) {
     UP(B->d_gp_ptr, none); UP(B->d_gp_i1, none); UP(B->d_gp_i2, none); UP(B->d_gtile, none); UP(B->d_gcam_ptr, none); UP(B->d_gslot, none);
     AL(B->part_tiles, 1); AL(B->part_coef, 1);
   }
+  mark("Schur schedule");
   // ---- cuboid / odometry edges and their vertex adjacency
   for (int k = 0; k < B->n_cub; k++)
     if (B->ce_cam[k] < 0 || B->ce_cam[k] >= nc || B->ce_cub[k] < 0 || B->ce_cub[k] >= no) { cs_set_error_ba("cuboid edge index out of range"); return CS_ERR_INVALID_ARG; }
@@ -507,6 +522,7 @@ int finalize_structure(cs_ba* B) {
   // the allocations above were zeroed by hipMemset on the NULL stream, which a non-blocking stream does not wait for:
   // drain it before the first kernel of B->st can write into those buffers
   BA_TRY(hipDeviceSynchronize());
+  mark("pose edges + allocations");
   B->structure_dirty = false;
   B->have_system = false;
   return CS_OK;

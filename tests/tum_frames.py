@@ -1,8 +1,8 @@
 """The reference's bundled TUM cabinet sequence as detect_cuboid inputs (test infrastructure).
 
 Data under tests/golden/object_slam_data are copies of files the reference ships (object_slam/data: raw_imgs/*.jpg,
-filter_2d_obj_txts/*.txt, pop_cam_poses_saved.txt, detect_cuboids_saved.txt); segments/*.txt come from
-tools/make_tum_segments.py (the reference's line detector is out of scope).  A frame is set up the way main_obj.cpp does it in
+filter_2d_obj_txts/*.txt, pop_cam_poses_saved.txt, detect_cuboids_saved.txt); segments/*.txt are the output of the EDLines
+restatement (oracle/edlines_oracle.cpp) on each JPEG, written by tools/make_tum_segments.py.  A frame is set up the way main_obj.cpp does it in
 its online branch (:585-640): TUM calibration (:484-486), the first 2D box of the frame's file shifted to 0-based (:621),
 no height sampling, nominal_skew_ratio 2 (:496-498) -- with one difference: the camera pose is the frame's row of
 pop_cam_poses_saved.txt (camera above the origin of its own ground frame), because that is the frame

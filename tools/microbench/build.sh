@@ -5,3 +5,5 @@ cd "$(dirname "$0")/../.."
 mkdir -p build_tmp
 hipcc --offload-arch=gfx950 -O3 -c -x hip tools/microbench/band_bench.cpp -o build_tmp/band_bench.o
 hipcc --offload-arch=gfx950 build_tmp/band_bench.o cube_slam_wu_amd/csrc/ba_kernels.o -o build_tmp/band_bench
+# counter calibration (tools/pmc_calib.sh)
+hipcc --offload-arch=gfx950 -O3 -x hip tools/microbench/pmc_calib.cpp -o build_tmp/pmc_calib
