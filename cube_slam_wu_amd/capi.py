@@ -62,7 +62,7 @@ class CsDetectTiming(C.Structure):
 DECLARED_SYMBOLS = [
     "cs_last_error", "cs_device_count", "cs_detect_default_params", "cs_box_rois", "cs_cam_euler_zyx", "cs_detector_create",
     "cs_detector_destroy", "cs_detect_cuboids", "cs_batch_create", "cs_batch_max_boxes", "cs_batch_run",
-    "cs_bgr_to_gray", "cs_edge_distance_maps", "cs_edge_distance_maps_multi", "cs_detect_cuboids_gray", "cs_batch_create_gray", "cs_batch_destroy", "cs_batch_last_timing", "cs_batch_debug_candidates", "cs_batch_debug_kept", "cs_batch_set_debug", "cs_batch_set_pipeline_chunks",
+    "cs_bgr_to_gray", "cs_edge_distance_maps", "cs_edge_distance_maps_multi", "cs_detect_cuboids_gray", "cs_batch_create_gray", "cs_batch_destroy", "cs_batch_last_timing", "cs_batch_debug_candidates", "cs_batch_debug_kept", "cs_batch_set_debug", "cs_batch_set_pipeline_chunks", "cs_detect_lines_gray",
 ]
 
 _lib = None
@@ -165,6 +165,17 @@ class Detector:
         if rc != 0:
             raise RuntimeError("cs_edge_distance_maps_multi failed (%d): %s" % (rc, last_error()))
         return ms.value
+
+    def detect_lines(self, gray, length_thres=15.0, cap=20000):
+        """cs_detect_lines_gray: line_lbd_detect::detect_filter_lines (EDLines, one octave) -> (n, 4) float32 x1 y1 x2 y2."""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        out = np.zeros((cap, 4), np.float32)
+        n = C.c_int()
+        rc = lib().cs_detect_lines_gray(self.h, gray.ctypes.data_as(C.POINTER(C.c_ubyte)), int(gray.shape[1]), int(gray.shape[0]), C.c_double(length_thres),
+                                        out.ctypes.data_as(C.POINTER(C.c_float)), int(cap), C.byref(n))
+        if rc != 0:
+            raise RuntimeError("cs_detect_lines_gray failed (%d): %s" % (rc, last_error()))
+        return out[:n.value].copy()
 
     def detect_gray(self, frame, gray):
         """cs_detect_cuboids_gray: image in, cuboids out (the frame's 'maps' are not used)."""

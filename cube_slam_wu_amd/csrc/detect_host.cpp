@@ -558,6 +558,10 @@ int cs_cam_euler_zyx(const double T_wc[16], double euler3[3]) {
   return CS_OK;
 }
 
+// internal (not in the public header): the line-segment producer (lines_host.cpp) runs on the detector's stream
+void* cs_internal_detector_stream(cs_detector* d) { return (void*)d->stream; }
+int cs_internal_detector_device(cs_detector* d) { return d->device; }
+
 int cs_detector_create(const cs_detect_params* params, int device, cs_detector** out) {
   if (!out) return CS_ERR_INVALID_ARG;
   *out = nullptr;

@@ -1,0 +1,338 @@
+// lines_host.cpp -- the line-segment producer behind the C ABI:
+//   line_lbd_detect::detect_filter_lines(gray, lines)     line_lbd/class/line_lbd_allclass.cpp:199-235   (use_LSD = false: EDLines;
+//                                                          the graph driver sets line_length_thres = 15, object_slam/src/main_obj.cpp:504-505)
+// i.e. BinaryDescriptor::detect -> OctaveKeyLines -> EDLineDetector::EDline (libs/binary_descriptor.cpp:421-590, :796-1148, :1583-2905),
+// one octave.  The per-pixel stages (Gaussian blur, Sobel, gradient / direction maps, anchors) run on the device
+// (csrc/lines_kernels.hip); what is sequential by definition stays here:
+//   smart routing   (EdgeDrawing :1672-2381)   anchors in column-major scan order, two routed walks per anchor, chains under 16 pixels dropped
+//   line extraction (EDline :2383-2630)        least-squares fit of the first 15 pixels, extension with at most 3 consecutive outliers,
+//                                              refits from running float normal equations (the reference's Mat_<float> members)
+//   validation      (LineValidation_ :2793-2874, nfa descriptor.hpp:764-848), end points, start / end order (OctaveKeyLines :1074-1143)
+// The arithmetic follows the reference operation for operation (same types: float normal-equation terms, double solve, float end points);
+// tests/test_lines_gpu.py holds it to the CPU restatement of the same detector bit for bit.  No CPU fallback for the device stages.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cubeslam_hip.h"
+
+void cs_set_error_ba(const std::string& s);
+extern "C" void* cs_internal_detector_stream(cs_detector* d);
+extern "C" int cs_internal_detector_device(cs_detector* d);
+
+namespace cs {
+struct LineMaps { short* g; short* dx; short* dy; unsigned char* dir; unsigned char* anchor; };
+void launch_lines_maps(const unsigned char* gray, int W, int H, const LineMaps& m, const int k[3], int grad_thr, int anchor_thr, int scan, hipStream_t st);
+}  // namespace cs
+
+namespace {
+
+#define LN_TRY(expr)                                                           \
+  do {                                                                         \
+    hipError_t _e = (expr);                                                    \
+    if (_e != hipSuccess) {                                                    \
+      cs_set_error_ba(std::string(#expr) + ": " + hipGetErrorString(_e));      \
+      return CS_ERR_HIP;                                                       \
+    }                                                                          \
+  } while (0)
+
+// EDLineDetector() :1515-1526 and BinaryDescriptor::Params() :110-117
+struct EdParams { int grad_thr = 80, anchor_thr = 8, scan = 2, min_len = 15, try_time = 6, skip = 2, max_outlier = 3; double fit_err = 1.6; };
+
+struct Maps {     // host copies of the device maps
+  int W = 0, H = 0;
+  std::vector<short> g, dx, dy;
+  std::vector<unsigned char> dir, anchor;
+  bool horizontal(unsigned x, unsigned y) const { return dir[(size_t)y * W + x] == 255; }
+};
+
+struct Chain { std::vector<unsigned> x, y; };
+
+// ---- smart routing ---------------------------------------------------------------------------------------------------------
+// A walk advances one pixel per step in one of four headings.  Per heading: the three candidate neighbours in the order the
+// reference compares them (first, straight, third) and the image sides that end the walk.
+enum Heading { UP = 1, RIGHT = 2, DOWN = 3, LEFT = 4 };
+struct Step { int dx[3], dy[3]; };
+static const Step kStep[5] = {
+    {{0, 0, 0}, {0, 0, 0}},
+    {{+1, 0, -1}, {-1, -1, -1}},   // up:    up-right, up, up-left
+    {{+1, +1, +1}, {-1, 0, +1}},   // right: up-right, right, down-right
+    {{+1, 0, -1}, {+1, +1, +1}},   // down:  down-right, down, down-left
+    {{-1, -1, -1}, {-1, 0, +1}},   // left:  up-left, left, down-left
+};
+
+struct Router {
+  const Maps& M;
+  std::vector<unsigned char> taken;
+  unsigned last_x = 0, last_y = 0;   // where the previous step stood (they outlive a walk, as in the reference)
+  explicit Router(const Maps& m) : M(m), taken((size_t)m.W * m.H, 0) {}
+
+  void walk(unsigned x, unsigned y, int heading, Chain& out) {
+    const unsigned W = M.W, H = M.H;
+    for (;;) {
+      const size_t at = (size_t)y * W + x;
+      if (!(M.g[at] > 0) || taken[at]) return;
+      taken[at] = 1;
+      out.x.push_back(x); out.y.push_back(y);
+      int go;
+      if (M.dir[at] == 255) go = (heading == UP || heading == DOWN) ? (x > last_x ? RIGHT : LEFT) : heading;     // horizontal pixel: left or right
+      else                  go = (heading == RIGHT || heading == LEFT) ? (y > last_y ? DOWN : UP) : heading;     // vertical pixel: up or down
+      last_x = x; last_y = y;
+      const bool at_border = go == RIGHT ? (x == W - 1 || y == 0 || y == H - 1)
+                           : go == LEFT  ? (x == 0 || y == 0 || y == H - 1)
+                           : go == DOWN  ? (x == 0 || x == W - 1 || y == H - 1)
+                                         : (x == 0 || x == W - 1 || y == 0);
+      if (at_border) return;
+      const Step& s = kStep[go];
+      unsigned char gv[3];   // the reference compares the gradients as unsigned char (values above 255 wrap)
+      for (int q = 0; q < 3; q++) gv[q] = (unsigned char)M.g[(size_t)(y + s.dy[q]) * W + (x + s.dx[q])];
+      const int pick = (gv[0] >= gv[1] && gv[0] >= gv[2]) ? 0 : ((gv[2] >= gv[1] && gv[2] >= gv[0]) ? 2 : 1);
+      x += s.dx[pick]; y += s.dy[pick];
+      heading = go;
+    }
+  }
+};
+
+// ---- running least squares: value = a * coord + b with float normal-equation terms (Mat_<float> ATA, ATV) ---------------------
+struct NormalEq {
+  float a00 = 0, a01 = 0, a11 = 0, v0 = 0, v1 = 0;
+  // the terms of a block of pixels: sums in double, stored as float (cv::gemm on CV_32F)
+  static NormalEq of(const unsigned* coord, const unsigned* value, int n) {
+    double s00 = 0, s01 = 0, t0 = 0, t1 = 0;
+    for (int i = 0; i < n; i++) { const double c = (double)coord[i], v = (double)value[i]; s00 += c * c; s01 += c; t0 += c * v; t1 += v; }
+    NormalEq r; r.a00 = (float)s00; r.a01 = (float)s01; r.a11 = (float)(double)n; r.v0 = (float)t0; r.v1 = (float)t1;
+    return r;
+  }
+  void add(const NormalEq& o) { a00 = a00 + o.a00; a01 = a01 + o.a01; a11 = a11 + o.a11; v0 = v0 + o.v0; v1 = v1 + o.v1; }
+  void solve(double& a, double& b) const {
+    const double det_inv = 1.0 / ((double)a00 * (double)a11 - (double)a01 * (double)a01);
+    a = det_inv * ((double)a11 * (double)v0 - (double)a01 * (double)v1);
+    b = det_inv * ((double)a00 * (double)v1 - (double)a01 * (double)v0);
+  }
+};
+
+// ---- number of false alarms (descriptor.hpp:650-848) ------------------------------------------------------------------------
+double lgamma_lanczos(double x) {
+  static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
+  double a = (x + 0.5) * std::log(x + 5.5) - (x + 5.5), b = 0.0;
+  for (int n = 0; n < 7; n++) { a -= std::log(x + (double)n); b += q[n] * std::pow(x, (double)n); }
+  return a + std::log(b);
+}
+double lgamma_windschitl(double x) { return 0.918938533204673 + (x - 0.5) * std::log(x) - x + 0.5 * x * std::log(x * std::sinh(1 / x) + 1 / (810.0 * std::pow(x, 6.0))); }
+double lgamma_pick(double x) { return x > 15.0 ? lgamma_windschitl(x) : lgamma_lanczos(x); }
+bool nearly_equal(double a, double b) {
+  if (a == b) return true;
+  double m = std::max(std::fabs(a), std::fabs(b));
+  if (m < DBL_MIN) m = DBL_MIN;
+  return std::fabs(a - b) / m <= 100.0 * DBL_EPSILON;
+}
+double minus_log10_nfa(int n, int k, double p, double logNT) {
+  if (n == 0 || k == 0) return -logNT;
+  if (n == k) return -logNT - (double)n * std::log10(p);
+  const double ratio = p / (1.0 - p);
+  const double log_first = lgamma_pick((double)n + 1.0) - lgamma_pick((double)k + 1.0) - lgamma_pick((double)(n - k) + 1.0) + (double)k * std::log(p) + (double)(n - k) * std::log(1.0 - p);
+  double term = std::exp(log_first);
+  if (nearly_equal(term, 0.0)) return ((double)k > (double)n * p) ? -log_first / 2.30258509299404568402 - logNT : -logNT;
+  double tail = term;
+  for (int i = k + 1; i <= n; i++) {
+    const double bin = (double)(n - i + 1) / (double)i, mult = bin * ratio;
+    term *= mult;
+    tail += term;
+    if (bin < 1.0) {
+      const double err = term * ((1.0 - std::pow(mult, (double)(n - i + 1))) / (1.0 - mult) - 1.0);
+      if (err < 0.1 * std::fabs(-std::log10(tail) - logNT) * tail) break;
+    }
+  }
+  return -std::log10(tail) - logNT;
+}
+
+struct Segment { float x1, y1, x2, y2, direction; };
+
+// ---- line extraction from the chains ------------------------------------------------------------------------------------------
+struct Extractor {
+  const Maps& M;
+  const EdParams& P;
+  double logNT;
+  std::vector<unsigned> lx, ly;     // pixels of the line being grown
+  Extractor(const Maps& m, const EdParams& p) : M(m), P(p), logNT(2.0 * (std::log10((double)m.W) + std::log10((double)m.H))) {}
+
+  // gradient orientation statistics + border test + NFA (LineValidation_)
+  bool accept(const double w[3], float& direction) const {
+    const int n = (int)lx.size();
+    int sum_gx = 0, sum_gy = 0;
+    std::vector<double> level(n);
+    for (int i = 0; i < n; i++) {
+      const size_t at = (size_t)ly[i] * M.W + lx[i];
+      sum_gx += M.dx[at]; sum_gy += M.dy[at];
+      level[i] = std::atan2(-(double)M.dx[at], (double)M.dy[at]);
+    }
+    if (sum_gx == 0 && sum_gy == 0) return false;
+    const double ax = std::fabs(w[1]), ay = std::fabs(w[0]);
+    if (sum_gx > 0 && sum_gy >= 0) direction = (float)std::atan2(-ay, ax);
+    if (sum_gx <= 0 && sum_gy > 0) direction = (float)std::atan2(ay, ax);
+    if (sum_gx < 0 && sum_gy <= 0) direction = (float)std::atan2(ay, -ax);
+    if (sum_gx >= 0 && sum_gy < 0) direction = (float)std::atan2(-ay, -ax);
+    const double ad = std::fabs(direction);
+    if ((ad < 0.15 || M_PI - ad < 0.15) && (std::fabs(w[2]) < 10 || std::fabs((unsigned)M.H - std::fabs(w[2])) < 10)) return false;     // along the top / bottom border
+    if (std::fabs(ad - M_PI * 0.5) < 0.15 && (std::fabs(w[2]) < 10 || std::fabs((unsigned)M.W - std::fabs(w[2])) < 10)) return false;    // along the left / right border
+    int aligned = 0;
+    for (int i = 0; i < n; i++) {
+      const double d = std::fabs(direction - level[i]);
+      if (std::fabs(2 * M_PI - d) < 0.392699 || d < 0.392699) aligned++;
+    }
+    return minus_log10_nfa(n, aligned, 0.125, logNT) > 0;
+  }
+
+  void run(const Chain& c, std::vector<Segment>& out) {
+    const unsigned* cx = c.x.data(); const unsigned* cy = c.y.data();
+    unsigned s = 0;
+    const unsigned e = (unsigned)c.x.size();
+    const unsigned L = (unsigned)P.min_len;
+    while (e > s + L) {
+      // an initial segment: slide along the chain until 15 consecutive pixels fit a line
+      NormalEq eq;
+      double a = 0, b = 0, err = 0;
+      bool hor = false;
+      while (e > s + L) {
+        hor = M.horizontal(cx[s], cy[s]);
+        const unsigned* coord = (hor ? cx : cy) + s; const unsigned* value = (hor ? cy : cx) + s;
+        eq = NormalEq::of(coord, value, (int)L);
+        eq.solve(a, b);
+        double sq = 0;
+        for (unsigned i = 0; i < L; i++) { const double r = (double)value[i] - (double)coord[i] * a - b; sq += r * r; }
+        err = std::sqrt(sq);
+        if (err <= P.fit_err) break;
+        s += P.skip;
+      }
+      if (err > P.fit_err) break;
+      // grow it.  The orientation of the first pixel decides the parametrisation (y = a x + b or x = a y + b) for the whole line.
+      lx.assign(cx + s, cx + s + L); ly.assign(cy + s, cy + s + L);
+      s += L;
+      double norm = 0;
+      size_t grown_from = 0;      // first pixel the latest attempt added
+      for (int attempt = 1;; attempt++) {
+        if (attempt > 1) {
+          // refit with the pixels the previous attempt added: their terms join the running (float) sums.  The parametrisation
+          // test reads the line's first pixel (LeastSquaresLineFit_ :2733 / :2762).
+          const bool h2 = M.horizontal(lx[0], ly[0]);
+          const size_t n_new = lx.size() - grown_from;
+          eq.add(NormalEq::of((h2 ? lx.data() : ly.data()) + grown_from, (h2 ? ly.data() : lx.data()) + grown_from, (int)n_new));
+          eq.solve(a, b);
+        }
+        norm = 1 / std::sqrt(a * a + 1);
+        grown_from = lx.size();
+        int outliers = 0;
+        while (e > s) {
+          const double d = (hor ? std::fabs(a * cx[s] - cy[s] + b) : std::fabs(cx[s] - a * cy[s] - b)) * norm;
+          lx.push_back(cx[s]); ly.push_back(cy[s]); s++;
+          if (d > P.fit_err) { if (++outliers > P.max_outlier) break; }
+          else outliers = 0;
+        }
+        lx.resize(lx.size() - outliers); ly.resize(ly.size() - outliers); s -= outliers;   // trailing outliers go back to the chain
+        if (!(lx.size() > grown_from && attempt < P.try_time)) break;
+      }
+      double w[3];   // w0 x + w1 y + w2 = 0, w0^2 + w1^2 = 1
+      if (hor) { w[0] = a * norm; w[1] = -1 * norm; w[2] = b * norm; }
+      else { w[0] = 1 * norm; w[1] = -a * norm; w[2] = -b * norm; }
+      float direction = 0;
+      if (accept(w, direction)) {
+        const double p1 = w[1] * w[1], p2 = w[0] * w[0], p3 = w[0] * w[1], p4 = w[2] * w[0], p5 = w[2] * w[1];
+        Segment sg;
+        unsigned X = lx.front(), Y = ly.front();
+        sg.x1 = (float)(p1 * X - p3 * Y - p4); sg.y1 = (float)(p2 * Y - p3 * X - p5);
+        X = lx.back(); Y = ly.back();
+        sg.x2 = (float)(p1 * X - p3 * Y - p4); sg.y2 = (float)(p2 * Y - p3 * X - p5);
+        sg.direction = direction;
+        out.push_back(sg);
+      }
+    }
+  }
+};
+
+}  // namespace
+
+extern "C" int cs_detect_lines_gray(cs_detector* d, const unsigned char* gray, int img_w, int img_h, double length_thres, float* lines4, int cap, int* n_lines) {
+  if (!d || !gray || img_w < 3 || img_h < 3 || cap < 0 || (cap && !lines4) || !n_lines) return CS_ERR_INVALID_ARG;
+  try {
+    *n_lines = 0;
+    LN_TRY(hipSetDevice(cs_internal_detector_device(d)));
+    hipStream_t st = (hipStream_t)cs_internal_detector_stream(d);
+    const EdParams P;
+    const size_t N = (size_t)img_w * img_h;
+    // getGaussianKernel(5, 1.0, CV_32F) rounded to 8-bit fixed point, as createSeparableLinearFilter does for 8-bit images
+    int k[3];
+    {
+      float cf[5]; double sum = 0;
+      for (int i = 0; i < 5; i++) { const double x = i - 2.0; cf[i] = (float)std::exp(-0.5 * x * x); sum += cf[i]; }
+      sum = 1. / sum;
+      for (int i = 0; i < 3; i++) k[i] = (int)std::nearbyint((double)(float)(cf[i] * sum) * 256.0);
+    }
+    unsigned char* d_gray = nullptr; unsigned char* d_u8 = nullptr; short* d_s16 = nullptr;
+    struct Free { void* p[3]; ~Free() { for (void* q : p) if (q) (void)hipFree(q); } } guard{{nullptr, nullptr, nullptr}};
+    LN_TRY(hipMalloc((void**)&d_gray, N)); guard.p[0] = d_gray;
+    LN_TRY(hipMalloc((void**)&d_u8, 2 * N)); guard.p[1] = d_u8;
+    LN_TRY(hipMalloc((void**)&d_s16, 3 * N * sizeof(short))); guard.p[2] = d_s16;
+    LN_TRY(hipMemcpyAsync(d_gray, gray, N, hipMemcpyHostToDevice, st));
+    cs::LineMaps dm{d_s16, d_s16 + N, d_s16 + 2 * N, d_u8, d_u8 + N};
+    cs::launch_lines_maps(d_gray, img_w, img_h, dm, k, P.grad_thr, P.anchor_thr, P.scan, st);
+    LN_TRY(hipGetLastError());
+    Maps M; M.W = img_w; M.H = img_h;
+    M.g.resize(N); M.dx.resize(N); M.dy.resize(N); M.dir.resize(N); M.anchor.resize(N);
+    LN_TRY(hipMemcpyAsync(M.g.data(), dm.g, N * sizeof(short), hipMemcpyDeviceToHost, st));
+    LN_TRY(hipMemcpyAsync(M.dx.data(), dm.dx, N * sizeof(short), hipMemcpyDeviceToHost, st));
+    LN_TRY(hipMemcpyAsync(M.dy.data(), dm.dy, N * sizeof(short), hipMemcpyDeviceToHost, st));
+    LN_TRY(hipMemcpyAsync(M.dir.data(), dm.dir, N, hipMemcpyDeviceToHost, st));
+    LN_TRY(hipMemcpyAsync(M.anchor.data(), dm.anchor, N, hipMemcpyDeviceToHost, st));
+    LN_TRY(hipStreamSynchronize(st));
+    // anchors in the reference's scan order: columns outermost (:1641-1643)
+    Router R(M);
+    Extractor X(M, P);
+    std::vector<Segment> segs;
+    Chain first, second, chain;
+    size_t n_anchor = 0;
+    for (int x = 1; x < img_w - 1; x += P.scan)
+      for (int y = 1; y < img_h - 1; y += P.scan) {
+        const size_t at = (size_t)y * img_w + x;
+        if (!M.anchor[at]) continue;
+        if (++n_anchor > N / 5) { cs_set_error_ba("cs_detect_lines_gray: more anchors than the reference's arrays hold"); return CS_ERR_CAPACITY; }
+        if (R.taken[at]) continue;
+        first.x.clear(); first.y.clear(); second.x.clear(); second.y.clear();
+        const bool hor = M.dir[at] == 255;
+        R.walk(x, y, hor ? RIGHT : DOWN, first);
+        R.taken[at] = 0;                                 // the anchor opens the second walk too
+        R.walk(x, y, hor ? LEFT : UP, second);
+        if ((int)(first.x.size() + second.x.size()) < P.min_len + 1) continue;     // too short: dropped, its pixels stay taken
+        chain.x.assign(first.x.rbegin(), first.x.rend()); chain.y.assign(first.y.rbegin(), first.y.rend());
+        chain.x.insert(chain.x.end(), second.x.begin() + 1, second.x.end()); chain.y.insert(chain.y.end(), second.y.begin() + 1, second.y.end());
+        X.run(chain, segs);
+      }
+    // OctaveKeyLines :862-875 (length), :1074-1143 (which end is the start), filter_lines: length > threshold
+    int n = 0;
+    for (const Segment& s : segs) {
+      const float ddx = std::fabs(s.x1 - s.x2), ddy = std::fabs(s.y1 - s.y2);
+      const float len = std::sqrt(ddx * ddx + ddy * ddy);
+      if (!(len > (float)length_thres)) continue;
+      const float ex = s.x2 - s.x1, ey = s.y2 - s.y1, dir = s.direction;
+      bool flip = false;
+      if (dir >= -0.75 * M_PI && dir < -0.25 * M_PI) flip = ey > 0;
+      if (dir >= -0.25 * M_PI && dir < 0.25 * M_PI) flip = flip || ex < 0;
+      if (dir >= 0.25 * M_PI && dir < 0.75 * M_PI) flip = flip || ey < 0;
+      if ((dir >= 0.75 * M_PI && dir < M_PI) || (dir >= -M_PI && dir < -0.75 * M_PI)) flip = flip || ex > 0;
+      if (n >= cap) { cs_set_error_ba("cs_detect_lines_gray: more segments than `cap`"); return CS_ERR_CAPACITY; }
+      float* o = lines4 + 4 * (size_t)n;
+      if (flip) { o[0] = s.x2; o[1] = s.y2; o[2] = s.x1; o[3] = s.y1; } else { o[0] = s.x1; o[1] = s.y1; o[2] = s.x2; o[3] = s.y2; }
+      n++;
+    }
+    *n_lines = n;
+    return CS_OK;
+  } catch (const std::exception& ex) {
+    cs_set_error_ba(std::string("cs_detect_lines_gray: ") + ex.what());
+    return CS_ERR_CAPACITY;
+  }
+}

@@ -15,13 +15,15 @@
 // With --online the driver follows the reference's online branch instead (:585-680): every frame's colour image is read
 // (binary PPM here; the reference reads the JPEG with cv::imread), converted with cs_bgr_to_gray (cvtColor) and handed to
 // cs_detect_cuboids_gray together with the frame's first 2D box (filter_2d_obj_txts/NNNN_yolo2_0.15.txt, 1-based, :619-621)
-// and its line segments (one x1 y1 x2 y2 row per segment; the reference gets them from line_lbd, :590-597).  The camera pose
+// and its line segments (one x1 y1 x2 y2 row per segment; the reference gets them from line_lbd, :590-597 -- cs_detect_lines_gray here).  The camera pose
 // handed to the detector is the current estimate for frame 0 and the first frame's pose with roll/pitch sampling afterwards
 // (:623-629); with sampling the measurement is re-expressed in the sampled camera frame (:660-668).
 //
 //   g++ -O2 -I include -I cube_slam_wu_amd/csrc examples/object_slam_main.cpp -L cube_slam_wu_amd -lcubeslam_hip ... -o build_tmp/object_slam_main
 //   build_tmp/object_slam_main <data_dir> <out_dir> [digits]
-//   build_tmp/object_slam_main --online <data_dir> <ppm_dir> <segments_dir> <out_dir> [digits]
+//   build_tmp/object_slam_main --online <data_dir> <ppm_dir> <segments_dir | detect> <out_dir> [digits]
+// (segments_dir: one NNNN.txt per frame; the literal `detect`: the segments come from cs_detect_lines_gray, the reference's
+// EDLines producer -- the whole online branch then runs image in, trajectory and object out, on the device)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -131,12 +133,13 @@ static Pose pose_from_euler_zyx(double roll, double pitch, double yaw, const dou
 int main(int argc, char** argv) {
   const bool online_detect_mode = argc > 1 && std::string(argv[1]) == "--online";
   if ((!online_detect_mode && argc < 3) || (online_detect_mode && argc < 6)) {
-    std::fprintf(stderr, "usage: %s <data_dir> <out_dir> [digits]\n       %s --online <data_dir> <ppm_dir> <segments_dir> <out_dir> [digits]\n", argv[0], argv[0]);
+    std::fprintf(stderr, "usage: %s <data_dir> <out_dir> [digits]\n       %s --online <data_dir> <ppm_dir> <segments_dir | detect> <out_dir> [digits]\n", argv[0], argv[0]);
     return 2;
   }
   const int a0 = online_detect_mode ? 2 : 1;
   const std::string base_folder = std::string(argv[a0]) + "/";
   const std::string ppm_folder = online_detect_mode ? std::string(argv[3]) + "/" : "", seg_folder = online_detect_mode ? std::string(argv[4]) + "/" : "";
+  const bool detect_lines = online_detect_mode && std::string(argv[4]) == "detect";
   const std::string out_folder = std::string(argv[online_detect_mode ? 5 : 2]) + "/";
   const int a_digits = online_detect_mode ? 6 : 3;
   const int digits = argc > a_digits ? std::atoi(argv[a_digits]) : 6;      // Eigen's stream precision is 6 significant digits
@@ -203,7 +206,11 @@ int main(int argc, char** argv) {
         if (!read_ppm_as_bgr(ppm_folder + frame_index_c + ".ppm", bgr, img_w, img_h)) { std::fprintf(stderr, "cannot read image of frame %d\n", frame_index); return 1; }
         std::vector<unsigned char> gray((size_t)img_w * img_h);
         CHECK(cs_bgr_to_gray(bgr.data(), img_w * img_h, gray.data()));
-        if (!read_all_number_txt(seg_folder + frame_index_c + ".txt", 4, all_lines_raw, n_lines)) return 1;
+        if (detect_lines) {      // line_lbd_obj.detect_filter_lines(raw_rgb_img, all_lines_mat) with line_length_thres = 15 (:502-505,593), float rows copied into doubles (:596-599)
+          std::vector<float> seg(4 * 20000);
+          CHECK(cs_detect_lines_gray(detect_cuboid_obj[0], gray.data(), img_w, img_h, 15.0, seg.data(), 20000, &n_lines));
+          all_lines_raw.assign(seg.begin(), seg.begin() + 4 * (size_t)n_lines);
+        } else if (!read_all_number_txt(seg_folder + frame_index_c + ".txt", 4, all_lines_raw, n_lines)) return 1;
         raw_2d_objs[0] -= 1; raw_2d_objs[1] -= 1;               // the box file is 1-based (:621); this data has one landmark, the first box is it
         const int sample = frame_index != 0;                     // roll/pitch sampling from the second frame on (:623)
         double transToWolrd[16];

@@ -144,6 +144,17 @@ int cs_batch_create_gray(cs_detector* d, const cs_frame_desc* frames, const unsi
 /* cs_detect_cuboids() with the frame's dist_maps computed here from the gray image (frame->dist_maps is ignored). */
 int cs_detect_cuboids_gray(cs_detector* d, const cs_frame_desc* frame, const unsigned char* gray, cs_cuboid* out, int* out_counts);
 
+/* ---- line-segment producer ------------------------------------------------------------------
+ * Replaces  void line_lbd_detect::detect_filter_lines(const cv::Mat& gray_img, cv::Mat& linesmat_out)
+ *           (line_lbd/include/line_lbd/line_lbd_allclass.h:23-79, line_lbd/class/line_lbd_allclass.cpp:199-235) with use_LSD = false:
+ *           the EDLines detector of line_lbd/libs/binary_descriptor.cpp (BinaryDescriptor::detect :421-590, OctaveKeyLines :796-1148,
+ *           EDLineDetector::EdgeDrawing / EDline :1583-2905), one octave, as the graph driver configures it
+ *           (object_slam/src/main_obj.cpp:502-505,593; length_thres = its line_length_thres, 15 there, 50 by default).
+ * gray: img_h x img_w 8-bit (cvtColor BGR2GRAY of the input: cs_bgr_to_gray).  lines4: cap x 4 floats x1 y1 x2 y2 (the CV_32F
+ * rows of linesmat_out, start / end in the reference's order); *n_lines = rows written.  Per-pixel stages on the device, the
+ * routing / fitting / validation chain on the host.                                                                        */
+int cs_detect_lines_gray(cs_detector* d, const unsigned char* gray, int img_w, int img_h, double length_thres, float* lines4, int cap, int* n_lines);
+
 /* Batched form for throughput: cs_batch_create() copies the frames' inputs into HBM (maps, lines,
  * boxes, cameras); cs_batch_run() is the hot path proper -- resident inputs in, cuboids out.
  * out / out_counts are laid out frame-major with stride max_boxes = max over frames of n_boxes:

@@ -209,10 +209,16 @@ def test_graph_driver_online_mode_from_images(tmp_path):
         img = np.asarray(Image.open(os.path.join(tum_frames.DATA, "raw_imgs", "%04d_rgb_raw.jpg" % k)).convert("RGB"))
         with open(ppm / ("%04d.ppm" % k), "wb") as f:
             f.write(b"P6\n%d %d\n255\n" % (img.shape[1], img.shape[0]) + np.ascontiguousarray(img).tobytes())
+    # segments from the fixture files ...
     out = subprocess.run([exe, "--online", tum_frames.DATA, str(ppm), os.path.join(tum_frames.DATA, "segments"), str(tmp_path), "12"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    cams_f = np.loadtxt(tmp_path / "output_cam_poses.txt")
+    # ... and, the full image-in pipeline, from the library's own line-segment producer (cs_detect_lines_gray): identical files
+    out = subprocess.run([exe, "--online", tum_frames.DATA, str(ppm), "detect", str(tmp_path), "12"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     cams = np.loadtxt(tmp_path / "output_cam_poses.txt")
     objs = np.loadtxt(tmp_path / "output_obj_poses.txt")
+    assert np.array_equal(cams, cams_f)
     TR.check_online_run_against_saved_outputs(objs, cams[:, 1:])
     obj_r, cam_r, _ = O.run_online_sequence(tum_frames.DATA, lambda k: tum_frames.load_for_online_run(k, E.bgr_to_gray), TR._oracle_detect)
     assert np.abs(objs - obj_r).max() < 1e-5 * max(1.0, np.abs(obj_r).max())

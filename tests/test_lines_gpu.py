@@ -1,0 +1,66 @@
+"""The line-segment producer (cs_detect_lines_gray: EDLines with its per-pixel stages on the device, routing / fitting on the host)
+against oracle/edlines_oracle.cpp, bit for bit: same number of segments, same order, identical float coordinates."""
+import os
+
+import numpy as np
+import pytest
+
+from cube_slam_wu_amd import capi
+from oracle import edge_oracle_py as E
+from oracle import edlines_oracle_py as L
+
+pytestmark = pytest.mark.gpu
+DATA = os.path.join(os.path.dirname(__file__), "golden", "object_slam_data")
+
+
+def _synthetic(rng, h, w):
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.full((h, w), 100.0)
+    for _ in range(12):
+        a = rng.uniform(0, np.pi)
+        img += np.where((xx - rng.uniform(0, w)) * np.cos(a) + (yy - rng.uniform(0, h)) * np.sin(a) > 0, rng.uniform(-60, 60), 0)
+    img += rng.normal(0, 3, (h, w))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def test_reference_tum_frames_bit_identical_to_the_oracle():
+    from PIL import Image
+    det = capi.Detector(capi.default_params())
+    total = 0
+    for k in range(58):
+        img = np.asarray(Image.open(os.path.join(DATA, "raw_imgs", "%04d_rgb_raw.jpg" % k)).convert("RGB"))
+        gray = E.bgr_to_gray(np.ascontiguousarray(img[:, :, ::-1]))
+        got = det.detect_lines(gray, 15.0)
+        ref = L.detect_filter_lines(gray, 15.0)
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        assert np.array_equal(got, ref), k
+        total += len(ref)
+    assert total > 800
+    det.close()
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (376, 1241), (97, 131), (33, 64), (64, 33), (200, 7), (5, 300)])
+def test_synthetic_images_and_odd_sizes(shape):
+    """Sizes that are not multiples of the 32-pixel device tile, images narrower than the blur's support, the KITTI frame size."""
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    det = capi.Detector(capi.default_params())
+    n = 0
+    for _ in range(3):
+        gray = _synthetic(rng, *shape)
+        for thr in (15.0, 50.0):       # the graph driver's threshold and the class default (line_lbd_allclass.cpp:147)
+            got = det.detect_lines(gray, thr)
+            ref = L.detect_filter_lines(gray, thr)
+            assert got.shape == ref.shape and np.array_equal(got, ref)
+            n += len(ref)
+    if min(shape) >= 64:
+        assert n > 0
+    det.close()
+
+
+def test_flat_and_noise_images():
+    det = capi.Detector(capi.default_params())
+    flat = np.full((120, 160), 77, np.uint8)
+    assert det.detect_lines(flat).shape == (0, 4) and L.detect_filter_lines(flat).shape == (0, 4)
+    noise = np.random.default_rng(5).integers(0, 256, (240, 320), dtype=np.uint8)
+    assert np.array_equal(det.detect_lines(noise), L.detect_filter_lines(noise))
+    det.close()
