@@ -900,10 +900,8 @@ __device__ __forceinline__ int band_seg_t0(const BandSegX& s) { return s.lc_t0; 
 template <bool AUG, class SEG, int RW>
 __device__ __forceinline__ void band_gather_gemm_impl(const SEG& s0, const SEG& s1, int nseg, const BandAug& aug, const double* zero, int n, int bw, int k0, int nb, const int* rowidx,
                                                            double* R, double (*U)[BS + 1], long long* tp, long long* t_prev) {
-  constexpr int NR = BS + RW + 8, NRP = BAND_NRP, NOWN = RW + 8, NRT = NOWN / 8, TR = NOWN / 8, NV = BAND_NV, DC = BAND_DC;
+  constexpr int NR = BS + RW + 8, NRP = BAND_NRP, NOWN = RW + 8, NRT = NOWN / 8, NV = BAND_NV, DC = BAND_DC;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int cg = lane & 7, rgp = lane >> 3;     // register tile: own rows BS + 3 rgp .. + 2 (the block's 32 rows are only the other operand: their
-                                                // diagonal block belongs to the diagonal workgroup), columns 4 cg .. 4 cg + 3
   const int c1 = tid & 31, rg1 = tid >> 5;      // one-column mapping of the finishing pass
 #define BAND_TICK(k) do { if (tp) { long long t_now = wall_clock64(); tp[k] += t_now - *t_prev; *t_prev = t_now; } } while (0)
   // the block's own columns (A of U = A - sum), in the step's own view s0.v: loads in flight while the strip is gathered
@@ -917,11 +915,12 @@ __device__ __forceinline__ void band_gather_gemm_impl(const SEG& s0, const SEG& 
                                           : s0.v.base + (long long)i * s0.v.si + (long long)(k0 + c1) * s0.v.sj;
     aval[m] = band_gload(ok ? ptr : zero);
   }
-  double acc[TR][4];
+  static_assert(NOWN <= 32 && NRP >= BS + 32, "two 16-row MFMA tiles of own rows");
+  ba_v4d macc[2][2];
 #pragma unroll
-  for (int m = 0; m < TR; m++)
+  for (int t = 0; t < 2; t++)
 #pragma unroll
-    for (int t = 0; t < 4; t++) acc[m][t] = 0.0;
+    for (int u = 0; u < 2; u++) macc[t][u] = ba_v4d{0.0, 0.0, 0.0, 0.0};
   const int row0 = lane < NR ? rowidx[lane] : -1;            // the row this thread gathers (in the step's view)
   for (int sg = 0; sg < nseg; sg++) {
     const SEG S = sg ? s1 : s0;
@@ -954,30 +953,32 @@ __device__ __forceinline__ void band_gather_gemm_impl(const SEG& s0, const SEG& 
       BAND_TICK(7);
       if (j0 + DC < S.jhi) fetch(j0 + DC);
       BAND_TICK(6);
-      // this wave's quarter of the depth: acc(rows, cols) += R(jj, rows) * R(jj, cols)   (LDS-bandwidth bound: 56 B of
-      // operands per lane and depth index for 12 multiply-adds)
-#pragma unroll 8
-      for (int jj = wv; jj < jn; jj += 4) {
-        const double* rj = R + jj * NRP;
-        double colv[4], rowv[TR];
-#pragma unroll
-        for (int t = 0; t < 4; t++) colv[t] = rj[4 * cg + t];
-#pragma unroll
-        for (int m = 0; m < TR; m++) rowv[m] = rj[BS + rgp * TR + m];
-#pragma unroll
-        for (int m = 0; m < TR; m++)
-#pragma unroll
-          for (int t = 0; t < 4; t++) acc[m][t] = fma(rowv[m], colv[t], acc[m][t]);
+      // this wave's quarter of the depth on the matrix cores: acc(own rows, block columns) += sum_d R(d, rows) R(d, cols) as
+      // v_mfma_f64_16x16x4_f64 tiles (own rows padded to 32: 2 x 2 tiles), four depth indices per issue; of every 16 depth indices
+      // wave w takes 4 w .. 4 w + 3.  Rows of R past the chunk's jn were stored as zeros by the gather, so the last step may
+      // overrun jn.  Operand lane map: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15].
+      {
+        const int li = lane & 15, lk = lane >> 4;
+        for (int d0 = 4 * wv; d0 < jn; d0 += 16) {
+          const double* rj = R + (d0 + lk) * NRP;
+          const double a0 = rj[BS + li], a1 = rj[BS + 16 + li], b0 = rj[li], b1 = rj[16 + li];
+          macc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, macc[0][0], 0, 0, 0);
+          macc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, macc[0][1], 0, 0, 0);
+          macc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, macc[1][0], 0, 0, 0);
+          macc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, macc[1][1], 0, 0, 0);
+        }
       }
       __syncthreads();
       BAND_TICK(8);
     }
   }
-  // partial sums of the 4 waves -> LDS (over the strip buffer), then U = A - sum
+  // partial sums of the 4 waves -> LDS (over the strip buffer), then U = A - sum.  D[row = (lane >> 4) + 4 g][col = lane & 15].
 #pragma unroll
-  for (int m = 0; m < TR; m++)
+  for (int t = 0; t < 2; t++)
 #pragma unroll
-    for (int t = 0; t < 4; t++) R[(wv * NRP + BS + rgp * TR + m) * BS + 4 * cg + t] = acc[m][t];
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) R[(wv * NRP + BS + 16 * t + (lane >> 4) + 4 * g) * BS + 16 * u + (lane & 15)] = macc[t][u][g];
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < NRT; m++) {
