@@ -349,7 +349,13 @@ def main():
                        "frames_per_batch_per_gpu": args.frames, "unique_frames": n_unique, "yaw_step_deg": 0.5, "batches_in_flight": inflight,
                        "proposal_slots_per_frame": acc["n_slots"] / args.steps / args.frames,
                        "valid_proposals_per_frame": acc["n_valid"] / args.steps / args.frames, "parallelism": "frames sharded, no collective"},
-            "roofline": {"kernel": "score_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "score_kernel", "bound": "hbm",
+                         # what the SQ counters say the kernel waits for (profiles/r1j_detect_sq_counters.csv): ~3.8 k FP64 VALU instructions per
+                         # proposal at 52 % VALU-busy, 45 % of the wave cycles parked on the 77-99 scattered map samples; its HBM traffic
+                         # equals its algorithmic bytes.  Staging the map in LDS (one workgroup per job) was measured and lost: 1.63 vs 1.22 ms.
+                         "limiter": "fp64 VALU issue + gather latency (HBM traffic = algorithmic bytes)",
+                         "traffic_correction": "FETCH_SIZE x 2 + WRITE_SIZE x 1: measured on known byte counts for 4/8/16-byte coalesced, 8-byte strided and 4-byte gather patterns (profiles/r2_pmc_calibration.json)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": kern_ms,
                          # the same kernel with nothing else on the device (warm-up steps, one batch in flight): with several batches in
                          # flight the timed region's launches share the CUs with the other batch's kernels

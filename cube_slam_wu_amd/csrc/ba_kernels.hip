@@ -213,42 +213,79 @@ __global__ __launch_bounds__(256) void ba_lin_cam_kernel(BaView v) {
   }
 }
 
+// Landmark side of the projection edges: A_jj (3x3), b_j and the 6x3 H_pl block of every edge.  One LANE PER EDGE (edges are stored
+// landmark-major, so a wavefront reads its 64 edge records -- uv, information, intrinsics, kernel width, camera id -- as coalesced
+// streams; a lane per landmark read them 80-byte-strided and fetched every line ~3 times: 415 MB for 150 MB of records by PMC).
+// A workgroup owns LIN_PT_GROUP consecutive landmarks = one contiguous run of edges; every edge's J_p^T W J_p / J_p^T r terms go to
+// LDS and the landmark's first lane adds them up in edge order -- the order, and therefore every bit, of the sequential loop this
+// replaces.  Groups with more than LIN_PT_CAP edges (landmarks with very long tracks) walk their edges per landmark instead.
+enum { LIN_PT_GROUP = 48, LIN_PT_CAP = 512 };
+
+__device__ __forceinline__ void lin_pt_edge(const BaView& v, int k, bool free_pt, double* H6, double* b3) {
+  const int c = v.pm_cam[k];
+  Pose T = pose_load(v.cams + 7 * c);
+  double R[9];
+  pose_rotmat(T, R);
+  ProjLin L;
+  proj_linearize(T, R, v.points + 3 * v.pm_pt[k], v.pm_uv + 2 * k, v.pm_info + 4 * k, v.pm_intr + 4 * k, v.pm_huber[k], L);
+  double pw[6];  // Jp^T W (3x2)
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    pw[2 * i] = L.Jp[i] * L.Wm[0] + L.Jp[3 + i] * L.Wm[2];
+    pw[2 * i + 1] = L.Jp[i] * L.Wm[1] + L.Jp[3 + i] * L.Wm[3];
+  }
+  int q = 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = i; j < 3; j++) H6[q++] = pw[2 * i] * L.Jp[j] + pw[2 * i + 1] * L.Jp[3 + j];
+    b3[i] = L.Jp[i] * L.r[0] + L.Jp[3 + i] * L.r[1];
+  }
+  double* Wk = v.W + 18 * (size_t)k;
+  const bool both = free_pt && v.cam_col[c] >= 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const double jw0 = L.Jc[i] * L.Wm[0] + L.Jc[6 + i] * L.Wm[2];
+    const double jw1 = L.Jc[i] * L.Wm[1] + L.Jc[6 + i] * L.Wm[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) Wk[3 * i + j] = both ? (jw0 * L.Jp[j] + jw1 * L.Jp[3 + j]) : 0.0;
+  }
+}
+
 __global__ __launch_bounds__(256) void ba_lin_pt_kernel(BaView v) {
-  int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= v.np) return;
+  __shared__ double part[9][LIN_PT_CAP];     // [term][edge of the group]: consecutive lanes, consecutive words
+  const int p0 = blockIdx.x * LIN_PT_GROUP, p1 = min(v.np, p0 + LIN_PT_GROUP);
+  if (p0 >= v.np) return;
+  const int e0 = v.pt_ptr[p0], e1 = v.pt_ptr[p1];
+  const bool staged = e1 - e0 <= LIN_PT_CAP;
+  if (staged) {
+    for (int k = e0 + threadIdx.x; k < e1; k += 256) {
+      double H6[6], b3[3];
+      lin_pt_edge(v, k, v.pt_free[v.pm_pt[k]] != 0, H6, b3);
+#pragma unroll
+      for (int i = 0; i < 6; i++) part[i][k - e0] = H6[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) part[6 + i][k - e0] = b3[i];
+    }
+    __syncthreads();
+  }
+  const int p = p0 + threadIdx.x;
+  if (threadIdx.x >= LIN_PT_GROUP || p >= p1) return;
   double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-  bool free_pt = v.pt_free[p] != 0;
-  int e0 = v.pt_ptr[p], e1 = v.pt_ptr[p + 1];
-  const double* X = v.points + 3 * p;
-  for (int k = e0; k < e1; k++) {
-    int c = v.pm_cam[k];
-    Pose T = pose_load(v.cams + 7 * c);
-    double R[9];
-    pose_rotmat(T, R);
-    ProjLin L;
-    proj_linearize(T, R, X, v.pm_uv + 2 * k, v.pm_info + 4 * k, v.pm_intr + 4 * k, v.pm_huber[k], L);
-    double pw[6];  // Jp^T W (3x2)
+  for (int k = v.pt_ptr[p]; k < v.pt_ptr[p + 1]; k++) {
+    double H6[6], b3[3];
+    if (staged) {
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-      pw[2 * i] = L.Jp[i] * L.Wm[0] + L.Jp[3 + i] * L.Wm[2];
-      pw[2 * i + 1] = L.Jp[i] * L.Wm[1] + L.Jp[3 + i] * L.Wm[3];
+      for (int i = 0; i < 6; i++) H6[i] = part[i][k - e0];
+#pragma unroll
+      for (int i = 0; i < 3; i++) b3[i] = part[6 + i][k - e0];
+    } else {
+      lin_pt_edge(v, k, v.pt_free[p] != 0, H6, b3);
     }
-    int q = 0;
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < 6; i++) H[i] += H6[i];
 #pragma unroll
-      for (int j = i; j < 3; j++) H[q++] += pw[2 * i] * L.Jp[j] + pw[2 * i + 1] * L.Jp[3 + j];
-      b[i] += L.Jp[i] * L.r[0] + L.Jp[3 + i] * L.r[1];
-    }
-    double* Wk = v.W + 18 * (size_t)k;
-    bool both = free_pt && v.cam_col[c] >= 0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      double jw0 = L.Jc[i] * L.Wm[0] + L.Jc[6 + i] * L.Wm[2];
-      double jw1 = L.Jc[i] * L.Wm[1] + L.Jc[6 + i] * L.Wm[3];
-#pragma unroll
-      for (int j = 0; j < 3; j++) Wk[3 * i + j] = both ? (jw0 * L.Jp[j] + jw1 * L.Jp[3 + j]) : 0.0;
-    }
+    for (int i = 0; i < 3; i++) b[i] += b3[i];
   }
   double* Hp = v.Hll + 9 * (size_t)p;
   Hp[0] = H[0]; Hp[1] = H[1]; Hp[2] = H[2]; Hp[3] = H[1]; Hp[4] = H[3]; Hp[5] = H[4]; Hp[6] = H[2]; Hp[7] = H[4]; Hp[8] = H[5];
@@ -280,12 +317,21 @@ __device__ __forceinline__ void edge_rows_from_columns(const double (*J)[D], con
   }
 }
 
-__global__ __launch_bounds__(64) void ba_cub_edge_kernel(BaView v) {
+// 32 lanes per edge: lane (d, s), d = column 0..14 (camera tangent 0-5, cuboid tangent 6-14), s = 0 / 1 evaluates the error at
+// +delta / -delta of that column (lane (15, 0): the unperturbed error), so the two oplus + computeError chains of a column run side
+// by side instead of one after the other; the pair meets through a lane exchange.
+__device__ __forceinline__ double lane_xor16(double x) {
+  const int lo = __shfl_xor(__double2loint(x), 16), hi = __shfl_xor(__double2hiint(x), 16);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(128) void ba_cub_edge_kernel(BaView v) {
   __shared__ double J[4][16][9];    // [edge in block][column d (15 = e0)][row]
-  const int sub = threadIdx.x >> 4, d = threadIdx.x & 15;
+  const int sub = threadIdx.x >> 5, h = threadIdx.x & 31, d = h & 15, sgn = h >> 4;
   const int k = blockIdx.x * 4 + sub;
   const bool live = k < v.n_cub;
   const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+  const double step = sgn ? -delta : delta;
   const bool is3d = k < v.n_cub3;      // EdgeSE3Cuboid, else EdgeSE3CuboidProj
   double (*Jq)[4] = reinterpret_cast<double (*)[4]>(&J[sub][0][0]);   // the 4-row view of this edge's column store
   if (live && !is3d) {
@@ -296,24 +342,23 @@ __global__ __launch_bounds__(64) void ba_cub_edge_kernel(BaView v) {
     const double* meas = v.pe_meas + 4 * (size_t)q;
     const bool act = v.ce_active[k] != 0;
     const bool fa = act && v.cam_col[v.ce_cam[k]] >= 0, fb = act && v.cub_col[v.ce_cub[k]] >= 0;
-    double e1[4], e2[4];
+    double e1[4] = {0, 0, 0, 0};
     if (d == 15) {
-      cuboid_proj_error(T, cube, K, meas, e1);
-      for (int r = 0; r < 4; r++) Jq[15][r] = act ? e1[r] : 0.0;
+      if (sgn == 0) cuboid_proj_error(T, cube, K, meas, e1);
     } else if (d < 6) {
       double add[6] = {0, 0, 0, 0, 0, 0};
-      if (fa) {
-        add[d] = delta; cuboid_proj_error(cam_oplus(T, add), cube, K, meas, e1);
-        add[d] = -delta; cuboid_proj_error(cam_oplus(T, add), cube, K, meas, e2);
-      }
-      for (int r = 0; r < 4; r++) Jq[d][r] = fa ? scalar * (e1[r] - e2[r]) : 0.0;
+      add[d] = step;
+      if (fa) cuboid_proj_error(cam_oplus(T, add), cube, K, meas, e1);
     } else {
       double add[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      if (fb) {
-        add[d - 6] = delta; cuboid_proj_error(T, cube_oplus(cube, add), K, meas, e1);
-        add[d - 6] = -delta; cuboid_proj_error(T, cube_oplus(cube, add), K, meas, e2);
-      }
-      for (int r = 0; r < 4; r++) Jq[d][r] = fb ? scalar * (e1[r] - e2[r]) : 0.0;
+      add[d - 6] = step;
+      if (fb) cuboid_proj_error(T, cube_oplus(cube, add), K, meas, e1);
+    }
+    const bool on = d < 6 ? fa : fb;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const double e2 = lane_xor16(e1[r]);      // the partner's error: -delta for the s = 0 lanes
+      if (sgn == 0) Jq[d][r] = d == 15 ? (act ? e1[r] : 0.0) : (on ? scalar * (e1[r] - e2) : 0.0);
     }
   }
   if (live && is3d) {
@@ -322,31 +367,30 @@ __global__ __launch_bounds__(64) void ba_cub_edge_kernel(BaView v) {
     Cube meas = cube_load(v.ce_meas + 10 * k);
     const bool act = v.ce_active[k] != 0;  // sharded BA: the edge belongs to another rank -> zero blocks
     const bool fa = act && v.cam_col[v.ce_cam[k]] >= 0, fb = act && v.cub_col[v.ce_cub[k]] >= 0;
-    double e1[9], e2[9];
+    double e1[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (d == 15) {
-      cuboid_edge_error(T, cube, meas, e1);
-      for (int r = 0; r < 9; r++) J[sub][15][r] = act ? e1[r] : 0.0;
+      if (sgn == 0) cuboid_edge_error(T, cube, meas, e1);
     } else if (d < 6) {
       double add[6] = {0, 0, 0, 0, 0, 0};
-      if (fa) {
-        add[d] = delta; cuboid_edge_error(cam_oplus(T, add), cube, meas, e1);
-        add[d] = -delta; cuboid_edge_error(cam_oplus(T, add), cube, meas, e2);
-      }
-      for (int r = 0; r < 9; r++) J[sub][d][r] = fa ? scalar * (e1[r] - e2[r]) : 0.0;
+      add[d] = step;
+      if (fa) cuboid_edge_error(cam_oplus(T, add), cube, meas, e1);
     } else {
       double add[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      if (fb) {
-        add[d - 6] = delta; cuboid_edge_error(T, cube_oplus(cube, add), meas, e1);
-        add[d - 6] = -delta; cuboid_edge_error(T, cube_oplus(cube, add), meas, e2);
-      }
-      for (int r = 0; r < 9; r++) J[sub][d][r] = fb ? scalar * (e1[r] - e2[r]) : 0.0;
+      add[d - 6] = step;
+      if (fb) cuboid_edge_error(T, cube_oplus(cube, add), meas, e1);
+    }
+    const bool on = d < 6 ? fa : fb;
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+      const double e2 = lane_xor16(e1[r]);
+      if (sgn == 0) J[sub][d][r] = d == 15 ? (act ? e1[r] : 0.0) : (on ? scalar * (e1[r] - e2) : 0.0);
     }
   }
   __syncthreads();
-  if (live && is3d)
+  if (live && is3d && sgn == 0)
     edge_rows_from_columns<9, 6, 9>(J[sub], J[sub][15], v.ce_info + 81 * (size_t)k, d, v.ce_Hcc + 36 * (size_t)k, v.ce_Hoo + 81 * (size_t)k,
                                     v.ce_Hco + 54 * (size_t)k, v.ce_bc + 6 * (size_t)k, v.ce_bo + 9 * (size_t)k);
-  if (live && !is3d)
+  if (live && !is3d && sgn == 0)
     edge_rows_from_columns<4, 6, 9>(Jq, Jq[15], v.pe_info + 16 * (size_t)(k - v.n_cub3), d, v.ce_Hcc + 36 * (size_t)k, v.ce_Hoo + 81 * (size_t)k,
                                     v.ce_Hco + 54 * (size_t)k, v.ce_bc + 6 * (size_t)k, v.ce_bo + 9 * (size_t)k);
 }
@@ -1764,8 +1808,8 @@ void ba_launch_chi2(const BaView& v, int nb_proj, hipStream_t st) {
 }
 void ba_launch_linearize(const BaView& v, hipStream_t st) {
   if (v.n_proj > 0 || v.nc > 0) hipLaunchKernelGGL(ba_lin_cam_kernel, dim3(v.nc), dim3(256), 0, st, v);
-  if (v.np > 0) hipLaunchKernelGGL(ba_lin_pt_kernel, dim3((v.np + 255) / 256), dim3(256), 0, st, v);
-  if (v.n_cub > 0) hipLaunchKernelGGL(ba_cub_edge_kernel, dim3((v.n_cub + 3) / 4), dim3(64), 0, st, v);
+  if (v.np > 0) hipLaunchKernelGGL(ba_lin_pt_kernel, dim3((v.np + LIN_PT_GROUP - 1) / LIN_PT_GROUP), dim3(256), 0, st, v);
+  if (v.n_cub > 0) hipLaunchKernelGGL(ba_cub_edge_kernel, dim3((v.n_cub + 3) / 4), dim3(128), 0, st, v);
   if (v.n_odom > 0) hipLaunchKernelGGL(ba_odom_edge_kernel, dim3((v.n_odom + 3) / 4), dim3(64), 0, st, v);
   hipLaunchKernelGGL(ba_accum_pose_kernel, dim3(v.nc + v.no), dim3(128), 0, st, v, 0);
 }

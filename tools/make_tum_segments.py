@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Line segments of the reference's bundled TUM cabinet frames (object_slam/data/raw_imgs), written to
-tests/golden/object_slam_data/segments/NNNN.txt (x1 y1 x2 y2 per row, float32 values printed with 9 digits).
+tests/golden/object_slam_data/segments/NNNN.txt (x1 y1 x2 y2 per row, the float32 values as exact doubles).
 
 They are what line_lbd_detect::detect_filter_lines returns for each JPEG in the reference's graph driver
 (object_slam/src/main_obj.cpp:502-505,593: EDLines, one octave, line_length_thres 15), computed by the repository's restatement of
@@ -34,7 +34,7 @@ def main():
         seg = L.detect_filter_lines(gray, 15.0)
         with open(os.path.join(out_dir, "%04d.txt" % k), "w") as f:
             for r in seg:
-                f.write(" ".join("%.9g" % float(v) for v in r) + "\n")
+                f.write(" ".join("%.17g" % float(v) for v in r) + "\n")     # the exact double of the float32, as the reference's float -> double copy (main_obj.cpp:596-599)
         print(k, len(seg))
 
 
