@@ -925,12 +925,21 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
   double t_begin = now_ms();
   double lambda = -1, ni = 2;
   int nBad = 0, done = 0;
+  double carriedChi = 0;
+  bool have_carried = false;     // chi2 of the current state is known from the previous iteration's last trial
   for (int it = 0; it < iterations; it++) {
     double currentChi = 0;
     double t0 = now_ms();
-    rc = chi2_device(B, &currentChi); if (rc) return rc;
-    if (reduce_host(&currentChi, 1, 0)) { cs_set_error_ba("all-reduce failed"); return CS_ERR_HIP; }
-    B->tm.errors_ms += now_ms() - t0;
+    if (have_carried) {
+      // computeActiveErrors + activeRobustChi2 at the top of an iteration (:67-69) would re-evaluate the state the last trial left:
+      // the accepted trial's chi2 (same kernels, same state, fixed-shape sums: the same bits), or -- after ten rejections --
+      // the popped state's, which is the previous currentChi
+      currentChi = carriedChi;
+    } else {
+      rc = chi2_device(B, &currentChi); if (rc) return rc;
+      if (reduce_host(&currentChi, 1, 0)) { cs_set_error_ba("all-reduce failed"); return CS_ERR_HIP; }
+      B->tm.errors_ms += now_ms() - t0;
+    }
     double tempChi = currentChi, iniChi = currentChi;
     rc = build_system_device(B); if (rc) return rc;
     if (it == 0) {  // computeLambdaInit (:166-180): tau * max |H_jj| over all non-fixed vertices, landmarks included
@@ -1022,6 +1031,7 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
       if (trials_hist) trials_hist[done] = qmax;
     }
     done++;
+    carriedChi = currentChi; have_carried = true;
     if (qmax == 10 || rho == 0) break;
     if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
     if (nBad >= 3) break;
