@@ -323,7 +323,7 @@ DECLARED_SYMBOLS += [
     "cs_ba_create", "cs_ba_destroy", "cs_ba_set_vertices", "cs_ba_set_estimates", "cs_ba_set_edges_proj", "cs_ba_set_edges_cuboid", "cs_ba_set_edges_cuboid_proj", "cs_ba_set_edges_odom",
     "cs_ba_compute_errors", "cs_ba_build_system", "cs_ba_solve", "cs_ba_update", "cs_ba_push", "cs_ba_pop", "cs_ba_optimize",
     "cs_ba_get_state", "cs_ba_sizes", "cs_ba_solver_layout", "cs_ba_get_system", "cs_ba_last_timing", "cs_ba_set_shard", "cs_ba_optimize_sharded",
-    "cs_ba_shard_landmark_owners", "cs_ba_get_vertex_hessians", "cs_ba_schur_layout", "cs_ba_comm_unique_id", "cs_ba_comm_init",
+    "cs_ba_shard_landmark_owners", "cs_ba_get_vertex_hessians", "cs_ba_schur_layout", "cs_ba_reduced_size", "cs_ba_comm_unique_id", "cs_ba_comm_init",
 ]
 
 
@@ -423,6 +423,12 @@ class BaProblem:
         b, x = np.zeros(n + nl), np.zeros(n + nl)
         _chk(lib().cs_ba_get_system(self.h, None, None, None, _dp(b), _dp(x)), "cs_ba_get_system")
         return b, x
+
+    def reduced_size(self):
+        """(unknowns of the factorised system, cuboids eliminated?) -- cs_ba_reduced_size."""
+        a, b = C.c_int(), C.c_int()
+        _chk(lib().cs_ba_reduced_size(self.h, C.byref(a), C.byref(b)), "cs_ba_reduced_size")
+        return a.value, bool(b.value)
 
     def schur_layout(self):
         """(fused, segments, partial blocks, destination blocks) of the Schur-complement build (cs_ba_schur_layout)."""

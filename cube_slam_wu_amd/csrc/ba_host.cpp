@@ -126,6 +126,10 @@ struct cs_ba {
   std::vector<int> keep;                      // caller indices of the projection edges this rank owns
   size_t s_doubles = 0;                       // size of S; rhs follows it in the same allocation (one all-reduce)
   int n_pose = 0, n_lm = 0;
+  int n_red = 0;            // dimension of the system the solver factorises: n_pose, or the cameras' part when the cuboids are eliminated too
+  bool elim = false;        // free cuboids eliminated like landmarks (single rank, fused Schur schedule)
+  DBuf<int> d_cubS_ptr, d_cubS_cam, d_ce_slot, d_cub_tile, d_cub_coef, d_elim_fail, d_slotE_ptr, d_slotE_idx;
+  DBuf<double> cub_M, cub_Dinv;
   int n_proj = 0, n_cub = 0, n_odom = 0;   // n_cub = EdgeSE3Cuboid + EdgeSE3CuboidProj edges (the combined list ce_cam / ce_cub)
   int n_cub3 = 0;                          // of which EdgeSE3Cuboid (they come first)
   std::vector<int> u3_cam, u3_cub, up_cam, up_cub;      // the caller's two lists
@@ -228,15 +232,41 @@ int finalize_structure(cs_ba* B) {
     run_first.push_back((int)gorder.size());
   }
   mark("camera sets");
+  // ---- cuboid / odometry edge indices are used below: check them first
+  for (int k = 0; k < B->n_cub; k++)
+    if (B->ce_cam[k] < 0 || B->ce_cam[k] >= nc || B->ce_cub[k] < 0 || B->ce_cub[k] >= no) { cs_set_error_ba("cuboid edge index out of range"); return CS_ERR_INVALID_ARG; }
+  for (int k = 0; k < B->n_odom; k++)
+    if (B->oe_i[k] < 0 || B->oe_i[k] >= nc || B->oe_j[k] < 0 || B->oe_j[k] >= nc) { cs_set_error_ba("odometry edge index out of range"); return CS_ERR_INVALID_ARG; }
   // ---- solver ordering of the pose vertices: reverse Cuthill-McKee on the block graph of the reduced system
   // (camera-camera through shared landmarks and odometry edges, camera-cuboid through cuboid edges), so that S is
   // banded for trajectory-shaped graphs.  The ordering only permutes the linear system; g2o's order is kept for x/b
   // inspection (cam_col_ref).
+  // Two candidate systems.  (a) g2o's: cameras and cuboids (only the points are marginalised).  (b) The cuboids eliminated as
+  // well: a cuboid is coupled to the cameras that observe it and to nothing else, exactly like a landmark with a 9 x 9 block, so
+  // S_cc -= H_co D_oo^-1 H_co^T is the same exact block elimination -- a different elimination order of one Cholesky
+  // factorisation, not a different system -- and the reduced system shrinks to the cameras (C4: 10 494 -> 5 994 unknowns,
+  // bandwidth 182 -> 119: a cuboid couples the ~20 consecutive cameras that see it, which the landmarks' band nearly contains).
+  // The one with the cheaper banded factorisation (n bw^2) is taken; (b) needs the fused Schur schedule, a single rank (a cuboid's
+  // edges may live on two ranks) and at most BA_ELIM_MAX_SLOTS cameras per cuboid.  CS_BA_KEEP_CUBOIDS=1 forces (a).
   B->cam_col.assign(nc, -1); B->cub_col.assign(no, -1);
-  {
+  std::vector<std::vector<int>> cub_cams(no);     // free cameras observing a free cuboid, distinct, by camera id
+  int max_slots = 0, n_free_cub = 0;
+  for (int k = 0; k < B->n_cub; k++) if (!B->cub_fixed[B->ce_cub[k]] && !B->cam_fixed[B->ce_cam[k]]) cub_cams[B->ce_cub[k]].push_back(B->ce_cam[k]);
+  for (int o = 0; o < no; o++) {
+    std::sort(cub_cams[o].begin(), cub_cams[o].end());
+    cub_cams[o].erase(std::unique(cub_cams[o].begin(), cub_cams[o].end()), cub_cams[o].end());
+    max_slots = std::max(max_slots, (int)cub_cams[o].size());
+    if (!B->cub_fixed[o]) n_free_cub++;
+  }
+  bool fused_ok = getenv("CS_BA_SCHUR_PAIRS") == nullptr;
+  for (int p : gorder) if (cam_cnt[p + 1] - cam_cnt[p] > cs::BA_FUSED_KMAX) { fused_ok = false; break; }
+  struct Ordering { std::vector<int> cam_col, cub_col; int n_red = 0, bw = 0; };
+  auto make_ordering = [&](bool elim) -> Ordering {
+    Ordering O;
+    O.cam_col.assign(nc, -1); O.cub_col.assign(no, -1);
     const int NV = nc + no;
     std::vector<std::vector<int>> adj(NV);
-    auto is_free = [&](int v) { return v < nc ? !B->cam_fixed[v] : !B->cub_fixed[v - nc]; };
+    auto is_free = [&](int v) { return v < nc ? !B->cam_fixed[v] : (!elim && !B->cub_fixed[v - nc]); };
     auto link = [&](int a, int b) { if (a != b && is_free(a) && is_free(b)) { adj[a].push_back(b); adj[b].push_back(a); } };
     // landmarks couple the cameras that see them: one clique per DISTINCT camera set (the landmarks were grouped by camera set
     // above; KITTI-shaped problems have ~100x fewer sets than landmarks)
@@ -244,8 +274,9 @@ int finalize_structure(cs_ba* B) {
       const int p = gorder[run_first[r]];
       for (int a = cam_cnt[p]; a < cam_cnt[p + 1]; a++) for (int b = a + 1; b < cam_cnt[p + 1]; b++) link(cams_of[a], cams_of[b]);
     }
-    for (int k = 0; k < B->n_odom; k++) if (B->oe_i[k] >= 0 && B->oe_i[k] < nc && B->oe_j[k] >= 0 && B->oe_j[k] < nc) link(B->oe_i[k], B->oe_j[k]);
-    for (int k = 0; k < B->n_cub; k++) if (B->ce_cam[k] >= 0 && B->ce_cam[k] < nc && B->ce_cub[k] >= 0 && B->ce_cub[k] < no) link(B->ce_cam[k], nc + B->ce_cub[k]);
+    for (int k = 0; k < B->n_odom; k++) link(B->oe_i[k], B->oe_j[k]);
+    if (!elim) { for (int k = 0; k < B->n_cub; k++) link(B->ce_cam[k], nc + B->ce_cub[k]); }
+    else for (int o = 0; o < no; o++) if (!B->cub_fixed[o]) for (size_t a = 0; a < cub_cams[o].size(); a++) for (size_t b = a + 1; b < cub_cams[o].size(); b++) link(cub_cams[o][a], cub_cams[o][b]);
     for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
     std::vector<int> order;  // Cuthill-McKee, component by component, starting from a minimum-degree vertex
     std::vector<char> seen(NV, 0);
@@ -275,17 +306,32 @@ int finalize_structure(cs_ba* B) {
     }
     std::reverse(order.begin(), order.end());
     int col = 0;
-    for (int v : order) { if (v < nc) { B->cam_col[v] = col; col += 6; } else { B->cub_col[v - nc] = col; col += 9; } }
-    auto vcol = [&](int v) { return v < nc ? B->cam_col[v] : B->cub_col[v - nc]; };
+    for (int v : order) { if (v < nc) { O.cam_col[v] = col; col += 6; } else { O.cub_col[v - nc] = col; col += 9; } }
+    O.n_red = col;
+    if (elim) for (int o = 0; o < no; o++) if (!B->cub_fixed[o]) { O.cub_col[o] = col; col += 9; }   // increments of the eliminated cuboids: behind the reduced system's
+    auto vcol = [&](int v) { return v < nc ? O.cam_col[v] : O.cub_col[v - nc]; };
     auto vdim = [&](int v) { return v < nc ? 6 : 9; };
     int bw = 0;
     for (int v : order) {
       bw = std::max(bw, vdim(v) - 1);
       for (int w : adj[v]) { int lo = std::min(vcol(v), vcol(w)); int hi = (vcol(v) > vcol(w)) ? vcol(v) + vdim(v) - 1 : vcol(w) + vdim(w) - 1; bw = std::max(bw, hi - lo); }
     }
-    // banded path only where the persistent kernel's team is guaranteed to be resident on THIS device (occupancy query x CUs:
-    // 256 CUs admit bandwidths up to ~1900; a partitioned or smaller device proportionally less); dense rocSOLVER otherwise
-    B->band_ld = (!B->force_dense && B->n_pose > 128 && bw + 1 <= B->n_pose / 2 && cs::ba_band_fits_device(B->n_pose, bw + 1)) ? bw + 1 : 0;
+    O.bw = bw;
+    return O;
+  };
+  // banded path only where the persistent kernel's team is guaranteed to be resident on THIS device (occupancy query x CUs:
+  // 256 CUs admit bandwidths up to ~1900; a partitioned or smaller device proportionally less); dense rocSOLVER otherwise
+  auto band_ok = [&](const Ordering& O) { return !B->force_dense && O.n_red > 128 && O.bw + 1 <= O.n_red / 2 && cs::ba_band_fits_device(O.n_red, O.bw + 1); };
+  auto cost = [&](const Ordering& O) { return band_ok(O) ? (double)O.n_red * (O.bw + 1.0) * (O.bw + 1.0) : (double)O.n_red * O.n_red * O.n_red / 3.0; };
+  {
+    Ordering keep_o = make_ordering(false);
+    const bool try_elim = B->shard_n == 1 && fused_ok && n_free_cub > 0 && max_slots <= cs::BA_ELIM_MAX_SLOTS && getenv("CS_BA_KEEP_CUBOIDS") == nullptr;
+    Ordering elim_o;
+    if (try_elim) elim_o = make_ordering(true);
+    B->elim = try_elim && cost(elim_o) < cost(keep_o);
+    const Ordering& O = B->elim ? elim_o : keep_o;
+    B->cam_col = O.cam_col; B->cub_col = O.cub_col; B->n_red = O.n_red;
+    B->band_ld = band_ok(O) ? O.bw + 1 : 0;
   }
   // ---- this rank's projection edges
   mark("ordering (RCM)");
@@ -389,6 +435,48 @@ int finalize_structure(cs_ba* B) {
       }
       if (in_seg) seg_ptr.push_back((int)run_lm.size());
     }
+    // the eliminated cuboids join the destination schedule: per free cuboid one slot per observing camera (by column), the upper
+    // triangle of slot pairs as partial blocks, one partial vector per slot
+    std::vector<int> cubS_ptr(no + 1, 0), cubS_cam, ce_slot(B->n_cub, -1), cub_tile(no, 0), cub_coef(no, 0);
+    if (B->elim) {
+      for (int o = 0; o < no; o++) {
+        cubS_ptr[o] = (int)cubS_cam.size();
+        if (B->cub_fixed[o]) continue;
+        std::vector<int> sc = cub_cams[o];
+        std::sort(sc.begin(), sc.end(), [&](int a, int b) { return B->cam_col[a] != B->cam_col[b] ? B->cam_col[a] < B->cam_col[b] : a < b; });
+        const int k = (int)sc.size();
+        cub_tile[o] = n_tiles; cub_coef[o] = n_slots;
+        for (int a = 0; a < k; a++) {
+          cubS_cam.push_back(sc[a]);
+          cdst.push_back({sc[a], n_slots + a});
+          for (int b = a; b < k; b++) dst.push_back(Dst{(long long)B->cam_col[sc[a]] * NP + B->cam_col[sc[b]], n_tiles + a * k - a * (a - 1) / 2 + (b - a)});
+        }
+        n_tiles += k * (k + 1) / 2; n_slots += k;
+      }
+      cubS_ptr[no] = (int)cubS_cam.size();
+      for (int k = 0; k < B->n_cub; k++) {
+        const int o = B->ce_cub[k], c = B->ce_cam[k];
+        if (B->cub_fixed[o] || B->cam_fixed[c]) continue;
+        for (int q = cubS_ptr[o]; q < cubS_ptr[o + 1]; q++) if (cubS_cam[q] == c) { ce_slot[k] = q; break; }
+      }
+    } else {
+      for (int o = 0; o <= no; o++) cubS_ptr[o] = 0;
+    }
+    // edges of a slot, in edge order (a camera may hold an EdgeSE3Cuboid and an EdgeSE3CuboidProj to one cuboid)
+    std::vector<int> slotE_ptr(cubS_cam.size() + 1, 0), slotE_idx;
+    {
+      for (int k = 0; k < B->n_cub; k++) if (ce_slot[k] >= 0) slotE_ptr[ce_slot[k] + 1]++;
+      for (size_t q = 0; q < cubS_cam.size(); q++) slotE_ptr[q + 1] += slotE_ptr[q];
+      slotE_idx.assign(std::max(1, slotE_ptr.back()), 0);
+      std::vector<int> fill(slotE_ptr.begin(), slotE_ptr.end() - 1);
+      for (int k = 0; k < B->n_cub; k++) if (ce_slot[k] >= 0) slotE_idx[fill[ce_slot[k]]++] = k;
+    }
+    UP(B->d_slotE_ptr, slotE_ptr); UP(B->d_slotE_idx, slotE_idx);
+    if (cubS_cam.empty()) cubS_cam.push_back(0);
+    if (ce_slot.empty()) ce_slot.push_back(-1);
+    if (cub_tile.empty()) { cub_tile.push_back(0); cub_coef.push_back(0); }
+    UP(B->d_cubS_ptr, cubS_ptr); UP(B->d_cubS_cam, cubS_cam); UP(B->d_ce_slot, ce_slot); UP(B->d_cub_tile, cub_tile); UP(B->d_cub_coef, cub_coef);
+    AL(B->cub_M, 54 * cubS_cam.size()); AL(B->cub_Dinv, 81 * (size_t)std::max(1, no)); AL(B->d_elim_fail, 1);
     B->n_seg = (int)seg_k.size();
     for (int sgi = 0; sgi < B->n_seg; sgi++) { if (seg_k[sgi] <= 2) B->seg_class[0] = sgi + 1; if (seg_k[sgi] <= 5) B->seg_class[1] = sgi + 1; }   // segments are sorted by k
     std::stable_sort(dst.begin(), dst.end(), [](const Dst& x, const Dst& y) { return x.key < y.key; });
@@ -442,13 +530,13 @@ int finalize_structure(cs_ba* B) {
     UP(B->d_run_lm, none); UP(B->d_seg_ptr, none); UP(B->d_seg_k, none); UP(B->d_seg_tile, none); UP(B->d_seg_slot, none);
     UP(B->d_gp_ptr, none); UP(B->d_gp_i1, none); UP(B->d_gp_i2, none); UP(B->d_gtile, none); UP(B->d_gcam_ptr, none); UP(B->d_gslot, none);
     AL(B->part_tiles, 1); AL(B->part_coef, 1);
+    std::vector<int> zp(no + 1, 0);
+    UP(B->d_slotE_ptr, none); UP(B->d_slotE_idx, none);
+    UP(B->d_cubS_ptr, zp); UP(B->d_cubS_cam, none); UP(B->d_ce_slot, none); UP(B->d_cub_tile, none); UP(B->d_cub_coef, none);
+    AL(B->cub_M, 1); AL(B->cub_Dinv, 1); AL(B->d_elim_fail, 1);
   }
   mark("Schur schedule");
   // ---- cuboid / odometry edges and their vertex adjacency
-  for (int k = 0; k < B->n_cub; k++)
-    if (B->ce_cam[k] < 0 || B->ce_cam[k] >= nc || B->ce_cub[k] < 0 || B->ce_cub[k] >= no) { cs_set_error_ba("cuboid edge index out of range"); return CS_ERR_INVALID_ARG; }
-  for (int k = 0; k < B->n_odom; k++)
-    if (B->oe_i[k] < 0 || B->oe_i[k] >= nc || B->oe_j[k] < 0 || B->oe_j[k] >= nc) { cs_set_error_ba("odometry edge index out of range"); return CS_ERR_INVALID_ARG; }
   auto csr = [&](int nv, const std::vector<int>& owner, std::vector<int>& ptr, std::vector<int>& idx) {
     ptr.assign(nv + 1, 0);
     for (int o : owner) ptr[o + 1]++;
@@ -475,11 +563,11 @@ int finalize_structure(cs_ba* B) {
   // ---- linear system storage
   AL(B->Hcam, 36 * (size_t)nc); AL(B->bcam, 6 * (size_t)nc); AL(B->Hcub, 81 * (size_t)no); AL(B->bcub, 9 * (size_t)no);
   AL(B->Hll, 9 * (size_t)np); AL(B->bl, 3 * (size_t)np); AL(B->W, 18 * (size_t)E); AL(B->WD, 18 * (size_t)E);
-  AL(B->Dinv, 9 * (size_t)np); AL(B->dbl, 3 * (size_t)np); B->s_doubles = (size_t)B->n_pose * (B->band_ld ? B->band_ld : B->n_pose);
+  AL(B->Dinv, 9 * (size_t)np); AL(B->dbl, 3 * (size_t)np); B->s_doubles = (size_t)B->n_red * (B->band_ld ? B->band_ld : B->n_red);
   AL(B->S, B->s_doubles + B->n_pose);   // [S | rhs]: one buffer, one all-reduce in the sharded solve
   AL(B->xl, 3 * (size_t)np);
   AL(B->d_band_info, 24);  // [first bad pivot + 1, grid-barrier counters, a zero double]
-  AL(B->band_linv, B->band_ld ? cs::ba_band_workspace_doubles(B->n_pose, B->band_ld) : 1);   // inverted diagonal blocks (+ the separator's rows in the nested order)
+  AL(B->band_linv, B->band_ld ? cs::ba_band_workspace_doubles(B->n_red, B->band_ld) : 1);   // inverted diagonal blocks (+ the separator's rows in the nested order)
   B->nb_chi = cs::ba_chi2_blocks(E);
   B->n_chi_partials = B->nb_chi + (B->n_cub + B->n_odom + 63) / 64;
   AL(B->chi_partial, B->n_chi_partials);
@@ -500,7 +588,9 @@ int finalize_structure(cs_ba* B) {
 #undef AL
   cs::BaView& v = B->view;
   v.cams = B->cams.p; v.points = B->points.p; v.cubes = B->cubes.p; v.cam_col = B->d_cam_col.p; v.cub_col = B->d_cub_col.p; v.pt_free = B->d_pt_free.p;
-  v.nc = nc; v.np = np; v.no = no; v.n_pose = B->n_pose;
+  v.nc = nc; v.np = np; v.no = no; v.n_pose = B->n_pose; v.n_red = B->n_red; v.elim = B->elim ? 1 : 0;
+  v.cubS_ptr = B->d_cubS_ptr.p; v.cubS_cam = B->d_cubS_cam.p; v.ce_slot = B->d_ce_slot.p; v.cub_tile = B->d_cub_tile.p; v.cub_coef = B->d_cub_coef.p;
+  v.cub_M = B->cub_M.p; v.cub_Dinv = B->cub_Dinv.p; v.elim_fail = B->d_elim_fail.p; v.slotE_ptr = B->d_slotE_ptr.p; v.slotE_idx = B->d_slotE_idx.p;
   v.n_proj = E; v.pm_pt = B->pm_pt.p; v.pm_cam = B->pm_cam.p; v.pm_uv = B->pm_uv.p; v.pm_info = B->pm_info.p; v.pm_intr = B->pm_intr.p; v.pm_huber = B->pm_huber.p;
   v.pt_ptr = B->pt_ptr.p; v.cm_pm = B->cm_pm.p; v.cm_pt = B->cm_pt.p; v.cm_uv = B->cm_uv.p; v.cm_info = B->cm_info.p; v.cm_intr = B->cm_intr.p; v.cm_huber = B->cm_huber.p; v.cam_ptr = B->cam_ptr.p;
   v.n_cub3 = B->n_cub3; v.pe_meas = B->pe_meas.p; v.pe_info = B->pe_info.p; v.pe_K = B->pe_K.p;
@@ -604,18 +694,20 @@ int collect_solve_times(cs_ba* B) {
 // defer != nullptr (banded path only): everything is queued and the function returns WITHOUT synchronising; *defer then holds the
 // persistent-kernel turn, and the caller synchronises, reads *h_status, calls collect_solve_times() and releases the turn.
 int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr, void* ctx = nullptr, std::unique_lock<std::mutex>* defer = nullptr) {
-  const int n = B->n_pose;
+  const int n = B->n_red;
   *ok = true;
   if (n > 0) {
     BA_TRY(hipEventRecord(B->ev[2], B->st));
-    BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (B->s_doubles + n), B->st));
+    BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (B->s_doubles + B->n_pose), B->st));
+    BA_TRY(hipMemsetAsync(B->d_elim_fail.p, 0, sizeof(int), B->st));
     cs::ba_launch_reduce(B->view, lambda, B->st);
+    BA_TRY(hipMemcpyAsync(B->h_status + 1, B->d_elim_fail.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
     BA_TRY(hipGetLastError());
     if (fn && B->shard_n > 1) {  // sum the ranks' partial reduced systems: [S | rhs] in one message
       BA_TRY(hipStreamSynchronize(B->st));
-      if (fn(ctx, B->S.p, B->s_doubles + n, 1, 0) != 0) { cs_set_error_ba("all-reduce callback failed"); return CS_ERR_HIP; }
+      if (fn(ctx, B->S.p, B->s_doubles + B->n_pose, 1, 0) != 0) { cs_set_error_ba("all-reduce callback failed"); return CS_ERR_HIP; }
     } else if (!fn && B->comm) {  // RCCL, queued on this stream behind the kernels that produced the partial system: no host round trip
-      BA_NCCL(ncclAllReduce(B->S.p, B->S.p, B->s_doubles + n, ncclDouble, ncclSum, B->comm, B->st));
+      BA_NCCL(ncclAllReduce(B->S.p, B->S.p, B->s_doubles + B->n_pose, ncclDouble, ncclSum, B->comm, B->st));
     }
     BA_TRY(hipEventRecord(B->ev[3], B->st));
     if (B->band_ld) {
@@ -637,13 +729,13 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
         cs_set_error_ba("banded solver: team not co-resident (wait timed out); set CS_BA_FORCE_DENSE=1 on a shared device");
         return CS_ERR_HIP;
       }
-      if (*B->h_status != 0) *ok = false;
+      if (B->h_status[0] != 0 || B->h_status[1] != 0) *ok = false;
     } else {
       // dense: the lower triangle of the row-major S is the upper triangle of the column-major matrix rocSOLVER sees
       BA_ROC(rocsolver_dpotrf(B->blas, rocblas_fill_upper, n, B->S.p, n, B->d_info.p));
       BA_TRY(hipMemcpyAsync(B->h_status, B->d_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
       BA_TRY(hipStreamSynchronize(B->st));
-      if (*B->h_status != 0) *ok = false;
+      if (B->h_status[0] != 0 || B->h_status[1] != 0) *ok = false;
       else BA_ROC(rocsolver_dpotrs(B->blas, rocblas_fill_upper, n, 1, B->S.p, n, B->view.rhs, n));
       BA_TRY(hipEventRecord(B->ev[4], B->st));
       if (*ok) { cs::ba_launch_backsub(B->view, B->st); BA_TRY(hipGetLastError()); }
@@ -674,7 +766,8 @@ int cs_ba_create(int device, cs_ba** out) {
   BA_TRY(hipSetDevice(device));
   BA_TRY(hipStreamCreateWithFlags(&B->st, hipStreamNonBlocking));
   for (auto& e : B->ev) BA_TRY(hipEventCreate(&e));
-  BA_TRY(hipHostMalloc((void**)&B->h_status, sizeof(int)));
+  BA_TRY(hipHostMalloc((void**)&B->h_status, 2 * sizeof(int)));   // [factorisation status, a cuboid block failed]
+  B->h_status[0] = B->h_status[1] = 0;
   BA_ROC(rocblas_create_handle(&B->blas));
   BA_ROC(rocblas_set_stream(B->blas, B->st));
   *out = B;
@@ -689,12 +782,13 @@ void cs_ba_destroy(cs_ba* B) {
   DBuf<double>* dd[] = {&B->cams, &B->points, &B->cubes, &B->cams_bak, &B->points_bak, &B->cubes_bak, &B->pm_uv, &B->pm_info, &B->pm_intr, &B->pm_huber,
                         &B->cm_uv, &B->cm_info, &B->cm_intr, &B->cm_huber, &B->ce_meas, &B->ce_info, &B->ce_Hcc, &B->ce_Hoo, &B->ce_Hco, &B->ce_bc, &B->ce_bo,
                         &B->oe_meas, &B->oe_info, &B->oe_Hii, &B->oe_Hjj, &B->oe_Hij, &B->oe_bi, &B->oe_bj, &B->Hcam, &B->bcam, &B->Hcub, &B->bcub, &B->Hll, &B->bl,
-                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv, &B->scale_partial, &B->pe_meas, &B->pe_info, &B->pe_K, &B->part_tiles, &B->part_coef};
+                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv, &B->scale_partial, &B->pe_meas, &B->pe_info, &B->pe_K, &B->part_tiles, &B->part_coef, &B->cub_M, &B->cub_Dinv};
   for (auto* d : dd) d->release();
   DBuf<int>* di[] = {&B->d_ce_active, &B->d_oe_active, &B->d_cam_col, &B->d_cub_col, &B->d_pt_free, &B->pm_pt, &B->pm_cam, &B->pt_ptr, &B->cm_pm, &B->cm_pt, &B->cam_ptr, &B->d_ce_cam, &B->d_ce_cub,
                      &B->d_oe_i, &B->d_oe_j, &B->cam_ce_ptr, &B->cam_ce_idx, &B->cam_oei_ptr, &B->cam_oei_idx, &B->cam_oej_ptr, &B->cam_oej_idx, &B->cub_ce_ptr,
                      &B->cub_ce_idx, &B->pair_ptr, &B->pair_i1, &B->pair_i2, &B->ent_a, &B->ent_b, &B->d_run_lm, &B->d_seg_ptr, &B->d_seg_k, &B->d_seg_tile, &B->d_seg_slot,
-                     &B->d_gp_ptr, &B->d_gp_i1, &B->d_gp_i2, &B->d_gtile, &B->d_gcam_ptr, &B->d_gslot};
+                     &B->d_gp_ptr, &B->d_gp_i1, &B->d_gp_i2, &B->d_gtile, &B->d_gcam_ptr, &B->d_gslot, &B->d_cubS_ptr, &B->d_cubS_cam, &B->d_ce_slot, &B->d_cub_tile, &B->d_cub_coef,
+                     &B->d_elim_fail, &B->d_slotE_ptr, &B->d_slotE_idx};
   for (auto* d : di) d->release();
   B->d_info.release(); B->d_band_info.release();
   for (auto& e : B->ev) if (e) (void)hipEventDestroy(e);
@@ -921,7 +1015,7 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
   };
   // One trial entirely on the stream (banded solver, no callback): damped solve, LM scale term, update, chi2 of the new state and --
   // sharded -- ONE RCCL all-reduce of the pair [chi2, scale] are queued back to back; the host synchronises once per trial.
-  const bool stream_flow = !cb && B->band_ld > 0 && B->n_pose > 0;
+  const bool stream_flow = !cb && B->band_ld > 0 && B->n_red > 0;
   double t_begin = now_ms();
   double lambda = -1, ni = 2;
   int nBad = 0, done = 0;
@@ -984,7 +1078,7 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
         BA_TRY(hipStreamSynchronize(B->st));
         turn.unlock();
         if (*B->h_status == 0x7fffffff) { cs_set_error_ba("banded solver: team not co-resident (wait timed out); set CS_BA_FORCE_DENSE=1 on a shared device"); return CS_ERR_HIP; }
-        ok2 = *B->h_status == 0;
+        ok2 = B->h_status[0] == 0 && B->h_status[1] == 0;
         tempChi = B->h_scalars[0];
         scale = ok2 ? B->h_scalars[1] : 0.0;
         rc = collect_solve_times(B); if (rc) return rc;
@@ -1154,6 +1248,16 @@ int cs_ba_get_system(cs_ba* B, double* Hpp, double* Hll9, double* Hpl18, double*
   BA_GUARD_BEGIN
   return cs_ba_get_system_impl(B, Hpp, Hll9, Hpl18, b, x);
   BA_GUARD_END("cs_ba_get_system")
+}
+
+int cs_ba_reduced_size(cs_ba* B, int* n_reduced, int* cuboids_eliminated) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  BA_GUARD_BEGIN
+  int rc = finalize_structure(B); if (rc) return rc;
+  if (n_reduced) *n_reduced = B->n_red;
+  if (cuboids_eliminated) *cuboids_eliminated = B->elim ? 1 : 0;
+  return CS_OK;
+  BA_GUARD_END("cs_ba_reduced_size")
 }
 
 int cs_ba_schur_layout(cs_ba* B, int* fused, int* n_segments, int* n_partial_blocks, int* n_blocks) {

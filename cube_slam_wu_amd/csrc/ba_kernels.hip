@@ -527,6 +527,7 @@ __global__ __launch_bounds__(128) void ba_cub_scatter_kernel(BaView v, double la
 __global__ __launch_bounds__(64) void ba_offdiag_kernel(BaView v) {
   int k = blockIdx.x, t = threadIdx.x;
   if (k < v.n_cub) {
+    if (v.elim) return;       // the cuboids are not part of the reduced system
     int ca = v.cam_col[v.ce_cam[k]], cb = v.cub_col[v.ce_cub[k]];
     if (ca < 0 || cb < 0 || t >= 54) return;
     int i = t / 9, j = t % 9;
@@ -732,6 +733,114 @@ __global__ __launch_bounds__(64) void ba_cam_rhs_fused_kernel(BaView v, double l
   if (t < 36) {
     const int i = t / 6, j = t % 6;
     if (i >= j) *ba_S_at(v, col + i, col + j) = v.Hcam[36 * c + t] + ((i == j && v.add_lambda) ? lambda : 0.0);
+  }
+}
+
+// ---- elimination of the cuboids (BaView::elim) ------------------------------------------------------------------------------
+// A free cuboid is coupled to the cameras that observe it and to nothing else, so it leaves the reduced system exactly like a landmark
+// (block_solver.hpp:385-431 with a 9 x 9 block): D_oo^-1 = (H_oo + lambda I)^-1, S(c_a, c_b) -= M_a D_oo^-1 M_b^T for every pair of
+// observing cameras, b_schur(c_a) -= M_a D_oo^-1 b_o, with M_a = the 6 x 9 camera-cuboid block summed over the edges of slot a (a
+// camera may hold an EdgeSE3Cuboid and an EdgeSE3CuboidProj to the same cuboid).  One wavefront per cuboid; the blocks and vectors go
+// to the same partial arrays as the landmark segments' and are summed by the same destination schedule.
+__global__ __launch_bounds__(256) void ba_cub_elim_kernel(BaView v, double lambda) {
+  __shared__ double M[BA_ELIM_MAX_SLOTS][54], G[BA_ELIM_MAX_SLOTS][54];
+  __shared__ double A[9][9], Di[9][9], bo[9];
+  const int o = blockIdx.x, t = threadIdx.x;
+  if (v.cub_col[o] < 0) return;
+  const int s0 = v.cubS_ptr[o], ns = v.cubS_ptr[o + 1] - s0;
+  // M_s: one thread per (slot, element), the slot's edges in edge order
+  for (int e = t; e < ns * 54; e += 256) {
+    const int sl = e / 54, el = e - 54 * sl;
+    double sv = 0;
+    for (int q = v.slotE_ptr[s0 + sl]; q < v.slotE_ptr[s0 + sl + 1]; q++) sv += v.ce_Hco[54 * (size_t)v.slotE_idx[q] + el];
+    M[sl][el] = sv;
+    v.cub_M[54 * (size_t)(s0 + sl) + el] = sv;
+  }
+  for (int e = t; e < 81; e += 256) A[e / 9][e % 9] = v.Hcub[81 * (size_t)o + e] + ((e / 9 == e % 9) ? lambda : 0.0);
+  __syncthreads();
+  if (t == 0) {
+    // Cholesky A = L L^T, then Di = L^-T L^-1 (9 x 9: a few hundred flops, one lane)
+    double L[9][9], X[9][9];
+    bool fail = false;
+    for (int j = 0; j < 9; j++) {
+      double d = A[j][j];
+      for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
+      if (!(d > 0.0)) { fail = true; d = 1.0; }
+      const double r = sqrt(d);
+      L[j][j] = r;
+      for (int i = j + 1; i < 9; i++) {
+        double sv = A[i][j];
+        for (int k = 0; k < j; k++) sv -= L[i][k] * L[j][k];
+        L[i][j] = sv / r;
+      }
+    }
+    for (int c = 0; c < 9; c++)          // X = L^-1 (lower triangular), column by column
+      for (int i = 0; i < 9; i++) {
+        double sv = (i == c) ? 1.0 : 0.0;
+        for (int k = c; k < i; k++) sv -= L[i][k] * X[k][c];
+        X[i][c] = (i >= c) ? sv / L[i][i] : 0.0;
+      }
+    for (int i = 0; i < 9; i++)
+      for (int j = 0; j < 9; j++) {
+        double sv = 0;
+        for (int k = (i > j ? i : j); k < 9; k++) sv += X[k][i] * X[k][j];
+        Di[i][j] = sv;
+      }
+    if (fail) atomicExch(v.elim_fail, 1);
+  }
+  __syncthreads();
+  for (int e = t; e < 81; e += 256) v.cub_Dinv[81 * (size_t)o + e] = Di[e / 9][e % 9];
+  if (t < 9) { double sv = 0; for (int k = 0; k < 9; k++) sv += Di[t][k] * v.bcub[9 * (size_t)o + k]; bo[t] = sv; }
+  __syncthreads();
+  // G_s = M_s D^-1, the slot's share of the right-hand side
+  for (int e = t; e < ns * 54; e += 256) {
+    const int sl = e / 54, r = (e % 54) / 9, c = e % 9;
+    double sv = 0;
+    for (int k = 0; k < 9; k++) sv += M[sl][9 * r + k] * Di[k][c];
+    G[sl][9 * r + c] = sv;
+  }
+  for (int e = t; e < ns * 6; e += 256) {
+    const int sl = e / 6, r = e % 6;
+    double sv = 0;
+    for (int k = 0; k < 9; k++) sv += M[sl][9 * r + k] * bo[k];
+    v.part_coef[6 * (size_t)(v.cub_coef[o] + sl) + r] = sv;
+  }
+  __syncthreads();
+  // the slot pairs a <= b (slots are sorted by column): block(r, c) = sum_m G_a(r, m) M_b(c, m)
+  const int npair = ns * (ns + 1) / 2;
+  for (int e = t; e < npair * 36; e += 256) {
+    const int pr = e / 36, rc = e % 36, r = rc / 6, c = rc % 6;
+    int a = 0, rem = pr;
+    while (rem >= ns - a) { rem -= ns - a; a++; }
+    const int b = a + rem;
+    double sv = 0;
+    for (int m = 0; m < 9; m++) sv += G[a][9 * r + m] * M[b][9 * c + m];
+    v.part_tiles[36 * (size_t)(v.cub_tile[o] + pr) + rc] = sv;
+  }
+}
+
+// x_o = D_oo^-1 (b_o - sum_s M_s^T x_cam(s))   (block_solver.hpp:457-482 for the cuboid blocks)
+__global__ __launch_bounds__(64) void ba_cub_backsub_kernel(BaView v) {
+  __shared__ double cl[9];
+  const int o = blockIdx.x, t = threadIdx.x;
+  const int col = v.cub_col[o];
+  if (col < 0) return;
+  if (t < 9) {
+    double acc = v.bcub[9 * (size_t)o + t];
+    for (int sl = v.cubS_ptr[o]; sl < v.cubS_ptr[o + 1]; sl++) {
+      const double* Ms = v.cub_M + 54 * (size_t)sl;
+      const double* xp = v.rhs + v.cam_col[v.cubS_cam[sl]];
+      double sv = 0;
+      for (int r = 0; r < 6; r++) sv += Ms[9 * r + t] * (-xp[r]);
+      acc += sv;
+    }
+    cl[t] = acc;
+  }
+  __syncthreads();
+  if (t < 9) {
+    double sv = 0;
+    for (int k = 0; k < 9; k++) sv += v.cub_Dinv[81 * (size_t)o + 9 * t + k] * cl[k];
+    v.rhs[col + t] = sv;
   }
 }
 
@@ -1820,8 +1929,9 @@ void ba_launch_reduce(const BaView& v, double lambda, hipStream_t st) {
     if (v.seg_class[0] > 0) hipLaunchKernelGGL(ba_schur_fused_kernel<1>, dim3((v.seg_class[0] + 3) / 4), dim3(256), 0, st, v, lambda, 0, v.seg_class[0]);
     if (v.seg_class[1] > v.seg_class[0]) hipLaunchKernelGGL(ba_schur_fused_kernel<2>, dim3((v.seg_class[1] - v.seg_class[0] + 3) / 4), dim3(256), 0, st, v, lambda, v.seg_class[0], v.seg_class[1]);
     if (v.n_seg > v.seg_class[1]) hipLaunchKernelGGL(ba_schur_fused_kernel<3>, dim3((v.n_seg - v.seg_class[1] + 3) / 4), dim3(256), 0, st, v, lambda, v.seg_class[1], v.n_seg);
+    if (v.elim && v.no > 0) hipLaunchKernelGGL(ba_cub_elim_kernel, dim3(v.no), dim3(256), 0, st, v, lambda);
     hipLaunchKernelGGL(ba_cam_rhs_fused_kernel, dim3(v.nc), dim3(64), 0, st, v, lambda);
-    if (v.no > 0) hipLaunchKernelGGL(ba_cub_scatter_kernel, dim3(v.no), dim3(128), 0, st, v, lambda);
+    if (!v.elim && v.no > 0) hipLaunchKernelGGL(ba_cub_scatter_kernel, dim3(v.no), dim3(128), 0, st, v, lambda);
     if (v.n_cub + v.n_odom > 0) hipLaunchKernelGGL(ba_offdiag_kernel, dim3(v.n_cub + v.n_odom), dim3(64), 0, st, v);
     if (v.n_gpairs > 0) hipLaunchKernelGGL(ba_schur_gather_kernel, dim3((v.n_gpairs + 3) / 4), dim3(256), 0, st, v);
     return;
@@ -1853,6 +1963,7 @@ void ba_launch_scale(const BaView& v, double lambda_pose, double lambda_lm, doub
   hipLaunchKernelGGL(ba_scale_kernel, dim3(SCALE_BLOCKS), dim3(256), 0, st, v, lambda_pose, lambda_lm, partial);
 }
 void ba_launch_backsub(const BaView& v, hipStream_t st) {
+  if (v.elim && v.no > 0) hipLaunchKernelGGL(ba_cub_backsub_kernel, dim3(v.no), dim3(64), 0, st, v);
   if (v.np > 0) hipLaunchKernelGGL(ba_backsub_kernel, dim3((v.np + 255) / 256), dim3(256), 0, st, v);
 }
 void ba_launch_update(const BaView& v, hipStream_t st) {

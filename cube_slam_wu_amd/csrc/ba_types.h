@@ -14,6 +14,17 @@ struct BaView {
   const int* cub_col;  // no
   const int* pt_free;  // np: 1 = optimised, 0 = fixed
   int nc, np, no, n_pose;
+  // The system the solver factorises has n_red unknowns: n_pose (cameras and cuboids, g2o's reduced system) or, with elim = 1, the
+  // cameras only -- the free cuboids are then eliminated like landmarks (S_cc -= H_co D_oo^-1 H_co^T, block_solver.hpp:385-431
+  // applied to the 9 x 9 blocks too) and their increments live behind the reduced system's in `rhs` (cub_col >= n_red).
+  int n_red, elim;
+  const int* cubS_ptr; const int* cubS_cam;   // no + 1; slot -> camera: the distinct free cameras observing a free cuboid, by column
+  const int* ce_slot;                         // cuboid edge -> slot (-1: fixed camera / fixed cuboid)
+  const int* slotE_ptr; const int* slotE_idx; // slot -> its cuboid edges, in edge order
+  const int* cub_tile; const int* cub_coef;   // per cuboid: first partial block of its slot pairs (a <= b), first partial vector
+  double* cub_M;                              // 54 per slot: H_co summed over the slot's edges (6 x 9)
+  double* cub_Dinv;                           // 81 per cuboid: (H_oo + lambda I)^-1
+  int* elim_fail;                             // set when a damped 9 x 9 block is not positive definite
   // ---- projection edges (EdgeSE3ProjectXYZ) ---------------------------------------------------------
   // point-major copy: edges of one landmark are contiguous, sorted by pose column (the CCS column order of
   // block_solver.hpp:398-431); camera-major copy: edges of one camera are contiguous.
@@ -70,10 +81,10 @@ struct BaView {
   // chi2 partial sums
   double* chi_partial;
 };
-enum { BA_SEG_LM = 32, BA_FUSED_KMAX = 7 };
+enum { BA_SEG_LM = 32, BA_FUSED_KMAX = 7, BA_ELIM_MAX_SLOTS = 64 };
 
 CS_HD double* ba_S_at(const BaView& v, int r, int c) {  // requires r >= c (and r - c < band_ld in band mode)
-  return v.band_ld ? v.S + (size_t)c * v.band_ld + (r - c) : v.S + (size_t)r * v.n_pose + c;
+  return v.band_ld ? v.S + (size_t)c * v.band_ld + (r - c) : v.S + (size_t)r * v.n_red + c;
 }
 
 }  // namespace cs

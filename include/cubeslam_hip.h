@@ -285,6 +285,13 @@ int cs_ba_sizes(cs_ba* ba, int* size_pose, int* size_landmarks);
  * band_ld = bandwidth + 1 (one persistent kernel, `team` workgroups); band_ld == 0 = dense rocSOLVER potrf/potrs
  * (graphs whose bandwidth exceeds half the system, systems under 128 unknowns). */
 int cs_ba_solver_layout(cs_ba* ba, int* band_ld, int* team);
+/* The system the solver factorises.  g2o's reduced system holds cameras and cuboids (only the points are marginalised); since a cuboid
+ * is coupled to its observing cameras only, the library may eliminate the cuboids' 9 x 9 blocks as well -- the same exact block
+ * elimination as for the landmarks, i.e. a different elimination order of the same Cholesky factorisation -- when that makes the
+ * banded factorisation cheaper (C4: 10 494 -> 5 994 unknowns, bandwidth 182 -> 119).  n_reduced = unknowns of the factorised system;
+ * cuboids_eliminated = 1 if it holds the cameras only.  x() / b() / cs_ba_sizes keep g2o's layout either way.
+ * CS_BA_KEEP_CUBOIDS=1 (environment) keeps g2o's system.                                                              */
+int cs_ba_reduced_size(cs_ba* ba, int* n_reduced, int* cuboids_eliminated);
 /* How the Schur complement S -= sum_j W_j D_j^-1 W_j^T (block_solver.hpp:385-431) is formed.  fused = 1: landmarks grouped by
  * camera set, one wavefront per segment of <= 32 landmarks, the product on the matrix cores (v_mfma_f64_16x16x4_f64) with the
  * landmarks as contraction dimension, n_partial_blocks partial 6x6 blocks summed per destination in a fixed order; fused = 0

@@ -542,7 +542,8 @@ def test_fused_mfma_schur_matches_the_pair_major_path_and_the_oracle(obs, monkey
     monkeypatch.delenv("CS_BA_SCHUR_PAIRS")
     if fused:
         assert n_seg > 0 and n_part < 0.5 * sum(k * (k + 1) // 2 for k in np.bincount(np.asarray(pr["e_pt"])))   # far fewer partial blocks than (landmark, pair) entries
-        assert n_blk == Q.schur_layout()[3]
+        if not F.reduced_size()[1]:      # (with the cuboids eliminated too the fused path has the camera-camera blocks they fill in on top)
+            assert n_blk == Q.schur_layout()[3]
     R = _oracle(pr)
     for P in (F, Q, R):
         P.compute_errors() if P is not R else None
@@ -595,3 +596,45 @@ def test_rccl_path_inside_the_library_single_rank_communicator():
     for a, b in zip(A.state(), B.state()):
         assert np.array_equal(a, b)
     A.close(); B.close()
+
+
+@pytest.mark.parametrize("case", ["plain", "bbox_edges", "fixed", "cuboids_first"])
+def test_cuboid_elimination_equals_g2os_reduced_system(case, monkeypatch):
+    """The cuboids' 9 x 9 blocks eliminated like landmarks (reduced system = cameras only) against g2o's reduced system (cameras and
+    cuboids; CS_BA_KEEP_CUBOIDS=1) and against the oracle: same increments, same LM trajectory.  Cases: EdgeSE3Cuboid only; an
+    EdgeSE3Cuboid and an EdgeSE3CuboidProj per (camera, cuboid) pair (two edges in one slot); fixed cuboids and fixed cameras among
+    the observers; cuboids numbered before the cameras."""
+    pr = synth_ba.make_problem(n_cams=150, n_points=6000, n_cuboids=24, seed=41, bbox_edges=(case == "bbox_edges"))
+    cf = False
+    if case == "fixed":
+        pr["cub_fixed"] = pr["cub_fixed"].copy(); pr["cub_fixed"][[2, 9]] = 1
+        pr["cam_fixed"] = pr["cam_fixed"].copy(); pr["cam_fixed"][[0, 40, 41, 100]] = 1
+    if case == "cuboids_first":
+        cf = True
+    E = capi.ba_from_dict(pr, cuboids_first=cf)
+    n_red, elim = E.reduced_size()
+    assert elim and n_red == 6 * int((np.asarray(pr["cam_fixed"]) == 0).sum())
+    monkeypatch.setenv("CS_BA_KEEP_CUBOIDS", "1")
+    K = capi.ba_from_dict(pr, cuboids_first=cf)
+    n_keep, elim_k = K.reduced_size()
+    monkeypatch.delenv("CS_BA_KEEP_CUBOIDS")
+    assert not elim_k and n_keep == E.sizes()[0] == K.sizes()[0] and n_keep > n_red
+    assert n_red * E.solver_layout()[0] ** 2 < n_keep * K.solver_layout()[0] ** 2      # the cheaper banded factorisation (n bw^2) is what selects it
+    R = _oracle(pr, cuboids_first=cf)
+    E.build_system(); K.build_system(); R.build_system()
+    for lam in (1e-2, 40.0):
+        ok_e, x_e = E.solve(lam)
+        ok_k, x_k = K.solve(lam)
+        ok_r, x_r = R.solve(lam)
+        assert ok_e and ok_k and ok_r
+        assert _rel(x_e, x_k) < 1e-9 and _rel(x_e, x_r) < 1e-5
+    ok_e, _ = E.solve(-1e12)                    # an indefinite damped cuboid block must surface as "not positive definite"
+    assert not ok_e
+    assert E.optimize(5) == K.optimize(5) == R.optimize(5)
+    # (the two elimination orders agree to 1e-9 in one solve; over five iterations the 1e-9-step numeric Jacobians of the cuboid /
+    # odometry edges amplify that to ~1e-7 in chi2 -- the bar stays north_star's 1e-5)
+    assert np.array_equal(E.history()[2], K.history()[2]) and np.allclose(E.history()[0], K.history()[0], rtol=1e-6)
+    assert np.array_equal(E.history()[2], R.history()[2]) and np.allclose(E.history()[0], R.history()[0], rtol=1e-5)
+    for a, b in zip(E.state(), K.state()):
+        assert a.size == 0 or np.abs(a - b).max() < 1e-5 * max(1.0, np.abs(b).max())
+    E.close(); K.close(); R.close()
