@@ -28,8 +28,8 @@
 namespace cs {
 int ba_chi2_blocks(int n_proj);
 void ba_launch_chi2(const BaView& v, int nb_proj, hipStream_t st);
-void ba_launch_linearize(const BaView& v, hipStream_t st);
-void ba_launch_reduce(const BaView& v, double lambda, hipStream_t st);
+void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join);
+void ba_launch_reduce(const BaView& v, double lambda, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join);
 void ba_launch_backsub(const BaView& v, hipStream_t st);
 int ba_scale_blocks();
 void ba_launch_scale(const BaView& v, double lambda_pose, double lambda_lm, double* partial, hipStream_t st);
@@ -105,6 +105,8 @@ struct DBuf {
 struct cs_ba {
   int device = 0;
   hipStream_t st = nullptr;
+  hipStream_t st2 = nullptr;                 // side stream of the reduce phase (cuboid elimination beside the landmark segments)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   rocblas_handle blas = nullptr;
   hipEvent_t ev[8] = {};   // phase marks on the stream (linearise: 0-1; solve: 2 reduce 3 factor 4 back-substitution 5)
   bool lin_pending = false;  // ev[0..1] recorded but not yet read
@@ -666,7 +668,7 @@ int collect_lin_time(cs_ba* B) {
 
 int build_system_device(cs_ba* B) {
   BA_TRY(hipEventRecord(B->ev[0], B->st));
-  cs::ba_launch_linearize(B->view, B->st);
+  cs::ba_launch_linearize(B->view, B->st, B->st2, B->ev_fork, B->ev_join);
   BA_TRY(hipGetLastError());
   BA_TRY(hipEventRecord(B->ev[1], B->st));
   B->lin_pending = true;
@@ -700,7 +702,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
     BA_TRY(hipEventRecord(B->ev[2], B->st));
     BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (B->s_doubles + B->n_pose), B->st));
     BA_TRY(hipMemsetAsync(B->d_elim_fail.p, 0, sizeof(int), B->st));
-    cs::ba_launch_reduce(B->view, lambda, B->st);
+    cs::ba_launch_reduce(B->view, lambda, B->st, B->st2, B->ev_fork, B->ev_join);
     BA_TRY(hipMemcpyAsync(B->h_status + 1, B->d_elim_fail.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
     BA_TRY(hipGetLastError());
     if (fn && B->shard_n > 1) {  // sum the ranks' partial reduced systems: [S | rhs] in one message
@@ -765,6 +767,9 @@ int cs_ba_create(int device, cs_ba** out) {
   { const char* e = getenv("CS_BA_FORCE_DENSE"); B->force_dense = (e && atoi(e)) ? 1 : 0; }  // diagnostics: rocSOLVER dense path
   BA_TRY(hipSetDevice(device));
   BA_TRY(hipStreamCreateWithFlags(&B->st, hipStreamNonBlocking));
+  BA_TRY(hipStreamCreateWithFlags(&B->st2, hipStreamNonBlocking));
+  BA_TRY(hipEventCreateWithFlags(&B->ev_fork, hipEventDisableTiming));
+  BA_TRY(hipEventCreateWithFlags(&B->ev_join, hipEventDisableTiming));
   for (auto& e : B->ev) BA_TRY(hipEventCreate(&e));
   BA_TRY(hipHostMalloc((void**)&B->h_status, 2 * sizeof(int)));   // [factorisation status, a cuboid block failed]
   B->h_status[0] = B->h_status[1] = 0;
@@ -797,6 +802,9 @@ void cs_ba_destroy(cs_ba* B) {
   if (B->comm) (void)ncclCommDestroy(B->comm);
   B->d_scalars.release();
   if (B->blas) rocblas_destroy_handle(B->blas);
+  if (B->ev_fork) (void)hipEventDestroy(B->ev_fork);
+  if (B->ev_join) (void)hipEventDestroy(B->ev_join);
+  if (B->st2) (void)hipStreamDestroy(B->st2);
   if (B->st) (void)hipStreamDestroy(B->st);
   delete B;
 }

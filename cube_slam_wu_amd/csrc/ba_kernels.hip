@@ -1915,21 +1915,38 @@ void ba_launch_chi2(const BaView& v, int nb_proj, hipStream_t st) {
   int ne = v.n_cub + v.n_odom;
   if (ne > 0) hipLaunchKernelGGL(ba_chi2_pose_edges_kernel, dim3((ne + 63) / 64), dim3(64), 0, st, v, nb_proj);
 }
-void ba_launch_linearize(const BaView& v, hipStream_t st) {
+// the numeric-Jacobian edges (cuboid, odometry: few edges, long dependent chains) run beside the projection edges (many edges, short
+// chains) on a second stream; ba_accum_pose_kernel needs both
+void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join) {
+  const bool side = st2 != nullptr && (v.n_cub > 0 || v.n_odom > 0);
+  hipStream_t se = side ? st2 : st;
+  if (side) { (void)hipEventRecord(ev_fork, st); (void)hipStreamWaitEvent(st2, ev_fork, 0); }
+  if (v.n_cub > 0) hipLaunchKernelGGL(ba_cub_edge_kernel, dim3((v.n_cub + 3) / 4), dim3(128), 0, se, v);
+  if (v.n_odom > 0) hipLaunchKernelGGL(ba_odom_edge_kernel, dim3((v.n_odom + 3) / 4), dim3(64), 0, se, v);
+  if (side) (void)hipEventRecord(ev_join, st2);
   if (v.n_proj > 0 || v.nc > 0) hipLaunchKernelGGL(ba_lin_cam_kernel, dim3(v.nc), dim3(256), 0, st, v);
   if (v.np > 0) hipLaunchKernelGGL(ba_lin_pt_kernel, dim3((v.np + LIN_PT_GROUP - 1) / LIN_PT_GROUP), dim3(256), 0, st, v);
-  if (v.n_cub > 0) hipLaunchKernelGGL(ba_cub_edge_kernel, dim3((v.n_cub + 3) / 4), dim3(128), 0, st, v);
-  if (v.n_odom > 0) hipLaunchKernelGGL(ba_odom_edge_kernel, dim3((v.n_odom + 3) / 4), dim3(64), 0, st, v);
+  if (side) (void)hipStreamWaitEvent(st, ev_join, 0);
   hipLaunchKernelGGL(ba_accum_pose_kernel, dim3(v.nc + v.no), dim3(128), 0, st, v, 0);
 }
-void ba_launch_reduce(const BaView& v, double lambda, hipStream_t st) {
+void ba_launch_reduce(const BaView& v, double lambda, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join) {
   if (v.fused) {
+    // the cuboid elimination (one workgroup per cuboid, latency-bound) runs beside the landmark segments on a second stream; both
+    // write disjoint ranges of the partial arrays and meet before the destination schedule reads them
+    const bool side = v.elim && v.no > 0 && st2 != nullptr;
+    if (side) {
+      (void)hipEventRecord(ev_fork, st);
+      (void)hipStreamWaitEvent(st2, ev_fork, 0);
+      hipLaunchKernelGGL(ba_cub_elim_kernel, dim3(v.no), dim3(256), 0, st2, v, lambda);
+      (void)hipEventRecord(ev_join, st2);
+    }
     // the diagonal blocks / right-hand side of the cameras need the segments' partial vectors; the gather of the blocks runs last
     // (it subtracts from entries the vertex kernels have written)
     if (v.seg_class[0] > 0) hipLaunchKernelGGL(ba_schur_fused_kernel<1>, dim3((v.seg_class[0] + 3) / 4), dim3(256), 0, st, v, lambda, 0, v.seg_class[0]);
     if (v.seg_class[1] > v.seg_class[0]) hipLaunchKernelGGL(ba_schur_fused_kernel<2>, dim3((v.seg_class[1] - v.seg_class[0] + 3) / 4), dim3(256), 0, st, v, lambda, v.seg_class[0], v.seg_class[1]);
     if (v.n_seg > v.seg_class[1]) hipLaunchKernelGGL(ba_schur_fused_kernel<3>, dim3((v.n_seg - v.seg_class[1] + 3) / 4), dim3(256), 0, st, v, lambda, v.seg_class[1], v.n_seg);
-    if (v.elim && v.no > 0) hipLaunchKernelGGL(ba_cub_elim_kernel, dim3(v.no), dim3(256), 0, st, v, lambda);
+    if (side) (void)hipStreamWaitEvent(st, ev_join, 0);
+    else if (v.elim && v.no > 0) hipLaunchKernelGGL(ba_cub_elim_kernel, dim3(v.no), dim3(256), 0, st, v, lambda);
     hipLaunchKernelGGL(ba_cam_rhs_fused_kernel, dim3(v.nc), dim3(64), 0, st, v, lambda);
     if (!v.elim && v.no > 0) hipLaunchKernelGGL(ba_cub_scatter_kernel, dim3(v.no), dim3(128), 0, st, v, lambda);
     if (v.n_cub + v.n_odom > 0) hipLaunchKernelGGL(ba_offdiag_kernel, dim3(v.n_cub + v.n_odom), dim3(64), 0, st, v);
