@@ -130,6 +130,7 @@ struct cs_ba {
   int n_pose = 0, n_lm = 0;
   int n_red = 0;            // dimension of the system the solver factorises: n_pose, or the cameras' part when the cuboids are eliminated too
   bool elim = false;        // free cuboids eliminated like landmarks (single rank, fused Schur schedule)
+  DBuf<int> d_cub_mine;     // sharded + eliminated cuboids: 1 = this rank owns the cuboid (holds all its edges)
   DBuf<int> d_cubS_ptr, d_cubS_cam, d_ce_slot, d_cub_tile, d_cub_coef, d_elim_fail, d_slotE_ptr, d_slotE_idx;
   DBuf<double> cub_M, cub_Dinv;
   int n_proj = 0, n_cub = 0, n_odom = 0;   // n_cub = EdgeSE3Cuboid + EdgeSE3CuboidProj edges (the combined list ce_cam / ce_cub)
@@ -248,8 +249,10 @@ int finalize_structure(cs_ba* B) {
   // S_cc -= H_co D_oo^-1 H_co^T is the same exact block elimination -- a different elimination order of one Cholesky
   // factorisation, not a different system -- and the reduced system shrinks to the cameras (C4: 10 494 -> 5 994 unknowns,
   // bandwidth 182 -> 119: a cuboid couples the ~20 consecutive cameras that see it, which the landmarks' band nearly contains).
-  // The one with the cheaper banded factorisation (n bw^2) is taken; (b) needs the fused Schur schedule, a single rank (a cuboid's
-  // edges may live on two ranks) and at most BA_ELIM_MAX_SLOTS cameras per cuboid.  CS_BA_KEEP_CUBOIDS=1 forces (a).
+  // The one with the cheaper banded factorisation (n bw^2) is taken; (b) needs the fused Schur schedule and at most
+  // BA_ELIM_MAX_SLOTS cameras per cuboid; sharded, a cuboid's edges then all live on ONE rank (that of its lowest-index observing
+  // camera) so that its block is complete where it is eliminated, and the cuboids' increments are summed over the ranks after the
+  // back-substitution (zero on every rank but the owner).  CS_BA_KEEP_CUBOIDS=1 forces (a).
   B->cam_col.assign(nc, -1); B->cub_col.assign(no, -1);
   std::vector<std::vector<int>> cub_cams(no);     // free cameras observing a free cuboid, distinct, by camera id
   int max_slots = 0, n_free_cub = 0;
@@ -327,7 +330,7 @@ int finalize_structure(cs_ba* B) {
   auto cost = [&](const Ordering& O) { return band_ok(O) ? (double)O.n_red * (O.bw + 1.0) * (O.bw + 1.0) : (double)O.n_red * O.n_red * O.n_red / 3.0; };
   {
     Ordering keep_o = make_ordering(false);
-    const bool try_elim = B->shard_n == 1 && fused_ok && n_free_cub > 0 && max_slots <= cs::BA_ELIM_MAX_SLOTS && getenv("CS_BA_KEEP_CUBOIDS") == nullptr;
+    const bool try_elim = fused_ok && n_free_cub > 0 && max_slots <= cs::BA_ELIM_MAX_SLOTS && getenv("CS_BA_KEEP_CUBOIDS") == nullptr;
     Ordering elim_o;
     if (try_elim) elim_o = make_ordering(true);
     B->elim = try_elim && cost(elim_o) < cost(keep_o);
@@ -554,7 +557,19 @@ int finalize_structure(cs_ba* B) {
   UP(B->d_ce_cam, B->ce_cam); UP(B->d_ce_cub, B->ce_cub); UP(B->d_oe_i, B->oe_i); UP(B->d_oe_j, B->oe_j);
   {
     std::vector<int> ca(B->n_cub), oa(B->n_odom);
-    for (int k = 0; k < B->n_cub; k++) ca[k] = cam_rank(B->ce_cam[k], nc, B->shard_n) == B->shard_rank;
+    // cuboid edges: with their camera's rank, or -- cuboids eliminated -- all edges of a cuboid with the rank of its lowest-index camera
+    std::vector<int> cub_owner(no, 0);
+    {
+      std::vector<int> first(no, 0x7fffffff);
+      for (int k = 0; k < B->n_cub; k++) first[B->ce_cub[k]] = std::min(first[B->ce_cub[k]], B->ce_cam[k]);
+      for (int o = 0; o < no; o++) cub_owner[o] = first[o] == 0x7fffffff ? 0 : cam_rank(first[o], nc, B->shard_n);
+    }
+    for (int k = 0; k < B->n_cub; k++) ca[k] = (B->elim ? cub_owner[B->ce_cub[k]] : cam_rank(B->ce_cam[k], nc, B->shard_n)) == B->shard_rank;
+    {
+      std::vector<int> mine(std::max(1, no), 0);
+      for (int o = 0; o < no; o++) mine[o] = cub_owner[o] == B->shard_rank;
+      UP(B->d_cub_mine, mine);
+    }
     for (int k = 0; k < B->n_odom; k++) oa[k] = cam_rank(B->oe_j[k], nc, B->shard_n) == B->shard_rank;
     UP(B->d_ce_active, ca); UP(B->d_oe_active, oa);
   }
@@ -592,6 +607,7 @@ int finalize_structure(cs_ba* B) {
   v.cams = B->cams.p; v.points = B->points.p; v.cubes = B->cubes.p; v.cam_col = B->d_cam_col.p; v.cub_col = B->d_cub_col.p; v.pt_free = B->d_pt_free.p;
   v.nc = nc; v.np = np; v.no = no; v.n_pose = B->n_pose; v.n_red = B->n_red; v.elim = B->elim ? 1 : 0;
   v.cubS_ptr = B->d_cubS_ptr.p; v.cubS_cam = B->d_cubS_cam.p; v.ce_slot = B->d_ce_slot.p; v.cub_tile = B->d_cub_tile.p; v.cub_coef = B->d_cub_coef.p;
+  v.cub_mine = B->d_cub_mine.p;
   v.cub_M = B->cub_M.p; v.cub_Dinv = B->cub_Dinv.p; v.elim_fail = B->d_elim_fail.p; v.slotE_ptr = B->d_slotE_ptr.p; v.slotE_idx = B->d_slotE_idx.p;
   v.n_proj = E; v.pm_pt = B->pm_pt.p; v.pm_cam = B->pm_cam.p; v.pm_uv = B->pm_uv.p; v.pm_info = B->pm_info.p; v.pm_intr = B->pm_intr.p; v.pm_huber = B->pm_huber.p;
   v.pt_ptr = B->pt_ptr.p; v.cm_pm = B->cm_pm.p; v.cm_pt = B->cm_pt.p; v.cm_uv = B->cm_uv.p; v.cm_info = B->cm_info.p; v.cm_intr = B->cm_intr.p; v.cm_huber = B->cm_huber.p; v.cam_ptr = B->cam_ptr.p;
@@ -693,6 +709,21 @@ int collect_solve_times(cs_ba* B) {
   return collect_lin_time(B);
 }
 
+// Sharded with the cuboids eliminated: a cuboid's increment is computed by the rank that owns it (zero elsewhere); every rank updates
+// all vertices, so the increments (9 doubles per free cuboid, behind the reduced system's in `rhs`) are summed over the ranks.
+int share_cuboid_increments(cs_ba* B, cs_allreduce_fn fn, void* ctx) {
+  if (!B->elim || B->shard_n <= 1 || B->n_pose <= B->n_red) return CS_OK;
+  double* xo = B->view.rhs + B->n_red;
+  const size_t n = (size_t)(B->n_pose - B->n_red);
+  if (fn) {
+    BA_TRY(hipStreamSynchronize(B->st));
+    if (fn(ctx, xo, n, 1, 0) != 0) { cs_set_error_ba("all-reduce callback failed"); return CS_ERR_HIP; }
+  } else if (B->comm) {
+    BA_NCCL(ncclAllReduce(xo, xo, n, ncclDouble, ncclSum, B->comm, B->st));
+  }
+  return CS_OK;
+}
+
 // defer != nullptr (banded path only): everything is queued and the function returns WITHOUT synchronising; *defer then holds the
 // persistent-kernel turn, and the caller synchronises, reads *h_status, calls collect_solve_times() and releases the turn.
 int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr, void* ctx = nullptr, std::unique_lock<std::mutex>* defer = nullptr) {
@@ -723,6 +754,11 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       BA_TRY(hipEventRecord(B->ev[4], B->st));
       cs::ba_launch_backsub(B->view, B->st);
       BA_TRY(hipGetLastError());
+      if (fn && B->elim && B->shard_n > 1) {   // the callback waits for the other ranks: the persistent kernel's turn must be free by then
+        BA_TRY(hipStreamSynchronize(B->st));
+        coop_turn.unlock();
+      }
+      { int rc2 = share_cuboid_increments(B, fn, ctx); if (rc2) return rc2; }
       BA_TRY(hipEventRecord(B->ev[5], B->st));
       BA_TRY(hipMemcpyAsync(B->h_status, B->d_band_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
       if (defer) { *defer = std::move(coop_turn); B->tm.n_solves++; return CS_OK; }
@@ -740,7 +776,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       if (B->h_status[0] != 0 || B->h_status[1] != 0) *ok = false;
       else BA_ROC(rocsolver_dpotrs(B->blas, rocblas_fill_upper, n, 1, B->S.p, n, B->view.rhs, n));
       BA_TRY(hipEventRecord(B->ev[4], B->st));
-      if (*ok) { cs::ba_launch_backsub(B->view, B->st); BA_TRY(hipGetLastError()); }
+      if (*ok) { cs::ba_launch_backsub(B->view, B->st); BA_TRY(hipGetLastError()); int rc2 = share_cuboid_increments(B, fn, ctx); if (rc2) return rc2; }
       BA_TRY(hipEventRecord(B->ev[5], B->st));
       BA_TRY(hipStreamSynchronize(B->st));
     }
@@ -793,7 +829,7 @@ void cs_ba_destroy(cs_ba* B) {
                      &B->d_oe_i, &B->d_oe_j, &B->cam_ce_ptr, &B->cam_ce_idx, &B->cam_oei_ptr, &B->cam_oei_idx, &B->cam_oej_ptr, &B->cam_oej_idx, &B->cub_ce_ptr,
                      &B->cub_ce_idx, &B->pair_ptr, &B->pair_i1, &B->pair_i2, &B->ent_a, &B->ent_b, &B->d_run_lm, &B->d_seg_ptr, &B->d_seg_k, &B->d_seg_tile, &B->d_seg_slot,
                      &B->d_gp_ptr, &B->d_gp_i1, &B->d_gp_i2, &B->d_gtile, &B->d_gcam_ptr, &B->d_gslot, &B->d_cubS_ptr, &B->d_cubS_cam, &B->d_ce_slot, &B->d_cub_tile, &B->d_cub_coef,
-                     &B->d_elim_fail, &B->d_slotE_ptr, &B->d_slotE_idx};
+                     &B->d_elim_fail, &B->d_slotE_ptr, &B->d_slotE_idx, &B->d_cub_mine};
   for (auto* d : di) d->release();
   B->d_info.release(); B->d_band_info.release();
   for (auto& e : B->ev) if (e) (void)hipEventDestroy(e);

@@ -746,7 +746,7 @@ __global__ __launch_bounds__(256) void ba_cub_elim_kernel(BaView v, double lambd
   __shared__ double M[BA_ELIM_MAX_SLOTS][54], G[BA_ELIM_MAX_SLOTS][54];
   __shared__ double A[9][9], Di[9][9], bo[9];
   const int o = blockIdx.x, t = threadIdx.x;
-  if (v.cub_col[o] < 0) return;
+  if (v.cub_col[o] < 0 || !v.cub_mine[o]) return;      // another rank's cuboid: its partial blocks, M and D^-1 stay zero here
   const int s0 = v.cubS_ptr[o], ns = v.cubS_ptr[o + 1] - s0;
   // M_s: one thread per (slot, element), the slot's edges in edge order
   for (int e = t; e < ns * 54; e += 256) {

@@ -22,6 +22,7 @@ struct BaView {
   const int* ce_slot;                         // cuboid edge -> slot (-1: fixed camera / fixed cuboid)
   const int* slotE_ptr; const int* slotE_idx; // slot -> its cuboid edges, in edge order
   const int* cub_tile; const int* cub_coef;   // per cuboid: first partial block of its slot pairs (a <= b), first partial vector
+  const int* cub_mine;                        // no: 1 = this rank eliminates the cuboid (sharded BA: it holds all of its edges)
   double* cub_M;                              // 54 per slot: H_co summed over the slot's edges (6 x 9)
   double* cub_Dinv;                           // 81 per cuboid: (H_oo + lambda I)^-1
   int* elim_fail;                             // set when a damped 9 x 9 block is not positive definite

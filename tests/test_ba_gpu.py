@@ -235,6 +235,7 @@ def _run_sharded_in_threads(pr, n_ranks, iters):
         P = capi.ba_from_dict(pr)
         P.set_shard(r, n_ranks)
         probs.append(P)
+    assert len({P.reduced_size() for P in probs}) == 1        # every rank takes the same structural decisions (reduced system, elimination)
     barrier = threading.Barrier(n_ranks)
     slots = [None] * n_ranks
     import torch
