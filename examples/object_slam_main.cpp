@@ -179,6 +179,7 @@ int main(int argc, char** argv) {
   double cube10[10] = {0, 0, 0, 0, 0, 0, 1, 0, 0, 0};
   std::vector<double> cube_history;                  // 9 per frame
   int offline_cube_obs_row_id = 0, total_iterations = 0;
+  cs_ba* ba = nullptr;
 
   for (int frame_index = 0; frame_index < total_frame_number; frame_index++) {
     Pose curr_cam_pose_Twc, odom_val = {{0, 0, 0}, 0, 0, 0, 1};
@@ -275,16 +276,16 @@ int main(int argc, char** argv) {
     }
 
     // graph.initializeOptimization(); graph.optimize(5);  -- cuboid id 0 sorts before the cameras (ids frame + 1)
-    cs_ba* ba = nullptr;
+    // one solver handle for the whole run, like the reference's one graph (main_obj.cpp:510-520): every frame hands it the grown
+    // vertex / edge lists, and the structure phase is redone when they change
     const int cub_fixed = 0;
-    CHECK(cs_ba_create(0, &ba));
+    if (!ba) CHECK(cs_ba_create(0, &ba));
     CHECK(cs_ba_set_vertices(ba, cam_Tcw.data(), cam_fixed.data(), frame_index + 1, cube10, &cub_fixed, 1, nullptr, nullptr, 0, 1));
     if (!ce_cam.empty()) CHECK(cs_ba_set_edges_cuboid(ba, (int)ce_cam.size(), ce_cam.data(), ce_cub.data(), ce_meas.data(), ce_info.data()));
     if (!oe_i.empty()) CHECK(cs_ba_set_edges_odom(ba, (int)oe_i.size(), oe_i.data(), oe_j.data(), oe_meas.data(), oe_info.data()));
     int iterations_done = 0;
     CHECK(cs_ba_optimize(ba, 5, &iterations_done, nullptr, nullptr, nullptr, 0));
     CHECK(cs_ba_get_state(ba, cam_Tcw.data(), cube10, nullptr));
-    cs_ba_destroy(ba);
     total_iterations += iterations_done;
 
     double minimal[9];
@@ -292,6 +293,7 @@ int main(int argc, char** argv) {
     cube_history.insert(cube_history.end(), minimal, minimal + 9);
   }
   for (int sample = 0; sample < 2; sample++) if (detect_cuboid_obj[sample]) cs_detector_destroy(detect_cuboid_obj[sample]);
+  if (ba) cs_ba_destroy(ba);
   std::cout << "+++++++++++++Finish all optimization!+++++++++++++  LM iterations: " << total_iterations << std::endl;
 
   {
