@@ -152,11 +152,12 @@ CS_HD void plane_hit_world(const double* R, const double* t, const double* invK,
   double den = (plane[0] * ray[0] + plane[1] * ray[1]) + plane[2] * ray[2];
   double frac = -plane[3] / den;
   double p[3] = {frac * ray[0], frac * ray[1], frac * ray[2]};
-  // homogeneous row (0 0 0 1): ((0*x + 0*y) + 0*z) + 1*1 -- kept because 0*inf would be NaN in the reference too
+  // homogeneous row (0 0 0 1): w = ((0*x + 0*y) + 0*z) + 1*1 is exactly 1 for a finite point and NaN otherwise (0 * inf), and the
+  // reference divides by it: v / 1 == v bit for bit, v / NaN == NaN -- so the three divisions reduce to a select
   double w = ((0.0 * p[0] + 0.0 * p[1]) + 0.0 * p[2]) + 1.0 * 1.0;
   for (int i = 0; i < 3; i++) {
     double v = ((R[3 * i + 0] * p[0] + R[3 * i + 1] * p[1]) + R[3 * i + 2] * p[2]) + t[i] * 1.0;
-    out[i] = v / w;
+    out[i] = (w != w) ? w : v;
   }
 }
 

@@ -20,6 +20,9 @@
 
 #include "detect_types.h"
 
+#ifndef CS_EXP
+#define CS_EXP 0
+#endif
 namespace cs {
 
 __device__ __forceinline__ int find_job_i32(const int* prefix, int n, int v) {
@@ -36,6 +39,26 @@ __device__ __forceinline__ int find_job_i64(const long long* prefix, int n, long
     int mid = (lo + hi) >> 1;
     if (prefix[mid] <= v) lo = mid; else hi = mid;
   }
+  return lo;
+}
+
+// job of element `elem` of a prefix table, for a wave whose lanes hold consecutive elements: one binary search per wave on
+// the first lane's element (uniform operands: scalar loads), then every lane walks forward from there (jobs are thousands
+// of elements long, so the walk is 0 or 1 step) -- instead of a 13-step dependent chain of vector loads in every lane
+__device__ __forceinline__ int wave_uniform_i32(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ long long wave_uniform_i64(long long x) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x & 0xffffffffll)), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+template <typename T>
+__device__ __forceinline__ int find_job_wave(const T* __restrict__ prefix, int n, T elem) {
+  const T first = sizeof(T) == 8 ? (T)wave_uniform_i64((long long)elem) : (T)wave_uniform_i32((int)elem);   // lane 0 holds the smallest
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (prefix[mid] <= first) lo = mid; else hi = mid;
+  }
+  while (lo + 1 < n && prefix[lo + 1] <= elem) lo++;
   return lo;
 }
 
@@ -122,8 +145,8 @@ __global__ __launch_bounds__(256) void vp_support_kernel(DetectDeviceView v, Swe
   int j = 0;
   JobDesc jd{};
   int rp = 0, y = 0;
+  j = find_job_wave<int>(v.vp_prefix, v.n_jobs, on ? (int)e : vp_total - 1);
   if (on) {
-    j = find_job_i32(v.vp_prefix, v.n_jobs, (int)e);
     jd = v.jobs[j];
     int local = (int)e - jd.vp_off;
     rp = local / jd.Y; y = local - rp * jd.Y;
@@ -184,8 +207,8 @@ __global__ __launch_bounds__(64) void vp3_support_kernel(DetectDeviceView v, Swe
 // getVanishingPoints (object_3d_util.cpp:928-937) alone: the same arithmetic as the head of vp_support_kernel
 __global__ __launch_bounds__(256) void vp_points_kernel(DetectDeviceView v, int vp_total) {
   long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int j = find_job_wave<int>(v.vp_prefix, v.n_jobs, e < vp_total ? (int)e : vp_total - 1);
   if (e >= vp_total) return;
-  int j = find_job_i32(v.vp_prefix, v.n_jobs, (int)e);
   const JobDesc jd = v.jobs[j];
   int local = (int)e - jd.vp_off;
   int rp = local / jd.Y, y = local - rp * jd.Y;
@@ -207,34 +230,42 @@ __global__ __launch_bounds__(256) void vp_points_kernel(DetectDeviceView v, int 
 // ---- proposal geometry: one lane per slot -----------------------------------------------------------
 // The eight corners (box_proposal_detail.cpp:413-625).  ~70 % of the slots are rejected here, so scoring runs as a
 // second kernel over the compacted survivors (dense wavefronts) instead of inside this one.
+__device__ __forceinline__ int candidate_one(const DetectDeviceView& v, const SweepParams& sp, const JobDesc& jd, long long tid) {
+  // lane -> proposal: config-major inside the job so that a wave runs one configuration
+  // (a job's slot count fits 32 bits: checked when the batch is laid out)
+  const unsigned k = (unsigned)(tid - jd.slot_off);
+  const unsigned half = (unsigned)jd.RP * (unsigned)jd.Y * (unsigned)jd.T;
+  const int cfg = (k >= half) ? 2 : 1;
+  const unsigned rest = (k >= half) ? k - half : k;
+  const unsigned ryu = rest / (unsigned)jd.T;      // rp * Y + yaw
+  const int t = (int)(rest - ryu * (unsigned)jd.T);
+  const long long slot = jd.slot_off + (long long)rest * 2 + (cfg - 1);
+  const bool enabled = (cfg == 1) ? (sp.consider_config_1 != 0) : (sp.consider_config_2 != 0);
+  int flag = 0;
+  if (enabled) {
+    const double* vp = v.vp + 6 * (long long)(jd.vp_off + (int)ryu);
+    V2 c[8];
+    flag = build_corners(jd.g, v2(vp[0], vp[1]), v2(vp[2], vp[3]), v2(vp[4], vp[5]), (double)v.top_x[jd.top_off + t], cfg, sp.short_thre, c);
+    if (flag) {
+      double* co = v.corners + 16 * slot;
+#pragma unroll
+      for (int i = 0; i < 8; i++) { co[i] = c[i].x; co[8 + i] = c[i].y; }
+    }
+  }
+  v.flag[slot] = flag;
+  return flag;
+}
+
 __global__ __launch_bounds__(256) void candidate_kernel(DetectDeviceView v, SweepParams sp, long long slot_total) {
   long long tid = xcd_virtual_block() * blockDim.x + threadIdx.x;
   bool active = tid < slot_total;
   int flag = 0;
-  int j = 0;
-  if (active) {
-    j = find_job_i64(v.slot_prefix, v.n_jobs, tid);
-    const JobDesc jd = v.jobs[j];
-    // lane -> proposal: config-major inside the job so that a wave runs one configuration
-    long long k = tid - jd.slot_off;
-    long long half = (long long)jd.RP * jd.Y * jd.T;
-    int cfg = (k >= half) ? 2 : 1;
-    long long rest = (k >= half) ? k - half : k;
-    int t = (int)(rest % jd.T);
-    int ry = (int)(rest / jd.T);  // rp*Y + yaw
-    long long slot = jd.slot_off + rest * 2 + (cfg - 1);
-    bool enabled = (cfg == 1) ? (sp.consider_config_1 != 0) : (sp.consider_config_2 != 0);
-    if (enabled) {
-      const double* vp = v.vp + 6 * (long long)(jd.vp_off + ry);
-      V2 c[8];
-      flag = build_corners(jd.g, v2(vp[0], vp[1]), v2(vp[2], vp[3]), v2(vp[4], vp[5]), (double)v.top_x[jd.top_off + t], cfg, sp.short_thre, c);
-      if (flag) {
-        double* co = v.corners + 16 * slot;
-#pragma unroll
-        for (int i = 0; i < 8; i++) { co[i] = c[i].x; co[8 + i] = c[i].y; }
-      }
-    }
-    v.flag[slot] = flag;
+  int j = find_job_wave<long long>(v.slot_prefix, v.n_jobs, active ? tid : slot_total - 1);
+  const int ju = wave_uniform_i32(j);
+  if (__all(j == ju)) {          // the usual case: the job record is read once per wave (scalar loads), its fields live in SGPRs
+    if (active) flag = candidate_one(v, sp, v.jobs[ju], tid);
+  } else {
+    if (active) flag = candidate_one(v, sp, v.jobs[j], tid);
   }
   // per-job valid count: one atomic per (wave, job) run
   unsigned long long valid = __ballot(flag != 0);
@@ -262,7 +293,10 @@ __device__ __forceinline__ int sel(int cfg, int a, int b) { return cfg ? b : a; 
 
 enum { SCORE_JOBS = 4, SCORE_SUB = 128, SCORE_BINS = SCORE_JOBS * SCORE_SUB };   // sort keys of score_kernel: (job within the block, configuration x top sample)
 __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long long slot_total) {
-  __shared__ double CXt[8][256], CYt[8][256];   // [corner][lane]: lanes of a wave mostly ask for the same corner (sorted by configuration)
+  // [coordinate: x0..x7, y0..y7][lane]: lanes of a wave mostly ask for the same corner (sorted by configuration).  Row stride 260:
+  // the cooperative load below writes 16 coordinates x 4 proposals per wave, which then spread over all banks
+  __shared__ double C16[16][260];
+  double (*CXt)[260] = C16, (*CYt)[260] = C16 + 8;
   // the grid is sized for the worst case (every slot valid) because the exact count lives on the device; spread the
   // ACTIVE blocks over the 8 XCDs (contiguous range per XCD), the surplus blocks exit immediately
   const long long n_valid = v.job_cbase[v.n_jobs];
@@ -278,7 +312,7 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
   // almost the same pixels, so the block re-sorts its proposals by (job, configuration, top-edge sample) with a counting
   // sort in LDS and every lane takes the proposal at its sorted position; results go back to the proposal's own index.
   __shared__ int hist[SCORE_BINS + 1];
-  __shared__ int s_src[256], s_job[256];
+  __shared__ int s_src[256], s_job[256], s_flag[256];
   __shared__ long long s_slot[256];
   {
     const int t0 = threadIdx.x;
@@ -287,15 +321,16 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
     const long long i0 = base + t0;
     long long slot0 = 0;
     int j0 = 0;
-    if (i0 < n_valid) { slot0 = v.c_slot[i0]; j0 = find_job_i64(v.slot_prefix, v.n_jobs, slot0); }
-    s_slot[t0] = slot0; s_job[t0] = j0;
+    int flag0 = 0;
+    if (i0 < n_valid) { slot0 = v.c_slot[i0]; flag0 = v.c_flag[i0]; j0 = flag0 >> CAND_JOB_SHIFT; }
+    s_slot[t0] = slot0; s_job[t0] = j0; s_flag[t0] = flag0 & CAND_VP_MASK;
     __syncthreads();
     int key = SCORE_BINS;                       // beyond the list: sorted last, skipped below
     if (i0 < n_valid) {
       const int T0 = v.jobs[j0].T;
-      const long long loc = slot0 - v.jobs[j0].slot_off;
+      const unsigned loc = (unsigned)(slot0 - v.jobs[j0].slot_off);
       const int jrel = j0 - s_job[0];                                                // jobs in this block, in order
-      const int sub = (int)(loc & 1) * T0 + (int)((loc >> 1) % T0);                  // configuration-major, then top-edge sample
+      const int sub = CS_EXP == 8 ? (int)(loc & 1) : CS_EXP == 9 ? 0 : (int)(loc & 1) * T0 + (int)((loc >> 1) % (unsigned)T0);        // configuration-major, then top-edge sample
       key = (jrel < SCORE_JOBS && sub < SCORE_SUB) ? jrel * SCORE_SUB + sub : SCORE_BINS - 1;
     }
     const int rank = atomicAdd(&hist[key], 1);
@@ -316,49 +351,68 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
     s_src[hist[key] + rank] = t0;
     __syncthreads();
   }
+  if (CS_EXP == 4) { if (base + threadIdx.x < n_valid) v.c_angle[base + threadIdx.x] = s_src[threadIdx.x] + s_job[threadIdx.x]; return; }
+  // corners of the block's 256 proposals -> LDS.  A proposal's 16 doubles are one 128-byte line of the per-slot array: 16 lanes
+  // fetch one proposal (a wave instruction touches 4 lines, not 64 as it would with one proposal per lane)
+  {
+    const int k = threadIdx.x & 15;
+#pragma unroll 4
+    for (int it = 0; it < 16; it++) {
+      const int p = it * 16 + (threadIdx.x >> 4);
+      const int src = s_src[p];
+      if (base + src < n_valid) C16[k][p] = v.corners[16 * (CS_EXP == 7 ? base + src : s_slot[src]) + k];
+    }
+  }
+  __syncthreads();
   const int mine = s_src[threadIdx.x];
   const long long i = base + mine;
   if (i >= n_valid) return;                     // (no barrier below this point)
+  if (CS_EXP == 5 || CS_EXP == 7) { v.c_angle[i] = C16[3][threadIdx.x] + C16[12][threadIdx.x]; return; }
   const long long slot = s_slot[mine];
   const int j = s_job[mine];
   const JobDesc jd = v.jobs[j];
-  const long long local = slot - jd.slot_off;
+  const unsigned local = (unsigned)(slot - jd.slot_off);
   const int cfg = (int)(local & 1);          // 0 = configuration 1
-  const int ry = (int)((local >> 1) / jd.T);
-  const int rp = ry / jd.Y;
+  const int ry = (int)((local >> 1) / (unsigned)jd.T);
+  const int rp = (int)((unsigned)ry / (unsigned)jd.Y);
   const int tx = threadIdx.x;
-  {
-    const double* co = v.corners + 16 * slot;
-#pragma unroll
-    for (int q = 0; q < 8; q++) { CXt[q][tx] = co[q]; CYt[q][tx] = co[8 + q]; }
-  }
   const double ox = (double)jd.g.el, oy = (double)jd.g.et;
   const float* __restrict__ map = v.maps + jd.map_off;
   // ---- distance error: all gathers of an edge are issued before its (sequential, float) accumulation
   float sum_dist = 0;
   // corner ids of the 9 edges, one nibble each (edge 0 lowest): {0,1,2,3,1,2,3,4,4}-{1,2,3,0,5,4,7,7,5} / {0,1,2,3,1,2,4,0,0}-{1,2,3,0,5,4,5,0,0}
   const unsigned long long EA = cfg ? 0x004213210ull : 0x443213210ull, EB = cfg ? 0x005450321ull : 0x577450321ull;
+  // config 2 reweights edges 4, 5 by 3/2 and edge 6 by 2 (:655-661), one weight nibble per edge in halves.  The reference
+  // computes float(double(d) * 3.0 / 2.0) and float(double(d) * 2.0): both products are exact in double, so the one rounding
+  // to float is the rounding of the float product d * 1.5f (d * 2.0f), and d * 1.0f is d.
+  const unsigned long long EW = cfg ? 0x004332222ull : 0x222222222ull;
+  const int n_edges = cfg ? 7 : 9;
+  const int map_w = jd.map_w;
+  constexpr int EU = CS_EXP == 11 ? 9 : CS_EXP == 12 ? 1 : 3;   // edges per trip: their 11 * EU gathers are in flight together
 #pragma unroll 1
-  for (int e = 0; e < 9; e++) {
-    const bool on = (e < 7) || (cfg == 0);
-    const int a = (int)((EA >> (4 * e)) & 7), b = (int)((EB >> (4 * e)) & 7);
-    const double x1 = CXt[a][tx] - ox, y1 = CYt[a][tx] - oy, x2 = CXt[b][tx] - ox, y2 = CYt[b][tx] - oy;
-    float dv[11];
+  for (int e0 = 0; e0 < ((CS_EXP == 1 || CS_EXP == 6) ? 0 : n_edges); e0 += EU) {
+    float dv[EU][11];
 #pragma unroll
-    for (int s = 0; s < 11; s++) {
-      double w = (double)s / 10.0;
-      double sx = w * x1 + (1 - w) * x2;
-      double sy = w * y1 + (1 - w) * y2;
-      dv[s] = on ? map[(long long)(int)sy * jd.map_w + (int)sx] : 0.0f;
+    for (int u = 0; u < EU; u++) {
+      const int e = e0 + u;                    // (beyond the list: nibble 0 = corner 1, a valid address; the sum skips it)
+      const int a = (int)((EA >> (4 * e)) & 7), b = (int)((EB >> (4 * e)) & 7);
+      const double x1 = CXt[a][tx] - ox, y1 = CYt[a][tx] - oy, x2 = CXt[b][tx] - ox, y2 = CYt[b][tx] - oy;
+#pragma unroll
+      for (int s = 0; s < 11; s++) {
+        double w = (double)s / 10.0;
+        double sx = w * x1 + (1 - w) * x2;
+        double sy = w * y1 + (1 - w) * y2;
+        // samples lie inside the ROI the map covers (corners were tested against it): row * width + column fits 24 x 24 -> 32 bits
+        dv[u][s] = map[(unsigned)(__mul24((int)sy, map_w) + (int)sx)];
+      }
     }
-    // config 2 reweights edges 4, 5 by 3/2 and edge 6 by 2 (:655-661); x * 3.0 / 2.0 == (x * 3.0) * 0.5 exactly
-    const bool w32 = cfg && (e == 4 || e == 5), w2 = cfg && (e == 6);
 #pragma unroll
-    for (int s = 0; s < 11; s++) {
-      float d1 = dv[s];
-      if (w32) d1 = (float)((double)d1 * 3.0 * 0.5);
-      if (w2) d1 = (float)((double)d1 * 2.0);
-      if (on) sum_dist = sum_dist + d1;
+    for (int u = 0; u < EU; u++) {
+      const int e = e0 + u;
+      const float wt = 0.5f * (float)(int)((EW >> (4 * e)) & 7);
+      const bool on = e < n_edges;
+#pragma unroll
+      for (int s = 0; s < 11; s++) { const float nx = sum_dist + dv[u][s] * wt; sum_dist = on ? nx : sum_dist; }
     }
   }
   // ---- angle alignment error
@@ -367,7 +421,7 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
   const double not_found_penalty = 30.0 / 180.0 * CS_PI * 2;
   const int ID1[3][4] = {{0, 1, 7, 4}, {3, 0, 4, 5}, {3, 7, 1, 5}}, ID2[3][4] = {{0, 1, 2, 3}, {3, 0, 4, 5}, {2, 4, 1, 5}};
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
+  for (int k = 0; k < ((CS_EXP == 2 || CS_EXP == 6) ? 0 : 3); k++) {
     double b0 = bound[2 * k], b1 = bound[2 * k + 1];
     bool v0 = !(b0 != b0), v1 = !(b1 != b1);
     if (v0 || v1) {
@@ -390,8 +444,9 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
   for (int q = 0; q < 8; q++) c[q] = v2(CXt[q][tx], CYt[q][tx]);
   const RpPose* pose = v.rp + jd.rp_off + rp;
   double p3[3], s3[3];
+  if (CS_EXP == 3 || CS_EXP == 6) { s3[0] = c[0].x; s3[1] = c[1].y; s3[2] = c[2].x; } else
   lift_to_3d(c, pose->R, pose->t, v.invK + 9 * jd.frame, pose->plane, p3, s3);
-  int flag = v.c_flag[i];
+  int flag = s_flag[mine];
   if (s3[0] < 0 || s3[1] < 0 || s3[2] < 0) flag |= CAND_NEG_SCALE;
   v.c_flag[i] = flag;
   v.c_dist[i] = (double)sum_dist / jd.diag;
@@ -449,7 +504,7 @@ __global__ __launch_bounds__(256) void compact_kernel(DetectDeviceView v) {
     if (f != 0) {
       long long pos = off + __popcll(b & ((1ull << lane) - 1ull));
       v.c_slot[pos] = s;
-      v.c_flag[pos] = f;
+      v.c_flag[pos] = f | (j << CAND_JOB_SHIFT);
     }
     __syncthreads();
     if (threadIdx.x == 0) run_s = off + wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];

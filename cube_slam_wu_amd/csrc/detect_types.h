@@ -36,7 +36,9 @@ struct SweepParams {
 
 // Candidate flag bits (one int per slot): low 2 bits = vp_1_position (0 = rejected), bit 2 = a
 // negative half size after the 3D lift (the reference drops those only after normalisation, :766).
-enum { CAND_VP_MASK = 3, CAND_NEG_SCALE = 4 };
+// Between compact_kernel and score_kernel the bits from CAND_JOB_SHIFT up carry the proposal's job index (score_kernel needs it
+// for every lane and would otherwise search slot_prefix); score_kernel strips them again.
+enum { CAND_VP_MASK = 3, CAND_NEG_SCALE = 4, CAND_JOB_SHIFT = 3 };
 
 struct DetectDeviceView {
   const JobDesc* jobs;
