@@ -16,6 +16,11 @@ CS_HD double v2_dist(V2 a, V2 b) {
   double dx = a.x - b.x, dy = a.y - b.y;
   return __builtin_sqrt(dx * dx + dy * dy);
 }
+// squared distance, the argument of v2_dist's square root
+CS_HD double v2_dist2(V2 a, V2 b) {
+  double dx = a.x - b.x, dy = a.y - b.y;
+  return dx * dx + dy * dy;
+}
 CS_HD double dmin(double a, double b) { return (b < a) ? b : a; }  // std::min
 CS_HD double dmax(double a, double b) { return (a < b) ? b : a; }  // std::max
 CS_HD double dabs(double a) { return __builtin_fabs(a); }
@@ -89,7 +94,10 @@ struct BoxGeom {
 
 // The eight 2D corners of one proposal (box_proposal_detail.cpp:413-625).
 // Returns 0 when the proposal is rejected, else vp_1_position (1 = left, 2 = right).
-CS_HD int build_corners(const BoxGeom& g, V2 vp1, V2 vp2, V2 vp3, double top_x, int config_id, double short_thre, V2 c[8]) {
+// The reference rejects edges with sqrt(dx^2 + dy^2) < shorted_edge_thre.  The IEEE square root is monotone, so that test is
+// d2 < short_sq_bound with short_sq_bound = the smallest double whose rounded square root reaches the threshold (computed once
+// on the host, sqrt_lt_bound() in detect_host.cpp): the same decision for every d2 including NaN / inf, without the 13 roots.
+CS_HD int build_corners(const BoxGeom& g, V2 vp1, V2 vp2, V2 vp3, double top_x, int config_id, double short_sq_bound, V2 c[8]) {
   V2 c1 = v2(top_x, (double)g.top);
   int vp1_pos = 0;
   V2 c2 = ray_hit_vertical(vp1, c1, (double)g.right, (double)g.top, (double)g.down);
@@ -100,37 +108,37 @@ CS_HD int build_corners(const BoxGeom& g, V2 vp1, V2 vp2, V2 vp3, double top_x, 
     vp1_pos = 1;
   }
   if (!(vp1_pos > 0)) return 0;
-  if (v2_dist(c1, c2) < short_thre) return 0;
+  if (v2_dist2(c1, c2) < short_sq_bound) return 0;
   V2 c3, c4;
   if (config_id == 1) {
     if (vp1_pos == 1) c4 = ray_hit_vertical(vp2, c1, (double)g.left, (double)g.top, (double)g.down);
     else c4 = ray_hit_vertical(vp2, c1, (double)g.right, (double)g.top, (double)g.down);
     if (c4.y == -1) return 0;
-    if (v2_dist(c1, c4) < short_thre) return 0;
+    if (v2_dist2(c1, c4) < short_sq_bound) return 0;
     c3 = line_intersect(vp2, c2, vp1, c4);
     if (!inside_box(c3, g.left, g.top, g.right, g.down)) return 0;
-    if ((v2_dist(c3, c4) < short_thre) || (v2_dist(c3, c2) < short_thre)) return 0;
+    if ((v2_dist2(c3, c4) < short_sq_bound) || (v2_dist2(c3, c2) < short_sq_bound)) return 0;
   } else {
     if (vp1_pos == 1) c3 = ray_hit_vertical(vp2, c2, (double)g.left, (double)g.top, (double)g.down);
     else c3 = ray_hit_vertical(vp2, c2, (double)g.right, (double)g.top, (double)g.down);
     if (c3.y == -1) return 0;
-    if (v2_dist(c2, c3) < short_thre) return 0;
+    if (v2_dist2(c2, c3) < short_sq_bound) return 0;
     c4 = line_intersect(vp1, c3, vp2, c1);
     if (!inside_box(c4, g.left, g.et, g.right, g.eb)) return 0;  // raw x bounds, expanded y bounds (:558)
-    if ((v2_dist(c3, c4) < short_thre) || (v2_dist(c4, c1) < short_thre)) return 0;
+    if ((v2_dist2(c3, c4) < short_sq_bound) || (v2_dist2(c4, c1) < short_sq_bound)) return 0;
   }
   V2 c5 = ray_hit_horizontal(vp3, c3, (double)g.down, (double)g.left, (double)g.right);
   if (c5.y == -1) return 0;
-  if (v2_dist(c3, c5) < short_thre) return 0;
+  if (v2_dist2(c3, c5) < short_sq_bound) return 0;
   V2 c6 = line_intersect(vp2, c5, vp3, c2);
   if (!inside_box(c6, g.el, g.et, g.er, g.eb)) return 0;
-  if ((v2_dist(c6, c2) < short_thre) || (v2_dist(c6, c5) < short_thre)) return 0;
+  if ((v2_dist2(c6, c2) < short_sq_bound) || (v2_dist2(c6, c5) < short_sq_bound)) return 0;
   V2 c7 = line_intersect(vp1, c6, vp3, c1);
   if (!inside_box(c7, g.el, g.et, g.er, g.eb)) return 0;
-  if ((v2_dist(c7, c1) < short_thre) || (v2_dist(c7, c6) < short_thre)) return 0;
+  if ((v2_dist2(c7, c1) < short_sq_bound) || (v2_dist2(c7, c6) < short_sq_bound)) return 0;
   V2 c8 = line_intersect(vp1, c5, vp2, c7);
   if (!inside_box(c8, g.el, g.et, g.er, g.eb)) return 0;
-  if ((v2_dist(c8, c4) < short_thre) || (v2_dist(c8, c5) < short_thre) || (v2_dist(c8, c7) < short_thre)) return 0;
+  if ((v2_dist2(c8, c4) < short_sq_bound) || (v2_dist2(c8, c5) < short_sq_bound) || (v2_dist2(c8, c7) < short_sq_bound)) return 0;
   c[0] = c1; c[1] = c2; c[2] = c3; c[3] = c4; c[4] = c5; c[5] = c6; c[6] = c7; c[7] = c8;
   return vp1_pos;
 }

@@ -26,6 +26,7 @@
 #include <mutex>
 #include <chrono>
 #include <cmath>
+#include <limits>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -72,6 +73,18 @@ void set_err(const std::string& s) { g_cs_err = s; }
       return CS_ERR_HIP;                                                                      \
     }                                                                                         \
   } while (0)
+
+// The smallest double x with sqrt(x) >= t (IEEE square root, correctly rounded and monotone): sqrt(x) < t <=> x < sqrt_lt_bound(t).
+// t <= 0 or NaN: sqrt(x) < t never holds, and x < 0 never holds for a sum of squares.
+double sqrt_lt_bound(double t) {
+  if (!(t > 0)) return 0.0;
+  if (std::isinf(t)) return t;                         // sqrt(x) < inf <=> x < inf
+  double c = t * t;
+  if (std::isinf(c)) c = std::numeric_limits<double>::max();
+  while (c > 0 && std::sqrt(c) >= t) c = std::nextafter(c, 0.0);
+  while (std::sqrt(c) < t) { const double up = std::nextafter(c, std::numeric_limits<double>::infinity()); if (std::isinf(up)) return up; c = up; }
+  return c;
+}
 
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -941,7 +954,7 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
       cs::JobDesc& jd = S.h_jobs_in.p[j];
       jd.slot_off = so; jd.vp_off = (int)vo;
       S.h_slot_prefix.p[j] = so; S.h_vp_prefix.p[j] = (int)vo;
-      so += (long long)jd.Y * jd.T * 2; vo += jd.Y;
+      so += (long long)jd.Y * jd.T * 2; vo += (jd.Y + 63) & ~63;   // whole waves per job: a wave of the VP kernels then reads one job (scalar loads)
       if (jd.hid == 0 && jd.Y > 0 && jd.T > 0) { S.h_box_job0.p[nb] = (int)j; S.h_box_njobs.p[nb] = b->frames[jd.frame].n_heights[jd.box]; nb++; }
     }
     S.h_slot_prefix.p[nj] = so; S.h_vp_prefix.p[nj] = (int)vo;
@@ -1233,6 +1246,7 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
   sp.vp12_thre_rad = P.vp12_edge_angle_thre / 180.0 * CS_PI;
   sp.vp3_thre_rad = P.vp3_edge_angle_thre / 180.0 * CS_PI;
   sp.short_thre = P.shorted_edge_thre;
+  sp.short_sq_bound = sqrt_lt_bound(P.shorted_edge_thre);
   sp.consider_config_1 = P.consider_config_1; sp.consider_config_2 = P.consider_config_2;
 
   // ---- per-frame camera caches: raw pose and the roll/pitch sample poses (:78-79, :344-355, :368-377)

@@ -71,65 +71,195 @@ __device__ __forceinline__ long long xcd_virtual_block() {
 }
 
 // VP_support_edge_infos (object_3d_util.cpp:548-619) for ONE vanishing point: sequential over the job's merged lines.
-// Only inliers (a few percent of the segments) need the exact angle.  Per chunk of 64 segments: (1) a float
-// approximation of atan2 (|error| < 2e-6 rad, checked in tests/test_detect_oracle.py) marks every segment that is
-// not certainly an outlier -- "certainly" = further than 1e-4 rad from the threshold and from the +-pi/2 fold of
-// normalize_to_pi; (2) the marked ones are evaluated exactly, in order.  The wave runs the expensive cs_atan2
-// only max-over-lanes(marked) times instead of m times, and every decision is the exact one.
+//
+// The reference evaluates atan2 for every segment, keeps those whose direction is within `thre` of the segment's own angle,
+// unwraps the kept angles against the first one (smooth_jump_angles, :278-302) and returns the segment angles at the arg-max and
+// arg-min.  Only DECISIONS leave this function (which segments are inliers, which one is the extreme), so the angles are
+// evaluated in float (|error| < 2.5e-6 rad over all quadrants, tests/test_vp_float_atan.py) and every decision that falls
+// within a margin of its threshold -- a few per million -- is re-decided with the exact cs_atan2 values of the segments
+// involved.  Error budget of a float angle: conversion of the double differences 1e-7, quotient (__fdividef) 3e-7, polynomial
+// 2e-6, pi constants and the +-2 pi shift 7e-7; of a difference of two of them twice that.  Margins: 1e-5 on the inlier test,
+// 2e-5 on the unwrap decision and on the comparisons against the running extremes.  Each decision therefore equals the
+// reference's, including ties (equal angles keep the first occurrence, :609-614 maxCoeff / minCoeff).
 // out[0], out[1] = the two bounding segment angles (NaN = none): (max, min) for vp 1, swapped for vp 2, 3 (:609-614).
-__device__ __forceinline__ void vp_support_one(const double* __restrict__ mx, const double* __restrict__ my, const double* __restrict__ la, int m, double vpxk, double vpyk,
-                                               double thre, bool swapped, bool lane_on, double* out) {
-  const double NaN = __builtin_nan("");
-  bool have = false;
-  double base = 0, best_hi = 0, best_lo = 0, ang_hi = NaN, ang_lo = NaN;
-  const int mm = lane_on ? m : 0;
-  for (int i0 = 0; __any(i0 < mm); i0 += 64) {
-    unsigned long long mask = 0;
-    const int i1 = min(mm, i0 + 64);
-    for (int i = i0; i < i1; i++) {
-      float fy = (float)(my[i] - vpyk), fx = (float)(mx[i] - vpxk);
-      float ay = fabsf(fy), ax = fabsf(fx);
-      float hi = fmaxf(ax, ay), lo = fminf(ax, ay);
-      bool maybe = true;
-      if (hi > 0.0f && hi < 3.0e38f) {  // finite, non-degenerate; anything else goes to the exact evaluation
-        float q = lo / hi, q2 = q * q;
-        float at = q * (0.99997726f + q2 * (-0.33262347f + q2 * (0.19354346f + q2 * (-0.11643287f + q2 * (0.05265332f + q2 * -0.01172120f)))));
-        if (ay > ax) at = 1.57079637f - at;
-        if (fx < 0.0f) at = 3.14159274f - at;
-        if (fy < 0.0f) at = -at;
-        const float fold = fabsf(fabsf(at) - 1.57079637f);
-        float nr = at;
-        if (at > 1.57079637f) nr = at - 3.14159274f; else if (at < -1.57079637f) nr = at + 3.14159274f;
-        float df = fabsf((float)la[i] - nr);
-        df = fminf(df, 3.14159274f - df);
-        maybe = !(fold > 1.0e-4f && df > (float)thre + 1.0e-4f);
+__device__ __attribute__((noinline)) double vp_exact_raw(double dy, double dx) { return cs_atan2(dy, dx); }
+
+// exact unwrapped angle of segment i against the first inlier `ib` (both re-evaluated: this runs a few times per million segments)
+__device__ __forceinline__ double vp_exact_unwrapped(const double* __restrict__ mx, const double* __restrict__ my, int i, int ib, double vpxk, double vpyk) {
+  const double raw = vp_exact_raw(my[i] - vpyk, mx[i] - vpxk);
+  if (i == ib) return raw;
+  const double base = vp_exact_raw(my[ib] - vpyk, mx[ib] - vpxk);
+  if ((raw - base) < -CS_PI) return raw + 2 * CS_PI;
+  if ((raw - base) > CS_PI) return raw - 2 * CS_PI;
+  return raw;
+}
+// the rarely taken exact decisions, out of line so that the sweep's loop body stays small
+__device__ __attribute__((noinline)) float vp_rare_unwrapped_f(const double* mx, const double* my, int i, int ib, double vpxk, double vpyk) {
+  return (float)vp_exact_unwrapped(mx, my, i, ib, vpxk, vpyk);
+}
+__device__ __attribute__((noinline)) bool vp_rare_greater(const double* mx, const double* my, int i, int i_ref, int ib, double vpxk, double vpyk) {
+  return vp_exact_unwrapped(mx, my, i, ib, vpxk, vpyk) > vp_exact_unwrapped(mx, my, i_ref, ib, vpxk, vpyk);
+}
+__device__ __attribute__((noinline)) bool vp_rare_less(const double* mx, const double* my, int i, int i_ref, int ib, double vpxk, double vpyk) {
+  return vp_exact_unwrapped(mx, my, i, ib, vpxk, vpyk) < vp_exact_unwrapped(mx, my, i_ref, ib, vpxk, vpyk);
+}
+// exact inlier test of one segment, with its angle as a float (returned by value: a callee that stores through a pointer would
+// make the compiler assume the segment arrays may change, and their loads could no longer be scalar)
+struct VpExactInlier { float at; int inl; };
+__device__ __attribute__((noinline)) VpExactInlier vp_rare_inlier(double dyd, double dxd, double lai, double thre) {
+  const double raw = cs_atan2(dyd, dxd);
+  const double nrm = normalize_to_pi(raw);
+  double d = dabs(lai - nrm);
+  d = dmin(d, CS_PI - d);
+  return VpExactInlier{(float)raw, d < thre ? 1 : 0};
+}
+
+struct VpRun {               // running state of one vanishing point's sweep over the segments
+  bool have;
+  int ib, i_hi, i_lo;        // first inlier, running arg-max / arg-min of the unwrapped angle
+  float base_f, hi_f, lo_f;  // their float angles
+  double hx, hy, lx, ly;     // mid point - vanishing point of the two running extremes
+};
+
+// one segment (mid point mxi, myi; angle lai) against one vanishing point
+__device__ __forceinline__ void vp_step(const double* __restrict__ mx, const double* __restrict__ my, int i, double mxi, double myi, double lai,
+                                        double vpxk, double vpyk, double thre, float thre_f, VpRun& R) {
+  const float PI_F = 3.14159274f, HPI_F = 1.57079637f, M_IN = 1.0e-5f, M_ORD = 2.0e-5f;
+  const double dyd = myi - vpyk, dxd = mxi - vpxk;
+  const float fy = (float)dyd, fx = (float)dxd;
+  const float ay = fabsf(fy), ax = fabsf(fx);
+  const float hi = fmaxf(ax, ay), lo = fminf(ax, ay);
+  const float q = lo * __builtin_amdgcn_rcpf(hi), q2 = q * q;
+  float at = -0.01172120f;
+  at = __builtin_fmaf(at, q2, 0.05265332f);
+  at = __builtin_fmaf(at, q2, -0.11643287f);
+  at = __builtin_fmaf(at, q2, 0.19354346f);
+  at = __builtin_fmaf(at, q2, -0.33262347f);
+  at = __builtin_fmaf(at, q2, 0.99997726f);
+  at = at * q;
+  if (ay > ax) at = HPI_F - at;
+  if (fx < 0.0f) at = PI_F - at;
+  if (fy < 0.0f) at = -at;
+  float nr = at;                           // normalize_to_pi: the distance below is circular, so which side of the fold a float lands on does not matter
+  if (at > HPI_F) nr = at - PI_F; else if (at < -HPI_F) nr = at + PI_F;
+  float df = fabsf((float)lai - nr);
+  df = fminf(df, PI_F - df);
+  const bool usable = hi > 0.0f && hi < 3.0e38f;       // finite and non-degenerate; anything else is decided exactly
+  bool inl = usable && df < thre_f - M_IN;
+  if (!(inl || (usable && df > thre_f + M_IN))) { const VpExactInlier x = vp_rare_inlier(dyd, dxd, lai, thre); inl = x.inl != 0; at = x.at; }
+  if (inl) {
+    if (!R.have) {  // first inlier: base of smooth_jump_angles (:278-302), and initial arg-max / arg-min
+      R.have = true; R.ib = i; R.i_hi = i; R.i_lo = i; R.base_f = at; R.hi_f = at; R.lo_f = at; R.hx = dxd; R.hy = dyd; R.lx = dxd; R.ly = dyd;
+    } else {
+      const float d = at - R.base_f;
+      float sh = d < -PI_F ? at + 2.0f * PI_F : d > PI_F ? at - 2.0f * PI_F : at;
+      if (fabsf(fabsf(d) - PI_F) < M_ORD) sh = vp_rare_unwrapped_f(mx, my, i, R.ib, vpxk, vpyk);
+      // Against the running extremes.  Far vanishing points see all segments within a fraction of a milliradian, closer than the
+      // float angles resolve; inside the margin the order comes from the cross product of the two (double) difference vectors:
+      // its sign is the order of the true angles (both unwrapped angles lie within the margin of each other, far from the
+      // +-pi fold), reliable when it exceeds its rounding error -- 1e-12 of the product of the 1-norms, i.e. an angle
+      // difference above 1e-12 rad, thousands of ulps of the rounded atan2 values.  Below that (equal or nearly equal
+      // directions): the exact values decide, including the tie rule.
+      if (sh > R.hi_f + M_ORD) { R.hi_f = sh; R.i_hi = i; R.hx = dxd; R.hy = dyd; }                 // maxCoeff: first occurrence, strict
+      else if (sh > R.hi_f - M_ORD) {
+        const double c = R.hx * dyd - R.hy * dxd, lim = 1.0e-12 * ((dabs(dxd) + dabs(dyd)) * (dabs(R.hx) + dabs(R.hy)));
+        const bool greater = c > lim ? true : c < -lim ? false : vp_rare_greater(mx, my, i, R.i_hi, R.ib, vpxk, vpyk);
+        if (greater) { R.hi_f = sh; R.i_hi = i; R.hx = dxd; R.hy = dyd; }
       }
-      if (maybe) mask |= 1ull << (i - i0);
+      if (sh < R.lo_f - M_ORD) { R.lo_f = sh; R.i_lo = i; R.lx = dxd; R.ly = dyd; }                 // minCoeff
+      else if (sh < R.lo_f + M_ORD) {
+        const double c = R.lx * dyd - R.ly * dxd, lim = 1.0e-12 * ((dabs(dxd) + dabs(dyd)) * (dabs(R.lx) + dabs(R.ly)));
+        const bool less = c < -lim ? true : c > lim ? false : vp_rare_less(mx, my, i, R.i_lo, R.ib, vpxk, vpyk);
+        if (less) { R.lo_f = sh; R.i_lo = i; R.lx = dxd; R.ly = dyd; }
+      }
     }
-    while (__any(mask != 0)) {
-      if (mask != 0) {
-        const int i = i0 + __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        double raw = cs_atan2(my[i] - vpyk, mx[i] - vpxk);
-        double nrm = normalize_to_pi(raw);
-        double df = dabs(la[i] - nrm);
-        df = dmin(df, CS_PI - df);
-        if (df < thre) {
-          if (!have) {  // first inlier: base of smooth_jump_angles (:278-302), and initial arg-max / arg-min
-            have = true; base = raw; best_hi = raw; best_lo = raw; ang_hi = la[i]; ang_lo = la[i];
-          } else {
-            double sh = raw;
-            if ((raw - base) < -CS_PI) sh = raw + 2 * CS_PI;
-            else if ((raw - base) > CS_PI) sh = raw - 2 * CS_PI;
-            if (sh > best_hi) { best_hi = sh; ang_hi = la[i]; }  // maxCoeff: first occurrence, strict
-            if (sh < best_lo) { best_lo = sh; ang_lo = la[i]; }  // minCoeff
+  }
+}
+
+// One wave's staging area for a chunk of 64 segments (the wave sits inside one job: every lane sweeps the same segments).
+struct VpChunk {
+  double2 xy[64];   // mid point
+  double ang[64];   // segment angle
+  float2 dir[64];   // unit direction (cosf, sinf: 2 ulp)
+};
+
+// K vanishing points swept together over the job's segments, 64 segments per chunk.
+//   staging: lane u loads segment u of the chunk (one coalesced load per array) and its direction into LDS; both passes read
+//     from there (pass 1: every lane the same address = broadcast; pass 2: a gather), not from global memory.
+//   pass 1 (every segment, branch-free, ~10 instructions per vanishing point): drop what is certainly not an inlier.  With u the
+//     segment's unit direction and d = mid point - vanishing point, the circular angle between them is below thre exactly
+//     when |u x d| < tan(thre) |u . d|; in float, with thre widened by 1e-4 rad and 2e-6 (|dx| + |dy|) of slack for the
+//     roundings (error budget: direction 3e-7 rad, each product / sum 6e-8 relative), no true inlier fails the test.
+//     The survivors (about a fifth of the segments) are a bit mask per lane.
+//   pass 2 (survivors, in order): vp_step -- float angle, the inlier decision, the running extremes, exact where a margin is hit.
+// UNIFORM = false (a wave that spans jobs; only the round-based path produces those): no staging, every segment goes to vp_step.
+// out[2k], out[2k+1] = the two bounding segment angles of vanishing point k (NaN = none): (max, min) when !swapped[k], else (min, max) (:609-614)
+template <int K, bool UNIFORM>
+__device__ __forceinline__ void vp_support_multi(const double* __restrict__ mx, const double* __restrict__ my, const double* __restrict__ la, int m, VpChunk* ch,
+                                                 const double* vpx, const double* vpy, const double* thre, const bool* swapped, bool lane_on, double* out) {
+  VpRun R[K];
+  float thre_f[K], tan_f[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    R[k] = VpRun{false, 0, 0, 0, 0.f, 0.f, 0.f, 0., 0., 0., 0.}; thre_f[k] = (float)thre[k];
+    tan_f[k] = thre_f[k] < 1.5f ? tanf(thre_f[k] + 1.0e-4f) : __builtin_huge_valf();      // (a threshold near 90 degrees keeps everything)
+  }
+  if (UNIFORM) {
+    const int lane = threadIdx.x & 63;
+    for (int c0 = 0; c0 < m; c0 += 64) {
+      const int n = min(64, m - c0);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the previous chunk's readers are done (one wave, program order)
+      if (lane < n) {
+        const double a = la[c0 + lane];
+        ch->xy[lane] = make_double2(mx[c0 + lane], my[c0 + lane]);
+        ch->ang[lane] = a;
+        ch->dir[lane] = make_float2(cosf((float)a), sinf((float)a));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      unsigned long long mask[K];
+#pragma unroll
+      for (int k = 0; k < K; k++) mask[k] = 0;
+#pragma unroll 4
+      for (int u = 0; u < n; u++) {
+        const double2 P = ch->xy[u];
+        const float2 ud = ch->dir[u];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+          const float fx = (float)(P.x - vpx[k]), fy = (float)(P.y - vpy[k]);
+          const float cr = fabsf(__builtin_fmaf(fx, ud.y, -(fy * ud.x))), dt = fabsf(__builtin_fmaf(fx, ud.x, fy * ud.y));
+          const bool out_for_sure = cr > __builtin_fmaf(tan_f[k], dt, 2.0e-6f * (fabsf(fx) + fabsf(fy)));      // (false for NaN / inf: those go on)
+          mask[k] |= (unsigned long long)(out_for_sure ? 0 : 1) << u;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        unsigned long long mk = lane_on ? mask[k] : 0ull;
+        while (__any(mk != 0)) {
+          if (mk != 0) {
+            const int u = __ffsll((long long)mk) - 1;
+            mk &= mk - 1;
+            const double2 P = ch->xy[u];
+            vp_step(mx, my, c0 + u, P.x, P.y, ch->ang[u], vpx[k], vpy[k], thre[k], thre_f[k], R[k]);
           }
         }
       }
     }
+  } else {
+    const int mm = lane_on ? m : 0;
+    for (int i = 0; i < mm; i++) {
+      const double X = mx[i], Y = my[i], A = la[i];
+#pragma unroll
+      for (int k = 0; k < K; k++) vp_step(mx, my, i, X, Y, A, vpx[k], vpy[k], thre[k], thre_f[k], R[k]);
+    }
   }
-  out[0] = swapped ? ang_lo : ang_hi;
-  out[1] = swapped ? ang_hi : ang_lo;
+  const double NaN = __builtin_nan("");
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const double ang_hi = R[k].have ? la[R[k].i_hi] : NaN, ang_lo = R[k].have ? la[R[k].i_lo] : NaN;
+    out[2 * k] = swapped[k] ? ang_lo : ang_hi;
+    out[2 * k + 1] = swapped[k] ? ang_hi : ang_lo;
+  }
 }
 
 enum { VP3_RPCAP = 32 };   // slots of the per-(job, roll/pitch sample) table of the third vanishing point's support angles
@@ -138,17 +268,12 @@ enum { VP3_RPCAP = 32 };   // slots of the per-(job, roll/pitch sample) table of
 // MODE 1: the lean path -- the vanishing points are produced by vp_points_kernel on another stream (they do not depend on
 // the segments, so the corner construction runs beside line setup + VP support), and the support of the third
 // (vertical) vanishing point, which does not depend on the yaw sample, comes from vp3_support_kernel's table.
-template <int MODE>
-__global__ __launch_bounds__(256) void vp_support_kernel(DetectDeviceView v, SweepParams sp, int vp_total) {
-  long long e = xcd_virtual_block() * blockDim.x + threadIdx.x;
-  const bool on = e < vp_total;
-  int j = 0;
-  JobDesc jd{};
+template <int MODE, bool UNIFORM>
+__device__ __forceinline__ void vp_support_body(const DetectDeviceView& v, const SweepParams& sp, const JobDesc& jd, int j, long long e, bool on, VpChunk* ch) {
   int rp = 0, y = 0;
-  j = find_job_wave<int>(v.vp_prefix, v.n_jobs, on ? (int)e : vp_total - 1);
   if (on) {
-    jd = v.jobs[j];
     int local = (int)e - jd.vp_off;
+    on = local < jd.RP * jd.Y;             // (the lean path pads a job's entries to whole waves)
     rp = local / jd.Y; y = local - rp * jd.Y;
   }
   double vpx[3] = {0, 0, 0}, vpy[3] = {0, 0, 0};
@@ -175,13 +300,25 @@ __global__ __launch_bounds__(256) void vp_support_kernel(DetectDeviceView v, Swe
   const double* my = v.mid_y + jd.line_off;
   const double* la = v.line_angle + jd.line_off;
   double b6[6];
-#pragma unroll
-  for (int k = 0; k < (MODE == 0 ? 3 : 2); k++) vp_support_one(mx, my, la, jd.m, vpx[k], vpy[k], (k != 2) ? sp.vp12_thre_rad : sp.vp3_thre_rad, k > 0, on, b6 + 2 * k);
+  const double thre[3] = {sp.vp12_thre_rad, sp.vp12_thre_rad, sp.vp3_thre_rad};
+  const bool swapped[3] = {false, true, true};
+  vp_support_multi<(MODE == 0 ? 3 : 2), UNIFORM>(mx, my, la, jd.m, ch, vpx, vpy, thre, swapped, on, b6);
   if (!on) return;
   if (MODE == 1) { const double* t3 = v.bound3 + 2 * ((size_t)j * VP3_RPCAP + rp); b6[4] = t3[0]; b6[5] = t3[1]; }
   double* bout = v.bound + 6 * e;
 #pragma unroll
   for (int q = 0; q < 6; q++) bout[q] = b6[q];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void vp_support_kernel(DetectDeviceView v, SweepParams sp, int vp_total) {
+  long long e = xcd_virtual_block() * blockDim.x + threadIdx.x;
+  const bool on = e < vp_total;
+  const int j = find_job_wave<int>(v.vp_prefix, v.n_jobs, on ? (int)e : vp_total - 1);
+  const int ju = wave_uniform_i32(j);
+  __shared__ VpChunk chunk[4];
+  if (__all(j == ju)) vp_support_body<MODE, true>(v, sp, v.jobs[ju], ju, e, on, &chunk[threadIdx.x >> 6]);
+  else vp_support_body<MODE, false>(v, sp, v.jobs[j], j, e, on, nullptr);
 }
 
 // support angles of the third vanishing point, K R^-1 (0, 0, 1): one lane per (job, roll/pitch sample)
@@ -200,7 +337,8 @@ __global__ __launch_bounds__(64) void vp3_support_kernel(DetectDeviceView v, Swe
     vx = h0 / h2; vy = h1 / h2;
   }
   double o2[2];
-  vp_support_one(v.mid_x + jd.line_off, v.mid_y + jd.line_off, v.line_angle + jd.line_off, jd.m, vx, vy, sp.vp3_thre_rad, true, on, o2);
+  const bool swapped3 = true;
+  vp_support_multi<1, false>(v.mid_x + jd.line_off, v.mid_y + jd.line_off, v.line_angle + jd.line_off, on ? jd.m : 0, nullptr, &vx, &vy, &sp.vp3_thre_rad, &swapped3, on, o2);
   if (on) { double* t3 = v.bound3 + 2 * ((size_t)j * VP3_RPCAP + rp); t3[0] = o2[0]; t3[1] = o2[1]; }
 }
 
@@ -211,6 +349,7 @@ __global__ __launch_bounds__(256) void vp_points_kernel(DetectDeviceView v, int 
   if (e >= vp_total) return;
   const JobDesc jd = v.jobs[j];
   int local = (int)e - jd.vp_off;
+  if (local >= jd.RP * jd.Y) return;       // padding of the job's entries to whole waves
   int rp = local / jd.Y, y = local - rp * jd.Y;
   const RpPose* pose = v.rp + jd.rp_off + rp;
   double cy = v.yaw_cos[jd.yaw_off + y], sy = v.yaw_sin[jd.yaw_off + y];
@@ -245,7 +384,7 @@ __device__ __forceinline__ int candidate_one(const DetectDeviceView& v, const Sw
   if (enabled) {
     const double* vp = v.vp + 6 * (long long)(jd.vp_off + (int)ryu);
     V2 c[8];
-    flag = build_corners(jd.g, v2(vp[0], vp[1]), v2(vp[2], vp[3]), v2(vp[4], vp[5]), (double)v.top_x[jd.top_off + t], cfg, sp.short_thre, c);
+    flag = build_corners(jd.g, v2(vp[0], vp[1]), v2(vp[2], vp[3]), v2(vp[4], vp[5]), (double)v.top_x[jd.top_off + t], cfg, sp.short_sq_bound, c);
     if (flag) {
       double* co = v.corners + 16 * slot;
 #pragma unroll

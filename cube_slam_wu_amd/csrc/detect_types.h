@@ -31,6 +31,7 @@ struct JobDesc {
 struct SweepParams {
   double vp12_thre_rad, vp3_thre_rad;  // 15 deg, 10 deg (:102-103)
   double short_thre;                   // 20 px (:104)
+  double short_sq_bound;               // sqrt(x) < short_thre  <=>  x < short_sq_bound (see build_corners)
   int consider_config_1, consider_config_2;
 };
 
