@@ -21,6 +21,28 @@ CS_HD double v2_dist2(V2 a, V2 b) {
   double dx = a.x - b.x, dy = a.y - b.y;
   return dx * dx + dy * dy;
 }
+// Thresholds on a length become thresholds on the squared length: the IEEE square root is correctly rounded and monotone, so
+//   sqrt(x) <  t  <=>  x <  sqrt_lt_bound(t)   (the smallest double whose root reaches t)
+//   sqrt(x) >  t  <=>  x >  sqrt_le_bound(t)   (the largest double whose root does not exceed t)
+// for every x >= 0, inf and NaN included.  Host side, computed once per parameter set.
+static inline double cs_next_up(double x) { long long b = cs_bits(x); return cs_from_bits(b + 1); }     // x >= 0, finite
+static inline double cs_next_down(double x) { long long b = cs_bits(x); return cs_from_bits(b - 1); }   // x > 0
+static inline double sqrt_lt_bound(double t) {
+  if (!(t > 0)) return 0.0;                              // sqrt(x) < t never holds; neither does x < 0
+  if (t == __builtin_huge_val()) return t;
+  double c = t * t;
+  if (c == __builtin_huge_val()) c = 1.7976931348623157e308;
+  while (c > 0 && __builtin_sqrt(c) >= t) c = cs_next_down(c);
+  while (__builtin_sqrt(c) < t) { if (c >= 1.7976931348623157e308) return __builtin_huge_val(); c = cs_next_up(c); }
+  return c;
+}
+static inline double sqrt_le_bound(double t) {
+  if (!(t >= 0)) return -1.0;                            // sqrt(x) > t always holds for a number; so does x > -1
+  if (t == __builtin_huge_val()) return t;
+  const double lt = sqrt_lt_bound(cs_next_up(t));        // the smallest x with sqrt(x) > t ...
+  if (lt == __builtin_huge_val()) return 1.7976931348623157e308;
+  return lt > 0 ? cs_next_down(lt) : 0.0;                // ... and its predecessor
+}
 CS_HD double dmin(double a, double b) { return (b < a) ? b : a; }  // std::min
 CS_HD double dmax(double a, double b) { return (a < b) ? b : a; }  // std::max
 CS_HD double dabs(double a) { return __builtin_fabs(a); }

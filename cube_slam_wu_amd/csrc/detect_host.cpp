@@ -52,7 +52,8 @@ struct EdgeRoi { int l, t, w, h; long long img_off, cls_off, map_off; };
 void launch_edge_maps(const unsigned char* gray, int W, int H, const EdgeRoi* rois, int n_rois, unsigned char* cls_pool, float* map_pool, int max_w, int low, int high,
                       hipStream_t st);
 void launch_line_setup(JobDesc* jobs, int n_jobs, const double* frame_lines, const int* frame_line_ptr, double* mid_x, double* mid_y, double* line_angle,
-                       double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st, const int* order = nullptr);
+                       double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st, const int* order = nullptr, hipStream_t st_crowded = nullptr,
+                       hipEvent_t fork = nullptr, hipEvent_t join = nullptr);
 int line_setup_capacity();
 void launch_gather_ranges(const DetectDeviceView& v, const long long* src_off, const int* count, const long long* dst_off, int n_ranges,
                           double* o_dist, double* o_angle, double* o_skew, int* o_flag, long long* o_slot, hipStream_t st);
@@ -73,18 +74,6 @@ void set_err(const std::string& s) { g_cs_err = s; }
       return CS_ERR_HIP;                                                                      \
     }                                                                                         \
   } while (0)
-
-// The smallest double x with sqrt(x) >= t (IEEE square root, correctly rounded and monotone): sqrt(x) < t <=> x < sqrt_lt_bound(t).
-// t <= 0 or NaN: sqrt(x) < t never holds, and x < 0 never holds for a sum of squares.
-double sqrt_lt_bound(double t) {
-  if (!(t > 0)) return 0.0;
-  if (std::isinf(t)) return t;                         // sqrt(x) < inf <=> x < inf
-  double c = t * t;
-  if (std::isinf(c)) c = std::numeric_limits<double>::max();
-  while (c > 0 && std::sqrt(c) >= t) c = std::nextafter(c, 0.0);
-  while (std::sqrt(c) < t) { const double up = std::nextafter(c, std::numeric_limits<double>::infinity()); if (std::isinf(up)) return up; c = up; }
-  return c;
-}
 
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -379,6 +368,7 @@ struct cs_detector {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // tie-break re-ranking fetches of the previous chunk, concurrent with the next chunk's sweep
+  hipStream_t stream3 = nullptr;   // line setup of the crowded ROIs, beside the line setup of all the others
   hipEvent_t ev[12] = {};
   int n_threads = 1;
   std::unique_ptr<WorkerPool> pool;
@@ -436,7 +426,7 @@ struct PipeSlot {
   PinBuf<long long> h_fb_src, h_fb_dst, h_fb_slot, h_win_slots;
   PinBuf<int> h_fb_cnt, h_fb_flag;
   PinBuf<double> h_fb_dist, h_fb_angle, h_fb_skew, h_win_corners;
-  hipEvent_t done = nullptr, ev[13] = {};   // 0-6: phase marks on the main stream; 7: inputs resident; 8-11: second stream (corner construction); 12: spare
+  hipEvent_t done = nullptr, ev[13] = {};   // 0-6: phase marks on the main stream; 7: inputs resident; 8-11: second stream (corner construction); 12: line setup of the crowded ROIs done (third stream)
   cs::DetectDeviceView view{};
   int f0 = 0, f1 = 0, vp_total = 0;
   size_t nj = 0, nb = 0;
@@ -593,6 +583,7 @@ int cs_detector_create(const cs_detect_params* params, int device, cs_detector**
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&d->stream3, hipStreamNonBlocking));
   for (auto& e : d->ev) HIP_TRY(hipEventCreate(&e));
   int hc = (int)std::thread::hardware_concurrency();
   // default worker count: 64 on an unrestricted 256-thread EPYC (beats 32 and 128); under a cgroup CPU quota three threads
@@ -619,6 +610,7 @@ void cs_detector_destroy(cs_detector* d) {
   for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
   if (d->stream) (void)hipStreamDestroy(d->stream);
   if (d->stream2) (void)hipStreamDestroy(d->stream2);
+  if (d->stream3) (void)hipStreamDestroy(d->stream3);
   delete d;
 }
 
@@ -1011,7 +1003,8 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   cs::launch_scan_compact(v, stB);
   HIP_TRY(hipEventRecord(S.ev[10], stB));
   HIP_TRY(hipEventRecord(S.ev[0], st));
-  cs::launch_line_setup(S.jobs.p, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st, S.ls_order.p);
+  cs::launch_line_setup(S.jobs.p, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st, S.ls_order.p,
+                        d->stream3, S.ev[0], S.ev[12]);
   HIP_TRY(hipEventRecord(S.ev[1], st));
   cs::launch_vp_support_only(v, C.sp, S.vp_total, st);
   HIP_TRY(hipEventRecord(S.ev[2], st));
@@ -1246,7 +1239,7 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
   sp.vp12_thre_rad = P.vp12_edge_angle_thre / 180.0 * CS_PI;
   sp.vp3_thre_rad = P.vp3_edge_angle_thre / 180.0 * CS_PI;
   sp.short_thre = P.shorted_edge_thre;
-  sp.short_sq_bound = sqrt_lt_bound(P.shorted_edge_thre);
+  sp.short_sq_bound = cs::sqrt_lt_bound(P.shorted_edge_thre);
   sp.consider_config_1 = P.consider_config_1; sp.consider_config_2 = P.consider_config_2;
 
   // ---- per-frame camera caches: raw pose and the roll/pitch sample poses (:78-79, :344-355, :368-377)

@@ -121,12 +121,10 @@ struct VpRun {               // running state of one vanishing point's sweep ove
   double hx, hy, lx, ly;     // mid point - vanishing point of the two running extremes
 };
 
-// one segment (mid point mxi, myi; angle lai) against one vanishing point
-__device__ __forceinline__ void vp_step(const double* __restrict__ mx, const double* __restrict__ my, int i, double mxi, double myi, double lai,
-                                        double vpxk, double vpyk, double thre, float thre_f, VpRun& R) {
-  const float PI_F = 3.14159274f, HPI_F = 1.57079637f, M_IN = 1.0e-5f, M_ORD = 2.0e-5f;
-  const double dyd = myi - vpyk, dxd = mxi - vpxk;
-  const float fy = (float)dyd, fx = (float)dxd;
+// atan2 in float, all quadrants: |error| < 2.5e-6 rad (tests/test_vp_float_atan.py; budget in the comment above).
+// *usable = false for a zero or non-finite argument pair: the caller then decides exactly.
+__device__ __forceinline__ float atan2_float(float fy, float fx, bool* usable) {
+  const float PI_F = 3.14159274f, HPI_F = 1.57079637f;
   const float ay = fabsf(fy), ax = fabsf(fx);
   const float hi = fmaxf(ax, ay), lo = fminf(ax, ay);
   const float q = lo * __builtin_amdgcn_rcpf(hi), q2 = q * q;
@@ -140,12 +138,22 @@ __device__ __forceinline__ void vp_step(const double* __restrict__ mx, const dou
   if (ay > ax) at = HPI_F - at;
   if (fx < 0.0f) at = PI_F - at;
   if (fy < 0.0f) at = -at;
+  *usable = hi > 0.0f && hi < 3.0e38f;
+  return at;
+}
+
+// one segment (mid point mxi, myi; angle lai) against one vanishing point
+__device__ __forceinline__ void vp_step(const double* __restrict__ mx, const double* __restrict__ my, int i, double mxi, double myi, double lai,
+                                        double vpxk, double vpyk, double thre, float thre_f, VpRun& R) {
+  const float PI_F = 3.14159274f, HPI_F = 1.57079637f, M_IN = 1.0e-5f, M_ORD = 2.0e-5f;
+  const double dyd = myi - vpyk, dxd = mxi - vpxk;
+  bool usable;
+  float at = atan2_float((float)dyd, (float)dxd, &usable);
   float nr = at;                           // normalize_to_pi: the distance below is circular, so which side of the fold a float lands on does not matter
   if (at > HPI_F) nr = at - PI_F; else if (at < -HPI_F) nr = at + PI_F;
   float df = fabsf((float)lai - nr);
   df = fminf(df, PI_F - df);
-  const bool usable = hi > 0.0f && hi < 3.0e38f;       // finite and non-degenerate; anything else is decided exactly
-  bool inl = usable && df < thre_f - M_IN;
+  bool inl = usable && df < thre_f - M_IN;              // (zero or non-finite differences are decided exactly)
   if (!(inl || (usable && df > thre_f + M_IN))) { const VpExactInlier x = vp_rare_inlier(dyd, dxd, lai, thre); inl = x.inl != 0; at = x.at; }
   if (inl) {
     if (!R.have) {  // first inlier: base of smooth_jump_angles (:278-302), and initial arg-max / arg-min
@@ -928,28 +936,50 @@ enum { LS_CAP = 512, LS_THREADS = 64 };
 
 struct LineSetupParams {
   double dist_thre, angle_thre_rad, len_thre;  // 20 px, 5 deg, 30 px (:288-290)
+  double dist_sq_bound;                        // sqrt(x) < dist_thre <=> x < dist_sq_bound   (cs_geom.h sqrt_lt_bound)
+  double len_sq_bound;                         // sqrt(x) > len_thre  <=> x > len_sq_bound    (sqrt_le_bound)
 };
 
 struct LsRow { double ang, x1, y1, x2, y2; };
 
-// the three tests of object_3d_util.cpp:464-497 for the ordered pair (a, b)
+// third test of a pair, exactly as the reference evaluates it (rare: only inside the float test's margin)
+__device__ __attribute__((noinline)) bool ls_rare_angle_close(double ang, double dy, double dx, double thre) {
+  const double ma = cs_atan2(dy, dx);
+  const double t = dabs(ang - ma);
+  return dmin(t, CS_PI - t) < thre;
+}
+
+// the three tests of object_3d_util.cpp:464-497 for the ordered pair (a, b).  Only the decision leaves this function: the
+// end-point gaps are compared squared, and the angle of the would-be merged segment is taken in float (2.5e-6 rad) with
+// the exact evaluation inside a 1e-5 margin of the threshold.
 __device__ __forceinline__ bool ls_pair_pass(const LsRow& A, const LsRow& B, const LineSetupParams& lp) {
   double diff = dabs(A.ang - B.ang);
   if (dmin(diff, CS_PI - diff) >= lp.angle_thre_rad) return false;
-  double d_ab = v2_dist(v2(A.x2, A.y2), v2(B.x1, B.y1));
-  double d_ba = v2_dist(v2(B.x2, B.y2), v2(A.x1, A.y1));
-  if (!((d_ab < lp.dist_thre) || (d_ba < lp.dist_thre))) return false;
+  double d_ab = v2_dist2(v2(A.x2, A.y2), v2(B.x1, B.y1));
+  double d_ba = v2_dist2(v2(B.x2, B.y2), v2(A.x1, A.y1));
+  if (!((d_ab < lp.dist_sq_bound) || (d_ba < lp.dist_sq_bound))) return false;
   bool sa = A.x1 < B.x1, ea = A.x2 > B.x2;
   double sx = sa ? A.x1 : B.x1, sy = sa ? A.y1 : B.y1, ex = ea ? A.x2 : B.x2, ey = ea ? A.y2 : B.y2;
-  double ma = cs_atan2(ey - sy, ex - sx);
-  double t = dabs(A.ang - ma);
-  return dmin(t, CS_PI - t) < lp.angle_thre_rad;
+  const double dy = ey - sy, dx = ex - sx;
+  bool usable;
+  const float at = atan2_float((float)dy, (float)dx, &usable);
+  const float tf = fabsf((float)A.ang - at);
+  const float mf = fminf(tf, 3.14159274f - tf), th = (float)lp.angle_thre_rad;
+  if (usable && mf < th - 1.0e-5f) return true;
+  if (usable && mf > th + 1.0e-5f) return false;
+  return ls_rare_angle_close(A.ang, dy, dx, lp.angle_thre_rad);
 }
 
+// Two instances share the jobs: the wave is latency bound (dependent LDS reads, one lane's atan2 per merge), so what matters is
+// how many jobs a CU holds at once, and that is set by the row tables in LDS.  A typical ROI holds a few dozen segments:
+// CAP = LS_SMALL rows (5.6 KB) lets a CU hold every wave slot's worth of jobs; the few crowded ROIs go to the CAP = LS_CAP
+// instance.  Each instance counts the ROI's segments first and leaves the jobs of the other size class alone.
+enum { LS_SMALL = 128 };
+template <int CAP>
 __global__ __launch_bounds__(LS_THREADS) void line_setup_kernel(JobDesc* jobs, int n_jobs, const double* __restrict__ frame_lines, const int* __restrict__ frame_line_ptr,
                                                                double* mid_x, double* mid_y, double* line_angle, LineSetupParams lp, const int* __restrict__ order) {
-  __shared__ double X1[LS_CAP], Y1[LS_CAP], X2[LS_CAP], Y2[LS_CAP], ANG[LS_CAP];
-  __shared__ int F[LS_CAP];
+  __shared__ double X1[CAP], Y1[CAP], X2[CAP], Y2[CAP], ANG[CAP];
+  __shared__ int F[CAP];
   int j = order ? order[blockIdx.x] : blockIdx.x;   // longest jobs first (the kernel ends with its slowest workgroup)
   if (j >= n_jobs) return;
   const JobDesc jd = jobs[j];
@@ -958,6 +988,16 @@ __global__ __launch_bounds__(LS_THREADS) void line_setup_kernel(JobDesc* jobs, i
   const int M = frame_line_ptr[jd.frame + 1] - frame_line_ptr[jd.frame];
   const int lane = threadIdx.x;
   const int NONE = 0x7fffffff;
+  {  // size class of this job: segments with both end points inside the expanded ROI
+    int n_in = 0;
+    for (int base = 0; base < M; base += 64) {
+      const int i = base + lane;
+      bool in = false;
+      if (i < M) in = inside_box(v2(FL[4 * i], FL[4 * i + 1]), jd.g.el, jd.g.et, jd.g.er, jd.g.eb) && inside_box(v2(FL[4 * i + 2], FL[4 * i + 3]), jd.g.el, jd.g.et, jd.g.er, jd.g.eb);
+      n_in += __popcll(__ballot(in));
+    }
+    if ((n_in <= LS_SMALL) != (CAP == LS_SMALL)) return;
+  }
   auto row = [&](int i) { return LsRow{ANG[i], X1[i], Y1[i], X2[i], Y2[i]}; };
   // cooperative scan of row r: F[r] = first k > r with pair_pass(r, k)
   auto rescan = [&](int r, int total) {
@@ -984,8 +1024,8 @@ __global__ __launch_bounds__(LS_THREADS) void line_setup_kernel(JobDesc* jobs, i
     }
     unsigned long long bal = __ballot(in);
     int off = total + __popcll(bal & ((1ull << lane) - 1ull));
-    if (in && off < LS_CAP) { X1[off] = x1; Y1[off] = y1; X2[off] = x2; Y2[off] = y2; ANG[off] = cs_atan2(y2 - y1, x2 - x1); }
-    total = min(LS_CAP, total + __popcll(bal));
+    if (in && off < CAP) { X1[off] = x1; Y1[off] = y1; X2[off] = x2; Y2[off] = y2; ANG[off] = cs_atan2(y2 - y1, x2 - x1); }
+    total = min(CAP, total + __popcll(bal));
   }
   __syncthreads();
   // ---- 2. first partner of every row
@@ -1058,8 +1098,8 @@ __global__ __launch_bounds__(LS_THREADS) void line_setup_kernel(JobDesc* jobs, i
     int i = base + lane;
     bool keep = false;
     if (i < total) {
-      double len = v2_dist(v2(X2[i], Y2[i]), v2(X1[i], Y1[i]));
-      keep = (lp.len_thre > 0) ? (len > lp.len_thre) : true;
+      double len2 = v2_dist2(v2(X2[i], Y2[i]), v2(X1[i], Y1[i]));
+      keep = (lp.len_thre > 0) ? (len2 > lp.len_sq_bound) : true;
     }
     unsigned long long bal = __ballot(keep);
     int off = kept + __popcll(bal & ((1ull << lane) - 1ull));
@@ -1073,11 +1113,19 @@ __global__ __launch_bounds__(LS_THREADS) void line_setup_kernel(JobDesc* jobs, i
   if (lane == 0) jobs[j].m = kept;
 }
 
+// st_crowded (with the two events): the few crowded ROIs -- long, low-occupancy workgroups -- run on their own stream beside the
+// others; `fork` must already be recorded on st, `join` is recorded here and st waits for it.
 void launch_line_setup(JobDesc* jobs, int n_jobs, const double* frame_lines, const int* frame_line_ptr, double* mid_x, double* mid_y, double* line_angle,
-                       double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st, const int* order) {
+                       double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st, const int* order, hipStream_t st_crowded, hipEvent_t fork, hipEvent_t join) {
   if (n_jobs <= 0) return;
-  LineSetupParams lp{dist_thre, angle_thre_deg / 180.0 * CS_PI, len_thre};
-  hipLaunchKernelGGL(line_setup_kernel, dim3(n_jobs), dim3(LS_THREADS), 0, st, jobs, n_jobs, frame_lines, frame_line_ptr, mid_x, mid_y, line_angle, lp, order);
+  LineSetupParams lp{dist_thre, angle_thre_deg / 180.0 * CS_PI, len_thre, sqrt_lt_bound(dist_thre), sqrt_le_bound(len_thre)};
+  const bool beside = st_crowded && fork && join;
+  hipStream_t sc = beside ? st_crowded : st;
+  if (beside) (void)hipStreamWaitEvent(sc, fork, 0);
+  hipLaunchKernelGGL(line_setup_kernel<LS_CAP>, dim3(n_jobs), dim3(LS_THREADS), 0, sc, jobs, n_jobs, frame_lines, frame_line_ptr, mid_x, mid_y, line_angle, lp, order);
+  if (beside) (void)hipEventRecord(join, sc);
+  hipLaunchKernelGGL(line_setup_kernel<LS_SMALL>, dim3(n_jobs), dim3(LS_THREADS), 0, st, jobs, n_jobs, frame_lines, frame_line_ptr, mid_x, mid_y, line_angle, lp, order);
+  if (beside) (void)hipStreamWaitEvent(st, join, 0);
 }
 int line_setup_capacity() { return LS_CAP; }
 
