@@ -20,27 +20,7 @@
 
 #include "detect_types.h"
 
-#ifndef CS_EXP
-#define CS_EXP 0
-#endif
 namespace cs {
-
-__device__ __forceinline__ int find_job_i32(const int* prefix, int n, int v) {
-  int lo = 0, hi = n;  // prefix[lo] <= v < prefix[hi]
-  while (hi - lo > 1) {
-    int mid = (lo + hi) >> 1;
-    if (prefix[mid] <= v) lo = mid; else hi = mid;
-  }
-  return lo;
-}
-__device__ __forceinline__ int find_job_i64(const long long* prefix, int n, long long v) {
-  int lo = 0, hi = n;
-  while (hi - lo > 1) {
-    int mid = (lo + hi) >> 1;
-    if (prefix[mid] <= v) lo = mid; else hi = mid;
-  }
-  return lo;
-}
 
 // job of element `elem` of a prefix table, for a wave whose lanes hold consecutive elements: one binary search per wave on
 // the first lane's element (uniform operands: scalar loads), then every lane walks forward from there (jobs are thousands
@@ -477,7 +457,7 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
       const int T0 = v.jobs[j0].T;
       const unsigned loc = (unsigned)(slot0 - v.jobs[j0].slot_off);
       const int jrel = j0 - s_job[0];                                                // jobs in this block, in order
-      const int sub = CS_EXP == 8 ? (int)(loc & 1) : CS_EXP == 9 ? 0 : (int)(loc & 1) * T0 + (int)((loc >> 1) % (unsigned)T0);        // configuration-major, then top-edge sample
+      const int sub = (int)(loc & 1) * T0 + (int)((loc >> 1) % (unsigned)T0);        // configuration-major, then top-edge sample
       key = (jrel < SCORE_JOBS && sub < SCORE_SUB) ? jrel * SCORE_SUB + sub : SCORE_BINS - 1;
     }
     const int rank = atomicAdd(&hist[key], 1);
@@ -498,7 +478,6 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
     s_src[hist[key] + rank] = t0;
     __syncthreads();
   }
-  if (CS_EXP == 4) { if (base + threadIdx.x < n_valid) v.c_angle[base + threadIdx.x] = s_src[threadIdx.x] + s_job[threadIdx.x]; return; }
   // corners of the block's 256 proposals -> LDS.  A proposal's 16 doubles are one 128-byte line of the per-slot array: 16 lanes
   // fetch one proposal (a wave instruction touches 4 lines, not 64 as it would with one proposal per lane)
   {
@@ -507,14 +486,13 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
     for (int it = 0; it < 16; it++) {
       const int p = it * 16 + (threadIdx.x >> 4);
       const int src = s_src[p];
-      if (base + src < n_valid) C16[k][p] = v.corners[16 * (CS_EXP == 7 ? base + src : s_slot[src]) + k];
+      if (base + src < n_valid) C16[k][p] = v.corners[16 * s_slot[src] + k];
     }
   }
   __syncthreads();
   const int mine = s_src[threadIdx.x];
   const long long i = base + mine;
   if (i >= n_valid) return;                     // (no barrier below this point)
-  if (CS_EXP == 5 || CS_EXP == 7) { v.c_angle[i] = C16[3][threadIdx.x] + C16[12][threadIdx.x]; return; }
   const long long slot = s_slot[mine];
   const int j = s_job[mine];
   const JobDesc jd = v.jobs[j];
@@ -535,9 +513,9 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
   const unsigned long long EW = cfg ? 0x004332222ull : 0x222222222ull;
   const int n_edges = cfg ? 7 : 9;
   const int map_w = jd.map_w;
-  constexpr int EU = CS_EXP == 11 ? 9 : CS_EXP == 12 ? 1 : 3;   // edges per trip: their 11 * EU gathers are in flight together
+  constexpr int EU = 3;   // edges per trip: their 11 * EU gathers are in flight together
 #pragma unroll 1
-  for (int e0 = 0; e0 < ((CS_EXP == 1 || CS_EXP == 6) ? 0 : n_edges); e0 += EU) {
+  for (int e0 = 0; e0 < n_edges; e0 += EU) {
     float dv[EU][11];
 #pragma unroll
     for (int u = 0; u < EU; u++) {
@@ -568,7 +546,7 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
   const double not_found_penalty = 30.0 / 180.0 * CS_PI * 2;
   const int ID1[3][4] = {{0, 1, 7, 4}, {3, 0, 4, 5}, {3, 7, 1, 5}}, ID2[3][4] = {{0, 1, 2, 3}, {3, 0, 4, 5}, {2, 4, 1, 5}};
 #pragma unroll
-  for (int k = 0; k < ((CS_EXP == 2 || CS_EXP == 6) ? 0 : 3); k++) {
+  for (int k = 0; k < 3; k++) {
     double b0 = bound[2 * k], b1 = bound[2 * k + 1];
     bool v0 = !(b0 != b0), v1 = !(b1 != b1);
     if (v0 || v1) {
@@ -591,7 +569,6 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
   for (int q = 0; q < 8; q++) c[q] = v2(CXt[q][tx], CYt[q][tx]);
   const RpPose* pose = v.rp + jd.rp_off + rp;
   double p3[3], s3[3];
-  if (CS_EXP == 3 || CS_EXP == 6) { s3[0] = c[0].x; s3[1] = c[1].y; s3[2] = c[2].x; } else
   lift_to_3d(c, pose->R, pose->t, v.invK + 9 * jd.frame, pose->plane, p3, s3);
   int flag = s_flag[mine];
   if (s3[0] < 0 || s3[1] < 0 || s3[2] < 0) flag |= CAND_NEG_SCALE;
@@ -680,41 +657,48 @@ __device__ __forceinline__ unsigned long long order_key(double x) {
   return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
-// key of rank r (0-based, ascending) among n doubles; all 256 threads of the block must call it
-__device__ unsigned long long block_radix_select(const double* __restrict__ a, int n, int r, unsigned* hist /* LDS, 256 */, unsigned long long* bcast /* LDS, 2 */) {
-  unsigned long long prefix = 0, mask = 0;
+// radix selection, 8 passes of 8 bits over order_key(): all 256 threads of the block must call it.
+// Two columns at once (their passes share the barriers): keys of rank r (0-based, ascending) among a[0..n) and among b[0..n)
+__device__ void block_radix_select2(const double* __restrict__ a, const double* __restrict__ b, int n, int r, unsigned* hist /* LDS, 512 */, unsigned long long* bcast /* LDS, 4 */,
+                                    unsigned long long* key_a, unsigned long long* key_b) {
+  unsigned long long prefix[2] = {0, 0}, mask = 0;
+  int rr2[2] = {r, r};
   for (int pass = 0; pass < 8; pass++) {
-    int shift = 56 - 8 * pass;
-    hist[threadIdx.x] = 0;
+    const int shift = 56 - 8 * pass;
+    hist[threadIdx.x] = 0; hist[256 + threadIdx.x] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += 256) {
-      unsigned long long k = order_key(a[i]);
-      if ((k & mask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+      const unsigned long long ka = order_key(a[i]), kb = order_key(b[i]);
+      if ((ka & mask) == prefix[0]) atomicAdd(&hist[(unsigned)(ka >> shift) & 255u], 1u);
+      if ((kb & mask) == prefix[1]) atomicAdd(&hist[256 + ((unsigned)(kb >> shift) & 255u)], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < 64) {  // wave 0: each lane owns 4 consecutive bins
-      unsigned c0 = hist[4 * threadIdx.x], c1 = hist[4 * threadIdx.x + 1], c2 = hist[4 * threadIdx.x + 2], c3 = hist[4 * threadIdx.x + 3];
+    if (threadIdx.x < 128) {  // waves 0 and 1: one column each, every lane owns 4 consecutive bins
+      const int col = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      const unsigned* h = hist + 256 * col;
+      unsigned c0 = h[4 * lane], c1 = h[4 * lane + 1], c2 = h[4 * lane + 2], c3 = h[4 * lane + 3];
       unsigned tot = c0 + c1 + c2 + c3, incl = tot;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { unsigned y = __shfl_up(incl, o); if ((int)threadIdx.x >= o) incl += y; }
+      for (int o = 1; o < 64; o <<= 1) { unsigned y = __shfl_up(incl, o); if (lane >= o) incl += y; }
       unsigned excl = incl - tot;
-      if ((unsigned)r >= excl && (unsigned)r < incl) {
-        unsigned rr = (unsigned)r - excl, d;
+      const unsigned rk = (unsigned)rr2[col];
+      if (rk >= excl && rk < incl) {
+        unsigned rr = rk - excl, d;
         if (rr < c0) { d = 0; }
         else if (rr < c0 + c1) { d = 1; rr -= c0; }
         else if (rr < c0 + c1 + c2) { d = 2; rr -= c0 + c1; }
         else { d = 3; rr -= c0 + c1 + c2; }
-        bcast[0] = (unsigned long long)(4 * threadIdx.x + d);
-        bcast[1] = rr;
+        bcast[2 * col] = (unsigned long long)(4 * lane + d);
+        bcast[2 * col + 1] = rr;
       }
     }
     __syncthreads();
-    prefix |= bcast[0] << shift;
+    prefix[0] |= bcast[0] << shift; prefix[1] |= bcast[2] << shift;
     mask |= 255ull << shift;
-    r = (int)bcast[1];
+    rr2[0] = (int)bcast[1]; rr2[1] = (int)bcast[3];
     __syncthreads();
   }
-  return prefix;
+  *key_a = prefix[0]; *key_b = prefix[1];
 }
 
 __device__ __forceinline__ double block_reduce_min(double v, double* sh) {
@@ -754,13 +738,15 @@ struct JobCut {      // per height sample of the box
   int tie;           // several proposals share the cut value vd, and which of them the reference keeps depends on its heap order
 };
 
+enum { RANK_STAGE = 1536 };   // proposals of one height sample staged in LDS (2 x 12 KB)
 __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView rv, RankParams rp) {
-  __shared__ unsigned hist[256];
-  __shared__ unsigned long long bcast[2];
+  __shared__ unsigned hist[512];
+  __shared__ unsigned long long bcast[4];
   __shared__ double shd[4];
   __shared__ int shi[4];
   __shared__ JobCut cuts[3];
   __shared__ int s_fallback;
+  __shared__ double sD[RANK_STAGE], sA[RANK_STAGE];
   int box = blockIdx.x;
   if (box >= rv.n_boxes) return;
   if (threadIdx.x == 0) s_fallback = 0;
@@ -774,13 +760,21 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
     int V = v.job_valid[j];
     const double* D = v.c_dist + c0;
     const double* A = v.c_angle + c0;
+    // the selection below makes ~20 passes over the two columns: from LDS when they fit (they do unless nearly every slot of a
+    // large box is valid), each pass then costs LDS latency instead of a round trip to L2
+    if (V <= RANK_STAGE) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < V; i += 256) { sD[i] = D[i]; sA[i] = A[i]; }
+      __syncthreads();
+      D = sD; A = sA;
+    }
     double vd = INF, va = INF;
     int use_angle = 0, tie = 0, bn_keep = 0;
     if (V > 4) {
       int bn = (int)round((double)((float)V) / 3.0 * 2.0);
       bn_keep = bn - 1;
-      unsigned long long kd = block_radix_select(D, V, bn - 2, hist, bcast);
-      unsigned long long ka = block_radix_select(A, V, bn - 2, hist, bcast);
+      unsigned long long kd, ka;
+      block_radix_select2(D, A, V, bn - 2, hist, bcast, &kd, &ka);
       int cd = 0, ca = 0, nan = 0;
       for (int i = threadIdx.x; i < V; i += 256) {
         double d = D[i], a = A[i];
@@ -843,17 +837,20 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
     }
     __syncthreads();
   }
-  // ---- final ranking over the proposals of all height samples: kmax rounds of arg-min
+  // ---- final ranking over the proposals of all height samples: kmax rounds of arg-min, one pass over the proposals per round
+  // (every thread keeps its own minimum, how many of its proposals attain it, and that proposal's record)
+  const bool staged = (nj == 1) && (cuts[0].V <= RANK_STAGE);   // the columns of the only height sample are still in LDS
   double prev = -INF;
   int n_win = 0;
   for (int round = 0; round < rp.kmax; round++) {
-    double best = INF;
-    int bad = 0;
+    double best = INF, w_score = 0, w_d = 0, w_a = 0;
+    long long w_at = 0;
+    int bad = 0, cnt_local = 0;
     for (int h = 0; h < nj; h++) {
       const JobCut c = cuts[h];
       long long c0 = v.job_cbase[j0 + h];
       for (int i = threadIdx.x; i < c.V; i += 256) {
-        double d = v.c_dist[c0 + i], a = v.c_angle[c0 + i];
+        double d = staged ? sD[i] : v.c_dist[c0 + i], a = staged ? sA[i] : v.c_angle[c0 + i];
         bool keep = (d <= c.vd) && (!c.use_angle || a <= c.va);
         if (!keep || (v.c_flag[c0 + i] & CAND_NEG_SCALE)) continue;
         double score;
@@ -869,7 +866,10 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
         if (sk > rp.max_cut_skew) skew_error = 100;
         double comb = score + rp.w_skew * skew_error;
         if (comb != comb || comb == INF || comb == -INF) { bad = 1; continue; }  // NaN / inf: let the host decide
-        if (comb > prev && comb < best) best = comb;
+        if (!(comb > prev)) continue;
+        const int weight = (c.tie && d == c.vd) ? 3 : 1;   // a winner among the tied proposals: the reference may not have kept it -> host
+        if (comb < best) { best = comb; cnt_local = weight; w_score = score; w_d = d; w_a = a; w_at = c0 + i; }
+        else if (comb == best) cnt_local += weight;
       }
     }
     bad = block_reduce_sum_i(bad, shi);
@@ -877,40 +877,16 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
     if (bad && threadIdx.x == 0) s_fallback = 1;
     if (!(gbest < INF)) break;  // no proposal left
     // how many proposals attain the minimum?  (> 1: the reference's pick depends on the heap order)
-    int cnt = 0;
-    for (int h = 0; h < nj; h++) {
-      const JobCut c = cuts[h];
-      long long c0 = v.job_cbase[j0 + h];
-      for (int i = threadIdx.x; i < c.V; i += 256) {
-        double d = v.c_dist[c0 + i], a = v.c_angle[c0 + i];
-        bool keep = (d <= c.vd) && (!c.use_angle || a <= c.va);
-        if (!keep || (v.c_flag[c0 + i] & CAND_NEG_SCALE)) continue;
-        double score;
-        if (c.n_keep > 1) {
-          double dn = (d - c.dmin) / (c.dmax - c.dmin);
-          double an = ((c.amax - c.amin) > 0) ? (a - c.amin) / (c.amax - c.amin) : a;
-          score = (dn + rp.w_angle * an) / (1 + rp.w_angle);
-        } else {
-          score = (d + rp.w_angle * a) / (1 + rp.w_angle);
-        }
-        double sk = v.c_skew[c0 + i];
-        double skew_error = rp.w_skew * dmax(sk - rp.nominal_skew, 0.0);
-        if (sk > rp.max_cut_skew) skew_error = 100;
-        double comb = score + rp.w_skew * skew_error;
-        if (comb == gbest) {
-          cnt++;
-          if (c.tie && d == c.vd) cnt += 2;   // a winner among the tied proposals: the reference may not have kept it -> host
-          // the (unique) owner writes the winner record
-          RankWinner* w = rv.winners + (size_t)box * rp.kmax + round;
-          long long slot = v.c_slot[c0 + i];
-          w->slot = slot; w->normalized_error = score; w->dist_err = d; w->angle_err = a; w->flag = v.c_flag[c0 + i] & CAND_VP_MASK; w->pad = 0;
-          const double* co = v.corners + 16 * slot;
+    const bool mine = best == gbest;
+    int cnt = block_reduce_sum_i(mine ? cnt_local : 0, shi);
+    if (mine) {   // the (unique, unless the box goes to the host anyway) owner writes the winner record
+      RankWinner* w = rv.winners + (size_t)box * rp.kmax + round;
+      long long slot = v.c_slot[w_at];
+      w->slot = slot; w->normalized_error = w_score; w->dist_err = w_d; w->angle_err = w_a; w->flag = v.c_flag[w_at] & CAND_VP_MASK; w->pad = 0;
+      const double* co = v.corners + 16 * slot;
 #pragma unroll
-          for (int q = 0; q < 16; q++) w->corners[q] = co[q];
-        }
-      }
+      for (int q = 0; q < 16; q++) w->corners[q] = co[q];
     }
-    cnt = block_reduce_sum_i(cnt, shi);
     if (cnt != 1 && threadIdx.x == 0) s_fallback = 1;
     prev = gbest;
     n_win++;
