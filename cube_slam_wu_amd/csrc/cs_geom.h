@@ -37,7 +37,8 @@ static inline double sqrt_lt_bound(double t) {
   return c;
 }
 static inline double sqrt_le_bound(double t) {
-  if (!(t >= 0)) return -1.0;                            // sqrt(x) > t always holds for a number; so does x > -1
+  if (t != t) return __builtin_huge_val();               // nothing exceeds NaN; nothing exceeds inf
+  if (t < 0) return -1.0;                                // sqrt(x) > t holds for every x that is a number; so does x > -1
   if (t == __builtin_huge_val()) return t;
   const double lt = sqrt_lt_bound(cs_next_up(t));        // the smallest x with sqrt(x) > t ...
   if (lt == __builtin_huge_val()) return 1.7976931348623157e308;

@@ -55,7 +55,7 @@ __device__ __forceinline__ long long xcd_virtual_block() {
 // The reference evaluates atan2 for every segment, keeps those whose direction is within `thre` of the segment's own angle,
 // unwraps the kept angles against the first one (smooth_jump_angles, :278-302) and returns the segment angles at the arg-max and
 // arg-min.  Only DECISIONS leave this function (which segments are inliers, which one is the extreme), so the angles are
-// evaluated in float (|error| < 2.5e-6 rad over all quadrants, tests/test_vp_float_atan.py) and every decision that falls
+// evaluated in float (|error| < 2.5e-6 rad over all quadrants, tests/test_device_decisions.py) and every decision that falls
 // within a margin of its threshold -- a few per million -- is re-decided with the exact cs_atan2 values of the segments
 // involved.  Error budget of a float angle: conversion of the double differences 1e-7, quotient (__fdividef) 3e-7, polynomial
 // 2e-6, pi constants and the +-2 pi shift 7e-7; of a difference of two of them twice that.  Margins: 1e-5 on the inlier test,
@@ -101,7 +101,7 @@ struct VpRun {               // running state of one vanishing point's sweep ove
   double hx, hy, lx, ly;     // mid point - vanishing point of the two running extremes
 };
 
-// atan2 in float, all quadrants: |error| < 2.5e-6 rad (tests/test_vp_float_atan.py; budget in the comment above).
+// atan2 in float, all quadrants: |error| < 2.5e-6 rad (tests/test_device_decisions.py; budget in the comment above).
 // *usable = false for a zero or non-finite argument pair: the caller then decides exactly.
 __device__ __forceinline__ float atan2_float(float fy, float fx, bool* usable) {
   const float PI_F = 3.14159274f, HPI_F = 1.57079637f;
