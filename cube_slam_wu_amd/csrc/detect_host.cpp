@@ -475,6 +475,8 @@ struct cs_batch {
   PinBuf<int> h_c_flag, h_job_valid;
   PinBuf<double> h_c_dist, h_c_angle, h_c_skew, h_win_corners;
   DevBuf<int> d_box_job0, d_box_njobs, d_win_count, d_fallback;
+  DevBuf<long long> d_last_slot;
+  PinBuf<long long> h_last_slot;
   DevBuf<cs::RankWinner> d_winners;
   DevBuf<long long> d_fb_src, d_fb_dst, d_fb_slot;
   DevBuf<int> d_fb_cnt, d_fb_flag;
@@ -776,7 +778,7 @@ void cs_batch_destroy(cs_batch* b) {
   b->d_c_skew.release(); b->d_win_corners.release(); b->d_rp.release();
   b->h_stage.release(); b->h_c_slot.release(); b->h_job_cbase.release(); b->h_c_flag.release(); b->h_job_valid.release();
   b->h_c_dist.release(); b->h_c_angle.release(); b->h_c_skew.release(); b->h_win_corners.release();
-  b->d_box_job0.release(); b->d_box_njobs.release(); b->d_win_count.release(); b->d_fallback.release(); b->d_winners.release();
+  b->d_box_job0.release(); b->d_box_njobs.release(); b->d_win_count.release(); b->d_fallback.release(); b->d_winners.release(); b->d_last_slot.release(); b->h_last_slot.release();
   b->h_winners.release(); b->h_win_count.release(); b->h_fallback.release(); b->h_jobs.release();
   b->d_fb_src.release(); b->d_fb_dst.release(); b->d_fb_slot.release(); b->d_fb_cnt.release(); b->d_fb_flag.release();
   b->d_fb_dist.release(); b->d_fb_angle.release(); b->d_fb_skew.release();
@@ -1480,7 +1482,7 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
 
     // ------------------------------------------------------------------ rank on the device --------
     // (no roll/pitch sampling: boxes are independent, so nothing has to come back to the host before the ranking)
-    const bool device_rank = !sample_rp && !b->debug && !b->force_host_rank && KMAX <= cs::RANK_KMAX;
+    const bool device_rank = !b->debug && !b->force_host_rank && KMAX <= cs::RANK_KMAX;
     if (device_rank) {
       ENS(b->d_c_slot, slot_total + 1); ENS(b->d_c_flag, slot_total + 1); ENS(b->d_c_dist, slot_total + 1); ENS(b->d_c_angle, slot_total + 1); ENS(b->d_c_skew, slot_total + 1);
       v.c_slot = b->d_c_slot.p; v.c_flag = b->d_c_flag.p; v.c_dist = b->d_c_dist.p; v.c_angle = b->d_c_angle.p; v.c_skew = b->d_c_skew.p;
@@ -1499,6 +1501,7 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
       cs::RankView rv{};
       rv.box_job0 = b->d_box_job0.p; rv.box_njobs = b->d_box_njobs.p; rv.n_boxes = (int)nb;
       rv.winners = b->d_winners.p; rv.win_count = b->d_win_count.p; rv.fallback = b->d_fallback.p;
+      if (sample_rp) { ENS(b->d_last_slot, nb); ENS(b->h_last_slot, nb); rv.last_slot = b->d_last_slot.p; }
       cs::RankParams rkp{P.weight_vp_angle, P.weight_skew_error, P.nominal_skew_ratio, P.max_cut_skew, KMAX};
       cs::launch_rank(v, rv, rkp, st);
       HIP_TRY(hipEventRecord(d->ev[5], st));
@@ -1507,6 +1510,7 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
       HIP_TRY(hipMemcpyAsync(b->h_winners.p, b->d_winners.p, sizeof(cs::RankWinner) * nb * KMAX, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(b->h_win_count.p, b->d_win_count.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(b->h_fallback.p, b->d_fallback.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+      if (sample_rp) HIP_TRY(hipMemcpyAsync(b->h_last_slot.p, b->d_last_slot.p, sizeof(long long) * nb, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(b->h_job_valid.p, b->d_job_valid.p, sizeof(int) * nj, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(b->h_job_cbase.p, b->d_job_cbase.p, sizeof(long long) * (nj + 1), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
@@ -1585,7 +1589,17 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
         const FrameIn& F = b->frames[f];
         const double* bb = &F.boxes[5 * bi];
         std::vector<cs::RankWinner> wl;
+        // cam_pose.camera_yaw as the next box of this frame reads it (:180): the reference's last set_cam_pose() of this box is
+        // the one for the last kept proposal of the last height sample (:727-737), or, when nothing was kept, the sweep's last
+        // (roll, pitch) sample (:368-377).  (One box per frame and round: no two workers write the same entry.)
+        auto carry_yaw = [&](long long last_slot) {
+          const cs::JobDesc& jl = jobs[j0 + nh - 1];
+          if (last_slot < 0) { cur_yaw[f] = cam_rp[f].back().cam_yaw; return; }
+          const long long ry = ((last_slot - jl.slot_off) >> 1) / jl.T;
+          cur_yaw[f] = cam_rp[f][(size_t)(ry / jl.Y)].cam_yaw;
+        };
         if (!b->h_fallback.p[q]) {
+          if (sample_rp && phase == 0) carry_yaw(b->h_last_slot.p[q]);
           for (int r = 0; r < b->h_win_count.p[q]; r++) wl.push_back(b->h_winners.p[q * KMAX + r]);
         } else if (phase == 1) {
           wl = fb_winners[q];
@@ -1605,6 +1619,7 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
             std::vector<int> keep;
             std::vector<double> score;
             fuse_scores(hd[h].data(), ha[h].data(), V, P.weight_vp_angle, keep, score);
+            if (sample_rp && h == nh - 1) carry_yaw(keep.empty() ? -1 : hsl[h][keep.back()]);
             for (size_t z = 0; z < keep.size(); z++) {
               if (hf[h][keep[z]] & cs::CAND_NEG_SCALE) continue;
               props.push_back(HP{h, keep[z], score[z], hs[h][keep[z]]});

@@ -831,6 +831,31 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
       const bool safe = nk_s >= 2 && amin_s == amin && amax_s == amax && (nt == 0 || r - (ct - nt) >= 1);
       if (!safe && threadIdx.x == 0) s_fallback = 1;
     }
+    if (rv.last_slot && h == nj - 1) {
+      // The last element of the kept list (object_3d_util.cpp:760-781).  V <= 4: every proposal is kept, in order.  With the
+      // angle cut the list is a sorted-id intersection: its last element is the kept proposal with the largest index.
+      // Without it the list is the first bn - 1 of the distance order: its last element is THE proposal whose distance is the
+      // cut value -- when two share that value, or the cut itself is tied, the reference's heap order decides: host.
+      int last = -1, n_at_cut = 0;
+      if (V > 4) {
+        for (int i = threadIdx.x; i < V; i += 256) {
+          const double d = D[i], a = A[i];
+          if (use_angle) { if (d <= vd && a <= va) last = i; }
+          else if (d == vd) { last = i; n_at_cut++; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_down(last, o); last = y > last ? y : last; }
+        if ((threadIdx.x & 63) == 0) shi[threadIdx.x >> 6] = last;
+        __syncthreads();
+        last = max(max(shi[0], shi[1]), max(shi[2], shi[3]));
+        __syncthreads();
+        n_at_cut = block_reduce_sum_i(n_at_cut, shi);
+        if ((tie || (!use_angle && n_at_cut != 1)) && threadIdx.x == 0) s_fallback = 1;
+      } else {
+        last = V - 1;
+      }
+      if (threadIdx.x == 0) rv.last_slot[box] = last >= 0 ? v.c_slot[c0 + last] : -1;
+    }
     if (threadIdx.x == 0) {
       JobCut c; c.vd = vd; c.va = va; c.dmin = dmin; c.dmax = dmax; c.amin = amin; c.amax = amax; c.use_angle = use_angle; c.n_keep = nk; c.V = V; c.tie = tie;
       cuts[h] = c;

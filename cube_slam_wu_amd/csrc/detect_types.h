@@ -93,6 +93,8 @@ struct RankView {
   RankWinner* winners;   // n_boxes * kmax
   int* win_count;        // n_boxes
   int* fallback;         // n_boxes: 1 = a tie made the host ordering matter; redo this box on the host
+  long long* last_slot;  // n_boxes or null: slot of the last proposal fuse_normalize_scores_v2 keeps for the box's last height sample
+                         // (-1 = none) -- with roll/pitch sampling the next box of the frame starts from that proposal's camera yaw
 };
 
 }  // namespace cs

@@ -196,6 +196,31 @@ def test_many_tie_boxes_take_the_separate_host_pass():
     assert tm["n_fallback_boxes"] == 80
 
 
+def test_device_ranking_with_roll_pitch_sampling_carries_camera_yaw():
+    """The reference's default mode: 25 camera poses per box, and the camera yaw the next box of the frame starts from is the
+    yaw of the pose of the LAST proposal the previous box's ranking kept.  The device ranking hands that proposal back
+    (rank_kernel last_slot); the final records of every box -- whose yaw lists depend on it -- must be the oracle's."""
+    frames = [synth.make_frame(8500 + s, n_boxes=4, n_lines=250) for s in range(4)]
+    n, tm = _check_final(frames, capi.default_params(whether_sample_cam_roll_pitch=1, yaw_step_deg=6.0))
+    assert n >= 12 and tm["rank_kernel_ms"] > 0 and tm["rank_host_ms"] == 0
+    # with height sampling and several winners per box
+    frames = [synth.make_frame(8600 + s, n_boxes=3, n_lines=200, sample_height=True) for s in range(3)]
+    n, tm = _check_final(frames, capi.default_params(whether_sample_cam_roll_pitch=1, whether_sample_bbox_height=1, max_cuboid_num=3, yaw_step_deg=6.0))
+    assert n >= 9 and tm["rank_host_ms"] == 0
+
+
+def test_device_ranking_with_roll_pitch_sampling_ties_go_to_the_host():
+    """Constant distance maps: every cut is a tie, the last kept proposal is the heap order's choice -- the box (and the yaw it
+    leaves behind) comes from the exact host ranking."""
+    frames = []
+    for s in range(2):
+        fr = synth.make_frame(8700 + s, n_boxes=3, n_lines=200)
+        fr["maps"] = [[np.zeros_like(m) for m in mm] for mm in fr["maps"]]
+        frames.append(fr)
+    n, tm = _check_final(frames, capi.default_params(whether_sample_cam_roll_pitch=1, yaw_step_deg=6.0))
+    assert tm["n_fallback_boxes"] == 6
+
+
 def test_host_ranking_path_still_exact():
     frames = [synth.make_frame(8300)]
     det = capi.Detector(capi.default_params(whether_sample_cam_roll_pitch=0))
