@@ -84,11 +84,13 @@ def project_bbox(T_cw7, cub10, K):
     return np.array([(u.max() + u.min()) / 2, (v.max() + v.min()) / 2, u.max() - u.min(), v.max() - v.min()])
 
 
-def make_problem(n_cams=200, n_points=20000, n_cuboids=50, seed=42, huber=True, obs_per_point=5, obs_per_cuboid=20, bbox_edges=False):
+def make_problem(n_cams=200, n_points=20000, n_cuboids=50, seed=42, huber=True, obs_per_point=5, obs_per_cuboid=20, bbox_edges=False, loop=False):
+    """loop=True: the path is a closed circle -- the last cameras see the landmarks (and cuboids) of the first ones and an odometry
+    edge joins camera n-1 to camera 0: a loop closure.  The block graph of the reduced system is then a ring, not a chain."""
     rng = np.random.default_rng(seed)
-    # ---- trajectory: arc of radius 400 m, camera z forward along the tangent, y down, x right
+    # ---- trajectory: arc of radius 400 m (loop: the full circle the cameras fill), camera z forward along the tangent, y down, x right
     s = 0.8 * np.arange(n_cams)
-    Rad = 400.0
+    Rad = 0.8 * n_cams / (2 * np.pi) if loop else 400.0
     ang = s / Rad
     pos = np.stack([Rad * np.sin(ang), Rad * (1 - np.cos(ang)), np.full(n_cams, 1.65)], 1)
     fwd = np.stack([np.cos(ang), np.sin(ang), np.zeros(n_cams)], 1)
@@ -112,6 +114,8 @@ def make_problem(n_cams=200, n_points=20000, n_cuboids=50, seed=42, huber=True, 
         obs = []
         for d in range(obs_per_point):
             cam = anchor - d
+            if loop:
+                cam = cam % n_cams
             valid = cam >= 0
             camc = np.clip(cam, 0, n_cams - 1)
             p = quat_rot(T_cw_true[camc, 3:], pw) + T_cw_true[camc, :3]
@@ -143,8 +147,8 @@ def make_problem(n_cams=200, n_points=20000, n_cuboids=50, seed=42, huber=True, 
     cub_true = np.zeros((n_cuboids, 10))
     ce_cam, ce_cub, ce_meas, ce_info = [], [], [], []
     for o in range(n_cuboids):
-        c0 = int(rng.integers(0, max(1, n_cams - obs_per_cuboid)))
-        mid = min(n_cams - 1, c0 + obs_per_cuboid // 2)
+        c0 = int(rng.integers(0, n_cams if loop else max(1, n_cams - obs_per_cuboid)))
+        mid = (c0 + obs_per_cuboid // 2) % n_cams if loop else min(n_cams - 1, c0 + obs_per_cuboid // 2)
         side = rng.choice([-1.0, 1.0]) * rng.uniform(3, 7)
         ahead = rng.uniform(10, 18)
         half = np.array([rng.uniform(1.5, 2.4), rng.uniform(0.7, 1.0), rng.uniform(0.5, 0.76)])
@@ -156,7 +160,7 @@ def make_problem(n_cams=200, n_points=20000, n_cuboids=50, seed=42, huber=True, 
         if cub_true[o, 6] < 0:
             cub_true[o, 3:7] *= -1
         cub_true[o, 7:] = half
-        for c in range(c0, min(n_cams, c0 + obs_per_cuboid)):
+        for c in ([cc % n_cams for cc in range(c0, c0 + obs_per_cuboid)] if loop else range(c0, min(n_cams, c0 + obs_per_cuboid))):
             local = pose_mul(T_cw_true[c], cub_true[o, :7])
             noisy = pose_mul(local, small_pose(rng, 1, 0.05, 0.05)[0])
             q = rng.uniform(0.5, 1.0)
@@ -166,9 +170,11 @@ def make_problem(n_cams=200, n_points=20000, n_cuboids=50, seed=42, huber=True, 
     # ---- odometry
     oe_i = np.arange(n_cams - 1, dtype=np.int32)
     oe_j = oe_i + 1
-    oe_meas = pose_mul(T_cw_true[1:], pose_inv(T_cw_true[:-1]))   # error = log(C * T_i * T_j^-1) = 0 for C = T_j T_i^-1
-    oe_meas = pose_mul(small_pose(rng, n_cams - 1, 0.002, 0.01), oe_meas)
-    oe_info = np.tile(np.eye(6).ravel(), (n_cams - 1, 1))
+    if loop:
+        oe_i = np.append(oe_i, np.int32(n_cams - 1)); oe_j = np.append(oe_j, np.int32(0))
+    oe_meas = pose_mul(T_cw_true[oe_j], pose_inv(T_cw_true[oe_i]))   # error = log(C * T_i * T_j^-1) = 0 for C = T_j T_i^-1
+    oe_meas = pose_mul(small_pose(rng, len(oe_i), 0.002, 0.01), oe_meas)
+    oe_info = np.tile(np.eye(6).ravel(), (len(oe_i), 1))
 
     # ---- initial estimates
     cams0 = pose_mul(small_pose(rng, n_cams, 0.02, 0.1), T_cw_true)

@@ -435,6 +435,40 @@ def test_c3_at_its_named_size_against_the_oracle():
     G.close(); R.close()
 
 
+def test_loop_closure_stays_on_the_banded_solver_and_matches_the_oracle():
+    """A closed trajectory (the last cameras re-observe the first landmarks, an odometry edge joins camera n-1 to camera 0): the
+    block graph of the reduced system is a ring.  Reverse Cuthill-McKee walks a ring from one vertex in both directions, so the
+    bandwidth about doubles against the open chain -- still a narrow band, still the persistent banded Cholesky, not the dense
+    fallback -- and the LM trajectory is the oracle's."""
+    open_pr = synth_ba.make_problem(n_cams=300, n_points=9000, n_cuboids=12, seed=11)
+    pr = synth_ba.make_problem(n_cams=300, n_points=9000, n_cuboids=12, seed=11, loop=True)
+    assert len(pr["oe_i"]) == 300 and pr["oe_j"][-1] == 0
+    G0 = capi.ba_from_dict(open_pr)
+    G0.optimize(1)
+    ld_open, _ = G0.solver_layout()
+    n_open, _ = G0.reduced_size()
+    G0.close()
+    G, R = capi.ba_from_dict(pr), _oracle(pr)
+    n_g, n_r = G.optimize(6), R.optimize(6)
+    ld_loop, _ = G.solver_layout()
+    n_loop, _ = G.reduced_size()
+    assert ld_open > 0 and ld_loop > 0, (ld_open, ld_loop)                      # banded in both cases
+    assert ld_loop <= 2.6 * ld_open and ld_loop < n_loop // 4, (ld_open, ld_loop, n_open, n_loop)
+    assert n_g == n_r == 6
+    chi_g, lam_g, tr_g = G.history()
+    chi_r, lam_r, tr_r = R.history()
+    assert np.array_equal(tr_g, tr_r)
+    assert np.allclose(chi_g, chi_r, rtol=1e-6) and np.allclose(lam_g, lam_r, rtol=1e-6)
+    cg, og, pg = G.state()
+    cr, orr, prr = R.state()
+    scale = np.abs(prr).max()
+    assert np.abs(pg - prr).max() < 1e-5 * scale
+    assert np.abs(cg[:, :3] - cr[:, :3]).max() < 1e-5 * scale and np.abs(cg[:, 3:] - cr[:, 3:]).max() < 1e-5
+    assert np.abs(og[:, :3] - orr[:, :3]).max() < 1e-5 * scale and np.abs(og[:, 3:] - orr[:, 3:]).max() < 1e-5
+    print("loop closure: band_ld %d (open chain %d), reduced unknowns %d" % (ld_loop, ld_open, n_loop))
+    G.close(); R.close()
+
+
 def test_c5_eight_shards_of_the_c4_problem_equal_the_single_rank_run():
     """BASELINE.json config C5: the C4 problem (1 000 cameras, 200 000 points, 500 cuboids) cut into 8 camera subsequences.
     Eight cs_ba handles share one GPU here (one thread each, in-process all-reduce); the sharded LM trajectory must be the
