@@ -20,6 +20,7 @@
 #include <limits>
 #include <string>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/cubeslam_hip.h"
@@ -30,6 +31,7 @@ int ba_chi2_blocks(int n_proj);
 void ba_launch_chi2(const BaView& v, int nb_proj, hipStream_t st);
 void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join);
 void ba_launch_reduce(const BaView& v, double lambda, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join);
+void ba_launch_gather_rows(const double* src, const int* idx, int n, int width, double* dst, hipStream_t st);
 void ba_launch_backsub(const BaView& v, hipStream_t st);
 int ba_scale_blocks();
 void ba_launch_scale(const BaView& v, double lambda_pose, double lambda_lm, double* partial, hipStream_t st);
@@ -213,11 +215,31 @@ int finalize_structure(cs_ba* B) {
     for (int i = 0; i < np; i++) cam_cnt[i + 1] += cam_cnt[i];
     std::vector<int> fill(cam_cnt.begin(), cam_cnt.end() - 1);
     for (int k = 0; k < B->n_proj; k++) cams_of[fill[B->e_pt[k]]++] = B->e_cam[k];
+    {   // every landmark's camera list sorted (independent little sorts: a few host threads on disjoint ranges)
+      auto sort_lists = [&](int p0, int p1) { for (int p = p0; p < p1; p++) std::sort(cams_of.begin() + cam_cnt[p], cams_of.begin() + cam_cnt[p + 1]); };
+      const int NT = (B->n_proj > 100000) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+      if (NT > 1) {
+        std::vector<std::thread> th;
+        for (int t = 0; t < NT; t++) th.emplace_back(sort_lists, (int)((long long)np * t / NT), (int)((long long)np * (t + 1) / NT));
+        for (auto& t : th) t.join();
+      } else sort_lists(0, np);
+    }
     for (int p = 0; p < np; p++) {
-      std::sort(cams_of.begin() + cam_cnt[p], cams_of.begin() + cam_cnt[p + 1]);
       for (int a = cam_cnt[p] + 1; a < cam_cnt[p + 1]; a++)
         if (cams_of[a] == cams_of[a - 1]) { cs_set_error_ba("two projection edges between the same point and camera"); return CS_ERR_INVALID_ARG; }
       if (!B->pt_fixed[p] && cam_cnt[p + 1] > cam_cnt[p]) gorder.push_back(p);
+    }
+    // sort key = (number of cameras, first three camera ids) in one word: it decides almost every comparison of the sort below;
+    // the full lexicographic comparison only runs for landmarks that agree on it (same order as without the key)
+    std::vector<unsigned long long> gkey;
+    if (nc < (1 << 20)) {
+      gkey.resize(np);
+      for (int p : gorder) {
+        const int kp = cam_cnt[p + 1] - cam_cnt[p];
+        unsigned long long key = (unsigned long long)std::min(kp, 7) << 60;
+        for (int a = 0; a < 3; a++) key |= (unsigned long long)(a < kp ? cams_of[cam_cnt[p] + a] + 1 : 0) << (40 - 20 * a);
+        gkey[p] = key;
+      }
     }
     auto same_set = [&](int p, int q) {
       const int kp = cam_cnt[p + 1] - cam_cnt[p];
@@ -226,6 +248,7 @@ int finalize_structure(cs_ba* B) {
     std::sort(gorder.begin(), gorder.end(), [&](int p, int q) {
       const int kp = cam_cnt[p + 1] - cam_cnt[p], kq = cam_cnt[q + 1] - cam_cnt[q];
       if (kp != kq) return kp < kq;
+      if (!gkey.empty() && kp <= 7 && gkey[p] != gkey[q]) return gkey[p] < gkey[q];
       const int c = std::lexicographical_compare(cams_of.begin() + cam_cnt[p], cams_of.begin() + cam_cnt[p + 1], cams_of.begin() + cam_cnt[q], cams_of.begin() + cam_cnt[q + 1]);
       if (c) return true;
       if (std::lexicographical_compare(cams_of.begin() + cam_cnt[q], cams_of.begin() + cam_cnt[q + 1], cams_of.begin() + cam_cnt[p], cams_of.begin() + cam_cnt[p + 1])) return false;
@@ -362,24 +385,31 @@ int finalize_structure(cs_ba* B) {
     for (int i = 0; i < np; i++) off[i + 1] += off[i];
     std::vector<int> fill(off.begin(), off.end() - 1);
     for (int k = 0; k < E; k++) order[fill[B->e_pt[B->keep[k]]]++] = k;
-    for (int p = 0; p < np; p++)
-      std::stable_sort(order.begin() + off[p], order.begin() + off[p + 1], [&](int a, int b) {
-        const int ka = B->keep[a], kb = B->keep[b];
-        if (B->cam_col[B->e_cam[ka]] != B->cam_col[B->e_cam[kb]]) return B->cam_col[B->e_cam[ka]] < B->cam_col[B->e_cam[kb]];
-        return B->e_cam[ka] < B->e_cam[kb];   // fixed cameras (column -1) by id: landmarks with one camera set share one slot order
-      });
+    // (200 k independent little sorts at C4: a few host threads, disjoint ranges of `order`)
+    auto sort_points = [&](int p0, int p1) {
+      for (int p = p0; p < p1; p++)
+        std::stable_sort(order.begin() + off[p], order.begin() + off[p + 1], [&](int a, int b) {
+          const int ka = B->keep[a], kb = B->keep[b];
+          if (B->cam_col[B->e_cam[ka]] != B->cam_col[B->e_cam[kb]]) return B->cam_col[B->e_cam[ka]] < B->cam_col[B->e_cam[kb]];
+          return B->e_cam[ka] < B->e_cam[kb];   // fixed cameras (column -1) by id: landmarks with one camera set share one slot order
+        });
+    };
+    const int NT = (E > 100000) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+    if (NT > 1) {
+      std::vector<std::thread> th;
+      for (int t = 0; t < NT; t++) th.emplace_back(sort_points, (int)((long long)np * t / NT), (int)((long long)np * (t + 1) / NT));
+      for (auto& t : th) t.join();
+    } else sort_points(0, np);
   }
+  // The edge tables themselves (88 bytes per edge) go up once in the caller's order and are permuted on the device: point-major
+  // rows by src_of_slot, camera-major rows from the point-major ones by cm_pm.  The host only builds the index arrays.
   B->pm_of_orig.assign(B->n_proj, -1);
-  std::vector<int> pm_pt(E), pm_cam(E), pt_ptr(np + 1, 0);
-  std::vector<double> pm_uv(2 * (size_t)E), pm_info(4 * (size_t)E), pm_intr(4 * (size_t)E), pm_huber(E);
+  std::vector<int> pm_pt(E), pm_cam(E), pt_ptr(np + 1, 0), src_of_slot(E);
   for (int s = 0; s < E; s++) {
     int k = B->keep[order[s]];
     B->pm_of_orig[k] = s;
+    src_of_slot[s] = k;
     pm_pt[s] = B->e_pt[k]; pm_cam[s] = B->e_cam[k];
-    std::memcpy(&pm_uv[2 * (size_t)s], &B->h_uv[2 * (size_t)k], 16);
-    std::memcpy(&pm_info[4 * (size_t)s], &B->h_info[4 * (size_t)k], 32);
-    std::memcpy(&pm_intr[4 * (size_t)s], &B->h_intr[4 * (size_t)k], 32);
-    pm_huber[s] = B->h_huber.empty() ? 0.0 : B->h_huber[k];
     pt_ptr[pm_pt[s] + 1]++;
   }
   for (int i = 0; i < np; i++) pt_ptr[i + 1] += pt_ptr[i];
@@ -390,16 +420,27 @@ int finalize_structure(cs_ba* B) {
     std::vector<int> fill(cam_ptr.begin(), cam_ptr.end() - 1);
     for (int s = 0; s < E; s++) { int q = fill[pm_cam[s]]++; cm_pm[q] = s; cm_pt[q] = pm_pt[s]; }
   }
-  std::vector<double> cm_uv(2 * (size_t)E), cm_info(4 * (size_t)E), cm_intr(4 * (size_t)E), cm_huber(E);
-  for (int q = 0; q < E; q++) {
-    int s = cm_pm[q];
-    std::memcpy(&cm_uv[2 * (size_t)q], &pm_uv[2 * (size_t)s], 16);
-    std::memcpy(&cm_info[4 * (size_t)q], &pm_info[4 * (size_t)s], 32);
-    std::memcpy(&cm_intr[4 * (size_t)q], &pm_intr[4 * (size_t)s], 32);
-    cm_huber[q] = pm_huber[s];
+  UP(B->cm_pm, cm_pm);
+  {
+    DBuf<double> raw_uv, raw_info, raw_intr, raw_huber;
+    DBuf<int> d_src;
+    struct Free { DBuf<double>*a, *b, *c, *d; DBuf<int>* e; ~Free() { a->release(); b->release(); c->release(); d->release(); e->release(); } } guard{&raw_uv, &raw_info, &raw_intr, &raw_huber, &d_src};
+    UP(raw_uv, B->h_uv); UP(raw_info, B->h_info); UP(raw_intr, B->h_intr); UP(d_src, src_of_slot);
+    AL(B->pm_uv, 2 * (size_t)E); AL(B->pm_info, 4 * (size_t)E); AL(B->pm_intr, 4 * (size_t)E); AL(B->pm_huber, (size_t)E);
+    AL(B->cm_uv, 2 * (size_t)E); AL(B->cm_info, 4 * (size_t)E); AL(B->cm_intr, 4 * (size_t)E); AL(B->cm_huber, (size_t)E);
+    cs::ba_launch_gather_rows(raw_uv.p, d_src.p, E, 2, B->pm_uv.p, B->st);
+    cs::ba_launch_gather_rows(raw_info.p, d_src.p, E, 4, B->pm_info.p, B->st);
+    cs::ba_launch_gather_rows(raw_intr.p, d_src.p, E, 4, B->pm_intr.p, B->st);
+    if (!B->h_huber.empty()) { UP(raw_huber, B->h_huber); cs::ba_launch_gather_rows(raw_huber.p, d_src.p, E, 1, B->pm_huber.p, B->st); }   // (else: zeros from the allocation)
+    cs::ba_launch_gather_rows(B->pm_uv.p, B->cm_pm.p, E, 2, B->cm_uv.p, B->st);
+    cs::ba_launch_gather_rows(B->pm_info.p, B->cm_pm.p, E, 4, B->cm_info.p, B->st);
+    cs::ba_launch_gather_rows(B->pm_intr.p, B->cm_pm.p, E, 4, B->cm_intr.p, B->st);
+    cs::ba_launch_gather_rows(B->pm_huber.p, B->cm_pm.p, E, 1, B->cm_huber.p, B->st);
+    BA_TRY(hipGetLastError());
+    BA_TRY(hipStreamSynchronize(B->st));
   }
-  UP(B->pm_pt, pm_pt); UP(B->pm_cam, pm_cam); UP(B->pt_ptr, pt_ptr); UP(B->pm_uv, pm_uv); UP(B->pm_info, pm_info); UP(B->pm_intr, pm_intr); UP(B->pm_huber, pm_huber);
-  UP(B->cm_pm, cm_pm); UP(B->cm_pt, cm_pt); UP(B->cam_ptr, cam_ptr); UP(B->cm_uv, cm_uv); UP(B->cm_info, cm_info); UP(B->cm_intr, cm_intr); UP(B->cm_huber, cm_huber);
+  UP(B->pm_pt, pm_pt); UP(B->pm_cam, pm_cam); UP(B->pt_ptr, pt_ptr);
+  UP(B->cm_pt, cm_pt); UP(B->cam_ptr, cam_ptr);
   mark("edge orderings + upload");
   // ---- Schur pattern (block_solver.hpp:262-292).  Fused path: segments of landmarks with one camera set + the destination
   // schedule of their partial blocks (BaView::fused).  It needs every landmark to be seen by <= BA_FUSED_KMAX cameras; otherwise

@@ -1908,6 +1908,21 @@ void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rh
 }
 
 // ---------------------------------------------------------------------------------------- launchers --
+// dst[r][0..width) = src[idx[r]][0..width): the structure phase's edge tables are permuted on the device (point-major order from
+// the caller's order, camera-major from point-major) instead of on the host + a second upload
+__global__ __launch_bounds__(256) void ba_gather_rows_kernel(const double* __restrict__ src, const int* __restrict__ idx, long long total, int width, double* __restrict__ dst) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const long long r = t / width;
+  const int c = (int)(t - r * width);
+  dst[t] = src[(long long)idx[r] * width + c];
+}
+void ba_launch_gather_rows(const double* src, const int* idx, int n, int width, double* dst, hipStream_t st) {
+  const long long total = (long long)n * width;
+  if (total <= 0) return;
+  hipLaunchKernelGGL(ba_gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, idx, total, width, dst);
+}
+
 int ba_chi2_blocks(int n_proj) { int nb = (n_proj + 255) / 256; return nb < 1 ? 1 : (nb > 2048 ? 2048 : nb); }
 
 void ba_launch_chi2(const BaView& v, int nb_proj, hipStream_t st) {
