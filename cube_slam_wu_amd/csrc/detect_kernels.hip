@@ -480,22 +480,24 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
   }
   // corners of the block's 256 proposals -> LDS.  A proposal's 16 doubles are one 128-byte line of the per-slot array: 16 lanes
   // fetch one proposal (a wave instruction touches 4 lines, not 64 as it would with one proposal per lane)
+  const int mine = s_src[threadIdx.x];
+  const JobDesc jd = v.jobs[s_job[mine]];      // requested together with the corners: it is the next thing the lane needs
   {
     const int k = threadIdx.x & 15;
-#pragma unroll 4
-    for (int it = 0; it < 16; it++) {
+    double cv[16];
+#pragma unroll
+    for (int it = 0; it < 16; it++) {          // all 16 loads of a thread in flight before the first one is stored
       const int p = it * 16 + (threadIdx.x >> 4);
       const int src = s_src[p];
-      if (base + src < n_valid) C16[k][p] = v.corners[16 * s_slot[src] + k];
+      cv[it] = (base + src < n_valid) ? v.corners[16 * s_slot[src] + k] : 0.0;
     }
+#pragma unroll
+    for (int it = 0; it < 16; it++) C16[k][it * 16 + (threadIdx.x >> 4)] = cv[it];
   }
   __syncthreads();
-  const int mine = s_src[threadIdx.x];
   const long long i = base + mine;
   if (i >= n_valid) return;                     // (no barrier below this point)
   const long long slot = s_slot[mine];
-  const int j = s_job[mine];
-  const JobDesc jd = v.jobs[j];
   const unsigned local = (unsigned)(slot - jd.slot_off);
   const int cfg = (int)(local & 1);          // 0 = configuration 1
   const int ry = (int)((local >> 1) / (unsigned)jd.T);
@@ -503,6 +505,13 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
   const int tx = threadIdx.x;
   const double ox = (double)jd.g.el, oy = (double)jd.g.et;
   const float* __restrict__ map = v.maps + jd.map_off;
+  // (the six VP-support angles of the angle term are requested here, ahead of the gathers: one round trip less on the block's path)
+  double bnd[6];
+  {
+    const double* bound = v.bound + 6 * (long long)(jd.vp_off + ry);
+#pragma unroll
+    for (int q = 0; q < 6; q++) bnd[q] = bound[q];
+  }
   // ---- distance error: all gathers of an edge are issued before its (sequential, float) accumulation
   float sum_dist = 0;
   // corner ids of the 9 edges, one nibble each (edge 0 lowest): {0,1,2,3,1,2,3,4,4}-{1,2,3,0,5,4,7,7,5} / {0,1,2,3,1,2,4,0,0}-{1,2,3,0,5,4,5,0,0}
@@ -541,13 +550,12 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
     }
   }
   // ---- angle alignment error
-  const double* bound = v.bound + 6 * (long long)(jd.vp_off + ry);
   double total = 0;
   const double not_found_penalty = 30.0 / 180.0 * CS_PI * 2;
   const int ID1[3][4] = {{0, 1, 7, 4}, {3, 0, 4, 5}, {3, 7, 1, 5}}, ID2[3][4] = {{0, 1, 2, 3}, {3, 0, 4, 5}, {2, 4, 1, 5}};
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    double b0 = bound[2 * k], b1 = bound[2 * k + 1];
+    double b0 = bnd[2 * k], b1 = bnd[2 * k + 1];
     bool v0 = !(b0 != b0), v1 = !(b1 != b1);
     if (v0 || v1) {
 #pragma unroll
