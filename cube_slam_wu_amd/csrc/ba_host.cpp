@@ -29,7 +29,7 @@
 namespace cs {
 int ba_chi2_blocks(int n_proj);
 void ba_launch_chi2(const BaView& v, int nb_proj, hipStream_t st);
-void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join);
+void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, hipStream_t st3, hipEvent_t ev_join3);
 void ba_launch_reduce(const BaView& v, double lambda, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join);
 void ba_launch_gather_rows(const double* src, const int* idx, int n, int width, double* dst, hipStream_t st);
 void ba_launch_backsub(const BaView& v, hipStream_t st);
@@ -109,6 +109,8 @@ struct cs_ba {
   hipStream_t st = nullptr;
   hipStream_t st2 = nullptr;                 // side stream of the reduce phase (cuboid elimination beside the landmark segments)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t st3 = nullptr;                 // third stream of the linearisation: the landmark kernel beside the camera kernel (which fills a fraction of the CUs)
+  hipEvent_t ev_join3 = nullptr;
   rocblas_handle blas = nullptr;
   hipEvent_t ev[8] = {};   // phase marks on the stream (linearise: 0-1; solve: 2 reduce 3 factor 4 back-substitution 5)
   bool lin_pending = false;  // ev[0..1] recorded but not yet read
@@ -725,7 +727,7 @@ int collect_lin_time(cs_ba* B) {
 
 int build_system_device(cs_ba* B) {
   BA_TRY(hipEventRecord(B->ev[0], B->st));
-  cs::ba_launch_linearize(B->view, B->st, B->st2, B->ev_fork, B->ev_join);
+  cs::ba_launch_linearize(B->view, B->st, B->st2, B->ev_fork, B->ev_join, B->st3, B->ev_join3);
   BA_TRY(hipGetLastError());
   BA_TRY(hipEventRecord(B->ev[1], B->st));
   B->lin_pending = true;
@@ -847,6 +849,8 @@ int cs_ba_create(int device, cs_ba** out) {
   BA_TRY(hipStreamCreateWithFlags(&B->st2, hipStreamNonBlocking));
   BA_TRY(hipEventCreateWithFlags(&B->ev_fork, hipEventDisableTiming));
   BA_TRY(hipEventCreateWithFlags(&B->ev_join, hipEventDisableTiming));
+  BA_TRY(hipStreamCreateWithFlags(&B->st3, hipStreamNonBlocking));
+  BA_TRY(hipEventCreateWithFlags(&B->ev_join3, hipEventDisableTiming));
   for (auto& e : B->ev) BA_TRY(hipEventCreate(&e));
   BA_TRY(hipHostMalloc((void**)&B->h_status, 2 * sizeof(int)));   // [factorisation status, a cuboid block failed]
   B->h_status[0] = B->h_status[1] = 0;
@@ -882,6 +886,8 @@ void cs_ba_destroy(cs_ba* B) {
   if (B->ev_fork) (void)hipEventDestroy(B->ev_fork);
   if (B->ev_join) (void)hipEventDestroy(B->ev_join);
   if (B->st2) (void)hipStreamDestroy(B->st2);
+  if (B->st3) (void)hipStreamDestroy(B->st3);
+  if (B->ev_join3) (void)hipEventDestroy(B->ev_join3);
   if (B->st) (void)hipStreamDestroy(B->st);
   delete B;
 }
