@@ -26,6 +26,45 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak = half the FP32 vector 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def measure_traffic_live(args, n_unique):
+    """HBM bytes per score_kernel launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, --kernel-trace only, as
+    MI355X_MICROARCH.md prescribes) over a short child run of the same workload; FETCH_SIZE x 2 + WRITE_SIZE x 1 (KiB -> bytes), the
+    factors of profiles/r2_pmc_calibration.json.  None when rocprofv3 is not available or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    # never a profiler inside a profiler: when this process itself runs under rocprofv3 / rocprofiler, report the tracked figure
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    avg = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="cs_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "2", "--warmup", "1", "--inflight", "1", "--ba", "none", "--no-cpu-baseline", "--no-edge", "--rp-frames", "0", "--no-measure-traffic",
+                   "--frames", str(args.frames), "--unique", str(n_unique)]
+            subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp", "CS_BENCH_CHILD": "1"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            n, tot = 0, 0.0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r.get("Counter_Name") == ctr and "score_kernel" in r.get("Kernel_Name", ""):
+                            n += 1
+                            tot += float(r["Counter_Value"])
+            if n == 0:
+                return None
+            avg[ctr] = tot / n
+        except (OSError, subprocess.SubprocessError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return avg["FETCH_SIZE"] * 1024 * 2 + avg["WRITE_SIZE"] * 1024
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -43,6 +82,9 @@ def main():
     ap.add_argument("--rp-frames", type=int, default=100, help="frames of the roll/pitch-sampling stress variant (RP = 25 poses per box, the reference's class default); 0 = skip")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight per GPU: each has its own detector (streams, worker pool) and is driven by its own host thread, "
                     "so one batch's host stages (packing, record writing) overlap the other's sweep on the device")
+    ap.add_argument("--no-measure-traffic", action="store_true", help="do not collect roofline.traffic in this run (two rocprofv3 --pmc passes -- FETCH_SIZE, WRITE_SIZE; "
+                    "kernel-trace only -- over a short child run of the same workload, ~20 s at N = 1); report the figure of the last tools/profile_round.sh "
+                    "(profiles/pmc_traffic.json) instead, which is also the fallback when rocprofv3 is missing or a pass fails")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -333,14 +375,21 @@ def main():
         # HBM traffic of the kernel as measured by the PMC passes of the same workload (profiles/pmc_traffic.json, written
         # by tools/profile_round.sh); null when this run's workload differs from the profiled one
         traffic = None
+        traffic_source = None
+        if not args.no_measure_traffic and world == 1 and not os.environ.get("CS_BENCH_CHILD"):
+            traffic = measure_traffic_live(args, n_unique)
+            traffic_source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate, kernel-trace only) over a child run of this workload, collected by this bench run" if traffic else None
         try:
+            if traffic is not None:
+                raise KeyError("measured live")
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
                 pt = json.load(fh)
             wl = pt["workload"]
             if wl["frames_per_batch"] == args.frames and wl["unique"] == n_unique and world == 1:
                 traffic = pt["kernels"]["score_kernel"]["hbm_bytes_per_launch"]
+                traffic_source = "profiles/pmc_traffic.json: the same passes run by tools/profile_round.sh on this workload (not collected in this run: --no-measure-traffic, N > 1, or rocprofv3 unavailable)"
         except (OSError, KeyError, ValueError):
-            traffic = None
+            pass
         out = {
             "metric": "frames/sec detect_cuboid", "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -356,7 +405,7 @@ def main():
                          "limiter": "fp64 VALU issue + gather latency (HBM traffic = algorithmic bytes)",
                          "traffic_correction": "FETCH_SIZE x 2 + WRITE_SIZE x 1: measured on known byte counts for 4/8/16-byte coalesced, 8-byte strided and 4-byte gather patterns (profiles/r2_pmc_calibration.json)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": kern_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "alg_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": kern_ms,
                          # the same kernel with nothing else on the device (warm-up steps, one batch in flight): with several batches in
                          # flight the timed region's launches share the CUs with the other batch's kernels
                          "isolated": ({"kernel_ms_per_launch": iso["score_kernel_ms"] / max(1, int(iso["cand_kernel_launches"])),

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel times of the BA path (C4) under rocprofv3:  tools/ba_kernel_times.sh <tag>
 tag=${1:-x}; R=$(pwd); export TMPDIR=/tmp; cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ba_${tag} -o prof -- python $R/bench.py --frames 50 --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_ba_${tag}.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ba_${tag} -o prof -- python $R/bench.py --no-measure-traffic --frames 50 --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_ba_${tag}.log 2>&1
 cd $R
 python - <<PY
 import csv

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel times of the detect path under rocprofv3:  tools/detect_kernel_times.sh <tag>
 tag=${1:-x}; R=$(pwd); export TMPDIR=/tmp; cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_det_${tag} -o prof -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --ba none > $R/gpurun_out/prof_det_${tag}.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_det_${tag} -o prof -- python $R/bench.py --no-measure-traffic --steps 5 --warmup 2 --no-cpu-baseline --ba none > $R/gpurun_out/prof_det_${tag}.log 2>&1
 cd $R
 python - <<PY
 import csv
