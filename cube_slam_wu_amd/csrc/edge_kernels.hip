@@ -141,11 +141,18 @@ __global__ __launch_bounds__(256) void edge_canny_kernel(const unsigned char* __
   }
 }
 
-// inclusive prefix minimum over the 64 lanes of a wave
+// inclusive prefix minimum over the 64 lanes of a wave, on DPP: shifts by 1, 2, 4, 8 inside each row of 16 lanes (a lane without
+// a source keeps the identity), then lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2 / 3.  Six VALU
+// instructions with their data path in the ALU -- the rows of the distance transform are a dependent chain of these scans,
+// and the shuffle version went through the LDS crossbar six times per scan.
 __device__ __forceinline__ int wave_prefix_min(int v) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { int u = __shfl_up(v, o); if (lane >= o) v = min(u, v); }
+  const int ID = 0x7fffffff;
+  v = min(v, __builtin_amdgcn_update_dpp(ID, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+  v = min(v, __builtin_amdgcn_update_dpp(ID, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+  v = min(v, __builtin_amdgcn_update_dpp(ID, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+  v = min(v, __builtin_amdgcn_update_dpp(ID, v, 0x118, 0xf, 0xf, false));   // row_shr:8
+  v = min(v, __builtin_amdgcn_update_dpp(ID, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+  v = min(v, __builtin_amdgcn_update_dpp(ID, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
   return v;
 }
 
@@ -155,21 +162,125 @@ __device__ __forceinline__ int wave_prefix_min(int v) {
 // Working values: OpenCV's are 16.16 fixed point in unsigned 32 bits, saturated at DIST_MAX = UINT_MAX - b ("no feature
 // reachable").  Every finite distance inside an image is below 2^30, so the kernel carries 2^30 for "unreachable" in
 // signed 32 bits (nothing overflows, sums stay ordered) and writes DIST_MAX's float for it; finite values are identical.
-__global__ __launch_bounds__(64) void edge_dt_kernel(const EdgeRoi* __restrict__ rois, const unsigned char* __restrict__ cls_pool, float* map_pool, int row_cap) {
-  extern __shared__ int row_lds_i[];        // two rows of row_cap + 2 values (border cells at both ends): neighbour row, current row
-  const EdgeRoi R = rois[blockIdx.x];
-  const unsigned char* cls = cls_pool + R.cls_off;
-  int* tmp = reinterpret_cast<int*>(map_pool + R.map_off);
+enum { DT_CHUNKS = 6, DT_AHEAD = 4 };   // ROI widths up to 384 columns take the register-pipelined instances, 4 rows of operands in flight
+struct DtArgs { const unsigned char* cls; int* tmp; int* row_lds; int row_cap, w, h; };
+
+// The two passes for a ROI of exactly NC chunks of 64 columns.  Per row: the global operands (class bytes on the way down, the
+// forward distances on the way up) were requested one row ahead; the NC scans are independent of each other and of the
+// carry, which only enters the last minimum -- so a row costs one LDS round trip (neighbour row), one scan latency and NC
+// carry steps, not NC times all of it.
+template <int NC>
+__device__ __forceinline__ void edge_dt_rows(const DtArgs& A) {
   const int HV = 62587, DIAG = 89738, INF = 1 << 30;
   const float scale = 1.f / (1 << 16);
   const float far = (float)(0xffffffffu - 89738u) * scale;     // what OpenCV writes where no feature is reachable
-  const int w = R.w, h = R.h, lane = threadIdx.x;
-  int* nb = row_lds_i + 1;                  // nb[-1 .. w]: the neighbour row
-  int* cur = row_lds_i + (row_cap + 2) + 1; // the row being produced (becomes the neighbour row of the next one)
+  const int w = A.w, h = A.h, lane = threadIdx.x;
+  const unsigned char* cls = A.cls;
+  int* tmp = A.tmp;
+  int* nb = A.row_lds + 1;                      // nb[-1 .. w]: the neighbour row
+  int* cur = A.row_lds + (A.row_cap + 2) + 1;   // the row being produced (becomes the neighbour row of the next one)
+  constexpr int D = DT_AHEAD;                   // rows whose global operands are in flight ahead of the row being computed
+  int pre[D][NC];
   // ---- forward: top-left to bottom-right
-  for (int j = lane; j < 2 * (row_cap + 2); j += 64) row_lds_i[j] = INF;
+  for (int j = lane; j < 2 * (A.row_cap + 2); j += 64) A.row_lds[j] = INF;
+#pragma unroll
+  for (int u = 0; u < D; u++)
+#pragma unroll
+    for (int c = 0; c < NC; c++) { const int j = c * 64 + lane; pre[u][c] = (j < w && u < h) ? cls[u * w + j] : 0; }
+  for (int i0 = 0; i0 < h; i0 += D) {
+#pragma unroll
+    for (int u = 0; u < D; u++) {
+      const int i = i0 + u;
+      if (i < h) {
+        int now[NC], d[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) now[c] = pre[u][c];
+        if (i + D < h) {
+#pragma unroll
+          for (int c = 0; c < NC; c++) { const int j = c * 64 + lane; if (j < w) pre[u][c] = cls[(i + D) * w + j]; }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+          const int j = c * 64 + lane;
+          int a = 0x7fffffff;
+          if (j < w) {
+            int t = 0;
+            if (now[c] != 2) t = min(min(nb[j - 1] + DIAG, nb[j] + HV), nb[j + 1] + DIAG);
+            a = t - j * HV;
+          }
+          const int s = wave_prefix_min(a);
+          d[c] = (s == 0x7fffffff) ? INF : s + j * HV;
+        }
+        int carry = INF;                            // d at the column left of the running chunk
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+          const int j0 = c * 64, j = j0 + lane;
+          const int v = min(min(d[c], carry + (lane + 1) * HV), INF);
+          if (j < w) { tmp[i * w + j] = v; cur[j] = v; }
+          carry = __builtin_amdgcn_readlane(v, min(63, max(0, w - 1 - j0)));
+        }
+        int* sw = nb; nb = cur; cur = sw;           // the row just produced becomes the neighbour row (border cells stay INF)
+      }
+    }
+  }
+  __syncthreads();   // (one wave) the forward values written by other lanes are read back below
+  // ---- backward: bottom-right to top-left (mirrored scan), writing the floats
+  for (int j = lane; j < 2 * (A.row_cap + 2); j += 64) A.row_lds[j] = INF;
+#pragma unroll
+  for (int u = 0; u < D; u++)
+#pragma unroll
+    for (int c = 0; c < NC; c++) { const int jr = c * 64 + 63 - lane; pre[u][c] = (jr < w && h - 1 - u >= 0) ? tmp[(h - 1 - u) * w + jr] : 0; }
+  for (int i0 = h - 1; i0 >= 0; i0 -= D) {
+#pragma unroll
+    for (int u = 0; u < D; u++) {
+      const int i = i0 - u;
+      if (i >= 0) {
+        int now[NC], d[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) now[c] = pre[u][c];
+        if (i - D >= 0) {
+#pragma unroll
+          for (int c = 0; c < NC; c++) { const int jr = c * 64 + 63 - lane; if (jr < w) pre[u][c] = tmp[(i - D) * w + jr]; }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+          const int jr = c * 64 + 63 - lane;        // lane 0 takes the chunk's rightmost column: scan order = right to left
+          int a = 0x7fffffff;
+          if (jr < w) {
+            const int t0 = min(min(now[c], nb[jr + 1] + DIAG), min(nb[jr] + HV, nb[jr - 1] + DIAG));
+            a = t0 + jr * HV;                       // d[j] = min over k >= j of u[k] + (k - j) HV
+          }
+          const int s = wave_prefix_min(a);
+          d[c] = (s == 0x7fffffff) ? INF : s - jr * HV;
+        }
+        int carry = INF;                            // d at the column right of the running chunk
+#pragma unroll
+        for (int cc = 0; cc < NC; cc++) {
+          const int c = NC - 1 - cc, j0 = c * 64, jr = j0 + 63 - lane;
+          const int chunk_right = min(w - 1, j0 + 63);
+          const int v = min(min(d[c], carry + (chunk_right - jr + 1) * HV), INF);
+          if (jr < w) { cur[jr] = v; reinterpret_cast<float*>(tmp)[i * w + jr] = (v >= INF) ? far : (float)(unsigned)v * scale; }
+          carry = __builtin_amdgcn_readlane(v, 63);   // the chunk's leftmost column
+        }
+        int* sw = nb; nb = cur; cur = sw;
+      }
+    }
+  }
+}
+
+// any width: the plain loop over chunks (no prefetch, chunk after chunk)
+__device__ __forceinline__ void edge_dt_rows_wide(const DtArgs& A) {
+  const int HV = 62587, DIAG = 89738, INF = 1 << 30;
+  const float scale = 1.f / (1 << 16);
+  const float far = (float)(0xffffffffu - 89738u) * scale;
+  const int w = A.w, h = A.h, lane = threadIdx.x;
+  const unsigned char* cls = A.cls;
+  int* tmp = A.tmp;
+  int* nb = A.row_lds + 1;
+  int* cur = A.row_lds + (A.row_cap + 2) + 1;
+  for (int j = lane; j < 2 * (A.row_cap + 2); j += 64) A.row_lds[j] = INF;
   for (int i = 0; i < h; i++) {
-    int carry = INF;                        // d at the column left of the running chunk
+    int carry = INF;
     for (int j0 = 0; j0 < w; j0 += 64) {
       const int j = j0 + lane;
       int a = 0x7fffffff;
@@ -182,32 +293,47 @@ __global__ __launch_bounds__(64) void edge_dt_kernel(const EdgeRoi* __restrict__
       d = (d == 0x7fffffff) ? INF : d + j * HV;
       d = min(min(d, carry + (lane + 1) * HV), INF);
       if (j < w) { tmp[i * w + j] = d; cur[j] = d; }
-      carry = __shfl(d, min(63, w - 1 - j0));
+      carry = __builtin_amdgcn_readlane(d, min(63, w - 1 - j0));
     }
-    int* sw = nb; nb = cur; cur = sw;       // the row just produced becomes the neighbour row (border cells stay INF)
+    int* sw = nb; nb = cur; cur = sw;
   }
-  __syncthreads();   // (one wave) the forward values written by other lanes are read back below
-  // ---- backward: bottom-right to top-left (mirrored scan), writing the floats
-  for (int j = lane; j < 2 * (row_cap + 2); j += 64) row_lds_i[j] = INF;
+  __syncthreads();
+  for (int j = lane; j < 2 * (A.row_cap + 2); j += 64) A.row_lds[j] = INF;
+  const int nchunk = (w + 63) / 64;
   for (int i = h - 1; i >= 0; i--) {
-    int carry = INF;                        // d at the column right of the running chunk
-    const int nchunk = (w + 63) / 64;
+    int carry = INF;
     for (int cch = nchunk - 1; cch >= 0; cch--) {
       const int j0 = cch * 64;
-      const int jr = j0 + 63 - lane;        // lane 0 takes the chunk's rightmost column: scan order = right to left
+      const int jr = j0 + 63 - lane;
       int a = 0x7fffffff;
       if (jr < w) {
         const int t0 = min(min(tmp[i * w + jr], nb[jr + 1] + DIAG), min(nb[jr] + HV, nb[jr - 1] + DIAG));
-        a = t0 + jr * HV;                   // d[j] = min over k >= j of u[k] + (k - j) HV
+        a = t0 + jr * HV;
       }
       int d = wave_prefix_min(a);
       d = (d == 0x7fffffff) ? INF : d - jr * HV;
       const int chunk_right = min(w - 1, j0 + 63);
       d = min(min(d, carry + (chunk_right - jr + 1) * HV), INF);
       if (jr < w) { cur[jr] = d; reinterpret_cast<float*>(tmp)[i * w + jr] = (d >= INF) ? far : (float)(unsigned)d * scale; }
-      carry = __shfl(d, 63);                 // the chunk's leftmost column
+      carry = __builtin_amdgcn_readlane(d, 63);
     }
     int* sw = nb; nb = cur; cur = sw;
+  }
+}
+
+__global__ __launch_bounds__(64) void edge_dt_kernel(const EdgeRoi* __restrict__ rois, const unsigned char* __restrict__ cls_pool, float* map_pool, int row_cap) {
+  extern __shared__ int row_lds_i[];        // two rows of row_cap + 2 values (border cells at both ends): neighbour row, current row
+  const EdgeRoi R = rois[blockIdx.x];
+  const DtArgs A{cls_pool + R.cls_off, reinterpret_cast<int*>(map_pool + R.map_off), row_lds_i, row_cap, R.w, R.h};
+  switch ((R.w + 63) / 64) {
+    case 0: break;
+    case 1: edge_dt_rows<1>(A); break;
+    case 2: edge_dt_rows<2>(A); break;
+    case 3: edge_dt_rows<3>(A); break;
+    case 4: edge_dt_rows<4>(A); break;
+    case 5: edge_dt_rows<5>(A); break;
+    case 6: edge_dt_rows<6>(A); break;
+    default: edge_dt_rows_wide(A); break;
   }
 }
 
