@@ -39,10 +39,12 @@ __device__ __forceinline__ int edge_mag(const unsigned char* __restrict__ g, int
 // class per pixel: 0 = may belong to an edge, 1 = not an edge, 2 = edge.  Pass 1: one Sobel per pixel, L1 magnitude and
 // the suppression sector packed into the (not yet used) output buffer; pass 2: non-maximum suppression + thresholds
 // from the packed values; then hysteresis.  Waves walk rows, lanes walk columns (no divisions).
+enum { CANNY_BAND = 16, CANNY_TILE_W = 448 };   // LDS band of the fused Sobel + suppression: 18 x 450 x 2 bytes = 16 KB
 __global__ __launch_bounds__(256) void edge_canny_kernel(const unsigned char* __restrict__ gray, int W, int H, const EdgeRoi* __restrict__ rois, unsigned char* cls_pool,
                                                          float* map_pool, int low, int high) {
   __shared__ int n_front[2];
   __shared__ int changed;
+  __shared__ unsigned short canny_lds[(CANNY_BAND + 2) * (CANNY_TILE_W + 2)];
   const EdgeRoi R = rois[blockIdx.x];
   gray += R.img_off;
   unsigned char* cls = cls_pool + R.cls_off;
@@ -50,6 +52,55 @@ __global__ __launch_bounds__(256) void edge_canny_kernel(const unsigned char* __
   const int n = R.w * R.h;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int TG22 = 13573;
+  if (R.w <= CANNY_TILE_W) {
+    // ROIs up to CANNY_TILE_W columns: bands of CANNY_BAND rows through LDS.  The band's magnitudes (11 bits) and sectors (2 bits)
+    // sit in LDS as 16-bit words with a zero frame (cv::Canny's zero-padded magnitude buffer), one halo row above and below;
+    // the suppression reads its neighbours there.  Nothing but the class bytes goes to memory (the wide path below writes and
+    // re-reads a 4-byte word per pixel: that traffic, 3 GB per 8000 ROIs through L2, was most of the kernel).
+    const int ldw = R.w + 2;
+    for (int b0 = 0; b0 < R.h; b0 += CANNY_BAND) {
+      const int rows = min(CANNY_BAND, R.h - b0);
+      __syncthreads();                                   // the previous band's readers are done
+      for (int r = wv; r < rows + 2; r += 4) {           // LDS row r = ROI row b0 - 1 + r
+        const int i = b0 - 1 + r;
+        for (int c = lane; c < ldw; c += 64) {           // LDS column c = ROI column c - 1
+          const int j = c - 1;
+          unsigned short pv = 0;
+          if (i >= 0 && i < R.h && j >= 0 && j < R.w) {
+            int xs, ys;
+            edge_sobel(gray, W, H, R.l + j, R.t + i, xs, ys);
+            const int x = abs(xs), y = abs(ys) << 15;
+            const int tg22x = x * TG22;
+            unsigned sector;
+            if (y < tg22x) sector = 0;
+            else if (y > tg22x + (x << 16)) sector = 1;
+            else sector = ((xs ^ ys) < 0) ? 3u : 2u;
+            pv = (unsigned short)((unsigned)(abs(xs) + abs(ys)) | (sector << 11));     // |gx| + |gy| <= 2040 < 2^11
+          }
+          canny_lds[r * ldw + c] = pv;
+        }
+      }
+      __syncthreads();
+      for (int r = wv; r < rows; r += 4) {
+        const int i = b0 + r;
+        const unsigned short* up = canny_lds + r * ldw, *mid = up + ldw, *dn = mid + ldw;   // LDS rows of ROI rows i - 1, i, i + 1
+        for (int j = lane; j < R.w; j += 64) {
+          const unsigned v = mid[j + 1];
+          const int m = (int)(v & 0x7ffu);
+          unsigned char c = 1;
+          if (m > low) {
+            const unsigned sector = v >> 11;
+            bool keep;
+            if (sector == 0) keep = m > (int)(mid[j] & 0x7ffu) && m >= (int)(mid[j + 2] & 0x7ffu);
+            else if (sector == 1) keep = m > (int)(up[j + 1] & 0x7ffu) && m >= (int)(dn[j + 1] & 0x7ffu);
+            else { const int sg = (sector == 3) ? -1 : 1; keep = m > (int)(up[j + 1 - sg] & 0x7ffu) && m > (int)(dn[j + 1 + sg] & 0x7ffu); }
+            if (keep) c = (m > high) ? 2 : 0;
+          }
+          cls[i * R.w + j] = c;
+        }
+      }
+    }
+  } else {
   for (int i = wv; i < R.h; i += 4)
     for (int j = lane; j < R.w; j += 64) {
       int xs, ys;
@@ -79,6 +130,7 @@ __global__ __launch_bounds__(256) void edge_canny_kernel(const unsigned char* __
       }
       cls[i * R.w + j] = c;
     }
+  }
   __syncthreads();
   // hysteresis = 8-connected components of the surviving pixels that contain a strong one, by breadth-first growth from
   // the strong pixels: a frontier pixel claims its weak neighbours (atomic OR on the class word: exactly one claimant)
