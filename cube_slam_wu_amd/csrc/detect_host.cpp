@@ -369,6 +369,7 @@ struct cs_detector {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // tie-break re-ranking fetches of the previous chunk, concurrent with the next chunk's sweep
   hipStream_t stream3 = nullptr;   // line setup of the crowded ROIs, beside the line setup of all the others
+  hipStream_t stream_hi = nullptr; // high priority: the small fetches of the tie boxes, which the host waits for while another batch's sweep owns the device
   hipEvent_t ev[12] = {};
   int n_threads = 1;
   std::unique_ptr<WorkerPool> pool;
@@ -586,6 +587,11 @@ int cs_detector_create(const cs_detect_params* params, int device, cs_detector**
   HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&d->stream3, hipStreamNonBlocking));
+  {
+    int prio_low = 0, prio_high = 0;   // (numerically lowest = greatest priority)
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+    HIP_TRY(hipStreamCreateWithPriority(&d->stream_hi, hipStreamNonBlocking, prio_high));
+  }
   for (auto& e : d->ev) HIP_TRY(hipEventCreate(&e));
   int hc = (int)std::thread::hardware_concurrency();
   // default worker count: 64 on an unrestricted 256-thread EPYC (beats 32 and 128); under a cgroup CPU quota three threads
@@ -613,6 +619,7 @@ void cs_detector_destroy(cs_detector* d) {
   if (d->stream) (void)hipStreamDestroy(d->stream);
   if (d->stream2) (void)hipStreamDestroy(d->stream2);
   if (d->stream3) (void)hipStreamDestroy(d->stream3);
+  if (d->stream_hi) (void)hipStreamDestroy(d->stream_hi);
   delete d;
 }
 
@@ -1063,10 +1070,11 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
     tm.score_kernel_bytes += sbytes;
   }
   const cs::JobDesc* jobs = S.h_jobs_in.p;
-  hipStream_t st2 = d->stream2;
+  hipStream_t st2 = d->stream_hi;
   MARK(4, tq);   // wait for the GPU + timing bookkeeping
   // ---- boxes the kernel flagged (a tie at a cut or at the top): exact std::partial_sort ranking on the host.  Their
-  // columns are fetched on the second stream, concurrently with the next chunk's sweep on the first.
+  // columns are fetched on the high-priority stream: the host waits for them while other sweeps (the next chunk's, or another
+  // batch's of the same process) fill the device, and these few small kernels should not queue behind those.
   std::vector<long long> fb_src, fb_dst;
   std::vector<int> fb_cnt, fb_range_of_job(nj, -1);
   long long tot = 0;
