@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=0, help="cut the batch into this many chunks of the two-slot host/GPU pipeline (0 = library default)")
     ap.add_argument("--no-edge", action="store_true", help="skip the distance-map front end (Canny + distance transform) timing")
     ap.add_argument("--rp-frames", type=int, default=100, help="frames of the roll/pitch-sampling stress variant (RP = 25 poses per box, the reference's class default); 0 = skip")
-    ap.add_argument("--inflight", type=int, default=2, help="batches in flight per GPU: each has its own detector (streams, worker pool) and is driven by its own host thread, "
+    ap.add_argument("--inflight", type=int, default=4, help="batches in flight per GPU: each has its own detector (streams, worker pool) and is driven by its own host thread, "
                     "so one batch's host stages (packing, record writing) overlap the other's sweep on the device")
     ap.add_argument("--no-measure-traffic", action="store_true", help="do not collect roofline.traffic in this run (two rocprofv3 --pmc passes -- FETCH_SIZE, WRITE_SIZE; "
                     "kernel-trace only -- over a short child run of the same workload, ~20 s at N = 1); report the figure of the last tools/profile_round.sh "
@@ -134,7 +134,7 @@ def main():
     uniq = [synth.make_frame(100000 * (rank + 1) + s) for s in range(n_unique)]
     frames = [uniq[i % n_unique] for i in range(args.frames)]
     # host stages run on a worker pool per rank: with N ranks on one node the pools share the host's cores
-    # Batches in flight: every one is a full copy of the workload with its own detector; step s is run by pipeline s % inflight.
+    # Batches in flight: every one is a full copy of the workload with its own detector; the K steps are handed out first come, first served.
     import threading
     inflight = max(1, args.inflight)
     host_threads = args.host_threads
@@ -163,9 +163,19 @@ def main():
     accs = [dict() for _ in range(inflight)]
     errs = []
 
+    step_lock = threading.Lock()
+    steps_taken = [0]
+
+    def take_step():   # the K steps are a shared queue: a pipeline that finishes early takes the next one (no idle tail at small K)
+        with step_lock:
+            if steps_taken[0] >= args.steps:
+                return False
+            steps_taken[0] += 1
+            return True
+
     def drive(p):
         try:
-            for s_i in range(p, args.steps, inflight):
+            while take_step():
                 bats[p].run()
                 for k, v in bats[p].timing().items():
                     accs[p][k] = accs[p].get(k, 0) + v

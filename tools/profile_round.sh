@@ -1,13 +1,13 @@
 #!/bin/bash
 # Profiling recipe of a round (run on the GPU box through gpurun):  tools/profile_round.sh <tag>
-# 1. bench.py (full: detect + BA + CPU baseline) -> gpurun_out/bench_<tag>.json
+# 1. bench.py with its defaults, as the driver runs it (full: detect + BA + CPU baseline + the traffic passes) -> gpurun_out/bench_<tag>.json
 # 2. rocprofv3 --kernel-trace --stats of the same command -> gpurun_out/prof_<tag>/
 # 3. two PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, kernel-trace only) -> gpurun_out/pmc_<tag>_{fetch,write}/
 tag=${1:-rX}
 R=$(pwd)
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-python bench.py --steps 10 --warmup 2 > gpurun_out/bench_${tag}.json 2> gpurun_out/bench_${tag}.err
+python bench.py > gpurun_out/bench_${tag}.json 2> gpurun_out/bench_${tag}.err
 tail -c 3000 gpurun_out/bench_${tag}.json
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag} -o prof -- python $R/bench.py --no-measure-traffic --steps 10 --warmup 2 --no-cpu-baseline --rp-frames 0 > $R/gpurun_out/bench_prof_${tag}.log 2>&1
