@@ -615,32 +615,47 @@ __global__ __launch_bounds__(1024) void scan_jobs_kernel(const int* job_valid, l
   if (threadIdx.x == 0) job_cbase[n_jobs] = carry_s;
 }
 
-// Ordered compaction: one block per job walks the job's slots in slot order.
+// Ordered compaction: one block per job walks the job's slots in slot order, 4096 per trip (a C2 job's 3 943 slots are one trip, a
+// roll/pitch job's 79 k twenty).  Each wave owns 1024 consecutive slots as COMPACT_PER groups of 64 (lane = slot inside the
+// group: coalesced loads, ballot for the order inside a group, a running count from group to group); one barrier per trip gives
+// the waves their offsets.
+enum { COMPACT_PER = 16 };
 __global__ __launch_bounds__(256) void compact_kernel(DetectDeviceView v) {
   int j = blockIdx.x;
   if (j >= v.n_jobs) return;
-  __shared__ int wcnt[4];
-  __shared__ long long run_s;
-  long long s0 = v.slot_prefix[j], s1 = v.slot_prefix[j + 1];
-  if (threadIdx.x == 0) run_s = v.job_cbase[j];
-  __syncthreads();
-  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (long long base = s0; base < s1; base += 256) {
-    long long s = base + threadIdx.x;
-    int f = (s < s1) ? v.flag[s] : 0;
-    unsigned long long b = __ballot(f != 0);
-    if (lane == 0) wcnt[wid] = __popcll(b);
-    __syncthreads();
-    long long off = run_s;
-    for (int w = 0; w < wid; w++) off += wcnt[w];
-    if (f != 0) {
-      long long pos = off + __popcll(b & ((1ull << lane) - 1ull));
-      v.c_slot[pos] = s;
-      v.c_flag[pos] = f | (j << CAND_JOB_SHIFT);
+  __shared__ int wsum[4];
+  const long long s0 = v.slot_prefix[j], s1 = v.slot_prefix[j + 1];
+  long long run = v.job_cbase[j];                       // (every thread carries the same running base)
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (long long base = s0; base < s1; base += 256 * COMPACT_PER) {
+    const long long w0 = base + (long long)wid * (64 * COMPACT_PER) + lane;
+    int f[COMPACT_PER];
+    int wcount = 0;
+#pragma unroll
+    for (int q = 0; q < COMPACT_PER; q++) {
+      const long long sl = w0 + q * 64;
+      f[q] = (sl < s1) ? v.flag[sl] : 0;
+      wcount += __popcll(__ballot(f[q] != 0));
     }
+    if (lane == 0) wsum[wid] = wcount;
     __syncthreads();
-    if (threadIdx.x == 0) run_s = off + wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const int x = wsum[w]; if (w < wid) woff += x; total += x; }
+    long long pos0 = run + woff;
+#pragma unroll
+    for (int q = 0; q < COMPACT_PER; q++) {
+      const unsigned long long bal = __ballot(f[q] != 0);
+      if (f[q] != 0) {
+        const long long pos = pos0 + __popcll(bal & below);
+        v.c_slot[pos] = w0 + q * 64;
+        v.c_flag[pos] = f[q] | (j << CAND_JOB_SHIFT);
+      }
+      pos0 += __popcll(bal);
+    }
+    run += total;
+    __syncthreads();                                    // wsum is rewritten by the next trip
   }
 }
 
