@@ -1,20 +1,21 @@
 // detect_host.cpp -- host side of path A (detect_cuboid) behind the C ABI of include/cubeslam_hip.h.
 //
-// Stages of one cs_batch_run():
-//   setup   (host, threaded)  per frame: camera cache (box_proposal_detail.cpp:45-56); per box and height
-//                             sample: integer box/ROI geometry (:143-256), ROI line filter (:271-283),
-//                             merge_break_lines (object_3d_util.cpp:431-543), line angles/midpoints
-//                             (:309-315), yaw / top-edge / roll-pitch sample lists (:180-184, :212-219,
-//                             :344-355)  ->  JobDesc + pooled SoA arrays, one H2D copy;
-//   sweep   (HIP)             vp_support_kernel, candidate_kernel, ordered compaction (detect_kernels.hip);
-//   rank    (host, threaded)  fuse_normalize_scores_v2 (object_3d_util.cpp:726-837) and the final
-//                             skew-weighted ranking (box_proposal_detail.cpp:766-838) on the compacted
-//                             (dist, angle, skew) columns;
-//   finish  (HIP + host)      gather the winners' corners, build the cs_cuboid records (:740-798,
-//                             object_3d_util.cpp:941-1011).
+// Stages of one cs_batch_run() (production path: pipe_launch / pipe_finish):
+//   setup   (host, threaded)  per frame: camera cache (box_proposal_detail.cpp:45-56); per box and height sample: integer
+//                             box/ROI geometry (:143-256), yaw / top-edge / roll-pitch sample lists (:180-184, :212-219,
+//                             :344-355)  ->  JobDesc + pooled SoA arrays in pinned memory, one H2D copy;
+//   sweep   (HIP, 3 streams)  line setup (ROI filter + merge_break_lines) and VP support on one stream, vanishing points +
+//                             corner construction + ordered compaction on a second, the crowded ROIs' line setup on a
+//                             third; the scorer joins them (detect_kernels.hip);
+//   rank    (HIP)             fuse_normalize_scores_v2 (object_3d_util.cpp:726-837) and the final skew-weighted ranking
+//                             (box_proposal_detail.cpp:766-838) on the compacted (dist, angle, skew) columns; only the
+//                             winners come back;
+//   finish  (host, threaded)  cs_cuboid records of the winners (:740-798, object_3d_util.cpp:941-1011); the few boxes whose
+//                             ties could reach the output are fetched and ranked with the exact std::partial_sort.
+// The same stages exist as a general round-based path (debug getters, host ranking / host line setup on request).
 // With whether_sample_cam_roll_pitch the reference carries cam_pose.camera_yaw from one box to the next
 // (:180 reads what :374/:734 left behind), so boxes of a frame are processed in rounds (round r = box r of
-// every frame); without it all boxes of all frames go through the sweep in one launch.
+// every frame), each ranked on the device; without it all boxes of all frames go through the sweep in one launch.
 //
 // There is no CPU fallback for the sweep: without a HIP device cs_detector_create() fails.
 #include <hip/hip_runtime.h>

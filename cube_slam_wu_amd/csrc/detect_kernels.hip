@@ -1,18 +1,25 @@
 // detect_kernels.hip -- HIP kernels of the cuboid proposal sweep for gfx950 (MI355X).
 //
-// What runs here (reference loops L3..L5, detect_3d_cuboid/src/box_proposal_detail.cpp:360-705):
-//   vp_support_kernel   one lane per (job, roll/pitch, yaw): vanishing points (object_3d_util.cpp:928)
-//                       and their supporting line angles (object_3d_util.cpp:548-619);
-//   candidate_kernel    one lane per proposal slot (job, roll/pitch, yaw, top sample, config): the
-//                       eight corners (:413-625), the distance-map edge score (object_3d_util.cpp:622),
-//                       the VP angle alignment (object_3d_util.cpp:670) and the 3D half sizes;
-//   scan/compact        ordered stream compaction of the valid proposals per job (the reference
-//                       appends rows in loop order, :677-702, and that order defines tie-breaking);
-//   gather_corners      corners of the selected proposals for the final records.
+// What runs here (reference loops L2..L5 and the ranking, detect_3d_cuboid/src/box_proposal_detail.cpp:200-838):
+//   line_setup_kernel   one wave per job: ROI segment filter (:271-283), merge_break_lines (object_3d_util.cpp:431-543),
+//                       segment angles / mid points (:309-315);
+//   vp_points_kernel    one lane per (job, roll/pitch, yaw): the three vanishing points (object_3d_util.cpp:928);
+//   vp3_support_kernel / vp_support_kernel   their supporting segment angles (object_3d_util.cpp:548-619);
+//   candidate_kernel    one lane per proposal slot (job, roll/pitch, yaw, top sample, config): the eight corners (:413-625),
+//                       a flag per slot, corners of the valid ones;
+//   scan_jobs / compact ordered stream compaction of the valid proposals per job (the reference appends rows in loop
+//                       order, :677-702, and that order defines tie-breaking);
+//   score_kernel        one lane per valid proposal: distance-map edge score (object_3d_util.cpp:622), VP angle alignment
+//                       (:670), half sizes of the lifted cuboid (:941-990);
+//   rank_kernel         one workgroup per box: fuse_normalize_scores_v2 (object_3d_util.cpp:726-837) + the skew-weighted
+//                       final ranking (box_proposal_detail.cpp:804-838) as order statistics and arg-mins; boxes whose ties
+//                       could reach the output are flagged for the exact host ranking;
+//   gather_*            columns / corners of those boxes.
 //
-// Numerics: FP64 geometry, float32 gathers with a *sequential* float running sum per proposal (one lane
-// owns one proposal; no shuffles/tree reductions on scores), cs_atan2 (double-double) instead of libm.
-// Compiled with -ffp-contract=off: every result is bit-identical to the CPU oracle.
+// Numerics: values that leave a kernel -- corners, errors, merged angles -- are computed with the reference's
+// operations in its order (FP64 geometry, float32 gathers with a sequential float sum per proposal, cs_atan2 for libm's atan2);
+// decisions (inlier tests, extreme selection, merge tests, length thresholds) take a cheaper exact-equivalent form with the
+// reference's evaluation inside a margin.  Compiled with -ffp-contract=off: every result is bit-identical to the CPU oracle.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
