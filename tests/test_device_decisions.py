@@ -157,3 +157,171 @@ def test_squared_length_bounds_are_exact(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     n, bad = (int(v) for v in out.stdout.split())
     assert out.returncode == 0 and bad == 0 and n > 1_000_000, out.stdout
+
+
+def _vp_support_exact(mx, my, la, vpx, vpy, thre):
+    """VP_support_edge_infos as the reference evaluates it (object_3d_util.cpp:548-619), in float64: (inliers, arg-max, arg-min)."""
+    inl, base, hi, lo, i_hi, i_lo = [], None, None, None, -1, -1
+    for i in range(len(mx)):
+        raw = np.arctan2(my[i] - vpy, mx[i] - vpx)
+        nrm = raw - np.pi if raw > np.pi / 2 else (raw + np.pi if raw < -np.pi / 2 else raw)
+        d = abs(la[i] - nrm)
+        d = min(d, np.pi - d)
+        if not d < thre:
+            continue
+        inl.append(i)
+        if base is None:
+            base = hi = lo = raw
+            i_hi = i_lo = i
+            continue
+        sh = raw + 2 * np.pi if raw - base < -np.pi else (raw - 2 * np.pi if raw - base > np.pi else raw)
+        if sh > hi:
+            hi, i_hi = sh, i
+        if sh < lo:
+            lo, i_lo = sh, i
+    return inl, i_hi, i_lo
+
+
+def _vp_support_device_logic(mx, my, la, vpx, vpy, thre, stats):
+    """The decision logic of vp_support_multi / vp_step (pass 1 in float, float angles with margins, cross-product order,
+    float64 evaluation inside the margins), step by step as the kernel takes it."""
+    f32 = np.float32
+    PI_F, HPI_F, M_IN, M_ORD = f32(3.14159274), f32(1.57079637), f32(1.0e-5), f32(2.0e-5)
+    thre_f = f32(thre)
+    tan_f = f32(np.tan(f32(thre_f + f32(1e-4))))
+
+    def exact_unwrapped(i, ib):
+        raw = np.arctan2(my[i] - vpy, mx[i] - vpx)
+        if i == ib:
+            return raw
+        base = np.arctan2(my[ib] - vpy, mx[ib] - vpx)
+        return raw + 2 * np.pi if raw - base < -np.pi else (raw - 2 * np.pi if raw - base > np.pi else raw)
+
+    have, ib, i_hi, i_lo = False, 0, -1, -1
+    base_f = hi_f = lo_f = f32(0)
+    hx = hy = lx = ly = 0.0
+    inl_list = []
+    for i in range(len(mx)):
+        dxd, dyd = mx[i] - vpx, my[i] - vpy
+        fx, fy = f32(dxd), f32(dyd)
+        # pass 1
+        laf = f32(la[i])
+        ux, uy = f32(np.cos(laf)), f32(np.sin(laf))
+        cr = abs(f32(np.float64(fx) * np.float64(uy) - np.float64(f32(fy * ux))))
+        dt = abs(f32(np.float64(fx) * np.float64(ux) + np.float64(f32(fy * uy))))
+        slack = f32(f32(2.0e-6) * f32(abs(fx) + abs(fy)))
+        if cr > f32(np.float64(tan_f) * np.float64(dt) + np.float64(slack)):
+            stats["dropped"] += 1
+            continue
+        # pass 2
+        at = atan2_float_model(np.array([fy], f32), np.array([fx], f32))[0]
+        hi_mag = max(abs(fx), abs(fy))
+        usable = hi_mag > 0 and hi_mag < f32(3.0e38)
+        nr = at - PI_F if at > HPI_F else (at + PI_F if at < -HPI_F else at)
+        df = abs(f32(laf - nr))
+        df = min(df, f32(PI_F - df))
+        inl = bool(usable and df < f32(thre_f - M_IN))
+        if not (inl or (usable and df > f32(thre_f + M_IN))):
+            stats["exact_inlier"] += 1
+            raw = np.arctan2(dyd, dxd)
+            nrm = raw - np.pi if raw > np.pi / 2 else (raw + np.pi if raw < -np.pi / 2 else raw)
+            d = abs(la[i] - nrm)
+            inl = min(d, np.pi - d) < thre
+            at = f32(raw)
+        if not inl:
+            continue
+        inl_list.append(i)
+        if not have:
+            have, ib, i_hi, i_lo = True, i, i, i
+            base_f = hi_f = lo_f = at
+            hx = lx = dxd
+            hy = ly = dyd
+            continue
+        d = f32(at - base_f)
+        sh = f32(at + f32(2) * PI_F) if d < -PI_F else (f32(at - f32(2) * PI_F) if d > PI_F else at)
+        if abs(f32(abs(d) - PI_F)) < M_ORD:
+            stats["exact_unwrap"] += 1
+            sh = f32(exact_unwrapped(i, ib))
+        if sh > f32(hi_f + M_ORD):
+            hi_f, i_hi, hx, hy = sh, i, dxd, dyd
+        elif sh > f32(hi_f - M_ORD):
+            c = hx * dyd - hy * dxd
+            lim = 1.0e-12 * ((abs(dxd) + abs(dyd)) * (abs(hx) + abs(hy)))
+            stats["cross_order"] += 1
+            if c > lim:
+                greater = True
+            elif c < -lim:
+                greater = False
+            else:
+                stats["exact_order"] += 1
+                greater = exact_unwrapped(i, ib) > exact_unwrapped(i_hi, ib)
+            if greater:
+                hi_f, i_hi, hx, hy = sh, i, dxd, dyd
+        if sh < f32(lo_f - M_ORD):
+            lo_f, i_lo, lx, ly = sh, i, dxd, dyd
+        elif sh < f32(lo_f + M_ORD):
+            c = lx * dyd - ly * dxd
+            lim = 1.0e-12 * ((abs(dxd) + abs(dyd)) * (abs(lx) + abs(ly)))
+            stats["cross_order"] += 1
+            if c < -lim:
+                less = True
+            elif c > lim:
+                less = False
+            else:
+                stats["exact_order"] += 1
+                less = exact_unwrapped(i, ib) < exact_unwrapped(i_lo, ib)
+            if less:
+                lo_f, i_lo, lx, ly = sh, i, dxd, dyd
+    return inl_list, i_hi, i_lo
+
+
+def test_vp_support_decision_logic_equals_the_exact_evaluation():
+    """Inlier set, arg-max and arg-min of the device's decision procedure against the plain float64 evaluation of the reference's
+    loop, for vanishing points inside the ROI, around the image and far away (10^4 .. 10^9 px, where all segments lie within a
+    fraction of a milliradian and the float angles cannot order them), with duplicated and collinear segments mixed in."""
+    rng = np.random.default_rng(23)
+    stats = dict(dropped=0, exact_inlier=0, exact_unwrap=0, exact_order=0, cross_order=0)
+    n_cases = 0
+    for case in range(700):
+        m = int(rng.integers(3, 70))
+        mx, my = rng.uniform(200, 500, m), rng.uniform(100, 300, m)
+        la = rng.uniform(-np.pi / 2, np.pi / 2, m)
+        kind = case % 4
+        if kind == 0:
+            vpx, vpy = rng.uniform(150, 550), rng.uniform(50, 350)                    # inside the segment cloud: wrap-arounds
+        elif kind == 1:
+            vpx, vpy = rng.uniform(-2000, 3000), rng.uniform(-1500, 2000)
+        else:
+            r, a = 10.0 ** rng.uniform(4, 9), rng.uniform(0, 2 * np.pi)
+            vpx, vpy = r * np.cos(a), r * np.sin(a)
+        # many segments pointing at the vanishing point (what a real vanishing point has), some exactly duplicated
+        for i in range(m):
+            if rng.random() < 0.5:
+                raw = np.arctan2(my[i] - vpy, mx[i] - vpx)
+                nrm = raw - np.pi if raw > np.pi / 2 else (raw + np.pi if raw < -np.pi / 2 else raw)
+                la[i] = nrm + rng.uniform(-0.3, 0.3)
+        if m > 6:
+            mx[5], my[5], la[5] = mx[2], my[2], la[2]
+        if m > 12:   # a segment whose angle sits on the inlier threshold to within 1e-7 rad, and (vanishing point inside the cloud) a
+            # segment diametrically opposite the first one, so that the unwrap decision sits on +-pi
+            raw = np.arctan2(my[9] - vpy, mx[9] - vpx)
+            nrm = raw - np.pi if raw > np.pi / 2 else (raw + np.pi if raw < -np.pi / 2 else raw)
+            la[9] = nrm + (15.0 / 180.0 * np.pi) * (1 + rng.uniform(-1e-7, 1e-7))
+            la[9] = la[9] - np.pi if la[9] > np.pi / 2 else la[9]
+            if kind == 0:
+                mx[11], my[11] = 2 * vpx - mx[0] + rng.uniform(-1e-5, 1e-5), 2 * vpy - my[0]
+                raw0 = np.arctan2(my[0] - vpy, mx[0] - vpx)
+                nrm0 = raw0 - np.pi if raw0 > np.pi / 2 else (raw0 + np.pi if raw0 < -np.pi / 2 else raw0)
+                la[0] = nrm0
+                la[11] = nrm0
+        for thre_deg in (15.0, 10.0):
+            thre = thre_deg / 180.0 * np.pi
+            ref = _vp_support_exact(mx, my, la, vpx, vpy, thre)
+            got = _vp_support_device_logic(mx, my, la, vpx, vpy, thre, stats)
+            assert got == ref, (case, thre_deg)
+            n_cases += 1
+    # every branch of the procedure was taken, and the exact evaluations stay the exception
+    assert stats["dropped"] > 10000 and stats["cross_order"] > 500
+    assert stats["exact_inlier"] > 50 and stats["exact_unwrap"] > 20 and stats["exact_order"] > 50
+    assert stats["exact_inlier"] + stats["exact_unwrap"] + stats["exact_order"] < 0.05 * n_cases * 35
+    assert n_cases == 1400
