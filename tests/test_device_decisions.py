@@ -325,3 +325,77 @@ def test_vp_support_decision_logic_equals_the_exact_evaluation():
     assert stats["exact_inlier"] > 50 and stats["exact_unwrap"] > 20 and stats["exact_order"] > 50
     assert stats["exact_inlier"] + stats["exact_unwrap"] + stats["exact_order"] < 0.05 * n_cases * 35
     assert n_cases == 1400
+
+
+def test_line_pair_test_decisions_equal_the_exact_evaluation():
+    """ls_pair_pass (the three tests of merge_break_lines, object_3d_util.cpp:464-497): squared end-point gaps against the
+    squared bound and the float angle of the would-be merged segment with the exact evaluation inside the margin -- the same
+    decision as sqrt / atan2 in float64 for every pair, including pairs built to sit on the thresholds."""
+    rng = np.random.default_rng(31)
+    f32 = np.float32
+    dist_thre, ang_thre = 20.0, 5.0 / 180.0 * np.pi
+    # sqrt(x) < 20 <=> x < bound, bound = the smallest double whose rounded root reaches 20 (cs_geom.h sqrt_lt_bound; the C++
+    # function itself is checked in test_squared_length_bounds_are_exact): one ulp below 400, whose root already rounds to 20
+    dist_sq_bound = 400.0
+    while np.sqrt(np.nextafter(dist_sq_bound, 0.0)) >= dist_thre:
+        dist_sq_bound = np.nextafter(dist_sq_bound, 0.0)
+    assert dist_sq_bound == 399.99999999999994
+    n_exact = n_pass = 0
+    for trial in range(60000):
+        x1, y1 = rng.uniform(0, 600), rng.uniform(0, 300)
+        a = rng.uniform(-np.pi / 2, np.pi / 2)
+        la_ = rng.uniform(15, 120)
+        A = (x1, y1, x1 + la_ * np.cos(a), y1 + la_ * np.sin(a))
+        if A[2] < A[0]:
+            A = (A[2], A[3], A[0], A[1])
+        # B continues A after a gap, with a small angle change; every 4th pair sits on a threshold
+        gap = rng.uniform(0, 30) if trial % 4 else dist_thre * (1 + rng.uniform(-1e-9, 1e-9))
+        b = a + (rng.uniform(-0.15, 0.15) if trial % 4 != 1 else ang_thre * rng.choice([-1, 1]) * (1 + rng.uniform(-1e-7, 1e-7)))
+        bx, by = A[2] + gap * np.cos(a), A[3] + gap * np.sin(a)
+        lb = rng.uniform(15, 120)
+        B = (bx, by, bx + lb * np.cos(b), by + lb * np.sin(b))
+        if B[2] < B[0]:
+            B = (B[2], B[3], B[0], B[1])
+        angA, angB = np.arctan2(A[3] - A[1], A[2] - A[0]), np.arctan2(B[3] - B[1], B[2] - B[0])
+
+        def exact():
+            diff = abs(angA - angB)
+            if min(diff, np.pi - diff) >= ang_thre:
+                return False
+            d_ab = np.sqrt((A[2] - B[0]) ** 2 + (A[3] - B[1]) ** 2)
+            d_ba = np.sqrt((B[2] - A[0]) ** 2 + (B[3] - A[1]) ** 2)
+            if not (d_ab < dist_thre or d_ba < dist_thre):
+                return False
+            sx, sy = (A[0], A[1]) if A[0] < B[0] else (B[0], B[1])
+            ex, ey = (A[2], A[3]) if A[2] > B[2] else (B[2], B[3])
+            t = abs(angA - np.arctan2(ey - sy, ex - sx))
+            return min(t, np.pi - t) < ang_thre
+
+        def device():
+            nonlocal n_exact
+            diff = abs(angA - angB)
+            if min(diff, np.pi - diff) >= ang_thre:
+                return False
+            d_ab = (A[2] - B[0]) ** 2 + (A[3] - B[1]) ** 2
+            d_ba = (B[2] - A[0]) ** 2 + (B[3] - A[1]) ** 2
+            if not (d_ab < dist_sq_bound or d_ba < dist_sq_bound):
+                return False
+            sx, sy = (A[0], A[1]) if A[0] < B[0] else (B[0], B[1])
+            ex, ey = (A[2], A[3]) if A[2] > B[2] else (B[2], B[3])
+            dy, dx = ey - sy, ex - sx
+            at = atan2_float_model(np.array([dy], f32), np.array([dx], f32))[0]
+            tf = abs(f32(f32(angA) - at))
+            mf = min(tf, f32(f32(3.14159274) - tf))
+            th = f32(ang_thre)
+            if mf < f32(th - f32(1e-5)):
+                return True
+            if mf > f32(th + f32(1e-5)):
+                return False
+            n_exact += 1
+            t = abs(angA - np.arctan2(dy, dx))
+            return min(t, np.pi - t) < ang_thre
+
+        e = exact()
+        assert device() == e, trial
+        n_pass += e
+    assert n_pass > 5000 and 0 < n_exact < 2000
