@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -36,7 +37,12 @@ void ba_launch_backsub(const BaView& v, hipStream_t st);
 int ba_scale_blocks();
 void ba_launch_scale(const BaView& v, double lambda_pose, double lambda_lm, double* partial, hipStream_t st);
 void ba_launch_update(const BaView& v, hipStream_t st);
-void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st);
+void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st, bool one_sided = false);
+void ba_launch_sep_reduce(const double* S, int LD, const double* Linv, int ci, int ni, int zl, int wl, int zr, int wr, double* Y, const double* rhs, double* msg, int wm, hipStream_t st);
+void ba_launch_sep_assemble(const double* msgs, size_t msg_doubles, int wm, int R, const int* sep_off, int n, double* Ssep, double* rsep, hipStream_t st);
+void ba_launch_sep_scatter(const double* xsep, int n, int R, const int* sep_off, const int* sep_col, double* x, hipStream_t st);
+void ba_launch_sep_backsolve(double* S, int LD, double* work, int ci, int ni, int zl, int wl, int zr, int wr, double* Y, double* rhs, int* info, hipStream_t st);
+void ba_launch_fail_flag(const int* a, const int* b, const int* c, double* out, hipStream_t st);
 size_t ba_band_workspace_doubles(int n, int LD);
 int ba_band_team(int LD, int* rw_out);
 bool ba_band_fits_device(int n, int LD);
@@ -129,6 +135,20 @@ struct cs_ba {
   // sharded BA: landmarks (with all their projection edges) are dealt to ranks by the camera subsequence of their
   // first observation; cuboid / odometry edges follow their camera.  Every rank keeps all vertices.
   int shard_rank = 0, shard_n = 1;
+  // Separator mode of the sharded solve (shard_n > 1, banded system, every rank's interior wide enough): rank r owns the columns
+  // [cut[r], cut[r + 1]) of the band -- its first sepw[r] >= bandwidth columns are the separator Z_r (sepw[0] = 0), the rest its interior
+  // -- and everything whose lowest column falls into that range (landmarks with their projection edges, cuboids, odometry edges).
+  // What a rank builds then lies in its own columns and in the diagonal block of the next separator; it factorises its interior only,
+  // the ranks exchange the separators' Schur complements (3 w^2 + 2 w doubles each) and the interiors' solutions.  Otherwise
+  // (sep_mode == false) the whole [S | b] is summed over the ranks and every rank factorises it.
+  bool sep_mode = false;
+  std::vector<int> cut, sepw, sep_off, lm_owner;   // sep_off[k]: row of separator k in the separator system (k = 1 .. R - 1; sep_off[R] = n_sep)
+  int n_sep = 0, w_max = 0;
+  size_t msg_doubles = 0;                          // one rank's message: [LL | RL | RR | tL | tR]
+  int int_c = 0, int_n = 0, zl = 0, wl = 0, zr = 0, wr = 0;   // this rank's interior and its two separators
+  DBuf<double> sepY, sep_msgs, sepS, int_work;
+  DBuf<int> d_sep_off, d_sep_col, d_int_info;
+  long long bytes_per_trial = 0, bytes_per_trial_allreduce = 0;   // payload this rank contributes to the collectives of one LM trial; what the all-reduce of [S | b] would be
   std::vector<int> keep;                      // caller indices of the projection edges this rank owns
   size_t s_doubles = 0;                       // size of S; rhs follows it in the same allocation (one all-reduce)
   int n_pose = 0, n_lm = 0;
@@ -358,15 +378,67 @@ int finalize_structure(cs_ba* B) {
     const bool try_elim = fused_ok && n_free_cub > 0 && max_slots <= cs::BA_ELIM_MAX_SLOTS && getenv("CS_BA_KEEP_CUBOIDS") == nullptr;
     Ordering elim_o;
     if (try_elim) elim_o = make_ordering(true);
-    B->elim = try_elim && cost(elim_o) < cost(keep_o);
+    // (an ordering without unknowns -- every camera fixed, the driver's frame-0 graph -- is not a candidate: nothing would be
+    // factorised and the cuboids' elimination / back-substitution hang off the reduced solve)
+    B->elim = try_elim && elim_o.n_red > 0 && cost(elim_o) < cost(keep_o);
     const Ordering& O = B->elim ? elim_o : keep_o;
     B->cam_col = O.cam_col; B->cub_col = O.cub_col; B->n_red = O.n_red;
     B->band_ld = band_ok(O) ? O.bw + 1 : 0;
   }
-  // ---- this rank's projection edges
+  // ---- sharded: the column cut (separator mode) and who owns what
   mark("ordering (RCM)");
+  B->sep_mode = false; B->cut.clear(); B->sepw.clear(); B->sep_off.clear(); B->n_sep = 0; B->w_max = 0; B->msg_doubles = 0;
+  B->int_c = B->int_n = B->zl = B->wl = B->zr = B->wr = 0;
+  const int R = B->shard_n;
+  if (R > 1 && B->band_ld > 0 && getenv("CS_BA_SHARD_ALLREDUCE") == nullptr) {
+    struct Blk { int col, dim; };
+    std::vector<Blk> blks;
+    for (int i = 0; i < nc; i++) if (B->cam_col[i] >= 0) blks.push_back(Blk{B->cam_col[i], 6});
+    for (int i = 0; i < no; i++) if (B->cub_col[i] >= 0 && B->cub_col[i] < B->n_red) blks.push_back(Blk{B->cub_col[i], 9});
+    std::sort(blks.begin(), blks.end(), [](const Blk& a, const Blk& b) { return a.col < b.col; });
+    const int bw = B->band_ld - 1;
+    std::vector<int> cut(R + 1, 0), sepw(R, 0);
+    cut[R] = B->n_red;
+    bool ok = true;
+    for (int r = 1; r < R && ok; r++) {
+      const long long target = (long long)B->n_red * r / R;
+      size_t q = 0;
+      while (q < blks.size() && blks[q].col < target) q++;
+      if (q >= blks.size()) { ok = false; break; }
+      cut[r] = blks[q].col;
+      int w = 0;
+      while (q < blks.size() && w < bw) { w += blks[q].dim; q++; }
+      if (w < bw) { ok = false; break; }
+      sepw[r] = w;
+    }
+    for (int r = 0; r < R && ok; r++) {
+      const int ni = cut[r + 1] - cut[r] - sepw[r];
+      if (ni < 129 || ni <= B->band_ld) ok = false;     // (also: interiors further apart than the bandwidth, the regime the band kernels are tested in)
+    }
+    if (ok) {
+      B->sep_mode = true; B->cut = cut; B->sepw = sepw;
+      B->sep_off.assign(R + 1, 0);
+      for (int k = 1; k < R; k++) { B->sep_off[k + 1] = B->sep_off[k] + sepw[k]; B->w_max = std::max(B->w_max, sepw[k]); }
+      B->n_sep = B->sep_off[R];
+      B->msg_doubles = 3 * (size_t)B->w_max * B->w_max + 2 * (size_t)B->w_max;
+      const int r = B->shard_rank;
+      B->zl = cut[r]; B->wl = sepw[r]; B->int_c = cut[r] + sepw[r]; B->int_n = cut[r + 1] - B->int_c;
+      B->zr = cut[r + 1]; B->wr = (r + 1 < R) ? sepw[r + 1] : 0;
+    }
+  }
+  auto rank_of_col = [&](int col) { int r = 0; while (r + 1 < R && col >= B->cut[r + 1]) r++; return r; };
   std::vector<int> owner;
-  landmark_owners(B->shard_n, nc, np, B->n_proj, B->e_pt.data(), B->e_cam.data(), owner);
+  if (B->sep_mode) {   // a landmark goes to the rank that owns the lowest column among its free cameras (none: rank 0)
+    owner.assign(np, 0);
+    for (int p = 0; p < np; p++) {
+      int lo = 0x7fffffff;
+      for (int a = cam_cnt[p]; a < cam_cnt[p + 1]; a++) { const int c = B->cam_col[cams_of[a]]; if (c >= 0) lo = std::min(lo, c); }
+      if (lo != 0x7fffffff) owner[p] = rank_of_col(lo);
+    }
+  } else {
+    landmark_owners(B->shard_n, nc, np, B->n_proj, B->e_pt.data(), B->e_cam.data(), owner);
+  }
+  B->lm_owner = owner;
   B->keep.clear();
   for (int k = 0; k < B->n_proj; k++) if (owner[B->e_pt[k]] == B->shard_rank) B->keep.push_back(k);
   int nl = 0;
@@ -600,20 +672,45 @@ int finalize_structure(cs_ba* B) {
   UP(B->d_ce_cam, B->ce_cam); UP(B->d_ce_cub, B->ce_cub); UP(B->d_oe_i, B->oe_i); UP(B->d_oe_j, B->oe_j);
   {
     std::vector<int> ca(B->n_cub), oa(B->n_odom);
-    // cuboid edges: with their camera's rank, or -- cuboids eliminated -- all edges of a cuboid with the rank of its lowest-index camera
+    // cuboid edges: with their camera's rank, or -- cuboids eliminated -- all edges of a cuboid with the rank of its lowest-index camera.
+    // Separator mode: by the lowest column among the free vertices involved (an eliminated cuboid: among its observing cameras).
     std::vector<int> cub_owner(no, 0);
-    {
+    if (B->sep_mode) {
+      for (int o = 0; o < no; o++) {
+        int lo = 0x7fffffff;
+        for (int c : cub_cams[o]) lo = std::min(lo, B->cam_col[c]);
+        cub_owner[o] = lo == 0x7fffffff ? 0 : rank_of_col(lo);
+      }
+      for (int k = 0; k < B->n_cub; k++) {
+        const int o = B->ce_cub[k], c = B->ce_cam[k];
+        int own = 0;
+        if (B->elim && !B->cub_fixed[o]) own = cub_owner[o];
+        else {
+          int lo = 0x7fffffff;
+          if (B->cam_col[c] >= 0) lo = std::min(lo, B->cam_col[c]);
+          if (B->cub_col[o] >= 0 && B->cub_col[o] < B->n_red) lo = std::min(lo, B->cub_col[o]);
+          own = lo == 0x7fffffff ? 0 : rank_of_col(lo);
+        }
+        ca[k] = own == B->shard_rank;
+      }
+      for (int k = 0; k < B->n_odom; k++) {
+        int lo = 0x7fffffff;
+        if (B->cam_col[B->oe_i[k]] >= 0) lo = std::min(lo, B->cam_col[B->oe_i[k]]);
+        if (B->cam_col[B->oe_j[k]] >= 0) lo = std::min(lo, B->cam_col[B->oe_j[k]]);
+        oa[k] = (lo == 0x7fffffff ? 0 : rank_of_col(lo)) == B->shard_rank;
+      }
+    } else {
       std::vector<int> first(no, 0x7fffffff);
       for (int k = 0; k < B->n_cub; k++) first[B->ce_cub[k]] = std::min(first[B->ce_cub[k]], B->ce_cam[k]);
       for (int o = 0; o < no; o++) cub_owner[o] = first[o] == 0x7fffffff ? 0 : cam_rank(first[o], nc, B->shard_n);
+      for (int k = 0; k < B->n_cub; k++) ca[k] = (B->elim ? cub_owner[B->ce_cub[k]] : cam_rank(B->ce_cam[k], nc, B->shard_n)) == B->shard_rank;
+      for (int k = 0; k < B->n_odom; k++) oa[k] = cam_rank(B->oe_j[k], nc, B->shard_n) == B->shard_rank;
     }
-    for (int k = 0; k < B->n_cub; k++) ca[k] = (B->elim ? cub_owner[B->ce_cub[k]] : cam_rank(B->ce_cam[k], nc, B->shard_n)) == B->shard_rank;
     {
       std::vector<int> mine(std::max(1, no), 0);
       for (int o = 0; o < no; o++) mine[o] = cub_owner[o] == B->shard_rank;
       UP(B->d_cub_mine, mine);
     }
-    for (int k = 0; k < B->n_odom; k++) oa[k] = cam_rank(B->oe_j[k], nc, B->shard_n) == B->shard_rank;
     UP(B->d_ce_active, ca); UP(B->d_oe_active, oa);
   }
   UP(B->ce_meas, B->h_ce_meas); UP(B->ce_info, B->h_ce_info); UP(B->oe_meas, B->h_oe_meas); UP(B->oe_info, B->h_oe_info);
@@ -633,6 +730,24 @@ int finalize_structure(cs_ba* B) {
   AL(B->chi_partial, B->n_chi_partials);
   AL(B->scale_partial, (size_t)cs::ba_scale_blocks());
   AL(B->d_info, 1);
+  if (B->sep_mode) {
+    AL(B->sepY, (size_t)(B->wl + B->wr) * B->int_n);
+    AL(B->sep_msgs, B->msg_doubles * (size_t)R);
+    AL(B->sepS, (size_t)B->n_sep * B->n_sep + B->n_sep);       // [S_sep | rhs_sep]
+    AL(B->int_work, cs::ba_band_workspace_doubles(B->int_n, B->band_ld));
+    AL(B->d_int_info, 24);
+    std::vector<int> sep_col(R + 1, 0);
+    for (int k = 1; k < R; k++) sep_col[k] = B->cut[k];
+    UP(B->d_sep_off, B->sep_off); UP(B->d_sep_col, sep_col);
+    // what this rank contributes to the collectives of one LM trial: its separator message, the solution vector, three scalars
+    B->bytes_per_trial = 8 * ((long long)B->msg_doubles + B->n_pose + 3);
+  } else {
+    AL(B->sepY, 1); AL(B->sep_msgs, 1); AL(B->sepS, 1); AL(B->int_work, 1); AL(B->d_int_info, 24);
+    std::vector<int> none1(1, 0);
+    UP(B->d_sep_off, none1); UP(B->d_sep_col, none1);
+    B->bytes_per_trial = R > 1 ? 8 * ((long long)B->s_doubles + B->n_pose + 3 + (B->elim ? B->n_pose - B->n_red : 0)) : 0;
+  }
+  B->bytes_per_trial_allreduce = 8 * ((long long)B->s_doubles + B->n_pose + 3 + (B->elim ? B->n_pose - B->n_red : 0));
   {
     const size_t need = std::max<size_t>(16, (size_t)B->n_pose + 2);
     AL(B->d_scalars, need);
@@ -662,7 +777,7 @@ int finalize_structure(cs_ba* B) {
   v.cam_ce_ptr = B->cam_ce_ptr.p; v.cam_ce_idx = B->cam_ce_idx.p; v.cam_oei_ptr = B->cam_oei_ptr.p; v.cam_oei_idx = B->cam_oei_idx.p;
   v.cam_oej_ptr = B->cam_oej_ptr.p; v.cam_oej_idx = B->cam_oej_idx.p; v.cub_ce_ptr = B->cub_ce_ptr.p; v.cub_ce_idx = B->cub_ce_idx.p;
   v.Hcam = B->Hcam.p; v.bcam = B->bcam.p; v.Hcub = B->Hcub.p; v.bcub = B->bcub.p; v.Hll = B->Hll.p; v.bl = B->bl.p; v.W = B->W.p; v.WD = B->WD.p;
-  v.Dinv = B->Dinv.p; v.dbl = B->dbl.p; v.S = B->S.p; v.band_ld = B->band_ld; v.add_lambda = (B->shard_rank == 0); v.rhs = B->S.p + B->s_doubles; v.xl = B->xl.p;
+  v.Dinv = B->Dinv.p; v.dbl = B->dbl.p; v.S = B->S.p; v.band_ld = B->band_ld; v.lam_lo = B->sep_mode ? B->cut[B->shard_rank] : 0; v.lam_hi = B->sep_mode ? B->cut[B->shard_rank + 1] : (B->shard_rank == 0 ? 0x7fffffff : 0); v.rhs = B->S.p + B->s_doubles; v.xl = B->xl.p;
   v.n_pairs = B->n_pairs; v.pair_ptr = B->pair_ptr.p; v.pair_i1 = B->pair_i1.p; v.pair_i2 = B->pair_i2.p; v.ent_a = B->ent_a.p; v.ent_b = B->ent_b.p;
   v.fused = B->fused ? 1 : 0; v.n_seg = B->n_seg; v.seg_class[0] = B->seg_class[0]; v.seg_class[1] = B->seg_class[1];
   v.seg_ptr = B->d_seg_ptr.p; v.seg_k = B->d_seg_k.p; v.seg_tile = B->d_seg_tile.p; v.seg_slot = B->d_seg_slot.p; v.run_lm = B->d_run_lm.p;
@@ -742,6 +857,10 @@ int build_system_device(cs_ba* B) {
 // One such kernel fits many times over, but an unbounded number of concurrent solves (handles on different streams of
 // one process) would not; they take turns.
 static std::mutex g_coop_mutex;
+// The turn is held across the collectives of a trial when they are queued on the stream (RCCL): two communicator handles in one
+// process would wait for each other (one holds the turn inside a collective, the other needs the turn to enqueue its side).  One
+// process per GPU is the contract; cs_ba_comm_init enforces it.
+static std::atomic<int> g_comm_handles{0};
 
 // phase times of the last solve, read once the stream has been synchronised
 int collect_solve_times(cs_ba* B) {
@@ -769,9 +888,11 @@ int share_cuboid_increments(cs_ba* B, cs_allreduce_fn fn, void* ctx) {
 
 // defer != nullptr (banded path only): everything is queued and the function returns WITHOUT synchronising; *defer then holds the
 // persistent-kernel turn, and the caller synchronises, reads *h_status, calls collect_solve_times() and releases the turn.
+int solve_device_sep(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn, void* ctx, std::unique_lock<std::mutex>* defer);
 int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr, void* ctx = nullptr, std::unique_lock<std::mutex>* defer = nullptr) {
   const int n = B->n_red;
   *ok = true;
+  if (B->sep_mode && B->shard_n > 1) return solve_device_sep(B, lambda, ok, fn, ctx, defer);
   if (n > 0) {
     BA_TRY(hipEventRecord(B->ev[2], B->st));
     BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (B->s_doubles + B->n_pose), B->st));
@@ -804,6 +925,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       { int rc2 = share_cuboid_increments(B, fn, ctx); if (rc2) return rc2; }
       BA_TRY(hipEventRecord(B->ev[5], B->st));
       BA_TRY(hipMemcpyAsync(B->h_status, B->d_band_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
+      cs::ba_launch_fail_flag(B->d_band_info.p, B->d_elim_fail.p, nullptr, B->d_scalars.p + 2, B->st);   // rides in the trial's scalar all-reduce
       if (defer) { *defer = std::move(coop_turn); B->tm.n_solves++; return CS_OK; }
       BA_TRY(hipStreamSynchronize(B->st));
       if (*B->h_status == 0x7fffffff) {   // a workgroup waited ~1 s for its team: the device is shared with another persistent kernel
@@ -819,7 +941,8 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       if (B->h_status[0] != 0 || B->h_status[1] != 0) *ok = false;
       else BA_ROC(rocsolver_dpotrs(B->blas, rocblas_fill_upper, n, 1, B->S.p, n, B->view.rhs, n));
       BA_TRY(hipEventRecord(B->ev[4], B->st));
-      if (*ok) { cs::ba_launch_backsub(B->view, B->st); BA_TRY(hipGetLastError()); int rc2 = share_cuboid_increments(B, fn, ctx); if (rc2) return rc2; }
+      // (sharded: the collective is issued whether or not THIS rank's factorisation went through -- the ranks decide together, below)
+      if (*ok || B->shard_n > 1) { cs::ba_launch_backsub(B->view, B->st); BA_TRY(hipGetLastError()); int rc2 = share_cuboid_increments(B, fn, ctx); if (rc2) return rc2; }
       BA_TRY(hipEventRecord(B->ev[5], B->st));
       BA_TRY(hipStreamSynchronize(B->st));
     }
@@ -827,6 +950,90 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
   }
   B->tm.n_solves++;
   return CS_OK;
+}
+
+
+// collectives of the sharded solve: RCCL on the handle's stream (queued, no host round trip), or the caller's callback (which is
+// host-synchronous: the stream is drained first)
+int coll_allreduce(cs_ba* B, cs_allreduce_fn fn, void* ctx, double* d, size_t n) {
+  if (fn) {
+    BA_TRY(hipStreamSynchronize(B->st));
+    if (fn(ctx, d, n, 1, 0) != 0) { cs_set_error_ba("all-reduce callback failed"); return CS_ERR_HIP; }
+  } else if (B->comm) {
+    BA_NCCL(ncclAllReduce(d, d, n, ncclDouble, ncclSum, B->comm, B->st));
+  }
+  return CS_OK;
+}
+// in place: rank r's part sits at buf + r * per_rank.  Through the callback an all-gather is the sum of the zero-padded buffers
+// (the caller zeroes the other ranks' slots first).
+int coll_allgather(cs_ba* B, cs_allreduce_fn fn, void* ctx, double* buf, size_t per_rank) {
+  if (fn) {
+    BA_TRY(hipStreamSynchronize(B->st));
+    if (fn(ctx, buf, per_rank * (size_t)B->shard_n, 1, 0) != 0) { cs_set_error_ba("all-reduce callback failed"); return CS_ERR_HIP; }
+  } else if (B->comm) {
+    BA_NCCL(ncclAllGather(buf + (size_t)B->shard_rank * per_rank, buf, per_rank, ncclDouble, B->comm, B->st));
+  }
+  return CS_OK;
+}
+
+// The damped solve in separator mode (cs_ba::sep_mode; kernels: "sharded reduced solve" in ba_kernels.hip).  What is built here lies
+// in this rank's columns and in the next separator's diagonal block; only the interior is factorised here.  Collectives per solve:
+// one all-gather of the separator messages (3 w^2 + 2 w doubles per rank) and one all-reduce of the solution vector (n_pose doubles:
+// every rank contributes its interior's increments and those of the cuboids it eliminated).  block_solver.hpp:385-485 for what a
+// shard builds and solves.
+int solve_device_sep(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn, void* ctx, std::unique_lock<std::mutex>* defer) {
+  *ok = true;
+  const int R = B->shard_n, LD = B->band_ld, ns = B->n_sep;
+  double* rhs = B->view.rhs;
+  double* rsep = B->sepS.p + (size_t)ns * ns;
+  BA_TRY(hipEventRecord(B->ev[2], B->st));
+  BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (B->s_doubles + B->n_pose), B->st));
+  BA_TRY(hipMemsetAsync(B->d_elim_fail.p, 0, sizeof(int), B->st));
+  if (fn) BA_TRY(hipMemsetAsync(B->sep_msgs.p, 0, sizeof(double) * B->msg_doubles * (size_t)R, B->st));
+  cs::ba_launch_reduce(B->view, lambda, B->st, B->st2, B->ev_fork, B->ev_join);
+  BA_TRY(hipMemcpyAsync(B->h_status + 1, B->d_elim_fail.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
+  BA_TRY(hipGetLastError());
+  BA_TRY(hipEventRecord(B->ev[3], B->st));
+  std::unique_lock<std::mutex> coop_turn(g_coop_mutex);
+  BA_TRY(hipMemsetAsync(B->d_int_info.p, 0, 24 * sizeof(int), B->st));
+  // the interior: L L^T = S(I, I), y = L^-1 b_I in place (one-sided order, right-hand side riding along)
+  cs::ba_launch_band_cholesky(B->S.p + (size_t)B->int_c * LD, B->int_work.p, B->int_n, LD, rhs + B->int_c, B->d_int_info.p, false, B->st, true);
+  BA_TRY(hipGetLastError());
+  if (fn) {   // the callback waits for the other ranks (threads of this process in the tests): the persistent kernel's turn must be free by then
+    BA_TRY(hipStreamSynchronize(B->st));
+    coop_turn.unlock();
+  }
+  cs::ba_launch_sep_reduce(B->S.p, LD, B->int_work.p, B->int_c, B->int_n, B->zl, B->wl, B->zr, B->wr, B->sepY.p, rhs, B->sep_msgs.p + (size_t)B->shard_rank * B->msg_doubles, B->w_max, B->st);
+  BA_TRY(hipGetLastError());
+  { int rc = coll_allgather(B, fn, ctx, B->sep_msgs.p, B->msg_doubles); if (rc) return rc; }
+  // every rank assembles and solves the (small) separator system: nothing to broadcast afterwards
+  cs::ba_launch_sep_assemble(B->sep_msgs.p, B->msg_doubles, B->w_max, R, B->d_sep_off.p, ns, B->sepS.p, rsep, B->st);
+  BA_TRY(hipGetLastError());
+  BA_ROC(rocsolver_dpotrf(B->blas, rocblas_fill_upper, ns, B->sepS.p, ns, B->d_info.p));
+  BA_ROC(rocsolver_dpotrs(B->blas, rocblas_fill_upper, ns, 1, B->sepS.p, ns, rsep, ns));   // (after a failed factorisation: garbage, flagged below)
+  cs::ba_launch_sep_scatter(rsep, ns, R, B->d_sep_off.p, B->d_sep_col.p, rhs, B->st);
+  cs::ba_launch_sep_backsolve(B->S.p, LD, B->int_work.p, B->int_c, B->int_n, B->zl, B->wl, B->zr, B->wr, B->sepY.p, rhs, B->d_int_info.p, B->st);
+  BA_TRY(hipGetLastError());
+  BA_TRY(hipEventRecord(B->ev[4], B->st));
+  cs::ba_launch_backsub(B->view, B->st);   // this rank's landmarks and cuboids see its own columns and the next separator only
+  BA_TRY(hipGetLastError());
+  // the solution vector: every rank contributes ITS columns (its separator as it solved it, its interior) and its cuboids' increments
+  // behind the reduced system, zeros elsewhere -- every entry then has one source, so all ranks end with the same bits
+  if (B->zl > 0) BA_TRY(hipMemsetAsync(rhs, 0, sizeof(double) * (size_t)B->zl, B->st));
+  if (B->int_c + B->int_n < B->n_red) BA_TRY(hipMemsetAsync(rhs + B->int_c + B->int_n, 0, sizeof(double) * (size_t)(B->n_red - B->int_c - B->int_n), B->st));
+  { int rc = coll_allreduce(B, fn, ctx, rhs, (size_t)B->n_pose); if (rc) return rc; }
+  BA_TRY(hipEventRecord(B->ev[5], B->st));
+  cs::ba_launch_fail_flag(B->d_int_info.p, B->d_elim_fail.p, reinterpret_cast<const int*>(B->d_info.p), B->d_scalars.p + 2, B->st);
+  BA_TRY(hipMemcpyAsync(B->h_status, B->d_int_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
+  BA_TRY(hipGetLastError());
+  B->tm.n_solves++;
+  if (defer) { if (coop_turn.owns_lock()) *defer = std::move(coop_turn); return CS_OK; }
+  BA_TRY(hipMemcpyAsync(B->h_scalars + 2, B->d_scalars.p + 2, sizeof(double), hipMemcpyDeviceToHost, B->st));
+  BA_TRY(hipStreamSynchronize(B->st));
+  if (coop_turn.owns_lock()) coop_turn.unlock();
+  if (*B->h_status == 0x7fffffff) { cs_set_error_ba("banded solver: team not co-resident (wait timed out); set CS_BA_FORCE_DENSE=1 on a shared device"); return CS_ERR_HIP; }
+  if (B->h_scalars[2] != 0.0) *ok = false;
+  return collect_solve_times(B);
 }
 
 }  // namespace
@@ -868,19 +1075,19 @@ void cs_ba_destroy(cs_ba* B) {
   DBuf<double>* dd[] = {&B->cams, &B->points, &B->cubes, &B->cams_bak, &B->points_bak, &B->cubes_bak, &B->pm_uv, &B->pm_info, &B->pm_intr, &B->pm_huber,
                         &B->cm_uv, &B->cm_info, &B->cm_intr, &B->cm_huber, &B->ce_meas, &B->ce_info, &B->ce_Hcc, &B->ce_Hoo, &B->ce_Hco, &B->ce_bc, &B->ce_bo,
                         &B->oe_meas, &B->oe_info, &B->oe_Hii, &B->oe_Hjj, &B->oe_Hij, &B->oe_bi, &B->oe_bj, &B->Hcam, &B->bcam, &B->Hcub, &B->bcub, &B->Hll, &B->bl,
-                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv, &B->scale_partial, &B->pe_meas, &B->pe_info, &B->pe_K, &B->part_tiles, &B->part_coef, &B->cub_M, &B->cub_Dinv};
+                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv, &B->scale_partial, &B->pe_meas, &B->pe_info, &B->pe_K, &B->part_tiles, &B->part_coef, &B->cub_M, &B->cub_Dinv, &B->sepY, &B->sep_msgs, &B->sepS, &B->int_work};
   for (auto* d : dd) d->release();
   DBuf<int>* di[] = {&B->d_ce_active, &B->d_oe_active, &B->d_cam_col, &B->d_cub_col, &B->d_pt_free, &B->pm_pt, &B->pm_cam, &B->pt_ptr, &B->cm_pm, &B->cm_pt, &B->cam_ptr, &B->d_ce_cam, &B->d_ce_cub,
                      &B->d_oe_i, &B->d_oe_j, &B->cam_ce_ptr, &B->cam_ce_idx, &B->cam_oei_ptr, &B->cam_oei_idx, &B->cam_oej_ptr, &B->cam_oej_idx, &B->cub_ce_ptr,
                      &B->cub_ce_idx, &B->pair_ptr, &B->pair_i1, &B->pair_i2, &B->ent_a, &B->ent_b, &B->d_run_lm, &B->d_seg_ptr, &B->d_seg_k, &B->d_seg_tile, &B->d_seg_slot,
                      &B->d_gp_ptr, &B->d_gp_i1, &B->d_gp_i2, &B->d_gtile, &B->d_gcam_ptr, &B->d_gslot, &B->d_cubS_ptr, &B->d_cubS_cam, &B->d_ce_slot, &B->d_cub_tile, &B->d_cub_coef,
-                     &B->d_elim_fail, &B->d_slotE_ptr, &B->d_slotE_idx, &B->d_cub_mine};
+                     &B->d_elim_fail, &B->d_slotE_ptr, &B->d_slotE_idx, &B->d_cub_mine, &B->d_sep_off, &B->d_sep_col, &B->d_int_info};
   for (auto* d : di) d->release();
   B->d_info.release(); B->d_band_info.release();
   for (auto& e : B->ev) if (e) (void)hipEventDestroy(e);
   if (B->h_status) (void)hipHostFree(B->h_status);
   if (B->h_scalars) (void)hipHostFree(B->h_scalars);
-  if (B->comm) (void)ncclCommDestroy(B->comm);
+  if (B->comm) { (void)ncclCommDestroy(B->comm); g_comm_handles--; }
   B->d_scalars.release();
   if (B->blas) rocblas_destroy_handle(B->blas);
   if (B->ev_fork) (void)hipEventDestroy(B->ev_fork);
@@ -1035,6 +1242,8 @@ int cs_ba_solve(cs_ba* B, double lambda, int* pd) {
 
 int cs_ba_update(cs_ba* B) {
   if (!B) return CS_ERR_INVALID_ARG;
+  BA_GUARD_BEGIN
+  if (B->structure_dirty || !B->have_system) { cs_set_error_ba("cs_ba_update: no solution to apply (call cs_ba_build_system and cs_ba_solve first)"); return CS_ERR_NOT_RUN; }
   BA_TRY(hipSetDevice(B->device));
   double t0 = now_ms();
   cs::ba_launch_update(B->view, B->st);
@@ -1042,25 +1251,31 @@ int cs_ba_update(cs_ba* B) {
   BA_TRY(hipStreamSynchronize(B->st));
   B->tm.update_ms += now_ms() - t0;
   return CS_OK;
+  BA_GUARD_END("cs_ba_update")
 }
 
 int cs_ba_push(cs_ba* B) {
   if (!B) return CS_ERR_INVALID_ARG;
+  BA_GUARD_BEGIN
   BA_TRY(hipSetDevice(B->device));
   int rc = finalize_structure(B); if (rc) return rc;
   if (B->nc) BA_TRY(hipMemcpyAsync(B->cams_bak.p, B->cams.p, 56 * (size_t)B->nc, hipMemcpyDeviceToDevice, B->st));
   if (B->np) BA_TRY(hipMemcpyAsync(B->points_bak.p, B->points.p, 24 * (size_t)B->np, hipMemcpyDeviceToDevice, B->st));
   if (B->no) BA_TRY(hipMemcpyAsync(B->cubes_bak.p, B->cubes.p, 80 * (size_t)B->no, hipMemcpyDeviceToDevice, B->st));
   return CS_OK;
+  BA_GUARD_END("cs_ba_push")
 }
 
 int cs_ba_pop(cs_ba* B) {
   if (!B) return CS_ERR_INVALID_ARG;
+  BA_GUARD_BEGIN
+  if (B->structure_dirty) { cs_set_error_ba("cs_ba_pop: nothing was pushed since the graph changed"); return CS_ERR_NOT_RUN; }
   BA_TRY(hipSetDevice(B->device));
   if (B->nc) BA_TRY(hipMemcpyAsync(B->cams.p, B->cams_bak.p, 56 * (size_t)B->nc, hipMemcpyDeviceToDevice, B->st));
   if (B->np) BA_TRY(hipMemcpyAsync(B->points.p, B->points_bak.p, 24 * (size_t)B->np, hipMemcpyDeviceToDevice, B->st));
   if (B->no) BA_TRY(hipMemcpyAsync(B->cubes.p, B->cubes_bak.p, 80 * (size_t)B->no, hipMemcpyDeviceToDevice, B->st));
   return CS_OK;
+  BA_GUARD_END("cs_ba_pop")
 }
 
 // optimization_algorithm_levenberg.cpp:61-163 + sparse_optimizer.cpp:354-419
@@ -1108,6 +1323,16 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
   // sharded -- ONE RCCL all-reduce of the pair [chi2, scale] are queued back to back; the host synchronises once per trial.
   const bool stream_flow = !cb && B->band_ld > 0 && B->n_red > 0;
   double t_begin = now_ms();
+  if (B->shard_n > 1) {
+    // every rank decides the solver layout from its own structure phase (and device query): the collectives below only match if
+    // they all decided alike
+    const double q[5] = {(double)B->n_red, (double)B->band_ld, B->elim ? 1.0 : 0.0, B->sep_mode ? 1.0 : 0.0, (double)B->n_sep};
+    double v[10];
+    for (int i = 0; i < 5; i++) { v[i] = q[i]; v[5 + i] = -q[i]; }
+    if (reduce_host(v, 10, 1)) { cs_set_error_ba("all-reduce failed"); return CS_ERR_HIP; }
+    for (int i = 0; i < 5; i++)
+      if (v[i] != q[i] || v[5 + i] != -q[i]) { cs_set_error_ba("sharded BA: the ranks disagree on the solver layout (reduced size / bandwidth / cuboid elimination / separator mode); check CS_BA_* environment variables and devices"); return CS_ERR_INVALID_ARG; }
+  }
   double lambda = -1, ni = 2;
   int nBad = 0, done = 0;
   double carriedChi = 0;
@@ -1163,13 +1388,14 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
         cs::ba_launch_chi2(B->view, B->nb_chi, B->st);
         cs::ba_launch_sum2(B->chi_partial.p, B->n_chi_partials, B->scale_partial.p, cs::ba_scale_blocks(), B->d_scalars.p, B->st);
         BA_TRY(hipGetLastError());
-        if (rccl) BA_NCCL(ncclAllReduce(B->d_scalars.p, B->d_scalars.p, 2, ncclDouble, ncclSum, B->comm, B->st));
-        BA_TRY(hipMemcpyAsync(B->h_scalars, B->d_scalars.p, 2 * sizeof(double), hipMemcpyDeviceToHost, B->st));
+        // [chi2, scale term, "a factorisation failed somewhere"]: one message; every rank takes the same accept / reject branch
+        if (rccl) BA_NCCL(ncclAllReduce(B->d_scalars.p, B->d_scalars.p, 3, ncclDouble, ncclSum, B->comm, B->st));
+        BA_TRY(hipMemcpyAsync(B->h_scalars, B->d_scalars.p, 3 * sizeof(double), hipMemcpyDeviceToHost, B->st));
         BA_TRY(hipEventRecord(B->ev[7], B->st));
         BA_TRY(hipStreamSynchronize(B->st));
         turn.unlock();
         if (*B->h_status == 0x7fffffff) { cs_set_error_ba("banded solver: team not co-resident (wait timed out); set CS_BA_FORCE_DENSE=1 on a shared device"); return CS_ERR_HIP; }
-        ok2 = B->h_status[0] == 0 && B->h_status[1] == 0;
+        ok2 = B->h_scalars[2] == 0.0;
         tempChi = B->h_scalars[0];
         scale = ok2 ? B->h_scalars[1] : 0.0;
         rc = collect_solve_times(B); if (rc) return rc;
@@ -1177,6 +1403,11 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
         BA_TRY(hipEventElapsedTime(&ms, B->ev[6], B->ev[7])); B->tm.errors_ms += ms;
       } else {
         rc = solve_device(B, lambda, &ok2, fn, ctx); if (rc) return rc;
+        if (B->shard_n > 1) {   // a failed factorisation on one rank is everybody's rejected trial
+          double ff = ok2 ? 0.0 : 1.0;
+          if (reduce_host(&ff, 1, 1)) { cs_set_error_ba("all-reduce failed"); return CS_ERR_HIP; }
+          ok2 = ff == 0.0;
+        }
         if (ok2) {
           const int nsb = cs::ba_scale_blocks();
           std::vector<double> sp(nsb);
@@ -1244,21 +1475,50 @@ int cs_ba_comm_unique_id(unsigned char id128[128]) {
 int cs_ba_comm_init(cs_ba* B, int rank, int n_ranks, const unsigned char id128[128]) {
   if (!B || !id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return CS_ERR_INVALID_ARG;
   BA_TRY(hipSetDevice(B->device));
-  if (B->comm) { (void)ncclCommDestroy(B->comm); B->comm = nullptr; }
+  if (B->comm) { (void)ncclCommDestroy(B->comm); B->comm = nullptr; g_comm_handles--; }
+  if (g_comm_handles.load() > 0) { cs_set_error_ba("cs_ba_comm_init: this process already holds a communicator handle (one process per GPU)"); return CS_ERR_INVALID_ARG; }
   ncclUniqueId id;
   std::memcpy(id.internal, id128, 128);
   BA_NCCL(ncclCommInitRank(&B->comm, n_ranks, id, rank));
+  g_comm_handles++;
   return cs_ba_set_shard(B, rank, n_ranks);
+}
+
+// How the sharded solve is organised (after the structure phase): separator mode or the all-reduce of the whole [S | b]; the size of
+// the separator system; the bytes this rank contributes to the collectives of one LM trial, and what the all-reduce would be.
+int cs_ba_shard_info(cs_ba* B, int* sep_mode, int* n_sep, int* w_max, long long* bytes_per_trial, long long* bytes_per_trial_allreduce, int* interior_n) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  BA_GUARD_BEGIN
+  int rc = finalize_structure(B); if (rc) return rc;
+  if (sep_mode) *sep_mode = B->sep_mode ? 1 : 0;
+  if (n_sep) *n_sep = B->n_sep;
+  if (w_max) *w_max = B->w_max;
+  if (bytes_per_trial) *bytes_per_trial = B->bytes_per_trial;
+  if (bytes_per_trial_allreduce) *bytes_per_trial_allreduce = B->bytes_per_trial_allreduce;
+  if (interior_n) *interior_n = B->sep_mode ? B->int_n : B->n_red;
+  return CS_OK;
+  BA_GUARD_END("cs_ba_shard_info")
+}
+// The rank that owns each landmark under the rule in force (separator mode: by the lowest column of its free cameras).
+int cs_ba_get_landmark_owners(cs_ba* B, int* owner_out) {
+  if (!B || (B->np && !owner_out)) return CS_ERR_INVALID_ARG;
+  BA_GUARD_BEGIN
+  int rc = finalize_structure(B); if (rc) return rc;
+  std::copy(B->lm_owner.begin(), B->lm_owner.end(), owner_out);
+  return CS_OK;
+  BA_GUARD_END("cs_ba_get_landmark_owners")
 }
 
 int cs_ba_get_state(cs_ba* B, double* cams7, double* cuboids10, double* points3) {
   if (!B) return CS_ERR_INVALID_ARG;
+  BA_GUARD_BEGIN
   BA_TRY(hipSetDevice(B->device));
   BA_TRY(hipStreamSynchronize(B->st));
   if (cams7 && B->nc) BA_TRY(hipMemcpy(cams7, B->cams.p, 56 * (size_t)B->nc, hipMemcpyDeviceToHost));
   if (cuboids10 && B->no) BA_TRY(hipMemcpy(cuboids10, B->cubes.p, 80 * (size_t)B->no, hipMemcpyDeviceToHost));
   if (points3 && B->np) BA_TRY(hipMemcpy(points3, B->points.p, 24 * (size_t)B->np, hipMemcpyDeviceToHost));
   return CS_OK;
+  BA_GUARD_END("cs_ba_get_state")
 }
 
 static int cs_ba_sizes_impl(cs_ba* B, int* size_pose, int* size_lm) {

@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void ba_cam_rhs_kernel(BaView v, double lambda
   }
   if (threadIdx.x < 36) {
     int i = threadIdx.x / 6, j = threadIdx.x % 6;
-    if (i >= j) *ba_S_at(v, col + i, col + j) = v.Hcam[36 * c + threadIdx.x] + ((i == j && v.add_lambda) ? lambda : 0.0);
+    if (i >= j) *ba_S_at(v, col + i, col + j) = v.Hcam[36 * c + threadIdx.x] + ((i == j && col >= v.lam_lo && col < v.lam_hi) ? lambda : 0.0);
   }
 }
 
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(128) void ba_cub_scatter_kernel(BaView v, double la
   if (col < 0) return;
   if (t < 81) {
     int i = t / 9, j = t % 9;
-    if (i >= j) *ba_S_at(v, col + i, col + j) = v.Hcub[81 * o + t] + ((i == j && v.add_lambda) ? lambda : 0.0);
+    if (i >= j) *ba_S_at(v, col + i, col + j) = v.Hcub[81 * o + t] + ((i == j && col >= v.lam_lo && col < v.lam_hi) ? lambda : 0.0);
   } else if (t < 90) {
     v.rhs[col + t - 81] = v.bcub[9 * o + t - 81];
   }
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(64) void ba_cam_rhs_fused_kernel(BaView v, double l
   }
   if (t < 36) {
     const int i = t / 6, j = t % 6;
-    if (i >= j) *ba_S_at(v, col + i, col + j) = v.Hcam[36 * c + t] + ((i == j && v.add_lambda) ? lambda : 0.0);
+    if (i >= j) *ba_S_at(v, col + i, col + j) = v.Hcam[36 * c + t] + ((i == j && col >= v.lam_lo && col < v.lam_hi) ? lambda : 0.0);
   }
 }
 
@@ -1764,16 +1764,17 @@ int ba_band_team(int LD, int* rw_out) {   // workgroups of the factorisation tea
   return G;
 }
 
-void ba_band_split(int n, int LD, int* K1, int* K2) {   // column blocks of the two fronts; the middle block keeps >= bw columns
+void ba_band_split(int n, int LD, int* K1, int* K2, bool force_one_sided = false) {   // column blocks of the two fronts; the middle block keeps >= bw columns
   const int bw = LD - 1;
   const int Kt = n > bw ? (n - bw) / BS : 0;
   static const bool one_sided = getenv("CS_BAND_ONE_SIDED") != nullptr;   // diagnostics: plain left-looking order
-  *K2 = (Kt >= 8 && !one_sided) ? Kt / 2 : 0;
+  *K2 = (Kt >= 8 && !one_sided && !force_one_sided) ? Kt / 2 : 0;
   *K1 = Kt - *K2;
 }
 // The nested (four-front) order pays when both halves still have two real fronts; it needs the separator's row
 // workgroups co-resident with the four teams, which bounds the bandwidth it is used for.
-bool ba_band_nested(int n, int LD, int* wc_out, int* c0_out) {
+bool ba_band_nested(int n, int LD, int* wc_out, int* c0_out, bool force_one_sided = false) {
+  if (force_one_sided) return false;
   static const bool off = getenv("CS_BAND_TWO_FRONTS") != nullptr || getenv("CS_BAND_ONE_SIDED") != nullptr;   // diagnostics: the two-front order
   const int bw = LD - 1;
   const int wc = ((bw + BS - 1) / BS) * BS;
@@ -1786,6 +1787,7 @@ static size_t band_blocks(int n) { return (size_t)((n + BS - 1) / BS) * BS * BS;
 // doubles of workspace behind `work` (inverted diagonal blocks; nested order: + the separator's factor rows, partial
 // Schur complements and dense block)
 size_t ba_band_workspace_doubles(int n, int LD) {
+  if (n <= 0) return 1;
   size_t two = 2 * band_blocks(n);
   int wc = 0, c0 = 0;
   if (!ba_band_nested(n, LD, &wc, &c0)) return two;
@@ -1819,14 +1821,16 @@ bool ba_band_fits_device(int n, int LD) {
 // info (24 ints, zeroed by the caller): [0] first non-positive pivot (+1; INT_MAX: a wait timed out, see band_wait_ge), [1..3] barrier counters of the two-front
 // order (forward team, reverse team, both), [4..5] a zero double (the target of masked loads), [6..14] barrier counters
 // of the nested order, [15..18] published-block counters of the fronts' diagonal workgroups, [19] abort word.  work: ba_band_workspace_doubles(n, LD) doubles.
-void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st) {
+// one_sided: the plain left-looking order (the factor then lies in the band in the matrix's own index space: what the sharded
+// solve's interior elimination needs, ba_launch_sep_*)
+void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st, bool one_sided) {
   int rw = 0, K1 = 0, K2 = 0, wc = 0, c0 = 0;
   const int G = ba_band_team(LD, &rw);
   const int bw = LD - 1;
   const double* zero = reinterpret_cast<const double*>(info + 4);
   const BandView fwd{Sb, 1, (long long)bw, rhs, 1};
   const BandView rev{Sb + (size_t)(n - 1) * LD, -(long long)bw, -1, rhs + (n - 1), -1};
-  if (ba_band_nested(n, LD, &wc, &c0)) {
+  if (ba_band_nested(n, LD, &wc, &c0, one_sided)) {
     BandNested P;
     const int c1 = c0 + wc, nh[2] = {c0, n - c1};
     double* wp = work;
@@ -1880,7 +1884,7 @@ void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rh
     }
     return;
   }
-  ba_band_split(n, LD, &K1, &K2);
+  ba_band_split(n, LD, &K1, &K2, one_sided);
   unsigned* bars = reinterpret_cast<unsigned*>(info + 1);
   double* Linv_f = work;
   double* Linv_r = work + band_blocks(n);
@@ -1905,6 +1909,216 @@ void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rh
     Q.h[0] = BandHalf{fwd, rev, n, K1, K2, 0, Linv_f, Linv_r, nullptr}; Q.h[1] = Q.h[0]; Q.bw = bw; Q.zero = zero;
     hipLaunchKernelGGL(band_backsolve_kernel, dim3(K2 > 0 ? 2 : 1), dim3(256), 0, st, Q);
   }
+}
+
+
+// ------------------------------------------------------------- sharded reduced solve: interiors and separators --
+// Sharded BA (ba_host.cpp, "separator mode"): rank r owns the columns [cut_r, cut_r+1) of the band; its first w >= bw columns are the
+// separator Z_r (none on rank 0), the rest its interior I_r.  Interiors of different ranks are further apart than the bandwidth, so
+// they are decoupled; an interior is coupled to the separator in front of it (Z_r, "left") and to the one behind it (Z_r+1, the next
+// rank's, "right").  Per damped solve a rank factorises ITS interior only (band_chol_coop_kernel, one-sided order, right-hand side
+// riding along), and forms what the separators need of it:
+//     Y = B L^-T   (rows: the unknowns of Z_r and Z_r+1, columns: the interior)      ba_sep_trsm_kernel
+//     T = C - Y Y^T,   t = b_Z - Y y                                                  ba_sep_schur_kernel, ba_sep_rhs_kernel
+// with C the rank's own partial blocks S(Z_r, Z_r), S(Z_r+1, Z_r+1).  The ranks exchange (T, t) -- three w x w blocks and two
+// w-vectors each, the only matrix data that crosses the links --, every rank assembles and solves the small block-tridiagonal
+// separator system, then x_I = L^-T (y - Y^T x_Z) (ba_sep_correct_kernel + band_backsolve_kernel).
+struct SepView {
+  const double* S; int LD;          // the band (lower, LD doubles per column), the interior's factor in place
+  const double* Linv;               // inverted diagonal blocks of the interior's factor (32 x 32 each, row-major)
+  int ci, ni;                       // interior = columns [ci, ci + ni)
+  int zl, wl, zr, wr;               // left separator [zl, zl + wl), right separator [zr, zr + wr); widths may be 0
+  double* Y;                        // (wl + wr) x ni, row-major
+  const double* rhs;                // the global right-hand side / solution vector (y of the interior at rhs + ci)
+};
+// A(q, j): coupling of separator row q (0 .. wl - 1 left, wl .. wl + wr - 1 right) with interior column j
+__device__ __forceinline__ double sep_coupling(const SepView& V, int q, int j) {
+  const int bw = V.LD - 1;
+  if (q < V.wl) {           // S(row ci + j, col zl + q): stored in the separator's column
+    const int d = (V.ci + j) - (V.zl + q);
+    return d <= bw ? V.S[(size_t)(V.zl + q) * V.LD + d] : 0.0;
+  }
+  const int d = (V.zr + (q - V.wl)) - (V.ci + j);     // S(row zr + q', col ci + j): stored in the interior's column, below the interior
+  return d <= bw ? V.S[(size_t)(V.ci + j) * V.LD + d] : 0.0;
+}
+enum { SEP_RW = 8 };
+// One workgroup per SEP_RW separator rows, walking the interior's column blocks in order (the rows are independent of each other:
+// no grid barrier).  Thread (rq, c): row rq of the group, column c of the block.
+__global__ __launch_bounds__(256) void ba_sep_trsm_kernel(SepView V) {
+  __shared__ double Lc[BS][BS + 1];      // Lc[c'][d] = L(k0 + c', s0 + d)
+  __shared__ double Yc[SEP_RW][BS + 1];  // Yc[rq][d] = Y(q, s0 + d); afterwards U
+  __shared__ double Li[BS][BS + 1];
+  const int tid = threadIdx.x, c = tid & 31, rq = tid >> 5;
+  const int nq = V.wl + V.wr, q = blockIdx.x * SEP_RW + rq, bw = V.LD - 1;
+  const bool qok = q < nq;
+  const double* Sint = V.S + (size_t)V.ci * V.LD;      // &L(i, j) = Sint + j LD + (i - j)
+  // rows of the right separator are zero up to the first interior column inside their band
+  int first = 0;
+  {
+    const int q_lo = blockIdx.x * SEP_RW;              // the group's first row decides (left rows: column 0)
+    if (q_lo >= V.wl) first = max(0, (V.zr + (q_lo - V.wl)) - bw - V.ci) / BS;
+  }
+  double* Yrow = V.Y + (size_t)(qok ? q : 0) * V.ni;
+  for (int j = tid; j < first * BS; j += 256)
+    for (int r = 0; r < SEP_RW; r++) if (blockIdx.x * SEP_RW + r < nq) V.Y[(size_t)(blockIdx.x * SEP_RW + r) * V.ni + j] = 0.0;
+  const int nblk = (V.ni + BS - 1) / BS;
+  for (int kb = first; kb < nblk; kb++) {
+    const int k0 = kb * BS, nb = min(BS, V.ni - k0);
+    double acc = 0.0;
+    const int jlo = max(first * BS, max(0, k0 - bw) & ~(BS - 1));
+    for (int s0 = jlo; s0 < k0; s0 += BS) {
+      // L(k0 + c', s0 + d): thread loads c' = c, d = rq + 8 u (consecutive c' are consecutive addresses)
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int d = rq + 8 * u, i = k0 + c, j = s0 + d;
+        Lc[c][d] = (c < nb && i - j <= bw) ? Sint[(size_t)j * V.LD + (i - j)] : 0.0;
+      }
+      Yc[rq][c] = qok ? Yrow[s0 + c] : 0.0;
+      __syncthreads();
+#pragma unroll 8
+      for (int d = 0; d < BS; d++) acc = fma(Yc[rq][d], Lc[c][d], acc);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int e = tid + 256 * u; Li[e >> 5][e & 31] = V.Linv[(size_t)kb * BS * BS + e]; }
+    Yc[rq][c] = (qok && c < nb) ? sep_coupling(V, q, k0 + c) - acc : 0.0;     // U
+    __syncthreads();
+    double y = 0.0;
+    for (int cc = 0; cc <= c; cc++) y = fma(Yc[rq][cc], Li[c][cc], y);        // U L_kk^-T
+    if (qok && c < nb) Yrow[k0 + c] = y;
+    __syncthreads();   // (also orders this block's stores before the next block's loads of them)
+  }
+}
+// T = C - Y Y^T on the index pairs a >= b of the combined separator index (left rows first): one 16 x 16 tile per workgroup.
+// msg = [LL | RL | RR | tL | tR] with blocks of wm x wm (row-major, wm = the widest separator of the job) and vectors of wm.
+__global__ __launch_bounds__(256) void ba_sep_schur_kernel(SepView V, double* msg, int wm) {
+  __shared__ double Ya[16][BS + 1], Yb[16][BS + 1];
+  const int nq = V.wl + V.wr, nt = (nq + 15) / 16;
+  // tile (ta, tb), ta >= tb, from the linear block index
+  int ta = 0, rem = blockIdx.x;
+  while (rem > ta) { rem -= ta + 1; ta++; }
+  const int tb = rem;
+  if (ta >= nt) return;
+  const int tid = threadIdx.x, la = tid >> 4, lb = tid & 15;
+  const int a = ta * 16 + la, b = tb * 16 + lb;
+  double acc = 0.0;
+  for (int j0 = 0; j0 < V.ni; j0 += BS) {
+    for (int e = tid; e < 16 * BS; e += 256) {
+      const int r = e >> 5, d = e & 31, j = j0 + d;
+      Ya[r][d] = (ta * 16 + r < nq && j < V.ni) ? V.Y[(size_t)(ta * 16 + r) * V.ni + j] : 0.0;
+      Yb[r][d] = (tb * 16 + r < nq && j < V.ni) ? V.Y[(size_t)(tb * 16 + r) * V.ni + j] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int d = 0; d < BS; d++) acc = fma(Ya[la][d], Yb[lb][d], acc);
+    __syncthreads();
+  }
+  if (a >= nq || b >= nq || a < b) return;
+  const int bw = V.LD - 1;
+  const bool ar = a >= V.wl, br = b >= V.wl;
+  double cval = 0.0;
+  if (ar == br) {         // both in one separator: the rank's own partial block of S
+    const int z = ar ? V.zr : V.zl, ia = ar ? a - V.wl : a, ib = br ? b - V.wl : b;
+    if (ia - ib <= bw) cval = V.S[(size_t)(z + ib) * V.LD + (ia - ib)];
+  }
+  double* dst = (!ar) ? msg + (size_t)a * wm + b                                   // LL
+              : (!br) ? msg + (size_t)wm * wm + (size_t)(a - V.wl) * wm + b        // RL (row: right, column: left)
+                      : msg + 2 * (size_t)wm * wm + (size_t)(a - V.wl) * wm + (b - V.wl);   // RR
+  *dst = cval - acc;
+}
+// t = b_Z - Y y: one wavefront per separator row
+__global__ __launch_bounds__(64) void ba_sep_rhs_kernel(SepView V, double* msg, int wm) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  if (q >= V.wl + V.wr) return;
+  double s = 0.0;
+  for (int j = lane; j < V.ni; j += 64) s = fma(V.Y[(size_t)q * V.ni + j], V.rhs[V.ci + j], s);
+  s = wave_sum(s);
+  if (lane == 0) {
+    const bool right = q >= V.wl;
+    const int g = right ? V.zr + (q - V.wl) : V.zl + q;
+    msg[3 * (size_t)wm * wm + (right ? wm + (q - V.wl) : q)] = V.rhs[g] - s;
+  }
+}
+// The separator system from the ranks' messages.  Separator k (k = 1 .. R - 1, rows sep_off[k] .. sep_off[k + 1] of the system) is
+// the left separator of rank k and the right separator of rank k - 1: its diagonal block is LL of rank k + RR of rank k - 1, its
+// right-hand side tL of rank k + tR of rank k - 1; the block (Z_k+1, Z_k) is RL of rank k, whose interior lies between the two.
+// Dense, lower triangle, element (r, c) at Ssep[r * n + c] (the layout of the dense reduced system).
+__global__ __launch_bounds__(256) void ba_sep_assemble_kernel(const double* msgs, size_t msg_doubles, int wm, int R, const int* sep_off, int n, double* Ssep, double* rsep) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)n * (n + 1)) return;
+  const int r = (int)(e / (n + 1)), c = (int)(e % (n + 1));
+  // separator of row r: sep_off[k] <= r < sep_off[k + 1], k = 1 .. R - 1 (sep_off[1] = 0, sep_off[R] = n)
+  int kr = 1;
+  while (kr + 1 < R && sep_off[kr + 1] <= r) kr++;
+  const int lr = r - sep_off[kr];
+  if (c == n) {   // right-hand side: tL of rank kr + tR of rank kr - 1
+    rsep[r] = msgs[(size_t)kr * msg_doubles + 3 * (size_t)wm * wm + lr] + msgs[(size_t)(kr - 1) * msg_doubles + 3 * (size_t)wm * wm + wm + lr];
+    return;
+  }
+  if (c > r) return;
+  int kc = 1;
+  while (kc + 1 < R && sep_off[kc + 1] <= c) kc++;
+  const int lc = c - sep_off[kc];
+  double v = 0.0;
+  if (kr == kc) v = msgs[(size_t)kr * msg_doubles + (size_t)lr * wm + lc] + msgs[(size_t)(kr - 1) * msg_doubles + 2 * (size_t)wm * wm + (size_t)lr * wm + lc];
+  else if (kr == kc + 1) v = msgs[(size_t)kc * msg_doubles + (size_t)wm * wm + (size_t)lr * wm + lc];
+  Ssep[(size_t)r * n + c] = v;
+}
+// x of the separators to their places in the solution vector (sep_col[k]: first column of Z_k)
+__global__ __launch_bounds__(256) void ba_sep_scatter_kernel(const double* xsep, int n, int R, const int* sep_off, const int* sep_col, double* x) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  int k = 1;
+  while (k + 1 < R && sep_off[k + 1] <= r) k++;
+  x[sep_col[k] + (r - sep_off[k])] = xsep[r];
+}
+// y_I -= Y^T x_Z
+__global__ __launch_bounds__(256) void ba_sep_correct_kernel(SepView V, double* y) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= V.ni) return;
+  double s = 0.0;
+  for (int q = 0; q < V.wl; q++) s = fma(V.Y[(size_t)q * V.ni + j], V.rhs[V.zl + q], s);
+  for (int q = 0; q < V.wr; q++) s = fma(V.Y[(size_t)(V.wl + q) * V.ni + j], V.rhs[V.zr + q], s);
+  y[V.ci + j] -= s;
+}
+// status words of a trial -> one double (0 = fine), so that the flag can ride in the scalar all-reduce of the trial
+__global__ void ba_fail_flag_kernel(const int* a, const int* b, const int* c, double* out) {
+  if (threadIdx.x == 0) *out = ((a && *a) || (b && *b) || (c && *c)) ? 1.0 : 0.0;
+}
+
+void ba_launch_sep_reduce(const double* S, int LD, const double* Linv, int ci, int ni, int zl, int wl, int zr, int wr, double* Y, const double* rhs, double* msg, int wm, hipStream_t st) {
+  const SepView V{S, LD, Linv, ci, ni, zl, wl, zr, wr, Y, rhs};
+  const int nq = wl + wr;
+  if (nq <= 0) return;
+  hipLaunchKernelGGL(ba_sep_trsm_kernel, dim3((nq + SEP_RW - 1) / SEP_RW), dim3(256), 0, st, V);
+  const int nt = (nq + 15) / 16;
+  hipLaunchKernelGGL(ba_sep_schur_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, V, msg, wm);
+  hipLaunchKernelGGL(ba_sep_rhs_kernel, dim3(nq), dim3(64), 0, st, V, msg, wm);
+}
+void ba_launch_sep_assemble(const double* msgs, size_t msg_doubles, int wm, int R, const int* sep_off, int n, double* Ssep, double* rsep, hipStream_t st) {
+  const long long total = (long long)n * (n + 1);
+  if (total > 0) hipLaunchKernelGGL(ba_sep_assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, msgs, msg_doubles, wm, R, sep_off, n, Ssep, rsep);
+}
+void ba_launch_sep_scatter(const double* xsep, int n, int R, const int* sep_off, const int* sep_col, double* x, hipStream_t st) {
+  if (n > 0) hipLaunchKernelGGL(ba_sep_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, xsep, n, R, sep_off, sep_col, x);
+}
+// x_I = L^-T (y - Y^T x_Z): the correction, then the interior's back-substitution (one-sided order: one workgroup)
+void ba_launch_sep_backsolve(double* S, int LD, double* work, int ci, int ni, int zl, int wl, int zr, int wr, double* Y, double* rhs, int* info, hipStream_t st) {
+  if (ni <= 0) return;
+  const SepView V{S, LD, work, ci, ni, zl, wl, zr, wr, Y, rhs};
+  if (wl + wr > 0) hipLaunchKernelGGL(ba_sep_correct_kernel, dim3((ni + 255) / 256), dim3(256), 0, st, V, rhs);
+  int K1 = 0, K2 = 0;
+  ba_band_split(ni, LD, &K1, &K2, true);
+  const int bw = LD - 1;
+  double* Sb = S + (size_t)ci * LD;
+  const BandView fwd{Sb, 1, (long long)bw, rhs + ci, 1};
+  const BandView rev{Sb + (size_t)(ni - 1) * LD, -(long long)bw, -1, rhs + ci + (ni - 1), -1};
+  BandSolve Q;
+  Q.h[0] = BandHalf{fwd, rev, ni, K1, K2, 0, work, work + band_blocks(ni), nullptr}; Q.h[1] = Q.h[0]; Q.bw = bw; Q.zero = reinterpret_cast<const double*>(info + 4);
+  hipLaunchKernelGGL(band_backsolve_kernel, dim3(1), dim3(256), 0, st, Q);
+}
+void ba_launch_fail_flag(const int* a, const int* b, const int* c, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(ba_fail_flag_kernel, dim3(1), dim3(64), 0, st, a, b, c, out);
 }
 
 // ---------------------------------------------------------------------------------------- launchers --

@@ -61,7 +61,8 @@ struct BaView {
                                 // S[r * n_pose + c]; band_ld > 0: band storage, element (r, c) at S[c * band_ld + (r - c)],
                                 // band_ld = bandwidth + 1 (the pose vertices are ordered by reverse Cuthill-McKee)
   int band_ld;
-  int add_lambda;               // sharded BA: exactly one rank adds lambda to the pose diagonals (the partial systems are summed)
+  int lam_lo, lam_hi;           // sharded BA: lambda goes to the pose diagonals of the columns [lam_lo, lam_hi) only -- every column
+                                // gets it from exactly one rank (the partial systems are summed)
   double* rhs;                  // n_pose       b_schur, overwritten by x_p
   double* xl;                   // np x 3       landmark increments
   // Schur structure: one entry per (landmark, ordered camera pair i1 <= i2), grouped by block pair

@@ -256,14 +256,25 @@ int cs_ba_pop(cs_ba* ba);
 int cs_ba_optimize(cs_ba* ba, int iterations, int* iterations_done, double* chi2_hist, double* lambda_hist, int* trials_hist, int hist_cap);
 
 /* Sharded BA over the GPUs of one node (one process per GPU).  Every rank describes the FULL problem
- * (cs_ba_set_vertices / set_edges_*) and then calls cs_ba_set_shard(rank, n_ranks): the library keeps the landmarks
- * whose first observing camera falls into this rank's camera subsequence [rank*Nc/R, (rank+1)*Nc/R) together with
- * all their projection edges, and the cuboid / odometry edges of its own cameras.  Residuals, Jacobians, landmark
- * blocks and Schur products are then rank-local; the ranks' partial reduced systems [S | b_schur] are summed with
- * ONE all-reduce per damped solve (RCCL over xGMI when the caller passes torch.distributed / ncclAllReduce), the
- * reduced solve is replicated, back-substitution is local.  `fn` performs an in-place all-reduce of n doubles at
- * `data` (device memory if on_device != 0, else host), op 0 = SUM, 1 = MAX; it must return 0 on success and have
- * completed when it returns.  With n_ranks == 1 (or fn == NULL) this is cs_ba_optimize.                          */
+ * (cs_ba_set_vertices / set_edges_*) and then calls cs_ba_set_shard(rank, n_ranks) (or cs_ba_comm_init).
+ *
+ * Separator mode (the banded reduced system, every rank's share wide enough; cs_ba_shard_info reports it): rank r owns the
+ * columns [cut_r, cut_r+1) of the band in solver order -- its first >= bandwidth columns are the separator Z_r, the rest its
+ * interior -- and every landmark (with all its projection edges), cuboid and odometry edge whose lowest column falls into that
+ * range.  Residuals, Jacobians, landmark blocks and Schur products are rank-local and land in the rank's own columns and in the
+ * diagonal block of the next separator; each rank factorises ITS interior only, the ranks exchange the separators' Schur
+ * complements (one all-gather of 3 w^2 + 2 w doubles per rank, w = separator width ~ bandwidth: ~0.35 MB at KITTI shape), every
+ * rank solves the small separator system, back-substitutes its interior, and one all-reduce of the solution vector (8 n_pose bytes)
+ * hands every rank all increments (block_solver.hpp:385-485 is what a shard builds and solves).  A third, three-double all-reduce
+ * carries [chi2, LM scale term, "a factorisation failed"].
+ *
+ * Fallback (dense reduced system, or shares narrower than the band): landmarks go to the rank of the camera subsequence
+ * [rank*Nc/R, (rank+1)*Nc/R) of their first observing camera, cuboid / odometry edges to their camera's; the ranks' partial
+ * reduced systems [S | b_schur] are summed with ONE all-reduce per damped solve and the reduced solve is replicated.
+ *
+ * `fn` performs an in-place all-reduce of n doubles at `data` (device memory if on_device != 0, else host), op 0 = SUM, 1 = MAX;
+ * it must return 0 on success and have completed when it returns (an all-gather is issued through it as the sum of zero-padded
+ * buffers).  With n_ranks == 1 (or fn == NULL and no communicator) this is cs_ba_optimize.                                   */
 typedef int (*cs_allreduce_fn)(void* ctx, void* data, size_t n_doubles, int on_device, int op);
 int cs_ba_set_shard(cs_ba* ba, int rank, int n_ranks);
 /* RCCL (librccl, the collectives run over xGMI): the library issues ncclAllReduce itself, on the handle's own stream, queued
@@ -271,13 +282,19 @@ int cs_ba_set_shard(cs_ba* ba, int rank, int n_ranks);
  * cs_ba_comm_unique_id() (ncclGetUniqueId) and hands the 128 bytes to every rank by whatever means the application has (MPI,
  * torch.distributed, a file); every rank then calls cs_ba_comm_init(), which creates the communicator (ncclCommInitRank: a
  * collective call) and sets the shard like cs_ba_set_shard().  cs_ba_optimize_sharded(..., fn = NULL, ...) then uses it: per LM
- * trial one all-reduce of [S | b_schur] and one of the pair [chi2, x^T(lambda x + b)], one host synchronisation.            */
+ * trial the collectives above, queued on the stream, and one host synchronisation.  One communicator handle per process.    */
 int cs_ba_comm_unique_id(unsigned char id128[128]);
 int cs_ba_comm_init(cs_ba* ba, int rank, int n_ranks, const unsigned char id128[128]);
 int cs_ba_optimize_sharded(cs_ba* ba, int iterations, cs_allreduce_fn fn, void* ctx, int* iterations_done,
                            double* chi2_hist, double* lambda_hist, int* trials_hist, int hist_cap);
-/* Host-only: the rank that owns each landmark under that rule (no GPU needed; used by the CPU multi-process test). */
+/* Host-only: the rank that owns each landmark under the FALLBACK rule (no GPU needed; used by the CPU multi-process test). */
 int cs_ba_shard_landmark_owners(int n_ranks, int n_cams, int n_points, int n_proj, const int* e_pt, const int* e_cam, int* owner_out);
+/* The rule in force for this handle (after the structure phase): owner of every landmark; how the sharded solve is organised --
+ * sep_mode 1 = separator mode, n_sep / w_max = size of the separator system / widest separator, bytes_per_trial = what this rank
+ * contributes to the collectives of one LM trial, bytes_per_trial_allreduce = what the all-reduce of [S | b] would move instead,
+ * interior_n = unknowns this rank factorises.  Any pointer may be NULL.                                                          */
+int cs_ba_get_landmark_owners(cs_ba* ba, int* owner_out);
+int cs_ba_shard_info(cs_ba* ba, int* sep_mode, int* n_sep, int* w_max, long long* bytes_per_trial, long long* bytes_per_trial_allreduce, int* interior_n);
 
 int cs_ba_get_state(cs_ba* ba, double* cams7, double* cuboids10, double* points3);
 int cs_ba_sizes(cs_ba* ba, int* size_pose, int* size_landmarks);

@@ -265,28 +265,57 @@ def _run_sharded_in_threads(pr, n_ranks, iters):
         done[r] = probs[r].optimize_sharded(iters, make_cb(r))
     th = [threading.Thread(target=work, args=(r,)) for r in range(n_ranks)]
     [t.start() for t in th]; [t.join() for t in th]
-    owners = capi.landmark_owners(n_ranks, len(pr["cams"]), len(pr["points"]), pr["e_pt"], pr["e_cam"])
+    owners = probs[0].landmark_owners()      # the rule in force (separator mode: lowest column; fallback: first camera's subsequence)
+    assert all(np.array_equal(owners, P.landmark_owners()) for P in probs)
     cams, cubs, _ = probs[0].state()
     pts = np.zeros_like(pr["points"])
     for r in range(n_ranks):
         pts[owners == r] = probs[r].state()[2][owners == r]
     hist = probs[0].history()
+    _run_sharded_in_threads.info = [P.shard_info() for P in probs]
+    _run_sharded_in_threads.owners = owners
+    for r in range(1, n_ranks):     # every rank ends with the same cameras and cuboids
+        cr, orr, _ = probs[r].state()
+        assert np.array_equal(cr, cams) and np.array_equal(orr, cubs), (r, np.abs(cr - cams).max(), np.abs(orr - cubs).max())
     for P in probs:
         P.close()
     return done, hist, cams, cubs, pts
 
 
-@pytest.mark.parametrize("n_ranks", [2, 3])
-def test_sharded_ba_equals_single_rank(n_ranks):
-    """Landmark-sharded BA with summed partial reduced systems == the unsharded optimisation (same LM trajectory)."""
-    pr = synth_ba.make_problem(n_cams=60, n_points=4000, n_cuboids=8, seed=21)
+@pytest.mark.parametrize("n_ranks,n_cams,sep", [(2, 60, 0), (3, 60, 0), (2, 160, 1), (3, 240, 1), (4, 330, 1)])
+def test_sharded_ba_equals_single_rank(n_ranks, n_cams, sep):
+    """Sharded BA == the unsharded optimisation (same LM trajectory): small problems through the all-reduce of the partial reduced
+    systems (shares narrower than the band), larger ones in separator mode -- interiors factorised per rank, separator complements
+    exchanged, the separator system solved by every rank."""
+    pr = synth_ba.make_problem(n_cams=n_cams, n_points=70 * n_cams, n_cuboids=max(8, n_cams // 8), seed=21)
     G = capi.ba_from_dict(pr)
     n1 = G.optimize(6)
     chi1, lam1, tr1 = G.history()
     c1, o1, p1 = G.state()
     done, (chiS, lamS, trS), cS, oS, pS = _run_sharded_in_threads(pr, n_ranks, 6)
+    info = _run_sharded_in_threads.info
+    assert [i["sep_mode"] for i in info] == [sep] * n_ranks, info
+    if sep:    # what a rank sends per trial is the separator message + the solution vector, not the band
+        assert all(i["bytes_per_trial"] < i["bytes_per_trial_allreduce"] for i in info), info
     assert done == [n1] * n_ranks
     assert np.array_equal(tr1, trS) and np.allclose(chi1, chiS, rtol=1e-9) and np.allclose(lam1, lamS, rtol=1e-9)
+    scale = np.abs(p1).max()
+    assert np.abs(pS - p1).max() < 1e-7 * scale and np.abs(cS - c1).max() < 1e-7 * scale and np.abs(oS - o1).max() < 1e-7 * scale
+
+
+def test_sharded_ba_separator_mode_without_cuboid_elimination(monkeypatch):
+    """g2o's reduced system (cuboids kept as unknowns, 9-column blocks in the ordering) through the separator mode."""
+    monkeypatch.setenv("CS_BA_KEEP_CUBOIDS", "1")
+    pr = synth_ba.make_problem(n_cams=260, n_points=12000, n_cuboids=30, seed=5)
+    G = capi.ba_from_dict(pr)
+    n1 = G.optimize(4)
+    chi1, lam1, tr1 = G.history()
+    c1, o1, p1 = G.state()
+    assert G.reduced_size()[1] == 0
+    G.close()
+    done, (chiS, lamS, trS), cS, oS, pS = _run_sharded_in_threads(pr, 2, 4)
+    assert [i["sep_mode"] for i in _run_sharded_in_threads.info] == [1, 1]
+    assert done == [n1] * 2 and np.array_equal(tr1, trS) and np.allclose(chi1, chiS, rtol=1e-9)
     scale = np.abs(p1).max()
     assert np.abs(pS - p1).max() < 1e-7 * scale and np.abs(cS - c1).max() < 1e-7 * scale and np.abs(oS - o1).max() < 1e-7 * scale
 
@@ -315,6 +344,26 @@ def test_banded_solver_matches_dense_solver(shape, monkeypatch):
     for a, b in zip(B.state(), D.state()):
         assert a.shape == b.shape and (a.size == 0 or np.abs(a - b).max() < 1e-8 * max(1.0, np.abs(b).max()))
     B.close(); D.close()
+
+
+def test_all_cameras_fixed_free_cuboids_and_points_still_optimise():
+    """Every camera fixed (the graph driver's frame-0 shape): nothing is left of the cameras-only system, so the cuboids must stay in
+    the reduced system (an elimination without a factorisation behind it would leave x = 0 and stop LM after one trial)."""
+    pr = synth_ba.make_problem(n_cams=12, n_points=300, n_cuboids=3, seed=8)
+    pr = dict(pr); pr["cam_fixed"] = np.ones_like(pr["cam_fixed"])
+    G = capi.ba_from_dict(pr)
+    n_red, elim = G.reduced_size()
+    assert n_red == 9 * 3 and not elim
+    chi0 = G.compute_errors()
+    n = G.optimize(5)
+    chi = G.history()[0]
+    R = _oracle(pr)
+    assert R.optimize(5) == n
+    assert chi[-1] < 0.9 * chi0 and np.allclose(chi, R.history()[0], rtol=1e-6)
+    scale = np.abs(R.state()[2]).max()
+    for a, b in zip(G.state(), R.state()):
+        assert np.abs(a - b).max() < 1e-5 * scale
+    G.close(); R.close()
 
 
 def test_banded_solver_reports_indefinite_system():
@@ -478,14 +527,23 @@ def test_c5_eight_shards_of_the_c4_problem_equal_the_single_rank_run():
     n1 = G.optimize(3)
     chi1, lam1, tr1 = G.history()
     c1, o1, p1 = G.state()
+    G_n_red = G.reduced_size()[0]
     G.close()
     done, (chiS, lamS, trS), cS, oS, pS = _run_sharded_in_threads(pr, 8, 3)
     assert done == [n1] * 8
     assert np.array_equal(tr1, trS) and np.allclose(chi1, chiS, rtol=1e-9) and np.allclose(lam1, lamS, rtol=1e-9)
     scale = np.abs(p1).max()
     assert np.abs(pS - p1).max() < 1e-7 * scale and np.abs(cS - c1).max() < 1e-7 * scale and np.abs(oS - o1).max() < 1e-7 * scale
+    # separator mode at this size: what a rank sends per LM trial is its separator message (3 w^2 + 2 w doubles) + the solution vector
+    # + three scalars -- under half a megabyte, against the 5.8 MB band an all-reduce of [S | b] would move
+    info = _run_sharded_in_threads.info
+    assert all(i["sep_mode"] == 1 for i in info), info
+    assert max(i["bytes_per_trial"] for i in info) < 500_000 < min(i["bytes_per_trial_allreduce"] for i in info), info
+    assert max(i["interior_n"] for i in info) < 0.2 * G_n_red
+    print("C5: separator system %d unknowns (w_max %d), interiors %s, bytes per trial and rank %d (all-reduce of the band: %d)"
+          % (info[0]["n_sep"], info[0]["w_max"], [i["interior_n"] for i in info], info[0]["bytes_per_trial"], info[0]["bytes_per_trial_allreduce"]))
     # every shard owns a share of the landmarks and the shares partition them
-    owners = capi.landmark_owners(8, 1000, 200000, pr["e_pt"], pr["e_cam"])
+    owners = _run_sharded_in_threads.owners
     cnt = np.bincount(owners, minlength=8)
     assert cnt.sum() == 200000 and cnt.min() > 0.5 * 200000 / 8
 

@@ -11,7 +11,7 @@
 #include <vector>
 
 namespace cs {
-void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st);
+void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st, bool one_sided);
 size_t ba_band_workspace_doubles(int n, int LD);
 }
 
@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
     hipMemcpyAsync(dr, b.data(), n * 8, hipMemcpyHostToDevice, st);
     hipMemsetAsync(dinfo, 0, 96, st);
     hipEventRecord(e0, st);
-    cs::ba_launch_band_cholesky(dS, dL, n, LD, dr, dinfo, true, st);
+    cs::ba_launch_band_cholesky(dS, dL, n, LD, dr, dinfo, true, st, argc > 4 && atoi(argv[4]) != 0);
     hipEventRecord(e1, st);
     hipStreamSynchronize(st);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
