@@ -45,7 +45,7 @@ def measure_traffic_live(args, n_unique):
         d = tempfile.mkdtemp(prefix="cs_pmc_", dir="/tmp")
         try:
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "2", "--warmup", "1", "--inflight", "1", "--ba", "none", "--no-cpu-baseline", "--no-edge", "--rp-frames", "0", "--no-measure-traffic",
+                   "--steps", "2", "--warmup", "1", "--inflight", "1", "--steady-steps", "0", "--ba", "none", "--no-cpu-baseline", "--no-edge", "--rp-frames", "0", "--no-measure-traffic",
                    "--frames", str(args.frames), "--unique", str(n_unique)]
             subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp", "CS_BENCH_CHILD": "1"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             n, tot = 0, 0.0
@@ -77,9 +77,11 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0, help="worker threads of the host stages (0 = library default)")
     ap.add_argument("--ba", default="C4", choices=["C4", "C3", "none"], help="also time the g2o BA path (second half of the BASELINE metric)")
     ap.add_argument("--ba-iters", type=int, default=10)
+    ap.add_argument("--shard-probe", type=int, default=8, help="N = 1 only: time one middle rank of this many (separator-mode sharded BA, loop-back transport) for the multi-GPU projection; 0 = skip")
     ap.add_argument("--chunks", type=int, default=0, help="cut the batch into this many chunks of the two-slot host/GPU pipeline (0 = library default)")
     ap.add_argument("--no-edge", action="store_true", help="skip the distance-map front end (Canny + distance transform) timing")
     ap.add_argument("--rp-frames", type=int, default=100, help="frames of the roll/pitch-sampling stress variant (RP = 25 poses per box, the reference's class default); 0 = skip")
+    ap.add_argument("--steady-steps", type=int, default=200, help="steps of the steady-state measurement reported beside the contract run (0 = skip)")
     ap.add_argument("--inflight", type=int, default=4, help="batches in flight per GPU: each has its own detector (streams, worker pool) and is driven by its own host thread, "
                     "so one batch's host stages (packing, record writing) overlap the other's sweep on the device")
     ap.add_argument("--no-measure-traffic", action="store_true", help="do not collect roofline.traffic in this run (two rocprofv3 --pmc passes -- FETCH_SIZE, WRITE_SIZE; "
@@ -109,13 +111,13 @@ def main():
         # only promise that for the small two-front teams (26 workgroups each), not for the nested order (106 each)
         os.environ.setdefault("CS_BAND_TWO_FRONTS", "1")
     torch.cuda.set_device(local_rank)
+    # Control plane (barriers, the max over ranks, the 128 bytes of the RCCL id): torch.distributed over gloo, on the CPU.  The data
+    # path's collectives are issued by libcubeslam_hip on its own RCCL communicator (cs_ba_comm_init), so exactly one RCCL is ever
+    # initialised in this process -- the one the library links -- and torch's bundled copy stays untouched.
     dist = None
     if world > 1:
         import torch.distributed as dist
-        if share_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")
 
     def barrier():
         if dist is not None:
@@ -125,7 +127,7 @@ def main():
     def max_over_ranks(x):
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
+        t = torch.tensor([x], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -197,6 +199,30 @@ def main():
     for a in accs:
         for k, v in a.items():
             acc[k] = acc.get(k, 0) + v
+    # steady state: the contract run's K steps include the pipelines' fill and drain (4 batches in flight: 15-30 % at K = 10-20); the
+    # same loop over >= 200 steps is the rate a long-running caller sees.  Reported beside `value`, never instead of it.
+    steady = None
+    if args.steady_steps > 0:
+        contract_steps = args.steps
+        args.steps = args.steady_steps
+        steps_taken[0] = 0
+        scratch = [dict() for _ in range(inflight)]
+        accs_saved, accs[:] = list(accs), scratch
+        barrier()
+        t1 = time.perf_counter()
+        if inflight == 1:
+            drive(0)
+        else:
+            th = [threading.Thread(target=drive, args=(p,)) for p in range(inflight)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+        barrier()
+        el2 = max_over_ranks(time.perf_counter() - t1)
+        accs[:] = accs_saved
+        args.steps = contract_steps
+        if errs:
+            raise errs[0]
+        steady = {"steps": args.steady_steps, "value": args.frames * args.steady_steps * world / el2, "unit": "frames/s", "ms_per_step": el2 / args.steady_steps * 1e3}
 
     # ---- stress variant of SURVEY 8(d): whether_sample_cam_roll_pitch = 1 (the reference class's default, detect_3d_cuboid.h:110;
     # main_obj.cpp:623 uses it from the second frame on): 5 x 5 roll / pitch samples around the camera pose, i.e. 25x the proposals
@@ -249,11 +275,11 @@ def main():
             if use_cb:
                 P.set_shard(rank, world)
             else:   # the library's own RCCL communicator: rank 0 draws the id, torch.distributed carries the 128 bytes
-                idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                idt = torch.zeros(128, dtype=torch.uint8)
                 if rank == 0:
-                    idt = torch.tensor(list(capi.comm_unique_id()), dtype=torch.uint8, device="cuda")
+                    idt = torch.tensor(list(capi.comm_unique_id()), dtype=torch.uint8)
                 dist.broadcast(idt, 0)
-                P.comm_init(rank, world, bytes(idt.cpu().tolist()))
+                P.comm_init(rank, world, bytes(idt.tolist()))
         P.sizes()                     # forces the structure phase
         torch.cuda.synchronize()
         structure_ms = (time.perf_counter() - ts) * 1e3
@@ -272,9 +298,15 @@ def main():
         nlin = max(1, tm["n_linearizations"] - t_before["n_linearizations"])
         nsol = max(1, tm["n_solves"] - t_before["n_solves"])
         build_ms = d["linearize_ms"] / nlin + d["reduce_ms"] / nsol
+        sinfo = P.shard_info()
+        sharding = "none"
+        if world > 1:
+            sharding = ("separator mode: every rank owns a column range of the banded reduced system (landmarks, cuboids and odometry edges by their lowest column), factorises its interior only; "
+                        "per LM trial one all-gather of the separator messages (3 w^2 + 2 w doubles per rank), one all-reduce of the solution vector and one of [chi2, scale, failure flag]"
+                        if sinfo["sep_mode"] else "landmarks by camera subsequence; per LM trial one all-reduce of [S | b_schur] + one of [chi2, scale, failure flag], replicated factorisation")
+            sharding += ("; collectives issued by the library on its own RCCL communicator and stream" if not use_cb else "; collectives through a torch.distributed callback (host round trips)")
         ba_out = {"metric": "BA LM iterations/sec", "value": n_it / ba_el, "unit": "iters/s", "config": args.ba, "cams": nc, "points": npt, "cuboids": no,
-                  "projection_edges": int(len(pr["e_pt"])), "iterations": int(n_it), "lm_trials": int(nsol), "sharding": ("landmarks by camera subsequence; per LM trial one ncclAllReduce of [S | b_schur] + one of [chi2, scale], issued by the library on its own stream"
-                                                                                                                                   if not use_cb else "landmarks by camera subsequence, all-reduce through a torch.distributed callback") if world > 1 else "none",
+                  "projection_edges": int(len(pr["e_pt"])), "iterations": int(n_it), "lm_trials": int(nsol), "sharding": sharding,
                   "ms_per_iteration": ba_el / max(1, n_it) * 1e3,
                   "structure_ms": structure_ms,
                   "value_including_structure": n_it / (ba_el + structure_ms * 1e-3),
@@ -284,6 +316,72 @@ def main():
                                "achieved": tm["linearize_bytes"] / (build_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": tm["linearize_bytes"] / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_linearisation": tm["linearize_bytes"],
                                "ms_linearise_plus_schur": build_ms}}
+        if world > 1:
+            # what the N ranks exchange per LM trial, this rank's stage times (rank 0's; the max over ranks is in ms_per_iteration), and the
+            # same problem unsharded on rank 0's GPU right afterwards: the speed-ups of the build and of the whole iteration against N = 1
+            st_sep = P.shard_timing()
+            ba_out["multi_gpu"] = {"ranks": world, "separator_mode": bool(sinfo["sep_mode"]), "separator_system_unknowns": sinfo["n_sep"], "separator_width_max": sinfo["w_max"],
+                                   "interior_unknowns_rank0": sinfo["interior_n"], "bytes_exchanged_per_trial": sinfo["bytes_per_trial"],
+                                   "bytes_exchanged_per_trial_if_band_all_reduce": sinfo["bytes_per_trial_allreduce"],
+                                   "separator_stage_ms_per_trial_rank0": {k: v / nsol for k, v in st_sep.items()}}
+            if rank == 0:
+                P1 = capi.ba_from_dict(pr, device=local_rank)
+                P1.optimize(1)
+                tb1 = P1.timing()
+                t1 = time.perf_counter()
+                n1 = P1.optimize(args.ba_iters)
+                el1 = time.perf_counter() - t1
+                ta1 = P1.timing()
+                d1 = {k: ta1[k] - tb1[k] for k in ta1 if k.endswith("_ms")}
+                P1.close()
+                b1 = (d1["linearize_ms"] + d1["reduce_ms"] + d1["errors_ms"]) / max(1, n1)
+                ba_out["multi_gpu"].update({"single_gpu_ms_per_iteration": el1 / max(1, n1) * 1e3, "single_gpu_build_only_ms_per_iteration": b1,
+                                            "speedup_iteration_vs_1gpu": (el1 / max(1, n1)) / (ba_el / max(1, n_it)),
+                                            "speedup_build_only_vs_1gpu": b1 / ba_out["build_only_ms_per_iteration"]})
+            barrier()
+        elif args.ba == "C4" and os.environ.get("CS_BENCH_CHILD") is None and args.shard_probe > 1:
+            # N = 1: what ONE rank of an R-rank job does per LM trial, measured alone on this GPU.  The handle is set up as a middle rank
+            # of R; the transport is a loop-back (the gathered separator messages are R copies of this rank's own -- still a positive
+            # definite separator system --, sums are the rank's own contribution), so every kernel of the sharded trial runs at its real
+            # size while the numbers it produces are not a solution.  The stage times are GPU events; collectives are not timed here.
+            R = args.shard_probe
+            Pp = capi.ba_from_dict(pr, device=local_rank)
+            Pp.set_shard(R // 2, R)
+            si = Pp.shard_info()
+            if si["sep_mode"]:
+                wmx = si["w_max"]
+                msg = 3 * wmx * wmx + 2 * wmx
+                mine = R // 2
+
+                def loopback(ptr, n, on_device, op):
+                    if on_device and n == msg * R:
+                        t = torch.as_tensor(capi.DeviceDoubles(ptr, n), device="cuda").view(R, msg)
+                        t.copy_(t[mine].clone().expand(R, msg))
+                        torch.cuda.synchronize()
+                    return 0
+                Pp.optimize_sharded(1, loopback)
+                tb0, sb0 = Pp.timing(), Pp.shard_timing()
+                Pp.optimize_sharded(3, loopback)
+                ta0, sa0 = Pp.timing(), Pp.shard_timing()
+                ns_ = max(1, ta0["n_solves"] - tb0["n_solves"]); nl_ = max(1, ta0["n_linearizations"] - tb0["n_linearizations"])
+                stg = {k: (sa0[k] - sb0[k]) / ns_ for k in sa0}
+                lin_r, red_r = (ta0["linearize_ms"] - tb0["linearize_ms"]) / nl_, (ta0["reduce_ms"] - tb0["reduce_ms"]) / ns_
+                lin_1, red_1 = d["linearize_ms"] / nlin, d["reduce_ms"] / nsol
+                comm_us = 3 * 30.0       # three small collectives per trial over xGMI, latency-bound (assumed 30 us each: not measurable on one GPU)
+                solve_r = stg["interior_factor_ms"] + stg["separator_message_ms"] + stg["separator_solve_ms"] + stg["interior_backsolve_ms"]
+                rest_1 = (d["backsub_ms"] + d["errors_ms"] + d["update_ms"]) / max(1, nsol)
+                it_1 = ba_el / max(1, n_it) * 1e3
+                it_r = lin_r + red_r + solve_r + rest_1 / R + comm_us * 1e-3
+                ba_out["sharded_projection"] = {
+                    "what": "one middle rank of %d, alone on this GPU, loop-back transport: GPU-event stage times of the separator-mode trial at C4/C5 size; the N-GPU figures below are "
+                            "arithmetic on these measured stage times, not measurements" % R,
+                    "ranks": R, "interior_unknowns": si["interior_n"], "separator_system_unknowns": si["n_sep"], "bytes_exchanged_per_trial": si["bytes_per_trial"],
+                    "bytes_exchanged_per_trial_if_band_all_reduce": si["bytes_per_trial_allreduce"],
+                    "rank_ms": {"linearize": lin_r, "schur_reduce": red_r, **stg}, "single_gpu_ms": {"linearize": lin_1, "schur_reduce": red_1, "factor_and_substitution": d["factor_ms"] / nsol},
+                    "projected_build_only_speedup": (lin_1 + red_1) / max(1e-9, lin_r + red_r),
+                    "projected_solve_speedup": (d["factor_ms"] / nsol) / max(1e-9, solve_r),
+                    "assumed_collective_latency_us": comm_us, "projected_ms_per_iteration": it_r, "projected_iteration_speedup": it_1 / max(1e-9, it_r)}
+            Pp.close()
         # CPU baseline of the BA half (rank 0, N = 1): the oracle (oracle/ba_oracle.cpp, -O2, one thread) on the SAME problem, wall time
         # per LM iteration split as g2o's G2OBatchStatistics does (core/batch_stats.h:48-62).  C3: the full run.  C4: one LM
         # iteration with residuals / linearisation / Schur complement / update in full and the dense LDL^T (the reference
@@ -436,6 +534,8 @@ def main():
             "stage_ms_per_step": {k: acc[k] / args.steps for k in acc if k.endswith("_ms")},
             "fallback_boxes_per_step": acc["n_fallback_boxes"] / args.steps,
         }
+        if steady is not None:
+            out["steady_state"] = steady
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle_py
             oracle_py.lib()

@@ -323,7 +323,7 @@ DECLARED_SYMBOLS += [
     "cs_ba_create", "cs_ba_destroy", "cs_ba_set_vertices", "cs_ba_set_estimates", "cs_ba_set_edges_proj", "cs_ba_set_edges_cuboid", "cs_ba_set_edges_cuboid_proj", "cs_ba_set_edges_odom",
     "cs_ba_compute_errors", "cs_ba_build_system", "cs_ba_solve", "cs_ba_update", "cs_ba_push", "cs_ba_pop", "cs_ba_optimize",
     "cs_ba_get_state", "cs_ba_sizes", "cs_ba_solver_layout", "cs_ba_get_system", "cs_ba_last_timing", "cs_ba_set_shard", "cs_ba_optimize_sharded",
-    "cs_ba_shard_landmark_owners", "cs_ba_get_landmark_owners", "cs_ba_shard_info", "cs_ba_get_vertex_hessians", "cs_ba_schur_layout", "cs_ba_reduced_size", "cs_ba_comm_unique_id", "cs_ba_comm_init",
+    "cs_ba_shard_landmark_owners", "cs_ba_get_landmark_owners", "cs_ba_shard_info", "cs_ba_shard_timing", "cs_ba_get_vertex_hessians", "cs_ba_schur_layout", "cs_ba_reduced_size", "cs_ba_comm_unique_id", "cs_ba_comm_init",
 ]
 
 
@@ -484,6 +484,12 @@ class BaProblem:
         d, e = C.c_longlong(), C.c_longlong()
         _chk(lib().cs_ba_shard_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e), C.byref(f)), "cs_ba_shard_info")
         return dict(sep_mode=a.value, n_sep=b.value, w_max=c.value, bytes_per_trial=d.value, bytes_per_trial_allreduce=e.value, interior_n=f.value)
+
+    def shard_timing(self):
+        """Accumulated ms of the separator-mode solve stages (cs_ba_shard_timing)."""
+        out = (C.c_double * 5)()
+        _chk(lib().cs_ba_shard_timing(self.h, out), "cs_ba_shard_timing")
+        return dict(zip(("interior_factor_ms", "separator_message_ms", "gather_ms", "separator_solve_ms", "interior_backsolve_ms"), list(out)))
 
     def optimize_sharded(self, iters, allreduce=None, cap=64):
         """allreduce(ptr, n_doubles, on_device, op) -> 0: in-place all-reduce (op 0 = SUM, 1 = MAX) of n doubles; None = the

@@ -39,7 +39,7 @@ void ba_launch_scale(const BaView& v, double lambda_pose, double lambda_lm, doub
 void ba_launch_update(const BaView& v, hipStream_t st);
 void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st, bool one_sided = false);
 void ba_launch_sep_reduce(const double* S, int LD, const double* Linv, int ci, int ni, int zl, int wl, int zr, int wr, double* Y, const double* rhs, double* msg, int wm, hipStream_t st);
-void ba_launch_sep_assemble(const double* msgs, size_t msg_doubles, int wm, int R, const int* sep_off, int n, double* Ssep, double* rsep, hipStream_t st);
+void ba_launch_sep_assemble(const double* msgs, size_t msg_doubles, int wm, int R, const int* sep_off, int n, int LDs, double* Ssep, double* rsep, hipStream_t st);
 void ba_launch_sep_scatter(const double* xsep, int n, int R, const int* sep_off, const int* sep_col, double* x, hipStream_t st);
 void ba_launch_sep_backsolve(double* S, int LD, double* work, int ci, int ni, int zl, int wl, int zr, int wr, double* Y, double* rhs, int* info, hipStream_t st);
 void ba_launch_fail_flag(const int* a, const int* b, const int* c, double* out, hipStream_t st);
@@ -119,6 +119,8 @@ struct cs_ba {
   hipEvent_t ev_join3 = nullptr;
   rocblas_handle blas = nullptr;
   hipEvent_t ev[8] = {};   // phase marks on the stream (linearise: 0-1; solve: 2 reduce 3 factor 4 back-substitution 5)
+  hipEvent_t sev[4] = {};  // separator mode, inside [3, 4]: interior factorised, separator message formed, messages gathered, separator system solved
+  double sep_ms[5] = {0, 0, 0, 0, 0};   // accumulated: interior factorisation, message (Y, T, t), gather, separator solve, interior back-substitution
   bool lin_pending = false;  // ev[0..1] recorded but not yet read
   int* h_status = nullptr;   // pinned: factorisation status
   // sharded BA over RCCL (cs_ba_comm_init): the collectives are issued from here, on this handle's stream
@@ -146,8 +148,8 @@ struct cs_ba {
   int n_sep = 0, w_max = 0;
   size_t msg_doubles = 0;                          // one rank's message: [LL | RL | RR | tL | tR]
   int int_c = 0, int_n = 0, zl = 0, wl = 0, zr = 0, wr = 0;   // this rank's interior and its two separators
-  DBuf<double> sepY, sep_msgs, sepS, int_work;
-  DBuf<int> d_sep_off, d_sep_col, d_int_info;
+  DBuf<double> sepY, sep_msgs, sepS, int_work, sep_work;
+  DBuf<int> d_sep_off, d_sep_col, d_int_info, d_sep_info;
   long long bytes_per_trial = 0, bytes_per_trial_allreduce = 0;   // payload this rank contributes to the collectives of one LM trial; what the all-reduce of [S | b] would be
   std::vector<int> keep;                      // caller indices of the projection edges this rank owns
   size_t s_doubles = 0;                       // size of S; rhs follows it in the same allocation (one all-reduce)
@@ -414,6 +416,11 @@ int finalize_structure(cs_ba* B) {
     for (int r = 0; r < R && ok; r++) {
       const int ni = cut[r + 1] - cut[r] - sepw[r];
       if (ni < 129 || ni <= B->band_ld) ok = false;     // (also: interiors further apart than the bandwidth, the regime the band kernels are tested in)
+    }
+    if (ok) {   // the separator system (block tridiagonal, blocks <= w_max: a band of 2 w_max) goes through the same persistent kernels
+      int wm = 0, nsep = 0;
+      for (int k = 1; k < R; k++) { wm = std::max(wm, sepw[k]); nsep += sepw[k]; }
+      if (!cs::ba_band_fits_device(nsep, 2 * wm) || !cs::ba_band_fits_device(cut[1], B->band_ld)) ok = false;
     }
     if (ok) {
       B->sep_mode = true; B->cut = cut; B->sepw = sepw;
@@ -733,7 +740,9 @@ int finalize_structure(cs_ba* B) {
   if (B->sep_mode) {
     AL(B->sepY, (size_t)(B->wl + B->wr) * B->int_n);
     AL(B->sep_msgs, B->msg_doubles * (size_t)R);
-    AL(B->sepS, (size_t)B->n_sep * B->n_sep + B->n_sep);       // [S_sep | rhs_sep]
+    AL(B->sepS, (size_t)B->n_sep * 2 * B->w_max + B->n_sep);   // [S_sep (band of 2 w_max) | rhs_sep]
+    AL(B->sep_work, cs::ba_band_workspace_doubles(B->n_sep, 2 * B->w_max));
+    AL(B->d_sep_info, 24);
     AL(B->int_work, cs::ba_band_workspace_doubles(B->int_n, B->band_ld));
     AL(B->d_int_info, 24);
     std::vector<int> sep_col(R + 1, 0);
@@ -742,7 +751,7 @@ int finalize_structure(cs_ba* B) {
     // what this rank contributes to the collectives of one LM trial: its separator message, the solution vector, three scalars
     B->bytes_per_trial = 8 * ((long long)B->msg_doubles + B->n_pose + 3);
   } else {
-    AL(B->sepY, 1); AL(B->sep_msgs, 1); AL(B->sepS, 1); AL(B->int_work, 1); AL(B->d_int_info, 24);
+    AL(B->sepY, 1); AL(B->sep_msgs, 1); AL(B->sepS, 1); AL(B->int_work, 1); AL(B->d_int_info, 24); AL(B->sep_work, 1); AL(B->d_sep_info, 24);
     std::vector<int> none1(1, 0);
     UP(B->d_sep_off, none1); UP(B->d_sep_col, none1);
     B->bytes_per_trial = R > 1 ? 8 * ((long long)B->s_doubles + B->n_pose + 3 + (B->elim ? B->n_pose - B->n_red : 0)) : 0;
@@ -868,6 +877,10 @@ int collect_solve_times(cs_ba* B) {
   BA_TRY(hipEventElapsedTime(&ms, B->ev[2], B->ev[3])); B->tm.reduce_ms += ms;
   BA_TRY(hipEventElapsedTime(&ms, B->ev[3], B->ev[4])); B->tm.factor_ms += ms;
   BA_TRY(hipEventElapsedTime(&ms, B->ev[4], B->ev[5])); B->tm.backsub_ms += ms;
+  if (B->sep_mode && B->shard_n > 1) {
+    hipEvent_t seq[6] = {B->ev[3], B->sev[0], B->sev[1], B->sev[2], B->sev[3], B->ev[4]};
+    for (int i = 0; i < 5; i++) { BA_TRY(hipEventElapsedTime(&ms, seq[i], seq[i + 1])); B->sep_ms[i] += ms; }
+  }
   return collect_lin_time(B);
 }
 
@@ -985,7 +998,8 @@ int solve_device_sep(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn, void
   *ok = true;
   const int R = B->shard_n, LD = B->band_ld, ns = B->n_sep;
   double* rhs = B->view.rhs;
-  double* rsep = B->sepS.p + (size_t)ns * ns;
+  const int LDs = 2 * B->w_max;
+  double* rsep = B->sepS.p + (size_t)ns * LDs;
   BA_TRY(hipEventRecord(B->ev[2], B->st));
   BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (B->s_doubles + B->n_pose), B->st));
   BA_TRY(hipMemsetAsync(B->d_elim_fail.p, 0, sizeof(int), B->st));
@@ -999,19 +1013,30 @@ int solve_device_sep(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn, void
   // the interior: L L^T = S(I, I), y = L^-1 b_I in place (one-sided order, right-hand side riding along)
   cs::ba_launch_band_cholesky(B->S.p + (size_t)B->int_c * LD, B->int_work.p, B->int_n, LD, rhs + B->int_c, B->d_int_info.p, false, B->st, true);
   BA_TRY(hipGetLastError());
+  BA_TRY(hipEventRecord(B->sev[0], B->st));
   if (fn) {   // the callback waits for the other ranks (threads of this process in the tests): the persistent kernel's turn must be free by then
     BA_TRY(hipStreamSynchronize(B->st));
     coop_turn.unlock();
   }
   cs::ba_launch_sep_reduce(B->S.p, LD, B->int_work.p, B->int_c, B->int_n, B->zl, B->wl, B->zr, B->wr, B->sepY.p, rhs, B->sep_msgs.p + (size_t)B->shard_rank * B->msg_doubles, B->w_max, B->st);
   BA_TRY(hipGetLastError());
+  BA_TRY(hipEventRecord(B->sev[1], B->st));
   { int rc = coll_allgather(B, fn, ctx, B->sep_msgs.p, B->msg_doubles); if (rc) return rc; }
-  // every rank assembles and solves the (small) separator system: nothing to broadcast afterwards
-  cs::ba_launch_sep_assemble(B->sep_msgs.p, B->msg_doubles, B->w_max, R, B->d_sep_off.p, ns, B->sepS.p, rsep, B->st);
+  BA_TRY(hipEventRecord(B->sev[2], B->st));
+  // every rank assembles and solves the (small) separator system: nothing to broadcast afterwards.  Block tridiagonal = a band of
+  // 2 w_max: the persistent banded Cholesky again (two fronts at 7 separators: 18 dependent steps)
+  cs::ba_launch_sep_assemble(B->sep_msgs.p, B->msg_doubles, B->w_max, R, B->d_sep_off.p, ns, LDs, B->sepS.p, rsep, B->st);
   BA_TRY(hipGetLastError());
-  BA_ROC(rocsolver_dpotrf(B->blas, rocblas_fill_upper, ns, B->sepS.p, ns, B->d_info.p));
-  BA_ROC(rocsolver_dpotrs(B->blas, rocblas_fill_upper, ns, 1, B->sepS.p, ns, rsep, ns));   // (after a failed factorisation: garbage, flagged below)
+  if (!coop_turn.owns_lock()) coop_turn.lock();
+  BA_TRY(hipMemsetAsync(B->d_sep_info.p, 0, 24 * sizeof(int), B->st));
+  cs::ba_launch_band_cholesky(B->sepS.p, B->sep_work.p, ns, LDs, rsep, B->d_sep_info.p, true, B->st);
+  BA_TRY(hipGetLastError());
+  if (fn) {
+    BA_TRY(hipStreamSynchronize(B->st));
+    coop_turn.unlock();
+  }
   cs::ba_launch_sep_scatter(rsep, ns, R, B->d_sep_off.p, B->d_sep_col.p, rhs, B->st);
+  BA_TRY(hipEventRecord(B->sev[3], B->st));
   cs::ba_launch_sep_backsolve(B->S.p, LD, B->int_work.p, B->int_c, B->int_n, B->zl, B->wl, B->zr, B->wr, B->sepY.p, rhs, B->d_int_info.p, B->st);
   BA_TRY(hipGetLastError());
   BA_TRY(hipEventRecord(B->ev[4], B->st));
@@ -1023,7 +1048,7 @@ int solve_device_sep(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn, void
   if (B->int_c + B->int_n < B->n_red) BA_TRY(hipMemsetAsync(rhs + B->int_c + B->int_n, 0, sizeof(double) * (size_t)(B->n_red - B->int_c - B->int_n), B->st));
   { int rc = coll_allreduce(B, fn, ctx, rhs, (size_t)B->n_pose); if (rc) return rc; }
   BA_TRY(hipEventRecord(B->ev[5], B->st));
-  cs::ba_launch_fail_flag(B->d_int_info.p, B->d_elim_fail.p, reinterpret_cast<const int*>(B->d_info.p), B->d_scalars.p + 2, B->st);
+  cs::ba_launch_fail_flag(B->d_int_info.p, B->d_elim_fail.p, B->d_sep_info.p, B->d_scalars.p + 2, B->st);
   BA_TRY(hipMemcpyAsync(B->h_status, B->d_int_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
   BA_TRY(hipGetLastError());
   B->tm.n_solves++;
@@ -1059,6 +1084,7 @@ int cs_ba_create(int device, cs_ba** out) {
   BA_TRY(hipStreamCreateWithFlags(&B->st3, hipStreamNonBlocking));
   BA_TRY(hipEventCreateWithFlags(&B->ev_join3, hipEventDisableTiming));
   for (auto& e : B->ev) BA_TRY(hipEventCreate(&e));
+  for (auto& e : B->sev) BA_TRY(hipEventCreate(&e));
   BA_TRY(hipHostMalloc((void**)&B->h_status, 2 * sizeof(int)));   // [factorisation status, a cuboid block failed]
   B->h_status[0] = B->h_status[1] = 0;
   BA_ROC(rocblas_create_handle(&B->blas));
@@ -1075,16 +1101,17 @@ void cs_ba_destroy(cs_ba* B) {
   DBuf<double>* dd[] = {&B->cams, &B->points, &B->cubes, &B->cams_bak, &B->points_bak, &B->cubes_bak, &B->pm_uv, &B->pm_info, &B->pm_intr, &B->pm_huber,
                         &B->cm_uv, &B->cm_info, &B->cm_intr, &B->cm_huber, &B->ce_meas, &B->ce_info, &B->ce_Hcc, &B->ce_Hoo, &B->ce_Hco, &B->ce_bc, &B->ce_bo,
                         &B->oe_meas, &B->oe_info, &B->oe_Hii, &B->oe_Hjj, &B->oe_Hij, &B->oe_bi, &B->oe_bj, &B->Hcam, &B->bcam, &B->Hcub, &B->bcub, &B->Hll, &B->bl,
-                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv, &B->scale_partial, &B->pe_meas, &B->pe_info, &B->pe_K, &B->part_tiles, &B->part_coef, &B->cub_M, &B->cub_Dinv, &B->sepY, &B->sep_msgs, &B->sepS, &B->int_work};
+                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv, &B->scale_partial, &B->pe_meas, &B->pe_info, &B->pe_K, &B->part_tiles, &B->part_coef, &B->cub_M, &B->cub_Dinv, &B->sepY, &B->sep_msgs, &B->sepS, &B->int_work, &B->sep_work};
   for (auto* d : dd) d->release();
   DBuf<int>* di[] = {&B->d_ce_active, &B->d_oe_active, &B->d_cam_col, &B->d_cub_col, &B->d_pt_free, &B->pm_pt, &B->pm_cam, &B->pt_ptr, &B->cm_pm, &B->cm_pt, &B->cam_ptr, &B->d_ce_cam, &B->d_ce_cub,
                      &B->d_oe_i, &B->d_oe_j, &B->cam_ce_ptr, &B->cam_ce_idx, &B->cam_oei_ptr, &B->cam_oei_idx, &B->cam_oej_ptr, &B->cam_oej_idx, &B->cub_ce_ptr,
                      &B->cub_ce_idx, &B->pair_ptr, &B->pair_i1, &B->pair_i2, &B->ent_a, &B->ent_b, &B->d_run_lm, &B->d_seg_ptr, &B->d_seg_k, &B->d_seg_tile, &B->d_seg_slot,
                      &B->d_gp_ptr, &B->d_gp_i1, &B->d_gp_i2, &B->d_gtile, &B->d_gcam_ptr, &B->d_gslot, &B->d_cubS_ptr, &B->d_cubS_cam, &B->d_ce_slot, &B->d_cub_tile, &B->d_cub_coef,
-                     &B->d_elim_fail, &B->d_slotE_ptr, &B->d_slotE_idx, &B->d_cub_mine, &B->d_sep_off, &B->d_sep_col, &B->d_int_info};
+                     &B->d_elim_fail, &B->d_slotE_ptr, &B->d_slotE_idx, &B->d_cub_mine, &B->d_sep_off, &B->d_sep_col, &B->d_int_info, &B->d_sep_info};
   for (auto* d : di) d->release();
   B->d_info.release(); B->d_band_info.release();
   for (auto& e : B->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : B->sev) if (e) (void)hipEventDestroy(e);
   if (B->h_status) (void)hipHostFree(B->h_status);
   if (B->h_scalars) (void)hipHostFree(B->h_scalars);
   if (B->comm) { (void)ncclCommDestroy(B->comm); g_comm_handles--; }
@@ -1498,6 +1525,14 @@ int cs_ba_shard_info(cs_ba* B, int* sep_mode, int* n_sep, int* w_max, long long*
   if (interior_n) *interior_n = B->sep_mode ? B->int_n : B->n_red;
   return CS_OK;
   BA_GUARD_END("cs_ba_shard_info")
+}
+// Accumulated stage times of the separator-mode solves (ms; divide by cs_ba_timing::n_solves): interior factorisation, separator
+// message (Y = B L^-T, T, t), gather of the messages (through a callback this includes the host round trip), separator system
+// (assembly + dense Cholesky + solve), interior back-substitution.  They partition cs_ba_timing::factor_ms.
+int cs_ba_shard_timing(cs_ba* B, double out5[5]) {
+  if (!B || !out5) return CS_ERR_INVALID_ARG;
+  for (int i = 0; i < 5; i++) out5[i] = B->sep_ms[i];
+  return CS_OK;
 }
 // The rank that owns each landmark under the rule in force (separator mode: by the lowest column of its free cameras).
 int cs_ba_get_landmark_owners(cs_ba* B, int* owner_out) {

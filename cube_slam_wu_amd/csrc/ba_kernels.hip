@@ -2042,27 +2042,30 @@ __global__ __launch_bounds__(64) void ba_sep_rhs_kernel(SepView V, double* msg, 
 // The separator system from the ranks' messages.  Separator k (k = 1 .. R - 1, rows sep_off[k] .. sep_off[k + 1] of the system) is
 // the left separator of rank k and the right separator of rank k - 1: its diagonal block is LL of rank k + RR of rank k - 1, its
 // right-hand side tL of rank k + tR of rank k - 1; the block (Z_k+1, Z_k) is RL of rank k, whose interior lies between the two.
-// Dense, lower triangle, element (r, c) at Ssep[r * n + c] (the layout of the dense reduced system).
-__global__ __launch_bounds__(256) void ba_sep_assemble_kernel(const double* msgs, size_t msg_doubles, int wm, int R, const int* sep_off, int n, double* Ssep, double* rsep) {
+// Lower band, LDs = 2 * wm doubles per column (a block-tridiagonal matrix with blocks <= wm wide has bandwidth < 2 wm): element
+// (r, c), r >= c, at Ssep[c * LDs + (r - c)] -- the layout band_chol_*_kernel factorises.
+__global__ __launch_bounds__(256) void ba_sep_assemble_kernel(const double* msgs, size_t msg_doubles, int wm, int R, const int* sep_off, int n, int LDs, double* Ssep, double* rsep) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (long long)n * (n + 1)) return;
-  const int r = (int)(e / (n + 1)), c = (int)(e % (n + 1));
-  // separator of row r: sep_off[k] <= r < sep_off[k + 1], k = 1 .. R - 1 (sep_off[1] = 0, sep_off[R] = n)
-  int kr = 1;
-  while (kr + 1 < R && sep_off[kr + 1] <= r) kr++;
-  const int lr = r - sep_off[kr];
-  if (c == n) {   // right-hand side: tL of rank kr + tR of rank kr - 1
-    rsep[r] = msgs[(size_t)kr * msg_doubles + 3 * (size_t)wm * wm + lr] + msgs[(size_t)(kr - 1) * msg_doubles + 3 * (size_t)wm * wm + wm + lr];
+  if (e >= (long long)n * (LDs + 1)) return;
+  const int c = (int)(e / (LDs + 1)), dd = (int)(e % (LDs + 1));
+  if (dd == LDs) {   // right-hand side of row c: tL of rank k + tR of rank k - 1
+    int k = 1;
+    while (k + 1 < R && sep_off[k + 1] <= c) k++;
+    const int l = c - sep_off[k];
+    rsep[c] = msgs[(size_t)k * msg_doubles + 3 * (size_t)wm * wm + l] + msgs[(size_t)(k - 1) * msg_doubles + 3 * (size_t)wm * wm + wm + l];
     return;
   }
-  if (c > r) return;
-  int kc = 1;
-  while (kc + 1 < R && sep_off[kc + 1] <= c) kc++;
-  const int lc = c - sep_off[kc];
+  const int r = c + dd;
   double v = 0.0;
-  if (kr == kc) v = msgs[(size_t)kr * msg_doubles + (size_t)lr * wm + lc] + msgs[(size_t)(kr - 1) * msg_doubles + 2 * (size_t)wm * wm + (size_t)lr * wm + lc];
-  else if (kr == kc + 1) v = msgs[(size_t)kc * msg_doubles + (size_t)wm * wm + (size_t)lr * wm + lc];
-  Ssep[(size_t)r * n + c] = v;
+  if (r < n) {
+    int kr = 1, kc = 1;
+    while (kr + 1 < R && sep_off[kr + 1] <= r) kr++;
+    while (kc + 1 < R && sep_off[kc + 1] <= c) kc++;
+    const int lr = r - sep_off[kr], lc = c - sep_off[kc];
+    if (kr == kc) v = msgs[(size_t)kr * msg_doubles + (size_t)lr * wm + lc] + msgs[(size_t)(kr - 1) * msg_doubles + 2 * (size_t)wm * wm + (size_t)lr * wm + lc];
+    else if (kr == kc + 1) v = msgs[(size_t)kc * msg_doubles + (size_t)wm * wm + (size_t)lr * wm + lc];
+  }
+  Ssep[(size_t)c * LDs + dd] = v;
 }
 // x of the separators to their places in the solution vector (sep_col[k]: first column of Z_k)
 __global__ __launch_bounds__(256) void ba_sep_scatter_kernel(const double* xsep, int n, int R, const int* sep_off, const int* sep_col, double* x) {
@@ -2095,9 +2098,9 @@ void ba_launch_sep_reduce(const double* S, int LD, const double* Linv, int ci, i
   hipLaunchKernelGGL(ba_sep_schur_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, V, msg, wm);
   hipLaunchKernelGGL(ba_sep_rhs_kernel, dim3(nq), dim3(64), 0, st, V, msg, wm);
 }
-void ba_launch_sep_assemble(const double* msgs, size_t msg_doubles, int wm, int R, const int* sep_off, int n, double* Ssep, double* rsep, hipStream_t st) {
-  const long long total = (long long)n * (n + 1);
-  if (total > 0) hipLaunchKernelGGL(ba_sep_assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, msgs, msg_doubles, wm, R, sep_off, n, Ssep, rsep);
+void ba_launch_sep_assemble(const double* msgs, size_t msg_doubles, int wm, int R, const int* sep_off, int n, int LDs, double* Ssep, double* rsep, hipStream_t st) {
+  const long long total = (long long)n * (LDs + 1);
+  if (total > 0) hipLaunchKernelGGL(ba_sep_assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, msgs, msg_doubles, wm, R, sep_off, n, LDs, Ssep, rsep);
 }
 void ba_launch_sep_scatter(const double* xsep, int n, int R, const int* sep_off, const int* sep_col, double* x, hipStream_t st) {
   if (n > 0) hipLaunchKernelGGL(ba_sep_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, xsep, n, R, sep_off, sep_col, x);

@@ -294,6 +294,9 @@ int cs_ba_shard_landmark_owners(int n_ranks, int n_cams, int n_points, int n_pro
  * contributes to the collectives of one LM trial, bytes_per_trial_allreduce = what the all-reduce of [S | b] would move instead,
  * interior_n = unknowns this rank factorises.  Any pointer may be NULL.                                                          */
 int cs_ba_get_landmark_owners(cs_ba* ba, int* owner_out);
+/* Accumulated stage times (ms) of the separator-mode solves: interior factorisation, separator message, gather (through a callback:
+ * including the host round trip), separator system, interior back-substitution -- they partition cs_ba_timing.factor_ms. */
+int cs_ba_shard_timing(cs_ba* ba, double out5[5]);
 int cs_ba_shard_info(cs_ba* ba, int* sep_mode, int* n_sep, int* w_max, long long* bytes_per_trial, long long* bytes_per_trial_allreduce, int* interior_n);
 
 int cs_ba_get_state(cs_ba* ba, double* cams7, double* cuboids10, double* points3);
