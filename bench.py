@@ -45,7 +45,7 @@ def measure_traffic_live(args, n_unique):
         d = tempfile.mkdtemp(prefix="cs_pmc_", dir="/tmp")
         try:
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "2", "--warmup", "1", "--inflight", "1", "--steady-steps", "0", "--ba", "none", "--no-cpu-baseline", "--no-edge", "--rp-frames", "0", "--no-measure-traffic",
+                   "--steps", "2", "--warmup", "1", "--inflight", "1", "--depth", "1", "--steady-steps", "0", "--ba", "none", "--no-cpu-baseline", "--no-edge", "--rp-frames", "0", "--no-measure-traffic",
                    "--frames", str(args.frames), "--unique", str(n_unique)]
             subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp", "CS_BENCH_CHILD": "1"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             n, tot = 0, 0.0
@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=0, help="cut the batch into this many chunks of the two-slot host/GPU pipeline (0 = library default)")
     ap.add_argument("--no-edge", action="store_true", help="skip the distance-map front end (Canny + distance transform) timing")
     ap.add_argument("--rp-frames", type=int, default=100, help="frames of the roll/pitch-sampling stress variant (RP = 25 poses per box, the reference's class default); 0 = skip")
+    ap.add_argument("--depth", type=int, default=1, help="batches per pipeline: the next one is submitted (packed + queued) before the current one is collected")
     ap.add_argument("--steady-steps", type=int, default=200, help="steps of the steady-state measurement reported beside the contract run (0 = skip)")
     ap.add_argument("--inflight", type=int, default=4, help="batches in flight per GPU: each has its own detector (streams, worker pool) and is driven by its own host thread, "
                     "so one batch's host stages (packing, record writing) overlap the other's sweep on the device")
@@ -150,13 +151,16 @@ def main():
             pass
         host_threads = max(8, min(64, cpus // (world * inflight)))
     params = capi.default_params(whether_sample_cam_roll_pitch=0, whether_sample_bbox_height=0, yaw_range_deg=45.0, yaw_step_deg=0.5, host_threads=host_threads)
+    # every pipeline (host thread + detector) owns `depth` batches: it submits the next one (cs_batch_submit: host packing + the sweep
+    # queued on the detector's streams) before it collects the current one, so the device never waits for a pipeline's host stages
+    depth = max(1, args.depth)
     dets = [capi.Detector(params, device=local_rank) for _ in range(inflight)]
-    bats = [capi.Batch(dets[p], frames, pipeline_chunks=(args.chunks if args.chunks > 0 else 1)) for p in range(inflight)]
+    bats = [capi.Batch(dets[p // depth], frames, pipeline_chunks=(args.chunks if args.chunks > 0 else 1)) for p in range(inflight * depth)]
     det, bat = dets[0], bats[0]
 
     # warm-up: every pipeline alone (also the isolated kernel timings: nothing else runs on the device)
     iso = {}
-    for p in range(inflight):
+    for p in range(inflight * depth):
         for _ in range(args.warmup):
             bats[p].run()
             if p == 0:
@@ -177,9 +181,18 @@ def main():
 
     def drive(p):
         try:
-            while take_step():
-                bats[p].run()
-                for k, v in bats[p].timing().items():
+            free, queued = [bats[p * depth + q] for q in range(depth)], []
+            while True:
+                while free and take_step():      # a step = one batch through the whole sweep; its collect below is inside the timed region too
+                    bq = free.pop(0)
+                    bq.submit()
+                    queued.append(bq)
+                if not queued:
+                    break
+                bq = queued.pop(0)
+                bq.collect()
+                free.append(bq)
+                for k, v in bq.timing().items():
                     accs[p][k] = accs[p].get(k, 0) + v
         except Exception as e:   # surfaced after the join
             errs.append(e)
@@ -510,7 +523,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not share_gpu else "synthetic (CS_BENCH_SHARE_GPU functional check: ranks share one device, not a performance number)",
             "config": {"workload": "C2: per-frame cuboid proposal sweep, 181 yaw x 8 boxes x ~400 line segments, 1241x376 KITTI-shaped",
-                       "frames_per_batch_per_gpu": args.frames, "unique_frames": n_unique, "yaw_step_deg": 0.5, "batches_in_flight": inflight,
+                       "frames_per_batch_per_gpu": args.frames, "unique_frames": n_unique, "yaw_step_deg": 0.5, "batches_in_flight": inflight * depth, "pipelines": inflight, "batches_per_pipeline": depth,
                        "proposal_slots_per_frame": acc["n_slots"] / args.steps / args.frames,
                        "valid_proposals_per_frame": acc["n_valid"] / args.steps / args.frames, "parallelism": "frames sharded, no collective"},
             "roofline": {"kernel": "score_kernel", "bound": "hbm",

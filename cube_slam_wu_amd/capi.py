@@ -61,7 +61,7 @@ class CsDetectTiming(C.Structure):
 # every symbol include/cubeslam_hip.h declares (tests/test_capi_symbols.py checks the export table)
 DECLARED_SYMBOLS = [
     "cs_last_error", "cs_device_count", "cs_detect_default_params", "cs_box_rois", "cs_cam_euler_zyx", "cs_detector_create",
-    "cs_detector_destroy", "cs_detect_cuboids", "cs_batch_create", "cs_batch_max_boxes", "cs_batch_run",
+    "cs_detector_destroy", "cs_detect_cuboids", "cs_batch_create", "cs_batch_max_boxes", "cs_batch_run", "cs_batch_submit", "cs_batch_collect",
     "cs_bgr_to_gray", "cs_edge_distance_maps", "cs_edge_distance_maps_multi", "cs_detect_cuboids_gray", "cs_batch_create_gray", "cs_batch_destroy", "cs_batch_last_timing", "cs_batch_debug_candidates", "cs_batch_debug_kept", "cs_batch_set_debug", "cs_batch_set_pipeline_chunks", "cs_detect_lines_gray",
 ]
 
@@ -256,6 +256,18 @@ class Batch:
         rc = lib().cs_batch_run(self.det.h, self.h, self._out, self._counts.ctypes.data_as(C.POINTER(C.c_int)))
         if rc != 0:
             raise RuntimeError("cs_batch_run failed (%d): %s" % (rc, last_error()))
+
+    def submit(self):
+        """First half of run(): pack + queue the sweep, do not wait (cs_batch_submit)."""
+        rc = lib().cs_batch_submit(self.det.h, self.h, self._out, self._counts.ctypes.data_as(C.POINTER(C.c_int)))
+        if rc != 0:
+            raise RuntimeError("cs_batch_submit failed (%d): %s" % (rc, last_error()))
+
+    def collect(self):
+        """Second half of run(): wait for the sweep, write the records (cs_batch_collect)."""
+        rc = lib().cs_batch_collect(self.det.h, self.h)
+        if rc != 0:
+            raise RuntimeError("cs_batch_collect failed (%d): %s" % (rc, last_error()))
 
     def cuboids(self, frame):
         res = []

@@ -46,9 +46,10 @@ void launch_vp_points(const DetectDeviceView& v, int vp_total, hipStream_t st);
 int vp3_table_doubles_per_job();
 void launch_candidates(const DetectDeviceView& v, const SweepParams& sp, long long slot_total, hipStream_t st);
 void launch_scan_compact(const DetectDeviceView& v, hipStream_t st);
-void launch_score(const DetectDeviceView& v, long long n_valid_bound, long long slot_total, hipStream_t st);
-void launch_gather_corners(const double* corners, const long long* slots, int n, double* out, hipStream_t st);
+void launch_score(const DetectDeviceView& v, const SweepParams& sp, long long n_valid_bound, long long slot_total, hipStream_t st);
+void launch_gather_corners(const DetectDeviceView& v, const SweepParams& sp, const long long* slots, int n, double* out, hipStream_t st);
 void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams& rp, hipStream_t st);
+void launch_records(const DetectDeviceView& v, const RankView& rv, int kmax, cs_cuboid* out, hipStream_t st);
 struct EdgeRoi { int l, t, w, h; long long img_off, cls_off, map_off; };
 void launch_edge_maps(const unsigned char* gray, int W, int H, const EdgeRoi* rois, int n_rois, unsigned char* cls_pool, float* map_pool, int max_w, int low, int high,
                       hipStream_t st);
@@ -420,6 +421,8 @@ struct PipeSlot {
   PinBuf<int> h_ls_order;
   DevBuf<double> mid_x, mid_y, ang, yaw, yaw_c, yaw_s, vp, bound, corners, c_dist, c_angle, c_skew, fb_dist, fb_angle, fb_skew, win_corners;
   DevBuf<cs::RankWinner> winners;
+  DevBuf<cs_cuboid> records;        // the winners' records of the device-ranked boxes (record_kernel)
+  PinBuf<cs_cuboid> h_records;
   PinBuf<cs::JobDesc> h_jobs_in, h_jobs_out;
   PinBuf<long long> h_slot_prefix, h_job_cbase;
   PinBuf<int> h_vp_prefix, h_top_x, h_box_job0, h_box_njobs, h_win_count, h_fallback, h_job_valid;
@@ -439,7 +442,7 @@ struct PipeSlot {
     vp_prefix.release(); top_x.release(); flag.release(); job_valid.release(); c_flag.release(); box_job0.release(); box_njobs.release(); win_count.release();
     fallback.release(); fb_cnt.release(); fb_flag.release(); mid_x.release(); mid_y.release(); ang.release(); yaw.release(); yaw_c.release(); yaw_s.release();
     vp.release(); bound.release(); bound3.release(); ls_order.release(); h_ls_order.release(); corners.release(); c_dist.release(); c_angle.release(); c_skew.release(); fb_dist.release(); fb_angle.release(); fb_skew.release();
-    win_corners.release(); winners.release(); h_jobs_in.release(); h_jobs_out.release(); h_slot_prefix.release(); h_job_cbase.release(); h_vp_prefix.release();
+    win_corners.release(); winners.release(); records.release(); h_records.release(); h_jobs_in.release(); h_jobs_out.release(); h_slot_prefix.release(); h_job_cbase.release(); h_vp_prefix.release();
     h_top_x.release(); h_box_job0.release(); h_box_njobs.release(); h_win_count.release(); h_fallback.release(); h_job_valid.release(); h_yaw.release();
     h_yaw_c.release(); h_yaw_s.release(); h_winners.release();
     h_fb_src.release(); h_fb_dst.release(); h_fb_slot.release(); h_win_slots.release(); h_fb_cnt.release(); h_fb_flag.release(); h_fb_dist.release(); h_fb_angle.release();
@@ -450,8 +453,11 @@ struct PipeSlot {
   }
 };
 
+struct BatchRunState;   // what a submitted (not yet collected) sweep keeps alive: camera caches, timing, the caller's output arrays
 struct cs_batch {
   cs_detector* det = nullptr;
+  BatchRunState* run_state = nullptr;
+  PinBuf<cs::RpPose> h_rp;
   PipeSlot pipe[2];
   // capacity layout of the lean path's staging pools (from the inputs alone): first job / first box of a frame, first
   // merged-segment row of a frame's jobs, first top-edge sample of a box
@@ -774,16 +780,18 @@ int cs_batch_create_gray(cs_detector* d, const cs_frame_desc* fr, const unsigned
 
 int cs_batch_max_boxes(const cs_batch* b) { return b ? b->max_boxes : CS_ERR_INVALID_ARG; }
 
+static void batch_drop_run_state(cs_batch* b);
 void cs_batch_destroy(cs_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->det->device);
+  if (b->run_state) { (void)hipDeviceSynchronize(); batch_drop_run_state(b); }   // a submitted sweep that was never collected
   b->pipe[0].release(); b->pipe[1].release();
   b->d_maps.release(); b->d_invK.release(); b->d_frame_lines.release(); b->d_frame_line_ptr.release(); b->d_jobs.release(); b->d_slot_prefix.release(); b->d_job_cbase.release();
   b->d_c_slot.release(); b->d_win_slots.release(); b->d_vp_prefix.release(); b->d_top_x.release(); b->d_flag.release();
   b->d_job_valid.release(); b->d_c_flag.release(); b->d_mid_x.release(); b->d_mid_y.release(); b->d_ang.release();
   b->d_yaw.release(); b->d_yaw_c.release(); b->d_yaw_s.release(); b->d_vp.release(); b->d_bound.release(); b->d_dist.release();
   b->d_angle.release(); b->d_skew.release(); b->d_corners.release(); b->d_c_dist.release(); b->d_c_angle.release();
-  b->d_c_skew.release(); b->d_win_corners.release(); b->d_rp.release();
+  b->d_c_skew.release(); b->d_win_corners.release(); b->d_rp.release(); b->h_rp.release();
   b->h_stage.release(); b->h_c_slot.release(); b->h_job_cbase.release(); b->h_c_flag.release(); b->h_job_valid.release();
   b->h_c_dist.release(); b->h_c_angle.release(); b->h_c_skew.release(); b->h_win_corners.release();
   b->d_box_job0.release(); b->d_box_njobs.release(); b->d_win_count.release(); b->d_fallback.release(); b->d_winners.release(); b->d_last_slot.release(); b->h_last_slot.release();
@@ -873,6 +881,18 @@ struct PipeCtx {
   const std::vector<CamCache>* cam_raw; const std::vector<int>* rp_off;
   cs::SweepParams sp; cs_detect_timing* tm;
 };
+
+}  // namespace
+struct BatchRunState {
+  std::vector<CamCache> cam_raw;
+  std::vector<std::vector<CamCache>> cam_rp;
+  std::vector<int> rp_off;
+  cs_detect_timing tm{};
+  double t_begin = 0;
+  PipeCtx C{};
+  bool deferred = false;    // pipe_launch done, pipe_finish pending (cs_batch_collect)
+};
+namespace {
 
 static double g_mark[16];
 static int g_runs = 0;
@@ -985,9 +1005,9 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   PENS(S.ls_order, nj); PENS(S.jobs, nj); PENS(S.slot_prefix, nj + 1); PENS(S.vp_prefix, nj + 1); PENS(S.job_valid, nj); PENS(S.job_cbase, nj + 1);
   PENS(S.mid_x, n_lines + 1); PENS(S.mid_y, n_lines + 1); PENS(S.ang, n_lines + 1); PENS(S.yaw, n_yaw + 1); PENS(S.yaw_c, n_yaw + 1); PENS(S.yaw_s, n_yaw + 1);
   PENS(S.top_x, n_top + 1); PENS(S.vp, 6 * (size_t)S.vp_total + 6); PENS(S.bound, 6 * (size_t)S.vp_total + 6); PENS(S.bound3, nj * (size_t)cs::vp3_table_doubles_per_job()); PENS(S.flag, slot_total + 1);
-  PENS(S.corners, 16 * (size_t)slot_total + 16); PENS(S.c_slot, slot_total + 1); PENS(S.c_flag, slot_total + 1); PENS(S.c_dist, slot_total + 1);
+  PENS(S.c_slot, slot_total + 1); PENS(S.c_flag, slot_total + 1); PENS(S.c_dist, slot_total + 1);
   PENS(S.c_angle, slot_total + 1); PENS(S.c_skew, slot_total + 1); PENS(S.box_job0, nb + 1); PENS(S.box_njobs, nb + 1); PENS(S.win_count, nb + 1);
-  PENS(S.fallback, nb + 1); PENS(S.winners, nb * KMAX + 1);
+  PENS(S.fallback, nb + 1); PENS(S.winners, nb * KMAX + 1); PENS(S.records, nb * KMAX + 1); PENS(S.h_records, nb * KMAX + 1);
   PENS(S.h_winners, nb * KMAX + 1); PENS(S.h_win_count, nb + 1); PENS(S.h_fallback, nb + 1); PENS(S.h_job_valid, nj); PENS(S.h_job_cbase, nj + 1); PENS(S.h_jobs_out, nj);
 #define PH2D(dst, src, n) HIP_TRY(hipMemcpyAsync((dst).p, (src).p, sizeof(*(src).p) * (n), hipMemcpyHostToDevice, st))
   PH2D(S.ls_order, S.h_ls_order, nj); PH2D(S.jobs, S.h_jobs_in, nj); PH2D(S.slot_prefix, S.h_slot_prefix, nj + 1); PH2D(S.vp_prefix, S.h_vp_prefix, nj + 1);
@@ -999,7 +1019,7 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   v = cs::DetectDeviceView{};
   v.jobs = S.jobs.p; v.n_jobs = (int)nj; v.slot_prefix = S.slot_prefix.p; v.vp_prefix = S.vp_prefix.p; v.maps = b->d_maps.p;
   v.mid_x = S.mid_x.p; v.mid_y = S.mid_y.p; v.line_angle = S.ang.p; v.yaw = S.yaw.p; v.yaw_cos = S.yaw_c.p; v.yaw_sin = S.yaw_s.p; v.top_x = S.top_x.p;
-  v.rp = b->d_rp.p; v.invK = b->d_invK.p; v.vp = S.vp.p; v.bound = S.bound.p; v.bound3 = S.bound3.p; v.flag = S.flag.p; v.corners = S.corners.p; v.job_valid = S.job_valid.p;
+  v.rp = b->d_rp.p; v.invK = b->d_invK.p; v.vp = S.vp.p; v.bound = S.bound.p; v.bound3 = S.bound3.p; v.flag = S.flag.p; v.job_valid = S.job_valid.p;
   v.job_cbase = S.job_cbase.p; v.c_slot = S.c_slot.p; v.c_flag = S.c_flag.p; v.c_dist = S.c_dist.p; v.c_angle = S.c_angle.p; v.c_skew = S.c_skew.p;
   // The corner construction needs the vanishing points but not the segments: it runs on the second stream beside line
   // setup + VP support (a latency-bound and an ALU-bound kernel), and the scorer waits for both.
@@ -1020,16 +1040,17 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   HIP_TRY(hipEventRecord(S.ev[2], st));
   HIP_TRY(hipStreamWaitEvent(st, S.ev[10], 0));
   HIP_TRY(hipEventRecord(S.ev[4], st));
-  cs::launch_score(v, slot_total, slot_total, st);
+  cs::launch_score(v, C.sp, slot_total, slot_total, st);
   HIP_TRY(hipEventRecord(S.ev[5], st));
   cs::RankView rv{};
   rv.box_job0 = S.box_job0.p; rv.box_njobs = S.box_njobs.p; rv.n_boxes = (int)nb; rv.winners = S.winners.p; rv.win_count = S.win_count.p; rv.fallback = S.fallback.p;
-  cs::RankParams rkp{P.weight_vp_angle, P.weight_skew_error, P.nominal_skew_ratio, P.max_cut_skew, KMAX};
+  cs::RankParams rkp{P.weight_vp_angle, P.weight_skew_error, P.nominal_skew_ratio, P.max_cut_skew, KMAX, C.sp.short_sq_bound};
   cs::launch_rank(v, rv, rkp, st);
+  cs::launch_records(v, rv, KMAX, S.records.p, st);     // the records of the boxes the device ranked: only they come back
   HIP_TRY(hipEventRecord(S.ev[6], st));
   HIP_TRY(hipGetLastError());
   if (nb) {
-    HIP_TRY(hipMemcpyAsync(S.h_winners.p, S.winners.p, sizeof(cs::RankWinner) * nb * KMAX, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(S.h_records.p, S.records.p, sizeof(cs_cuboid) * nb * KMAX, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(S.h_win_count.p, S.win_count.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(S.h_fallback.p, S.fallback.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
   }
@@ -1065,8 +1086,8 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
     tm.cand_kernel_launches += 1;
     const long long n_valid = S.h_job_cbase.p[nj];
     tm.n_valid += n_valid;
-    tm.cand_kernel_bytes += 48LL * S.vp_total + 4LL * S.slot_total + 128LL * n_valid;
-    long long sbytes = 48LL * S.vp_total + (128LL + 28LL + 8LL) * n_valid;
+    tm.cand_kernel_bytes += 48LL * S.vp_total + 4LL * S.slot_total;
+    long long sbytes = 96LL * S.vp_total + (28LL + 8LL + 4LL) * n_valid;
     for (size_t j = 0; j < nj; j++) if (S.h_jobs_in.p[j].Y > 0 && S.h_jobs_in.p[j].T > 0) sbytes += 4LL * S.h_jobs_in.p[j].map_w * (S.h_jobs_in.p[j].g.eb - S.h_jobs_in.p[j].g.et);
     tm.score_kernel_bytes += sbytes;
   }
@@ -1170,9 +1191,18 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
   std::vector<int> fbq;
   for (size_t q = 0; q < nb; q++) if (S.h_fallback.p[q]) fbq.push_back((int)q);
   tm.n_fallback_boxes += (int)fbq.size();
-  auto records = [&](int qi) {
+  auto records = [&](int qi) {      // a device-ranked box: its records are complete but for the caller's rectangle
     const size_t q = (size_t)qi;
-    if (!S.h_fallback.p[q]) write_box(q, S.h_winners.p + q * KMAX, S.h_win_count.p[q]);
+    if (S.h_fallback.p[q]) return;
+    const int j0 = S.h_box_job0.p[q];
+    const int f = jobs[j0].frame, bi = jobs[j0].box, nw = S.h_win_count.p[q];
+    const double* bb = &b->frames[f].boxes[5 * bi];
+    for (int r = 0; r < nw; r++) {
+      cs_cuboid& o = C.out[((size_t)f * MB + bi) * KMAX + r];
+      o = S.h_records.p[q * KMAX + r];
+      o.rect_detect_2d[0] = (int)bb[0]; o.rect_detect_2d[1] = (int)bb[1]; o.rect_detect_2d[2] = (int)bb[2]; o.rect_detect_2d[3] = (int)bb[3];
+    }
+    C.out_counts[(size_t)f * MB + bi] = nw;
   };
   static const bool tie_separate = getenv("CS_TIE_SEPARATE_PASS") != nullptr;   // diagnostics: always the two-pass order
   if (fbq.size() <= 64 && !tie_separate) {
@@ -1181,7 +1211,12 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
     if (!fb_src.empty()) HIP_TRY(hipStreamSynchronize(st2));
     MARK(7, tq);   // wait for the tie columns
     const int nfb = (int)fbq.size();
-    d->pool->run(nfb + (int)nb, [&](int z) { if (z < nfb) rank_on_host((size_t)fbq[z]); else records(z - nfb); });
+    constexpr int RCH = 256;           // records are a 400-byte copy each: hand them out in chunks
+    const int nch = ((int)nb + RCH - 1) / RCH;
+    d->pool->run(nfb + nch, [&](int z) {
+      if (z < nfb) { rank_on_host((size_t)fbq[z]); return; }
+      for (int q = (z - nfb) * RCH, q1 = std::min((int)nb, q + RCH); q < q1; q++) records(q);
+    });
     MARK(6, tq);   // records of the device-ranked boxes (+ exact ranking of the tie boxes)
   } else {
     d->pool->run((int)nb, records);
@@ -1198,7 +1233,7 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
       PENS(S.win_slots, ws.size()); PENS(S.win_corners, 16 * ws.size()); PENS(S.h_win_slots, ws.size()); PENS(S.h_win_corners, 16 * ws.size());
       std::copy(ws.begin(), ws.end(), S.h_win_slots.p);
       HIP_TRY(hipMemcpyAsync(S.win_slots.p, S.h_win_slots.p, 8 * ws.size(), hipMemcpyHostToDevice, st2));
-      cs::launch_gather_corners(S.corners.p, S.win_slots.p, (int)ws.size(), S.win_corners.p, st2);
+      cs::launch_gather_corners(S.view, C.sp, S.win_slots.p, (int)ws.size(), S.win_corners.p, st2);
       HIP_TRY(hipMemcpyAsync(S.h_win_corners.p, S.win_corners.p, 8 * 16 * ws.size(), hipMemcpyDeviceToHost, st2));
       HIP_TRY(hipStreamSynchronize(st2));
       const double* hc = S.h_win_corners.p;
@@ -1224,23 +1259,62 @@ extern "C" int cs_batch_set_pipeline_chunks(cs_batch* b, int n_chunks) {
   return CS_OK;
 }
 
-static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_counts);
+static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_counts, bool defer);
+static int batch_collect_impl(cs_detector* d, cs_batch* b);
 extern "C" int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_counts) {
   CS_GUARD_BEGIN
-  return batch_run_impl(d, b, out, out_counts);
+  return batch_run_impl(d, b, out, out_counts, false);
   CS_GUARD_END("cs_batch_run")
 }
-static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_counts) {
-  if (!d || !b || b->det != d || !out || !out_counts) return CS_ERR_INVALID_ARG;
+// cs_batch_run in two halves: submit packs the batch on the host and queues the whole sweep on the detector's streams, collect waits
+// for it and writes the records.  A caller that owns several batches keeps the next one queued while the current one is on the
+// device (one submit outstanding per batch; batches of one detector are submitted and collected from one thread, in order).
+extern "C" int cs_batch_submit(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_counts) {
+  CS_GUARD_BEGIN
+  return batch_run_impl(d, b, out, out_counts, true);
+  CS_GUARD_END("cs_batch_submit")
+}
+extern "C" int cs_batch_collect(cs_detector* d, cs_batch* b) {
+  CS_GUARD_BEGIN
+  if (!d || !b || b->det != d) return CS_ERR_INVALID_ARG;
+  return batch_collect_impl(d, b);
+  CS_GUARD_END("cs_batch_collect")
+}
+static void batch_drop_run_state(cs_batch* b) { delete b->run_state; b->run_state = nullptr; }
+static int batch_collect_impl(cs_detector* d, cs_batch* b) {
+  if (!b->run_state) return CS_OK;                        // nothing outstanding (or the sweep ran to completion inside submit)
+  std::unique_ptr<BatchRunState> rs(b->run_state);
+  b->run_state = nullptr;
+  if (!rs->deferred) return CS_OK;
   HIP_TRY(hipSetDevice(d->device));
+  int rc = pipe_finish(rs->C, b->pipe[0], rs->cam_rp);
+  if (rc) return rc;
+  rs->tm.total_ms = now_ms() - rs->t_begin;
+  b->timing = rs->tm;
+  b->ran = true;
+  if (g_prof && (++g_runs % 8) == 0) {
+    const char* nm[11] = {"jobs+samples", "prefix+pack", "box table", "alloc+enqueue", "gpu wait", "tie lists", "records", "tie wait", "tie rank", "tie corners", "tie records"};
+    fprintf(stderr, "[detect] host ms/run:");
+    for (int k = 0; k < 11; k++) { fprintf(stderr, " %s %.3f", nm[k], g_mark[k] / 8); g_mark[k] = 0; }
+    fprintf(stderr, " | pre %.3f total %.3f\n", g_mark[11] / 8, rs->tm.total_ms); g_mark[11] = 0;
+  }
+  return CS_OK;
+}
+static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_counts, bool defer) {
+  if (!d || !b || b->det != d || !out || !out_counts) return CS_ERR_INVALID_ARG;
+  if (b->run_state) { set_err("cs_batch_submit: the previous submit of this batch has not been collected"); return CS_ERR_INVALID_ARG; }
+  HIP_TRY(hipSetDevice(d->device));
+  std::unique_ptr<BatchRunState> rs_owner(new BatchRunState());
+  BatchRunState* rs = rs_owner.get();
   const cs_detect_params& P = d->prm;
   const bool sample_rp = P.whether_sample_cam_roll_pitch != 0;
   const int NF = b->n_frames, MB = b->max_boxes, KMAX = P.max_cuboid_num;
   auto parallel_for = [d](int n, int /*nt*/, const std::function<void(int)>& fn) { d->pool->run(n, fn); };
   const int NT = d->n_threads;
   hipStream_t st = d->stream;
-  cs_detect_timing tm{};
+  cs_detect_timing& tm = rs->tm;
   double t_begin = now_ms();
+  rs->t_begin = t_begin;
 
   std::fill(out_counts, out_counts + (size_t)NF * std::max(MB, 0), 0);
   b->results.clear();
@@ -1255,8 +1329,8 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
 
   // ---- per-frame camera caches: raw pose and the roll/pitch sample poses (:78-79, :344-355, :368-377)
   double t0 = now_ms();
-  std::vector<CamCache> cam_raw(NF);
-  std::vector<std::vector<CamCache>> cam_rp(NF);
+  std::vector<CamCache>& cam_raw = rs->cam_raw; cam_raw.resize(NF);
+  std::vector<std::vector<CamCache>>& cam_rp = rs->cam_rp; cam_rp.resize(NF);
   std::vector<double> cur_yaw(NF);  // cam_pose.camera_yaw as the next box will see it (:180)
   parallel_for(NF, NT, [&](int f) {
     const FrameIn& F = b->frames[f];
@@ -1280,24 +1354,35 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
     }
   });
   // rp pool: identical for every round -> upload once
-  std::vector<int> rp_off(NF + 1, 0);
+  std::vector<int>& rp_off = rs->rp_off; rp_off.assign(NF + 1, 0);
   for (int f = 0; f < NF; f++) rp_off[f + 1] = rp_off[f] + (int)cam_rp[f].size();
   {
-    std::vector<cs::RpPose> pool(std::max(1, rp_off[NF]));
-    for (int f = 0; f < NF; f++)
-      for (size_t k = 0; k < cam_rp[f].size(); k++) pool[rp_off[f] + k] = cam_rp[f][k].pose;
-    int rc = b->d_rp.ensure(pool.size());
+    // (pinned staging owned by the batch: the copy is queued behind whatever the detector's stream still runs -- another batch's sweep --
+    // and nobody waits for it here)
+    const size_t np_ = (size_t)std::max(1, rp_off[NF]);
+    int rc = b->h_rp.ensure(np_);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(b->d_rp.p, pool.data(), sizeof(cs::RpPose) * pool.size(), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    for (int f = 0; f < NF; f++)
+      for (size_t k = 0; k < cam_rp[f].size(); k++) b->h_rp.p[rp_off[f] + k] = cam_rp[f][k].pose;
+    rc = b->d_rp.ensure(np_);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(b->d_rp.p, b->h_rp.p, sizeof(cs::RpPose) * np_, hipMemcpyHostToDevice, st));
   }
   tm.setup_host_ms += now_ms() - t0;
 
   if (g_prof) g_mark[11] += now_ms() - t_begin;   // camera caches + pose pool upload
   // ---- production path: chunked two-slot pipeline (host packs chunk k+1 / finishes chunk k-1 while the GPU sweeps k)
   if (!sample_rp && !b->debug && !b->force_host_rank && !b->force_host_setup && !b->force_no_pipeline && b->device_setup && KMAX <= cs::RANK_KMAX && MB > 0) {
-    PipeCtx C{d, b, out, out_counts, &cam_raw, &rp_off, sp, &tm};
+    rs->C = PipeCtx{d, b, out, out_counts, &rs->cam_raw, &rs->rp_off, sp, &rs->tm};
+    PipeCtx& C = rs->C;
     const int n_chunks = std::max(1, std::min(NF, b->pipe_chunks));
+    if (n_chunks == 1) {    // the usual shape: one launch, one finish -- the finish may be left to cs_batch_collect
+      int rc = pipe_launch(C, b->pipe[0], 0, NF);
+      if (rc) return rc;
+      rs->deferred = true;
+      b->run_state = rs_owner.release();
+      return defer ? CS_OK : batch_collect_impl(d, b);
+    }
     for (int k = 0; k <= n_chunks; k++) {
       if (k < n_chunks) {
         int f0 = (int)((long long)NF * k / n_chunks), f1 = (int)((long long)NF * (k + 1) / n_chunks);
@@ -1454,7 +1539,6 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
     ENS(b->d_yaw, n_yaw + 1); ENS(b->d_yaw_c, n_yaw + 1); ENS(b->d_yaw_s, n_yaw + 1); ENS(b->d_top_x, n_top + 1);
     ENS(b->d_vp, 6 * (size_t)vp_total + 6); ENS(b->d_bound, 6 * (size_t)vp_total + 6);
     ENS(b->d_flag, slot_total + 1);
-    ENS(b->d_corners, 16 * (size_t)slot_total + 16);
 #define H2D(dst, vec) HIP_TRY(hipMemcpyAsync((dst).p, (vec).data(), sizeof((vec)[0]) * (vec).size(), hipMemcpyHostToDevice, st))
     H2D(b->d_jobs, jobs); H2D(b->d_slot_prefix, slot_prefix); H2D(b->d_vp_prefix, vp_prefix);
     if (n_lines && !dev_setup) { H2D(b->d_mid_x, mid_x); H2D(b->d_mid_y, mid_y); H2D(b->d_ang, ang); }
@@ -1470,7 +1554,7 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
     v.maps = b->d_maps.p; v.mid_x = b->d_mid_x.p; v.mid_y = b->d_mid_y.p; v.line_angle = b->d_ang.p;
     v.yaw = b->d_yaw.p; v.yaw_cos = b->d_yaw_c.p; v.yaw_sin = b->d_yaw_s.p; v.top_x = b->d_top_x.p; v.rp = b->d_rp.p; v.invK = b->d_invK.p;
     v.vp = b->d_vp.p; v.bound = b->d_bound.p; v.flag = b->d_flag.p;
-    v.corners = b->d_corners.p; v.job_valid = b->d_job_valid.p; v.job_cbase = b->d_job_cbase.p;
+    v.job_valid = b->d_job_valid.p; v.job_cbase = b->d_job_cbase.p;
     HIP_TRY(hipEventRecord(d->ev[6], st));
     if (dev_setup) {
       cs::launch_line_setup(b->d_jobs.p, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, b->d_mid_x.p, b->d_mid_y.p, b->d_ang.p,
@@ -1498,7 +1582,7 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
       HIP_TRY(hipEventRecord(d->ev[3], st));
       cs::launch_scan_compact(v, st);
       HIP_TRY(hipEventRecord(d->ev[8], st));
-      cs::launch_score(v, slot_total, slot_total, st);   // the exact number of valid proposals stays on the device
+      cs::launch_score(v, sp, slot_total, slot_total, st);   // the exact number of valid proposals stays on the device
       HIP_TRY(hipEventRecord(d->ev[4], st));
       std::vector<int> box_job0, box_njobs;
       for (size_t j = 0; j < nj; j++)
@@ -1511,7 +1595,7 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
       rv.box_job0 = b->d_box_job0.p; rv.box_njobs = b->d_box_njobs.p; rv.n_boxes = (int)nb;
       rv.winners = b->d_winners.p; rv.win_count = b->d_win_count.p; rv.fallback = b->d_fallback.p;
       if (sample_rp) { ENS(b->d_last_slot, nb); ENS(b->h_last_slot, nb); rv.last_slot = b->d_last_slot.p; }
-      cs::RankParams rkp{P.weight_vp_angle, P.weight_skew_error, P.nominal_skew_ratio, P.max_cut_skew, KMAX};
+      cs::RankParams rkp{P.weight_vp_angle, P.weight_skew_error, P.nominal_skew_ratio, P.max_cut_skew, KMAX, sp.short_sq_bound};
       cs::launch_rank(v, rv, rkp, st);
       HIP_TRY(hipEventRecord(d->ev[5], st));
       HIP_TRY(hipGetLastError());
@@ -1536,11 +1620,11 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
         HIP_TRY(hipEventElapsedTime(&ms, d->ev[4], d->ev[5])); tm.rank_kernel_ms += ms;
         HIP_TRY(hipEventElapsedTime(&ms, d->ev[6], d->ev[7])); tm.line_setup_ms += ms;
         tm.cand_kernel_launches += 1;
-        // algorithmic bytes: geometry kernel = vanishing points read once per (job, rp, yaw) + one flag
-        // per slot + 128 B of corners per valid proposal; scoring kernel = each distance map once + the VP support table
-        // + 128 B of corners read and 28 B of scores written per valid proposal
-        tm.cand_kernel_bytes += 48LL * vp_total + 4LL * slot_total + 128LL * n_valid;
-        long long sbytes = 48LL * vp_total + (128LL + 28LL + 8LL) * n_valid;
+        // algorithmic bytes: geometry kernel = vanishing points read once per (job, rp, yaw) + one flag per slot
+        // (the corners stay in registers); scoring kernel = each distance map once + the vanishing points and the VP support table
+        // once per (job, rp, yaw) + per valid proposal 12 B read (slot id, flag) and 28 B of scores written
+        tm.cand_kernel_bytes += 48LL * vp_total + 4LL * slot_total;
+        long long sbytes = 96LL * vp_total + (28LL + 8LL + 4LL) * n_valid;
         for (size_t j = 0; j < nj; j++) sbytes += 4LL * jobs[j].map_w * (jobs[j].g.eb - jobs[j].g.et);
         tm.score_kernel_bytes += sbytes;
       }
@@ -1675,7 +1759,7 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
         if (!ws.empty()) {
           ENS(b->d_win_slots, ws.size()); ENS(b->d_win_corners, 16 * ws.size()); ENS(b->h_win_corners, 16 * ws.size());
           H2D(b->d_win_slots, ws);
-          cs::launch_gather_corners(b->d_corners.p, b->d_win_slots.p, (int)ws.size(), b->d_win_corners.p, st);
+          cs::launch_gather_corners(v, sp, b->d_win_slots.p, (int)ws.size(), b->d_win_corners.p, st);
           HIP_TRY(hipMemcpyAsync(b->h_win_corners.p, b->d_win_corners.p, sizeof(double) * 16 * ws.size(), hipMemcpyDeviceToHost, st));
           HIP_TRY(hipStreamSynchronize(st));
           size_t z = 0;
@@ -1703,7 +1787,7 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
     HIP_TRY(hipEventRecord(d->ev[3], st));
     cs::launch_scan_compact(v, st);
     HIP_TRY(hipEventRecord(d->ev[8], st));
-    cs::launch_score(v, n_valid, slot_total, st);
+    cs::launch_score(v, sp, n_valid, slot_total, st);
     HIP_TRY(hipEventRecord(d->ev[4], st));
     HIP_TRY(hipGetLastError());
     ENS(b->h_c_slot, n_valid + 1); ENS(b->h_c_flag, n_valid + 1); ENS(b->h_c_dist, n_valid + 1); ENS(b->h_c_angle, n_valid + 1); ENS(b->h_c_skew, n_valid + 1);
@@ -1727,11 +1811,9 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
       tm.cand_kernel_launches += 1;
       // algorithmic bytes of the candidate kernel: maps + line arrays + vp/bound read once,
       // 200 B written per valid proposal, 4 B flag per slot
-      // algorithmic bytes: geometry kernel = vanishing points read once per (job, rp, yaw) + one flag
-      // per slot + 128 B of corners per valid proposal; scoring kernel = each distance map once + the VP support table
-      // + 128 B of corners read and 28 B of scores written per valid proposal
-      tm.cand_kernel_bytes += 48LL * vp_total + 4LL * slot_total + 128LL * n_valid;
-      long long sbytes = 48LL * vp_total + (128LL + 28LL + 8LL) * n_valid;
+      // algorithmic bytes: as above
+      tm.cand_kernel_bytes += 48LL * vp_total + 4LL * slot_total;
+      long long sbytes = 96LL * vp_total + (28LL + 8LL + 4LL) * n_valid;
       for (size_t j = 0; j < nj; j++) sbytes += 4LL * jobs[j].map_w * (jobs[j].g.eb - jobs[j].g.et);
       tm.score_kernel_bytes += sbytes;
     }
@@ -1830,7 +1912,7 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
     if (n_gather) {
       ENS(b->d_win_slots, n_gather); ENS(b->d_win_corners, 16 * n_gather); ENS(b->h_win_corners, 16 * n_gather);
       HIP_TRY(hipMemcpyAsync(b->d_win_slots.p, wslots.data(), sizeof(long long) * n_gather, hipMemcpyHostToDevice, st));
-      cs::launch_gather_corners(b->d_corners.p, b->d_win_slots.p, (int)n_gather, b->d_win_corners.p, st);
+      cs::launch_gather_corners(v, sp, b->d_win_slots.p, (int)n_gather, b->d_win_corners.p, st);
       HIP_TRY(hipMemcpyAsync(b->h_win_corners.p, b->d_win_corners.p, sizeof(double) * 16 * n_gather, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
     }

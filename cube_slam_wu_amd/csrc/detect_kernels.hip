@@ -24,7 +24,9 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
+#include "../../include/cubeslam_hip.h"
 #include "detect_types.h"
 
 namespace cs {
@@ -379,12 +381,10 @@ __device__ __forceinline__ int candidate_one(const DetectDeviceView& v, const Sw
   if (enabled) {
     const double* vp = v.vp + 6 * (long long)(jd.vp_off + (int)ryu);
     V2 c[8];
+    // only the decision leaves this kernel (4 bytes per slot): whoever needs the corners of a valid proposal -- the scorer, the
+    // winners' records, the tie boxes' gather -- rebuilds them from the same inputs with the same build_corners (slot_corners below:
+    // the same instructions on the same operands, hence the same bits), instead of 128 bytes per valid slot going to memory and back
     flag = build_corners(jd.g, v2(vp[0], vp[1]), v2(vp[2], vp[3]), v2(vp[4], vp[5]), (double)v.top_x[jd.top_off + t], cfg, sp.short_sq_bound, c);
-    if (flag) {
-      double* co = v.corners + 16 * slot;
-#pragma unroll
-      for (int i = 0; i < 8; i++) { co[i] = c[i].x; co[8 + i] = c[i].y; }
-    }
   }
   v.flag[slot] = flag;
   return flag;
@@ -415,6 +415,27 @@ __global__ __launch_bounds__(256) void candidate_kernel(DetectDeviceView v, Swee
   }
 }
 
+// The eight corners of the proposal in `slot` of job jd (box_proposal_detail.cpp:413-625), rebuilt: slot = slot_off + ((rp Y + yaw) T
+// + top) 2 + (config - 1).  Returns build_corners' flag.
+__device__ __forceinline__ int slot_corners(const DetectDeviceView& v, const JobDesc& jd, long long slot, double short_sq_bound, V2 c[8]) {
+  const unsigned local = (unsigned)(slot - jd.slot_off);
+  const unsigned rest = local >> 1, ryu = rest / (unsigned)jd.T;
+  const int t = (int)(rest - ryu * (unsigned)jd.T);
+  const double* vp = v.vp + 6 * (long long)(jd.vp_off + (int)ryu);
+  return build_corners(jd.g, v2(vp[0], vp[1]), v2(vp[2], vp[3]), v2(vp[4], vp[5]), (double)v.top_x[jd.top_off + t], (int)(local & 1) + 1, short_sq_bound, c);
+}
+// ... of a slot whose job is not at hand (winners, tie boxes: a handful per box)
+__device__ __forceinline__ void slot_corners16(const DetectDeviceView& v, long long slot, double short_sq_bound, double out16[16]) {
+  int lo = 0, hi = v.n_jobs;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (v.slot_prefix[mid] <= slot) lo = mid; else hi = mid; }
+  V2 c[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) c[q] = v2(0.0, 0.0);
+  slot_corners(v, v.jobs[lo], slot, short_sq_bound, c);
+#pragma unroll
+  for (int q = 0; q < 8; q++) { out16[q] = c[q].x; out16[8 + q] = c[q].y; }
+}
+
 // ---- proposal scoring: one lane per VALID proposal (compacted, in the reference's row order) ------------------
 // box_edge_sum_dists (object_3d_util.cpp:622-667: 11 samples per visible edge, float gathers from the distance map,
 // sequential float running sum), box_edge_alignment_angle_error (:670-723) and the 3D half sizes (:941-990).
@@ -426,9 +447,9 @@ __global__ __launch_bounds__(256) void candidate_kernel(DetectDeviceView v, Swee
 __device__ __forceinline__ int sel(int cfg, int a, int b) { return cfg ? b : a; }
 
 enum { SCORE_JOBS = 4, SCORE_SUB = 128, SCORE_BINS = SCORE_JOBS * SCORE_SUB };   // sort keys of score_kernel: (job within the block, configuration x top sample)
-__global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long long slot_total) {
-  // [coordinate: x0..x7, y0..y7][lane]: lanes of a wave mostly ask for the same corner (sorted by configuration).  Row stride 260:
-  // the cooperative load below writes 16 coordinates x 4 proposals per wave, which then spread over all banks
+__global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long long slot_total, double short_sq_bound) {
+  // [coordinate: x0..x7, y0..y7][lane]: every lane keeps its proposal's corners in its own column (LDS because the edge tables index
+  // them dynamically); lanes of a wave mostly ask for the same corner (sorted by configuration)
   __shared__ double C16[16][260];
   double (*CXt)[260] = C16, (*CYt)[260] = C16 + 8;
   // the grid is sized for the worst case (every slot valid) because the exact count lives on the device; spread the
@@ -485,23 +506,8 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
     s_src[hist[key] + rank] = t0;
     __syncthreads();
   }
-  // corners of the block's 256 proposals -> LDS.  A proposal's 16 doubles are one 128-byte line of the per-slot array: 16 lanes
-  // fetch one proposal (a wave instruction touches 4 lines, not 64 as it would with one proposal per lane)
   const int mine = s_src[threadIdx.x];
-  const JobDesc jd = v.jobs[s_job[mine]];      // requested together with the corners: it is the next thing the lane needs
-  {
-    const int k = threadIdx.x & 15;
-    double cv[16];
-#pragma unroll
-    for (int it = 0; it < 16; it++) {          // all 16 loads of a thread in flight before the first one is stored
-      const int p = it * 16 + (threadIdx.x >> 4);
-      const int src = s_src[p];
-      cv[it] = (base + src < n_valid) ? v.corners[16 * s_slot[src] + k] : 0.0;
-    }
-#pragma unroll
-    for (int it = 0; it < 16; it++) C16[k][it * 16 + (threadIdx.x >> 4)] = cv[it];
-  }
-  __syncthreads();
+  const JobDesc jd = v.jobs[s_job[mine]];
   const long long i = base + mine;
   if (i >= n_valid) return;                     // (no barrier below this point)
   const long long slot = s_slot[mine];
@@ -512,6 +518,15 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
   const int tx = threadIdx.x;
   const double ox = (double)jd.g.el, oy = (double)jd.g.et;
   const float* __restrict__ map = v.maps + jd.map_off;
+  // the proposal's corners, rebuilt (candidate_kernel kept only the decision): into this lane's own LDS column, no barrier needed
+  {
+    V2 cb[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) cb[q] = v2(0.0, 0.0);
+    slot_corners(v, jd, slot, short_sq_bound, cb);
+#pragma unroll
+    for (int q = 0; q < 8; q++) { CXt[q][tx] = cb[q].x; CYt[q][tx] = cb[q].y; }
+  }
   // (the six VP-support angles of the angle term are requested here, ahead of the gathers: one round trip less on the block's path)
   double bnd[6];
   {
@@ -666,12 +681,16 @@ __global__ __launch_bounds__(256) void compact_kernel(DetectDeviceView v) {
   }
 }
 
-__global__ __launch_bounds__(256) void gather_corners_kernel(const double* corners, const long long* slots, int n, double* out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * 16) return;
-  int w = i >> 4, k = i & 15;
+__global__ __launch_bounds__(64) void gather_corners_kernel(DetectDeviceView v, double short_sq_bound, const long long* slots, int n, double* out) {
+  int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n) return;
   long long s = slots[w];
-  out[i] = (s >= 0) ? corners[16 * s + k] : 0.0;
+  double c16[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) c16[q] = 0.0;
+  if (s >= 0) slot_corners16(v, s, short_sq_bound, c16);
+#pragma unroll
+  for (int q = 0; q < 16; q++) out[16 * (size_t)w + q] = c16[q];
 }
 
 
@@ -938,9 +957,7 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
       RankWinner* w = rv.winners + (size_t)box * rp.kmax + round;
       long long slot = v.c_slot[w_at];
       w->slot = slot; w->normalized_error = w_score; w->dist_err = w_d; w->angle_err = w_a; w->flag = v.c_flag[w_at] & CAND_VP_MASK; w->pad = 0;
-      const double* co = v.corners + 16 * slot;
-#pragma unroll
-      for (int q = 0; q < 16; q++) w->corners[q] = co[q];
+      slot_corners16(v, slot, rp.short_sq_bound, w->corners);
     }
     if (cnt != 1 && threadIdx.x == 0) s_fallback = 1;
     prev = gbest;
@@ -1146,8 +1163,15 @@ __global__ __launch_bounds__(LS_THREADS) void line_setup_kernel(JobDesc* jobs, i
 
 // st_crowded (with the two events): the few crowded ROIs -- long, low-occupancy workgroups -- run on their own stream beside the
 // others; `fork` must already be recorded on st, `join` is recorded here and st waits for it.
+// diagnostics: CS_DETECT_SKIP=<names> leaves the named kernels out of the sweep, to measure their marginal cost in the saturated
+// pipeline (the results are then meaningless; never set outside a timing experiment)
+static bool skip_kernel(const char* name) {
+  static const char* e = getenv("CS_DETECT_SKIP");
+  return e && strstr(e, name) != nullptr;
+}
 void launch_line_setup(JobDesc* jobs, int n_jobs, const double* frame_lines, const int* frame_line_ptr, double* mid_x, double* mid_y, double* line_angle,
                        double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st, const int* order, hipStream_t st_crowded, hipEvent_t fork, hipEvent_t join) {
+  if (skip_kernel("line_setup")) return;
   if (n_jobs <= 0) return;
   LineSetupParams lp{dist_thre, angle_thre_deg / 180.0 * CS_PI, len_thre, sqrt_lt_bound(dist_thre), sqrt_le_bound(len_thre)};
   const bool beside = st_crowded && fork && join;
@@ -1159,6 +1183,79 @@ void launch_line_setup(JobDesc* jobs, int n_jobs, const double* frame_lines, con
   if (beside) (void)hipStreamWaitEvent(st, join, 0);
 }
 int line_setup_capacity() { return LS_CAP; }
+
+
+// ---- the winners' records, written on the device ----------------------------------------------------------------------------
+// One cs_cuboid per (box, winner) of the boxes the device ranked (the tie boxes go through the host's exact ranking and are written
+// there): box_proposal_detail.cpp:740-798 -- the row's columns, change_2d_corner_to_3d_object (object_3d_util.cpp:941-1011) and
+// compute3D_BoxCorner (:59-73) with similarityTransformation (:15-44).  cos / sin of the yaw come from the sample tables the host
+// filled with glibc's values (the same calls the host-side record writer makes), so every field carries the host writer's bits.
+// rect_detect_2d is the caller's box and is filled in by the host when it copies the record out.
+__global__ __launch_bounds__(64) void record_kernel(DetectDeviceView v, RankView rv, int kmax, cs_cuboid* __restrict__ out) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= rv.n_boxes * kmax) return;
+  const int q = e / kmax, r = e - q * kmax;
+  if (rv.fallback[q] || r >= rv.win_count[q]) return;
+  const RankWinner& w = rv.winners[e];
+  const int j0 = rv.box_job0[q], nh = rv.box_njobs[q];
+  int h = 0;
+  while (h + 1 < nh && w.slot >= v.jobs[j0 + h + 1].slot_off) h++;
+  const JobDesc& jd = v.jobs[j0 + h];
+  const long long local = w.slot - jd.slot_off, rest = local >> 1;
+  const int y = (int)(rest / jd.T);
+  const RpPose& pose = v.rp[jd.rp_off];
+  cs_cuboid o;
+  {
+    double* z = reinterpret_cast<double*>(&o);
+    static_assert(sizeof(cs_cuboid) % 8 == 0, "cs_cuboid is a whole number of doubles");
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(cs_cuboid) / 8); i++) z[i] = 0.0;
+  }
+  V2 c[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) c[i] = v2(w.corners[i], w.corners[8 + i]);
+  lift_to_3d(c, pose.R, pose.t, v.invK + 9 * jd.frame, pose.plane, o.pos, o.scale);
+  o.rotY = v.yaw[jd.yaw_off + y];
+  const int vp1_pos = w.flag & CAND_VP_MASK;
+  o.box_config_type[0] = (double)((local & 1) + 1); o.box_config_type[1] = (double)vp1_pos;
+  const int left_ids[8] = {6, 5, 8, 7, 2, 3, 4, 1}, right_ids[8] = {5, 6, 7, 8, 3, 2, 1, 4};
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int id = (vp1_pos == 1) ? left_ids[i] : right_ids[i];
+    o.box_corners_2d[i] = (int)w.corners[id - 1];
+    o.box_corners_2d[8 + i] = (int)w.corners[8 + id - 1];
+  }
+  const double body[3][8] = {{1, 1, -1, -1, 1, 1, -1, -1}, {1, -1, -1, 1, 1, -1, -1, 1}, {-1, -1, -1, -1, 1, 1, 1, 1}};
+  const double cr = v.yaw_cos[jd.yaw_off + y], sr = v.yaw_sin[jd.yaw_off + y];
+  const double rot[3][3] = {{cr, -sr, 0}, {sr, cr, 0}, {0, 0, 1}};
+  double S[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) S[i][j] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) S[i][j] = rot[i][j] * o.scale[j];
+    S[i][3] = o.pos[i];
+  }
+  S[3][3] = 1;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const double p[4] = {body[0][k], body[1][k], body[2][k], 1.0};
+    double wv[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) wv[i] = ((S[i][0] * p[0] + S[i][1] * p[1]) + S[i][2] * p[2]) + S[i][3] * p[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) o.box_corners_3d_world[8 * i + k] = wv[i] / wv[3];
+  }
+  o.edge_distance_error = w.dist_err;
+  o.edge_angle_error = w.angle_err;
+  o.normalized_error = w.normalized_error;
+  o.skew_ratio = ((o.scale[0] < o.scale[1]) ? o.scale[1] : o.scale[0]) / ((o.scale[1] < o.scale[0]) ? o.scale[1] : o.scale[0]);   // std::max / std::min
+  o.down_expand_height = (double)jd.down_expand;
+  out[e] = o;
+}
 
 // ------------------------------------------------------------------ launchers (host side) -----
 static inline unsigned grid8(long long n, int bs) {
@@ -1172,6 +1269,7 @@ void launch_vp_support(const DetectDeviceView& v, const SweepParams& sp, int vp_
   vp_support_kernel<0><<<dim3(grid8(vp_total, 256)), dim3(256), 0, st>>>(v, sp, vp_total);
 }
 void launch_vp_support_only(const DetectDeviceView& v, const SweepParams& sp, int vp_total, hipStream_t st) {
+  if (skip_kernel("vp_support")) return;
   if (vp_total <= 0) return;
   hipLaunchKernelGGL(vp3_support_kernel, dim3((unsigned)(((long long)v.n_jobs * VP3_RPCAP + 63) / 64)), dim3(64), 0, st, v, sp);
   vp_support_kernel<1><<<dim3(grid8(vp_total, 256)), dim3(256), 0, st>>>(v, sp, vp_total);
@@ -1182,6 +1280,7 @@ void launch_vp_points(const DetectDeviceView& v, int vp_total, hipStream_t st) {
   hipLaunchKernelGGL(vp_points_kernel, dim3((vp_total + 255) / 256), dim3(256), 0, st, v, vp_total);
 }
 void launch_candidates(const DetectDeviceView& v, const SweepParams& sp, long long slot_total, hipStream_t st) {
+  if (skip_kernel("candidate")) return;
   if (slot_total <= 0) return;
   hipLaunchKernelGGL(candidate_kernel, dim3(grid8(slot_total, 256)), dim3(256), 0, st, v, sp, slot_total);
 }
@@ -1191,9 +1290,10 @@ void launch_scan_compact(const DetectDeviceView& v, hipStream_t st) {
   hipLaunchKernelGGL(compact_kernel, dim3(v.n_jobs), dim3(256), 0, st, v);
 }
 // scoring over the compacted proposals; n_valid_bound is an upper bound known on the host (the exact count stays on the device)
-void launch_score(const DetectDeviceView& v, long long n_valid_bound, long long slot_total, hipStream_t st) {
+void launch_score(const DetectDeviceView& v, const SweepParams& sp, long long n_valid_bound, long long slot_total, hipStream_t st) {
+  if (skip_kernel("score")) return;
   if (n_valid_bound <= 0) return;
-  hipLaunchKernelGGL(score_kernel, dim3(grid8(n_valid_bound, 256)), dim3(256), 0, st, v, slot_total);
+  hipLaunchKernelGGL(score_kernel, dim3(grid8(n_valid_bound, 256)), dim3(256), 0, st, v, slot_total, sp.short_sq_bound);
 }
 // copy [src_off, src_off + count) ranges of the compacted columns into packed buffers (fallback boxes)
 __global__ __launch_bounds__(256) void gather_ranges_kernel(DetectDeviceView v, const long long* src_off, const int* count, const long long* dst_off, int n_ranges,
@@ -1212,12 +1312,19 @@ void launch_gather_ranges(const DetectDeviceView& v, const long long* src_off, c
   hipLaunchKernelGGL(gather_ranges_kernel, dim3(n_ranges), dim3(256), 0, st, v, src_off, count, dst_off, n_ranges, o_dist, o_angle, o_skew, o_flag, o_slot);
 }
 void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams& rp, hipStream_t st) {
+  if (skip_kernel("rank")) return;
   if (rv.n_boxes <= 0) return;
   hipLaunchKernelGGL(rank_kernel, dim3(rv.n_boxes), dim3(256), 0, st, v, rv, rp);
 }
-void launch_gather_corners(const double* corners, const long long* slots, int n, double* out, hipStream_t st) {
+void launch_records(const DetectDeviceView& v, const RankView& rv, int kmax, cs_cuboid* out, hipStream_t st) {
+  if (skip_kernel("records")) return;
+  const int n = rv.n_boxes * kmax;
   if (n <= 0) return;
-  hipLaunchKernelGGL(gather_corners_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, st, corners, slots, n, out);
+  hipLaunchKernelGGL(record_kernel, dim3((n + 63) / 64), dim3(64), 0, st, v, rv, kmax, out);
+}
+void launch_gather_corners(const DetectDeviceView& v, const SweepParams& sp, const long long* slots, int n, double* out, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(gather_corners_kernel, dim3((n + 63) / 64), dim3(64), 0, st, v, sp.short_sq_bound, slots, n, out);
 }
 
 }  // namespace cs

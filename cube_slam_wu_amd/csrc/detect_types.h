@@ -58,7 +58,6 @@ struct DetectDeviceView {
   double* bound3;                // lean path: 2 per (job, rp) slot -- the third VP's support angles (they do not depend on yaw)
   // per-slot outputs
   int* flag;
-  double* corners;               // 16 per slot (x0..x7, y0..y7), written for valid slots only
   // per-job valid counts and compacted outputs
   int* job_valid;                // n_jobs
   long long* job_cbase;          // n_jobs + 1, exclusive scan of job_valid
@@ -74,6 +73,7 @@ struct RankParams {
   double nominal_skew;   // nominal_skew_ratio
   double max_cut_skew;   // max_cut_skew
   int kmax;              // max_cuboid_num (<= RANK_KMAX on the device path)
+  double short_sq_bound; // SweepParams::short_sq_bound: the winners' corners are rebuilt (slot_corners16)
 };
 enum { RANK_KMAX = 8 };
 

@@ -162,6 +162,14 @@ int cs_detect_lines_gray(cs_detector* d, const unsigned char* gray, int img_w, i
 int cs_batch_create(cs_detector* d, const cs_frame_desc* frames, int n_frames, cs_batch** out);
 int cs_batch_max_boxes(const cs_batch* b);
 int cs_batch_run(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_counts);
+/* cs_batch_run() in two halves.  cs_batch_submit packs the batch on the host and queues the whole sweep on the detector's streams
+ * without waiting for it; cs_batch_collect waits, writes `out` / `out_counts` (which must stay valid until then) and the timing.  A
+ * throughput caller that owns several batches keeps the next one queued while the current one is on the device, so the host stages
+ * of one batch overlap the sweep of another.  One outstanding submit per batch; the batches of one detector are submitted and
+ * collected by one thread, in submission order.  (Configurations that need host round trips inside the sweep -- roll/pitch
+ * sampling, debug retention, chunked pipeline -- run to completion inside cs_batch_submit; collect is then a no-op.)            */
+int cs_batch_submit(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_counts);
+int cs_batch_collect(cs_detector* d, cs_batch* b);
 void cs_batch_destroy(cs_batch* b);
 
 /* Timing of the last cs_batch_run() (milliseconds; kernel times from hipEvents on the detector's

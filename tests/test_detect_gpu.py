@@ -301,6 +301,34 @@ def test_chunk_pipeline_matches_single_pass():
     a.close(); b.close(); det.close()
 
 
+def test_submit_collect_two_batches_of_one_detector_in_flight():
+    """cs_batch_submit / cs_batch_collect: the next batch is packed and queued while the previous one is still on the device.  Two
+    different batches of one detector, both submitted before either is collected, give the records of their synchronous runs (the
+    device-written records of the lean path: byte-identical to the path that writes them on the host, tie boxes included); a second
+    submit of an uncollected batch is refused."""
+    fa = [synth.make_frame(8700 + s, n_boxes=1 + s % 3, n_lines=140 + 15 * s) for s in range(9)]
+    fb = [synth.make_frame(8800 + s, n_boxes=2, n_lines=120) for s in range(5)]
+    tie = synth.make_frame(8600, n_boxes=2, n_lines=150)
+    tie["maps"] = [[np.zeros_like(m) for m in mm] for mm in tie["maps"]]
+    fb[2] = tie
+    det = capi.Detector(capi.default_params(whether_sample_cam_roll_pitch=0, yaw_step_deg=3.0, max_cuboid_num=2))
+    ra = capi.Batch(det, fa, force_no_pipeline=True); ra.run()
+    rb = capi.Batch(det, fb, force_no_pipeline=True); rb.run()
+    a, b = capi.Batch(det, fa), capi.Batch(det, fb)
+    for _ in range(2):          # the second round reuses the slots
+        a.submit(); b.submit()
+        with pytest.raises(RuntimeError):
+            a.submit()
+        a.collect(); b.collect()
+        assert a.raw_out_bytes() == ra.raw_out_bytes() and a.counts_bytes() == ra.counts_bytes()
+        assert b.raw_out_bytes() == rb.raw_out_bytes() and b.counts_bytes() == rb.counts_bytes()
+    assert b.timing()["n_fallback_boxes"] >= 2
+    a.collect()                 # nothing outstanding: a no-op
+    for x in (a, b, ra, rb):
+        x.close()
+    det.close()
+
+
 def test_full_size_c2_batch_against_oracle_sample_and_properties():
     """BASELINE.json's C2 at the bench's full batch size (1000 frames x 8 boxes x 181 yaw x ~400 segments, 31.5 M
     proposal slots per run): (a) 48 frames drawn from the batch are bit-identical to the oracle's records,
