@@ -731,3 +731,16 @@ def test_cuboid_elimination_equals_g2os_reduced_system(case, monkeypatch):
     for a, b in zip(E.state(), K.state()):
         assert a.size == 0 or np.abs(a - b).max() < 1e-5 * max(1.0, np.abs(b).max())
     E.close(); K.close(); R.close()
+
+
+def test_hip_path_against_the_independent_projection_schur_fixture():
+    """The same file the oracle is held to on the CPU (tests/test_ba_oracle.py, tools/make_ba_golden.py: a numpy restatement of the
+    reference's projection edge, quadratic form, Schur complement and LM loop that shares nothing with oracle/ or csrc/), through
+    the C ABI on the device: system blocks, one damped solve, five LM iterations, final states."""
+    from test_ba_oracle import check_against_independent_fixture
+
+    def make(g):
+        P = capi.BaProblem(g["cams"], g["cam_fixed"], np.zeros((0, 10)), np.zeros(0, np.int32), g["points"], g["pt_fixed"])
+        P.set_edges_proj(g["e_pt"], g["e_cam"], g["e_uv"], g["e_info"], g["e_intr"], g["e_huber"])
+        return P
+    check_against_independent_fixture(make, 1e-10, 1e-7)

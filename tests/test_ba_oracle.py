@@ -139,3 +139,60 @@ def test_cuboid_projection_edges_errors_and_descent():
     n = P.optimize(5)
     hist = P.history()[0]
     assert n >= 2 and hist[n - 1] < 0.5 * chi
+
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "ba_proj_schur_30.npz")
+
+
+def check_against_independent_fixture(make_problem, tol_sys, tol_state):
+    """The projection-edge + Schur half against tests/golden/ba_proj_schur_30.npz: an independent numpy restatement of
+    types_six_dof_expmap.cpp:148-192, base_binary_edge.hpp:54-120, block_solver.hpp:367-486 and
+    optimization_algorithm_levenberg.cpp:61-189 (tools/make_ba_golden.py -- nothing of oracle/ or csrc/ went into it) produced the
+    linear system at the initial state, one damped solve, the chi2 / lambda / trial history of five LM iterations and the final
+    states of a 30-camera chain with Huber kernels.  `make_problem(g)` returns an object with the oracle's Python interface."""
+    g = np.load(GOLD)
+    P = make_problem(g)
+    chi0 = P.compute_errors()
+    chi0 = chi0[0] if isinstance(chi0, tuple) else chi0
+    assert abs(chi0 - g["chi2_initial"]) <= 1e-10 * g["chi2_initial"]
+    Hpp, Hll, Hpl, b = P.build_system()
+    n = Hpp.shape[0]
+    free = np.nonzero(g["cam_fixed"] == 0)[0]
+    assert n == 6 * len(free)
+    scale_h = np.abs(g["Hcam"]).max()
+    for k, c in enumerate(free):     # camera diagonal blocks and gradients, g2o's order (free cameras by id)
+        assert np.abs(Hpp[6 * k:6 * k + 6, 6 * k:6 * k + 6] - g["Hcam"][c].reshape(6, 6)).max() <= tol_sys * scale_h
+        assert np.abs(b[6 * k:6 * k + 6] - g["bcam"][c]).max() <= tol_sys * np.abs(g["bcam"]).max()
+    off = Hpp.copy()
+    for k in range(len(free)):
+        off[6 * k:6 * k + 6, 6 * k:6 * k + 6] = 0
+    assert np.abs(off).max() == 0                                  # projection edges only: no pose-pose blocks before the Schur step
+    assert np.abs(Hll - g["Hpt"]).max() <= tol_sys * np.abs(g["Hpt"]).max()
+    assert np.abs(b[n:].reshape(-1, 3) - g["bpt"]).max() <= tol_sys * np.abs(g["bpt"]).max()
+    assert np.abs(Hpl - g["Hpl"]).max() <= tol_sys * np.abs(g["Hpl"]).max()
+    ok, x = P.solve(float(g["solve_lambda"]))
+    assert ok
+    assert np.abs(x[:n] - g["solve_xp"]).max() <= 1e-7 * np.abs(g["solve_xp"]).max()
+    assert np.abs(x[n:].reshape(-1, 3) - g["solve_xl"]).max() <= 1e-7 * np.abs(g["solve_xl"]).max()
+    P.close()
+    P = make_problem(g)
+    assert P.optimize(5) == len(g["chi2_hist"])
+    chi, lam, tr = P.history()
+    assert np.array_equal(tr, g["trials_hist"])
+    assert np.allclose(chi, g["chi2_hist"], rtol=1e-8) and np.allclose(lam, g["lambda_hist"], rtol=1e-6)
+    cams, _, pts = P.state()
+    scale = np.abs(g["final_points"]).max()
+    assert np.abs(pts - g["final_points"]).max() <= tol_state * scale
+    assert np.abs(cams[:, :3] - g["final_cams"][:, :3]).max() <= tol_state * scale
+    assert np.abs(np.abs(np.sum(cams[:, 3:] * g["final_cams"][:, 3:], axis=1)) - 1).max() <= tol_state      # same rotations (q ~ -q)
+    P.close()
+
+
+def _oracle_from_fixture(g):
+    P = O.Problem(g["cams"], g["cam_fixed"], np.zeros((0, 10)), np.zeros(0, np.int32), g["points"], g["pt_fixed"])
+    P.set_edges_proj(g["e_pt"], g["e_cam"], g["e_uv"], g["e_info"], g["e_intr"], g["e_huber"])
+    return P
+
+
+def test_oracle_against_the_independent_projection_schur_fixture():
+    check_against_independent_fixture(_oracle_from_fixture, 1e-11, 1e-8)
