@@ -45,7 +45,7 @@ def measure_traffic_live(args, n_unique):
         d = tempfile.mkdtemp(prefix="cs_pmc_", dir="/tmp")
         try:
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "2", "--warmup", "1", "--inflight", "1", "--depth", "1", "--steady-steps", "0", "--ba", "none", "--no-cpu-baseline", "--no-edge", "--rp-frames", "0", "--no-measure-traffic",
+                   "--steps", "2", "--warmup", "1", "--inflight", "1", "--depth", "1", "--steady-steps", "0", "--latency-calls", "0", "--ba", "none", "--no-cpu-baseline", "--no-edge", "--rp-frames", "0", "--no-measure-traffic",
                    "--frames", str(args.frames), "--unique", str(n_unique)]
             subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp", "CS_BENCH_CHILD": "1"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             n, tot = 0, 0.0
@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=0, help="cut the batch into this many chunks of the two-slot host/GPU pipeline (0 = library default)")
     ap.add_argument("--no-edge", action="store_true", help="skip the distance-map front end (Canny + distance transform) timing")
     ap.add_argument("--rp-frames", type=int, default=100, help="frames of the roll/pitch-sampling stress variant (RP = 25 poses per box, the reference's class default); 0 = skip")
+    ap.add_argument("--latency-calls", type=int, default=200, help="calls per entry point of the single-call latency report (0 = skip)")
     ap.add_argument("--depth", type=int, default=1, help="batches per pipeline: the next one is submitted (packed + queued) before the current one is collected")
     ap.add_argument("--steady-steps", type=int, default=200, help="steps of the steady-state measurement reported beside the contract run (0 = skip)")
     ap.add_argument("--inflight", type=int, default=4, help="batches in flight per GPU: each has its own detector (streams, worker pool) and is driven by its own host thread, "
@@ -483,6 +484,40 @@ def main():
                 n += 1
             edge_out["cpu_oracle_rois_per_s"] = n / (time.perf_counter() - t1)
 
+    # ---- single-call latency: the drop-in call is per frame (detect_cuboid once per image, main_obj.cpp:633; detect_filter_lines :593)
+    lat_out = None
+    if rank == 0 and args.latency_calls > 0:
+        def pct(call, n):
+            call(); call()
+            ts = []
+            for _ in range(n):
+                t1 = time.perf_counter(); call(); ts.append((time.perf_counter() - t1) * 1e3)
+            ts.sort()
+            return {"p50_ms": ts[len(ts) // 2], "p99_ms": ts[min(len(ts) - 1, int(len(ts) * 0.99))], "mean_ms": sum(ts) / len(ts), "calls": n}
+        fr1 = uniq[0]
+        H1, W1 = int(fr1["img_h"]), int(fr1["img_w"])
+        rngl = np.random.default_rng(11)
+        yyl, xxl = np.mgrid[0:H1, 0:W1]
+        img1 = np.full((H1, W1), 95.0)
+        for _ in range(30):
+            a = rngl.uniform(0, np.pi)
+            img1 += np.where((xxl - rngl.uniform(0, W1)) * np.cos(a) + (yyl - rngl.uniform(0, H1)) * np.sin(a) > 0, rngl.uniform(-45, 45), 0)
+        gray1 = np.clip(img1 + rngl.normal(0, 4, img1.shape), 0, 255).astype(np.uint8)
+        n_l = args.latency_calls
+        d_rp = capi.Detector(capi.default_params(whether_sample_bbox_height=0, yaw_range_deg=45.0, yaw_step_deg=6.0), device=local_rank)     # the reference class's defaults: 6 deg yaw step, roll/pitch sampling on
+        d_c2 = capi.Detector(capi.default_params(whether_sample_cam_roll_pitch=0, whether_sample_bbox_height=0, yaw_range_deg=45.0, yaw_step_deg=0.5), device=local_rank)
+        lat_out = {"what": "wall time of ONE call on one KITTI-shaped frame (1241 x 376, 8 boxes, ~400 segments), host buffers in, records out; p50 / p99 over %d calls" % n_l,
+                   "cs_detect_cuboids (C2 sweep: 181 yaw, no roll/pitch sampling)": pct(d_c2.frame_call(fr1), n_l),
+                   "cs_detect_cuboids_gray (the same, distance maps from the gray image on the device)": pct(d_c2.frame_call(fr1, gray1), n_l),
+                   "cs_detect_cuboids (reference defaults: 6 deg yaw step, 25 roll/pitch samples)": pct(d_rp.frame_call(fr1), n_l),
+                   "cs_detect_lines_gray (EDLines, one octave, length >= 15)": pct(lambda: d_c2.detect_lines(gray1, 15.0), n_l)}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle_py
+            t1 = time.perf_counter()
+            oracle_py.detect_cuboid(fr1, oracle_py.default_params(yaw_step_deg=0.5), atan2_mode=0)
+            lat_out["cpu_oracle_detect_cuboid_C2_ms"] = (time.perf_counter() - t1) * 1e3
+        d_rp.close(); d_c2.close()
+
     if rank == 0:
         total_frames = args.frames * args.steps * world
         value = total_frames / elapsed
@@ -567,6 +602,8 @@ def main():
             out["edge_front_end"] = edge_out
         if rp_out is not None:
             out["roll_pitch_sampling_stress"] = rp_out
+        if lat_out is not None:
+            out["latency"] = lat_out
         print(json.dumps(out))
     for b_ in bats:
         b_.close()

@@ -177,6 +177,42 @@ class Detector:
             raise RuntimeError("cs_detect_lines_gray failed (%d): %s" % (rc, last_error()))
         return out[:n.value].copy()
 
+    def frame_call(self, frame, gray=None):
+        """A reusable zero-argument callable for cs_detect_cuboids (or cs_detect_cuboids_gray when `gray` is given) on one frame: the
+        ctypes descriptor is built once, so repeated calls time the library, not the marshalling.  call() -> list of lists of dicts."""
+        K = np.ascontiguousarray(frame["K"], np.float64).reshape(9)
+        T = np.ascontiguousarray(frame["T_wc"], np.float64).reshape(16)
+        boxes = np.ascontiguousarray(frame["boxes"], np.float64).reshape(-1, 5)
+        lines = np.ascontiguousarray(frame["lines"], np.float64).reshape(-1, 4)
+        nb = boxes.shape[0]
+        arr = (C.POINTER(C.c_float) * max(1, 3 * nb))()
+        keep = [K, T, boxes, lines]
+        if gray is None:
+            for i in range(nb):
+                for k, m in enumerate(frame["maps"][i]):
+                    m = np.ascontiguousarray(m, np.float32); keep.append(m)
+                    arr[3 * i + k] = m.ctypes.data_as(C.POINTER(C.c_float))
+        else:
+            gray = np.ascontiguousarray(gray, np.uint8); keep.append(gray)
+        d = CsFrameDesc()
+        d.K, d.T_wc, d.img_w, d.img_h = _dp(K), _dp(T), int(frame["img_w"]), int(frame["img_h"])
+        d.boxes, d.n_boxes, d.lines, d.n_lines, d.dist_maps = _dp(boxes), nb, _dp(lines), lines.shape[0], arr
+        kmax = self.params.max_cuboid_num
+        out = (CsCuboid * max(1, nb * kmax))()
+        counts = np.zeros(max(1, nb), np.int32)
+        cp = counts.ctypes.data_as(C.POINTER(C.c_int))
+        L, h = lib(), self.h
+        gp = gray.ctypes.data_as(C.POINTER(C.c_ubyte)) if gray is not None else None
+
+        def call(parse=False):
+            rc = L.cs_detect_cuboids(h, C.byref(d), out, cp) if gp is None else L.cs_detect_cuboids_gray(h, C.byref(d), gp, out, cp)
+            if rc != 0:
+                raise RuntimeError("cs_detect_cuboids failed (%d): %s" % (rc, last_error()))
+            if parse:
+                return [[cuboid_to_dict(out[i * kmax + k]) for k in range(int(counts[i]))] for i in range(nb)]
+        call._keep = keep
+        return call
+
     def detect_gray(self, frame, gray):
         """cs_detect_cuboids_gray: image in, cuboids out (the frame's 'maps' are not used)."""
         gray = np.ascontiguousarray(gray, np.uint8)

@@ -375,6 +375,10 @@ struct cs_detector {
   hipEvent_t ev[12] = {};
   int n_threads = 1;
   std::unique_ptr<WorkerPool> pool;
+  // cs_detect_cuboids / cs_detect_cuboids_gray: one resident single-frame batch whose device and pinned buffers are reused from
+  // call to call (a batch built and torn down per frame spent most of the call in hipMalloc / hipFree)
+  cs_batch* single = nullptr;
+  std::mutex single_mu;
 };
 
 struct FrameIn {
@@ -458,6 +462,9 @@ struct cs_batch {
   cs_detector* det = nullptr;
   BatchRunState* run_state = nullptr;
   PinBuf<cs::RpPose> h_rp;
+  DevBuf<unsigned char> d_gray, d_cls;      // image input: gray images and Canny's class bytes (kept: a refilled batch reuses them)
+  DevBuf<cs::EdgeRoi> d_edge_rois;
+  PinBuf<float> h_maps_stage;               // map upload staging
   PipeSlot pipe[2];
   // capacity layout of the lean path's staging pools (from the inputs alone): first job / first box of a frame, first
   // merged-segment row of a frame's jobs, first top-edge sample of a box
@@ -622,6 +629,7 @@ int cs_detector_create(const cs_detect_params* params, int device, cs_detector**
 void cs_detector_destroy(cs_detector* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
+  if (d->single) { cs_batch_destroy(d->single); d->single = nullptr; }
   for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
   if (d->stream) (void)hipStreamDestroy(d->stream);
   if (d->stream2) (void)hipStreamDestroy(d->stream2);
@@ -630,15 +638,28 @@ void cs_detector_destroy(cs_detector* d) {
   delete d;
 }
 
+static int batch_fill(cs_detector* d, cs_batch* b, const cs_frame_desc* fr, const unsigned char* const* grays, int n_frames);
 static int batch_create_impl(cs_detector* d, const cs_frame_desc* fr, const unsigned char* const* grays, int n_frames, cs_batch** out) {
   if (!d || !out || (!fr && n_frames) || n_frames < 0) return CS_ERR_INVALID_ARG;
   *out = nullptr;
   CS_GUARD_BEGIN
   HIP_TRY(hipSetDevice(d->device));
   struct Guard { cs_batch* b; ~Guard() { if (b) cs_batch_destroy(b); } } g{new cs_batch()};   // freed on every early return
-  cs_batch* b = g.b;
-  b->det = d;
+  g.b->det = d;
+  int rc = batch_fill(d, g.b, fr, grays, n_frames);
+  if (rc) return rc;
+  *out = g.b;
+  g.b = nullptr;
+  return CS_OK;
+  CS_GUARD_END("cs_batch_create")
+}
+// (Re)describe the frames of a batch: host copies, ROIs, the map pool (uploaded, or produced in place from gray images), the
+// segment pool, the capacity layout.  Device and pinned buffers only ever grow, so refilling a batch with frames of a similar size --
+// the resident single-frame batch of cs_detect_cuboids -- allocates nothing.
+static int batch_fill(cs_detector* d, cs_batch* b, const cs_frame_desc* fr, const unsigned char* const* grays, int n_frames) {
   b->n_frames = n_frames;
+  b->max_boxes = 0;
+  b->ran = false;
   b->frames.resize(n_frames);
   size_t map_floats = 0;
   for (int f = 0; f < n_frames; f++) {
@@ -686,7 +707,13 @@ static int batch_create_impl(cs_detector* d, const cs_frame_desc* fr, const unsi
   if (rc) { return rc; }
   {
     if (!grays) {
-      std::vector<float> stage(map_floats + 1, 0.0f);
+      // small pools (a frame, a few frames) go through pinned staging kept by the batch and a queued copy; a large batch's pool is
+      // staged once in pageable memory and copied synchronously -- pinning gigabytes for a one-off upload costs more than it saves
+      const bool pinned = map_floats + 1 <= ((size_t)16 << 20);
+      std::vector<float> big;
+      float* stage = nullptr;
+      if (pinned) { rc = b->h_maps_stage.ensure(map_floats + 1); if (rc) return rc; stage = b->h_maps_stage.p; std::memset(stage, 0, sizeof(float) * (map_floats + 1)); }
+      else { big.assign(map_floats + 1, 0.0f); stage = big.data(); }
       for (int f = 0; f < n_frames; f++) {
         FrameIn& F = b->frames[f];
         for (int i = 0; i < F.n_boxes; i++)
@@ -695,7 +722,8 @@ static int batch_create_impl(cs_detector* d, const cs_frame_desc* fr, const unsi
             std::memcpy(&stage[F.map_offs[3 * i + k]], fr[f].dist_maps[3 * i + k], sizeof(float) * (size_t)r.width * r.height);
           }
       }
-      HIP_TRY(hipMemcpy(b->d_maps.p, stage.data(), sizeof(float) * (map_floats + 1), hipMemcpyHostToDevice));
+      if (pinned) HIP_TRY(hipMemcpyAsync(b->d_maps.p, stage, sizeof(float) * (map_floats + 1), hipMemcpyHostToDevice, d->stream));   // the sweep follows on the same stream
+      else HIP_TRY(hipMemcpy(b->d_maps.p, stage, sizeof(float) * (map_floats + 1), hipMemcpyHostToDevice));
     } else {
       // image in: upload the gray images, produce every job's map in place in the pool (Canny + distance transform on the
       // device, box_proposal_detail.cpp:320-327); the padding between the maps stays zero.  All frames share one size.
@@ -715,8 +743,8 @@ static int batch_create_impl(cs_detector* d, const cs_frame_desc* fr, const unsi
             max_w = std::max(max_w, r.width);
           }
       }
-      DevBuf<unsigned char> d_gray, d_cls;
-      DevBuf<cs::EdgeRoi> d_rois;
+      DevBuf<unsigned char>& d_gray = b->d_gray; DevBuf<unsigned char>& d_cls = b->d_cls;
+      DevBuf<cs::EdgeRoi>& d_rois = b->d_edge_rois;
       if ((rc = d_gray.ensure((size_t)W * H * std::max(1, n_frames))) || (rc = d_cls.ensure((size_t)cls_tot + 1)) || (rc = d_rois.ensure(er.size() + 1))) { return rc; }
       hipStream_t st = d->stream;
       HIP_TRY(hipMemsetAsync(b->d_maps.p, 0, sizeof(float) * (map_floats + 1), st));
@@ -726,8 +754,7 @@ static int batch_create_impl(cs_detector* d, const cs_frame_desc* fr, const unsi
         cs::launch_edge_maps(d_gray.p, W, H, d_rois.p, (int)er.size(), d_cls.p, b->d_maps.p, max_w, 80, 200, st);
         HIP_TRY(hipGetLastError());
       }
-      HIP_TRY(hipStreamSynchronize(st));
-      d_gray.release(); d_cls.release(); d_rois.release();
+      HIP_TRY(hipStreamSynchronize(st));      // (the host arrays `grays` and `er` are read by the copies above)
     }
     std::vector<double> ik(9 * (size_t)std::max(1, n_frames));
     for (int f = 0; f < n_frames; f++) std::memcpy(&ik[9 * f], b->frames[f].invK, 9 * sizeof(double));
@@ -765,10 +792,7 @@ static int batch_create_impl(cs_detector* d, const cs_frame_desc* fr, const unsi
       b->line_base[f + 1] = b->line_base[f] + (long long)nj * F.n_lines;
     }
   }
-  *out = b;
-  g.b = nullptr;
   return CS_OK;
-  CS_GUARD_END("cs_batch_create")
 }
 
 int cs_batch_create(cs_detector* d, const cs_frame_desc* fr, int n_frames, cs_batch** out) { return batch_create_impl(d, fr, nullptr, n_frames, out); }
@@ -792,6 +816,7 @@ void cs_batch_destroy(cs_batch* b) {
   b->d_yaw.release(); b->d_yaw_c.release(); b->d_yaw_s.release(); b->d_vp.release(); b->d_bound.release(); b->d_dist.release();
   b->d_angle.release(); b->d_skew.release(); b->d_corners.release(); b->d_c_dist.release(); b->d_c_angle.release();
   b->d_c_skew.release(); b->d_win_corners.release(); b->d_rp.release(); b->h_rp.release();
+  b->d_gray.release(); b->d_cls.release(); b->d_edge_rois.release(); b->h_maps_stage.release();
   b->h_stage.release(); b->h_c_slot.release(); b->h_job_cbase.release(); b->h_c_flag.release(); b->h_job_valid.release();
   b->h_c_dist.release(); b->h_c_angle.release(); b->h_c_skew.release(); b->h_win_corners.release();
   b->d_box_job0.release(); b->d_box_njobs.release(); b->d_win_count.release(); b->d_fallback.release(); b->d_winners.release(); b->d_last_slot.release(); b->h_last_slot.release();
@@ -2040,43 +2065,27 @@ int cs_edge_distance_maps(cs_detector* d, const unsigned char* gray, int img_w, 
   return cs_edge_distance_maps_multi(d, &gray, 1, img_w, img_h, rois, zero.data(), n_rois, out_maps, nullptr);
 }
 
+// One frame through the detector's resident single-frame batch (gray == nullptr: the frame's dist_maps are uploaded; else they are
+// produced on the device from the gray image, in place in the map pool).
+static int detect_single(cs_detector* d, const cs_frame_desc* frame, const unsigned char* gray, cs_cuboid* out, int* out_counts) {
+  if (!d || !frame || !out || !out_counts) return CS_ERR_INVALID_ARG;
+  CS_GUARD_BEGIN
+  std::lock_guard<std::mutex> lk(d->single_mu);
+  HIP_TRY(hipSetDevice(d->device));
+  if (!d->single) { d->single = new cs_batch(); d->single->det = d; }
+  int rc = batch_fill(d, d->single, frame, gray ? &gray : nullptr, 1);
+  if (rc) return rc;
+  return cs_batch_run(d, d->single, out, out_counts);
+  CS_GUARD_END("cs_detect_cuboids")
+}
 // image in, cuboids out: the frame's dist_maps are ignored and computed from the gray image on the device
 int cs_detect_cuboids_gray(cs_detector* d, const cs_frame_desc* frame, const unsigned char* gray, cs_cuboid* out, int* out_counts) {
-  if (!d || !frame || !gray || !out || !out_counts) return CS_ERR_INVALID_ARG;
-  const int n = frame->n_boxes;
-  if (n < 0 || (n && !frame->boxes)) return CS_ERR_INVALID_ARG;
-  for (int i = 0; i < n; i++)
-    if (!box_inside_image(frame->boxes + 5 * (size_t)i, frame->img_w, frame->img_h)) { set_err("2D box outside the image"); return CS_ERR_INVALID_ARG; }
-  CS_GUARD_BEGIN
-  std::vector<cs_roi> rois;
-  std::vector<int> first(n + 1, 0);
-  for (int i = 0; i < n; i++) {
-    cs_roi r3[3];
-    int nh = cs_box_rois(frame->boxes + 5 * i, frame->img_w, frame->img_h, d->prm.whether_sample_bbox_height, r3);
-    for (int k = 0; k < nh; k++) rois.push_back(r3[k]);
-    first[i + 1] = (int)rois.size();
-  }
-  std::vector<std::vector<float>> store(rois.size());
-  std::vector<float*> outp(rois.size());
-  for (size_t k = 0; k < rois.size(); k++) { store[k].assign((size_t)rois[k].width * rois[k].height, 0.f); outp[k] = store[k].data(); }
-  int rc = cs_edge_distance_maps(d, gray, frame->img_w, frame->img_h, rois.data(), (int)rois.size(), outp.data());
-  if (rc) return rc;
-  std::vector<const float*> maps(3 * (size_t)std::max(n, 1), nullptr);
-  for (int i = 0; i < n; i++) for (int k = first[i]; k < first[i + 1]; k++) maps[3 * i + (k - first[i])] = outp[k];
-  cs_frame_desc f2 = *frame;
-  f2.dist_maps = maps.data();
-  return cs_detect_cuboids(d, &f2, out, out_counts);
-  CS_GUARD_END("cs_detect_cuboids_gray")
+  if (!gray) return CS_ERR_INVALID_ARG;
+  return detect_single(d, frame, gray, out, out_counts);
 }
 
 int cs_detect_cuboids(cs_detector* d, const cs_frame_desc* frame, cs_cuboid* out, int* out_counts) {
-  if (!d || !frame || !out || !out_counts) return CS_ERR_INVALID_ARG;
-  cs_batch* b = nullptr;
-  int rc = cs_batch_create(d, frame, 1, &b);
-  if (rc) return rc;
-  rc = cs_batch_run(d, b, out, out_counts);
-  cs_batch_destroy(b);
-  return rc;
+  return detect_single(d, frame, nullptr, out, out_counts);
 }
 
 }  // extern "C"
