@@ -54,7 +54,7 @@ class CsDetectTiming(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("setup_host_ms", "h2d_ms", "vp_kernel_ms", "cand_kernel_ms", "compact_ms", "d2h_ms",
                                           "rank_host_ms", "finalize_ms", "total_ms")] + \
                [("n_jobs", C.c_longlong), ("n_slots", C.c_longlong), ("n_valid", C.c_longlong),
-                ("cand_kernel_bytes", C.c_longlong), ("cand_kernel_launches", C.c_int), ("n_fallback_boxes", C.c_int),
+                ("cand_kernel_bytes", C.c_longlong), ("cand_kernel_launches", C.c_int), ("n_fallback_boxes", C.c_int), ("n_redo_frames", C.c_int),
                 ("rank_kernel_ms", C.c_double), ("line_setup_ms", C.c_double), ("score_kernel_ms", C.c_double), ("score_kernel_bytes", C.c_longlong)]
 
 

@@ -49,7 +49,9 @@ void launch_scan_compact(const DetectDeviceView& v, hipStream_t st);
 void launch_score(const DetectDeviceView& v, const SweepParams& sp, long long n_valid_bound, long long slot_total, hipStream_t st);
 void launch_gather_corners(const DetectDeviceView& v, const SweepParams& sp, const long long* slots, int n, double* out, hipStream_t st);
 void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams& rp, hipStream_t st);
-void launch_records(const DetectDeviceView& v, const RankView& rv, int kmax, cs_cuboid* out, hipStream_t st);
+void launch_records(const DetectDeviceView& v, const RankView& rv, int kmax, cs_cuboid* out, hipStream_t st, const double* raw_euler = nullptr);
+void launch_rp_carry(const RpCarryView& c, JobDesc* jobs, hipStream_t st);
+void launch_rp_save_fallback(const DetectDeviceView& v, const RpSaveView& s, hipStream_t st);
 struct EdgeRoi { int l, t, w, h; long long img_off, cls_off, map_off; };
 void launch_edge_maps(const unsigned char* gray, int W, int H, const EdgeRoi* rois, int n_rois, unsigned char* cls_pool, float* map_pool, int max_w, int low, int high,
                       hipStream_t st);
@@ -427,6 +429,22 @@ struct PipeSlot {
   DevBuf<cs::RankWinner> winners;
   DevBuf<cs_cuboid> records;        // the winners' records of the device-ranked boxes (record_kernel)
   PinBuf<cs_cuboid> h_records;
+  // lean roll/pitch path (rp_launch / rp_finish): all rounds of the batch queued at once
+  struct RpRound { size_t j0 = 0, nj = 0, b0 = 0, nb = 0; long long slot_cap = 0; int vp_cap = 0; };
+  std::vector<RpRound> rp_rounds;
+  std::vector<int> rp_box_frame, rp_box_index;      // per box (all rounds): frame, box of the frame
+  DevBuf<int> rp_cur_idx, rp_tab_count, rp_maps;    // per frame: list in force; (frame, list) -> samples; per round: box / first job / jobs of a frame
+  DevBuf<long long> rp_last_slot, rp_box_base;
+  DevBuf<unsigned long long> rp_pool_used;
+  DevBuf<double> rp_raw_euler;
+  PinBuf<int> h_rp_tab_count, h_rp_maps;
+  PinBuf<double> h_rp_raw_euler;
+  PinBuf<long long> h_rp_last_slot, h_rp_box_base;
+  PinBuf<unsigned long long> h_rp_pool_used;
+  long long rp_pool_cap = 0;
+  int rp_NT = 0, rp_YCAP = 0;
+  std::vector<hipEvent_t> rp_ev;     // 5 per round: start, corners + compaction, VP support, scorer, ranking + records
+  bool rp_mode = false;
   PinBuf<cs::JobDesc> h_jobs_in, h_jobs_out;
   PinBuf<long long> h_slot_prefix, h_job_cbase;
   PinBuf<int> h_vp_prefix, h_top_x, h_box_job0, h_box_njobs, h_win_count, h_fallback, h_job_valid;
@@ -446,13 +464,15 @@ struct PipeSlot {
     vp_prefix.release(); top_x.release(); flag.release(); job_valid.release(); c_flag.release(); box_job0.release(); box_njobs.release(); win_count.release();
     fallback.release(); fb_cnt.release(); fb_flag.release(); mid_x.release(); mid_y.release(); ang.release(); yaw.release(); yaw_c.release(); yaw_s.release();
     vp.release(); bound.release(); bound3.release(); ls_order.release(); h_ls_order.release(); corners.release(); c_dist.release(); c_angle.release(); c_skew.release(); fb_dist.release(); fb_angle.release(); fb_skew.release();
-    win_corners.release(); winners.release(); records.release(); h_records.release(); h_jobs_in.release(); h_jobs_out.release(); h_slot_prefix.release(); h_job_cbase.release(); h_vp_prefix.release();
+    win_corners.release(); winners.release(); records.release(); h_records.release(); rp_cur_idx.release(); rp_tab_count.release(); rp_maps.release(); rp_last_slot.release(); rp_box_base.release(); rp_pool_used.release(); rp_raw_euler.release(); h_rp_tab_count.release(); h_rp_maps.release(); h_rp_raw_euler.release(); h_rp_last_slot.release(); h_rp_box_base.release(); h_rp_pool_used.release(); h_jobs_in.release(); h_jobs_out.release(); h_slot_prefix.release(); h_job_cbase.release(); h_vp_prefix.release();
     h_top_x.release(); h_box_job0.release(); h_box_njobs.release(); h_win_count.release(); h_fallback.release(); h_job_valid.release(); h_yaw.release();
     h_yaw_c.release(); h_yaw_s.release(); h_winners.release();
     h_fb_src.release(); h_fb_dst.release(); h_fb_slot.release(); h_win_slots.release(); h_fb_cnt.release(); h_fb_flag.release(); h_fb_dist.release(); h_fb_angle.release();
     h_fb_skew.release(); h_win_corners.release();
     if (done) (void)hipEventDestroy(done);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : rp_ev) if (e) (void)hipEventDestroy(e);
+    rp_ev.clear();
     done = nullptr; for (auto& e : ev) e = nullptr;
   }
 };
@@ -500,6 +520,7 @@ struct cs_batch {
   PinBuf<int> h_win_count, h_fallback;
   PinBuf<cs::JobDesc> h_jobs;
   bool force_host_rank = false;
+  bool force_round_path = false;   // roll/pitch sampling through the round-by-round path (the lean path's redo of frames with tie boxes)
   // state
   bool debug = false, ran = false;
   std::vector<JobResult> results;             // all jobs of the last run (index via job_index)
@@ -639,6 +660,9 @@ void cs_detector_destroy(cs_detector* d) {
 }
 
 static int batch_fill(cs_detector* d, cs_batch* b, const cs_frame_desc* fr, const unsigned char* const* grays, int n_frames);
+static int batch_layout(cs_detector* d, cs_batch* b);
+static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_counts, bool defer);
+static void release_batch_buffers(cs_batch* b);
 static int batch_create_impl(cs_detector* d, const cs_frame_desc* fr, const unsigned char* const* grays, int n_frames, cs_batch** out) {
   if (!d || !out || (!fr && n_frames) || n_frames < 0) return CS_ERR_INVALID_ARG;
   *out = nullptr;
@@ -756,6 +780,14 @@ static int batch_fill(cs_detector* d, cs_batch* b, const cs_frame_desc* fr, cons
       }
       HIP_TRY(hipStreamSynchronize(st));      // (the host arrays `grays` and `er` are read by the copies above)
     }
+  }
+  return batch_layout(d, b);
+}
+// Second half of describing a batch: per-frame invK, the pooled line segments, the capacity layout of the staging pools.
+static int batch_layout(cs_detector* d, cs_batch* b) {
+  const int n_frames = b->n_frames;
+  int rc;
+  {
     std::vector<double> ik(9 * (size_t)std::max(1, n_frames));
     for (int f = 0; f < n_frames; f++) std::memcpy(&ik[9 * f], b->frames[f].invK, 9 * sizeof(double));
     rc = b->d_invK.ensure(ik.size());
@@ -809,6 +841,10 @@ void cs_batch_destroy(cs_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->det->device);
   if (b->run_state) { (void)hipDeviceSynchronize(); batch_drop_run_state(b); }   // a submitted sweep that was never collected
+  release_batch_buffers(b);
+  delete b;
+}
+static void release_batch_buffers(cs_batch* b) {
   b->pipe[0].release(); b->pipe[1].release();
   b->d_maps.release(); b->d_invK.release(); b->d_frame_lines.release(); b->d_frame_line_ptr.release(); b->d_jobs.release(); b->d_slot_prefix.release(); b->d_job_cbase.release();
   b->d_c_slot.release(); b->d_win_slots.release(); b->d_vp_prefix.release(); b->d_top_x.release(); b->d_flag.release();
@@ -823,7 +859,6 @@ void cs_batch_destroy(cs_batch* b) {
   b->h_winners.release(); b->h_win_count.release(); b->h_fallback.release(); b->h_jobs.release();
   b->d_fb_src.release(); b->d_fb_dst.release(); b->d_fb_slot.release(); b->d_fb_cnt.release(); b->d_fb_flag.release();
   b->d_fb_dist.release(); b->d_fb_angle.release(); b->d_fb_skew.release();
-  delete b;
 }
 
 int cs_batch_set_debug(cs_batch* b, int enable) {
@@ -905,6 +940,7 @@ struct PipeCtx {
   cs_detector* d; cs_batch* b; cs_cuboid* out; int* out_counts;
   const std::vector<CamCache>* cam_raw; const std::vector<int>* rp_off;
   cs::SweepParams sp; cs_detect_timing* tm;
+  const std::vector<std::vector<CamCache>>* cam_rp_all = nullptr;
 };
 
 }  // namespace
@@ -916,6 +952,7 @@ struct BatchRunState {
   double t_begin = 0;
   PipeCtx C{};
   bool deferred = false;    // pipe_launch done, pipe_finish pending (cs_batch_collect)
+  bool rp_lean = false;     // ... of the lean roll/pitch path (rp_launch / rp_finish)
 };
 namespace {
 
@@ -1276,6 +1313,402 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
 #undef PENS
 #undef PH2D
 
+// ================================================================== lean roll/pitch path =========
+// whether_sample_cam_roll_pitch = 1 (the reference class's default; main_obj.cpp:623 uses it from the second frame on).  The boxes of a
+// frame depend on each other through cam_pose.camera_yaw (box_proposal_detail.cpp:180 reads what :374 / :734 left), so box r of
+// every frame forms round r.  The carried value is the camera yaw of one of the frame's RP roll/pitch samples (or the raw pose's before
+// the first box): the host lays down all 1 + RP yaw lists of every frame up front -- glibc's cos / sin, as everywhere -- and
+// rp_carry_kernel picks the list of the next round on the device.  All rounds are queued back to back; nothing comes back before the
+// last one.  Per round the kernels are those of the production path on the round's jobs (slot / vanishing-point numbering relative to
+// the round; slots laid out for the longest list a box can get).  A box whose ranking needs the exact host order (a tie that can
+// reach the output or the carried proposal) invalidates what the device assumed for the rest of its frame: those frames -- under one
+// in a hundred boxes -- are redone through the round-by-round path below, as a small batch that shares this one's distance maps.
+int rp_launch(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>>& cam_rp) {
+  cs_detector* d = C.d; cs_batch* b = C.b;
+  const cs_detect_params& P = d->prm;
+  hipStream_t st = d->stream;
+  const int KMAX = P.max_cuboid_num, NF = b->n_frames, MB = b->max_boxes;
+  double t0 = now_ms();
+  if (!S.done) { HIP_TRY(hipEventCreate(&S.done)); for (auto& e : S.ev) HIP_TRY(hipEventCreate(&e)); }
+  S.rp_mode = true;
+  S.f0 = 0; S.f1 = NF;
+  int rc;
+#define PENS(buf, n) do { rc = (buf).ensure(n); if (rc) return rc; } while (0)
+  // ---- yaw lists: NT = 1 + max RP per frame, YCAP samples each
+  int max_rp = 1;
+  for (int f = 0; f < NF; f++) max_rp = std::max(max_rp, (int)cam_rp[f].size());
+  const int NT = 1 + max_rp;
+  const int YCAP = (int)(2.0 * P.yaw_range_deg / std::max(1e-9, P.yaw_step_deg)) + 3;
+  const size_t n_yaw = (size_t)NF * NT * YCAP;
+  if (n_yaw > 0x7fffffffULL) { set_err("too many yaw samples"); return CS_ERR_CAPACITY; }
+  PENS(S.h_yaw, n_yaw + 1); PENS(S.h_yaw_c, n_yaw + 1); PENS(S.h_yaw_s, n_yaw + 1); PENS(S.h_rp_tab_count, (size_t)NF * NT + 1); PENS(S.h_rp_raw_euler, 3 * (size_t)NF + 1);
+  std::atomic<int> overflow{0};
+  std::vector<int> ycap_f(NF, 0);     // longest list of the frame: its boxes' slots are laid out for it
+  d->pool->run(NF * NT, [&](int z) {
+    const int f = z / NT, i = z % NT;
+    const int nrp = (int)cam_rp[f].size();
+    int* cnt = S.h_rp_tab_count.p + (size_t)f * NT + i;
+    *cnt = 0;
+    if (i > nrp) return;
+    const double cam_yaw = i == 0 ? (*C.cam_raw)[f].cam_yaw : cam_rp[f][i - 1].cam_yaw;
+    const double yaw_init = cam_yaw - 90.0 / 180.0 * CS_PI;
+    std::vector<double> yl;
+    linespace<double>(yaw_init - P.yaw_range_deg / 180.0 * CS_PI, yaw_init + P.yaw_range_deg / 180.0 * CS_PI, P.yaw_step_deg / 180.0 * CS_PI, yl);
+    if ((int)yl.size() > YCAP) { overflow = 1; return; }
+    double* yw = S.h_yaw.p + ((size_t)f * NT + i) * YCAP; double* yc = S.h_yaw_c.p + ((size_t)f * NT + i) * YCAP; double* ys = S.h_yaw_s.p + ((size_t)f * NT + i) * YCAP;
+    for (size_t y = 0; y < yl.size(); y++) { yw[y] = yl[y]; yc[y] = h_cos(yl[y]); ys[y] = h_sin(yl[y]); }
+    *cnt = (int)yl.size();
+  });
+  if (overflow) { set_err("yaw sample list exceeds its capacity"); return CS_ERR_CAPACITY; }
+  for (int f = 0; f < NF; f++) {
+    for (int i = 0; i < NT; i++) ycap_f[f] = std::max(ycap_f[f], S.h_rp_tab_count.p[(size_t)f * NT + i]);
+    for (int e = 0; e < 3; e++) S.h_rp_raw_euler.p[3 * f + e] = (*C.cam_raw)[f].euler[e];
+  }
+  // ---- jobs of all rounds: (round, frame, height sample); per round its own slot / vanishing-point numbering
+  const int tp0 = 0;
+  size_t nj_tot = 0, nb_tot = 0;
+  for (int f = 0; f < NF; f++) for (int bi = 0; bi < b->frames[f].n_boxes; bi++) nj_tot += b->frames[f].n_heights[bi];
+  const size_t n_top = (size_t)b->top_base[b->box_base[NF]];
+  PENS(S.h_jobs_in, nj_tot + 1); PENS(S.h_slot_prefix, nj_tot + MB + 1); PENS(S.h_vp_prefix, nj_tot + MB + 1); PENS(S.h_top_x, n_top + 1);
+  PENS(S.h_box_job0, nj_tot + 1); PENS(S.h_box_njobs, nj_tot + 1); PENS(S.h_ls_order, nj_tot + 1); PENS(S.h_rp_maps, 3 * (size_t)MB * NF + 1);
+  S.rp_rounds.assign(MB, PipeSlot::RpRound{});
+  S.rp_box_frame.clear(); S.rp_box_index.clear();
+  size_t ji = 0;
+  long long n_lines = 0, slot_cap_max = 0, slots_all = 0;
+  int vp_cap_max = 0;
+  size_t nj_round_max = 0;
+  for (int r = 0; r < MB; r++) {
+    PipeSlot::RpRound& Rr = S.rp_rounds[r];
+    Rr.j0 = ji; Rr.b0 = nb_tot;
+    long long so = 0, vo = 0;
+    int* box_of = S.h_rp_maps.p + (size_t)(3 * r) * NF; int* job0_of = box_of + NF; int* njobs_of = job0_of + NF;
+    for (int f = 0; f < NF; f++) {
+      box_of[f] = -1; job0_of[f] = -1; njobs_of[f] = 0;
+      const FrameIn& F = b->frames[f];
+      if (r >= F.n_boxes) continue;
+      const int bi = r;
+      const double* bb = &F.boxes[5 * bi];
+      const int left = bb[0], top = bb[1], w = bb[2], h = bb[3], right = left + bb[2];
+      const int res = (int)std::round(std::min(20, w / 10));
+      if (res < 1) continue;              // :215: the box is skipped and leaves the carried yaw alone
+      const int tb = b->top_base[b->box_base[f] + bi] - tp0, tcap = b->top_base[b->box_base[f] + bi + 1] - tp0 - tb;
+      int nT = 0;
+      int* tx = S.h_top_x.p + tb;
+      for (int x = left + 5; x <= right - 5 && nT < tcap; x += res) tx[nT++] = x;
+      const int nrp = (int)cam_rp[f].size();
+      box_of[f] = (int)(nb_tot - Rr.b0); job0_of[f] = (int)(ji - Rr.j0); njobs_of[f] = F.n_heights[bi];
+      S.h_box_job0.p[nb_tot] = (int)(ji - Rr.j0); S.h_box_njobs.p[nb_tot] = F.n_heights[bi];
+      S.rp_box_frame.push_back(f); S.rp_box_index.push_back(bi);
+      nb_tot++;
+      for (int k = 0; k < F.n_heights[bi]; k++) {
+        const cs_roi& roi = F.rois[3 * bi + k];
+        cs::JobDesc jd;
+        std::memset(&jd, 0, sizeof(jd));
+        const int he = h + roi.down_expand;
+        jd.g.left = left; jd.g.top = top; jd.g.right = right; jd.g.down = top + he;
+        jd.g.el = roi.left; jd.g.et = roi.top; jd.g.er = roi.left + roi.width; jd.g.eb = roi.top + roi.height;
+        jd.map_w = roi.width; jd.T = nT; jd.RP = nrp; jd.down_expand = roi.down_expand;
+        jd.Y = S.h_rp_tab_count.p[(size_t)f * NT];            // list 0 (the raw pose) until rp_carry_kernel says otherwise
+        jd.yaw_off = (int)(((size_t)f * NT) * YCAP);
+        jd.frame = f; jd.box = bi; jd.hid = k; jd.map_off = F.map_offs[3 * bi + k]; jd.rp_off = (*C.rp_off)[f];
+        jd.diag = std::sqrt(double(w * w + he * he));
+        jd.top_off = tb;
+        jd.line_off = (int)n_lines; n_lines += F.n_lines;
+        jd.slot_off = so; jd.vp_off = (int)vo;
+        S.h_slot_prefix.p[ji + r] = so; S.h_vp_prefix.p[ji + r] = (int)vo;
+        so += (long long)nrp * ycap_f[f] * nT * 2;
+        vo += ((long long)nrp * ycap_f[f] + 63) & ~63LL;
+        S.h_jobs_in.p[ji++] = jd;
+      }
+    }
+    Rr.nj = ji - Rr.j0; Rr.nb = nb_tot - Rr.b0; Rr.slot_cap = so; Rr.vp_cap = (int)vo;
+    S.h_slot_prefix.p[ji + r] = so; S.h_vp_prefix.p[ji + r] = (int)vo;
+    if (vo > 0x7fffffffLL || so > 0x7fffffff00LL) { set_err("too many samples in one round"); return CS_ERR_CAPACITY; }
+    slot_cap_max = std::max(slot_cap_max, so); vp_cap_max = std::max(vp_cap_max, (int)vo); nj_round_max = std::max(nj_round_max, Rr.nj);
+    slots_all += so;
+  }
+  const size_t nj = ji, nb = nb_tot;
+  S.nj = nj; S.nb = nb; S.slot_total = slots_all; S.vp_total = vp_cap_max;
+  if (n_lines > 0x7fffffffLL) { set_err("chunk too large"); return CS_ERR_CAPACITY; }
+  for (size_t j = 0; j < nj; j++) S.h_ls_order.p[j] = (int)j;
+  C.tm->setup_host_ms += now_ms() - t0;
+  C.tm->n_jobs += (long long)nj;
+  if (nj == 0) { S.in_flight = true; HIP_TRY(hipEventRecord(S.done, st)); return CS_OK; }
+  // ---- device buffers; the per-round arrays are sized for the largest round and reused from round to round (one stream: in order)
+  PENS(S.ls_order, nj); PENS(S.jobs, nj); PENS(S.slot_prefix, nj + MB + 1); PENS(S.vp_prefix, nj + MB + 1); PENS(S.job_valid, nj); PENS(S.job_cbase, nj + MB + 1);
+  PENS(S.mid_x, (size_t)n_lines + 1); PENS(S.mid_y, (size_t)n_lines + 1); PENS(S.ang, (size_t)n_lines + 1); PENS(S.yaw, n_yaw + 1); PENS(S.yaw_c, n_yaw + 1); PENS(S.yaw_s, n_yaw + 1);
+  PENS(S.top_x, n_top + 1); PENS(S.vp, 6 * (size_t)vp_cap_max + 6); PENS(S.bound, 6 * (size_t)vp_cap_max + 6); PENS(S.bound3, nj_round_max * (size_t)cs::vp3_table_doubles_per_job() + 1);
+  PENS(S.flag, slot_cap_max + 1); PENS(S.c_slot, slot_cap_max + 1); PENS(S.c_flag, slot_cap_max + 1); PENS(S.c_dist, slot_cap_max + 1); PENS(S.c_angle, slot_cap_max + 1); PENS(S.c_skew, slot_cap_max + 1);
+  PENS(S.box_job0, nb + 1); PENS(S.box_njobs, nb + 1); PENS(S.win_count, nb + 1); PENS(S.fallback, nb + 1); PENS(S.rp_last_slot, nb + 1);
+  PENS(S.winners, nb * KMAX + 1); PENS(S.records, nb * KMAX + 1); PENS(S.h_records, nb * KMAX + 1); PENS(S.h_win_count, nb + 1); PENS(S.h_fallback, nb + 1);
+  PENS(S.h_job_cbase, nj + MB + 1);
+  S.rp_NT = NT; S.rp_YCAP = YCAP;
+  S.rp_pool_cap = std::max<long long>(1 << 18, slots_all / 64);        // columns of the flagged boxes (about one box in a hundred)
+  PENS(S.fb_dist, (size_t)S.rp_pool_cap + 1); PENS(S.fb_angle, (size_t)S.rp_pool_cap + 1); PENS(S.fb_skew, (size_t)S.rp_pool_cap + 1); PENS(S.fb_flag, (size_t)S.rp_pool_cap + 1); PENS(S.fb_slot, (size_t)S.rp_pool_cap + 1);
+  PENS(S.rp_box_base, nb + 1); PENS(S.rp_pool_used, 1); PENS(S.h_rp_box_base, nb + 1); PENS(S.h_rp_pool_used, 1); PENS(S.h_rp_last_slot, nb + 1); PENS(S.h_job_valid, nj + 1); PENS(S.h_jobs_out, nj + 1);
+  HIP_TRY(hipMemsetAsync(S.rp_pool_used.p, 0, sizeof(unsigned long long), st));
+  PENS(S.rp_cur_idx, (size_t)NF + 1); PENS(S.rp_tab_count, (size_t)NF * NT + 1); PENS(S.rp_maps, 3 * (size_t)MB * NF + 1); PENS(S.rp_raw_euler, 3 * (size_t)NF + 1);
+#define PH2D(dst, src, n) HIP_TRY(hipMemcpyAsync((dst).p, (src).p, sizeof(*(src).p) * (n), hipMemcpyHostToDevice, st))
+  PH2D(S.ls_order, S.h_ls_order, nj); PH2D(S.jobs, S.h_jobs_in, nj); PH2D(S.slot_prefix, S.h_slot_prefix, nj + MB); PH2D(S.vp_prefix, S.h_vp_prefix, nj + MB);
+  PH2D(S.yaw, S.h_yaw, n_yaw); PH2D(S.yaw_c, S.h_yaw_c, n_yaw); PH2D(S.yaw_s, S.h_yaw_s, n_yaw);
+  if (n_top) PH2D(S.top_x, S.h_top_x, n_top);
+  PH2D(S.box_job0, S.h_box_job0, nb); PH2D(S.box_njobs, S.h_box_njobs, nb);
+  PH2D(S.rp_tab_count, S.h_rp_tab_count, (size_t)NF * NT); PH2D(S.rp_maps, S.h_rp_maps, 3 * (size_t)MB * NF); PH2D(S.rp_raw_euler, S.h_rp_raw_euler, 3 * (size_t)NF);
+  HIP_TRY(hipMemsetAsync(S.job_valid.p, 0, sizeof(int) * nj, st));
+  HIP_TRY(hipMemsetAsync(S.rp_cur_idx.p, 0, sizeof(int) * NF, st));
+  HIP_TRY(hipEventRecord(S.ev[0], st));
+  // ---- line setup of every job of the batch at once (it depends on the box and the frame's segments only)
+  cs::launch_line_setup(S.jobs.p, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st, S.ls_order.p,
+                        d->stream3, S.ev[0], S.ev[12]);
+  HIP_TRY(hipEventRecord(S.ev[1], st));
+  cs::RankParams rkp{P.weight_vp_angle, P.weight_skew_error, P.nominal_skew_ratio, P.max_cut_skew, KMAX, C.sp.short_sq_bound};
+  while (S.rp_ev.size() < 5 * (size_t)MB) { hipEvent_t e = nullptr; HIP_TRY(hipEventCreate(&e)); S.rp_ev.push_back(e); }
+  for (int r = 0; r < MB; r++) {
+    const PipeSlot::RpRound& Rr = S.rp_rounds[r];
+    if (Rr.nj == 0) continue;
+    hipEvent_t* re = &S.rp_ev[5 * (size_t)r];
+    cs::DetectDeviceView v{};
+    v.jobs = S.jobs.p + Rr.j0; v.n_jobs = (int)Rr.nj; v.slot_prefix = S.slot_prefix.p + Rr.j0 + r; v.vp_prefix = S.vp_prefix.p + Rr.j0 + r; v.maps = b->d_maps.p;
+    v.mid_x = S.mid_x.p; v.mid_y = S.mid_y.p; v.line_angle = S.ang.p; v.yaw = S.yaw.p; v.yaw_cos = S.yaw_c.p; v.yaw_sin = S.yaw_s.p; v.top_x = S.top_x.p;
+    v.rp = b->d_rp.p; v.invK = b->d_invK.p; v.vp = S.vp.p; v.bound = S.bound.p; v.bound3 = S.bound3.p; v.flag = S.flag.p; v.job_valid = S.job_valid.p + Rr.j0;
+    v.job_cbase = S.job_cbase.p + Rr.j0 + r; v.c_slot = S.c_slot.p; v.c_flag = S.c_flag.p; v.c_dist = S.c_dist.p; v.c_angle = S.c_angle.p; v.c_skew = S.c_skew.p;
+    if (r > 0) {      // the carried yaw: this round's jobs get the list the previous round's result selects
+      // (the previous round WITH jobs decides for the frames it held a box of; a frame without a box there keeps its list)
+      int rq = r - 1;
+      while (rq > 0 && S.rp_rounds[rq].nj == 0) rq--;
+      const PipeSlot::RpRound& Rq = S.rp_rounds[rq];
+      cs::RpCarryView c{};
+      c.n_frames = NF; c.NT = NT; c.YCAP = YCAP;
+      c.prev_box_of_frame = Rq.nj ? S.rp_maps.p + (size_t)(3 * rq) * NF : nullptr;
+      c.prev_last_slot = S.rp_last_slot.p + Rq.b0; c.prev_jobs = S.jobs.p + Rq.j0; c.prev_box_job0 = S.box_job0.p + Rq.b0; c.prev_box_njobs = S.box_njobs.p + Rq.b0;
+      c.job0_of_frame = S.rp_maps.p + (size_t)(3 * r + 1) * NF; c.njobs_of_frame = S.rp_maps.p + (size_t)(3 * r + 2) * NF;
+      c.tab_count = S.rp_tab_count.p; c.cur_idx = S.rp_cur_idx.p;
+      cs::launch_rp_carry(c, S.jobs.p + Rr.j0, st);
+    }
+    HIP_TRY(hipEventRecord(re[0], st));
+    cs::launch_vp_points(v, Rr.vp_cap, st);
+    cs::launch_candidates(v, C.sp, Rr.slot_cap, st);
+    cs::launch_scan_compact(v, st);
+    HIP_TRY(hipEventRecord(re[1], st));
+    cs::launch_vp_support_only(v, C.sp, Rr.vp_cap, st);
+    HIP_TRY(hipEventRecord(re[2], st));
+    cs::launch_score(v, C.sp, Rr.slot_cap, Rr.slot_cap, st);
+    HIP_TRY(hipEventRecord(re[3], st));
+    cs::RankView rv{};
+    rv.box_job0 = S.box_job0.p + Rr.b0; rv.box_njobs = S.box_njobs.p + Rr.b0; rv.n_boxes = (int)Rr.nb; rv.winners = S.winners.p + Rr.b0 * KMAX;
+    rv.win_count = S.win_count.p + Rr.b0; rv.fallback = S.fallback.p + Rr.b0; rv.last_slot = S.rp_last_slot.p + Rr.b0;
+    cs::launch_rank(v, rv, rkp, st);
+    cs::launch_records(v, rv, KMAX, S.records.p + Rr.b0 * KMAX, st, S.rp_raw_euler.p);
+    {   // the flagged boxes' columns, before the next round reuses the arrays
+      cs::RpSaveView sv{};
+      sv.fallback = rv.fallback; sv.box_job0 = rv.box_job0; sv.box_njobs = rv.box_njobs; sv.n_boxes = rv.n_boxes; sv.pool_used = S.rp_pool_used.p; sv.pool_cap = S.rp_pool_cap;
+      sv.box_base = S.rp_box_base.p + Rr.b0; sv.p_dist = S.fb_dist.p; sv.p_angle = S.fb_angle.p; sv.p_skew = S.fb_skew.p; sv.p_flag = S.fb_flag.p; sv.p_slot = S.fb_slot.p;
+      cs::launch_rp_save_fallback(v, sv, st);
+    }
+    HIP_TRY(hipEventRecord(re[4], st));
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(S.ev[6], st));
+  HIP_TRY(hipMemcpyAsync(S.h_records.p, S.records.p, sizeof(cs_cuboid) * nb * KMAX, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(S.h_win_count.p, S.win_count.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(S.h_fallback.p, S.fallback.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(S.h_job_cbase.p, S.job_cbase.p, sizeof(long long) * (nj + MB), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(S.h_job_valid.p, S.job_valid.p, sizeof(int) * nj, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(S.h_jobs_out.p, S.jobs.p, sizeof(cs::JobDesc) * nj, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(S.h_rp_last_slot.p, S.rp_last_slot.p, sizeof(long long) * nb, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(S.h_rp_box_base.p, S.rp_box_base.p, sizeof(long long) * nb, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(S.h_rp_pool_used.p, S.rp_pool_used.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipEventRecord(S.done, st));
+  S.in_flight = true;
+  return CS_OK;
+}
+
+int rp_finish(PipeCtx& C, PipeSlot& S) {
+  cs_detector* d = C.d; cs_batch* b = C.b;
+  const cs_detect_params& P = d->prm;
+  const int KMAX = P.max_cuboid_num, MB = b->max_boxes, NF = b->n_frames;
+  cs_detect_timing& tm = *C.tm;
+  double tw = now_ms();
+  HIP_TRY(hipEventSynchronize(S.done));
+  tm.d2h_ms += now_ms() - tw;
+  S.in_flight = false;
+  if (S.nj == 0) return CS_OK;
+  double t0 = now_ms();
+  {
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, S.ev[0], S.ev[1])); tm.line_setup_ms += ms;
+    for (int r = 0; r < MB; r++) {
+      if (S.rp_rounds[r].nj == 0) continue;
+      hipEvent_t* re = &S.rp_ev[5 * (size_t)r];
+      HIP_TRY(hipEventElapsedTime(&ms, re[0], re[1])); tm.cand_kernel_ms += ms;      // vanishing points, corners, compaction
+      HIP_TRY(hipEventElapsedTime(&ms, re[1], re[2])); tm.vp_kernel_ms += ms;
+      HIP_TRY(hipEventElapsedTime(&ms, re[2], re[3])); tm.score_kernel_ms += ms;
+      HIP_TRY(hipEventElapsedTime(&ms, re[3], re[4])); tm.rank_kernel_ms += ms;      // ranking, records, the flagged boxes' columns
+      tm.cand_kernel_launches += 1;
+    }
+    tm.n_slots += S.slot_total;
+    for (int r = 0; r < MB; r++) if (S.rp_rounds[r].nj) tm.n_valid += S.h_job_cbase.p[S.rp_rounds[r].j0 + r + S.rp_rounds[r].nj];
+  }
+  // ---- the flagged boxes: exact ranking on the host from their saved columns.  A frame is only redone when the exact ranking
+  // carries a different camera yaw to the frame's next box than the device assumed (or the columns did not fit the pool).
+  std::vector<char> redo(NF, 0);
+  std::vector<char> host_done(S.nb, 0);     // box written from the host ranking
+  int n_redo = 0;
+  size_t n_fb = 0;
+  for (size_t q = 0; q < S.nb; q++) n_fb += S.h_fallback.p[q] ? 1 : 0;
+  tm.n_fallback_boxes += (int)n_fb;
+  if (n_fb) {
+    hipStream_t st2 = d->stream_hi;
+    const size_t used = (size_t)std::min<unsigned long long>(*S.h_rp_pool_used.p, (unsigned long long)S.rp_pool_cap);
+    int rc;
+#define PENS(buf, n) do { rc = (buf).ensure(n); if (rc) return rc; } while (0)
+    PENS(S.h_fb_dist, used + 1); PENS(S.h_fb_angle, used + 1); PENS(S.h_fb_skew, used + 1); PENS(S.h_fb_flag, used + 1); PENS(S.h_fb_slot, used + 1);
+#undef PENS
+    if (used) {
+      HIP_TRY(hipMemcpyAsync(S.h_fb_dist.p, S.fb_dist.p, 8 * used, hipMemcpyDeviceToHost, st2));
+      HIP_TRY(hipMemcpyAsync(S.h_fb_angle.p, S.fb_angle.p, 8 * used, hipMemcpyDeviceToHost, st2));
+      HIP_TRY(hipMemcpyAsync(S.h_fb_skew.p, S.fb_skew.p, 8 * used, hipMemcpyDeviceToHost, st2));
+      HIP_TRY(hipMemcpyAsync(S.h_fb_flag.p, S.fb_flag.p, 4 * used, hipMemcpyDeviceToHost, st2));
+      HIP_TRY(hipMemcpyAsync(S.h_fb_slot.p, S.fb_slot.p, 8 * used, hipMemcpyDeviceToHost, st2));
+      HIP_TRY(hipStreamSynchronize(st2));
+    }
+    const std::vector<std::vector<CamCache>>& cam_rp = *C.cam_rp_all;
+    // boxes of a frame in round order
+    std::vector<std::vector<size_t>> boxes_of(NF);
+    for (size_t q = 0; q < S.nb; q++) boxes_of[S.rp_box_frame[q]].push_back(q);
+    auto carry_idx = [&](const cs::JobDesc& jl, long long last) { return last < 0 ? jl.RP : 1 + (int)((((last - jl.slot_off) >> 1) / jl.T) / jl.Y); };
+    std::vector<int> fb_frames;
+    for (int f = 0; f < NF; f++) { bool any = false; for (size_t q : boxes_of[f]) any = any || S.h_fallback.p[q]; if (any) fb_frames.push_back(f); }
+    d->pool->run((int)fb_frames.size(), [&](int z) {
+      const int f = fb_frames[z];
+      const FrameIn& F = b->frames[f];
+      for (size_t bq = 0; bq < boxes_of[f].size(); bq++) {
+        const size_t q = boxes_of[f][bq];
+        if (!S.h_fallback.p[q]) continue;
+        const long long base = S.h_rp_box_base.p[q];
+        if (base < 0) { redo[f] = 1; return; }
+        // which round the box belongs to: its jobs are relative to that round's first job
+        size_t r = 0;
+        while (r + 1 < S.rp_rounds.size() && q >= S.rp_rounds[r + 1].b0) r++;
+        const cs::JobDesc* jobs = S.h_jobs_out.p + S.rp_rounds[r].j0;
+        const int* jvalid = S.h_job_valid.p + S.rp_rounds[r].j0;
+        const int j0 = S.h_box_job0.p[q], nh = S.h_box_njobs.p[q], bi = S.rp_box_index[q];
+        struct HP { int h, cand; double score, skew; };
+        std::vector<HP> props;
+        std::vector<long long> p0(nh);
+        long long run = base, exact_last = -1;
+        for (int h = 0; h < nh; h++) {
+          const int V = jvalid[j0 + h];
+          p0[h] = run; run += V;
+          std::vector<int> keep;
+          std::vector<double> score;
+          fuse_scores(S.h_fb_dist.p + p0[h], S.h_fb_angle.p + p0[h], V, P.weight_vp_angle, keep, score);
+          if (h == nh - 1) exact_last = keep.empty() ? -1 : S.h_fb_slot.p[p0[h] + keep.back()];
+          for (size_t k = 0; k < keep.size(); k++) {
+            if (S.h_fb_flag.p[p0[h] + keep[k]] & cs::CAND_NEG_SCALE) continue;
+            props.push_back(HP{h, keep[k], score[k], S.h_fb_skew.p[p0[h] + keep[k]]});
+          }
+        }
+        const int n = (int)props.size(), kk = std::min(KMAX, n);
+        std::vector<double> comb(n);
+        for (int i = 0; i < n; i++) {
+          double skew_error = P.weight_skew_error * std::max(props[i].skew - P.nominal_skew_ratio, 0.0);
+          if (props[i].skew > P.max_cut_skew) skew_error = 100;
+          comb[i] = props[i].score + P.weight_skew_error * skew_error;
+        }
+        std::vector<int> idx(n);
+        std::iota(idx.begin(), idx.end(), 0);
+        std::partial_sort(idx.begin(), idx.begin() + kk, idx.end(), [&comb](int a, int c) { return comb[a] < comb[c]; });
+        const double* bb = &F.boxes[5 * bi];
+        for (int w = 0; w < kk; w++) {
+          const HP& hp = props[idx[w]];
+          const cs::JobDesc& jd = jobs[j0 + hp.h];
+          const long long slot = S.h_fb_slot.p[p0[hp.h] + hp.cand];
+          const long long local = slot - jd.slot_off, rest = local >> 1;
+          const int t = (int)(rest % jd.T), ry = (int)(rest / jd.T), rp = ry / jd.Y, y = ry - rp * jd.Y;
+          // the winner's corners: the vanishing points (vp_points_kernel's arithmetic) and build_corners, on the host
+          const double* A = cam_rp[f][rp].pose.KinvR;
+          const double cy = S.h_yaw_c.p[jd.yaw_off + y], sy = S.h_yaw_s.p[jd.yaw_off + y];
+          const double dd[3][3] = {{cy, sy, 0.0}, {-sy, cy, 0.0}, {0.0, 0.0, 1.0}};
+          cs::V2 vp[3];
+          for (int k = 0; k < 3; k++) {
+            const double h0 = (A[0] * dd[k][0] + A[1] * dd[k][1]) + A[2] * dd[k][2];
+            const double h1 = (A[3] * dd[k][0] + A[4] * dd[k][1]) + A[5] * dd[k][2];
+            const double h2 = (A[6] * dd[k][0] + A[7] * dd[k][1]) + A[8] * dd[k][2];
+            vp[k] = cs::v2(h0 / h2, h1 / h2);
+          }
+          cs::V2 c8[8];
+          for (auto& c : c8) c = cs::v2(0.0, 0.0);
+          (void)cs::build_corners(jd.g, vp[0], vp[1], vp[2], (double)S.h_top_x.p[jd.top_off + t], (int)(local & 1) + 1, C.sp.short_sq_bound, c8);
+          double c16[16];
+          for (int k = 0; k < 8; k++) { c16[k] = c8[k].x; c16[8 + k] = c8[k].y; }
+          double r9[9] = {(double)((local & 1) + 1), (double)(S.h_fb_flag.p[p0[hp.h] + hp.cand] & cs::CAND_VP_MASK), S.h_yaw.p[jd.yaw_off + y], (double)t,
+                          S.h_fb_dist.p[p0[hp.h] + hp.cand], S.h_fb_angle.p[p0[hp.h] + hp.cand], (double)jd.down_expand, cam_rp[f][rp].pose.roll, cam_rp[f][rp].pose.pitch};
+          cs_cuboid& o = C.out[((size_t)f * MB + bi) * KMAX + w];
+          finish_cuboid(F, cam_rp[f][rp].pose, r9, c16, (*C.cam_raw)[f].euler, true, hp.score, o);
+          o.rect_detect_2d[0] = (int)bb[0]; o.rect_detect_2d[1] = (int)bb[1]; o.rect_detect_2d[2] = (int)bb[2]; o.rect_detect_2d[3] = (int)bb[3];
+        }
+        C.out_counts[(size_t)f * MB + bi] = kk;
+        host_done[q] = 1;
+        // does the frame's next box start from the yaw the device assumed?
+        const cs::JobDesc& jl = jobs[j0 + nh - 1];
+        if (bq + 1 < boxes_of[f].size() && carry_idx(jl, exact_last) != carry_idx(jl, S.h_rp_last_slot.p[q])) { redo[f] = 1; return; }
+      }
+    });
+    for (int f = 0; f < NF; f++) n_redo += redo[f] ? 1 : 0;
+  }
+  constexpr int RCH = 256;
+  const int nch = ((int)S.nb + RCH - 1) / RCH;
+  d->pool->run(nch, [&](int z) {
+    for (size_t q = (size_t)z * RCH, q1 = std::min(S.nb, q + RCH); q < q1; q++) {
+      const int f = S.rp_box_frame[q], bi = S.rp_box_index[q];
+      if (redo[f] || host_done[q]) continue;
+      const int nw = S.h_win_count.p[q];
+      const double* bb = &b->frames[f].boxes[5 * bi];
+      for (int r = 0; r < nw; r++) {
+        cs_cuboid& o = C.out[((size_t)f * MB + bi) * KMAX + r];
+        o = S.h_records.p[q * KMAX + r];
+        o.rect_detect_2d[0] = (int)bb[0]; o.rect_detect_2d[1] = (int)bb[1]; o.rect_detect_2d[2] = (int)bb[2]; o.rect_detect_2d[3] = (int)bb[3];
+      }
+      C.out_counts[(size_t)f * MB + bi] = nw;
+    }
+  });
+  if (n_redo) {
+    // a small batch of those frames, sharing this batch's map pool (same offsets), through the round-by-round path
+    cs_batch sub;
+    sub.det = d;
+    sub.force_round_path = true;
+    std::vector<int> ids;
+    for (int f = 0; f < NF; f++) if (redo[f]) ids.push_back(f);
+    sub.n_frames = (int)ids.size();
+    sub.frames.resize(ids.size());
+    sub.max_boxes = 0;
+    for (size_t z = 0; z < ids.size(); z++) { sub.frames[z] = b->frames[ids[z]]; sub.max_boxes = std::max(sub.max_boxes, sub.frames[z].n_boxes); }
+    sub.d_maps.p = b->d_maps.p; sub.d_maps.cap = b->d_maps.cap;           // borrowed
+    struct Unborrow { cs_batch* s; ~Unborrow() { s->d_maps.p = nullptr; s->d_maps.cap = 0; release_batch_buffers(s); } } ub{&sub};
+    int rc = batch_layout(d, &sub);
+    if (rc) return rc;
+    const int MBs = sub.max_boxes;
+    std::vector<cs_cuboid> o2((size_t)ids.size() * std::max(1, MBs) * KMAX);
+    std::vector<int> c2((size_t)ids.size() * std::max(1, MBs), 0);
+    rc = batch_run_impl(d, &sub, o2.data(), c2.data(), false);
+    if (rc) return rc;
+    for (size_t z = 0; z < ids.size(); z++) {
+      const int f = ids[z];
+      for (int bi = 0; bi < b->frames[f].n_boxes; bi++) {
+        const int nw = c2[z * MBs + bi];
+        for (int r = 0; r < nw; r++) C.out[((size_t)f * MB + bi) * KMAX + r] = o2[(z * MBs + bi) * KMAX + r];
+        C.out_counts[(size_t)f * MB + bi] = nw;
+      }
+    }
+    tm.n_redo_frames += n_redo;
+  }
+  tm.finalize_ms += now_ms() - t0;
+  return CS_OK;
+}
+#undef PENS
+#undef PH2D
+
 }  // namespace
 
 extern "C" int cs_batch_set_pipeline_chunks(cs_batch* b, int n_chunks) {
@@ -1312,7 +1745,7 @@ static int batch_collect_impl(cs_detector* d, cs_batch* b) {
   b->run_state = nullptr;
   if (!rs->deferred) return CS_OK;
   HIP_TRY(hipSetDevice(d->device));
-  int rc = pipe_finish(rs->C, b->pipe[0], rs->cam_rp);
+  int rc = rs->rp_lean ? rp_finish(rs->C, b->pipe[0]) : pipe_finish(rs->C, b->pipe[0], rs->cam_rp);
   if (rc) return rc;
   rs->tm.total_ms = now_ms() - rs->t_begin;
   b->timing = rs->tm;
@@ -1431,6 +1864,21 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
     return CS_OK;
   }
 
+  // ---- roll/pitch sampling, lean path: every round queued at once, the carried yaw picked on the device
+  {
+    int max_rp = 0;
+    for (int f = 0; f < NF; f++) max_rp = std::max(max_rp, (int)cam_rp[f].size());
+    static const bool rp_rounds_forced = getenv("CS_DETECT_RP_ROUNDS") != nullptr;   // diagnostics: always the round-by-round path
+    if (sample_rp && !b->debug && !b->force_host_rank && !b->force_host_setup && !b->force_no_pipeline && !b->force_round_path && !rp_rounds_forced && b->device_setup &&
+        KMAX <= cs::RANK_KMAX && MB > 0 && max_rp <= cs::vp3_table_doubles_per_job() / 2) {
+      rs->C = PipeCtx{d, b, out, out_counts, &rs->cam_raw, &rs->rp_off, sp, &rs->tm, &rs->cam_rp};
+      int rc = rp_launch(rs->C, b->pipe[0], rs->cam_rp);
+      if (rc) return rc;
+      rs->deferred = true; rs->rp_lean = true;
+      b->run_state = rs_owner.release();
+      return defer ? CS_OK : batch_collect_impl(d, b);
+    }
+  }
   // proposals per (frame, box) accumulate over height samples inside a round
   std::vector<Winner> winners;
   const int n_rounds = sample_rp ? MB : (MB > 0 ? 1 : 0);

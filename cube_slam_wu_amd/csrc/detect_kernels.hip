@@ -371,6 +371,9 @@ __device__ __forceinline__ int candidate_one(const DetectDeviceView& v, const Sw
   // (a job's slot count fits 32 bits: checked when the batch is laid out)
   const unsigned k = (unsigned)(tid - jd.slot_off);
   const unsigned half = (unsigned)jd.RP * (unsigned)jd.Y * (unsigned)jd.T;
+  // (the lean roll/pitch path lays a job's slots out for the longest yaw list the box can get; the list in force may be a sample
+  // shorter, and the slots behind the job's 2 * half proposals are empty)
+  if (k >= 2 * half) { v.flag[tid] = 0; return 0; }
   const int cfg = (k >= half) ? 2 : 1;
   const unsigned rest = (k >= half) ? k - half : k;
   const unsigned ryu = rest / (unsigned)jd.T;      // rp * Y + yaw
@@ -1191,7 +1194,7 @@ int line_setup_capacity() { return LS_CAP; }
 // compute3D_BoxCorner (:59-73) with similarityTransformation (:15-44).  cos / sin of the yaw come from the sample tables the host
 // filled with glibc's values (the same calls the host-side record writer makes), so every field carries the host writer's bits.
 // rect_detect_2d is the caller's box and is filled in by the host when it copies the record out.
-__global__ __launch_bounds__(64) void record_kernel(DetectDeviceView v, RankView rv, int kmax, cs_cuboid* __restrict__ out) {
+__global__ __launch_bounds__(64) void record_kernel(DetectDeviceView v, RankView rv, int kmax, cs_cuboid* __restrict__ out, const double* __restrict__ raw_euler) {
   const int e = blockIdx.x * 64 + threadIdx.x;
   if (e >= rv.n_boxes * kmax) return;
   const int q = e / kmax, r = e - q * kmax;
@@ -1202,8 +1205,8 @@ __global__ __launch_bounds__(64) void record_kernel(DetectDeviceView v, RankView
   while (h + 1 < nh && w.slot >= v.jobs[j0 + h + 1].slot_off) h++;
   const JobDesc& jd = v.jobs[j0 + h];
   const long long local = w.slot - jd.slot_off, rest = local >> 1;
-  const int y = (int)(rest / jd.T);
-  const RpPose& pose = v.rp[jd.rp_off];
+  const int ry = (int)(rest / jd.T), rp = ry / jd.Y, y = ry - rp * jd.Y;   // (roll/pitch sample, yaw sample)
+  const RpPose& pose = v.rp[jd.rp_off + rp];
   cs_cuboid o;
   {
     double* z = reinterpret_cast<double*>(&o);
@@ -1254,6 +1257,10 @@ __global__ __launch_bounds__(64) void record_kernel(DetectDeviceView v, RankView
   o.normalized_error = w.normalized_error;
   o.skew_ratio = ((o.scale[0] < o.scale[1]) ? o.scale[1] : o.scale[0]) / ((o.scale[1] < o.scale[0]) ? o.scale[1] : o.scale[0]);   // std::max / std::min
   o.down_expand_height = (double)jd.down_expand;
+  if (raw_euler) {   // roll/pitch sampling: the sample's angles against the frame's own camera pose (box_proposal_detail.cpp:686, :790-791)
+    o.camera_roll_delta = pose.roll - raw_euler[3 * jd.frame];
+    o.camera_pitch_delta = pose.pitch - raw_euler[3 * jd.frame + 1];
+  }
   out[e] = o;
 }
 
@@ -1316,11 +1323,68 @@ void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams
   if (rv.n_boxes <= 0) return;
   hipLaunchKernelGGL(rank_kernel, dim3(rv.n_boxes), dim3(256), 0, st, v, rv, rp);
 }
-void launch_records(const DetectDeviceView& v, const RankView& rv, int kmax, cs_cuboid* out, hipStream_t st) {
+void launch_records(const DetectDeviceView& v, const RankView& rv, int kmax, cs_cuboid* out, hipStream_t st, const double* raw_euler) {
   if (skip_kernel("records")) return;
   const int n = rv.n_boxes * kmax;
   if (n <= 0) return;
-  hipLaunchKernelGGL(record_kernel, dim3((n + 63) / 64), dim3(64), 0, st, v, rv, kmax, out);
+  hipLaunchKernelGGL(record_kernel, dim3((n + 63) / 64), dim3(64), 0, st, v, rv, kmax, out, raw_euler);
+}
+// ---- roll/pitch sampling on the device: the camera yaw carried from box to box ----------------------------------------------
+// With whether_sample_cam_roll_pitch the yaw list of a box starts from cam_pose.camera_yaw as the previous box of the frame left it
+// (box_proposal_detail.cpp:180 reads what :374 / :734 wrote): the camera yaw of the roll/pitch sample of the last proposal that
+// box's ranking kept, or -- nothing kept -- of the sweep's last sample.  That value is one of 1 + RP numbers known up front (the raw
+// camera yaw, the RP samples' yaws), so the host lays down all 1 + RP yaw lists of a frame (with glibc's cos / sin) and the device
+// only picks: one lane per frame reads the previous round's last kept proposal of the frame's box, moves the frame's table index,
+// and points this round's jobs of the frame at that list.  The rounds then follow each other on the stream without a host decision.
+__global__ __launch_bounds__(64) void rp_carry_kernel(RpCarryView c, JobDesc* jobs) {
+  const int f = blockIdx.x * 64 + threadIdx.x;
+  if (f >= c.n_frames) return;
+  int idx = c.cur_idx[f];
+  const int q = c.prev_box_of_frame ? c.prev_box_of_frame[f] : -1;
+  if (q >= 0) {
+    const JobDesc& jl = c.prev_jobs[c.prev_box_job0[q] + c.prev_box_njobs[q] - 1];
+    const long long last = c.prev_last_slot[q];
+    idx = last < 0 ? jl.RP : 1 + (int)((((last - jl.slot_off) >> 1) / jl.T) / jl.Y);
+    c.cur_idx[f] = idx;
+  }
+  const int j0 = c.job0_of_frame[f];
+  if (j0 < 0) return;
+  for (int h = 0; h < c.njobs_of_frame[f]; h++) {
+    jobs[j0 + h].yaw_off = (f * c.NT + idx) * c.YCAP;
+    jobs[j0 + h].Y = c.tab_count[f * c.NT + idx];
+  }
+}
+__global__ __launch_bounds__(256) void rp_save_fallback_kernel(DetectDeviceView v, RpSaveView s) {
+  const int q = blockIdx.x;
+  if (q >= s.n_boxes) return;
+  __shared__ long long base_s;
+  if (!s.fallback[q]) { if (threadIdx.x == 0) s.box_base[q] = -1; return; }
+  const int j0 = s.box_job0[q], nh = s.box_njobs[q];
+  if (threadIdx.x == 0) {
+    long long V = 0;
+    for (int h = 0; h < nh; h++) V += v.job_valid[j0 + h];
+    const long long base = (long long)atomicAdd(s.pool_used, (unsigned long long)V);
+    base_s = (base + V <= s.pool_cap) ? base : -1;
+    s.box_base[q] = base_s;
+  }
+  __syncthreads();
+  long long dst = base_s;
+  if (dst < 0) return;
+  for (int h = 0; h < nh; h++) {
+    const long long c0 = v.job_cbase[j0 + h];
+    const int V = v.job_valid[j0 + h];
+    for (int i = threadIdx.x; i < V; i += 256) {
+      s.p_dist[dst + i] = v.c_dist[c0 + i]; s.p_angle[dst + i] = v.c_angle[c0 + i]; s.p_skew[dst + i] = v.c_skew[c0 + i];
+      s.p_flag[dst + i] = v.c_flag[c0 + i]; s.p_slot[dst + i] = v.c_slot[c0 + i];
+    }
+    dst += V;
+  }
+}
+void launch_rp_save_fallback(const DetectDeviceView& v, const RpSaveView& s, hipStream_t st) {
+  if (s.n_boxes > 0) hipLaunchKernelGGL(rp_save_fallback_kernel, dim3(s.n_boxes), dim3(256), 0, st, v, s);
+}
+void launch_rp_carry(const RpCarryView& c, JobDesc* jobs, hipStream_t st) {
+  if (c.n_frames > 0) hipLaunchKernelGGL(rp_carry_kernel, dim3((c.n_frames + 63) / 64), dim3(64), 0, st, c, jobs);
 }
 void launch_gather_corners(const DetectDeviceView& v, const SweepParams& sp, const long long* slots, int n, double* out, hipStream_t st) {
   if (n <= 0) return;

@@ -97,4 +97,23 @@ struct RankView {
                          // (-1 = none) -- with roll/pitch sampling the next box of the frame starts from that proposal's camera yaw
 };
 
+// Lean roll/pitch path: the compacted columns of the boxes the ranking flagged (a tie that can reach the output or the carried
+// proposal) are copied to a side pool before the next round reuses the per-round arrays; the host ranks them exactly afterwards.
+struct RpSaveView {
+  const int* fallback; const int* box_job0; const int* box_njobs; int n_boxes;
+  unsigned long long* pool_used; long long pool_cap;
+  long long* box_base;             // per box of the round: first pool entry, -1 = not saved (not flagged, or the pool is full)
+  double* p_dist; double* p_angle; double* p_skew; int* p_flag; long long* p_slot;
+};
+
+struct RpCarryView {
+  int n_frames, NT, YCAP;
+  const int* prev_box_of_frame;     // [n_frames] box (index into the previous round's boxes) or -1
+  const long long* prev_last_slot;  // previous round, per box
+  const JobDesc* prev_jobs; const int* prev_box_job0; const int* prev_box_njobs;
+  const int* job0_of_frame; const int* njobs_of_frame;   // this round: first job of the frame (-1: none), its height samples
+  const int* tab_count;             // [n_frames * NT] yaw samples of list i of frame f
+  int* cur_idx;                     // [n_frames] list in force
+};
+
 }  // namespace cs

@@ -180,6 +180,7 @@ typedef struct cs_detect_timing {
   long long cand_kernel_bytes;       /* algorithmic bytes of the candidate kernel     */
   int cand_kernel_launches;
   int n_fallback_boxes;              /* boxes whose ranking hit a tie and was redone on the host  */
+  int n_redo_frames;                 /* roll/pitch sampling, lean path: frames redone round by round because of such a box */
   double rank_kernel_ms;
   double line_setup_ms;              /* line_setup_kernel (ROI filter + merge_break_lines on the device)  */
   double score_kernel_ms;            /* score_kernel: distance + angle errors of the valid proposals       */
