@@ -21,7 +21,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_FLOP_PER_PROPOSAL = 1400.0
+FP64_FLOP_PER_PROPOSAL = 1700.0   # 88 map samples x 6, six cs_atan2 (light path ~90 each), the 3D lift; + ~300 for the corners the scorer now rebuilds (13 squared lengths, 6 line intersections, 3 ray hits)
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak = half the FP32 vector peak of MI355X_MICROARCH.md (157.3)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -583,9 +583,9 @@ def main():
                        "proposal_slots_per_frame": acc["n_slots"] / args.steps / args.frames,
                        "valid_proposals_per_frame": acc["n_valid"] / args.steps / args.frames, "parallelism": "frames sharded, no collective"},
             "roofline": {"kernel": "score_kernel", "bound": "hbm",
-                         # what the SQ counters say the kernel waits for (profiles/r1j_detect_sq_counters.csv): ~3.8 k FP64 VALU instructions per
-                         # proposal at 52 % VALU-busy, 45 % of the wave cycles parked on the 77-99 scattered map samples; its HBM traffic
-                         # equals its algorithmic bytes.  Staging the map in LDS (one workgroup per job) was measured and lost: 1.63 vs 1.22 ms.
+                         # what the SQ counters say the kernel waits for (profiles/r2u_detect_sq_counters.csv + the corner rebuild of round 3):
+                         # ~3.4 k FP64 VALU instructions per proposal at ~55 % VALU-busy, the rest parked on the 77-99 scattered map samples;
+                         # its HBM traffic is below its algorithmic bytes.  Staging the map in LDS (one workgroup per job) was measured and lost.
                          "limiter": "fp64 VALU issue + gather latency (HBM traffic = algorithmic bytes)",
                          "traffic_correction": "FETCH_SIZE x 2 + WRITE_SIZE x 1: measured on known byte counts for 4/8/16-byte coalesced, 8-byte strided and 4-byte gather patterns (profiles/r2_pmc_calibration.json)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -595,7 +595,7 @@ def main():
                          "timed_region": {"event_ms_per_launch": timed_ms, "achieved": alg_bytes / (timed_ms * 1e-3) / 1e9 if timed_ms > 0 else 0.0,
                                           "frac": alg_bytes / (timed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if timed_ms > 0 else 0.0, "batches_in_flight": inflight},
                          # the per-proposal math is FP64 vector ALU -- both fractions, the larger one names the bound.
-                         # ~1400 FP64 flop per valid proposal: 88 map samples x 6, six cs_atan2 (light path ~90) + comparisons, the 3D lift
+                         # ~1700 FP64 flop per valid proposal (FP64_FLOP_PER_PROPOSAL above)
                          "fp64_alu": {"flop_per_valid_proposal": FP64_FLOP_PER_PROPOSAL, "achieved": FP64_FLOP_PER_PROPOSAL * (acc["n_valid"] / launches) / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0,
                                       "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": FP64_FLOP_PER_PROPOSAL * (acc["n_valid"] / launches) / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS if kern_ms > 0 else 0.0},
