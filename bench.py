@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--rp-frames", type=int, default=100, help="frames of the roll/pitch-sampling stress variant (RP = 25 poses per box, the reference's class default); 0 = skip")
     ap.add_argument("--rp-inflight", type=int, default=4, help="batches in flight of the roll/pitch-sampling stress variant")
     ap.add_argument("--latency-calls", type=int, default=200, help="calls per entry point of the single-call latency report (0 = skip)")
-    ap.add_argument("--depth", type=int, default=1, help="batches per pipeline: the next one is submitted (packed + queued) before the current one is collected")
+    ap.add_argument("--depth", type=int, default=2, help="batches per pipeline: the next one is submitted (packed + queued) before the current one is collected")
     ap.add_argument("--steady-steps", type=int, default=200, help="steps of the steady-state measurement reported beside the contract run (0 = skip)")
     ap.add_argument("--inflight", type=int, default=4, help="batches in flight per GPU: each has its own detector (streams, worker pool) and is driven by its own host thread, "
                     "so one batch's host stages (packing, record writing) overlap the other's sweep on the device")

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <string>
 #include <mutex>
@@ -91,6 +92,13 @@ template <class T>
 struct DBuf {
   T* p = nullptr;
   size_t n = 0;
+  int upload_ptr(const T* h, size_t count) {   // from the caller's memory
+    if (p) { (void)hipFree(p); p = nullptr; }
+    n = count;
+    BA_TRY(hipMalloc((void**)&p, std::max<size_t>(1, n) * sizeof(T)));
+    if (n) BA_TRY(hipMemcpy(p, h, n * sizeof(T), hipMemcpyHostToDevice));
+    return CS_OK;
+  }
   int upload(const std::vector<T>& h) {
     if (p) { (void)hipFree(p); p = nullptr; }
     n = h.size();
@@ -188,7 +196,11 @@ struct cs_ba {
   int n_pairs = 0, nb_chi = 1, n_chi_partials = 1;
   long long schur_entries = 0;
   // raw edge payloads kept until finalisation
-  std::vector<double> h_uv, h_info, h_intr, h_huber, h_ce_meas, h_ce_info, h_oe_meas, h_oe_info;
+  std::vector<double> h_ce_meas, h_ce_info, h_oe_meas, h_oe_info;
+  // the projection edges' payload (88 bytes per edge) goes straight to the device when the edges are set, in the caller's order;
+  // the structure phase permutes it there (ba_gather_rows_kernel)
+  DBuf<double> raw_uv, raw_info, raw_intr, raw_huber;
+  bool have_huber = false;
   // last solution / rhs on the host (for LM's scale term and for inspection)
   std::vector<double> h_b, h_x;
   bool have_system = false;
@@ -198,6 +210,26 @@ struct cs_ba {
 
 
 namespace {
+
+// std::sort on chunks in a few host threads, then pairwise merges (the structure phase's large sorts)
+template <class It, class Cmp>
+void parallel_sort(It b, It e, Cmp cmp, int nt) {
+  const size_t n = (size_t)(e - b);
+  if (nt <= 1 || n < 50000) { std::sort(b, e, cmp); return; }
+  std::vector<size_t> cut(nt + 1);
+  for (int t = 0; t <= nt; t++) cut[t] = n * t / nt;
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++) th.emplace_back([&, t] { std::sort(b + cut[t], b + cut[t + 1], cmp); });
+    for (auto& t : th) t.join();
+  }
+  for (int step = 1; step < nt; step *= 2) {
+    std::vector<std::thread> th;
+    for (int t = 0; t + step < nt; t += 2 * step)
+      th.emplace_back([&, t] { std::inplace_merge(b + cut[t], b + cut[t + step], b + cut[std::min(nt, t + 2 * step)], cmp); });
+    for (auto& t : th) t.join();
+  }
+}
 
 // camera -> rank (contiguous subsequences), landmark -> rank of the subsequence of its lowest-index observing camera
 inline int cam_rank(int cam, int n_cams, int n_ranks) { return (int)(((long long)cam * n_ranks) / std::max(1, n_cams)); }
@@ -233,14 +265,25 @@ int finalize_structure(cs_ba* B) {
   // gorder: free landmarks with >= 1 edge sorted by (number of cameras, camera list); run_first: where each distinct set starts
   for (int k = 0; k < B->n_proj; k++)
     if (B->e_pt[k] < 0 || B->e_pt[k] >= np || B->e_cam[k] < 0 || B->e_cam[k] >= nc) { cs_set_error_ba("projection edge index out of range"); return CS_ERR_INVALID_ARG; }
-  std::vector<int> cam_cnt(np + 1, 0), cams_of(B->n_proj), gorder, run_first;
+  std::vector<int> cam_cnt(np + 1, 0), cams_of(B->n_proj), edge_of, gorder, run_first;   // edges grouped by landmark: camera (sorted by id) and caller edge index
   {
     for (int k = 0; k < B->n_proj; k++) cam_cnt[B->e_pt[k] + 1]++;
     for (int i = 0; i < np; i++) cam_cnt[i + 1] += cam_cnt[i];
     std::vector<int> fill(cam_cnt.begin(), cam_cnt.end() - 1);
-    for (int k = 0; k < B->n_proj; k++) cams_of[fill[B->e_pt[k]]++] = B->e_cam[k];
-    {   // every landmark's camera list sorted (independent little sorts: a few host threads on disjoint ranges)
-      auto sort_lists = [&](int p0, int p1) { for (int p = p0; p < p1; p++) std::sort(cams_of.begin() + cam_cnt[p], cams_of.begin() + cam_cnt[p + 1]); };
+    edge_of.resize(B->n_proj);
+    for (int k = 0; k < B->n_proj; k++) { const int q = fill[B->e_pt[k]]++; cams_of[q] = B->e_cam[k]; edge_of[q] = k; }
+    {   // every landmark's camera list sorted, its edges with it (independent little sorts: a few host threads on disjoint ranges)
+      auto sort_lists = [&](int p0, int p1) {
+        for (int p = p0; p < p1; p++) {
+          const int a0 = cam_cnt[p], a1 = cam_cnt[p + 1];
+          for (int a = a0 + 1; a < a1; a++) {      // insertion sort (a handful of edges; stable: caller order among equal cameras)
+            const int c = cams_of[a], e = edge_of[a];
+            int q = a;
+            while (q > a0 && cams_of[q - 1] > c) { cams_of[q] = cams_of[q - 1]; edge_of[q] = edge_of[q - 1]; q--; }
+            cams_of[q] = c; edge_of[q] = e;
+          }
+        }
+      };
       const int NT = (B->n_proj > 100000) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
       if (NT > 1) {
         std::vector<std::thread> th;
@@ -248,6 +291,7 @@ int finalize_structure(cs_ba* B) {
         for (auto& t : th) t.join();
       } else sort_lists(0, np);
     }
+    mark("  camera lists (count, fill, sort)");
     for (int p = 0; p < np; p++) {
       for (int a = cam_cnt[p] + 1; a < cam_cnt[p + 1]; a++)
         if (cams_of[a] == cams_of[a - 1]) { cs_set_error_ba("two projection edges between the same point and camera"); return CS_ERR_INVALID_ARG; }
@@ -265,19 +309,28 @@ int finalize_structure(cs_ba* B) {
         gkey[p] = key;
       }
     }
+    mark("  duplicate check + keys");
     auto same_set = [&](int p, int q) {
       const int kp = cam_cnt[p + 1] - cam_cnt[p];
       return kp == cam_cnt[q + 1] - cam_cnt[q] && std::equal(cams_of.begin() + cam_cnt[p], cams_of.begin() + cam_cnt[p + 1], cams_of.begin() + cam_cnt[q]);
     };
-    std::sort(gorder.begin(), gorder.end(), [&](int p, int q) {
-      const int kp = cam_cnt[p + 1] - cam_cnt[p], kq = cam_cnt[q + 1] - cam_cnt[q];
-      if (kp != kq) return kp < kq;
-      if (!gkey.empty() && kp <= 7 && gkey[p] != gkey[q]) return gkey[p] < gkey[q];
-      const int c = std::lexicographical_compare(cams_of.begin() + cam_cnt[p], cams_of.begin() + cam_cnt[p + 1], cams_of.begin() + cam_cnt[q], cams_of.begin() + cam_cnt[q + 1]);
-      if (c) return true;
-      if (std::lexicographical_compare(cams_of.begin() + cam_cnt[q], cams_of.begin() + cam_cnt[q + 1], cams_of.begin() + cam_cnt[p], cams_of.begin() + cam_cnt[p + 1])) return false;
-      return p < q;
-    });
+    {
+      // (the key travels with the landmark: the comparator touches nothing else unless two landmarks agree on it)
+      struct GK { unsigned long long key; int p, k; };
+      std::vector<GK> gk(gorder.size());
+      for (size_t i = 0; i < gorder.size(); i++) { const int p = gorder[i]; gk[i] = GK{gkey.empty() ? 0ull : gkey[p], p, cam_cnt[p + 1] - cam_cnt[p]}; }
+      const bool keyed = !gkey.empty();
+      parallel_sort(gk.begin(), gk.end(), [&](const GK& x, const GK& y) {
+        if (x.k != y.k) return x.k < y.k;
+        if (keyed && x.k <= 7 && x.key != y.key) return x.key < y.key;
+        const int p = x.p, q = y.p;
+        if (std::lexicographical_compare(cams_of.begin() + cam_cnt[p], cams_of.begin() + cam_cnt[p + 1], cams_of.begin() + cam_cnt[q], cams_of.begin() + cam_cnt[q + 1])) return true;
+        if (std::lexicographical_compare(cams_of.begin() + cam_cnt[q], cams_of.begin() + cam_cnt[q + 1], cams_of.begin() + cam_cnt[p], cams_of.begin() + cam_cnt[p + 1])) return false;
+        return p < q;
+      }, (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+      for (size_t i = 0; i < gorder.size(); i++) gorder[i] = gk[i].p;
+    }
+    mark("  sort by camera set");
     for (size_t i = 0; i < gorder.size(); i++) if (i == 0 || !same_set(gorder[i - 1], gorder[i])) run_first.push_back((int)i);
     run_first.push_back((int)gorder.size());
   }
@@ -456,63 +509,70 @@ int finalize_structure(cs_ba* B) {
 #define UP(buf, vec) do { rc = (buf).upload(vec); if (rc) return rc; } while (0)
 #define AL(buf, n) do { rc = (buf).alloc(n); if (rc) return rc; } while (0)
   UP(B->d_cam_col, B->cam_col); UP(B->d_cub_col, B->cub_col); UP(B->d_pt_free, pt_free);
-  // ---- projection edges: point-major order (sorted by pose column inside a point), camera-major copy
-  const int E = (int)B->keep.size();   // local edges; slot s of the point-major order holds caller edge keep[order[s]]
-  // counting sort by landmark (stable: caller order inside a landmark), then each landmark's handful of edges by (column, camera id)
-  std::vector<int> order(E);
-  {
-    std::vector<int> off(np + 1, 0);
-    for (int k = 0; k < E; k++) off[B->e_pt[B->keep[k]] + 1]++;
-    for (int i = 0; i < np; i++) off[i + 1] += off[i];
-    std::vector<int> fill(off.begin(), off.end() - 1);
-    for (int k = 0; k < E; k++) order[fill[B->e_pt[B->keep[k]]]++] = k;
-    // (200 k independent little sorts at C4: a few host threads, disjoint ranges of `order`)
-    auto sort_points = [&](int p0, int p1) {
-      for (int p = p0; p < p1; p++)
-        std::stable_sort(order.begin() + off[p], order.begin() + off[p + 1], [&](int a, int b) {
-          const int ka = B->keep[a], kb = B->keep[b];
-          if (B->cam_col[B->e_cam[ka]] != B->cam_col[B->e_cam[kb]]) return B->cam_col[B->e_cam[ka]] < B->cam_col[B->e_cam[kb]];
-          return B->e_cam[ka] < B->e_cam[kb];   // fixed cameras (column -1) by id: landmarks with one camera set share one slot order
-        });
-    };
-    const int NT = (E > 100000) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
-    if (NT > 1) {
-      std::vector<std::thread> th;
-      for (int t = 0; t < NT; t++) th.emplace_back(sort_points, (int)((long long)np * t / NT), (int)((long long)np * (t + 1) / NT));
-      for (auto& t : th) t.join();
-    } else sort_points(0, np);
-  }
-  // The edge tables themselves (88 bytes per edge) go up once in the caller's order and are permuted on the device: point-major
-  // rows by src_of_slot, camera-major rows from the point-major ones by cm_pm.  The host only builds the index arrays.
+  // ---- projection edges: point-major order (sorted by pose column inside a point), camera-major copy.  The edges are already
+  // grouped by landmark with their cameras sorted by id (cams_of / edge_of above); a rank's point-major table is its own landmarks'
+  // groups, each re-ordered by (column, camera id) -- k <= a handful of entries -- in a few host threads on disjoint ranges.
+  std::vector<int> pt_ptr(np + 1, 0);
+  for (int p = 0; p < np; p++) pt_ptr[p + 1] = pt_ptr[p] + (owner[p] == B->shard_rank ? cam_cnt[p + 1] - cam_cnt[p] : 0);
+  const int E = pt_ptr[np];   // local edges
   B->pm_of_orig.assign(B->n_proj, -1);
-  std::vector<int> pm_pt(E), pm_cam(E), pt_ptr(np + 1, 0), src_of_slot(E);
-  for (int s = 0; s < E; s++) {
-    int k = B->keep[order[s]];
-    B->pm_of_orig[k] = s;
-    src_of_slot[s] = k;
-    pm_pt[s] = B->e_pt[k]; pm_cam[s] = B->e_cam[k];
-    pt_ptr[pm_pt[s] + 1]++;
-  }
-  for (int i = 0; i < np; i++) pt_ptr[i + 1] += pt_ptr[i];
-  std::vector<int> cm_pm(E), cm_pt(E), cam_ptr(nc + 1, 0);
-  for (int s = 0; s < E; s++) cam_ptr[pm_cam[s] + 1]++;
-  for (int i = 0; i < nc; i++) cam_ptr[i + 1] += cam_ptr[i];
+  std::vector<int> pm_pt(E), pm_cam(E), src_of_slot(E);
+  const int NTH = (E > 100000) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
   {
-    std::vector<int> fill(cam_ptr.begin(), cam_ptr.end() - 1);
-    for (int s = 0; s < E; s++) { int q = fill[pm_cam[s]]++; cm_pm[q] = s; cm_pt[q] = pm_pt[s]; }
+    auto build_points = [&](int p0, int p1) {
+      for (int p = p0; p < p1; p++) {
+        if (owner[p] != B->shard_rank) continue;
+        const int a0 = cam_cnt[p], k = cam_cnt[p + 1] - a0, s0 = pt_ptr[p];
+        for (int a = 0; a < k; a++) { pm_cam[s0 + a] = cams_of[a0 + a]; src_of_slot[s0 + a] = edge_of[a0 + a]; pm_pt[s0 + a] = p; }
+        for (int a = 1; a < k; a++) {     // by (column, camera id): fixed cameras (column -1) first, by id; stable
+          const int c = pm_cam[s0 + a], e = src_of_slot[s0 + a], col = B->cam_col[c];
+          int q = a;
+          while (q > 0 && (B->cam_col[pm_cam[s0 + q - 1]] > col || (B->cam_col[pm_cam[s0 + q - 1]] == col && pm_cam[s0 + q - 1] > c))) {
+            pm_cam[s0 + q] = pm_cam[s0 + q - 1]; src_of_slot[s0 + q] = src_of_slot[s0 + q - 1]; q--;
+          }
+          pm_cam[s0 + q] = c; src_of_slot[s0 + q] = e;
+        }
+        for (int a = 0; a < k; a++) B->pm_of_orig[src_of_slot[s0 + a]] = s0 + a;
+      }
+    };
+    if (NTH > 1) {
+      std::vector<std::thread> th;
+      for (int t = 0; t < NTH; t++) th.emplace_back(build_points, (int)((long long)np * t / NTH), (int)((long long)np * (t + 1) / NTH));
+      for (auto& t : th) t.join();
+    } else build_points(0, np);
+  }
+  mark("  point-major order");
+  // camera-major: a stable counting sort of the point-major slots by camera, the slots cut into NTH ranges (per-range histograms)
+  std::vector<int> cm_pm(E), cm_pt(E), cam_ptr(nc + 1, 0);
+  {
+    std::vector<std::vector<int>> hist(NTH, std::vector<int>(nc, 0));
+    auto count = [&](int t) { for (int sl = (int)((long long)E * t / NTH), s1 = (int)((long long)E * (t + 1) / NTH); sl < s1; sl++) hist[t][pm_cam[sl]]++; };
+    auto fillr = [&](int t) { std::vector<int>& h = hist[t]; for (int sl = (int)((long long)E * t / NTH), s1 = (int)((long long)E * (t + 1) / NTH); sl < s1; sl++) { const int q = h[pm_cam[sl]]++; cm_pm[q] = sl; cm_pt[q] = pm_pt[sl]; } };
+    auto run_threads = [&](const std::function<void(int)>& fn) {
+      if (NTH > 1) { std::vector<std::thread> th; for (int t = 0; t < NTH; t++) th.emplace_back(fn, t); for (auto& t : th) t.join(); } else fn(0);
+    };
+    run_threads(count);
+    int run = 0;
+    for (int c = 0; c < nc; c++) {
+      cam_ptr[c] = run;
+      for (int t = 0; t < NTH; t++) { const int v = hist[t][c]; hist[t][c] = run; run += v; }    // where range t starts writing camera c
+    }
+    cam_ptr[nc] = run;
+    run_threads(fillr);
   }
   UP(B->cm_pm, cm_pm);
+  mark("  index arrays (point-major, camera-major)");
   {
-    DBuf<double> raw_uv, raw_info, raw_intr, raw_huber;
+    DBuf<double>& raw_uv = B->raw_uv; DBuf<double>& raw_info = B->raw_info; DBuf<double>& raw_intr = B->raw_intr; DBuf<double>& raw_huber = B->raw_huber;
     DBuf<int> d_src;
-    struct Free { DBuf<double>*a, *b, *c, *d; DBuf<int>* e; ~Free() { a->release(); b->release(); c->release(); d->release(); e->release(); } } guard{&raw_uv, &raw_info, &raw_intr, &raw_huber, &d_src};
-    UP(raw_uv, B->h_uv); UP(raw_info, B->h_info); UP(raw_intr, B->h_intr); UP(d_src, src_of_slot);
+    struct Free { DBuf<int>* e; ~Free() { e->release(); } } guard{&d_src};
+    UP(d_src, src_of_slot);
     AL(B->pm_uv, 2 * (size_t)E); AL(B->pm_info, 4 * (size_t)E); AL(B->pm_intr, 4 * (size_t)E); AL(B->pm_huber, (size_t)E);
     AL(B->cm_uv, 2 * (size_t)E); AL(B->cm_info, 4 * (size_t)E); AL(B->cm_intr, 4 * (size_t)E); AL(B->cm_huber, (size_t)E);
     cs::ba_launch_gather_rows(raw_uv.p, d_src.p, E, 2, B->pm_uv.p, B->st);
     cs::ba_launch_gather_rows(raw_info.p, d_src.p, E, 4, B->pm_info.p, B->st);
     cs::ba_launch_gather_rows(raw_intr.p, d_src.p, E, 4, B->pm_intr.p, B->st);
-    if (!B->h_huber.empty()) { UP(raw_huber, B->h_huber); cs::ba_launch_gather_rows(raw_huber.p, d_src.p, E, 1, B->pm_huber.p, B->st); }   // (else: zeros from the allocation)
+    if (B->have_huber) cs::ba_launch_gather_rows(raw_huber.p, d_src.p, E, 1, B->pm_huber.p, B->st);   // (else: zeros from the allocation)
     cs::ba_launch_gather_rows(B->pm_uv.p, B->cm_pm.p, E, 2, B->cm_uv.p, B->st);
     cs::ba_launch_gather_rows(B->pm_info.p, B->cm_pm.p, E, 4, B->cm_info.p, B->st);
     cs::ba_launch_gather_rows(B->pm_intr.p, B->cm_pm.p, E, 4, B->cm_intr.p, B->st);
@@ -1101,7 +1161,7 @@ void cs_ba_destroy(cs_ba* B) {
   DBuf<double>* dd[] = {&B->cams, &B->points, &B->cubes, &B->cams_bak, &B->points_bak, &B->cubes_bak, &B->pm_uv, &B->pm_info, &B->pm_intr, &B->pm_huber,
                         &B->cm_uv, &B->cm_info, &B->cm_intr, &B->cm_huber, &B->ce_meas, &B->ce_info, &B->ce_Hcc, &B->ce_Hoo, &B->ce_Hco, &B->ce_bc, &B->ce_bo,
                         &B->oe_meas, &B->oe_info, &B->oe_Hii, &B->oe_Hjj, &B->oe_Hij, &B->oe_bi, &B->oe_bj, &B->Hcam, &B->bcam, &B->Hcub, &B->bcub, &B->Hll, &B->bl,
-                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv, &B->scale_partial, &B->pe_meas, &B->pe_info, &B->pe_K, &B->part_tiles, &B->part_coef, &B->cub_M, &B->cub_Dinv, &B->sepY, &B->sep_msgs, &B->sepS, &B->int_work, &B->sep_work};
+                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv, &B->scale_partial, &B->pe_meas, &B->pe_info, &B->pe_K, &B->part_tiles, &B->part_coef, &B->cub_M, &B->cub_Dinv, &B->raw_uv, &B->raw_info, &B->raw_intr, &B->raw_huber, &B->sepY, &B->sep_msgs, &B->sepS, &B->int_work, &B->sep_work};
   for (auto* d : dd) d->release();
   DBuf<int>* di[] = {&B->d_ce_active, &B->d_oe_active, &B->d_cam_col, &B->d_cub_col, &B->d_pt_free, &B->pm_pt, &B->pm_cam, &B->pt_ptr, &B->cm_pm, &B->cm_pt, &B->cam_ptr, &B->d_ce_cam, &B->d_ce_cub,
                      &B->d_oe_i, &B->d_oe_j, &B->cam_ce_ptr, &B->cam_ce_idx, &B->cam_oei_ptr, &B->cam_oei_idx, &B->cam_oej_ptr, &B->cam_oej_idx, &B->cub_ce_ptr,
@@ -1171,8 +1231,11 @@ static int cs_ba_set_edges_proj_impl(cs_ba* B, int n, const int* pt, const int* 
   if (!B || n < 0 || (n && (!pt || !cam || !uv || !info4 || !intr4))) return CS_ERR_INVALID_ARG;
   B->n_proj = n;
   B->e_pt.assign(pt, pt + n); B->e_cam.assign(cam, cam + n);
-  B->h_uv.assign(uv, uv + 2 * (size_t)n); B->h_info.assign(info4, info4 + 4 * (size_t)n); B->h_intr.assign(intr4, intr4 + 4 * (size_t)n);
-  if (huber) B->h_huber.assign(huber, huber + n); else B->h_huber.clear();
+  BA_TRY(hipSetDevice(B->device));
+  int rc;
+  if ((rc = B->raw_uv.upload_ptr(uv, 2 * (size_t)n)) || (rc = B->raw_info.upload_ptr(info4, 4 * (size_t)n)) || (rc = B->raw_intr.upload_ptr(intr4, 4 * (size_t)n))) return rc;
+  B->have_huber = huber != nullptr;
+  if (huber) { rc = B->raw_huber.upload_ptr(huber, (size_t)n); if (rc) return rc; } else B->raw_huber.release();
   B->structure_dirty = true;
   return CS_OK;
 }

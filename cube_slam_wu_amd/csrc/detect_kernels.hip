@@ -709,24 +709,27 @@ __device__ __forceinline__ unsigned long long order_key(double x) {
   return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
-// radix selection, 8 passes of 8 bits over order_key(): all 256 threads of the block must call it.
+// radix selection, 8 passes of 8 bits over order_key(): all NT threads of the block must call it (NT = 64, 128 or 256).
 // Two columns at once (their passes share the barriers): keys of rank r (0-based, ascending) among a[0..n) and among b[0..n)
+template <int NT>
 __device__ void block_radix_select2(const double* __restrict__ a, const double* __restrict__ b, int n, int r, unsigned* hist /* LDS, 512 */, unsigned long long* bcast /* LDS, 4 */,
                                     unsigned long long* key_a, unsigned long long* key_b) {
   unsigned long long prefix[2] = {0, 0}, mask = 0;
   int rr2[2] = {r, r};
   for (int pass = 0; pass < 8; pass++) {
     const int shift = 56 - 8 * pass;
-    hist[threadIdx.x] = 0; hist[256 + threadIdx.x] = 0;
+    for (int q = threadIdx.x; q < 512; q += NT) hist[q] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 256) {
+    for (int i = threadIdx.x; i < n; i += NT) {
       const unsigned long long ka = order_key(a[i]), kb = order_key(b[i]);
       if ((ka & mask) == prefix[0]) atomicAdd(&hist[(unsigned)(ka >> shift) & 255u], 1u);
       if ((kb & mask) == prefix[1]) atomicAdd(&hist[256 + ((unsigned)(kb >> shift) & 255u)], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < 128) {  // waves 0 and 1: one column each, every lane owns 4 consecutive bins
-      const int col = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // one wave per column (waves 0 and 1; a single-wave block does both in turn), every lane owns 4 consecutive bins
+    for (int col = 0; col < 2; col++) {
+      if ((int)(threadIdx.x >> 6) != (NT >= 128 ? col : 0)) continue;
+      const int lane = threadIdx.x & 63;
       const unsigned* h = hist + 256 * col;
       unsigned c0 = h[4 * lane], c1 = h[4 * lane + 1], c2 = h[4 * lane + 2], c3 = h[4 * lane + 3];
       unsigned tot = c0 + c1 + c2 + c3, incl = tot;
@@ -753,32 +756,36 @@ __device__ void block_radix_select2(const double* __restrict__ a, const double* 
   *key_a = prefix[0]; *key_b = prefix[1];
 }
 
+template <int NT>
 __device__ __forceinline__ double block_reduce_min(double v, double* sh) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { double y = __shfl_down(v, o); v = (y < v) ? y : v; }
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
   __syncthreads();
   double r = sh[0];
-  for (int w = 1; w < 4; w++) r = (sh[w] < r) ? sh[w] : r;
+  for (int w = 1; w < NT / 64; w++) r = (sh[w] < r) ? sh[w] : r;
   __syncthreads();
   return r;
 }
+template <int NT>
 __device__ __forceinline__ double block_reduce_max(double v, double* sh) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { double y = __shfl_down(v, o); v = (y > v) ? y : v; }
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
   __syncthreads();
   double r = sh[0];
-  for (int w = 1; w < 4; w++) r = (sh[w] > r) ? sh[w] : r;
+  for (int w = 1; w < NT / 64; w++) r = (sh[w] > r) ? sh[w] : r;
   __syncthreads();
   return r;
 }
+template <int NT>
 __device__ __forceinline__ int block_reduce_sum_i(int v, int* sh) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
   __syncthreads();
-  int r = sh[0] + sh[1] + sh[2] + sh[3];
+  int r = sh[0];
+  for (int w = 1; w < NT / 64; w++) r += sh[w];
   __syncthreads();
   return r;
 }
@@ -790,8 +797,9 @@ struct JobCut {      // per height sample of the box
   int tie;           // several proposals share the cut value vd, and which of them the reference keeps depends on its heap order
 };
 
-enum { RANK_STAGE = 1536 };   // proposals of one height sample staged in LDS (2 x 12 KB)
-__global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView rv, RankParams rp) {
+enum { RANK_STAGE = 1536, RANK_THREADS_DEFAULT = 256 };   // proposals of one height sample staged in LDS (2 x 12 KB)
+template <int NT>
+__global__ __launch_bounds__(NT) void rank_kernel(DetectDeviceView v, RankView rv, RankParams rp) {
   __shared__ unsigned hist[512];
   __shared__ unsigned long long bcast[4];
   __shared__ double shd[4];
@@ -816,7 +824,7 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
     // large box is valid), each pass then costs LDS latency instead of a round trip to L2
     if (V <= RANK_STAGE) {
       __syncthreads();
-      for (int i = threadIdx.x; i < V; i += 256) { sD[i] = D[i]; sA[i] = A[i]; }
+      for (int i = threadIdx.x; i < V; i += NT) { sD[i] = D[i]; sA[i] = A[i]; }
       __syncthreads();
       D = sD; A = sA;
     }
@@ -826,14 +834,14 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
       int bn = (int)round((double)((float)V) / 3.0 * 2.0);
       bn_keep = bn - 1;
       unsigned long long kd, ka;
-      block_radix_select2(D, A, V, bn - 2, hist, bcast, &kd, &ka);
+      block_radix_select2<NT>(D, A, V, bn - 2, hist, bcast, &kd, &ka);
       int cd = 0, ca = 0, nan = 0;
-      for (int i = threadIdx.x; i < V; i += 256) {
+      for (int i = threadIdx.x; i < V; i += NT) {
         double d = D[i], a = A[i];
         cd += order_key(d) <= kd; ca += order_key(a) <= ka;
         nan += (d != d) || (a != a);
       }
-      cd = block_reduce_sum_i(cd, shi); ca = block_reduce_sum_i(ca, shi); nan = block_reduce_sum_i(nan, shi);
+      cd = block_reduce_sum_i<NT>(cd, shi); ca = block_reduce_sum_i<NT>(ca, shi); nan = block_reduce_sum_i<NT>(nan, shi);
       // the (bn-1)-th and bn-th smallest distance errors may coincide (float sums: 4 % of the boxes): then which of the tied
       // proposals is kept depends on the heap order of std::partial_sort.  That is decided below -- the box only goes to the
       // host when the choice can change the output
@@ -842,16 +850,16 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
       use_angle = (ca == bn - 1);  // angle[sorted[bn-1]] > angle[sorted[bn-2]] (:766)
       // thresholds as doubles: the largest kept value
       double md = -INF, ma = -INF;
-      for (int i = threadIdx.x; i < V; i += 256) {
+      for (int i = threadIdx.x; i < V; i += NT) {
         if (order_key(D[i]) <= kd) md = (D[i] > md) ? D[i] : md;
         if (order_key(A[i]) <= ka) ma = (A[i] > ma) ? A[i] : ma;
       }
-      vd = block_reduce_max(md, shd);
-      va = block_reduce_max(ma, shd);
+      vd = block_reduce_max<NT>(md, shd);
+      va = block_reduce_max<NT>(ma, shd);
     }
     double dmin = 1e6, dmax = -1, amin = 1e6, amax = -1;  // :798-801
     int nk = 0;
-    for (int i = threadIdx.x; i < V; i += 256) {
+    for (int i = threadIdx.x; i < V; i += NT) {
       double d = D[i], a = A[i];
       bool keep = (d <= vd) && (!use_angle || a <= va);
       if (keep) {
@@ -860,9 +868,9 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
         amin = (a < amin) ? a : amin; amax = (amax < a) ? a : amax;
       }
     }
-    dmin = block_reduce_min(dmin, shd); dmax = block_reduce_max(dmax, shd);
-    amin = block_reduce_min(amin, shd); amax = block_reduce_max(amax, shd);
-    nk = block_reduce_sum_i(nk, shi);
+    dmin = block_reduce_min<NT>(dmin, shd); dmax = block_reduce_max<NT>(dmax, shd);
+    amin = block_reduce_min<NT>(amin, shd); amax = block_reduce_max<NT>(amax, shd);
+    nk = block_reduce_sum_i<NT>(nk, shi);
     if (tie) {
       // The reference keeps all proposals below the cut value ("sure") and r >= 1 of the ct proposals at it.  The constants
       // above were taken over sure + ALL tied proposals (that pass the angle cut).  They equal the reference's whatever it
@@ -871,14 +879,14 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
       // cannot avoid keeping one that does (dmax = the cut value either way).  Then a tied proposal only matters if it wins.
       double amin_s = 1e6, amax_s = -1;
       int nk_s = 0, nt = 0, ct = 0, cl = 0;
-      for (int i = threadIdx.x; i < V; i += 256) {
+      for (int i = threadIdx.x; i < V; i += NT) {
         double d = D[i], a = A[i];
         const bool pass = !use_angle || a <= va;
         if (d < vd) { cl++; if (pass) { nk_s++; amin_s = (a < amin_s) ? a : amin_s; amax_s = (amax_s < a) ? a : amax_s; } }
         else if (d == vd) { ct++; nt += pass; }
       }
-      amin_s = block_reduce_min(amin_s, shd); amax_s = block_reduce_max(amax_s, shd);
-      nk_s = block_reduce_sum_i(nk_s, shi); nt = block_reduce_sum_i(nt, shi); ct = block_reduce_sum_i(ct, shi); cl = block_reduce_sum_i(cl, shi);
+      amin_s = block_reduce_min<NT>(amin_s, shd); amax_s = block_reduce_max<NT>(amax_s, shd);
+      nk_s = block_reduce_sum_i<NT>(nk_s, shi); nt = block_reduce_sum_i<NT>(nt, shi); ct = block_reduce_sum_i<NT>(ct, shi); cl = block_reduce_sum_i<NT>(cl, shi);
       const int r = bn_keep - cl;                  // tied proposals the reference keeps
       const bool safe = nk_s >= 2 && amin_s == amin && amax_s == amax && (nt == 0 || r - (ct - nt) >= 1);
       if (!safe && threadIdx.x == 0) s_fallback = 1;
@@ -890,7 +898,7 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
       // cut value -- when two share that value, or the cut itself is tied, the reference's heap order decides: host.
       int last = -1, n_at_cut = 0;
       if (V > 4) {
-        for (int i = threadIdx.x; i < V; i += 256) {
+        for (int i = threadIdx.x; i < V; i += NT) {
           const double d = D[i], a = A[i];
           if (use_angle) { if (d <= vd && a <= va) last = i; }
           else if (d == vd) { last = i; n_at_cut++; }
@@ -899,9 +907,9 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
         for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_down(last, o); last = y > last ? y : last; }
         if ((threadIdx.x & 63) == 0) shi[threadIdx.x >> 6] = last;
         __syncthreads();
-        last = max(max(shi[0], shi[1]), max(shi[2], shi[3]));
+        { int mx = shi[0]; for (int w = 1; w < NT / 64; w++) mx = max(mx, shi[w]); last = mx; }
         __syncthreads();
-        n_at_cut = block_reduce_sum_i(n_at_cut, shi);
+        n_at_cut = block_reduce_sum_i<NT>(n_at_cut, shi);
         if ((tie || (!use_angle && n_at_cut != 1)) && threadIdx.x == 0) s_fallback = 1;
       } else {
         last = V - 1;
@@ -926,7 +934,7 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
     for (int h = 0; h < nj; h++) {
       const JobCut c = cuts[h];
       long long c0 = v.job_cbase[j0 + h];
-      for (int i = threadIdx.x; i < c.V; i += 256) {
+      for (int i = threadIdx.x; i < c.V; i += NT) {
         double d = staged ? sD[i] : v.c_dist[c0 + i], a = staged ? sA[i] : v.c_angle[c0 + i];
         bool keep = (d <= c.vd) && (!c.use_angle || a <= c.va);
         if (!keep || (v.c_flag[c0 + i] & CAND_NEG_SCALE)) continue;
@@ -949,13 +957,13 @@ __global__ __launch_bounds__(256) void rank_kernel(DetectDeviceView v, RankView 
         else if (comb == best) cnt_local += weight;
       }
     }
-    bad = block_reduce_sum_i(bad, shi);
-    double gbest = block_reduce_min(best, shd);
+    bad = block_reduce_sum_i<NT>(bad, shi);
+    double gbest = block_reduce_min<NT>(best, shd);
     if (bad && threadIdx.x == 0) s_fallback = 1;
     if (!(gbest < INF)) break;  // no proposal left
     // how many proposals attain the minimum?  (> 1: the reference's pick depends on the heap order)
     const bool mine = best == gbest;
-    int cnt = block_reduce_sum_i(mine ? cnt_local : 0, shi);
+    int cnt = block_reduce_sum_i<NT>(mine ? cnt_local : 0, shi);
     if (mine) {   // the (unique, unless the box goes to the host anyway) owner writes the winner record
       RankWinner* w = rv.winners + (size_t)box * rp.kmax + round;
       long long slot = v.c_slot[w_at];
@@ -1321,7 +1329,10 @@ void launch_gather_ranges(const DetectDeviceView& v, const long long* src_off, c
 void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams& rp, hipStream_t st) {
   if (skip_kernel("rank")) return;
   if (rv.n_boxes <= 0) return;
-  hipLaunchKernelGGL(rank_kernel, dim3(rv.n_boxes), dim3(256), 0, st, v, rv, rp);
+  static const int nt = [] { const char* e = getenv("CS_RANK_THREADS"); const int q = e ? atoi(e) : 0; return (q == 64 || q == 128 || q == 256) ? q : RANK_THREADS_DEFAULT; }();
+  if (nt == 64) hipLaunchKernelGGL(rank_kernel<64>, dim3(rv.n_boxes), dim3(64), 0, st, v, rv, rp);
+  else if (nt == 128) hipLaunchKernelGGL(rank_kernel<128>, dim3(rv.n_boxes), dim3(128), 0, st, v, rv, rp);
+  else hipLaunchKernelGGL(rank_kernel<256>, dim3(rv.n_boxes), dim3(256), 0, st, v, rv, rp);
 }
 void launch_records(const DetectDeviceView& v, const RankView& rv, int kmax, cs_cuboid* out, hipStream_t st, const double* raw_euler) {
   if (skip_kernel("records")) return;
