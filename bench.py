@@ -417,6 +417,46 @@ def main():
                     "projected_solve_speedup": (d["factor_ms"] / nsol) / max(1e-9, solve_r),
                     "assumed_collective_latency_us": comm_us, "projected_ms_per_iteration": it_r, "projected_iteration_speedup": it_1 / max(1e-9, it_r)}
             Pp.close()
+        # the reference's usage pattern (main_obj.cpp:802-803): a frame is appended, then optimize(5) on the grown graph -- structure phase
+        # included, because g2o pays it inside optimize() too (updateStructure)
+        if world == 1 and os.environ.get("CS_BENCH_CHILD") is None:
+            pr3 = synth_ba.make_problem(n_cams=200, n_points=20000, n_cuboids=50, seed=42) if args.ba == "C4" else pr
+            nc3 = len(pr3["cams"])
+            fp = np.full(len(pr3["points"]), nc3); np.minimum.at(fp, pr3["e_pt"], pr3["e_cam"])
+            order3 = np.argsort(fp, kind="stable"); rank3 = np.empty_like(order3); rank3[order3] = np.arange(len(order3))
+            fp = fp[order3]
+            ep3 = rank3[pr3["e_pt"]]
+            T0 = nc3 - 10
+            keep_c = pr3["ce_cam"] < T0
+            sel = pr3["e_cam"] < T0
+            selo = np.maximum(pr3["oe_i"], pr3["oe_j"]) < T0
+            n_p = int((fp < T0).sum())
+            Pg = capi.BaProblem(pr3["cams"][:T0], pr3["cam_fixed"][:T0], pr3["cuboids"], pr3["cub_fixed"], pr3["points"][order3][:n_p], pr3["pt_fixed"][order3][:n_p], device=local_rank)
+            Pg.set_edges_proj(ep3[sel], pr3["e_cam"][sel], pr3["e_uv"][sel], pr3["e_info"][sel], pr3["e_intr"][sel], pr3["e_huber"][sel])
+            Pg.set_edges_cuboid(pr3["ce_cam"][keep_c], pr3["ce_cub"][keep_c], pr3["ce_meas"][keep_c], pr3["ce_info"][keep_c])
+            Pg.set_edges_odom(pr3["oe_i"][selo], pr3["oe_j"][selo], pr3["oe_meas"][selo], pr3["oe_info"][selo])
+            Pg.optimize(5)
+            t_app, t_opt = [], []
+            for t in range(T0, nc3):
+                sel = pr3["e_cam"] == t; keep_c = pr3["ce_cam"] == t; selo = np.maximum(pr3["oe_i"], pr3["oe_j"]) == t
+                n_p2 = int((fp < t + 1).sum())
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                Pg.append_vertices(pr3["cams"][t:t + 1], pr3["cam_fixed"][t:t + 1], None, None, pr3["points"][order3][n_p:n_p2], pr3["pt_fixed"][order3][n_p:n_p2])
+                Pg.append_edges_proj(ep3[sel], pr3["e_cam"][sel], pr3["e_uv"][sel], pr3["e_info"][sel], pr3["e_intr"][sel], pr3["e_huber"][sel])
+                Pg.append_edges_cuboid(pr3["ce_cam"][keep_c], pr3["ce_cub"][keep_c], pr3["ce_meas"][keep_c], pr3["ce_info"][keep_c])
+                Pg.append_edges_odom(pr3["oe_i"][selo], pr3["oe_j"][selo], pr3["oe_meas"][selo], pr3["oe_info"][selo])
+                Pg.sizes()          # the structure phase of the grown graph
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                Pg.optimize(5)
+                torch.cuda.synchronize()
+                t_app.append((t2 - t1) * 1e3); t_opt.append((time.perf_counter() - t2) * 1e3)
+                n_p = n_p2
+            Pg.close()
+            ba_out["growing_graph"] = {"what": "C3-sized graph (%d cameras, 20 k points, 50 cuboids) grown by one frame at a time through cs_ba_append_*, optimize(5) after every frame (main_obj.cpp:802-803); medians over 10 frames" % nc3,
+                                       "append_and_structure_ms": float(np.median(t_app)), "optimize5_on_appended_graph_ms": float(np.median(t_opt)),
+                                       "frame_ms": float(np.median(np.array(t_app) + np.array(t_opt)))}
         # CPU baseline of the BA half (rank 0, N = 1): the oracle (oracle/ba_oracle.cpp, -O2, one thread) on the SAME problem, wall time
         # per LM iteration split as g2o's G2OBatchStatistics does (core/batch_stats.h:48-62).  C3: the full run.  C4: one LM
         # iteration with residuals / linearisation / Schur complement / update in full and the dense LDL^T (the reference

@@ -124,7 +124,66 @@ class BlockSolverHIP : public g2o::Solver {
     }
     return true;
   }
-  virtual bool updateStructure(const std::vector<g2o::HyperGraph::Vertex*>&, const g2o::HyperGraph::EdgeSet&) { return buildStructure(); }
+  // core/block_solver.hpp:297-350 (online processing: the graph grew by `vset` / `edges`).  New cameras, points and edges are appended
+  // behind the existing ones (cs_ba_append_*: the library keeps what it has and re-runs its structure phase on the next solve); a
+  // new cuboid would break the class-contiguous vertex order x() / b() rely on, so that case packs the graph again from scratch.
+  virtual bool updateStructure(const std::vector<g2o::HyperGraph::Vertex*>& vset, const g2o::HyperGraph::EdgeSet& edges) {
+    for (auto* v : vset) if (dynamic_cast<g2o::VertexCuboid*>(v)) return buildStructure();
+    std::vector<double> cam7, pt3;
+    std::vector<int> cam_fixed, pt_fixed;
+    for (auto* hv : vset) {
+      if (auto* c = dynamic_cast<g2o::VertexSE3Expmap*>(hv)) {
+        index_[hv] = (int)cams_.size(); cams_.push_back(c); cam_fixed.push_back(c->fixed());
+        g2o::Vector7d e = c->estimate().toVector(); cam7.insert(cam7.end(), e.data(), e.data() + 7);
+      } else if (auto* p = dynamic_cast<g2o::VertexSBAPointXYZ*>(hv)) {
+        index_[hv] = (int)pts_.size(); pts_.push_back(p); pt_fixed.push_back(p->fixed());
+        pt3.insert(pt3.end(), p->estimate().data(), p->estimate().data() + 3);
+      } else {
+        throw std::runtime_error("BlockSolverHIP: unsupported vertex type");
+      }
+    }
+    if (cs_ba_append_vertices(ba_, cam7.data(), cam_fixed.data(), (int)cam_fixed.size(), nullptr, nullptr, 0, pt3.data(), pt_fixed.data(), (int)pt_fixed.size()) != CS_OK) return false;
+    std::vector<int> e_pt, e_cam, ce_cam, ce_cub, pe_cam, pe_cub, oe_i, oe_j;
+    std::vector<double> uv, info4, intr4, huber, meas10, info81, meas7, info36, meas4, info16, K9;
+    for (auto* he : edges) {
+      if (auto* pe = dynamic_cast<g2o::EdgeSE3ProjectXYZ*>(he)) {
+        e_pt.push_back(index_[pe->vertex(0)]); e_cam.push_back(index_[pe->vertex(1)]);
+        uv.push_back(pe->measurement()[0]); uv.push_back(pe->measurement()[1]);
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) info4.push_back(pe->information()(i, j));
+        intr4.push_back(pe->fx); intr4.push_back(pe->fy); intr4.push_back(pe->cx); intr4.push_back(pe->cy);
+        auto* hk = dynamic_cast<g2o::RobustKernelHuber*>(pe->robustKernel());
+        huber.push_back(hk ? hk->delta() : 0.0);
+      } else if (auto* ce = dynamic_cast<g2o::EdgeSE3Cuboid*>(he)) {
+        ce_cam.push_back(index_[ce->vertex(0)]); ce_cub.push_back(index_[ce->vertex(1)]);
+        Vector10d m = ce->measurement().toVector(); meas10.insert(meas10.end(), m.data(), m.data() + 10);
+        for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) info81.push_back(ce->information()(i, j));
+      } else if (auto* qe = dynamic_cast<g2o::EdgeSE3CuboidProj*>(he)) {
+        pe_cam.push_back(index_[qe->vertex(0)]); pe_cub.push_back(index_[qe->vertex(1)]);
+        for (int i = 0; i < 4; i++) meas4.push_back(qe->measurement()[i]);
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) info16.push_back(qe->information()(i, j));
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) K9.push_back(qe->Kalib(i, j));
+      } else if (auto* oe = dynamic_cast<g2o::EdgeSE3Expmap*>(he)) {
+        oe_i.push_back(index_[oe->vertex(0)]); oe_j.push_back(index_[oe->vertex(1)]);
+        g2o::Vector7d m = oe->measurement().toVector(); meas7.insert(meas7.end(), m.data(), m.data() + 7);
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) info36.push_back(oe->information()(i, j));
+      } else {
+        throw std::runtime_error("BlockSolverHIP: unsupported edge type (no CPU fallback by design)");
+      }
+    }
+    if (cs_ba_append_edges_proj(ba_, (int)e_pt.size(), e_pt.data(), e_cam.data(), uv.data(), info4.data(), intr4.data(), huber.data()) != CS_OK) return false;
+    if (cs_ba_append_edges_cuboid(ba_, (int)ce_cam.size(), ce_cam.data(), ce_cub.data(), meas10.data(), info81.data()) != CS_OK) return false;
+    if (cs_ba_append_edges_cuboid_proj(ba_, (int)pe_cam.size(), pe_cam.data(), pe_cub.data(), meas4.data(), info16.data(), K9.data()) != CS_OK) return false;
+    if (cs_ba_append_edges_odom(ba_, (int)oe_i.size(), oe_i.data(), oe_j.data(), meas7.data(), info36.data()) != CS_OK) return false;
+    int sp = 0, sl = 0;
+    if (cs_ba_sizes(ba_, &sp, &sl) != CS_OK) return false;
+    resizeVector(sp + sl);
+    size_t tot = 0;
+    for (auto* v : _optimizer->indexMapping()) tot += (size_t)v->dimension() * v->dimension();
+    diag_.assign(tot, 0.0);
+    size_t off = 0;
+    for (auto* v : _optimizer->indexMapping()) { v->mapHessianMemory(diag_.data() + off); off += (size_t)v->dimension() * v->dimension(); }
+    return true;
+  }
 
   // core/block_solver.hpp:501-560.  Estimates may have changed on the CPU side (update/pop): push them first.
   virtual bool buildSystem() {

@@ -371,7 +371,7 @@ DECLARED_SYMBOLS += [
     "cs_ba_create", "cs_ba_destroy", "cs_ba_set_vertices", "cs_ba_set_estimates", "cs_ba_set_edges_proj", "cs_ba_set_edges_cuboid", "cs_ba_set_edges_cuboid_proj", "cs_ba_set_edges_odom",
     "cs_ba_compute_errors", "cs_ba_build_system", "cs_ba_solve", "cs_ba_update", "cs_ba_push", "cs_ba_pop", "cs_ba_optimize",
     "cs_ba_get_state", "cs_ba_sizes", "cs_ba_solver_layout", "cs_ba_get_system", "cs_ba_last_timing", "cs_ba_set_shard", "cs_ba_optimize_sharded",
-    "cs_ba_shard_landmark_owners", "cs_ba_get_landmark_owners", "cs_ba_shard_info", "cs_ba_shard_timing", "cs_ba_get_vertex_hessians", "cs_ba_schur_layout", "cs_ba_reduced_size", "cs_ba_comm_unique_id", "cs_ba_comm_init",
+    "cs_ba_shard_landmark_owners", "cs_ba_get_landmark_owners", "cs_ba_shard_info", "cs_ba_shard_timing", "cs_ba_append_vertices", "cs_ba_append_edges_proj", "cs_ba_append_edges_cuboid", "cs_ba_append_edges_cuboid_proj", "cs_ba_append_edges_odom", "cs_ba_get_vertex_hessians", "cs_ba_schur_layout", "cs_ba_reduced_size", "cs_ba_comm_unique_id", "cs_ba_comm_init",
 ]
 
 
@@ -425,6 +425,28 @@ class BaProblem:
     def set_edges_odom(self, ci, cj, meas7, info36):
         ci, cj = _i32(ci), _i32(cj); self.n_odom = len(ci)
         _chk(lib().cs_ba_set_edges_odom(self.h, self.n_odom, _ip(ci), _ip(cj), _dp(_f64(meas7, (-1, 7))), _dp(_f64(info36, (-1, 36)))), "cs_ba_set_edges_odom")
+
+    # ---- growing graphs: new vertices / edges behind the existing ones, device-side estimates kept
+    def append_vertices(self, cams=None, cam_fixed=None, cuboids=None, cub_fixed=None, points=None, pt_fixed=None):
+        c = _f64(cams if cams is not None else np.zeros((0, 7)), (-1, 7)); o = _f64(cuboids if cuboids is not None else np.zeros((0, 10)), (-1, 10))
+        q = _f64(points if points is not None else np.zeros((0, 3)), (-1, 3))
+        cf = _i32(cam_fixed if cam_fixed is not None else np.zeros(len(c))); of = _i32(cub_fixed if cub_fixed is not None else np.zeros(len(o))); pf = _i32(pt_fixed if pt_fixed is not None else np.zeros(len(q)))
+        _chk(lib().cs_ba_append_vertices(self.h, _dp(c), _ip(cf), len(c), _dp(o), _ip(of), len(o), _dp(q), _ip(pf), len(q)), "cs_ba_append_vertices")
+        self.nc += len(c); self.no += len(o); self.np_ += len(q)
+
+    def append_edges_proj(self, pt, cam, uv, info4, intr4, huber=None):
+        pt, cam = _i32(pt), _i32(cam)
+        hb = _f64(huber, (-1,)) if huber is not None else None
+        _chk(lib().cs_ba_append_edges_proj(self.h, len(pt), _ip(pt), _ip(cam), _dp(_f64(uv, (-1, 2))), _dp(_f64(info4, (-1, 4))), _dp(_f64(intr4, (-1, 4))), _dp(hb) if hb is not None else None), "cs_ba_append_edges_proj")
+        self.n_proj = getattr(self, "n_proj", 0) + len(pt)
+
+    def append_edges_cuboid(self, cam, cub, meas10, info81):
+        cam, cub = _i32(cam), _i32(cub)
+        _chk(lib().cs_ba_append_edges_cuboid(self.h, len(cam), _ip(cam), _ip(cub), _dp(_f64(meas10, (-1, 10))), _dp(_f64(info81, (-1, 81)))), "cs_ba_append_edges_cuboid")
+
+    def append_edges_odom(self, ci, cj, meas7, info36):
+        ci, cj = _i32(ci), _i32(cj)
+        _chk(lib().cs_ba_append_edges_odom(self.h, len(ci), _ip(ci), _ip(cj), _dp(_f64(meas7, (-1, 7))), _dp(_f64(info36, (-1, 36)))), "cs_ba_append_edges_odom")
 
     def compute_errors(self):
         chi = C.c_double()

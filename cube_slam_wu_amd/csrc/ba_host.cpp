@@ -99,6 +99,16 @@ struct DBuf {
     if (n) BA_TRY(hipMemcpy(p, h, n * sizeof(T), hipMemcpyHostToDevice));
     return CS_OK;
   }
+  int append_ptr(const T* h, size_t count) {   // the old contents stay where they are on the device, `count` new entries follow
+    if (!count) return CS_OK;
+    T* q = nullptr;
+    BA_TRY(hipMalloc((void**)&q, (n + count) * sizeof(T)));
+    if (n) BA_TRY(hipMemcpy(q, p, n * sizeof(T), hipMemcpyDeviceToDevice));
+    BA_TRY(hipMemcpy(q + n, h, count * sizeof(T), hipMemcpyHostToDevice));
+    if (p) (void)hipFree(p);
+    p = q; n += count;
+    return CS_OK;
+  }
   int upload(const std::vector<T>& h) {
     if (p) { (void)hipFree(p); p = nullptr; }
     n = h.size();
@@ -1206,6 +1216,82 @@ int cs_ba_set_vertices(cs_ba* B, const double* cams7, const int* cam_fixed, int 
   BA_GUARD_BEGIN
   return cs_ba_set_vertices_impl(B, cams7, cam_fixed, nc, cuboids10, cub_fixed, no, points3, pt_fixed, np, cuboids_first);
   BA_GUARD_END("cs_ba_set_vertices")
+}
+
+// ---- growing graphs (the reference's pattern: main_obj.cpp:802-803 adds a frame and calls optimize(5); g2o's seam is
+// Solver::updateStructure, core/solver.h:62, core/block_solver.hpp:297-350).  New vertices and edges are appended behind the existing
+// ones; the estimates that live on the device (possibly optimised there) stay untouched; the structure phase runs again on the
+// next solve (49 ms at C4, a few ms at C3 -- DESIGN.md section 3).
+static int cs_ba_append_vertices_impl(cs_ba* B, const double* cams7, const int* cam_fixed, int n_cams, const double* cuboids10, const int* cub_fixed, int n_cub,
+                                      const double* points3, const int* pt_fixed, int n_pts) {
+  if (!B || n_cams < 0 || n_cub < 0 || n_pts < 0 || (n_cams && (!cams7 || !cam_fixed)) || (n_cub && (!cuboids10 || !cub_fixed)) || (n_pts && (!points3 || !pt_fixed))) return CS_ERR_INVALID_ARG;
+  BA_TRY(hipSetDevice(B->device));
+  BA_TRY(hipStreamSynchronize(B->st));
+  std::vector<double> c(cams7, cams7 + 7 * (size_t)n_cams);
+  for (int i = 0; i < n_cams; i++) { cs::Pose p = cs::pose_load(&c[7 * (size_t)i]); cs::pose_normalize(p); cs::pose_store(p, &c[7 * (size_t)i]); }
+  int rc;
+  if ((rc = B->cams.append_ptr(c.data(), 7 * (size_t)n_cams)) || (rc = B->cubes.append_ptr(cuboids10, 10 * (size_t)n_cub)) || (rc = B->points.append_ptr(points3, 3 * (size_t)n_pts))) return rc;
+  B->cam_fixed.insert(B->cam_fixed.end(), cam_fixed, cam_fixed + n_cams);
+  B->cub_fixed.insert(B->cub_fixed.end(), cub_fixed, cub_fixed + n_cub);
+  B->pt_fixed.insert(B->pt_fixed.end(), pt_fixed, pt_fixed + n_pts);
+  B->nc += n_cams; B->no += n_cub; B->np += n_pts;
+  B->structure_dirty = true;
+  return CS_OK;
+}
+int cs_ba_append_vertices(cs_ba* B, const double* cams7, const int* cam_fixed, int n_cams, const double* cuboids10, const int* cub_fixed, int n_cub,
+                          const double* points3, const int* pt_fixed, int n_pts) {
+  BA_GUARD_BEGIN
+  return cs_ba_append_vertices_impl(B, cams7, cam_fixed, n_cams, cuboids10, cub_fixed, n_cub, points3, pt_fixed, n_pts);
+  BA_GUARD_END("cs_ba_append_vertices")
+}
+int cs_ba_append_edges_proj(cs_ba* B, int n, const int* pt, const int* cam, const double* uv, const double* info4, const double* intr4, const double* huber) {
+  if (!B || n < 0 || (n && (!pt || !cam || !uv || !info4 || !intr4))) return CS_ERR_INVALID_ARG;
+  BA_GUARD_BEGIN
+  if (n == 0) return CS_OK;
+  if (B->n_proj > 0 && (huber != nullptr) != B->have_huber) { cs_set_error_ba("cs_ba_append_edges_proj: Huber deltas must be given for all projection edges or for none"); return CS_ERR_INVALID_ARG; }
+  BA_TRY(hipSetDevice(B->device));
+  BA_TRY(hipStreamSynchronize(B->st));
+  int rc;
+  if ((rc = B->raw_uv.append_ptr(uv, 2 * (size_t)n)) || (rc = B->raw_info.append_ptr(info4, 4 * (size_t)n)) || (rc = B->raw_intr.append_ptr(intr4, 4 * (size_t)n))) return rc;
+  if (huber) { rc = B->raw_huber.append_ptr(huber, (size_t)n); if (rc) return rc; }
+  B->have_huber = huber != nullptr;
+  B->e_pt.insert(B->e_pt.end(), pt, pt + n); B->e_cam.insert(B->e_cam.end(), cam, cam + n);
+  B->n_proj += n;
+  B->structure_dirty = true;
+  return CS_OK;
+  BA_GUARD_END("cs_ba_append_edges_proj")
+}
+int cs_ba_append_edges_cuboid(cs_ba* B, int n, const int* cam, const int* cub, const double* meas10, const double* info81) {
+  if (!B || n < 0 || (n && (!cam || !cub || !meas10 || !info81))) return CS_ERR_INVALID_ARG;
+  BA_GUARD_BEGIN
+  B->u3_cam.insert(B->u3_cam.end(), cam, cam + n); B->u3_cub.insert(B->u3_cub.end(), cub, cub + n);
+  B->h_ce_meas.insert(B->h_ce_meas.end(), meas10, meas10 + 10 * (size_t)n); B->h_ce_info.insert(B->h_ce_info.end(), info81, info81 + 81 * (size_t)n);
+  B->structure_dirty = true;
+  return CS_OK;
+  BA_GUARD_END("cs_ba_append_edges_cuboid")
+}
+int cs_ba_append_edges_cuboid_proj(cs_ba* B, int n, const int* cam, const int* cub, const double* meas4, const double* info16, const double* K9) {
+  if (!B || n < 0 || (n && (!cam || !cub || !meas4 || !info16 || !K9))) return CS_ERR_INVALID_ARG;
+  BA_GUARD_BEGIN
+  B->up_cam.insert(B->up_cam.end(), cam, cam + n); B->up_cub.insert(B->up_cub.end(), cub, cub + n);
+  B->h_pe_meas.insert(B->h_pe_meas.end(), meas4, meas4 + 4 * (size_t)n); B->h_pe_info.insert(B->h_pe_info.end(), info16, info16 + 16 * (size_t)n);
+  B->h_pe_K.insert(B->h_pe_K.end(), K9, K9 + 9 * (size_t)n);
+  B->structure_dirty = true;
+  return CS_OK;
+  BA_GUARD_END("cs_ba_append_edges_cuboid_proj")
+}
+int cs_ba_append_edges_odom(cs_ba* B, int n, const int* ci, const int* cj, const double* meas7, const double* info36) {
+  if (!B || n < 0 || (n && (!ci || !cj || !meas7 || !info36))) return CS_ERR_INVALID_ARG;
+  BA_GUARD_BEGIN
+  B->oe_i.insert(B->oe_i.end(), ci, ci + n); B->oe_j.insert(B->oe_j.end(), cj, cj + n);
+  const size_t m0 = B->h_oe_meas.size();
+  B->h_oe_meas.insert(B->h_oe_meas.end(), meas7, meas7 + 7 * (size_t)n);
+  for (int k = 0; k < n; k++) { cs::Pose p = cs::pose_load(&B->h_oe_meas[m0 + 7 * (size_t)k]); cs::pose_normalize(p); cs::pose_store(p, &B->h_oe_meas[m0 + 7 * (size_t)k]); }
+  B->h_oe_info.insert(B->h_oe_info.end(), info36, info36 + 36 * (size_t)n);
+  B->n_odom += n;
+  B->structure_dirty = true;
+  return CS_OK;
+  BA_GUARD_END("cs_ba_append_edges_odom")
 }
 
 static int cs_ba_set_estimates_impl(cs_ba* B, const double* cams7, const double* cuboids10, const double* points3) {

@@ -256,6 +256,16 @@ int cs_ba_set_edges_odom(cs_ba* ba, int n, const int* cam_i, const int* cam_j, c
 int cs_ba_compute_errors(cs_ba* ba, double* robust_chi2);   /* computeActiveErrors + activeRobustChi2 */
 int cs_ba_build_system(cs_ba* ba);                           /* Solver::buildSystem (needs current errors) */
 int cs_ba_solve(cs_ba* ba, double lambda, int* positive_definite); /* setLambda + solve + restoreDiagonal */
+/* Growing graphs (the reference adds a frame and calls optimize(5): main_obj.cpp:802-803; g2o's seam is Solver::updateStructure,
+ * core/solver.h:62).  The new vertices / edges are appended behind the existing ones (indices continue); estimates that live on the
+ * device -- possibly optimised there -- are kept; the structure phase runs again on the next solve.  Huber deltas must be given for
+ * all projection edges or for none.                                                                                               */
+int cs_ba_append_vertices(cs_ba* ba, const double* cams7, const int* cam_fixed, int n_cams, const double* cuboids10, const int* cub_fixed, int n_cuboids,
+                          const double* points3, const int* pt_fixed, int n_points);
+int cs_ba_append_edges_proj(cs_ba* ba, int n, const int* pt, const int* cam, const double* uv, const double* info4, const double* intr4, const double* huber);
+int cs_ba_append_edges_cuboid(cs_ba* ba, int n, const int* cam, const int* cub, const double* meas10, const double* info81);
+int cs_ba_append_edges_cuboid_proj(cs_ba* ba, int n, const int* cam, const int* cub, const double* meas4, const double* info16, const double* K9);
+int cs_ba_append_edges_odom(cs_ba* ba, int n, const int* cam_i, const int* cam_j, const double* meas7, const double* info36);
 int cs_ba_update(cs_ba* ba);                                 /* SparseOptimizer::update(x)              */
 int cs_ba_push(cs_ba* ba);                                   /* SparseOptimizer::push / pop / discardTop */
 int cs_ba_pop(cs_ba* ba);

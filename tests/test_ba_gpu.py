@@ -744,3 +744,63 @@ def test_hip_path_against_the_independent_projection_schur_fixture():
         P.set_edges_proj(g["e_pt"], g["e_cam"], g["e_uv"], g["e_info"], g["e_intr"], g["e_huber"])
         return P
     check_against_independent_fixture(make, 1e-10, 1e-7)
+
+
+def test_growing_graph_append_equals_rebuild_every_frame():
+    """The reference's pattern (main_obj.cpp:802-803): a frame is added -- a camera, the landmarks and cuboids it sees first, its
+    edges -- and optimize(5) runs on the grown graph.  cs_ba_append_* extends the handle (the estimates optimised on the device stay
+    there); the result of every step must equal a handle built from scratch from the previous step's states and all edges."""
+    pr = synth_ba.make_problem(n_cams=48, n_points=2400, n_cuboids=5, seed=3)
+    nc = len(pr["cams"])
+    first_pt = np.full(len(pr["points"]), nc); np.minimum.at(first_pt, pr["e_pt"], pr["e_cam"])
+    first_cub = np.full(len(pr["cuboids"]), nc); np.minimum.at(first_cub, pr["ce_cub"], pr["ce_cam"])
+    p_new = np.argsort(first_pt, kind="stable"); p_rank = np.empty_like(p_new); p_rank[p_new] = np.arange(len(p_new))
+    o_new = np.argsort(first_cub, kind="stable"); o_rank = np.empty_like(o_new); o_rank[o_new] = np.arange(len(o_new))
+    pts, pt_fixed, first_pt = pr["points"][p_new], pr["pt_fixed"][p_new], first_pt[p_new]
+    cubs, cub_fixed, first_cub = pr["cuboids"][o_new], pr["cub_fixed"][o_new], first_cub[o_new]
+    e_pt, ce_cub = p_rank[pr["e_pt"]], o_rank[pr["ce_cub"]]
+
+    def edges_of(lo, hi):      # edges that arrive with the cameras lo .. hi - 1 (an odometry edge with its later camera)
+        a = (pr["e_cam"] >= lo) & (pr["e_cam"] < hi)
+        c = (pr["ce_cam"] >= lo) & (pr["ce_cam"] < hi)
+        o = (np.maximum(pr["oe_i"], pr["oe_j"]) >= lo) & (np.maximum(pr["oe_i"], pr["oe_j"]) < hi)
+        return a, c, o
+
+    T0, steps = 24, 6
+    a, c, o = edges_of(0, T0)
+    n_p, n_o = int((first_pt < T0).sum()), int((first_cub < T0).sum())
+    G = capi.BaProblem(pr["cams"][:T0], pr["cam_fixed"][:T0], cubs[:n_o], cub_fixed[:n_o], pts[:n_p], pt_fixed[:n_p])
+    G.set_edges_proj(e_pt[a], pr["e_cam"][a], pr["e_uv"][a], pr["e_info"][a], pr["e_intr"][a], pr["e_huber"][a])
+    G.set_edges_cuboid(pr["ce_cam"][c], ce_cub[c], pr["ce_meas"][c], pr["ce_info"][c])
+    G.set_edges_odom(pr["oe_i"][o], pr["oe_j"][o], pr["oe_meas"][o], pr["oe_info"][o])
+    acc = {k: [v] for k, v in dict(ep=e_pt[a], ec=pr["e_cam"][a], uv=pr["e_uv"][a], inf=pr["e_info"][a], intr=pr["e_intr"][a], hub=pr["e_huber"][a], cc=pr["ce_cam"][c], co=ce_cub[c],
+                                   cm=pr["ce_meas"][c], ci=pr["ce_info"][c], oi=pr["oe_i"][o], oj=pr["oe_j"][o], om=pr["oe_meas"][o], oinf=pr["oe_info"][o]).items()}
+    assert G.optimize(5) >= 1
+    for t in range(T0, T0 + steps):
+        cams_prev, cubs_prev, pts_prev = G.state()
+        a, c, o = edges_of(t, t + 1)
+        n_p2, n_o2 = int((first_pt < t + 1).sum()), int((first_cub < t + 1).sum())
+        G.append_vertices(pr["cams"][t:t + 1], pr["cam_fixed"][t:t + 1], cubs[n_o:n_o2], cub_fixed[n_o:n_o2], pts[n_p:n_p2], pt_fixed[n_p:n_p2])
+        G.append_edges_proj(e_pt[a], pr["e_cam"][a], pr["e_uv"][a], pr["e_info"][a], pr["e_intr"][a], pr["e_huber"][a])
+        G.append_edges_cuboid(pr["ce_cam"][c], ce_cub[c], pr["ce_meas"][c], pr["ce_info"][c])
+        G.append_edges_odom(pr["oe_i"][o], pr["oe_j"][o], pr["oe_meas"][o], pr["oe_info"][o])
+        for k, v in dict(ep=e_pt[a], ec=pr["e_cam"][a], uv=pr["e_uv"][a], inf=pr["e_info"][a], intr=pr["e_intr"][a], hub=pr["e_huber"][a], cc=pr["ce_cam"][c], co=ce_cub[c],
+                         cm=pr["ce_meas"][c], ci=pr["ce_info"][c], oi=pr["oe_i"][o], oj=pr["oe_j"][o], om=pr["oe_meas"][o], oinf=pr["oe_info"][o]).items():
+            acc[k].append(v)
+        n1 = G.optimize(5)
+        cat = {k: np.concatenate(v) for k, v in acc.items()}
+        R = capi.BaProblem(np.concatenate([cams_prev, pr["cams"][t:t + 1]]), pr["cam_fixed"][:t + 1], np.concatenate([cubs_prev, cubs[n_o:n_o2]]), cub_fixed[:n_o2],
+                           np.concatenate([pts_prev, pts[n_p:n_p2]]), pt_fixed[:n_p2])
+        R.set_edges_proj(cat["ep"], cat["ec"], cat["uv"], cat["inf"], cat["intr"], cat["hub"])
+        R.set_edges_cuboid(cat["cc"], cat["co"], cat["cm"], cat["ci"])
+        R.set_edges_odom(cat["oi"], cat["oj"], cat["om"], cat["oinf"])
+        n2 = R.optimize(5)
+        # (the rebuilt handle re-normalises the camera quaternions it is handed, and the cuboid / odometry Jacobians are central
+        # differences with a 1e-9 step: last-bit differences of the states grow to ~1e-8 within five iterations)
+        assert n1 == n2 and np.array_equal(G.history()[2], R.history()[2]) and np.allclose(G.history()[0], R.history()[0], rtol=1e-7)
+        for x, y in zip(G.state(), R.state()):
+            assert x.shape == y.shape and np.abs(x - y).max() <= 1e-6 * max(1.0, np.abs(y).max())
+        R.close()
+        n_p, n_o = n_p2, n_o2
+    assert G.sizes()[0] > 0
+    G.close()
