@@ -45,7 +45,7 @@ def measure_traffic_live(args, n_unique):
         d = tempfile.mkdtemp(prefix="cs_pmc_", dir="/tmp")
         try:
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "2", "--warmup", "1", "--inflight", "1", "--depth", "1", "--steady-steps", "0", "--latency-calls", "0", "--ba", "none", "--no-cpu-baseline", "--no-edge", "--rp-frames", "0", "--no-measure-traffic",
+                   "--steps", "2", "--warmup", "1", "--inflight", "1", "--depth", "1", "--steady-steps", "0", "--latency-calls", "0", "--lines-images", "0", "--ba", "none", "--no-cpu-baseline", "--no-edge", "--rp-frames", "0", "--no-measure-traffic",
                    "--frames", str(args.frames), "--unique", str(n_unique)]
             subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp", "CS_BENCH_CHILD": "1"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             n, tot = 0, 0.0
@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=0, help="cut the batch into this many chunks of the two-slot host/GPU pipeline (0 = library default)")
     ap.add_argument("--no-edge", action="store_true", help="skip the distance-map front end (Canny + distance transform) timing")
     ap.add_argument("--rp-frames", type=int, default=100, help="frames of the roll/pitch-sampling stress variant (RP = 25 poses per box, the reference's class default); 0 = skip")
+    ap.add_argument("--lines-images", type=int, default=64, help="images per batch of the line-producer entry (0 = skip)")
     ap.add_argument("--rp-inflight", type=int, default=4, help="batches in flight of the roll/pitch-sampling stress variant")
     ap.add_argument("--latency-calls", type=int, default=200, help="calls per entry point of the single-call latency report (0 = skip)")
     ap.add_argument("--depth", type=int, default=2, help="batches per pipeline: the next one is submitted (packed + queued) before the current one is collected")
@@ -579,6 +580,43 @@ def main():
             lat_out["cpu_oracle_detect_cuboid_C2_ms"] = (time.perf_counter() - t1) * 1e3
         d_rp.close(); d_c2.close()
 
+    # ---- the segment producer in front of path A (line_lbd_detect::detect_filter_lines, EDLines): a batch of KITTI-sized images
+    lines_out = None
+    if rank == 0 and args.lines_images > 0:
+        rngq = np.random.default_rng(21)
+        Hq, Wq = int(uniq[0]["img_h"]), int(uniq[0]["img_w"])
+        yyq, xxq = np.mgrid[0:Hq, 0:Wq]
+        imgs = []
+        for _ in range(min(8, args.lines_images)):
+            im = np.full((Hq, Wq), 95.0)
+            for _ in range(30):
+                a = rngq.uniform(0, np.pi)
+                im += np.where((xxq - rngq.uniform(0, Wq)) * np.cos(a) + (yyq - rngq.uniform(0, Hq)) * np.sin(a) > 0, rngq.uniform(-45, 45), 0)
+            imgs.append(np.clip(im + rngq.normal(0, 4, im.shape), 0, 255).astype(np.uint8))
+        batch_imgs = [imgs[i % len(imgs)] for i in range(args.lines_images)]
+        dl = capi.Detector(capi.default_params(host_threads=host_threads), device=local_rank)
+        dl.detect_lines_batch(batch_imgs, 15.0)
+        t1 = time.perf_counter()
+        reps = 5
+        dev_ms = host_ms = 0.0
+        for _ in range(reps):
+            segs = dl.detect_lines_batch(batch_imgs, 15.0)
+            tq = dl.lines_timing(); dev_ms += tq["device_ms"]; host_ms += tq["host_ms"]
+        dtq = time.perf_counter() - t1
+        px = Hq * Wq * args.lines_images
+        lines_out = {"what": "cs_detect_lines_batch: EDLines (one octave, length >= 15) of %d images of %d x %d; Gaussian / Sobel / gradient / anchors on the device, routing + fitting + validation on the host pool" % (args.lines_images, Wq, Hq),
+                     "images_per_s": args.lines_images * reps / dtq, "segments_per_image": float(np.mean([len(x) for x in segs])),
+                     "device_ms_per_batch": dev_ms / reps, "host_stage_ms_per_batch": host_ms / reps,
+                     "maps_kernel": {"alg_bytes_per_batch": 9 * px, "GB/s": 9 * px / (dev_ms / reps * 1e-3) / 1e9, "frac_of_hbm_peak": 9 * px / (dev_ms / reps * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import edlines_oracle_py
+            t1, nq = time.perf_counter(), 0
+            while time.perf_counter() - t1 < 3.0:
+                edlines_oracle_py.detect_filter_lines(batch_imgs[nq % len(batch_imgs)], 15.0)
+                nq += 1
+            lines_out["cpu_oracle_images_per_s"] = nq / (time.perf_counter() - t1)
+        dl.close()
+
     if rank == 0:
         total_frames = args.frames * args.steps * world
         value = total_frames / elapsed
@@ -665,6 +703,8 @@ def main():
             out["roll_pitch_sampling_stress"] = rp_out
         if lat_out is not None:
             out["latency"] = lat_out
+        if lines_out is not None:
+            out["line_producer"] = lines_out
         print(json.dumps(out))
     for b_ in bats:
         b_.close()

@@ -16,7 +16,9 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <chrono>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -25,6 +27,9 @@
 void cs_set_error_ba(const std::string& s);
 extern "C" void* cs_internal_detector_stream(cs_detector* d);
 extern "C" int cs_internal_detector_device(cs_detector* d);
+extern "C" void** cs_internal_detector_lines_slot(cs_detector* d, void (*deleter)(void*));
+extern "C" void* cs_internal_detector_lines_mutex(cs_detector* d);
+extern "C" void cs_internal_detector_parallel(cs_detector* d, int n, void (*fn)(int, void*), void* ctx);
 
 namespace cs {
 struct LineMaps { short* g; short* dx; short* dy; unsigned char* dir; unsigned char* anchor; };
@@ -45,10 +50,10 @@ namespace {
 // EDLineDetector() :1515-1526 and BinaryDescriptor::Params() :110-117
 struct EdParams { int grad_thr = 80, anchor_thr = 8, scan = 2, min_len = 15, try_time = 6, skip = 2, max_outlier = 3; double fit_err = 1.6; };
 
-struct Maps {     // host copies of the device maps
+struct Maps {     // host copies of the device maps (pinned staging of the detector's scratch)
   int W = 0, H = 0;
-  std::vector<short> g, dx, dy;
-  std::vector<unsigned char> dir, anchor;
+  const short* g = nullptr; const short* dx = nullptr; const short* dy = nullptr;
+  const unsigned char* dir = nullptr; const unsigned char* anchor = nullptr;
   bool horizontal(unsigned x, unsigned y) const { return dir[(size_t)y * W + x] == 255; }
 };
 
@@ -255,16 +260,112 @@ struct Extractor {
   }
 };
 
+// Resident scratch of a detector's line producer: device maps and pinned host copies for `cap_images` images of `cap_pixels` pixels
+// (grows only).  A call used to pay three hipMalloc / hipFree pairs and five copies into pageable vectors.
+struct LinesScratch {
+  unsigned char* d_gray = nullptr; unsigned char* d_u8 = nullptr; short* d_s16 = nullptr;
+  char* h_pin = nullptr;           // per image: g, dx, dy (short each), dir, anchor (byte each) = 8 bytes per pixel
+  size_t cap = 0;                  // pixels x images
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double device_ms = 0, host_ms = 0, total_ms = 0;
+  int n_images = 0;
+};
+void lines_scratch_free(void* p) {
+  LinesScratch* S = (LinesScratch*)p;
+  if (!S) return;
+  if (S->d_gray) (void)hipFree(S->d_gray);
+  if (S->d_u8) (void)hipFree(S->d_u8);
+  if (S->d_s16) (void)hipFree(S->d_s16);
+  if (S->h_pin) (void)hipHostFree(S->h_pin);
+  if (S->ev0) (void)hipEventDestroy(S->ev0);
+  if (S->ev1) (void)hipEventDestroy(S->ev1);
+  delete S;
+}
+
+// the sequential half of one image: routing, fitting, validation, end points (all of it independent of the other images)
+int lines_host_stage(const Maps& M, const EdParams& P, double length_thres, float* lines4, int cap, int* n_lines) {
+  const int img_w = M.W, img_h = M.H;
+  const size_t N = (size_t)img_w * img_h;
+  *n_lines = 0;
+  // anchors in the reference's scan order: columns outermost (:1641-1643)
+  Router R(M);
+  Extractor X(M, P);
+  std::vector<Segment> segs;
+  Chain first, second, chain;
+  size_t n_anchor = 0;
+  for (int x = 1; x < img_w - 1; x += P.scan)
+    for (int y = 1; y < img_h - 1; y += P.scan) {
+      const size_t at = (size_t)y * img_w + x;
+      if (!M.anchor[at]) continue;
+      if (++n_anchor > N / 5) { cs_set_error_ba("cs_detect_lines_gray: more anchors than the reference's arrays hold"); return CS_ERR_CAPACITY; }
+      if (R.taken[at]) continue;
+      first.x.clear(); first.y.clear(); second.x.clear(); second.y.clear();
+      const bool hor = M.dir[at] == 255;
+      R.walk(x, y, hor ? RIGHT : DOWN, first);
+      R.taken[at] = 0;                                 // the anchor opens the second walk too
+      R.walk(x, y, hor ? LEFT : UP, second);
+      if ((int)(first.x.size() + second.x.size()) < P.min_len + 1) continue;     // too short: dropped, its pixels stay taken
+      chain.x.assign(first.x.rbegin(), first.x.rend()); chain.y.assign(first.y.rbegin(), first.y.rend());
+      chain.x.insert(chain.x.end(), second.x.begin() + 1, second.x.end()); chain.y.insert(chain.y.end(), second.y.begin() + 1, second.y.end());
+      X.run(chain, segs);
+    }
+  // OctaveKeyLines :862-875 (length), :1074-1143 (which end is the start), filter_lines: length > threshold
+  int n = 0;
+  for (const Segment& s : segs) {
+    const float ddx = std::fabs(s.x1 - s.x2), ddy = std::fabs(s.y1 - s.y2);
+    const float len = std::sqrt(ddx * ddx + ddy * ddy);
+    if (!(len > (float)length_thres)) continue;
+    const float ex = s.x2 - s.x1, ey = s.y2 - s.y1, dir = s.direction;
+    bool flip = false;
+    if (dir >= -0.75 * M_PI && dir < -0.25 * M_PI) flip = ey > 0;
+    if (dir >= -0.25 * M_PI && dir < 0.25 * M_PI) flip = flip || ex < 0;
+    if (dir >= 0.25 * M_PI && dir < 0.75 * M_PI) flip = flip || ey < 0;
+    if ((dir >= 0.75 * M_PI && dir < M_PI) || (dir >= -M_PI && dir < -0.75 * M_PI)) flip = flip || ex > 0;
+    if (n >= cap) { cs_set_error_ba("cs_detect_lines_gray: more segments than `cap`"); return CS_ERR_CAPACITY; }
+    float* o = lines4 + 4 * (size_t)n;
+    if (flip) { o[0] = s.x2; o[1] = s.y2; o[2] = s.x1; o[3] = s.y1; } else { o[0] = s.x1; o[1] = s.y1; o[2] = s.x2; o[3] = s.y2; }
+    n++;
+  }
+  *n_lines = n;
+  return CS_OK;
+}
+
+double ln_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 }  // namespace
 
-extern "C" int cs_detect_lines_gray(cs_detector* d, const unsigned char* gray, int img_w, int img_h, double length_thres, float* lines4, int cap, int* n_lines) {
-  if (!d || !gray || img_w < 3 || img_h < 3 || cap < 0 || (cap && !lines4) || !n_lines) return CS_ERR_INVALID_ARG;
+// n_images gray images of one size: the per-pixel stages of all of them on the device (one kernel per image, queued back to back, the
+// maps copied into pinned staging), then the sequential halves side by side on the detector's worker pool.  lines4[i] receives image
+// i's segments (cap rows of 4), n_lines[i] their number.
+extern "C" int cs_detect_lines_batch(cs_detector* d, const unsigned char* const* grays, int n_images, int img_w, int img_h, double length_thres, float* const* lines4, int cap,
+                                     int* n_lines) {
+  if (!d || n_images < 0 || (n_images && (!grays || !n_lines || (cap && !lines4))) || img_w < 3 || img_h < 3 || cap < 0) return CS_ERR_INVALID_ARG;
+  for (int i = 0; i < n_images; i++) if (!grays[i] || (cap && !lines4[i])) return CS_ERR_INVALID_ARG;
   try {
-    *n_lines = 0;
+    for (int i = 0; i < n_images; i++) n_lines[i] = 0;
+    if (n_images == 0) return CS_OK;
+    std::lock_guard<std::mutex> lk(*(std::mutex*)cs_internal_detector_lines_mutex(d));
     LN_TRY(hipSetDevice(cs_internal_detector_device(d)));
     hipStream_t st = (hipStream_t)cs_internal_detector_stream(d);
+    void** slot = cs_internal_detector_lines_slot(d, lines_scratch_free);
+    if (!*slot) *slot = new LinesScratch();
+    LinesScratch& S = *(LinesScratch*)*slot;
+    const double t_begin = ln_now_ms();
     const EdParams P;
-    const size_t N = (size_t)img_w * img_h;
+    const size_t N = (size_t)img_w * img_h, need = N * (size_t)n_images;
+    if (need > S.cap) {
+      if (S.d_gray) (void)hipFree(S.d_gray);
+      if (S.d_u8) (void)hipFree(S.d_u8);
+      if (S.d_s16) (void)hipFree(S.d_s16);
+      if (S.h_pin) (void)hipHostFree(S.h_pin);
+      S.d_gray = S.d_u8 = nullptr; S.d_s16 = nullptr; S.h_pin = nullptr; S.cap = 0;
+      LN_TRY(hipMalloc((void**)&S.d_gray, need));
+      LN_TRY(hipMalloc((void**)&S.d_u8, 2 * need));
+      LN_TRY(hipMalloc((void**)&S.d_s16, 3 * need * sizeof(short)));
+      LN_TRY(hipHostMalloc((void**)&S.h_pin, 8 * need));
+      S.cap = need;
+    }
+    if (!S.ev0) { LN_TRY(hipEventCreate(&S.ev0)); LN_TRY(hipEventCreate(&S.ev1)); }
     // getGaussianKernel(5, 1.0, CV_32F) rounded to 8-bit fixed point, as createSeparableLinearFilter does for 8-bit images
     int k[3];
     {
@@ -273,66 +374,60 @@ extern "C" int cs_detect_lines_gray(cs_detector* d, const unsigned char* gray, i
       sum = 1. / sum;
       for (int i = 0; i < 3; i++) k[i] = (int)std::nearbyint((double)(float)(cf[i] * sum) * 256.0);
     }
-    unsigned char* d_gray = nullptr; unsigned char* d_u8 = nullptr; short* d_s16 = nullptr;
-    struct Free { void* p[3]; ~Free() { for (void* q : p) if (q) (void)hipFree(q); } } guard{{nullptr, nullptr, nullptr}};
-    LN_TRY(hipMalloc((void**)&d_gray, N)); guard.p[0] = d_gray;
-    LN_TRY(hipMalloc((void**)&d_u8, 2 * N)); guard.p[1] = d_u8;
-    LN_TRY(hipMalloc((void**)&d_s16, 3 * N * sizeof(short))); guard.p[2] = d_s16;
-    LN_TRY(hipMemcpyAsync(d_gray, gray, N, hipMemcpyHostToDevice, st));
-    cs::LineMaps dm{d_s16, d_s16 + N, d_s16 + 2 * N, d_u8, d_u8 + N};
-    cs::launch_lines_maps(d_gray, img_w, img_h, dm, k, P.grad_thr, P.anchor_thr, P.scan, st);
-    LN_TRY(hipGetLastError());
-    Maps M; M.W = img_w; M.H = img_h;
-    M.g.resize(N); M.dx.resize(N); M.dy.resize(N); M.dir.resize(N); M.anchor.resize(N);
-    LN_TRY(hipMemcpyAsync(M.g.data(), dm.g, N * sizeof(short), hipMemcpyDeviceToHost, st));
-    LN_TRY(hipMemcpyAsync(M.dx.data(), dm.dx, N * sizeof(short), hipMemcpyDeviceToHost, st));
-    LN_TRY(hipMemcpyAsync(M.dy.data(), dm.dy, N * sizeof(short), hipMemcpyDeviceToHost, st));
-    LN_TRY(hipMemcpyAsync(M.dir.data(), dm.dir, N, hipMemcpyDeviceToHost, st));
-    LN_TRY(hipMemcpyAsync(M.anchor.data(), dm.anchor, N, hipMemcpyDeviceToHost, st));
-    LN_TRY(hipStreamSynchronize(st));
-    // anchors in the reference's scan order: columns outermost (:1641-1643)
-    Router R(M);
-    Extractor X(M, P);
-    std::vector<Segment> segs;
-    Chain first, second, chain;
-    size_t n_anchor = 0;
-    for (int x = 1; x < img_w - 1; x += P.scan)
-      for (int y = 1; y < img_h - 1; y += P.scan) {
-        const size_t at = (size_t)y * img_w + x;
-        if (!M.anchor[at]) continue;
-        if (++n_anchor > N / 5) { cs_set_error_ba("cs_detect_lines_gray: more anchors than the reference's arrays hold"); return CS_ERR_CAPACITY; }
-        if (R.taken[at]) continue;
-        first.x.clear(); first.y.clear(); second.x.clear(); second.y.clear();
-        const bool hor = M.dir[at] == 255;
-        R.walk(x, y, hor ? RIGHT : DOWN, first);
-        R.taken[at] = 0;                                 // the anchor opens the second walk too
-        R.walk(x, y, hor ? LEFT : UP, second);
-        if ((int)(first.x.size() + second.x.size()) < P.min_len + 1) continue;     // too short: dropped, its pixels stay taken
-        chain.x.assign(first.x.rbegin(), first.x.rend()); chain.y.assign(first.y.rbegin(), first.y.rend());
-        chain.x.insert(chain.x.end(), second.x.begin() + 1, second.x.end()); chain.y.insert(chain.y.end(), second.y.begin() + 1, second.y.end());
-        X.run(chain, segs);
-      }
-    // OctaveKeyLines :862-875 (length), :1074-1143 (which end is the start), filter_lines: length > threshold
-    int n = 0;
-    for (const Segment& s : segs) {
-      const float ddx = std::fabs(s.x1 - s.x2), ddy = std::fabs(s.y1 - s.y2);
-      const float len = std::sqrt(ddx * ddx + ddy * ddy);
-      if (!(len > (float)length_thres)) continue;
-      const float ex = s.x2 - s.x1, ey = s.y2 - s.y1, dir = s.direction;
-      bool flip = false;
-      if (dir >= -0.75 * M_PI && dir < -0.25 * M_PI) flip = ey > 0;
-      if (dir >= -0.25 * M_PI && dir < 0.25 * M_PI) flip = flip || ex < 0;
-      if (dir >= 0.25 * M_PI && dir < 0.75 * M_PI) flip = flip || ey < 0;
-      if ((dir >= 0.75 * M_PI && dir < M_PI) || (dir >= -M_PI && dir < -0.75 * M_PI)) flip = flip || ex > 0;
-      if (n >= cap) { cs_set_error_ba("cs_detect_lines_gray: more segments than `cap`"); return CS_ERR_CAPACITY; }
-      float* o = lines4 + 4 * (size_t)n;
-      if (flip) { o[0] = s.x2; o[1] = s.y2; o[2] = s.x1; o[3] = s.y1; } else { o[0] = s.x1; o[1] = s.y1; o[2] = s.x2; o[3] = s.y2; }
-      n++;
+    for (int i = 0; i < n_images; i++) LN_TRY(hipMemcpyAsync(S.d_gray + (size_t)i * N, grays[i], N, hipMemcpyHostToDevice, st));
+    LN_TRY(hipEventRecord(S.ev0, st));
+    for (int i = 0; i < n_images; i++) {
+      short* s16 = S.d_s16 + 3 * (size_t)i * N; unsigned char* u8 = S.d_u8 + 2 * (size_t)i * N;
+      cs::LineMaps dm{s16, s16 + N, s16 + 2 * N, u8, u8 + N};
+      cs::launch_lines_maps(S.d_gray + (size_t)i * N, img_w, img_h, dm, k, P.grad_thr, P.anchor_thr, P.scan, st);
     }
-    *n_lines = n;
+    LN_TRY(hipGetLastError());
+    LN_TRY(hipEventRecord(S.ev1, st));
+    for (int i = 0; i < n_images; i++) {     // per image: [g | dx | dy] (6 N bytes, contiguous on the device too) and [dir | anchor] (2 N bytes)
+      char* h = S.h_pin + 8 * (size_t)i * N;
+      LN_TRY(hipMemcpyAsync(h, S.d_s16 + 3 * (size_t)i * N, 6 * N, hipMemcpyDeviceToHost, st));
+      LN_TRY(hipMemcpyAsync(h + 6 * N, S.d_u8 + 2 * (size_t)i * N, 2 * N, hipMemcpyDeviceToHost, st));
+    }
+    LN_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    LN_TRY(hipEventElapsedTime(&ms, S.ev0, S.ev1));
+    S.device_ms = ms;
+    const double t_host = ln_now_ms();
+    struct Ctx { LinesScratch* S; int W, H; size_t N; const EdParams* P; double thr; float* const* lines4; int cap; int* n_lines; std::vector<int> rc; } ctx{&S, img_w, img_h, N, &P, length_thres, lines4, cap, n_lines, std::vector<int>(n_images, 0)};
+    auto one = [](int i, void* vp) {
+      Ctx& c = *(Ctx*)vp;
+      const char* h = c.S->h_pin + 8 * (size_t)i * c.N;
+      Maps M; M.W = c.W; M.H = c.H;
+      M.g = (const short*)h; M.dx = M.g + c.N; M.dy = M.dx + c.N; M.dir = (const unsigned char*)(h + 6 * c.N); M.anchor = M.dir + c.N;
+      try { c.rc[i] = lines_host_stage(M, *c.P, c.thr, c.lines4 ? c.lines4[i] : nullptr, c.cap, &c.n_lines[i]); }
+      catch (const std::exception&) { c.rc[i] = CS_ERR_CAPACITY; }
+    };
+    if (n_images == 1) one(0, &ctx);
+    else cs_internal_detector_parallel(d, n_images, one, &ctx);
+    S.host_ms = ln_now_ms() - t_host; S.total_ms = ln_now_ms() - t_begin; S.n_images = n_images;
+    for (int r : ctx.rc) if (r) return r;
     return CS_OK;
   } catch (const std::exception& ex) {
-    cs_set_error_ba(std::string("cs_detect_lines_gray: ") + ex.what());
+    cs_set_error_ba(std::string("cs_detect_lines_batch: ") + ex.what());
     return CS_ERR_CAPACITY;
   }
+}
+
+// timing of the last cs_detect_lines_batch / cs_detect_lines_gray of this detector: the device kernels, the host stage (wall), the whole call
+extern "C" int cs_detect_lines_last_timing(cs_detector* d, double* device_ms, double* host_ms, double* total_ms) {
+  if (!d) return CS_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(*(std::mutex*)cs_internal_detector_lines_mutex(d));
+  void** slot = cs_internal_detector_lines_slot(d, lines_scratch_free);
+  const LinesScratch* S = (const LinesScratch*)*slot;
+  if (!S) return CS_ERR_NOT_RUN;
+  if (device_ms) *device_ms = S->device_ms;
+  if (host_ms) *host_ms = S->host_ms;
+  if (total_ms) *total_ms = S->total_ms;
+  return CS_OK;
+}
+
+extern "C" int cs_detect_lines_gray(cs_detector* d, const unsigned char* gray, int img_w, int img_h, double length_thres, float* lines4, int cap, int* n_lines) {
+  if (!d || !gray || img_w < 3 || img_h < 3 || cap < 0 || (cap && !lines4) || !n_lines) return CS_ERR_INVALID_ARG;
+  float* l4 = lines4;
+  return cs_detect_lines_batch(d, &gray, 1, img_w, img_h, length_thres, &l4, cap, n_lines);
 }

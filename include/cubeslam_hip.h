@@ -154,6 +154,12 @@ int cs_detect_cuboids_gray(cs_detector* d, const cs_frame_desc* frame, const uns
  * rows of linesmat_out, start / end in the reference's order); *n_lines = rows written.  Per-pixel stages on the device, the
  * routing / fitting / validation chain on the host.                                                                        */
 int cs_detect_lines_gray(cs_detector* d, const unsigned char* gray, int img_w, int img_h, double length_thres, float* lines4, int cap, int* n_lines);
+/* The same for n_images gray images of one size: the per-pixel stages of all of them on the device, the sequential halves side by
+ * side on the detector's worker pool.  lines4[i]: image i's segments (cap rows of 4 floats), n_lines[i]: their number.           */
+int cs_detect_lines_batch(cs_detector* d, const unsigned char* const* grays, int n_images, int img_w, int img_h, double length_thres,
+                          float* const* lines4, int cap, int* n_lines);
+/* Timing (ms) of this detector's last line-detection call: the device kernels, the host stage (wall), the whole call.            */
+int cs_detect_lines_last_timing(cs_detector* d, double* device_ms, double* host_ms, double* total_ms);
 
 /* Batched form for throughput: cs_batch_create() copies the frames' inputs into HBM (maps, lines,
  * boxes, cameras); cs_batch_run() is the hot path proper -- resident inputs in, cuboids out.

@@ -64,3 +64,34 @@ def test_flat_and_noise_images():
     noise = np.random.default_rng(5).integers(0, 256, (240, 320), dtype=np.uint8)
     assert np.array_equal(det.detect_lines(noise), L.detect_filter_lines(noise))
     det.close()
+
+
+def test_batch_entry_point_equals_the_single_image_calls():
+    """cs_detect_lines_batch: the per-pixel stages of all images on the device, the sequential halves on the worker pool -- the same
+    segments as one cs_detect_lines_gray call per image (which is the oracle's output), also on a second call that reuses the scratch
+    and after a call with a different image size."""
+    rng = np.random.default_rng(5)
+    def image(h, w, seed):
+        r = np.random.default_rng(seed)
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.full((h, w), 100.0)
+        for _ in range(14):
+            a = r.uniform(0, np.pi)
+            img += np.where((xx - r.uniform(0, w)) * np.cos(a) + (yy - r.uniform(0, h)) * np.sin(a) > 0, r.uniform(-60, 60), 0)
+        return np.clip(img + r.normal(0, 3, img.shape), 0, 255).astype(np.uint8)
+    det = capi.Detector(capi.default_params())
+    grays = [image(200, 311, 40 + i) for i in range(9)]
+    single = [det.detect_lines(g, 15.0) for g in grays]
+    for _ in range(2):
+        got = det.detect_lines_batch(grays, 15.0)
+        assert len(got) == len(single)
+        for a, b in zip(got, single):
+            assert a.shape == b.shape and np.array_equal(a, b) and len(b) > 0
+    small = image(97, 120, 77)
+    assert np.array_equal(det.detect_lines_batch([small], 15.0)[0], det.detect_lines(small, 15.0))
+    got = det.detect_lines_batch(grays[:3], 15.0)
+    for a, b in zip(got, single[:3]):
+        assert np.array_equal(a, b)
+    t = det.lines_timing()
+    assert t["device_ms"] > 0 and t["total_ms"] >= t["host_ms"] > 0
+    det.close()

@@ -1,7 +1,7 @@
 # edge front end: parity tests + the bench's edge line + per-kernel times (run on the GPU box)
 timeout 200 python -m pytest tests/test_edge_gpu.py -q -m gpu -x 2>&1 | tail -2
 export TMPDIR=/tmp; R=$(pwd); cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kt_edge -o kt -- python $R/bench.py --steps 2 --warmup 1 --ba none --no-cpu-baseline --rp-frames 0 --latency-calls 0 --no-measure-traffic > $R/gpurun_out/kt_edge.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kt_edge -o kt -- python $R/bench.py --steps 2 --warmup 1 --ba none --no-cpu-baseline --rp-frames 0 --latency-calls 0 --lines-images 0 --no-measure-traffic > $R/gpurun_out/kt_edge.log 2>&1
 cd $R
 python - <<PY
 import csv, json

@@ -2,7 +2,7 @@
 # SQ counter pass over the bundle-adjustment kernels (one rocprofv3 run, kernel-trace + pmc only):  tools/pmc_ba.sh <tag>
 # -> gpurun_out/pmc_<tag>_ba.csv: per kernel SQ_INSTS_VALU_MFMA_F64 (matrix-core issues), SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES, waves ...
 tag=${1:-x}; R=$(pwd); export TMPDIR=/tmp; cd /tmp
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/pmc_${tag}_ba -o pmc -- python $R/bench.py --no-measure-traffic --steps 1 --warmup 1 --frames 50 --no-cpu-baseline --no-edge --rp-frames 0 --latency-calls 0 --ba-iters 4 > $R/gpurun_out/pmc_${tag}_ba.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/pmc_${tag}_ba -o pmc -- python $R/bench.py --no-measure-traffic --steps 1 --warmup 1 --frames 50 --no-cpu-baseline --no-edge --rp-frames 0 --latency-calls 0 --lines-images 0 --ba-iters 4 > $R/gpurun_out/pmc_${tag}_ba.log 2>&1
 cd $R
 python - <<PY > gpurun_out/pmc_${tag}_ba.csv
 import csv, glob, collections
