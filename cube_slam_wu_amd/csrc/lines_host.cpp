@@ -33,7 +33,7 @@ extern "C" void cs_internal_detector_parallel(cs_detector* d, int n, void (*fn)(
 
 namespace cs {
 struct LineMaps { short* g; short* dx; short* dy; unsigned char* dir; unsigned char* anchor; };
-void launch_lines_maps(const unsigned char* gray, int W, int H, const LineMaps& m, const int k[3], int grad_thr, int anchor_thr, int scan, hipStream_t st);
+void launch_lines_maps(const unsigned char* gray, int W, int H, const LineMaps& m, const int k[3], int grad_thr, int anchor_thr, int scan, hipStream_t st, int n_images);
 }  // namespace cs
 
 namespace {
@@ -376,29 +376,27 @@ extern "C" int cs_detect_lines_batch(cs_detector* d, const unsigned char* const*
     }
     for (int i = 0; i < n_images; i++) LN_TRY(hipMemcpyAsync(S.d_gray + (size_t)i * N, grays[i], N, hipMemcpyHostToDevice, st));
     LN_TRY(hipEventRecord(S.ev0, st));
-    for (int i = 0; i < n_images; i++) {
-      short* s16 = S.d_s16 + 3 * (size_t)i * N; unsigned char* u8 = S.d_u8 + 2 * (size_t)i * N;
-      cs::LineMaps dm{s16, s16 + N, s16 + 2 * N, u8, u8 + N};
-      cs::launch_lines_maps(S.d_gray + (size_t)i * N, img_w, img_h, dm, k, P.grad_thr, P.anchor_thr, P.scan, st);
+    {   // one launch for the whole batch (blockIdx.z = image)
+      cs::LineMaps dm{S.d_s16, S.d_s16 + N, S.d_s16 + 2 * N, S.d_u8, S.d_u8 + N};
+      cs::launch_lines_maps(S.d_gray, img_w, img_h, dm, k, P.grad_thr, P.anchor_thr, P.scan, st, n_images);
     }
     LN_TRY(hipGetLastError());
     LN_TRY(hipEventRecord(S.ev1, st));
-    for (int i = 0; i < n_images; i++) {     // per image: [g | dx | dy] (6 N bytes, contiguous on the device too) and [dir | anchor] (2 N bytes)
-      char* h = S.h_pin + 8 * (size_t)i * N;
-      LN_TRY(hipMemcpyAsync(h, S.d_s16 + 3 * (size_t)i * N, 6 * N, hipMemcpyDeviceToHost, st));
-      LN_TRY(hipMemcpyAsync(h + 6 * N, S.d_u8 + 2 * (size_t)i * N, 2 * N, hipMemcpyDeviceToHost, st));
-    }
+    // two copies for the whole batch: the short planes ([g | dx | dy] per image, 6 N bytes) and the byte planes ([dir | anchor], 2 N)
+    char* const h_s16 = S.h_pin;
+    char* const h_u8 = S.h_pin + 6 * N * (size_t)n_images;
+    LN_TRY(hipMemcpyAsync(h_s16, S.d_s16, 6 * N * (size_t)n_images, hipMemcpyDeviceToHost, st));
+    LN_TRY(hipMemcpyAsync(h_u8, S.d_u8, 2 * N * (size_t)n_images, hipMemcpyDeviceToHost, st));
     LN_TRY(hipStreamSynchronize(st));
     float ms = 0;
     LN_TRY(hipEventElapsedTime(&ms, S.ev0, S.ev1));
     S.device_ms = ms;
     const double t_host = ln_now_ms();
-    struct Ctx { LinesScratch* S; int W, H; size_t N; const EdParams* P; double thr; float* const* lines4; int cap; int* n_lines; std::vector<int> rc; } ctx{&S, img_w, img_h, N, &P, length_thres, lines4, cap, n_lines, std::vector<int>(n_images, 0)};
+    struct Ctx { const char* h_s16; const char* h_u8; int W, H; size_t N; const EdParams* P; double thr; float* const* lines4; int cap; int* n_lines; std::vector<int> rc; } ctx{h_s16, h_u8, img_w, img_h, N, &P, length_thres, lines4, cap, n_lines, std::vector<int>(n_images, 0)};
     auto one = [](int i, void* vp) {
       Ctx& c = *(Ctx*)vp;
-      const char* h = c.S->h_pin + 8 * (size_t)i * c.N;
       Maps M; M.W = c.W; M.H = c.H;
-      M.g = (const short*)h; M.dx = M.g + c.N; M.dy = M.dx + c.N; M.dir = (const unsigned char*)(h + 6 * c.N); M.anchor = M.dir + c.N;
+      M.g = (const short*)(c.h_s16 + 6 * c.N * (size_t)i); M.dx = M.g + c.N; M.dy = M.dx + c.N; M.dir = (const unsigned char*)(c.h_u8 + 2 * c.N * (size_t)i); M.anchor = M.dir + c.N;
       try { c.rc[i] = lines_host_stage(M, *c.P, c.thr, c.lines4 ? c.lines4[i] : nullptr, c.cap, &c.n_lines[i]); }
       catch (const std::exception&) { c.rc[i] = CS_ERR_CAPACITY; }
     };

@@ -34,8 +34,15 @@ __device__ __forceinline__ int lines_div4_half_even(int v) {   // cvRound(v * 0.
 
 enum { LT = 32, LG = LT + 8, LB = LT + 4, LS = LT + 2 };
 
+// blockIdx.z = image of a batch: image i's gray at gray + i N, its maps at m.{g,dx,dy} + 3 i N (the three short planes of an image are
+// adjacent) and m.{dir,anchor} + 2 i N
 __global__ __launch_bounds__(256) void lines_maps_kernel(const unsigned char* __restrict__ gray, int W, int H, LineMaps m, int k0, int k1, int k2,
                                                          int grad_thr, int anchor_thr, int scan) {
+  {
+    const size_t N = (size_t)W * H, img = blockIdx.z;
+    gray += img * N;
+    m.g += 3 * img * N; m.dx += 3 * img * N; m.dy += 3 * img * N; m.dir += 2 * img * N; m.anchor += 2 * img * N;
+  }
   __shared__ unsigned char sg[LG][LG + 4];     // gray, tile origin - 4
   __shared__ int rs[LG][LB];                   // row pass of the blur
   __shared__ unsigned char sb[LB][LB + 4];     // blurred, tile origin - 2
@@ -89,8 +96,14 @@ __global__ __launch_bounds__(256) void lines_maps_kernel(const unsigned char* __
   }
 }
 
-void launch_lines_maps(const unsigned char* gray, int W, int H, const LineMaps& m, const int k[3], int grad_thr, int anchor_thr, int scan, hipStream_t st) {
-  hipLaunchKernelGGL(lines_maps_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT), dim3(256), 0, st, gray, W, H, m, k[0], k[1], k[2], grad_thr, anchor_thr, scan);
+// n_images images laid out back to back (gray: N bytes each; m: image 0's planes, image i's at the strides lines_maps_kernel states)
+void launch_lines_maps(const unsigned char* gray, int W, int H, const LineMaps& m, const int k[3], int grad_thr, int anchor_thr, int scan, hipStream_t st, int n_images) {
+  for (int i0 = 0; i0 < n_images; i0 += 65535) {      // gridDim.z limit
+    const int nz = n_images - i0 < 65535 ? n_images - i0 : 65535;
+    const size_t N = (size_t)W * H;
+    LineMaps mi{m.g + 3 * (size_t)i0 * N, m.dx + 3 * (size_t)i0 * N, m.dy + 3 * (size_t)i0 * N, m.dir + 2 * (size_t)i0 * N, m.anchor + 2 * (size_t)i0 * N};
+    hipLaunchKernelGGL(lines_maps_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, nz), dim3(256), 0, st, gray + (size_t)i0 * N, W, H, mi, k[0], k[1], k[2], grad_thr, anchor_thr, scan);
+  }
 }
 
 }  // namespace cs
