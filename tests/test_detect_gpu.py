@@ -329,20 +329,22 @@ def test_submit_collect_two_batches_of_one_detector_in_flight():
     det.close()
 
 
-def test_roll_pitch_rounds_queued_at_once_equal_the_round_by_round_path():
+@pytest.mark.parametrize("heights,step", [(0, 0.5), (1, 3.0)])
+def test_roll_pitch_rounds_queued_at_once_equal_the_round_by_round_path(heights, step):
     """The lean roll/pitch path (every yaw list of a frame laid down up front, the carried yaw picked on the device, all rounds queued
     at once, tie boxes ranked exactly from columns saved on the device) against the round-by-round path with a host decision after
     every box round: byte-identical records at the 0.5 degree sweep (25 camera poses per box: ~70 k valid proposals per frame), with
     ragged frames (no boxes, one box, no lines), a frame whose maps are all zero (every box a tie: the host ranks it, and its carried
-    yaw has to match), two cuboids per box, on a second run that reuses the slots, and through submit / collect."""
-    uniq = [synth.make_frame(8900 + s, n_boxes=1 + s % 8, n_lines=200 + 25 * s) for s in range(10)]
+    yaw has to match), two cuboids per box, with and without height sampling (three jobs per box), on a second run that reuses the
+    slots, and through submit / collect."""
+    uniq = [synth.make_frame(8900 + s, n_boxes=1 + s % 8, n_lines=200 + 25 * s, sample_height=bool(heights)) for s in range(10)]
     empty = dict(uniq[0]); empty["boxes"] = np.zeros((0, 5)); empty["maps"] = []
     nolines = dict(uniq[3]); nolines["lines"] = np.zeros((0, 4))
-    tie = synth.make_frame(8950, n_boxes=3, n_lines=150)
+    tie = synth.make_frame(8950, n_boxes=3, n_lines=150, sample_height=bool(heights))
     tie["maps"] = [[np.zeros_like(m) for m in mm] for mm in tie["maps"]]
     frames = [uniq[i % 10] for i in range(24)]
     frames[5] = empty; frames[6] = nolines; frames[11] = tie; frames[23] = empty
-    det = capi.Detector(capi.default_params(whether_sample_cam_roll_pitch=1, yaw_step_deg=0.5, max_cuboid_num=2))
+    det = capi.Detector(capi.default_params(whether_sample_cam_roll_pitch=1, whether_sample_bbox_height=heights, yaw_step_deg=step, max_cuboid_num=2))
     ref = capi.Batch(det, frames, force_no_pipeline=True); ref.run()
     lean = capi.Batch(det, frames)
     for mode in ("run", "run", "submit"):
@@ -353,7 +355,7 @@ def test_roll_pitch_rounds_queued_at_once_equal_the_round_by_round_path():
         assert lean.raw_out_bytes() == ref.raw_out_bytes() and lean.counts_bytes() == ref.counts_bytes()
     tl, tr = lean.timing(), ref.timing()
     assert tl["n_valid"] == tr["n_valid"] and tl["n_fallback_boxes"] >= 3 and tl["rank_host_ms"] == 0
-    assert tl["cand_kernel_launches"] == tr["cand_kernel_launches"] == 8      # eight box rounds either way
+    assert tl["cand_kernel_launches"] == tr["cand_kernel_launches"] == 8      # eight box rounds either way (three height samples per box: one job each)
     print("lean %.2f ms (fallback boxes %d, frames redone %d), round by round %.2f ms" % (tl["total_ms"], tl["n_fallback_boxes"], tl["n_redo_frames"], tr["total_ms"]))
     lean.close(); ref.close(); det.close()
 
