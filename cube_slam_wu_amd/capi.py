@@ -62,7 +62,7 @@ class CsDetectTiming(C.Structure):
 DECLARED_SYMBOLS = [
     "cs_last_error", "cs_device_count", "cs_detect_default_params", "cs_box_rois", "cs_cam_euler_zyx", "cs_detector_create",
     "cs_detector_destroy", "cs_detect_cuboids", "cs_batch_create", "cs_batch_max_boxes", "cs_batch_run", "cs_batch_submit", "cs_batch_collect",
-    "cs_bgr_to_gray", "cs_edge_distance_maps", "cs_edge_distance_maps_multi", "cs_detect_cuboids_gray", "cs_batch_create_gray", "cs_batch_destroy", "cs_batch_last_timing", "cs_batch_debug_candidates", "cs_batch_debug_kept", "cs_batch_set_debug", "cs_batch_set_pipeline_chunks", "cs_detect_lines_gray", "cs_detect_lines_batch", "cs_detect_lines_last_timing",
+    "cs_bgr_to_gray", "cs_edge_distance_maps", "cs_edge_distance_maps_multi", "cs_detect_cuboids_gray", "cs_batch_create_gray", "cs_batch_destroy", "cs_batch_last_timing", "cs_batch_debug_candidates", "cs_batch_debug_kept", "cs_batch_set_debug", "cs_batch_set_pipeline_chunks", "cs_detect_lines_gray", "cs_detect_lines_batch", "cs_detect_lines_last_timing", "cs_detect_lsd_gray", "cs_detect_lsd_batch", "cs_detect_lsd_last_timing",
 ]
 
 _lib = None
@@ -166,19 +166,20 @@ class Detector:
             raise RuntimeError("cs_edge_distance_maps_multi failed (%d): %s" % (rc, last_error()))
         return ms.value
 
-    def detect_lines(self, gray, length_thres=15.0, cap=20000):
-        """cs_detect_lines_gray: line_lbd_detect::detect_filter_lines (EDLines, one octave) -> (n, 4) float32 x1 y1 x2 y2."""
+    def detect_lines(self, gray, length_thres=15.0, cap=20000, use_lsd=False):
+        """cs_detect_lines_gray / cs_detect_lsd_gray: line_lbd_detect::detect_filter_lines (EDLines, or LSD with the reference's
+        use_LSD flag; one octave) -> (n, 4) float32 x1 y1 x2 y2."""
         gray = np.ascontiguousarray(gray, np.uint8)
         out = np.zeros((cap, 4), np.float32)
         n = C.c_int()
-        rc = lib().cs_detect_lines_gray(self.h, gray.ctypes.data_as(C.POINTER(C.c_ubyte)), int(gray.shape[1]), int(gray.shape[0]), C.c_double(length_thres),
+        rc = (lib().cs_detect_lsd_gray if use_lsd else lib().cs_detect_lines_gray)(self.h, gray.ctypes.data_as(C.POINTER(C.c_ubyte)), int(gray.shape[1]), int(gray.shape[0]), C.c_double(length_thres),
                                         out.ctypes.data_as(C.POINTER(C.c_float)), int(cap), C.byref(n))
         if rc != 0:
-            raise RuntimeError("cs_detect_lines_gray failed (%d): %s" % (rc, last_error()))
+            raise RuntimeError("%s failed (%d): %s" % ("cs_detect_lsd_gray" if use_lsd else "cs_detect_lines_gray", rc, last_error()))
         return out[:n.value].copy()
 
-    def detect_lines_batch(self, grays, length_thres=15.0, cap=20000):
-        """cs_detect_lines_batch: images of one size -> list of (n_i, 4) float32 arrays."""
+    def detect_lines_batch(self, grays, length_thres=15.0, cap=20000, use_lsd=False):
+        """cs_detect_lines_batch / cs_detect_lsd_batch: images of one size -> list of (n_i, 4) float32 arrays."""
         grays = [np.ascontiguousarray(g, np.uint8) for g in grays]
         n = len(grays)
         H, W = grays[0].shape
@@ -186,14 +187,14 @@ class Detector:
         cnt = np.zeros(n, np.int32)
         gp = (C.POINTER(C.c_ubyte) * n)(*[g.ctypes.data_as(C.POINTER(C.c_ubyte)) for g in grays])
         op = (C.POINTER(C.c_float) * n)(*[out[i].ctypes.data_as(C.POINTER(C.c_float)) for i in range(n)])
-        rc = lib().cs_detect_lines_batch(self.h, gp, n, int(W), int(H), C.c_double(length_thres), op, int(cap), cnt.ctypes.data_as(C.POINTER(C.c_int)))
+        rc = (lib().cs_detect_lsd_batch if use_lsd else lib().cs_detect_lines_batch)(self.h, gp, n, int(W), int(H), C.c_double(length_thres), op, int(cap), cnt.ctypes.data_as(C.POINTER(C.c_int)))
         if rc != 0:
-            raise RuntimeError("cs_detect_lines_batch failed (%d): %s" % (rc, last_error()))
+            raise RuntimeError("%s failed (%d): %s" % ("cs_detect_lsd_batch" if use_lsd else "cs_detect_lines_batch", rc, last_error()))
         return [out[i, :cnt[i]].copy() for i in range(n)]
 
-    def lines_timing(self):
+    def lines_timing(self, use_lsd=False):
         a, b, c = C.c_double(), C.c_double(), C.c_double()
-        rc = lib().cs_detect_lines_last_timing(self.h, C.byref(a), C.byref(b), C.byref(c))
+        rc = (lib().cs_detect_lsd_last_timing if use_lsd else lib().cs_detect_lines_last_timing)(self.h, C.byref(a), C.byref(b), C.byref(c))
         if rc != 0:
             raise RuntimeError("cs_detect_lines_last_timing failed (%d)" % rc)
         return {"device_ms": a.value, "host_ms": b.value, "total_ms": c.value}

@@ -384,6 +384,8 @@ struct cs_detector {
   // the line-segment producer's resident scratch (lines_host.cpp owns its type; freed through lines_free)
   void* lines_scratch = nullptr;
   void (*lines_free)(void*) = nullptr;
+  void* lsd_scratch = nullptr;          // the same for the LSD branch (lsd_host.cpp)
+  void (*lsd_free)(void*) = nullptr;
   std::mutex lines_mu;
 };
 
@@ -607,6 +609,7 @@ int cs_cam_euler_zyx(const double T_wc[16], double euler3[3]) {
 void* cs_internal_detector_stream(cs_detector* d) { return (void*)d->stream; }
 // lines_host.cpp: the producer's scratch slot, its lock, and the detector's worker pool
 void** cs_internal_detector_lines_slot(cs_detector* d, void (*deleter)(void*)) { d->lines_free = deleter; return &d->lines_scratch; }
+void** cs_internal_detector_lsd_slot(cs_detector* d, void (*deleter)(void*)) { d->lsd_free = deleter; return &d->lsd_scratch; }
 void* cs_internal_detector_lines_mutex(cs_detector* d) { return (void*)&d->lines_mu; }
 void cs_internal_detector_parallel(cs_detector* d, int n, void (*fn)(int, void*), void* ctx) { d->pool->run(n, [&](int i) { fn(i, ctx); }); }
 int cs_internal_detector_device(cs_detector* d) { return d->device; }
@@ -660,6 +663,7 @@ void cs_detector_destroy(cs_detector* d) {
   (void)hipSetDevice(d->device);
   if (d->single) { cs_batch_destroy(d->single); d->single = nullptr; }
   if (d->lines_scratch && d->lines_free) { d->lines_free(d->lines_scratch); d->lines_scratch = nullptr; }
+  if (d->lsd_scratch && d->lsd_free) { d->lsd_free(d->lsd_scratch); d->lsd_scratch = nullptr; }
   for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
   if (d->stream) (void)hipStreamDestroy(d->stream);
   if (d->stream2) (void)hipStreamDestroy(d->stream2);

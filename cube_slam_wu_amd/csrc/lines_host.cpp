@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/cubeslam_hip.h"
+#include "cs_nfa.h"
 
 void cs_set_error_ba(const std::string& s);
 extern "C" void* cs_internal_detector_stream(cs_detector* d);
@@ -122,40 +123,8 @@ struct NormalEq {
   }
 };
 
-// ---- number of false alarms (descriptor.hpp:650-848) ------------------------------------------------------------------------
-double lgamma_lanczos(double x) {
-  static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
-  double a = (x + 0.5) * std::log(x + 5.5) - (x + 5.5), b = 0.0;
-  for (int n = 0; n < 7; n++) { a -= std::log(x + (double)n); b += q[n] * std::pow(x, (double)n); }
-  return a + std::log(b);
-}
-double lgamma_windschitl(double x) { return 0.918938533204673 + (x - 0.5) * std::log(x) - x + 0.5 * x * std::log(x * std::sinh(1 / x) + 1 / (810.0 * std::pow(x, 6.0))); }
-double lgamma_pick(double x) { return x > 15.0 ? lgamma_windschitl(x) : lgamma_lanczos(x); }
-bool nearly_equal(double a, double b) {
-  if (a == b) return true;
-  double m = std::max(std::fabs(a), std::fabs(b));
-  if (m < DBL_MIN) m = DBL_MIN;
-  return std::fabs(a - b) / m <= 100.0 * DBL_EPSILON;
-}
-double minus_log10_nfa(int n, int k, double p, double logNT) {
-  if (n == 0 || k == 0) return -logNT;
-  if (n == k) return -logNT - (double)n * std::log10(p);
-  const double ratio = p / (1.0 - p);
-  const double log_first = lgamma_pick((double)n + 1.0) - lgamma_pick((double)k + 1.0) - lgamma_pick((double)(n - k) + 1.0) + (double)k * std::log(p) + (double)(n - k) * std::log(1.0 - p);
-  double term = std::exp(log_first);
-  if (nearly_equal(term, 0.0)) return ((double)k > (double)n * p) ? -log_first / 2.30258509299404568402 - logNT : -logNT;
-  double tail = term;
-  for (int i = k + 1; i <= n; i++) {
-    const double bin = (double)(n - i + 1) / (double)i, mult = bin * ratio;
-    term *= mult;
-    tail += term;
-    if (bin < 1.0) {
-      const double err = term * ((1.0 - std::pow(mult, (double)(n - i + 1))) / (1.0 - mult) - 1.0);
-      if (err < 0.1 * std::fabs(-std::log10(tail) - logNT) * tail) break;
-    }
-  }
-  return -std::log10(tail) - logNT;
-}
+// number of false alarms (descriptor.hpp:650-848): cs_nfa.h, with the log-gamma first term
+double minus_log10_nfa(int n, int k, double p, double logNT) { return cs::minus_log10_nfa(n, k, p, logNT, true); }
 
 struct Segment { float x1, y1, x2, y2, direction; };
 

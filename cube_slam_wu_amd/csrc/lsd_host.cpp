@@ -1,0 +1,471 @@
+// lsd_host.cpp -- the LSD branch of the line-segment producer behind the C ABI:
+//   line_lbd_detect::detect_filter_lines(gray, lines) with use_LSD = true     line_lbd/class/line_lbd_allclass.cpp:130-150,199-235
+//   LSDDetector::detectImpl, one octave (clamp, border filter, length)         line_lbd/libs/LSDDetector.cpp:55-105,154-260
+//   LineSegmentDetectorImpl::flsd, LSD_REFINE_ADV with the default parameters  line_lbd/libs/lsd.cpp:402-1148
+// The per-pixel stages (double Gaussian blur, resize by 0.8, gradient modulus and level-line angle) run on the device
+// (csrc/lsd_kernels.hip) and come back as two double planes per image; what depends on the order pixels are visited in stays here:
+//   region growing (:644-692)      seeds in raster order (the reference fills a gradient-sorted list and then never follows it),
+//                                  8-neighbourhood, the region angle re-estimated from float cos / sin sums after every pixel
+//   rectangle fit  (:694-802)      modulus-weighted centre, inertia axis through fastAtan2, extents
+//   refinement     (:804-905)      angle tolerance from the spread near the seed, then the radius cut until density >= 0.7
+//   validation     (:907-1096)     rect_improve's five search loops over rect_nfa -- with its integer slopes and the x-for-y slip in
+//                                  the second slopes -- and the binomial tail of cs_nfa.h (first term n + 1, as :1107 has it)
+// The arithmetic follows the reference operation for operation; tests/test_lines_gpu.py holds the result to the CPU restatement
+// (itself pinned on the reference's saved segments) bit for bit.  No CPU fallback for the device stages.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/cubeslam_hip.h"
+#include "cs_nfa.h"
+
+void cs_set_error_ba(const std::string& s);
+extern "C" void* cs_internal_detector_stream(cs_detector* d);
+extern "C" int cs_internal_detector_device(cs_detector* d);
+extern "C" void** cs_internal_detector_lsd_slot(cs_detector* d, void (*deleter)(void*));
+extern "C" void* cs_internal_detector_lines_mutex(cs_detector* d);
+extern "C" void cs_internal_detector_parallel(cs_detector* d, int n, void (*fn)(int, void*), void* ctx);
+
+namespace cs {
+struct LsdGauss { double k[7]; };
+struct LsdScaleTab { const int* xo; const float* xa; const int* yo; const float* ya; };
+void launch_lsd_maps(const unsigned char* gray, int W, int H, int Ws, int Hs, const LsdGauss& G, const LsdScaleTab& T, double rho, double* blur, double* out, hipStream_t st, int n_images);
+}  // namespace cs
+
+namespace {
+
+#define LSD_TRY(expr)                                                          \
+  do {                                                                         \
+    hipError_t _e = (expr);                                                    \
+    if (_e != hipSuccess) {                                                    \
+      cs_set_error_ba(std::string(#expr) + ": " + hipGetErrorString(_e));      \
+      return CS_ERR_HIP;                                                       \
+    }                                                                          \
+  } while (0)
+
+// createLineSegmentDetector(LSD_REFINE_ADV) defaults (lsd.cpp:185-187) and the constants of :53-64
+constexpr double kScale = 0.8, kSigmaScale = 0.6, kQuant = 2.0, kAngTh = 22.5, kLogEps = 0.0, kDensityTh = 0.7;
+constexpr double kPi = 3.1415926535897932384626433832795, kUndefined = -1024.0, k3PiHalf = 4.71238898038, k2Pi = 6.28318530718;
+constexpr double kDegToRad = kPi / 180;
+
+// OpenCV's fastAtan2 (degrees): third party, restated from its published polynomial; the device copy is lsd_kernels.hip's
+float atan2_deg(float y, float x) {
+  static const float p1 = 0.9997878412794807f * (float)(180 / kPi), p3 = -0.3258083974640975f * (float)(180 / kPi), p5 = 0.1555786518463281f * (float)(180 / kPi),
+                     p7 = -0.04432655554792128f * (float)(180 / kPi);
+  const float ax = std::fabs(x), ay = std::fabs(y);
+  const bool steep = ay > ax;
+  const float c = steep ? ax / (ay + (float)DBL_EPSILON) : ay / (ax + (float)DBL_EPSILON);
+  const float c2 = c * c;
+  float a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  if (steep) a = 90.f - a;
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+inline double sq_dist(double ax, double ay, double bx, double by) { return (bx - ax) * (bx - ax) + (by - ay) * (by - ay); }
+inline double signed_angle_gap(double a, double b) {
+  double d = a - b;
+  while (d <= -kPi) d += k2Pi;
+  while (d > kPi) d -= k2Pi;
+  return d;
+}
+
+struct Pixel { int x, y; double angle, weight; };       // a region member: position, level-line angle, gradient modulus
+struct Box {                                             // the rectangle of a region (struct rect, :89-97)
+  double x1, y1, x2, y2, width, cx, cy, theta, ux, uy, tol, p;
+};
+
+// One scaled image's planes plus the state region growing threads through it
+struct Field {
+  int W, H;
+  const double* angle;
+  const double* weight;
+  std::vector<unsigned char> taken;
+  std::vector<Pixel> region;
+  int count = 0;                  // members of `region` in use
+  double log_nt = 0;
+
+  bool aligned(int at, double theta, double tol) const {      // isAligned :924-947
+    if (at < 0) return false;
+    const double a = angle[at];
+    if (a == kUndefined) return false;
+    double gap = theta - a;
+    if (gap < 0) gap = -gap;
+    if (gap > k3PiHalf) {
+      gap -= k2Pi;
+      if (gap < 0) gap = -gap;
+    }
+    return gap <= tol;
+  }
+
+  // :644-692.  Returns the region angle.
+  double grow(int sx, int sy, double tol) {
+    const int at0 = sx + sy * W;
+    double theta = angle[at0];
+    region[0] = Pixel{sx, sy, theta, weight[at0]};
+    count = 1;
+    taken[at0] = 1;
+    float sum_c = (float)std::cos(theta), sum_s = (float)std::sin(theta);
+    for (int i = 0; i < count; i++) {
+      const int px = region[i].x, py = region[i].y;
+      const int xa = std::max(px - 1, 0), xb = std::min(px + 1, W - 1), ya = std::max(py - 1, 0), yb = std::min(py + 1, H - 1);
+      for (int y = ya; y <= yb; y++)
+        for (int x = xa, at = xa + y * W; x <= xb; x++, at++) {
+          if (taken[at] == 1 || !aligned(at, theta, tol)) continue;
+          taken[at] = 1;
+          const double a = angle[at];
+          region[count++] = Pixel{x, y, a, weight[at]};
+          sum_c += std::cos((float)a);
+          sum_s += std::sin((float)a);
+          theta = (double)atan2_deg(sum_s, sum_c) * kDegToRad;
+        }
+    }
+    return theta;
+  }
+
+  // region2rect + get_theta :694-802
+  void fit(double region_theta, double tol, double p, Box& b) const {
+    double cx = 0, cy = 0, wsum = 0;
+    for (int i = 0; i < count; i++) { const double w = region[i].weight; cx += (double)region[i].x * w; cy += (double)region[i].y * w; wsum += w; }
+    cx /= wsum; cy /= wsum;
+    double ixx = 0, iyy = 0, ixy = 0;
+    for (int i = 0; i < count; i++) {
+      const double w = region[i].weight, dx = (double)region[i].x - cx, dy = (double)region[i].y - cy;
+      ixx += dy * dy * w; iyy += dx * dx * w; ixy -= dx * dy * w;
+    }
+    const double small_eig = 0.5 * (ixx + iyy - std::sqrt((ixx - iyy) * (ixx - iyy) + 4.0 * ixy * ixy));
+    double theta = (std::fabs(ixx) > std::fabs(iyy)) ? (double)atan2_deg((float)(small_eig - ixx), (float)ixy) : (double)atan2_deg((float)ixy, (float)(small_eig - iyy));
+    theta *= kDegToRad;
+    if (std::fabs(signed_angle_gap(theta, region_theta)) > tol) theta += kPi;
+    const double ux = std::cos(theta), uy = std::sin(theta);
+    double lo_l = 0, hi_l = 0, lo_w = 0, hi_w = 0;
+    for (int i = 0; i < count; i++) {
+      const double dx = (double)region[i].x - cx, dy = (double)region[i].y - cy;
+      const double along = dx * ux + dy * uy, across = -dx * uy + dy * ux;
+      if (along > hi_l) hi_l = along; else if (along < lo_l) lo_l = along;
+      if (across > hi_w) hi_w = across; else if (across < lo_w) lo_w = across;
+    }
+    b.x1 = cx + lo_l * ux; b.y1 = cy + lo_l * uy; b.x2 = cx + hi_l * ux; b.y2 = cy + hi_l * uy;
+    b.width = hi_w - lo_w; b.cx = cx; b.cy = cy; b.theta = theta; b.ux = ux; b.uy = uy; b.tol = tol; b.p = p;
+    if (b.width < 1.0) b.width = 1.0;
+  }
+
+  double density(const Box& b) const { return (double)count / (std::sqrt(sq_dist(b.x1, b.y1, b.x2, b.y2)) * b.width); }
+
+  // refine + reduce_region_radius :804-905.  False: the region is given up.
+  bool refine(double region_theta, double tol, double p, Box& b) {
+    double dens = density(b);
+    if (dens >= kDensityTh) return true;
+    // the angle spread of the members within one width of the seed sets a new tolerance, and the region is grown again from the seed
+    const double sx = (double)region[0].x, sy = (double)region[0].y, seed_angle = region[0].angle;
+    double s1 = 0, s2 = 0;
+    int near = 0;
+    for (int i = 0; i < count; i++) {
+      taken[region[i].x + region[i].y * W] = 0;
+      if (std::sqrt(sq_dist(sx, sy, (double)region[i].x, (double)region[i].y)) < b.width) {
+        const double g = signed_angle_gap(region[i].angle, seed_angle);
+        s1 += g; s2 += g * g; near++;
+      }
+    }
+    const double mean = s1 / (double)near;
+    const double tau = 2.0 * std::sqrt((s2 - 2.0 * mean * s1) / (double)near + mean * mean);
+    region_theta = grow(region[0].x, region[0].y, tau);
+    if (count < 2) return false;
+    fit(region_theta, tol, p, b);
+    dens = density(b);
+    if (dens >= kDensityTh) return true;
+    // still too sparse: keep only what lies within a shrinking radius of the seed
+    const double r1 = sq_dist(sx, sy, b.x1, b.y1), r2 = sq_dist(sx, sy, b.x2, b.y2);
+    double rad_sq = r1 > r2 ? r1 : r2;
+    while (dens < kDensityTh) {
+      rad_sq *= 0.75 * 0.75;
+      for (int i = 0; i < count; i++)
+        if (sq_dist(sx, sy, (double)region[i].x, (double)region[i].y) > rad_sq) {
+          taken[region[i].x + region[i].y * W] = 0;
+          std::swap(region[i], region[count - 1]);
+          count--;
+          i--;
+        }
+      if (count < 2) return false;
+      fit(region_theta, tol, p, b);
+      dens = density(b);
+    }
+    return true;
+  }
+
+  // rect_nfa :1008-1096: aligned / total pixels inside the rectangle, scanned row by row between two stepped borders
+  double box_score(const Box& b) const {
+    struct Corner { int x, y; bool used; };
+    const double hw = b.width / 2.0, oy = b.uy * hw, ox = b.ux * hw;
+    Corner c[4] = {{(int)(b.x1 - oy), (int)(b.y1 + ox), false}, {(int)(b.x2 - oy), (int)(b.y2 + ox), false}, {(int)(b.x2 + oy), (int)(b.y2 - ox), false}, {(int)(b.x1 + oy), (int)(b.y1 - ox), false}};
+    std::sort(c, c + 4, [](const Corner& l, const Corner& r) { return l.x == r.x ? l.y < r.y : l.x < r.x; });
+    Corner* top = &c[0];
+    Corner* bottom = &c[0];
+    for (int i = 1; i < 4; i++) {
+      if (top->y > c[i].y) top = &c[i];
+      if (bottom->y < c[i].y) bottom = &c[i];
+    }
+    top->used = true;
+    auto pick = [&](bool want_right) {
+      Corner* best = nullptr;
+      for (int i = 0; i < 4; i++) {
+        if (c[i].used) continue;
+        if (!best || (want_right ? best->x < c[i].x : best->x > c[i].x)) best = &c[i];
+      }
+      best->used = true;
+      return best;
+    };
+    const Corner* left = pick(false);
+    const Corner* right = pick(true);
+    const Corner* tail = pick(false);
+    // int / int, and tail->x where tail->y was meant: as the reference computes them
+    const double l_first = (top->y != left->y) ? (top->x - left->x) / (top->y - left->y) : 0;
+    const double l_second = (left->y != tail->x) ? (left->x - tail->x) / (left->y - tail->x) : 0;
+    const double r_first = (top->y != right->y) ? (top->x - right->x) / (top->y - right->y) : 0;
+    const double r_second = (right->y != tail->x) ? (right->x - tail->x) / (right->y - tail->x) : 0;
+    double l_step = l_first, r_step = r_first, xl = top->x, xr = top->x;
+    int total = 0, hits = 0;
+    for (int y = top->y; y <= bottom->y; y++) {
+      if (y < 0 || y >= H) continue;                     // (the borders do not advance on skipped rows either)
+      for (int x = (int)xl, at = y * W + (int)xl; x <= (int)xr; x++, at++) {
+        if (x < 0 || x >= W) continue;
+        total++;
+        if (aligned(at, b.theta, b.tol)) hits++;
+      }
+      if (y >= left->y) l_step = l_second;
+      if (y >= right->y) r_step = r_second;
+      xl += l_step;
+      xr += r_step;
+    }
+    return cs::minus_log10_nfa(total, hits, b.p, log_nt, false);
+  }
+
+  // rect_improve :907-1006
+  double improve(Box& b) const {
+    const double step = 0.5, half_step = step / 2.0;
+    double best = box_score(b);
+    if (best > kLogEps) return best;
+    auto consider = [&](const Box& trial) {
+      const double v = box_score(trial);
+      if (v > best) { best = v; b = trial; }
+    };
+    Box t = b;
+    for (int n = 0; n < 5; n++) { t.p /= 2; t.tol = t.p * kPi; consider(t); }                                   // finer precision
+    if (best > kLogEps) return best;
+    t = b;
+    for (int n = 0; n < 5; n++) if (t.width - step >= 0.5) { t.width -= step; consider(t); }                      // narrower
+    if (best > kLogEps) return best;
+    for (int side = 0; side < 2; side++) {                                                                       // narrower from one side, then the other
+      t = b;
+      for (int n = 0; n < 5; n++)
+        if (t.width - step >= 0.5) {
+          if (side == 0) { t.x1 += -t.uy * half_step; t.y1 += t.ux * half_step; t.x2 += -t.uy * half_step; t.y2 += t.ux * half_step; }
+          else { t.x1 -= -t.uy * half_step; t.y1 -= t.ux * half_step; t.x2 -= -t.uy * half_step; t.y2 -= t.ux * half_step; }
+          t.width -= step;
+          consider(t);
+        }
+      if (best > kLogEps) return best;
+    }
+    t = b;
+    for (int n = 0; n < 5; n++) if (t.width - step >= 0.5) { t.p /= 2; t.tol = t.p * kPi; consider(t); }          // finer precision again
+    return best;
+  }
+};
+
+// the sequential half of one image: segments in the reference's order, post-processed as LSDDetector::detectImpl and filter_lines do
+int lsd_host_stage(int img_w, int img_h, int Ws, int Hs, const double* angle, const double* weight, double length_thres, float* lines4, int cap, int* n_lines) {
+  *n_lines = 0;
+  Field F;
+  F.W = Ws; F.H = Hs; F.angle = angle; F.weight = weight;
+  F.taken.assign((size_t)Ws * Hs, 0);
+  F.region.resize((size_t)Ws * Hs);
+  const double tol = kPi * kAngTh / 180, p = kAngTh / 180;
+  F.log_nt = 5 * (std::log10((double)Ws) + std::log10((double)Hs)) / 2 + std::log10(11.0);
+  const int min_region = (int)(-F.log_nt / std::log10(p));
+  const float border = 10;                                     // pre_boundary_thre, LSDDetector.cpp:219
+  int n = 0;
+  for (int y = 0; y < Hs - 1; y++)
+    for (int x = 0; x < Ws - 1; x++) {
+      const int at = x + y * Ws;
+      if (F.taken[at] != 0 || angle[at] == kUndefined) continue;
+      const double theta = F.grow(x, y, tol);
+      if (F.count < min_region) continue;
+      Box b;
+      F.fit(theta, tol, p, b);
+      if (!F.refine(theta, tol, p, b)) continue;
+      if (!(F.improve(b) > kLogEps)) continue;
+      // back to the input image's frame (:528-539), to float, clamped into the image (checkLineExtremes)
+      float e[4] = {(float)((b.x1 + 0.5) / kScale), (float)((b.y1 + 0.5) / kScale), (float)((b.x2 + 0.5) / kScale), (float)((b.y2 + 0.5) / kScale)};
+      for (int q = 0; q < 4; q++) {
+        const int lim = (q & 1) ? img_h : img_w;
+        if (e[q] < 0) e[q] = 0;
+        if (e[q] >= lim) e[q] = (float)lim - 1.0f;
+      }
+      if ((e[0] < border && e[2] < border) || (e[0] > img_w - border && e[2] > img_w - border) || (e[1] < border && e[3] < border) || (e[1] > img_h - border && e[3] > img_h - border)) continue;
+      const float len = (float)std::sqrt(std::pow(e[0] - e[2], 2) + std::pow(e[1] - e[3], 2));
+      if (!(len > (float)length_thres)) continue;
+      if (n >= cap) { cs_set_error_ba("cs_detect_lsd_gray: more segments than `cap`"); return CS_ERR_CAPACITY; }
+      std::memcpy(lines4 + 4 * (size_t)n, e, sizeof(e));
+      n++;
+    }
+  *n_lines = n;
+  return CS_OK;
+}
+
+// Resident scratch of a detector's LSD producer (grows only)
+struct LsdScratch {
+  unsigned char* d_gray = nullptr; double* d_blur = nullptr; double* d_out = nullptr; char* d_tab = nullptr;
+  double* h_out = nullptr;          // pinned: per image [angle | modulus]
+  size_t cap_in = 0, cap_out = 0;   // pixels x images
+  int tab_w = 0, tab_h = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double device_ms = 0, host_ms = 0, total_ms = 0;
+};
+void lsd_scratch_free(void* p) {
+  LsdScratch* S = (LsdScratch*)p;
+  if (!S) return;
+  if (S->d_gray) (void)hipFree(S->d_gray);
+  if (S->d_blur) (void)hipFree(S->d_blur);
+  if (S->d_out) (void)hipFree(S->d_out);
+  if (S->d_tab) (void)hipFree(S->d_tab);
+  if (S->h_out) (void)hipHostFree(S->h_out);
+  if (S->ev0) (void)hipEventDestroy(S->ev0);
+  if (S->ev1) (void)hipEventDestroy(S->ev1);
+  delete S;
+}
+
+double lsd_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+extern "C" int cs_detect_lsd_batch(cs_detector* d, const unsigned char* const* grays, int n_images, int img_w, int img_h, double length_thres, float* const* lines4, int cap,
+                                   int* n_lines) {
+  if (!d || n_images < 0 || (n_images && (!grays || !n_lines || (cap && !lines4))) || img_w < 8 || img_h < 8 || cap < 0) return CS_ERR_INVALID_ARG;
+  for (int i = 0; i < n_images; i++) if (!grays[i] || (cap && !lines4[i])) return CS_ERR_INVALID_ARG;
+  try {
+    for (int i = 0; i < n_images; i++) n_lines[i] = 0;
+    if (n_images == 0) return CS_OK;
+    std::lock_guard<std::mutex> lk(*(std::mutex*)cs_internal_detector_lines_mutex(d));
+    LSD_TRY(hipSetDevice(cs_internal_detector_device(d)));
+    hipStream_t st = (hipStream_t)cs_internal_detector_stream(d);
+    void** slot = cs_internal_detector_lsd_slot(d, lsd_scratch_free);
+    if (!*slot) *slot = new LsdScratch();
+    LsdScratch& S = *(LsdScratch*)*slot;
+    const double t_begin = lsd_now_ms();
+    // the scaled size: resize(..., Size(), 0.8, 0.8) rounds (saturate_cast<int>)
+    const int Ws = (int)std::lrint(img_w * kScale), Hs = (int)std::lrint(img_h * kScale);
+    const size_t N = (size_t)img_w * img_h, Ns = (size_t)Ws * Hs;
+    if (N * (size_t)n_images > S.cap_in) {
+      if (S.d_gray) (void)hipFree(S.d_gray);
+      if (S.d_blur) (void)hipFree(S.d_blur);
+      S.d_gray = nullptr; S.d_blur = nullptr; S.cap_in = 0;
+      LSD_TRY(hipMalloc((void**)&S.d_gray, N * (size_t)n_images));
+      LSD_TRY(hipMalloc((void**)&S.d_blur, N * (size_t)n_images * sizeof(double)));
+      S.cap_in = N * (size_t)n_images;
+    }
+    if (Ns * (size_t)n_images > S.cap_out) {
+      if (S.d_out) (void)hipFree(S.d_out);
+      if (S.h_out) (void)hipHostFree(S.h_out);
+      S.d_out = nullptr; S.h_out = nullptr; S.cap_out = 0;
+      LSD_TRY(hipMalloc((void**)&S.d_out, 2 * Ns * (size_t)n_images * sizeof(double)));
+      LSD_TRY(hipHostMalloc((void**)&S.h_out, 2 * Ns * (size_t)n_images * sizeof(double)));
+      S.cap_out = Ns * (size_t)n_images;
+    }
+    if (!S.ev0) { LSD_TRY(hipEventCreate(&S.ev0)); LSD_TRY(hipEventCreate(&S.ev1)); }
+    // resize's tables for this size: source offset and the two float weights per scaled column / row (pixel centres, INTER_LINEAR)
+    const size_t tab_bytes = (size_t)(Ws + Hs) * (sizeof(int) + 2 * sizeof(float));
+    if (S.tab_w != img_w || S.tab_h != img_h) {
+      std::vector<char> host(tab_bytes);
+      int* xo = (int*)host.data();
+      int* yo = xo + Ws;
+      float* xa = (float*)(yo + Hs);
+      float* ya = xa + 2 * (size_t)Ws;
+      const double step = 1.0 / kScale;
+      for (int i = 0; i < Ws; i++) {
+        float f = (float)((i + 0.5) * step - 0.5);
+        int s = (int)std::floor(f);
+        f -= s;
+        if (s < 0) { f = 0; s = 0; }
+        if (s >= img_w - 1) { f = 0; s = img_w - 1; }
+        xo[i] = s; xa[2 * i] = 1.f - f; xa[2 * i + 1] = f;
+      }
+      for (int i = 0; i < Hs; i++) {
+        float f = (float)((i + 0.5) * step - 0.5);
+        const int s = (int)std::floor(f);
+        f -= s;
+        yo[i] = s; ya[2 * i] = 1.f - f; ya[2 * i + 1] = f;
+      }
+      if (S.d_tab) (void)hipFree(S.d_tab);
+      S.d_tab = nullptr; S.tab_w = S.tab_h = 0;
+      LSD_TRY(hipMalloc((void**)&S.d_tab, tab_bytes));
+      LSD_TRY(hipMemcpy(S.d_tab, host.data(), tab_bytes, hipMemcpyHostToDevice));
+      S.tab_w = img_w; S.tab_h = img_h;
+    }
+    cs::LsdScaleTab T;
+    T.xo = (const int*)S.d_tab; T.yo = T.xo + Ws; T.xa = (const float*)(T.yo + Hs); T.ya = T.xa + 2 * (size_t)Ws;
+    // getGaussianKernel(7, 0.6 / 0.8, CV_64F): the window is 1 + 2 ceil(sigma sqrt(2 * 3 ln 10)) = 7 for these parameters (:452-456)
+    cs::LsdGauss G;
+    {
+      const double sigma = kSigmaScale / kScale;
+      if (1 + 2 * (int)std::ceil(sigma * std::sqrt(2 * 3 * std::log(10.0))) != 7) { cs_set_error_ba("cs_detect_lsd_batch: window"); return CS_ERR_INVALID_ARG; }
+      double sum = 0;
+      for (int i = 0; i < 7; i++) { const double x = i - 3.0; G.k[i] = std::exp(-0.5 / (sigma * sigma) * x * x); sum += G.k[i]; }
+      sum = 1. / sum;
+      for (int i = 0; i < 7; i++) G.k[i] *= sum;
+    }
+    const double rho = kQuant / std::sin(kPi * kAngTh / 180);
+    for (int i = 0; i < n_images; i++) LSD_TRY(hipMemcpyAsync(S.d_gray + (size_t)i * N, grays[i], N, hipMemcpyHostToDevice, st));
+    LSD_TRY(hipEventRecord(S.ev0, st));
+    cs::launch_lsd_maps(S.d_gray, img_w, img_h, Ws, Hs, G, T, rho, S.d_blur, S.d_out, st, n_images);
+    LSD_TRY(hipGetLastError());
+    LSD_TRY(hipEventRecord(S.ev1, st));
+    LSD_TRY(hipMemcpyAsync(S.h_out, S.d_out, 2 * Ns * (size_t)n_images * sizeof(double), hipMemcpyDeviceToHost, st));
+    LSD_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    LSD_TRY(hipEventElapsedTime(&ms, S.ev0, S.ev1));
+    S.device_ms = ms;
+    const double t_host = lsd_now_ms();
+    struct Ctx { const double* h; int w, h0, Ws, Hs; size_t Ns; double thr; float* const* lines4; int cap; int* n_lines; std::vector<int> rc; } ctx{S.h_out, img_w, img_h, Ws, Hs, Ns, length_thres, lines4, cap, n_lines, std::vector<int>(n_images, 0)};
+    auto one = [](int i, void* vp) {
+      Ctx& c = *(Ctx*)vp;
+      const double* a = c.h + 2 * c.Ns * (size_t)i;
+      try { c.rc[i] = lsd_host_stage(c.w, c.h0, c.Ws, c.Hs, a, a + c.Ns, c.thr, c.lines4 ? c.lines4[i] : nullptr, c.cap, &c.n_lines[i]); }
+      catch (const std::exception&) { c.rc[i] = CS_ERR_CAPACITY; }
+    };
+    if (n_images == 1) one(0, &ctx);
+    else cs_internal_detector_parallel(d, n_images, one, &ctx);
+    S.host_ms = lsd_now_ms() - t_host; S.total_ms = lsd_now_ms() - t_begin;
+    for (int r : ctx.rc) if (r) return r;
+    return CS_OK;
+  } catch (const std::exception& ex) {
+    cs_set_error_ba(std::string("cs_detect_lsd_batch: ") + ex.what());
+    return CS_ERR_CAPACITY;
+  }
+}
+
+extern "C" int cs_detect_lsd_last_timing(cs_detector* d, double* device_ms, double* host_ms, double* total_ms) {
+  if (!d) return CS_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(*(std::mutex*)cs_internal_detector_lines_mutex(d));
+  void** slot = cs_internal_detector_lsd_slot(d, lsd_scratch_free);
+  const LsdScratch* S = (const LsdScratch*)*slot;
+  if (!S) return CS_ERR_NOT_RUN;
+  if (device_ms) *device_ms = S->device_ms;
+  if (host_ms) *host_ms = S->host_ms;
+  if (total_ms) *total_ms = S->total_ms;
+  return CS_OK;
+}
+
+extern "C" int cs_detect_lsd_gray(cs_detector* d, const unsigned char* gray, int img_w, int img_h, double length_thres, float* lines4, int cap, int* n_lines) {
+  if (!d || !gray || img_w < 8 || img_h < 8 || cap < 0 || (cap && !lines4) || !n_lines) return CS_ERR_INVALID_ARG;
+  float* l4 = lines4;
+  return cs_detect_lsd_batch(d, &gray, 1, img_w, img_h, length_thres, &l4, cap, n_lines);
+}

@@ -160,6 +160,17 @@ int cs_detect_lines_batch(cs_detector* d, const unsigned char* const* grays, int
                           float* const* lines4, int cap, int* n_lines);
 /* Timing (ms) of this detector's last line-detection call: the device kernels, the host stage (wall), the whole call.            */
 int cs_detect_lines_last_timing(cs_detector* d, double* device_ms, double* host_ms, double* total_ms);
+/* The same producer with use_LSD = true (line_lbd_allclass.cpp:130-150,199-215): LSDDetector::detectImpl, one octave
+ * (line_lbd/libs/LSDDetector.cpp:55-105,154-260 -- end points clamped into the image, segments hugging a border dropped) over the
+ * vendored OpenCV-3 detector LineSegmentDetectorImpl::flsd with LSD_REFINE_ADV and its default parameters
+ * (line_lbd/libs/lsd.cpp:185-187,402-1148), then filter_lines (length > length_thres).  This is the detector whose output the
+ * reference ships for its bundled frame (detect_3d_cuboid/data/edge_detection/LSD/0000_edge.txt).  Same arguments and layout as
+ * cs_detect_lines_gray / _batch / _last_timing.  Blur, resize and the gradient / level-line-angle planes on the device; region
+ * growing, rectangle fitting and the a-contrario validation (sequential in the pixel-visit order) on the host.                   */
+int cs_detect_lsd_gray(cs_detector* d, const unsigned char* gray, int img_w, int img_h, double length_thres, float* lines4, int cap, int* n_lines);
+int cs_detect_lsd_batch(cs_detector* d, const unsigned char* const* grays, int n_images, int img_w, int img_h, double length_thres,
+                        float* const* lines4, int cap, int* n_lines);
+int cs_detect_lsd_last_timing(cs_detector* d, double* device_ms, double* host_ms, double* total_ms);
 
 /* Batched form for throughput: cs_batch_create() copies the frames' inputs into HBM (maps, lines,
  * boxes, cameras); cs_batch_run() is the hot path proper -- resident inputs in, cuboids out.

@@ -1,5 +1,6 @@
 """The line-segment producer (cs_detect_lines_gray: EDLines with its per-pixel stages on the device, routing / fitting on the host)
-against oracle/edlines_oracle.cpp, bit for bit: same number of segments, same order, identical float coordinates."""
+against oracle/edlines_oracle.cpp, bit for bit: same number of segments, same order, identical float coordinates.  The LSD branch
+(cs_detect_lsd_gray: use_LSD = true) the same way against oracle/lsd_oracle.cpp, and against the reference's own saved segments."""
 import os
 
 import numpy as np
@@ -8,6 +9,7 @@ import pytest
 from cube_slam_wu_amd import capi
 from oracle import edge_oracle_py as E
 from oracle import edlines_oracle_py as L
+from oracle import lsd_oracle_py as LSD
 
 pytestmark = pytest.mark.gpu
 DATA = os.path.join(os.path.dirname(__file__), "golden", "object_slam_data")
@@ -94,4 +96,78 @@ def test_batch_entry_point_equals_the_single_image_calls():
         assert np.array_equal(a, b)
     t = det.lines_timing()
     assert t["device_ms"] > 0 and t["total_ms"] >= t["host_ms"] > 0
+    det.close()
+
+
+# ---- the LSD branch (use_LSD = true) ------------------------------------------------------------------------------------------
+def test_lsd_reference_frame_reproduces_the_saved_segments_token_for_token():
+    """The product on the gray image of the reference's bundled frame 0000 against detect_3d_cuboid/data/edge_detection/LSD/0000_edge.txt
+    (271 rows the reference's LSD branch wrote, six significant digits): every token equal -- the GPU path needs no oracle for this one."""
+    from PIL import Image
+    gdir = os.path.join(os.path.dirname(__file__), "golden", "detect_3d_cuboid_data")
+    gray = np.asarray(Image.open(os.path.join(gdir, "0000_gray.png")))
+    det = capi.Detector(capi.default_params())
+    got = det.detect_lines(gray, 15.0, use_lsd=True)
+    want = open(os.path.join(gdir, "0000_edge.txt")).read().split()
+    assert got.shape == (271, 4)
+    bad = [(i // 4, a, b) for i, (a, b) in enumerate(zip(["%g" % v for v in got.reshape(-1)], want)) if float(a) != float(b)]
+    assert not bad, bad[:5]
+    assert np.array_equal(got, LSD.detect_filter_lines(gray, 15.0))
+    det.close()
+
+
+def test_lsd_tum_frames_bit_identical_to_the_oracle():
+    from PIL import Image
+    det = capi.Detector(capi.default_params())
+    total = 0
+    for k in range(0, 58, 3):
+        img = np.asarray(Image.open(os.path.join(DATA, "raw_imgs", "%04d_rgb_raw.jpg" % k)).convert("RGB"))
+        gray = E.bgr_to_gray(np.ascontiguousarray(img[:, :, ::-1]))
+        got = det.detect_lines(gray, 15.0, use_lsd=True)
+        ref = LSD.detect_filter_lines(gray, 15.0)
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        assert np.array_equal(got, ref), k
+        total += len(ref)
+    assert total > 400
+    det.close()
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (376, 1241), (97, 131), (33, 64), (64, 33), (200, 9), (8, 300)])
+def test_lsd_synthetic_images_and_odd_sizes(shape):
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1] + 1)
+    det = capi.Detector(capi.default_params())
+    n = 0
+    for _ in range(3):
+        gray = _synthetic(rng, *shape)
+        for thr in (15.0, 50.0):
+            got = det.detect_lines(gray, thr, use_lsd=True)
+            ref = LSD.detect_filter_lines(gray, thr)
+            assert got.shape == ref.shape and np.array_equal(got, ref)
+            n += len(ref)
+    if min(shape) >= 64:
+        assert n > 0
+    flat = np.full(shape, 77, np.uint8)
+    assert det.detect_lines(flat, 15.0, use_lsd=True).shape == (0, 4)
+    det.close()
+
+
+def test_lsd_batch_equals_single_calls_and_reports_errors():
+    det = capi.Detector(capi.default_params())
+    rng = np.random.default_rng(11)
+    grays = [_synthetic(rng, 200, 311) for _ in range(9)]
+    single = [det.detect_lines(g, 15.0, use_lsd=True) for g in grays]
+    for _ in range(2):
+        got = det.detect_lines_batch(grays, 15.0, use_lsd=True)
+        for a, b, g in zip(got, single, grays):
+            assert np.array_equal(a, b) and np.array_equal(b, LSD.detect_filter_lines(g, 15.0)) and len(b) > 0
+    small = _synthetic(rng, 97, 120)
+    assert np.array_equal(det.detect_lines_batch([small], 15.0, use_lsd=True)[0], LSD.detect_filter_lines(small, 15.0))
+    # the EDLines producer of the same detector is untouched by the LSD calls in between
+    assert np.array_equal(det.detect_lines(grays[0], 15.0), L.detect_filter_lines(grays[0], 15.0))
+    t = det.lines_timing(use_lsd=True)
+    assert t["device_ms"] > 0 and t["total_ms"] >= t["host_ms"] > 0
+    with pytest.raises(RuntimeError):
+        det.detect_lines(grays[0], 15.0, cap=3, use_lsd=True)
+    with pytest.raises(RuntimeError):
+        det.detect_lines(np.zeros((4, 4), np.uint8), 15.0, use_lsd=True)
     det.close()
