@@ -2,9 +2,10 @@
 // (line_lbd/include/line_lbd/line_lbd_allclass.h:23-79): construction, the public flags use_LSD / line_length_thres, and
 //     void detect_filter_lines(const cv::Mat& gray_img, cv::Mat& linesmat_out);          // n x 4 CV_32F: x1 y1 x2 y2
 // as called by object_slam/src/main_obj.cpp:502-505,593.  Include this header instead of line_lbd/line_lbd_allclass.h and link
-// -lcubeslam_hip in place of the reference's libline_lbd_lib.  Only the EDLines branch (use_LSD = false, the one the graph
-// driver selects) is implemented; descriptors, matching and the LSD branch are not on the hot path and stay with the reference
-// library.  Needs OpenCV for cv::Mat / cvtColor and is therefore not compiled in the build container.
+// -lcubeslam_hip in place of the reference's libline_lbd_lib.  Both detector branches are served: EDLines (use_LSD = false, the one
+// the graph driver selects) by cs_detect_lines_gray, LSD (use_LSD = true, the one whose output the reference ships for its bundled
+// frame) by cs_detect_lsd_gray; descriptors and matching are not on the hot path and stay with the reference library.  Needs OpenCV
+// for cv::Mat / cvtColor; tests/test_adapters_compile.py compiles it against declaration-only stubs.
 #pragma once
 
 #include <opencv2/core/core.hpp>
@@ -27,11 +28,10 @@ class line_lbd_detect {
 
   int numoctaves_;
   float octaveratio_;
-  bool use_LSD;              // must stay false: the LSD branch is not on the accelerated path
+  bool use_LSD;              // line_lbd_allclass.cpp:130-150: LSD when set, EDLines otherwise
   float line_length_thres;   // line_lbd_allclass.cpp:147: 50 by default, 15 in the graph driver
 
   void detect_filter_lines(const cv::Mat& img, cv::Mat& linesmat_out) {
-    if (use_LSD) throw std::runtime_error("line_lbd_detect (HIP): only the EDLines branch (use_LSD = false) is accelerated");
     if (numoctaves_ != 1) throw std::runtime_error("line_lbd_detect (HIP): one octave, as the graph driver uses it");
     cv::Mat gray;
     if (img.channels() != 1) cv::cvtColor(img, gray, cv::COLOR_BGR2GRAY);     // BinaryDescriptor::detectImpl, binary_descriptor.cpp:489-495
@@ -39,8 +39,9 @@ class line_lbd_detect {
     if (!gray.isContinuous()) gray = gray.clone();
     std::vector<float> seg(4 * (size_t)kCap);
     int n = 0;
-    if (cs_detect_lines_gray(det_, gray.data, gray.cols, gray.rows, (double)line_length_thres, seg.data(), kCap, &n) != CS_OK)
-      throw std::runtime_error(std::string("cs_detect_lines_gray: ") + cs_last_error());
+    const int rc = use_LSD ? cs_detect_lsd_gray(det_, gray.data, gray.cols, gray.rows, (double)line_length_thres, seg.data(), kCap, &n)
+                           : cs_detect_lines_gray(det_, gray.data, gray.cols, gray.rows, (double)line_length_thres, seg.data(), kCap, &n);
+    if (rc != CS_OK) throw std::runtime_error(std::string(use_LSD ? "cs_detect_lsd_gray: " : "cs_detect_lines_gray: ") + cs_last_error());
     linesmat_out.create(n, 4, CV_32FC1);                                        // keylines_to_mat, line_lbd_allclass.cpp:33-43
     for (int j = 0; j < n; j++) for (int c = 0; c < 4; c++) linesmat_out.at<float>(j, c) = seg[4 * (size_t)j + c];
   }
