@@ -958,54 +958,105 @@ __device__ __forceinline__ double band_rsqrt(double x) {
   return h + h;
 }
 
-// Wave 0: Cholesky of the 32 x 32 block in U and the inverse of its factor, in one sweep over the columns.
-// Lanes 0..31 own row r of L, lanes 32..63 own column r of L^-1, both in the same register array v[]: once column c of
-// L is known, the trailing update of L, v[q] -= v[c] L(q, c), and the forward substitution of L^-1 are the same
-// instruction.  Column c travels unscaled through an LDS line (uniform-address reads) together with each lane's
-// v[c + 1], so every lane can form the NEXT pivot itself and its 1/sqrt leaves the critical path: per column the chain
-// is one LDS round trip and two multiply-adds.  colbuf: 2 x 128 doubles (double-buffered {v[c], v[c + 1]} pairs).
-__device__ __forceinline__ bool band_potf2_inv_impl(const double (*U)[BS + 1], int nb, double (*Dl)[BS + 1], double (*X)[BS + 1], double* colbuf) {
-  const int lane = threadIdx.x & 63;
+// 1 / x: hardware estimate + two Newton steps
+__device__ __forceinline__ double band_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y = fma(e, y, y);
+  e = fma(-x, y, 1.0);
+  return fma(e, y, y);
+}
+// The whole workgroup: Cholesky of the 32 x 32 block in U and the inverse of its factor, in one sweep over the columns, four columns
+// per LDS round trip.  Lanes 0..31 of every wave own row r of L, lanes 32..63 column r of L^-1 (the identity rides along as 32 more
+// rows, so the trailing update of L and the forward substitution of L^-1 are the same instructions); wave w keeps the columns
+// q = 4 i + w of every lane's row, i.e. one column of every round.  A round eliminates the columns c0 .. c0 + 3 together: the four
+// owners write them to LDS, one workgroup barrier, then every lane reads the 4 x 4 pivot block and its own row's four entries,
+// factorises the pivot block as L D L^T in its registers (a chain of four reciprocals, no square root on it), carries its own
+// entries through the same elimination (x_j = m_j - sum_t x_t g_jt) and updates the columns q it owns from lane q's four raw
+// entries, transformed the same way; the owner's final values are x_w / sqrt(d_w).  colbuf: 2 x 256 doubles.
+// History (tools/microbench/potf2_bench.cpp, one workgroup alone): one wave sweeping column by column with one LDS broadcast line per
+// column 6.5 us per block; the same spread over four waves 7.4 us (a workgroup barrier per column costs what the shorter update
+// saves); this one 4.8 us -- in the factorisation of C4's reduced system (53 dependent steps) 1.07 -> 0.99 ms.
+__device__ __forceinline__ bool band_potf2_inv4b_impl(const double (*U)[BS + 1], int nb, double (*Dl)[BS + 1], double (*X)[BS + 1], double* colbuf) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int row = lane & 31;
   const bool lower = lane < BS;
-  double v[BS + 1];
+  double v[BS / 4];
 #pragma unroll
-  for (int c = 0; c < BS; c++) {
-    const double u = U[row][c];
-    v[c] = (lower && row < nb && c <= row) ? u : ((c == row) ? 1.0 : 0.0);
+  for (int i = 0; i < BS / 4; i++) {
+    const int q = 4 * i + w;
+    const double u = U[row][q];
+    v[i] = (lower && row < nb && q <= row) ? u : ((q == row) ? 1.0 : 0.0);
   }
-  v[BS] = 0.0;
-  double piv = (nb > 0) ? U[0][0] : 1.0;   // pivot of column 0, uniform
   int bad = 0;
 #pragma unroll
-  for (int c = 0; c < BS; c++) {
-    double* cbA = colbuf + (c & 1) * 128;   // column c of every lane
-    double* cbB = cbA + 64;                 // v[c + 1] of every lane (only lane c + 1's is read)
-    cbA[lane] = v[c]; cbB[lane] = v[c + 1];
-    __builtin_amdgcn_wave_barrier();
-    double col[BS];
+  for (int i0 = 0; i0 < BS / 4; i0++) {
+    const int c0 = 4 * i0;
+    double* buf = colbuf + (i0 & 1) * 256;      // [column of the round][lane]
+    buf[w * 64 + lane] = v[i0];
+    __syncthreads();
+    double P[4][4], m[4];
 #pragma unroll
-    for (int q = c + 1; q < BS; q++) col[q] = cbA[q];     // one batch of uniform-address reads
-    const double nxt = (c + 1 < BS) ? cbB[c + 1] : 1.0;
-    bad |= (c < nb) & !(piv > 0.0);
-    const double rs = band_rsqrt(piv);
-    const double vc = v[c] * rs;    // L(row, c) for row >= c (the diagonal becomes d / sqrt(d)); X(c, col) in the upper lanes
-    const double vc2 = vc * rs;     // v[q] -= L(row, c) L(q, c) = (v[c] / d) * (unscaled column entry of row q)
-    v[c] = vc;
-    if (c + 1 < BS) piv = fma(-(col[c + 1] * rs * rs), col[c + 1], nxt);   // next pivot, with lane c + 1's own arithmetic
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int q = c + 1; q < BS; q++) v[q] = fma(-vc2, col[q], v[q]);
+      for (int j = 0; j <= i; j++) P[i][j] = buf[j * 64 + c0 + i];     // lane c0 + i's entry of column c0 + j (uniform address)
+#pragma unroll
+    for (int j = 0; j < 4; j++) m[j] = buf[j * 64 + lane];
+    double d[4], inv[4], g[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      d[j] = P[j][j];
+      bad |= (c0 + j < nb) & !(d[j] > 0.0);
+      inv[j] = band_rcp(d[j]);
+#pragma unroll
+      for (int i = j + 1; i < 4; i++) g[i][j] = P[i][j] * inv[j];
+#pragma unroll
+      for (int i = j + 1; i < 4; i++)
+#pragma unroll
+        for (int jj = j + 1; jj <= i; jj++) P[i][jj] = fma(-P[i][j], g[jj][j], P[i][jj]);
+    }
+    double x[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      x[j] = m[j];
+#pragma unroll
+      for (int t = 0; t < j; t++) x[j] = fma(-x[t], g[j][t], x[j]);
+    }
+    // this wave's column of the round is final: x_w / sqrt(d_w)
+    const double dw = w == 0 ? d[0] : (w == 1 ? d[1] : (w == 2 ? d[2] : d[3]));
+    const double xw = w == 0 ? x[0] : (w == 1 ? x[1] : (w == 2 ? x[2] : x[3]));
+    v[i0] = xw * band_rsqrt(dw);
+    double xs[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) xs[t] = x[t] * inv[t];
+#pragma unroll
+    for (int i = i0 + 1; i < BS / 4; i++) {
+      const int q = 4 * i + w;
+      double xq[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) xq[t] = buf[t * 64 + q];               // lane q's raw entries of the round's columns (uniform address)
+#pragma unroll
+      for (int j = 1; j < 4; j++)
+#pragma unroll
+        for (int t = 0; t < j; t++) xq[j] = fma(-xq[t], g[j][t], xq[j]);
+      double acc = v[i];
+#pragma unroll
+      for (int t = 0; t < 4; t++) acc = fma(-xs[t], xq[t], acc);
+      v[i] = acc;
+    }
   }
-  double* dst = lower ? &Dl[row][0] : &X[0][row];
-  const int stride = lower ? 1 : BS + 1;
 #pragma unroll
-  for (int c = 0; c < BS; c++) dst[c * stride] = ((lower ? row - c : c - row) >= 0) ? v[c] : 0.0;
+  for (int i = 0; i < BS / 4; i++) {
+    const int q = 4 * i + w;
+    if (lower) Dl[row][q] = (row - q >= 0) ? v[i] : 0.0;
+    else X[q][row] = (q - row >= 0) ? v[i] : 0.0;
+  }
   return bad != 0;
 }
 // Out-of-line, one instance per kernel: a device function with a single calling kernel keeps no callee-saved registers
 // (the compiler specialises its convention); shared between two kernels it would save and restore ~45 of them per call.
-__device__ __attribute__((noinline)) bool band_potf2_inv_k0(const double (*U)[BS + 1], int nb, double (*Dl)[BS + 1], double (*X)[BS + 1], double* colbuf) { return band_potf2_inv_impl(U, nb, Dl, X, colbuf); }
-__device__ __attribute__((noinline)) bool band_potf2_inv_k1(const double (*U)[BS + 1], int nb, double (*Dl)[BS + 1], double (*X)[BS + 1], double* colbuf) { return band_potf2_inv_impl(U, nb, Dl, X, colbuf); }
+__device__ __attribute__((noinline)) bool band_potf2_inv_k0(const double (*U)[BS + 1], int nb, double (*Dl)[BS + 1], double (*X)[BS + 1], double* colbuf) { return band_potf2_inv4b_impl(U, nb, Dl, X, colbuf); }
+__device__ __attribute__((noinline)) bool band_potf2_inv_k1(const double (*U)[BS + 1], int nb, double (*Dl)[BS + 1], double (*X)[BS + 1], double* colbuf) { return band_potf2_inv4b_impl(U, nb, Dl, X, colbuf); }
 
 typedef const __attribute__((address_space(1))) double* band_gptr;   // global address space: a noinline function would otherwise emit flat loads
 __device__ __forceinline__ double band_gload(const double* p) { return *(band_gptr)(p); }
@@ -1283,8 +1334,10 @@ __device__ __forceinline__ void band_diag_accum(const SEG& S, int jlo, int jhi, 
 template <int KID>
 __device__ __forceinline__ void band_diag_phase(const BandLds& M, const BandView& view, double* Linv, int k_begin, int k_end, bool two_seg, const BandView& v1, int jhi1,
                                                 unsigned* start, unsigned start_target, unsigned* bar, unsigned G, unsigned ep0, unsigned* flag, unsigned f0,
-                                                int n, int bw, const double* zero, int* info) {
+                                                int n, int bw, const double* zero, int* info, long long* dprof = nullptr) {
   const int tid = threadIdx.x, r = tid >> 3, cq = tid & 7, lane = tid & 63, wv = tid >> 6, rg = lane >> 3, cg = lane & 7;
+  long long dt_prev = dprof ? wall_clock64() : 0;      // optional phase clock of this workgroup (CS_BAND_PROF): wait, newest block + U, POTF2, publish, look-ahead
+#define BAND_DTICK(k) do { if (dprof && tid == 0) { const long long t_now = wall_clock64(); dprof[k] += t_now - dt_prev; dt_prev = t_now; } } while (0)
   auto wait_for = [&](unsigned* ctr, unsigned target) {
     if (tid == 0) {
       band_wait_ge(ctr, target);
@@ -1318,7 +1371,9 @@ __device__ __forceinline__ void band_diag_phase(const BandLds& M, const BandView
       band_diag_accum<BAND_DC>(s0, s0.jlo, k0, n, bw, k0, nb, zero, M.R, acc);
       if (two_seg) { const BandSeg s1 = seg1(k0, nb); band_diag_accum<BAND_DC>(s1, s1.jlo, s1.jhi, n, bw, k0, nb, zero, M.R, acc); }
     } else {
+      BAND_DTICK(4);
       wait_for(bar, (ep0 + s) * G);
+      BAND_DTICK(0);
       band_diag_accum<BS>(s0, max(s0.jlo, k0 - BS), k0, n, bw, k0, nb, zero, M.R, acc);   // the newest block: 4 loads per thread
     }
     // U = A - sum of the four waves' partial sums (lower triangle)
@@ -1337,11 +1392,13 @@ __device__ __forceinline__ void band_diag_phase(const BandLds& M, const BandView
       }
     }
     __syncthreads();
-    if (tid < 64) {
+    BAND_DTICK(1);
+    {
       const bool bad = KID == 0 ? band_potf2_inv_k0(M.U, nb, M.Dl, M.X, M.colbuf) : band_potf2_inv_k1(M.U, nb, M.Dl, M.X, M.colbuf);
       if (bad && tid == 0) atomicCAS(info, 0, k0 + 1);
     }
     __syncthreads();
+    BAND_DTICK(2);
     {
       double* Li = Linv + (size_t)(k0 / BS) * BS * BS;
       for (int e = tid; e < BS * BS; e += 256) {
@@ -1357,6 +1414,7 @@ __device__ __forceinline__ void band_diag_phase(const BandLds& M, const BandView
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_store(flag, f0 + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    BAND_DTICK(3);
     // the next block's history except its newest 32 columns (those wait for the team's barrier)
 #pragma unroll
     for (int m = 0; m < 4; m++)
@@ -1372,6 +1430,7 @@ __device__ __forceinline__ void band_diag_phase(const BandLds& M, const BandView
   }
 }
 
+#undef BAND_DTICK
 // (see band_potf2_inv_k0: a caller-side object whose address escapes before the first out-of-line call keeps those calls from
 // being marked as tail-call candidates, which would switch the callees back to the save-everything convention)
 __device__ __attribute__((noinline)) void band_clock_init(long long* t) { asm volatile("" : : "v"(t) : "memory"); *t = 0; }
@@ -1388,7 +1447,7 @@ __global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double*
   __shared__ double U[BAND_NR][BS + 1];
   __shared__ double Dl[BS][BS + 1];
   __shared__ double X[BS][BS + 1];
-  __shared__ double colbuf[2 * 128];
+  __shared__ double colbuf[2 * 256];
   __shared__ int rowidx[BAND_NR];
   const BandLds M{R, U, Dl, X, colbuf, rowidx};
   const int team = blockIdx.x / (G + 1), w = blockIdx.x % (G + 1);   // w == G: the front's diagonal workgroup
@@ -1482,7 +1541,7 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
   __shared__ double U[BAND_NR][BS + 1];
   __shared__ double Dl[BS][BS + 1];
   __shared__ double X[BS][BS + 1];
-  __shared__ double colbuf[2 * 128];
+  __shared__ double colbuf[2 * 256];
   __shared__ int rowidx[BAND_NR];
   const BandLds M{R, U, Dl, X, colbuf, rowidx};
   const int tid = threadIdx.x;
@@ -1515,7 +1574,7 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
   const int nslab = P.GS, GCC = P.GC;   // Schur slabs of 16 rows; workgroups of C's own factorisation
   if (diag) {
     if (team == 0) { band_diag_phase<1>(M, H.fv, H.Linv_f, 0, m_begin, false, H.rv, 0, nullptr, 0, bars + 0, (unsigned)G, 0, dflag, 0, nh, bw, zero, P.info); return; }
-    band_diag_phase<1>(M, H.rv, H.Linv_r, 0, Trev, false, H.fv, 0, nullptr, 0, bars + 1, (unsigned)G1, 0, dflag, 0, nh, bw, zero, P.info);
+    band_diag_phase<1>(M, H.rv, H.Linv_r, 0, Trev, false, H.fv, 0, nullptr, 0, bars + 1, (unsigned)G1, 0, dflag, 0, nh, bw, zero, P.info, (P.prof && hid == 0) ? P.prof + 34 : nullptr);
     band_diag_phase<1>(M, H.fv, H.Linv_f, m_begin, m_end, true, H.rv, Trev, bars + 2, (unsigned)(G + G1), bars + 1, (unsigned)G1, (unsigned)H.K2, dflag, (unsigned)H.K2, nh, bw, zero, P.info);
     if (hid != 0) return;
     const BandView vcd{P.SC, 1, (long long)wc, P.rhsC, 1};
@@ -1858,11 +1917,13 @@ void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rh
     P.Sb = Sb; P.rhs = rhs; P.zero = zero; P.info = info; P.bars = reinterpret_cast<unsigned*>(info + 6);
     static const bool want_stamps = getenv("CS_BAND_PROF") != nullptr;
     static long long* stamps = nullptr;
-    if (want_stamps && !stamps) (void)hipMalloc(&stamps, 34 * sizeof(long long));
+    if (want_stamps && !stamps) (void)hipMalloc(&stamps, 40 * sizeof(long long));
+    if (stamps) (void)hipMemsetAsync(stamps + 34, 0, 6 * sizeof(long long), st);
     P.prof = stamps;
     hipLaunchKernelGGL(band_chol_nested_kernel, dim3(2 * (P.G + 1 + G1 + 1 + P.GS)), dim3(256), 0, st, P);
+    long long hs_d[6] = {0, 0, 0, 0, 0, 0};
     if (stamps) {
-      long long h[34];
+      long long h[40];
       (void)hipMemcpyAsync(h, stamps, sizeof(h), hipMemcpyDeviceToHost, st);
       (void)hipStreamSynchronize(st);
       static int shown = 0;
@@ -1874,6 +1935,12 @@ void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rh
         for (int q = 0; q < 2; q++)
           fprintf(stderr, "[band nested] reverse front, %s workgroup us: fetch-issue %.0f  store+wait %.0f  gemm %.0f  reduce+U %.0f  wait for L^-1 %.0f  panel %.0f  barrier %.0f\n", q ? "separator-row" : "panel-row",
                   h[16 + 9 * q + 6] * 0.01, h[16 + 9 * q + 7] * 0.01, h[16 + 9 * q + 8] * 0.01, h[16 + 9 * q + 1] * 0.01, h[16 + 9 * q + 2] * 0.01, h[16 + 9 * q + 4] * 0.01, h[16 + 9 * q + 5] * 0.01);
+      for (int q = 0; q < 6; q++) hs_d[q] = h[34 + q];
+    }
+    if (stamps) {
+      static int shown_d = 0;
+      if (shown_d++ < 3) fprintf(stderr, "[band nested] reverse front, diagonal workgroup us: wait for the team's barrier %.0f  newest block + U %.0f  POTF2 + inverse %.0f  publish %.0f  look-ahead accumulation %.0f\n",
+                                 hs_d[0] * 0.01, hs_d[1] * 0.01, hs_d[2] * 0.01, hs_d[3] * 0.01, hs_d[4] * 0.01);
     }
     if (solve) {
       const int TT = (nh[0] - BS * P.h[0].K1) + (nh[1] - BS * P.h[1].K1);

@@ -7,3 +7,5 @@ hipcc --offload-arch=gfx950 -O3 -c -x hip tools/microbench/band_bench.cpp -o bui
 hipcc --offload-arch=gfx950 build_tmp/band_bench.o cube_slam_wu_amd/csrc/ba_kernels.o -o build_tmp/band_bench
 # counter calibration (tools/pmc_calib.sh)
 hipcc --offload-arch=gfx950 -O3 -x hip tools/microbench/pmc_calib.cpp -o build_tmp/pmc_calib
+# the diagonal-block routine of the banded solver alone
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -x hip tools/microbench/potf2_bench.cpp -o build_tmp/potf2_bench
