@@ -973,7 +973,7 @@ __device__ __forceinline__ double band_rcp(double x) {
 // owners write them to LDS, one workgroup barrier, then every lane reads the 4 x 4 pivot block and its own row's four entries,
 // factorises the pivot block as L D L^T in its registers (a chain of four reciprocals, no square root on it), carries its own
 // entries through the same elimination (x_j = m_j - sum_t x_t g_jt) and updates the columns q it owns from lane q's four raw
-// entries, transformed the same way; the owner's final values are x_w / sqrt(d_w).  colbuf: 2 x 256 doubles.
+// entries (weights G^-T (x / d)); the owner's final values are x_w / sqrt(d_w).  colbuf: 2 x 256 doubles.
 // History (tools/microbench/potf2_bench.cpp, one workgroup alone): one wave sweeping column by column with one LDS broadcast line per
 // column 6.5 us per block; the same spread over four waves 7.4 us (a workgroup barrier per column costs what the shorter update
 // saves); this one 4.8 us -- in the factorisation of C4's reduced system (53 dependent steps) 1.07 -> 0.99 ms.
@@ -1026,22 +1026,21 @@ __device__ __forceinline__ bool band_potf2_inv4b_impl(const double (*U)[BS + 1],
     const double dw = w == 0 ? d[0] : (w == 1 ? d[1] : (w == 2 ? d[2] : d[3]));
     const double xw = w == 0 ? x[0] : (w == 1 ? x[1] : (w == 2 ? x[2] : x[3]));
     v[i0] = xw * band_rsqrt(dw);
-    double xs[4];
+    // trailing update of the owned later columns: v_q -= sum_t (x_t / d_t) x_t(lane q), and x(lane q) = G^-1 m(lane q) with the unit lower
+    // G = (g_jt) -- so the weights are carried through G^-T once (z = G^-T (x / d)) and lane q's RAW entries are used as they are
+    double z[4];
 #pragma unroll
-    for (int t = 0; t < 4; t++) xs[t] = x[t] * inv[t];
+    for (int t = 3; t >= 0; t--) {
+      z[t] = x[t] * inv[t];
+#pragma unroll
+      for (int j = t + 1; j < 4; j++) z[t] = fma(-g[j][t], z[j], z[t]);
+    }
 #pragma unroll
     for (int i = i0 + 1; i < BS / 4; i++) {
       const int q = 4 * i + w;
-      double xq[4];
-#pragma unroll
-      for (int t = 0; t < 4; t++) xq[t] = buf[t * 64 + q];               // lane q's raw entries of the round's columns (uniform address)
-#pragma unroll
-      for (int j = 1; j < 4; j++)
-#pragma unroll
-        for (int t = 0; t < j; t++) xq[j] = fma(-xq[t], g[j][t], xq[j]);
       double acc = v[i];
 #pragma unroll
-      for (int t = 0; t < 4; t++) acc = fma(-xs[t], xq[t], acc);
+      for (int t = 0; t < 4; t++) acc = fma(-z[t], buf[t * 64 + q], acc);       // lane q's raw entries of the round's columns (uniform address)
       v[i] = acc;
     }
   }

@@ -53,7 +53,7 @@ void launch_records(const DetectDeviceView& v, const RankView& rv, int kmax, cs_
 void launch_rp_carry(const RpCarryView& c, JobDesc* jobs, hipStream_t st);
 void launch_rp_save_fallback(const DetectDeviceView& v, const RpSaveView& s, hipStream_t st);
 struct EdgeRoi { int l, t, w, h; long long img_off, cls_off, map_off; };
-void launch_edge_maps(const unsigned char* gray, int W, int H, const EdgeRoi* rois, int n_rois, unsigned char* cls_pool, float* map_pool, int max_w, int low, int high,
+void launch_edge_maps(const unsigned char* gray, int W, int H, const EdgeRoi* rois, int n_rois, unsigned char* cls_pool, float* map_pool, int max_w, long long max_px, int low, int high,
                       hipStream_t st);
 void launch_line_setup(JobDesc* jobs, int n_jobs, const double* frame_lines, const int* frame_line_ptr, double* mid_x, double* mid_y, double* line_angle,
                        double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st, const int* order = nullptr, hipStream_t st_crowded = nullptr,
@@ -766,7 +766,7 @@ static int batch_fill(cs_detector* d, cs_batch* b, const cs_frame_desc* fr, cons
       // device, box_proposal_detail.cpp:320-327); the padding between the maps stays zero.  All frames share one size.
       const int W = n_frames ? fr[0].img_w : 0, H = n_frames ? fr[0].img_h : 0;
       std::vector<cs::EdgeRoi> er;
-      long long cls_tot = 0;
+      long long cls_tot = 0, max_px = 1;
       int max_w = 1;
       for (int f = 0; f < n_frames; f++) {
         FrameIn& F = b->frames[f];
@@ -777,18 +777,18 @@ static int batch_fill(cs_detector* d, cs_batch* b, const cs_frame_desc* fr, cons
             if (r.left < 0 || r.top < 0 || r.left + r.width > W || r.top + r.height > H) { set_err("ROI outside the image"); return CS_ERR_INVALID_ARG; }
             er.push_back(cs::EdgeRoi{r.left, r.top, r.width, r.height, (long long)f * W * H, cls_tot, F.map_offs[3 * i + k]});
             cls_tot += (long long)r.width * r.height;
-            max_w = std::max(max_w, r.width);
+            max_w = std::max(max_w, r.width); max_px = std::max(max_px, 4LL * ((r.width + 5) / 4) * (r.height + 2));
           }
       }
       DevBuf<unsigned char>& d_gray = b->d_gray; DevBuf<unsigned char>& d_cls = b->d_cls;
       DevBuf<cs::EdgeRoi>& d_rois = b->d_edge_rois;
-      if ((rc = d_gray.ensure((size_t)W * H * std::max(1, n_frames))) || (rc = d_cls.ensure((size_t)cls_tot + 1)) || (rc = d_rois.ensure(er.size() + 1))) { return rc; }
+      if ((rc = d_gray.ensure((size_t)W * H * std::max(1, n_frames))) || (rc = d_cls.ensure((size_t)cls_tot + 8)) || (rc = d_rois.ensure(er.size() + 1))) { return rc; }
       hipStream_t st = d->stream;
       HIP_TRY(hipMemsetAsync(b->d_maps.p, 0, sizeof(float) * (map_floats + 1), st));
       for (int f = 0; f < n_frames; f++) HIP_TRY(hipMemcpyAsync(d_gray.p + (size_t)f * W * H, grays[f], (size_t)W * H, hipMemcpyHostToDevice, st));
       if (!er.empty()) {
         HIP_TRY(hipMemcpyAsync(d_rois.p, er.data(), sizeof(cs::EdgeRoi) * er.size(), hipMemcpyHostToDevice, st));
-        cs::launch_edge_maps(d_gray.p, W, H, d_rois.p, (int)er.size(), d_cls.p, b->d_maps.p, max_w, 80, 200, st);
+        cs::launch_edge_maps(d_gray.p, W, H, d_rois.p, (int)er.size(), d_cls.p, b->d_maps.p, max_w, max_px, 80, 200, st);
         HIP_TRY(hipGetLastError());
       }
       HIP_TRY(hipStreamSynchronize(st));      // (the host arrays `grays` and `er` are read by the copies above)
@@ -2481,7 +2481,7 @@ int cs_edge_distance_maps_multi(cs_detector* d, const unsigned char* const* gray
   if (n_rois == 0) return CS_OK;
   const size_t img_px = (size_t)img_w * img_h;
   std::vector<cs::EdgeRoi> er(n_rois);
-  long long tot = 0;
+  long long tot = 0, max_px = 1;
   int max_w = 1;
   for (int k = 0; k < n_rois; k++) {
     const cs_roi& r = rois[k];
@@ -2492,13 +2492,13 @@ int cs_edge_distance_maps_multi(cs_detector* d, const unsigned char* const* gray
     }
     er[k] = cs::EdgeRoi{r.left, r.top, r.width, r.height, (long long)(roi_image[k] * img_px), tot, tot};
     tot += (long long)r.width * r.height;
-    max_w = std::max(max_w, r.width);
+    max_w = std::max(max_w, r.width); max_px = std::max(max_px, 4LL * ((r.width + 5) / 4) * (r.height + 2));
   }
   DevBuf<unsigned char> d_gray, d_cls;
   DevBuf<cs::EdgeRoi> d_rois;
   DevBuf<float> d_map;
   int rc;
-  if ((rc = d_gray.ensure(img_px * n_images)) || (rc = d_cls.ensure((size_t)tot)) || (rc = d_rois.ensure((size_t)n_rois)) || (rc = d_map.ensure((size_t)tot))) return rc;
+  if ((rc = d_gray.ensure(img_px * n_images)) || (rc = d_cls.ensure((size_t)tot + 8)) || (rc = d_rois.ensure((size_t)n_rois)) || (rc = d_map.ensure((size_t)tot))) return rc;
   hipStream_t st = d->stream;
   for (int i = 0; i < n_images; i++) {
     if (!grays[i]) { set_err("cs_edge_distance_maps: null image"); return CS_ERR_INVALID_ARG; }
@@ -2507,7 +2507,7 @@ int cs_edge_distance_maps_multi(cs_detector* d, const unsigned char* const* gray
   HIP_TRY(hipMemcpyAsync(d_rois.p, er.data(), sizeof(cs::EdgeRoi) * n_rois, hipMemcpyHostToDevice, st));
   HIP_TRY(hipEventRecord(d->ev[0], st));
   // cv::Canny(gray_img(object_bbox), im_canny, 80, 200): the thresholds are literals of the reference (:324)
-  cs::launch_edge_maps(d_gray.p, img_w, img_h, d_rois.p, n_rois, d_cls.p, d_map.p, max_w, 80, 200, st);
+  cs::launch_edge_maps(d_gray.p, img_w, img_h, d_rois.p, n_rois, d_cls.p, d_map.p, max_w, max_px, 80, 200, st);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(d->ev[1], st));
   if (out_maps)

@@ -6,7 +6,9 @@
 // integer arithmetic (bit-reproducible on any host).  One workgroup per ROI.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 namespace cs {
 
@@ -39,9 +41,10 @@ __device__ __forceinline__ int edge_mag(const unsigned char* __restrict__ g, int
 // class per pixel: 0 = may belong to an edge, 1 = not an edge, 2 = edge.  Pass 1: one Sobel per pixel, L1 magnitude and
 // the suppression sector packed into the (not yet used) output buffer; pass 2: non-maximum suppression + thresholds
 // from the packed values; then hysteresis.  Waves walk rows, lanes walk columns (no divisions).
+__device__ void edge_hyst_global(const struct EdgeRoi& R, unsigned char* cls, unsigned* pk, int n, int* n_front, int& changed);
 enum { CANNY_BAND = 16, CANNY_TILE_W = 448 };   // LDS band of the fused Sobel + suppression: 18 x 450 x 2 bytes = 16 KB
 __global__ __launch_bounds__(256) void edge_canny_kernel(const unsigned char* __restrict__ gray, int W, int H, const EdgeRoi* __restrict__ rois, unsigned char* cls_pool,
-                                                         float* map_pool, int low, int high) {
+                                                         float* map_pool, int low, int high, int fuse_hyst) {
   __shared__ int n_front[2];
   __shared__ int changed;
   __shared__ unsigned short canny_lds[(CANNY_BAND + 2) * (CANNY_TILE_W + 2)];
@@ -49,7 +52,6 @@ __global__ __launch_bounds__(256) void edge_canny_kernel(const unsigned char* __
   gray += R.img_off;
   unsigned char* cls = cls_pool + R.cls_off;
   unsigned* pk = reinterpret_cast<unsigned*>(map_pool + R.map_off);   // magnitude (bits 0-15) | sector (16-17): 0 horizontal, 1 vertical, 2 diagonal same sign, 3 diagonal opposite sign
-  const int n = R.w * R.h;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int TG22 = 13573;
   if (R.w <= CANNY_TILE_W) {
@@ -131,10 +133,22 @@ __global__ __launch_bounds__(256) void edge_canny_kernel(const unsigned char* __
       cls[i * R.w + j] = c;
     }
   }
-  __syncthreads();
-  // hysteresis = 8-connected components of the surviving pixels that contain a strong one, by breadth-first growth from
-  // the strong pixels: a frontier pixel claims its weak neighbours (atomic OR on the class word: exactly one claimant)
-  // and they form the next frontier.  The two frontier lists live in the packed scratch, which is free now.
+  // large batches: the hysteresis right here on the class bytes in memory (the device is full of ROIs, what counts is how many of them
+  // a CU holds); small calls run edge_hyst_kernel instead (LDS-resident, a third of the latency, a quarter of the workgroups per CU)
+  if (fuse_hyst) {
+    __syncthreads();
+    edge_hyst_global(R, cls, pk, R.w * R.h, n_front, changed);
+  }
+}
+
+// ---- hysteresis ----------------------------------------------------------------------------------------------------------------
+// = the 8-connected components of the surviving pixels (class 0 or 2) that contain a strong one (class 2); every pixel of such a
+// component becomes 2.  The result does not depend on the order the pixels are visited in.
+//
+// Path for ROIs too large for LDS: class bytes in memory, breadth-first growth with the frontier lists in the (free) map scratch.
+__device__ void edge_hyst_global(const EdgeRoi& R, unsigned char* cls, unsigned* pk, int n, int* n_front, int& changed) {
+  // breadth-first growth from the strong pixels: a frontier pixel claims its weak neighbours (atomic OR on the class word: exactly
+  // one claimant) and they form the next frontier
   int* lists[2] = {reinterpret_cast<int*>(pk), reinterpret_cast<int*>(pk) + n / 2};
   const int cap = n / 2;
   bool overflow = false;
@@ -191,6 +205,160 @@ __global__ __launch_bounds__(256) void edge_canny_kernel(const unsigned char* __
     __syncthreads();
     if (!changed) break;
   }
+}
+
+// One workgroup per ROI, after edge_canny_kernel.  A chain of weak pixels is followed one pixel per round, so the rounds are a chain of
+// dependent steps (tens to a few hundred per ROI) and with the class bytes and the frontier lists in memory every round cost two or
+// three memory round trips: the per-ROI latency of the front end (0.5 ms of 0.9) and a third of its batch time.  Here the ROI's class
+// bytes (<= lds_px of them) and both frontier lists live in LDS: a round is two workgroup barriers and LDS atomics, and a thread follows
+// the chain it opens by itself, so rounds are spent on branches only.  Round one is a sweep (every weak pixel looks for a strong
+// neighbour), so the many strong pixels never have to be listed; a frontier that outgrows its list falls back to relaxation sweeps, still
+// in LDS.  Launched per size class (lo_px < pixels <= lds_px; take_rest: also the ROIs beyond every class, on the memory path).
+enum { HYST_LIST = 1024, HYST_BULK_SWEEPS = 6 };
+__device__ __forceinline__ int hyst_row_words(int w) { return (w + 2 + 3) >> 2; }              // a framed row, rounded up to whole words
+__global__ __launch_bounds__(256) void edge_hyst_kernel(const EdgeRoi* __restrict__ rois, unsigned char* cls_pool, float* map_pool, int lo_px, int lds_px, int list_cap, int take_rest) {
+  extern __shared__ unsigned hyst_lds[];      // [lds_px / 4 words: the ROI inside a frame of class 1, rows of SW words][2 x HYST_LIST byte indices]
+  __shared__ int n_front[2];
+  __shared__ int changed;
+  const EdgeRoi R = rois[blockIdx.x];
+  unsigned char* cls = cls_pool + R.cls_off;
+  const int n = R.w * R.h;
+  const int SW = hyst_row_words(R.w), SB = 4 * SW, nwords = SW * (R.h + 2);      // pixel (i, j) at byte (i + 1) SB + j + 1
+  const bool fits = 4 * nwords <= lds_px;
+  if (4 * nwords <= lo_px || (!fits && !take_rest)) return;   // another launch's size class
+  if (!fits) { edge_hyst_global(R, cls, reinterpret_cast<unsigned*>(map_pool + R.map_off), n, n_front, changed); return; }
+  unsigned char* c8 = reinterpret_cast<unsigned char*>(hyst_lds);
+  int* lists[2] = {reinterpret_cast<int*>(hyst_lds + lds_px / 4), reinterpret_cast<int*>(hyst_lds + lds_px / 4) + HYST_LIST};
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int e = threadIdx.x; e < nwords; e += 256) hyst_lds[e] = 0x01010101u;
+  if (threadIdx.x < 2) n_front[threadIdx.x] = 0;
+  if (threadIdx.x == 0) changed = 0;
+  __syncthreads();
+  {
+    // the class bytes, a wave per row, 64 columns per step, eight independent loads in flight per thread
+    const int chunks = (R.w + 63) >> 6, rows = (R.h - wv + 3) >> 2, T = rows * chunks;
+    for (int t0 = 0; t0 < T; t0 += 8) {
+      unsigned char vb[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int t = t0 + u, rr = t / chunks, i = wv + 4 * rr, j = lane + 64 * (t - rr * chunks);
+        vb[u] = (t < T && j < R.w) ? cls[i * R.w + j] : (unsigned char)1;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int t = t0 + u, rr = t / chunks, i = wv + 4 * rr, j = lane + 64 * (t - rr * chunks);
+        if (t < T && j < R.w) c8[(i + 1) * SB + j + 1] = vb[u];
+      }
+    }
+  }
+  __syncthreads();
+  // Classes in LDS: 0 weak, 1 not an edge, 2 strong, 3 = a weak pixel that joined here (bit 1 = "edge"); only the 3s go back to memory.
+  //
+  // Bulk: sweeps, a word (4 pixels) per lane per step, all in bit operations on nine words -- the "edge" bits of the word, its two
+  // neighbours in the row and the same three of the rows above and below, spread one byte left and right; a zero byte with an edge bit
+  // around it joins.  No divergence, no atomics (a word is written by one thread; a neighbour that sees the new value already only joins
+  // a sweep early).  The last sweep queues what it joined.
+  auto sweep = [&](bool queue) {
+    int joined = 0;
+    for (int r = 1 + wv; r <= R.h; r += 4)
+      for (int kw = lane; kw < SW; kw += 64) {
+        const unsigned* row = hyst_lds + r * SW;
+        const unsigned wd = row[kw];
+        const unsigned z = ~(wd | (wd >> 1)) & 0x01010101u;                      // 1 in the zero bytes
+        if (!z) continue;
+        unsigned nbr = 0;
+#pragma unroll
+        for (int dr = -1; dr <= 1; dr++) {
+          const unsigned* rw = row + dr * SW;
+          const unsigned c = (rw[kw] >> 1) & 0x01010101u;
+          const unsigned l = kw > 0 ? (rw[kw - 1] >> 25) & 1u : 0u, rr = kw + 1 < SW ? (rw[kw + 1] >> 1) & 1u : 0u;
+          const unsigned side = (c << 8) | l | (c >> 8) | (rr << 24);
+          nbr |= dr ? (side | c) : side;
+        }
+        const unsigned join = z & nbr;
+        if (!join) continue;
+        hyst_lds[r * SW + kw] = wd | (join * 3u);
+        joined += __popc(join);
+        if (queue) {
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if ((join >> (8 * q)) & 1u) { const int kk = atomicAdd(&n_front[0], 1); if (kk < list_cap) lists[0][kk] = 4 * (r * SW + kw) + q; }
+        }
+      }
+    return joined;
+  };
+  // a few bulk sweeps while they still join many pixels, then one that queues its (few) pixels for the chain following below
+  for (int it = 0; it < HYST_BULK_SWEEPS; it++) {
+    const int j = sweep(false);
+    if (j) atomicAdd(&changed, j);
+    __syncthreads();
+    const int total = changed;
+    __syncthreads();
+    if (threadIdx.x == 0) changed = 0;
+    __syncthreads();
+    if (total <= list_cap / 4) break;
+  }
+  sweep(true);
+  __syncthreads();
+  const int off[8] = {-SB - 1, -SB, -SB + 1, -1, 1, SB - 1, SB, SB + 1};
+  bool overflow = n_front[0] > list_cap;
+  int curl = 0;
+  while (!overflow) {
+    const int ncur = n_front[curl];
+    if (ncur == 0) break;
+    __syncthreads();
+    if (threadIdx.x == 0) n_front[curl ^ 1] = 0;
+    __syncthreads();
+    const int* cur = lists[curl];
+    int* nxt = lists[curl ^ 1];
+    for (int q = threadIdx.x; q < ncur; q += 256) {
+      // a thread follows the chain it opens: the first neighbour it claims is its next pixel, further ones (branches) go to the next
+      // frontier.  The eight neighbour bytes are requested together (the frame makes every address valid): one LDS round trip per pixel.
+      int at = cur[q];
+      while (at >= 0) {
+        unsigned char nb[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) nb[k] = c8[at + off[k]];
+        int follow = -1;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          if (nb[k] != 0) continue;
+          const int a2 = at + off[k];
+          const unsigned sh = (unsigned)(a2 & 3) * 8;
+          const unsigned old = atomicOr(&hyst_lds[a2 >> 2], 3u << sh);       // exactly one claimant per pixel
+          if (((old >> sh) & 0xffu) != 0) continue;
+          if (follow < 0) follow = a2;
+          else { const int kk = atomicAdd(&n_front[curl ^ 1], 1); if (kk < list_cap) nxt[kk] = a2; }
+        }
+        at = follow;
+      }
+    }
+    __syncthreads();
+    curl ^= 1;
+    overflow = n_front[curl] > list_cap;
+  }
+  if (overflow) {
+    // (entries beyond the list were claimed but not queued: what they would have reached is found by sweeping)
+    for (int it = 0; it < n; it++) {
+      __syncthreads();
+      if (threadIdx.x == 0) changed = 0;
+      __syncthreads();
+      if (sweep(false)) changed = 1;
+      __syncthreads();
+      if (!changed) break;
+    }
+  }
+  __syncthreads();
+  for (int r = 1 + wv; r <= R.h; r += 4)
+    for (int kw = lane; kw < SW; kw += 64) {
+      const unsigned wd = hyst_lds[r * SW + kw];
+      if (!(wd & (wd >> 1) & 0x01010101u)) continue;                    // no byte with both low bits set
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int j = 4 * kw + q - 1;
+        if (((wd >> (8 * q)) & 3u) == 3u && j >= 0 && j < R.w) cls[(r - 1) * R.w + j] = 2;
+      }
+    }
 }
 
 // inclusive prefix minimum over the 64 lanes of a wave, on DPP: shifts by 1, 2, 4, 8 inside each row of 16 lanes (a lane without
@@ -389,10 +557,27 @@ __global__ __launch_bounds__(64) void edge_dt_kernel(const EdgeRoi* __restrict__
   }
 }
 
-void launch_edge_maps(const unsigned char* gray, int W, int H, const EdgeRoi* rois, int n_rois, unsigned char* cls_pool, float* map_pool, int max_w, int low, int high,
-                      hipStream_t st) {
+void launch_edge_maps(const unsigned char* gray, int W, int H, const EdgeRoi* rois, int n_rois, unsigned char* cls_pool, float* map_pool, int max_w, long long max_px, int low, int high,
+                      hipStream_t st) {   // max_px: the largest framed size of an ROI, 4 ceil((w + 2) / 4) (h + 2)
   if (n_rois <= 0) return;
-  hipLaunchKernelGGL(edge_canny_kernel, dim3(n_rois), dim3(256), 0, st, gray, W, H, rois, cls_pool, map_pool, low, high);
+  // CS_EDGE_HYST (tests / measurements): "lds" or "fused" forces one hysteresis path; by default calls that cannot fill the device take the LDS kernel
+  static const int force = [] { const char* e = getenv("CS_EDGE_HYST"); return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'f' ? 2 : 0)); }();
+  const bool fused = force ? force == 2 : n_rois > 1024;
+  hipLaunchKernelGGL(edge_canny_kernel, dim3(n_rois), dim3(256), 0, st, gray, W, H, rois, cls_pool, map_pool, low, high, fused ? 1 : 0);
+  if (!fused) {
+    // the ROI's class bytes in LDS: sized for the largest ROI of the call, at most 64 KB (two workgroups per CU with the lists; larger ROIs take
+    // the memory path inside the kernel).  CS_EDGE_HYST_LIST (tests): a smaller frontier capacity, CS_EDGE_HYST_LDS: the cap in bytes.
+    static const int list_cap = [] { const char* e = getenv("CS_EDGE_HYST_LIST"); const int v = e ? atoi(e) : HYST_LIST; return std::min(std::max(v, 1), (int)HYST_LIST); }();
+    static const long long lds_cap = [] { const char* e = getenv("CS_EDGE_HYST_LDS"); const long long v = e ? atoll(e) : 64 * 1024; return std::min<long long>(std::max<long long>(v, 8), 96 * 1024); }();
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(edge_hyst_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024 + 2 * HYST_LIST * (int)sizeof(int)); attr_set = true; }
+    // two size classes, so that ordinary ROIs do not reserve the LDS of the largest one (4 workgroups per CU under 32 KB)
+    const int big_px = (int)((std::min<long long>(std::max<long long>(max_px, 8), lds_cap) + 3) & ~3LL);
+    const int small_px = std::min(big_px, 32 * 1024);
+    hipLaunchKernelGGL(edge_hyst_kernel, dim3(n_rois), dim3(256), (size_t)small_px + 2 * HYST_LIST * sizeof(int), st, rois, cls_pool, map_pool, 0, small_px, list_cap, max_px > small_px ? 0 : 1);
+    if (max_px > small_px)
+      hipLaunchKernelGGL(edge_hyst_kernel, dim3(n_rois), dim3(256), (size_t)big_px + 2 * HYST_LIST * sizeof(int), st, rois, cls_pool, map_pool, small_px, big_px, list_cap, 1);
+  }
   hipLaunchKernelGGL(edge_dt_kernel, dim3(n_rois), dim3(64), 2 * (size_t)(max_w + 2) * sizeof(unsigned), st, rois, cls_pool, map_pool, max_w);
 }
 

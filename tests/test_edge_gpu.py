@@ -49,6 +49,30 @@ def test_edge_distance_maps_bit_identical_to_oracle():
     det.close()
 
 
+def test_hysteresis_paths_agree(monkeypatch):
+    """Small calls run the hysteresis in LDS (class bytes + two frontier lists) for ROIs that fit and in memory for larger ones, a frontier
+    that outgrows its list is finished by sweeps; large batches run it fused into the Canny kernel.  All of them must give the oracle's
+    map: forced here with a tiny list, a tiny LDS cap and the path switch (read once per process, so the variants run in child processes)."""
+    import os, subprocess, sys
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from cube_slam_wu_amd import capi\n"
+        "from oracle import edge_oracle_py as E\n"
+        "from tests.test_edge_gpu import _scene\n"
+        "gray = _scene(4)\n"
+        "rois = [(0, 0, 200, 150), (1000, 200, 241, 176), (300, 50, 333, 301), (5, 300, 60, 70), (600, 0, 17, 9), (700, 100, 257, 130), (100, 10, 1, 300)]\n"
+        "det = capi.Detector(capi.default_params())\n"
+        "for r, g in zip(rois, det.edge_distance_maps(gray, rois)):\n"
+        "    assert np.array_equal(g.view(np.uint32), E.edge_distance_map(gray, r).view(np.uint32)), r\n"
+        "det.close()\n"
+        "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env in ({"CS_EDGE_HYST": "lds", "CS_EDGE_HYST_LIST": "3"}, {"CS_EDGE_HYST": "lds", "CS_EDGE_HYST_LDS": "20000"},
+                {"CS_EDGE_HYST": "lds", "CS_EDGE_HYST_LIST": "40", "CS_EDGE_HYST_LDS": "40000"}, {"CS_EDGE_HYST": "lds"}, {"CS_EDGE_HYST": "fused"}):
+        out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (env, out.stderr[-2000:])
+
+
 def test_image_in_cuboids_out_matches_oracle_on_the_same_maps():
     """cs_detect_cuboids_gray == the oracle's detect_cuboid fed with the oracle's own Canny/DT maps."""
     fr = synth.make_frame(9100, n_boxes=3, n_lines=250)
