@@ -89,8 +89,8 @@ struct Field {
   int W, H;
   const double* angle;
   const double* weight;
-  std::vector<unsigned char> taken;
-  std::vector<Pixel> region;
+  unsigned char* taken = nullptr;   // (both live in the worker thread's reusable scratch, see lsd_host_stage)
+  Pixel* region = nullptr;
   int count = 0;                  // members of `region` in use
   double log_nt = 0;
 
@@ -284,10 +284,15 @@ struct Field {
 // the sequential half of one image: segments in the reference's order, post-processed as LSDDetector::detectImpl and filter_lines do
 int lsd_host_stage(int img_w, int img_h, int Ws, int Hs, const double* angle, const double* weight, double length_thres, float* lines4, int cap, int* n_lines) {
   *n_lines = 0;
+  // a region can grow to the whole image, so its array is image-sized (8 MB at KITTI size): kept per worker thread across calls instead of
+  // being allocated and page-faulted in per image
+  static thread_local std::vector<unsigned char> tl_taken;
+  static thread_local std::vector<Pixel> tl_region;
+  tl_taken.assign((size_t)Ws * Hs, 0);
+  if (tl_region.size() < (size_t)Ws * Hs) tl_region.resize((size_t)Ws * Hs);
   Field F;
   F.W = Ws; F.H = Hs; F.angle = angle; F.weight = weight;
-  F.taken.assign((size_t)Ws * Hs, 0);
-  F.region.resize((size_t)Ws * Hs);
+  F.taken = tl_taken.data(); F.region = tl_region.data();
   const double tol = kPi * kAngTh / 180, p = kAngTh / 180;
   F.log_nt = 5 * (std::log10((double)Ws) + std::log10((double)Hs)) / 2 + std::log10(11.0);
   const int min_region = (int)(-F.log_nt / std::log10(p));
