@@ -46,9 +46,10 @@ void launch_vp_points(const DetectDeviceView& v, int vp_total, hipStream_t st);
 int vp3_table_doubles_per_job();
 void launch_candidates(const DetectDeviceView& v, const SweepParams& sp, long long slot_total, hipStream_t st);
 void launch_scan_compact(const DetectDeviceView& v, hipStream_t st);
+void launch_scan_compact_trips(const DetectDeviceView& v, int* cnt, int max_trips, hipStream_t st);
 void launch_score(const DetectDeviceView& v, const SweepParams& sp, long long n_valid_bound, long long slot_total, hipStream_t st);
 void launch_gather_corners(const DetectDeviceView& v, const SweepParams& sp, const long long* slots, int n, double* out, hipStream_t st);
-void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams& rp, hipStream_t st);
+void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams& rp, hipStream_t st, long long max_slots_per_box = 0);
 void launch_records(const DetectDeviceView& v, const RankView& rv, int kmax, cs_cuboid* out, hipStream_t st, const double* raw_euler = nullptr);
 void launch_rp_carry(const RpCarryView& c, JobDesc* jobs, hipStream_t st);
 void launch_rp_save_fallback(const DetectDeviceView& v, const RpSaveView& s, hipStream_t st);
@@ -439,6 +440,7 @@ struct PipeSlot {
   struct RpRound { size_t j0 = 0, nj = 0, b0 = 0, nb = 0; long long slot_cap = 0; int vp_cap = 0; };
   std::vector<RpRound> rp_rounds;
   std::vector<int> rp_box_frame, rp_box_index;      // per box (all rounds): frame, box of the frame
+  DevBuf<int> rp_trip_cnt;                           // valid slots per (job of a round, compaction trip)
   DevBuf<int> rp_cur_idx, rp_tab_count, rp_maps;    // per frame: list in force; (frame, list) -> samples; per round: box / first job / jobs of a frame
   DevBuf<long long> rp_last_slot, rp_box_base;
   DevBuf<unsigned long long> rp_pool_used;
@@ -470,7 +472,7 @@ struct PipeSlot {
     vp_prefix.release(); top_x.release(); flag.release(); job_valid.release(); c_flag.release(); box_job0.release(); box_njobs.release(); win_count.release();
     fallback.release(); fb_cnt.release(); fb_flag.release(); mid_x.release(); mid_y.release(); ang.release(); yaw.release(); yaw_c.release(); yaw_s.release();
     vp.release(); bound.release(); bound3.release(); ls_order.release(); h_ls_order.release(); corners.release(); c_dist.release(); c_angle.release(); c_skew.release(); fb_dist.release(); fb_angle.release(); fb_skew.release();
-    win_corners.release(); winners.release(); records.release(); h_records.release(); rp_cur_idx.release(); rp_tab_count.release(); rp_maps.release(); rp_last_slot.release(); rp_box_base.release(); rp_pool_used.release(); rp_raw_euler.release(); h_rp_tab_count.release(); h_rp_maps.release(); h_rp_raw_euler.release(); h_rp_last_slot.release(); h_rp_box_base.release(); h_rp_pool_used.release(); h_jobs_in.release(); h_jobs_out.release(); h_slot_prefix.release(); h_job_cbase.release(); h_vp_prefix.release();
+    win_corners.release(); winners.release(); records.release(); h_records.release(); rp_trip_cnt.release(); rp_cur_idx.release(); rp_tab_count.release(); rp_maps.release(); rp_last_slot.release(); rp_box_base.release(); rp_pool_used.release(); rp_raw_euler.release(); h_rp_tab_count.release(); h_rp_maps.release(); h_rp_raw_euler.release(); h_rp_last_slot.release(); h_rp_box_base.release(); h_rp_pool_used.release(); h_jobs_in.release(); h_jobs_out.release(); h_slot_prefix.release(); h_job_cbase.release(); h_vp_prefix.release();
     h_top_x.release(); h_box_job0.release(); h_box_njobs.release(); h_win_count.release(); h_fallback.release(); h_job_valid.release(); h_yaw.release();
     h_yaw_c.release(); h_yaw_s.release(); h_winners.release();
     h_fb_src.release(); h_fb_dst.release(); h_fb_slot.release(); h_win_slots.release(); h_fb_cnt.release(); h_fb_flag.release(); h_fb_dist.release(); h_fb_angle.release();
@@ -1387,7 +1389,7 @@ int rp_launch(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>>&
   S.rp_rounds.assign(MB, PipeSlot::RpRound{});
   S.rp_box_frame.clear(); S.rp_box_index.clear();
   size_t ji = 0;
-  long long n_lines = 0, slot_cap_max = 0, slots_all = 0;
+  long long n_lines = 0, slot_cap_max = 0, slots_all = 0, max_job_slots = 0;
   int vp_cap_max = 0;
   size_t nj_round_max = 0;
   for (int r = 0; r < MB; r++) {
@@ -1430,6 +1432,7 @@ int rp_launch(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>>&
         jd.slot_off = so; jd.vp_off = (int)vo;
         S.h_slot_prefix.p[ji + r] = so; S.h_vp_prefix.p[ji + r] = (int)vo;
         so += (long long)nrp * ycap_f[f] * nT * 2;
+        max_job_slots = std::max(max_job_slots, (long long)nrp * ycap_f[f] * nT * 2);
         vo += ((long long)nrp * ycap_f[f] + 63) & ~63LL;
         S.h_jobs_in.p[ji++] = jd;
       }
@@ -1449,6 +1452,8 @@ int rp_launch(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>>&
   if (nj == 0) { S.in_flight = true; HIP_TRY(hipEventRecord(S.done, st)); return CS_OK; }
   // ---- device buffers; the per-round arrays are sized for the largest round and reused from round to round (one stream: in order)
   PENS(S.ls_order, nj); PENS(S.jobs, nj); PENS(S.slot_prefix, nj + MB + 1); PENS(S.vp_prefix, nj + MB + 1); PENS(S.job_valid, nj); PENS(S.job_cbase, nj + MB + 1);
+  const int max_trips = (int)std::min<long long>((max_job_slots + 4095) / 4096, 1 << 20);      // compaction trips of the largest job (4096 slots each)
+  PENS(S.rp_trip_cnt, (size_t)nj_round_max * (size_t)std::max(1, max_trips) + 1);
   PENS(S.mid_x, (size_t)n_lines + 1); PENS(S.mid_y, (size_t)n_lines + 1); PENS(S.ang, (size_t)n_lines + 1); PENS(S.yaw, n_yaw + 1); PENS(S.yaw_c, n_yaw + 1); PENS(S.yaw_s, n_yaw + 1);
   PENS(S.top_x, n_top + 1); PENS(S.vp, 6 * (size_t)vp_cap_max + 6); PENS(S.bound, 6 * (size_t)vp_cap_max + 6); PENS(S.bound3, nj_round_max * (size_t)cs::vp3_table_doubles_per_job() + 1);
   PENS(S.flag, slot_cap_max + 1); PENS(S.c_slot, slot_cap_max + 1); PENS(S.c_flag, slot_cap_max + 1); PENS(S.c_dist, slot_cap_max + 1); PENS(S.c_angle, slot_cap_max + 1); PENS(S.c_skew, slot_cap_max + 1);
@@ -1501,7 +1506,7 @@ int rp_launch(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>>&
     HIP_TRY(hipEventRecord(re[0], st));
     cs::launch_vp_points(v, Rr.vp_cap, st);
     cs::launch_candidates(v, C.sp, Rr.slot_cap, st);
-    cs::launch_scan_compact(v, st);
+    cs::launch_scan_compact_trips(v, S.rp_trip_cnt.p, max_trips, st);
     HIP_TRY(hipEventRecord(re[1], st));
     cs::launch_vp_support_only(v, C.sp, Rr.vp_cap, st);
     HIP_TRY(hipEventRecord(re[2], st));
@@ -1510,7 +1515,7 @@ int rp_launch(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>>&
     cs::RankView rv{};
     rv.box_job0 = S.box_job0.p + Rr.b0; rv.box_njobs = S.box_njobs.p + Rr.b0; rv.n_boxes = (int)Rr.nb; rv.winners = S.winners.p + Rr.b0 * KMAX;
     rv.win_count = S.win_count.p + Rr.b0; rv.fallback = S.fallback.p + Rr.b0; rv.last_slot = S.rp_last_slot.p + Rr.b0;
-    cs::launch_rank(v, rv, rkp, st);
+    cs::launch_rank(v, rv, rkp, st, Rr.nb ? (long long)(Rr.slot_cap / (long long)Rr.nb) : 0);      // (average slots per box of the round: which instance ranks)
     cs::launch_records(v, rv, KMAX, S.records.p + Rr.b0 * KMAX, st, S.rp_raw_euler.p);
     {   // the flagged boxes' columns, before the next round reuses the arrays
       cs::RpSaveView sv{};

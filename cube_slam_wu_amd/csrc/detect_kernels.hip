@@ -684,6 +684,57 @@ __global__ __launch_bounds__(256) void compact_kernel(DetectDeviceView v) {
   }
 }
 
+// The same compaction for jobs of many trips (roll/pitch sampling: 25 poses, ~79 k slots, twenty trips that the one workgroup per job
+// above walks one after the other -- 0.13 ms per round on ~100 jobs): a workgroup per (job, trip).  compact_count_kernel counts the
+// valid slots of every trip, compact_chunk_kernel starts a trip at the job's base + the counts of the job's earlier trips.
+__global__ __launch_bounds__(256) void compact_count_kernel(DetectDeviceView v, int* __restrict__ cnt, int maxc) {
+  const int j = blockIdx.x, c = blockIdx.y;
+  __shared__ int wsum[4];
+  const long long end = v.slot_prefix[j + 1], s0 = v.slot_prefix[j] + (long long)c * (256 * COMPACT_PER), s1 = (s0 + 256 * COMPACT_PER < end) ? s0 + 256 * COMPACT_PER : end;
+  int n = 0;
+  for (long long sl = s0 + threadIdx.x; sl < s1; sl += 256) n += v.flag[sl] != 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[(size_t)j * maxc + c] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(256) void compact_chunk_kernel(DetectDeviceView v, const int* __restrict__ cnt, int maxc) {
+  const int j = blockIdx.x, c = blockIdx.y;
+  __shared__ int wsum[4];
+  const long long s1 = v.slot_prefix[j + 1], base = v.slot_prefix[j] + (long long)c * (256 * COMPACT_PER);
+  if (base >= s1) return;
+  long long run = v.job_cbase[j];
+  for (int q = 0; q < c; q++) run += cnt[(size_t)j * maxc + q];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const long long w0 = base + (long long)wid * (64 * COMPACT_PER) + lane;
+  int f[COMPACT_PER];
+  int wcount = 0;
+#pragma unroll
+  for (int q = 0; q < COMPACT_PER; q++) {
+    const long long sl = w0 + q * 64;
+    f[q] = (sl < s1) ? v.flag[sl] : 0;
+    wcount += __popcll(__ballot(f[q] != 0));
+  }
+  if (lane == 0) wsum[wid] = wcount;
+  __syncthreads();
+  int woff = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) if (w < wid) woff += wsum[w];
+  long long pos0 = run + woff;
+#pragma unroll
+  for (int q = 0; q < COMPACT_PER; q++) {
+    const unsigned long long bal = __ballot(f[q] != 0);
+    if (f[q] != 0) {
+      const long long pos = pos0 + __popcll(bal & below);
+      v.c_slot[pos] = w0 + q * 64;
+      v.c_flag[pos] = f[q] | (j << CAND_JOB_SHIFT);
+    }
+    pos0 += __popcll(bal);
+  }
+}
+
 __global__ __launch_bounds__(64) void gather_corners_kernel(DetectDeviceView v, double short_sq_bound, const long long* slots, int n, double* out) {
   int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n) return;
@@ -798,15 +849,23 @@ struct JobCut {      // per height sample of the box
 };
 
 enum { RANK_STAGE = 1536, RANK_THREADS_DEFAULT = 256 };   // proposals of one height sample staged in LDS (2 x 12 KB)
-template <int NT>
-__global__ __launch_bounds__(NT) void rank_kernel(DetectDeviceView v, RankView rv, RankParams rp) {
+// DYN: the staging columns in dynamic LDS, stage_cap proposals each -- the roll/pitch-sampling rounds, where a box holds ~9 000 valid
+// proposals (25 camera poses) and only ~100 boxes are ranked per launch: a workgroup then owns a CU's LDS and 16 waves, and the ~20
+// selection passes run from LDS instead of L2
+enum { RANK_STAGE_BIG = 9216, RANK_THREADS_BIG = 1024 };
+template <int NT, bool DYN>
+__global__ __launch_bounds__(NT) void rank_kernel(DetectDeviceView v, RankView rv, RankParams rp, int stage_cap) {
   __shared__ unsigned hist[512];
   __shared__ unsigned long long bcast[4];
-  __shared__ double shd[4];
-  __shared__ int shi[4];
+  __shared__ double shd[NT / 64 > 4 ? NT / 64 : 4];
+  __shared__ int shi[NT / 64 > 4 ? NT / 64 : 4];
   __shared__ JobCut cuts[3];
   __shared__ int s_fallback;
-  __shared__ double sD[RANK_STAGE], sA[RANK_STAGE];
+  __shared__ double sD_fixed[DYN ? 1 : RANK_STAGE], sA_fixed[DYN ? 1 : RANK_STAGE];
+  extern __shared__ double rank_dyn_lds[];
+  double* const sD = DYN ? rank_dyn_lds : sD_fixed;
+  double* const sA = DYN ? rank_dyn_lds + stage_cap : sA_fixed;
+  const int STAGE = DYN ? stage_cap : (int)RANK_STAGE;
   int box = blockIdx.x;
   if (box >= rv.n_boxes) return;
   if (threadIdx.x == 0) s_fallback = 0;
@@ -822,7 +881,7 @@ __global__ __launch_bounds__(NT) void rank_kernel(DetectDeviceView v, RankView r
     const double* A = v.c_angle + c0;
     // the selection below makes ~20 passes over the two columns: from LDS when they fit (they do unless nearly every slot of a
     // large box is valid), each pass then costs LDS latency instead of a round trip to L2
-    if (V <= RANK_STAGE) {
+    if (V <= STAGE) {
       __syncthreads();
       for (int i = threadIdx.x; i < V; i += NT) { sD[i] = D[i]; sA[i] = A[i]; }
       __syncthreads();
@@ -924,7 +983,7 @@ __global__ __launch_bounds__(NT) void rank_kernel(DetectDeviceView v, RankView r
   }
   // ---- final ranking over the proposals of all height samples: kmax rounds of arg-min, one pass over the proposals per round
   // (every thread keeps its own minimum, how many of its proposals attain it, and that proposal's record)
-  const bool staged = (nj == 1) && (cuts[0].V <= RANK_STAGE);   // the columns of the only height sample are still in LDS
+  const bool staged = (nj == 1) && (cuts[0].V <= STAGE);   // the columns of the only height sample are still in LDS
   double prev = -INF;
   int n_win = 0;
   for (int round = 0; round < rp.kmax; round++) {
@@ -1304,6 +1363,14 @@ void launch_scan_compact(const DetectDeviceView& v, hipStream_t st) {
   hipLaunchKernelGGL(scan_jobs_kernel, dim3(1), dim3(1024), 0, st, v.job_valid, v.job_cbase, v.n_jobs);
   hipLaunchKernelGGL(compact_kernel, dim3(v.n_jobs), dim3(256), 0, st, v);
 }
+// ... with a workgroup per (job, trip): cnt = n_jobs x max_trips ints of scratch, max_trips = the largest job's slots / 4096, rounded up
+void launch_scan_compact_trips(const DetectDeviceView& v, int* cnt, int max_trips, hipStream_t st) {
+  if (v.n_jobs <= 0) return;
+  if (max_trips <= 2 || max_trips > 65535) { launch_scan_compact(v, st); return; }
+  hipLaunchKernelGGL(scan_jobs_kernel, dim3(1), dim3(1024), 0, st, v.job_valid, v.job_cbase, v.n_jobs);
+  hipLaunchKernelGGL(compact_count_kernel, dim3(v.n_jobs, max_trips), dim3(256), 0, st, v, cnt, max_trips);
+  hipLaunchKernelGGL(compact_chunk_kernel, dim3(v.n_jobs, max_trips), dim3(256), 0, st, v, cnt, max_trips);
+}
 // scoring over the compacted proposals; n_valid_bound is an upper bound known on the host (the exact count stays on the device)
 void launch_score(const DetectDeviceView& v, const SweepParams& sp, long long n_valid_bound, long long slot_total, hipStream_t st) {
   if (skip_kernel("score")) return;
@@ -1326,13 +1393,22 @@ void launch_gather_ranges(const DetectDeviceView& v, const long long* src_off, c
   if (n_ranges <= 0) return;
   hipLaunchKernelGGL(gather_ranges_kernel, dim3(n_ranges), dim3(256), 0, st, v, src_off, count, dst_off, n_ranges, o_dist, o_angle, o_skew, o_flag, o_slot);
 }
-void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams& rp, hipStream_t st) {
+void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams& rp, hipStream_t st, long long max_slots_per_box) {
   if (skip_kernel("rank")) return;
   if (rv.n_boxes <= 0) return;
   static const int nt = [] { const char* e = getenv("CS_RANK_THREADS"); const int q = e ? atoi(e) : 0; return (q == 64 || q == 128 || q == 256) ? q : RANK_THREADS_DEFAULT; }();
-  if (nt == 64) hipLaunchKernelGGL(rank_kernel<64>, dim3(rv.n_boxes), dim3(64), 0, st, v, rv, rp);
-  else if (nt == 128) hipLaunchKernelGGL(rank_kernel<128>, dim3(rv.n_boxes), dim3(128), 0, st, v, rv, rp);
-  else hipLaunchKernelGGL(rank_kernel<256>, dim3(rv.n_boxes), dim3(256), 0, st, v, rv, rp);
+  static const bool no_big = getenv("CS_RANK_NO_BIG") != nullptr;     // diagnostics / tests: the ordinary instance for every launch
+  // boxes that can hold far more valid proposals than the fixed staging columns (the caller's bound on a box's slots): the big instance
+  if (!no_big && max_slots_per_box > 8 * (long long)RANK_STAGE) {
+    static bool attr_set = false;
+    const size_t lds = 2 * (size_t)RANK_STAGE_BIG * sizeof(double);
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rank_kernel<RANK_THREADS_BIG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    hipLaunchKernelGGL((rank_kernel<RANK_THREADS_BIG, true>), dim3(rv.n_boxes), dim3(RANK_THREADS_BIG), lds, st, v, rv, rp, (int)RANK_STAGE_BIG);
+    return;
+  }
+  if (nt == 64) hipLaunchKernelGGL((rank_kernel<64, false>), dim3(rv.n_boxes), dim3(64), 0, st, v, rv, rp, (int)RANK_STAGE);
+  else if (nt == 128) hipLaunchKernelGGL((rank_kernel<128, false>), dim3(rv.n_boxes), dim3(128), 0, st, v, rv, rp, (int)RANK_STAGE);
+  else hipLaunchKernelGGL((rank_kernel<256, false>), dim3(rv.n_boxes), dim3(256), 0, st, v, rv, rp, (int)RANK_STAGE);
 }
 void launch_records(const DetectDeviceView& v, const RankView& rv, int kmax, cs_cuboid* out, hipStream_t st, const double* raw_euler) {
   if (skip_kernel("records")) return;
