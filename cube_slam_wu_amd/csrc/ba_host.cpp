@@ -88,42 +88,81 @@ namespace {
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// Pinned staging for the structure phase's many small uploads: a blocking hipMemcpy from pageable memory costs ~40 us whatever its
+// size, and the phase makes a few dozen; through this arena they are queued on the handle's stream and waited for once.
+struct StageArena {
+  char* p = nullptr;
+  size_t cap = 0, off = 0;
+  void* take(size_t bytes) {          // nullptr: no room (the caller copies directly)
+    const size_t at = (off + 63) & ~(size_t)63;
+    if (!p || at + bytes > cap) return nullptr;
+    off = at + bytes;
+    return p + at;
+  }
+  int begin(size_t want) {            // at the start of a structure phase, the stream idle
+    off = 0;
+    if (p && cap >= want) return CS_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    BA_TRY(hipHostMalloc((void**)&p, want));
+    cap = want;
+    return CS_OK;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = off = 0; }
+};
+
 template <class T>
 struct DBuf {
   T* p = nullptr;
-  size_t n = 0;
+  size_t n = 0, cap = 0;       // entries in use / allocated (grow-only: a graph that is extended frame by frame re-runs the structure phase,
+                               // and ~100 hipFree + hipMalloc pairs were a quarter of it at 200 cameras)
+  int reserve(size_t count) {
+    count = std::max<size_t>(1, count);
+    if (p && count <= cap) return CS_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    BA_TRY(hipMalloc((void**)&p, count * sizeof(T)));
+    cap = count;
+    return CS_OK;
+  }
   int upload_ptr(const T* h, size_t count) {   // from the caller's memory
-    if (p) { (void)hipFree(p); p = nullptr; }
+    int rc = reserve(count); if (rc) return rc;
     n = count;
-    BA_TRY(hipMalloc((void**)&p, std::max<size_t>(1, n) * sizeof(T)));
     if (n) BA_TRY(hipMemcpy(p, h, n * sizeof(T), hipMemcpyHostToDevice));
     return CS_OK;
   }
   int append_ptr(const T* h, size_t count) {   // the old contents stay where they are on the device, `count` new entries follow
     if (!count) return CS_OK;
-    T* q = nullptr;
-    BA_TRY(hipMalloc((void**)&q, (n + count) * sizeof(T)));
-    if (n) BA_TRY(hipMemcpy(q, p, n * sizeof(T), hipMemcpyDeviceToDevice));
-    BA_TRY(hipMemcpy(q + n, h, count * sizeof(T), hipMemcpyHostToDevice));
-    if (p) (void)hipFree(p);
-    p = q; n += count;
+    if (!p || n + count > cap) {               // (with head room: the next frames append in place)
+      const size_t want = std::max(n + count, cap + cap / 2 + 16);
+      T* q = nullptr;
+      BA_TRY(hipMalloc((void**)&q, want * sizeof(T)));
+      if (n) BA_TRY(hipMemcpy(q, p, n * sizeof(T), hipMemcpyDeviceToDevice));
+      if (p) (void)hipFree(p);
+      p = q; cap = want;
+    }
+    BA_TRY(hipMemcpy(p + n, h, count * sizeof(T), hipMemcpyHostToDevice));
+    n += count;
     return CS_OK;
   }
-  int upload(const std::vector<T>& h) {
-    if (p) { (void)hipFree(p); p = nullptr; }
+  int upload(const std::vector<T>& h) { return upload_ptr(h.data(), h.size()); }
+  int upload_staged(const std::vector<T>& h, StageArena& stage, hipStream_t st) {   // small vectors: through the pinned arena, queued on st
+    const size_t bytes = h.size() * sizeof(T);
+    void* pin = (bytes && bytes <= (256u << 10)) ? stage.take(bytes) : nullptr;
+    if (!pin) return upload(h);
+    int rc = reserve(h.size()); if (rc) return rc;
     n = h.size();
-    BA_TRY(hipMalloc((void**)&p, std::max<size_t>(1, n) * sizeof(T)));
-    if (n) BA_TRY(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+    std::memcpy(pin, h.data(), bytes);
+    BA_TRY(hipMemcpyAsync(p, pin, bytes, hipMemcpyHostToDevice, st));
     return CS_OK;
   }
-  int alloc(size_t count) {
-    if (p) { (void)hipFree(p); p = nullptr; }
+  int alloc(size_t count, hipStream_t st = nullptr) {   // zeroed; st: queued on that stream instead of a blocking call per buffer
+    int rc = reserve(count); if (rc) return rc;
     n = count;
-    BA_TRY(hipMalloc((void**)&p, std::max<size_t>(1, n) * sizeof(T)));
-    BA_TRY(hipMemset(p, 0, std::max<size_t>(1, n) * sizeof(T)));
+    if (st) BA_TRY(hipMemsetAsync(p, 0, std::max<size_t>(1, n) * sizeof(T), st));
+    else BA_TRY(hipMemset(p, 0, std::max<size_t>(1, n) * sizeof(T)));
     return CS_OK;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; cap = 0; }
 };
 
 }  // namespace
@@ -131,6 +170,7 @@ struct DBuf {
 struct cs_ba {
   int device = 0;
   hipStream_t st = nullptr;
+  StageArena stage;                          // pinned staging of the structure phase's small uploads
   hipStream_t st2 = nullptr;                 // side stream of the reduce phase (cuboid elimination beside the landmark segments)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t st3 = nullptr;                 // third stream of the linearisation: the landmark kernel beside the camera kernel (which fills a fraction of the CUs)
@@ -253,6 +293,8 @@ void landmark_owners(int n_ranks, int n_cams, int n_points, int n_proj, const in
 int finalize_structure(cs_ba* B) {
   if (!B->structure_dirty) return CS_OK;
   BA_TRY(hipSetDevice(B->device));
+  BA_TRY(hipStreamSynchronize(B->st));             // nothing of an earlier call may still read the buffers (or the staging arena) reused below
+  { const int rc0 = B->stage.begin((size_t)8 << 20); if (rc0) return rc0; }
   static const bool prof = getenv("CS_BA_PROF") != nullptr;   // diagnostics: host phase clock of the structure phase
   double t_ph = now_ms();
   auto mark = [&](const char* what) { if (prof) { double t = now_ms(); fprintf(stderr, "[ba structure] %-28s %8.2f ms\n", what, t - t_ph); t_ph = t; } };
@@ -516,8 +558,8 @@ int finalize_structure(cs_ba* B) {
   for (int i = 0; i < np; i++) { pt_free[i] = B->pt_fixed[i] ? 0 : 1; if (pt_free[i]) B->pt_lm[i] = nl++; }
   B->n_lm = nl;
   int rc;
-#define UP(buf, vec) do { rc = (buf).upload(vec); if (rc) return rc; } while (0)
-#define AL(buf, n) do { rc = (buf).alloc(n); if (rc) return rc; } while (0)
+#define UP(buf, vec) do { rc = (buf).upload_staged(vec, B->stage, B->st); if (rc) return rc; } while (0)
+#define AL(buf, n) do { rc = (buf).alloc(n, B->st); if (rc) return rc; } while (0)
   UP(B->d_cam_col, B->cam_col); UP(B->d_cub_col, B->cub_col); UP(B->d_pt_free, pt_free);
   // ---- projection edges: point-major order (sorted by pose column inside a point), camera-major copy.  The edges are already
   // grouped by landmark with their cameras sorted by id (cams_of / edge_of above); a rank's point-major table is its own landmarks'
@@ -864,9 +906,8 @@ int finalize_structure(cs_ba* B) {
   v.n_gpairs = B->n_gpairs; v.gpair_ptr = B->d_gp_ptr.p; v.gpair_i1 = B->d_gp_i1.p; v.gpair_i2 = B->d_gp_i2.p; v.gtile = B->d_gtile.p;
   v.gcam_ptr = B->d_gcam_ptr.p; v.gslot = B->d_gslot.p;
   v.chi_partial = B->chi_partial.p;
-  // the allocations above were zeroed by hipMemset on the NULL stream, which a non-blocking stream does not wait for:
-  // drain it before the first kernel of B->st can write into those buffers
-  BA_TRY(hipDeviceSynchronize());
+  // the allocations above were zeroed on B->st (queued, one wait here); uploads went through blocking copies
+  BA_TRY(hipStreamSynchronize(B->st));
   mark("pose edges + allocations");
   B->structure_dirty = false;
   B->have_system = false;
@@ -1173,6 +1214,7 @@ void cs_ba_destroy(cs_ba* B) {
                         &B->oe_meas, &B->oe_info, &B->oe_Hii, &B->oe_Hjj, &B->oe_Hij, &B->oe_bi, &B->oe_bj, &B->Hcam, &B->bcam, &B->Hcub, &B->bcub, &B->Hll, &B->bl,
                         &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv, &B->scale_partial, &B->pe_meas, &B->pe_info, &B->pe_K, &B->part_tiles, &B->part_coef, &B->cub_M, &B->cub_Dinv, &B->raw_uv, &B->raw_info, &B->raw_intr, &B->raw_huber, &B->sepY, &B->sep_msgs, &B->sepS, &B->int_work, &B->sep_work};
   for (auto* d : dd) d->release();
+  B->stage.release();
   DBuf<int>* di[] = {&B->d_ce_active, &B->d_oe_active, &B->d_cam_col, &B->d_cub_col, &B->d_pt_free, &B->pm_pt, &B->pm_cam, &B->pt_ptr, &B->cm_pm, &B->cm_pt, &B->cam_ptr, &B->d_ce_cam, &B->d_ce_cub,
                      &B->d_oe_i, &B->d_oe_j, &B->cam_ce_ptr, &B->cam_ce_idx, &B->cam_oei_ptr, &B->cam_oei_idx, &B->cam_oej_ptr, &B->cam_oej_idx, &B->cub_ce_ptr,
                      &B->cub_ce_idx, &B->pair_ptr, &B->pair_i1, &B->pair_i2, &B->ent_a, &B->ent_b, &B->d_run_lm, &B->d_seg_ptr, &B->d_seg_k, &B->d_seg_tile, &B->d_seg_slot,
