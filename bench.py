@@ -722,6 +722,31 @@ def main():
             dt = time.perf_counter() - t1
             out["cpu_baseline"] = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": "%d frames of the same workload through oracle/detect_oracle.cpp (-O2, libm atan2, single thread) in %.1f s" % (n, dt)}
+            # for context only: the same restatement on every core this process may use, one independent process per core, the
+            # frames dealt out among them -- the reference itself is single-threaded, so `value` above stays the baseline
+            try:
+                import subprocess
+                ncore = len(os.sched_getaffinity(0))
+                try:
+                    q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                    if q != "max":
+                        ncore = max(1, min(ncore, int(q) // int(per)))
+                except (OSError, ValueError):
+                    pass
+                code = ("import sys, time; sys.path.insert(0, %r)\n"
+                        "from cube_slam_wu_amd import synth\n"
+                        "from oracle import oracle_py\n"
+                        "k = int(sys.argv[1]); uniq = [synth.make_frame(100000 + s) for s in range(k, %d, %d)][:6]\n"
+                        "op = oracle_py.default_params(yaw_step_deg=0.5); oracle_py.detect_cuboid(uniq[0], op, atan2_mode=0)\n"
+                        "n, t1 = 0, time.perf_counter()\n"
+                        "while time.perf_counter() - t1 < 4.0:\n"
+                        "    oracle_py.detect_cuboid(uniq[n %% len(uniq)], op, atan2_mode=0); n += 1\n"
+                        "print(n / (time.perf_counter() - t1))\n") % (os.path.dirname(os.path.abspath(__file__)), n_unique, ncore)
+                procs = [subprocess.Popen([sys.executable, "-c", code, str(k)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for k in range(ncore)]
+                rates = [float(pp.communicate(timeout=120)[0].strip().splitlines()[-1]) for pp in procs]
+                out["cpu_baseline"]["all_cores"] = {"value": sum(rates), "unit": "frames/s", "cores": ncore, "kind": "port, one process per core (context only: the reference is single-threaded)"}
+            except Exception as e:       # context only: never fatal
+                out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
         if edge_out is not None:
             out["edge_front_end"] = edge_out
         if rp_out is not None:
