@@ -761,6 +761,7 @@ def main():
         # every rank arms the same watchdog: if the collective leg does not come back (or a rank dies in it and the others wait for
         # it), rank 0 prints the line it has -- `ba` saying so -- and every rank leaves with status 0
         limit = float(os.environ.get("CS_BENCH_BA_LIMIT_S", "240"))
+        barrier()        # rank 0 comes from its single-GPU legs (front end, latency, line producer): the clocks below start together
 
         def bail(reason):
             if rank == 0:
