@@ -144,14 +144,20 @@ def main():
     import threading
     inflight = max(1, args.inflight)
     host_threads = args.host_threads
+    granted = os.cpu_count() or 64
+    quota = False
+    try:   # a cgroup CPU quota is what the host stages of all ranks really share
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            granted, quota = max(1, min(granted, int(q) // int(per))), True
+    except (OSError, ValueError):
+        pass
+    if world > 1:
+        # N ranks on one node share the node's cores: a pipeline's host stages (packing, records, the tie boxes' exact ranking) want about
+        # four of them, so a rank only keeps as many batches in flight as its share of the cores can feed
+        inflight = max(1, min(inflight, granted // (4 * world)))
     if host_threads == 0 and world * inflight > 1:
-        cpus = os.cpu_count() or 64
-        try:   # a cgroup CPU quota is what the pools really share (three threads per granted CPU, as the library's default)
-            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-            if q != "max":
-                cpus = min(cpus, 3 * int(q) // int(per))
-        except (OSError, ValueError):
-            pass
+        cpus = 3 * granted if quota else granted     # under a quota: three threads per granted CPU, as the library's default
         host_threads = max(8, min(64, cpus // (world * inflight)))
     params = capi.default_params(whether_sample_cam_roll_pitch=0, whether_sample_bbox_height=0, yaw_range_deg=45.0, yaw_step_deg=0.5, host_threads=host_threads)
     # every pipeline (host thread + detector) owns `depth` batches: it submits the next one (cs_batch_submit: host packing + the sweep
