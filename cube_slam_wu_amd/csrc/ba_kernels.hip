@@ -905,6 +905,29 @@ __global__ __launch_bounds__(256) void ba_update_kernel(BaView v) {
 //                           that does not depend on x prefetched one step ahead); band_sep_* handle the separator.
 enum { BS = 32 };
 
+// Hand-offs between workgroups (other CUs, mostly other XCDs -- whose L2s are not coherent with each other): every shared double is written
+// with a write-through (sc1) store and read with an sc1 load that bypasses the reader's L1 -- 8-byte agent-scope relaxed atomics on both
+// sides, the second of the valid forms of MI355X_MICROARCH.md -- so a producer only drains its stores (s_waitcnt vmcnt(0)) before it
+// raises a counter or a flag, and a consumer only polls: no buffer_wbl2 (a write-back of the XCD's whole L2, >= 1.7 us) per release and
+// no buffer_inv per acquire, which is what most of a step's chain used to consist of.  BAND_WT 0 restores plain accesses + agent fences.
+#ifndef BAND_WT
+#define BAND_WT 1
+#endif
+#ifndef BAND_WT_LOADS_
+#define BAND_WT_LOADS_ 0     // 1: sc1 loads instead of acquire fence + plain loads (measured slower: the strip gather re-reads every entry many times and sc1 loads never hit)
+#endif
+__device__ __forceinline__ void band_release() {
+#if !BAND_WT
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+}
+__device__ __forceinline__ void band_acquire() {
+#if !(BAND_WT && BAND_WT_LOADS_)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
+
+
 // Bounded wait on a monotone counter.  The persistent kernels below need their whole team resident; the host checks that
 // against the occupancy query before choosing the banded path (ba_band_fits_device), but a GPU shared with another process's
 // persistent kernel can still starve a team.  Such a launch must fail, not hang: after ~1 s of polling the waiter raises the
@@ -934,11 +957,11 @@ __device__ __forceinline__ void band_grid_sync(unsigned* bar, unsigned target) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    band_release();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     band_wait_ge(bar, target);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    band_acquire();
   }
   __syncthreads();
 }
@@ -1058,7 +1081,20 @@ __device__ __attribute__((noinline)) bool band_potf2_inv_k0(const double (*U)[BS
 __device__ __attribute__((noinline)) bool band_potf2_inv_k1(const double (*U)[BS + 1], int nb, double (*Dl)[BS + 1], double (*X)[BS + 1], double* colbuf) { return band_potf2_inv4b_impl(U, nb, Dl, X, colbuf); }
 
 typedef const __attribute__((address_space(1))) double* band_gptr;   // global address space: a noinline function would otherwise emit flat loads
-__device__ __forceinline__ double band_gload(const double* p) { return *(band_gptr)(p); }
+__device__ __forceinline__ double band_gload(const double* p) {
+#if BAND_WT && BAND_WT_LOADS_
+  return __longlong_as_double((long long)__hip_atomic_load((const __attribute__((address_space(1))) unsigned long long*)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#else
+  return *(band_gptr)(p);
+#endif
+}
+__device__ __forceinline__ void band_gstore(double* p, double v) {
+#if BAND_WT
+  __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *p = v;
+#endif
+}
 
 // panel rows per workgroup, per kernel.  16 in both: 8 rows in the nested kernel (twice the workgroups, half the product and
 // panel work) was measured slower, 1.95 -> 2.15 ms at C4 -- what the halves save, the doubled teams lose in the barrier (2.5 ->
@@ -1214,7 +1250,7 @@ __device__ __forceinline__ void band_grid_arrive(unsigned* bar) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    band_release();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -1255,7 +1291,7 @@ __device__ __forceinline__ void band_step(const BandLds& M, const BandView& view
   // the inverse of the block's factor comes from the front's diagonal workgroup (band_diag_phase), normally before it is asked for
   if (tid == 0) {
     band_wait_ge(dflag, dtarget);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    band_acquire();
   }
   __syncthreads();
   {
@@ -1279,9 +1315,9 @@ __device__ __forceinline__ void band_step(const BandLds& M, const BandView& view
 #pragma unroll
         for (int u = 0; u < 4; u++) sa[u] = fma(M.U[rr][t + u], M.X[cc][t + u], sa[u]);
       const double sacc = (sa[0] + sa[1]) + (sa[2] + sa[3]);
-      if (i >= 0) { if (i - (k0 + cc) <= bw) view.base[(long long)i * view.si + (long long)(k0 + cc) * view.sj] = sacc; }
-      else if (i == -2) view.rb[(long long)(k0 + cc) * view.sr] = sacc;
-      else if (AUG) { const int qa = -16 - i; aug.lc[(long long)(aug.t0 + k0 + cc) * aug.wc + (aug.qflip ? aug.wc - 1 - qa : qa)] = sacc; }
+      if (i >= 0) { if (i - (k0 + cc) <= bw) band_gstore(&view.base[(long long)i * view.si + (long long)(k0 + cc) * view.sj], sacc); }
+      else if (i == -2) band_gstore(&view.rb[(long long)(k0 + cc) * view.sr], sacc);
+      else if (AUG) { const int qa = -16 - i; band_gstore(&aug.lc[(long long)(aug.t0 + k0 + cc) * aug.wc + (aug.qflip ? aug.wc - 1 - qa : qa)], sacc); }
     }
   }
   if (tp) { long long t_now = wall_clock64(); tp[4] += t_now - *t_prev; *t_prev = t_now; }
@@ -1340,7 +1376,7 @@ __device__ __forceinline__ void band_diag_phase(const BandLds& M, const BandView
   auto wait_for = [&](unsigned* ctr, unsigned target) {
     if (tid == 0) {
       band_wait_ge(ctr, target);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      band_acquire();
     }
     __syncthreads();
   };
@@ -1402,14 +1438,14 @@ __device__ __forceinline__ void band_diag_phase(const BandLds& M, const BandView
       double* Li = Linv + (size_t)(k0 / BS) * BS * BS;
       for (int e = tid; e < BS * BS; e += 256) {
         const int rr = e >> 5, cc = e & 31;
-        Li[e] = M.X[rr][cc];
-        if (rr < nb && cc <= rr && rr - cc <= bw) view.base[(long long)(k0 + rr) * view.si + (long long)(k0 + cc) * view.sj] = M.Dl[rr][cc];
+        band_gstore(&Li[e], M.X[rr][cc]);
+        if (rr < nb && cc <= rr && rr - cc <= bw) band_gstore(&view.base[(long long)(k0 + rr) * view.si + (long long)(k0 + cc) * view.sj], M.Dl[rr][cc]);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      band_release();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_store(flag, f0 + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1597,14 +1633,18 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
     // one 32-column block behind it (waits on team 1's barrier counter without taking part in it)
     const int ldb = wc + 1, Th = nh - BS * H.K1, nstep = (Th + BS - 1) / BS;
     double* buf = R;                         // 32 x (wc + 1): rows of lc + the right-hand side entry
-    const int rr = tid >> 4, cg = tid & 15, tt8 = tid >> 3, l8 = tid & 7;
-    double acc[16], accy = 0.0;
+    const int tt8 = tid >> 3, l8 = tid & 7, lane = tid & 63, wv4 = tid >> 6, li = lane & 15, lk = lane >> 4;
+    // the slab's 16 x wc block on the matrix cores: wave w takes the 16-column tiles w, w + 4, ... (wc <= 256: at most four), every
+    // step is 8 x 16x16x4 issues per tile -- the multiply-add form read 17 LDS words per row of the step and per thread, and had
+    // become the slowest team of the kernel once the fronts' hand-offs got cheaper
+    ba_v4d acc[4];
 #pragma unroll
-    for (int u = 0; u < 16; u++) acc[u] = 0.0;
+    for (int q = 0; q < 4; q++) acc[q] = ba_v4d{0.0, 0.0, 0.0, 0.0};
+    double accy = 0.0;                       // threads 0..15: the slab's share of sum_t L(i, t) y(t)
     for (int sidx = 0; sidx < nstep; sidx++) {
       if (tid == 0) {
         band_wait_ge(bars + 1, (unsigned)(sidx + 1) * (unsigned)G1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        band_acquire();
       }
       __syncthreads();
       const int t = sidx * BS + tt8;
@@ -1617,18 +1657,29 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
       for (int u = 0; u < 32; u++) if (8 * u < wc) buf[tt8 * ldb + l8 + 8 * u] = vals[u];
       if (l8 == 0) buf[tt8 * ldb + wc] = yv;
       __syncthreads();
-#pragma unroll 4
-      for (int tt = 0; tt < 32; tt++) {
-        const double rv = buf[tt * ldb + wi * 16 + rr];
 #pragma unroll
-        for (int u = 0; u < 16; u++) if (16 * u < wc) acc[u] = fma(rv, buf[tt * ldb + cg + 16 * u], acc[u]);
-        accy = fma(rv, buf[tt * ldb + wc], accy);
+      for (int t0 = 0; t0 < BS; t0 += 4) {
+        const double* bt = buf + (t0 + lk) * ldb;
+        const double a = bt[wi * 16 + li];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int ct = wv4 + 4 * q;
+          if (16 * ct < wc) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bt[16 * ct + li], acc[q], 0, 0, 0);
+        }
+      }
+      if (tid < 16) {
+#pragma unroll 8
+        for (int tt = 0; tt < BS; tt++) accy = fma(buf[tt * ldb + wi * 16 + tid], buf[tt * ldb + wc], accy);
       }
     }
-    double* po = P.part + ((size_t)hid * wc + wi * 16 + rr) * ldb;
 #pragma unroll
-    for (int u = 0; u < 16; u++) if (16 * u < wc) po[cg + 16 * u] = acc[u];
-    if (cg == 0) po[wc] = accy;
+    for (int q = 0; q < 4; q++) {
+      const int ct = wv4 + 4 * q;
+      if (16 * ct >= wc) continue;
+#pragma unroll
+      for (int g = 0; g < 4; g++) band_gstore(&P.part[((size_t)hid * wc + wi * 16 + lk + 4 * g) * ldb + 16 * ct + li], acc[q][g]);
+    }
+    if (tid < 16) band_gstore(&P.part[((size_t)hid * wc + wi * 16 + tid) * ldb + wc], accy);
     band_grid_arrive(P.bars + 6);
     return;
   }
@@ -1672,11 +1723,11 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
   if (wi < nslab) {
     const int ldb = wc + 1, rr = tid >> 4, cg = tid & 15, i = wi * 16 + rr;
     for (int j = cg; j <= wc; j += 16) {
-      const double s = P.part[(size_t)i * ldb + j] + P.part[((size_t)wc + i) * ldb + j];
+      const double s = band_gload(&P.part[(size_t)i * ldb + j]) + band_gload(&P.part[((size_t)wc + i) * ldb + j]);
       if (j < wc) {
-        if (j <= i) P.SC[(size_t)j * wc + i] = ((i - j <= bw) ? P.Sb[(size_t)(P.c0 + j) * P.LD + (i - j)] : 0.0) - s;
+        if (j <= i) band_gstore(&P.SC[(size_t)j * wc + i], ((i - j <= bw) ? band_gload(&P.Sb[(size_t)(P.c0 + j) * P.LD + (i - j)]) : 0.0) - s);
       } else {
-        P.rhsC[i] = P.rhs[P.c0 + i] - s;
+        band_gstore(&P.rhsC[i], band_gload(&P.rhs[P.c0 + i]) - s);
       }
     }
   }
