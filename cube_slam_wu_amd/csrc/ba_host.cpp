@@ -37,7 +37,7 @@ void ba_launch_gather_rows(const double* src, const int* idx, int n, int width, 
 void ba_launch_backsub(const BaView& v, hipStream_t st);
 int ba_scale_blocks();
 void ba_launch_scale(const BaView& v, double lambda_pose, double lambda_lm, double* partial, hipStream_t st);
-void ba_launch_update(const BaView& v, hipStream_t st);
+void ba_launch_update(const BaView& v, hipStream_t st, double* bak_cams = nullptr, double* bak_points = nullptr, double* bak_cubes = nullptr);
 void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st, bool one_sided = false);
 void ba_launch_sep_reduce(const double* S, int LD, const double* Linv, int ci, int ni, int zl, int wl, int zr, int wr, double* Y, const double* rhs, double* msg, int wm, hipStream_t st);
 void ba_launch_sep_assemble(const double* msgs, size_t msg_doubles, int wm, int R, const int* sep_off, int n, int LDs, double* Ssep, double* rsep, hipStream_t st);
@@ -1591,7 +1591,7 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
     double rho = 0;
     int qmax = 0;
     do {
-      rc = cs_ba_push(B); if (rc) return rc;
+      if (!stream_flow) { rc = cs_ba_push(B); if (rc) return rc; }      // (stream flow: the update kernel below saves the estimates it replaces)
       bool ok2 = true;
       double scale = 0;
       if (stream_flow) {
@@ -1601,7 +1601,7 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
         // (rank 0); a landmark's terms live on exactly one rank.  A failed factorisation leaves garbage in x; the update below then
         // writes garbage estimates, which the pop restores (the decision is taken after the synchronisation).
         cs::ba_launch_scale(B->view, B->shard_rank == 0 ? lambda : 0.0, lambda, B->scale_partial.p, B->st);
-        cs::ba_launch_update(B->view, B->st);
+        cs::ba_launch_update(B->view, B->st, B->cams_bak.p, B->points_bak.p, B->cubes_bak.p);
         BA_TRY(hipEventRecord(B->ev[6], B->st));
         cs::ba_launch_chi2(B->view, B->nb_chi, B->st);
         cs::ba_launch_sum2(B->chi_partial.p, B->n_chi_partials, B->scale_partial.p, cs::ba_scale_blocks(), B->d_scalars.p, B->st);

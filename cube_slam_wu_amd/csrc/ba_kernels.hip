@@ -866,20 +866,26 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaView v) {
   v.xl[3 * p] = x[0]; v.xl[3 * p + 1] = x[1]; v.xl[3 * p + 2] = x[2];
 }
 
-__global__ __launch_bounds__(256) void ba_update_kernel(BaView v) {
+// bak_*: non-null = the push of the LM trial rides along (OptimizableGraph::push before the update, optimization_algorithm_levenberg.cpp:104-
+// 113): every vertex's estimate goes to its backup slot before it is changed -- three device-to-device copies of the whole state per trial
+// (~50 us at C4) become a few more stores of a kernel that reads the state anyway
+__global__ __launch_bounds__(256) void ba_update_kernel(BaView v, double* bak_cams, double* bak_points, double* bak_cubes) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i < v.np) {
+    if (bak_points) { bak_points[3 * i] = v.points[3 * i]; bak_points[3 * i + 1] = v.points[3 * i + 1]; bak_points[3 * i + 2] = v.points[3 * i + 2]; }
     if (v.pt_free[i]) { v.points[3 * i] += v.xl[3 * i]; v.points[3 * i + 1] += v.xl[3 * i + 1]; v.points[3 * i + 2] += v.xl[3 * i + 2]; }
     return;
   }
   i -= v.np;
   if (i < v.nc) {
+    if (bak_cams) for (int q = 0; q < 7; q++) bak_cams[7 * i + q] = v.cams[7 * i + q];
     int col = v.cam_col[i];
     if (col >= 0) pose_store(cam_oplus(pose_load(v.cams + 7 * i), v.rhs + col), v.cams + 7 * i);
     return;
   }
   i -= v.nc;
   if (i < v.no) {
+    if (bak_cubes) for (int q = 0; q < 10; q++) bak_cubes[10 * i + q] = v.cubes[10 * i + q];
     int col = v.cub_col[i];
     if (col >= 0) cube_store(cube_oplus(cube_load(v.cubes + 10 * i), v.rhs + col), v.cubes + 10 * i);
   }
@@ -2342,9 +2348,9 @@ void ba_launch_backsub(const BaView& v, hipStream_t st) {
   if (v.elim && v.no > 0) hipLaunchKernelGGL(ba_cub_backsub_kernel, dim3(v.no), dim3(64), 0, st, v);
   if (v.np > 0) hipLaunchKernelGGL(ba_backsub_kernel, dim3((v.np + 255) / 256), dim3(256), 0, st, v);
 }
-void ba_launch_update(const BaView& v, hipStream_t st) {
+void ba_launch_update(const BaView& v, hipStream_t st, double* bak_cams, double* bak_points, double* bak_cubes) {
   int n = v.np + v.nc + v.no;
-  if (n > 0) hipLaunchKernelGGL(ba_update_kernel, dim3((n + 255) / 256), dim3(256), 0, st, v);
+  if (n > 0) hipLaunchKernelGGL(ba_update_kernel, dim3((n + 255) / 256), dim3(256), 0, st, v, bak_cams, bak_points, bak_cubes);
 }
 
 }  // namespace cs
