@@ -46,7 +46,7 @@ void ba_launch_sep_backsolve(double* S, int LD, double* work, int ci, int ni, in
 void ba_launch_fail_flag(const int* a, const int* b, const int* c, double* out, hipStream_t st);
 size_t ba_band_workspace_doubles(int n, int LD);
 int ba_band_team(int LD, int* rw_out);
-bool ba_band_fits_device(int n, int LD);
+bool ba_band_fits_device(int n, int LD, bool one_sided = false);
 void ba_launch_sum2(const double* a, int na, const double* b, int nb, double* out, hipStream_t st);
 }  // namespace cs
 
@@ -180,7 +180,7 @@ struct cs_ba {
   hipEvent_t sev[4] = {};  // separator mode, inside [3, 4]: interior factorised, separator message formed, messages gathered, separator system solved
   double sep_ms[5] = {0, 0, 0, 0, 0};   // accumulated: interior factorisation, message (Y, T, t), gather, separator solve, interior back-substitution
   bool lin_pending = false;  // ev[0..1] recorded but not yet read
-  int* h_status = nullptr;   // pinned: factorisation status
+  int* h_status = nullptr;   // pinned: [status of the (interior's) factorisation, a cuboid block failed, status of the separator system's factorisation]
   // sharded BA over RCCL (cs_ba_comm_init): the collectives are issued from here, on this handle's stream
   ncclComm_t comm = nullptr;
   DBuf<double> d_scalars;    // [chi2, LM scale term] of a trial; lambda_0's diagonal on iteration 0
@@ -525,7 +525,10 @@ int finalize_structure(cs_ba* B) {
     if (ok) {   // the separator system (block tridiagonal, blocks <= w_max: a band of 2 w_max) goes through the same persistent kernels
       int wm = 0, nsep = 0;
       for (int k = 1; k < R; k++) { wm = std::max(wm, sepw[k]); nsep += sepw[k]; }
-      if (!cs::ba_band_fits_device(nsep, 2 * wm) || !cs::ba_band_fits_device(cut[1], B->band_ld)) ok = false;
+      // the interiors go through the ONE-SIDED kernel (grid = team + 1), whose residency depends on LD only: every rank decides alike
+      int ni_max = 0;
+      for (int r = 0; r < R; r++) ni_max = std::max(ni_max, cut[r + 1] - cut[r] - sepw[r]);
+      if (!cs::ba_band_fits_device(nsep, 2 * wm) || !cs::ba_band_fits_device(ni_max, B->band_ld, true)) ok = false;
     }
     if (ok) {
       B->sep_mode = true; B->cut = cut; B->sepw = sepw;
@@ -1107,6 +1110,10 @@ int coll_allgather(cs_ba* B, cs_allreduce_fn fn, void* ctx, double* buf, size_t 
 // shard builds and solves.
 int solve_device_sep(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn, void* ctx, std::unique_lock<std::mutex>* defer) {
   *ok = true;
+  // Without a collective the separator system would be assembled from the other ranks' stale / zero messages and "solve" to a
+  // meaningless x that reports positive_definite = 1 (the low-level path cs_ba_solve -> solve_device has neither callback nor, possibly,
+  // a communicator).  A sharded handle solves only through cs_ba_optimize_sharded or after cs_ba_comm_init.
+  if (!fn && !B->comm) { cs_set_error_ba("sharded handle in separator mode: the damped solve needs the ranks' separator messages -- use cs_ba_optimize_sharded (callback) or cs_ba_comm_init (RCCL); cs_ba_solve alone cannot"); return CS_ERR_INVALID_ARG; }
   const int R = B->shard_n, LD = B->band_ld, ns = B->n_sep;
   double* rhs = B->view.rhs;
   const int LDs = 2 * B->w_max;
@@ -1160,14 +1167,17 @@ int solve_device_sep(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn, void
   { int rc = coll_allreduce(B, fn, ctx, rhs, (size_t)B->n_pose); if (rc) return rc; }
   BA_TRY(hipEventRecord(B->ev[5], B->st));
   cs::ba_launch_fail_flag(B->d_int_info.p, B->d_elim_fail.p, B->d_sep_info.p, B->d_scalars.p + 2, B->st);
+  // both persistent factorisations of the trial report their own time-out (a team that was not co-resident): the interior's and the
+  // separator system's -- the latter must not be mistaken for "not positive definite" (LM would raise lambda and retry, ~1 s a trial)
   BA_TRY(hipMemcpyAsync(B->h_status, B->d_int_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
+  BA_TRY(hipMemcpyAsync(B->h_status + 2, B->d_sep_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
   BA_TRY(hipGetLastError());
   B->tm.n_solves++;
   if (defer) { if (coop_turn.owns_lock()) *defer = std::move(coop_turn); return CS_OK; }
   BA_TRY(hipMemcpyAsync(B->h_scalars + 2, B->d_scalars.p + 2, sizeof(double), hipMemcpyDeviceToHost, B->st));
   BA_TRY(hipStreamSynchronize(B->st));
   if (coop_turn.owns_lock()) coop_turn.unlock();
-  if (*B->h_status == 0x7fffffff) { cs_set_error_ba("banded solver: team not co-resident (wait timed out); set CS_BA_FORCE_DENSE=1 on a shared device"); return CS_ERR_HIP; }
+  if (B->h_status[0] == 0x7fffffff || B->h_status[2] == 0x7fffffff) { cs_set_error_ba("banded solver: team not co-resident (wait timed out); set CS_BA_FORCE_DENSE=1 on a shared device"); return CS_ERR_HIP; }
   if (B->h_scalars[2] != 0.0) *ok = false;
   return collect_solve_times(B);
 }
@@ -1196,8 +1206,8 @@ int cs_ba_create(int device, cs_ba** out) {
   BA_TRY(hipEventCreateWithFlags(&B->ev_join3, hipEventDisableTiming));
   for (auto& e : B->ev) BA_TRY(hipEventCreate(&e));
   for (auto& e : B->sev) BA_TRY(hipEventCreate(&e));
-  BA_TRY(hipHostMalloc((void**)&B->h_status, 2 * sizeof(int)));   // [factorisation status, a cuboid block failed]
-  B->h_status[0] = B->h_status[1] = 0;
+  BA_TRY(hipHostMalloc((void**)&B->h_status, 3 * sizeof(int)));   // [factorisation status, a cuboid block failed, separator system's status]
+  B->h_status[0] = B->h_status[1] = B->h_status[2] = 0;
   BA_ROC(rocblas_create_handle(&B->blas));
   BA_ROC(rocblas_set_stream(B->blas, B->st));
   *out = B;
@@ -1612,7 +1622,7 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
         BA_TRY(hipEventRecord(B->ev[7], B->st));
         BA_TRY(hipStreamSynchronize(B->st));
         turn.unlock();
-        if (*B->h_status == 0x7fffffff) { cs_set_error_ba("banded solver: team not co-resident (wait timed out); set CS_BA_FORCE_DENSE=1 on a shared device"); return CS_ERR_HIP; }
+        if (B->h_status[0] == 0x7fffffff || (B->sep_mode && B->shard_n > 1 && B->h_status[2] == 0x7fffffff)) { cs_set_error_ba("banded solver: team not co-resident (wait timed out); set CS_BA_FORCE_DENSE=1 on a shared device"); return CS_ERR_HIP; }
         ok2 = B->h_scalars[2] == 0.0;
         tempChi = B->h_scalars[0];
         scale = ok2 ? B->h_scalars[1] : 0.0;

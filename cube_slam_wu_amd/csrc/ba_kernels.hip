@@ -1094,13 +1094,16 @@ __device__ __forceinline__ double band_gload(const double* p) {
   return *(band_gptr)(p);
 #endif
 }
-__device__ __forceinline__ void band_gstore(double* p, double v) {
+__device__ __forceinline__ void band_gstore(const double* p, double v) {
 #if BAND_WT
-  __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)(const_cast<double*>(p)), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
-  *p = v;
+  *const_cast<double*>(p) = v;
 #endif
 }
+// plain store: ONLY in kernels whose workgroups hand nothing to each other within a launch (the substitution kernels: a front is
+// walked by one workgroup, the kernel boundary publishes the result)
+__device__ __forceinline__ void band_pstore(const double* p, double v) { *const_cast<double*>(p) = v; }
 
 // panel rows per workgroup, per kernel.  16 in both: 8 rows in the nested kernel (twice the workgroups, half the product and
 // panel work) was measured slower, 1.95 -> 2.15 ms at C4 -- what the halves save, the doubled teams lose in the barrier (2.5 ->
@@ -1113,9 +1116,12 @@ __host__ __device__ constexpr int band_rw(int kid) { return kid ? BAND_RW_NESTED
 // (v = n - 1 - original index).  In both spaces the factor is lower triangular and banded; only the strides differ:
 //   &L(i, j) = base + i * si + j * sj   (i >= j, i - j <= bw),      &rhs(v) = rb + v * sr
 //   forward: base = Sb, si = 1, sj = bw              reverse: base = Sb + (n - 1) LD, si = -bw, sj = -1
+// (Every global pointer of the persistent kernels is const-qualified: the ONLY ways to write through one are band_gstore -- the
+// write-through store the hand-offs rely on -- and band_pstore, a plain store for kernels whose workgroups exchange nothing within a
+// launch.  A plain `p[i] = v` in a step routine does not compile, so a future edit cannot slip a store past the hand-off protocol.)
 struct BandView {
-  double* base; long long si, sj;
-  double* rb; long long sr;
+  const double* base; long long si, sj;
+  const double* rb; long long sr;
 };
 struct BandSeg {            // one run of history columns [jlo, jhi) of a view; flip: the step's rows are re-indexed i -> n - 1 - i
   BandView v; int jlo, jhi, flip;
@@ -1129,7 +1135,7 @@ struct BandSegX : BandSeg { // ... of a front that carries separator rows (BandA
 struct BandAug {
   const double* a_base; long long a_sq, a_sj;   // &A(q, j) = a_base + q a_sq + j a_sj, inside the band iff m0 + q + ms j <= bw
   int m0, ms;
-  double* lc; int wc, qflip, t0;                // &L(q, j) = lc + (t0 + j) wc + (qflip ? wc - 1 - q : q)   (t0: the view being eliminated)
+  const double* lc; int wc, qflip, t0;          // &L(q, j) = lc + (t0 + j) wc + (qflip ? wc - 1 - q : q)   (t0: the view being eliminated)
 };
 struct BandLds { double* R; double (*U)[BS + 1]; double (*Dl)[BS + 1]; double (*X)[BS + 1]; double* colbuf; int* rowidx; };
 
@@ -1277,7 +1283,7 @@ __device__ __forceinline__ void band_gather_gemm(const BandSegX& s0, const BandS
   band_gather_gemm_sep(s0, s1, nseg, aug, zero, n, bw, k0, nb, rowidx, R, U, tp, t_prev);
 }
 template <bool AUG, int KID, class SEG>
-__device__ __forceinline__ void band_step(const BandLds& M, const BandView& view, double* Linv, int k0, int nb, int i_end, const SEG& s0, const SEG& s1, int nseg,
+__device__ __forceinline__ void band_step(const BandLds& M, const BandView& view, const double* Linv, int k0, int nb, int i_end, const SEG& s0, const SEG& s1, int nseg,
                                           const BandAug& aug, int w, int cw, bool has_rhs, int n, int bw, const double* zero, unsigned* dflag, unsigned dtarget, long long* tp, long long* t_prev) {
   constexpr int RW = band_rw(KID), NR = BS + RW + 8;
   const int tid = threadIdx.x;
@@ -1373,7 +1379,7 @@ __device__ __forceinline__ void band_diag_accum(const SEG& S, int jlo, int jhi, 
 // of the other front's view v1 (rows re-indexed i -> n - 1 - i).  start: counter/target that opens the phase (may be null);
 // bar: the team's step barrier, which reads G ep0 when the phase starts; flag: published block count, f0 at the start.
 template <int KID>
-__device__ __forceinline__ void band_diag_phase(const BandLds& M, const BandView& view, double* Linv, int k_begin, int k_end, bool two_seg, const BandView& v1, int jhi1,
+__device__ __forceinline__ void band_diag_phase(const BandLds& M, const BandView& view, const double* Linv, int k_begin, int k_end, bool two_seg, const BandView& v1, int jhi1,
                                                 unsigned* start, unsigned start_target, unsigned* bar, unsigned G, unsigned ep0, unsigned* flag, unsigned f0,
                                                 int n, int bw, const double* zero, int* info, long long* dprof = nullptr) {
   const int tid = threadIdx.x, r = tid >> 3, cq = tid & 7, lane = tid & 63, wv = tid >> 6, rg = lane >> 3, cg = lane & 7;
@@ -1441,7 +1447,7 @@ __device__ __forceinline__ void band_diag_phase(const BandLds& M, const BandView
     __syncthreads();
     BAND_DTICK(2);
     {
-      double* Li = Linv + (size_t)(k0 / BS) * BS * BS;
+      const double* Li = Linv + (size_t)(k0 / BS) * BS * BS;
       for (int e = tid; e < BS * BS; e += 256) {
         const int rr = e >> 5, cc = e & 31;
         band_gstore(&Li[e], M.X[rr][cc]);
@@ -1482,7 +1488,7 @@ __device__ __attribute__((noinline)) void band_clock_init(long long* t) { asm vo
 // middle block M = [32 K1, n - 32 K2).  Phase 2: team 0 eliminates M, whose history now has two segments (the tails of
 // both fronts).  The chain of dependent steps is halved.  K2 = 0 degenerates to the one-sided left-looking algorithm.
 // bars: [team 0, team 1, both].
-__global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double* __restrict__ Linv_f, double* __restrict__ Linv_r, double* rhs, const double* zero, int n,
+__global__ __launch_bounds__(256) void band_chol_coop_kernel(const double* Sb, const double* __restrict__ Linv_f, const double* __restrict__ Linv_r, const double* rhs, const double* zero, int n,
                                                              int LD, int K1, int K2, int* info, unsigned* bars, int G, long long* prof) {
   __shared__ double R[BAND_DC * BAND_NRP];   // strip chunk, transposed: R[jj * 64 + rr]; afterwards the 4 waves' partial sums
   __shared__ double U[BAND_NR][BS + 1];
@@ -1519,7 +1525,7 @@ __global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double*
   }
   {
     const BandView view = team ? rev : fwd;
-    double* Linv = team ? Linv_r : Linv_f;
+    const double* Linv = team ? Linv_r : Linv_f;
     const int Kt = team ? K2 : K1;
     for (int kb = 0; kb < Kt; kb++) {
       const int k0 = kb * BS;
@@ -1564,12 +1570,12 @@ __global__ __launch_bounds__(256) void band_chol_coop_kernel(double* Sb, double*
 struct BandHalf {
   BandView fv, rv;        // the half's index space [0, nh) (C at rows nh ...) and its reverse front's (u = nh - 1 - v)
   int nh, K1, K2, qflip;  // column blocks of the two fronts; qflip: C's rows appear in reverse order below this half
-  double* Linv_f; double* Linv_r; double* lc;
+  const double* Linv_f; const double* Linv_r; const double* lc;
 };
 struct BandNested {
   BandHalf h[2];
   int n, bw, wc, c0, LD, G, GC, GS;     // C = [c0, c0 + wc); G workgroups per front, GC for C's rows (and C's own factorisation), GS Schur accumulators
-  double* Sb; double* rhs; double* SC; double* rhsC; double* LinvC; double* part;
+  const double* Sb; const double* rhs; const double* SC; const double* rhsC; const double* LinvC; const double* part;
   const double* zero; int* info; unsigned* bars;   // bars: [half 0: team 0, team 1, join][half 1: ...][teams 1 + 2 of both halves][-][C team]
   long long* prof;                                 // optional phase stamps of half 0's team 1 (CS_BAND_PROF)
 };
@@ -1806,7 +1812,7 @@ __device__ __forceinline__ void band_backsolve_run(const BandSolveLds& M, const 
       double a2 = 0;
 #pragma unroll 8
       for (int r = 0; r < BS; r++) a2 = fma(M.Li[r][tid], M.z[r], a2);   // (L^-1)^T z
-      view.rb[(long long)(k0 + tid) * view.sr] = a2;
+      band_pstore(&view.rb[(long long)(k0 + tid) * view.sr], a2);
       M.xw[(k0 + tid) & (WIN - 1)] = a2;
     }
     __syncthreads();
@@ -1855,7 +1861,7 @@ __global__ __launch_bounds__(256) void band_sep_correct_kernel(BandNested P) {
   const int tid = threadIdx.x, wc = P.wc;
   for (int e = tid; e < wc; e += 256) xc[e] = P.rhsC[e];
   __syncthreads();
-  if (blockIdx.x == 0) for (int e = tid; e < wc; e += 256) P.rhs[P.c0 + e] = xc[e];
+  if (blockIdx.x == 0) for (int e = tid; e < wc; e += 256) band_pstore(&P.rhs[P.c0 + e], xc[e]);
   const int T0 = P.h[0].nh - BS * P.h[0].K1, T1 = P.h[1].nh - BS * P.h[1].K1;
   const int t = blockIdx.x * 32 + (tid >> 3), l8 = tid & 7;
   double s = 0.0;
@@ -1866,8 +1872,8 @@ __global__ __launch_bounds__(256) void band_sep_correct_kernel(BandNested P) {
   }
   s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
   if (t < T0 + T1 && l8 == 0) {
-    double* y = const_cast<double*>(band_half_y(P.h[t < T0 ? 0 : 1], t < T0 ? t : t - T0));
-    *y -= s;
+    const double* y = band_half_y(P.h[t < T0 ? 0 : 1], t < T0 ? t : t - T0);
+    band_pstore(y, *y - s);
   }
 }
 
@@ -1915,18 +1921,18 @@ size_t ba_band_workspace_doubles(int n, int LD) {
 // each other, so the whole grid must be resident at once: the grid may not exceed (workgroups the occupancy query admits per
 // CU, capped at 1: the kernels are written for one workgroup per CU) x (CUs of the device or partition).  The caller takes the
 // dense rocSOLVER path otherwise.
-bool ba_band_fits_device(int n, int LD) {
+bool ba_band_fits_device(int n, int LD, bool one_sided) {   // one_sided: the order ba_launch_band_cholesky(..., one_sided = true) runs (the sharded solve's interiors)
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
   int rw = 0, K1 = 0, K2 = 0, wc = 0, c0 = 0, occ = 0, grid = 0;
   const int G = ba_band_team(LD, &rw), bw = LD - 1;
-  if (ba_band_nested(n, LD, &wc, &c0)) {
+  if (ba_band_nested(n, LD, &wc, &c0, one_sided)) {
     const int Gn = (bw + BAND_RW_NESTED - 1) / BAND_RW_NESTED, GC = wc / BAND_RW_NESTED, GS = wc / 16;
     grid = 2 * (Gn + 1 + Gn + GC + 1 + GS);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, band_chol_nested_kernel, 256, 0) != hipSuccess) return false;
   } else {
-    ba_band_split(n, LD, &K1, &K2);
+    ba_band_split(n, LD, &K1, &K2, one_sided);
     grid = K2 > 0 ? 2 * (G + 1) : G + 1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, band_chol_coop_kernel, 256, 0) != hipSuccess) return false;
   }

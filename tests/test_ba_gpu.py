@@ -456,9 +456,31 @@ def test_band_solver_harness_shapes():
                 continue
             out = subprocess.run([exe, str(n), str(ld), "2"], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
             assert out.returncode == 0, out.stderr
-            res = [float(l.split("residual")[1]) for l in out.stdout.splitlines() if "residual" in l]
+            res = [float(l.split("residual")[1].split()[0]) for l in out.stdout.splitlines() if "residual" in l]
             infos = [int(l.split("info")[1].split()[0]) for l in out.stdout.splitlines() if "info" in l]
             assert len(res) == 2 and max(res) < 1e-12 and infos == [0, 0], (n, ld, env, out.stdout)
+
+
+def test_band_write_through_handoffs_equal_the_fenced_build_bitwise():
+    """The persistent band kernels hand values between workgroups (other XCDs) through write-through stores + drained counters
+    (BAND_WT = 1) instead of agent-scope release / acquire fences.  The same kernels built with BAND_WT = 0 (plain stores, fences:
+    the form the LLVM memory model orders) must give bit-identical factors and solutions on a multi-XCD device -- a hand-off that the
+    write-through form fails to publish shows up here as a different hash (or a bad residual), not as a rare wrong factor in the field."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe, exe_f = os.path.join(root, "build_tmp", "band_bench"), os.path.join(root, "build_tmp", "band_bench_fence")
+    if not (os.path.exists(exe) and os.path.exists(exe_f)):
+        import __graft_entry__
+        __graft_entry__.build()
+    for n, ld, one_sided in [(5994, 120, 0), (10494, 183, 0), (1902, 190, 0), (840, 241, 0), (2500, 97, 0), (630, 120, 1), (2000, 64, 1), (1345, 129, 0)]:
+        outs = []
+        for e in (exe, exe_f):
+            out = subprocess.run([e, str(n), str(ld), "6", str(one_sided)], capture_output=True, text=True, timeout=300)
+            assert out.returncode == 0, out.stderr
+            lines = [l for l in out.stdout.splitlines() if l.startswith("rep")]
+            assert len(lines) == 6 and all(float(l.split("residual")[1].split()[0]) < 1e-12 and int(l.split("info")[1].split()[0]) == 0 for l in lines), out.stdout
+            outs.append([l.split("hash")[1].strip() for l in lines])
+        assert outs[0] == outs[1], (n, ld, one_sided, outs)
 
 
 def test_c3_at_its_named_size_against_the_oracle():

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace cs {
@@ -50,7 +51,16 @@ int main(int argc, char** argv) {
       for (int j = std::max(0, i - bw); j <= std::min(n - 1, i + bw); j++) acc += (j <= i ? A[(size_t)j * LD + (i - j)] : A[(size_t)i * LD + (j - i)]) * x[j];
       rmax = std::max(rmax, std::fabs(acc - b[i])); bmax = std::max(bmax, std::fabs(b[i]));
     }
-    printf("rep %d: factor+solve %.3f ms  info %d  residual %.3e\n", r, ms, info[0], rmax / bmax);
+    // FNV-1a over the bits of x and of the factor: tests/test_ba_gpu.py holds the write-through build (BAND_WT = 1) and the fenced
+    // build (BAND_WT = 0: plain stores + agent release / acquire fences) to the same hash on the same system
+    unsigned long long hsh = 1469598103934665603ULL;
+    {
+      std::vector<double> Lg(A.size());
+      hipMemcpy(Lg.data(), dS, A.size() * 8, hipMemcpyDeviceToHost);
+      auto mix = [&](const std::vector<double>& v) { for (double d : v) { unsigned long long u; memcpy(&u, &d, 8); for (int q = 0; q < 8; q++) { hsh ^= (u >> (8 * q)) & 0xff; hsh *= 1099511628211ULL; } } };
+      mix(x); mix(Lg);
+    }
+    printf("rep %d: factor+solve %.3f ms  info %d  residual %.3e  hash %016llx\n", r, ms, info[0], rmax / bmax, hsh);
     if (rmax / bmax > 1e-9) {   // locate the first wrong entry of L against a CPU band Cholesky
       std::vector<double> L(A), Lg(A.size());
       hipMemcpy(Lg.data(), dS, A.size() * 8, hipMemcpyDeviceToHost);
