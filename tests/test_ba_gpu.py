@@ -320,6 +320,19 @@ def test_sharded_ba_separator_mode_without_cuboid_elimination(monkeypatch):
     assert np.abs(pS - p1).max() < 1e-7 * scale and np.abs(cS - c1).max() < 1e-7 * scale and np.abs(oS - o1).max() < 1e-7 * scale
 
 
+def test_low_level_solve_on_a_separator_mode_shard_without_collective_is_refused():
+    """cs_ba_solve on a handle sharded in separator mode has no way to obtain the other ranks' separator messages (no callback, no
+    communicator): it must say so instead of solving a system assembled from zeros and reporting positive_definite = 1."""
+    pr = synth_ba.make_problem(n_cams=160, n_points=70 * 160, n_cuboids=20, seed=21)
+    P = capi.ba_from_dict(pr)
+    P.set_shard(0, 2)
+    assert P.shard_info()["sep_mode"] == 1
+    P.build_system()
+    with pytest.raises(RuntimeError, match="separator mode"):
+        P.solve(1.0)
+    P.close()
+
+
 @pytest.mark.parametrize("shape", [(150, 6000, 30), (300, 9000, 0), (90, 3000, 12)])
 def test_banded_solver_matches_dense_solver(shape, monkeypatch):
     """The persistent banded Cholesky (RCM ordering, one grid barrier per 32-column step) and rocSOLVER's dense
