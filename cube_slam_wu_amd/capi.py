@@ -393,7 +393,7 @@ DECLARED_SYMBOLS += [
     "cs_ba_create", "cs_ba_destroy", "cs_ba_set_vertices", "cs_ba_set_estimates", "cs_ba_set_edges_proj", "cs_ba_set_edges_cuboid", "cs_ba_set_edges_cuboid_proj", "cs_ba_set_edges_odom",
     "cs_ba_compute_errors", "cs_ba_build_system", "cs_ba_solve", "cs_ba_update", "cs_ba_push", "cs_ba_pop", "cs_ba_optimize",
     "cs_ba_get_state", "cs_ba_sizes", "cs_ba_solver_layout", "cs_ba_get_system", "cs_ba_last_timing", "cs_ba_set_shard", "cs_ba_optimize_sharded",
-    "cs_ba_shard_landmark_owners", "cs_ba_get_landmark_owners", "cs_ba_shard_info", "cs_ba_shard_timing", "cs_ba_append_vertices", "cs_ba_append_edges_proj", "cs_ba_append_edges_cuboid", "cs_ba_append_edges_cuboid_proj", "cs_ba_append_edges_odom", "cs_ba_get_vertex_hessians", "cs_ba_schur_layout", "cs_ba_reduced_size", "cs_ba_comm_unique_id", "cs_ba_comm_init",
+    "cs_ba_shard_landmark_owners", "cs_ba_get_landmark_owners", "cs_ba_shard_info", "cs_ba_shard_timing", "cs_ba_append_vertices", "cs_ba_append_edges_proj", "cs_ba_append_edges_cuboid", "cs_ba_append_edges_cuboid_proj", "cs_ba_append_edges_odom", "cs_ba_get_vertex_hessians", "cs_ba_schur_layout", "cs_ba_reduced_size", "cs_ba_comm_unique_id", "cs_ba_comm_init", "cs_ba_set_robust_kernels",
 ]
 
 
@@ -447,6 +447,16 @@ class BaProblem:
     def set_edges_odom(self, ci, cj, meas7, info36):
         ci, cj = _i32(ci), _i32(cj); self.n_odom = len(ci)
         _chk(lib().cs_ba_set_edges_odom(self.h, self.n_odom, _ip(ci), _ip(cj), _dp(_f64(meas7, (-1, 7))), _dp(_f64(info36, (-1, 36)))), "cs_ba_set_edges_odom")
+
+    def set_robust_kernels(self, edge_class, kind, delta):
+        """cs_ba_set_robust_kernels: edge_class 0 projection / 1 EdgeSE3Cuboid / 2 EdgeSE3CuboidProj / 3 EdgeSE3Expmap; kind per edge
+        (RK_* below), delta = RobustKernel::delta().  kind None removes the class's kernels."""
+        if kind is None:
+            n = {0: self.n_proj, 1: self.n_cub, 2: getattr(self, "n_cproj", 0), 3: self.n_odom}[int(edge_class)]
+            _chk(lib().cs_ba_set_robust_kernels(self.h, int(edge_class), n, None, None), "cs_ba_set_robust_kernels")
+            return
+        kind, delta = _i32(kind), _f64(delta, (-1,))
+        _chk(lib().cs_ba_set_robust_kernels(self.h, int(edge_class), len(kind), _ip(kind), _dp(delta)), "cs_ba_set_robust_kernels")
 
     # ---- growing graphs: new vertices / edges behind the existing ones, device-side estimates kept
     def append_vertices(self, cams=None, cam_fixed=None, cuboids=None, cub_fixed=None, points=None, pt_fixed=None):
@@ -630,6 +640,10 @@ class BaProblem:
             pass
 
 
+RK_NONE, RK_HUBER, RK_PSEUDO_HUBER, RK_CAUCHY, RK_SATURATED, RK_DCS, RK_TUKEY = range(7)      # enum cs_robust_kernel
+EDGE_PROJ, EDGE_CUBOID, EDGE_CUBOID_PROJ, EDGE_ODOM = range(4)                                 # enum cs_edge_class
+
+
 def ba_from_dict(pr, device=0, cuboids_first=False):
     """BaProblem from a cube_slam_wu_amd.synth_ba.make_problem() dict."""
     P = BaProblem(pr["cams"], pr["cam_fixed"], pr["cuboids"], pr["cub_fixed"], pr["points"], pr["pt_fixed"], cuboids_first=cuboids_first, device=device)
@@ -641,6 +655,8 @@ def ba_from_dict(pr, device=0, cuboids_first=False):
         P.set_edges_cuboid_proj(pr["pe_cam"], pr["pe_cub"], pr["pe_meas"], pr["pe_info"], pr["pe_K"])
     if len(pr["oe_i"]):
         P.set_edges_odom(pr["oe_i"], pr["oe_j"], pr["oe_meas"], pr["oe_info"])
+    for cls, (kind, delta) in pr.get("robust", {}).items():       # optional: {edge class: (kinds, deltas)}
+        P.set_robust_kernels(cls, kind, delta)
     return P
 
 

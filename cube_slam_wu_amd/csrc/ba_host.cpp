@@ -251,6 +251,12 @@ struct cs_ba {
   // the structure phase permutes it there (ba_gather_rows_kernel)
   DBuf<double> raw_uv, raw_info, raw_intr, raw_huber;
   bool have_huber = false;
+  // robust kernels (cs_ba_set_robust_kernels; cs_robust.h): kinds per edge in the caller's order, empty = none of the class has one.
+  // The projection edges' deltas live in raw_huber (Huber is the fast path: kinds all 0 / 1 -> no kind array on the device).
+  std::vector<int> rk_proj, rk_cub3, rk_cproj, rk_odom;
+  std::vector<double> rd_cub3, rd_cproj, rd_odom;
+  DBuf<int> d_pm_rk, d_cm_rk, d_ce_rk, d_oe_rk;
+  DBuf<double> d_ce_rdelta, d_oe_rdelta;
   // last solution / rhs on the host (for LM's scale term and for inspection)
   std::vector<double> h_b, h_x;
   bool have_system = false;
@@ -636,6 +642,16 @@ int finalize_structure(cs_ba* B) {
     BA_TRY(hipStreamSynchronize(B->st));
   }
   UP(B->pm_pt, pm_pt); UP(B->pm_cam, pm_cam); UP(B->pt_ptr, pt_ptr);
+  {   // kernel kinds of the projection edges in both orders -- only if some edge has a kernel other than Huber
+    bool generic = false;
+    for (int kd : B->rk_proj) if (kd != cs::RK_NONE && kd != cs::RK_HUBER) { generic = true; break; }
+    if (generic) {
+      std::vector<int> pk(std::max(1, E), 0), ck(std::max(1, E), 0);
+      for (int sl = 0; sl < E; sl++) pk[sl] = B->rk_proj[src_of_slot[sl]];
+      for (int q = 0; q < E; q++) ck[q] = pk[cm_pm[q]];
+      UP(B->d_pm_rk, pk); UP(B->d_cm_rk, ck);
+    } else { B->d_pm_rk.release(); B->d_cm_rk.release(); }
+  }
   UP(B->cm_pt, cm_pt); UP(B->cam_ptr, cam_ptr);
   mark("edge orderings + upload");
   // ---- Schur pattern (block_solver.hpp:262-292).  Fused path: segments of landmarks with one camera set + the destination
@@ -835,6 +851,24 @@ int finalize_structure(cs_ba* B) {
     }
     UP(B->d_ce_active, ca); UP(B->d_oe_active, oa);
   }
+  {   // kernels of the camera-cuboid edges (EdgeSE3Cuboid list, then EdgeSE3CuboidProj list) and of the odometry edges
+    bool any = false;
+    for (int kd : B->rk_cub3) any |= kd != 0;
+    for (int kd : B->rk_cproj) any |= kd != 0;
+    if (any) {
+      std::vector<int> kk(std::max(1, B->n_cub), 0); std::vector<double> dd(std::max(1, B->n_cub), 0.0);
+      for (size_t k = 0; k < B->rk_cub3.size() && (int)k < B->n_cub3; k++) { kk[k] = B->rk_cub3[k]; dd[k] = B->rd_cub3[k]; }
+      for (size_t k = 0; k < B->rk_cproj.size() && B->n_cub3 + (int)k < B->n_cub; k++) { kk[B->n_cub3 + k] = B->rk_cproj[k]; dd[B->n_cub3 + k] = B->rd_cproj[k]; }
+      UP(B->d_ce_rk, kk); UP(B->d_ce_rdelta, dd);
+    } else { B->d_ce_rk.release(); B->d_ce_rdelta.release(); }
+    any = false;
+    for (int kd : B->rk_odom) any |= kd != 0;
+    if (any) {
+      std::vector<int> kk(B->rk_odom); std::vector<double> dd(B->rd_odom);
+      kk.resize(std::max(1, B->n_odom), 0); dd.resize(std::max(1, B->n_odom), 0.0);
+      UP(B->d_oe_rk, kk); UP(B->d_oe_rdelta, dd);
+    } else { B->d_oe_rk.release(); B->d_oe_rdelta.release(); }
+  }
   UP(B->ce_meas, B->h_ce_meas); UP(B->ce_info, B->h_ce_info); UP(B->oe_meas, B->h_oe_meas); UP(B->oe_info, B->h_oe_info);
   UP(B->pe_meas, B->h_pe_meas); UP(B->pe_info, B->h_pe_info); UP(B->pe_K, B->h_pe_K);
   AL(B->ce_Hcc, 36 * (size_t)B->n_cub); AL(B->ce_Hoo, 81 * (size_t)B->n_cub); AL(B->ce_Hco, 54 * (size_t)B->n_cub); AL(B->ce_bc, 6 * (size_t)B->n_cub); AL(B->ce_bo, 9 * (size_t)B->n_cub);
@@ -892,6 +926,7 @@ int finalize_structure(cs_ba* B) {
   v.cub_mine = B->d_cub_mine.p;
   v.cub_M = B->cub_M.p; v.cub_Dinv = B->cub_Dinv.p; v.elim_fail = B->d_elim_fail.p; v.slotE_ptr = B->d_slotE_ptr.p; v.slotE_idx = B->d_slotE_idx.p;
   v.n_proj = E; v.pm_pt = B->pm_pt.p; v.pm_cam = B->pm_cam.p; v.pm_uv = B->pm_uv.p; v.pm_info = B->pm_info.p; v.pm_intr = B->pm_intr.p; v.pm_huber = B->pm_huber.p;
+  v.pm_rk = B->d_pm_rk.p; v.cm_rk = B->d_cm_rk.p; v.ce_rk = B->d_ce_rk.p; v.ce_rdelta = B->d_ce_rdelta.p; v.oe_rk = B->d_oe_rk.p; v.oe_rdelta = B->d_oe_rdelta.p;
   v.pt_ptr = B->pt_ptr.p; v.cm_pm = B->cm_pm.p; v.cm_pt = B->cm_pt.p; v.cm_uv = B->cm_uv.p; v.cm_info = B->cm_info.p; v.cm_intr = B->cm_intr.p; v.cm_huber = B->cm_huber.p; v.cam_ptr = B->cam_ptr.p;
   v.n_cub3 = B->n_cub3; v.pe_meas = B->pe_meas.p; v.pe_info = B->pe_info.p; v.pe_K = B->pe_K.p;
   v.n_cub = B->n_cub; v.ce_cam = B->d_ce_cam.p; v.ce_cub = B->d_ce_cub.p; v.ce_meas = B->ce_meas.p; v.ce_info = B->ce_info.p; v.ce_active = B->d_ce_active.p;
@@ -1222,14 +1257,14 @@ void cs_ba_destroy(cs_ba* B) {
   DBuf<double>* dd[] = {&B->cams, &B->points, &B->cubes, &B->cams_bak, &B->points_bak, &B->cubes_bak, &B->pm_uv, &B->pm_info, &B->pm_intr, &B->pm_huber,
                         &B->cm_uv, &B->cm_info, &B->cm_intr, &B->cm_huber, &B->ce_meas, &B->ce_info, &B->ce_Hcc, &B->ce_Hoo, &B->ce_Hco, &B->ce_bc, &B->ce_bo,
                         &B->oe_meas, &B->oe_info, &B->oe_Hii, &B->oe_Hjj, &B->oe_Hij, &B->oe_bi, &B->oe_bj, &B->Hcam, &B->bcam, &B->Hcub, &B->bcub, &B->Hll, &B->bl,
-                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv, &B->scale_partial, &B->pe_meas, &B->pe_info, &B->pe_K, &B->part_tiles, &B->part_coef, &B->cub_M, &B->cub_Dinv, &B->raw_uv, &B->raw_info, &B->raw_intr, &B->raw_huber, &B->sepY, &B->sep_msgs, &B->sepS, &B->int_work, &B->sep_work};
+                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv, &B->scale_partial, &B->pe_meas, &B->pe_info, &B->pe_K, &B->part_tiles, &B->part_coef, &B->cub_M, &B->cub_Dinv, &B->raw_uv, &B->raw_info, &B->raw_intr, &B->raw_huber, &B->sepY, &B->sep_msgs, &B->sepS, &B->int_work, &B->sep_work, &B->d_ce_rdelta, &B->d_oe_rdelta};
   for (auto* d : dd) d->release();
   B->stage.release();
   DBuf<int>* di[] = {&B->d_ce_active, &B->d_oe_active, &B->d_cam_col, &B->d_cub_col, &B->d_pt_free, &B->pm_pt, &B->pm_cam, &B->pt_ptr, &B->cm_pm, &B->cm_pt, &B->cam_ptr, &B->d_ce_cam, &B->d_ce_cub,
                      &B->d_oe_i, &B->d_oe_j, &B->cam_ce_ptr, &B->cam_ce_idx, &B->cam_oei_ptr, &B->cam_oei_idx, &B->cam_oej_ptr, &B->cam_oej_idx, &B->cub_ce_ptr,
                      &B->cub_ce_idx, &B->pair_ptr, &B->pair_i1, &B->pair_i2, &B->ent_a, &B->ent_b, &B->d_run_lm, &B->d_seg_ptr, &B->d_seg_k, &B->d_seg_tile, &B->d_seg_slot,
                      &B->d_gp_ptr, &B->d_gp_i1, &B->d_gp_i2, &B->d_gtile, &B->d_gcam_ptr, &B->d_gslot, &B->d_cubS_ptr, &B->d_cubS_cam, &B->d_ce_slot, &B->d_cub_tile, &B->d_cub_coef,
-                     &B->d_elim_fail, &B->d_slotE_ptr, &B->d_slotE_idx, &B->d_cub_mine, &B->d_sep_off, &B->d_sep_col, &B->d_int_info, &B->d_sep_info};
+                     &B->d_elim_fail, &B->d_slotE_ptr, &B->d_slotE_idx, &B->d_cub_mine, &B->d_sep_off, &B->d_sep_col, &B->d_int_info, &B->d_sep_info, &B->d_pm_rk, &B->d_cm_rk, &B->d_ce_rk, &B->d_oe_rk};
   for (auto* d : di) d->release();
   B->d_info.release(); B->d_band_info.release();
   for (auto& e : B->ev) if (e) (void)hipEventDestroy(e);
@@ -1308,6 +1343,7 @@ int cs_ba_append_edges_proj(cs_ba* B, int n, const int* pt, const int* cam, cons
   if (huber) { rc = B->raw_huber.append_ptr(huber, (size_t)n); if (rc) return rc; }
   B->have_huber = huber != nullptr;
   B->e_pt.insert(B->e_pt.end(), pt, pt + n); B->e_cam.insert(B->e_cam.end(), cam, cam + n);
+  if (!B->rk_proj.empty()) for (int k = 0; k < n; k++) B->rk_proj.push_back((huber && huber[k] > 0) ? cs::RK_HUBER : cs::RK_NONE);
   B->n_proj += n;
   B->structure_dirty = true;
   return CS_OK;
@@ -1317,6 +1353,7 @@ int cs_ba_append_edges_cuboid(cs_ba* B, int n, const int* cam, const int* cub, c
   if (!B || n < 0 || (n && (!cam || !cub || !meas10 || !info81))) return CS_ERR_INVALID_ARG;
   BA_GUARD_BEGIN
   B->u3_cam.insert(B->u3_cam.end(), cam, cam + n); B->u3_cub.insert(B->u3_cub.end(), cub, cub + n);
+  if (!B->rk_cub3.empty()) { B->rk_cub3.resize(B->u3_cam.size(), 0); B->rd_cub3.resize(B->u3_cam.size(), 0.0); }
   B->h_ce_meas.insert(B->h_ce_meas.end(), meas10, meas10 + 10 * (size_t)n); B->h_ce_info.insert(B->h_ce_info.end(), info81, info81 + 81 * (size_t)n);
   B->structure_dirty = true;
   return CS_OK;
@@ -1326,6 +1363,7 @@ int cs_ba_append_edges_cuboid_proj(cs_ba* B, int n, const int* cam, const int* c
   if (!B || n < 0 || (n && (!cam || !cub || !meas4 || !info16 || !K9))) return CS_ERR_INVALID_ARG;
   BA_GUARD_BEGIN
   B->up_cam.insert(B->up_cam.end(), cam, cam + n); B->up_cub.insert(B->up_cub.end(), cub, cub + n);
+  if (!B->rk_cproj.empty()) { B->rk_cproj.resize(B->up_cam.size(), 0); B->rd_cproj.resize(B->up_cam.size(), 0.0); }
   B->h_pe_meas.insert(B->h_pe_meas.end(), meas4, meas4 + 4 * (size_t)n); B->h_pe_info.insert(B->h_pe_info.end(), info16, info16 + 16 * (size_t)n);
   B->h_pe_K.insert(B->h_pe_K.end(), K9, K9 + 9 * (size_t)n);
   B->structure_dirty = true;
@@ -1341,6 +1379,7 @@ int cs_ba_append_edges_odom(cs_ba* B, int n, const int* ci, const int* cj, const
   for (int k = 0; k < n; k++) { cs::Pose p = cs::pose_load(&B->h_oe_meas[m0 + 7 * (size_t)k]); cs::pose_normalize(p); cs::pose_store(p, &B->h_oe_meas[m0 + 7 * (size_t)k]); }
   B->h_oe_info.insert(B->h_oe_info.end(), info36, info36 + 36 * (size_t)n);
   B->n_odom += n;
+  if (!B->rk_odom.empty()) { B->rk_odom.resize(B->n_odom, 0); B->rd_odom.resize(B->n_odom, 0.0); }
   B->structure_dirty = true;
   return CS_OK;
   BA_GUARD_END("cs_ba_append_edges_odom")
@@ -1373,6 +1412,7 @@ static int cs_ba_set_edges_proj_impl(cs_ba* B, int n, const int* pt, const int* 
   int rc;
   if ((rc = B->raw_uv.upload_ptr(uv, 2 * (size_t)n)) || (rc = B->raw_info.upload_ptr(info4, 4 * (size_t)n)) || (rc = B->raw_intr.upload_ptr(intr4, 4 * (size_t)n))) return rc;
   B->have_huber = huber != nullptr;
+  B->rk_proj.clear();
   if (huber) { rc = B->raw_huber.upload_ptr(huber, (size_t)n); if (rc) return rc; } else B->raw_huber.release();
   B->structure_dirty = true;
   return CS_OK;
@@ -1386,6 +1426,7 @@ int cs_ba_set_edges_proj(cs_ba* B, int n, const int* pt, const int* cam, const d
 static int cs_ba_set_edges_cuboid_impl(cs_ba* B, int n, const int* cam, const int* cub, const double* meas10, const double* info81) {
   if (!B || n < 0 || (n && (!cam || !cub || !meas10 || !info81))) return CS_ERR_INVALID_ARG;
   B->u3_cam.assign(cam, cam + n); B->u3_cub.assign(cub, cub + n);
+  B->rk_cub3.clear(); B->rd_cub3.clear();
   B->h_ce_meas.assign(meas10, meas10 + 10 * (size_t)n); B->h_ce_info.assign(info81, info81 + 81 * (size_t)n);
   B->structure_dirty = true;
   return CS_OK;
@@ -1399,6 +1440,7 @@ int cs_ba_set_edges_cuboid(cs_ba* B, int n, const int* cam, const int* cub, cons
 static int cs_ba_set_edges_cuboid_proj_impl(cs_ba* B, int n, const int* cam, const int* cub, const double* meas4, const double* info16, const double* K9) {
   if (!B || n < 0 || (n && (!cam || !cub || !meas4 || !info16 || !K9))) return CS_ERR_INVALID_ARG;
   B->up_cam.assign(cam, cam + n); B->up_cub.assign(cub, cub + n);
+  B->rk_cproj.clear(); B->rd_cproj.clear();
   B->h_pe_meas.assign(meas4, meas4 + 4 * (size_t)n); B->h_pe_info.assign(info16, info16 + 16 * (size_t)n); B->h_pe_K.assign(K9, K9 + 9 * (size_t)n);
   B->structure_dirty = true;
   return CS_OK;
@@ -1413,6 +1455,7 @@ static int cs_ba_set_edges_odom_impl(cs_ba* B, int n, const int* ci, const int* 
   if (!B || n < 0 || (n && (!ci || !cj || !meas7 || !info36))) return CS_ERR_INVALID_ARG;
   B->n_odom = n;
   B->oe_i.assign(ci, ci + n); B->oe_j.assign(cj, cj + n);
+  B->rk_odom.clear(); B->rd_odom.clear();
   B->h_oe_meas.assign(meas7, meas7 + 7 * (size_t)n);
   for (int k = 0; k < n; k++) { cs::Pose p = cs::pose_load(&B->h_oe_meas[7 * (size_t)k]); cs::pose_normalize(p); cs::pose_store(p, &B->h_oe_meas[7 * (size_t)k]); }
   B->h_oe_info.assign(info36, info36 + 36 * (size_t)n);
@@ -1423,6 +1466,38 @@ int cs_ba_set_edges_odom(cs_ba* B, int n, const int* ci, const int* cj, const do
   BA_GUARD_BEGIN
   return cs_ba_set_edges_odom_impl(B, n, ci, cj, meas7, info36);
   BA_GUARD_END("cs_ba_set_edges_odom")
+}
+
+// Robust kernels of one edge class (OptimizableGraph::Edge::setRobustKernel, core/optimizable_graph.h:419-423; the kernels:
+// core/robust_kernel_impl.cpp:78-165).  Replaces the class's kernels; n = the class's edge count.
+static int cs_ba_set_robust_kernels_impl(cs_ba* B, int edge_class, int n, const int* kind, const double* delta) {
+  if (!B || n < 0 || (n && kind && !delta)) return CS_ERR_INVALID_ARG;
+  const int have = edge_class == CS_EDGE_PROJ ? B->n_proj : edge_class == CS_EDGE_CUBOID ? (int)B->u3_cam.size() : edge_class == CS_EDGE_CUBOID_PROJ ? (int)B->up_cam.size()
+                 : edge_class == CS_EDGE_ODOM ? B->n_odom : -1;
+  if (have < 0) { cs_set_error_ba("cs_ba_set_robust_kernels: unknown edge class"); return CS_ERR_INVALID_ARG; }
+  if (n != have) { cs_set_error_ba("cs_ba_set_robust_kernels: n must equal the number of edges of the class (set the edges first)"); return CS_ERR_INVALID_ARG; }
+  std::vector<int> kk(n, 0); std::vector<double> dd(n, 0.0);
+  for (int k = 0; k < n && kind; k++) {
+    if (kind[k] < 0 || kind[k] >= cs::RK_KINDS) { cs_set_error_ba("cs_ba_set_robust_kernels: unknown kernel kind"); return CS_ERR_INVALID_ARG; }
+    if (kind[k] != cs::RK_NONE && !(delta[k] > 0)) { cs_set_error_ba("cs_ba_set_robust_kernels: a kernel needs delta > 0"); return CS_ERR_INVALID_ARG; }
+    kk[k] = kind[k]; dd[k] = kind[k] != cs::RK_NONE ? delta[k] : 0.0;
+  }
+  if (edge_class == CS_EDGE_PROJ) {
+    BA_TRY(hipSetDevice(B->device));
+    BA_TRY(hipStreamSynchronize(B->st));
+    int rc = B->raw_huber.upload_ptr(dd.data(), (size_t)n); if (rc) return rc;    // delta per edge, 0 = none
+    B->have_huber = true;
+    B->rk_proj = kk;
+  } else if (edge_class == CS_EDGE_CUBOID) { B->rk_cub3 = kk; B->rd_cub3 = dd; }
+  else if (edge_class == CS_EDGE_CUBOID_PROJ) { B->rk_cproj = kk; B->rd_cproj = dd; }
+  else { B->rk_odom = kk; B->rd_odom = dd; }
+  B->structure_dirty = true;
+  return CS_OK;
+}
+int cs_ba_set_robust_kernels(cs_ba* B, int edge_class, int n, const int* kind, const double* delta) {
+  BA_GUARD_BEGIN
+  return cs_ba_set_robust_kernels_impl(B, edge_class, n, kind, delta);
+  BA_GUARD_END("cs_ba_set_robust_kernels")
 }
 
 static int cs_ba_compute_errors_impl(cs_ba* B, double* chi2) {

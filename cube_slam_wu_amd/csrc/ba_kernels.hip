@@ -33,13 +33,9 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// Huber (robust_kernel_impl.cpp:78-91): rho0, rho1 for squared error e
-__device__ __forceinline__ void huber_rho(double e, double delta, double& rho0, double& rho1) {
-  if (delta > 0) {
-    double dsqr = delta * delta;
-    if (e <= dsqr) { rho0 = e; rho1 = 1.0; }
-    else { double sq = sqrt(e); rho0 = 2 * sq * delta - dsqr; rho1 = delta / sq; }
-  } else { rho0 = e; rho1 = 1.0; }
+// rho, rho' of a projection edge's squared error (cs_robust.h): Huber-or-none from the delta alone, any kernel through the kind array
+__device__ __forceinline__ void proj_rho(const int* rk, int k, double delta, double e, double& rho0, double& rho1) {
+  if (rk) robust_rho(rk[k], delta, e, rho0, rho1); else huber_rho(e, delta, rho0, rho1);
 }
 
 struct ProjLin {
@@ -51,7 +47,7 @@ struct ProjLin {
   double chi;      // rho0
 };
 
-__device__ __forceinline__ void proj_linearize(const Pose& T, const double* R, const double* X, const double* uv, const double* info, const double* intr, double huber, ProjLin& L) {
+__device__ __forceinline__ void proj_linearize(const Pose& T, const double* R, const double* X, const double* uv, const double* info, const double* intr, double huber, const int* rk, int k, ProjLin& L) {
   double pc[3];
   proj_error(T, X, uv, intr, L.e, pc);
   double x = pc[0], y = pc[1], z = pc[2], z_2 = z * z, fx = intr[0], fy = intr[1];
@@ -69,7 +65,7 @@ __device__ __forceinline__ void proj_linearize(const Pose& T, const double* R, c
   L.Jc[6] = (1 + y * y / z_2) * fy; L.Jc[7] = -x * y / z_2 * fy; L.Jc[8] = -x / z * fy; L.Jc[9] = 0; L.Jc[10] = -1. / z * fy; L.Jc[11] = y / z_2 * fy;
   double c = L.e[0] * (info[0] * L.e[0] + info[1] * L.e[1]) + L.e[1] * (info[2] * L.e[0] + info[3] * L.e[1]);
   double rho1;
-  huber_rho(c, huber, L.chi, rho1);
+  proj_rho(rk, k, huber, c, L.chi, rho1);
 #pragma unroll
   for (int i = 0; i < 4; i++) L.Wm[i] = rho1 * info[i];
   L.r[0] = -(info[0] * L.e[0] + info[1] * L.e[1]) * rho1;
@@ -87,7 +83,7 @@ __global__ __launch_bounds__(256) void ba_chi2_proj_kernel(BaView v) {
     const double* info = v.pm_info + 4 * k;
     double c = e[0] * (info[0] * e[0] + info[1] * e[1]) + e[1] * (info[2] * e[0] + info[3] * e[1]);
     double rho0, rho1;
-    huber_rho(c, v.pm_huber[k], rho0, rho1);
+    proj_rho(v.pm_rk, k, v.pm_huber[k], c, rho0, rho1);
     acc += rho0;
   }
   acc = wave_sum(acc);
@@ -114,12 +110,14 @@ __global__ __launch_bounds__(64) void ba_chi2_pose_edges_kernel(BaView v, int pa
     double e[9];
     if (v.ce_active[k]) cuboid_edge_error(pose_load(v.cams + 7 * v.ce_cam[k]), cube_load(v.cubes + 10 * v.ce_cub[k]), cube_load(v.ce_meas + 10 * k), e);
     if (v.ce_active[k]) c = quad_form(e, v.ce_info + 81 * k, 9);
+    if (v.ce_active[k] && v.ce_rk && v.ce_rk[k]) { double r1; robust_rho(v.ce_rk[k], v.ce_rdelta[k], c, c, r1); }
   } else if (k < v.n_cub) {
     const int q = k - v.n_cub3;
     double e[4];
     if (v.ce_active[k]) {
       cuboid_proj_error(pose_load(v.cams + 7 * v.ce_cam[k]), cube_load(v.cubes + 10 * v.ce_cub[k]), v.pe_K + 9 * (size_t)q, v.pe_meas + 4 * (size_t)q, e);
       c = quad_form(e, v.pe_info + 16 * (size_t)q, 4);
+      if (v.ce_rk && v.ce_rk[k]) { double r1; robust_rho(v.ce_rk[k], v.ce_rdelta[k], c, c, r1); }
     }
   } else if (k < v.n_cub + v.n_odom) {
     int q = k - v.n_cub;
@@ -127,6 +125,7 @@ __global__ __launch_bounds__(64) void ba_chi2_pose_edges_kernel(BaView v, int pa
     if (v.oe_active[q]) {
       odom_edge_error(pose_load(v.cams + 7 * v.oe_i[q]), pose_load(v.cams + 7 * v.oe_j[q]), pose_load(v.oe_meas + 7 * q), e);
       c = quad_form(e, v.oe_info + 36 * q, 6);
+      if (v.oe_rk && v.oe_rk[q]) { double r1; robust_rho(v.oe_rk[q], v.oe_rdelta[q], c, c, r1); }
     }
   }
   c = wave_sum(c);
@@ -180,7 +179,7 @@ __global__ __launch_bounds__(256) void ba_lin_cam_kernel(BaView v) {
   int e0 = v.cam_ptr[c], e1 = v.cam_ptr[c + 1];
   for (int k = e0 + threadIdx.x; k < e1; k += 256) {
     ProjLin L;
-    proj_linearize(T, R, v.points + 3 * v.cm_pt[k], v.cm_uv + 2 * k, v.cm_info + 4 * k, v.cm_intr + 4 * k, v.cm_huber[k], L);
+    proj_linearize(T, R, v.points + 3 * v.cm_pt[k], v.cm_uv + 2 * k, v.cm_info + 4 * k, v.cm_intr + 4 * k, v.cm_huber[k], v.cm_rk, k, L);
     // JW = Jc^T W (6x2)
     int q = 0;
 #pragma unroll
@@ -227,7 +226,7 @@ __device__ __forceinline__ void lin_pt_edge(const BaView& v, int k, bool free_pt
   double R[9];
   pose_rotmat(T, R);
   ProjLin L;
-  proj_linearize(T, R, v.points + 3 * v.pm_pt[k], v.pm_uv + 2 * k, v.pm_info + 4 * k, v.pm_intr + 4 * k, v.pm_huber[k], L);
+  proj_linearize(T, R, v.points + 3 * v.pm_pt[k], v.pm_uv + 2 * k, v.pm_info + 4 * k, v.pm_intr + 4 * k, v.pm_huber[k], v.pm_rk, k, L);
   double pw[6];  // Jp^T W (3x2)
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -297,13 +296,15 @@ __global__ __launch_bounds__(256) void ba_lin_pt_kernel(BaView v) {
 // error), the columns meet in LDS, and lane i then forms row i of J^T Omega J and of -J^T Omega e.
 // NA / NB = tangent dimensions of the two vertices, D = error dimension; J is stored J[d][r] (column d, row r).
 template <int D, int NA, int NB>
+// w = rho' of the edge's robust kernel (1 without one: the products below are then exactly the unweighted ones): Omega is weighted
+// entry by entry like robustInformation() (base_edge.h:96-102), which also weights b = -J^T (rho' Omega) e (base_binary_edge.hpp:99).
 __device__ __forceinline__ void edge_rows_from_columns(const double (*J)[D], const double* e0, const double* __restrict__ info, int i,
-                                                       double* Haa, double* Hbb, double* Hab, double* ba, double* bb) {
+                                                       double* Haa, double* Hbb, double* Hab, double* ba, double* bb, double w) {
   constexpr int N = NA + NB;
   if (i >= N) return;
-  double t[D];   // t = J(:, i)^T Omega
+  double t[D];   // t = J(:, i)^T (w Omega)
 #pragma unroll
-  for (int j = 0; j < D; j++) { double s = 0; for (int k = 0; k < D; k++) s = fma(J[i][k], info[D * k + j], s); t[j] = s; }
+  for (int j = 0; j < D; j++) { double s = 0; for (int k = 0; k < D; k++) s = fma(J[i][k], w * info[D * k + j], s); t[j] = s; }
   double bi = 0;
 #pragma unroll
   for (int k = 0; k < D; k++) bi = fma(t[k], e0[k], bi);
@@ -387,12 +388,18 @@ __global__ __launch_bounds__(128) void ba_cub_edge_kernel(BaView v) {
     }
   }
   __syncthreads();
+  double w = 1.0;      // rho' of the edge's kernel at its chi2 (every lane of the edge computes the same value)
+  if (live && sgn == 0 && v.ce_rk && v.ce_rk[k]) {
+    const double c = is3d ? quad_form(J[sub][15], v.ce_info + 81 * (size_t)k, 9) : quad_form(Jq[15], v.pe_info + 16 * (size_t)(k - v.n_cub3), 4);
+    double r0;
+    robust_rho(v.ce_rk[k], v.ce_rdelta[k], c, r0, w);
+  }
   if (live && is3d && sgn == 0)
     edge_rows_from_columns<9, 6, 9>(J[sub], J[sub][15], v.ce_info + 81 * (size_t)k, d, v.ce_Hcc + 36 * (size_t)k, v.ce_Hoo + 81 * (size_t)k,
-                                    v.ce_Hco + 54 * (size_t)k, v.ce_bc + 6 * (size_t)k, v.ce_bo + 9 * (size_t)k);
+                                    v.ce_Hco + 54 * (size_t)k, v.ce_bc + 6 * (size_t)k, v.ce_bo + 9 * (size_t)k, w);
   if (live && !is3d && sgn == 0)
     edge_rows_from_columns<4, 6, 9>(Jq, Jq[15], v.pe_info + 16 * (size_t)(k - v.n_cub3), d, v.ce_Hcc + 36 * (size_t)k, v.ce_Hoo + 81 * (size_t)k,
-                                    v.ce_Hco + 54 * (size_t)k, v.ce_bc + 6 * (size_t)k, v.ce_bo + 9 * (size_t)k);
+                                    v.ce_Hco + 54 * (size_t)k, v.ce_bc + 6 * (size_t)k, v.ce_bo + 9 * (size_t)k, w);
 }
 
 __global__ __launch_bounds__(64) void ba_odom_edge_kernel(BaView v) {
@@ -424,9 +431,12 @@ __global__ __launch_bounds__(64) void ba_odom_edge_kernel(BaView v) {
     }
   }
   __syncthreads();
-  if (live)
+  if (live) {
+    double w = 1.0;
+    if (v.oe_rk && v.oe_rk[k]) { double r0; robust_rho(v.oe_rk[k], v.oe_rdelta[k], quad_form(J[sub][15], v.oe_info + 36 * (size_t)k, 6), r0, w); }
     edge_rows_from_columns<6, 6, 6>(J[sub], J[sub][15], v.oe_info + 36 * (size_t)k, d, v.oe_Hii + 36 * (size_t)k, v.oe_Hjj + 36 * (size_t)k,
-                                    v.oe_Hij + 36 * (size_t)k, v.oe_bi + 6 * (size_t)k, v.oe_bj + 6 * (size_t)k);
+                                    v.oe_Hij + 36 * (size_t)k, v.oe_bi + 6 * (size_t)k, v.oe_bj + 6 * (size_t)k, w);
+  }
 }
 
 // gather the numeric-edge blocks into the pose vertices' A_ii / b_i (fixed order: deterministic)

@@ -2,6 +2,7 @@
 // See DESIGN.md "Path B: data layout in HBM".
 #pragma once
 #include "cs_se3.h"
+#include "cs_robust.h"
 
 namespace cs {
 
@@ -35,12 +36,17 @@ struct BaView {
   const int* cm_pm;    // n_proj: index into the point-major arrays
   const int* cm_pt; const double* cm_uv; const double* cm_info; const double* cm_intr; const double* cm_huber;
   const int* cam_ptr;  // nc + 1
+  // robust kernels (cs_robust.h).  Projection edges: pm_huber / cm_huber hold RobustKernel::delta(); pm_rk / cm_rk the kernel kind, or
+  // nullptr when every projection edge has Huber or none (then delta > 0 means Huber -- the common case keeps its 8-byte record)
+  const int* pm_rk; const int* cm_rk;
   // ---- cuboid edges and odometry edges (EdgeSE3Expmap): numeric Jacobians ------------------------------
   // camera-cuboid edges 0 .. n_cub3 - 1 are EdgeSE3Cuboid (9-dim, ce_meas / ce_info), edges n_cub3 .. n_cub - 1 are
   // EdgeSE3CuboidProj (4-dim bounding-box error, pe_meas 4 / pe_info 16 / pe_K 9 per edge, indexed k - n_cub3); both
   // kinds share the index lists, the output blocks and the vertex adjacency
   int n_cub3; const double* pe_meas; const double* pe_info; const double* pe_K;
   int n_cub; const int* ce_cam; const int* ce_cub; const double* ce_meas; const double* ce_info; const int* ce_active;
+  const int* ce_rk; const double* ce_rdelta;   // n_cub: kernel kind / delta of the camera-cuboid edges (nullptr: none has a kernel)
+  const int* oe_rk; const double* oe_rdelta;   // n_odom
   double* ce_Hcc; double* ce_Hoo; double* ce_Hco; double* ce_bc; double* ce_bo;   // 36, 81, 54, 6, 9 per edge
   int n_odom; const int* oe_i; const int* oe_j; const double* oe_meas; const double* oe_info; const int* oe_active;
   double* oe_Hii; double* oe_Hjj; double* oe_Hij; double* oe_bi; double* oe_bj;   // 36, 36, 36, 6, 6 per edge

@@ -246,10 +246,14 @@ inline void min_log_error(const Cuboid& self, const Cuboid& newone, double res[9
   std::memcpy(res, errs[m], sizeof(double) * 9);
 }
 
-struct EdgeProj { int pt, cam; double uv[2], info[4], intr[4], huber; };
-struct EdgeCub { int cam, cub; Cuboid meas; double info[81]; };
-struct EdgeOdom { int ci, cj; SE3 meas; double info[36]; };
-struct EdgeCubProj { int cam, cub; double meas[4], info[16], K[9]; };  // EdgeSE3CuboidProj (g2o_Object.h:264-293): bbox centre, width, height
+// An edge's robust kernel (OptimizableGraph::Edge::robustKernel(), core/optimizable_graph.h:419-421): which of the classes of
+// core/robust_kernel_impl.h:41-172 and its RobustKernel::_delta; kind 0 = no kernel.  Kinds: 1 Huber, 2 PseudoHuber, 3 Cauchy, 4 Saturated,
+// 5 DCS, 6 Tukey.
+struct Robust { int kind = 0; double delta = 0; };
+struct EdgeProj { int pt, cam; double uv[2], info[4], intr[4]; Robust rk; };
+struct EdgeCub { int cam, cub; Cuboid meas; double info[81]; Robust rk; };
+struct EdgeOdom { int ci, cj; SE3 meas; double info[36]; Robust rk; };
+struct EdgeCubProj { int cam, cub; double meas[4], info[16], K[9]; Robust rk; };  // EdgeSE3CuboidProj (g2o_Object.h:264-293): bbox centre, width, height
 
 struct Problem {
   std::vector<SE3> cams; std::vector<int> cam_fixed;
@@ -376,21 +380,59 @@ void compute_errors(Problem& P) {  // sparse_optimizer.cpp:61-76
   for (size_t k = 0; k < P.eodom.size(); k++) err_odom_fn(P.cams[P.eodom[k].ci], P.cams[P.eodom[k].cj], P.eodom[k], &P.err_odom[6 * k]);
 }
 
-inline void huber(double e, double delta, double rho[3]) {  // robust_kernel_impl.cpp:78-91
-  double dsqr = delta * delta;
-  if (e <= dsqr) { rho[0] = e; rho[1] = 1.; rho[2] = 0.; }
-  else { double sq = std::sqrt(e); rho[0] = 2 * sq * delta - dsqr; rho[1] = delta / sq; rho[2] = -0.5 * rho[1] / e; }
+// RobustKernel::robustify of the vendored g2o (core/robust_kernel_impl.cpp), kernel by kernel.  Two members of this (ORB-SLAM2-derived)
+// copy are single precision: RobustKernelHuber::dsqr (`float dsqr`, robust_kernel_impl.h:86; setDelta stores delta * delta into it,
+// robust_kernel_impl.cpp:65-69) and RobustKernelTukey::_deltaSqr / _invDeltaSqr (`float`, robust_kernel_impl.h:107-108, set by
+// setDeltaSqr(deltaSqr, inv), robust_kernel_impl.cpp:94-99 -- here from delta: deltaSqr = delta^2, inv = 1 / delta^2, the call a user of
+// that class makes).  The comparisons and products below therefore see the float-rounded squares, as the reference's do.
+inline void robustify(const Robust& k, double e, double rho[3]) {
+  const double delta = k.delta;
+  switch (k.kind) {
+    case 1: {   // RobustKernelHuber::robustify :78-91
+      const float dsqr = (float)(delta * delta);
+      if (e <= dsqr) { rho[0] = e; rho[1] = 1.; rho[2] = 0.; }
+      else { double sqrte = std::sqrt(e); rho[0] = 2 * sqrte * delta - dsqr; rho[1] = delta / sqrte; rho[2] = -0.5 * rho[1] / e; }
+      break;
+    }
+    case 2: {   // RobustKernelPseudoHuber::robustify :119-128
+      double dsqr = delta * delta, dsqrReci = 1. / dsqr, aux1 = dsqrReci * e + 1.0, aux2 = std::sqrt(aux1);
+      rho[0] = 2 * dsqr * (aux2 - 1); rho[1] = 1. / aux2; rho[2] = -0.5 * dsqrReci * rho[1] / aux1;
+      break;
+    }
+    case 3: {   // RobustKernelCauchy::robustify :130-138
+      double dsqr = delta * delta, dsqrReci = 1. / dsqr, aux = dsqrReci * e + 1.0;
+      rho[0] = dsqr * std::log(aux); rho[1] = 1. / aux; rho[2] = -dsqrReci * std::pow(rho[1], 2);
+      break;
+    }
+    case 4: {   // RobustKernelSaturated::robustify :140-152
+      double dsqr = delta * delta;
+      if (e <= dsqr) { rho[0] = e; rho[1] = 1.; rho[2] = 0.; } else { rho[0] = dsqr; rho[1] = 0.; rho[2] = 0.; }
+      break;
+    }
+    case 5: {   // RobustKernelDCS::robustify :155-165 (delta is phi)
+      double scale = (2.0 * delta) / (delta + e);
+      if (scale >= 1.0) scale = 1.0;
+      rho[0] = scale * e * scale; rho[1] = scale * scale; rho[2] = 0;
+      break;
+    }
+    case 6: {   // RobustKernelTukey::robustify :101-117
+      const float deltaSqr = (float)(delta * delta), invDeltaSqr = (float)(1.0 / (delta * delta));
+      if (e <= deltaSqr) { double factor = e * invDeltaSqr, d = 1 - factor, dd = d * d; rho[0] = deltaSqr * (1 - dd * d); rho[1] = 3 * dd; rho[2] = -6 * invDeltaSqr * d; }
+      else { rho[0] = deltaSqr; rho[1] = 0.; rho[2] = 0.; }
+      break;
+    }
+    default: rho[0] = e; rho[1] = 1.; rho[2] = 0.;   // no kernel: chi2 itself (sparse_optimizer.cpp:100-114), Omega unweighted
+  }
 }
 
 double robust_chi2(const Problem& P) {  // sparse_optimizer.cpp:100-114 (edges in insertion order: proj, cuboid, cuboid-projection, odom)
   double chi = 0;
   for (size_t k = 0; k < P.eproj.size(); k++) {
-    double c = quad(&P.err_proj[2 * k], P.eproj[k].info, 2);
-    if (P.eproj[k].huber > 0) { double rho[3]; huber(c, P.eproj[k].huber, rho); chi += rho[0]; } else chi += c;
+    double rho[3]; robustify(P.eproj[k].rk, quad(&P.err_proj[2 * k], P.eproj[k].info, 2), rho); chi += rho[0];
   }
-  for (size_t k = 0; k < P.ecub.size(); k++) chi += quad(&P.err_cub[9 * k], P.ecub[k].info, 9);
-  for (size_t k = 0; k < P.ecproj.size(); k++) chi += quad(&P.err_cproj[4 * k], P.ecproj[k].info, 4);
-  for (size_t k = 0; k < P.eodom.size(); k++) chi += quad(&P.err_odom[6 * k], P.eodom[k].info, 6);
+  for (size_t k = 0; k < P.ecub.size(); k++) { double rho[3]; robustify(P.ecub[k].rk, quad(&P.err_cub[9 * k], P.ecub[k].info, 9), rho); chi += rho[0]; }
+  for (size_t k = 0; k < P.ecproj.size(); k++) { double rho[3]; robustify(P.ecproj[k].rk, quad(&P.err_cproj[4 * k], P.ecproj[k].info, 4), rho); chi += rho[0]; }
+  for (size_t k = 0; k < P.eodom.size(); k++) { double rho[3]; robustify(P.eodom[k].rk, quad(&P.err_odom[6 * k], P.eodom[k].info, 6), rho); chi += rho[0]; }
   return chi;
 }
 
@@ -475,7 +517,7 @@ void build_system(Problem& P) {  // block_solver.hpp:501-560
     Jj[6] = (1 + y * y / z_2) * fy; Jj[7] = -x * y / z_2 * fy; Jj[8] = -x / z * fy; Jj[9] = 0; Jj[10] = -1. / z * fy; Jj[11] = y / z_2 * fy;
     const double* err = &P.err_proj[2 * k];
     double rho1 = 1.0;
-    if (e.huber > 0) { double rho[3]; huber(quad(err, e.info, 2), e.huber, rho); rho1 = rho[1]; }
+    if (e.rk.kind) { double rho[3]; robustify(e.rk, quad(err, e.info, 2), rho); rho1 = rho[1]; }
     double W[4], r[2];
     for (int i = 0; i < 4; i++) W[i] = rho1 * e.info[i];
     for (int i = 0; i < 2; i++) r[i] = -(e.info[2 * i] * err[0] + e.info[2 * i + 1] * err[1]) * rho1;
@@ -534,7 +576,9 @@ void build_system(Problem& P) {  // block_solver.hpp:501-560
         err_cub_fn(P.cams[e.cam], cub_exp_update(P.cubs[e.cub], add), e, e2);
         for (int r = 0; r < 9; r++) Jj[r * 9 + d] = scalar * (e1[r] - e2[r]);
       }
-    quadratic_form_pp(P, ca, 6, Ji, cb, 9, Jj, &P.err_cub[9 * k], e.info, 9, 1.0);
+    double rho1 = 1.0;   // base_binary_edge.hpp:88-92: with a kernel, rho' of the edge's chi2 weights Omega and omega_r
+    if (e.rk.kind) { double rho[3]; robustify(e.rk, quad(&P.err_cub[9 * k], e.info, 9), rho); rho1 = rho[1]; }
+    quadratic_form_pp(P, ca, 6, Ji, cb, 9, Jj, &P.err_cub[9 * k], e.info, 9, rho1);
   }
   // --- cuboid projection edges (EdgeSE3CuboidProj): vertex 0 = camera, vertex 1 = cuboid; numeric Jacobians, 4-dim error
   for (size_t k = 0; k < P.ecproj.size(); k++) {
@@ -560,7 +604,9 @@ void build_system(Problem& P) {  // block_solver.hpp:501-560
         err_cproj_fn(P.cams[e.cam], cub_exp_update(P.cubs[e.cub], add), e, e2);
         for (int r = 0; r < 4; r++) Jj[r * 9 + d] = scalar * (e1[r] - e2[r]);
       }
-    quadratic_form_pp(P, ca, 6, Ji, cb, 9, Jj, &P.err_cproj[4 * k], e.info, 4, 1.0);
+    double rho1 = 1.0;
+    if (e.rk.kind) { double rho[3]; robustify(e.rk, quad(&P.err_cproj[4 * k], e.info, 4), rho); rho1 = rho[1]; }
+    quadratic_form_pp(P, ca, 6, Ji, cb, 9, Jj, &P.err_cproj[4 * k], e.info, 4, rho1);
   }
   // --- odometry edges
   for (size_t k = 0; k < P.eodom.size(); k++) {
@@ -586,7 +632,9 @@ void build_system(Problem& P) {  // block_solver.hpp:501-560
         err_odom_fn(P.cams[e.ci], cam_oplus(P.cams[e.cj], add), e, e2);
         for (int r = 0; r < 6; r++) Jj[r * 6 + d] = scalar * (e1[r] - e2[r]);
       }
-    quadratic_form_pp(P, ca, 6, Ji, cb, 6, Jj, &P.err_odom[6 * k], e.info, 6, 1.0);
+    double rho1 = 1.0;
+    if (e.rk.kind) { double rho[3]; robustify(e.rk, quad(&P.err_odom[6 * k], e.info, 6), rho); rho1 = rho[1]; }
+    quadratic_form_pp(P, ca, 6, Ji, cb, 6, Jj, &P.err_odom[6 * k], e.info, 6, rho1);
   }
 }
 
@@ -834,9 +882,24 @@ void ba_oracle_set_edges_proj(void* h, int n, const int* pt, const int* cam, con
     EdgeProj& e = P.eproj[k];
     e.pt = pt[k]; e.cam = cam[k];
     std::memcpy(e.uv, uv + 2 * k, 16); std::memcpy(e.info, info4 + 4 * k, 32); std::memcpy(e.intr, intr4 + 4 * k, 32);
-    e.huber = huber ? huber[k] : 0.0;
+    e.rk = Robust{};
+    if (huber && huber[k] > 0) { e.rk.kind = 1; e.rk.delta = huber[k]; }   // RobustKernelHuber with setDelta(huber[k])
   }
 }
+// Robust kernels of one edge class (0 projection, 1 EdgeSE3Cuboid, 2 EdgeSE3CuboidProj, 3 EdgeSE3Expmap): kind as in struct Robust,
+// delta = RobustKernel::delta().  n must be the class's edge count; call after the class's edges are set.
+int ba_oracle_set_robust_kernels(void* h, int edge_class, int n, const int* kind, const double* delta) {
+  Problem& P = *(Problem*)h;
+  auto put = [&](auto& edges) -> int {
+    if ((size_t)n != edges.size()) return 1;
+    for (int k = 0; k < n; k++) { edges[k].rk.kind = kind ? kind[k] : 0; edges[k].rk.delta = delta ? delta[k] : 0.0; }
+    return 0;
+  };
+  switch (edge_class) { case 0: return put(P.eproj); case 1: return put(P.ecub); case 2: return put(P.ecproj); case 3: return put(P.eodom); }
+  return 1;
+}
+// RobustKernel::robustify for a known-answer table (tests/test_ba_oracle.py)
+void ba_oracle_robustify(int kind, double delta, double e, double rho3[3]) { robustify(Robust{kind, delta}, e, rho3); }
 void ba_oracle_set_edges_cuboid(void* h, int n, const int* cam, const int* cub, const double* meas10, const double* info81) {
   Problem& P = *(Problem*)h;
   P.ecub.resize(n);

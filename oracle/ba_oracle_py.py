@@ -83,6 +83,13 @@ class Problem:
         ci, cj = _i(ci), _i(cj); self.n_odom = len(ci)
         lib().ba_oracle_set_edges_odom(self.h, self.n_odom, _ip(ci), _ip(cj), _dp(_f(meas7, (-1, 7))), _dp(_f(info36, (-1, 36))))
 
+    def set_robust_kernels(self, edge_class, kind, delta):
+        """Robust kernels of one edge class (0 projection, 1 EdgeSE3Cuboid, 2 EdgeSE3CuboidProj, 3 EdgeSE3Expmap); kinds as in
+        core/robust_kernel_impl.cpp: 1 Huber, 2 PseudoHuber, 3 Cauchy, 4 Saturated, 5 DCS, 6 Tukey; 0 none."""
+        kind, delta = _i(kind), _f(delta, (-1,))
+        if lib().ba_oracle_set_robust_kernels(self.h, int(edge_class), len(kind), _ip(kind), _dp(delta)) != 0:
+            raise ValueError("set_robust_kernels: edge class / count mismatch")
+
     def optimize(self, iters):
         return lib().ba_oracle_optimize(self.h, int(iters))
 
@@ -146,6 +153,13 @@ class Problem:
             self.close()
         except Exception:
             pass
+
+
+def robustify(kind, delta, e):
+    """RobustKernel::robustify of the restatement: (rho, rho', rho'') of the squared error e."""
+    out = np.zeros(3)
+    lib().ba_oracle_robustify(int(kind), C.c_double(delta), C.c_double(e), _dp(out))
+    return out
 
 
 def se3_exp(u):

@@ -28,7 +28,95 @@ def _oracle(pr, cuboids_first=False):
         P.set_edges_cuboid_proj(pr["pe_cam"], pr["pe_cub"], pr["pe_meas"], pr["pe_info"], pr["pe_K"])
     if len(pr["oe_i"]):
         P.set_edges_odom(pr["oe_i"], pr["oe_j"], pr["oe_meas"], pr["oe_info"])
+    for cls, (kind, delta) in pr.get("robust", {}).items():
+        P.set_robust_kernels(cls, kind, delta)
     return P
+
+
+def _with_kernels(pr, seed, kinds=(0, 1, 2, 3, 4, 5, 6)):
+    """Every edge class gets a random mix of the given kernel kinds, with widths around the edges' typical chi (so that inliers and
+    outliers of every kernel occur)."""
+    rng = np.random.default_rng(seed)
+    pr = dict(pr)
+    rob = {}
+    for cls, n, typ in ((0, len(pr["e_pt"]), 2.5), (1, len(pr["ce_cam"]), 3.0), (2, len(pr.get("pe_cam", [])), 8.0), (3, len(pr["oe_i"]), 0.3)):
+        if n == 0:
+            continue
+        kind = rng.choice(np.asarray(kinds), n)
+        delta = typ * rng.uniform(0.3, 2.0, n)
+        rob[cls] = (kind, delta)
+    pr["robust"] = rob
+    return pr
+
+
+@pytest.mark.parametrize("bbox", [False, True])
+def test_robust_kernels_on_every_edge_class(bbox):
+    """g2o's robust kernels (robust_kernel_impl.cpp:78-165: Huber, PseudoHuber, Cauchy, Saturated, DCS, Tukey) on projection,
+    EdgeSE3Cuboid, EdgeSE3CuboidProj and EdgeSE3Expmap edges: chi2, linear system, one damped solve and a 6-iteration LM run
+    against the oracle (base_binary_edge.hpp:88-111 weights Omega and -Omega e with rho')."""
+    pr = _with_kernels(synth_ba.make_problem(n_cams=40, n_points=2000, n_cuboids=6, seed=17, bbox_edges=bbox), 5)
+    assert set(pr["robust"]) == ({0, 1, 2, 3} if bbox else {0, 1, 3})
+    G, R = capi.ba_from_dict(pr), _oracle(pr)
+    chi_r = R.compute_errors()[0]
+    assert abs(G.compute_errors() - chi_r) < 1e-9 * chi_r
+    # the kernels must matter: without them chi2 differs by far more than the tolerance
+    pr0 = dict(pr); pr0["robust"] = {}
+    G0 = capi.ba_from_dict(pr0)
+    assert abs(G0.compute_errors() - chi_r) > 1e-3 * chi_r
+    Hpp_g, Hll_g, Hpl_g, b_g = G.build_system()
+    Hpp_r, Hll_r, Hpl_r, b_r = R.build_system()
+    assert _rel(Hpp_g, Hpp_r) < 1e-5 and _rel(b_g, b_r) < 1e-5 and _rel(Hll_g, Hll_r) < 1e-11 and _rel(Hpl_g, Hpl_r) < 1e-11
+    ok_g, x_g = G.solve(1.0)
+    ok_r, x_r = R.solve(1.0)
+    assert ok_g and ok_r and _rel(x_g, x_r) < 1e-5
+    n_g, n_r = G.optimize(6), R.optimize(6)
+    assert n_g == n_r
+    assert np.array_equal(G.history()[2], R.history()[2]) and np.allclose(G.history()[0], R.history()[0], rtol=1e-5)
+    scale = np.abs(R.state()[2]).max()
+    for a, b in zip(G.state(), R.state()):
+        assert np.abs(a - b).max() < 1e-5 * scale
+    G.close(); G0.close(); R.close()
+
+
+def test_robust_kernels_huber_width_is_single_precision():
+    """RobustKernelHuber::dsqr is a float member of the vendored g2o (robust_kernel_impl.h:86): an edge whose chi2 lies between
+    delta^2 and float(delta^2) is an inlier there (and here), an outlier under a double-precision square."""
+    pr = synth_ba.make_problem(n_cams=12, n_points=300, n_cuboids=0, seed=2)
+    G0 = capi.ba_from_dict(pr)
+    G0.compute_errors()
+    R = _oracle(pr)
+    _, ep, _, _ = R.compute_errors()
+    info = np.asarray(pr["e_info"]).reshape(-1, 2, 2)
+    chi = np.einsum("ei,eij,ej->e", ep, info, ep)
+    # give every edge the width whose float square lies just ABOVE its chi2 while the double square lies below it (where one exists)
+    d = np.sqrt(chi)
+    cand = np.nextafter(d, 0)      # d^2 <= chi, possibly float(d^2) > chi
+    f32 = (cand * cand).astype(np.float32).astype(np.float64)
+    pick = (f32 >= chi) & (cand * cand < chi)
+    assert pick.sum() > 50
+    pr2 = dict(pr); pr2["e_huber"] = np.where(pick, cand, 0.0)
+    G, R2 = capi.ba_from_dict(pr2), _oracle(pr2)
+    # all picked edges count as inliers (rho = e): the robust chi2 equals the plain one to rounding; a double dsqr would lose ~1e-7 each
+    chi_plain = chi.sum()
+    assert abs(R2.compute_errors()[0] - chi_plain) < 1e-12 * chi_plain
+    assert abs(G.compute_errors() - chi_plain) < 1e-12 * chi_plain
+    G.close(); G0.close()
+
+
+def test_robust_kernel_arguments_are_checked():
+    pr = synth_ba.make_problem(n_cams=12, n_points=300, n_cuboids=2, seed=2)
+    G = capi.ba_from_dict(pr)
+    with pytest.raises(RuntimeError, match="number of edges"):
+        G.set_robust_kernels(capi.EDGE_ODOM, [1, 1], [1.0, 1.0])
+    with pytest.raises(RuntimeError, match="unknown kernel kind"):
+        G.set_robust_kernels(capi.EDGE_ODOM, np.full(len(pr["oe_i"]), 9), np.ones(len(pr["oe_i"])))
+    with pytest.raises(RuntimeError, match="delta > 0"):
+        G.set_robust_kernels(capi.EDGE_ODOM, np.full(len(pr["oe_i"]), 3), np.zeros(len(pr["oe_i"])))
+    G.set_robust_kernels(capi.EDGE_ODOM, np.full(len(pr["oe_i"]), 3), np.ones(len(pr["oe_i"])))
+    c1 = G.compute_errors()
+    G.set_robust_kernels(capi.EDGE_ODOM, None, None)
+    assert G.compute_errors() != c1
+    G.close()
 
 
 def _rel(a, b):

@@ -194,5 +194,31 @@ def _oracle_from_fixture(g):
     return P
 
 
+def test_robust_kernels_known_answers():
+    """RobustKernel::robustify of the restatement against the published formulas (core/robust_kernel_impl.h:64-170 comments), written
+    out independently in numpy, incl. the two single-precision members of the vendored g2o (Huber's dsqr, Tukey's deltaSqr / inverse)."""
+    f32 = lambda v: float(np.float32(v))
+    for delta in (0.7, 1.0, np.sqrt(5.991), 2.5):
+        d2 = delta * delta
+        for e in (0.0, 0.3, d2 * (1 - 1e-9), d2, d2 * (1 + 1e-6), 7.0, 40.0, 1e4):
+            want = {
+                0: (e, 1.0, 0.0),
+                1: (e, 1.0, 0.0) if e <= f32(d2) else (2 * np.sqrt(e) * delta - f32(d2), delta / np.sqrt(e), -0.5 * (delta / np.sqrt(e)) / e),
+                2: (2 * d2 * (np.sqrt(e / d2 + 1) - 1), 1 / np.sqrt(e / d2 + 1), -0.5 / d2 / np.sqrt(e / d2 + 1) / (e / d2 + 1)),
+                3: (d2 * np.log(e / d2 + 1), 1 / (e / d2 + 1), -(1 / d2) / (e / d2 + 1) ** 2),
+                4: (e, 1.0, 0.0) if e <= d2 else (d2, 0.0, 0.0),
+                5: (min(1.0, 2 * delta / (delta + e)) ** 2 * e, min(1.0, 2 * delta / (delta + e)) ** 2, 0.0),
+                6: (f32(d2) * (1 - (1 - e * f32(1 / d2)) ** 3), 3 * (1 - e * f32(1 / d2)) ** 2, f32(np.float32(-6) * np.float32(1 / d2)) * (1 - e * f32(1 / d2))) if e <= f32(d2) else (f32(d2), 0.0, 0.0),   # (`-6*_invDeltaSqr` is an int * float product)
+            }
+            for kind, w in want.items():
+                got = O.robustify(kind, delta, e)
+                assert np.allclose(got, w, rtol=1e-13, atol=1e-300), (kind, delta, e, got, w)
+    # Huber's single-precision square decides the inlier test: sqrt(5.991)^2 = 5.991 (double) but the member holds 5.99100017...
+    d = np.sqrt(5.991)
+    e = 5.9910001
+    assert d * d < e <= f32(d * d)
+    assert O.robustify(1, d, e)[1] == 1.0
+
+
 def test_oracle_against_the_independent_projection_schur_fixture():
     check_against_independent_fixture(_oracle_from_fixture, 1e-11, 1e-8)

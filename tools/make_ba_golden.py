@@ -116,9 +116,12 @@ class Graph:
         """Huber: rho(e), rho'(e) of the squared error e (robust_kernel_impl.cpp:78-91); delta = 0 means no kernel."""
         rho0, rho1 = chi.copy(), np.ones_like(chi)
         d = self.huber
-        out = (d > 0) & (chi > d * d)
+        # RobustKernelHuber keeps delta^2 in a `float` member (robust_kernel_impl.h:86: `float dsqr`, assigned delta * delta by setDelta,
+        # robust_kernel_impl.cpp:65-69): the inlier test and rho(e) see the single-precision square
+        dsqr = (d * d).astype(np.float32).astype(np.float64)
+        out = (d > 0) & (chi > dsqr)
         s = np.sqrt(chi[out])
-        rho0[out] = 2 * s * d[out] - d[out] ** 2
+        rho0[out] = 2 * s * d[out] - dsqr[out]
         rho1[out] = d[out] / s
         return rho0, rho1
 
