@@ -394,6 +394,7 @@ DECLARED_SYMBOLS += [
     "cs_ba_compute_errors", "cs_ba_build_system", "cs_ba_solve", "cs_ba_update", "cs_ba_push", "cs_ba_pop", "cs_ba_optimize",
     "cs_ba_get_state", "cs_ba_sizes", "cs_ba_solver_layout", "cs_ba_get_system", "cs_ba_last_timing", "cs_ba_set_shard", "cs_ba_optimize_sharded",
     "cs_ba_shard_landmark_owners", "cs_ba_get_landmark_owners", "cs_ba_shard_info", "cs_ba_shard_timing", "cs_ba_append_vertices", "cs_ba_append_edges_proj", "cs_ba_append_edges_cuboid", "cs_ba_append_edges_cuboid_proj", "cs_ba_append_edges_odom", "cs_ba_get_vertex_hessians", "cs_ba_schur_layout", "cs_ba_reduced_size", "cs_ba_comm_unique_id", "cs_ba_comm_init", "cs_ba_set_robust_kernels",
+    "cs_ba_set_external_edges", "cs_ba_set_external_terms", "cs_ba_set_external_chi2", "cs_ba_set_external_callback", "cs_ba_check_finite", "cs_ba_dump", "cs_ba_load",
 ]
 
 
@@ -457,6 +458,34 @@ class BaProblem:
             return
         kind, delta = _i32(kind), _f64(delta, (-1,))
         _chk(lib().cs_ba_set_robust_kernels(self.h, int(edge_class), len(kind), _ip(kind), _dp(delta)), "cs_ba_set_robust_kernels")
+
+    # ---- external (host-evaluated) edges
+    def set_external_edges(self, class_i, idx_i, class_j, idx_j):
+        ci, ii, cj, ij = _i32(class_i), _i32(idx_i), _i32(class_j), _i32(idx_j)
+        self.n_ext = len(ci)
+        _chk(lib().cs_ba_set_external_edges(self.h, len(ci), _ip(ci), _ip(ii), _ip(cj), _ip(ij)), "cs_ba_set_external_edges")
+
+    def set_external_terms(self, cam36=None, cam6=None, cub81=None, cub9=None, pt9=None, pt3=None, Hij81=None, chi2=0.0):
+        a = [(_f64(x, (-1,)) if x is not None else None) for x in (cam36, cam6, cub81, cub9, pt9, pt3, Hij81)]
+        _chk(lib().cs_ba_set_external_terms(self.h, *[(_dp(x) if x is not None else None) for x in a], C.c_double(chi2)), "cs_ba_set_external_terms")
+
+    def set_external_chi2(self, chi2):
+        _chk(lib().cs_ba_set_external_chi2(self.h, C.c_double(chi2)), "cs_ba_set_external_chi2")
+
+    def set_external_callback(self, fn):
+        """fn(want_system) -> None: re-evaluates the external edges at self.state() (see cs_ba_set_external_callback)."""
+        CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+
+        def _cb(ctx, ba, want_system):
+            try:
+                fn(int(want_system))
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._ext_cb = CB(_cb) if fn is not None else None
+        _chk(lib().cs_ba_set_external_callback(self.h, self._ext_cb, None), "cs_ba_set_external_callback")
 
     # ---- growing graphs: new vertices / edges behind the existing ones, device-side estimates kept
     def append_vertices(self, cams=None, cam_fixed=None, cuboids=None, cub_fixed=None, points=None, pt_fixed=None):
@@ -617,6 +646,25 @@ class BaProblem:
         _chk(lib().cs_ba_optimize_sharded(self.h, int(iters), cb, None, C.byref(done), _dp(self._chi), _dp(self._lam), _ip(self._tr), cap), "cs_ba_optimize_sharded")
         self._done = done.value
         return done.value
+
+    def check_finite(self):
+        """(number of non-finite values, report) -- cs_ba_check_finite."""
+        n, buf = C.c_int(), C.create_string_buffer(4096)
+        _chk(lib().cs_ba_check_finite(self.h, C.byref(n), buf, 4096), "cs_ba_check_finite")
+        return n.value, buf.value.decode()
+
+    def dump(self, path):
+        _chk(lib().cs_ba_dump(self.h, str(path).encode()), "cs_ba_dump")
+
+    @classmethod
+    def load(cls, path, sizes, device=0):
+        """cs_ba_load; sizes = (n_cams, n_cuboids, n_points, n_proj) of the dumped problem (the Python wrapper sizes its host arrays with them)."""
+        P = cls.__new__(cls)
+        P.h = C.c_void_p()
+        _chk(lib().cs_ba_load(str(path).encode(), int(device), C.byref(P.h)), "cs_ba_load")
+        P.nc, P.no, P.np_, P.n_proj = [int(x) for x in sizes]
+        P.n_cub = P.n_odom = 0
+        return P
 
     def state(self):
         cams, cubs, pts = np.zeros((self.nc, 7)), np.zeros((self.no, 10)), np.zeros((self.np_, 3))

@@ -48,6 +48,10 @@ size_t ba_band_workspace_doubles(int n, int LD);
 int ba_band_team(int LD, int* rw_out);
 bool ba_band_fits_device(int n, int LD, bool one_sided = false);
 void ba_launch_sum2(const double* a, int na, const double* b, int nb, double* out, hipStream_t st);
+void ba_launch_ext_add(const BaView& v, const double* cam36, const double* cam6, const double* cub81, const double* cub9, const double* pt9, const double* pt3, hipStream_t st);
+void ba_launch_ext_offdiag(const BaView& v, int n, const int* e4, const double* Hij, hipStream_t st);
+void ba_launch_scan_finite(const double* p, long long n, int* out, hipStream_t st);
+void ba_launch_edge_chi(const BaView& v, double* out, hipStream_t st);
 }  // namespace cs
 
 extern "C" const char* cs_last_error(void);
@@ -257,6 +261,15 @@ struct cs_ba {
   std::vector<double> rd_cub3, rd_cproj, rd_odom;
   DBuf<int> d_pm_rk, d_cm_rk, d_ce_rk, d_oe_rk;
   DBuf<double> d_ce_rdelta, d_oe_rdelta;
+  // external (host-evaluated) edges: the coupling pattern of the binary ones (structure), the terms of the current linearisation
+  int ext_n = 0;
+  std::vector<int> ext_e4;                       // (class_i, idx_i, class_j, idx_j) per edge; idx_j < 0: unary
+  DBuf<int> d_ext_e4;
+  DBuf<double> ext_cam36, ext_cam6, ext_cub81, ext_cub9, ext_pt9, ext_pt3, ext_Hij;
+  std::vector<double> h_ext_Hij;                 // host copy (cs_ba_get_system's dense H_pp)
+  bool ext_has_cam = false, ext_has_cub = false, ext_has_pt = false, ext_terms_set = false;
+  double ext_chi2 = 0;
+  cs_external_fn ext_fn = nullptr; void* ext_ctx = nullptr;
   // last solution / rhs on the host (for LM's scale term and for inspection)
   std::vector<double> h_b, h_x;
   bool have_system = false;
@@ -412,6 +425,17 @@ int finalize_structure(cs_ba* B) {
   // camera) so that its block is complete where it is eliminated, and the cuboids' increments are summed over the ranks after the
   // back-substitution (zero on every rank but the owner).  CS_BA_KEEP_CUBOIDS=1 forces (a).
   B->cam_col.assign(nc, -1); B->cub_col.assign(no, -1);
+  // external (host-evaluated) edges: indices, and what their pattern means for the choices below
+  bool ext_binary_on_cuboid = false;
+  for (int k = 0; k < B->ext_n; k++) {
+    const int ci = B->ext_e4[4 * k], ii = B->ext_e4[4 * k + 1], cj = B->ext_e4[4 * k + 2], ij = B->ext_e4[4 * k + 3];
+    auto bad = [&](int c, int i) { return c < 0 || c > 2 || i < 0 || i >= (c == 0 ? nc : c == 1 ? no : np); };
+    if (bad(ci, ii) || (ij >= 0 && bad(cj, ij))) { cs_set_error_ba("external edge: vertex class / index out of range"); return CS_ERR_INVALID_ARG; }
+    if (ij >= 0 && (ci == 2 || cj == 2)) { cs_set_error_ba("external edge: a binary edge may join cameras and cuboids only (a marginalised point takes unary terms only: its coupling to a pose would change the Schur structure)"); return CS_ERR_INVALID_ARG; }
+    if (ij >= 0 && ci == cj && ii == ij) { cs_set_error_ba("external edge: both ends are the same vertex"); return CS_ERR_INVALID_ARG; }
+    if (ij >= 0 && (ci == 1 || cj == 1)) ext_binary_on_cuboid = true;
+  }
+  if (B->shard_n > 1 && (B->ext_n > 0 || B->ext_fn || B->ext_terms_set)) { cs_set_error_ba("external (host-evaluated) edges are not supported on a sharded handle"); return CS_ERR_INVALID_ARG; }
   std::vector<std::vector<int>> cub_cams(no);     // free cameras observing a free cuboid, distinct, by camera id
   int max_slots = 0, n_free_cub = 0;
   for (int k = 0; k < B->n_cub; k++) if (!B->cub_fixed[B->ce_cub[k]] && !B->cam_fixed[B->ce_cam[k]]) cub_cams[B->ce_cub[k]].push_back(B->ce_cam[k]);
@@ -438,6 +462,7 @@ int finalize_structure(cs_ba* B) {
       for (int a = cam_cnt[p]; a < cam_cnt[p + 1]; a++) for (int b = a + 1; b < cam_cnt[p + 1]; b++) link(cams_of[a], cams_of[b]);
     }
     for (int k = 0; k < B->n_odom; k++) link(B->oe_i[k], B->oe_j[k]);
+    for (int k = 0; k < B->ext_n; k++) if (B->ext_e4[4 * k + 3] >= 0) link((B->ext_e4[4 * k] ? nc : 0) + B->ext_e4[4 * k + 1], (B->ext_e4[4 * k + 2] ? nc : 0) + B->ext_e4[4 * k + 3]);
     if (!elim) { for (int k = 0; k < B->n_cub; k++) link(B->ce_cam[k], nc + B->ce_cub[k]); }
     else for (int o = 0; o < no; o++) if (!B->cub_fixed[o]) for (size_t a = 0; a < cub_cams[o].size(); a++) for (size_t b = a + 1; b < cub_cams[o].size(); b++) link(cub_cams[o][a], cub_cams[o][b]);
     for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
@@ -488,7 +513,8 @@ int finalize_structure(cs_ba* B) {
   auto cost = [&](const Ordering& O) { return band_ok(O) ? (double)O.n_red * (O.bw + 1.0) * (O.bw + 1.0) : (double)O.n_red * O.n_red * O.n_red / 3.0; };
   {
     Ordering keep_o = make_ordering(false);
-    const bool try_elim = fused_ok && n_free_cub > 0 && max_slots <= cs::BA_ELIM_MAX_SLOTS && getenv("CS_BA_KEEP_CUBOIDS") == nullptr;
+    // (an external binary edge on a cuboid couples it to something besides its observing cameras: the cuboids then stay in the system)
+    const bool try_elim = fused_ok && n_free_cub > 0 && max_slots <= cs::BA_ELIM_MAX_SLOTS && getenv("CS_BA_KEEP_CUBOIDS") == nullptr && !ext_binary_on_cuboid;
     Ordering elim_o;
     if (try_elim) elim_o = make_ordering(true);
     // (an ordering without unknowns -- every camera fixed, the driver's frame-0 graph -- is not a candidate: nothing would be
@@ -570,6 +596,7 @@ int finalize_structure(cs_ba* B) {
 #define UP(buf, vec) do { rc = (buf).upload_staged(vec, B->stage, B->st); if (rc) return rc; } while (0)
 #define AL(buf, n) do { rc = (buf).alloc(n, B->st); if (rc) return rc; } while (0)
   UP(B->d_cam_col, B->cam_col); UP(B->d_cub_col, B->cub_col); UP(B->d_pt_free, pt_free);
+  { std::vector<int> e4(B->ext_e4); if (e4.empty()) e4.assign(4, 0); UP(B->d_ext_e4, e4); }
   // ---- projection edges: point-major order (sorted by pose column inside a point), camera-major copy.  The edges are already
   // grouped by landmark with their cameras sorted by id (cams_of / edge_of above); a rank's point-major table is its own landmarks'
   // groups, each re-ordered by (column, camera id) -- k <= a handful of entries -- in a few host threads on disjoint ranges.
@@ -952,6 +979,10 @@ int finalize_structure(cs_ba* B) {
   return CS_OK;
 }
 
+}  // namespace
+static void debug_nan_scan(cs_ba* B, const char* where);
+namespace {
+
 int chi2_device(cs_ba* B, double* chi) {
   cs::ba_launch_chi2(B->view, B->nb_chi, B->st);
   BA_TRY(hipGetLastError());
@@ -1001,6 +1032,11 @@ int collect_lin_time(cs_ba* B) {
 int build_system_device(cs_ba* B) {
   BA_TRY(hipEventRecord(B->ev[0], B->st));
   cs::ba_launch_linearize(B->view, B->st, B->st2, B->ev_fork, B->ev_join, B->st3, B->ev_join3);
+  if (B->ext_terms_set) {
+    if (B->ext_cam36.n != 36 * (size_t)B->nc || B->ext_cub81.n != 81 * (size_t)B->no || B->ext_pt9.n != 9 * (size_t)B->np) { cs_set_error_ba("external terms were set for a graph of another size: call cs_ba_set_external_terms again"); return CS_ERR_INVALID_ARG; }
+    cs::ba_launch_ext_add(B->view, B->ext_has_cam ? B->ext_cam36.p : nullptr, B->ext_cam6.p, B->ext_has_cub ? B->ext_cub81.p : nullptr, B->ext_cub9.p,
+                          B->ext_has_pt ? B->ext_pt9.p : nullptr, B->ext_pt3.p, B->st);
+  }
   BA_TRY(hipGetLastError());
   BA_TRY(hipEventRecord(B->ev[1], B->st));
   B->lin_pending = true;
@@ -1060,6 +1096,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
     BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (B->s_doubles + B->n_pose), B->st));
     BA_TRY(hipMemsetAsync(B->d_elim_fail.p, 0, sizeof(int), B->st));
     cs::ba_launch_reduce(B->view, lambda, B->st, B->st2, B->ev_fork, B->ev_join);
+    if (B->ext_n > 0 && B->ext_terms_set) cs::ba_launch_ext_offdiag(B->view, B->ext_n, B->d_ext_e4.p, B->ext_Hij.p, B->st);
     BA_TRY(hipMemcpyAsync(B->h_status + 1, B->d_elim_fail.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
     BA_TRY(hipGetLastError());
     if (fn && B->shard_n > 1) {  // sum the ranks' partial reduced systems: [S | rhs] in one message
@@ -1257,14 +1294,14 @@ void cs_ba_destroy(cs_ba* B) {
   DBuf<double>* dd[] = {&B->cams, &B->points, &B->cubes, &B->cams_bak, &B->points_bak, &B->cubes_bak, &B->pm_uv, &B->pm_info, &B->pm_intr, &B->pm_huber,
                         &B->cm_uv, &B->cm_info, &B->cm_intr, &B->cm_huber, &B->ce_meas, &B->ce_info, &B->ce_Hcc, &B->ce_Hoo, &B->ce_Hco, &B->ce_bc, &B->ce_bo,
                         &B->oe_meas, &B->oe_info, &B->oe_Hii, &B->oe_Hjj, &B->oe_Hij, &B->oe_bi, &B->oe_bj, &B->Hcam, &B->bcam, &B->Hcub, &B->bcub, &B->Hll, &B->bl,
-                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv, &B->scale_partial, &B->pe_meas, &B->pe_info, &B->pe_K, &B->part_tiles, &B->part_coef, &B->cub_M, &B->cub_Dinv, &B->raw_uv, &B->raw_info, &B->raw_intr, &B->raw_huber, &B->sepY, &B->sep_msgs, &B->sepS, &B->int_work, &B->sep_work, &B->d_ce_rdelta, &B->d_oe_rdelta};
+                        &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv, &B->scale_partial, &B->pe_meas, &B->pe_info, &B->pe_K, &B->part_tiles, &B->part_coef, &B->cub_M, &B->cub_Dinv, &B->raw_uv, &B->raw_info, &B->raw_intr, &B->raw_huber, &B->sepY, &B->sep_msgs, &B->sepS, &B->int_work, &B->sep_work, &B->d_ce_rdelta, &B->d_oe_rdelta, &B->ext_cam36, &B->ext_cam6, &B->ext_cub81, &B->ext_cub9, &B->ext_pt9, &B->ext_pt3, &B->ext_Hij};
   for (auto* d : dd) d->release();
   B->stage.release();
   DBuf<int>* di[] = {&B->d_ce_active, &B->d_oe_active, &B->d_cam_col, &B->d_cub_col, &B->d_pt_free, &B->pm_pt, &B->pm_cam, &B->pt_ptr, &B->cm_pm, &B->cm_pt, &B->cam_ptr, &B->d_ce_cam, &B->d_ce_cub,
                      &B->d_oe_i, &B->d_oe_j, &B->cam_ce_ptr, &B->cam_ce_idx, &B->cam_oei_ptr, &B->cam_oei_idx, &B->cam_oej_ptr, &B->cam_oej_idx, &B->cub_ce_ptr,
                      &B->cub_ce_idx, &B->pair_ptr, &B->pair_i1, &B->pair_i2, &B->ent_a, &B->ent_b, &B->d_run_lm, &B->d_seg_ptr, &B->d_seg_k, &B->d_seg_tile, &B->d_seg_slot,
                      &B->d_gp_ptr, &B->d_gp_i1, &B->d_gp_i2, &B->d_gtile, &B->d_gcam_ptr, &B->d_gslot, &B->d_cubS_ptr, &B->d_cubS_cam, &B->d_ce_slot, &B->d_cub_tile, &B->d_cub_coef,
-                     &B->d_elim_fail, &B->d_slotE_ptr, &B->d_slotE_idx, &B->d_cub_mine, &B->d_sep_off, &B->d_sep_col, &B->d_int_info, &B->d_sep_info, &B->d_pm_rk, &B->d_cm_rk, &B->d_ce_rk, &B->d_oe_rk};
+                     &B->d_elim_fail, &B->d_slotE_ptr, &B->d_slotE_idx, &B->d_cub_mine, &B->d_sep_off, &B->d_sep_col, &B->d_int_info, &B->d_sep_info, &B->d_pm_rk, &B->d_cm_rk, &B->d_ce_rk, &B->d_oe_rk, &B->d_ext_e4};
   for (auto* d : di) d->release();
   B->d_info.release(); B->d_band_info.release();
   for (auto& e : B->ev) if (e) (void)hipEventDestroy(e);
@@ -1468,6 +1505,56 @@ int cs_ba_set_edges_odom(cs_ba* B, int n, const int* ci, const int* cj, const do
   BA_GUARD_END("cs_ba_set_edges_odom")
 }
 
+// ---- external (host-evaluated) edges: the CPU path for edge types the library does not evaluate.  The caller runs such an edge through
+// its own virtuals -- computeError, linearizeOplus, constructQuadraticForm (core/optimizable_graph.h:394-454, base_binary_edge.hpp:54-205,
+// base_unary_edge.hpp:42-123) -- and hands over what they accumulate.
+int cs_ba_set_external_edges(cs_ba* B, int n, const int* class_i, const int* idx_i, const int* class_j, const int* idx_j) {
+  if (!B || n < 0 || (n && (!class_i || !idx_i || !class_j || !idx_j))) return CS_ERR_INVALID_ARG;
+  BA_GUARD_BEGIN
+  B->ext_n = n;
+  B->ext_e4.resize(4 * (size_t)n);
+  for (int k = 0; k < n; k++) { B->ext_e4[4 * k] = class_i[k]; B->ext_e4[4 * k + 1] = idx_i[k]; B->ext_e4[4 * k + 2] = class_j[k]; B->ext_e4[4 * k + 3] = idx_j[k]; }
+  B->ext_terms_set = false;
+  B->structure_dirty = true;
+  return CS_OK;
+  BA_GUARD_END("cs_ba_set_external_edges")
+}
+static int cs_ba_set_external_terms_impl(cs_ba* B, const double* cam36, const double* cam6, const double* cub81, const double* cub9, const double* pt9, const double* pt3,
+                                         const double* Hij81, double chi2) {
+  if (!B || (cam36 && !cam6) || (cub81 && !cub9) || (pt9 && !pt3) || (B->ext_n > 0 && !Hij81)) return CS_ERR_INVALID_ARG;
+  BA_TRY(hipSetDevice(B->device));
+  BA_TRY(hipStreamSynchronize(B->st));     // the previous linearisation may still read the buffers
+  int rc;
+  auto put = [&](DBuf<double>& d, const double* h, size_t n) -> int { return h ? d.upload_ptr(h, n) : d.alloc(n, B->st); };
+  if ((rc = put(B->ext_cam36, cam36, 36 * (size_t)B->nc)) || (rc = put(B->ext_cam6, cam6, 6 * (size_t)B->nc)) || (rc = put(B->ext_cub81, cub81, 81 * (size_t)B->no)) ||
+      (rc = put(B->ext_cub9, cub9, 9 * (size_t)B->no)) || (rc = put(B->ext_pt9, pt9, 9 * (size_t)B->np)) || (rc = put(B->ext_pt3, pt3, 3 * (size_t)B->np)) ||
+      (rc = put(B->ext_Hij, Hij81, 81 * (size_t)B->ext_n))) return rc;
+  BA_TRY(hipStreamSynchronize(B->st));
+  B->ext_has_cam = cam36 != nullptr; B->ext_has_cub = cub81 != nullptr; B->ext_has_pt = pt9 != nullptr;
+  if (Hij81) B->h_ext_Hij.assign(Hij81, Hij81 + 81 * (size_t)B->ext_n); else B->h_ext_Hij.clear();
+  B->ext_chi2 = chi2;
+  B->ext_terms_set = true;
+  B->have_system = false;
+  return CS_OK;
+}
+int cs_ba_set_external_terms(cs_ba* B, const double* cam36, const double* cam6, const double* cub81, const double* cub9, const double* pt9, const double* pt3,
+                             const double* Hij81, double chi2) {
+  BA_GUARD_BEGIN
+  return cs_ba_set_external_terms_impl(B, cam36, cam6, cub81, cub9, pt9, pt3, Hij81, chi2);
+  BA_GUARD_END("cs_ba_set_external_terms")
+}
+int cs_ba_set_external_chi2(cs_ba* B, double chi2) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  if (!B->ext_terms_set) { cs_set_error_ba("cs_ba_set_external_chi2: call cs_ba_set_external_terms first"); return CS_ERR_NOT_RUN; }
+  B->ext_chi2 = chi2;
+  return CS_OK;
+}
+int cs_ba_set_external_callback(cs_ba* B, cs_external_fn fn, void* ctx) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  B->ext_fn = fn; B->ext_ctx = ctx;
+  return CS_OK;
+}
+
 // Robust kernels of one edge class (OptimizableGraph::Edge::setRobustKernel, core/optimizable_graph.h:419-423; the kernels:
 // core/robust_kernel_impl.cpp:78-165).  Replaces the class's kernels; n = the class's edge count.
 static int cs_ba_set_robust_kernels_impl(cs_ba* B, int edge_class, int n, const int* kind, const double* delta) {
@@ -1506,6 +1593,7 @@ static int cs_ba_compute_errors_impl(cs_ba* B, double* chi2) {
   int rc = finalize_structure(B); if (rc) return rc;
   double t0 = now_ms();
   rc = chi2_device(B, chi2);
+  if (B->ext_terms_set) *chi2 += B->ext_chi2;      // the host-evaluated edges' share (cs_ba_set_external_terms / _chi2)
   B->tm.errors_ms += now_ms() - t0;
   return rc;
 }
@@ -1520,7 +1608,9 @@ static int cs_ba_build_system_impl(cs_ba* B) {
   BA_TRY(hipSetDevice(B->device));
   int rc = finalize_structure(B); if (rc) return rc;
   rc = build_system_device(B); if (rc) return rc;
-  return fetch_b(B);
+  rc = fetch_b(B); if (rc) return rc;
+  debug_nan_scan(B, "after cs_ba_build_system");
+  return CS_OK;
 }
 int cs_ba_build_system(cs_ba* B) {
   BA_GUARD_BEGIN
@@ -1534,6 +1624,7 @@ static int cs_ba_solve_impl(cs_ba* B, double lambda, int* pd) {
   if (B->structure_dirty || !B->have_system) { cs_set_error_ba("cs_ba_solve: call cs_ba_build_system first"); return CS_ERR_NOT_RUN; }
   bool ok = false;
   int rc = solve_device(B, lambda, &ok); if (rc) return rc;
+  if (ok) debug_nan_scan(B, "after cs_ba_solve");
   if (pd) *pd = ok ? 1 : 0;
   return ok ? fetch_x(B) : CS_OK;
 }
@@ -1553,6 +1644,7 @@ int cs_ba_update(cs_ba* B) {
   BA_TRY(hipGetLastError());
   BA_TRY(hipStreamSynchronize(B->st));
   B->tm.update_ms += now_ms() - t0;
+  debug_nan_scan(B, "after cs_ba_update");
   return CS_OK;
   BA_GUARD_END("cs_ba_update")
 }
@@ -1636,6 +1728,17 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
     for (int i = 0; i < 5; i++)
       if (v[i] != q[i] || v[5 + i] != -q[i]) { cs_set_error_ba("sharded BA: the ranks disagree on the solver layout (reduced size / bandwidth / cuboid elimination / separator mode); check CS_BA_* environment variables and devices"); return CS_ERR_INVALID_ARG; }
   }
+  // external (host-evaluated) edges: their terms depend on the state, so the caller's callback re-evaluates them before every
+  // linearisation (want_system = 1: cs_ba_set_external_terms) and after every trial's update (want_system = 0: cs_ba_set_external_chi2)
+  const bool ext_active = B->ext_n > 0 || B->ext_terms_set || B->ext_fn;
+  if (ext_active && !B->ext_fn) { cs_set_error_ba("cs_ba_optimize: the graph has external (host-evaluated) edges but no cs_ba_set_external_callback; drive the stepwise calls instead"); return CS_ERR_NOT_RUN; }
+  auto ext_refresh = [&](int want_system) -> int {
+    if (!ext_active) return CS_OK;
+    BA_TRY(hipStreamSynchronize(B->st));
+    if (B->ext_fn(B->ext_ctx, B, want_system) != 0) { cs_set_error_ba("external-edge callback failed"); return CS_ERR_INVALID_ARG; }
+    if (!B->ext_terms_set) { cs_set_error_ba("external-edge callback did not call cs_ba_set_external_terms"); return CS_ERR_NOT_RUN; }
+    return CS_OK;
+  };
   double lambda = -1, ni = 2;
   int nBad = 0, done = 0;
   double carriedChi = 0;
@@ -1643,6 +1746,7 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
   for (int it = 0; it < iterations; it++) {
     double currentChi = 0;
     double t0 = now_ms();
+    rc = ext_refresh(1); if (rc) return rc;        // (the terms of this iteration's linearisation, and the chi2 share at the current state)
     if (have_carried) {
       // computeActiveErrors + activeRobustChi2 at the top of an iteration (:67-69) would re-evaluate the state the last trial left:
       // the accepted trial's chi2 (same kernels, same state, fixed-shape sums: the same bits), or -- after ten rejections --
@@ -1650,11 +1754,13 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
       currentChi = carriedChi;
     } else {
       rc = chi2_device(B, &currentChi); if (rc) return rc;
+      if (ext_active) currentChi += B->ext_chi2;
       if (reduce_host(&currentChi, 1, 0)) { cs_set_error_ba("all-reduce failed"); return CS_ERR_HIP; }
       B->tm.errors_ms += now_ms() - t0;
     }
     double tempChi = currentChi, iniChi = currentChi;
     rc = build_system_device(B); if (rc) return rc;
+    debug_nan_scan(B, "cs_ba_optimize: after the linearisation");
     if (it == 0) {  // computeLambdaInit (:166-180): tau * max |H_jj| over all non-fixed vertices, landmarks included
       BA_TRY(hipStreamSynchronize(B->st));   // the copies below run on the NULL stream, which B->st does not order with
       std::vector<double> hc(36 * (size_t)B->nc), ho(81 * (size_t)B->no), hl(9 * (size_t)B->np);
@@ -1704,6 +1810,7 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
         rc = collect_solve_times(B); if (rc) return rc;
         float ms = 0;
         BA_TRY(hipEventElapsedTime(&ms, B->ev[6], B->ev[7])); B->tm.errors_ms += ms;
+        if (ext_active && ok2) { rc = ext_refresh(0); if (rc) return rc; tempChi += B->ext_chi2; }
       } else {
         rc = solve_device(B, lambda, &ok2, fn, ctx); if (rc) return rc;
         if (B->shard_n > 1) {   // a failed factorisation on one rank is everybody's rejected trial
@@ -1722,10 +1829,12 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
         }
         t0 = now_ms();
         rc = chi2_device(B, &tempChi); if (rc) return rc;
+        if (ext_active && ok2) { rc = ext_refresh(0); if (rc) return rc; tempChi += B->ext_chi2; }
         if (reduce_host(&tempChi, 1, 0)) { cs_set_error_ba("all-reduce failed"); return CS_ERR_HIP; }
         B->tm.errors_ms += now_ms() - t0;
         if (reduce_host(&scale, 1, 0)) { cs_set_error_ba("all-reduce failed"); return CS_ERR_HIP; }
       }
+      if (ok2) debug_nan_scan(B, "cs_ba_optimize: after a trial's solve + update");
       if (!ok2) tempChi = std::numeric_limits<double>::max();
       rho = currentChi - tempChi;
       scale += 1e-3;
@@ -1883,6 +1992,13 @@ static int cs_ba_get_system_impl(cs_ba* B, double* Hpp, double* Hll9, double* Hp
       if (ca < 0 || cb < 0) continue;
       for (int r = 0; r < 6; r++) for (int q = 0; q < 6; q++) { double val = hij[36 * (size_t)k + 6 * r + q]; Hpp[(size_t)(ca + r) * n + cb + q] += val; Hpp[(size_t)(cb + q) * n + ca + r] += val; }
     }
+    for (int k = 0; k < B->ext_n && B->ext_terms_set; k++) {     // the host-evaluated binary edges' blocks
+      const int ci = B->ext_e4[4 * k], ii = B->ext_e4[4 * k + 1], cj = B->ext_e4[4 * k + 2], ij = B->ext_e4[4 * k + 3];
+      if (ij < 0) continue;
+      const int ca = ci ? B->cub_col_ref[ii] : B->cam_col_ref[ii], cb = cj ? B->cub_col_ref[ij] : B->cam_col_ref[ij], di = ci ? 9 : 6, dj = cj ? 9 : 6;
+      if (ca < 0 || cb < 0) continue;
+      for (int r = 0; r < di; r++) for (int q = 0; q < dj; q++) { const double val = B->h_ext_Hij[81 * (size_t)k + dj * r + q]; Hpp[(size_t)(ca + r) * n + cb + q] += val; Hpp[(size_t)(cb + q) * n + ca + r] += val; }
+    }
   }
   if (Hll9) {
     std::vector<double> hl(9 * (size_t)B->np);
@@ -1957,6 +2073,7 @@ int cs_ba_get_vertex_hessians(cs_ba* B, double* cam36, double* cub81, double* pt
   return CS_OK;
 }
 
+
 int cs_ba_last_timing(cs_ba* B, cs_ba_timing* t) {
   if (!B || !t) return CS_ERR_INVALID_ARG;
   *t = B->tm;
@@ -1969,3 +2086,155 @@ int cs_ba_last_timing(cs_ba* B, cs_ba_timing* t) {
 }
 
 }  // extern "C"
+
+// ---- debug / repro aids --------------------------------------------------------------------------------------------------------------
+// cs_ba_check_finite: the stand-in for the NaN checks of g2o's debug builds (errors: sparse_optimizer.cpp:78-86; Jacobians:
+// block_solver.hpp:533-544) -- see ba_scan_finite_kernel.  CS_BA_DEBUG_NAN=1 runs it after every linearisation, solve and update and
+// prints what it finds to stderr.
+static int check_finite_impl(cs_ba* B, char* report, int report_cap, int* n_bad_out) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  BA_TRY(hipSetDevice(B->device));
+  int rc = finalize_structure(B); if (rc) return rc;
+  const cs::BaView& v = B->view;
+  const int E = v.n_proj, n_edges = E + B->n_cub + B->n_odom;
+  DBuf<double> chi; DBuf<int> out;
+  struct Free { DBuf<double>* a; DBuf<int>* b; ~Free() { a->release(); b->release(); } } guard{&chi, &out};
+  if ((rc = chi.alloc(std::max(1, n_edges), B->st))) return rc;
+  cs::ba_launch_edge_chi(v, chi.p, B->st);
+  struct Arr { const char* name; const double* p; long long n; int per; const char* owner; };
+  std::vector<Arr> arrs = {
+    {"squared error of a projection edge", chi.p, E, 1, "projection edge (caller's index)"},
+    {"squared error of a camera-cuboid edge", chi.p + E, B->n_cub, 1, "camera-cuboid edge (EdgeSE3Cuboid list, then EdgeSE3CuboidProj list)"},
+    {"squared error of an odometry edge", chi.p + E + B->n_cub, B->n_odom, 1, "odometry edge"},
+    {"camera estimates", v.cams, 7LL * B->nc, 7, "camera"}, {"cuboid estimates", v.cubes, 10LL * B->no, 10, "cuboid"}, {"point estimates", v.points, 3LL * B->np, 3, "point"},
+  };
+  if (B->have_system) {
+    const Arr sys[] = {
+      {"A_ii of a camera", v.Hcam, 36LL * B->nc, 36, "camera"}, {"b_i of a camera", v.bcam, 6LL * B->nc, 6, "camera"},
+      {"A_ii of a cuboid", v.Hcub, 81LL * B->no, 81, "cuboid"}, {"b_i of a cuboid", v.bcub, 9LL * B->no, 9, "cuboid"},
+      {"A_jj of a point", v.Hll, 9LL * B->np, 9, "point"}, {"b_j of a point", v.bl, 3LL * B->np, 3, "point"},
+      {"H_pl block of a projection edge (J_cam^T Omega J_point)", v.W, 18LL * E, 18, "projection edge (caller's index)"},
+      {"J^T Omega J block of a camera-cuboid edge", v.ce_Hco, 54LL * B->n_cub, 54, "camera-cuboid edge"},
+      {"J^T Omega J block of an odometry edge", v.oe_Hij, 36LL * B->n_odom, 36, "odometry edge"},
+    };
+    arrs.insert(arrs.end(), std::begin(sys), std::end(sys));
+  }
+  if (B->tm.n_solves > 0) {
+    arrs.push_back({"pose increment x_p (solver order)", v.rhs, B->n_pose, 1, "column"});
+    arrs.push_back({"landmark increment", v.xl, 3LL * B->np, 3, "point"});
+  }
+  std::vector<int> h(2 * arrs.size());
+  for (size_t t = 0; t < arrs.size(); t++) { h[2 * t] = 0; h[2 * t + 1] = 0x7fffffff; }
+  if ((rc = out.upload(h))) return rc;
+  for (size_t t = 0; t < arrs.size(); t++) cs::ba_launch_scan_finite(arrs[t].p, arrs[t].n, out.p + 2 * t, B->st);
+  BA_TRY(hipGetLastError());
+  BA_TRY(hipMemcpyAsync(h.data(), out.p, sizeof(int) * h.size(), hipMemcpyDeviceToHost, B->st));
+  BA_TRY(hipStreamSynchronize(B->st));
+  std::vector<int> slot_to_orig;
+  long long total = 0;
+  std::string rep;
+  for (size_t t = 0; t < arrs.size(); t++) {
+    if (!h[2 * t]) continue;
+    total += h[2 * t];
+    long long owner = (h[2 * t + 1] - 1) / arrs[t].per;
+    if (arrs[t].per == 18 || (arrs[t].per == 1 && t == 0)) {      // projection edges: point-major slot -> the caller's edge index
+      if (slot_to_orig.empty()) { slot_to_orig.assign(std::max(1, E), -1); for (size_t k = 0; k < B->pm_of_orig.size(); k++) if (B->pm_of_orig[k] >= 0) slot_to_orig[B->pm_of_orig[k]] = (int)k; }
+      owner = slot_to_orig[(size_t)owner];
+    }
+    rep += std::string(arrs[t].name) + ": " + std::to_string(h[2 * t]) + " non-finite value(s), first in " + arrs[t].owner + " " + std::to_string(owner) + "\n";
+  }
+  if (report && report_cap > 0) { const size_t n = std::min(rep.size(), (size_t)report_cap - 1); std::memcpy(report, rep.data(), n); report[n] = 0; }
+  if (n_bad_out) *n_bad_out = (int)std::min<long long>(total, 0x7fffffff);
+  return CS_OK;
+}
+int cs_ba_check_finite(cs_ba* B, int* n_bad, char* report, int report_cap) {
+  BA_GUARD_BEGIN
+  return check_finite_impl(B, report, report_cap, n_bad);
+  BA_GUARD_END("cs_ba_check_finite")
+}
+static bool debug_nan_enabled() { static const bool on = [] { const char* e = getenv("CS_BA_DEBUG_NAN"); return e && atoi(e) != 0; }(); return on; }
+static void debug_nan_scan(cs_ba* B, const char* where) {
+  if (!debug_nan_enabled()) return;
+  char rep[2048]; int n = 0;
+  if (check_finite_impl(B, rep, (int)sizeof(rep), &n) == CS_OK && n > 0) fprintf(stderr, "[cs_ba CS_BA_DEBUG_NAN] %s:\n%s", where, rep);
+}
+
+// cs_ba_dump / cs_ba_load: the whole problem description (current estimates included) as one flat binary file, so that a failing field
+// case becomes a fixture -- the stand-in for OptimizableGraph::save / load (core/optimizable_graph.h:594-606), which the reference's own
+// graph cannot use (its vendored g2o registers none of its types with the Factory).  Layout: magic "CSBA0002", 16 int32 counts / flags,
+// then the arrays in the order written below, each raw little-endian.  Shard settings and external edges are not part of it.
+namespace {
+struct DumpHeader { char magic[8]; int v[16]; };
+template <class T> bool wr(FILE* f, const std::vector<T>& a) { return a.empty() || fwrite(a.data(), sizeof(T), a.size(), f) == a.size(); }
+template <class T> bool rd(FILE* f, std::vector<T>& a, size_t n) { a.resize(n); return n == 0 || fread(a.data(), sizeof(T), n, f) == n; }
+}  // namespace
+static int cs_ba_dump_impl(cs_ba* B, const char* path) {
+  if (!B || !path) return CS_ERR_INVALID_ARG;
+  BA_TRY(hipSetDevice(B->device));
+  BA_TRY(hipStreamSynchronize(B->st));
+  const int np_e = B->n_proj, n3 = (int)B->u3_cam.size(), n4 = (int)B->up_cam.size(), n6 = B->n_odom;
+  std::vector<double> cams(7 * (size_t)B->nc), cubs(10 * (size_t)B->no), pts(3 * (size_t)B->np), uv(2 * (size_t)np_e), info(4 * (size_t)np_e), intr(4 * (size_t)np_e), hub(B->have_huber ? np_e : 0);
+  auto d2h = [&](std::vector<double>& h, const double* d) -> int { if (!h.empty()) BA_TRY(hipMemcpy(h.data(), d, 8 * h.size(), hipMemcpyDeviceToHost)); return CS_OK; };
+  int rc;
+  if ((rc = d2h(cams, B->cams.p)) || (rc = d2h(cubs, B->cubes.p)) || (rc = d2h(pts, B->points.p)) || (rc = d2h(uv, B->raw_uv.p)) || (rc = d2h(info, B->raw_info.p)) ||
+      (rc = d2h(intr, B->raw_intr.p)) || (rc = d2h(hub, B->raw_huber.p))) return rc;
+  FILE* f = fopen(path, "wb");
+  if (!f) { cs_set_error_ba(std::string("cs_ba_dump: cannot open ") + path); return CS_ERR_INVALID_ARG; }
+  DumpHeader H{};
+  std::memcpy(H.magic, "CSBA0002", 8);
+  const int counts[16] = {B->nc, B->no, B->np, B->cuboids_first, np_e, B->have_huber ? 1 : 0, (int)B->rk_proj.size(), n3, (int)B->rk_cub3.size(), n4, (int)B->rk_cproj.size(), n6, (int)B->rk_odom.size(), 0, 0, 0};
+  std::memcpy(H.v, counts, sizeof(counts));
+  bool ok = fwrite(&H, sizeof(H), 1, f) == 1;
+  ok = ok && wr(f, cams) && wr(f, B->cam_fixed) && wr(f, cubs) && wr(f, B->cub_fixed) && wr(f, pts) && wr(f, B->pt_fixed);
+  ok = ok && wr(f, B->e_pt) && wr(f, B->e_cam) && wr(f, uv) && wr(f, info) && wr(f, intr) && wr(f, hub) && wr(f, B->rk_proj);
+  ok = ok && wr(f, B->u3_cam) && wr(f, B->u3_cub) && wr(f, B->h_ce_meas) && wr(f, B->h_ce_info) && wr(f, B->rk_cub3) && wr(f, B->rd_cub3);
+  ok = ok && wr(f, B->up_cam) && wr(f, B->up_cub) && wr(f, B->h_pe_meas) && wr(f, B->h_pe_info) && wr(f, B->h_pe_K) && wr(f, B->rk_cproj) && wr(f, B->rd_cproj);
+  ok = ok && wr(f, B->oe_i) && wr(f, B->oe_j) && wr(f, B->h_oe_meas) && wr(f, B->h_oe_info) && wr(f, B->rk_odom) && wr(f, B->rd_odom);
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) { cs_set_error_ba(std::string("cs_ba_dump: write to ") + path + " failed"); return CS_ERR_INVALID_ARG; }
+  return CS_OK;
+}
+int cs_ba_dump(cs_ba* B, const char* path) {
+  BA_GUARD_BEGIN
+  return cs_ba_dump_impl(B, path);
+  BA_GUARD_END("cs_ba_dump")
+}
+static int cs_ba_load_impl(const char* path, int device, cs_ba** out) {
+  if (!path || !out) return CS_ERR_INVALID_ARG;
+  *out = nullptr;
+  FILE* f = fopen(path, "rb");
+  if (!f) { cs_set_error_ba(std::string("cs_ba_load: cannot open ") + path); return CS_ERR_INVALID_ARG; }
+  struct Close { FILE* f; ~Close() { fclose(f); } } cl{f};
+  DumpHeader H;
+  if (fread(&H, sizeof(H), 1, f) != 1 || std::memcmp(H.magic, "CSBA0002", 8) != 0) { cs_set_error_ba("cs_ba_load: not a cs_ba dump (magic CSBA0002)"); return CS_ERR_INVALID_ARG; }
+  for (int i = 0; i < 13; i++) if (H.v[i] < 0) { cs_set_error_ba("cs_ba_load: corrupt header"); return CS_ERR_INVALID_ARG; }
+  const int nc = H.v[0], no = H.v[1], np = H.v[2], cf = H.v[3], npe = H.v[4], hh = H.v[5], nrk = H.v[6], n3 = H.v[7], nrk3 = H.v[8], n4 = H.v[9], nrk4 = H.v[10], n6 = H.v[11], nrk6 = H.v[12];
+  std::vector<double> cams, cubs, pts, uv, info, intr, hub, m10, i81, rd3, m4, i16, k9, rd4, m7, i36, rd6;
+  std::vector<int> camf, cubf, ptf, ept, ecam, rkp, c3, o3, rk3, c4, o4, rk4, oi, oj, rk6;
+  bool ok = rd(f, cams, 7 * (size_t)nc) && rd(f, camf, nc) && rd(f, cubs, 10 * (size_t)no) && rd(f, cubf, no) && rd(f, pts, 3 * (size_t)np) && rd(f, ptf, np);
+  ok = ok && rd(f, ept, npe) && rd(f, ecam, npe) && rd(f, uv, 2 * (size_t)npe) && rd(f, info, 4 * (size_t)npe) && rd(f, intr, 4 * (size_t)npe) && rd(f, hub, hh ? npe : 0) && rd(f, rkp, nrk);
+  ok = ok && rd(f, c3, n3) && rd(f, o3, n3) && rd(f, m10, 10 * (size_t)n3) && rd(f, i81, 81 * (size_t)n3) && rd(f, rk3, nrk3) && rd(f, rd3, nrk3);
+  ok = ok && rd(f, c4, n4) && rd(f, o4, n4) && rd(f, m4, 4 * (size_t)n4) && rd(f, i16, 16 * (size_t)n4) && rd(f, k9, 9 * (size_t)n4) && rd(f, rk4, nrk4) && rd(f, rd4, nrk4);
+  ok = ok && rd(f, oi, n6) && rd(f, oj, n6) && rd(f, m7, 7 * (size_t)n6) && rd(f, i36, 36 * (size_t)n6) && rd(f, rk6, nrk6) && rd(f, rd6, nrk6);
+  if (!ok || (nrk && nrk != npe) || (nrk3 && nrk3 != n3) || (nrk4 && nrk4 != n4) || (nrk6 && nrk6 != n6)) { cs_set_error_ba("cs_ba_load: truncated or inconsistent file"); return CS_ERR_INVALID_ARG; }
+  cs_ba* B = nullptr;
+  int rc = cs_ba_create(device, &B); if (rc) return rc;
+  struct Guard { cs_ba* b; ~Guard() { if (b) cs_ba_destroy(b); } } g{B};
+  if ((rc = cs_ba_set_vertices(B, cams.data(), camf.data(), nc, cubs.data(), cubf.data(), no, pts.data(), ptf.data(), np, cf))) return rc;
+  if (npe && (rc = cs_ba_set_edges_proj(B, npe, ept.data(), ecam.data(), uv.data(), info.data(), intr.data(), hh ? hub.data() : nullptr))) return rc;
+  if (nrk && (rc = cs_ba_set_robust_kernels(B, CS_EDGE_PROJ, npe, rkp.data(), hub.data()))) return rc;
+  if (n3 && (rc = cs_ba_set_edges_cuboid(B, n3, c3.data(), o3.data(), m10.data(), i81.data()))) return rc;
+  if (nrk3 && (rc = cs_ba_set_robust_kernels(B, CS_EDGE_CUBOID, n3, rk3.data(), rd3.data()))) return rc;
+  if (n4 && (rc = cs_ba_set_edges_cuboid_proj(B, n4, c4.data(), o4.data(), m4.data(), i16.data(), k9.data()))) return rc;
+  if (nrk4 && (rc = cs_ba_set_robust_kernels(B, CS_EDGE_CUBOID_PROJ, n4, rk4.data(), rd4.data()))) return rc;
+  if (n6 && (rc = cs_ba_set_edges_odom(B, n6, oi.data(), oj.data(), m7.data(), i36.data()))) return rc;
+  if (nrk6 && (rc = cs_ba_set_robust_kernels(B, CS_EDGE_ODOM, n6, rk6.data(), rd6.data()))) return rc;
+  *out = B;
+  g.b = nullptr;
+  return CS_OK;
+}
+int cs_ba_load(const char* path, int device, cs_ba** out) {
+  BA_GUARD_BEGIN
+  return cs_ba_load_impl(path, device, out);
+  BA_GUARD_END("cs_ba_load")
+}

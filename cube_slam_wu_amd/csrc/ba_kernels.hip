@@ -2341,6 +2341,108 @@ void ba_launch_reduce(const BaView& v, double lambda, hipStream_t st, hipStream_
   if (v.n_cub + v.n_odom > 0) hipLaunchKernelGGL(ba_offdiag_kernel, dim3(v.n_cub + v.n_odom), dim3(64), 0, st, v);
   if (v.n_pairs > 0) hipLaunchKernelGGL(ba_schur_kernel, dim3((v.n_pairs + 1) / 2), dim3(128), 0, st, v);
 }
+// ---- debug: NaN / Inf scan (cs_ba_check_finite, CS_BA_DEBUG_NAN) -------------------------------------------------------------------
+// g2o's debug builds look for NaNs where they are born: in the errors (SparseOptimizer::computeActiveErrors, sparse_optimizer.cpp:78-86)
+// and in the Jacobians of every edge (BlockSolver::buildSystem, block_solver.hpp:533-544).  Here the errors and Jacobians never reach
+// memory, so the scan covers what they turn into -- the edges' squared errors, every block of the linear system, the increments and
+// the estimates -- and names the first offending entry of each array.  out[2 t] = number of non-finite entries of array t,
+// out[2 t + 1] = smallest offending index + 1.
+__global__ __launch_bounds__(256) void ba_scan_finite_kernel(const double* p, long long n, int* out) {
+  int bad = 0;
+  long long first = -1;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const double x = p[i];
+    if (!(x - x == 0.0)) { bad++; if (first < 0) first = i; }     // NaN and +-Inf
+  }
+  if (bad) { atomicAdd(out, bad); atomicMin((unsigned*)(out + 1), (unsigned)min(first + 1, 0x7ffffffeLL)); }
+}
+void ba_launch_scan_finite(const double* p, long long n, int* out, hipStream_t st) {
+  if (n <= 0 || !p) return;
+  const long long nb = (n + 255) / 256;
+  hipLaunchKernelGGL(ba_scan_finite_kernel, dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, st, p, n, out);
+}
+// the edges' (un-robustified) squared errors e^T Omega e, one double per edge: projection edges (point-major order), then the
+// camera-cuboid and the odometry edges -- what a NaN in an error vector turns into
+__global__ __launch_bounds__(256) void ba_edge_chi_kernel(BaView v, double* out) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < v.n_proj) {
+    Pose T = pose_load(v.cams + 7 * v.pm_cam[k]);
+    double e[2], pc[3];
+    proj_error(T, v.points + 3 * v.pm_pt[k], v.pm_uv + 2 * k, v.pm_intr + 4 * k, e, pc);
+    const double* info = v.pm_info + 4 * k;
+    out[k] = e[0] * (info[0] * e[0] + info[1] * e[1]) + e[1] * (info[2] * e[0] + info[3] * e[1]);
+    return;
+  }
+  const int q = k - v.n_proj;
+  if (q < v.n_cub3) {
+    double e[9];
+    cuboid_edge_error(pose_load(v.cams + 7 * v.ce_cam[q]), cube_load(v.cubes + 10 * v.ce_cub[q]), cube_load(v.ce_meas + 10 * q), e);
+    out[k] = quad_form(e, v.ce_info + 81 * q, 9);
+  } else if (q < v.n_cub) {
+    const int r = q - v.n_cub3;
+    double e[4];
+    cuboid_proj_error(pose_load(v.cams + 7 * v.ce_cam[q]), cube_load(v.cubes + 10 * v.ce_cub[q]), v.pe_K + 9 * (size_t)r, v.pe_meas + 4 * (size_t)r, e);
+    out[k] = quad_form(e, v.pe_info + 16 * (size_t)r, 4);
+  } else if (q < v.n_cub + v.n_odom) {
+    const int r = q - v.n_cub;
+    double e[6];
+    odom_edge_error(pose_load(v.cams + 7 * v.oe_i[r]), pose_load(v.cams + 7 * v.oe_j[r]), pose_load(v.oe_meas + 7 * r), e);
+    out[k] = quad_form(e, v.oe_info + 36 * r, 6);
+  }
+}
+void ba_launch_edge_chi(const BaView& v, double* out, hipStream_t st) {
+  const int n = v.n_proj + v.n_cub + v.n_odom;
+  if (n > 0) hipLaunchKernelGGL(ba_edge_chi_kernel, dim3((n + 255) / 256), dim3(256), 0, st, v, out);
+}
+
+// ---- external (host-evaluated) edges: cs_ba_set_external_edges / cs_ba_set_external_terms ---------------------------------------
+// Edges of types the library does not evaluate go through their own linearizeOplus + constructQuadraticForm on the host
+// (core/base_binary_edge.hpp:54-205, core/base_unary_edge.hpp:42-123); what those accumulate -- A_ii / b_i of the vertices, the
+// off-diagonal block of a binary edge -- is added here to the blocks the device built from its own edges.
+__global__ __launch_bounds__(256) void ba_ext_add_kernel(BaView v, const double* cam36, const double* cam6, const double* cub81, const double* cub9, const double* pt9, const double* pt3) {
+  const long long nCam = (long long)v.nc * 42, nCub = (long long)v.no * 90, nPt = (long long)v.np * 12;
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t < nCam) {
+    const int c = (int)(t / 42), e = (int)(t % 42);
+    if (!cam36 || v.cam_col[c] < 0) return;
+    if (e < 36) v.Hcam[36 * (size_t)c + e] += cam36[36 * (size_t)c + e]; else v.bcam[6 * (size_t)c + e - 36] += cam6[6 * (size_t)c + e - 36];
+    return;
+  }
+  t -= nCam;
+  if (t < nCub) {
+    const int o = (int)(t / 90), e = (int)(t % 90);
+    if (!cub81 || v.cub_col[o] < 0) return;
+    if (e < 81) v.Hcub[81 * (size_t)o + e] += cub81[81 * (size_t)o + e]; else v.bcub[9 * (size_t)o + e - 81] += cub9[9 * (size_t)o + e - 81];
+    return;
+  }
+  t -= nCub;
+  if (t < nPt) {
+    const int p = (int)(t / 12), e = (int)(t % 12);
+    if (!pt9 || !v.pt_free[p]) return;
+    if (e < 9) v.Hll[9 * (size_t)p + e] += pt9[9 * (size_t)p + e]; else v.bl[3 * (size_t)p + e - 9] += pt3[3 * (size_t)p + e - 9];
+  }
+}
+// e4: (class_i, idx_i, class_j, idx_j) per edge, class 0 = camera (6), 1 = cuboid (9); Hij: 81 per edge, row-major dim_i x dim_j.
+// A binary edge between two free pose vertices adds its block to the reduced system like an odometry edge's (ba_offdiag_kernel).
+__global__ __launch_bounds__(128) void ba_ext_offdiag_kernel(BaView v, int n, const int* e4, const double* Hij) {
+  const int k = blockIdx.x, t = threadIdx.x;
+  if (k >= n) return;
+  const int ci = e4[4 * k], ii = e4[4 * k + 1], cj = e4[4 * k + 2], ij = e4[4 * k + 3];
+  if (ij < 0 || ci > 1 || cj > 1) return;                 // unary edge: diagonal terms only
+  const int ca = ci ? v.cub_col[ii] : v.cam_col[ii], cb = cj ? v.cub_col[ij] : v.cam_col[ij];
+  const int di = ci ? 9 : 6, dj = cj ? 9 : 6;
+  if (ca < 0 || cb < 0 || ca >= v.n_red || cb >= v.n_red || t >= di * dj) return;
+  const int i = t / dj, j = t % dj;
+  const double val = Hij[81 * (size_t)k + t];
+  if (cb > ca) atomicAdd(ba_S_at(v, cb + j, ca + i), val); else atomicAdd(ba_S_at(v, ca + i, cb + j), val);
+}
+void ba_launch_ext_add(const BaView& v, const double* cam36, const double* cam6, const double* cub81, const double* cub9, const double* pt9, const double* pt3, hipStream_t st) {
+  const long long total = (long long)v.nc * 42 + (long long)v.no * 90 + (long long)v.np * 12;
+  if (total > 0) hipLaunchKernelGGL(ba_ext_add_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, v, cam36, cam6, cub81, cub9, pt9, pt3);
+}
+void ba_launch_ext_offdiag(const BaView& v, int n, const int* e4, const double* Hij, hipStream_t st) {
+  if (n > 0) hipLaunchKernelGGL(ba_ext_offdiag_kernel, dim3(n), dim3(128), 0, st, v, n, e4, Hij);
+}
 int ba_scale_blocks() { return SCALE_BLOCKS; }
 // out[0] = sum of a[0 .. na), out[1] = sum of b[0 .. nb): fixed-shape tree (one workgroup), so the value does not depend on
 // scheduling; lets chi2 and the LM scale term stay on the device until the one read-back (and RCCL all-reduce) of a trial

@@ -280,6 +280,34 @@ enum cs_robust_kernel { CS_RK_NONE = 0, CS_RK_HUBER = 1, CS_RK_PSEUDO_HUBER = 2,
 enum cs_edge_class { CS_EDGE_PROJ = 0, CS_EDGE_CUBOID = 1, CS_EDGE_CUBOID_PROJ = 2, CS_EDGE_ODOM = 3 };
 int cs_ba_set_robust_kernels(cs_ba* ba, int edge_class, int n, const int* kind, const double* delta);
 
+/* External (host-evaluated) edges: the CPU path for edge types the library does not evaluate -- what g2o's BlockSolver does for
+ * EVERY edge, kept for the ones that have no kernel here.  The caller runs such an edge through its own virtuals (computeError,
+ * linearizeOplus(JacobianWorkspace&), constructQuadraticForm: core/optimizable_graph.h:394-454; the numeric default of linearizeOplus:
+ * core/base_binary_edge.hpp:130-205, core/base_unary_edge.hpp:82-123; the quadratic form incl. robust kernel: base_binary_edge.hpp:54-120,
+ * base_unary_edge.hpp:42-72) and hands over what those accumulate (cube_slam_wu_amd/adapters/block_solver_hip.h does exactly this):
+ *   cs_ba_set_external_edges   the coupling pattern (structure: ordering, bandwidth).  Edge k joins vertex (class_i[k], idx_i[k]) and
+ *                              (class_j[k], idx_j[k]); idx_j[k] < 0 = unary.  A binary edge may join cameras and cuboids; a (marginalised)
+ *                              point takes unary terms only.  Indices are the caller's per-class vertex indices.
+ *   cs_ba_set_external_terms   the terms at the CURRENT estimates, to be refreshed before every cs_ba_build_system(): per vertex the sum
+ *                              over its external edges of A_ii (cam36: n_cams x 36, cub81, pt9; row-major, symmetric) and b_i (cam6,
+ *                              cub9, pt3); a NULL pair = the class has none.  Hij81: n x 81, the off-diagonal block A_i^T Omega A_j of
+ *                              binary edge k, row-major dim_i x dim_j in the first dim_i * dim_j entries.  chi2: the edges' summed
+ *                              (robustified) chi2, which cs_ba_compute_errors() adds to the device edges'.  Terms of fixed vertices are ignored.
+ *   cs_ba_set_external_chi2    the chi2 share alone (after an update, when only the error is needed).
+ *   cs_ba_set_external_callback  for cs_ba_optimize(), whose LM loop runs inside the library: fn(ctx, ba, want_system) is called before
+ *                              every linearisation (want_system = 1: read the state with cs_ba_get_state, call cs_ba_set_external_terms)
+ *                              and after every trial's update (want_system = 0: call cs_ba_set_external_chi2 ONLY -- a rejected trial
+ *                              re-solves the system built before it); it returns 0 on success.  Each call is a host round trip of the
+ *                              state: a fallback for a handful of unusual edges, not a fast path.
+ * Not available on a sharded handle.  A binary external edge on a cuboid keeps the cuboids in the reduced system (cs_ba_reduced_size). */
+enum cs_vertex_class { CS_VERTEX_CAM = 0, CS_VERTEX_CUBOID = 1, CS_VERTEX_POINT = 2 };
+typedef int (*cs_external_fn)(void* ctx, cs_ba* ba, int want_system);
+int cs_ba_set_external_edges(cs_ba* ba, int n, const int* class_i, const int* idx_i, const int* class_j, const int* idx_j);
+int cs_ba_set_external_terms(cs_ba* ba, const double* cam36, const double* cam6, const double* cub81, const double* cub9, const double* pt9, const double* pt3,
+                             const double* Hij81, double chi2);
+int cs_ba_set_external_chi2(cs_ba* ba, double chi2);
+int cs_ba_set_external_callback(cs_ba* ba, cs_external_fn fn, void* ctx);
+
 /* The g2o::Solver / SparseOptimizer steps, one call each (all state stays in HBM):                   */
 int cs_ba_compute_errors(cs_ba* ba, double* robust_chi2);   /* computeActiveErrors + activeRobustChi2 */
 int cs_ba_build_system(cs_ba* ba);                           /* Solver::buildSystem (needs current errors) */
@@ -383,6 +411,21 @@ typedef struct cs_ba_timing {
   long long schur_entries;          /* sum over landmarks of k_j (k_j + 1) / 2                           */
 } cs_ba_timing;
 int cs_ba_last_timing(cs_ba* ba, cs_ba_timing* t);
+
+/* Debug / repro aids (what g2o offers through its debug builds and its text IO).
+ * cs_ba_check_finite: scans for NaN / Inf where g2o's debug builds look for them -- the edges' errors (SparseOptimizer::
+ * computeActiveErrors, core/sparse_optimizer.cpp:78-86) and Jacobians (BlockSolver::buildSystem, core/block_solver.hpp:533-544) --
+ * through what they turn into on the device: every edge's squared error, every block of the linear system (after cs_ba_build_system),
+ * the increments (after a solve) and the estimates.  *n_bad = number of non-finite values (0 = clean); report (may be NULL) receives one
+ * line per offending array naming the first offending vertex / edge in the caller's indices.  With CS_BA_DEBUG_NAN=1 in the
+ * environment the library runs the scan itself after every linearisation, solve and update and prints the report to stderr.
+ * cs_ba_dump / cs_ba_load: the complete problem (vertices with their CURRENT estimates and fixed flags, all four edge lists, robust
+ * kernels) as one flat binary file, so that a failing field case becomes a fixture -- the stand-in for OptimizableGraph::save / load
+ * (core/optimizable_graph.h:594-606), which the reference's own graph cannot use (no type of it is registered with g2o's Factory).
+ * Shard settings and external edges are not stored.                                                                               */
+int cs_ba_check_finite(cs_ba* ba, int* n_bad, char* report, int report_cap);
+int cs_ba_dump(cs_ba* ba, const char* path);
+int cs_ba_load(const char* path, int device, cs_ba** out);
 
 #ifdef __cplusplus
 }

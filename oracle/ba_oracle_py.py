@@ -62,7 +62,14 @@ class Problem:
         cf = _i(cam_fixed); of = _i(cub_fixed if cub_fixed is not None else np.zeros(self.no)); pf = _i(pt_fixed if pt_fixed is not None else np.zeros(self.np_))
         L.ba_oracle_set_vertices(self.h, _dp(self.cams), _ip(cf), self.nc, _dp(self.cuboids), _ip(of), self.no, _dp(self.points), _ip(pf), self.np_,
                                  int(cuboids_first), int(marginalize_points))
+        self._fixed, self._flags = (cf, of, pf), (int(cuboids_first), int(marginalize_points))
         self.n_proj = self.n_cub = self.n_odom = 0
+
+    def set_estimates(self, cams, cuboids, points):
+        """New estimates for the same graph (the edges stay)."""
+        self.cams, self.cuboids, self.points = _f(cams, (-1, 7)), _f(cuboids, (-1, 10)), _f(points, (-1, 3))
+        cf, of, pf = self._fixed
+        lib().ba_oracle_set_vertices(self.h, _dp(self.cams), _ip(cf), self.nc, _dp(self.cuboids), _ip(of), self.no, _dp(self.points), _ip(pf), self.np_, *self._flags)
 
     def set_edges_proj(self, pt, cam, uv, info4, intr4, huber=None):
         pt, cam = _i(pt), _i(cam); self.n_proj = len(pt)

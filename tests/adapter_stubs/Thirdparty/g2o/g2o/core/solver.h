@@ -12,24 +12,50 @@
 namespace g2o {
 using Eigen::MatrixXd;
 class RobustKernel;
-class HyperGraph {
+class HyperGraph {      // core/hyper_graph.h:93-140
  public:
   class Vertex { public: virtual ~Vertex(); int id() const; };
-  class Edge { public: virtual ~Edge(); Vertex* vertex(size_t i); const Vertex* vertex(size_t i) const; };
+  typedef std::vector<Vertex*> VertexContainer;
+  class Edge {
+   public:
+    virtual ~Edge();
+    const VertexContainer& vertices() const;
+    Vertex* vertex(size_t i);
+    const Vertex* vertex(size_t i) const;
+  };
   typedef std::set<Edge*> EdgeSet;
 };
-class OptimizableGraph : public HyperGraph {
+class JacobianWorkspace {   // core/jacobian_workspace.h:49-96
+ public:
+  bool allocate();
+  void updateSize(const HyperGraph::Edge* e);
+  double* workspaceForVertex(int vertexIndex);
+};
+class OptimizableGraph : public HyperGraph {   // core/optimizable_graph.h:127-525, 659
  public:
   class Vertex : public HyperGraph::Vertex {
    public:
     bool fixed() const;
+    bool marginalized() const;
     int dimension() const;
+    int hessianIndex() const;
+    int colInHessian() const;
     virtual void mapHessianMemory(double* d) = 0;
+    virtual const double& b(int i) const = 0;
+    virtual double& b(int i) = 0;
+    virtual void clearQuadraticForm() = 0;
   };
   class Edge : public HyperGraph::Edge {
    public:
     RobustKernel* robustKernel() const;
+    int dimension() const;
+    virtual void computeError() = 0;
+    virtual double chi2() const = 0;
+    virtual void constructQuadraticForm() = 0;
+    virtual void mapHessianMemory(double* d, int i, int j, bool rowMajor) = 0;
+    virtual void linearizeOplus(JacobianWorkspace& jacobianWorkspace) = 0;
   };
+  JacobianWorkspace& jacobianWorkspace();
 };
 template <class M> class SparseBlockMatrix;
 class SparseOptimizer;

@@ -13,12 +13,20 @@ class BaseVertex : public OptimizableGraph::Vertex {
  public:
   const T& estimate() const;
   virtual void mapHessianMemory(double* d);
+  virtual const double& b(int i) const;
+  virtual double& b(int i);
+  virtual void clearQuadraticForm();
 };
 template <int D, class E, class VertexXi, class VertexXj>
 class BaseBinaryEdge : public OptimizableGraph::Edge {
  public:
   const E& measurement() const;
   const Eigen::Matrix<double, D, D>& information() const;
+  virtual void computeError();
+  virtual double chi2() const;
+  virtual void constructQuadraticForm();
+  virtual void mapHessianMemory(double* d, int i, int j, bool rowMajor);
+  virtual void linearizeOplus(JacobianWorkspace& jacobianWorkspace);
 };
 class VertexSE3Expmap : public BaseVertex<6, SE3Quat> {};
 class VertexSBAPointXYZ : public BaseVertex<3, Vector3d> {};

@@ -103,6 +103,153 @@ def test_robust_kernels_huber_width_is_single_precision():
     G.close(); G0.close()
 
 
+def _odom_terms_on_the_host(pr, cams, cuboids, points):
+    """The odometry edges' quadratic-form terms at the given estimates, evaluated on the host (the restated numeric linearizeOplus +
+    constructQuadraticForm, base_binary_edge.hpp:54-205): what an application would obtain from the edges' own virtuals."""
+    nc, no = len(pr["cams"]), len(pr["cuboids"])
+    R = O.Problem(cams, pr["cam_fixed"], cuboids, pr["cub_fixed"], points[:0], np.zeros(0, np.int32))
+    R.set_edges_odom(pr["oe_i"], pr["oe_j"], pr["oe_meas"], pr["oe_info"])
+    chi = R.compute_errors()[0]
+    Hpp, _, _, b = R.build_system()
+    col = np.full(nc, -1); c = 0
+    for i in range(nc):
+        if not pr["cam_fixed"][i]:
+            col[i] = c; c += 6
+    cam36, cam6 = np.zeros((nc, 36)), np.zeros((nc, 6))
+    for i in range(nc):
+        if col[i] >= 0:
+            cam36[i] = Hpp[col[i]:col[i] + 6, col[i]:col[i] + 6].ravel(); cam6[i] = b[col[i]:col[i] + 6]
+    Hij = np.zeros((len(pr["oe_i"]), 81))
+    for k, (i, j) in enumerate(zip(pr["oe_i"], pr["oe_j"])):
+        if col[i] >= 0 and col[j] >= 0:
+            Hij[k, :36] = Hpp[col[i]:col[i] + 6, col[j]:col[j] + 6].ravel()
+    R.close()
+    return cam36, cam6, Hij, chi
+
+
+def test_external_edges_equal_the_same_edges_evaluated_on_the_device():
+    """The CPU path for edge types the library does not evaluate (cs_ba_set_external_edges / _terms / _callback): the odometry edges
+    of a graph are taken away from the device and handed in as external pose-pose edges whose terms the host evaluates -- chi2, the
+    linear system, a damped solve and a whole LM run must equal the all-device graph's.  Plus unary terms on a point and a cuboid."""
+    pr = synth_ba.make_problem(n_cams=40, n_points=2000, n_cuboids=6, seed=9)
+    G = capi.ba_from_dict(pr)
+    pr_x = dict(pr); pr_x["oe_i"] = pr["oe_i"][:0]; pr_x["oe_j"] = pr["oe_j"][:0]; pr_x["oe_meas"] = pr["oe_meas"][:0]; pr_x["oe_info"] = pr["oe_info"][:0]
+    X = capi.ba_from_dict(pr_x)
+    n_e = len(pr["oe_i"])
+    X.set_external_edges(np.zeros(n_e), pr["oe_i"], np.zeros(n_e), pr["oe_j"])
+
+    def refresh(want_system):
+        cams, cubs, pts = X.state()
+        cam36, cam6, Hij, chi = _odom_terms_on_the_host(pr, cams, cubs, pts)
+        if want_system:
+            X.set_external_terms(cam36=cam36, cam6=cam6, Hij81=Hij, chi2=chi)
+        else:
+            X.set_external_chi2(chi)
+    refresh(1)
+    chi_g = G.compute_errors()
+    assert abs(X.compute_errors() - chi_g) < 1e-12 * chi_g
+    sys_g, sys_x = G.build_system(), X.build_system()
+    for a, b in zip(sys_g, sys_x):
+        assert _rel(b, a) < 1e-12
+    assert G.solver_layout() == X.solver_layout()       # the external edges took part in the ordering: same band
+    (ok_g, x_g), (ok_x, x_x) = G.solve(2.0), X.solve(2.0)
+    assert ok_g and ok_x and _rel(x_x, x_g) < 1e-9
+    # without a callback the library's own LM loop cannot re-evaluate them
+    with pytest.raises(RuntimeError, match="callback"):
+        X.optimize(2)
+    X.set_external_callback(refresh)
+    n_g, n_x = G.optimize(6), X.optimize(6)
+    assert n_g == n_x and np.array_equal(G.history()[2], X.history()[2]) and np.allclose(G.history()[0], X.history()[0], rtol=1e-9)
+    scale = np.abs(G.state()[2]).max()
+    for a, b in zip(G.state(), X.state()):
+        assert np.abs(a - b).max() < 1e-8 * scale
+    # unary terms: a prior w |x - x0|^2 on every point and a 9 x 9 block on every cuboid land in A_ii / b_i of the free vertices only
+    Y = capi.ba_from_dict(pr)
+    base = Y.build_system()
+    hc0, ho0, hp0 = [h.copy() for h in Y.vertex_hessians()]
+    w = 3.0
+    npt, no = len(pr["points"]), len(pr["cuboids"])
+    pt9 = np.tile((w * np.eye(3)).ravel(), (npt, 1)); pt3 = np.full((npt, 3), -0.25)
+    M = np.arange(81, dtype=float).reshape(9, 9); M = M + M.T
+    cub81 = np.tile(M.ravel(), (no, 1)); cub9 = np.full((no, 9), 0.5)
+    Y.set_external_terms(cub81=cub81, cub9=cub9, pt9=pt9, pt3=pt3, chi2=7.0)
+    assert abs(Y.compute_errors() - (chi_g + 7.0)) < 1e-12 * chi_g
+    ext = Y.build_system()
+    hc1, ho1, hp1 = Y.vertex_hessians()
+    free_p = np.asarray(pr["pt_fixed"]) == 0
+    assert np.allclose(hp1[free_p] - hp0[free_p], w * np.eye(3), atol=1e-9) and np.array_equal(hp1[~free_p], hp0[~free_p])
+    free_o = np.asarray(pr["cub_fixed"]) == 0
+    assert np.allclose(ho1[free_o] - ho0[free_o], M, rtol=0, atol=1e-6 * np.abs(ho0).max()) and np.array_equal(hc1, hc0)
+    assert np.allclose((ext[3] - base[3])[-3 * free_p.sum():], -0.25, atol=1e-9)
+    G.close(); X.close(); Y.close()
+
+
+def test_external_edges_are_validated():
+    pr = synth_ba.make_problem(n_cams=12, n_points=300, n_cuboids=2, seed=2)
+    G = capi.ba_from_dict(pr)
+    G.set_external_edges([0], [1], [2], [5])                 # camera - point: would change the Schur structure
+    with pytest.raises(RuntimeError, match="cameras and cuboids only"):
+        G.sizes()
+    G.set_external_edges([0], [1], [0], [99])
+    with pytest.raises(RuntimeError, match="out of range"):
+        G.sizes()
+    G.set_external_edges([0], [1], [1], [0])                 # camera - cuboid: the cuboids stay in the reduced system
+    G.sizes()
+    assert G.reduced_size()[1] is False
+    G.set_shard(0, 2)
+    with pytest.raises(RuntimeError, match="sharded"):
+        G.sizes()
+    G.close()
+
+
+def test_check_finite_names_where_a_nan_was_born():
+    """cs_ba_check_finite (the stand-in for the NaN checks of g2o's debug builds, sparse_optimizer.cpp:78-86 / block_solver.hpp:533-544):
+    clean on a healthy problem; a poisoned point estimate is reported through the estimate itself, the squared error of an edge that sees
+    it, and -- after the linearisation -- the blocks it contaminates, with the caller's indices."""
+    pr = synth_ba.make_problem(n_cams=20, n_points=600, n_cuboids=3, seed=4)
+    G = capi.ba_from_dict(pr)
+    G.build_system()
+    G.solve(1.0)
+    n, rep = G.check_finite()
+    assert n == 0 and rep == ""
+    cams, cubs, pts = G.state()
+    victim = int(np.asarray(pr["e_pt"])[137])
+    pts[victim, 1] = np.nan
+    G.set_estimates(points=pts)
+    n, rep = G.check_finite()
+    assert n > 0 and "point estimates" in rep and "first in point %d" % victim in rep
+    line = [l for l in rep.splitlines() if l.startswith("squared error of a projection edge")][0]
+    edge = int(line.rsplit(" ", 1)[1])
+    assert np.asarray(pr["e_pt"])[edge] == victim
+    G.build_system()
+    n2, rep2 = G.check_finite()
+    assert n2 > n and "A_jj of a point" in rep2 and "A_ii of a camera" in rep2 and "H_pl block" in rep2
+    G.close()
+
+
+def test_dump_and_load_round_trip(tmp_path):
+    """cs_ba_dump / cs_ba_load: a problem in mid-optimisation (estimates that only exist on the device, all four edge classes, robust
+    kernels) written to one flat file and read back into a fresh handle continues bit-identically."""
+    pr = _with_kernels(synth_ba.make_problem(n_cams=30, n_points=1200, n_cuboids=5, seed=8, bbox_edges=True), 3, kinds=(0, 1, 3, 5))
+    G = capi.ba_from_dict(pr)
+    G.optimize(2)
+    path = tmp_path / "problem.csba"
+    G.dump(path)
+    L = capi.BaProblem.load(path, (len(pr["cams"]), len(pr["cuboids"]), len(pr["points"]), len(pr["e_pt"])))
+    for a, b in zip(G.state(), L.state()):
+        assert np.array_equal(a, b)
+    assert G.optimize(3) == L.optimize(3)
+    for a, b in zip(G.history(), L.history()):
+        assert np.array_equal(a, b)
+    for a, b in zip(G.state(), L.state()):
+        assert np.array_equal(a, b)
+    with open(path, "r+b") as f:
+        f.truncate(os.path.getsize(path) - 100)
+    with pytest.raises(RuntimeError, match="truncated"):
+        capi.BaProblem.load(path, (1, 1, 1, 1))
+    G.close(); L.close()
+
+
 def test_robust_kernel_arguments_are_checked():
     pr = synth_ba.make_problem(n_cams=12, n_points=300, n_cuboids=2, seed=2)
     G = capi.ba_from_dict(pr)
