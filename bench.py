@@ -480,6 +480,20 @@ def main():
                 sampled = args.ba == "C4"
                 if sampled:
                     R.set_ldlt_stride(256)
+                # parity at this size, printed instead of thrown away: one linearisation of a fresh handle at the initial estimates against
+                # the oracle (oracle/ba_parity.py: chi2, b, H_ll, H_pl, every block of the damped reduced system, one damped solve with the
+                # oracle's S factorised by LAPACK) -- the same comparison tests/test_ba_gpu.py asserts on
+                try:
+                    from oracle import ba_parity
+                    G0 = capi.ba_from_dict(pr, device=local_rank)
+                    t_par = time.perf_counter()
+                    par = ba_parity.compare_linearisation(G0, R, pr, 50.0)
+                    par["seconds"] = time.perf_counter() - t_par
+                    par["what"] = "max relative difference device vs oracle/ba_oracle.cpp, one linearisation + one damped solve (lambda = 50) of this problem at its initial estimates"
+                    ba_out["parity_vs_oracle"] = par
+                    G0.close()
+                except Exception as ex:       # (a missing scipy or an out-of-memory host must not take the bench line with it)
+                    ba_out["parity_vs_oracle"] = {"error": repr(ex)}
                 tc = time.perf_counter()
                 n_cpu = R.optimize(1 if sampled else args.ba_iters)
                 cpu_wall = time.perf_counter() - tc

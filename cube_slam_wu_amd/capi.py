@@ -394,7 +394,7 @@ DECLARED_SYMBOLS += [
     "cs_ba_compute_errors", "cs_ba_build_system", "cs_ba_solve", "cs_ba_update", "cs_ba_push", "cs_ba_pop", "cs_ba_optimize",
     "cs_ba_get_state", "cs_ba_sizes", "cs_ba_solver_layout", "cs_ba_get_system", "cs_ba_last_timing", "cs_ba_set_shard", "cs_ba_optimize_sharded",
     "cs_ba_shard_landmark_owners", "cs_ba_get_landmark_owners", "cs_ba_shard_info", "cs_ba_shard_timing", "cs_ba_append_vertices", "cs_ba_append_edges_proj", "cs_ba_append_edges_cuboid", "cs_ba_append_edges_cuboid_proj", "cs_ba_append_edges_odom", "cs_ba_get_vertex_hessians", "cs_ba_schur_layout", "cs_ba_reduced_size", "cs_ba_comm_unique_id", "cs_ba_comm_init", "cs_ba_set_robust_kernels",
-    "cs_ba_set_external_edges", "cs_ba_set_external_terms", "cs_ba_set_external_chi2", "cs_ba_set_external_callback", "cs_ba_check_finite", "cs_ba_dump", "cs_ba_load",
+    "cs_ba_set_external_edges", "cs_ba_set_external_terms", "cs_ba_set_external_chi2", "cs_ba_set_external_callback", "cs_ba_check_finite", "cs_ba_dump", "cs_ba_load", "cs_ba_get_reduced_system",
 ]
 
 
@@ -519,12 +519,19 @@ class BaProblem:
         _chk(lib().cs_ba_sizes(self.h, C.byref(a), C.byref(b)), "cs_ba_sizes")
         return a.value, b.value
 
-    def build_system(self):
+    def build_system(self, dense_hpp=True):
         _chk(lib().cs_ba_build_system(self.h), "cs_ba_build_system")
         n, nl = self.sizes()
-        Hpp, Hll, Hpl, b = np.zeros((n, n)), np.zeros((nl // 3, 9)), np.zeros((self.n_proj, 18)), np.zeros(n + nl)
-        _chk(lib().cs_ba_get_system(self.h, _dp(Hpp), _dp(Hll), _dp(Hpl), _dp(b), None), "cs_ba_get_system")
+        Hpp, Hll, Hpl, b = (np.zeros((n, n)) if dense_hpp else None), np.zeros((nl // 3, 9)), np.zeros((self.n_proj, 18)), np.zeros(n + nl)
+        _chk(lib().cs_ba_get_system(self.h, _dp(Hpp) if dense_hpp else None, _dp(Hll), _dp(Hpl), _dp(b), None), "cs_ba_get_system")
         return Hpp, Hll, Hpl, b
+
+    def reduced_system(self, lam):
+        """(S dense n_red x n_red, rhs, camera columns, cuboid columns) in solver order -- cs_ba_get_reduced_system."""
+        n = self.reduced_size()[0]
+        S, rhs, cc, oc = np.zeros((n, n)), np.zeros(n), np.zeros(max(1, self.nc), np.int32), np.zeros(max(1, self.no), np.int32)
+        _chk(lib().cs_ba_get_reduced_system(self.h, C.c_double(lam), _dp(S), _dp(rhs), _ip(cc), _ip(oc)), "cs_ba_get_reduced_system")
+        return S, rhs, cc[:self.nc], oc[:self.no]
 
     def vertex_hessians(self):
         """A_ii of every vertex (what g2o maps into BaseVertex::_hessian): (nc, 6, 6), (no, 9, 9), (np, 3, 3)."""

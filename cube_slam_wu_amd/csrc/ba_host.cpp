@@ -2028,6 +2028,45 @@ int cs_ba_get_system(cs_ba* B, double* Hpp, double* Hll9, double* Hpl18, double*
   BA_GUARD_END("cs_ba_get_system")
 }
 
+// Inspection for parity tests: the damped reduced system exactly as the solver is about to factorise it -- dense symmetric n_red x n_red
+// (n_red = cs_ba_reduced_size), its right-hand side, and the column of every camera / cuboid in it (solver order = reverse
+// Cuthill-McKee; -1: fixed; a cuboid column >= n_red: the cuboid was eliminated and is not part of S).  Runs the Schur-complement build
+// (block_solver.hpp:373-439) at `lambda` on the current linearisation; no factorisation.
+static int cs_ba_get_reduced_system_impl(cs_ba* B, double lambda, double* S_dense, double* rhs, int* cam_col, int* cub_col) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  if (B->structure_dirty || !B->have_system) { cs_set_error_ba("cs_ba_get_reduced_system: call cs_ba_build_system first"); return CS_ERR_NOT_RUN; }
+  if (B->shard_n > 1) { cs_set_error_ba("cs_ba_get_reduced_system: not on a sharded handle (a rank holds a partial system)"); return CS_ERR_INVALID_ARG; }
+  BA_TRY(hipSetDevice(B->device));
+  const int n = B->n_red;
+  if (cam_col) std::copy(B->cam_col.begin(), B->cam_col.end(), cam_col);
+  if (cub_col) std::copy(B->cub_col.begin(), B->cub_col.end(), cub_col);
+  if (n <= 0) return CS_OK;
+  BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (B->s_doubles + B->n_pose), B->st));
+  BA_TRY(hipMemsetAsync(B->d_elim_fail.p, 0, sizeof(int), B->st));
+  cs::ba_launch_reduce(B->view, lambda, B->st, B->st2, B->ev_fork, B->ev_join);
+  if (B->ext_n > 0 && B->ext_terms_set) cs::ba_launch_ext_offdiag(B->view, B->ext_n, B->d_ext_e4.p, B->ext_Hij.p, B->st);
+  BA_TRY(hipGetLastError());
+  std::vector<double> h(B->s_doubles + B->n_pose);
+  BA_TRY(hipMemcpyAsync(h.data(), B->S.p, 8 * h.size(), hipMemcpyDeviceToHost, B->st));
+  BA_TRY(hipStreamSynchronize(B->st));
+  if (rhs) std::copy(h.begin() + B->s_doubles, h.begin() + B->s_doubles + n, rhs);
+  if (S_dense) {
+    std::memset(S_dense, 0, sizeof(double) * (size_t)n * n);
+    if (B->band_ld) {
+      for (int c = 0; c < n; c++)
+        for (int d = 0; d < B->band_ld && c + d < n; d++) { const double v = h[(size_t)c * B->band_ld + d]; S_dense[(size_t)(c + d) * n + c] = v; S_dense[(size_t)c * n + c + d] = v; }
+    } else {
+      for (int r = 0; r < n; r++) for (int c = 0; c <= r; c++) { const double v = h[(size_t)r * n + c]; S_dense[(size_t)r * n + c] = v; S_dense[(size_t)c * n + r] = v; }
+    }
+  }
+  return CS_OK;
+}
+int cs_ba_get_reduced_system(cs_ba* B, double lambda, double* S_dense, double* rhs, int* cam_col, int* cub_col) {
+  BA_GUARD_BEGIN
+  return cs_ba_get_reduced_system_impl(B, lambda, S_dense, rhs, cam_col, cub_col);
+  BA_GUARD_END("cs_ba_get_reduced_system")
+}
+
 int cs_ba_reduced_size(cs_ba* B, int* n_reduced, int* cuboids_eliminated) {
   if (!B) return CS_ERR_INVALID_ARG;
   BA_GUARD_BEGIN
@@ -2221,6 +2260,8 @@ static int cs_ba_load_impl(const char* path, int device, cs_ba** out) {
   int rc = cs_ba_create(device, &B); if (rc) return rc;
   struct Guard { cs_ba* b; ~Guard() { if (b) cs_ba_destroy(b); } } g{B};
   if ((rc = cs_ba_set_vertices(B, cams.data(), camf.data(), nc, cubs.data(), cubf.data(), no, pts.data(), ptf.data(), np, cf))) return rc;
+  // (the setters normalise quaternions; the dumped ones are normalised already and must come back with their exact bits)
+  if (nc) BA_TRY(hipMemcpy(B->cams.p, cams.data(), 56 * (size_t)nc, hipMemcpyHostToDevice));
   if (npe && (rc = cs_ba_set_edges_proj(B, npe, ept.data(), ecam.data(), uv.data(), info.data(), intr.data(), hh ? hub.data() : nullptr))) return rc;
   if (nrk && (rc = cs_ba_set_robust_kernels(B, CS_EDGE_PROJ, npe, rkp.data(), hub.data()))) return rc;
   if (n3 && (rc = cs_ba_set_edges_cuboid(B, n3, c3.data(), o3.data(), m10.data(), i81.data()))) return rc;
@@ -2228,6 +2269,7 @@ static int cs_ba_load_impl(const char* path, int device, cs_ba** out) {
   if (n4 && (rc = cs_ba_set_edges_cuboid_proj(B, n4, c4.data(), o4.data(), m4.data(), i16.data(), k9.data()))) return rc;
   if (nrk4 && (rc = cs_ba_set_robust_kernels(B, CS_EDGE_CUBOID_PROJ, n4, rk4.data(), rd4.data()))) return rc;
   if (n6 && (rc = cs_ba_set_edges_odom(B, n6, oi.data(), oj.data(), m7.data(), i36.data()))) return rc;
+  if (n6) B->h_oe_meas = m7;
   if (nrk6 && (rc = cs_ba_set_robust_kernels(B, CS_EDGE_ODOM, n6, rk6.data(), rd6.data()))) return rc;
   *out = B;
   g.b = nullptr;

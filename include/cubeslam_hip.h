@@ -397,6 +397,11 @@ int cs_ba_schur_layout(cs_ba* ba, int* fused, int* n_segments, int* n_partial_bl
  * free point in point order), Hpl (18 per projection edge in the caller's edge order), b, x.            */
 int cs_ba_get_system(cs_ba* ba, double* Hpp_dense, double* Hll9, double* Hpl18, double* b, double* x);
 
+/* The damped reduced system as the solver is about to factorise it (the Schur-complement build of block_solver.hpp:373-439 at `lambda`
+ * on the current linearisation, no factorisation): S_dense n_red x n_red symmetric (n_red from cs_ba_reduced_size), rhs n_red, and the
+ * column of every camera / cuboid in solver order (-1: fixed; a cuboid column >= n_red: eliminated, not part of S).  NULL = skip.   */
+int cs_ba_get_reduced_system(cs_ba* ba, double lambda, double* S_dense, double* rhs, int* cam_col, int* cub_col);
+
 /* A_ii of every vertex after cs_ba_build_system(): what g2o keeps mapped into its vertices (BaseVertex::mapHessianMemory,
  * core/base_vertex.hpp:52-54, mapped by BlockSolver::buildStructure block_solver.hpp:185,191) and what
  * OptimizationAlgorithmLevenberg::computeLambdaInit() reads through v->hessian(j, j)

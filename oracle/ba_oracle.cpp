@@ -717,14 +717,12 @@ inline void inv3(const double* a, double* r) {  // Eigen 3x3 inverse, cofactor f
   r[6] = cof(0, 2) * id; r[7] = cof(1, 2) * id; r[8] = cof(2, 2) * id;
 }
 
-bool solve_system(Problem& P) {  // block_solver.hpp:353-486
+// the Schur complement of the landmarks (block_solver.hpp:373-439): S = Hpp - sum_j W_j D_j^-1 W_j^T, bschur = b_p - sum_j W_j D_j^-1 b_j
+void schur_complement(Problem& P, std::vector<double>& S, std::vector<double>& bschur, std::vector<double>& Dinv) {
   int n = P.size_pose;
-  P.x.assign(n + P.size_lm, 0.0);
-  if (P.n_lm == 0) { const double t0 = wall_ms(); bool ok = ldlt_solve(P.Hpp, n, P.b.data(), P.x.data()); P.stage_ms[3] += wall_ms() - t0; return ok; }
-  double t_stage = wall_ms();
-  std::vector<double> S = P.Hpp;  // Hschur = Hpp
+  S = P.Hpp;  // Hschur = Hpp
   std::vector<double> coeff(n, 0.0);
-  std::vector<double> Dinv((size_t)P.n_lm * 9);
+  Dinv.assign((size_t)P.n_lm * 9, 0.0);
   // edges per landmark, sorted by pose row (the CCS column order, block_solver.hpp:398-431)
   std::vector<std::vector<int>> lm_edges(P.n_lm);
   for (size_t k = 0; k < P.eproj.size(); k++) {
@@ -757,13 +755,12 @@ bool solve_system(Problem& P) {  // block_solver.hpp:353-486
       }
     }
   }
-  std::vector<double> bschur(n);
+  bschur.resize(n);
   for (int i = 0; i < n; i++) bschur[i] = P.b[i] - coeff[i];
-  P.stage_ms[2] += wall_ms() - t_stage;
-  t_stage = wall_ms();
-  if (P.ldlt_stride > 1) { P.stage_ms[3] += ldlt_sampled_ms(S, n, P.ldlt_stride); return true; }   // timing run: no increment
-  if (!ldlt_solve(std::move(S), n, bschur.data(), P.x.data())) { P.stage_ms[3] += wall_ms() - t_stage; return false; }
-  // landmarks: xl = Dinv (bl - Hpl^T xp)
+}
+// x_l = D^-1 (b_l - W^T x_p) (block_solver.hpp:457-482); x holds x_p in its first size_pose entries
+void back_substitute(Problem& P, const std::vector<double>& Dinv, std::vector<double>& x) {
+  int n = P.size_pose;
   std::vector<double> cl(P.b.begin() + n, P.b.end());
   for (size_t k = 0; k < P.eproj.size(); k++) {
     int li = P.pt_lmidx[P.eproj[k].pt], cc = P.cam_col[P.eproj[k].cam];
@@ -771,11 +768,24 @@ bool solve_system(Problem& P) {  // block_solver.hpp:353-486
     const double* B = &P.Hpl[18 * k];
     for (int c = 0; c < 3; c++) {
       double s = 0;
-      for (int r = 0; r < 6; r++) s += B[3 * r + c] * (-P.x[cc + r]);
+      for (int r = 0; r < 6; r++) s += B[3 * r + c] * (-x[cc + r]);
       cl[3 * li + c] += s;
     }
   }
-  for (int j = 0; j < P.n_lm; j++) mv3(&Dinv[9 * j], &cl[3 * j], &P.x[n + 3 * j]);
+  for (int j = 0; j < P.n_lm; j++) mv3(&Dinv[9 * j], &cl[3 * j], &x[n + 3 * j]);
+}
+bool solve_system(Problem& P) {  // block_solver.hpp:353-486
+  int n = P.size_pose;
+  P.x.assign(n + P.size_lm, 0.0);
+  if (P.n_lm == 0) { const double t0 = wall_ms(); bool ok = ldlt_solve(P.Hpp, n, P.b.data(), P.x.data()); P.stage_ms[3] += wall_ms() - t0; return ok; }
+  double t_stage = wall_ms();
+  std::vector<double> S, bschur, Dinv;
+  schur_complement(P, S, bschur, Dinv);
+  P.stage_ms[2] += wall_ms() - t_stage;
+  t_stage = wall_ms();
+  if (P.ldlt_stride > 1) { P.stage_ms[3] += ldlt_sampled_ms(S, n, P.ldlt_stride); return true; }   // timing run: no increment
+  if (!ldlt_solve(std::move(S), n, bschur.data(), P.x.data())) { P.stage_ms[3] += wall_ms() - t_stage; return false; }
+  back_substitute(P, Dinv, P.x);   // landmarks: xl = Dinv (bl - Hpl^T xp)
   P.stage_ms[3] += wall_ms() - t_stage;
   return true;
 }
@@ -988,6 +998,30 @@ int ba_oracle_solve(void* h, double lambda, double* x) {
   restore_diagonal(P);
   if (x) std::memcpy(x, P.x.data(), 8 * P.x.size());
   return ok ? 1 : 0;
+}
+
+// Stage access at sizes where the oracle's own unblocked dense LDL^T is out of reach (C4: 10 494 unknowns): the damped reduced system
+// [S | b_schur] of the current linearisation (dense size_pose^2, both triangles), and the landmark back-substitution for pose
+// increments solved elsewhere (the tests factorise the oracle's S with LAPACK).  Both apply lambda as setLambda does (:563-589) and
+// restore the diagonals afterwards.
+void ba_oracle_schur(void* h, double lambda, double* S_dense, double* bschur) {
+  Problem& P = *(Problem*)h;
+  set_lambda(P, lambda);
+  std::vector<double> S, bs, Dinv;
+  if (P.n_lm == 0) { S = P.Hpp; bs.assign(P.b.begin(), P.b.begin() + P.size_pose); } else schur_complement(P, S, bs, Dinv);
+  restore_diagonal(P);
+  if (S_dense) std::memcpy(S_dense, S.data(), 8 * S.size());
+  if (bschur) std::memcpy(bschur, bs.data(), 8 * bs.size());
+}
+void ba_oracle_backsub(void* h, double lambda, const double* xp, double* x_full) {
+  Problem& P = *(Problem*)h;
+  set_lambda(P, lambda);
+  std::vector<double> Dinv((size_t)P.n_lm * 9), x(P.size_pose + P.size_lm, 0.0);
+  for (int j = 0; j < P.n_lm; j++) inv3(&P.Hll[9 * j], &Dinv[9 * j]);
+  std::memcpy(x.data(), xp, 8 * (size_t)P.size_pose);
+  back_substitute(P, Dinv, x);
+  restore_diagonal(P);
+  std::memcpy(x_full, x.data(), 8 * x.size());
 }
 
 // SE3 / cuboid primitives for known-answer tests

@@ -144,6 +144,28 @@ class Problem:
         lib().ba_oracle_get_system(self.h, _dp(Hpp), _dp(Hll), _dp(Hpl), _dp(b))
         return Hpp, Hll, Hpl, b
 
+    def build_system_blocks(self):
+        """build_system without copying the dense H_pp out (C4: 881 MB): (Hll, Hpl, b)."""
+        lib().ba_oracle_build_system(self.h)
+        n, nl = self.sizes()
+        Hll, Hpl, b = np.zeros((nl // 3, 9)), np.zeros((self.n_proj, 18)), np.zeros(n + nl)
+        lib().ba_oracle_get_system(self.h, None, _dp(Hll), _dp(Hpl), _dp(b))
+        return Hll, Hpl, b
+
+    def schur(self, lam):
+        """The damped reduced system of the current linearisation (block_solver.hpp:373-439): dense S (size_pose^2, g2o's order), b_schur."""
+        n, _ = self.sizes()
+        S, bs = np.zeros((n, n)), np.zeros(n)
+        lib().ba_oracle_schur(self.h, C.c_double(lam), _dp(S), _dp(bs))
+        return S, bs
+
+    def backsub(self, lam, xp):
+        """Landmark back-substitution (block_solver.hpp:457-482) for pose increments solved elsewhere: the full x."""
+        n, nl = self.sizes()
+        x = np.zeros(n + nl)
+        lib().ba_oracle_backsub(self.h, C.c_double(lam), _dp(_f(xp, (n,))), _dp(x))
+        return x
+
     def solve(self, lam):
         n, nl = self.sizes()
         x = np.zeros(n + nl)

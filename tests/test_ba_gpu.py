@@ -655,6 +655,35 @@ def test_full_size_c4_properties(monkeypatch):
     B.close(); D.close()
 
 
+@pytest.mark.parametrize("shape,keep", [((1000, 200000, 500), False), ((120, 6000, 16), True), ((120, 6000, 16), False)])
+def test_one_linearisation_at_full_c4_size_against_the_oracle(shape, keep, monkeypatch):
+    """BASELINE.json's C4 -- 1 000 cameras, 200 000 landmarks, 500 cuboids, ~1 M projection edges -- compared with oracle/ba_oracle.cpp
+    itself, not only through properties: robust chi2, the gradient b, every H_ll and H_pl block, EVERY block of the damped reduced system
+    (the oracle forms g2o's camera + cuboid system, block_solver.hpp:373-439; the device's extra cuboid elimination is applied to it with
+    numpy) and one damped solve (the oracle's S factorised by LAPACK instead of its 24-minute textbook LDL^T; its own landmark
+    back-substitution).  Bars as in test_system_parity_all_edge_types: 1e-9 for what is closed-form, 1e-5 for what passes through the
+    numeric (delta = 1e-9) Jacobians of the cuboid and odometry edges.  The small shapes run the same comparison with and without the
+    cuboid elimination."""
+    from oracle import ba_parity
+    if keep:
+        monkeypatch.setenv("CS_BA_KEEP_CUBOIDS", "1")
+    nc, npt, no = shape
+    pr = synth_ba.make_problem(n_cams=nc, n_points=npt, n_cuboids=no, seed=42)
+    G, R = capi.ba_from_dict(pr), _oracle(pr)
+    assert G.reduced_size()[1] == (not keep)
+    G.build_system(dense_hpp=False)
+    hc, ho, hp = G.vertex_hessians()
+    lam = 1e-5 * max(np.abs(np.diagonal(hc, axis1=1, axis2=2)).max(), np.abs(np.diagonal(ho, axis1=1, axis2=2)).max(), np.abs(np.diagonal(hp, axis1=1, axis2=2)).max())
+    d = ba_parity.compare_linearisation(G, R, pr, lam)
+    print("C4 parity" if nc == 1000 else "parity", shape, "keep_cuboids" if keep else "cuboids eliminated", d)
+    assert d["chi2"] < 1e-11 and d["H_ll"] < 1e-11 and d["H_pl"] < 1e-11
+    assert d["b"] < 1e-5 and d["S"] < 1e-5 and d["b_schur"] < 1e-5          # (numeric Jacobians of the cuboid / odometry edges inside)
+    if "S_worst_block" in d:
+        assert d["S_worst_block"] < 1e-4 and d["S_nonzero_where_oracle_is_zero"] == 0.0 and d["S_blocks_compared"] > nc
+    assert d["solve_ok"] and d["x_pose"] < 1e-5 and d["x_landmarks"] < 1e-5
+    G.close(); R.close()
+
+
 def test_cuboid_projection_edges_system_and_optimize_parity():
     """EdgeSE3CuboidProj (4-dim bounding-box error of the projected cuboid, numeric Jacobians) next to the other three
     edge types: linear system and a 6-iteration LM run against the oracle."""
