@@ -166,6 +166,34 @@ CS_HD int build_corners(const BoxGeom& g, V2 vp1, V2 vp2, V2 vp3, double top_x, 
   return vp1_pos;
 }
 
+// The corners of a proposal that build_corners ACCEPTED, values only.  vp1_pos = build_corners' return value (1 / 2: which side the
+// top edge runs into).  Every corner is the same expression on the same operands as in build_corners -- an accepted ray hit is
+// (bx, s.y + ((bx - s.x) / dx) * dy) resp. (s.x + ((by - s.y) / dy) * dx, by), the intersections are line_intersect itself -- so the
+// values carry the same bits; what is left out is everything that only DECIDES (the second attempt of the first ray, the miss
+// sentinels, the inside-box tests, the 13 edge-length tests): a proposal that reaches the scorer has passed them.  (An accepted
+// proposal's box is never degenerate -- top == down would put corner 5 on corner 3 and fail the 20-pixel test -- so the degenerate
+// branches of the ray hits do not contribute.)  Both configurations share the code: configuration 1 hits the far side from corner 1
+// and intersects for corner 3, configuration 2 hits it from corner 2 and intersects for corner 4 (box_proposal_detail.cpp:468-572).
+CS_HD void rebuild_accepted_corners(const BoxGeom& g, V2 vp1, V2 vp2, V2 vp3, double top_x, int config_id, int vp1_pos, V2 c[8]) {
+  const V2 c1 = v2(top_x, (double)g.top);
+  const bool right_first = vp1_pos == 1;
+  const double side1 = (double)(right_first ? g.right : g.left), side2 = (double)(right_first ? g.left : g.right);
+  const bool k1 = config_id == 1;
+  V2 c2;
+  { const double dx = c1.x - vp1.x, dy = c1.y - vp1.y, lambd = (side1 - vp1.x) / dx; c2 = v2(side1, vp1.y + lambd * dy); }
+  const V2 P = k1 ? c1 : c2;
+  V2 H;
+  { const double dx = P.x - vp2.x, dy = P.y - vp2.y, lambd = (side2 - vp2.x) / dx; H = v2(side2, vp2.y + lambd * dy); }
+  const V2 L = line_intersect(k1 ? vp2 : vp1, k1 ? c2 : H, k1 ? vp1 : vp2, k1 ? H : c1);
+  const V2 c3 = k1 ? L : H, c4 = k1 ? H : L;
+  V2 c5;
+  { const double dx = c3.x - vp3.x, dy = c3.y - vp3.y, lambd = ((double)g.down - vp3.y) / dy; c5 = v2(vp3.x + lambd * dx, (double)g.down); }
+  const V2 c6 = line_intersect(vp2, c5, vp3, c2);
+  const V2 c7 = line_intersect(vp1, c6, vp3, c1);
+  const V2 c8 = line_intersect(vp1, c5, vp2, c7);
+  c[0] = c1; c[1] = c2; c[2] = c3; c[3] = c4; c[4] = c5; c[5] = c6; c[6] = c7; c[7] = c8;
+}
+
 // Camera data of one (roll, pitch) sample: what set_cam_pose() leaves behind for the sweep and the
 // 3D lift (box_proposal_detail.cpp:45-56, :131/:376).
 struct RpPose {

@@ -450,7 +450,7 @@ __device__ __forceinline__ void slot_corners16(const DetectDeviceView& v, long l
 __device__ __forceinline__ int sel(int cfg, int a, int b) { return cfg ? b : a; }
 
 enum { SCORE_JOBS = 4, SCORE_SUB = 128, SCORE_BINS = SCORE_JOBS * SCORE_SUB };   // sort keys of score_kernel: (job within the block, configuration x top sample)
-__global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long long slot_total, double short_sq_bound) {
+__global__ __launch_bounds__(256) void score_kernel_lds(DetectDeviceView v, long long slot_total, double short_sq_bound) {
   // [coordinate: x0..x7, y0..y7][lane]: every lane keeps its proposal's corners in its own column (LDS because the edge tables index
   // them dynamically); lanes of a wave mostly ask for the same corner (sorted by configuration)
   __shared__ double C16[16][260];
@@ -604,6 +604,191 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
   double p3[3], s3[3];
   lift_to_3d(c, pose->R, pose->t, v.invK + 9 * jd.frame, pose->plane, p3, s3);
   int flag = s_flag[mine];
+  if (s3[0] < 0 || s3[1] < 0 || s3[2] < 0) flag |= CAND_NEG_SCALE;
+  v.c_flag[i] = flag;
+  v.c_dist[i] = (double)sum_dist / jd.diag;
+  v.c_angle[i] = total;
+  v.c_skew[i] = dmax(s3[0], s3[1]) / dmin(s3[0], s3[1]);
+}
+
+// ---- the scorer, corners in registers (round 4) -------------------------------------------------------------------------------------
+// The same work as score_kernel_lds above (kept for A / B timing: CS_SCORE_LDS=1) with three changes, all invisible in the results:
+//   * the corners never touch LDS.  A lane rebuilds its accepted proposal's eight corners with rebuild_accepted_corners (cs_geom.h: the
+//     value expressions of build_corners without its decisions) and keeps them in registers; the edge tables of the two configurations
+//     differ in ONE visible edge and two of the six vanishing-point edges, which become register selects.  The kernel's LDS drops from
+//     40 KB to the 7 KB of the re-sort, so that it no longer keeps the latency-bound kernels of the other batches (ranking, line setup)
+//     off the CU;
+//   * of an edge's 11 samples s/10 * p1 + (1 - s/10) * p2 (object_3d_util.cpp:645-652), s = 0 and s = 10 ARE the end points
+//     (0 * a + 1 * b: the product with 0 is +-0, the product with 1 is exact, and the sum with +-0 leaves b unless b is itself a zero,
+//     whose sign the integer cast drops), and s = 5 is (a + b) * 0.5 (both halves are exact, so the single rounding happens in the sum
+//     either way): 14 of an edge's 66 double operations go;
+//   * a wavefront that holds configuration-2 proposals only skips the two edges that configuration does not have.
+__device__ __forceinline__ V2 sel_v2(bool c, V2 a, V2 b) { return v2(c ? a.x : b.x, c ? a.y : b.y); }
+__device__ __forceinline__ void edge_gathers(const float* __restrict__ map, int map_w, double x1, double y1, double x2, double y2, float dv[11]) {
+  // (the end points are made opaque per edge: edges share corners, and value numbering would otherwise keep a corner's eighteen
+  // products w * x, w * y alive from one edge to the next -- fewer multiplications, but well over 200 live registers)
+  asm volatile("" : "+v"(x1), "+v"(y1), "+v"(x2), "+v"(y2));
+#pragma unroll
+  for (int s = 0; s < 11; s++) {
+    double sx, sy;
+    if (s == 0) { sx = x2; sy = y2; }
+    else if (s == 10) { sx = x1; sy = y1; }
+    else if (s == 5) { sx = (x1 + x2) * 0.5; sy = (y1 + y2) * 0.5; }
+    else { const double w = (double)s / 10.0; sx = w * x1 + (1 - w) * x2; sy = w * y1 + (1 - w) * y2; }
+    // samples lie inside the ROI the map covers (corners were tested against it): row * width + column fits 24 x 24 -> 32 bits
+    dv[s] = map[(unsigned)(__mul24((int)sy, map_w) + (int)sx)];
+    // (a scheduling fence per sample: a gather leaves as soon as its address exists -- left alone, the scheduler computes the
+    // coordinates of a whole group first, 33 x 2 doubles, and the kernel needs 230 VGPRs)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void score_kernel(DetectDeviceView v, long long slot_total, double short_sq_bound) {
+  const long long n_valid = v.job_cbase[v.n_jobs];
+  const long long per_xcd = ((n_valid + 255) / 256 + 7) / 8;
+  const long long kx = blockIdx.x >> 3;
+  if (kx >= per_xcd) return;
+  const long long base = ((long long)(blockIdx.x & 7) * per_xcd + kx) * blockDim.x;
+  if (base >= n_valid) return;
+  // ---- who scores what: the block's 256 consecutive proposals re-sorted by (job, configuration, top-edge sample), see score_kernel_lds
+  __shared__ int hist[SCORE_BINS + 1];
+  __shared__ int s_src[256], s_job[256], s_flag[256];
+  __shared__ long long s_slot[256];
+  {
+    const int t0 = threadIdx.x;
+    for (int b = t0; b <= SCORE_BINS; b += 256) hist[b] = 0;
+    __syncthreads();
+    const long long i0 = base + t0;
+    long long slot0 = 0;
+    int j0 = 0;
+    int flag0 = 0;
+    if (i0 < n_valid) { slot0 = v.c_slot[i0]; flag0 = v.c_flag[i0]; j0 = flag0 >> CAND_JOB_SHIFT; }
+    s_slot[t0] = slot0; s_job[t0] = j0; s_flag[t0] = flag0 & CAND_VP_MASK;
+    __syncthreads();
+    int key = SCORE_BINS;                       // beyond the list: sorted last, skipped below
+    if (i0 < n_valid) {
+      const int T0 = v.jobs[j0].T;
+      const unsigned loc = (unsigned)(slot0 - v.jobs[j0].slot_off);
+      const int jrel = j0 - s_job[0];                                                // jobs in this block, in order
+      const int sub = (int)(loc & 1) * T0 + (int)((loc >> 1) % (unsigned)T0);        // configuration-major, then top-edge sample
+      key = (jrel < SCORE_JOBS && sub < SCORE_SUB) ? jrel * SCORE_SUB + sub : SCORE_BINS - 1;
+    }
+    const int rank = atomicAdd(&hist[key], 1);
+    __syncthreads();
+    if (t0 < 64) {                              // exclusive prefix over the bins: 64 lanes x (SCORE_BINS + 1) / 64 bins each
+      constexpr int PER = (SCORE_BINS + 1 + 63) / 64;
+      int loc_sum = 0, vals[PER];
+#pragma unroll
+      for (int q = 0; q < PER; q++) { const int b = t0 * PER + q; vals[q] = b <= SCORE_BINS ? hist[b] : 0; loc_sum += vals[q]; }
+      int incl = loc_sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (t0 >= o) incl += y; }
+      int run = incl - loc_sum;
+#pragma unroll
+      for (int q = 0; q < PER; q++) { const int b = t0 * PER + q; if (b <= SCORE_BINS) hist[b] = run; run += vals[q]; }
+    }
+    __syncthreads();
+    s_src[hist[key] + rank] = t0;
+    __syncthreads();
+  }
+  const int mine = s_src[threadIdx.x];
+  const JobDesc jd = v.jobs[s_job[mine]];
+  const long long i = base + mine;
+  if (i >= n_valid) return;                     // (no barrier below this point)
+  const long long slot = s_slot[mine];
+  const int vp1_pos = s_flag[mine];
+  const unsigned local = (unsigned)(slot - jd.slot_off);
+  const int cfg = (int)(local & 1);          // 0 = configuration 1
+  const unsigned rest = local >> 1;
+  const int ry = (int)(rest / (unsigned)jd.T);
+  const int top_i = (int)(rest - (unsigned)ry * (unsigned)jd.T);
+  const int rp = (int)((unsigned)ry / (unsigned)jd.Y);
+  const double ox = (double)jd.g.el, oy = (double)jd.g.et;
+  const float* __restrict__ map = v.maps + jd.map_off;
+  const int map_w = jd.map_w;
+  V2 c[8];
+  {
+    const double* vp = v.vp + 6 * (long long)(jd.vp_off + ry);
+    rebuild_accepted_corners(jd.g, v2(vp[0], vp[1]), v2(vp[2], vp[3]), v2(vp[4], vp[5]), (double)v.top_x[jd.top_off + top_i], cfg + 1, vp1_pos, c);
+  }
+  // ---- distance error (object_3d_util.cpp:622-667): the gathers of two edges in flight, then their sequential float accumulation.
+  // Visible edges: 1-2 2-3 3-4 4-1 2-6 3-5 in both configurations, then 4-8 5-8 5-6 (configuration 1, :646) or 5-6 (configuration 2, :663);
+  // configuration 2 weighs edges 4, 5 by 3/2 and edge 6 by 2 (:655-661: float(double(d) * 3.0 / 2.0) is the float product d * 1.5f,
+  // both being one rounding of an exact value).
+  const bool c2 = cfg != 0;
+  float sum_dist = 0;
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    // (scheduling fences between the groups and after every sample: left alone, the scheduler hoists the coordinate arithmetic of a
+    // whole group -- or of all 99 gathers -- to the top and pays for it with 230 VGPRs)
+    float dv[2][11];
+#define SCORE_ACC(u, wt) _Pragma("unroll") for (int s = 0; s < 11; s++) sum_dist = sum_dist + dv[u][s] * (wt)
+    edge_gathers(map, map_w, c[0].x - ox, c[0].y - oy, c[1].x - ox, c[1].y - oy, dv[0]);
+    edge_gathers(map, map_w, c[1].x - ox, c[1].y - oy, c[2].x - ox, c[2].y - oy, dv[1]);
+    SCORE_ACC(0, 1.0f); SCORE_ACC(1, 1.0f);
+    __builtin_amdgcn_sched_barrier(0);
+    edge_gathers(map, map_w, c[2].x - ox, c[2].y - oy, c[3].x - ox, c[3].y - oy, dv[0]);
+    edge_gathers(map, map_w, c[3].x - ox, c[3].y - oy, c[0].x - ox, c[0].y - oy, dv[1]);
+    SCORE_ACC(0, 1.0f); SCORE_ACC(1, 1.0f);
+    __builtin_amdgcn_sched_barrier(0);
+    const float w45 = c2 ? 1.5f : 1.0f;
+    edge_gathers(map, map_w, c[1].x - ox, c[1].y - oy, c[5].x - ox, c[5].y - oy, dv[0]);
+    edge_gathers(map, map_w, c[2].x - ox, c[2].y - oy, c[4].x - ox, c[4].y - oy, dv[1]);
+    SCORE_ACC(0, w45); SCORE_ACC(1, w45);
+    __builtin_amdgcn_sched_barrier(0);
+    const V2 a6 = sel_v2(c2, c[4], c[3]), b6 = sel_v2(c2, c[5], c[7]);
+    const float w6 = c2 ? 2.0f : 1.0f;
+    const bool more = __any(!c2);               // wave-uniform: a wavefront of configuration-2 proposals has no edges 7 and 8
+    edge_gathers(map, map_w, a6.x - ox, a6.y - oy, b6.x - ox, b6.y - oy, dv[0]);
+    if (more) edge_gathers(map, map_w, c[4].x - ox, c[4].y - oy, c[7].x - ox, c[7].y - oy, dv[1]);
+    SCORE_ACC(0, w6);
+    if (more) {
+#pragma unroll
+      for (int s = 0; s < 11; s++) { const float nx = sum_dist + dv[1][s] * 1.0f; sum_dist = c2 ? sum_dist : nx; }
+      __builtin_amdgcn_sched_barrier(0);
+      edge_gathers(map, map_w, c[4].x - ox, c[4].y - oy, c[5].x - ox, c[5].y - oy, dv[0]);
+#pragma unroll
+      for (int s = 0; s < 11; s++) { const float nx = sum_dist + dv[0][s] * 1.0f; sum_dist = c2 ? sum_dist : nx; }
+    }
+#undef SCORE_ACC
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- angle alignment error (object_3d_util.cpp:670-723).  VP edges: 1-2 and 8-5 / 3-4 for vp1, 4-1 and 5-6 for vp2, 4-8 / 3-5 and 2-6
+  // for vp3 (configuration 1 / 2: box_proposal_detail.cpp:651, :665)
+  double total = 0;
+  const double not_found_penalty = 30.0 / 180.0 * CS_PI * 2;
+  double bnd[6];
+  {
+    const double* bound = v.bound + 6 * (long long)(jd.vp_off + ry);
+#pragma unroll
+    for (int q = 0; q < 6; q++) bnd[q] = bound[q];
+  }
+  const V2 EA[6] = {c[0], sel_v2(c2, c[2], c[7]), c[3], c[4], sel_v2(c2, c[2], c[3]), c[1]};
+  const V2 EB[6] = {c[1], sel_v2(c2, c[3], c[4]), c[0], c[5], sel_v2(c2, c[4], c[7]), c[5]};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const double b0 = bnd[2 * k], b1 = bnd[2 * k + 1];
+    const bool v0 = !(b0 != b0), v1 = !(b1 != b1);
+    if (v0 || v1) {
+#pragma unroll
+      for (int ee = 0; ee < 2; ee++) {
+        const V2 pa = EA[2 * k + ee], pb = EB[2 * k + ee];
+        const double ang = normalize_to_pi(cs_atan2(pb.y - pa.y, pb.x - pa.x));
+        double best = 100;
+        if (v0) { double t = dabs(ang - b0); t = dmin(t, CS_PI - t); if (t < best) best = t; }
+        if (v1) { double t = dabs(ang - b1); t = dmin(t, CS_PI - t); if (t < best) best = t; }
+        total = total + best;
+      }
+    } else {
+      total = total + not_found_penalty;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- half sizes of the lifted cuboid -> skew ratio, negative-scale flag
+  const RpPose* pose = v.rp + jd.rp_off + rp;
+  double p3[3], s3[3];
+  lift_to_3d(c, pose->R, pose->t, v.invK + 9 * jd.frame, pose->plane, p3, s3);
+  int flag = vp1_pos;
   if (s3[0] < 0 || s3[1] < 0 || s3[2] < 0) flag |= CAND_NEG_SCALE;
   v.c_flag[i] = flag;
   v.c_dist[i] = (double)sum_dist / jd.diag;
@@ -1375,7 +1560,12 @@ void launch_scan_compact_trips(const DetectDeviceView& v, int* cnt, int max_trip
 void launch_score(const DetectDeviceView& v, const SweepParams& sp, long long n_valid_bound, long long slot_total, hipStream_t st) {
   if (skip_kernel("score")) return;
   if (n_valid_bound <= 0) return;
-  hipLaunchKernelGGL(score_kernel, dim3(grid8(n_valid_bound, 256)), dim3(256), 0, st, v, slot_total, sp.short_sq_bound);
+  static const bool lds_form = getenv("CS_SCORE_LDS") != nullptr;      // diagnostics: the round-3 kernel (corners in LDS), for A / B timing
+  static const bool w4 = [] { const char* e = getenv("CS_SCORE_WAVES"); return e && atoi(e) == 4; }();
+  if (lds_form) hipLaunchKernelGGL(score_kernel_lds, dim3(grid8(n_valid_bound, 256)), dim3(256), 0, st, v, slot_total, sp.short_sq_bound);
+  // (instances by register budget: 3 wavefronts per SIMD without spills -- the default --, 4 with ~40 spilled registers; CS_SCORE_WAVES=4 for A / B timing)
+  else if (w4) hipLaunchKernelGGL(score_kernel<4>, dim3(grid8(n_valid_bound, 256)), dim3(256), 0, st, v, slot_total, sp.short_sq_bound);
+  else hipLaunchKernelGGL(score_kernel<3>, dim3(grid8(n_valid_bound, 256)), dim3(256), 0, st, v, slot_total, sp.short_sq_bound);
 }
 // copy [src_off, src_off + count) ranges of the compacted columns into packed buffers (fallback boxes)
 __global__ __launch_bounds__(256) void gather_ranges_kernel(DetectDeviceView v, const long long* src_off, const int* count, const long long* dst_off, int n_ranges,
