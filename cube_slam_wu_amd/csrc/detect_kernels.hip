@@ -642,6 +642,113 @@ __device__ __forceinline__ void edge_gathers(const float* __restrict__ map, int 
     __builtin_amdgcn_sched_barrier(0);
   }
 }
+// one accepted proposal: corners, distance error, angle error, half sizes.  jd is the proposal's job record; the caller hands a
+// wave-uniform one (scalar loads, fields in SGPRs, the distance map's base a scalar pair that the gathers take as `saddr`)
+__device__ __forceinline__ void score_one(const DetectDeviceView& v, const JobDesc& jd, long long slot, int vp1_pos, long long i) {
+  const unsigned local = (unsigned)(slot - jd.slot_off);
+  const int cfg = (int)(local & 1);          // 0 = configuration 1
+  const unsigned rest = local >> 1;
+  const int ry = (int)(rest / (unsigned)jd.T);
+  const int top_i = (int)(rest - (unsigned)ry * (unsigned)jd.T);
+  const int rp = (int)((unsigned)ry / (unsigned)jd.Y);
+  const double ox = (double)jd.g.el, oy = (double)jd.g.et;
+  const float* __restrict__ map = v.maps + jd.map_off;
+  const int map_w = jd.map_w;
+  V2 c[8];
+  {
+    const double* vp = v.vp + 6 * (long long)(jd.vp_off + ry);
+    rebuild_accepted_corners(jd.g, v2(vp[0], vp[1]), v2(vp[2], vp[3]), v2(vp[4], vp[5]), (double)v.top_x[jd.top_off + top_i], cfg + 1, vp1_pos, c);
+  }
+  // ---- distance error (object_3d_util.cpp:622-667): sequential float accumulation in the reference's edge order.
+  // Visible edges: 1-2 2-3 3-4 4-1 2-6 3-5 in both configurations, then 4-8 5-8 5-6 (configuration 1, :646) or 5-6 (configuration 2, :663);
+  // configuration 2 weighs edges 4, 5 by 3/2 and edge 6 by 2 (:655-661: float(double(d) * 3.0 / 2.0) is the float product d * 1.5f,
+  // both being one rounding of an exact value).
+  const bool c2 = cfg != 0;
+  float sum_dist = 0;
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    // Two edges' gathers are requested while the previous two edges' values are summed (two buffers of 22 floats).  The order is pinned:
+    // an empty asm that takes the running sum and clobbers memory after every accumulation keeps the float additions where they are
+    // written (instruction selection would otherwise sink all 99 of them below the last gather and hold every gathered value -- 150
+    // live registers) and keeps the next gathers below it; a scheduling fence after every sample keeps a gather next to its address
+    // arithmetic (otherwise a group's coordinates are all computed first).
+    float dvA[2][11], dvB[2][11];
+#define SCORE_ACC(dv, u, wt) _Pragma("unroll") for (int s = 0; s < 11; s++) sum_dist = sum_dist + dv[u][s] * (wt)
+#define SCORE_PIN() asm volatile("" : "+v"(sum_dist) : : "memory")
+    edge_gathers(map, map_w, c[0].x - ox, c[0].y - oy, c[1].x - ox, c[1].y - oy, dvA[0]);
+    edge_gathers(map, map_w, c[1].x - ox, c[1].y - oy, c[2].x - ox, c[2].y - oy, dvA[1]);
+    edge_gathers(map, map_w, c[2].x - ox, c[2].y - oy, c[3].x - ox, c[3].y - oy, dvB[0]);
+    edge_gathers(map, map_w, c[3].x - ox, c[3].y - oy, c[0].x - ox, c[0].y - oy, dvB[1]);
+    SCORE_ACC(dvA, 0, 1.0f); SCORE_ACC(dvA, 1, 1.0f);
+    SCORE_PIN();
+    const float w45 = c2 ? 1.5f : 1.0f;
+    edge_gathers(map, map_w, c[1].x - ox, c[1].y - oy, c[5].x - ox, c[5].y - oy, dvA[0]);
+    edge_gathers(map, map_w, c[2].x - ox, c[2].y - oy, c[4].x - ox, c[4].y - oy, dvA[1]);
+    SCORE_ACC(dvB, 0, 1.0f); SCORE_ACC(dvB, 1, 1.0f);
+    SCORE_PIN();
+    const V2 a6 = sel_v2(c2, c[4], c[3]), b6 = sel_v2(c2, c[5], c[7]);
+    const float w6 = c2 ? 2.0f : 1.0f;
+    const bool more = __any(!c2);               // wave-uniform: a wavefront of configuration-2 proposals has no edges 7 and 8
+    edge_gathers(map, map_w, a6.x - ox, a6.y - oy, b6.x - ox, b6.y - oy, dvB[0]);
+    if (more) edge_gathers(map, map_w, c[4].x - ox, c[4].y - oy, c[7].x - ox, c[7].y - oy, dvB[1]);
+    SCORE_ACC(dvA, 0, w45); SCORE_ACC(dvA, 1, w45);
+    SCORE_PIN();
+    if (more) edge_gathers(map, map_w, c[4].x - ox, c[4].y - oy, c[5].x - ox, c[5].y - oy, dvA[0]);
+    SCORE_ACC(dvB, 0, w6);
+    if (more) {
+#pragma unroll
+      for (int s = 0; s < 11; s++) { const float nx = sum_dist + dvB[1][s] * 1.0f; sum_dist = c2 ? sum_dist : nx; }
+#pragma unroll
+      for (int s = 0; s < 11; s++) { const float nx = sum_dist + dvA[0][s] * 1.0f; sum_dist = c2 ? sum_dist : nx; }
+    }
+    SCORE_PIN();
+#undef SCORE_ACC
+#undef SCORE_PIN
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- angle alignment error (object_3d_util.cpp:670-723).  VP edges: 1-2 and 8-5 / 3-4 for vp1, 4-1 and 5-6 for vp2, 4-8 / 3-5 and 2-6
+  // for vp3 (configuration 1 / 2: box_proposal_detail.cpp:651, :665)
+  double total = 0;
+  const double not_found_penalty = 30.0 / 180.0 * CS_PI * 2;
+  double bnd[6];
+  {
+    const double* bound = v.bound + 6 * (long long)(jd.vp_off + ry);
+#pragma unroll
+    for (int q = 0; q < 6; q++) bnd[q] = bound[q];
+  }
+  const V2 EA[6] = {c[0], sel_v2(c2, c[2], c[7]), c[3], c[4], sel_v2(c2, c[2], c[3]), c[1]};
+  const V2 EB[6] = {c[1], sel_v2(c2, c[3], c[4]), c[0], c[5], sel_v2(c2, c[4], c[7]), c[5]};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const double b0 = bnd[2 * k], b1 = bnd[2 * k + 1];
+    const bool v0 = !(b0 != b0), v1 = !(b1 != b1);
+    if (v0 || v1) {
+#pragma unroll
+      for (int ee = 0; ee < 2; ee++) {
+        const V2 pa = EA[2 * k + ee], pb = EB[2 * k + ee];
+        const double ang = normalize_to_pi(cs_atan2(pb.y - pa.y, pb.x - pa.x));
+        double best = 100;
+        if (v0) { double t = dabs(ang - b0); t = dmin(t, CS_PI - t); if (t < best) best = t; }
+        if (v1) { double t = dabs(ang - b1); t = dmin(t, CS_PI - t); if (t < best) best = t; }
+        total = total + best;
+      }
+    } else {
+      total = total + not_found_penalty;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- half sizes of the lifted cuboid -> skew ratio, negative-scale flag
+  const RpPose* pose = v.rp + jd.rp_off + rp;
+  double p3[3], s3[3];
+  lift_to_3d(c, pose->R, pose->t, v.invK + 9 * jd.frame, pose->plane, p3, s3);
+  int flag = vp1_pos;
+  if (s3[0] < 0 || s3[1] < 0 || s3[2] < 0) flag |= CAND_NEG_SCALE;
+  v.c_flag[i] = flag;
+  v.c_dist[i] = (double)sum_dist / jd.diag;
+  v.c_angle[i] = total;
+  v.c_skew[i] = dmax(s3[0], s3[1]) / dmin(s3[0], s3[1]);
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(256, WAVES) void score_kernel(DetectDeviceView v, long long slot_total, double short_sq_bound) {
   const long long n_valid = v.job_cbase[v.n_jobs];
@@ -692,108 +799,19 @@ __global__ __launch_bounds__(256, WAVES) void score_kernel(DetectDeviceView v, l
     __syncthreads();
   }
   const int mine = s_src[threadIdx.x];
-  const JobDesc jd = v.jobs[s_job[mine]];
   const long long i = base + mine;
-  if (i >= n_valid) return;                     // (no barrier below this point)
+  const int myjob = s_job[mine];
   const long long slot = s_slot[mine];
   const int vp1_pos = s_flag[mine];
-  const unsigned local = (unsigned)(slot - jd.slot_off);
-  const int cfg = (int)(local & 1);          // 0 = configuration 1
-  const unsigned rest = local >> 1;
-  const int ry = (int)(rest / (unsigned)jd.T);
-  const int top_i = (int)(rest - (unsigned)ry * (unsigned)jd.T);
-  const int rp = (int)((unsigned)ry / (unsigned)jd.Y);
-  const double ox = (double)jd.g.el, oy = (double)jd.g.et;
-  const float* __restrict__ map = v.maps + jd.map_off;
-  const int map_w = jd.map_w;
-  V2 c[8];
-  {
-    const double* vp = v.vp + 6 * (long long)(jd.vp_off + ry);
-    rebuild_accepted_corners(jd.g, v2(vp[0], vp[1]), v2(vp[2], vp[3]), v2(vp[4], vp[5]), (double)v.top_x[jd.top_off + top_i], cfg + 1, vp1_pos, c);
+  // (no barrier below this point)  The block's lanes are sorted by job, so a wavefront holds one job -- its record then lives in SGPRs
+  // -- or, where the block's 256 consecutive proposals cross a job boundary (one wavefront in sixteen), two: one pass per job
+  bool todo = i < n_valid;
+  while (true) {
+    const unsigned long long left = __ballot(todo);
+    if (!left) break;
+    const int ju = __builtin_amdgcn_readlane(myjob, __ffsll((long long)left) - 1);
+    if (todo && myjob == ju) { score_one(v, v.jobs[ju], slot, vp1_pos, i); todo = false; }
   }
-  // ---- distance error (object_3d_util.cpp:622-667): the gathers of two edges in flight, then their sequential float accumulation.
-  // Visible edges: 1-2 2-3 3-4 4-1 2-6 3-5 in both configurations, then 4-8 5-8 5-6 (configuration 1, :646) or 5-6 (configuration 2, :663);
-  // configuration 2 weighs edges 4, 5 by 3/2 and edge 6 by 2 (:655-661: float(double(d) * 3.0 / 2.0) is the float product d * 1.5f,
-  // both being one rounding of an exact value).
-  const bool c2 = cfg != 0;
-  float sum_dist = 0;
-  __builtin_amdgcn_sched_barrier(0);
-  {
-    // (scheduling fences between the groups and after every sample: left alone, the scheduler hoists the coordinate arithmetic of a
-    // whole group -- or of all 99 gathers -- to the top and pays for it with 230 VGPRs)
-    float dv[2][11];
-#define SCORE_ACC(u, wt) _Pragma("unroll") for (int s = 0; s < 11; s++) sum_dist = sum_dist + dv[u][s] * (wt)
-    edge_gathers(map, map_w, c[0].x - ox, c[0].y - oy, c[1].x - ox, c[1].y - oy, dv[0]);
-    edge_gathers(map, map_w, c[1].x - ox, c[1].y - oy, c[2].x - ox, c[2].y - oy, dv[1]);
-    SCORE_ACC(0, 1.0f); SCORE_ACC(1, 1.0f);
-    __builtin_amdgcn_sched_barrier(0);
-    edge_gathers(map, map_w, c[2].x - ox, c[2].y - oy, c[3].x - ox, c[3].y - oy, dv[0]);
-    edge_gathers(map, map_w, c[3].x - ox, c[3].y - oy, c[0].x - ox, c[0].y - oy, dv[1]);
-    SCORE_ACC(0, 1.0f); SCORE_ACC(1, 1.0f);
-    __builtin_amdgcn_sched_barrier(0);
-    const float w45 = c2 ? 1.5f : 1.0f;
-    edge_gathers(map, map_w, c[1].x - ox, c[1].y - oy, c[5].x - ox, c[5].y - oy, dv[0]);
-    edge_gathers(map, map_w, c[2].x - ox, c[2].y - oy, c[4].x - ox, c[4].y - oy, dv[1]);
-    SCORE_ACC(0, w45); SCORE_ACC(1, w45);
-    __builtin_amdgcn_sched_barrier(0);
-    const V2 a6 = sel_v2(c2, c[4], c[3]), b6 = sel_v2(c2, c[5], c[7]);
-    const float w6 = c2 ? 2.0f : 1.0f;
-    const bool more = __any(!c2);               // wave-uniform: a wavefront of configuration-2 proposals has no edges 7 and 8
-    edge_gathers(map, map_w, a6.x - ox, a6.y - oy, b6.x - ox, b6.y - oy, dv[0]);
-    if (more) edge_gathers(map, map_w, c[4].x - ox, c[4].y - oy, c[7].x - ox, c[7].y - oy, dv[1]);
-    SCORE_ACC(0, w6);
-    if (more) {
-#pragma unroll
-      for (int s = 0; s < 11; s++) { const float nx = sum_dist + dv[1][s] * 1.0f; sum_dist = c2 ? sum_dist : nx; }
-      __builtin_amdgcn_sched_barrier(0);
-      edge_gathers(map, map_w, c[4].x - ox, c[4].y - oy, c[5].x - ox, c[5].y - oy, dv[0]);
-#pragma unroll
-      for (int s = 0; s < 11; s++) { const float nx = sum_dist + dv[0][s] * 1.0f; sum_dist = c2 ? sum_dist : nx; }
-    }
-#undef SCORE_ACC
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  // ---- angle alignment error (object_3d_util.cpp:670-723).  VP edges: 1-2 and 8-5 / 3-4 for vp1, 4-1 and 5-6 for vp2, 4-8 / 3-5 and 2-6
-  // for vp3 (configuration 1 / 2: box_proposal_detail.cpp:651, :665)
-  double total = 0;
-  const double not_found_penalty = 30.0 / 180.0 * CS_PI * 2;
-  double bnd[6];
-  {
-    const double* bound = v.bound + 6 * (long long)(jd.vp_off + ry);
-#pragma unroll
-    for (int q = 0; q < 6; q++) bnd[q] = bound[q];
-  }
-  const V2 EA[6] = {c[0], sel_v2(c2, c[2], c[7]), c[3], c[4], sel_v2(c2, c[2], c[3]), c[1]};
-  const V2 EB[6] = {c[1], sel_v2(c2, c[3], c[4]), c[0], c[5], sel_v2(c2, c[4], c[7]), c[5]};
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const double b0 = bnd[2 * k], b1 = bnd[2 * k + 1];
-    const bool v0 = !(b0 != b0), v1 = !(b1 != b1);
-    if (v0 || v1) {
-#pragma unroll
-      for (int ee = 0; ee < 2; ee++) {
-        const V2 pa = EA[2 * k + ee], pb = EB[2 * k + ee];
-        const double ang = normalize_to_pi(cs_atan2(pb.y - pa.y, pb.x - pa.x));
-        double best = 100;
-        if (v0) { double t = dabs(ang - b0); t = dmin(t, CS_PI - t); if (t < best) best = t; }
-        if (v1) { double t = dabs(ang - b1); t = dmin(t, CS_PI - t); if (t < best) best = t; }
-        total = total + best;
-      }
-    } else {
-      total = total + not_found_penalty;
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  // ---- half sizes of the lifted cuboid -> skew ratio, negative-scale flag
-  const RpPose* pose = v.rp + jd.rp_off + rp;
-  double p3[3], s3[3];
-  lift_to_3d(c, pose->R, pose->t, v.invK + 9 * jd.frame, pose->plane, p3, s3);
-  int flag = vp1_pos;
-  if (s3[0] < 0 || s3[1] < 0 || s3[2] < 0) flag |= CAND_NEG_SCALE;
-  v.c_flag[i] = flag;
-  v.c_dist[i] = (double)sum_dist / jd.diag;
-  v.c_angle[i] = total;
-  v.c_skew[i] = dmax(s3[0], s3[1]) / dmin(s3[0], s3[1]);
 }
 
 // Exclusive scan of job_valid -> job_cbase (n_jobs + 1).  Single block.
