@@ -450,7 +450,8 @@ __device__ __forceinline__ void slot_corners16(const DetectDeviceView& v, long l
 __device__ __forceinline__ int sel(int cfg, int a, int b) { return cfg ? b : a; }
 
 enum { SCORE_JOBS = 4, SCORE_SUB = 128, SCORE_BINS = SCORE_JOBS * SCORE_SUB };   // sort keys of score_kernel: (job within the block, configuration x top sample)
-__global__ __launch_bounds__(256) void score_kernel_lds(DetectDeviceView v, long long slot_total, double short_sq_bound) {
+// (the round-3 form, kept for A / B timing: CS_SCORE_R3=1)
+__global__ __launch_bounds__(256) void score_kernel_r3(DetectDeviceView v, long long slot_total, double short_sq_bound) {
   // [coordinate: x0..x7, y0..y7][lane]: every lane keeps its proposal's corners in its own column (LDS because the edge tables index
   // them dynamically); lanes of a wave mostly ask for the same corner (sorted by configuration)
   __shared__ double C16[16][260];
@@ -611,153 +612,25 @@ __global__ __launch_bounds__(256) void score_kernel_lds(DetectDeviceView v, long
   v.c_skew[i] = dmax(s3[0], s3[1]) / dmin(s3[0], s3[1]);
 }
 
-// ---- the scorer, corners in registers (round 4) -------------------------------------------------------------------------------------
-// The same work as score_kernel_lds above (kept for A / B timing: CS_SCORE_LDS=1) with three changes, all invisible in the results:
-//   * the corners never touch LDS.  A lane rebuilds its accepted proposal's eight corners with rebuild_accepted_corners (cs_geom.h: the
-//     value expressions of build_corners without its decisions) and keeps them in registers; the edge tables of the two configurations
-//     differ in ONE visible edge and two of the six vanishing-point edges, which become register selects.  The kernel's LDS drops from
-//     40 KB to the 7 KB of the re-sort, so that it no longer keeps the latency-bound kernels of the other batches (ranking, line setup)
-//     off the CU;
-//   * of an edge's 11 samples s/10 * p1 + (1 - s/10) * p2 (object_3d_util.cpp:645-652), s = 0 and s = 10 ARE the end points
-//     (0 * a + 1 * b: the product with 0 is +-0, the product with 1 is exact, and the sum with +-0 leaves b unless b is itself a zero,
-//     whose sign the integer cast drops), and s = 5 is (a + b) * 0.5 (both halves are exact, so the single rounding happens in the sum
-//     either way): 14 of an edge's 66 double operations go;
-//   * a wavefront that holds configuration-2 proposals only skips the two edges that configuration does not have.
-__device__ __forceinline__ V2 sel_v2(bool c, V2 a, V2 b) { return v2(c ? a.x : b.x, c ? a.y : b.y); }
-__device__ __forceinline__ void edge_gathers(const float* __restrict__ map, int map_w, double x1, double y1, double x2, double y2, float dv[11]) {
-  // (the end points are made opaque per edge: edges share corners, and value numbering would otherwise keep a corner's eighteen
-  // products w * x, w * y alive from one edge to the next -- fewer multiplications, but well over 200 live registers)
-  asm volatile("" : "+v"(x1), "+v"(y1), "+v"(x2), "+v"(y2));
-#pragma unroll
-  for (int s = 0; s < 11; s++) {
-    double sx, sy;
-    if (s == 0) { sx = x2; sy = y2; }
-    else if (s == 10) { sx = x1; sy = y1; }
-    else if (s == 5) { sx = (x1 + x2) * 0.5; sy = (y1 + y2) * 0.5; }
-    else { const double w = (double)s / 10.0; sx = w * x1 + (1 - w) * x2; sy = w * y1 + (1 - w) * y2; }
-    // samples lie inside the ROI the map covers (corners were tested against it): row * width + column fits 24 x 24 -> 32 bits
-    dv[s] = map[(unsigned)(__mul24((int)sy, map_w) + (int)sx)];
-    // (a scheduling fence per sample: a gather leaves as soon as its address exists -- left alone, the scheduler computes the
-    // coordinates of a whole group first, 33 x 2 doubles, and the kernel needs 230 VGPRs)
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-// one accepted proposal: corners, distance error, angle error, half sizes.  jd is the proposal's job record; the caller hands a
-// wave-uniform one (scalar loads, fields in SGPRs, the distance map's base a scalar pair that the gathers take as `saddr`)
-__device__ __forceinline__ void score_one(const DetectDeviceView& v, const JobDesc& jd, long long slot, int vp1_pos, long long i) {
-  const unsigned local = (unsigned)(slot - jd.slot_off);
-  const int cfg = (int)(local & 1);          // 0 = configuration 1
-  const unsigned rest = local >> 1;
-  const int ry = (int)(rest / (unsigned)jd.T);
-  const int top_i = (int)(rest - (unsigned)ry * (unsigned)jd.T);
-  const int rp = (int)((unsigned)ry / (unsigned)jd.Y);
-  const double ox = (double)jd.g.el, oy = (double)jd.g.et;
-  const float* __restrict__ map = v.maps + jd.map_off;
-  const int map_w = jd.map_w;
-  V2 c[8];
-  {
-    const double* vp = v.vp + 6 * (long long)(jd.vp_off + ry);
-    rebuild_accepted_corners(jd.g, v2(vp[0], vp[1]), v2(vp[2], vp[3]), v2(vp[4], vp[5]), (double)v.top_x[jd.top_off + top_i], cfg + 1, vp1_pos, c);
-  }
-  // ---- distance error (object_3d_util.cpp:622-667): sequential float accumulation in the reference's edge order.
-  // Visible edges: 1-2 2-3 3-4 4-1 2-6 3-5 in both configurations, then 4-8 5-8 5-6 (configuration 1, :646) or 5-6 (configuration 2, :663);
-  // configuration 2 weighs edges 4, 5 by 3/2 and edge 6 by 2 (:655-661: float(double(d) * 3.0 / 2.0) is the float product d * 1.5f,
-  // both being one rounding of an exact value).
-  const bool c2 = cfg != 0;
-  float sum_dist = 0;
-  __builtin_amdgcn_sched_barrier(0);
-  {
-    // Two edges' gathers are requested while the previous two edges' values are summed (two buffers of 22 floats).  The order is pinned:
-    // an empty asm that takes the running sum and clobbers memory after every accumulation keeps the float additions where they are
-    // written (instruction selection would otherwise sink all 99 of them below the last gather and hold every gathered value -- 150
-    // live registers) and keeps the next gathers below it; a scheduling fence after every sample keeps a gather next to its address
-    // arithmetic (otherwise a group's coordinates are all computed first).
-    float dvA[2][11], dvB[2][11];
-#define SCORE_ACC(dv, u, wt) _Pragma("unroll") for (int s = 0; s < 11; s++) sum_dist = sum_dist + dv[u][s] * (wt)
-#define SCORE_PIN() asm volatile("" : "+v"(sum_dist) : : "memory")
-    edge_gathers(map, map_w, c[0].x - ox, c[0].y - oy, c[1].x - ox, c[1].y - oy, dvA[0]);
-    edge_gathers(map, map_w, c[1].x - ox, c[1].y - oy, c[2].x - ox, c[2].y - oy, dvA[1]);
-    edge_gathers(map, map_w, c[2].x - ox, c[2].y - oy, c[3].x - ox, c[3].y - oy, dvB[0]);
-    edge_gathers(map, map_w, c[3].x - ox, c[3].y - oy, c[0].x - ox, c[0].y - oy, dvB[1]);
-    SCORE_ACC(dvA, 0, 1.0f); SCORE_ACC(dvA, 1, 1.0f);
-    SCORE_PIN();
-    const float w45 = c2 ? 1.5f : 1.0f;
-    edge_gathers(map, map_w, c[1].x - ox, c[1].y - oy, c[5].x - ox, c[5].y - oy, dvA[0]);
-    edge_gathers(map, map_w, c[2].x - ox, c[2].y - oy, c[4].x - ox, c[4].y - oy, dvA[1]);
-    SCORE_ACC(dvB, 0, 1.0f); SCORE_ACC(dvB, 1, 1.0f);
-    SCORE_PIN();
-    const V2 a6 = sel_v2(c2, c[4], c[3]), b6 = sel_v2(c2, c[5], c[7]);
-    const float w6 = c2 ? 2.0f : 1.0f;
-    const bool more = __any(!c2);               // wave-uniform: a wavefront of configuration-2 proposals has no edges 7 and 8
-    edge_gathers(map, map_w, a6.x - ox, a6.y - oy, b6.x - ox, b6.y - oy, dvB[0]);
-    if (more) edge_gathers(map, map_w, c[4].x - ox, c[4].y - oy, c[7].x - ox, c[7].y - oy, dvB[1]);
-    SCORE_ACC(dvA, 0, w45); SCORE_ACC(dvA, 1, w45);
-    SCORE_PIN();
-    if (more) edge_gathers(map, map_w, c[4].x - ox, c[4].y - oy, c[5].x - ox, c[5].y - oy, dvA[0]);
-    SCORE_ACC(dvB, 0, w6);
-    if (more) {
-#pragma unroll
-      for (int s = 0; s < 11; s++) { const float nx = sum_dist + dvB[1][s] * 1.0f; sum_dist = c2 ? sum_dist : nx; }
-#pragma unroll
-      for (int s = 0; s < 11; s++) { const float nx = sum_dist + dvA[0][s] * 1.0f; sum_dist = c2 ? sum_dist : nx; }
-    }
-    SCORE_PIN();
-#undef SCORE_ACC
-#undef SCORE_PIN
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  // ---- angle alignment error (object_3d_util.cpp:670-723).  VP edges: 1-2 and 8-5 / 3-4 for vp1, 4-1 and 5-6 for vp2, 4-8 / 3-5 and 2-6
-  // for vp3 (configuration 1 / 2: box_proposal_detail.cpp:651, :665)
-  double total = 0;
-  const double not_found_penalty = 30.0 / 180.0 * CS_PI * 2;
-  double bnd[6];
-  {
-    const double* bound = v.bound + 6 * (long long)(jd.vp_off + ry);
-#pragma unroll
-    for (int q = 0; q < 6; q++) bnd[q] = bound[q];
-  }
-  const V2 EA[6] = {c[0], sel_v2(c2, c[2], c[7]), c[3], c[4], sel_v2(c2, c[2], c[3]), c[1]};
-  const V2 EB[6] = {c[1], sel_v2(c2, c[3], c[4]), c[0], c[5], sel_v2(c2, c[4], c[7]), c[5]};
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const double b0 = bnd[2 * k], b1 = bnd[2 * k + 1];
-    const bool v0 = !(b0 != b0), v1 = !(b1 != b1);
-    if (v0 || v1) {
-#pragma unroll
-      for (int ee = 0; ee < 2; ee++) {
-        const V2 pa = EA[2 * k + ee], pb = EB[2 * k + ee];
-        const double ang = normalize_to_pi(cs_atan2(pb.y - pa.y, pb.x - pa.x));
-        double best = 100;
-        if (v0) { double t = dabs(ang - b0); t = dmin(t, CS_PI - t); if (t < best) best = t; }
-        if (v1) { double t = dabs(ang - b1); t = dmin(t, CS_PI - t); if (t < best) best = t; }
-        total = total + best;
-      }
-    } else {
-      total = total + not_found_penalty;
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  // ---- half sizes of the lifted cuboid -> skew ratio, negative-scale flag
-  const RpPose* pose = v.rp + jd.rp_off + rp;
-  double p3[3], s3[3];
-  lift_to_3d(c, pose->R, pose->t, v.invK + 9 * jd.frame, pose->plane, p3, s3);
-  int flag = vp1_pos;
-  if (s3[0] < 0 || s3[1] < 0 || s3[2] < 0) flag |= CAND_NEG_SCALE;
-  v.c_flag[i] = flag;
-  v.c_dist[i] = (double)sum_dist / jd.diag;
-  v.c_angle[i] = total;
-  v.c_skew[i] = dmax(s3[0], s3[1]) / dmin(s3[0], s3[1]);
-}
-
-template <int WAVES>
-__global__ __launch_bounds__(256, WAVES) void score_kernel(DetectDeviceView v, long long slot_total, double short_sq_bound) {
+__global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long long slot_total, double short_sq_bound) {
+  // [coordinate: x0..x7, y0..y7][lane]: every lane keeps its proposal's corners in its own column (LDS because the edge tables index
+  // them dynamically); lanes of a wave mostly ask for the same corner (sorted by configuration)
+  __shared__ double C16[16][260];
+  double (*CXt)[260] = C16, (*CYt)[260] = C16 + 8;
+  // the grid is sized for the worst case (every slot valid) because the exact count lives on the device; spread the
+  // ACTIVE blocks over the 8 XCDs (contiguous range per XCD), the surplus blocks exit immediately
   const long long n_valid = v.job_cbase[v.n_jobs];
   const long long per_xcd = ((n_valid + 255) / 256 + 7) / 8;
   const long long kx = blockIdx.x >> 3;
   if (kx >= per_xcd) return;
   const long long base = ((long long)(blockIdx.x & 7) * per_xcd + kx) * blockDim.x;
   if (base >= n_valid) return;
-  // ---- who scores what: the block's 256 consecutive proposals re-sorted by (job, configuration, top-edge sample), see score_kernel_lds
+  // ---- who scores what.  The 256 proposals of this block are consecutive in the reference's order: configuration
+  // fastest, then top-edge sample, then yaw.  Neighbouring lanes would gather from unrelated places of the distance map,
+  // and a wave load that touches 64 different cache lines occupies the L1 tag pipeline for 64 cycles -- that, not the
+  // arithmetic, used to bound this kernel.  Proposals that differ only in yaw (0.5 degrees: corners 1-2 px apart) sample
+  // almost the same pixels, so the block re-sorts its proposals by (job, configuration, top-edge sample) with a counting
+  // sort in LDS and every lane takes the proposal at its sorted position; results go back to the proposal's own index.
   __shared__ int hist[SCORE_BINS + 1];
   __shared__ int s_src[256], s_job[256], s_flag[256];
   __shared__ long long s_slot[256];
@@ -799,19 +672,120 @@ __global__ __launch_bounds__(256, WAVES) void score_kernel(DetectDeviceView v, l
     __syncthreads();
   }
   const int mine = s_src[threadIdx.x];
+  const JobDesc jd = v.jobs[s_job[mine]];
   const long long i = base + mine;
-  const int myjob = s_job[mine];
+  if (i >= n_valid) return;                     // (no barrier below this point)
   const long long slot = s_slot[mine];
-  const int vp1_pos = s_flag[mine];
-  // (no barrier below this point)  The block's lanes are sorted by job, so a wavefront holds one job -- its record then lives in SGPRs
-  // -- or, where the block's 256 consecutive proposals cross a job boundary (one wavefront in sixteen), two: one pass per job
-  bool todo = i < n_valid;
-  while (true) {
-    const unsigned long long left = __ballot(todo);
-    if (!left) break;
-    const int ju = __builtin_amdgcn_readlane(myjob, __ffsll((long long)left) - 1);
-    if (todo && myjob == ju) { score_one(v, v.jobs[ju], slot, vp1_pos, i); todo = false; }
+  const unsigned local = (unsigned)(slot - jd.slot_off);
+  const int cfg = (int)(local & 1);          // 0 = configuration 1
+  const int ry = (int)((local >> 1) / (unsigned)jd.T);
+  const int rp = (int)((unsigned)ry / (unsigned)jd.Y);
+  const int tx = threadIdx.x;
+  const double ox = (double)jd.g.el, oy = (double)jd.g.et;
+  const float* __restrict__ map = v.maps + jd.map_off;
+  // the proposal's corners, rebuilt (candidate_kernel kept only the decision): into this lane's own LDS column, no barrier needed.
+  // Round 4: values only (rebuild_accepted_corners, cs_geom.h: build_corners' value expressions without its decisions -- the second
+  // attempt of the first ray, the miss sentinels, the inside-box tests and the 13 edge-length tests), the side from the kept flag
+  {
+    V2 cb[8];
+    const unsigned rest = local >> 1;
+    const double* vp = v.vp + 6 * (long long)(jd.vp_off + ry);
+    rebuild_accepted_corners(jd.g, v2(vp[0], vp[1]), v2(vp[2], vp[3]), v2(vp[4], vp[5]), (double)v.top_x[jd.top_off + (int)(rest - (unsigned)ry * (unsigned)jd.T)], cfg + 1,
+                             s_flag[mine], cb);
+#pragma unroll
+    for (int q = 0; q < 8; q++) { CXt[q][tx] = cb[q].x; CYt[q][tx] = cb[q].y; }
   }
+  // (the six VP-support angles of the angle term are requested here, ahead of the gathers: one round trip less on the block's path)
+  double bnd[6];
+  {
+    const double* bound = v.bound + 6 * (long long)(jd.vp_off + ry);
+#pragma unroll
+    for (int q = 0; q < 6; q++) bnd[q] = bound[q];
+  }
+  // ---- distance error: all gathers of an edge are issued before its (sequential, float) accumulation
+  float sum_dist = 0;
+  // corner ids of the 9 edges, one nibble each (edge 0 lowest): {0,1,2,3,1,2,3,4,4}-{1,2,3,0,5,4,7,7,5} / {0,1,2,3,1,2,4,0,0}-{1,2,3,0,5,4,5,0,0}
+  const unsigned long long EA = cfg ? 0x004213210ull : 0x443213210ull, EB = cfg ? 0x005450321ull : 0x577450321ull;
+  // config 2 reweights edges 4, 5 by 3/2 and edge 6 by 2 (:655-661), one weight nibble per edge in halves.  The reference
+  // computes float(double(d) * 3.0 / 2.0) and float(double(d) * 2.0): both products are exact in double, so the one rounding
+  // to float is the rounding of the float product d * 1.5f (d * 2.0f), and d * 1.0f is d.
+  const unsigned long long EW = cfg ? 0x004332222ull : 0x222222222ull;
+  const int n_edges = cfg ? 7 : 9;
+  const int map_w = jd.map_w;
+  constexpr int EU = 3;   // edges per trip: their 11 * EU gathers are in flight together
+  const bool wave_has_cfg1 = __any(cfg == 0);  // round 4: a wavefront of configuration-2 proposals has no edges 7 and 8 (it mostly is one
+                                               // configuration after the re-sort), so its last trip gathers one edge instead of three
+#pragma unroll 1
+  for (int e0 = 0; e0 < n_edges; e0 += EU) {
+    float dv[EU][11];
+#pragma unroll
+    for (int u = 0; u < EU; u++) {
+      const int e = e0 + u;                    // (beyond the list: nibble 0 = corner 1, a valid address; the sum skips it)
+      if (u > 0 && e0 == 6 && !wave_has_cfg1) {
+#pragma unroll
+        for (int s = 0; s < 11; s++) dv[u][s] = 0.0f;
+        continue;
+      }
+      const int a = (int)((EA >> (4 * e)) & 7), b = (int)((EB >> (4 * e)) & 7);
+      const double x1 = CXt[a][tx] - ox, y1 = CYt[a][tx] - oy, x2 = CXt[b][tx] - ox, y2 = CYt[b][tx] - oy;
+#pragma unroll
+      for (int s = 0; s < 11; s++) {
+        // s / 10 * p1 + (1 - s / 10) * p2 (object_3d_util.cpp:645-652).  Round 4: s = 0 and s = 10 ARE the end points (0 * a + 1 * b: the
+        // product with 0 is +-0, the product with 1 exact, and the sum with +-0 leaves b unless b is itself a zero, whose sign the
+        // integer cast drops); s = 5 is (a + b) * 0.5 (both halves are exact, the single rounding happens in the sum either way)
+        double sx, sy;
+        if (s == 0) { sx = x2; sy = y2; }
+        else if (s == 10) { sx = x1; sy = y1; }
+        else if (s == 5) { sx = (x1 + x2) * 0.5; sy = (y1 + y2) * 0.5; }
+        else { const double w = (double)s / 10.0; sx = w * x1 + (1 - w) * x2; sy = w * y1 + (1 - w) * y2; }
+        // samples lie inside the ROI the map covers (corners were tested against it): row * width + column fits 24 x 24 -> 32 bits
+        dv[u][s] = map[(unsigned)(__mul24((int)sy, map_w) + (int)sx)];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < EU; u++) {
+      const int e = e0 + u;
+      const float wt = 0.5f * (float)(int)((EW >> (4 * e)) & 7);
+      const bool on = e < n_edges;
+#pragma unroll
+      for (int s = 0; s < 11; s++) { const float nx = sum_dist + dv[u][s] * wt; sum_dist = on ? nx : sum_dist; }
+    }
+  }
+  // ---- angle alignment error
+  double total = 0;
+  const double not_found_penalty = 30.0 / 180.0 * CS_PI * 2;
+  const int ID1[3][4] = {{0, 1, 7, 4}, {3, 0, 4, 5}, {3, 7, 1, 5}}, ID2[3][4] = {{0, 1, 2, 3}, {3, 0, 4, 5}, {2, 4, 1, 5}};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    double b0 = bnd[2 * k], b1 = bnd[2 * k + 1];
+    bool v0 = !(b0 != b0), v1 = !(b1 != b1);
+    if (v0 || v1) {
+#pragma unroll
+      for (int ee = 0; ee < 2; ee++) {
+        int pa = sel(cfg, ID1[k][2 * ee], ID2[k][2 * ee]), pb = sel(cfg, ID1[k][2 * ee + 1], ID2[k][2 * ee + 1]);
+        double ang = normalize_to_pi(cs_atan2(CYt[pb][tx] - CYt[pa][tx], CXt[pb][tx] - CXt[pa][tx]));
+        double best = 100;
+        if (v0) { double t = dabs(ang - b0); t = dmin(t, CS_PI - t); if (t < best) best = t; }
+        if (v1) { double t = dabs(ang - b1); t = dmin(t, CS_PI - t); if (t < best) best = t; }
+        total = total + best;
+      }
+    } else {
+      total = total + not_found_penalty;
+    }
+  }
+  // ---- half sizes of the lifted cuboid -> skew ratio, negative-scale flag
+  V2 c[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) c[q] = v2(CXt[q][tx], CYt[q][tx]);
+  const RpPose* pose = v.rp + jd.rp_off + rp;
+  double p3[3], s3[3];
+  lift_to_3d(c, pose->R, pose->t, v.invK + 9 * jd.frame, pose->plane, p3, s3);
+  int flag = s_flag[mine];
+  if (s3[0] < 0 || s3[1] < 0 || s3[2] < 0) flag |= CAND_NEG_SCALE;
+  v.c_flag[i] = flag;
+  v.c_dist[i] = (double)sum_dist / jd.diag;
+  v.c_angle[i] = total;
+  v.c_skew[i] = dmax(s3[0], s3[1]) / dmin(s3[0], s3[1]);
 }
 
 // Exclusive scan of job_valid -> job_cbase (n_jobs + 1).  Single block.
@@ -1578,12 +1552,9 @@ void launch_scan_compact_trips(const DetectDeviceView& v, int* cnt, int max_trip
 void launch_score(const DetectDeviceView& v, const SweepParams& sp, long long n_valid_bound, long long slot_total, hipStream_t st) {
   if (skip_kernel("score")) return;
   if (n_valid_bound <= 0) return;
-  static const bool lds_form = getenv("CS_SCORE_LDS") != nullptr;      // diagnostics: the round-3 kernel (corners in LDS), for A / B timing
-  static const bool w4 = [] { const char* e = getenv("CS_SCORE_WAVES"); return e && atoi(e) == 4; }();
-  if (lds_form) hipLaunchKernelGGL(score_kernel_lds, dim3(grid8(n_valid_bound, 256)), dim3(256), 0, st, v, slot_total, sp.short_sq_bound);
-  // (instances by register budget: 3 wavefronts per SIMD without spills -- the default --, 4 with ~40 spilled registers; CS_SCORE_WAVES=4 for A / B timing)
-  else if (w4) hipLaunchKernelGGL(score_kernel<4>, dim3(grid8(n_valid_bound, 256)), dim3(256), 0, st, v, slot_total, sp.short_sq_bound);
-  else hipLaunchKernelGGL(score_kernel<3>, dim3(grid8(n_valid_bound, 256)), dim3(256), 0, st, v, slot_total, sp.short_sq_bound);
+  static const bool r3_form = getenv("CS_SCORE_R3") != nullptr;      // diagnostics: the round-3 kernel, for A / B timing
+  if (r3_form) hipLaunchKernelGGL(score_kernel_r3, dim3(grid8(n_valid_bound, 256)), dim3(256), 0, st, v, slot_total, sp.short_sq_bound);
+  else hipLaunchKernelGGL(score_kernel, dim3(grid8(n_valid_bound, 256)), dim3(256), 0, st, v, slot_total, sp.short_sq_bound);
 }
 // copy [src_off, src_off + count) ranges of the compacted columns into packed buffers (fallback boxes)
 __global__ __launch_bounds__(256) void gather_ranges_kernel(DetectDeviceView v, const long long* src_off, const int* count, const long long* dst_off, int n_ranges,
