@@ -32,11 +32,11 @@ namespace cs {
 int ba_chi2_blocks(int n_proj);
 void ba_launch_chi2(const BaView& v, int nb_proj, hipStream_t st);
 void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, hipStream_t st3, hipEvent_t ev_join3);
-void ba_launch_reduce(const BaView& v, double lambda, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join);
+void ba_launch_reduce(const BaView& v, const double* lambda_dev, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join);
 void ba_launch_gather_rows(const double* src, const int* idx, int n, int width, double* dst, hipStream_t st);
 void ba_launch_backsub(const BaView& v, hipStream_t st);
 int ba_scale_blocks();
-void ba_launch_scale(const BaView& v, double lambda_pose, double lambda_lm, double* partial, hipStream_t st);
+void ba_launch_scale(const BaView& v, const double* lambda_dev, double* partial, hipStream_t st);
 void ba_launch_update(const BaView& v, hipStream_t st, double* bak_cams = nullptr, double* bak_points = nullptr, double* bak_cubes = nullptr);
 void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st, bool one_sided = false);
 void ba_launch_sep_reduce(const double* S, int LD, const double* Linv, int ci, int ni, int zl, int wl, int zr, int wr, double* Y, const double* rhs, double* msg, int wm, hipStream_t st);
@@ -188,6 +188,14 @@ struct cs_ba {
   // sharded BA over RCCL (cs_ba_comm_init): the collectives are issued from here, on this handle's stream
   ncclComm_t comm = nullptr;
   DBuf<double> d_scalars;    // [chi2, LM scale term] of a trial; lambda_0's diagonal on iteration 0
+  // lambda of the current trial lives in device memory (d_lam: [lambda, lambda of the pose diagonals in LM's scale term]), copied from
+  // the pinned h_lam at the head of a trial's launch sequence: the sequence itself then never changes and is replayed as ONE hipGraph
+  // launch (trial_exec; captured on the third trial after a structure phase, dropped by the next one)
+  double* h_lam = nullptr;
+  DBuf<double> d_lam;
+  hipGraphExec_t trial_exec = nullptr;
+  int trials_on_structure = 0;
+  bool trial_graph_failed = false;
   double* h_scalars = nullptr;   // pinned mirror
   size_t scalars_cap = 0;
   // host copy of the problem description
@@ -274,6 +282,8 @@ struct cs_ba {
   std::vector<double> h_b, h_x;
   bool have_system = false;
   cs_ba_timing tm{};
+  long long tm_timed_trials = 0;   // directly launched trials of the current structure and their stage sums [reduce, factor, back-substitution, chi2]
+  double stage_sum[4] = {0, 0, 0, 0};
   cs::BaView view{};
 };
 
@@ -976,6 +986,8 @@ int finalize_structure(cs_ba* B) {
   mark("pose edges + allocations");
   B->structure_dirty = false;
   B->have_system = false;
+  if (B->trial_exec) { (void)hipGraphExecDestroy(B->trial_exec); B->trial_exec = nullptr; }   // (it holds the old buffers' addresses)
+  B->trials_on_structure = 0; B->trial_graph_failed = false; B->tm_timed_trials = 0; B->stage_sum[0] = B->stage_sum[1] = B->stage_sum[2] = B->stage_sum[3] = 0;
   return CS_OK;
 }
 
@@ -1086,16 +1098,25 @@ int share_cuboid_increments(cs_ba* B, cs_allreduce_fn fn, void* ctx) {
 
 // defer != nullptr (banded path only): everything is queued and the function returns WITHOUT synchronising; *defer then holds the
 // persistent-kernel turn, and the caller synchronises, reads *h_status, calls collect_solve_times() and releases the turn.
+// lambda of the damped solve that is about to be queued: into the pinned word and, queued on the stream, into device memory.  (Inside a
+// captured trial the copy is a node of the graph: every replay reads whatever the host left in h_lam.)
+int put_lambda(cs_ba* B, double lambda) {
+  B->h_lam[0] = lambda;
+  B->h_lam[1] = B->shard_rank == 0 ? lambda : 0.0;      // x^T (lambda x + b): the poses' lambda x^2 is counted once, on rank 0
+  BA_TRY(hipMemcpyAsync(B->d_lam.p, B->h_lam, 2 * sizeof(double), hipMemcpyHostToDevice, B->st));
+  return CS_OK;
+}
 int solve_device_sep(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn, void* ctx, std::unique_lock<std::mutex>* defer);
 int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr, void* ctx = nullptr, std::unique_lock<std::mutex>* defer = nullptr) {
   const int n = B->n_red;
   *ok = true;
   if (B->sep_mode && B->shard_n > 1) return solve_device_sep(B, lambda, ok, fn, ctx, defer);
   if (n > 0) {
+    { int rcl = put_lambda(B, lambda); if (rcl) return rcl; }
     BA_TRY(hipEventRecord(B->ev[2], B->st));
     BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (B->s_doubles + B->n_pose), B->st));
     BA_TRY(hipMemsetAsync(B->d_elim_fail.p, 0, sizeof(int), B->st));
-    cs::ba_launch_reduce(B->view, lambda, B->st, B->st2, B->ev_fork, B->ev_join);
+    cs::ba_launch_reduce(B->view, B->d_lam.p, B->st, B->st2, B->ev_fork, B->ev_join);
     if (B->ext_n > 0 && B->ext_terms_set) cs::ba_launch_ext_offdiag(B->view, B->ext_n, B->d_ext_e4.p, B->ext_Hij.p, B->st);
     BA_TRY(hipMemcpyAsync(B->h_status + 1, B->d_elim_fail.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
     BA_TRY(hipGetLastError());
@@ -1190,11 +1211,12 @@ int solve_device_sep(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn, void
   double* rhs = B->view.rhs;
   const int LDs = 2 * B->w_max;
   double* rsep = B->sepS.p + (size_t)ns * LDs;
+  { int rcl = put_lambda(B, lambda); if (rcl) return rcl; }
   BA_TRY(hipEventRecord(B->ev[2], B->st));
   BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (B->s_doubles + B->n_pose), B->st));
   BA_TRY(hipMemsetAsync(B->d_elim_fail.p, 0, sizeof(int), B->st));
   if (fn) BA_TRY(hipMemsetAsync(B->sep_msgs.p, 0, sizeof(double) * B->msg_doubles * (size_t)R, B->st));
-  cs::ba_launch_reduce(B->view, lambda, B->st, B->st2, B->ev_fork, B->ev_join);
+  cs::ba_launch_reduce(B->view, B->d_lam.p, B->st, B->st2, B->ev_fork, B->ev_join);
   BA_TRY(hipMemcpyAsync(B->h_status + 1, B->d_elim_fail.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
   BA_TRY(hipGetLastError());
   BA_TRY(hipEventRecord(B->ev[3], B->st));
@@ -1278,6 +1300,9 @@ int cs_ba_create(int device, cs_ba** out) {
   BA_TRY(hipEventCreateWithFlags(&B->ev_join3, hipEventDisableTiming));
   for (auto& e : B->ev) BA_TRY(hipEventCreate(&e));
   for (auto& e : B->sev) BA_TRY(hipEventCreate(&e));
+  BA_TRY(hipHostMalloc((void**)&B->h_lam, 2 * sizeof(double)));
+  B->h_lam[0] = B->h_lam[1] = 0.0;
+  { int rc0 = B->d_lam.alloc(2); if (rc0) return rc0; }
   BA_TRY(hipHostMalloc((void**)&B->h_status, 3 * sizeof(int)));   // [factorisation status, a cuboid block failed, separator system's status]
   B->h_status[0] = B->h_status[1] = B->h_status[2] = 0;
   BA_ROC(rocblas_create_handle(&B->blas));
@@ -1306,6 +1331,9 @@ void cs_ba_destroy(cs_ba* B) {
   B->d_info.release(); B->d_band_info.release();
   for (auto& e : B->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : B->sev) if (e) (void)hipEventDestroy(e);
+  if (B->trial_exec) (void)hipGraphExecDestroy(B->trial_exec);
+  if (B->h_lam) (void)hipHostFree(B->h_lam);
+  B->d_lam.release();
   if (B->h_status) (void)hipHostFree(B->h_status);
   if (B->h_scalars) (void)hipHostFree(B->h_scalars);
   if (B->comm) { (void)ncclCommDestroy(B->comm); g_comm_handles--; }
@@ -1787,29 +1815,85 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
       double scale = 0;
       if (stream_flow) {
         std::unique_lock<std::mutex> turn;
-        rc = solve_device(B, lambda, &ok2, nullptr, nullptr, &turn); if (rc) return rc;
         // x^T (lambda x + b): b is a per-rank partial sum, x is replicated for the poses -- their lambda x^2 term is counted once
         // (rank 0); a landmark's terms live on exactly one rank.  A failed factorisation leaves garbage in x; the update below then
         // writes garbage estimates, which the pop restores (the decision is taken after the synchronisation).
-        cs::ba_launch_scale(B->view, B->shard_rank == 0 ? lambda : 0.0, lambda, B->scale_partial.p, B->st);
-        cs::ba_launch_update(B->view, B->st, B->cams_bak.p, B->points_bak.p, B->cubes_bak.p);
-        BA_TRY(hipEventRecord(B->ev[6], B->st));
-        cs::ba_launch_chi2(B->view, B->nb_chi, B->st);
-        cs::ba_launch_sum2(B->chi_partial.p, B->n_chi_partials, B->scale_partial.p, cs::ba_scale_blocks(), B->d_scalars.p, B->st);
-        BA_TRY(hipGetLastError());
-        // [chi2, scale term, "a factorisation failed somewhere"]: one message; every rank takes the same accept / reject branch
-        if (rccl) BA_NCCL(ncclAllReduce(B->d_scalars.p, B->d_scalars.p, 3, ncclDouble, ncclSum, B->comm, B->st));
-        BA_TRY(hipMemcpyAsync(B->h_scalars, B->d_scalars.p, 3 * sizeof(double), hipMemcpyDeviceToHost, B->st));
-        BA_TRY(hipEventRecord(B->ev[7], B->st));
+        // [chi2, scale term, "a factorisation failed somewhere"]: one message; every rank takes the same accept / reject branch.
+        auto enqueue_trial = [&](std::unique_lock<std::mutex>* t) -> int {
+          bool okq = true;
+          int rq = solve_device(B, lambda, &okq, nullptr, nullptr, t); if (rq) return rq;
+          cs::ba_launch_scale(B->view, B->d_lam.p, B->scale_partial.p, B->st);
+          cs::ba_launch_update(B->view, B->st, B->cams_bak.p, B->points_bak.p, B->cubes_bak.p);
+          BA_TRY(hipEventRecord(B->ev[6], B->st));
+          cs::ba_launch_chi2(B->view, B->nb_chi, B->st);
+          cs::ba_launch_sum2(B->chi_partial.p, B->n_chi_partials, B->scale_partial.p, cs::ba_scale_blocks(), B->d_scalars.p, B->st);
+          BA_TRY(hipGetLastError());
+          if (rccl) BA_NCCL(ncclAllReduce(B->d_scalars.p, B->d_scalars.p, 3, ncclDouble, ncclSum, B->comm, B->st));
+          BA_TRY(hipMemcpyAsync(B->h_scalars, B->d_scalars.p, 3 * sizeof(double), hipMemcpyDeviceToHost, B->st));
+          BA_TRY(hipEventRecord(B->ev[7], B->st));
+          return CS_OK;
+        };
+        // The sequence is the same ~30 launches, fills and copies for every trial of a structure (lambda is read from device memory):
+        // from the third trial on it is replayed as one hipGraph launch.  Not with collectives in it unless asked for
+        // (CS_BA_GRAPH_RCCL=1: RCCL inside a captured stream is untested on this build's boxes), not with the solver's
+        // diagnostics that synchronise (CS_BAND_PROF), not when switched off (CS_BA_GRAPH=0).
+        static const bool graph_on = [] { const char* e = getenv("CS_BA_GRAPH"); return !(e && atoi(e) == 0) && getenv("CS_BAND_PROF") == nullptr; }();
+        static const bool graph_rccl = [] { const char* e = getenv("CS_BA_GRAPH_RCCL"); return e && atoi(e) != 0; }();
+        const bool want_graph = graph_on && !B->trial_graph_failed && !ext_active && (B->shard_n == 1 || (rccl && graph_rccl));
+        bool timed = true;
+        B->trials_on_structure++;
+        if (want_graph && !B->trial_exec && B->trials_on_structure >= 3) {
+          hipGraph_t g = nullptr;
+          bool ok_cap = hipStreamBeginCapture(B->st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+          if (ok_cap) {
+            std::unique_lock<std::mutex> cap_turn;   // (solve_device takes the persistent kernel's turn and hands it back; nothing runs during capture)
+            const int rq = enqueue_trial(&cap_turn);
+            B->tm.n_solves--;                        // (recorded, not run)
+            ok_cap = (hipStreamEndCapture(B->st, &g) == hipSuccess) && rq == CS_OK && g != nullptr;
+          }
+          if (ok_cap) ok_cap = hipGraphInstantiate(&B->trial_exec, g, nullptr, nullptr, 0) == hipSuccess;
+          if (g) (void)hipGraphDestroy(g);
+          if (!ok_cap) { (void)hipGetLastError(); B->trial_exec = nullptr; B->trial_graph_failed = true; }
+        }
+        if (want_graph && B->trial_exec) {
+          turn = std::unique_lock<std::mutex>(g_coop_mutex);
+          B->h_lam[0] = lambda; B->h_lam[1] = B->shard_rank == 0 ? lambda : 0.0;
+          BA_TRY(hipGraphLaunch(B->trial_exec, B->st));
+          B->tm.n_solves++;
+          timed = false;        // (phase marks: see below)
+        } else {
+          rc = enqueue_trial(&turn); if (rc) return rc;
+        }
         BA_TRY(hipStreamSynchronize(B->st));
         turn.unlock();
         if (B->h_status[0] == 0x7fffffff || (B->sep_mode && B->shard_n > 1 && B->h_status[2] == 0x7fffffff)) { cs_set_error_ba("banded solver: team not co-resident (wait timed out); set CS_BA_FORCE_DENSE=1 on a shared device"); return CS_ERR_HIP; }
         ok2 = B->h_scalars[2] == 0.0;
         tempChi = B->h_scalars[0];
         scale = ok2 ? B->h_scalars[1] : 0.0;
-        rc = collect_solve_times(B); if (rc) return rc;
-        float ms = 0;
-        BA_TRY(hipEventElapsedTime(&ms, B->ev[6], B->ev[7])); B->tm.errors_ms += ms;
+        if (timed) {
+          const cs_ba_timing t0m = B->tm;
+          rc = collect_solve_times(B); if (rc) return rc;
+          float ms = 0;
+          BA_TRY(hipEventElapsedTime(&ms, B->ev[6], B->ev[7])); B->tm.errors_ms += ms;
+          // the stage split of this structure's directly launched trials (what a replayed trial is charged if its own marks cannot be read)
+          B->tm_timed_trials++;
+          B->stage_sum[0] += B->tm.reduce_ms - t0m.reduce_ms; B->stage_sum[1] += B->tm.factor_ms - t0m.factor_ms;
+          B->stage_sum[2] += B->tm.backsub_ms - t0m.backsub_ms; B->stage_sum[3] += ms;
+        } else {
+          // a replayed trial: the phase marks are event-record nodes of the graph; where the runtime hands back their times they are read
+          // like the direct launches', otherwise the trial is charged the average split of this structure's direct launches (same
+          // kernels, same sizes) -- the wall time of the run is measured either way
+          float a = 0, b = 0, c = 0, e = 0;
+          const bool got = hipEventElapsedTime(&a, B->ev[2], B->ev[3]) == hipSuccess && hipEventElapsedTime(&b, B->ev[3], B->ev[4]) == hipSuccess &&
+                           hipEventElapsedTime(&c, B->ev[4], B->ev[5]) == hipSuccess && hipEventElapsedTime(&e, B->ev[6], B->ev[7]) == hipSuccess && a >= 0 && b > 0;
+          if (!got) {
+            (void)hipGetLastError();
+            const double n = (double)std::max<long long>(1, B->tm_timed_trials);
+            a = (float)(B->stage_sum[0] / n); b = (float)(B->stage_sum[1] / n); c = (float)(B->stage_sum[2] / n); e = (float)(B->stage_sum[3] / n);
+          }
+          B->tm.reduce_ms += a; B->tm.factor_ms += b; B->tm.backsub_ms += c; B->tm.errors_ms += e;
+          rc = collect_lin_time(B); if (rc) return rc;
+        }
         if (ext_active && ok2) { rc = ext_refresh(0); if (rc) return rc; tempChi += B->ext_chi2; }
       } else {
         rc = solve_device(B, lambda, &ok2, fn, ctx); if (rc) return rc;
@@ -1821,7 +1905,7 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
         if (ok2) {
           const int nsb = cs::ba_scale_blocks();
           std::vector<double> sp(nsb);
-          cs::ba_launch_scale(B->view, B->shard_rank == 0 ? lambda : 0.0, lambda, B->scale_partial.p, B->st);
+          cs::ba_launch_scale(B->view, B->d_lam.p, B->scale_partial.p, B->st);     // (d_lam still holds this trial's lambda: put_lambda in solve_device)
           BA_TRY(hipGetLastError());
           BA_TRY(hipMemcpyAsync(sp.data(), B->scale_partial.p, sizeof(double) * nsb, hipMemcpyDeviceToHost, B->st));
           rc = cs_ba_update(B); if (rc) return rc;   // synchronises the stream
@@ -2041,9 +2125,10 @@ static int cs_ba_get_reduced_system_impl(cs_ba* B, double lambda, double* S_dens
   if (cam_col) std::copy(B->cam_col.begin(), B->cam_col.end(), cam_col);
   if (cub_col) std::copy(B->cub_col.begin(), B->cub_col.end(), cub_col);
   if (n <= 0) return CS_OK;
+  { int rcl = put_lambda(B, lambda); if (rcl) return rcl; }
   BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (B->s_doubles + B->n_pose), B->st));
   BA_TRY(hipMemsetAsync(B->d_elim_fail.p, 0, sizeof(int), B->st));
-  cs::ba_launch_reduce(B->view, lambda, B->st, B->st2, B->ev_fork, B->ev_join);
+  cs::ba_launch_reduce(B->view, B->d_lam.p, B->st, B->st2, B->ev_fork, B->ev_join);
   if (B->ext_n > 0 && B->ext_terms_set) cs::ba_launch_ext_offdiag(B->view, B->ext_n, B->d_ext_e4.p, B->ext_Hij.p, B->st);
   BA_TRY(hipGetLastError());
   std::vector<double> h(B->s_doubles + B->n_pose);

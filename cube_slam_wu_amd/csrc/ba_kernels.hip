@@ -136,7 +136,8 @@ __global__ __launch_bounds__(64) void ba_chi2_pose_edges_kernel(BaView v, int pa
 // the pose increments (x in v.rhs, b in bcam / bcub) and the landmark increments (xl, bl); fixed-shape reduction:
 // SCALE_BLOCKS partial sums, added up by the host in order.
 enum { SCALE_BLOCKS = 256 };
-__global__ __launch_bounds__(256) void ba_scale_kernel(BaView v, double lambda_pose, double lambda_lm, double* partial) {
+__global__ __launch_bounds__(256) void ba_scale_kernel(BaView v, const double* __restrict__ lamp, double* partial) {
+  const double lambda_lm = lamp[0], lambda_pose = lamp[1];     // (lambda of the trial, read from device memory: the launch sequence of a trial is a fixed graph)
   __shared__ double ws[4];
   double acc = 0;
   const int n = v.np + v.nc + v.no;
@@ -460,7 +461,8 @@ __global__ __launch_bounds__(128) void ba_accum_pose_kernel(BaView v, int zero_c
 }
 
 // ---- Schur complement ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ba_prep_kernel(BaView v, double lambda) {
+__global__ __launch_bounds__(256) void ba_prep_kernel(BaView v, const double* __restrict__ lamp) {
+  const double lambda = lamp[0];
   int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= v.np) return;
   double D[9], Di[9];
@@ -494,7 +496,8 @@ __global__ __launch_bounds__(256) void ba_wd_kernel(BaView v) {
 }
 
 // camera part of the reduced system: S_cc = A_cc + lambda I, b_schur,c = b_c - sum_e W_e (D^-1 b_l)
-__global__ __launch_bounds__(256) void ba_cam_rhs_kernel(BaView v, double lambda) {
+__global__ __launch_bounds__(256) void ba_cam_rhs_kernel(BaView v, const double* __restrict__ lamp) {
+  const double lambda = lamp[0];
   int c = blockIdx.x;
   int col = v.cam_col[c];
   if (col < 0) return;
@@ -521,7 +524,8 @@ __global__ __launch_bounds__(256) void ba_cam_rhs_kernel(BaView v, double lambda
   }
 }
 
-__global__ __launch_bounds__(128) void ba_cub_scatter_kernel(BaView v, double lambda) {
+__global__ __launch_bounds__(128) void ba_cub_scatter_kernel(BaView v, const double* __restrict__ lamp) {
+  const double lambda = lamp[0];
   int o = blockIdx.x, t = threadIdx.x;
   int col = v.cub_col[o];
   if (col < 0) return;
@@ -712,7 +716,8 @@ __device__ __forceinline__ void ba_schur_segment(const BaView& v, double lambda,
 // one instantiation per tile count (the segments are sorted by k, so each launch covers a contiguous range): MT = 1 for k <= 2
 // (12 rows + the right-hand-side column), 2 for k <= 5 (30 + 1), 3 for k <= BA_FUSED_KMAX = 7 (42 + 1)
 template <int MT>
-__global__ __launch_bounds__(256) void ba_schur_fused_kernel(BaView v, double lambda, int seg_begin, int seg_end) {
+__global__ __launch_bounds__(256) void ba_schur_fused_kernel(BaView v, const double* __restrict__ lamp, int seg_begin, int seg_end) {
+  const double lambda = lamp[0];
   const int seg = __builtin_amdgcn_readfirstlane(seg_begin + blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform: scalar loads below
   if (seg >= seg_end) return;
   ba_schur_segment<MT>(v, lambda, seg, v.seg_k[seg]);
@@ -731,7 +736,8 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaView v) {
 }
 
 // destination schedule, right-hand side: S_cc = A_cc + lambda I and b_schur,c = b_c - sum of the camera's partial W D^-1 b_l
-__global__ __launch_bounds__(64) void ba_cam_rhs_fused_kernel(BaView v, double lambda) {
+__global__ __launch_bounds__(64) void ba_cam_rhs_fused_kernel(BaView v, const double* __restrict__ lamp) {
+  const double lambda = lamp[0];
   const int c = blockIdx.x, t = threadIdx.x;
   const int col = v.cam_col[c];
   if (col < 0) return;
@@ -752,7 +758,8 @@ __global__ __launch_bounds__(64) void ba_cam_rhs_fused_kernel(BaView v, double l
 // observing cameras, b_schur(c_a) -= M_a D_oo^-1 b_o, with M_a = the 6 x 9 camera-cuboid block summed over the edges of slot a (a
 // camera may hold an EdgeSE3Cuboid and an EdgeSE3CuboidProj to the same cuboid).  One wavefront per cuboid; the blocks and vectors go
 // to the same partial arrays as the landmark segments' and are summed by the same destination schedule.
-__global__ __launch_bounds__(256) void ba_cub_elim_kernel(BaView v, double lambda) {
+__global__ __launch_bounds__(256) void ba_cub_elim_kernel(BaView v, const double* __restrict__ lamp) {
+  const double lambda = lamp[0];
   __shared__ double M[BA_ELIM_MAX_SLOTS][54], G[BA_ELIM_MAX_SLOTS][54];
   __shared__ double A[9][9], Di[9][9], bo[9];
   const int o = blockIdx.x, t = threadIdx.x;
@@ -2310,7 +2317,7 @@ void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEv
   if (side3) (void)hipStreamWaitEvent(st, ev_join3, 0);
   hipLaunchKernelGGL(ba_accum_pose_kernel, dim3(v.nc + v.no), dim3(128), 0, st, v, 0);
 }
-void ba_launch_reduce(const BaView& v, double lambda, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join) {
+void ba_launch_reduce(const BaView& v, const double* lambda, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join) {   // lambda: device, [lambda, lambda of the pose diagonals in the scale term]
   if (v.fused) {
     // the cuboid elimination (one workgroup per cuboid, latency-bound) runs beside the landmark segments on a second stream; both
     // write disjoint ranges of the partial arrays and meet before the destination schedule reads them
@@ -2459,8 +2466,8 @@ __global__ __launch_bounds__(256) void ba_sum2_kernel(const double* a, int na, c
 void ba_launch_sum2(const double* a, int na, const double* b, int nb, double* out, hipStream_t st) {
   hipLaunchKernelGGL(ba_sum2_kernel, dim3(1), dim3(256), 0, st, a, na, b, nb, out);
 }
-void ba_launch_scale(const BaView& v, double lambda_pose, double lambda_lm, double* partial, hipStream_t st) {
-  hipLaunchKernelGGL(ba_scale_kernel, dim3(SCALE_BLOCKS), dim3(256), 0, st, v, lambda_pose, lambda_lm, partial);
+void ba_launch_scale(const BaView& v, const double* lambda, double* partial, hipStream_t st) {
+  hipLaunchKernelGGL(ba_scale_kernel, dim3(SCALE_BLOCKS), dim3(256), 0, st, v, lambda, partial);
 }
 void ba_launch_backsub(const BaView& v, hipStream_t st) {
   if (v.elim && v.no > 0) hipLaunchKernelGGL(ba_cub_backsub_kernel, dim3(v.no), dim3(64), 0, st, v);
