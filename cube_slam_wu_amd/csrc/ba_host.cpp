@@ -1833,11 +1833,13 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
           BA_TRY(hipEventRecord(B->ev[7], B->st));
           return CS_OK;
         };
-        // The sequence is the same ~30 launches, fills and copies for every trial of a structure (lambda is read from device memory):
-        // from the third trial on it is replayed as one hipGraph launch.  Not with collectives in it unless asked for
-        // (CS_BA_GRAPH_RCCL=1: RCCL inside a captured stream is untested on this build's boxes), not with the solver's
-        // diagnostics that synchronise (CS_BAND_PROF), not when switched off (CS_BA_GRAPH=0).
-        static const bool graph_on = [] { const char* e = getenv("CS_BA_GRAPH"); return !(e && atoi(e) == 0) && getenv("CS_BAND_PROF") == nullptr; }();
+        // The sequence is the same ~30 launches, fills and copies for every trial of a structure (lambda is read from device memory), so
+        // it CAN be replayed as one hipGraph launch from the third trial on -- opt-in, CS_BA_GRAPH=1.  Measured on MI355X / ROCm 7.0
+        // (tools/ba_quick.py, two boxes): the replay itself is no faster than the stream launches (the host runs ahead of the device either
+        // way; the graph's nodes carry the same dependency barriers), and the instantiation costs ~0.8 ms per structure: C4 540 / 546
+        // against 564 / 570 LM it/s, C3 1 258 against 1 415.  Not with collectives in it unless asked for (CS_BA_GRAPH_RCCL=1: RCCL
+        // inside a captured stream is untested on this build's boxes), not with the solver's diagnostics that synchronise (CS_BAND_PROF).
+        static const bool graph_on = [] { const char* e = getenv("CS_BA_GRAPH"); return e && atoi(e) != 0 && getenv("CS_BAND_PROF") == nullptr; }();
         static const bool graph_rccl = [] { const char* e = getenv("CS_BA_GRAPH_RCCL"); return e && atoi(e) != 0; }();
         const bool want_graph = graph_on && !B->trial_graph_failed && !ext_active && (B->shard_n == 1 || (rccl && graph_rccl));
         bool timed = true;
