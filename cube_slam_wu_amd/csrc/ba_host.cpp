@@ -46,7 +46,6 @@ void ba_launch_sep_backsolve(double* S, int LD, double* work, int ci, int ni, in
 void ba_launch_fail_flag(const int* a, const int* b, const int* c, double* out, hipStream_t st);
 size_t ba_band_workspace_doubles(int n, int LD);
 int ba_band_team(int LD, int* rw_out);
-int ba_band_info_ints();
 bool ba_band_fits_device(int n, int LD, bool one_sided = false);
 void ba_launch_sum2(const double* a, int na, const double* b, int nb, double* out, hipStream_t st);
 void ba_launch_ext_add(const BaView& v, const double* cam36, const double* cam6, const double* cub81, const double* cub9, const double* pt9, const double* pt3, hipStream_t st);
@@ -702,7 +701,6 @@ int finalize_structure(cs_ba* B) {
   for (int p : gorder) if (owner[p] == B->shard_rank) { const long long k = cam_cnt[p + 1] - cam_cnt[p]; B->schur_entries += k * (k + 1) / 2; }
   if (B->fused) {
     std::vector<int> run_lm, seg_ptr{0}, seg_k, seg_tile, seg_slot;
-    static const int seg_lm = [] { const char* e = getenv("CS_BA_SEG_LM"); const int q = e ? atoi(e) : 0; return (q >= 1 && q <= 64) ? q : (int)cs::BA_SEG_LM; }();   // (diagnostics: landmarks per segment)
     struct Dst { long long key; int id; };
     std::vector<Dst> dst;                      // (block key, partial block id), segment order
     std::vector<std::pair<int, int>> cdst;     // (camera, partial vector id)
@@ -728,7 +726,7 @@ int finalize_structure(cs_ba* B) {
           n_tiles += k * (k + 1) / 2; n_slots += k;
         }
         run_lm.push_back(p);
-        if (++in_seg == seg_lm) { seg_ptr.push_back((int)run_lm.size()); in_seg = 0; }
+        if (++in_seg == cs::BA_SEG_LM) { seg_ptr.push_back((int)run_lm.size()); in_seg = 0; }
       }
       if (in_seg) seg_ptr.push_back((int)run_lm.size());
     }
@@ -918,7 +916,7 @@ int finalize_structure(cs_ba* B) {
   AL(B->Dinv, 9 * (size_t)np); AL(B->dbl, 3 * (size_t)np); B->s_doubles = (size_t)B->n_red * (B->band_ld ? B->band_ld : B->n_red);
   AL(B->S, B->s_doubles + B->n_pose);   // [S | rhs]: one buffer, one all-reduce in the sharded solve
   AL(B->xl, 3 * (size_t)np);
-  AL(B->d_band_info, cs::ba_band_info_ints());  // [first bad pivot + 1, grid-barrier counters, a zero double]
+  AL(B->d_band_info, 24);  // [first bad pivot + 1, grid-barrier counters, a zero double]
   AL(B->band_linv, B->band_ld ? cs::ba_band_workspace_doubles(B->n_red, B->band_ld) : 1);   // inverted diagonal blocks (+ the separator's rows in the nested order)
   B->nb_chi = cs::ba_chi2_blocks(E);
   B->n_chi_partials = B->nb_chi + (B->n_cub + B->n_odom + 63) / 64;
@@ -930,16 +928,16 @@ int finalize_structure(cs_ba* B) {
     AL(B->sep_msgs, B->msg_doubles * (size_t)R);
     AL(B->sepS, (size_t)B->n_sep * 2 * B->w_max + B->n_sep);   // [S_sep (band of 2 w_max) | rhs_sep]
     AL(B->sep_work, cs::ba_band_workspace_doubles(B->n_sep, 2 * B->w_max));
-    AL(B->d_sep_info, cs::ba_band_info_ints());
+    AL(B->d_sep_info, 24);
     AL(B->int_work, cs::ba_band_workspace_doubles(B->int_n, B->band_ld));
-    AL(B->d_int_info, cs::ba_band_info_ints());
+    AL(B->d_int_info, 24);
     std::vector<int> sep_col(R + 1, 0);
     for (int k = 1; k < R; k++) sep_col[k] = B->cut[k];
     UP(B->d_sep_off, B->sep_off); UP(B->d_sep_col, sep_col);
     // what this rank contributes to the collectives of one LM trial: its separator message, the solution vector, three scalars
     B->bytes_per_trial = 8 * ((long long)B->msg_doubles + B->n_pose + 3);
   } else {
-    AL(B->sepY, 1); AL(B->sep_msgs, 1); AL(B->sepS, 1); AL(B->int_work, 1); AL(B->d_int_info, cs::ba_band_info_ints()); AL(B->sep_work, 1); AL(B->d_sep_info, cs::ba_band_info_ints());
+    AL(B->sepY, 1); AL(B->sep_msgs, 1); AL(B->sepS, 1); AL(B->int_work, 1); AL(B->d_int_info, 24); AL(B->sep_work, 1); AL(B->d_sep_info, 24);
     std::vector<int> none1(1, 0);
     UP(B->d_sep_off, none1); UP(B->d_sep_col, none1);
     B->bytes_per_trial = R > 1 ? 8 * ((long long)B->s_doubles + B->n_pose + 3 + (B->elim ? B->n_pose - B->n_red : 0)) : 0;
@@ -1134,7 +1132,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       // pivot flag comes home with the single synchronisation (a failed factorisation just leaves garbage increments
       // that the caller discards)
       std::unique_lock<std::mutex> coop_turn(g_coop_mutex);
-      BA_TRY(hipMemsetAsync(B->d_band_info.p, 0, cs::ba_band_info_ints() * sizeof(int), B->st));
+      BA_TRY(hipMemsetAsync(B->d_band_info.p, 0, 24 * sizeof(int), B->st));
       cs::ba_launch_band_cholesky(B->S.p, B->band_linv.p, n, B->band_ld, B->view.rhs, B->d_band_info.p, true, B->st);
       BA_TRY(hipGetLastError());
       BA_TRY(hipEventRecord(B->ev[4], B->st));
@@ -1223,7 +1221,7 @@ int solve_device_sep(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn, void
   BA_TRY(hipGetLastError());
   BA_TRY(hipEventRecord(B->ev[3], B->st));
   std::unique_lock<std::mutex> coop_turn(g_coop_mutex);
-  BA_TRY(hipMemsetAsync(B->d_int_info.p, 0, cs::ba_band_info_ints() * sizeof(int), B->st));
+  BA_TRY(hipMemsetAsync(B->d_int_info.p, 0, 24 * sizeof(int), B->st));
   // the interior: L L^T = S(I, I), y = L^-1 b_I in place (one-sided order, right-hand side riding along)
   cs::ba_launch_band_cholesky(B->S.p + (size_t)B->int_c * LD, B->int_work.p, B->int_n, LD, rhs + B->int_c, B->d_int_info.p, false, B->st, true);
   BA_TRY(hipGetLastError());
@@ -1242,7 +1240,7 @@ int solve_device_sep(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn, void
   cs::ba_launch_sep_assemble(B->sep_msgs.p, B->msg_doubles, B->w_max, R, B->d_sep_off.p, ns, LDs, B->sepS.p, rsep, B->st);
   BA_TRY(hipGetLastError());
   if (!coop_turn.owns_lock()) coop_turn.lock();
-  BA_TRY(hipMemsetAsync(B->d_sep_info.p, 0, cs::ba_band_info_ints() * sizeof(int), B->st));
+  BA_TRY(hipMemsetAsync(B->d_sep_info.p, 0, 24 * sizeof(int), B->st));
   cs::ba_launch_band_cholesky(B->sepS.p, B->sep_work.p, ns, LDs, rsep, B->d_sep_info.p, true, B->st);
   BA_TRY(hipGetLastError());
   if (fn) {

@@ -957,16 +957,12 @@ __device__ __forceinline__ void band_acquire() {
 // abort word of the launch's info block (all barrier counters and flags live in that one 96-byte, 256-byte-aligned block:
 // info[19]), marks the factorisation as failed (info[0] = INT_MAX) and every later wait of the launch returns at once.
 enum { BAND_ABORT_SLOT = 19, BAND_SPIN_LIMIT = 1 << 21, BAND_TIMEOUT_INFO = 0x7fffffff };
-// Progress flags (round 4): besides the counters above, every workgroup of a front publishes how many steps it has completed
-// (info[BAND_PROG_OFF + stride f + w], f = front index, w = its index in the team; stride 32 in the four-front kernel, 128 in the two-front one), and a step waits for the two or three workgroups whose
-// rows it reads instead of for the whole team: see band_step.  info is now BAND_INFO_INTS ints (ba_band_info_ints()), zeroed per launch.
-enum { BAND_PROG_OFF = 32, BAND_PROG_STRIDE = 32, BAND_PROG_STRIDE_COOP = 128, BAND_INFO_INTS = BAND_PROG_OFF + 2 * BAND_PROG_STRIDE_COOP };   // nested: 4 fronts x <= 32 workgroups; two-front: 2 x <= 128
-__device__ __forceinline__ void band_wait_ge(unsigned* ctr, unsigned target, unsigned* info_base = nullptr) {
+__device__ __forceinline__ void band_wait_ge(unsigned* ctr, unsigned target) {
   unsigned spins = 0;
   while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
     __builtin_amdgcn_s_sleep(1);
     if ((++spins & 1023u) == 0) {
-      unsigned* base = info_base ? info_base : reinterpret_cast<unsigned*>(reinterpret_cast<unsigned long long>(ctr) & ~127ull);
+      unsigned* base = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned long long>(ctr) & ~127ull);
       if (__hip_atomic_load(base + BAND_ABORT_SLOT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
       if (spins >= (unsigned)BAND_SPIN_LIMIT) {
         __hip_atomic_store(base + BAND_ABORT_SLOT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1289,35 +1285,6 @@ __device__ __forceinline__ void band_grid_arrive(unsigned* bar) {
   }
 }
 
-// The end of a step without a team barrier: the workgroup's panel rows are stored and drained, it publishes its step count (the
-// workgroups that read those rows wait for exactly this word) and adds itself to the team's counter, which now only says when a whole
-// PHASE is complete (count == steps x team: every workgroup contributes one per step, so the total is reached only when all are done).
-__device__ __forceinline__ void band_step_done(unsigned* my_prog, unsigned steps_done, unsigned* bar) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    band_release();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(my_prog, steps_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-// What step `step` (0-based count of the steps this team has completed before it) reads of the previous step: the 32 block rows were the
-// panel rows of workgroups 0 and 1 (own0 = k0 + nb + 16 w one step earlier is k0 + 16 w), this workgroup's own rows those of workgroup
-// w + 2; separator rows and the right-hand side row carry their own history.  Everything older is implied: a workgroup that has
-// finished step s - 1 had waited for its own sources of step s - 2, and every hand-off is a write-through store drained before the flag.
-struct BandProg { unsigned* flags; unsigned* info; int G; };      // the team's flag array, the launch's info block, panel-row workgroups
-__device__ __forceinline__ void band_wait_sources(const BandProg& pg, unsigned step, int w, bool panel_rows) {
-  if (!pg.flags || step == 0) return;
-  if (threadIdx.x == 0) {
-    band_wait_ge(pg.flags + 0, step, pg.info);
-    if (pg.G > 1) band_wait_ge(pg.flags + 1, step, pg.info);
-    if (panel_rows && w + 2 < pg.G) band_wait_ge(pg.flags + w + 2, step, pg.info);
-    band_acquire();
-  }
-  __syncthreads();
-}
-
 // One elimination step of `view`: block column k0 (nb wide), rows up to i_end, history segments s0 (the view's own
 // columns) and s1.  Workgroup roles: cw < 0: panel rows own0 = k0 + nb + RW w ... of the view (has_rhs: plus the
 // right-hand side); cw >= 0: separator rows RW cw ... of aug.  Every workgroup factorises the diagonal block itself.
@@ -1334,12 +1301,10 @@ __device__ __forceinline__ void band_gather_gemm(const BandSegX& s0, const BandS
 }
 template <bool AUG, int KID, class SEG>
 __device__ __forceinline__ void band_step(const BandLds& M, const BandView& view, const double* Linv, int k0, int nb, int i_end, const SEG& s0, const SEG& s1, int nseg,
-                                          const BandAug& aug, int w, int cw, bool has_rhs, int n, int bw, const double* zero, unsigned* dflag, unsigned dtarget, long long* tp, long long* t_prev,
-                                          const BandProg& pg = BandProg{nullptr, nullptr, 0}, unsigned step = 0) {
+                                          const BandAug& aug, int w, int cw, bool has_rhs, int n, int bw, const double* zero, unsigned* dflag, unsigned dtarget, long long* tp, long long* t_prev) {
   constexpr int RW = band_rw(KID), NR = BS + RW + 8;
   const int tid = threadIdx.x;
   const int own0 = k0 + nb + w * RW;
-  band_wait_sources(pg, step, w, cw < 0);          // (pg.flags == nullptr: the caller synchronises the team with a barrier after every step)
   if (tid < NR) {                                   // row (in the view's index space) of gathered row rr; -1 = none, -2 = right-hand side, <= -16: separator row
     int i = -1;
     if (tid < BS) i = tid < nb ? k0 + tid : -1;
@@ -1433,21 +1398,13 @@ __device__ __forceinline__ void band_diag_accum(const SEG& S, int jlo, int jhi, 
 template <int KID>
 __device__ __forceinline__ void band_diag_phase(const BandLds& M, const BandView& view, const double* Linv, int k_begin, int k_end, bool two_seg, const BandView& v1, int jhi1,
                                                 unsigned* start, unsigned start_target, unsigned* bar, unsigned G, unsigned ep0, unsigned* flag, unsigned f0,
-                                                int n, int bw, const double* zero, int* info, long long* dprof = nullptr, const BandProg& pg = BandProg{nullptr, nullptr, 0}) {
+                                                int n, int bw, const double* zero, int* info, long long* dprof = nullptr) {
   const int tid = threadIdx.x, r = tid >> 3, cq = tid & 7, lane = tid & 63, wv = tid >> 6, rg = lane >> 3, cg = lane & 7;
   long long dt_prev = dprof ? wall_clock64() : 0;      // optional phase clock of this workgroup (CS_BAND_PROF): wait, newest block + U, POTF2, publish, look-ahead
 #define BAND_DTICK(k) do { if (dprof && tid == 0) { const long long t_now = wall_clock64(); dprof[k] += t_now - dt_prev; dt_prev = t_now; } } while (0)
   auto wait_for = [&](unsigned* ctr, unsigned target) {
     if (tid == 0) {
       band_wait_ge(ctr, target);
-      band_acquire();
-    }
-    __syncthreads();
-  };
-  // progress flags a .. b - 1 of the team (those that exist) at `target` steps
-  auto wait_flags = [&](int a, int b, unsigned target) {
-    if (tid == 0) {
-      for (int q = a; q < b && q < pg.G; q++) band_wait_ge(pg.flags + q, target, pg.info);
       band_acquire();
     }
     __syncthreads();
@@ -1479,9 +1436,7 @@ __device__ __forceinline__ void band_diag_phase(const BandLds& M, const BandView
       if (two_seg) { const BandSeg s1 = seg1(k0, nb); band_diag_accum<BAND_DC>(s1, s1.jlo, s1.jhi, n, bw, k0, nb, zero, M.R, acc); }
     } else {
       BAND_DTICK(4);
-      // the newest 32 columns of the block's rows: the panel rows of workgroups 0 and 1 one step ago (round 4: their two flags, not
-      // the whole team's barrier -- the team's other rows finish beside this block's factorisation)
-      if (pg.flags) wait_flags(0, 2, ep0 + s); else wait_for(bar, (ep0 + s) * G);
+      wait_for(bar, (ep0 + s) * G);
       BAND_DTICK(0);
       band_diag_accum<BS>(s0, max(s0.jlo, k0 - BS), k0, n, bw, k0, nb, zero, M.R, acc);   // the newest block: 4 loads per thread
     }
@@ -1533,8 +1488,6 @@ __device__ __forceinline__ void band_diag_phase(const BandLds& M, const BandView
     if (k1 < k_end) {
       const int nb1 = min(BS, k_end - k1);
       const BandSeg n0{view, max(0, k1 - bw), k1, 0};
-      // (the next block's rows were the panel rows of workgroups 2 and 3 one step ago: their columns up to k0 are what is read here)
-      if (pg.flags) wait_flags(2, 4, ep0 + s);
       band_diag_accum<BAND_DC>(n0, n0.jlo, max(n0.jlo, k1 - BS), n, bw, k1, nb1, zero, M.R, acc);
       if (two_seg) { const BandSeg n1 = seg1(k1, nb1); band_diag_accum<BAND_DC>(n1, n1.jlo, n1.jhi, n, bw, k1, nb1, zero, M.R, acc); }
     }
@@ -1579,15 +1532,12 @@ __global__ __launch_bounds__(256) void band_chol_coop_kernel(const double* Sb, c
   const BandAug noaug{zero, 0, 0, 0, 0, nullptr, 0, 0, 0};
   // ---- phase 1: the two fronts, each with its own barrier (after every step, the last one included: the deferred
   // write of the diagonal block must not overtake a team-mate still reading A's block)
-  unsigned ep = 0;   // steps completed by this team
-  unsigned* const info_u = reinterpret_cast<unsigned*>(info);
-  const BandProg pg{info_u + BAND_PROG_OFF + BAND_PROG_STRIDE_COOP * team, info_u, G};     // (G <= 128: a team of ceil(bw / 16) workgroups at bw <= 1900, ba_band_fits_device)
+  unsigned ep = 0;   // barriers completed on this team's counter
   if (w == G) {
     const BandView view = team ? rev : fwd;
-    band_diag_phase<0>(M, view, team ? Linv_r : Linv_f, 0, BS * (team ? K2 : K1), false, rev, 0, nullptr, 0, bars + team, (unsigned)G, 0, dflag, 0, n, bw, zero, info, nullptr, pg);
-    // the middle block opens when both fronts have met (one-sided order: when the forward front's last step is through: its counter
-    // then stands at K1 G)
-    if (team == 0) band_diag_phase<0>(M, fwd, Linv_f, m_begin, m_end, K2 > 0, rev, BS * K2, K2 > 0 ? bars + 2 : bars + 0, K2 > 0 ? 2u * (unsigned)G : (unsigned)K1 * (unsigned)G, bars + 0, (unsigned)G, (unsigned)K1, dflag, (unsigned)K1, n, bw, zero, info, nullptr, pg);
+    band_diag_phase<0>(M, view, team ? Linv_r : Linv_f, 0, BS * (team ? K2 : K1), false, rev, 0, nullptr, 0, bars + team, (unsigned)G, 0, dflag, 0, n, bw, zero, info);
+    // the middle block opens when both fronts have met (one-sided order: when the forward front's last barrier is through)
+    if (team == 0) band_diag_phase<0>(M, fwd, Linv_f, m_begin, m_end, K2 > 0, rev, BS * K2, K2 > 0 ? bars + 2 : bars + 0, K2 > 0 ? 2u * (unsigned)G : (unsigned)K1 * (unsigned)G, bars + 0, (unsigned)G, (unsigned)K1, dflag, (unsigned)K1, n, bw, zero, info);
     return;
   }
   {
@@ -1597,9 +1547,9 @@ __global__ __launch_bounds__(256) void band_chol_coop_kernel(const double* Sb, c
     for (int kb = 0; kb < Kt; kb++) {
       const int k0 = kb * BS;
       const BandSeg s0{view, max(0, k0 - bw), k0, 0};
-      band_step<false, 0>(M, view, Linv, k0, BS, min(n, k0 + BS + bw), s0, none, 1, noaug, w, -1, has_rhs, n, bw, zero, dflag, ep + 1, tpp, &t_prev, pg, ep);
+      band_step<false, 0>(M, view, Linv, k0, BS, min(n, k0 + BS + bw), s0, none, 1, noaug, w, -1, has_rhs, n, bw, zero, dflag, ep + 1, tpp, &t_prev);
       ep++;
-      band_step_done(pg.flags + w, ep, bars + team);
+      band_grid_sync(bars + team, ep * (unsigned)G);
       BAND_TICK(5);
     }
     if (K2 > 0) {   // the fronts meet: the reverse team publishes and leaves, the forward team waits for it
@@ -1614,9 +1564,9 @@ __global__ __launch_bounds__(256) void band_chol_coop_kernel(const double* Sb, c
     const int i_end = min(m_end, k0 + nb + bw);
     const BandSeg s0{fwd, max(0, k0 - bw), k0, 0};
     const BandSeg s1{rev, max(0, (n - i_end) - bw), BS * K2, 1};     // rows i -> i' = n - 1 - i; columns of the reverse front within the band
-    band_step<false, 0>(M, fwd, Linv_f, k0, nb, i_end, s0, s1, K2 > 0 ? 2 : 1, noaug, w, -1, has_rhs, n, bw, zero, dflag, ep + 1, tpp, &t_prev, pg, ep);
+    band_step<false, 0>(M, fwd, Linv_f, k0, nb, i_end, s0, s1, K2 > 0 ? 2 : 1, noaug, w, -1, has_rhs, n, bw, zero, dflag, ep + 1, tpp, &t_prev);
     ep++;
-    band_step_done(pg.flags + w, ep, bars + 0);
+    band_grid_sync(bars + 0, ep * (unsigned)G);
     BAND_TICK(5);
   }
   if (prof && tid == 0 && (w == 0 || w == G - 1)) for (int k = 0; k < 9; k++) prof[(w == 0 ? 0 : 9) + k] = tp[k];
@@ -1682,16 +1632,14 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
   long long* tpp = (P.prof && hid == 0 && team == 1 && (wi == 0 || wi == G1 - 1)) ? tp : nullptr;   // phase clock of a panel-row and a separator-row workgroup
   if (tpp) t_prev = wall_clock64();
   unsigned ep = 0;
-  unsigned* const info_u = reinterpret_cast<unsigned*>(P.info);
-  const BandProg pg{info_u + BAND_PROG_OFF + BAND_PROG_STRIDE * (2 * hid + (team == 1)), info_u, G};    // this front's flags (team 2 reads team 1's)
   const bool stamp = P.prof && hid == 0 && team == 1 && wi == 0 && tid == 0;
 #define BAND_STAMP(k) do { if (stamp) P.prof[k] = wall_clock64(); } while (0)
   BAND_STAMP(0);
   const int nslab = P.GS, GCC = P.GC;   // Schur slabs of 16 rows; workgroups of C's own factorisation
   if (diag) {
-    if (team == 0) { band_diag_phase<1>(M, H.fv, H.Linv_f, 0, m_begin, false, H.rv, 0, nullptr, 0, bars + 0, (unsigned)G, 0, dflag, 0, nh, bw, zero, P.info, nullptr, pg); return; }
-    band_diag_phase<1>(M, H.rv, H.Linv_r, 0, Trev, false, H.fv, 0, nullptr, 0, bars + 1, (unsigned)G1, 0, dflag, 0, nh, bw, zero, P.info, (P.prof && hid == 0) ? P.prof + 34 : nullptr, pg);
-    band_diag_phase<1>(M, H.fv, H.Linv_f, m_begin, m_end, true, H.rv, Trev, bars + 2, (unsigned)(G + G1), bars + 1, (unsigned)G1, (unsigned)H.K2, dflag, (unsigned)H.K2, nh, bw, zero, P.info, nullptr, pg);
+    if (team == 0) { band_diag_phase<1>(M, H.fv, H.Linv_f, 0, m_begin, false, H.rv, 0, nullptr, 0, bars + 0, (unsigned)G, 0, dflag, 0, nh, bw, zero, P.info); return; }
+    band_diag_phase<1>(M, H.rv, H.Linv_r, 0, Trev, false, H.fv, 0, nullptr, 0, bars + 1, (unsigned)G1, 0, dflag, 0, nh, bw, zero, P.info, (P.prof && hid == 0) ? P.prof + 34 : nullptr);
+    band_diag_phase<1>(M, H.fv, H.Linv_f, m_begin, m_end, true, H.rv, Trev, bars + 2, (unsigned)(G + G1), bars + 1, (unsigned)G1, (unsigned)H.K2, dflag, (unsigned)H.K2, nh, bw, zero, P.info);
     if (hid != 0) return;
     const BandView vcd{P.SC, 1, (long long)wc, P.rhsC, 1};
     const unsigned km = (unsigned)((m_end - m_begin + BS - 1) / BS);
@@ -1702,9 +1650,9 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
     for (int kb = 0; kb < H.K1; kb++) {
       const int k0 = kb * BS;
       const BandSeg s0{H.fv, max(0, k0 - bw), k0, 0};
-      band_step<false, 1>(M, H.fv, H.Linv_f, k0, BS, min(nh, k0 + BS + bw), s0, none, 1, noaug, w, -1, has_rhs, nh, bw, zero, dflag, ep + 1, tpp, &t_prev, pg, ep);
+      band_step<false, 1>(M, H.fv, H.Linv_f, k0, BS, min(nh, k0 + BS + bw), s0, none, 1, noaug, w, -1, has_rhs, nh, bw, zero, dflag, ep + 1, tpp, &t_prev);
       ep++;
-      band_step_done(pg.flags + wi, ep, bars + 0);
+      band_grid_sync(bars + 0, ep * (unsigned)G);
     }
     band_grid_arrive(bars + 2);
     return;
@@ -1724,10 +1672,7 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
     double accy = 0.0;                       // threads 0..15: the slab's share of sum_t L(i, t) y(t)
     for (int sidx = 0; sidx < nstep; sidx++) {
       if (tid == 0) {
-        // step sidx of the front next to C: the separator-row workgroups (flags G .. G1 - 1) wrote this step's columns of lc, the last
-        // panel-row workgroup (flag G - 1) its right-hand-side entries
-        band_wait_ge(pg.flags + (G - 1), (unsigned)(sidx + 1), pg.info);
-        for (int q = G; q < G1; q++) band_wait_ge(pg.flags + q, (unsigned)(sidx + 1), pg.info);
+        band_wait_ge(bars + 1, (unsigned)(sidx + 1) * (unsigned)G1);
         band_acquire();
       }
       __syncthreads();
@@ -1774,9 +1719,9 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
     for (int kb = 0; kb < H.K2; kb++) {
       const int k0 = kb * BS;
       const BandSegX s0{{H.rv, max(0, k0 - bw), k0, 0}, 0, 0};
-      band_step<true, 1>(M, H.rv, H.Linv_r, k0, BS, min(nh, k0 + BS + bw), s0, nonex, 1, aug, w, cw, has_rhs, nh, bw, zero, dflag, ep + 1, tpp, &t_prev, pg, ep);
+      band_step<true, 1>(M, H.rv, H.Linv_r, k0, BS, min(nh, k0 + BS + bw), s0, nonex, 1, aug, w, cw, has_rhs, nh, bw, zero, dflag, ep + 1, tpp, &t_prev);
       ep++;
-      band_step_done(pg.flags + wi, ep, bars + 1);
+      band_grid_sync(bars + 1, ep * (unsigned)G1);
       if (tpp) { long long t_now = wall_clock64(); tp[5] += t_now - t_prev; t_prev = t_now; }
     }
   }
@@ -1793,9 +1738,9 @@ __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
       const int i_end = min(m_end, k0 + nb + bw);
       const BandSegX s0{{H.fv, max(0, k0 - bw), k0, 0}, Trev - m_begin, m_begin};
       const BandSegX s1{{H.rv, max(0, (nh - i_end) - bw), Trev, 1}, 0, 0};
-      band_step<true, 1>(M, H.fv, H.Linv_f, k0, nb, i_end, s0, s1, 2, aug, w, cw, has_rhs, nh, bw, zero, dflag, ep + 1, tpp, &t_prev, pg, ep);
+      band_step<true, 1>(M, H.fv, H.Linv_f, k0, nb, i_end, s0, s1, 2, aug, w, cw, has_rhs, nh, bw, zero, dflag, ep + 1, tpp, &t_prev);
       ep++;
-      band_step_done(pg.flags + wi, ep, bars + 1);
+      band_grid_sync(bars + 1, ep * (unsigned)G1);
     }
   }
   // ---- both halves (and their Schur accumulators, team 2) done
@@ -1949,7 +1894,6 @@ __global__ __launch_bounds__(256) void band_sep_correct_kernel(BandNested P) {
   }
 }
 
-int ba_band_info_ints() { return BAND_INFO_INTS; }    // size of the `info` block a launch needs (zeroed by the caller before every launch)
 int ba_band_team(int LD, int* rw_out) {   // workgroups of the factorisation team and their rows per step
   const int bw = LD - 1;
   int G = (bw + BAND_RW - 1) / BAND_RW;

@@ -14,7 +14,6 @@
 namespace cs {
 void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st, bool one_sided);
 size_t ba_band_workspace_doubles(int n, int LD);
-int ba_band_info_ints();
 }
 
 int main(int argc, char** argv) {
@@ -28,7 +27,7 @@ int main(int argc, char** argv) {
     for (int d = 1; d <= bw && c + d < n; d++) { double v = rnd(); A[(size_t)c * LD + d] = v; diag[c] += std::fabs(v); diag[c + d] += std::fabs(v); }
   for (int c = 0; c < n; c++) { A[(size_t)c * LD] = diag[c]; b[c] = rnd(); }
   double *dS, *dL, *dr; int* dinfo;
-  hipMalloc(&dS, A.size() * 8); hipMalloc(&dL, cs::ba_band_workspace_doubles(n, LD) * 8); hipMalloc(&dr, n * 8); hipMalloc(&dinfo, cs::ba_band_info_ints() * 4);
+  hipMalloc(&dS, A.size() * 8); hipMalloc(&dL, cs::ba_band_workspace_doubles(n, LD) * 8); hipMalloc(&dr, n * 8); hipMalloc(&dinfo, 96);
   hipStream_t st; hipStreamCreate(&st);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   std::vector<double> x(n);
@@ -37,7 +36,7 @@ int main(int argc, char** argv) {
     if (r > 0) { for (auto& v : A) v *= 1.25; for (int c = 0; c < n; c++) A[(size_t)c * LD] += 0.5 * r; for (auto& v : b) v = rnd(); }
     hipMemcpyAsync(dS, A.data(), A.size() * 8, hipMemcpyHostToDevice, st);
     hipMemcpyAsync(dr, b.data(), n * 8, hipMemcpyHostToDevice, st);
-    hipMemsetAsync(dinfo, 0, cs::ba_band_info_ints() * 4, st);
+    hipMemsetAsync(dinfo, 0, 96, st);
     hipEventRecord(e0, st);
     cs::ba_launch_band_cholesky(dS, dL, n, LD, dr, dinfo, true, st, argc > 4 && atoi(argv[4]) != 0);
     hipEventRecord(e1, st);
