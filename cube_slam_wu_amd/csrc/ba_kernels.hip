@@ -327,16 +327,20 @@ __device__ __forceinline__ double lane_xor16(double x) {
   return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(128) void ba_cub_edge_kernel(BaView v) {
+// (one instance per edge class -- IS3D: EdgeSE3Cuboid, the edges [0, n_cub3) of the combined list; else EdgeSE3CuboidProj, [n_cub3, n_cub) --
+// so that the bounding-box path's eight unrolled corners do not set the register budget of the 9-dim path: 196 -> 168 VGPRs, three
+// wavefronts per SIMD instead of two)
+template <bool IS3D>
+__global__ __launch_bounds__(128, 3) void ba_cub_edge_kernel(BaView v) {
   __shared__ double J[4][16][9];    // [edge in block][column d (15 = e0)][row]
   const int sub = threadIdx.x >> 5, h = threadIdx.x & 31, d = h & 15, sgn = h >> 4;
-  const int k = blockIdx.x * 4 + sub;
-  const bool live = k < v.n_cub;
+  const int k = (IS3D ? 0 : v.n_cub3) + blockIdx.x * 4 + sub;
+  const bool live = k < (IS3D ? v.n_cub3 : v.n_cub);
   const double delta = 1e-9, scalar = 1.0 / (2 * delta);
   const double step = sgn ? -delta : delta;
-  const bool is3d = k < v.n_cub3;      // EdgeSE3Cuboid, else EdgeSE3CuboidProj
+  constexpr bool is3d = IS3D;
   double (*Jq)[4] = reinterpret_cast<double (*)[4]>(&J[sub][0][0]);   // the 4-row view of this edge's column store
-  if (live && !is3d) {
+  if (!IS3D && live) {
     const int q = k - v.n_cub3;
     Pose T = pose_load(v.cams + 7 * v.ce_cam[k]);
     Cube cube = cube_load(v.cubes + 10 * v.ce_cub[k]);
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(128) void ba_cub_edge_kernel(BaView v) {
       if (sgn == 0) Jq[d][r] = d == 15 ? (act ? e1[r] : 0.0) : (on ? scalar * (e1[r] - e2) : 0.0);
     }
   }
-  if (live && is3d) {
+  if (IS3D && live) {
     Pose T = pose_load(v.cams + 7 * v.ce_cam[k]);
     Cube cube = cube_load(v.cubes + 10 * v.ce_cub[k]);
     Cube meas = cube_load(v.ce_meas + 10 * k);
@@ -2303,7 +2307,8 @@ void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEv
   hipStream_t se = side ? st2 : st;
   if (side || side3) (void)hipEventRecord(ev_fork, st);
   if (side) (void)hipStreamWaitEvent(st2, ev_fork, 0);
-  if (v.n_cub > 0) hipLaunchKernelGGL(ba_cub_edge_kernel, dim3((v.n_cub + 3) / 4), dim3(128), 0, se, v);
+  if (v.n_cub3 > 0) hipLaunchKernelGGL(ba_cub_edge_kernel<true>, dim3((v.n_cub3 + 3) / 4), dim3(128), 0, se, v);
+  if (v.n_cub > v.n_cub3) hipLaunchKernelGGL(ba_cub_edge_kernel<false>, dim3((v.n_cub - v.n_cub3 + 3) / 4), dim3(128), 0, se, v);
   if (v.n_odom > 0) hipLaunchKernelGGL(ba_odom_edge_kernel, dim3((v.n_odom + 3) / 4), dim3(64), 0, se, v);
   if (side) (void)hipEventRecord(ev_join, st2);
   if (side3) {

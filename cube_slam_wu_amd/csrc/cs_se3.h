@@ -190,13 +190,17 @@ CS_HD void cube_log_error(const Cube& self, const Cube& other, double* res) {
 // cuboid::min_log_error over yaw rotations {-90, 0, 90, 180} deg (g2o_Object.h:76-114): first minimum,
 // strict <, so a NaN norm (log of an exact 180 deg rotation) never wins unless it is candidate 0.
 CS_HD void cube_min_log_error(const Cube& self, const Cube& other, double* res) {
-  const double PI_ = 3.14159265358979323846;
+  // sin / cos of half the yaw angles (i - 1) pi / 2: glibc's values of sin(ang * 0.5), cos(ang * 0.5) (the four candidates are a LOOP on
+  // the device -- unrolled, their four independent SE3 chains cost the numeric-Jacobian kernels 197 registers and two wavefronts per SIMD)
+  const double QZ[4] = {-0x1.6a09e667f3bccp-1, 0.0, 0x1.6a09e667f3bccp-1, 1.0}, QW[4] = {0x1.6a09e667f3bcdp-1, 1.0, 0x1.6a09e667f3bcdp-1, 0x1.1a62633145c07p-54};
   double best_n = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
   for (int i = 0; i < 4; i++) {
-    double ang = (double)(i - 1) * PI_ / 2.0;
     Pose rot;
     rot.t[0] = rot.t[1] = rot.t[2] = 0;
-    rot.qx = 0; rot.qy = 0; rot.qz = sin(ang * 0.5); rot.qw = cos(ang * 0.5);
+    rot.qx = 0; rot.qy = 0; rot.qz = QZ[i]; rot.qw = QW[i];
     pose_normalize(rot);
     Cube rc;
     rc.pose = pose_mul(other.pose, rot);
