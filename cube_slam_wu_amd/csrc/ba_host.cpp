@@ -1043,7 +1043,8 @@ int collect_lin_time(cs_ba* B) {
 
 int build_system_device(cs_ba* B) {
   BA_TRY(hipEventRecord(B->ev[0], B->st));
-  cs::ba_launch_linearize(B->view, B->st, B->st2, B->ev_fork, B->ev_join, B->st3, B->ev_join3);
+  static const int lin_mode = [] { const char* e = getenv("CS_BA_LIN_STREAMS"); return e ? atoi(e) : 3; }();   // diagnostics: 3 = camera / landmark / pose-edge kernels side by side, 2 = landmark kernel behind the camera kernel, 1 = one stream
+  cs::ba_launch_linearize(B->view, B->st, lin_mode >= 2 ? B->st2 : nullptr, B->ev_fork, B->ev_join, lin_mode >= 3 ? B->st3 : nullptr, B->ev_join3);
   if (B->ext_terms_set) {
     if (B->ext_cam36.n != 36 * (size_t)B->nc || B->ext_cub81.n != 81 * (size_t)B->no || B->ext_pt9.n != 9 * (size_t)B->np) { cs_set_error_ba("external terms were set for a graph of another size: call cs_ba_set_external_terms again"); return CS_ERR_INVALID_ARG; }
     cs::ba_launch_ext_add(B->view, B->ext_has_cam ? B->ext_cam36.p : nullptr, B->ext_cam6.p, B->ext_has_cub ? B->ext_cub81.p : nullptr, B->ext_cub9.p,

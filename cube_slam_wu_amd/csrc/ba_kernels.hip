@@ -2302,14 +2302,16 @@ void ba_launch_chi2(const BaView& v, int nb_proj, hipStream_t st) {
 // Three streams: the camera kernel is one workgroup per camera (1000 at C4: a fraction of the CUs), so the landmark kernel runs
 // beside it on st3 and the numeric-Jacobian edges (cuboid, odometry) on st2; all meet before the per-vertex accumulation.
 void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, hipStream_t st3, hipEvent_t ev_join3) {
-  const bool side = st2 != nullptr && (v.n_cub > 0 || v.n_odom > 0);
+  const bool side = st2 != nullptr && v.n_cub > 0;
   const bool side3 = st3 != nullptr && ev_join3 != nullptr && v.np > 0 && (v.n_proj > 0 || v.nc > 0);
   hipStream_t se = side ? st2 : st;
   if (side || side3) (void)hipEventRecord(ev_fork, st);
   if (side) (void)hipStreamWaitEvent(st2, ev_fork, 0);
   if (v.n_cub3 > 0) hipLaunchKernelGGL(ba_cub_edge_kernel<true>, dim3((v.n_cub3 + 3) / 4), dim3(128), 0, se, v);
   if (v.n_cub > v.n_cub3) hipLaunchKernelGGL(ba_cub_edge_kernel<false>, dim3((v.n_cub - v.n_cub3 + 3) / 4), dim3(128), 0, se, v);
-  if (v.n_odom > 0) hipLaunchKernelGGL(ba_odom_edge_kernel, dim3((v.n_odom + 3) / 4), dim3(64), 0, se, v);
+  // (the odometry edges: a single short wave per four edges, 38 us of latency -- beside the cuboid edges on the main stream, not behind
+  // them on the side stream, whose 135 us are the phase's critical path)
+  if (v.n_odom > 0) hipLaunchKernelGGL(ba_odom_edge_kernel, dim3((v.n_odom + 3) / 4), dim3(64), 0, st, v);
   if (side) (void)hipEventRecord(ev_join, st2);
   if (side3) {
     (void)hipStreamWaitEvent(st3, ev_fork, 0);
