@@ -388,43 +388,75 @@ def main():
                 # definite separator system --, sums are the rank's own contribution), so every kernel of the sharded trial runs at its real
                 # size while the numbers it produces are not a solution.  The stage times are GPU events; collectives are not timed here.
                 R = args.shard_probe
-                Pp = capi.ba_from_dict(pr, device=local_rank)
-                Pp.set_shard(R // 2, R)
-                si = Pp.shard_info()
-                if si["sep_mode"]:
-                    wmx = si["w_max"]
-                    msg = 3 * wmx * wmx + 2 * wmx
-                    mine = R // 2
 
-                    def loopback(ptr, n, on_device, op):
-                        if on_device and n == msg * R:
-                            t = torch.as_tensor(capi.DeviceDoubles(ptr, n), device="cuda").view(R, msg)
-                            t.copy_(t[mine].clone().expand(R, msg))
-                            torch.cuda.synchronize()
-                        return 0
-                    Pp.optimize_sharded(1, loopback)
-                    tb0, sb0 = Pp.timing(), Pp.shard_timing()
-                    Pp.optimize_sharded(3, loopback)
-                    ta0, sa0 = Pp.timing(), Pp.shard_timing()
-                    ns_ = max(1, ta0["n_solves"] - tb0["n_solves"]); nl_ = max(1, ta0["n_linearizations"] - tb0["n_linearizations"])
-                    stg = {k: (sa0[k] - sb0[k]) / ns_ for k in sa0}
-                    lin_r, red_r = (ta0["linearize_ms"] - tb0["linearize_ms"]) / nl_, (ta0["reduce_ms"] - tb0["reduce_ms"]) / ns_
-                    lin_1, red_1 = d["linearize_ms"] / nlin, d["reduce_ms"] / nsol
-                    comm_us = 3 * 30.0       # three small collectives per trial over xGMI, latency-bound (assumed 30 us each: not measurable on one GPU)
-                    solve_r = stg["interior_factor_ms"] + stg["separator_message_ms"] + stg["separator_solve_ms"] + stg["interior_backsolve_ms"]
-                    rest_1 = (d["backsub_ms"] + d["errors_ms"] + d["update_ms"]) / max(1, nsol)
-                    it_1 = ba_el / max(1, n_it) * 1e3
-                    it_r = lin_r + red_r + solve_r + rest_1 / R + comm_us * 1e-3
-                    ba_out["sharded_projection"] = {
-                        "what": "one middle rank of %d, alone on this GPU, loop-back transport: GPU-event stage times of the separator-mode trial at C4/C5 size; the N-GPU figures below are "
-                                "arithmetic on these measured stage times, not measurements" % R,
-                        "ranks": R, "interior_unknowns": si["interior_n"], "separator_system_unknowns": si["n_sep"], "bytes_exchanged_per_trial": si["bytes_per_trial"],
-                        "bytes_exchanged_per_trial_if_band_all_reduce": si["bytes_per_trial_allreduce"],
-                        "rank_ms": {"linearize": lin_r, "schur_reduce": red_r, **stg}, "single_gpu_ms": {"linearize": lin_1, "schur_reduce": red_1, "factor_and_substitution": d["factor_ms"] / nsol},
-                        "projected_build_only_speedup": (lin_1 + red_1) / max(1e-9, lin_r + red_r),
-                        "projected_solve_speedup": (d["factor_ms"] / nsol) / max(1e-9, solve_r),
-                        "assumed_collective_latency_us": comm_us, "projected_ms_per_iteration": it_r, "projected_iteration_speedup": it_1 / max(1e-9, it_r)}
-                Pp.close()
+                def shard_probe(prx, d1, nlin1, nsol1, it_1, what):
+                    """one middle rank of R alone on this GPU (loop-back transport) against the single-GPU stage times d1 of the same problem"""
+                    Pp = capi.ba_from_dict(prx, device=local_rank)
+                    Pp.set_shard(R // 2, R)
+                    si = Pp.shard_info()
+                    out = None
+                    if si["sep_mode"]:
+                        wmx = si["w_max"]
+                        msg = 3 * wmx * wmx + 2 * wmx
+                        mine = R // 2
+
+                        def loopback(ptr, n, on_device, op):
+                            if on_device and n == msg * R:
+                                t = torch.as_tensor(capi.DeviceDoubles(ptr, n), device="cuda").view(R, msg)
+                                t.copy_(t[mine].clone().expand(R, msg))
+                                torch.cuda.synchronize()
+                            return 0
+                        Pp.optimize_sharded(1, loopback)
+                        tb0, sb0 = Pp.timing(), Pp.shard_timing()
+                        Pp.optimize_sharded(3, loopback)
+                        ta0, sa0 = Pp.timing(), Pp.shard_timing()
+                        ns_ = max(1, ta0["n_solves"] - tb0["n_solves"]); nl_ = max(1, ta0["n_linearizations"] - tb0["n_linearizations"])
+                        stg = {k: (sa0[k] - sb0[k]) / ns_ for k in sa0}
+                        lin_r, red_r = (ta0["linearize_ms"] - tb0["linearize_ms"]) / nl_, (ta0["reduce_ms"] - tb0["reduce_ms"]) / ns_
+                        lin_1, red_1 = d1["linearize_ms"] / nlin1, d1["reduce_ms"] / nsol1
+                        comm_us = 3 * 30.0       # three small collectives per trial over xGMI, latency-bound (assumed 30 us each: not measurable on one GPU)
+                        solve_r = stg["interior_factor_ms"] + stg["separator_message_ms"] + stg["separator_solve_ms"] + stg["interior_backsolve_ms"]
+                        rest_1 = (d1["backsub_ms"] + d1["errors_ms"] + d1["update_ms"]) / max(1, nsol1)
+                        it_r = lin_r + red_r + solve_r + rest_1 / R + comm_us * 1e-3
+                        out = {
+                            "what": what, "cams": len(prx["cams"]), "points": len(prx["points"]),
+                            "ranks": R, "interior_unknowns": si["interior_n"], "separator_system_unknowns": si["n_sep"], "bytes_exchanged_per_trial": si["bytes_per_trial"],
+                            "bytes_exchanged_per_trial_if_band_all_reduce": si["bytes_per_trial_allreduce"],
+                            "rank_ms": {"linearize": lin_r, "schur_reduce": red_r, **stg}, "single_gpu_ms": {"linearize": lin_1, "schur_reduce": red_1, "factor_and_substitution": d1["factor_ms"] / nsol1},
+                            "projected_build_only_speedup": (lin_1 + red_1) / max(1e-9, lin_r + red_r),
+                            "projected_solve_speedup": (d1["factor_ms"] / nsol1) / max(1e-9, solve_r),
+                            "assumed_collective_latency_us": comm_us, "single_gpu_ms_per_iteration": it_1, "projected_ms_per_iteration": it_r, "projected_iteration_speedup": it_1 / max(1e-9, it_r)}
+                    Pp.close()
+                    return out
+                sp = shard_probe(pr, d, nlin, nsol, ba_el / max(1, n_it) * 1e3,
+                                 "one middle rank of %d, alone on this GPU, loop-back transport: GPU-event stage times of the separator-mode trial at C4/C5 size; the N-GPU figures below are "
+                                 "arithmetic on these measured stage times, not measurements" % R)
+                if sp:
+                    ba_out["sharded_projection"] = sp
+                # a second, larger point of the same probe (interiors ~25x the band instead of ~5x): where the latency chains of the separator
+                # system stop dominating a rank's trial.  CS_BENCH_BA_WEAK=0 skips it (~25 s: generating 800 k points dominates).
+                if os.environ.get("CS_BENCH_BA_WEAK", "1") != "0":
+                    try:
+                        prw = synth_ba.make_problem(n_cams=4000, n_points=800000, n_cuboids=2000, seed=42)
+                        Pw = capi.ba_from_dict(prw, device=local_rank)
+                        Pw.optimize(1)
+                        tbw = Pw.timing()
+                        torch.cuda.synchronize(); t1 = time.perf_counter()
+                        nw = Pw.optimize(5)
+                        torch.cuda.synchronize(); elw = time.perf_counter() - t1
+                        taw = Pw.timing()
+                        dw = {k: taw[k] - tbw[k] for k in taw if k.endswith("_ms")}
+                        nlw = max(1, taw["n_linearizations"] - tbw["n_linearizations"]); nsw = max(1, taw["n_solves"] - tbw["n_solves"])
+                        Pw.close()
+                        spw = shard_probe(prw, dw, nlw, nsw, elw / max(1, nw) * 1e3,
+                                          "the same probe on a 4x larger trajectory (4 000 cameras, 800 k points, 2 000 cuboids): one middle rank of %d alone on this GPU against the whole problem on "
+                                          "this GPU; projected figures are arithmetic on measured stage times, not measurements" % R)
+                        if spw:
+                            spw["single_gpu_lm_iterations_per_s"] = nw / elw
+                            ba_out["sharded_projection_large"] = spw
+                        del prw
+                    except Exception as ex:
+                        ba_out["sharded_projection_large"] = {"error": repr(ex)}
             # the reference's usage pattern (main_obj.cpp:802-803): a frame is appended, then optimize(5) on the grown graph -- structure phase
             # included, because g2o pays it inside optimize() too (updateStructure)
             if world == 1 and os.environ.get("CS_BENCH_CHILD") is None:
