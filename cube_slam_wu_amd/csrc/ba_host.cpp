@@ -20,6 +20,7 @@
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <memory>
 #include <string>
 #include <mutex>
 #include <thread>
@@ -167,6 +168,23 @@ struct DBuf {
     return CS_OK;
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; cap = 0; }
+};
+
+// Host scratch of the structure phase: UNINITIALISED storage (std::vector<int>(n) zero-fills on the constructing thread, which takes the
+// page faults of a fresh multi-megabyte array one by one; the worker threads that fill these arrays then fault their own ranges side by side)
+template <class T>
+struct UBuf {
+  std::unique_ptr<T[]> p;
+  size_t n = 0;
+  UBuf() {}
+  explicit UBuf(size_t m) : p(new T[std::max<size_t>(1, m)]), n(m) {}
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  T* begin() { return p.get(); }
+  const T* begin() const { return p.get(); }
+  T* data() { return p.get(); }
+  const T* data() const { return p.get(); }
+  size_t size() const { return n; }
 };
 
 }  // namespace
@@ -346,15 +364,18 @@ int finalize_structure(cs_ba* B) {
   // gorder: free landmarks with >= 1 edge sorted by (number of cameras, camera list); run_first: where each distinct set starts
   for (int k = 0; k < B->n_proj; k++)
     if (B->e_pt[k] < 0 || B->e_pt[k] >= np || B->e_cam[k] < 0 || B->e_cam[k] >= nc) { cs_set_error_ba("projection edge index out of range"); return CS_ERR_INVALID_ARG; }
-  std::vector<int> cam_cnt(np + 1, 0), cams_of(B->n_proj), edge_of, gorder, run_first;   // edges grouped by landmark: camera (sorted by id) and caller edge index
+  std::vector<int> cam_cnt(np + 1, 0), gorder, run_first;
+  UBuf<int> cams_of((size_t)B->n_proj), edge_of((size_t)B->n_proj);   // edges grouped by landmark: camera (sorted by id) and caller edge index
   {
     for (int k = 0; k < B->n_proj; k++) cam_cnt[B->e_pt[k] + 1]++;
     for (int i = 0; i < np; i++) cam_cnt[i + 1] += cam_cnt[i];
     std::vector<int> fill(cam_cnt.begin(), cam_cnt.end() - 1);
-    edge_of.resize(B->n_proj);
-    for (int k = 0; k < B->n_proj; k++) { const int q = fill[B->e_pt[k]]++; cams_of[q] = B->e_cam[k]; edge_of[q] = k; }
     {   // every landmark's camera list sorted, its edges with it (independent little sorts: a few host threads on disjoint ranges)
+      const bool threaded = B->n_proj > 100000;
       auto sort_lists = [&](int p0, int p1) {
+        // the counting sort's fill, landmark range by landmark range: a thread scans all edges and keeps those of ITS landmarks (the
+        // edge order inside a landmark stays the caller's; the writes -- and the page faults of the two fresh arrays -- are partitioned)
+        for (int k = 0; k < B->n_proj; k++) { const int pp = B->e_pt[k]; if (pp >= p0 && pp < p1) { const int q = fill[pp]++; cams_of[q] = B->e_cam[k]; edge_of[q] = k; } }
         for (int p = p0; p < p1; p++) {
           const int a0 = cam_cnt[p], a1 = cam_cnt[p + 1];
           for (int a = a0 + 1; a < a1; a++) {      // insertion sort (a handful of edges; stable: caller order among equal cameras)
@@ -365,7 +386,7 @@ int finalize_structure(cs_ba* B) {
           }
         }
       };
-      const int NT = (B->n_proj > 100000) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+      const int NT = threaded ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
       if (NT > 1) {
         std::vector<std::thread> th;
         for (int t = 0; t < NT; t++) th.emplace_back(sort_lists, (int)((long long)np * t / NT), (int)((long long)np * (t + 1) / NT));
@@ -378,42 +399,80 @@ int finalize_structure(cs_ba* B) {
         if (cams_of[a] == cams_of[a - 1]) { cs_set_error_ba("two projection edges between the same point and camera"); return CS_ERR_INVALID_ARG; }
       if (!B->pt_fixed[p] && cam_cnt[p + 1] > cam_cnt[p]) gorder.push_back(p);
     }
-    // sort key = (number of cameras, first three camera ids) in one word: it decides almost every comparison of the sort below;
-    // the full lexicographic comparison only runs for landmarks that agree on it (same order as without the key)
-    std::vector<unsigned long long> gkey;
-    if (nc < (1 << 20)) {
-      gkey.resize(np);
-      for (int p : gorder) {
-        const int kp = cam_cnt[p + 1] - cam_cnt[p];
-        unsigned long long key = (unsigned long long)std::min(kp, 7) << 60;
-        for (int a = 0; a < 3; a++) key |= (unsigned long long)(a < kp ? cams_of[cam_cnt[p] + a] + 1 : 0) << (40 - 20 * a);
-        gkey[p] = key;
-      }
-    }
-    mark("  duplicate check + keys");
-    auto same_set = [&](int p, int q) {
-      const int kp = cam_cnt[p + 1] - cam_cnt[p];
-      return kp == cam_cnt[q + 1] - cam_cnt[q] && std::equal(cams_of.begin() + cam_cnt[p], cams_of.begin() + cam_cnt[p + 1], cams_of.begin() + cam_cnt[q]);
-    };
+    mark("  duplicate check");
+    // Group the landmarks by camera set.  A KITTI-shaped problem has ~70x fewer distinct sets than landmarks (2 862 for 200 k at C4), so
+    // instead of sorting the landmarks (9.6 ms of comparisons at C4) every thread hashes its range of landmarks into its own table of
+    // sets, the tables are merged, the few DISTINCT sets are sorted by (number of cameras, camera list), and the landmarks are laid
+    // out group by group -- in landmark order inside a group, because every thread walks its range in order and the ranges are laid
+    // down in order.  Same gorder / run_first as the sort produced.
     {
-      // (the key travels with the landmark: the comparator touches nothing else unless two landmarks agree on it)
-      struct GK { unsigned long long key; int p, k; };
-      std::vector<GK> gk(gorder.size());
-      for (size_t i = 0; i < gorder.size(); i++) { const int p = gorder[i]; gk[i] = GK{gkey.empty() ? 0ull : gkey[p], p, cam_cnt[p + 1] - cam_cnt[p]}; }
-      const bool keyed = !gkey.empty();
-      parallel_sort(gk.begin(), gk.end(), [&](const GK& x, const GK& y) {
-        if (x.k != y.k) return x.k < y.k;
-        if (keyed && x.k <= 7 && x.key != y.key) return x.key < y.key;
-        const int p = x.p, q = y.p;
-        if (std::lexicographical_compare(cams_of.begin() + cam_cnt[p], cams_of.begin() + cam_cnt[p + 1], cams_of.begin() + cam_cnt[q], cams_of.begin() + cam_cnt[q + 1])) return true;
-        if (std::lexicographical_compare(cams_of.begin() + cam_cnt[q], cams_of.begin() + cam_cnt[q + 1], cams_of.begin() + cam_cnt[p], cams_of.begin() + cam_cnt[p + 1])) return false;
-        return p < q;
-      }, (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
-      for (size_t i = 0; i < gorder.size(); i++) gorder[i] = gk[i].p;
+      const int NTg = (gorder.size() > 20000) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+      struct LGroup { int rep; std::vector<int> members; };
+      std::vector<std::vector<LGroup>> local(NTg);
+      auto set_hash = [&](int p) {
+        unsigned long long h = 1469598103934665603ull;
+        for (int a = cam_cnt[p]; a < cam_cnt[p + 1]; a++) { h ^= (unsigned)cams_of[a] + 0x9e3779b9u; h *= 1099511628211ull; }
+        return h ^ (h >> 29);
+      };
+      auto same_set = [&](int p, int q) {
+        const int kp = cam_cnt[p + 1] - cam_cnt[p];
+        return kp == cam_cnt[q + 1] - cam_cnt[q] && std::equal(cams_of.begin() + cam_cnt[p], cams_of.begin() + cam_cnt[p + 1], cams_of.begin() + cam_cnt[q]);
+      };
+      auto group_range = [&](int t) {
+        const size_t i0 = gorder.size() * t / NTg, i1 = gorder.size() * (t + 1) / NTg;
+        std::vector<LGroup>& G = local[t];
+        size_t cap = 1024;
+        std::vector<int> table(cap, -1);
+        for (size_t i = i0; i < i1; i++) {
+          const int p = gorder[i];
+          if ((G.size() + 1) * 2 > cap) {            // grow: re-insert the groups' representatives
+            cap *= 4; table.assign(cap, -1);
+            for (size_t g = 0; g < G.size(); g++) { size_t s = set_hash(G[g].rep) & (cap - 1); while (table[s] >= 0) s = (s + 1) & (cap - 1); table[s] = (int)g; }
+          }
+          size_t s = set_hash(p) & (cap - 1);
+          while (table[s] >= 0 && !same_set(G[table[s]].rep, p)) s = (s + 1) & (cap - 1);
+          if (table[s] < 0) { table[s] = (int)G.size(); G.push_back(LGroup{p, {}}); }
+          G[table[s]].members.push_back(p);
+        }
+      };
+      if (NTg > 1) { std::vector<std::thread> th; for (int t = 0; t < NTg; t++) th.emplace_back(group_range, t); for (auto& t : th) t.join(); } else group_range(0);
+      // merge: global groups = distinct sets over all threads
+      struct GGroup { int rep; std::vector<std::pair<int, int>> parts; };     // (thread, local group), thread order = landmark order
+      std::vector<GGroup> GG;
+      {
+        size_t cap = 4096;
+        std::vector<int> table(cap, -1);
+        for (int t = 0; t < NTg; t++)
+          for (size_t g = 0; g < local[t].size(); g++) {
+            const int p = local[t][g].rep;
+            if ((GG.size() + 1) * 2 > cap) {
+              cap *= 4; table.assign(cap, -1);
+              for (size_t q = 0; q < GG.size(); q++) { size_t s = set_hash(GG[q].rep) & (cap - 1); while (table[s] >= 0) s = (s + 1) & (cap - 1); table[s] = (int)q; }
+            }
+            size_t s = set_hash(p) & (cap - 1);
+            while (table[s] >= 0 && !same_set(GG[table[s]].rep, p)) s = (s + 1) & (cap - 1);
+            if (table[s] < 0) { table[s] = (int)GG.size(); GG.push_back(GGroup{p, {}}); }
+            GG[table[s]].parts.push_back({t, (int)g});
+          }
+      }
+      std::vector<int> gidx(GG.size());
+      for (size_t q = 0; q < GG.size(); q++) gidx[q] = (int)q;
+      std::sort(gidx.begin(), gidx.end(), [&](int x, int y) {
+        const int p = GG[x].rep, q = GG[y].rep;
+        const int kp = cam_cnt[p + 1] - cam_cnt[p], kq = cam_cnt[q + 1] - cam_cnt[q];
+        if (kp != kq) return kp < kq;
+        return std::lexicographical_compare(cams_of.begin() + cam_cnt[p], cams_of.begin() + cam_cnt[p + 1], cams_of.begin() + cam_cnt[q], cams_of.begin() + cam_cnt[q + 1]);
+      });
+      std::vector<int> sorted;
+      sorted.reserve(gorder.size());
+      for (int q : gidx) {
+        run_first.push_back((int)sorted.size());
+        for (auto& pt : GG[q].parts) { const std::vector<int>& m = local[pt.first][pt.second].members; sorted.insert(sorted.end(), m.begin(), m.end()); }
+      }
+      run_first.push_back((int)sorted.size());
+      gorder.swap(sorted);
     }
-    mark("  sort by camera set");
-    for (size_t i = 0; i < gorder.size(); i++) if (i == 0 || !same_set(gorder[i - 1], gorder[i])) run_first.push_back((int)i);
-    run_first.push_back((int)gorder.size());
+    mark("  group by camera set");
   }
   mark("camera sets");
   // ---- cuboid / odometry edge indices are used below: check them first
@@ -522,11 +581,19 @@ int finalize_structure(cs_ba* B) {
   auto band_ok = [&](const Ordering& O) { return !B->force_dense && O.n_red > 128 && O.bw + 1 <= O.n_red / 2 && cs::ba_band_fits_device(O.n_red, O.bw + 1); };
   auto cost = [&](const Ordering& O) { return band_ok(O) ? (double)O.n_red * (O.bw + 1.0) * (O.bw + 1.0) : (double)O.n_red * O.n_red * O.n_red / 3.0; };
   {
-    Ordering keep_o = make_ordering(false);
     // (an external binary edge on a cuboid couples it to something besides its observing cameras: the cuboids then stay in the system)
     const bool try_elim = fused_ok && n_free_cub > 0 && max_slots <= cs::BA_ELIM_MAX_SLOTS && getenv("CS_BA_KEEP_CUBOIDS") == nullptr && !ext_binary_on_cuboid;
-    Ordering elim_o;
-    if (try_elim) elim_o = make_ordering(true);
+    // (the two candidate orderings only read shared data: g2o's system on a second thread while this one orders the cameras-only system)
+    Ordering keep_o, elim_o;
+    if (try_elim && nc + no > 64) {
+      std::thread keep_th([&] { keep_o = make_ordering(false); });
+      struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } keep_join{keep_th};
+      elim_o = make_ordering(true);
+      keep_th.join();
+    } else {
+      keep_o = make_ordering(false);
+      if (try_elim) elim_o = make_ordering(true);
+    }
     // (an ordering without unknowns -- every camera fixed, the driver's frame-0 graph -- is not a candidate: nothing would be
     // factorised and the cuboids' elimination / back-substitution hang off the reduced solve)
     B->elim = try_elim && elim_o.n_red > 0 && cost(elim_o) < cost(keep_o);
@@ -605,6 +672,7 @@ int finalize_structure(cs_ba* B) {
   int rc;
 #define UP(buf, vec) do { rc = (buf).upload_staged(vec, B->stage, B->st); if (rc) return rc; } while (0)
 #define AL(buf, n) do { rc = (buf).alloc(n, B->st); if (rc) return rc; } while (0)
+#define UPB(buf, ub) do { rc = (buf).upload_ptr((ub).data(), (ub).size()); if (rc) return rc; } while (0)
   UP(B->d_cam_col, B->cam_col); UP(B->d_cub_col, B->cub_col); UP(B->d_pt_free, pt_free);
   { std::vector<int> e4(B->ext_e4); if (e4.empty()) e4.assign(4, 0); UP(B->d_ext_e4, e4); }
   // ---- projection edges: point-major order (sorted by pose column inside a point), camera-major copy.  The edges are already
@@ -614,7 +682,7 @@ int finalize_structure(cs_ba* B) {
   for (int p = 0; p < np; p++) pt_ptr[p + 1] = pt_ptr[p] + (owner[p] == B->shard_rank ? cam_cnt[p + 1] - cam_cnt[p] : 0);
   const int E = pt_ptr[np];   // local edges
   B->pm_of_orig.assign(B->n_proj, -1);
-  std::vector<int> pm_pt(E), pm_cam(E), src_of_slot(E);
+  UBuf<int> pm_pt((size_t)E), pm_cam((size_t)E), src_of_slot((size_t)E);
   const int NTH = (E > 100000) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
   {
     auto build_points = [&](int p0, int p1) {
@@ -641,7 +709,8 @@ int finalize_structure(cs_ba* B) {
   }
   mark("  point-major order");
   // camera-major: a stable counting sort of the point-major slots by camera, the slots cut into NTH ranges (per-range histograms)
-  std::vector<int> cm_pm(E), cm_pt(E), cam_ptr(nc + 1, 0);
+  UBuf<int> cm_pm((size_t)E), cm_pt((size_t)E);
+  std::vector<int> cam_ptr(nc + 1, 0);
   {
     std::vector<std::vector<int>> hist(NTH, std::vector<int>(nc, 0));
     auto count = [&](int t) { for (int sl = (int)((long long)E * t / NTH), s1 = (int)((long long)E * (t + 1) / NTH); sl < s1; sl++) hist[t][pm_cam[sl]]++; };
@@ -658,13 +727,13 @@ int finalize_structure(cs_ba* B) {
     cam_ptr[nc] = run;
     run_threads(fillr);
   }
-  UP(B->cm_pm, cm_pm);
+  UPB(B->cm_pm, cm_pm);
   mark("  index arrays (point-major, camera-major)");
   {
     DBuf<double>& raw_uv = B->raw_uv; DBuf<double>& raw_info = B->raw_info; DBuf<double>& raw_intr = B->raw_intr; DBuf<double>& raw_huber = B->raw_huber;
     DBuf<int> d_src;
     struct Free { DBuf<int>* e; ~Free() { e->release(); } } guard{&d_src};
-    UP(d_src, src_of_slot);
+    UPB(d_src, src_of_slot);
     AL(B->pm_uv, 2 * (size_t)E); AL(B->pm_info, 4 * (size_t)E); AL(B->pm_intr, 4 * (size_t)E); AL(B->pm_huber, (size_t)E);
     AL(B->cm_uv, 2 * (size_t)E); AL(B->cm_info, 4 * (size_t)E); AL(B->cm_intr, 4 * (size_t)E); AL(B->cm_huber, (size_t)E);
     cs::ba_launch_gather_rows(raw_uv.p, d_src.p, E, 2, B->pm_uv.p, B->st);
@@ -678,7 +747,7 @@ int finalize_structure(cs_ba* B) {
     BA_TRY(hipGetLastError());
     BA_TRY(hipStreamSynchronize(B->st));
   }
-  UP(B->pm_pt, pm_pt); UP(B->pm_cam, pm_cam); UP(B->pt_ptr, pt_ptr);
+  UPB(B->pm_pt, pm_pt); UPB(B->pm_cam, pm_cam); UP(B->pt_ptr, pt_ptr);
   {   // kernel kinds of the projection edges in both orders -- only if some edge has a kernel other than Huber
     bool generic = false;
     for (int kd : B->rk_proj) if (kd != cs::RK_NONE && kd != cs::RK_HUBER) { generic = true; break; }
@@ -689,7 +758,7 @@ int finalize_structure(cs_ba* B) {
       UP(B->d_pm_rk, pk); UP(B->d_cm_rk, ck);
     } else { B->d_pm_rk.release(); B->d_cm_rk.release(); }
   }
-  UP(B->cm_pt, cm_pt); UP(B->cam_ptr, cam_ptr);
+  UPB(B->cm_pt, cm_pt); UP(B->cam_ptr, cam_ptr);
   mark("edge orderings + upload");
   // ---- Schur pattern (block_solver.hpp:262-292).  Fused path: segments of landmarks with one camera set + the destination
   // schedule of their partial blocks (BaView::fused).  It needs every landmark to be seen by <= BA_FUSED_KMAX cameras; otherwise
@@ -956,6 +1025,7 @@ int finalize_structure(cs_ba* B) {
   AL(B->cams_bak, 7 * (size_t)nc); AL(B->points_bak, 3 * (size_t)np); AL(B->cubes_bak, 10 * (size_t)no);
 #undef UP
 #undef AL
+#undef UPB
   cs::BaView& v = B->view;
   v.cams = B->cams.p; v.points = B->points.p; v.cubes = B->cubes.p; v.cam_col = B->d_cam_col.p; v.cub_col = B->d_cub_col.p; v.pt_free = B->d_pt_free.p;
   v.nc = nc; v.np = np; v.no = no; v.n_pose = B->n_pose; v.n_red = B->n_red; v.elim = B->elim ? 1 : 0;
