@@ -843,7 +843,8 @@ int finalize_structure(cs_ba* B) {
     AL(B->cub_M, 54 * cubS_cam.size()); AL(B->cub_Dinv, 81 * (size_t)std::max(1, no)); AL(B->d_elim_fail, 1);
     B->n_seg = (int)seg_k.size();
     for (int sgi = 0; sgi < B->n_seg; sgi++) { if (seg_k[sgi] <= 2) B->seg_class[0] = sgi + 1; if (seg_k[sgi] <= 5) B->seg_class[1] = sgi + 1; }   // segments are sorted by k
-    std::stable_sort(dst.begin(), dst.end(), [](const Dst& x, const Dst& y) { return x.key < y.key; });
+    // by destination block, the partial blocks of one destination in creation (= segment) order: ids grow with creation, so (key, id) is the stable order
+    parallel_sort(dst.begin(), dst.end(), [](const Dst& x, const Dst& y) { return x.key != y.key ? x.key < y.key : x.id < y.id; }, (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
     std::vector<int> gp_ptr, gp_i1, gp_i2, gtile(dst.size());
     for (size_t i = 0; i < dst.size(); i++) {
       if (i == 0 || dst[i].key != dst[i - 1].key) { gp_ptr.push_back((int)i); gp_i1.push_back((int)(dst[i].key / NP)); gp_i2.push_back((int)(dst[i].key % NP)); }
