@@ -15,7 +15,7 @@
 #include <opencv2/imgproc/imgproc.hpp>
 
 #include <cstring>
-#include <stdexcept>
+#include <iostream>
 #include <string>
 #include <vector>
 
@@ -68,7 +68,9 @@ class detect_3d_cuboid {
 
   void detect_cuboid(const cv::Mat& rgb_img, const Eigen::Matrix4d& transToWolrd, const Eigen::MatrixXd& obj_bbox_coors,
                      Eigen::MatrixXd edges, std::vector<ObjectSet>& all_object_cuboids) {
-    ensure_detector();
+    const int n_boxes_in = (int)obj_bbox_coors.rows();
+    // (the reference's detect_cuboid is void and has no error channel: it prints and leaves empty object sets.  Same here: no throw.)
+    if (!ensure_detector()) { all_object_cuboids.assign((size_t)n_boxes_in, ObjectSet()); return; }
     set_cam_pose(transToWolrd);
     cam_pose_raw = cam_pose;  // :79
     cv::Mat gray;
@@ -101,7 +103,11 @@ class detect_3d_cuboid {
     std::vector<cs_cuboid> out((size_t)n * max_cuboid_num);
     std::vector<int> counts(n);
     int rc = cs_detect_cuboids(det_, &fr, out.data(), counts.data());
-    if (rc != CS_OK) throw std::runtime_error(std::string("cs_detect_cuboids: ") + cs_last_error());
+    if (rc != CS_OK) {
+      std::cerr << "detect_3d_cuboid (HIP): cs_detect_cuboids: " << cs_last_error() << std::endl;
+      for (int i = 0; i < n; i++) all_object_cuboids[i].clear();
+      return;
+    }
     for (int i = 0; i < n; i++) {
       all_object_cuboids[i].clear();
       for (int k = 0; k < counts[i]; k++) {
@@ -156,18 +162,23 @@ class detect_3d_cuboid {
            a.weight_skew_error == b.weight_skew_error && a.pre_merge_dist_thre == b.pre_merge_dist_thre && a.pre_merge_angle_thre == b.pre_merge_angle_thre &&
            a.edge_length_threshold == b.edge_length_threshold && a.host_threads == b.host_threads;
   }
-  void ensure_detector() {
+  bool ensure_detector() {
     cs_detect_params p{};
     cs_detect_default_params(&p);
     p.consider_config_1 = consider_config_1; p.consider_config_2 = consider_config_2;
     p.whether_sample_cam_roll_pitch = whether_sample_cam_roll_pitch; p.whether_sample_bbox_height = whether_sample_bbox_height;
     p.max_cuboid_num = max_cuboid_num; p.nominal_skew_ratio = nominal_skew_ratio; p.max_cut_skew = max_cut_skew;
     const int slot = whether_sample_cam_roll_pitch ? 1 : 0;
-    if (dets_[slot] && same_params(p, last_[slot])) { det_ = dets_[slot]; return; }
+    if (dets_[slot] && same_params(p, last_[slot])) { det_ = dets_[slot]; return true; }
     if (dets_[slot]) cs_detector_destroy(dets_[slot]);
     dets_[slot] = nullptr;
-    if (cs_detector_create(&p, 0, &dets_[slot]) != CS_OK) throw std::runtime_error(std::string("cs_detector_create: ") + cs_last_error());
+    if (cs_detector_create(&p, 0, &dets_[slot]) != CS_OK) {
+      std::cerr << "detect_3d_cuboid (HIP): cs_detector_create: " << cs_last_error() << std::endl;
+      dets_[slot] = nullptr; det_ = nullptr;
+      return false;
+    }
     last_[slot] = p;
     det_ = dets_[slot];
+    return true;
   }
 };

@@ -11,7 +11,7 @@
 #include <opencv2/core/core.hpp>
 #include <opencv2/imgproc/imgproc.hpp>
 
-#include <stdexcept>
+#include <iostream>
 #include <string>
 #include <vector>
 
@@ -19,10 +19,8 @@
 
 class line_lbd_detect {
  public:
-  explicit line_lbd_detect(int numoctaves = 1, float octaveratio = 1) : numoctaves_(numoctaves), octaveratio_(octaveratio), use_LSD(false), line_length_thres(50) {
-    if (cs_detector_create(nullptr, 0, &det_) != CS_OK) throw std::runtime_error(std::string("cs_detector_create: ") + cs_last_error());
-  }
-  ~line_lbd_detect() { cs_detector_destroy(det_); }
+  explicit line_lbd_detect(int numoctaves = 1, float octaveratio = 1) : numoctaves_(numoctaves), octaveratio_(octaveratio), use_LSD(false), line_length_thres(50) {}
+  ~line_lbd_detect() { if (det_) cs_detector_destroy(det_); }
   line_lbd_detect(const line_lbd_detect&) = delete;
   line_lbd_detect& operator=(const line_lbd_detect&) = delete;
 
@@ -32,7 +30,10 @@ class line_lbd_detect {
   float line_length_thres;   // line_lbd_allclass.cpp:147: 50 by default, 15 in the graph driver
 
   void detect_filter_lines(const cv::Mat& img, cv::Mat& linesmat_out) {
-    if (numoctaves_ != 1) throw std::runtime_error("line_lbd_detect (HIP): one octave, as the graph driver uses it");
+    // (the reference's detect_filter_lines is void and has no error channel; a failure here prints and hands back no segments)
+    linesmat_out.create(0, 4, CV_32FC1);
+    if (numoctaves_ != 1) { std::cerr << "line_lbd_detect (HIP): one octave only, as the graph driver uses it (main_obj.cpp:502)" << std::endl; return; }
+    if (!det_ && cs_detector_create(nullptr, 0, &det_) != CS_OK) { std::cerr << "line_lbd_detect (HIP): cs_detector_create: " << cs_last_error() << std::endl; det_ = nullptr; return; }
     cv::Mat gray;
     if (img.channels() != 1) cv::cvtColor(img, gray, cv::COLOR_BGR2GRAY);     // BinaryDescriptor::detectImpl, binary_descriptor.cpp:489-495
     else gray = img;
@@ -41,7 +42,7 @@ class line_lbd_detect {
     int n = 0;
     const int rc = use_LSD ? cs_detect_lsd_gray(det_, gray.data, gray.cols, gray.rows, (double)line_length_thres, seg.data(), kCap, &n)
                            : cs_detect_lines_gray(det_, gray.data, gray.cols, gray.rows, (double)line_length_thres, seg.data(), kCap, &n);
-    if (rc != CS_OK) throw std::runtime_error(std::string(use_LSD ? "cs_detect_lsd_gray: " : "cs_detect_lines_gray: ") + cs_last_error());
+    if (rc != CS_OK) { std::cerr << "line_lbd_detect (HIP): " << (use_LSD ? "cs_detect_lsd_gray: " : "cs_detect_lines_gray: ") << cs_last_error() << std::endl; return; }
     linesmat_out.create(n, 4, CV_32FC1);                                        // keylines_to_mat, line_lbd_allclass.cpp:33-43
     for (int j = 0; j < n; j++) for (int c = 0; c < 4; c++) linesmat_out.at<float>(j, c) = seg[4 * (size_t)j + c];
   }
