@@ -25,8 +25,12 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / d) if d > 0 else float(np.abs(a - b).max() if a.size else 0.0)
 
 
-def compare_linearisation(G, R, pr, lam, with_solve=True):
-    """G: cube_slam_wu_amd.capi.BaProblem, R: oracle.ba_oracle_py.Problem on the same problem dict pr (both at the same estimates)."""
+def compare_linearisation(G, R, pr, lam, with_solve=True, one_thread=False):
+    """G: cube_slam_wu_amd.capi.BaProblem, R: oracle.ba_oracle_py.Problem on the same problem dict pr (both at the same estimates).
+    one_thread: factorise the oracle's S on ONE thread and report the seconds (bench.py's cpu_baseline prices the reference's dense
+    solve with it: LAPACK's blocked dpotrf on the real 10 494-unknown matrix, measured instead of extrapolated)."""
+    import contextlib
+    import time
     import scipy.linalg
 
     out = {}
@@ -98,8 +102,17 @@ def compare_linearisation(G, R, pr, lam, with_solve=True):
     del S_ref, S_dev, S_g
     if with_solve:
         ok_g, x_g = G.solve(lam)
-        c, low = scipy.linalg.cho_factor(S_r, lower=True, overwrite_a=True, check_finite=False)
-        xp = scipy.linalg.cho_solve((c, low), bs_r, check_finite=False)
+        limit = contextlib.nullcontext()
+        if one_thread:
+            from threadpoolctl import threadpool_limits
+            limit = threadpool_limits(limits=1)
+        with limit:
+            t0 = time.perf_counter()
+            c, low = scipy.linalg.cho_factor(S_r, lower=True, overwrite_a=True, check_finite=False)
+            xp = scipy.linalg.cho_solve((c, low), bs_r, check_finite=False)
+            out["dense_solve_seconds"] = time.perf_counter() - t0
+            out["dense_solve_threads"] = 1 if one_thread else 0      # 0 = LAPACK's default thread count
+            out["dense_solve_unknowns"] = int(n_pose)
         x_r = R.backsub(lam, xp)
         out["solve_ok"] = bool(ok_g)
         out["x_pose"] = _rel(x_g[:n_pose], x_r[:n_pose])

@@ -1,5 +1,6 @@
-#!/bin/bash
-# steady-state frames/s against the workgroup size of rank_kernel (diagnostics: CS_RANK_THREADS)
-for nt in 256 128 64 256 128 64; do
-  CS_RANK_THREADS=$nt python bench.py --no-measure-traffic --steps 8 --warmup 3 --steady-steps 200 --ba none --no-cpu-baseline --no-edge --rp-frames 0 --latency-calls 0 --lines-images 0 2>/dev/null | tail -1 | python -c "import json,sys; o=json.load(sys.stdin); print('rank threads $nt: steady %.0f frames/s  rank_kernel %.3f ms per sweep (events, 4 in flight)' % (o['steady_state']['value'], o['stage_ms_per_step']['rank_kernel_ms']))"
+ARGS="--no-measure-traffic --ba none --no-cpu-baseline --no-edge --rp-frames 0 --latency-calls 0 --lines-images 0 --steady-steps 0"
+for nt in 256 128 64; do
+  export CS_RANK_THREADS=$nt
+  echo "== rank threads $nt"
+  for rep in 1 2 3; do python bench.py $ARGS --steps 80 --warmup 8 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('   frames/s %.0f  ms/step %.3f' % (d['value'], d['ms_per_step']))"; done
 done
