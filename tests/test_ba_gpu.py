@@ -765,6 +765,24 @@ def test_band_solver_harness_shapes():
             assert len(res) == 2 and max(res) < 1e-12 and infos == [0, 0], (n, ld, env, out.stdout)
 
 
+def test_band_window_resident_fronts_opt_in():
+    """CS_BAND_WIN=1: the window-resident fronts (csrc/band_win.h: one workgroup per front, the active window in matrix-core accumulator
+    registers) instead of the cooperative kernels, for bandwidths up to 128 -- one front (the sharded interiors' order), two fronts with
+    the join through the dumps, and the nested order with separator-row workgroups; partial last blocks, every block reach D = 1 .. 4."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "build_tmp", "band_bench")
+    if not os.path.exists(exe):
+        import __graft_entry__
+        __graft_entry__.build()
+    for n, ld, one_sided in [(5994, 120, 0), (630, 120, 1), (600, 109, 0), (2500, 97, 0), (300, 60, 0), (129, 40, 0), (4000, 33, 0), (3000, 128, 0), (3001, 129, 0),
+                             (2000, 64, 1), (1217, 100, 0), (2049, 33, 0), (4097, 2, 0), (1500, 65, 0)]:
+        out = subprocess.run([exe, str(n), str(ld), "3", str(one_sided)], capture_output=True, text=True, timeout=300, env={**os.environ, "CS_BAND_WIN": "1"})
+        assert out.returncode == 0, out.stderr
+        lines = [l for l in out.stdout.splitlines() if l.startswith("rep")]
+        assert len(lines) == 3 and all(float(l.split("residual")[1].split()[0]) < 1e-12 and int(l.split("info")[1].split()[0]) == 0 for l in lines), (n, ld, out.stdout)
+
+
 def test_band_write_through_handoffs_equal_the_fenced_build_bitwise():
     """The persistent band kernels hand values between workgroups (other XCDs) through write-through stores + drained counters
     (BAND_WT = 1) instead of agent-scope release / acquire fences.  The same kernels built with BAND_WT = 0 (plain stores, fences:
