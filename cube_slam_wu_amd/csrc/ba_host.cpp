@@ -9,6 +9,8 @@
 // Eigen::LDLT, solvers/linear_solver_dense.h:104-111).  There is no CPU fallback.
 #include <hip/hip_runtime.h>
 #include <rocsolver/rocsolver.h>
+
+#include "ba_sparse.h"
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -244,6 +246,13 @@ struct cs_ba {
   int n_pose = 0, n_lm = 0;
   int n_red = 0;            // dimension of the system the solver factorises: n_pose, or the cameras' part when the cuboids are eliminated too
   bool elim = false;        // free cuboids eliminated like landmarks (single rank, fused Schur schedule)
+  // general sparse Cholesky of the reduced system (ba_sparse.h): graphs the ordering cannot band
+  bool sparse = false;
+  cs::SparsePlan sp_plan;
+  DBuf<int> sp_ndim, sp_ncol, sp_sptr, sp_srow, sp_sroff, sp_prow, sp_rbase, sp_rent, sp_rptr, sp_rcol, sp_rpos, sp_order, sp_info;
+  DBuf<long long> sp_poff;
+  DBuf<double> sp_L, sp_xs;
+  DBuf<unsigned> sp_done, sp_xdone;
   DBuf<int> d_cub_mine;     // sharded + eliminated cuboids: 1 = this rank owns the cuboid (holds all its edges)
   DBuf<int> d_cubS_ptr, d_cubS_cam, d_ce_slot, d_cub_tile, d_cub_coef, d_elim_fail, d_slotE_ptr, d_slotE_idx;
   DBuf<double> cub_M, cub_Dinv;
@@ -516,7 +525,7 @@ int finalize_structure(cs_ba* B) {
   }
   bool fused_ok = getenv("CS_BA_SCHUR_PAIRS") == nullptr;
   for (int p : gorder) if (cam_cnt[p + 1] - cam_cnt[p] > cs::BA_FUSED_KMAX) { fused_ok = false; break; }
-  struct Ordering { std::vector<int> cam_col, cub_col; int n_red = 0, bw = 0; };
+  struct Ordering { std::vector<int> cam_col, cub_col; int n_red = 0, bw = 0; std::vector<std::vector<int>> adj; std::vector<int> free_ids; };
   auto make_ordering = [&](bool elim) -> Ordering {
     Ordering O;
     O.cam_col.assign(nc, -1); O.cub_col.assign(no, -1);
@@ -574,6 +583,8 @@ int finalize_structure(cs_ba* B) {
       for (int w : adj[v]) { int lo = std::min(vcol(v), vcol(w)); int hi = (vcol(v) > vcol(w)) ? vcol(v) + vdim(v) - 1 : vcol(w) + vdim(w) - 1; bw = std::max(bw, hi - lo); }
     }
     O.bw = bw;
+    O.free_ids = order;          // (for the sparse plan: the block graph of the free vertices)
+    O.adj = std::move(adj);
     return O;
   };
   // banded path only where the persistent kernel's team is guaranteed to be resident on THIS device (occupancy query x CUs:
@@ -600,6 +611,33 @@ int finalize_structure(cs_ba* B) {
     const Ordering& O = B->elim ? elim_o : keep_o;
     B->cam_col = O.cam_col; B->cub_col = O.cub_col; B->n_red = O.n_red;
     B->band_ld = band_ok(O) ? O.bw + 1 : 0;
+    // A general sparse factorisation (fill-reducing order of the block graph, ba_sparse.h) where it is the fastest of the three.  The
+    // estimates are fits to measurements on MI355X (tools/ba_mesh_quick.py): banded -- n / 64 dependent steps of
+    // (10 + 0.043 bw) us; dense rocSOLVER potrf -- n^3 / 3 at 11 Tflop/s + 1 ms; sparse -- 40 us per level of the elimination tree +
+    // 17 ms per Gflop (it is a latency chain of small columns, not a throughput kernel).  The plan (an O(N^2) minimum-degree sweep) is only
+    // built when the alternative costs more than 5 ms.  CS_BA_SPARSE=0 never, =1 whenever the plan fits.
+    B->sparse = false;
+    {
+      const char* e = getenv("CS_BA_SPARSE");
+      const int mode = e ? atoi(e) : -1;
+      const double nn = (double)O.n_red;
+      const double est_band = B->band_ld ? nn / 64.0 * (10.0 + 0.043 * (B->band_ld - 1)) * 1e-3 : 1e30, est_dense = nn * nn * nn / 3.0 / 11e12 * 1e3 + 1.0;
+      const double est_other = std::min(est_band, est_dense);
+      const bool consider = mode != 0 && !B->force_dense && B->shard_n == 1 && O.n_red >= 256 && (mode == 1 || est_other > 5.0);
+      if (consider) {
+        std::vector<int> dim(nc + no, 0), col(nc + no, 0);
+        for (int v : O.free_ids) { dim[v] = v < nc ? 6 : 9; col[v] = v < nc ? O.cam_col[v] : O.cub_col[v - nc]; }
+        cs::SparsePlan plan;
+        const bool fits = cs::sparse_plan_build(O.adj, O.free_ids, dim, col, cs::sparse_max_panel_doubles(), 0.35, plan) && cs::sparse_fits_device(cs::sparse_max_panel_doubles(), plan.N);
+        const double est_sparse = 0.04 * plan.levels + 17.0 * plan.flops * 2e-9;
+        if (prof && fits) fprintf(stderr, "[ba structure] sparse plan: %d vertices, %d levels, %lld values (%.1f%% of the dense triangle), largest panel %d, %.2f Gflop; estimates ms: sparse %.1f, band %.1f, dense %.1f\n",
+                                  plan.N, plan.levels, plan.nvals, 100.0 * plan.nvals / (0.5 * nn * nn), plan.max_panel, plan.flops * 2e-9, est_sparse, est_band < 1e29 ? est_band : -1.0, est_dense);
+        if (fits && (mode == 1 || est_sparse < est_other)) {
+          B->sparse = true; B->band_ld = 0;
+          B->sp_plan = std::move(plan);
+        }
+      }
+    }
   }
   // ---- sharded: the column cut (separator mode) and who owns what
   mark("ordering (RCM)");
@@ -993,6 +1031,13 @@ int finalize_structure(cs_ba* B) {
   AL(B->chi_partial, B->n_chi_partials);
   AL(B->scale_partial, (size_t)cs::ba_scale_blocks());
   AL(B->d_info, 1);
+  if (B->sparse) {
+    const cs::SparsePlan& SP = B->sp_plan;
+    UP(B->sp_ndim, SP.ndim); UP(B->sp_ncol, SP.ncol); UP(B->sp_sptr, SP.sptr); UP(B->sp_srow, SP.srow); UP(B->sp_sroff, SP.sroff); UP(B->sp_prow, SP.prow);
+    UP(B->sp_rbase, SP.rbase); UP(B->sp_rent, SP.rent); UP(B->sp_rptr, SP.rptr); UP(B->sp_order, SP.order); UP(B->sp_poff, SP.poff);
+    { std::vector<int> v_rcol(SP.rcol), v_rpos(SP.rpos); if (v_rcol.empty()) { v_rcol.push_back(0); v_rpos.push_back(0); } UP(B->sp_rcol, v_rcol); UP(B->sp_rpos, v_rpos); }
+    AL(B->sp_L, (size_t)SP.nvals); AL(B->sp_xs, 9 * (size_t)(SP.N + 1)); AL(B->sp_done, (size_t)SP.N + 1); AL(B->sp_xdone, (size_t)SP.N + 2); AL(B->sp_info, 2);
+  }
   if (B->sep_mode) {
     AL(B->sepY, (size_t)(B->wl + B->wr) * B->int_n);
     AL(B->sep_msgs, B->msg_doubles * (size_t)R);
@@ -1222,6 +1267,29 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       BA_TRY(hipStreamSynchronize(B->st));
       if (*B->h_status == 0x7fffffff) {   // a workgroup waited ~1 s for its team: the device is shared with another persistent kernel
         cs_set_error_ba("banded solver: team not co-resident (wait timed out); set CS_BA_FORCE_DENSE=1 on a shared device");
+        return CS_ERR_HIP;
+      }
+      if (B->h_status[0] != 0 || B->h_status[1] != 0) *ok = false;
+    } else if (B->sparse) {
+      // general sparse: the pattern's blocks are gathered from the dense S by the factorisation itself (sparse_kernels.hip)
+      std::unique_lock<std::mutex> coop_turn(g_coop_mutex);
+      BA_TRY(hipMemsetAsync(B->sp_info.p, 0, 2 * sizeof(int), B->st));
+      cs::SparseView SV;
+      SV.N = B->sp_plan.N; SV.n = n;
+      SV.ndim = B->sp_ndim.p; SV.ncol = B->sp_ncol.p; SV.sptr = B->sp_sptr.p; SV.srow = B->sp_srow.p; SV.sroff = B->sp_sroff.p; SV.prow = B->sp_prow.p;
+      SV.rbase = B->sp_rbase.p; SV.rent = B->sp_rent.p; SV.rptr = B->sp_rptr.p; SV.rcol = B->sp_rcol.p; SV.rpos = B->sp_rpos.p; SV.order = B->sp_order.p; SV.poff = B->sp_poff.p;
+      SV.S = B->S.p; SV.rhs = B->view.rhs; SV.L = B->sp_L.p; SV.xs = B->sp_xs.p; SV.done = B->sp_done.p; SV.xdone = B->sp_xdone.p; SV.info = B->sp_info.p;
+      cs::launch_sparse_cholesky(SV, cs::sparse_max_panel_doubles(), B->st);
+      BA_TRY(hipGetLastError());
+      BA_TRY(hipEventRecord(B->ev[4], B->st));
+      cs::ba_launch_backsub(B->view, B->st);
+      BA_TRY(hipGetLastError());
+      { int rc2 = share_cuboid_increments(B, fn, ctx); if (rc2) return rc2; }
+      BA_TRY(hipEventRecord(B->ev[5], B->st));
+      BA_TRY(hipMemcpyAsync(B->h_status, B->sp_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
+      BA_TRY(hipStreamSynchronize(B->st));
+      if (*B->h_status == 0x7fffffff) {
+        cs_set_error_ba("sparse solver: grid not co-resident (wait timed out); set CS_BA_SPARSE=0 on a shared device");
         return CS_ERR_HIP;
       }
       if (B->h_status[0] != 0 || B->h_status[1] != 0) *ok = false;
@@ -2234,6 +2302,17 @@ int cs_ba_reduced_size(cs_ba* B, int* n_reduced, int* cuboids_eliminated) {
   if (cuboids_eliminated) *cuboids_eliminated = B->elim ? 1 : 0;
   return CS_OK;
   BA_GUARD_END("cs_ba_reduced_size")
+}
+
+int cs_ba_solver_path(cs_ba* B, int* path, int* bandwidth, double* sparse_fill) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  BA_GUARD_BEGIN
+  int rc = finalize_structure(B); if (rc) return rc;
+  if (path) *path = B->band_ld ? CS_BA_PATH_BAND : (B->sparse ? CS_BA_PATH_SPARSE : CS_BA_PATH_DENSE);
+  if (bandwidth) *bandwidth = B->band_ld ? B->band_ld - 1 : 0;
+  if (sparse_fill) *sparse_fill = B->sparse ? (double)B->sp_plan.nvals / (0.5 * (double)B->n_red * (double)B->n_red) : 0.0;
+  return CS_OK;
+  BA_GUARD_END("cs_ba_solver_path")
 }
 
 int cs_ba_schur_layout(cs_ba* B, int* fused, int* n_segments, int* n_partial_blocks, int* n_blocks) {

@@ -1,0 +1,139 @@
+// ba_sparse.h -- general sparse Cholesky of the reduced pose system, for graphs reverse Cuthill-McKee cannot band (2-D covisibility
+// meshes, many loop closures): what the reference leaves to Eigen::SimplicialLDLT behind a fill-reducing block ordering
+// (g2o/solvers/linear_solver_eigen.h:94-232, blockOrdering + AMD).  Host side: the SYMBOLIC phase, once per structure --
+//   * minimum-degree elimination of the block graph (vertices = free cameras / cuboids, 6 or 9 unknowns each); eliminating a vertex joins
+//     its remaining neighbours, which at that moment are exactly the rows of its column of L;
+//   * per column j its row structure, per row i the columns k < i that update it (left-looking), a processing order by elimination-tree level;
+//   * storage: column j of L is a dense PANEL, rows = [the diagonal block | the blocks below it | one row for the right-hand side], dj wide.
+// Device side (sparse_kernels.hip): one persistent kernel factorises (a workgroup per column, columns taken in level order, a column waits
+// for the flags of the columns that update it), the right-hand side riding along as a row of every panel; a second one substitutes backwards.
+// The values come from the densely assembled S (ba_types.h: S[r n + c], lower triangle): the sparse path replaces rocSOLVER's potrf / potrs only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <iterator>
+#include <cstdint>
+#include <vector>
+
+namespace cs {
+
+struct SparsePlan {
+  int N = 0;                          // vertices (elimination positions 0 .. N - 1; position N is the right-hand side's pseudo-vertex, 1 wide)
+  std::vector<int> ndim, ncol;        // per position: unknowns, first column in S (and in the right-hand side)
+  std::vector<int> sptr, srow, sroff; // per position: entries below the diagonal (positions ascending, the pseudo-vertex N last) and their first row in the panel
+  std::vector<int> prow, rbase, rent; // rows of the panel; first index of the panel's rows in rent; per row: the entry it belongs to (-1: diagonal block)
+  std::vector<long long> poff;        // first value of the panel in L
+  std::vector<int> rptr, rcol, rpos;  // per position j: the columns k < j with L(j, k) != 0 (ascending) and j's entry index in column k
+  std::vector<int> order;             // processing order: by level (longest chain of updating columns), then by position
+  long long nvals = 0; int max_panel = 0, levels = 0;
+  double flops = 0;                   // multiply-adds of the numeric factorisation
+};
+
+// adj: symmetric adjacency of the block graph over ids 0 .. adj.size() - 1; `verts`: the ids that take part (free vertices), dim / col per id.
+// Returns false when the plan would not pay (fill above max_fill of the dense triangle) or a panel would not fit the kernel's LDS.
+inline bool sparse_plan_build(const std::vector<std::vector<int>>& adj, const std::vector<int>& verts, const std::vector<int>& dim, const std::vector<int>& col,
+                              int max_panel_doubles, double max_fill, SparsePlan& P) {
+  const int N = (int)verts.size();
+  P = SparsePlan();
+  P.N = N;
+  if (N == 0) return false;
+  std::vector<int> local(adj.size(), -1);
+  for (int a = 0; a < N; a++) local[verts[a]] = a;
+  std::vector<std::vector<int>> nb(N);
+  for (int a = 0; a < N; a++) {
+    for (int w : adj[verts[a]]) if (local[w] >= 0 && local[w] != a) nb[a].push_back(local[w]);
+    std::sort(nb[a].begin(), nb[a].end());
+    nb[a].erase(std::unique(nb[a].begin(), nb[a].end()), nb[a].end());
+  }
+  // ---- minimum degree (weighted by unknowns), plain elimination graph: N is a few thousand at most
+  std::vector<int> pos(N, -1), at(N);
+  std::vector<char> gone(N, 0);
+  std::vector<std::vector<int>> colstruct(N);      // by elimination position: local ids of the rows below
+  std::vector<long long> deg(N);
+  auto weight = [&](int a) { long long s = 0; for (int w : nb[a]) s += dim[verts[w]]; return s; };
+  for (int a = 0; a < N; a++) deg[a] = weight(a);
+  std::vector<int> merged;
+  long long total_rows = 0;
+  for (int step = 0; step < N; step++) {
+    int best = -1;
+    for (int a = 0; a < N; a++) if (!gone[a] && (best < 0 || deg[a] < deg[best])) best = a;
+    pos[best] = step; at[step] = best; gone[best] = 1;
+    colstruct[step] = nb[best];
+    const std::vector<int>& S = colstruct[step];
+    for (int u : S) {
+      // nb[u] = (nb[u] U S) \ {u, best}
+      merged.clear();
+      std::set_union(nb[u].begin(), nb[u].end(), S.begin(), S.end(), std::back_inserter(merged));
+      merged.erase(std::remove_if(merged.begin(), merged.end(), [&](int w) { return w == u || w == best; }), merged.end());
+      nb[u].swap(merged);
+      deg[u] = weight(u);
+    }
+    for (int u : S) total_rows += dim[verts[u]];
+    nb[best].clear(); nb[best].shrink_to_fit();
+  }
+  // ---- by position
+  P.ndim.resize(N + 1); P.ncol.resize(N + 1);
+  for (int j = 0; j < N; j++) { P.ndim[j] = dim[verts[at[j]]]; P.ncol[j] = col[verts[at[j]]]; }
+  P.ndim[N] = 1; P.ncol[N] = 0;
+  P.sptr.assign(N + 1, 0); P.prow.resize(N); P.poff.resize(N); P.rbase.resize(N);
+  long long nvals = 0, nrows = 0, n_unk = 0;
+  double flops = 0, dense_tri = 0;
+  for (int j = 0; j < N; j++) n_unk += P.ndim[j];
+  dense_tri = 0.5 * (double)n_unk * (double)n_unk;
+  for (int j = 0; j < N; j++) {
+    std::vector<int> rows;
+    for (int u : colstruct[j]) rows.push_back(pos[u]);
+    std::sort(rows.begin(), rows.end());
+    rows.push_back(N);
+    P.sptr[j + 1] = P.sptr[j] + (int)rows.size();
+    int r = P.ndim[j];
+    for (int i : rows) { P.srow.push_back(i); P.sroff.push_back(r); r += P.ndim[i]; }
+    P.prow[j] = r; P.poff[j] = nvals; P.rbase[j] = (int)nrows;
+    nvals += (long long)r * P.ndim[j]; nrows += r;
+    P.max_panel = std::max(P.max_panel, r * P.ndim[j]);
+    flops += 0.5 * (double)r * (double)r * P.ndim[j];
+  }
+  P.nvals = nvals; P.flops = flops;
+  if (P.max_panel > max_panel_doubles) return false;
+  if ((double)nvals > max_fill * dense_tri) return false;
+  P.rent.resize(nrows);
+  for (int j = 0; j < N; j++) {
+    int* re = P.rent.data() + P.rbase[j];
+    for (int a = 0; a < P.ndim[j]; a++) re[a] = -1;
+    for (int t = P.sptr[j]; t < P.sptr[j + 1]; t++)
+      for (int a = 0; a < P.ndim[P.srow[t]]; a++) re[P.sroff[t] + a] = t - P.sptr[j];
+  }
+  // ---- who updates whom (left-looking), levels, order
+  std::vector<int> cnt(N + 1, 0);
+  for (int k = 0; k < N; k++) for (int t = P.sptr[k]; t < P.sptr[k + 1]; t++) if (P.srow[t] < N) cnt[P.srow[t] + 1]++;
+  P.rptr.assign(N + 1, 0);
+  for (int j = 0; j < N; j++) P.rptr[j + 1] = P.rptr[j] + cnt[j + 1];
+  P.rcol.resize(P.rptr[N]); P.rpos.resize(P.rptr[N]);
+  std::vector<int> fill(P.rptr.begin(), P.rptr.end() - 1);
+  for (int k = 0; k < N; k++)
+    for (int t = P.sptr[k]; t < P.sptr[k + 1]; t++) { const int i = P.srow[t]; if (i < N) { P.rcol[fill[i]] = k; P.rpos[fill[i]] = t - P.sptr[k]; fill[i]++; } }
+  std::vector<int> level(N, 0);
+  for (int j = 0; j < N; j++) for (int u = P.rptr[j]; u < P.rptr[j + 1]; u++) level[j] = std::max(level[j], level[P.rcol[u]] + 1);
+  P.order.resize(N);
+  for (int j = 0; j < N; j++) P.order[j] = j;
+  std::stable_sort(P.order.begin(), P.order.end(), [&](int a, int b) { return level[a] < level[b]; });
+  for (int j = 0; j < N; j++) P.levels = std::max(P.levels, level[j] + 1);
+  return true;
+}
+
+// device side (sparse_kernels.hip)
+struct SparseView {
+  int N, n;                           // vertices; unknowns (S is n x n)
+  const int *ndim, *ncol, *sptr, *srow, *sroff, *prow, *rbase, *rent, *rptr, *rcol, *rpos, *order;
+  const long long* poff;
+  const double* S; double* rhs;       // assembled system; right-hand side in, solution out
+  double* L; double* xs;              // panels; the solution by elimination position (N x 9)
+  unsigned* done; unsigned* xdone;    // per position: factorised / solved (zeroed by the launcher)
+  int* info;                          // [0]: first non-positive pivot + 1 (0x7fffffff: a wait timed out), [1]: abort word
+};
+bool sparse_fits_device(int max_panel_doubles, int N);
+int sparse_max_panel_doubles();
+void launch_sparse_cholesky(const SparseView& V, int max_panel_doubles, hipStream_t st);
+
+}  // namespace cs

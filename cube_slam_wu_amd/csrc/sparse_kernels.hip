@@ -1,0 +1,208 @@
+// sparse_kernels.hip -- numeric phase of the general sparse Cholesky of the reduced pose system (plan: ba_sparse.h).
+//
+//   sparse_chol_kernel     persistent; workgroup w takes the columns order[w], order[w + G], ... (level order: everything a column waits
+//                          for sits earlier in the order, so a grid that is resident as a whole cannot deadlock).  Column j: the panel
+//                          (rows = diagonal block, blocks below, right-hand side row) is gathered from the dense S into LDS, every column
+//                          k with L(j, k) != 0 subtracts L(rows >= j of k, k) L(j, k)^T (rows found through a vertex -> panel-row map in
+//                          LDS), the diagonal block is factorised, the rows below are scaled by L_jj^-T -- the right-hand side's row
+//                          becomes y_j -- and the panel is written through to memory before the column's flag is raised.
+//   sparse_back_kernel     L^T x = y the same way in the reverse order, a wavefront per column.
+// Hand-offs between workgroups follow the banded solver's protocol (ba_kernels.hip): write-through stores, drained, then a flag; the
+// consumer polls the flag, takes one agent-scope acquire and reads with plain loads.  Waits are bounded (~1 s): a starved grid fails.
+#include <hip/hip_runtime.h>
+
+#include "ba_sparse.h"
+
+namespace cs {
+
+namespace {
+enum { SP_T = 256, SP_SPIN_LIMIT = 1 << 21, SP_TIMEOUT = 0x7fffffff };
+
+__device__ __forceinline__ void sp_gstore(double* p, double v) {
+  __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool sp_wait(const unsigned* flag, int* info) {   // false: aborted
+  unsigned spins = 0;
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 1023u) == 0) {
+      if (__hip_atomic_load(info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+      if (spins >= (unsigned)SP_SPIN_LIMIT) {
+        __hip_atomic_store(info + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(info, (int)SP_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+  return true;
+}
+__device__ __forceinline__ void sp_publish(unsigned* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(SP_T) void sparse_chol_kernel(SparseView V, int panel_cap) {
+  extern __shared__ double sp_lds[];
+  double* P = sp_lds;                                   // the panel, row-major, dj doubles per row
+  double* Ljk = P + panel_cap;                          // 2 x 81: L(j, k), two buffers
+  double* Dj = Ljk + 162;                               // 81: L_jj (lower, row-major)
+  int* map = reinterpret_cast<int*>(Dj + 81);           // vertex position -> first row of its block in the panel (N + 1 entries)
+  __shared__ int s_ok;
+  const int tid = threadIdx.x, N = V.N, n = V.n;
+  for (int idx = blockIdx.x; idx < N; idx += gridDim.x) {
+    const int j = V.order[idx], dj = V.ndim[j], cj = V.ncol[j], e0 = V.sptr[j], nent = V.sptr[j + 1] - e0, rows = V.prow[j];
+    const int* rentj = V.rent + V.rbase[j];
+    __syncthreads();                                    // (the previous column's LDS is free)
+    if (tid == 0) map[j] = 0;
+    for (int t = tid; t < nent; t += SP_T) map[V.srow[e0 + t]] = V.sroff[e0 + t];
+    // ---- the panel's original entries
+    for (int e = tid; e < rows * dj; e += SP_T) {
+      const int rho = e / dj, b = e - rho * dj, t = rentj[rho];
+      double v;
+      if (t < 0) {
+        v = rho >= b ? V.S[(size_t)(cj + rho) * n + cj + b] : 0.0;
+      } else {
+        const int i = V.srow[e0 + t];
+        if (i == N) v = V.rhs[cj + b];
+        else {
+          const int rs = V.ncol[i] + (rho - V.sroff[e0 + t]), cs_ = cj + b;
+          v = rs >= cs_ ? V.S[(size_t)rs * n + cs_] : V.S[(size_t)cs_ * n + rs];
+        }
+      }
+      P[e] = v;
+    }
+    __syncthreads();
+    // ---- the columns that update this one, in ascending order (a fixed order: the sums are reproducible).  (Tried: L(j, k) of the next
+    // column loaded and the flag after it polled while the current one is applied, one barrier per column instead of three -- slower, 62 ->
+    // 73 ms on a 1 919-camera mesh: waiting AHEAD stalls the columns that are ready behind the one that is still being factorised.)
+    for (int u = V.rptr[j]; u < V.rptr[j + 1]; u++) {
+      const int k = V.rcol[u], t0 = V.rpos[u], dk = V.ndim[k], ek = V.sptr[k];
+      if (tid == 0) {
+        s_ok = sp_wait(V.done + k, V.info) ? 1 : 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+      if (!s_ok) return;
+      const double* Lk = V.L + V.poff[k];
+      const int row0 = V.sroff[ek + t0], R = V.prow[k] - row0;
+      if (tid < dj * dk) Ljk[tid] = Lk[(size_t)row0 * dk + tid];
+      __syncthreads();
+      const int* rentk = V.rent + V.rbase[k] + row0;
+      for (int e = tid; e < R * dj; e += SP_T) {
+        const int rho = e / dj, b = e - rho * dj, t = rentk[rho];
+        const int i = V.srow[ek + t], a = row0 + rho - V.sroff[ek + t];
+        const double* src = Lk + (size_t)(row0 + rho) * dk;
+        double s = 0.0;
+        for (int c = 0; c < dk; c++) s = fma(src[c], Ljk[b * dk + c], s);
+        P[(map[i] + a) * dj + b] -= s;
+      }
+      __syncthreads();
+    }
+    // ---- the diagonal block (dj <= 9: one thread), then every row below times L_jj^-T
+    if (tid == 0) {
+      int bad = 0;
+      for (int c = 0; c < dj; c++) {
+        double d = P[c * dj + c];
+        for (int q = 0; q < c; q++) d = fma(-Dj[c * 9 + q], Dj[c * 9 + q], d);
+        if (!(d > 0.0)) { bad = 1; d = 1.0; }
+        const double l = sqrt(d), inv = 1.0 / l;
+        Dj[c * 9 + c] = l;
+        for (int r = c + 1; r < dj; r++) {
+          double v = P[r * dj + c];
+          for (int q = 0; q < c; q++) v = fma(-Dj[r * 9 + q], Dj[c * 9 + q], v);
+          Dj[r * 9 + c] = v * inv;
+        }
+      }
+      if (bad) atomicCAS(V.info, 0, cj + 1);
+    }
+    __syncthreads();
+    double* Lj = V.L + V.poff[j];
+    for (int rho = tid; rho < rows; rho += SP_T) {
+      double x[9];
+      if (rho < dj) {
+        for (int c = 0; c < dj; c++) x[c] = c <= rho ? Dj[rho * 9 + c] : 0.0;
+      } else {
+        for (int c = 0; c < dj; c++) {
+          double v = P[rho * dj + c];
+          for (int q = 0; q < c; q++) v = fma(-x[q], Dj[c * 9 + q], v);
+          x[c] = v / Dj[c * 9 + c];
+        }
+      }
+      for (int c = 0; c < dj; c++) sp_gstore(Lj + (size_t)rho * dj + c, x[c]);
+    }
+    sp_publish(V.done + j);
+  }
+}
+
+// x_j = L_jj^-T (y_j - sum over the blocks below of L(i, j)^T x_i), columns in the reverse of the factorisation's order, a wavefront each
+__global__ __launch_bounds__(64) void sparse_back_kernel(SparseView V) {
+  const int lane = threadIdx.x, N = V.N;
+  for (int idx = N - 1 - (int)blockIdx.x; idx >= 0; idx -= (int)gridDim.x) {
+    const int j = V.order[idx], dj = V.ndim[j], cj = V.ncol[j], e0 = V.sptr[j], nent = V.sptr[j + 1] - e0 - 1;   // (without the right-hand side's entry)
+    const double* Lj = V.L + V.poff[j];
+    // the factorisation is complete (kernel boundary); wait for the solution of the vertices below
+    double acc[9];
+    for (int c = 0; c < 9; c++) acc[c] = 0.0;
+    for (int t = 0; t < nent; t++) {
+      const int i = V.srow[e0 + t], di = V.ndim[i], r0 = V.sroff[e0 + t];
+      if (lane == 0) { if (!sp_wait(V.xdone + i, V.info)) acc[0] = __builtin_nan(""); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+      __builtin_amdgcn_wave_barrier();
+      if (__hip_atomic_load(V.info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+      if (lane < di) {
+        const double xi = V.xs[(size_t)i * 9 + lane];
+        for (int c = 0; c < dj; c++) acc[c] = fma(Lj[(size_t)(r0 + lane) * dj + c], xi, acc[c]);
+      }
+    }
+    for (int c = 0; c < dj; c++) {
+      double v = acc[c];
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+      acc[c] = v;
+    }
+    if (lane == 0) {
+      const double* yrow = Lj + (size_t)(V.prow[j] - 1) * dj;   // the right-hand side's row: y_j
+      double x[9];
+      for (int c = dj - 1; c >= 0; c--) {
+        double v = yrow[c] - acc[c];
+        for (int q = c + 1; q < dj; q++) v = fma(-Lj[(size_t)q * dj + c], x[q], v);
+        x[c] = v / Lj[(size_t)c * dj + c];
+      }
+      for (int c = 0; c < dj; c++) { sp_gstore(V.xs + (size_t)j * 9 + c, x[c]); V.rhs[cj + c] = x[c]; }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(V.xdone + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+}  // namespace
+
+int sparse_max_panel_doubles() { return 16384; }   // 128 KB of the 160 KB LDS: panels of up to ~1 800 rows x 9
+static size_t sparse_lds_bytes(int panel_cap, int N) { return (size_t)(panel_cap + 243) * sizeof(double) + (size_t)(N + 2) * sizeof(int); }
+
+// the factorisation's workgroups wait for each other: the grid must be resident as a whole
+static int sparse_grid(int panel_cap, int N) {
+  int dev = 0, occ = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  const size_t lds = sparse_lds_bytes(panel_cap, N);
+  if (lds > 156 * 1024) return 0;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_chol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sparse_chol_kernel, SP_T, lds) != hipSuccess || occ < 1) return 0;
+  return std::min(N, occ * prop.multiProcessorCount);
+}
+bool sparse_fits_device(int max_panel_doubles, int N) { return sparse_grid(max_panel_doubles, N) > 0; }
+
+void launch_sparse_cholesky(const SparseView& V, int max_panel_doubles, hipStream_t st) {
+  const int G = sparse_grid(max_panel_doubles, V.N);
+  if (G <= 0) return;
+  (void)hipMemsetAsync(V.done, 0, sizeof(unsigned) * (size_t)V.N, st);
+  (void)hipMemsetAsync(V.xdone, 0, sizeof(unsigned) * (size_t)(V.N + 1), st);
+  hipLaunchKernelGGL(sparse_chol_kernel, dim3(G), dim3(SP_T), sparse_lds_bytes(max_panel_doubles, V.N), st, V, max_panel_doubles);
+  int occ = 0, dev = 0;
+  hipDeviceProp_t prop;
+  (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&prop, dev);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sparse_back_kernel, 64, 0) != hipSuccess || occ < 1) occ = 1;
+  hipLaunchKernelGGL(sparse_back_kernel, dim3(std::min(V.N, occ * prop.multiProcessorCount)), dim3(64), 0, st, V);
+}
+
+}  // namespace cs

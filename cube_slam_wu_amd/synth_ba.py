@@ -205,3 +205,65 @@ def make_problem(n_cams=200, n_points=20000, n_cuboids=50, seed=42, huber=True, 
         ce_meas=np.array(ce_meas).reshape(-1, 10), ce_info=np.array(ce_info).reshape(-1, 81),
         oe_i=oe_i, oe_j=oe_j, oe_meas=oe_meas, oe_info=oe_info,
         truth=dict(cams=T_cw_true, cuboids=cub_true, points=pts))
+
+
+def make_mesh_problem(nx=16, ny=16, n_points=20000, seed=7, spacing=(7.0, 2.5), height=12.0, huber=True):
+    """A survey flight instead of a street: nx x ny cameras on a grid, all looking straight down at the ground from `height`, every
+    landmark seen by the cameras whose image it falls into -- the covisibility graph of the cameras is a 2-D MESH (each camera shares
+    landmarks with its neighbours in both directions), which no ordering turns into a narrow band: the case of a general sparse
+    reduced solve (the reference: Eigen::SimplicialLDLT behind g2o's LinearSolverEigen, solvers/linear_solver_eigen.h:94-232).
+    Odometry edges follow the flight lines (boustrophedon).  Same dictionary as make_problem, without cuboids."""
+    rng = np.random.default_rng(seed)
+    n_cams = nx * ny
+    gx, gy = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+    order = []
+    for i in range(nx):                      # boustrophedon: the camera index follows the flight path
+        col = [(i, j) for j in range(ny)]
+        order += col if i % 2 == 0 else col[::-1]
+    order = np.array(order)
+    sx, sy = spacing
+    pos = np.stack([order[:, 0] * sx, order[:, 1] * sy, np.full(n_cams, height)], 1).astype(float)
+    pos[:, :2] += rng.normal(0, 0.3, (n_cams, 2))
+    # camera axes in the world: x right = +x, y (image down) = -y, z forward = -z (down)
+    R_wc = np.tile(np.array([[1.0, 0, 0], [0, -1.0, 0], [0, 0, -1.0]]), (n_cams, 1, 1))
+    q_wc = quat_from_R(R_wc)
+    T_wc = np.concatenate([pos, q_wc], 1)
+    T_cw_true = pose_inv(T_wc)
+    half_w, half_h = height * (IMG_W / 2) / FX, height * (IMG_H / 2) / FY
+    pts = np.stack([rng.uniform(-half_w, (nx - 1) * sx + half_w, n_points), rng.uniform(-half_h, (ny - 1) * sy + half_h, n_points), rng.uniform(0.0, 1.0, n_points)], 1)
+    e_pt, e_cam, e_uv = [], [], []
+    seen = np.zeros(n_points, int)
+    for c in range(n_cams):
+        p = quat_rot(T_cw_true[c, 3:], pts) + T_cw_true[c, :3]
+        z = p[:, 2]
+        u = FX * p[:, 0] / np.where(z > 0.1, z, 1) + CX
+        v = FY * p[:, 1] / np.where(z > 0.1, z, 1) + CY
+        ok = np.nonzero((z > 0.5) & (u >= 0) & (u < IMG_W) & (v >= 0) & (v < IMG_H))[0]
+        e_pt.append(ok); e_cam.append(np.full(len(ok), c)); e_uv.append(np.stack([u[ok], v[ok]], 1))
+        seen[ok] += 1
+    e_pt = np.concatenate(e_pt); e_cam = np.concatenate(e_cam); e_uv = np.concatenate(e_uv)
+    keep_pt = seen >= 2                       # a landmark needs two views
+    remap = np.cumsum(keep_pt) - 1
+    sel = keep_pt[e_pt]
+    e_pt, e_cam, e_uv = remap[e_pt[sel]].astype(np.int32), e_cam[sel].astype(np.int32), e_uv[sel] + rng.normal(0, 1.0, (int(sel.sum()), 2))
+    pts = pts[keep_pt]
+    n_points = len(pts)
+    n_e = len(e_pt)
+    perm = rng.permutation(n_e)
+    e_pt, e_cam, e_uv = e_pt[perm], e_cam[perm], e_uv[perm]
+    oe_i = np.arange(n_cams - 1, dtype=np.int32); oe_j = oe_i + 1
+    oe_meas = pose_mul(T_cw_true[oe_j], pose_inv(T_cw_true[oe_i]))
+    oe_meas = pose_mul(small_pose(rng, len(oe_i), 0.002, 0.01), oe_meas)
+    cams0 = pose_mul(small_pose(rng, n_cams, 0.01, 0.05), T_cw_true)
+    cams0[0] = T_cw_true[0]
+    cam_fixed = np.zeros(n_cams, np.int32); cam_fixed[0] = 1
+    Kmat = np.array([[FX, 0, CX], [0, FY, CY], [0, 0, 1.0]])
+    return dict(
+        pe_cam=np.zeros(0, np.int32), pe_cub=np.zeros(0, np.int32), pe_meas=np.zeros((0, 4)), pe_info=np.zeros((0, 16)), pe_K=np.tile(Kmat.ravel(), (0, 1)),
+        cams=cams0, cam_fixed=cam_fixed, cuboids=np.zeros((0, 10)), cub_fixed=np.zeros(0, np.int32), points=pts + rng.normal(0, 0.05, pts.shape),
+        pt_fixed=np.zeros(n_points, np.int32),
+        e_pt=e_pt, e_cam=e_cam, e_uv=e_uv, e_info=np.tile(np.eye(2).ravel(), (n_e, 1)), e_intr=np.tile(np.array([FX, FY, CX, CY]), (n_e, 1)),
+        e_huber=np.full(n_e, np.sqrt(5.991) if huber else 0.0),
+        ce_cam=np.zeros(0, np.int32), ce_cub=np.zeros(0, np.int32), ce_meas=np.zeros((0, 10)), ce_info=np.zeros((0, 81)),
+        oe_i=oe_i, oe_j=oe_j, oe_meas=oe_meas, oe_info=np.tile(np.eye(6).ravel(), (len(oe_i), 1)),
+        truth=dict(cams=T_cw_true, cuboids=np.zeros((0, 10)), points=pts))

@@ -387,6 +387,14 @@ int cs_ba_solver_layout(cs_ba* ba, int* band_ld, int* team);
  * cuboids_eliminated = 1 if it holds the cameras only.  x() / b() / cs_ba_sizes keep g2o's layout either way.
  * CS_BA_KEEP_CUBOIDS=1 (environment) keeps g2o's system.                                                              */
 int cs_ba_reduced_size(cs_ba* ba, int* n_reduced, int* cuboids_eliminated);
+/* Which factorisation the reduced system takes (the place of g2o's LinearSolverDense / LinearSolverEigen, solvers/linear_solver_dense.h:65-113,
+ * solvers/linear_solver_eigen.h:94-232): CS_BA_PATH_BAND (reverse Cuthill-McKee band, persistent banded Cholesky), CS_BA_PATH_SPARSE (minimum-degree
+ * block ordering, symbolic factorisation on the host, level-scheduled sparse Cholesky on the device: graphs the ordering cannot band -- 2-D
+ * covisibility meshes, many loop closures), CS_BA_PATH_DENSE (rocSOLVER potrf / potrs: small systems, graphs that fill in anyway).  *bandwidth:
+ * the band's (0 otherwise); *sparse_fill: values of the sparse factor / those of the dense triangle (0 otherwise).  CS_BA_FORCE_DENSE=1,
+ * CS_BA_SPARSE=0 / 1 (never / whenever the plan fits) override the choice.                                                             */
+typedef enum { CS_BA_PATH_DENSE = 0, CS_BA_PATH_BAND = 1, CS_BA_PATH_SPARSE = 2 } cs_ba_solver_path_kind;
+int cs_ba_solver_path(cs_ba* ba, int* path, int* bandwidth, double* sparse_fill);
 /* How the Schur complement S -= sum_j W_j D_j^-1 W_j^T (block_solver.hpp:385-431) is formed.  fused = 1: landmarks grouped by
  * camera set, one wavefront per segment of <= 32 landmarks, the product on the matrix cores (v_mfma_f64_16x16x4_f64) with the
  * landmarks as contraction dimension, n_partial_blocks partial 6x6 blocks summed per destination in a fixed order; fused = 0

@@ -1148,3 +1148,46 @@ def test_growing_graph_append_equals_rebuild_every_frame():
         n_p, n_o = n_p2, n_o2
     assert G.sizes()[0] > 0
     G.close()
+
+
+def test_general_sparse_reduced_solve_on_a_covisibility_mesh():
+    """A survey-flight graph (cameras on a 2-D grid looking down: synth_ba.make_mesh_problem): the cameras' covisibility graph is a mesh
+    that reverse Cuthill-McKee cannot band narrowly.  The general sparse path (CS_BA_SPARSE=1: minimum-degree block ordering + symbolic
+    factorisation on the host, ba_sparse.h; level-scheduled persistent Cholesky + substitution on the device, sparse_kernels.hip --
+    the place of Eigen::SimplicialLDLT behind g2o's LinearSolverEigen, solvers/linear_solver_eigen.h:94-232) gives the same damped
+    solve as the banded / dense paths (1e-9) and the same LM run as the oracle (north_star's 1e-5)."""
+    import subprocess, sys, json, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, json, numpy as np
+        sys.path.insert(0, %r)
+        from cube_slam_wu_amd import capi, synth_ba
+        pr = synth_ba.make_mesh_problem(16, 16, 20000)
+        G = capi.ba_from_dict(pr)
+        G.compute_errors(); G.build_system(dense_hpp=False)
+        ok, x = G.solve(1e-3)
+        n = G.optimize(6)
+        chi, lam, tr = G.history()
+        c, o, p = G.state()
+        np.savez(sys.argv[1], x=x, chi=chi, lam=lam, tr=tr, cams=c, pts=p, ok=ok, n=n, path=np.array(G.solver_path()))
+    """ % root)
+    out = {}
+    for mode in ("1", "0"):
+        f = os.path.join(root, "build_tmp", "mesh_sparse_%s.npz" % mode)
+        os.makedirs(os.path.dirname(f), exist_ok=True)
+        r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=600, env={**os.environ, "CS_BA_SPARSE": mode})
+        assert r.returncode == 0, r.stderr
+        out[mode] = np.load(f)
+    a, b = out["1"], out["0"]
+    assert str(a["path"]) == "sparse" and str(b["path"]) in ("band", "dense")
+    assert bool(a["ok"]) and bool(b["ok"]) and int(a["n"]) == int(b["n"]) == 6
+    assert np.abs(a["x"] - b["x"]).max() <= 1e-9 * np.abs(b["x"]).max()
+    assert np.array_equal(a["tr"], b["tr"]) and np.allclose(a["chi"], b["chi"], rtol=1e-9)
+    pr = synth_ba.make_mesh_problem(16, 16, 20000)
+    R = _oracle(pr)
+    assert R.optimize(6) == 6
+    chi_r, lam_r, tr_r = R.history()
+    assert np.array_equal(a["tr"], tr_r) and np.allclose(a["chi"], chi_r, rtol=1e-6)
+    cr, _, prr = R.state()
+    assert np.abs(a["cams"] - cr).max() <= 1e-5 * np.abs(cr).max() and np.abs(a["pts"] - prr).max() <= 1e-5 * np.abs(prr).max()
+    assert a["chi"][-1] < 0.5 * a["chi"][0]

@@ -13,3 +13,5 @@ hipcc --offload-arch=gfx950 build_tmp/band_bench.o build_tmp/ba_kernels_fence.o 
 hipcc --offload-arch=gfx950 -O3 -x hip tools/microbench/pmc_calib.cpp -o build_tmp/pmc_calib
 # the diagonal-block routine of the banded solver alone
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -x hip tools/microbench/potf2_bench.cpp -o build_tmp/potf2_bench
+# host-only check of the symbolic phase of the general sparse reduced solve (tests/test_ba_oracle.py runs it)
+hipcc -O2 -std=c++17 tools/microbench/sparse_plan_check.cpp -o build_tmp/sparse_plan_check
