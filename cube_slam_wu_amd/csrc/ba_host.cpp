@@ -251,7 +251,8 @@ struct cs_ba {
   cs::SparsePlan sp_plan;
   DBuf<int> sp_ndim, sp_ncol, sp_sptr, sp_srow, sp_sroff, sp_prow, sp_rbase, sp_rent, sp_rptr, sp_rcol, sp_rpos, sp_order, sp_info;
   DBuf<long long> sp_poff;
-  DBuf<double> sp_L, sp_xs;
+  DBuf<double> sp_L, sp_xs, sp_T;
+  DBuf<int> sp_tcol;
   DBuf<unsigned> sp_done, sp_xdone;
   DBuf<int> d_cub_mine;     // sharded + eliminated cuboids: 1 = this rank owns the cuboid (holds all its edges)
   DBuf<int> d_cubS_ptr, d_cubS_cam, d_ce_slot, d_cub_tile, d_cub_coef, d_elim_fail, d_slotE_ptr, d_slotE_idx;
@@ -628,10 +629,11 @@ int finalize_structure(cs_ba* B) {
         std::vector<int> dim(nc + no, 0), col(nc + no, 0);
         for (int v : O.free_ids) { dim[v] = v < nc ? 6 : 9; col[v] = v < nc ? O.cam_col[v] : O.cub_col[v - nc]; }
         cs::SparsePlan plan;
-        const bool fits = cs::sparse_plan_build(O.adj, O.free_ids, dim, col, cs::sparse_max_panel_doubles(), 0.35, plan) && cs::sparse_fits_device(cs::sparse_max_panel_doubles(), plan.N);
-        const double est_sparse = 0.04 * plan.levels + 17.0 * plan.flops * 2e-9;
-        if (prof && fits) fprintf(stderr, "[ba structure] sparse plan: %d vertices, %d levels, %lld values (%.1f%% of the dense triangle), largest panel %d, %.2f Gflop; estimates ms: sparse %.1f, band %.1f, dense %.1f\n",
-                                  plan.N, plan.levels, plan.nvals, 100.0 * plan.nvals / (0.5 * nn * nn), plan.max_panel, plan.flops * 2e-9, est_sparse, est_band < 1e29 ? est_band : -1.0, est_dense);
+        const bool fits = cs::sparse_plan_build(O.adj, O.free_ids, dim, col, cs::sparse_max_panel_doubles(), 0.35, plan, getenv("CS_BA_SPARSE_NO_TAIL") ? 0 : (getenv("CS_BA_SPARSE_TAIL_MAX") ? atoi(getenv("CS_BA_SPARSE_TAIL_MAX")) : 9000)) && cs::sparse_fits_device(cs::sparse_max_panel_doubles(), plan.N);
+        const double nt = (double)plan.n_tail;
+        const double est_sparse = 0.04 * plan.levels + 17.0 * plan.flops * 2e-9 + (nt > 0 ? nt * nt * nt / 3.0 / 11e12 * 1e3 + 1.0 : 0.0);
+        if (prof && fits) fprintf(stderr, "[ba structure] sparse plan: %d vertices, %d levels, %lld values (%.1f%% of the dense triangle), largest panel %d, %.2f Gflop + a dense tail of %d unknowns; estimates ms: sparse %.1f, band %.1f, dense %.1f\n",
+                                  plan.N, plan.levels, plan.nvals, 100.0 * plan.nvals / (0.5 * nn * nn), plan.max_panel, plan.flops * 2e-9, plan.n_tail, est_sparse, est_band < 1e29 ? est_band : -1.0, est_dense);
         if (fits && (mode == 1 || est_sparse < est_other)) {
           B->sparse = true; B->band_ld = 0;
           B->sp_plan = std::move(plan);
@@ -1036,6 +1038,7 @@ int finalize_structure(cs_ba* B) {
     UP(B->sp_ndim, SP.ndim); UP(B->sp_ncol, SP.ncol); UP(B->sp_sptr, SP.sptr); UP(B->sp_srow, SP.srow); UP(B->sp_sroff, SP.sroff); UP(B->sp_prow, SP.prow);
     UP(B->sp_rbase, SP.rbase); UP(B->sp_rent, SP.rent); UP(B->sp_rptr, SP.rptr); UP(B->sp_order, SP.order); UP(B->sp_poff, SP.poff);
     { std::vector<int> v_rcol(SP.rcol), v_rpos(SP.rpos); if (v_rcol.empty()) { v_rcol.push_back(0); v_rpos.push_back(0); } UP(B->sp_rcol, v_rcol); UP(B->sp_rpos, v_rpos); }
+    UP(B->sp_tcol, SP.tcol); AL(B->sp_T, (size_t)SP.n_tail * SP.n_tail + SP.n_tail + 1);
     AL(B->sp_L, (size_t)SP.nvals); AL(B->sp_xs, 9 * (size_t)(SP.N + 1)); AL(B->sp_done, (size_t)SP.N + 1); AL(B->sp_xdone, (size_t)SP.N + 2); AL(B->sp_info, 2);
   }
   if (B->sep_mode) {
@@ -1278,8 +1281,16 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       SV.N = B->sp_plan.N; SV.n = n;
       SV.ndim = B->sp_ndim.p; SV.ncol = B->sp_ncol.p; SV.sptr = B->sp_sptr.p; SV.srow = B->sp_srow.p; SV.sroff = B->sp_sroff.p; SV.prow = B->sp_prow.p;
       SV.rbase = B->sp_rbase.p; SV.rent = B->sp_rent.p; SV.rptr = B->sp_rptr.p; SV.rcol = B->sp_rcol.p; SV.rpos = B->sp_rpos.p; SV.order = B->sp_order.p; SV.poff = B->sp_poff.p;
+      SV.tcol = B->sp_tcol.p; SV.tail_start = B->sp_plan.tail_start; SV.n_tail = B->sp_plan.n_tail; SV.T = B->sp_T.p; SV.rhs_t = B->sp_T.p + (size_t)SV.n_tail * SV.n_tail;
       SV.S = B->S.p; SV.rhs = B->view.rhs; SV.L = B->sp_L.p; SV.xs = B->sp_xs.p; SV.done = B->sp_done.p; SV.xdone = B->sp_xdone.p; SV.info = B->sp_info.p;
       cs::launch_sparse_cholesky(SV, cs::sparse_max_panel_doubles(), B->st);
+      BA_TRY(hipGetLastError());
+      BA_TRY(hipMemsetAsync(B->d_info.p, 0, sizeof(int), B->st));
+      if (SV.n_tail > 0) {   // the top of the elimination tree as one dense block (same storage convention as the dense path's S)
+        BA_ROC(rocsolver_dpotrf(B->blas, rocblas_fill_upper, SV.n_tail, SV.T, SV.n_tail, B->d_info.p));
+        BA_ROC(rocsolver_dpotrs(B->blas, rocblas_fill_upper, SV.n_tail, 1, SV.T, SV.n_tail, SV.rhs_t, SV.n_tail));
+      }
+      cs::launch_sparse_backsolve(SV, B->st);
       BA_TRY(hipGetLastError());
       BA_TRY(hipEventRecord(B->ev[4], B->st));
       cs::ba_launch_backsub(B->view, B->st);
@@ -1287,7 +1298,9 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       { int rc2 = share_cuboid_increments(B, fn, ctx); if (rc2) return rc2; }
       BA_TRY(hipEventRecord(B->ev[5], B->st));
       BA_TRY(hipMemcpyAsync(B->h_status, B->sp_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
+      BA_TRY(hipMemcpyAsync(B->h_status + 2, B->d_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
       BA_TRY(hipStreamSynchronize(B->st));
+      if (B->h_status[2] != 0 && B->h_status[0] == 0) B->h_status[0] = B->h_status[2];     // (the dense tail's pivot)
       if (*B->h_status == 0x7fffffff) {
         cs_set_error_ba("sparse solver: grid not co-resident (wait timed out); set CS_BA_SPARSE=0 on a shared device");
         return CS_ERR_HIP;

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <iterator>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 namespace cs {
@@ -27,13 +28,18 @@ struct SparsePlan {
   std::vector<int> rptr, rcol, rpos;  // per position j: the columns k < j with L(j, k) != 0 (ascending) and j's entry index in column k
   std::vector<int> order;             // processing order: by level (longest chain of updating columns), then by position
   long long nvals = 0; int max_panel = 0, levels = 0;
+  // the dense tail: positions >= tail_start (the top of the elimination tree, where the columns have become a near-clique) are not
+  // factorised column by column -- their panels, updated by the columns before them, are written into a dense n_tail x n_tail block that
+  // a dense Cholesky takes; tcol: first row / column of a tail position in that block
+  int tail_start = 0, n_tail = 0;
+  std::vector<int> tcol;
   double flops = 0;                   // multiply-adds of the numeric factorisation
 };
 
 // adj: symmetric adjacency of the block graph over ids 0 .. adj.size() - 1; `verts`: the ids that take part (free vertices), dim / col per id.
 // Returns false when the plan would not pay (fill above max_fill of the dense triangle) or a panel would not fit the kernel's LDS.
 inline bool sparse_plan_build(const std::vector<std::vector<int>>& adj, const std::vector<int>& verts, const std::vector<int>& dim, const std::vector<int>& col,
-                              int max_panel_doubles, double max_fill, SparsePlan& P) {
+                              int max_panel_doubles, double max_fill, SparsePlan& P, int max_tail_unknowns = 0) {
   const int N = (int)verts.size();
   P = SparsePlan();
   P.N = N;
@@ -113,12 +119,34 @@ inline bool sparse_plan_build(const std::vector<std::vector<int>>& adj, const st
   std::vector<int> fill(P.rptr.begin(), P.rptr.end() - 1);
   for (int k = 0; k < N; k++)
     for (int t = P.sptr[k]; t < P.sptr[k + 1]; t++) { const int i = P.srow[t]; if (i < N) { P.rcol[fill[i]] = k; P.rpos[fill[i]] = t - P.sptr[k]; fill[i]++; } }
+  // ---- the dense tail: the longest suffix of positions whose columns hold at least tail_density of the positions after them
+  static const double tail_density = [] { const char* e = getenv("CS_BA_SPARSE_TAIL_DENSITY"); return e ? atof(e) : 0.12; }();   // (swept on the survey-flight meshes: 0.1 - 0.15 is the optimum)
+  P.tail_start = N; P.n_tail = 0; P.tcol.assign(N + 1, 0);
+  if (max_tail_unknowns > 0) {
+    int c = N, unk = 0;
+    while (c > 0) {
+      const int j = c - 1, below = P.sptr[j + 1] - P.sptr[j] - 1;
+      if ((double)below < tail_density * (double)(N - 1 - j) || unk + P.ndim[j] > max_tail_unknowns) break;
+      unk += P.ndim[j]; c--;
+    }
+    if (N - c >= 24) {
+      P.tail_start = c; P.n_tail = unk;
+      int t = 0;
+      for (int j = c; j < N; j++) { P.tcol[j] = t; t += P.ndim[j]; }
+    }
+  }
   std::vector<int> level(N, 0);
-  for (int j = 0; j < N; j++) for (int u = P.rptr[j]; u < P.rptr[j + 1]; u++) level[j] = std::max(level[j], level[P.rcol[u]] + 1);
+  for (int j = 0; j < N; j++)
+    for (int u = P.rptr[j]; u < P.rptr[j + 1]; u++) if (P.rcol[u] < P.tail_start) level[j] = std::max(level[j], level[P.rcol[u]] + 1);
   P.order.resize(N);
   for (int j = 0; j < N; j++) P.order[j] = j;
   std::stable_sort(P.order.begin(), P.order.end(), [&](int a, int b) { return level[a] < level[b]; });
   for (int j = 0; j < N; j++) P.levels = std::max(P.levels, level[j] + 1);
+  if (P.n_tail > 0) {   // (the tail's own factorisation is the dense block's: what stays here is the columns before it)
+    double f = 0;
+    for (int j = 0; j < P.tail_start; j++) f += 0.5 * (double)P.prow[j] * (double)P.prow[j] * P.ndim[j];
+    P.flops = f;
+  }
   return true;
 }
 
@@ -127,6 +155,8 @@ struct SparseView {
   int N, n;                           // vertices; unknowns (S is n x n)
   const int *ndim, *ncol, *sptr, *srow, *sroff, *prow, *rbase, *rent, *rptr, *rcol, *rpos, *order;
   const long long* poff;
+  const int* tcol; int tail_start, n_tail;   // the dense tail (SparsePlan)
+  double* T; double* rhs_t;           // its n_tail x n_tail block (row-major, lower; zeroed by the launcher) and right-hand side
   const double* S; double* rhs;       // assembled system; right-hand side in, solution out
   double* L; double* xs;              // panels; the solution by elimination position (N x 9)
   unsigned* done; unsigned* xdone;    // per position: factorised / solved (zeroed by the launcher)
@@ -134,6 +164,7 @@ struct SparseView {
 };
 bool sparse_fits_device(int max_panel_doubles, int N);
 int sparse_max_panel_doubles();
-void launch_sparse_cholesky(const SparseView& V, int max_panel_doubles, hipStream_t st);
+void launch_sparse_cholesky(const SparseView& V, int max_panel_doubles, hipStream_t st);     // factorisation (+ the tail's block assembled)
+void launch_sparse_backsolve(const SparseView& V, hipStream_t st);                           // after the tail's x sits in rhs_t: L^T x = y
 
 }  // namespace cs

@@ -76,8 +76,10 @@ __global__ __launch_bounds__(SP_T) void sparse_chol_kernel(SparseView V, int pan
     // ---- the columns that update this one, in ascending order (a fixed order: the sums are reproducible).  (Tried: L(j, k) of the next
     // column loaded and the flag after it polled while the current one is applied, one barrier per column instead of three -- slower, 62 ->
     // 73 ms on a 1 919-camera mesh: waiting AHEAD stalls the columns that are ready behind the one that is still being factorised.)
+    const bool tail = j >= V.tail_start;
     for (int u = V.rptr[j]; u < V.rptr[j + 1]; u++) {
       const int k = V.rcol[u], t0 = V.rpos[u], dk = V.ndim[k], ek = V.sptr[k];
+      if (k >= V.tail_start) break;                     // (ascending: the rest are tail columns, whose part the dense factorisation does)
       if (tid == 0) {
         s_ok = sp_wait(V.done + k, V.info) ? 1 : 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -98,6 +100,20 @@ __global__ __launch_bounds__(SP_T) void sparse_chol_kernel(SparseView V, int pan
         P[(map[i] + a) * dj + b] -= s;
       }
       __syncthreads();
+    }
+    if (tail) {
+      // ---- a column of the dense tail: its updated panel goes into the dense block (row-major, lower triangle), unfactorised
+      for (int e = tid; e < rows * dj; e += SP_T) {
+        const int rho = e / dj, b = e - rho * dj, t = rentj[rho];
+        const int tc = V.tcol[j] + b;
+        if (t < 0) { if (rho >= b) V.T[(size_t)(V.tcol[j] + rho) * V.n_tail + tc] = P[e]; }
+        else {
+          const int i = V.srow[e0 + t];
+          if (i == N) V.rhs_t[tc] = P[e];
+          else V.T[(size_t)(V.tcol[i] + rho - V.sroff[e0 + t]) * V.n_tail + tc] = P[e];
+        }
+      }
+      continue;
     }
     // ---- the diagonal block (dj <= 9: one thread), then every row below times L_jj^-T
     if (tid == 0) {
@@ -140,6 +156,7 @@ __global__ __launch_bounds__(64) void sparse_back_kernel(SparseView V) {
   const int lane = threadIdx.x, N = V.N;
   for (int idx = N - 1 - (int)blockIdx.x; idx >= 0; idx -= (int)gridDim.x) {
     const int j = V.order[idx], dj = V.ndim[j], cj = V.ncol[j], e0 = V.sptr[j], nent = V.sptr[j + 1] - e0 - 1;   // (without the right-hand side's entry)
+    if (j >= V.tail_start) continue;                    // (solved by the dense factorisation; sparse_tail_scatter_kernel published it)
     const double* Lj = V.L + V.poff[j];
     // the factorisation is complete (kernel boundary); wait for the solution of the vertices below
     double acc[9];
@@ -174,6 +191,13 @@ __global__ __launch_bounds__(64) void sparse_back_kernel(SparseView V) {
     __builtin_amdgcn_wave_barrier();
   }
 }
+// the dense tail's solution to where the substitution reads it (by position) and to the solution vector; its flags are raised
+__global__ __launch_bounds__(64) void sparse_tail_scatter_kernel(SparseView V) {
+  const int j = V.tail_start + blockIdx.x, c = threadIdx.x;
+  if (j >= V.N) return;
+  if (c < V.ndim[j]) { const double x = V.rhs_t[V.tcol[j] + c]; V.xs[(size_t)j * 9 + c] = x; V.rhs[V.ncol[j] + c] = x; }
+  if (c == 0) V.xdone[j] = 1u;
+}
 }  // namespace
 
 int sparse_max_panel_doubles() { return 16384; }   // 128 KB of the 160 KB LDS: panels of up to ~1 800 rows x 9
@@ -197,7 +221,11 @@ void launch_sparse_cholesky(const SparseView& V, int max_panel_doubles, hipStrea
   if (G <= 0) return;
   (void)hipMemsetAsync(V.done, 0, sizeof(unsigned) * (size_t)V.N, st);
   (void)hipMemsetAsync(V.xdone, 0, sizeof(unsigned) * (size_t)(V.N + 1), st);
+  if (V.n_tail > 0) (void)hipMemsetAsync(V.T, 0, sizeof(double) * ((size_t)V.n_tail * V.n_tail + V.n_tail), st);
   hipLaunchKernelGGL(sparse_chol_kernel, dim3(G), dim3(SP_T), sparse_lds_bytes(max_panel_doubles, V.N), st, V, max_panel_doubles);
+}
+void launch_sparse_backsolve(const SparseView& V, hipStream_t st) {
+  if (V.n_tail > 0) hipLaunchKernelGGL(sparse_tail_scatter_kernel, dim3(V.N - V.tail_start), dim3(64), 0, st, V);
   int occ = 0, dev = 0;
   hipDeviceProp_t prop;
   (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&prop, dev);

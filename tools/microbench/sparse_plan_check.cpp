@@ -28,7 +28,7 @@ int main() {
     }
     for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
     cs::SparsePlan P;
-    if (!cs::sparse_plan_build(adj, verts, dim, col, 1 << 30, 2.0, P)) { printf("trial %d: no plan\n", trial); return 1; }
+    if (!cs::sparse_plan_build(adj, verts, dim, col, 1 << 30, 2.0, P, trial % 3 ? 400 : 0)) { printf("trial %d: no plan\n", trial); return 1; }
     const int N = P.N;
     if (N != nfree) { printf("trial %d: N\n", trial); return 1; }
     // which vertex sits at which position: by its column
@@ -65,9 +65,12 @@ int main() {
       if (have != std::vector<int>(want.begin(), want.end())) { printf("trial %d: update list of %d\n", trial, j); return 1; }
       for (int u = P.rptr[j]; u < P.rptr[j + 1]; u++) {
         if (P.srow[P.sptr[P.rcol[u]] + P.rpos[u]] != j) { printf("trial %d: entry index of %d in %d\n", trial, j, P.rcol[u]); return 1; }
-        if (where[P.rcol[u]] >= where[j]) { printf("trial %d: order is not topological\n", trial); return 1; }
+        if (P.rcol[u] < P.tail_start && where[P.rcol[u]] >= where[j]) { printf("trial %d: order is not topological\n", trial); return 1; }   // (tail columns do not wait for each other)
       }
     }
+    // the dense tail: a suffix of positions, its columns laid end to end
+    if (P.tail_start < 0 || P.tail_start > N || (P.n_tail == 0) != (P.tail_start == N)) { printf("trial %d: tail bounds\n", trial); return 1; }
+    { int t = 0; for (int j = P.tail_start; j < N; j++) { if (P.tcol[j] != t) { printf("trial %d: tail columns\n", trial); return 1; } t += P.ndim[j]; } if (t != P.n_tail || t > 400) { printf("trial %d: tail size\n", trial); return 1; } }
     checked++;
   }
   printf("sparse plan: %d random block graphs, pattern = fill, offsets / update lists / order consistent\n", checked);
