@@ -497,6 +497,46 @@ def main():
                 ba_out["growing_graph"] = {"what": "C3-sized graph (%d cameras, 20 k points, 50 cuboids) grown by one frame at a time through cs_ba_append_*, optimize(5) after every frame (main_obj.cpp:802-803); medians over 10 frames" % nc3,
                                            "append_and_structure_ms": float(np.median(t_app)), "optimize5_on_appended_graph_ms": float(np.median(t_opt)),
                                            "frame_ms": float(np.median(np.array(t_app) + np.array(t_opt)))}
+            # the three factorisations of the reduced system (cs_ba_solver_path) on a graph that is NOT a trajectory: a survey flight, cameras on a
+            # 2-D grid looking down (synth_ba.make_mesh_problem) -- a 2-D covisibility mesh; one damped solve (reduce + factor + substitute)
+            # through the banded path, the general sparse path (minimum-degree ordering, level-scheduled Cholesky, dense tail) and rocSOLVER's
+            # dense potrf.  CS_BENCH_BA_MESH=0 skips it (~25 s: generating the problem dominates).
+            if world == 1 and os.environ.get("CS_BENCH_CHILD") is None and os.environ.get("CS_BENCH_BA_MESH", "1") != "0":
+                try:
+                    prm = synth_ba.make_mesh_problem(48, 40, 150000)
+                    paths = {}
+                    saved = {k: os.environ.get(k) for k in ("CS_BA_SPARSE", "CS_BA_FORCE_DENSE")}
+                    xs = {}
+                    for name, env in (("band", {"CS_BA_SPARSE": "0"}), ("sparse", {"CS_BA_SPARSE": "1"}), ("dense", {"CS_BA_SPARSE": "0", "CS_BA_FORCE_DENSE": "1"})):
+                        for k in saved:
+                            os.environ.pop(k, None)
+                        os.environ.update(env)
+                        Gm = capi.ba_from_dict(prm, device=local_rank)
+                        n_red_m, _ = Gm.reduced_size()
+                        path, bw_m, fill_m = Gm.solver_path(detail=True)
+                        Gm.compute_errors(); Gm.build_system(dense_hpp=False)
+                        okm, xm = Gm.solve(1e-3)
+                        tsm = []
+                        for _ in range(3):
+                            torch.cuda.synchronize(); t1 = time.perf_counter(); okm, xm = Gm.solve(1e-3); torch.cuda.synchronize(); tsm.append((time.perf_counter() - t1) * 1e3)
+                        paths[name] = {"path_taken": path, "solve_ms": min(tsm), "ok": bool(okm)}
+                        if path == "band":
+                            paths[name]["bandwidth"] = bw_m
+                        if path == "sparse":
+                            paths[name]["fill_of_dense_triangle"] = fill_m
+                        xs[name] = xm
+                        Gm.close()
+                    for k, v in saved.items():
+                        os.environ.pop(k, None)
+                        if v is not None:
+                            os.environ[k] = v
+                    ref = xs["dense"]
+                    ba_out["solver_paths"] = {"what": "one damped solve (reduce + factor + substitute) of a survey-flight graph -- %d cameras on a 48 x 40 grid, %d points, %d edges, %d unknowns in the reduced system: a 2-D covisibility mesh -- through each factorisation" % (len(prm["cams"]), len(prm["points"]), len(prm["e_pt"]), n_red_m),
+                                              **paths,
+                                              "max_rel_diff_to_dense": {k: float(np.abs(xs[k] - ref).max() / np.abs(ref).max()) for k in ("band", "sparse")}}
+                    del prm
+                except Exception as ex:
+                    ba_out["solver_paths"] = {"error": repr(ex)}
             # CPU baseline of the BA half (rank 0, N = 1): the oracle (oracle/ba_oracle.cpp, -O2, one thread) on the SAME problem, wall time
             # per LM iteration split as g2o's G2OBatchStatistics does (core/batch_stats.h:48-62).  C3: the full run.  C4: one LM
             # iteration with residuals / linearisation / Schur complement / update in full and the dense LDL^T (the reference
