@@ -427,6 +427,10 @@ struct JobResult {        // rank-stage products retained for cs_batch_debug_*
 // One of the two in-flight chunks of the pipelined production path (run_pipelined).
 struct PipeSlot {
   DevBuf<cs::JobDesc> jobs;
+  DevBuf<unsigned char> tab_arena;       // a small call's tables in one block: one upload instead of ten (single-frame latency)
+  PinBuf<unsigned char> h_tab_arena;
+  bool merged_io = false;                // this slot's call went through the block: its results are unpacked from h_tab_arena in pipe_finish
+  size_t o_jobs = 0, o_rec = 0, o_wc = 0, o_fb = 0, o_jv = 0, o_cb = 0, o_end = 0;
   DevBuf<long long> slot_prefix, job_cbase, c_slot, fb_src, fb_dst, fb_slot, win_slots;
   DevBuf<int> vp_prefix, top_x, flag, job_valid, c_flag, box_job0, box_njobs, win_count, fallback, fb_cnt, fb_flag;
   DevBuf<double> bound3;
@@ -527,6 +531,7 @@ struct cs_batch {
   PinBuf<cs::RankWinner> h_winners;
   PinBuf<int> h_win_count, h_fallback;
   PinBuf<cs::JobDesc> h_jobs;
+  PinBuf<unsigned char> h_tables, h_tables2;   // the job tables of one round, staged in pinned memory: their uploads are asynchronous and back to back
   bool force_host_rank = false;
   bool force_round_path = false;   // roll/pitch sampling through the round-by-round path (the lean path's redo of frames with tie boxes)
   // state
@@ -871,7 +876,7 @@ static void release_batch_buffers(cs_batch* b) {
   b->h_stage.release(); b->h_c_slot.release(); b->h_job_cbase.release(); b->h_c_flag.release(); b->h_job_valid.release();
   b->h_c_dist.release(); b->h_c_angle.release(); b->h_c_skew.release(); b->h_win_corners.release();
   b->d_box_job0.release(); b->d_box_njobs.release(); b->d_win_count.release(); b->d_fallback.release(); b->d_winners.release(); b->d_last_slot.release(); b->h_last_slot.release();
-  b->h_winners.release(); b->h_win_count.release(); b->h_fallback.release(); b->h_jobs.release();
+  b->h_winners.release(); b->h_win_count.release(); b->h_fallback.release(); b->h_jobs.release(); b->h_tables.release(); b->h_tables2.release();
   b->d_fb_src.release(); b->d_fb_dst.release(); b->d_fb_slot.release(); b->d_fb_cnt.release(); b->d_fb_flag.release();
   b->d_fb_dist.release(); b->d_fb_angle.release(); b->d_fb_skew.release();
 }
@@ -1087,17 +1092,48 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   PENS(S.fallback, nb + 1); PENS(S.winners, nb * KMAX + 1); PENS(S.records, nb * KMAX + 1); PENS(S.h_records, nb * KMAX + 1);
   PENS(S.h_winners, nb * KMAX + 1); PENS(S.h_win_count, nb + 1); PENS(S.h_fallback, nb + 1); PENS(S.h_job_valid, nj); PENS(S.h_job_cbase, nj + 1); PENS(S.h_jobs_out, nj);
 #define PH2D(dst, src, n) HIP_TRY(hipMemcpyAsync((dst).p, (src).p, sizeof(*(src).p) * (n), hipMemcpyHostToDevice, st))
-  PH2D(S.ls_order, S.h_ls_order, nj); PH2D(S.jobs, S.h_jobs_in, nj); PH2D(S.slot_prefix, S.h_slot_prefix, nj + 1); PH2D(S.vp_prefix, S.h_vp_prefix, nj + 1);
-  if (n_yaw) { PH2D(S.yaw, S.h_yaw, n_yaw); PH2D(S.yaw_c, S.h_yaw_c, n_yaw); PH2D(S.yaw_s, S.h_yaw_s, n_yaw); }
-  if (n_top) PH2D(S.top_x, S.h_top_x, n_top);
-  if (nb) { PH2D(S.box_job0, S.h_box_job0, nb); PH2D(S.box_njobs, S.h_box_njobs, nb); }
-  HIP_TRY(hipMemsetAsync(S.job_valid.p, 0, sizeof(int) * nj, st));
+  // the tables' device addresses: the slot's own buffers, or -- a call of a frame or two, where ten copies of a few hundred bytes cost ten
+  // launch latencies (~150 us of a 0.46 ms call) -- pieces of ONE block that goes up in one copy
+  int* p_ls_order = S.ls_order.p; cs::JobDesc* p_jobs = S.jobs.p; long long* p_slot_prefix = S.slot_prefix.p; int* p_vp_prefix = S.vp_prefix.p;
+  double *p_yaw = S.yaw.p, *p_yaw_c = S.yaw_c.p, *p_yaw_s = S.yaw_s.p;
+  int *p_top_x = S.top_x.p, *p_box_job0 = S.box_job0.p, *p_box_njobs = S.box_njobs.p;
+  cs_cuboid* p_records = S.records.p; int *p_win_count = S.win_count.p, *p_fallback = S.fallback.p, *p_job_valid = S.job_valid.p; long long* p_job_cbase = S.job_cbase.p;
+  S.merged_io = nj <= 256;
+  if (S.merged_io) {
+    // layout: [inputs | the job table (in and out) | outputs] -- one copy up ([0, end of the job table)), one copy back (from the job table on)
+    size_t need = 0;
+    auto room = [&](size_t bytes) { const size_t at = need; need += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t o_ls = room(sizeof(int) * nj), o_sp = room(sizeof(long long) * (nj + 1)), o_vp = room(sizeof(int) * (nj + 1));
+    const size_t o_y = room(8 * n_yaw), o_yc = room(8 * n_yaw), o_ys = room(8 * n_yaw), o_tx = room(sizeof(int) * n_top), o_b0 = room(sizeof(int) * nb), o_bn = room(sizeof(int) * nb);
+    const size_t o_jobs = room(sizeof(cs::JobDesc) * nj), in_end = need;
+    S.o_jobs = o_jobs; S.o_rec = room(sizeof(cs_cuboid) * nb * KMAX); S.o_wc = room(sizeof(int) * nb); S.o_fb = room(sizeof(int) * nb); S.o_jv = room(sizeof(int) * nj);
+    S.o_cb = room(sizeof(long long) * (nj + 1)); S.o_end = need;
+    PENS(S.tab_arena, need + 256); PENS(S.h_tab_arena, need + 256);
+    unsigned char *hb = S.h_tab_arena.p, *db = S.tab_arena.p;
+    memcpy(hb + o_ls, S.h_ls_order.p, sizeof(int) * nj); memcpy(hb + o_jobs, S.h_jobs_in.p, sizeof(cs::JobDesc) * nj);
+    memcpy(hb + o_sp, S.h_slot_prefix.p, sizeof(long long) * (nj + 1)); memcpy(hb + o_vp, S.h_vp_prefix.p, sizeof(int) * (nj + 1));
+    if (n_yaw) { memcpy(hb + o_y, S.h_yaw.p, 8 * n_yaw); memcpy(hb + o_yc, S.h_yaw_c.p, 8 * n_yaw); memcpy(hb + o_ys, S.h_yaw_s.p, 8 * n_yaw); }
+    if (n_top) memcpy(hb + o_tx, S.h_top_x.p, sizeof(int) * n_top);
+    if (nb) { memcpy(hb + o_b0, S.h_box_job0.p, sizeof(int) * nb); memcpy(hb + o_bn, S.h_box_njobs.p, sizeof(int) * nb); }
+    HIP_TRY(hipMemcpyAsync(db, hb, in_end, hipMemcpyHostToDevice, st));
+    p_ls_order = reinterpret_cast<int*>(db + o_ls); p_jobs = reinterpret_cast<cs::JobDesc*>(db + o_jobs); p_slot_prefix = reinterpret_cast<long long*>(db + o_sp);
+    p_vp_prefix = reinterpret_cast<int*>(db + o_vp); p_yaw = reinterpret_cast<double*>(db + o_y); p_yaw_c = reinterpret_cast<double*>(db + o_yc); p_yaw_s = reinterpret_cast<double*>(db + o_ys);
+    p_top_x = reinterpret_cast<int*>(db + o_tx); p_box_job0 = reinterpret_cast<int*>(db + o_b0); p_box_njobs = reinterpret_cast<int*>(db + o_bn);
+    p_records = reinterpret_cast<cs_cuboid*>(db + S.o_rec); p_win_count = reinterpret_cast<int*>(db + S.o_wc); p_fallback = reinterpret_cast<int*>(db + S.o_fb);
+    p_job_valid = reinterpret_cast<int*>(db + S.o_jv); p_job_cbase = reinterpret_cast<long long*>(db + S.o_cb);
+  } else {
+    PH2D(S.ls_order, S.h_ls_order, nj); PH2D(S.jobs, S.h_jobs_in, nj); PH2D(S.slot_prefix, S.h_slot_prefix, nj + 1); PH2D(S.vp_prefix, S.h_vp_prefix, nj + 1);
+    if (n_yaw) { PH2D(S.yaw, S.h_yaw, n_yaw); PH2D(S.yaw_c, S.h_yaw_c, n_yaw); PH2D(S.yaw_s, S.h_yaw_s, n_yaw); }
+    if (n_top) PH2D(S.top_x, S.h_top_x, n_top);
+    if (nb) { PH2D(S.box_job0, S.h_box_job0, nb); PH2D(S.box_njobs, S.h_box_njobs, nb); }
+  }
+  HIP_TRY(hipMemsetAsync(p_job_valid, 0, sizeof(int) * nj, st));
   cs::DetectDeviceView& v = S.view;
   v = cs::DetectDeviceView{};
-  v.jobs = S.jobs.p; v.n_jobs = (int)nj; v.slot_prefix = S.slot_prefix.p; v.vp_prefix = S.vp_prefix.p; v.maps = b->d_maps.p;
-  v.mid_x = S.mid_x.p; v.mid_y = S.mid_y.p; v.line_angle = S.ang.p; v.yaw = S.yaw.p; v.yaw_cos = S.yaw_c.p; v.yaw_sin = S.yaw_s.p; v.top_x = S.top_x.p;
-  v.rp = b->d_rp.p; v.invK = b->d_invK.p; v.vp = S.vp.p; v.bound = S.bound.p; v.bound3 = S.bound3.p; v.flag = S.flag.p; v.job_valid = S.job_valid.p;
-  v.job_cbase = S.job_cbase.p; v.c_slot = S.c_slot.p; v.c_flag = S.c_flag.p; v.c_dist = S.c_dist.p; v.c_angle = S.c_angle.p; v.c_skew = S.c_skew.p;
+  v.jobs = p_jobs; v.n_jobs = (int)nj; v.slot_prefix = p_slot_prefix; v.vp_prefix = p_vp_prefix; v.maps = b->d_maps.p;
+  v.mid_x = S.mid_x.p; v.mid_y = S.mid_y.p; v.line_angle = S.ang.p; v.yaw = p_yaw; v.yaw_cos = p_yaw_c; v.yaw_sin = p_yaw_s; v.top_x = p_top_x;
+  v.rp = b->d_rp.p; v.invK = b->d_invK.p; v.vp = S.vp.p; v.bound = S.bound.p; v.bound3 = S.bound3.p; v.flag = S.flag.p; v.job_valid = p_job_valid;
+  v.job_cbase = p_job_cbase; v.c_slot = S.c_slot.p; v.c_flag = S.c_flag.p; v.c_dist = S.c_dist.p; v.c_angle = S.c_angle.p; v.c_skew = S.c_skew.p;
   // The corner construction needs the vanishing points but not the segments: it runs on the second stream beside line
   // setup + VP support (a latency-bound and an ALU-bound kernel), and the scorer waits for both.
   hipStream_t stB = d->stream2;
@@ -1110,7 +1146,7 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   cs::launch_scan_compact(v, stB);
   HIP_TRY(hipEventRecord(S.ev[10], stB));
   HIP_TRY(hipEventRecord(S.ev[0], st));
-  cs::launch_line_setup(S.jobs.p, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st, S.ls_order.p,
+  cs::launch_line_setup(p_jobs, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st, p_ls_order,
                         d->stream3, S.ev[0], S.ev[12]);
   HIP_TRY(hipEventRecord(S.ev[1], st));
   cs::launch_vp_support_only(v, C.sp, S.vp_total, st);
@@ -1120,20 +1156,24 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   cs::launch_score(v, C.sp, slot_total, slot_total, st);
   HIP_TRY(hipEventRecord(S.ev[5], st));
   cs::RankView rv{};
-  rv.box_job0 = S.box_job0.p; rv.box_njobs = S.box_njobs.p; rv.n_boxes = (int)nb; rv.winners = S.winners.p; rv.win_count = S.win_count.p; rv.fallback = S.fallback.p;
+  rv.box_job0 = p_box_job0; rv.box_njobs = p_box_njobs; rv.n_boxes = (int)nb; rv.winners = S.winners.p; rv.win_count = p_win_count; rv.fallback = p_fallback;
   cs::RankParams rkp{P.weight_vp_angle, P.weight_skew_error, P.nominal_skew_ratio, P.max_cut_skew, KMAX, C.sp.short_sq_bound};
   cs::launch_rank(v, rv, rkp, st);
-  cs::launch_records(v, rv, KMAX, S.records.p, st);     // the records of the boxes the device ranked: only they come back
+  cs::launch_records(v, rv, KMAX, p_records, st);     // the records of the boxes the device ranked: only they come back
   HIP_TRY(hipEventRecord(S.ev[6], st));
   HIP_TRY(hipGetLastError());
-  if (nb) {
-    HIP_TRY(hipMemcpyAsync(S.h_records.p, S.records.p, sizeof(cs_cuboid) * nb * KMAX, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(S.h_win_count.p, S.win_count.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(S.h_fallback.p, S.fallback.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+  if (S.merged_io) {
+    HIP_TRY(hipMemcpyAsync(S.h_tab_arena.p + S.o_jobs, S.tab_arena.p + S.o_jobs, S.o_end - S.o_jobs, hipMemcpyDeviceToHost, st));   // unpacked in pipe_finish
+  } else {
+    if (nb) {
+      HIP_TRY(hipMemcpyAsync(S.h_records.p, S.records.p, sizeof(cs_cuboid) * nb * KMAX, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(S.h_win_count.p, S.win_count.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(S.h_fallback.p, S.fallback.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipMemcpyAsync(S.h_job_valid.p, S.job_valid.p, sizeof(int) * nj, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(S.h_job_cbase.p, S.job_cbase.p, sizeof(long long) * (nj + 1), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(S.h_jobs_out.p, p_jobs, sizeof(cs::JobDesc) * nj, hipMemcpyDeviceToHost, st));
   }
-  HIP_TRY(hipMemcpyAsync(S.h_job_valid.p, S.job_valid.p, sizeof(int) * nj, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(S.h_job_cbase.p, S.job_cbase.p, sizeof(long long) * (nj + 1), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(S.h_jobs_out.p, S.jobs.p, sizeof(cs::JobDesc) * nj, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipEventRecord(S.done, st));
   S.in_flight = true;
   MARK(3, tq);   // allocations + enqueue of copies and kernels
@@ -1151,6 +1191,12 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
   S.in_flight = false;
   const size_t nj = S.nj, nb = S.nb;
   if (nj == 0) return CS_OK;
+  if (S.merged_io) {     // a small call's results came back in one block (pipe_submit): to the places the rest of this function reads
+    const unsigned char* hb = S.h_tab_arena.p;
+    memcpy(S.h_jobs_out.p, hb + S.o_jobs, sizeof(cs::JobDesc) * nj);
+    if (nb) { memcpy(S.h_records.p, hb + S.o_rec, sizeof(cs_cuboid) * nb * KMAX); memcpy(S.h_win_count.p, hb + S.o_wc, sizeof(int) * nb); memcpy(S.h_fallback.p, hb + S.o_fb, sizeof(int) * nb); }
+    memcpy(S.h_job_valid.p, hb + S.o_jv, sizeof(int) * nj); memcpy(S.h_job_cbase.p, hb + S.o_cb, sizeof(long long) * (nj + 1));
+  }
   double t0 = now_ms();
   {
     float ms = 0;
@@ -2030,13 +2076,26 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
     ENS(b->d_yaw, n_yaw + 1); ENS(b->d_yaw_c, n_yaw + 1); ENS(b->d_yaw_s, n_yaw + 1); ENS(b->d_top_x, n_top + 1);
     ENS(b->d_vp, 6 * (size_t)vp_total + 6); ENS(b->d_bound, 6 * (size_t)vp_total + 6);
     ENS(b->d_flag, slot_total + 1);
+    // The tables are small (a frame: ~10 of them, a few KB each).  From the std::vectors every hipMemcpyAsync is a staged, effectively
+    // synchronous copy (10-25 us apiece, ~150 us per call); copied first into ONE pinned block they go out back to back and the host
+    // does not wait (the round's results are awaited further down, before the block is written again).
+    {
+      size_t need = 0;
+      auto room = [&](size_t bytes) { const size_t at = need; need += (bytes + 63) & ~(size_t)63; return at; };
+      const size_t o_jobs = room(sizeof(cs::JobDesc) * jobs.size()), o_sp = room(sizeof(long long) * slot_prefix.size()), o_vp = room(sizeof(int) * vp_prefix.size());
+      const size_t o_mx = room(8 * mid_x.size()), o_my = room(8 * mid_y.size()), o_an = room(8 * ang.size());
+      const size_t o_y = room(8 * yaw.size()), o_yc = room(8 * yaw_c.size()), o_ys = room(8 * yaw_s.size()), o_tx = room(sizeof(int) * top_x.size());
+      ENS(b->h_tables, need + 64);
+      unsigned char* hb = b->h_tables.p;
+#define H2DP(dst, vec, off) do { if (!(vec).empty()) { memcpy(hb + (off), (vec).data(), sizeof((vec)[0]) * (vec).size()); \
+                                   HIP_TRY(hipMemcpyAsync((dst).p, hb + (off), sizeof((vec)[0]) * (vec).size(), hipMemcpyHostToDevice, st)); } } while (0)
+      H2DP(b->d_jobs, jobs, o_jobs); H2DP(b->d_slot_prefix, slot_prefix, o_sp); H2DP(b->d_vp_prefix, vp_prefix, o_vp);
+      if (n_lines && !dev_setup) { H2DP(b->d_mid_x, mid_x, o_mx); H2DP(b->d_mid_y, mid_y, o_my); H2DP(b->d_ang, ang, o_an); }
+      if (n_yaw) { H2DP(b->d_yaw, yaw, o_y); H2DP(b->d_yaw_c, yaw_c, o_yc); H2DP(b->d_yaw_s, yaw_s, o_ys); }
+      if (n_top) H2DP(b->d_top_x, top_x, o_tx);
+    }
 #define H2D(dst, vec) HIP_TRY(hipMemcpyAsync((dst).p, (vec).data(), sizeof((vec)[0]) * (vec).size(), hipMemcpyHostToDevice, st))
-    H2D(b->d_jobs, jobs); H2D(b->d_slot_prefix, slot_prefix); H2D(b->d_vp_prefix, vp_prefix);
-    if (n_lines && !dev_setup) { H2D(b->d_mid_x, mid_x); H2D(b->d_mid_y, mid_y); H2D(b->d_ang, ang); }
-    if (n_yaw) { H2D(b->d_yaw, yaw); H2D(b->d_yaw_c, yaw_c); H2D(b->d_yaw_s, yaw_s); }
-    if (n_top) H2D(b->d_top_x, top_x);
     HIP_TRY(hipMemsetAsync(b->d_job_valid.p, 0, sizeof(int) * nj, st));
-    HIP_TRY(hipStreamSynchronize(st));
     tm.h2d_ms += now_ms() - t0;
 
     // ------------------------------------------------------------------ sweep (HIP) ----------
@@ -2081,7 +2140,12 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
       const size_t nb = box_job0.size();
       ENS(b->d_box_job0, nb); ENS(b->d_box_njobs, nb); ENS(b->d_win_count, nb); ENS(b->d_fallback, nb); ENS(b->d_winners, nb * KMAX);
       ENS(b->h_winners, nb * KMAX); ENS(b->h_win_count, nb); ENS(b->h_fallback, nb); ENS(b->h_job_valid, nj); ENS(b->h_job_cbase, nj + 1);
-      H2D(b->d_box_job0, box_job0); H2D(b->d_box_njobs, box_njobs);
+      {
+        ENS(b->h_tables2, 2 * sizeof(int) * nb + 128);
+        unsigned char* hb = b->h_tables2.p;
+        const size_t o1 = (sizeof(int) * nb + 63) & ~(size_t)63;
+        H2DP(b->d_box_job0, box_job0, 0); H2DP(b->d_box_njobs, box_njobs, o1);
+      }
       cs::RankView rv{};
       rv.box_job0 = b->d_box_job0.p; rv.box_njobs = b->d_box_njobs.p; rv.n_boxes = (int)nb;
       rv.winners = b->d_winners.p; rv.win_count = b->d_win_count.p; rv.fallback = b->d_fallback.p;
