@@ -59,8 +59,10 @@ __global__ __launch_bounds__(256) void edge_canny_kernel(const unsigned char* __
     // sit in LDS as 16-bit words with a zero frame (cv::Canny's zero-padded magnitude buffer), one halo row above and below;
     // the suppression reads its neighbours there.  Nothing but the class bytes goes to memory (the wide path below writes and
     // re-reads a 4-byte word per pixel: that traffic, 3 GB per 8000 ROIs through L2, was most of the kernel).
+    // (gridDim.y > 1: a call of a few ROIs -- the bands are independent, each loads its own halo rows: workgroup y takes the bands
+    // y, y + gridDim.y, ...; with one workgroup per ROI a KITTI frame's 8 boxes were 8 workgroups working through ~10 bands each, 198 us)
     const int ldw = R.w + 2;
-    for (int b0 = 0; b0 < R.h; b0 += CANNY_BAND) {
+    for (int b0 = (int)blockIdx.y * CANNY_BAND; b0 < R.h; b0 += CANNY_BAND * (int)gridDim.y) {
       const int rows = min(CANNY_BAND, R.h - b0);
       __syncthreads();                                   // the previous band's readers are done
       for (int r = wv; r < rows + 2; r += 4) {           // LDS row r = ROI row b0 - 1 + r
@@ -103,6 +105,7 @@ __global__ __launch_bounds__(256) void edge_canny_kernel(const unsigned char* __
       }
     }
   } else {
+  if (blockIdx.y) return;      // (the wide path is not split)
   for (int i = wv; i < R.h; i += 4)
     for (int j = lane; j < R.w; j += 64) {
       int xs, ys;
@@ -382,7 +385,10 @@ __device__ __forceinline__ int wave_prefix_min(int v) {
 // Working values: OpenCV's are 16.16 fixed point in unsigned 32 bits, saturated at DIST_MAX = UINT_MAX - b ("no feature
 // reachable").  Every finite distance inside an image is below 2^30, so the kernel carries 2^30 for "unreachable" in
 // signed 32 bits (nothing overflows, sums stay ordered) and writes DIST_MAX's float for it; finite values are identical.
-enum { DT_CHUNKS = 6, DT_AHEAD = 4 };   // ROI widths up to 384 columns take the register-pipelined instances, 4 rows of operands in flight
+#ifndef CS_DT_AHEAD
+#define CS_DT_AHEAD 4
+#endif
+enum { DT_CHUNKS = 6, DT_AHEAD = CS_DT_AHEAD };   // ROI widths up to 384 columns take the register-pipelined instances, 4 rows of operands in flight
 struct DtArgs { const unsigned char* cls; int* tmp; int* row_lds; int row_cap, w, h; };
 
 // The two passes for a ROI of exactly NC chunks of 64 columns.  Per row: the global operands (class bytes on the way down, the
@@ -563,7 +569,7 @@ void launch_edge_maps(const unsigned char* gray, int W, int H, const EdgeRoi* ro
   // CS_EDGE_HYST (tests / measurements): "lds" or "fused" forces one hysteresis path; by default calls that cannot fill the device take the LDS kernel
   static const int force = [] { const char* e = getenv("CS_EDGE_HYST"); return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'f' ? 2 : 0)); }();
   const bool fused = force ? force == 2 : n_rois > 1024;
-  hipLaunchKernelGGL(edge_canny_kernel, dim3(n_rois), dim3(256), 0, st, gray, W, H, rois, cls_pool, map_pool, low, high, fused ? 1 : 0);
+  hipLaunchKernelGGL(edge_canny_kernel, dim3(n_rois, (!fused && n_rois <= 64) ? 8 : 1), dim3(256), 0, st, gray, W, H, rois, cls_pool, map_pool, low, high, fused ? 1 : 0);
   if (!fused) {
     // the ROI's class bytes in LDS: sized for the largest ROI of the call, at most 64 KB (two workgroups per CU with the lists; larger ROIs take
     // the memory path inside the kernel).  CS_EDGE_HYST_LIST (tests): a smaller frontier capacity, CS_EDGE_HYST_LDS: the cap in bytes.
