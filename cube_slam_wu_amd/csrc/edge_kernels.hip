@@ -412,7 +412,7 @@ __device__ __forceinline__ void edge_dt_rows(const DtArgs& A) {
 #pragma unroll
   for (int u = 0; u < D; u++)
 #pragma unroll
-    for (int c = 0; c < NC; c++) { const int j = c * 64 + lane; pre[u][c] = (j < w && u < h) ? cls[u * w + j] : 0; }
+    for (int c = 0; c < NC; c++) { const int j = c * 64 + lane; pre[u][c] = (u < h) ? cls[u * w + min(j, w - 1)] : 0; }
   for (int i0 = 0; i0 < h; i0 += D) {
 #pragma unroll
     for (int u = 0; u < D; u++) {
@@ -421,19 +421,18 @@ __device__ __forceinline__ void edge_dt_rows(const DtArgs& A) {
         int now[NC], d[NC];
 #pragma unroll
         for (int c = 0; c < NC; c++) now[c] = pre[u][c];
+        // (branch-free up to the stores: lanes past the ROI's last column read its last column's cells and are masked by a select --
+        // with `if (j < w)` around the loads every chunk of every row cost several EXEC-mask branches, most of a row's latency)
         if (i + D < h) {
 #pragma unroll
-          for (int c = 0; c < NC; c++) { const int j = c * 64 + lane; if (j < w) pre[u][c] = cls[(i + D) * w + j]; }
+          for (int c = 0; c < NC; c++) { const int j = c * 64 + lane; pre[u][c] = cls[(i + D) * w + min(j, w - 1)]; }
         }
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-          const int j = c * 64 + lane;
-          int a = 0x7fffffff;
-          if (j < w) {
-            int t = 0;
-            if (now[c] != 2) t = min(min(nb[j - 1] + DIAG, nb[j] + HV), nb[j + 1] + DIAG);
-            a = t - j * HV;
-          }
+          const int j = c * 64 + lane, jc = min(j, w - 1);
+          int t = min(min(nb[jc - 1] + DIAG, nb[jc] + HV), nb[jc + 1] + DIAG);
+          t = (now[c] == 2) ? 0 : t;
+          const int a = (j < w) ? t - j * HV : 0x7fffffff;
           const int s = wave_prefix_min(a);
           d[c] = (s == 0x7fffffff) ? INF : s + j * HV;
         }
@@ -455,7 +454,7 @@ __device__ __forceinline__ void edge_dt_rows(const DtArgs& A) {
 #pragma unroll
   for (int u = 0; u < D; u++)
 #pragma unroll
-    for (int c = 0; c < NC; c++) { const int jr = c * 64 + 63 - lane; pre[u][c] = (jr < w && h - 1 - u >= 0) ? tmp[(h - 1 - u) * w + jr] : 0; }
+    for (int c = 0; c < NC; c++) { const int jr = c * 64 + 63 - lane; pre[u][c] = (h - 1 - u >= 0) ? tmp[(h - 1 - u) * w + min(jr, w - 1)] : 0; }
   for (int i0 = h - 1; i0 >= 0; i0 -= D) {
 #pragma unroll
     for (int u = 0; u < D; u++) {
@@ -466,16 +465,13 @@ __device__ __forceinline__ void edge_dt_rows(const DtArgs& A) {
         for (int c = 0; c < NC; c++) now[c] = pre[u][c];
         if (i - D >= 0) {
 #pragma unroll
-          for (int c = 0; c < NC; c++) { const int jr = c * 64 + 63 - lane; if (jr < w) pre[u][c] = tmp[(i - D) * w + jr]; }
+          for (int c = 0; c < NC; c++) { const int jr = c * 64 + 63 - lane; pre[u][c] = tmp[(i - D) * w + min(jr, w - 1)]; }
         }
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-          const int jr = c * 64 + 63 - lane;        // lane 0 takes the chunk's rightmost column: scan order = right to left
-          int a = 0x7fffffff;
-          if (jr < w) {
-            const int t0 = min(min(now[c], nb[jr + 1] + DIAG), min(nb[jr] + HV, nb[jr - 1] + DIAG));
-            a = t0 + jr * HV;                       // d[j] = min over k >= j of u[k] + (k - j) HV
-          }
+          const int jr = c * 64 + 63 - lane, jc = min(jr, w - 1);        // lane 0 takes the chunk's rightmost column: scan order = right to left
+          const int t0 = min(min(now[c], nb[jc + 1] + DIAG), min(nb[jc] + HV, nb[jc - 1] + DIAG));
+          const int a = (jr < w) ? t0 + jr * HV : 0x7fffffff;             // d[j] = min over k >= j of u[k] + (k - j) HV
           const int s = wave_prefix_min(a);
           d[c] = (s == 0x7fffffff) ? INF : s - jr * HV;
         }
