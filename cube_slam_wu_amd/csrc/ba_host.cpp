@@ -613,16 +613,16 @@ int finalize_structure(cs_ba* B) {
     B->cam_col = O.cam_col; B->cub_col = O.cub_col; B->n_red = O.n_red;
     B->band_ld = band_ok(O) ? O.bw + 1 : 0;
     // A general sparse factorisation (fill-reducing order of the block graph, ba_sparse.h) where it is the fastest of the three.  The
-    // estimates are fits to measurements on MI355X (tools/ba_mesh_quick.py): banded -- n / 64 dependent steps of
-    // (10 + 0.043 bw) us; dense rocSOLVER potrf -- n^3 / 3 at 11 Tflop/s + 1 ms; sparse -- 40 us per level of the elimination tree +
-    // 17 ms per Gflop (it is a latency chain of small columns, not a throughput kernel).  The plan (an O(N^2) minimum-degree sweep) is only
-    // built when the alternative costs more than 5 ms.  CS_BA_SPARSE=0 never, =1 whenever the plan fits.
+    // estimates are fits to measurements on MI355X (tools/ba_mesh_quick.py): banded -- 1.15 n / 64 dependent steps of
+    // (10 + 0.043 bw) us; dense rocSOLVER potrf -- n^3 / 3 at 11 Tflop/s + 1 ms; sparse -- 25 us per level of the elimination tree +
+    // 1.5 ms per Gflop + the dense tail's n^3 / 3 at 3 Tflop/s (rocSOLVER at 1-2 k unknowns) + the dense assembly's extra cost (1 ms + the
+    // n x n fill).  The plan (an O(N^2) minimum-degree sweep) is only built when the alternative costs more than 5 ms.  CS_BA_SPARSE=0 never, =1 whenever the plan fits.
     B->sparse = false;
     {
       const char* e = getenv("CS_BA_SPARSE");
       const int mode = e ? atoi(e) : -1;
       const double nn = (double)O.n_red;
-      const double est_band = B->band_ld ? nn / 64.0 * (10.0 + 0.043 * (B->band_ld - 1)) * 1e-3 : 1e30, est_dense = nn * nn * nn / 3.0 / 11e12 * 1e3 + 1.0;
+      const double est_band = B->band_ld ? 1.15 * nn / 64.0 * (10.0 + 0.043 * (B->band_ld - 1)) * 1e-3 : 1e30, est_dense = nn * nn * nn / 3.0 / 11e12 * 1e3 + 1.0;
       const double est_other = std::min(est_band, est_dense);
       const bool consider = mode != 0 && !B->force_dense && B->shard_n == 1 && O.n_red >= 256 && (mode == 1 || est_other > 5.0);
       if (consider) {
@@ -631,7 +631,7 @@ int finalize_structure(cs_ba* B) {
         cs::SparsePlan plan;
         const bool fits = cs::sparse_plan_build(O.adj, O.free_ids, dim, col, cs::sparse_max_panel_doubles(), 0.35, plan, getenv("CS_BA_SPARSE_NO_TAIL") ? 0 : (getenv("CS_BA_SPARSE_TAIL_MAX") ? atoi(getenv("CS_BA_SPARSE_TAIL_MAX")) : 9000)) && cs::sparse_fits_device(cs::sparse_max_panel_doubles(), plan.N);
         const double nt = (double)plan.n_tail;
-        const double est_sparse = 0.04 * plan.levels + 17.0 * plan.flops * 2e-9 + (nt > 0 ? nt * nt * nt / 3.0 / 11e12 * 1e3 + 1.0 : 0.0);
+        const double est_sparse = 0.025 * plan.levels + 1.5 * plan.flops * 2e-9 + (nt > 0 ? nt * nt * nt / 3.0 / 3e12 * 1e3 + 1.0 : 0.0) + 1.0 + nn * nn * 8.0 / 2e12 * 1e3;
         if (prof && fits) fprintf(stderr, "[ba structure] sparse plan: %d vertices, %d levels, %lld values (%.1f%% of the dense triangle), largest panel %d, %.2f Gflop + a dense tail of %d unknowns; estimates ms: sparse %.1f, band %.1f, dense %.1f\n",
                                   plan.N, plan.levels, plan.nvals, 100.0 * plan.nvals / (0.5 * nn * nn), plan.max_panel, plan.flops * 2e-9, plan.n_tail, est_sparse, est_band < 1e29 ? est_band : -1.0, est_dense);
         if (fits && (mode == 1 || est_sparse < est_other)) {
@@ -1994,7 +1994,7 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
         // inside a captured stream is untested on this build's boxes), not with the solver's diagnostics that synchronise (CS_BAND_PROF).
         static const bool graph_on = [] { const char* e = getenv("CS_BA_GRAPH"); return e && atoi(e) != 0 && getenv("CS_BAND_PROF") == nullptr; }();
         static const bool graph_rccl = [] { const char* e = getenv("CS_BA_GRAPH_RCCL"); return e && atoi(e) != 0; }();
-        const bool want_graph = graph_on && !B->trial_graph_failed && !ext_active && (B->shard_n == 1 || (rccl && graph_rccl));
+        const bool want_graph = graph_on && B->band_ld > 0 && !B->trial_graph_failed && !ext_active && (B->shard_n == 1 || (rccl && graph_rccl));   // (the sparse / dense solves synchronise inside)
         bool timed = true;
         B->trials_on_structure++;
         if (want_graph && !B->trial_exec && B->trials_on_structure >= 3) {

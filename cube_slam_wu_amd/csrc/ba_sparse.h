@@ -120,7 +120,7 @@ inline bool sparse_plan_build(const std::vector<std::vector<int>>& adj, const st
   for (int k = 0; k < N; k++)
     for (int t = P.sptr[k]; t < P.sptr[k + 1]; t++) { const int i = P.srow[t]; if (i < N) { P.rcol[fill[i]] = k; P.rpos[fill[i]] = t - P.sptr[k]; fill[i]++; } }
   // ---- the dense tail: the longest suffix of positions whose columns hold at least tail_density of the positions after them
-  static const double tail_density = [] { const char* e = getenv("CS_BA_SPARSE_TAIL_DENSITY"); return e ? atof(e) : 0.12; }();   // (swept on the survey-flight meshes: 0.1 - 0.15 is the optimum)
+  static const double tail_density = [] { const char* e = getenv("CS_BA_SPARSE_TAIL_DENSITY"); return e ? atof(e) : 0.45; }();   // (swept on the survey-flight meshes: flat between 0.3 and 0.8)
   P.tail_start = N; P.n_tail = 0; P.tcol.assign(N + 1, 0);
   if (max_tail_unknowns > 0) {
     int c = N, unk = 0;

@@ -73,9 +73,11 @@ __global__ __launch_bounds__(SP_T) void sparse_chol_kernel(SparseView V, int pan
       P[e] = v;
     }
     __syncthreads();
-    // ---- the columns that update this one, in ascending order (a fixed order: the sums are reproducible).  (Tried: L(j, k) of the next
-    // column loaded and the flag after it polled while the current one is applied, one barrier per column instead of three -- slower, 62 ->
-    // 73 ms on a 1 919-camera mesh: waiting AHEAD stalls the columns that are ready behind the one that is still being factorised.)
+    // ---- the columns that update this one, in ascending order (a fixed order: the sums are reproducible), each waited for when it is
+    // needed.  (Tried, both slower: L(j, k) of the next column loaded and the flag after it polled while the current one is applied, one
+    // barrier per column instead of three -- 62 -> 73 ms on a 1 919-camera mesh; and the flags of all but the last three columns taken
+    // together up front -- 16 -> 43 ms: the columns of the near-clique region are factorised side by side on different workgroups, each
+    // applying the others' columns as they appear, and waiting AHEAD of need serialises them.)
     const bool tail = j >= V.tail_start;
     for (int u = V.rptr[j]; u < V.rptr[j + 1]; u++) {
       const int k = V.rcol[u], t0 = V.rpos[u], dk = V.ndim[k], ek = V.sptr[k];
@@ -151,7 +153,11 @@ __global__ __launch_bounds__(SP_T) void sparse_chol_kernel(SparseView V, int pan
   }
 }
 
-// x_j = L_jj^-T (y_j - sum over the blocks below of L(i, j)^T x_i), columns in the reverse of the factorisation's order, a wavefront each
+// x_j = L_jj^-T (y_j - sum over the blocks below of L(i, j)^T x_i), columns in the reverse of the factorisation's order, a wavefront each.
+// The lanes first wait for the flags of ALL the vertices below, 64 at a time (the last one to arrive is what the column waits for
+// anyway), then share the panel's rows: lane l takes rows l, l + 64, ...; partial sums meet in a fixed shuffle tree (reproducible).
+// (First form: lane 0 waited for the entries one after the other and the rows of an entry went to di <= 9 lanes -- 8.6 ms of a 17 ms
+// solve on the 1 920-camera mesh, four times the factorisation.)
 __global__ __launch_bounds__(64) void sparse_back_kernel(SparseView V) {
   const int lane = threadIdx.x, N = V.N;
   for (int idx = N - 1 - (int)blockIdx.x; idx >= 0; idx -= (int)gridDim.x) {
@@ -159,17 +165,19 @@ __global__ __launch_bounds__(64) void sparse_back_kernel(SparseView V) {
     if (j >= V.tail_start) continue;                    // (solved by the dense factorisation; sparse_tail_scatter_kernel published it)
     const double* Lj = V.L + V.poff[j];
     // the factorisation is complete (kernel boundary); wait for the solution of the vertices below
+    int ok = 1;
+    for (int t = lane; t < nent; t += 64) ok &= sp_wait(V.xdone + V.srow[e0 + t], V.info) ? 1 : 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (__ballot(!ok)) return;
+    const int* rentj = V.rent + V.rbase[j];
+    const int nrows = V.prow[j] - dj - 1;               // rows below the diagonal block, without the right-hand side's
     double acc[9];
     for (int c = 0; c < 9; c++) acc[c] = 0.0;
-    for (int t = 0; t < nent; t++) {
-      const int i = V.srow[e0 + t], di = V.ndim[i], r0 = V.sroff[e0 + t];
-      if (lane == 0) { if (!sp_wait(V.xdone + i, V.info)) acc[0] = __builtin_nan(""); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
-      __builtin_amdgcn_wave_barrier();
-      if (__hip_atomic_load(V.info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-      if (lane < di) {
-        const double xi = V.xs[(size_t)i * 9 + lane];
-        for (int c = 0; c < dj; c++) acc[c] = fma(Lj[(size_t)(r0 + lane) * dj + c], xi, acc[c]);
-      }
+    for (int r = lane; r < nrows; r += 64) {
+      const int rho = dj + r, t = rentj[rho], i = V.srow[e0 + t];
+      const double xi = V.xs[(size_t)i * 9 + (rho - V.sroff[e0 + t])];
+      const double* lrow = Lj + (size_t)rho * dj;
+      for (int c = 0; c < dj; c++) acc[c] = fma(lrow[c], xi, acc[c]);
     }
     for (int c = 0; c < dj; c++) {
       double v = acc[c];
@@ -191,6 +199,7 @@ __global__ __launch_bounds__(64) void sparse_back_kernel(SparseView V) {
     __builtin_amdgcn_wave_barrier();
   }
 }
+
 // the dense tail's solution to where the substitution reads it (by position) and to the solution vector; its flags are raised
 __global__ __launch_bounds__(64) void sparse_tail_scatter_kernel(SparseView V) {
   const int j = V.tail_start + blockIdx.x, c = threadIdx.x;
