@@ -530,6 +530,9 @@ def main():
                         os.environ.pop(k, None)
                         if v is not None:
                             os.environ[k] = v
+                    Gm = capi.ba_from_dict(prm, device=local_rank)       # ... and the one the library picks by itself
+                    paths["chosen_by_default"] = Gm.solver_path()
+                    Gm.close()
                     ref = xs["dense"]
                     ba_out["solver_paths"] = {"what": "one damped solve (reduce + factor + substitute) of a survey-flight graph -- %d cameras on a 48 x 40 grid, %d points, %d edges, %d unknowns in the reduced system: a 2-D covisibility mesh -- through each factorisation" % (len(prm["cams"]), len(prm["points"]), len(prm["e_pt"]), n_red_m),
                                               **paths,
