@@ -248,6 +248,7 @@ struct cs_ba {
   bool elim = false;        // free cuboids eliminated like landmarks (single rank, fused Schur schedule)
   // general sparse Cholesky of the reduced system (ba_sparse.h): graphs the ordering cannot band
   bool sparse = false;
+  bool sp_S_clean = false;     // S holds nothing outside the plan's pattern (set by the first trial's full clear)
   cs::SparsePlan sp_plan;
   DBuf<int> sp_ndim, sp_ncol, sp_sptr, sp_srow, sp_sroff, sp_prow, sp_rbase, sp_rent, sp_rptr, sp_rcol, sp_rpos, sp_order, sp_info;
   DBuf<long long> sp_poff;
@@ -617,7 +618,7 @@ int finalize_structure(cs_ba* B) {
     // (10 + 0.043 bw) us; dense rocSOLVER potrf -- n^3 / 3 at 11 Tflop/s + 1 ms; sparse -- 25 us per level of the elimination tree +
     // 1.5 ms per Gflop + the dense tail's n^3 / 3 at 3 Tflop/s (rocSOLVER at 1-2 k unknowns) + the dense assembly's extra cost (1 ms + the
     // n x n fill).  The plan (an O(N^2) minimum-degree sweep) is only built when the alternative costs more than 5 ms.  CS_BA_SPARSE=0 never, =1 whenever the plan fits.
-    B->sparse = false;
+    B->sparse = false; B->sp_S_clean = false;
     {
       const char* e = getenv("CS_BA_SPARSE");
       const int mode = e ? atoi(e) : -1;
@@ -1227,6 +1228,16 @@ int put_lambda(cs_ba* B, double lambda) {
   return CS_OK;
 }
 int solve_device_sep(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn, void* ctx, std::unique_lock<std::mutex>* defer);
+static cs::SparseView sparse_view(cs_ba* B) {
+  cs::SparseView SV;
+  SV.N = B->sp_plan.N; SV.n = B->n_red;
+  SV.ndim = B->sp_ndim.p; SV.ncol = B->sp_ncol.p; SV.sptr = B->sp_sptr.p; SV.srow = B->sp_srow.p; SV.sroff = B->sp_sroff.p; SV.prow = B->sp_prow.p;
+  SV.rbase = B->sp_rbase.p; SV.rent = B->sp_rent.p; SV.rptr = B->sp_rptr.p; SV.rcol = B->sp_rcol.p; SV.rpos = B->sp_rpos.p; SV.order = B->sp_order.p; SV.poff = B->sp_poff.p;
+  SV.tcol = B->sp_tcol.p; SV.tail_start = B->sp_plan.tail_start; SV.n_tail = B->sp_plan.n_tail; SV.T = B->sp_T.p; SV.rhs_t = B->sp_T.p + (size_t)SV.n_tail * SV.n_tail;
+  SV.S = B->S.p; SV.rhs = B->view.rhs; SV.L = B->sp_L.p; SV.xs = B->sp_xs.p; SV.done = B->sp_done.p; SV.xdone = B->sp_xdone.p; SV.info = B->sp_info.p;
+  return SV;
+}
+
 int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr, void* ctx = nullptr, std::unique_lock<std::mutex>* defer = nullptr) {
   const int n = B->n_red;
   *ok = true;
@@ -1234,7 +1245,14 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
   if (n > 0) {
     { int rcl = put_lambda(B, lambda); if (rcl) return rcl; }
     BA_TRY(hipEventRecord(B->ev[2], B->st));
-    BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (B->s_doubles + B->n_pose), B->st));
+    if (B->sparse && B->sp_S_clean) {
+      // (sparse path: S was cleared by the structure phase and only the plan's pattern is ever written -- the pattern and the right-hand side)
+      cs::launch_sparse_zero_pattern(sparse_view(B), B->S.p, B->st);
+      BA_TRY(hipMemsetAsync(B->S.p + B->s_doubles, 0, sizeof(double) * B->n_pose, B->st));
+    } else {
+      BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (B->s_doubles + B->n_pose), B->st));
+      B->sp_S_clean = B->sparse;
+    }
     BA_TRY(hipMemsetAsync(B->d_elim_fail.p, 0, sizeof(int), B->st));
     cs::ba_launch_reduce(B->view, B->d_lam.p, B->st, B->st2, B->ev_fork, B->ev_join);
     if (B->ext_n > 0 && B->ext_terms_set) cs::ba_launch_ext_offdiag(B->view, B->ext_n, B->d_ext_e4.p, B->ext_Hij.p, B->st);
@@ -1277,12 +1295,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       // general sparse: the pattern's blocks are gathered from the dense S by the factorisation itself (sparse_kernels.hip)
       std::unique_lock<std::mutex> coop_turn(g_coop_mutex);
       BA_TRY(hipMemsetAsync(B->sp_info.p, 0, 2 * sizeof(int), B->st));
-      cs::SparseView SV;
-      SV.N = B->sp_plan.N; SV.n = n;
-      SV.ndim = B->sp_ndim.p; SV.ncol = B->sp_ncol.p; SV.sptr = B->sp_sptr.p; SV.srow = B->sp_srow.p; SV.sroff = B->sp_sroff.p; SV.prow = B->sp_prow.p;
-      SV.rbase = B->sp_rbase.p; SV.rent = B->sp_rent.p; SV.rptr = B->sp_rptr.p; SV.rcol = B->sp_rcol.p; SV.rpos = B->sp_rpos.p; SV.order = B->sp_order.p; SV.poff = B->sp_poff.p;
-      SV.tcol = B->sp_tcol.p; SV.tail_start = B->sp_plan.tail_start; SV.n_tail = B->sp_plan.n_tail; SV.T = B->sp_T.p; SV.rhs_t = B->sp_T.p + (size_t)SV.n_tail * SV.n_tail;
-      SV.S = B->S.p; SV.rhs = B->view.rhs; SV.L = B->sp_L.p; SV.xs = B->sp_xs.p; SV.done = B->sp_done.p; SV.xdone = B->sp_xdone.p; SV.info = B->sp_info.p;
+      const cs::SparseView SV = sparse_view(B);
       cs::launch_sparse_cholesky(SV, cs::sparse_max_panel_doubles(), B->st);
       BA_TRY(hipGetLastError());
       BA_TRY(hipMemsetAsync(B->d_info.p, 0, sizeof(int), B->st));

@@ -165,6 +165,7 @@ struct SparseView {
 bool sparse_fits_device(int max_panel_doubles, int N);
 int sparse_max_panel_doubles();
 void launch_sparse_cholesky(const SparseView& V, int max_panel_doubles, hipStream_t st);     // factorisation (+ the tail's block assembled)
-void launch_sparse_backsolve(const SparseView& V, hipStream_t st);                           // after the tail's x sits in rhs_t: L^T x = y
+void launch_sparse_backsolve(const SparseView& V, hipStream_t st);
+void launch_sparse_zero_pattern(const SparseView& V, double* S, hipStream_t st);                // S's pattern blocks <- 0 (before a trial's assembly)                           // after the tail's x sits in rhs_t: L^T x = y
 
 }  // namespace cs
