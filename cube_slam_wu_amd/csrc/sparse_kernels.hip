@@ -16,7 +16,7 @@
 namespace cs {
 
 namespace {
-enum { SP_T = 256, SP_SPIN_LIMIT = 1 << 21, SP_TIMEOUT = 0x7fffffff };
+enum { SP_T = 256, SP_PF = 4, SB_PF = 3, SP_SPIN_LIMIT = 1 << 21, SP_TIMEOUT = 0x7fffffff };
 
 __device__ __forceinline__ void sp_gstore(double* p, double v) {
   __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -79,6 +79,26 @@ __global__ __launch_bounds__(SP_T) void sparse_chol_kernel(SparseView V, int pan
     // together up front -- 16 -> 43 ms: the columns of the near-clique region are factorised side by side on different workgroups, each
     // applying the others' columns as they appear, and waiting AHEAD of need serialises them.)
     const bool tail = j >= V.tail_start;
+    // (where an updating column's rows land in this panel is plan data, independent of its flag: the destinations of a thread's first
+    // SP_PF elements of the NEXT update are looked up -- three dependent loads: row -> entry -> vertex -> panel row -- while the barrier
+    // and the wait for that column's flag pass)
+    int pf_dst[SP_PF], pf_src[SP_PF];
+    auto prep = [&](int u) {
+      const bool none = u >= V.rptr[j + 1] || V.rcol[u] >= V.tail_start;
+      const int k = none ? 0 : V.rcol[u], ek = V.sptr[k], row0 = none ? 0 : V.sroff[ek + V.rpos[u]], R = none ? 0 : V.prow[k] - row0;
+      const int* rentk = V.rent + V.rbase[k] + row0;
+#pragma unroll
+      for (int q = 0; q < SP_PF; q++) {
+        const int e = tid + q * SP_T;
+        pf_dst[q] = -1; pf_src[q] = 0;
+        if (e < R * dj) {
+          const int rho = e / dj, b = e - rho * dj, t = rentk[rho];
+          const int i = V.srow[ek + t], a = row0 + rho - V.sroff[ek + t];
+          pf_dst[q] = (map[i] + a) * dj + b; pf_src[q] = row0 + rho;
+        }
+      }
+    };
+    prep(V.rptr[j]);
     for (int u = V.rptr[j]; u < V.rptr[j + 1]; u++) {
       const int k = V.rcol[u], t0 = V.rpos[u], dk = V.ndim[k], ek = V.sptr[k];
       if (k >= V.tail_start) break;                     // (ascending: the rest are tail columns, whose part the dense factorisation does)
@@ -92,8 +112,17 @@ __global__ __launch_bounds__(SP_T) void sparse_chol_kernel(SparseView V, int pan
       const int row0 = V.sroff[ek + t0], R = V.prow[k] - row0;
       if (tid < dj * dk) Ljk[tid] = Lk[(size_t)row0 * dk + tid];
       __syncthreads();
+#pragma unroll
+      for (int q = 0; q < SP_PF; q++) {
+        if (pf_dst[q] < 0) continue;
+        const int b = (tid + q * SP_T) % dj;
+        const double* src = Lk + (size_t)pf_src[q] * dk;
+        double s = 0.0;
+        for (int c = 0; c < dk; c++) s = fma(src[c], Ljk[b * dk + c], s);
+        P[pf_dst[q]] -= s;
+      }
       const int* rentk = V.rent + V.rbase[k] + row0;
-      for (int e = tid; e < R * dj; e += SP_T) {
+      for (int e = tid + SP_PF * SP_T; e < R * dj; e += SP_T) {
         const int rho = e / dj, b = e - rho * dj, t = rentk[rho];
         const int i = V.srow[ek + t], a = row0 + rho - V.sroff[ek + t];
         const double* src = Lk + (size_t)(row0 + rho) * dk;
@@ -101,6 +130,7 @@ __global__ __launch_bounds__(SP_T) void sparse_chol_kernel(SparseView V, int pan
         for (int c = 0; c < dk; c++) s = fma(src[c], Ljk[b * dk + c], s);
         P[(map[i] + a) * dj + b] -= s;
       }
+      prep(u + 1);
       __syncthreads();
     }
     if (tail) {
@@ -164,16 +194,38 @@ __global__ __launch_bounds__(64) void sparse_back_kernel(SparseView V) {
     const int j = V.order[idx], dj = V.ndim[j], cj = V.ncol[j], e0 = V.sptr[j], nent = V.sptr[j + 1] - e0 - 1;   // (without the right-hand side's entry)
     if (j >= V.tail_start) continue;                    // (solved by the dense factorisation; sparse_tail_scatter_kernel published it)
     const double* Lj = V.L + V.poff[j];
-    // the factorisation is complete (kernel boundary); wait for the solution of the vertices below
+    // the factorisation is complete (kernel boundary).  What does not depend on the vertices below -- a lane's first SB_PF rows of the
+    // panel and where their x sits -- is requested BEFORE the wait for them
+    const int* rentj = V.rent + V.rbase[j];
+    const int nrows = V.prow[j] - dj - 1;               // rows below the diagonal block, without the right-hand side's
+    double lpre[SB_PF][9];
+    int xat[SB_PF];
+#pragma unroll
+    for (int q = 0; q < SB_PF; q++) {
+      const int r = lane + 64 * q;
+      xat[q] = -1;
+      if (r < nrows) {
+        const int rho = dj + r, t = rentj[rho];
+        xat[q] = V.srow[e0 + t] * 9 + (rho - V.sroff[e0 + t]);
+        const double* lrow = Lj + (size_t)rho * dj;
+#pragma unroll
+        for (int c = 0; c < 9; c++) lpre[q][c] = c < dj ? lrow[c] : 0.0;
+      }
+    }
     int ok = 1;
     for (int t = lane; t < nent; t += 64) ok &= sp_wait(V.xdone + V.srow[e0 + t], V.info) ? 1 : 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (__ballot(!ok)) return;
-    const int* rentj = V.rent + V.rbase[j];
-    const int nrows = V.prow[j] - dj - 1;               // rows below the diagonal block, without the right-hand side's
     double acc[9];
     for (int c = 0; c < 9; c++) acc[c] = 0.0;
-    for (int r = lane; r < nrows; r += 64) {
+#pragma unroll
+    for (int q = 0; q < SB_PF; q++) {
+      if (xat[q] < 0) continue;
+      const double xi = V.xs[xat[q]];
+#pragma unroll
+      for (int c = 0; c < 9; c++) acc[c] = fma(lpre[q][c], xi, acc[c]);
+    }
+    for (int r = lane + 64 * SB_PF; r < nrows; r += 64) {
       const int rho = dj + r, t = rentj[rho], i = V.srow[e0 + t];
       const double xi = V.xs[(size_t)i * 9 + (rho - V.sroff[e0 + t])];
       const double* lrow = Lj + (size_t)rho * dj;
