@@ -279,7 +279,7 @@ struct cs_ba {
   DBuf<int> pair_ptr, pair_i1, pair_i2, ent_a, ent_b;
   // fused Schur schedule (BaView::fused)
   bool fused = false;
-  int n_seg = 0, n_gpairs = 0, seg_class[2] = {0, 0};
+  int n_seg = 0, n_gpairs = 0, seg_class[4] = {0, 0, 0, 0};
   DBuf<int> d_run_lm, d_seg_ptr, d_seg_k, d_seg_tile, d_seg_slot, d_gp_ptr, d_gp_i1, d_gp_i2, d_gtile, d_gcam_ptr, d_gslot;
   DBuf<double> part_tiles, part_coef;
   DBuf<rocblas_int> d_info;
@@ -806,7 +806,7 @@ int finalize_structure(cs_ba* B) {
   // (or with CS_BA_SCHUR_PAIRS=1, diagnostics) the pair-major path: (landmark, i1 <= i2) entries grouped by camera pair.
   B->fused = getenv("CS_BA_SCHUR_PAIRS") == nullptr;
   for (int p : gorder) if (owner[p] == B->shard_rank && cam_cnt[p + 1] - cam_cnt[p] > cs::BA_FUSED_KMAX) { B->fused = false; break; }
-  B->n_seg = 0; B->n_gpairs = 0; B->seg_class[0] = B->seg_class[1] = 0;
+  B->n_seg = 0; B->n_gpairs = 0; B->seg_class[0] = B->seg_class[1] = B->seg_class[2] = B->seg_class[3] = 0;
   B->schur_entries = 0;
   for (int p : gorder) if (owner[p] == B->shard_rank) { const long long k = cam_cnt[p + 1] - cam_cnt[p]; B->schur_entries += k * (k + 1) / 2; }
   if (B->fused) {
@@ -883,7 +883,12 @@ int finalize_structure(cs_ba* B) {
     UP(B->d_cubS_ptr, cubS_ptr); UP(B->d_cubS_cam, cubS_cam); UP(B->d_ce_slot, ce_slot); UP(B->d_cub_tile, cub_tile); UP(B->d_cub_coef, cub_coef);
     AL(B->cub_M, 54 * cubS_cam.size()); AL(B->cub_Dinv, 81 * (size_t)std::max(1, no)); AL(B->d_elim_fail, 1);
     B->n_seg = (int)seg_k.size();
-    for (int sgi = 0; sgi < B->n_seg; sgi++) { if (seg_k[sgi] <= 2) B->seg_class[0] = sgi + 1; if (seg_k[sgi] <= 5) B->seg_class[1] = sgi + 1; }   // segments are sorted by k
+    for (int sgi = 0; sgi < B->n_seg; sgi++) {   // segments are sorted by k
+      if (seg_k[sgi] <= 2) B->seg_class[0] = sgi + 1;
+      if (seg_k[sgi] <= 5) B->seg_class[1] = sgi + 1;
+      if (seg_k[sgi] <= 7) B->seg_class[2] = sgi + 1;
+      if (seg_k[sgi] <= 10) B->seg_class[3] = sgi + 1;
+    }
     // by destination block, the partial blocks of one destination in creation (= segment) order: ids grow with creation, so (key, id) is the stable order
     parallel_sort(dst.begin(), dst.end(), [](const Dst& x, const Dst& y) { return x.key != y.key ? x.key < y.key : x.id < y.id; }, (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
     std::vector<int> gp_ptr, gp_i1, gp_i2, gtile(dst.size());
@@ -1095,7 +1100,7 @@ int finalize_structure(cs_ba* B) {
   v.Hcam = B->Hcam.p; v.bcam = B->bcam.p; v.Hcub = B->Hcub.p; v.bcub = B->bcub.p; v.Hll = B->Hll.p; v.bl = B->bl.p; v.W = B->W.p; v.WD = B->WD.p;
   v.Dinv = B->Dinv.p; v.dbl = B->dbl.p; v.S = B->S.p; v.band_ld = B->band_ld; v.lam_lo = B->sep_mode ? B->cut[B->shard_rank] : 0; v.lam_hi = B->sep_mode ? B->cut[B->shard_rank + 1] : (B->shard_rank == 0 ? 0x7fffffff : 0); v.rhs = B->S.p + B->s_doubles; v.xl = B->xl.p;
   v.n_pairs = B->n_pairs; v.pair_ptr = B->pair_ptr.p; v.pair_i1 = B->pair_i1.p; v.pair_i2 = B->pair_i2.p; v.ent_a = B->ent_a.p; v.ent_b = B->ent_b.p;
-  v.fused = B->fused ? 1 : 0; v.n_seg = B->n_seg; v.seg_class[0] = B->seg_class[0]; v.seg_class[1] = B->seg_class[1];
+  v.fused = B->fused ? 1 : 0; v.n_seg = B->n_seg; for (int q = 0; q < 4; q++) v.seg_class[q] = B->seg_class[q];
   v.seg_ptr = B->d_seg_ptr.p; v.seg_k = B->d_seg_k.p; v.seg_tile = B->d_seg_tile.p; v.seg_slot = B->d_seg_slot.p; v.run_lm = B->d_run_lm.p;
   v.part_tiles = B->part_tiles.p; v.part_coef = B->part_coef.p;
   v.n_gpairs = B->n_gpairs; v.gpair_ptr = B->d_gp_ptr.p; v.gpair_i1 = B->d_gp_i1.p; v.gpair_i2 = B->d_gp_i2.p; v.gtile = B->d_gtile.p;

@@ -718,7 +718,7 @@ __device__ __forceinline__ void ba_schur_segment(const BaView& v, double lambda,
 }
 
 // one instantiation per tile count (the segments are sorted by k, so each launch covers a contiguous range): MT = 1 for k <= 2
-// (12 rows + the right-hand-side column), 2 for k <= 5 (30 + 1), 3 for k <= BA_FUSED_KMAX = 7 (42 + 1)
+// (12 rows + the right-hand-side column), 2 for k <= 5 (30 + 1), 3 for k <= 7 (42 + 1), 4 for k <= 10 (60 + 1), 5 for k <= BA_FUSED_KMAX = 13 (78 + 1)
 template <int MT>
 __global__ __launch_bounds__(256) void ba_schur_fused_kernel(BaView v, const double* __restrict__ lamp, int seg_begin, int seg_end) {
   const double lambda = lamp[0];
@@ -2435,9 +2435,15 @@ void ba_launch_reduce(const BaView& v, const double* lambda, hipStream_t st, hip
     }
     // the diagonal blocks / right-hand side of the cameras need the segments' partial vectors; the gather of the blocks runs last
     // (it subtracts from entries the vertex kernels have written)
-    if (v.seg_class[0] > 0) hipLaunchKernelGGL(ba_schur_fused_kernel<1>, dim3((v.seg_class[0] + 3) / 4), dim3(256), 0, st, v, lambda, 0, v.seg_class[0]);
-    if (v.seg_class[1] > v.seg_class[0]) hipLaunchKernelGGL(ba_schur_fused_kernel<2>, dim3((v.seg_class[1] - v.seg_class[0] + 3) / 4), dim3(256), 0, st, v, lambda, v.seg_class[0], v.seg_class[1]);
-    if (v.n_seg > v.seg_class[1]) hipLaunchKernelGGL(ba_schur_fused_kernel<3>, dim3((v.n_seg - v.seg_class[1] + 3) / 4), dim3(256), 0, st, v, lambda, v.seg_class[1], v.n_seg);
+    {
+      // (class boundaries are cumulative: a class without segments repeats the boundary before it)
+      int c0 = v.seg_class[0], c1 = max(c0, v.seg_class[1]), c2 = max(c1, v.seg_class[2]), c3 = max(c2, v.seg_class[3]);
+      if (c0 > 0) hipLaunchKernelGGL(ba_schur_fused_kernel<1>, dim3((c0 + 3) / 4), dim3(256), 0, st, v, lambda, 0, c0);
+      if (c1 > c0) hipLaunchKernelGGL(ba_schur_fused_kernel<2>, dim3((c1 - c0 + 3) / 4), dim3(256), 0, st, v, lambda, c0, c1);
+      if (c2 > c1) hipLaunchKernelGGL(ba_schur_fused_kernel<3>, dim3((c2 - c1 + 3) / 4), dim3(256), 0, st, v, lambda, c1, c2);
+      if (c3 > c2) hipLaunchKernelGGL(ba_schur_fused_kernel<4>, dim3((c3 - c2 + 3) / 4), dim3(256), 0, st, v, lambda, c2, c3);
+      if (v.n_seg > c3) hipLaunchKernelGGL(ba_schur_fused_kernel<5>, dim3((v.n_seg - c3 + 3) / 4), dim3(256), 0, st, v, lambda, c3, v.n_seg);
+    }
     if (side) (void)hipStreamWaitEvent(st, ev_join, 0);
     else if (v.elim && v.no > 0) hipLaunchKernelGGL(ba_cub_elim_kernel, dim3(v.no), dim3(256), 0, st, v, lambda);
     hipLaunchKernelGGL(ba_cam_rhs_fused_kernel, dim3(v.nc), dim3(64), 0, st, v, lambda);
