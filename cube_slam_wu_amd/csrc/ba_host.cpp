@@ -279,7 +279,7 @@ struct cs_ba {
   DBuf<int> pair_ptr, pair_i1, pair_i2, ent_a, ent_b;
   // fused Schur schedule (BaView::fused)
   bool fused = false;
-  int n_seg = 0, n_gpairs = 0, seg_class[4] = {0, 0, 0, 0};
+  int n_seg = 0, n_gpairs = 0, seg_class[5] = {0, 0, 0, 0, 0};
   DBuf<int> d_run_lm, d_seg_ptr, d_seg_k, d_seg_tile, d_seg_slot, d_gp_ptr, d_gp_i1, d_gp_i2, d_gtile, d_gcam_ptr, d_gslot;
   DBuf<double> part_tiles, part_coef;
   DBuf<rocblas_int> d_info;
@@ -526,7 +526,17 @@ int finalize_structure(cs_ba* B) {
     if (!B->cub_fixed[o]) n_free_cub++;
   }
   bool fused_ok = getenv("CS_BA_SCHUR_PAIRS") == nullptr;
-  for (int p : gorder) if (cam_cnt[p + 1] - cam_cnt[p] > cs::BA_FUSED_KMAX) { fused_ok = false; break; }
+  {
+    // (tracks of more than BA_FUSED_KMAX views go through the segments' plain multiply-add kernel: meant for the tail of a map -- when a
+    // quarter of the landmarks are such tracks the pair-major path is the faster build again, measured at C4's size with 20 views each)
+    size_t n_long = 0;
+    for (int p : gorder) {
+      const int kk = cam_cnt[p + 1] - cam_cnt[p];
+      if (kk > cs::BA_LONG_KMAX) { fused_ok = false; break; }
+      if (kk > cs::BA_FUSED_KMAX) n_long++;
+    }
+    if (4 * n_long > gorder.size()) fused_ok = false;
+  }
   struct Ordering { std::vector<int> cam_col, cub_col; int n_red = 0, bw = 0; std::vector<std::vector<int>> adj; std::vector<int> free_ids; };
   auto make_ordering = [&](bool elim) -> Ordering {
     Ordering O;
@@ -802,11 +812,11 @@ int finalize_structure(cs_ba* B) {
   UPB(B->cm_pt, cm_pt); UP(B->cam_ptr, cam_ptr);
   mark("edge orderings + upload");
   // ---- Schur pattern (block_solver.hpp:262-292).  Fused path: segments of landmarks with one camera set + the destination
-  // schedule of their partial blocks (BaView::fused).  It needs every landmark to be seen by <= BA_FUSED_KMAX cameras; otherwise
+  // schedule of their partial blocks (BaView::fused).  It needs every landmark to be seen by <= BA_LONG_KMAX cameras; otherwise
   // (or with CS_BA_SCHUR_PAIRS=1, diagnostics) the pair-major path: (landmark, i1 <= i2) entries grouped by camera pair.
-  B->fused = getenv("CS_BA_SCHUR_PAIRS") == nullptr;
-  for (int p : gorder) if (owner[p] == B->shard_rank && cam_cnt[p + 1] - cam_cnt[p] > cs::BA_FUSED_KMAX) { B->fused = false; break; }
-  B->n_seg = 0; B->n_gpairs = 0; B->seg_class[0] = B->seg_class[1] = B->seg_class[2] = B->seg_class[3] = 0;
+  B->fused = fused_ok;        // (CS_BA_SCHUR_PAIRS unset, no track beyond BA_LONG_KMAX views, long tracks a minority: decided with the orderings above)
+  for (int p : gorder) if (owner[p] == B->shard_rank && cam_cnt[p + 1] - cam_cnt[p] > cs::BA_LONG_KMAX) { B->fused = false; break; }
+  B->n_seg = 0; B->n_gpairs = 0; B->seg_class[0] = B->seg_class[1] = B->seg_class[2] = B->seg_class[3] = B->seg_class[4] = 0;
   B->schur_entries = 0;
   for (int p : gorder) if (owner[p] == B->shard_rank) { const long long k = cam_cnt[p + 1] - cam_cnt[p]; B->schur_entries += k * (k + 1) / 2; }
   if (B->fused) {
@@ -888,6 +898,7 @@ int finalize_structure(cs_ba* B) {
       if (seg_k[sgi] <= 5) B->seg_class[1] = sgi + 1;
       if (seg_k[sgi] <= 7) B->seg_class[2] = sgi + 1;
       if (seg_k[sgi] <= 10) B->seg_class[3] = sgi + 1;
+      if (seg_k[sgi] <= cs::BA_FUSED_KMAX) B->seg_class[4] = sgi + 1;
     }
     // by destination block, the partial blocks of one destination in creation (= segment) order: ids grow with creation, so (key, id) is the stable order
     parallel_sort(dst.begin(), dst.end(), [](const Dst& x, const Dst& y) { return x.key != y.key ? x.key < y.key : x.id < y.id; }, (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
@@ -1100,7 +1111,7 @@ int finalize_structure(cs_ba* B) {
   v.Hcam = B->Hcam.p; v.bcam = B->bcam.p; v.Hcub = B->Hcub.p; v.bcub = B->bcub.p; v.Hll = B->Hll.p; v.bl = B->bl.p; v.W = B->W.p; v.WD = B->WD.p;
   v.Dinv = B->Dinv.p; v.dbl = B->dbl.p; v.S = B->S.p; v.band_ld = B->band_ld; v.lam_lo = B->sep_mode ? B->cut[B->shard_rank] : 0; v.lam_hi = B->sep_mode ? B->cut[B->shard_rank + 1] : (B->shard_rank == 0 ? 0x7fffffff : 0); v.rhs = B->S.p + B->s_doubles; v.xl = B->xl.p;
   v.n_pairs = B->n_pairs; v.pair_ptr = B->pair_ptr.p; v.pair_i1 = B->pair_i1.p; v.pair_i2 = B->pair_i2.p; v.ent_a = B->ent_a.p; v.ent_b = B->ent_b.p;
-  v.fused = B->fused ? 1 : 0; v.n_seg = B->n_seg; for (int q = 0; q < 4; q++) v.seg_class[q] = B->seg_class[q];
+  v.fused = B->fused ? 1 : 0; v.n_seg = B->n_seg; for (int q = 0; q < 5; q++) v.seg_class[q] = B->seg_class[q];
   v.seg_ptr = B->d_seg_ptr.p; v.seg_k = B->d_seg_k.p; v.seg_tile = B->d_seg_tile.p; v.seg_slot = B->d_seg_slot.p; v.run_lm = B->d_run_lm.p;
   v.part_tiles = B->part_tiles.p; v.part_coef = B->part_coef.p;
   v.n_gpairs = B->n_gpairs; v.gpair_ptr = B->d_gp_ptr.p; v.gpair_i1 = B->d_gp_i1.p; v.gpair_i2 = B->d_gp_i2.p; v.gtile = B->d_gtile.p;

@@ -727,6 +727,75 @@ __global__ __launch_bounds__(256) void ba_schur_fused_kernel(BaView v, const dou
   ba_schur_segment<MT>(v, lambda, seg, v.seg_k[seg]);
 }
 
+// Long tracks (BA_FUSED_KMAX < k <= BA_LONG_KMAX cameras: the tail of a real map, landmarks seen from dozens of key frames): the same
+// segment, the same partial blocks and vectors for the destination schedule, formed with plain multiply-adds -- a wavefront per
+// segment, its landmarks one after the other (such landmarks rarely share their camera set: usually one), W and W D^-1 of the landmark
+// in LDS, the k (k + 1) / 2 blocks spread over the lanes.  Without it ONE such landmark sent the whole problem to the pair-major path.
+__global__ __launch_bounds__(256) void ba_schur_long_kernel(BaView v, const double* __restrict__ lamp, int seg_begin, int seg_end) {
+  __shared__ double Wl[4][6 * BA_LONG_KMAX * 3], WDl[4][6 * BA_LONG_KMAX * 3];
+  const double lambda = lamp[0];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int seg = __builtin_amdgcn_readfirstlane(seg_begin + blockIdx.x * 4 + wv);
+  if (seg >= seg_end) return;
+  const int k = v.seg_k[seg], rows = 6 * k, q0 = v.seg_ptr[seg], q1 = v.seg_ptr[seg + 1], tile0 = v.seg_tile[seg], slot0 = v.seg_slot[seg];
+  const int npair = k * (k + 1) / 2;
+  double* W = Wl[wv];
+  double* WD = WDl[wv];
+  for (int q = q0; q < q1; q++) {
+    const int p = v.run_lm[q], e0 = v.pt_ptr[p];
+    double D[9], Di[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) D[e] = v.Hll[9 * (size_t)p + e];
+    D[0] += lambda; D[4] += lambda; D[8] += lambda;
+    inv3x3(D, Di);
+    if (lane < 9) v.Dinv[9 * (size_t)p + lane] = Di[lane];
+    const double bl0 = v.bl[3 * (size_t)p], bl1 = v.bl[3 * (size_t)p + 1], bl2 = v.bl[3 * (size_t)p + 2];
+    const double* Wp = v.W + 18 * (size_t)e0;            // the landmark's k edges, camera slots ascending: row 6 a + r at Wp + 3 (6 a + r)
+    __builtin_amdgcn_wave_barrier();
+    for (int row = lane; row < rows; row += 64) {
+      const double w0 = Wp[3 * row], w1 = Wp[3 * row + 1], w2 = Wp[3 * row + 2];
+      W[3 * row] = w0; W[3 * row + 1] = w1; W[3 * row + 2] = w2;
+#pragma unroll
+      for (int m = 0; m < 3; m++) WD[3 * row + m] = w0 * Di[m] + w1 * Di[3 + m] + w2 * Di[6 + m];       // (W D^-1)(row, m), as ba_wd_kernel
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool first = q == q0;
+    // an item = one row of one block: (pair of slots, r) -> the six entries (r, 0 .. 5), 48 contiguous bytes of the tile
+    for (int item = lane; item < 6 * npair; item += 64) {
+      const int pi = item / 6, r = item - 6 * pi;
+      // pair index -> (sa, sb), sa <= sb: pi = sa k - sa (sa - 1) / 2 + (sb - sa)
+      const float tk = (float)(2 * k + 1);
+      int sa = (int)((tk - __builtin_sqrtf(tk * tk - 8.0f * (float)pi)) * 0.5f);
+      sa = max(0, min(k - 1, sa));
+      while (sa > 0 && sa * k - sa * (sa - 1) / 2 > pi) sa--;
+      while ((sa + 1) * k - (sa + 1) * sa / 2 <= pi) sa++;
+      const int sb = sa + (pi - (sa * k - sa * (sa - 1) / 2));
+      const double* x = WD + 3 * (6 * sa + r);
+      const double x0 = x[0], x1 = x[1], x2 = x[2];
+      const double* y = W + 18 * sb;
+      double* dst = v.part_tiles + 36 * (size_t)(tile0 + pi) + 6 * r;
+      double val[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) val[c] = fma(x2, y[3 * c + 2], fma(x1, y[3 * c + 1], x0 * y[3 * c]));
+      const int c_lo = sa == sb ? r : 0;                 // (diagonal blocks: the upper triangle is what the reduced system stores)
+      if (first) {                                       // (wave-uniform: the segment's first landmark stores, the others add -- no load before a plain store)
+#pragma unroll
+        for (int c = 0; c < 6; c++) if (c >= c_lo) dst[c] = val[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < 6; c++) if (c >= c_lo) dst[c] += val[c];
+      }
+    }
+    for (int row = lane; row < rows; row += 64) {
+      const double val = fma(WD[3 * row + 2], bl2, fma(WD[3 * row + 1], bl1, WD[3 * row] * bl0));
+      double* dst = v.part_coef + 6 * (size_t)slot0 + row;
+      if (first) *dst = val; else *dst += val;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+}
+
 // destination schedule, blocks: one wavefront per block of the reduced system sums the partial blocks written for it, in the
 // order of the segments (fixed: the result does not depend on scheduling), and subtracts the sum (block_solver.hpp:409-431)
 __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaView v) {
@@ -2442,7 +2511,9 @@ void ba_launch_reduce(const BaView& v, const double* lambda, hipStream_t st, hip
       if (c1 > c0) hipLaunchKernelGGL(ba_schur_fused_kernel<2>, dim3((c1 - c0 + 3) / 4), dim3(256), 0, st, v, lambda, c0, c1);
       if (c2 > c1) hipLaunchKernelGGL(ba_schur_fused_kernel<3>, dim3((c2 - c1 + 3) / 4), dim3(256), 0, st, v, lambda, c1, c2);
       if (c3 > c2) hipLaunchKernelGGL(ba_schur_fused_kernel<4>, dim3((c3 - c2 + 3) / 4), dim3(256), 0, st, v, lambda, c2, c3);
-      if (v.n_seg > c3) hipLaunchKernelGGL(ba_schur_fused_kernel<5>, dim3((v.n_seg - c3 + 3) / 4), dim3(256), 0, st, v, lambda, c3, v.n_seg);
+      const int c4 = max(c3, v.seg_class[4]);
+      if (c4 > c3) hipLaunchKernelGGL(ba_schur_fused_kernel<5>, dim3((c4 - c3 + 3) / 4), dim3(256), 0, st, v, lambda, c3, c4);
+      if (v.n_seg > c4) hipLaunchKernelGGL(ba_schur_long_kernel, dim3((v.n_seg - c4 + 3) / 4), dim3(256), 0, st, v, lambda, c4, v.n_seg);
     }
     if (side) (void)hipStreamWaitEvent(st, ev_join, 0);
     else if (v.elim && v.no > 0) hipLaunchKernelGGL(ba_cub_elim_kernel, dim3(v.no), dim3(256), 0, st, v, lambda);

@@ -80,7 +80,7 @@ struct BaView {
   // dimension, and writes k (k + 1) / 2 partial 6 x 6 blocks + k partial 6-vectors of W D^-1 b_l; per destination block / camera
   // the partials are then summed in a fixed order (gpair_* / gcam_*: the destination schedule).
   int fused;                    // 0 = pair-major path (ba_prep / ba_wd / ba_schur kernels)
-  int n_seg; int seg_class[4];   // segments [0, seg_class[0]): k <= 2, then k <= 5, k <= 7, k <= 10, the rest: k <= 13 (one 16-row tile more per class)
+  int n_seg; int seg_class[5];   // segments [0, seg_class[0]): k <= 2, then k <= 5, k <= 7, k <= 10, k <= 13 (one 16-row tile more per class), the rest: long tracks, k <= BA_LONG_KMAX
   const int* seg_ptr; const int* seg_k; const int* seg_tile; const int* seg_slot; const int* run_lm;
   double* part_tiles;           // 36 per partial block
   double* part_coef;            // 6 per (segment, camera slot)
@@ -89,7 +89,7 @@ struct BaView {
   // chi2 partial sums
   double* chi_partial;
 };
-enum { BA_SEG_LM = 32, BA_FUSED_KMAX = 13, BA_ELIM_MAX_SLOTS = 64 };   // (6 k + 1 <= 80 rows = five tiles: 15 accumulator tiles per wavefront)
+enum { BA_SEG_LM = 32, BA_FUSED_KMAX = 13, BA_LONG_KMAX = 32, BA_ELIM_MAX_SLOTS = 64 };   // (6 k + 1 <= 80 rows = five tiles: 15 accumulator tiles per wavefront)
 
 CS_HD double* ba_S_at(const BaView& v, int r, int c) {  // requires r >= c (and r - c < band_ld in band mode)
   return v.band_ld ? v.S + (size_t)c * v.band_ld + (r - c) : v.S + (size_t)r * v.n_red + c;
