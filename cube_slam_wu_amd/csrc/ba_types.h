@@ -89,7 +89,7 @@ struct BaView {
   // chi2 partial sums
   double* chi_partial;
 };
-enum { BA_SEG_LM = 32, BA_FUSED_KMAX = 13, BA_LONG_KMAX = 32, BA_ELIM_MAX_SLOTS = 64 };   // (6 k + 1 <= 80 rows = five tiles: 15 accumulator tiles per wavefront)
+enum { BA_SEG_LM = 32, BA_FUSED_KMAX = 13, BA_LONG_KMAX = 64, BA_ELIM_MAX_SLOTS = 64 };   // (6 k + 1 <= 80 rows = five tiles: 15 accumulator tiles per wavefront)
 
 CS_HD double* ba_S_at(const BaView& v, int r, int c) {  // requires r >= c (and r - c < band_ld in band mode)
   return v.band_ld ? v.S + (size_t)c * v.band_ld + (r - c) : v.S + (size_t)r * v.n_red + c;

@@ -398,8 +398,8 @@ int cs_ba_solver_path(cs_ba* ba, int* path, int* bandwidth, double* sparse_fill)
 /* How the Schur complement S -= sum_j W_j D_j^-1 W_j^T (block_solver.hpp:385-431) is formed.  fused = 1: landmarks grouped by
  * camera set, one wavefront per segment of <= 32 landmarks, the product on the matrix cores (v_mfma_f64_16x16x4_f64) with the
  * landmarks as contraction dimension, n_partial_blocks partial 6x6 blocks summed per destination in a fixed order; fused = 0
- * (some landmark is seen by more than 32 cameras, or more than a quarter of them by more than 13, or CS_BA_SCHUR_PAIRS=1): one wavefront
- * per covisible camera pair.  Tracks of 14 .. 32 views ride in the fused schedule through a plain multiply-add kernel.
+ * (some landmark is seen by more than 64 cameras, or more than a quarter of them by more than 13, or CS_BA_SCHUR_PAIRS=1): one wavefront
+ * per covisible camera pair.  Tracks of 14 .. 64 views ride in the fused schedule through a plain multiply-add kernel.
  * n_blocks = 6x6 blocks of S the landmarks touch.                                                                  */
 int cs_ba_schur_layout(cs_ba* ba, int* fused, int* n_segments, int* n_partial_blocks, int* n_blocks);
 /* Inspection for parity tests (host copies, caller-sized): dense Hpp (size_pose^2, no lambda), Hll (9 per
