@@ -46,37 +46,44 @@ inline bool sparse_plan_build(const std::vector<std::vector<int>>& adj, const st
   if (N == 0) return false;
   std::vector<int> local(adj.size(), -1);
   for (int a = 0; a < N; a++) local[verts[a]] = a;
-  std::vector<std::vector<int>> nb(N);
+  // ---- minimum degree (weighted by unknowns) on the plain elimination graph, the vertices' neighbourhoods as BIT ROWS: eliminating a
+  // vertex ORs its row into its neighbours' (N / 64 words each) -- with sorted lists and set_union the same sweep took 230 ms at 3 072
+  // vertices (a 2-D mesh's fill), a tenth of that this way.  N is a few thousand at most (the kernel's LDS map bounds it).
+  const int Wd = (N + 63) / 64;
+  std::vector<unsigned long long> bits((size_t)N * Wd, 0ull), mask9(Wd, 0ull), S(Wd);
   for (int a = 0; a < N; a++) {
-    for (int w : adj[verts[a]]) if (local[w] >= 0 && local[w] != a) nb[a].push_back(local[w]);
-    std::sort(nb[a].begin(), nb[a].end());
-    nb[a].erase(std::unique(nb[a].begin(), nb[a].end()), nb[a].end());
+    if (dim[verts[a]] == 9) mask9[a >> 6] |= 1ull << (a & 63);
+    for (int w : adj[verts[a]]) { const int b2 = local[w]; if (b2 >= 0 && b2 != a) bits[(size_t)a * Wd + (b2 >> 6)] |= 1ull << (b2 & 63); }
   }
-  // ---- minimum degree (weighted by unknowns), plain elimination graph: N is a few thousand at most
   std::vector<int> pos(N, -1), at(N);
   std::vector<char> gone(N, 0);
   std::vector<std::vector<int>> colstruct(N);      // by elimination position: local ids of the rows below
   std::vector<long long> deg(N);
-  auto weight = [&](int a) { long long s = 0; for (int w : nb[a]) s += dim[verts[w]]; return s; };
+  auto weight = [&](int a) {                        // unknowns of the neighbours: 6 per vertex, 9 for the cuboids
+    const unsigned long long* r = bits.data() + (size_t)a * Wd;
+    long long c6 = 0, c9 = 0;
+    for (int w = 0; w < Wd; w++) { c6 += __builtin_popcountll(r[w]); c9 += __builtin_popcountll(r[w] & mask9[w]); }
+    return 6 * c6 + 3 * c9;
+  };
   for (int a = 0; a < N; a++) deg[a] = weight(a);
-  std::vector<int> merged;
-  long long total_rows = 0;
   for (int step = 0; step < N; step++) {
     int best = -1;
     for (int a = 0; a < N; a++) if (!gone[a] && (best < 0 || deg[a] < deg[best])) best = a;
     pos[best] = step; at[step] = best; gone[best] = 1;
-    colstruct[step] = nb[best];
-    const std::vector<int>& S = colstruct[step];
-    for (int u : S) {
-      // nb[u] = (nb[u] U S) \ {u, best}
-      merged.clear();
-      std::set_union(nb[u].begin(), nb[u].end(), S.begin(), S.end(), std::back_inserter(merged));
-      merged.erase(std::remove_if(merged.begin(), merged.end(), [&](int w) { return w == u || w == best; }), merged.end());
-      nb[u].swap(merged);
+    const unsigned long long* rb = bits.data() + (size_t)best * Wd;
+    std::vector<int>& cs_ = colstruct[step];
+    for (int w = 0; w < Wd; w++) {
+      S[w] = rb[w];
+      for (unsigned long long m = rb[w]; m; m &= m - 1) cs_.push_back(64 * w + __builtin_ctzll(m));
+    }
+    const unsigned long long bbit = 1ull << (best & 63);
+    for (int u : cs_) {
+      unsigned long long* ru = bits.data() + (size_t)u * Wd;
+      for (int w = 0; w < Wd; w++) ru[w] |= S[w];
+      ru[u >> 6] &= ~(1ull << (u & 63));
+      ru[best >> 6] &= ~bbit;
       deg[u] = weight(u);
     }
-    for (int u : S) total_rows += dim[verts[u]];
-    nb[best].clear(); nb[best].shrink_to_fit();
   }
   // ---- by position
   P.ndim.resize(N + 1); P.ncol.resize(N + 1);
