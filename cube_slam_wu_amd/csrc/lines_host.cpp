@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/cubeslam_hip.h"
+#include "batch_gate.h"
 #include "cs_nfa.h"
 
 void cs_set_error_ba(const std::string& s);
@@ -234,7 +235,9 @@ struct Extractor {
 struct LinesScratch {
   unsigned char* d_gray = nullptr; unsigned char* d_u8 = nullptr; short* d_s16 = nullptr;
   char* h_pin = nullptr;           // per image: g, dx, dy (short each), dir, anchor (byte each) = 8 bytes per pixel
+  unsigned char* h_in = nullptr;   // pinned: the batch's images side by side (one upload)
   size_t cap = 0;                  // pixels x images
+  cs::ChunkEvents chunks;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double device_ms = 0, host_ms = 0, total_ms = 0;
   int n_images = 0;
@@ -246,6 +249,8 @@ void lines_scratch_free(void* p) {
   if (S->d_u8) (void)hipFree(S->d_u8);
   if (S->d_s16) (void)hipFree(S->d_s16);
   if (S->h_pin) (void)hipHostFree(S->h_pin);
+  if (S->h_in) (void)hipHostFree(S->h_in);
+  S->chunks.release();
   if (S->ev0) (void)hipEventDestroy(S->ev0);
   if (S->ev1) (void)hipEventDestroy(S->ev1);
   delete S;
@@ -327,11 +332,13 @@ extern "C" int cs_detect_lines_batch(cs_detector* d, const unsigned char* const*
       if (S.d_u8) (void)hipFree(S.d_u8);
       if (S.d_s16) (void)hipFree(S.d_s16);
       if (S.h_pin) (void)hipHostFree(S.h_pin);
-      S.d_gray = S.d_u8 = nullptr; S.d_s16 = nullptr; S.h_pin = nullptr; S.cap = 0;
+      if (S.h_in) (void)hipHostFree(S.h_in);
+      S.d_gray = S.d_u8 = nullptr; S.d_s16 = nullptr; S.h_pin = nullptr; S.h_in = nullptr; S.cap = 0;
       LN_TRY(hipMalloc((void**)&S.d_gray, need));
       LN_TRY(hipMalloc((void**)&S.d_u8, 2 * need));
       LN_TRY(hipMalloc((void**)&S.d_s16, 3 * need * sizeof(short)));
       LN_TRY(hipHostMalloc((void**)&S.h_pin, 8 * need));
+      LN_TRY(hipHostMalloc((void**)&S.h_in, need));
       S.cap = need;
     }
     if (!S.ev0) { LN_TRY(hipEventCreate(&S.ev0)); LN_TRY(hipEventCreate(&S.ev1)); }
@@ -343,25 +350,15 @@ extern "C" int cs_detect_lines_batch(cs_detector* d, const unsigned char* const*
       sum = 1. / sum;
       for (int i = 0; i < 3; i++) k[i] = (int)std::nearbyint((double)(float)(cf[i] * sum) * 256.0);
     }
-    for (int i = 0; i < n_images; i++) LN_TRY(hipMemcpyAsync(S.d_gray + (size_t)i * N, grays[i], N, hipMemcpyHostToDevice, st));
-    LN_TRY(hipEventRecord(S.ev0, st));
-    {   // one launch for the whole batch (blockIdx.z = image)
-      cs::LineMaps dm{S.d_s16, S.d_s16 + N, S.d_s16 + 2 * N, S.d_u8, S.d_u8 + N};
-      cs::launch_lines_maps(S.d_gray, img_w, img_h, dm, k, P.grad_thr, P.anchor_thr, P.scan, st, n_images);
-    }
-    LN_TRY(hipGetLastError());
-    LN_TRY(hipEventRecord(S.ev1, st));
-    // two copies for the whole batch: the short planes ([g | dx | dy] per image, 6 N bytes) and the byte planes ([dir | anchor], 2 N)
+    // the short planes ([g | dx | dy] per image, 6 N bytes) and the byte planes ([dir | anchor], 2 N) in pinned staging
     char* const h_s16 = S.h_pin;
     char* const h_u8 = S.h_pin + 6 * N * (size_t)n_images;
-    LN_TRY(hipMemcpyAsync(h_s16, S.d_s16, 6 * N * (size_t)n_images, hipMemcpyDeviceToHost, st));
-    LN_TRY(hipMemcpyAsync(h_u8, S.d_u8, 2 * N * (size_t)n_images, hipMemcpyDeviceToHost, st));
-    LN_TRY(hipStreamSynchronize(st));
-    float ms = 0;
-    LN_TRY(hipEventElapsedTime(&ms, S.ev0, S.ev1));
-    S.device_ms = ms;
-    const double t_host = ln_now_ms();
-    struct Ctx { const char* h_s16; const char* h_u8; int W, H; size_t N; const EdParams* P; double thr; float* const* lines4; int cap; int* n_lines; std::vector<int> rc; } ctx{h_s16, h_u8, img_w, img_h, N, &P, length_thres, lines4, cap, n_lines, std::vector<int>(n_images, 0)};
+    const cs::LineMaps dm{S.d_s16, S.d_s16 + N, S.d_s16 + 2 * N, S.d_u8, S.d_u8 + N};
+    struct Ctx {
+      const char* h_s16; const char* h_u8; int W, H; size_t N; const EdParams* P; double thr; float* const* lines4; int cap; int* n_lines; std::vector<int> rc;
+      cs::ChunkGate gate; int device; const hipEvent_t* done; int n_chunks, n_images;
+      const unsigned char* const* grays; unsigned char* h_in;
+    } ctx{h_s16, h_u8, img_w, img_h, N, &P, length_thres, lines4, cap, n_lines, std::vector<int>(n_images, 0), {}, cs_internal_detector_device(d), nullptr, 0, n_images, grays, S.h_in};
     auto one = [](int i, void* vp) {
       Ctx& c = *(Ctx*)vp;
       Maps M; M.W = c.W; M.H = c.H;
@@ -369,8 +366,56 @@ extern "C" int cs_detect_lines_batch(cs_detector* d, const unsigned char* const*
       try { c.rc[i] = lines_host_stage(M, *c.P, c.thr, c.lines4 ? c.lines4[i] : nullptr, c.cap, &c.n_lines[i]); }
       catch (const std::exception&) { c.rc[i] = CS_ERR_CAPACITY; }
     };
-    if (n_images == 1) one(0, &ctx);
-    else cs_internal_detector_parallel(d, n_images, one, &ctx);
+    double t_host;
+    if (n_images == 1) {
+      LN_TRY(hipMemcpyAsync(S.d_gray, grays[0], N, hipMemcpyHostToDevice, st));
+      LN_TRY(hipEventRecord(S.ev0, st));
+      cs::launch_lines_maps(S.d_gray, img_w, img_h, dm, k, P.grad_thr, P.anchor_thr, P.scan, st, 1);
+      LN_TRY(hipGetLastError());
+      LN_TRY(hipEventRecord(S.ev1, st));
+      LN_TRY(hipMemcpyAsync(h_s16, S.d_s16, 6 * N, hipMemcpyDeviceToHost, st));
+      LN_TRY(hipMemcpyAsync(h_u8, S.d_u8, 2 * N, hipMemcpyDeviceToHost, st));
+      LN_TRY(hipStreamSynchronize(st));
+      float ms = 0;
+      LN_TRY(hipEventElapsedTime(&ms, S.ev0, S.ev1));
+      S.device_ms = ms;
+      t_host = ln_now_ms();
+      one(0, &ctx);
+    } else {
+      // a batch: the images gathered into pinned memory by the pool (the caller's buffers are pageable), one upload, then chunk by chunk
+      // [kernel | two copies back | event], all queued before the pool starts on the first chunk's images (batch_gate.h)
+      cs_internal_detector_parallel(d, n_images, [](int i, void* vp) { Ctx& c = *(Ctx*)vp; std::memcpy(c.h_in + c.N * (size_t)i, c.grays[i], c.N); }, &ctx);
+      const int CH = cs::BATCH_CHUNK, n_chunks = (n_images + CH - 1) / CH;
+      LN_TRY(S.chunks.reserve(n_chunks));
+      LN_TRY(hipMemcpyAsync(S.d_gray, S.h_in, N * (size_t)n_images, hipMemcpyHostToDevice, st));
+      for (int c = 0; c < n_chunks; c++) {
+        const int i0 = c * CH, ni = std::min(CH, n_images - i0);
+        const cs::LineMaps mi{dm.g + 3 * (size_t)i0 * N, dm.dx + 3 * (size_t)i0 * N, dm.dy + 3 * (size_t)i0 * N, dm.dir + 2 * (size_t)i0 * N, dm.anchor + 2 * (size_t)i0 * N};
+        LN_TRY(hipEventRecord(S.chunks.k0[c], st));
+        cs::launch_lines_maps(S.d_gray + (size_t)i0 * N, img_w, img_h, mi, k, P.grad_thr, P.anchor_thr, P.scan, st, ni);
+        LN_TRY(hipGetLastError());
+        LN_TRY(hipEventRecord(S.chunks.k1[c], st));
+        LN_TRY(hipMemcpyAsync(h_s16 + 6 * N * (size_t)i0, (const char*)S.d_s16 + 6 * N * (size_t)i0, 6 * N * (size_t)ni, hipMemcpyDeviceToHost, st));
+        LN_TRY(hipMemcpyAsync(h_u8 + 2 * N * (size_t)i0, (const char*)S.d_u8 + 2 * N * (size_t)i0, 2 * N * (size_t)ni, hipMemcpyDeviceToHost, st));
+        LN_TRY(hipEventRecord(S.chunks.done[c], st));
+      }
+      ctx.done = S.chunks.done.data(); ctx.n_chunks = n_chunks;
+      t_host = ln_now_ms();
+      cs_internal_detector_parallel(d, n_images + 1, [](int t, void* vp) {
+        Ctx& c = *(Ctx*)vp;
+        if (t == 0) { c.gate.watch(c.device, c.done, c.n_chunks, cs::BATCH_CHUNK, c.n_images); return; }
+        const int i = t - 1;
+        if (!c.gate.wait_for(i)) { c.rc[i] = CS_ERR_HIP; return; }
+        Maps M; M.W = c.W; M.H = c.H;
+        M.g = (const short*)(c.h_s16 + 6 * c.N * (size_t)i); M.dx = M.g + c.N; M.dy = M.dx + c.N; M.dir = (const unsigned char*)(c.h_u8 + 2 * c.N * (size_t)i); M.anchor = M.dir + c.N;
+        try { c.rc[i] = lines_host_stage(M, *c.P, c.thr, c.lines4 ? c.lines4[i] : nullptr, c.cap, &c.n_lines[i]); }
+        catch (const std::exception&) { c.rc[i] = CS_ERR_CAPACITY; }
+      }, &ctx);
+      LN_TRY(hipStreamSynchronize(st));
+      double dev = 0;
+      for (int c = 0; c < n_chunks; c++) { float ms = 0; LN_TRY(hipEventElapsedTime(&ms, S.chunks.k0[c], S.chunks.k1[c])); dev += ms; }
+      S.device_ms = dev;
+    }
     S.host_ms = ln_now_ms() - t_host; S.total_ms = ln_now_ms() - t_begin; S.n_images = n_images;
     for (int r : ctx.rc) if (r) return r;
     return CS_OK;

@@ -25,6 +25,8 @@
 #include <vector>
 
 #include "../../include/cubeslam_hip.h"
+#include "batch_gate.h"
+#include "cs_fast_atan.h"
 #include "cs_nfa.h"
 
 void cs_set_error_ba(const std::string& s);
@@ -37,7 +39,7 @@ extern "C" void cs_internal_detector_parallel(cs_detector* d, int n, void (*fn)(
 namespace cs {
 struct LsdGauss { double k[7]; };
 struct LsdScaleTab { const int* xo; const float* xa; const int* yo; const float* ya; };
-void launch_lsd_maps(const unsigned char* gray, int W, int H, int Ws, int Hs, const LsdGauss& G, const LsdScaleTab& T, double rho, double* blur, double* out, hipStream_t st, int n_images);
+void launch_lsd_maps(const unsigned char* gray, int W, int H, int Ws, int Hs, const LsdGauss& G, const LsdScaleTab& T, double rho, double* blur, char* out, size_t out_stride, hipStream_t st, int n_images);
 }  // namespace cs
 
 namespace {
@@ -53,23 +55,11 @@ namespace {
 
 // createLineSegmentDetector(LSD_REFINE_ADV) defaults (lsd.cpp:185-187) and the constants of :53-64
 constexpr double kScale = 0.8, kSigmaScale = 0.6, kQuant = 2.0, kAngTh = 22.5, kLogEps = 0.0, kDensityTh = 0.7;
-constexpr double kPi = 3.1415926535897932384626433832795, kUndefined = -1024.0, k3PiHalf = 4.71238898038, k2Pi = 6.28318530718;
+constexpr double kPi = 3.1415926535897932384626433832795, k3PiHalf = 4.71238898038, k2Pi = 6.28318530718;
 constexpr double kDegToRad = kPi / 180;
+constexpr double kGrowMargin = 0.2 * kDegToRad;   // (Field::grow)
 
-// OpenCV's fastAtan2 (degrees): third party, restated from its published polynomial; the device copy is lsd_kernels.hip's
-float atan2_deg(float y, float x) {
-  static const float p1 = 0.9997878412794807f * (float)(180 / kPi), p3 = -0.3258083974640975f * (float)(180 / kPi), p5 = 0.1555786518463281f * (float)(180 / kPi),
-                     p7 = -0.04432655554792128f * (float)(180 / kPi);
-  const float ax = std::fabs(x), ay = std::fabs(y);
-  const bool steep = ay > ax;
-  const float c = steep ? ax / (ay + (float)DBL_EPSILON) : ay / (ax + (float)DBL_EPSILON);
-  const float c2 = c * c;
-  float a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-  if (steep) a = 90.f - a;
-  if (x < 0) a = 180.f - a;
-  if (y < 0) a = 360.f - a;
-  return a;
-}
+inline float atan2_deg(float y, float x) { return cs::fast_atan2_deg(y, x); }      // OpenCV's fastAtan2 (cs_fast_atan.h)
 
 inline double sq_dist(double ax, double ay, double bx, double by) { return (bx - ax) * (bx - ax) + (by - ay) * (by - ay); }
 inline double signed_angle_gap(double a, double b) {
@@ -84,20 +74,24 @@ struct Box {                                             // the rectangle of a r
   double x1, y1, x2, y2, width, cx, cy, theta, ux, uy, tol, p;
 };
 
-// One scaled image's planes plus the state region growing threads through it
+// One scaled image's planes plus the state region growing threads through it.  The level-line angle arrives as the float fastAtan2
+// returned (degrees; kUndefinedDeg where the gradient is below the threshold): the reference's double is that float times pi / 180,
+// one IEEE multiplication, redone here wherever the angle is used -- half the bytes to copy back and to miss the cache on.
+constexpr float kUndefinedDeg = -1024.f;
+enum : unsigned char { ST_TAKEN = 1, ST_UNIT = 2, ST_UNDEF = 4 };
 struct Field {
   int W, H;
-  const double* angle;
+  const float* deg;
   const double* weight;
-  unsigned char* taken = nullptr;   // (both live in the worker thread's reusable scratch, see lsd_host_stage)
+  unsigned char* state = nullptr;   // ST_TAKEN: the pixel belongs to a region; ST_UNIT: its cos / sin are in `unit`; ST_UNDEF: no angle (all of these live in the worker thread's reusable scratch, see lsd_host_stage)
+  float* unit = nullptr;            // per pixel: cos((float)angle), sin((float)angle), filled the first time a region tests the pixel
   Pixel* region = nullptr;
   int count = 0;                  // members of `region` in use
   double log_nt = 0;
 
-  bool aligned(int at, double theta, double tol) const {      // isAligned :924-947
-    if (at < 0) return false;
-    const double a = angle[at];
-    if (a == kUndefined) return false;
+  double ang(int at) const { return (double)deg[at] * kDegToRad; }
+
+  static bool within(double theta, double a, double tol) {      // isAligned :924-947 for a pixel that has an angle
     double gap = theta - a;
     if (gap < 0) gap = -gap;
     if (gap > k3PiHalf) {
@@ -106,29 +100,99 @@ struct Field {
     }
     return gap <= tol;
   }
+  bool aligned(int at, double theta, double tol) const {
+    if (at < 0) return false;
+    const float d = deg[at];
+    if (d == kUndefinedDeg) return false;
+    return within(theta, (double)d * kDegToRad, tol);
+  }
+
+  // isAligned over a run of a row, without branches (the loop is a plain count: the compiler vectorises it)
+  static int count_aligned(const float* d, int n, double theta, double tol) {
+    int hits = 0;
+    for (int i = 0; i < n; i++) {
+      const float di = d[i];
+      const double gap = std::fabs(theta - (double)di * kDegToRad), folded = std::fabs(gap - k2Pi);
+      hits += (int)((di != kUndefinedDeg) & ((gap > k3PiHalf ? folded : gap) <= tol));
+    }
+    return hits;
+  }
 
   // :644-692.  Returns the region angle.
+  // The reference re-estimates the region angle after EVERY pixel it adds (theta = fastAtan2(sum sin, sum cos)) and tests the next
+  // neighbour against it: a chain of ~60 cycles of dependent arithmetic per pixel (division, polynomial, fix-ups) that the rest of
+  // the loop waits for.  The sums are kept exactly as the reference keeps them, but a neighbour's test is first decided from the
+  // sums themselves: with v = (sum cos, sum sin) and u = (cos a, sin a), cos(angle between them) = v.u / |v|, compared (squared, no
+  // root) against cos(tol -+ kGrowMargin).  fastAtan2 is within 0.0096 degrees of the true angle of v (every quotient, every
+  // branch: tools/microbench/lsd_atan_bound.cpp runs through all of them), u within 3e-5 degrees of a, so outside a band of 0.2 degrees around
+  // the tolerance the reference's comparison cannot come out differently; inside the band (about one test in a thousand) -- and
+  // whenever the sums nearly cancel, or the tolerance is not well inside (0, 90) degrees -- the reference's own arithmetic decides.
+  // A pixel's cos / sin (the reference's float calls, needed exactly for the sums) are computed once and kept: a pixel is tested
+  // from about three neighbours before it joins a region.  Which of the eight neighbours are free AND have an angle comes from the
+  // state bytes of the three rows at once (away from the image border), so the loop runs over candidates only -- in the reference's order.
   double grow(int sx, int sy, double tol) {
     const int at0 = sx + sy * W;
-    double theta = angle[at0];
+    double theta = ang(at0);
     region[0] = Pixel{sx, sy, theta, weight[at0]};
     count = 1;
-    taken[at0] = 1;
+    state[at0] |= ST_TAKEN;
     float sum_c = (float)std::cos(theta), sum_s = (float)std::sin(theta);
+    const bool fast = tol - kGrowMargin > 0 && tol + kGrowMargin < kPi / 2;
+    const double k_in = fast ? std::cos(tol - kGrowMargin) : 0, k_out = fast ? std::cos(tol + kGrowMargin) : 0;
+    const double k_in2 = k_in * k_in * (1 + 1e-9), k_out2 = k_out * k_out * (1 - 1e-9);
+    bool theta_current = true;          // theta is the estimate that belongs to the sums (the seed's own angle before the first addition)
+    auto candidate = [&](int x, int y, int at) {
+      const double a = ang(at);
+      float ca, sa;
+      if (state[at] & ST_UNIT) { ca = unit[2 * at]; sa = unit[2 * at + 1]; }
+      else { ca = std::cos((float)a); sa = std::sin((float)a); unit[2 * at] = ca; unit[2 * at + 1] = sa; state[at] |= ST_UNIT; }
+      int verdict = -1;                 // 1 aligned, 0 not, -1 the reference's arithmetic decides
+      if (fast && count > 1) {
+        const double vc = sum_c, vs = sum_s, dot = vc * ca + vs * sa, n2 = vc * vc + vs * vs, d2 = dot * dot;
+        if (n2 > 0.25) {
+          if (dot > 0 && d2 >= k_in2 * n2) verdict = 1;
+          else if (dot <= 0 || d2 <= k_out2 * n2) verdict = 0;
+        }
+      }
+      if (verdict < 0) {
+        if (!theta_current) { theta = (double)atan2_deg(sum_s, sum_c) * kDegToRad; theta_current = true; }
+        verdict = within(theta, a, tol) ? 1 : 0;
+      }
+      if (!verdict) return;
+      state[at] |= ST_TAKEN;
+      region[count++] = Pixel{x, y, a, weight[at]};
+      sum_c += ca;
+      sum_s += sa;
+      theta_current = false;
+    };
     for (int i = 0; i < count; i++) {
       const int px = region[i].x, py = region[i].y;
-      const int xa = std::max(px - 1, 0), xb = std::min(px + 1, W - 1), ya = std::max(py - 1, 0), yb = std::min(py + 1, H - 1);
-      for (int y = ya; y <= yb; y++)
-        for (int x = xa, at = xa + y * W; x <= xb; x++, at++) {
-          if (taken[at] == 1 || !aligned(at, theta, tol)) continue;
-          taken[at] = 1;
-          const double a = angle[at];
-          region[count++] = Pixel{x, y, a, weight[at]};
-          sum_c += std::cos((float)a);
-          sum_s += std::sin((float)a);
-          theta = (double)atan2_deg(sum_s, sum_c) * kDegToRad;
+      if (px > 0 && px < W - 1 && py > 0 && py < H - 1) {
+        // bit 3 r + c of m: the neighbour in row py - 1 + r, column px - 1 + c is neither taken nor without an angle
+        unsigned m = 0;
+        const unsigned char* row = state + (py - 1) * W + (px - 1);
+#pragma unroll
+        for (int r = 0; r < 3; r++, row += W) {
+          unsigned v;
+          std::memcpy(&v, row, 4);      // (three bytes of the row and one beyond: the scratch is padded)
+          v &= 0x050505u;
+          const unsigned free3 = ~(v | (v >> 2)) & 0x010101u;
+          m |= ((free3 & 1u) | ((free3 >> 7) & 2u) | ((free3 >> 14) & 4u)) << (3 * r);
         }
+        while (m) {
+          const int bit = __builtin_ctz(m);
+          m &= m - 1;
+          const int r = (bit * 11) >> 5, c = bit - 3 * r;      // bit / 3 for bit < 9
+          candidate(px - 1 + c, py - 1 + r, (py - 1 + r) * W + px - 1 + c);
+        }
+      } else {
+        const int xa = std::max(px - 1, 0), xb = std::min(px + 1, W - 1), ya = std::max(py - 1, 0), yb = std::min(py + 1, H - 1);
+        for (int y = ya; y <= yb; y++)
+          for (int x = xa, at = xa + y * W; x <= xb; x++, at++)
+            if (!(state[at] & (ST_TAKEN | ST_UNDEF))) candidate(x, y, at);
+      }
     }
+    if (!theta_current) theta = (double)atan2_deg(sum_s, sum_c) * kDegToRad;
     return theta;
   }
 
@@ -170,7 +234,7 @@ struct Field {
     double s1 = 0, s2 = 0;
     int near = 0;
     for (int i = 0; i < count; i++) {
-      taken[region[i].x + region[i].y * W] = 0;
+      state[region[i].x + region[i].y * W] &= (unsigned char)~ST_TAKEN;
       if (std::sqrt(sq_dist(sx, sy, (double)region[i].x, (double)region[i].y)) < b.width) {
         const double g = signed_angle_gap(region[i].angle, seed_angle);
         s1 += g; s2 += g * g; near++;
@@ -190,7 +254,7 @@ struct Field {
       rad_sq *= 0.75 * 0.75;
       for (int i = 0; i < count; i++)
         if (sq_dist(sx, sy, (double)region[i].x, (double)region[i].y) > rad_sq) {
-          taken[region[i].x + region[i].y * W] = 0;
+          state[region[i].x + region[i].y * W] &= (unsigned char)~ST_TAKEN;
           std::swap(region[i], region[count - 1]);
           count--;
           i--;
@@ -236,10 +300,10 @@ struct Field {
     int total = 0, hits = 0;
     for (int y = top->y; y <= bottom->y; y++) {
       if (y < 0 || y >= H) continue;                     // (the borders do not advance on skipped rows either)
-      for (int x = (int)xl, at = y * W + (int)xl; x <= (int)xr; x++, at++) {
-        if (x < 0 || x >= W) continue;
-        total++;
-        if (aligned(at, b.theta, b.tol)) hits++;
+      const int x0 = std::max((int)xl, 0), x1 = std::min((int)xr, W - 1);      // (the reference walks (int)xl .. (int)xr and skips what lies outside the image)
+      if (x1 >= x0) {
+        total += x1 - x0 + 1;
+        hits += count_aligned(deg + (size_t)y * W + x0, x1 - x0 + 1, b.theta, b.tol);
       }
       if (y >= left->y) l_step = l_second;
       if (y >= right->y) r_step = r_second;
@@ -282,26 +346,43 @@ struct Field {
 };
 
 // the sequential half of one image: segments in the reference's order, post-processed as LSDDetector::detectImpl and filter_lines do
-int lsd_host_stage(int img_w, int img_h, int Ws, int Hs, const double* angle, const double* weight, double length_thres, float* lines4, int cap, int* n_lines) {
+int lsd_host_stage(int img_w, int img_h, int Ws, int Hs, const float* deg, const double* weight, double length_thres, float* lines4, int cap, int* n_lines) {
   *n_lines = 0;
   // a region can grow to the whole image, so its array is image-sized (8 MB at KITTI size): kept per worker thread across calls instead of
   // being allocated and page-faulted in per image
-  static thread_local std::vector<unsigned char> tl_taken;
+  static thread_local std::vector<unsigned char> tl_state;
   static thread_local std::vector<Pixel> tl_region;
-  tl_taken.assign((size_t)Ws * Hs, 0);
+  static thread_local std::vector<float> tl_unit;
+  const size_t Ns = (size_t)Ws * Hs;
+  if (tl_state.size() < Ns + 16) tl_state.resize(Ns + 16, ST_UNDEF);
+  {
+    unsigned char* st = tl_state.data();
+    for (size_t at = 0; at < Ns; at++) st[at] = deg[at] == kUndefinedDeg ? ST_UNDEF : 0;
+    for (size_t at = Ns; at < Ns + 16; at++) st[at] = ST_UNDEF;
+  }
   if (tl_region.size() < (size_t)Ws * Hs) tl_region.resize((size_t)Ws * Hs);
+  if (tl_unit.size() < 2 * (size_t)Ws * Hs) tl_unit.resize(2 * (size_t)Ws * Hs);
   Field F;
-  F.W = Ws; F.H = Hs; F.angle = angle; F.weight = weight;
-  F.taken = tl_taken.data(); F.region = tl_region.data();
+  F.W = Ws; F.H = Hs; F.deg = deg; F.weight = weight;
+  F.state = tl_state.data(); F.region = tl_region.data(); F.unit = tl_unit.data();
   const double tol = kPi * kAngTh / 180, p = kAngTh / 180;
   F.log_nt = 5 * (std::log10((double)Ws) + std::log10((double)Hs)) / 2 + std::log10(11.0);
   const int min_region = (int)(-F.log_nt / std::log10(p));
   const float border = 10;                                     // pre_boundary_thre, LSDDetector.cpp:219
   int n = 0;
-  for (int y = 0; y < Hs - 1; y++)
-    for (int x = 0; x < Ws - 1; x++) {
-      const int at = x + y * Ws;
-      if (F.taken[at] != 0 || angle[at] == kUndefined) continue;
+  // the seeds in raster order (the last column and the last row have no angle, so walking every pixel is walking the reference's
+  // (Hs - 1) x (Ws - 1) area): eight state bytes at a time, re-read after every region because growing it takes pixels further on
+  for (size_t g0 = 0; g0 < Ns; g0 += 8)
+    for (int from = 0; from < 8;) {
+      unsigned long long v;
+      std::memcpy(&v, F.state + g0, 8);
+      v &= 0x0505050505050505ull;
+      unsigned long long free8 = ~(v | (v >> 2)) & 0x0101010101010101ull;
+      free8 &= ~0ull << (8 * from);
+      if (!free8) break;
+      const int k = __builtin_ctzll(free8) >> 3;
+      from = k + 1;
+      const int at = (int)g0 + k, y = at / Ws, x = at - y * Ws;
       const double theta = F.grow(x, y, tol);
       if (F.count < min_region) continue;
       Box b;
@@ -328,9 +409,11 @@ int lsd_host_stage(int img_w, int img_h, int Ws, int Hs, const double* angle, co
 
 // Resident scratch of a detector's LSD producer (grows only)
 struct LsdScratch {
-  unsigned char* d_gray = nullptr; double* d_blur = nullptr; double* d_out = nullptr; char* d_tab = nullptr;
-  double* h_out = nullptr;          // pinned: per image [angle | modulus]
-  size_t cap_in = 0, cap_out = 0;   // pixels x images
+  unsigned char* d_gray = nullptr; double* d_blur = nullptr; char* d_out = nullptr; char* d_tab = nullptr;
+  char* h_out = nullptr;            // pinned: per image [modulus (double) | angle (float degrees)]
+  unsigned char* h_in = nullptr;    // pinned: the batch's images side by side (one upload)
+  size_t cap_in = 0, cap_out = 0;   // input pixels x images; bytes of the planes
+  cs::ChunkEvents chunks;
   int tab_w = 0, tab_h = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double device_ms = 0, host_ms = 0, total_ms = 0;
@@ -343,6 +426,8 @@ void lsd_scratch_free(void* p) {
   if (S->d_out) (void)hipFree(S->d_out);
   if (S->d_tab) (void)hipFree(S->d_tab);
   if (S->h_out) (void)hipHostFree(S->h_out);
+  if (S->h_in) (void)hipHostFree(S->h_in);
+  S->chunks.release();
   if (S->ev0) (void)hipEventDestroy(S->ev0);
   if (S->ev1) (void)hipEventDestroy(S->ev1);
   delete S;
@@ -369,21 +454,24 @@ extern "C" int cs_detect_lsd_batch(cs_detector* d, const unsigned char* const* g
     // the scaled size: resize(..., Size(), 0.8, 0.8) rounds (saturate_cast<int>)
     const int Ws = (int)std::lrint(img_w * kScale), Hs = (int)std::lrint(img_h * kScale);
     const size_t N = (size_t)img_w * img_h, Ns = (size_t)Ws * Hs;
+    const size_t out_stride = 8 * Ns + 4 * ((Ns + 1) & ~(size_t)1);       // per image: Ns doubles, Ns floats (padded to a multiple of 8 bytes)
     if (N * (size_t)n_images > S.cap_in) {
       if (S.d_gray) (void)hipFree(S.d_gray);
       if (S.d_blur) (void)hipFree(S.d_blur);
-      S.d_gray = nullptr; S.d_blur = nullptr; S.cap_in = 0;
+      if (S.h_in) (void)hipHostFree(S.h_in);
+      S.d_gray = nullptr; S.d_blur = nullptr; S.h_in = nullptr; S.cap_in = 0;
       LSD_TRY(hipMalloc((void**)&S.d_gray, N * (size_t)n_images));
+      LSD_TRY(hipHostMalloc((void**)&S.h_in, N * (size_t)n_images));
       LSD_TRY(hipMalloc((void**)&S.d_blur, N * (size_t)n_images * sizeof(double)));
       S.cap_in = N * (size_t)n_images;
     }
-    if (Ns * (size_t)n_images > S.cap_out) {
+    if (out_stride * (size_t)n_images > S.cap_out) {
       if (S.d_out) (void)hipFree(S.d_out);
       if (S.h_out) (void)hipHostFree(S.h_out);
       S.d_out = nullptr; S.h_out = nullptr; S.cap_out = 0;
-      LSD_TRY(hipMalloc((void**)&S.d_out, 2 * Ns * (size_t)n_images * sizeof(double)));
-      LSD_TRY(hipHostMalloc((void**)&S.h_out, 2 * Ns * (size_t)n_images * sizeof(double)));
-      S.cap_out = Ns * (size_t)n_images;
+      LSD_TRY(hipMalloc((void**)&S.d_out, out_stride * (size_t)n_images));
+      LSD_TRY(hipHostMalloc((void**)&S.h_out, out_stride * (size_t)n_images));
+      S.cap_out = out_stride * (size_t)n_images;
     }
     if (!S.ev0) { LSD_TRY(hipEventCreate(&S.ev0)); LSD_TRY(hipEventCreate(&S.ev1)); }
     // resize's tables for this size: source offset and the two float weights per scaled column / row (pixel centres, INTER_LINEAR)
@@ -428,26 +516,63 @@ extern "C" int cs_detect_lsd_batch(cs_detector* d, const unsigned char* const* g
       for (int i = 0; i < 7; i++) G.k[i] *= sum;
     }
     const double rho = kQuant / std::sin(kPi * kAngTh / 180);
-    for (int i = 0; i < n_images; i++) LSD_TRY(hipMemcpyAsync(S.d_gray + (size_t)i * N, grays[i], N, hipMemcpyHostToDevice, st));
-    LSD_TRY(hipEventRecord(S.ev0, st));
-    cs::launch_lsd_maps(S.d_gray, img_w, img_h, Ws, Hs, G, T, rho, S.d_blur, S.d_out, st, n_images);
-    LSD_TRY(hipGetLastError());
-    LSD_TRY(hipEventRecord(S.ev1, st));
-    LSD_TRY(hipMemcpyAsync(S.h_out, S.d_out, 2 * Ns * (size_t)n_images * sizeof(double), hipMemcpyDeviceToHost, st));
-    LSD_TRY(hipStreamSynchronize(st));
-    float ms = 0;
-    LSD_TRY(hipEventElapsedTime(&ms, S.ev0, S.ev1));
-    S.device_ms = ms;
-    const double t_host = lsd_now_ms();
-    struct Ctx { const double* h; int w, h0, Ws, Hs; size_t Ns; double thr; float* const* lines4; int cap; int* n_lines; std::vector<int> rc; } ctx{S.h_out, img_w, img_h, Ws, Hs, Ns, length_thres, lines4, cap, n_lines, std::vector<int>(n_images, 0)};
+    struct Ctx {
+      const char* h; size_t out_stride; int w, h0, Ws, Hs; size_t Ns; double thr; float* const* lines4; int cap; int* n_lines; std::vector<int> rc;
+      cs::ChunkGate gate; int device; const hipEvent_t* done; int n_chunks, n_images;
+      const unsigned char* const* grays; unsigned char* h_in; size_t N;
+    } ctx{S.h_out, out_stride, img_w, img_h, Ws, Hs, Ns, length_thres, lines4, cap, n_lines, std::vector<int>(n_images, 0), {}, cs_internal_detector_device(d), nullptr, 0, n_images, grays, S.h_in, N};
     auto one = [](int i, void* vp) {
       Ctx& c = *(Ctx*)vp;
-      const double* a = c.h + 2 * c.Ns * (size_t)i;
-      try { c.rc[i] = lsd_host_stage(c.w, c.h0, c.Ws, c.Hs, a, a + c.Ns, c.thr, c.lines4 ? c.lines4[i] : nullptr, c.cap, &c.n_lines[i]); }
+      const double* mod = (const double*)(c.h + c.out_stride * (size_t)i);
+      try { c.rc[i] = lsd_host_stage(c.w, c.h0, c.Ws, c.Hs, (const float*)(mod + c.Ns), mod, c.thr, c.lines4 ? c.lines4[i] : nullptr, c.cap, &c.n_lines[i]); }
       catch (const std::exception&) { c.rc[i] = CS_ERR_CAPACITY; }
     };
-    if (n_images == 1) one(0, &ctx);
-    else cs_internal_detector_parallel(d, n_images, one, &ctx);
+    double t_host;
+    if (n_images == 1) {
+      LSD_TRY(hipMemcpyAsync(S.d_gray, grays[0], N, hipMemcpyHostToDevice, st));
+      LSD_TRY(hipEventRecord(S.ev0, st));
+      cs::launch_lsd_maps(S.d_gray, img_w, img_h, Ws, Hs, G, T, rho, S.d_blur, S.d_out, out_stride, st, 1);
+      LSD_TRY(hipGetLastError());
+      LSD_TRY(hipEventRecord(S.ev1, st));
+      LSD_TRY(hipMemcpyAsync(S.h_out, S.d_out, out_stride, hipMemcpyDeviceToHost, st));
+      LSD_TRY(hipStreamSynchronize(st));
+      float ms = 0;
+      LSD_TRY(hipEventElapsedTime(&ms, S.ev0, S.ev1));
+      S.device_ms = ms;
+      t_host = lsd_now_ms();
+      one(0, &ctx);
+    } else {
+      // a batch: the images gathered into pinned memory by the pool (the caller's buffers are pageable: 64 staged copies otherwise), one
+      // upload, then chunk by chunk [kernels | copy back | event] -- all queued before the pool starts on the first chunk (batch_gate.h)
+      cs_internal_detector_parallel(d, n_images, [](int i, void* vp) { Ctx& c = *(Ctx*)vp; std::memcpy(c.h_in + c.N * (size_t)i, c.grays[i], c.N); }, &ctx);
+      const int CH = cs::BATCH_CHUNK, n_chunks = (n_images + CH - 1) / CH;
+      LSD_TRY(S.chunks.reserve(n_chunks));
+      LSD_TRY(hipMemcpyAsync(S.d_gray, S.h_in, N * (size_t)n_images, hipMemcpyHostToDevice, st));
+      for (int c = 0; c < n_chunks; c++) {
+        const int i0 = c * CH, ni = std::min(CH, n_images - i0);
+        LSD_TRY(hipEventRecord(S.chunks.k0[c], st));
+        cs::launch_lsd_maps(S.d_gray + (size_t)i0 * N, img_w, img_h, Ws, Hs, G, T, rho, S.d_blur + (size_t)i0 * N, S.d_out + out_stride * (size_t)i0, out_stride, st, ni);
+        LSD_TRY(hipGetLastError());
+        LSD_TRY(hipEventRecord(S.chunks.k1[c], st));
+        LSD_TRY(hipMemcpyAsync(S.h_out + out_stride * (size_t)i0, S.d_out + out_stride * (size_t)i0, out_stride * (size_t)ni, hipMemcpyDeviceToHost, st));
+        LSD_TRY(hipEventRecord(S.chunks.done[c], st));
+      }
+      ctx.done = S.chunks.done.data(); ctx.n_chunks = n_chunks;
+      t_host = lsd_now_ms();
+      cs_internal_detector_parallel(d, n_images + 1, [](int t, void* vp) {
+        Ctx& c = *(Ctx*)vp;
+        if (t == 0) { c.gate.watch(c.device, c.done, c.n_chunks, cs::BATCH_CHUNK, c.n_images); return; }
+        const int i = t - 1;
+        if (!c.gate.wait_for(i)) { c.rc[i] = CS_ERR_HIP; return; }
+        const double* mod = (const double*)(c.h + c.out_stride * (size_t)i);
+        try { c.rc[i] = lsd_host_stage(c.w, c.h0, c.Ws, c.Hs, (const float*)(mod + c.Ns), mod, c.thr, c.lines4 ? c.lines4[i] : nullptr, c.cap, &c.n_lines[i]); }
+        catch (const std::exception&) { c.rc[i] = CS_ERR_CAPACITY; }
+      }, &ctx);
+      LSD_TRY(hipStreamSynchronize(st));          // (every chunk's event has been waited for; this also surfaces a late error)
+      double dev = 0;
+      for (int c = 0; c < n_chunks; c++) { float ms = 0; LSD_TRY(hipEventElapsedTime(&ms, S.chunks.k0[c], S.chunks.k1[c])); dev += ms; }
+      S.device_ms = dev;
+    }
     S.host_ms = lsd_now_ms() - t_host; S.total_ms = lsd_now_ms() - t_begin;
     for (int r : ctx.rc) if (r) return r;
     return CS_OK;

@@ -83,12 +83,14 @@ __global__ __launch_bounds__(256) void lsd_blur_kernel(const unsigned char* __re
 }
 
 // One workgroup per 32 x 32 tile of the scaled image: 33 x 33 scaled values (the gradient looks one to the right and one down) in LDS,
-// then angle and modulus.  out: per image [angle | modulus], Ws Hs doubles each.
-__global__ __launch_bounds__(256) void lsd_scale_grad_kernel(const double* __restrict__ blur, int W, int H, int Ws, int Hs, LsdScaleTab T, double rho, double* __restrict__ out) {
+// then angle and modulus.  out: per image (out_stride bytes apart) [modulus: Ws Hs doubles | angle: Ws Hs floats] -- the angle as the
+// float fastAtan2 returns (degrees, LSD_NOTDEF where the modulus is below the threshold): the reference's double is that float times
+// pi / 180, which the host stage forms where it needs it (lsd_host.cpp).
+__global__ __launch_bounds__(256) void lsd_scale_grad_kernel(const double* __restrict__ blur, int W, int H, int Ws, int Hs, LsdScaleTab T, double rho, char* __restrict__ out, size_t out_stride) {
   const size_t N = (size_t)W * H, Ns = (size_t)Ws * Hs;
   blur += blockIdx.z * N;
-  double* __restrict__ ang = out + 2 * blockIdx.z * Ns;
-  double* __restrict__ mod = ang + Ns;
+  double* __restrict__ mod = reinterpret_cast<double*>(out + blockIdx.z * out_stride);
+  float* __restrict__ ang = reinterpret_cast<float*>(mod + Ns);
   __shared__ double sc[BT + 1][BT + 2];
   const int x0 = blockIdx.x * BT, y0 = blockIdx.y * BT, t = threadIdx.x;
   for (int e = t; e < (BT + 1) * (BT + 1); e += 256) {
@@ -112,24 +114,25 @@ __global__ __launch_bounds__(256) void lsd_scale_grad_kernel(const double* __res
     const int r = e / BT, c = e - r * BT;
     const int x = x0 + c, y = y0 + r;
     if (x >= Ws || y >= Hs) continue;
-    double a = LSD_NOTDEF, m = 0.0;
+    float a = (float)LSD_NOTDEF;
+    double m = 0.0;
     if (x < Ws - 1 && y < Hs - 1) {
       const double DA = sc[r + 1][c + 1] - sc[r][c], BC = sc[r][c + 1] - sc[r + 1][c];
       const double gx = DA + BC, gy = DA - BC;
       m = sqrt((gx * gx + gy * gy) / 4);
-      if (m > rho) a = (double)lsd_fast_atan2((float)gx, (float)(-gy)) * (3.1415926535897932384626433832795 / 180);
+      if (m > rho) a = lsd_fast_atan2((float)gx, (float)(-gy));
     }
     ang[(size_t)y * Ws + x] = a;
     mod[(size_t)y * Ws + x] = m;
   }
 }
 
-void launch_lsd_maps(const unsigned char* gray, int W, int H, int Ws, int Hs, const LsdGauss& G, const LsdScaleTab& T, double rho, double* blur, double* out, hipStream_t st, int n_images) {
+void launch_lsd_maps(const unsigned char* gray, int W, int H, int Ws, int Hs, const LsdGauss& G, const LsdScaleTab& T, double rho, double* blur, char* out, size_t out_stride, hipStream_t st, int n_images) {
   for (int i0 = 0; i0 < n_images; i0 += 65535) {      // gridDim.z limit
     const int nz = n_images - i0 < 65535 ? n_images - i0 : 65535;
-    const size_t N = (size_t)W * H, Ns = (size_t)Ws * Hs;
+    const size_t N = (size_t)W * H;
     hipLaunchKernelGGL(lsd_blur_kernel, dim3((W + BT - 1) / BT, (H + BT - 1) / BT, nz), dim3(256), 0, st, gray + (size_t)i0 * N, W, H, G, blur + (size_t)i0 * N);
-    hipLaunchKernelGGL(lsd_scale_grad_kernel, dim3((Ws + BT - 1) / BT, (Hs + BT - 1) / BT, nz), dim3(256), 0, st, blur + (size_t)i0 * N, W, H, Ws, Hs, T, rho, out + 2 * (size_t)i0 * Ns);
+    hipLaunchKernelGGL(lsd_scale_grad_kernel, dim3((Ws + BT - 1) / BT, (Hs + BT - 1) / BT, nz), dim3(256), 0, st, blur + (size_t)i0 * N, W, H, Ws, Hs, T, rho, out + (size_t)i0 * out_stride, out_stride);
   }
 }
 

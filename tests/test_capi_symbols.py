@@ -67,3 +67,18 @@ def test_sparse_plan_symbolic_phase_on_random_block_graphs():
         subprocess.check_call(["hipcc", "-O2", "-std=c++17", os.path.join(ROOT, "tools", "microbench", "sparse_plan_check.cpp"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "40 random block graphs" in out.stdout, out.stdout + out.stderr
+
+
+def test_fast_atan2_error_bound_behind_the_lsd_region_growing():
+    """Field::grow (csrc/lsd_host.cpp; the reference: line_lbd/libs/lsd.cpp:644-692) decides a neighbour's alignment from the cos / sin sums
+    themselves unless the angle is within 0.2 degrees of the tolerance -- sound because OpenCV's fastAtan2 (csrc/cs_fast_atan.h) is never more
+    than 0.0096 degrees from the true angle.  The tool walks every 61st float quotient through all sign / branch cases here (stride 1, every
+    quotient, gives 0.009559 degrees in 45 s); the segments themselves are held to the restatement bit for bit in tests/test_lines_gpu.py."""
+    import subprocess
+    exe = os.path.join(ROOT, "build_tmp", "lsd_atan_bound")
+    src = os.path.join(ROOT, "tools", "microbench", "lsd_atan_bound.cpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", src, "-o", exe, "-pthread"])
+    out = subprocess.run([exe, "61"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "at most 0.0095" in out.stdout, out.stdout + out.stderr

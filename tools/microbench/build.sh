@@ -15,3 +15,5 @@ hipcc --offload-arch=gfx950 -O3 -x hip tools/microbench/pmc_calib.cpp -o build_t
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -x hip tools/microbench/potf2_bench.cpp -o build_tmp/potf2_bench
 # host-only check of the symbolic phase of the general sparse reduced solve (tests/test_ba_oracle.py runs it)
 hipcc -O2 -std=c++17 tools/microbench/sparse_plan_check.cpp -o build_tmp/sparse_plan_check
+# host-only: the error bound of fastAtan2 that the LSD host stage's region growing relies on (tests/test_capi_symbols.py runs it with a stride)
+g++ -O2 -std=c++17 tools/microbench/lsd_atan_bound.cpp -o build_tmp/lsd_atan_bound -pthread
