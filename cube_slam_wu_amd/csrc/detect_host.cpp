@@ -95,12 +95,14 @@ class WorkerPool {
     cv_.notify_all();
     for (auto& t : th_) t.join();
   }
-  void run(int n, const std::function<void(int)>& fn) {
+  // max_threads: at most this many threads (the caller included) take items -- for items that run for milliseconds, where more
+  // runnable threads than the CPU quota tolerates only get the process throttled
+  void run(int n, const std::function<void(int)>& fn, int max_threads = 0x7fffffff) {
     if (n <= 0) return;
     if (th_.empty() || n == 1) { for (int i = 0; i < n; i++) fn(i); return; }
     {
       std::lock_guard<std::mutex> lk(m_);
-      fn_ = &fn; n_ = n; next_.store(0); pending_ = (int)th_.size(); gen_++;
+      fn_ = &fn; n_ = n; next_.store(0); joined_.store(0); limit_ = std::max(1, max_threads); pending_ = (int)th_.size(); gen_++;
     }
     cv_.notify_all();
     work();
@@ -110,6 +112,7 @@ class WorkerPool {
   }
  private:
   void work() {
+    if (joined_.fetch_add(1) >= limit_) return;
     for (;;) {
       int i = next_.fetch_add(1);
       if (i >= n_) break;
@@ -136,8 +139,8 @@ class WorkerPool {
   std::mutex m_;
   std::condition_variable cv_, done_;
   const std::function<void(int)>* fn_ = nullptr;
-  std::atomic<int> next_{0};
-  int n_ = 0, pending_ = 0;
+  std::atomic<int> next_{0}, joined_{0};
+  int n_ = 0, pending_ = 0, limit_ = 0x7fffffff;
   unsigned long long gen_ = 0;
   bool stop_ = false;
 };
@@ -377,6 +380,7 @@ struct cs_detector {
   hipStream_t stream_hi = nullptr; // high priority: the small fetches of the tie boxes, which the host waits for while another batch's sweep owns the device
   hipEvent_t ev[12] = {};
   int n_threads = 1;
+  int cpu_grant = 1;          // CPUs this process may use at once (cgroup quota, else the hardware threads)
   std::unique_ptr<WorkerPool> pool;
   // cs_detect_cuboids / cs_detect_cuboids_gray: one resident single-frame batch whose device and pinned buffers are reused from
   // call to call (a batch built and torn down per frame spent most of the call in hipMalloc / hipFree)
@@ -619,6 +623,8 @@ void** cs_internal_detector_lines_slot(cs_detector* d, void (*deleter)(void*)) {
 void** cs_internal_detector_lsd_slot(cs_detector* d, void (*deleter)(void*)) { d->lsd_free = deleter; return &d->lsd_scratch; }
 void* cs_internal_detector_lines_mutex(cs_detector* d) { return (void*)&d->lines_mu; }
 void cs_internal_detector_parallel(cs_detector* d, int n, void (*fn)(int, void*), void* ctx) { d->pool->run(n, [&](int i) { fn(i, ctx); }); }
+// (for the segment producers' image-long items: two threads per granted CPU at most, see cs_detector_create)
+void cs_internal_detector_parallel_long(cs_detector* d, int n, void (*fn)(int, void*), void* ctx) { d->pool->run(n, [&](int i) { fn(i, ctx); }, 2 * d->cpu_grant + 1); }
 int cs_internal_detector_device(cs_detector* d) { return d->device; }
 
 int cs_detector_create(const cs_detect_params* params, int device, cs_detector** out) {
@@ -651,10 +657,13 @@ int cs_detector_create(const cs_detect_params* params, int device, cs_detector**
   // per granted CPU (measured under a 16-CPU quota: 48 threads 187 k frames/s, 32: 184 k, 64: 171-181 k, 16: 166-172 k --
   // the stages are short bursts, more runnable threads than the quota tolerates get the process throttled)
   int dflt = std::max(1, std::min(hc, 64));
+  d->cpu_grant = std::max(1, hc);
   if (FILE* fq = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
     long long quota = 0, period = 0;
-    if (std::fscanf(fq, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+    if (std::fscanf(fq, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
       dflt = std::max(1, std::min(dflt, std::max(8, (int)(3 * quota / period))));
+      d->cpu_grant = std::max(1, std::min(d->cpu_grant, (int)(quota / period)));
+    }
     std::fclose(fq);
   }
   d->n_threads = d->prm.host_threads > 0 ? d->prm.host_threads : dflt;

@@ -32,9 +32,10 @@ extern "C" int cs_internal_detector_device(cs_detector* d);
 extern "C" void** cs_internal_detector_lines_slot(cs_detector* d, void (*deleter)(void*));
 extern "C" void* cs_internal_detector_lines_mutex(cs_detector* d);
 extern "C" void cs_internal_detector_parallel(cs_detector* d, int n, void (*fn)(int, void*), void* ctx);
+extern "C" void cs_internal_detector_parallel_long(cs_detector* d, int n, void (*fn)(int, void*), void* ctx);
 
 namespace cs {
-struct LineMaps { short* g; short* dx; short* dy; unsigned char* dir; unsigned char* anchor; };
+struct LineMaps { int* pk; };
 void launch_lines_maps(const unsigned char* gray, int W, int H, const LineMaps& m, const int k[3], int grad_thr, int anchor_thr, int scan, hipStream_t st, int n_images);
 }  // namespace cs
 
@@ -52,11 +53,22 @@ namespace {
 // EDLineDetector() :1515-1526 and BinaryDescriptor::Params() :110-117
 struct EdParams { int grad_thr = 80, anchor_thr = 8, scan = 2, min_len = 15, try_time = 6, skip = 2, max_outlier = 3; double fit_err = 1.6; };
 
-struct Maps {     // host copies of the device maps (pinned staging of the detector's scratch)
-  int W = 0, H = 0;
-  const short* g = nullptr; const short* dx = nullptr; const short* dy = nullptr;
-  const unsigned char* dir = nullptr; const unsigned char* anchor = nullptr;
-  bool horizontal(unsigned x, unsigned y) const { return dir[(size_t)y * W + x] == 255; }
+// Host copy of the device's packed map (pinned staging of the detector's scratch): one word per pixel = dx | (2 dy + anchor) << 16
+// (lines_kernels.hip).  The reference's gImg_ and dirImg_ are functions of dx and dy, evaluated where they are read:
+//   gImg_ = cvRound((|dx| + |dy| thresholded at gradienThreshold_ + 1) / 4)     binary_descriptor.cpp:1630-1640
+//   dirImg_ = |dx| < |dy| ? Horizontal : Vertical
+struct Maps {
+  int W = 0, H = 0, grad_thr = 0;
+  const int* pk = nullptr;
+  int dx(size_t at) const { return (short)(pk[at] & 0xffff); }
+  int dy(size_t at) const { return (pk[at] >> 16) >> 1; }
+  bool anchor(size_t at) const { return (pk[at] >> 16) & 1; }
+  short g(size_t at) const {
+    const int s = std::abs(dx(at)) + std::abs(dy(at)), v = s > grad_thr + 1 ? s : 0, q = v >> 2, r = v & 3;
+    return (short)(q + ((r == 3) || (r == 2 && (q & 1))));        // round half to even
+  }
+  bool horizontal(size_t at) const { return std::abs(dx(at)) < std::abs(dy(at)); }
+  bool horizontal(unsigned x, unsigned y) const { return horizontal((size_t)y * W + x); }
 };
 
 struct Chain { std::vector<unsigned> x, y; };
@@ -84,11 +96,11 @@ struct Router {
     const unsigned W = M.W, H = M.H;
     for (;;) {
       const size_t at = (size_t)y * W + x;
-      if (!(M.g[at] > 0) || taken[at]) return;
+      if (!(M.g(at) > 0) || taken[at]) return;
       taken[at] = 1;
       out.x.push_back(x); out.y.push_back(y);
       int go;
-      if (M.dir[at] == 255) go = (heading == UP || heading == DOWN) ? (x > last_x ? RIGHT : LEFT) : heading;     // horizontal pixel: left or right
+      if (M.horizontal(at)) go = (heading == UP || heading == DOWN) ? (x > last_x ? RIGHT : LEFT) : heading;     // horizontal pixel: left or right
       else                  go = (heading == RIGHT || heading == LEFT) ? (y > last_y ? DOWN : UP) : heading;     // vertical pixel: up or down
       last_x = x; last_y = y;
       const bool at_border = go == RIGHT ? (x == W - 1 || y == 0 || y == H - 1)
@@ -98,7 +110,7 @@ struct Router {
       if (at_border) return;
       const Step& s = kStep[go];
       unsigned char gv[3];   // the reference compares the gradients as unsigned char (values above 255 wrap)
-      for (int q = 0; q < 3; q++) gv[q] = (unsigned char)M.g[(size_t)(y + s.dy[q]) * W + (x + s.dx[q])];
+      for (int q = 0; q < 3; q++) gv[q] = (unsigned char)M.g((size_t)(y + s.dy[q]) * W + (x + s.dx[q]));
       const int pick = (gv[0] >= gv[1] && gv[0] >= gv[2]) ? 0 : ((gv[2] >= gv[1] && gv[2] >= gv[0]) ? 2 : 1);
       x += s.dx[pick]; y += s.dy[pick];
       heading = go;
@@ -144,8 +156,9 @@ struct Extractor {
     std::vector<double> level(n);
     for (int i = 0; i < n; i++) {
       const size_t at = (size_t)ly[i] * M.W + lx[i];
-      sum_gx += M.dx[at]; sum_gy += M.dy[at];
-      level[i] = std::atan2(-(double)M.dx[at], (double)M.dy[at]);
+      const int gx = M.dx(at), gy = M.dy(at);
+      sum_gx += gx; sum_gy += gy;
+      level[i] = std::atan2(-(double)gx, (double)gy);
     }
     if (sum_gx == 0 && sum_gy == 0) return false;
     const double ax = std::fabs(w[1]), ay = std::fabs(w[0]);
@@ -233,8 +246,8 @@ struct Extractor {
 // Resident scratch of a detector's line producer: device maps and pinned host copies for `cap_images` images of `cap_pixels` pixels
 // (grows only).  A call used to pay three hipMalloc / hipFree pairs and five copies into pageable vectors.
 struct LinesScratch {
-  unsigned char* d_gray = nullptr; unsigned char* d_u8 = nullptr; short* d_s16 = nullptr;
-  char* h_pin = nullptr;           // per image: g, dx, dy (short each), dir, anchor (byte each) = 8 bytes per pixel
+  unsigned char* d_gray = nullptr; int* d_pk = nullptr;
+  int* h_pin = nullptr;            // per image: the packed map, 4 bytes per pixel
   unsigned char* h_in = nullptr;   // pinned: the batch's images side by side (one upload)
   size_t cap = 0;                  // pixels x images
   cs::ChunkEvents chunks;
@@ -246,8 +259,7 @@ void lines_scratch_free(void* p) {
   LinesScratch* S = (LinesScratch*)p;
   if (!S) return;
   if (S->d_gray) (void)hipFree(S->d_gray);
-  if (S->d_u8) (void)hipFree(S->d_u8);
-  if (S->d_s16) (void)hipFree(S->d_s16);
+  if (S->d_pk) (void)hipFree(S->d_pk);
   if (S->h_pin) (void)hipHostFree(S->h_pin);
   if (S->h_in) (void)hipHostFree(S->h_in);
   S->chunks.release();
@@ -270,11 +282,11 @@ int lines_host_stage(const Maps& M, const EdParams& P, double length_thres, floa
   for (int x = 1; x < img_w - 1; x += P.scan)
     for (int y = 1; y < img_h - 1; y += P.scan) {
       const size_t at = (size_t)y * img_w + x;
-      if (!M.anchor[at]) continue;
+      if (!M.anchor(at)) continue;
       if (++n_anchor > N / 5) { cs_set_error_ba("cs_detect_lines_gray: more anchors than the reference's arrays hold"); return CS_ERR_CAPACITY; }
       if (R.taken[at]) continue;
       first.x.clear(); first.y.clear(); second.x.clear(); second.y.clear();
-      const bool hor = M.dir[at] == 255;
+      const bool hor = M.horizontal(at);
       R.walk(x, y, hor ? RIGHT : DOWN, first);
       R.taken[at] = 0;                                 // the anchor opens the second walk too
       R.walk(x, y, hor ? LEFT : UP, second);
@@ -329,15 +341,13 @@ extern "C" int cs_detect_lines_batch(cs_detector* d, const unsigned char* const*
     const size_t N = (size_t)img_w * img_h, need = N * (size_t)n_images;
     if (need > S.cap) {
       if (S.d_gray) (void)hipFree(S.d_gray);
-      if (S.d_u8) (void)hipFree(S.d_u8);
-      if (S.d_s16) (void)hipFree(S.d_s16);
+      if (S.d_pk) (void)hipFree(S.d_pk);
       if (S.h_pin) (void)hipHostFree(S.h_pin);
       if (S.h_in) (void)hipHostFree(S.h_in);
-      S.d_gray = S.d_u8 = nullptr; S.d_s16 = nullptr; S.h_pin = nullptr; S.h_in = nullptr; S.cap = 0;
+      S.d_gray = nullptr; S.d_pk = nullptr; S.h_pin = nullptr; S.h_in = nullptr; S.cap = 0;
       LN_TRY(hipMalloc((void**)&S.d_gray, need));
-      LN_TRY(hipMalloc((void**)&S.d_u8, 2 * need));
-      LN_TRY(hipMalloc((void**)&S.d_s16, 3 * need * sizeof(short)));
-      LN_TRY(hipHostMalloc((void**)&S.h_pin, 8 * need));
+      LN_TRY(hipMalloc((void**)&S.d_pk, need * sizeof(int)));
+      LN_TRY(hipHostMalloc((void**)&S.h_pin, need * sizeof(int)));
       LN_TRY(hipHostMalloc((void**)&S.h_in, need));
       S.cap = need;
     }
@@ -350,19 +360,15 @@ extern "C" int cs_detect_lines_batch(cs_detector* d, const unsigned char* const*
       sum = 1. / sum;
       for (int i = 0; i < 3; i++) k[i] = (int)std::nearbyint((double)(float)(cf[i] * sum) * 256.0);
     }
-    // the short planes ([g | dx | dy] per image, 6 N bytes) and the byte planes ([dir | anchor], 2 N) in pinned staging
-    char* const h_s16 = S.h_pin;
-    char* const h_u8 = S.h_pin + 6 * N * (size_t)n_images;
-    const cs::LineMaps dm{S.d_s16, S.d_s16 + N, S.d_s16 + 2 * N, S.d_u8, S.d_u8 + N};
+    const cs::LineMaps dm{S.d_pk};
     struct Ctx {
-      const char* h_s16; const char* h_u8; int W, H; size_t N; const EdParams* P; double thr; float* const* lines4; int cap; int* n_lines; std::vector<int> rc;
+      const int* h_pk; int W, H; size_t N; const EdParams* P; double thr; float* const* lines4; int cap; int* n_lines; std::vector<int> rc;
       cs::ChunkGate gate; int device; const hipEvent_t* done; int n_chunks, n_images;
       const unsigned char* const* grays; unsigned char* h_in;
-    } ctx{h_s16, h_u8, img_w, img_h, N, &P, length_thres, lines4, cap, n_lines, std::vector<int>(n_images, 0), {}, cs_internal_detector_device(d), nullptr, 0, n_images, grays, S.h_in};
+    } ctx{S.h_pin, img_w, img_h, N, &P, length_thres, lines4, cap, n_lines, std::vector<int>(n_images, 0), {}, cs_internal_detector_device(d), nullptr, 0, n_images, grays, S.h_in};
     auto one = [](int i, void* vp) {
       Ctx& c = *(Ctx*)vp;
-      Maps M; M.W = c.W; M.H = c.H;
-      M.g = (const short*)(c.h_s16 + 6 * c.N * (size_t)i); M.dx = M.g + c.N; M.dy = M.dx + c.N; M.dir = (const unsigned char*)(c.h_u8 + 2 * c.N * (size_t)i); M.anchor = M.dir + c.N;
+      Maps M; M.W = c.W; M.H = c.H; M.grad_thr = c.P->grad_thr; M.pk = c.h_pk + c.N * (size_t)i;
       try { c.rc[i] = lines_host_stage(M, *c.P, c.thr, c.lines4 ? c.lines4[i] : nullptr, c.cap, &c.n_lines[i]); }
       catch (const std::exception&) { c.rc[i] = CS_ERR_CAPACITY; }
     };
@@ -373,8 +379,7 @@ extern "C" int cs_detect_lines_batch(cs_detector* d, const unsigned char* const*
       cs::launch_lines_maps(S.d_gray, img_w, img_h, dm, k, P.grad_thr, P.anchor_thr, P.scan, st, 1);
       LN_TRY(hipGetLastError());
       LN_TRY(hipEventRecord(S.ev1, st));
-      LN_TRY(hipMemcpyAsync(h_s16, S.d_s16, 6 * N, hipMemcpyDeviceToHost, st));
-      LN_TRY(hipMemcpyAsync(h_u8, S.d_u8, 2 * N, hipMemcpyDeviceToHost, st));
+      LN_TRY(hipMemcpyAsync(S.h_pin, S.d_pk, N * sizeof(int), hipMemcpyDeviceToHost, st));
       LN_TRY(hipStreamSynchronize(st));
       float ms = 0;
       LN_TRY(hipEventElapsedTime(&ms, S.ev0, S.ev1));
@@ -383,31 +388,29 @@ extern "C" int cs_detect_lines_batch(cs_detector* d, const unsigned char* const*
       one(0, &ctx);
     } else {
       // a batch: the images gathered into pinned memory by the pool (the caller's buffers are pageable), one upload, then chunk by chunk
-      // [kernel | two copies back | event], all queued before the pool starts on the first chunk's images (batch_gate.h)
+      // [kernel | copy back | event], all queued before the pool starts on the first chunk's images (batch_gate.h)
       cs_internal_detector_parallel(d, n_images, [](int i, void* vp) { Ctx& c = *(Ctx*)vp; std::memcpy(c.h_in + c.N * (size_t)i, c.grays[i], c.N); }, &ctx);
       const int CH = cs::BATCH_CHUNK, n_chunks = (n_images + CH - 1) / CH;
       LN_TRY(S.chunks.reserve(n_chunks));
       LN_TRY(hipMemcpyAsync(S.d_gray, S.h_in, N * (size_t)n_images, hipMemcpyHostToDevice, st));
       for (int c = 0; c < n_chunks; c++) {
         const int i0 = c * CH, ni = std::min(CH, n_images - i0);
-        const cs::LineMaps mi{dm.g + 3 * (size_t)i0 * N, dm.dx + 3 * (size_t)i0 * N, dm.dy + 3 * (size_t)i0 * N, dm.dir + 2 * (size_t)i0 * N, dm.anchor + 2 * (size_t)i0 * N};
+        const cs::LineMaps mi{dm.pk + (size_t)i0 * N};
         LN_TRY(hipEventRecord(S.chunks.k0[c], st));
         cs::launch_lines_maps(S.d_gray + (size_t)i0 * N, img_w, img_h, mi, k, P.grad_thr, P.anchor_thr, P.scan, st, ni);
         LN_TRY(hipGetLastError());
         LN_TRY(hipEventRecord(S.chunks.k1[c], st));
-        LN_TRY(hipMemcpyAsync(h_s16 + 6 * N * (size_t)i0, (const char*)S.d_s16 + 6 * N * (size_t)i0, 6 * N * (size_t)ni, hipMemcpyDeviceToHost, st));
-        LN_TRY(hipMemcpyAsync(h_u8 + 2 * N * (size_t)i0, (const char*)S.d_u8 + 2 * N * (size_t)i0, 2 * N * (size_t)ni, hipMemcpyDeviceToHost, st));
+        LN_TRY(hipMemcpyAsync(S.h_pin + N * (size_t)i0, S.d_pk + N * (size_t)i0, N * (size_t)ni * sizeof(int), hipMemcpyDeviceToHost, st));
         LN_TRY(hipEventRecord(S.chunks.done[c], st));
       }
       ctx.done = S.chunks.done.data(); ctx.n_chunks = n_chunks;
       t_host = ln_now_ms();
-      cs_internal_detector_parallel(d, n_images + 1, [](int t, void* vp) {
+      cs_internal_detector_parallel_long(d, n_images + 1, [](int t, void* vp) {
         Ctx& c = *(Ctx*)vp;
         if (t == 0) { c.gate.watch(c.device, c.done, c.n_chunks, cs::BATCH_CHUNK, c.n_images); return; }
         const int i = t - 1;
         if (!c.gate.wait_for(i)) { c.rc[i] = CS_ERR_HIP; return; }
-        Maps M; M.W = c.W; M.H = c.H;
-        M.g = (const short*)(c.h_s16 + 6 * c.N * (size_t)i); M.dx = M.g + c.N; M.dy = M.dx + c.N; M.dir = (const unsigned char*)(c.h_u8 + 2 * c.N * (size_t)i); M.anchor = M.dir + c.N;
+        Maps M; M.W = c.W; M.H = c.H; M.grad_thr = c.P->grad_thr; M.pk = c.h_pk + c.N * (size_t)i;
         try { c.rc[i] = lines_host_stage(M, *c.P, c.thr, c.lines4 ? c.lines4[i] : nullptr, c.cap, &c.n_lines[i]); }
         catch (const std::exception&) { c.rc[i] = CS_ERR_CAPACITY; }
       }, &ctx);

@@ -15,11 +15,12 @@
 
 namespace cs {
 
+// What goes back to the host, one 32-bit word per pixel: the Sobel derivatives (dxImg_, dyImg_; |.| <= 1020) and the anchor flag,
+//   bits 0..15  dx (two's complement)        bits 16..31  2 dy + anchor (two's complement)
+// The thresholded gradient / 4 (gImg_) and the direction map (dirImg_: |dx| < |dy| = horizontal) are functions of dx and dy that the
+// host stage evaluates where it reads them (lines_host.cpp, Maps) -- half the bytes of the five planes the reference keeps.
 struct LineMaps {
-  short* g;              // thresholded gradient / 4 (gImg_)
-  short* dx; short* dy;  // Sobel derivatives (dxImg_, dyImg_)
-  unsigned char* dir;    // 255 = horizontal edge pixel (|dx| < |dy|), 0 = vertical (dirImg_)
-  unsigned char* anchor; // 1 = anchor
+  int* pk;
 };
 
 __device__ __forceinline__ int lines_reflect101(int p, int n) {
@@ -34,20 +35,20 @@ __device__ __forceinline__ int lines_div4_half_even(int v) {   // cvRound(v * 0.
 
 enum { LT = 32, LG = LT + 8, LB = LT + 4, LS = LT + 2 };
 
-// blockIdx.z = image of a batch: image i's gray at gray + i N, its maps at m.{g,dx,dy} + 3 i N (the three short planes of an image are
-// adjacent) and m.{dir,anchor} + 2 i N
+// blockIdx.z = image of a batch: image i's gray at gray + i N, its packed map at m.pk + i N
 __global__ __launch_bounds__(256) void lines_maps_kernel(const unsigned char* __restrict__ gray, int W, int H, LineMaps m, int k0, int k1, int k2,
                                                          int grad_thr, int anchor_thr, int scan) {
   {
     const size_t N = (size_t)W * H, img = blockIdx.z;
     gray += img * N;
-    m.g += 3 * img * N; m.dx += 3 * img * N; m.dy += 3 * img * N; m.dir += 2 * img * N; m.anchor += 2 * img * N;
+    m.pk += img * N;
   }
   __shared__ unsigned char sg[LG][LG + 4];     // gray, tile origin - 4
   __shared__ int rs[LG][LB];                   // row pass of the blur
   __shared__ unsigned char sb[LB][LB + 4];     // blurred, tile origin - 2
   __shared__ short sgr[LS][LS + 2];            // gImg, tile origin - 1
   __shared__ unsigned char sdir[LS][LS + 2];   // direction, tile origin - 1
+  __shared__ short sdx[LS][LS + 2], sdy[LS][LS + 2];   // Sobel derivatives, tile origin - 1
   const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT, t = threadIdx.x;
   for (int e = t; e < LG * LG; e += 256) {
     const int r = e / LG, c = e - r * LG;
@@ -73,11 +74,7 @@ __global__ __launch_bounds__(256) void lines_maps_kernel(const unsigned char* __
     const int gq = lines_div4_half_even(s > grad_thr + 1 ? s : 0);
     sgr[r][c] = (short)gq;
     sdir[r][c] = ax < ay ? 255 : 0;
-    const int x = x0 - 1 + c, y = y0 - 1 + r;
-    if (r >= 1 && r <= LT && c >= 1 && c <= LT && x < W && y < H) {
-      const size_t o = (size_t)y * W + x;
-      m.g[o] = (short)gq; m.dx[o] = (short)gx; m.dy[o] = (short)gy; m.dir[o] = ax < ay ? 255 : 0;
-    }
+    sdx[r][c] = (short)gx; sdy[r][c] = (short)gy;
   }
   __syncthreads();
   for (int e = t; e < LT * LT; e += 256) {
@@ -92,7 +89,7 @@ __global__ __launch_bounds__(256) void lines_maps_kernel(const unsigned char* __
       const int n1 = hor ? sgr[r][c + 1] : sgr[r + 1][c], n2 = hor ? sgr[r + 2][c + 1] : sgr[r + 1][c + 2];
       an = (g >= n1 + anchor_thr && g >= n2 + anchor_thr) ? 1 : 0;
     }
-    m.anchor[(size_t)y * W + x] = an;
+    m.pk[(size_t)y * W + x] = (int)(((unsigned)(2 * (int)sdy[r + 1][c + 1] + an) << 16) | ((unsigned)(int)sdx[r + 1][c + 1] & 0xffffu));
   }
 }
 
@@ -101,7 +98,7 @@ void launch_lines_maps(const unsigned char* gray, int W, int H, const LineMaps& 
   for (int i0 = 0; i0 < n_images; i0 += 65535) {      // gridDim.z limit
     const int nz = n_images - i0 < 65535 ? n_images - i0 : 65535;
     const size_t N = (size_t)W * H;
-    LineMaps mi{m.g + 3 * (size_t)i0 * N, m.dx + 3 * (size_t)i0 * N, m.dy + 3 * (size_t)i0 * N, m.dir + 2 * (size_t)i0 * N, m.anchor + 2 * (size_t)i0 * N};
+    LineMaps mi{m.pk + (size_t)i0 * N};
     hipLaunchKernelGGL(lines_maps_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, nz), dim3(256), 0, st, gray + (size_t)i0 * N, W, H, mi, k[0], k[1], k[2], grad_thr, anchor_thr, scan);
   }
 }

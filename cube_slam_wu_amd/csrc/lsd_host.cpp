@@ -35,6 +35,7 @@ extern "C" int cs_internal_detector_device(cs_detector* d);
 extern "C" void** cs_internal_detector_lsd_slot(cs_detector* d, void (*deleter)(void*));
 extern "C" void* cs_internal_detector_lines_mutex(cs_detector* d);
 extern "C" void cs_internal_detector_parallel(cs_detector* d, int n, void (*fn)(int, void*), void* ctx);
+extern "C" void cs_internal_detector_parallel_long(cs_detector* d, int n, void (*fn)(int, void*), void* ctx);
 
 namespace cs {
 struct LsdGauss { double k[7]; };
@@ -116,6 +117,68 @@ struct Field {
       hits += (int)((di != kUndefinedDeg) & ((gap > k3PiHalf ? folded : gap) <= tol));
     }
     return hits;
+  }
+
+  // The same test for one (theta, tol) and many pixels (rect_nfa scans ~700 k of them per image): as a function of the stored float
+  // the test passes on at most two intervals -- around theta and around theta -+ 2 pi, where the reference folds the difference --
+  // because every step from the float to the comparison (the multiplication by pi / 180, the subtraction, the fold) is monotone in
+  // IEEE arithmetic on either side of the interval's centre.  The intervals' end points are found by bisection over the float bit
+  // patterns WITH the reference's own arithmetic, inside a quarter turn of the centre where nothing else can pass (tol < 90 degrees);
+  // a pixel then costs two range comparisons on the stored float.
+  struct AlignedSet {
+    float lo[2], hi[2];
+    bool exact = false;       // false: intervals not established, use count_aligned
+    int count(const float* d, int n) const {
+      int hits = 0;
+      for (int i = 0; i < n; i++) hits += (int)(((d[i] >= lo[0]) & (d[i] <= hi[0])) | ((d[i] >= lo[1]) & (d[i] <= hi[1])));
+      return hits;
+    }
+  };
+  static AlignedSet aligned_set(double theta, double tol) {
+    AlignedSet S;
+    S.lo[0] = S.lo[1] = 1.f; S.hi[0] = S.hi[1] = 0.f;      // empty
+    if (!(tol > 0) || !(tol < kPi / 2 - 0.01) || !(theta >= -k2Pi) || !(theta <= 2 * k2Pi)) return S;
+    auto pass = [&](float d) { return within(theta, (double)d * kDegToRad, tol); };
+    auto bits = [](float f) { unsigned u; std::memcpy(&u, &f, 4); return u; };
+    auto flt = [](unsigned u) { float f; std::memcpy(&f, &u, 4); return f; };
+    auto clampd = [](double deg) { return (float)std::min(360.0, std::max(0.0, deg)); };
+    int n = 0;
+    const double centres[3] = {theta, theta - k2Pi, theta + k2Pi};
+    for (double c : centres) {
+      if (c < -tol || c > k2Pi + tol) continue;
+      // a float that passes, next to the centre (the centre itself may lie just outside [0, 360] or be rounded across the end point)
+      float mid = clampd(c / kDegToRad);
+      if (!pass(mid)) continue;                                  // (an interval that does not reach into [0, 360]; or a tolerance of a few ulps: see `exact`)
+      if (n == 2) return S;                                      // (cannot happen for tol < 90 degrees; stay with the plain loop)
+      const float left_end = clampd((c - kPi / 2) / kDegToRad), right_end = clampd((c + kPi / 2) / kDegToRad);
+      // smallest passing float in [left_end, mid], largest in [mid, right_end]: a few steps from where c -+ tol lands; bisection if not
+      const unsigned bl = bits(left_end), bm = bits(mid), br = bits(right_end);
+      unsigned lo_b, hi_b;
+      if (pass(left_end)) lo_b = bl;
+      else {
+        unsigned e = std::min(bm, std::max(bl + 1, bits(clampd((c - tol) / kDegToRad))));
+        int steps = 0;
+        if (pass(flt(e))) { while (steps < 32 && e > bl + 1 && pass(flt(e - 1))) { e--; steps++; } }
+        else { while (steps < 32 && !pass(flt(e))) { e++; steps++; } }          // (e <= bm, and mid passes)
+        if (steps == 32) { unsigned a = bl, b = bm; while (b - a > 1) { const unsigned m = a + (b - a) / 2; if (pass(flt(m))) b = m; else a = m; } e = b; }
+        lo_b = e;
+      }
+      if (pass(right_end)) hi_b = br;
+      else {
+        unsigned e = std::max(bm, std::min(br - 1, bits(clampd((c + tol) / kDegToRad))));
+        int steps = 0;
+        if (pass(flt(e))) { while (steps < 32 && e < br - 1 && pass(flt(e + 1))) { e++; steps++; } }
+        else { while (steps < 32 && !pass(flt(e))) { e--; steps++; } }          // (e >= bm, and mid passes)
+        if (steps == 32) { unsigned a = bm, b = br; while (b - a > 1) { const unsigned m = a + (b - a) / 2; if (pass(flt(m))) a = m; else b = m; } e = a; }
+        hi_b = e;
+      }
+      S.lo[n] = flt(lo_b); S.hi[n] = flt(hi_b);
+      n++;
+    }
+    // a tolerance so small that no float next to the centre passes would leave the set empty although a pixel might pass: such
+    // tolerances (below 1e-5 rad) do not occur (p >= 0.125 / 1024), and the plain loop takes them if they ever did
+    S.exact = tol > 1e-5;
+    return S;
   }
 
   // :644-692.  Returns the region angle.
@@ -298,12 +361,13 @@ struct Field {
     const double r_second = (right->y != tail->x) ? (right->x - tail->x) / (right->y - tail->x) : 0;
     double l_step = l_first, r_step = r_first, xl = top->x, xr = top->x;
     int total = 0, hits = 0;
+    const AlignedSet set = aligned_set(b.theta, b.tol);
     for (int y = top->y; y <= bottom->y; y++) {
       if (y < 0 || y >= H) continue;                     // (the borders do not advance on skipped rows either)
       const int x0 = std::max((int)xl, 0), x1 = std::min((int)xr, W - 1);      // (the reference walks (int)xl .. (int)xr and skips what lies outside the image)
       if (x1 >= x0) {
         total += x1 - x0 + 1;
-        hits += count_aligned(deg + (size_t)y * W + x0, x1 - x0 + 1, b.theta, b.tol);
+        hits += set.exact ? set.count(deg + (size_t)y * W + x0, x1 - x0 + 1) : count_aligned(deg + (size_t)y * W + x0, x1 - x0 + 1, b.theta, b.tol);
       }
       if (y >= left->y) l_step = l_second;
       if (y >= right->y) r_step = r_second;
@@ -559,7 +623,7 @@ extern "C" int cs_detect_lsd_batch(cs_detector* d, const unsigned char* const* g
       }
       ctx.done = S.chunks.done.data(); ctx.n_chunks = n_chunks;
       t_host = lsd_now_ms();
-      cs_internal_detector_parallel(d, n_images + 1, [](int t, void* vp) {
+      cs_internal_detector_parallel_long(d, n_images + 1, [](int t, void* vp) {
         Ctx& c = *(Ctx*)vp;
         if (t == 0) { c.gate.watch(c.device, c.done, c.n_chunks, cs::BATCH_CHUNK, c.n_images); return; }
         const int i = t - 1;
