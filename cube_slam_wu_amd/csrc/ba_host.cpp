@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -324,6 +325,60 @@ struct cs_ba {
 
 namespace {
 
+// The structure phase's threaded loops (seven or eight short bursts of <= 8 items): a process-wide set of seven parked threads instead of
+// 8 x std::thread per burst (20-30 us each to create and join: over a millisecond of the phase at a million edges).  One user at a time;
+// a second handle building its structure at the same moment (the sharded tests' rank threads) falls back to plain threads.
+class StructPool {
+ public:
+  static StructPool& get() { static StructPool p; return p; }
+  bool try_run(int n, const std::function<void(int)>& fn) {
+    std::unique_lock<std::mutex> use(use_, std::try_to_lock);
+    if (!use.owns_lock()) return false;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      if (th_.empty()) for (int i = 0; i < 7; i++) th_.emplace_back([this] { loop(); });
+      fn_ = &fn; n_ = n; next_.store(0); pending_ = (int)th_.size(); gen_++;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this] { return pending_ == 0; });
+    fn_ = nullptr;
+    return true;
+  }
+  ~StructPool() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; gen_++; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+ private:
+  void work() { for (;;) { const int i = next_.fetch_add(1); if (i >= n_) break; (*fn_)(i); } }
+  void loop() {
+    unsigned long long seen = 0;
+    for (;;) {
+      { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return gen_ != seen; }); seen = gen_; if (stop_) return; }
+      work();
+      { std::lock_guard<std::mutex> lk(m_); if (--pending_ == 0) done_.notify_all(); }
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex use_, m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  std::atomic<int> next_{0};
+  int n_ = 0, pending_ = 0;
+  unsigned long long gen_ = 0;
+  bool stop_ = false;
+};
+// items 0 .. n - 1 side by side (n <= 8 in the structure phase)
+inline void run_items(int n, const std::function<void(int)>& fn) {
+  if (n <= 1) { if (n == 1) fn(0); return; }
+  if (StructPool::get().try_run(n, fn)) return;
+  std::vector<std::thread> th;
+  for (int t = 0; t < n; t++) th.emplace_back(fn, t);
+  for (auto& t : th) t.join();
+}
+
 // std::sort on chunks in a few host threads, then pairwise merges (the structure phase's large sorts)
 template <class It, class Cmp>
 void parallel_sort(It b, It e, Cmp cmp, int nt) {
@@ -383,15 +438,13 @@ int finalize_structure(cs_ba* B) {
   std::vector<int> cam_cnt(np + 1, 0), gorder, run_first;
   UBuf<int> cams_of((size_t)B->n_proj), edge_of((size_t)B->n_proj);   // edges grouped by landmark: camera (sorted by id) and caller edge index
   {
-    for (int k = 0; k < B->n_proj; k++) cam_cnt[B->e_pt[k] + 1]++;
-    for (int i = 0; i < np; i++) cam_cnt[i + 1] += cam_cnt[i];
-    std::vector<int> fill(cam_cnt.begin(), cam_cnt.end() - 1);
-    {   // every landmark's camera list sorted, its edges with it (independent little sorts: a few host threads on disjoint ranges)
-      const bool threaded = B->n_proj > 100000;
+    {   // a counting sort of the edges by landmark (the edge order inside a landmark stays the caller's), then every landmark's camera list
+        // sorted, its edges with it.  Threaded in two levels: the edges are first dealt into landmark ranges (thread t walks its share of the
+        // edges and appends to its own list per range), then range r's thread counts, fills and sorts from the lists of its range only --
+        // every edge is read three times in all, every write (and the page faults of the two fresh arrays) is partitioned.  (First form: one
+        // thread counted all edges, then every thread scanned ALL edges for those of its landmarks -- 5.9 ms at a million edges.)
+      const int NT = B->n_proj > 100000 ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
       auto sort_lists = [&](int p0, int p1) {
-        // the counting sort's fill, landmark range by landmark range: a thread scans all edges and keeps those of ITS landmarks (the
-        // edge order inside a landmark stays the caller's; the writes -- and the page faults of the two fresh arrays -- are partitioned)
-        for (int k = 0; k < B->n_proj; k++) { const int pp = B->e_pt[k]; if (pp >= p0 && pp < p1) { const int q = fill[pp]++; cams_of[q] = B->e_cam[k]; edge_of[q] = k; } }
         for (int p = p0; p < p1; p++) {
           const int a0 = cam_cnt[p], a1 = cam_cnt[p + 1];
           for (int a = a0 + 1; a < a1; a++) {      // insertion sort (a handful of edges; stable: caller order among equal cameras)
@@ -402,12 +455,42 @@ int finalize_structure(cs_ba* B) {
           }
         }
       };
-      const int NT = threaded ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
-      if (NT > 1) {
-        std::vector<std::thread> th;
-        for (int t = 0; t < NT; t++) th.emplace_back(sort_lists, (int)((long long)np * t / NT), (int)((long long)np * (t + 1) / NT));
-        for (auto& t : th) t.join();
-      } else sort_lists(0, np);
+      if (NT == 1) {
+        for (int k = 0; k < B->n_proj; k++) cam_cnt[B->e_pt[k] + 1]++;
+        for (int i = 0; i < np; i++) cam_cnt[i + 1] += cam_cnt[i];
+        std::vector<int> fill(cam_cnt.begin(), cam_cnt.end() - 1);
+        for (int k = 0; k < B->n_proj; k++) { const int q = fill[B->e_pt[k]]++; cams_of[q] = B->e_cam[k]; edge_of[q] = k; }
+        sort_lists(0, np);
+      } else {
+        auto range_of = [&](int p) { return (int)(((long long)p * NT) / np); };                    // landmark -> range
+        auto range_lo = [&](int r) { return (int)(((long long)r * np + NT - 1) / NT); };            // first landmark of range r (inverse of range_of)
+        std::vector<std::vector<int>> dealt((size_t)NT * NT);                                      // [dealing thread][range]: edge indices, ascending
+        run_items(NT, [&](int t) {
+          const int k0 = (int)((long long)B->n_proj * t / NT), k1 = (int)((long long)B->n_proj * (t + 1) / NT);
+          for (int r = 0; r < NT; r++) dealt[(size_t)t * NT + r].reserve((size_t)(k1 - k0) / NT + 64);
+          for (int k = k0; k < k1; k++) dealt[(size_t)t * NT + range_of(B->e_pt[k])].push_back(k);
+        });
+        std::vector<int> range_edges(NT + 1, 0);       // where a range's edges start in the grouped arrays
+        for (int r = 0; r < NT; r++) { size_t m = 0; for (int t = 0; t < NT; t++) m += dealt[(size_t)t * NT + r].size(); range_edges[r + 1] = range_edges[r] + (int)m; }
+        run_items(NT, [&](int r) {       // (cam_cnt[p + 1] of the range's landmarks is this thread's alone: count, then end offset)
+          const int p0 = range_lo(r), p1 = r + 1 < NT ? range_lo(r + 1) : np;
+          for (int t = 0; t < NT; t++) for (int k : dealt[(size_t)t * NT + r]) cam_cnt[B->e_pt[k] + 1]++;
+          std::vector<int> fill((size_t)(p1 - p0));
+          int at = range_edges[r];
+          for (int p = p0; p < p1; p++) { fill[p - p0] = at; at += cam_cnt[p + 1]; cam_cnt[p + 1] = at; }
+          for (int t = 0; t < NT; t++) for (int k : dealt[(size_t)t * NT + r]) { const int q = fill[B->e_pt[k] - p0]++; cams_of[q] = B->e_cam[k]; edge_of[q] = k; }
+          // (the lists' bounds: cam_cnt[p0] belongs to the range before -- its value is range_edges[r])
+          for (int p = p0; p < p1; p++) {
+            const int a0 = p == p0 ? range_edges[r] : cam_cnt[p], a1 = cam_cnt[p + 1];
+            for (int a = a0 + 1; a < a1; a++) {
+              const int c = cams_of[a], e = edge_of[a];
+              int q = a;
+              while (q > a0 && cams_of[q - 1] > c) { cams_of[q] = cams_of[q - 1]; edge_of[q] = edge_of[q - 1]; q--; }
+              cams_of[q] = c; edge_of[q] = e;
+            }
+          }
+        });
+      }
     }
     mark("  camera lists (count, fill, sort)");
     for (int p = 0; p < np; p++) {
@@ -451,7 +534,7 @@ int finalize_structure(cs_ba* B) {
           G[table[s]].members.push_back(p);
         }
       };
-      if (NTg > 1) { std::vector<std::thread> th; for (int t = 0; t < NTg; t++) th.emplace_back(group_range, t); for (auto& t : th) t.join(); } else group_range(0);
+      run_items(NTg, group_range);
       // merge: global groups = distinct sets over all threads
       struct GGroup { int rep; std::vector<std::pair<int, int>> parts; };     // (thread, local group), thread order = landmark order
       std::vector<GGroup> GG;
@@ -777,11 +860,7 @@ int finalize_structure(cs_ba* B) {
         }
       }
     };
-    if (NTH > 1) {
-      std::vector<std::thread> th;
-      for (int t = 0; t < NTH; t++) th.emplace_back(build_points, (int)((long long)np * t / NTH), (int)((long long)np * (t + 1) / NTH));
-      for (auto& t : th) t.join();
-    } else build_points(0, np);
+    run_items(NTH, [&](int t) { build_points((int)((long long)np * t / NTH), (int)((long long)np * (t + 1) / NTH)); });
   }
   mark("  point-major order");
   // camera-major: a stable counting sort of the point-major slots by camera, the slots cut into NTH ranges (per-range histograms)
@@ -792,7 +871,7 @@ int finalize_structure(cs_ba* B) {
     auto count = [&](int t) { for (int sl = (int)((long long)E * t / NTH), s1 = (int)((long long)E * (t + 1) / NTH); sl < s1; sl++) hist[t][pm_cam[sl]]++; };
     auto fillr = [&](int t) { std::vector<int>& h = hist[t]; for (int sl = (int)((long long)E * t / NTH), s1 = (int)((long long)E * (t + 1) / NTH); sl < s1; sl++) { const int q = h[pm_cam[sl]]++; cm_pm[q] = sl; cm_pt[q] = pm_pt[sl]; } };
     auto run_threads = [&](const std::function<void(int)>& fn) {
-      if (NTH > 1) { std::vector<std::thread> th; for (int t = 0; t < NTH; t++) th.emplace_back(fn, t); for (auto& t : th) t.join(); } else fn(0);
+      run_items(NTH, fn);
     };
     run_threads(count);
     int run = 0;
