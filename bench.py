@@ -705,16 +705,17 @@ def main():
         dl = capi.Detector(capi.default_params(host_threads=host_threads), device=local_rank)
         dl.detect_lines_batch(batch_imgs, 15.0)
         t1 = time.perf_counter()
-        reps = 5
+        reps = 20      # (a burst of pool work can run into the cgroup's CPU quota and stall for the rest of a 100 ms period: enough batches to see the sustained rate, the median beside the mean)
         dev_ms = host_ms = call_ms = 0.0
+        calls = []
         for _ in range(reps):
             segs = dl.detect_lines_batch(batch_imgs, 15.0)
-            tq = dl.lines_timing(); dev_ms += tq["device_ms"]; host_ms += tq["host_ms"]; call_ms += tq["total_ms"]
+            tq = dl.lines_timing(); dev_ms += tq["device_ms"]; host_ms += tq["host_ms"]; call_ms += tq["total_ms"]; calls.append(tq["total_ms"])
         dtq = time.perf_counter() - t1
         px = Hq * Wq * args.lines_images
         lines_out = {"what": "cs_detect_lines_batch: EDLines (one octave, length >= 15) of %d images of %d x %d; Gaussian / Sobel / gradient / anchors on the device (one packed word per pixel comes back), routing + fitting + validation on the host pool, which starts on the first images while the later ones are still being computed and copied (chunks of 4)" % (args.lines_images, Wq, Hq),
                      "images_per_s": args.lines_images * reps / dtq, "segments_per_image": float(np.mean([len(x) for x in segs])),
-                     "device_ms_per_batch": dev_ms / reps, "host_stage_ms_per_batch": host_ms / reps, "library_call_ms_per_batch": call_ms / reps,
+                     "device_ms_per_batch": dev_ms / reps, "host_stage_ms_per_batch": host_ms / reps, "library_call_ms_per_batch": call_ms / reps, "library_call_ms_median": float(np.median(calls)),
                      "maps_kernel": {"alg_bytes_per_batch": 5 * px, "GB/s": 5 * px / (dev_ms / reps * 1e-3) / 1e9, "frac_of_hbm_peak": 5 * px / (dev_ms / reps * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import edlines_oracle_py
@@ -728,14 +729,15 @@ def main():
         dl.detect_lines_batch(batch_imgs, 15.0, use_lsd=True)
         t1 = time.perf_counter()
         dev_ms = host_ms = call_ms = 0.0
+        calls = []
         for _ in range(reps):
             segs = dl.detect_lines_batch(batch_imgs, 15.0, use_lsd=True)
-            tq = dl.lines_timing(use_lsd=True); dev_ms += tq["device_ms"]; host_ms += tq["host_ms"]; call_ms += tq["total_ms"]
+            tq = dl.lines_timing(use_lsd=True); dev_ms += tq["device_ms"]; host_ms += tq["host_ms"]; call_ms += tq["total_ms"]; calls.append(tq["total_ms"])
         dtq = time.perf_counter() - t1
         lsd_bytes = px + 12 * int(round(Hq * 0.8)) * int(round(Wq * 0.8)) * args.lines_images
         lines_out["lsd"] = {"what": "cs_detect_lsd_batch: the reference's LSD branch on the same images",
                             "images_per_s": args.lines_images * reps / dtq, "segments_per_image": float(np.mean([len(x) for x in segs])),
-                            "device_ms_per_batch": dev_ms / reps, "host_stage_ms_per_batch": host_ms / reps, "library_call_ms_per_batch": call_ms / reps,
+                            "device_ms_per_batch": dev_ms / reps, "host_stage_ms_per_batch": host_ms / reps, "library_call_ms_per_batch": call_ms / reps, "library_call_ms_median": float(np.median(calls)),
                             "maps_kernels": {"alg_bytes_per_batch": lsd_bytes, "GB/s": lsd_bytes / (dev_ms / reps * 1e-3) / 1e9, "frac_of_hbm_peak": lsd_bytes / (dev_ms / reps * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import lsd_oracle_py

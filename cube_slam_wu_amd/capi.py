@@ -179,14 +179,19 @@ class Detector:
         return out[:n.value].copy()
 
     def detect_lines_batch(self, grays, length_thres=15.0, cap=20000, use_lsd=False):
-        """cs_detect_lines_batch / cs_detect_lsd_batch: images of one size -> list of (n_i, 4) float32 arrays."""
-        grays = [np.ascontiguousarray(g, np.uint8) for g in grays]
+        """cs_detect_lines_batch / cs_detect_lsd_batch: images of one size -> list of (n_i, 4) float32 arrays.
+        (The marshalling is kept light -- uninitialised result rows, plain addresses instead of a typed pointer object per image: it was
+        3.4 ms per 64-image call, against 5 ms for the library's own work.)"""
+        grays = [g if (isinstance(g, np.ndarray) and g.dtype == np.uint8 and g.flags.c_contiguous) else np.ascontiguousarray(g, np.uint8) for g in grays]
         n = len(grays)
         H, W = grays[0].shape
-        out = np.zeros((n, cap, 4), np.float32)
+        if any(g.shape != (H, W) for g in grays):
+            raise ValueError("detect_lines_batch: the images of a batch have one size")
+        out = np.empty((n, cap, 4), np.float32)
         cnt = np.zeros(n, np.int32)
-        gp = (C.POINTER(C.c_ubyte) * n)(*[g.ctypes.data_as(C.POINTER(C.c_ubyte)) for g in grays])
-        op = (C.POINTER(C.c_float) * n)(*[out[i].ctypes.data_as(C.POINTER(C.c_float)) for i in range(n)])
+        gp = (C.c_void_p * n)(*[g.ctypes.data for g in grays])
+        base, stride = out.ctypes.data, out.strides[0]
+        op = (C.c_void_p * n)(*[base + i * stride for i in range(n)])
         rc = (lib().cs_detect_lsd_batch if use_lsd else lib().cs_detect_lines_batch)(self.h, gp, n, int(W), int(H), C.c_double(length_thres), op, int(cap), cnt.ctypes.data_as(C.POINTER(C.c_int)))
         if rc != 0:
             raise RuntimeError("%s failed (%d): %s" % ("cs_detect_lsd_batch" if use_lsd else "cs_detect_lines_batch", rc, last_error()))
