@@ -1223,6 +1223,9 @@ int finalize_structure(cs_ba* B) {
 #undef UP
 #undef AL
 #undef UPB
+  // (the helper thread allocates the edge tables' device buffers: their addresses are final only once it is done)
+  edge_th.join();
+  if (edge_rc) return edge_rc;
   cs::BaView& v = B->view;
   v.cams = B->cams.p; v.points = B->points.p; v.cubes = B->cubes.p; v.cam_col = B->d_cam_col.p; v.cub_col = B->d_cub_col.p; v.pt_free = B->d_pt_free.p;
   v.nc = nc; v.np = np; v.no = no; v.n_pose = B->n_pose; v.n_red = B->n_red; v.elim = B->elim ? 1 : 0;
@@ -1249,8 +1252,6 @@ int finalize_structure(cs_ba* B) {
   v.gcam_ptr = B->d_gcam_ptr.p; v.gslot = B->d_gslot.p;
   v.chi_partial = B->chi_partial.p;
   // the allocations above were zeroed on B->st (queued, one wait here); uploads went through blocking copies
-  edge_th.join();
-  if (edge_rc) return edge_rc;
   BA_TRY(hipStreamSynchronize(B->st));
   mark("pose edges + allocations");
   B->structure_dirty = false;
