@@ -46,3 +46,32 @@ def test_lsd_restatement_edge_cases():
     assert len(b) < len(a) and np.array_equal(a[keep], b)
     with pytest.raises(RuntimeError):
         LSD.detect_filter_lines(g, 15.0, cap=10)
+
+
+def test_product_host_stage_equals_the_restatement_on_the_reference_frames_without_a_gpu(tmp_path):
+    """The sequential half of the LSD producer (cube_slam_wu_amd/csrc/lsd_host.cpp) is plain host C++: compiled here against the planes the
+    restatement computes (tools/hostonly/), it has to return the restatement's segments bit for bit on all 58 frames of the reference's
+    sequence (object_slam/data/raw_imgs) -- region growing decided from the cos / sin sums, the interval form of rect_nfa's test and
+    the word-wise seed scan included.  (With a GPU the same comparison runs through the C ABI in tests/test_lines_gpu.py.)"""
+    import shutil, subprocess
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hip_inc, hip_lib = "/opt/rocm/include", "/opt/rocm/lib"
+    if shutil.which("g++") is None or not os.path.exists(os.path.join(hip_inc, "hip", "hip_runtime.h")):
+        pytest.skip("needs g++ and the HIP headers")
+    raw = os.path.join(os.path.dirname(__file__), "golden", "object_slam_data", "raw_imgs")
+    frames = sorted(f for f in os.listdir(raw) if f.endswith(".jpg"))
+    assert len(frames) == 58
+    blob = tmp_path / "frames.gray"
+    with open(blob, "wb") as fo:
+        for f in frames:
+            img = np.asarray(Image.open(os.path.join(raw, f)).convert("L"))
+            assert img.shape == (480, 640)
+            fo.write(img.tobytes())
+    exe = tmp_path / "lsd_host_check"
+    o1, o2 = tmp_path / "planes.o", tmp_path / "check.o"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-c", os.path.join(root, "tools", "hostonly", "lsd_planes_from_oracle.cpp"), "-o", str(o1)])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I" + hip_inc, "-c", os.path.join(root, "tools", "hostonly", "lsd_host_check.cpp"), "-o", str(o2)])
+    subprocess.check_call(["g++", str(o2), str(o1), "-o", str(exe), "-L" + hip_lib, "-lamdhip64", "-Wl,-rpath," + hip_lib, "-pthread"])
+    out = subprocess.run([str(exe), str(blob), "640", "480", "58", "1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "58 images" in out.stdout and " 0 differ" in out.stdout, out.stdout + out.stderr
