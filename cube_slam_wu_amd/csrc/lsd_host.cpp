@@ -204,18 +204,18 @@ struct Field {
     const double k_in = fast ? std::cos(tol - kGrowMargin) : 0, k_out = fast ? std::cos(tol + kGrowMargin) : 0;
     const double k_in2 = k_in * k_in * (1 + 1e-9), k_out2 = k_out * k_out * (1 - 1e-9);
     bool theta_current = true;          // theta is the estimate that belongs to the sums (the seed's own angle before the first addition)
+    bool sums_usable = false;           // at least one pixel added, the tolerance inside (0, 90) degrees, the sums not nearly cancelling
+    double vc = 0, vs = 0, in_thr = 0, out_thr = 0;
     auto candidate = [&](int x, int y, int at) {
       const double a = ang(at);
       float ca, sa;
       if (state[at] & ST_UNIT) { ca = unit[2 * at]; sa = unit[2 * at + 1]; }
       else { ca = std::cos((float)a); sa = std::sin((float)a); unit[2 * at] = ca; unit[2 * at + 1] = sa; state[at] |= ST_UNIT; }
       int verdict = -1;                 // 1 aligned, 0 not, -1 the reference's arithmetic decides
-      if (fast && count > 1) {
-        const double vc = sum_c, vs = sum_s, dot = vc * ca + vs * sa, n2 = vc * vc + vs * vs, d2 = dot * dot;
-        if (n2 > 0.25) {
-          if (dot > 0 && d2 >= k_in2 * n2) verdict = 1;
-          else if (dot <= 0 || d2 <= k_out2 * n2) verdict = 0;
-        }
+      if (sums_usable) {                // (vc, vs, the two thresholds: functions of the sums, refreshed when a pixel is added)
+        const double dot = vc * ca + vs * sa, d2 = dot * dot;
+        if (dot > 0 && d2 >= in_thr) verdict = 1;
+        else if (dot <= 0 || d2 <= out_thr) verdict = 0;
       }
       if (verdict < 0) {
         if (!theta_current) { theta = (double)atan2_deg(sum_s, sum_c) * kDegToRad; theta_current = true; }
@@ -227,6 +227,10 @@ struct Field {
       sum_c += ca;
       sum_s += sa;
       theta_current = false;
+      vc = sum_c; vs = sum_s;
+      const double n2 = vc * vc + vs * vs;
+      sums_usable = fast && n2 > 0.25;
+      in_thr = k_in2 * n2; out_thr = k_out2 * n2;
     };
     for (int i = 0; i < count; i++) {
       const int px = region[i].x, py = region[i].y;
@@ -240,7 +244,7 @@ struct Field {
           std::memcpy(&v, row, 4);      // (three bytes of the row and one beyond: the scratch is padded)
           v &= 0x050505u;
           const unsigned free3 = ~(v | (v >> 2)) & 0x010101u;
-          m |= ((free3 & 1u) | ((free3 >> 7) & 2u) | ((free3 >> 14) & 4u)) << (3 * r);
+          m |= (((free3 * 0x10204u) >> 16) & 7u) << (3 * r);      // bits 0, 8, 16 -> 0, 1, 2 (the partial products land on distinct bits)
         }
         while (m) {
           const int bit = __builtin_ctz(m);
