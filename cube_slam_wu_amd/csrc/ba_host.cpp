@@ -370,6 +370,12 @@ class StructPool {
   unsigned long long gen_ = 0;
   bool stop_ = false;
 };
+// threads of a structure-phase burst: min(8, hardware threads), or fewer with CS_BA_STRUCT_THREADS (= 1: every loop on the calling thread --
+// tests hold the threaded tables to the sequential ones, cs_ba_structure_digest)
+inline int struct_threads() {
+  static const int cap = [] { const char* e = getenv("CS_BA_STRUCT_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 8; }();
+  return (int)std::max(1u, std::min((unsigned)cap, std::thread::hardware_concurrency()));
+}
 // items 0 .. n - 1 side by side (n <= 8 in the structure phase)
 inline void run_items(int n, const std::function<void(int)>& fn) {
   if (n <= 1) { if (n == 1) fn(0); return; }
@@ -443,7 +449,7 @@ int finalize_structure(cs_ba* B) {
         // edges and appends to its own list per range), then range r's thread counts, fills and sorts from the lists of its range only --
         // every edge is read three times in all, every write (and the page faults of the two fresh arrays) is partitioned.  (First form: one
         // thread counted all edges, then every thread scanned ALL edges for those of its landmarks -- 5.9 ms at a million edges.)
-      const int NT = B->n_proj > 20000 ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;   // (200 cameras / 100 k edges: 0.67 -> 0.35 ms)
+      const int NT = B->n_proj > 20000 ? struct_threads() : 1;   // (200 cameras / 100 k edges: 0.67 -> 0.35 ms)
       auto sort_lists = [&](int p0, int p1) {
         for (int p = p0; p < p1; p++) {
           const int a0 = cam_cnt[p], a1 = cam_cnt[p + 1];
@@ -505,7 +511,7 @@ int finalize_structure(cs_ba* B) {
     // out group by group -- in landmark order inside a group, because every thread walks its range in order and the ranges are laid
     // down in order.  Same gorder / run_first as the sort produced.
     {
-      const int NTg = (gorder.size() > 5000) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+      const int NTg = (gorder.size() > 5000) ? struct_threads() : 1;
       struct LGroup { int rep; std::vector<int> members; };
       std::vector<std::vector<LGroup>> local(NTg);
       auto set_hash = [&](int p) {
@@ -843,7 +849,7 @@ int finalize_structure(cs_ba* B) {
   B->slot_src_n = E;
   int* const src_of_slot = B->slot_src.get();
   UBuf<int> pm_pt((size_t)E), pm_cam((size_t)E);
-  const int NTH = (E > 20000) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+  const int NTH = (E > 20000) ? struct_threads() : 1;
   {
     auto build_points = [&](int p0, int p1) {
       for (int p = p0; p < p1; p++) {
@@ -2501,6 +2507,34 @@ int cs_ba_schur_layout(cs_ba* B, int* fused, int* n_segments, int* n_partial_blo
   if (n_blocks) *n_blocks = B->fused ? B->n_gpairs : B->n_pairs;
   return CS_OK;
   BA_GUARD_END("cs_ba_schur_layout")
+}
+
+// Inspection for tests: a fingerprint of every index table the structure phase leaves on the device (edge orders, per-vertex lists,
+// the Schur schedule, the solver's column maps), one 64-bit FNV-1a hash per table in a fixed order.  Two builds of one graph -- the
+// threaded loops and CS_BA_STRUCT_THREADS=1, an appended graph and the same graph set up at once -- must agree table by table.
+int cs_ba_structure_digest(cs_ba* B, unsigned long long* out, int cap, int* n_tables) {
+  if (!B || !n_tables || cap < 0 || (cap && !out)) return CS_ERR_INVALID_ARG;
+  BA_GUARD_BEGIN
+  int rc = finalize_structure(B); if (rc) return rc;
+  BA_TRY(hipSetDevice(B->device));
+  BA_TRY(hipStreamSynchronize(B->st));
+  const DBuf<int>* tabs[] = {&B->d_cam_col, &B->d_cub_col, &B->d_pt_free, &B->pm_pt, &B->pm_cam, &B->pt_ptr, &B->cm_pm, &B->cm_pt, &B->cam_ptr, &B->d_src,
+                             &B->d_run_lm, &B->d_seg_ptr, &B->d_seg_k, &B->d_seg_tile, &B->d_seg_slot, &B->d_gp_ptr, &B->d_gp_i1, &B->d_gp_i2, &B->d_gtile, &B->d_gcam_ptr, &B->d_gslot,
+                             &B->pair_ptr, &B->pair_i1, &B->pair_i2, &B->ent_a, &B->ent_b, &B->d_cubS_ptr, &B->d_cubS_cam, &B->d_ce_slot, &B->d_cub_tile, &B->d_cub_coef,
+                             &B->d_slotE_ptr, &B->d_slotE_idx, &B->cam_ce_ptr, &B->cam_ce_idx, &B->cam_oei_ptr, &B->cam_oei_idx, &B->cam_oej_ptr, &B->cam_oej_idx, &B->cub_ce_ptr, &B->cub_ce_idx,
+                             &B->d_ce_active, &B->d_oe_active};
+  const int nt = (int)(sizeof(tabs) / sizeof(tabs[0]));
+  *n_tables = nt;
+  std::vector<int> h;
+  for (int t = 0; t < nt && t < cap; t++) {
+    h.resize(tabs[t]->n);
+    if (tabs[t]->n) BA_TRY(hipMemcpy(h.data(), tabs[t]->p, sizeof(int) * tabs[t]->n, hipMemcpyDeviceToHost));
+    unsigned long long f = 1469598103934665603ull ^ (unsigned long long)tabs[t]->n;
+    for (int v : h) { f ^= (unsigned)v; f *= 1099511628211ull; }
+    out[t] = f;
+  }
+  return CS_OK;
+  BA_GUARD_END("cs_ba_structure_digest")
 }
 
 // The diagonal Hessian blocks g2o keeps mapped into its vertices (BaseVertex::_hessian, core/base_vertex.hpp:30,52-54; mapped by

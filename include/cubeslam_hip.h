@@ -402,6 +402,10 @@ int cs_ba_solver_path(cs_ba* ba, int* path, int* bandwidth, double* sparse_fill)
  * per covisible camera pair.  Tracks of 14 .. 64 views ride in the fused schedule through a plain multiply-add kernel.
  * n_blocks = 6x6 blocks of S the landmarks touch.                                                                  */
 int cs_ba_schur_layout(cs_ba* ba, int* fused, int* n_segments, int* n_partial_blocks, int* n_blocks);
+/* Inspection for tests: one 64-bit hash per index table the structure phase (BlockSolver::buildStructure, block_solver.hpp:142-295)
+ * leaves on the device, in a fixed order; n_tables = how many there are (out holds min(cap, n_tables)).  Two builds of the same graph
+ * -- threaded and sequential (CS_BA_STRUCT_THREADS=1), appended frame by frame and set up at once -- agree table by table.          */
+int cs_ba_structure_digest(cs_ba* ba, unsigned long long* out, int cap, int* n_tables);
 /* Inspection for parity tests (host copies, caller-sized): dense Hpp (size_pose^2, no lambda), Hll (9 per
  * free point in point order), Hpl (18 per projection edge in the caller's edge order), b, x.            */
 int cs_ba_get_system(cs_ba* ba, double* Hpp_dense, double* Hll9, double* Hpl18, double* b, double* x);
