@@ -51,6 +51,10 @@ void ba_launch_fail_flag(const int* a, const int* b, const int* c, double* out, 
 size_t ba_band_workspace_doubles(int n, int LD);
 int ba_band_team(int LD, int* rw_out);
 bool ba_band_fits_device(int n, int LD, bool one_sided = false);
+bool ba_bcr_ok(int n, int LD);
+double ba_bcr_estimate_ms(int n);
+size_t ba_bcr_workspace_doubles(int n, int Bv);
+void ba_launch_bcr(const double* Sb, double* work, int n, int LD, int Bv, double* rhs, int* info, hipStream_t st);
 void ba_launch_sum2(const double* a, int na, const double* b, int nb, double* out, hipStream_t st);
 void ba_launch_ext_add(const BaView& v, const double* cam36, const double* cam6, const double* cub81, const double* cub9, const double* pt9, const double* pt3, hipStream_t st);
 void ba_launch_ext_offdiag(const BaView& v, int n, const int* e4, const double* Hij, hipStream_t st);
@@ -228,6 +232,7 @@ struct cs_ba {
   std::vector<int> cam_fixed, cub_fixed, pt_fixed, cam_col, cub_col, pt_lm;  // pt_lm: landmark index among free points or -1
   std::vector<int> cam_col_ref, cub_col_ref;  // columns in g2o's sort-by-id order (inspection only); cam_col / cub_col are in solver (RCM) order
   int band_ld = 0;                            // 0 = dense reduced system
+  bool use_bcr = false;                       // banded system solved by block cyclic reduction (bcr_kernels.hip) instead of the persistent banded kernels
   int force_dense = 0;
   // sharded BA: landmarks (with all their projection edges) are dealt to ranks by the camera subsequence of their
   // first observation; cuboid / odometry edges follow their camera.  Every rank keeps all vertices.
@@ -746,7 +751,15 @@ int finalize_structure(cs_ba* B) {
       const char* e = getenv("CS_BA_SPARSE");
       const int mode = e ? atoi(e) : -1;
       const double nn = (double)O.n_red;
-      const double est_band = B->band_ld ? 1.15 * nn / 64.0 * (10.0 + 0.043 * (B->band_ld - 1)) * 1e-3 : 1e30, est_dense = nn * nn * nn / 3.0 / 11e12 * 1e3 + 1.0;
+      double est_band = B->band_ld ? 1.15 * nn / 64.0 * (10.0 + 0.043 * (B->band_ld - 1)) * 1e-3 : 1e30;
+      const double est_dense = nn * nn * nn / 3.0 / 11e12 * 1e3 + 1.0;
+      // block cyclic reduction where the band is narrow enough for 128-unknown blocks and its few levels beat the banded kernels' chain of steps
+      B->use_bcr = false;
+      if (B->band_ld && cs::ba_bcr_ok(O.n_red, B->band_ld)) {
+        const double est_bcr = cs::ba_bcr_estimate_ms(O.n_red);
+        const char* eb = getenv("CS_BAND_BCR");
+        if (est_bcr < est_band || (eb && atoi(eb) == 2)) { B->use_bcr = true; est_band = est_bcr; }
+      }
       const double est_other = std::min(est_band, est_dense);
       const bool consider = mode != 0 && !B->force_dense && B->shard_n == 1 && O.n_red >= 256 && (mode == 1 || est_other > 5.0);
       if (consider) {
@@ -759,7 +772,7 @@ int finalize_structure(cs_ba* B) {
         if (prof && fits) fprintf(stderr, "[ba structure] sparse plan: %d vertices, %d levels, %lld values (%.1f%% of the dense triangle), largest panel %d, %.2f Gflop + a dense tail of %d unknowns; estimates ms: sparse %.1f, band %.1f, dense %.1f\n",
                                   plan.N, plan.levels, plan.nvals, 100.0 * plan.nvals / (0.5 * nn * nn), plan.max_panel, plan.flops * 2e-9, plan.n_tail, est_sparse, est_band < 1e29 ? est_band : -1.0, est_dense);
         if (fits && (mode == 1 || est_sparse < est_other)) {
-          B->sparse = true; B->band_ld = 0;
+          B->sparse = true; B->band_ld = 0; B->use_bcr = false;
           B->sp_plan = std::move(plan);
         }
       }
@@ -1181,7 +1194,7 @@ int finalize_structure(cs_ba* B) {
   AL(B->S, B->s_doubles + B->n_pose);   // [S | rhs]: one buffer, one all-reduce in the sharded solve
   AL(B->xl, 3 * (size_t)np);
   AL(B->d_band_info, 24);  // [first bad pivot + 1, grid-barrier counters, a zero double]
-  AL(B->band_linv, B->band_ld ? cs::ba_band_workspace_doubles(B->n_red, B->band_ld) : 1);   // inverted diagonal blocks (+ the separator's rows in the nested order)
+  AL(B->band_linv, B->band_ld ? std::max(cs::ba_band_workspace_doubles(B->n_red, B->band_ld), B->use_bcr ? cs::ba_bcr_workspace_doubles(B->n_red, 128) : (size_t)1) : 1);   // inverted diagonal blocks (+ the separator's rows in the nested order)
   B->nb_chi = cs::ba_chi2_blocks(E);
   B->n_chi_partials = B->nb_chi + (B->n_cub + B->n_odom + 63) / 64;
   AL(B->chi_partial, B->n_chi_partials);
@@ -1427,7 +1440,8 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       // that the caller discards)
       std::unique_lock<std::mutex> coop_turn(g_coop_mutex);
       BA_TRY(hipMemsetAsync(B->d_band_info.p, 0, 24 * sizeof(int), B->st));
-      cs::ba_launch_band_cholesky(B->S.p, B->band_linv.p, n, B->band_ld, B->view.rhs, B->d_band_info.p, true, B->st);
+      if (B->use_bcr) cs::ba_launch_bcr(B->S.p, B->band_linv.p, n, B->band_ld, 128, B->view.rhs, B->d_band_info.p, B->st);
+      else cs::ba_launch_band_cholesky(B->S.p, B->band_linv.p, n, B->band_ld, B->view.rhs, B->d_band_info.p, true, B->st);
       BA_TRY(hipGetLastError());
       BA_TRY(hipEventRecord(B->ev[4], B->st));
       cs::ba_launch_backsub(B->view, B->st);

@@ -765,6 +765,28 @@ def test_band_solver_harness_shapes():
             assert len(res) == 2 and max(res) < 1e-12 and infos == [0, 0], (n, ld, env, out.stdout)
 
 
+def test_block_cyclic_reduction_harness_shapes():
+    """tools/microbench/band_bench, order 2: the same random SPD bands through the block-cyclic-reduction solver (csrc/bcr_kernels.hip:
+    bandwidth <= 128, blocks of 128 unknowns eliminated in odd-even order, six levels at C4's 5 994 unknowns).  Shapes: C4's and
+    g2o's-system-sized bands, one / two / three / many blocks, a last block of one unknown, a full last block, the widest band the
+    blocks admit (LD = 129), tiny bandwidths, block sizes below 128 (padding rows inside every block), and a different system every
+    repetition (the kernels keep nothing between solves)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "build_tmp", "band_bench")
+    if not os.path.exists(exe):
+        import __graft_entry__
+        __graft_entry__.build()
+    shapes = [(5994, 120, 128), (10494, 120, 128), (1194, 120, 128), (640, 120, 128), (3000, 40, 128), (777, 12, 128), (2049, 33, 128), (4097, 2, 128), (1217, 100, 128),
+              (1345, 129, 128), (9999, 65, 128), (260, 100, 128), (129, 20, 128), (257, 129, 128), (256, 129, 128), (384, 90, 128), (1500, 101, 120), (1000, 60, 64), (2000, 97, 96),
+              (130, 31, 31)]
+    for n, ld, bv in shapes:
+        out = subprocess.run([exe, str(n), str(ld), "3", "2", str(bv)], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        lines = [l for l in out.stdout.splitlines() if l.startswith("rep")]
+        assert len(lines) == 3 and all(float(l.split("residual")[1].split()[0]) < 1e-12 and int(l.split("info")[1].split()[0]) == 0 for l in lines), (n, ld, bv, out.stdout)
+
+
 @pytest.mark.skipif(os.environ.get("CS_TEST_BAND_WIN") != "1", reason="experimental opt-in path (CS_BAND_WIN=1): run with CS_TEST_BAND_WIN=1; tools/band_win_stress.sh is its stress")
 def test_band_window_resident_fronts_opt_in():
     """CS_BAND_WIN=1: the window-resident fronts (csrc/band_win.h: one workgroup per front, the active window in matrix-core accumulator

@@ -1,10 +1,11 @@
 // band_bench -- standalone timing + residual check of the banded Cholesky kernels (development tool, not shipped).
 //   hipcc --offload-arch=gfx950 -O3 -x hip tools/microbench/band_bench.cpp cube_slam_wu_amd/csrc/ba_kernels.o -o /tmp/band_bench
-//   /tmp/band_bench [n] [LD] [reps]
+//   /tmp/band_bench [n] [LD] [reps] [order: 0 nested / two fronts, 1 one-sided, 2 block cyclic reduction] [Bv of order 2, default 128]
 #include <hip/hip_runtime.h>
 #pragma clang diagnostic ignored "-Wunused-value"
 #pragma clang diagnostic ignored "-Wunused-result"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -14,11 +15,14 @@
 namespace cs {
 void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st, bool one_sided);
 size_t ba_band_workspace_doubles(int n, int LD);
+void ba_launch_bcr(const double* Sb, double* work, int n, int LD, int Bv, double* rhs, int* info, hipStream_t st);
+size_t ba_bcr_workspace_doubles(int n, int Bv);
 }
 
 int main(int argc, char** argv) {
   int n = argc > 1 ? atoi(argv[1]) : 10494, LD = argc > 2 ? atoi(argv[2]) : 183, reps = argc > 3 ? atoi(argv[3]) : 5;
   const int bw = LD - 1;
+  const int order = argc > 4 ? atoi(argv[4]) : 0, Bv = argc > 5 ? atoi(argv[5]) : 128;
   // SPD band: random off-diagonals in [-1, 1], diagonal = row sum of |.| + 1
   std::vector<double> A((size_t)n * LD, 0.0), b(n), diag(n, 1.0);
   unsigned long long s = 12345;
@@ -27,7 +31,7 @@ int main(int argc, char** argv) {
     for (int d = 1; d <= bw && c + d < n; d++) { double v = rnd(); A[(size_t)c * LD + d] = v; diag[c] += std::fabs(v); diag[c + d] += std::fabs(v); }
   for (int c = 0; c < n; c++) { A[(size_t)c * LD] = diag[c]; b[c] = rnd(); }
   double *dS, *dL, *dr; int* dinfo;
-  hipMalloc(&dS, A.size() * 8); hipMalloc(&dL, cs::ba_band_workspace_doubles(n, LD) * 8); hipMalloc(&dr, n * 8); hipMalloc(&dinfo, 96);
+  hipMalloc(&dS, A.size() * 8); hipMalloc(&dL, std::max(cs::ba_band_workspace_doubles(n, LD), cs::ba_bcr_workspace_doubles(n, Bv)) * 8); hipMalloc(&dr, n * 8); hipMalloc(&dinfo, 96);
   hipStream_t st; hipStreamCreate(&st);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   std::vector<double> x(n);
@@ -38,7 +42,8 @@ int main(int argc, char** argv) {
     hipMemcpyAsync(dr, b.data(), n * 8, hipMemcpyHostToDevice, st);
     hipMemsetAsync(dinfo, 0, 96, st);
     hipEventRecord(e0, st);
-    cs::ba_launch_band_cholesky(dS, dL, n, LD, dr, dinfo, true, st, argc > 4 && atoi(argv[4]) != 0);
+    if (order == 2) cs::ba_launch_bcr(dS, dL, n, LD, Bv, dr, dinfo, st);
+    else cs::ba_launch_band_cholesky(dS, dL, n, LD, dr, dinfo, true, st, order == 1);
     hipEventRecord(e1, st);
     hipStreamSynchronize(st);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
@@ -61,7 +66,7 @@ int main(int argc, char** argv) {
       mix(x); mix(Lg);
     }
     printf("rep %d: factor+solve %.3f ms  info %d  residual %.3e  hash %016llx\n", r, ms, info[0], rmax / bmax, hsh);
-    if (rmax / bmax > 1e-9) {   // locate the first wrong entry of L against a CPU band Cholesky
+    if (rmax / bmax > 1e-9 && order != 2) {   // locate the first wrong entry of L against a CPU band Cholesky
       std::vector<double> L(A), Lg(A.size());
       hipMemcpy(Lg.data(), dS, A.size() * 8, hipMemcpyDeviceToHost);
       for (int c = 0; c < n; c++) {

@@ -4,11 +4,11 @@ set -e
 cd "$(dirname "$0")/../.."
 mkdir -p build_tmp
 hipcc --offload-arch=gfx950 -O3 -c -x hip tools/microbench/band_bench.cpp -o build_tmp/band_bench.o
-hipcc --offload-arch=gfx950 build_tmp/band_bench.o cube_slam_wu_amd/csrc/ba_kernels.o -o build_tmp/band_bench
+hipcc --offload-arch=gfx950 build_tmp/band_bench.o cube_slam_wu_amd/csrc/ba_kernels.o cube_slam_wu_amd/csrc/bcr_kernels.o -o build_tmp/band_bench
 # the same harness over the band kernels built with plain stores + agent release / acquire fences instead of the write-through hand-offs
 # (BAND_WT = 0): tests/test_ba_gpu.py holds the two builds to bit-identical factors and solutions
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DBAND_WT=0 -c cube_slam_wu_amd/csrc/ba_kernels.hip -o build_tmp/ba_kernels_fence.o
-hipcc --offload-arch=gfx950 build_tmp/band_bench.o build_tmp/ba_kernels_fence.o -o build_tmp/band_bench_fence
+hipcc --offload-arch=gfx950 build_tmp/band_bench.o build_tmp/ba_kernels_fence.o cube_slam_wu_amd/csrc/bcr_kernels.o -o build_tmp/band_bench_fence
 # counter calibration (tools/pmc_calib.sh)
 hipcc --offload-arch=gfx950 -O3 -x hip tools/microbench/pmc_calib.cpp -o build_tmp/pmc_calib
 # the diagonal-block routine of the banded solver alone
