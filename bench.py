@@ -569,6 +569,25 @@ def main():
                     G0.close()
                 except Exception as ex:       # (a missing scipy or an out-of-memory host must not take the bench line with it)
                     ba_out["parity_vs_oracle"] = {"error": repr(ex)}
+                # ... and as a trajectory: three LM iterations, device beside oracle (C4: the oracle's dense solve through LAPACK, everything else
+                # of the iteration its own; oracle/ba_parity.py compare_trajectory -- tests/test_ba_gpu.py asserts on the same)
+                if "error" not in ba_out["parity_vs_oracle"]:
+                    try:
+                        G1 = capi.ba_from_dict(pr, device=local_rank)
+                        R1 = ba_oracle_py.Problem(pr["cams"], pr["cam_fixed"], pr["cuboids"], pr["cub_fixed"], pr["points"], pr["pt_fixed"])
+                        R1.set_edges_proj(pr["e_pt"], pr["e_cam"], pr["e_uv"], pr["e_info"], pr["e_intr"], pr["e_huber"])
+                        if len(pr["ce_cam"]):
+                            R1.set_edges_cuboid(pr["ce_cam"], pr["ce_cub"], pr["ce_meas"], pr["ce_info"])
+                        R1.set_edges_odom(pr["oe_i"], pr["oe_j"], pr["oe_meas"], pr["oe_info"])
+                        if sampled:
+                            R1.use_lapack_solver()
+                        tr = ba_parity.compare_trajectory(G1, R1, 3)
+                        tr["what"] = ("3 LM iterations of this problem from its initial estimates, device vs oracle/ba_oracle.cpp%s: trial sequences, max relative differences of the chi2 / lambda histories and of the final states"
+                                      % (" (its dense solve through LAPACK, the rest of the iteration its own)" if sampled else ""))
+                        ba_out["parity_vs_oracle"]["trajectory"] = tr
+                        G1.close(); R1.close()
+                    except Exception as ex:
+                        ba_out["parity_vs_oracle"]["trajectory"] = {"error": repr(ex)}
                 tc = time.perf_counter()
                 n_cpu = R.optimize(1 if sampled else args.ba_iters)
                 cpu_wall = time.perf_counter() - tc

@@ -218,13 +218,9 @@ struct cs_ba {
   ncclComm_t comm = nullptr;
   DBuf<double> d_scalars;    // [chi2, LM scale term] of a trial; lambda_0's diagonal on iteration 0
   // lambda of the current trial lives in device memory (d_lam: [lambda, lambda of the pose diagonals in LM's scale term]), copied from
-  // the pinned h_lam at the head of a trial's launch sequence: the sequence itself then never changes and is replayed as ONE hipGraph
-  // launch (trial_exec; captured on the third trial after a structure phase, dropped by the next one)
+  // the pinned h_lam at the head of a trial's launch sequence: the sequence itself never changes
   double* h_lam = nullptr;
   DBuf<double> d_lam;
-  hipGraphExec_t trial_exec = nullptr;
-  int trials_on_structure = 0;
-  bool trial_graph_failed = false;
   double* h_scalars = nullptr;   // pinned mirror
   size_t scalars_cap = 0;
   // host copy of the problem description
@@ -322,8 +318,6 @@ struct cs_ba {
   std::vector<double> h_b, h_x;
   bool have_system = false;
   cs_ba_timing tm{};
-  long long tm_timed_trials = 0;   // directly launched trials of the current structure and their stage sums [reduce, factor, back-substitution, chi2]
-  double stage_sum[4] = {0, 0, 0, 0};
   cs::BaView view{};
 };
 
@@ -1275,8 +1269,6 @@ int finalize_structure(cs_ba* B) {
   mark("pose edges + allocations");
   B->structure_dirty = false;
   B->have_system = false;
-  if (B->trial_exec) { (void)hipGraphExecDestroy(B->trial_exec); B->trial_exec = nullptr; }   // (it holds the old buffers' addresses)
-  B->trials_on_structure = 0; B->trial_graph_failed = false; B->tm_timed_trials = 0; B->stage_sum[0] = B->stage_sum[1] = B->stage_sum[2] = B->stage_sum[3] = 0;
   return CS_OK;
 }
 
@@ -1669,7 +1661,6 @@ void cs_ba_destroy(cs_ba* B) {
   B->d_info.release(); B->d_band_info.release();
   for (auto& e : B->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : B->sev) if (e) (void)hipEventDestroy(e);
-  if (B->trial_exec) (void)hipGraphExecDestroy(B->trial_exec);
   if (B->h_lam) (void)hipHostFree(B->h_lam);
   B->d_lam.release();
   if (B->h_status) (void)hipHostFree(B->h_status);
@@ -2171,68 +2162,20 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
           BA_TRY(hipEventRecord(B->ev[7], B->st));
           return CS_OK;
         };
-        // The sequence is the same ~30 launches, fills and copies for every trial of a structure (lambda is read from device memory), so
-        // it CAN be replayed as one hipGraph launch from the third trial on -- opt-in, CS_BA_GRAPH=1.  Measured on MI355X / ROCm 7.0
-        // (tools/ba_quick.py, two boxes): the replay itself is no faster than the stream launches (the host runs ahead of the device either
-        // way; the graph's nodes carry the same dependency barriers), and the instantiation costs ~0.8 ms per structure: C4 540 / 546
-        // against 564 / 570 LM it/s, C3 1 258 against 1 415.  Not with collectives in it unless asked for (CS_BA_GRAPH_RCCL=1: RCCL
-        // inside a captured stream is untested on this build's boxes), not with the solver's diagnostics that synchronise (CS_BAND_PROF).
-        static const bool graph_on = [] { const char* e = getenv("CS_BA_GRAPH"); return e && atoi(e) != 0 && getenv("CS_BAND_PROF") == nullptr; }();
-        static const bool graph_rccl = [] { const char* e = getenv("CS_BA_GRAPH_RCCL"); return e && atoi(e) != 0; }();
-        const bool want_graph = graph_on && B->band_ld > 0 && !B->trial_graph_failed && !ext_active && (B->shard_n == 1 || (rccl && graph_rccl));   // (the sparse / dense solves synchronise inside)
-        bool timed = true;
-        B->trials_on_structure++;
-        if (want_graph && !B->trial_exec && B->trials_on_structure >= 3) {
-          hipGraph_t g = nullptr;
-          bool ok_cap = hipStreamBeginCapture(B->st, hipStreamCaptureModeThreadLocal) == hipSuccess;
-          if (ok_cap) {
-            std::unique_lock<std::mutex> cap_turn;   // (solve_device takes the persistent kernel's turn and hands it back; nothing runs during capture)
-            const int rq = enqueue_trial(&cap_turn);
-            B->tm.n_solves--;                        // (recorded, not run)
-            ok_cap = (hipStreamEndCapture(B->st, &g) == hipSuccess) && rq == CS_OK && g != nullptr;
-          }
-          if (ok_cap) ok_cap = hipGraphInstantiate(&B->trial_exec, g, nullptr, nullptr, 0) == hipSuccess;
-          if (g) (void)hipGraphDestroy(g);
-          if (!ok_cap) { (void)hipGetLastError(); B->trial_exec = nullptr; B->trial_graph_failed = true; }
-        }
-        if (want_graph && B->trial_exec) {
-          turn = std::unique_lock<std::mutex>(g_coop_mutex);
-          B->h_lam[0] = lambda; B->h_lam[1] = B->shard_rank == 0 ? lambda : 0.0;
-          BA_TRY(hipGraphLaunch(B->trial_exec, B->st));
-          B->tm.n_solves++;
-          timed = false;        // (phase marks: see below)
-        } else {
-          rc = enqueue_trial(&turn); if (rc) return rc;
-        }
+        // (The sequence is the same ~30 launches, fills and copies for every trial of a structure -- lambda is read from device memory -- and was
+        // replayed as one hipGraph in round 4: measured no faster on MI355X / ROCm 7.0 and +0.8 ms of instantiation per structure, DESIGN.md section 3;
+        // removed in round 5.)
+        rc = enqueue_trial(&turn); if (rc) return rc;
         BA_TRY(hipStreamSynchronize(B->st));
         turn.unlock();
         if (B->h_status[0] == 0x7fffffff || (B->sep_mode && B->shard_n > 1 && B->h_status[2] == 0x7fffffff)) { cs_set_error_ba("banded solver: team not co-resident (wait timed out); set CS_BA_FORCE_DENSE=1 on a shared device"); return CS_ERR_HIP; }
         ok2 = B->h_scalars[2] == 0.0;
         tempChi = B->h_scalars[0];
         scale = ok2 ? B->h_scalars[1] : 0.0;
-        if (timed) {
-          const cs_ba_timing t0m = B->tm;
+        {
           rc = collect_solve_times(B); if (rc) return rc;
           float ms = 0;
           BA_TRY(hipEventElapsedTime(&ms, B->ev[6], B->ev[7])); B->tm.errors_ms += ms;
-          // the stage split of this structure's directly launched trials (what a replayed trial is charged if its own marks cannot be read)
-          B->tm_timed_trials++;
-          B->stage_sum[0] += B->tm.reduce_ms - t0m.reduce_ms; B->stage_sum[1] += B->tm.factor_ms - t0m.factor_ms;
-          B->stage_sum[2] += B->tm.backsub_ms - t0m.backsub_ms; B->stage_sum[3] += ms;
-        } else {
-          // a replayed trial: the phase marks are event-record nodes of the graph; where the runtime hands back their times they are read
-          // like the direct launches', otherwise the trial is charged the average split of this structure's direct launches (same
-          // kernels, same sizes) -- the wall time of the run is measured either way
-          float a = 0, b = 0, c = 0, e = 0;
-          const bool got = hipEventElapsedTime(&a, B->ev[2], B->ev[3]) == hipSuccess && hipEventElapsedTime(&b, B->ev[3], B->ev[4]) == hipSuccess &&
-                           hipEventElapsedTime(&c, B->ev[4], B->ev[5]) == hipSuccess && hipEventElapsedTime(&e, B->ev[6], B->ev[7]) == hipSuccess && a >= 0 && b > 0;
-          if (!got) {
-            (void)hipGetLastError();
-            const double n = (double)std::max<long long>(1, B->tm_timed_trials);
-            a = (float)(B->stage_sum[0] / n); b = (float)(B->stage_sum[1] / n); c = (float)(B->stage_sum[2] / n); e = (float)(B->stage_sum[3] / n);
-          }
-          B->tm.reduce_ms += a; B->tm.factor_ms += b; B->tm.backsub_ms += c; B->tm.errors_ms += e;
-          rc = collect_lin_time(B); if (rc) return rc;
         }
         if (ext_active && ok2) { rc = ext_refresh(0); if (rc) return rc; tempChi += B->ext_chi2; }
       } else {

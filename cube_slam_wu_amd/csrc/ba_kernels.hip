@@ -1552,7 +1552,6 @@ struct BandHalf {
   BandView fv, rv;        // the half's index space [0, nh) (C at rows nh ...) and its reverse front's (u = nh - 1 - v)
   int nh, K1, K2, qflip;  // column blocks of the two fronts; qflip: C's rows appear in reverse order below this half
   const double* Linv_f; const double* Linv_r; const double* lc;
-  int win = 0;            // factorised by band_chol_win_kernel: front B (rv) runs on through the middle (blocks [K2, ceil((nh - 32 K1) / 32)) of rv)
 };
 struct BandNested {
   BandHalf h[2];
@@ -1563,7 +1562,6 @@ struct BandNested {
 };
 __device__ __forceinline__ const double* band_half_y(const BandHalf& H, int t) {   // right-hand side entry of elimination column t of team 1
   const int Trev = BS * H.K2;
-  if (H.win) return H.rv.rb + (long long)t * H.rv.sr;
   return t < Trev ? H.rv.rb + (long long)t * H.rv.sr : H.fv.rb + (long long)(BS * H.K1 + t - Trev) * H.fv.sr;
 }
 __global__ __launch_bounds__(256) void band_chol_nested_kernel(BandNested P) {
@@ -1812,23 +1810,6 @@ __global__ __launch_bounds__(256) void band_backsolve_kernel(BandSolve P) {
   const BandHalf H = P.h[blockIdx.x >> 1];
   const int bw = P.bw, nh = H.nh, m_end = nh - BS * H.K2;
   for (int e = tid; e < BAND_WIN; e += 256) xw[e] = 0.0;
-  if (H.win) {
-    // window-resident fronts: B eliminated the middle too (mirrored space, blocks K2 .. KB - 1); both workgroups solve it, then
-    // one walks B's first run back, the other -- the middle's x at its forward indices in the window -- front A
-    const int nvB = nh - BS * H.K1, KB = (nvB + BS - 1) / BS;
-    band_backsolve_run(M, H.rv, H.Linv_r, KB - 1, H.K2, nvB, bw, P.zero);
-    if (blockIdx.x & 1) {
-      band_backsolve_run(M, H.rv, H.Linv_r, H.K2 - 1, 0, nvB, bw, P.zero);
-    } else {
-      __syncthreads();
-      for (int e = tid; e < BAND_WIN; e += 256) xw[e] = 0.0;
-      __syncthreads();
-      for (int v = BS * H.K1 + tid; v < min(nh, BS * H.K1 + bw + BS); v += 256) xw[v & (BAND_WIN - 1)] = H.fv.rb[(long long)v * H.fv.sr];
-      __syncthreads();
-      band_backsolve_run(M, H.fv, H.Linv_f, H.K1 - 1, 0, m_end, bw, P.zero);
-    }
-    return;
-  }
   // the middle block (the half's own view; rows end at m_end)
   band_backsolve_run(M, H.fv, H.Linv_f, (m_end - 1) / BS, H.K1, m_end, bw, P.zero);
   if ((blockIdx.x & 1) == 0) {
@@ -1877,36 +1858,6 @@ __global__ __launch_bounds__(256) void band_sep_correct_kernel(BandNested P) {
   }
 }
 
-#include "band_win.h"
-
-// The window-resident fronts (band_win.h) take bandwidths up to 32 WIN_DMAX.  OPT-IN (CS_BAND_WIN=1): measured on MI355X they
-// only match the cooperative kernels (C4's reduced system: 0.83-0.92 ms against 0.88-0.90 per factor + solve; a step of a front 10.4-12 us
-// against 13.2) -- what the single workgroup saves in hand-offs between compute units it loses to its own SIMDs, where the block
-// waves' FP64 matrix-core instructions and the team's FP64 vector instructions take turns instead of overlapping.
-static bool band_win_ok(int LD) {
-  static const bool on = getenv("CS_BAND_WIN") != nullptr && atoi(getenv("CS_BAND_WIN")) != 0;
-  const int bw = LD - 1;
-  return on && bw >= 1 && (bw + BS - 1) / BS <= WIN_DMAX;
-}
-// CS_BAND_PROF: phase clock of one front (front B of half 0, or the only front)
-static long long* band_win_prof(hipStream_t st) {
-  static const bool want = getenv("CS_BAND_PROF") != nullptr;
-  static long long* buf = nullptr;
-  if (!want) return nullptr;
-  if (!buf) (void)hipMalloc(&buf, 8 * sizeof(long long));
-  (void)hipMemsetAsync(buf, 0, 8 * sizeof(long long), st);
-  return buf;
-}
-static void band_win_prof_show(long long* buf, hipStream_t st) {
-  if (!buf) return;
-  long long h[8];
-  (void)hipMemcpyAsync(h, buf, sizeof(h), hipMemcpyDeviceToHost, st);
-  (void)hipStreamSynchronize(st);
-  static int shown = 0;
-  if (shown++ < 4 && h[4] > 0)
-    fprintf(stderr, "[band win] %lld steps of one front, us per step: panel %.2f  look-ahead %.2f  rounds (POTF2 || trailing) %.2f  post %.2f\n", h[4], h[0] * 0.01 / h[4], h[1] * 0.01 / h[4],
-            h[2] * 0.01 / h[4], h[3] * 0.01 / h[4]);
-}
 int ba_band_team(int LD, int* rw_out) {   // workgroups of the factorisation team and their rows per step
   const int bw = LD - 1;
   int G = (bw + BAND_RW - 1) / BAND_RW;
@@ -1939,11 +1890,11 @@ static size_t band_blocks(int n) { return (size_t)((n + BS - 1) / BS) * BS * BS;
 // Schur complements and dense block)
 size_t ba_band_workspace_doubles(int n, int LD) {
   if (n <= 0) return 1;
-  size_t two = 2 * band_blocks(n) + 4 * ((size_t)WIN_W * WIN_W + WIN_W);   // (+ the dumps of the window-resident fronts)
+  size_t two = 2 * band_blocks(n);
   int wc = 0, c0 = 0;
   if (!ba_band_nested(n, LD, &wc, &c0)) return two;
   const int nh0 = c0, nh1 = n - c0 - wc;
-  size_t nest = 2 * band_blocks(nh0) + 2 * band_blocks(nh1) + band_blocks(wc) + (size_t)(nh0 + nh1) * wc + (size_t)2 * wc * (wc + 1) + (size_t)wc * wc + wc + 4 * ((size_t)WIN_W * WIN_W + WIN_W);
+  size_t nest = 2 * band_blocks(nh0) + 2 * band_blocks(nh1) + band_blocks(wc) + (size_t)(nh0 + nh1) * wc + (size_t)2 * wc * (wc + 1) + (size_t)wc * wc + wc;
   return nest > two ? nest : two;
 }
 
@@ -1957,12 +1908,6 @@ bool ba_band_fits_device(int n, int LD, bool one_sided) {   // one_sided: the or
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
   int rw = 0, K1 = 0, K2 = 0, wc = 0, c0 = 0, occ = 0, grid = 0;
   const int G = ba_band_team(LD, &rw), bw = LD - 1;
-  if (band_win_ok(LD)) {
-    if (ba_band_nested(n, LD, &wc, &c0, one_sided)) grid = 2 * (2 + (wc / BS + 1) / 2 + wc / 16);
-    else grid = 2;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, band_chol_win_kernel, WIN_T, 0) != hipSuccess) return false;
-    return occ >= 1 && grid <= prop.multiProcessorCount;
-  }
   if (ba_band_nested(n, LD, &wc, &c0, one_sided)) {
     const int Gn = (bw + BAND_RW_NESTED - 1) / BAND_RW_NESTED, GC = wc / BAND_RW_NESTED, GS = wc / 16;
     grid = 2 * (Gn + 1 + Gn + GC + 1 + GS);
@@ -2013,29 +1958,6 @@ void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rh
     P.n = n; P.bw = bw; P.wc = wc; P.c0 = c0; P.LD = LD; P.G = (bw + BAND_RW_NESTED - 1) / BAND_RW_NESTED; P.GC = wc / BAND_RW_NESTED; P.GS = wc / 16;
     const int G1 = P.G + P.GC;
     P.Sb = Sb; P.rhs = rhs; P.zero = zero; P.info = info; P.bars = reinterpret_cast<unsigned*>(info + 6);
-    if (band_win_ok(LD)) {
-      WinNested W;
-      for (int h = 0; h < 2; h++) {
-        BandHalf& H = P.h[h];
-        H.win = 1;
-        WinHalf& Q = W.h[h];
-        Q.fv = H.fv; Q.rv = H.rv; Q.nh = H.nh; Q.K1 = H.K1; Q.K2 = H.K2; Q.qflip = H.qflip; Q.Linv_f = H.Linv_f; Q.Linv_r = H.Linv_r; Q.lc = H.lc;
-        Q.dumpA = wp; wp += (size_t)WIN_W * WIN_W; Q.dumpB = wp; wp += (size_t)WIN_W * WIN_W; Q.dumprA = wp; wp += WIN_W; Q.dumprB = wp; wp += WIN_W;
-      }
-      W.n = n; W.bw = bw; W.wc = wc; W.c0 = c0; W.LD = LD; W.D = (bw + BS - 1) / BS; W.NCR = (wc / BS + 1) / 2; W.GS = wc / 16; W.nested = 1;
-      W.Sb = Sb; W.rhs = rhs; W.SC = P.SC; W.rhsC = P.rhsC; W.LinvC = P.LinvC; W.part = P.part; W.zero = zero; W.info = info; W.bars = P.bars;
-      W.prof = band_win_prof(st);
-      hipLaunchKernelGGL(band_chol_win_kernel, dim3(2 * (2 + W.NCR + W.GS)), dim3(WIN_T), 0, st, W);
-      band_win_prof_show(W.prof, st);
-      if (solve) {
-        const int TT = (nh[0] - BS * P.h[0].K1) + (nh[1] - BS * P.h[1].K1);
-        hipLaunchKernelGGL(band_sep_solve_kernel, dim3(1), dim3(256), 0, st, P);
-        hipLaunchKernelGGL(band_sep_correct_kernel, dim3((TT + 31) / 32), dim3(256), 0, st, P);
-        BandSolve Q; Q.h[0] = P.h[0]; Q.h[1] = P.h[1]; Q.bw = bw; Q.zero = zero;
-        hipLaunchKernelGGL(band_backsolve_kernel, dim3(4), dim3(256), 0, st, Q);
-      }
-      return;
-    }
     static const bool want_stamps = getenv("CS_BAND_PROF") != nullptr;
     static long long* stamps = nullptr;
     if (want_stamps && !stamps) (void)hipMalloc(&stamps, 40 * sizeof(long long));
@@ -2076,26 +1998,6 @@ void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rh
   unsigned* bars = reinterpret_cast<unsigned*>(info + 1);
   double* Linv_f = work;
   double* Linv_r = work + band_blocks(n);
-  if (band_win_ok(LD)) {
-    WinNested W;
-    if (K2 == 0) K1 = (n + BS - 1) / BS;      // one front: all column blocks
-    double* wp = work + 2 * band_blocks(n);
-    WinHalf& Q = W.h[0];
-    Q.fv = fwd; Q.rv = rev; Q.nh = n; Q.K1 = K1; Q.K2 = K2; Q.qflip = 0; Q.Linv_f = Linv_f; Q.Linv_r = Linv_r; Q.lc = nullptr;
-    Q.dumpA = wp; wp += (size_t)WIN_W * WIN_W; Q.dumpB = wp; wp += (size_t)WIN_W * WIN_W; Q.dumprA = wp; wp += WIN_W; Q.dumprB = wp; wp += WIN_W;
-    W.h[1] = W.h[0];
-    W.n = n; W.bw = bw; W.wc = 0; W.c0 = 0; W.LD = LD; W.D = (bw + BS - 1) / BS; W.NCR = 0; W.GS = 0; W.nested = 0;
-    W.Sb = Sb; W.rhs = rhs; W.SC = nullptr; W.rhsC = nullptr; W.LinvC = nullptr; W.part = nullptr; W.zero = zero; W.info = info; W.bars = reinterpret_cast<unsigned*>(info + 6);
-    W.prof = band_win_prof(st);
-    hipLaunchKernelGGL(band_chol_win_kernel, dim3(K2 > 0 ? 2 : 1), dim3(WIN_T), 0, st, W);
-    band_win_prof_show(W.prof, st);
-    if (solve) {
-      BandSolve S2;
-      S2.h[0] = BandHalf{fwd, rev, n, K1, K2, 0, Linv_f, Linv_r, nullptr, K2 > 0 ? 1 : 0}; S2.h[1] = S2.h[0]; S2.bw = bw; S2.zero = zero;
-      hipLaunchKernelGGL(band_backsolve_kernel, dim3(K2 > 0 ? 2 : 1), dim3(256), 0, st, S2);
-    }
-    return;
-  }
   static const bool want_prof = getenv("CS_BAND_PROF") != nullptr;   // diagnostics: phase clock of the forward team's first / last workgroup
   static long long* prof = nullptr;
   if (want_prof && !prof) (void)hipMalloc(&prof, 20 * sizeof(long long));

@@ -450,168 +450,6 @@ __device__ __forceinline__ void slot_corners16(const DetectDeviceView& v, long l
 __device__ __forceinline__ int sel(int cfg, int a, int b) { return cfg ? b : a; }
 
 enum { SCORE_JOBS = 4, SCORE_SUB = 128, SCORE_BINS = SCORE_JOBS * SCORE_SUB };   // sort keys of score_kernel: (job within the block, configuration x top sample)
-// (the round-3 form, kept for A / B timing: CS_SCORE_R3=1)
-__global__ __launch_bounds__(256) void score_kernel_r3(DetectDeviceView v, long long slot_total, double short_sq_bound) {
-  // [coordinate: x0..x7, y0..y7][lane]: every lane keeps its proposal's corners in its own column (LDS because the edge tables index
-  // them dynamically); lanes of a wave mostly ask for the same corner (sorted by configuration)
-  __shared__ double C16[16][260];
-  double (*CXt)[260] = C16, (*CYt)[260] = C16 + 8;
-  // the grid is sized for the worst case (every slot valid) because the exact count lives on the device; spread the
-  // ACTIVE blocks over the 8 XCDs (contiguous range per XCD), the surplus blocks exit immediately
-  const long long n_valid = v.job_cbase[v.n_jobs];
-  const long long per_xcd = ((n_valid + 255) / 256 + 7) / 8;
-  const long long kx = blockIdx.x >> 3;
-  if (kx >= per_xcd) return;
-  const long long base = ((long long)(blockIdx.x & 7) * per_xcd + kx) * blockDim.x;
-  if (base >= n_valid) return;
-  // ---- who scores what.  The 256 proposals of this block are consecutive in the reference's order: configuration
-  // fastest, then top-edge sample, then yaw.  Neighbouring lanes would gather from unrelated places of the distance map,
-  // and a wave load that touches 64 different cache lines occupies the L1 tag pipeline for 64 cycles -- that, not the
-  // arithmetic, used to bound this kernel.  Proposals that differ only in yaw (0.5 degrees: corners 1-2 px apart) sample
-  // almost the same pixels, so the block re-sorts its proposals by (job, configuration, top-edge sample) with a counting
-  // sort in LDS and every lane takes the proposal at its sorted position; results go back to the proposal's own index.
-  __shared__ int hist[SCORE_BINS + 1];
-  __shared__ int s_src[256], s_job[256], s_flag[256];
-  __shared__ long long s_slot[256];
-  {
-    const int t0 = threadIdx.x;
-    for (int b = t0; b <= SCORE_BINS; b += 256) hist[b] = 0;
-    __syncthreads();
-    const long long i0 = base + t0;
-    long long slot0 = 0;
-    int j0 = 0;
-    int flag0 = 0;
-    if (i0 < n_valid) { slot0 = v.c_slot[i0]; flag0 = v.c_flag[i0]; j0 = flag0 >> CAND_JOB_SHIFT; }
-    s_slot[t0] = slot0; s_job[t0] = j0; s_flag[t0] = flag0 & CAND_VP_MASK;
-    __syncthreads();
-    int key = SCORE_BINS;                       // beyond the list: sorted last, skipped below
-    if (i0 < n_valid) {
-      const int T0 = v.jobs[j0].T;
-      const unsigned loc = (unsigned)(slot0 - v.jobs[j0].slot_off);
-      const int jrel = j0 - s_job[0];                                                // jobs in this block, in order
-      const int sub = (int)(loc & 1) * T0 + (int)((loc >> 1) % (unsigned)T0);        // configuration-major, then top-edge sample
-      key = (jrel < SCORE_JOBS && sub < SCORE_SUB) ? jrel * SCORE_SUB + sub : SCORE_BINS - 1;
-    }
-    const int rank = atomicAdd(&hist[key], 1);
-    __syncthreads();
-    if (t0 < 64) {                              // exclusive prefix over the bins: 64 lanes x (SCORE_BINS + 1) / 64 bins each
-      constexpr int PER = (SCORE_BINS + 1 + 63) / 64;
-      int loc_sum = 0, vals[PER];
-#pragma unroll
-      for (int q = 0; q < PER; q++) { const int b = t0 * PER + q; vals[q] = b <= SCORE_BINS ? hist[b] : 0; loc_sum += vals[q]; }
-      int incl = loc_sum;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (t0 >= o) incl += y; }
-      int run = incl - loc_sum;
-#pragma unroll
-      for (int q = 0; q < PER; q++) { const int b = t0 * PER + q; if (b <= SCORE_BINS) hist[b] = run; run += vals[q]; }
-    }
-    __syncthreads();
-    s_src[hist[key] + rank] = t0;
-    __syncthreads();
-  }
-  const int mine = s_src[threadIdx.x];
-  const JobDesc jd = v.jobs[s_job[mine]];
-  const long long i = base + mine;
-  if (i >= n_valid) return;                     // (no barrier below this point)
-  const long long slot = s_slot[mine];
-  const unsigned local = (unsigned)(slot - jd.slot_off);
-  const int cfg = (int)(local & 1);          // 0 = configuration 1
-  const int ry = (int)((local >> 1) / (unsigned)jd.T);
-  const int rp = (int)((unsigned)ry / (unsigned)jd.Y);
-  const int tx = threadIdx.x;
-  const double ox = (double)jd.g.el, oy = (double)jd.g.et;
-  const float* __restrict__ map = v.maps + jd.map_off;
-  // the proposal's corners, rebuilt (candidate_kernel kept only the decision): into this lane's own LDS column, no barrier needed
-  {
-    V2 cb[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) cb[q] = v2(0.0, 0.0);
-    slot_corners(v, jd, slot, short_sq_bound, cb);
-#pragma unroll
-    for (int q = 0; q < 8; q++) { CXt[q][tx] = cb[q].x; CYt[q][tx] = cb[q].y; }
-  }
-  // (the six VP-support angles of the angle term are requested here, ahead of the gathers: one round trip less on the block's path)
-  double bnd[6];
-  {
-    const double* bound = v.bound + 6 * (long long)(jd.vp_off + ry);
-#pragma unroll
-    for (int q = 0; q < 6; q++) bnd[q] = bound[q];
-  }
-  // ---- distance error: all gathers of an edge are issued before its (sequential, float) accumulation
-  float sum_dist = 0;
-  // corner ids of the 9 edges, one nibble each (edge 0 lowest): {0,1,2,3,1,2,3,4,4}-{1,2,3,0,5,4,7,7,5} / {0,1,2,3,1,2,4,0,0}-{1,2,3,0,5,4,5,0,0}
-  const unsigned long long EA = cfg ? 0x004213210ull : 0x443213210ull, EB = cfg ? 0x005450321ull : 0x577450321ull;
-  // config 2 reweights edges 4, 5 by 3/2 and edge 6 by 2 (:655-661), one weight nibble per edge in halves.  The reference
-  // computes float(double(d) * 3.0 / 2.0) and float(double(d) * 2.0): both products are exact in double, so the one rounding
-  // to float is the rounding of the float product d * 1.5f (d * 2.0f), and d * 1.0f is d.
-  const unsigned long long EW = cfg ? 0x004332222ull : 0x222222222ull;
-  const int n_edges = cfg ? 7 : 9;
-  const int map_w = jd.map_w;
-  constexpr int EU = 3;   // edges per trip: their 11 * EU gathers are in flight together
-#pragma unroll 1
-  for (int e0 = 0; e0 < n_edges; e0 += EU) {
-    float dv[EU][11];
-#pragma unroll
-    for (int u = 0; u < EU; u++) {
-      const int e = e0 + u;                    // (beyond the list: nibble 0 = corner 1, a valid address; the sum skips it)
-      const int a = (int)((EA >> (4 * e)) & 7), b = (int)((EB >> (4 * e)) & 7);
-      const double x1 = CXt[a][tx] - ox, y1 = CYt[a][tx] - oy, x2 = CXt[b][tx] - ox, y2 = CYt[b][tx] - oy;
-#pragma unroll
-      for (int s = 0; s < 11; s++) {
-        double w = (double)s / 10.0;
-        double sx = w * x1 + (1 - w) * x2;
-        double sy = w * y1 + (1 - w) * y2;
-        // samples lie inside the ROI the map covers (corners were tested against it): row * width + column fits 24 x 24 -> 32 bits
-        dv[u][s] = map[(unsigned)(__mul24((int)sy, map_w) + (int)sx)];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < EU; u++) {
-      const int e = e0 + u;
-      const float wt = 0.5f * (float)(int)((EW >> (4 * e)) & 7);
-      const bool on = e < n_edges;
-#pragma unroll
-      for (int s = 0; s < 11; s++) { const float nx = sum_dist + dv[u][s] * wt; sum_dist = on ? nx : sum_dist; }
-    }
-  }
-  // ---- angle alignment error
-  double total = 0;
-  const double not_found_penalty = 30.0 / 180.0 * CS_PI * 2;
-  const int ID1[3][4] = {{0, 1, 7, 4}, {3, 0, 4, 5}, {3, 7, 1, 5}}, ID2[3][4] = {{0, 1, 2, 3}, {3, 0, 4, 5}, {2, 4, 1, 5}};
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    double b0 = bnd[2 * k], b1 = bnd[2 * k + 1];
-    bool v0 = !(b0 != b0), v1 = !(b1 != b1);
-    if (v0 || v1) {
-#pragma unroll
-      for (int ee = 0; ee < 2; ee++) {
-        int pa = sel(cfg, ID1[k][2 * ee], ID2[k][2 * ee]), pb = sel(cfg, ID1[k][2 * ee + 1], ID2[k][2 * ee + 1]);
-        double ang = normalize_to_pi(cs_atan2(CYt[pb][tx] - CYt[pa][tx], CXt[pb][tx] - CXt[pa][tx]));
-        double best = 100;
-        if (v0) { double t = dabs(ang - b0); t = dmin(t, CS_PI - t); if (t < best) best = t; }
-        if (v1) { double t = dabs(ang - b1); t = dmin(t, CS_PI - t); if (t < best) best = t; }
-        total = total + best;
-      }
-    } else {
-      total = total + not_found_penalty;
-    }
-  }
-  // ---- half sizes of the lifted cuboid -> skew ratio, negative-scale flag
-  V2 c[8];
-#pragma unroll
-  for (int q = 0; q < 8; q++) c[q] = v2(CXt[q][tx], CYt[q][tx]);
-  const RpPose* pose = v.rp + jd.rp_off + rp;
-  double p3[3], s3[3];
-  lift_to_3d(c, pose->R, pose->t, v.invK + 9 * jd.frame, pose->plane, p3, s3);
-  int flag = s_flag[mine];
-  if (s3[0] < 0 || s3[1] < 0 || s3[2] < 0) flag |= CAND_NEG_SCALE;
-  v.c_flag[i] = flag;
-  v.c_dist[i] = (double)sum_dist / jd.diag;
-  v.c_angle[i] = total;
-  v.c_skew[i] = dmax(s3[0], s3[1]) / dmin(s3[0], s3[1]);
-}
-
 __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long long slot_total, double short_sq_bound) {
   // [coordinate: x0..x7, y0..y7][lane]: every lane keeps its proposal's corners in its own column (LDS because the edge tables index
   // them dynamically); lanes of a wave mostly ask for the same corner (sorted by configuration)
@@ -1552,9 +1390,7 @@ void launch_scan_compact_trips(const DetectDeviceView& v, int* cnt, int max_trip
 void launch_score(const DetectDeviceView& v, const SweepParams& sp, long long n_valid_bound, long long slot_total, hipStream_t st) {
   if (skip_kernel("score")) return;
   if (n_valid_bound <= 0) return;
-  static const bool r3_form = getenv("CS_SCORE_R3") != nullptr;      // diagnostics: the round-3 kernel, for A / B timing
-  if (r3_form) hipLaunchKernelGGL(score_kernel_r3, dim3(grid8(n_valid_bound, 256)), dim3(256), 0, st, v, slot_total, sp.short_sq_bound);
-  else hipLaunchKernelGGL(score_kernel, dim3(grid8(n_valid_bound, 256)), dim3(256), 0, st, v, slot_total, sp.short_sq_bound);
+  hipLaunchKernelGGL(score_kernel, dim3(grid8(n_valid_bound, 256)), dim3(256), 0, st, v, slot_total, sp.short_sq_bound);
 }
 // copy [src_off, src_off + count) ranges of the compacted columns into packed buffers (fallback boxes)
 __global__ __launch_bounds__(256) void gather_ranges_kernel(DetectDeviceView v, const long long* src_off, const int* count, const long long* dst_off, int n_ranges,

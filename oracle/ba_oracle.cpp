@@ -287,6 +287,10 @@ struct Problem {
   // bench.py's cpu_baseline at C4 only: > 1 = time every ldlt_stride-th column of the dense LDL^T and scale up (the
   // factorisation of a 10 494 x 10 494 system is ~5e11 flop, minutes on one core); the increment is then NOT computed
   int ldlt_stride = 1;
+  // tests / bench at C4 only: the dense solve of the reduced system handed to the caller (LAPACK through scipy, oracle/ba_parity.py) -- the
+  // textbook LDL^T below streams the 881 MB matrix once per column at 10 494 unknowns (24 minutes); everything else of an LM iteration
+  // stays this file's.  0 = solved, anything else = not positive definite (the trial is then rejected like a failed LDL^T).
+  int (*dense_solver)(double* S, int n, const double* b, double* x) = nullptr;
 };
 inline double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -777,14 +781,21 @@ void back_substitute(Problem& P, const std::vector<double>& Dinv, std::vector<do
 bool solve_system(Problem& P) {  // block_solver.hpp:353-486
   int n = P.size_pose;
   P.x.assign(n + P.size_lm, 0.0);
-  if (P.n_lm == 0) { const double t0 = wall_ms(); bool ok = ldlt_solve(P.Hpp, n, P.b.data(), P.x.data()); P.stage_ms[3] += wall_ms() - t0; return ok; }
+  if (P.n_lm == 0) {
+    const double t0 = wall_ms();
+    bool ok;
+    if (P.dense_solver) { std::vector<double> H = P.Hpp; ok = P.dense_solver(H.data(), n, P.b.data(), P.x.data()) == 0; }
+    else ok = ldlt_solve(P.Hpp, n, P.b.data(), P.x.data());
+    P.stage_ms[3] += wall_ms() - t0;
+    return ok;
+  }
   double t_stage = wall_ms();
   std::vector<double> S, bschur, Dinv;
   schur_complement(P, S, bschur, Dinv);
   P.stage_ms[2] += wall_ms() - t_stage;
   t_stage = wall_ms();
   if (P.ldlt_stride > 1) { P.stage_ms[3] += ldlt_sampled_ms(S, n, P.ldlt_stride); return true; }   // timing run: no increment
-  if (!ldlt_solve(std::move(S), n, bschur.data(), P.x.data())) { P.stage_ms[3] += wall_ms() - t_stage; return false; }
+  if (P.dense_solver ? P.dense_solver(S.data(), n, bschur.data(), P.x.data()) != 0 : !ldlt_solve(std::move(S), n, bschur.data(), P.x.data())) { P.stage_ms[3] += wall_ms() - t_stage; return false; }
   back_substitute(P, Dinv, P.x);   // landmarks: xl = Dinv (bl - Hpl^T xp)
   P.stage_ms[3] += wall_ms() - t_stage;
   return true;
@@ -972,6 +983,8 @@ void ba_oracle_stage_ms(void* h, double out5[5], int reset) {
 }
 // bench.py's cpu_baseline at C4: time every stride-th column of the dense LDL^T (Problem::ldlt_stride); 1 = the real solve
 void ba_oracle_set_ldlt_stride(void* h, int stride) { ((Problem*)h)->ldlt_stride = stride < 1 ? 1 : stride; }
+// The reduced system's dense solve through a caller's routine (see Problem::dense_solver); nullptr restores the LDL^T of this file.
+void ba_oracle_set_dense_solver(void* h, int (*fn)(double*, int, const double*, double*)) { ((Problem*)h)->dense_solver = fn; }
 // stage-level access for parity tests
 double ba_oracle_compute_errors(void* h) { Problem& P = *(Problem*)h; compute_errors(P); return robust_chi2(P); }
 void ba_oracle_get_errors_cproj(void* h, double* cproj4) { Problem& P = *(Problem*)h; if (cproj4) std::memcpy(cproj4, P.err_cproj.data(), 8 * P.err_cproj.size()); }

@@ -110,6 +110,39 @@ class Problem:
         """Timing runs only: sample every stride-th column of the dense LDL^T (no increment is computed)."""
         lib().ba_oracle_set_ldlt_stride(self.h, int(stride))
 
+    def use_lapack_solver(self, one_thread=False):
+        """The reduced system's dense solve through LAPACK (scipy cho_factor / cho_solve on the matrix ba_oracle.cpp assembled) instead of
+        the file's textbook LDL^T -- for sizes where that one is out of reach (C4: 10 494 unknowns, 24 minutes per solve).  Linearisation,
+        Schur complement, back-substitution, update and the LM control stay the C++ restatement's.  Returns the list the solve times (s)
+        are appended to."""
+        import time
+        import scipy.linalg
+        times = []
+
+        def solve(S_ptr, n, b_ptr, x_ptr):
+            S = np.ctypeslib.as_array(S_ptr, shape=(n, n))
+            b = np.ctypeslib.as_array(b_ptr, shape=(n,))
+            x = np.ctypeslib.as_array(x_ptr, shape=(n,))
+            t0 = time.perf_counter()
+            try:
+                if one_thread:
+                    from threadpoolctl import threadpool_limits
+                    with threadpool_limits(limits=1):
+                        c, low = scipy.linalg.cho_factor(S.T, lower=False, overwrite_a=True, check_finite=False)
+                        x[:] = scipy.linalg.cho_solve((c, low), b, check_finite=False)
+                else:
+                    c, low = scipy.linalg.cho_factor(S.T, lower=False, overwrite_a=True, check_finite=False)   # (S is symmetric and stored in full: its transpose view is Fortran-ordered)
+                    x[:] = scipy.linalg.cho_solve((c, low), b, check_finite=False)
+            except np.linalg.LinAlgError:
+                return 1
+            finally:
+                times.append(time.perf_counter() - t0)
+            return 0 if np.isfinite(x).all() else 1
+
+        self._dense_cb = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double))(solve)
+        lib().ba_oracle_set_dense_solver(self.h, self._dense_cb)
+        return times
+
     def history(self, cap=64):
         chi, lam, tr = np.zeros(cap), np.zeros(cap), np.zeros(cap, np.int32)
         n = lib().ba_oracle_history(self.h, _dp(chi), _dp(lam), _ip(tr), cap)

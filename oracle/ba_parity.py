@@ -119,3 +119,33 @@ def compare_linearisation(G, R, pr, lam, with_solve=True, one_thread=False):
         out["x_landmarks"] = _rel(x_g[n_pose:], x_r[n_pose:])
     return out
 
+
+
+def compare_trajectory(G, R, iters=3):
+    """iters LM iterations of the device (G.optimize) beside the same of the oracle (R.optimize; for C4 with R.use_lapack_solver(): the
+    10 494-unknown dense solve through LAPACK, everything else of the iteration ba_oracle.cpp's -- optimization_algorithm_levenberg.cpp:61-189
+    restated at ba_oracle.cpp lm_solve).  north_star's bar: the same accept / reject sequence, states within 1e-5 relative after the same
+    iteration count.  Returns the trial sequences, max relative differences of the chi2 / lambda histories and of the final states
+    (positions relative to the scene's extent, quaternions and cuboid half sizes absolute)."""
+    import time
+    t0 = time.perf_counter()
+    n_g = G.optimize(iters)
+    t1 = time.perf_counter()
+    n_r = R.optimize(iters)
+    t2 = time.perf_counter()
+    chi_g, lam_g, tr_g = G.history()
+    chi_r, lam_r, tr_r = R.history()
+    cg, og, pg = G.state()
+    cr, orr, prr = R.state()
+    scale = float(np.abs(prr).max()) if prr.size else 1.0
+    out = {"iterations_device": int(n_g), "iterations_oracle": int(n_r), "trials_device": [int(t) for t in tr_g], "trials_oracle": [int(t) for t in tr_r],
+           "same_trial_sequence": bool(np.array_equal(tr_g, tr_r)),
+           "chi2": float(np.abs(chi_g - chi_r).max() / np.abs(chi_r).max()) if len(chi_g) == len(chi_r) and len(chi_r) else float("nan"),
+           "lambda": float(np.abs(lam_g / lam_r - 1).max()) if len(lam_g) == len(lam_r) and len(lam_r) else float("nan"),
+           "chi2_first_last": [float(chi_r[0]), float(chi_r[-1])] if len(chi_r) else [],
+           "points": float(np.abs(pg - prr).max() / scale) if prr.size else 0.0,
+           "camera_positions": float(np.abs(cg[:, :3] - cr[:, :3]).max() / scale), "camera_quaternions": float(np.abs(cg[:, 3:] - cr[:, 3:]).max()),
+           "cuboid_positions": float(np.abs(og[:, :3] - orr[:, :3]).max() / scale) if orr.size else 0.0,
+           "cuboid_quaternions_and_sizes": float(np.abs(og[:, 3:] - orr[:, 3:]).max()) if orr.size else 0.0,
+           "device_seconds": t1 - t0, "oracle_seconds": t2 - t1}
+    return out

@@ -222,3 +222,27 @@ def test_robust_kernels_known_answers():
 
 def test_oracle_against_the_independent_projection_schur_fixture():
     check_against_independent_fixture(_oracle_from_fixture, 1e-11, 1e-8)
+
+
+def test_lapack_hook_of_the_dense_solve_equals_the_restatements_own_ldlt():
+    """Problem.use_lapack_solver (ba_oracle_set_dense_solver): the reduced system's dense solve handed to LAPACK, what the C4-sized
+    trajectory comparison of tests/test_ba_gpu.py relies on.  On a problem the restatement's textbook LDL^T can solve itself, both give
+    the same LM run: trial sequence, chi2 / lambda histories to 1e-9, states to 1e-6."""
+    from cube_slam_wu_amd import synth_ba
+    pr = synth_ba.make_problem(n_cams=40, n_points=2000, n_cuboids=6, seed=5)
+
+    def mk():
+        R = O.Problem(pr["cams"], pr["cam_fixed"], pr["cuboids"], pr["cub_fixed"], pr["points"], pr["pt_fixed"])
+        R.set_edges_proj(pr["e_pt"], pr["e_cam"], pr["e_uv"], pr["e_info"], pr["e_intr"], pr["e_huber"])
+        R.set_edges_cuboid(pr["ce_cam"], pr["ce_cub"], pr["ce_meas"], pr["ce_info"])
+        R.set_edges_odom(pr["oe_i"], pr["oe_j"], pr["oe_meas"], pr["oe_info"])
+        return R
+    A, B = mk(), mk()
+    times = B.use_lapack_solver()
+    assert A.optimize(5) == B.optimize(5) == 5
+    (ca, la, ta), (cb, lb, tb) = A.history(), B.history()
+    assert np.array_equal(ta, tb) and len(times) == int(tb.sum())
+    assert np.allclose(ca, cb, rtol=1e-9) and np.allclose(la, lb, rtol=1e-9)
+    for a, b in zip(A.state(), B.state()):
+        assert np.abs(a - b).max() < 1e-6
+    A.close(); B.close()

@@ -1,5 +1,5 @@
 """LM iterations/s of the C4 (or C3) bundle adjustment alone, with the stage split -- a quick A / B harness for the BA path:
-   python tools/ba_quick.py [C4|C3] [iterations] [views per point]      (environment switches such as CS_BA_GRAPH=0 apply)"""
+   python tools/ba_quick.py [C4|C3] [iterations] [views per point]      (environment switches such as CS_BAND_BCR=0 apply)"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
