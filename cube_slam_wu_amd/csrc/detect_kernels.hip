@@ -1060,11 +1060,20 @@ __global__ __launch_bounds__(NT) void rank_kernel(DetectDeviceView v, RankView r
 // merge_break_lines is sequential -- merge the lexicographically first pair (a, b), a < b, that passes three tests
 // (angle difference, end-point gap, angle of the merged segment), overwrite row a, move the last row into b,
 // restart -- and its result depends on that order, so the order is reproduced exactly.  Rescanning all pairs every
-// round (what the reference does) costs O(m^2) per merge; instead the wave keeps F[a] = the first partner b > a of
-// every row, picks the smallest a with a partner (a wave-wide minimum), applies the merge, and repairs F: only
-// pairs that involve the two rewritten rows can change, so every other row re-tests exactly two pairs, and the
-// rewritten rows (plus the rare row whose first partner was rewritten) are re-scanned cooperatively, 64 partners
-// per step.  Same merges in the same order as the reference, O(m) work per merge.
+// round (what the reference does) costs O(m^2) pair tests per merge.  Round 5: the wave keeps the whole PAIR-TEST MATRIX as
+// bits -- PM[a] = the set of partners b > a of row a -- built once (every lane owns the rows lane, lane + 64, ... and tests them
+// against row b, broadcast from LDS, for b = 1 .. m-1; the two cheap tests first, the third only for their few survivors), and a
+// round is: the first row with a partner (one ballot per 64 rows), its first partner (a find-first-set), the merge, and a repair
+// of the matrix -- only pairs that involve the two rewritten rows can change: every row tests itself against the merged row (the
+// merged row's own partner set is those tests' ballot), the row that moved into b inherits the bits of the old last row from the
+// rows before it and tests the rows behind it.  No lane ever scans for a first partner again.  (Rounds 1-4 kept F[a] = the first
+// partner only: every lane walked its row's partners until the first hit -- the wave as long as its unluckiest lane -- and a
+// rewritten first partner meant a cooperative re-scan: 23 k wave instructions per job, now ~10 k.)
+//
+// Angles.  Only DECISIONS need a row's angle during the merges, so rows carry it as a float (atan2_float, 2.5e-6 rad) and the
+// two angle tests are taken on floats with the exact evaluation (cs_atan2 of the row's end points -- the value the reference
+// holds, whether the row is an input segment or a merge product) inside a margin; the exact angles of the rows that survive are
+// computed once at the end, in parallel, where they leave the kernel.
 enum { LS_CAP = 512, LS_THREADS = 64 };
 
 struct LineSetupParams {
@@ -1073,55 +1082,81 @@ struct LineSetupParams {
   double len_sq_bound;                         // sqrt(x) > len_thre  <=> x > len_sq_bound    (sqrt_le_bound)
 };
 
-struct LsRow { double ang, x1, y1, x2, y2; };
+struct LsRow { float af; double x1, y1, x2, y2; };   // af: the float angle, NaN = unusable (zero-length / non-finite): decided exactly
 
-// third test of a pair, exactly as the reference evaluates it (rare: only inside the float test's margin)
-__device__ __attribute__((noinline)) bool ls_rare_angle_close(double ang, double dy, double dx, double thre) {
-  const double ma = cs_atan2(dy, dx);
-  const double t = dabs(ang - ma);
+__device__ __forceinline__ float ls_angf(double x1, double y1, double x2, double y2) {
+  bool usable;
+  const float a = atan2_float((float)(y2 - y1), (float)(x2 - x1), &usable);
+  return usable ? a : __builtin_nanf("");
+}
+// first test of a pair, exactly as the reference evaluates it (rare: only inside the float test's margin)
+__device__ __attribute__((noinline)) bool ls_rare_angle_diff(double ax1, double ay1, double ax2, double ay2, double bx1, double by1, double bx2, double by2, double thre) {
+  const double diff = dabs(cs_atan2(ay2 - ay1, ax2 - ax1) - cs_atan2(by2 - by1, bx2 - bx1));
+  return dmin(diff, CS_PI - diff) < thre;
+}
+// third test of a pair, exactly as the reference evaluates it (rare)
+__device__ __attribute__((noinline)) bool ls_rare_angle_close(double ax1, double ay1, double ax2, double ay2, double dy, double dx, double thre) {
+  const double t = dabs(cs_atan2(ay2 - ay1, ax2 - ax1) - cs_atan2(dy, dx));
   return dmin(t, CS_PI - t) < thre;
 }
-
-// the three tests of object_3d_util.cpp:464-497 for the ordered pair (a, b).  Only the decision leaves this function: the
-// end-point gaps are compared squared, and the angle of the would-be merged segment is taken in float (2.5e-6 rad) with
-// the exact evaluation inside a 1e-5 margin of the threshold.
-__device__ __forceinline__ bool ls_pair_pass(const LsRow& A, const LsRow& B, const LineSetupParams& lp) {
-  double diff = dabs(A.ang - B.ang);
-  if (dmin(diff, CS_PI - diff) >= lp.angle_thre_rad) return false;
-  double d_ab = v2_dist2(v2(A.x2, A.y2), v2(B.x1, B.y1));
-  double d_ba = v2_dist2(v2(B.x2, B.y2), v2(A.x1, A.y1));
-  if (!((d_ab < lp.dist_sq_bound) || (d_ba < lp.dist_sq_bound))) return false;
-  bool sa = A.x1 < B.x1, ea = A.x2 > B.x2;
-  double sx = sa ? A.x1 : B.x1, sy = sa ? A.y1 : B.y1, ex = ea ? A.x2 : B.x2, ey = ea ? A.y2 : B.y2;
+// The three tests of object_3d_util.cpp:464-497 for the ordered pair (A = the row with the lower index, B).  Only decisions leave
+// these functions: float angles (each within 2.5e-6 rad of the row's exact angle, so a float difference is within 5.4e-6 of the exact
+// one: margin 1.5e-5, the exact evaluation inside it), end-point gaps compared squared (sqrt_lt_bound).  Tests 1 + 2 are symmetric
+// in A and B; test 3 is not (it compares the merged segment's angle with A's and breaks end-point ties towards B).
+#define LS_MARGIN 1.5e-5f
+__device__ __forceinline__ bool ls_t12(const LsRow& A, const LsRow& B, const LineSetupParams& lp, float thf) {
+  float df = fabsf(A.af - B.af);
+  df = fminf(df, 3.14159274f - df);
+  bool p1 = df < thf - LS_MARGIN;
+  if (!p1 && !(df > thf + LS_MARGIN)) p1 = ls_rare_angle_diff(A.x1, A.y1, A.x2, A.y2, B.x1, B.y1, B.x2, B.y2, lp.angle_thre_rad);   // (a NaN lands here)
+  if (!p1) return false;
+  const double d_ab = v2_dist2(v2(A.x2, A.y2), v2(B.x1, B.y1));
+  const double d_ba = v2_dist2(v2(B.x2, B.y2), v2(A.x1, A.y1));
+  return (d_ab < lp.dist_sq_bound) || (d_ba < lp.dist_sq_bound);
+}
+// test 3 of the pair {P, Q}; p_is_a: P is the row with the lower index (A).  The merged segment starts at A's start if A.x1 < B.x1,
+// else at B's (a tie goes to B), ends at A's end if A.x2 > B.x2, else at B's, and its angle is compared with A's (rows hold finite
+// coordinates: a NaN end point is never inside the ROI).
+__device__ __forceinline__ bool ls_t3(const LsRow& P, const LsRow& Q, bool p_is_a, const LineSetupParams& lp, float thf) {
+  const bool sp = p_is_a ? (P.x1 < Q.x1) : !(Q.x1 < P.x1), ep = p_is_a ? (P.x2 > Q.x2) : !(Q.x2 > P.x2);
+  const double sx = sp ? P.x1 : Q.x1, sy = sp ? P.y1 : Q.y1, ex = ep ? P.x2 : Q.x2, ey = ep ? P.y2 : Q.y2;
   const double dy = ey - sy, dx = ex - sx;
   bool usable;
   const float at = atan2_float((float)dy, (float)dx, &usable);
-  const float tf = fabsf((float)A.ang - at);
-  const float mf = fminf(tf, 3.14159274f - tf), th = (float)lp.angle_thre_rad;
-  if (usable && mf < th - 1.0e-5f) return true;
-  if (usable && mf > th + 1.0e-5f) return false;
-  return ls_rare_angle_close(A.ang, dy, dx, lp.angle_thre_rad);
+  const float tf = fabsf((p_is_a ? P.af : Q.af) - at);
+  const float mf = fminf(tf, 3.14159274f - tf);
+  if (usable && mf < thf - LS_MARGIN) return true;
+  if (usable && mf > thf + LS_MARGIN) return false;
+  return p_is_a ? ls_rare_angle_close(P.x1, P.y1, P.x2, P.y2, dy, dx, lp.angle_thre_rad) : ls_rare_angle_close(Q.x1, Q.y1, Q.x2, Q.y2, dy, dx, lp.angle_thre_rad);
 }
 
-// Two instances share the jobs: the wave is latency bound (dependent LDS reads, one lane's atan2 per merge), so what matters is
-// how many jobs a CU holds at once, and that is set by the row tables in LDS.  A typical ROI holds a few dozen segments:
-// CAP = LS_SMALL rows (5.6 KB) lets a CU hold every wave slot's worth of jobs; the few crowded ROIs go to the CAP = LS_CAP
-// instance.  Each instance counts the ROI's segments first and leaves the jobs of the other size class alone.
-enum { LS_SMALL = 128 };
-template <int CAP>
-__global__ __launch_bounds__(LS_THREADS) void line_setup_kernel(JobDesc* jobs, int n_jobs, const double* __restrict__ frame_lines, const int* __restrict__ frame_line_ptr,
-                                                               double* mid_x, double* mid_y, double* line_angle, LineSetupParams lp, const int* __restrict__ order) {
-  __shared__ double X1[CAP], Y1[CAP], X2[CAP], Y2[CAP], ANG[CAP];
-  __shared__ int F[CAP];
+// Two instances share the jobs.  A typical ROI holds a few dozen segments: CAP = LS_SMALL rows, one wavefront, 6.6 KB of LDS -- the
+// kernel is bound by instruction issue, and a CU holds every wave slot's worth of such jobs.  The few crowded ROIs (6 % at C2) go to the
+// CAP = LS_CAP instance: what counts there is the latency of the longest job (the batch's chain waits for it), so a job gets four
+// wavefronts, rows tid and tid + 256 per thread -- each wavefront's ballot is one 64-bit word of a partner set.  Each instance counts
+// the ROI's segments first and leaves the jobs of the other size class alone.
+enum { LS_SMALL = 128, LS_CROWDED_THREADS = 64 };
+template <int CAP, int NT>
+__global__ __launch_bounds__(NT) void line_setup_kernel(JobDesc* jobs, int n_jobs, const double* __restrict__ frame_lines, const int* __restrict__ frame_line_ptr,
+                                                       double* mid_x, double* mid_y, double* line_angle, LineSetupParams lp, const int* __restrict__ order) {
+  constexpr int SL = CAP / NT;                  // rows per thread: tid + NT s
+  constexpr int W = CAP / 64;                   // 64-bit words per partner set; row a's own bit sits in word a >> 6 = wave + NW s
+  constexpr int NW = NT / 64;
+  __shared__ double X1[CAP], Y1[CAP], X2[CAP], Y2[CAP];
+  __shared__ float AF[CAP];
+  __shared__ unsigned long long PM[CAP * W];    // PM[r * W + w]: the partners b in [64 w, 64 w + 64) of row r (bits b > r only)
+  __shared__ int CAND[NW > 1 ? NW : 1];
+  __shared__ int TOT;
   int j = order ? order[blockIdx.x] : blockIdx.x;   // longest jobs first (the kernel ends with its slowest workgroup)
   if (j >= n_jobs) return;
   const JobDesc jd = jobs[j];
   if (jd.Y == 0 || jd.T == 0) return;   // a box the sweep skips (no yaw / top-edge samples): m stays 0
   const double* FL = frame_lines + 4 * (size_t)frame_line_ptr[jd.frame];
   const int M = frame_line_ptr[jd.frame + 1] - frame_line_ptr[jd.frame];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float thf = (float)lp.angle_thre_rad;
   const int NONE = 0x7fffffff;
-  {  // size class of this job: segments with both end points inside the expanded ROI
+  {  // size class of this job: segments with both end points inside the expanded ROI (every wavefront counts for itself)
     int n_in = 0;
     for (int base = 0; base < M; base += 64) {
       const int i = base + lane;
@@ -1131,21 +1166,212 @@ __global__ __launch_bounds__(LS_THREADS) void line_setup_kernel(JobDesc* jobs, i
     }
     if ((n_in <= LS_SMALL) != (CAP == LS_SMALL)) return;
   }
-  auto row = [&](int i) { return LsRow{ANG[i], X1[i], Y1[i], X2[i], Y2[i]}; };
-  // cooperative scan of row r: F[r] = first k > r with pair_pass(r, k)
-  auto rescan = [&](int r, int total) {
-    LsRow R = row(r);
-    int f = NONE;
-    for (int k0 = r + 1; k0 < total; k0 += 64) {
-      int k = k0 + lane;
-      bool ok = (k < total) && ls_pair_pass(R, row(k), lp);
-      unsigned long long bal = __ballot(ok);
-      if (bal) { f = k0 + __ffsll((long long)bal) - 1; break; }
-    }
-    if (lane == 0) F[r] = f;
-  };
+  auto row = [&](int i) { return LsRow{AF[i], X1[i], Y1[i], X2[i], Y2[i]}; };
 
-  // ---- 1. segments with both end points inside the expanded ROI, in input order
+  // ---- 1. segments with both end points inside the expanded ROI, in input order (the first wavefront)
+  if (wave == 0) {
+    int total = 0;
+    for (int base = 0; base < M; base += 64) {
+      int i = base + lane;
+      double x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+      bool in = false;
+      if (i < M) {
+        x1 = FL[4 * i]; y1 = FL[4 * i + 1]; x2 = FL[4 * i + 2]; y2 = FL[4 * i + 3];
+        in = inside_box(v2(x1, y1), jd.g.el, jd.g.et, jd.g.er, jd.g.eb) && inside_box(v2(x2, y2), jd.g.el, jd.g.et, jd.g.er, jd.g.eb);
+      }
+      unsigned long long bal = __ballot(in);
+      int off = total + __popcll(bal & ((1ull << lane) - 1ull));
+      if (in && off < CAP) { X1[off] = x1; Y1[off] = y1; X2[off] = x2; Y2[off] = y2; AF[off] = ls_angf(x1, y1, x2, y2); }
+      total = min(CAP, total + __popcll(bal));
+    }
+    if (lane == 0) TOT = total;
+  }
+  for (int e = tid; e < CAP * W; e += NT) PM[e] = 0ull;
+  __syncthreads();
+  int total = TOT;
+  // ---- 2. the pair-test matrix.  Own rows in registers; tests 1 + 2 against every later row b (broadcast), then test 3 for the survivors
+  LsRow own[SL];
+  int cnt[SL];
+#pragma unroll
+  for (int s = 0; s < SL; s++) {
+    const int a = tid + NT * s;
+    own[s] = (a < total) ? row(a) : LsRow{0.f, 0., 0., 0., 0.};
+    cnt[s] = 0;
+  }
+  for (int b = 1; b < total; b++) {
+    const LsRow Rb = row(b);
+#pragma unroll
+    for (int s = 0; s < SL; s++) {
+      if (NT * s >= b) break;
+      const int a = tid + NT * s;
+      if (a < b && ls_t12(own[s], Rb, lp, thf)) PM[a * W + (b >> 6)] |= 1ull << (b & 63);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < SL; s++) {
+    if (NT * s >= total) break;
+    const int a = tid + NT * s;
+    if (a < total) {
+      for (int w = a >> 6; 64 * w < total; w++) {
+        unsigned long long v = PM[a * W + w], keep = v;
+        while (v) {
+          const int b = 64 * w + __ffsll((long long)v) - 1;
+          v &= v - 1;
+          if (!ls_t3(own[s], row(b), true, lp, thf)) keep &= ~(1ull << (b & 63));
+        }
+        PM[a * W + w] = keep;
+        cnt[s] += __popcll(keep);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 3. merge rounds
+  for (int rounds = 0; rounds < CAP; rounds++) {
+    // the first row with a partner
+    int as = NONE;
+#pragma unroll
+    for (int s = 0; s < SL; s++) {
+      if (NT * s >= total) break;
+      const unsigned long long bal = __ballot(cnt[s] > 0 && tid + NT * s < total);
+      if (bal && as == NONE) as = 64 * (wave + NW * s) + __ffsll((long long)bal) - 1;
+    }
+    if (NW > 1) {
+      if (lane == 0) CAND[wave] = as;
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < NW; q++) as = min(as, CAND[q]);
+    }
+    if (as == NONE) break;
+    int bs = -1;
+    for (int w = as >> 6; 64 * w < total; w++) {
+      const unsigned long long v = PM[as * W + w];
+      if (v) { bs = 64 * w + __ffsll((long long)v) - 1; break; }
+    }
+    const int last = total - 1;
+    const LsRow Ra = row(as), Rb = row(bs), RL = row(last);
+    LsRow Mg;                                   // the merged row (:499-523): the wider start / end of the two
+    {
+      const bool sa = Ra.x1 < Rb.x1, ea = Ra.x2 > Rb.x2;
+      Mg.x1 = sa ? Ra.x1 : Rb.x1; Mg.y1 = sa ? Ra.y1 : Rb.y1; Mg.x2 = ea ? Ra.x2 : Rb.x2; Mg.y2 = ea ? Ra.y2 : Rb.y2;
+      Mg.af = ls_angf(Mg.x1, Mg.y1, Mg.x2, Mg.y2);
+    }
+    const bool moved = (bs != last);            // row bs takes what used to be the last row (fast_RemoveRow, matrix_utils.cpp:183)
+    __syncthreads();                            // (everybody holds the three rows: they may be rewritten)
+    if (tid == 0) {
+      X1[as] = Mg.x1; Y1[as] = Mg.y1; X2[as] = Mg.x2; Y2[as] = Mg.y2; AF[as] = Mg.af;
+      if (moved) { X1[bs] = RL.x1; Y1[bs] = RL.y1; X2[bs] = RL.x2; Y2[bs] = RL.y2; AF[bs] = RL.af; }
+    }
+    total = last;
+#pragma unroll
+    for (int s = 0; s < SL; s++) {
+      const int wd = wave + NW * s;             // this wavefront's word of a partner set, for its rows of slot s
+      if (NT * s >= total) {                    // (no rows here any more: the two rebuilt rows hold nothing in these words)
+        if (lane == 0) { PM[as * W + wd] = 0ull; if (moved) PM[bs * W + wd] = 0ull; }
+        continue;
+      }
+      const int a = tid + NT * s;
+      if (a == as) own[s] = Mg;
+      else if (moved && a == bs) own[s] = RL;
+      const bool valid = a < total;
+      // tests 1 + 2 of this row against the merged row and -- behind bs -- against the row that moved there
+      bool c_as = valid && a != as && ls_t12(own[s], Mg, lp, thf);
+      bool c_bs = moved && valid && a > bs && ls_t12(RL, own[s], lp, thf);
+      // test 3 for the survivors through one call site: every lane takes its pending test against the merged row first, then the one
+      // against the moved row (a second trip only if some lane has both)
+      bool p_as = false, p_bs = false;
+      while (__ballot(c_as | c_bs)) {
+        const bool vs_merged = c_as, pending = c_as | c_bs;
+        const LsRow Q = vs_merged ? Mg : RL;
+        const bool r = pending && ls_t3(own[s], Q, vs_merged && a < as, lp, thf);
+        if (vs_merged) { p_as = r; c_as = false; } else if (pending) { p_bs = r; c_bs = false; }
+      }
+      // the two rebuilt rows' partner sets are these tests' ballots
+      const unsigned long long bal_as = __ballot(p_as && a > as), bal_bs = __ballot(p_bs);
+      if (lane == 0) { PM[as * W + wd] = bal_as; if (moved) PM[bs * W + wd] = bal_bs; }
+      // every other row: its bit for the old last row goes; its bit for `as` is the fresh test; its bit for `bs` is what its bit for the old last row was
+      if (valid && a != as && !(moved && a == bs)) {
+        unsigned long long* pm = PM + a * W;
+        int d = 0;
+        bool old_last = false;
+        { const unsigned long long v = pm[last >> 6]; old_last = (v >> (last & 63)) & 1ull; if (old_last) { pm[last >> 6] = v & ~(1ull << (last & 63)); d--; } }
+        if (a < as) { const unsigned long long v = pm[as >> 6]; const bool old = (v >> (as & 63)) & 1ull; if (old != p_as) { pm[as >> 6] = v ^ (1ull << (as & 63)); d += p_as ? 1 : -1; } }
+        if (moved && a < bs) { const unsigned long long v = pm[bs >> 6]; const bool old = (v >> (bs & 63)) & 1ull; if (old != old_last) { pm[bs >> 6] = v ^ (1ull << (bs & 63)); d += old_last ? 1 : -1; } }
+        cnt[s] += d;
+      }
+    }
+    __syncthreads();
+    // the owners of the two rebuilt rows count their new partner sets
+#pragma unroll
+    for (int s = 0; s < SL; s++) {
+      const int a = tid + NT * s;
+      if (a == as || (moved && a == bs)) {
+        int c = 0;
+        for (int w = a >> 6; w < W; w++) c += __popcll(PM[a * W + w]);
+        cnt[s] = c;
+      }
+    }
+  }
+  // ---- 4. keep segments longer than the threshold (in order) and emit the angle (exact: cs_atan2 of the row's end points) / midpoint tables
+  if (wave == 0) {
+    int kept = 0;
+    for (int base = 0; base < total; base += 64) {
+      int i = base + lane;
+      bool keep = false;
+      if (i < total) {
+        double len2 = v2_dist2(v2(X2[i], Y2[i]), v2(X1[i], Y1[i]));
+        keep = (lp.len_thre > 0) ? (len2 > lp.len_sq_bound) : true;
+      }
+      unsigned long long bal = __ballot(keep);
+      int off = kept + __popcll(bal & ((1ull << lane) - 1ull));
+      if (keep) {
+        line_angle[jd.line_off + off] = cs_atan2(Y2[i] - Y1[i], X2[i] - X1[i]);
+        mid_x[jd.line_off + off] = (X1[i] + X2[i]) / 2;
+        mid_y[jd.line_off + off] = (Y1[i] + Y2[i]) / 2;
+      }
+      kept += __popcll(bal);
+    }
+    if (lane == 0) jobs[j].m = kept;
+  }
+}
+
+// The typical job -- at most 128 segments inside the ROI -- on one wavefront with the pair-test matrix in REGISTERS: lane l owns the rows
+// l and l + 64; row l's partner set is two words (partners below / from 64 on), row l + 64's one.  Same procedure as line_setup_kernel
+// above (which keeps the matrix in LDS and serves the crowded ROIs), written without data-dependent branches: both cheap tests are
+// evaluated for every pair, the exact evaluations sit behind wave-uniform ballots, bit updates select their word with a uniform branch.
+__device__ __forceinline__ bool ls_t12_flat(const LsRow& A, const LsRow& B, const LineSetupParams& lp, float thf) {
+  float df = fabsf(A.af - B.af);
+  df = fminf(df, 3.14159274f - df);
+  bool p1 = df < thf - LS_MARGIN;
+  const bool unsure = !p1 && !(df > thf + LS_MARGIN);             // (a NaN lands here)
+  const double d_ab = v2_dist2(v2(A.x2, A.y2), v2(B.x1, B.y1));
+  const double d_ba = v2_dist2(v2(B.x2, B.y2), v2(A.x1, A.y1));
+  const bool p2 = (d_ab < lp.dist_sq_bound) || (d_ba < lp.dist_sq_bound);
+  if (__ballot(unsure && p2)) { if (unsure && p2) p1 = ls_rare_angle_diff(A.x1, A.y1, A.x2, A.y2, B.x1, B.y1, B.x2, B.y2, lp.angle_thre_rad); }
+  return p1 && p2;
+}
+__device__ __forceinline__ void ls_setbit(unsigned long long& lo, unsigned long long& hi, int pos, bool val) {   // pos: wave-uniform
+  const unsigned long long bit = 1ull << (pos & 63);
+  if (pos < 64) lo = val ? (lo | bit) : (lo & ~bit); else hi = val ? (hi | bit) : (hi & ~bit);
+}
+__device__ __forceinline__ bool ls_getbit(unsigned long long lo, unsigned long long hi, int pos) {
+  return (((pos < 64) ? lo : hi) >> (pos & 63)) & 1ull;
+}
+__global__ __launch_bounds__(64) void line_setup_small_kernel(JobDesc* jobs, int n_jobs, const double* __restrict__ frame_lines, const int* __restrict__ frame_line_ptr,
+                                                              double* mid_x, double* mid_y, double* line_angle, LineSetupParams lp, const int* __restrict__ order) {
+  constexpr int CAP = LS_SMALL;
+  __shared__ double X1[CAP], Y1[CAP], X2[CAP], Y2[CAP];
+  __shared__ float AF[CAP];
+  int j = order ? order[blockIdx.x] : blockIdx.x;   // longest jobs first (the kernel ends with its slowest workgroup)
+  if (j >= n_jobs) return;
+  const JobDesc jd = jobs[j];
+  if (jd.Y == 0 || jd.T == 0) return;   // a box the sweep skips (no yaw / top-edge samples): m stays 0
+  const double* FL = frame_lines + 4 * (size_t)frame_line_ptr[jd.frame];
+  const int M = frame_line_ptr[jd.frame + 1] - frame_line_ptr[jd.frame];
+  const int lane = threadIdx.x;
+  const float thf = (float)lp.angle_thre_rad;
+  const int NONE = 0x7fffffff;
+  auto row = [&](int i) { return LsRow{AF[i], X1[i], Y1[i], X2[i], Y2[i]}; };
+  // ---- 1. segments with both end points inside the expanded ROI, in input order; more than LS_SMALL: the other instance's job
   int total = 0;
   for (int base = 0; base < M; base += 64) {
     int i = base + lane;
@@ -1157,75 +1383,138 @@ __global__ __launch_bounds__(LS_THREADS) void line_setup_kernel(JobDesc* jobs, i
     }
     unsigned long long bal = __ballot(in);
     int off = total + __popcll(bal & ((1ull << lane) - 1ull));
-    if (in && off < CAP) { X1[off] = x1; Y1[off] = y1; X2[off] = x2; Y2[off] = y2; ANG[off] = cs_atan2(y2 - y1, x2 - x1); }
-    total = min(CAP, total + __popcll(bal));
+    if (in && off < CAP) { X1[off] = x1; Y1[off] = y1; X2[off] = x2; Y2[off] = y2; AF[off] = ls_angf(x1, y1, x2, y2); }
+    total += __popcll(bal);
   }
+  if (total > CAP) return;
   __syncthreads();
-  // ---- 2. first partner of every row
-  for (int a0 = 0; a0 < total; a0 += 64) {
-    int a = a0 + lane;
-    int f = NONE;
-    if (a < total - 1) {
-      LsRow A = row(a);
-      for (int b = a + 1; b < total; b++)
-        if (ls_pair_pass(A, row(b), lp)) { f = b; break; }
+  // ---- 2. the pair-test matrix: tests 1 + 2 of the own rows against every later row b (broadcast), then test 3 for the survivors
+  LsRow own0 = (lane < total) ? row(lane) : LsRow{0.f, 0., 0., 0., 0.};
+  LsRow own1 = (lane + 64 < total) ? row(lane + 64) : LsRow{0.f, 0., 0., 0., 0.};
+  unsigned long long m00 = 0ull, m01 = 0ull, m11 = 0ull;    // row lane: partners < 64 / >= 64; row lane + 64: partners >= 64
+  for (int b = 1; b < total; b++) {
+    const LsRow Rb = row(b);
+    const bool t0 = ls_t12_flat(own0, Rb, lp, thf) && lane < b;
+    const unsigned long long bit = 1ull << (b & 63);
+    if (b < 64) m00 |= t0 ? bit : 0ull;
+    else {
+      m01 |= t0 ? bit : 0ull;
+      if (b > 64) { const bool t1 = ls_t12_flat(own1, Rb, lp, thf) && lane + 64 < b; m11 |= t1 ? bit : 0ull; }
     }
-    if (a < total) F[a] = f;
   }
-  __syncthreads();
-  // ---- 3. merge rounds
-  for (int rounds = 0; rounds < 500; rounds++) {
-    int best = NONE;
-    for (int a = lane; a < total - 1; a += 64) {
-      int f = F[a];
-      if (f != NONE) { best = a * LS_CAP + f; break; }  // rows are visited in increasing order: the first hit is this lane's smallest
-    }
+  {
+    // every lane walks the survivors of its rows (lowest partner first; three words)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { int y = __shfl_xor(best, o); best = (y < best) ? y : best; }
-    if (best == NONE) break;
-    const int as = best / LS_CAP, bs = best % LS_CAP, last = total - 1;
-    if (lane == 0) {
-      bool sa = X1[as] < X1[bs], ea = X2[as] > X2[bs];
-      double sx = sa ? X1[as] : X1[bs], sy = sa ? Y1[as] : Y1[bs], ex = ea ? X2[as] : X2[bs], ey = ea ? Y2[as] : Y2[bs];
-      X1[as] = sx; Y1[as] = sy; X2[as] = ex; Y2[as] = ey;
-      ANG[as] = cs_atan2(ey - sy, ex - sx);
-      X1[bs] = X1[last]; Y1[bs] = Y1[last]; X2[bs] = X2[last]; Y2[bs] = Y2[last]; ANG[bs] = ANG[last];  // fast_RemoveRow (matrix_utils.cpp:183)
-      F[bs] = F[last];  // placeholder; row bs is re-scanned below
-    }
-    total = last;
-    __syncthreads();
-    const bool moved = (bs != last);  // row bs now holds what used to be the last row
-    // every other row: only its pairs with the two rewritten rows can have changed
-    unsigned long long need = 0;
-    for (int a0 = 0; a0 < total; a0 += 64) {
-      int a = a0 + lane;
-      bool redo = false;
-      if (a < total && a != as && !(moved && a == bs)) {
-        int f = F[a];
-        if (f == last) f = NONE;                            // partner moved (re-tested as bs below) or vanished; everything before it failed
-        if (f == as || (moved && f == bs)) redo = true;     // first partner was rewritten: what comes after it was never tested
-        else {
-          LsRow A = row(a);
-          if (a < as && as < f && ls_pair_pass(A, row(as), lp)) f = as;
-          if (moved && a < bs && bs < f && ls_pair_pass(A, row(bs), lp)) f = bs;
-          F[a] = f;
-        }
+    for (int q = 0; q < 3; q++) {
+      unsigned long long v = q == 0 ? m00 : (q == 1 ? m01 : m11), keep = v;
+      const int wbase = q == 0 ? 0 : 64;
+      while (__ballot(v != 0ull)) {
+        const bool have = v != 0ull;
+        const int b = have ? wbase + __ffsll((long long)v) - 1 : 0;
+        const unsigned long long lowbit = v & (0ull - v);
+        v ^= lowbit;
+        const bool ok = have && ls_t3(q == 2 ? own1 : own0, row(b), true, lp, thf);
+        if (have && !ok) keep ^= lowbit;
       }
-      unsigned long long bal = __ballot(redo);
-      // cooperative re-scans of the flagged rows of this stripe (rare)
-      while (bal) {
-        int l = __ffsll((long long)bal) - 1;
-        bal &= bal - 1;
-        rescan(a0 + l, total);
-      }
-      (void)need;
+      if (q == 0) m00 = keep; else if (q == 1) m01 = keep; else m11 = keep;
     }
-    rescan(as, total);
-    if (moved) rescan(bs, total);
-    if (lane == 0 && total > 0) F[total - 1] = NONE;
-    __syncthreads();
   }
-  // ---- 4. keep segments longer than the threshold (in order) and emit angle / midpoint tables
+  // ---- 3. merge rounds
+  for (int rounds = 0; rounds < CAP; rounds++) {
+    const int first0 = m00 ? __ffsll((long long)m00) - 1 : (m01 ? 64 + __ffsll((long long)m01) - 1 : NONE);
+    const int first1 = m11 ? 64 + __ffsll((long long)m11) - 1 : NONE;
+    int as, bs;
+    const unsigned long long bal0 = __ballot(first0 != NONE);
+    if (bal0) {
+      as = __ffsll((long long)bal0) - 1;
+      bs = __builtin_amdgcn_readlane(first0, as);
+    } else {
+      const unsigned long long bal1 = __ballot(first1 != NONE);
+      if (!bal1) break;
+      const int l = __ffsll((long long)bal1) - 1;
+      as = 64 + l;
+      bs = __builtin_amdgcn_readlane(first1, l);
+    }
+    const int last = total - 1;
+    const LsRow Ra = row(as), Rb = row(bs), RL = row(last);
+    LsRow Mg;                                   // the merged row (:499-523): the wider start / end of the two
+    {
+      const bool sa = Ra.x1 < Rb.x1, ea = Ra.x2 > Rb.x2;
+      Mg.x1 = sa ? Ra.x1 : Rb.x1; Mg.y1 = sa ? Ra.y1 : Rb.y1; Mg.x2 = ea ? Ra.x2 : Rb.x2; Mg.y2 = ea ? Ra.y2 : Rb.y2;
+      Mg.af = ls_angf(Mg.x1, Mg.y1, Mg.x2, Mg.y2);
+    }
+    const bool moved = (bs != last);            // row bs takes what used to be the last row (fast_RemoveRow, matrix_utils.cpp:183)
+    __syncthreads();
+    if (lane == 0) {
+      X1[as] = Mg.x1; Y1[as] = Mg.y1; X2[as] = Mg.x2; Y2[as] = Mg.y2; AF[as] = Mg.af;
+      if (moved) { X1[bs] = RL.x1; Y1[bs] = RL.y1; X2[bs] = RL.x2; Y2[bs] = RL.y2; AF[bs] = RL.af; }
+    }
+    __syncthreads();
+    total = last;
+    // the removed row's partner set goes; the two rewritten rows are read back by their owners
+    if (lane == (last & 63)) { if (last < 64) { m00 = 0ull; m01 = 0ull; } else m11 = 0ull; }
+    if (lane < total) own0 = row(lane);
+    const bool two = total > 64;
+    if (two && lane + 64 < total) own1 = row(lane + 64);
+    // this round's tests: every row against the merged row, the rows behind bs against the row that moved there
+    unsigned long long bal_as0 = 0ull, bal_as1 = 0ull, bal_bs0 = 0ull, bal_bs1 = 0ull;
+    bool p_as0 = false, p_as1 = false;
+    {
+      const int a = lane;
+      const bool valid = a < total;
+      bool c_as = valid && a != as && ls_t12_flat(own0, Mg, lp, thf);
+      bool c_bs = false;
+      if (moved && bs < 63) c_bs = valid && a > bs && ls_t12_flat(RL, own0, lp, thf);
+      bool p_bs = false;
+      while (__ballot(c_as | c_bs)) {
+        const bool vs_merged = c_as, pending = c_as | c_bs;
+        const LsRow Q = vs_merged ? Mg : RL;
+        const bool r = pending && ls_t3(own0, Q, vs_merged && a < as, lp, thf);
+        if (vs_merged) { p_as0 = r; c_as = false; } else if (pending) { p_bs = r; c_bs = false; }
+      }
+      bal_as0 = __ballot(p_as0 && a > as); bal_bs0 = __ballot(p_bs);
+    }
+    if (two) {
+      const int a = lane + 64;
+      const bool valid = a < total;
+      bool c_as = valid && a != as && ls_t12_flat(own1, Mg, lp, thf);
+      bool c_bs = false;
+      if (moved) c_bs = valid && a > bs && ls_t12_flat(RL, own1, lp, thf);
+      bool p_bs = false;
+      while (__ballot(c_as | c_bs)) {
+        const bool vs_merged = c_as, pending = c_as | c_bs;
+        const LsRow Q = vs_merged ? Mg : RL;
+        const bool r = pending && ls_t3(own1, Q, vs_merged && a < as, lp, thf);
+        if (vs_merged) { p_as1 = r; c_as = false; } else if (pending) { p_bs = r; c_bs = false; }
+      }
+      bal_as1 = __ballot(p_as1 && a > as); bal_bs1 = __ballot(p_bs);
+    }
+    // every other row: its bit for the old last row goes; its bit for `as` is the fresh test; its bit for `bs` is what its bit for the old last row was
+    {
+      const int a = lane;
+      if (a < total && a != as && !(moved && a == bs)) {
+        const bool old_last = ls_getbit(m00, m01, last);
+        ls_setbit(m00, m01, last, false);
+        if (a < as) ls_setbit(m00, m01, as, p_as0);
+        if (moved && a < bs) ls_setbit(m00, m01, bs, old_last);
+      }
+    }
+    if (two) {
+      const int a = lane + 64;
+      if (a < total && a != as && !(moved && a == bs)) {
+        unsigned long long none = 0ull;
+        const bool old_last = ls_getbit(none, m11, last);
+        ls_setbit(none, m11, last, false);
+        if (a < as) ls_setbit(none, m11, as, p_as1);
+        if (moved && a < bs) ls_setbit(none, m11, bs, old_last);
+      }
+    }
+    // the two rebuilt rows' partner sets are the tests' ballots
+    if (as < 64) { if (lane == as) { m00 = bal_as0; m01 = bal_as1; } } else if (lane == as - 64) m11 = bal_as1;
+    if (moved) { if (bs < 64) { if (lane == bs) { m00 = bal_bs0; m01 = bal_bs1; } } else if (lane == bs - 64) m11 = bal_bs1; }
+  }
+  __syncthreads();
+  // ---- 4. keep segments longer than the threshold (in order) and emit the angle (exact: cs_atan2 of the row's end points) / midpoint tables
   int kept = 0;
   for (int base = 0; base < total; base += 64) {
     int i = base + lane;
@@ -1237,7 +1526,7 @@ __global__ __launch_bounds__(LS_THREADS) void line_setup_kernel(JobDesc* jobs, i
     unsigned long long bal = __ballot(keep);
     int off = kept + __popcll(bal & ((1ull << lane) - 1ull));
     if (keep) {
-      line_angle[jd.line_off + off] = ANG[i];
+      line_angle[jd.line_off + off] = cs_atan2(Y2[i] - Y1[i], X2[i] - X1[i]);
       mid_x[jd.line_off + off] = (X1[i] + X2[i]) / 2;
       mid_y[jd.line_off + off] = (Y1[i] + Y2[i]) / 2;
     }
@@ -1262,9 +1551,9 @@ void launch_line_setup(JobDesc* jobs, int n_jobs, const double* frame_lines, con
   const bool beside = st_crowded && fork && join;
   hipStream_t sc = beside ? st_crowded : st;
   if (beside) (void)hipStreamWaitEvent(sc, fork, 0);
-  hipLaunchKernelGGL(line_setup_kernel<LS_CAP>, dim3(n_jobs), dim3(LS_THREADS), 0, sc, jobs, n_jobs, frame_lines, frame_line_ptr, mid_x, mid_y, line_angle, lp, order);
+  hipLaunchKernelGGL((line_setup_kernel<LS_CAP, LS_CROWDED_THREADS>), dim3(n_jobs), dim3(LS_CROWDED_THREADS), 0, sc, jobs, n_jobs, frame_lines, frame_line_ptr, mid_x, mid_y, line_angle, lp, order);
   if (beside) (void)hipEventRecord(join, sc);
-  hipLaunchKernelGGL(line_setup_kernel<LS_SMALL>, dim3(n_jobs), dim3(LS_THREADS), 0, st, jobs, n_jobs, frame_lines, frame_line_ptr, mid_x, mid_y, line_angle, lp, order);
+  hipLaunchKernelGGL(line_setup_small_kernel, dim3(n_jobs), dim3(64), 0, st, jobs, n_jobs, frame_lines, frame_line_ptr, mid_x, mid_y, line_angle, lp, order);
   if (beside) (void)hipStreamWaitEvent(st, join, 0);
 }
 int line_setup_capacity() { return LS_CAP; }

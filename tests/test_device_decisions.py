@@ -328,11 +328,17 @@ def test_vp_support_decision_logic_equals_the_exact_evaluation():
 
 
 def test_line_pair_test_decisions_equal_the_exact_evaluation():
-    """ls_pair_pass (the three tests of merge_break_lines, object_3d_util.cpp:464-497): squared end-point gaps against the
-    squared bound and the float angle of the would-be merged segment with the exact evaluation inside the margin -- the same
-    decision as sqrt / atan2 in float64 for every pair, including pairs built to sit on the thresholds."""
+    """ls_t12 / ls_t3 (the three tests of merge_break_lines, object_3d_util.cpp:464-497) as line_setup_kernel takes them since round 5:
+    every row carries its angle as a FLOAT (atan2_float of its end points); the angle-difference test and the test of the would-be merged
+    segment's angle are taken on floats, with the exact evaluation (float64 atan2 of the rows' end points) inside a margin of 1.5e-5 rad;
+    end-point gaps are compared squared against the squared bound.  The same decision as sqrt / atan2 in float64 for every pair,
+    including pairs built to sit on the thresholds.  The margin is read from the source."""
     rng = np.random.default_rng(31)
     f32 = np.float32
+    text = open(SRC).read()
+    margin = f32(float(re.search(r"#define LS_MARGIN ([0-9.e+-]+)f", text).group(1)))
+    assert margin == f32(1.5e-5)
+    PI_F = f32(3.14159274)
     dist_thre, ang_thre = 20.0, 5.0 / 180.0 * np.pi
     # sqrt(x) < 20 <=> x < bound, bound = the smallest double whose rounded root reaches 20 (cs_geom.h sqrt_lt_bound; the C++
     # function itself is checked in test_squared_length_bounds_are_exact): one ulp below 400, whose root already rounds to 20
@@ -340,7 +346,8 @@ def test_line_pair_test_decisions_equal_the_exact_evaluation():
     while np.sqrt(np.nextafter(dist_sq_bound, 0.0)) >= dist_thre:
         dist_sq_bound = np.nextafter(dist_sq_bound, 0.0)
     assert dist_sq_bound == 399.99999999999994
-    n_exact = n_pass = 0
+    n_exact1 = n_exact3 = n_pass = 0
+    worst_af = 0.0
     for trial in range(60000):
         x1, y1 = rng.uniform(0, 600), rng.uniform(0, 300)
         a = rng.uniform(-np.pi / 2, np.pi / 2)
@@ -357,6 +364,10 @@ def test_line_pair_test_decisions_equal_the_exact_evaluation():
         if B[2] < B[0]:
             B = (B[2], B[3], B[0], B[1])
         angA, angB = np.arctan2(A[3] - A[1], A[2] - A[0]), np.arctan2(B[3] - B[1], B[2] - B[0])
+        # the rows' float angles, as the kernel stores them
+        afA = atan2_float_model(np.array([A[3] - A[1]], f32), np.array([A[2] - A[0]], f32))[0]
+        afB = atan2_float_model(np.array([B[3] - B[1]], f32), np.array([B[2] - B[0]], f32))[0]
+        worst_af = max(worst_af, abs(float(afA) - angA), abs(float(afB) - angB))
 
         def exact():
             diff = abs(angA - angB)
@@ -372,9 +383,19 @@ def test_line_pair_test_decisions_equal_the_exact_evaluation():
             return min(t, np.pi - t) < ang_thre
 
         def device():
-            nonlocal n_exact
-            diff = abs(angA - angB)
-            if min(diff, np.pi - diff) >= ang_thre:
+            nonlocal n_exact1, n_exact3
+            th = f32(ang_thre)
+            df = abs(f32(afA - afB))
+            df = min(df, f32(PI_F - df))
+            if df < f32(th - margin):
+                p1 = True
+            elif df > f32(th + margin):
+                p1 = False
+            else:
+                n_exact1 += 1
+                diff = abs(angA - angB)
+                p1 = min(diff, np.pi - diff) < ang_thre
+            if not p1:
                 return False
             d_ab = (A[2] - B[0]) ** 2 + (A[3] - B[1]) ** 2
             d_ba = (B[2] - A[0]) ** 2 + (B[3] - A[1]) ** 2
@@ -384,18 +405,20 @@ def test_line_pair_test_decisions_equal_the_exact_evaluation():
             ex, ey = (A[2], A[3]) if A[2] > B[2] else (B[2], B[3])
             dy, dx = ey - sy, ex - sx
             at = atan2_float_model(np.array([dy], f32), np.array([dx], f32))[0]
-            tf = abs(f32(f32(angA) - at))
-            mf = min(tf, f32(f32(3.14159274) - tf))
-            th = f32(ang_thre)
-            if mf < f32(th - f32(1e-5)):
+            tf = abs(f32(afA - at))
+            mf = min(tf, f32(PI_F - tf))
+            if mf < f32(th - margin):
                 return True
-            if mf > f32(th + f32(1e-5)):
+            if mf > f32(th + margin):
                 return False
-            n_exact += 1
+            n_exact3 += 1
             t = abs(angA - np.arctan2(dy, dx))
             return min(t, np.pi - t) < ang_thre
 
         e = exact()
         assert device() == e, trial
         n_pass += e
-    assert n_pass > 5000 and 0 < n_exact < 2000
+    # a float difference of two row angles is within 2 x 2.5e-6 (+ rounding) of the exact difference: a third of the margin
+    assert worst_af < 2.5e-6 and 2 * worst_af + 1e-6 < float(margin)
+    # (a quarter of the pairs is built ON the angle threshold: 15 000 exact evaluations of the first test by construction)
+    assert n_pass > 5000 and 15000 <= n_exact1 < 15200 and 0 < n_exact3 < 3000
