@@ -55,6 +55,9 @@ bool ba_bcr_ok(int n, int LD);
 double ba_bcr_estimate_ms(int n);
 size_t ba_bcr_workspace_doubles(int n, int Bv);
 void ba_launch_bcr(const double* Sb, double* work, int n, int LD, int Bv, double* rhs, int* info, hipStream_t st);
+bool ba_bcr_sep_ok(int wm, int R);
+size_t ba_bcr_sep_workspace_doubles(int R);
+void ba_launch_bcr_sep(const double* msgs, size_t msg_doubles, int wm, int R, const int* sep_off, const int* sep_col, int ns, double* work, double* x, int* info, hipStream_t st);
 void ba_launch_sum2(const double* a, int na, const double* b, int nb, double* out, hipStream_t st);
 void ba_launch_ext_add(const BaView& v, const double* cam36, const double* cam6, const double* cub81, const double* cub9, const double* pt9, const double* pt3, hipStream_t st);
 void ba_launch_ext_offdiag(const BaView& v, int n, const int* e4, const double* Hij, hipStream_t st);
@@ -1206,7 +1209,7 @@ int finalize_structure(cs_ba* B) {
     AL(B->sepY, (size_t)(B->wl + B->wr) * B->int_n);
     AL(B->sep_msgs, B->msg_doubles * (size_t)R);
     AL(B->sepS, (size_t)B->n_sep * 2 * B->w_max + B->n_sep);   // [S_sep (band of 2 w_max) | rhs_sep]
-    AL(B->sep_work, cs::ba_band_workspace_doubles(B->n_sep, 2 * B->w_max));
+    AL(B->sep_work, std::max(cs::ba_band_workspace_doubles(B->n_sep, 2 * B->w_max), cs::ba_bcr_sep_ok(B->w_max, B->shard_n) ? cs::ba_bcr_sep_workspace_doubles(B->shard_n) : (size_t)1));
     AL(B->d_sep_info, 24);
     AL(B->int_work, cs::ba_band_workspace_doubles(B->int_n, B->band_ld));
     AL(B->d_int_info, 24);
@@ -1565,17 +1568,24 @@ int solve_device_sep(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn, void
   BA_TRY(hipEventRecord(B->sev[2], B->st));
   // every rank assembles and solves the (small) separator system: nothing to broadcast afterwards.  Block tridiagonal = a band of
   // 2 w_max: the persistent banded Cholesky again (two fronts at 7 separators: 18 dependent steps)
-  cs::ba_launch_sep_assemble(B->sep_msgs.p, B->msg_doubles, B->w_max, R, B->d_sep_off.p, ns, LDs, B->sepS.p, rsep, B->st);
-  BA_TRY(hipGetLastError());
-  if (!coop_turn.owns_lock()) coop_turn.lock();
-  BA_TRY(hipMemsetAsync(B->d_sep_info.p, 0, 24 * sizeof(int), B->st));
-  cs::ba_launch_band_cholesky(B->sepS.p, B->sep_work.p, ns, LDs, rsep, B->d_sep_info.p, true, B->st);
-  BA_TRY(hipGetLastError());
-  if (fn) {
-    BA_TRY(hipStreamSynchronize(B->st));
-    coop_turn.unlock();
+  if (cs::ba_bcr_sep_ok(B->w_max, R)) {
+    // ... by block cyclic reduction, straight from the messages' blocks (bcr_kernels.hip): 7 separators = 3 levels instead of 18 dependent steps
+    BA_TRY(hipMemsetAsync(B->d_sep_info.p, 0, 24 * sizeof(int), B->st));
+    cs::ba_launch_bcr_sep(B->sep_msgs.p, B->msg_doubles, B->w_max, R, B->d_sep_off.p, B->d_sep_col.p, ns, B->sep_work.p, rhs, B->d_sep_info.p, B->st);
+    BA_TRY(hipGetLastError());
+  } else {
+    cs::ba_launch_sep_assemble(B->sep_msgs.p, B->msg_doubles, B->w_max, R, B->d_sep_off.p, ns, LDs, B->sepS.p, rsep, B->st);
+    BA_TRY(hipGetLastError());
+    if (!coop_turn.owns_lock()) coop_turn.lock();
+    BA_TRY(hipMemsetAsync(B->d_sep_info.p, 0, 24 * sizeof(int), B->st));
+    cs::ba_launch_band_cholesky(B->sepS.p, B->sep_work.p, ns, LDs, rsep, B->d_sep_info.p, true, B->st);
+    BA_TRY(hipGetLastError());
+    if (fn) {
+      BA_TRY(hipStreamSynchronize(B->st));
+      coop_turn.unlock();
+    }
+    cs::ba_launch_sep_scatter(rsep, ns, R, B->d_sep_off.p, B->d_sep_col.p, rhs, B->st);
   }
-  cs::ba_launch_sep_scatter(rsep, ns, R, B->d_sep_off.p, B->d_sep_col.p, rhs, B->st);
   BA_TRY(hipEventRecord(B->sev[3], B->st));
   cs::ba_launch_sep_backsolve(B->S.p, LD, B->int_work.p, B->int_c, B->int_n, B->zl, B->wl, B->zr, B->wr, B->sepY.p, rhs, B->d_int_info.p, B->st);
   BA_TRY(hipGetLastError());

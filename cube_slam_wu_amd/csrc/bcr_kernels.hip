@@ -41,6 +41,7 @@ typedef double (*bcr_blk)[BS + 1];
 
 struct BcrLevel {
   int N, lvl;                 // blocks of this level; level index
+  int packed;                 // level 0 only: D / YL / YR / b were filled by the caller (block form), there is no band
   // level 0 reads the band: S(r, c), r >= c, at Sb[c * LD + (r - c)]; block k holds the unknowns [k Bv, k Bv + Bv) (the last one fewer)
   const double* Sb; int LD, n, Bv;
   double* rhs;                // level-0 right-hand side in, solution out
@@ -68,7 +69,7 @@ __device__ __forceinline__ double bcr_band_diag(const BcrLevel& P, int k, int vr
   return off < P.LD ? P.Sb[(size_t)(k * P.Bv + C) * P.LD + off] : 0.0;
 }
 __device__ __forceinline__ double bcr_b_at(const BcrLevel& P, int k, int r) {
-  if (P.lvl > 0) return P.b[(size_t)k * BCR_B + r];
+  if (P.lvl > 0 || P.packed) return P.b[(size_t)k * BCR_B + r];
   return r < bcr_valid_rows(P, k) ? P.rhs[k * P.Bv + r] : 0.0;
 }
 
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void bcr_factor_kernel(BcrLevel P, int n_elim)
   // ---- load D_e (the ten lower blocks: 40 entries per thread, all in flight) and b_e
   {
     double v[BCR_SLOTS][4];
-    if (P.lvl == 0) {
+    if (P.lvl == 0 && !P.packed) {
       const int vr = bcr_valid_rows(P, e);
 #pragma unroll
       for (int i = 0; i < BCR_NB; i++)
@@ -535,7 +536,7 @@ size_t ba_bcr_workspace_doubles(int n, int Bv) {
 // Factorise and solve: Sb = the lower band (LD doubles per column), block size Bv (bandwidth <= Bv <= 128, or a matrix that is block
 // tridiagonal in blocks of Bv whatever its band storage), rhs in / solution out, info[0] != 0: a non-positive pivot.  The band itself
 // is left untouched.
-void ba_launch_bcr(const double* Sb, double* work, int n, int LD, int Bv, double* rhs, int* info, hipStream_t st) {
+static void bcr_run(const double* Sb, double* work, int n, int LD, int Bv, double* rhs, int* info, hipStream_t st, bool packed, void (*fill)(const BcrLevel&, void*, hipStream_t), void* fill_arg) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bcr_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BCR_LDS_DOUBLES * (int)sizeof(double));
@@ -548,7 +549,7 @@ void ba_launch_bcr(const double* Sb, double* work, int n, int LD, int Bv, double
   for (int l = 0; l < L; l++) {
     BcrLevel& P = lev[l];
     const size_t N = Ns[l], ne = (N + 1) / 2;
-    P.N = (int)N; P.lvl = l; P.Sb = Sb; P.LD = LD; P.n = n; P.Bv = Bv; P.rhs = rhs; P.info = info;
+    P.N = (int)N; P.lvl = l; P.packed = (l == 0 && packed) ? 1 : 0; P.Sb = Sb; P.LD = LD; P.n = n; P.Bv = Bv; P.rhs = rhs; P.info = info;
     P.D = wp; wp += N * BCR_BB;
     P.YL = wp; wp += ne * BCR_BB;
     P.YR = wp; wp += ne * BCR_BB;
@@ -560,10 +561,11 @@ void ba_launch_bcr(const double* Sb, double* work, int n, int LD, int Bv, double
     P.Dn = P.YLn = P.YRn = P.bn = nullptr;
   }
   for (int l = 0; l + 1 < L; l++) { lev[l].Dn = lev[l + 1].D; lev[l].YLn = lev[l + 1].YL; lev[l].YRn = lev[l + 1].YR; lev[l].bn = lev[l + 1].b; }
+  if (packed && L > 0) fill(lev[0], fill_arg, st);
   for (int l = 0; l < L; l++) {
     const BcrLevel& P = lev[l];
     const int ne = (P.N + 1) / 2, nr = P.N / 2;
-    hipLaunchKernelGGL(bcr_factor_kernel, dim3(ne + (l == 0 ? 8 * P.N : 0)), dim3(256), BCR_LDS_DOUBLES * sizeof(double), st, P, ne);
+    hipLaunchKernelGGL(bcr_factor_kernel, dim3(ne + ((l == 0 && !packed) ? 8 * P.N : 0)), dim3(256), BCR_LDS_DOUBLES * sizeof(double), st, P, ne);
     if (nr > 0) {
       hipLaunchKernelGGL(bcr_panel_kernel, dim3(16 * ne), dim3(256), 0, st, P);
       hipLaunchKernelGGL(bcr_update_kernel, dim3(nr * BCR_UPD_SLOTS), dim3(256), 0, st, P);
@@ -573,6 +575,75 @@ void ba_launch_bcr(const double* Sb, double* work, int n, int LD, int Bv, double
     const BcrLevel& P = lev[l];
     hipLaunchKernelGGL(bcr_back_kernel, dim3((P.N + 1) / 2), dim3(512), 0, st, P);
   }
+}
+void ba_launch_bcr(const double* Sb, double* work, int n, int LD, int Bv, double* rhs, int* info, hipStream_t st) {
+  bcr_run(Sb, work, n, LD, Bv, rhs, info, st, false, nullptr, nullptr);
+}
+
+// ------------------------------------------------------------------------- the sharded solve's separator system, in block form --
+// Separator mode of the sharded BA (ba_kernels.hip, "sharded reduced solve"): after the all-gather every rank holds the R messages
+// [LL | RL | RR | tL | tR] (three wm x wm blocks, two wm-vectors) and solves the block-tridiagonal system of the R - 1 separators:
+//   D_k = LL(rank k + 1) + RR(rank k),   A(k + 1, k) = RL(rank k + 1),   b_k = tL(rank k + 1) + tR(rank k)        (block k = separator Z_(k+1))
+// The blocks (<= 128 wide, padded with the identity) go straight into the level-0 arrays; x comes back as N x 128 padded blocks.
+struct BcrSepSrc { const double* msgs; size_t msg_doubles; int wm, R, ns; const int* sep_off; };
+__global__ __launch_bounds__(256) void bcr_pack_sep_kernel(BcrLevel P, BcrSepSrc S) {
+  const int k = blockIdx.x >> 4, which = (blockIdx.x >> 2) & 3, q = blockIdx.x & 3, tid = threadIdx.x;
+  if (k >= P.N) return;
+  auto width = [&](int z) { return (z + 1 < S.R ? S.sep_off[z + 1] : S.ns) - S.sep_off[z]; };     // of separator Z_z, z = 1 .. R - 1
+  const int wm = S.wm;
+  const size_t ww = (size_t)wm * wm;
+  const int z = k + 1, w = width(z);
+  const double* mz = S.msgs + (size_t)z * S.msg_doubles;          // message of rank z: Z_z is its left separator
+  const double* mp = S.msgs + (size_t)(z - 1) * S.msg_doubles;    // message of rank z - 1: Z_z is its right separator
+  if (which == 0) {
+    double* D = P.D + (size_t)k * BCR_BB;
+    for (int u = 0; u < 16; u++) {
+      const int idx = tid + 256 * u, c = idx & (BCR_B - 1), r = 32 * q + (idx >> 7);
+      const int lr = r >= c ? r : c, lc = r >= c ? c : r;
+      D[r * BCR_B + c] = (lr < w) ? mz[(size_t)lr * wm + lc] + mp[2 * ww + (size_t)lr * wm + lc] : (r == c ? 1.0 : 0.0);
+    }
+  } else if (which == 1) {
+    if ((k & 1) || k == 0) return;                                 // YL of an eliminated block: A(k, k - 1), rows Z_z, columns Z_(z-1) = RL of rank z - 1
+    double* Y = P.YL + (size_t)(k >> 1) * BCR_BB;
+    const int wc = width(z - 1);
+    for (int u = 0; u < 16; u++) {
+      const int idx = tid + 256 * u, c = idx & (BCR_B - 1), r = 32 * q + (idx >> 7);
+      Y[r * BCR_B + c] = (r < w && c < wc) ? mp[ww + (size_t)r * wm + c] : 0.0;
+    }
+  } else if (which == 2) {
+    if ((k & 1) || k + 1 >= P.N) return;                           // YR: A(k, k + 1) = A(k + 1, k)^T, A(k + 1, k) = RL of rank z (rows Z_(z+1), columns Z_z)
+    double* Y = P.YR + (size_t)(k >> 1) * BCR_BB;
+    const int wn = width(z + 1);
+    for (int u = 0; u < 16; u++) {
+      const int idx = tid + 256 * u, c = idx & (BCR_B - 1), r = 32 * q + (idx >> 7);
+      Y[r * BCR_B + c] = (r < w && c < wn) ? mz[ww + (size_t)c * wm + r] : 0.0;
+    }
+  } else if (q == 0 && tid < BCR_B) {
+    P.b[(size_t)k * BCR_B + tid] = tid < w ? mz[3 * ww + tid] + mp[3 * ww + wm + tid] : 0.0;
+  }
+}
+static void bcr_fill_sep(const BcrLevel& P, void* arg, hipStream_t st) {
+  hipLaunchKernelGGL(bcr_pack_sep_kernel, dim3(16 * P.N), dim3(256), 0, st, P, *static_cast<BcrSepSrc*>(arg));
+}
+// x of separator Z_z to its place in the solution vector (sep_col[z]: its first column), from the padded blocks
+__global__ __launch_bounds__(128) void bcr_sep_scatter_kernel(const double* xpad, int R, int ns, const int* sep_off, const int* sep_col, double* x) {
+  const int z = blockIdx.x + 1, l = threadIdx.x;
+  const int w = (z + 1 < R ? sep_off[z + 1] : ns) - sep_off[z];
+  if (l < w) x[sep_col[z] + l] = xpad[(size_t)(z - 1) * BCR_B + l];
+}
+bool ba_bcr_sep_ok(int wm, int R) {
+  static const int on = getenv("CS_BAND_BCR") ? atoi(getenv("CS_BAND_BCR")) : 1;
+  return on != 0 && wm >= 1 && wm <= BCR_B && R >= 2;
+}
+size_t ba_bcr_sep_workspace_doubles(int R) { return ba_bcr_workspace_doubles((R - 1) * BCR_B, BCR_B) + (size_t)(R - 1) * BCR_B; }
+// msgs: the R gathered messages; x: the solution vector the separators' unknowns are scattered into; info[0] != 0: a non-positive pivot
+void ba_launch_bcr_sep(const double* msgs, size_t msg_doubles, int wm, int R, const int* sep_off, const int* sep_col, int ns, double* work, double* x, int* info, hipStream_t st) {
+  const int N = R - 1;
+  if (N < 1) return;
+  double* xpad = work + ba_bcr_workspace_doubles(N * BCR_B, BCR_B);
+  BcrSepSrc src{msgs, msg_doubles, wm, R, ns, sep_off};
+  bcr_run(nullptr, work, N * BCR_B, 0, BCR_B, xpad, info, st, true, bcr_fill_sep, &src);
+  hipLaunchKernelGGL(bcr_sep_scatter_kernel, dim3(N), dim3(128), 0, st, xpad, R, ns, sep_off, sep_col, x);
 }
 
 }  // namespace cs

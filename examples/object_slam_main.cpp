@@ -22,6 +22,10 @@
 //   g++ -O2 -I include -I cube_slam_wu_amd/csrc examples/object_slam_main.cpp -L cube_slam_wu_amd -lcubeslam_hip ... -o build_tmp/object_slam_main
 //   build_tmp/object_slam_main <data_dir> <out_dir> [digits]
 //   build_tmp/object_slam_main --online <data_dir> <ppm_dir> <segments_dir | detect> <out_dir> [digits]
+//   build_tmp/object_slam_main --g2o <in.g2o> <out.g2o> [iterations = 5] [digits = 17]
+// Either run also writes <out_dir>/graph.g2o: the whole graph (final estimates, every edge) in g2o's text format -- examples/g2o_text.h
+// (OptimizableGraph::save, core/optimizable_graph.h:594-606, with the classes' own write() field order).  --g2o reads such a file back
+// (OptimizableGraph::load), runs cs_ba_optimize over it (0 iterations: no device is touched) and saves the result.
 // (segments_dir: one NNNN.txt per frame; the literal `detect`: the segments come from cs_detect_lines_gray, the reference's
 // EDLines producer -- the whole online branch then runs image in, trajectory and object out, on the device)
 #include <cmath>
@@ -35,6 +39,7 @@
 
 #include "cs_se3.h"
 #include "cubeslam_hip.h"
+#include "g2o_text.h"
 
 using cs::Cube;
 using cs::Pose;
@@ -65,29 +70,8 @@ static Pose pose_from_vector7(const double* v) {
   return p;
 }
 
-// g2o::cuboid::fromMinimalVector (g2o_Object.h:37-42) with zyx_euler_to_quat (matrix_utils.cpp:19-33)
-static Cube cuboid_from_minimal(const double* v) {
-  const double roll = v[3], pitch = v[4], yaw = v[5];
-  const double sy = std::sin(yaw * 0.5), cy = std::cos(yaw * 0.5), sp = std::sin(pitch * 0.5), cp = std::cos(pitch * 0.5);
-  const double sr = std::sin(roll * 0.5), cr = std::cos(roll * 0.5);
-  Cube c;
-  c.pose.qw = cr * cp * cy + sr * sp * sy;
-  c.pose.qx = sr * cp * cy - cr * sp * sy;
-  c.pose.qy = cr * sp * cy + sr * cp * sy;
-  c.pose.qz = cr * cp * sy - sr * sp * cy;
-  for (int d = 0; d < 3; d++) { c.pose.t[d] = v[d]; c.scale[d] = v[6 + d]; }
-  cs::pose_normalize(c.pose);
-  return c;
-}
-
-// toMinimalVector (g2o_Object.h:137-143; SE3Quat::toXYZPRYVector se3quat.h:196-222)
-static void cuboid_to_minimal(const Cube& c, double* o) {
-  const double qx = c.pose.qx, qy = c.pose.qy, qz = c.pose.qz, qw = c.pose.qw;
-  for (int d = 0; d < 3; d++) { o[d] = c.pose.t[d]; o[6 + d] = c.scale[d]; }
-  o[3] = std::atan2(2 * (qw * qx + qy * qz), 1 - 2 * (qx * qx + qy * qy));
-  o[4] = std::asin(2 * (qw * qy - qz * qx));
-  o[5] = std::atan2(2 * (qw * qz + qx * qy), 1 - 2 * (qy * qy + qz * qz));
-}
+using g2o_text::cuboid_from_minimal;     // g2o::cuboid::fromMinimalVector / toMinimalVector (g2o_Object.h:37-42, 137-143): examples/g2o_text.h
+using g2o_text::cuboid_to_minimal;
 
 // transform_to / transform_from (g2o_Object.h:117-133): the pose moves, the half sizes stay
 static Cube cuboid_transform_to(const Cube& c, const Pose& Twc) { Cube r = c; r.pose = cs::pose_mul(cs::pose_inv(Twc), c.pose); return r; }
@@ -130,7 +114,34 @@ static Pose pose_from_euler_zyx(double roll, double pitch, double yaw, const dou
 
 #define CHECK(call) do { int st_ = (call); if (st_ != 0) { std::fprintf(stderr, "%s failed: %d\n", #call, st_); return 1; } } while (0)
 
+static int run_g2o_file(const char* in, const char* out, int iterations, int digits) {
+  g2o_text::Graph g;
+  std::string warnings;
+  if (!g2o_text::load(in, g, &warnings)) { std::fprintf(stderr, "cannot read %s\n", in); return 1; }
+  if (!warnings.empty()) std::cerr << warnings;
+  std::cout << "loaded " << g.cam_id.size() << " cameras, " << g.cub_id.size() << " cuboids, " << g.ce_cam.size() << " camera-cuboid edges, " << g.oe_i.size() << " odometry edges" << std::endl;
+  if (iterations > 0) {
+    cs_ba* ba = nullptr;
+    CHECK(cs_ba_create(0, &ba));
+    CHECK(cs_ba_set_vertices(ba, g.cam_Tcw.data(), g.cam_fixed.data(), (int)g.cam_id.size(), g.cuboids.data(), g.cub_fixed.data(), (int)g.cub_id.size(), nullptr, nullptr, 0,
+                             !g.cub_id.empty() && !g.cam_id.empty() && g.cub_id[0] < g.cam_id[0]));
+    if (!g.ce_cam.empty()) CHECK(cs_ba_set_edges_cuboid(ba, (int)g.ce_cam.size(), g.ce_cam.data(), g.ce_cub.data(), g.ce_meas.data(), g.ce_info.data()));
+    if (!g.oe_i.empty()) CHECK(cs_ba_set_edges_odom(ba, (int)g.oe_i.size(), g.oe_i.data(), g.oe_j.data(), g.oe_meas.data(), g.oe_info.data()));
+    int done = 0;
+    CHECK(cs_ba_optimize(ba, iterations, &done, nullptr, nullptr, nullptr, 0));
+    CHECK(cs_ba_get_state(ba, g.cam_Tcw.data(), g.cuboids.data(), nullptr));
+    cs_ba_destroy(ba);
+    std::cout << "LM iterations: " << done << std::endl;
+  }
+  if (!g2o_text::save(out, g, digits)) { std::fprintf(stderr, "cannot write %s\n", out); return 1; }
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "--g2o") {
+    if (argc < 4) { std::fprintf(stderr, "usage: %s --g2o <in.g2o> <out.g2o> [iterations] [digits]\n", argv[0]); return 2; }
+    return run_g2o_file(argv[2], argv[3], argc > 4 ? std::atoi(argv[4]) : 5, argc > 5 ? std::atoi(argv[5]) : 17);
+  }
   const bool online_detect_mode = argc > 1 && std::string(argv[1]) == "--online";
   if ((!online_detect_mode && argc < 3) || (online_detect_mode && argc < 6)) {
     std::fprintf(stderr, "usage: %s <data_dir> <out_dir> [digits]\n       %s --online <data_dir> <ppm_dir> <segments_dir | detect> <out_dir> [digits]\n", argv[0], argv[0]);
@@ -296,6 +307,15 @@ int main(int argc, char** argv) {
   if (ba) cs_ba_destroy(ba);
   std::cout << "+++++++++++++Finish all optimization!+++++++++++++  LM iterations: " << total_iterations << std::endl;
 
+  {   // the graph itself, g2o text (vertex ids as the reference assigns them: the object 0, camera of frame f: f + 1, main_obj.cpp:529-575)
+    g2o_text::Graph g;
+    g.cub_id.push_back(0); g.cub_fixed.push_back(0); g.cuboids.assign(cube10, cube10 + 10);
+    for (int i = 0; i < total_frame_number; i++) g.cam_id.push_back(i + 1);
+    g.cam_Tcw = cam_Tcw; g.cam_fixed = cam_fixed;
+    g.ce_cam = ce_cam; g.ce_cub = ce_cub; g.ce_meas = ce_meas; g.ce_info = ce_info;
+    g.oe_i = oe_i; g.oe_j = oe_j; g.oe_meas = oe_meas; g.oe_info = oe_info;
+    if (!g2o_text::save(out_folder + "graph.g2o", g, 17)) { std::fprintf(stderr, "cannot write %sgraph.g2o\n", out_folder.c_str()); return 1; }
+  }
   {
     const std::string path = out_folder + "output_cam_poses.txt";
     FILE* f = std::fopen(path.c_str(), "w");

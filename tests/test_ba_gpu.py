@@ -415,6 +415,80 @@ def test_online_run_on_the_device_reproduces_the_references_saved_outputs():
         d.close()
 
 
+def _read_g2o(path):
+    """g2o text -> {tag: list of float rows}; FIX ids in a set."""
+    rows, fixed = {}, set()
+    for line in open(path):
+        tok = line.split()
+        if not tok or tok[0].startswith("#"):
+            continue
+        if tok[0] == "FIX":
+            fixed.update(int(t) for t in tok[1:])
+        else:
+            rows.setdefault(tok[0], []).append([float(t) for t in tok[1:]])
+    return {k: np.array(v) for k, v in rows.items()}, fixed
+
+
+def test_graph_driver_g2o_text_round_trip_on_the_58_frame_graph(tmp_path):
+    """g2o's text format for the driver's graph (examples/g2o_text.h: OptimizableGraph::save / load, core/optimizable_graph.h:594-606, with the
+    field order of VertexSE3Expmap / VertexCuboid / EdgeSE3Expmap::write).  The offline run leaves graph.g2o (58 cameras, the object, 57
+    odometry edges, the camera-object edges); `--g2o in out 0` reads it back and writes it again: the same numbers; `--g2o in out 5`
+    optimises the loaded graph on the device: the same five LM iterations as the graph built through the Python binding from the file's
+    numbers, and -- the run having converged -- no visible change of the saved estimates."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "build_tmp", "object_slam_main")
+    if not os.path.exists(exe):
+        import __graft_entry__
+        __graft_entry__.build()
+    out = subprocess.run([exe, DATA, str(tmp_path), "12"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    g, fixed = _read_g2o(tmp_path / "graph.g2o")
+    assert g["VERTEX_SE3:EXPMAP"].shape == (58, 8) and g["VERTEX_CUBOID"].shape == (1, 10) and g["EDGE_SE3:EXPMAP"].shape == (57, 2 + 7 + 21)
+    assert g["EDGE_SE3_CUBOID"].shape[1] == 2 + 9 + 45 and 40 < len(g["EDGE_SE3_CUBOID"]) <= 58 and fixed == {1}
+    # the camera lines are camera-to-world, as VertexSE3Expmap::write has them: the result file's poses
+    cams = np.loadtxt(tmp_path / "output_cam_poses.txt")
+    assert np.abs(g["VERTEX_SE3:EXPMAP"][:, 1:] - cams[:, 1:]).max() < 1e-11
+    assert np.abs(g["VERTEX_CUBOID"][0, 1:] - np.loadtxt(tmp_path / "output_obj_poses.txt")[-1]).max() < 1e-11
+    # read + write without optimising: the same file up to the Euler <-> quaternion round trip of the cuboid lines
+    out = subprocess.run([exe, "--g2o", str(tmp_path / "graph.g2o"), str(tmp_path / "again.g2o"), "0"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "loaded 58 cameras, 1 cuboids" in out.stdout, out.stdout + out.stderr
+    g2, fixed2 = _read_g2o(tmp_path / "again.g2o")
+    assert fixed2 == fixed and sorted(g2) == sorted(g)
+    for k in g:
+        assert g2[k].shape == g[k].shape and np.abs(g2[k] - g[k]).max() < 1e-12, k
+    # optimise the loaded graph: equal to the same graph handed to the library through the Python binding
+    out = subprocess.run([exe, "--g2o", str(tmp_path / "graph.g2o"), str(tmp_path / "opt.g2o"), "5"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    g3, _ = _read_g2o(tmp_path / "opt.g2o")
+    assert np.abs(g3["VERTEX_SE3:EXPMAP"] - g["VERTEX_SE3:EXPMAP"]).max() < 1e-4 and np.abs(g3["VERTEX_CUBOID"] - g["VERTEX_CUBOID"]).max() < 1e-4
+    from scipy.spatial.transform import Rotation
+    def inv7(v):     # camera-to-world line -> world-to-camera estimate
+        R = Rotation.from_quat(v[:, 3:7]); t = -R.inv().apply(v[:, :3]); q = R.inv().as_quat()
+        q = np.where(q[:, 3:4] < 0, -q, q)
+        return np.concatenate([t, q], axis=1)
+    def cub10(m):    # minimal vector -> pose + half sizes
+        q = Rotation.from_euler("ZYX", m[:, [5, 4, 3]]).as_quat(); q = np.where(q[:, 3:4] < 0, -q, q)
+        return np.concatenate([m[:, :3], q, m[:, 6:9]], axis=1)
+    def full(tri, n):
+        M = np.zeros((len(tri), n, n)); iu = np.triu_indices(n)
+        M[:, iu[0], iu[1]] = tri; M[:, iu[1], iu[0]] = tri
+        return M.reshape(len(tri), n * n)
+    ce, oe = g["EDGE_SE3_CUBOID"], g["EDGE_SE3:EXPMAP"]
+    pr = dict(cams=inv7(g["VERTEX_SE3:EXPMAP"][:, 1:]), cam_fixed=np.array([1] + [0] * 57), cuboids=cub10(g["VERTEX_CUBOID"][:, 1:]), cub_fixed=np.array([0]),
+              points=np.zeros((0, 3)), pt_fixed=np.zeros(0, int), e_pt=np.zeros(0, int), e_cam=np.zeros(0, int), e_uv=np.zeros((0, 2)), e_info=np.zeros((0, 4)),
+              e_intr=np.zeros((0, 4)), e_huber=np.zeros(0),
+              ce_cam=ce[:, 0].astype(int) - 1, ce_cub=ce[:, 1].astype(int), ce_meas=cub10(ce[:, 2:11]), ce_info=full(ce[:, 11:], 9),
+              oe_i=oe[:, 0].astype(int) - 1, oe_j=oe[:, 1].astype(int) - 1, oe_meas=inv7(oe[:, 2:9]), oe_info=full(oe[:, 9:], 6))
+    G = capi.ba_from_dict(pr, cuboids_first=True)
+    G.optimize(5)
+    cg, og, _ = G.state()
+    # (1e-5: the edges' numeric delta = 1e-9 Jacobians amplify the last-digit differences of the two Euler <-> quaternion conversions to ~1e-7)
+    assert np.abs(inv7(g3["VERTEX_SE3:EXPMAP"][:, 1:]) - cg).max() < 1e-5
+    assert np.abs(cub10(g3["VERTEX_CUBOID"][:, 1:]) - og).max() < 1e-5
+    G.close()
+
+
 def test_graph_driver_online_mode_from_images(tmp_path):
     """examples/object_slam_main.cpp --online: the reference's online branch in C++ on the C ABI -- colour image in
     (PPM copies of the reference's JPEGs), cs_bgr_to_gray, cs_detect_cuboids_gray with the roll/pitch sampling schedule of
