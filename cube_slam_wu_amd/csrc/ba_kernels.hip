@@ -375,16 +375,51 @@ __global__ __launch_bounds__(128, 3) void ba_cub_edge_kernel(BaView v) {
     const bool act = v.ce_active[k] != 0;  // sharded BA: the edge belongs to another rank -> zero blocks
     const bool fa = act && v.cam_col[v.ce_cam[k]] >= 0, fb = act && v.cub_col[v.ce_cub[k]] >= 0;
     double e1[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (d == 15) {
-      if (sgn == 0) cuboid_edge_error(T, cube, meas, e1);
-    } else if (d < 6) {
+    // Two phases.  (1) The unperturbed error: min_log_error's four yaw candidates on four lanes (h = 0 .. 3) instead of a loop on one;
+    // the norms meet through lane exchanges, the winner by the reference's rule (first minimum, strict <; g2o_Object.h:76-114).
+    // (2) The 30 perturbed evaluations: a 1e-9 step moves a candidate's norm by ~1e-7 at most, so where the winner leads the runner-up
+    // by more than 1e-3 (1 + norm) every perturbed evaluation has the same winner and computes THAT candidate only -- the same
+    // instructions on the same operands as the loop would run for it, hence the same bits; otherwise (a near tie: yaw near 45 degrees
+    // off with a square footprint) the full loop.  Two candidate evaluations per wavefront instead of four: 135 -> ~80 us at C4.
+    Cube esti0;
+    esti0.pose = pose_mul(pose_inv(T), meas.pose);
+    esti0.scale[0] = meas.scale[0]; esti0.scale[1] = meas.scale[1]; esti0.scale[2] = meas.scale[2];
+    double ec[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double nc = 0.0;
+    if (h < 4) nc = cube_log_error_candidate(cube, esti0, h, ec);
+    const int gbase = threadIdx.x & 32;          // first lane of this edge's 32 within the wavefront
+    double n4[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int lo = __shfl(__double2loint(nc), gbase + i), hi = __shfl(__double2hiint(nc), gbase + i); n4[i] = __hiloint2double(hi, lo); }
+    int win = 0;
+    double best_n = n4[0];
+#pragma unroll
+    for (int i = 1; i < 4; i++) if (n4[i] < best_n) { best_n = n4[i]; win = i; }
+    bool clear = best_n == best_n;               // (a NaN leader: the loop decides)
+#pragma unroll
+    for (int i = 0; i < 4; i++) if (i != win && !(n4[i] - best_n > 1e-3 * (1.0 + best_n))) clear = false;
+    // the unperturbed error: the winner's, fetched from the lane that holds it (every lane takes part in the exchange: an inactive
+    // source lane would read as zero)
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+      const int lo = __shfl(__double2loint(ec[r]), gbase + win), hi = __shfl(__double2hiint(ec[r]), gbase + win);
+      if (d == 15) e1[r] = __hiloint2double(hi, lo);
+    }
+    if (d < 6) {
       double add[6] = {0, 0, 0, 0, 0, 0};
       add[d] = step;
-      if (fa) cuboid_edge_error(cam_oplus(T, add), cube, meas, e1);
-    } else {
+      if (fa) {
+        const Pose Tp = cam_oplus(T, add);
+        if (clear) { Cube es; es.pose = pose_mul(pose_inv(Tp), meas.pose); es.scale[0] = meas.scale[0]; es.scale[1] = meas.scale[1]; es.scale[2] = meas.scale[2]; cube_log_error_candidate(cube, es, win, e1); }
+        else cuboid_edge_error(Tp, cube, meas, e1);
+      }
+    } else if (d < 15) {
       double add[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
       add[d - 6] = step;
-      if (fb) cuboid_edge_error(T, cube_oplus(cube, add), meas, e1);
+      if (fb) {
+        if (clear) cube_log_error_candidate(cube_oplus(cube, add), esti0, win, e1);
+        else cuboid_edge_error(T, cube_oplus(cube, add), meas, e1);
+      }
     }
     const bool on = d < 6 ? fa : fb;
 #pragma unroll
@@ -2271,14 +2306,16 @@ void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEv
   if (v.n_cub > v.n_cub3) hipLaunchKernelGGL(ba_cub_edge_kernel<false>, dim3((v.n_cub - v.n_cub3 + 3) / 4), dim3(128), 0, se, v);
   // (the odometry edges: a single short wave per four edges, 38 us of latency -- beside the cuboid edges on the main stream, not behind
   // them on the side stream, whose 135 us are the phase's critical path)
-  if (v.n_odom > 0) hipLaunchKernelGGL(ba_odom_edge_kernel, dim3((v.n_odom + 3) / 4), dim3(64), 0, st, v);
   if (side) (void)hipEventRecord(ev_join, st2);
   if (side3) {
     (void)hipStreamWaitEvent(st3, ev_fork, 0);
     hipLaunchKernelGGL(ba_lin_pt_kernel, dim3((v.np + LIN_PT_GROUP - 1) / LIN_PT_GROUP), dim3(256), 0, st3, v);
     (void)hipEventRecord(ev_join3, st3);
   }
+  // main stream: the camera sums first, the odometry edges behind them (round 5: in front of them, sharing the device with the cuboid
+  // edges, the ~250 short wavefronts of the odometry kernel waited for wave slots for 112 us and the camera sums started that late)
   if (v.n_proj > 0 || v.nc > 0) hipLaunchKernelGGL(ba_lin_cam_kernel, dim3(v.nc), dim3(256), 0, st, v);
+  if (v.n_odom > 0) hipLaunchKernelGGL(ba_odom_edge_kernel, dim3((v.n_odom + 3) / 4), dim3(64), 0, st, v);
   if (!side3 && v.np > 0) hipLaunchKernelGGL(ba_lin_pt_kernel, dim3((v.np + LIN_PT_GROUP - 1) / LIN_PT_GROUP), dim3(256), 0, st, v);
   if (side) (void)hipStreamWaitEvent(st, ev_join, 0);
   if (side3) (void)hipStreamWaitEvent(st, ev_join3, 0);
@@ -2293,8 +2330,11 @@ void ba_launch_reduce(const BaView& v, const double* lambda, hipStream_t st, hip
       (void)hipEventRecord(ev_fork, st);
       (void)hipStreamWaitEvent(st2, ev_fork, 0);
       hipLaunchKernelGGL(ba_cub_elim_kernel, dim3(v.no), dim3(256), 0, st2, v, lambda);
-      (void)hipEventRecord(ev_join, st2);
     }
+    // (the cuboid elimination must be dispatched BEFORE the bulk of the segments fills the device: started 18 us ahead -- behind the short
+    // kernel of the one- and two-camera segments below -- its 500 workgroups run 90 us beside the bulk; started together with it they
+    // queue for slots and take 200 us, whatever the stream priority.  Measured in round 5 by moving that short kernel to this stream.)
+    if (side) (void)hipEventRecord(ev_join, st2);
     // the diagonal blocks / right-hand side of the cameras need the segments' partial vectors; the gather of the blocks runs last
     // (it subtracts from entries the vertex kernels have written)
     {

@@ -217,6 +217,26 @@ CS_HD void cube_min_log_error(const Cube& self, const Cube& other, double* res) 
     }
   }
 }
+// one candidate of min_log_error: the error against `other` turned by yaw (i - 1) pi / 2, and its norm -- the loop body above, for callers
+// that know which candidate wins (ba_cub_edge_kernel: the perturbed evaluations of a numeric Jacobian take the unperturbed winner when
+// its lead over the runner-up is a hundred thousand times what a 1e-9 step can move a norm)
+CS_HD double cube_log_error_candidate(const Cube& self, const Cube& other, int i, double* e) {
+  // (the same constants as the loop above, by selects: a runtime index into a local array would live in scratch memory on the device)
+  Pose rot;
+  rot.t[0] = rot.t[1] = rot.t[2] = 0;
+  rot.qx = 0; rot.qy = 0;
+  rot.qz = i == 0 ? -0x1.6a09e667f3bccp-1 : (i == 1 ? 0.0 : (i == 2 ? 0x1.6a09e667f3bccp-1 : 1.0));
+  rot.qw = i == 0 ? 0x1.6a09e667f3bcdp-1 : (i == 1 ? 1.0 : (i == 2 ? 0x1.6a09e667f3bcdp-1 : 0x1.1a62633145c07p-54));
+  pose_normalize(rot);
+  Cube rc;
+  rc.pose = pose_mul(other.pose, rot);
+  const bool swap = i == 0 || i == 2;
+  rc.scale[0] = swap ? other.scale[1] : other.scale[0]; rc.scale[1] = swap ? other.scale[0] : other.scale[1]; rc.scale[2] = other.scale[2];
+  cube_log_error(self, rc, e);
+  double s = 0;
+  for (int k = 0; k < 9; k++) s += e[k] * e[k];
+  return sqrt(s);
+}
 // EdgeSE3Cuboid::computeError (g2o_Object.h:250-259)
 CS_HD void cuboid_edge_error(const Pose& Tcw, const Cube& cube, const Cube& meas, double* r) {
   Cube esti;
