@@ -721,7 +721,10 @@ def main():
                 im += np.where((xxq - rngq.uniform(0, Wq)) * np.cos(a) + (yyq - rngq.uniform(0, Hq)) * np.sin(a) > 0, rngq.uniform(-45, 45), 0)
             imgs.append(np.clip(im + rngq.normal(0, 4, im.shape), 0, 255).astype(np.uint8))
         batch_imgs = [imgs[i % len(imgs)] for i in range(args.lines_images)]
-        dl = capi.Detector(capi.default_params(host_threads=host_threads), device=local_rank)
+        # (the producer's own detector with the LIBRARY's default pool -- or the caller's --host-threads -- not the per-pipeline share of the
+        # path-A run above: rounds 3-4 passed that share, 12 threads, and read 12-13 ms per LSD batch where the call alone takes 8.3 --
+        # tools/lsd_busy_probe.py: the call does not care what else lives in the process, it scales with its pool up to ~32 threads)
+        dl = capi.Detector(capi.default_params(host_threads=args.host_threads), device=local_rank)
         dl.detect_lines_batch(batch_imgs, 15.0)
         t1 = time.perf_counter()
         reps = 20      # (a burst of pool work can run into the cgroup's CPU quota and stall for the rest of a 100 ms period: enough batches to see the sustained rate, the median beside the mean)

@@ -59,6 +59,8 @@ bool ba_bcr_sep_ok(int wm, int R);
 size_t ba_bcr_sep_workspace_doubles(int R);
 void ba_launch_bcr_sep(const double* msgs, size_t msg_doubles, int wm, int R, const int* sep_off, const int* sep_col, int ns, double* work, double* x, int* info, hipStream_t st);
 void ba_launch_sum2(const double* a, int na, const double* b, int nb, double* out, hipStream_t st);
+void ba_launch_sum2_flag(const double* a, int na, const double* b, int nb, const int* f0, const int* f1, double* out, hipStream_t st);
+void ba_launch_trial_prologue(double* d_lam, double lam0, double lam1, int* info24, int* elim_fail, double* rhs, int n_rhs, hipStream_t st);
 void ba_launch_ext_add(const BaView& v, const double* cam36, const double* cam6, const double* cub81, const double* cub9, const double* pt9, const double* pt3, hipStream_t st);
 void ba_launch_ext_offdiag(const BaView& v, int n, const int* e4, const double* Hij, hipStream_t st);
 void ba_launch_scan_finite(const double* p, long long n, int* out, hipStream_t st);
@@ -231,7 +233,7 @@ struct cs_ba {
   std::vector<int> cam_fixed, cub_fixed, pt_fixed, cam_col, cub_col, pt_lm;  // pt_lm: landmark index among free points or -1
   std::vector<int> cam_col_ref, cub_col_ref;  // columns in g2o's sort-by-id order (inspection only); cam_col / cub_col are in solver (RCM) order
   int band_ld = 0;                            // 0 = dense reduced system
-  bool use_bcr = false;                       // banded system solved by block cyclic reduction (bcr_kernels.hip) instead of the persistent banded kernels
+  bool use_bcr = false;
   int force_dense = 0;
   // sharded BA: landmarks (with all their projection edges) are dealt to ranks by the camera subsequence of their
   // first observation; cuboid / odometry edges follow their camera.  Every rank keeps all vertices.
@@ -1407,9 +1409,15 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
   *ok = true;
   if (B->sep_mode && B->shard_n > 1) return solve_device_sep(B, lambda, ok, fn, ctx, defer);
   if (n > 0) {
-    { int rcl = put_lambda(B, lambda); if (rcl) return rcl; }
+    const bool lean_head = B->band_ld > 0 && !B->sparse;      // (banded path: one prologue kernel instead of a copy and three fills)
+    if (lean_head) {
+      B->h_lam[0] = lambda; B->h_lam[1] = B->shard_rank == 0 ? lambda : 0.0;
+      cs::ba_launch_trial_prologue(B->d_lam.p, B->h_lam[0], B->h_lam[1], B->d_band_info.p, B->d_elim_fail.p, B->S.p + B->s_doubles, B->n_pose, B->st);
+    } else { int rcl = put_lambda(B, lambda); if (rcl) return rcl; }
     BA_TRY(hipEventRecord(B->ev[2], B->st));
-    if (B->sparse && B->sp_S_clean) {
+    if (lean_head) {
+      BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * B->s_doubles, B->st));
+    } else if (B->sparse && B->sp_S_clean) {
       // (sparse path: S was cleared by the structure phase and only the plan's pattern is ever written -- the pattern and the right-hand side)
       cs::launch_sparse_zero_pattern(sparse_view(B), B->S.p, B->st);
       BA_TRY(hipMemsetAsync(B->S.p + B->s_doubles, 0, sizeof(double) * B->n_pose, B->st));
@@ -1417,7 +1425,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (B->s_doubles + B->n_pose), B->st));
       B->sp_S_clean = B->sparse;
     }
-    BA_TRY(hipMemsetAsync(B->d_elim_fail.p, 0, sizeof(int), B->st));
+    if (!lean_head) BA_TRY(hipMemsetAsync(B->d_elim_fail.p, 0, sizeof(int), B->st));
     cs::ba_launch_reduce(B->view, B->d_lam.p, B->st, B->st2, B->ev_fork, B->ev_join);
     if (B->ext_n > 0 && B->ext_terms_set) cs::ba_launch_ext_offdiag(B->view, B->ext_n, B->d_ext_e4.p, B->ext_Hij.p, B->st);
     BA_TRY(hipMemcpyAsync(B->h_status + 1, B->d_elim_fail.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
@@ -1434,11 +1442,13 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       // pivot flag comes home with the single synchronisation (a failed factorisation just leaves garbage increments
       // that the caller discards)
       std::unique_lock<std::mutex> coop_turn(g_coop_mutex);
-      BA_TRY(hipMemsetAsync(B->d_band_info.p, 0, 24 * sizeof(int), B->st));
       if (B->use_bcr) cs::ba_launch_bcr(B->S.p, B->band_linv.p, n, B->band_ld, 128, B->view.rhs, B->d_band_info.p, B->st);
       else cs::ba_launch_band_cholesky(B->S.p, B->band_linv.p, n, B->band_ld, B->view.rhs, B->d_band_info.p, true, B->st);
       BA_TRY(hipGetLastError());
       BA_TRY(hipEventRecord(B->ev[4], B->st));
+      // (Round 5 tried clearing the band for the NEXT trial on the side stream here -- block cyclic reduction is done with it after its first
+      // level -- to take the 10 us fill off the head of a trial: the event record / wait / fill / record sequence stalled the host's enqueue of the
+      // kernels behind it by 35-60 us each, profiles/r5_ba_timeline_prezero.txt; the fill stays at the head.)
       cs::ba_launch_backsub(B->view, B->st);
       BA_TRY(hipGetLastError());
       if (fn && B->elim && B->shard_n > 1) {   // the callback waits for the other ranks: the persistent kernel's turn must be free by then
@@ -1448,8 +1458,8 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       { int rc2 = share_cuboid_increments(B, fn, ctx); if (rc2) return rc2; }
       BA_TRY(hipEventRecord(B->ev[5], B->st));
       BA_TRY(hipMemcpyAsync(B->h_status, B->d_band_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
-      cs::ba_launch_fail_flag(B->d_band_info.p, B->d_elim_fail.p, nullptr, B->d_scalars.p + 2, B->st);   // rides in the trial's scalar all-reduce
-      if (defer) { *defer = std::move(coop_turn); B->tm.n_solves++; return CS_OK; }
+      if (defer) { *defer = std::move(coop_turn); B->tm.n_solves++; return CS_OK; }   // (the caller's sum kernel folds the two status words into the trial's scalars)
+      cs::ba_launch_fail_flag(B->d_band_info.p, B->d_elim_fail.p, nullptr, B->d_scalars.p + 2, B->st);
       BA_TRY(hipStreamSynchronize(B->st));
       if (*B->h_status == 0x7fffffff) {   // a workgroup waited ~1 s for its team: the device is shared with another persistent kernel
         cs_set_error_ba("banded solver: team not co-resident (wait timed out); set CS_BA_FORCE_DENSE=1 on a shared device");
@@ -1631,14 +1641,7 @@ int cs_ba_create(int device, cs_ba** out) {
   { const char* e = getenv("CS_BA_FORCE_DENSE"); B->force_dense = (e && atoi(e)) ? 1 : 0; }  // diagnostics: rocSOLVER dense path
   BA_TRY(hipSetDevice(device));
   BA_TRY(hipStreamCreateWithFlags(&B->st, hipStreamNonBlocking));
-  {
-    // the side stream carries the latency-bound kernels that run BESIDE a device-filling one (the cuboid elimination beside the landmark
-    // segments' Schur products, the cuboid edges beside the projection edges): high priority, so that their few workgroups are placed as
-    // slots come free instead of queueing behind the bulk (measured at C4: ba_cub_elim_kernel 90 us with a head start, 202 us without)
-    int pr_lo = 0, pr_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
-    BA_TRY(hipStreamCreateWithPriority(&B->st2, hipStreamNonBlocking, pr_hi));
-  }
+  BA_TRY(hipStreamCreateWithFlags(&B->st2, hipStreamNonBlocking));   // (a high-priority side stream was measured in round 5: no effect on the kernels that run beside a device-filling one)
   BA_TRY(hipEventCreateWithFlags(&B->ev_fork, hipEventDisableTiming));
   BA_TRY(hipEventCreateWithFlags(&B->ev_join, hipEventDisableTiming));
   BA_TRY(hipStreamCreateWithFlags(&B->st3, hipStreamNonBlocking));
@@ -2172,7 +2175,8 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
           cs::ba_launch_update(B->view, B->st, B->cams_bak.p, B->points_bak.p, B->cubes_bak.p);
           BA_TRY(hipEventRecord(B->ev[6], B->st));
           cs::ba_launch_chi2(B->view, B->nb_chi, B->st);
-          cs::ba_launch_sum2(B->chi_partial.p, B->n_chi_partials, B->scale_partial.p, cs::ba_scale_blocks(), B->d_scalars.p, B->st);
+          if (B->sep_mode && B->shard_n > 1) cs::ba_launch_sum2(B->chi_partial.p, B->n_chi_partials, B->scale_partial.p, cs::ba_scale_blocks(), B->d_scalars.p, B->st);   // (separator mode set its flag itself: three status words)
+          else cs::ba_launch_sum2_flag(B->chi_partial.p, B->n_chi_partials, B->scale_partial.p, cs::ba_scale_blocks(), B->d_band_info.p, B->d_elim_fail.p, B->d_scalars.p, B->st);
           BA_TRY(hipGetLastError());
           if (rccl) BA_NCCL(ncclAllReduce(B->d_scalars.p, B->d_scalars.p, 3, ncclDouble, ncclSum, B->comm, B->st));
           BA_TRY(hipMemcpyAsync(B->h_scalars, B->d_scalars.p, 3 * sizeof(double), hipMemcpyDeviceToHost, B->st));

@@ -2481,6 +2481,38 @@ __global__ __launch_bounds__(256) void ba_sum2_kernel(const double* a, int na, c
 void ba_launch_sum2(const double* a, int na, const double* b, int nb, double* out, hipStream_t st) {
   hipLaunchKernelGGL(ba_sum2_kernel, dim3(1), dim3(256), 0, st, a, na, b, nb, out);
 }
+// the same with the trial's failure flag in out[2] (ba_fail_flag_kernel's job, one launch fewer at the end of a trial)
+__global__ __launch_bounds__(256) void ba_sum2_flag_kernel(const double* a, int na, const double* b, int nb, const int* f0, const int* f1, double* out) {
+  __shared__ double ws[2][4];
+  double sa = 0, sb = 0;
+  for (int i = threadIdx.x; i < na; i += 256) sa += a[i];
+  for (int i = threadIdx.x; i < nb; i += 256) sb += b[i];
+  sa = wave_sum(sa); sb = wave_sum(sb);
+  if ((threadIdx.x & 63) == 0) { ws[0][threadIdx.x >> 6] = sa; ws[1][threadIdx.x >> 6] = sb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = (ws[0][0] + ws[0][1]) + (ws[0][2] + ws[0][3]); out[1] = (ws[1][0] + ws[1][1]) + (ws[1][2] + ws[1][3]);
+    out[2] = ((f0 && *f0) || (f1 && *f1)) ? 1.0 : 0.0;
+  }
+}
+void ba_launch_sum2_flag(const double* a, int na, const double* b, int nb, const int* f0, const int* f1, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(ba_sum2_flag_kernel, dim3(1), dim3(256), 0, st, a, na, b, nb, f0, f1, out);
+}
+// Head of a trial on the banded path: lambda into device memory (the kernels read it from there), the factorisation's status words,
+// the cuboid elimination's failure word and the reduced system's right-hand side cleared -- one launch instead of a copy and three fills.
+__global__ __launch_bounds__(256) void ba_trial_prologue_kernel(double* d_lam, double lam0, double lam1, int* info24, int* elim_fail, double* rhs, int n_rhs) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < n_rhs) rhs[t] = 0.0;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 24) info24[threadIdx.x] = 0;
+    if (threadIdx.x == 24) *elim_fail = 0;
+    if (threadIdx.x == 25) d_lam[0] = lam0;
+    if (threadIdx.x == 26) d_lam[1] = lam1;
+  }
+}
+void ba_launch_trial_prologue(double* d_lam, double lam0, double lam1, int* info24, int* elim_fail, double* rhs, int n_rhs, hipStream_t st) {
+  hipLaunchKernelGGL(ba_trial_prologue_kernel, dim3((n_rhs + 255) / 256 + 1), dim3(256), 0, st, d_lam, lam0, lam1, info24, elim_fail, rhs, n_rhs);
+}
 void ba_launch_scale(const BaView& v, const double* lambda, double* partial, hipStream_t st) {
   hipLaunchKernelGGL(ba_scale_kernel, dim3(SCALE_BLOCKS), dim3(256), 0, st, v, lambda, partial);
 }
