@@ -1261,6 +1261,7 @@ int finalize_structure(cs_ba* B) {
   v.cam_ce_ptr = B->cam_ce_ptr.p; v.cam_ce_idx = B->cam_ce_idx.p; v.cam_oei_ptr = B->cam_oei_ptr.p; v.cam_oei_idx = B->cam_oei_idx.p;
   v.cam_oej_ptr = B->cam_oej_ptr.p; v.cam_oej_idx = B->cam_oej_idx.p; v.cub_ce_ptr = B->cub_ce_ptr.p; v.cub_ce_idx = B->cub_ce_idx.p;
   v.Hcam = B->Hcam.p; v.bcam = B->bcam.p; v.Hcub = B->Hcub.p; v.bcub = B->bcub.p; v.Hll = B->Hll.p; v.bl = B->bl.p; v.W = B->W.p; v.WD = B->WD.p;
+  v.fuse_lin = 0;
   v.Dinv = B->Dinv.p; v.dbl = B->dbl.p; v.S = B->S.p; v.band_ld = B->band_ld; v.lam_lo = B->sep_mode ? B->cut[B->shard_rank] : 0; v.lam_hi = B->sep_mode ? B->cut[B->shard_rank + 1] : (B->shard_rank == 0 ? 0x7fffffff : 0); v.rhs = B->S.p + B->s_doubles; v.xl = B->xl.p;
   v.n_pairs = B->n_pairs; v.pair_ptr = B->pair_ptr.p; v.pair_i1 = B->pair_i1.p; v.pair_i2 = B->pair_i2.p; v.ent_a = B->ent_a.p; v.ent_b = B->ent_b.p;
   v.fused = B->fused ? 1 : 0; v.n_seg = B->n_seg; for (int q = 0; q < 5; q++) v.seg_class[q] = B->seg_class[q];
@@ -2116,6 +2117,11 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
     if (!B->ext_terms_set) { cs_set_error_ba("external-edge callback did not call cs_ba_set_external_terms"); return CS_ERR_NOT_RUN; }
     return CS_OK;
   };
+  const bool fuse_lin_env = [] { const char* e = getenv("CS_BA_FUSE_LIN"); return !e || atoi(e) != 0; }();     // (read per call: the tests hold the two paths to each other in one process)
+  const bool fuse_lin_ok = fuse_lin_env && stream_flow && B->fused && B->shard_n == 1 && !ext_active && B->n_proj > 0 &&
+                           B->n_seg == std::max(std::max(std::max(B->seg_class[0], B->seg_class[1]), std::max(B->seg_class[2], B->seg_class[3])), B->seg_class[4]) &&
+                           getenv("CS_BA_DEBUG_NAN") == nullptr;
+  struct FuseLinGuard { cs_ba* b; ~FuseLinGuard() { b->view.fuse_lin = 0; } } fuse_lin_guard{B};   // (every other entry point linearises with the classic kernels)
   double lambda = -1, ni = 2;
   int nBad = 0, done = 0;
   double carriedChi = 0;
@@ -2136,6 +2142,10 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
       B->tm.errors_ms += now_ms() - t0;
     }
     double tempChi = currentChi, iniChi = currentChi;
+    // From the second iteration on the landmark side of the projection edges is linearised inside the trial's Schur kernels
+    // (ba_lin_schur_kernel: one pass over the edges, H_pl never read back); the first iteration needs H_ll for lambda's initial value
+    // before any trial.  Same bits either way (CS_BA_FUSE_LIN=0: the classic pair of kernels throughout).
+    B->view.fuse_lin = (it > 0 && fuse_lin_ok) ? 1 : 0;
     rc = build_system_device(B); if (rc) return rc;
     debug_nan_scan(B, "cs_ba_optimize: after the linearisation");
     if (it == 0) {  // computeLambdaInit (:166-180): tau * max |H_jj| over all non-fixed vertices, landmarks included

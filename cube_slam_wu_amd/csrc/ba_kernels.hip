@@ -763,6 +763,196 @@ __global__ __launch_bounds__(256) void ba_schur_fused_kernel(BaView v, const dou
   ba_schur_segment<MT>(v, lambda, seg, v.seg_k[seg]);
 }
 
+// ---- linearisation + Schur product in one pass over the projection edges (round 5) ------------------------------------------------
+// ba_lin_pt_kernel wrote every edge's H_pl block (163 MB at C4) for ba_schur_fused_kernel to read back two kernels later, and spent
+// 70-140 us of the linearisation phase doing so.  Here the segment's wavefront linearises its own edges -- a lane per edge, a chunk of
+// floor(64 / k) landmarks at a time (types_six_dof_expmap.cpp:148-184, base_binary_edge.hpp:54-120: the same proj_linearize and the
+// same products as ba_lin_pt_kernel, hence the same bits) -- keeps the blocks in LDS as the matrix-core operands, sums H_ll / b_l per
+// landmark in edge order, inverts the damped block once per landmark (not once per lane) and runs ba_schur_segment's products.  H_pl,
+// H_ll, b_l and D^-1 are still written, once, for the back-substitution (block_solver.hpp:457-482); nothing is read back.  A lane's
+// camera is its slot's -- the same for every landmark of the segment -- so its pose and rotation matrix are loaded and formed once.
+// Used by cs_ba_optimize from the second iteration on (the first needs H_ll for lambda's initial value before any trial), on unsharded
+// graphs without long tracks or host-evaluated edges; the classic pair of kernels serves everything else and the inspection entries.
+enum { LS_PLANES = 18, LS_DCOLS = 16, LS_WAVE_DOUBLES = LS_PLANES * 64 + 12 * LS_DCOLS };   // 10.75 KB per wavefront: three workgroups per CU
+template <int MT>
+__device__ __forceinline__ void ba_lin_schur_segment(const BaView& v, double lambda, int seg, int k, double* lds) {
+  const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4, rows = 6 * k;
+  const int q0 = v.seg_ptr[seg], q1 = v.seg_ptr[seg + 1], n = q1 - q0;
+  double (*Wl)[64] = reinterpret_cast<double (*)[64]>(lds);                  // [18][edge of the chunk]
+  double (*Dl)[LS_DCOLS] = reinterpret_cast<double (*)[LS_DCOLS]>(lds + LS_PLANES * 64);   // [12][landmark of the chunk]: D^-1 (9), b_l (3)
+  int my_p = 0, my_e0 = 0;
+  if (q0 + lane < q1) { my_p = v.run_lm[q0 + lane]; my_e0 = v.pt_ptr[my_p]; }
+  ba_v4d acc[MT][MT];
+#pragma unroll
+  for (int t = 0; t < MT; t++)
+#pragma unroll
+    for (int u = 0; u < MT; u++) acc[t][u] = ba_v4d{0.0, 0.0, 0.0, 0.0};
+  const int C = min((int)LS_DCOLS, 64 / k);             // landmarks per chunk
+  const int lc = lane / k, sa_l = lane - lc * k;        // this lane's (landmark of the chunk, camera slot)
+  // the slot's camera: from the segment's first landmark
+  const int e_first = __builtin_amdgcn_readlane(my_e0, 0);
+  const int cam = v.pm_cam[e_first + (lc < C ? sa_l : 0)];
+  const Pose T = pose_load(v.cams + 7 * cam);
+  double R[9];
+  pose_rotmat(T, R);
+  const bool cam_free = v.cam_col[cam] >= 0;
+  // operand rows of this lane, per 16-row tile: row = 16 t + i = 6 a + r
+  int w_off[MT]; bool w_in[MT];
+#pragma unroll
+  for (int t = 0; t < MT; t++) {
+    const int row = 16 * t + i;
+    w_in[t] = row < rows;
+    const int rr = w_in[t] ? row : 0, a = rr / 6, r = rr - 6 * a;
+    w_off[t] = (3 * r) * 64 + a;                        // plane 3 r (+ c), edge a (+ l k)
+  }
+  const int k3 = kk < 3 ? kk : 0;
+  // an edge's record (point, measurement, information, intrinsics, kernel width): requested one chunk ahead, with clamped
+  // indices -- every load unconditional, so that the requests of the next chunk are in flight under this chunk's products
+  struct EdgeRec { double X[3], uv[2], info[4], intr[4], huber; int p, e; };
+  auto fetch = [&](int c0) {
+    EdgeRec r;
+    const int ncl = min(C, n - c0);
+    const int src = (c0 < n && lc < ncl) ? c0 + lc : 0;
+    r.p = __shfl(my_p, src); r.e = __shfl(my_e0, src) + ((c0 < n && lc < ncl) ? sa_l : 0);
+#pragma unroll
+    for (int q = 0; q < 3; q++) r.X[q] = v.points[3 * (size_t)r.p + q];
+#pragma unroll
+    for (int q = 0; q < 2; q++) r.uv[q] = v.pm_uv[2 * (size_t)r.e + q];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { r.info[q] = v.pm_info[4 * (size_t)r.e + q]; r.intr[q] = v.pm_intr[4 * (size_t)r.e + q]; }
+    r.huber = v.pm_huber[r.e];
+    return r;
+  };
+  EdgeRec rec = fetch(0);
+  for (int c0 = 0; c0 < n; c0 += C) {
+    const int ncl = min(C, n - c0);
+    // ---- the chunk's edges, a lane each
+    double h9[9];          // this edge's J_p^T W J_p (upper triangle, 6) and J_p^T r (3)
+    const int p_edge = rec.p;
+    {
+      const int p = rec.p, e = rec.e;
+#pragma unroll
+      for (int q = 0; q < 9; q++) h9[q] = 0.0;
+      if (lc < ncl) {
+        ProjLin L;
+        proj_linearize(T, R, rec.X, rec.uv, rec.info, rec.intr, rec.huber, v.pm_rk, e, L);
+        double pw[6];  // Jp^T W (3x2)
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          pw[2 * q] = L.Jp[q] * L.Wm[0] + L.Jp[3 + q] * L.Wm[2];
+          pw[2 * q + 1] = L.Jp[q] * L.Wm[1] + L.Jp[3 + q] * L.Wm[3];
+        }
+        int o = 0;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+#pragma unroll
+          for (int j = q; j < 3; j++) h9[o++] = pw[2 * q] * L.Jp[j] + pw[2 * q + 1] * L.Jp[3 + j];
+          h9[6 + q] = L.Jp[q] * L.r[0] + L.Jp[3 + q] * L.r[1];
+        }
+        double* Wk = v.W + 18 * (size_t)e;
+        const bool both = cam_free && v.pt_free[p] != 0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+          const double jw0 = L.Jc[q] * L.Wm[0] + L.Jc[6 + q] * L.Wm[2];
+          const double jw1 = L.Jc[q] * L.Wm[1] + L.Jc[6 + q] * L.Wm[3];
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            const double w = both ? (jw0 * L.Jp[j] + jw1 * L.Jp[3 + j]) : 0.0;
+            Wk[3 * q + j] = w;
+            Wl[3 * q + j][lane] = w;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- per landmark: H_ll, b_l summed in edge order (the landmark's first lane collects its k edges' terms through lane exchanges:
+    // 0 + h_0 + h_1 + ..., the order and the bits of ba_lin_pt_kernel's loop); the damped block's inverse
+    {
+      double H[6], b[3];
+#pragma unroll
+      for (int q = 0; q < 6; q++) H[q] = h9[q];
+#pragma unroll
+      for (int q = 0; q < 3; q++) b[q] = h9[6 + q];
+      for (int a = 1; a < k; a++) {
+        const int from = (lane + a) & 63;
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+          const int lo = __shfl(__double2loint(h9[q]), from), hi = __shfl(__double2hiint(h9[q]), from);
+          const double t = __hiloint2double(hi, lo);
+          if (q < 6) H[q] += t; else b[q - 6] += t;
+        }
+      }
+      if (sa_l == 0 && lc < ncl) {
+        double* Hp = v.Hll + 9 * (size_t)p_edge;
+        Hp[0] = H[0]; Hp[1] = H[1]; Hp[2] = H[2]; Hp[3] = H[1]; Hp[4] = H[3]; Hp[5] = H[4]; Hp[6] = H[2]; Hp[7] = H[4]; Hp[8] = H[5];
+        v.bl[3 * (size_t)p_edge] = b[0]; v.bl[3 * (size_t)p_edge + 1] = b[1]; v.bl[3 * (size_t)p_edge + 2] = b[2];
+        double D[9] = {H[0], H[1], H[2], H[1], H[3], H[4], H[2], H[4], H[5]}, Di[9];
+        D[0] += lambda; D[4] += lambda; D[8] += lambda;
+        inv3x3(D, Di);
+#pragma unroll
+        for (int q = 0; q < 9; q++) { v.Dinv[9 * (size_t)p_edge + q] = Di[q]; Dl[q][lc] = Di[q]; }
+#pragma unroll
+        for (int q = 0; q < 3; q++) Dl[9 + q][lc] = b[q];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    rec = fetch(c0 + C);
+    // ---- the products, landmark by landmark (ba_schur_segment's, operands out of LDS)
+    for (int l = 0; l < ncl; l++) {
+      double Di[9];
+#pragma unroll
+      for (int q = 0; q < 9; q++) Di[q] = Dl[q][l];
+      const double blv = Dl[9 + k3][l];
+      double a[MT], bcol[MT];
+#pragma unroll
+      for (int t = 0; t < MT; t++) {
+        const double* wp = lds + w_off[t] + l * k;
+        const double x0 = wp[0], x1 = wp[64], x2 = wp[128];
+        const double w0 = w_in[t] ? x0 : 0.0, w1 = w_in[t] ? x1 : 0.0, w2 = w_in[t] ? x2 : 0.0;
+        const double wd = w0 * Di[k3] + w1 * Di[3 + k3] + w2 * Di[6 + k3];
+        a[t] = kk < 3 ? wd : 0.0;
+        const double wk = k3 == 0 ? w0 : (k3 == 1 ? w1 : w2);
+        bcol[t] = kk < 3 ? (w_in[t] ? wk : (16 * t + i == rows ? blv : 0.0)) : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int u = t; u < MT; u++) acc[t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bcol[u], acc[t][u], 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // flush: as ba_schur_segment
+  const int tile0 = v.seg_tile[seg], slot0 = v.seg_slot[seg];
+#pragma unroll
+  for (int t = 0; t < MT; t++)
+#pragma unroll
+    for (int u = t; u < MT; u++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int Rr = 16 * t + (lane >> 4) + 4 * g, Cc = 16 * u + (lane & 15);
+        if (Rr >= rows) continue;
+        const int sa = Rr / 6, r = Rr - 6 * sa;
+        const double val = acc[t][u][g];
+        if (Cc < rows) {
+          const int sb = Cc / 6, c = Cc - 6 * sb;
+          if (sa < sb || (sa == sb && c >= r)) v.part_tiles[36 * (size_t)(tile0 + sa * k - sa * (sa - 1) / 2 + (sb - sa)) + 6 * r + c] = val;
+        } else if (Cc == rows) {
+          v.part_coef[6 * (size_t)(slot0 + sa) + r] = val;
+        }
+      }
+}
+template <int MT>
+__global__ __launch_bounds__(256) void ba_lin_schur_kernel(BaView v, const double* __restrict__ lamp, int seg_begin, int seg_end) {
+  __shared__ double lds[4][LS_WAVE_DOUBLES];
+  const double lambda = lamp[0];
+  const int seg = __builtin_amdgcn_readfirstlane(seg_begin + blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (seg >= seg_end) return;
+  ba_lin_schur_segment<MT>(v, lambda, seg, v.seg_k[seg], lds[threadIdx.x >> 6]);
+}
+
 // Long tracks (BA_FUSED_KMAX < k <= BA_LONG_KMAX cameras: the tail of a real map, landmarks seen from dozens of key frames): the same
 // segment, the same partial blocks and vectors for the destination schedule, formed with plain multiply-adds -- a wavefront per
 // segment, its landmarks one after the other (such landmarks rarely share their camera set: usually one), W and W D^-1 of the landmark
@@ -2298,7 +2488,8 @@ void ba_launch_chi2(const BaView& v, int nb_proj, hipStream_t st) {
 // beside it on st3 and the numeric-Jacobian edges (cuboid, odometry) on st2; all meet before the per-vertex accumulation.
 void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, hipStream_t st3, hipEvent_t ev_join3) {
   const bool side = st2 != nullptr && v.n_cub > 0;
-  const bool side3 = st3 != nullptr && ev_join3 != nullptr && v.np > 0 && (v.n_proj > 0 || v.nc > 0);
+  const bool lin_pt = v.np > 0 && !v.fuse_lin;       // (fuse_lin: the Schur kernels of this iteration's trials linearise the landmark side themselves)
+  const bool side3 = st3 != nullptr && ev_join3 != nullptr && lin_pt && (v.n_proj > 0 || v.nc > 0);
   hipStream_t se = side ? st2 : st;
   if (side || side3) (void)hipEventRecord(ev_fork, st);
   if (side) (void)hipStreamWaitEvent(st2, ev_fork, 0);
@@ -2306,17 +2497,17 @@ void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEv
   if (v.n_cub > v.n_cub3) hipLaunchKernelGGL(ba_cub_edge_kernel<false>, dim3((v.n_cub - v.n_cub3 + 3) / 4), dim3(128), 0, se, v);
   // (the odometry edges: a single short wave per four edges, 38 us of latency -- beside the cuboid edges on the main stream, not behind
   // them on the side stream, whose 135 us are the phase's critical path)
+  // (the odometry edges behind the cuboid edges on the side stream: ~250 short wavefronts, 35 us; in front of the camera sums on the main
+  // stream -- rounds 3-4 -- they waited for wave slots beside the cuboid edges for 112 us, behind them they lengthen the main stream's chain)
+  if (v.n_odom > 0) hipLaunchKernelGGL(ba_odom_edge_kernel, dim3((v.n_odom + 3) / 4), dim3(64), 0, se, v);
   if (side) (void)hipEventRecord(ev_join, st2);
   if (side3) {
     (void)hipStreamWaitEvent(st3, ev_fork, 0);
     hipLaunchKernelGGL(ba_lin_pt_kernel, dim3((v.np + LIN_PT_GROUP - 1) / LIN_PT_GROUP), dim3(256), 0, st3, v);
     (void)hipEventRecord(ev_join3, st3);
   }
-  // main stream: the camera sums first, the odometry edges behind them (round 5: in front of them, sharing the device with the cuboid
-  // edges, the ~250 short wavefronts of the odometry kernel waited for wave slots for 112 us and the camera sums started that late)
   if (v.n_proj > 0 || v.nc > 0) hipLaunchKernelGGL(ba_lin_cam_kernel, dim3(v.nc), dim3(256), 0, st, v);
-  if (v.n_odom > 0) hipLaunchKernelGGL(ba_odom_edge_kernel, dim3((v.n_odom + 3) / 4), dim3(64), 0, st, v);
-  if (!side3 && v.np > 0) hipLaunchKernelGGL(ba_lin_pt_kernel, dim3((v.np + LIN_PT_GROUP - 1) / LIN_PT_GROUP), dim3(256), 0, st, v);
+  if (!side3 && lin_pt) hipLaunchKernelGGL(ba_lin_pt_kernel, dim3((v.np + LIN_PT_GROUP - 1) / LIN_PT_GROUP), dim3(256), 0, st, v);
   if (side) (void)hipStreamWaitEvent(st, ev_join, 0);
   if (side3) (void)hipStreamWaitEvent(st, ev_join3, 0);
   hipLaunchKernelGGL(ba_accum_pose_kernel, dim3(v.nc + v.no), dim3(128), 0, st, v, 0);
@@ -2340,12 +2531,20 @@ void ba_launch_reduce(const BaView& v, const double* lambda, hipStream_t st, hip
     {
       // (class boundaries are cumulative: a class without segments repeats the boundary before it)
       int c0 = v.seg_class[0], c1 = max(c0, v.seg_class[1]), c2 = max(c1, v.seg_class[2]), c3 = max(c2, v.seg_class[3]);
-      if (c0 > 0) hipLaunchKernelGGL(ba_schur_fused_kernel<1>, dim3((c0 + 3) / 4), dim3(256), 0, st, v, lambda, 0, c0);
-      if (c1 > c0) hipLaunchKernelGGL(ba_schur_fused_kernel<2>, dim3((c1 - c0 + 3) / 4), dim3(256), 0, st, v, lambda, c0, c1);
-      if (c2 > c1) hipLaunchKernelGGL(ba_schur_fused_kernel<3>, dim3((c2 - c1 + 3) / 4), dim3(256), 0, st, v, lambda, c1, c2);
-      if (c3 > c2) hipLaunchKernelGGL(ba_schur_fused_kernel<4>, dim3((c3 - c2 + 3) / 4), dim3(256), 0, st, v, lambda, c2, c3);
       const int c4 = max(c3, v.seg_class[4]);
-      if (c4 > c3) hipLaunchKernelGGL(ba_schur_fused_kernel<5>, dim3((c4 - c3 + 3) / 4), dim3(256), 0, st, v, lambda, c3, c4);
+      if (v.fuse_lin) {
+        if (c0 > 0) hipLaunchKernelGGL(ba_lin_schur_kernel<1>, dim3((c0 + 3) / 4), dim3(256), 0, st, v, lambda, 0, c0);
+        if (c1 > c0) hipLaunchKernelGGL(ba_lin_schur_kernel<2>, dim3((c1 - c0 + 3) / 4), dim3(256), 0, st, v, lambda, c0, c1);
+        if (c2 > c1) hipLaunchKernelGGL(ba_lin_schur_kernel<3>, dim3((c2 - c1 + 3) / 4), dim3(256), 0, st, v, lambda, c1, c2);
+        if (c3 > c2) hipLaunchKernelGGL(ba_lin_schur_kernel<4>, dim3((c3 - c2 + 3) / 4), dim3(256), 0, st, v, lambda, c2, c3);
+        if (c4 > c3) hipLaunchKernelGGL(ba_lin_schur_kernel<5>, dim3((c4 - c3 + 3) / 4), dim3(256), 0, st, v, lambda, c3, c4);
+      } else {
+        if (c0 > 0) hipLaunchKernelGGL(ba_schur_fused_kernel<1>, dim3((c0 + 3) / 4), dim3(256), 0, st, v, lambda, 0, c0);
+        if (c1 > c0) hipLaunchKernelGGL(ba_schur_fused_kernel<2>, dim3((c1 - c0 + 3) / 4), dim3(256), 0, st, v, lambda, c0, c1);
+        if (c2 > c1) hipLaunchKernelGGL(ba_schur_fused_kernel<3>, dim3((c2 - c1 + 3) / 4), dim3(256), 0, st, v, lambda, c1, c2);
+        if (c3 > c2) hipLaunchKernelGGL(ba_schur_fused_kernel<4>, dim3((c3 - c2 + 3) / 4), dim3(256), 0, st, v, lambda, c2, c3);
+        if (c4 > c3) hipLaunchKernelGGL(ba_schur_fused_kernel<5>, dim3((c4 - c3 + 3) / 4), dim3(256), 0, st, v, lambda, c3, c4);
+      }
       if (v.n_seg > c4) hipLaunchKernelGGL(ba_schur_long_kernel, dim3((v.n_seg - c4 + 3) / 4), dim3(256), 0, st, v, lambda, c4, v.n_seg);
     }
     if (side) (void)hipStreamWaitEvent(st, ev_join, 0);

@@ -80,6 +80,7 @@ struct BaView {
   // dimension, and writes k (k + 1) / 2 partial 6 x 6 blocks + k partial 6-vectors of W D^-1 b_l; per destination block / camera
   // the partials are then summed in a fixed order (gpair_* / gcam_*: the destination schedule).
   int fused;                    // 0 = pair-major path (ba_prep / ba_wd / ba_schur kernels)
+  int fuse_lin;                 // 1: the landmark side of the projection edges is linearised inside the Schur kernels (ba_lin_schur_kernel): ba_launch_linearize leaves ba_lin_pt_kernel out
   int n_seg; int seg_class[5];   // segments [0, seg_class[0]): k <= 2, then k <= 5, k <= 7, k <= 10, k <= 13 (one 16-row tile more per class), the rest: long tracks, k <= BA_LONG_KMAX
   const int* seg_ptr; const int* seg_k; const int* seg_tile; const int* seg_slot; const int* run_lm;
   double* part_tiles;           // 36 per partial block

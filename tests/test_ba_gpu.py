@@ -776,6 +776,31 @@ def test_three_lm_iterations_at_full_c4_size_against_the_oracle():
     G.close(); R.close()
 
 
+@pytest.mark.parametrize("views", [2, 4, 6, 9, 12])
+def test_fused_linearise_schur_kernel_equals_the_classic_pair_bitwise(views, monkeypatch):
+    """Round 5: from the second LM iteration on cs_ba_optimize linearises the landmark side of the projection edges INSIDE the Schur kernels
+    (ba_lin_schur_kernel<MT>: one pass over the edges, H_pl kept in LDS as the matrix-core operands) instead of ba_lin_pt_kernel +
+    ba_schur_fused_kernel<MT>.  Same proj_linearize, same sums in the same order, same products: the LM run must be BIT-identical to the
+    classic pair (CS_BA_FUSE_LIN=0) -- chi2 / lambda histories, trial counts and every state -- for tracks of up to 2 / 4 / 6 / 9 / 12 views
+    (the five tile-count instances), with Huber kernels on and fixed vertices in the graph."""
+    pr = synth_ba.make_problem(n_cams=120, n_points=6000, n_cuboids=20, seed=7 + views, obs_per_point=views)
+    runs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CS_BA_FUSE_LIN", flag)
+        G = capi.ba_from_dict(pr)
+        assert G.schur_layout()[0]
+        n = G.optimize(6)
+        runs.append((n, G.history(), G.state()))
+        G.close()
+    (n1, h1, s1), (n0, h0, s0) = runs
+    assert n1 == n0 >= 3
+    for a, b in zip(h1, h0):
+        assert np.array_equal(a, b)
+    for a, b in zip(s1, s0):
+        assert np.array_equal(a, b)
+    assert h1[0][-1] < 0.5 * h1[0][0]
+
+
 def test_cuboid_projection_edges_system_and_optimize_parity():
     """EdgeSE3CuboidProj (4-dim bounding-box error of the projected cuboid, numeric Jacobians) next to the other three
     edge types: linear system and a 6-iteration LM run against the oracle."""
