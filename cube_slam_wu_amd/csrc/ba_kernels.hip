@@ -1025,10 +1025,29 @@ __global__ __launch_bounds__(256) void ba_schur_long_kernel(BaView v, const doub
 // destination schedule, blocks: one wavefront per block of the reduced system sums the partial blocks written for it, in the
 // order of the segments (fixed: the result does not depend on scheduling), and subtracts the sum (block_solver.hpp:409-431)
 __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaView v) {
-  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (pair >= v.n_gpairs || lane >= 36) return;
+  const int pair = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  if (pair >= v.n_gpairs) return;
+  // (round 5: the partial blocks' indices are fetched 64 at a time, one per lane, and the blocks eight at a time -- all requests of a
+  // batch in flight together; the additions stay in the schedule's order.  One index load + one block load per term, each waiting for
+  // the one before, made this kernel 55 us of pure latency at C4.)
+  const int q0 = v.gpair_ptr[pair], nq = v.gpair_ptr[pair + 1] - q0;
+  const int l36 = lane < 36 ? lane : 0;
   double s = 0;
-  for (int q = v.gpair_ptr[pair]; q < v.gpair_ptr[pair + 1]; q++) s += v.part_tiles[36 * (size_t)v.gtile[q] + lane];
+  for (int base = 0; base < nq; base += 64) {
+    const int cnt = min(64, nq - base);
+    const int my_t = v.gtile[q0 + base + (lane < cnt ? lane : 0)];
+    for (int j = 0; j < cnt; j += 8) {
+      double x[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int tq = __builtin_amdgcn_readlane(my_t, min(j + u, cnt - 1));
+        x[u] = v.part_tiles[36 * (size_t)tq + l36];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) if (j + u < cnt) s += x[u];
+    }
+  }
+  if (lane >= 36) return;
   const int r = lane / 6, c = lane % 6;
   const int i1 = v.gpair_i1[pair], i2 = v.gpair_i2[pair];
   if (i1 != i2 || c >= r) *ba_S_at(v, i2 + c, i1 + r) -= s;
@@ -1040,10 +1059,22 @@ __global__ __launch_bounds__(64) void ba_cam_rhs_fused_kernel(BaView v, const do
   const int c = blockIdx.x, t = threadIdx.x;
   const int col = v.cam_col[c];
   if (col < 0) return;
-  if (t < 6) {
+  {
+    const int q0 = v.gcam_ptr[c], nq = v.gcam_ptr[c + 1] - q0;
+    const int t6 = t < 6 ? t : 0;
     double s = 0;
-    for (int q = v.gcam_ptr[c]; q < v.gcam_ptr[c + 1]; q++) s += v.part_coef[6 * (size_t)v.gslot[q] + t];
-    v.rhs[col + t] = v.bcam[6 * c + t] - s;
+    for (int base = 0; base < nq; base += 64) {       // (as ba_schur_gather_kernel: indices 64 at a time, vectors eight at a time, sums in order)
+      const int cnt = min(64, nq - base);
+      const int my_s = v.gslot[q0 + base + (t < cnt ? t : 0)];
+      for (int j = 0; j < cnt; j += 8) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = v.part_coef[6 * (size_t)__builtin_amdgcn_readlane(my_s, min(j + u, cnt - 1)) + t6];
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (j + u < cnt) s += x[u];
+      }
+    }
+    if (t < 6) v.rhs[col + t] = v.bcam[6 * c + t] - s;
   }
   if (t < 36) {
     const int i = t / 6, j = t % 6;
@@ -1160,6 +1191,8 @@ __global__ __launch_bounds__(64) void ba_cub_backsub_kernel(BaView v) {
   }
 }
 
+// (Round 5 tried the H_pl records as one coalesced stream through LDS, a lane per edge, the landmark's lane summing in edge order: 84 us
+// against 80 at C4 -- the 163 MB read is not what this kernel waits for -- and was dropped.)
 __global__ __launch_bounds__(256) void ba_backsub_kernel(BaView v) {
   int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= v.np) return;
