@@ -59,6 +59,7 @@ bool ba_bcr_sep_ok(int wm, int R);
 size_t ba_bcr_sep_workspace_doubles(int R);
 void ba_launch_bcr_sep(const double* msgs, size_t msg_doubles, int wm, int R, const int* sep_off, const int* sep_col, int ns, double* work, double* x, int* info, hipStream_t st);
 void ba_launch_sum2(const double* a, int na, const double* b, int nb, double* out, hipStream_t st);
+void ba_launch_multi_zero(const std::pair<void*, size_t>* list, int n, hipStream_t st);
 void ba_launch_sum2_flag(const double* a, int na, const double* b, int nb, const int* f0, const int* f1, double* out, hipStream_t st);
 void ba_launch_trial_prologue(double* d_lam, double lam0, double lam1, int* info24, int* elim_fail, double* rhs, int n_rhs, hipStream_t st);
 void ba_launch_ext_add(const BaView& v, const double* cam36, const double* cam6, const double* cub81, const double* cub9, const double* pt9, const double* pt3, hipStream_t st);
@@ -181,6 +182,13 @@ struct DBuf {
     n = count;
     if (st) BA_TRY(hipMemsetAsync(p, 0, std::max<size_t>(1, n) * sizeof(T), st));
     else BA_TRY(hipMemset(p, 0, std::max<size_t>(1, n) * sizeof(T)));
+    return CS_OK;
+  }
+  // zeroed like alloc(), but the fill is left to the caller's batched launch (cs::ba_launch_multi_zero): ptr / bytes are appended to the list
+  int alloc_deferred(size_t count, std::vector<std::pair<void*, size_t>>& zero_list) {
+    int rc = reserve(count); if (rc) return rc;
+    n = count;
+    zero_list.emplace_back((void*)p, std::max<size_t>(1, n) * sizeof(T));
     return CS_OK;
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; cap = 0; }
@@ -847,7 +855,17 @@ int finalize_structure(cs_ba* B) {
   B->n_lm = nl;
   int rc;
 #define UP(buf, vec) do { rc = (buf).upload_staged(vec, B->stage, B->st); if (rc) return rc; } while (0)
-#define AL(buf, n) do { rc = (buf).alloc(n, B->st); if (rc) return rc; } while (0)
+  // (the ~50 zero fills of a structure phase -- one hipMemsetAsync each, 4-6 us of host time apiece, a third of an appended frame's phase --
+  // are collected and go out as one kernel per group of up to 48 buffers: ZFLUSH() where the order against other device work matters)
+  std::vector<std::pair<void*, size_t>> zero_list;
+  auto zflush = [&]() -> int {
+    for (size_t i = 0; i < zero_list.size(); i += 48) cs::ba_launch_multi_zero(zero_list.data() + i, (int)std::min<size_t>(48, zero_list.size() - i), B->st);
+    zero_list.clear();
+    BA_TRY(hipGetLastError());
+    return CS_OK;
+  };
+#define AL(buf, n) do { rc = (buf).alloc_deferred(n, zero_list); if (rc) return rc; } while (0)
+#define ZFLUSH() do { rc = zflush(); if (rc) return rc; } while (0)
 #define UPB(buf, ub) do { rc = (buf).upload_ptr_staged((ub).data(), (ub).size(), B->stage, B->st); if (rc) return rc; } while (0)
   UP(B->d_cam_col, B->cam_col); UP(B->d_cub_col, B->cub_col); UP(B->d_pt_free, pt_free);
   { std::vector<int> e4(B->ext_e4); if (e4.empty()) e4.assign(4, 0); UP(B->d_ext_e4, e4); }
@@ -1024,7 +1042,7 @@ int finalize_structure(cs_ba* B) {
     if (ce_slot.empty()) ce_slot.push_back(-1);
     if (cub_tile.empty()) { cub_tile.push_back(0); cub_coef.push_back(0); }
     UP(B->d_cubS_ptr, cubS_ptr); UP(B->d_cubS_cam, cubS_cam); UP(B->d_ce_slot, ce_slot); UP(B->d_cub_tile, cub_tile); UP(B->d_cub_coef, cub_coef);
-    AL(B->cub_M, 54 * cubS_cam.size()); AL(B->cub_Dinv, 81 * (size_t)std::max(1, no)); AL(B->d_elim_fail, 1);
+    AL(B->cub_M, 54 * cubS_cam.size()); AL(B->cub_Dinv, 81 * (size_t)std::max(1, no)); AL(B->d_elim_fail, 1); ZFLUSH();
     B->n_seg = (int)seg_k.size();
     for (int sgi = 0; sgi < B->n_seg; sgi++) {   // segments are sorted by k
       if (seg_k[sgi] <= 2) B->seg_class[0] = sgi + 1;
@@ -1064,7 +1082,7 @@ int finalize_structure(cs_ba* B) {
     mark("  destination lists");
     UP(B->d_run_lm, run_lm); UP(B->d_seg_ptr, seg_ptr); UP(B->d_seg_k, seg_k); UP(B->d_seg_tile, seg_tile); UP(B->d_seg_slot, seg_slot);
     UP(B->d_gp_ptr, gp_ptr); UP(B->d_gp_i1, gp_i1); UP(B->d_gp_i2, gp_i2); UP(B->d_gtile, gtile); UP(B->d_gcam_ptr, gcam_ptr); UP(B->d_gslot, gslot);
-    AL(B->part_tiles, 36 * (size_t)n_tiles); AL(B->part_coef, 6 * (size_t)n_slots);
+    AL(B->part_tiles, 36 * (size_t)n_tiles); AL(B->part_coef, 6 * (size_t)n_slots); ZFLUSH();
     B->n_pairs = 0;
     std::vector<int> none(1, 0);
     UP(B->pair_ptr, none); UP(B->pair_i1, none); UP(B->pair_i2, none); UP(B->ent_a, none); UP(B->ent_b, none);
@@ -1100,11 +1118,11 @@ int finalize_structure(cs_ba* B) {
     std::vector<int> none(1, 0);
     UP(B->d_run_lm, none); UP(B->d_seg_ptr, none); UP(B->d_seg_k, none); UP(B->d_seg_tile, none); UP(B->d_seg_slot, none);
     UP(B->d_gp_ptr, none); UP(B->d_gp_i1, none); UP(B->d_gp_i2, none); UP(B->d_gtile, none); UP(B->d_gcam_ptr, none); UP(B->d_gslot, none);
-    AL(B->part_tiles, 1); AL(B->part_coef, 1);
+    AL(B->part_tiles, 1); AL(B->part_coef, 1); ZFLUSH();
     std::vector<int> zp(no + 1, 0);
     UP(B->d_slotE_ptr, none); UP(B->d_slotE_idx, none);
     UP(B->d_cubS_ptr, zp); UP(B->d_cubS_cam, none); UP(B->d_ce_slot, none); UP(B->d_cub_tile, none); UP(B->d_cub_coef, none);
-    AL(B->cub_M, 1); AL(B->cub_Dinv, 1); AL(B->d_elim_fail, 1);
+    AL(B->cub_M, 1); AL(B->cub_Dinv, 1); AL(B->d_elim_fail, 1); ZFLUSH();
   }
   mark("Schur schedule");
   // ---- cuboid / odometry edges and their vertex adjacency
@@ -1270,7 +1288,8 @@ int finalize_structure(cs_ba* B) {
   v.n_gpairs = B->n_gpairs; v.gpair_ptr = B->d_gp_ptr.p; v.gpair_i1 = B->d_gp_i1.p; v.gpair_i2 = B->d_gp_i2.p; v.gtile = B->d_gtile.p;
   v.gcam_ptr = B->d_gcam_ptr.p; v.gslot = B->d_gslot.p;
   v.chi_partial = B->chi_partial.p;
-  // the allocations above were zeroed on B->st (queued, one wait here); uploads went through blocking copies
+  // the allocations above are zeroed on B->st (one batched fill, one wait here); uploads went through blocking copies
+  ZFLUSH();
   BA_TRY(hipStreamSynchronize(B->st));
   mark("pose edges + allocations");
   B->structure_dirty = false;

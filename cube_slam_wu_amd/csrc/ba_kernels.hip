@@ -21,7 +21,9 @@
 // All FP64.  No atomics on the data path except the (unique-pair) off-diagonal pose blocks.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
+#include <utility>
 
 #include "ba_types.h"
 #include "band_potf2.h"
@@ -2729,6 +2731,30 @@ __global__ __launch_bounds__(256) void ba_sum2_flag_kernel(const double* a, int 
 }
 void ba_launch_sum2_flag(const double* a, int na, const double* b, int nb, const int* f0, const int* f1, double* out, hipStream_t st) {
   hipLaunchKernelGGL(ba_sum2_flag_kernel, dim3(1), dim3(256), 0, st, a, na, b, nb, f0, f1, out);
+}
+// up to 48 buffers zeroed by one launch (the structure phase's allocations): blockIdx.y = buffer, 4-byte words
+struct BaZeroList { unsigned* p[48]; unsigned long long words[48]; };
+__global__ __launch_bounds__(256) void ba_multi_zero_kernel(BaZeroList L) {
+  unsigned* __restrict__ p = L.p[blockIdx.y];
+  const unsigned long long n = L.words[blockIdx.y];
+  // 16 bytes per thread and step where the buffer allows it (hipMalloc aligns to 256 bytes)
+  const unsigned long long n4 = n / 4;
+  uint4* __restrict__ p4 = reinterpret_cast<uint4*>(p);
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (unsigned long long)gridDim.x * 256) p4[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3ull)) p[4 * n4 + threadIdx.x] = 0u;
+}
+void ba_launch_multi_zero(const std::pair<void*, size_t>* list, int n, hipStream_t st) {
+  if (n <= 0) return;
+  BaZeroList L;
+  unsigned long long mx = 0;
+  for (int i = 0; i < 48; i++) {
+    const int q = i < n ? i : 0;
+    L.p[i] = static_cast<unsigned*>(list[q].first);
+    L.words[i] = i < n ? (list[q].second + 3) / 4 : 0;          // (every buffer's size is a multiple of 4 bytes: int and double elements)
+    if (L.words[i] > mx) mx = L.words[i];
+  }
+  unsigned gx = (unsigned)std::min<unsigned long long>(512, (mx / 4 + 255) / 256 + 1);
+  hipLaunchKernelGGL(ba_multi_zero_kernel, dim3(gx, n), dim3(256), 0, st, L);
 }
 // Head of a trial on the banded path: lambda into device memory (the kernels read it from there), the factorisation's status words,
 // the cuboid elimination's failure word and the reduced system's right-hand side cleared -- one launch instead of a copy and three fills.
