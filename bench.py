@@ -351,11 +351,13 @@ def main():
             ba_out = {"metric": "BA LM iterations/sec", "value": n_it / ba_el, "unit": "iters/s", "config": args.ba, "cams": nc, "points": npt, "cuboids": no,
                       "projection_edges": int(len(pr["e_pt"])), "iterations": int(n_it), "lm_trials": int(nsol), "sharding": sharding,
                       "ms_per_iteration": ba_el / max(1, n_it) * 1e3,
+                      "reduced_solve": (lambda pth, bo: {"path": pth[0], "unknowns": P.reduced_size()[0], "bandwidth": pth[1], "block_cyclic_reduction": bo[0], "levels": bo[1],
+                                                         "what": "block cyclic reduction over blocks of 128 unknowns (bcr_kernels.hip)" if bo[0] else "see cs_ba_solver_path"})(P.solver_path(detail=True), P.band_order()),
                       "structure_ms": structure_ms,
                       "value_including_structure": n_it / (ba_el + structure_ms * 1e-3),
                       "stage_ms_per_iteration": {k: v / max(1, n_it) for k, v in d.items()},
                       "build_only_ms_per_iteration": (d["linearize_ms"] + d["reduce_ms"] + d["errors_ms"]) / max(1, n_it),
-                      "roofline": {"kernels": "linearise (ba_lin_*, ba_*_edge) + Schur build (ba_prep, ba_cam_rhs, ba_schur*)", "bound": "hbm",
+                      "roofline": {"kernels": "linearise (ba_lin_cam, ba_*_edge) + Schur build with the landmark side linearised inside it (ba_lin_schur, ba_cam_rhs, ba_schur_gather, ba_cub_elim)", "bound": "hbm",
                                    "achieved": tm["linearize_bytes"] / (build_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": tm["linearize_bytes"] / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_linearisation": tm["linearize_bytes"],
                                    "ms_linearise_plus_schur": build_ms}}

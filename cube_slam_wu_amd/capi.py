@@ -398,7 +398,7 @@ DECLARED_SYMBOLS += [
     "cs_ba_create", "cs_ba_destroy", "cs_ba_set_vertices", "cs_ba_set_estimates", "cs_ba_set_edges_proj", "cs_ba_set_edges_cuboid", "cs_ba_set_edges_cuboid_proj", "cs_ba_set_edges_odom",
     "cs_ba_compute_errors", "cs_ba_build_system", "cs_ba_solve", "cs_ba_update", "cs_ba_push", "cs_ba_pop", "cs_ba_optimize",
     "cs_ba_get_state", "cs_ba_sizes", "cs_ba_solver_layout", "cs_ba_get_system", "cs_ba_last_timing", "cs_ba_set_shard", "cs_ba_optimize_sharded",
-    "cs_ba_shard_landmark_owners", "cs_ba_get_landmark_owners", "cs_ba_shard_info", "cs_ba_shard_timing", "cs_ba_append_vertices", "cs_ba_append_edges_proj", "cs_ba_append_edges_cuboid", "cs_ba_append_edges_cuboid_proj", "cs_ba_append_edges_odom", "cs_ba_get_vertex_hessians", "cs_ba_schur_layout", "cs_ba_structure_digest", "cs_ba_reduced_size", "cs_ba_solver_path", "cs_ba_comm_unique_id", "cs_ba_comm_init", "cs_ba_set_robust_kernels",
+    "cs_ba_shard_landmark_owners", "cs_ba_get_landmark_owners", "cs_ba_shard_info", "cs_ba_shard_timing", "cs_ba_append_vertices", "cs_ba_append_edges_proj", "cs_ba_append_edges_cuboid", "cs_ba_append_edges_cuboid_proj", "cs_ba_append_edges_odom", "cs_ba_get_vertex_hessians", "cs_ba_schur_layout", "cs_ba_structure_digest", "cs_ba_reduced_size", "cs_ba_solver_path", "cs_ba_band_order", "cs_ba_comm_unique_id", "cs_ba_comm_init", "cs_ba_set_robust_kernels",
     "cs_ba_set_external_edges", "cs_ba_set_external_terms", "cs_ba_set_external_chi2", "cs_ba_set_external_callback", "cs_ba_check_finite", "cs_ba_dump", "cs_ba_load", "cs_ba_get_reduced_system",
 ]
 
@@ -572,6 +572,12 @@ class BaProblem:
         a, b = C.c_int(), C.c_int()
         _chk(lib().cs_ba_reduced_size(self.h, C.byref(a), C.byref(b)), "cs_ba_reduced_size")
         return a.value, bool(b.value)
+
+    def band_order(self):
+        """(block cyclic reduction?, levels) of a banded reduced system -- cs_ba_band_order."""
+        a, b = C.c_int(0), C.c_int(0)
+        _chk(lib().cs_ba_band_order(self.h, C.byref(a), C.byref(b)), "cs_ba_band_order")
+        return bool(a.value), b.value
 
     def solver_path(self, detail=False):
         """'band' / 'sparse' / 'dense': the factorisation the reduced system takes (cs_ba_solver_path); detail: (path, bandwidth, sparse fill)."""

@@ -2493,6 +2493,16 @@ int cs_ba_reduced_size(cs_ba* B, int* n_reduced, int* cuboids_eliminated) {
   BA_GUARD_END("cs_ba_reduced_size")
 }
 
+int cs_ba_band_order(cs_ba* B, int* block_cyclic_reduction, int* levels) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  BA_GUARD_BEGIN
+  int rc = finalize_structure(B); if (rc) return rc;
+  const bool bcr = B->band_ld > 0 && B->use_bcr;
+  if (block_cyclic_reduction) *block_cyclic_reduction = bcr ? 1 : 0;
+  if (levels) { int L = 0; for (int N = (B->n_red + 127) / 128; bcr && N >= 1; N /= 2) L++; *levels = L; }
+  return CS_OK;
+  BA_GUARD_END("cs_ba_band_order")
+}
 int cs_ba_solver_path(cs_ba* B, int* path, int* bandwidth, double* sparse_fill) {
   if (!B) return CS_ERR_INVALID_ARG;
   BA_GUARD_BEGIN

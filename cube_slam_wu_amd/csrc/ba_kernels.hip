@@ -851,6 +851,11 @@ __device__ __forceinline__ void ba_lin_schur_segment(const BaView& v, double lam
           for (int j = q; j < 3; j++) h9[o++] = pw[2 * q] * L.Jp[j] + pw[2 * q + 1] * L.Jp[3 + j];
           h9[6 + q] = L.Jp[q] * L.r[0] + L.Jp[3 + q] * L.r[1];
         }
+        // (H_pl goes out as 18 eight-byte stores per lane.  Round 5 measured the alternative -- the chunk's records through LDS as runs of 18 k
+        // contiguous doubles, 64 consecutive doubles per store instruction --: the same HBM traffic by the counters (251 MB read, 227 MB written per
+        // launch at C4: L2 merges the partial lines either way) and a kernel 7 % slower for the index arithmetic; dropped.  What the kernel
+        // over-fetches is its INPUT: a landmark's k edge records are 80 / 160 bytes in a stream ordered by landmark id, and the landmarks of a
+        // segment are not neighbours in it.)
         double* Wk = v.W + 18 * (size_t)e;
         const bool both = cam_free && v.pt_free[p] != 0;
 #pragma unroll

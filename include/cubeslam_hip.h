@@ -395,6 +395,11 @@ int cs_ba_reduced_size(cs_ba* ba, int* n_reduced, int* cuboids_eliminated);
  * CS_BA_SPARSE=0 / 1 (never / whenever the plan fits) override the choice.                                                             */
 typedef enum { CS_BA_PATH_DENSE = 0, CS_BA_PATH_BAND = 1, CS_BA_PATH_SPARSE = 2 } cs_ba_solver_path_kind;
 int cs_ba_solver_path(cs_ba* ba, int* path, int* bandwidth, double* sparse_fill);
+/* How a CS_BA_PATH_BAND system is eliminated (round 5): *block_cyclic_reduction = 1: odd-even (nested dissection) order over blocks of 128
+ * unknowns, ceil(log2(n / 128 + 1)) levels of one 128-column factorisation each -- bcr_kernels.hip; bandwidth <= 128 and the levels cheaper than
+ * the persistent banded kernels' chain of 32-column steps (C4: 6 levels against 53 steps); 0: those kernels (wider bands, short systems).  *levels:
+ * the number of levels (0 otherwise).  CS_BAND_BCR=0 / 2 (environment): never / whenever the band allows it.                          */
+int cs_ba_band_order(cs_ba* ba, int* block_cyclic_reduction, int* levels);
 /* How the Schur complement S -= sum_j W_j D_j^-1 W_j^T (block_solver.hpp:385-431) is formed.  fused = 1: landmarks grouped by
  * camera set, one wavefront per segment of <= 32 landmarks, the product on the matrix cores (v_mfma_f64_16x16x4_f64) with the
  * landmarks as contraction dimension, n_partial_blocks partial 6x6 blocks summed per destination in a fixed order; fused = 0

@@ -765,6 +765,7 @@ def test_three_lm_iterations_at_full_c4_size_against_the_oracle():
     pr = synth_ba.make_problem(n_cams=1000, n_points=200000, n_cuboids=500, seed=42)
     G, R = capi.ba_from_dict(pr), _oracle(pr)
     assert G.sizes() == (6 * 999 + 9 * 500, 3 * 200000)
+    assert G.solver_path() == "band" and G.band_order() == (True, 6)      # (the cameras-only system, 5 994 unknowns: 47 blocks of 128, six levels)
     R.use_lapack_solver()
     d = ba_parity.compare_trajectory(G, R, 3)
     print("C4 trajectory", d)
