@@ -311,6 +311,11 @@ struct cs_ba {
   // the projection edges' payload (88 bytes per edge) goes straight to the device when the edges are set, in the caller's order;
   // the structure phase permutes it there (ba_gather_rows_kernel)
   DBuf<double> raw_uv, raw_info, raw_intr, raw_huber;
+  // every projection edge with the same information matrix / intrinsics (decided by comparing the caller's records when they are set or
+  // appended): the kernels then read these 4 + 4 doubles instead of the per-edge records (BaView::info_u / intr_u).  CS_BA_UNIFORM=0: never.
+  bool info_uniform = false, intr_uniform = false;
+  double uni8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  DBuf<double> d_uni;
   bool have_huber = false;
   // robust kernels (cs_ba_set_robust_kernels; cs_robust.h): kinds per edge in the caller's order, empty = none of the class has one.
   // The projection edges' deltas live in raw_huber (Huber is the fast path: kinds all 0 / 1 -> no kind array on the device).
@@ -931,15 +936,18 @@ int finalize_structure(cs_ba* B) {
       const size_t Ez = (size_t)E;
 #define ER(call) do { r = (call); if (r) return r; } while (0)
       ER(B->cm_pm.upload_ptr(cm_pm.data(), Ez)); ER(B->d_src.upload_ptr(src_of_slot, Ez));
-      ER(B->pm_uv.alloc(2 * Ez, B->st)); ER(B->pm_info.alloc(4 * Ez, B->st)); ER(B->pm_intr.alloc(4 * Ez, B->st)); ER(B->pm_huber.alloc(Ez, B->st));
-      ER(B->cm_uv.alloc(2 * Ez, B->st)); ER(B->cm_info.alloc(4 * Ez, B->st)); ER(B->cm_intr.alloc(4 * Ez, B->st)); ER(B->cm_huber.alloc(Ez, B->st));
+      // (the information / intrinsics records in the two edge orders only when they differ between edges: BaView::info_u / intr_u otherwise)
+      const bool per_info = !B->info_uniform, per_intr = !B->intr_uniform;
+      ER(B->pm_uv.alloc(2 * Ez, B->st)); ER(B->pm_huber.alloc(Ez, B->st)); ER(B->cm_uv.alloc(2 * Ez, B->st)); ER(B->cm_huber.alloc(Ez, B->st));
+      if (per_info) { ER(B->pm_info.alloc(4 * Ez, B->st)); ER(B->cm_info.alloc(4 * Ez, B->st)); }
+      if (per_intr) { ER(B->pm_intr.alloc(4 * Ez, B->st)); ER(B->cm_intr.alloc(4 * Ez, B->st)); }
       cs::ba_launch_gather_rows(B->raw_uv.p, B->d_src.p, E, 2, B->pm_uv.p, B->st);
-      cs::ba_launch_gather_rows(B->raw_info.p, B->d_src.p, E, 4, B->pm_info.p, B->st);
-      cs::ba_launch_gather_rows(B->raw_intr.p, B->d_src.p, E, 4, B->pm_intr.p, B->st);
+      if (per_info) cs::ba_launch_gather_rows(B->raw_info.p, B->d_src.p, E, 4, B->pm_info.p, B->st);
+      if (per_intr) cs::ba_launch_gather_rows(B->raw_intr.p, B->d_src.p, E, 4, B->pm_intr.p, B->st);
       if (B->have_huber) cs::ba_launch_gather_rows(B->raw_huber.p, B->d_src.p, E, 1, B->pm_huber.p, B->st);   // (else: zeros from the allocation)
       cs::ba_launch_gather_rows(B->pm_uv.p, B->cm_pm.p, E, 2, B->cm_uv.p, B->st);
-      cs::ba_launch_gather_rows(B->pm_info.p, B->cm_pm.p, E, 4, B->cm_info.p, B->st);
-      cs::ba_launch_gather_rows(B->pm_intr.p, B->cm_pm.p, E, 4, B->cm_intr.p, B->st);
+      if (per_info) cs::ba_launch_gather_rows(B->pm_info.p, B->cm_pm.p, E, 4, B->cm_info.p, B->st);
+      if (per_intr) cs::ba_launch_gather_rows(B->pm_intr.p, B->cm_pm.p, E, 4, B->cm_intr.p, B->st);
       cs::ba_launch_gather_rows(B->pm_huber.p, B->cm_pm.p, E, 1, B->cm_huber.p, B->st);
       BA_TRY(hipGetLastError());
       ER(B->pm_pt.upload_ptr(pm_pt.data(), Ez)); ER(B->pm_cam.upload_ptr(pm_cam.data(), Ez)); ER(B->cm_pt.upload_ptr(cm_pt.data(), Ez));
@@ -1256,6 +1264,7 @@ int finalize_structure(cs_ba* B) {
     }
   }
   AL(B->cams_bak, 7 * (size_t)nc); AL(B->points_bak, 3 * (size_t)np); AL(B->cubes_bak, 10 * (size_t)no);
+  { std::vector<double> u8(B->uni8, B->uni8 + 8); UP(B->d_uni, u8); }
 #undef UP
 #undef AL
 #undef UPB
@@ -1280,6 +1289,10 @@ int finalize_structure(cs_ba* B) {
   v.cam_oej_ptr = B->cam_oej_ptr.p; v.cam_oej_idx = B->cam_oej_idx.p; v.cub_ce_ptr = B->cub_ce_ptr.p; v.cub_ce_idx = B->cub_ce_idx.p;
   v.Hcam = B->Hcam.p; v.bcam = B->bcam.p; v.Hcub = B->Hcub.p; v.bcub = B->bcub.p; v.Hll = B->Hll.p; v.bl = B->bl.p; v.W = B->W.p; v.WD = B->WD.p;
   v.fuse_lin = 0;
+  {
+    v.info_u = B->info_uniform && E > 0 ? B->d_uni.p : nullptr;
+    v.intr_u = B->intr_uniform && E > 0 ? B->d_uni.p + 4 : nullptr;
+  }
   v.Dinv = B->Dinv.p; v.dbl = B->dbl.p; v.S = B->S.p; v.band_ld = B->band_ld; v.lam_lo = B->sep_mode ? B->cut[B->shard_rank] : 0; v.lam_hi = B->sep_mode ? B->cut[B->shard_rank + 1] : (B->shard_rank == 0 ? 0x7fffffff : 0); v.rhs = B->S.p + B->s_doubles; v.xl = B->xl.p;
   v.n_pairs = B->n_pairs; v.pair_ptr = B->pair_ptr.p; v.pair_i1 = B->pair_i1.p; v.pair_i2 = B->pair_i2.p; v.ent_a = B->ent_a.p; v.ent_b = B->ent_b.p;
   v.fused = B->fused ? 1 : 0; v.n_seg = B->n_seg; for (int q = 0; q < 5; q++) v.seg_class[q] = B->seg_class[q];
@@ -1765,6 +1778,30 @@ int cs_ba_append_vertices(cs_ba* B, const double* cams7, const int* cam_fixed, i
   return cs_ba_append_vertices_impl(B, cams7, cam_fixed, n_cams, cuboids10, cub_fixed, n_cub, points3, pt_fixed, n_pts);
   BA_GUARD_END("cs_ba_append_vertices")
 }
+// are the n new records all equal to the handle's reference record (the first record ever set)?  A few threads over the caller's arrays.
+static void scan_uniform_records(cs_ba* B, bool first, const double* info4, const double* intr4, int n) {
+  if (first) {
+    const char* env = getenv("CS_BA_UNIFORM");   // (read per call: the parity test sets the same graph up both ways in one process)
+    const bool on = !env || atoi(env) != 0;
+    B->info_uniform = B->intr_uniform = on && n > 0;
+    if (n > 0) { std::memcpy(B->uni8, info4, 32); std::memcpy(B->uni8 + 4, intr4, 32); }
+  }
+  if (!(B->info_uniform || B->intr_uniform) || n <= 0) return;
+  const int nt = n > (1 << 16) ? 8 : 1;
+  std::vector<char> ok_i(nt, 1), ok_k(nt, 1);
+  auto work = [&](int t) {
+    const size_t lo = (size_t)n * t / nt, hi = (size_t)n * (t + 1) / nt;
+    bool a = B->info_uniform, b = B->intr_uniform;
+    for (size_t k = lo; k < hi && (a || b); k++) {
+      if (a && std::memcmp(info4 + 4 * k, B->uni8, 32) != 0) a = false;
+      if (b && std::memcmp(intr4 + 4 * k, B->uni8 + 4, 32) != 0) b = false;
+    }
+    ok_i[t] = a; ok_k[t] = b;
+  };
+  if (nt == 1) work(0);
+  else { std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+  for (int t = 0; t < nt; t++) { B->info_uniform = B->info_uniform && ok_i[t]; B->intr_uniform = B->intr_uniform && ok_k[t]; }
+}
 int cs_ba_append_edges_proj(cs_ba* B, int n, const int* pt, const int* cam, const double* uv, const double* info4, const double* intr4, const double* huber) {
   if (!B || n < 0 || (n && (!pt || !cam || !uv || !info4 || !intr4))) return CS_ERR_INVALID_ARG;
   BA_GUARD_BEGIN
@@ -1773,6 +1810,7 @@ int cs_ba_append_edges_proj(cs_ba* B, int n, const int* pt, const int* cam, cons
   BA_TRY(hipSetDevice(B->device));
   BA_TRY(hipStreamSynchronize(B->st));
   int rc;
+  scan_uniform_records(B, B->n_proj == 0, info4, intr4, n);
   if ((rc = B->raw_uv.append_ptr(uv, 2 * (size_t)n)) || (rc = B->raw_info.append_ptr(info4, 4 * (size_t)n)) || (rc = B->raw_intr.append_ptr(intr4, 4 * (size_t)n))) return rc;
   if (huber) { rc = B->raw_huber.append_ptr(huber, (size_t)n); if (rc) return rc; }
   B->have_huber = huber != nullptr;
@@ -1844,6 +1882,7 @@ static int cs_ba_set_edges_proj_impl(cs_ba* B, int n, const int* pt, const int* 
   B->e_pt.assign(pt, pt + n); B->e_cam.assign(cam, cam + n);
   BA_TRY(hipSetDevice(B->device));
   int rc;
+  scan_uniform_records(B, true, info4, intr4, n);
   if ((rc = B->raw_uv.upload_ptr(uv, 2 * (size_t)n)) || (rc = B->raw_info.upload_ptr(info4, 4 * (size_t)n)) || (rc = B->raw_intr.upload_ptr(intr4, 4 * (size_t)n))) return rc;
   B->have_huber = huber != nullptr;
   B->rk_proj.clear();

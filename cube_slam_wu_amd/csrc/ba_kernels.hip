@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256) void ba_chi2_proj_kernel(BaView v) {
   for (int k = blockIdx.x * 256 + threadIdx.x; k < v.n_proj; k += gridDim.x * 256) {
     Pose T = pose_load(v.cams + 7 * v.pm_cam[k]);
     double e[2], pc[3];
-    proj_error(T, v.points + 3 * v.pm_pt[k], v.pm_uv + 2 * k, v.pm_intr + 4 * k, e, pc);
-    const double* info = v.pm_info + 4 * k;
+    proj_error(T, v.points + 3 * v.pm_pt[k], v.pm_uv + 2 * k, v.intr_u ? v.intr_u : v.pm_intr + 4 * k, e, pc);
+    const double* info = v.info_u ? v.info_u : v.pm_info + 4 * k;
     double c = e[0] * (info[0] * e[0] + info[1] * e[1]) + e[1] * (info[2] * e[0] + info[3] * e[1]);
     double rho0, rho1;
     proj_rho(v.pm_rk, k, v.pm_huber[k], c, rho0, rho1);
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void ba_lin_cam_kernel(BaView v) {
   int e0 = v.cam_ptr[c], e1 = v.cam_ptr[c + 1];
   for (int k = e0 + threadIdx.x; k < e1; k += 256) {
     ProjLin L;
-    proj_linearize(T, R, v.points + 3 * v.cm_pt[k], v.cm_uv + 2 * k, v.cm_info + 4 * k, v.cm_intr + 4 * k, v.cm_huber[k], v.cm_rk, k, L);
+    proj_linearize(T, R, v.points + 3 * v.cm_pt[k], v.cm_uv + 2 * k, v.info_u ? v.info_u : v.cm_info + 4 * k, v.intr_u ? v.intr_u : v.cm_intr + 4 * k, v.cm_huber[k], v.cm_rk, k, L);
     // JW = Jc^T W (6x2)
     int q = 0;
 #pragma unroll
@@ -230,7 +230,7 @@ __device__ __forceinline__ void lin_pt_edge(const BaView& v, int k, bool free_pt
   double R[9];
   pose_rotmat(T, R);
   ProjLin L;
-  proj_linearize(T, R, v.points + 3 * v.pm_pt[k], v.pm_uv + 2 * k, v.pm_info + 4 * k, v.pm_intr + 4 * k, v.pm_huber[k], v.pm_rk, k, L);
+  proj_linearize(T, R, v.points + 3 * v.pm_pt[k], v.pm_uv + 2 * k, v.info_u ? v.info_u : v.pm_info + 4 * k, v.intr_u ? v.intr_u : v.pm_intr + 4 * k, v.pm_huber[k], v.pm_rk, k, L);
   double pw[6];  // Jp^T W (3x2)
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -821,7 +821,7 @@ __device__ __forceinline__ void ba_lin_schur_segment(const BaView& v, double lam
 #pragma unroll
     for (int q = 0; q < 2; q++) r.uv[q] = v.pm_uv[2 * (size_t)r.e + q];
 #pragma unroll
-    for (int q = 0; q < 4; q++) { r.info[q] = v.pm_info[4 * (size_t)r.e + q]; r.intr[q] = v.pm_intr[4 * (size_t)r.e + q]; }
+    for (int q = 0; q < 4; q++) { r.info[q] = v.info_u ? v.info_u[q] : v.pm_info[4 * (size_t)r.e + q]; r.intr[q] = v.intr_u ? v.intr_u[q] : v.pm_intr[4 * (size_t)r.e + q]; }
     r.huber = v.pm_huber[r.e];
     return r;
   };
@@ -2629,8 +2629,8 @@ __global__ __launch_bounds__(256) void ba_edge_chi_kernel(BaView v, double* out)
   if (k < v.n_proj) {
     Pose T = pose_load(v.cams + 7 * v.pm_cam[k]);
     double e[2], pc[3];
-    proj_error(T, v.points + 3 * v.pm_pt[k], v.pm_uv + 2 * k, v.pm_intr + 4 * k, e, pc);
-    const double* info = v.pm_info + 4 * k;
+    proj_error(T, v.points + 3 * v.pm_pt[k], v.pm_uv + 2 * k, v.intr_u ? v.intr_u : v.pm_intr + 4 * k, e, pc);
+    const double* info = v.info_u ? v.info_u : v.pm_info + 4 * k;
     out[k] = e[0] * (info[0] * e[0] + info[1] * e[1]) + e[1] * (info[2] * e[0] + info[3] * e[1]);
     return;
   }

@@ -802,6 +802,66 @@ def test_fused_linearise_schur_kernel_equals_the_classic_pair_bitwise(views, mon
     assert h1[0][-1] < 0.5 * h1[0][0]
 
 
+@pytest.mark.parametrize("vary", ["none", "info", "intr", "both"])
+def test_uniform_information_and_intrinsics_constants_equal_the_per_edge_records(vary, monkeypatch):
+    """Round 5: when every projection edge carries the same information matrix and / or the same intrinsics (one camera, one sigma) the
+    kernels read 4 + 4 doubles (BaView::info_u / intr_u) instead of the 32-byte per-edge records.  Same values into the same arithmetic:
+    the LM run must be BIT-identical to the per-edge records (CS_BA_UNIFORM=0), and with per-edge values that do differ (pyramid-level
+    sigmas, a second camera) the handle must fall back to the records on its own and agree with the oracle."""
+    pr = synth_ba.make_problem(n_cams=60, n_points=3000, n_cuboids=8, seed=91, obs_per_point=5)
+    rng = np.random.default_rng(5)
+    n_e = len(pr["e_pt"])
+    if vary in ("info", "both"):
+        pr["e_info"] = pr["e_info"] * (1.2 ** -rng.integers(0, 8, n_e))[:, None]
+    if vary in ("intr", "both"):
+        second = rng.random(n_e) < 0.3
+        pr["e_intr"] = np.where(second[:, None], pr["e_intr"] * np.array([1.01, 0.99, 1.0, 1.0]), pr["e_intr"])
+    runs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CS_BA_UNIFORM", flag)
+        G = capi.ba_from_dict(pr)
+        chi0 = G.compute_errors()
+        n = G.optimize(5)
+        runs.append((chi0, n, G.history(), G.state()))
+        G.close()
+    (c1, n1, h1, s1), (c0, n0, h0, s0) = runs
+    assert c1 == c0 and n1 == n0 >= 3
+    for a, b in zip(h1, h0):
+        assert np.array_equal(a, b)
+    for a, b in zip(s1, s0):
+        assert np.array_equal(a, b)
+    R = _oracle(pr)
+    chi_r = R.compute_errors()[0]
+    assert abs(c1 - chi_r) < 1e-9 * chi_r
+    assert R.optimize(5) == n1 and np.allclose(h1[0], R.history()[0], rtol=1e-5)
+
+
+def test_appended_edges_with_other_information_switch_the_handle_back_to_per_edge_records():
+    """A handle whose first edges all share one information matrix reads the constant; edges appended later with another sigma must
+    switch it to the per-edge records: chi2 and the LM run equal a handle that was given all edges at once."""
+    pr = synth_ba.make_problem(n_cams=40, n_points=1500, n_cuboids=4, seed=17, obs_per_point=4)
+    n_e = len(pr["e_pt"]); h = n_e // 2
+    info = pr["e_info"].copy(); info[h:] *= 0.5
+    args = lambda sl: (pr["e_pt"][sl], pr["e_cam"][sl], pr["e_uv"][sl], info[sl], pr["e_intr"][sl], pr["e_huber"][sl])
+    mk = lambda: capi.BaProblem(pr["cams"], pr["cam_fixed"], pr["cuboids"], pr["cub_fixed"], pr["points"], pr["pt_fixed"])
+    A, B = mk(), mk()
+    A.set_edges_proj(*args(slice(0, h))); A.append_edges_proj(*args(slice(h, n_e)))
+    B.set_edges_proj(*args(slice(0, n_e)))
+    for G in (A, B):
+        G.set_edges_cuboid(pr["ce_cam"], pr["ce_cub"], pr["ce_meas"], pr["ce_info"])
+        G.set_edges_odom(pr["oe_i"], pr["oe_j"], pr["oe_meas"], pr["oe_info"])
+    assert A.compute_errors() == B.compute_errors()
+    assert A.optimize(4) == B.optimize(4)
+    for a, b in zip(A.history(), B.history()):
+        assert np.array_equal(a, b)
+    for a, b in zip(A.state(), B.state()):
+        assert np.array_equal(a, b)
+    pr2 = dict(pr); pr2["e_info"] = info
+    R = _oracle(pr2); R.optimize(4)
+    assert np.allclose(A.history()[0], R.history()[0], rtol=1e-5)
+    A.close(); B.close()
+
+
 def test_cuboid_projection_edges_system_and_optimize_parity():
     """EdgeSE3CuboidProj (4-dim bounding-box error of the projected cuboid, numeric Jacobians) next to the other three
     edge types: linear system and a 6-iteration LM run against the oracle."""
