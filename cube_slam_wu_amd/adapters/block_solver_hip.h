@@ -181,26 +181,35 @@ class BlockSolverHIP : public g2o::Solver {
 
   // RobustKernel -> (cs_robust_kernel, delta); false: a kernel the device cannot evaluate (the edge then takes the CPU path, whose
   // constructQuadraticForm applies whatever kernel the edge carries)
-  static bool kernel_of(const g2o::OptimizableGraph::Edge* e, int* kind, double* delta) {
+  // KERNEL_OTHER: a kernel class the device does not know; KERNEL_BAD_DELTA: one it knows, with delta <= 0 -- the reference's formulas
+  // (robust_kernel_impl.cpp:78-135) divide by delta^2 or give zero / negative weights there, nothing the device reproduces; such an edge
+  // takes the CPU path like KERNEL_OTHER, and a camera-point edge is refused with a message that names delta.
+  // Restriction: the device's Huber threshold is float(delta * delta), what RobustKernelHuber::setDelta stores (robust_kernel_impl.cpp:65-69,
+  // `float dsqr`).  A kernel configured through setDeltaSqr(delta, dsqr) with dsqr != delta^2 (robust_kernel_impl.cpp:72-76) cannot be
+  // told apart from outside (dsqr is private) and is evaluated with delta^2: configure such edges' kernels through setDelta.
+  enum KernelClass { KERNEL_DEVICE = 0, KERNEL_OTHER = 1, KERNEL_BAD_DELTA = 2 };
+  static KernelClass kernel_of(const g2o::OptimizableGraph::Edge* e, int* kind, double* delta) {
     g2o::RobustKernel* rk = e->robustKernel();
     *kind = CS_RK_NONE; *delta = 0.0;
-    if (!rk) return true;
+    if (!rk) return KERNEL_DEVICE;
     *delta = rk->delta();
     if (dynamic_cast<g2o::RobustKernelHuber*>(rk)) *kind = CS_RK_HUBER;
     else if (dynamic_cast<g2o::RobustKernelPseudoHuber*>(rk)) *kind = CS_RK_PSEUDO_HUBER;
     else if (dynamic_cast<g2o::RobustKernelCauchy*>(rk)) *kind = CS_RK_CAUCHY;
     else if (dynamic_cast<g2o::RobustKernelSaturated*>(rk)) *kind = CS_RK_SATURATED;
     else if (dynamic_cast<g2o::RobustKernelDCS*>(rk)) *kind = CS_RK_DCS;
-    else return false;
-    return *delta > 0.0;
+    else return KERNEL_OTHER;
+    return *delta > 0.0 ? KERNEL_DEVICE : KERNEL_BAD_DELTA;   // (NaN: bad)
   }
 
   bool add_edge(g2o::OptimizableGraph::Edge* e, EdgePack& E) {
     int kind = 0; double delta = 0;
-    const bool dev_kernel = kernel_of(e, &kind, &delta);
+    const KernelClass kclass = kernel_of(e, &kind, &delta);
+    const bool dev_kernel = kclass == KERNEL_DEVICE;
     for (auto* hv : e->vertices()) if (!hv || index_.find(hv) == index_.end()) return refuse("an active edge ends in a vertex that is not an active vertex");
     auto slot = [&](size_t k) { return index_[e->vertex(k)]; };
     if (auto* pe = dynamic_cast<g2o::EdgeSE3ProjectXYZ*>(e)) {
+      if (kclass == KERNEL_BAD_DELTA) return refuse("EdgeSE3ProjectXYZ with a robust kernel whose delta is not positive: set a delta > 0 or remove the kernel (a camera-point edge cannot take the CPU path, it is part of the Schur structure)");
       if (!dev_kernel) return refuse("EdgeSE3ProjectXYZ with a robust kernel other than Huber / PseudoHuber / Cauchy / Saturated / DCS: a camera-point edge cannot take the CPU path (it is part of the Schur structure)");
       E.e_pt.push_back(slot(0).idx); E.e_cam.push_back(slot(1).idx);
       E.uv.push_back(pe->measurement()[0]); E.uv.push_back(pe->measurement()[1]);

@@ -457,9 +457,8 @@ class BaProblem:
     def set_robust_kernels(self, edge_class, kind, delta):
         """cs_ba_set_robust_kernels: edge_class 0 projection / 1 EdgeSE3Cuboid / 2 EdgeSE3CuboidProj / 3 EdgeSE3Expmap; kind per edge
         (RK_* below), delta = RobustKernel::delta().  kind None removes the class's kernels."""
-        if kind is None:
-            n = {0: self.n_proj, 1: self.n_cub, 2: getattr(self, "n_cproj", 0), 3: self.n_odom}[int(edge_class)]
-            _chk(lib().cs_ba_set_robust_kernels(self.h, int(edge_class), n, None, None), "cs_ba_set_robust_kernels")
+        if kind is None:        # (the library counts the class's edges itself: no shadow count here, a handle from Problem.load() has none)
+            _chk(lib().cs_ba_set_robust_kernels(self.h, int(edge_class), 0, None, None), "cs_ba_set_robust_kernels")
             return
         kind, delta = _i32(kind), _f64(delta, (-1,))
         _chk(lib().cs_ba_set_robust_kernels(self.h, int(edge_class), len(kind), _ip(kind), _dp(delta)), "cs_ba_set_robust_kernels")

@@ -60,10 +60,11 @@ size_t ba_bcr_sep_workspace_doubles(int R);
 void ba_launch_bcr_sep(const double* msgs, size_t msg_doubles, int wm, int R, const int* sep_off, const int* sep_col, int ns, double* work, double* x, int* info, hipStream_t st);
 void ba_launch_sum2(const double* a, int na, const double* b, int nb, double* out, hipStream_t st);
 void ba_launch_multi_zero(const std::pair<void*, size_t>* list, int n, hipStream_t st);
+void ba_launch_multi_copy(const BaCopyItem* list, int n, hipStream_t st);
 void ba_launch_sum2_flag(const double* a, int na, const double* b, int nb, const int* f0, const int* f1, double* out, hipStream_t st);
 void ba_launch_trial_prologue(double* d_lam, double lam0, double lam1, int* info24, int* elim_fail, double* rhs, int n_rhs, hipStream_t st);
 void ba_launch_ext_add(const BaView& v, const double* cam36, const double* cam6, const double* cub81, const double* cub9, const double* pt9, const double* pt3, hipStream_t st);
-void ba_launch_ext_offdiag(const BaView& v, int n, const int* e4, const double* Hij, hipStream_t st);
+void ba_launch_ext_offdiag(const BaView& v, int n_groups, const int* gptr, const int* order, const int* e4, const double* Hij, hipStream_t st);
 void ba_launch_scan_finite(const double* p, long long n, int* out, hipStream_t st);
 void ba_launch_edge_chi(const BaView& v, double* out, hipStream_t st);
 }  // namespace cs
@@ -129,6 +130,7 @@ struct StageArena {
   void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = off = 0; }
 };
 
+static int g_dbuf_reallocs = 0;     // (diagnostics: device (re)allocations, printed with the structure phase's clock under CS_BA_PROF)
 template <class T>
 struct DBuf {
   T* p = nullptr;
@@ -140,6 +142,7 @@ struct DBuf {
     // (a buffer that has to grow belongs to a graph that is being extended: a quarter of head room, so that the next frames fit --
     // without it every appended frame re-allocated every buffer whose size follows the edges or the points, ~60 of them)
     const size_t want = p ? count + count / 4 + 64 : count;
+    g_dbuf_reallocs++;
     if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
     BA_TRY(hipMalloc((void**)&p, want * sizeof(T)));
     cap = want;
@@ -165,6 +168,21 @@ struct DBuf {
     n += count;
     return CS_OK;
   }
+  // the same through a pinned arena, queued on st (a frame's appends: a dozen blocking copies from pageable memory were 0.3-0.5 ms); the
+  // arena's contents must stay until st has run (the handle rewinds it after the next structure phase's wait)
+  int append_ptr_staged(const T* h, size_t count, StageArena& stage, hipStream_t st) {
+    if (!count) return CS_OK;
+    const size_t bytes = count * sizeof(T);
+    void* pin = (p && n + count <= cap && bytes <= (256u << 10)) ? stage.take(bytes) : nullptr;
+    if (!pin) {                                   // growing (the old contents are copied: nothing may still be writing them) or no room
+      BA_TRY(hipStreamSynchronize(st));
+      return append_ptr(h, count);
+    }
+    std::memcpy(pin, h, bytes);
+    BA_TRY(hipMemcpyAsync(p + n, pin, bytes, hipMemcpyHostToDevice, st));
+    n += count;
+    return CS_OK;
+  }
   int upload(const std::vector<T>& h) { return upload_ptr(h.data(), h.size()); }
   int upload_staged(const std::vector<T>& h, StageArena& stage, hipStream_t st) { return upload_ptr_staged(h.data(), h.size(), stage, st); }
   int upload_ptr_staged(const T* h, size_t count, StageArena& stage, hipStream_t st) {   // up to 1 MB: through the pinned arena, queued on st (a blocking copy from pageable memory costs 50-100 us)
@@ -175,6 +193,21 @@ struct DBuf {
     n = count;
     std::memcpy(pin, h, bytes);
     BA_TRY(hipMemcpyAsync(p, pin, bytes, hipMemcpyHostToDevice, st));
+    return CS_OK;
+  }
+  // like upload_ptr_staged, but the copy itself is left to the caller's batched launch (cs::ba_launch_multi_copy): destination, staged
+  // source and size are appended to the list.  No room in the arena: a blocking copy now.
+  // Tables of more than 64 KB keep their own hipMemcpyAsync (the copy engine moves a large table faster than a kernel reads it over the link:
+  // at a million edges the all-kernel form cost the phase 1.5 ms).
+  int upload_ptr_deferred(const T* h, size_t count, StageArena& stage, std::vector<cs::BaCopyItem>& list, hipStream_t st) {
+    const size_t bytes = count * sizeof(T);
+    if (bytes > (64u << 10)) return upload_ptr_staged(h, count, stage, st);
+    void* pin = bytes ? stage.take(bytes) : nullptr;
+    if (!pin) return upload_ptr(h, count);
+    int rc = reserve(count); if (rc) return rc;
+    n = count;
+    std::memcpy(pin, h, bytes);
+    list.push_back(cs::BaCopyItem{p, pin, bytes});
     return CS_OK;
   }
   int alloc(size_t count, hipStream_t st = nullptr) {   // zeroed; st: queued on that stream instead of a blocking call per buffer
@@ -199,9 +232,12 @@ struct DBuf {
 template <class T>
 struct UBuf {
   std::unique_ptr<T[]> p;
-  size_t n = 0;
+  size_t n = 0, cap = 0;
   UBuf() {}
-  explicit UBuf(size_t m) : p(new T[std::max<size_t>(1, m)]), n(m) {}
+  explicit UBuf(size_t m) : p(new T[std::max<size_t>(1, m)]), n(m), cap(std::max<size_t>(1, m)) {}
+  // a buffer kept on the handle between structure phases: the same (already faulted-in) memory again, grown with head room -- a fresh
+  // 400 KB array is ~100 page faults, 0.1-0.2 ms on the thread that fills it; contents are NOT kept when it grows
+  void ensure(size_t m) { if (m > cap || !p) { cap = m + m / 4 + 1024; p.reset(new T[cap]); } n = m; }
   T& operator[](size_t i) { return p[i]; }
   const T& operator[](size_t i) const { return p[i]; }
   T* begin() { return p.get(); }
@@ -217,6 +253,10 @@ struct cs_ba {
   int device = 0;
   hipStream_t st = nullptr;
   StageArena stage;                          // pinned staging of the structure phase's small uploads
+  // the landmarks' camera lists of the last structure phase (host): a graph that is only appended to extends them instead of re-sorting all edges
+  int st_lists_edges = 0, st_cur = 0; std::vector<int> st_cam_cnt; UBuf<int> st_cams_of[2], st_edge_of[2];   // (two sets: a phase reads the last one's and fills the other)
+  UBuf<int> st_pm_pt, st_pm_cam, st_cm_pm, st_cm_pt;   // host scratch of the edge orders, kept for its memory only
+  StageArena append_stage;                   // ... and of cs_ba_append_*'s rows (queued on st, rewound by the structure phase)
   hipStream_t st2 = nullptr;                 // side stream of the reduce phase (cuboid elimination beside the landmark segments)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t st3 = nullptr;                 // third stream of the linearisation: the landmark kernel beside the camera kernel (which fills a fraction of the CUs)
@@ -268,6 +308,7 @@ struct cs_ba {
   bool sparse = false;
   bool sp_S_clean = false;     // S holds nothing outside the plan's pattern (set by the first trial's full clear)
   cs::SparsePlan sp_plan;
+  cs::SparseGrids sp_grids{0, 0};   // launch grids of the sparse factorisation / substitution, decided with the plan
   DBuf<int> sp_ndim, sp_ncol, sp_sptr, sp_srow, sp_sroff, sp_prow, sp_rbase, sp_rent, sp_rptr, sp_rcol, sp_rpos, sp_order, sp_info;
   DBuf<long long> sp_poff;
   DBuf<double> sp_L, sp_xs, sp_T;
@@ -326,7 +367,8 @@ struct cs_ba {
   // external (host-evaluated) edges: the coupling pattern of the binary ones (structure), the terms of the current linearisation
   int ext_n = 0;
   std::vector<int> ext_e4;                       // (class_i, idx_i, class_j, idx_j) per edge; idx_j < 0: unary
-  DBuf<int> d_ext_e4;
+  DBuf<int> d_ext_e4, d_ext_order, d_ext_gptr;   // (+ the binary ones grouped by destination pair: ba_ext_offdiag_kernel)
+  int ext_groups = 0;
   DBuf<double> ext_cam36, ext_cam6, ext_cub81, ext_cub9, ext_pt9, ext_pt3, ext_Hij;
   std::vector<double> h_ext_Hij;                 // host copy (cs_ba_get_system's dense H_pp)
   bool ext_has_cam = false, ext_has_cub = false, ext_has_pt = false, ext_terms_set = false;
@@ -351,41 +393,63 @@ class StructPool {
   bool try_run(int n, const std::function<void(int)>& fn) {
     std::unique_lock<std::mutex> use(use_, std::try_to_lock);
     if (!use.owns_lock()) return false;
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      if (th_.empty()) for (int i = 0; i < 7; i++) th_.emplace_back([this] { loop(); });
-      fn_ = &fn; n_ = n; next_.store(0); pending_ = (int)th_.size(); gen_++;
-    }
-    cv_.notify_all();
+    if (th_.empty()) for (int i = 0; i < 7; i++) th_.emplace_back([this] { loop(); });
+    fn_ = &fn; n_ = n; next_.store(0); pending_.store((int)th_.size());
+    gen_.fetch_add(1);                                   // (publishes fn_ / n_ / next_ / pending_ to the workers)
+    if (sleepers_.load() > 0) { std::lock_guard<std::mutex> lk(m_); cv_.notify_all(); }
     work();
-    std::unique_lock<std::mutex> lk(m_);
-    done_.wait(lk, [this] { return pending_ == 0; });
+    // every worker acknowledges the burst (fn must outlive their last look at it): the hot ones within a microsecond, a parked one after its wake-up
+    for (int spins = 0; pending_.load(std::memory_order_acquire) != 0; spins++) { if (spins < 2000) cpu_relax(); else std::this_thread::yield(); }
     fn_ = nullptr;
     return true;
   }
   ~StructPool() {
-    { std::lock_guard<std::mutex> lk(m_); stop_ = true; gen_++; }
-    cv_.notify_all();
+    stop_.store(true); gen_.fetch_add(1);
+    { std::lock_guard<std::mutex> lk(m_); cv_.notify_all(); }
     for (auto& t : th_) t.join();
   }
  private:
+  static void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+  }
   void work() { for (;;) { const int i = next_.fetch_add(1); if (i >= n_) break; (*fn_)(i); } }
+  // A worker can stay hot for SPIN_US after a burst (CS_BA_POOL_SPIN_US; the structure phase is seven or eight bursts inside 1-2 ms, and
+  // waking a parked thread is 20-40 us of the calling thread's wait each time) before it parks on the condition variable.  Default 0: on the
+  // measurement boxes (a 16-CPU cgroup quota) seven spinning threads bought nothing -- 1.2 ms per appended frame at 200 cameras either way --
+  // and their burnt quota came back as 5 ms throttling stalls in one frame out of ten.
   void loop() {
     unsigned long long seen = 0;
     for (;;) {
-      { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [&] { return gen_ != seen; }); seen = gen_; if (stop_) return; }
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int spins = 0; gen_.load(std::memory_order_acquire) == seen; spins++) {
+        cpu_relax();
+        if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(SPIN_US)) {
+          std::unique_lock<std::mutex> lk(m_);
+          sleepers_.fetch_add(1);                        // (seq_cst against try_run's gen_ increment + sleepers_ read: one of the two sees the other)
+          cv_.wait(lk, [&] { return gen_.load() != seen; });
+          sleepers_.fetch_sub(1);
+          break;
+        }
+      }
+      seen = gen_.load(std::memory_order_acquire);
+      if (stop_.load()) return;
       work();
-      { std::lock_guard<std::mutex> lk(m_); if (--pending_ == 0) done_.notify_all(); }
+      pending_.fetch_sub(1, std::memory_order_release);
     }
   }
+  const int SPIN_US = [] { const char* e = getenv("CS_BA_POOL_SPIN_US"); return e ? atoi(e) : 0; }();
   std::vector<std::thread> th_;
   std::mutex use_, m_;
-  std::condition_variable cv_, done_;
+  std::condition_variable cv_;
   const std::function<void(int)>* fn_ = nullptr;
-  std::atomic<int> next_{0};
-  int n_ = 0, pending_ = 0;
-  unsigned long long gen_ = 0;
-  bool stop_ = false;
+  std::atomic<int> next_{0}, pending_{0}, sleepers_{0};
+  int n_ = 0;
+  std::atomic<unsigned long long> gen_{0};
+  std::atomic<bool> stop_{false};
 };
 // threads of a structure-phase burst: min(8, hardware threads), or fewer with CS_BA_STRUCT_THREADS (= 1: every loop on the calling thread --
 // tests hold the threaded tables to the sequential ones, cs_ba_structure_digest)
@@ -438,7 +502,7 @@ int finalize_structure(cs_ba* B) {
   { const int rc0 = B->stage.begin((size_t)8 << 20); if (rc0) return rc0; }
   static const bool prof = getenv("CS_BA_PROF") != nullptr;   // diagnostics: host phase clock of the structure phase
   double t_ph = now_ms();
-  auto mark = [&](const char* what) { if (prof) { double t = now_ms(); fprintf(stderr, "[ba structure] %-28s %8.2f ms\n", what, t - t_ph); t_ph = t; } };
+  auto mark = [&](const char* what) { if (prof) { double t = now_ms(); fprintf(stderr, "[ba structure] %-28s %8.2f ms   (%d device allocations so far)\n", what, t - t_ph, g_dbuf_reallocs); t_ph = t; } };
   const int nc = B->nc, no = B->no, np = B->np;
   // camera-cuboid edges of both kinds as one list: EdgeSE3Cuboid first, then EdgeSE3CuboidProj
   B->ce_cam = B->u3_cam; B->ce_cam.insert(B->ce_cam.end(), B->up_cam.begin(), B->up_cam.end());
@@ -456,17 +520,28 @@ int finalize_structure(cs_ba* B) {
   }
   // ---- the free landmarks grouped by the set of cameras that see them.  cams_of: every landmark's cameras sorted by id;
   // gorder: free landmarks with >= 1 edge sorted by (number of cameras, camera list); run_first: where each distinct set starts
-  for (int k = 0; k < B->n_proj; k++)
+  // (edges that an earlier phase of this handle has seen were checked then, and append only raises nc / np)
+  for (int k = std::min(B->st_lists_edges, B->n_proj); k < B->n_proj; k++)
     if (B->e_pt[k] < 0 || B->e_pt[k] >= np || B->e_cam[k] < 0 || B->e_cam[k] >= nc) { cs_set_error_ba("projection edge index out of range"); return CS_ERR_INVALID_ARG; }
+  mark("  checks, index mapping");
   std::vector<int> cam_cnt(np + 1, 0), gorder, run_first;
-  UBuf<int> cams_of((size_t)B->n_proj), edge_of((size_t)B->n_proj);   // edges grouped by landmark: camera (sorted by id) and caller edge index
+  // edges grouped by landmark: camera (sorted by id) and caller edge index
+  const int st_nb = 1 - B->st_cur;
+  UBuf<int>& cams_of = B->st_cams_of[st_nb]; UBuf<int>& edge_of = B->st_edge_of[st_nb];
+  cams_of.ensure((size_t)B->n_proj); edge_of.ensure((size_t)B->n_proj);
   {
     {   // a counting sort of the edges by landmark (the edge order inside a landmark stays the caller's), then every landmark's camera list
         // sorted, its edges with it.  Threaded in two levels: the edges are first dealt into landmark ranges (thread t walks its share of the
         // edges and appends to its own list per range), then range r's thread counts, fills and sorts from the lists of its range only --
         // every edge is read three times in all, every write (and the page faults of the two fresh arrays) is partitioned.  (First form: one
         // thread counted all edges, then every thread scanned ALL edges for those of its landmarks -- 5.9 ms at a million edges.)
-      const int NT = B->n_proj > 20000 ? struct_threads() : 1;   // (200 cameras / 100 k edges: 0.67 -> 0.35 ms)
+      // A graph that was only APPENDED to since the last structure phase (cs_ba_append_*): the lists of that phase are kept on the handle, every
+      // landmark's old list is copied, its new edges follow in the caller's order, and the same stable insertion sort runs over the landmarks
+      // that got edges -- the same lists as the counting sort below gives (old edges precede new ones in the caller's order), in one linear
+      // pass instead of three (200 cameras / 100 k edges, a frame of 500 edges appended: 0.28 -> 0.08 ms).
+      const int E0 = B->st_lists_edges, np0 = (int)B->st_cam_cnt.size() - 1;
+      const bool grown = E0 > 0 && np0 >= 0 && np0 <= np && E0 <= B->n_proj && (B->n_proj - E0) <= E0 / 4 && B->st_cams_of[B->st_cur].size() == (size_t)E0 && B->st_edge_of[B->st_cur].size() == (size_t)E0;
+      const int NT = grown ? 0 : (B->n_proj > 20000 ? struct_threads() : 1);   // (200 cameras / 100 k edges: 0.67 -> 0.35 ms)
       auto sort_lists = [&](int p0, int p1) {
         for (int p = p0; p < p1; p++) {
           const int a0 = cam_cnt[p], a1 = cam_cnt[p + 1];
@@ -478,7 +553,33 @@ int finalize_structure(cs_ba* B) {
           }
         }
       };
-      if (NT == 1) {
+      if (grown) {
+        std::vector<int> add(np + 1, 0), used(np, 0);
+        for (int k = E0; k < B->n_proj; k++) add[B->e_pt[k] + 1]++;
+        for (int p = 0; p < np; p++) add[p + 1] += add[p];                          // new edges of the landmarks before p
+        for (int p = 0; p <= np; p++) cam_cnt[p] = (p <= np0 ? B->st_cam_cnt[p] : E0) + add[p];
+        const int* oc = B->st_cams_of[B->st_cur].data(); const int* oe = B->st_edge_of[B->st_cur].data();
+        const int NTc = B->n_proj > 20000 ? struct_threads() : 1;                   // (the old lists are out of cache by now: the copy is a burst of misses)
+        run_items(NTc, [&](int t) {
+          const int p0 = (int)((long long)np0 * t / NTc), p1 = (int)((long long)np0 * (t + 1) / NTc);
+          if (p1 <= p0) return;
+          // (the landmarks of a range that got no edge in between move as one block: runs are copied whole)
+          int p = p0;
+          while (p < p1) {
+            int q = p + 1;
+            while (q < p1 && add[q] == add[p]) q++;                                 // landmarks p .. q - 1: the same shift (only the last may have new edges)
+            const int a0 = B->st_cam_cnt[p], a1 = B->st_cam_cnt[q], d0 = cam_cnt[p];
+            std::memcpy(&cams_of[d0], oc + a0, sizeof(int) * (size_t)(a1 - a0));
+            std::memcpy(&edge_of[d0], oe + a0, sizeof(int) * (size_t)(a1 - a0));
+            p = q;
+          }
+        });
+        for (int k = E0; k < B->n_proj; k++) {
+          const int p = B->e_pt[k], m_old = p < np0 ? B->st_cam_cnt[p + 1] - B->st_cam_cnt[p] : 0, q = cam_cnt[p] + m_old + used[p]++;
+          cams_of[q] = B->e_cam[k]; edge_of[q] = k;
+        }
+        for (int k = E0; k < B->n_proj; k++) sort_lists(B->e_pt[k], B->e_pt[k] + 1);
+      } else if (NT == 1) {
         for (int k = 0; k < B->n_proj; k++) cam_cnt[B->e_pt[k] + 1]++;
         for (int i = 0; i < np; i++) cam_cnt[i + 1] += cam_cnt[i];
         std::vector<int> fill(cam_cnt.begin(), cam_cnt.end() - 1);
@@ -737,10 +838,7 @@ int finalize_structure(cs_ba* B) {
     // (the two candidate orderings only read shared data: g2o's system on a second thread while this one orders the cameras-only system)
     Ordering keep_o, elim_o;
     if (try_elim && nc + no > 64) {
-      std::thread keep_th([&] { keep_o = make_ordering(false); });
-      struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } keep_join{keep_th};
-      elim_o = make_ordering(true);
-      keep_th.join();
+      run_items(2, [&](int t) { if (t == 0) elim_o = make_ordering(true); else keep_o = make_ordering(false); });
     } else {
       keep_o = make_ordering(false);
       if (try_elim) elim_o = make_ordering(true);
@@ -778,14 +876,16 @@ int finalize_structure(cs_ba* B) {
         std::vector<int> dim(nc + no, 0), col(nc + no, 0);
         for (int v : O.free_ids) { dim[v] = v < nc ? 6 : 9; col[v] = v < nc ? O.cam_col[v] : O.cub_col[v - nc]; }
         cs::SparsePlan plan;
-        const bool fits = cs::sparse_plan_build(O.adj, O.free_ids, dim, col, cs::sparse_max_panel_doubles(), 0.35, plan, getenv("CS_BA_SPARSE_NO_TAIL") ? 0 : (getenv("CS_BA_SPARSE_TAIL_MAX") ? atoi(getenv("CS_BA_SPARSE_TAIL_MAX")) : 9000)) && cs::sparse_fits_device(cs::sparse_max_panel_doubles(), plan.N);
+        cs::SparseGrids sp_grids{0, 0};
+        const bool fits = cs::sparse_plan_build(O.adj, O.free_ids, dim, col, cs::sparse_max_panel_doubles(), 0.35, plan, getenv("CS_BA_SPARSE_NO_TAIL") ? 0 : (getenv("CS_BA_SPARSE_TAIL_MAX") ? atoi(getenv("CS_BA_SPARSE_TAIL_MAX")) : 9000)) && cs::sparse_grids(cs::sparse_max_panel_doubles(), plan.N, &sp_grids);
         const double nt = (double)plan.n_tail;
-        const double est_sparse = 0.025 * plan.levels + 1.5 * plan.flops * 2e-9 + (nt > 0 ? nt * nt * nt / 3.0 / 3e12 * 1e3 + 1.0 : 0.0) + 1.0 + nn * nn * 8.0 / 2e12 * 1e3;
+        const double est_sparse = 0.025 * plan.levels + 1.5 * plan.flops * 2e-9 + (nt > 0 ? nt * nt * nt / 3.0 / 3e12 * 1e3 + 1.0 : 0.0) + 1.0 + nn * nn * 8.0 / 2e12 * 1e3
+                                  + 0.3;   // (the sparse solve is not deferrable: its trials take cs_ba_optimize's synchronising flow -- four more host round trips than the stream flow of the band)
         if (prof && fits) fprintf(stderr, "[ba structure] sparse plan: %d vertices, %d levels, %lld values (%.1f%% of the dense triangle), largest panel %d, %.2f Gflop + a dense tail of %d unknowns; estimates ms: sparse %.1f, band %.1f, dense %.1f\n",
                                   plan.N, plan.levels, plan.nvals, 100.0 * plan.nvals / (0.5 * nn * nn), plan.max_panel, plan.flops * 2e-9, plan.n_tail, est_sparse, est_band < 1e29 ? est_band : -1.0, est_dense);
         if (fits && (mode == 1 || est_sparse < est_other)) {
           B->sparse = true; B->band_ld = 0; B->use_bcr = false;
-          B->sp_plan = std::move(plan);
+          B->sp_plan = std::move(plan); B->sp_grids = sp_grids;
         }
       }
     }
@@ -859,7 +959,21 @@ int finalize_structure(cs_ba* B) {
   for (int i = 0; i < np; i++) { pt_free[i] = B->pt_fixed[i] ? 0 : 1; if (pt_free[i]) B->pt_lm[i] = nl++; }
   B->n_lm = nl;
   int rc;
-#define UP(buf, vec) do { rc = (buf).upload_staged(vec, B->stage, B->st); if (rc) return rc; } while (0)
+  // (the ~80 small uploads of a structure phase likewise: staged in the pinned arena, copied by one kernel per group of up to 48 tables at
+  // the end of the phase -- nothing launched inside the phase reads them.  CS_BA_UPLOAD_KERNEL=0: one hipMemcpyAsync per table, as before.)
+  std::vector<cs::BaCopyItem> copy_list;
+  const bool upload_kernel = [] { const char* e = getenv("CS_BA_UPLOAD_KERNEL"); return !e || atoi(e) != 0; }();
+  // (a launch per 24 tables or 2 MB staged, so that a large graph's transfers run beside the host work that follows them)
+  auto cflush = [&](bool all) -> int {
+    size_t bytes = 0;
+    for (const cs::BaCopyItem& c : copy_list) bytes += c.bytes;
+    if (!all && copy_list.size() < 24 && bytes < ((size_t)2 << 20)) return CS_OK;
+    for (size_t i = 0; i < copy_list.size(); i += 48) cs::ba_launch_multi_copy(copy_list.data() + i, (int)std::min<size_t>(48, copy_list.size() - i), B->st);
+    copy_list.clear();
+    BA_TRY(hipGetLastError());
+    return CS_OK;
+  };
+#define UP(buf, vec) do { rc = upload_kernel ? (buf).upload_ptr_deferred((vec).data(), (vec).size(), B->stage, copy_list, B->st) : (buf).upload_staged(vec, B->stage, B->st); if (!rc) rc = cflush(false); if (rc) return rc; } while (0)
   // (the ~50 zero fills of a structure phase -- one hipMemsetAsync each, 4-6 us of host time apiece, a third of an appended frame's phase --
   // are collected and go out as one kernel per group of up to 48 buffers: ZFLUSH() where the order against other device work matters)
   std::vector<std::pair<void*, size_t>> zero_list;
@@ -871,9 +985,22 @@ int finalize_structure(cs_ba* B) {
   };
 #define AL(buf, n) do { rc = (buf).alloc_deferred(n, zero_list); if (rc) return rc; } while (0)
 #define ZFLUSH() do { rc = zflush(); if (rc) return rc; } while (0)
-#define UPB(buf, ub) do { rc = (buf).upload_ptr_staged((ub).data(), (ub).size(), B->stage, B->st); if (rc) return rc; } while (0)
+#define UPB(buf, ub) do { rc = upload_kernel ? (buf).upload_ptr_deferred((ub).data(), (ub).size(), B->stage, copy_list, B->st) : (buf).upload_ptr_staged((ub).data(), (ub).size(), B->stage, B->st); if (!rc) rc = cflush(false); if (rc) return rc; } while (0)
   UP(B->d_cam_col, B->cam_col); UP(B->d_cub_col, B->cub_col); UP(B->d_pt_free, pt_free);
   { std::vector<int> e4(B->ext_e4); if (e4.empty()) e4.assign(4, 0); UP(B->d_ext_e4, e4); }
+  {  // the host-evaluated binary edges grouped by the unordered pair of vertices they join (stable: the caller's order inside a group)
+    std::vector<int> order, gptr(1, 0);
+    auto key = [&](int k) {
+      const long long a = ((long long)B->ext_e4[4 * k] << 32) | (unsigned)B->ext_e4[4 * k + 1], b = ((long long)B->ext_e4[4 * k + 2] << 32) | (unsigned)B->ext_e4[4 * k + 3];
+      return std::make_pair(std::min(a, b), std::max(a, b));
+    };
+    for (int k = 0; k < B->ext_n; k++) if (B->ext_e4[4 * k + 3] >= 0) order.push_back(k);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return key(x) < key(y); });
+    for (size_t q = 0; q < order.size(); q++) if (q + 1 == order.size() || key(order[q]) != key(order[q + 1])) gptr.push_back((int)q + 1);
+    B->ext_groups = (int)gptr.size() - 1;
+    if (order.empty()) order.push_back(0);
+    UP(B->d_ext_order, order); UP(B->d_ext_gptr, gptr);
+  }
   // ---- projection edges: point-major order (sorted by pose column inside a point), camera-major copy.  The edges are already
   // grouped by landmark with their cameras sorted by id (cams_of / edge_of above); a rank's point-major table is its own landmarks'
   // groups, each re-ordered by (column, camera id) -- k <= a handful of entries -- in a few host threads on disjoint ranges.
@@ -883,7 +1010,8 @@ int finalize_structure(cs_ba* B) {
   if (B->slot_src_cap < (size_t)E) { B->slot_src_cap = (size_t)E + (B->slot_src ? (size_t)E / 4 : 0) + 1; B->slot_src.reset(new int[B->slot_src_cap]); }
   B->slot_src_n = E;
   int* const src_of_slot = B->slot_src.get();
-  UBuf<int> pm_pt((size_t)E), pm_cam((size_t)E);
+  UBuf<int>& pm_pt = B->st_pm_pt; UBuf<int>& pm_cam = B->st_pm_cam;
+  pm_pt.ensure((size_t)E); pm_cam.ensure((size_t)E);
   const int NTH = (E > 20000) ? struct_threads() : 1;
   {
     auto build_points = [&](int p0, int p1) {
@@ -905,7 +1033,8 @@ int finalize_structure(cs_ba* B) {
   }
   mark("  point-major order");
   // camera-major: a stable counting sort of the point-major slots by camera, the slots cut into NTH ranges (per-range histograms)
-  UBuf<int> cm_pm((size_t)E), cm_pt((size_t)E);
+  UBuf<int>& cm_pm = B->st_cm_pm; UBuf<int>& cm_pt = B->st_cm_pt;
+  cm_pm.ensure((size_t)E); cm_pt.ensure((size_t)E);
   std::vector<int> cam_ptr(nc + 1, 0);
   {
     std::vector<std::vector<int>> hist(NTH, std::vector<int>(nc, 0));
@@ -1208,10 +1337,12 @@ int finalize_structure(cs_ba* B) {
       UP(B->d_oe_rk, kk); UP(B->d_oe_rdelta, dd);
     } else { B->d_oe_rk.release(); B->d_oe_rdelta.release(); }
   }
+  mark("  pose edge lists");
   UP(B->ce_meas, B->h_ce_meas); UP(B->ce_info, B->h_ce_info); UP(B->oe_meas, B->h_oe_meas); UP(B->oe_info, B->h_oe_info);
   UP(B->pe_meas, B->h_pe_meas); UP(B->pe_info, B->h_pe_info); UP(B->pe_K, B->h_pe_K);
   AL(B->ce_Hcc, 36 * (size_t)B->n_cub); AL(B->ce_Hoo, 81 * (size_t)B->n_cub); AL(B->ce_Hco, 54 * (size_t)B->n_cub); AL(B->ce_bc, 6 * (size_t)B->n_cub); AL(B->ce_bo, 9 * (size_t)B->n_cub);
   AL(B->oe_Hii, 36 * (size_t)B->n_odom); AL(B->oe_Hjj, 36 * (size_t)B->n_odom); AL(B->oe_Hij, 36 * (size_t)B->n_odom); AL(B->oe_bi, 6 * (size_t)B->n_odom); AL(B->oe_bj, 6 * (size_t)B->n_odom);
+  mark("  pose edge measurements");
   // ---- linear system storage
   AL(B->Hcam, 36 * (size_t)nc); AL(B->bcam, 6 * (size_t)nc); AL(B->Hcub, 81 * (size_t)no); AL(B->bcub, 9 * (size_t)no);
   AL(B->Hll, 9 * (size_t)np); AL(B->bl, 3 * (size_t)np); AL(B->W, 18 * (size_t)E); AL(B->WD, 18 * (size_t)E);
@@ -1256,11 +1387,12 @@ int finalize_structure(cs_ba* B) {
   {
     const size_t need = std::max<size_t>(16, (size_t)B->n_pose + 2);
     AL(B->d_scalars, need);
-    if (B->scalars_cap < need) {
+    if (B->scalars_cap < need) {     // (with head room: a graph that grows by a camera per frame would re-pin this buffer every frame, ~0.1 ms)
       if (B->h_scalars) (void)hipHostFree(B->h_scalars);
       B->h_scalars = nullptr;
-      BA_TRY(hipHostMalloc((void**)&B->h_scalars, need * sizeof(double)));
-      B->scalars_cap = need;
+      const size_t want = need + need / 4 + 256;
+      BA_TRY(hipHostMalloc((void**)&B->h_scalars, want * sizeof(double)));
+      B->scalars_cap = want;
     }
   }
   AL(B->cams_bak, 7 * (size_t)nc); AL(B->points_bak, 3 * (size_t)np); AL(B->cubes_bak, 10 * (size_t)no);
@@ -1269,7 +1401,9 @@ int finalize_structure(cs_ba* B) {
 #undef AL
 #undef UPB
   // (the helper thread allocates the edge tables' device buffers: their addresses are final only once it is done)
+  mark("  pose edge tables staged");
   edge_th.join();
+  mark("  edge-table thread joined");
   if (edge_rc) return edge_rc;
   cs::BaView& v = B->view;
   v.cams = B->cams.p; v.points = B->points.p; v.cubes = B->cubes.p; v.cam_col = B->d_cam_col.p; v.cub_col = B->d_cub_col.p; v.pt_free = B->d_pt_free.p;
@@ -1303,7 +1437,10 @@ int finalize_structure(cs_ba* B) {
   v.chi_partial = B->chi_partial.p;
   // the allocations above are zeroed on B->st (one batched fill, one wait here); uploads went through blocking copies
   ZFLUSH();
+  rc = cflush(true); if (rc) return rc;
   BA_TRY(hipStreamSynchronize(B->st));
+  B->append_stage.off = 0;           // (the appended rows have arrived)
+  B->st_lists_edges = B->n_proj; B->st_cam_cnt = std::move(cam_cnt); B->st_cur = st_nb;   // (for a grown graph's next phase)
   mark("pose edges + allocations");
   B->structure_dirty = false;
   B->have_system = false;
@@ -1460,7 +1597,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
     }
     if (!lean_head) BA_TRY(hipMemsetAsync(B->d_elim_fail.p, 0, sizeof(int), B->st));
     cs::ba_launch_reduce(B->view, B->d_lam.p, B->st, B->st2, B->ev_fork, B->ev_join);
-    if (B->ext_n > 0 && B->ext_terms_set) cs::ba_launch_ext_offdiag(B->view, B->ext_n, B->d_ext_e4.p, B->ext_Hij.p, B->st);
+    if (B->ext_n > 0 && B->ext_terms_set) cs::ba_launch_ext_offdiag(B->view, B->ext_groups, B->d_ext_gptr.p, B->d_ext_order.p, B->d_ext_e4.p, B->ext_Hij.p, B->st);
     BA_TRY(hipMemcpyAsync(B->h_status + 1, B->d_elim_fail.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
     BA_TRY(hipGetLastError());
     if (fn && B->shard_n > 1) {  // sum the ranks' partial reduced systems: [S | rhs] in one message
@@ -1504,15 +1641,13 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       std::unique_lock<std::mutex> coop_turn(g_coop_mutex);
       BA_TRY(hipMemsetAsync(B->sp_info.p, 0, 2 * sizeof(int), B->st));
       const cs::SparseView SV = sparse_view(B);
-      cs::launch_sparse_cholesky(SV, cs::sparse_max_panel_doubles(), B->st);
-      BA_TRY(hipGetLastError());
+      if (!cs::launch_sparse_cholesky(SV, cs::sparse_max_panel_doubles(), B->sp_grids, B->st)) { cs_set_error_ba("sparse solver: the factorisation could not be launched (grid " + std::to_string(B->sp_grids.chol) + " for " + std::to_string(SV.N) + " vertices)"); return CS_ERR_HIP; }
       BA_TRY(hipMemsetAsync(B->d_info.p, 0, sizeof(int), B->st));
       if (SV.n_tail > 0) {   // the top of the elimination tree as one dense block (same storage convention as the dense path's S)
         BA_ROC(rocsolver_dpotrf(B->blas, rocblas_fill_upper, SV.n_tail, SV.T, SV.n_tail, B->d_info.p));
         BA_ROC(rocsolver_dpotrs(B->blas, rocblas_fill_upper, SV.n_tail, 1, SV.T, SV.n_tail, SV.rhs_t, SV.n_tail));
       }
-      cs::launch_sparse_backsolve(SV, B->st);
-      BA_TRY(hipGetLastError());
+      if (!cs::launch_sparse_backsolve(SV, B->sp_grids, B->st)) { cs_set_error_ba("sparse solver: the substitution could not be launched (grid " + std::to_string(B->sp_grids.back) + " for " + std::to_string(SV.N) + " vertices)"); return CS_ERR_HIP; }
       BA_TRY(hipEventRecord(B->ev[4], B->st));
       cs::ba_launch_backsub(B->view, B->st);
       BA_TRY(hipGetLastError());
@@ -1702,12 +1837,12 @@ void cs_ba_destroy(cs_ba* B) {
                         &B->oe_meas, &B->oe_info, &B->oe_Hii, &B->oe_Hjj, &B->oe_Hij, &B->oe_bi, &B->oe_bj, &B->Hcam, &B->bcam, &B->Hcub, &B->bcub, &B->Hll, &B->bl,
                         &B->W, &B->WD, &B->Dinv, &B->dbl, &B->S, &B->rhs, &B->xl, &B->chi_partial, &B->band_linv, &B->scale_partial, &B->pe_meas, &B->pe_info, &B->pe_K, &B->part_tiles, &B->part_coef, &B->cub_M, &B->cub_Dinv, &B->raw_uv, &B->raw_info, &B->raw_intr, &B->raw_huber, &B->sepY, &B->sep_msgs, &B->sepS, &B->int_work, &B->sep_work, &B->d_ce_rdelta, &B->d_oe_rdelta, &B->ext_cam36, &B->ext_cam6, &B->ext_cub81, &B->ext_cub9, &B->ext_pt9, &B->ext_pt3, &B->ext_Hij, &B->sp_L, &B->sp_xs, &B->sp_T};
   for (auto* d : dd) d->release();
-  B->stage.release();
+  B->stage.release(); B->append_stage.release();
   DBuf<int>* di[] = {&B->d_ce_active, &B->d_oe_active, &B->d_cam_col, &B->d_cub_col, &B->d_pt_free, &B->pm_pt, &B->pm_cam, &B->pt_ptr, &B->cm_pm, &B->cm_pt, &B->cam_ptr, &B->d_ce_cam, &B->d_ce_cub,
                      &B->d_oe_i, &B->d_oe_j, &B->cam_ce_ptr, &B->cam_ce_idx, &B->cam_oei_ptr, &B->cam_oei_idx, &B->cam_oej_ptr, &B->cam_oej_idx, &B->cub_ce_ptr,
                      &B->cub_ce_idx, &B->pair_ptr, &B->pair_i1, &B->pair_i2, &B->ent_a, &B->ent_b, &B->d_run_lm, &B->d_seg_ptr, &B->d_seg_k, &B->d_seg_tile, &B->d_seg_slot,
                      &B->d_gp_ptr, &B->d_gp_i1, &B->d_gp_i2, &B->d_gtile, &B->d_gcam_ptr, &B->d_gslot, &B->d_cubS_ptr, &B->d_cubS_cam, &B->d_ce_slot, &B->d_cub_tile, &B->d_cub_coef,
-                     &B->d_elim_fail, &B->d_slotE_ptr, &B->d_slotE_idx, &B->d_cub_mine, &B->d_sep_off, &B->d_sep_col, &B->d_int_info, &B->d_sep_info, &B->d_pm_rk, &B->d_cm_rk, &B->d_ce_rk, &B->d_oe_rk, &B->d_ext_e4, &B->d_src, &B->sp_ndim, &B->sp_ncol, &B->sp_sptr, &B->sp_srow, &B->sp_sroff, &B->sp_prow, &B->sp_rbase, &B->sp_rent, &B->sp_rptr, &B->sp_rcol, &B->sp_rpos,
+                     &B->d_elim_fail, &B->d_slotE_ptr, &B->d_slotE_idx, &B->d_cub_mine, &B->d_sep_off, &B->d_sep_col, &B->d_int_info, &B->d_sep_info, &B->d_pm_rk, &B->d_cm_rk, &B->d_ce_rk, &B->d_oe_rk, &B->d_ext_e4, &B->d_ext_order, &B->d_ext_gptr, &B->d_src, &B->sp_ndim, &B->sp_ncol, &B->sp_sptr, &B->sp_srow, &B->sp_sroff, &B->sp_prow, &B->sp_rbase, &B->sp_rent, &B->sp_rptr, &B->sp_rcol, &B->sp_rpos,
                      &B->sp_order, &B->sp_info, &B->sp_tcol};
   for (auto* d : di) d->release();
   B->sp_poff.release(); B->sp_done.release(); B->sp_xdone.release();
@@ -1734,7 +1869,9 @@ static int cs_ba_set_vertices_impl(cs_ba* B, const double* cams7, const int* cam
                        const double* points3, const int* pt_fixed, int np, int cuboids_first) {
   if (!B || nc < 0 || no < 0 || np < 0 || (nc && (!cams7 || !cam_fixed)) || (no && (!cuboids10 || !cub_fixed)) || (np && (!points3 || !pt_fixed))) return CS_ERR_INVALID_ARG;
   BA_TRY(hipSetDevice(B->device));
+  BA_TRY(hipStreamSynchronize(B->st));       // (appended rows may still be on their way: cs_ba_append_* queues them on st)
   B->nc = nc; B->no = no; B->np = np; B->cuboids_first = cuboids_first;
+  B->st_lists_edges = 0;
   B->cam_fixed.assign(cam_fixed, cam_fixed + nc); B->cub_fixed.assign(cub_fixed, cub_fixed + no); B->pt_fixed.assign(pt_fixed, pt_fixed + np);
   // SE3Quat(Vector7d) normalises the rotation and makes w >= 0 (se3quat.h:68-71); cuboid::fromVector does not.
   std::vector<double> c(cams7, cams7 + 7 * (size_t)nc);
@@ -1756,6 +1893,11 @@ int cs_ba_set_vertices(cs_ba* B, const double* cams7, const int* cam_fixed, int 
 // Solver::updateStructure, core/solver.h:62, core/block_solver.hpp:297-350).  New vertices and edges are appended behind the existing
 // ones; the estimates that live on the device (possibly optimised there) stay untouched; the structure phase runs again on the
 // next solve (49 ms at C4, a few ms at C3 -- DESIGN.md section 3).
+// the appends' pinned staging arena (1 MB, made by the first append; rewound once the structure phase has waited for the stream)
+static int append_arena(cs_ba* B) {
+  if (B->append_stage.p) return CS_OK;
+  return B->append_stage.begin((size_t)1 << 20);
+}
 static int cs_ba_append_vertices_impl(cs_ba* B, const double* cams7, const int* cam_fixed, int n_cams, const double* cuboids10, const int* cub_fixed, int n_cub,
                                       const double* points3, const int* pt_fixed, int n_pts) {
   if (!B || n_cams < 0 || n_cub < 0 || n_pts < 0 || (n_cams && (!cams7 || !cam_fixed)) || (n_cub && (!cuboids10 || !cub_fixed)) || (n_pts && (!points3 || !pt_fixed))) return CS_ERR_INVALID_ARG;
@@ -1764,7 +1906,9 @@ static int cs_ba_append_vertices_impl(cs_ba* B, const double* cams7, const int* 
   std::vector<double> c(cams7, cams7 + 7 * (size_t)n_cams);
   for (int i = 0; i < n_cams; i++) { cs::Pose p = cs::pose_load(&c[7 * (size_t)i]); cs::pose_normalize(p); cs::pose_store(p, &c[7 * (size_t)i]); }
   int rc;
-  if ((rc = B->cams.append_ptr(c.data(), 7 * (size_t)n_cams)) || (rc = B->cubes.append_ptr(cuboids10, 10 * (size_t)n_cub)) || (rc = B->points.append_ptr(points3, 3 * (size_t)n_pts))) return rc;
+  if ((rc = append_arena(B))) return rc;
+  if ((rc = B->cams.append_ptr_staged(c.data(), 7 * (size_t)n_cams, B->append_stage, B->st)) || (rc = B->cubes.append_ptr_staged(cuboids10, 10 * (size_t)n_cub, B->append_stage, B->st)) ||
+      (rc = B->points.append_ptr_staged(points3, 3 * (size_t)n_pts, B->append_stage, B->st))) return rc;
   B->cam_fixed.insert(B->cam_fixed.end(), cam_fixed, cam_fixed + n_cams);
   B->cub_fixed.insert(B->cub_fixed.end(), cub_fixed, cub_fixed + n_cub);
   B->pt_fixed.insert(B->pt_fixed.end(), pt_fixed, pt_fixed + n_pts);
@@ -1787,6 +1931,7 @@ static void scan_uniform_records(cs_ba* B, bool first, const double* info4, cons
     if (n > 0) { std::memcpy(B->uni8, info4, 32); std::memcpy(B->uni8 + 4, intr4, 32); }
   }
   if (!(B->info_uniform || B->intr_uniform) || n <= 0) return;
+  const double t_scan = now_ms();
   const int nt = n > (1 << 16) ? 8 : 1;
   std::vector<char> ok_i(nt, 1), ok_k(nt, 1);
   auto work = [&](int t) {
@@ -1801,6 +1946,7 @@ static void scan_uniform_records(cs_ba* B, bool first, const double* info4, cons
   if (nt == 1) work(0);
   else { std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(work, t); for (auto& x : th) x.join(); }
   for (int t = 0; t < nt; t++) { B->info_uniform = B->info_uniform && ok_i[t]; B->intr_uniform = B->intr_uniform && ok_k[t]; }
+  if (getenv("CS_BA_PROF")) fprintf(stderr, "[ba set edges] uniform-record scan of %d edges: %.2f ms\n", n, now_ms() - t_scan);
 }
 int cs_ba_append_edges_proj(cs_ba* B, int n, const int* pt, const int* cam, const double* uv, const double* info4, const double* intr4, const double* huber) {
   if (!B || n < 0 || (n && (!pt || !cam || !uv || !info4 || !intr4))) return CS_ERR_INVALID_ARG;
@@ -1811,8 +1957,10 @@ int cs_ba_append_edges_proj(cs_ba* B, int n, const int* pt, const int* cam, cons
   BA_TRY(hipStreamSynchronize(B->st));
   int rc;
   scan_uniform_records(B, B->n_proj == 0, info4, intr4, n);
-  if ((rc = B->raw_uv.append_ptr(uv, 2 * (size_t)n)) || (rc = B->raw_info.append_ptr(info4, 4 * (size_t)n)) || (rc = B->raw_intr.append_ptr(intr4, 4 * (size_t)n))) return rc;
-  if (huber) { rc = B->raw_huber.append_ptr(huber, (size_t)n); if (rc) return rc; }
+  if ((rc = append_arena(B))) return rc;
+  if ((rc = B->raw_uv.append_ptr_staged(uv, 2 * (size_t)n, B->append_stage, B->st)) || (rc = B->raw_info.append_ptr_staged(info4, 4 * (size_t)n, B->append_stage, B->st)) ||
+      (rc = B->raw_intr.append_ptr_staged(intr4, 4 * (size_t)n, B->append_stage, B->st))) return rc;
+  if (huber) { rc = B->raw_huber.append_ptr_staged(huber, (size_t)n, B->append_stage, B->st); if (rc) return rc; }
   B->have_huber = huber != nullptr;
   B->e_pt.insert(B->e_pt.end(), pt, pt + n); B->e_cam.insert(B->e_cam.end(), cam, cam + n);
   if (!B->rk_proj.empty()) for (int k = 0; k < n; k++) B->rk_proj.push_back((huber && huber[k] > 0) ? cs::RK_HUBER : cs::RK_NONE);
@@ -1860,6 +2008,7 @@ int cs_ba_append_edges_odom(cs_ba* B, int n, const int* ci, const int* cj, const
 static int cs_ba_set_estimates_impl(cs_ba* B, const double* cams7, const double* cuboids10, const double* points3) {
   if (!B) return CS_ERR_INVALID_ARG;
   BA_TRY(hipSetDevice(B->device));
+  BA_TRY(hipStreamSynchronize(B->st));       // (appended rows may still be on their way)
   if (cams7 && B->nc) {
     std::vector<double> c(cams7, cams7 + 7 * (size_t)B->nc);
     for (int i = 0; i < B->nc; i++) { cs::Pose p = cs::pose_load(&c[7 * (size_t)i]); cs::pose_normalize(p); cs::pose_store(p, &c[7 * (size_t)i]); }
@@ -1879,8 +2028,10 @@ int cs_ba_set_estimates(cs_ba* B, const double* cams7, const double* cuboids10, 
 static int cs_ba_set_edges_proj_impl(cs_ba* B, int n, const int* pt, const int* cam, const double* uv, const double* info4, const double* intr4, const double* huber) {
   if (!B || n < 0 || (n && (!pt || !cam || !uv || !info4 || !intr4))) return CS_ERR_INVALID_ARG;
   B->n_proj = n;
+  B->st_lists_edges = 0;
   B->e_pt.assign(pt, pt + n); B->e_cam.assign(cam, cam + n);
   BA_TRY(hipSetDevice(B->device));
+  BA_TRY(hipStreamSynchronize(B->st));       // (appended rows may still be on their way)
   int rc;
   scan_uniform_records(B, true, info4, intr4, n);
   if ((rc = B->raw_uv.upload_ptr(uv, 2 * (size_t)n)) || (rc = B->raw_info.upload_ptr(info4, 4 * (size_t)n)) || (rc = B->raw_intr.upload_ptr(intr4, 4 * (size_t)n))) return rc;
@@ -1998,6 +2149,7 @@ static int cs_ba_set_robust_kernels_impl(cs_ba* B, int edge_class, int n, const 
   const int have = edge_class == CS_EDGE_PROJ ? B->n_proj : edge_class == CS_EDGE_CUBOID ? (int)B->u3_cam.size() : edge_class == CS_EDGE_CUBOID_PROJ ? (int)B->up_cam.size()
                  : edge_class == CS_EDGE_ODOM ? B->n_odom : -1;
   if (have < 0) { cs_set_error_ba("cs_ba_set_robust_kernels: unknown edge class"); return CS_ERR_INVALID_ARG; }
+  if (!kind) n = have;         // removing the class's kernels: the count is the library's own (n is ignored)
   if (n != have) { cs_set_error_ba("cs_ba_set_robust_kernels: n must equal the number of edges of the class (set the edges first)"); return CS_ERR_INVALID_ARG; }
   std::vector<int> kk(n, 0); std::vector<double> dd(n, 0.0);
   for (int k = 0; k < n && kind; k++) {
@@ -2499,7 +2651,7 @@ static int cs_ba_get_reduced_system_impl(cs_ba* B, double lambda, double* S_dens
   BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (B->s_doubles + B->n_pose), B->st));
   BA_TRY(hipMemsetAsync(B->d_elim_fail.p, 0, sizeof(int), B->st));
   cs::ba_launch_reduce(B->view, B->d_lam.p, B->st, B->st2, B->ev_fork, B->ev_join);
-  if (B->ext_n > 0 && B->ext_terms_set) cs::ba_launch_ext_offdiag(B->view, B->ext_n, B->d_ext_e4.p, B->ext_Hij.p, B->st);
+  if (B->ext_n > 0 && B->ext_terms_set) cs::ba_launch_ext_offdiag(B->view, B->ext_groups, B->d_ext_gptr.p, B->d_ext_order.p, B->d_ext_e4.p, B->ext_Hij.p, B->st);
   BA_TRY(hipGetLastError());
   std::vector<double> h(B->s_doubles + B->n_pose);
   BA_TRY(hipMemcpyAsync(h.data(), B->S.p, 8 * h.size(), hipMemcpyDeviceToHost, B->st));

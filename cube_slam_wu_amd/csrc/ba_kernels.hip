@@ -2685,24 +2685,33 @@ __global__ __launch_bounds__(256) void ba_ext_add_kernel(BaView v, const double*
 }
 // e4: (class_i, idx_i, class_j, idx_j) per edge, class 0 = camera (6), 1 = cuboid (9); Hij: 81 per edge, row-major dim_i x dim_j.
 // A binary edge between two free pose vertices adds its block to the reduced system like an odometry edge's (ba_offdiag_kernel).
-__global__ __launch_bounds__(128) void ba_ext_offdiag_kernel(BaView v, int n, const int* e4, const double* Hij) {
-  const int k = blockIdx.x, t = threadIdx.x;
-  if (k >= n) return;
-  const int ci = e4[4 * k], ii = e4[4 * k + 1], cj = e4[4 * k + 2], ij = e4[4 * k + 3];
-  if (ij < 0 || ci > 1 || cj > 1) return;                 // unary edge: diagonal terms only
-  const int ca = ci ? v.cub_col[ii] : v.cam_col[ii], cb = cj ? v.cub_col[ij] : v.cam_col[ij];
-  const int di = ci ? 9 : 6, dj = cj ? 9 : 6;
-  if (ca < 0 || cb < 0 || ca >= v.n_red || cb >= v.n_red || t >= di * dj) return;
-  const int i = t / dj, j = t % dj;
-  const double val = Hij[81 * (size_t)k + t];
-  if (cb > ca) atomicAdd(ba_S_at(v, cb + j, ca + i), val); else atomicAdd(ba_S_at(v, ca + i, cb + j), val);
+// One workgroup per destination pair of vertices (gptr / order: the edges grouped by unordered pair on the host, in the caller's order inside
+// a group): its edges are added one after the other with plain read-modify-writes -- several edges on one pair, in either orientation, sum in
+// a fixed order, like every other sum of the reduced system (no atomics: a trial's S does not depend on scheduling).
+__global__ __launch_bounds__(128) void ba_ext_offdiag_kernel(BaView v, int n_groups, const int* gptr, const int* order, const int* e4, const double* Hij) {
+  const int g = blockIdx.x, t = threadIdx.x;
+  if (g >= n_groups) return;
+  for (int q = gptr[g]; q < gptr[g + 1]; q++) {
+    const int k = order[q];
+    const int ci = e4[4 * k], ii = e4[4 * k + 1], cj = e4[4 * k + 2], ij = e4[4 * k + 3];
+    if (ij < 0 || ci > 1 || cj > 1) continue;               // unary edge: diagonal terms only   (uniform over the workgroup)
+    const int ca = ci ? v.cub_col[ii] : v.cam_col[ii], cb = cj ? v.cub_col[ij] : v.cam_col[ij];
+    const int di = ci ? 9 : 6, dj = cj ? 9 : 6;
+    if (ca < 0 || cb < 0 || ca >= v.n_red || cb >= v.n_red) continue;
+    if (t < di * dj) {
+      const int i = t / dj, j = t % dj;
+      double* dst = cb > ca ? ba_S_at(v, cb + j, ca + i) : ba_S_at(v, ca + i, cb + j);
+      *dst += Hij[81 * (size_t)k + t];
+    }
+    __syncthreads();     // (the next edge of the pair may be stored the other way round: another thread's element)
+  }
 }
 void ba_launch_ext_add(const BaView& v, const double* cam36, const double* cam6, const double* cub81, const double* cub9, const double* pt9, const double* pt3, hipStream_t st) {
   const long long total = (long long)v.nc * 42 + (long long)v.no * 90 + (long long)v.np * 12;
   if (total > 0) hipLaunchKernelGGL(ba_ext_add_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, v, cam36, cam6, cub81, cub9, pt9, pt3);
 }
-void ba_launch_ext_offdiag(const BaView& v, int n, const int* e4, const double* Hij, hipStream_t st) {
-  if (n > 0) hipLaunchKernelGGL(ba_ext_offdiag_kernel, dim3(n), dim3(128), 0, st, v, n, e4, Hij);
+void ba_launch_ext_offdiag(const BaView& v, int n_groups, const int* gptr, const int* order, const int* e4, const double* Hij, hipStream_t st) {
+  if (n_groups > 0) hipLaunchKernelGGL(ba_ext_offdiag_kernel, dim3(n_groups), dim3(128), 0, st, v, n_groups, gptr, order, e4, Hij);
 }
 int ba_scale_blocks() { return SCALE_BLOCKS; }
 // out[0] = sum of a[0 .. na), out[1] = sum of b[0 .. nb): fixed-shape tree (one workgroup), so the value does not depend on
@@ -2760,6 +2769,32 @@ void ba_launch_multi_zero(const std::pair<void*, size_t>* list, int n, hipStream
   }
   unsigned gx = (unsigned)std::min<unsigned long long>(512, (mx / 4 + 255) / 256 + 1);
   hipLaunchKernelGGL(ba_multi_zero_kernel, dim3(gx, n), dim3(256), 0, st, L);
+}
+// up to 48 small uploads by one launch: the sources sit in the structure phase's pinned staging arena (host memory the device reads over
+// the link), the destinations are the handle's tables.  One hipMemcpyAsync per table was ~80 copies of a few KB in an appended frame's
+// structure phase: 5 us of host time and a blit of its own on the stream apiece.  blockIdx.y = table, 4-byte words, 16-byte steps.
+struct BaCopyList { unsigned* dst[48]; const unsigned* src[48]; unsigned long long words[48]; };
+__global__ __launch_bounds__(256) void ba_multi_copy_kernel(BaCopyList L) {
+  unsigned* __restrict__ d = L.dst[blockIdx.y];
+  const unsigned* __restrict__ s = L.src[blockIdx.y];
+  const unsigned long long n = L.words[blockIdx.y], n4 = n / 4;
+  uint4* __restrict__ d4 = reinterpret_cast<uint4*>(d);
+  const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(s);      // (arena offsets are multiples of 64 bytes, hipMalloc aligns to 256)
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (unsigned long long)gridDim.x * 256) d4[i] = s4[i];
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3ull)) d[4 * n4 + threadIdx.x] = s[4 * n4 + threadIdx.x];
+}
+void ba_launch_multi_copy(const BaCopyItem* list, int n, hipStream_t st) {
+  if (n <= 0) return;
+  BaCopyList L;
+  unsigned long long mx = 0;
+  for (int i = 0; i < 48; i++) {
+    const int q = i < n ? i : 0;
+    L.dst[i] = static_cast<unsigned*>(list[q].dst); L.src[i] = static_cast<const unsigned*>(list[q].src);
+    L.words[i] = i < n ? list[q].bytes / 4 : 0;                   // (int and double elements: a multiple of 4 bytes)
+    if (L.words[i] > mx) mx = L.words[i];
+  }
+  unsigned gx = (unsigned)std::min<unsigned long long>(64, (mx / 4 + 255) / 256 + 1);
+  hipLaunchKernelGGL(ba_multi_copy_kernel, dim3(gx, n), dim3(256), 0, st, L);
 }
 // Head of a trial on the banded path: lambda into device memory (the kernels read it from there), the factorisation's status words,
 // the cuboid elimination's failure word and the reduced system's right-hand side cleared -- one launch instead of a copy and three fills.

@@ -169,10 +169,11 @@ struct SparseView {
   unsigned* done; unsigned* xdone;    // per position: factorised / solved (zeroed by the launcher)
   int* info;                          // [0]: first non-positive pivot + 1 (0x7fffffff: a wait timed out), [1]: abort word
 };
-bool sparse_fits_device(int max_panel_doubles, int N);
+struct SparseGrids { int chol, back; };   // workgroups of the factorisation (co-resident) and of the substitution
+bool sparse_grids(int max_panel_doubles, int N, SparseGrids* g);   // structure phase, once per plan; false: the factorisation does not fit the device
 int sparse_max_panel_doubles();
-void launch_sparse_cholesky(const SparseView& V, int max_panel_doubles, hipStream_t st);     // factorisation (+ the tail's block assembled)
-void launch_sparse_backsolve(const SparseView& V, hipStream_t st);
+bool launch_sparse_cholesky(const SparseView& V, int max_panel_doubles, const SparseGrids& g, hipStream_t st);     // factorisation (+ the tail's block assembled); false: not launched
+bool launch_sparse_backsolve(const SparseView& V, const SparseGrids& g, hipStream_t st);
 void launch_sparse_zero_pattern(const SparseView& V, double* S, hipStream_t st);                // S's pattern blocks <- 0 (before a trial's assembly)                           // after the tail's x sits in rhs_t: L^T x = y
 
 }  // namespace cs

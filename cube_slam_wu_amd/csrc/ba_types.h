@@ -6,6 +6,9 @@
 
 namespace cs {
 
+// one small upload of the structure phase, deferred to a batched launch (ba_launch_multi_copy): src in pinned host memory
+struct BaCopyItem { void* dst; const void* src; size_t bytes; };
+
 struct BaView {
   // ---- vertices (estimates) -------------------------------------------------------------------------
   double* cams;      // nc x 7   world-to-camera SE3Quat (VertexSE3Expmap)

@@ -280,37 +280,41 @@ __global__ __launch_bounds__(64) void sparse_tail_scatter_kernel(SparseView V) {
 int sparse_max_panel_doubles() { return 16384; }   // 128 KB of the 160 KB LDS: panels of up to ~1 800 rows x 9
 static size_t sparse_lds_bytes(int panel_cap, int N) { return (size_t)(panel_cap + 243) * sizeof(double) + (size_t)(N + 2) * sizeof(int); }
 
-// the factorisation's workgroups wait for each other: the grid must be resident as a whole
-static int sparse_grid(int panel_cap, int N) {
-  int dev = 0, occ = 0;
+// the factorisation's workgroups wait for each other: the grid must be resident as a whole.  Decided ONCE, in the structure phase (device
+// properties, the kernel's LDS attribute and the occupancy query are not per-trial work), and kept with the handle.
+bool sparse_grids(int panel_cap, int N, SparseGrids* g) {
+  int dev = 0, occ = 0, occ_b = 0;
   hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  g->chol = g->back = 0;
+  if (N <= 0 || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
   const size_t lds = sparse_lds_bytes(panel_cap, N);
-  if (lds > 156 * 1024) return 0;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_chol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sparse_chol_kernel, SP_T, lds) != hipSuccess || occ < 1) return 0;
-  return std::min(N, occ * prop.multiProcessorCount);
+  if (lds > 156 * 1024) return false;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_chol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sparse_chol_kernel, SP_T, lds) != hipSuccess || occ < 1) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, sparse_back_kernel, 64, 0) != hipSuccess || occ_b < 1) occ_b = 1;
+  g->chol = std::min(N, occ * prop.multiProcessorCount);
+  g->back = std::min(N, occ_b * prop.multiProcessorCount);
+  return g->chol > 0;
 }
-bool sparse_fits_device(int max_panel_doubles, int N) { return sparse_grid(max_panel_doubles, N) > 0; }
 
-void launch_sparse_cholesky(const SparseView& V, int max_panel_doubles, hipStream_t st) {
-  const int G = sparse_grid(max_panel_doubles, V.N);
-  if (G <= 0) return;
-  (void)hipMemsetAsync(V.done, 0, sizeof(unsigned) * (size_t)V.N, st);
-  (void)hipMemsetAsync(V.xdone, 0, sizeof(unsigned) * (size_t)(V.N + 1), st);
-  if (V.n_tail > 0) (void)hipMemsetAsync(V.T, 0, sizeof(double) * ((size_t)V.n_tail * V.n_tail + V.n_tail), st);
-  hipLaunchKernelGGL(sparse_chol_kernel, dim3(G), dim3(SP_T), sparse_lds_bytes(max_panel_doubles, V.N), st, V, max_panel_doubles);
+// (false: no launch -- grids that sparse_grids() did not produce, or a failed clear / launch; the caller reports it instead of waiting
+// on flags nobody raises)
+bool launch_sparse_cholesky(const SparseView& V, int max_panel_doubles, const SparseGrids& g, hipStream_t st) {
+  if (g.chol <= 0 || g.chol > V.N) return false;
+  if (hipMemsetAsync(V.done, 0, sizeof(unsigned) * (size_t)V.N, st) != hipSuccess) return false;
+  if (hipMemsetAsync(V.xdone, 0, sizeof(unsigned) * (size_t)(V.N + 1), st) != hipSuccess) return false;
+  if (V.n_tail > 0 && hipMemsetAsync(V.T, 0, sizeof(double) * ((size_t)V.n_tail * V.n_tail + V.n_tail), st) != hipSuccess) return false;
+  hipLaunchKernelGGL(sparse_chol_kernel, dim3(g.chol), dim3(SP_T), sparse_lds_bytes(max_panel_doubles, V.N), st, V, max_panel_doubles);
+  return hipGetLastError() == hipSuccess;
 }
 void launch_sparse_zero_pattern(const SparseView& V, double* S, hipStream_t st) {
   if (V.N > 0) hipLaunchKernelGGL(sparse_zero_pattern_kernel, dim3(V.N), dim3(256), 0, st, V, S);
 }
-void launch_sparse_backsolve(const SparseView& V, hipStream_t st) {
+bool launch_sparse_backsolve(const SparseView& V, const SparseGrids& g, hipStream_t st) {
+  if (g.back <= 0 || g.back > V.N) return false;
   if (V.n_tail > 0) hipLaunchKernelGGL(sparse_tail_scatter_kernel, dim3(V.N - V.tail_start), dim3(64), 0, st, V);
-  int occ = 0, dev = 0;
-  hipDeviceProp_t prop;
-  (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&prop, dev);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sparse_back_kernel, 64, 0) != hipSuccess || occ < 1) occ = 1;
-  hipLaunchKernelGGL(sparse_back_kernel, dim3(std::min(V.N, occ * prop.multiProcessorCount)), dim3(64), 0, st, V);
+  hipLaunchKernelGGL(sparse_back_kernel, dim3(g.back), dim3(64), 0, st, V);
+  return hipGetLastError() == hipSuccess;
 }
 
 }  // namespace cs

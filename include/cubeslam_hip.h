@@ -274,7 +274,7 @@ int cs_ba_set_edges_odom(cs_ba* ba, int n, const int* cam_i, const int* cam_j, c
  * base_unary_edge.hpp:55-63, base_edge.h:96-102; rho'' is unused there).  delta[k] = RobustKernel::delta() (for DCS: phi; for Tukey:
  * _deltaSqr = delta^2, _invDeltaSqr = 1 / delta^2 as single-precision members, as in the reference).  Huber's delta^2 is a
  * single-precision member too (robust_kernel_impl.h:86) and is used as such.  Call after the class's edges are set; n = the class's
- * edge count; kind == NULL removes the class's kernels.  cs_ba_set_edges_proj's `huber` argument is shorthand for
+ * edge count; kind == NULL removes the class's kernels (n is then ignored).  cs_ba_set_edges_proj's `huber` argument is shorthand for
  * (CS_RK_HUBER, huber[k]) where huber[k] > 0.  Edges appended later carry no kernel (projection edges: their `huber` value).     */
 enum cs_robust_kernel { CS_RK_NONE = 0, CS_RK_HUBER = 1, CS_RK_PSEUDO_HUBER = 2, CS_RK_CAUCHY = 3, CS_RK_SATURATED = 4, CS_RK_DCS = 5, CS_RK_TUKEY = 6 };
 enum cs_edge_class { CS_EDGE_PROJ = 0, CS_EDGE_CUBOID = 1, CS_EDGE_CUBOID_PROJ = 2, CS_EDGE_ODOM = 3 };

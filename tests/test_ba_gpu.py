@@ -179,6 +179,35 @@ def test_external_edges_equal_the_same_edges_evaluated_on_the_device():
     G.close(); X.close(); Y.close()
 
 
+def test_external_edges_on_one_vertex_pair_sum_in_a_fixed_order():
+    """Several host-evaluated edges between the same two vertices -- one of them stored the other way round -- go into the reduced system
+    one after the other inside one workgroup (ba_ext_offdiag_kernel: no atomics).  With dyadic block values the sum is exact in any
+    order, so the damped solve must equal, bit for bit, a handle that carries the summed block as ONE edge; and repeat itself."""
+    pr = synth_ba.make_problem(n_cams=30, n_points=1200, n_cuboids=3, seed=4)
+    rng = np.random.default_rng(0)
+    blk = rng.integers(-64, 64, (3, 6, 6)) / 16.0
+    pairs = [(3, 7), (3, 7), (7, 3), (10, 11)]
+    H = np.zeros((4, 81))
+    H[0, :36] = blk[0].ravel(); H[1, :36] = blk[1].ravel(); H[2, :36] = blk[2].T.ravel(); H[3, :36] = blk[0].ravel()
+    one = np.zeros((2, 81)); one[0, :36] = (blk[0] + blk[1] + blk[2]).ravel(); one[1, :36] = blk[0].ravel()
+    nc = len(pr["cams"])
+    xs = []
+    for edges, Hij in ((pairs, H), ([(3, 7), (10, 11)], one), (pairs, H)):
+        X = capi.ba_from_dict(pr)
+        X.set_external_edges(np.zeros(len(edges)), [a for a, _ in edges], np.zeros(len(edges)), [b for _, b in edges])
+        X.set_external_terms(cam36=np.zeros((nc, 36)), cam6=np.zeros((nc, 6)), Hij81=Hij, chi2=0.0)
+        X.compute_errors(); X.build_system()
+        ok, x = X.solve(1.5)
+        assert ok
+        xs.append(x)
+        X.close()
+    assert np.array_equal(xs[0], xs[1]) and np.array_equal(xs[0], xs[2])
+    G = capi.ba_from_dict(pr)
+    G.compute_errors(); G.build_system()
+    assert not np.array_equal(G.solve(1.5)[1], xs[0])         # (the blocks matter)
+    G.close()
+
+
 def test_external_edges_are_validated():
     pr = synth_ba.make_problem(n_cams=12, n_points=300, n_cuboids=2, seed=2)
     G = capi.ba_from_dict(pr)
@@ -238,6 +267,11 @@ def test_dump_and_load_round_trip(tmp_path):
         assert np.array_equal(a, b)
     for a, b in zip(G.state(), L.state()):
         assert np.array_equal(a, b)
+    # removing a class's kernels needs no edge count from the caller: a loaded handle (no setter ever ran on the Python object) can do it too
+    c_with = L.compute_errors()
+    for cls in (capi.EDGE_PROJ, capi.EDGE_CUBOID, capi.EDGE_CUBOID_PROJ, capi.EDGE_ODOM):
+        L.set_robust_kernels(cls, None, None); G.set_robust_kernels(cls, None, None)
+    assert L.compute_errors() == G.compute_errors() != c_with
     with open(path, "r+b") as f:
         f.truncate(os.path.getsize(path) - 100)
     with pytest.raises(RuntimeError, match="truncated"):

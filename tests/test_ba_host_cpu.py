@@ -39,14 +39,17 @@ def edges(sel_p, sel_c, sel_o):
 omax = np.maximum(pr["oe_i"], pr["oe_j"])
 n_p = int((fp < T0).sum())
 G = capi.BaProblem(pr["cams"][:T0], pr["cam_fixed"][:T0], pr["cuboids"], pr["cub_fixed"], pts[:n_p], ptf[:n_p])
-ep, ec, eo = edges(pr["e_cam"] < T0, pr["ce_cam"] < T0, omax < T0)
+# (2 %% of the early cameras' projection edges are held back and arrive with the last frame: appended edges whose camera sorts BEFORE the
+# landmark's existing ones -- the grown graph's camera lists are extended, not rebuilt, and must still come out sorted)
+late = (np.random.default_rng(1).random(len(ept)) < 0.02) & (pr["e_cam"] < T0)
+ep, ec, eo = edges((pr["e_cam"] < T0) & ~late, pr["ce_cam"] < T0, omax < T0)
 G.set_edges_proj(*ep); G.set_edges_cuboid(*ec); G.set_edges_odom(*eo)
 G.structure_digest()
 parts = [(ep, ec, eo)]
 for t in range(T0, nc):
     n_p2 = int((fp < t + 1).sum())
     G.append_vertices(pr["cams"][t:t + 1], pr["cam_fixed"][t:t + 1], None, None, pts[n_p:n_p2], ptf[n_p:n_p2])
-    ep, ec, eo = edges(pr["e_cam"] == t, pr["ce_cam"] == t, omax == t)
+    ep, ec, eo = edges((pr["e_cam"] == t) | (late if t == nc - 1 else False), pr["ce_cam"] == t, omax == t)
     G.append_edges_proj(*ep); G.append_edges_cuboid(*ec); G.append_edges_odom(*eo)
     parts.append((ep, ec, eo)); n_p = n_p2
     G.structure_digest()                      # (the structure phase after every frame, as optimize() would run it)
@@ -61,7 +64,7 @@ H.close()
 
 
 def _run(shim, threads):
-    env = dict(os.environ, LD_PRELOAD=str(shim))
+    env = dict(os.environ, LD_PRELOAD=str(shim), CS_BA_UPLOAD_KERNEL="0")     # (kernels do not run under the shim: the tables go up by per-table copies)
     env.pop("CS_BA_STRUCT_THREADS", None)
     if threads:
         env["CS_BA_STRUCT_THREADS"] = str(threads)
