@@ -862,6 +862,9 @@ int finalize_structure(cs_ba* B) {
       const int mode = e ? atoi(e) : -1;
       const double nn = (double)O.n_red;
       double est_band = B->band_ld ? 1.15 * nn / 64.0 * (10.0 + 0.043 * (B->band_ld - 1)) * 1e-3 : 1e30;
+      // (wide bands: the line above was fitted on bandwidths of 100-200; the 1 920-camera survey mesh -- 11 514 unknowns, bandwidth 1 121 -- takes the banded
+      // kernels 14.2 ms where it says 12.0 (bench.py, ba.solver_paths: 17.2 ms per damped solve against 14.8 through the sparse path, ~3 ms of either the reduce))
+      if (B->band_ld > 128) est_band *= 1.0 + 0.00018 * (B->band_ld - 128);
       const double est_dense = nn * nn * nn / 3.0 / 11e12 * 1e3 + 1.0;
       // block cyclic reduction where the band is narrow enough for 128-unknown blocks and its few levels beat the banded kernels' chain of steps
       B->use_bcr = false;
