@@ -133,7 +133,7 @@ class detect_3d_cuboid {
   }
 
   // public flags, same names and defaults as the reference (:95-117); plotting flags are accepted and ignored
-  bool whether_plot_detail_images = false;
+  bool whether_plot_detail_images = true;    // (the reference's default, :95; nothing is plotted here whatever it says)
   bool whether_plot_final_images = false;
   bool whether_save_final_images = false;
   cv::Mat cuboids_2d_img;
