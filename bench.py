@@ -211,6 +211,24 @@ def main():
             return int(kv.get("usage_usec", 0)), int(kv.get("nr_throttled", 0)), int(kv.get("throttled_usec", 0))
         except (OSError, ValueError):
             return None
+    # The warm-up steps once more the way the timed steps run: all pipelines side by side, four rounds of the batches in flight (untimed).  The loop
+    # above runs every batch ALONE (it also gives the isolated kernel timings); a device that has only seen one batch at a time entered the timed region
+    # cold -- a fixed ~16 ms per run whatever K (400 steps 2.74 ms per step, 40: 3.15, 20: 3.6 on one box) -- and the contract run read 8-20 % under the
+    # steady rate for that reason, not for its pipe's fill and drain: with this warm-up 40 steps went 326-329 k -> 359-382 k frames/s on the same box,
+    # 20 steps 313-338 k -> 347-390 k.  CS_BENCH_CONCURRENT_WARMUP=0: the old behaviour.
+    if args.warmup > 0 and inflight > 1 and os.environ.get("CS_BENCH_CONCURRENT_WARMUP", "1") != "0":
+        contract_steps = args.steps
+        args.steps = max(args.warmup, inflight * depth) * int(os.environ.get("CS_BENCH_WARMUP_ROUNDS", "4"))
+        steps_taken[0] = 0
+        accs_saved, accs[:] = list(accs), [dict() for _ in range(inflight)]
+        th = [threading.Thread(target=drive, args=(p,)) for p in range(inflight)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        accs[:] = accs_saved
+        args.steps = contract_steps
+        steps_taken[0] = 0
+        if errs:
+            raise errs[0]
     barrier()
     cg0 = cgroup_cpu()
     t0 = time.perf_counter()
