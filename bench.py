@@ -170,7 +170,7 @@ def main():
     # warm-up: every pipeline alone (also the isolated kernel timings: nothing else runs on the device)
     iso = {}
     for p in range(inflight * depth):
-        for _ in range(args.warmup):
+        for _ in range(max(1, args.warmup)):     # (at least once: a batch's device and pinned buffers are sized by its first run -- set-up, whatever W says)
             bats[p].run()
             if p == 0:
                 for k, v in bats[p].timing().items():
