@@ -62,7 +62,7 @@ void ba_launch_sum2(const double* a, int na, const double* b, int nb, double* ou
 void ba_launch_multi_zero(const std::pair<void*, size_t>* list, int n, hipStream_t st);
 void ba_launch_multi_copy(const BaCopyItem* list, int n, hipStream_t st);
 void ba_launch_sum2_flag(const double* a, int na, const double* b, int nb, const int* f0, const int* f1, double* out, hipStream_t st);
-void ba_launch_trial_prologue(double* d_lam, double lam0, double lam1, int* info24, int* elim_fail, double* rhs, int n_rhs, hipStream_t st);
+void ba_launch_trial_prologue(double* d_lam, double lam0, double lam1, int* info24, int* elim_fail, double* S, size_t n_clear, hipStream_t st);
 void ba_launch_ext_add(const BaView& v, const double* cam36, const double* cam6, const double* cub81, const double* cub9, const double* pt9, const double* pt3, hipStream_t st);
 void ba_launch_ext_offdiag(const BaView& v, int n_groups, const int* gptr, const int* order, const int* e4, const double* Hij, hipStream_t st);
 void ba_launch_scan_finite(const double* p, long long n, int* out, hipStream_t st);
@@ -1585,11 +1585,10 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
     const bool lean_head = B->band_ld > 0 && !B->sparse;      // (banded path: one prologue kernel instead of a copy and three fills)
     if (lean_head) {
       B->h_lam[0] = lambda; B->h_lam[1] = B->shard_rank == 0 ? lambda : 0.0;
-      cs::ba_launch_trial_prologue(B->d_lam.p, B->h_lam[0], B->h_lam[1], B->d_band_info.p, B->d_elim_fail.p, B->S.p + B->s_doubles, B->n_pose, B->st);
+      cs::ba_launch_trial_prologue(B->d_lam.p, B->h_lam[0], B->h_lam[1], B->d_band_info.p, B->d_elim_fail.p, B->S.p, B->s_doubles + (size_t)B->n_pose, B->st);   // (+ [S | rhs] cleared: no fill of its own)
     } else { int rcl = put_lambda(B, lambda); if (rcl) return rcl; }
     BA_TRY(hipEventRecord(B->ev[2], B->st));
     if (lean_head) {
-      BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * B->s_doubles, B->st));
     } else if (B->sparse && B->sp_S_clean) {
       // (sparse path: S was cleared by the structure phase and only the plan's pattern is ever written -- the pattern and the right-hand side)
       cs::launch_sparse_zero_pattern(sparse_view(B), B->S.p, B->st);
@@ -1601,7 +1600,11 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
     if (!lean_head) BA_TRY(hipMemsetAsync(B->d_elim_fail.p, 0, sizeof(int), B->st));
     cs::ba_launch_reduce(B->view, B->d_lam.p, B->st, B->st2, B->ev_fork, B->ev_join);
     if (B->ext_n > 0 && B->ext_terms_set) cs::ba_launch_ext_offdiag(B->view, B->ext_groups, B->d_ext_gptr.p, B->d_ext_order.p, B->d_ext_e4.p, B->ext_Hij.p, B->st);
-    BA_TRY(hipMemcpyAsync(B->h_status + 1, B->d_elim_fail.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
+    // (block cyclic reduction in a deferred trial: no kernel of it waits for another -- no time-out word to read --, and the two failure words
+    // reach the host folded into the trial's scalars by the caller's sum kernel: the two 4-byte copies, a blit launch each, stay away)
+    const bool status_in_scalars = defer != nullptr && B->band_ld > 0 && B->use_bcr;
+    if (status_in_scalars) { B->h_status[0] = 0; B->h_status[1] = 0; }
+    else BA_TRY(hipMemcpyAsync(B->h_status + 1, B->d_elim_fail.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
     BA_TRY(hipGetLastError());
     if (fn && B->shard_n > 1) {  // sum the ranks' partial reduced systems: [S | rhs] in one message
       BA_TRY(hipStreamSynchronize(B->st));
@@ -1630,7 +1633,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       }
       { int rc2 = share_cuboid_increments(B, fn, ctx); if (rc2) return rc2; }
       BA_TRY(hipEventRecord(B->ev[5], B->st));
-      BA_TRY(hipMemcpyAsync(B->h_status, B->d_band_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
+      if (!status_in_scalars) BA_TRY(hipMemcpyAsync(B->h_status, B->d_band_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
       if (defer) { *defer = std::move(coop_turn); B->tm.n_solves++; return CS_OK; }   // (the caller's sum kernel folds the two status words into the trial's scalars)
       cs::ba_launch_fail_flag(B->d_band_info.p, B->d_elim_fail.p, nullptr, B->d_scalars.p + 2, B->st);
       BA_TRY(hipStreamSynchronize(B->st));

@@ -2798,18 +2798,23 @@ void ba_launch_multi_copy(const BaCopyItem* list, int n, hipStream_t st) {
 }
 // Head of a trial on the banded path: lambda into device memory (the kernels read it from there), the factorisation's status words,
 // the cuboid elimination's failure word and the reduced system's right-hand side cleared -- one launch instead of a copy and three fills.
-__global__ __launch_bounds__(256) void ba_trial_prologue_kernel(double* d_lam, double lam0, double lam1, int* info24, int* elim_fail, double* rhs, int n_rhs) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t < n_rhs) rhs[t] = 0.0;
+__global__ __launch_bounds__(256) void ba_trial_prologue_kernel(double* d_lam, double lam0, double lam1, int* info24, int* elim_fail, double* S, size_t n_clear) {
+  // [S | rhs] cleared (16 bytes per thread and step: hipMalloc aligns to 256 bytes), the status words, lambda
+  double2* __restrict__ S2 = reinterpret_cast<double2*>(S);
+  const size_t n2 = n_clear / 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) S2[i] = make_double2(0.0, 0.0);
   if (blockIdx.x == 0) {
+    if ((n_clear & 1) && threadIdx.x == 27) S[n_clear - 1] = 0.0;
     if (threadIdx.x < 24) info24[threadIdx.x] = 0;
     if (threadIdx.x == 24) *elim_fail = 0;
     if (threadIdx.x == 25) d_lam[0] = lam0;
     if (threadIdx.x == 26) d_lam[1] = lam1;
   }
 }
-void ba_launch_trial_prologue(double* d_lam, double lam0, double lam1, int* info24, int* elim_fail, double* rhs, int n_rhs, hipStream_t st) {
-  hipLaunchKernelGGL(ba_trial_prologue_kernel, dim3((n_rhs + 255) / 256 + 1), dim3(256), 0, st, d_lam, lam0, lam1, info24, elim_fail, rhs, n_rhs);
+// S: the reduced system's buffer, n_clear = its doubles + the right-hand side's behind them (one buffer)
+void ba_launch_trial_prologue(double* d_lam, double lam0, double lam1, int* info24, int* elim_fail, double* S, size_t n_clear, hipStream_t st) {
+  const unsigned blocks = (unsigned)std::min<size_t>(1024, (n_clear / 2 + 255) / 256 + 1);
+  hipLaunchKernelGGL(ba_trial_prologue_kernel, dim3(blocks), dim3(256), 0, st, d_lam, lam0, lam1, info24, elim_fail, S, n_clear);
 }
 void ba_launch_scale(const BaView& v, const double* lambda, double* partial, hipStream_t st) {
   hipLaunchKernelGGL(ba_scale_kernel, dim3(SCALE_BLOCKS), dim3(256), 0, st, v, lambda, partial);
