@@ -21,6 +21,13 @@ for k in range(n_prob):
         pr["pt_fixed"][:: int(rng.integers(3, 11))] = 1
     if no and rng.uniform() < 0.3:
         pr["cub_fixed"][int(rng.integers(0, no))] = 1
+    # (half of the problems: per-edge information matrices / a second camera's intrinsics -- the handle then reads the per-edge records;
+    # the others share them and take the constants, BaView::info_u / intr_u)
+    if rng.uniform() < 0.5:
+        pr["e_info"] = pr["e_info"] * (1.2 ** -rng.integers(0, 8, len(pr["e_pt"])))[:, None]
+    if rng.uniform() < 0.3:
+        second = rng.random(len(pr["e_pt"])) < 0.3
+        pr["e_intr"] = np.where(second[:, None], pr["e_intr"] * np.array([1.01, 0.99, 1.0, 1.0]), pr["e_intr"])
     iters = int(rng.integers(3, 9))
     G = capi.ba_from_dict(pr, cuboids_first=cf)
     R = O.Problem(pr["cams"], pr["cam_fixed"], pr["cuboids"], pr["cub_fixed"], pr["points"], pr["pt_fixed"], cuboids_first=cf)
