@@ -26,10 +26,9 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak = half the FP32 vector 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def measure_traffic_live(args, n_unique):
-    """HBM bytes per score_kernel launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, --kernel-trace only, as
-    MI355X_MICROARCH.md prescribes) over a short child run of the same workload; FETCH_SIZE x 2 + WRITE_SIZE x 1 (KiB -> bytes), the
-    factors of profiles/r2_pmc_calibration.json.  None when rocprofv3 is not available or a pass fails."""
+def _pmc_child_pass(args, n_unique, counters, kernels):
+    """One rocprofv3 counter pass (--kernel-trace + --pmc only, as MI355X_MICROARCH.md prescribes) over a short child run of the same workload:
+    {kernel: {counter: average per launch}} for the kernels named, None when the pass cannot run."""
     import csv
     import glob
     import shutil
@@ -40,28 +39,69 @@ def measure_traffic_live(args, n_unique):
     # never a profiler inside a profiler: when this process itself runs under rocprofv3 / rocprofiler, report the tracked figure
     if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
         return None
+    d = tempfile.mkdtemp(prefix="cs_pmc_", dir="/tmp")
+    try:
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "2", "--warmup", "1", "--inflight", "1", "--depth", "1", "--steady-steps", "0", "--latency-calls", "0", "--lines-images", "0", "--ba", "none", "--no-cpu-baseline", "--no-edge", "--rp-frames", "0", "--no-measure-traffic",
+               "--frames", str(args.frames), "--unique", str(n_unique)]
+        subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp", "CS_BENCH_CHILD": "1"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+        tot, cnt = {}, {}
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    kn = r.get("Kernel_Name", "")
+                    for k in kernels:
+                        if k in kn and r.get("Counter_Name") in counters:
+                            key = (k, r["Counter_Name"])
+                            tot[key] = tot.get(key, 0.0) + float(r["Counter_Value"])
+                            cnt[key] = cnt.get(key, 0) + 1
+        if not tot:
+            return None
+        out = {}
+        for (k, c), v in tot.items():
+            out.setdefault(k, {})[c] = v / cnt[(k, c)]
+        return out
+    except (OSError, subprocess.SubprocessError, ValueError, KeyError):
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+SIMDS_PER_SE = 32   # MI355X: 8 XCDs x 4 shader engines, 8 CUs (32 SIMDs) per shader engine; SQ_BUSY_CYCLES is summed over the 32 engines
+
+
+def measure_valu_issue_live(args, n_unique):
+    """VALU issue utilisation of the two FP64-bound sweep kernels from one SQ counter pass over a child run of the same workload:
+    frac = 4 x SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES x 32) -- SQ_ACTIVE_INST_VALU counts quad-cycles a SIMD's arbiter spends issuing VALU
+    instructions, summed over all SIMDs (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* are in quad-cycles); SQ_BUSY_CYCLES counts the cycles a
+    shader engine's SQ is busy, summed over the 32 engines, each with 32 SIMDs.  None when the pass cannot run."""
+    ctrs = ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY")
+    res = _pmc_child_pass(args, n_unique, ctrs, ("score_kernel", "candidate_kernel"))
+    if not res:
+        return None
+    out = {"formula": "4 x SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES x %d SIMDs per shader engine): the share of the busy SIMD cycles in which a VALU instruction issues (counters per launch, one rocprofv3 --pmc pass, kernel-trace only, child run of this workload)" % SIMDS_PER_SE}
+    for k, c in res.items():
+        if c.get("SQ_BUSY_CYCLES", 0) > 0 and "SQ_ACTIVE_INST_VALU" in c:
+            e = {"frac": 4.0 * c["SQ_ACTIVE_INST_VALU"] / (c["SQ_BUSY_CYCLES"] * SIMDS_PER_SE)}
+            if c.get("SQ_WAVES", 0) > 0 and "SQ_INSTS_VALU" in c:
+                e["valu_instructions_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
+            if c.get("SQ_WAVE_CYCLES", 0) > 0 and "SQ_WAIT_ANY" in c:
+                e["wave_cycles_waiting_frac"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+            e["counters_per_launch"] = {n: c[n] for n in sorted(c)}
+            out[k] = e
+    return out if len(out) > 1 else None
+
+
+def measure_traffic_live(args, n_unique):
+    """HBM bytes per score_kernel launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, --kernel-trace only, as
+    MI355X_MICROARCH.md prescribes) over a short child run of the same workload; FETCH_SIZE x 2 + WRITE_SIZE x 1 (KiB -> bytes), the
+    factors of profiles/r2_pmc_calibration.json.  None when rocprofv3 is not available or a pass fails."""
     avg = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = tempfile.mkdtemp(prefix="cs_pmc_", dir="/tmp")
-        try:
-            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "2", "--warmup", "1", "--inflight", "1", "--depth", "1", "--steady-steps", "0", "--latency-calls", "0", "--lines-images", "0", "--ba", "none", "--no-cpu-baseline", "--no-edge", "--rp-frames", "0", "--no-measure-traffic",
-                   "--frames", str(args.frames), "--unique", str(n_unique)]
-            subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp", "CS_BENCH_CHILD": "1"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
-            n, tot = 0, 0.0
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                with open(f) as fh:
-                    for r in csv.DictReader(fh):
-                        if r.get("Counter_Name") == ctr and "score_kernel" in r.get("Kernel_Name", ""):
-                            n += 1
-                            tot += float(r["Counter_Value"])
-            if n == 0:
-                return None
-            avg[ctr] = tot / n
-        except (OSError, subprocess.SubprocessError, ValueError):
+        r = _pmc_child_pass(args, n_unique, (ctr,), ("score_kernel",))
+        if not r or ctr not in r.get("score_kernel", {}):
             return None
-        finally:
-            shutil.rmtree(d, ignore_errors=True)
+        avg[ctr] = r["score_kernel"][ctr]
     return avg["FETCH_SIZE"] * 1024 * 2 + avg["WRITE_SIZE"] * 1024
 
 
@@ -106,6 +146,13 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
+    # The line proves what it ran with: every CS_* variable of the environment is printed with it (the library's diagnostic switches and this
+    # script's own), and the one switch that changes RESULTS -- CS_DETECT_SKIP, honoured only by a diagnostic build (make DIAG=1) -- is refused.
+    env_overrides = {k: os.environ[k] for k in sorted(os.environ) if k.startswith("CS_") and k != "CS_BENCH_CHILD"}
+    if "CS_DETECT_SKIP" in os.environ:
+        raise SystemExit("bench.py: CS_DETECT_SKIP is set (kernels left out of the sweep: results meaningless) -- refusing to measure")
+    if capi.lib().cs_diag_build():
+        raise SystemExit("bench.py: libcubeslam_hip.so is a diagnostic build (make DIAG=1) -- rebuild without DIAG before measuring")
     # CS_BENCH_SHARE_GPU=1: functional check of the N > 1 code path on a box with fewer GPUs than ranks (every rank on
     # device 0, gloo instead of RCCL, which refuses two ranks on one device); never a performance number
     share_gpu = os.environ.get("CS_BENCH_SHARE_GPU") == "1"
@@ -180,6 +227,9 @@ def main():
 
     step_lock = threading.Lock()
     steps_taken = [0]
+    last_collected = [None]
+    warm_alone_runs = max(1, args.warmup) * inflight * depth
+    warm_concurrent_steps = 0
 
     def take_step():   # the K steps are a shared queue: a pipeline that finishes early takes the next one (no idle tail at small K)
         with step_lock:
@@ -200,6 +250,7 @@ def main():
                     break
                 bq = queued.pop(0)
                 bq.collect()
+                last_collected[0] = bq      # (whichever pipeline collects last: the batch of the region's last finished step)
                 free.append(bq)
                 for k, v in bq.timing().items():
                     accs[p][k] = accs[p].get(k, 0) + v
@@ -219,6 +270,7 @@ def main():
     if args.warmup > 0 and inflight > 1 and os.environ.get("CS_BENCH_CONCURRENT_WARMUP", "1") != "0":
         contract_steps = args.steps
         args.steps = max(args.warmup, inflight * depth) * int(os.environ.get("CS_BENCH_WARMUP_ROUNDS", "4"))
+        warm_concurrent_steps = args.steps
         steps_taken[0] = 0
         accs_saved, accs[:] = list(accs), [dict() for _ in range(inflight)]
         th = [threading.Thread(target=drive, args=(p,)) for p in range(inflight)]
@@ -241,6 +293,9 @@ def main():
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     cg1 = cgroup_cpu()
+    # parity of the TIMED region's own output: the records the last timed step wrote, kept before any later leg reuses the batch
+    N_PARITY = min(16, args.frames)
+    timed_records = [last_collected[0].cuboids(f) for f in range(N_PARITY)] if (rank == 0 and last_collected[0] is not None) else None
     host_cpu = None
     if cg0 and cg1:      # how much CPU the timed region took and whether the container's quota throttled it (a throttled period stalls every thread)
         host_cpu = {"granted_cpus": granted if quota else None, "host_threads_per_pipeline": host_threads, "cpu_seconds_per_wall_second": (cg1[0] - cg0[0]) * 1e-6 / max(elapsed, 1e-9),
@@ -845,6 +900,9 @@ def main():
         if not args.no_measure_traffic and world == 1 and not os.environ.get("CS_BENCH_CHILD"):
             traffic = measure_traffic_live(args, n_unique)
             traffic_source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate, kernel-trace only) over a child run of this workload, collected by this bench run" if traffic else None
+        valu_issue = None
+        if not args.no_measure_traffic and world == 1 and not os.environ.get("CS_BENCH_CHILD"):
+            valu_issue = measure_valu_issue_live(args, n_unique)
         try:
             if traffic is not None:
                 raise KeyError("measured live")
@@ -858,7 +916,12 @@ def main():
             pass
         out = {
             "metric": "frames/sec detect_cuboid", "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup,
+            # what really ran before the clock started: every batch alone (sizes its buffers; the isolated kernel timings), then all pipelines side by side
+            "warmup_untimed_steps": {"total": warm_alone_runs + warm_concurrent_steps, "each_batch_alone": warm_alone_runs, "all_pipelines_side_by_side": warm_concurrent_steps,
+                                     "what": "--warmup W = %d: W runs of each of the %d batches alone, then max(W, batches) x %s steps driven exactly like the timed steps" % (args.warmup, inflight * depth, os.environ.get("CS_BENCH_WARMUP_ROUNDS", "4"))},
+            "env_overrides": env_overrides, "diag_build": False,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not share_gpu else "synthetic (CS_BENCH_SHARE_GPU functional check: ranks share one device, not a performance number)",
             "config": {"workload": "C2: per-frame cuboid proposal sweep, 181 yaw x 8 boxes x ~400 line segments, 1241x376 KITTI-shaped",
                        "frames_per_batch_per_gpu": args.frames, "unique_frames": n_unique, "yaw_step_deg": 0.5, "batches_in_flight": inflight * depth, "pipelines": inflight, "batches_per_pipeline": depth,
@@ -881,6 +944,8 @@ def main():
                          "fp64_alu": {"flop_per_valid_proposal": FP64_FLOP_PER_PROPOSAL, "achieved": FP64_FLOP_PER_PROPOSAL * (acc["n_valid"] / launches) / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0,
                                       "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": FP64_FLOP_PER_PROPOSAL * (acc["n_valid"] / launches) / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS if kern_ms > 0 else 0.0},
+                         # the bound the kernel really runs against: the share of busy SIMD cycles that issue a VALU instruction (SQ counters, this run)
+                         "valu_issue": valu_issue,
                          "other_kernels": {"candidate_kernel": {"ms": geo_ms, "alg_bytes": geo_bytes, "GB/s": geo_bytes / (geo_ms * 1e-3) / 1e9 if geo_ms > 0 else 0.0}}},
             "stage_ms_per_step": {k: acc[k] / args.steps for k in acc if k.endswith("_ms")},
             "fallback_boxes_per_step": acc["n_fallback_boxes"] / args.steps,
@@ -901,6 +966,32 @@ def main():
             dt = time.perf_counter() - t1
             out["cpu_baseline"] = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": "%d frames of the same workload through oracle/detect_oracle.cpp (-O2, libm atan2, single thread) in %.1f s" % (n, dt)}
+            # the records of the last TIMED step against the oracle (its cs_atan2 build: every field bit for bit, as tests/test_detect_gpu.py asserts)
+            if timed_records is not None:
+                opx = oracle_py.default_params(yaw_step_deg=0.5, whether_sample_cam_roll_pitch=0, whether_sample_bbox_height=0)
+                n_cub = n_fld = n_bad = 0
+                first_bad = None
+                for f in range(len(timed_records)):
+                    ref, _ = oracle_py.detect_cuboid(frames[f], opx, atan2_mode=1)
+                    got = timed_records[f]
+                    for bi in range(max(len(ref), len(got))):
+                        g = got[bi] if bi < len(got) else []
+                        r = ref[bi] if bi < len(ref) else []
+                        if len(g) != len(r):
+                            n_bad += 1
+                            first_bad = first_bad or "frame %d box %d: %d cuboids against the oracle's %d" % (f, bi, len(g), len(r))
+                            continue
+                        for a, b in zip(g, r):
+                            n_cub += 1
+                            for k in b:
+                                n_fld += 1
+                                if not np.array_equal(np.asarray(a[k]), np.asarray(b[k])):
+                                    n_bad += 1
+                                    first_bad = first_bad or "frame %d box %d field %s" % (f, bi, k)
+                out["parity_vs_oracle"] = {"what": "the cs_cuboid records the last timed step wrote for its first %d frames against oracle/detect_oracle.cpp on the same frames (same parameters, shared cs_atan2): every field of every record compared bit for bit" % len(timed_records),
+                                           "frames": len(timed_records), "cuboids_compared": n_cub, "fields_compared": n_fld, "mismatches": n_bad, "bit_identical": n_bad == 0}
+                if first_bad:
+                    out["parity_vs_oracle"]["first_mismatch"] = first_bad
             # for context only: the same restatement on every core this process may use, one independent process per core, the
             # frames dealt out among them -- the reference itself is single-threaded, so `value` above stays the baseline
             try:
@@ -956,16 +1047,20 @@ def main():
         except Exception as e:     # the other ranks may be waiting in a collective: no further rendezvous from here
             bail("multi-GPU BA leg failed on rank %d: %r" % (rank, e))
         tmr.cancel()
+    parity_failed = False
     if rank == 0:
         if ba_out is not None:
             out["ba"] = ba_out
         print(json.dumps(out), flush=True)
+        parity_failed = out.get("parity_vs_oracle", {}).get("bit_identical") is False
     for b_ in bats:
         b_.close()
     for d_ in dets:
         d_.close()
     if dist is not None:
         dist.destroy_process_group()
+    if parity_failed:
+        raise SystemExit("bench.py: the timed region's records differ from the oracle's (parity_vs_oracle in the line above)")
 
 
 if __name__ == "__main__":

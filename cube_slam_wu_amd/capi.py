@@ -60,7 +60,7 @@ class CsDetectTiming(C.Structure):
 
 # every symbol include/cubeslam_hip.h declares (tests/test_capi_symbols.py checks the export table)
 DECLARED_SYMBOLS = [
-    "cs_last_error", "cs_device_count", "cs_detect_default_params", "cs_box_rois", "cs_cam_euler_zyx", "cs_detector_create",
+    "cs_last_error", "cs_device_count", "cs_diag_build", "cs_detect_default_params", "cs_box_rois", "cs_cam_euler_zyx", "cs_detector_create",
     "cs_detector_destroy", "cs_detect_cuboids", "cs_batch_create", "cs_batch_max_boxes", "cs_batch_run", "cs_batch_submit", "cs_batch_collect",
     "cs_bgr_to_gray", "cs_edge_distance_maps", "cs_edge_distance_maps_multi", "cs_detect_cuboids_gray", "cs_batch_create_gray", "cs_batch_destroy", "cs_batch_last_timing", "cs_batch_debug_candidates", "cs_batch_debug_kept", "cs_batch_set_debug", "cs_batch_set_pipeline_chunks", "cs_detect_lines_gray", "cs_detect_lines_batch", "cs_detect_lines_last_timing", "cs_detect_lsd_gray", "cs_detect_lsd_batch", "cs_detect_lsd_last_timing",
 ]

@@ -488,6 +488,10 @@ void parallel_sort(It b, It e, Cmp cmp, int nt) {
 
 // camera -> rank (contiguous subsequences), landmark -> rank of the subsequence of its lowest-index observing camera
 inline int cam_rank(int cam, int n_cams, int n_ranks) { return (int)(((long long)cam * n_ranks) / std::max(1, n_cams)); }
+// The per-landmark camera lists of the last structure phase (st_cams_of / st_edge_of, st_cam_cnt) stay valid only while the projection edges
+// [0, st_lists_edges) and the landmark count they were built for are untouched -- cs_ba_append_* only adds behind them.  EVERY entry point that
+// rewrites e_pt / e_cam or the vertex arrays calls this, so that the next phase checks every edge's indices again and rebuilds the lists.
+inline void proj_edge_lists_invalidate(cs_ba* B) { B->st_lists_edges = 0; B->st_cam_cnt.clear(); }
 void landmark_owners(int n_ranks, int n_cams, int n_points, int n_proj, const int* e_pt, const int* e_cam, std::vector<int>& owner) {
   std::vector<int> first(n_points, 0x7fffffff);
   for (int k = 0; k < n_proj; k++) if (e_pt[k] >= 0 && e_pt[k] < n_points) first[e_pt[k]] = std::min(first[e_pt[k]], e_cam[k]);
@@ -1877,7 +1881,7 @@ static int cs_ba_set_vertices_impl(cs_ba* B, const double* cams7, const int* cam
   BA_TRY(hipSetDevice(B->device));
   BA_TRY(hipStreamSynchronize(B->st));       // (appended rows may still be on their way: cs_ba_append_* queues them on st)
   B->nc = nc; B->no = no; B->np = np; B->cuboids_first = cuboids_first;
-  B->st_lists_edges = 0;
+  proj_edge_lists_invalidate(B);
   B->cam_fixed.assign(cam_fixed, cam_fixed + nc); B->cub_fixed.assign(cub_fixed, cub_fixed + no); B->pt_fixed.assign(pt_fixed, pt_fixed + np);
   // SE3Quat(Vector7d) normalises the rotation and makes w >= 0 (se3quat.h:68-71); cuboid::fromVector does not.
   std::vector<double> c(cams7, cams7 + 7 * (size_t)nc);
@@ -2034,7 +2038,7 @@ int cs_ba_set_estimates(cs_ba* B, const double* cams7, const double* cuboids10, 
 static int cs_ba_set_edges_proj_impl(cs_ba* B, int n, const int* pt, const int* cam, const double* uv, const double* info4, const double* intr4, const double* huber) {
   if (!B || n < 0 || (n && (!pt || !cam || !uv || !info4 || !intr4))) return CS_ERR_INVALID_ARG;
   B->n_proj = n;
-  B->st_lists_edges = 0;
+  proj_edge_lists_invalidate(B);
   B->e_pt.assign(pt, pt + n); B->e_cam.assign(cam, cam + n);
   BA_TRY(hipSetDevice(B->device));
   BA_TRY(hipStreamSynchronize(B->st));       // (appended rows may still be on their way)
@@ -2104,6 +2108,10 @@ int cs_ba_set_edges_odom(cs_ba* B, int n, const int* ci, const int* cj, const do
 int cs_ba_set_external_edges(cs_ba* B, int n, const int* class_i, const int* idx_i, const int* class_j, const int* idx_j) {
   if (!B || n < 0 || (n && (!class_i || !idx_i || !class_j || !idx_j))) return CS_ERR_INVALID_ARG;
   BA_GUARD_BEGIN
+  // an edge whose two ends are the same vertex has no off-diagonal block (its whole quadratic form belongs to the vertex's diagonal terms,
+  // cs_ba_set_external_terms' cam36 / cub81 / pt9): the off-diagonal kernel would address the upper triangle of a diagonal block
+  for (int k = 0; k < n; k++)
+    if (class_i[k] == class_j[k] && idx_i[k] == idx_j[k]) { cs_set_error_ba("cs_ba_set_external_edges: edge " + std::to_string(k) + " joins a vertex to itself; add its terms to the vertex's diagonal block instead"); return CS_ERR_INVALID_ARG; }
   B->ext_n = n;
   B->ext_e4.resize(4 * (size_t)n);
   for (int k = 0; k < n; k++) { B->ext_e4[4 * k] = class_i[k]; B->ext_e4[4 * k + 1] = idx_i[k]; B->ext_e4[4 * k + 2] = class_j[k]; B->ext_e4[4 * k + 3] = idx_j[k]; }

@@ -30,6 +30,7 @@
 #include <cstdlib>
 
 #include "band_potf2.h"
+#include "cs_hip_util.h"
 
 namespace cs {
 
@@ -508,20 +509,26 @@ __global__ __launch_bounds__(512) void bcr_back_kernel(BcrLevel P) {
 // Block size for a band: any Bv with bandwidth <= Bv <= 128 makes the band block tridiagonal; 128 gives the fewest blocks.
 // (measured on MI355X, tools/bcr_try.sh: 640 unknowns at bandwidth 119 0.17 ms against the banded kernels' 0.20, 1 194: 0.23 / 0.35, 5 994: 0.36 / 0.87,
 // 10 494: 0.57 / 1.46; narrow bands of a few hundred unknowns stay with the banded kernels -- ba_bcr_estimate_ms is what ba_host.cpp compares)
+// The factor kernel's LDS (107 520 bytes) is above the 64 KB a kernel gets by default: raised once per DEVICE -- the attribute belongs to the
+// current device's instance of the kernel (a handle on a second GPU, sharded ranks as threads on several devices).  Both ..._ok() below
+// are asked by the structure phase on the handle's device; a refusal there keeps the handle on the persistent banded kernels.
+static DynLdsOnce g_bcr_factor_lds;
+static bool bcr_device_ready() { return g_bcr_factor_lds.set(reinterpret_cast<const void*>(bcr_factor_kernel), BCR_LDS_DOUBLES * (int)sizeof(double)); }
 bool ba_bcr_ok(int n, int LD) {
   static const int on = getenv("CS_BAND_BCR") ? atoi(getenv("CS_BAND_BCR")) : 1;
-  return on != 0 && LD - 1 >= 1 && LD - 1 <= BCR_B && n > BCR_B;
-}
-double ba_bcr_estimate_ms(int n) {
-  int Ns[BCR_MAXLEV];
-  int N = (n + BCR_B - 1) / BCR_B, L = 0;
-  while (N >= 1 && L < BCR_MAXLEV) { Ns[L++] = N; N = N / 2; }
-  return 0.048 * L + 0.045 + 2e-6 * n;
+  // (every level halves the block count: BCR_MAXLEV levels reach one block from at most 2^BCR_MAXLEV - 1 -- a larger system would stop short of it)
+  const long long blocks = ((long long)n + BCR_B - 1) / BCR_B;
+  return on != 0 && LD - 1 >= 1 && LD - 1 <= BCR_B && n > BCR_B && blocks < (1ll << BCR_MAXLEV) && bcr_device_ready();
 }
 static int bcr_levels(int n, int Bv, int* Ns) {
   int N = (n + Bv - 1) / Bv, L = 0;
   while (N >= 1 && L < BCR_MAXLEV) { Ns[L++] = N; N = N / 2; }
   return L;
+}
+double ba_bcr_estimate_ms(int n) {
+  int Ns[BCR_MAXLEV];
+  const int L = bcr_levels(n, BCR_B, Ns);
+  return 0.048 * L + 0.045 + 2e-6 * n;
 }
 size_t ba_bcr_workspace_doubles(int n, int Bv) {
   int Ns[BCR_MAXLEV];
@@ -537,11 +544,7 @@ size_t ba_bcr_workspace_doubles(int n, int Bv) {
 // tridiagonal in blocks of Bv whatever its band storage), rhs in / solution out, info[0] != 0: a non-positive pivot.  The band itself
 // is left untouched.
 static void bcr_run(const double* Sb, double* work, int n, int LD, int Bv, double* rhs, int* info, hipStream_t st, bool packed, void (*fill)(const BcrLevel&, void*, hipStream_t), void* fill_arg) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bcr_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BCR_LDS_DOUBLES * (int)sizeof(double));
-    attr_set = true;
-  }
+  (void)bcr_device_ready();     // (a table look-up after the structure phase's ba_bcr_ok / ba_bcr_sep_ok; covers callers that come here on another device)
   int Ns[BCR_MAXLEV];
   const int L = bcr_levels(n, Bv, Ns);
   BcrLevel lev[BCR_MAXLEV];
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(128) void bcr_sep_scatter_kernel(const double* xpad
 }
 bool ba_bcr_sep_ok(int wm, int R) {
   static const int on = getenv("CS_BAND_BCR") ? atoi(getenv("CS_BAND_BCR")) : 1;
-  return on != 0 && wm >= 1 && wm <= BCR_B && R >= 2;
+  return on != 0 && wm >= 1 && wm <= BCR_B && R >= 2 && R - 1 < (1 << BCR_MAXLEV) && bcr_device_ready();
 }
 size_t ba_bcr_sep_workspace_doubles(int R) { return ba_bcr_workspace_doubles((R - 1) * BCR_B, BCR_B) + (size_t)(R - 1) * BCR_B; }
 // msgs: the R gathered messages; x: the solution vector the separators' unknowns are scattered into; info[0] != 0: a non-positive pivot

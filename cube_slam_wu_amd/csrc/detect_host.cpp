@@ -573,6 +573,14 @@ int cs_device_count(void) {
   return n;
 }
 
+int cs_diag_build(void) {
+#ifdef CS_DIAG
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 void cs_detect_default_params(cs_detect_params* p) {
   if (!p) return;
   p->consider_config_1 = 1; p->consider_config_2 = 1;

@@ -21,6 +21,7 @@
 // decisions (inlier tests, extreme selection, merge tests, length thresholds) take a cheaper exact-equivalent form with the
 // reference's evaluation inside a margin.  Compiled with -ffp-contract=off: every result is bit-identical to the CPU oracle.
 #include <hip/hip_runtime.h>
+#include "cs_hip_util.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -1539,10 +1540,16 @@ __global__ __launch_bounds__(64) void line_setup_small_kernel(JobDesc* jobs, int
 // others; `fork` must already be recorded on st, `join` is recorded here and st waits for it.
 // diagnostics: CS_DETECT_SKIP=<names> leaves the named kernels out of the sweep, to measure their marginal cost in the saturated
 // pipeline (the results are then meaningless; never set outside a timing experiment)
+// Compiled in only with -DCS_DIAG (make DIAG=1): the shipped library has no switch that changes results, cs_diag_build() says which
+// build is loaded and bench.py refuses a diagnostic one.
+#ifdef CS_DIAG
 static bool skip_kernel(const char* name) {
   static const char* e = getenv("CS_DETECT_SKIP");
   return e && strstr(e, name) != nullptr;
 }
+#else
+static constexpr bool skip_kernel(const char*) { return false; }
+#endif
 void launch_line_setup(JobDesc* jobs, int n_jobs, const double* frame_lines, const int* frame_line_ptr, double* mid_x, double* mid_y, double* line_angle,
                        double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st, const int* order, hipStream_t st_crowded, hipEvent_t fork, hipEvent_t join) {
   if (skip_kernel("line_setup")) return;
@@ -1704,11 +1711,13 @@ void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams
   static const bool no_big = getenv("CS_RANK_NO_BIG") != nullptr;     // diagnostics / tests: the ordinary instance for every launch
   // boxes that can hold far more valid proposals than the fixed staging columns (the caller's bound on a box's slots): the big instance
   if (!no_big && max_slots_per_box > 8 * (long long)RANK_STAGE) {
-    static bool attr_set = false;
+    static DynLdsOnce big_lds;      // per device (cs_hip_util.h)
     const size_t lds = 2 * (size_t)RANK_STAGE_BIG * sizeof(double);
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rank_kernel<RANK_THREADS_BIG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-    hipLaunchKernelGGL((rank_kernel<RANK_THREADS_BIG, true>), dim3(rv.n_boxes), dim3(RANK_THREADS_BIG), lds, st, v, rv, rp, (int)RANK_STAGE_BIG);
-    return;
+    if (big_lds.set(reinterpret_cast<const void*>(rank_kernel<RANK_THREADS_BIG, true>), (int)lds)) {
+      hipLaunchKernelGGL((rank_kernel<RANK_THREADS_BIG, true>), dim3(rv.n_boxes), dim3(RANK_THREADS_BIG), lds, st, v, rv, rp, (int)RANK_STAGE_BIG);
+      return;
+    }
+    // (refused: the ordinary instance below ranks the same boxes in more passes over its fixed staging columns)
   }
   if (nt == 64) hipLaunchKernelGGL((rank_kernel<64, false>), dim3(rv.n_boxes), dim3(64), 0, st, v, rv, rp, (int)RANK_STAGE);
   else if (nt == 128) hipLaunchKernelGGL((rank_kernel<128, false>), dim3(rv.n_boxes), dim3(128), 0, st, v, rv, rp, (int)RANK_STAGE);

@@ -5,6 +5,7 @@
 // fixed-point tangent test + hysteresis as connected components; two-pass 3x3 chamfer in 16.16 fixed point), all in
 // integer arithmetic (bit-reproducible on any host).  One workgroup per ROI.
 #include <hip/hip_runtime.h>
+#include "cs_hip_util.h"
 
 #include <algorithm>
 #include <cstdint>
@@ -571,10 +572,12 @@ void launch_edge_maps(const unsigned char* gray, int W, int H, const EdgeRoi* ro
     // the memory path inside the kernel).  CS_EDGE_HYST_LIST (tests): a smaller frontier capacity, CS_EDGE_HYST_LDS: the cap in bytes.
     static const int list_cap = [] { const char* e = getenv("CS_EDGE_HYST_LIST"); const int v = e ? atoi(e) : HYST_LIST; return std::min(std::max(v, 1), (int)HYST_LIST); }();
     static const long long lds_cap = [] { const char* e = getenv("CS_EDGE_HYST_LDS"); const long long v = e ? atoll(e) : 64 * 1024; return std::min<long long>(std::max<long long>(v, 8), 96 * 1024); }();
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(edge_hyst_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024 + 2 * HYST_LIST * (int)sizeof(int)); attr_set = true; }
+    static DynLdsOnce hyst_lds_once;     // per device (cs_hip_util.h)
+    const bool big_lds_ok = hyst_lds_once.set(reinterpret_cast<const void*>(edge_hyst_kernel), 96 * 1024 + 2 * HYST_LIST * (int)sizeof(int));
     // two size classes, so that ordinary ROIs do not reserve the LDS of the largest one (4 workgroups per CU under 32 KB)
-    const int big_px = (int)((std::min<long long>(std::max<long long>(max_px, 8), lds_cap) + 3) & ~3LL);
+    // (refused: stay inside the default 64 KB -- larger ROIs take the memory path inside the kernel)
+    const long long cap_px = big_lds_ok ? lds_cap : std::min<long long>(lds_cap, 64 * 1024 - 2 * HYST_LIST * (long long)sizeof(int));
+    const int big_px = (int)((std::min<long long>(std::max<long long>(max_px, 8), cap_px) + 3) & ~3LL);
     // (a call of a few ROIs -- one frame -- cannot fill the device either way: ONE launch sized for its largest ROI instead of two in a row,
     // 85 + 206 us for a KITTI frame's 8 boxes)
     const int small_px = n_rois <= 64 ? big_px : std::min(big_px, 32 * 1024);

@@ -35,6 +35,10 @@ typedef enum cs_status {
 
 const char* cs_last_error(void);
 int cs_device_count(void);
+/* 1 when the library was built with -DCS_DIAG (make DIAG=1): only that build honours CS_DETECT_SKIP=<kernel names>, a timing
+ * experiment that leaves kernels out of the sweep and makes the results meaningless.  The default build returns 0 and has no
+ * switch that changes results; bench.py refuses to print a line from a diagnostic build. */
+int cs_diag_build(void);
 
 /* ------------------------------------------------------------------ Path A: detect_cuboid ----- */
 
