@@ -35,7 +35,7 @@
 namespace cs {
 int ba_chi2_blocks(int n_proj);
 void ba_launch_chi2(const BaView& v, int nb_proj, hipStream_t st);
-void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, hipStream_t st3, hipEvent_t ev_join3);
+void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, hipStream_t st3, hipEvent_t ev_join3, hipEvent_t ev_pre = nullptr);
 void ba_launch_reduce(const BaView& v, const double* lambda_dev, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join);
 void ba_launch_gather_rows(const double* src, const int* idx, int n, int width, double* dst, hipStream_t st);
 void ba_launch_backsub(const BaView& v, hipStream_t st);
@@ -61,7 +61,8 @@ void ba_launch_bcr_sep(const double* msgs, size_t msg_doubles, int wm, int R, co
 void ba_launch_sum2(const double* a, int na, const double* b, int nb, double* out, hipStream_t st);
 void ba_launch_multi_zero(const std::pair<void*, size_t>* list, int n, hipStream_t st);
 void ba_launch_multi_copy(const BaCopyItem* list, int n, hipStream_t st);
-void ba_launch_sum2_flag(const double* a, int na, const double* b, int nb, const int* f0, const int* f1, double* out, hipStream_t st);
+void ba_launch_sum2_flag(const double* a, int na, const double* b, int nb, const int* f0, const int* f1, double* out, hipStream_t st, double* host_out = nullptr, double seq = 0.0);
+void ba_launch_max_diag(const BaView& v, double* out, hipStream_t st);
 void ba_launch_trial_prologue(double* d_lam, double lam0, double lam1, int* info24, int* elim_fail, double* S, size_t n_clear, hipStream_t st);
 void ba_launch_ext_add(const BaView& v, const double* cam36, const double* cam6, const double* cub81, const double* cub9, const double* pt9, const double* pt3, hipStream_t st);
 void ba_launch_ext_offdiag(const BaView& v, int n_groups, const int* gptr, const int* order, const int* e4, const double* Hij, hipStream_t st);
@@ -82,6 +83,8 @@ namespace {
       return CS_ERR_HIP;                                                       \
     }                                                                          \
   } while (0)
+// a phase mark on the handle's stream -- only while the stage split is asked for (cs_ba_set_stage_timing)
+#define BA_MARK(B, e) do { if ((B)->stage_timing) BA_TRY(hipEventRecord((e), (B)->st)); } while (0)
 #define BA_NCCL(expr)                                                          \
   do {                                                                         \
     ncclResult_t _r = (expr);                                                  \
@@ -275,6 +278,14 @@ struct cs_ba {
   double* h_lam = nullptr;
   DBuf<double> d_lam;
   double* h_scalars = nullptr;   // pinned mirror
+  // the trial's [chi2, scale term, failure flag, sequence number], written by the trial's last kernel itself (ba_sum2_flag_kernel) and polled by
+  // cs_ba_optimize: pinned, device-visible
+  double* h_trial = nullptr;
+  double trial_seq = 0.0;
+  // G2OBatchStatistics-like stage split (core/batch_stats.h:48-62): like g2o's setComputeBatchStatistics it is OFF unless asked for
+  // (cs_ba_set_stage_timing) -- every phase mark is an event on the stream, ~6 us of dispatch gap each, eight per LM trial
+  bool stage_timing = false;
+  hipEvent_t ev_upd = nullptr;     // recorded behind a trial's update kernel when the next linearisation is speculated: its side streams fork there
   size_t scalars_cap = 0;
   // host copy of the problem description
   int nc = 0, no = 0, np = 0, cuboids_first = 0;
@@ -1456,6 +1467,7 @@ int finalize_structure(cs_ba* B) {
 
 }  // namespace
 static void debug_nan_scan(cs_ba* B, const char* where);
+static bool debug_nan_enabled();
 namespace {
 
 int chi2_device(cs_ba* B, double* chi) {
@@ -1496,6 +1508,7 @@ int fetch_x(cs_ba* B) {
 
 // phase times come from events read after the next stream synchronisation, so that no phase boundary stalls the host
 int collect_lin_time(cs_ba* B) {
+  if (!B->stage_timing) { B->lin_pending = false; return CS_OK; }
   if (!B->lin_pending) return CS_OK;
   float ms = 0;
   BA_TRY(hipEventElapsedTime(&ms, B->ev[0], B->ev[1]));
@@ -1504,17 +1517,17 @@ int collect_lin_time(cs_ba* B) {
   return CS_OK;
 }
 
-int build_system_device(cs_ba* B) {
-  BA_TRY(hipEventRecord(B->ev[0], B->st));
+int build_system_device(cs_ba* B, hipEvent_t ev_pre = nullptr) {
+  BA_MARK(B, B->ev[0]);
   static const int lin_mode = [] { const char* e = getenv("CS_BA_LIN_STREAMS"); return e ? atoi(e) : 3; }();   // diagnostics: 3 = camera / landmark / pose-edge kernels side by side, 2 = landmark kernel behind the camera kernel, 1 = one stream
-  cs::ba_launch_linearize(B->view, B->st, lin_mode >= 2 ? B->st2 : nullptr, B->ev_fork, B->ev_join, lin_mode >= 3 ? B->st3 : nullptr, B->ev_join3);
+  cs::ba_launch_linearize(B->view, B->st, lin_mode >= 2 ? B->st2 : nullptr, B->ev_fork, B->ev_join, lin_mode >= 3 ? B->st3 : nullptr, B->ev_join3, lin_mode >= 2 ? ev_pre : nullptr);
   if (B->ext_terms_set) {
     if (B->ext_cam36.n != 36 * (size_t)B->nc || B->ext_cub81.n != 81 * (size_t)B->no || B->ext_pt9.n != 9 * (size_t)B->np) { cs_set_error_ba("external terms were set for a graph of another size: call cs_ba_set_external_terms again"); return CS_ERR_INVALID_ARG; }
     cs::ba_launch_ext_add(B->view, B->ext_has_cam ? B->ext_cam36.p : nullptr, B->ext_cam6.p, B->ext_has_cub ? B->ext_cub81.p : nullptr, B->ext_cub9.p,
                           B->ext_has_pt ? B->ext_pt9.p : nullptr, B->ext_pt3.p, B->st);
   }
   BA_TRY(hipGetLastError());
-  BA_TRY(hipEventRecord(B->ev[1], B->st));
+  BA_MARK(B, B->ev[1]);
   B->lin_pending = true;
   B->tm.n_linearizations++;
   B->have_system = true;
@@ -1534,6 +1547,7 @@ static std::atomic<int> g_comm_handles{0};
 
 // phase times of the last solve, read once the stream has been synchronised
 int collect_solve_times(cs_ba* B) {
+  if (!B->stage_timing) { B->lin_pending = false; return CS_OK; }
   float ms = 0;
   BA_TRY(hipEventElapsedTime(&ms, B->ev[2], B->ev[3])); B->tm.reduce_ms += ms;
   BA_TRY(hipEventElapsedTime(&ms, B->ev[3], B->ev[4])); B->tm.factor_ms += ms;
@@ -1591,7 +1605,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       B->h_lam[0] = lambda; B->h_lam[1] = B->shard_rank == 0 ? lambda : 0.0;
       cs::ba_launch_trial_prologue(B->d_lam.p, B->h_lam[0], B->h_lam[1], B->d_band_info.p, B->d_elim_fail.p, B->S.p, B->s_doubles + (size_t)B->n_pose, B->st);   // (+ [S | rhs] cleared: no fill of its own)
     } else { int rcl = put_lambda(B, lambda); if (rcl) return rcl; }
-    BA_TRY(hipEventRecord(B->ev[2], B->st));
+    BA_MARK(B, B->ev[2]);
     if (lean_head) {
     } else if (B->sparse && B->sp_S_clean) {
       // (sparse path: S was cleared by the structure phase and only the plan's pattern is ever written -- the pattern and the right-hand side)
@@ -1616,7 +1630,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
     } else if (!fn && B->comm) {  // RCCL, queued on this stream behind the kernels that produced the partial system: no host round trip
       BA_NCCL(ncclAllReduce(B->S.p, B->S.p, B->s_doubles + B->n_pose, ncclDouble, ncclSum, B->comm, B->st));
     }
-    BA_TRY(hipEventRecord(B->ev[3], B->st));
+    BA_MARK(B, B->ev[3]);
     if (B->band_ld) {
       // banded: factorisation, both substitutions and the landmark back-substitution are queued back to back; the
       // pivot flag comes home with the single synchronisation (a failed factorisation just leaves garbage increments
@@ -1625,7 +1639,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       if (B->use_bcr) cs::ba_launch_bcr(B->S.p, B->band_linv.p, n, B->band_ld, 128, B->view.rhs, B->d_band_info.p, B->st);
       else cs::ba_launch_band_cholesky(B->S.p, B->band_linv.p, n, B->band_ld, B->view.rhs, B->d_band_info.p, true, B->st);
       BA_TRY(hipGetLastError());
-      BA_TRY(hipEventRecord(B->ev[4], B->st));
+      BA_MARK(B, B->ev[4]);
       // (Round 5 tried clearing the band for the NEXT trial on the side stream here -- block cyclic reduction is done with it after its first
       // level -- to take the 10 us fill off the head of a trial: the event record / wait / fill / record sequence stalled the host's enqueue of the
       // kernels behind it by 35-60 us each, profiles/r5_ba_timeline_prezero.txt; the fill stays at the head.)
@@ -1636,7 +1650,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
         coop_turn.unlock();
       }
       { int rc2 = share_cuboid_increments(B, fn, ctx); if (rc2) return rc2; }
-      BA_TRY(hipEventRecord(B->ev[5], B->st));
+      BA_MARK(B, B->ev[5]);
       if (!status_in_scalars) BA_TRY(hipMemcpyAsync(B->h_status, B->d_band_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
       if (defer) { *defer = std::move(coop_turn); B->tm.n_solves++; return CS_OK; }   // (the caller's sum kernel folds the two status words into the trial's scalars)
       cs::ba_launch_fail_flag(B->d_band_info.p, B->d_elim_fail.p, nullptr, B->d_scalars.p + 2, B->st);
@@ -1658,11 +1672,11 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
         BA_ROC(rocsolver_dpotrs(B->blas, rocblas_fill_upper, SV.n_tail, 1, SV.T, SV.n_tail, SV.rhs_t, SV.n_tail));
       }
       if (!cs::launch_sparse_backsolve(SV, B->sp_grids, B->st)) { cs_set_error_ba("sparse solver: the substitution could not be launched (grid " + std::to_string(B->sp_grids.back) + " for " + std::to_string(SV.N) + " vertices)"); return CS_ERR_HIP; }
-      BA_TRY(hipEventRecord(B->ev[4], B->st));
+      BA_MARK(B, B->ev[4]);
       cs::ba_launch_backsub(B->view, B->st);
       BA_TRY(hipGetLastError());
       { int rc2 = share_cuboid_increments(B, fn, ctx); if (rc2) return rc2; }
-      BA_TRY(hipEventRecord(B->ev[5], B->st));
+      BA_MARK(B, B->ev[5]);
       BA_TRY(hipMemcpyAsync(B->h_status, B->sp_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
       BA_TRY(hipMemcpyAsync(B->h_status + 2, B->d_info.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
       BA_TRY(hipStreamSynchronize(B->st));
@@ -1679,10 +1693,10 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       BA_TRY(hipStreamSynchronize(B->st));
       if (B->h_status[0] != 0 || B->h_status[1] != 0) *ok = false;
       else BA_ROC(rocsolver_dpotrs(B->blas, rocblas_fill_upper, n, 1, B->S.p, n, B->view.rhs, n));
-      BA_TRY(hipEventRecord(B->ev[4], B->st));
+      BA_MARK(B, B->ev[4]);
       // (sharded: the collective is issued whether or not THIS rank's factorisation went through -- the ranks decide together, below)
       if (*ok || B->shard_n > 1) { cs::ba_launch_backsub(B->view, B->st); BA_TRY(hipGetLastError()); int rc2 = share_cuboid_increments(B, fn, ctx); if (rc2) return rc2; }
-      BA_TRY(hipEventRecord(B->ev[5], B->st));
+      BA_MARK(B, B->ev[5]);
       BA_TRY(hipStreamSynchronize(B->st));
     }
     int rc = collect_solve_times(B); if (rc) return rc;
@@ -1731,29 +1745,29 @@ int solve_device_sep(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn, void
   const int LDs = 2 * B->w_max;
   double* rsep = B->sepS.p + (size_t)ns * LDs;
   { int rcl = put_lambda(B, lambda); if (rcl) return rcl; }
-  BA_TRY(hipEventRecord(B->ev[2], B->st));
+  BA_MARK(B, B->ev[2]);
   BA_TRY(hipMemsetAsync(B->S.p, 0, sizeof(double) * (B->s_doubles + B->n_pose), B->st));
   BA_TRY(hipMemsetAsync(B->d_elim_fail.p, 0, sizeof(int), B->st));
   if (fn) BA_TRY(hipMemsetAsync(B->sep_msgs.p, 0, sizeof(double) * B->msg_doubles * (size_t)R, B->st));
   cs::ba_launch_reduce(B->view, B->d_lam.p, B->st, B->st2, B->ev_fork, B->ev_join);
   BA_TRY(hipMemcpyAsync(B->h_status + 1, B->d_elim_fail.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
   BA_TRY(hipGetLastError());
-  BA_TRY(hipEventRecord(B->ev[3], B->st));
+  BA_MARK(B, B->ev[3]);
   std::unique_lock<std::mutex> coop_turn(g_coop_mutex);
   BA_TRY(hipMemsetAsync(B->d_int_info.p, 0, 24 * sizeof(int), B->st));
   // the interior: L L^T = S(I, I), y = L^-1 b_I in place (one-sided order, right-hand side riding along)
   cs::ba_launch_band_cholesky(B->S.p + (size_t)B->int_c * LD, B->int_work.p, B->int_n, LD, rhs + B->int_c, B->d_int_info.p, false, B->st, true);
   BA_TRY(hipGetLastError());
-  BA_TRY(hipEventRecord(B->sev[0], B->st));
+  BA_MARK(B, B->sev[0]);
   if (fn) {   // the callback waits for the other ranks (threads of this process in the tests): the persistent kernel's turn must be free by then
     BA_TRY(hipStreamSynchronize(B->st));
     coop_turn.unlock();
   }
   cs::ba_launch_sep_reduce(B->S.p, LD, B->int_work.p, B->int_c, B->int_n, B->zl, B->wl, B->zr, B->wr, B->sepY.p, rhs, B->sep_msgs.p + (size_t)B->shard_rank * B->msg_doubles, B->w_max, B->st);
   BA_TRY(hipGetLastError());
-  BA_TRY(hipEventRecord(B->sev[1], B->st));
+  BA_MARK(B, B->sev[1]);
   { int rc = coll_allgather(B, fn, ctx, B->sep_msgs.p, B->msg_doubles); if (rc) return rc; }
-  BA_TRY(hipEventRecord(B->sev[2], B->st));
+  BA_MARK(B, B->sev[2]);
   // every rank assembles and solves the (small) separator system: nothing to broadcast afterwards.  Block tridiagonal = a band of
   // 2 w_max: the persistent banded Cholesky again (two fronts at 7 separators: 18 dependent steps)
   if (cs::ba_bcr_sep_ok(B->w_max, R)) {
@@ -1774,10 +1788,10 @@ int solve_device_sep(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn, void
     }
     cs::ba_launch_sep_scatter(rsep, ns, R, B->d_sep_off.p, B->d_sep_col.p, rhs, B->st);
   }
-  BA_TRY(hipEventRecord(B->sev[3], B->st));
+  BA_MARK(B, B->sev[3]);
   cs::ba_launch_sep_backsolve(B->S.p, LD, B->int_work.p, B->int_c, B->int_n, B->zl, B->wl, B->zr, B->wr, B->sepY.p, rhs, B->d_int_info.p, B->st);
   BA_TRY(hipGetLastError());
-  BA_TRY(hipEventRecord(B->ev[4], B->st));
+  BA_MARK(B, B->ev[4]);
   cs::ba_launch_backsub(B->view, B->st);   // this rank's landmarks and cuboids see its own columns and the next separator only
   BA_TRY(hipGetLastError());
   // the solution vector: every rank contributes ITS columns (its separator as it solved it, its interior) and its cuboids' increments
@@ -1785,7 +1799,7 @@ int solve_device_sep(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn, void
   if (B->zl > 0) BA_TRY(hipMemsetAsync(rhs, 0, sizeof(double) * (size_t)B->zl, B->st));
   if (B->int_c + B->int_n < B->n_red) BA_TRY(hipMemsetAsync(rhs + B->int_c + B->int_n, 0, sizeof(double) * (size_t)(B->n_red - B->int_c - B->int_n), B->st));
   { int rc = coll_allreduce(B, fn, ctx, rhs, (size_t)B->n_pose); if (rc) return rc; }
-  BA_TRY(hipEventRecord(B->ev[5], B->st));
+  BA_MARK(B, B->ev[5]);
   cs::ba_launch_fail_flag(B->d_int_info.p, B->d_elim_fail.p, B->d_sep_info.p, B->d_scalars.p + 2, B->st);
   // both persistent factorisations of the trial report their own time-out (a team that was not co-resident): the interior's and the
   // separator system's -- the latter must not be mistaken for "not positive definite" (LM would raise lambda and retry, ~1 s a trial)
@@ -1824,11 +1838,14 @@ int cs_ba_create(int device, cs_ba** out) {
   BA_TRY(hipEventCreateWithFlags(&B->ev_join, hipEventDisableTiming));
   BA_TRY(hipStreamCreateWithFlags(&B->st3, hipStreamNonBlocking));
   BA_TRY(hipEventCreateWithFlags(&B->ev_join3, hipEventDisableTiming));
+  BA_TRY(hipEventCreateWithFlags(&B->ev_upd, hipEventDisableTiming));
   for (auto& e : B->ev) BA_TRY(hipEventCreate(&e));
   for (auto& e : B->sev) BA_TRY(hipEventCreate(&e));
   BA_TRY(hipHostMalloc((void**)&B->h_lam, 2 * sizeof(double)));
   B->h_lam[0] = B->h_lam[1] = 0.0;
   { int rc0 = B->d_lam.alloc(2); if (rc0) return rc0; }
+  BA_TRY(hipHostMalloc((void**)&B->h_trial, 8 * sizeof(double)));
+  for (int i = 0; i < 8; i++) B->h_trial[i] = 0.0;
   BA_TRY(hipHostMalloc((void**)&B->h_status, 3 * sizeof(int)));   // [factorisation status, a cuboid block failed, separator system's status]
   B->h_status[0] = B->h_status[1] = B->h_status[2] = 0;
   BA_ROC(rocblas_create_handle(&B->blas));
@@ -1862,6 +1879,7 @@ void cs_ba_destroy(cs_ba* B) {
   if (B->h_lam) (void)hipHostFree(B->h_lam);
   B->d_lam.release();
   if (B->h_status) (void)hipHostFree(B->h_status);
+  if (B->h_trial) (void)hipHostFree(B->h_trial);
   if (B->h_scalars) (void)hipHostFree(B->h_scalars);
   if (B->comm) { (void)ncclCommDestroy(B->comm); g_comm_handles--; }
   B->d_scalars.release();
@@ -1871,6 +1889,7 @@ void cs_ba_destroy(cs_ba* B) {
   if (B->st2) (void)hipStreamDestroy(B->st2);
   if (B->st3) (void)hipStreamDestroy(B->st3);
   if (B->ev_join3) (void)hipEventDestroy(B->ev_join3);
+  if (B->ev_upd) (void)hipEventDestroy(B->ev_upd);
   if (B->st) (void)hipStreamDestroy(B->st);
   delete B;
 }
@@ -2346,6 +2365,32 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
                            B->n_seg == std::max(std::max(std::max(B->seg_class[0], B->seg_class[1]), std::max(B->seg_class[2], B->seg_class[3])), B->seg_class[4]) &&
                            getenv("CS_BA_DEBUG_NAN") == nullptr;
   struct FuseLinGuard { cs_ba* b; ~FuseLinGuard() { b->view.fuse_lin = 0; } } fuse_lin_guard{B};   // (every other entry point linearises with the classic kernels)
+  // The NEXT iteration's linearisation is queued right behind a trial, before the host has the trial's verdict: nearly every trial is accepted, and
+  // the ~70 us the host needs to read the scalars, decide and queue again then pass while the device linearises (the timeline showed the device
+  // idle for exactly that long after every trial).  A rejected trial pops the estimates and linearises the restored state once more -- the same
+  // kernels on the same state: the same bits as the system the speculation overwrote.  Off whenever something else must see the stream between
+  // trials: external (host-evaluated) edges, sharded runs, the NaN scans, the stage split's phase marks.
+  const bool can_spec = stream_flow && B->shard_n == 1 && !ext_active && !B->stage_timing && !debug_nan_enabled();
+  bool spec_lin = false;         // this iteration's system is already queued (speculated behind the last iteration's accepted trial)
+  // a trial's scalars straight from its last kernel into pinned memory, polled here (single rank: no collective behind the kernel)
+  const bool direct_scalars = stream_flow && !rccl && B->h_trial != nullptr;
+  auto wait_trial = [&](double seq) -> int {
+    volatile double* h = B->h_trial;
+    const double t_w = now_ms();
+    unsigned spins = 0;
+    while (h[3] != seq) {
+      if ((++spins & 0xfffu) == 0 && now_ms() - t_w > 5000.0) {      // five seconds without the word: ask the runtime what happened
+        BA_TRY(hipStreamSynchronize(B->st));
+        if (h[3] != seq) { cs_set_error_ba("cs_ba_optimize: the trial's scalars never arrived in pinned memory"); return CS_ERR_HIP; }
+        break;
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return CS_OK;
+  };
   double lambda = -1, ni = 2;
   int nBad = 0, done = 0;
   double carriedChi = 0;
@@ -2370,9 +2415,20 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
     // (ba_lin_schur_kernel: one pass over the edges, H_pl never read back); the first iteration needs H_ll for lambda's initial value
     // before any trial.  Same bits either way (CS_BA_FUSE_LIN=0: the classic pair of kernels throughout).
     B->view.fuse_lin = (it > 0 && fuse_lin_ok) ? 1 : 0;
-    rc = build_system_device(B); if (rc) return rc;
+    if (!spec_lin) { rc = build_system_device(B); if (rc) return rc; }
+    spec_lin = false;
     debug_nan_scan(B, "cs_ba_optimize: after the linearisation");
-    if (it == 0) {  // computeLambdaInit (:166-180): tau * max |H_jj| over all non-fixed vertices, landmarks included
+    if (it == 0 && B->shard_n == 1) {  // computeLambdaInit (:166-180): tau * max |H_jj| over all non-fixed vertices, landmarks included
+      // one rank: the maximum is taken where the blocks are (ba_max_diag_kernel) and eight bytes come back, instead of every H_cc / H_oo / H_ll
+      // block (14 MB at C4, 0.6 ms of every cs_ba_optimize call)
+      BA_TRY(hipMemsetAsync(B->d_scalars.p, 0, sizeof(double), B->st));
+      cs::ba_launch_max_diag(B->view, B->d_scalars.p, B->st);
+      BA_TRY(hipGetLastError());
+      BA_TRY(hipMemcpyAsync(B->h_scalars, B->d_scalars.p, sizeof(double), hipMemcpyDeviceToHost, B->st));
+      BA_TRY(hipStreamSynchronize(B->st));
+      lambda = 1e-5 * B->h_scalars[0];
+      ni = 2; nBad = 0;
+    } else if (it == 0) {
       BA_TRY(hipStreamSynchronize(B->st));   // the copies below run on the NULL stream, which B->st does not order with
       std::vector<double> hc(36 * (size_t)B->nc), ho(81 * (size_t)B->no), hl(9 * (size_t)B->np);
       if (B->nc) BA_TRY(hipMemcpy(hc.data(), B->Hcam.p, 8 * hc.size(), hipMemcpyDeviceToHost));
@@ -2395,6 +2451,7 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
     do {
       if (!stream_flow) { rc = cs_ba_push(B); if (rc) return rc; }      // (stream flow: the update kernel below saves the estimates it replaces)
       bool ok2 = true;
+      bool spec_now = false;
       double scale = 0;
       if (stream_flow) {
         std::unique_lock<std::mutex> turn;
@@ -2407,27 +2464,40 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
           int rq = solve_device(B, lambda, &okq, nullptr, nullptr, t); if (rq) return rq;
           cs::ba_launch_scale(B->view, B->d_lam.p, B->scale_partial.p, B->st);
           cs::ba_launch_update(B->view, B->st, B->cams_bak.p, B->points_bak.p, B->cubes_bak.p);
-          BA_TRY(hipEventRecord(B->ev[6], B->st));
+          if (spec_now) BA_TRY(hipEventRecord(B->ev_upd, B->st));      // the state the next linearisation reads is final from here
+          BA_MARK(B, B->ev[6]);
           cs::ba_launch_chi2(B->view, B->nb_chi, B->st);
           if (B->sep_mode && B->shard_n > 1) cs::ba_launch_sum2(B->chi_partial.p, B->n_chi_partials, B->scale_partial.p, cs::ba_scale_blocks(), B->d_scalars.p, B->st);   // (separator mode set its flag itself: three status words)
-          else cs::ba_launch_sum2_flag(B->chi_partial.p, B->n_chi_partials, B->scale_partial.p, cs::ba_scale_blocks(), B->d_band_info.p, B->d_elim_fail.p, B->d_scalars.p, B->st);
+          else cs::ba_launch_sum2_flag(B->chi_partial.p, B->n_chi_partials, B->scale_partial.p, cs::ba_scale_blocks(), B->d_band_info.p, B->d_elim_fail.p, B->d_scalars.p, B->st,
+                                       direct_scalars ? B->h_trial : nullptr, direct_scalars ? (B->trial_seq += 1.0) : 0.0);
           BA_TRY(hipGetLastError());
           if (rccl) BA_NCCL(ncclAllReduce(B->d_scalars.p, B->d_scalars.p, 3, ncclDouble, ncclSum, B->comm, B->st));
-          BA_TRY(hipMemcpyAsync(B->h_scalars, B->d_scalars.p, 3 * sizeof(double), hipMemcpyDeviceToHost, B->st));
-          BA_TRY(hipEventRecord(B->ev[7], B->st));
+          if (!direct_scalars) BA_TRY(hipMemcpyAsync(B->h_scalars, B->d_scalars.p, 3 * sizeof(double), hipMemcpyDeviceToHost, B->st));
+          BA_MARK(B, B->ev[7]);
           return CS_OK;
         };
         // (The sequence is the same ~30 launches, fills and copies for every trial of a structure -- lambda is read from device memory -- and was
         // replayed as one hipGraph in round 4: measured no faster on MI355X / ROCm 7.0 and +0.8 ms of instantiation per structure, DESIGN.md section 3;
         // removed in round 5.)
+        spec_now = can_spec && direct_scalars && it + 1 < iterations;
         rc = enqueue_trial(&turn); if (rc) return rc;
-        BA_TRY(hipStreamSynchronize(B->st));
+        if (spec_now) {      // the next iteration's linearisation (it + 1 > 0: the fused form where the graph allows it), queued before the verdict
+          const int fl = B->view.fuse_lin;
+          B->view.fuse_lin = fuse_lin_ok ? 1 : 0;
+          rc = build_system_device(B, B->ev_upd);      // (its numeric-Jacobian edges start behind the update, beside this trial's chi2 kernels)
+          B->view.fuse_lin = fl;       // (a retry of THIS iteration reduces the way this iteration linearised)
+          if (rc) return rc;
+        }
+        const double* hs = B->h_scalars;
+        if (direct_scalars) { rc = wait_trial(B->trial_seq); if (rc) return rc; hs = B->h_trial; }
+        else BA_TRY(hipStreamSynchronize(B->st));
         turn.unlock();
         if (B->h_status[0] == 0x7fffffff || (B->sep_mode && B->shard_n > 1 && B->h_status[2] == 0x7fffffff)) { cs_set_error_ba("banded solver: team not co-resident (wait timed out); set CS_BA_FORCE_DENSE=1 on a shared device"); return CS_ERR_HIP; }
-        ok2 = B->h_scalars[2] == 0.0;
-        tempChi = B->h_scalars[0];
-        scale = ok2 ? B->h_scalars[1] : 0.0;
-        {
+        ok2 = hs[2] == 0.0;
+        tempChi = hs[0];
+        scale = ok2 ? hs[1] : 0.0;
+        if (B->stage_timing) {
+          if (direct_scalars) BA_TRY(hipStreamSynchronize(B->st));     // (the phase marks are read below: the last one must have passed)
           rc = collect_solve_times(B); if (rc) return rc;
           float ms = 0;
           BA_TRY(hipEventElapsedTime(&ms, B->ev[6], B->ev[7])); B->tm.errors_ms += ms;
@@ -2467,14 +2537,18 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
         lambda *= std::max(1. / 3., alpha);
         ni = 2;
         currentChi = tempChi;
+        spec_lin = spec_now;       // the system of the state this trial left is already on the stream
       } else {
         lambda *= ni;
         ni *= 2;
         rc = cs_ba_pop(B); if (rc) return rc;
+        if (spec_now) {            // the speculation linearised the rejected state: the restored one again, as this iteration linearises
+          rc = build_system_device(B); if (rc) return rc;
+        }
       }
       qmax++;
     } while (rho < 0 && qmax < 10);
-    BA_TRY(hipStreamSynchronize(B->st));
+    if (!spec_lin) BA_TRY(hipStreamSynchronize(B->st));
     if (done < cap) {
       if (chi_hist) chi_hist[done] = currentChi;
       if (lambda_hist) lambda_hist[done] = lambda;
@@ -2486,6 +2560,7 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
     if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
     if (nBad >= 3) break;
   }
+  if (spec_lin) BA_TRY(hipStreamSynchronize(B->st));      // (a stopping rule ended the loop behind an accepted trial: its speculated system is the current state's)
   if (iterations_done) *iterations_done = done;
   B->tm.total_ms += now_ms() - t_begin;
   return CS_OK;
@@ -2783,6 +2858,12 @@ int cs_ba_get_vertex_hessians(cs_ba* B, double* cam36, double* cub81, double* pt
 }
 
 
+int cs_ba_set_stage_timing(cs_ba* B, int on) {
+  if (!B) return CS_ERR_INVALID_ARG;
+  B->stage_timing = on != 0;
+  B->lin_pending = false;
+  return CS_OK;
+}
 int cs_ba_last_timing(cs_ba* B, cs_ba_timing* t) {
   if (!B || !t) return CS_ERR_INVALID_ARG;
   *t = B->tm;

@@ -856,7 +856,9 @@ __device__ __forceinline__ void ba_lin_schur_segment(const BaView& v, double lam
         // launch at C4: L2 merges the partial lines either way) and a kernel 7 % slower for the index arithmetic; dropped.  What the kernel
         // over-fetches is its INPUT: a landmark's k edge records are 80 / 160 bytes in a stream ordered by landmark id, and the landmarks of a
         // segment are not neighbours in it.)
-        double* Wk = v.W + 18 * (size_t)e;
+        // Round 6: H_pl does not go to memory at all here (231 MB written per launch at C4, 259 MB read back by the back-substitution): the only
+        // reader behind this kernel, x_l = D^-1 (b_l - H_pl^T x_p), forms the blocks again from the same state with the same arithmetic
+        // (ba_backsub_lin_kernel) -- 20 bytes of edge record instead of a 144-byte block per edge, the same bits.
         const bool both = cam_free && v.pt_free[p] != 0;
 #pragma unroll
         for (int q = 0; q < 6; q++) {
@@ -865,7 +867,6 @@ __device__ __forceinline__ void ba_lin_schur_segment(const BaView& v, double lam
 #pragma unroll
           for (int j = 0; j < 3; j++) {
             const double w = both ? (jw0 * L.Jp[j] + jw1 * L.Jp[3 + j]) : 0.0;
-            Wk[3 * q + j] = w;
             Wl[3 * q + j][lane] = w;
           }
         }
@@ -1215,6 +1216,46 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaView v) {
 #pragma unroll
       for (int r = 0; r < 6; r++) s += Wk[3 * r + c] * (-xp[r]);
       cl[c] += s;
+    }
+  }
+  double x[3];
+  mat3_vec(v.Dinv + 9 * (size_t)p, cl, x);
+  v.xl[3 * p] = x[0]; v.xl[3 * p + 1] = x[1]; v.xl[3 * p + 2] = x[2];
+}
+
+// The same with H_pl formed on the spot (the fused linearise-in-Schur trials, which never write it): per edge the camera, the point, the
+// measurement -- proj_linearize and the J_c^T (rho' Omega) J_p product exactly as ba_lin_schur_segment / lin_pt_edge form them, then the same
+// sums in the same order as the kernel above: the same x_l bit for bit (tests/test_ba_gpu.py holds the LM run to the classic pair).
+__global__ __launch_bounds__(256) void ba_backsub_lin_kernel(BaView v) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= v.np) return;
+  double cl[3] = {v.bl[3 * p], v.bl[3 * p + 1], v.bl[3 * p + 2]};
+  const bool free_pt = v.pt_free[p] != 0;
+  const double X[3] = {v.points[3 * (size_t)p], v.points[3 * (size_t)p + 1], v.points[3 * (size_t)p + 2]};
+  for (int k = v.pt_ptr[p]; k < v.pt_ptr[p + 1]; k++) {
+    const int c = v.pm_cam[k];
+    int col = v.cam_col[c];
+    if (col < 0) continue;
+    Pose T = pose_load(v.cams + 7 * c);
+    double R[9];
+    pose_rotmat(T, R);
+    ProjLin L;
+    proj_linearize(T, R, X, v.pm_uv + 2 * (size_t)k, v.info_u ? v.info_u : v.pm_info + 4 * (size_t)k, v.intr_u ? v.intr_u : v.pm_intr + 4 * (size_t)k, v.pm_huber[k], v.pm_rk, k, L);
+    double Wk[18];
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      const double jw0 = L.Jc[q] * L.Wm[0] + L.Jc[6 + q] * L.Wm[2];
+      const double jw1 = L.Jc[q] * L.Wm[1] + L.Jc[6 + q] * L.Wm[3];
+#pragma unroll
+      for (int j = 0; j < 3; j++) Wk[3 * q + j] = free_pt ? (jw0 * L.Jp[j] + jw1 * L.Jp[3 + j]) : 0.0;      // (the camera is free here)
+    }
+    const double* xp = v.rhs + col;
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) {
+      double s = 0;
+#pragma unroll
+      for (int r = 0; r < 6; r++) s += Wk[3 * r + cc] * (-xp[r]);
+      cl[cc] += s;
     }
   }
   double x[3];
@@ -2526,12 +2567,15 @@ void ba_launch_chi2(const BaView& v, int nb_proj, hipStream_t st) {
 // chains) on a second stream; ba_accum_pose_kernel needs both
 // Three streams: the camera kernel is one workgroup per camera (1000 at C4: a fraction of the CUs), so the landmark kernel runs
 // beside it on st3 and the numeric-Jacobian edges (cuboid, odometry) on st2; all meet before the per-vertex accumulation.
-void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, hipStream_t st3, hipEvent_t ev_join3) {
+// ev_pre (optional): an event ALREADY recorded on st at the point from which the state no longer changes -- the side streams then start from
+// there instead of from this call (a speculated linearisation: the numeric-Jacobian edges run beside the chi2 kernels of the trial before it)
+void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, hipStream_t st3, hipEvent_t ev_join3, hipEvent_t ev_pre) {
   const bool side = st2 != nullptr && v.n_cub > 0;
   const bool lin_pt = v.np > 0 && !v.fuse_lin;       // (fuse_lin: the Schur kernels of this iteration's trials linearise the landmark side themselves)
   const bool side3 = st3 != nullptr && ev_join3 != nullptr && lin_pt && (v.n_proj > 0 || v.nc > 0);
   hipStream_t se = side ? st2 : st;
-  if (side || side3) (void)hipEventRecord(ev_fork, st);
+  if ((side || side3) && !ev_pre) (void)hipEventRecord(ev_fork, st);
+  if (ev_pre) ev_fork = ev_pre;
   if (side) (void)hipStreamWaitEvent(st2, ev_fork, 0);
   if (v.n_cub3 > 0) hipLaunchKernelGGL(ba_cub_edge_kernel<true>, dim3((v.n_cub3 + 3) / 4), dim3(128), 0, se, v);
   if (v.n_cub > v.n_cub3) hipLaunchKernelGGL(ba_cub_edge_kernel<false>, dim3((v.n_cub - v.n_cub3 + 3) / 4), dim3(128), 0, se, v);
@@ -2730,7 +2774,9 @@ void ba_launch_sum2(const double* a, int na, const double* b, int nb, double* ou
   hipLaunchKernelGGL(ba_sum2_kernel, dim3(1), dim3(256), 0, st, a, na, b, nb, out);
 }
 // the same with the trial's failure flag in out[2] (ba_fail_flag_kernel's job, one launch fewer at the end of a trial)
-__global__ __launch_bounds__(256) void ba_sum2_flag_kernel(const double* a, int na, const double* b, int nb, const int* f0, const int* f1, double* out) {
+// host_out (optional): the pinned mirror of the trial's scalars -- the three values and, behind a system-scope fence, the trial's sequence
+// number, which the host polls: no copy command, no event, no signal between the last kernel of a trial and the host's decision
+__global__ __launch_bounds__(256) void ba_sum2_flag_kernel(const double* a, int na, const double* b, int nb, const int* f0, const int* f1, double* out, double* host_out, double seq) {
   __shared__ double ws[2][4];
   double sa = 0, sb = 0;
   for (int i = threadIdx.x; i < na; i += 256) sa += a[i];
@@ -2741,10 +2787,38 @@ __global__ __launch_bounds__(256) void ba_sum2_flag_kernel(const double* a, int 
   if (threadIdx.x == 0) {
     out[0] = (ws[0][0] + ws[0][1]) + (ws[0][2] + ws[0][3]); out[1] = (ws[1][0] + ws[1][1]) + (ws[1][2] + ws[1][3]);
     out[2] = ((f0 && *f0) || (f1 && *f1)) ? 1.0 : 0.0;
+    if (host_out) {
+      host_out[0] = out[0]; host_out[1] = out[1]; host_out[2] = out[2];
+      __threadfence_system();
+      __hip_atomic_store(host_out + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
-void ba_launch_sum2_flag(const double* a, int na, const double* b, int nb, const int* f0, const int* f1, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(ba_sum2_flag_kernel, dim3(1), dim3(256), 0, st, a, na, b, nb, f0, f1, out);
+void ba_launch_sum2_flag(const double* a, int na, const double* b, int nb, const int* f0, const int* f1, double* out, hipStream_t st, double* host_out, double seq) {
+  hipLaunchKernelGGL(ba_sum2_flag_kernel, dim3(1), dim3(256), 0, st, a, na, b, nb, f0, f1, out, host_out, seq);
+}
+// computeLambdaInit (optimization_algorithm_levenberg.cpp:166-180): max |H_jj| over every non-fixed vertex -- cameras, cuboids, landmarks -- on the
+// device (the maximum is exact whatever the order; non-negative doubles order like their bit patterns).  out[0] must be zero on entry.
+__global__ __launch_bounds__(256) void ba_max_diag_kernel(BaView v, unsigned long long* out) {
+  const long long nCam = 6ll * v.nc, nCub = 9ll * v.no, nPt = 3ll * v.np;
+  double m = 0.0;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < nCam + nCub + nPt; t += (long long)gridDim.x * 256) {
+    double x = 0.0;
+    if (t < nCam) { const int i = (int)(t / 6), d = (int)(t % 6); if (v.cam_col[i] >= 0) x = v.Hcam[36 * (size_t)i + 7 * d]; }
+    else if (t < nCam + nCub) { const long long q = t - nCam; const int i = (int)(q / 9), d = (int)(q % 9); if (v.cub_col[i] >= 0) x = v.Hcub[81 * (size_t)i + 10 * d]; }
+    else { const long long q = t - nCam - nCub; const int i = (int)(q / 3), d = (int)(q % 3); if (v.pt_free[i]) x = v.Hll[9 * (size_t)i + 4 * d]; }
+    x = fabs(x);
+    if (x > m) m = x;      // (a NaN never wins, as in the reference's std::max(fabs(x), m) chain once a later entry follows it)
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { const double y = __shfl_xor(m, o); if (y > m) m = y; }
+  if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+void ba_launch_max_diag(const BaView& v, double* out, hipStream_t st) {
+  const long long n = 6ll * v.nc + 9ll * v.no + 3ll * v.np;
+  if (n <= 0) return;
+  const long long nb = (n + 255) / 256;
+  hipLaunchKernelGGL(ba_max_diag_kernel, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(256), 0, st, v, reinterpret_cast<unsigned long long*>(out));
 }
 // up to 48 buffers zeroed by one launch (the structure phase's allocations): blockIdx.y = buffer, 4-byte words
 struct BaZeroList { unsigned* p[48]; unsigned long long words[48]; };
@@ -2821,7 +2895,10 @@ void ba_launch_scale(const BaView& v, const double* lambda, double* partial, hip
 }
 void ba_launch_backsub(const BaView& v, hipStream_t st) {
   if (v.elim && v.no > 0) hipLaunchKernelGGL(ba_cub_backsub_kernel, dim3(v.no), dim3(64), 0, st, v);
-  if (v.np > 0) hipLaunchKernelGGL(ba_backsub_kernel, dim3((v.np + 255) / 256), dim3(256), 0, st, v);
+  if (v.np > 0) {
+    if (v.fuse_lin) hipLaunchKernelGGL(ba_backsub_lin_kernel, dim3((v.np + 255) / 256), dim3(256), 0, st, v);      // (the trial's Schur kernels did not write H_pl)
+    else hipLaunchKernelGGL(ba_backsub_kernel, dim3((v.np + 255) / 256), dim3(256), 0, st, v);
+  }
 }
 void ba_launch_update(const BaView& v, hipStream_t st, double* bak_cams, double* bak_points, double* bak_cubes) {
   int n = v.np + v.nc + v.no;

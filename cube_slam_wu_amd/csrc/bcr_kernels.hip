@@ -37,7 +37,6 @@ namespace cs {
 typedef double bcr_v4d __attribute__((ext_vector_type(4)));
 enum { BCR_B = 128, BCR_NB = BCR_B / BS, BCR_NT = BCR_B / 16, BCR_NS = BCR_B / 4, BCR_BB = BCR_B * BCR_B, BCR_SLOTS = BCR_NB * (BCR_NB + 1) / 2,
        BCR_MAXLEV = 16, BCR_UPD_SLOTS = BCR_NT * (BCR_NT + 1) / 2 + BCR_NT * BCR_NT + 1 };
-enum { BCR_LDS_DOUBLES = BCR_SLOTS * BS * (BS + 1) + 2 * BS * (BS + 1) + 512 + 2 * BCR_B };
 typedef double (*bcr_blk)[BS + 1];
 
 struct BcrLevel {
@@ -88,17 +87,17 @@ __device__ __forceinline__ void bcr_ctile_store(bcr_blk M, int ti, int tj, int l
 }
 #define BCR_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
-__device__ __attribute__((noinline)) bool bcr_potf2_inv(const double (*U)[BS + 1], int nb, double (*Dl)[BS + 1], double (*X)[BS + 1], double* colbuf) { return band_potf2_inv4b_impl(U, nb, Dl, X, colbuf); }
-
 // ---------------------------------------------------------------------------------------------------------------- level 0: pack --
 // The couplings of the eliminated blocks and the diagonal blocks of the remaining ones, out of the band into plain row-major blocks
 // (the panel / update kernels then read one layout at every level).  Runs beside the factor workgroups of level 0, off the chain.
+template <int NT>
 __device__ void bcr_pack(const BcrLevel& P, int p) {
   const int k = p >> 3, which = (p >> 2) & 1, q = p & 3, tid = threadIdx.x;
   if (k >= P.N) return;
   const int Bv = P.Bv, LD = P.LD;
   const double* __restrict__ Sb = P.Sb;
-  double v[16];
+  constexpr int NU = 4096 / NT;       // entries of a 32-row quarter per thread
+  double v[NU];
   if ((k & 1) == 0) {
     const int je = k >> 1;
     if (which == 0) {
@@ -106,49 +105,57 @@ __device__ void bcr_pack(const BcrLevel& P, int p) {
       double* __restrict__ Y = P.YL + (size_t)je * BCR_BB;
       const int vr = bcr_valid_rows(P, k);
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const int idx = tid + 256 * u, c = idx & (BCR_B - 1), kr = 32 * q + (idx >> 7);
+      for (int u = 0; u < NU; u++) {
+        const int idx = tid + NT * u, c = idx & (BCR_B - 1), kr = 32 * q + (idx >> 7);
         const int off = Bv + kr - c;
         v[u] = (kr < vr && c < Bv && off < LD) ? Sb[(size_t)((k - 1) * Bv + c) * LD + off] : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 16; u++) { const int idx = tid + 256 * u; Y[(32 * q + (idx >> 7)) * BCR_B + (idx & (BCR_B - 1))] = v[u]; }
+      for (int u = 0; u < NU; u++) { const int idx = tid + NT * u; Y[(32 * q + (idx >> 7)) * BCR_B + (idx & (BCR_B - 1))] = v[u]; }
     } else {
       if (k + 1 >= P.N) return;
       double* __restrict__ Y = P.YR + (size_t)je * BCR_BB;
       const int vrn = bcr_valid_rows(P, k + 1);
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const int idx = tid + 256 * u, c = idx & (BCR_B - 1), kr = 32 * q + (idx >> 7);
+      for (int u = 0; u < NU; u++) {
+        const int idx = tid + NT * u, c = idx & (BCR_B - 1), kr = 32 * q + (idx >> 7);
         const int off = Bv + c - kr;
         v[u] = (c < vrn && kr < Bv && off < LD) ? Sb[(size_t)(k * Bv + kr) * LD + off] : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 16; u++) { const int idx = tid + 256 * u; Y[(32 * q + (idx >> 7)) * BCR_B + (idx & (BCR_B - 1))] = v[u]; }
+      for (int u = 0; u < NU; u++) { const int idx = tid + NT * u; Y[(32 * q + (idx >> 7)) * BCR_B + (idx & (BCR_B - 1))] = v[u]; }
     }
   } else if (which == 0) {
     double* __restrict__ D = P.D + (size_t)k * BCR_BB;
     const int vr = bcr_valid_rows(P, k);
 #pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const int idx = tid + 256 * u, C = idx & (BCR_B - 1), R = 32 * q + (idx >> 7);
+    for (int u = 0; u < NU; u++) {
+      const int idx = tid + NT * u, C = idx & (BCR_B - 1), R = 32 * q + (idx >> 7);
       v[u] = R >= C ? bcr_band_diag(P, k, vr, R, C) : bcr_band_diag(P, k, vr, C, R);
     }
 #pragma unroll
-    for (int u = 0; u < 16; u++) { const int idx = tid + 256 * u; D[(32 * q + (idx >> 7)) * BCR_B + (idx & (BCR_B - 1))] = v[u]; }
+    for (int u = 0; u < NU; u++) { const int idx = tid + NT * u; D[(32 * q + (idx >> 7)) * BCR_B + (idx & (BCR_B - 1))] = v[u]; }
   }
 }
 
 // -------------------------------------------------------------------------------------------------------------------- factor --
-// One workgroup per eliminated block: D = L L^T and Linv = L^-1, blocked right-looking over 32-column steps, all of it in LDS.  The
-// lower block triangle lives in ten 32 x 32 slots; slot (i, j) holds A_ij -> L_ij (after the panel of step j) -> T_ij = sum_m L_im Linv_mj
-// (accumulated by the steps m = j .. i-1) -> Linv_ij = -Linv_ii T_ij (step i).  Step k:
-//   a  POTF2 + inverse of slot (k, k) (band_potf2.h)                                       -> X = Linv_kk
-//   b  Linv_kj = -X T_kj (j < k);   d  L_ik = A_ik X^T (i > k);   slot (k, k) = X            (in place: results held back over a barrier)
-//   e  A_ij -= L_ik L_jk^T (i >= j > k);   f' T_ij += L_ik Linv_kj (i > k > j)
-//   f  T_ik = L_ik X (i > k)                                                                (in place)
-// Wave w owns the 16 x 16 tile (w >> 1, w & 1) of every 32 x 32 block it is handed; operands come out of LDS eight depth steps at a time.
-#define BCR_SLOT(i, j) (reinterpret_cast<bcr_blk>(slots + ((i) * ((i) + 1) / 2 + (j)) * (BS * (BS + 1))))
+// One workgroup of EIGHT waves per eliminated block: D = L L^T and Linv = L^-1 over four 32-column steps, all of it in LDS.  Round 6: the
+// chain of the kernel is the four 32 x 32 diagonal sweeps (a dependent chain of 128 pivots) -- everything else is matrix-core work that
+// does not have to wait for them.  So the waves are two sets:
+//   P (waves 0-3)  the diagonal sweep of step K (potf4: Cholesky factor + inverse, four columns per LDS round trip), then only the two block
+//                  products the next sweep waits for:  L(K+1,K) = A(K+1,K) X_K^T  and  A(K+1,K+1) -= L(K+1,K) L(K+1,K)^T
+//   M (waves 4-7)  the rest of step K, beside sweep K + 1:  the other panels L(i,K), the trailing updates A(i,j) -= L(i,K) L(j,K)^T, and the
+//                  running products of the inverse  T(i,j) = sum_m L(i,m) Linv(m,j)  ->  Linv(i,j) = -X_i T(i,j)
+// Every hand-over between the sets is one of the workgroup barriers both execute in lockstep (the M set's work is dealt into the intervals
+// between the sweep's barriers); a SIMD holds one wave of each set, so the sweep's FP64 vector chain and the other set's matrix-core
+// instructions issue side by side.  Storage: the ten lower blocks A(i,j) (A(i,j), i > j, is reused for T(i,j) once L(i,j) has been formed from
+// it; A(K,K) receives X_K), six blocks L(i,j) (L(i,j), later Linv(i,j)).  No block is read and written by different waves inside one interval.
+enum { F8_SLOT = BS * (BS + 1), F8_NA = BCR_NB * (BCR_NB + 1) / 2, F8_NL = BCR_NB * (BCR_NB - 1) / 2, F8_COLBUF = 2 * 4 * 64,
+       BCR_LDS_DOUBLES = (F8_NA + F8_NL) * F8_SLOT + F8_COLBUF + 4 * BCR_B, BCR_FACTOR_THREADS = 512 };
+#define F8_A(i, j) (reinterpret_cast<bcr_blk>(lds + ((i) * ((i) + 1) / 2 + (j)) * F8_SLOT))
+#define F8_L(i, j) (reinterpret_cast<bcr_blk>(lds + (F8_NA + (i) * ((i) - 1) / 2 + (j)) * F8_SLOT))
+#define F8_ZERO (bcr_v4d{0.0, 0.0, 0.0, 0.0})
+
 __device__ __forceinline__ void bcr_row8(bcr_blk M, int t, int lane, double (&a)[8]) {
 #pragma unroll
   for (int s = 0; s < 8; s++) a[s] = M[16 * t + (lane & 15)][4 * s + (lane >> 4)];
@@ -157,96 +164,142 @@ __device__ __forceinline__ void bcr_col8(bcr_blk M, int t, int lane, double (&b)
 #pragma unroll
   for (int s = 0; s < 8; s++) b[s] = M[4 * s + (lane >> 4)][16 * t + (lane & 15)];
 }
-template <int K>
-__device__ __forceinline__ void bcr_factor_step(double* slots, bcr_blk X, int tid, int lane, int ti, int tj) {
-  // ---- b + d: three blocks (K of kind b, 3 - K of kind d), results kept in registers over the barrier
-  {
-    bcr_v4d acc[BCR_NB - 1];
-    double xa[8], xb[8];
-    bcr_row8(X, ti, lane, xa);
-    bcr_row8(X, tj, lane, xb);
+// c (+/-)= rows ti of MA times  BCOL ? columns tj of MB : rows tj of MB transposed,  depth steps [s0, s1) of the 32
+template <bool NEG, bool BCOL>
+__device__ __forceinline__ bcr_v4d f8_mma(bcr_v4d c, bcr_blk MA, int ti, bcr_blk MB, int tj, int lane, int s0, int s1) {
+  double a[8], b[8];
+  bcr_row8(MA, ti, lane, a);
+  if (BCOL) bcr_col8(MB, tj, lane, b); else bcr_row8(MB, tj, lane, b);
 #pragma unroll
-    for (int j = 0; j < K; j++) {
-      double tc[8];
-      bcr_col8(BCR_SLOT(K, j), tj, lane, tc);
-      acc[j] = bcr_v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < 8; s++)
-        if (s < 4 * (ti + 1)) acc[j] = BCR_MFMA(-xa[s], tc[s], acc[j]);
-    }
-#pragma unroll
-    for (int i = K + 1; i < BCR_NB; i++) {
-      double ar[8];
-      bcr_row8(BCR_SLOT(i, K), ti, lane, ar);
-      acc[i - 1] = bcr_v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < 8; s++)
-        if (s < 4 * (tj + 1)) acc[i - 1] = BCR_MFMA(ar[s], xb[s], acc[i - 1]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < K; j++) bcr_ctile_store(BCR_SLOT(K, j), ti, tj, lane, acc[j]);
-#pragma unroll
-    for (int i = K + 1; i < BCR_NB; i++) bcr_ctile_store(BCR_SLOT(i, K), ti, tj, lane, acc[i - 1]);
-    bcr_blk Skk = BCR_SLOT(K, K);
-#pragma unroll
-    for (int q = 0; q < 4; q++) { const int idx = tid + 256 * q; Skk[idx >> 5][idx & 31] = X[idx >> 5][idx & 31]; }
-    __syncthreads();
-  }
-  if (K + 1 < BCR_NB) {
-    // ---- e + f' (no slot both read and written) and f (in place: held back over the barrier)
-    bcr_v4d facc[BCR_NB - 1];
-    double xc[8];
-    bcr_col8(X, tj, lane, xc);
-#pragma unroll
-    for (int i = K + 1; i < BCR_NB; i++) {
-      double ar[8];
-      bcr_row8(BCR_SLOT(i, K), ti, lane, ar);
-#pragma unroll
-      for (int j = K + 1; j <= i; j++) {
-        double br[8];
-        bcr_row8(BCR_SLOT(j, K), tj, lane, br);
-        bcr_v4d c = bcr_ctile_load(BCR_SLOT(i, j), ti, tj, lane);
-#pragma unroll
-        for (int s = 0; s < 8; s++) c = BCR_MFMA(-ar[s], br[s], c);
-        bcr_ctile_store(BCR_SLOT(i, j), ti, tj, lane, c);
-      }
-#pragma unroll
-      for (int j = 0; j < K; j++) {
-        double bc[8];
-        bcr_col8(BCR_SLOT(K, j), tj, lane, bc);
-        bcr_v4d c = bcr_ctile_load(BCR_SLOT(i, j), ti, tj, lane);
-#pragma unroll
-        for (int s = 0; s < 8; s++) c = BCR_MFMA(ar[s], bc[s], c);
-        bcr_ctile_store(BCR_SLOT(i, j), ti, tj, lane, c);
-      }
-      facc[i - 1] = bcr_v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < 8; s++)
-        if (s >= 4 * tj) facc[i - 1] = BCR_MFMA(ar[s], xc[s], facc[i - 1]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = K + 1; i < BCR_NB; i++) bcr_ctile_store(BCR_SLOT(i, K), ti, tj, lane, facc[i - 1]);
-    __syncthreads();
-  }
+  for (int s = 0; s < 8; s++)
+    if (s >= s0 && s < s1) c = BCR_MFMA(NEG ? -a[s] : a[s], b[s], c);
+  return c;
+}
+// the block operations of a step K (a wave computes the 16 x 16 tile (ti, tj) of the block):
+//   D  L(i,K) = A(i,K) X_K^T                    E  A(i,j) -= L(i,K) L(j,K)^T              F  T(i,K) = L(i,K) X_K          (into A(i,K))
+//   G  T(i,j) += L(i,K) Linv(K,j)  (j < K < i)   B  Linv(K,j) = -X_K T(K,j)               (into L(K,j))
+__device__ __forceinline__ void f8_D(double* lds, int i, int K, int ti, int tj, int lane) {
+  bcr_ctile_store(F8_L(i, K), ti, tj, lane, f8_mma<false, false>(F8_ZERO, F8_A(i, K), ti, F8_A(K, K), tj, lane, 0, 4 * (tj + 1)));
+}
+__device__ __forceinline__ void f8_E(double* lds, int i, int j, int K, int ti, int tj, int lane) {
+  bcr_ctile_store(F8_A(i, j), ti, tj, lane, f8_mma<true, false>(bcr_ctile_load(F8_A(i, j), ti, tj, lane), F8_L(i, K), ti, F8_L(j, K), tj, lane, 0, 8));
+}
+__device__ __forceinline__ void f8_F(double* lds, int i, int K, int ti, int tj, int lane) {
+  bcr_ctile_store(F8_A(i, K), ti, tj, lane, f8_mma<false, true>(F8_ZERO, F8_L(i, K), ti, F8_A(K, K), tj, lane, 4 * tj, 8));
+}
+__device__ __forceinline__ void f8_G(double* lds, int i, int j, int K, int ti, int tj, int lane) {
+  bcr_ctile_store(F8_A(i, j), ti, tj, lane, f8_mma<false, true>(bcr_ctile_load(F8_A(i, j), ti, tj, lane), F8_L(i, K), ti, F8_L(K, j), tj, lane, 0, 8));
+}
+__device__ __forceinline__ void f8_B(double* lds, int K, int j, int ti, int tj, int lane) {
+  bcr_ctile_store(F8_L(K, j), ti, tj, lane, f8_mma<true, true>(F8_ZERO, F8_A(K, K), ti, F8_A(K, j), tj, lane, 0, 4 * (ti + 1)));
 }
 
-__global__ __launch_bounds__(256) void bcr_factor_kernel(BcrLevel P, int n_elim) {
-  if ((int)blockIdx.x >= n_elim) { bcr_pack(P, blockIdx.x - n_elim); return; }
+// ---- the diagonal sweep (four waves), four columns per round as band_potf2.h's routine: lanes 0..31 of every wave own row r of the block,
+// lanes 32..63 row r of an identity that rides along (what the elimination turns it into is column r of L^-1); wave ws keeps the column
+// q = 4 i + ws of every lane's row.  Round i0 eliminates the columns 4 i0 .. 4 i0 + 3 together: their owners write them to LDS (potf4_pre),
+// one workgroup barrier, then (potf4_post) every lane reads its own row's four entries -- four ordinary LDS reads -- and takes everything that
+// is the same for all lanes OUT OF ITS WAVE'S REGISTERS with v_readlane: the 4 x 4 pivot block (lane c0 + i's entries) and, for the trailing
+// update of a later column q, lane q's raw entries.  (Measured, tools/microbench/bcr_factor_probe.cpp: the uniform-address LDS reads of the
+// first form -- 14 per round here, 68 in an eight-column round -- cost ~35 cycles each with four waves issuing the same reads, and WERE the
+// round: 0.7 us per four-column round, 1.6 us per eight-column round.)  Only the inverse is kept.
+struct Potf4 { double v[8]; int bad; };
+__device__ __forceinline__ void potf4_init(Potf4& S, bcr_blk U, int lane, int ws) {
+  const int row = lane & 31;
+  const bool lower = lane < BS;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int q = 4 * i + ws;
+    const double x = U[row][q];
+    S.v[i] = (lower && q <= row) ? x : (q == row ? 1.0 : 0.0);
+  }
+  S.bad = 0;
+}
+__device__ __forceinline__ void potf4_pre(const Potf4& S, int i0, double* colbuf, int lane, int ws) { colbuf[(i0 & 1) * 256 + ws * 64 + lane] = S.v[i0]; }
+__device__ __forceinline__ void potf4_post(Potf4& S, int i0, const double* colbuf, int lane, int ws) {
+  const double* buf = colbuf + (i0 & 1) * 256;
+  const int c0 = 4 * i0;
+  double m[4], P[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) m[j] = buf[j * 64 + lane];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) P[i][j] = band_rdlane(m[j], c0 + i);       // lane c0 + i's entry of column c0 + j
+  double d[4], inv[4], g[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    d[j] = P[j][j];
+    S.bad |= !(d[j] > 0.0);
+    inv[j] = band_rcp(d[j]);
+#pragma unroll
+    for (int i = j + 1; i < 4; i++) g[i][j] = P[i][j] * inv[j];
+#pragma unroll
+    for (int i = j + 1; i < 4; i++)
+#pragma unroll
+      for (int jj = j + 1; jj <= i; jj++) P[i][jj] = fma(-P[i][j], g[jj][j], P[i][jj]);
+  }
+  double x[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    x[j] = m[j];
+#pragma unroll
+    for (int t = 0; t < j; t++) x[j] = fma(-x[t], g[j][t], x[j]);
+  }
+  const double dw = ws == 0 ? d[0] : (ws == 1 ? d[1] : (ws == 2 ? d[2] : d[3]));
+  const double xw = ws == 0 ? x[0] : (ws == 1 ? x[1] : (ws == 2 ? x[2] : x[3]));
+  S.v[i0] = xw * band_rsqrt(dw);
+  double z[4];
+#pragma unroll
+  for (int t = 3; t >= 0; t--) {
+    z[t] = x[t] * inv[t];
+#pragma unroll
+    for (int j = t + 1; j < 4; j++) z[t] = fma(-g[j][t], z[j], z[t]);
+  }
+#pragma unroll
+  for (int i = i0 + 1; i < 8; i++) {
+    const int q = 4 * i + ws;            // (wave-uniform: ws comes from a readfirstlane)
+    double acc = S.v[i];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc = fma(-z[t], band_rdlane(m[t], q), acc);      // lane q's raw entries of the round's columns
+    S.v[i] = acc;
+  }
+}
+// the inverse of the factor, X[q][row] (lower triangular, the rest zero), into the diagonal block's own slot
+__device__ __forceinline__ void potf4_store(const Potf4& S, bcr_blk X, int lane, int ws) {
+  if (lane < BS) return;
+  const int row = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int q = 4 * i + ws;
+    X[q][row] = (q >= row) ? S.v[i] : 0.0;
+  }
+}
+// -DBCR_PROBE (tools/microbench/bcr_factor_probe.cpp only): wave w of workgroup 0 stamps the constant 100 MHz clock at every barrier
+#ifdef BCR_PROBE
+__device__ long long* g_bcr_probe = nullptr;
+#define BCR_STAMP() do { if (g_bcr_probe && blockIdx.x == 0 && lane == 0 && probe_k < 64) g_bcr_probe[w * 64 + probe_k++] = wall_clock64(); } while (0)
+#else
+#define BCR_STAMP() do { } while (0)
+#endif
+__global__ __launch_bounds__(BCR_FACTOR_THREADS) void bcr_factor_kernel(BcrLevel P, int n_elim) {
+  if ((int)blockIdx.x >= n_elim) { bcr_pack<BCR_FACTOR_THREADS>(P, blockIdx.x - n_elim); return; }
   extern __shared__ double bcr_lds[];
+  double* lds = bcr_lds;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#ifdef BCR_PROBE
+  int probe_k = 0;
+#endif
+  BCR_STAMP();
+  const bool isP = w < 4;
+  const int ws = __builtin_amdgcn_readfirstlane(w & 3), ti = ws >> 1, tj = ws & 1;
   const int je = blockIdx.x, e = 2 * je;
-  double* slots = bcr_lds;
-  bcr_blk Dl = reinterpret_cast<bcr_blk>(bcr_lds + BCR_SLOTS * BS * (BS + 1));
-  bcr_blk X = reinterpret_cast<bcr_blk>(bcr_lds + (BCR_SLOTS + 1) * BS * (BS + 1));
-  double* colbuf = bcr_lds + (BCR_SLOTS + 2) * BS * (BS + 1);
-  double* bv = colbuf + 512;
-  double* part = bv + BCR_B;
+  double* colbuf = lds + (F8_NA + F8_NL) * F8_SLOT;
+  double* bv = colbuf + F8_COLBUF;
+  double* part = bv + BCR_B;          // 3 x 128
 
-  // ---- load D_e (the ten lower blocks: 40 entries per thread, all in flight) and b_e
+  // ---- load D_e (the ten lower blocks: 20 entries per thread, all in flight) and b_e
   {
-    double v[BCR_SLOTS][4];
+    double v[F8_NA][2];
     if (P.lvl == 0 && !P.packed) {
       const int vr = bcr_valid_rows(P, e);
 #pragma unroll
@@ -254,8 +307,8 @@ __global__ __launch_bounds__(256) void bcr_factor_kernel(BcrLevel P, int n_elim)
 #pragma unroll
         for (int j = 0; j <= i; j++)
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const int idx = tid + 256 * q, R = 32 * i + (idx & 31), C = 32 * j + (idx >> 5);
+          for (int q = 0; q < 2; q++) {
+            const int idx = tid + BCR_FACTOR_THREADS * q, R = 32 * i + (idx & 31), C = 32 * j + (idx >> 5);
             v[i * (i + 1) / 2 + j][q] = R >= C ? bcr_band_diag(P, e, vr, R, C) : 0.0;
           }
 #pragma unroll
@@ -263,7 +316,7 @@ __global__ __launch_bounds__(256) void bcr_factor_kernel(BcrLevel P, int n_elim)
 #pragma unroll
         for (int j = 0; j <= i; j++)
 #pragma unroll
-          for (int q = 0; q < 4; q++) { const int idx = tid + 256 * q; BCR_SLOT(i, j)[idx & 31][idx >> 5] = v[i * (i + 1) / 2 + j][q]; }
+          for (int q = 0; q < 2; q++) { const int idx = tid + BCR_FACTOR_THREADS * q; F8_A(i, j)[idx & 31][idx >> 5] = v[i * (i + 1) / 2 + j][q]; }
     } else {
       const double* __restrict__ D = P.D + (size_t)e * BCR_BB;
 #pragma unroll
@@ -271,8 +324,8 @@ __global__ __launch_bounds__(256) void bcr_factor_kernel(BcrLevel P, int n_elim)
 #pragma unroll
         for (int j = 0; j <= i; j++)
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const int idx = tid + 256 * q;
+          for (int q = 0; q < 2; q++) {
+            const int idx = tid + BCR_FACTOR_THREADS * q;
             v[i * (i + 1) / 2 + j][q] = D[(32 * i + (idx >> 5)) * BCR_B + 32 * j + (idx & 31)];
           }
 #pragma unroll
@@ -280,53 +333,82 @@ __global__ __launch_bounds__(256) void bcr_factor_kernel(BcrLevel P, int n_elim)
 #pragma unroll
         for (int j = 0; j <= i; j++)
 #pragma unroll
-          for (int q = 0; q < 4; q++) { const int idx = tid + 256 * q; BCR_SLOT(i, j)[idx >> 5][idx & 31] = v[i * (i + 1) / 2 + j][q]; }
+          for (int q = 0; q < 2; q++) { const int idx = tid + BCR_FACTOR_THREADS * q; F8_A(i, j)[idx >> 5][idx & 31] = v[i * (i + 1) / 2 + j][q]; }
     }
   }
   if (tid < BCR_B) bv[tid] = bcr_b_at(P, e, tid);
-  __syncthreads();
+  BCR_STAMP(); __syncthreads();
 
-  const int ti = (w >> 1) & 1, tj = w & 1;
-  bool bad = false;
-  bad |= bcr_potf2_inv(BCR_SLOT(0, 0), BS, Dl, X, colbuf);
-  __syncthreads();
-  bcr_factor_step<0>(slots, X, tid, lane, ti, tj);
-  bad |= bcr_potf2_inv(BCR_SLOT(1, 1), BS, Dl, X, colbuf);
-  __syncthreads();
-  bcr_factor_step<1>(slots, X, tid, lane, ti, tj);
-  bad |= bcr_potf2_inv(BCR_SLOT(2, 2), BS, Dl, X, colbuf);
-  __syncthreads();
-  bcr_factor_step<2>(slots, X, tid, lane, ti, tj);
-  bad |= bcr_potf2_inv(BCR_SLOT(3, 3), BS, Dl, X, colbuf);
-  __syncthreads();
-  bcr_factor_step<3>(slots, X, tid, lane, ti, tj);
+  Potf4 S;
+  int bad = 0;
+  // One sweep = init pre(0) | B | post(0) pre(1) | B | ... | post(6) pre(7) | B | post(7) store | B  (P set); the M set runs the statements
+  // M0 .. M7 in the eight intervals behind the sweep's first eight barriers.
+#define F8_ROUND(r, MS)                                                                                                     \
+  if (isP) { potf4_post(S, r, colbuf, lane, ws); potf4_pre(S, (r) + 1, colbuf, lane, ws); } else { MS; }                    \
+  BCR_STAMP(); __syncthreads();
+#define F8_SWEEP(K, M0, M1, M2, M3, M4, M5, M6, M7)                                                                        \
+  if (isP) { potf4_init(S, F8_A(K, K), lane, ws); potf4_pre(S, 0, colbuf, lane, ws); }                                     \
+  BCR_STAMP(); __syncthreads();                                                                                            \
+  F8_ROUND(0, M0) F8_ROUND(1, M1) F8_ROUND(2, M2) F8_ROUND(3, M3) F8_ROUND(4, M4) F8_ROUND(5, M5) F8_ROUND(6, M6)            \
+  if (isP) { potf4_post(S, 7, colbuf, lane, ws); potf4_store(S, F8_A(K, K), lane, ws); bad |= S.bad; } else { M7; }         \
+  BCR_STAMP(); __syncthreads();
+#define F8_NONE (void)0
+
+  // ---- step 0
+  F8_SWEEP(0, F8_NONE, F8_NONE, F8_NONE, F8_NONE, F8_NONE, F8_NONE, F8_NONE, F8_NONE)
+  if (isP) f8_D(lds, 1, 0, ti, tj, lane); else f8_D(lds, 2, 0, ti, tj, lane);
+  BCR_STAMP(); __syncthreads();
+  if (isP) f8_E(lds, 1, 1, 0, ti, tj, lane); else f8_D(lds, 3, 0, ti, tj, lane);
+  BCR_STAMP(); __syncthreads();
+  // ---- step 1 (beside its sweep: the rest of step 0)
+  F8_SWEEP(1, f8_E(lds, 2, 1, 0, ti, tj, lane), f8_E(lds, 2, 2, 0, ti, tj, lane), f8_E(lds, 3, 1, 0, ti, tj, lane), f8_E(lds, 3, 2, 0, ti, tj, lane),
+           f8_E(lds, 3, 3, 0, ti, tj, lane), f8_F(lds, 1, 0, ti, tj, lane), f8_F(lds, 2, 0, ti, tj, lane), f8_F(lds, 3, 0, ti, tj, lane))
+  if (isP) f8_D(lds, 2, 1, ti, tj, lane); else f8_D(lds, 3, 1, ti, tj, lane);
+  BCR_STAMP(); __syncthreads();
+  if (isP) f8_E(lds, 2, 2, 1, ti, tj, lane); else f8_B(lds, 1, 0, ti, tj, lane);
+  BCR_STAMP(); __syncthreads();
+  // ---- step 2 (beside its sweep: the rest of step 1)
+  F8_SWEEP(2, f8_E(lds, 3, 2, 1, ti, tj, lane), f8_G(lds, 2, 0, 1, ti, tj, lane), f8_E(lds, 3, 3, 1, ti, tj, lane), f8_F(lds, 2, 1, ti, tj, lane),
+           f8_F(lds, 3, 1, ti, tj, lane), f8_G(lds, 3, 0, 1, ti, tj, lane), F8_NONE, F8_NONE)
+  if (isP) f8_D(lds, 3, 2, ti, tj, lane); else f8_B(lds, 2, 0, ti, tj, lane);
+  BCR_STAMP(); __syncthreads();
+  if (isP) f8_E(lds, 3, 3, 2, ti, tj, lane); else f8_B(lds, 2, 1, ti, tj, lane);
+  BCR_STAMP(); __syncthreads();
+  // ---- step 3 (beside its sweep: the rest of step 2), then the last row of the inverse on all eight waves
+  F8_SWEEP(3, f8_G(lds, 3, 0, 2, ti, tj, lane), f8_G(lds, 3, 1, 2, ti, tj, lane), f8_F(lds, 3, 2, ti, tj, lane), F8_NONE, F8_NONE, F8_NONE, F8_NONE, F8_NONE)
   static_assert(BCR_NB == 4, "four 32-column steps");
+  if (isP) f8_B(lds, 3, 0, ti, tj, lane); else f8_B(lds, 3, 1, ti, tj, lane);
+  if (isP ? ws < 2 : ws >= 2) f8_B(lds, 3, 2, ti, tj, lane);
   if (bad && tid == 0) atomicMax(P.info, e + 1);
+  BCR_STAMP(); __syncthreads();
+#undef F8_SWEEP
+#undef F8_ROUND
+#undef F8_NONE
 
-  // ---- Linv in the TA layout (row tile m: depth steps s < 4 (m + 1)), y = Linv b
+  // ---- Linv in the TA layout (row tile m: depth steps s < 4 (m + 1); s = 8 u + w lies in block column u), y = Linv b
   double* __restrict__ TA = P.Linv + (size_t)je * BCR_BB;
 #pragma unroll
   for (int m = 0; m < BCR_NT; m++)
 #pragma unroll
-    for (int u = 0; u < m + 1; u++) {
-      const int s = 4 * u + w;
-      const int R = 16 * m + (lane & 15), C = 4 * s + (lane >> 4);
-      TA[(size_t)(m * BCR_NS + s) * 64 + lane] = (&BCR_SLOT(m >> 1, 0)[R & 31][0])[(C >> 5) * (BS * (BS + 1)) + (C & 31)];   // (the slots of a block row are contiguous)
+    for (int u = 0; u < (m + 2) / 2; u++) {
+      const int s = 8 * u + w;
+      bcr_blk Sl = (m >> 1) == u ? F8_A(m >> 1, m >> 1) : F8_L(m >> 1, u < (m >> 1) ? u : 0);
+      if (s < 4 * (m + 1)) TA[(size_t)(m * BCR_NS + s) * 64 + lane] = Sl[16 * (m & 1) + (lane & 15)][4 * w + (lane >> 4)];
     }
   {
-    const int R = tid & (BCR_B - 1), h = tid >> 7;
-    const double* rowp = &BCR_SLOT(R >> 5, 0)[R & 31][0];
+    const int R = tid & (BCR_B - 1), h = tid >> 7, bi = R >> 5;          // h: the block column (32 columns) this thread sums
     double s0 = 0.0, s1 = 0.0;
+    if (h <= bi) {
+      const double* rowp = lds + (h == bi ? bi * (bi + 1) / 2 + bi : F8_NA + bi * (bi - 1) / 2 + h) * F8_SLOT + (R & 31) * (BS + 1);
+      const double* bh = bv + 32 * h;
 #pragma unroll 8
-    for (int C = 64 * h; C < 64 * h + 64; C += 2) {
-      const double l0 = C <= R ? rowp[(C >> 5) * (BS * (BS + 1)) + (C & 31)] : 0.0;
-      const double l1 = C + 1 <= R ? rowp[((C + 1) >> 5) * (BS * (BS + 1)) + ((C + 1) & 31)] : 0.0;
-      s0 = fma(l0, bv[C], s0); s1 = fma(l1, bv[C + 1], s1);
+      for (int C = 0; C < 32; C += 2) { s0 = fma(rowp[C], bh[C], s0); s1 = fma(rowp[C + 1], bh[C + 1], s1); }      // (the diagonal slot's upper triangle holds zeros)
     }
-    if (h) part[R] = s0 + s1;
-    __syncthreads();
-    if (!h) P.y[(size_t)je * BCR_B + R] = (s0 + s1) + part[R];
+    if (h) part[(h - 1) * BCR_B + R] = s0 + s1;
+    BCR_STAMP(); __syncthreads();
+    if (!h) P.y[(size_t)je * BCR_B + R] = ((s0 + s1) + part[R]) + (part[BCR_B + R] + part[2 * BCR_B + R]);
   }
+  BCR_STAMP();
 }
 
 // --------------------------------------------------------------------------------------------------------------------- panel --
@@ -568,7 +650,7 @@ static void bcr_run(const double* Sb, double* work, int n, int LD, int Bv, doubl
   for (int l = 0; l < L; l++) {
     const BcrLevel& P = lev[l];
     const int ne = (P.N + 1) / 2, nr = P.N / 2;
-    hipLaunchKernelGGL(bcr_factor_kernel, dim3(ne + ((l == 0 && !packed) ? 8 * P.N : 0)), dim3(256), BCR_LDS_DOUBLES * sizeof(double), st, P, ne);
+    hipLaunchKernelGGL(bcr_factor_kernel, dim3(ne + ((l == 0 && !packed) ? 8 * P.N : 0)), dim3(BCR_FACTOR_THREADS), BCR_LDS_DOUBLES * sizeof(double), st, P, ne);
     if (nr > 0) {
       hipLaunchKernelGGL(bcr_panel_kernel, dim3(16 * ne), dim3(256), 0, st, P);
       hipLaunchKernelGGL(bcr_update_kernel, dim3(nr * BCR_UPD_SLOTS), dim3(256), 0, st, P);

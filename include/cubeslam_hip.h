@@ -438,6 +438,11 @@ typedef struct cs_ba_timing {
   long long schur_entries;          /* sum over landmarks of k_j (k_j + 1) / 2                           */
 } cs_ba_timing;
 int cs_ba_last_timing(cs_ba* ba, cs_ba_timing* t);
+/* The stage split above (errors / linearize / reduce / factor / backsub _ms) is g2o's G2OBatchStatistics (core/batch_stats.h:48-62) and, like
+ * there (SparseOptimizer::setComputeBatchStatistics, core/sparse_optimizer.cpp:379-397), it is OFF until asked for: every phase mark is an
+ * event on the handle's stream (~6 us of dispatch gap each, eight per LM trial), and with the marks on, cs_ba_optimize also gives up queueing the
+ * next iteration's linearisation behind a trial before the trial's verdict is known.  total_ms, the counters and the byte figures are always kept. */
+int cs_ba_set_stage_timing(cs_ba* ba, int on);
 
 /* Debug / repro aids (what g2o offers through its debug builds and its text IO).
  * cs_ba_check_finite: scans for NaN / Inf where g2o's debug builds look for them -- the edges' errors (SparseOptimizer::

@@ -15,6 +15,18 @@ P = capi.ba_from_dict(pr)
 P.sizes()
 t_struct = (time.perf_counter() - t0) * 1e3
 P.optimize(1)
+t0 = time.perf_counter()
+n0 = P.optimize(iters)
+el0 = time.perf_counter() - t0
+print("%s, stage split off (the default): %d iterations, %.1f it/s, %.3f ms/it" % (cfg, n0, n0 / el0, el0 / max(1, n0) * 1e3))
+if len(sys.argv) > 4 and sys.argv[4] == "nosplit":      # (tools/ba_timeline.sh: the timeline of the default mode)
+    P.close()
+    sys.exit(0)
+# the same once more with the stage split on (cs_ba_set_stage_timing: phase marks on the stream, no speculative linearisation), on a fresh handle
+P.close()
+P = capi.ba_from_dict(pr)
+P.stage_timing(True)
+P.optimize(1)
 tb = P.timing()
 t0 = time.perf_counter()
 n = P.optimize(iters)

@@ -14,6 +14,7 @@ for k in ("e_cam", "e_uv", "e_info", "e_intr", "e_huber"):
     pr[k] = np.concatenate([a[k], b[k]])
 pr["e_pt"] = np.concatenate([a["e_pt"], b["e_pt"] + off]).astype(np.int32)
 P = capi.ba_from_dict(pr)
+P.stage_timing(True)
 t0 = time.perf_counter(); P.sizes(); t_struct = (time.perf_counter() - t0) * 1e3
 print("edges %d, longest track %d, reduced system %s, Schur layout %s, structure %.0f ms" % (len(pr["e_pt"]), np.bincount(pr["e_pt"]).max(), P.reduced_size(), P.schur_layout(), t_struct))
 P.optimize(1)

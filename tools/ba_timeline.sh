@@ -2,7 +2,7 @@
 # kernel timeline of one LM iteration of the C4 bundle adjustment (rocprofv3 --kernel-trace): start offset, duration, gap to the previous
 # kernel's end, queue -- shows what a trial's ~1.75 ms consist of besides kernel time
 R=$(pwd); export TMPDIR=/tmp; cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/ba_tl -o tl -- python $R/tools/ba_quick.py ${1:-C4} 6 > $R/gpurun_out/ba_tl.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/ba_tl -o tl -- python $R/tools/ba_quick.py ${1:-C4} 6 5 ${2:-nosplit} > $R/gpurun_out/ba_tl.log 2>&1
 cd $R
 f=$(find gpurun_out/ba_tl -name '*kernel_trace.csv' | head -1)
 python - <<PY

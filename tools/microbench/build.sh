@@ -17,3 +17,6 @@ hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -x hip tools/microb
 hipcc -O2 -std=c++17 tools/microbench/sparse_plan_check.cpp -o build_tmp/sparse_plan_check
 # host-only: the error bound of fastAtan2 that the LSD host stage's region growing relies on (tests/test_capi_symbols.py runs it with a stride)
 g++ -O2 -std=c++17 tools/microbench/lsd_atan_bound.cpp -o build_tmp/lsd_atan_bound -pthread
+# where the time of bcr_factor_kernel goes (stamps at its barriers; development tool)
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -x hip tools/microbench/bcr_factor_probe.cpp -o build_tmp/bcr_factor_probe
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -x hip tools/microbench/potf4_bench.cpp -o build_tmp/potf4_bench

@@ -6,6 +6,7 @@ from cube_slam_wu_amd import capi, synth_ba
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 pr = synth_ba.make_problem(n_cams=1000, n_points=200000, n_cuboids=500, seed=42)
 P = capi.ba_from_dict(pr)
+P.stage_timing(True)
 if R > 1:
     P.set_shard(R // 2, R)
     si = P.shard_info()
