@@ -42,6 +42,7 @@ void ba_launch_backsub(const BaView& v, hipStream_t st);
 int ba_scale_blocks();
 void ba_launch_scale(const BaView& v, const double* lambda_dev, double* partial, hipStream_t st);
 void ba_launch_update(const BaView& v, hipStream_t st, double* bak_cams = nullptr, double* bak_points = nullptr, double* bak_cubes = nullptr);
+void ba_launch_scale_update(const BaView& v, const double* lambda_dev, double* partial, hipStream_t st, double* bak_cams, double* bak_points, double* bak_cubes);
 void ba_launch_band_cholesky(double* Sb, double* work, int n, int LD, double* rhs, int* info, bool solve, hipStream_t st, bool one_sided = false);
 void ba_launch_sep_reduce(const double* S, int LD, const double* Linv, int ci, int ni, int zl, int wl, int zr, int wr, double* Y, const double* rhs, double* msg, int wm, hipStream_t st);
 void ba_launch_sep_assemble(const double* msgs, size_t msg_doubles, int wm, int R, const int* sep_off, int n, int LDs, double* Ssep, double* rsep, hipStream_t st);
@@ -2462,8 +2463,7 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
         auto enqueue_trial = [&](std::unique_lock<std::mutex>* t) -> int {
           bool okq = true;
           int rq = solve_device(B, lambda, &okq, nullptr, nullptr, t); if (rq) return rq;
-          cs::ba_launch_scale(B->view, B->d_lam.p, B->scale_partial.p, B->st);
-          cs::ba_launch_update(B->view, B->st, B->cams_bak.p, B->points_bak.p, B->cubes_bak.p);
+          cs::ba_launch_scale_update(B->view, B->d_lam.p, B->scale_partial.p, B->st, B->cams_bak.p, B->points_bak.p, B->cubes_bak.p);
           if (spec_now) BA_TRY(hipEventRecord(B->ev_upd, B->st));      // the state the next linearisation reads is final from here
           BA_MARK(B, B->ev[6]);
           cs::ba_launch_chi2(B->view, B->nb_chi, B->st);

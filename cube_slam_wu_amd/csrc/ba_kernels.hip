@@ -76,10 +76,10 @@ __device__ __forceinline__ void proj_linearize(const Pose& T, const double* R, c
 }
 
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ba_chi2_proj_kernel(BaView v) {
-  __shared__ double ws[4];
+// (device bodies with the block index / block count as arguments: ba_chi2_kernel below runs both kinds of block in ONE launch)
+__device__ __forceinline__ void chi2_proj_block(const BaView& v, int bid, int nblocks, double* ws) {
   double acc = 0;
-  for (int k = blockIdx.x * 256 + threadIdx.x; k < v.n_proj; k += gridDim.x * 256) {
+  for (int k = bid * 256 + threadIdx.x; k < v.n_proj; k += nblocks * 256) {
     Pose T = pose_load(v.cams + 7 * v.pm_cam[k]);
     double e[2], pc[3];
     proj_error(T, v.points + 3 * v.pm_pt[k], v.pm_uv + 2 * k, v.intr_u ? v.intr_u : v.pm_intr + 4 * k, e, pc);
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void ba_chi2_proj_kernel(BaView v) {
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) v.chi_partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+  if (threadIdx.x == 0) v.chi_partial[bid] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
 __device__ __forceinline__ double quad_form(const double* e, const double* info, int n) {
@@ -106,8 +106,8 @@ __device__ __forceinline__ double quad_form(const double* e, const double* info,
 }
 
 // one lane per cuboid / odometry edge; partial sums appended after the projection partials
-__global__ __launch_bounds__(64) void ba_chi2_pose_edges_kernel(BaView v, int partial_off) {
-  int k = blockIdx.x * 64 + threadIdx.x;
+__device__ __forceinline__ void chi2_pose_edges_wave(const BaView& v, int partial_off, int bid, int lane) {
+  int k = bid * 64 + lane;
   double c = 0;
   if (k < v.n_cub3) {
     double e[9];
@@ -132,19 +132,31 @@ __global__ __launch_bounds__(64) void ba_chi2_pose_edges_kernel(BaView v, int pa
     }
   }
   c = wave_sum(c);
-  if (threadIdx.x == 0) v.chi_partial[partial_off + blockIdx.x] = c;
+  if (lane == 0) v.chi_partial[partial_off + bid] = c;
+}
+// chi2 of every active edge in one launch: the blocks of the cuboid / odometry edges FIRST (a wave per 64 edges: few, long -- four SE3 logs
+// per cuboid edge), the projection edges' blocks behind them.  The partial sums keep their places: [0, nb_proj) projection blocks, then one
+// per 64 pose edges -- the same values in the same slots as the two launches this replaces (round 6: one dispatch less on every trial's chain).
+__global__ __launch_bounds__(256) void ba_chi2_kernel(BaView v, int nb_proj, int nb_pose) {
+  __shared__ double ws[4];
+  const int nb4 = (nb_pose + 3) / 4;
+  if ((int)blockIdx.x < nb4) {
+    const int pb = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pb < nb_pose) chi2_pose_edges_wave(v, nb_proj, pb, threadIdx.x & 63);
+    return;
+  }
+  chi2_proj_block(v, blockIdx.x - nb4, nb_proj, ws);
 }
 
 // x^T (lambda x + b) of the LM gain ratio (optimization_algorithm_levenberg.cpp:117-126, computeScale :182-189) over
 // the pose increments (x in v.rhs, b in bcam / bcub) and the landmark increments (xl, bl); fixed-shape reduction:
 // SCALE_BLOCKS partial sums, added up by the host in order.
 enum { SCALE_BLOCKS = 256 };
-__global__ __launch_bounds__(256) void ba_scale_kernel(BaView v, const double* __restrict__ lamp, double* partial) {
+__device__ __forceinline__ void scale_block(const BaView& v, const double* __restrict__ lamp, double* partial, int bid, double* ws) {
   const double lambda_lm = lamp[0], lambda_pose = lamp[1];     // (lambda of the trial, read from device memory: the launch sequence of a trial is a fixed graph)
-  __shared__ double ws[4];
   double acc = 0;
   const int n = v.np + v.nc + v.no;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += SCALE_BLOCKS * 256) {
+  for (int i = bid * 256 + threadIdx.x; i < n; i += SCALE_BLOCKS * 256) {
     if (i < v.np) {
       if (v.pt_free[i])
 #pragma unroll
@@ -164,7 +176,11 @@ __global__ __launch_bounds__(256) void ba_scale_kernel(BaView v, const double* _
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+  if (threadIdx.x == 0) partial[bid] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+__global__ __launch_bounds__(256) void ba_scale_kernel(BaView v, const double* __restrict__ lamp, double* partial) {
+  __shared__ double ws[4];
+  scale_block(v, lamp, partial, blockIdx.x, ws);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -858,7 +874,7 @@ __device__ __forceinline__ void ba_lin_schur_segment(const BaView& v, double lam
         // segment are not neighbours in it.)
         // Round 6: H_pl does not go to memory at all here (231 MB written per launch at C4, 259 MB read back by the back-substitution): the only
         // reader behind this kernel, x_l = D^-1 (b_l - H_pl^T x_p), forms the blocks again from the same state with the same arithmetic
-        // (ba_backsub_lin_kernel) -- 20 bytes of edge record instead of a 144-byte block per edge, the same bits.
+        // (backsub_lin_point) -- 20 bytes of edge record instead of a 144-byte block per edge, the same bits.
         const bool both = cam_free && v.pt_free[p] != 0;
 #pragma unroll
         for (int q = 0; q < 6; q++) {
@@ -1175,9 +1191,7 @@ __global__ __launch_bounds__(256) void ba_cub_elim_kernel(BaView v, const double
 }
 
 // x_o = D_oo^-1 (b_o - sum_s M_s^T x_cam(s))   (block_solver.hpp:457-482 for the cuboid blocks)
-__global__ __launch_bounds__(64) void ba_cub_backsub_kernel(BaView v) {
-  __shared__ double cl[9];
-  const int o = blockIdx.x, t = threadIdx.x;
+__device__ __forceinline__ void cub_backsub_wave(const BaView& v, int o, int t, double* cl) {     // one wavefront; cl: 9 doubles of LDS of its own
   const int col = v.cub_col[o];
   if (col < 0) return;
   if (t < 9) {
@@ -1191,18 +1205,22 @@ __global__ __launch_bounds__(64) void ba_cub_backsub_kernel(BaView v) {
     }
     cl[t] = acc;
   }
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   if (t < 9) {
     double sv = 0;
     for (int k = 0; k < 9; k++) sv += v.cub_Dinv[81 * (size_t)o + 9 * t + k] * cl[k];
     v.rhs[col + t] = sv;
   }
 }
+__global__ __launch_bounds__(64) void ba_cub_backsub_kernel(BaView v) {
+  __shared__ double cl[9];
+  cub_backsub_wave(v, blockIdx.x, threadIdx.x, cl);
+}
 
 // (Round 5 tried the H_pl records as one coalesced stream through LDS, a lane per edge, the landmark's lane summing in edge order: 84 us
 // against 80 at C4 -- the 163 MB read is not what this kernel waits for -- and was dropped.)
-__global__ __launch_bounds__(256) void ba_backsub_kernel(BaView v) {
-  int p = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void backsub_point(const BaView& v, int p) {
   if (p >= v.np) return;
   double cl[3] = {v.bl[3 * p], v.bl[3 * p + 1], v.bl[3 * p + 2]};
   for (int k = v.pt_ptr[p]; k < v.pt_ptr[p + 1]; k++) {
@@ -1226,8 +1244,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaView v) {
 // The same with H_pl formed on the spot (the fused linearise-in-Schur trials, which never write it): per edge the camera, the point, the
 // measurement -- proj_linearize and the J_c^T (rho' Omega) J_p product exactly as ba_lin_schur_segment / lin_pt_edge form them, then the same
 // sums in the same order as the kernel above: the same x_l bit for bit (tests/test_ba_gpu.py holds the LM run to the classic pair).
-__global__ __launch_bounds__(256) void ba_backsub_lin_kernel(BaView v) {
-  int p = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void backsub_lin_point(const BaView& v, int p) {
   if (p >= v.np) return;
   double cl[3] = {v.bl[3 * p], v.bl[3 * p + 1], v.bl[3 * p + 2]};
   const bool free_pt = v.pt_free[p] != 0;
@@ -1263,11 +1280,24 @@ __global__ __launch_bounds__(256) void ba_backsub_lin_kernel(BaView v) {
   v.xl[3 * p] = x[0]; v.xl[3 * p + 1] = x[1]; v.xl[3 * p + 2] = x[2];
 }
 
+// Both back-substitutions of a trial in ONE launch: the eliminated cuboids' blocks first (a wave per cuboid: x_o from the cameras' x_p), the
+// landmarks' behind them -- the two read the cameras' increments only and write disjoint outputs.  LIN: H_pl formed on the spot (above).
+template <bool LIN>
+__global__ __launch_bounds__(256) void ba_backsub_all_kernel(BaView v, int n_cub_blocks) {
+  __shared__ double cl[4][9];
+  if ((int)blockIdx.x < n_cub_blocks) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o < v.no) cub_backsub_wave(v, o, threadIdx.x & 63, cl[threadIdx.x >> 6]);
+    return;
+  }
+  const int p = (blockIdx.x - n_cub_blocks) * 256 + threadIdx.x;
+  if (LIN) backsub_lin_point(v, p); else backsub_point(v, p);
+}
+
 // bak_*: non-null = the push of the LM trial rides along (OptimizableGraph::push before the update, optimization_algorithm_levenberg.cpp:104-
 // 113): every vertex's estimate goes to its backup slot before it is changed -- three device-to-device copies of the whole state per trial
 // (~50 us at C4) become a few more stores of a kernel that reads the state anyway
-__global__ __launch_bounds__(256) void ba_update_kernel(BaView v, double* bak_cams, double* bak_points, double* bak_cubes) {
-  int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void update_vertex(const BaView& v, int i, double* bak_cams, double* bak_points, double* bak_cubes) {
   if (i < v.np) {
     if (bak_points) { bak_points[3 * i] = v.points[3 * i]; bak_points[3 * i + 1] = v.points[3 * i + 1]; bak_points[3 * i + 2] = v.points[3 * i + 2]; }
     if (v.pt_free[i]) { v.points[3 * i] += v.xl[3 * i]; v.points[3 * i + 1] += v.xl[3 * i + 1]; v.points[3 * i + 2] += v.xl[3 * i + 2]; }
@@ -1286,6 +1316,16 @@ __global__ __launch_bounds__(256) void ba_update_kernel(BaView v, double* bak_ca
     int col = v.cub_col[i];
     if (col >= 0) cube_store(cube_oplus(cube_load(v.cubes + 10 * i), v.rhs + col), v.cubes + 10 * i);
   }
+}
+__global__ __launch_bounds__(256) void ba_update_kernel(BaView v, double* bak_cams, double* bak_points, double* bak_cubes) {
+  update_vertex(v, blockIdx.x * 256 + threadIdx.x, bak_cams, bak_points, bak_cubes);
+}
+// the LM scale term and the update of a trial in ONE launch: x^T (lambda x + b) reads the increments and the right-hand sides, the update reads
+// the increments and writes the estimates -- independent; the SCALE_BLOCKS partial sums keep their places
+__global__ __launch_bounds__(256) void ba_scale_update_kernel(BaView v, const double* __restrict__ lamp, double* partial, double* bak_cams, double* bak_points, double* bak_cubes) {
+  __shared__ double ws[4];
+  if (blockIdx.x < SCALE_BLOCKS) { scale_block(v, lamp, partial, blockIdx.x, ws); return; }
+  update_vertex(v, (blockIdx.x - SCALE_BLOCKS) * 256 + threadIdx.x, bak_cams, bak_points, bak_cubes);
 }
 
 
@@ -2559,9 +2599,8 @@ void ba_launch_gather_rows(const double* src, const int* idx, int n, int width, 
 int ba_chi2_blocks(int n_proj) { int nb = (n_proj + 255) / 256; return nb < 1 ? 1 : (nb > 2048 ? 2048 : nb); }
 
 void ba_launch_chi2(const BaView& v, int nb_proj, hipStream_t st) {
-  hipLaunchKernelGGL(ba_chi2_proj_kernel, dim3(nb_proj), dim3(256), 0, st, v);
-  int ne = v.n_cub + v.n_odom;
-  if (ne > 0) hipLaunchKernelGGL(ba_chi2_pose_edges_kernel, dim3((ne + 63) / 64), dim3(64), 0, st, v, nb_proj);
+  const int ne = v.n_cub + v.n_odom, nb_pose = (ne + 63) / 64;
+  hipLaunchKernelGGL(ba_chi2_kernel, dim3(nb_proj + (nb_pose + 3) / 4), dim3(256), 0, st, v, nb_proj, nb_pose);
 }
 // the numeric-Jacobian edges (cuboid, odometry: few edges, long dependent chains) run beside the projection edges (many edges, short
 // chains) on a second stream; ba_accum_pose_kernel needs both
@@ -2812,13 +2851,19 @@ __global__ __launch_bounds__(256) void ba_max_diag_kernel(BaView v, unsigned lon
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) { const double y = __shfl_xor(m, o); if (y > m) m = y; }
-  if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+  __shared__ double wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {      // one atomic per workgroup (4096 wavefronts on one address took 50 us)
+    const double a = wm[0] > wm[1] ? wm[0] : wm[1], b = wm[2] > wm[3] ? wm[2] : wm[3], mm = a > b ? a : b;
+    if (mm > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(mm));
+  }
 }
 void ba_launch_max_diag(const BaView& v, double* out, hipStream_t st) {
   const long long n = 6ll * v.nc + 9ll * v.no + 3ll * v.np;
   if (n <= 0) return;
   const long long nb = (n + 255) / 256;
-  hipLaunchKernelGGL(ba_max_diag_kernel, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(256), 0, st, v, reinterpret_cast<unsigned long long*>(out));
+  hipLaunchKernelGGL(ba_max_diag_kernel, dim3((unsigned)(nb > 512 ? 512 : nb)), dim3(256), 0, st, v, reinterpret_cast<unsigned long long*>(out));
 }
 // up to 48 buffers zeroed by one launch (the structure phase's allocations): blockIdx.y = buffer, 4-byte words
 struct BaZeroList { unsigned* p[48]; unsigned long long words[48]; };
@@ -2894,11 +2939,14 @@ void ba_launch_scale(const BaView& v, const double* lambda, double* partial, hip
   hipLaunchKernelGGL(ba_scale_kernel, dim3(SCALE_BLOCKS), dim3(256), 0, st, v, lambda, partial);
 }
 void ba_launch_backsub(const BaView& v, hipStream_t st) {
-  if (v.elim && v.no > 0) hipLaunchKernelGGL(ba_cub_backsub_kernel, dim3(v.no), dim3(64), 0, st, v);
-  if (v.np > 0) {
-    if (v.fuse_lin) hipLaunchKernelGGL(ba_backsub_lin_kernel, dim3((v.np + 255) / 256), dim3(256), 0, st, v);      // (the trial's Schur kernels did not write H_pl)
-    else hipLaunchKernelGGL(ba_backsub_kernel, dim3((v.np + 255) / 256), dim3(256), 0, st, v);
-  }
+  const int ncb = (v.elim && v.no > 0) ? (v.no + 3) / 4 : 0, npb = (v.np + 255) / 256;
+  if (ncb + npb <= 0) return;
+  if (v.fuse_lin) hipLaunchKernelGGL(ba_backsub_all_kernel<true>, dim3(ncb + npb), dim3(256), 0, st, v, ncb);      // (the trial's Schur kernels did not write H_pl)
+  else hipLaunchKernelGGL(ba_backsub_all_kernel<false>, dim3(ncb + npb), dim3(256), 0, st, v, ncb);
+}
+void ba_launch_scale_update(const BaView& v, const double* lambda, double* partial, hipStream_t st, double* bak_cams, double* bak_points, double* bak_cubes) {
+  const int n = v.np + v.nc + v.no;
+  hipLaunchKernelGGL(ba_scale_update_kernel, dim3(SCALE_BLOCKS + (n + 255) / 256), dim3(256), 0, st, v, lambda, partial, bak_cams, bak_points, bak_cubes);
 }
 void ba_launch_update(const BaView& v, hipStream_t st, double* bak_cams, double* bak_points, double* bak_cubes) {
   int n = v.np + v.nc + v.no;

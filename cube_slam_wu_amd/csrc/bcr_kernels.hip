@@ -194,6 +194,26 @@ __device__ __forceinline__ void f8_B(double* lds, int K, int j, int ti, int tj, 
   bcr_ctile_store(F8_L(K, j), ti, tj, lane, f8_mma<true, true>(F8_ZERO, F8_A(K, K), ti, F8_A(K, j), tj, lane, 0, 4 * (ti + 1)));
 }
 
+// The M set's products beside a sweep are ISSUED in one interval and STORED at the head of the next: the interval then holds the operand loads
+// and the issue of the eight matrix-core instructions only -- shorter than a round of the sweep, which the set would otherwise hold up at
+// the barrier (measured: 0.7 us per whole product against 0.5 us per round) -- and nothing reads the tile before the barrier after its store.
+struct F8Pend { bcr_v4d c; int off; };      // off: the destination slot's offset in doubles, -1 = nothing pending
+#define F8_OFF_A(i, j) (((i) * ((i) + 1) / 2 + (j)) * F8_SLOT)
+#define F8_OFF_L(i, j) ((F8_NA + (i) * ((i) - 1) / 2 + (j)) * F8_SLOT)
+__device__ __forceinline__ void f8_flush(double* lds, F8Pend& q, int ti, int tj, int lane) {
+  if (q.off >= 0) bcr_ctile_store(reinterpret_cast<bcr_blk>(lds + q.off), ti, tj, lane, q.c);
+  q.off = -1;
+}
+__device__ __forceinline__ F8Pend f8_E_issue(double* lds, int i, int j, int K, int ti, int tj, int lane) {
+  return F8Pend{f8_mma<true, false>(bcr_ctile_load(F8_A(i, j), ti, tj, lane), F8_L(i, K), ti, F8_L(j, K), tj, lane, 0, 8), F8_OFF_A(i, j)};
+}
+__device__ __forceinline__ F8Pend f8_F_issue(double* lds, int i, int K, int ti, int tj, int lane) {
+  return F8Pend{f8_mma<false, true>(F8_ZERO, F8_L(i, K), ti, F8_A(K, K), tj, lane, 4 * tj, 8), F8_OFF_A(i, K)};
+}
+__device__ __forceinline__ F8Pend f8_G_issue(double* lds, int i, int j, int K, int ti, int tj, int lane) {
+  return F8Pend{f8_mma<false, true>(bcr_ctile_load(F8_A(i, j), ti, tj, lane), F8_L(i, K), ti, F8_L(K, j), tj, lane, 0, 8), F8_OFF_A(i, j)};
+}
+
 // ---- the diagonal sweep (four waves), four columns per round as band_potf2.h's routine: lanes 0..31 of every wave own row r of the block,
 // lanes 32..63 row r of an identity that rides along (what the elimination turns it into is column r of L^-1); wave ws keeps the column
 // q = 4 i + ws of every lane's row.  Round i0 eliminates the columns 4 i0 .. 4 i0 + 3 together: their owners write them to LDS (potf4_pre),
@@ -343,16 +363,22 @@ __global__ __launch_bounds__(BCR_FACTOR_THREADS) void bcr_factor_kernel(BcrLevel
   int bad = 0;
   // One sweep = init pre(0) | B | post(0) pre(1) | B | ... | post(6) pre(7) | B | post(7) store | B  (P set); the M set runs the statements
   // M0 .. M7 in the eight intervals behind the sweep's first eight barriers.
+#ifdef BCR_EXPERIMENT_NO_M      /* timing experiment of tools/microbench only: the sweeps without the other set's work (results wrong) */
+#define F8_MWORK(x) (void)0
+#else
+#define F8_MWORK(x) x
+#endif
 #define F8_ROUND(r, MS)                                                                                                     \
-  if (isP) { potf4_post(S, r, colbuf, lane, ws); potf4_pre(S, (r) + 1, colbuf, lane, ws); } else { MS; }                    \
+  if (isP) { potf4_post(S, r, colbuf, lane, ws); potf4_pre(S, (r) + 1, colbuf, lane, ws); } else { f8_flush(lds, pend, ti, tj, lane); F8_MWORK(MS); } \
   BCR_STAMP(); __syncthreads();
 #define F8_SWEEP(K, M0, M1, M2, M3, M4, M5, M6, M7)                                                                        \
   if (isP) { potf4_init(S, F8_A(K, K), lane, ws); potf4_pre(S, 0, colbuf, lane, ws); }                                     \
   BCR_STAMP(); __syncthreads();                                                                                            \
   F8_ROUND(0, M0) F8_ROUND(1, M1) F8_ROUND(2, M2) F8_ROUND(3, M3) F8_ROUND(4, M4) F8_ROUND(5, M5) F8_ROUND(6, M6)            \
-  if (isP) { potf4_post(S, 7, colbuf, lane, ws); potf4_store(S, F8_A(K, K), lane, ws); bad |= S.bad; } else { M7; }         \
+  if (isP) { potf4_post(S, 7, colbuf, lane, ws); potf4_store(S, F8_A(K, K), lane, ws); bad |= S.bad; } else { f8_flush(lds, pend, ti, tj, lane); F8_MWORK(M7); } \
   BCR_STAMP(); __syncthreads();
 #define F8_NONE (void)0
+  F8Pend pend{F8_ZERO, -1};
 
   // ---- step 0
   F8_SWEEP(0, F8_NONE, F8_NONE, F8_NONE, F8_NONE, F8_NONE, F8_NONE, F8_NONE, F8_NONE)
@@ -361,21 +387,23 @@ __global__ __launch_bounds__(BCR_FACTOR_THREADS) void bcr_factor_kernel(BcrLevel
   if (isP) f8_E(lds, 1, 1, 0, ti, tj, lane); else f8_D(lds, 3, 0, ti, tj, lane);
   BCR_STAMP(); __syncthreads();
   // ---- step 1 (beside its sweep: the rest of step 0)
-  F8_SWEEP(1, f8_E(lds, 2, 1, 0, ti, tj, lane), f8_E(lds, 2, 2, 0, ti, tj, lane), f8_E(lds, 3, 1, 0, ti, tj, lane), f8_E(lds, 3, 2, 0, ti, tj, lane),
-           f8_E(lds, 3, 3, 0, ti, tj, lane), f8_F(lds, 1, 0, ti, tj, lane), f8_F(lds, 2, 0, ti, tj, lane), f8_F(lds, 3, 0, ti, tj, lane))
-  if (isP) f8_D(lds, 2, 1, ti, tj, lane); else f8_D(lds, 3, 1, ti, tj, lane);
+  F8_SWEEP(1, pend = f8_E_issue(lds, 2, 1, 0, ti, tj, lane), pend = f8_E_issue(lds, 2, 2, 0, ti, tj, lane), pend = f8_E_issue(lds, 3, 1, 0, ti, tj, lane),
+           pend = f8_E_issue(lds, 3, 2, 0, ti, tj, lane), pend = f8_E_issue(lds, 3, 3, 0, ti, tj, lane), pend = f8_F_issue(lds, 1, 0, ti, tj, lane),
+           pend = f8_F_issue(lds, 2, 0, ti, tj, lane), pend = f8_F_issue(lds, 3, 0, ti, tj, lane))
+  if (isP) f8_D(lds, 2, 1, ti, tj, lane); else { f8_flush(lds, pend, ti, tj, lane); f8_D(lds, 3, 1, ti, tj, lane); }
   BCR_STAMP(); __syncthreads();
   if (isP) f8_E(lds, 2, 2, 1, ti, tj, lane); else f8_B(lds, 1, 0, ti, tj, lane);
   BCR_STAMP(); __syncthreads();
   // ---- step 2 (beside its sweep: the rest of step 1)
-  F8_SWEEP(2, f8_E(lds, 3, 2, 1, ti, tj, lane), f8_G(lds, 2, 0, 1, ti, tj, lane), f8_E(lds, 3, 3, 1, ti, tj, lane), f8_F(lds, 2, 1, ti, tj, lane),
-           f8_F(lds, 3, 1, ti, tj, lane), f8_G(lds, 3, 0, 1, ti, tj, lane), F8_NONE, F8_NONE)
+  F8_SWEEP(2, pend = f8_E_issue(lds, 3, 2, 1, ti, tj, lane), pend = f8_G_issue(lds, 2, 0, 1, ti, tj, lane), pend = f8_E_issue(lds, 3, 3, 1, ti, tj, lane),
+           pend = f8_F_issue(lds, 2, 1, ti, tj, lane), pend = f8_F_issue(lds, 3, 1, ti, tj, lane), pend = f8_G_issue(lds, 3, 0, 1, ti, tj, lane), F8_NONE, F8_NONE)
   if (isP) f8_D(lds, 3, 2, ti, tj, lane); else f8_B(lds, 2, 0, ti, tj, lane);
   BCR_STAMP(); __syncthreads();
   if (isP) f8_E(lds, 3, 3, 2, ti, tj, lane); else f8_B(lds, 2, 1, ti, tj, lane);
   BCR_STAMP(); __syncthreads();
   // ---- step 3 (beside its sweep: the rest of step 2), then the last row of the inverse on all eight waves
-  F8_SWEEP(3, f8_G(lds, 3, 0, 2, ti, tj, lane), f8_G(lds, 3, 1, 2, ti, tj, lane), f8_F(lds, 3, 2, ti, tj, lane), F8_NONE, F8_NONE, F8_NONE, F8_NONE, F8_NONE)
+  F8_SWEEP(3, pend = f8_G_issue(lds, 3, 0, 2, ti, tj, lane), pend = f8_G_issue(lds, 3, 1, 2, ti, tj, lane), pend = f8_F_issue(lds, 3, 2, ti, tj, lane),
+           F8_NONE, F8_NONE, F8_NONE, F8_NONE, F8_NONE)
   static_assert(BCR_NB == 4, "four 32-column steps");
   if (isP) f8_B(lds, 3, 0, ti, tj, lane); else f8_B(lds, 3, 1, ti, tj, lane);
   if (isP ? ws < 2 : ws >= 2) f8_B(lds, 3, 2, ti, tj, lane);
@@ -383,6 +411,7 @@ __global__ __launch_bounds__(BCR_FACTOR_THREADS) void bcr_factor_kernel(BcrLevel
   BCR_STAMP(); __syncthreads();
 #undef F8_SWEEP
 #undef F8_ROUND
+#undef F8_MWORK
 #undef F8_NONE
 
   // ---- Linv in the TA layout (row tile m: depth steps s < 4 (m + 1); s = 8 u + w lies in block column u), y = Linv b
@@ -406,7 +435,30 @@ __global__ __launch_bounds__(BCR_FACTOR_THREADS) void bcr_factor_kernel(BcrLevel
     }
     if (h) part[(h - 1) * BCR_B + R] = s0 + s1;
     BCR_STAMP(); __syncthreads();
-    if (!h) P.y[(size_t)je * BCR_B + R] = ((s0 + s1) + part[R]) + (part[BCR_B + R] + part[2 * BCR_B + R]);
+    const double yR = ((s0 + s1) + part[R]) + (part[BCR_B + R] + part[2 * BCR_B + R]);
+    if (!h) P.y[(size_t)je * BCR_B + R] = yR;
+    // The LAST level (one block, no neighbour): its substitution x = Linv^T y right here, out of the slots -- one launch less on the chain
+    // (bcr_run leaves this level's bcr_back_kernel out).  Thread (column C, row block h) sums its 32 rows; the four parts in a fixed order.
+    if (P.N == 1) {
+      __syncthreads();                       // (every thread has read its parts)
+      if (!h) bv[R] = yR;
+      __syncthreads();
+      const int C = R, bj = C >> 5;
+      double t0 = 0.0, t1 = 0.0;
+      if (h >= bj) {
+        const double* colp = lds + (h == bj ? h * (h + 1) / 2 + h : F8_NA + h * (h - 1) / 2 + bj) * F8_SLOT + (C & 31);
+        const double* yh = bv + 32 * h;
+#pragma unroll 8
+        for (int r = 0; r < 32; r += 2) { t0 = fma(colp[r * (BS + 1)], yh[r], t0); t1 = fma(colp[(r + 1) * (BS + 1)], yh[r + 1], t1); }      // (the diagonal slot's upper triangle holds zeros)
+      }
+      if (h) part[(h - 1) * BCR_B + C] = t0 + t1;
+      __syncthreads();
+      if (!h) {
+        const double x = ((t0 + t1) + part[C]) + (part[BCR_B + C] + part[2 * BCR_B + C]);
+        const int g0 = (1 << P.lvl) - 1;       // level-l block 0 is level-0 block 2^l - 1
+        if (C < P.Bv && g0 * P.Bv + C < P.n) P.rhs[g0 * P.Bv + C] = x;
+      }
+    }
   }
   BCR_STAMP();
 }
@@ -658,6 +710,7 @@ static void bcr_run(const double* Sb, double* work, int n, int LD, int Bv, doubl
   }
   for (int l = L - 1; l >= 0; l--) {
     const BcrLevel& P = lev[l];
+    if (P.N == 1) continue;        // (the one block of the last level: substituted by its own factor workgroup)
     hipLaunchKernelGGL(bcr_back_kernel, dim3((P.N + 1) / 2), dim3(512), 0, st, P);
   }
 }

@@ -21,7 +21,7 @@ for f in glob.glob("gpurun_out/${tag}_bapmc_sq/**/*counter_collection.csv", recu
 names = sorted({c for k in acc for c in acc[k]})
 print("kernel,launches," + ",".join(n + "_per_launch" for n in names))
 for k in sorted(acc, key=lambda k: -acc[k].get("SQ_BUSY_CYCLES", 0)):
-    if k.startswith("cs::ba_") or k.startswith("cs::band_"): print(k + ",%d," % len(disp[k]) + ",".join("%.6g" % (acc[k][c] / len(disp[k])) for c in names))
+    if k.startswith(("cs::ba_", "cs::band_", "cs::bcr_")): print(k + ",%d," % len(disp[k]) + ",".join("%.6g" % (acc[k][c] / len(disp[k])) for c in names))
 PY
 cp $(find gpurun_out/${tag}_bapmc_kt -name '*kernel_stats.csv' | head -1) gpurun_out/${tag}_ba_kernel_stats.csv 2>/dev/null
 head -30 gpurun_out/${tag}_ba_pmc_summary.csv; head -30 gpurun_out/${tag}_ba_sq_counters.csv; head -25 gpurun_out/${tag}_ba_kernel_stats.csv
