@@ -39,6 +39,8 @@
 
 #include "cs_se3.h"
 #include "cubeslam_hip.h"
+#include <algorithm>
+
 #include "g2o_text.h"
 
 using cs::Cube;
@@ -119,18 +121,25 @@ static int run_g2o_file(const char* in, const char* out, int iterations, int dig
   std::string warnings;
   if (!g2o_text::load(in, g, &warnings)) { std::fprintf(stderr, "cannot read %s\n", in); return 1; }
   if (!warnings.empty()) std::cerr << warnings;
-  std::cout << "loaded " << g.cam_id.size() << " cameras, " << g.cub_id.size() << " cuboids, " << g.ce_cam.size() << " camera-cuboid edges, " << g.oe_i.size() << " odometry edges" << std::endl;
+  std::cout << "loaded " << g.cam_id.size() << " cameras, " << g.cub_id.size() << " cuboids, " << g.ce_cam.size() << " camera-cuboid edges, " << g.oe_i.size() << " odometry edges";
+  if (!g.pt_id.empty() || !g.pe_pt.empty()) std::cout << ", " << g.pt_id.size() << " points, " << g.pe_pt.size() << " camera-point edges";
+  std::cout << std::endl;
   if (iterations > 0) {
-    cs_ba* ba = nullptr;
-    CHECK(cs_ba_create(0, &ba));
-    CHECK(cs_ba_set_vertices(ba, g.cam_Tcw.data(), g.cam_fixed.data(), (int)g.cam_id.size(), g.cuboids.data(), g.cub_fixed.data(), (int)g.cub_id.size(), nullptr, nullptr, 0,
-                             !g.cub_id.empty() && !g.cam_id.empty() && g.cub_id[0] < g.cam_id[0]));
-    if (!g.ce_cam.empty()) CHECK(cs_ba_set_edges_cuboid(ba, (int)g.ce_cam.size(), g.ce_cam.data(), g.ce_cub.data(), g.ce_meas.data(), g.ce_info.data()));
-    if (!g.oe_i.empty()) CHECK(cs_ba_set_edges_odom(ba, (int)g.oe_i.size(), g.oe_i.data(), g.oe_j.data(), g.oe_meas.data(), g.oe_info.data()));
+    // (the handle goes with the scope, whichever CHECK leaves it)
+    struct BaGuard { cs_ba* p = nullptr; ~BaGuard() { if (p) cs_ba_destroy(p); } } ba;
+    CHECK(cs_ba_create(0, &ba.p));
+    // Column order of the reduced system = g2o's: pose vertices by id (sparse_optimizer.cpp:174-187).  The C ABI orders a CLASS at a time, so
+    // a file whose cuboid ids all lie below (above) its camera ids is ordered exactly as g2o would; interleaved ids keep the cameras first
+    // (the LM run is then the same problem in another elimination order: same minimum, trial sequence not guaranteed).
+    const bool cuboids_first = !g.cub_id.empty() && !g.cam_id.empty() && *std::max_element(g.cub_id.begin(), g.cub_id.end()) < *std::min_element(g.cam_id.begin(), g.cam_id.end());
+    CHECK(cs_ba_set_vertices(ba.p, g.cam_Tcw.data(), g.cam_fixed.data(), (int)g.cam_id.size(), g.cuboids.data(), g.cub_fixed.data(), (int)g.cub_id.size(),
+                             g.points.data(), g.pt_fixed.data(), (int)g.pt_id.size(), cuboids_first));
+    if (!g.pe_pt.empty()) CHECK(cs_ba_set_edges_proj(ba.p, (int)g.pe_pt.size(), g.pe_pt.data(), g.pe_cam.data(), g.pe_uv.data(), g.pe_info.data(), g.pe_intr.data(), g.pe_huber.data()));
+    if (!g.ce_cam.empty()) CHECK(cs_ba_set_edges_cuboid(ba.p, (int)g.ce_cam.size(), g.ce_cam.data(), g.ce_cub.data(), g.ce_meas.data(), g.ce_info.data()));
+    if (!g.oe_i.empty()) CHECK(cs_ba_set_edges_odom(ba.p, (int)g.oe_i.size(), g.oe_i.data(), g.oe_j.data(), g.oe_meas.data(), g.oe_info.data()));
     int done = 0;
-    CHECK(cs_ba_optimize(ba, iterations, &done, nullptr, nullptr, nullptr, 0));
-    CHECK(cs_ba_get_state(ba, g.cam_Tcw.data(), g.cuboids.data(), nullptr));
-    cs_ba_destroy(ba);
+    CHECK(cs_ba_optimize(ba.p, iterations, &done, nullptr, nullptr, nullptr, 0));
+    CHECK(cs_ba_get_state(ba.p, g.cam_Tcw.data(), g.cuboids.data(), g.points.empty() ? nullptr : g.points.data()));
     std::cout << "LM iterations: " << done << std::endl;
   }
   if (!g2o_text::save(out, g, digits)) { std::fprintf(stderr, "cannot write %s\n", out); return 1; }
