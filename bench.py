@@ -42,7 +42,7 @@ def _pmc_child_pass(args, n_unique, counters, kernels):
     d = tempfile.mkdtemp(prefix="cs_pmc_", dir="/tmp")
     try:
         cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-               "--steps", "2", "--warmup", "1", "--inflight", "1", "--depth", "1", "--steady-steps", "0", "--latency-calls", "0", "--lines-images", "0", "--ba", "none", "--no-cpu-baseline", "--no-edge", "--rp-frames", "0", "--no-measure-traffic",
+               "--steps", "2", "--warmup", "1", "--inflight", "1", "--depth", "1", "--steady-steps", "0", "--latency-calls", "0", "--image-in-steps", "0", "--lines-images", "0", "--ba", "none", "--no-cpu-baseline", "--no-edge", "--rp-frames", "0", "--no-measure-traffic",
                "--frames", str(args.frames), "--unique", str(n_unique)]
         subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp", "CS_BENCH_CHILD": "1"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
         tot, cnt = {}, {}
@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--rp-frames", type=int, default=100, help="frames of the roll/pitch-sampling stress variant (RP = 25 poses per box, the reference's class default); 0 = skip")
     ap.add_argument("--lines-images", type=int, default=64, help="images per batch of the line-producer entry (0 = skip)")
     ap.add_argument("--rp-inflight", type=int, default=4, help="batches in flight of the roll/pitch-sampling stress variant")
+    ap.add_argument("--image-in-steps", type=int, default=12, help="steps of the image-in entry (upload + edge front end + sweep inside the clock); 0 = skip")
     ap.add_argument("--latency-calls", type=int, default=200, help="calls per entry point of the single-call latency report (0 = skip)")
     ap.add_argument("--depth", type=int, default=2, help="batches per pipeline: the next one is submitted (packed + queued) before the current one is collected")
     ap.add_argument("--steady-steps", type=int, default=200, help="steps of the steady-state measurement reported beside the contract run (0 = skip)")
@@ -802,6 +803,78 @@ def main():
                 n += 1
             edge_out["cpu_oracle_rois_per_s"] = n / (time.perf_counter() - t1)
 
+    # ---- image in, cuboids out, with the upload INSIDE the clock (the reference's caller hands detect_cuboid an image per call,
+    # box_proposal_detail.cpp:84,320-327): per step the gray images of all frames go up from pinned host memory (cs_batch_refill_gray: one
+    # contiguous block -> one DMA on a copy stream, beside the sweep that is still running), then Canny + distance transform of every ROI,
+    # then the sweep.  Never `value` (BASELINE's metric has its inputs resident); reported beside the measured H2D rate, which bounds it.
+    image_in = None
+    if rank == 0 and world == 1 and args.image_in_steps > 0 and os.environ.get("CS_BENCH_CHILD") is None:
+        try:
+            H, W = int(uniq[0]["img_h"]), int(uniq[0]["img_w"])
+            rngi = np.random.default_rng(17)
+            yy, xx = np.mgrid[0:H, 0:W]
+            base_imgs = []
+            for _ in range(16):
+                img = np.full((H, W), 90.0)
+                for _ in range(25):
+                    a = rngi.uniform(0, np.pi)
+                    img += np.where((xx - rngi.uniform(0, W)) * np.cos(a) + (yy - rngi.uniform(0, H)) * np.sin(a) > 0, rngi.uniform(-40, 40), 0)
+                img += 12 * np.sin(xx / 7.0) * np.cos(yy / 5.0) + rngi.normal(0, 6, (H, W))
+                base_imgs.append(np.clip(img, 0, 255).astype(np.uint8))
+            nfi = args.frames
+            # two pinned blocks of nfi images each (different images at the same frame index), refilled alternately
+            blocks = [torch.empty((nfi, H, W), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            for q, blk in enumerate(blocks):
+                nb_ = blk.numpy()
+                for f in range(nfi):
+                    nb_[f] = base_imgs[(f + 5 * q) % len(base_imgs)]
+            frames_img = [dict(fr) for fr in frames]
+            # (one pipeline: the detector's own default worker count, not the main entry's per-pipeline share)
+            det_i = capi.Detector(capi.default_params(whether_sample_cam_roll_pitch=0, whether_sample_bbox_height=0, yaw_range_deg=45.0, yaw_step_deg=0.5, host_threads=args.host_threads), device=local_rank)
+            bat_i = capi.Batch(det_i, frames_img, grays=[blocks[0].numpy()[f] for f in range(nfi)])
+            bat_i.run()
+            bat_i.refill_gray(base_ptr=blocks[1].data_ptr()); bat_i.run()          # warm: second buffer, copy stream
+            bat_i.refill_gray(base_ptr=blocks[0].data_ptr()); bat_i.refill_wait()      # the first timed step's images: uploaded, front end not run yet
+            torch.cuda.synchronize()
+            K_i = args.image_in_steps
+            step_log = []
+            t1 = time.perf_counter()
+            for k in range(K_i):
+                # the upload AFTER next goes behind the one this step's submit waits for (two image buffers, two uploads queued): the copy
+                # engine never idles, and the step's whole device side (front end + sweep) runs beside an upload
+                ts0 = time.perf_counter()
+                bat_i.refill_gray(base_ptr=blocks[(k + 1) % 2].data_ptr())
+                bat_i.submit()                                                       # waits for its images, queues front end + sweep
+                ts1 = time.perf_counter()
+                bat_i.collect()
+                tmg_i = bat_i.timing()
+                step_log.append([round((ts1 - ts0) * 1e3, 2), round((time.perf_counter() - ts1) * 1e3, 2), round(tmg_i["d2h_ms"], 2), round(tmg_i["finalize_ms"], 2)])
+            bat_i.refill_wait()                      # (the upload queued by the last step: K_i whole uploads inside the clock, as K_i front ends and sweeps)
+            torch.cuda.synchronize()
+            dt_i = time.perf_counter() - t1
+            bat_i.run()
+            rec_i = bat_i.cuboids(0)
+            # the H2D rate this box gives a pinned block of that size, alone
+            dev_blk = torch.empty((nfi, H, W), dtype=torch.uint8, device="cuda")
+            dev_blk.copy_(blocks[0], non_blocking=True); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for q in range(4):
+                dev_blk.copy_(blocks[q % 2], non_blocking=True)
+            torch.cuda.synchronize()
+            h2d = 4 * nfi * H * W / (time.perf_counter() - t1)
+            del dev_blk
+            bytes_frame = H * W
+            image_in = {"what": "image in, cuboids out: per step %d gray images (%d x %d, %.0f KB each) uploaded from one pinned block (cs_batch_refill_gray: one copy on a copy stream into the batch's second image buffer, beside the running front end + sweep), "
+                                "Canny + distance transform of every ROI on the device, then the C2 sweep, records on the host; one batch, one detector; upload, front end, sweep and collection all inside the clock" % (nfi, W, H, bytes_frame / 1e3),
+                        "steps": K_i, "value": nfi * K_i / dt_i, "unit": "frames/s", "ms_per_step": dt_i / K_i * 1e3,
+                        "h2d_GBps_measured_alone": h2d / 1e9, "upload_bound_frames_per_s": h2d / bytes_frame, "fraction_of_upload_bound": (nfi * K_i / dt_i) / (h2d / bytes_frame),
+                        "cuboids_in_frame_0": int(sum(len(c) for c in rec_i)),
+                        "per_step_ms [refill + submit (waits for its upload), collect, of which: wait for the device, records on the host]": step_log}
+            bat_i.close(); det_i.close()
+            del blocks
+        except Exception as ex:       # (pinning ~1 GB can fail on a constrained box: never fatal)
+            image_in = {"error": repr(ex)}
+
     # ---- single-call latency: the drop-in call is per frame (detect_cuboid once per image, main_obj.cpp:633; detect_filter_lines :593)
     lat_out = None
     if rank == 0 and args.latency_calls > 0:
@@ -1042,6 +1115,8 @@ def main():
                 out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
         if edge_out is not None:
             out["edge_front_end"] = edge_out
+        if image_in is not None:
+            out["image_in"] = image_in
         if rp_out is not None:
             out["roll_pitch_sampling_stress"] = rp_out
         if lat_out is not None:

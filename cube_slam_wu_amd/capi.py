@@ -62,7 +62,7 @@ class CsDetectTiming(C.Structure):
 DECLARED_SYMBOLS = [
     "cs_last_error", "cs_device_count", "cs_diag_build", "cs_detect_default_params", "cs_box_rois", "cs_cam_euler_zyx", "cs_detector_create",
     "cs_detector_destroy", "cs_detect_cuboids", "cs_batch_create", "cs_batch_max_boxes", "cs_batch_run", "cs_batch_submit", "cs_batch_collect",
-    "cs_bgr_to_gray", "cs_edge_distance_maps", "cs_edge_distance_maps_multi", "cs_detect_cuboids_gray", "cs_batch_create_gray", "cs_batch_destroy", "cs_batch_last_timing", "cs_batch_debug_candidates", "cs_batch_debug_kept", "cs_batch_set_debug", "cs_batch_set_pipeline_chunks", "cs_detect_lines_gray", "cs_detect_lines_batch", "cs_detect_lines_last_timing", "cs_detect_lsd_gray", "cs_detect_lsd_batch", "cs_detect_lsd_last_timing",
+    "cs_bgr_to_gray", "cs_edge_distance_maps", "cs_edge_distance_maps_multi", "cs_detect_cuboids_gray", "cs_batch_create_gray", "cs_batch_refill_gray", "cs_batch_refill_wait", "cs_batch_destroy", "cs_batch_last_timing", "cs_batch_debug_candidates", "cs_batch_debug_kept", "cs_batch_set_debug", "cs_batch_set_pipeline_chunks", "cs_detect_lines_gray", "cs_detect_lines_batch", "cs_detect_lines_last_timing", "cs_detect_lsd_gray", "cs_detect_lsd_batch", "cs_detect_lsd_last_timing",
 ]
 
 _lib = None
@@ -299,6 +299,7 @@ class Batch:
             rc = lib().cs_batch_create(det.h, descs, self.n_frames, C.byref(self.h))
         else:   # image input: the maps are produced on the device from the gray images
             gs = [np.ascontiguousarray(g, np.uint8) for g in grays]
+            self._gray_px = int(gs[0].size) if gs else 0
             gp = (C.POINTER(C.c_ubyte) * max(1, len(gs)))(*[g.ctypes.data_as(C.POINTER(C.c_ubyte)) for g in gs])
             rc = lib().cs_batch_create_gray(det.h, descs, gp, self.n_frames, C.byref(self.h))
         if rc != 0:
@@ -314,6 +315,26 @@ class Batch:
         if pipeline_chunks != 1:
             if lib().cs_batch_set_pipeline_chunks(self.h, int(pipeline_chunks)) != 0:
                 raise RuntimeError("cs_batch_set_pipeline_chunks failed")
+
+    def refill_gray(self, grays=None, base_ptr=None):
+        """cs_batch_refill_gray: new gray images for the same frames (asynchronous).  grays: a list of uint8 arrays, or base_ptr: the address of
+        n_frames images contiguous in (ideally pinned) host memory."""
+        px = None
+        if base_ptr is not None:
+            t = lib().cs_batch_max_boxes(self.h)      # (any call: keeps the handle checked)
+            px = self._gray_px
+            ptrs = (C.POINTER(C.c_ubyte) * self.n_frames)(*[C.cast(base_ptr + f * px, C.POINTER(C.c_ubyte)) for f in range(self.n_frames)])
+        else:
+            self._refill_keep = [np.ascontiguousarray(g, np.uint8) for g in grays]
+            ptrs = (C.POINTER(C.c_ubyte) * self.n_frames)(*[g.ctypes.data_as(C.POINTER(C.c_ubyte)) for g in self._refill_keep])
+        rc = lib().cs_batch_refill_gray(self.det.h, self.h, ptrs)
+        if rc != 0:
+            raise RuntimeError("cs_batch_refill_gray failed (%d): %s" % (rc, last_error()))
+
+    def refill_wait(self):
+        rc = lib().cs_batch_refill_wait(self.h)
+        if rc != 0:
+            raise RuntimeError("cs_batch_refill_wait failed (%d): %s" % (rc, last_error()))
 
     def run(self):
         rc = lib().cs_batch_run(self.det.h, self.h, self._out, self._counts.ctypes.data_as(C.POINTER(C.c_int)))

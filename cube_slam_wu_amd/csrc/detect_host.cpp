@@ -54,6 +54,9 @@ void launch_records(const DetectDeviceView& v, const RankView& rv, int kmax, cs_
 void launch_rp_carry(const RpCarryView& c, JobDesc* jobs, hipStream_t st);
 void launch_rp_save_fallback(const DetectDeviceView& v, const RpSaveView& s, hipStream_t st);
 struct EdgeRoi { int l, t, w, h; long long img_off, cls_off, map_off; };
+struct CopySeg { const void* src; void* dst; unsigned long long bytes; };
+struct CopySegs { CopySeg s[16]; int n; };
+void launch_multi_copy(const CopySegs& segs, hipStream_t st);
 void launch_edge_maps(const unsigned char* gray, int W, int H, const EdgeRoi* rois, int n_rois, unsigned char* cls_pool, float* map_pool, int max_w, long long max_px, int low, int high,
                       hipStream_t st);
 void launch_line_setup(JobDesc* jobs, int n_jobs, const double* frame_lines, const int* frame_line_ptr, double* mid_x, double* mid_y, double* line_angle,
@@ -500,6 +503,15 @@ struct cs_batch {
   PinBuf<cs::RpPose> h_rp;
   DevBuf<unsigned char> d_gray, d_cls;      // image input: gray images and Canny's class bytes (kept: a refilled batch reuses them)
   DevBuf<cs::EdgeRoi> d_edge_rois;
+  // cs_batch_refill_gray: a second image buffer (the upload of the next images runs on copy_stream beside the sweep over the current maps),
+  // what launch_edge_maps needs again, and the events that order copy -> front end -> the buffer's next upload
+  DevBuf<unsigned char> d_gray2;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_edge_done[2] = {nullptr, nullptr};
+  int gray_cur = 0, gray_w = 0, gray_h = 0, edge_n_rois = 0, edge_max_w = 1;
+  long long edge_max_px = 1;
+  bool gray_batch = false;
+  int refill_q[2] = {-1, -1}, n_refill = 0;   // image buffers whose upload is on its way, oldest first; the next submit queues the oldest one's front end
   PinBuf<float> h_maps_stage;               // map upload staging
   PipeSlot pipe[2];
   // capacity layout of the lean path's staging pools (from the inputs alone): first job / first box of a frame, first
@@ -699,6 +711,7 @@ void cs_detector_destroy(cs_detector* d) {
 static int batch_fill(cs_detector* d, cs_batch* b, const cs_frame_desc* fr, const unsigned char* const* grays, int n_frames);
 static int batch_layout(cs_detector* d, cs_batch* b);
 static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_counts, bool defer);
+static int batch_flush_refill(cs_detector* d, cs_batch* b);
 static void release_batch_buffers(cs_batch* b);
 static int batch_create_impl(cs_detector* d, const cs_frame_desc* fr, const unsigned char* const* grays, int n_frames, cs_batch** out) {
   if (!d || !out || (!fr && n_frames) || n_frames < 0) return CS_ERR_INVALID_ARG;
@@ -808,6 +821,7 @@ static int batch_fill(cs_detector* d, cs_batch* b, const cs_frame_desc* fr, cons
       DevBuf<cs::EdgeRoi>& d_rois = b->d_edge_rois;
       if ((rc = d_gray.ensure((size_t)W * H * std::max(1, n_frames))) || (rc = d_cls.ensure((size_t)cls_tot + 8)) || (rc = d_rois.ensure(er.size() + 1))) { return rc; }
       hipStream_t st = d->stream;
+      b->gray_batch = true; b->gray_w = W; b->gray_h = H; b->edge_n_rois = (int)er.size(); b->edge_max_w = max_w; b->edge_max_px = max_px; b->gray_cur = 0;
       HIP_TRY(hipMemsetAsync(b->d_maps.p, 0, sizeof(float) * (map_floats + 1), st));
       for (int f = 0; f < n_frames; f++) HIP_TRY(hipMemcpyAsync(d_gray.p + (size_t)f * W * H, grays[f], (size_t)W * H, hipMemcpyHostToDevice, st));
       if (!er.empty()) {
@@ -871,6 +885,81 @@ int cs_batch_create_gray(cs_detector* d, const cs_frame_desc* fr, const unsigned
   return batch_create_impl(d, fr, grays, n_frames, out);
 }
 
+// New images for the frames of an image-input batch (same frame descriptions: boxes, segments, cameras): the upload goes to the batch's OTHER
+// image buffer on a copy stream of its own -- beside whatever sweep is running --, the front end (Canny + distance transform of every ROI)
+// is queued by the next cs_batch_submit in front of its sweep.  Up to two uploads may be queued (one per image buffer): a caller that
+// queues the upload AFTER next before each submit keeps the copy engine busy without a gap, and the whole device side of a step (front end
+// + sweep) runs beside an upload.  Returns at once.
+int cs_batch_refill_gray(cs_detector* d, cs_batch* b, const unsigned char* const* grays) {
+  if (!d || !b || !grays || b->det != d) return CS_ERR_INVALID_ARG;
+  if (!b->gray_batch) { set_err("cs_batch_refill_gray: the batch was not created by cs_batch_create_gray"); return CS_ERR_INVALID_ARG; }
+  CS_GUARD_BEGIN
+  HIP_TRY(hipSetDevice(d->device));
+  const size_t px = (size_t)b->gray_w * b->gray_h;
+  const int n = b->n_frames;
+  if (n <= 0 || px == 0) return CS_OK;
+  int rc;
+  if ((rc = b->d_gray2.ensure(px * (size_t)n))) return rc;
+  if (b->n_refill == 2) { set_err("cs_batch_refill_gray: two uploads are queued already (one per image buffer); cs_batch_submit / cs_batch_run takes the older one"); return CS_ERR_INVALID_ARG; }
+  if (!b->copy_stream) {
+    // (lowest priority: bulk traffic, and a hardware queue of its own)
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    HIP_TRY(hipStreamCreateWithPriority(&b->copy_stream, hipStreamNonBlocking, prio_least));
+    for (auto& e : b->ev_copied) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : b->ev_edge_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(b->ev_edge_done[0], d->stream));      // buffer 0's reader so far: the front end of cs_batch_create_gray (finished)
+    HIP_TRY(hipEventRecord(b->ev_edge_done[1], d->stream));
+  }
+  // Which buffer: the one that is neither being read (gray_cur, or -- with an upload already queued -- that upload's target, which the next
+  // submit's front end reads) ...  With one upload queued the new one goes BEHIND it on the copy stream into the buffer of the current maps:
+  // the stream never idles between two batches of images, whatever the host does in between.
+  const int nxt = b->n_refill == 1 ? 1 - b->refill_q[0] : 1 - b->gray_cur;
+  unsigned char* dst = nxt ? b->d_gray2.p : b->d_gray.p;
+  // the buffer's last reader -- the front end queued when it became current -- must be through before it is overwritten
+  HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_edge_done[nxt], 0));
+  // images that follow each other in host memory go up as one copy (a batch decoded into one pinned block: a single DMA)
+  for (int f = 0; f < n;) {
+    int g = f + 1;
+    while (g < n && grays[g] == grays[g - 1] + px) g++;
+    // The copy engine, not the shader cores: a kernel that reads pinned host memory keeps hundreds of PCIe reads in flight through the same
+    // request queues the other kernels' HBM traffic takes -- with it beside them the distance transform ran 0.8 -> 7.7 ms and Canny
+    // 2.4 -> 7.5 ms (profiles/r6_image_in_timeline.txt); the engine's 8.3 ms for 467 MB is the same and costs the kernels nothing.
+    HIP_TRY(hipMemcpyAsync(dst + (size_t)f * px, grays[f], px * (size_t)(g - f), hipMemcpyHostToDevice, b->copy_stream));
+    f = g;
+  }
+  HIP_TRY(hipEventRecord(b->ev_copied[nxt], b->copy_stream));
+  b->refill_q[b->n_refill++] = nxt;
+  return CS_OK;
+  CS_GUARD_END("cs_batch_refill_gray")
+}
+// The front end over freshly uploaded images, queued by the next cs_batch_submit / cs_batch_run: the HOST waits for the upload and then queues
+// the kernels.  (First form: the detector's stream waited for the copy's event on the device.  A wait that sits in a hardware queue for the
+// 8 ms of a 467 MB upload blocks every stream the runtime maps to that queue -- the tie boxes' gather on the detector's second stream
+// waited behind it and a step took 16.7 ms instead of 8.3.)
+static int batch_flush_refill(cs_detector* d, cs_batch* b) {
+  if (b->n_refill == 0) return CS_OK;
+  const int nxt = b->refill_q[0];
+  HIP_TRY(hipEventSynchronize(b->ev_copied[nxt]));
+  hipStream_t st = d->stream;
+  if (b->edge_n_rois > 0) {
+    cs::launch_edge_maps(nxt ? b->d_gray2.p : b->d_gray.p, b->gray_w, b->gray_h, b->d_edge_rois.p, b->edge_n_rois, b->d_cls.p, b->d_maps.p, b->edge_max_w, b->edge_max_px, 80, 200, st);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(b->ev_edge_done[nxt], st));
+  b->gray_cur = nxt;
+  b->refill_q[0] = b->refill_q[1]; b->refill_q[1] = -1; b->n_refill--;
+  return CS_OK;
+}
+// ... and wait for the upload only (the host images may be reused / freed from here; the front end may still be queued)
+int cs_batch_refill_wait(cs_batch* b) {
+  if (!b) return CS_ERR_INVALID_ARG;
+  if (!b->copy_stream) return CS_OK;
+  HIP_TRY(hipSetDevice(b->det->device));
+  HIP_TRY(hipStreamSynchronize(b->copy_stream));
+  return CS_OK;
+}
+
 int cs_batch_max_boxes(const cs_batch* b) { return b ? b->max_boxes : CS_ERR_INVALID_ARG; }
 
 static void batch_drop_run_state(cs_batch* b);
@@ -889,7 +978,10 @@ static void release_batch_buffers(cs_batch* b) {
   b->d_yaw.release(); b->d_yaw_c.release(); b->d_yaw_s.release(); b->d_vp.release(); b->d_bound.release(); b->d_dist.release();
   b->d_angle.release(); b->d_skew.release(); b->d_corners.release(); b->d_c_dist.release(); b->d_c_angle.release();
   b->d_c_skew.release(); b->d_win_corners.release(); b->d_rp.release(); b->h_rp.release();
-  b->d_gray.release(); b->d_cls.release(); b->d_edge_rois.release(); b->h_maps_stage.release();
+  b->d_gray.release(); b->d_cls.release(); b->d_edge_rois.release(); b->h_maps_stage.release(); b->d_gray2.release();
+  if (b->copy_stream) { (void)hipStreamSynchronize(b->copy_stream); (void)hipStreamDestroy(b->copy_stream); b->copy_stream = nullptr; }
+  for (auto& e : b->ev_copied) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  for (auto& e : b->ev_edge_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   b->h_stage.release(); b->h_c_slot.release(); b->h_job_cbase.release(); b->h_c_flag.release(); b->h_job_valid.release();
   b->h_c_dist.release(); b->h_c_angle.release(); b->h_c_skew.release(); b->h_win_corners.release();
   b->d_box_job0.release(); b->d_box_njobs.release(); b->d_win_count.release(); b->d_fallback.release(); b->d_winners.release(); b->d_last_slot.release(); b->h_last_slot.release();
@@ -996,6 +1088,7 @@ namespace {
 static double g_mark[16];
 static int g_runs = 0;
 static const bool g_prof = getenv("CS_DETECT_PROF") != nullptr;   // diagnostics: host phase clock of the lean path
+static const bool g_dma_tables = getenv("CS_DETECT_DMA_TABLES") != nullptr;   // a batch's tables / results through hipMemcpyAsync (the form before round 6) instead of multi_copy_kernel
 #define MARK(k, t_ref) do { if (g_prof) { double t_now = now_ms(); g_mark[k] += t_now - (t_ref); (t_ref) = t_now; } } while (0)
 
 int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
@@ -1139,10 +1232,20 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
     p_records = reinterpret_cast<cs_cuboid*>(db + S.o_rec); p_win_count = reinterpret_cast<int*>(db + S.o_wc); p_fallback = reinterpret_cast<int*>(db + S.o_fb);
     p_job_valid = reinterpret_cast<int*>(db + S.o_jv); p_job_cbase = reinterpret_cast<long long*>(db + S.o_cb);
   } else {
-    PH2D(S.ls_order, S.h_ls_order, nj); PH2D(S.jobs, S.h_jobs_in, nj); PH2D(S.slot_prefix, S.h_slot_prefix, nj + 1); PH2D(S.vp_prefix, S.h_vp_prefix, nj + 1);
-    if (n_yaw) { PH2D(S.yaw, S.h_yaw, n_yaw); PH2D(S.yaw_c, S.h_yaw_c, n_yaw); PH2D(S.yaw_s, S.h_yaw_s, n_yaw); }
-    if (n_top) PH2D(S.top_x, S.h_top_x, n_top);
-    if (nb) { PH2D(S.box_job0, S.h_box_job0, nb); PH2D(S.box_njobs, S.h_box_njobs, nb); }
+    // a batch's tables: one kernel reads all ten out of the pinned staging pools (no copy-engine ring in the sweep: see multi_copy_kernel)
+    cs::CopySegs cp{};
+#define SEG(to_, from_, cnt_) do { if ((cnt_) > 0) { cp.s[cp.n].src = (from_).p; cp.s[cp.n].dst = (to_).p; cp.s[cp.n].bytes = sizeof(*(from_).p) * (unsigned long long)(cnt_); cp.n++; } } while (0)
+    if (g_dma_tables) {
+      PH2D(S.ls_order, S.h_ls_order, nj); PH2D(S.jobs, S.h_jobs_in, nj); PH2D(S.slot_prefix, S.h_slot_prefix, nj + 1); PH2D(S.vp_prefix, S.h_vp_prefix, nj + 1);
+      if (n_yaw) { PH2D(S.yaw, S.h_yaw, n_yaw); PH2D(S.yaw_c, S.h_yaw_c, n_yaw); PH2D(S.yaw_s, S.h_yaw_s, n_yaw); }
+      if (n_top) PH2D(S.top_x, S.h_top_x, n_top);
+      if (nb) { PH2D(S.box_job0, S.h_box_job0, nb); PH2D(S.box_njobs, S.h_box_njobs, nb); }
+    } else {
+      SEG(S.ls_order, S.h_ls_order, nj); SEG(S.jobs, S.h_jobs_in, nj); SEG(S.slot_prefix, S.h_slot_prefix, nj + 1); SEG(S.vp_prefix, S.h_vp_prefix, nj + 1);
+      SEG(S.yaw, S.h_yaw, n_yaw); SEG(S.yaw_c, S.h_yaw_c, n_yaw); SEG(S.yaw_s, S.h_yaw_s, n_yaw); SEG(S.top_x, S.h_top_x, n_top);
+      SEG(S.box_job0, S.h_box_job0, nb); SEG(S.box_njobs, S.h_box_njobs, nb);
+      cs::launch_multi_copy(cp, st);
+    }
   }
   HIP_TRY(hipMemsetAsync(p_job_valid, 0, sizeof(int) * nj, st));
   cs::DetectDeviceView& v = S.view;
@@ -1182,14 +1285,22 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   if (S.merged_io) {
     HIP_TRY(hipMemcpyAsync(S.h_tab_arena.p + S.o_jobs, S.tab_arena.p + S.o_jobs, S.o_end - S.o_jobs, hipMemcpyDeviceToHost, st));   // unpacked in pipe_finish
   } else {
-    if (nb) {
-      HIP_TRY(hipMemcpyAsync(S.h_records.p, S.records.p, sizeof(cs_cuboid) * nb * KMAX, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(S.h_win_count.p, S.win_count.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(S.h_fallback.p, S.fallback.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+    if (g_dma_tables) {
+      if (nb) {
+        HIP_TRY(hipMemcpyAsync(S.h_records.p, S.records.p, sizeof(cs_cuboid) * nb * KMAX, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(S.h_win_count.p, S.win_count.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(S.h_fallback.p, S.fallback.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+      }
+      HIP_TRY(hipMemcpyAsync(S.h_job_valid.p, S.job_valid.p, sizeof(int) * nj, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(S.h_job_cbase.p, S.job_cbase.p, sizeof(long long) * (nj + 1), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(S.h_jobs_out.p, p_jobs, sizeof(cs::JobDesc) * nj, hipMemcpyDeviceToHost, st));
+    } else {   // the results: written to the pinned host pools by one kernel
+      cs::CopySegs cp{};
+      SEG(S.h_records, S.records, nb * KMAX); SEG(S.h_win_count, S.win_count, nb); SEG(S.h_fallback, S.fallback, nb);
+      SEG(S.h_job_valid, S.job_valid, nj); SEG(S.h_job_cbase, S.job_cbase, nj + 1); SEG(S.h_jobs_out, S.jobs, nj);
+      cs::launch_multi_copy(cp, st);
     }
-    HIP_TRY(hipMemcpyAsync(S.h_job_valid.p, S.job_valid.p, sizeof(int) * nj, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(S.h_job_cbase.p, S.job_cbase.p, sizeof(long long) * (nj + 1), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(S.h_jobs_out.p, p_jobs, sizeof(cs::JobDesc) * nj, hipMemcpyDeviceToHost, st));
+#undef SEG
   }
   HIP_TRY(hipEventRecord(S.done, st));
   S.in_flight = true;
@@ -1255,16 +1366,23 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
     PENS(S.fb_dist, tot + 1); PENS(S.fb_angle, tot + 1); PENS(S.fb_skew, tot + 1); PENS(S.fb_flag, tot + 1); PENS(S.fb_slot, tot + 1);
     PENS(S.h_fb_dist, tot + 1); PENS(S.h_fb_angle, tot + 1); PENS(S.h_fb_skew, tot + 1); PENS(S.h_fb_flag, tot + 1); PENS(S.h_fb_slot, tot + 1);
     std::copy(fb_src.begin(), fb_src.end(), S.h_fb_src.p); std::copy(fb_dst.begin(), fb_dst.end(), S.h_fb_dst.p); std::copy(fb_cnt.begin(), fb_cnt.end(), S.h_fb_cnt.p);
-    HIP_TRY(hipMemcpyAsync(S.fb_src.p, S.h_fb_src.p, 8 * nr, hipMemcpyHostToDevice, st2));
-    HIP_TRY(hipMemcpyAsync(S.fb_dst.p, S.h_fb_dst.p, 8 * nr, hipMemcpyHostToDevice, st2));
-    HIP_TRY(hipMemcpyAsync(S.fb_cnt.p, S.h_fb_cnt.p, 4 * nr, hipMemcpyHostToDevice, st2));
-    cs::launch_gather_ranges(S.view, S.fb_src.p, S.fb_cnt.p, S.fb_dst.p, (int)nr, S.fb_dist.p, S.fb_angle.p, S.fb_skew.p, S.fb_flag.p, S.fb_slot.p, st2);
-    if (tot) {
-      HIP_TRY(hipMemcpyAsync(S.h_fb_dist.p, S.fb_dist.p, 8 * (size_t)tot, hipMemcpyDeviceToHost, st2));
-      HIP_TRY(hipMemcpyAsync(S.h_fb_angle.p, S.fb_angle.p, 8 * (size_t)tot, hipMemcpyDeviceToHost, st2));
-      HIP_TRY(hipMemcpyAsync(S.h_fb_skew.p, S.fb_skew.p, 8 * (size_t)tot, hipMemcpyDeviceToHost, st2));
-      HIP_TRY(hipMemcpyAsync(S.h_fb_flag.p, S.fb_flag.p, 4 * (size_t)tot, hipMemcpyDeviceToHost, st2));
-      HIP_TRY(hipMemcpyAsync(S.h_fb_slot.p, S.fb_slot.p, 8 * (size_t)tot, hipMemcpyDeviceToHost, st2));
+    if (g_dma_tables) {
+      HIP_TRY(hipMemcpyAsync(S.fb_src.p, S.h_fb_src.p, 8 * nr, hipMemcpyHostToDevice, st2));
+      HIP_TRY(hipMemcpyAsync(S.fb_dst.p, S.h_fb_dst.p, 8 * nr, hipMemcpyHostToDevice, st2));
+      HIP_TRY(hipMemcpyAsync(S.fb_cnt.p, S.h_fb_cnt.p, 4 * nr, hipMemcpyHostToDevice, st2));
+      cs::launch_gather_ranges(S.view, S.fb_src.p, S.fb_cnt.p, S.fb_dst.p, (int)nr, S.fb_dist.p, S.fb_angle.p, S.fb_skew.p, S.fb_flag.p, S.fb_slot.p, st2);
+      if (tot) {
+        HIP_TRY(hipMemcpyAsync(S.h_fb_dist.p, S.fb_dist.p, 8 * (size_t)tot, hipMemcpyDeviceToHost, st2));
+        HIP_TRY(hipMemcpyAsync(S.h_fb_angle.p, S.fb_angle.p, 8 * (size_t)tot, hipMemcpyDeviceToHost, st2));
+        HIP_TRY(hipMemcpyAsync(S.h_fb_skew.p, S.fb_skew.p, 8 * (size_t)tot, hipMemcpyDeviceToHost, st2));
+        HIP_TRY(hipMemcpyAsync(S.h_fb_flag.p, S.fb_flag.p, 4 * (size_t)tot, hipMemcpyDeviceToHost, st2));
+        HIP_TRY(hipMemcpyAsync(S.h_fb_slot.p, S.fb_slot.p, 8 * (size_t)tot, hipMemcpyDeviceToHost, st2));
+      }
+    } else {
+      // the range lists are read from, and the columns written to, the pinned host pools by the gather kernel itself (coalesced rows; no
+      // copy engine between the device and a host that is waiting for a few kilobytes)
+      cs::launch_gather_ranges(S.view, S.h_fb_src.p, S.h_fb_cnt.p, S.h_fb_dst.p, (int)nr, S.h_fb_dist.p, S.h_fb_angle.p, S.h_fb_skew.p, S.h_fb_flag.p, S.h_fb_slot.p, st2);
+      HIP_TRY(hipGetLastError());
     }
   }
   MARK(5, tq);   // tie lists + gather enqueue
@@ -1372,9 +1490,13 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
     if (!ws.empty()) {
       PENS(S.win_slots, ws.size()); PENS(S.win_corners, 16 * ws.size()); PENS(S.h_win_slots, ws.size()); PENS(S.h_win_corners, 16 * ws.size());
       std::copy(ws.begin(), ws.end(), S.h_win_slots.p);
-      HIP_TRY(hipMemcpyAsync(S.win_slots.p, S.h_win_slots.p, 8 * ws.size(), hipMemcpyHostToDevice, st2));
-      cs::launch_gather_corners(S.view, C.sp, S.win_slots.p, (int)ws.size(), S.win_corners.p, st2);
-      HIP_TRY(hipMemcpyAsync(S.h_win_corners.p, S.win_corners.p, 8 * 16 * ws.size(), hipMemcpyDeviceToHost, st2));
+      if (g_dma_tables) {
+        HIP_TRY(hipMemcpyAsync(S.win_slots.p, S.h_win_slots.p, 8 * ws.size(), hipMemcpyHostToDevice, st2));
+        cs::launch_gather_corners(S.view, C.sp, S.win_slots.p, (int)ws.size(), S.win_corners.p, st2);
+        HIP_TRY(hipMemcpyAsync(S.h_win_corners.p, S.win_corners.p, 8 * 16 * ws.size(), hipMemcpyDeviceToHost, st2));
+      } else {
+        cs::launch_gather_corners(S.view, C.sp, S.h_win_slots.p, (int)ws.size(), S.h_win_corners.p, st2);     // (pinned host memory on both sides)
+      }
       HIP_TRY(hipStreamSynchronize(st2));
       const double* hc = S.h_win_corners.p;
       size_t z = 0;
@@ -1530,11 +1652,21 @@ int rp_launch(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>>&
   HIP_TRY(hipMemsetAsync(S.rp_pool_used.p, 0, sizeof(unsigned long long), st));
   PENS(S.rp_cur_idx, (size_t)NF + 1); PENS(S.rp_tab_count, (size_t)NF * NT + 1); PENS(S.rp_maps, 3 * (size_t)MB * NF + 1); PENS(S.rp_raw_euler, 3 * (size_t)NF + 1);
 #define PH2D(dst, src, n) HIP_TRY(hipMemcpyAsync((dst).p, (src).p, sizeof(*(src).p) * (n), hipMemcpyHostToDevice, st))
-  PH2D(S.ls_order, S.h_ls_order, nj); PH2D(S.jobs, S.h_jobs_in, nj); PH2D(S.slot_prefix, S.h_slot_prefix, nj + MB); PH2D(S.vp_prefix, S.h_vp_prefix, nj + MB);
-  PH2D(S.yaw, S.h_yaw, n_yaw); PH2D(S.yaw_c, S.h_yaw_c, n_yaw); PH2D(S.yaw_s, S.h_yaw_s, n_yaw);
-  if (n_top) PH2D(S.top_x, S.h_top_x, n_top);
-  PH2D(S.box_job0, S.h_box_job0, nb); PH2D(S.box_njobs, S.h_box_njobs, nb);
-  PH2D(S.rp_tab_count, S.h_rp_tab_count, (size_t)NF * NT); PH2D(S.rp_maps, S.h_rp_maps, 3 * (size_t)MB * NF); PH2D(S.rp_raw_euler, S.h_rp_raw_euler, 3 * (size_t)NF);
+#define SEG(to_, from_, cnt_) do { if ((cnt_) > 0) { cp.s[cp.n].src = (from_).p; cp.s[cp.n].dst = (to_).p; cp.s[cp.n].bytes = sizeof(*(from_).p) * (unsigned long long)(cnt_); cp.n++; } } while (0)
+  if (g_dma_tables) {
+    PH2D(S.ls_order, S.h_ls_order, nj); PH2D(S.jobs, S.h_jobs_in, nj); PH2D(S.slot_prefix, S.h_slot_prefix, nj + MB); PH2D(S.vp_prefix, S.h_vp_prefix, nj + MB);
+    PH2D(S.yaw, S.h_yaw, n_yaw); PH2D(S.yaw_c, S.h_yaw_c, n_yaw); PH2D(S.yaw_s, S.h_yaw_s, n_yaw);
+    if (n_top) PH2D(S.top_x, S.h_top_x, n_top);
+    PH2D(S.box_job0, S.h_box_job0, nb); PH2D(S.box_njobs, S.h_box_njobs, nb);
+    PH2D(S.rp_tab_count, S.h_rp_tab_count, (size_t)NF * NT); PH2D(S.rp_maps, S.h_rp_maps, 3 * (size_t)MB * NF); PH2D(S.rp_raw_euler, S.h_rp_raw_euler, 3 * (size_t)NF);
+  } else {     // (one kernel reads all thirteen tables out of the pinned pools: multi_copy_kernel)
+    cs::CopySegs cp{};
+    SEG(S.ls_order, S.h_ls_order, nj); SEG(S.jobs, S.h_jobs_in, nj); SEG(S.slot_prefix, S.h_slot_prefix, nj + MB); SEG(S.vp_prefix, S.h_vp_prefix, nj + MB);
+    SEG(S.yaw, S.h_yaw, n_yaw); SEG(S.yaw_c, S.h_yaw_c, n_yaw); SEG(S.yaw_s, S.h_yaw_s, n_yaw); SEG(S.top_x, S.h_top_x, n_top);
+    SEG(S.box_job0, S.h_box_job0, nb); SEG(S.box_njobs, S.h_box_njobs, nb);
+    SEG(S.rp_tab_count, S.h_rp_tab_count, (size_t)NF * NT); SEG(S.rp_maps, S.h_rp_maps, 3 * (size_t)MB * NF); SEG(S.rp_raw_euler, S.h_rp_raw_euler, 3 * (size_t)NF);
+    cs::launch_multi_copy(cp, st);
+  }
   HIP_TRY(hipMemsetAsync(S.job_valid.p, 0, sizeof(int) * nj, st));
   HIP_TRY(hipMemsetAsync(S.rp_cur_idx.p, 0, sizeof(int) * NF, st));
   HIP_TRY(hipEventRecord(S.ev[0], st));
@@ -1590,15 +1722,24 @@ int rp_launch(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>>&
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(S.ev[6], st));
-  HIP_TRY(hipMemcpyAsync(S.h_records.p, S.records.p, sizeof(cs_cuboid) * nb * KMAX, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(S.h_win_count.p, S.win_count.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(S.h_fallback.p, S.fallback.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(S.h_job_cbase.p, S.job_cbase.p, sizeof(long long) * (nj + MB), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(S.h_job_valid.p, S.job_valid.p, sizeof(int) * nj, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(S.h_jobs_out.p, S.jobs.p, sizeof(cs::JobDesc) * nj, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(S.h_rp_last_slot.p, S.rp_last_slot.p, sizeof(long long) * nb, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(S.h_rp_box_base.p, S.rp_box_base.p, sizeof(long long) * nb, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(S.h_rp_pool_used.p, S.rp_pool_used.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  if (g_dma_tables) {
+    HIP_TRY(hipMemcpyAsync(S.h_records.p, S.records.p, sizeof(cs_cuboid) * nb * KMAX, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(S.h_win_count.p, S.win_count.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(S.h_fallback.p, S.fallback.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(S.h_job_cbase.p, S.job_cbase.p, sizeof(long long) * (nj + MB), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(S.h_job_valid.p, S.job_valid.p, sizeof(int) * nj, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(S.h_jobs_out.p, S.jobs.p, sizeof(cs::JobDesc) * nj, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(S.h_rp_last_slot.p, S.rp_last_slot.p, sizeof(long long) * nb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(S.h_rp_box_base.p, S.rp_box_base.p, sizeof(long long) * nb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(S.h_rp_pool_used.p, S.rp_pool_used.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  } else {
+    cs::CopySegs cp{};
+    SEG(S.h_records, S.records, nb * KMAX); SEG(S.h_win_count, S.win_count, nb); SEG(S.h_fallback, S.fallback, nb); SEG(S.h_job_cbase, S.job_cbase, nj + MB);
+    SEG(S.h_job_valid, S.job_valid, nj); SEG(S.h_jobs_out, S.jobs, nj); SEG(S.h_rp_last_slot, S.rp_last_slot, nb); SEG(S.h_rp_box_base, S.rp_box_base, nb);
+    SEG(S.h_rp_pool_used, S.rp_pool_used, 1);
+    cs::launch_multi_copy(cp, st);
+  }
+#undef SEG
   HIP_TRY(hipEventRecord(S.done, st));
   S.in_flight = true;
   return CS_OK;
@@ -1645,7 +1786,16 @@ int rp_finish(PipeCtx& C, PipeSlot& S) {
 #define PENS(buf, n) do { rc = (buf).ensure(n); if (rc) return rc; } while (0)
     PENS(S.h_fb_dist, used + 1); PENS(S.h_fb_angle, used + 1); PENS(S.h_fb_skew, used + 1); PENS(S.h_fb_flag, used + 1); PENS(S.h_fb_slot, used + 1);
 #undef PENS
-    if (used) {
+    if (used && !g_dma_tables) {
+      cs::CopySegs cp{};
+      const void* srcs[5] = {S.fb_dist.p, S.fb_angle.p, S.fb_skew.p, S.fb_flag.p, S.fb_slot.p};
+      void* dsts[5] = {S.h_fb_dist.p, S.h_fb_angle.p, S.h_fb_skew.p, S.h_fb_flag.p, S.h_fb_slot.p};
+      const unsigned long long widths[5] = {8, 8, 8, 4, 8};
+      for (int z = 0; z < 5; z++) { cp.s[z].src = srcs[z]; cp.s[z].dst = dsts[z]; cp.s[z].bytes = widths[z] * used; }
+      cp.n = 5;
+      cs::launch_multi_copy(cp, st2);
+      HIP_TRY(hipStreamSynchronize(st2));
+    } else if (used) {
       HIP_TRY(hipMemcpyAsync(S.h_fb_dist.p, S.fb_dist.p, 8 * used, hipMemcpyDeviceToHost, st2));
       HIP_TRY(hipMemcpyAsync(S.h_fb_angle.p, S.fb_angle.p, 8 * used, hipMemcpyDeviceToHost, st2));
       HIP_TRY(hipMemcpyAsync(S.h_fb_skew.p, S.fb_skew.p, 8 * used, hipMemcpyDeviceToHost, st2));
@@ -1843,6 +1993,7 @@ static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_
   if (!d || !b || b->det != d || !out || !out_counts) return CS_ERR_INVALID_ARG;
   if (b->run_state) { set_err("cs_batch_submit: the previous submit of this batch has not been collected"); return CS_ERR_INVALID_ARG; }
   HIP_TRY(hipSetDevice(d->device));
+  { const int rcf = batch_flush_refill(d, b); if (rcf) return rcf; }      // (cs_batch_refill_gray: the new images' maps, in front of this sweep)
   std::unique_ptr<BatchRunState> rs_owner(new BatchRunState());
   BatchRunState* rs = rs_owner.get();
   const cs_detect_params& P = d->prm;

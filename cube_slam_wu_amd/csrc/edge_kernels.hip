@@ -560,6 +560,28 @@ __global__ __launch_bounds__(64) void edge_dt_kernel(const EdgeRoi* __restrict__
   }
 }
 
+// A handful of tables between PINNED host memory and device memory in ONE launch (either direction; the host side is addressed through the
+// unified address space).  Why not one hipMemcpyAsync each: ten small copies are ten trips through a copy-engine ring (~0.3 ms of latency in
+// front of a sweep, ~0.15 ms behind it), and a ring that holds a bulk upload (cs_batch_refill_gray) makes every one of them wait for it.
+struct CopySeg { const void* src; void* dst; unsigned long long bytes; };
+struct CopySegs { CopySeg s[16]; int n; };
+__global__ __launch_bounds__(256) void multi_copy_kernel(CopySegs segs) {
+  const CopySeg sg = segs.s[blockIdx.y];
+  const size_t n16 = ((reinterpret_cast<uintptr_t>(sg.src) | reinterpret_cast<uintptr_t>(sg.dst)) & 15) ? 0 : sg.bytes / 16;
+  const uint4* s16 = static_cast<const uint4*>(sg.src);
+  uint4* d16 = static_cast<uint4*>(sg.dst);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) d16[i] = s16[i];
+  const unsigned char* sb = static_cast<const unsigned char*>(sg.src);
+  unsigned char* db = static_cast<unsigned char*>(sg.dst);
+  for (size_t i = 16 * n16 + (size_t)blockIdx.x * 256 + threadIdx.x; i < sg.bytes; i += (size_t)gridDim.x * 256) db[i] = sb[i];
+}
+void launch_multi_copy(const CopySegs& segs, hipStream_t st) {
+  if (segs.n <= 0) return;
+  unsigned long long mx = 0;
+  for (int i = 0; i < segs.n; i++) mx = segs.s[i].bytes > mx ? segs.s[i].bytes : mx;
+  const int bx = (int)std::min<unsigned long long>(32, std::max<unsigned long long>(1, mx / (16 * 256 * 4)));
+  hipLaunchKernelGGL(multi_copy_kernel, dim3(bx, segs.n), dim3(256), 0, st, segs);
+}
 void launch_edge_maps(const unsigned char* gray, int W, int H, const EdgeRoi* rois, int n_rois, unsigned char* cls_pool, float* map_pool, int max_w, long long max_px, int low, int high,
                       hipStream_t st) {   // max_px: the largest framed size of an ROI, 4 ceil((w + 2) / 4) (h + 2)
   if (n_rois <= 0) return;

@@ -145,6 +145,15 @@ int cs_edge_distance_maps_multi(cs_detector* d, const unsigned char* const* gray
 /* cs_batch_create() for image input: grays[f] is frame f's 8-bit gray image (img_h x img_w, all frames one size); the
  * frames' dist_maps are ignored and every (box, height sample) map is produced in HBM by the kernels above.          */
 int cs_batch_create_gray(cs_detector* d, const cs_frame_desc* frames, const unsigned char* const* grays, int n_frames, cs_batch** out);
+/* New images for the same frame descriptions (the caller of detect_cuboid hands over an image per call, box_proposal_detail.cpp:84,320-327;
+ * a batch of a fixed rig keeps its boxes' layout): grays[f] as above.  Asynchronous: the upload runs on a copy stream of the batch into its
+ * second image buffer -- beside a front end / sweep that is still running --, images that are contiguous in host memory go up as ONE copy
+ * (pinned host memory gives the copy engine its full rate); the next cs_batch_submit / cs_batch_run waits for the OLDEST queued upload and
+ * queues the front end over it in front of its sweep.  Up to two uploads may be queued (one per image buffer; a third returns
+ * CS_ERR_INVALID_ARG): queueing the upload after next before each submit keeps the copy engine busy without a gap.  The host images must
+ * stay valid until cs_batch_refill_wait() returns (it waits for every queued upload).  */
+int cs_batch_refill_gray(cs_detector* d, cs_batch* batch, const unsigned char* const* grays);
+int cs_batch_refill_wait(cs_batch* batch);
 /* cs_detect_cuboids() with the frame's dist_maps computed here from the gray image (frame->dist_maps is ignored). */
 int cs_detect_cuboids_gray(cs_detector* d, const cs_frame_desc* frame, const unsigned char* gray, cs_cuboid* out, int* out_counts);
 

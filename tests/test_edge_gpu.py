@@ -182,6 +182,52 @@ def test_batch_from_gray_images_equals_batch_from_host_maps():
     a.close(); b.close(); det.close()
 
 
+def test_refilled_gray_batch_equals_a_fresh_one():
+    """cs_batch_refill_gray (round 6: image in with the upload beside the running sweep -- new images for the same frame descriptions, second
+    image buffer, copy stream, the front end queued behind the sweep): after every refill the batch's records are byte-identical to those of
+    a fresh cs_batch_create_gray batch over the same images -- three refills in a row (both buffers reused), one of them queued while the
+    previous sweep is still in flight (submit, refill, collect), one from a single contiguous block of host memory."""
+    sets = [[_scene(40 + 3 * k + s) for s in range(3)] for k in range(3)]
+    frames = [synth.make_frame(9300 + s, n_boxes=1 + s % 4, n_lines=200) for s in range(6)]
+    det = capi.Detector(capi.default_params(whether_sample_cam_roll_pitch=0, yaw_step_deg=3.0, max_cuboid_num=2))
+    want = []
+    for k in range(3):
+        f = capi.Batch(det, frames, grays=[sets[k][s % 3] for s in range(6)]); f.run()
+        want.append((f.raw_out_bytes(), f.counts_bytes())); f.close()
+    assert want[0] != want[1] and want[1] != want[2]
+    b = capi.Batch(det, frames, grays=[sets[0][s % 3] for s in range(6)]); b.run()
+    assert (b.raw_out_bytes(), b.counts_bytes()) == want[0]
+    b.refill_gray([sets[1][s % 3] for s in range(6)]); b.run()
+    assert (b.raw_out_bytes(), b.counts_bytes()) == want[1]
+    # the next images go up while the sweep over the current ones is in flight; its records are the CURRENT images'
+    b.submit()
+    b.refill_gray([sets[2][s % 3] for s in range(6)])
+    b.collect()
+    assert (b.raw_out_bytes(), b.counts_bytes()) == want[1]
+    b.refill_wait(); b.run()
+    assert (b.raw_out_bytes(), b.counts_bytes()) == want[2]
+    # one contiguous block (a single copy)
+    block = np.ascontiguousarray(np.stack([sets[0][s % 3] for s in range(6)]))
+    b.refill_gray(base_ptr=block.ctypes.data); b.run()
+    assert (b.raw_out_bytes(), b.counts_bytes()) == want[0]
+    # two uploads queued (one per image buffer): the runs take them oldest first; a third is refused
+    b.refill_gray([sets[1][s % 3] for s in range(6)])
+    b.refill_gray([sets[2][s % 3] for s in range(6)])
+    with pytest.raises(RuntimeError):
+        b.refill_gray([sets[0][s % 3] for s in range(6)])
+    b.run()
+    assert (b.raw_out_bytes(), b.counts_bytes()) == want[1]
+    # ... and the loop bench.py's image_in entry runs: the upload after next queued before each submit
+    order = [2, 0, 1, 2]
+    for k, nx in enumerate(order):
+        b.refill_gray([sets[nx][s % 3] for s in range(6)])
+        b.submit(); b.collect()
+        assert (b.raw_out_bytes(), b.counts_bytes()) == want[([2] + order)[k]]
+    b.refill_wait(); b.run()
+    assert (b.raw_out_bytes(), b.counts_bytes()) == want[order[-1]]
+    b.close(); det.close()
+
+
 def test_reference_tum_frames_image_in_on_the_device_equal_the_oracle():
     """The reference's 51 bundled TUM frames with a 2D box (tests/tum_frames.py; tests/test_reference_frames.py compares the
     oracle's cuboids with the detections the reference saved for them): cs_bgr_to_gray + cs_detect_cuboids_gray, image in /
