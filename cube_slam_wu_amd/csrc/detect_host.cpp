@@ -45,6 +45,7 @@ void launch_vp_support_only(const DetectDeviceView& v, const SweepParams& sp, in
 void launch_vp_points(const DetectDeviceView& v, int vp_total, hipStream_t st);
 int vp3_table_doubles_per_job();
 void launch_candidates(const DetectDeviceView& v, const SweepParams& sp, long long slot_total, hipStream_t st);
+void launch_candidate_compact(const DetectDeviceView& v, const SweepParams& sp, hipStream_t st);
 void launch_scan_compact(const DetectDeviceView& v, hipStream_t st);
 void launch_scan_compact_trips(const DetectDeviceView& v, int* cnt, int max_trips, hipStream_t st);
 void launch_score(const DetectDeviceView& v, const SweepParams& sp, long long n_valid_bound, long long slot_total, hipStream_t st);
@@ -441,7 +442,7 @@ struct PipeSlot {
   DevBuf<long long> slot_prefix, job_cbase, c_slot, fb_src, fb_dst, fb_slot, win_slots;
   DevBuf<int> vp_prefix, top_x, flag, job_valid, c_flag, box_job0, box_njobs, win_count, fallback, fb_cnt, fb_flag;
   DevBuf<double> bound3;
-  DevBuf<int> ls_order;
+  DevBuf<int> ls_order, blk_info;
   PinBuf<int> h_ls_order;
   DevBuf<double> mid_x, mid_y, ang, yaw, yaw_c, yaw_s, vp, bound, corners, c_dist, c_angle, c_skew, fb_dist, fb_angle, fb_skew, win_corners;
   DevBuf<cs::RankWinner> winners;
@@ -482,7 +483,7 @@ struct PipeSlot {
     jobs.release(); slot_prefix.release(); job_cbase.release(); c_slot.release(); fb_src.release(); fb_dst.release(); fb_slot.release(); win_slots.release();
     vp_prefix.release(); top_x.release(); flag.release(); job_valid.release(); c_flag.release(); box_job0.release(); box_njobs.release(); win_count.release();
     fallback.release(); fb_cnt.release(); fb_flag.release(); mid_x.release(); mid_y.release(); ang.release(); yaw.release(); yaw_c.release(); yaw_s.release();
-    vp.release(); bound.release(); bound3.release(); ls_order.release(); h_ls_order.release(); corners.release(); c_dist.release(); c_angle.release(); c_skew.release(); fb_dist.release(); fb_angle.release(); fb_skew.release();
+    vp.release(); bound.release(); bound3.release(); ls_order.release(); blk_info.release(); h_ls_order.release(); corners.release(); c_dist.release(); c_angle.release(); c_skew.release(); fb_dist.release(); fb_angle.release(); fb_skew.release();
     win_corners.release(); winners.release(); records.release(); h_records.release(); rp_trip_cnt.release(); rp_cur_idx.release(); rp_tab_count.release(); rp_maps.release(); rp_last_slot.release(); rp_box_base.release(); rp_pool_used.release(); rp_raw_euler.release(); h_rp_tab_count.release(); h_rp_maps.release(); h_rp_raw_euler.release(); h_rp_last_slot.release(); h_rp_box_base.release(); h_rp_pool_used.release(); h_jobs_in.release(); h_jobs_out.release(); h_slot_prefix.release(); h_job_cbase.release(); h_vp_prefix.release();
     h_top_x.release(); h_box_job0.release(); h_box_njobs.release(); h_win_count.release(); h_fallback.release(); h_job_valid.release(); h_yaw.release();
     h_yaw_c.release(); h_yaw_s.release(); h_winners.release();
@@ -1088,6 +1089,7 @@ namespace {
 static double g_mark[16];
 static int g_runs = 0;
 static const bool g_prof = getenv("CS_DETECT_PROF") != nullptr;   // diagnostics: host phase clock of the lean path
+static const bool g_split_candidates = getenv("CS_DETECT_SPLIT_CANDIDATES") != nullptr;   // vp_points + candidate + scan + compact as separate kernels (the form before round 6) instead of candidate_compact_kernel
 static const bool g_dma_tables = getenv("CS_DETECT_DMA_TABLES") != nullptr;   // a batch's tables / results through hipMemcpyAsync (the form before round 6) instead of multi_copy_kernel
 #define MARK(k, t_ref) do { if (g_prof) { double t_now = now_ms(); g_mark[k] += t_now - (t_ref); (t_ref) = t_now; } } while (0)
 
@@ -1162,13 +1164,18 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   MARK(0, tq);   // per-frame jobs + sample lists
   // ---- slot / vanishing-point prefixes and the box table: one serial pass over the jobs
   size_t nb = 0;
+  long long real_slots = 0;      // proposals (the slot space itself is padded per job)
   {
     long long so = 0, vo = 0;
+    real_slots = 0;
     for (size_t j = 0; j < nj; j++) {
       cs::JobDesc& jd = S.h_jobs_in.p[j];
       jd.slot_off = so; jd.vp_off = (int)vo;
       S.h_slot_prefix.p[j] = so; S.h_vp_prefix.p[j] = (int)vo;
-      so += (long long)jd.Y * jd.T * 2; vo += (jd.Y + 63) & ~63;   // whole waves per job: a wave of the VP kernels then reads one job (scalar loads)
+      // (a job's slots in multiples of 256: its compacted rows start there -- candidate_compact_kernel's capacity layout -- and a scorer
+      // workgroup never straddles two jobs)
+      real_slots += (long long)jd.Y * jd.T * 2;
+      so += ((long long)jd.Y * jd.T * 2 + 255) & ~255LL; vo += (jd.Y + 63) & ~63;   // whole waves per job: a wave of the VP kernels then reads one job (scalar loads)
       if (jd.hid == 0 && jd.Y > 0 && jd.T > 0) { S.h_box_job0.p[nb] = (int)j; S.h_box_njobs.p[nb] = b->frames[jd.frame].n_heights[jd.box]; nb++; }
     }
     S.h_slot_prefix.p[nj] = so; S.h_vp_prefix.p[nj] = (int)vo;
@@ -1191,12 +1198,13 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   MARK(1, tq);   // prefixes + box table
   MARK(2, tq);   // box table
   C.tm->setup_host_ms += now_ms() - t0;
-  C.tm->n_jobs += (long long)nj; C.tm->n_slots += S.slot_total;
+  C.tm->n_jobs += (long long)nj; C.tm->n_slots += real_slots;
   // ---- device buffers, H2D, kernels, D2H: all asynchronous on the detector's stream
   const long long slot_total = S.slot_total;
   PENS(S.ls_order, nj); PENS(S.jobs, nj); PENS(S.slot_prefix, nj + 1); PENS(S.vp_prefix, nj + 1); PENS(S.job_valid, nj); PENS(S.job_cbase, nj + 1);
   PENS(S.mid_x, n_lines + 1); PENS(S.mid_y, n_lines + 1); PENS(S.ang, n_lines + 1); PENS(S.yaw, n_yaw + 1); PENS(S.yaw_c, n_yaw + 1); PENS(S.yaw_s, n_yaw + 1);
-  PENS(S.top_x, n_top + 1); PENS(S.vp, 6 * (size_t)S.vp_total + 6); PENS(S.bound, 6 * (size_t)S.vp_total + 6); PENS(S.bound3, nj * (size_t)cs::vp3_table_doubles_per_job()); PENS(S.flag, slot_total + 1);
+  PENS(S.top_x, n_top + 1); PENS(S.vp, 6 * (size_t)S.vp_total + 6); PENS(S.bound, 6 * (size_t)S.vp_total + 6); PENS(S.bound3, nj * (size_t)cs::vp3_table_doubles_per_job());
+  if (g_split_candidates) PENS(S.flag, slot_total + 1); else PENS(S.blk_info, 2 * (size_t)(slot_total >> 8) + 4);
   PENS(S.c_slot, slot_total + 1); PENS(S.c_flag, slot_total + 1); PENS(S.c_dist, slot_total + 1);
   PENS(S.c_angle, slot_total + 1); PENS(S.c_skew, slot_total + 1); PENS(S.box_job0, nb + 1); PENS(S.box_njobs, nb + 1); PENS(S.win_count, nb + 1);
   PENS(S.fallback, nb + 1); PENS(S.winners, nb * KMAX + 1); PENS(S.records, nb * KMAX + 1); PENS(S.h_records, nb * KMAX + 1);
@@ -1247,7 +1255,7 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
       cs::launch_multi_copy(cp, st);
     }
   }
-  HIP_TRY(hipMemsetAsync(p_job_valid, 0, sizeof(int) * nj, st));
+  if (g_split_candidates) HIP_TRY(hipMemsetAsync(p_job_valid, 0, sizeof(int) * nj, st));      // (candidate_kernel counts with atomics; the fused kernel writes every job's count)
   cs::DetectDeviceView& v = S.view;
   v = cs::DetectDeviceView{};
   v.jobs = p_jobs; v.n_jobs = (int)nj; v.slot_prefix = p_slot_prefix; v.vp_prefix = p_vp_prefix; v.maps = b->d_maps.p;
@@ -1260,10 +1268,19 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   HIP_TRY(hipEventRecord(S.ev[7], st));                      // inputs resident, job_valid zeroed
   HIP_TRY(hipStreamWaitEvent(stB, S.ev[7], 0));
   HIP_TRY(hipEventRecord(S.ev[8], stB));
-  cs::launch_vp_points(v, S.vp_total, stB);
-  cs::launch_candidates(v, C.sp, slot_total, stB);
-  HIP_TRY(hipEventRecord(S.ev[9], stB));
-  cs::launch_scan_compact(v, stB);
+  if (g_split_candidates) {
+    cs::launch_vp_points(v, S.vp_total, stB);
+    cs::launch_candidates(v, C.sp, slot_total, stB);
+    HIP_TRY(hipEventRecord(S.ev[9], stB));
+    cs::launch_scan_compact(v, stB);
+  } else {
+    // vanishing points, corner construction and ordered compaction of a job in one workgroup (candidate_compact_kernel); the compacted rows
+    // of job j start at slot_prefix[j]: no scan over all jobs between this kernel and the scorer
+    v.blk_info = S.blk_info.p;
+    HIP_TRY(hipMemsetAsync(S.blk_info.p, 0, sizeof(int), stB));
+    cs::launch_candidate_compact(v, C.sp, stB);
+    HIP_TRY(hipEventRecord(S.ev[9], stB));
+  }
   HIP_TRY(hipEventRecord(S.ev[10], stB));
   HIP_TRY(hipEventRecord(S.ev[0], st));
   cs::launch_line_setup(p_jobs, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st, p_ls_order,
@@ -1335,7 +1352,8 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
     HIP_TRY(hipEventElapsedTime(&ms, S.ev[4], S.ev[5])); tm.score_kernel_ms += ms;
     HIP_TRY(hipEventElapsedTime(&ms, S.ev[5], S.ev[6])); tm.rank_kernel_ms += ms;
     tm.cand_kernel_launches += 1;
-    const long long n_valid = S.h_job_cbase.p[nj];
+    long long n_valid = 0;      // (the capacity layout has no running total: job_cbase[j] = slot_prefix[j])
+    for (size_t j = 0; j < nj; j++) n_valid += S.h_job_valid.p[j];
     tm.n_valid += n_valid;
     tm.cand_kernel_bytes += 48LL * S.vp_total + 4LL * S.slot_total;
     long long sbytes = 96LL * S.vp_total + (28LL + 8LL + 4LL) * n_valid;

@@ -419,6 +419,108 @@ __global__ __launch_bounds__(256) void candidate_kernel(DetectDeviceView v, Swee
   }
 }
 
+// Round 6: vanishing points + corner construction + ordered compaction of ONE job per workgroup (the lean path; replaces vp_points_kernel,
+// candidate_kernel, scan_jobs_kernel and compact_kernel there).  The job record is uniform (scalar registers), the decisions of a trip of
+// 4096 slots stay in LDS (a byte each) instead of going through a 4-byte flag per slot in memory, the valid count needs no atomics, and --
+// with the compacted rows of job j starting at slot_prefix[j] (capacity layout, DetectDeviceView::blk_info) -- nothing waits for a scan over
+// all jobs.  Lane -> proposal as in candidate_kernel: a wave runs one configuration (eight passes of 256 top-edge/yaw samples per
+// configuration and trip); the compaction then walks the trip in slot order (configuration fastest: the reference's row order, :677-702).
+enum { COMPACT_PER = 16 };     // groups of 64 slots a wave owns per compaction trip (compact_kernel below, candidate_compact_kernel)
+enum { CC_TRIP = 4096 };
+__global__ __launch_bounds__(256) void candidate_compact_kernel(DetectDeviceView v, SweepParams sp) {
+  const int j = blockIdx.x;
+  if (j >= v.n_jobs) return;
+  __shared__ unsigned char s_flag[CC_TRIP];
+  __shared__ int wsum[4];
+  const JobDesc& jd = v.jobs[j];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // ---- getVanishingPoints (object_3d_util.cpp:928-937) of the job's (roll/pitch, yaw) samples: vp_points_kernel's arithmetic
+  const int n_vp = jd.RP * jd.Y;
+  for (int e = tid; e < n_vp; e += 256) {
+    const int rp = e / jd.Y, y = e - rp * jd.Y;
+    const RpPose* pose = v.rp + jd.rp_off + rp;
+    const double cy = v.yaw_cos[jd.yaw_off + y], sy = v.yaw_sin[jd.yaw_off + y];
+    const double* A = pose->KinvR;
+    const double d[3][3] = {{cy, sy, 0.0}, {-sy, cy, 0.0}, {0.0, 0.0, 1.0}};
+    double* vout = v.vp + 6 * (long long)(jd.vp_off + e);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const double h0 = (A[0] * d[k][0] + A[1] * d[k][1]) + A[2] * d[k][2];
+      const double h1 = (A[3] * d[k][0] + A[4] * d[k][1]) + A[5] * d[k][2];
+      const double h2 = (A[6] * d[k][0] + A[7] * d[k][1]) + A[8] * d[k][2];
+      vout[2 * k] = h0 / h2;
+      vout[2 * k + 1] = h1 / h2;
+    }
+  }
+  __syncthreads();        // (one workgroup, one CU: the rows written above are read back below)
+  const unsigned half = (unsigned)n_vp * (unsigned)jd.T;            // proposals per configuration
+  const long long base = v.slot_prefix[j];
+  long long run = base;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const bool en1 = sp.consider_config_1 != 0, en2 = sp.consider_config_2 != 0;
+  for (unsigned r0 = 0; r0 < half; r0 += CC_TRIP / 2) {
+    // ---- decisions of the trip's proposals
+#pragma unroll 1
+    for (int q = 0; q < 16; q++) {
+      const int cfg = 1 + (q >> 3);
+      const unsigned rl = (unsigned)(q & 7) * 256u + (unsigned)tid, rest = r0 + rl;
+      int flag = 0;
+      if (rest < half && (cfg == 1 ? en1 : en2)) {
+        const unsigned ryu = rest / (unsigned)jd.T;
+        const int t = (int)(rest - ryu * (unsigned)jd.T);
+        const double* vp = v.vp + 6 * (long long)(jd.vp_off + (int)ryu);
+        V2 c[8];
+        flag = build_corners(jd.g, v2(vp[0], vp[1]), v2(vp[2], vp[3]), v2(vp[4], vp[5]), (double)v.top_x[jd.top_off + t], cfg, sp.short_sq_bound, c);
+      }
+      s_flag[2 * rl + (unsigned)(cfg - 1)] = (unsigned char)flag;
+    }
+    __syncthreads();
+    // ---- ordered compaction of the trip (compact_kernel's scheme on the LDS bytes): a wave owns 1024 consecutive slots
+    int f[COMPACT_PER];
+    int wcount = 0;
+#pragma unroll
+    for (int q = 0; q < COMPACT_PER; q++) {
+      f[q] = s_flag[wid * (64 * COMPACT_PER) + q * 64 + lane];
+      wcount += __popcll(__ballot(f[q] != 0));
+    }
+    if (lane == 0) wsum[wid] = wcount;
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const int x = wsum[w]; if (w < wid) woff += x; total += x; }
+    long long pos0 = run + woff;
+    const long long sl0 = base + 2ll * r0 + wid * (64 * COMPACT_PER) + lane;
+#pragma unroll
+    for (int q = 0; q < COMPACT_PER; q++) {
+      const unsigned long long bal = __ballot(f[q] != 0);
+      if (f[q] != 0) {
+        const long long pos = pos0 + __popcll(bal & below);
+        v.c_slot[pos] = sl0 + q * 64;
+        v.c_flag[pos] = f[q] | (j << CAND_JOB_SHIFT);
+      }
+      pos0 += __popcll(bal);
+    }
+    run += total;
+    __syncthreads();                                    // s_flag and wsum are rewritten by the next trip
+  }
+  const int n_valid = (int)(run - base);
+  if (tid == 0) { v.job_valid[j] = n_valid; v.job_cbase[j] = base; }
+  // the scorer's work list: this job's blocks of 256 rows, appended as the job finishes (the list's order is roughly the jobs' order:
+  // neighbouring entries read the same distance maps; it does not matter for any result)
+  const int nblk = (n_valid + 255) >> 8;
+  if (nblk > 0) {
+    __shared__ int s_at;
+    if (tid == 0) s_at = atomicAdd(&v.blk_info[0], nblk);
+    __syncthreads();
+    const int at = s_at, b0 = (int)(base >> 8);
+    for (int k = tid; k < nblk; k += 256) {
+      const int left = n_valid - 256 * k;
+      v.blk_info[2 + 2 * (long long)(at + k)] = b0 + k;
+      v.blk_info[3 + 2 * (long long)(at + k)] = left > 256 ? 256 : left;
+    }
+  }
+}
+
 // The eight corners of the proposal in `slot` of job jd (box_proposal_detail.cpp:413-625), rebuilt: slot = slot_off + ((rp Y + yaw) T
 // + top) 2 + (config - 1).  Returns build_corners' flag.
 __device__ __forceinline__ int slot_corners(const DetectDeviceView& v, const JobDesc& jd, long long slot, double short_sq_bound, V2 c[8]) {
@@ -458,12 +560,19 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
   double (*CXt)[260] = C16, (*CYt)[260] = C16 + 8;
   // the grid is sized for the worst case (every slot valid) because the exact count lives on the device; spread the
   // ACTIVE blocks over the 8 XCDs (contiguous range per XCD), the surplus blocks exit immediately
-  const long long n_valid = v.job_cbase[v.n_jobs];
+  // (capacity layout, candidate_compact_kernel: the work list names the blocks of 256 rows that hold valid rows -- all of one job, leading the block)
+  const bool cap = v.blk_info != nullptr;
+  long long n_valid = cap ? 256ll * v.blk_info[0] : v.job_cbase[v.n_jobs];
   const long long per_xcd = ((n_valid + 255) / 256 + 7) / 8;
   const long long kx = blockIdx.x >> 3;
   if (kx >= per_xcd) return;
-  const long long base = ((long long)(blockIdx.x & 7) * per_xcd + kx) * blockDim.x;
+  long long base = ((long long)(blockIdx.x & 7) * per_xcd + kx) * blockDim.x;
   if (base >= n_valid) return;
+  if (cap) {
+    const int* entry = v.blk_info + 2 + 2 * (base >> 8);
+    base = 256ll * entry[0];
+    n_valid = base + entry[1];
+  }
   // ---- who scores what.  The 256 proposals of this block are consecutive in the reference's order: configuration
   // fastest, then top-edge sample, then yaw.  Neighbouring lanes would gather from unrelated places of the distance map,
   // and a wave load that touches 64 different cache lines occupies the L1 tag pipeline for 64 cycles -- that, not the
@@ -660,7 +769,6 @@ __global__ __launch_bounds__(1024) void scan_jobs_kernel(const int* job_valid, l
 // roll/pitch job's 79 k twenty).  Each wave owns 1024 consecutive slots as COMPACT_PER groups of 64 (lane = slot inside the
 // group: coalesced loads, ballot for the order inside a group, a running count from group to group); one barrier per trip gives
 // the waves their offsets.
-enum { COMPACT_PER = 16 };
 __global__ __launch_bounds__(256) void compact_kernel(DetectDeviceView v) {
   int j = blockIdx.x;
   if (j >= v.n_jobs) return;
@@ -1668,6 +1776,11 @@ void launch_candidates(const DetectDeviceView& v, const SweepParams& sp, long lo
   if (skip_kernel("candidate")) return;
   if (slot_total <= 0) return;
   hipLaunchKernelGGL(candidate_kernel, dim3(grid8(slot_total, 256)), dim3(256), 0, st, v, sp, slot_total);
+}
+void launch_candidate_compact(const DetectDeviceView& v, const SweepParams& sp, hipStream_t st) {     // (v.blk_info set; slot_prefix in multiples of 256)
+  if (skip_kernel("candidate")) return;
+  if (v.n_jobs <= 0) return;
+  hipLaunchKernelGGL(candidate_compact_kernel, dim3(v.n_jobs), dim3(256), 0, st, v, sp);
 }
 void launch_scan_compact(const DetectDeviceView& v, hipStream_t st) {
   if (v.n_jobs <= 0) return;

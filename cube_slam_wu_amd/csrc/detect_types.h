@@ -64,6 +64,11 @@ struct DetectDeviceView {
   long long* c_slot;             // compacted (valid proposals in the reference's row order): slot id
   double* c_dist; double* c_angle; double* c_skew;   // written by score_kernel
   int* c_flag;
+  // capacity layout (candidate_compact_kernel, the lean path): a job's compacted rows start at slot_prefix[j] (a multiple of 256) instead of
+  // at the exclusive scan of the counts -- no pass over all jobs between the corner construction and the scorer.  blk_info: [0] = number of
+  // blocks of 256 rows that hold valid rows (counted up by the jobs' workgroups as they finish; zeroed before the launch), then from [2] on
+  // one (block index, valid rows) pair per such block: the scorer's work list.  null = the scanned (dense) layout.
+  int* blk_info;
 };
 
 // Ranking stage on the device (fuse_normalize_scores_v2 + the skew-weighted final ranking).

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel times of the detect path, one batch in flight, nothing else in the run:  tools/kernel_times_quick.sh <tag>
 tag=${1:-x}; R=$(pwd); export TMPDIR=/tmp; cd /tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --ba none --no-edge --rp-frames 0 --latency-calls 0 --lines-images 0 --inflight ${INFLIGHT:-1}"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --ba none --no-edge --rp-frames 0 --latency-calls 0 --lines-images 0 --image-in-steps 0 --steady-steps 0 --inflight ${INFLIGHT:-1}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kt_${tag} -o kt -- python $R/bench.py --no-measure-traffic $ARGS > $R/gpurun_out/kt_${tag}.log 2>&1
 cd $R
 f=$(find gpurun_out/kt_${tag} -name '*kernel_stats.csv' | head -1)
