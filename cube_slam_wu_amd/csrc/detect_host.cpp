@@ -710,6 +710,12 @@ void cs_detector_destroy(cs_detector* d) {
 }
 
 static int batch_fill(cs_detector* d, cs_batch* b, const cs_frame_desc* fr, const unsigned char* const* grays, int n_frames);
+// Launch order of the distance-map front end's workgroups (one per ROI, its time grows with the ROI's area): largest first, so that the
+// kernels do not end on a late-started large ROI.  The entries carry their own offsets: their order in the table means nothing else.
+static void edge_rois_largest_first(std::vector<cs::EdgeRoi>& er) {
+  if (er.size() <= 1024) return;
+  std::stable_sort(er.begin(), er.end(), [](const cs::EdgeRoi& a, const cs::EdgeRoi& c) { return (long long)a.w * a.h > (long long)c.w * c.h; });
+}
 static int batch_layout(cs_detector* d, cs_batch* b);
 static int batch_run_impl(cs_detector* d, cs_batch* b, cs_cuboid* out, int* out_counts, bool defer);
 static int batch_flush_refill(cs_detector* d, cs_batch* b);
@@ -826,6 +832,7 @@ static int batch_fill(cs_detector* d, cs_batch* b, const cs_frame_desc* fr, cons
       HIP_TRY(hipMemsetAsync(b->d_maps.p, 0, sizeof(float) * (map_floats + 1), st));
       for (int f = 0; f < n_frames; f++) HIP_TRY(hipMemcpyAsync(d_gray.p + (size_t)f * W * H, grays[f], (size_t)W * H, hipMemcpyHostToDevice, st));
       if (!er.empty()) {
+        edge_rois_largest_first(er);
         HIP_TRY(hipMemcpyAsync(d_rois.p, er.data(), sizeof(cs::EdgeRoi) * er.size(), hipMemcpyHostToDevice, st));
         cs::launch_edge_maps(d_gray.p, W, H, d_rois.p, (int)er.size(), d_cls.p, b->d_maps.p, max_w, max_px, 80, 200, st);
         HIP_TRY(hipGetLastError());
@@ -2759,7 +2766,9 @@ int cs_edge_distance_maps_multi(cs_detector* d, const unsigned char* const* gray
     if (!grays[i]) { set_err("cs_edge_distance_maps: null image"); return CS_ERR_INVALID_ARG; }
     HIP_TRY(hipMemcpyAsync(d_gray.p + img_px * i, grays[i], img_px, hipMemcpyHostToDevice, st));
   }
-  HIP_TRY(hipMemcpyAsync(d_rois.p, er.data(), sizeof(cs::EdgeRoi) * n_rois, hipMemcpyHostToDevice, st));
+  std::vector<cs::EdgeRoi> er_launch(er.begin(), er.end());      // (er keeps the caller's order for the copies back)
+  edge_rois_largest_first(er_launch);
+  HIP_TRY(hipMemcpyAsync(d_rois.p, er_launch.data(), sizeof(cs::EdgeRoi) * n_rois, hipMemcpyHostToDevice, st));
   HIP_TRY(hipEventRecord(d->ev[0], st));
   // cv::Canny(gray_img(object_bbox), im_canny, 80, 200): the thresholds are literals of the reference (:324)
   cs::launch_edge_maps(d_gray.p, img_w, img_h, d_rois.p, n_rois, d_cls.p, d_map.p, max_w, max_px, 80, 200, st);

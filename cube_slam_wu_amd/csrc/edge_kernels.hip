@@ -145,6 +145,170 @@ __global__ __launch_bounds__(256) void edge_canny_kernel(const unsigned char* __
   }
 }
 
+// ---- round 6: Canny of a whole ROI in one workgroup with the hysteresis on bit planes in LDS (large batches) ---------------------------
+// What the fused form above spends: nine clamped byte loads and ~110 instructions per pixel for the Sobel taps, and a breadth-first growth on
+// the class bytes in memory (rounds of atomics and barriers: 0.8 of its 1.5 ms per 8000 ROIs).  Here
+//   * a band's gray rows are staged in LDS once (clamped at the image border: BORDER_REPLICATE, the ROI is not isolated) and a lane computes
+//     four neighbouring Sobel responses from six words of it (column sums t + 2m + b and differences b - t shared between the four);
+//   * the suppression's classes leave as bytes (as before) AND as two bit planes in LDS -- strong (class 2) and weak (class 0), one bit per
+//     pixel, a wave ballot per 64 pixels;
+//   * the hysteresis is sweeps over the words of the weak plane: a word that still has weak pixels gathers the strong bits around it (its
+//     own row and the rows above / below, shifted by one either way, with the neighbouring words' edge bits), and every RUN of weak pixels
+//     that touches one joins at once -- the carry of an addition walks up a run, the same on the bit-reversed word walks down.  32 pixels
+//     per instruction, no atomics (a word is written by its owner only; a reader that sees the new value merely joins a sweep early),
+//     one barrier per sweep; the joined pixels' bytes are patched in memory as they join.
+// The result is the set of weak pixels connected to a strong one (8-neighbourhood) -- the same fixed point whatever the order.
+enum { CB_BAND = 8, HYST_WAVE_REPEATS = 8 };     // (bands of 8 rows: 16-row bands cost a workgroup per CU in LDS, 1.18 -> 1.08 ms per 8000 ROIs)
+// e / d for small e (< 2^16) by a multiplication: inv = cb_inv(d)  (d = 1 has no 32-bit reciprocal of this form: the high product of e and
+// 0xffffffff is e - 1 for e > 0, so it gets its own arm)
+__device__ __forceinline__ unsigned cb_inv(int d) { return d <= 1 ? 0u : 0xffffffffu / (unsigned)d + 1u; }
+__device__ __forceinline__ int cb_div(int e, unsigned inv) { return inv ? (int)__umulhi((unsigned)e, inv) : e; }
+__device__ __forceinline__ int cb_ms_stride(int w) { return (w + 2 + 3) & ~3; }           // 16-bit words per row of the magnitude band
+__device__ __forceinline__ int cb_gray_stride(int w) { return (w + 9 + 3) & ~3; }         // bytes per row of the gray band (ROI columns -2 ...)
+__host__ __device__ __forceinline__ int cb_ms_words(int max_w) { return (((CB_BAND + 2) * ((max_w + 2 + 3) & ~3)) + 1) >> 1; }
+__host__ __device__ __forceinline__ int cb_gray_words(int max_w) { return ((CB_BAND + 4) * ((max_w + 9 + 3) & ~3)) >> 2; }
+__global__ __launch_bounds__(256) void edge_canny_bits_kernel(const unsigned char* __restrict__ gray, int W, int H, const EdgeRoi* __restrict__ rois, unsigned char* cls_pool, int low, int high,
+                                                              int max_w) {
+  extern __shared__ unsigned cb_lds[];
+  const EdgeRoi R = rois[blockIdx.x];
+  gray += R.img_off;
+  unsigned char* cls = cls_pool + R.cls_off;
+  const int w = R.w, h = R.h;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int MS = cb_ms_stride(w), GW = cb_gray_stride(w), Wd = (w + 31) >> 5;
+  unsigned short* ms = reinterpret_cast<unsigned short*>(cb_lds);
+  unsigned* gw32 = cb_lds + cb_ms_words(max_w);
+  unsigned* Sp = gw32 + cb_gray_words(max_w);          // strong plane: row i of the ROI at words [(i + 1) Wd, (i + 2) Wd); rows 0 and h + 1 stay empty
+  unsigned* Kp = Sp + (h + 2) * Wd;                    // weak plane
+  const int TG22 = 13573;
+  for (int e = tid; e < Wd; e += 256) { Sp[e] = 0; Sp[(h + 1) * Wd + e] = 0; Kp[e] = 0; Kp[(h + 1) * Wd + e] = 0; }
+  const int GQ = GW >> 2, MQ = MS >> 2;
+  const unsigned inv_gq = cb_inv(GQ), inv_mq = cb_inv(MQ);
+  for (int b0 = 0; b0 < h; b0 += CB_BAND) {
+    const int rows = min(CB_BAND, h - b0);
+    __syncthreads();                                   // the previous band's readers are done
+    // ---- gray rows b0 - 2 .. b0 + rows + 1, ROI columns -2 .. GW - 3, four bytes per lane
+    for (int e = tid; e < (rows + 4) * GQ; e += 256) {
+      const int g = cb_div(e, inv_gq), q = e - g * GQ;
+      const int y = min(max(R.t + b0 - 2 + g, 0), H - 1);
+      const unsigned char* src = gray + (size_t)y * W;
+      const int x0 = R.l - 2 + 4 * q;
+      const unsigned v = (unsigned)src[min(max(x0, 0), W - 1)] | ((unsigned)src[min(max(x0 + 1, 0), W - 1)] << 8) | ((unsigned)src[min(max(x0 + 2, 0), W - 1)] << 16) |
+                         ((unsigned)src[min(max(x0 + 3, 0), W - 1)] << 24);
+      gw32[g * GQ + q] = v;
+    }
+    __syncthreads();
+    // ---- Sobel + L1 magnitude + sector of band rows -1 .. rows (ROI rows b0 - 1 + r), four columns per lane
+    for (int e = tid; e < (rows + 2) * MQ; e += 256) {
+      const int r = cb_div(e, inv_mq), q = e - r * MQ;
+      const int i = b0 - 1 + r, c0 = 4 * q;            // magnitude columns c0 .. c0 + 3 = ROI columns c0 - 1 .. c0 + 2
+      unsigned out[2] = {0u, 0u};
+      if (i >= 0 && i < h) {
+        const unsigned* g0 = gw32 + r * GQ + q;        // gray rows i - 1, i, i + 1 from byte column c0 on (ROI column c0 - 2)
+        const unsigned t0 = g0[0], t1 = g0[1], m0 = g0[GQ], m1 = g0[GQ + 1], d0 = g0[2 * GQ], d1 = g0[2 * GQ + 1];
+        int S6[6], D6[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          const int tt = (int)(((k < 4 ? t0 : t1) >> (8 * (k & 3))) & 0xffu), mm = (int)(((k < 4 ? m0 : m1) >> (8 * (k & 3))) & 0xffu), bb = (int)(((k < 4 ? d0 : d1) >> (8 * (k & 3))) & 0xffu);
+          S6[k] = tt + 2 * mm + bb; D6[k] = bb - tt;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          const int c = c0 + p;
+          unsigned pv = 0;
+          if (c >= 1 && c <= w) {
+            const int xs = S6[p + 2] - S6[p], ys = D6[p] + 2 * D6[p + 1] + D6[p + 2];
+            const int x = abs(xs), y = abs(ys) << 15;
+            const int tg22x = x * TG22;
+            unsigned sector;
+            if (y < tg22x) sector = 0;
+            else if (y > tg22x + (x << 16)) sector = 1;
+            else sector = ((xs ^ ys) < 0) ? 3u : 2u;
+            pv = (unsigned)(abs(xs) + abs(ys)) | (sector << 11);
+          }
+          out[p >> 1] |= pv << (16 * (p & 1));
+        }
+      }
+      unsigned* dst = reinterpret_cast<unsigned*>(ms + r * MS + c0);
+      dst[0] = out[0]; dst[1] = out[1];
+    }
+    __syncthreads();
+    // ---- non-maximum suppression + thresholds: class bytes to memory, strong / weak bits to the planes
+    for (int r = wv; r < rows; r += 4) {
+      const int i = b0 + r;
+      const unsigned short* mid = ms + (r + 1) * MS;      // band row r + 1 = ROI row i (row 0 of the band is the halo above)
+      for (int j0 = 0; j0 < w; j0 += 64) {
+        const int j = j0 + lane;
+        unsigned char c = 1;
+        if (j < w) {
+          // branch-free: both neighbours of the pixel's sector are read whatever its magnitude (a wave always holds pixels of every sector,
+          // so the three-way branch ran all its arms anyway)
+          const unsigned v = mid[j + 1];
+          const int m = (int)(v & 0x7ffu);
+          const unsigned sector = v >> 11;
+          const int step = sector == 0 ? 1 : (sector == 1 ? MS : (sector == 2 ? MS + 1 : MS - 1));      // towards the second neighbour; the first is opposite
+          const int ma = (int)(mid[j + 1 - step] & 0x7ffu), mb = (int)(mid[j + 1 + step] & 0x7ffu);
+          const bool keep = m > low && m > ma && (sector < 2 ? m >= mb : m > mb);
+          c = keep ? (m > high ? 2 : 0) : 1;
+          cls[i * w + j] = c;
+        }
+        const unsigned long long bs = __ballot(j < w && c == 2), bk = __ballot(j < w && c == 0);
+        if (lane < 2) {
+          const int kw = (j0 >> 5) + lane;
+          if (kw < Wd) { Sp[(i + 1) * Wd + kw] = (unsigned)(bs >> (32 * lane)); Kp[(i + 1) * Wd + kw] = (unsigned)(bk >> (32 * lane)); }
+        }
+      }
+    }
+  }
+  // ---- hysteresis on the planes
+  const int nwords = h * Wd;
+  const unsigned inv_wd = cb_inv(Wd);
+  for (;;) {
+    __syncthreads();
+    int ch = 0;
+    for (int e0 = 0; e0 < nwords; e0 += 256) {         // (wave-uniform trip count: the inner repeats vote)
+      const int e = e0 + tid;
+      const bool in = e < nwords;
+      const int i = cb_div(in ? e : 0, inv_wd), kw = (in ? e : 0) - i * Wd;
+      const int at = (i + 1) * Wd + kw;
+      unsigned k = in ? Kp[at] : 0u;
+      if (!__any(k != 0)) continue;
+      const unsigned k_in = k;
+      // a wave's 64 words are ~64 / Wd whole rows: repeating the step lets a chain cross several of them within one sweep (the wave
+      // reads what its own lanes have just written: LDS operations of a wave stay in order)
+      for (int rep = 0; rep < HYST_WAVE_REPEATS; rep++) {
+        unsigned f = 0;
+        if (k) {
+          unsigned nb = 0, s_mid = 0;
+#pragma unroll
+          for (int dr = -1; dr <= 1; dr++) {
+            const unsigned* rw = Sp + at + dr * Wd;
+            const unsigned sv = rw[0];
+            const unsigned l = kw > 0 ? rw[-1] >> 31 : 0u, rr = kw + 1 < Wd ? rw[1] << 31 : 0u;
+            nb |= sv | (sv << 1) | (sv >> 1) | l | rr;
+            if (dr == 0) s_mid = sv;
+          }
+          const unsigned jn = k & nb;
+          if (jn) {
+            f = ((k + jn) ^ k) | jn;                                      // up the runs: the carry walks from a touched bit to the run's end
+            const unsigned kr = __brev(k), jr = __brev(jn);
+            f |= __brev(((kr + jr) ^ kr) | jr);                           // ... and down
+            f &= k;
+            Sp[at] = s_mid | f;
+            k &= ~f;
+            for (unsigned t = f; t; t &= t - 1) cls[i * w + 32 * kw + (__ffs((int)t) - 1)] = 2;
+          }
+        }
+        if (!__any(f != 0)) break;
+        ch = 1;
+      }
+      if (k != k_in) Kp[at] = k;
+    }
+    if (!__syncthreads_or(ch)) break;
+  }
+
+}
+
 // ---- hysteresis ----------------------------------------------------------------------------------------------------------------
 // = the 8-connected components of the surviving pixels (class 0 or 2) that contain a strong one (class 2); every pixel of such a
 // component becomes 2.  The result does not depend on the order the pixels are visited in.
@@ -582,12 +746,24 @@ void launch_multi_copy(const CopySegs& segs, hipStream_t st) {
   const int bx = (int)std::min<unsigned long long>(32, std::max<unsigned long long>(1, mx / (16 * 256 * 4)));
   hipLaunchKernelGGL(multi_copy_kernel, dim3(bx, segs.n), dim3(256), 0, st, segs);
 }
+// (Tried in round 6: the batch as four chunks of ROIs, the distance transform of chunk c on a second stream beside the Canny of chunk c + 1 --
+// a latency chain beside an issue-bound kernel.  Side by side both crawl: 2.44 ms per 8000 ROIs against 1.84 one after the other.)
 void launch_edge_maps(const unsigned char* gray, int W, int H, const EdgeRoi* rois, int n_rois, unsigned char* cls_pool, float* map_pool, int max_w, long long max_px, int low, int high,
                       hipStream_t st) {   // max_px: the largest framed size of an ROI, 4 ceil((w + 2) / 4) (h + 2)
   if (n_rois <= 0) return;
-  // CS_EDGE_HYST (tests / measurements): "lds" or "fused" forces one hysteresis path; by default calls that cannot fill the device take the LDS kernel
-  static const int force = [] { const char* e = getenv("CS_EDGE_HYST"); return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'f' ? 2 : 0)); }();
-  const bool fused = force ? force == 2 : n_rois > 1024;
+  // CS_EDGE_HYST (tests / measurements): "lds", "fused" or "bits" forces one hysteresis path; by default calls that cannot fill the device take the LDS kernel
+  static const int force = [] { const char* e = getenv("CS_EDGE_HYST"); return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'f' ? 2 : (e[0] == 'b' ? 3 : 0))); }();
+  const bool fused = force ? force >= 2 : n_rois > 1024;
+  // large batches whose ROIs fit: the whole Canny of an ROI in one workgroup, hysteresis on bit planes in LDS (edge_canny_bits_kernel).
+  // LDS: the magnitude band, the gray band and two planes of (h + 2) ceil(w / 32) words -- bounded through the largest framed ROI
+  // (max_px = 4 ceil((w + 2) / 4) (h + 2) >= w (h + 2)): w (h + 2) / 32 + (h + 2) words each.  CS_EDGE_HYST=fused keeps the memory form (tests).
+  const size_t bits_lds = 4 * ((size_t)cb_ms_words(max_w) + (size_t)cb_gray_words(max_w) + 2 * ((size_t)max_px / 32 + (size_t)H + 2 + 8));
+  if ((force == 3 || (!force && fused)) && max_w <= CANNY_TILE_W && bits_lds <= 64 * 1024) {
+    const size_t dt_lds = 2 * (size_t)(max_w + 2) * sizeof(unsigned);
+    hipLaunchKernelGGL(edge_canny_bits_kernel, dim3(n_rois), dim3(256), bits_lds, st, gray, W, H, rois, cls_pool, low, high, max_w);
+    hipLaunchKernelGGL(edge_dt_kernel, dim3(n_rois), dim3(64), dt_lds, st, rois, cls_pool, map_pool, max_w);
+    return;
+  }
   hipLaunchKernelGGL(edge_canny_kernel, dim3(n_rois, (!fused && n_rois <= 64) ? 8 : 1), dim3(256), 0, st, gray, W, H, rois, cls_pool, map_pool, low, high, fused ? 1 : 0);
   if (!fused) {
     // the ROI's class bytes in LDS: sized for the largest ROI of the call, at most 64 KB (two workgroups per CU with the lists; larger ROIs take

@@ -68,9 +68,47 @@ def test_hysteresis_paths_agree(monkeypatch):
         "det.close()\n"
         "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for env in ({"CS_EDGE_HYST": "lds", "CS_EDGE_HYST_LIST": "3"}, {"CS_EDGE_HYST": "lds", "CS_EDGE_HYST_LDS": "20000"},
-                {"CS_EDGE_HYST": "lds", "CS_EDGE_HYST_LIST": "40", "CS_EDGE_HYST_LDS": "40000"}, {"CS_EDGE_HYST": "lds"}, {"CS_EDGE_HYST": "fused"}):
+                {"CS_EDGE_HYST": "lds", "CS_EDGE_HYST_LIST": "40", "CS_EDGE_HYST_LDS": "40000"}, {"CS_EDGE_HYST": "lds"}, {"CS_EDGE_HYST": "fused"}, {"CS_EDGE_HYST": "bits"}):
         out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (env, out.stderr[-2000:])
+
+
+def test_bit_plane_canny_on_narrow_and_flat_rois():
+    """edge_canny_bits_kernel (round 6: the whole Canny of an ROI in one workgroup, hysteresis on bit planes in LDS; the path of calls with
+    more than 1024 ROIs, forced here): noisy scenes with long weak edges, ROIs of 1 .. 40 columns (one plane word per row: the index
+    arithmetic's divisor-1 arm -- tools/fuzz_edge.py found joined pixels patched at the wrong byte there), a few rows, and ordinary ones."""
+    import os, subprocess, sys
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from cube_slam_wu_amd import capi\n"
+        "from oracle import edge_oracle_py as E\n"
+        "rng = np.random.default_rng(5)\n"
+        "det = capi.Detector(capi.default_params())\n"
+        "n = 0\n"
+        "for k in range(6):\n"
+        "    H, W = int(rng.integers(60, 380)), int(rng.integers(60, 440))\n"
+        "    yy, xx = np.mgrid[0:H, 0:W]\n"
+        "    img = np.full((H, W), float(rng.uniform(60, 160)))\n"
+        "    for _ in range(int(rng.integers(4, 30))):\n"
+        "        a = rng.uniform(0, np.pi)\n"
+        "        img += np.where((xx - rng.uniform(0, W)) * np.cos(a) + (yy - rng.uniform(0, H)) * np.sin(a) > 0, rng.uniform(-60, 60), 0)\n"
+        "    img += rng.normal(0, rng.uniform(2, 8), (H, W))\n"
+        "    gray = np.clip(img, 0, 255).astype(np.uint8)\n"
+        "    rois = [(0, 0, W, H)]\n"
+        "    for _ in range(24):\n"
+        "        w, h = int(rng.integers(1, 41)), int(rng.integers(1, H + 1))\n"
+        "        rois.append((int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1)), w, h))\n"
+        "    for _ in range(12):\n"
+        "        w, h = int(rng.integers(1, W + 1)), int(rng.integers(1, 9))\n"
+        "        rois.append((int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1)), w, h))\n"
+        "    for r, g in zip(rois, det.edge_distance_maps(gray, rois)):\n"
+        "        assert np.array_equal(g.view(np.uint32), E.edge_distance_map(gray, r).view(np.uint32)), (k, (H, W), r)\n"
+        "        n += 1\n"
+        "det.close()\n"
+        "print('ok', n)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, "CS_EDGE_HYST": "bits"}, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
 def test_image_in_cuboids_out_matches_oracle_on_the_same_maps():
