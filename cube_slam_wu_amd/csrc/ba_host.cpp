@@ -354,6 +354,7 @@ struct cs_ba {
   bool fused = false;
   int n_seg = 0, n_gpairs = 0, seg_class[5] = {0, 0, 0, 0, 0};
   DBuf<int> d_run_lm, d_seg_ptr, d_seg_k, d_seg_tile, d_seg_slot, d_gp_ptr, d_gp_i1, d_gp_i2, d_gtile, d_gcam_ptr, d_gslot;
+  DBuf<int> d_run_e0, d_seg_cam;     // round 6: a run entry's first point-major edge (= pt_ptr[run_lm]) and a segment slot's camera (= pm_cam of the segment's first landmark): two dependent loads less at the head of ba_lin_schur_kernel
   DBuf<double> part_tiles, part_coef;
   DBuf<rocblas_int> d_info;
   DBuf<int> d_band_info;
@@ -1126,7 +1127,7 @@ int finalize_structure(cs_ba* B) {
   B->schur_entries = 0;
   for (int p : gorder) if (owner[p] == B->shard_rank) { const long long k = cam_cnt[p + 1] - cam_cnt[p]; B->schur_entries += k * (k + 1) / 2; }
   if (B->fused) {
-    std::vector<int> run_lm, seg_ptr{0}, seg_k, seg_tile, seg_slot;
+    std::vector<int> run_lm, seg_ptr{0}, seg_k, seg_tile, seg_slot, run_e0, seg_cam;
     struct Dst { int a, b, id; };
     std::vector<Dst> dst;                      // (destination block = its two columns, partial block id), in creation order: ids grow
     std::vector<std::pair<int, int>> cdst;     // (camera, partial vector id)
@@ -1143,6 +1144,7 @@ int finalize_structure(cs_ba* B) {
         if (owner[p] != B->shard_rank) continue;
         if (in_seg == 0) {   // open a segment
           seg_k.push_back(k); seg_tile.push_back(n_tiles); seg_slot.push_back(n_slots);
+          for (int a = 0; a < k; a++) seg_cam.push_back(slot_cam[a]);      // (= pm_cam[pt_ptr[p] + a]: the point-major order of a landmark's edges is this slot order)
           for (int a = 0; a < k; a++) {
             const int ca = B->cam_col[slot_cam[a]];
             if (ca < 0) continue;
@@ -1151,7 +1153,7 @@ int finalize_structure(cs_ba* B) {
           }
           n_tiles += k * (k + 1) / 2; n_slots += k;
         }
-        run_lm.push_back(p);
+        run_lm.push_back(p); run_e0.push_back(pt_ptr[p]);
         if (++in_seg == cs::BA_SEG_LM) { seg_ptr.push_back((int)run_lm.size()); in_seg = 0; }
       }
       if (in_seg) seg_ptr.push_back((int)run_lm.size());
@@ -1237,6 +1239,7 @@ int finalize_structure(cs_ba* B) {
     { std::vector<int> fill(gcam_ptr.begin(), gcam_ptr.end() - 1); for (auto& e : cdst) gslot[fill[e.first]++] = e.second; }
     mark("  destination lists");
     UP(B->d_run_lm, run_lm); UP(B->d_seg_ptr, seg_ptr); UP(B->d_seg_k, seg_k); UP(B->d_seg_tile, seg_tile); UP(B->d_seg_slot, seg_slot);
+    UP(B->d_run_e0, run_e0); UP(B->d_seg_cam, seg_cam);
     UP(B->d_gp_ptr, gp_ptr); UP(B->d_gp_i1, gp_i1); UP(B->d_gp_i2, gp_i2); UP(B->d_gtile, gtile); UP(B->d_gcam_ptr, gcam_ptr); UP(B->d_gslot, gslot);
     AL(B->part_tiles, 36 * (size_t)n_tiles); AL(B->part_coef, 6 * (size_t)n_slots); ZFLUSH();
     B->n_pairs = 0;
@@ -1272,7 +1275,7 @@ int finalize_structure(cs_ba* B) {
     B->n_pairs = (int)pair_i1.size();
     UP(B->pair_ptr, pair_ptr); UP(B->pair_i1, pair_i1); UP(B->pair_i2, pair_i2); UP(B->ent_a, ent_a); UP(B->ent_b, ent_b);
     std::vector<int> none(1, 0);
-    UP(B->d_run_lm, none); UP(B->d_seg_ptr, none); UP(B->d_seg_k, none); UP(B->d_seg_tile, none); UP(B->d_seg_slot, none);
+    UP(B->d_run_lm, none); UP(B->d_seg_ptr, none); UP(B->d_seg_k, none); UP(B->d_seg_tile, none); UP(B->d_seg_slot, none); UP(B->d_run_e0, none); UP(B->d_seg_cam, none);
     UP(B->d_gp_ptr, none); UP(B->d_gp_i1, none); UP(B->d_gp_i2, none); UP(B->d_gtile, none); UP(B->d_gcam_ptr, none); UP(B->d_gslot, none);
     AL(B->part_tiles, 1); AL(B->part_coef, 1); ZFLUSH();
     std::vector<int> zp(no + 1, 0);
@@ -1449,7 +1452,7 @@ int finalize_structure(cs_ba* B) {
   v.Dinv = B->Dinv.p; v.dbl = B->dbl.p; v.S = B->S.p; v.band_ld = B->band_ld; v.lam_lo = B->sep_mode ? B->cut[B->shard_rank] : 0; v.lam_hi = B->sep_mode ? B->cut[B->shard_rank + 1] : (B->shard_rank == 0 ? 0x7fffffff : 0); v.rhs = B->S.p + B->s_doubles; v.xl = B->xl.p;
   v.n_pairs = B->n_pairs; v.pair_ptr = B->pair_ptr.p; v.pair_i1 = B->pair_i1.p; v.pair_i2 = B->pair_i2.p; v.ent_a = B->ent_a.p; v.ent_b = B->ent_b.p;
   v.fused = B->fused ? 1 : 0; v.n_seg = B->n_seg; for (int q = 0; q < 5; q++) v.seg_class[q] = B->seg_class[q];
-  v.seg_ptr = B->d_seg_ptr.p; v.seg_k = B->d_seg_k.p; v.seg_tile = B->d_seg_tile.p; v.seg_slot = B->d_seg_slot.p; v.run_lm = B->d_run_lm.p;
+  v.seg_ptr = B->d_seg_ptr.p; v.seg_k = B->d_seg_k.p; v.seg_tile = B->d_seg_tile.p; v.seg_slot = B->d_seg_slot.p; v.run_lm = B->d_run_lm.p; v.run_e0 = B->d_run_e0.p; v.seg_cam = B->d_seg_cam.p;
   v.part_tiles = B->part_tiles.p; v.part_coef = B->part_coef.p;
   v.n_gpairs = B->n_gpairs; v.gpair_ptr = B->d_gp_ptr.p; v.gpair_i1 = B->d_gp_i1.p; v.gpair_i2 = B->d_gp_i2.p; v.gtile = B->d_gtile.p;
   v.gcam_ptr = B->d_gcam_ptr.p; v.gslot = B->d_gslot.p;
@@ -1868,7 +1871,7 @@ void cs_ba_destroy(cs_ba* B) {
   B->stage.release(); B->append_stage.release();
   DBuf<int>* di[] = {&B->d_ce_active, &B->d_oe_active, &B->d_cam_col, &B->d_cub_col, &B->d_pt_free, &B->pm_pt, &B->pm_cam, &B->pt_ptr, &B->cm_pm, &B->cm_pt, &B->cam_ptr, &B->d_ce_cam, &B->d_ce_cub,
                      &B->d_oe_i, &B->d_oe_j, &B->cam_ce_ptr, &B->cam_ce_idx, &B->cam_oei_ptr, &B->cam_oei_idx, &B->cam_oej_ptr, &B->cam_oej_idx, &B->cub_ce_ptr,
-                     &B->cub_ce_idx, &B->pair_ptr, &B->pair_i1, &B->pair_i2, &B->ent_a, &B->ent_b, &B->d_run_lm, &B->d_seg_ptr, &B->d_seg_k, &B->d_seg_tile, &B->d_seg_slot,
+                     &B->cub_ce_idx, &B->pair_ptr, &B->pair_i1, &B->pair_i2, &B->ent_a, &B->ent_b, &B->d_run_lm, &B->d_seg_ptr, &B->d_seg_k, &B->d_seg_tile, &B->d_seg_slot, &B->d_run_e0, &B->d_seg_cam,
                      &B->d_gp_ptr, &B->d_gp_i1, &B->d_gp_i2, &B->d_gtile, &B->d_gcam_ptr, &B->d_gslot, &B->d_cubS_ptr, &B->d_cubS_cam, &B->d_ce_slot, &B->d_cub_tile, &B->d_cub_coef,
                      &B->d_elim_fail, &B->d_slotE_ptr, &B->d_slotE_idx, &B->d_cub_mine, &B->d_sep_off, &B->d_sep_col, &B->d_int_info, &B->d_sep_info, &B->d_pm_rk, &B->d_cm_rk, &B->d_ce_rk, &B->d_oe_rk, &B->d_ext_e4, &B->d_ext_order, &B->d_ext_gptr, &B->d_src, &B->sp_ndim, &B->sp_ncol, &B->sp_sptr, &B->sp_srow, &B->sp_sroff, &B->sp_prow, &B->sp_rbase, &B->sp_rent, &B->sp_rptr, &B->sp_rcol, &B->sp_rpos,
                      &B->sp_order, &B->sp_info, &B->sp_tcol};

@@ -798,8 +798,11 @@ __device__ __forceinline__ void ba_lin_schur_segment(const BaView& v, double lam
   const int q0 = v.seg_ptr[seg], q1 = v.seg_ptr[seg + 1], n = q1 - q0;
   double (*Wl)[64] = reinterpret_cast<double (*)[64]>(lds);                  // [18][edge of the chunk]
   double (*Dl)[LS_DCOLS] = reinterpret_cast<double (*)[LS_DCOLS]>(lds + LS_PLANES * 64);   // [12][landmark of the chunk]: D^-1 (9), b_l (3)
+  // (round 6: the run entry's first edge and the slot's camera come from tables of their own -- run_e0 = pt_ptr[run_lm], seg_cam = pm_cam of the
+  // segment's first landmark -- so that the head of a segment is three dependent round trips (segment scalars -> these -> pose / records)
+  // instead of five; with three waves per SIMD the kernel is those round trips)
   int my_p = 0, my_e0 = 0;
-  if (q0 + lane < q1) { my_p = v.run_lm[q0 + lane]; my_e0 = v.pt_ptr[my_p]; }
+  if (q0 + lane < q1) { my_p = v.run_lm[q0 + lane]; my_e0 = v.run_e0[q0 + lane]; }
   ba_v4d acc[MT][MT];
 #pragma unroll
   for (int t = 0; t < MT; t++)
@@ -807,9 +810,8 @@ __device__ __forceinline__ void ba_lin_schur_segment(const BaView& v, double lam
     for (int u = 0; u < MT; u++) acc[t][u] = ba_v4d{0.0, 0.0, 0.0, 0.0};
   const int C = min((int)LS_DCOLS, 64 / k);             // landmarks per chunk
   const int lc = lane / k, sa_l = lane - lc * k;        // this lane's (landmark of the chunk, camera slot)
-  // the slot's camera: from the segment's first landmark
-  const int e_first = __builtin_amdgcn_readlane(my_e0, 0);
-  const int cam = v.pm_cam[e_first + (lc < C ? sa_l : 0)];
+  // the slot's camera (the same for every landmark of the segment)
+  const int cam = v.seg_cam[v.seg_slot[seg] + (lc < C ? sa_l : 0)];
   const Pose T = pose_load(v.cams + 7 * cam);
   double R[9];
   pose_rotmat(T, R);

@@ -89,6 +89,7 @@ struct BaView {
   int fuse_lin;                 // 1: the landmark side of the projection edges is linearised inside the Schur kernels (ba_lin_schur_kernel): ba_launch_linearize leaves ba_lin_pt_kernel out
   int n_seg; int seg_class[5];   // segments [0, seg_class[0]): k <= 2, then k <= 5, k <= 7, k <= 10, k <= 13 (one 16-row tile more per class), the rest: long tracks, k <= BA_LONG_KMAX
   const int* seg_ptr; const int* seg_k; const int* seg_tile; const int* seg_slot; const int* run_lm;
+  const int* run_e0; const int* seg_cam;      // per run entry: pt_ptr[run_lm]; per segment slot (seg_slot[seg] + a): the slot's camera
   double* part_tiles;           // 36 per partial block
   double* part_coef;            // 6 per (segment, camera slot)
   int n_gpairs; const int* gpair_ptr; const int* gpair_i1; const int* gpair_i2; const int* gtile;
