@@ -316,6 +316,7 @@ struct cs_ba {
   int n_pose = 0, n_lm = 0;
   int n_red = 0;            // dimension of the system the solver factorises: n_pose, or the cameras' part when the cuboids are eliminated too
   bool elim = false;        // free cuboids eliminated like landmarks (single rank, fused Schur schedule)
+  int elim_max_slots = 1;   // observing cameras of the widest free cuboid
   // general sparse Cholesky of the reduced system (ba_sparse.h): graphs the ordering cannot band
   bool sparse = false;
   bool sp_S_clean = false;     // S holds nothing outside the plan's pattern (set by the first trial's full clear)
@@ -851,6 +852,7 @@ int finalize_structure(cs_ba* B) {
   auto cost = [&](const Ordering& O) { return band_ok(O) ? (double)O.n_red * (O.bw + 1.0) * (O.bw + 1.0) : (double)O.n_red * O.n_red * O.n_red / 3.0; };
   {
     // (an external binary edge on a cuboid couples it to something besides its observing cameras: the cuboids then stay in the system)
+    B->elim_max_slots = std::max(1, std::min(max_slots, (int)cs::BA_ELIM_MAX_SLOTS));
     const bool try_elim = fused_ok && n_free_cub > 0 && max_slots <= cs::BA_ELIM_MAX_SLOTS && getenv("CS_BA_KEEP_CUBOIDS") == nullptr && !ext_binary_on_cuboid;
     // (the two candidate orderings only read shared data: g2o's system on a second thread while this one orders the cameras-only system)
     Ordering keep_o, elim_o;
@@ -1429,7 +1431,7 @@ int finalize_structure(cs_ba* B) {
   if (edge_rc) return edge_rc;
   cs::BaView& v = B->view;
   v.cams = B->cams.p; v.points = B->points.p; v.cubes = B->cubes.p; v.cam_col = B->d_cam_col.p; v.cub_col = B->d_cub_col.p; v.pt_free = B->d_pt_free.p;
-  v.nc = nc; v.np = np; v.no = no; v.n_pose = B->n_pose; v.n_red = B->n_red; v.elim = B->elim ? 1 : 0;
+  v.nc = nc; v.np = np; v.no = no; v.n_pose = B->n_pose; v.n_red = B->n_red; v.elim = B->elim ? 1 : 0; v.elim_max_slots = B->elim_max_slots;
   v.cubS_ptr = B->d_cubS_ptr.p; v.cubS_cam = B->d_cubS_cam.p; v.ce_slot = B->d_ce_slot.p; v.cub_tile = B->d_cub_tile.p; v.cub_coef = B->d_cub_coef.p;
   v.cub_mine = B->d_cub_mine.p;
   v.cub_M = B->cub_M.p; v.cub_Dinv = B->cub_Dinv.p; v.elim_fail = B->d_elim_fail.p; v.slotE_ptr = B->d_slotE_ptr.p; v.slotE_idx = B->d_slotE_idx.p;

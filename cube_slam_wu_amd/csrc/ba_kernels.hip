@@ -1116,7 +1116,11 @@ __global__ __launch_bounds__(64) void ba_cam_rhs_fused_kernel(BaView v, const do
 // to the same partial arrays as the landmark segments' and are summed by the same destination schedule.
 __global__ __launch_bounds__(256) void ba_cub_elim_kernel(BaView v, const double* __restrict__ lamp) {
   const double lambda = lamp[0];
-  __shared__ double M[BA_ELIM_MAX_SLOTS][54], G[BA_ELIM_MAX_SLOTS][54];
+  // M, G: 54 doubles per slot of the graph's widest cuboid (dynamic: sized for BA_ELIM_MAX_SLOTS = 64 slots they took 55 KB of a CU's LDS from the
+  // landmark segments' kernel that runs beside this one; a C4 cuboid has ~20 observing cameras)
+  extern __shared__ double elim_lds[];
+  double (*M)[54] = reinterpret_cast<double (*)[54]>(elim_lds);
+  double (*G)[54] = reinterpret_cast<double (*)[54]>(elim_lds + 54 * (size_t)v.elim_max_slots);
   __shared__ double A[9][9], Di[9][9], bo[9];
   const int o = blockIdx.x, t = threadIdx.x;
   if (v.cub_col[o] < 0 || !v.cub_mine[o]) return;      // another rank's cuboid: its partial blocks, M and D^-1 stay zero here
@@ -1131,35 +1135,44 @@ __global__ __launch_bounds__(256) void ba_cub_elim_kernel(BaView v, const double
   }
   for (int e = t; e < 81; e += 256) A[e / 9][e % 9] = v.Hcub[81 * (size_t)o + e] + ((e / 9 == e % 9) ? lambda : 0.0);
   __syncthreads();
-  if (t == 0) {
-    // Cholesky A = L L^T, then Di = L^-T L^-1 (9 x 9: a few hundred flops, one lane)
-    double L[9][9], X[9][9];
+  // Cholesky A = L L^T, then Di = L^-T L^-1 (9 x 9).  Round 6: on the lanes of the first wave with L and X in LDS -- as one lane with L and X
+  // as local arrays (dynamic indices: 1.3 KB of scratch per lane) it was ~1 500 dependent scratch accesses, most of the kernel's 80-95 us.
+  // Every entry is formed by the same operations in the same order as before (a column of L by the lanes of its rows, a column of L^-1 by
+  // one lane, an entry of Di by one lane): the same bits.
+  __shared__ double Lm[9][9], Xm[9][9];
+  if (t < 64) {
     bool fail = false;
     for (int j = 0; j < 9; j++) {
       double d = A[j][j];
-      for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
+      for (int k = 0; k < j; k++) d -= Lm[j][k] * Lm[j][k];
       if (!(d > 0.0)) { fail = true; d = 1.0; }
       const double r = sqrt(d);
-      L[j][j] = r;
-      for (int i = j + 1; i < 9; i++) {
-        double sv = A[i][j];
-        for (int k = 0; k < j; k++) sv -= L[i][k] * L[j][k];
-        L[i][j] = sv / r;
+      if (t == j) Lm[j][j] = r;
+      if (t > j && t < 9) {
+        double sv = A[t][j];
+        for (int k = 0; k < j; k++) sv -= Lm[t][k] * Lm[j][k];
+        Lm[t][j] = sv / r;
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    for (int c = 0; c < 9; c++)          // X = L^-1 (lower triangular), column by column
+    if (t < 9) {         // X = L^-1 (lower triangular): lane c forms column c
+      const int c = t;
       for (int i = 0; i < 9; i++) {
         double sv = (i == c) ? 1.0 : 0.0;
-        for (int k = c; k < i; k++) sv -= L[i][k] * X[k][c];
-        X[i][c] = (i >= c) ? sv / L[i][i] : 0.0;
+        for (int k = c; k < i; k++) sv -= Lm[i][k] * Xm[k][c];
+        Xm[i][c] = (i >= c) ? sv / Lm[i][i] : 0.0;
       }
-    for (int i = 0; i < 9; i++)
-      for (int j = 0; j < 9; j++) {
-        double sv = 0;
-        for (int k = (i > j ? i : j); k < 9; k++) sv += X[k][i] * X[k][j];
-        Di[i][j] = sv;
-      }
-    if (fail) atomicExch(v.elim_fail, 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int e = t; e < 81; e += 64) {
+      const int i = e / 9, j = e - 9 * i;
+      double sv = 0;
+      for (int k = (i > j ? i : j); k < 9; k++) sv += Xm[k][i] * Xm[k][j];
+      Di[i][j] = sv;
+    }
+    if (fail && t == 0) atomicExch(v.elim_fail, 1);
   }
   __syncthreads();
   for (int e = t; e < 81; e += 256) v.cub_Dinv[81 * (size_t)o + e] = Di[e / 9][e % 9];
@@ -1183,9 +1196,14 @@ __global__ __launch_bounds__(256) void ba_cub_elim_kernel(BaView v, const double
   const int npair = ns * (ns + 1) / 2;
   for (int e = t; e < npair * 36; e += 256) {
     const int pr = e / 36, rc = e % 36, r = rc / 6, c = rc % 6;
-    int a = 0, rem = pr;
-    while (rem >= ns - a) { rem -= ns - a; a++; }
-    const int b = a + rem;
+    // pair index -> (a, b), a <= b: pr = a ns - a (a - 1) / 2 + (b - a)  (closed form + correction, as ba_schur_long_kernel; the walk over
+    // the rows it replaces was up to ns steps for every one of the block's 36 entries)
+    const float tk = (float)(2 * ns + 1);
+    int a = (int)((tk - __builtin_sqrtf(tk * tk - 8.0f * (float)pr)) * 0.5f);
+    a = max(0, min(ns - 1, a));
+    while (a > 0 && a * ns - a * (a - 1) / 2 > pr) a--;
+    while ((a + 1) * ns - (a + 1) * a / 2 <= pr) a++;
+    const int b = a + (pr - (a * ns - a * (a - 1) / 2));
     double sv = 0;
     for (int m = 0; m < 9; m++) sv += G[a][9 * r + m] * M[b][9 * c + m];
     v.part_tiles[36 * (size_t)(v.cub_tile[o] + pr) + rc] = sv;
@@ -2645,7 +2663,7 @@ void ba_launch_reduce(const BaView& v, const double* lambda, hipStream_t st, hip
     if (side) {
       (void)hipEventRecord(ev_fork, st);
       (void)hipStreamWaitEvent(st2, ev_fork, 0);
-      hipLaunchKernelGGL(ba_cub_elim_kernel, dim3(v.no), dim3(256), 0, st2, v, lambda);
+      hipLaunchKernelGGL(ba_cub_elim_kernel, dim3(v.no), dim3(256), 2 * 54 * sizeof(double) * (size_t)v.elim_max_slots, st2, v, lambda);
     }
     // (the cuboid elimination must be dispatched BEFORE the bulk of the segments fills the device: started 18 us ahead -- behind the short
     // kernel of the one- and two-camera segments below -- its 500 workgroups run 90 us beside the bulk; started together with it they
@@ -2673,7 +2691,7 @@ void ba_launch_reduce(const BaView& v, const double* lambda, hipStream_t st, hip
       if (v.n_seg > c4) hipLaunchKernelGGL(ba_schur_long_kernel, dim3((v.n_seg - c4 + 3) / 4), dim3(256), 0, st, v, lambda, c4, v.n_seg);
     }
     if (side) (void)hipStreamWaitEvent(st, ev_join, 0);
-    else if (v.elim && v.no > 0) hipLaunchKernelGGL(ba_cub_elim_kernel, dim3(v.no), dim3(256), 0, st, v, lambda);
+    else if (v.elim && v.no > 0) hipLaunchKernelGGL(ba_cub_elim_kernel, dim3(v.no), dim3(256), 2 * 54 * sizeof(double) * (size_t)v.elim_max_slots, st, v, lambda);
     hipLaunchKernelGGL(ba_cam_rhs_fused_kernel, dim3(v.nc), dim3(64), 0, st, v, lambda);
     if (!v.elim && v.no > 0) hipLaunchKernelGGL(ba_cub_scatter_kernel, dim3(v.no), dim3(128), 0, st, v, lambda);
     if (v.n_cub + v.n_odom > 0) hipLaunchKernelGGL(ba_offdiag_kernel, dim3(v.n_cub + v.n_odom), dim3(64), 0, st, v);

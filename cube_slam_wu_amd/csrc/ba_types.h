@@ -18,6 +18,7 @@ struct BaView {
   const int* cub_col;  // no
   const int* pt_free;  // np: 1 = optimised, 0 = fixed
   int nc, np, no, n_pose;
+  int elim_max_slots;     // observing cameras of the widest free cuboid (sizes ba_cub_elim_kernel's dynamic LDS; <= BA_ELIM_MAX_SLOTS)
   // The system the solver factorises has n_red unknowns: n_pose (cameras and cuboids, g2o's reduced system) or, with elim = 1, the
   // cameras only -- the free cuboids are then eliminated like landmarks (S_cc -= H_co D_oo^-1 H_co^T, block_solver.hpp:385-431
   // applied to the 9 x 9 blocks too) and their increments live behind the reduced system's in `rhs` (cub_col >= n_red).
