@@ -40,6 +40,7 @@
 #include <vector>
 
 #include "Thirdparty/g2o/g2o/core/solver.h"
+#include "Thirdparty/g2o/g2o/core/sparse_block_matrix.h"
 #include "Thirdparty/g2o/g2o/core/sparse_optimizer.h"
 #include "Thirdparty/g2o/g2o/core/robust_kernel_impl.h"
 #include "Thirdparty/g2o/g2o/types/types_six_dof_expmap.h"
@@ -140,7 +141,46 @@ class BlockSolverHIP : public g2o::Solver {
     for (const Perm& p : perm_) std::copy(lib_.begin() + p.lib, lib_.begin() + p.lib + p.dim, _x + p.g2o);
     return true;
   }
-  virtual bool computeMarginals(g2o::SparseBlockMatrix<g2o::MatrixXd>&, const std::vector<std::pair<int, int> >&) { return false; }
+  // core/block_solver.hpp:488-499 -> LinearSolver::solvePattern(spinv, blockIndices, *_Hpp) -> MarginalCovarianceCholesky::computeCovariance
+  // (core/marginal_covariance_cholesky.cpp:154-222): spinv is re-created over the pose blocks' row layout and receives block (first, second) of
+  // the inverse of H_pp for every requested pair of hessian indices.  cs_ba_pose_marginals does the factorisation and the solves on the device.
+  // (Pairs that name a marginalised vertex -- a point -- are outside _Hpp in the reference too: refused.)
+  virtual bool computeMarginals(g2o::SparseBlockMatrix<g2o::MatrixXd>& spinv, const std::vector<std::pair<int, int> >& blockIndices) {
+    if (!ba_) return refuse("computeMarginals before buildStructure");
+    const auto& im = _optimizer->indexMapping();
+    std::vector<int> rbi;                                  // end column of every non-marginalised vertex's block, in hessian-index order
+    std::vector<Slot> slot_of;
+    int end = 0;
+    for (auto* v : im) {
+      if (v->marginalized()) break;                        // (indexMapping: the non-marginalised vertices first, sparse_optimizer.cpp:166-190)
+      end += v->dimension();
+      rbi.push_back(end);
+      slot_of.push_back(index_[v]);
+    }
+    if (rbi.empty()) return refuse("computeMarginals: no pose vertex in the graph");
+    std::vector<int> ci, ii, cj, ij;
+    size_t total = 0;
+    for (const auto& pr : blockIndices) {
+      if (pr.first < 0 || pr.second < 0 || pr.first >= (int)rbi.size() || pr.second >= (int)rbi.size()) return refuse("computeMarginals: a block index outside the pose block (a marginalised vertex?)");
+      const Slot a = slot_of[pr.first], b = slot_of[pr.second];
+      ci.push_back(a.cls); ii.push_back(a.idx); cj.push_back(b.cls); ij.push_back(b.idx);
+      total += (size_t)(a.cls == CS_VERTEX_CAM ? 6 : 9) * (size_t)(b.cls == CS_VERTEX_CAM ? 6 : 9);
+    }
+    std::vector<double> blocks(total + 1);
+    int pd = 1;
+    if (cs_ba_pose_marginals(ba_, (int)blockIndices.size(), ci.data(), ii.data(), cj.data(), ij.data(), blocks.data(), &pd) != CS_OK) return fail("cs_ba_pose_marginals");
+    if (!pd) return false;                                 // (Cholesky failure: the reference's solvePattern returns false)
+    spinv = g2o::SparseBlockMatrix<g2o::MatrixXd>(&rbi[0], &rbi[0], (int)rbi.size(), (int)rbi.size(), true);
+    size_t o = 0;
+    for (size_t k = 0; k < blockIndices.size(); k++) {
+      g2o::MatrixXd* blk = spinv.block(blockIndices[k].first, blockIndices[k].second, true);
+      if (!blk) return refuse("computeMarginals: SparseBlockMatrix::block returned null");
+      const int dr = ci[k] == CS_VERTEX_CAM ? 6 : 9, dc = cj[k] == CS_VERTEX_CAM ? 6 : 9;
+      for (int r = 0; r < dr; r++) for (int c = 0; c < dc; c++) (*blk)(r, c) = blocks[o + (size_t)r * dc + c];
+      o += (size_t)dr * dc;
+    }
+    return true;
+  }
   virtual bool schur() { return true; }
   virtual void setSchur(bool) {}
   virtual bool supportsSchur() { return true; }

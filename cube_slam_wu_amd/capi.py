@@ -420,7 +420,7 @@ DECLARED_SYMBOLS += [
     "cs_ba_compute_errors", "cs_ba_build_system", "cs_ba_solve", "cs_ba_update", "cs_ba_push", "cs_ba_pop", "cs_ba_optimize",
     "cs_ba_get_state", "cs_ba_sizes", "cs_ba_solver_layout", "cs_ba_get_system", "cs_ba_last_timing", "cs_ba_set_shard", "cs_ba_optimize_sharded",
     "cs_ba_shard_landmark_owners", "cs_ba_get_landmark_owners", "cs_ba_shard_info", "cs_ba_shard_timing", "cs_ba_append_vertices", "cs_ba_append_edges_proj", "cs_ba_append_edges_cuboid", "cs_ba_append_edges_cuboid_proj", "cs_ba_append_edges_odom", "cs_ba_get_vertex_hessians", "cs_ba_schur_layout", "cs_ba_structure_digest", "cs_ba_reduced_size", "cs_ba_solver_path", "cs_ba_band_order", "cs_ba_comm_unique_id", "cs_ba_comm_init", "cs_ba_set_robust_kernels",
-    "cs_ba_set_external_edges", "cs_ba_set_external_terms", "cs_ba_set_external_chi2", "cs_ba_set_external_callback", "cs_ba_check_finite", "cs_ba_dump", "cs_ba_load", "cs_ba_get_reduced_system", "cs_ba_set_stage_timing",
+    "cs_ba_set_external_edges", "cs_ba_set_external_terms", "cs_ba_set_external_chi2", "cs_ba_set_external_callback", "cs_ba_check_finite", "cs_ba_dump", "cs_ba_load", "cs_ba_get_reduced_system", "cs_ba_set_stage_timing", "cs_ba_pose_marginals",
 ]
 
 
@@ -550,6 +550,21 @@ class BaProblem:
         Hpp, Hll, Hpl, b = (np.zeros((n, n)) if dense_hpp else None), np.zeros((nl // 3, 9)), np.zeros((self.n_proj, 18)), np.zeros(n + nl)
         _chk(lib().cs_ba_get_system(self.h, _dp(Hpp) if dense_hpp else None, _dp(Hll), _dp(Hpl), _dp(b), None), "cs_ba_get_system")
         return Hpp, Hll, Hpl, b
+
+    def pose_marginals(self, pairs):
+        """cs_ba_pose_marginals (Solver::computeMarginals): pairs = [((class_i, idx_i), (class_j, idx_j)), ...] with class 0 = camera (6), 1 = cuboid (9);
+        -> (list of d_i x d_j blocks of inv(H_pp), positive_definite)."""
+        n = len(pairs)
+        ci = np.array([p[0][0] for p in pairs], np.int32); ii = np.array([p[0][1] for p in pairs], np.int32)
+        cj = np.array([p[1][0] for p in pairs], np.int32); ij = np.array([p[1][1] for p in pairs], np.int32)
+        dims = [({0: 6, 1: 9}.get(int(a), 3), {0: 6, 1: 9}.get(int(b), 3)) for a, b in zip(ci, cj)]      # (a point: the library refuses it)
+        out = np.zeros(max(1, sum(a * b for a, b in dims)))
+        pd = C.c_int(1)
+        _chk(lib().cs_ba_pose_marginals(self.h, n, _ip(ci), _ip(ii), _ip(cj), _ip(ij), _dp(out), C.byref(pd)), "cs_ba_pose_marginals")
+        blocks, o = [], 0
+        for a, b in dims:
+            blocks.append(out[o:o + a * b].reshape(a, b).copy()); o += a * b
+        return blocks, bool(pd.value)
 
     def reduced_system(self, lam):
         """(S dense n_red x n_red, rhs, camera columns, cuboid columns) in solver order -- cs_ba_get_reduced_system."""

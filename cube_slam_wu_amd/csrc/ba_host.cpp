@@ -27,6 +27,7 @@
 #include <string>
 #include <mutex>
 #include <thread>
+#include <map>
 #include <vector>
 
 #include "../../include/cubeslam_hip.h"
@@ -2726,6 +2727,77 @@ int cs_ba_get_system(cs_ba* B, double* Hpp, double* Hll9, double* Hpl18, double*
   BA_GUARD_BEGIN
   return cs_ba_get_system_impl(B, Hpp, Hll9, Hpl18, b, x);
   BA_GUARD_END("cs_ba_get_system")
+}
+
+// Solver::computeMarginals (core/block_solver.hpp:488-499): LinearSolver::solvePattern(spinv, blockIndices, *_Hpp) -- blocks of the INVERSE of
+// the pose-pose Hessian H_pp as buildSystem left it (no lambda: restoreDiagonal has run; no Schur complement: the reference's call factorises
+// _Hpp itself, core/marginal_covariance_cholesky.cpp:154-222).  Block k = rows of vertex (class_i[k], idx_i[k]) x columns of vertex
+// (class_j[k], idx_j[k]), row-major, d_i x d_j doubles (6 per camera, 9 per cuboid), one after the other in `out`.  H_pp is assembled dense in
+// g2o's index order (as cs_ba_get_system), factorised by rocSOLVER, and the columns of the requested j-vertices are solved for: a call for
+// inspection and for covariance queries of a handful of vertices, not a per-iteration path.  Returns CS_ERR_NOT_RUN before cs_ba_build_system,
+// CS_ERR_INVALID_ARG for a fixed vertex or a point, *positive_definite = 0 (and CS_OK) when the factorisation fails (g2o: false).
+static int cs_ba_pose_marginals_impl(cs_ba* B, int n_pairs, const int* class_i, const int* idx_i, const int* class_j, const int* idx_j, double* out, int* positive_definite) {
+  if (!B || n_pairs < 0 || (n_pairs && (!class_i || !idx_i || !class_j || !idx_j || !out))) return CS_ERR_INVALID_ARG;
+  if (positive_definite) *positive_definite = 1;
+  if (B->structure_dirty || !B->have_system) { cs_set_error_ba("cs_ba_pose_marginals: call cs_ba_build_system first"); return CS_ERR_NOT_RUN; }
+  if (B->shard_n > 1) { cs_set_error_ba("cs_ba_pose_marginals: not on a sharded handle (a rank holds a partial system)"); return CS_ERR_INVALID_ARG; }
+  if (n_pairs == 0) return CS_OK;
+  const int n = B->n_pose;
+  if (n <= 0) { cs_set_error_ba("cs_ba_pose_marginals: the graph has no free camera or cuboid"); return CS_ERR_INVALID_ARG; }
+  if ((long long)n * n > (1ll << 28)) { cs_set_error_ba("cs_ba_pose_marginals: the dense pose Hessian would exceed 2 GB"); return CS_ERR_CAPACITY; }
+  auto col_of = [&](int cls, int idx, int& dim) -> int {
+    if (cls == CS_VERTEX_CAM) { dim = 6; return (idx >= 0 && idx < B->nc) ? B->cam_col_ref[idx] : -1; }
+    if (cls == CS_VERTEX_CUBOID) { dim = 9; return (idx >= 0 && idx < B->no) ? B->cub_col_ref[idx] : -1; }
+    dim = 0; return -1;
+  };
+  // the distinct column vertices: one block column of right-hand sides each
+  std::vector<int> col_base, col_dim, rhs_of_pair(n_pairs);
+  std::map<int, int> rhs_at;            // pose column -> first right-hand-side column
+  int m = 0;
+  for (int k = 0; k < n_pairs; k++) {
+    int di, dj;
+    const int ci = col_of(class_i[k], idx_i[k], di), cj = col_of(class_j[k], idx_j[k], dj);
+    if (ci < 0 || cj < 0) { cs_set_error_ba("cs_ba_pose_marginals: pair " + std::to_string(k) + " names a fixed vertex, a point or an index out of range"); return CS_ERR_INVALID_ARG; }
+    auto it = rhs_at.find(cj);
+    if (it == rhs_at.end()) { it = rhs_at.emplace(cj, m).first; col_base.push_back(cj); col_dim.push_back(dj); m += dj; }
+    rhs_of_pair[k] = it->second;
+  }
+  BA_TRY(hipSetDevice(B->device));
+  BA_TRY(hipStreamSynchronize(B->st));
+  std::vector<double> H((size_t)n * n);
+  { const int rc = cs_ba_get_system_impl(B, H.data(), nullptr, nullptr, nullptr, nullptr); if (rc) return rc; }
+  std::vector<double> E((size_t)n * m, 0.0);      // column-major n x m: unit vectors
+  for (size_t q = 0, c0 = 0; q < col_base.size(); c0 += col_dim[q], q++)
+    for (int d = 0; d < col_dim[q]; d++) E[(c0 + d) * (size_t)n + col_base[q] + d] = 1.0;
+  DBuf<double> dH, dE;
+  DBuf<int> dinfo;
+  struct Rel { DBuf<double>&a, &b; DBuf<int>& c; ~Rel() { a.release(); b.release(); c.release(); } } rel{dH, dE, dinfo};
+  int rc;
+  if ((rc = dH.reserve((size_t)n * n)) || (rc = dE.reserve((size_t)n * m)) || (rc = dinfo.reserve(1))) return rc;
+  BA_TRY(hipMemcpyAsync(dH.p, H.data(), 8 * H.size(), hipMemcpyHostToDevice, B->st));
+  BA_TRY(hipMemcpyAsync(dE.p, E.data(), 8 * E.size(), hipMemcpyHostToDevice, B->st));
+  BA_ROC(rocblas_set_stream(B->blas, B->st));
+  BA_ROC(rocsolver_dpotrf(B->blas, rocblas_fill_upper, n, dH.p, n, dinfo.p));      // (symmetric: row- and column-major are the same matrix)
+  int info = 0;
+  BA_TRY(hipMemcpyAsync(&info, dinfo.p, sizeof(int), hipMemcpyDeviceToHost, B->st));
+  BA_TRY(hipStreamSynchronize(B->st));
+  if (info != 0) { if (positive_definite) *positive_definite = 0; return CS_OK; }
+  BA_ROC(rocsolver_dpotrs(B->blas, rocblas_fill_upper, n, m, dH.p, n, dE.p, n));
+  BA_TRY(hipMemcpyAsync(E.data(), dE.p, 8 * E.size(), hipMemcpyDeviceToHost, B->st));
+  BA_TRY(hipStreamSynchronize(B->st));
+  size_t o = 0;
+  for (int k = 0; k < n_pairs; k++) {
+    int di, dj;
+    const int ci = col_of(class_i[k], idx_i[k], di);
+    (void)col_of(class_j[k], idx_j[k], dj);
+    for (int r = 0; r < di; r++) for (int c = 0; c < dj; c++) out[o++] = E[(size_t)(rhs_of_pair[k] + c) * n + ci + r];
+  }
+  return CS_OK;
+}
+int cs_ba_pose_marginals(cs_ba* B, int n_pairs, const int* class_i, const int* idx_i, const int* class_j, const int* idx_j, double* out, int* positive_definite) {
+  BA_GUARD_BEGIN
+  return cs_ba_pose_marginals_impl(B, n_pairs, class_i, idx_i, class_j, idx_j, out, positive_definite);
+  BA_GUARD_END("cs_ba_pose_marginals")
 }
 
 // Inspection for parity tests: the damped reduced system exactly as the solver is about to factorise it -- dense symmetric n_red x n_red

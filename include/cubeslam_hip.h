@@ -427,6 +427,12 @@ int cs_ba_structure_digest(cs_ba* ba, unsigned long long* out, int cap, int* n_t
 /* Inspection for parity tests (host copies, caller-sized): dense Hpp (size_pose^2, no lambda), Hll (9 per
  * free point in point order), Hpl (18 per projection edge in the caller's edge order), b, x.            */
 int cs_ba_get_system(cs_ba* ba, double* Hpp_dense, double* Hll9, double* Hpl18, double* b, double* x);
+/* Solver::computeMarginals (core/block_solver.hpp:488-499 -> LinearSolver::solvePattern on _Hpp, core/marginal_covariance_cholesky.cpp:154-222):
+ * blocks of the inverse of the pose-pose Hessian as cs_ba_build_system left it (no lambda, no Schur complement -- what the reference's call
+ * factorises).  Pair k = rows of vertex (class_i[k], idx_i[k]) x columns of vertex (class_j[k], idx_j[k]) (cs_vertex_class: cameras 6, cuboids
+ * 9; free vertices only), written row-major one after the other into `out`.  *positive_definite = 0 when H_pp cannot be factorised (g2o
+ * returns false there).  A query call (dense rocSOLVER factorisation of H_pp), not a per-iteration path.                                  */
+int cs_ba_pose_marginals(cs_ba* ba, int n_pairs, const int* class_i, const int* idx_i, const int* class_j, const int* idx_j, double* out, int* positive_definite);
 
 /* The damped reduced system as the solver is about to factorise it (the Schur-complement build of block_solver.hpp:373-439 at `lambda`
  * on the current linearisation, no factorisation): S_dense n_red x n_red symmetric (n_red from cs_ba_reduced_size), rhs n_red, and the

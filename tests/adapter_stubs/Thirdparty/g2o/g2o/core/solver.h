@@ -57,7 +57,7 @@ class OptimizableGraph : public HyperGraph {   // core/optimizable_graph.h:127-5
   };
   JacobianWorkspace& jacobianWorkspace();
 };
-template <class M> class SparseBlockMatrix;
+template <class M> class SparseBlockMatrix;      // (core/solver.h includes sparse_block_matrix.h; the stand-in for it is a file of its own)
 class SparseOptimizer;
 class Solver {
  public:

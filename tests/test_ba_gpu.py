@@ -329,6 +329,40 @@ def test_system_parity_all_edge_types():
     assert _rel(x_g, x_r) < 1e-5
 
 
+def test_pose_marginals_are_blocks_of_the_inverse_pose_hessian():
+    """cs_ba_pose_marginals = Solver::computeMarginals (core/block_solver.hpp:488-499: LinearSolver::solvePattern on _Hpp, i.e. blocks of
+    inv(H_pp) as buildSystem left it -- no lambda, no Schur complement): camera-camera, camera-cuboid, cuboid-cuboid and off-diagonal blocks
+    against numpy's inverse of the device's own dense H_pp (1e-9) and of the ORACLE's H_pp (1e-5: numeric Jacobians inside); a fixed vertex
+    is refused; before cs_ba_build_system the call says so."""
+    pr = synth_ba.make_problem(n_cams=30, n_points=1500, n_cuboids=6, seed=11)
+    G, R = capi.ba_from_dict(pr), _oracle(pr)
+    with pytest.raises(RuntimeError):
+        G.pose_marginals([((0, 1), (0, 1))])
+    G.compute_errors(); R.compute_errors()
+    Hpp_g = G.build_system()[0]
+    Hpp_r = R.build_system()[0]
+    cam_fixed, cub_fixed = np.asarray(pr["cam_fixed"]), np.asarray(pr["cub_fixed"])
+    assert cam_fixed[0] and not cam_fixed[1:].any() and not cub_fixed.any()
+    nfree = int((cam_fixed == 0).sum())
+    cam_col = {i: 6 * (int((cam_fixed[:i] == 0).sum())) for i in range(len(cam_fixed)) if not cam_fixed[i]}
+    cub_col = {j: 6 * nfree + 9 * j for j in range(len(cub_fixed))}
+    pairs = [((0, 1), (0, 1)), ((0, 5), (0, 9)), ((0, 9), (0, 5)), ((0, 3), (1, 2)), ((1, 2), (0, 3)), ((1, 4), (1, 4)), ((1, 0), (1, 5)), ((0, 29), (0, 29))]
+    blocks, pd = G.pose_marginals(pairs)
+    assert pd
+    inv_g, inv_r = np.linalg.inv(Hpp_g), np.linalg.inv(Hpp_r)
+    for ((ca, ia), (cb, ib)), blk in zip(pairs, blocks):
+        r0 = cam_col[ia] if ca == 0 else cub_col[ia]; c0 = cam_col[ib] if cb == 0 else cub_col[ib]
+        da, db = (6, 9)[ca], (6, 9)[cb]
+        assert blk.shape == (da, db)
+        assert _rel(blk, inv_g[r0:r0 + da, c0:c0 + db]) < 1e-9, (ia, ib)
+        assert _rel(blk, inv_r[r0:r0 + da, c0:c0 + db]) < 1e-4, (ia, ib)
+    with pytest.raises(RuntimeError):
+        G.pose_marginals([((0, 0), (0, 1))])       # camera 0 is fixed
+    with pytest.raises(RuntimeError):
+        G.pose_marginals([((2, 0), (0, 1))])       # a point
+    G.close()
+
+
 @pytest.mark.parametrize("huber", [True, False])
 def test_optimize_parity_10_iterations(huber):
     pr = synth_ba.make_problem(n_cams=40, n_points=2500, n_cuboids=8, seed=3, huber=huber)
