@@ -798,9 +798,10 @@ def main():
         det.edge_distance_maps_time(grays, rois[:64], roi_img[:64])     # warm-up
         ms = det.edge_distance_maps_time(grays, rois, roi_img)
         px = sum(w * h for _, _, w, h in rois)
-        edge_out = {"what": "cv::Canny(80,200) + cv::distanceTransform(DIST_L2,3) of every ROI, on the device (edge_canny_kernel + edge_dt_kernel)",
+        edge_out = {"what": "cv::Canny(80,200) + cv::distanceTransform(DIST_L2,3) of every ROI, on the device",
                     "rois": len(rois), "pixels": int(px), "device_ms": ms, "rois_per_s": len(rois) / (ms * 1e-3), "ms_per_1000_frames": ms * 1000.0 / max(1, args.frames),
-                    "alg_bytes": int(px * (1 + 1 + 1 + 4 * 3)), "GB/s": px * 15 / (ms * 1e-3) / 1e9}
+                    "alg_bytes": int(px * (1 + 1 + 1 + 4 * 3)), "GB/s": px * 15 / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": px * 15 / (ms * 1e-3) / 1e9 / 8000.0,
+                    "kernels": "edge_canny_bits_kernel (gray band in LDS, four Sobel responses per lane, hysteresis on bit planes in LDS) + edge_dt_kernel, workgroups largest ROI first"}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import edge_oracle_py
             edge_oracle_py.lib()
