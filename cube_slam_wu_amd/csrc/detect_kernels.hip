@@ -454,6 +454,12 @@ __global__ __launch_bounds__(256) void candidate_compact_kernel(DetectDeviceView
   }
   __syncthreads();        // (one workgroup, one CU: the rows written above are read back below)
   const unsigned half = (unsigned)n_vp * (unsigned)jd.T;            // proposals per configuration
+  // rest / T by one multiplication (T is uniform; the generic 32-bit division is ~20 instructions per slot): m = floor(2^32 / T) + 1 gives
+  // floor(rest m / 2^32) = floor(rest / T) whenever rest T < 2^32 (the error term rest (m T - 2^32) / (2^32 T) stays below 1 / T);
+  // rest < half, so half T < 2^32 decides -- otherwise (never at any image size: n_vp T^2 in the millions) the division itself
+  const unsigned Tu = (unsigned)jd.T;
+  const bool fast_div = Tu > 1 && (unsigned long long)half * Tu < (1ull << 32);
+  const unsigned inv_T = fast_div ? 0xffffffffu / Tu + 1u : 0u;
   const long long base = v.slot_prefix[j];
   long long run = base;
   const unsigned long long below = (1ull << lane) - 1ull;
@@ -466,8 +472,8 @@ __global__ __launch_bounds__(256) void candidate_compact_kernel(DetectDeviceView
       const unsigned rl = (unsigned)(q & 7) * 256u + (unsigned)tid, rest = r0 + rl;
       int flag = 0;
       if (rest < half && (cfg == 1 ? en1 : en2)) {
-        const unsigned ryu = rest / (unsigned)jd.T;
-        const int t = (int)(rest - ryu * (unsigned)jd.T);
+        const unsigned ryu = fast_div ? __umulhi(rest, inv_T) : rest / Tu;
+        const int t = (int)(rest - ryu * Tu);
         const double* vp = v.vp + 6 * (long long)(jd.vp_off + (int)ryu);
         V2 c[8];
         flag = build_corners(jd.g, v2(vp[0], vp[1]), v2(vp[2], vp[3]), v2(vp[4], vp[5]), (double)v.top_x[jd.top_off + t], cfg, sp.short_sq_bound, c);
