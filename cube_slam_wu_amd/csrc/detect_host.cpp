@@ -1321,7 +1321,7 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
     } else {   // the results: written to the pinned host pools by one kernel
       cs::CopySegs cp{};
       SEG(S.h_records, S.records, nb * KMAX); SEG(S.h_win_count, S.win_count, nb); SEG(S.h_fallback, S.fallback, nb);
-      SEG(S.h_job_valid, S.job_valid, nj); SEG(S.h_job_cbase, S.job_cbase, nj + 1); SEG(S.h_jobs_out, S.jobs, nj);
+      SEG(S.h_job_valid, S.job_valid, nj); SEG(S.h_job_cbase, S.job_cbase, nj + 1);      // (the job table itself is not read back: pipe_finish works from the host's own copy)
       cs::launch_multi_copy(cp, st);
     }
 #undef SEG

@@ -1,4 +1,4 @@
-ARGS="--no-measure-traffic --ba none --no-cpu-baseline --no-edge --rp-frames 0 --latency-calls 0 --lines-images 0 --steady-steps 0"
+ARGS="--no-measure-traffic --ba none --no-cpu-baseline --no-edge --rp-frames 0 --latency-calls 0 --lines-images 0 --steady-steps 0 --image-in-steps 0"
 for nt in 256 128 64; do
   export CS_RANK_THREADS=$nt
   echo "== rank threads $nt"
