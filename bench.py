@@ -76,7 +76,7 @@ def measure_valu_issue_live(args, n_unique):
     instructions, summed over all SIMDs (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* are in quad-cycles); SQ_BUSY_CYCLES counts the cycles a
     shader engine's SQ is busy, summed over the 32 engines, each with 32 SIMDs.  None when the pass cannot run."""
     ctrs = ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY")
-    res = _pmc_child_pass(args, n_unique, ctrs, ("score_kernel", "candidate_kernel"))
+    res = _pmc_child_pass(args, n_unique, ctrs, ("score_kernel", "candidate_compact_kernel", "vp_support_kernel"))
     if not res:
         return None
     out = {"formula": "4 x SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES x %d SIMDs per shader engine): the share of the busy SIMD cycles in which a VALU instruction issues (counters per launch, one rocprofv3 --pmc pass, kernel-trace only, child run of this workload)" % SIMDS_PER_SE}
@@ -1053,7 +1053,7 @@ def main():
                                       "frac": FP64_FLOP_PER_PROPOSAL * (acc["n_valid"] / launches) / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS if kern_ms > 0 else 0.0},
                          # the bound the kernel really runs against: the share of busy SIMD cycles that issue a VALU instruction (SQ counters, this run)
                          "valu_issue": valu_issue,
-                         "other_kernels": {"candidate_kernel": {"ms": geo_ms, "alg_bytes": geo_bytes, "GB/s": geo_bytes / (geo_ms * 1e-3) / 1e9 if geo_ms > 0 else 0.0}}},
+                         "other_kernels": {"candidate_compact_kernel (vanishing points + corners + ordered compaction)": {"ms": geo_ms, "alg_bytes": geo_bytes, "GB/s": geo_bytes / (geo_ms * 1e-3) / 1e9 if geo_ms > 0 else 0.0}}},
             "stage_ms_per_step": {k: acc[k] / args.steps for k in acc if k.endswith("_ms")},
             "fallback_boxes_per_step": acc["n_fallback_boxes"] / args.steps,
         }

@@ -1362,7 +1362,9 @@ int pipe_finish(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>
     long long n_valid = 0;      // (the capacity layout has no running total: job_cbase[j] = slot_prefix[j])
     for (size_t j = 0; j < nj; j++) n_valid += S.h_job_valid.p[j];
     tm.n_valid += n_valid;
-    tm.cand_kernel_bytes += 48LL * S.vp_total + 4LL * S.slot_total;
+    // algorithmic bytes of the corner construction: the vanishing points it writes (48 B each) + what leaves it per slot -- a 4-byte flag per
+    // slot in the four-kernel form, 12 bytes (slot id, flag) per VALID proposal from candidate_compact_kernel
+    tm.cand_kernel_bytes += g_split_candidates ? 48LL * S.vp_total + 4LL * S.slot_total : 48LL * S.vp_total + 12LL * n_valid;
     long long sbytes = 96LL * S.vp_total + (28LL + 8LL + 4LL) * n_valid;
     for (size_t j = 0; j < nj; j++) if (S.h_jobs_in.p[j].Y > 0 && S.h_jobs_in.p[j].T > 0) sbytes += 4LL * S.h_jobs_in.p[j].map_w * (S.h_jobs_in.p[j].g.eb - S.h_jobs_in.p[j].g.et);
     tm.score_kernel_bytes += sbytes;
