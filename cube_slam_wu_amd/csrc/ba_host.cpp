@@ -36,6 +36,7 @@
 namespace cs {
 int ba_chi2_blocks(int n_proj);
 void ba_launch_chi2(const BaView& v, int nb_proj, hipStream_t st);
+void ba_launch_fill_rows4(double* dst, const double* rec4, long long rows, hipStream_t st);
 void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, hipStream_t st3, hipEvent_t ev_join3, hipEvent_t ev_pre = nullptr);
 void ba_launch_reduce(const BaView& v, const double* lambda_dev, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join);
 void ba_launch_gather_rows(const double* src, const int* idx, int n, int width, double* dst, hipStream_t st);
@@ -370,6 +371,9 @@ struct cs_ba {
   // every projection edge with the same information matrix / intrinsics (decided by comparing the caller's records when they are set or
   // appended): the kernels then read these 4 + 4 doubles instead of the per-edge records (BaView::info_u / intr_u).  CS_BA_UNIFORM=0: never.
   bool info_uniform = false, intr_uniform = false;
+  // the per-edge records are not stored while every edge carries the handle's reference record (uni8): 64 bytes per edge that no kernel would
+  // read -- a third of a C4 problem's upload; they are written out from the reference record the moment an appended edge brings another one
+  bool raw_info_virtual = false, raw_intr_virtual = false;
   double uni8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   DBuf<double> d_uni;
   bool have_huber = false;
@@ -1992,10 +1996,25 @@ int cs_ba_append_edges_proj(cs_ba* B, int n, const int* pt, const int* cam, cons
   BA_TRY(hipSetDevice(B->device));
   BA_TRY(hipStreamSynchronize(B->st));
   int rc;
-  scan_uniform_records(B, B->n_proj == 0, info4, intr4, n);
+  const bool first_edges = B->n_proj == 0;
+  scan_uniform_records(B, first_edges, info4, intr4, n);
+  if (first_edges) { B->raw_info_virtual = B->info_uniform; B->raw_intr_virtual = B->intr_uniform; B->raw_info.n = 0; B->raw_intr.n = 0; }
+  // an appended edge with another record: the records of the edges so far are written out from the reference record, then kept per edge
+  auto write_out = [&](DBuf<double>& raw, const double* rec4, bool& is_virtual) -> int {
+    int r = raw.reserve(4 * (size_t)(B->n_proj + n));
+    if (r) return r;
+    cs::ba_launch_fill_rows4(raw.p, rec4, B->n_proj, B->st);
+    BA_TRY(hipGetLastError());
+    raw.n = 4 * (size_t)B->n_proj;
+    is_virtual = false;
+    return CS_OK;
+  };
+  if (B->raw_info_virtual && !B->info_uniform && (rc = write_out(B->raw_info, B->uni8, B->raw_info_virtual))) return rc;
+  if (B->raw_intr_virtual && !B->intr_uniform && (rc = write_out(B->raw_intr, B->uni8 + 4, B->raw_intr_virtual))) return rc;
   if ((rc = append_arena(B))) return rc;
-  if ((rc = B->raw_uv.append_ptr_staged(uv, 2 * (size_t)n, B->append_stage, B->st)) || (rc = B->raw_info.append_ptr_staged(info4, 4 * (size_t)n, B->append_stage, B->st)) ||
-      (rc = B->raw_intr.append_ptr_staged(intr4, 4 * (size_t)n, B->append_stage, B->st))) return rc;
+  if ((rc = B->raw_uv.append_ptr_staged(uv, 2 * (size_t)n, B->append_stage, B->st))) return rc;
+  if (!B->raw_info_virtual && (rc = B->raw_info.append_ptr_staged(info4, 4 * (size_t)n, B->append_stage, B->st))) return rc;
+  if (!B->raw_intr_virtual && (rc = B->raw_intr.append_ptr_staged(intr4, 4 * (size_t)n, B->append_stage, B->st))) return rc;
   if (huber) { rc = B->raw_huber.append_ptr_staged(huber, (size_t)n, B->append_stage, B->st); if (rc) return rc; }
   B->have_huber = huber != nullptr;
   B->e_pt.insert(B->e_pt.end(), pt, pt + n); B->e_cam.insert(B->e_cam.end(), cam, cam + n);
@@ -2070,7 +2089,10 @@ static int cs_ba_set_edges_proj_impl(cs_ba* B, int n, const int* pt, const int* 
   BA_TRY(hipStreamSynchronize(B->st));       // (appended rows may still be on their way)
   int rc;
   scan_uniform_records(B, true, info4, intr4, n);
-  if ((rc = B->raw_uv.upload_ptr(uv, 2 * (size_t)n)) || (rc = B->raw_info.upload_ptr(info4, 4 * (size_t)n)) || (rc = B->raw_intr.upload_ptr(intr4, 4 * (size_t)n))) return rc;
+  if ((rc = B->raw_uv.upload_ptr(uv, 2 * (size_t)n))) return rc;
+  B->raw_info_virtual = B->info_uniform; B->raw_intr_virtual = B->intr_uniform;
+  if (B->raw_info_virtual) B->raw_info.n = 0; else if ((rc = B->raw_info.upload_ptr(info4, 4 * (size_t)n))) return rc;
+  if (B->raw_intr_virtual) B->raw_intr.n = 0; else if ((rc = B->raw_intr.upload_ptr(intr4, 4 * (size_t)n))) return rc;
   B->have_huber = huber != nullptr;
   B->rk_proj.clear();
   if (huber) { rc = B->raw_huber.upload_ptr(huber, (size_t)n); if (rc) return rc; } else B->raw_huber.release();
@@ -3041,8 +3063,10 @@ static int cs_ba_dump_impl(cs_ba* B, const char* path) {
   std::vector<double> cams(7 * (size_t)B->nc), cubs(10 * (size_t)B->no), pts(3 * (size_t)B->np), uv(2 * (size_t)np_e), info(4 * (size_t)np_e), intr(4 * (size_t)np_e), hub(B->have_huber ? np_e : 0);
   auto d2h = [&](std::vector<double>& h, const double* d) -> int { if (!h.empty()) BA_TRY(hipMemcpy(h.data(), d, 8 * h.size(), hipMemcpyDeviceToHost)); return CS_OK; };
   int rc;
-  if ((rc = d2h(cams, B->cams.p)) || (rc = d2h(cubs, B->cubes.p)) || (rc = d2h(pts, B->points.p)) || (rc = d2h(uv, B->raw_uv.p)) || (rc = d2h(info, B->raw_info.p)) ||
-      (rc = d2h(intr, B->raw_intr.p)) || (rc = d2h(hub, B->raw_huber.p))) return rc;
+  if ((rc = d2h(cams, B->cams.p)) || (rc = d2h(cubs, B->cubes.p)) || (rc = d2h(pts, B->points.p)) || (rc = d2h(uv, B->raw_uv.p)) || (rc = d2h(hub, B->raw_huber.p))) return rc;
+  // (records that were never stored -- every edge carries the reference record -- are written out here)
+  if (B->raw_info_virtual) { for (int k = 0; k < np_e; k++) std::memcpy(&info[4 * (size_t)k], B->uni8, 32); } else if ((rc = d2h(info, B->raw_info.p))) return rc;
+  if (B->raw_intr_virtual) { for (int k = 0; k < np_e; k++) std::memcpy(&intr[4 * (size_t)k], B->uni8 + 4, 32); } else if ((rc = d2h(intr, B->raw_intr.p))) return rc;
   FILE* f = fopen(path, "wb");
   if (!f) { cs_set_error_ba(std::string("cs_ba_dump: cannot open ") + path); return CS_ERR_INVALID_ARG; }
   DumpHeader H{};

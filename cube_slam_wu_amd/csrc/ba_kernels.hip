@@ -2610,6 +2610,18 @@ __global__ __launch_bounds__(256) void ba_gather_rows_kernel(const double* __res
   const int c = (int)(t - r * width);
   dst[t] = src[(long long)idx[r] * width + c];
 }
+// dst[r][0..4) = the same four doubles for every row: the per-edge information / intrinsics records of a graph whose edges all shared one
+// record, written out when an appended edge brings another (cs_ba_append_edges_proj) -- such a graph never uploads the records themselves
+__global__ __launch_bounds__(256) void ba_fill_rows4_kernel(double* __restrict__ dst, double a, double b, double c, double d, long long total) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int q = (int)(t & 3);
+  dst[t] = q == 0 ? a : (q == 1 ? b : (q == 2 ? c : d));
+}
+void ba_launch_fill_rows4(double* dst, const double* rec4, long long rows, hipStream_t st) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(ba_fill_rows4_kernel, dim3((unsigned)((4 * rows + 255) / 256)), dim3(256), 0, st, dst, rec4[0], rec4[1], rec4[2], rec4[3], 4 * rows);
+}
 void ba_launch_gather_rows(const double* src, const int* idx, int n, int width, double* dst, hipStream_t st) {
   const long long total = (long long)n * width;
   if (total <= 0) return;
