@@ -1174,7 +1174,13 @@ int finalize_structure(cs_ba* B) {
         o_tile[r + 1] = o_tile[r] + ns * (k * (k + 1) / 2); o_slot[r + 1] = o_slot[r] + ns * k;
       }
       run_lm.resize(o_lm[R]); run_e0.resize(o_lm[R]); seg_ptr.assign(o_seg[R] + 1, 0); seg_k.resize(o_seg[R]); seg_tile.resize(o_seg[R]); seg_slot.resize(o_seg[R]);
-      seg_cam.resize(o_cam[R]); dst.resize(o_dst[R]); cdst.resize(o_cd[R]);
+      seg_cam.resize(o_cam[R]);
+      {   // (room for what the eliminated cuboids append below: without it their first push_back copies the whole table)
+        size_t cub_dst = 0, cub_cd = 0;
+        if (B->elim) for (int o = 0; o < no; o++) if (!B->cub_fixed[o]) { const size_t kc = cub_cams[o].size(); cub_dst += kc * (kc + 1) / 2; cub_cd += kc; }
+        dst.reserve(o_dst[R] + cub_dst); cdst.reserve(o_cd[R] + cub_cd);
+      }
+      dst.resize(o_dst[R]); cdst.resize(o_cd[R]);
       run_items(NTs, [&](int t) {
         for (size_t r = R * t / NTs, r1 = R * (t + 1) / NTs; r < r1; r++) {
           const int k = rc_[r].k;
