@@ -250,7 +250,6 @@ __global__ __launch_bounds__(256) void edge_canny_bits_kernel(const unsigned cha
           const int ma = (int)(mid[j + 1 - step] & 0x7ffu), mb = (int)(mid[j + 1 + step] & 0x7ffu);
           const bool keep = m > low && m > ma && (sector < 2 ? m >= mb : m > mb);
           c = keep ? (m > high ? 2 : 0) : 1;
-          cls[i * w + j] = c;
         }
         const unsigned long long bs = __ballot(j < w && c == 2), bk = __ballot(j < w && c == 0);
         if (lane < 2) {
@@ -296,7 +295,6 @@ __global__ __launch_bounds__(256) void edge_canny_bits_kernel(const unsigned cha
             f &= k;
             Sp[at] = s_mid | f;
             k &= ~f;
-            for (unsigned t = f; t; t &= t - 1) cls[i * w + 32 * kw + (__ffs((int)t) - 1)] = 2;
           }
         }
         if (!__any(f != 0)) break;
@@ -306,7 +304,14 @@ __global__ __launch_bounds__(256) void edge_canny_bits_kernel(const unsigned cha
     }
     if (!__syncthreads_or(ch)) break;
   }
-
+  // ---- what the distance transform needs: the strong plane, a row of ceil(w / 8) bytes per ROI row (bit j & 7 of byte j >> 3 = pixel j is an
+  // edge) in the ROI's class-byte region -- an eighth of the class bytes, and neither the suppression nor the hysteresis writes a byte per pixel
+  const int RS = (w + 7) >> 3;
+  const unsigned inv_rs = cb_inv(RS);
+  for (int e = tid; e < h * RS; e += 256) {
+    const int i = cb_div(e, inv_rs), b = e - i * RS;
+    cls[e] = (unsigned char)(Sp[(i + 1) * Wd + (b >> 2)] >> (8 * (b & 3)));
+  }
 }
 
 // ---- hysteresis ----------------------------------------------------------------------------------------------------------------
@@ -555,12 +560,18 @@ __device__ __forceinline__ int wave_prefix_min(int v) {
 #endif
 enum { DT_CHUNKS = 6, DT_AHEAD = CS_DT_AHEAD };   // ROI widths up to 384 columns take the register-pipelined instances, 4 rows of operands in flight
 struct DtArgs { const unsigned char* cls; int* tmp; int* row_lds; int row_cap, w, h; };
+// pixel (row, column jc) is an edge: class byte 2, or -- BITS: the strong plane edge_canny_bits_kernel leaves, ceil(w / 8) bytes per row -- its bit
+template <bool BITS>
+__device__ __forceinline__ int dt_class(const unsigned char* __restrict__ cls, int w, int row, int jc) {
+  if (BITS) return (int)((cls[row * ((w + 7) >> 3) + (jc >> 3)] >> (jc & 7)) & 1u) << 1;
+  return cls[row * w + jc];
+}
 
 // The two passes for a ROI of exactly NC chunks of 64 columns.  Per row: the global operands (class bytes on the way down, the
 // forward distances on the way up) were requested one row ahead; the NC scans are independent of each other and of the
 // carry, which only enters the last minimum -- so a row costs one LDS round trip (neighbour row), one scan latency and NC
 // carry steps, not NC times all of it.
-template <int NC>
+template <int NC, bool BITS>
 __device__ __forceinline__ void edge_dt_rows(const DtArgs& A) {
   const int HV = 62587, DIAG = 89738, INF = 1 << 30;
   const float scale = 1.f / (1 << 16);
@@ -577,7 +588,7 @@ __device__ __forceinline__ void edge_dt_rows(const DtArgs& A) {
 #pragma unroll
   for (int u = 0; u < D; u++)
 #pragma unroll
-    for (int c = 0; c < NC; c++) { const int j = c * 64 + lane; pre[u][c] = (u < h) ? cls[u * w + min(j, w - 1)] : 0; }
+    for (int c = 0; c < NC; c++) { const int j = c * 64 + lane; pre[u][c] = (u < h) ? dt_class<BITS>(cls, w, u, min(j, w - 1)) : 0; }
   for (int i0 = 0; i0 < h; i0 += D) {
 #pragma unroll
     for (int u = 0; u < D; u++) {
@@ -590,7 +601,7 @@ __device__ __forceinline__ void edge_dt_rows(const DtArgs& A) {
         // with `if (j < w)` around the loads every chunk of every row cost several EXEC-mask branches, most of a row's latency)
         if (i + D < h) {
 #pragma unroll
-          for (int c = 0; c < NC; c++) { const int j = c * 64 + lane; pre[u][c] = cls[(i + D) * w + min(j, w - 1)]; }
+          for (int c = 0; c < NC; c++) { const int j = c * 64 + lane; pre[u][c] = dt_class<BITS>(cls, w, i + D, min(j, w - 1)); }
         }
 #pragma unroll
         for (int c = 0; c < NC; c++) {
@@ -656,6 +667,7 @@ __device__ __forceinline__ void edge_dt_rows(const DtArgs& A) {
 }
 
 // any width: the plain loop over chunks (no prefetch, chunk after chunk)
+template <bool BITS>
 __device__ __forceinline__ void edge_dt_rows_wide(const DtArgs& A) {
   const int HV = 62587, DIAG = 89738, INF = 1 << 30;
   const float scale = 1.f / (1 << 16);
@@ -673,7 +685,7 @@ __device__ __forceinline__ void edge_dt_rows_wide(const DtArgs& A) {
       int a = 0x7fffffff;
       if (j < w) {
         int t = 0;
-        if (cls[i * w + j] != 2) t = min(min(nb[j - 1] + DIAG, nb[j] + HV), nb[j + 1] + DIAG);
+        if (dt_class<BITS>(cls, w, i, j) != 2) t = min(min(nb[j - 1] + DIAG, nb[j] + HV), nb[j + 1] + DIAG);
         a = t - j * HV;
       }
       int d = wave_prefix_min(a);
@@ -708,20 +720,24 @@ __device__ __forceinline__ void edge_dt_rows_wide(const DtArgs& A) {
   }
 }
 
-__global__ __launch_bounds__(64) void edge_dt_kernel(const EdgeRoi* __restrict__ rois, const unsigned char* __restrict__ cls_pool, float* map_pool, int row_cap) {
+template <bool BITS>
+__device__ __forceinline__ void edge_dt_dispatch(const DtArgs& A, int w) {
+  switch ((w + 63) / 64) {
+    case 0: break;
+    case 1: edge_dt_rows<1, BITS>(A); break;
+    case 2: edge_dt_rows<2, BITS>(A); break;
+    case 3: edge_dt_rows<3, BITS>(A); break;
+    case 4: edge_dt_rows<4, BITS>(A); break;
+    case 5: edge_dt_rows<5, BITS>(A); break;
+    case 6: edge_dt_rows<6, BITS>(A); break;
+    default: edge_dt_rows_wide<BITS>(A); break;
+  }
+}
+__global__ __launch_bounds__(64) void edge_dt_kernel(const EdgeRoi* __restrict__ rois, const unsigned char* __restrict__ cls_pool, float* map_pool, int row_cap, int bits) {
   extern __shared__ int row_lds_i[];        // two rows of row_cap + 2 values (border cells at both ends): neighbour row, current row
   const EdgeRoi R = rois[blockIdx.x];
   const DtArgs A{cls_pool + R.cls_off, reinterpret_cast<int*>(map_pool + R.map_off), row_lds_i, row_cap, R.w, R.h};
-  switch ((R.w + 63) / 64) {
-    case 0: break;
-    case 1: edge_dt_rows<1>(A); break;
-    case 2: edge_dt_rows<2>(A); break;
-    case 3: edge_dt_rows<3>(A); break;
-    case 4: edge_dt_rows<4>(A); break;
-    case 5: edge_dt_rows<5>(A); break;
-    case 6: edge_dt_rows<6>(A); break;
-    default: edge_dt_rows_wide(A); break;
-  }
+  if (bits) edge_dt_dispatch<true>(A, R.w); else edge_dt_dispatch<false>(A, R.w);
 }
 
 // A handful of tables between PINNED host memory and device memory in ONE launch (either direction; the host side is addressed through the
@@ -761,7 +777,7 @@ void launch_edge_maps(const unsigned char* gray, int W, int H, const EdgeRoi* ro
   if ((force == 3 || (!force && fused)) && max_w <= CANNY_TILE_W && bits_lds <= 64 * 1024) {
     const size_t dt_lds = 2 * (size_t)(max_w + 2) * sizeof(unsigned);
     hipLaunchKernelGGL(edge_canny_bits_kernel, dim3(n_rois), dim3(256), bits_lds, st, gray, W, H, rois, cls_pool, low, high, max_w);
-    hipLaunchKernelGGL(edge_dt_kernel, dim3(n_rois), dim3(64), dt_lds, st, rois, cls_pool, map_pool, max_w);
+    hipLaunchKernelGGL(edge_dt_kernel, dim3(n_rois), dim3(64), dt_lds, st, rois, cls_pool, map_pool, max_w, 1);
     return;
   }
   hipLaunchKernelGGL(edge_canny_kernel, dim3(n_rois, (!fused && n_rois <= 64) ? 8 : 1), dim3(256), 0, st, gray, W, H, rois, cls_pool, map_pool, low, high, fused ? 1 : 0);
@@ -783,7 +799,7 @@ void launch_edge_maps(const unsigned char* gray, int W, int H, const EdgeRoi* ro
     if (max_px > small_px)
       hipLaunchKernelGGL(edge_hyst_kernel, dim3(n_rois), dim3(256), (size_t)big_px + 2 * HYST_LIST * sizeof(int), st, rois, cls_pool, map_pool, small_px, big_px, list_cap, 1);
   }
-  hipLaunchKernelGGL(edge_dt_kernel, dim3(n_rois), dim3(64), 2 * (size_t)(max_w + 2) * sizeof(unsigned), st, rois, cls_pool, map_pool, max_w);
+  hipLaunchKernelGGL(edge_dt_kernel, dim3(n_rois), dim3(64), 2 * (size_t)(max_w + 2) * sizeof(unsigned), st, rois, cls_pool, map_pool, max_w, 0);
 }
 
 }  // namespace cs
