@@ -559,6 +559,11 @@ __device__ __forceinline__ void slot_corners16(const DetectDeviceView& v, long l
 __device__ __forceinline__ int sel(int cfg, int a, int b) { return cfg ? b : a; }
 
 enum { SCORE_JOBS = 4, SCORE_SUB = 128, SCORE_BINS = SCORE_JOBS * SCORE_SUB };   // sort keys of score_kernel: (job within the block, configuration x top sample)
+// CAP (round 6): the capacity layout -- a workgroup's proposals are all of ONE job, so the job record is read through a uniform index (scalar
+// loads: its 34 words per lane were vector loads of one address) and the three integer divisions by T and Y per proposal are one
+// multiplication each (reciprocals formed once; exact while n d < 2^32, the division itself otherwise -- as in candidate_compact_kernel).
+__device__ __forceinline__ unsigned score_udiv(unsigned n, unsigned d, unsigned inv) { return inv ? __umulhi(n, inv) : n / d; }
+template <bool CAP>
 __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long long slot_total, double short_sq_bound) {
   // [coordinate: x0..x7, y0..y7][lane]: every lane keeps its proposal's corners in its own column (LDS because the edge tables index
   // them dynamically); lanes of a wave mostly ask for the same corner (sorted by configuration)
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
   // the grid is sized for the worst case (every slot valid) because the exact count lives on the device; spread the
   // ACTIVE blocks over the 8 XCDs (contiguous range per XCD), the surplus blocks exit immediately
   // (capacity layout, candidate_compact_kernel: the work list names the blocks of 256 rows that hold valid rows -- all of one job, leading the block)
-  const bool cap = v.blk_info != nullptr;
+  const bool cap = CAP;
   long long n_valid = cap ? 256ll * v.blk_info[0] : v.job_cbase[v.n_jobs];
   const long long per_xcd = ((n_valid + 255) / 256 + 7) / 8;
   const long long kx = blockIdx.x >> 3;
@@ -601,10 +606,13 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
     __syncthreads();
     int key = SCORE_BINS;                       // beyond the list: sorted last, skipped below
     if (i0 < n_valid) {
-      const int T0 = v.jobs[j0].T;
-      const unsigned loc = (unsigned)(slot0 - v.jobs[j0].slot_off);
+      const int jq = CAP ? __builtin_amdgcn_readfirstlane(s_job[0]) : j0;
+      const int T0 = v.jobs[jq].T;
+      const unsigned loc = (unsigned)(slot0 - v.jobs[jq].slot_off);
       const int jrel = j0 - s_job[0];                                                // jobs in this block, in order
-      const int sub = (int)(loc & 1) * T0 + (int)((loc >> 1) % (unsigned)T0);        // configuration-major, then top-edge sample
+      const unsigned hq = loc >> 1;
+      const unsigned qT = CAP ? score_udiv(hq, (unsigned)T0, ((unsigned long long)v.jobs[jq].RP * v.jobs[jq].Y * T0 * T0 < (1ull << 32) && T0 > 1) ? 0xffffffffu / (unsigned)T0 + 1u : 0u) : hq / (unsigned)T0;
+      const int sub = (int)(loc & 1) * T0 + (int)(hq - qT * (unsigned)T0);           // configuration-major, then top-edge sample
       key = (jrel < SCORE_JOBS && sub < SCORE_SUB) ? jrel * SCORE_SUB + sub : SCORE_BINS - 1;
     }
     const int rank = atomicAdd(&hist[key], 1);
@@ -626,14 +634,16 @@ __global__ __launch_bounds__(256) void score_kernel(DetectDeviceView v, long lon
     __syncthreads();
   }
   const int mine = s_src[threadIdx.x];
-  const JobDesc jd = v.jobs[s_job[mine]];
+  const JobDesc& jd = v.jobs[CAP ? __builtin_amdgcn_readfirstlane(s_job[0]) : s_job[mine]];
   const long long i = base + mine;
   if (i >= n_valid) return;                     // (no barrier below this point)
   const long long slot = s_slot[mine];
   const unsigned local = (unsigned)(slot - jd.slot_off);
   const int cfg = (int)(local & 1);          // 0 = configuration 1
-  const int ry = (int)((local >> 1) / (unsigned)jd.T);
-  const int rp = (int)((unsigned)ry / (unsigned)jd.Y);
+  const unsigned inv_T = (CAP && jd.T > 1 && (unsigned long long)jd.RP * jd.Y * jd.T * jd.T < (1ull << 32)) ? 0xffffffffu / (unsigned)jd.T + 1u : 0u;
+  const unsigned inv_Y = (CAP && jd.Y > 1 && (unsigned long long)jd.RP * jd.Y * jd.Y < (1ull << 32)) ? 0xffffffffu / (unsigned)jd.Y + 1u : 0u;
+  const int ry = (int)score_udiv(local >> 1, (unsigned)jd.T, inv_T);
+  const int rp = (int)score_udiv((unsigned)ry, (unsigned)jd.Y, inv_Y);
   const int tx = threadIdx.x;
   const double ox = (double)jd.g.el, oy = (double)jd.g.et;
   const float* __restrict__ map = v.maps + jd.map_off;
@@ -1805,7 +1815,8 @@ void launch_scan_compact_trips(const DetectDeviceView& v, int* cnt, int max_trip
 void launch_score(const DetectDeviceView& v, const SweepParams& sp, long long n_valid_bound, long long slot_total, hipStream_t st) {
   if (skip_kernel("score")) return;
   if (n_valid_bound <= 0) return;
-  hipLaunchKernelGGL(score_kernel, dim3(grid8(n_valid_bound, 256)), dim3(256), 0, st, v, slot_total, sp.short_sq_bound);
+  if (v.blk_info) hipLaunchKernelGGL(score_kernel<true>, dim3(grid8(n_valid_bound, 256)), dim3(256), 0, st, v, slot_total, sp.short_sq_bound);
+  else hipLaunchKernelGGL(score_kernel<false>, dim3(grid8(n_valid_bound, 256)), dim3(256), 0, st, v, slot_total, sp.short_sq_bound);
 }
 // copy [src_off, src_off + count) ranges of the compacted columns into packed buffers (fallback boxes)
 __global__ __launch_bounds__(256) void gather_ranges_kernel(DetectDeviceView v, const long long* src_off, const int* count, const long long* dst_off, int n_ranges,
