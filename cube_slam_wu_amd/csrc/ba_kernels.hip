@@ -596,8 +596,7 @@ __global__ __launch_bounds__(128) void ba_cub_scatter_kernel(BaView v, const dou
 }
 
 // off-diagonal pose blocks: camera-cuboid (6x9) per cuboid edge, camera-camera (6x6) per odometry edge
-__global__ __launch_bounds__(64) void ba_offdiag_kernel(BaView v) {
-  int k = blockIdx.x, t = threadIdx.x;
+__device__ __forceinline__ void ba_offdiag_body(const BaView& v, int k, int t) {
   if (k < v.n_cub) {
     if (v.elim) return;       // the cuboids are not part of the reduced system
     int ca = v.cam_col[v.ce_cam[k]], cb = v.cub_col[v.ce_cub[k]];
@@ -616,6 +615,7 @@ __global__ __launch_bounds__(64) void ba_offdiag_kernel(BaView v) {
     if (cb > ca) atomicAdd(ba_S_at(v, cb + j, ca + i), val); else atomicAdd(ba_S_at(v, ca + i, cb + j), val);
   }
 }
+__global__ __launch_bounds__(64) void ba_offdiag_kernel(BaView v) { ba_offdiag_body(v, blockIdx.x, threadIdx.x); }
 
 // One wavefront per covisible camera pair.  Every lane walks its own landmarks of the pair (entries q0 + lane,
 // + 64, ...), accumulating the whole 6 x 6 block W_a D^-1 W_b^T in registers (each lane streams two contiguous
@@ -1080,9 +1080,8 @@ __global__ __launch_bounds__(256) void ba_schur_gather_kernel(BaView v) {
 }
 
 // destination schedule, right-hand side: S_cc = A_cc + lambda I and b_schur,c = b_c - sum of the camera's partial W D^-1 b_l
-__global__ __launch_bounds__(64) void ba_cam_rhs_fused_kernel(BaView v, const double* __restrict__ lamp) {
+__device__ __forceinline__ void ba_cam_rhs_fused_body(const BaView& v, const double* __restrict__ lamp, int c, int t) {
   const double lambda = lamp[0];
-  const int c = blockIdx.x, t = threadIdx.x;
   const int col = v.cam_col[c];
   if (col < 0) return;
   {
@@ -1106,6 +1105,13 @@ __global__ __launch_bounds__(64) void ba_cam_rhs_fused_kernel(BaView v, const do
     const int i = t / 6, j = t % 6;
     if (i >= j) *ba_S_at(v, col + i, col + j) = v.Hcam[36 * c + t] + ((i == j && col >= v.lam_lo && col < v.lam_hi) ? lambda : 0.0);
   }
+}
+__global__ __launch_bounds__(64) void ba_cam_rhs_fused_kernel(BaView v, const double* __restrict__ lamp) { ba_cam_rhs_fused_body(v, lamp, blockIdx.x, threadIdx.x); }
+// ... and the off-diagonal pose blocks in the same launch (round 6: the cameras' diagonal blocks / right-hand sides and the pose edges' off-diagonal
+// blocks touch disjoint entries of S; two 5-7 us launches in a row on every trial's chain were one launch boundary too many)
+__global__ __launch_bounds__(64) void ba_cam_rhs_offdiag_kernel(BaView v, const double* __restrict__ lamp) {
+  if ((int)blockIdx.x < v.nc) ba_cam_rhs_fused_body(v, lamp, blockIdx.x, threadIdx.x);
+  else ba_offdiag_body(v, (int)blockIdx.x - v.nc, threadIdx.x);
 }
 
 // ---- elimination of the cuboids (BaView::elim) ------------------------------------------------------------------------------
@@ -2707,9 +2713,8 @@ void ba_launch_reduce(const BaView& v, const double* lambda, hipStream_t st, hip
     }
     if (side) (void)hipStreamWaitEvent(st, ev_join, 0);
     else if (v.elim && v.no > 0) hipLaunchKernelGGL(ba_cub_elim_kernel, dim3(v.no), dim3(256), 2 * 54 * sizeof(double) * (size_t)v.elim_max_slots, st, v, lambda);
-    hipLaunchKernelGGL(ba_cam_rhs_fused_kernel, dim3(v.nc), dim3(64), 0, st, v, lambda);
+    hipLaunchKernelGGL(ba_cam_rhs_offdiag_kernel, dim3(v.nc + v.n_cub + v.n_odom), dim3(64), 0, st, v, lambda);
     if (!v.elim && v.no > 0) hipLaunchKernelGGL(ba_cub_scatter_kernel, dim3(v.no), dim3(128), 0, st, v, lambda);
-    if (v.n_cub + v.n_odom > 0) hipLaunchKernelGGL(ba_offdiag_kernel, dim3(v.n_cub + v.n_odom), dim3(64), 0, st, v);
     if (v.n_gpairs > 0) hipLaunchKernelGGL(ba_schur_gather_kernel, dim3((v.n_gpairs + 3) / 4), dim3(256), 0, st, v);
     return;
   }
