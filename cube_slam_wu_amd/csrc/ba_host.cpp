@@ -38,7 +38,7 @@ int ba_chi2_blocks(int n_proj);
 void ba_launch_chi2(const BaView& v, int nb_proj, hipStream_t st);
 void ba_launch_fill_rows4(double* dst, const double* rec4, long long rows, hipStream_t st);
 void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, hipStream_t st3, hipEvent_t ev_join3, hipEvent_t ev_pre = nullptr);
-void ba_launch_reduce(const BaView& v, const double* lambda_dev, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join);
+void ba_launch_reduce(const BaView& v, const double* lambda_dev, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, const BaSidePrologue* sp = nullptr);
 void ba_launch_gather_rows(const double* src, const int* idx, int n, int width, double* dst, hipStream_t st);
 void ba_launch_backsub(const BaView& v, hipStream_t st);
 int ba_scale_blocks();
@@ -1656,9 +1656,14 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
   if (B->sep_mode && B->shard_n > 1) return solve_device_sep(B, lambda, ok, fn, ctx, defer);
   if (n > 0) {
     const bool lean_head = B->band_ld > 0 && !B->sparse;      // (banded path: one prologue kernel instead of a copy and three fills)
+    // (the prologue's launch is ba_launch_reduce's when nothing reads the phase marks and no host-evaluated edge writes S in between: it then
+    // runs on the side stream, beside the landmark segments -- BaSidePrologue)
+    cs::BaSidePrologue side_pro{};
+    const bool pro_in_reduce = lean_head && defer != nullptr && !B->stage_timing && B->shard_n == 1 && !(B->ext_n > 0 && B->ext_terms_set);
     if (lean_head) {
       B->h_lam[0] = lambda; B->h_lam[1] = B->shard_rank == 0 ? lambda : 0.0;
-      cs::ba_launch_trial_prologue(B->d_lam.p, B->h_lam[0], B->h_lam[1], B->d_band_info.p, B->d_elim_fail.p, B->S.p, B->s_doubles + (size_t)B->n_pose, B->st);   // (+ [S | rhs] cleared: no fill of its own)
+      side_pro = cs::BaSidePrologue{B->d_lam.p, B->h_lam[0], B->h_lam[1], B->d_band_info.p, B->d_elim_fail.p, B->S.p, B->s_doubles + (size_t)B->n_pose};
+      if (!pro_in_reduce) cs::ba_launch_trial_prologue(B->d_lam.p, B->h_lam[0], B->h_lam[1], B->d_band_info.p, B->d_elim_fail.p, B->S.p, B->s_doubles + (size_t)B->n_pose, B->st);   // (+ [S | rhs] cleared: no fill of its own)
     } else { int rcl = put_lambda(B, lambda); if (rcl) return rcl; }
     BA_MARK(B, B->ev[2]);
     if (lean_head) {
@@ -1671,7 +1676,7 @@ int solve_device(cs_ba* B, double lambda, bool* ok, cs_allreduce_fn fn = nullptr
       B->sp_S_clean = B->sparse;
     }
     if (!lean_head) BA_TRY(hipMemsetAsync(B->d_elim_fail.p, 0, sizeof(int), B->st));
-    cs::ba_launch_reduce(B->view, B->d_lam.p, B->st, B->st2, B->ev_fork, B->ev_join);
+    cs::ba_launch_reduce(B->view, B->d_lam.p, B->st, B->st2, B->ev_fork, B->ev_join, pro_in_reduce ? &side_pro : nullptr);
     if (B->ext_n > 0 && B->ext_terms_set) cs::ba_launch_ext_offdiag(B->view, B->ext_groups, B->d_ext_gptr.p, B->d_ext_order.p, B->d_ext_e4.p, B->ext_Hij.p, B->st);
     // (block cyclic reduction in a deferred trial: no kernel of it waits for another -- no time-out word to read --, and the two failure words
     // reach the host folded into the trial's scalars by the caller's sum kernel: the two 4-byte copies, a blit launch each, stay away)

@@ -971,9 +971,9 @@ __device__ __forceinline__ void ba_lin_schur_segment(const BaView& v, double lam
       }
 }
 template <int MT>
-__global__ __launch_bounds__(256) void ba_lin_schur_kernel(BaView v, const double* __restrict__ lamp, int seg_begin, int seg_end) {
+__global__ __launch_bounds__(256) void ba_lin_schur_kernel(BaView v, const double* __restrict__ lamp, int seg_begin, int seg_end, double lam_val) {
   __shared__ double lds[4][LS_WAVE_DOUBLES];
-  const double lambda = lamp[0];
+  const double lambda = lamp ? lamp[0] : lam_val;      // (by value: the trial's prologue runs beside this kernel, BaSidePrologue)
   const int seg = __builtin_amdgcn_readfirstlane(seg_begin + blockIdx.x * 4 + (threadIdx.x >> 6));
   if (seg >= seg_end) return;
   ba_lin_schur_segment<MT>(v, lambda, seg, v.seg_k[seg], lds[threadIdx.x >> 6]);
@@ -2673,7 +2673,15 @@ void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEv
   if (side3) (void)hipStreamWaitEvent(st, ev_join3, 0);
   hipLaunchKernelGGL(ba_accum_pose_kernel, dim3(v.nc + v.no), dim3(128), 0, st, v, 0);
 }
-void ba_launch_reduce(const BaView& v, const double* lambda, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join) {   // lambda: device, [lambda, lambda of the pose diagonals in the scale term]
+void ba_launch_trial_prologue(double* d_lam, double lam0, double lam1, int* info24, int* elim_fail, double* S, size_t n_clear, hipStream_t st);
+void ba_launch_reduce(const BaView& v, const double* lambda, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, const BaSidePrologue* sp) {   // lambda: device, [lambda, lambda of the pose diagonals in the scale term]
+  // sp (optional): the trial's prologue has NOT been launched yet -- it goes to the side stream when there is one and the landmark segments can take
+  // lambda by value (the fused-linearisation kernels, no long-track segments), else in front of everything on the main stream
+  const bool side0 = v.fused && v.elim && v.no > 0 && st2 != nullptr;
+  const bool sp_side = sp && side0 && v.fuse_lin && v.n_seg <= max(max(max(v.seg_class[0], v.seg_class[1]), max(v.seg_class[2], v.seg_class[3])), v.seg_class[4]);
+  if (sp && !sp_side) ba_launch_trial_prologue(sp->d_lam, sp->lam0, sp->lam1, sp->info24, sp->elim_fail, sp->S, sp->n_clear, st);
+  const double* lin_lamp = sp_side ? nullptr : lambda;
+  const double lin_lam = sp_side ? sp->lam0 : 0.0;
   if (v.fused) {
     // the cuboid elimination (one workgroup per cuboid, latency-bound) runs beside the landmark segments on a second stream; both
     // write disjoint ranges of the partial arrays and meet before the destination schedule reads them
@@ -2681,6 +2689,7 @@ void ba_launch_reduce(const BaView& v, const double* lambda, hipStream_t st, hip
     if (side) {
       (void)hipEventRecord(ev_fork, st);
       (void)hipStreamWaitEvent(st2, ev_fork, 0);
+      if (sp_side) ba_launch_trial_prologue(sp->d_lam, sp->lam0, sp->lam1, sp->info24, sp->elim_fail, sp->S, sp->n_clear, st2);
       hipLaunchKernelGGL(ba_cub_elim_kernel, dim3(v.no), dim3(256), 2 * 54 * sizeof(double) * (size_t)v.elim_max_slots, st2, v, lambda);
     }
     // (the cuboid elimination must be dispatched BEFORE the bulk of the segments fills the device: started 18 us ahead -- behind the short
@@ -2697,11 +2706,11 @@ void ba_launch_reduce(const BaView& v, const double* lambda, hipStream_t st, hip
         // (round 6: the one- and two-camera segments ride in the <2> launch -- the same products on the same operands, their second tile idle --
         // instead of a 17 us launch of their own in front of it: the two kernels never overlapped; C4 1 312-1 324 -> 1 336-1 342 LM it/s)
         if (c1 > c0) c0 = 0;
-        if (c0 > 0) hipLaunchKernelGGL(ba_lin_schur_kernel<1>, dim3((c0 + 3) / 4), dim3(256), 0, st, v, lambda, 0, c0);
-        if (c1 > c0) hipLaunchKernelGGL(ba_lin_schur_kernel<2>, dim3((c1 - c0 + 3) / 4), dim3(256), 0, st, v, lambda, c0, c1);
-        if (c2 > c1) hipLaunchKernelGGL(ba_lin_schur_kernel<3>, dim3((c2 - c1 + 3) / 4), dim3(256), 0, st, v, lambda, c1, c2);
-        if (c3 > c2) hipLaunchKernelGGL(ba_lin_schur_kernel<4>, dim3((c3 - c2 + 3) / 4), dim3(256), 0, st, v, lambda, c2, c3);
-        if (c4 > c3) hipLaunchKernelGGL(ba_lin_schur_kernel<5>, dim3((c4 - c3 + 3) / 4), dim3(256), 0, st, v, lambda, c3, c4);
+        if (c0 > 0) hipLaunchKernelGGL(ba_lin_schur_kernel<1>, dim3((c0 + 3) / 4), dim3(256), 0, st, v, lin_lamp, 0, c0, lin_lam);
+        if (c1 > c0) hipLaunchKernelGGL(ba_lin_schur_kernel<2>, dim3((c1 - c0 + 3) / 4), dim3(256), 0, st, v, lin_lamp, c0, c1, lin_lam);
+        if (c2 > c1) hipLaunchKernelGGL(ba_lin_schur_kernel<3>, dim3((c2 - c1 + 3) / 4), dim3(256), 0, st, v, lin_lamp, c1, c2, lin_lam);
+        if (c3 > c2) hipLaunchKernelGGL(ba_lin_schur_kernel<4>, dim3((c3 - c2 + 3) / 4), dim3(256), 0, st, v, lin_lamp, c2, c3, lin_lam);
+        if (c4 > c3) hipLaunchKernelGGL(ba_lin_schur_kernel<5>, dim3((c4 - c3 + 3) / 4), dim3(256), 0, st, v, lin_lamp, c3, c4, lin_lam);
       } else {
         if (c0 > 0) hipLaunchKernelGGL(ba_schur_fused_kernel<1>, dim3((c0 + 3) / 4), dim3(256), 0, st, v, lambda, 0, c0);
         if (c1 > c0) hipLaunchKernelGGL(ba_schur_fused_kernel<2>, dim3((c1 - c0 + 3) / 4), dim3(256), 0, st, v, lambda, c0, c1);

@@ -98,6 +98,10 @@ struct BaView {
   // chi2 partial sums
   double* chi_partial;
 };
+// A trial's prologue (lambda into device memory, status words and [S | rhs] cleared) handed to ba_launch_reduce: with the cuboid elimination on
+// a side stream the prologue runs THERE, in front of it, and the landmark segments' kernel takes lambda by value -- nothing on the main stream
+// reads what the prologue writes before the streams join, so its launch leaves the trial's chain.
+struct BaSidePrologue { double* d_lam; double lam0, lam1; int* info24; int* elim_fail; double* S; size_t n_clear; };
 enum { BA_SEG_LM = 32, BA_FUSED_KMAX = 13, BA_LONG_KMAX = 64, BA_ELIM_MAX_SLOTS = 64 };   // (6 k + 1 <= 80 rows = five tiles: 15 accumulator tiles per wavefront)
 
 CS_HD double* ba_S_at(const BaView& v, int r, int c) {  // requires r >= c (and r - c < band_ld in band mode)
