@@ -988,13 +988,36 @@ struct JobCut {      // per height sample of the box
   int tie;           // several proposals share the cut value vd, and which of them the reference keeps depends on its heap order
 };
 
+// (rank_wave_kernel, below rank_kernel: boxes whose height samples hold <= RW_CAP valid proposals each)
+enum { RW_K = 28, RW_CAP = 64 * RW_K, RW_BATCH = 8 };      // (a lane's candidate bits are one 32-bit word)
+// does the box go to the wavefront kernel?  (uniform; both kernels ask)
+__device__ __forceinline__ bool rank_box_fits_wave(const DetectDeviceView& v, int j0, int nj) {
+  bool fits = true;
+  for (int h = 0; h < nj; h++) fits = fits && v.job_valid[j0 + h] <= (int)RW_CAP;
+  return fits;
+}
+// the score of a kept proposal (fuse_normalize_scores_v2's normalisation + the skew penalty): ONE definition for both ranking kernels
+__device__ __forceinline__ double rank_combined_score(const JobCut& c, const RankParams& rp, double d, double a, double sk, double* score_out) {
+  double score;
+  if (c.n_keep > 1) {
+    double dn = (d - c.dmin) / (c.dmax - c.dmin);
+    double an = ((c.amax - c.amin) > 0) ? (a - c.amin) / (c.amax - c.amin) : a;
+    score = (dn + rp.w_angle * an) / (1 + rp.w_angle);
+  } else {
+    score = (d + rp.w_angle * a) / (1 + rp.w_angle);
+  }
+  double skew_error = rp.w_skew * dmax(sk - rp.nominal_skew, 0.0);
+  if (sk > rp.max_cut_skew) skew_error = 100;
+  *score_out = score;
+  return score + rp.w_skew * skew_error;
+}
 enum { RANK_STAGE = 1536, RANK_THREADS_DEFAULT = 256 };   // proposals of one height sample staged in LDS (2 x 12 KB)
 // DYN: the staging columns in dynamic LDS, stage_cap proposals each -- the roll/pitch-sampling rounds, where a box holds ~9 000 valid
 // proposals (25 camera poses) and only ~100 boxes are ranked per launch: a workgroup then owns a CU's LDS and 16 waves, and the ~20
 // selection passes run from LDS instead of L2
 enum { RANK_STAGE_BIG = 9216, RANK_THREADS_BIG = 1024 };
 template <int NT, bool DYN>
-__global__ __launch_bounds__(NT) void rank_kernel(DetectDeviceView v, RankView rv, RankParams rp, int stage_cap) {
+__global__ __launch_bounds__(NT) void rank_kernel(DetectDeviceView v, RankView rv, RankParams rp, int stage_cap, int wave_boxes_elsewhere) {
   __shared__ unsigned hist[512];
   __shared__ unsigned long long bcast[4];
   __shared__ double shd[NT / 64 > 4 ? NT / 64 : 4];
@@ -1008,9 +1031,10 @@ __global__ __launch_bounds__(NT) void rank_kernel(DetectDeviceView v, RankView r
   const int STAGE = DYN ? stage_cap : (int)RANK_STAGE;
   int box = blockIdx.x;
   if (box >= rv.n_boxes) return;
+  const int j0 = rv.box_job0[box], nj = rv.box_njobs[box];
+  if (wave_boxes_elsewhere && rank_box_fits_wave(v, j0, nj)) return;     // rank_wave_kernel's box
   if (threadIdx.x == 0) s_fallback = 0;
   __syncthreads();
-  const int j0 = rv.box_job0[box], nj = rv.box_njobs[box];
   const double INF = __builtin_huge_val();
   // ---- per height sample: the cuts of fuse_normalize_scores_v2 and the min/max over the kept set
   for (int h = 0; h < nj; h++) {
@@ -1138,17 +1162,7 @@ __global__ __launch_bounds__(NT) void rank_kernel(DetectDeviceView v, RankView r
         bool keep = (d <= c.vd) && (!c.use_angle || a <= c.va);
         if (!keep || (v.c_flag[c0 + i] & CAND_NEG_SCALE)) continue;
         double score;
-        if (c.n_keep > 1) {
-          double dn = (d - c.dmin) / (c.dmax - c.dmin);
-          double an = ((c.amax - c.amin) > 0) ? (a - c.amin) / (c.amax - c.amin) : a;
-          score = (dn + rp.w_angle * an) / (1 + rp.w_angle);
-        } else {
-          score = (d + rp.w_angle * a) / (1 + rp.w_angle);
-        }
-        double sk = v.c_skew[c0 + i];
-        double skew_error = rp.w_skew * dmax(sk - rp.nominal_skew, 0.0);
-        if (sk > rp.max_cut_skew) skew_error = 100;
-        double comb = score + rp.w_skew * skew_error;
+        const double comb = rank_combined_score(c, rp, d, a, v.c_skew[c0 + i], &score);
         if (comb != comb || comb == INF || comb == -INF) { bad = 1; continue; }  // NaN / inf: let the host decide
         if (!(comb > prev)) continue;
         const int weight = (c.tie && d == c.vd) ? 3 : 1;   // a winner among the tied proposals: the reference may not have kept it -> host
@@ -1167,7 +1181,7 @@ __global__ __launch_bounds__(NT) void rank_kernel(DetectDeviceView v, RankView r
       RankWinner* w = rv.winners + (size_t)box * rp.kmax + round;
       long long slot = v.c_slot[w_at];
       w->slot = slot; w->normalized_error = w_score; w->dist_err = w_d; w->angle_err = w_a; w->flag = v.c_flag[w_at] & CAND_VP_MASK; w->pad = 0;
-      slot_corners16(v, slot, rp.short_sq_bound, w->corners);
+      // (its corners: winner_corners_kernel, behind the ranking -- one lane per winner instead of one lane of this workgroup)
     }
     if (cnt != 1 && threadIdx.x == 0) s_fallback = 1;
     prev = gbest;
@@ -1834,6 +1848,289 @@ void launch_gather_ranges(const DetectDeviceView& v, const long long* src_off, c
   if (n_ranges <= 0) return;
   hipLaunchKernelGGL(gather_ranges_kernel, dim3(n_ranges), dim3(256), 0, st, v, src_off, count, dst_off, n_ranges, o_dist, o_angle, o_skew, o_flag, o_slot);
 }
+// ---- the ranking with ONE WAVEFRONT per box (round 6) ------------------------------------------------------------------------
+// rank_kernel above is a chain of ~60 workgroup barriers per box (eight radix passes of four, twenty reductions of two) over ~900
+// proposals: 66 us per box, nearly all of it waiting.  A box whose height samples hold <= RW_CAP valid proposals each is ranked by one
+// wavefront instead, without LDS and without a barrier:
+//   * an order statistic is found by walking the bits of order_key() from the highest bit in which the proposals differ (sign, exponent
+//     and whatever else they share are skipped): lane l keeps the upper key words of proposals l, l + 64, ... in registers and ONE word
+//     of candidate bits (bit q = proposal 64 q + l is still a candidate); a bit of the walk is two instructions per register (extract,
+//     insert), a population count, a row reduction in DPP and four v_readlane -- and the walk stops when one candidate is left
+//     (~11 bits for ~900 distinct doubles).  The lower key words are only fetched when candidates tie in the upper ones.
+//   * the walk also yields how many keys are <= the statistic (the tie / angle-cut decisions), and the statistic's double IS the cut value
+//     (order_key is a bijection): rank_kernel's counting and maximum passes have no counterpart;
+//   * the remaining passes (extremes of the kept set, the final arg-min rounds) stream the columns from L2, coalesced.
+// Every DECISION is the one rank_kernel takes, in the same arithmetic (selection and counts on order_key(), thresholds / normalisation /
+// scores on the doubles, rank_combined_score): the two kernels agree bit for bit (CS_RANK_WAVE=0 in the tests), boxes with a larger
+// height sample stay with rank_kernel (launched behind this one; its workgroups of the boxes ranked here return at once).
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
+// sums / and / or / min / max over the wavefront, result in every lane: four DPP exchanges inside the rows of 16 (xor 1, xor 2, half-row
+// mirror, row mirror), then the four rows' values through v_readlane
+__device__ __forceinline__ int wave_sum_i32(int x) {
+  x += dpp_i32<0xB1>(x); x += dpp_i32<0x4E>(x); x += dpp_i32<0x141>(x); x += dpp_i32<0x140>(x);
+  return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
+}
+__device__ __forceinline__ unsigned wave_and_u32(unsigned u) {
+  int x = (int)u;
+  x &= dpp_i32<0xB1>(x); x &= dpp_i32<0x4E>(x); x &= dpp_i32<0x141>(x); x &= dpp_i32<0x140>(x);
+  return (unsigned)(__builtin_amdgcn_readlane(x, 0) & __builtin_amdgcn_readlane(x, 16) & __builtin_amdgcn_readlane(x, 32) & __builtin_amdgcn_readlane(x, 48));
+}
+__device__ __forceinline__ unsigned wave_or_u32(unsigned u) {
+  int x = (int)u;
+  x |= dpp_i32<0xB1>(x); x |= dpp_i32<0x4E>(x); x |= dpp_i32<0x141>(x); x |= dpp_i32<0x140>(x);
+  return (unsigned)(__builtin_amdgcn_readlane(x, 0) | __builtin_amdgcn_readlane(x, 16) | __builtin_amdgcn_readlane(x, 32) | __builtin_amdgcn_readlane(x, 48));
+}
+__device__ __forceinline__ int wave_max_i32(int x) {
+  x = max(x, dpp_i32<0xB1>(x)); x = max(x, dpp_i32<0x4E>(x)); x = max(x, dpp_i32<0x141>(x)); x = max(x, dpp_i32<0x140>(x));
+  return max(max(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 16)), max(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double x) {
+  return __hiloint2double(dpp_i32<CTRL>(__double2hiint(x)), dpp_i32<CTRL>(__double2loint(x)));
+}
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+// (no NaN reaches these: a NaN in a column sends the box to the host before the extremes matter)
+__device__ __forceinline__ double wave_min_f64(double x) {
+  double y;
+  y = dpp_f64<0xB1>(x); x = (y < x) ? y : x; y = dpp_f64<0x4E>(x); x = (y < x) ? y : x;
+  y = dpp_f64<0x141>(x); x = (y < x) ? y : x; y = dpp_f64<0x140>(x); x = (y < x) ? y : x;
+  double r = readlane_f64(x, 0);
+  y = readlane_f64(x, 16); r = (y < r) ? y : r; y = readlane_f64(x, 32); r = (y < r) ? y : r; y = readlane_f64(x, 48); r = (y < r) ? y : r;
+  return r;
+}
+__device__ __forceinline__ double wave_max_f64(double x) {
+  double y;
+  y = dpp_f64<0xB1>(x); x = (y > x) ? y : x; y = dpp_f64<0x4E>(x); x = (y > x) ? y : x;
+  y = dpp_f64<0x141>(x); x = (y > x) ? y : x; y = dpp_f64<0x140>(x); x = (y > x) ? y : x;
+  double r = readlane_f64(x, 0);
+  y = readlane_f64(x, 16); r = (y > r) ? y : r; y = readlane_f64(x, 32); r = (y > r) ? y : r; y = readlane_f64(x, 48); r = (y > r) ? y : r;
+  return r;
+}
+__device__ __forceinline__ double order_key_to_double(unsigned long long k) {      // order_key()'s inverse
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+// one 32-bit word of the selection, KQ registers (proposals behind the column's end carry no candidate bit): the candidates are narrowed
+// bit by bit from start_bit down until one is left; r = the rank wanted among the candidates, nact = their number
+template <int KQ>
+__device__ __forceinline__ void wave_select_walk(const unsigned (&w)[RW_K], unsigned& act, int start_bit, int& r, int& nact) {
+  for (int bit = start_bit; bit >= 0 && nact > 1; bit--) {
+    unsigned ones = 0;
+#pragma unroll
+    for (int q = 0; q < KQ; q++) ones |= ((w[q] >> bit) & 1u) << q;
+    const unsigned zer = act & ~ones;
+    const int c0 = wave_sum_i32(__popc(zer));
+    if (r < c0) { act = zer; nact = c0; }
+    else { act &= ones; r -= c0; nact -= c0; }
+  }
+}
+__device__ __forceinline__ void wave_select_phase(const unsigned (&w)[RW_K], unsigned& act, int Q, int& r, int& nact) {
+  // the highest bit in which the candidates' words differ; none: they all carry the same word
+  unsigned a = 0xffffffffu, o = 0u;
+#pragma unroll
+  for (int q = 0; q < RW_K; q++) { if (q >= Q) continue; if ((act >> q) & 1u) { a &= w[q]; o |= w[q]; } }
+  const unsigned diff = wave_and_u32(a) ^ wave_or_u32(o);
+  if (!diff) return;
+  const int start = 31 - __clz((int)diff);
+  if (Q <= 8) wave_select_walk<8>(w, act, start, r, nact);
+  else if (Q <= 12) wave_select_walk<12>(w, act, start, r, nact);
+  else if (Q <= 16) wave_select_walk<16>(w, act, start, r, nact);
+  else if (Q <= 20) wave_select_walk<20>(w, act, start, r, nact);
+  else if (Q <= 24) wave_select_walk<24>(w, act, start, r, nact);
+  else wave_select_walk<RW_K>(w, act, start, r, nact);
+}
+// order_key() of rank r (0-based, ascending) among X[0 .. V) (global memory, V <= RW_CAP); n_le = how many keys are <= it.
+// (NOT inlined: with its two instances inside the kernel the compiler's schedule needs 512 registers and spills 4 800)
+struct WaveSelected { unsigned long long key; int n_le; };
+__device__ __attribute__((noinline)) WaveSelected wave_select_key(const double* __restrict__ X, int V, int Q, int r) {
+  const int lane = threadIdx.x & 63;
+  const unsigned* __restrict__ X32 = reinterpret_cast<const unsigned*>(X);
+  unsigned w[RW_K];
+  unsigned act = 0;
+  // (every load asked for before the first is used -- indices behind the column's end re-read its last proposal --: one round trip to L2)
+#pragma unroll
+  for (int q = 0; q < RW_K; q++) { w[q] = 0u; if (q >= Q) continue; w[q] = X32[2 * (size_t)min(64 * q + lane, V - 1) + 1]; }
+#pragma unroll
+  for (int q = 0; q < RW_K; q++) {
+    if (q >= Q) continue;
+    const unsigned h = w[q];
+    const bool in = 64 * q + lane < V;
+    w[q] = in ? ((h >> 31) ? ~h : (h | 0x80000000u)) : 0u;      // order_key()'s upper word
+    act |= in ? 1u << q : 0u;
+  }
+  const int r0 = r;
+  int nact = V;
+  wave_select_phase(w, act, Q, r, nact);
+  if (nact > 1) {      // candidates tie in the upper word: the lower words (of a negative double: complemented)
+#pragma unroll
+    for (int q = 0; q < RW_K; q++) {
+      if (q >= Q) continue;
+      const long long x = __double_as_longlong(X[min(64 * q + lane, V - 1)]);
+      w[q] = (x < 0) ? ~(unsigned)x : (unsigned)x;
+    }
+    wave_select_phase(w, act, Q, r, nact);
+  }
+  // the candidates left all carry the key (one of them, or equal keys): the first one's lane fetches it
+  const int owner = __ffsll((long long)__ballot(act != 0u)) - 1;
+  unsigned long long key = 0;
+  if (lane == owner) key = order_key(X[64 * (__ffs((int)act) - 1) + lane]);
+  key = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(key >> 32), owner) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)key, owner);
+  WaveSelected out;
+  out.key = key;
+  out.n_le = (r0 - r) + nact;      // the keys below the candidates + the candidates
+  return out;
+}
+__global__ __launch_bounds__(64) void rank_wave_kernel(DetectDeviceView v, RankView rv, RankParams rp) {
+  const int box = blockIdx.x;
+  if (box >= rv.n_boxes) return;
+  const int j0 = rv.box_job0[box], nj = rv.box_njobs[box];
+  if (!rank_box_fits_wave(v, j0, nj)) return;
+  const int lane = threadIdx.x;
+  const double INF = __builtin_huge_val();
+  int fallback = 0;
+  __shared__ JobCut cuts[3];      // (written and read by this one wavefront)
+  for (int h = 0; h < nj && h < 3; h++) {
+    const int j = j0 + h;
+    const long long c0 = v.job_cbase[j];
+    const int V = v.job_valid[j];
+    const int Q = (V + 63) >> 6;
+    const double* __restrict__ D = v.c_dist + c0;
+    const double* __restrict__ A = v.c_angle + c0;
+    double vd = INF, va = INF;
+    int use_angle = 0, tie = 0, bn_keep = 0;
+    if (V > 4) {
+      const int bn = (int)round((double)((float)V) / 3.0 * 2.0);
+      bn_keep = bn - 1;
+      const WaveSelected sd = wave_select_key(D, V, Q, bn - 2), sa = wave_select_key(A, V, Q, bn - 2);
+      tie = (sd.n_le != bn - 1);
+      use_angle = (sa.n_le == bn - 1);
+      vd = order_key_to_double(sd.key);      // the largest kept value: the statistic itself
+      va = order_key_to_double(sa.key);
+    }
+    double dmin = 1e6, dmax = -1, amin = 1e6, amax = -1, amin_s = 1e6, amax_s = -1;
+    int nk = 0, nan = 0, nk_s = 0, nt = 0, ct = 0, cl = 0, last = -1, n_at_cut = 0;
+    const bool want_last = rv.last_slot && h == nj - 1 && V > 4;
+    for (int q0 = 0; q0 < Q; q0 += RW_BATCH) {
+      double db[RW_BATCH], ab[RW_BATCH];
+#pragma unroll
+      for (int u = 0; u < RW_BATCH; u++) { const int ic = min(64 * (q0 + u) + lane, V - 1); db[u] = D[ic]; ab[u] = A[ic]; }
+#pragma unroll
+      for (int u = 0; u < RW_BATCH; u++) {
+      const int i = 64 * (q0 + u) + lane;
+      if (i < V) {
+        const double d = db[u], a = ab[u];
+        nan += (d != d) || (a != a);
+        const bool pass = !use_angle || a <= va;
+        if (d <= vd && pass) {
+          nk++;
+          dmin = (d < dmin) ? d : dmin; dmax = (dmax < d) ? d : dmax;
+          amin = (a < amin) ? a : amin; amax = (amax < a) ? a : amax;
+        }
+        if (tie) {      // (rank_kernel: when do the tied proposals at the cut not matter?)
+          if (d < vd) { cl++; if (pass) { nk_s++; amin_s = (a < amin_s) ? a : amin_s; amax_s = (amax_s < a) ? a : amax_s; } }
+          else if (d == vd) { ct++; nt += pass; }
+        }
+        if (want_last) {
+          if (use_angle) { if (d <= vd && a <= va) last = i; }
+          else if (d == vd) { last = i; n_at_cut++; }
+        }
+      }
+      }
+    }
+    dmin = wave_min_f64(dmin); dmax = wave_max_f64(dmax);
+    amin = wave_min_f64(amin); amax = wave_max_f64(amax);
+    nk = wave_sum_i32(nk);
+    if (V > 4 && wave_sum_i32(nan)) fallback = 1;
+    if (tie) {
+      amin_s = wave_min_f64(amin_s); amax_s = wave_max_f64(amax_s);
+      nk_s = wave_sum_i32(nk_s); nt = wave_sum_i32(nt); ct = wave_sum_i32(ct); cl = wave_sum_i32(cl);
+      const int r = bn_keep - cl;
+      const bool safe = nk_s >= 2 && amin_s == amin && amax_s == amax && (nt == 0 || r - (ct - nt) >= 1);
+      if (!safe) fallback = 1;
+    }
+    if (rv.last_slot && h == nj - 1) {
+      if (V > 4) {
+        last = wave_max_i32(last);
+        n_at_cut = wave_sum_i32(n_at_cut);
+        if (tie || (!use_angle && n_at_cut != 1)) fallback = 1;
+      } else {
+        last = V - 1;
+      }
+      if (lane == 0) rv.last_slot[box] = last >= 0 ? v.c_slot[c0 + last] : -1;
+    }
+    if (lane == 0) {
+      JobCut c; c.vd = vd; c.va = va; c.dmin = dmin; c.dmax = dmax; c.amin = amin; c.amax = amax; c.use_angle = use_angle; c.n_keep = nk; c.V = V; c.tie = tie;
+      cuts[h] = c;
+    }
+  }
+  __syncthreads();
+  // ---- final ranking: kmax rounds of arg-min, one pass over the proposals per round
+  double prev = -INF;
+  int n_win = 0;
+  for (int round = 0; round < rp.kmax; round++) {
+    double best = INF, w_score = 0, w_d = 0, w_a = 0;
+    long long w_at = 0;
+    int bad = 0, cnt_local = 0;
+    for (int h = 0; h < nj && h < 3; h++) {
+      const JobCut c = cuts[h];
+      const long long c0 = v.job_cbase[j0 + h];
+      const int Q = (c.V + 63) >> 6;
+      for (int q0 = 0; q0 < Q; q0 += RW_BATCH) {
+        double db[RW_BATCH], ab[RW_BATCH], sb[RW_BATCH];
+        int fb[RW_BATCH];
+#pragma unroll
+        for (int u = 0; u < RW_BATCH; u++) {
+          const long long at = c0 + min(64 * (q0 + u) + lane, c.V - 1);
+          db[u] = v.c_dist[at]; ab[u] = v.c_angle[at]; sb[u] = v.c_skew[at]; fb[u] = v.c_flag[at];
+        }
+#pragma unroll
+        for (int u = 0; u < RW_BATCH; u++) {
+        const int i = 64 * (q0 + u) + lane;
+        if (i < c.V) {
+          const double d = db[u], a = ab[u], sk = sb[u];
+          const int fl = fb[u];
+          const bool keep = (d <= c.vd) && (!c.use_angle || a <= c.va);
+          if (keep && !(fl & CAND_NEG_SCALE)) {
+            double score;
+            const double comb = rank_combined_score(c, rp, d, a, sk, &score);
+            if (comb != comb || comb == INF || comb == -INF) bad = 1;
+            else if (comb > prev) {
+              const int weight = (c.tie && d == c.vd) ? 3 : 1;
+              if (comb < best) { best = comb; cnt_local = weight; w_score = score; w_d = d; w_a = a; w_at = c0 + i; }
+              else if (comb == best) cnt_local += weight;
+            }
+          }
+        }
+        }
+      }
+    }
+    if (__ballot(bad != 0)) fallback = 1;
+    const double gbest = wave_min_f64(best);
+    if (!(gbest < INF)) break;
+    const bool mine = best == gbest;
+    const int cnt = wave_sum_i32(mine ? cnt_local : 0);
+    // the owner of the minimum (unique unless the box goes to the host anyway) writes the winner's scores (its corners: winner_corners_kernel)
+    if (mine) {
+      RankWinner* w = rv.winners + (size_t)box * rp.kmax + round;
+      w->slot = v.c_slot[w_at]; w->normalized_error = w_score; w->dist_err = w_d; w->angle_err = w_a; w->flag = v.c_flag[w_at] & CAND_VP_MASK; w->pad = 0;
+    }
+    if (cnt != 1) fallback = 1;
+    prev = gbest;
+    n_win++;
+  }
+  if (lane == 0) { rv.win_count[box] = n_win; rv.fallback[box] = fallback; }
+}
+// the winners' corners, rebuilt from their slots (slot_corners16: the values the scorer saw): one lane per winner, behind the ranking kernels
+// (round 6; a winner's corners used to be one lane's work inside its box's ranking workgroup -- ~800 instructions with the others idle)
+__global__ __launch_bounds__(64) void winner_corners_kernel(DetectDeviceView v, RankView rv, int kmax, double short_sq_bound) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= rv.n_boxes * kmax) return;
+  const int q = e / kmax, r = e - q * kmax;
+  if (r >= rv.win_count[q]) return;
+  RankWinner* w = rv.winners + e;
+  slot_corners16(v, w->slot, short_sq_bound, w->corners);
+}
 void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams& rp, hipStream_t st, long long max_slots_per_box) {
   if (skip_kernel("rank")) return;
   if (rv.n_boxes <= 0) return;
@@ -1844,14 +2141,22 @@ void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams
     static DynLdsOnce big_lds;      // per device (cs_hip_util.h)
     const size_t lds = 2 * (size_t)RANK_STAGE_BIG * sizeof(double);
     if (big_lds.set(reinterpret_cast<const void*>(rank_kernel<RANK_THREADS_BIG, true>), (int)lds)) {
-      hipLaunchKernelGGL((rank_kernel<RANK_THREADS_BIG, true>), dim3(rv.n_boxes), dim3(RANK_THREADS_BIG), lds, st, v, rv, rp, (int)RANK_STAGE_BIG);
+      hipLaunchKernelGGL((rank_kernel<RANK_THREADS_BIG, true>), dim3(rv.n_boxes), dim3(RANK_THREADS_BIG), lds, st, v, rv, rp, (int)RANK_STAGE_BIG, 0);
+      hipLaunchKernelGGL(winner_corners_kernel, dim3((rv.n_boxes * rp.kmax + 63) / 64), dim3(64), 0, st, v, rv, rp.kmax, rp.short_sq_bound);
       return;
     }
     // (refused: the ordinary instance below ranks the same boxes in more passes over its fixed staging columns)
   }
-  if (nt == 64) hipLaunchKernelGGL((rank_kernel<64, false>), dim3(rv.n_boxes), dim3(64), 0, st, v, rv, rp, (int)RANK_STAGE);
-  else if (nt == 128) hipLaunchKernelGGL((rank_kernel<128, false>), dim3(rv.n_boxes), dim3(128), 0, st, v, rv, rp, (int)RANK_STAGE);
-  else hipLaunchKernelGGL((rank_kernel<256, false>), dim3(rv.n_boxes), dim3(256), 0, st, v, rv, rp, (int)RANK_STAGE);
+  // boxes of <= RW_CAP valid proposals per height sample: a wavefront each (CS_RANK_WAVE=0: every box to rank_kernel -- the A / B switch and
+  // the tests that hold the two kernels to each other); the others in rank_kernel behind it
+  static const int wave = [] { const char* e = getenv("CS_RANK_WAVE"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (wave) hipLaunchKernelGGL(rank_wave_kernel, dim3(rv.n_boxes), dim3(64), 0, st, v, rv, rp);
+  {     // (its workgroups of the boxes ranked above return at once: 8 us for 8 000 boxes)
+    if (nt == 64) hipLaunchKernelGGL((rank_kernel<64, false>), dim3(rv.n_boxes), dim3(64), 0, st, v, rv, rp, (int)RANK_STAGE, wave);
+    else if (nt == 128) hipLaunchKernelGGL((rank_kernel<128, false>), dim3(rv.n_boxes), dim3(128), 0, st, v, rv, rp, (int)RANK_STAGE, wave);
+    else hipLaunchKernelGGL((rank_kernel<256, false>), dim3(rv.n_boxes), dim3(256), 0, st, v, rv, rp, (int)RANK_STAGE, wave);
+  }
+  hipLaunchKernelGGL(winner_corners_kernel, dim3((rv.n_boxes * rp.kmax + 63) / 64), dim3(64), 0, st, v, rv, rp.kmax, rp.short_sq_bound);
 }
 void launch_records(const DetectDeviceView& v, const RankView& rv, int kmax, cs_cuboid* out, hipStream_t st, const double* raw_euler) {
   if (skip_kernel("records")) return;

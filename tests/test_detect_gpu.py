@@ -196,6 +196,19 @@ def test_many_tie_boxes_take_the_separate_host_pass():
     assert tm["n_fallback_boxes"] == 80
 
 
+def test_workgroup_ranking_kernel_alone_gives_the_same_records():
+    """The boxes of <= 1 792 valid proposals per height sample are ranked by rank_wave_kernel (one wavefront per box, the order
+    statistics by a bit walk over candidate masks), the others by rank_kernel (a workgroup per box, radix selection): with
+    CS_RANK_WAVE=0 every box goes to rank_kernel -- the ranking tests above must hold to the oracle either way, so the two kernels
+    agree with each other record for record."""
+    import subprocess, sys
+    here = os.path.abspath(__file__)
+    out = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-k", "device_ranking or tie_boxes or ties_decided or height_sampling"],
+                         env={**os.environ, "CS_RANK_WAVE": "0"}, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(here)))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout
+
+
 def test_device_ranking_with_roll_pitch_sampling_carries_camera_yaw():
     """The reference's default mode: 25 camera poses per box, and the camera yaw the next box of the frame starts from is the
     yaw of the pose of the LAST proposal the previous box's ranking kept.  The device ranking hands that proposal back
