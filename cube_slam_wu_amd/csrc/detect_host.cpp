@@ -50,8 +50,8 @@ void launch_scan_compact(const DetectDeviceView& v, hipStream_t st);
 void launch_scan_compact_trips(const DetectDeviceView& v, int* cnt, int max_trips, hipStream_t st);
 void launch_score(const DetectDeviceView& v, const SweepParams& sp, long long n_valid_bound, long long slot_total, hipStream_t st);
 void launch_gather_corners(const DetectDeviceView& v, const SweepParams& sp, const long long* slots, int n, double* out, hipStream_t st);
-void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams& rp, hipStream_t st, long long max_slots_per_box = 0);
-void launch_records(const DetectDeviceView& v, const RankView& rv, int kmax, cs_cuboid* out, hipStream_t st, const double* raw_euler = nullptr);
+void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams& rp, hipStream_t st, long long max_slots_per_box = 0, bool with_corners = true);
+void launch_records(const DetectDeviceView& v, const RankView& rv, int kmax, cs_cuboid* out, hipStream_t st, const double* raw_euler = nullptr, double rebuild_short_sq_bound = -1.0);
 void launch_rp_carry(const RpCarryView& c, JobDesc* jobs, hipStream_t st);
 void launch_rp_save_fallback(const DetectDeviceView& v, const RpSaveView& s, hipStream_t st);
 struct EdgeRoi { int l, t, w, h; long long img_off, cls_off, map_off; };
@@ -1302,8 +1302,8 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   cs::RankView rv{};
   rv.box_job0 = p_box_job0; rv.box_njobs = p_box_njobs; rv.n_boxes = (int)nb; rv.winners = S.winners.p; rv.win_count = p_win_count; rv.fallback = p_fallback;
   cs::RankParams rkp{P.weight_vp_angle, P.weight_skew_error, P.nominal_skew_ratio, P.max_cut_skew, KMAX, C.sp.short_sq_bound};
-  cs::launch_rank(v, rv, rkp, st);
-  cs::launch_records(v, rv, KMAX, p_records, st);     // the records of the boxes the device ranked: only they come back
+  cs::launch_rank(v, rv, rkp, st, 0, false);          // (the host reads no winner of the device: record_kernel rebuilds their corners)
+  cs::launch_records(v, rv, KMAX, p_records, st, nullptr, rkp.short_sq_bound);     // the records of the boxes the device ranked: only they come back
   HIP_TRY(hipEventRecord(S.ev[6], st));
   HIP_TRY(hipGetLastError());
   if (S.merged_io) {
@@ -1737,8 +1737,8 @@ int rp_launch(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>>&
     cs::RankView rv{};
     rv.box_job0 = S.box_job0.p + Rr.b0; rv.box_njobs = S.box_njobs.p + Rr.b0; rv.n_boxes = (int)Rr.nb; rv.winners = S.winners.p + Rr.b0 * KMAX;
     rv.win_count = S.win_count.p + Rr.b0; rv.fallback = S.fallback.p + Rr.b0; rv.last_slot = S.rp_last_slot.p + Rr.b0;
-    cs::launch_rank(v, rv, rkp, st, Rr.nb ? (long long)(Rr.slot_cap / (long long)Rr.nb) : 0);      // (average slots per box of the round: which instance ranks)
-    cs::launch_records(v, rv, KMAX, S.records.p + Rr.b0 * KMAX, st, S.rp_raw_euler.p);
+    cs::launch_rank(v, rv, rkp, st, Rr.nb ? (long long)(Rr.slot_cap / (long long)Rr.nb) : 0, false);      // (average slots per box of the round: which instance ranks)
+    cs::launch_records(v, rv, KMAX, S.records.p + Rr.b0 * KMAX, st, S.rp_raw_euler.p, rkp.short_sq_bound);
     {   // the flagged boxes' columns, before the next round reuses the arrays
       cs::RpSaveView sv{};
       sv.fallback = rv.fallback; sv.box_job0 = rv.box_job0; sv.box_njobs = rv.box_njobs; sv.n_boxes = rv.n_boxes; sv.pool_used = S.rp_pool_used.p; sv.pool_cap = S.rp_pool_cap;

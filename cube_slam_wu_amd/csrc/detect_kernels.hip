@@ -1016,8 +1016,10 @@ enum { RANK_STAGE = 1536, RANK_THREADS_DEFAULT = 256 };   // proposals of one he
 // proposals (25 camera poses) and only ~100 boxes are ranked per launch: a workgroup then owns a CU's LDS and 16 waves, and the ~20
 // selection passes run from LDS instead of L2
 enum { RANK_STAGE_BIG = 9216, RANK_THREADS_BIG = 1024 };
+// (the body: rank_kernel's workgroups, and -- NT = 64, no staging columns -- rank_wave_kernel's wavefront for a box with a height sample
+// too large for its registers)
 template <int NT, bool DYN>
-__global__ __launch_bounds__(NT) void rank_kernel(DetectDeviceView v, RankView rv, RankParams rp, int stage_cap, int wave_boxes_elsewhere) {
+__device__ __forceinline__ void rank_block_body(const DetectDeviceView& v, const RankView& rv, const RankParams& rp, int stage_cap, int box) {
   __shared__ unsigned hist[512];
   __shared__ unsigned long long bcast[4];
   __shared__ double shd[NT / 64 > 4 ? NT / 64 : 4];
@@ -1029,10 +1031,7 @@ __global__ __launch_bounds__(NT) void rank_kernel(DetectDeviceView v, RankView r
   double* const sD = DYN ? rank_dyn_lds : sD_fixed;
   double* const sA = DYN ? rank_dyn_lds + stage_cap : sA_fixed;
   const int STAGE = DYN ? stage_cap : (int)RANK_STAGE;
-  int box = blockIdx.x;
-  if (box >= rv.n_boxes) return;
   const int j0 = rv.box_job0[box], nj = rv.box_njobs[box];
-  if (wave_boxes_elsewhere && rank_box_fits_wave(v, j0, nj)) return;     // rank_wave_kernel's box
   if (threadIdx.x == 0) s_fallback = 0;
   __syncthreads();
   const double INF = __builtin_huge_val();
@@ -1189,6 +1188,10 @@ __global__ __launch_bounds__(NT) void rank_kernel(DetectDeviceView v, RankView r
   }
   __syncthreads();
   if (threadIdx.x == 0) { rv.win_count[box] = n_win; rv.fallback[box] = s_fallback; }
+}
+template <int NT, bool DYN>
+__global__ __launch_bounds__(NT) void rank_kernel(DetectDeviceView v, RankView rv, RankParams rp, int stage_cap) {
+  if ((int)blockIdx.x < rv.n_boxes) rank_block_body<NT, DYN>(v, rv, rp, stage_cap, blockIdx.x);
 }
 
 
@@ -1710,12 +1713,21 @@ int line_setup_capacity() { return LS_CAP; }
 // compute3D_BoxCorner (:59-73) with similarityTransformation (:15-44).  cos / sin of the yaw come from the sample tables the host
 // filled with glibc's values (the same calls the host-side record writer makes), so every field carries the host writer's bits.
 // rect_detect_2d is the caller's box and is filled in by the host when it copies the record out.
-__global__ __launch_bounds__(64) void record_kernel(DetectDeviceView v, RankView rv, int kmax, cs_cuboid* __restrict__ out, const double* __restrict__ raw_euler) {
+// REBUILD: the winner's corners are rebuilt here from its slot (slot_corners16) instead of read from the winner record -- the paths whose
+// host never reads the device's winners launch no winner_corners_kernel
+template <bool REBUILD>
+__global__ __launch_bounds__(64) void record_kernel(DetectDeviceView v, RankView rv, int kmax, cs_cuboid* __restrict__ out, const double* __restrict__ raw_euler, double short_sq_bound) {
   const int e = blockIdx.x * 64 + threadIdx.x;
   if (e >= rv.n_boxes * kmax) return;
   const int q = e / kmax, r = e - q * kmax;
   if (rv.fallback[q] || r >= rv.win_count[q]) return;
   const RankWinner& w = rv.winners[e];
+  double wc[16];
+  if (REBUILD) slot_corners16(v, w.slot, short_sq_bound, wc);
+  else {
+#pragma unroll
+    for (int i = 0; i < 16; i++) wc[i] = w.corners[i];
+  }
   const int j0 = rv.box_job0[q], nh = rv.box_njobs[q];
   int h = 0;
   while (h + 1 < nh && w.slot >= v.jobs[j0 + h + 1].slot_off) h++;
@@ -1732,7 +1744,7 @@ __global__ __launch_bounds__(64) void record_kernel(DetectDeviceView v, RankView
   }
   V2 c[8];
 #pragma unroll
-  for (int i = 0; i < 8; i++) c[i] = v2(w.corners[i], w.corners[8 + i]);
+  for (int i = 0; i < 8; i++) c[i] = v2(wc[i], wc[8 + i]);
   lift_to_3d(c, pose.R, pose.t, v.invK + 9 * jd.frame, pose.plane, o.pos, o.scale);
   o.rotY = v.yaw[jd.yaw_off + y];
   const int vp1_pos = w.flag & CAND_VP_MASK;
@@ -1741,8 +1753,8 @@ __global__ __launch_bounds__(64) void record_kernel(DetectDeviceView v, RankView
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     const int id = (vp1_pos == 1) ? left_ids[i] : right_ids[i];
-    o.box_corners_2d[i] = (int)w.corners[id - 1];
-    o.box_corners_2d[8 + i] = (int)w.corners[8 + id - 1];
+    o.box_corners_2d[i] = (int)wc[id - 1];
+    o.box_corners_2d[8 + i] = (int)wc[8 + id - 1];
   }
   const double body[3][8] = {{1, 1, -1, -1, 1, 1, -1, -1}, {1, -1, -1, 1, 1, -1, -1, 1}, {-1, -1, -1, -1, 1, 1, 1, 1}};
   const double cr = v.yaw_cos[jd.yaw_off + y], sr = v.yaw_sin[jd.yaw_off + y];
@@ -1985,7 +1997,9 @@ __global__ __launch_bounds__(64) void rank_wave_kernel(DetectDeviceView v, RankV
   const int box = blockIdx.x;
   if (box >= rv.n_boxes) return;
   const int j0 = rv.box_job0[box], nj = rv.box_njobs[box];
-  if (!rank_box_fits_wave(v, j0, nj)) return;
+  // (a height sample too large for the registers: rank_kernel's procedure on this one wavefront, its columns read from L2 -- rare outside
+  // the roll/pitch rounds, which have their own instance; no second launch in the batch's chain)
+  if (!rank_box_fits_wave(v, j0, nj)) { rank_block_body<64, true>(v, rv, rp, 0, box); return; }
   const int lane = threadIdx.x;
   const double INF = __builtin_huge_val();
   int fallback = 0;
@@ -2131,38 +2145,40 @@ __global__ __launch_bounds__(64) void winner_corners_kernel(DetectDeviceView v, 
   RankWinner* w = rv.winners + e;
   slot_corners16(v, w->slot, short_sq_bound, w->corners);
 }
-void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams& rp, hipStream_t st, long long max_slots_per_box) {
+// with_corners: the winners' corners are written into the winner records (winner_corners_kernel) -- the paths whose host reads the device's
+// winners; the others let record_kernel rebuild them (launch_records' rebuild_short_sq_bound)
+void launch_rank(const DetectDeviceView& v, const RankView& rv, const RankParams& rp, hipStream_t st, long long max_slots_per_box, bool with_corners) {
   if (skip_kernel("rank")) return;
   if (rv.n_boxes <= 0) return;
   static const int nt = [] { const char* e = getenv("CS_RANK_THREADS"); const int q = e ? atoi(e) : 0; return (q == 64 || q == 128 || q == 256) ? q : RANK_THREADS_DEFAULT; }();
   static const bool no_big = getenv("CS_RANK_NO_BIG") != nullptr;     // diagnostics / tests: the ordinary instance for every launch
+  // one wavefront per box (boxes with a height sample above RW_CAP valid proposals: rank_kernel's procedure on that wavefront); CS_RANK_WAVE=0:
+  // a workgroup per box, rank_kernel -- the A / B switch, and the tests that hold the two kernels to each other
+  static const int wave = [] { const char* e = getenv("CS_RANK_WAVE"); return (e && e[0] == '0') ? 0 : 1; }();
+  bool done = false;
   // boxes that can hold far more valid proposals than the fixed staging columns (the caller's bound on a box's slots): the big instance
   if (!no_big && max_slots_per_box > 8 * (long long)RANK_STAGE) {
     static DynLdsOnce big_lds;      // per device (cs_hip_util.h)
     const size_t lds = 2 * (size_t)RANK_STAGE_BIG * sizeof(double);
     if (big_lds.set(reinterpret_cast<const void*>(rank_kernel<RANK_THREADS_BIG, true>), (int)lds)) {
-      hipLaunchKernelGGL((rank_kernel<RANK_THREADS_BIG, true>), dim3(rv.n_boxes), dim3(RANK_THREADS_BIG), lds, st, v, rv, rp, (int)RANK_STAGE_BIG, 0);
-      hipLaunchKernelGGL(winner_corners_kernel, dim3((rv.n_boxes * rp.kmax + 63) / 64), dim3(64), 0, st, v, rv, rp.kmax, rp.short_sq_bound);
-      return;
+      hipLaunchKernelGGL((rank_kernel<RANK_THREADS_BIG, true>), dim3(rv.n_boxes), dim3(RANK_THREADS_BIG), lds, st, v, rv, rp, (int)RANK_STAGE_BIG);
+      done = true;
     }
-    // (refused: the ordinary instance below ranks the same boxes in more passes over its fixed staging columns)
+    // (refused: the ordinary instances below rank the same boxes in more passes)
   }
-  // boxes of <= RW_CAP valid proposals per height sample: a wavefront each (CS_RANK_WAVE=0: every box to rank_kernel -- the A / B switch and
-  // the tests that hold the two kernels to each other); the others in rank_kernel behind it
-  static const int wave = [] { const char* e = getenv("CS_RANK_WAVE"); return (e && e[0] == '0') ? 0 : 1; }();
-  if (wave) hipLaunchKernelGGL(rank_wave_kernel, dim3(rv.n_boxes), dim3(64), 0, st, v, rv, rp);
-  {     // (its workgroups of the boxes ranked above return at once: 8 us for 8 000 boxes)
-    if (nt == 64) hipLaunchKernelGGL((rank_kernel<64, false>), dim3(rv.n_boxes), dim3(64), 0, st, v, rv, rp, (int)RANK_STAGE, wave);
-    else if (nt == 128) hipLaunchKernelGGL((rank_kernel<128, false>), dim3(rv.n_boxes), dim3(128), 0, st, v, rv, rp, (int)RANK_STAGE, wave);
-    else hipLaunchKernelGGL((rank_kernel<256, false>), dim3(rv.n_boxes), dim3(256), 0, st, v, rv, rp, (int)RANK_STAGE, wave);
-  }
-  hipLaunchKernelGGL(winner_corners_kernel, dim3((rv.n_boxes * rp.kmax + 63) / 64), dim3(64), 0, st, v, rv, rp.kmax, rp.short_sq_bound);
+  if (done) { }
+  else if (wave) hipLaunchKernelGGL(rank_wave_kernel, dim3(rv.n_boxes), dim3(64), 0, st, v, rv, rp);
+  else if (nt == 64) hipLaunchKernelGGL((rank_kernel<64, false>), dim3(rv.n_boxes), dim3(64), 0, st, v, rv, rp, (int)RANK_STAGE);
+  else if (nt == 128) hipLaunchKernelGGL((rank_kernel<128, false>), dim3(rv.n_boxes), dim3(128), 0, st, v, rv, rp, (int)RANK_STAGE);
+  else hipLaunchKernelGGL((rank_kernel<256, false>), dim3(rv.n_boxes), dim3(256), 0, st, v, rv, rp, (int)RANK_STAGE);
+  if (with_corners) hipLaunchKernelGGL(winner_corners_kernel, dim3((rv.n_boxes * rp.kmax + 63) / 64), dim3(64), 0, st, v, rv, rp.kmax, rp.short_sq_bound);
 }
-void launch_records(const DetectDeviceView& v, const RankView& rv, int kmax, cs_cuboid* out, hipStream_t st, const double* raw_euler) {
+void launch_records(const DetectDeviceView& v, const RankView& rv, int kmax, cs_cuboid* out, hipStream_t st, const double* raw_euler, double rebuild_short_sq_bound) {
   if (skip_kernel("records")) return;
   const int n = rv.n_boxes * kmax;
   if (n <= 0) return;
-  hipLaunchKernelGGL(record_kernel, dim3((n + 63) / 64), dim3(64), 0, st, v, rv, kmax, out, raw_euler);
+  if (rebuild_short_sq_bound >= 0) hipLaunchKernelGGL(record_kernel<true>, dim3((n + 63) / 64), dim3(64), 0, st, v, rv, kmax, out, raw_euler, rebuild_short_sq_bound);
+  else hipLaunchKernelGGL(record_kernel<false>, dim3((n + 63) / 64), dim3(64), 0, st, v, rv, kmax, out, raw_euler, 0.0);
 }
 // ---- roll/pitch sampling on the device: the camera yaw carried from box to box ----------------------------------------------
 // With whether_sample_cam_roll_pitch the yaw list of a box starts from cam_pose.camera_yaw as the previous box of the frame left it
