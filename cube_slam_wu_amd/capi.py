@@ -420,7 +420,7 @@ DECLARED_SYMBOLS += [
     "cs_ba_compute_errors", "cs_ba_build_system", "cs_ba_solve", "cs_ba_update", "cs_ba_push", "cs_ba_pop", "cs_ba_optimize",
     "cs_ba_get_state", "cs_ba_sizes", "cs_ba_solver_layout", "cs_ba_get_system", "cs_ba_last_timing", "cs_ba_set_shard", "cs_ba_optimize_sharded",
     "cs_ba_shard_landmark_owners", "cs_ba_get_landmark_owners", "cs_ba_shard_info", "cs_ba_shard_timing", "cs_ba_append_vertices", "cs_ba_append_edges_proj", "cs_ba_append_edges_cuboid", "cs_ba_append_edges_cuboid_proj", "cs_ba_append_edges_odom", "cs_ba_get_vertex_hessians", "cs_ba_schur_layout", "cs_ba_structure_digest", "cs_ba_reduced_size", "cs_ba_solver_path", "cs_ba_band_order", "cs_ba_comm_unique_id", "cs_ba_comm_init", "cs_ba_set_robust_kernels",
-    "cs_ba_set_external_edges", "cs_ba_set_external_terms", "cs_ba_set_external_chi2", "cs_ba_set_external_callback", "cs_ba_check_finite", "cs_ba_dump", "cs_ba_load", "cs_ba_get_reduced_system", "cs_ba_set_stage_timing", "cs_ba_pose_marginals",
+    "cs_ba_set_external_edges", "cs_ba_set_external_terms", "cs_ba_set_external_chi2", "cs_ba_set_external_callback", "cs_ba_check_finite", "cs_ba_dump", "cs_ba_load", "cs_ba_get_reduced_system", "cs_ba_set_stage_timing", "cs_ba_set_lm_params", "cs_ba_pose_marginals",
 ]
 
 
@@ -742,6 +742,12 @@ class BaProblem:
     def stage_timing(self, on=True):
         """g2o's setComputeBatchStatistics: turn the per-stage split of timing() on (off by default: its phase marks cost ~6 us each on the stream)."""
         _chk(lib().cs_ba_set_stage_timing(self.h, 1 if on else 0), "cs_ba_set_stage_timing")
+        return self
+
+    def set_lm_params(self, user_lambda_init=0.0, max_trials_after_failure=10):
+        """OptimizationAlgorithmLevenberg::setUserLambdaInit / setMaxTrialsAfterFailure (optimization_algorithm_levenberg.cpp:191-199)."""
+        lib().cs_ba_set_lm_params.argtypes = [C.c_void_p, C.c_double, C.c_int]
+        _chk(lib().cs_ba_set_lm_params(self.h, float(user_lambda_init), int(max_trials_after_failure)), "cs_ba_set_lm_params")
         return self
 
     def timing(self):

@@ -288,6 +288,9 @@ struct cs_ba {
   // G2OBatchStatistics-like stage split (core/batch_stats.h:48-62): like g2o's setComputeBatchStatistics it is OFF unless asked for
   // (cs_ba_set_stage_timing) -- every phase mark is an event on the stream, ~6 us of dispatch gap each, eight per LM trial
   bool stage_timing = false;
+  // OptimizationAlgorithmLevenberg's two properties (optimization_algorithm_levenberg.cpp:50-51, setters :191-199): cs_ba_set_lm_params
+  double user_lambda_init = 0.0;      // "initialLambda": > 0 replaces tau * max |H_jj| (computeLambdaInit :168-169)
+  int max_trials_after_failure = 10;  // "maxTrialsAfterFailure": trials of one iteration (:149-151)
   hipEvent_t ev_upd = nullptr;     // recorded behind a trial's update kernel when the next linearisation is speculated: its side streams fork there
   size_t scalars_cap = 0;
   // host copy of the problem description
@@ -2504,7 +2507,7 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
       BA_TRY(hipGetLastError());
       BA_TRY(hipMemcpyAsync(B->h_scalars, B->d_scalars.p, sizeof(double), hipMemcpyDeviceToHost, B->st));
       BA_TRY(hipStreamSynchronize(B->st));
-      lambda = 1e-5 * B->h_scalars[0];
+      lambda = B->user_lambda_init > 0 ? B->user_lambda_init : 1e-5 * B->h_scalars[0];      // (:168-169: a user value wins)
       ni = 2; nBad = 0;
     } else if (it == 0) {
       BA_TRY(hipStreamSynchronize(B->st));   // the copies below run on the NULL stream, which B->st does not order with
@@ -2521,7 +2524,7 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
       for (int i = 0; i < B->n_pose; i++) md = std::max(std::fabs(pd[i]), md);
       for (int i = 0; i < B->np; i++) if (B->pt_lm[i] >= 0) for (int d = 0; d < 3; d++) md = std::max(std::fabs(hl[9 * (size_t)i + 4 * d]), md);
       if (reduce_host(&md, 1, 1)) { cs_set_error_ba("all-reduce failed"); return CS_ERR_HIP; }
-      lambda = 1e-5 * md;
+      lambda = B->user_lambda_init > 0 ? B->user_lambda_init : 1e-5 * md;
       ni = 2; nBad = 0;
     }
     double rho = 0;
@@ -2624,7 +2627,7 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
         }
       }
       qmax++;
-    } while (rho < 0 && qmax < 10);
+    } while (rho < 0 && qmax < B->max_trials_after_failure);
     if (!spec_lin) BA_TRY(hipStreamSynchronize(B->st));
     if (done < cap) {
       if (chi_hist) chi_hist[done] = currentChi;
@@ -2633,7 +2636,7 @@ static int cs_ba_optimize_sharded_impl(cs_ba* B, int iterations, cs_allreduce_fn
     }
     done++;
     carriedChi = currentChi; have_carried = true;
-    if (qmax == 10 || rho == 0) break;
+    if (qmax == B->max_trials_after_failure || rho == 0) break;
     if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
     if (nBad >= 3) break;
   }
@@ -3006,6 +3009,12 @@ int cs_ba_get_vertex_hessians(cs_ba* B, double* cam36, double* cub81, double* pt
 }
 
 
+int cs_ba_set_lm_params(cs_ba* B, double user_lambda_init, int max_trials_after_failure) {
+  if (!B || !(user_lambda_init == user_lambda_init) || max_trials_after_failure < 1) return CS_ERR_INVALID_ARG;
+  B->user_lambda_init = user_lambda_init > 0 ? user_lambda_init : 0.0;
+  B->max_trials_after_failure = max_trials_after_failure;
+  return CS_OK;
+}
 int cs_ba_set_stage_timing(cs_ba* B, int on) {
   if (!B) return CS_ERR_INVALID_ARG;
   B->stage_timing = on != 0;

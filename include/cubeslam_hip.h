@@ -458,6 +458,11 @@ int cs_ba_last_timing(cs_ba* ba, cs_ba_timing* t);
  * event on the handle's stream (~6 us of dispatch gap each, eight per LM trial), and with the marks on, cs_ba_optimize also gives up queueing the
  * next iteration's linearisation behind a trial before the trial's verdict is known.  total_ms, the counters and the byte figures are always kept. */
 int cs_ba_set_stage_timing(cs_ba* ba, int on);
+/* OptimizationAlgorithmLevenberg's two properties (core/optimization_algorithm_levenberg.cpp:50-51; setUserLambdaInit :196-199,
+ * setMaxTrialsAfterFailure :191-194): user_lambda_init > 0 is the first iteration's lambda instead of tau * max |H_jj| (computeLambdaInit
+ * :166-180; <= 0: computed, the default), max_trials_after_failure (>= 1, default 10) bounds the trials of one iteration (:149) -- an iteration
+ * that uses them all ends the run as in :151.  Applies to cs_ba_optimize calls that follow. */
+int cs_ba_set_lm_params(cs_ba* ba, double user_lambda_init, int max_trials_after_failure);
 
 /* Debug / repro aids (what g2o offers through its debug builds and its text IO).
  * cs_ba_check_finite: scans for NaN / Inf where g2o's debug builds look for them -- the edges' errors (SparseOptimizer::

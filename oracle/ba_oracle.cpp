@@ -276,6 +276,7 @@ struct Problem {
   std::vector<double> err_proj, err_cub, err_cproj, err_odom;  // 2, 9, 4, 6 per edge
   // LM state
   double lambda = -1, ni = 2; int nBad = 0, levenberg_iterations = 0;
+  double user_lambda_init = 0; int max_trials_after_failure = 10;      // the class's two properties (optimization_algorithm_levenberg.cpp:50-51, :191-199)
   // backup stack (depth 1 is all LM needs)
   std::vector<SE3> cams_bak; std::vector<Cuboid> cubs_bak; std::vector<double> pts_bak;
   // stats
@@ -828,7 +829,7 @@ int lm_solve(Problem& P, int iteration) {
     int n = P.size_pose;
     for (int i = 0; i < n; i++) maxDiagonal = std::max(std::fabs(P.Hpp[(size_t)i * n + i]), maxDiagonal);
     for (int j = 0; j < P.n_lm; j++) for (int d = 0; d < 3; d++) maxDiagonal = std::max(std::fabs(P.Hll[9 * j + 4 * d]), maxDiagonal);
-    P.lambda = 1e-5 * maxDiagonal;
+    P.lambda = P.user_lambda_init > 0 ? P.user_lambda_init : 1e-5 * maxDiagonal;      // (:168-169)
     P.ni = 2; P.nBad = 0;
   }
   double rho = 0;
@@ -864,10 +865,10 @@ int lm_solve(Problem& P, int iteration) {
       P.cams = P.cams_bak; P.cubs = P.cubs_bak; P.pts = P.pts_bak;  // pop
     }
     qmax++;
-  } while (rho < 0 && qmax < 10);
+  } while (rho < 0 && qmax < P.max_trials_after_failure);
   P.levenberg_iterations = qmax;
   P.chi_hist.push_back(currentChi); P.lambda_hist.push_back(P.lambda); P.trials_hist.push_back(qmax);
-  if (qmax == 10 || rho == 0) return 1;
+  if (qmax == P.max_trials_after_failure || rho == 0) return 1;
   if ((iniChi - currentChi) * 1e3 < iniChi) P.nBad++; else P.nBad = 0;
   if (P.nBad >= 3) return 1;
   return 0;
@@ -984,6 +985,7 @@ void ba_oracle_stage_ms(void* h, double out5[5], int reset) {
 // bench.py's cpu_baseline at C4: time every stride-th column of the dense LDL^T (Problem::ldlt_stride); 1 = the real solve
 void ba_oracle_set_ldlt_stride(void* h, int stride) { ((Problem*)h)->ldlt_stride = stride < 1 ? 1 : stride; }
 // The reduced system's dense solve through a caller's routine (see Problem::dense_solver); nullptr restores the LDL^T of this file.
+void ba_oracle_set_lm_params(void* h, double user_lambda_init, int max_trials) { ((Problem*)h)->user_lambda_init = user_lambda_init; ((Problem*)h)->max_trials_after_failure = max_trials; }
 void ba_oracle_set_dense_solver(void* h, int (*fn)(double*, int, const double*, double*)) { ((Problem*)h)->dense_solver = fn; }
 // stage-level access for parity tests
 double ba_oracle_compute_errors(void* h) { Problem& P = *(Problem*)h; compute_errors(P); return robust_chi2(P); }

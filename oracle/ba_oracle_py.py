@@ -110,6 +110,12 @@ class Problem:
         """Timing runs only: sample every stride-th column of the dense LDL^T (no increment is computed)."""
         lib().ba_oracle_set_ldlt_stride(self.h, int(stride))
 
+    def set_lm_params(self, user_lambda_init=0.0, max_trials_after_failure=10):
+        """setUserLambdaInit / setMaxTrialsAfterFailure (optimization_algorithm_levenberg.cpp:191-199)."""
+        lib().ba_oracle_set_lm_params.argtypes = [C.c_void_p, C.c_double, C.c_int]
+        lib().ba_oracle_set_lm_params(self.h, float(user_lambda_init), int(max_trials_after_failure))
+        return self
+
     def use_lapack_solver(self, one_thread=False):
         """The reduced system's dense solve through LAPACK (scipy cho_factor / cho_solve on the matrix ba_oracle.cpp assembled) instead of
         the file's textbook LDL^T -- for sizes where that one is out of reach (C4: 10 494 unknowns, 24 minutes per solve).  Linearisation,

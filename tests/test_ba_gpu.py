@@ -922,6 +922,54 @@ def test_three_lm_iterations_at_full_c4_size_against_the_oracle():
     G.close(); R.close()
 
 
+def test_lm_properties_user_lambda_init_and_max_trials_against_the_oracle():
+    """OptimizationAlgorithmLevenberg's two properties (optimization_algorithm_levenberg.cpp:50-51, setters :191-199) through
+    cs_ba_set_lm_params: a user lambda far below tau * max |H_jj| makes the first steps overshoot -- iterations of up to seven trials, the
+    nu-doubling branch (:143-148) taken again and again --, and the device has to walk the oracle's accept / reject sequence trial for trial;
+    with maxTrialsAfterFailure = 2 the run ends at the iteration that uses both trials (:151), on both sides."""
+    from oracle import ba_parity
+    pr = synth_ba.make_problem(n_cams=60, n_points=3000, n_cuboids=8, seed=42)
+    G, R = capi.ba_from_dict(pr), _oracle(pr)
+    G.set_lm_params(1e-6, 10); R.set_lm_params(1e-6, 10)
+    d = ba_parity.compare_trajectory(G, R, 5)
+    print("user lambda 1e-6", d)
+    assert d["iterations_device"] == d["iterations_oracle"] == 5 and d["same_trial_sequence"]
+    assert sum(d["trials_oracle"]) >= 12 and max(d["trials_oracle"]) >= 4          # (rejected trials in a row)
+    assert d["chi2"] < 1e-6 and d["lambda"] < 1e-6
+    assert d["points"] < 1e-5 and d["camera_positions"] < 1e-5 and d["camera_quaternions"] < 1e-5
+    G.close(); R.close()
+    G, R = capi.ba_from_dict(pr), _oracle(pr)
+    G.set_lm_params(1e-8, 2); R.set_lm_params(1e-8, 2)
+    n_g, n_r = G.optimize(6), R.optimize(6)
+    assert n_g == n_r and n_r < 6                       # both gave up at the same iteration
+    assert np.array_equal(G.history()[2], R.history()[2]) and int(R.history()[2][-1]) == 2
+    assert np.allclose(G.history()[0], R.history()[0], rtol=1e-9)
+    with pytest.raises(Exception):
+        G.set_lm_params(0.0, 0)
+    G.close(); R.close()
+
+
+def test_rejected_trials_at_full_c4_size_against_the_oracle():
+    """The branch the C4 trajectory test above never takes (its three iterations are accepted at the first trial): at C4's full size with a
+    user lambda of 1e-4 (cs_ba_set_lm_params; at 1e-6 the first step is so badly conditioned that the chi2 it lands on is only reproducible to 3e-5,
+    states to 1e-7) the second iteration rejects trial after trial -- estimates restored, lambda times nu, nu doubled
+    (optimization_algorithm_levenberg.cpp:143-148), the speculated linearisation of the next iteration discarded every time -- and the device
+    has to walk the oracle's sequence.  (The oracle's 10 494-unknown solves through LAPACK: ~8 s per trial.)"""
+    from oracle import ba_parity
+    pr = synth_ba.make_problem(n_cams=1000, n_points=200000, n_cuboids=500, seed=42)
+    G, R = capi.ba_from_dict(pr), _oracle(pr)
+    R.use_lapack_solver()
+    G.set_lm_params(1e-4, 10); R.set_lm_params(1e-4, 10)
+    d = ba_parity.compare_trajectory(G, R, 2)
+    print("C4 with rejected trials", d)
+    assert d["iterations_device"] == d["iterations_oracle"] == 2 and d["same_trial_sequence"]
+    assert max(d["trials_oracle"]) >= 3                                             # (rejected trials in a row)
+    assert d["chi2"] < 1e-6 and d["lambda"] < 1e-6
+    assert d["points"] < 1e-5 and d["camera_positions"] < 1e-5 and d["camera_quaternions"] < 1e-5
+    assert d["cuboid_positions"] < 1e-5 and d["cuboid_quaternions_and_sizes"] < 1e-5
+    G.close(); R.close()
+
+
 @pytest.mark.parametrize("views", [2, 4, 6, 9, 12])
 def test_fused_linearise_schur_kernel_equals_the_classic_pair_bitwise(views, monkeypatch):
     """Round 5: from the second LM iteration on cs_ba_optimize linearises the landmark side of the projection edges INSIDE the Schur kernels

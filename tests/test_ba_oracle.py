@@ -246,3 +246,36 @@ def test_lapack_hook_of_the_dense_solve_equals_the_restatements_own_ldlt():
     for a, b in zip(A.state(), B.state()):
         assert np.abs(a - b).max() < 1e-6
     A.close(); B.close()
+
+
+def test_lm_properties_of_the_restatement():
+    """The class's two properties as ba_oracle.cpp restates them (optimization_algorithm_levenberg.cpp:50-51, setters :191-199): a user
+    lambda is the first iteration's lambda (computeLambdaInit :168-169) -- the first recorded value is it times the accept factor, which the
+    clamp of :137-138 keeps in [1/3, 2/3] --, and maxTrialsAfterFailure bounds an iteration's trials and ends the run when they are used up
+    (:149-151).  The accept / reject walk itself (rho < 0: estimates restored, lambda times nu, nu doubled, :143-148) is checked by its own
+    bookkeeping: every rejected trial multiplies lambda by 2, 4, 8, ..."""
+    from cube_slam_wu_amd import synth_ba
+    pr = synth_ba.make_problem(n_cams=40, n_points=2000, n_cuboids=6, seed=5)
+
+    def mk(lam0, trials):
+        R = O.Problem(pr["cams"], pr["cam_fixed"], pr["cuboids"], pr["cub_fixed"], pr["points"], pr["pt_fixed"])
+        R.set_edges_proj(pr["e_pt"], pr["e_cam"], pr["e_uv"], pr["e_info"], pr["e_intr"], pr["e_huber"])
+        R.set_edges_cuboid(pr["ce_cam"], pr["ce_cub"], pr["ce_meas"], pr["ce_info"])
+        R.set_edges_odom(pr["oe_i"], pr["oe_j"], pr["oe_meas"], pr["oe_info"])
+        return R.set_lm_params(lam0, trials)
+    D = mk(0.0, 10)                                 # the defaults: tau * max |H_jj|
+    assert D.optimize(2) == 2
+    lam_default = D.history()[1][0]
+    A = mk(1e-6, 10)
+    assert A.optimize(4) == 4
+    chi, lam, tr = A.history()
+    assert tr[0] == 1 and 1e-6 / 3 * (1 - 1e-12) <= lam[0] <= 1e-6 * 2 / 3 * (1 + 1e-12) and lam[0] < 1e-6 * lam_default
+    assert tr.max() >= 3 and np.all(np.diff(chi) <= 0)            # rejected trials happened, and no accepted step raised chi2
+    k = int(np.argmax(tr))                                          # an iteration of q trials: q - 1 rejections = lambda x 2 x 4 x ... before the accept factor
+    grown = lam[k] / lam[k - 1]
+    assert grown >= 2.0 ** ((tr[k] - 1) * tr[k] // 2) / 3 * (1 - 1e-9)
+    B = mk(1e-8, 2)
+    n = B.optimize(6)
+    assert n < 6 and int(B.history()[2][-1]) == 2                   # gave up at the iteration that used both trials
+    for P in (D, A, B):
+        P.close()
