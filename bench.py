@@ -962,10 +962,10 @@ def main():
             tq = dl.lines_timing(); dev_ms += tq["device_ms"]; host_ms += tq["host_ms"]; call_ms += tq["total_ms"]; calls.append(tq["total_ms"])
         dtq = time.perf_counter() - t1
         px = Hq * Wq * args.lines_images
-        lines_out = {"what": "cs_detect_lines_batch: EDLines (one octave, length >= 15) of %d images of %d x %d; Gaussian / Sobel / gradient / anchors on the device (one packed word per pixel comes back), routing + fitting + validation on the host pool, which starts on the first images while the later ones are still being computed and copied (chunks of 4)" % (args.lines_images, Wq, Hq),
+        lines_out = {"what": "cs_detect_lines_batch: EDLines (one octave, length >= 15) of %d images of %d x %d; Gaussian / Sobel / gradient / anchors on the device (three packed bytes per pixel come back), routing + fitting + validation on the host pool, which starts on the first images while the later ones are still being computed and copied (chunks of 4)" % (args.lines_images, Wq, Hq),
                      "images_per_s": args.lines_images * reps / dtq, "segments_per_image": float(np.mean([len(x) for x in segs])),
                      "device_ms_per_batch": dev_ms / reps, "host_stage_ms_per_batch": host_ms / reps, "library_call_ms_per_batch": call_ms / reps, "library_call_ms_median": float(np.median(calls)),
-                     "maps_kernel": {"alg_bytes_per_batch": 5 * px, "GB/s": 5 * px / (dev_ms / reps * 1e-3) / 1e9, "frac_of_hbm_peak": 5 * px / (dev_ms / reps * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                     "maps_kernel": {"alg_bytes_per_batch": 4 * px, "GB/s": 4 * px / (dev_ms / reps * 1e-3) / 1e9, "frac_of_hbm_peak": 4 * px / (dev_ms / reps * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import edlines_oracle_py
             t1, nq = time.perf_counter(), 0

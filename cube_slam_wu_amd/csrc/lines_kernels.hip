@@ -15,12 +15,13 @@
 
 namespace cs {
 
-// What goes back to the host, one 32-bit word per pixel: the Sobel derivatives (dxImg_, dyImg_; |.| <= 1020) and the anchor flag,
-//   bits 0..15  dx (two's complement)        bits 16..31  2 dy + anchor (two's complement)
-// The thresholded gradient / 4 (gImg_) and the direction map (dirImg_: |dx| < |dy| = horizontal) are functions of dx and dy that the
-// host stage evaluates where it reads them (lines_host.cpp, Maps) -- half the bytes of the five planes the reference keeps.
+// What goes back to the host, THREE bytes per pixel (round 6; a 32-bit word until then -- the copy back is the batch's longest stage): the Sobel
+// derivatives (dxImg_, dyImg_; |.| <= 4 x 255 = 1020: eleven bits each) and the anchor flag, little endian,
+//   bits 0..10  dx (two's complement)        bit 11  anchor        bits 12..22  dy (two's complement)        bit 23  0
+// i.e. bits 11..22 are 2 dy + anchor as before.  The thresholded gradient / 4 (gImg_) and the direction map (dirImg_: |dx| < |dy| = horizontal) are
+// functions of dx and dy that the host stage evaluates where it reads them (lines_host.cpp, Maps).  Image i's map starts at p3 + 3 N i.
 struct LineMaps {
-  int* pk;
+  unsigned char* p3;
 };
 
 __device__ __forceinline__ int lines_reflect101(int p, int n) {
@@ -35,13 +36,13 @@ __device__ __forceinline__ int lines_div4_half_even(int v) {   // cvRound(v * 0.
 
 enum { LT = 32, LG = LT + 8, LB = LT + 4, LS = LT + 2 };
 
-// blockIdx.z = image of a batch: image i's gray at gray + i N, its packed map at m.pk + i N
+// blockIdx.z = image of a batch: image i's gray at gray + i N, its packed map at m.p3 + 3 i N
 __global__ __launch_bounds__(256) void lines_maps_kernel(const unsigned char* __restrict__ gray, int W, int H, LineMaps m, int k0, int k1, int k2,
                                                          int grad_thr, int anchor_thr, int scan) {
   {
     const size_t N = (size_t)W * H, img = blockIdx.z;
     gray += img * N;
-    m.pk += img * N;
+    m.p3 += 3 * img * N;
   }
   __shared__ unsigned char sg[LG][LG + 4];     // gray, tile origin - 4
   __shared__ int rs[LG][LB];                   // row pass of the blur
@@ -89,7 +90,9 @@ __global__ __launch_bounds__(256) void lines_maps_kernel(const unsigned char* __
       const int n1 = hor ? sgr[r][c + 1] : sgr[r + 1][c], n2 = hor ? sgr[r + 2][c + 1] : sgr[r + 1][c + 2];
       an = (g >= n1 + anchor_thr && g >= n2 + anchor_thr) ? 1 : 0;
     }
-    m.pk[(size_t)y * W + x] = (int)(((unsigned)(2 * (int)sdy[r + 1][c + 1] + an) << 16) | ((unsigned)(int)sdx[r + 1][c + 1] & 0xffffu));
+    const unsigned wd = (((unsigned)(2 * (int)sdy[r + 1][c + 1] + an) & 0xfffu) << 11) | ((unsigned)(int)sdx[r + 1][c + 1] & 0x7ffu);
+    unsigned char* o = m.p3 + 3 * ((size_t)y * W + x);
+    o[0] = (unsigned char)wd; o[1] = (unsigned char)(wd >> 8); o[2] = (unsigned char)(wd >> 16);
   }
 }
 
@@ -98,7 +101,7 @@ void launch_lines_maps(const unsigned char* gray, int W, int H, const LineMaps& 
   for (int i0 = 0; i0 < n_images; i0 += 65535) {      // gridDim.z limit
     const int nz = n_images - i0 < 65535 ? n_images - i0 : 65535;
     const size_t N = (size_t)W * H;
-    LineMaps mi{m.pk + (size_t)i0 * N};
+    LineMaps mi{m.p3 + 3 * (size_t)i0 * N};
     hipLaunchKernelGGL(lines_maps_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, nz), dim3(256), 0, st, gray + (size_t)i0 * N, W, H, mi, k[0], k[1], k[2], grad_thr, anchor_thr, scan);
   }
 }

@@ -1,6 +1,6 @@
 // Host-only check of the EDLines producer's sequential half (csrc/lines_host.cpp: routing, fitting, validation on the packed map, the
 // gradient and direction maps evaluated from dx / dy where they are read) against the CPU restatement, image by image, bit for bit.
-// No GPU: the packed map comes from the restatement (lines_map_from_oracle.cpp); the device entry points are stubs that are never called.
+// No GPU: the packed map comes from the restatement (lines_map_from_oracle.cpp; repacked to the device's three bytes per pixel); the device entry points are stubs that are never called.
 //   lines_host_check <raw gray file> <width> <height> <images>        (images back to back, 8 bit)
 #include "../../cube_slam_wu_amd/csrc/lines_host.cpp"
 
@@ -32,8 +32,10 @@ int main(int argc, char** argv) {
   for (int i = 0; i < ni; i++) {
     const unsigned char* gi = g.data() + (size_t)w * h * i;
     oracle_lines_packed_map(gi, w, h, pk.data());
+    std::vector<unsigned char> p3;
+    maps_pack3(pk.data(), pk.size(), p3);
     Maps M;
-    M.W = w; M.H = h; M.grad_thr = P.grad_thr; M.pk = pk.data();
+    M.W = w; M.H = h; M.grad_thr = P.grad_thr; M.p3 = p3.data();
     int n = 0;
     if (lines_host_stage(M, P, 15.0, out.data(), 20000, &n) != CS_OK) { bad++; continue; }
     const int nr = oracle_edlines_detect(gi, w, h, 15.0f, ref.data(), 20000);
