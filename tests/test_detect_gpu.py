@@ -196,6 +196,18 @@ def test_many_tie_boxes_take_the_separate_host_pass():
     assert tm["n_fallback_boxes"] == 80
 
 
+def test_boxes_too_large_for_the_wavefront_rankings_registers():
+    """rank_wave_kernel keeps a height sample's upper key words in 28 registers per lane: 1 792 valid proposals.  A quarter-degree yaw sweep
+    (361 samples) gives a box ~2 500 of them, so the wavefront runs rank_kernel's procedure (rank_block_body<64, true>) instead -- records
+    still the oracle's, with top-3 and a height-sampled frame in the mix."""
+    plain = [synth.make_frame(8700 + s) for s in range(2)]
+    tall = [synth.make_frame(8710, n_boxes=3, n_lines=250, sample_height=True)]
+    for kmax, hs in ((1, 0), (3, 1)):
+        n, tm = _check_final(tall if hs else plain, capi.default_params(whether_sample_cam_roll_pitch=0, whether_sample_bbox_height=hs, yaw_step_deg=0.25, max_cuboid_num=kmax))
+        assert n >= 3 and tm["rank_kernel_ms"] > 0
+        assert tm["n_valid"] / max(1, tm["n_jobs"]) > 1792, (tm["n_valid"], tm["n_jobs"])      # (the average height sample is beyond the registers)
+
+
 def test_workgroup_ranking_kernel_alone_gives_the_same_records():
     """The boxes of <= 1 792 valid proposals per height sample are ranked by rank_wave_kernel (one wavefront per box, the order
     statistics by a bit walk over candidate masks), the others by rank_kernel (a workgroup per box, radix selection): with
