@@ -349,11 +349,22 @@ __device__ __forceinline__ double lane_xor16(double x) {
 // (one instance per edge class -- IS3D: EdgeSE3Cuboid, the edges [0, n_cub3) of the combined list; else EdgeSE3CuboidProj, [n_cub3, n_cub) --
 // so that the bounding-box path's eight unrolled corners do not set the register budget of the 9-dim path: 196 -> 168 VGPRs, three
 // wavefronts per SIMD instead of two)
+__device__ __forceinline__ void odom_edge_block(const BaView& v, int blk, int tid, double (*J)[16][6]);
+// odom_blocks (IS3D instance only): that many workgroups IN FRONT of the cuboid edges' do the odometry edges instead, eight per workgroup (round 6,
+// last: their ~250 short wavefronts used to be a launch of their own behind this one on the side stream -- 20-38 us that ba_accum_pose_kernel waited
+// for; on a stream of their own they queue for wave slots behind this kernel's and the chi2 kernel's workgroups; as this launch's FIRST workgroups
+// they are dispatched first and are done long before the cuboid edges)
 template <bool IS3D>
-__global__ __launch_bounds__(128, 3) void ba_cub_edge_kernel(BaView v) {
-  __shared__ double J[4][16][9];    // [edge in block][column d (15 = e0)][row]
+__global__ __launch_bounds__(128, 3) void ba_cub_edge_kernel(BaView v, int odom_blocks) {
+  __shared__ double Jbuf[2 * 4 * 16 * 6];      // the cuboid edges' [4][16][9] column store, or two odometry column stores of [4][16][6]
+  static_assert(2 * 4 * 16 * 6 >= 4 * 16 * 9, "one buffer for both kinds of workgroup");
+  if (IS3D && (int)blockIdx.x < odom_blocks) {
+    odom_edge_block(v, 2 * blockIdx.x + (threadIdx.x >> 6), threadIdx.x & 63, reinterpret_cast<double (*)[16][6]>(Jbuf + 4 * 16 * 6 * (threadIdx.x >> 6)));
+    return;
+  }
+  double (*J)[16][9] = reinterpret_cast<double (*)[16][9]>(Jbuf);    // [edge in block][column d (15 = e0)][row]
   const int sub = threadIdx.x >> 5, h = threadIdx.x & 31, d = h & 15, sgn = h >> 4;
-  const int k = (IS3D ? 0 : v.n_cub3) + blockIdx.x * 4 + sub;
+  const int k = (IS3D ? 0 : v.n_cub3) + ((int)blockIdx.x - (IS3D ? odom_blocks : 0)) * 4 + sub;
   const bool live = k < (IS3D ? v.n_cub3 : v.n_cub);
   const double delta = 1e-9, scalar = 1.0 / (2 * delta);
   const double step = sgn ? -delta : delta;
@@ -461,10 +472,10 @@ __global__ __launch_bounds__(128, 3) void ba_cub_edge_kernel(BaView v) {
                                     v.ce_Hco + 54 * (size_t)k, v.ce_bc + 6 * (size_t)k, v.ce_bo + 9 * (size_t)k, w);
 }
 
-__global__ __launch_bounds__(64) void ba_odom_edge_kernel(BaView v) {
-  __shared__ double J[4][16][6];
-  const int sub = threadIdx.x >> 4, d = threadIdx.x & 15;
-  const int k = blockIdx.x * 4 + sub;
+// (four odometry edges per 64 threads; blk = which four, tid = 0 .. 63, J: the four edges' column store.  Every thread of the workgroup reaches the barrier.)
+__device__ __forceinline__ void odom_edge_block(const BaView& v, int blk, int tid, double (*J)[16][6]) {
+  const int sub = tid >> 4, d = tid & 15;
+  const int k = blk * 4 + sub;
   const bool live = k < v.n_odom;
   const double delta = 1e-9, scalar = 1.0 / (2 * delta);
   if (live) {
@@ -496,6 +507,11 @@ __global__ __launch_bounds__(64) void ba_odom_edge_kernel(BaView v) {
     edge_rows_from_columns<6, 6, 6>(J[sub], J[sub][15], v.oe_info + 36 * (size_t)k, d, v.oe_Hii + 36 * (size_t)k, v.oe_Hjj + 36 * (size_t)k,
                                     v.oe_Hij + 36 * (size_t)k, v.oe_bi + 6 * (size_t)k, v.oe_bj + 6 * (size_t)k, w);
   }
+}
+
+__global__ __launch_bounds__(64) void ba_odom_edge_kernel(BaView v) {
+  __shared__ double J[4][16][6];
+  odom_edge_block(v, blockIdx.x, threadIdx.x, J);
 }
 
 // gather the numeric-edge blocks into the pose vertices' A_ii / b_i (fixed order: deterministic)
@@ -2654,13 +2670,15 @@ void ba_launch_linearize(const BaView& v, hipStream_t st, hipStream_t st2, hipEv
   if ((side || side3) && !ev_pre) (void)hipEventRecord(ev_fork, st);
   if (ev_pre) ev_fork = ev_pre;
   if (side) (void)hipStreamWaitEvent(st2, ev_fork, 0);
-  if (v.n_cub3 > 0) hipLaunchKernelGGL(ba_cub_edge_kernel<true>, dim3((v.n_cub3 + 3) / 4), dim3(128), 0, se, v);
-  if (v.n_cub > v.n_cub3) hipLaunchKernelGGL(ba_cub_edge_kernel<false>, dim3((v.n_cub - v.n_cub3 + 3) / 4), dim3(128), 0, se, v);
+  static const bool odom_own_launch = getenv("CS_BA_ODOM_OWN_LAUNCH") != nullptr;      // (the former form: A / B)
+  const int ob = (!odom_own_launch && v.n_cub3 > 0 && v.n_odom > 0) ? (v.n_odom + 7) / 8 : 0;      // the odometry edges as the cuboid launch's first workgroups
+  if (v.n_cub3 > 0) hipLaunchKernelGGL(ba_cub_edge_kernel<true>, dim3((v.n_cub3 + 3) / 4 + ob), dim3(128), 0, se, v, ob);
+  if (v.n_cub > v.n_cub3) hipLaunchKernelGGL(ba_cub_edge_kernel<false>, dim3((v.n_cub - v.n_cub3 + 3) / 4), dim3(128), 0, se, v, 0);
   // (the odometry edges: a single short wave per four edges, 38 us of latency -- beside the cuboid edges on the main stream, not behind
   // them on the side stream, whose 135 us are the phase's critical path)
   // (the odometry edges behind the cuboid edges on the side stream: ~250 short wavefronts, 35 us; in front of the camera sums on the main
   // stream -- rounds 3-4 -- they waited for wave slots beside the cuboid edges for 112 us, behind them they lengthen the main stream's chain)
-  if (v.n_odom > 0) hipLaunchKernelGGL(ba_odom_edge_kernel, dim3((v.n_odom + 3) / 4), dim3(64), 0, se, v);
+  if (v.n_odom > 0 && ob == 0) hipLaunchKernelGGL(ba_odom_edge_kernel, dim3((v.n_odom + 3) / 4), dim3(64), 0, se, v);
   if (side) (void)hipEventRecord(ev_join, st2);
   if (side3) {
     (void)hipStreamWaitEvent(st3, ev_fork, 0);
