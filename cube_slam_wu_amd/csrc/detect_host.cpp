@@ -63,6 +63,8 @@ void launch_edge_maps(const unsigned char* gray, int W, int H, const EdgeRoi* ro
 void launch_line_setup(JobDesc* jobs, int n_jobs, const double* frame_lines, const int* frame_line_ptr, double* mid_x, double* mid_y, double* line_angle,
                        double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st, const int* order = nullptr, hipStream_t st_crowded = nullptr,
                        hipEvent_t fork = nullptr, hipEvent_t join = nullptr);
+void launch_line_setup_listed(JobDesc* jobs, int n_jobs, const double* frame_lines, const int* frame_line_ptr, double* mid_x, double* mid_y, double* line_angle,
+                              double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st, const int* order, hipStream_t st_crowded, hipEvent_t fork, hipEvent_t join, int* crowded);
 int line_setup_capacity();
 void launch_gather_ranges(const DetectDeviceView& v, const long long* src_off, const int* count, const long long* dst_off, int n_ranges,
                           double* o_dist, double* o_angle, double* o_skew, int* o_flag, long long* o_slot, hipStream_t st);
@@ -442,7 +444,7 @@ struct PipeSlot {
   DevBuf<long long> slot_prefix, job_cbase, c_slot, fb_src, fb_dst, fb_slot, win_slots;
   DevBuf<int> vp_prefix, top_x, flag, job_valid, c_flag, box_job0, box_njobs, win_count, fallback, fb_cnt, fb_flag;
   DevBuf<double> bound3;
-  DevBuf<int> ls_order, blk_info;
+  DevBuf<int> ls_order, blk_info, ls_crowded;
   PinBuf<int> h_ls_order;
   DevBuf<double> mid_x, mid_y, ang, yaw, yaw_c, yaw_s, vp, bound, corners, c_dist, c_angle, c_skew, fb_dist, fb_angle, fb_skew, win_corners;
   DevBuf<cs::RankWinner> winners;
@@ -483,7 +485,7 @@ struct PipeSlot {
     jobs.release(); slot_prefix.release(); job_cbase.release(); c_slot.release(); fb_src.release(); fb_dst.release(); fb_slot.release(); win_slots.release();
     vp_prefix.release(); top_x.release(); flag.release(); job_valid.release(); c_flag.release(); box_job0.release(); box_njobs.release(); win_count.release();
     fallback.release(); fb_cnt.release(); fb_flag.release(); mid_x.release(); mid_y.release(); ang.release(); yaw.release(); yaw_c.release(); yaw_s.release();
-    vp.release(); bound.release(); bound3.release(); ls_order.release(); blk_info.release(); h_ls_order.release(); corners.release(); c_dist.release(); c_angle.release(); c_skew.release(); fb_dist.release(); fb_angle.release(); fb_skew.release();
+    vp.release(); bound.release(); bound3.release(); ls_order.release(); blk_info.release(); ls_crowded.release(); h_ls_order.release(); corners.release(); c_dist.release(); c_angle.release(); c_skew.release(); fb_dist.release(); fb_angle.release(); fb_skew.release();
     win_corners.release(); winners.release(); records.release(); h_records.release(); rp_trip_cnt.release(); rp_cur_idx.release(); rp_tab_count.release(); rp_maps.release(); rp_last_slot.release(); rp_box_base.release(); rp_pool_used.release(); rp_raw_euler.release(); h_rp_tab_count.release(); h_rp_maps.release(); h_rp_raw_euler.release(); h_rp_last_slot.release(); h_rp_box_base.release(); h_rp_pool_used.release(); h_jobs_in.release(); h_jobs_out.release(); h_slot_prefix.release(); h_job_cbase.release(); h_vp_prefix.release();
     h_top_x.release(); h_box_job0.release(); h_box_njobs.release(); h_win_count.release(); h_fallback.release(); h_job_valid.release(); h_yaw.release();
     h_yaw_c.release(); h_yaw_s.release(); h_winners.release();
@@ -1212,6 +1214,7 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   PENS(S.mid_x, n_lines + 1); PENS(S.mid_y, n_lines + 1); PENS(S.ang, n_lines + 1); PENS(S.yaw, n_yaw + 1); PENS(S.yaw_c, n_yaw + 1); PENS(S.yaw_s, n_yaw + 1);
   PENS(S.top_x, n_top + 1); PENS(S.vp, 6 * (size_t)S.vp_total + 6); PENS(S.bound, 6 * (size_t)S.vp_total + 6); PENS(S.bound3, nj * (size_t)cs::vp3_table_doubles_per_job());
   if (g_split_candidates) PENS(S.flag, slot_total + 1); else PENS(S.blk_info, 2 * (size_t)(slot_total >> 8) + 4);
+  PENS(S.ls_crowded, nj + 2);
   PENS(S.c_slot, slot_total + 1); PENS(S.c_flag, slot_total + 1); PENS(S.c_dist, slot_total + 1);
   PENS(S.c_angle, slot_total + 1); PENS(S.c_skew, slot_total + 1); PENS(S.box_job0, nb + 1); PENS(S.box_njobs, nb + 1); PENS(S.win_count, nb + 1);
   PENS(S.fallback, nb + 1); PENS(S.winners, nb * KMAX + 1); PENS(S.records, nb * KMAX + 1); PENS(S.h_records, nb * KMAX + 1);
@@ -1290,8 +1293,13 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   }
   HIP_TRY(hipEventRecord(S.ev[10], stB));
   HIP_TRY(hipEventRecord(S.ev[0], st));
-  cs::launch_line_setup(p_jobs, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st, p_ls_order,
-                        d->stream3, S.ev[0], S.ev[12]);
+  static const bool ls_unlisted = getenv("CS_DETECT_LS_UNLISTED") != nullptr;      // (the former form: a workgroup of the crowded instance per job -- A / B)
+  if (!ls_unlisted && d->stream3)
+    cs::launch_line_setup_listed(p_jobs, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st, p_ls_order,
+                                 d->stream3, S.ev[0], S.ev[12], S.ls_crowded.p);
+  else
+    cs::launch_line_setup(p_jobs, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st, p_ls_order,
+                          d->stream3, S.ev[0], S.ev[12]);
   HIP_TRY(hipEventRecord(S.ev[1], st));
   cs::launch_vp_support_only(v, C.sp, S.vp_total, st);
   HIP_TRY(hipEventRecord(S.ev[2], st));

@@ -1278,9 +1278,10 @@ __device__ __forceinline__ bool ls_t3(const LsRow& P, const LsRow& Q, bool p_is_
 // wavefronts, rows tid and tid + 256 per thread -- each wavefront's ballot is one 64-bit word of a partner set.  Each instance counts
 // the ROI's segments first and leaves the jobs of the other size class alone.
 enum { LS_SMALL = 128, LS_CROWDED_THREADS = 64 };
+// (one job: `listed` = the job comes from line_classify_kernel's list of crowded ROIs -- no counting pass, no size-class test)
 template <int CAP, int NT>
-__global__ __launch_bounds__(NT) void line_setup_kernel(JobDesc* jobs, int n_jobs, const double* __restrict__ frame_lines, const int* __restrict__ frame_line_ptr,
-                                                       double* mid_x, double* mid_y, double* line_angle, LineSetupParams lp, const int* __restrict__ order) {
+__device__ __forceinline__ void line_setup_job(int j, bool listed, JobDesc* jobs, int n_jobs, const double* __restrict__ frame_lines, const int* __restrict__ frame_line_ptr,
+                                               double* mid_x, double* mid_y, double* line_angle, const LineSetupParams& lp) {
   constexpr int SL = CAP / NT;                  // rows per thread: tid + NT s
   constexpr int W = CAP / 64;                   // 64-bit words per partner set; row a's own bit sits in word a >> 6 = wave + NW s
   constexpr int NW = NT / 64;
@@ -1289,7 +1290,6 @@ __global__ __launch_bounds__(NT) void line_setup_kernel(JobDesc* jobs, int n_job
   __shared__ unsigned long long PM[CAP * W];    // PM[r * W + w]: the partners b in [64 w, 64 w + 64) of row r (bits b > r only)
   __shared__ int CAND[NW > 1 ? NW : 1];
   __shared__ int TOT;
-  int j = order ? order[blockIdx.x] : blockIdx.x;   // longest jobs first (the kernel ends with its slowest workgroup)
   if (j >= n_jobs) return;
   const JobDesc jd = jobs[j];
   if (jd.Y == 0 || jd.T == 0) return;   // a box the sweep skips (no yaw / top-edge samples): m stays 0
@@ -1298,7 +1298,7 @@ __global__ __launch_bounds__(NT) void line_setup_kernel(JobDesc* jobs, int n_job
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float thf = (float)lp.angle_thre_rad;
   const int NONE = 0x7fffffff;
-  {  // size class of this job: segments with both end points inside the expanded ROI (every wavefront counts for itself)
+  if (!listed) {  // size class of this job: segments with both end points inside the expanded ROI (every wavefront counts for itself)
     int n_in = 0;
     for (int base = 0; base < M; base += 64) {
       const int i = base + lane;
@@ -1473,6 +1473,45 @@ __global__ __launch_bounds__(NT) void line_setup_kernel(JobDesc* jobs, int n_job
       kept += __popcll(bal);
     }
     if (lane == 0) jobs[j].m = kept;
+  }
+}
+template <int CAP, int NT>
+__global__ __launch_bounds__(NT) void line_setup_kernel(JobDesc* jobs, int n_jobs, const double* __restrict__ frame_lines, const int* __restrict__ frame_line_ptr,
+                                                       double* mid_x, double* mid_y, double* line_angle, LineSetupParams lp, const int* __restrict__ order) {
+  const int j = order ? order[blockIdx.x] : blockIdx.x;   // longest jobs first (the kernel ends with its slowest workgroup)
+  line_setup_job<CAP, NT>(j, false, jobs, n_jobs, frame_lines, frame_line_ptr, mid_x, mid_y, line_angle, lp);
+}
+// Round 6, last.  line_setup_kernel above is launched with a workgroup per job of the batch, and 94 % of them count their ROI's segments and leave
+// again -- each holding the instance's 50 KB of LDS while it counts: ~7 500 such workgroups per batch, three at a time on a CU, beside the other
+// batches' kernels (what that costs: a second, 17 KB instance launched the same way for the ROIs of <= 256 rows took 5.5 % OFF the sweep's rate;
+// doubling this instance's LDS took 5-7 %).  The lean path asks first: line_classify_kernel (a wavefront per job, no LDS) appends the crowded jobs to
+// a list, and this kernel's workgroups -- a fixed, modest grid -- take their jobs from it.
+// crowded[0] = how many, crowded[1 ..] = the jobs (in the order the atomics fell: the jobs are independent).
+__global__ __launch_bounds__(256) void line_classify_kernel(const JobDesc* __restrict__ jobs, int n_jobs, const double* __restrict__ frame_lines, const int* __restrict__ frame_line_ptr,
+                                                            int* __restrict__ crowded) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (j >= n_jobs) return;
+  const JobDesc& jd = jobs[j];
+  if (jd.Y == 0 || jd.T == 0) return;
+  const int f = jd.frame, el = jd.g.el, et = jd.g.et, er = jd.g.er, eb = jd.g.eb;
+  const double* FL = frame_lines + 4 * (size_t)frame_line_ptr[f];
+  const int M = frame_line_ptr[f + 1] - frame_line_ptr[f];
+  int n_in = 0;
+  for (int base = 0; base < M; base += 64) {
+    const int i = base + lane;
+    bool in = false;
+    if (i < M) in = inside_box(v2(FL[4 * i], FL[4 * i + 1]), el, et, er, eb) && inside_box(v2(FL[4 * i + 2], FL[4 * i + 3]), el, et, er, eb);
+    n_in += __popcll(__ballot(in));
+  }
+  if (n_in > LS_SMALL && lane == 0) crowded[1 + atomicAdd(crowded, 1)] = j;
+}
+template <int CAP, int NT>
+__global__ __launch_bounds__(NT) void line_setup_listed_kernel(JobDesc* jobs, int n_jobs, const double* __restrict__ frame_lines, const int* __restrict__ frame_line_ptr,
+                                                              double* mid_x, double* mid_y, double* line_angle, LineSetupParams lp, const int* __restrict__ crowded) {
+  const int n = crowded[0];
+  for (int k = blockIdx.x; k < n; k += gridDim.x) {
+    line_setup_job<CAP, NT>(crowded[1 + k], true, jobs, n_jobs, frame_lines, frame_line_ptr, mid_x, mid_y, line_angle, lp);
+    __syncthreads();      // (the next job rewrites the rows and the matrix)
   }
 }
 
@@ -1703,6 +1742,22 @@ void launch_line_setup(JobDesc* jobs, int n_jobs, const double* frame_lines, con
   if (beside) (void)hipEventRecord(join, sc);
   hipLaunchKernelGGL(line_setup_small_kernel, dim3(n_jobs), dim3(64), 0, st, jobs, n_jobs, frame_lines, frame_line_ptr, mid_x, mid_y, line_angle, lp, order);
   if (beside) (void)hipStreamWaitEvent(st, join, 0);
+}
+// the lean path's form: the crowded ROIs from line_classify_kernel's list (crowded: n_jobs + 1 ints of scratch), the others as above
+void launch_line_setup_listed(JobDesc* jobs, int n_jobs, const double* frame_lines, const int* frame_line_ptr, double* mid_x, double* mid_y, double* line_angle,
+                              double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st, const int* order, hipStream_t st_crowded, hipEvent_t fork, hipEvent_t join, int* crowded) {
+  if (skip_kernel("line_setup")) return;
+  if (n_jobs <= 0) return;
+  LineSetupParams lp{dist_thre, angle_thre_deg / 180.0 * CS_PI, len_thre, sqrt_lt_bound(dist_thre), sqrt_le_bound(len_thre)};
+  (void)hipMemsetAsync(crowded, 0, sizeof(int), st);
+  hipLaunchKernelGGL(line_classify_kernel, dim3((n_jobs + 3) / 4), dim3(256), 0, st, jobs, n_jobs, frame_lines, frame_line_ptr, crowded);
+  (void)hipEventRecord(fork, st);
+  (void)hipStreamWaitEvent(st_crowded, fork, 0);
+  const int grid = n_jobs < 1024 ? n_jobs : 1024;      // (more crowded ROIs than workgroups: a workgroup takes several)
+  hipLaunchKernelGGL((line_setup_listed_kernel<LS_CAP, LS_CROWDED_THREADS>), dim3(grid), dim3(LS_CROWDED_THREADS), 0, st_crowded, jobs, n_jobs, frame_lines, frame_line_ptr, mid_x, mid_y, line_angle, lp, crowded);
+  (void)hipEventRecord(join, st_crowded);
+  hipLaunchKernelGGL(line_setup_small_kernel, dim3(n_jobs), dim3(64), 0, st, jobs, n_jobs, frame_lines, frame_line_ptr, mid_x, mid_y, line_angle, lp, order);
+  (void)hipStreamWaitEvent(st, join, 0);
 }
 int line_setup_capacity() { return LS_CAP; }
 
