@@ -1683,6 +1683,7 @@ int rp_launch(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>>&
   S.rp_NT = NT; S.rp_YCAP = YCAP;
   S.rp_pool_cap = std::max<long long>(1 << 18, slots_all / 64);        // columns of the flagged boxes (about one box in a hundred)
   PENS(S.fb_dist, (size_t)S.rp_pool_cap + 1); PENS(S.fb_angle, (size_t)S.rp_pool_cap + 1); PENS(S.fb_skew, (size_t)S.rp_pool_cap + 1); PENS(S.fb_flag, (size_t)S.rp_pool_cap + 1); PENS(S.fb_slot, (size_t)S.rp_pool_cap + 1);
+  PENS(S.ls_crowded, nj + 2);
   PENS(S.rp_box_base, nb + 1); PENS(S.rp_pool_used, 1); PENS(S.h_rp_box_base, nb + 1); PENS(S.h_rp_pool_used, 1); PENS(S.h_rp_last_slot, nb + 1); PENS(S.h_job_valid, nj + 1); PENS(S.h_jobs_out, nj + 1);
   HIP_TRY(hipMemsetAsync(S.rp_pool_used.p, 0, sizeof(unsigned long long), st));
   PENS(S.rp_cur_idx, (size_t)NF + 1); PENS(S.rp_tab_count, (size_t)NF * NT + 1); PENS(S.rp_maps, 3 * (size_t)MB * NF + 1); PENS(S.rp_raw_euler, 3 * (size_t)NF + 1);
@@ -1706,8 +1707,13 @@ int rp_launch(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>>&
   HIP_TRY(hipMemsetAsync(S.rp_cur_idx.p, 0, sizeof(int) * NF, st));
   HIP_TRY(hipEventRecord(S.ev[0], st));
   // ---- line setup of every job of the batch at once (it depends on the box and the frame's segments only)
-  cs::launch_line_setup(S.jobs.p, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st, S.ls_order.p,
-                        d->stream3, S.ev[0], S.ev[12]);
+  static const bool ls_unlisted = getenv("CS_DETECT_LS_UNLISTED") != nullptr;
+  if (!ls_unlisted && d->stream3)
+    cs::launch_line_setup_listed(S.jobs.p, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st, S.ls_order.p,
+                                 d->stream3, S.ev[0], S.ev[12], S.ls_crowded.p);
+  else
+    cs::launch_line_setup(S.jobs.p, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st, S.ls_order.p,
+                          d->stream3, S.ev[0], S.ev[12]);
   HIP_TRY(hipEventRecord(S.ev[1], st));
   cs::RankParams rkp{P.weight_vp_angle, P.weight_skew_error, P.nominal_skew_ratio, P.max_cut_skew, KMAX, C.sp.short_sq_bound};
   while (S.rp_ev.size() < 5 * (size_t)MB) { hipEvent_t e = nullptr; HIP_TRY(hipEventCreate(&e)); S.rp_ev.push_back(e); }
