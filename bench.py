@@ -20,6 +20,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The library runs five streams per detector (main, corner construction, crowded line setup, tie fetches, image upload) and the bench three detectors side
+# by side; the ROCm runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues -- 4 by default -- and streams that share a queue
+# serialise.  Eight queues: 497-500 k -> 530 k frames/s at the contract run, steady 510-512 k -> 547-552 k (2: 453-460 k; 16: erratic) -- INTEGRATION.md.
+# Read by the runtime when it initialises, so it is set before anything touches HIP; a value already in the environment wins and is reported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 FP64_FLOP_PER_PROPOSAL = 1700.0   # 88 map samples x 6, six cs_atan2 (light path ~90 each), the 3D lift; + ~300 for the corners the scorer now rebuilds (13 squared lengths, 6 line intersections, 3 ray hits)
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak = half the FP32 vector peak of MI355X_MICROARCH.md (157.3)
@@ -1041,7 +1046,7 @@ def main():
             # what really ran before the clock started: every batch alone (sizes its buffers; the isolated kernel timings), then all pipelines side by side
             "warmup_untimed_steps": {"total": warm_alone_runs + warm_concurrent_steps, "each_batch_alone": warm_alone_runs, "all_pipelines_side_by_side": warm_concurrent_steps,
                                      "what": "--warmup W = %d: W runs of each of the %d batches alone, then max(W, batches) x %s steps driven exactly like the timed steps" % (args.warmup, inflight * depth, os.environ.get("CS_BENCH_WARMUP_ROUNDS", "4"))},
-            "env_overrides": env_overrides, "diag_build": False,
+            "env_overrides": env_overrides, "runtime_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}, "diag_build": False,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not share_gpu else "synthetic (CS_BENCH_SHARE_GPU functional check: ranks share one device, not a performance number)",
             "config": {"workload": "C2: per-frame cuboid proposal sweep, 181 yaw x 8 boxes x ~400 line segments, 1241x376 KITTI-shaped",

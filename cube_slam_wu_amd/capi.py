@@ -5,6 +5,10 @@ loading fails loudly when the HIP library has not been built (run __graft_entry_
 """
 from __future__ import annotations
 
+import os as _os
+# (five streams per detector: with the ROCm runtime's default of four hardware queues they share queues and serialise -- INTEGRATION.md; only effective
+# when nothing has initialised HIP yet, and a value already in the environment wins)
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import ctypes as C
 import os
 

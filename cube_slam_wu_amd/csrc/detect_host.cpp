@@ -64,7 +64,8 @@ void launch_line_setup(JobDesc* jobs, int n_jobs, const double* frame_lines, con
                        double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st, const int* order = nullptr, hipStream_t st_crowded = nullptr,
                        hipEvent_t fork = nullptr, hipEvent_t join = nullptr);
 void launch_line_setup_listed(JobDesc* jobs, int n_jobs, const double* frame_lines, const int* frame_line_ptr, double* mid_x, double* mid_y, double* line_angle,
-                              double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st, const int* order, hipStream_t st_crowded, hipEvent_t fork, hipEvent_t join, int* crowded);
+                              double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st, const int* order, hipStream_t st_crowded, hipEvent_t fork, hipEvent_t join, int* crowded,
+                              hipStream_t st_mid = nullptr, hipEvent_t join_mid = nullptr);
 int line_setup_capacity();
 void launch_gather_ranges(const DetectDeviceView& v, const long long* src_off, const int* count, const long long* dst_off, int n_ranges,
                           double* o_dist, double* o_angle, double* o_skew, int* o_flag, long long* o_slot, hipStream_t st);
@@ -383,6 +384,7 @@ struct cs_detector {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // tie-break re-ranking fetches of the previous chunk, concurrent with the next chunk's sweep
   hipStream_t stream3 = nullptr;   // line setup of the crowded ROIs, beside the line setup of all the others
+  hipStream_t stream4 = nullptr;   // ... of the ROIs of 129 .. 256 segments (their own, smaller instance)
   hipStream_t stream_hi = nullptr; // high priority: the small fetches of the tie boxes, which the host waits for while another batch's sweep owns the device
   hipEvent_t ev[12] = {};
   int n_threads = 1;
@@ -475,7 +477,7 @@ struct PipeSlot {
   PinBuf<long long> h_fb_src, h_fb_dst, h_fb_slot, h_win_slots;
   PinBuf<int> h_fb_cnt, h_fb_flag;
   PinBuf<double> h_fb_dist, h_fb_angle, h_fb_skew, h_win_corners;
-  hipEvent_t done = nullptr, ev[13] = {};   // 0-6: phase marks on the main stream; 7: inputs resident; 8-11: second stream (corner construction); 12: line setup of the crowded ROIs done (third stream)
+  hipEvent_t done = nullptr, ev[14] = {};   // 0-6: phase marks on the main stream; 7: inputs resident; 8-11: second stream (corner construction); 12: line setup of the crowded ROIs done (third stream)
   cs::DetectDeviceView view{};
   int f0 = 0, f1 = 0, vp_total = 0;
   size_t nj = 0, nb = 0;
@@ -669,6 +671,7 @@ int cs_detector_create(const cs_detect_params* params, int device, cs_detector**
   HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&d->stream3, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&d->stream4, hipStreamNonBlocking));
   {
     int prio_low = 0, prio_high = 0;   // (numerically lowest = greatest priority)
     HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
@@ -707,6 +710,7 @@ void cs_detector_destroy(cs_detector* d) {
   if (d->stream) (void)hipStreamDestroy(d->stream);
   if (d->stream2) (void)hipStreamDestroy(d->stream2);
   if (d->stream3) (void)hipStreamDestroy(d->stream3);
+  if (d->stream4) (void)hipStreamDestroy(d->stream4);
   if (d->stream_hi) (void)hipStreamDestroy(d->stream_hi);
   delete d;
 }
@@ -1214,7 +1218,7 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   PENS(S.mid_x, n_lines + 1); PENS(S.mid_y, n_lines + 1); PENS(S.ang, n_lines + 1); PENS(S.yaw, n_yaw + 1); PENS(S.yaw_c, n_yaw + 1); PENS(S.yaw_s, n_yaw + 1);
   PENS(S.top_x, n_top + 1); PENS(S.vp, 6 * (size_t)S.vp_total + 6); PENS(S.bound, 6 * (size_t)S.vp_total + 6); PENS(S.bound3, nj * (size_t)cs::vp3_table_doubles_per_job());
   if (g_split_candidates) PENS(S.flag, slot_total + 1); else PENS(S.blk_info, 2 * (size_t)(slot_total >> 8) + 4);
-  PENS(S.ls_crowded, nj + 2);
+  PENS(S.ls_crowded, 2 * (nj + 1) + 2);
   PENS(S.c_slot, slot_total + 1); PENS(S.c_flag, slot_total + 1); PENS(S.c_dist, slot_total + 1);
   PENS(S.c_angle, slot_total + 1); PENS(S.c_skew, slot_total + 1); PENS(S.box_job0, nb + 1); PENS(S.box_njobs, nb + 1); PENS(S.win_count, nb + 1);
   PENS(S.fallback, nb + 1); PENS(S.winners, nb * KMAX + 1); PENS(S.records, nb * KMAX + 1); PENS(S.h_records, nb * KMAX + 1);
@@ -1296,7 +1300,7 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
   static const bool ls_unlisted = getenv("CS_DETECT_LS_UNLISTED") != nullptr;      // (the former form: a workgroup of the crowded instance per job -- A / B)
   if (!ls_unlisted && d->stream3)
     cs::launch_line_setup_listed(p_jobs, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st, p_ls_order,
-                                 d->stream3, S.ev[0], S.ev[12], S.ls_crowded.p);
+                                 d->stream3, S.ev[0], S.ev[12], S.ls_crowded.p, d->stream4, S.ev[13]);
   else
     cs::launch_line_setup(p_jobs, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st, p_ls_order,
                           d->stream3, S.ev[0], S.ev[12]);
@@ -1683,7 +1687,7 @@ int rp_launch(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>>&
   S.rp_NT = NT; S.rp_YCAP = YCAP;
   S.rp_pool_cap = std::max<long long>(1 << 18, slots_all / 64);        // columns of the flagged boxes (about one box in a hundred)
   PENS(S.fb_dist, (size_t)S.rp_pool_cap + 1); PENS(S.fb_angle, (size_t)S.rp_pool_cap + 1); PENS(S.fb_skew, (size_t)S.rp_pool_cap + 1); PENS(S.fb_flag, (size_t)S.rp_pool_cap + 1); PENS(S.fb_slot, (size_t)S.rp_pool_cap + 1);
-  PENS(S.ls_crowded, nj + 2);
+  PENS(S.ls_crowded, 2 * (nj + 1) + 2);
   PENS(S.rp_box_base, nb + 1); PENS(S.rp_pool_used, 1); PENS(S.h_rp_box_base, nb + 1); PENS(S.h_rp_pool_used, 1); PENS(S.h_rp_last_slot, nb + 1); PENS(S.h_job_valid, nj + 1); PENS(S.h_jobs_out, nj + 1);
   HIP_TRY(hipMemsetAsync(S.rp_pool_used.p, 0, sizeof(unsigned long long), st));
   PENS(S.rp_cur_idx, (size_t)NF + 1); PENS(S.rp_tab_count, (size_t)NF * NT + 1); PENS(S.rp_maps, 3 * (size_t)MB * NF + 1); PENS(S.rp_raw_euler, 3 * (size_t)NF + 1);
@@ -1710,7 +1714,7 @@ int rp_launch(PipeCtx& C, PipeSlot& S, const std::vector<std::vector<CamCache>>&
   static const bool ls_unlisted = getenv("CS_DETECT_LS_UNLISTED") != nullptr;
   if (!ls_unlisted && d->stream3)
     cs::launch_line_setup_listed(S.jobs.p, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st, S.ls_order.p,
-                                 d->stream3, S.ev[0], S.ev[12], S.ls_crowded.p);
+                                 d->stream3, S.ev[0], S.ev[12], S.ls_crowded.p, d->stream4, S.ev[13]);
   else
     cs::launch_line_setup(S.jobs.p, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st, S.ls_order.p,
                           d->stream3, S.ev[0], S.ev[12]);

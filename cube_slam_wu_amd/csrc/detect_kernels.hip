@@ -1277,7 +1277,7 @@ __device__ __forceinline__ bool ls_t3(const LsRow& P, const LsRow& Q, bool p_is_
 // CAP = LS_CAP instance: what counts there is the latency of the longest job (the batch's chain waits for it), so a job gets four
 // wavefronts, rows tid and tid + 256 per thread -- each wavefront's ballot is one 64-bit word of a partner set.  Each instance counts
 // the ROI's segments first and leaves the jobs of the other size class alone.
-enum { LS_SMALL = 128, LS_CROWDED_THREADS = 64 };
+enum { LS_SMALL = 128, LS_MID = 256, LS_CROWDED_THREADS = 64 };
 // (one job: `listed` = the job comes from line_classify_kernel's list of crowded ROIs -- no counting pass, no size-class test)
 template <int CAP, int NT>
 __device__ __forceinline__ void line_setup_job(int j, bool listed, JobDesc* jobs, int n_jobs, const double* __restrict__ frame_lines, const int* __restrict__ frame_line_ptr,
@@ -1488,7 +1488,7 @@ __global__ __launch_bounds__(NT) void line_setup_kernel(JobDesc* jobs, int n_job
 // a list, and this kernel's workgroups -- a fixed, modest grid -- take their jobs from it.
 // crowded[0] = how many, crowded[1 ..] = the jobs (in the order the atomics fell: the jobs are independent).
 __global__ __launch_bounds__(256) void line_classify_kernel(const JobDesc* __restrict__ jobs, int n_jobs, const double* __restrict__ frame_lines, const int* __restrict__ frame_line_ptr,
-                                                            int* __restrict__ crowded) {
+                                                            int* __restrict__ crowded, int* __restrict__ crowded_big) {
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (j >= n_jobs) return;
   const JobDesc& jd = jobs[j];
@@ -1503,7 +1503,11 @@ __global__ __launch_bounds__(256) void line_classify_kernel(const JobDesc* __res
     if (i < M) in = inside_box(v2(FL[4 * i], FL[4 * i + 1]), el, et, er, eb) && inside_box(v2(FL[4 * i + 2], FL[4 * i + 3]), el, et, er, eb);
     n_in += __popcll(__ballot(in));
   }
-  if (n_in > LS_SMALL && lane == 0) crowded[1 + atomicAdd(crowded, 1)] = j;
+  // (two lists: ROIs of up to LS_MID rows -- their instance holds 17 KB of LDS -- and the rest, 50 KB; `crowded_big` null: one list for both)
+  if (n_in > LS_SMALL && lane == 0) {
+    int* list = (crowded_big && n_in > LS_MID) ? crowded_big : crowded;
+    list[1 + atomicAdd(list, 1)] = j;
+  }
 }
 template <int CAP, int NT>
 __global__ __launch_bounds__(NT) void line_setup_listed_kernel(JobDesc* jobs, int n_jobs, const double* __restrict__ frame_lines, const int* __restrict__ frame_line_ptr,
@@ -1745,19 +1749,33 @@ void launch_line_setup(JobDesc* jobs, int n_jobs, const double* frame_lines, con
 }
 // the lean path's form: the crowded ROIs from line_classify_kernel's list (crowded: n_jobs + 1 ints of scratch), the others as above
 void launch_line_setup_listed(JobDesc* jobs, int n_jobs, const double* frame_lines, const int* frame_line_ptr, double* mid_x, double* mid_y, double* line_angle,
-                              double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st, const int* order, hipStream_t st_crowded, hipEvent_t fork, hipEvent_t join, int* crowded) {
+                              double dist_thre, double angle_thre_deg, double len_thre, hipStream_t st, const int* order, hipStream_t st_crowded, hipEvent_t fork, hipEvent_t join, int* crowded,
+                              hipStream_t st_mid, hipEvent_t join_mid) {
   if (skip_kernel("line_setup")) return;
   if (n_jobs <= 0) return;
   LineSetupParams lp{dist_thre, angle_thre_deg / 180.0 * CS_PI, len_thre, sqrt_lt_bound(dist_thre), sqrt_le_bound(len_thre)};
+  // crowded: 2 (n_jobs + 1) ints -- the list of the ROIs of up to LS_MID rows, behind it the list of the larger ones (one list when there is no second stream)
+  static const bool one_list = getenv("CS_DETECT_LS_ONE_LIST") != nullptr;
+  const bool two = st_mid && join_mid && !one_list;
+  int* big = two ? crowded + n_jobs + 1 : nullptr;
   (void)hipMemsetAsync(crowded, 0, sizeof(int), st);
-  hipLaunchKernelGGL(line_classify_kernel, dim3((n_jobs + 3) / 4), dim3(256), 0, st, jobs, n_jobs, frame_lines, frame_line_ptr, crowded);
+  if (two) (void)hipMemsetAsync(big, 0, sizeof(int), st);
+  hipLaunchKernelGGL(line_classify_kernel, dim3((n_jobs + 3) / 4), dim3(256), 0, st, jobs, n_jobs, frame_lines, frame_line_ptr, crowded, big);
   (void)hipEventRecord(fork, st);
-  (void)hipStreamWaitEvent(st_crowded, fork, 0);
   const int grid = n_jobs < 1024 ? n_jobs : 1024;      // (more crowded ROIs than workgroups: a workgroup takes several)
-  hipLaunchKernelGGL((line_setup_listed_kernel<LS_CAP, LS_CROWDED_THREADS>), dim3(grid), dim3(LS_CROWDED_THREADS), 0, st_crowded, jobs, n_jobs, frame_lines, frame_line_ptr, mid_x, mid_y, line_angle, lp, crowded);
+  (void)hipStreamWaitEvent(st_crowded, fork, 0);
+  hipLaunchKernelGGL((line_setup_listed_kernel<LS_CAP, LS_CROWDED_THREADS>), dim3(grid), dim3(LS_CROWDED_THREADS), 0, st_crowded, jobs, n_jobs, frame_lines, frame_line_ptr, mid_x, mid_y, line_angle, lp, two ? big : crowded);
   (void)hipEventRecord(join, st_crowded);
+  if (two) {
+    static const bool mid_own_stream = getenv("CS_DETECT_LS_MID_STREAM") != nullptr;
+    hipStream_t sm = mid_own_stream ? st_mid : st_crowded;       // (behind the large ROIs' instance on ITS stream: a fourth stream per detector cost 7 % of the sweep's rate)
+    if (mid_own_stream) (void)hipStreamWaitEvent(st_mid, fork, 0);
+    hipLaunchKernelGGL((line_setup_listed_kernel<LS_MID, LS_CROWDED_THREADS>), dim3(grid), dim3(LS_CROWDED_THREADS), 0, sm, jobs, n_jobs, frame_lines, frame_line_ptr, mid_x, mid_y, line_angle, lp, crowded);
+    (void)hipEventRecord(join_mid, sm);
+  }
   hipLaunchKernelGGL(line_setup_small_kernel, dim3(n_jobs), dim3(64), 0, st, jobs, n_jobs, frame_lines, frame_line_ptr, mid_x, mid_y, line_angle, lp, order);
   (void)hipStreamWaitEvent(st, join, 0);
+  if (two) (void)hipStreamWaitEvent(st, join_mid, 0);
 }
 int line_setup_capacity() { return LS_CAP; }
 
