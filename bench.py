@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--latency-calls", type=int, default=200, help="calls per entry point of the single-call latency report (0 = skip)")
     ap.add_argument("--depth", type=int, default=2, help="batches per pipeline: the next one is submitted (packed + queued) before the current one is collected")
     ap.add_argument("--steady-steps", type=int, default=200, help="steps of the steady-state measurement reported beside the contract run (0 = skip)")
-    ap.add_argument("--inflight", type=int, default=3, help="batches in flight per GPU: each has its own detector (streams, worker pool) and is driven by its own host thread, "
+    ap.add_argument("--inflight", type=int, default=4, help="(4 since eight hardware queues -- round 6, last: 4 x 2 550 k / 570 k steady against 3 x 2 521 k / 541 k; with the runtime's four queues 3 x 2 was the best) batches in flight per GPU: each has its own detector (streams, worker pool) and is driven by its own host thread, "
                     "so one batch's host stages (packing, record writing) overlap the other's sweep on the device")
     ap.add_argument("--no-measure-traffic", action="store_true", help="do not collect roofline.traffic in this run (two rocprofv3 --pmc passes -- FETCH_SIZE, WRITE_SIZE; "
                     "kernel-trace only -- over a short child run of the same workload, ~20 s at N = 1); report the figure of the last tools/profile_round.sh "
