@@ -41,7 +41,7 @@
 
 namespace cs {
 void launch_vp_support(const DetectDeviceView& v, const SweepParams& sp, int vp_total, hipStream_t st);
-void launch_vp_support_only(const DetectDeviceView& v, const SweepParams& sp, int vp_total, hipStream_t st);
+void launch_vp_support_only(const DetectDeviceView& v, const SweepParams& sp, int vp_total, hipStream_t st, int rp_max = 0);      // rp_max: the jobs' largest roll/pitch sample count (0: unknown)
 void launch_vp_points(const DetectDeviceView& v, int vp_total, hipStream_t st);
 int vp3_table_doubles_per_job();
 void launch_candidates(const DetectDeviceView& v, const SweepParams& sp, long long slot_total, hipStream_t st);
@@ -1305,7 +1305,7 @@ int pipe_launch(PipeCtx& C, PipeSlot& S, int f0, int f1) {
     cs::launch_line_setup(p_jobs, (int)nj, b->d_frame_lines.p, b->d_frame_line_ptr.p, S.mid_x.p, S.mid_y.p, S.ang.p, P.pre_merge_dist_thre, P.pre_merge_angle_thre, P.edge_length_threshold, st, p_ls_order,
                           d->stream3, S.ev[0], S.ev[12]);
   HIP_TRY(hipEventRecord(S.ev[1], st));
-  cs::launch_vp_support_only(v, C.sp, S.vp_total, st);
+  cs::launch_vp_support_only(v, C.sp, S.vp_total, st, 1);      // (this path's jobs have one roll/pitch sample: jd.RP = 1 above)
   HIP_TRY(hipEventRecord(S.ev[2], st));
   HIP_TRY(hipStreamWaitEvent(st, S.ev[10], 0));
   HIP_TRY(hipEventRecord(S.ev[4], st));

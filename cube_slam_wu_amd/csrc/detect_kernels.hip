@@ -320,9 +320,11 @@ __global__ __launch_bounds__(256) void vp_support_kernel(DetectDeviceView v, Swe
 }
 
 // support angles of the third vanishing point, K R^-1 (0, 0, 1): one lane per (job, roll/pitch sample)
-__global__ __launch_bounds__(64) void vp3_support_kernel(DetectDeviceView v, SweepParams sp) {
+// rp_stride: lanes per job = the largest roll/pitch sample count of the launch's jobs (1 without roll/pitch sampling: a lane per job, 125 wavefronts for
+// 8 000 jobs -- with VP3_RPCAP lanes per job it was 4 000 wavefronts of two live lanes each); the table keeps its VP3_RPCAP slots per job
+__global__ __launch_bounds__(64) void vp3_support_kernel(DetectDeviceView v, SweepParams sp, int rp_stride) {
   const long long e = (long long)blockIdx.x * 64 + threadIdx.x;
-  const int j = (int)(e / VP3_RPCAP), rp = (int)(e % VP3_RPCAP);
+  const int j = (int)(e / rp_stride), rp = (int)(e % rp_stride);
   bool on = j < v.n_jobs;
   JobDesc jd{};
   if (on) { jd = v.jobs[j]; on = rp < jd.RP && jd.Y > 0; }
@@ -1876,10 +1878,12 @@ void launch_vp_support(const DetectDeviceView& v, const SweepParams& sp, int vp_
   if (vp_total <= 0) return;
   vp_support_kernel<0><<<dim3(grid8(vp_total, 256)), dim3(256), 0, st>>>(v, sp, vp_total);
 }
-void launch_vp_support_only(const DetectDeviceView& v, const SweepParams& sp, int vp_total, hipStream_t st) {
+void launch_vp_support_only(const DetectDeviceView& v, const SweepParams& sp, int vp_total, hipStream_t st, int rp_max) {
   if (skip_kernel("vp_support")) return;
   if (vp_total <= 0) return;
-  hipLaunchKernelGGL(vp3_support_kernel, dim3((unsigned)(((long long)v.n_jobs * VP3_RPCAP + 63) / 64)), dim3(64), 0, st, v, sp);
+  static const bool sparse = getenv("CS_DETECT_VP3_SPARSE") != nullptr;      // (VP3_RPCAP lanes per job whatever the jobs hold: the form until round 6's end -- A / B)
+  const int stride = (!sparse && rp_max >= 1 && rp_max <= (int)VP3_RPCAP) ? rp_max : (int)VP3_RPCAP;
+  hipLaunchKernelGGL(vp3_support_kernel, dim3((unsigned)(((long long)v.n_jobs * stride + 63) / 64)), dim3(64), 0, st, v, sp, stride);
   vp_support_kernel<1><<<dim3(grid8(vp_total, 256)), dim3(256), 0, st>>>(v, sp, vp_total);
 }
 int vp3_table_doubles_per_job() { return 2 * VP3_RPCAP; }
